@@ -1,0 +1,123 @@
+/*
+ * xvcgpu_types.h -- plain-C data formats shared by the C-ABI (xvcgpu.h), the
+ * HIP kernels and the CPU oracle.  No HIP / torch / C++ types here.
+ *
+ * Every struct restates (as a flat POD) exactly the fields that the cited
+ * reference code reads on the hot path; nothing else is carried.
+ */
+#ifndef XVCGPU_TYPES_H_
+#define XVCGPU_TYPES_H_
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Sample = uint16_t (reference: common.h:34-38, XVC_HIGH_BITDEPTH=1 build),
+ * Coeff / Residual = int16_t (common.h:39-40). */
+typedef uint16_t xvc_sample;
+typedef int16_t xvc_coeff;
+
+/* Distortion metric selector; numeric values follow the declaration order of
+ * the reference's `enum class MetricType` (sample_metric.h:37-46). */
+enum xvcgpu_metric {
+  XVC_METRIC_SSD = 0,
+  XVC_METRIC_SATD = 1,
+  XVC_METRIC_SATD_ACONLY = 2,
+  XVC_METRIC_SAD = 3,
+  XVC_METRIC_SAD_FAST = 4,
+  XVC_METRIC_SAD_ACONLY = 5,
+  XVC_METRIC_SAD_ACONLY_FAST = 6,
+  XVC_METRIC_STRUCTURAL_SSD = 7
+};
+
+/* 1-D transform type; values follow `enum class TransformType`
+ * (cu_types.h): kDefault, kDct2, kDct5, kDct8, kDst1, kDst7. */
+enum xvcgpu_tx_type {
+  XVC_TX_DEFAULT = 0,
+  XVC_TX_DCT2 = 1,
+  XVC_TX_DCT5 = 2,
+  XVC_TX_DCT8 = 3,
+  XVC_TX_DST1 = 4,
+  XVC_TX_DST7 = 5
+};
+
+/* MvCorner order (cu_types.h / coding_unit.h:152-155 GetMvCorner). */
+enum xvcgpu_mv_corner {
+  XVC_CORNER_UL = 0,
+  XVC_CORNER_UR = 1,
+  XVC_CORNER_DL = 2,
+  XVC_CORNER_DR = 3
+};
+
+/* Per-CU metadata read by the deblocking filter
+ * (deblocking_filter.cc:79-241: position/size, pred mode, luma cbf, raw qp
+ * per component, ref idx / ref POC per list, the four corner MVs per list).
+ * The per-4x4-cell table (picture_data.h:102-107 cu_pic_table_) becomes an
+ * int32 index into an array of these records (-1 = no CU, i.e. nullptr). */
+typedef struct xvcgpu_cu_info {
+  uint16_t x, y;       /* luma position of the CU                          */
+  uint8_t w, h;        /* luma size                                        */
+  uint8_t intra;       /* CodingUnit::IsIntra()                            */
+  uint8_t cbf_luma;    /* CodingUnit::GetCbf(kY)                           */
+  int8_t qp_y;         /* CodingUnit::GetQp(kY)  (raw qp)                  */
+  int8_t qp_c;         /* CodingUnit::GetQp(kU)  (raw chroma qp)           */
+  int8_t ref_idx0;     /* GetRefIdx(L0) (uni-pred pictures compare this)   */
+  int8_t reserved;
+  int32_t ref_poc[2];  /* GetRefPoc(list); -1 when the list is unused      */
+  int32_t mv[2][4][2]; /* [list][corner][x,y] in 1/16 pel                  */
+} xvcgpu_cu_info;
+
+/* One motion-estimation job = one (CU, reference picture) pair, i.e. one call
+ * of InterSearch::MotionEstNormal (inter_search.cc:606-662) with the TZ
+ * search method.  Everything the reference derives from neighbouring CUs
+ * (AMVP predictor, previous CU's full-pel result) is an input here. */
+typedef struct xvcgpu_me_block {
+  int16_t x, y;        /* luma position                                    */
+  uint8_t w, h;        /* luma size, each in {4,8,16,32,64}                */
+  uint8_t depth_nonzero; /* cu.GetDepth() != 0 (inter_tz_search.cc:117)    */
+  uint8_t fullpel_mv;  /* cu.GetFullpelMv() (mvd down-shift, :96)          */
+  int32_t mvp_x, mvp_y;   /* AMVP predictor, 1/16 pel (unclipped)          */
+  int32_t prev_x, prev_y; /* previous_fullpel_ for this (list,ref_idx)     */
+  uint32_t lambda16;   /* floor(65536*sqrt(lambda)) (inter_tz_search.cc:98)*/
+  int32_t search_range;/* GetSearchRangeUniPred (inter_search.cc:1050)     */
+} xvcgpu_me_block;
+
+/* Result of the full-pel + sub-pel search for one xvcgpu_me_block. */
+typedef struct xvcgpu_me_result {
+  int32_t fullpel_x, fullpel_y; /* TzSearch::Search return value           */
+  int32_t mv_x, mv_y;           /* SubpelSearch return value, 1/16 pel     */
+  uint32_t fullpel_cost;        /* state.cost_best at exit                 */
+  uint32_t subpel_dist;         /* *out_dist of SubpelSearch (SATD)        */
+} xvcgpu_me_result;
+
+/* One residual-pipeline job = one (CU, component) pair, i.e. one call of
+ * TransformEncoder::TransformAndReconstruct (transform_encoder.cc:203-285)
+ * with the non-RDO quantiser. Positions/sizes are in samples of `comp`. */
+typedef struct xvcgpu_tx_block {
+  int16_t x, y;        /* position in the component plane                  */
+  uint8_t w, h;        /* size in the component plane, {2,4,...,64}        */
+  uint8_t comp;        /* 0 = Y, 1 = U, 2 = V                              */
+  uint8_t tx_hor;      /* xvcgpu_tx_type for the horizontal 1-D pass       */
+  uint8_t tx_ver;      /* xvcgpu_tx_type for the vertical 1-D pass         */
+  uint8_t dst4x4;      /* can_dst_4x4 (intra luma 4x4 default)             */
+  int8_t qp;           /* raw qp for this component (Qp::GetQpRaw)         */
+  uint8_t intra_pic;   /* pic_type == kIntra (quantiser rounding offset)   */
+} xvcgpu_tx_block;
+
+/* One motion-compensation job (InterPrediction::MotionCompensationMv,
+ * inter_prediction.cc:740-758) for one component of one uni-pred CU. */
+typedef struct xvcgpu_mc_block {
+  int16_t x, y;        /* luma position of the CU                          */
+  uint8_t w, h;        /* luma size of the CU                              */
+  uint8_t comp;        /* 0 = Y, 1 = U, 2 = V                              */
+  uint8_t reserved;
+  int32_t mv_x, mv_y;  /* 1/16 pel luma MV (clipped inside, ClipMv)        */
+} xvcgpu_mc_block;
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* XVCGPU_TYPES_H_ */

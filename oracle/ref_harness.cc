@@ -1,0 +1,562 @@
+/*
+ * ref_harness.cc -- thin extern "C" shim over the REFERENCE's own code.
+ *
+ * TEST INFRASTRUCTURE ONLY; builds only in the authoring container where
+ * /root/reference exists (oracle/Makefile target `ref`), into
+ * oracle/_ref/libxvcref.so (git-ignored).  It contains no reference source:
+ * it #includes the reference headers (and one .cc, for member templates that
+ * are only defined there) from where they lie and calls the reference's
+ * classes, so that tests/ can pin the oracle (xvc_oracle.c) against what the
+ * reference really computes, and so that tools/gen_golden.py can capture
+ * golden vectors.  Each xr_* function has the same signature as the xo_*
+ * function it pins.
+ */
+#include <algorithm>
+#include <array>
+#include <cassert>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <limits>
+#include <map>
+#include <memory>
+#include <set>
+#include <string>
+#include <vector>
+#include <mutex>
+#include <thread>
+#include <condition_variable>
+#include <functional>
+#include <list>
+#include <deque>
+#include <sstream>
+#include <iostream>
+#include <unordered_map>
+#include <unordered_set>
+#include <utility>
+#include <cstddef>
+#include <cstdlib>
+
+#define private public
+#define protected public
+#include "xvc_common_lib/coding_unit.h"
+#include "xvc_common_lib/deblocking_filter.h"
+#include "xvc_common_lib/inter_prediction.h"
+#include "xvc_common_lib/picture_data.h"
+#include "xvc_common_lib/quantize.h"
+#include "xvc_common_lib/restrictions.h"
+#include "xvc_common_lib/segment_header.h"
+#include "xvc_common_lib/transform.h"
+#include "xvc_common_lib/yuv_pic.h"
+#include "xvc_enc_lib/encoder_settings.h"
+#include "xvc_enc_lib/encoder_simd_functions.h"
+#include "xvc_enc_lib/inter_tz_search.h"
+#include "xvc_enc_lib/rdo_quant.h"
+#include "xvc_enc_lib/sample_metric.h"
+/* member templates (SubpelSearch<>, ...) are defined only in the .cc */
+#include "xvc_enc_lib/inter_search.cc"
+#undef private
+#undef protected
+
+#include "../include/xvcgpu_types.h"
+
+using namespace xvc;  // NOLINT
+
+namespace {
+
+int g_use_simd = 1;
+
+const EncoderSimdFunctions &Simd(int bd) {
+  static std::map<int, std::unique_ptr<EncoderSimdFunctions>> cache;
+  int key = bd * 2 + g_use_simd;
+  auto it = cache.find(key);
+  if (it == cache.end()) {
+    std::set<CpuCapability> caps;
+    if (g_use_simd) caps = SimdCpu::GetRuntimeCapabilities();
+    it = cache.emplace(key, std::unique_ptr<EncoderSimdFunctions>(
+                                new EncoderSimdFunctions(caps, bd))).first;
+  }
+  return *it->second;
+}
+
+Qp MakeQp(int qp_raw, int bd, double lambda = 1.0) {
+  return Qp(qp_raw, ChromaFormat::k420, bd, lambda, 1, 0, 0);
+}
+
+/* Copy padded planes (pointer at sample (0,0), >= 80/40 samples of border
+ * available on every side) into a reference YuvPicture incl. its border. */
+void FillPic(YuvPicture *pic, const uint16_t *const planes[3],
+             const ptrdiff_t strides[3]) {
+  for (int c = 0; c < 3; c++) {
+    YuvComponent comp = YuvComponent(c);
+    const int w = pic->GetWidth(comp), h = pic->GetHeight(comp);
+    const int bx = static_cast<int>((pic->GetStride(comp) - w) >> 1);
+    const int by = bx;
+    if (!planes[c]) continue;
+    for (int y = -by; y < h + by; y++) {
+      Sample *dst = pic->GetSamplePtr(comp, -bx, y);
+      const uint16_t *src = planes[c] + y * strides[c] - bx;
+      std::memcpy(dst, src, sizeof(Sample) * (w + 2 * bx));
+    }
+  }
+}
+
+void ReadPic(const YuvPicture &pic, uint16_t *const planes[3],
+             const ptrdiff_t strides[3], bool with_border) {
+  for (int c = 0; c < 3; c++) {
+    YuvComponent comp = YuvComponent(c);
+    const int w = pic.GetWidth(comp), h = pic.GetHeight(comp);
+    const int bx =
+        with_border ? static_cast<int>((pic.GetStride(comp) - w) >> 1) : 0;
+    if (!planes[c]) continue;
+    for (int y = -bx; y < h + bx; y++) {
+      const Sample *src = pic.GetSamplePtr(comp, -bx, y);
+      uint16_t *dst = planes[c] + y * strides[c] - bx;
+      std::memcpy(dst, src, sizeof(Sample) * (w + 2 * bx));
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+void xr_set_simd(int use_simd) { g_use_simd = use_simd ? 1 : 0; }
+
+/* ---- metrics ---- */
+uint64_t xr_metric_ss(int metric, int bd, int qp_raw_y, int strength,
+                      double weight, int w, int h, const uint16_t *s1,
+                      ptrdiff_t st1, const uint16_t *s2, ptrdiff_t st2) {
+  (void)weight;
+  SampleMetric m(Simd(bd).sample_metric, bd, static_cast<MetricType>(metric),
+                 strength);
+  Qp qp = MakeQp(qp_raw_y, bd);
+  return m.CompareSample(qp, YuvComponent::kY, w, h, s1, st1, s2, st2);
+}
+
+uint64_t xr_metric_rs(int metric, int bd, int qp_raw_y, int strength,
+                      double weight, int w, int h, const int16_t *s1,
+                      ptrdiff_t st1, const uint16_t *s2, ptrdiff_t st2) {
+  (void)weight;
+  SampleMetric m(Simd(bd).sample_metric, bd, static_cast<MetricType>(metric),
+                 strength);
+  Qp qp = MakeQp(qp_raw_y, bd);
+  return m.CompareSample(qp, YuvComponent::kY, w, h, s1, st1, s2, st2);
+}
+
+uint64_t xr_ssd_rr(int bd, double weight, int w, int h, const int16_t *s1,
+                   ptrdiff_t st1, const int16_t *s2, ptrdiff_t st2) {
+  (void)weight;
+  SampleMetric m(Simd(bd).sample_metric, bd, MetricType::kSsd);
+  Qp qp = MakeQp(32, bd);
+  return m.CompareShort(qp, YuvComponent::kY, w, h, s1, st1, s2, st2);
+}
+
+uint64_t xr_picture_ssd(int bd, int w, int h, const uint16_t *p1,
+                        ptrdiff_t st1, const uint16_t *p2, ptrdiff_t st2,
+                        uint64_t *psnr_dist, uint64_t *psnr_samples) {
+  /* luma-only pictures of size w x h (chroma planes unused) */
+  YuvPicture a(ChromaFormat::k420, w, h, bd, true, 0, 0);
+  YuvPicture b(ChromaFormat::k420, w, h, bd, true, 0, 0);
+  for (int y = 0; y < h; y++) {
+    std::memcpy(a.GetSamplePtr(YuvComponent::kY, 0, y), p1 + y * st1,
+                sizeof(Sample) * w);
+    std::memcpy(b.GetSamplePtr(YuvComponent::kY, 0, y), p2 + y * st2,
+                sizeof(Sample) * w);
+  }
+  SampleMetric m(Simd(bd).sample_metric, bd, MetricType::kSsd);
+  Qp qp = MakeQp(32, bd);
+  uint64_t dist =
+      m.ComparePicture(qp, YuvComponent::kY, YuvComponent::kY, a, b);
+  if (psnr_dist) *psnr_dist = dist;
+  if (psnr_samples) {
+    /* recover the sample count from the PSNR the reference reports */
+    double psnr = m.ComputePsnr(qp, YuvComponent::kY, YuvComponent::kY, a, b);
+    if (dist == 0) {
+      *psnr_samples = 0;
+    } else {
+      double mse = 255.0 * 255.0 / std::pow(10.0, psnr / 10.0);
+      *psnr_samples = static_cast<uint64_t>(std::llround(dist / mse));
+    }
+  }
+  return dist;
+}
+
+/* ---- interpolation ---- */
+static InterPrediction *MakeIp(int bd, std::unique_ptr<YuvPicture> *rec) {
+  rec->reset(new YuvPicture(ChromaFormat::k420, 8, 8, bd, true, 0, 0));
+  return new InterPrediction(Simd(bd).inter_prediction, **rec, bd);
+}
+
+void xr_mc_uni(int bd, int is_chroma, int w, int h, int frac_x, int frac_y,
+               const uint16_t *ref, ptrdiff_t rs, uint16_t *pred,
+               ptrdiff_t ps) {
+  std::unique_ptr<YuvPicture> rec;
+  std::unique_ptr<InterPrediction> ip(MakeIp(bd, &rec));
+  SampleBufferConst rb(ref, rs);
+  SampleBuffer pb(pred, ps);
+  ip->MotionCompUniPred(w, h, is_chroma ? YuvComponent::kU : YuvComponent::kY,
+                        rb, frac_x, frac_y, &pb);
+}
+
+void xr_mc_uni_bipred(int bd, int is_chroma, int w, int h, int frac_x,
+                      int frac_y, const uint16_t *ref, ptrdiff_t rs,
+                      int16_t *pred, ptrdiff_t ps) {
+  std::unique_ptr<YuvPicture> rec;
+  std::unique_ptr<InterPrediction> ip(MakeIp(bd, &rec));
+  SampleBufferConst rb(ref, rs);
+  DataBuffer<int16_t> pb(pred, ps);
+  ip->MotionCompUniPred(w, h, is_chroma ? YuvComponent::kU : YuvComponent::kY,
+                        rb, frac_x, frac_y, &pb);
+}
+
+void xr_add_avg(int bd, int w, int h, const int16_t *s1, ptrdiff_t st1,
+                const int16_t *s2, ptrdiff_t st2, uint16_t *dst,
+                ptrdiff_t ds) {
+  /* AddAvgBi body, inter_prediction.cc:1540-1553, via the fn table */
+  const int shift = std::max(2, InterPrediction::kInternalPrecision - bd) + 1;
+  const int offset = (1 << (shift - 1)) + 2 * InterPrediction::kInternalOffset;
+  Simd(bd).inter_prediction.add_avg[w > 2](w, h, offset, shift, bd, s1, st1, s2,
+                                           st2, dst, ds);
+}
+
+void xr_mc_block(int bd, int comp, int x, int y, int w, int h, int mv_x,
+                 int mv_y, int pic_w, int pic_h, const uint16_t *ref_plane,
+                 ptrdiff_t rs, uint16_t *pred, ptrdiff_t ps) {
+  PictureData pic_data(ChromaFormat::k420, pic_w, pic_h, bd);
+  CodingUnit *cu = pic_data.CreateCu(CuTree::Primary, 1, x, y, w, h);
+  YuvPicture ref_pic(ChromaFormat::k420, pic_w, pic_h, bd, true, 0, 0);
+  const uint16_t *planes[3] = {nullptr, nullptr, nullptr};
+  ptrdiff_t strides[3] = {0, 0, 0};
+  planes[comp] = ref_plane;
+  strides[comp] = rs;
+  FillPic(&ref_pic, planes, strides);
+  InterPrediction ip(Simd(bd).inter_prediction, ref_pic, bd);
+  SampleBuffer pb(pred, ps);
+  ip.MotionCompensationMv(*cu, YuvComponent(comp), ref_pic,
+                          MotionVector(mv_x, mv_y), false, &pb);
+}
+
+void xr_clip_mv(int pos_x, int pos_y, int pic_w, int pic_h, int *mv_x,
+                int *mv_y) {
+  PictureData pic_data(ChromaFormat::k420, pic_w, pic_h, 8);
+  CodingUnit *cu = pic_data.CreateCu(CuTree::Primary, 1, pos_x, pos_y, 8, 8);
+  YuvPicture ref_pic(ChromaFormat::k420, pic_w, pic_h, 8, false, 0, 0);
+  InterPrediction ip(Simd(8).inter_prediction, ref_pic, 8);
+  MotionVector mv(*mv_x, *mv_y);
+  ip.ClipMv(*cu, ref_pic, &mv);
+  *mv_x = mv.x;
+  *mv_y = mv.y;
+}
+
+/* ---- transforms ---- */
+void xr_fwd_transform(int bd, int w, int h, int tx_hor, int tx_ver, int dst4x4,
+                      const int16_t *resi, ptrdiff_t rs, int16_t *coeff,
+                      ptrdiff_t cs) {
+  PictureData pic_data(ChromaFormat::k420, 64, 64, bd);
+  CodingUnit *cu = pic_data.CreateCu(CuTree::Primary, 0, 0, 0, w, h);
+  cu->SetPredMode(dst4x4 ? PredictionMode::kIntra : PredictionMode::kInter);
+  cu->SetTransformType(YuvComponent::kY, static_cast<TransformType>(tx_ver),
+                       static_cast<TransformType>(tx_hor));
+  ForwardTransform fwd(bd);
+  ResidualBuffer in(const_cast<int16_t *>(resi), rs);
+  CoeffBuffer out(coeff, cs);
+  fwd.Transform(*cu, YuvComponent::kY, in, &out);
+}
+
+void xr_inv_transform(int bd, int w, int h, int tx_hor, int tx_ver, int dst4x4,
+                      int dc_only, const int16_t *coeff, ptrdiff_t cs,
+                      int16_t *resi, ptrdiff_t rs) {
+  PictureData pic_data(ChromaFormat::k420, 64, 64, bd);
+  CodingUnit *cu = pic_data.CreateCu(CuTree::Primary, 0, 0, 0, w, h);
+  cu->SetPredMode(dst4x4 ? PredictionMode::kIntra : PredictionMode::kInter);
+  cu->SetTransformType(YuvComponent::kY, static_cast<TransformType>(tx_ver),
+                       static_cast<TransformType>(tx_hor));
+  cu->SetDcCoeffOnly(YuvComponent::kY, dc_only != 0);
+  InverseTransform inv(bd);
+  CoeffBuffer in(const_cast<int16_t *>(coeff), cs);
+  ResidualBuffer out(resi, rs);
+  inv.Transform(*cu, YuvComponent::kY, in, &out);
+}
+
+void xr_fwd_transform_skip(int bd, int w, int h, const int16_t *resi,
+                           ptrdiff_t rs, int16_t *coeff, ptrdiff_t cs) {
+  ForwardTransform fwd(bd);
+  ResidualBuffer in(const_cast<int16_t *>(resi), rs);
+  CoeffBuffer out(coeff, cs);
+  fwd.TransformSkip(w, h, in, &out);
+}
+
+void xr_inv_transform_skip(int bd, int w, int h, const int16_t *coeff,
+                           ptrdiff_t cs, int16_t *resi, ptrdiff_t rs) {
+  InverseTransform inv(bd);
+  CoeffBuffer in(const_cast<int16_t *>(coeff), cs);
+  ResidualBuffer out(resi, rs);
+  inv.TransformSkip(w, h, in, &out);
+}
+
+void xr_dequant(int bd, int qp_raw, int w, int h, const int16_t *in,
+                ptrdiff_t is, int16_t *out, ptrdiff_t os) {
+  Quantize q;
+  Qp qp = MakeQp(qp_raw, bd);
+  q.Inverse(YuvComponent::kY, qp, w, h, bd, in, is, out, os);
+}
+
+int xr_quant_fast(int bd, int qp_raw, int intra_pic, int w, int h,
+                  const int16_t *in, ptrdiff_t is, int16_t *out,
+                  ptrdiff_t os) {
+  /* QuantFast with sign hiding off: the restriction flag is thread-local
+   * state of the reference; flip it around the call. */
+  PictureData pic_data(ChromaFormat::k420, 64, 64, bd);
+  CodingUnit *cu = pic_data.CreateCu(CuTree::Primary, 0, 0, 0, w, h);
+  cu->SetPredMode(PredictionMode::kInter);
+  Qp qp = MakeQp(qp_raw, bd);
+  EncoderSettings es;
+  es.Initialize(SpeedMode::kSlow);
+  RdoQuant rq(bd, es);
+  Restrictions &r = Restrictions::GetRW();
+  bool saved = r.disable_transform_sign_hiding;
+  r.disable_transform_sign_hiding = true;
+  int nnz = rq.QuantFast(*cu, YuvComponent::kY, qp,
+                         intra_pic ? PicturePredictionType::kIntra
+                                   : PicturePredictionType::kBi,
+                         in, is, out, os);
+  r.disable_transform_sign_hiding = saved;
+  return nnz;
+}
+
+/* ---- transform tables ---- */
+const int16_t *xr_transform_matrix(int tx_type, int size) {
+  typedef TransformData T;
+  switch (tx_type) {
+    case XVC_TX_DEFAULT:
+    case XVC_TX_DCT2:
+      switch (size) {
+        case 2: return &T::kDct2Transform2High[0][0];
+        case 4: return &T::kDct2Transform4High[0][0];
+        case 8: return &T::kDct2Transform8High[0][0];
+        case 16: return &T::kDct2Transform16High[0][0];
+        case 32: return &T::kDct2Transform32High[0][0];
+        case 64: return &T::kDct2Transform64High[0][0];
+      }
+      return nullptr;
+#define XR_TAB(NAME)                                  \
+  switch (size) {                                     \
+    case 4: return T::k##NAME##Transform4High;        \
+    case 8: return T::k##NAME##Transform8High;        \
+    case 16: return T::k##NAME##Transform16High;      \
+    case 32: return T::k##NAME##Transform32High;      \
+    case 64: return T::k##NAME##Transform64High;      \
+  }                                                   \
+  return nullptr;
+    case XVC_TX_DCT5: XR_TAB(Dct5)
+    case XVC_TX_DCT8: XR_TAB(Dct8)
+    case XVC_TX_DST1: XR_TAB(Dst1)
+    case XVC_TX_DST7: XR_TAB(Dst7)
+#undef XR_TAB
+  }
+  return nullptr;
+}
+
+/* ---- deblocking ---- */
+void xr_deblock_picture(int bd, int pic_w, int pic_h, int bipred,
+                        int beta_offset, int tc_offset, int subblock_size,
+                        const xvcgpu_cu_info *cus, int n_cus,
+                        uint16_t *const planes[3], const ptrdiff_t strides[3],
+                        const int32_t *l0_pocs, int n0, const int32_t *l1_pocs,
+                        int n1) {
+  (void)subblock_size; /* reference default: 4 */
+  PictureData pic_data(ChromaFormat::k420, pic_w, pic_h, bd);
+  pic_data.SetNalType(bipred ? NalUnitType::kBipredictedPicture
+                             : NalUnitType::kPredictedPicture);
+  pic_data.SetPoc(1000);
+  ReferencePictureLists *rpl = pic_data.GetRefPicLists();
+  rpl->Reset(1000);
+  auto dummy = std::make_shared<PictureData>(ChromaFormat::k420, 8, 8, bd);
+  dummy->SetNalType(NalUnitType::kPredictedPicture);
+  for (int i = 0; i < n0; i++)
+    rpl->SetRefPic(RefPicList::kL0, i, static_cast<PicNum>(l0_pocs[i]), dummy,
+                   nullptr, nullptr);
+  for (int i = 0; i < n1; i++)
+    rpl->SetRefPic(RefPicList::kL1, i, static_cast<PicNum>(l1_pocs[i]), dummy,
+                   nullptr, nullptr);
+  SegmentHeader segment;
+  segment.chroma_qp_offset_table = 1;
+  segment.chroma_qp_offset_u = 0;
+  segment.chroma_qp_offset_v = 0;
+  segment.max_binary_split_depth = 3;
+  Qp pic_qp = MakeQp(32, bd, 57.9);
+  pic_data.Init(segment, pic_qp, true);
+
+  for (int i = 0; i < n_cus; i++) {
+    const xvcgpu_cu_info &ci = cus[i];
+    CodingUnit *cu =
+        pic_data.CreateCu(CuTree::Primary, 1, ci.x, ci.y, ci.w, ci.h);
+    assert(cu);
+    cu->SetSplit(SplitType::kNone);
+    cu->SetPredMode(ci.intra ? PredictionMode::kIntra : PredictionMode::kInter);
+    cu->SetCbf(YuvComponent::kY, ci.cbf_luma != 0);
+    cu->SetQp(ci.qp_y);
+    bool use0 = ci.ref_poc[0] >= 0, use1 = ci.ref_poc[1] >= 0;
+    cu->SetInterDir(use0 && use1 ? InterDir::kBi
+                                 : (use1 ? InterDir::kL1 : InterDir::kL0));
+    int idx0 = ci.ref_idx0, idx1 = 0;
+    if (use1) {
+      for (int k = 0; k < n1; k++)
+        if (l1_pocs[k] == ci.ref_poc[1]) { idx1 = k; break; }
+    }
+    cu->SetRefIdx(idx0, RefPicList::kL0);
+    cu->SetRefIdx(idx1, RefPicList::kL1);
+    for (int l = 0; l < 2; l++)
+      for (int c = 0; c < 4; c++)
+        cu->inter_.mv[l][c] = MotionVector(ci.mv[l][c][0], ci.mv[l][c][1]);
+    pic_data.MarkUsedInPic(cu);
+  }
+
+  YuvPicture rec(ChromaFormat::k420, pic_w, pic_h, bd, true, 0, 0);
+  FillPic(&rec, const_cast<const uint16_t *const *>(planes), strides);
+  DeblockingFilter df(&pic_data, &rec, beta_offset, tc_offset);
+  df.DeblockPicture();
+  ReadPic(rec, planes, strides, false);
+}
+
+/* ---- border extension ---- */
+void xr_pad_border(int w, int h, uint16_t *const planes[3],
+                   const ptrdiff_t strides[3]) {
+  /* whole 4:2:0 picture; border 80/40 as in yuv_pic.cc:39 */
+  YuvPicture pic(ChromaFormat::k420, w, h, 10, true, 0, 0);
+  FillPic(&pic, const_cast<const uint16_t *const *>(planes), strides);
+  pic.PadBorder();
+  ReadPic(pic, planes, strides, true);
+}
+
+/* ---- motion search ---- */
+uint32_t xr_mvd_bits_fullpel(int mvp_x, int mvp_y, int fx, int fy, int down) {
+  return InterSearch::GetMvdBitsFullpel(MotionVector(mvp_x, mvp_y), fx, fy,
+                                        down);
+}
+uint32_t xr_mvd_bits(int mvp_x, int mvp_y, int mv_x, int mv_y, int down) {
+  return InterSearch::GetMvdBits(MotionVector(mvp_x, mvp_y),
+                                 MotionVector(mv_x, mv_y), down);
+}
+
+void xr_min_max_mv(int pos_x, int pos_y, int pic_w, int pic_h, int center_x,
+                   int center_y, int search_range, int mv_min[2],
+                   int mv_max[2]) {
+  PictureData pic_data(ChromaFormat::k420, pic_w, pic_h, 8);
+  CodingUnit *cu = pic_data.CreateCu(CuTree::Primary, 1, pos_x, pos_y, 8, 8);
+  YuvPicture ref_pic(ChromaFormat::k420, pic_w, pic_h, 8, false, 0, 0);
+  InterPrediction ip(Simd(8).inter_prediction, ref_pic, 8);
+  MvFullpel mn, mx;
+  ip.DetermineMinMaxMv(*cu, ref_pic, MotionVector(center_x, center_y),
+                       search_range, &mn, &mx);
+  mv_min[0] = mn.x; mv_min[1] = mn.y;
+  mv_max[0] = mx.x; mv_max[1] = mx.y;
+}
+
+struct MeEnv {
+  PictureData pic_data;
+  YuvPicture orig_pic, ref_pic, rec_pic;
+  EncoderSettings settings;
+  ReferencePictureLists rpl;
+  MeEnv(int bd, int pic_w, int pic_h, const uint16_t *orig, ptrdiff_t os,
+        const uint16_t *ref, ptrdiff_t rs)
+      : pic_data(ChromaFormat::k420, pic_w, pic_h, bd),
+        orig_pic(ChromaFormat::k420, pic_w, pic_h, bd, true, 0, 0),
+        ref_pic(ChromaFormat::k420, pic_w, pic_h, bd, true, 0, 0),
+        rec_pic(ChromaFormat::k420, pic_w, pic_h, bd, true, 0, 0) {
+    const uint16_t *po[3] = {orig, nullptr, nullptr};
+    const uint16_t *pr[3] = {ref, nullptr, nullptr};
+    ptrdiff_t so[3] = {os, 0, 0}, sr[3] = {rs, 0, 0};
+    /* orig needs no border: copy the visible area only */
+    for (int y = 0; y < pic_h; y++)
+      std::memcpy(orig_pic.GetSamplePtr(YuvComponent::kY, 0, y), po[0] + y * so[0],
+                  sizeof(Sample) * pic_w);
+    FillPic(&ref_pic, pr, sr);
+    settings.Initialize(SpeedMode::kSlow);
+    pic_data.SetSubGopLength(16);
+    pic_data.SetPoc(8);
+  }
+};
+
+void xr_tz_search(int bd, const xvcgpu_me_block *b, int pic_w, int pic_h,
+                  const uint16_t *orig, ptrdiff_t os, const uint16_t *ref,
+                  ptrdiff_t rs, int out_mv[2], uint32_t *out_cost) {
+  MeEnv env(bd, pic_w, pic_h, orig, os, ref, rs);
+  CodingUnit *cu = env.pic_data.CreateCu(CuTree::Primary,
+                                         b->depth_nonzero ? 1 : 0, b->x, b->y,
+                                         b->w, b->h);
+  cu->SetFullpelMv(b->fullpel_mv != 0);
+  InterPrediction ip(Simd(bd).inter_prediction, env.rec_pic, bd);
+  /* a Qp whose sqrt(lambda) reproduces lambda16 exactly */
+  double ls = (b->lambda16 + 0.5) / 65536.0;
+  Qp qp = MakeQp(32, bd, ls * ls);
+  /* make sure floor(65536*sqrt(lambda)) == lambda16 */
+  assert(static_cast<uint32_t>(std::floor(65536.0 * qp.GetLambdaSqrt())) ==
+         b->lambda16);
+  MotionVector mvp(b->mvp_x, b->mvp_y);
+  MvFullpel mn, mx;
+  ip.DetermineMinMaxMv(*cu, env.ref_pic, mvp, b->search_range, &mn, &mx);
+  SampleMetric metric(Simd(bd).sample_metric, bd,
+                      b->h > 8 ? MetricType::kSadFast : MetricType::kSad);
+  TzSearch tz(env.orig_pic, ip, env.settings, b->search_range);
+  MvFullpel r = tz.Search(*cu, qp, metric, mvp, env.ref_pic, mn, mx,
+                          MvFullpel(b->prev_x, b->prev_y));
+  out_mv[0] = r.x;
+  out_mv[1] = r.y;
+  if (out_cost) *out_cost = 0; /* not observable through the reference API */
+}
+
+void xr_subpel_search(int bd, const xvcgpu_me_block *b, int pic_w, int pic_h,
+                      const uint16_t *orig, ptrdiff_t os, const uint16_t *ref,
+                      ptrdiff_t rs, const int fullpel[2], int out_mv[2],
+                      uint32_t *out_dist) {
+  MeEnv env(bd, pic_w, pic_h, orig, os, ref, rs);
+  CodingUnit *cu = env.pic_data.CreateCu(CuTree::Primary, 1, b->x, b->y, b->w,
+                                         b->h);
+  cu->SetFullpelMv(false);
+  InterSearch is(Simd(bd), env.pic_data, env.orig_pic, env.rec_pic, env.rpl,
+                 env.settings);
+  double ls = (b->lambda16 + 0.5) / 65536.0;
+  Qp qp = MakeQp(32, bd, ls * ls);
+  SampleMetric metric(Simd(bd).sample_metric, bd, MetricType::kSatd);
+  SampleBufferConst orig_buffer =
+      env.orig_pic.GetSampleBuffer(YuvComponent::kY, b->x, b->y);
+  SampleBufferStorage pred(64, 64);
+  Distortion dist = 0;
+  MotionVector mv = is.SubpelSearch(*cu, qp, metric, env.ref_pic,
+                                    MotionVector(b->mvp_x, b->mvp_y),
+                                    MvFullpel(fullpel[0], fullpel[1]),
+                                    orig_buffer, &pred, &dist);
+  out_mv[0] = mv.x;
+  out_mv[1] = mv.y;
+  if (out_dist) *out_dist = static_cast<uint32_t>(dist);
+}
+
+void xr_full_search(int bd, int x, int y, int w, int h, int fullpel_mv,
+                    int mvp_x, int mvp_y, uint32_t lambda16, const int mv_min[2],
+                    const int mv_max[2], const int16_t *target, ptrdiff_t ts,
+                    const uint16_t *ref, ptrdiff_t rs, int pic_w, int pic_h,
+                    int out_mv[2]) {
+  std::vector<uint16_t> dummy_orig(static_cast<size_t>(pic_w) * pic_h, 0);
+  MeEnv env(bd, pic_w, pic_h, dummy_orig.data(), pic_w, ref, rs);
+  CodingUnit *cu = env.pic_data.CreateCu(CuTree::Primary, 1, x, y, w, h);
+  cu->SetFullpelMv(fullpel_mv != 0);
+  InterSearch is(Simd(bd), env.pic_data, env.orig_pic, env.rec_pic, env.rpl,
+                 env.settings);
+  for (int yy = 0; yy < h; yy++)
+    std::memcpy(is.bipred_orig_buffer_.GetDataPtr() +
+                    yy * is.bipred_orig_buffer_.GetStride(),
+                target + yy * ts, sizeof(int16_t) * w);
+  double ls = (lambda16 + 0.5) / 65536.0;
+  Qp qp = MakeQp(32, bd, ls * ls);
+  SampleMetric metric(Simd(bd).sample_metric, bd,
+                      h > 8 ? MetricType::kSadFast : MetricType::kSad);
+  MvFullpel r = is.FullSearch(*cu, qp, metric, MotionVector(mvp_x, mvp_y),
+                              env.ref_pic, MvFullpel(mv_min[0], mv_min[1]),
+                              MvFullpel(mv_max[0], mv_max[1]));
+  out_mv[0] = r.x;
+  out_mv[1] = r.y;
+}
+
+}  // extern "C"

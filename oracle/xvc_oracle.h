@@ -1,0 +1,167 @@
+/*
+ * xvc_oracle.h -- CPU restatement ("oracle") of the xvc per-CU hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is part of the product:
+ * only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * load this library, and only as the checker / the CPU baseline.  The product
+ * path (xvc_amd/, libxvcgpu.so) never links, imports or falls back to it.
+ *
+ * Parity status: PINNED.  Every function below is checked (tests/test_oracle_
+ * vs_ref.py, this container only) against the reference's own compiled code
+ * (oracle/_ref/libxvcref.so, built by oracle/Makefile from /root/reference
+ * sources where they lie) on seeded random inputs, and against the committed
+ * golden vectors in tests/golden/ (generated from that same reference build
+ * by tools/gen_golden.py).  The reference has no known-answer vectors of its
+ * own for this path (its tests are relational).
+ *
+ * Each function cites the reference file:line it restates (paths relative to
+ * /root/reference/src).
+ */
+#ifndef XVC_ORACLE_H_
+#define XVC_ORACLE_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#include "../include/xvcgpu_types.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- M1..M7 distortion metrics (xvc_enc_lib/sample_metric.cc:171-223) ---- *
+ * Returns static_cast<Distortion>(dist * weight) exactly as Compare() does.
+ * qp_raw_y / structural_strength only matter for XVC_METRIC_STRUCTURAL_SSD. */
+uint64_t xo_metric_ss(int metric, int bitdepth, int qp_raw_y,
+                      int structural_strength, double weight, int w, int h,
+                      const uint16_t *s1, ptrdiff_t st1,
+                      const uint16_t *s2, ptrdiff_t st2);
+/* Residual (int16) x Sample overload (sample_metric.cc:226-277). */
+uint64_t xo_metric_rs(int metric, int bitdepth, int qp_raw_y,
+                      int structural_strength, double weight, int w, int h,
+                      const int16_t *s1, ptrdiff_t st1,
+                      const uint16_t *s2, ptrdiff_t st2);
+/* Residual x Residual SSD (sample_metric.cc:279-298). */
+uint64_t xo_ssd_rr(int bitdepth, double weight, int w, int h,
+                   const int16_t *s1, ptrdiff_t st1,
+                   const int16_t *s2, ptrdiff_t st2);
+/* SampleMetric::ComparePicture with kSsd over one plane, and the sample
+ * count used by ComputePsnr (sample_metric.cc:37-155): per-64x64-block SSD
+ * each right-shifted by 2*(bd-8). Returns the summed distortion. */
+uint64_t xo_picture_ssd(int bitdepth, int w, int h,
+                        const uint16_t *p1, ptrdiff_t st1,
+                        const uint16_t *p2, ptrdiff_t st2,
+                        uint64_t *psnr_dist, uint64_t *psnr_samples);
+
+/* ---- I1/I2 interpolation (xvc_common_lib/inter_prediction.cc) ---- */
+/* MotionCompUniPred -> Sample (inter_prediction.cc:1138-1154). `ref` points
+ * at the full-pel position; frac in 1/16 (luma) or 1/32 (chroma) units. */
+void xo_mc_uni(int bitdepth, int is_chroma, int w, int h, int frac_x,
+               int frac_y, const uint16_t *ref, ptrdiff_t ref_stride,
+               uint16_t *pred, ptrdiff_t pred_stride);
+/* MotionCompUniPred -> int16 14-bit intermediate (:1156-1172). */
+void xo_mc_uni_bipred(int bitdepth, int is_chroma, int w, int h, int frac_x,
+                      int frac_y, const uint16_t *ref, ptrdiff_t ref_stride,
+                      int16_t *pred, ptrdiff_t pred_stride);
+/* AddAvgBi (inter_prediction.cc:1540-1553, sample_buffer.h:89-106). */
+void xo_add_avg(int bitdepth, int w, int h, const int16_t *s1, ptrdiff_t st1,
+                const int16_t *s2, ptrdiff_t st2, uint16_t *dst,
+                ptrdiff_t dst_stride);
+/* ClipMv (inter_prediction.cc:769-782). mv in/out 1/16 pel. */
+void xo_clip_mv(int pos_x, int pos_y, int pic_w, int pic_h, int *mv_x,
+                int *mv_y);
+/* MotionCompensationMv for one component of a uni-pred CU
+ * (inter_prediction.cc:740-758 + GetFullpelRef :1174-1205). Planes point at
+ * sample (0,0) of a padded picture. (x,y,w,h) are LUMA position/size. */
+void xo_mc_block(int bitdepth, int comp, int x, int y, int w, int h, int mv_x,
+                 int mv_y, int pic_w, int pic_h, const uint16_t *ref_plane,
+                 ptrdiff_t ref_stride, uint16_t *pred, ptrdiff_t pred_stride);
+
+/* ---- X1..X3, Q1 transforms and (de)quantisation ---- */
+/* ForwardTransform::Transform (transform.cc:869-961), high-precision mode. */
+void xo_fwd_transform(int bitdepth, int w, int h, int tx_hor, int tx_ver,
+                      int dst4x4, const int16_t *resi, ptrdiff_t resi_stride,
+                      int16_t *coeff, ptrdiff_t coeff_stride);
+/* InverseTransform::Transform (transform.cc:83-182). */
+void xo_inv_transform(int bitdepth, int w, int h, int tx_hor, int tx_ver,
+                      int dst4x4, int dc_only, const int16_t *coeff,
+                      ptrdiff_t coeff_stride, int16_t *resi,
+                      ptrdiff_t resi_stride);
+/* TransformSkip forward / inverse (transform.cc:963-995, :184-215). */
+void xo_fwd_transform_skip(int bitdepth, int w, int h, const int16_t *resi,
+                           ptrdiff_t resi_stride, int16_t *coeff,
+                           ptrdiff_t coeff_stride);
+void xo_inv_transform_skip(int bitdepth, int w, int h, const int16_t *coeff,
+                           ptrdiff_t coeff_stride, int16_t *resi,
+                           ptrdiff_t resi_stride);
+/* Quantize::Inverse (quantize.cc:94-125). qp_raw = Qp::GetQpRaw(comp). */
+void xo_dequant(int bitdepth, int qp_raw, int w, int h, const int16_t *in,
+                ptrdiff_t in_stride, int16_t *out, ptrdiff_t out_stride);
+/* RdoQuant::QuantFast without sign hiding (rdo_quant.cc:156-195, the
+ * disable_transform_sign_hiding / num_non_zero<=1 path). Returns the number
+ * of non-zero levels. */
+int xo_quant_fast(int bitdepth, int qp_raw, int intra_pic, int w, int h,
+                  const int16_t *in, ptrdiff_t in_stride, int16_t *out,
+                  ptrdiff_t out_stride);
+/* TransformAndReconstruct with QuantFast (transform_encoder.cc:203-285):
+ * resi = orig - pred; fwd; quant; [dequant; inv; rec = clip(pred + resi')]
+ * or rec = pred when cbf == 0.  Writes levels to `coeff_out` (stride w).
+ * Returns num_non_zero. */
+int xo_residual_pipeline(int bitdepth, const xvcgpu_tx_block *blk,
+                         const uint16_t *orig, ptrdiff_t orig_stride,
+                         const uint16_t *pred, ptrdiff_t pred_stride,
+                         uint16_t *rec, ptrdiff_t rec_stride,
+                         int16_t *coeff_out);
+
+/* ---- D1..D4 deblocking (xvc_common_lib/deblocking_filter.cc:56-450) ---- */
+/* planes[c] point at sample (0,0). cu_map: one int32 per 4x4 luma cell,
+ * row-major with `map_stride` entries per row, -1 = no CU. */
+void xo_deblock_picture(int bitdepth, int pic_w, int pic_h, int pic_is_bipred,
+                        int beta_offset, int tc_offset, int subblock_size,
+                        const xvcgpu_cu_info *cus, const int32_t *cu_map,
+                        int map_stride, uint16_t *const planes[3],
+                        const ptrdiff_t strides[3]);
+
+/* ---- P1 border extension (xvc_common_lib/yuv_pic.cc:118-150) ---- */
+void xo_pad_border(int w, int h, int border_x, int border_y, uint16_t *plane,
+                   ptrdiff_t stride);
+
+/* ---- T1..T3 motion search ---- */
+/* DetermineMinMaxMv (inter_prediction.cc:801-817) in full-pel units. */
+void xo_min_max_mv(int pos_x, int pos_y, int pic_w, int pic_h, int center_x,
+                   int center_y, int search_range, int mv_min[2],
+                   int mv_max[2]);
+/* TzSearch::Search (inter_tz_search.cc:84-171) with kSad / kSadFast chosen by
+ * GetFullpelMetric (inter_search.cc:1059-1069), eval_prev_mv_search_result
+ * on. Planes point at (0,0) of padded pictures. */
+void xo_tz_search(int bitdepth, const xvcgpu_me_block *blk, int pic_w,
+                  int pic_h, const uint16_t *orig, ptrdiff_t orig_stride,
+                  const uint16_t *ref, ptrdiff_t ref_stride, int out_mv[2],
+                  uint32_t *out_cost);
+/* InterSearch::FullSearch (inter_search.cc:853-891) on an int16 target
+ * (bi-pred "2*orig - pred_other", 64-stride buffer). */
+void xo_full_search(int bitdepth, int x, int y, int w, int h, int fullpel_mv,
+                    int mvp_x, int mvp_y, uint32_t lambda16, const int mv_min[2],
+                    const int mv_max[2], const int16_t *target,
+                    ptrdiff_t target_stride, const uint16_t *ref,
+                    ptrdiff_t ref_stride, int out_mv[2]);
+/* InterSearch::SubpelSearch (inter_search.cc:893-949) with kSatd. */
+void xo_subpel_search(int bitdepth, const xvcgpu_me_block *blk, int pic_w,
+                      int pic_h, const uint16_t *orig, ptrdiff_t orig_stride,
+                      const uint16_t *ref, ptrdiff_t ref_stride,
+                      const int fullpel[2], int out_mv[2], uint32_t *out_dist);
+/* GetMvdBitsFullpel / GetMvdBits / GetNumExpGolombBits
+ * (inter_search.cc:1150-1188). */
+uint32_t xo_mvd_bits_fullpel(int mvp_x, int mvp_y, int fx, int fy,
+                             int mvd_down_shift);
+uint32_t xo_mvd_bits(int mvp_x, int mvp_y, int mv_x, int mv_y,
+                     int mvd_down_shift);
+
+/* Transform matrix access (transform_data.cc, high-precision tables) for
+ * table-equality tests: returns pointer to N*N int16 row-major, or NULL. */
+const int16_t *xo_transform_matrix(int tx_type, int size);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* XVC_ORACLE_H_ */

@@ -1,0 +1,418 @@
+"""Pins the CPU oracle (oracle/xvc_oracle*.c) against the reference's own
+compiled code (oracle/_ref/libxvcref.so) on seeded random inputs.
+
+Runs only where the reference harness has been built (this container:
+`make -C oracle ref`); elsewhere the committed golden vectors
+(test_oracle_golden.py) carry the same pin.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+
+pytestmark = pytest.mark.skipif(not ol.have_ref(),
+                                reason="reference harness not built")
+
+SIZES = [4, 8, 16, 32, 64]
+
+
+@pytest.fixture(scope="module")
+def libs():
+    return ol.Lib("xo"), ol.Lib("xr")
+
+
+def rnd_samples(rng, bd, h, w, smooth=False):
+    if smooth:
+        base = rng.integers(0, 1 << bd)
+        a = base + rng.integers(-6, 7, size=(h, w))
+        return np.clip(a, 0, (1 << bd) - 1).astype(np.uint16)
+    return rng.integers(0, 1 << bd, size=(h, w), dtype=np.uint16)
+
+
+@pytest.mark.parametrize("bd", [8, 10, 12])
+@pytest.mark.parametrize("simd", [0, 1])
+def test_metrics_sample_sample(libs, bd, simd):
+    xo, xr = libs
+    xr._set_simd(simd)
+    rng = np.random.default_rng(100 + bd)
+    n = 0
+    for w in [2] + SIZES:
+        for h in [2] + SIZES:
+            if (w == 2) != (h == 2) and min(w, h) == 2 and max(w, h) > 8:
+                continue
+            for smooth in (False, True):
+                a = rnd_samples(rng, bd, h + 3, w + 5, smooth)[1:h + 1, 2:w + 2]
+                b = rnd_samples(rng, bd, h + 2, w + 9, smooth)[1:h + 1, 3:w + 3]
+                for metric in range(8):
+                    if metric in (4, 6) and h <= 8:  # Fast only used for H > 8 (inter_search.cc:1067)
+                        continue
+                    if metric == 7 and (w < 4 or h < 4):
+                        continue
+                    for qp in ((32,) if metric != 7 else (12, 27, 32, 45, 63)):
+                        r = xr.metric_ss(metric, bd, a, b, qp=qp)
+                        o = xo.metric_ss(metric, bd, a, b, qp=qp)
+                        assert r == o, (metric, bd, w, h, smooth, qp)
+                        n += 1
+    xr._set_simd(1)
+    assert n > 500
+
+
+@pytest.mark.parametrize("bd", [8, 10])
+def test_metrics_residual_sample(libs, bd):
+    xo, xr = libs
+    rng = np.random.default_rng(7 + bd)
+    for w in SIZES:
+        for h in SIZES:
+            # "2*orig - pred" range
+            a = rng.integers(-(1 << bd), 2 << bd, size=(h, 64)).astype(np.int16)[:, :w]
+            b = rnd_samples(rng, bd, h, w + 7)[:, 3:w + 3]
+            for metric in range(7):
+                if metric in (4, 6) and h <= 8:
+                    continue
+                assert xr.metric_rs(metric, bd, a, b) == xo.metric_rs(metric, bd, a, b), \
+                    (metric, w, h)
+            a2 = rng.integers(-2000, 2000, size=(h, 64)).astype(np.int16)[:, :w]
+            b2 = rng.integers(-2000, 2000, size=(h, 64)).astype(np.int16)[:, :w]
+            assert xr.ssd_rr(bd, a2, b2) == xo.ssd_rr(bd, a2, b2)
+
+
+@pytest.mark.parametrize("bd", [8, 10])
+def test_picture_ssd(libs, bd):
+    xo, xr = libs
+    rng = np.random.default_rng(3)
+    for (w, h) in [(64, 64), (72, 40), (128, 128), (136, 72), (200, 136), (352, 288)]:
+        a = rnd_samples(rng, bd, h, w)
+        b = np.clip(a.astype(np.int32) + rng.integers(-9, 10, size=(h, w)), 0,
+                    (1 << bd) - 1).astype(np.uint16)
+        ro, rn = xr.picture_ssd(bd, a, b)
+        oo, on = xo.picture_ssd(bd, a, b)
+        assert ro == oo and rn == on, (w, h, ro, oo, rn, on)
+
+
+@pytest.mark.parametrize("bd", [8, 10, 12])
+@pytest.mark.parametrize("simd", [0, 1])
+def test_interpolation(libs, bd, simd):
+    xo, xr = libs
+    xr._set_simd(simd)
+    rng = np.random.default_rng(11 + bd)
+    for is_chroma in (0, 1):
+        nph = 32 if is_chroma else 16
+        for w in ([2] if is_chroma else []) + SIZES:
+            for h in ([2] if is_chroma else []) + SIZES[:4]:
+                plane = rnd_samples(rng, bd, h + 16, w + 16)
+                fracs = [(0, 0), (0, 5), (7, 0)] + \
+                    [(int(rng.integers(1, nph)), int(rng.integers(1, nph))) for _ in range(3)]
+                for fx, fy in fracs:
+                    for bip in (False, True):
+                        r = xr.mc_uni(bd, is_chroma, w, h, fx, fy, plane, 8, 8, bip)
+                        o = xo.mc_uni(bd, is_chroma, w, h, fx, fy, plane, 8, 8, bip)
+                        assert np.array_equal(r, o), (is_chroma, w, h, fx, fy, bip)
+    # bi-pred average
+    for w in [2] + SIZES:
+        a = rng.integers(-8192, 8191, size=(8, 64)).astype(np.int16)[:, :w]
+        b = rng.integers(-8192, 8191, size=(8, 64)).astype(np.int16)[:, :w]
+        assert np.array_equal(xr.add_avg(bd, a, b), xo.add_avg(bd, a, b))
+    xr._set_simd(1)
+
+
+def test_clip_and_window(libs):
+    xo, xr = libs
+    rng = np.random.default_rng(5)
+    for _ in range(300):
+        pw, ph = int(rng.choice([64, 352, 1920])), int(rng.choice([64, 288, 1080]))
+        x = int(rng.integers(0, pw // 8)) * 8
+        y = int(rng.integers(0, ph // 8)) * 8
+        mx, my = int(rng.integers(-40000, 40000)), int(rng.integers(-40000, 40000))
+        assert xr.clip_mv(x, y, pw, ph, mx, my) == xo.clip_mv(x, y, pw, ph, mx, my)
+        rng_ = int(rng.choice([4, 96, 256]))
+        a = xr.min_max_mv(x, y, pw, ph, mx // 8, my // 8, rng_)
+        b = xo.min_max_mv(x, y, pw, ph, mx // 8, my // 8, rng_)
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+        assert xr._mvd_bits_fullpel(mx, my, x - 50, y - 30, 0) == \
+            xo._mvd_bits_fullpel(mx, my, x - 50, y - 30, 0)
+        assert xr._mvd_bits_fullpel(mx, my, x - 50, y - 30, 2) == \
+            xo._mvd_bits_fullpel(mx, my, x - 50, y - 30, 2)
+        assert xr._mvd_bits(mx, my, x * 3, -y, 0) == xo._mvd_bits(mx, my, x * 3, -y, 0)
+
+
+@pytest.mark.parametrize("bd", [8, 10])
+def test_mc_block(libs, bd):
+    xo, xr = libs
+    rng = np.random.default_rng(9)
+    pw, ph = 128, 96
+    for comp in (0, 1):
+        cs = 1 if comp else 0
+        border = 96 >> cs
+        padded = rnd_samples(rng, bd, (ph >> cs) + 2 * border, (pw >> cs) + 2 * border)
+        for _ in range(40):
+            w = int(rng.choice([8, 16, 32])); h = int(rng.choice([8, 16, 32]))
+            x = int(rng.integers(0, (pw - w) // 8 + 1)) * 8
+            y = int(rng.integers(0, (ph - h) // 8 + 1)) * 8
+            mx, my = int(rng.integers(-3000, 3000)), int(rng.integers(-3000, 3000))
+            r = xr.mc_block(bd, comp, x, y, w, h, mx, my, pw, ph, padded, border)
+            o = xo.mc_block(bd, comp, x, y, w, h, mx, my, pw, ph, padded, border)
+            assert np.array_equal(r, o), (comp, x, y, w, h, mx, my)
+
+
+def test_transform_tables(libs):
+    xo, xr = libs
+    for tx in range(1, 6):
+        for size in (2, 4, 8, 16, 32, 64):
+            r = xr.transform_matrix(tx, size)
+            o = xo.transform_matrix(tx, size)
+            if r is None:
+                assert tx != 1 and size == 2
+                continue
+            assert np.array_equal(r, o), (tx, size)
+
+
+@pytest.mark.parametrize("bd", [8, 10, 12])
+def test_transforms(libs, bd):
+    xo, xr = libs
+    rng = np.random.default_rng(21 + bd)
+    for w in [2] + SIZES:
+        for h in [2] + SIZES:
+            types = [(0, 0), (1, 1)]
+            if w >= 4 and h >= 4:
+                types += [(3, 5), (5, 3), (5, 5), (3, 3), (2, 4), (4, 2), (1, 5), (2, 2), (4, 4)]
+            for tx_hor, tx_ver in types:
+                resi = rng.integers(-(1 << bd) + 1, 1 << bd, size=(h, 64)).astype(np.int16)[:, :w]
+                r = xr.fwd_transform(bd, resi, tx_hor, tx_ver)
+                o = xo.fwd_transform(bd, resi, tx_hor, tx_ver)
+                assert np.array_equal(r, o), ("fwd", w, h, tx_hor, tx_ver)
+                # inverse on plausible dequantised coefficients
+                coeff = (r.astype(np.int32) // 16 * 16).astype(np.int16)
+                ri = xr.inv_transform(bd, coeff, tx_hor, tx_ver)
+                oi = xo.inv_transform(bd, coeff, tx_hor, tx_ver)
+                assert np.array_equal(ri, oi), ("inv", w, h, tx_hor, tx_ver)
+                # inverse on extreme coefficients (exercises clipping)
+                big = rng.integers(-32768, 32767, size=(h, 64)).astype(np.int16)[:, :w]
+                assert np.array_equal(xr.inv_transform(bd, big, tx_hor, tx_ver),
+                                      xo.inv_transform(bd, big, tx_hor, tx_ver))
+            # dc-only shortcut
+            dc = np.zeros((h, w), np.int16)
+            dc[0, 0] = rng.integers(-3000, 3000)
+            assert np.array_equal(xr.inv_transform(bd, dc, 0, 0, 0, 1),
+                                  xo.inv_transform(bd, dc, 0, 0, 0, 1))
+    # 4x4 DST
+    resi = rng.integers(-(1 << bd) + 1, 1 << bd, size=(4, 4)).astype(np.int16)
+    r = xr.fwd_transform(bd, resi, 0, 0, 1)
+    assert np.array_equal(r, xo.fwd_transform(bd, resi, 0, 0, 1))
+    assert np.array_equal(xr.inv_transform(bd, r, 0, 0, 1), xo.inv_transform(bd, r, 0, 0, 1))
+    # transform skip
+    for (w, h) in [(2, 2), (4, 2), (2, 4), (4, 4)]:
+        resi = rng.integers(-(1 << bd) + 1, 1 << bd, size=(h, w)).astype(np.int16)
+        r = xr.fwd_transform_skip(bd, resi)
+        assert np.array_equal(r, xo.fwd_transform_skip(bd, resi))
+        assert np.array_equal(xr.inv_transform_skip(bd, r), xo.inv_transform_skip(bd, r))
+
+
+@pytest.mark.parametrize("bd", [8, 10])
+def test_quant_dequant(libs, bd):
+    xo, xr = libs
+    rng = np.random.default_rng(31)
+    for w in [2] + SIZES:
+        for h in [2] + SIZES:
+            for qp in (0, 7, 22, 27, 32, 37, 51):
+                c = (rng.standard_normal((h, w)) * 600).astype(np.int16)
+                for intra in (0, 1):
+                    rl, rn = xr.quant_fast(bd, qp, intra, c)
+                    ol_, on = xo.quant_fast(bd, qp, intra, c)
+                    assert rn == on and np.array_equal(rl, ol_), (w, h, qp, intra)
+                lv = (rng.standard_normal((h, w)) * 20).astype(np.int16)
+                assert np.array_equal(xr.dequant(bd, qp, lv), xo.dequant(bd, qp, lv)), (w, h, qp)
+
+
+def random_partition(rng, pw, ph, min_size=4):
+    """Random quad/binary partition of the picture into CUs (x,y,w,h)."""
+    out = []
+
+    def split(x, y, w, h, depth):
+        if x >= pw or y >= ph:
+            return
+        inside = x + w <= pw and y + h <= ph
+        r = rng.random()
+        can_h = h > min_size
+        can_w = w > min_size
+        if not inside or depth < 1 or (depth < 2 and r < 0.8) or (r < 0.45 and (can_h or can_w)):
+            mode = rng.integers(0, 3) if inside else 0
+            if mode == 0 and can_h and can_w:
+                for (dx, dy) in ((0, 0), (w // 2, 0), (0, h // 2), (w // 2, h // 2)):
+                    split(x + dx, y + dy, w // 2, h // 2, depth + 1)
+                return
+            if mode == 1 and can_w:
+                split(x, y, w // 2, h, depth + 1)
+                split(x + w // 2, y, w // 2, h, depth + 1)
+                return
+            if can_h:
+                split(x, y, w, h // 2, depth + 1)
+                split(x, y + h // 2, w, h // 2, depth + 1)
+                return
+            if can_w:
+                split(x, y, w // 2, h, depth + 1)
+                split(x + w // 2, y, w // 2, h, depth + 1)
+                return
+        out.append((x, y, w, h))
+
+    for cy in range(0, ph, 64):
+        for cx in range(0, pw, 64):
+            split(cx, cy, 64, 64, 0)
+    return out
+
+
+def make_cus(rng, parts, bipred, l0, l1, pw, ph):
+    cus = np.zeros(len(parts), ol.CU_DTYPE)
+    cmap = -np.ones(((ph + 3) // 4, (pw + 3) // 4), np.int32)
+    for i, (x, y, w, h) in enumerate(parts):
+        c = cus[i]
+        c["x"], c["y"], c["w"], c["h"] = x, y, w, h
+        c["intra"] = rng.random() < 0.15
+        c["cbf_luma"] = rng.random() < 0.4
+        qp = int(rng.integers(20, 45))
+        c["qp_y"] = qp
+        c["qp_c"] = ol.chroma_qp(qp)
+        if bipred:
+            d = rng.integers(0, 3)
+        else:
+            d = 0
+        i0 = int(rng.integers(0, len(l0)))
+        i1 = int(rng.integers(0, len(l1)))
+        c["ref_idx0"] = i0 if d != 1 else 0
+        c["ref_poc"][0] = l0[i0] if d != 1 else -1
+        c["ref_poc"][1] = l1[i1] if d != 0 else -1
+        base = rng.integers(-40, 41, size=(2, 1, 2))
+        if rng.random() < 0.2:
+            mv = base + rng.integers(-20, 21, size=(2, 4, 2))
+        else:
+            mv = np.repeat(base, 4, axis=1)
+        c["mv"] = mv
+        cmap[y // 4:(y + h) // 4, x // 4:(x + w) // 4] = i
+    return cus, cmap
+
+
+@pytest.mark.parametrize("bd", [8, 10])
+@pytest.mark.parametrize("bipred", [0, 1])
+def test_deblock(libs, bd, bipred):
+    xo, xr = libs
+    rng = np.random.default_rng(41 + bd + bipred)
+    for (pw, ph) in [(64, 64), (136, 72), (200, 136)]:
+        for trial in range(3):
+            parts = random_partition(rng, pw, ph)
+            l0 = [8, 0, 16][:2 + trial % 2]
+            l1 = [16, 8]
+            cus, cmap = make_cus(rng, parts, bipred, l0, l1, pw, ph)
+            borders = [96, 48, 48]
+            planes = []
+            for c in range(3):
+                w, h = (pw, ph) if c == 0 else (pw // 2, ph // 2)
+                # blocky content so that filters trigger
+                base = rng.integers(0, 1 << bd, size=((h + 7) // 8, (w + 7) // 8))
+                p = np.kron(base, np.ones((8, 8), np.int64))[:h, :w]
+                amp = [2, 6, 30][trial]
+                p = np.clip(p // [16, 4, 1][trial] + (1 << (bd - 1)) +
+                            rng.integers(-amp, amp + 1, size=(h, w)), 0, (1 << bd) - 1)
+                full = np.zeros((h + 2 * borders[c], w + 2 * borders[c]), np.uint16)
+                full[borders[c]:borders[c] + h, borders[c]:borders[c] + w] = p
+                planes.append(full)
+            pr = [p.copy() for p in planes]
+            po = [p.copy() for p in planes]
+            beta, tc = [(0, 0), (2, -2), (-4, 4)][trial]
+            xr.deblock(bd, pw, ph, bipred, beta, tc, 4, cus, cmap, pr, borders, l0, l1)
+            xo.deblock(bd, pw, ph, bipred, beta, tc, 4, cus, cmap, po, borders)
+            changed = 0
+            for c in range(3):
+                b = borders[c]
+                w, h = (pw, ph) if c == 0 else (pw // 2, ph // 2)
+                assert np.array_equal(pr[c][b:b + h, b:b + w], po[c][b:b + h, b:b + w]), \
+                    (pw, ph, trial, c)
+                changed += int((pr[c] != planes[c]).sum())
+            assert changed > 0
+
+
+def test_pad_border(libs):
+    xo, xr = libs
+    rng = np.random.default_rng(51)
+    for (w, h) in [(64, 64), (136, 72)]:
+        borders = [80, 40, 40]
+        pr, po = [], []
+        for c in range(3):
+            cw, ch = (w, h) if c == 0 else (w // 2, h // 2)
+            full = rng.integers(0, 1024, size=(ch + 2 * borders[c], cw + 2 * borders[c]),
+                                dtype=np.uint16)
+            pr.append(full.copy())
+            po.append(full.copy())
+        xr.pad_border(w, h, pr, borders)
+        xo.pad_border(w, h, po, borders)
+        for c in range(3):
+            assert np.array_equal(pr[c], po[c])
+
+
+def make_pics(rng, bd, pw, ph, border, motion=(3, -2), noise=3):
+    """orig = shifted ref + noise over a textured plane -> searches do real work."""
+    H, W = ph + 2 * border, pw + 2 * border
+    yy, xx = np.mgrid[0:H, 0:W]
+    tex = (np.sin(xx / 7.0) * np.cos(yy / 9.0) * 0.25 + np.sin((xx + yy) / 23.0) * 0.2 + 0.5)
+    tex = tex * ((1 << bd) - 1) + rng.integers(-noise * 4, noise * 4 + 1, size=(H, W))
+    ref = np.clip(tex, 0, (1 << bd) - 1).astype(np.uint16)
+    orig = np.roll(ref, (-motion[1], -motion[0]), axis=(0, 1)).astype(np.int32)
+    orig = np.clip(orig + rng.integers(-noise, noise + 1, size=(H, W)), 0,
+                   (1 << bd) - 1).astype(np.uint16)
+    return orig, ref
+
+
+@pytest.mark.parametrize("bd", [8, 10])
+def test_tz_and_subpel_search(libs, bd):
+    xo, xr = libs
+    rng = np.random.default_rng(61 + bd)
+    pw, ph, border = 192, 128, 96
+    n_grid = 0
+    for motion in [(3, -2), (0, 0), (-17, 9), (40, 26)]:
+        orig, ref = make_pics(rng, bd, pw, ph, border, motion)
+        for _ in range(14):
+            w = int(rng.choice([8, 16, 32, 64])); h = int(rng.choice([8, 16, 32, 64]))
+            if w * h < 64:
+                continue
+            x = int(rng.integers(0, (pw - w) // 8 + 1)) * 8
+            y = int(rng.integers(0, (ph - h) // 8 + 1)) * 8
+            blk = ol.MeBlock()
+            blk.x, blk.y, blk.w, blk.h = x, y, w, h
+            blk.depth_nonzero = int(rng.integers(0, 2))
+            blk.fullpel_mv = int(rng.integers(0, 4) == 0)
+            blk.mvp_x = int(rng.integers(-200, 200))
+            blk.mvp_y = int(rng.integers(-200, 200))
+            blk.prev_x = int(rng.integers(-20, 20))
+            blk.prev_y = int(rng.integers(-20, 20))
+            blk.lambda16 = int(rng.choice([120000, 498000, 1500000]))
+            blk.search_range = int(rng.choice([96, 96, 128, 256]))
+            (rmv, _) = xr.tz_search(bd, blk, pw, ph, orig, ref, border)
+            (omv, ocost) = xo.tz_search(bd, blk, pw, ph, orig, ref, border)
+            assert rmv == omv, (motion, x, y, w, h, rmv, omv)
+            blk.fullpel_mv = 0
+            rs_, rd = xr.subpel_search(bd, blk, pw, ph, orig, ref, border, omv)
+            os_, od = xo.subpel_search(bd, blk, pw, ph, orig, ref, border, omv)
+            assert rs_ == os_ and rd == od, (motion, x, y, w, h, rs_, os_, rd, od)
+            n_grid += 1
+    assert n_grid > 30
+
+
+@pytest.mark.parametrize("bd", [8, 10])
+def test_full_search(libs, bd):
+    xo, xr = libs
+    rng = np.random.default_rng(71)
+    pw, ph, border = 128, 96, 96
+    orig, ref = make_pics(rng, bd, pw, ph, border, (2, 1))
+    for _ in range(12):
+        w = int(rng.choice([8, 16, 32])); h = int(rng.choice([8, 16, 32]))
+        x = int(rng.integers(0, (pw - w) // 8 + 1)) * 8
+        y = int(rng.integers(0, (ph - h) // 8 + 1)) * 8
+        o = orig[border + y:border + y + h, border + x:border + x + w].astype(np.int32)
+        p = ref[border + y + 1:border + y + 1 + h, border + x:border + x + w].astype(np.int32)
+        target = np.zeros((h, 64), np.int16)
+        target[:, :w] = 2 * o - p
+        mvp = (int(rng.integers(-60, 60)), int(rng.integers(-60, 60)))
+        mn, mx = xo.min_max_mv(x, y, pw, ph, mvp[0], mvp[1], 4)
+        a = xr.full_search(bd, x, y, w, h, 0, mvp, 498000, mn, mx, target[:, :w], ref, border, pw, ph)
+        b = xo.full_search(bd, x, y, w, h, 0, mvp, 498000, mn, mx, target[:, :w], ref, border, pw, ph)
+        assert a == b
