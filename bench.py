@@ -1,0 +1,241 @@
+#!/usr/bin/env python3
+"""bench.py -- hot-path frame passes per second on MI355X.
+
+One "step" = one hot-path frame pass (xvc_amd/pipeline.py) over one 1920x1080
+4:2:0 picture of a synthetic clip at QP 32, internal bit depth 10: TZ + sub-pel
+motion search, motion compensation, transform/quant/dequant/inverse/recon,
+deblocking, border extension and PSNR-Y parts - every kernel of SURVEY.md
+section 8a's M/T/I/X/Q/D/P rows, chained picture to picture (the deblocked,
+padded reconstruction of step i is the reference of step i+1).  Pictures,
+descriptors and decisions are resident in HBM before the timed region starts.
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+N > 1: every picture is sharded by rows of CUs across the ranks (CTU-row
+shards); the in-loop filter exchanges a 4-row halo with
+the neighbouring shards and the reconstructed rows are all-gathered over
+RCCL/xGMI so every rank holds the next reference picture.  Same pictures as
+N = 1 => "scaling": "strong".
+
+Prints ONE JSON line (rank 0).
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import numpy as np  # noqa: E402
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=60)
+    ap.add_argument("--warmup", type=int, default=6)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--qp", type=int, default=32)
+    ap.add_argument("--frames", type=int, default=8, help="distinct synthetic frames")
+    ap.add_argument("--cpu-frames", type=float, default=0.5,
+                    help="fraction of one picture's CUs timed on the CPU oracle")
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--kernel-times", action="store_true", default=True)
+    return ap.parse_args()
+
+
+def pad_planes(planes, border):
+    return [np.ascontiguousarray(np.pad(p, border if c == 0 else border // 2, mode="edge"))
+            for c, p in enumerate(planes)]
+
+
+def cpu_baseline(args, clip, bd, border):
+    """Oracle (kind "port") frame pass on the host, bounded sample: the first
+    rows of CUs of one picture, single thread."""
+    import oracle_frame
+    import oracle_lib as ol
+    from xvc_amd import pipeline
+    lib = ol.Lib("xo")
+    n_rows_total = (args.height + 15) // 16
+    rows = max(1, int(round(n_rows_total * args.cpu_frames)))
+    desc = pipeline.FrameDescriptors(args.width, args.height, args.qp,
+                                     row_range=(0, rows * 16))
+    ref, orig = pad_planes(clip.frame(0), border), pad_planes(clip.frame(1), border)
+    t0 = time.perf_counter()
+    oracle_frame.frame_pass(desc, bd, orig, ref, border, lib=lib)
+    dt = time.perf_counter() - t0
+    full = pipeline.FrameDescriptors(args.width, args.height, args.qp)
+    frac = desc.n_cus / full.n_cus
+    return {
+        "value": frac / dt, "unit": "frames/s", "cores": 1, "kind": "port",
+        "sample": "%d of %d CUs of one %dx%d picture (%.1f s of CPU work, "
+                  "single-thread C oracle, gcc -O2)" %
+                  (desc.n_cus, full.n_cus, args.width, args.height, dt),
+    }
+
+
+def main():
+    args = parse()
+    import torch
+    from xvc_amd import api, pipeline, synth
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if args.gpus != world and world > 1:
+        raise SystemExit("--gpus must equal WORLD_SIZE")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (there is no CPU fallback)")
+
+    bd, border = 10, api.BORDER_LUMA
+    W, H = args.width, args.height
+    ctx = api.Context(local_rank)
+    clip = synth.SyntheticClip(W, H, bd)
+
+    if world > 1:
+        from xvc_amd import sharded
+        runner = sharded.ShardedFramePass(ctx, W, H, bd, args.qp, rank, world,
+                                          torch.device("cuda", local_rank))
+    else:
+        runner = None
+
+    # resident inputs: `frames` original pictures + ping-pong reconstructions
+    origs = []
+    for n in range(1, args.frames + 1):
+        p = ctx.picture(W, H, bd)
+        p.upload(pad_planes(clip.frame(n), border), border)
+        origs.append(p)
+    if runner is None:
+        recs = [ctx.picture(W, H, bd), ctx.picture(W, H, bd)]
+        fp = pipeline.FramePass(ctx, W, H, bd, qp=args.qp)
+    else:
+        recs = runner.pictures
+        fp = runner.fp
+    recs[0].upload(pad_planes(clip.frame(0), border), border)
+    ctx.sync()
+
+    def step(i):
+        o = origs[i % len(origs)]
+        ref, rec = recs[i % 2], recs[(i + 1) % 2]
+        if runner is None:
+            fp.run(o, ref, rec, ref_poc=i)
+        else:
+            runner.run(o, i % 2, (i + 1) % 2, ref_poc=i)
+
+    def barrier():
+        ctx.sync()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    barrier()
+    t0 = time.perf_counter()
+    ctx.timer_begin()
+    for i in range(args.warmup, args.warmup + args.steps):
+        step(i)
+    gpu_ms = ctx.timer_end()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # PSNR-Y of the last reconstructed picture (sanity, not timed)
+    _, _, _, ssd = fp.results()
+    psnr_y = pipeline.psnr_from_ssd(int(ssd[0]), int(ssd[1])) if ssd[1] else None
+
+    # ---- roofline of the dominant kernel: HIP events around it on the
+    # context's stream, per launch, same data as the timed region ----
+    roof = None
+    if rank == 0:
+        d = fp.desc
+        o, ref, rec = origs[0], recs[0], recs[1]
+        reps = 20
+
+        def timed(fn):
+            fn()
+            ctx.sync()
+            ctx.timer_begin()
+            for _ in range(reps):
+                fn()
+            return ctx.timer_end() / reps
+
+        times = {
+            "me_search": timed(lambda: ctx.me_search_dev(
+                o, ref, api.ME_FULLPEL | api.ME_SUBPEL, fp.d_me.ptr, d.n_cus,
+                fp.d_res.ptr)),
+            "mc_from_me": timed(lambda: ctx.mc_from_me_dev(
+                ref, fp.pred, fp.d_me.ptr, fp.d_res.ptr, d.n_cus)),
+            "residual": timed(lambda: ctx.residual_batch_dev(
+                o, fp.pred, rec, fp.d_tx.ptr, len(d.tx), None, None, fp.d_nnz.ptr)),
+            "deblock": timed(lambda: ctx.deblock_dev(
+                rec, fp.d_cus.ptr, d.n_cus, fp.d_map.ptr, d.cu_map.shape[1])),
+            "pad_border": timed(lambda: ctx.pad_border(rec)),
+            "picture_ssd": timed(lambda: ctx.picture_ssd_dev(o, rec, 0, bd,
+                                                             fp.d_ssd.ptr)),
+        }
+        dom = max(times, key=times.get)
+        # algorithmic bytes per launch
+        S = 2
+        n_luma = sum(int(b["w"]) * int(b["h"]) for b in d.me)
+        alg = {
+            # each plane read once: original + reference luma of the CUs
+            "me_search": 2 * n_luma * S,
+            "mc_from_me": 2 * int(1.5 * n_luma) * S,
+            "residual": 3 * int(1.5 * n_luma) * S,
+            "deblock": 2 * int(1.5 * n_luma) * S + 16 * (n_luma // 16),
+            "pad_border": 2 * 80 * (W + H + 160) * S * 2,
+            "picture_ssd": 2 * n_luma * S,
+        }
+        achieved = alg[dom] / (times[dom] * 1e-3) / 1e9
+        roof = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": 8000.0,
+                "unit": "GB/s", "frac": achieved / 8000.0, "traffic": None,
+                "ms_per_launch": times[dom],
+                "all_kernels_ms": {k: round(v, 4) for k, v in times.items()}}
+
+    cpu = None
+    if rank == 0 and not args.no_cpu:
+        cpu = cpu_baseline(args, clip, bd, border)
+
+    if rank == 0:
+        value = args.steps / dt
+        out = {
+            "metric": "hot-path encoded frames/sec (ME+MC+transform/quant+deblock+pad), "
+                      "bit-exact recon vs oracle",
+            "value": value, "unit": "frames/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * dt / args.steps,
+            "gpu_ms_per_step_events": gpu_ms / args.steps,
+            "higher_is_better": True,
+            "scaling": "strong" if world > 1 else "weak",
+            "vs_baseline": None, "dtype": "u16", "data": "synthetic",
+            "psnr_y": psnr_y,
+            "config": {"workload": "%dx%d yuv420p 30fps synthetic, QP %d, internal "
+                                   "bitdepth 10, 16x16 CUs, TZ range 96, QuantFast" %
+                                   (W, H, args.qp),
+                       "cus_per_picture": fp.desc.n_cus if runner is None
+                       else runner.total_cus,
+                       "parallelism": "single" if world == 1 else "cu-row-shard%d" % world},
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,240 @@
+/*
+ * xvcgpu.h -- C-ABI of libxvcgpu.so: the MI355X (gfx950) implementation of the
+ * data-parallel part of xvc's per-CU encoder inner loop.
+ *
+ * This is the drop-in boundary.  The reference
+ * has no device boundary: its "operator plug-in point" is three structs of
+ * C function pointers called once per block (sample_metric.h:166-191,
+ * inter_prediction.h:176-216) plus direct member calls for transforms,
+ * dequant, deblocking and padding.  One block per call is tens of ns - far
+ * below a kernel launch - so every entry point here is the BATCHED form of
+ * one of those calls: same arithmetic, same argument meaning, N independent
+ * blocks per launch.  The reference-side binding a maintainer would add is
+ * shown in INTEGRATION.md.
+ *
+ * Conventions
+ *  - plain C types only; no HIP/torch types.  Device memory is passed as
+ *    `void *` device pointers obtained from xvcgpu_malloc() (or any HIP
+ *    allocation of the same device, e.g. a torch tensor's data_ptr()).
+ *  - every function returns an xvcgpu_status; xvcgpu_last_error() gives text.
+ *    No exceptions cross the ABI (mirrors xvc_enc_return_code, xvcenc.h:34-45).
+ *  - all launches go to the context's stream (xvcgpu_set_stream) and are
+ *    asynchronous; xvcgpu_sync() waits.  Calls on one context must come from
+ *    one thread at a time (the reference API is single-caller too,
+ *    xvcenc.h:153-190); use one context per worker for concurrency, exactly
+ *    as the reference uses one PictureEncoder per worker thread
+ *    (thread_encoder.cc:99-159).
+ *  - there is NO CPU fallback: without a gfx950 device xvcgpu_create() fails.
+ */
+#ifndef XVCGPU_H_
+#define XVCGPU_H_
+
+#include "xvcgpu_types.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum xvcgpu_status {
+  XVCGPU_OK = 0,
+  XVCGPU_INVALID_ARGUMENT = 10, /* cf. XVC_ENC_INVALID_ARGUMENT, xvcenc.h:37 */
+  XVCGPU_NO_DEVICE = 20,
+  XVCGPU_OUT_OF_MEMORY = 30,
+  XVCGPU_DEVICE_ERROR = 40,
+  XVCGPU_UNSUPPORTED = 50
+} xvcgpu_status;
+
+typedef struct xvcgpu_ctx xvcgpu_ctx;         /* one per device/worker      */
+typedef struct xvcgpu_picture xvcgpu_picture; /* padded 4:2:0 planes in HBM */
+
+/* ---- context ------------------------------------------------------------ */
+xvcgpu_status xvcgpu_create(int device, xvcgpu_ctx **out);
+void xvcgpu_destroy(xvcgpu_ctx *ctx);
+const char *xvcgpu_last_error(const xvcgpu_ctx *ctx);
+/* Version string "xvcgpu <major>.<minor> gfx950". Callable without a GPU. */
+const char *xvcgpu_version(void);
+/* Use an external hipStream_t (e.g. torch's current stream); NULL = own. */
+xvcgpu_status xvcgpu_set_stream(xvcgpu_ctx *ctx, void *hip_stream);
+xvcgpu_status xvcgpu_sync(xvcgpu_ctx *ctx);
+/* HIP-event stopwatch on the context's stream (bench.py's timed region). */
+xvcgpu_status xvcgpu_timer_begin(xvcgpu_ctx *ctx);
+xvcgpu_status xvcgpu_timer_end(xvcgpu_ctx *ctx, float *elapsed_ms);
+
+/* ---- raw device memory -------------------------------------------------- */
+xvcgpu_status xvcgpu_malloc(xvcgpu_ctx *ctx, size_t bytes, void **dev_ptr);
+xvcgpu_status xvcgpu_free(xvcgpu_ctx *ctx, void *dev_ptr);
+xvcgpu_status xvcgpu_memcpy_h2d(xvcgpu_ctx *ctx, void *dst, const void *src,
+                                size_t bytes);
+xvcgpu_status xvcgpu_memcpy_d2h(xvcgpu_ctx *ctx, void *dst, const void *src,
+                                size_t bytes);
+xvcgpu_status xvcgpu_memset(xvcgpu_ctx *ctx, void *dst, int value, size_t bytes);
+
+/* ---- pictures ----------------------------------------------------------- *
+ * Device twin of YuvPicture (yuv_pic.cc:32-68): planar Y,U,V of 16-bit
+ * samples, every plane surrounded by a replicated border.  The reference uses
+ * 80 luma / 40 chroma samples; here the border is 128 / 64 and strides are
+ * rounded to 64 samples so that every row starts 256-byte aligned in HBM.
+ * All MV clipping rules (inter_prediction.cc:769-782) keep reads within 80. */
+#define XVCGPU_BORDER_LUMA 128
+#define XVCGPU_BORDER_CHROMA 64
+
+xvcgpu_status xvcgpu_picture_create(xvcgpu_ctx *ctx, int width, int height,
+                                    int bitdepth, xvcgpu_picture **out);
+/* Bytes needed by a picture of this size (for xvcgpu_picture_wrap). */
+size_t xvcgpu_picture_bytes(int width, int height);
+/* Build a picture over caller-owned device memory (e.g. a torch tensor) of at
+ * least xvcgpu_picture_bytes() bytes, 256-byte aligned. */
+xvcgpu_status xvcgpu_picture_wrap(xvcgpu_ctx *ctx, int width, int height,
+                                  int bitdepth, void *dev_mem, size_t bytes,
+                                  xvcgpu_picture **out);
+void xvcgpu_picture_destroy(xvcgpu_picture *pic);
+/* Host <-> device transfer of the visible area; planes are tightly described
+ * by (pointer, stride in samples).  Cf. YuvPicture::CopyToSameBitdepth
+ * (yuv_pic.cc:78-116) for the download direction. */
+xvcgpu_status xvcgpu_picture_upload(xvcgpu_picture *pic,
+                                    const uint16_t *const planes[3],
+                                    const ptrdiff_t strides[3]);
+xvcgpu_status xvcgpu_picture_download(const xvcgpu_picture *pic,
+                                      uint16_t *const planes[3],
+                                      const ptrdiff_t strides[3]);
+/* Transfer including the border (tests of PadBorder). border_x/y <= 128/64
+ * luma, halved for chroma. */
+xvcgpu_status xvcgpu_picture_upload_padded(xvcgpu_picture *pic,
+                                           const uint16_t *const planes[3],
+                                           const ptrdiff_t strides[3],
+                                           int border_luma);
+xvcgpu_status xvcgpu_picture_download_padded(const xvcgpu_picture *pic,
+                                             uint16_t *const planes[3],
+                                             const ptrdiff_t strides[3],
+                                             int border_luma);
+/* Device pointer to sample (0,0) of a plane and its stride in samples. */
+xvcgpu_status xvcgpu_picture_plane(const xvcgpu_picture *pic, int comp,
+                                   void **dev_ptr, ptrdiff_t *stride);
+xvcgpu_status xvcgpu_picture_copy(xvcgpu_ctx *ctx, xvcgpu_picture *dst,
+                                  const xvcgpu_picture *src);
+
+/* ---- P1: YuvPicture::PadBorder (yuv_pic.cc:118-150) --------------------- */
+xvcgpu_status xvcgpu_pad_border(xvcgpu_ctx *ctx, xvcgpu_picture *pic);
+
+/* ---- M1..M7: SampleMetric::Compare, Sample x Sample --------------------- *
+ * (sample_metric.cc:171-223, fn table sample_metric.h:166-191).
+ * One candidate = block (x,y,w,h) of component `comp` in pic `a` against the
+ * block displaced by the full-pel vector (mv_x,mv_y) in pic `b`.
+ * out[i] = static_cast<Distortion>(dist * weight), exactly as Compare(). */
+typedef struct xvcgpu_metric_cand {
+  int16_t x, y;       /* position in the component plane                    */
+  uint8_t w, h;       /* size in the component plane                        */
+  uint8_t metric;     /* xvcgpu_metric                                      */
+  int8_t qp;          /* raw luma qp (structural SSD only)                  */
+  int16_t mv_x, mv_y; /* full-pel displacement into `b`                     */
+} xvcgpu_metric_cand;
+
+xvcgpu_status xvcgpu_metric_batch(xvcgpu_ctx *ctx, const xvcgpu_picture *a,
+                                  const xvcgpu_picture *b, int comp,
+                                  double weight, int structural_strength,
+                                  const xvcgpu_metric_cand *d_cands, int n,
+                                  uint64_t *d_out);
+
+/* ---- T1 + T3 (+W1, I1, M1, M4): MotionEstNormal with TZ search ---------- *
+ * (inter_search.cc:606-662, inter_tz_search.cc:84-171, inter_search.cc:
+ * 893-964).  One result per xvcgpu_me_block, bit-identical to running the
+ * reference search on that block with the same predictor inputs.
+ * flags: XVCGPU_ME_FULLPEL runs the TZ search; XVCGPU_ME_SUBPEL runs the
+ * 9+8 point half/quarter-pel refinement starting from results[i].fullpel_*
+ * (taken from the TZ search when both flags are set). */
+#define XVCGPU_ME_FULLPEL 1
+#define XVCGPU_ME_SUBPEL 2
+xvcgpu_status xvcgpu_me_search(xvcgpu_ctx *ctx, const xvcgpu_picture *orig,
+                               const xvcgpu_picture *ref, int flags,
+                               const xvcgpu_me_block *d_blocks, int n,
+                               xvcgpu_me_result *d_results);
+
+/* ---- I1: MotionCompensationMv, uni-prediction --------------------------- *
+ * (inter_prediction.cc:740-758 -> FilterLuma/FilterChroma :1387-1448).
+ * Writes the predicted block of component blk.comp into `pred` at the CU's
+ * position (pred plays the role of TransformEncoder's pred buffers,
+ * transform_encoder.cc:45-47). */
+xvcgpu_status xvcgpu_mc_batch(xvcgpu_ctx *ctx, const xvcgpu_picture *ref,
+                              xvcgpu_picture *pred,
+                              const xvcgpu_mc_block *d_blocks, int n);
+
+/* Same for all three components of every CU of a motion search batch, taking
+ * the MV from d_results[i].mv_* (InterPrediction::MotionCompensation for a
+ * uni-pred CU, inter_prediction.cc:710-722): decisions stay in HBM. */
+xvcgpu_status xvcgpu_mc_from_me(xvcgpu_ctx *ctx, const xvcgpu_picture *ref,
+                                xvcgpu_picture *pred,
+                                const xvcgpu_me_block *d_blocks,
+                                const xvcgpu_me_result *d_results, int n);
+/* Device-side host-driver glue: fill the deblocking metadata of n uni-pred
+ * inter CUs (what CuEncoder stores into CodingUnit, cu_encoder.cc:543-577)
+ * from the search results and the luma non-zero counts of the residual batch.
+ * d_luma_tx_index[i] = index of CU i's luma block in d_nnz (NULL: identity). */
+xvcgpu_status xvcgpu_cu_info_from_me(xvcgpu_ctx *ctx,
+                                     const xvcgpu_me_block *d_blocks,
+                                     const xvcgpu_me_result *d_results,
+                                     const int32_t *d_nnz,
+                                     const int32_t *d_luma_tx_index, int n,
+                                     int qp_y, int qp_c, int ref_poc,
+                                     xvcgpu_cu_info *d_cus);
+
+/* ---- X1 + Q + Q1 + X2 + R1: TransformAndReconstruct --------------------- *
+ * (transform_encoder.cc:203-285) with the reference's non-RDO quantiser
+ * RdoQuant::QuantFast (rdo_quant.cc:156-195, sign hiding off).  For block i:
+ * resi = orig - pred; coeff = T(resi); level = Q(coeff) -> d_levels +
+ * d_level_offsets[i] (w*h int16, row-major, stride w); d_nnz[i] = non-zero
+ * count; rec = cbf ? clip(pred + T^-1(Q^-1(level))) : pred.
+ * d_levels / d_level_offsets / d_nnz may be NULL when not wanted. */
+xvcgpu_status xvcgpu_residual_batch(xvcgpu_ctx *ctx, const xvcgpu_picture *orig,
+                                    const xvcgpu_picture *pred,
+                                    xvcgpu_picture *rec,
+                                    const xvcgpu_tx_block *d_blocks, int n,
+                                    int16_t *d_levels,
+                                    const uint32_t *d_level_offsets,
+                                    int32_t *d_nnz);
+/* X1 only: coefficients of (orig - pred) for a host-side quantiser (RDOQ stays
+ * on the host). Output layout as d_levels. */
+xvcgpu_status xvcgpu_fwd_transform_batch(xvcgpu_ctx *ctx,
+                                         const xvcgpu_picture *orig,
+                                         const xvcgpu_picture *pred,
+                                         const xvcgpu_tx_block *d_blocks, int n,
+                                         int16_t *d_coeffs,
+                                         const uint32_t *d_coeff_offsets);
+/* Q1 + X2 + R1: Quantize::Inverse -> InverseTransform -> AddClip for levels
+ * chosen by the host (decoder reconstruction shares this entry point,
+ * cu_decoder.cc:102-138). d_nnz[i] == 0 copies pred; dc-only shortcut applied
+ * when d_nnz[i] == 1 and level[0] != 0 (transform_encoder.cc:241). */
+xvcgpu_status xvcgpu_inv_transform_batch(xvcgpu_ctx *ctx,
+                                         const xvcgpu_picture *pred,
+                                         xvcgpu_picture *rec,
+                                         const xvcgpu_tx_block *d_blocks, int n,
+                                         const int16_t *d_levels,
+                                         const uint32_t *d_level_offsets,
+                                         const int32_t *d_nnz);
+
+/* ---- D1..D4: DeblockingFilter::DeblockPicture --------------------------- *
+ * (deblocking_filter.cc:56-77). d_cu_map: one int32 per 4x4 luma cell,
+ * row-major, `map_stride` entries per row, ceil(height/4) rows, value = index
+ * into d_cus or -1. subblock_size 4 (default) or 8 (restricted mode). */
+xvcgpu_status xvcgpu_deblock(xvcgpu_ctx *ctx, xvcgpu_picture *rec,
+                             const xvcgpu_cu_info *d_cus, int n_cus,
+                             const int32_t *d_cu_map, int map_stride,
+                             int pic_is_bipred, int beta_offset, int tc_offset,
+                             int subblock_size);
+
+/* ---- picture SSD / PSNR parts ------------------------------------------- *
+ * SampleMetric::ComparePicture / ComputePsnr block walk (sample_metric.cc:
+ * 37-155): per-64x64-block SSD, each >> 2*(shift_bitdepth-8), summed.
+ * d_out[0] = distortion, d_out[1] = sample count. */
+xvcgpu_status xvcgpu_picture_ssd(xvcgpu_ctx *ctx, const xvcgpu_picture *a,
+                                 const xvcgpu_picture *b, int comp,
+                                 int shift_bitdepth, uint64_t *d_out);
+
+/* ---- tables (host side, no GPU needed) ---------------------------------- *
+ * The 8-bit-fraction transform matrices the kernels use (transform_data.cc:
+ * 109-796), for table-equality tests. out: size*size int16 row-major. */
+xvcgpu_status xvcgpu_get_transform_matrix(int tx_type, int size, int16_t *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* XVCGPU_H_ */

@@ -610,6 +610,7 @@ int xo_residual_pipeline(int bd, const xvcgpu_tx_block *b, const uint16_t *orig,
   /* transform_encoder.cc:203-285 with QuantFast, no transform skip */
   int16_t resi[64 * 64], coeff[64 * 64], deq[64 * 64];
   const int w = b->w, h = b->h;
+  memset(resi, 0, sizeof(resi));
   const uint16_t *o = orig + (ptrdiff_t)b->y * os + b->x;
   const uint16_t *p = pred + (ptrdiff_t)b->y * ps + b->x;
   uint16_t *r = rec + (ptrdiff_t)b->y * rs + b->x;

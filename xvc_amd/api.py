@@ -1,0 +1,430 @@
+"""Python host side of libxvcgpu.so (ctypes over the C-ABI in include/xvcgpu.h).
+
+This is plumbing for tests and bench.py: it mirrors the C-ABI one-to-one and
+adds numpy conveniences (host arrays in, host arrays out).  There is no CPU
+fallback: if the HIP library is missing or no gfx950 device is present the
+constructors raise.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libxvcgpu.so")
+
+BORDER_LUMA = 128
+BORDER_CHROMA = 64
+ME_FULLPEL = 1
+ME_SUBPEL = 2
+
+METRIC_SSD, METRIC_SATD, METRIC_SATD_ACONLY, METRIC_SAD, METRIC_SAD_FAST, \
+    METRIC_SAD_ACONLY, METRIC_SAD_ACONLY_FAST, METRIC_STRUCTURAL_SSD = range(8)
+TX_DEFAULT, TX_DCT2, TX_DCT5, TX_DCT8, TX_DST1, TX_DST7 = range(6)
+
+CU_DTYPE = np.dtype([("x", "<u2"), ("y", "<u2"), ("w", "u1"), ("h", "u1"),
+                     ("intra", "u1"), ("cbf_luma", "u1"), ("qp_y", "i1"),
+                     ("qp_c", "i1"), ("ref_idx0", "i1"), ("reserved", "i1"),
+                     ("ref_poc", "<i4", (2,)), ("mv", "<i4", (2, 4, 2))])
+ME_DTYPE = np.dtype([("x", "<i2"), ("y", "<i2"), ("w", "u1"), ("h", "u1"),
+                     ("depth_nonzero", "u1"), ("fullpel_mv", "u1"),
+                     ("mvp_x", "<i4"), ("mvp_y", "<i4"), ("prev_x", "<i4"),
+                     ("prev_y", "<i4"), ("lambda16", "<u4"),
+                     ("search_range", "<i4")])
+MERES_DTYPE = np.dtype([("fullpel_x", "<i4"), ("fullpel_y", "<i4"),
+                        ("mv_x", "<i4"), ("mv_y", "<i4"),
+                        ("fullpel_cost", "<u4"), ("subpel_dist", "<u4")])
+TX_DTYPE = np.dtype([("x", "<i2"), ("y", "<i2"), ("w", "u1"), ("h", "u1"),
+                     ("comp", "u1"), ("tx_hor", "u1"), ("tx_ver", "u1"),
+                     ("dst4x4", "u1"), ("qp", "i1"), ("intra_pic", "u1")])
+MC_DTYPE = np.dtype([("x", "<i2"), ("y", "<i2"), ("w", "u1"), ("h", "u1"),
+                     ("comp", "u1"), ("reserved", "u1"), ("mv_x", "<i4"),
+                     ("mv_y", "<i4")])
+CAND_DTYPE = np.dtype([("x", "<i2"), ("y", "<i2"), ("w", "u1"), ("h", "u1"),
+                       ("metric", "u1"), ("qp", "i1"), ("mv_x", "<i2"),
+                       ("mv_y", "<i2")])
+assert CU_DTYPE.itemsize == 84 and ME_DTYPE.itemsize == 32
+assert MERES_DTYPE.itemsize == 24 and TX_DTYPE.itemsize == 12
+assert MC_DTYPE.itemsize == 16 and CAND_DTYPE.itemsize == 12
+
+# every symbol include/xvcgpu.h declares
+SYMBOLS = [
+    "xvcgpu_create", "xvcgpu_destroy", "xvcgpu_last_error", "xvcgpu_version",
+    "xvcgpu_set_stream", "xvcgpu_sync", "xvcgpu_timer_begin", "xvcgpu_timer_end",
+    "xvcgpu_malloc", "xvcgpu_free", "xvcgpu_memcpy_h2d", "xvcgpu_memcpy_d2h",
+    "xvcgpu_memset", "xvcgpu_picture_create", "xvcgpu_picture_bytes",
+    "xvcgpu_picture_wrap", "xvcgpu_picture_destroy", "xvcgpu_picture_upload",
+    "xvcgpu_picture_download", "xvcgpu_picture_upload_padded",
+    "xvcgpu_picture_download_padded", "xvcgpu_picture_plane",
+    "xvcgpu_picture_copy", "xvcgpu_pad_border", "xvcgpu_metric_batch",
+    "xvcgpu_me_search", "xvcgpu_mc_batch", "xvcgpu_mc_from_me",
+    "xvcgpu_cu_info_from_me", "xvcgpu_residual_batch",
+    "xvcgpu_fwd_transform_batch", "xvcgpu_inv_transform_batch",
+    "xvcgpu_deblock", "xvcgpu_picture_ssd", "xvcgpu_get_transform_matrix",
+]
+
+_vp = C.c_void_p
+_pd = C.c_ssize_t
+_lib = None
+
+
+class XvcGpuError(RuntimeError):
+    pass
+
+
+def load_library():
+    """Load libxvcgpu.so (fails loudly; never substitutes a CPU path)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise XvcGpuError(
+            "libxvcgpu.so is not built: run `python -m xvc_amd.build` "
+            "(there is no CPU fallback)")
+    lib = C.CDLL(LIB_PATH)
+    lib.xvcgpu_version.restype = C.c_char_p
+    lib.xvcgpu_last_error.restype = C.c_char_p
+    lib.xvcgpu_last_error.argtypes = [_vp]
+    lib.xvcgpu_picture_bytes.restype = C.c_size_t
+    lib.xvcgpu_picture_bytes.argtypes = [C.c_int, C.c_int]
+    lib.xvcgpu_destroy.restype = None
+    lib.xvcgpu_destroy.argtypes = [_vp]
+    lib.xvcgpu_picture_destroy.restype = None
+    lib.xvcgpu_picture_destroy.argtypes = [_vp]
+    sigs = {
+        "xvcgpu_create": [C.c_int, C.POINTER(_vp)],
+        "xvcgpu_set_stream": [_vp, _vp],
+        "xvcgpu_sync": [_vp],
+        "xvcgpu_timer_begin": [_vp],
+        "xvcgpu_timer_end": [_vp, C.POINTER(C.c_float)],
+        "xvcgpu_malloc": [_vp, C.c_size_t, C.POINTER(_vp)],
+        "xvcgpu_free": [_vp, _vp],
+        "xvcgpu_memcpy_h2d": [_vp, _vp, _vp, C.c_size_t],
+        "xvcgpu_memcpy_d2h": [_vp, _vp, _vp, C.c_size_t],
+        "xvcgpu_memset": [_vp, _vp, C.c_int, C.c_size_t],
+        "xvcgpu_picture_create": [_vp, C.c_int, C.c_int, C.c_int, C.POINTER(_vp)],
+        "xvcgpu_picture_wrap": [_vp, C.c_int, C.c_int, C.c_int, _vp, C.c_size_t,
+                                C.POINTER(_vp)],
+        "xvcgpu_picture_upload": [_vp, C.POINTER(_vp), C.POINTER(_pd)],
+        "xvcgpu_picture_download": [_vp, C.POINTER(_vp), C.POINTER(_pd)],
+        "xvcgpu_picture_upload_padded": [_vp, C.POINTER(_vp), C.POINTER(_pd), C.c_int],
+        "xvcgpu_picture_download_padded": [_vp, C.POINTER(_vp), C.POINTER(_pd), C.c_int],
+        "xvcgpu_picture_plane": [_vp, C.c_int, C.POINTER(_vp), C.POINTER(_pd)],
+        "xvcgpu_picture_copy": [_vp, _vp, _vp],
+        "xvcgpu_pad_border": [_vp, _vp],
+        "xvcgpu_metric_batch": [_vp, _vp, _vp, C.c_int, C.c_double, C.c_int, _vp,
+                                C.c_int, _vp],
+        "xvcgpu_me_search": [_vp, _vp, _vp, C.c_int, _vp, C.c_int, _vp],
+        "xvcgpu_mc_batch": [_vp, _vp, _vp, _vp, C.c_int],
+        "xvcgpu_mc_from_me": [_vp, _vp, _vp, _vp, _vp, C.c_int],
+        "xvcgpu_cu_info_from_me": [_vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int,
+                                   C.c_int, C.c_int, _vp],
+        "xvcgpu_residual_batch": [_vp, _vp, _vp, _vp, _vp, C.c_int, _vp, _vp, _vp],
+        "xvcgpu_fwd_transform_batch": [_vp, _vp, _vp, _vp, C.c_int, _vp, _vp],
+        "xvcgpu_inv_transform_batch": [_vp, _vp, _vp, _vp, C.c_int, _vp, _vp, _vp],
+        "xvcgpu_deblock": [_vp, _vp, _vp, C.c_int, _vp, C.c_int, C.c_int, C.c_int,
+                           C.c_int, C.c_int],
+        "xvcgpu_picture_ssd": [_vp, _vp, _vp, C.c_int, C.c_int, _vp],
+        "xvcgpu_get_transform_matrix": [C.c_int, C.c_int, _vp],
+    }
+    for name, args in sigs.items():
+        f = getattr(lib, name)
+        f.restype = C.c_int
+        f.argtypes = args
+    _lib = lib
+    return lib
+
+
+def transform_matrix(tx_type, size):
+    """Host-side table query (works without a GPU)."""
+    lib = load_library()
+    out = np.zeros((size, size), np.int16)
+    st = lib.xvcgpu_get_transform_matrix(tx_type, size, out.ctypes.data)
+    if st != 0:
+        return None
+    return out
+
+
+class DeviceBuffer:
+    """Raw device allocation owned by a Context."""
+
+    def __init__(self, ctx, nbytes):
+        self.ctx = ctx
+        self.nbytes = int(nbytes)
+        p = _vp()
+        ctx._check(ctx.lib.xvcgpu_malloc(ctx.h, self.nbytes, C.byref(p)))
+        self.ptr = p.value
+
+    @classmethod
+    def from_array(cls, ctx, arr):
+        arr = np.ascontiguousarray(arr)
+        buf = cls(ctx, max(arr.nbytes, 1))
+        if arr.nbytes:
+            ctx._check(ctx.lib.xvcgpu_memcpy_h2d(ctx.h, buf.ptr, arr.ctypes.data,
+                                                 arr.nbytes))
+        return buf
+
+    def to_array(self, dtype, count):
+        out = np.zeros(count, dtype)
+        if out.nbytes:
+            self.ctx._check(self.ctx.lib.xvcgpu_memcpy_d2h(
+                self.ctx.h, out.ctypes.data, self.ptr, out.nbytes))
+        return out
+
+    def free(self):
+        if self.ptr:
+            self.ctx.lib.xvcgpu_free(self.ctx.h, self.ptr)
+            self.ptr = None
+
+
+class Picture:
+    """Device twin of YuvPicture (padded 4:2:0 16-bit planes in HBM)."""
+
+    def __init__(self, ctx, width, height, bitdepth=10, wrap_ptr=None,
+                 wrap_bytes=0):
+        self.ctx = ctx
+        self.w, self.h, self.bd = width, height, bitdepth
+        p = _vp()
+        if wrap_ptr is None:
+            ctx._check(ctx.lib.xvcgpu_picture_create(ctx.h, width, height, bitdepth,
+                                                     C.byref(p)))
+        else:
+            ctx._check(ctx.lib.xvcgpu_picture_wrap(ctx.h, width, height, bitdepth,
+                                                   wrap_ptr, wrap_bytes, C.byref(p)))
+        self.h_pic = p.value
+
+    def _args(self, planes, border=0):
+        pp = (_vp * 3)()
+        ss = (_pd * 3)()
+        keep = []
+        for c in range(3):
+            a = planes[c]
+            if a is None:
+                pp[c] = None
+                ss[c] = 0
+                continue
+            assert a.dtype == np.uint16 and a.strides[1] == 2
+            b = border if c == 0 else border // 2
+            pp[c] = a.ctypes.data + (b * a.strides[0] + b * 2)
+            ss[c] = a.strides[0] // 2
+            keep.append(a)
+        return pp, ss, keep
+
+    def upload(self, planes, border=0):
+        """planes: [Y,U,V] uint16 2-D arrays; with border>0 the arrays include
+        `border` (luma) / border//2 (chroma) samples on every side."""
+        pp, ss, keep = self._args(planes, border)
+        lib = self.ctx.lib
+        if border:
+            self.ctx._check(lib.xvcgpu_picture_upload_padded(self.h_pic, pp, ss, border))
+        else:
+            self.ctx._check(lib.xvcgpu_picture_upload(self.h_pic, pp, ss))
+        del keep
+
+    def download(self, border=0):
+        planes = []
+        for c in range(3):
+            b = border if c == 0 else border // 2
+            w, h = (self.w, self.h) if c == 0 else (self.w // 2, self.h // 2)
+            planes.append(np.zeros((h + 2 * b, w + 2 * b), np.uint16))
+        pp, ss, keep = self._args(planes, border)
+        lib = self.ctx.lib
+        if border:
+            self.ctx._check(lib.xvcgpu_picture_download_padded(self.h_pic, pp, ss, border))
+        else:
+            self.ctx._check(lib.xvcgpu_picture_download(self.h_pic, pp, ss))
+        del keep
+        return planes
+
+    def plane_ptr(self, comp):
+        p = _vp()
+        s = _pd()
+        self.ctx._check(self.ctx.lib.xvcgpu_picture_plane(self.h_pic, comp,
+                                                          C.byref(p), C.byref(s)))
+        return p.value, s.value
+
+    def destroy(self):
+        if self.h_pic:
+            self.ctx.lib.xvcgpu_picture_destroy(self.h_pic)
+            self.h_pic = None
+
+
+class Context:
+    def __init__(self, device=0):
+        self.lib = load_library()
+        h = _vp()
+        st = self.lib.xvcgpu_create(device, C.byref(h))
+        if st != 0:
+            raise XvcGpuError("xvcgpu_create failed with status %d "
+                              "(no gfx950 device? there is no CPU fallback)" % st)
+        self.h = h.value
+
+    def _check(self, st):
+        if st != 0:
+            raise XvcGpuError("xvcgpu status %d: %s" % (
+                st, self.lib.xvcgpu_last_error(self.h).decode()))
+
+    def close(self):
+        if self.h:
+            self.lib.xvcgpu_destroy(self.h)
+            self.h = None
+
+    def sync(self):
+        self._check(self.lib.xvcgpu_sync(self.h))
+
+    def set_stream(self, hip_stream):
+        self._check(self.lib.xvcgpu_set_stream(self.h, hip_stream))
+
+    def timer_begin(self):
+        self._check(self.lib.xvcgpu_timer_begin(self.h))
+
+    def timer_end(self):
+        ms = C.c_float(0)
+        self._check(self.lib.xvcgpu_timer_end(self.h, C.byref(ms)))
+        return ms.value
+
+    def picture(self, w, h, bd=10):
+        return Picture(self, w, h, bd)
+
+    def buffer(self, arr):
+        return DeviceBuffer.from_array(self, arr)
+
+    def alloc(self, nbytes):
+        return DeviceBuffer(self, nbytes)
+
+    # ---- device-pointer level calls (bench) ----
+    def pad_border(self, pic):
+        self._check(self.lib.xvcgpu_pad_border(self.h, pic.h_pic))
+
+    def me_search_dev(self, orig, ref, flags, d_blocks, n, d_results):
+        self._check(self.lib.xvcgpu_me_search(self.h, orig.h_pic, ref.h_pic, flags,
+                                              d_blocks, n, d_results))
+
+    def mc_batch_dev(self, ref, pred, d_blocks, n):
+        self._check(self.lib.xvcgpu_mc_batch(self.h, ref.h_pic, pred.h_pic,
+                                             d_blocks, n))
+
+    def mc_from_me_dev(self, ref, pred, d_blocks, d_results, n):
+        self._check(self.lib.xvcgpu_mc_from_me(self.h, ref.h_pic, pred.h_pic,
+                                               d_blocks, d_results, n))
+
+    def cu_info_from_me_dev(self, d_blocks, d_results, d_nnz, d_luma_idx, n, qp_y,
+                            qp_c, ref_poc, d_cus):
+        self._check(self.lib.xvcgpu_cu_info_from_me(
+            self.h, d_blocks, d_results, d_nnz, d_luma_idx, n, qp_y, qp_c, ref_poc,
+            d_cus))
+
+    def residual_batch_dev(self, orig, pred, rec, d_blocks, n, d_levels=None,
+                           d_offsets=None, d_nnz=None):
+        self._check(self.lib.xvcgpu_residual_batch(
+            self.h, orig.h_pic, pred.h_pic, rec.h_pic, d_blocks, n, d_levels,
+            d_offsets, d_nnz))
+
+    def deblock_dev(self, rec, d_cus, n_cus, d_map, map_stride, bipred=0,
+                    beta=0, tc=0, sub=4):
+        self._check(self.lib.xvcgpu_deblock(self.h, rec.h_pic, d_cus, n_cus, d_map,
+                                            map_stride, bipred, beta, tc, sub))
+
+    def picture_ssd_dev(self, a, b, comp, shift_bd, d_out):
+        self._check(self.lib.xvcgpu_picture_ssd(self.h, a.h_pic, b.h_pic, comp,
+                                                shift_bd, d_out))
+
+    # ---- numpy conveniences (tests) ----
+    def metric_batch(self, a, b, comp, cands, weight=1.0, strength=16):
+        cands = np.ascontiguousarray(cands, CAND_DTYPE)
+        dc = self.buffer(cands)
+        do = self.alloc(8 * max(1, len(cands)))
+        self._check(self.lib.xvcgpu_metric_batch(self.h, a.h_pic, b.h_pic, comp,
+                                                 weight, strength, dc.ptr,
+                                                 len(cands), do.ptr))
+        out = do.to_array(np.uint64, len(cands))
+        dc.free()
+        do.free()
+        return out
+
+    def me_search(self, orig, ref, blocks, flags=ME_FULLPEL | ME_SUBPEL,
+                  results=None):
+        blocks = np.ascontiguousarray(blocks, ME_DTYPE)
+        db = self.buffer(blocks)
+        if results is None:
+            results = np.zeros(len(blocks), MERES_DTYPE)
+        dr = self.buffer(np.ascontiguousarray(results, MERES_DTYPE))
+        self.me_search_dev(orig, ref, flags, db.ptr, len(blocks), dr.ptr)
+        out = dr.to_array(MERES_DTYPE, len(blocks))
+        db.free()
+        dr.free()
+        return out
+
+    def mc_batch(self, ref, pred, blocks):
+        blocks = np.ascontiguousarray(blocks, MC_DTYPE)
+        db = self.buffer(blocks)
+        self.mc_batch_dev(ref, pred, db.ptr, len(blocks))
+        self.sync()
+        db.free()
+
+    @staticmethod
+    def level_offsets(blocks):
+        sizes = blocks["w"].astype(np.int64) * blocks["h"].astype(np.int64)
+        off = np.zeros(len(blocks), np.uint32)
+        if len(blocks) > 1:
+            off[1:] = np.cumsum(sizes)[:-1]
+        return off, int(sizes.sum())
+
+    def residual_batch(self, orig, pred, rec, blocks):
+        blocks = np.ascontiguousarray(blocks, TX_DTYPE)
+        off, total = self.level_offsets(blocks)
+        db = self.buffer(blocks)
+        dof = self.buffer(off)
+        dl = self.alloc(2 * max(1, total))
+        dn = self.alloc(4 * max(1, len(blocks)))
+        self.residual_batch_dev(orig, pred, rec, db.ptr, len(blocks), dl.ptr,
+                                dof.ptr, dn.ptr)
+        levels = dl.to_array(np.int16, total)
+        nnz = dn.to_array(np.int32, len(blocks))
+        for b in (db, dof, dl, dn):
+            b.free()
+        return levels, off, nnz
+
+    def fwd_transform_batch(self, orig, pred, blocks):
+        blocks = np.ascontiguousarray(blocks, TX_DTYPE)
+        off, total = self.level_offsets(blocks)
+        db = self.buffer(blocks)
+        dof = self.buffer(off)
+        dl = self.alloc(2 * max(1, total))
+        self._check(self.lib.xvcgpu_fwd_transform_batch(
+            self.h, orig.h_pic, pred.h_pic, db.ptr, len(blocks), dl.ptr, dof.ptr))
+        coeffs = dl.to_array(np.int16, total)
+        for b in (db, dof, dl):
+            b.free()
+        return coeffs, off
+
+    def inv_transform_batch(self, pred, rec, blocks, levels, off, nnz):
+        blocks = np.ascontiguousarray(blocks, TX_DTYPE)
+        db = self.buffer(blocks)
+        dof = self.buffer(np.ascontiguousarray(off, np.uint32))
+        dl = self.buffer(np.ascontiguousarray(levels, np.int16))
+        dn = self.buffer(np.ascontiguousarray(nnz, np.int32))
+        self._check(self.lib.xvcgpu_inv_transform_batch(
+            self.h, pred.h_pic, rec.h_pic, db.ptr, len(blocks), dl.ptr, dof.ptr,
+            dn.ptr))
+        self.sync()
+        for b in (db, dof, dl, dn):
+            b.free()
+
+    def deblock(self, rec, cus, cu_map, bipred=0, beta=0, tc=0, sub=4):
+        cus = np.ascontiguousarray(cus, CU_DTYPE)
+        cu_map = np.ascontiguousarray(cu_map, np.int32)
+        dc = self.buffer(cus)
+        dm = self.buffer(cu_map)
+        self.deblock_dev(rec, dc.ptr, len(cus), dm.ptr, cu_map.shape[1], bipred,
+                         beta, tc, sub)
+        self.sync()
+        dc.free()
+        dm.free()
+
+    def picture_ssd(self, a, b, comp=0, shift_bd=8):
+        do = self.alloc(16)
+        self.picture_ssd_dev(a, b, comp, shift_bd, do.ptr)
+        out = do.to_array(np.uint64, 2)
+        do.free()
+        return int(out[0]), int(out[1])

@@ -1,0 +1,130 @@
+// k_misc.h -- I1 batched motion compensation and the picture SSD walk.
+#ifndef XVCGPU_K_MISC_H_
+#define XVCGPU_K_MISC_H_
+
+#include "dev_common.h"
+#include "k_interp.h"
+#include "k_metric.h"
+#include "xvcgpu_internal.h"
+
+// One workgroup = InterPrediction::MotionCompensationMv for one component of
+// one uni-pred CU (inter_prediction.cc:740-758, GetFullpelRef :1174-1205,
+// 4:2:0).  grid: n; block: 256.
+__global__ void __launch_bounds__(256)
+mc_batch_kernel(PicView ref, PicView pred, const xvcgpu_mc_block *blocks, int n) {
+  __shared__ int16_t tmp[64 * 71];
+  const int bi = blockIdx.x;
+  if (bi >= n) return;
+  const xvcgpu_mc_block b = blocks[bi];
+  int mx = b.mv_x, my = b.mv_y;
+  d_clip_mv(b.x, b.y, ref.c[0].w, ref.c[0].h, mx, my);
+  const int cs = b.comp ? 1 : 0;
+  const int shift = 4 + cs;
+  const int pel_x = mx >> shift, pel_y = my >> shift;
+  // chroma: frac = (mv & mask) << (1 - size_shift) = << 0 for 4:2:0
+  const int fx = mx & ((1 << shift) - 1), fy = my & ((1 << shift) - 1);
+  const PlaneView pr = ref.c[b.comp], pd = pred.c[b.comp];
+  const int cx = b.x >> cs, cy = b.y >> cs, cw = b.w >> cs, ch = b.h >> cs;
+  const uint16_t *r = pr.p + (ptrdiff_t)(cy + pel_y) * pr.stride + cx + pel_x;
+  uint16_t *dst = pd.p + (ptrdiff_t)cy * pd.stride + cx;
+  if (b.comp)
+    wg_interp_block<true>(ref.bd, cw, ch, fx, fy, r, pr.stride, tmp, dst, pd.stride);
+  else
+    wg_interp_block<false>(ref.bd, cw, ch, fx, fy, r, pr.stride, tmp, dst, pd.stride);
+}
+
+// Same, with the MV taken from the motion search result of the CU: one
+// workgroup per (CU, component) = InterPrediction::MotionCompensation for a
+// uni-pred CU (inter_prediction.cc:710-722).  grid: (n, 3); block: 256.
+__global__ void __launch_bounds__(256)
+mc_from_me_kernel(PicView ref, PicView pred, const xvcgpu_me_block *blocks,
+                  const xvcgpu_me_result *results, int n) {
+  __shared__ int16_t tmp[64 * 71];
+  const int bi = blockIdx.x, comp = blockIdx.y;
+  if (bi >= n) return;
+  const xvcgpu_me_block b = blocks[bi];
+  int mx = results[bi].mv_x, my = results[bi].mv_y;
+  d_clip_mv(b.x, b.y, ref.c[0].w, ref.c[0].h, mx, my);
+  const int cs = comp ? 1 : 0;
+  const int shift = 4 + cs;
+  const int pel_x = mx >> shift, pel_y = my >> shift;
+  const int fx = mx & ((1 << shift) - 1), fy = my & ((1 << shift) - 1);
+  const PlaneView pr = ref.c[comp], pd = pred.c[comp];
+  const int cx = b.x >> cs, cy = b.y >> cs, cw = b.w >> cs, ch = b.h >> cs;
+  const uint16_t *r = pr.p + (ptrdiff_t)(cy + pel_y) * pr.stride + cx + pel_x;
+  uint16_t *dst = pd.p + (ptrdiff_t)cy * pd.stride + cx;
+  if (comp)
+    wg_interp_block<true>(ref.bd, cw, ch, fx, fy, r, pr.stride, tmp, dst, pd.stride);
+  else
+    wg_interp_block<false>(ref.bd, cw, ch, fx, fy, r, pr.stride, tmp, dst, pd.stride);
+}
+
+// Host-driver glue kept on the device so pictures and decisions never leave
+// HBM: fills the deblocking metadata of uni-pred inter CUs from the motion
+// search results and the luma cbf of the residual pipeline (what the
+// reference's CuEncoder writes into CodingUnit, cu_encoder.cc:543-577).
+__global__ void cu_info_from_me_kernel(const xvcgpu_me_block *blocks,
+                                       const xvcgpu_me_result *results,
+                                       const int32_t *nnz,
+                                       const int32_t *luma_tx_index, int n,
+                                       int qp_y, int qp_c, int ref_poc,
+                                       xvcgpu_cu_info *cus) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const xvcgpu_me_block b = blocks[i];
+  xvcgpu_cu_info c;
+  c.x = (uint16_t)b.x;
+  c.y = (uint16_t)b.y;
+  c.w = b.w;
+  c.h = b.h;
+  c.intra = 0;
+  c.cbf_luma = nnz[luma_tx_index ? luma_tx_index[i] : i] != 0;
+  c.qp_y = (int8_t)qp_y;
+  c.qp_c = (int8_t)qp_c;
+  c.ref_idx0 = 0;
+  c.reserved = 0;
+  c.ref_poc[0] = ref_poc;
+  c.ref_poc[1] = -1;
+  for (int k = 0; k < 4; k++) {
+    c.mv[0][k][0] = results[i].mv_x;
+    c.mv[0][k][1] = results[i].mv_y;
+    c.mv[1][k][0] = 0;
+    c.mv[1][k][1] = 0;
+  }
+  cus[i] = c;
+}
+
+// SampleMetric::ComparePicture / ComputePsnr block walk (sample_metric.cc:
+// 37-155).  The reference visits full 64x64 blocks only while
+// x < width-64 / y < height-64 (strict) and the remainder in steps of the
+// lowest set bit of the dimension, starting at (dim & ~63) - so when a
+// dimension is a multiple of 64 its last block column/row is never visited.
+// Each visited block is one Compare(): SSD >> 2*(bd-8), summed.
+// One wave per visited block; grid: ceil(items/4); block 256.
+__global__ void __launch_bounds__(256)
+picture_ssd_kernel(PlaneView a, PlaneView b, int shift, unsigned long long *out) {
+  const int w = a.w, h = a.h;
+  const int mbx = w & ~(w - 1), mby = h & ~(h - 1);
+  const int nfx = w > 64 ? (w - 64 + 63) / 64 : 0;
+  const int nrx = (w - (w & ~63)) / mbx;
+  const int nfy = h > 64 ? (h - 64 + 63) / 64 : 0;
+  const int nry = (h - (h & ~63)) / mby;
+  const int ncx = nfx + nrx, ncy = nfy + nry;
+  const int item = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (item >= ncx * ncy) return;
+  const int ix = item % ncx, iy = item / ncx;
+  int x, y, bw, bh;
+  if (ix < nfx) { x = ix * 64; bw = 64; } else { x = (w & ~63) + (ix - nfx) * mbx; bw = mbx; }
+  if (iy < nfy) { y = iy * 64; bh = 64; } else { y = (h & ~63) + (iy - nfy) * mby; bh = mby; }
+  const uint16_t *pa = a.p + (ptrdiff_t)y * a.stride + x;
+  const uint16_t *pb = b.p + (ptrdiff_t)y * b.stride + x;
+  // generic (non power-of-two widths possible for remainders? mbx/mby are
+  // powers of two by construction)
+  const uint64_t ssd = wave_ssd(bw, bh, pa, a.stride, pb, b.stride) >> shift;
+  if ((threadIdx.x & 63) == 0) {
+    atomicAdd(&out[0], (unsigned long long)ssd);
+    atomicAdd(&out[1], (unsigned long long)bw * bh);
+  }
+}
+
+#endif  // XVCGPU_K_MISC_H_

@@ -1,0 +1,552 @@
+// xvcgpu.hip -- C-ABI implementation of libxvcgpu.so (see include/xvcgpu.h).
+// gfx950 only; no CPU fallback anywhere in this file.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <new>
+#include <vector>
+
+#include "k_deblock.h"
+#include "k_me.h"
+#include "k_metric.h"
+#include "k_misc.h"
+#include "k_pad.h"
+#include "k_tx.h"
+#include "xvcgpu_internal.h"
+
+namespace {
+
+xvcgpu_status fail(xvcgpu_ctx *ctx, xvcgpu_status st, const char *what,
+                   hipError_t e = hipSuccess) {
+  if (ctx) {
+    ctx->err = what;
+    if (e != hipSuccess) {
+      ctx->err += ": ";
+      ctx->err += hipGetErrorString(e);
+    }
+  }
+  return st;
+}
+
+#define HIP_TRY(ctx, call)                                              \
+  do {                                                                  \
+    hipError_t e_ = (call);                                             \
+    if (e_ != hipSuccess) return fail(ctx, XVCGPU_DEVICE_ERROR, #call, e_); \
+  } while (0)
+
+#define CHECK_LAUNCH(ctx, name)                                          \
+  do {                                                                   \
+    hipError_t e_ = hipGetLastError();                                   \
+    if (e_ != hipSuccess) return fail(ctx, XVCGPU_DEVICE_ERROR, name, e_); \
+  } while (0)
+
+inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+// Plane geometry shared by create / wrap / bytes.
+struct Geometry {
+  int w[3], h[3], border[3], stride[3], rows[3];
+  size_t offset[3];  // byte offset of the plane's first padded row
+  size_t bytes;
+};
+
+Geometry geometry(int width, int height) {
+  Geometry g;
+  size_t off = 0;
+  for (int c = 0; c < 3; c++) {
+    g.w[c] = c ? width / 2 : width;
+    g.h[c] = c ? height / 2 : height;
+    g.border[c] = c ? XVCGPU_BORDER_CHROMA : XVCGPU_BORDER_LUMA;
+    g.stride[c] = round_up(g.w[c] + 2 * g.border[c], 64);
+    g.rows[c] = g.h[c] + 2 * g.border[c];
+    g.offset[c] = off;
+    off += (size_t)g.stride[c] * g.rows[c] * sizeof(uint16_t);
+    off = (off + 255) & ~(size_t)255;
+  }
+  g.bytes = off;
+  return g;
+}
+
+bool valid_size(int width, int height, int bitdepth) {
+  return width >= 8 && height >= 8 && (width % 8) == 0 && (height % 8) == 0 &&
+         width <= 16384 && height <= 16384 && bitdepth >= 8 && bitdepth <= 12;
+}
+
+void init_views(xvcgpu_picture *p) {
+  const Geometry g = geometry(p->w, p->h);
+  for (int c = 0; c < 3; c++) {
+    PlaneView &v = p->v.c[c];
+    v.w = g.w[c];
+    v.h = g.h[c];
+    v.border = g.border[c];
+    v.stride = g.stride[c];
+    v.p = reinterpret_cast<uint16_t *>(static_cast<char *>(p->base) + g.offset[c]) +
+          (size_t)g.border[c] * g.stride[c] + g.border[c];
+  }
+  p->v.bd = p->bd;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *xvcgpu_version(void) { return "xvcgpu 0.1 gfx950"; }
+
+xvcgpu_status xvcgpu_create(int device, xvcgpu_ctx **out) {
+  if (!out) return XVCGPU_INVALID_ARGUMENT;
+  *out = nullptr;
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0 || device < 0 ||
+      device >= count)
+    return XVCGPU_NO_DEVICE;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) != hipSuccess) return XVCGPU_NO_DEVICE;
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) return XVCGPU_NO_DEVICE;
+  xvcgpu_ctx *ctx = new (std::nothrow) xvcgpu_ctx();
+  if (!ctx) return XVCGPU_OUT_OF_MEMORY;
+  ctx->device = device;
+  ctx->stream = nullptr;
+  ctx->own_stream = false;
+  ctx->d_tx_tables = nullptr;
+  if (hipSetDevice(device) != hipSuccess ||
+      hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+    delete ctx;
+    return XVCGPU_DEVICE_ERROR;
+  }
+  ctx->own_stream = true;
+  hipEventCreate(&ctx->ev0);
+  hipEventCreate(&ctx->ev1);
+  const TxTableLayout &lay = xvcgpu_tx_layout();
+  if (hipMalloc(&ctx->d_tx_tables, lay.total * sizeof(int16_t)) != hipSuccess ||
+      hipMemcpy(ctx->d_tx_tables, xvcgpu_tx_host_tables(),
+                lay.total * sizeof(int16_t), hipMemcpyHostToDevice) != hipSuccess) {
+    xvcgpu_destroy(ctx);
+    return XVCGPU_OUT_OF_MEMORY;
+  }
+  *out = ctx;
+  return XVCGPU_OK;
+}
+
+void xvcgpu_destroy(xvcgpu_ctx *ctx) {
+  if (!ctx) return;
+  hipSetDevice(ctx->device);
+  hipStreamSynchronize(ctx->stream);
+  if (ctx->d_tx_tables) hipFree(ctx->d_tx_tables);
+  hipEventDestroy(ctx->ev0);
+  hipEventDestroy(ctx->ev1);
+  if (ctx->own_stream && ctx->stream) hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+const char *xvcgpu_last_error(const xvcgpu_ctx *ctx) {
+  return ctx ? ctx->err.c_str() : "null context";
+}
+
+xvcgpu_status xvcgpu_set_stream(xvcgpu_ctx *ctx, void *hip_stream) {
+  if (!ctx) return XVCGPU_INVALID_ARGUMENT;
+  if (ctx->own_stream && ctx->stream) {
+    hipStreamSynchronize(ctx->stream);
+    hipStreamDestroy(ctx->stream);
+  }
+  if (hip_stream) {
+    ctx->stream = static_cast<hipStream_t>(hip_stream);
+    ctx->own_stream = false;
+  } else {
+    HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    ctx->own_stream = true;
+  }
+  return XVCGPU_OK;
+}
+
+xvcgpu_status xvcgpu_sync(xvcgpu_ctx *ctx) {
+  if (!ctx) return XVCGPU_INVALID_ARGUMENT;
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return XVCGPU_OK;
+}
+
+xvcgpu_status xvcgpu_timer_begin(xvcgpu_ctx *ctx) {
+  if (!ctx) return XVCGPU_INVALID_ARGUMENT;
+  HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+  return XVCGPU_OK;
+}
+
+xvcgpu_status xvcgpu_timer_end(xvcgpu_ctx *ctx, float *elapsed_ms) {
+  if (!ctx || !elapsed_ms) return XVCGPU_INVALID_ARGUMENT;
+  HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+  HIP_TRY(ctx, hipEventSynchronize(ctx->ev1));
+  HIP_TRY(ctx, hipEventElapsedTime(elapsed_ms, ctx->ev0, ctx->ev1));
+  return XVCGPU_OK;
+}
+
+xvcgpu_status xvcgpu_malloc(xvcgpu_ctx *ctx, size_t bytes, void **dev_ptr) {
+  if (!ctx || !dev_ptr) return XVCGPU_INVALID_ARGUMENT;
+  hipSetDevice(ctx->device);
+  hipError_t e = hipMalloc(dev_ptr, bytes ? bytes : 1);
+  if (e != hipSuccess) return fail(ctx, XVCGPU_OUT_OF_MEMORY, "hipMalloc", e);
+  return XVCGPU_OK;
+}
+
+xvcgpu_status xvcgpu_free(xvcgpu_ctx *ctx, void *dev_ptr) {
+  if (!ctx) return XVCGPU_INVALID_ARGUMENT;
+  if (dev_ptr) {
+    hipStreamSynchronize(ctx->stream);
+    HIP_TRY(ctx, hipFree(dev_ptr));
+  }
+  return XVCGPU_OK;
+}
+
+xvcgpu_status xvcgpu_memcpy_h2d(xvcgpu_ctx *ctx, void *dst, const void *src,
+                                size_t bytes) {
+  if (!ctx || (!dst && bytes) || (!src && bytes)) return XVCGPU_INVALID_ARGUMENT;
+  if (!bytes) return XVCGPU_OK;
+  HIP_TRY(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return XVCGPU_OK;
+}
+
+xvcgpu_status xvcgpu_memcpy_d2h(xvcgpu_ctx *ctx, void *dst, const void *src,
+                                size_t bytes) {
+  if (!ctx || (!dst && bytes) || (!src && bytes)) return XVCGPU_INVALID_ARGUMENT;
+  if (!bytes) return XVCGPU_OK;
+  HIP_TRY(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return XVCGPU_OK;
+}
+
+xvcgpu_status xvcgpu_memset(xvcgpu_ctx *ctx, void *dst, int value, size_t bytes) {
+  if (!ctx || (!dst && bytes)) return XVCGPU_INVALID_ARGUMENT;
+  if (!bytes) return XVCGPU_OK;
+  HIP_TRY(ctx, hipMemsetAsync(dst, value, bytes, ctx->stream));
+  return XVCGPU_OK;
+}
+
+/* ---- pictures ---- */
+size_t xvcgpu_picture_bytes(int width, int height) {
+  if (!valid_size(width, height, 8)) return 0;
+  return geometry(width, height).bytes;
+}
+
+xvcgpu_status xvcgpu_picture_wrap(xvcgpu_ctx *ctx, int width, int height,
+                                  int bitdepth, void *dev_mem, size_t bytes,
+                                  xvcgpu_picture **out) {
+  if (!ctx || !out) return XVCGPU_INVALID_ARGUMENT;
+  *out = nullptr;
+  if (!valid_size(width, height, bitdepth))
+    return fail(ctx, XVCGPU_INVALID_ARGUMENT, "picture size/bitdepth");
+  if (!dev_mem || bytes < geometry(width, height).bytes ||
+      (reinterpret_cast<uintptr_t>(dev_mem) & 255))
+    return fail(ctx, XVCGPU_INVALID_ARGUMENT, "picture memory");
+  xvcgpu_picture *p = new (std::nothrow) xvcgpu_picture();
+  if (!p) return XVCGPU_OUT_OF_MEMORY;
+  p->ctx = ctx;
+  p->w = width;
+  p->h = height;
+  p->bd = bitdepth;
+  p->base = dev_mem;
+  p->bytes = bytes;
+  p->own = false;
+  init_views(p);
+  *out = p;
+  return XVCGPU_OK;
+}
+
+xvcgpu_status xvcgpu_picture_create(xvcgpu_ctx *ctx, int width, int height,
+                                    int bitdepth, xvcgpu_picture **out) {
+  if (!ctx || !out) return XVCGPU_INVALID_ARGUMENT;
+  *out = nullptr;
+  if (!valid_size(width, height, bitdepth))
+    return fail(ctx, XVCGPU_INVALID_ARGUMENT, "picture size/bitdepth");
+  const size_t bytes = geometry(width, height).bytes;
+  void *mem = nullptr;
+  xvcgpu_status st = xvcgpu_malloc(ctx, bytes, &mem);
+  if (st != XVCGPU_OK) return st;
+  hipMemsetAsync(mem, 0, bytes, ctx->stream);
+  st = xvcgpu_picture_wrap(ctx, width, height, bitdepth, mem, bytes, out);
+  if (st != XVCGPU_OK) {
+    hipFree(mem);
+    return st;
+  }
+  (*out)->own = true;
+  return XVCGPU_OK;
+}
+
+void xvcgpu_picture_destroy(xvcgpu_picture *pic) {
+  if (!pic) return;
+  if (pic->own && pic->base) {
+    hipStreamSynchronize(pic->ctx->stream);
+    hipFree(pic->base);
+  }
+  delete pic;
+}
+
+static xvcgpu_status transfer(const xvcgpu_picture *pic,
+                              const uint16_t *const planes[3],
+                              const ptrdiff_t strides[3], int border_luma,
+                              bool upload) {
+  if (!pic || !planes || !strides) return XVCGPU_INVALID_ARGUMENT;
+  xvcgpu_ctx *ctx = pic->ctx;
+  if (border_luma < 0 || border_luma > XVCGPU_BORDER_LUMA || (border_luma & 1))
+    return fail(ctx, XVCGPU_INVALID_ARGUMENT, "border");
+  for (int c = 0; c < 3; c++) {
+    if (!planes[c]) continue;
+    const PlaneView &v = pic->v.c[c];
+    const int b = c ? border_luma / 2 : border_luma;
+    uint16_t *dev = v.p - (ptrdiff_t)b * v.stride - b;
+    // host pointer addresses sample (0,0); step back to the border start
+    uint16_t *host = const_cast<uint16_t *>(planes[c]) - (ptrdiff_t)b * strides[c] - b;
+    const size_t wbytes = (size_t)(v.w + 2 * b) * sizeof(uint16_t);
+    const size_t rows = v.h + 2 * b;
+    hipError_t e;
+    if (upload)
+      e = hipMemcpy2DAsync(dev, (size_t)v.stride * 2, host, (size_t)strides[c] * 2,
+                           wbytes, rows, hipMemcpyHostToDevice, ctx->stream);
+    else
+      e = hipMemcpy2DAsync(host, (size_t)strides[c] * 2, dev, (size_t)v.stride * 2,
+                           wbytes, rows, hipMemcpyDeviceToHost, ctx->stream);
+    if (e != hipSuccess) return fail(ctx, XVCGPU_DEVICE_ERROR, "hipMemcpy2DAsync", e);
+  }
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return XVCGPU_OK;
+}
+
+xvcgpu_status xvcgpu_picture_upload(xvcgpu_picture *pic,
+                                    const uint16_t *const planes[3],
+                                    const ptrdiff_t strides[3]) {
+  return transfer(pic, planes, strides, 0, true);
+}
+xvcgpu_status xvcgpu_picture_download(const xvcgpu_picture *pic,
+                                      uint16_t *const planes[3],
+                                      const ptrdiff_t strides[3]) {
+  return transfer(pic, const_cast<const uint16_t *const *>(planes), strides, 0, false);
+}
+xvcgpu_status xvcgpu_picture_upload_padded(xvcgpu_picture *pic,
+                                           const uint16_t *const planes[3],
+                                           const ptrdiff_t strides[3],
+                                           int border_luma) {
+  return transfer(pic, planes, strides, border_luma, true);
+}
+xvcgpu_status xvcgpu_picture_download_padded(const xvcgpu_picture *pic,
+                                             uint16_t *const planes[3],
+                                             const ptrdiff_t strides[3],
+                                             int border_luma) {
+  return transfer(pic, const_cast<const uint16_t *const *>(planes), strides,
+                  border_luma, false);
+}
+
+xvcgpu_status xvcgpu_picture_plane(const xvcgpu_picture *pic, int comp,
+                                   void **dev_ptr, ptrdiff_t *stride) {
+  if (!pic || comp < 0 || comp > 2 || !dev_ptr || !stride)
+    return XVCGPU_INVALID_ARGUMENT;
+  *dev_ptr = pic->v.c[comp].p;
+  *stride = pic->v.c[comp].stride;
+  return XVCGPU_OK;
+}
+
+xvcgpu_status xvcgpu_picture_copy(xvcgpu_ctx *ctx, xvcgpu_picture *dst,
+                                  const xvcgpu_picture *src) {
+  if (!ctx || !dst || !src) return XVCGPU_INVALID_ARGUMENT;
+  if (dst->w != src->w || dst->h != src->h)
+    return fail(ctx, XVCGPU_INVALID_ARGUMENT, "picture size mismatch");
+  HIP_TRY(ctx, hipMemcpyAsync(dst->base, src->base, geometry(src->w, src->h).bytes,
+                              hipMemcpyDeviceToDevice, ctx->stream));
+  return XVCGPU_OK;
+}
+
+/* ---- kernels ---- */
+xvcgpu_status xvcgpu_pad_border(xvcgpu_ctx *ctx, xvcgpu_picture *pic) {
+  if (!ctx || !pic) return XVCGPU_INVALID_ARGUMENT;
+  hipLaunchKernelGGL(pad_lr_kernel, dim3(pic->h, 3), dim3(64), 0, ctx->stream,
+                     pic->v);
+  hipLaunchKernelGGL(pad_tb_kernel, dim3(2 * XVCGPU_BORDER_LUMA, 3), dim3(256), 0,
+                     ctx->stream, pic->v);
+  CHECK_LAUNCH(ctx, "pad_border");
+  return XVCGPU_OK;
+}
+
+xvcgpu_status xvcgpu_metric_batch(xvcgpu_ctx *ctx, const xvcgpu_picture *a,
+                                  const xvcgpu_picture *b, int comp,
+                                  double weight, int structural_strength,
+                                  const xvcgpu_metric_cand *d_cands, int n,
+                                  uint64_t *d_out) {
+  if (!ctx || !a || !b || comp < 0 || comp > 2 || n < 0 || (n && (!d_cands || !d_out)))
+    return XVCGPU_INVALID_ARGUMENT;
+  if (n == 0) return XVCGPU_OK;
+  hipLaunchKernelGGL(metric_batch_kernel, dim3((n + 3) / 4), dim3(256), 0,
+                     ctx->stream, a->v.c[comp], b->v.c[comp], a->bd, weight,
+                     structural_strength, d_cands, n, d_out);
+  CHECK_LAUNCH(ctx, "metric_batch");
+  return XVCGPU_OK;
+}
+
+xvcgpu_status xvcgpu_me_search(xvcgpu_ctx *ctx, const xvcgpu_picture *orig,
+                               const xvcgpu_picture *ref, int flags,
+                               const xvcgpu_me_block *d_blocks, int n,
+                               xvcgpu_me_result *d_results) {
+  if (!ctx || !orig || !ref || n < 0 || (n && (!d_blocks || !d_results)) ||
+      !(flags & (XVCGPU_ME_FULLPEL | XVCGPU_ME_SUBPEL)))
+    return XVCGPU_INVALID_ARGUMENT;
+  if (orig->w != ref->w || orig->h != ref->h || orig->bd != ref->bd)
+    return fail(ctx, XVCGPU_INVALID_ARGUMENT, "picture mismatch");
+  if (n == 0) return XVCGPU_OK;
+  hipLaunchKernelGGL(me_search_kernel, dim3(n), dim3(ME_THREADS), 0, ctx->stream,
+                     orig->v, ref->v, flags, d_blocks, n, d_results);
+  CHECK_LAUNCH(ctx, "me_search");
+  return XVCGPU_OK;
+}
+
+xvcgpu_status xvcgpu_mc_batch(xvcgpu_ctx *ctx, const xvcgpu_picture *ref,
+                              xvcgpu_picture *pred,
+                              const xvcgpu_mc_block *d_blocks, int n) {
+  if (!ctx || !ref || !pred || n < 0 || (n && !d_blocks))
+    return XVCGPU_INVALID_ARGUMENT;
+  if (pred->w != ref->w || pred->h != ref->h)
+    return fail(ctx, XVCGPU_INVALID_ARGUMENT, "picture mismatch");
+  if (n == 0) return XVCGPU_OK;
+  hipLaunchKernelGGL(mc_batch_kernel, dim3(n), dim3(256), 0, ctx->stream, ref->v,
+                     pred->v, d_blocks, n);
+  CHECK_LAUNCH(ctx, "mc_batch");
+  return XVCGPU_OK;
+}
+
+xvcgpu_status xvcgpu_mc_from_me(xvcgpu_ctx *ctx, const xvcgpu_picture *ref,
+                                xvcgpu_picture *pred,
+                                const xvcgpu_me_block *d_blocks,
+                                const xvcgpu_me_result *d_results, int n) {
+  if (!ctx || !ref || !pred || n < 0 || (n && (!d_blocks || !d_results)))
+    return XVCGPU_INVALID_ARGUMENT;
+  if (pred->w != ref->w || pred->h != ref->h)
+    return fail(ctx, XVCGPU_INVALID_ARGUMENT, "picture mismatch");
+  if (n == 0) return XVCGPU_OK;
+  hipLaunchKernelGGL(mc_from_me_kernel, dim3(n, 3), dim3(256), 0, ctx->stream,
+                     ref->v, pred->v, d_blocks, d_results, n);
+  CHECK_LAUNCH(ctx, "mc_from_me");
+  return XVCGPU_OK;
+}
+
+xvcgpu_status xvcgpu_cu_info_from_me(xvcgpu_ctx *ctx,
+                                     const xvcgpu_me_block *d_blocks,
+                                     const xvcgpu_me_result *d_results,
+                                     const int32_t *d_nnz,
+                                     const int32_t *d_luma_tx_index, int n,
+                                     int qp_y, int qp_c, int ref_poc,
+                                     xvcgpu_cu_info *d_cus) {
+  if (!ctx || n < 0 || (n && (!d_blocks || !d_results || !d_nnz || !d_cus)))
+    return XVCGPU_INVALID_ARGUMENT;
+  if (n == 0) return XVCGPU_OK;
+  hipLaunchKernelGGL(cu_info_from_me_kernel, dim3((n + 255) / 256), dim3(256), 0,
+                     ctx->stream, d_blocks, d_results, d_nnz, d_luma_tx_index, n,
+                     qp_y, qp_c, ref_poc, d_cus);
+  CHECK_LAUNCH(ctx, "cu_info_from_me");
+  return XVCGPU_OK;
+}
+
+xvcgpu_status xvcgpu_residual_batch(xvcgpu_ctx *ctx, const xvcgpu_picture *orig,
+                                    const xvcgpu_picture *pred,
+                                    xvcgpu_picture *rec,
+                                    const xvcgpu_tx_block *d_blocks, int n,
+                                    int16_t *d_levels,
+                                    const uint32_t *d_level_offsets,
+                                    int32_t *d_nnz) {
+  if (!ctx || !orig || !pred || !rec || n < 0 || (n && !d_blocks))
+    return XVCGPU_INVALID_ARGUMENT;
+  if (n == 0) return XVCGPU_OK;
+  hipLaunchKernelGGL(residual_kernel<TX_MODE_FULL>, dim3(n), dim3(TX_THREADS), 0,
+                     ctx->stream, orig->v, pred->v, rec->v, d_blocks, n, d_levels,
+                     d_level_offsets, d_nnz, ctx->d_tx_tables, xvcgpu_tx_layout());
+  CHECK_LAUNCH(ctx, "residual_batch");
+  return XVCGPU_OK;
+}
+
+xvcgpu_status xvcgpu_fwd_transform_batch(xvcgpu_ctx *ctx,
+                                         const xvcgpu_picture *orig,
+                                         const xvcgpu_picture *pred,
+                                         const xvcgpu_tx_block *d_blocks, int n,
+                                         int16_t *d_coeffs,
+                                         const uint32_t *d_coeff_offsets) {
+  if (!ctx || !orig || !pred || n < 0 ||
+      (n && (!d_blocks || !d_coeffs || !d_coeff_offsets)))
+    return XVCGPU_INVALID_ARGUMENT;
+  if (n == 0) return XVCGPU_OK;
+  hipLaunchKernelGGL(residual_kernel<TX_MODE_FWD>, dim3(n), dim3(TX_THREADS), 0,
+                     ctx->stream, orig->v, pred->v, pred->v, d_blocks, n, d_coeffs,
+                     d_coeff_offsets, (int32_t *)nullptr, ctx->d_tx_tables,
+                     xvcgpu_tx_layout());
+  CHECK_LAUNCH(ctx, "fwd_transform_batch");
+  return XVCGPU_OK;
+}
+
+xvcgpu_status xvcgpu_inv_transform_batch(xvcgpu_ctx *ctx,
+                                         const xvcgpu_picture *pred,
+                                         xvcgpu_picture *rec,
+                                         const xvcgpu_tx_block *d_blocks, int n,
+                                         const int16_t *d_levels,
+                                         const uint32_t *d_level_offsets,
+                                         const int32_t *d_nnz) {
+  if (!ctx || !pred || !rec || n < 0 ||
+      (n && (!d_blocks || !d_levels || !d_level_offsets || !d_nnz)))
+    return XVCGPU_INVALID_ARGUMENT;
+  if (n == 0) return XVCGPU_OK;
+  hipLaunchKernelGGL(residual_kernel<TX_MODE_INV>, dim3(n), dim3(TX_THREADS), 0,
+                     ctx->stream, pred->v, pred->v, rec->v, d_blocks, n,
+                     const_cast<int16_t *>(d_levels), d_level_offsets,
+                     const_cast<int32_t *>(d_nnz), ctx->d_tx_tables,
+                     xvcgpu_tx_layout());
+  CHECK_LAUNCH(ctx, "inv_transform_batch");
+  return XVCGPU_OK;
+}
+
+xvcgpu_status xvcgpu_deblock(xvcgpu_ctx *ctx, xvcgpu_picture *rec,
+                             const xvcgpu_cu_info *d_cus, int n_cus,
+                             const int32_t *d_cu_map, int map_stride,
+                             int pic_is_bipred, int beta_offset, int tc_offset,
+                             int subblock_size) {
+  if (!ctx || !rec || !d_cus || n_cus <= 0 || !d_cu_map ||
+      map_stride < (rec->w + 3) / 4 || (subblock_size != 4 && subblock_size != 8))
+    return XVCGPU_INVALID_ARGUMENT;
+  DbParams d;
+  d.bd = rec->bd;
+  d.pic_w = rec->w;
+  d.pic_h = rec->h;
+  d.bipred = pic_is_bipred;
+  d.beta_off = beta_offset;
+  d.tc_off = tc_offset;
+  d.sub = subblock_size;
+  d.cus = d_cus;
+  d.map = d_cu_map;
+  d.map_stride = map_stride;
+  d.map_rows = (rec->h + 3) / 4;
+  const int nx = (rec->w + subblock_size - 1) / subblock_size;
+  const int ny = (rec->h + subblock_size - 1) / subblock_size;
+  const dim3 grid((nx + 63) / 64, ny);
+  hipLaunchKernelGGL(deblock_pass_kernel<true>, grid, dim3(64), 0, ctx->stream, d,
+                     rec->v);
+  hipLaunchKernelGGL(deblock_pass_kernel<false>, grid, dim3(64), 0, ctx->stream, d,
+                     rec->v);
+  CHECK_LAUNCH(ctx, "deblock");
+  return XVCGPU_OK;
+}
+
+xvcgpu_status xvcgpu_picture_ssd(xvcgpu_ctx *ctx, const xvcgpu_picture *a,
+                                 const xvcgpu_picture *b, int comp,
+                                 int shift_bitdepth, uint64_t *d_out) {
+  if (!ctx || !a || !b || comp < 0 || comp > 2 || !d_out || shift_bitdepth < 8)
+    return XVCGPU_INVALID_ARGUMENT;
+  if (a->w != b->w || a->h != b->h)
+    return fail(ctx, XVCGPU_INVALID_ARGUMENT, "picture mismatch");
+  HIP_TRY(ctx, hipMemsetAsync(d_out, 0, 2 * sizeof(uint64_t), ctx->stream));
+  const PlaneView pa = a->v.c[comp], pb = b->v.c[comp];
+  const int w = pa.w, h = pa.h;
+  const int mbx = w & ~(w - 1), mby = h & ~(h - 1);
+  const int ncx = (w > 64 ? (w - 64 + 63) / 64 : 0) + (w - (w & ~63)) / mbx;
+  const int ncy = (h > 64 ? (h - 64 + 63) / 64 : 0) + (h - (h & ~63)) / mby;
+  const int items = ncx * ncy;
+  if (items > 0) {
+    hipLaunchKernelGGL(picture_ssd_kernel, dim3((items + 3) / 4), dim3(256), 0,
+                       ctx->stream, pa, pb, 2 * (shift_bitdepth - 8),
+                       reinterpret_cast<unsigned long long *>(d_out));
+    CHECK_LAUNCH(ctx, "picture_ssd");
+  }
+  return XVCGPU_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,55 @@
+// xvcgpu_internal.h -- host-side structs and device-side views shared by the
+// kernels of libxvcgpu.so.  gfx950 (CDNA4, wave64) only.
+#ifndef XVCGPU_INTERNAL_H_
+#define XVCGPU_INTERNAL_H_
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+
+#include "../../include/xvcgpu.h"
+
+// One plane of a device picture: `p` addresses sample (0,0); the replicated
+// border of `border` samples lies at negative / beyond-size coordinates.
+struct PlaneView {
+  uint16_t *p;
+  int stride;  // in samples
+  int w, h;
+  int border;
+};
+
+struct PicView {
+  PlaneView c[3];
+  int bd;
+};
+
+struct xvcgpu_ctx {
+  int device;
+  hipStream_t stream;
+  bool own_stream;
+  hipEvent_t ev0, ev1;
+  std::string err;
+  // transform matrices [type 1..5][log2 size 1..6], device copy
+  int16_t *d_tx_tables;
+};
+
+struct xvcgpu_picture {
+  xvcgpu_ctx *ctx;
+  int w, h, bd;
+  void *base;
+  size_t bytes;
+  bool own;
+  PicView v;
+};
+
+// Offsets (in int16 entries) of the transform matrices inside the packed
+// table blob: index [type-1][log2 size]; filled by xvcgpu_tables.cpp.
+struct TxTableLayout {
+  int off[5][7];
+  int total;
+};
+const TxTableLayout &xvcgpu_tx_layout();
+const int16_t *xvcgpu_tx_host_tables();  // packed host copy
+
+#endif  // XVCGPU_INTERNAL_H_

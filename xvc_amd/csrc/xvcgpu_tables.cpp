@@ -1,0 +1,90 @@
+// xvcgpu_tables.cpp -- host-side generation of the 8-bit-fraction transform
+// matrices used by the kernels (reference: transform_data.cc:109-796 ships
+// them as literal tables; they are the JEM definitions
+//   coef = (int)(256*sqrt(N)*v + (v > 0 ? 0.5 : -0.5)),
+// v = orthonormal DCT-2 / DCT-5 / DCT-8 / DST-1 / DST-7 basis).
+// tests/test_tables.py checks every entry against the oracle, the reference
+// build and a committed checksum.  Pure host code: no GPU needed.
+#include <math.h>
+#include <string.h>
+
+#include <vector>
+
+#include "xvcgpu_internal.h"
+
+namespace {
+
+struct Tables {
+  TxTableLayout layout;
+  std::vector<int16_t> data;
+  Tables() {
+    memset(&layout, 0xff, sizeof(layout));
+    const double pi = 3.14159265358979323846;
+    int total = 0;
+    for (int t = XVC_TX_DCT2; t <= XVC_TX_DST7; t++) {
+      for (int l = 1; l <= 6; l++) {
+        const int N = 1 << l;
+        if (N == 2 && t != XVC_TX_DCT2) continue;
+        layout.off[t - 1][l] = total;
+        data.resize(total + N * N);
+        int16_t *m = &data[total];
+        const double s = sqrt((double)N) * 256.0;
+        for (int k = 0; k < N; k++) {
+          for (int n = 0; n < N; n++) {
+            double v;
+            const double w0 = (k == 0) ? sqrt(0.5) : 1.0;
+            const double w1 = (n == 0) ? sqrt(0.5) : 1.0;
+            switch (t) {
+              case XVC_TX_DCT2:
+                v = cos(pi * (n + 0.5) * k / N) * w0 * sqrt(2.0 / N);
+                break;
+              case XVC_TX_DCT5:
+                v = cos(pi * n * k / (N - 0.5)) * w0 * w1 *
+                    sqrt(2.0 / (N - 0.5));
+                break;
+              case XVC_TX_DCT8:
+                v = cos(pi * (k + 0.5) * (n + 0.5) / (N + 0.5)) *
+                    sqrt(2.0 / (N + 0.5));
+                break;
+              case XVC_TX_DST1:
+                v = sin(pi * (n + 1) * (k + 1) / (N + 1)) * sqrt(2.0 / (N + 1));
+                break;
+              default:
+                v = sin(pi * (k + 0.5) * (n + 1) / (N + 0.5)) *
+                    sqrt(2.0 / (N + 0.5));
+                break;
+            }
+            m[k * N + n] = (int16_t)(int)(s * v + (v > 0 ? 0.5 : -0.5));
+          }
+        }
+        total += N * N;
+      }
+    }
+    layout.total = total;
+  }
+};
+
+const Tables &tables() {
+  static Tables t;
+  return t;
+}
+
+}  // namespace
+
+const TxTableLayout &xvcgpu_tx_layout() { return tables().layout; }
+const int16_t *xvcgpu_tx_host_tables() { return tables().data.data(); }
+
+extern "C" xvcgpu_status xvcgpu_get_transform_matrix(int tx_type, int size,
+                                                     int16_t *out) {
+  if (!out) return XVCGPU_INVALID_ARGUMENT;
+  if (tx_type == XVC_TX_DEFAULT) tx_type = XVC_TX_DCT2;
+  if (tx_type < XVC_TX_DCT2 || tx_type > XVC_TX_DST7)
+    return XVCGPU_INVALID_ARGUMENT;
+  int l = 1;
+  while ((1 << l) < size) l++;
+  if ((1 << l) != size || l > 6) return XVCGPU_INVALID_ARGUMENT;
+  const int off = tables().layout.off[tx_type - 1][l];
+  if (off < 0) return XVCGPU_INVALID_ARGUMENT;
+  memcpy(out, tables().data.data() + off, sizeof(int16_t) * size * size);
+  return XVCGPU_OK;
+}

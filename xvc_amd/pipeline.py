@@ -1,0 +1,147 @@
+"""Hot-path frame pass on the GPU: the composition bench.py times.
+
+For one picture with a fixed CU partition (16x16 CUs, 16x8 / 8x16 / 8x8 at the
+picture edges, as the reference's forced boundary splits produce):
+
+  me_search        T1+T3   TZ full-pel + 9+8 point sub-pel search per CU
+  mc_from_me       I1      motion compensation Y,U,V with the searched MV
+  residual_batch   X1,Q,Q1,X2,R1  transform -> quant -> dequant -> inverse -> rec
+  cu_info_from_me          CU metadata for the in-loop filter (device-side glue)
+  deblock          D1-D4   vertical-edge pass, horizontal-edge pass
+  pad_border       P1      so the result can serve as the next reference
+  picture_ssd      M6      PSNR-Y parts
+
+Everything (pictures, descriptors, decisions) stays resident in HBM; the host
+only enqueues ~9 launches per picture.  What the reference derives serially
+from neighbouring CUs (AMVP predictor, previous CU's MV, CABAC state for RDOQ)
+is an INPUT of the batched kernels: here the predictor is the zero vector and
+the quantiser is the reference's non-RDO QuantFast (scope).
+"""
+import math
+
+import numpy as np
+
+from . import api
+
+# Qp::kChromaScale_ for 4:2:0 with chroma_qp_offset_table == 1
+# (quantize.cc:34-38)
+_CHROMA_SCALE = list(range(30)) + [29, 30, 31, 32, 33, 33, 34, 34, 35, 35, 36,
+                                   36, 37, 37, 38, 39, 40, 41, 42, 43, 44, 45,
+                                   46, 47, 48, 49, 50, 51]
+
+
+def chroma_qp(qp):
+    return _CHROMA_SCALE[max(0, min(57, qp))]
+
+
+def lambda16_for_qp(qp):
+    """floor(65536*sqrt(lambda)) with lambda = 0.57*2^((qp-12)/3)
+    (PictureData::Init, picture_data.cc:96-97; inter_tz_search.cc:98-99)."""
+    lam = 0.57 * math.pow(2.0, (qp - 12) / 3.0)
+    return int(math.floor(65536.0 * math.sqrt(lam)))
+
+
+def cu_partition(width, height, cu=16):
+    """Raster list of (x, y, w, h): cu x cu CUs, smaller at right/bottom edge."""
+    parts = []
+    for y in range(0, height, cu):
+        h = min(cu, height - y)
+        for x in range(0, width, cu):
+            w = min(cu, width - x)
+            parts.append((x, y, w, h))
+    return parts
+
+
+class FrameDescriptors:
+    """Host-side (numpy) descriptors of one picture's jobs; shared by the GPU
+    frame pass and the CPU oracle frame pass in tests / bench."""
+
+    def __init__(self, width, height, qp=32, cu=16, search_range=96,
+                 row_range=None):
+        self.w, self.h, self.qp = width, height, qp
+        parts = cu_partition(width, height, cu)
+        if row_range is not None:  # CTU-row shard [y0, y1)
+            parts = [p for p in parts if row_range[0] <= p[1] < row_range[1]]
+        n = len(parts)
+        self.n_cus = n
+        me = np.zeros(n, api.ME_DTYPE)
+        tx = np.zeros(3 * n, api.TX_DTYPE)
+        luma_idx = np.zeros(n, np.int32)
+        cmap = -np.ones(((height + 3) // 4, (width + 3) // 4), np.int32)
+        qpc = chroma_qp(qp)
+        lam = lambda16_for_qp(qp)
+        for i, (x, y, w, h) in enumerate(parts):
+            b = me[i]
+            b["x"], b["y"], b["w"], b["h"] = x, y, w, h
+            b["depth_nonzero"] = 1
+            b["lambda16"] = lam
+            b["search_range"] = search_range
+            luma_idx[i] = 3 * i
+            t = tx[3 * i]
+            t["x"], t["y"], t["w"], t["h"], t["comp"], t["qp"] = x, y, w, h, 0, qp
+            for c in (1, 2):
+                t = tx[3 * i + c]
+                t["x"], t["y"], t["w"], t["h"] = x // 2, y // 2, w // 2, h // 2
+                t["comp"], t["qp"] = c, qpc
+            cmap[y // 4:(y + h) // 4, x // 4:(x + w) // 4] = i
+        self.me, self.tx, self.luma_idx, self.cu_map = me, tx, luma_idx, cmap
+        self.qp_c = qpc
+
+
+class FramePass:
+    """Device-resident state for running frame passes of one picture size."""
+
+    def __init__(self, ctx, width, height, bitdepth=10, qp=32, cu=16,
+                 search_range=96, row_range=None):
+        self.ctx = ctx
+        self.w, self.h, self.bd = width, height, bitdepth
+        self.desc = d = FrameDescriptors(width, height, qp, cu, search_range,
+                                         row_range)
+        self.d_me = ctx.buffer(d.me)
+        self.d_tx = ctx.buffer(d.tx)
+        self.d_luma_idx = ctx.buffer(d.luma_idx)
+        self.d_map = ctx.buffer(d.cu_map)
+        self.d_res = ctx.alloc(api.MERES_DTYPE.itemsize * d.n_cus)
+        self.d_nnz = ctx.alloc(4 * len(d.tx))
+        self.d_cus = ctx.alloc(api.CU_DTYPE.itemsize * d.n_cus)
+        self.d_ssd = ctx.alloc(16)
+        self.pred = ctx.picture(width, height, bitdepth)
+
+    def run(self, orig, ref, rec, ref_poc=0, deblock=True, pad=True, ssd=True):
+        """Enqueue one frame pass (asynchronous)."""
+        ctx, d = self.ctx, self.desc
+        n = d.n_cus
+        ctx.me_search_dev(orig, ref, api.ME_FULLPEL | api.ME_SUBPEL, self.d_me.ptr,
+                          n, self.d_res.ptr)
+        ctx.mc_from_me_dev(ref, self.pred, self.d_me.ptr, self.d_res.ptr, n)
+        ctx.residual_batch_dev(orig, self.pred, rec, self.d_tx.ptr, len(d.tx),
+                               None, None, self.d_nnz.ptr)
+        if deblock:
+            ctx.cu_info_from_me_dev(self.d_me.ptr, self.d_res.ptr, self.d_nnz.ptr,
+                                    self.d_luma_idx.ptr, n, d.qp, d.qp_c, ref_poc,
+                                    self.d_cus.ptr)
+            ctx.deblock_dev(rec, self.d_cus.ptr, n, self.d_map.ptr,
+                            d.cu_map.shape[1], 0, 0, 0, 4)
+        if pad:
+            ctx.pad_border(rec)
+        if ssd:
+            ctx.picture_ssd_dev(orig, rec, 0, self.bd, self.d_ssd.ptr)
+
+    def results(self):
+        d = self.desc
+        return (self.d_res.to_array(api.MERES_DTYPE, d.n_cus),
+                self.d_nnz.to_array(np.int32, len(d.tx)),
+                self.d_cus.to_array(api.CU_DTYPE, d.n_cus),
+                self.d_ssd.to_array(np.uint64, 2))
+
+    def destroy(self):
+        for b in (self.d_me, self.d_tx, self.d_luma_idx, self.d_map, self.d_res,
+                  self.d_nnz, self.d_cus, self.d_ssd):
+            b.free()
+        self.pred.destroy()
+
+
+def psnr_from_ssd(dist, samples):
+    """SampleMetric::ComputePsnr tail (sample_metric.cc:143-154)."""
+    mse = dist / samples if samples else 0.0
+    return 10.0 * math.log10(255.0 * 255.0 / mse) if mse > 0 else 99.999
