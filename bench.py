@@ -104,8 +104,8 @@ def main():
 
     if world > 1:
         from xvc_amd import sharded
-        runner = sharded.ShardedFramePass(ctx, W, H, bd, args.qp, rank, world,
-                                          torch.device("cuda", local_rank))
+        runner = sharded.make_gpu_sharded(ctx, W, H, bd, args.qp, rank, world,
+                                          torch.device("cuda", local_rank), dist)
     else:
         runner = None
 
@@ -119,8 +119,8 @@ def main():
         recs = [ctx.picture(W, H, bd), ctx.picture(W, H, bd)]
         fp = pipeline.FramePass(ctx, W, H, bd, qp=args.qp)
     else:
-        recs = runner.pictures
-        fp = runner.fp
+        recs = runner.e.pictures
+        fp = runner.e.fp
     recs[0].upload(pad_planes(clip.frame(0), border), border)
     ctx.sync()
 
@@ -155,7 +155,7 @@ def main():
         dt = float(t.item())
 
     # PSNR-Y of the last reconstructed picture (sanity, not timed)
-    _, _, _, ssd = fp.results()
+    ssd = fp.d_ssd.to_array(np.uint64, 2)
     psnr_y = pipeline.psnr_from_ssd(int(ssd[0]), int(ssd[1])) if ssd[1] else None
 
     # ---- roofline of the dominant kernel: HIP events around it on the
@@ -163,7 +163,10 @@ def main():
     roof = None
     if rank == 0:
         d = fp.desc
-        o, ref, rec = origs[0], recs[0], recs[1]
+        # replay the inputs of the last timed step (ME/MC/residual are
+        # idempotent on them)
+        i_last = args.warmup + args.steps - 1
+        o, ref, rec = origs[i_last % len(origs)], recs[i_last % 2], recs[(i_last + 1) % 2]
         reps = 20
 
         def timed(fn):
@@ -183,7 +186,7 @@ def main():
             "residual": timed(lambda: ctx.residual_batch_dev(
                 o, fp.pred, rec, fp.d_tx.ptr, len(d.tx), None, None, fp.d_nnz.ptr)),
             "deblock": timed(lambda: ctx.deblock_dev(
-                rec, fp.d_cus.ptr, d.n_cus, fp.d_map.ptr, d.cu_map.shape[1])),
+                rec, fp.d_cus.ptr, d.n_cus_total, fp.d_map.ptr, d.cu_map.shape[1])),
             "pad_border": timed(lambda: ctx.pad_border(rec)),
             "picture_ssd": timed(lambda: ctx.picture_ssd_dev(o, rec, 0, bd,
                                                              fp.d_ssd.ptr)),
@@ -227,8 +230,7 @@ def main():
             "config": {"workload": "%dx%d yuv420p 30fps synthetic, QP %d, internal "
                                    "bitdepth 10, 16x16 CUs, TZ range 96, QuantFast" %
                                    (W, H, args.qp),
-                       "cus_per_picture": fp.desc.n_cus if runner is None
-                       else runner.total_cus,
+                       "cus_per_picture": fp.desc.n_cus_total,
                        "parallelism": "single" if world == 1 else "cu-row-shard%d" % world},
             "roofline": roof, "cpu_baseline": cpu,
         }

@@ -221,6 +221,19 @@ xvcgpu_status xvcgpu_deblock(xvcgpu_ctx *ctx, xvcgpu_picture *rec,
                              int pic_is_bipred, int beta_offset, int tc_offset,
                              int subblock_size);
 
+/* One pass (0 = vertical edges, 1 = horizontal edges) restricted to the
+ * subblock rows y in [y_begin, y_end): the unit of CTU-row sharding.  Pass 1
+ * of a shard must include the first subblock row of the shard below
+ * (y_end = shard_end + subblock_size) once that shard's pass-0 rows have been
+ * received (scheme B).  xvcgpu_deblock() == pass 0 then
+ * pass 1 over [0, height). */
+xvcgpu_status xvcgpu_deblock_rows(xvcgpu_ctx *ctx, xvcgpu_picture *rec,
+                                  const xvcgpu_cu_info *d_cus, int n_cus,
+                                  const int32_t *d_cu_map, int map_stride,
+                                  int pic_is_bipred, int beta_offset,
+                                  int tc_offset, int subblock_size, int pass,
+                                  int y_begin, int y_end);
+
 /* ---- picture SSD / PSNR parts ------------------------------------------- *
  * SampleMetric::ComparePicture / ComputePsnr block walk (sample_metric.cc:
  * 37-155): per-64x64-block SSD, each >> 2*(shift_bitdepth-8), summed.

@@ -122,6 +122,13 @@ void xo_deblock_picture(int bitdepth, int pic_w, int pic_h, int pic_is_bipred,
                         int map_stride, uint16_t *const planes[3],
                         const ptrdiff_t strides[3]);
 
+void xo_deblock_rows(int bitdepth, int pic_w, int pic_h, int pic_is_bipred,
+                     int beta_offset, int tc_offset, int subblock_size,
+                     const xvcgpu_cu_info *cus, const int32_t *cu_map,
+                     int map_stride, uint16_t *const planes[3],
+                     const ptrdiff_t strides[3], int pass, int y_begin,
+                     int y_end);
+
 /* ---- P1 border extension (xvc_common_lib/yuv_pic.cc:118-150) ---- */
 void xo_pad_border(int w, int h, int border_x, int border_y, uint16_t *plane,
                    ptrdiff_t stride);

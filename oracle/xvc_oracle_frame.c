@@ -38,7 +38,10 @@ typedef struct xo_frame_args {
   ptrdiff_t rec_stride[3];
   xvcgpu_me_result *me_results; /* out, n_cus */
   int32_t *nnz;                 /* out, n_tx */
-  xvcgpu_cu_info *cus;          /* out, n_cus */
+  xvcgpu_cu_info *cus;          /* in/out: whole picture's CU array; the own
+                                   CUs [cu_base, cu_base + n_cus) are written */
+  int cu_base;
+  int encode_only;              /* stop before deblock / pad / SSD */
   uint64_t ssd[2];              /* out: luma SSD as ComputePsnr sums it, samples */
 } xo_frame_args;
 
@@ -88,7 +91,7 @@ void xo_frame_pass(xo_frame_args *a) {
   /* CU metadata for the in-loop filter */
   for (int i = 0; i < a->n_cus; i++) {
     const xvcgpu_me_block *b = &a->me_blocks[i];
-    xvcgpu_cu_info *c = &a->cus[i];
+    xvcgpu_cu_info *c = &a->cus[a->cu_base + i];
     memset(c, 0, sizeof(*c));
     c->x = (uint16_t)b->x;
     c->y = (uint16_t)b->y;
@@ -104,6 +107,7 @@ void xo_frame_pass(xo_frame_args *a) {
       c->mv[0][k][1] = a->me_results[i].mv_y;
     }
   }
+  if (a->encode_only) return;
   xo_deblock_picture(bd, a->pic_w, a->pic_h, 0, a->beta_offset, a->tc_offset,
                      a->subblock, a->cus, a->cu_map, a->map_stride, a->rec,
                      a->rec_stride);

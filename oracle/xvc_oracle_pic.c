@@ -261,6 +261,48 @@ void xo_deblock_picture(int bd, int pic_w, int pic_h, int bipred,
         xp_deblock_ctu(&d, cx * 64, cy * 64, vertical);
 }
 
+/* One pass restricted to subblock rows [y_begin, y_end): the shard unit of
+ * the multi-GPU path (same semantics as xvcgpu_deblock_rows). */
+void xo_deblock_rows(int bd, int pic_w, int pic_h, int bipred, int beta_offset,
+                     int tc_offset, int subblock_size,
+                     const xvcgpu_cu_info *cus, const int32_t *cu_map,
+                     int map_stride, uint16_t *const planes[3],
+                     const ptrdiff_t strides[3], int pass, int y_begin,
+                     int y_end) {
+  xp_db d;
+  d.bd = bd;
+  d.pic_w = pic_w;
+  d.pic_h = pic_h;
+  d.bipred = bipred;
+  d.beta_off = beta_offset;
+  d.tc_off = tc_offset;
+  d.sub = subblock_size;
+  d.cus = cus;
+  d.map = cu_map;
+  d.map_stride = map_stride;
+  d.map_rows = (pic_h + 3) / 4;
+  d.planes = planes;
+  d.strides = strides;
+  const int vertical = pass == 0;
+  if (y_end > pic_h) y_end = pic_h;
+  for (int y = y_begin; y < y_end; y += subblock_size)
+    for (int x = 0; x < pic_w; x += subblock_size) {
+      const xvcgpu_cu_info *q = xp_cu_at(&d, x, y);
+      if (!q) continue;
+      const xvcgpu_cu_info *p =
+          vertical ? xp_cu_at(&d, x - 1, y) : xp_cu_at(&d, x, y - 1);
+      if (!p || (p->x == q->x && p->y == q->y)) continue;
+      int bs = xp_bs(&d, p, q, x, y, vertical);
+      if (!bs) continue;
+      xp_filter_luma(&d, x, y, vertical, bs, (p->qp_y + q->qp_y + 1) >> 1);
+      if (bs == 2) {
+        int cx = x >> 1, cy = y >> 1;
+        if (vertical ? ((cx & 7) == 0) : ((cy & 7) == 0))
+          xp_filter_chroma(&d, cx, cy, vertical, (p->qp_c + q->qp_c + 1) >> 1);
+      }
+    }
+}
+
 /* ========================================================================= *
  *  Border extension                                                         *
  * ========================================================================= */

@@ -25,11 +25,12 @@ class FrameArgs(C.Structure):
         ("pred", C.c_void_p * 3), ("pred_stride", C.c_ssize_t * 3),
         ("rec", C.c_void_p * 3), ("rec_stride", C.c_ssize_t * 3),
         ("me_results", C.c_void_p), ("nnz", C.c_void_p), ("cus", C.c_void_p),
+        ("cu_base", C.c_int), ("encode_only", C.c_int),
         ("ssd", C.c_uint64 * 2),
     ]
 
 
-def frame_pass(desc, bd, orig, ref, border, ref_poc=0, lib=None):
+def frame_pass(desc, bd, orig, ref, border, ref_poc=0, lib=None, encode_only=False):
     """desc: xvc_amd.pipeline.FrameDescriptors; orig/ref: [Y,U,V] padded uint16
     planes with `border` (luma) / border//2 (chroma) samples on each side.
     Returns (rec padded planes, me_results, nnz, cus, (ssd, samples))."""
@@ -62,7 +63,9 @@ def frame_pass(desc, bd, orig, ref, border, ref_poc=0, lib=None):
             keep.append(arr)
     res = np.zeros(len(me), ol.MERES_DTYPE)
     nnz = np.zeros(len(tx), np.int32)
-    cus = np.zeros(len(me), ol.CU_DTYPE)
+    cus = np.zeros(desc.n_cus_total, ol.CU_DTYPE)
     a.me_results, a.nnz, a.cus = res.ctypes.data, nnz.ctypes.data, cus.ctypes.data
+    a.cu_base = desc.cu_base
+    a.encode_only = 1 if encode_only else 0
     f(C.byref(a))
     return rec, res, nnz, cus, (int(a.ssd[0]), int(a.ssd[1]))

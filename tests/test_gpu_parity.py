@@ -502,3 +502,53 @@ def test_frame_pass(gpu, xo, size):
     fp.destroy()
     for p in (O, R, Rec):
         p.destroy()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_gpu_engine_loopback(gpu, xo, world):
+    """The multi-GPU orchestration with the real HIP engine: `world` shards of
+    one picture handled by separate GpuEngine instances on this one GPU, data
+    exchanged by device-to-device copies instead of RCCL.  Must equal the
+    unsharded oracle frame pass bit for bit."""
+    import torch
+    import oracle_frame
+    from test_sharded import LoopbackComm
+    from xvc_amd import pipeline, sharded, synth
+    api, ctx = gpu
+    pw, ph, bd, qp = 208, 112, 10, 32
+    dev = torch.device("cuda", 0)
+    clip = synth.SyntheticClip(pw, ph, bd)
+    desc = pipeline.FrameDescriptors(pw, ph, qp)
+    rows = sharded.shard_rows(ph, world)
+    ranks = []
+    for r in range(world):
+        e = sharded.GpuEngine(ctx, pw, ph, bd, qp, rows[r], dev)
+        e.pictures[0].upload(pad_planes(clip.frame(0), bd), BL)
+        ranks.append(sharded.ShardedFramePass(e, LoopbackComm(), r, world))
+    O = ctx.picture(pw, ph, bd)
+    ref_host = pad_planes(clip.frame(0), bd)
+    for n in (1, 2):
+        orig_host = pad_planes(clip.frame(n), bd)
+        O.upload(orig_host, BL)
+        ref_idx, rec_idx = (n - 1) % 2, n % 2
+        for s in ranks:
+            s.phase_a(O, ref_idx, rec_idx, n - 1)
+        LoopbackComm.exchange_all({s.rank: s.halo_ops(rec_idx) for s in ranks})
+        for s in ranks:
+            s.phase_b(rec_idx)
+        LoopbackComm.exchange_all({s.rank: s.gather_ops(rec_idx) for s in ranks})
+        for s in ranks:
+            s.phase_c(O, rec_idx)
+        torch.cuda.synchronize()
+        ctx.sync()
+        e_rec, _, _, _, e_ssd = oracle_frame.frame_pass(desc, bd, orig_host, ref_host, BL,
+                                                        n - 1, lib=xo)
+        for s in ranks:
+            got = s.e.pictures[rec_idx].download(BL)
+            for c in range(3):
+                assert np.array_equal(got[c], e_rec[c]), (world, n, s.rank, c)
+            ssd = s.e.fp.d_ssd.to_array(np.uint64, 2)
+            assert (int(ssd[0]), int(ssd[1])) == e_ssd
+        ref_host = e_rec
+    ctx.set_stream(None)
+    O.destroy()

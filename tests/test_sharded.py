@@ -1,0 +1,228 @@
+"""CTU-row sharding of the frame pass (xvc_amd/sharded.py): the orchestration
+(shard plan, halo exchange, redundant boundary edge, gather) is run with a CPU
+engine built on the oracle and must reproduce the unsharded frame pass bit for
+bit - in one process with a loop-back comm (3 shards) and as two real
+processes over gloo."""
+import ctypes as C
+import os
+import socket
+
+import numpy as np
+import pytest
+
+import oracle_frame
+import oracle_lib as ol
+from xvc_amd import api, pipeline, sharded, synth
+
+BL, BC = 128, 64
+PW, PH, BD, QP = 208, 112, 10, 32
+
+
+def pad_planes(planes):
+    return [np.ascontiguousarray(np.pad(p, BL if c == 0 else BC, mode="edge"))
+            for c, p in enumerate(planes)]
+
+
+class OracleEngine:
+    """Same interface as sharded.GpuEngine, computed by the CPU oracle on numpy
+    planes (shared with torch CPU tensors for the exchange)."""
+
+    def __init__(self, lib, width, height, bd, qp, row_range, cu=16):
+        import torch
+        self.torch = torch
+        self.lib, self.w, self.h, self.bd, self.cu = lib, width, height, bd, cu
+        self.desc = pipeline.FrameDescriptors(width, height, qp, cu, row_range=row_range)
+        self.cus_per_row = self.desc.cus_per_row
+        self.pics = [[np.zeros(((height >> (c > 0)) + 2 * (BL >> (c > 0)),
+                                (width >> (c > 0)) + 2 * (BL >> (c > 0))), np.uint16)
+                      for c in range(3)] for _ in range(2)]
+        self.cus = np.zeros(self.desc.n_cus_total, ol.CU_DTYPE)
+        self.ssd_out = None
+        self._parts = pipeline.cu_partition(width, height, cu)
+
+    def min_cu_height_at(self, y):
+        if y <= 0 or y >= self.h:
+            return 64
+        hs = [p[3] for p in self._parts if p[1] == y or p[1] + p[3] == y]
+        return min(hs) if hs else 64
+
+    def encode(self, orig, ref_idx, rec_idx, ref_poc):
+        # ME + MC + residual + metadata for the own CUs via the oracle's frame
+        # pass restricted to the shard, without deblock/pad (done by phases)
+        rec, res, nnz, cus, _ = oracle_frame.frame_pass(
+            self.desc, self.bd, orig, self.pics[ref_idx], BL, ref_poc, lib=self.lib,
+            encode_only=True)
+        d = self.desc
+        y0, y1 = d.row_range
+        for c in range(3):
+            b, s = (BL, 0) if c == 0 else (BC, 1)
+            self.pics[rec_idx][c][b + (y0 >> s):b + (y1 >> s), :] = \
+                rec[c][b + (y0 >> s):b + (y1 >> s), :]
+        self.cus[d.cu_base:d.cu_base + d.n_cus] = cus[d.cu_base:d.cu_base + d.n_cus]
+
+    def _planes(self, idx):
+        pp = (ol.u16p * 3)()
+        ss = (ol.pd * 3)()
+        for c in range(3):
+            b = BL if c == 0 else BC
+            a = self.pics[idx][c]
+            pp[c] = C.cast(a.ctypes.data + (b * a.strides[0] + b * 2), ol.u16p)
+            ss[c] = a.strides[0] // 2
+        return pp, ss
+
+    def deblock_rows(self, rec_idx, pass_, ya, yb):
+        f = self.lib.dll.xo_deblock_rows
+        f.restype = None
+        f.argtypes = [C.c_int] * 7 + [C.c_void_p, C.c_void_p, C.c_int,
+                                      C.POINTER(ol.u16p), C.POINTER(ol.pd),
+                                      C.c_int, C.c_int, C.c_int]
+        pp, ss = self._planes(rec_idx)
+        cm = np.ascontiguousarray(self.desc.cu_map, np.int32)
+        f(self.bd, self.w, self.h, 0, 0, 0, 4, self.cus.ctypes.data, cm.ctypes.data,
+          cm.shape[1], pp, ss, pass_, ya, yb)
+
+    def pad(self, rec_idx):
+        self.lib.pad_border(self.w, self.h, self.pics[rec_idx], [BL, BC, BC])
+
+    def ssd(self, orig, rec_idx):
+        o = np.ascontiguousarray(orig[0][BL:BL + self.h, BL:BL + self.w])
+        r = np.ascontiguousarray(self.pics[rec_idx][0][BL:BL + self.h, BL:BL + self.w])
+        self.ssd_out = self.lib.picture_ssd(self.bd, o, r)
+
+    def row_slab(self, rec_idx, comp, ya, yb):
+        b = BL if comp == 0 else BC
+        a = self.pics[rec_idx][comp]
+        return self.torch.from_numpy(a[b + ya:b + yb, :].view(np.int16)).reshape(-1)
+
+    def cu_slab(self, first_cu, n):
+        return self.torch.from_numpy(self.cus[first_cu:first_cu + n].view(np.uint8)) \
+            .reshape(-1)
+
+
+class LoopbackComm:
+    """All ranks in one process: collect every rank's ops, then copy."""
+
+    def __init__(self):
+        self.pending = {}
+
+    def exchange(self, sends, recvs):
+        raise RuntimeError("use exchange_all")
+
+    @staticmethod
+    def exchange_all(ops_by_rank):
+        # queue per (src, dst) in issue order
+        queues = {}
+        for src, (sends, _) in ops_by_rank.items():
+            for dst, t in sends:
+                queues.setdefault((src, dst), []).append(t.clone())
+        for dst, (_, recvs) in ops_by_rank.items():
+            for src, t in recvs:
+                t.copy_(queues[(src, dst)].pop(0))
+        assert all(len(q) == 0 for q in queues.values())
+
+
+def reference_frames(lib, n_frames):
+    """Unsharded oracle chain: returns list of (rec planes, ssd)."""
+    clip = synth.SyntheticClip(PW, PH, BD)
+    desc = pipeline.FrameDescriptors(PW, PH, QP)
+    ref = pad_planes(clip.frame(0))
+    out = []
+    for n in range(1, n_frames + 1):
+        orig = pad_planes(clip.frame(n))
+        rec, _, _, _, ssd = oracle_frame.frame_pass(desc, BD, orig, ref, BL, n - 1, lib=lib)
+        out.append((rec, ssd))
+        ref = rec
+    return out
+
+
+def test_shard_rows():
+    assert sharded.shard_rows(1080, 8) == [(0, 144), (144, 288), (288, 432), (432, 576),
+                                           (576, 704), (704, 832), (832, 960), (960, 1080)]
+    assert sharded.shard_rows(1080, 1) == [(0, 1080)]
+    for h, w in ((1080, 8), (2160, 8), (288, 2), (112, 3), (4320, 8)):
+        r = sharded.shard_rows(h, w)
+        assert r[0][0] == 0 and r[-1][1] == h
+        assert all(a[1] == b[0] for a, b in zip(r, r[1:]))
+        assert all(a[0] % 16 == 0 for a in r)
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_loopback_matches_unsharded(world):
+    lib = ol.Lib("xo")
+    expect = reference_frames(lib, 2)
+    clip = synth.SyntheticClip(PW, PH, BD)
+    rows = sharded.shard_rows(PH, world)
+    ranks = []
+    for r in range(world):
+        e = OracleEngine(lib, PW, PH, BD, QP, rows[r])
+        for c, p in enumerate(pad_planes(clip.frame(0))):
+            e.pics[0][c][:] = p
+        ranks.append(sharded.ShardedFramePass(e, LoopbackComm(), r, world))
+    for n in (1, 2):
+        orig = pad_planes(clip.frame(n))
+        ref_idx, rec_idx = (n - 1) % 2, n % 2
+        for s in ranks:
+            s.phase_a(orig, ref_idx, rec_idx, n - 1)
+        LoopbackComm.exchange_all({s.rank: s.halo_ops(rec_idx) for s in ranks})
+        for s in ranks:
+            s.phase_b(rec_idx)
+        LoopbackComm.exchange_all({s.rank: s.gather_ops(rec_idx) for s in ranks})
+        for s in ranks:
+            s.phase_c(orig, rec_idx)
+        exp_rec, exp_ssd = expect[n - 1]
+        for s in ranks:
+            for c in range(3):
+                assert np.array_equal(s.e.pics[rec_idx][c], exp_rec[c]), (world, n, s.rank, c)
+            assert s.e.ssd_out == exp_ssd
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _gloo_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lib = ol.Lib("xo")
+    clip = synth.SyntheticClip(PW, PH, BD)
+    rows = sharded.shard_rows(PH, world)
+    e = OracleEngine(lib, PW, PH, BD, QP, rows[rank])
+    for c, p in enumerate(pad_planes(clip.frame(0))):
+        e.pics[0][c][:] = p
+    s = sharded.ShardedFramePass(e, sharded.TorchComm(dist, rank, world), rank, world)
+    out = []
+    for n in (1, 2):
+        orig = pad_planes(clip.frame(n))
+        s.run(orig, (n - 1) % 2, n % 2, n - 1)
+        out.append(([p.copy() for p in e.pics[n % 2]], e.ssd_out))
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_gloo_two_ranks():
+    import torch.multiprocessing as mp
+    lib = ol.Lib("xo")
+    expect = reference_frames(lib, 2)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gloo_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=300) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank in range(2):
+        for n in range(2):
+            rec, ssd = got[rank][n]
+            for c in range(3):
+                assert np.array_equal(rec[c], expect[n][0][c]), (rank, n, c)
+            assert ssd == expect[n][1]

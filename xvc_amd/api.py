@@ -60,7 +60,7 @@ SYMBOLS = [
     "xvcgpu_me_search", "xvcgpu_mc_batch", "xvcgpu_mc_from_me",
     "xvcgpu_cu_info_from_me", "xvcgpu_residual_batch",
     "xvcgpu_fwd_transform_batch", "xvcgpu_inv_transform_batch",
-    "xvcgpu_deblock", "xvcgpu_picture_ssd", "xvcgpu_get_transform_matrix",
+    "xvcgpu_deblock", "xvcgpu_deblock_rows", "xvcgpu_picture_ssd", "xvcgpu_get_transform_matrix",
 ]
 
 _vp = C.c_void_p
@@ -124,6 +124,8 @@ def load_library():
         "xvcgpu_inv_transform_batch": [_vp, _vp, _vp, _vp, C.c_int, _vp, _vp, _vp],
         "xvcgpu_deblock": [_vp, _vp, _vp, C.c_int, _vp, C.c_int, C.c_int, C.c_int,
                            C.c_int, C.c_int],
+        "xvcgpu_deblock_rows": [_vp, _vp, _vp, C.c_int, _vp, C.c_int, C.c_int, C.c_int,
+                                C.c_int, C.c_int, C.c_int, C.c_int, C.c_int],
         "xvcgpu_picture_ssd": [_vp, _vp, _vp, C.c_int, C.c_int, _vp],
         "xvcgpu_get_transform_matrix": [C.c_int, C.c_int, _vp],
     }
@@ -324,6 +326,12 @@ class Context:
                     beta=0, tc=0, sub=4):
         self._check(self.lib.xvcgpu_deblock(self.h, rec.h_pic, d_cus, n_cus, d_map,
                                             map_stride, bipred, beta, tc, sub))
+
+    def deblock_rows_dev(self, rec, d_cus, n_cus, d_map, map_stride, pass_, y0, y1,
+                         bipred=0, beta=0, tc=0, sub=4):
+        self._check(self.lib.xvcgpu_deblock_rows(self.h, rec.h_pic, d_cus, n_cus,
+                                                 d_map, map_stride, bipred, beta, tc,
+                                                 sub, pass_, y0, y1))
 
     def picture_ssd_dev(self, a, b, comp, shift_bd, d_out):
         self._check(self.lib.xvcgpu_picture_ssd(self.h, a.h_pic, b.h_pic, comp,

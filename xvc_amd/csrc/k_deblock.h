@@ -27,6 +27,7 @@
 
 struct DbParams {
   int bd, pic_w, pic_h, bipred, beta_off, tc_off, sub;
+  int y_begin, y_end;  // subblock rows [y_begin, y_end) handled by this launch
   const xvcgpu_cu_info *cus;
   const int32_t *map;
   int map_stride, map_rows;
@@ -244,8 +245,8 @@ template <bool VERTICAL>
 __global__ void __launch_bounds__(64)
 deblock_pass_kernel(DbParams d, PicView pic) {
   const int ix = blockIdx.x * 64 + threadIdx.x, iy = blockIdx.y;
-  int x = ix * d.sub, y = iy * d.sub;
-  if (x >= d.pic_w || y >= d.pic_h) return;
+  int x = ix * d.sub, y = d.y_begin + iy * d.sub;
+  if (x >= d.pic_w || y >= d.pic_h || y >= d.y_end) return;
   int qp, cqp;
   int bs = db_candidate(d, x, y, VERTICAL, qp, cqp);
   if (!bs) return;
@@ -253,13 +254,15 @@ deblock_pass_kernel(DbParams d, PicView pic) {
     // not a chain head if the previous position along the filtering axis is
     // a candidate as well
     int q2, c2;
-    if (db_candidate(d, VERTICAL ? x - 4 : x, VERTICAL ? y : y - 4, VERTICAL, q2, c2))
+    if ((VERTICAL || y - 4 >= d.y_begin) &&
+        db_candidate(d, VERTICAL ? x - 4 : x, VERTICAL ? y : y - 4, VERTICAL, q2, c2))
       return;
   }
   for (;;) {
     db_filter_edge<VERTICAL>(d, pic, x, y, bs, qp, cqp);
     if (d.sub != 4) break;
     if (VERTICAL) x += 4; else y += 4;
+    if (y >= d.y_end) break;
     bs = db_candidate(d, x, y, VERTICAL, qp, cqp);
     if (!bs) break;
   }

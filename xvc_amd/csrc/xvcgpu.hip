@@ -495,14 +495,18 @@ xvcgpu_status xvcgpu_inv_transform_batch(xvcgpu_ctx *ctx,
   return XVCGPU_OK;
 }
 
-xvcgpu_status xvcgpu_deblock(xvcgpu_ctx *ctx, xvcgpu_picture *rec,
-                             const xvcgpu_cu_info *d_cus, int n_cus,
-                             const int32_t *d_cu_map, int map_stride,
-                             int pic_is_bipred, int beta_offset, int tc_offset,
-                             int subblock_size) {
+xvcgpu_status xvcgpu_deblock_rows(xvcgpu_ctx *ctx, xvcgpu_picture *rec,
+                                  const xvcgpu_cu_info *d_cus, int n_cus,
+                                  const int32_t *d_cu_map, int map_stride,
+                                  int pic_is_bipred, int beta_offset,
+                                  int tc_offset, int subblock_size, int pass,
+                                  int y_begin, int y_end) {
   if (!ctx || !rec || !d_cus || n_cus <= 0 || !d_cu_map ||
-      map_stride < (rec->w + 3) / 4 || (subblock_size != 4 && subblock_size != 8))
+      map_stride < (rec->w + 3) / 4 || (subblock_size != 4 && subblock_size != 8) ||
+      (pass != 0 && pass != 1) || y_begin < 0 || (y_begin % subblock_size) != 0)
     return XVCGPU_INVALID_ARGUMENT;
+  if (y_end > rec->h) y_end = rec->h;
+  if (y_end <= y_begin) return XVCGPU_OK;
   DbParams d;
   d.bd = rec->bd;
   d.pic_w = rec->w;
@@ -511,19 +515,38 @@ xvcgpu_status xvcgpu_deblock(xvcgpu_ctx *ctx, xvcgpu_picture *rec,
   d.beta_off = beta_offset;
   d.tc_off = tc_offset;
   d.sub = subblock_size;
+  d.y_begin = y_begin;
+  d.y_end = y_end;
   d.cus = d_cus;
   d.map = d_cu_map;
   d.map_stride = map_stride;
   d.map_rows = (rec->h + 3) / 4;
   const int nx = (rec->w + subblock_size - 1) / subblock_size;
-  const int ny = (rec->h + subblock_size - 1) / subblock_size;
+  const int ny = (y_end - y_begin + subblock_size - 1) / subblock_size;
   const dim3 grid((nx + 63) / 64, ny);
-  hipLaunchKernelGGL(deblock_pass_kernel<true>, grid, dim3(64), 0, ctx->stream, d,
-                     rec->v);
-  hipLaunchKernelGGL(deblock_pass_kernel<false>, grid, dim3(64), 0, ctx->stream, d,
-                     rec->v);
-  CHECK_LAUNCH(ctx, "deblock");
+  if (pass == 0)
+    hipLaunchKernelGGL(deblock_pass_kernel<true>, grid, dim3(64), 0, ctx->stream, d,
+                       rec->v);
+  else
+    hipLaunchKernelGGL(deblock_pass_kernel<false>, grid, dim3(64), 0, ctx->stream, d,
+                       rec->v);
+  CHECK_LAUNCH(ctx, "deblock_rows");
   return XVCGPU_OK;
+}
+
+xvcgpu_status xvcgpu_deblock(xvcgpu_ctx *ctx, xvcgpu_picture *rec,
+                             const xvcgpu_cu_info *d_cus, int n_cus,
+                             const int32_t *d_cu_map, int map_stride,
+                             int pic_is_bipred, int beta_offset, int tc_offset,
+                             int subblock_size) {
+  if (!rec) return XVCGPU_INVALID_ARGUMENT;
+  xvcgpu_status st = xvcgpu_deblock_rows(ctx, rec, d_cus, n_cus, d_cu_map, map_stride,
+                                         pic_is_bipred, beta_offset, tc_offset,
+                                         subblock_size, 0, 0, rec->h);
+  if (st != XVCGPU_OK) return st;
+  return xvcgpu_deblock_rows(ctx, rec, d_cus, n_cus, d_cu_map, map_stride,
+                             pic_is_bipred, beta_offset, tc_offset, subblock_size, 1,
+                             0, rec->h);
 }
 
 xvcgpu_status xvcgpu_picture_ssd(xvcgpu_ctx *ctx, const xvcgpu_picture *a,

@@ -54,15 +54,26 @@ def cu_partition(width, height, cu=16):
 
 class FrameDescriptors:
     """Host-side (numpy) descriptors of one picture's jobs; shared by the GPU
-    frame pass and the CPU oracle frame pass in tests / bench."""
+    frame pass and the CPU oracle frame pass in tests / bench.
+
+    With `row_range=(y0, y1)` only the CUs whose top row lies in [y0, y1) get
+    motion-search / residual jobs (one CTU-row shard); the CU map and the CU
+    metadata array stay global (indices into the whole picture's raster list)
+    because the in-loop filter looks across the shard boundary."""
 
     def __init__(self, width, height, qp=32, cu=16, search_range=96,
                  row_range=None):
         self.w, self.h, self.qp = width, height, qp
-        parts = cu_partition(width, height, cu)
-        if row_range is not None:  # CTU-row shard [y0, y1)
-            parts = [p for p in parts if row_range[0] <= p[1] < row_range[1]]
-        n = len(parts)
+        parts_all = cu_partition(width, height, cu)
+        self.n_cus_total = len(parts_all)
+        if row_range is None:
+            row_range = (0, height)
+        self.row_range = (max(0, row_range[0]), min(height, row_range[1]))
+        own = [i for i, p in enumerate(parts_all)
+               if self.row_range[0] <= p[1] < self.row_range[1]]
+        self.cu_base = own[0] if own else 0
+        assert own == list(range(self.cu_base, self.cu_base + len(own)))
+        n = len(own)
         self.n_cus = n
         me = np.zeros(n, api.ME_DTYPE)
         tx = np.zeros(3 * n, api.TX_DTYPE)
@@ -70,7 +81,10 @@ class FrameDescriptors:
         cmap = -np.ones(((height + 3) // 4, (width + 3) // 4), np.int32)
         qpc = chroma_qp(qp)
         lam = lambda16_for_qp(qp)
-        for i, (x, y, w, h) in enumerate(parts):
+        for gi, (x, y, w, h) in enumerate(parts_all):
+            cmap[y // 4:(y + h) // 4, x // 4:(x + w) // 4] = gi
+        for i, gi in enumerate(own):
+            x, y, w, h = parts_all[gi]
             b = me[i]
             b["x"], b["y"], b["w"], b["h"] = x, y, w, h
             b["depth_nonzero"] = 1
@@ -83,13 +97,16 @@ class FrameDescriptors:
                 t = tx[3 * i + c]
                 t["x"], t["y"], t["w"], t["h"] = x // 2, y // 2, w // 2, h // 2
                 t["comp"], t["qp"] = c, qpc
-            cmap[y // 4:(y + h) // 4, x // 4:(x + w) // 4] = i
         self.me, self.tx, self.luma_idx, self.cu_map = me, tx, luma_idx, cmap
         self.qp_c = qpc
+        self.cu_rows = (height + cu - 1) // cu
+        self.cus_per_row = (width + cu - 1) // cu
+        self.cu_size = cu
 
 
 class FramePass:
-    """Device-resident state for running frame passes of one picture size."""
+    """Device-resident state for running frame passes of one picture size
+    (or of one CTU-row shard of it)."""
 
     def __init__(self, ctx, width, height, bitdepth=10, qp=32, cu=16,
                  search_range=96, row_range=None):
@@ -101,26 +118,44 @@ class FramePass:
         self.d_tx = ctx.buffer(d.tx)
         self.d_luma_idx = ctx.buffer(d.luma_idx)
         self.d_map = ctx.buffer(d.cu_map)
-        self.d_res = ctx.alloc(api.MERES_DTYPE.itemsize * d.n_cus)
-        self.d_nnz = ctx.alloc(4 * len(d.tx))
-        self.d_cus = ctx.alloc(api.CU_DTYPE.itemsize * d.n_cus)
+        self.d_res = ctx.alloc(api.MERES_DTYPE.itemsize * max(1, d.n_cus))
+        self.d_nnz = ctx.alloc(4 * max(1, len(d.tx)))
+        self.d_cus = ctx.alloc(api.CU_DTYPE.itemsize * d.n_cus_total)
+        ctx._check(ctx.lib.xvcgpu_memset(ctx.h, self.d_cus.ptr, 0,
+                                         api.CU_DTYPE.itemsize * d.n_cus_total))
         self.d_ssd = ctx.alloc(16)
         self.pred = ctx.picture(width, height, bitdepth)
 
-    def run(self, orig, ref, rec, ref_poc=0, deblock=True, pad=True, ssd=True):
-        """Enqueue one frame pass (asynchronous)."""
+    @property
+    def d_cus_own(self):
+        return self.d_cus.ptr + api.CU_DTYPE.itemsize * self.desc.cu_base
+
+    def encode(self, orig, ref, rec, ref_poc=0):
+        """ME -> MC -> residual -> CU metadata for the own CUs (asynchronous)."""
         ctx, d = self.ctx, self.desc
         n = d.n_cus
+        if n == 0:
+            return
         ctx.me_search_dev(orig, ref, api.ME_FULLPEL | api.ME_SUBPEL, self.d_me.ptr,
                           n, self.d_res.ptr)
         ctx.mc_from_me_dev(ref, self.pred, self.d_me.ptr, self.d_res.ptr, n)
         ctx.residual_batch_dev(orig, self.pred, rec, self.d_tx.ptr, len(d.tx),
                                None, None, self.d_nnz.ptr)
+        ctx.cu_info_from_me_dev(self.d_me.ptr, self.d_res.ptr, self.d_nnz.ptr,
+                                self.d_luma_idx.ptr, n, d.qp, d.qp_c, ref_poc,
+                                self.d_cus_own)
+
+    def deblock_rows(self, rec, pass_, y0, y1):
+        d = self.desc
+        self.ctx.deblock_rows_dev(rec, self.d_cus.ptr, d.n_cus_total, self.d_map.ptr,
+                                  d.cu_map.shape[1], pass_, y0, y1)
+
+    def run(self, orig, ref, rec, ref_poc=0, deblock=True, pad=True, ssd=True):
+        """Enqueue one whole-picture frame pass (asynchronous)."""
+        ctx, d = self.ctx, self.desc
+        self.encode(orig, ref, rec, ref_poc)
         if deblock:
-            ctx.cu_info_from_me_dev(self.d_me.ptr, self.d_res.ptr, self.d_nnz.ptr,
-                                    self.d_luma_idx.ptr, n, d.qp, d.qp_c, ref_poc,
-                                    self.d_cus.ptr)
-            ctx.deblock_dev(rec, self.d_cus.ptr, n, self.d_map.ptr,
+            ctx.deblock_dev(rec, self.d_cus.ptr, d.n_cus_total, self.d_map.ptr,
                             d.cu_map.shape[1], 0, 0, 0, 4)
         if pad:
             ctx.pad_border(rec)
@@ -131,7 +166,7 @@ class FramePass:
         d = self.desc
         return (self.d_res.to_array(api.MERES_DTYPE, d.n_cus),
                 self.d_nnz.to_array(np.int32, len(d.tx)),
-                self.d_cus.to_array(api.CU_DTYPE, d.n_cus),
+                self.d_cus.to_array(api.CU_DTYPE, d.n_cus_total),
                 self.d_ssd.to_array(np.uint64, 2))
 
     def destroy(self):

@@ -1,0 +1,221 @@
+"""Multi-GPU frame pass: one process per GPU, pictures sharded by rows of CUs.
+
+North star: "frames shard by CTU rows across the GPUs of one node with RCCL
+halo exchange over xGMI for in-loop filtering".  Shards are contiguous runs of
+CU rows (16 luma lines; CTU rows when they divide evenly).  Per picture:
+
+  A  local   motion search, motion compensation, residual pipeline and CU
+             metadata for the own CUs; deblocking pass 0 (vertical edges never
+             cross rows) on the own rows
+  X1 halo    neighbour ranks swap the 4 luma / 2 chroma rows on each side of
+             the shard boundary (pass-0 output) and the metadata of the
+             boundary CU rows - point-to-point, one batched RCCL group
+  B  local   deblocking pass 1 (horizontal edges) on the own rows plus the
+             first edge row of the shard below, computed redundantly by both
+             neighbours (SURVEY.md section 8e scheme B: no return traffic).
+             Exact whenever no 4-tall CU touches a shard boundary (no deblock
+             chain crosses it) - checked when the plan is built.
+  X2 gather  every rank sends its finished rows to every other rank so all of
+             them hold the complete reconstruction = next reference picture
+  C  local   border extension, PSNR parts
+
+The orchestration is engine-agnostic: `GpuEngine` (HIP kernels through the
+C-ABI, torch tensors as picture memory so RCCL can address row slabs) is the
+product; tests drive the same plan with a CPU engine over gloo.
+"""
+import numpy as np
+
+from . import api, pipeline
+
+
+def shard_rows(height, world, cu=16):
+    """Split the CU rows of a picture into `world` contiguous shards.
+    Returns [(y0, y1)] in luma lines (y1 clipped to height)."""
+    n_rows = (height + cu - 1) // cu
+    assert world <= n_rows, "more ranks than CU rows"
+    base, extra = divmod(n_rows, world)
+    out, r = [], 0
+    for k in range(world):
+        n = base + (1 if k < extra else 0)
+        out.append((r * cu, min(height, (r + n) * cu)))
+        r += n
+    return out
+
+
+class TorchComm:
+    """Batched point-to-point exchange over torch.distributed (RCCL on GPUs,
+    gloo in the CPU tests)."""
+
+    def __init__(self, dist, rank, world):
+        self.dist, self.rank, self.world = dist, rank, world
+
+    def exchange(self, sends, recvs):
+        """sends / recvs: lists of (peer, 1-D tensor); per peer the order of
+        sends on one side matches the order of recvs on the other."""
+        d = self.dist
+        ops = [d.P2POp(d.isend, t, p) for p, t in sends] + \
+              [d.P2POp(d.irecv, t, p) for p, t in recvs]
+        if not ops:
+            return
+        for req in d.batch_isend_irecv(ops):
+            req.wait()
+
+
+class ShardedFramePass:
+    HALO = 4  # luma rows on each side of a shard boundary
+
+    def __init__(self, engine, comm, rank, world):
+        self.e, self.comm, self.rank, self.world = engine, comm, rank, world
+        self.rows = shard_rows(engine.h, world, engine.cu)
+        self.y0, self.y1 = self.rows[rank]
+        self.up = rank - 1 if rank > 0 else None
+        self.down = rank + 1 if rank < world - 1 else None
+        # exactness precondition of the redundant-halo scheme
+        assert engine.min_cu_height_at(self.y0) >= 8 and \
+            engine.min_cu_height_at(self.y1) >= 8, \
+            "4-tall CUs at a shard boundary need the ordered hand-off protocol"
+
+    # ---- slabs ----
+    def _plane_rows(self, rec_idx, ya, yb):
+        """Row slabs [ya, yb) (luma lines) of the three planes."""
+        return [self.e.row_slab(rec_idx, 0, ya, yb),
+                self.e.row_slab(rec_idx, 1, ya // 2, yb // 2),
+                self.e.row_slab(rec_idx, 2, ya // 2, yb // 2)]
+
+    def _cu_row_slab(self, y):
+        """Metadata of the CU row that starts at luma line y."""
+        first = (y // self.e.cu) * self.e.cus_per_row
+        return self.e.cu_slab(first, self.e.cus_per_row)
+
+    # ---- phases ----
+    def phase_a(self, orig, ref_idx, rec_idx, ref_poc):
+        self.e.encode(orig, ref_idx, rec_idx, ref_poc)
+        self.e.deblock_rows(rec_idx, 0, self.y0, self.y1)
+
+    def halo_ops(self, rec_idx):
+        H = self.HALO
+        sends, recvs = [], []
+        if self.up is not None:
+            sends += [(self.up, t) for t in self._plane_rows(rec_idx, self.y0, self.y0 + H)]
+            sends.append((self.up, self._cu_row_slab(self.y0)))
+            recvs += [(self.up, t) for t in self._plane_rows(rec_idx, self.y0 - H, self.y0)]
+            recvs.append((self.up, self._cu_row_slab(self.y0 - self.e.cu)))
+        if self.down is not None:
+            sends += [(self.down, t) for t in self._plane_rows(rec_idx, self.y1 - H, self.y1)]
+            sends.append((self.down, self._cu_row_slab(self.y1 - self.e.cu)))
+            recvs += [(self.down, t) for t in self._plane_rows(rec_idx, self.y1, self.y1 + H)]
+            recvs.append((self.down, self._cu_row_slab(self.y1)))
+        return sends, recvs
+
+    def phase_b(self, rec_idx):
+        y_end = self.y1 + self.HALO if self.down is not None else self.y1
+        self.e.deblock_rows(rec_idx, 1, self.y0, y_end)
+
+    def gather_ops(self, rec_idx):
+        sends, recvs = [], []
+        mine = self._plane_rows(rec_idx, self.y0, self.y1)
+        for peer in range(self.world):
+            if peer == self.rank:
+                continue
+            sends += [(peer, t) for t in mine]
+            ya, yb = self.rows[peer]
+            recvs += [(peer, t) for t in self._plane_rows(rec_idx, ya, yb)]
+        return sends, recvs
+
+    def phase_c(self, orig, rec_idx):
+        self.e.pad(rec_idx)
+        self.e.ssd(orig, rec_idx)
+
+    def run(self, orig, ref_idx, rec_idx, ref_poc=0):
+        self.phase_a(orig, ref_idx, rec_idx, ref_poc)
+        self.comm.exchange(*self.halo_ops(rec_idx))
+        self.phase_b(rec_idx)
+        self.comm.exchange(*self.gather_ops(rec_idx))
+        self.phase_c(orig, rec_idx)
+
+
+class GpuEngine:
+    """HIP engine: pictures live in torch tensors (so RCCL can send row slabs)
+    wrapped as xvcgpu pictures; kernels run on torch's current stream."""
+
+    def __init__(self, ctx, width, height, bitdepth, qp, row_range, device,
+                 n_pictures=2, cu=16):
+        import torch
+        self.torch = torch
+        self.ctx, self.w, self.h, self.bd, self.cu = ctx, width, height, bitdepth, cu
+        ctx.set_stream(torch.cuda.current_stream(device).cuda_stream)
+        nbytes = ctx.lib.xvcgpu_picture_bytes(width, height)
+        self.mem, self.pictures, self.geom = [], [], []
+        for _ in range(n_pictures):
+            t = torch.zeros(nbytes // 2, dtype=torch.int16, device=device)
+            pic = api.Picture(ctx, width, height, bitdepth, wrap_ptr=t.data_ptr(),
+                              wrap_bytes=nbytes)
+            self.mem.append(t)
+            self.pictures.append(pic)
+            g = []
+            for c in range(3):
+                ptr, stride = pic.plane_ptr(c)
+                g.append(((ptr - t.data_ptr()) // 2, stride,
+                          api.BORDER_LUMA if c == 0 else api.BORDER_CHROMA))
+            self.geom.append(g)
+        self.fp = pipeline.FramePass(ctx, width, height, bitdepth, qp=qp, cu=cu,
+                                     row_range=row_range)
+        d = self.fp.desc
+        self.cus_per_row = d.cus_per_row
+        # CU metadata in a torch tensor so boundary rows can be exchanged
+        self.cu_mem = torch.zeros(d.n_cus_total * api.CU_DTYPE.itemsize,
+                                  dtype=torch.uint8, device=device)
+        self.fp.d_cus.free()
+        self.fp.d_cus = _ExternalBuffer(ctx, self.cu_mem.data_ptr())
+        self._parts = pipeline.cu_partition(width, height, cu)
+
+    def min_cu_height_at(self, y):
+        if y <= 0 or y >= self.h:
+            return 64
+        hs = [p[3] for p in self._parts if p[1] == y or p[1] + p[3] == y]
+        return min(hs) if hs else 64
+
+    def encode(self, orig, ref_idx, rec_idx, ref_poc):
+        self.fp.encode(orig, self.pictures[ref_idx], self.pictures[rec_idx], ref_poc)
+
+    def deblock_rows(self, rec_idx, pass_, ya, yb):
+        self.fp.deblock_rows(self.pictures[rec_idx], pass_, ya, yb)
+
+    def pad(self, rec_idx):
+        self.ctx.pad_border(self.pictures[rec_idx])
+
+    def ssd(self, orig, rec_idx):
+        self.ctx.picture_ssd_dev(orig, self.pictures[rec_idx], 0, self.bd,
+                                 self.fp.d_ssd.ptr)
+
+    def row_slab(self, rec_idx, comp, ya, yb):
+        off, stride, border = self.geom[rec_idx][comp]
+        # full padded rows: from the left border of row ya to the end of row yb-1
+        start = off + ya * stride - border
+        return self.mem[rec_idx][start:start + (yb - ya) * stride]
+
+    def cu_slab(self, first_cu, n):
+        s = api.CU_DTYPE.itemsize
+        return self.cu_mem[first_cu * s:(first_cu + n) * s]
+
+
+class _ExternalBuffer:
+    """DeviceBuffer look-alike over memory owned by a torch tensor."""
+
+    def __init__(self, ctx, ptr):
+        self.ctx, self.ptr = ctx, ptr
+
+    def to_array(self, dtype, count):
+        out = np.zeros(count, dtype)
+        self.ctx._check(self.ctx.lib.xvcgpu_memcpy_d2h(self.ctx.h, out.ctypes.data,
+                                                       self.ptr, out.nbytes))
+        return out
+
+    def free(self):
+        self.ptr = None
+
+
+def make_gpu_sharded(ctx, width, height, bitdepth, qp, rank, world, device, dist):
+    rows = shard_rows(height, world)
+    engine = GpuEngine(ctx, width, height, bitdepth, qp, rows[rank], device)
+    return ShardedFramePass(engine, TorchComm(dist, rank, world), rank, world)
