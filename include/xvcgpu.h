@@ -53,8 +53,12 @@ void xvcgpu_destroy(xvcgpu_ctx *ctx);
 const char *xvcgpu_last_error(const xvcgpu_ctx *ctx);
 /* Version string "xvcgpu <major>.<minor> gfx950". Callable without a GPU. */
 const char *xvcgpu_version(void);
-/* Use an external hipStream_t (e.g. torch's current stream); NULL = own. */
+/* Launch on an external hipStream_t (e.g. torch's current stream, so kernels
+ * order with torch copies and RCCL collectives); NULL = the device's default
+ * stream.  xvcgpu_use_own_stream() returns to a private non-blocking stream
+ * (the state after xvcgpu_create). */
 xvcgpu_status xvcgpu_set_stream(xvcgpu_ctx *ctx, void *hip_stream);
+xvcgpu_status xvcgpu_use_own_stream(xvcgpu_ctx *ctx);
 xvcgpu_status xvcgpu_sync(xvcgpu_ctx *ctx);
 /* HIP-event stopwatch on the context's stream (bench.py's timed region). */
 xvcgpu_status xvcgpu_timer_begin(xvcgpu_ctx *ctx);

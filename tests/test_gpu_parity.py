@@ -550,5 +550,5 @@ def test_sharded_gpu_engine_loopback(gpu, xo, world):
             ssd = s.e.fp.d_ssd.to_array(np.uint64, 2)
             assert (int(ssd[0]), int(ssd[1])) == e_ssd
         ref_host = e_rec
-    ctx.set_stream(None)
+    ctx.use_own_stream()
     O.destroy()

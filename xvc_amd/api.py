@@ -50,7 +50,7 @@ assert MC_DTYPE.itemsize == 16 and CAND_DTYPE.itemsize == 12
 # every symbol include/xvcgpu.h declares
 SYMBOLS = [
     "xvcgpu_create", "xvcgpu_destroy", "xvcgpu_last_error", "xvcgpu_version",
-    "xvcgpu_set_stream", "xvcgpu_sync", "xvcgpu_timer_begin", "xvcgpu_timer_end",
+    "xvcgpu_set_stream", "xvcgpu_use_own_stream", "xvcgpu_sync", "xvcgpu_timer_begin", "xvcgpu_timer_end",
     "xvcgpu_malloc", "xvcgpu_free", "xvcgpu_memcpy_h2d", "xvcgpu_memcpy_d2h",
     "xvcgpu_memset", "xvcgpu_picture_create", "xvcgpu_picture_bytes",
     "xvcgpu_picture_wrap", "xvcgpu_picture_destroy", "xvcgpu_picture_upload",
@@ -77,6 +77,14 @@ def load_library():
     global _lib
     if _lib is not None:
         return _lib
+    # One HIP runtime per process: PyTorch ships its own libamdhip64 (same
+    # SONAME as /opt/rocm's).  Importing torch first makes the dynamic linker
+    # resolve libxvcgpu.so's dependency to that already-loaded copy, so torch
+    # tensors, streams and RCCL share the runtime our kernels launch on.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     if not os.path.exists(LIB_PATH):
         raise XvcGpuError(
             "libxvcgpu.so is not built: run `python -m xvc_amd.build` "
@@ -94,6 +102,7 @@ def load_library():
     sigs = {
         "xvcgpu_create": [C.c_int, C.POINTER(_vp)],
         "xvcgpu_set_stream": [_vp, _vp],
+        "xvcgpu_use_own_stream": [_vp],
         "xvcgpu_sync": [_vp],
         "xvcgpu_timer_begin": [_vp],
         "xvcgpu_timer_end": [_vp, C.POINTER(C.c_float)],
@@ -276,6 +285,9 @@ class Context:
 
     def set_stream(self, hip_stream):
         self._check(self.lib.xvcgpu_set_stream(self.h, hip_stream))
+
+    def use_own_stream(self):
+        self._check(self.lib.xvcgpu_use_own_stream(self.h))
 
     def timer_begin(self):
         self._check(self.lib.xvcgpu_timer_begin(self.h))

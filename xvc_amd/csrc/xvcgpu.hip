@@ -148,13 +148,18 @@ xvcgpu_status xvcgpu_set_stream(xvcgpu_ctx *ctx, void *hip_stream) {
     hipStreamSynchronize(ctx->stream);
     hipStreamDestroy(ctx->stream);
   }
-  if (hip_stream) {
-    ctx->stream = static_cast<hipStream_t>(hip_stream);
-    ctx->own_stream = false;
-  } else {
-    HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
-    ctx->own_stream = true;
-  }
+  // NULL is a valid hipStream_t: the device's default stream
+  ctx->stream = static_cast<hipStream_t>(hip_stream);
+  ctx->own_stream = false;
+  return XVCGPU_OK;
+}
+
+xvcgpu_status xvcgpu_use_own_stream(xvcgpu_ctx *ctx) {
+  if (!ctx) return XVCGPU_INVALID_ARGUMENT;
+  if (ctx->own_stream) return XVCGPU_OK;
+  hipStreamSynchronize(ctx->stream);
+  HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+  ctx->own_stream = true;
   return XVCGPU_OK;
 }
 
