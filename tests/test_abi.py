@@ -78,3 +78,35 @@ def test_no_cpu_fallback_without_device(api):
         pytest.skip("GPU present")
     with pytest.raises(api.XvcGpuError):
         api.Context(0)
+
+
+def _build_host_demo(tmpdir):
+    import subprocess
+    exe = os.path.join(tmpdir, "host_demo")
+    subprocess.check_call([
+        "g++", "-std=c++11", "-Wall", "-Wextra", "-Werror",
+        "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "xvc_amd", "host"),
+        os.path.join(ROOT, "tests", "host_demo.cc"), "-o", exe,
+        "-L", os.path.join(ROOT, "xvc_amd"), "-lxvcgpu",
+        "-Wl,-rpath," + os.path.join(ROOT, "xvc_amd"), "-Wl,-rpath,/opt/rocm/lib"])
+    return exe
+
+
+def test_cpp_host_layer_compiles_and_refuses_without_gpu(api, tmp_path):
+    """The C++ host mirror builds with plain g++ against the C-ABI; without a
+    device it reports XVCGPU_NO_DEVICE instead of computing on the CPU."""
+    import subprocess
+    import torch
+    exe = _build_host_demo(str(tmp_path))
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: covered by the gpu-marked run")
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 3, r.stdout + r.stderr
+
+
+@pytest.mark.gpu
+def test_cpp_host_layer_runs_on_gpu(api, tmp_path):
+    import subprocess
+    exe = _build_host_demo(str(tmp_path))
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr

@@ -1,0 +1,177 @@
+"""Generates tests/golden/*.npz from the REFERENCE's own compiled code
+(oracle/_ref/libxvcref.so, `make -C oracle ref`; this container only).
+
+Each fixture holds seeded inputs and the outputs the reference produced for
+them - data only, no reference source.  tests/test_golden.py replays them
+against the oracle (everywhere) and against the HIP kernels (-m gpu).
+
+    python tools/gen_golden.py
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, ROOT)
+import oracle_lib as ol  # noqa: E402
+from helpers import make_cus, make_pics, random_partition, rnd_samples  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+BL, BC = 128, 64
+
+
+def main():
+    assert ol.have_ref(), "build the reference harness first: make -C oracle ref"
+    xr = ol.Lib("xr")
+    os.makedirs(OUT, exist_ok=True)
+    rng = np.random.default_rng(20260928)
+
+    # ---- metrics ----
+    cases, a_list, b_list, exp = [], [], [], []
+    for bd in (8, 10):
+        for (w, h) in [(4, 4), (8, 4), (4, 8), (8, 8), (16, 8), (8, 16), (16, 16),
+                       (32, 16), (32, 32), (64, 64), (64, 32)]:
+            for smooth in (0, 1):
+                a = rnd_samples(rng, bd, h, w, smooth)
+                b = rnd_samples(rng, bd, h, w, smooth)
+                for metric in range(8):
+                    if metric in (4, 6) and h <= 8:
+                        continue
+                    qp = int(rng.integers(12, 52))
+                    cases.append((bd, w, h, metric, qp))
+                    pa = np.zeros((64, 64), np.uint16); pa[:h, :w] = a
+                    pb = np.zeros((64, 64), np.uint16); pb[:h, :w] = b
+                    a_list.append(pa); b_list.append(pb)
+                    exp.append(xr.metric_ss(metric, bd, np.ascontiguousarray(a),
+                                            np.ascontiguousarray(b), qp=qp))
+    np.savez_compressed(os.path.join(OUT, "metrics.npz"), cases=np.array(cases, np.int32),
+                        a=np.array(a_list), b=np.array(b_list),
+                        expected=np.array(exp, np.uint64))
+
+    # ---- interpolation (block level) ----
+    cases, planes, preds, bip = [], [], [], []
+    for bd in (8, 10):
+        for is_chroma in (0, 1):
+            for (w, h) in [(4, 4), (8, 8), (16, 16), (32, 8), (16, 32)]:
+                plane = rnd_samples(rng, bd, 48, 48)
+                nph = 32 if is_chroma else 16
+                for fx, fy in [(0, 0), (0, 5), (7, 0), (4, 4), (8, 8), (12, 4),
+                               (int(rng.integers(1, nph)), int(rng.integers(1, nph)))]:
+                    cases.append((bd, is_chroma, w, h, fx, fy))
+                    planes.append(plane)
+                    p = np.zeros((32, 32), np.uint16)
+                    p[:h, :w] = xr.mc_uni(bd, is_chroma, w, h, fx, fy, plane, 8, 8)
+                    q = np.zeros((32, 32), np.int16)
+                    q[:h, :w] = xr.mc_uni(bd, is_chroma, w, h, fx, fy, plane, 8, 8, True)
+                    preds.append(p); bip.append(q)
+    np.savez_compressed(os.path.join(OUT, "interp.npz"), cases=np.array(cases, np.int32),
+                        planes=np.array(planes), pred=np.array(preds), bipred=np.array(bip))
+
+    # ---- transforms + quant ----
+    cases, resi_l, coeff_l, inv_l, lev_l, deq_l, nnz_l = [], [], [], [], [], [], []
+    for bd in (8, 10):
+        for (w, h) in [(2, 2), (4, 4), (8, 4), (8, 8), (16, 16), (32, 8), (32, 32),
+                       (64, 64), (64, 16)]:
+            types = [(0, 0)] + ([(3, 5), (5, 3), (5, 5), (2, 4)] if min(w, h) >= 4 else [])
+            for tx_hor, tx_ver in types:
+                qp = int(rng.choice([22, 27, 32, 37]))
+                resi = rng.integers(-90, 91, size=(h, w)).astype(np.int16)
+                coeff = xr.fwd_transform(bd, resi, tx_hor, tx_ver)
+                lev, nnz = xr.quant_fast(bd, qp, 0, coeff)
+                deq = xr.dequant(bd, qp, lev)
+                inv = xr.inv_transform(bd, deq, tx_hor, tx_ver)
+                cases.append((bd, w, h, tx_hor, tx_ver, qp, nnz))
+                for lst, arr in ((resi_l, resi), (coeff_l, coeff), (lev_l, lev),
+                                 (deq_l, deq), (inv_l, inv)):
+                    p = np.zeros((64, 64), np.int16); p[:h, :w] = arr; lst.append(p)
+    np.savez_compressed(os.path.join(OUT, "transform.npz"),
+                        cases=np.array(cases, np.int32), resi=np.array(resi_l),
+                        coeff=np.array(coeff_l), level=np.array(lev_l),
+                        dequant=np.array(deq_l), inverse=np.array(inv_l))
+
+    # ---- deblocking + padding ----
+    for name, (pw, ph, bd, bipred) in {"deblock_a": (136, 72, 10, 0),
+                                       "deblock_b": (128, 64, 8, 1)}.items():
+        parts = random_partition(rng, pw, ph)
+        l0, l1 = [8, 0], [16, 8]
+        cus, cmap = make_cus(rng, parts, bipred, l0, l1, pw, ph)
+        planes = []
+        for c in range(3):
+            w, h = (pw, ph) if c == 0 else (pw // 2, ph // 2)
+            b = BL if c == 0 else BC
+            base = rng.integers(0, 1 << bd, size=((h + 7) // 8, (w + 7) // 8))
+            p = np.kron(base, np.ones((8, 8), np.int64))[:h, :w]
+            p = np.clip(p // 4 + (1 << (bd - 1)) + rng.integers(-6, 7, size=(h, w)), 0,
+                        (1 << bd) - 1)
+            full = np.zeros((h + 2 * b, w + 2 * b), np.uint16)
+            full[b:b + h, b:b + w] = p
+            planes.append(full)
+        out = [p.copy() for p in planes]
+        xr.deblock(bd, pw, ph, bipred, 0, 0, 4, cus, cmap, out, [BL, BC, BC], l0, l1)
+        padded = [p.copy() for p in out]
+        # reference border is 80/40: compare that region only
+        xr.pad_border(pw, ph, padded, [BL, BC, BC])
+        np.savez_compressed(
+            os.path.join(OUT, name + ".npz"), dims=np.array([pw, ph, bd, bipred], np.int32),
+            cus=cus, cu_map=cmap,
+            **{"in%d" % c: planes[c][(BL >> (c > 0)):(BL >> (c > 0)) + (ph >> (c > 0)),
+                                     (BL >> (c > 0)):(BL >> (c > 0)) + (pw >> (c > 0))]
+               for c in range(3)},
+            **{"out%d" % c: out[c][(BL >> (c > 0)):(BL >> (c > 0)) + (ph >> (c > 0)),
+                                   (BL >> (c > 0)):(BL >> (c > 0)) + (pw >> (c > 0))]
+               for c in range(3)},
+            **{"pad%d" % c: padded[c][(BL - 80 >> (c > 0)) if c == 0 else (BC - 40):
+                                      (padded[c].shape[0] - (BL - 80)) if c == 0 else
+                                      (padded[c].shape[0] - (BC - 40)),
+                                      (BL - 80) if c == 0 else (BC - 40):
+                                      (padded[c].shape[1] - (BL - 80)) if c == 0 else
+                                      (padded[c].shape[1] - (BC - 40))]
+               for c in range(3)})
+
+    # ---- motion search ----
+    pw, ph, bd = 192, 128, 10
+    orig, ref = make_pics(rng, bd, pw, ph, BL, (5, -3))
+    blocks = np.zeros(24, ol.ME_DTYPE)
+    res = np.zeros(24, ol.MERES_DTYPE)
+    for i in range(24):
+        b = blocks[i]
+        w = int(rng.choice([8, 16, 32, 64])); h = int(rng.choice([8, 16, 32, 64]))
+        b["w"], b["h"] = w, h
+        b["x"] = int(rng.integers(0, (pw - w) // 8 + 1)) * 8
+        b["y"] = int(rng.integers(0, (ph - h) // 8 + 1)) * 8
+        b["depth_nonzero"] = int(rng.integers(0, 2))
+        b["mvp_x"], b["mvp_y"] = int(rng.integers(-150, 150)), int(rng.integers(-150, 150))
+        b["prev_x"], b["prev_y"] = int(rng.integers(-12, 12)), int(rng.integers(-12, 12))
+        b["lambda16"] = int(rng.choice([120000, 498712, 1500000]))
+        b["search_range"] = int(rng.choice([96, 128]))
+        s = ol.MeBlock()
+        for name in ol.ME_DTYPE.names:
+            setattr(s, name, int(b[name]))
+        (fx, fy), _ = xr.tz_search(bd, s, pw, ph, orig, ref, BL)
+        (sx, sy), sd = xr.subpel_search(bd, s, pw, ph, orig, ref, BL, (fx, fy))
+        res[i] = (fx, fy, sx, sy, 0, sd)
+    np.savez_compressed(os.path.join(OUT, "me.npz"), dims=np.array([pw, ph, bd], np.int32),
+                        orig=orig[BL - 8:BL + ph + 8, BL - 8:BL + pw + 8],
+                        ref=ref, blocks=blocks, results=res)
+
+    # ---- picture SSD ----
+    cases, a_l, b_l, exp = [], [], [], []
+    for (w, h, bd) in [(64, 64, 8), (136, 72, 10), (128, 128, 10), (200, 136, 8)]:
+        a = rnd_samples(rng, bd, h, w)
+        b = np.clip(a.astype(np.int32) + rng.integers(-9, 10, size=(h, w)), 0,
+                    (1 << bd) - 1).astype(np.uint16)
+        d, n = xr.picture_ssd(bd, a, b)
+        cases.append((w, h, bd, d, n))
+        pa = np.zeros((136, 200), np.uint16); pa[:h, :w] = a
+        pb = np.zeros((136, 200), np.uint16); pb[:h, :w] = b
+        a_l.append(pa); b_l.append(pb)
+    np.savez_compressed(os.path.join(OUT, "picture_ssd.npz"),
+                        cases=np.array(cases, np.int64), a=np.array(a_l), b=np.array(b_l))
+    total = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))
+    print("golden fixtures written to", OUT, "total bytes", total)
+
+
+if __name__ == "__main__":
+    main()
