@@ -153,6 +153,15 @@ xvcgpu_status xvcgpu_me_search(xvcgpu_ctx *ctx, const xvcgpu_picture *orig,
                                const xvcgpu_me_block *d_blocks, int n,
                                xvcgpu_me_result *d_results);
 
+/* Same, when the caller knows that no block of the batch exceeds
+ * max_block_size (16, 32 or 64) in either dimension: only the kernel variants
+ * whose LDS footprint is needed are launched. */
+xvcgpu_status xvcgpu_me_search_sized(xvcgpu_ctx *ctx, const xvcgpu_picture *orig,
+                                     const xvcgpu_picture *ref, int flags,
+                                     const xvcgpu_me_block *d_blocks, int n,
+                                     xvcgpu_me_result *d_results,
+                                     int max_block_size);
+
 /* ---- I1: MotionCompensationMv, uni-prediction --------------------------- *
  * (inter_prediction.cc:740-758 -> FilterLuma/FilterChroma :1387-1448).
  * Writes the predicted block of component blk.comp into `pred` at the CU's

@@ -372,6 +372,10 @@ void xo_min_max_mv(int pos_x, int pos_y, int pic_w, int pic_h, int center_x,
   mv_max[1] = maxy >> 4;
 }
 
+/* debug counters (tests/tools only): [0] SAD evaluations, [1] grid searches,
+ * [2] refinement iterations, [3] searches */
+uint64_t xo_dbg_counters[4];
+
 /* TZ search state, inter_tz_search.cc:66-82 */
 typedef struct {
   int bd, w, h, metric;
@@ -389,6 +393,7 @@ enum { XP_LEFT = -1, XP_RIGHT = 1, XP_UP = -3, XP_DOWN = 3 };
 
 static int xp_check_best(xp_tz *s, int mx, int my) { /* :261-276 */
   const uint16_t *r = s->ref + (ptrdiff_t)my * s->rs + mx;
+  xo_dbg_counters[0]++;
   uint64_t dist = xo_metric_ss(s->metric, s->bd, 0, 1, 1.0, s->w, s->h, s->orig,
                                s->os, r, s->rs);
   if (dist >= s->cost_best) return 0;
@@ -557,12 +562,15 @@ void xo_tz_search(int bd, const xvcgpu_me_block *b, int pic_w, int pic_h,
     s.last_range = 0;
     xp_neighbor(&s);
   }
+  xo_dbg_counters[3]++;
   if (s.last_range > 5) {
+    xo_dbg_counters[1]++;
     s.last_range = 5;
     for (int y = fs_min[1]; y <= fs_max[1]; y += 5)
       for (int x = fs_min[0]; x <= fs_max[0]; x += 5) xp_check_best(&s, x, y);
   }
   while (s.last_range > 0) {
+    xo_dbg_counters[2]++;
     int sx = s.best[0], sy = s.best[1];
     s.last_range = 0;
     for (int r = 1; r <= range; r *= 2) xp_diamond(&s, sx, sy, r);

@@ -7,7 +7,7 @@ from xvc_amd import api, pipeline, synth
 
 W, H, bd, border = 1920, 1080, 10, 128
 ctx = api.Context(0)
-clip = synth.SyntheticClip(W, H, bd)
+clip = synth.SyntheticClip(W, H, bd, square=not os.environ.get('NOSQUARE'))
 pad = lambda planes: [np.ascontiguousarray(np.pad(p, border if c == 0 else border // 2, mode="edge")) for c, p in enumerate(planes)]
 O, R = ctx.picture(W, H, bd), ctx.picture(W, H, bd)
 R.upload(pad(clip.frame(0)), border); O.upload(pad(clip.frame(1)), border)

@@ -57,7 +57,7 @@ SYMBOLS = [
     "xvcgpu_picture_download", "xvcgpu_picture_upload_padded",
     "xvcgpu_picture_download_padded", "xvcgpu_picture_plane",
     "xvcgpu_picture_copy", "xvcgpu_pad_border", "xvcgpu_metric_batch",
-    "xvcgpu_me_search", "xvcgpu_mc_batch", "xvcgpu_mc_from_me",
+    "xvcgpu_me_search", "xvcgpu_me_search_sized", "xvcgpu_mc_batch", "xvcgpu_mc_from_me",
     "xvcgpu_cu_info_from_me", "xvcgpu_residual_batch",
     "xvcgpu_fwd_transform_batch", "xvcgpu_inv_transform_batch",
     "xvcgpu_deblock", "xvcgpu_deblock_rows", "xvcgpu_picture_ssd", "xvcgpu_get_transform_matrix",
@@ -124,6 +124,7 @@ def load_library():
         "xvcgpu_metric_batch": [_vp, _vp, _vp, C.c_int, C.c_double, C.c_int, _vp,
                                 C.c_int, _vp],
         "xvcgpu_me_search": [_vp, _vp, _vp, C.c_int, _vp, C.c_int, _vp],
+        "xvcgpu_me_search_sized": [_vp, _vp, _vp, C.c_int, _vp, C.c_int, _vp, C.c_int],
         "xvcgpu_mc_batch": [_vp, _vp, _vp, _vp, C.c_int],
         "xvcgpu_mc_from_me": [_vp, _vp, _vp, _vp, _vp, C.c_int],
         "xvcgpu_cu_info_from_me": [_vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int,
@@ -310,9 +311,10 @@ class Context:
     def pad_border(self, pic):
         self._check(self.lib.xvcgpu_pad_border(self.h, pic.h_pic))
 
-    def me_search_dev(self, orig, ref, flags, d_blocks, n, d_results):
-        self._check(self.lib.xvcgpu_me_search(self.h, orig.h_pic, ref.h_pic, flags,
-                                              d_blocks, n, d_results))
+    def me_search_dev(self, orig, ref, flags, d_blocks, n, d_results, max_size=64):
+        self._check(self.lib.xvcgpu_me_search_sized(self.h, orig.h_pic, ref.h_pic,
+                                                    flags, d_blocks, n, d_results,
+                                                    max_size))
 
     def mc_batch_dev(self, ref, pred, d_blocks, n):
         self._check(self.lib.xvcgpu_mc_batch(self.h, ref.h_pic, pred.h_pic,

@@ -61,4 +61,16 @@ __device__ __forceinline__ uint32_t d_mvd_bits(int mvp_x, int mvp_y, int mx,
          d_eg_bits((my - mvp_y) >> (2 + down));
 }
 
+// XCD-aware job index (MI355X: 8 XCDs, each with a private 4 MiB L2; workgroup
+// b is observed to run on XCD b % 8).  Jobs are laid out in picture raster
+// order, so giving XCD k the k-th contiguous eighth of the job list keeps each
+// L2's working set to one horizontal band of the pictures instead of all of
+// them.  Launch ceil(n/8)*8 workgroups; returns -1 for the padding ones.
+// Placement only affects speed, never results.
+__device__ __forceinline__ int xcd_job_index(int block, int n) {
+  const int chunk = (n + 7) >> 3;
+  const int job = (block & 7) * chunk + (block >> 3);
+  return ((block >> 3) < chunk && job < n) ? job : -1;
+}
+
 #endif  // XVCGPU_DEV_COMMON_H_

@@ -1,0 +1,825 @@
+// k_me2.h -- T1 + T3 (+W1, I1, M1, M4), throughput form: ONE WAVEFRONT per
+// motion-estimation job (= one InterSearch::MotionEstNormal call,
+// inter_search.cc:606-662).  A 1080p picture has 8160 such jobs: with one wave
+// each the whole picture is resident at once (32 waves/CU x 256 CUs) and the
+// serial phase structure of the search is hidden by occupancy instead of being
+// paid in barriers.  No workgroup barrier is needed (a 64-thread workgroup is
+// one wave; __syncthreads() only orders LDS traffic).
+//
+// Full-pel (TzSearch::Search, inter_tz_search.cc:84-171): the candidate
+// pattern is a table (tz_pattern.h), lane i owns entries i and i+64; quads of
+// 4 lanes evaluate 16 candidates per pass (16-byte unaligned loads, v_sad_u16,
+// quad_perm DPP sums); costs go through LDS so that lane i gets the costs of
+// its own candidates, and the reference's ordered folds become wave-wide keyed
+// minima ((cost << 7) | index: lowest index wins ties, exactly the strict-<
+// left-to-right fold).  The initial predictor / zero / previous-MV checks are
+// one pass; the rare step-5 grid runs one candidate per lane.
+//
+// Sub-pel (InterSearch::SubpelSearch, inter_search.cc:893-964): the reference
+// window (block + 8-tap support + 1 pel) is staged once in LDS; for every
+// distinct horizontal phase of the 9 (then 8) candidates the horizontally
+// filtered planes are built once (14-bit intermediate for the two-stage path,
+// Sample-rounded for the horizontal-only path); every candidate is then a
+// vertical 8-tap over one of those planes - identity taps reproduce the copy /
+// horizontal-only paths bit-exactly - evaluated directly in SATD tile layout
+// (one lane = one tile row in registers, vertical WHT by DPP/swizzle), so no
+// predicted block is ever stored.
+#ifndef XVCGPU_K_ME2_H_
+#define XVCGPU_K_ME2_H_
+
+#include "dev_common.h"
+#include "dev_tables.h"
+#include "k_me.h"
+#include "xvcgpu_internal.h"
+
+// ---- cross-lane helpers (DPP / swizzle; no LDS traffic) ---------------------
+template <int S>
+__device__ __forceinline__ int lane_xor(int v) {
+  if (S == 1) return __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, false);
+  if (S == 2) return __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, false);
+  if (S == 4) return __builtin_amdgcn_ds_swizzle(v, 0x101F);
+  if (S == 8) return __builtin_amdgcn_update_dpp(0, v, 0x128, 0xF, 0xF, false);
+  if (S == 16) return __builtin_amdgcn_ds_swizzle(v, 0x401F);
+  return __shfl_xor(v, 32, 64);
+}
+
+// Sum over each aligned group of G lanes (G in {4, 8, 16}); all lanes get it.
+template <int G>
+__device__ __forceinline__ int dpp_group_sum(int v) {
+  v += lane_xor<1>(v);
+  v += lane_xor<2>(v);
+  if (G >= 8) v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, false);
+  if (G >= 16) v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, false);
+  return v;
+}
+
+// Wave-wide minimum of a 32-bit key, returned wave-uniform.
+__device__ __forceinline__ uint32_t wave_min_key(uint32_t v) {
+  uint32_t o;
+  o = (uint32_t)lane_xor<1>((int)v); v = v < o ? v : o;
+  o = (uint32_t)lane_xor<2>((int)v); v = v < o ? v : o;
+  o = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, false);
+  v = v < o ? v : o;
+  o = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xF, 0xF, false);
+  v = v < o ? v : o;
+  const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)v, 0);
+  const uint32_t b = (uint32_t)__builtin_amdgcn_readlane((int)v, 16);
+  const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)v, 32);
+  const uint32_t d = (uint32_t)__builtin_amdgcn_readlane((int)v, 48);
+  const uint32_t ab = a < b ? a : b, cd = c < d ? c : d;
+  return ab < cd ? ab : cd;
+}
+
+#define ME2_NOKEY 0xffffffffu
+// independent jobs (waves) per workgroup, by block-size class (LDS budget)
+#define ME2_WAVES(MS) ((MS) > 32 ? 2 : 4)
+
+// Orders LDS traffic between the lanes of ONE wave (jobs never share data
+// across waves, so no workgroup barrier is ever needed): LDS requests of a
+// wave are serviced in issue order; this only stops compiler reordering and
+// drains outstanding LDS returns.
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+#define ME2_LANE ((int)(threadIdx.x & 63))
+
+template <int MS>
+struct __attribute__((aligned(16))) Me2Shared {
+  uint16_t orig[MS * MS];                   // row stride w
+  uint16_t win[(MS + 8) * (MS + 16)];       // rows -4..h+3, cols -8..w+7
+  int16_t hint[3][(MS + 8) * MS];           // 14-bit H-filtered, rows -4..h+3
+  int16_t hh[3][(MS + 8) * MS];             // Sample-rounded H-filtered
+  uint32_t cost[128];
+  // per sub-pel candidate: plane offset (int16 units from `orig`), stride,
+  // rounding offset, shift, 8 taps
+  int cand_plane[12], cand_stride[12], cand_off[12], cand_shift[12];
+  int16_t cand_taps[12][8];
+  uint32_t dist[12];
+};
+
+// ---- full-pel SAD evaluation: 4 lanes per candidate ------------------------
+// s.cost[0..n) holds packed positions ((y << 16) | (x & 0xffff), or
+// ME2_NOPOS); on return s.cost[i] is the kSad / kSadFast value of candidate i.
+// The block's 8-sample (4 for w == 4) segments are dealt round-robin to the 4
+// lanes of a quad (segment sg -> lane sg & 3), which keeps the two halves of a
+// 16-wide row - or 4 rows of an 8-wide block - in one wave instruction: every
+// cache line of a candidate is looked up once, exactly as with one candidate
+// per 16 lanes, but 16 candidates are in flight per pass, the reduction is two
+// quad_perm DPP adds and a pass costs ~2 instructions per candidate.
+#define ME2_NOPOS 0x80008000u
+
+template <int SPL>  // segments per lane, original segments kept in registers
+__device__ __forceinline__ void me2_eval_quads_reg(const MeCtx &c, uint32_t *cost,
+                                                   const uint16_t *s_orig, int n) {
+  const int lane = ME2_LANE, qd = lane >> 2, q = lane & 3;
+  const int spr = c.w >> 3, lspr = 31 - __clz(spr);
+  uint4 a[SPL];
+  int goff[SPL];
+#pragma unroll
+  for (int u = 0; u < SPL; u++) {
+    const int sg = q + 4 * u;
+    const int y = (sg >> lspr) * c.row_step, x = (sg & (spr - 1)) << 3;
+    a[u] = *reinterpret_cast<const uint4 *>(s_orig + y * c.w + x);
+    goff[u] = y * c.rs + x;
+  }
+  for (int i0 = 0; i0 < n; i0 += 16) {
+    const int i = i0 + qd;
+    const uint32_t pk = i < n ? cost[i] : ME2_NOPOS;
+    if (pk == ME2_NOPOS) continue;  // uniform within the quad
+    const int x = (int)(int16_t)(pk & 0xffffu), y = (int)pk >> 16;
+    const uint16_t *r = c.ref + (ptrdiff_t)y * c.rs + x;
+    U16x8 b[SPL];
+#pragma unroll
+    for (int u = 0; u < SPL; u++) b[u] = *reinterpret_cast<const U16x8 *>(r + goff[u]);
+    uint32_t sum = 0;
+#pragma unroll
+    for (int u = 0; u < SPL; u++) {
+      sum = __builtin_amdgcn_sad_u16(a[u].x, b[u].v[0], sum);
+      sum = __builtin_amdgcn_sad_u16(a[u].y, b[u].v[1], sum);
+      sum = __builtin_amdgcn_sad_u16(a[u].z, b[u].v[2], sum);
+      sum = __builtin_amdgcn_sad_u16(a[u].w, b[u].v[3], sum);
+    }
+    sum += (uint32_t)lane_xor<1>((int)sum);
+    sum += (uint32_t)lane_xor<2>((int)sum);
+    if (q == 0) cost[i] = (sum * c.sad_mul) >> c.sad_shift;
+  }
+}
+
+// generic form (large blocks, w == 4): segments streamed from LDS
+__device__ __forceinline__ void me2_eval_quads_gen(const MeCtx &c, uint32_t *cost,
+                                                   const uint16_t *s_orig, int n) {
+  const int lane = ME2_LANE, qd = lane >> 2, q = lane & 3;
+  const bool wide = c.w >= 8;
+  const int spr = wide ? c.w >> 3 : 1, lspr = 31 - __clz(spr);
+  const int nseg = c.rows * spr;
+  for (int i0 = 0; i0 < n; i0 += 16) {
+    const int i = i0 + qd;
+    const uint32_t pk = i < n ? cost[i] : ME2_NOPOS;
+    if (pk == ME2_NOPOS) continue;
+    const int x = (int)(int16_t)(pk & 0xffffu), y = (int)pk >> 16;
+    const uint16_t *r = c.ref + (ptrdiff_t)y * c.rs + x;
+    uint32_t sum = 0;
+    if (wide) {
+      for (int sg = q; sg < nseg; sg += 4) {
+        const int yy = (sg >> lspr) * c.row_step, xx = (sg & (spr - 1)) << 3;
+        const uint4 a = *reinterpret_cast<const uint4 *>(s_orig + yy * c.w + xx);
+        const U16x8 b = *reinterpret_cast<const U16x8 *>(r + (ptrdiff_t)yy * c.rs + xx);
+        sum = __builtin_amdgcn_sad_u16(a.x, b.v[0], sum);
+        sum = __builtin_amdgcn_sad_u16(a.y, b.v[1], sum);
+        sum = __builtin_amdgcn_sad_u16(a.z, b.v[2], sum);
+        sum = __builtin_amdgcn_sad_u16(a.w, b.v[3], sum);
+      }
+    } else {
+      for (int sg = q; sg < nseg; sg += 4) {
+        const int yy = sg * c.row_step;
+        const uint2 a = *reinterpret_cast<const uint2 *>(s_orig + yy * 4);
+        const U16x4 b = *reinterpret_cast<const U16x4 *>(r + (ptrdiff_t)yy * c.rs);
+        sum = __builtin_amdgcn_sad_u16(a.x, b.v[0], sum);
+        sum = __builtin_amdgcn_sad_u16(a.y, b.v[1], sum);
+      }
+    }
+    sum += (uint32_t)lane_xor<1>((int)sum);
+    sum += (uint32_t)lane_xor<2>((int)sum);
+    if (q == 0) cost[i] = (sum * c.sad_mul) >> c.sad_shift;
+  }
+}
+
+// Dispatch on the (wave-uniform) block shape.  Callers wave_sync() around it.
+__device__ __forceinline__ void me2_eval_positions(const MeCtx &c, uint32_t *cost,
+                                                   const uint16_t *s_orig, int n) {
+  const int nseg = c.w >= 8 ? c.rows * (c.w >> 3) : 0;
+  if (nseg == 16) me2_eval_quads_reg<4>(c, cost, s_orig, n);
+  else if (nseg == 8) me2_eval_quads_reg<2>(c, cost, s_orig, n);
+  else if (nseg == 4) me2_eval_quads_reg<1>(c, cost, s_orig, n);
+  else me2_eval_quads_gen(c, cost, s_orig, n);
+}
+
+__device__ __forceinline__ uint32_t me2_pack_pos(int x, int y) {
+  return ((uint32_t)y << 16) | ((uint32_t)x & 0xffffu);
+}
+
+// This lane's two pattern entries (indices lane and lane + 64 of the TZ
+// candidate pattern, tz_pattern.h), unpacked once per job.
+struct Me2Pattern {
+  int dx0, dy0, d10, d20, dx1, dy1, d11, d21;
+  int meta0, meta1;  // (rng << 8) | ((d1 + d2) & 0xff), for winner look-up
+  int off0, off1;    // (dy << 16) | (dx & 0xffff)
+  int round0, round1;
+};
+
+__device__ __forceinline__ Me2Pattern me2_load_pattern(const TzCand *tzp) {
+  const int lane = ME2_LANE;
+  const TzCand a = tzp[lane];
+  const TzCand b = tzp[lane + 64 < TZ_MAX_CANDS ? lane + 64 : 0];
+  Me2Pattern p;
+  p.dx0 = a.dx; p.dy0 = a.dy; p.d10 = a.d1; p.d20 = a.d2; p.round0 = a.round;
+  p.dx1 = b.dx; p.dy1 = b.dy; p.d11 = b.d1; p.d21 = b.d2; p.round1 = b.round;
+  p.meta0 = ((int)a.rng << 8) | ((a.d1 + a.d2) & 0xff);
+  p.meta1 = ((int)b.rng << 8) | ((b.d1 + b.d2) & 0xff);
+  p.off0 = ((int)a.dy << 16) | ((int)a.dx & 0xffff);
+  p.off1 = ((int)b.dy << 16) | ((int)b.dx & 0xffff);
+  return p;
+}
+
+// Pattern entry `idx` (wave-uniform) as seen from centre (bx,by).
+__device__ __forceinline__ void me2_pattern_at(const Me2Pattern &p, int idx, int bx,
+                                               int by, int &x, int &y, int &pos,
+                                               int &rng) {
+  const int l = idx & 63;
+  const int o0 = __builtin_amdgcn_readlane(p.off0, l), o1 = __builtin_amdgcn_readlane(p.off1, l);
+  const int m0 = __builtin_amdgcn_readlane(p.meta0, l), m1 = __builtin_amdgcn_readlane(p.meta1, l);
+  const int o = (idx >> 6) ? o1 : o0, m = (idx >> 6) ? m1 : m0;
+  x = bx + (int)(int16_t)(o & 0xffff);
+  y = by + (o >> 16);
+  pos = (int)(int8_t)(m & 0xff);
+  rng = m >> 8;
+}
+
+// Evaluate pattern entries [lo, total) of the diamond list around (bx,by):
+// afterwards lane l holds the keys of candidates l and l+64
+// ((cost << 7) | index, or ME2_NOKEY when outside the window).
+template <int MS>
+__device__ __forceinline__ void me2_eval_diamonds(const MeCtx &c, Me2Shared<MS> &s,
+                                                  const Me2Pattern &p, int bx, int by,
+                                                  int lo, int total, uint32_t &key0,
+                                                  uint32_t &key1) {
+  const int lane = ME2_LANE;
+  const int x0 = bx + p.dx0, y0 = by + p.dy0, x1 = bx + p.dx1, y1 = by + p.dy1;
+  const bool v0 = lane >= lo && lane < total && tz_inside(c, p.d10, x0, y0) &&
+                  (p.d20 == 0 || tz_inside(c, p.d20, x0, y0));
+  const bool v1 = lane + 64 >= lo && lane + 64 < total && tz_inside(c, p.d11, x1, y1) &&
+                  (p.d21 == 0 || tz_inside(c, p.d21, x1, y1));
+  wave_sync();
+  s.cost[lane] = v0 ? me2_pack_pos(x0, y0) : ME2_NOPOS;
+  s.cost[lane + 64] = v1 ? me2_pack_pos(x1, y1) : ME2_NOPOS;
+  wave_sync();
+  me2_eval_positions(c, s.cost, s.orig, total);
+  wave_sync();
+  key0 = key1 = ME2_NOKEY;
+  if (v0) key0 = (me_cost(c, s.cost[lane], x0, y0) << 7) | (uint32_t)lane;
+  if (v1) key1 = (me_cost(c, s.cost[lane + 64], x1, y1) << 7) | (uint32_t)(lane + 64);
+}
+
+// ---- sub-pel ---------------------------------------------------------------
+// Build the horizontally filtered planes of x-phase (pel_x, fx) into slot p:
+// hint = FilterHorSampleShort, hh = FilterHorSampleSample
+// (inter_prediction.cc:1207-1265), all h+8 rows.
+template <int MS>
+__device__ __forceinline__ void me2_build_hplanes(Me2Shared<MS> &s, int bd, int w,
+                                                  int h, int p, int pel_x, int fx) {
+  const int lw = 31 - __clz(w);
+  const int ws = w + 16;
+  const int16_t *f = kLumaTaps[fx];
+  const int f0 = f[0], f1 = f[1], f2 = f[2], f3 = f[3], f4 = f[4], f5 = f[5],
+            f6 = f[6], f7 = f[7];
+  const int shift = 6 - (14 - bd), offset = -(8192 << shift);
+  const int smax = (1 << bd) - 1;
+  const int n = (h + 8) * w;
+  for (int i = ME2_LANE; i < n; i += 64) {
+    const int r = i >> lw, x = i & (w - 1);
+    // window column of sample (x + pel_x - 3): cols start at -8
+    const uint16_t *src = s.win + r * ws + x + pel_x - 3 + 8;
+    const int sum = (int)src[0] * f0 + (int)src[1] * f1 + (int)src[2] * f2 +
+                    (int)src[3] * f3 + (int)src[4] * f4 + (int)src[5] * f5 +
+                    (int)src[6] * f6 + (int)src[7] * f7;
+    s.hint[p][i] = (int16_t)((sum + offset) >> shift);
+    s.hh[p][i] = (int16_t)d_clip_bd((sum + 32) >> 6, smax);
+  }
+}
+
+// One SATD pass over `ncand` candidates described in s.cand_*: lane = one tile
+// row (TW samples) of one TW x TH tile of one candidate; s.dist[c] accumulates
+// the normalised tile sums (ComputeSatdNxM, sample_metric.cc:403-641).
+template <int MS, int TW, int TH>
+__device__ __forceinline__ void me2_satd_cands(Me2Shared<MS> &s, int bd, int w,
+                                               int h, int ncand) {
+  const int lane = ME2_LANE;
+  const int tiles_x = w / TW;
+  const int upc = (w / TW) * h;  // tile rows per candidate, multiple of TH
+  const int total = upc * ncand;
+  const int smax = (1 << bd) - 1;
+  const int16_t *lds = reinterpret_cast<const int16_t *>(s.orig);
+  for (int g0 = 0; g0 < total; g0 += 64) {
+    const int g = g0 + lane;
+    const bool active = g < total;
+    int m[TW];
+    int cnd = 0;
+    if (active) {
+      cnd = g / upc;
+      const int u = g - cnd * upc;
+      const int tile = u / TH, row = u % TH;
+      const int x0 = (tile % tiles_x) * TW, y = (tile / tiles_x) * TH + row;
+      const int stride = s.cand_stride[cnd];
+      const int16_t *pl = lds + s.cand_plane[cnd] + y * stride + x0;
+      const int off = s.cand_off[cnd], sh = s.cand_shift[cnd];
+      int t[8];
+#pragma unroll
+      for (int k = 0; k < 8; k++) t[k] = s.cand_taps[cnd][k];
+      int acc[TW];
+#pragma unroll
+      for (int j = 0; j < TW; j++) acc[j] = off;
+#pragma unroll
+      for (int k = 0; k < 8; k++) {
+        const int16_t *rowp = pl + k * stride;
+        // rows are 8-byte (TW == 4) or 16-byte aligned: packed pair loads
+        uint32_t pk[TW / 2];
+        if (TW == 4) {
+          const uint2 v = *reinterpret_cast<const uint2 *>(rowp);
+          pk[0] = v.x; pk[1] = v.y;
+        } else {
+#pragma unroll
+          for (int q = 0; q < TW / 8; q++) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(rowp + 8 * q);
+            pk[4 * q + 0] = v.x; pk[4 * q + 1] = v.y; pk[4 * q + 2] = v.z; pk[4 * q + 3] = v.w;
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < TW / 2; j++) {
+          acc[2 * j] += (int)(int16_t)(pk[j] & 0xffff) * t[k];
+          acc[2 * j + 1] += ((int)pk[j] >> 16) * t[k];
+        }
+      }
+      const uint16_t *o = s.orig + y * w + x0;
+      uint32_t ok[TW / 2];
+      if (TW == 4) {
+        const uint2 v = *reinterpret_cast<const uint2 *>(o);
+        ok[0] = v.x; ok[1] = v.y;
+      } else {
+#pragma unroll
+        for (int q = 0; q < TW / 8; q++) {
+          const uint4 v = *reinterpret_cast<const uint4 *>(o + 8 * q);
+          ok[4 * q + 0] = v.x; ok[4 * q + 1] = v.y; ok[4 * q + 2] = v.z; ok[4 * q + 3] = v.w;
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < TW; j++) {
+        const int pred = d_clip_bd((int16_t)(acc[j] >> sh), smax);
+        const int ov = (j & 1) ? (int)(ok[j / 2] >> 16) : (int)(ok[j / 2] & 0xffff);
+        m[j] = ov - pred;
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < TW; j++) m[j] = 0;
+    }
+    // horizontal WHT in registers
+#pragma unroll
+    for (int len = 1; len < TW; len <<= 1)
+#pragma unroll
+      for (int i = 0; i < TW; i += len << 1)
+#pragma unroll
+        for (int j = i; j < i + len; j++) {
+          const int a = m[j], b = m[j + len];
+          m[j] = a + b;
+          m[j + len] = a - b;
+        }
+    // vertical WHT across the TH lanes of the tile
+    const int row = lane % TH;
+    if (TH >= 2) {
+      const bool up = (row & 1) != 0;
+#pragma unroll
+      for (int j = 0; j < TW; j++) { const int o2 = lane_xor<1>(m[j]); m[j] = up ? o2 - m[j] : m[j] + o2; }
+    }
+    if (TH >= 4) {
+      const bool up = (row & 2) != 0;
+#pragma unroll
+      for (int j = 0; j < TW; j++) { const int o2 = lane_xor<2>(m[j]); m[j] = up ? o2 - m[j] : m[j] + o2; }
+    }
+    if (TH >= 8) {
+      const bool up = (row & 4) != 0;
+#pragma unroll
+      for (int j = 0; j < TW; j++) { const int o2 = lane_xor<4>(m[j]); m[j] = up ? o2 - m[j] : m[j] + o2; }
+    }
+    if (TH >= 16) {
+      const bool up = (row & 8) != 0;
+#pragma unroll
+      for (int j = 0; j < TW; j++) { const int o2 = lane_xor<8>(m[j]); m[j] = up ? o2 - m[j] : m[j] + o2; }
+    }
+    int sum = 0;
+#pragma unroll
+    for (int j = 0; j < TW; j++) sum += d_abs(m[j]);
+    sum = dpp_group_sum<TH>(sum);
+    if (TW == 4 && TH == 4) sum = (sum + 1) >> 1;
+    else if (TW == TH) sum = (sum + 2) >> 2;
+    else sum = (int)(2.0 * (double)sum / sqrt((double)(TW * TH)));
+    if (active && row == 0) atomicAdd(&s.dist[cnd], (uint32_t)sum);
+  }
+}
+
+template <int MS>
+__device__ __forceinline__ void me2_satd_dispatch(Me2Shared<MS> &s, int bd, int w,
+                                                  int h, int ncand) {
+  if (w == 4 && h == 4) me2_satd_cands<MS, 4, 4>(s, bd, w, h, ncand);
+  else if (h == 4 && w > h) me2_satd_cands<MS, 8, 4>(s, bd, w, h, ncand);
+  else if (w == 4 && h > w) me2_satd_cands<MS, 4, 8>(s, bd, w, h, ncand);
+  else if (w > h) me2_satd_cands<MS, 16, 8>(s, bd, w, h, ncand);
+  else if (w < h) me2_satd_cands<MS, 8, 16>(s, bd, w, h, ncand);
+  else me2_satd_cands<MS, 8, 8>(s, bd, w, h, ncand);
+}
+
+// Offsets of the 9 half-pel / 8 quarter-pel candidates in issue order
+// (kSquareXYHalf / kSquareXYQpel, inter_search.cc:38-43).
+__constant__ int8_t kSubpelOff[2][9][2] = {
+    {{0, 0}, {0, -1}, {0, 1}, {-1, 0}, {1, 0}, {-1, -1}, {1, -1}, {-1, 1}, {1, 1}},
+    {{0, 0}, {0, -1}, {0, 1}, {-1, -1}, {1, -1}, {-1, 0}, {1, 0}, {-1, 1}, {1, 1}}};
+
+// i-th candidate MV of sub-pel pass `pass` (0 = half, 1 = quarter) around base.
+__device__ __forceinline__ void me2_subpel_mv(int pass, int i, int base_x, int base_y,
+                                              int &mx, int &my) {
+  const int k = i + pass, scale = pass == 0 ? 8 : 4;
+  mx = base_x + kSubpelOff[pass][k][0] * scale;
+  my = base_y + kSubpelOff[pass][k][1] * scale;
+}
+
+// Evaluate the SATD of the n = 9 - pass candidates of a sub-pel pass (or, with
+// pass < 0, of the single MV (base_x, base_y)) around the staged full-pel
+// position (fpx,fpy); raw tile sums in s.dist[0..n).  Arguments wave-uniform.
+template <int MS>
+__device__ __forceinline__ void me2_subpel_eval(Me2Shared<MS> &s, const MeCtx &c,
+                                                const xvcgpu_me_block &b, int pic_w,
+                                                int pic_h, int fpx, int fpy, int pass,
+                                                int base_x, int base_y) {
+  const int w = c.w, h = c.h, bd = c.bd;
+  const int ws = w + 16;
+  const int lane = ME2_LANE;
+  const int n = pass < 0 ? 1 : 9 - pass;
+  // this lane's candidate (lanes >= n idle)
+  int mx = base_x, my = base_y;
+  if (pass >= 0 && lane < n) me2_subpel_mv(pass, lane, base_x, base_y, mx, my);
+  d_clip_mv(b.x, b.y, pic_w, pic_h, mx, my);  // MotionCompensationMv, :749
+  const int cpx = (mx >> 4) - fpx, cpy = (my >> 4) - fpy;
+  const int cfx = mx & 15, cfy = my & 15;
+  // distinct horizontal phases with fx != 0 -> plane slots (<= 3)
+  const int mykey = (cpx + 1) * 16 + cfx;
+  const bool need = lane < n && cfx != 0;
+  int myslot = -1, nslots = 0, slot_key[3] = {0, 0, 0};
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    const unsigned long long m = __ballot(need && myslot < 0);
+    if (m) {
+      const int leader = __ffsll((long long)m) - 1;
+      const int key = __builtin_amdgcn_readlane(mykey, leader);
+      if (need && mykey == key) myslot = k;
+      slot_key[k] = key;
+      nslots = k + 1;
+    }
+  }
+  wave_sync();  // previous readers of the planes / tables are done
+#pragma unroll
+  for (int k = 0; k < 3; k++)
+    if (k < nslots)
+      me2_build_hplanes(s, bd, w, h, k, (slot_key[k] >> 4) - 1, slot_key[k] & 15);
+  if (lane < n) {
+    const int16_t *base = reinterpret_cast<const int16_t *>(s.orig);
+    int plane, stride, off, sh;
+    // plane element for output (x=0,y=0), tap 0: row (pel_y - 3) + 4
+    if (cfx == 0) {
+      // vertical-only / copy: FilterVerSampleSample on the window samples
+      plane = (int)(reinterpret_cast<const int16_t *>(s.win) - base) +
+              (cpy + 1) * ws + cpx + 8;
+      stride = ws;
+      off = 32;
+      sh = 6;
+    } else if (cfy == 0) {
+      // horizontal-only: Sample-rounded plane through identity taps
+      plane = (int)(s.hh[0] - base) + myslot * (MS + 8) * MS + (cpy + 1) * w;
+      stride = w;
+      off = 32;
+      sh = 6;
+    } else {
+      // two-stage: FilterVerShortSample on the 14-bit plane
+      plane = (int)(s.hint[0] - base) + myslot * (MS + 8) * MS + (cpy + 1) * w;
+      stride = w;
+      sh = 6 + (14 - bd);
+      off = (8192 << 6) + (1 << (sh - 1));
+    }
+    s.cand_plane[lane] = plane;
+    s.cand_stride[lane] = stride;
+    s.cand_off[lane] = off;
+    s.cand_shift[lane] = sh;
+#pragma unroll
+    for (int k = 0; k < 8; k++) s.cand_taps[lane][k] = kLumaTaps[cfy][k];
+    s.dist[lane] = 0;
+  }
+  wave_sync();
+  me2_satd_dispatch(s, bd, w, h, n);
+  wave_sync();
+}
+
+// grid: n jobs; block: 64 threads (one wave).  Handles the jobs whose block
+// fits class MS (max(w,h) <= MS) and no smaller class.
+template <int MS>
+__global__ void __launch_bounds__(64 * ME2_WAVES(MS))
+me_search_wave_kernel(PicView orig, PicView ref, int flags,
+                      const xvcgpu_me_block *blocks, int n,
+                      xvcgpu_me_result *results, const TzCand *tz_pattern) {
+  constexpr int WPG = ME2_WAVES(MS);
+  __shared__ Me2Shared<MS> s_all[WPG];
+  Me2Shared<MS> &s = s_all[threadIdx.x >> 6];
+  // job = (workgroup, wave); workgroups are XCD-swizzled, waves consecutive
+  const int n_wg = (n + WPG - 1) / WPG;
+  const int wg = xcd_job_index(blockIdx.x, n_wg);
+  if (wg < 0) return;
+  const int bi = wg * WPG + (int)(threadIdx.x >> 6);
+  if (bi >= n) return;
+  const xvcgpu_me_block b = blocks[bi];
+  {
+    const int mx = b.w > b.h ? b.w : b.h;
+    if (mx > MS || (MS > 16 && mx <= MS / 2)) return;  // other class
+  }
+  const int lane = ME2_LANE;
+  const PlaneView po = orig.c[0], pr = ref.c[0];
+  const int pic_w = po.w, pic_h = po.h;
+
+  MeCtx c;
+  c.bd = orig.bd;
+  c.w = b.w;
+  c.h = b.h;
+  const bool fast = b.h > 8;
+  c.rows = fast ? b.h / 2 : b.h;
+  c.row_step = fast ? 2 : 1;
+  c.sad_mul = fast ? 2 : 1;
+  c.sad_shift = c.bd - 8;
+  c.rs = pr.stride;
+  c.ref = pr.p + (ptrdiff_t)b.y * pr.stride + b.x;
+  c.mvp_x = b.mvp_x;
+  c.mvp_y = b.mvp_y;
+  c.down = b.fullpel_mv ? 2 : 0;
+  c.lambda = b.lambda16;
+
+  {  // stage the original block
+    const int lw = 31 - __clz(c.w);
+    const uint16_t *o = po.p + (ptrdiff_t)b.y * po.stride + b.x;
+    for (int i = lane; i < c.w * c.h; i += 64)
+      s.orig[i] = o[(ptrdiff_t)(i >> lw) * po.stride + (i & (c.w - 1))];
+  }
+
+  xvcgpu_me_result res;
+  if (flags & XVCGPU_ME_FULLPEL) {
+    const int range = b.search_range;
+    d_min_max_mv(b.x, b.y, pic_w, pic_h, b.mvp_x, b.mvp_y, range, c.min_x,
+                 c.min_y, c.max_x, c.max_y);
+    int fs_min_x = c.min_x, fs_min_y = c.min_y, fs_max_x = c.max_x,
+        fs_max_y = c.max_y;
+    TzState st;
+    st.bx = 0; st.by = 0; st.cost = 0xffffffffu; st.last_pos = 0; st.last_range = 0;
+
+    // predictor, zero MV and previous CU's MV in one pass (groups 0..2)
+    {
+      int px = b.mvp_x, py = b.mvp_y;
+      d_clip_mv(b.x, b.y, pic_w, pic_h, px, py);
+      int qx = b.prev_x * 16, qy = b.prev_y * 16;
+      d_clip_mv(b.x, b.y, pic_w, pic_h, qx, qy);
+      const int ax = px >> 4, ay = py >> 4, zx = qx >> 4, zy = qy >> 4;
+      wave_sync();
+      if (lane < 3)
+        s.cost[lane] = me2_pack_pos(lane == 0 ? ax : (lane == 1 ? 0 : zx),
+                                    lane == 0 ? ay : (lane == 1 ? 0 : zy));
+      wave_sync();
+      me2_eval_positions(c, s.cost, s.orig, 3);
+      wave_sync();
+      if (lane < 3) {
+        const int px_ = lane == 0 ? ax : (lane == 1 ? 0 : zx);
+        const int py_ = lane == 0 ? ay : (lane == 1 ? 0 : zy);
+        s.cost[lane] = me_cost(c, s.cost[lane], px_, py_);
+      }
+      wave_sync();
+      const uint32_t c0 = s.cost[0], c1 = s.cost[1], c2 = s.cost[2];
+      st.cost = c0; st.bx = ax; st.by = ay;
+      bool change = false;
+      if (st.bx != 0 || st.by != 0) {
+        if (c1 < st.cost) { st.cost = c1; st.bx = 0; st.by = 0; change = true; }
+      }
+      st.last_range = 0;
+      if (b.depth_nonzero) {
+        if (c2 < st.cost) { st.cost = c2; st.bx = zx; st.by = zy; change = true; }
+        if (change)
+          d_min_max_mv(b.x, b.y, pic_w, pic_h, st.bx * 16, st.by * 16, range,
+                       fs_min_x, fs_min_y, fs_max_x, fs_max_y);
+      }
+    }
+
+    int total = 0, n_rounds = 0;
+    for (int r = 1; r <= range; r *= 2) { total += tz_pattern_count(r); n_rounds++; }
+    const Me2Pattern pat = me2_load_pattern(tz_pattern);
+
+    // initial raster around the fixed base with per-round early termination
+    {
+      uint32_t k0, k1;
+      const int bx = st.bx, by = st.by;
+      // The reference stops the raster after 3 rounds without a hit, which
+      // is the common case: evaluate rounds 0..2 (ranges 1,2,4 = 20 nearby
+      // candidates) first and the far rounds only if the search goes on.
+      const int near_total = total < 20 ? total : 20;
+      me2_eval_diamonds(c, s, pat, bx, by, 0, near_total, k0, k1);
+      int no_match = 0;
+      bool far_done = near_total == total;
+      for (int r = 0; r < n_rounds; r++) {
+        if (r == 3 && !far_done) {
+          uint32_t f0, f1;
+          me2_eval_diamonds(c, s, pat, bx, by, near_total, total, f0, f1);
+          if (f0 != ME2_NOKEY) k0 = f0;
+          if (f1 != ME2_NOKEY) k1 = f1;
+          far_done = true;
+        }
+        uint32_t k = ME2_NOKEY;
+        if (pat.round0 == r && k0 < k) k = k0;
+        if (pat.round1 == r && k1 < k) k = k1;
+        k = wave_min_key(k);
+        bool changed = false;
+        if (k != ME2_NOKEY && (k >> 7) < st.cost) {
+          int x, y, pos, rng;
+          me2_pattern_at(pat, (int)(k & 127), bx, by, x, y, pos, rng);
+          st.cost = k >> 7; st.bx = x; st.by = y; st.last_pos = pos; st.last_range = rng;
+          changed = true;
+        }
+        if (changed) no_match = 0;
+        else if (++no_match >= 3) break;
+      }
+    }
+    // neighbour refinement (2 candidates), shared by raster and refinement
+    auto neighbor = [&]() {
+      const int r = 1, bx = st.bx, by = st.by;
+      int x[2], y[2], d1[2], d2[2];
+      bool any = true;
+      switch (st.last_pos) {
+        case TZ_UP + TZ_LEFT: x[0]=bx-r;y[0]=by;d1[0]=TZ_LEFT;d2[0]=0; x[1]=bx;y[1]=by-r;d1[1]=TZ_UP;d2[1]=0; break;
+        case TZ_UP: x[0]=bx-r;y[0]=by-r;d1[0]=TZ_UP;d2[0]=TZ_LEFT; x[1]=bx+r;y[1]=by-r;d1[1]=TZ_UP;d2[1]=TZ_RIGHT; break;
+        case TZ_UP + TZ_RIGHT: x[0]=bx;y[0]=by-r;d1[0]=TZ_UP;d2[0]=0; x[1]=bx+r;y[1]=by;d1[1]=TZ_RIGHT;d2[1]=0; break;
+        case TZ_LEFT: x[0]=bx-r;y[0]=by+r;d1[0]=TZ_DOWN;d2[0]=TZ_LEFT; x[1]=bx-r;y[1]=by-r;d1[1]=TZ_UP;d2[1]=TZ_LEFT; break;
+        case TZ_RIGHT: x[0]=bx+r;y[0]=by-r;d1[0]=TZ_UP;d2[0]=TZ_RIGHT; x[1]=bx+r;y[1]=by+r;d1[1]=TZ_DOWN;d2[1]=TZ_RIGHT; break;
+        case TZ_DOWN + TZ_LEFT: x[0]=bx-r;y[0]=by;d1[0]=TZ_LEFT;d2[0]=0; x[1]=bx;y[1]=by+r;d1[1]=TZ_DOWN;d2[1]=0; break;
+        case TZ_DOWN: x[0]=bx-r;y[0]=by+r;d1[0]=TZ_DOWN;d2[0]=TZ_LEFT; x[1]=bx+r;y[1]=by+r;d1[1]=TZ_DOWN;d2[1]=TZ_RIGHT; break;
+        case TZ_DOWN + TZ_RIGHT: x[0]=bx+r;y[0]=by;d1[0]=TZ_RIGHT;d2[0]=0; x[1]=bx;y[1]=by+r;d1[1]=TZ_DOWN;d2[1]=0; break;
+        default: any = false; break;
+      }
+      if (!any) return;
+      const bool v0 = tz_inside(c, d1[0], x[0], y[0]) && (d2[0] == 0 || tz_inside(c, d2[0], x[0], y[0]));
+      const bool v1 = tz_inside(c, d1[1], x[1], y[1]) && (d2[1] == 0 || tz_inside(c, d2[1], x[1], y[1]));
+      wave_sync();
+      if (lane == 0) s.cost[0] = v0 ? me2_pack_pos(x[0], y[0]) : ME2_NOPOS;
+      if (lane == 1) s.cost[1] = v1 ? me2_pack_pos(x[1], y[1]) : ME2_NOPOS;
+      wave_sync();
+      me2_eval_positions(c, s.cost, s.orig, 2);
+      wave_sync();
+      if (lane == 0 && v0) s.cost[0] = me_cost(c, s.cost[0], x[0], y[0]);
+      if (lane == 1 && v1) s.cost[1] = me_cost(c, s.cost[1], x[1], y[1]);
+      wave_sync();
+      if (v0) {
+        const uint32_t cc = s.cost[0];
+        if (cc < st.cost) { st.cost = cc; st.bx = x[0]; st.by = y[0]; st.last_pos = d1[0] + d2[0]; st.last_range = r; }
+      }
+      if (v1) {
+        const uint32_t cc = s.cost[1];
+        if (cc < st.cost) { st.cost = cc; st.bx = x[1]; st.by = y[1]; st.last_pos = d1[1] + d2[1]; st.last_range = r; }
+      }
+    };
+    if (st.last_range == 1) { st.last_range = 0; neighbor(); }
+    // step-5 grid
+    if (st.last_range > 5) {
+      st.last_range = 5;
+      const int nx = (fs_max_x - fs_min_x) / 5 + 1;
+      const int ny = (fs_max_y - fs_min_y) / 5 + 1;
+      const int tot = (fs_max_x >= fs_min_x && fs_max_y >= fs_min_y) ? nx * ny : 0;
+      // Rare (a CU whose raster hit was >= 8 away) but ~1500 candidates: one
+      // candidate per LANE here, so the straggler wave keeps 64 independent
+      // load streams in flight instead of 4; no cross-lane reduction at all.
+      uint32_t best = 0xffffffffu;
+      int best_i = 0x7fffffff;
+      const int segw = c.w >= 8 ? 8 : 4, spr = c.w / segw, nsg = c.rows * spr;
+      for (int i = lane; i < tot; i += 64) {
+        const int gx = fs_min_x + (i % nx) * 5, gy = fs_min_y + (i / nx) * 5;
+        const uint16_t *r = c.ref + (ptrdiff_t)gy * c.rs + gx;
+        uint32_t sum = 0;
+        if (segw == 8 && (nsg & 7) == 0) {
+          // 8 independent 16-byte loads in flight per lane
+          for (int sg0 = 0; sg0 < nsg; sg0 += 8) {
+            U16x8 bb[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+              const int sg = sg0 + u;
+              const int y = (sg / spr) * c.row_step, x = (sg % spr) << 3;
+              bb[u] = *reinterpret_cast<const U16x8 *>(r + (ptrdiff_t)y * c.rs + x);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+              const int sg = sg0 + u;
+              const int y = (sg / spr) * c.row_step, x = (sg % spr) << 3;
+              const uint4 a = *reinterpret_cast<const uint4 *>(s.orig + y * c.w + x);
+              sum = __builtin_amdgcn_sad_u16(a.x, bb[u].v[0], sum);
+              sum = __builtin_amdgcn_sad_u16(a.y, bb[u].v[1], sum);
+              sum = __builtin_amdgcn_sad_u16(a.z, bb[u].v[2], sum);
+              sum = __builtin_amdgcn_sad_u16(a.w, bb[u].v[3], sum);
+            }
+          }
+        } else if (segw == 8) {
+          for (int sg = 0; sg < nsg; sg++) {
+            const int y = (sg / spr) * c.row_step, x = (sg % spr) << 3;
+            const uint4 a = *reinterpret_cast<const uint4 *>(s.orig + y * c.w + x);
+            const U16x8 bb = *reinterpret_cast<const U16x8 *>(r + (ptrdiff_t)y * c.rs + x);
+            sum = __builtin_amdgcn_sad_u16(a.x, bb.v[0], sum);
+            sum = __builtin_amdgcn_sad_u16(a.y, bb.v[1], sum);
+            sum = __builtin_amdgcn_sad_u16(a.z, bb.v[2], sum);
+            sum = __builtin_amdgcn_sad_u16(a.w, bb.v[3], sum);
+          }
+        } else {
+          for (int sg = 0; sg < nsg; sg++) {
+            const int y = sg * c.row_step;
+            const uint2 a = *reinterpret_cast<const uint2 *>(s.orig + y * 4);
+            const U16x4 bb = *reinterpret_cast<const U16x4 *>(r + (ptrdiff_t)y * c.rs);
+            sum = __builtin_amdgcn_sad_u16(a.x, bb.v[0], sum);
+            sum = __builtin_amdgcn_sad_u16(a.y, bb.v[1], sum);
+          }
+        }
+        const uint32_t cost = me_cost(c, (sum * c.sad_mul) >> c.sad_shift, gx, gy);
+        if (cost < best) { best = cost; best_i = i; }
+      }
+      // lowest cost, then lowest index (= the reference's raster-order fold)
+      const uint32_t gb = wave_min_key(best);
+      const int gi = (int)wave_min_key(best == gb ? (uint32_t)best_i : 0x7fffffffu);
+      if (gb < st.cost) {
+        st.cost = gb;
+        st.bx = fs_min_x + (gi % nx) * 5;
+        st.by = fs_min_y + (gi / nx) * 5;
+      }
+    }
+    // iterative refinement: all diamonds around the current best, one fold
+    while (st.last_range > 0) {
+      st.last_range = 0;
+      uint32_t k0, k1;
+      const int bx = st.bx, by = st.by;
+      me2_eval_diamonds(c, s, pat, bx, by, 0, total, k0, k1);
+      const uint32_t k = wave_min_key(k0 < k1 ? k0 : k1);
+      if (k != ME2_NOKEY && (k >> 7) < st.cost) {
+        int x, y, pos, rng;
+        me2_pattern_at(pat, (int)(k & 127), bx, by, x, y, pos, rng);
+        st.cost = k >> 7; st.bx = x; st.by = y; st.last_pos = pos; st.last_range = rng;
+      }
+      if (st.last_range == 1) { st.last_range = 0; neighbor(); }
+    }
+    res.fullpel_x = st.bx;
+    res.fullpel_y = st.by;
+    res.fullpel_cost = st.cost;
+  } else {
+    res.fullpel_x = results[bi].fullpel_x;
+    res.fullpel_y = results[bi].fullpel_y;
+    res.fullpel_cost = results[bi].fullpel_cost;
+  }
+  res.mv_x = res.fullpel_x * 16;
+  res.mv_y = res.fullpel_y * 16;
+  res.subpel_dist = 0;
+
+  if (flags & XVCGPU_ME_SUBPEL) {
+    const int w = c.w, h = c.h, ws = w + 16;
+    const int fpx = res.fullpel_x, fpy = res.fullpel_y;
+    // stage the reference window: rows -4..h+3, cols -8..w+7 around the
+    // full-pel position (16-byte unaligned global loads, aligned LDS stores)
+    {
+      wave_sync();
+      const uint16_t *r0 = pr.p + (ptrdiff_t)(b.y + fpy - 4) * pr.stride + b.x + fpx - 8;
+      const int cpr = ws >> 3;  // 8-sample chunks per row (ws is 12..80: w+16)
+      if ((ws & 7) == 0) {
+        const int nchunk = (h + 8) * cpr;
+        for (int i = lane; i < nchunk; i += 64) {
+          const int r = i / cpr, ch = i - r * cpr;
+          const U16x8 v = *reinterpret_cast<const U16x8 *>(r0 + (ptrdiff_t)r * pr.stride + ch * 8);
+          *reinterpret_cast<uint4 *>(s.win + r * ws + ch * 8) =
+              make_uint4(v.v[0], v.v[1], v.v[2], v.v[3]);
+        }
+      } else {  // w == 4: ws = 20
+        for (int i = lane; i < (h + 8) * ws; i += 64) {
+          const int r = i / ws, x = i - r * ws;
+          s.win[i] = r0[(ptrdiff_t)r * pr.stride + x];
+        }
+      }
+    }
+    if (b.fullpel_mv) {
+      me2_subpel_eval(s, c, b, pic_w, pic_h, fpx, fpy, -1, res.mv_x, res.mv_y);
+      res.subpel_dist = s.dist[0] >> (c.bd - 8);
+    } else {
+      uint32_t best_cost = 0xffffffffu, best_dist = 0xffffffffu;
+      int best_x = res.mv_x, best_y = res.mv_y;
+      for (int pass = 0; pass < 2; pass++) {
+        const int base_x = best_x, base_y = best_y;
+        const int n = 9 - pass;
+        me2_subpel_eval(s, c, b, pic_w, pic_h, fpx, fpy, pass, base_x, base_y);
+        for (int i = 0; i < n; i++) {
+          int mx, my;
+          me2_subpel_mv(pass, i, base_x, base_y, mx, my);
+          const uint32_t dist = s.dist[i] >> (c.bd - 8);
+          const uint32_t cost =
+              dist + ((c.lambda * d_mvd_bits(b.mvp_x, b.mvp_y, mx, my, 0)) >> 16);
+          if (cost < best_cost) {
+            best_cost = cost; best_dist = dist; best_x = mx; best_y = my;
+          }
+        }
+      }
+      res.mv_x = best_x;
+      res.mv_y = best_y;
+      res.subpel_dist = best_dist;
+    }
+  }
+  if (lane == 0) results[bi] = res;
+}
+
+#endif  // XVCGPU_K_ME2_H_

@@ -9,6 +9,7 @@
 
 #include "k_deblock.h"
 #include "k_me.h"
+#include "k_me2.h"
 #include "k_metric.h"
 #include "k_misc.h"
 #include "k_pad.h"
@@ -108,6 +109,7 @@ xvcgpu_status xvcgpu_create(int device, xvcgpu_ctx **out) {
   ctx->stream = nullptr;
   ctx->own_stream = false;
   ctx->d_tx_tables = nullptr;
+  ctx->d_tz_pattern = nullptr;
   if (hipSetDevice(device) != hipSuccess ||
       hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
     delete ctx;
@@ -123,6 +125,17 @@ xvcgpu_status xvcgpu_create(int device, xvcgpu_ctx **out) {
     xvcgpu_destroy(ctx);
     return XVCGPU_OUT_OF_MEMORY;
   }
+  {
+    TzCand pattern[TZ_MAX_CANDS];
+    const int np = tz_pattern_build(pattern);
+    if (np != TZ_MAX_CANDS ||
+        hipMalloc(&ctx->d_tz_pattern, sizeof(pattern)) != hipSuccess ||
+        hipMemcpy(ctx->d_tz_pattern, pattern, sizeof(pattern),
+                  hipMemcpyHostToDevice) != hipSuccess) {
+      xvcgpu_destroy(ctx);
+      return XVCGPU_OUT_OF_MEMORY;
+    }
+  }
   *out = ctx;
   return XVCGPU_OK;
 }
@@ -132,6 +145,7 @@ void xvcgpu_destroy(xvcgpu_ctx *ctx) {
   hipSetDevice(ctx->device);
   hipStreamSynchronize(ctx->stream);
   if (ctx->d_tx_tables) hipFree(ctx->d_tx_tables);
+  if (ctx->d_tz_pattern) hipFree(ctx->d_tz_pattern);
   hipEventDestroy(ctx->ev0);
   hipEventDestroy(ctx->ev1);
   if (ctx->own_stream && ctx->stream) hipStreamDestroy(ctx->stream);
@@ -383,20 +397,42 @@ xvcgpu_status xvcgpu_metric_batch(xvcgpu_ctx *ctx, const xvcgpu_picture *a,
   return XVCGPU_OK;
 }
 
-xvcgpu_status xvcgpu_me_search(xvcgpu_ctx *ctx, const xvcgpu_picture *orig,
-                               const xvcgpu_picture *ref, int flags,
-                               const xvcgpu_me_block *d_blocks, int n,
-                               xvcgpu_me_result *d_results) {
+static dim3 me2_grid(int n, int waves) {
+  const int n_wg = (n + waves - 1) / waves;
+  return dim3((n_wg + 7) / 8 * 8);
+}
+
+xvcgpu_status xvcgpu_me_search_sized(xvcgpu_ctx *ctx, const xvcgpu_picture *orig,
+                                     const xvcgpu_picture *ref, int flags,
+                                     const xvcgpu_me_block *d_blocks, int n,
+                                     xvcgpu_me_result *d_results,
+                                     int max_block_size) {
   if (!ctx || !orig || !ref || n < 0 || (n && (!d_blocks || !d_results)) ||
-      !(flags & (XVCGPU_ME_FULLPEL | XVCGPU_ME_SUBPEL)))
+      !(flags & (XVCGPU_ME_FULLPEL | XVCGPU_ME_SUBPEL)) || max_block_size < 4 ||
+      max_block_size > 64)
     return XVCGPU_INVALID_ARGUMENT;
   if (orig->w != ref->w || orig->h != ref->h || orig->bd != ref->bd)
     return fail(ctx, XVCGPU_INVALID_ARGUMENT, "picture mismatch");
   if (n == 0) return XVCGPU_OK;
-  hipLaunchKernelGGL(me_search_kernel, dim3(n), dim3(ME_THREADS), 0, ctx->stream,
-                     orig->v, ref->v, flags, d_blocks, n, d_results);
+  // one wave per job; the LDS footprint is a compile-time function of the
+  // block-size class, each class kernel skips the jobs of the other classes
+  hipLaunchKernelGGL(me_search_wave_kernel<16>, me2_grid(n, ME2_WAVES(16)), dim3(64 * ME2_WAVES(16)), 0, ctx->stream,
+                     orig->v, ref->v, flags, d_blocks, n, d_results, ctx->d_tz_pattern);
+  if (max_block_size > 16)
+    hipLaunchKernelGGL(me_search_wave_kernel<32>, me2_grid(n, ME2_WAVES(32)), dim3(64 * ME2_WAVES(32)), 0, ctx->stream,
+                       orig->v, ref->v, flags, d_blocks, n, d_results, ctx->d_tz_pattern);
+  if (max_block_size > 32)
+    hipLaunchKernelGGL(me_search_wave_kernel<64>, me2_grid(n, ME2_WAVES(64)), dim3(64 * ME2_WAVES(64)), 0, ctx->stream,
+                       orig->v, ref->v, flags, d_blocks, n, d_results, ctx->d_tz_pattern);
   CHECK_LAUNCH(ctx, "me_search");
   return XVCGPU_OK;
+}
+
+xvcgpu_status xvcgpu_me_search(xvcgpu_ctx *ctx, const xvcgpu_picture *orig,
+                               const xvcgpu_picture *ref, int flags,
+                               const xvcgpu_me_block *d_blocks, int n,
+                               xvcgpu_me_result *d_results) {
+  return xvcgpu_me_search_sized(ctx, orig, ref, flags, d_blocks, n, d_results, 64);
 }
 
 xvcgpu_status xvcgpu_mc_batch(xvcgpu_ctx *ctx, const xvcgpu_picture *ref,

@@ -9,6 +9,7 @@
 #include <string>
 
 #include "../../include/xvcgpu.h"
+#include "tz_pattern.h"
 
 // One plane of a device picture: `p` addresses sample (0,0); the replicated
 // border of `border` samples lies at negative / beyond-size coordinates.
@@ -32,6 +33,8 @@ struct xvcgpu_ctx {
   std::string err;
   // transform matrices [type 1..5][log2 size 1..6], device copy
   int16_t *d_tx_tables;
+  // TZ candidate pattern (tz_pattern.h), device copy
+  TzCand *d_tz_pattern;
 };
 
 struct xvcgpu_picture {

@@ -137,7 +137,7 @@ class FramePass:
         if n == 0:
             return
         ctx.me_search_dev(orig, ref, api.ME_FULLPEL | api.ME_SUBPEL, self.d_me.ptr,
-                          n, self.d_res.ptr)
+                          n, self.d_res.ptr, d.cu_size)
         ctx.mc_from_me_dev(ref, self.pred, self.d_me.ptr, self.d_res.ptr, n)
         ctx.residual_batch_dev(orig, self.pred, rec, self.d_tx.ptr, len(d.tx),
                                None, None, self.d_nnz.ptr)

@@ -36,8 +36,9 @@ def _tri(v, period):
 
 
 class SyntheticClip:
-    def __init__(self, width, height, bitdepth=10, seed=1234):
+    def __init__(self, width, height, bitdepth=10, seed=1234, square=True):
         self.w, self.h, self.bd = width, height, bitdepth
+        self.square = square
         H, W = height + 64, width + 128
         yy, xx = np.mgrid[0:H, 0:W].astype(np.int64)
         low = (_tri(xx * 3 + yy, 211) * 120) // 105 + (_tri(yy * 5 - xx, 157) * 60) // 78
@@ -52,7 +53,8 @@ class SyntheticClip:
         ox, oy = (2 * n) % 64, n % 64
         y = self.base[oy:oy + h, ox:ox + w].copy()
         sx, sy = (40 + 5 * n) % max(1, w - 32), (24 + 3 * n) % max(1, h - 32)
-        y[sy:sy + 32, sx:sx + 32] = 255 - y[sy:sy + 32, sx:sx + 32]
+        if self.square:
+            y[sy:sy + 32, sx:sx + 32] = 255 - y[sy:sy + 32, sx:sx + 32]
         nz = (_lcg_field(self.seed + 7919 * (n + 1), (h, w)) >> np.uint32(30)).astype(np.int64)
         y = np.clip(y + nz - 2 + (nz == 0), 0, 255)
         sub = (y[0::2, 0::2] + y[1::2, 0::2] + y[0::2, 1::2] + y[1::2, 1::2] + 2) >> 2
