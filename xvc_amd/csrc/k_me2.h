@@ -70,6 +70,13 @@ __device__ __forceinline__ uint32_t wave_min_key(uint32_t v) {
   return ab < cd ? ab : cd;
 }
 
+// Wave-wide integer sum, returned wave-uniform (all 64 lanes participate).
+__device__ __forceinline__ int wave_reduce_add_i32(int v) {
+  v = dpp_group_sum<16>(v);
+  return __builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16) +
+         __builtin_amdgcn_readlane(v, 32) + __builtin_amdgcn_readlane(v, 48);
+}
+
 #define ME2_NOKEY 0xffffffffu
 // independent jobs (waves) per workgroup, by block-size class (LDS budget)
 #define ME2_WAVES(MS) ((MS) > 32 ? 2 : 4)

@@ -113,16 +113,23 @@ __device__ __forceinline__ void tx_inv_dst4(int shift, const int16_t *in,
   }
 }
 
-// grid: n blocks; block: 256 threads.
+// Jobs taken by the one-wave-per-job kernel (k_tx2.h); the rest stay here.
+__device__ __forceinline__ bool tx_small_job(const xvcgpu_tx_block &b) {
+  const bool okw = b.w == 4 || b.w == 8 || b.w == 16;
+  const bool okh = b.h == 4 || b.h == 8 || b.h == 16;
+  return okw && okh && !(b.dst4x4 && b.w == 4 && b.h == 4);
+}
+
+// One workgroup (256 threads) = one job: the general path (blocks above
+// 16x16, 2-wide blocks, the 4x4 DST).
 template <int MODE>
-__global__ void __launch_bounds__(TX_THREADS)
-residual_kernel(PicView orig, PicView pred, PicView rec,
-                const xvcgpu_tx_block *blocks, int n, int16_t *levels,
-                const uint32_t *level_off, int32_t *nnz_out,
-                const int16_t *tx_tables, TxTableLayout lay) {
-  __shared__ __attribute__((aligned(16))) TxShared s;
-  const int bi = blockIdx.x;
-  if (bi >= n) return;
+__device__ __forceinline__ void residual_job(TxShared &s, int bi, const PicView &orig,
+                                             const PicView &pred, const PicView &rec,
+                                             const xvcgpu_tx_block *blocks,
+                                             int16_t *levels, const uint32_t *level_off,
+                                             int32_t *nnz_out, const int16_t *tx_tables,
+                                             const TxTableLayout &lay) {
+  __syncthreads();  // previous job of this workgroup is done with s
   const xvcgpu_tx_block b = blocks[bi];
   const int w = b.w, h = b.h, bd = pred.bd;
   const int lw = 31 - __clz(w);
@@ -264,6 +271,29 @@ residual_kernel(PicView orig, PicView pred, PicView rec,
     pr.p[(ptrdiff_t)(b.y + y) * pr.stride + b.x + x] =
         (uint16_t)d_clip3(p + (int)s.a[y * TX_S + x], 0, smax);
   }
+}
+
+// grid: ceil(n/256) workgroups of 256 threads.  Each workgroup scans 256
+// descriptors, collects the jobs that need the general path and runs them one
+// after the other (normally none: every job of a 16x16-CU picture is "small").
+template <int MODE>
+__global__ void __launch_bounds__(TX_THREADS)
+residual_kernel(PicView orig, PicView pred, PicView rec,
+                const xvcgpu_tx_block *blocks, int n, int16_t *levels,
+                const uint32_t *level_off, int32_t *nnz_out,
+                const int16_t *tx_tables, TxTableLayout lay) {
+  __shared__ __attribute__((aligned(16))) TxShared s;
+  __shared__ int jobs[TX_THREADS];
+  __shared__ int n_jobs;
+  if (threadIdx.x == 0) n_jobs = 0;
+  __syncthreads();
+  const int idx = blockIdx.x * TX_THREADS + threadIdx.x;
+  if (idx < n && !tx_small_job(blocks[idx])) jobs[atomicAdd(&n_jobs, 1)] = idx;
+  __syncthreads();
+  const int nj = n_jobs;
+  for (int k = 0; k < nj; k++)
+    residual_job<MODE>(s, jobs[k], orig, pred, rec, blocks, levels, level_off, nnz_out,
+                       tx_tables, lay);
 }
 
 #endif  // XVCGPU_K_TX_H_

@@ -1,0 +1,280 @@
+// k_tx2.h -- X1, Q (QuantFast), Q1, X2, R1 for blocks up to 16x16, throughput
+// form: ONE WAVEFRONT per TransformAndReconstruct call
+// (transform_encoder.cc:203-285); a 1080p picture has 24480 of them (8160
+// luma 16x16 + 16320 chroma 8x8), all independent.
+//
+// Every 1-D pass of the reference is `out = (M x in + add) >> shift` read as a
+// transposing matrix product.  Here all four passes have
+// the same "NT" shape  out[a][b] = sum_j A[a][j] * B[b][j]  with both operands
+// contiguous in j, so a lane loads one row of A and OPL rows of B as 16-byte
+// vectors and accumulates with v_dot2_i32_i16 (two int16 MACs, int32 wrap-
+// around = the reference's int32 accumulation):
+//   fwd 1  T[k][y]   = sum_j Mh[k][j]  * R[y][j]     (R = orig - pred)
+//   fwd 2  C[x][k2]  = sum_j T[x][j]   * Mv[k2][j]   (coefficients, transposed)
+//   inv 1  U[r][x]   = sum_j MvT[r][j] * C[x][j]     (after quant + dequant)
+//   inv 2  res[y][c] = sum_j U[y][j]   * MhT[c][j]   -> AddClip -> rec
+// Matrices (both orientations) are read from the device tables through L1;
+// the three 512-byte block buffers per wave live in LDS.  No workgroup
+// barrier: jobs never share data across waves.
+#ifndef XVCGPU_K_TX2_H_
+#define XVCGPU_K_TX2_H_
+
+#include "dev_common.h"
+#include "dev_tables.h"
+#include "k_me.h"
+#include "k_me2.h"
+#include "k_tx.h"
+#include "xvcgpu_internal.h"
+
+#define TX2_WAVES 4
+
+typedef short tx2_v2s __attribute__((ext_vector_type(2)));
+
+struct __attribute__((aligned(16))) Tx2Shared {
+  int16_t r[256];  // R, later U
+  int16_t t[256];  // T
+  int16_t c[256];  // C (transposed coefficients / levels / dequantised)
+};
+
+__device__ __forceinline__ int tx2_dot2(uint32_t a, uint32_t b, int acc) {
+  return __builtin_amdgcn_sdot2(__builtin_bit_cast(tx2_v2s, a),
+                                __builtin_bit_cast(tx2_v2s, b), acc, false);
+}
+
+// Load a row of NJ int16 (NJ in {4,8,16}) as NJ/2 packed dwords.
+template <int NJ>
+__device__ __forceinline__ void tx2_load_row(const int16_t *p, uint32_t *d) {
+  if (NJ == 4) {
+    const uint2 v = *reinterpret_cast<const uint2 *>(p);
+    d[0] = v.x; d[1] = v.y;
+  } else {
+#pragma unroll
+    for (int q = 0; q < NJ / 8; q++) {
+      const uint4 v = *reinterpret_cast<const uint4 *>(p + 8 * q);
+      d[4 * q] = v.x; d[4 * q + 1] = v.y; d[4 * q + 2] = v.z; d[4 * q + 3] = v.w;
+    }
+  }
+}
+
+// out[a][b] = f((sum_j A[a][j]*B[b][j] + add) >> shift), a < na, b < nb;
+// rows of A / B / out are contiguous (strides NJ, NJ, nb).  OPL outputs/lane.
+template <int NJ, int OPL, bool CLIP>
+__device__ __forceinline__ void tx2_stage(const int16_t *A, const int16_t *B,
+                                          int na, int nb, int add, int shift,
+                                          int16_t *out) {
+  const int lane = ME2_LANE;
+  const int gb = nb / OPL;
+  const int a = lane / gb, b0 = (lane - a * gb) * OPL;
+  if (a >= na) return;
+  uint32_t ra[NJ / 2];
+  tx2_load_row<NJ>(A + a * NJ, ra);
+  int16_t res[OPL];
+#pragma unroll
+  for (int o = 0; o < OPL; o++) {
+    uint32_t rb[NJ / 2];
+    tx2_load_row<NJ>(B + (b0 + o) * NJ, rb);
+    int acc = add;
+#pragma unroll
+    for (int j = 0; j < NJ / 2; j++) acc = tx2_dot2(ra[j], rb[j], acc);
+    int v = acc >> shift;
+    if (CLIP) v = d_clip3(v, -32768, 32767);
+    res[o] = (int16_t)v;
+  }
+  int16_t *dst = out + a * nb + b0;
+  if (OPL == 4) {
+    *reinterpret_cast<uint2 *>(dst) =
+        make_uint2((uint16_t)res[0] | ((uint32_t)(uint16_t)res[1] << 16),
+                   (uint16_t)res[2 % OPL] | ((uint32_t)(uint16_t)res[3 % OPL] << 16));
+  } else if (OPL == 2) {
+    *reinterpret_cast<uint32_t *>(dst) =
+        (uint16_t)res[0] | ((uint32_t)(uint16_t)res[1 % OPL] << 16);
+  } else {
+    dst[0] = res[0];
+  }
+}
+
+template <bool CLIP>
+__device__ __forceinline__ void tx2_stage_dispatch(int nj, const int16_t *A,
+                                                   const int16_t *B, int na, int nb,
+                                                   int add, int shift, int16_t *out) {
+  // outputs per lane so that na*nb/OPL <= 64 lanes
+  const int total = na * nb;
+  if (nj == 16) {
+    if (total > 128) tx2_stage<16, 4, CLIP>(A, B, na, nb, add, shift, out);
+    else if (total > 64) tx2_stage<16, 2, CLIP>(A, B, na, nb, add, shift, out);
+    else tx2_stage<16, 1, CLIP>(A, B, na, nb, add, shift, out);
+  } else if (nj == 8) {
+    if (total > 128) tx2_stage<8, 4, CLIP>(A, B, na, nb, add, shift, out);
+    else if (total > 64) tx2_stage<8, 2, CLIP>(A, B, na, nb, add, shift, out);
+    else tx2_stage<8, 1, CLIP>(A, B, na, nb, add, shift, out);
+  } else {
+    if (total > 128) tx2_stage<4, 4, CLIP>(A, B, na, nb, add, shift, out);
+    else if (total > 64) tx2_stage<4, 2, CLIP>(A, B, na, nb, add, shift, out);
+    else tx2_stage<4, 1, CLIP>(A, B, na, nb, add, shift, out);
+  }
+}
+
+// grid: XCD-swizzled workgroups of TX2_WAVES waves; one job per wave.
+// tx_tables_t: the same matrices transposed (same layout offsets).
+template <int MODE>
+__global__ void __launch_bounds__(64 * TX2_WAVES)
+residual_wave_kernel(PicView orig, PicView pred, PicView rec,
+                     const xvcgpu_tx_block *blocks, int n, int16_t *levels,
+                     const uint32_t *level_off, int32_t *nnz_out,
+                     const int16_t *tx_tables, const int16_t *tx_tables_t,
+                     TxTableLayout lay) {
+  __shared__ Tx2Shared s_all[TX2_WAVES];
+  Tx2Shared &s = s_all[threadIdx.x >> 6];
+  const int n_wg = (n + TX2_WAVES - 1) / TX2_WAVES;
+  const int wg = xcd_job_index(blockIdx.x, n_wg);
+  if (wg < 0) return;
+  const int bi = wg * TX2_WAVES + (int)(threadIdx.x >> 6);
+  if (bi >= n) return;
+  const xvcgpu_tx_block b = blocks[bi];
+  if (!tx_small_job(b)) return;  // general path: residual_kernel<>
+  const int lane = ME2_LANE;
+  const int w = b.w, h = b.h, bd = pred.bd;
+  const int lw = 31 - __clz(w);
+  const int lgw = d_log2_size(w), lgh = d_log2_size(h);
+  const PlaneView pp = pred.c[b.comp], pr = rec.c[b.comp];
+  int16_t *lv = (levels && level_off) ? levels + level_off[bi] : nullptr;
+  const int offh = tx_table_off(lay, b.tx_hor, w), offv = tx_table_off(lay, b.tx_ver, h);
+  const int16_t *Mh = tx_tables + offh, *Mv = tx_tables + offv;
+  const int16_t *MhT = tx_tables_t + offh, *MvT = tx_tables_t + offv;
+
+  int qpb = b.qp + 6 * (bd - 8);
+  qpb = qpb > 0 ? qpb : 0;
+  const bool bias = ((lgw + lgh) & 1) != 0;
+  const int tshift = 15 - bd - ((lgw + lgh) >> 1);
+  const int n_el = w * h;
+
+  int nnz;
+  if (MODE != TX_MODE_INV) {
+    const PlaneView po = orig.c[b.comp];
+    // residual, 4 samples per lane along a row
+    for (int i = lane * 4; i < n_el; i += 256) {
+      const int y = i >> lw, x = i & (w - 1);
+      const U16x4 o = *reinterpret_cast<const U16x4 *>(
+          po.p + (ptrdiff_t)(b.y + y) * po.stride + b.x + x);
+      const U16x4 p = *reinterpret_cast<const U16x4 *>(
+          pp.p + (ptrdiff_t)(b.y + y) * pp.stride + b.x + x);
+      const int d0 = (int)(o.v[0] & 0xffff) - (int)(p.v[0] & 0xffff);
+      const int d1 = (int)(o.v[0] >> 16) - (int)(p.v[0] >> 16);
+      const int d2 = (int)(o.v[1] & 0xffff) - (int)(p.v[1] & 0xffff);
+      const int d3 = (int)(o.v[1] >> 16) - (int)(p.v[1] >> 16);
+      *reinterpret_cast<uint2 *>(s.r + i) =
+          make_uint2((uint32_t)(d0 & 0xffff) | ((uint32_t)d1 << 16),
+                     (uint32_t)(d2 & 0xffff) | ((uint32_t)d3 << 16));
+    }
+    wave_sync();
+    const int shift1 = lgw + bd - 9 + 2, shift2 = lgh + 6 + 2;
+    // fwd 1: T[k][y] (w rows of h), fwd 2: C[x][k2] (w rows of h)
+    tx2_stage_dispatch<false>(w, Mh, s.r, w, h, 1 << (shift1 - 1), shift1, s.t);
+    wave_sync();
+    tx2_stage_dispatch<false>(h, s.t, Mv, w, h, 1 << (shift2 - 1), shift2, s.c);
+    wave_sync();
+    if (MODE == TX_MODE_FWD) {
+      if (lv)
+        for (int i = lane; i < n_el; i += 64) {
+          const int x = i / h, k2 = i - x * h;  // C[x][k2]
+          lv[k2 * w + x] = s.c[i];
+        }
+      return;
+    }
+    // QuantFast (rdo_quant.cc:156-195) on C, in place
+    const int qshift = 14 + qpb / 6 + tshift + (bias ? 7 : 0);
+    const int qscale = kFwdQuantScales[qpb % 6] * (bias ? 181 : 1);
+    const long long qoff = (long long)((b.intra_pic ? 171ull : 85ull) << (qshift - 9));
+    int local = 0;
+    for (int i = lane; i < n_el; i += 64) {
+      const int v = s.c[i];
+      const int sign = v < 0 ? -1 : 1;
+      const long long abs_coeff = d_abs(v);
+      const int level = (int)(((abs_coeff * qscale) + qoff) >> qshift);
+      local += level != 0;
+      const int16_t q = (int16_t)d_clip3(level * sign, -32768, 32767);
+      s.c[i] = q;
+      if (lv) {
+        const int x = i / h, k2 = i - x * h;
+        lv[k2 * w + x] = q;
+      }
+    }
+    nnz = wave_reduce_add_i32(local);
+    if (nnz_out && lane == 0) nnz_out[bi] = nnz;
+  } else {
+    nnz = nnz_out[bi];
+    if (nnz)
+      for (int i = lane; i < n_el; i += 64) {
+        const int x = i / h, k2 = i - x * h;
+        s.c[i] = lv[k2 * w + x];
+      }
+  }
+  wave_sync();
+
+  if (nnz == 0) {  // cbf == 0: rec = pred
+    for (int i = lane * 4; i < n_el; i += 256) {
+      const int y = i >> lw, x = i & (w - 1);
+      const U16x4 p = *reinterpret_cast<const U16x4 *>(
+          pp.p + (ptrdiff_t)(b.y + y) * pp.stride + b.x + x);
+      *reinterpret_cast<U16x4 *>(pr.p + (ptrdiff_t)(b.y + y) * pr.stride + b.x + x) = p;
+    }
+    return;
+  }
+  const bool dc_only = nnz == 1 && s.c[0] != 0;
+  wave_sync();
+  // Quantize::Inverse (quantize.cc:94-125), in place
+  {
+    const int shift = 6 - tshift + (bias ? 8 : 0);
+    const int scale = (kInvQuantScales[qpb % 6] << (qpb / 6)) * (bias ? 181 : 1);
+    for (int i = lane; i < n_el; i += 64) {
+      const int prod = (int)s.c[i] * scale;
+      int cf;
+      if (shift > 0) cf = (prod + (1 << (shift - 1))) >> shift;
+      else cf = (int)((unsigned)prod << -shift);
+      s.c[i] = (int16_t)d_clip3(cf, -32768, 32767);
+    }
+  }
+  wave_sync();
+  const int smax = (1 << bd) - 1;
+  const bool dct2_both = (b.tx_ver == XVC_TX_DEFAULT || b.tx_ver == XVC_TX_DCT2) &&
+                         (b.tx_hor == XVC_TX_DEFAULT || b.tx_hor == XVC_TX_DCT2);
+  if (dc_only && dct2_both) {  // InvDct2Dc, transform.cc:279-291
+    const int sh = 14 - bd, add = 1 << (sh - 1);
+    const int cf = (int16_t)(((((int)s.c[0] + 1) >> 1) + add) >> sh);
+    for (int i = lane * 4; i < n_el; i += 256) {
+      const int y = i >> lw, x = i & (w - 1);
+      const U16x4 p = *reinterpret_cast<const U16x4 *>(
+          pp.p + (ptrdiff_t)(b.y + y) * pp.stride + b.x + x);
+      U16x4 o;
+      o.v[0] = (uint32_t)d_clip3((int)(p.v[0] & 0xffff) + cf, 0, smax) |
+               ((uint32_t)d_clip3((int)(p.v[0] >> 16) + cf, 0, smax) << 16);
+      o.v[1] = (uint32_t)d_clip3((int)(p.v[1] & 0xffff) + cf, 0, smax) |
+               ((uint32_t)d_clip3((int)(p.v[1] >> 16) + cf, 0, smax) << 16);
+      *reinterpret_cast<U16x4 *>(pr.p + (ptrdiff_t)(b.y + y) * pr.stride + b.x + x) = o;
+    }
+    return;
+  }
+  // inverse: U[r][x] (h rows of w) into s.r, then residual rows into s.t
+  {
+    const int shift1 = 7 + 2, shift2 = 20 - bd + 2;
+    tx2_stage_dispatch<true>(h, MvT, s.c, h, w, 1 << (shift1 - 1), shift1, s.r);
+    wave_sync();
+    tx2_stage_dispatch<true>(w, s.r, MhT, h, w, 1 << (shift2 - 1), shift2, s.t);
+    wave_sync();
+  }
+  // SampleBuffer::AddClip
+  for (int i = lane * 4; i < n_el; i += 256) {
+    const int y = i >> lw, x = i & (w - 1);
+    const U16x4 p = *reinterpret_cast<const U16x4 *>(
+        pp.p + (ptrdiff_t)(b.y + y) * pp.stride + b.x + x);
+    const uint2 rs = *reinterpret_cast<const uint2 *>(s.t + i);
+    U16x4 o;
+    o.v[0] = (uint32_t)d_clip3((int)(p.v[0] & 0xffff) + (int)(int16_t)(rs.x & 0xffff), 0, smax) |
+             ((uint32_t)d_clip3((int)(p.v[0] >> 16) + ((int)rs.x >> 16), 0, smax) << 16);
+    o.v[1] = (uint32_t)d_clip3((int)(p.v[1] & 0xffff) + (int)(int16_t)(rs.y & 0xffff), 0, smax) |
+             ((uint32_t)d_clip3((int)(p.v[1] >> 16) + ((int)rs.y >> 16), 0, smax) << 16);
+    *reinterpret_cast<U16x4 *>(pr.p + (ptrdiff_t)(b.y + y) * pr.stride + b.x + x) = o;
+  }
+}
+
+#endif  // XVCGPU_K_TX2_H_

@@ -14,6 +14,7 @@
 #include "k_misc.h"
 #include "k_pad.h"
 #include "k_tx.h"
+#include "k_tx2.h"
 #include "xvcgpu_internal.h"
 
 namespace {
@@ -87,6 +88,22 @@ void init_views(xvcgpu_picture *p) {
   p->v.bd = p->bd;
 }
 
+// Both residual kernels over one batch: the one-wave-per-job kernel takes the
+// blocks up to 16x16, the scanning general-path kernel the rest.
+template <int MODE>
+void launch_residual(xvcgpu_ctx *ctx, const PicView &o, const PicView &p,
+                            const PicView &r, const xvcgpu_tx_block *d_blocks, int n,
+                            int16_t *d_levels, const uint32_t *d_off, int32_t *d_nnz) {
+  const int n_wg = (n + TX2_WAVES - 1) / TX2_WAVES;
+  hipLaunchKernelGGL(residual_wave_kernel<MODE>, dim3((n_wg + 7) / 8 * 8),
+                     dim3(64 * TX2_WAVES), 0, ctx->stream, o, p, r, d_blocks, n,
+                     d_levels, d_off, d_nnz, ctx->d_tx_tables, ctx->d_tx_tables_t,
+                     xvcgpu_tx_layout());
+  hipLaunchKernelGGL(residual_kernel<MODE>, dim3((n + TX_THREADS - 1) / TX_THREADS),
+                     dim3(TX_THREADS), 0, ctx->stream, o, p, r, d_blocks, n, d_levels,
+                     d_off, d_nnz, ctx->d_tx_tables, xvcgpu_tx_layout());
+}
+
 }  // namespace
 
 extern "C" {
@@ -109,6 +126,7 @@ xvcgpu_status xvcgpu_create(int device, xvcgpu_ctx **out) {
   ctx->stream = nullptr;
   ctx->own_stream = false;
   ctx->d_tx_tables = nullptr;
+  ctx->d_tx_tables_t = nullptr;
   ctx->d_tz_pattern = nullptr;
   if (hipSetDevice(device) != hipSuccess ||
       hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
@@ -121,6 +139,9 @@ xvcgpu_status xvcgpu_create(int device, xvcgpu_ctx **out) {
   const TxTableLayout &lay = xvcgpu_tx_layout();
   if (hipMalloc(&ctx->d_tx_tables, lay.total * sizeof(int16_t)) != hipSuccess ||
       hipMemcpy(ctx->d_tx_tables, xvcgpu_tx_host_tables(),
+                lay.total * sizeof(int16_t), hipMemcpyHostToDevice) != hipSuccess ||
+      hipMalloc(&ctx->d_tx_tables_t, lay.total * sizeof(int16_t)) != hipSuccess ||
+      hipMemcpy(ctx->d_tx_tables_t, xvcgpu_tx_host_tables_t(),
                 lay.total * sizeof(int16_t), hipMemcpyHostToDevice) != hipSuccess) {
     xvcgpu_destroy(ctx);
     return XVCGPU_OUT_OF_MEMORY;
@@ -145,6 +166,7 @@ void xvcgpu_destroy(xvcgpu_ctx *ctx) {
   hipSetDevice(ctx->device);
   hipStreamSynchronize(ctx->stream);
   if (ctx->d_tx_tables) hipFree(ctx->d_tx_tables);
+  if (ctx->d_tx_tables_t) hipFree(ctx->d_tx_tables_t);
   if (ctx->d_tz_pattern) hipFree(ctx->d_tz_pattern);
   hipEventDestroy(ctx->ev0);
   hipEventDestroy(ctx->ev1);
@@ -491,9 +513,8 @@ xvcgpu_status xvcgpu_residual_batch(xvcgpu_ctx *ctx, const xvcgpu_picture *orig,
   if (!ctx || !orig || !pred || !rec || n < 0 || (n && !d_blocks))
     return XVCGPU_INVALID_ARGUMENT;
   if (n == 0) return XVCGPU_OK;
-  hipLaunchKernelGGL(residual_kernel<TX_MODE_FULL>, dim3(n), dim3(TX_THREADS), 0,
-                     ctx->stream, orig->v, pred->v, rec->v, d_blocks, n, d_levels,
-                     d_level_offsets, d_nnz, ctx->d_tx_tables, xvcgpu_tx_layout());
+  launch_residual<TX_MODE_FULL>(ctx, orig->v, pred->v, rec->v, d_blocks, n, d_levels,
+                                d_level_offsets, d_nnz);
   CHECK_LAUNCH(ctx, "residual_batch");
   return XVCGPU_OK;
 }
@@ -508,10 +529,8 @@ xvcgpu_status xvcgpu_fwd_transform_batch(xvcgpu_ctx *ctx,
       (n && (!d_blocks || !d_coeffs || !d_coeff_offsets)))
     return XVCGPU_INVALID_ARGUMENT;
   if (n == 0) return XVCGPU_OK;
-  hipLaunchKernelGGL(residual_kernel<TX_MODE_FWD>, dim3(n), dim3(TX_THREADS), 0,
-                     ctx->stream, orig->v, pred->v, pred->v, d_blocks, n, d_coeffs,
-                     d_coeff_offsets, (int32_t *)nullptr, ctx->d_tx_tables,
-                     xvcgpu_tx_layout());
+  launch_residual<TX_MODE_FWD>(ctx, orig->v, pred->v, pred->v, d_blocks, n, d_coeffs,
+                               d_coeff_offsets, (int32_t *)nullptr);
   CHECK_LAUNCH(ctx, "fwd_transform_batch");
   return XVCGPU_OK;
 }
@@ -527,11 +546,9 @@ xvcgpu_status xvcgpu_inv_transform_batch(xvcgpu_ctx *ctx,
       (n && (!d_blocks || !d_levels || !d_level_offsets || !d_nnz)))
     return XVCGPU_INVALID_ARGUMENT;
   if (n == 0) return XVCGPU_OK;
-  hipLaunchKernelGGL(residual_kernel<TX_MODE_INV>, dim3(n), dim3(TX_THREADS), 0,
-                     ctx->stream, pred->v, pred->v, rec->v, d_blocks, n,
-                     const_cast<int16_t *>(d_levels), d_level_offsets,
-                     const_cast<int32_t *>(d_nnz), ctx->d_tx_tables,
-                     xvcgpu_tx_layout());
+  launch_residual<TX_MODE_INV>(ctx, pred->v, pred->v, rec->v, d_blocks, n,
+                               const_cast<int16_t *>(d_levels), d_level_offsets,
+                               const_cast<int32_t *>(d_nnz));
   CHECK_LAUNCH(ctx, "inv_transform_batch");
   return XVCGPU_OK;
 }

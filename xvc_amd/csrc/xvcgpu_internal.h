@@ -33,6 +33,7 @@ struct xvcgpu_ctx {
   std::string err;
   // transform matrices [type 1..5][log2 size 1..6], device copy
   int16_t *d_tx_tables;
+  int16_t *d_tx_tables_t;  // transposed
   // TZ candidate pattern (tz_pattern.h), device copy
   TzCand *d_tz_pattern;
 };
@@ -53,6 +54,7 @@ struct TxTableLayout {
   int total;
 };
 const TxTableLayout &xvcgpu_tx_layout();
-const int16_t *xvcgpu_tx_host_tables();  // packed host copy
+const int16_t *xvcgpu_tx_host_tables();    // packed host copy, M[k][n]
+const int16_t *xvcgpu_tx_host_tables_t();  // same layout, transposed
 
 #endif  // XVCGPU_INTERNAL_H_

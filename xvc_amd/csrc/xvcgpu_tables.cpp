@@ -16,7 +16,8 @@ namespace {
 
 struct Tables {
   TxTableLayout layout;
-  std::vector<int16_t> data;
+  std::vector<int16_t> data;    // M[k][n], row-major
+  std::vector<int16_t> data_t;  // transposed: M[n][k]
   Tables() {
     memset(&layout, 0xff, sizeof(layout));
     const double pi = 3.14159265358979323846;
@@ -25,6 +26,7 @@ struct Tables {
       for (int l = 1; l <= 6; l++) {
         const int N = 1 << l;
         if (N == 2 && t != XVC_TX_DCT2) continue;
+        total = (total + 7) & ~7;  // 16-byte aligned rows for vector loads
         layout.off[t - 1][l] = total;
         data.resize(total + N * N);
         int16_t *m = &data[total];
@@ -61,6 +63,15 @@ struct Tables {
       }
     }
     layout.total = total;
+    data_t.assign(data.size(), 0);
+    for (int t = 0; t < 5; t++)
+      for (int l = 1; l <= 6; l++) {
+        const int off = layout.off[t][l];
+        if (off < 0) continue;
+        const int N = 1 << l;
+        for (int k = 0; k < N; k++)
+          for (int n = 0; n < N; n++) data_t[off + n * N + k] = data[off + k * N + n];
+      }
   }
 };
 
@@ -73,6 +84,7 @@ const Tables &tables() {
 
 const TxTableLayout &xvcgpu_tx_layout() { return tables().layout; }
 const int16_t *xvcgpu_tx_host_tables() { return tables().data.data(); }
+const int16_t *xvcgpu_tx_host_tables_t() { return tables().data_t.data(); }
 
 extern "C" xvcgpu_status xvcgpu_get_transform_matrix(int tx_type, int size,
                                                      int16_t *out) {
