@@ -180,11 +180,10 @@ def main():
         times = {
             "me_search": timed(lambda: ctx.me_search_dev(
                 o, ref, api.ME_FULLPEL | api.ME_SUBPEL, fp.d_me.ptr, d.n_cus,
-                fp.d_res.ptr)),
-            "mc_from_me": timed(lambda: ctx.mc_from_me_dev(
-                ref, fp.pred, fp.d_me.ptr, fp.d_res.ptr, d.n_cus)),
-            "residual": timed(lambda: ctx.residual_batch_dev(
-                o, fp.pred, rec, fp.d_tx.ptr, len(d.tx), None, None, fp.d_nnz.ptr)),
+                fp.d_res.ptr, d.cu_size)),
+            "recon_from_me": timed(lambda: ctx.recon_from_me_dev(
+                o, ref, rec, fp.d_me.ptr, fp.d_res.ptr, d.n_cus, d.qp, d.qp_c, 0,
+                fp.d_nnz.ptr, fp.d_cus_own)),
             "deblock": timed(lambda: ctx.deblock_dev(
                 rec, fp.d_cus.ptr, d.n_cus_total, fp.d_map.ptr, d.cu_map.shape[1])),
             "pad_border": timed(lambda: ctx.pad_border(rec)),
@@ -198,8 +197,8 @@ def main():
         alg = {
             # each plane read once: original + reference luma of the CUs
             "me_search": 2 * n_luma * S,
-            "mc_from_me": 2 * int(1.5 * n_luma) * S,
-            "residual": 3 * int(1.5 * n_luma) * S,
+            # orig + reference read, reconstruction written, all three planes
+            "recon_from_me": 3 * int(1.5 * n_luma) * S,
             "deblock": 2 * int(1.5 * n_luma) * S + 16 * (n_luma // 16),
             "pad_border": 2 * 80 * (W + H + 160) * S * 2,
             "picture_ssd": 2 * n_luma * S,

@@ -204,6 +204,21 @@ xvcgpu_status xvcgpu_residual_batch(xvcgpu_ctx *ctx, const xvcgpu_picture *orig,
                                     int16_t *d_levels,
                                     const uint32_t *d_level_offsets,
                                     int32_t *d_nnz);
+/* I1 + the above fused, for the uni-pred inter CUs of a motion search batch
+ * (InterSearch::CompressAndEvalCbf without the RD bookkeeping,
+ * inter_search.cc:261-365): for CU i and each component, motion-compensate
+ * with d_results[i].mv_*, run TransformAndReconstruct (DCT-2, QuantFast) into
+ * `rec`, store the non-zero count at d_nnz[3*i + comp] and - when d_cus is
+ * given - CU i's deblocking metadata at d_cus[i].  The prediction stays in
+ * LDS.  CUs up to 16x16 with both dimensions >= 8 (else use xvcgpu_mc_from_me
+ * + xvcgpu_residual_batch + xvcgpu_cu_info_from_me, which compute the same). */
+xvcgpu_status xvcgpu_recon_from_me(xvcgpu_ctx *ctx, const xvcgpu_picture *orig,
+                                   const xvcgpu_picture *ref, xvcgpu_picture *rec,
+                                   const xvcgpu_me_block *d_blocks,
+                                   const xvcgpu_me_result *d_results, int n,
+                                   int qp_y, int qp_c, int intra_pic, int ref_poc,
+                                   int32_t *d_nnz, xvcgpu_cu_info *d_cus);
+
 /* X1 only: coefficients of (orig - pred) for a host-side quantiser (RDOQ stays
  * on the host). Output layout as d_levels. */
 xvcgpu_status xvcgpu_fwd_transform_batch(xvcgpu_ctx *ctx,

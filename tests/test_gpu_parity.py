@@ -464,8 +464,9 @@ def pad_planes(planes, bd):
             for c, p in enumerate(planes)]
 
 
+@pytest.mark.parametrize("fused", [True, False])
 @pytest.mark.parametrize("size", [(352, 288), (136, 72)])
-def test_frame_pass(gpu, xo, size):
+def test_frame_pass(gpu, xo, size, fused):
     """Whole frame pass (ME -> MC -> residual -> deblock -> pad -> SSD) on the
     GPU against the oracle's frame pass, two chained frames."""
     api, ctx = gpu
@@ -474,7 +475,7 @@ def test_frame_pass(gpu, xo, size):
     pw, ph = size
     bd = 10
     clip = synth.SyntheticClip(pw, ph, bd)
-    fp = pipeline.FramePass(ctx, pw, ph, bd, qp=32)
+    fp = pipeline.FramePass(ctx, pw, ph, bd, qp=32, fused=fused)
     ref_host = pad_planes(clip.frame(0), bd)
     O, R, Rec = ctx.picture(pw, ph, bd), ctx.picture(pw, ph, bd), ctx.picture(pw, ph, bd)
     R.upload(ref_host, BL)

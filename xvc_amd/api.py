@@ -58,7 +58,7 @@ SYMBOLS = [
     "xvcgpu_picture_download_padded", "xvcgpu_picture_plane",
     "xvcgpu_picture_copy", "xvcgpu_pad_border", "xvcgpu_metric_batch",
     "xvcgpu_me_search", "xvcgpu_me_search_sized", "xvcgpu_mc_batch", "xvcgpu_mc_from_me",
-    "xvcgpu_cu_info_from_me", "xvcgpu_residual_batch",
+    "xvcgpu_cu_info_from_me", "xvcgpu_recon_from_me", "xvcgpu_residual_batch",
     "xvcgpu_fwd_transform_batch", "xvcgpu_inv_transform_batch",
     "xvcgpu_deblock", "xvcgpu_deblock_rows", "xvcgpu_picture_ssd", "xvcgpu_get_transform_matrix",
 ]
@@ -129,6 +129,8 @@ def load_library():
         "xvcgpu_mc_from_me": [_vp, _vp, _vp, _vp, _vp, C.c_int],
         "xvcgpu_cu_info_from_me": [_vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int,
                                    C.c_int, C.c_int, _vp],
+        "xvcgpu_recon_from_me": [_vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int,
+                                 C.c_int, C.c_int, _vp, _vp],
         "xvcgpu_residual_batch": [_vp, _vp, _vp, _vp, _vp, C.c_int, _vp, _vp, _vp],
         "xvcgpu_fwd_transform_batch": [_vp, _vp, _vp, _vp, C.c_int, _vp, _vp],
         "xvcgpu_inv_transform_batch": [_vp, _vp, _vp, _vp, C.c_int, _vp, _vp, _vp],
@@ -329,6 +331,12 @@ class Context:
         self._check(self.lib.xvcgpu_cu_info_from_me(
             self.h, d_blocks, d_results, d_nnz, d_luma_idx, n, qp_y, qp_c, ref_poc,
             d_cus))
+
+    def recon_from_me_dev(self, orig, ref, rec, d_blocks, d_results, n, qp_y, qp_c,
+                          ref_poc, d_nnz, d_cus, intra_pic=0):
+        self._check(self.lib.xvcgpu_recon_from_me(
+            self.h, orig.h_pic, ref.h_pic, rec.h_pic, d_blocks, d_results, n, qp_y,
+            qp_c, intra_pic, ref_poc, d_nnz, d_cus))
 
     def residual_batch_dev(self, orig, pred, rec, d_blocks, n, d_levels=None,
                            d_offsets=None, d_nnz=None):

@@ -1,0 +1,159 @@
+// k_recon.h -- I1 + X1 + Q + Q1 + X2 + R1 fused per (CU, component): what
+// InterSearch::CompressAndEvalCbf does for a uni-pred CU once the MV is known
+// (inter_search.cc:261-365: MotionCompensation, then
+// TransformEncoder::TransformAndReconstruct, transform_encoder.cc:203-285),
+// with the MV taken from the motion-search result still resident in HBM.
+// One wave per (CU, component); the prediction never leaves LDS, and the luma
+// wave also stores the CU's deblocking metadata (what CuEncoder writes into
+// CodingUnit, cu_encoder.cc:543-577).  CUs up to 16x16 (chroma >= 4x4).
+#ifndef XVCGPU_K_RECON_H_
+#define XVCGPU_K_RECON_H_
+
+#include "dev_common.h"
+#include "dev_tables.h"
+#include "k_me2.h"
+#include "k_tx2.h"
+#include "xvcgpu_internal.h"
+
+struct __attribute__((aligned(16))) ReconShared {
+  Tx2Shared tx;
+  uint16_t pred[256];
+  int16_t tmp[16 * 23];
+};
+
+// MotionCompUniPred -> Sample by one wave (same arithmetic as wg_interp_block
+// in k_interp.h; inter_prediction.cc:1138-1154, :1207-1448).
+template <bool CHROMA>
+__device__ __forceinline__ void wave_interp_block(int bd, int w, int h, int fx,
+                                                  int fy, const uint16_t *ref, int rs,
+                                                  int16_t *tmp, uint16_t *dst) {
+  constexpr int N = CHROMA ? 4 : 8;
+  constexpr int BACK = N / 2 - 1;
+  const int lane = ME2_LANE;
+  const int smax = (1 << bd) - 1;
+  const int lw = 31 - __clz(w);
+  const int16_t *fh = CHROMA ? kChromaTaps[fx] : kLumaTaps[fx];
+  const int16_t *fv = CHROMA ? kChromaTaps[fy] : kLumaTaps[fy];
+  if (fx == 0 && fy == 0) {
+    for (int i = lane; i < w * h; i += 64)
+      dst[i] = ref[(ptrdiff_t)(i >> lw) * rs + (i & (w - 1))];
+    return;
+  }
+  if (fy == 0) {
+    for (int i = lane; i < w * h; i += 64) {
+      const uint16_t *s = ref + (ptrdiff_t)(i >> lw) * rs + (i & (w - 1)) - BACK;
+      int sum = 0;
+#pragma unroll
+      for (int k = 0; k < N; k++) sum += (int)s[k] * fh[k];
+      dst[i] = d_clip_bd((sum + 32) >> 6, smax);
+    }
+    return;
+  }
+  if (fx == 0) {
+    for (int i = lane; i < w * h; i += 64) {
+      const uint16_t *s = ref + (ptrdiff_t)((i >> lw) - BACK) * rs + (i & (w - 1));
+      int sum = 0;
+#pragma unroll
+      for (int k = 0; k < N; k++) sum += (int)s[(ptrdiff_t)k * rs] * fv[k];
+      dst[i] = d_clip_bd((int16_t)((sum + 32) >> 6), smax);
+    }
+    return;
+  }
+  {
+    const int shift = 6 - (14 - bd), offset = -(8192 << shift);
+    for (int i = lane; i < w * (h + N - 1); i += 64) {
+      const uint16_t *s =
+          ref + (ptrdiff_t)((i >> lw) - BACK) * rs + (i & (w - 1)) - BACK;
+      int sum = 0;
+#pragma unroll
+      for (int k = 0; k < N; k++) sum += (int)s[k] * fh[k];
+      tmp[i] = (int16_t)((sum + offset) >> shift);
+    }
+  }
+  wave_sync();
+  {
+    const int shift = 6 + (14 - bd);
+    const int offset = (8192 << 6) + (1 << (shift - 1));
+    for (int i = lane; i < w * h; i += 64) {
+      const int16_t *s = tmp + i;
+      int sum = 0;
+#pragma unroll
+      for (int k = 0; k < N; k++) sum += (int)s[k * w] * fv[k];
+      dst[i] = d_clip_bd((int16_t)((sum + offset) >> shift), smax);
+    }
+  }
+}
+
+// grid: XCD-swizzled workgroups of 4 waves; job = (CU, component), component
+// fastest, so the three planes of a CU share a workgroup.
+__global__ void __launch_bounds__(256)
+recon_from_me_kernel(PicView orig, PicView ref, PicView rec,
+                     const xvcgpu_me_block *blocks, const xvcgpu_me_result *results,
+                     int n_cus, int qp_y, int qp_c, int intra_pic, int ref_poc,
+                     int32_t *nnz_out, xvcgpu_cu_info *cus,
+                     const int16_t *tx_tables, const int16_t *tx_tables_t,
+                     TxTableLayout lay) {
+  __shared__ ReconShared s_all[4];
+  ReconShared &s = s_all[threadIdx.x >> 6];
+  const int n = n_cus * 3;
+  const int n_wg = (n + 3) / 4;
+  const int wg = xcd_job_index(blockIdx.x, n_wg);
+  if (wg < 0) return;
+  const int job = wg * 4 + (int)(threadIdx.x >> 6);
+  if (job >= n) return;
+  const int ci = job / 3, comp = job - ci * 3;
+  const xvcgpu_me_block mb = blocks[ci];
+  const xvcgpu_me_result mr = results[ci];
+  const int bd = ref.bd;
+  // MotionCompensationMv: clip, split (GetFullpelRef, 4:2:0)
+  int mx = mr.mv_x, my = mr.mv_y;
+  d_clip_mv(mb.x, mb.y, ref.c[0].w, ref.c[0].h, mx, my);
+  const int cs = comp ? 1 : 0, shift = 4 + cs;
+  const int fx = mx & ((1 << shift) - 1), fy = my & ((1 << shift) - 1);
+  const PlaneView prf = ref.c[comp];
+  const int cx = mb.x >> cs, cy = mb.y >> cs, cw = mb.w >> cs, ch = mb.h >> cs;
+  const uint16_t *r = prf.p + (ptrdiff_t)(cy + (my >> shift)) * prf.stride + cx + (mx >> shift);
+  if (comp)
+    wave_interp_block<true>(bd, cw, ch, fx, fy, r, prf.stride, s.tmp, s.pred);
+  else
+    wave_interp_block<false>(bd, cw, ch, fx, fy, r, prf.stride, s.tmp, s.pred);
+  wave_sync();
+  xvcgpu_tx_block tb;
+  tb.x = (int16_t)cx;
+  tb.y = (int16_t)cy;
+  tb.w = (uint8_t)cw;
+  tb.h = (uint8_t)ch;
+  tb.comp = (uint8_t)comp;
+  tb.tx_hor = XVC_TX_DEFAULT;
+  tb.tx_ver = XVC_TX_DEFAULT;
+  tb.dst4x4 = 0;
+  tb.qp = (int8_t)(comp ? qp_c : qp_y);
+  tb.intra_pic = (uint8_t)intra_pic;
+  const int nnz = tx2_job<TX_MODE_FULL>(s.tx, tb, job, bd, orig.c[comp], s.pred, cw,
+                                        rec.c[comp], nullptr, nullptr, nnz_out,
+                                        tx_tables, tx_tables_t, lay);
+  if (comp == 0 && cus && ME2_LANE == 0) {
+    xvcgpu_cu_info c;
+    c.x = (uint16_t)mb.x;
+    c.y = (uint16_t)mb.y;
+    c.w = mb.w;
+    c.h = mb.h;
+    c.intra = 0;
+    c.cbf_luma = nnz != 0;
+    c.qp_y = (int8_t)qp_y;
+    c.qp_c = (int8_t)qp_c;
+    c.ref_idx0 = 0;
+    c.reserved = 0;
+    c.ref_poc[0] = ref_poc;
+    c.ref_poc[1] = -1;
+    for (int k = 0; k < 4; k++) {
+      c.mv[0][k][0] = mr.mv_x;
+      c.mv[0][k][1] = mr.mv_y;
+      c.mv[1][k][0] = 0;
+      c.mv[1][k][1] = 0;
+    }
+    cus[ci] = c;
+  }
+}
+
+#endif  // XVCGPU_K_RECON_H_

@@ -114,29 +114,21 @@ __device__ __forceinline__ void tx2_stage_dispatch(int nj, const int16_t *A,
   }
 }
 
-// grid: XCD-swizzled workgroups of TX2_WAVES waves; one job per wave.
-// tx_tables_t: the same matrices transposed (same layout offsets).
+// One TransformAndReconstruct job by one wave.  pred_p / pred_stride address
+// the predicted block (a picture plane in global memory, or an LDS buffer when
+// the caller has just motion-compensated it).
 template <int MODE>
-__global__ void __launch_bounds__(64 * TX2_WAVES)
-residual_wave_kernel(PicView orig, PicView pred, PicView rec,
-                     const xvcgpu_tx_block *blocks, int n, int16_t *levels,
-                     const uint32_t *level_off, int32_t *nnz_out,
-                     const int16_t *tx_tables, const int16_t *tx_tables_t,
-                     TxTableLayout lay) {
-  __shared__ Tx2Shared s_all[TX2_WAVES];
-  Tx2Shared &s = s_all[threadIdx.x >> 6];
-  const int n_wg = (n + TX2_WAVES - 1) / TX2_WAVES;
-  const int wg = xcd_job_index(blockIdx.x, n_wg);
-  if (wg < 0) return;
-  const int bi = wg * TX2_WAVES + (int)(threadIdx.x >> 6);
-  if (bi >= n) return;
-  const xvcgpu_tx_block b = blocks[bi];
-  if (!tx_small_job(b)) return;  // general path: residual_kernel<>
+__device__ __forceinline__ int tx2_job(Tx2Shared &s, const xvcgpu_tx_block &b, int bi,
+                                       int bd, const PlaneView &po, const uint16_t *pred_p,
+                                       int pred_stride, const PlaneView &pr,
+                                       int16_t *levels, const uint32_t *level_off,
+                                       int32_t *nnz_out, const int16_t *tx_tables,
+                                       const int16_t *tx_tables_t,
+                                       const TxTableLayout &lay) {
   const int lane = ME2_LANE;
-  const int w = b.w, h = b.h, bd = pred.bd;
+  const int w = b.w, h = b.h;
   const int lw = 31 - __clz(w);
   const int lgw = d_log2_size(w), lgh = d_log2_size(h);
-  const PlaneView pp = pred.c[b.comp], pr = rec.c[b.comp];
   int16_t *lv = (levels && level_off) ? levels + level_off[bi] : nullptr;
   const int offh = tx_table_off(lay, b.tx_hor, w), offv = tx_table_off(lay, b.tx_ver, h);
   const int16_t *Mh = tx_tables + offh, *Mv = tx_tables + offv;
@@ -150,14 +142,13 @@ residual_wave_kernel(PicView orig, PicView pred, PicView rec,
 
   int nnz;
   if (MODE != TX_MODE_INV) {
-    const PlaneView po = orig.c[b.comp];
     // residual, 4 samples per lane along a row
     for (int i = lane * 4; i < n_el; i += 256) {
       const int y = i >> lw, x = i & (w - 1);
       const U16x4 o = *reinterpret_cast<const U16x4 *>(
           po.p + (ptrdiff_t)(b.y + y) * po.stride + b.x + x);
       const U16x4 p = *reinterpret_cast<const U16x4 *>(
-          pp.p + (ptrdiff_t)(b.y + y) * pp.stride + b.x + x);
+          pred_p + (ptrdiff_t)y * pred_stride + x);
       const int d0 = (int)(o.v[0] & 0xffff) - (int)(p.v[0] & 0xffff);
       const int d1 = (int)(o.v[0] >> 16) - (int)(p.v[0] >> 16);
       const int d2 = (int)(o.v[1] & 0xffff) - (int)(p.v[1] & 0xffff);
@@ -179,7 +170,7 @@ residual_wave_kernel(PicView orig, PicView pred, PicView rec,
           const int x = i / h, k2 = i - x * h;  // C[x][k2]
           lv[k2 * w + x] = s.c[i];
         }
-      return;
+      return 0;
     }
     // QuantFast (rdo_quant.cc:156-195) on C, in place
     const int qshift = 14 + qpb / 6 + tshift + (bias ? 7 : 0);
@@ -215,10 +206,10 @@ residual_wave_kernel(PicView orig, PicView pred, PicView rec,
     for (int i = lane * 4; i < n_el; i += 256) {
       const int y = i >> lw, x = i & (w - 1);
       const U16x4 p = *reinterpret_cast<const U16x4 *>(
-          pp.p + (ptrdiff_t)(b.y + y) * pp.stride + b.x + x);
+          pred_p + (ptrdiff_t)y * pred_stride + x);
       *reinterpret_cast<U16x4 *>(pr.p + (ptrdiff_t)(b.y + y) * pr.stride + b.x + x) = p;
     }
-    return;
+    return 0;
   }
   const bool dc_only = nnz == 1 && s.c[0] != 0;
   wave_sync();
@@ -244,7 +235,7 @@ residual_wave_kernel(PicView orig, PicView pred, PicView rec,
     for (int i = lane * 4; i < n_el; i += 256) {
       const int y = i >> lw, x = i & (w - 1);
       const U16x4 p = *reinterpret_cast<const U16x4 *>(
-          pp.p + (ptrdiff_t)(b.y + y) * pp.stride + b.x + x);
+          pred_p + (ptrdiff_t)y * pred_stride + x);
       U16x4 o;
       o.v[0] = (uint32_t)d_clip3((int)(p.v[0] & 0xffff) + cf, 0, smax) |
                ((uint32_t)d_clip3((int)(p.v[0] >> 16) + cf, 0, smax) << 16);
@@ -252,7 +243,7 @@ residual_wave_kernel(PicView orig, PicView pred, PicView rec,
                ((uint32_t)d_clip3((int)(p.v[1] >> 16) + cf, 0, smax) << 16);
       *reinterpret_cast<U16x4 *>(pr.p + (ptrdiff_t)(b.y + y) * pr.stride + b.x + x) = o;
     }
-    return;
+    return nnz;
   }
   // inverse: U[r][x] (h rows of w) into s.r, then residual rows into s.t
   {
@@ -266,7 +257,7 @@ residual_wave_kernel(PicView orig, PicView pred, PicView rec,
   for (int i = lane * 4; i < n_el; i += 256) {
     const int y = i >> lw, x = i & (w - 1);
     const U16x4 p = *reinterpret_cast<const U16x4 *>(
-        pp.p + (ptrdiff_t)(b.y + y) * pp.stride + b.x + x);
+        pred_p + (ptrdiff_t)y * pred_stride + x);
     const uint2 rs = *reinterpret_cast<const uint2 *>(s.t + i);
     U16x4 o;
     o.v[0] = (uint32_t)d_clip3((int)(p.v[0] & 0xffff) + (int)(int16_t)(rs.x & 0xffff), 0, smax) |
@@ -275,6 +266,31 @@ residual_wave_kernel(PicView orig, PicView pred, PicView rec,
              ((uint32_t)d_clip3((int)(p.v[1] >> 16) + ((int)rs.y >> 16), 0, smax) << 16);
     *reinterpret_cast<U16x4 *>(pr.p + (ptrdiff_t)(b.y + y) * pr.stride + b.x + x) = o;
   }
+  return nnz;
+}
+
+// grid: XCD-swizzled workgroups of TX2_WAVES waves; one job per wave.
+// tx_tables_t: the same matrices transposed (same layout offsets).
+template <int MODE>
+__global__ void __launch_bounds__(64 * TX2_WAVES)
+residual_wave_kernel(PicView orig, PicView pred, PicView rec,
+                     const xvcgpu_tx_block *blocks, int n, int16_t *levels,
+                     const uint32_t *level_off, int32_t *nnz_out,
+                     const int16_t *tx_tables, const int16_t *tx_tables_t,
+                     TxTableLayout lay) {
+  __shared__ Tx2Shared s_all[TX2_WAVES];
+  Tx2Shared &s = s_all[threadIdx.x >> 6];
+  const int n_wg = (n + TX2_WAVES - 1) / TX2_WAVES;
+  const int wg = xcd_job_index(blockIdx.x, n_wg);
+  if (wg < 0) return;
+  const int bi = wg * TX2_WAVES + (int)(threadIdx.x >> 6);
+  if (bi >= n) return;
+  const xvcgpu_tx_block b = blocks[bi];
+  if (!tx_small_job(b)) return;  // general path: residual_kernel<>
+  const PlaneView pp = pred.c[b.comp];
+  tx2_job<MODE>(s, b, bi, pred.bd, orig.c[b.comp],
+                pp.p + (ptrdiff_t)b.y * pp.stride + b.x, pp.stride, rec.c[b.comp], levels,
+                level_off, nnz_out, tx_tables, tx_tables_t, lay);
 }
 
 #endif  // XVCGPU_K_TX2_H_

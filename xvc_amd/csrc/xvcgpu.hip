@@ -15,6 +15,7 @@
 #include "k_pad.h"
 #include "k_tx.h"
 #include "k_tx2.h"
+#include "k_recon.h"
 #include "xvcgpu_internal.h"
 
 namespace {
@@ -500,6 +501,26 @@ xvcgpu_status xvcgpu_cu_info_from_me(xvcgpu_ctx *ctx,
                      ctx->stream, d_blocks, d_results, d_nnz, d_luma_tx_index, n,
                      qp_y, qp_c, ref_poc, d_cus);
   CHECK_LAUNCH(ctx, "cu_info_from_me");
+  return XVCGPU_OK;
+}
+
+xvcgpu_status xvcgpu_recon_from_me(xvcgpu_ctx *ctx, const xvcgpu_picture *orig,
+                                   const xvcgpu_picture *ref, xvcgpu_picture *rec,
+                                   const xvcgpu_me_block *d_blocks,
+                                   const xvcgpu_me_result *d_results, int n,
+                                   int qp_y, int qp_c, int intra_pic, int ref_poc,
+                                   int32_t *d_nnz, xvcgpu_cu_info *d_cus) {
+  if (!ctx || !orig || !ref || !rec || n < 0 || (n && (!d_blocks || !d_results)))
+    return XVCGPU_INVALID_ARGUMENT;
+  if (orig->w != ref->w || orig->h != ref->h || rec->w != ref->w || rec->h != ref->h)
+    return fail(ctx, XVCGPU_INVALID_ARGUMENT, "picture mismatch");
+  if (n == 0) return XVCGPU_OK;
+  const int n_wg = (3 * n + 3) / 4;
+  hipLaunchKernelGGL(recon_from_me_kernel, dim3((n_wg + 7) / 8 * 8), dim3(256), 0,
+                     ctx->stream, orig->v, ref->v, rec->v, d_blocks, d_results, n, qp_y,
+                     qp_c, intra_pic, ref_poc, d_nnz, d_cus, ctx->d_tx_tables,
+                     ctx->d_tx_tables_t, xvcgpu_tx_layout());
+  CHECK_LAUNCH(ctx, "recon_from_me");
   return XVCGPU_OK;
 }
 

@@ -109,8 +109,9 @@ class FramePass:
     (or of one CTU-row shard of it)."""
 
     def __init__(self, ctx, width, height, bitdepth=10, qp=32, cu=16,
-                 search_range=96, row_range=None):
+                 search_range=96, row_range=None, fused=True):
         self.ctx = ctx
+        self.fused = fused and width % 8 == 0 and height % 8 == 0
         self.w, self.h, self.bd = width, height, bitdepth
         self.desc = d = FrameDescriptors(width, height, qp, cu, search_range,
                                          row_range)
@@ -138,6 +139,12 @@ class FramePass:
             return
         ctx.me_search_dev(orig, ref, api.ME_FULLPEL | api.ME_SUBPEL, self.d_me.ptr,
                           n, self.d_res.ptr, d.cu_size)
+        if self.fused and d.cu_size <= 16:
+            # MC + transform/quant/recon + CU metadata in one launch; the
+            # prediction never leaves LDS
+            ctx.recon_from_me_dev(orig, ref, rec, self.d_me.ptr, self.d_res.ptr, n,
+                                  d.qp, d.qp_c, ref_poc, self.d_nnz.ptr, self.d_cus_own)
+            return
         ctx.mc_from_me_dev(ref, self.pred, self.d_me.ptr, self.d_res.ptr, n)
         ctx.residual_batch_dev(orig, self.pred, rec, self.d_tx.ptr, len(d.tx),
                                None, None, self.d_nnz.ptr)
