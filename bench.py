@@ -125,7 +125,11 @@ def main():
     ctx.sync()
 
     def step(i):
-        o = origs[i % len(origs)]
+        # frames 1..F then back down: consecutive pictures are always one
+        # frame apart (no artificial scene cut when the clip wraps around)
+        F = len(origs)
+        k = i % (2 * F - 2) if F > 1 else 0
+        o = origs[k if k < F else 2 * F - 2 - k]
         ref, rec = recs[i % 2], recs[(i + 1) % 2]
         if runner is None:
             fp.run(o, ref, rec, ref_poc=i)
@@ -166,7 +170,10 @@ def main():
         # replay the inputs of the last timed step (ME/MC/residual are
         # idempotent on them)
         i_last = args.warmup + args.steps - 1
-        o, ref, rec = origs[i_last % len(origs)], recs[i_last % 2], recs[(i_last + 1) % 2]
+        F = len(origs)
+        k_last = i_last % (2 * F - 2) if F > 1 else 0
+        o = origs[k_last if k_last < F else 2 * F - 2 - k_last]
+        ref, rec = recs[i_last % 2], recs[(i_last + 1) % 2]
         reps = 20
 
         def timed(fn):
@@ -203,9 +210,24 @@ def main():
             "pad_border": 2 * 80 * (W + H + 160) * S * 2,
             "picture_ssd": 2 * n_luma * S,
         }
+        # HBM bytes per launch from the committed PMC profile (rocprofv3 --pmc
+        # FETCH_SIZE / WRITE_SIZE passes of this same command, corrected as
+        # MI355X_MICROARCH.md prescribes; tools/pmc_traffic.py)
+        traffic = None
+        try:
+            prof = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
+            kname = {"me_search": "void me_search_wave_kernel<16>",
+                     "recon_from_me": "recon_from_me_kernel",
+                     "picture_ssd": "picture_ssd_kernel", "pad_border": "pad_tb_kernel",
+                     "deblock": "void deblock_pass_kernel<true>"}[dom]
+            if W == 1920 and H == 1080 and world == 1:
+                traffic = prof[kname]["hbm_bytes_per_launch"]
+        except (OSError, KeyError, ValueError):
+            traffic = None
         achieved = alg[dom] / (times[dom] * 1e-3) / 1e9
         roof = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": 8000.0,
-                "unit": "GB/s", "frac": achieved / 8000.0, "traffic": None,
+                "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic,
+                "algorithmic_bytes": alg[dom],
                 "ms_per_launch": times[dom],
                 "all_kernels_ms": {k: round(v, 4) for k, v in times.items()}}
 
