@@ -93,6 +93,26 @@ typedef struct xvcgpu_me_result {
   uint32_t subpel_dist;         /* *out_dist of SubpelSearch (SATD)        */
 } xvcgpu_me_result;
 
+/* One bi-prediction refinement step for one CU (SearchBiIterative inner
+ * loop, inter_search.cc:392-433): the searched list's block descriptor, the
+ * MV already chosen for the OTHER list and the uni-pred MV of the searched
+ * list that centres the +-4 window (mv_bootstrap, inter_search.cc:620-627). */
+typedef struct xvcgpu_bi_block {
+  xvcgpu_me_block blk;            /* x,y,w,h, fullpel_mv, mvp, lambda16 used   */
+  int32_t other_mv_x, other_mv_y; /* MV into the other list's picture, 1/16   */
+  int32_t boot_mv_x, boot_mv_y;   /* window centre, 1/16 pel                   */
+} xvcgpu_bi_block;
+
+/* One bi-pred motion-compensation job (inter_prediction.cc:710-738). */
+typedef struct xvcgpu_mc_bi_block {
+  int16_t x, y;        /* luma position of the CU                          */
+  uint8_t w, h;        /* luma size of the CU                              */
+  uint8_t comp;        /* 0 = Y, 1 = U, 2 = V                              */
+  uint8_t reserved;
+  int32_t mv0_x, mv0_y; /* list-0 MV, 1/16 pel luma                        */
+  int32_t mv1_x, mv1_y; /* list-1 MV                                       */
+} xvcgpu_mc_bi_block;
+
 /* One residual-pipeline job = one (CU, component) pair, i.e. one call of
  * TransformEncoder::TransformAndReconstruct (transform_encoder.cc:203-285)
  * with the non-RDO quantiser. Positions/sizes are in samples of `comp`. */

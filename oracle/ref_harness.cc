@@ -559,4 +559,99 @@ void xr_full_search(int bd, int x, int y, int w, int h, int fullpel_mv,
   out_mv[1] = r.y;
 }
 
+/* ---- bi-prediction ---- */
+struct BiEnv {
+  PictureData pic_data;
+  YuvPicture orig_pic, rec_pic;
+  std::shared_ptr<YuvPicture> ref[2];
+  std::shared_ptr<PictureData> ref_data;
+  EncoderSettings settings;
+  BiEnv(int bd, int pic_w, int pic_h)
+      : pic_data(ChromaFormat::k420, pic_w, pic_h, bd),
+        orig_pic(ChromaFormat::k420, pic_w, pic_h, bd, true, 0, 0),
+        rec_pic(ChromaFormat::k420, pic_w, pic_h, bd, true, 0, 0) {
+    for (int l = 0; l < 2; l++)
+      ref[l] = std::make_shared<YuvPicture>(ChromaFormat::k420, pic_w, pic_h, bd,
+                                            true, 0, 0);
+    ref_data = std::make_shared<PictureData>(ChromaFormat::k420, 8, 8, bd);
+    ref_data->SetNalType(NalUnitType::kPredictedPicture);
+    settings.Initialize(SpeedMode::kSlow);
+    pic_data.SetSubGopLength(16);
+    pic_data.SetPoc(8);
+    pic_data.SetNalType(NalUnitType::kBipredictedPicture);
+    ReferencePictureLists *rpl = pic_data.GetRefPicLists();
+    rpl->Reset(8);
+    rpl->SetRefPic(RefPicList::kL0, 0, 0, ref_data, ref[0], nullptr);
+    rpl->SetRefPic(RefPicList::kL1, 0, 16, ref_data, ref[1], nullptr);
+  }
+};
+
+void xr_mc_bipred_block(int bd, int comp, int x, int y, int w, int h, int mv0_x,
+                        int mv0_y, int mv1_x, int mv1_y, int pic_w, int pic_h,
+                        const uint16_t *ref0, ptrdiff_t rs0, const uint16_t *ref1,
+                        ptrdiff_t rs1, uint16_t *pred, ptrdiff_t ps) {
+  BiEnv env(bd, pic_w, pic_h);
+  const uint16_t *p0[3] = {nullptr, nullptr, nullptr}, *p1[3] = {nullptr, nullptr, nullptr};
+  ptrdiff_t s0[3] = {0, 0, 0}, s1[3] = {0, 0, 0};
+  p0[comp] = ref0; s0[comp] = rs0;
+  p1[comp] = ref1; s1[comp] = rs1;
+  FillPic(env.ref[0].get(), p0, s0);
+  FillPic(env.ref[1].get(), p1, s1);
+  CodingUnit *cu = env.pic_data.CreateCu(CuTree::Primary, 1, x, y, w, h);
+  cu->SetPredMode(PredictionMode::kInter);
+  cu->SetInterDir(InterDir::kBi);
+  cu->SetRefIdx(0, RefPicList::kL0);
+  cu->SetRefIdx(0, RefPicList::kL1);
+  cu->SetMv(MotionVector(mv0_x, mv0_y), RefPicList::kL0);
+  cu->SetMv(MotionVector(mv1_x, mv1_y), RefPicList::kL1);
+  InterPrediction ip(Simd(bd).inter_prediction, env.rec_pic, bd);
+  SampleBuffer pb(pred, ps);
+  ip.MotionCompensation(*cu, YuvComponent(comp), &pb);
+}
+
+void xr_bipred_search(int bd, const xvcgpu_bi_block *j, int pic_w, int pic_h,
+                      const uint16_t *orig, ptrdiff_t os, const uint16_t *ref_other,
+                      ptrdiff_t ros, const uint16_t *ref_search, ptrdiff_t rss,
+                      xvcgpu_me_result *out) {
+  /* searched list = L0 (ref[0] = ref_search), other list = L1 (ref[1]) */
+  const xvcgpu_me_block *b = &j->blk;
+  BiEnv env(bd, pic_w, pic_h);
+  for (int y = 0; y < pic_h; y++)
+    std::memcpy(env.orig_pic.GetSamplePtr(YuvComponent::kY, 0, y), orig + y * os,
+                sizeof(Sample) * pic_w);
+  const uint16_t *ps[3] = {ref_search, nullptr, nullptr}, *po[3] = {ref_other, nullptr, nullptr};
+  ptrdiff_t ss[3] = {rss, 0, 0}, so[3] = {ros, 0, 0};
+  FillPic(env.ref[0].get(), ps, ss);
+  FillPic(env.ref[1].get(), po, so);
+  CodingUnit *cu = env.pic_data.CreateCu(CuTree::Primary, 1, b->x, b->y, b->w, b->h);
+  cu->SetPredMode(PredictionMode::kInter);
+  cu->SetFullpelMv(b->fullpel_mv != 0);
+  cu->SetRefIdx(0, RefPicList::kL0);
+  cu->SetRefIdx(0, RefPicList::kL1);
+  cu->SetMv(MotionVector(j->other_mv_x, j->other_mv_y), RefPicList::kL1);
+  InterSearch is(Simd(bd), env.pic_data, env.orig_pic, env.rec_pic,
+                 *env.pic_data.GetRefPicLists(), env.settings);
+  const YuvComponent comp = YuvComponent::kY;
+  /* SearchBiIterative body, inter_search.cc:418-423 */
+  cu->SetInterDir(InterDir::kL1);
+  is.MotionCompensation(*cu, comp, &is.bipred_pred_buffer_);
+  SampleBufferConst orig_luma = env.orig_pic.GetSampleBuffer(comp, b->x, b->y);
+  is.bipred_orig_buffer_.SubtractWeighted(b->w, b->h, orig_luma, is.bipred_pred_buffer_);
+  cu->SetInterDir(InterDir::kBi);
+  double ls = (b->lambda16 + 0.5) / 65536.0;
+  Qp qp = MakeQp(32, bd, ls * ls);
+  MotionVector boot(j->boot_mv_x, j->boot_mv_y);
+  SampleBufferStorage pred(64, 64);
+  Distortion dist = 0;
+  MotionVector mv = is.MotionEstNormal(
+      *cu, qp, InterSearch::SearchMethod::kFullSearch, RefPicList::kL0, 0, true,
+      is.bipred_orig_buffer_, MotionVector(b->mvp_x, b->mvp_y), &boot, &pred, &dist);
+  out->fullpel_x = 0;
+  out->fullpel_y = 0;
+  out->mv_x = mv.x;
+  out->mv_y = mv.y;
+  out->fullpel_cost = 0;
+  out->subpel_dist = static_cast<uint32_t>(dist);
+}
+
 }  // extern "C"

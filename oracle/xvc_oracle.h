@@ -157,6 +157,22 @@ void xo_subpel_search(int bitdepth, const xvcgpu_me_block *blk, int pic_w,
                       int pic_h, const uint16_t *orig, ptrdiff_t orig_stride,
                       const uint16_t *ref, ptrdiff_t ref_stride,
                       const int fullpel[2], int out_mv[2], uint32_t *out_dist);
+/* One bi-prediction refinement step: target = 2*orig - MC(other list)
+ * (SearchBiIterative, inter_search.cc:392-433), +-4 FullSearch on the int16
+ * target (:853-891), SubpelSearch with TOrig = Residual, distortion halved
+ * (MotionEstNormal, :606-662). */
+void xo_bipred_search(int bitdepth, const xvcgpu_bi_block *job, int pic_w,
+                      int pic_h, const uint16_t *orig, ptrdiff_t orig_stride,
+                      const uint16_t *ref_other, ptrdiff_t other_stride,
+                      const uint16_t *ref_search, ptrdiff_t search_stride,
+                      xvcgpu_me_result *out);
+/* MotionCompensation for a bi-pred CU, one component
+ * (inter_prediction.cc:710-738: two 14-bit predictions + AddAvgBi). */
+void xo_mc_bipred_block(int bitdepth, int comp, int x, int y, int w, int h,
+                        int mv0_x, int mv0_y, int mv1_x, int mv1_y, int pic_w,
+                        int pic_h, const uint16_t *ref0, ptrdiff_t rs0,
+                        const uint16_t *ref1, ptrdiff_t rs1, uint16_t *pred,
+                        ptrdiff_t pred_stride);
 /* GetMvdBitsFullpel / GetMvdBits / GetNumExpGolombBits
  * (inter_search.cc:1150-1188). */
 uint32_t xo_mvd_bits_fullpel(int mvp_x, int mvp_y, int fx, int fy,

@@ -650,6 +650,108 @@ void xo_subpel_search(int bd, const xvcgpu_me_block *b, int pic_w, int pic_h,
   if (out_dist) *out_dist = (uint32_t)best_dist;
 }
 
+/* SubpelSearch on an int16 target (bi-pred: TOrig = Residual), same fold. */
+static void xp_subpel_search_rs(int bd, const xvcgpu_me_block *b, int pic_w,
+                                int pic_h, const int16_t *target, ptrdiff_t ts,
+                                const uint16_t *ref, ptrdiff_t rs,
+                                const int fullpel[2], int out_mv[2],
+                                uint32_t *out_dist) {
+  static const int8_t half[9][2] = {{0, 0},  {0, -1},  {0, 1},  {-1, 0}, {1, 0},
+                                    {-1, -1}, {1, -1}, {-1, 1}, {1, 1}};
+  static const int8_t qpel[9][2] = {{0, 0},  {0, -1}, {0, 1},  {-1, -1}, {1, -1},
+                                    {-1, 0}, {1, 0},  {-1, 1}, {1, 1}};
+  uint16_t pred[64 * 64];
+  uint64_t best_cost = UINT64_MAX, best_dist = UINT64_MAX;
+  int best_x = fullpel[0] * 16, best_y = fullpel[1] * 16;
+  for (int pass = 0; pass < 2; pass++) {
+    const int base_x = best_x, base_y = best_y;
+    const int scale = pass == 0 ? 8 : 4;
+    for (int i = pass; i < 9; i++) {
+      const int8_t *d = pass == 0 ? half[i] : qpel[i];
+      const int mx = base_x + d[0] * scale, my = base_y + d[1] * scale;
+      xo_mc_block(bd, 0, b->x, b->y, b->w, b->h, mx, my, pic_w, pic_h, ref, rs,
+                  pred, 64);
+      uint64_t dist = xo_metric_rs(XVC_METRIC_SATD, bd, 0, 1, 1.0, b->w, b->h,
+                                   target, ts, pred, 64);
+      if (dist >= best_cost) continue;
+      uint32_t bits = xo_mvd_bits(b->mvp_x, b->mvp_y, mx, my, 0);
+      uint64_t cost = dist + ((uint32_t)(b->lambda16 * bits) >> 16);
+      if (cost < best_cost) {
+        best_cost = cost;
+        best_dist = dist;
+        best_x = mx;
+        best_y = my;
+      }
+    }
+  }
+  out_mv[0] = best_x;
+  out_mv[1] = best_y;
+  *out_dist = (uint32_t)best_dist;
+}
+
+void xo_bipred_search(int bd, const xvcgpu_bi_block *j, int pic_w, int pic_h,
+                      const uint16_t *orig, ptrdiff_t os,
+                      const uint16_t *ref_other, ptrdiff_t ros,
+                      const uint16_t *ref_search, ptrdiff_t rss,
+                      xvcgpu_me_result *out) {
+  /* One inner step of SearchBiIterative (inter_search.cc:392-433) +
+   * MotionEstNormal(kFullSearch, bipred) (:606-662) */
+  const xvcgpu_me_block *b = &j->blk;
+  uint16_t pred[64 * 64];
+  int16_t target[64 * 64];
+  xo_mc_block(bd, 0, b->x, b->y, b->w, b->h, j->other_mv_x, j->other_mv_y, pic_w,
+              pic_h, ref_other, ros, pred, 64);
+  for (int y = 0; y < b->h; y++) /* SubtractWeighted, sample_buffer.h:147-161 */
+    for (int x = 0; x < b->w; x++)
+      target[y * 64 + x] =
+          (int16_t)(2 * (int)orig[(ptrdiff_t)(b->y + y) * os + b->x + x] -
+                    (int)pred[y * 64 + x]);
+  int mn[2], mx[2], fp[2], mv[2];
+  xo_min_max_mv(b->x, b->y, pic_w, pic_h, j->boot_mv_x, j->boot_mv_y, 4, mn, mx);
+  xo_full_search(bd, b->x, b->y, b->w, b->h, b->fullpel_mv, b->mvp_x, b->mvp_y,
+                 b->lambda16, mn, mx, target, 64, ref_search, rss, fp);
+  uint32_t dist = 0;
+  if (b->fullpel_mv) {
+    mv[0] = fp[0] * 16;
+    mv[1] = fp[1] * 16;
+    xo_mc_block(bd, 0, b->x, b->y, b->w, b->h, mv[0], mv[1], pic_w, pic_h,
+                ref_search, rss, pred, 64);
+    dist = (uint32_t)xo_metric_rs(XVC_METRIC_SATD, bd, 0, 1, 1.0, b->w, b->h,
+                                  target, 64, pred, 64);
+  } else {
+    xp_subpel_search_rs(bd, b, pic_w, pic_h, target, 64, ref_search, rss, fp, mv,
+                        &dist);
+  }
+  out->fullpel_x = fp[0];
+  out->fullpel_y = fp[1];
+  out->mv_x = mv[0];
+  out->mv_y = mv[1];
+  out->fullpel_cost = 0;
+  out->subpel_dist = dist >> 1; /* *out_dist = bipred ? dist >> 1 : dist */
+}
+
+void xo_mc_bipred_block(int bd, int comp, int x, int y, int w, int h, int mv0_x,
+                        int mv0_y, int mv1_x, int mv1_y, int pic_w, int pic_h,
+                        const uint16_t *ref0, ptrdiff_t rs0, const uint16_t *ref1,
+                        ptrdiff_t rs1, uint16_t *pred, ptrdiff_t ps) {
+  /* MotionCompensation, normal bi-prediction (inter_prediction.cc:710-738) */
+  int16_t p0[64 * 64], p1[64 * 64];
+  const int cs = comp ? 1 : 0, shift = 4 + cs;
+  const int cx = x >> cs, cy = y >> cs, cw = w >> cs, ch = h >> cs;
+  const uint16_t *refs[2] = {ref0, ref1};
+  const ptrdiff_t rss[2] = {rs0, rs1};
+  int mvs[2][2] = {{mv0_x, mv0_y}, {mv1_x, mv1_y}};
+  int16_t *outs[2] = {p0, p1};
+  for (int l = 0; l < 2; l++) {
+    int mx = mvs[l][0], my = mvs[l][1];
+    xo_clip_mv(x, y, pic_w, pic_h, &mx, &my);
+    const int fx = mx & ((1 << shift) - 1), fy = my & ((1 << shift) - 1);
+    const uint16_t *r = refs[l] + (ptrdiff_t)(cy + (my >> shift)) * rss[l] + cx + (mx >> shift);
+    xo_mc_uni_bipred(bd, comp != 0, cw, ch, fx, fy, r, rss[l], outs[l], 64);
+  }
+  xo_add_avg(bd, cw, ch, p0, 64, p1, 64, pred, ps);
+}
+
 /* ========================================================================= *
  *  Residual pipeline                                                        *
  * ========================================================================= */

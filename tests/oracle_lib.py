@@ -48,6 +48,19 @@ class MeResult(C.Structure):
                 ("fullpel_cost", C.c_uint32), ("subpel_dist", C.c_uint32)]
 
 
+class BiBlock(C.Structure):
+    _fields_ = [("blk", MeBlock), ("other_mv_x", C.c_int32),
+                ("other_mv_y", C.c_int32), ("boot_mv_x", C.c_int32),
+                ("boot_mv_y", C.c_int32)]
+
+
+class McBiBlock(C.Structure):
+    _fields_ = [("x", C.c_int16), ("y", C.c_int16), ("w", C.c_uint8),
+                ("h", C.c_uint8), ("comp", C.c_uint8), ("reserved", C.c_uint8),
+                ("mv0_x", C.c_int32), ("mv0_y", C.c_int32),
+                ("mv1_x", C.c_int32), ("mv1_y", C.c_int32)]
+
+
 class TxBlock(C.Structure):
     _fields_ = [("x", C.c_int16), ("y", C.c_int16), ("w", C.c_uint8),
                 ("h", C.c_uint8), ("comp", C.c_uint8), ("tx_hor", C.c_uint8),
@@ -163,6 +176,11 @@ class Lib:
         sig("subpel_search", None,
             [C.c_int, C.POINTER(MeBlock), C.c_int, C.c_int, u16p, pd, u16p, pd,
              i32p, i32p, u32p])
+        sig("bipred_search", None,
+            [C.c_int, C.POINTER(BiBlock), C.c_int, C.c_int, u16p, pd, u16p, pd,
+             u16p, pd, C.POINTER(MeResult)])
+        sig("mc_bipred_block", None,
+            [C.c_int] * 12 + [u16p, pd, u16p, pd, u16p, pd])
         if p == "xo":
             sig("full_search", None,
                 [C.c_int] * 8 + [C.c_uint32, i32p, i32p, i16p, pd, u16p, pd,
@@ -339,6 +357,30 @@ class Lib:
                               ptr(target, i16p), self._s(target), ptr(r, u16p),
                               self._s(ref_pad), pw, ph, ptr(mv, i32p))
         return int(mv[0]), int(mv[1])
+
+    def bipred_search(self, bd, job, pw, ph, orig_pad, other_pad, search_pad,
+                      border):
+        """job: BiBlock; padded luma planes.  Returns ((mvx, mvy), dist)."""
+        res = MeResult()
+        o = orig_pad[border:, border:]
+        a = other_pad[border:, border:]
+        b = search_pad[border:, border:]
+        self._bipred_search(bd, C.byref(job), pw, ph, ptr(o, u16p),
+                            self._s(orig_pad), ptr(a, u16p), self._s(other_pad),
+                            ptr(b, u16p), self._s(search_pad), C.byref(res))
+        return (res.mv_x, res.mv_y), res.subpel_dist
+
+    def mc_bipred_block(self, bd, comp, x, y, w, h, mv0, mv1, pw, ph, pad0,
+                        pad1, border):
+        sh = 1 if comp else 0
+        out = np.zeros((h >> sh, w >> sh), np.uint16)
+        r0 = pad0[border:, border:]
+        r1 = pad1[border:, border:]
+        self._mc_bipred_block(bd, comp, x, y, w, h, mv0[0], mv0[1], mv1[0],
+                              mv1[1], pw, ph, ptr(r0, u16p), self._s(pad0),
+                              ptr(r1, u16p), self._s(pad1), ptr(out, u16p),
+                              self._s(out))
+        return out
 
     def deblock(self, bd, pw, ph, bipred, beta, tc, sub, cus, cu_map, planes,
                 borders, l0=None, l1=None):

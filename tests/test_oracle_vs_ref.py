@@ -328,3 +328,59 @@ def test_full_search(libs, bd):
         a = xr.full_search(bd, x, y, w, h, 0, mvp, 498000, mn, mx, target[:, :w], ref, border, pw, ph)
         b = xo.full_search(bd, x, y, w, h, 0, mvp, 498000, mn, mx, target[:, :w], ref, border, pw, ph)
         assert a == b
+
+
+@pytest.mark.parametrize("bd", [8, 10])
+def test_mc_bipred_block(libs, bd):
+    xo, xr = libs
+    rng = np.random.default_rng(83 + bd)
+    pw, ph, border = 128, 96, 96
+    _, ref0 = make_pics(rng, bd, pw, ph, border, (2, 1))
+    _, ref1 = make_pics(rng, bd, pw, ph, border, (-3, 2))
+    c0 = np.ascontiguousarray(ref0[::2, ::2])
+    c1 = np.ascontiguousarray(ref1[::2, ::2])
+    for i in range(40):
+        w = int(rng.choice([8, 16, 32, 64])); h = int(rng.choice([8, 16, 32, 64]))
+        x = int(rng.integers(0, (pw - w) // 8 + 1)) * 8
+        y = int(rng.integers(0, (ph - h) // 8 + 1)) * 8
+        big = i % 5 == 0
+        lim = 3000 if big else 200
+        mv0 = (int(rng.integers(-lim, lim)), int(rng.integers(-lim, lim)))
+        mv1 = (int(rng.integers(-lim, lim)), int(rng.integers(-lim, lim)))
+        if i % 7 == 0:
+            mv1 = (mv1[0] & ~15, mv1[1] & ~15)
+        for comp in range(3):
+            p0, p1, b = (ref0, ref1, border) if comp == 0 else (c0, c1, border // 2)
+            a = xr.mc_bipred_block(bd, comp, x, y, w, h, mv0, mv1, pw, ph, p0, p1, b)
+            o = xo.mc_bipred_block(bd, comp, x, y, w, h, mv0, mv1, pw, ph, p0, p1, b)
+            assert np.array_equal(a, o), (x, y, w, h, mv0, mv1, comp)
+
+
+@pytest.mark.parametrize("bd", [8, 10])
+def test_bipred_search(libs, bd):
+    xo, xr = libs
+    rng = np.random.default_rng(91 + bd)
+    pw, ph, border = 128, 96, 96
+    n = 0
+    for motion in [(2, 1), (-5, 3)]:
+        orig, ref_s = make_pics(rng, bd, pw, ph, border, motion)
+        _, ref_o = make_pics(rng, bd, pw, ph, border, (-motion[0], -motion[1]))
+        for _ in range(16):
+            w = int(rng.choice([8, 16, 32, 64])); h = int(rng.choice([8, 16, 32, 64]))
+            x = int(rng.integers(0, (pw - w) // 8 + 1)) * 8
+            y = int(rng.integers(0, (ph - h) // 8 + 1)) * 8
+            job = ol.BiBlock()
+            job.blk.x, job.blk.y, job.blk.w, job.blk.h = x, y, w, h
+            job.blk.fullpel_mv = int(rng.integers(0, 4) == 0)
+            job.blk.mvp_x = int(rng.integers(-120, 120))
+            job.blk.mvp_y = int(rng.integers(-120, 120))
+            job.blk.lambda16 = int(rng.choice([120000, 498000, 1500000]))
+            job.other_mv_x = int(rng.integers(-100, 100))
+            job.other_mv_y = int(rng.integers(-100, 100))
+            job.boot_mv_x = motion[0] * 16 + int(rng.integers(-40, 40))
+            job.boot_mv_y = motion[1] * 16 + int(rng.integers(-40, 40))
+            a = xr.bipred_search(bd, job, pw, ph, orig, ref_o, ref_s, border)
+            o = xo.bipred_search(bd, job, pw, ph, orig, ref_o, ref_s, border)
+            assert a == o, (x, y, w, h, a, o)
+            n += 1
+    assert n == 32
