@@ -171,6 +171,32 @@ xvcgpu_status xvcgpu_mc_batch(xvcgpu_ctx *ctx, const xvcgpu_picture *ref,
                               xvcgpu_picture *pred,
                               const xvcgpu_mc_block *d_blocks, int n);
 
+/* ---- I2: MotionCompensation of bi-predicted CUs --------------------------- *
+ * (inter_prediction.cc:710-738: MotionCompUniPred -> int16 for both lists,
+ * :1156-1172, then AddAvgBi :1545-1547).  ref0 / ref1 are the list-0 / list-1
+ * reference pictures; writes component blk.comp of the CU into `pred`. */
+xvcgpu_status xvcgpu_mc_bipred_batch(xvcgpu_ctx *ctx, const xvcgpu_picture *ref0,
+                                     const xvcgpu_picture *ref1,
+                                     xvcgpu_picture *pred,
+                                     const xvcgpu_mc_bi_block *d_blocks, int n);
+
+/* ---- M2 + T2 + T7: bi-prediction refinement search ------------------------ *
+ * One inner step of InterSearch::SearchBiIterative (inter_search.cc:392-433)
+ * per job: predict from the OTHER list with job.other_mv (ref_other), form
+ * the int16 target 2*orig - pred (SubtractWeighted, sample_buffer.h:147-161),
+ * then MotionEstNormal(kFullSearch, bipred=true, mv_bootstrap) on ref_search
+ * (:606-662): FullSearch over DetermineMinMaxMv(boot, 4) with kSad/kSadFast
+ * on the target (:853-891) and SubpelSearch with SATD on the target
+ * (:893-964).  d_results[i]: fullpel_x/y = FullSearch result, mv_x/y = final
+ * MV, subpel_dist = the function's *out_dist (SATD >> 1, :660),
+ * fullpel_cost = 0.  max_block_size as in xvcgpu_me_search_sized. */
+xvcgpu_status xvcgpu_bipred_search(xvcgpu_ctx *ctx, const xvcgpu_picture *orig,
+                                   const xvcgpu_picture *ref_other,
+                                   const xvcgpu_picture *ref_search,
+                                   const xvcgpu_bi_block *d_jobs, int n,
+                                   xvcgpu_me_result *d_results,
+                                   int max_block_size);
+
 /* Same for all three components of every CU of a motion search batch, taking
  * the MV from d_results[i].mv_* (InterPrediction::MotionCompensation for a
  * uni-pred CU, inter_prediction.cc:710-722): decisions stay in HBM. */

@@ -86,6 +86,12 @@ ME_DTYPE = np.dtype([("x", "<i2"), ("y", "<i2"), ("w", "u1"), ("h", "u1"),
 MERES_DTYPE = np.dtype([("fullpel_x", "<i4"), ("fullpel_y", "<i4"),
                         ("mv_x", "<i4"), ("mv_y", "<i4"),
                         ("fullpel_cost", "<u4"), ("subpel_dist", "<u4")])
+BI_DTYPE = np.dtype([("blk", ME_DTYPE), ("other_mv_x", "<i4"),
+                     ("other_mv_y", "<i4"), ("boot_mv_x", "<i4"),
+                     ("boot_mv_y", "<i4")])
+MCBI_DTYPE = np.dtype([("x", "<i2"), ("y", "<i2"), ("w", "u1"), ("h", "u1"),
+                       ("comp", "u1"), ("reserved", "u1"), ("mv0_x", "<i4"),
+                       ("mv0_y", "<i4"), ("mv1_x", "<i4"), ("mv1_y", "<i4")])
 TX_DTYPE = np.dtype([("x", "<i2"), ("y", "<i2"), ("w", "u1"), ("h", "u1"),
                      ("comp", "u1"), ("tx_hor", "u1"), ("tx_ver", "u1"),
                      ("dst4x4", "u1"), ("qp", "i1"), ("intra_pic", "u1")])

@@ -112,6 +112,46 @@ def test_oracle_me(xo):
         assert (sx, sy, sd) == (int(r["mv_x"]), int(r["mv_y"]), int(r["subpel_dist"]))
 
 
+def bipred_inputs(g):
+    pw, ph, bd, keep = (int(v) for v in g["dims"])
+
+    def pad(a, border, k):
+        out = np.zeros((a.shape[0] + 2 * (border - k), a.shape[1] + 2 * (border - k)),
+                       np.uint16)
+        out[border - k:out.shape[0] - (border - k),
+            border - k:out.shape[1] - (border - k)] = a
+        return out
+    orig = np.zeros((ph + 2 * BL, pw + 2 * BL), np.uint16)
+    orig[BL:BL + ph, BL:BL + pw] = g["orig"]
+    luma = [pad(g["ref_s"], BL, keep), pad(g["ref_o"], BL, keep)]
+    chroma = [pad(g["c_s"], BC, keep // 2), pad(g["c_o"], BC, keep // 2)]
+    return pw, ph, bd, orig, luma, chroma
+
+
+def bi_struct(j):
+    s = ol.BiBlock()
+    for name in ol.ME_DTYPE.names:
+        setattr(s.blk, name, int(j["blk"][name]))
+    for name in ("other_mv_x", "other_mv_y", "boot_mv_x", "boot_mv_y"):
+        setattr(s, name, int(j[name]))
+    return s
+
+
+def test_oracle_bipred(xo):
+    g = load("bipred")
+    pw, ph, bd, orig, luma, chroma = bipred_inputs(g)
+    for j, r in zip(g["jobs"], g["results"]):
+        mv, d = xo.bipred_search(bd, bi_struct(j), pw, ph, orig, luma[1], luma[0], BL)
+        assert (mv, d) == ((int(r["mv_x"]), int(r["mv_y"])), int(r["subpel_dist"]))
+    for b, exp in zip(g["mc"], g["preds"]):
+        comp = int(b["comp"]); cs = 1 if comp else 0
+        r0, r1, bo = (luma[0], luma[1], BL) if comp == 0 else (chroma[0], chroma[1], BC)
+        p = xo.mc_bipred_block(bd, comp, int(b["x"]), int(b["y"]), int(b["w"]),
+                               int(b["h"]), (int(b["mv0_x"]), int(b["mv0_y"])),
+                               (int(b["mv1_x"]), int(b["mv1_y"])), pw, ph, r0, r1, bo)
+        assert np.array_equal(p, exp[:int(b["h"]) >> cs, :int(b["w"]) >> cs]), tuple(b)
+
+
 def test_oracle_picture_ssd(xo):
     g = load("picture_ssd")
     for i, (w, h, bd, d, n) in enumerate(g["cases"]):
@@ -235,6 +275,28 @@ def test_gpu_me(gpu):
         assert np.array_equal(res[name], g["results"][name]), name
     O.destroy()
     R.destroy()
+
+
+@pytest.mark.gpu
+def test_gpu_bipred(gpu):
+    api, ctx = gpu
+    g = load("bipred")
+    pw, ph, bd, orig, luma, chroma = bipred_inputs(g)
+    O, RS, RO, P = (ctx.picture(pw, ph, bd) for _ in range(4))
+    O.upload([orig, None, None], BL)
+    RS.upload([luma[0], chroma[0], chroma[0]], BL)
+    RO.upload([luma[1], chroma[1], chroma[1]], BL)
+    res = ctx.bipred_search(O, RO, RS, g["jobs"])
+    for name in ("mv_x", "mv_y", "subpel_dist"):
+        assert np.array_equal(res[name], g["results"][name]), name
+    for b, exp in zip(g["mc"], g["preds"]):
+        ctx.mc_bipred_batch(RS, RO, P, np.array([b], api.MCBI_DTYPE))
+        comp = int(b["comp"]); cs = 1 if comp else 0
+        x, y, w, h = int(b["x"]), int(b["y"]), int(b["w"]), int(b["h"])
+        got = P.download()[comp][y >> cs:(y + h) >> cs, x >> cs:(x + w) >> cs]
+        assert np.array_equal(got, exp[:h >> cs, :w >> cs]), tuple(b)
+    for p in (O, RS, RO, P):
+        p.destroy()
 
 
 @pytest.mark.gpu

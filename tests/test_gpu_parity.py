@@ -212,6 +212,92 @@ def test_me_search(gpu, xo, bd):
         R.destroy()
 
 
+@pytest.mark.parametrize("bd", [8, 10])
+def test_bipred_search(gpu, xo, bd):
+    """M2/T2/T7: one SearchBiIterative step per job vs the oracle."""
+    api, ctx = gpu
+    rng = np.random.default_rng(3500 + bd)
+    pw, ph = 320, 192
+    for motion in [(2, 1), (-9, 5), (0, 0)]:
+        orig, ref_s = make_pics(rng, bd, pw, ph, BL, motion)
+        _, ref_o = make_pics(rng, bd, pw, ph, BL, (-motion[0], -motion[1]))
+        O, RO, RS = (ctx.picture(pw, ph, bd) for _ in range(3))
+        O.upload([orig, None, None], BL)
+        RO.upload([ref_o, None, None], BL)
+        RS.upload([ref_s, None, None], BL)
+        n = 60
+        jobs = np.zeros(n, api.BI_DTYPE)
+        jobs["blk"] = me_blocks(rng, api, pw, ph, n)
+        for j in jobs:
+            j["other_mv_x"] = -motion[0] * 16 + int(rng.integers(-100, 100))
+            j["other_mv_y"] = -motion[1] * 16 + int(rng.integers(-100, 100))
+            j["boot_mv_x"] = motion[0] * 16 + int(rng.integers(-60, 60))
+            j["boot_mv_y"] = motion[1] * 16 + int(rng.integers(-60, 60))
+        # a few windows clipped by the picture edge (DetermineMinMaxMv)
+        jobs[0]["blk"]["x"], jobs[0]["blk"]["y"] = 0, 0
+        jobs[0]["boot_mv_x"], jobs[0]["boot_mv_y"] = -(70 << 4), -(75 << 4)
+        jobs[1]["blk"]["x"] = pw - int(jobs[1]["blk"]["w"])
+        jobs[1]["boot_mv_x"] = 12 << 4
+        res = ctx.bipred_search(O, RO, RS, jobs)
+        for i, j in enumerate(jobs):
+            s = ol.BiBlock()
+            for name in ol.ME_DTYPE.names:
+                setattr(s.blk, name, int(j["blk"][name]))
+            for name in ("other_mv_x", "other_mv_y", "boot_mv_x", "boot_mv_y"):
+                setattr(s, name, int(j[name]))
+            mv, dist = xo.bipred_search(bd, s, pw, ph, orig, ref_o, ref_s, BL)
+            got = ((int(res[i]["mv_x"]), int(res[i]["mv_y"])), int(res[i]["subpel_dist"]))
+            assert got == (mv, dist), (motion, i, j, got, mv, dist)
+        for p in (O, RO, RS):
+            p.destroy()
+
+
+@pytest.mark.parametrize("bd", [8, 10, 12])
+def test_mc_bipred_batch(gpu, xo, bd):
+    """I2: two 14-bit predictions + AddAvg vs the oracle."""
+    api, ctx = gpu
+    rng = np.random.default_rng(3700 + bd)
+    pw, ph = 256, 192
+    p0 = padded_planes(rng, bd, pw, ph)
+    p1 = padded_planes(rng, bd, pw, ph, smooth=True)
+    R0, R1, P = (ctx.picture(pw, ph, bd) for _ in range(3))
+    R0.upload(p0, BL)
+    R1.upload(p1, BL)
+    grid = []
+    sizes = [(64, 64), (32, 64), (64, 16), (16, 16), (8, 8), (8, 32), (32, 8), (16, 4),
+             (4, 8)]
+    y = 0
+    for (w, h) in sizes:
+        if y + h > ph:
+            break
+        for x in range(0, pw - w + 1, w):
+            r = rng.random()
+            lim = 8000 if r < 0.1 else 400
+            mv = [int(rng.integers(-lim, lim)) for _ in range(4)]
+            if 0.1 <= r < 0.3:
+                mv = [v & ~15 for v in mv]           # both full-pel: copy path
+            elif r < 0.45:
+                mv[0] &= ~15; mv[3] &= ~15           # one direction only
+            for comp in range(3):
+                grid.append((x, y, w, h, comp, 0, *mv))
+        y += h
+    grid = np.array(grid, api.MCBI_DTYPE)
+    ctx.mc_bipred_batch(R0, R1, P, grid)
+    got = P.download()
+    for b in grid:
+        comp = int(b["comp"]); cs = 1 if comp else 0
+        x, y, w, h = int(b["x"]), int(b["y"]), int(b["w"]), int(b["h"])
+        exp = xo.mc_bipred_block(bd, comp, x, y, w, h,
+                                 (int(b["mv0_x"]), int(b["mv0_y"])),
+                                 (int(b["mv1_x"]), int(b["mv1_y"])), pw, ph,
+                                 p0[comp], p1[comp], BL if comp == 0 else BC)
+        g = got[comp][y >> cs:(y + h) >> cs, x >> cs:(x + w) >> cs]
+        assert np.array_equal(g, exp), tuple(b)
+    assert len(grid) > 100
+    for p in (R0, R1, P):
+        p.destroy()
+
+
 def tx_blocks(rng, api, pw, ph, n, with_types=True):
     blocks = np.zeros(n, api.TX_DTYPE)
     for i in range(n):

@@ -22,10 +22,78 @@ OUT = os.path.join(ROOT, "tests", "golden")
 BL, BC = 128, 64
 
 
+def crop(a, border, keep):
+    """Keep `keep` border samples of a padded plane (the rest is never read)."""
+    c = border - keep
+    return np.ascontiguousarray(a[c:a.shape[0] - c, c:a.shape[1] - c])
+
+
+def gen_bipred(xr):
+    """bipred.npz: SearchBiIterative steps and bi-pred MC (own seed, so the
+    other fixtures do not move when this one is regenerated)."""
+    rng = np.random.default_rng(20260929)
+    pw, ph, bd, keep = 128, 96, 10, 24
+    orig, ref_s = make_pics(rng, bd, pw, ph, BL, (3, -2))
+    _, ref_o = make_pics(rng, bd, pw, ph, BL, (-3, 2))
+    n = 28
+    jobs = np.zeros(n, ol.BI_DTYPE)
+    res = np.zeros(n, ol.MERES_DTYPE)
+    for i in range(n):
+        j = jobs[i]
+        w = int(rng.choice([8, 16, 32, 64])); h = int(rng.choice([8, 16, 32, 64]))
+        j["blk"]["w"], j["blk"]["h"] = w, h
+        j["blk"]["x"] = int(rng.integers(0, (pw - w) // 8 + 1)) * 8
+        j["blk"]["y"] = int(rng.integers(0, (ph - h) // 8 + 1)) * 8
+        j["blk"]["fullpel_mv"] = int(i % 6 == 5)
+        j["blk"]["mvp_x"] = int(rng.integers(-100, 100))
+        j["blk"]["mvp_y"] = int(rng.integers(-100, 100))
+        j["blk"]["lambda16"] = int(rng.choice([120000, 498712, 1500000]))
+        j["other_mv_x"] = -48 + int(rng.integers(-50, 50))
+        j["other_mv_y"] = 32 + int(rng.integers(-50, 50))
+        j["boot_mv_x"] = 48 + int(rng.integers(-40, 40))
+        j["boot_mv_y"] = -32 + int(rng.integers(-40, 40))
+        s = ol.BiBlock()
+        for name in ol.ME_DTYPE.names:
+            setattr(s.blk, name, int(j["blk"][name]))
+        for name in ("other_mv_x", "other_mv_y", "boot_mv_x", "boot_mv_y"):
+            setattr(s, name, int(j[name]))
+        (mx, my), d = xr.bipred_search(bd, s, pw, ph, orig, ref_o, ref_s, BL)
+        res[i] = (0, 0, mx, my, 0, d)
+    # bi-pred MC, all components
+    c_s = np.ascontiguousarray(ref_s[::2, ::2])
+    c_o = np.ascontiguousarray(ref_o[::2, ::2])
+    mc, preds = [], []
+    for i in range(24):
+        w = int(rng.choice([8, 16, 32, 64])); h = int(rng.choice([8, 16, 32, 64]))
+        x = int(rng.integers(0, (pw - w) // 8 + 1)) * 8
+        y = int(rng.integers(0, (ph - h) // 8 + 1)) * 8
+        mv = [int(rng.integers(-120, 120)) for _ in range(4)]
+        if i % 5 == 0:
+            mv = [v & ~15 for v in mv]
+        if i % 7 == 3:
+            mv[1] &= ~15; mv[2] &= ~15
+        comp = i % 3
+        r0, r1, b = (ref_s, ref_o, BL) if comp == 0 else (c_s, c_o, BC)
+        p = xr.mc_bipred_block(bd, comp, x, y, w, h, mv[:2], mv[2:], pw, ph, r0, r1, b)
+        mc.append((x, y, w, h, comp, 0, *mv))
+        pp = np.zeros((64, 64), np.uint16)
+        pp[:p.shape[0], :p.shape[1]] = p
+        preds.append(pp)
+    np.savez_compressed(
+        os.path.join(OUT, "bipred.npz"), dims=np.array([pw, ph, bd, keep], np.int32),
+        orig=orig[BL:BL + ph, BL:BL + pw], ref_s=crop(ref_s, BL, keep),
+        ref_o=crop(ref_o, BL, keep), c_s=crop(c_s, BC, keep // 2),
+        c_o=crop(c_o, BC, keep // 2), jobs=jobs, results=res,
+        mc=np.array(mc, ol.MCBI_DTYPE), preds=np.array(preds))
+
+
 def main():
     assert ol.have_ref(), "build the reference harness first: make -C oracle ref"
     xr = ol.Lib("xr")
     os.makedirs(OUT, exist_ok=True)
+    if sys.argv[1:] == ["bipred"]:
+        gen_bipred(xr)
+        return
     rng = np.random.default_rng(20260928)
 
     # ---- metrics ----
@@ -169,6 +237,7 @@ def main():
         a_l.append(pa); b_l.append(pb)
     np.savez_compressed(os.path.join(OUT, "picture_ssd.npz"),
                         cases=np.array(cases, np.int64), a=np.array(a_l), b=np.array(b_l))
+    gen_bipred(xr)
     total = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))
     print("golden fixtures written to", OUT, "total bytes", total)
 

@@ -40,6 +40,13 @@ TX_DTYPE = np.dtype([("x", "<i2"), ("y", "<i2"), ("w", "u1"), ("h", "u1"),
 MC_DTYPE = np.dtype([("x", "<i2"), ("y", "<i2"), ("w", "u1"), ("h", "u1"),
                      ("comp", "u1"), ("reserved", "u1"), ("mv_x", "<i4"),
                      ("mv_y", "<i4")])
+BI_DTYPE = np.dtype([("blk", ME_DTYPE), ("other_mv_x", "<i4"),
+                     ("other_mv_y", "<i4"), ("boot_mv_x", "<i4"),
+                     ("boot_mv_y", "<i4")])
+MCBI_DTYPE = np.dtype([("x", "<i2"), ("y", "<i2"), ("w", "u1"), ("h", "u1"),
+                       ("comp", "u1"), ("reserved", "u1"), ("mv0_x", "<i4"),
+                       ("mv0_y", "<i4"), ("mv1_x", "<i4"), ("mv1_y", "<i4")])
+assert BI_DTYPE.itemsize == 48 and MCBI_DTYPE.itemsize == 24
 CAND_DTYPE = np.dtype([("x", "<i2"), ("y", "<i2"), ("w", "u1"), ("h", "u1"),
                        ("metric", "u1"), ("qp", "i1"), ("mv_x", "<i2"),
                        ("mv_y", "<i2")])
@@ -58,6 +65,7 @@ SYMBOLS = [
     "xvcgpu_picture_download_padded", "xvcgpu_picture_plane",
     "xvcgpu_picture_copy", "xvcgpu_pad_border", "xvcgpu_metric_batch",
     "xvcgpu_me_search", "xvcgpu_me_search_sized", "xvcgpu_mc_batch", "xvcgpu_mc_from_me",
+    "xvcgpu_mc_bipred_batch", "xvcgpu_bipred_search",
     "xvcgpu_cu_info_from_me", "xvcgpu_recon_from_me", "xvcgpu_residual_batch",
     "xvcgpu_fwd_transform_batch", "xvcgpu_inv_transform_batch",
     "xvcgpu_deblock", "xvcgpu_deblock_rows", "xvcgpu_picture_ssd", "xvcgpu_get_transform_matrix",
@@ -127,6 +135,8 @@ def load_library():
         "xvcgpu_me_search_sized": [_vp, _vp, _vp, C.c_int, _vp, C.c_int, _vp, C.c_int],
         "xvcgpu_mc_batch": [_vp, _vp, _vp, _vp, C.c_int],
         "xvcgpu_mc_from_me": [_vp, _vp, _vp, _vp, _vp, C.c_int],
+        "xvcgpu_mc_bipred_batch": [_vp, _vp, _vp, _vp, _vp, C.c_int],
+        "xvcgpu_bipred_search": [_vp, _vp, _vp, _vp, _vp, C.c_int, _vp, C.c_int],
         "xvcgpu_cu_info_from_me": [_vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int,
                                    C.c_int, C.c_int, _vp],
         "xvcgpu_recon_from_me": [_vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int,
@@ -322,6 +332,16 @@ class Context:
         self._check(self.lib.xvcgpu_mc_batch(self.h, ref.h_pic, pred.h_pic,
                                              d_blocks, n))
 
+    def mc_bipred_batch_dev(self, ref0, ref1, pred, d_blocks, n):
+        self._check(self.lib.xvcgpu_mc_bipred_batch(
+            self.h, ref0.h_pic, ref1.h_pic, pred.h_pic, d_blocks, n))
+
+    def bipred_search_dev(self, orig, ref_other, ref_search, d_jobs, n, d_results,
+                          max_size=64):
+        self._check(self.lib.xvcgpu_bipred_search(
+            self.h, orig.h_pic, ref_other.h_pic, ref_search.h_pic, d_jobs, n,
+            d_results, max_size))
+
     def mc_from_me_dev(self, ref, pred, d_blocks, d_results, n):
         self._check(self.lib.xvcgpu_mc_from_me(self.h, ref.h_pic, pred.h_pic,
                                                d_blocks, d_results, n))
@@ -391,6 +411,23 @@ class Context:
         self.mc_batch_dev(ref, pred, db.ptr, len(blocks))
         self.sync()
         db.free()
+
+    def mc_bipred_batch(self, ref0, ref1, pred, blocks):
+        blocks = np.ascontiguousarray(blocks, MCBI_DTYPE)
+        db = self.buffer(blocks)
+        self.mc_bipred_batch_dev(ref0, ref1, pred, db.ptr, len(blocks))
+        self.sync()
+        db.free()
+
+    def bipred_search(self, orig, ref_other, ref_search, jobs):
+        jobs = np.ascontiguousarray(jobs, BI_DTYPE)
+        dj = self.buffer(jobs)
+        dr = self.buffer(np.zeros(len(jobs), MERES_DTYPE))
+        self.bipred_search_dev(orig, ref_other, ref_search, dj.ptr, len(jobs), dr.ptr)
+        out = dr.to_array(MERES_DTYPE, len(jobs))
+        dj.free()
+        dr.free()
+        return out
 
     @staticmethod
     def level_offsets(blocks):

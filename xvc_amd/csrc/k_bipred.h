@@ -1,0 +1,264 @@
+// k_bipred.h -- bi-prediction: M2 / T2 / T7 (the refinement search on the
+// int16 target 2*orig - pred_other) and I2 (two 14-bit predictions + AddAvg).
+//
+//   bipred_search_kernel  = one inner step of InterSearch::SearchBiIterative
+//     (inter_search.cc:392-433): MotionCompensation of the other list,
+//     SubtractWeighted (sample_buffer.h:147-161), then
+//     MotionEstNormal<int16 target>(kFullSearch, bipred) (:606-662) =
+//     FullSearch +-4 (:853-891) + SubpelSearch (:893-964) on that target.
+//   mc_bipred_kernel      = InterPrediction::MotionCompensation for a bi-pred
+//     CU (inter_prediction.cc:710-738): MotionCompUniPred -> int16 per list
+//     (:1156-1172, Filter*Bipred) and AddAvgBi (:1545-1547).
+//
+// One workgroup of BI_WAVES(MS) waves per job.  The candidates of a phase (81
+// full-pel positions, 9 + 8 sub-pel positions) are dealt round-robin to the
+// waves; every candidate cost is independent of the running best (see
+// k_me.h), so the ordered strict-< fold of the reference equals the minimum
+// of (cost << 8 | index).
+#ifndef XVCGPU_K_BIPRED_H_
+#define XVCGPU_K_BIPRED_H_
+
+#include "dev_common.h"
+#include "dev_tables.h"
+#include "k_me.h"
+#include "k_metric.h"
+#include "k_recon.h"
+#include "xvcgpu_internal.h"
+
+#define BI_WAVES(MS) ((MS) > 32 ? 3 : 4)
+
+template <int MS>
+struct __attribute__((aligned(16))) BiShared {
+  int16_t target[MS * MS];  // row stride w
+  struct {
+    int16_t tmp[MS * (MS + 7)];
+    uint16_t pred[MS * MS];
+  } wv[BI_WAVES(MS)];
+  unsigned long long key[BI_WAVES(MS)];
+  uint32_t dist[18];
+};
+
+// MotionCompensationMv of one luma block into LDS (clip, split, interpolate).
+__device__ __forceinline__ void bi_mc_luma(int bd, const xvcgpu_me_block &b,
+                                           const PlaneView &pr, int mx, int my,
+                                           int16_t *tmp, uint16_t *pred) {
+  d_clip_mv(b.x, b.y, pr.w, pr.h, mx, my);
+  const uint16_t *r = pr.p + (ptrdiff_t)(b.y + (my >> 4)) * pr.stride + b.x + (mx >> 4);
+  wave_interp_block<false>(bd, b.w, b.h, mx & 15, my & 15, r, pr.stride, tmp, pred);
+}
+
+template <int MS>
+__global__ void __launch_bounds__(64 * BI_WAVES(MS))
+bipred_search_kernel(PlaneView orig, PlaneView ref_other, PlaneView ref_search,
+                     int bd, const xvcgpu_bi_block *jobs, int n,
+                     xvcgpu_me_result *out) {
+  constexpr int NW = BI_WAVES(MS);
+  __shared__ BiShared<MS> s;
+  const int ji = xcd_job_index(blockIdx.x, n);
+  if (ji < 0) return;
+  const xvcgpu_bi_block job = jobs[ji];
+  const xvcgpu_me_block &b = job.blk;
+  {  // block-size class of this kernel instance (LDS footprint)
+    const int m = b.w > b.h ? b.w : b.h;
+    if ((MS == 16 && m > 16) || (MS == 32 && (m <= 16 || m > 32)) || (MS == 64 && m <= 32))
+      return;
+  }
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int w = b.w, h = b.h, lw = 31 - __clz(w);
+  int16_t *tmp = s.wv[wave].tmp;
+  uint16_t *pred = s.wv[wave].pred;
+
+  // prediction from the other list, then target = 2*orig - pred
+  if (wave == 0)
+    bi_mc_luma(bd, b, ref_other, job.other_mv_x, job.other_mv_y, tmp, pred);
+  __syncthreads();
+  {
+    const uint16_t *o = orig.p + (ptrdiff_t)b.y * orig.stride + b.x;
+    const uint16_t *p0 = s.wv[0].pred;
+    for (int i = threadIdx.x; i < w * h; i += 64 * NW)
+      s.target[i] = (int16_t)(2 * (int)o[(ptrdiff_t)(i >> lw) * orig.stride + (i & (w - 1))] -
+                              (int)p0[i]);
+  }
+  __syncthreads();
+
+  // FullSearch: window = DetermineMinMaxMv(mv_bootstrap, 4)
+  int mnx, mny, mxx, mxy;
+  d_min_max_mv(b.x, b.y, ref_search.w, ref_search.h, job.boot_mv_x, job.boot_mv_y, 4,
+               mnx, mny, mxx, mxy);
+  const int nx = mxx - mnx + 1, ny = mxy - mny + 1;
+  const int down = b.fullpel_mv ? 2 : 0;
+  const uint16_t *rcu = ref_search.p + (ptrdiff_t)b.y * ref_search.stride + b.x;
+  unsigned long long best = ~0ull;
+  for (int c = wave; c < nx * ny; c += NW) {
+    const int my = mny + c / nx, mx = mnx + c % nx;
+    const uint16_t *r = rcu + (ptrdiff_t)my * ref_search.stride + mx;
+    unsigned long long dist;
+    if (h > 8)  // kSadFast
+      dist = ((unsigned long long)(long long)wave_sad(w, h / 2, 2, s.target, w, r,
+                                                      ref_search.stride) * 2) >> (bd - 8);
+    else
+      dist = (unsigned long long)(long long)wave_sad(w, h, 1, s.target, w, r,
+                                                     ref_search.stride) >> (bd - 8);
+    const uint32_t bits = d_mvd_bits_fullpel(b.mvp_x, b.mvp_y, mx, my, down);
+    const unsigned long long cost = dist + ((b.lambda16 * bits) >> 16);
+    const unsigned long long key = (cost << 8) | (unsigned)c;
+    best = key < best ? key : best;
+  }
+  if (lane == 0) s.key[wave] = best;
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < NW; k++) best = s.key[k] < best ? s.key[k] : best;
+  const int fc = (int)(best & 0xff);
+  const int fpx = mnx + fc % nx, fpy = mny + fc / nx;
+  __syncthreads();
+
+  int bx = fpx * 16, by = fpy * 16;
+  uint32_t bdist;
+  if (b.fullpel_mv) {
+    if (wave == 0) {
+      bi_mc_luma(bd, b, ref_search, bx, by, tmp, pred);
+      wave_sync();
+      const uint32_t d = (uint32_t)wave_satd(bd, w, h, 0, s.target, w, pred, w);
+      if (lane == 0) s.dist[0] = d;
+    }
+    __syncthreads();
+    bdist = s.dist[0];
+  } else {
+    unsigned long long carry = ~0ull;  // best cost so far (key form, idx 0)
+    for (int pass = 0; pass < 2; pass++) {
+      const int scale = pass == 0 ? 8 : 4;
+      best = ~0ull;
+      for (int i = pass + wave; i < 9; i += NW) {
+        const int8_t *d = pass == 0 ? kSubpelOff[0][i] : kSubpelOff[1][i];
+        const int mx = bx + d[0] * scale, my = by + d[1] * scale;
+        bi_mc_luma(bd, b, ref_search, mx, my, tmp, pred);
+        wave_sync();
+        const uint32_t dist = (uint32_t)wave_satd(bd, w, h, 0, s.target, w, pred, w);
+        wave_sync();
+        const uint32_t bits = d_mvd_bits(b.mvp_x, b.mvp_y, mx, my, 0);
+        const unsigned long long cost =
+            (unsigned long long)dist + ((b.lambda16 * bits) >> 16);
+        const unsigned long long key = (cost << 8) | (unsigned)i;
+        best = key < best ? key : best;
+        if (lane == 0) s.dist[pass * 9 + i] = dist;
+      }
+      if (lane == 0) s.key[wave] = best;
+      __syncthreads();
+      best = carry;
+#pragma unroll
+      for (int k = 0; k < NW; k++) best = s.key[k] < best ? s.key[k] : best;
+      const int bi = (int)(best & 0xff);
+      if (pass == 0 || bi != 0) {
+        const int8_t *d = pass == 0 ? kSubpelOff[0][bi] : kSubpelOff[1][bi];
+        bdist = s.dist[pass * 9 + bi];
+        bx += d[0] * scale;
+        by += d[1] * scale;
+      }
+      carry = best & ~0xffull;  // same cost, index 0: later equal costs lose
+      __syncthreads();
+    }
+  }
+  if (threadIdx.x == 0) {
+    xvcgpu_me_result r;
+    r.fullpel_x = fpx;
+    r.fullpel_y = fpy;
+    r.mv_x = bx;
+    r.mv_y = by;
+    r.fullpel_cost = 0;
+    r.subpel_dist = bdist >> 1;  // inter_search.cc:660
+    out[ji] = r;
+  }
+}
+
+// MotionCompUniPred -> int16 (14-bit, offset removed) by the workgroup
+// (inter_prediction.cc:1156-1172; FilterCopyBipred :1462-1473; shift/offset
+// rules inter_prediction.h:218-254).  tmp: w * (h + N - 1); dst stride w.
+// Contains __syncthreads(): call uniformly.
+template <bool CHROMA>
+__device__ __forceinline__ void wg_interp_block_bipred(int bd, int w, int h, int fx,
+                                                       int fy, const uint16_t *ref,
+                                                       int rs, int16_t *tmp,
+                                                       int16_t *dst) {
+  constexpr int N = CHROMA ? 4 : 8;
+  constexpr int BACK = N / 2 - 1;
+  const int tid = threadIdx.x, nt = blockDim.x;
+  const int lw = 31 - __clz(w);
+  const int16_t *fh = CHROMA ? kChromaTaps[fx] : kLumaTaps[fx];
+  const int16_t *fv = CHROMA ? kChromaTaps[fy] : kLumaTaps[fy];
+  const int head = 14 - bd;
+  const int sh1 = 6 - head, off1 = -(8192 << sh1);  // Sample -> int16
+  if (fx == 0 && fy == 0) {
+    for (int i = tid; i < w * h; i += nt) {
+      const int16_t v = (int16_t)(ref[(ptrdiff_t)(i >> lw) * rs + (i & (w - 1))] << head);
+      dst[i] = (int16_t)(v - (int16_t)8192);
+    }
+    return;
+  }
+  if (fy == 0 || fx == 0) {
+    const int16_t *f = fy == 0 ? fh : fv;
+    const ptrdiff_t step = fy == 0 ? 1 : rs;
+    for (int i = tid; i < w * h; i += nt) {
+      const uint16_t *s = ref + (ptrdiff_t)(i >> lw) * rs + (i & (w - 1)) - BACK * step;
+      int sum = 0;
+#pragma unroll
+      for (int k = 0; k < N; k++) sum += (int)s[k * step] * f[k];
+      dst[i] = (int16_t)((sum + off1) >> sh1);
+    }
+    return;
+  }
+  for (int i = tid; i < w * (h + N - 1); i += nt) {
+    const uint16_t *s = ref + (ptrdiff_t)((i >> lw) - BACK) * rs + (i & (w - 1)) - BACK;
+    int sum = 0;
+#pragma unroll
+    for (int k = 0; k < N; k++) sum += (int)s[k] * fh[k];
+    tmp[i] = (int16_t)((sum + off1) >> sh1);
+  }
+  __syncthreads();
+  for (int i = tid; i < w * h; i += nt) {  // int16 -> int16: shift 6, offset 0
+    const int16_t *s = tmp + i;
+    int sum = 0;
+#pragma unroll
+    for (int k = 0; k < N; k++) sum += (int)s[k * w] * fv[k];
+    dst[i] = (int16_t)(sum >> 6);
+  }
+}
+
+// grid: n; block: 256.  ref0 / ref1 are the list-0 / list-1 pictures.
+__global__ void __launch_bounds__(256)
+mc_bipred_kernel(PicView ref0, PicView ref1, PicView pred,
+                 const xvcgpu_mc_bi_block *blocks, int n) {
+  __shared__ int16_t tmp[64 * 71];
+  __shared__ int16_t p[2][64 * 64];
+  const int bi = blockIdx.x;
+  if (bi >= n) return;
+  const xvcgpu_mc_bi_block b = blocks[bi];
+  const int bd = ref0.bd;
+  const int cs = b.comp ? 1 : 0, shift = 4 + cs;
+  const int cx = b.x >> cs, cy = b.y >> cs, cw = b.w >> cs, ch = b.h >> cs;
+  for (int l = 0; l < 2; l++) {
+    int mx = l ? b.mv1_x : b.mv0_x, my = l ? b.mv1_y : b.mv0_y;
+    const PlaneView pr = l ? ref1.c[b.comp] : ref0.c[b.comp];
+    d_clip_mv(b.x, b.y, ref0.c[0].w, ref0.c[0].h, mx, my);
+    const int fx = mx & ((1 << shift) - 1), fy = my & ((1 << shift) - 1);
+    const uint16_t *r = pr.p + (ptrdiff_t)(cy + (my >> shift)) * pr.stride + cx + (mx >> shift);
+    __syncthreads();  // tmp reuse
+    if (b.comp)
+      wg_interp_block_bipred<true>(bd, cw, ch, fx, fy, r, pr.stride, tmp, p[l]);
+    else
+      wg_interp_block_bipred<false>(bd, cw, ch, fx, fy, r, pr.stride, tmp, p[l]);
+  }
+  __syncthreads();
+  // AddAvgBi (inter_prediction.cc:1545-1547)
+  const int head = 14 - bd;
+  const int sh = (head > 2 ? head : 2) + 1;
+  const int off = (1 << (sh - 1)) + 2 * 8192;
+  const int smax = (1 << bd) - 1;
+  const PlaneView pd = pred.c[b.comp];
+  uint16_t *dst = pd.p + (ptrdiff_t)cy * pd.stride + cx;
+  const int lw = 31 - __clz(cw);
+  for (int i = threadIdx.x; i < cw * ch; i += 256)
+    dst[(ptrdiff_t)(i >> lw) * pd.stride + (i & (cw - 1))] =
+        d_clip_bd(((int)p[0][i] + (int)p[1][i] + off) >> sh, smax);
+}
+
+#endif  // XVCGPU_K_BIPRED_H_

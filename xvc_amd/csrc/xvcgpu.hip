@@ -16,6 +16,7 @@
 #include "k_tx.h"
 #include "k_tx2.h"
 #include "k_recon.h"
+#include "k_bipred.h"
 #include "xvcgpu_internal.h"
 
 namespace {
@@ -469,6 +470,50 @@ xvcgpu_status xvcgpu_mc_batch(xvcgpu_ctx *ctx, const xvcgpu_picture *ref,
   hipLaunchKernelGGL(mc_batch_kernel, dim3(n), dim3(256), 0, ctx->stream, ref->v,
                      pred->v, d_blocks, n);
   CHECK_LAUNCH(ctx, "mc_batch");
+  return XVCGPU_OK;
+}
+
+xvcgpu_status xvcgpu_mc_bipred_batch(xvcgpu_ctx *ctx, const xvcgpu_picture *ref0,
+                                     const xvcgpu_picture *ref1, xvcgpu_picture *pred,
+                                     const xvcgpu_mc_bi_block *d_blocks, int n) {
+  if (!ctx || !ref0 || !ref1 || !pred || n < 0 || (n && !d_blocks))
+    return XVCGPU_INVALID_ARGUMENT;
+  if (pred->w != ref0->w || pred->h != ref0->h || ref1->w != ref0->w ||
+      ref1->h != ref0->h || ref1->bd != ref0->bd)
+    return fail(ctx, XVCGPU_INVALID_ARGUMENT, "picture mismatch");
+  if (n == 0) return XVCGPU_OK;
+  hipLaunchKernelGGL(mc_bipred_kernel, dim3(n), dim3(256), 0, ctx->stream, ref0->v,
+                     ref1->v, pred->v, d_blocks, n);
+  CHECK_LAUNCH(ctx, "mc_bipred_batch");
+  return XVCGPU_OK;
+}
+
+xvcgpu_status xvcgpu_bipred_search(xvcgpu_ctx *ctx, const xvcgpu_picture *orig,
+                                   const xvcgpu_picture *ref_other,
+                                   const xvcgpu_picture *ref_search,
+                                   const xvcgpu_bi_block *d_jobs, int n,
+                                   xvcgpu_me_result *d_results, int max_block_size) {
+  if (!ctx || !orig || !ref_other || !ref_search || n < 0 ||
+      (n && (!d_jobs || !d_results)) || max_block_size < 4 || max_block_size > 64)
+    return XVCGPU_INVALID_ARGUMENT;
+  if (orig->w != ref_other->w || orig->h != ref_other->h ||
+      orig->bd != ref_other->bd || orig->w != ref_search->w ||
+      orig->h != ref_search->h || orig->bd != ref_search->bd)
+    return fail(ctx, XVCGPU_INVALID_ARGUMENT, "picture mismatch");
+  if (n == 0) return XVCGPU_OK;
+  const dim3 grid((n + 7) / 8 * 8);
+  hipLaunchKernelGGL(bipred_search_kernel<16>, grid, dim3(64 * BI_WAVES(16)), 0,
+                     ctx->stream, orig->v.c[0], ref_other->v.c[0], ref_search->v.c[0],
+                     orig->bd, d_jobs, n, d_results);
+  if (max_block_size > 16)
+    hipLaunchKernelGGL(bipred_search_kernel<32>, grid, dim3(64 * BI_WAVES(32)), 0,
+                       ctx->stream, orig->v.c[0], ref_other->v.c[0],
+                       ref_search->v.c[0], orig->bd, d_jobs, n, d_results);
+  if (max_block_size > 32)
+    hipLaunchKernelGGL(bipred_search_kernel<64>, grid, dim3(64 * BI_WAVES(64)), 0,
+                       ctx->stream, orig->v.c[0], ref_other->v.c[0],
+                       ref_search->v.c[0], orig->bd, d_jobs, n, d_results);
+  CHECK_LAUNCH(ctx, "bipred_search");
   return XVCGPU_OK;
 }
 

@@ -142,6 +142,19 @@ class InterSearch {
                                 static_cast<int>(blocks.size()), r.data()));
     return r.ToHost();
   }
+  // One SearchBiIterative refinement step per job (inter_search.cc:392-433):
+  // ref_other = picture of the list whose MV is fixed (job.other_mv),
+  // ref_search = picture of the list being refined.
+  std::vector<xvcgpu_me_result> SearchBiStepBatch(
+      const Picture &orig_pic, const Picture &ref_other, const Picture &ref_search,
+      const std::vector<xvcgpu_bi_block> &jobs) const {
+    DeviceArray<xvcgpu_bi_block> d(ctx_, jobs);
+    DeviceArray<xvcgpu_me_result> r(ctx_, jobs.size());
+    ctx_.Check(xvcgpu_bipred_search(ctx_.get(), orig_pic.get(), ref_other.get(),
+                                    ref_search.get(), d.data(),
+                                    static_cast<int>(jobs.size()), r.data(), 64));
+    return r.ToHost();
+  }
 
  private:
   const Context &ctx_;
@@ -156,6 +169,16 @@ class InterPrediction {
     DeviceArray<xvcgpu_mc_block> d(ctx_, blocks);
     ctx_.Check(xvcgpu_mc_batch(ctx_.get(), ref_pic.get(), pred->get(), d.data(),
                                static_cast<int>(blocks.size())));
+    ctx_.Sync();
+  }
+  // InterPrediction::MotionCompensation for bi-pred CUs (two lists + AddAvg).
+  void MotionCompensationBiBatch(const Picture &ref_l0, const Picture &ref_l1,
+                                 Picture *pred,
+                                 const std::vector<xvcgpu_mc_bi_block> &blocks) const {
+    DeviceArray<xvcgpu_mc_bi_block> d(ctx_, blocks);
+    ctx_.Check(xvcgpu_mc_bipred_batch(ctx_.get(), ref_l0.get(), ref_l1.get(),
+                                      pred->get(), d.data(),
+                                      static_cast<int>(blocks.size())));
     ctx_.Sync();
   }
 
