@@ -11,7 +11,9 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libxvcgpu.so")
+# XVCGPU_LIB: developer knob to load an alternative build of the same library
+# (kernel tuning experiments); always a HIP build, never a CPU path.
+LIB_PATH = os.environ.get("XVCGPU_LIB") or os.path.join(HERE, "libxvcgpu.so")
 
 BORDER_LUMA = 128
 BORDER_CHROMA = 64

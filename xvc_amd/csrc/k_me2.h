@@ -91,12 +91,13 @@ __device__ __forceinline__ void wave_sync() {
 }
 #define ME2_LANE ((int)(threadIdx.x & 63))
 
-template <int MS>
-struct __attribute__((aligned(16))) Me2Shared {
+// SUB = false: layout of a full-pel-only kernel instance (orig + cost).
+template <int MS, bool SUB>
+struct __attribute__((aligned(16))) Me2SharedT {
   uint16_t orig[MS * MS];                   // row stride w
-  uint16_t win[(MS + 8) * (MS + 16)];       // rows -4..h+3, cols -8..w+7
-  int16_t hint[3][(MS + 8) * MS];           // 14-bit H-filtered, rows -4..h+3
-  int16_t hh[3][(MS + 8) * MS];             // Sample-rounded H-filtered
+  uint16_t win[SUB ? (MS + 8) * (MS + 16) : 8];  // rows -4..h+3, cols -8..w+7
+  int16_t hint[3][SUB ? (MS + 8) * MS : 8];  // 14-bit H-filtered, rows -4..h+3
+  int16_t hh[3][SUB ? (MS + 8) * MS : 8];    // Sample-rounded H-filtered
   uint32_t cost[128];
   // per sub-pel candidate: plane offset (int16 units from `orig`), stride,
   // rounding offset, shift, 8 taps
@@ -104,6 +105,8 @@ struct __attribute__((aligned(16))) Me2Shared {
   int16_t cand_taps[12][8];
   uint32_t dist[12];
 };
+template <int MS>
+using Me2Shared = Me2SharedT<MS, true>;
 
 // ---- full-pel SAD evaluation: 4 lanes per candidate ------------------------
 // s.cost[0..n) holds packed positions ((y << 16) | (x & 0xffff), or
@@ -246,8 +249,8 @@ __device__ __forceinline__ void me2_pattern_at(const Me2Pattern &p, int idx, int
 // Evaluate pattern entries [lo, total) of the diamond list around (bx,by):
 // afterwards lane l holds the keys of candidates l and l+64
 // ((cost << 7) | index, or ME2_NOKEY when outside the window).
-template <int MS>
-__device__ __forceinline__ void me2_eval_diamonds(const MeCtx &c, Me2Shared<MS> &s,
+template <class SH>
+__device__ __forceinline__ void me2_eval_diamonds(const MeCtx &c, SH &s,
                                                   const Me2Pattern &p, int bx, int by,
                                                   int lo, int total, uint32_t &key0,
                                                   uint32_t &key1) {
@@ -515,14 +518,17 @@ __device__ __forceinline__ void me2_subpel_eval(Me2Shared<MS> &s, const MeCtx &c
 
 // grid: n jobs; block: 64 threads (one wave).  Handles the jobs whose block
 // fits class MS (max(w,h) <= MS) and no smaller class.
-template <int MS>
+// PH = phases compiled in.  (Forcing more waves per SIMD onto the full-pel
+// instance via a register cap spills and measured slower: 64 -> 88..149 us.)
+template <int MS, int PH>
 __global__ void __launch_bounds__(64 * ME2_WAVES(MS))
-me_search_wave_kernel(PicView orig, PicView ref, int flags,
+me_search_wave_kernel(PicView orig, PicView ref,
                       const xvcgpu_me_block *blocks, int n,
                       xvcgpu_me_result *results, const TzCand *tz_pattern) {
   constexpr int WPG = ME2_WAVES(MS);
-  __shared__ Me2Shared<MS> s_all[WPG];
-  Me2Shared<MS> &s = s_all[threadIdx.x >> 6];
+  typedef Me2SharedT<MS, (PH & XVCGPU_ME_SUBPEL) != 0> Shared;
+  __shared__ Shared s_all[WPG];
+  Shared &s = s_all[threadIdx.x >> 6];
   // job = (workgroup, wave); workgroups are XCD-swizzled, waves consecutive
   const int n_wg = (n + WPG - 1) / WPG;
   const int wg = xcd_job_index(blockIdx.x, n_wg);
@@ -562,7 +568,7 @@ me_search_wave_kernel(PicView orig, PicView ref, int flags,
   }
 
   xvcgpu_me_result res;
-  if (flags & XVCGPU_ME_FULLPEL) {
+  if constexpr ((PH & XVCGPU_ME_FULLPEL) != 0) {
     const int range = b.search_range;
     d_min_max_mv(b.x, b.y, pic_w, pic_h, b.mvp_x, b.mvp_y, range, c.min_x,
                  c.min_y, c.max_x, c.max_y);
@@ -776,7 +782,7 @@ me_search_wave_kernel(PicView orig, PicView ref, int flags,
   res.mv_y = res.fullpel_y * 16;
   res.subpel_dist = 0;
 
-  if (flags & XVCGPU_ME_SUBPEL) {
+  if constexpr ((PH & XVCGPU_ME_SUBPEL) != 0) {
     const int w = c.w, h = c.h, ws = w + 16;
     const int fpx = res.fullpel_x, fpy = res.fullpel_y;
     // stage the reference window: rows -4..h+3, cols -8..w+7 around the

@@ -439,15 +439,27 @@ xvcgpu_status xvcgpu_me_search_sized(xvcgpu_ctx *ctx, const xvcgpu_picture *orig
     return fail(ctx, XVCGPU_INVALID_ARGUMENT, "picture mismatch");
   if (n == 0) return XVCGPU_OK;
   // one wave per job; the LDS footprint is a compile-time function of the
-  // block-size class, each class kernel skips the jobs of the other classes
-  hipLaunchKernelGGL(me_search_wave_kernel<16>, me2_grid(n, ME2_WAVES(16)), dim3(64 * ME2_WAVES(16)), 0, ctx->stream,
-                     orig->v, ref->v, flags, d_blocks, n, d_results, ctx->d_tz_pattern);
-  if (max_block_size > 16)
-    hipLaunchKernelGGL(me_search_wave_kernel<32>, me2_grid(n, ME2_WAVES(32)), dim3(64 * ME2_WAVES(32)), 0, ctx->stream,
-                       orig->v, ref->v, flags, d_blocks, n, d_results, ctx->d_tz_pattern);
-  if (max_block_size > 32)
-    hipLaunchKernelGGL(me_search_wave_kernel<64>, me2_grid(n, ME2_WAVES(64)), dim3(64 * ME2_WAVES(64)), 0, ctx->stream,
-                       orig->v, ref->v, flags, d_blocks, n, d_results, ctx->d_tz_pattern);
+  // block-size class, each class kernel skips the jobs of the other classes.
+  // The phases are compile-time instances: a single-phase call gets a kernel
+  // with only that phase's registers and LDS; the usual both-phases call runs
+  // the fused instance (measured faster than two launches: waves in the
+  // latency-bound full-pel search overlap waves in the VALU-bound sub-pel
+  // search on the same SIMD).
+#define ME_LAUNCH(MS, PH)                                                          \
+  hipLaunchKernelGGL((me_search_wave_kernel<MS, PH>), me2_grid(n, ME2_WAVES(MS)),  \
+                     dim3(64 * ME2_WAVES(MS)), 0, ctx->stream, orig->v, ref->v,    \
+                     d_blocks, n, d_results, ctx->d_tz_pattern)
+#define ME_LAUNCH_CLASS(MS)                                \
+  do {                                                     \
+    if ((flags & 3) == 3) ME_LAUNCH(MS, 3);                \
+    else if (flags & XVCGPU_ME_FULLPEL) ME_LAUNCH(MS, 1);  \
+    else ME_LAUNCH(MS, 2);                                 \
+  } while (0)
+  ME_LAUNCH_CLASS(16);
+  if (max_block_size > 16) ME_LAUNCH_CLASS(32);
+  if (max_block_size > 32) ME_LAUNCH_CLASS(64);
+#undef ME_LAUNCH_CLASS
+#undef ME_LAUNCH
   CHECK_LAUNCH(ctx, "me_search");
   return XVCGPU_OK;
 }
