@@ -13,6 +13,8 @@ O, R = ctx.picture(W, H, bd), ctx.picture(W, H, bd)
 R.upload(pad(clip.frame(0)), border); O.upload(pad(clip.frame(1)), border)
 fp = pipeline.FramePass(ctx, W, H, bd)
 d = fp.desc
+if flags != 3:  # real full-pel results for a sub-pel-only run
+    ctx.me_search_dev(O, R, 3, fp.d_me.ptr, d.n_cus, fp.d_res.ptr, 16)
 for _ in range(5):
     ctx.me_search_dev(O, R, flags, fp.d_me.ptr, d.n_cus, fp.d_res.ptr, 16)
 ctx.sync()

@@ -30,6 +30,7 @@
 #include "dev_common.h"
 #include "dev_tables.h"
 #include "k_me.h"
+#include "k_subpel.h"
 #include "xvcgpu_internal.h"
 
 // ---- cross-lane helpers (DPP / swizzle; no LDS traffic) ---------------------
@@ -80,6 +81,9 @@ __device__ __forceinline__ int wave_reduce_add_i32(int v) {
 #define ME2_NOKEY 0xffffffffu
 // independent jobs (waves) per workgroup, by block-size class (LDS budget)
 #define ME2_WAVES(MS) ((MS) > 32 ? 2 : 4)
+// waves per SIMD the register allocator leaves room for: the 16-class fits 4
+// workgroups per CU by LDS, so cap its registers at 128 (measured +3 %)
+#define ME2_MIN_WAVES(MS) ((MS) <= 16 ? 4 : 1)
 
 // Orders LDS traffic between the lanes of ONE wave (jobs never share data
 // across waves, so no workgroup barrier is ever needed): LDS requests of a
@@ -104,6 +108,8 @@ struct __attribute__((aligned(16))) Me2SharedT {
   int cand_plane[12], cand_stride[12], cand_off[12], cand_shift[12];
   int16_t cand_taps[12][8];
   uint32_t dist[12];
+  SpCand sp[SUB ? 10 : 1];                  // fast path (k_subpel.h)
+  int16_t taps[SUB ? 16 : 1][8];            // LDS copy of kLumaTaps
 };
 template <int MS>
 using Me2Shared = Me2SharedT<MS, true>;
@@ -441,6 +447,10 @@ __device__ __forceinline__ void me2_subpel_mv(int pass, int i, int base_x, int b
   my = base_y + kSubpelOff[pass][k][1] * scale;
 }
 
+__device__ __forceinline__ bool me2_subpel_fast(int w, int h, int bd) {
+  return w == h && w >= 8 && bd <= 10;
+}
+
 // Evaluate the SATD of the n = 9 - pass candidates of a sub-pel pass (or, with
 // pass < 0, of the single MV (base_x, base_y)) around the staged full-pel
 // position (fpx,fpy); raw tile sums in s.dist[0..n).  Arguments wave-uniform.
@@ -461,7 +471,10 @@ __device__ __forceinline__ void me2_subpel_eval(Me2Shared<MS> &s, const MeCtx &c
   const int cfx = mx & 15, cfy = my & 15;
   // distinct horizontal phases with fx != 0 -> plane slots (<= 3)
   const int mykey = (cpx + 1) * 16 + cfx;
-  const bool need = lane < n && cfx != 0;
+  // fast path (k_subpel.h): square block, 8x8 tiles, 16-bit-safe residuals;
+  // the caller has transposed s.orig to column-major for it
+  const bool fastp = me2_subpel_fast(w, h, bd);
+  const bool need = lane < n && (fastp || cfx != 0);
   int myslot = -1, nslots = 0, slot_key[3] = {0, 0, 0};
 #pragma unroll
   for (int k = 0; k < 3; k++) {
@@ -475,6 +488,27 @@ __device__ __forceinline__ void me2_subpel_eval(Me2Shared<MS> &s, const MeCtx &c
     }
   }
   wave_sync();  // previous readers of the planes / tables are done
+  if (fastp) {
+#pragma unroll
+    for (int k = 0; k < 3; k++)
+      if (k < nslots)
+        sp_build_planes(s.win, s.hint[k], s.hh[k], s.taps, bd, w, h,
+                        (slot_key[k] >> 4) - 1, slot_key[k] & 15);
+    if (lane < n) {
+      const int16_t *base = reinterpret_cast<const int16_t *>(s.orig);
+      SpCand &cd = s.sp[lane];
+      const bool two_stage = cfx != 0 && cfy != 0;
+      cd.plane = (int)((two_stage ? s.hint[0] : s.hh[0]) - base) + myslot * (MS + 8) * MS;
+      cd.sh = two_stage ? 6 + (14 - bd) : 6;
+      cd.off = two_stage ? (8192 << 6) + (1 << (cd.sh - 1)) : 32;
+      sp_fill_taps(cd, s.taps, cfy, cpy + 1);
+      s.dist[lane] = 0;
+    }
+    wave_sync();
+    sp_satd_pairs(reinterpret_cast<const int16_t *>(s.orig), s.sp, s.orig, s.dist, bd, w, h, n);
+    wave_sync();
+    return;
+  }
 #pragma unroll
   for (int k = 0; k < 3; k++)
     if (k < nslots)
@@ -521,7 +555,7 @@ __device__ __forceinline__ void me2_subpel_eval(Me2Shared<MS> &s, const MeCtx &c
 // PH = phases compiled in.  (Forcing more waves per SIMD onto the full-pel
 // instance via a register cap spills and measured slower: 64 -> 88..149 us.)
 template <int MS, int PH>
-__global__ void __launch_bounds__(64 * ME2_WAVES(MS))
+__global__ void __launch_bounds__(64 * ME2_WAVES(MS), ME2_MIN_WAVES(MS))
 me_search_wave_kernel(PicView orig, PicView ref,
                       const xvcgpu_me_block *blocks, int n,
                       xvcgpu_me_result *results, const TzCand *tz_pattern) {
@@ -560,6 +594,9 @@ me_search_wave_kernel(PicView orig, PicView ref,
   c.down = b.fullpel_mv ? 2 : 0;
   c.lambda = b.lambda16;
 
+  if constexpr ((PH & XVCGPU_ME_SUBPEL) != 0)  // per-lane phase lookups come from LDS
+    reinterpret_cast<uint32_t *>(&s.taps[0][0])[lane] =
+        reinterpret_cast<const uint32_t *>(&kLumaTaps[0][0])[lane];
   {  // stage the original block
     const int lw = 31 - __clz(c.w);
     const uint16_t *o = po.p + (ptrdiff_t)b.y * po.stride + b.x;
@@ -806,6 +843,19 @@ me_search_wave_kernel(PicView orig, PicView ref,
         }
       }
     }
+    if (me2_subpel_fast(w, h, c.bd)) {
+      // column-major original for k_subpel.h: swap across the diagonal
+      wave_sync();
+      const int lw = 31 - __clz(w);
+      for (int i = lane; i < w * h; i += 64) {
+        const int y = i >> lw, x = i & (w - 1);
+        if (x < y) {
+          const uint16_t a = s.orig[i], bb = s.orig[x * w + y];
+          s.orig[i] = bb;
+          s.orig[x * w + y] = a;
+        }
+      }
+    }
     if (b.fullpel_mv) {
       me2_subpel_eval(s, c, b, pic_w, pic_h, fpx, fpy, -1, res.mv_x, res.mv_y);
       res.subpel_dist = s.dist[0] >> (c.bd - 8);
@@ -816,15 +866,21 @@ me_search_wave_kernel(PicView orig, PicView ref,
         const int base_x = best_x, base_y = best_y;
         const int n = 9 - pass;
         me2_subpel_eval(s, c, b, pic_w, pic_h, fpx, fpy, pass, base_x, base_y);
-        for (int i = 0; i < n; i++) {
+        // the reference's ordered strict-< fold = (lowest cost, lowest index),
+        // one candidate per lane
+        uint32_t my_cost = 0xffffffffu;
+        if (lane < n) {
           int mx, my;
-          me2_subpel_mv(pass, i, base_x, base_y, mx, my);
-          const uint32_t dist = s.dist[i] >> (c.bd - 8);
-          const uint32_t cost =
-              dist + ((c.lambda * d_mvd_bits(b.mvp_x, b.mvp_y, mx, my, 0)) >> 16);
-          if (cost < best_cost) {
-            best_cost = cost; best_dist = dist; best_x = mx; best_y = my;
-          }
+          me2_subpel_mv(pass, lane, base_x, base_y, mx, my);
+          my_cost = (s.dist[lane] >> (c.bd - 8)) +
+                    ((c.lambda * d_mvd_bits(b.mvp_x, b.mvp_y, mx, my, 0)) >> 16);
+        }
+        const uint32_t gmin = wave_min_key(my_cost);
+        const int gi = (int)wave_min_key(my_cost == gmin ? (uint32_t)lane : 64u);
+        if (gmin < best_cost) {
+          best_cost = gmin;
+          best_dist = s.dist[gi] >> (c.bd - 8);
+          me2_subpel_mv(pass, gi, base_x, base_y, best_x, best_y);
         }
       }
       res.mv_x = best_x;
