@@ -64,6 +64,23 @@ xvcgpu_status xvcgpu_sync(xvcgpu_ctx *ctx);
 xvcgpu_status xvcgpu_timer_begin(xvcgpu_ctx *ctx);
 xvcgpu_status xvcgpu_timer_end(xvcgpu_ctx *ctx, float *elapsed_ms);
 
+/* ---- recorded call sequences (HIP graphs) --------------------------------- *
+ * The per-picture sequence of launches is short kernels (8-110 us each), so
+ * the launch path matters.  xvcgpu_record_begin() puts the context's private
+ * stream into capture: the xvcgpu_* calls that follow are recorded instead of
+ * executed (no call that synchronises - sync, timer_end, free, upload,
+ * download - may be made while recording); xvcgpu_record_end() returns the
+ * recording as a replayable handle.  xvcgpu_replay() enqueues the whole
+ * sequence with one submission; the recorded device pointers and pictures
+ * must stay alive and are used as they were passed.  This has no counterpart
+ * in the reference (it has no launch cost); it is the device-side analogue of
+ * one PictureEncoder::Encode call (picture_encoder.cc:75-160). */
+typedef struct xvcgpu_recording xvcgpu_recording;
+xvcgpu_status xvcgpu_record_begin(xvcgpu_ctx *ctx);
+xvcgpu_status xvcgpu_record_end(xvcgpu_ctx *ctx, xvcgpu_recording **out);
+xvcgpu_status xvcgpu_replay(xvcgpu_ctx *ctx, xvcgpu_recording *rec);
+void xvcgpu_recording_destroy(xvcgpu_recording *rec);
+
 /* ---- raw device memory -------------------------------------------------- */
 xvcgpu_status xvcgpu_malloc(xvcgpu_ctx *ctx, size_t bytes, void **dev_ptr);
 xvcgpu_status xvcgpu_free(xvcgpu_ctx *ctx, void *dev_ptr);

@@ -551,7 +551,7 @@ def pad_planes(planes, bd):
 
 
 @pytest.mark.parametrize("fused", [True, False])
-@pytest.mark.parametrize("size", [(352, 288), (136, 72)])
+@pytest.mark.parametrize("size", [(352, 288), (136, 72), (1920, 1080)])
 def test_frame_pass(gpu, xo, size, fused):
     """Whole frame pass (ME -> MC -> residual -> deblock -> pad -> SSD) on the
     GPU against the oracle's frame pass, two chained frames."""
@@ -586,6 +586,46 @@ def test_frame_pass(gpu, xo, size, fused):
         # next frame references this reconstruction
         ref_host = e_rec
         R, Rec = Rec, R
+    fp.destroy()
+    for p in (O, R, Rec):
+        p.destroy()
+
+
+def test_recorded_frame_pass_replay(gpu, xo):
+    """xvcgpu_record_* / xvcgpu_replay: the recorded frame pass replayed as one
+    HIP graph gives the same bytes as the oracle, on every replay."""
+    api, ctx = gpu
+    from xvc_amd import pipeline, synth
+    import oracle_frame
+    pw, ph, bd = 208, 112, 10
+    clip = synth.SyntheticClip(pw, ph, bd)
+    fp = pipeline.FramePass(ctx, pw, ph, bd, qp=32)
+    ref_host = pad_planes(clip.frame(0), bd)
+    orig_host = pad_planes(clip.frame(1), bd)
+    O, R, Rec = ctx.picture(pw, ph, bd), ctx.picture(pw, ph, bd), ctx.picture(pw, ph, bd)
+    R.upload(ref_host, BL)
+    O.upload(orig_host, BL)
+    ctx.sync()
+    rec = ctx.record(lambda: fp.run(O, R, Rec, ref_poc=0))
+    # nothing ran while recording
+    assert not np.any(Rec.download()[0])
+    e_rec, e_res, e_nnz, e_cus, e_ssd = oracle_frame.frame_pass(
+        fp.desc, bd, orig_host, ref_host, BL, ref_poc=0, lib=xo)
+    for _ in range(3):
+        ctx.replay(rec)
+        ctx.sync()
+        res, nnz, cus, ssd = fp.results()
+        assert np.array_equal(res, e_res) and np.array_equal(cus, e_cus)
+        got = Rec.download(BL)
+        for c in range(3):
+            assert np.array_equal(got[c], e_rec[c]), c
+        assert (int(ssd[0]), int(ssd[1])) == e_ssd
+    ctx.recording_destroy(rec)
+    # synchronising calls are refused while recording
+    ctx._check(ctx.lib.xvcgpu_record_begin(ctx.h))
+    h = C.c_void_p()
+    assert ctx.lib.xvcgpu_record_end(ctx.h, C.byref(h)) == 0
+    ctx.recording_destroy(h)
     fp.destroy()
     for p in (O, R, Rec):
         p.destroy()

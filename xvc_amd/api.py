@@ -60,6 +60,7 @@ assert MC_DTYPE.itemsize == 16 and CAND_DTYPE.itemsize == 12
 SYMBOLS = [
     "xvcgpu_create", "xvcgpu_destroy", "xvcgpu_last_error", "xvcgpu_version",
     "xvcgpu_set_stream", "xvcgpu_use_own_stream", "xvcgpu_sync", "xvcgpu_timer_begin", "xvcgpu_timer_end",
+    "xvcgpu_record_begin", "xvcgpu_record_end", "xvcgpu_replay", "xvcgpu_recording_destroy",
     "xvcgpu_malloc", "xvcgpu_free", "xvcgpu_memcpy_h2d", "xvcgpu_memcpy_d2h",
     "xvcgpu_memset", "xvcgpu_picture_create", "xvcgpu_picture_bytes",
     "xvcgpu_picture_wrap", "xvcgpu_picture_destroy", "xvcgpu_picture_upload",
@@ -109,6 +110,8 @@ def load_library():
     lib.xvcgpu_destroy.argtypes = [_vp]
     lib.xvcgpu_picture_destroy.restype = None
     lib.xvcgpu_picture_destroy.argtypes = [_vp]
+    lib.xvcgpu_recording_destroy.argtypes = [_vp]
+    lib.xvcgpu_recording_destroy.restype = None
     sigs = {
         "xvcgpu_create": [C.c_int, C.POINTER(_vp)],
         "xvcgpu_set_stream": [_vp, _vp],
@@ -116,6 +119,9 @@ def load_library():
         "xvcgpu_sync": [_vp],
         "xvcgpu_timer_begin": [_vp],
         "xvcgpu_timer_end": [_vp, C.POINTER(C.c_float)],
+        "xvcgpu_record_begin": [_vp],
+        "xvcgpu_record_end": [_vp, C.POINTER(_vp)],
+        "xvcgpu_replay": [_vp, _vp],
         "xvcgpu_malloc": [_vp, C.c_size_t, C.POINTER(_vp)],
         "xvcgpu_free": [_vp, _vp],
         "xvcgpu_memcpy_h2d": [_vp, _vp, _vp, C.c_size_t],
@@ -300,6 +306,23 @@ class Context:
 
     def set_stream(self, hip_stream):
         self._check(self.lib.xvcgpu_set_stream(self.h, hip_stream))
+
+    def record(self, fn):
+        """Record the xvcgpu calls made by fn() into a replayable handle."""
+        self._check(self.lib.xvcgpu_record_begin(self.h))
+        try:
+            fn()
+        finally:
+            h = _vp()
+            st = self.lib.xvcgpu_record_end(self.h, C.byref(h))
+        self._check(st)
+        return h
+
+    def replay(self, recording):
+        self._check(self.lib.xvcgpu_replay(self.h, recording))
+
+    def recording_destroy(self, recording):
+        self.lib.xvcgpu_recording_destroy(recording)
 
     def use_own_stream(self):
         self._check(self.lib.xvcgpu_use_own_stream(self.h))

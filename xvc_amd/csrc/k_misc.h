@@ -100,29 +100,53 @@ __global__ void cu_info_from_me_kernel(const xvcgpu_me_block *blocks,
 // lowest set bit of the dimension, starting at (dim & ~63) - so when a
 // dimension is a multiple of 64 its last block column/row is never visited.
 // Each visited block is one Compare(): SSD >> 2*(bd-8), summed.
-// One wave per visited block; grid: ceil(items/4); block 256.
+// One workgroup per visited block (the per-block `>> shift` needs the whole
+// block's sum): thread = 8 samples (one 16-byte load from each picture),
+// 256 / (bw / 8) rows per sweep.  grid: items; block 256.
 __global__ void __launch_bounds__(256)
 picture_ssd_kernel(PlaneView a, PlaneView b, int shift, unsigned long long *out) {
+  __shared__ unsigned long long part[4];
   const int w = a.w, h = a.h;
   const int mbx = w & ~(w - 1), mby = h & ~(h - 1);
   const int nfx = w > 64 ? (w - 64 + 63) / 64 : 0;
   const int nrx = (w - (w & ~63)) / mbx;
   const int nfy = h > 64 ? (h - 64 + 63) / 64 : 0;
-  const int nry = (h - (h & ~63)) / mby;
-  const int ncx = nfx + nrx, ncy = nfy + nry;
-  const int item = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (item >= ncx * ncy) return;
+  const int ncx = nfx + nrx;
+  const int item = blockIdx.x;
   const int ix = item % ncx, iy = item / ncx;
   int x, y, bw, bh;
   if (ix < nfx) { x = ix * 64; bw = 64; } else { x = (w & ~63) + (ix - nfx) * mbx; bw = mbx; }
   if (iy < nfy) { y = iy * 64; bh = 64; } else { y = (h & ~63) + (iy - nfy) * mby; bh = mby; }
   const uint16_t *pa = a.p + (ptrdiff_t)y * a.stride + x;
   const uint16_t *pb = b.p + (ptrdiff_t)y * b.stride + x;
-  // generic (non power-of-two widths possible for remainders? mbx/mby are
-  // powers of two by construction)
-  const uint64_t ssd = wave_ssd(bw, bh, pa, a.stride, pb, b.stride) >> shift;
-  if ((threadIdx.x & 63) == 0) {
-    atomicAdd(&out[0], (unsigned long long)ssd);
+  uint32_t acc = 0;  // <= 16 squares of 12-bit differences per thread
+  if (bw >= 8) {     // picture widths are multiples of 8
+    const int cpr = bw >> 3, lc = 31 - __clz(cpr);
+    const int c8 = (threadIdx.x & (cpr - 1)) << 3;
+    for (int r = threadIdx.x >> lc; r < bh; r += 256 >> lc) {
+      const uint4 va = *reinterpret_cast<const uint4 *>(pa + (ptrdiff_t)r * a.stride + c8);
+      const uint4 vb = *reinterpret_cast<const uint4 *>(pb + (ptrdiff_t)r * b.stride + c8);
+      const uint32_t ua[4] = {va.x, va.y, va.z, va.w}, ub[4] = {vb.x, vb.y, vb.z, vb.w};
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const int d0 = (int)(ua[k] & 0xffff) - (int)(ub[k] & 0xffff);
+        const int d1 = (int)(ua[k] >> 16) - (int)(ub[k] >> 16);
+        acc += (uint32_t)(d0 * d0) + (uint32_t)(d1 * d1);
+      }
+    }
+  } else {
+    for (int i = threadIdx.x; i < bw * bh; i += 256) {
+      const int r = i / bw, c = i - r * bw;
+      const int d = (int)pa[(ptrdiff_t)r * a.stride + c] - (int)pb[(ptrdiff_t)r * b.stride + c];
+      acc += (uint32_t)(d * d);
+    }
+  }
+  const unsigned long long ws = group_sum<64>((unsigned long long)acc);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = ws;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned long long ssd = (part[0] + part[1] + part[2] + part[3]) >> shift;
+    atomicAdd(&out[0], ssd);
     atomicAdd(&out[1], (unsigned long long)bw * bh);
   }
 }

@@ -221,6 +221,55 @@ xvcgpu_status xvcgpu_timer_end(xvcgpu_ctx *ctx, float *elapsed_ms) {
   return XVCGPU_OK;
 }
 
+struct xvcgpu_recording {
+  hipGraph_t graph;
+  hipGraphExec_t exec;
+};
+
+xvcgpu_status xvcgpu_record_begin(xvcgpu_ctx *ctx) {
+  if (!ctx) return XVCGPU_INVALID_ARGUMENT;
+  if (!ctx->own_stream)
+    return fail(ctx, XVCGPU_UNSUPPORTED, "recording needs the private stream");
+  HIP_TRY(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
+  return XVCGPU_OK;
+}
+
+xvcgpu_status xvcgpu_record_end(xvcgpu_ctx *ctx, xvcgpu_recording **out) {
+  if (!ctx || !out) return XVCGPU_INVALID_ARGUMENT;
+  *out = nullptr;
+  hipGraph_t graph = nullptr;
+  HIP_TRY(ctx, hipStreamEndCapture(ctx->stream, &graph));
+  hipGraphExec_t exec = nullptr;
+  hipError_t e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+  if (e != hipSuccess) {
+    hipGraphDestroy(graph);
+    return fail(ctx, XVCGPU_DEVICE_ERROR, "hipGraphInstantiate", e);
+  }
+  xvcgpu_recording *r = new (std::nothrow) xvcgpu_recording();
+  if (!r) {
+    hipGraphExecDestroy(exec);
+    hipGraphDestroy(graph);
+    return XVCGPU_OUT_OF_MEMORY;
+  }
+  r->graph = graph;
+  r->exec = exec;
+  *out = r;
+  return XVCGPU_OK;
+}
+
+xvcgpu_status xvcgpu_replay(xvcgpu_ctx *ctx, xvcgpu_recording *rec) {
+  if (!ctx || !rec) return XVCGPU_INVALID_ARGUMENT;
+  HIP_TRY(ctx, hipGraphLaunch(rec->exec, ctx->stream));
+  return XVCGPU_OK;
+}
+
+void xvcgpu_recording_destroy(xvcgpu_recording *rec) {
+  if (!rec) return;
+  hipGraphExecDestroy(rec->exec);
+  hipGraphDestroy(rec->graph);
+  delete rec;
+}
+
 xvcgpu_status xvcgpu_malloc(xvcgpu_ctx *ctx, size_t bytes, void **dev_ptr) {
   if (!ctx || !dev_ptr) return XVCGPU_INVALID_ARGUMENT;
   hipSetDevice(ctx->device);
@@ -700,7 +749,7 @@ xvcgpu_status xvcgpu_picture_ssd(xvcgpu_ctx *ctx, const xvcgpu_picture *a,
   const int ncy = (h > 64 ? (h - 64 + 63) / 64 : 0) + (h - (h & ~63)) / mby;
   const int items = ncx * ncy;
   if (items > 0) {
-    hipLaunchKernelGGL(picture_ssd_kernel, dim3((items + 3) / 4), dim3(256), 0,
+    hipLaunchKernelGGL(picture_ssd_kernel, dim3(items), dim3(256), 0,
                        ctx->stream, pa, pb, 2 * (shift_bitdepth - 8),
                        reinterpret_cast<unsigned long long *>(d_out));
     CHECK_LAUNCH(ctx, "picture_ssd");
