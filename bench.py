@@ -45,8 +45,8 @@ def parse():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--qp", type=int, default=32)
     ap.add_argument("--frames", type=int, default=8, help="distinct synthetic frames")
-    ap.add_argument("--cpu-frames", type=float, default=0.5,
-                    help="fraction of one picture's CUs timed on the CPU oracle")
+    ap.add_argument("--cpu-frames", type=int, default=24,
+                    help="frame passes timed on the CPU oracle (rank 0, N=1)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--graph", action="store_true",
                     help="N=1: replay one recorded HIP graph per step instead of "
@@ -62,27 +62,28 @@ def pad_planes(planes, border):
 
 
 def cpu_baseline(args, clip, bd, border):
-    """Oracle (kind "port") frame pass on the host, bounded sample: the first
-    rows of CUs of one picture, single thread."""
+    """Oracle (kind "port") on the host, single thread: `--cpu-frames` whole
+    frame passes of the same workload, chained like the GPU steps (each
+    reconstruction is the next reference) - about 10 s of CPU work."""
     import oracle_frame
     import oracle_lib as ol
     from xvc_amd import pipeline
     lib = ol.Lib("xo")
-    n_rows_total = (args.height + 15) // 16
-    rows = max(1, int(round(n_rows_total * args.cpu_frames)))
-    desc = pipeline.FrameDescriptors(args.width, args.height, args.qp,
-                                     row_range=(0, rows * 16))
-    ref, orig = pad_planes(clip.frame(0), border), pad_planes(clip.frame(1), border)
+    desc = pipeline.FrameDescriptors(args.width, args.height, args.qp)
+    n = max(1, int(args.cpu_frames))
+    frames = [pad_planes(clip.frame(i), border) for i in range(min(n, args.frames) + 1)]
+    ref = frames[0]
     t0 = time.perf_counter()
-    oracle_frame.frame_pass(desc, bd, orig, ref, border, lib=lib)
+    for i in range(n):
+        F = len(frames) - 1
+        k = i % (2 * F - 2) if F > 1 else 0
+        orig = frames[1 + (k if k < F else 2 * F - 2 - k)]
+        ref = oracle_frame.frame_pass(desc, bd, orig, ref, border, lib=lib)[0]
     dt = time.perf_counter() - t0
-    full = pipeline.FrameDescriptors(args.width, args.height, args.qp)
-    frac = desc.n_cus / full.n_cus
     return {
-        "value": frac / dt, "unit": "frames/s", "cores": 1, "kind": "port",
-        "sample": "%d of %d CUs of one %dx%d picture (%.1f s of CPU work, "
-                  "single-thread C oracle, gcc -O2)" %
-                  (desc.n_cus, full.n_cus, args.width, args.height, dt),
+        "value": n / dt, "unit": "frames/s", "cores": 1, "kind": "port",
+        "sample": "%d chained frame passes of the %dx%d workload (%.1f s of CPU work, "
+                  "single-thread C oracle, gcc -O2)" % (n, args.width, args.height, dt),
     }
 
 
@@ -187,14 +188,16 @@ def main():
     roof = None
     if rank == 0:
         d = fp.desc
-        # replay the inputs of the last timed step (ME/MC/residual are
-        # idempotent on them)
-        i_last = args.warmup + args.steps - 1
+        # Per-kernel launch durations, averaged over one whole cycle of the
+        # frame sequence (the searches are data dependent: 0.08-0.13 ms per
+        # picture): for every step of the cycle each kernel is replayed
+        # `reps` times on that step's inputs between two HIP events, then the
+        # step itself runs to advance the reconstruction chain.
         F = len(origs)
-        k_last = i_last % (2 * F - 2) if F > 1 else 0
-        o = origs[k_last if k_last < F else 2 * F - 2 - k_last]
-        ref, rec = recs[i_last % 2], recs[(i_last + 1) % 2]
-        reps = 20
+        cycle = 2 * F - 2 if F > 1 else 1
+        reps = 5
+        times = dict.fromkeys(["me_search", "recon_from_me", "deblock", "pad_border",
+                               "picture_ssd"], 0.0)
 
         def timed(fn):
             fn()
@@ -204,19 +207,24 @@ def main():
                 fn()
             return ctx.timer_end() / reps
 
-        times = {
-            "me_search": timed(lambda: ctx.me_search_dev(
+        base = args.warmup + args.steps
+        for i in range(base, base + cycle):
+            k = i % cycle
+            o = origs[k if k < F else 2 * F - 2 - k]
+            ref, rec = recs[i % 2], recs[(i + 1) % 2]
+            times["me_search"] += timed(lambda: ctx.me_search_dev(
                 o, ref, api.ME_FULLPEL | api.ME_SUBPEL, fp.d_me.ptr, d.n_cus,
-                fp.d_res.ptr, d.cu_size)),
-            "recon_from_me": timed(lambda: ctx.recon_from_me_dev(
+                fp.d_res.ptr, d.cu_size))
+            times["recon_from_me"] += timed(lambda: ctx.recon_from_me_dev(
                 o, ref, rec, fp.d_me.ptr, fp.d_res.ptr, d.n_cus, d.qp, d.qp_c, 0,
-                fp.d_nnz.ptr, fp.d_cus_own)),
-            "deblock": timed(lambda: ctx.deblock_dev(
-                rec, fp.d_cus.ptr, d.n_cus_total, fp.d_map.ptr, d.cu_map.shape[1])),
-            "pad_border": timed(lambda: ctx.pad_border(rec)),
-            "picture_ssd": timed(lambda: ctx.picture_ssd_dev(o, rec, 0, bd,
-                                                             fp.d_ssd.ptr)),
-        }
+                fp.d_nnz.ptr, fp.d_cus_own))
+            times["deblock"] += timed(lambda: ctx.deblock_dev(
+                rec, fp.d_cus.ptr, d.n_cus_total, fp.d_map.ptr, d.cu_map.shape[1]))
+            times["pad_border"] += timed(lambda: ctx.pad_border(rec))
+            times["picture_ssd"] += timed(lambda: ctx.picture_ssd_dev(o, rec, 0, bd,
+                                                                      fp.d_ssd.ptr))
+            fp.run(o, ref, rec, ref_poc=i)
+        times = {k: v / cycle for k, v in times.items()}
         dom = max(times, key=times.get)
         # algorithmic bytes per launch
         S = 2
@@ -235,8 +243,8 @@ def main():
         # MI355X_MICROARCH.md prescribes; tools/pmc_traffic.py)
         traffic = None
         try:
-            prof = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
-            kname = {"me_search": "void me_search_wave_kernel<16>",
+            prof = json.load(open(os.path.join(ROOT, "profiles", "r01_v3_traffic.json")))
+            kname = {"me_search": "void me_search_wave_kernel<16, 3>",
                      "recon_from_me": "recon_from_me_kernel",
                      "picture_ssd": "picture_ssd_kernel", "pad_border": "pad_tb_kernel",
                      "deblock": "void deblock_pass_kernel<true>"}[dom]
@@ -252,7 +260,7 @@ def main():
                 "all_kernels_ms": {k: round(v, 4) for k, v in times.items()}}
 
     cpu = None
-    if rank == 0 and not args.no_cpu:
+    if rank == 0 and world == 1 and not args.no_cpu:
         cpu = cpu_baseline(args, clip, bd, border)
 
     if rank == 0:

@@ -1,0 +1,39 @@
+"""Per-job phase timeline of the ME kernel (developer build, -DXVCGPU_TRACE):
+
+    hipcc ... -DXVCGPU_TRACE -o xvc_amd/libxvcgpu_trace.so
+    XVCGPU_LIB=$PWD/xvc_amd/libxvcgpu_trace.so python tools/trace_me.py [flags]
+"""
+import ctypes as C, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+from xvc_amd import api, pipeline, synth
+flags = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+W, H, bd, border = 1920, 1080, 10, 128
+ctx = api.Context(0)
+clip = synth.SyntheticClip(W, H, bd)
+pad = lambda planes: [np.ascontiguousarray(np.pad(p, border if c == 0 else border // 2, mode="edge")) for c, p in enumerate(planes)]
+O, R = ctx.picture(W, H, bd), ctx.picture(W, H, bd)
+R.upload(pad(clip.frame(0)), border); O.upload(pad(clip.frame(1)), border)
+fp = pipeline.FramePass(ctx, W, H, bd)
+d = fp.desc
+lib = api.load_library()
+for _ in range(3):
+    ctx.me_search_dev(O, R, 3, fp.d_me.ptr, d.n_cus, fp.d_res.ptr, 16)
+ctx.sync(); ctx.timer_begin()
+ctx.me_search_dev(O, R, flags, fp.d_me.ptr, d.n_cus, fp.d_res.ptr, 16)
+ms = ctx.timer_end()
+n = d.n_cus
+buf = np.zeros((n, 16), np.uint64)
+lib.xvcgpu_debug_me_trace(buf.ctypes.data_as(C.c_void_p), n)
+t = buf[:, :9].astype(np.int64)
+t0 = t[:, 0].min()
+names = ["desc+orig", "predictors", "raster", "neighbour", "grid", "refine", "subpel win", "subpel"]
+print("kernel %.4f ms; span of timestamps %d ticks -> %.1f ticks/us" % (ms, t[:, 8].max() - t0, (t[:, 8].max() - t0) / (ms * 1e3)))
+life = t[:, 8] - t[:, 0]
+print("wave lifetime ticks: mean %.0f p50 %.0f p90 %.0f max %d" % (life.mean(), np.median(life), np.percentile(life, 90), life.max()))
+for k, nm in enumerate(names):
+    dph = t[:, k + 1] - t[:, k]
+    print("%-12s mean %7.0f  p50 %7.0f  p90 %7.0f  max %8d  share %5.1f%%" % (nm, dph.mean(), np.median(dph), np.percentile(dph, 90), dph.max(), 100.0 * dph.sum() / life.sum()))
+start = t[:, 0] - t0
+print("start time ticks: p10 %.0f p50 %.0f p90 %.0f max %d" % (np.percentile(start, 10), np.median(start), np.percentile(start, 90), start.max()))

@@ -33,6 +33,19 @@
 #include "k_subpel.h"
 #include "xvcgpu_internal.h"
 
+// Developer build (-DXVCGPU_TRACE): per-job phase timestamps (s_memtime) of
+// the ME kernel, one row per job, plain stores (tools/trace_me.py).
+#ifdef XVCGPU_TRACE
+__device__ unsigned long long g_me2_trace[16384][16];
+#define ME2_TRACE(k)                                                        \
+  do {                                                                      \
+    if ((threadIdx.x & 63) == 0 && bi < 16384)                              \
+      g_me2_trace[bi][k] = __builtin_amdgcn_s_memtime();                    \
+  } while (0)
+#else
+#define ME2_TRACE(k) do {} while (0)
+#endif
+
 // ---- cross-lane helpers (DPP / swizzle; no LDS traffic) ---------------------
 template <int S>
 __device__ __forceinline__ int lane_xor(int v) {
@@ -569,6 +582,7 @@ me_search_wave_kernel(PicView orig, PicView ref,
   if (wg < 0) return;
   const int bi = wg * WPG + (int)(threadIdx.x >> 6);
   if (bi >= n) return;
+  ME2_TRACE(0);
   const xvcgpu_me_block b = blocks[bi];
   {
     const int mx = b.w > b.h ? b.w : b.h;
@@ -604,6 +618,7 @@ me_search_wave_kernel(PicView orig, PicView ref,
       s.orig[i] = o[(ptrdiff_t)(i >> lw) * po.stride + (i & (c.w - 1))];
   }
 
+  ME2_TRACE(1);  // block descriptor read, original block loads issued
   xvcgpu_me_result res;
   if constexpr ((PH & XVCGPU_ME_FULLPEL) != 0) {
     const int range = b.search_range;
@@ -649,6 +664,7 @@ me_search_wave_kernel(PicView orig, PicView ref,
       }
     }
 
+    ME2_TRACE(2);  // predictor pass
     int total = 0, n_rounds = 0;
     for (int r = 1; r <= range; r *= 2) { total += tz_pattern_count(r); n_rounds++; }
     const Me2Pattern pat = me2_load_pattern(tz_pattern);
@@ -724,7 +740,9 @@ me_search_wave_kernel(PicView orig, PicView ref,
         if (cc < st.cost) { st.cost = cc; st.bx = x[1]; st.by = y[1]; st.last_pos = d1[1] + d2[1]; st.last_range = r; }
       }
     };
+    ME2_TRACE(3);  // raster
     if (st.last_range == 1) { st.last_range = 0; neighbor(); }
+    ME2_TRACE(4);  // neighbour
     // step-5 grid
     if (st.last_range > 5) {
       st.last_range = 5;
@@ -793,6 +811,7 @@ me_search_wave_kernel(PicView orig, PicView ref,
         st.by = fs_min_y + (gi / nx) * 5;
       }
     }
+    ME2_TRACE(5);  // grid
     // iterative refinement: all diamonds around the current best, one fold
     while (st.last_range > 0) {
       st.last_range = 0;
@@ -807,6 +826,7 @@ me_search_wave_kernel(PicView orig, PicView ref,
       }
       if (st.last_range == 1) { st.last_range = 0; neighbor(); }
     }
+    ME2_TRACE(6);  // refinement
     res.fullpel_x = st.bx;
     res.fullpel_y = st.by;
     res.fullpel_cost = st.cost;
@@ -843,6 +863,7 @@ me_search_wave_kernel(PicView orig, PicView ref,
         }
       }
     }
+    ME2_TRACE(7);  // sub-pel window loads issued
     if (me2_subpel_fast(w, h, c.bd)) {
       // column-major original for k_subpel.h: swap across the diagonal
       wave_sync();
@@ -888,6 +909,7 @@ me_search_wave_kernel(PicView orig, PicView ref,
       res.subpel_dist = best_dist;
     }
   }
+  ME2_TRACE(8);  // sub-pel passes
   if (lane == 0) results[bi] = res;
 }
 

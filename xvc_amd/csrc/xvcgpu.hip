@@ -513,6 +513,17 @@ xvcgpu_status xvcgpu_me_search_sized(xvcgpu_ctx *ctx, const xvcgpu_picture *orig
   return XVCGPU_OK;
 }
 
+#ifdef XVCGPU_TRACE
+// developer build only (tools/trace_me.py): copy out the ME phase timestamps
+xvcgpu_status xvcgpu_debug_me_trace(unsigned long long *out, int n_jobs) {
+  hipDeviceSynchronize();
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_me2_trace),
+                             sizeof(unsigned long long) * 16 * (size_t)n_jobs) == hipSuccess
+             ? XVCGPU_OK
+             : XVCGPU_DEVICE_ERROR;
+}
+#endif
+
 xvcgpu_status xvcgpu_me_search(xvcgpu_ctx *ctx, const xvcgpu_picture *orig,
                                const xvcgpu_picture *ref, int flags,
                                const xvcgpu_me_block *d_blocks, int n,
