@@ -104,7 +104,7 @@ __global__ void cu_info_from_me_kernel(const xvcgpu_me_block *blocks,
 // block's sum): thread = 8 samples (one 16-byte load from each picture),
 // 256 / (bw / 8) rows per sweep.  grid: items; block 256.
 __global__ void __launch_bounds__(256)
-picture_ssd_kernel(PlaneView a, PlaneView b, int shift, unsigned long long *out) {
+picture_ssd_kernel(PlaneView a, PlaneView b, int shift, unsigned long long *part_out) {
   __shared__ unsigned long long part[4];
   const int w = a.w, h = a.h;
   const int mbx = w & ~(w - 1), mby = h & ~(h - 1);
@@ -144,10 +144,34 @@ picture_ssd_kernel(PlaneView a, PlaneView b, int shift, unsigned long long *out)
   const unsigned long long ws = group_sum<64>((unsigned long long)acc);
   if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = ws;
   __syncthreads();
+  // per-block results go to a scratch array (no same-address atomics, no
+  // zero-fill launch); picture_ssd_sum_kernel folds them
   if (threadIdx.x == 0) {
-    const unsigned long long ssd = (part[0] + part[1] + part[2] + part[3]) >> shift;
-    atomicAdd(&out[0], ssd);
-    atomicAdd(&out[1], (unsigned long long)bw * bh);
+    part_out[2 * item] = (part[0] + part[1] + part[2] + part[3]) >> shift;
+    part_out[2 * item + 1] = (unsigned long long)bw * bh;
+  }
+}
+
+// grid: 1; block: 256.  out[0] = sum of block SSDs, out[1] = samples visited.
+__global__ void __launch_bounds__(256)
+picture_ssd_sum_kernel(const unsigned long long *part_in, int items,
+                       unsigned long long *out) {
+  __shared__ unsigned long long red[2][4];
+  unsigned long long s0 = 0, s1 = 0;
+  for (int i = threadIdx.x; i < items; i += 256) {
+    s0 += part_in[2 * i];
+    s1 += part_in[2 * i + 1];
+  }
+  s0 = group_sum<64>(s0);
+  s1 = group_sum<64>(s1);
+  if ((threadIdx.x & 63) == 0) {
+    red[0][threadIdx.x >> 6] = s0;
+    red[1][threadIdx.x >> 6] = s1;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    out[0] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+    out[1] = red[1][0] + red[1][1] + red[1][2] + red[1][3];
   }
 }
 

@@ -47,6 +47,14 @@ xvcgpu_status fail(xvcgpu_ctx *ctx, xvcgpu_status st, const char *what,
 
 inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
+// Blocks visited by ComparePicture on a w x h plane (sample_metric.cc:64-88).
+inline int ssd_items(int w, int h) {
+  const int mbx = w & ~(w - 1), mby = h & ~(h - 1);
+  const int ncx = (w > 64 ? (w - 64 + 63) / 64 : 0) + (w - (w & ~63)) / mbx;
+  const int ncy = (h > 64 ? (h - 64 + 63) / 64 : 0) + (h - (h & ~63)) / mby;
+  return ncx * ncy;
+}
+
 // Plane geometry shared by create / wrap / bytes.
 struct Geometry {
   int w[3], h[3], border[3], stride[3], rows[3];
@@ -130,6 +138,8 @@ xvcgpu_status xvcgpu_create(int device, xvcgpu_ctx **out) {
   ctx->d_tx_tables = nullptr;
   ctx->d_tx_tables_t = nullptr;
   ctx->d_tz_pattern = nullptr;
+  ctx->d_ssd_part = nullptr;
+  ctx->ssd_part_cap = 0;
   if (hipSetDevice(device) != hipSuccess ||
       hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
     delete ctx;
@@ -170,6 +180,7 @@ void xvcgpu_destroy(xvcgpu_ctx *ctx) {
   if (ctx->d_tx_tables) hipFree(ctx->d_tx_tables);
   if (ctx->d_tx_tables_t) hipFree(ctx->d_tx_tables_t);
   if (ctx->d_tz_pattern) hipFree(ctx->d_tz_pattern);
+  if (ctx->d_ssd_part) hipFree(ctx->d_ssd_part);
   hipEventDestroy(ctx->ev0);
   hipEventDestroy(ctx->ev1);
   if (ctx->own_stream && ctx->stream) hipStreamDestroy(ctx->stream);
@@ -312,6 +323,8 @@ xvcgpu_status xvcgpu_memset(xvcgpu_ctx *ctx, void *dst, int value, size_t bytes)
   return XVCGPU_OK;
 }
 
+static xvcgpu_status ensure_ssd_part(xvcgpu_ctx *ctx, int items);
+
 /* ---- pictures ---- */
 size_t xvcgpu_picture_bytes(int width, int height) {
   if (!valid_size(width, height, 8)) return 0;
@@ -338,6 +351,11 @@ xvcgpu_status xvcgpu_picture_wrap(xvcgpu_ctx *ctx, int width, int height,
   p->bytes = bytes;
   p->own = false;
   init_views(p);
+  const xvcgpu_status st = ensure_ssd_part(ctx, ssd_items(width, height));
+  if (st != XVCGPU_OK) {
+    delete p;
+    return st;
+  }
   *out = p;
   return XVCGPU_OK;
 }
@@ -447,10 +465,8 @@ xvcgpu_status xvcgpu_picture_copy(xvcgpu_ctx *ctx, xvcgpu_picture *dst,
 /* ---- kernels ---- */
 xvcgpu_status xvcgpu_pad_border(xvcgpu_ctx *ctx, xvcgpu_picture *pic) {
   if (!ctx || !pic) return XVCGPU_INVALID_ARGUMENT;
-  hipLaunchKernelGGL(pad_lr_kernel, dim3(pic->h, 3), dim3(64), 0, ctx->stream,
-                     pic->v);
-  hipLaunchKernelGGL(pad_tb_kernel, dim3(2 * XVCGPU_BORDER_LUMA, 3), dim3(256), 0,
-                     ctx->stream, pic->v);
+  hipLaunchKernelGGL(pad_border_kernel, dim3(pic->h + 2 * XVCGPU_BORDER_LUMA, 3),
+                     dim3(128), 0, ctx->stream, pic->v);
   CHECK_LAUNCH(ctx, "pad_border");
   return XVCGPU_OK;
 }
@@ -745,6 +761,22 @@ xvcgpu_status xvcgpu_deblock(xvcgpu_ctx *ctx, xvcgpu_picture *rec,
                              0, rec->h);
 }
 
+// Scratch for the per-block results of xvcgpu_picture_ssd; grown when a larger
+// picture is created, so no allocation happens on the measurement path.
+static xvcgpu_status ensure_ssd_part(xvcgpu_ctx *ctx, int items) {
+  if (items <= ctx->ssd_part_cap) return XVCGPU_OK;
+  if (ctx->d_ssd_part) {
+    hipStreamSynchronize(ctx->stream);
+    hipFree(ctx->d_ssd_part);
+    ctx->d_ssd_part = nullptr;
+    ctx->ssd_part_cap = 0;
+  }
+  hipError_t e = hipMalloc(&ctx->d_ssd_part, sizeof(unsigned long long) * 2 * items);
+  if (e != hipSuccess) return fail(ctx, XVCGPU_OUT_OF_MEMORY, "hipMalloc", e);
+  ctx->ssd_part_cap = items;
+  return XVCGPU_OK;
+}
+
 xvcgpu_status xvcgpu_picture_ssd(xvcgpu_ctx *ctx, const xvcgpu_picture *a,
                                  const xvcgpu_picture *b, int comp,
                                  int shift_bitdepth, uint64_t *d_out) {
@@ -752,19 +784,19 @@ xvcgpu_status xvcgpu_picture_ssd(xvcgpu_ctx *ctx, const xvcgpu_picture *a,
     return XVCGPU_INVALID_ARGUMENT;
   if (a->w != b->w || a->h != b->h)
     return fail(ctx, XVCGPU_INVALID_ARGUMENT, "picture mismatch");
-  HIP_TRY(ctx, hipMemsetAsync(d_out, 0, 2 * sizeof(uint64_t), ctx->stream));
   const PlaneView pa = a->v.c[comp], pb = b->v.c[comp];
-  const int w = pa.w, h = pa.h;
-  const int mbx = w & ~(w - 1), mby = h & ~(h - 1);
-  const int ncx = (w > 64 ? (w - 64 + 63) / 64 : 0) + (w - (w & ~63)) / mbx;
-  const int ncy = (h > 64 ? (h - 64 + 63) / 64 : 0) + (h - (h & ~63)) / mby;
-  const int items = ncx * ncy;
-  if (items > 0) {
-    hipLaunchKernelGGL(picture_ssd_kernel, dim3(items), dim3(256), 0,
-                       ctx->stream, pa, pb, 2 * (shift_bitdepth - 8),
-                       reinterpret_cast<unsigned long long *>(d_out));
-    CHECK_LAUNCH(ctx, "picture_ssd");
+  const int items = ssd_items(pa.w, pa.h);
+  {
+    const xvcgpu_status st = ensure_ssd_part(ctx, items);
+    if (st != XVCGPU_OK) return st;
   }
+  if (items > 0)
+    hipLaunchKernelGGL(picture_ssd_kernel, dim3(items), dim3(256), 0, ctx->stream, pa,
+                       pb, 2 * (shift_bitdepth - 8), ctx->d_ssd_part);
+  hipLaunchKernelGGL(picture_ssd_sum_kernel, dim3(1), dim3(256), 0, ctx->stream,
+                     ctx->d_ssd_part, items,
+                     reinterpret_cast<unsigned long long *>(d_out));
+  CHECK_LAUNCH(ctx, "picture_ssd");
   return XVCGPU_OK;
 }
 

@@ -36,6 +36,9 @@ struct xvcgpu_ctx {
   int16_t *d_tx_tables_t;  // transposed
   // TZ candidate pattern (tz_pattern.h), device copy
   TzCand *d_tz_pattern;
+  // per-block partial results of xvcgpu_picture_ssd
+  unsigned long long *d_ssd_part;
+  int ssd_part_cap;  // in blocks
 };
 
 struct xvcgpu_picture {
