@@ -24,6 +24,34 @@ struct __attribute__((packed, aligned(2))) U16x4 {
   uint32_t v[2];
 };
 
+// Copy `rows` rows of `cpr` 8-sample chunks from global memory (row stride
+// ss samples, any 2-byte alignment) to LDS (row stride ds samples, 16-byte
+// aligned rows) by one wave.  The loads of a batch (up to 8 per lane) are all
+// issued before the first store, so the copy costs one memory round trip per
+// batch rather than one per loop iteration.
+__device__ __forceinline__ void wave_copy_chunks(uint16_t *dst, int ds, const uint16_t *src,
+                                                 int ss, int rows, int cpr) {
+  const int lane = threadIdx.x & 63;
+  const int n = rows * cpr;
+  const uint32_t inv = (65536u + (uint32_t)cpr - 1u) / (uint32_t)cpr;  // exact for n < 4096
+  for (int base = lane; base < n; base += 64 * 8) {
+    U16x8 v[8];
+    int off[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      const int i = base + 64 * u;
+      const int r = (int)(((uint32_t)i * inv) >> 16), ch = i - r * cpr;
+      off[u] = r * ds + ch * 8;
+      if (i < n) v[u] = *reinterpret_cast<const U16x8 *>(src + (ptrdiff_t)r * ss + ch * 8);
+    }
+#pragma unroll
+    for (int u = 0; u < 8; u++)
+      if (base + 64 * u < n)
+        *reinterpret_cast<uint4 *>(dst + off[u]) =
+            make_uint4(v[u].v[0], v[u].v[1], v[u].v[2], v[u].v[3]);
+  }
+}
+
 struct MeCtx {
   int bd, w, h, rows, row_step, sad_shift, sad_mul;  // kSad / kSadFast
   const uint16_t *ref;  // reference plane at the CU position

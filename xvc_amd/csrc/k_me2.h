@@ -36,10 +36,10 @@
 // Developer build (-DXVCGPU_TRACE): per-job phase timestamps (s_memtime) of
 // the ME kernel, one row per job, plain stores (tools/trace_me.py).
 #ifdef XVCGPU_TRACE
-__device__ unsigned long long g_me2_trace[16384][16];
+__device__ unsigned long long g_me2_trace[32768][16];
 #define ME2_TRACE(k)                                                        \
   do {                                                                      \
-    if ((threadIdx.x & 63) == 0 && bi < 16384)                              \
+    if ((threadIdx.x & 63) == 0 && bi < 32768)                              \
       g_me2_trace[bi][k] = __builtin_amdgcn_s_memtime();                    \
   } while (0)
 #else

@@ -19,6 +19,7 @@ struct __attribute__((aligned(16))) ReconShared {
   Tx2Shared tx;
   uint16_t pred[256];
   int16_t tmp[16 * 23];
+  uint16_t win[23 * 24];  // reference window of the block, rows/cols -3..+4
 };
 
 // MotionCompUniPred -> Sample by one wave (same arithmetic as wg_interp_block
@@ -84,6 +85,89 @@ __device__ __forceinline__ void wave_interp_block(int bd, int w, int h, int fx,
   }
 }
 
+// Same arithmetic with the reference window staged in LDS first: one batch of
+// 16-byte loads (one memory round trip) instead of a dependent load per filter
+// tap and loop iteration, and the horizontal pass on packed pairs
+// (v_dot2c_i32_i16: even outputs use the tap pairs as they are, odd outputs
+// the set shifted by one sample).  Blocks up to 16x16.
+template <bool CHROMA>
+__device__ __forceinline__ void wave_interp_block_lds(int bd, int w, int h, int fx, int fy,
+                                                      const uint16_t *ref, int rs,
+                                                      uint16_t *win, int16_t *tmp,
+                                                      uint16_t *dst) {
+  constexpr int N = CHROMA ? 4 : 8;
+  constexpr int BACK = N / 2 - 1;
+  constexpr int NP = N / 2;  // tap pairs
+  const int lane = ME2_LANE;
+  const int smax = (1 << bd) - 1;
+  const int lw = 31 - __clz(w);
+  const int ws = (w + N - 1 + 7) & ~7;  // window row stride, 16-byte rows
+  const int16_t *fh = CHROMA ? kChromaTaps[fx] : kLumaTaps[fx];
+  const int16_t *fv = CHROMA ? kChromaTaps[fy] : kLumaTaps[fy];
+  wave_copy_chunks(win, ws, ref - (ptrdiff_t)BACK * rs - BACK, rs, h + N - 1, ws >> 3);
+  wave_sync();
+  if (fx == 0 && fy == 0) {
+    for (int i = lane; i < w * h; i += 64)
+      dst[i] = win[((i >> lw) + BACK) * ws + (i & (w - 1)) + BACK];
+    return;
+  }
+  if (fx == 0) {  // FilterVerSampleSample (narrows to int16 before the clip)
+    for (int i = lane; i < w * h; i += 64) {
+      const uint16_t *s = win + (i >> lw) * ws + (i & (w - 1)) + BACK;
+      int sum = 0;
+#pragma unroll
+      for (int k = 0; k < N; k++) sum += (int)s[k * ws] * fv[k];
+      dst[i] = d_clip_bd((int16_t)((sum + 32) >> 6), smax);
+    }
+    return;
+  }
+  // horizontal pass, two outputs (x0 even, x0 + 1) per lane
+  uint32_t ta[NP], tb[NP + 1];
+#pragma unroll
+  for (int k = 0; k < NP; k++) ta[k] = sp_pack_taps(fh[2 * k], fh[2 * k + 1]);
+  tb[0] = sp_pack_taps(0, fh[0]);
+#pragma unroll
+  for (int k = 1; k < NP; k++) tb[k] = sp_pack_taps(fh[2 * k - 1], fh[2 * k]);
+  tb[NP] = sp_pack_taps(fh[N - 1], 0);
+  const uint32_t *win32 = reinterpret_cast<const uint32_t *>(win);
+  const int hw = w >> 1, lhw = lw - 1;
+  const bool two_stage = fy != 0;
+  const int rows = two_stage ? h + N - 1 : h, r0 = two_stage ? 0 : BACK;
+  const int shift = 6 - (14 - bd), offset = -(8192 << shift);
+  for (int i = lane; i < rows * hw; i += 64) {
+    const int r = i >> lhw, x0 = (i & (hw - 1)) << 1;
+    const uint32_t *d = win32 + (((r + r0) * ws + x0) >> 1);
+    uint32_t dv[NP + 1];
+#pragma unroll
+    for (int k = 0; k <= NP; k++) dv[k] = d[k];
+    int s0 = 0, s1 = 0;
+#pragma unroll
+    for (int k = 0; k < NP; k++) s0 = sp_dot2(dv[k], ta[k], s0);
+#pragma unroll
+    for (int k = 0; k <= NP; k++) s1 = sp_dot2(dv[k], tb[k], s1);
+    if (two_stage) {
+      tmp[r * w + x0] = (int16_t)((s0 + offset) >> shift);
+      tmp[r * w + x0 + 1] = (int16_t)((s1 + offset) >> shift);
+    } else {
+      dst[r * w + x0] = d_clip_bd((s0 + 32) >> 6, smax);
+      dst[r * w + x0 + 1] = d_clip_bd((s1 + 32) >> 6, smax);
+    }
+  }
+  if (!two_stage) return;
+  wave_sync();
+  {
+    const int sh2 = 6 + (14 - bd);
+    const int off2 = (8192 << 6) + (1 << (sh2 - 1));
+    for (int i = lane; i < w * h; i += 64) {
+      const int16_t *s = tmp + i;
+      int sum = 0;
+#pragma unroll
+      for (int k = 0; k < N; k++) sum += (int)s[k * w] * fv[k];
+      dst[i] = d_clip_bd((int16_t)((sum + off2) >> sh2), smax);
+    }
+  }
+}
+
 // grid: XCD-swizzled workgroups of 4 waves; job = (CU, component), component
 // fastest, so the three planes of a CU share a workgroup.
 __global__ void __launch_bounds__(256)
@@ -102,6 +186,10 @@ recon_from_me_kernel(PicView orig, PicView ref, PicView rec,
   const int job = wg * 4 + (int)(threadIdx.x >> 6);
   if (job >= n) return;
   const int ci = job / 3, comp = job - ci * 3;
+#ifdef XVCGPU_TRACE
+  const int bi = job;
+#endif
+  ME2_TRACE(0);
   const xvcgpu_me_block mb = blocks[ci];
   const xvcgpu_me_result mr = results[ci];
   const int bd = ref.bd;
@@ -113,11 +201,24 @@ recon_from_me_kernel(PicView orig, PicView ref, PicView rec,
   const PlaneView prf = ref.c[comp];
   const int cx = mb.x >> cs, cy = mb.y >> cs, cw = mb.w >> cs, ch = mb.h >> cs;
   const uint16_t *r = prf.p + (ptrdiff_t)(cy + (my >> shift)) * prf.stride + cx + (mx >> shift);
+  // this lane's four original samples for the residual: fetched now, together
+  // with the reference window, instead of after the interpolation
+  U16x4 orig_pre = {{0u, 0u}};
+  {
+    const int i = ME2_LANE * 4;
+    if (i < cw * ch) {
+      const int lw = 31 - __clz(cw);
+      const PlaneView po = orig.c[comp];
+      orig_pre = *reinterpret_cast<const U16x4 *>(
+          po.p + (ptrdiff_t)(cy + (i >> lw)) * po.stride + cx + (i & (cw - 1)));
+    }
+  }
   if (comp)
-    wave_interp_block<true>(bd, cw, ch, fx, fy, r, prf.stride, s.tmp, s.pred);
+    wave_interp_block_lds<true>(bd, cw, ch, fx, fy, r, prf.stride, s.win, s.tmp, s.pred);
   else
-    wave_interp_block<false>(bd, cw, ch, fx, fy, r, prf.stride, s.tmp, s.pred);
+    wave_interp_block_lds<false>(bd, cw, ch, fx, fy, r, prf.stride, s.win, s.tmp, s.pred);
   wave_sync();
+  ME2_TRACE(1);
   xvcgpu_tx_block tb;
   tb.x = (int16_t)cx;
   tb.y = (int16_t)cy;
@@ -131,7 +232,8 @@ recon_from_me_kernel(PicView orig, PicView ref, PicView rec,
   tb.intra_pic = (uint8_t)intra_pic;
   const int nnz = tx2_job<TX_MODE_FULL>(s.tx, tb, job, bd, orig.c[comp], s.pred, cw,
                                         rec.c[comp], nullptr, nullptr, nnz_out,
-                                        tx_tables, tx_tables_t, lay);
+                                        tx_tables, tx_tables_t, lay, &orig_pre);
+  ME2_TRACE(8);
   if (comp == 0 && cus && ME2_LANE == 0) {
     xvcgpu_cu_info c;
     c.x = (uint16_t)mb.x;

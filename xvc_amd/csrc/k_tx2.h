@@ -124,7 +124,8 @@ __device__ __forceinline__ int tx2_job(Tx2Shared &s, const xvcgpu_tx_block &b, i
                                        int16_t *levels, const uint32_t *level_off,
                                        int32_t *nnz_out, const int16_t *tx_tables,
                                        const int16_t *tx_tables_t,
-                                       const TxTableLayout &lay) {
+                                       const TxTableLayout &lay,
+                                       const U16x4 *orig_pre = nullptr) {
   const int lane = ME2_LANE;
   const int w = b.w, h = b.h;
   const int lw = 31 - __clz(w);
@@ -145,8 +146,11 @@ __device__ __forceinline__ int tx2_job(Tx2Shared &s, const xvcgpu_tx_block &b, i
     // residual, 4 samples per lane along a row
     for (int i = lane * 4; i < n_el; i += 256) {
       const int y = i >> lw, x = i & (w - 1);
-      const U16x4 o = *reinterpret_cast<const U16x4 *>(
-          po.p + (ptrdiff_t)(b.y + y) * po.stride + b.x + x);
+      // blocks are <= 256 samples: one iteration, so a caller may have
+      // fetched this lane's four original samples ahead of time
+      const U16x4 o = orig_pre ? *orig_pre
+                               : *reinterpret_cast<const U16x4 *>(
+                                     po.p + (ptrdiff_t)(b.y + y) * po.stride + b.x + x);
       const U16x4 p = *reinterpret_cast<const U16x4 *>(
           pred_p + (ptrdiff_t)y * pred_stride + x);
       const int d0 = (int)(o.v[0] & 0xffff) - (int)(p.v[0] & 0xffff);
@@ -158,12 +162,15 @@ __device__ __forceinline__ int tx2_job(Tx2Shared &s, const xvcgpu_tx_block &b, i
                      (uint32_t)(d2 & 0xffff) | ((uint32_t)d3 << 16));
     }
     wave_sync();
+    ME2_TRACE(2);
     const int shift1 = lgw + bd - 9 + 2, shift2 = lgh + 6 + 2;
     // fwd 1: T[k][y] (w rows of h), fwd 2: C[x][k2] (w rows of h)
     tx2_stage_dispatch<false>(w, Mh, s.r, w, h, 1 << (shift1 - 1), shift1, s.t);
     wave_sync();
+    ME2_TRACE(3);
     tx2_stage_dispatch<false>(h, s.t, Mv, w, h, 1 << (shift2 - 1), shift2, s.c);
     wave_sync();
+    ME2_TRACE(4);
     if (MODE == TX_MODE_FWD) {
       if (lv)
         for (int i = lane; i < n_el; i += 64) {
@@ -213,6 +220,7 @@ __device__ __forceinline__ int tx2_job(Tx2Shared &s, const xvcgpu_tx_block &b, i
   }
   const bool dc_only = nnz == 1 && s.c[0] != 0;
   wave_sync();
+  ME2_TRACE(5);
   // Quantize::Inverse (quantize.cc:94-125), in place
   {
     const int shift = 6 - tshift + (bias ? 8 : 0);
@@ -226,6 +234,7 @@ __device__ __forceinline__ int tx2_job(Tx2Shared &s, const xvcgpu_tx_block &b, i
     }
   }
   wave_sync();
+  ME2_TRACE(6);
   const int smax = (1 << bd) - 1;
   const bool dct2_both = (b.tx_ver == XVC_TX_DEFAULT || b.tx_ver == XVC_TX_DCT2) &&
                          (b.tx_hor == XVC_TX_DEFAULT || b.tx_hor == XVC_TX_DCT2);
@@ -252,6 +261,7 @@ __device__ __forceinline__ int tx2_job(Tx2Shared &s, const xvcgpu_tx_block &b, i
     wave_sync();
     tx2_stage_dispatch<true>(w, s.r, MhT, h, w, 1 << (shift2 - 1), shift2, s.t);
     wave_sync();
+    ME2_TRACE(7);
   }
   // SampleBuffer::AddClip
   for (int i = lane * 4; i < n_el; i += 256) {
