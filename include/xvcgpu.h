@@ -156,6 +156,27 @@ xvcgpu_status xvcgpu_metric_batch(xvcgpu_ctx *ctx, const xvcgpu_picture *a,
                                   const xvcgpu_metric_cand *d_cands, int n,
                                   uint64_t *d_out);
 
+/* ---- T4 building block: motion-compensate, then Compare ------------------- *
+ * What InterSearch::GetSubpelDist (inter_search.cc:1022-1031), EvalStartMvp
+ * (:966-997) and SearchMergeCandidates (:165-197) do per candidate MV:
+ * MotionCompensationMv of the luma block (x,y,w,h) of `orig` from `ref` with
+ * the 1/16-pel vector (mv_x,mv_y) (clipped inside, ClipMv), then
+ * SampleMetric::CompareSample(orig, prediction) with `metric`.
+ * out[i] = the Distortion (weight 1.0: luma). */
+typedef struct xvcgpu_mc_metric_cand {
+  int16_t x, y;         /* luma position                                     */
+  uint8_t w, h;         /* luma size                                         */
+  uint8_t metric;       /* xvcgpu_metric                                     */
+  int8_t qp;            /* raw luma qp (structural SSD only)                 */
+  int32_t mv_x, mv_y;   /* 1/16-pel vector into `ref`                        */
+} xvcgpu_mc_metric_cand;
+
+xvcgpu_status xvcgpu_mc_metric_batch(xvcgpu_ctx *ctx, const xvcgpu_picture *orig,
+                                     const xvcgpu_picture *ref,
+                                     int structural_strength,
+                                     const xvcgpu_mc_metric_cand *d_cands, int n,
+                                     uint64_t *d_out);
+
 /* ---- T1 + T3 (+W1, I1, M1, M4): MotionEstNormal with TZ search ---------- *
  * (inter_search.cc:606-662, inter_tz_search.cc:84-171, inter_search.cc:
  * 893-964).  One result per xvcgpu_me_block, bit-identical to running the

@@ -41,7 +41,11 @@ enum xvcgpu_tx_type {
   XVC_TX_DCT5 = 2,
   XVC_TX_DCT8 = 3,
   XVC_TX_DST1 = 4,
-  XVC_TX_DST7 = 5
+  XVC_TX_DST7 = 5,
+  /* not a TransformType: in xvcgpu_tx_block.tx_hor it selects
+   * Forward/InverseTransform::TransformSkip (cu.GetTransformSkip(comp),
+   * transform_encoder.cc:213-227, :270-274; blocks <= 4x4 only) */
+  XVC_TX_SKIP = 6
 };
 
 /* MvCorner order (cu_types.h / coding_unit.h:152-155 GetMvCorner). */

@@ -533,6 +533,24 @@ void xr_subpel_search(int bd, const xvcgpu_me_block *b, int pic_w, int pic_h,
   if (out_dist) *out_dist = static_cast<uint32_t>(dist);
 }
 
+uint64_t xr_mc_metric(int bd, int metric_type, int qp_raw, int strength, int x, int y,
+                      int w, int h,
+                      int mv_x, int mv_y, int pic_w, int pic_h, const uint16_t *orig,
+                      ptrdiff_t os, const uint16_t *ref, ptrdiff_t rs) {
+  /* InterSearch::GetSubpelDist with an arbitrary metric */
+  MeEnv env(bd, pic_w, pic_h, orig, os, ref, rs);
+  CodingUnit *cu = env.pic_data.CreateCu(CuTree::Primary, 1, x, y, w, h);
+  InterSearch is(Simd(bd), env.pic_data, env.orig_pic, env.rec_pic, env.rpl,
+                 env.settings);
+  Qp qp = MakeQp(qp_raw, bd, 1.0);
+  SampleMetric metric(Simd(bd).sample_metric, bd, MetricType(metric_type), strength);
+  SampleBufferConst orig_buffer =
+      env.orig_pic.GetSampleBuffer(YuvComponent::kY, x, y);
+  SampleBufferStorage pred(64, 64);
+  return is.GetSubpelDist(*cu, qp, env.ref_pic, metric, MotionVector(mv_x, mv_y),
+                          orig_buffer, &pred);
+}
+
 void xr_full_search(int bd, int x, int y, int w, int h, int fullpel_mv,
                     int mvp_x, int mvp_y, uint32_t lambda16, const int mv_min[2],
                     const int mv_max[2], const int16_t *target, ptrdiff_t ts,

@@ -166,6 +166,12 @@ void xo_bipred_search(int bitdepth, const xvcgpu_bi_block *job, int pic_w,
                       const uint16_t *ref_other, ptrdiff_t other_stride,
                       const uint16_t *ref_search, ptrdiff_t search_stride,
                       xvcgpu_me_result *out);
+/* InterSearch::GetSubpelDist (inter_search.cc:951-964): MotionCompensationMv
+ * of a luma block, then CompareSample(orig, prediction). */
+uint64_t xo_mc_metric(int bitdepth, int metric, int qp_raw_y, int strength, int x,
+                      int y, int w, int h, int mv_x, int mv_y, int pic_w, int pic_h,
+                      const uint16_t *orig, ptrdiff_t orig_stride,
+                      const uint16_t *ref, ptrdiff_t ref_stride);
 /* MotionCompensation for a bi-pred CU, one component
  * (inter_prediction.cc:710-738: two 14-bit predictions + AddAvgBi). */
 void xo_mc_bipred_block(int bitdepth, int comp, int x, int y, int w, int h,

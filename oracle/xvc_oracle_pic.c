@@ -650,6 +650,18 @@ void xo_subpel_search(int bd, const xvcgpu_me_block *b, int pic_w, int pic_h,
   if (out_dist) *out_dist = (uint32_t)best_dist;
 }
 
+uint64_t xo_mc_metric(int bd, int metric, int qp_raw, int strength, int x, int y, int w,
+                      int h, int mv_x, int mv_y, int pic_w, int pic_h,
+                      const uint16_t *orig, ptrdiff_t os, const uint16_t *ref,
+                      ptrdiff_t rs) {
+  /* GetSubpelDist, inter_search.cc:951-964 (the per-candidate step of
+   * EvalStartMvp :966-997 and SearchMergeCandidates :165-197) */
+  uint16_t pred[64 * 64];
+  xo_mc_block(bd, 0, x, y, w, h, mv_x, mv_y, pic_w, pic_h, ref, rs, pred, 64);
+  return xo_metric_ss(metric, bd, qp_raw, strength, 1.0, w, h,
+                      orig + (ptrdiff_t)y * os + x, os, pred, 64);
+}
+
 /* SubpelSearch on an int16 target (bi-pred: TOrig = Residual), same fold. */
 static void xp_subpel_search_rs(int bd, const xvcgpu_me_block *b, int pic_w,
                                 int pic_h, const int16_t *target, ptrdiff_t ts,
@@ -769,14 +781,20 @@ int xo_residual_pipeline(int bd, const xvcgpu_tx_block *b, const uint16_t *orig,
   for (int y = 0; y < h; y++)
     for (int x = 0; x < w; x++)
       resi[y * 64 + x] = (int16_t)((int)o[y * os + x] - (int)p[y * ps + x]);
-  xo_fwd_transform(bd, w, h, b->tx_hor, b->tx_ver, b->dst4x4, resi, 64, coeff,
-                   64);
+  const int skip = b->tx_hor == XVC_TX_SKIP; /* cu->GetTransformSkip(comp) */
+  if (skip)
+    xo_fwd_transform_skip(bd, w, h, resi, 64, coeff, 64);
+  else
+    xo_fwd_transform(bd, w, h, b->tx_hor, b->tx_ver, b->dst4x4, resi, 64, coeff, 64);
   int nnz = xo_quant_fast(bd, b->qp, b->intra_pic, w, h, coeff, 64, coeff_out, w);
   if (nnz) {
     int dc_only = nnz == 1 && coeff_out[0] != 0;
     xo_dequant(bd, b->qp, w, h, coeff_out, w, deq, 64);
-    xo_inv_transform(bd, w, h, b->tx_hor, b->tx_ver, b->dst4x4, dc_only, deq, 64,
-                     resi, 64);
+    if (skip)
+      xo_inv_transform_skip(bd, w, h, deq, 64, resi, 64);
+    else
+      xo_inv_transform(bd, w, h, b->tx_hor, b->tx_ver, b->dst4x4, dc_only, deq, 64,
+                       resi, 64);
     const int smax = (1 << bd) - 1;
     for (int y = 0; y < h; y++)
       for (int x = 0; x < w; x++)

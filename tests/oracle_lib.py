@@ -92,6 +92,8 @@ BI_DTYPE = np.dtype([("blk", ME_DTYPE), ("other_mv_x", "<i4"),
 MCBI_DTYPE = np.dtype([("x", "<i2"), ("y", "<i2"), ("w", "u1"), ("h", "u1"),
                        ("comp", "u1"), ("reserved", "u1"), ("mv0_x", "<i4"),
                        ("mv0_y", "<i4"), ("mv1_x", "<i4"), ("mv1_y", "<i4")])
+MCM_DTYPE = np.dtype([("x", "<i2"), ("y", "<i2"), ("w", "u1"), ("h", "u1"),
+                      ("metric", "u1"), ("qp", "i1"), ("mv_x", "<i4"), ("mv_y", "<i4")])
 TX_DTYPE = np.dtype([("x", "<i2"), ("y", "<i2"), ("w", "u1"), ("h", "u1"),
                      ("comp", "u1"), ("tx_hor", "u1"), ("tx_ver", "u1"),
                      ("dst4x4", "u1"), ("qp", "i1"), ("intra_pic", "u1")])
@@ -185,6 +187,8 @@ class Lib:
         sig("bipred_search", None,
             [C.c_int, C.POINTER(BiBlock), C.c_int, C.c_int, u16p, pd, u16p, pd,
              u16p, pd, C.POINTER(MeResult)])
+        sig("mc_metric", C.c_uint64,
+            [C.c_int] * 12 + [u16p, pd, u16p, pd])
         sig("mc_bipred_block", None,
             [C.c_int] * 12 + [u16p, pd, u16p, pd, u16p, pd])
         if p == "xo":
@@ -363,6 +367,14 @@ class Lib:
                               ptr(target, i16p), self._s(target), ptr(r, u16p),
                               self._s(ref_pad), pw, ph, ptr(mv, i32p))
         return int(mv[0]), int(mv[1])
+
+    def mc_metric(self, bd, metric, qp, strength, x, y, w, h, mv, pw, ph, orig_pad,
+                  ref_pad, border):
+        o = orig_pad[border:, border:]
+        r = ref_pad[border:, border:]
+        return int(self._mc_metric(bd, metric, qp, strength, x, y, w, h, mv[0], mv[1],
+                                   pw, ph, ptr(o, u16p), self._s(orig_pad),
+                                   ptr(r, u16p), self._s(ref_pad)))
 
     def bipred_search(self, bd, job, pw, ph, orig_pad, other_pad, search_pad,
                       border):

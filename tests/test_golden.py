@@ -143,6 +143,11 @@ def test_oracle_bipred(xo):
     for j, r in zip(g["jobs"], g["results"]):
         mv, d = xo.bipred_search(bd, bi_struct(j), pw, ph, orig, luma[1], luma[0], BL)
         assert (mv, d) == ((int(r["mv_x"]), int(r["mv_y"])), int(r["subpel_dist"]))
+    for c, exp in zip(g["mcm"], g["mcm_out"]):
+        got = xo.mc_metric(bd, int(c["metric"]), int(c["qp"]), 16, int(c["x"]), int(c["y"]),
+                           int(c["w"]), int(c["h"]), (int(c["mv_x"]), int(c["mv_y"])),
+                           pw, ph, orig, luma[0], BL)
+        assert got == int(exp), tuple(c)
     for b, exp in zip(g["mc"], g["preds"]):
         comp = int(b["comp"]); cs = 1 if comp else 0
         r0, r1, bo = (luma[0], luma[1], BL) if comp == 0 else (chroma[0], chroma[1], BC)
@@ -289,6 +294,7 @@ def test_gpu_bipred(gpu):
     res = ctx.bipred_search(O, RO, RS, g["jobs"])
     for name in ("mv_x", "mv_y", "subpel_dist"):
         assert np.array_equal(res[name], g["results"][name]), name
+    assert np.array_equal(ctx.mc_metric_batch(O, RS, g["mcm"], strength=16), g["mcm_out"])
     for b, exp in zip(g["mc"], g["preds"]):
         ctx.mc_bipred_batch(RS, RO, P, np.array([b], api.MCBI_DTYPE))
         comp = int(b["comp"]); cs = 1 if comp else 0

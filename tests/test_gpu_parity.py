@@ -253,6 +253,44 @@ def test_bipred_search(gpu, xo, bd):
 
 
 @pytest.mark.parametrize("bd", [8, 10, 12])
+def test_mc_metric_batch(gpu, xo, bd):
+    """T4 building block: motion-compensate then Compare, every metric."""
+    api, ctx = gpu
+    rng = np.random.default_rng(3600 + bd)
+    pw, ph = 256, 192
+    orig, ref = make_pics(rng, bd, pw, ph, BL, (3, -2))
+    O, R = ctx.picture(pw, ph, bd), ctx.picture(pw, ph, bd)
+    O.upload([orig, None, None], BL)
+    R.upload([ref, None, None], BL)
+    n = 240
+    cands = np.zeros(n, api.MCM_DTYPE)
+    for i, c in enumerate(cands):
+        w = int(rng.choice(SIZES)); h = int(rng.choice(SIZES))
+        c["w"], c["h"] = w, h
+        c["x"] = int(rng.integers(0, (pw - w) // 4 + 1)) * 4
+        c["y"] = int(rng.integers(0, (ph - h) // 4 + 1)) * 4
+        metric = int(rng.integers(0, 8))
+        if metric in (4, 6) and h <= 8:
+            metric = 3          # the fast variants are only used for h > 8
+        c["metric"] = metric
+        c["qp"] = int(rng.integers(20, 45))
+        lim = 6000 if i % 8 == 0 else 200
+        c["mv_x"], c["mv_y"] = int(rng.integers(-lim, lim)), int(rng.integers(-lim, lim))
+        if i % 5 == 0:
+            c["mv_x"] &= ~15
+        if i % 7 == 0:
+            c["mv_y"] &= ~15
+    got = ctx.mc_metric_batch(O, R, cands, strength=16)
+    for i, c in enumerate(cands):
+        exp = xo.mc_metric(bd, int(c["metric"]), int(c["qp"]), 16, int(c["x"]), int(c["y"]),
+                           int(c["w"]), int(c["h"]), (int(c["mv_x"]), int(c["mv_y"])),
+                           pw, ph, orig, ref, BL)
+        assert int(got[i]) == exp, (tuple(c), int(got[i]), exp)
+    O.destroy()
+    R.destroy()
+
+
+@pytest.mark.parametrize("bd", [8, 10, 12])
 def test_mc_bipred_batch(gpu, xo, bd):
     """I2: two 14-bit predictions + AddAvg vs the oracle."""
     api, ctx = gpu
@@ -370,6 +408,53 @@ def test_residual_pipeline(gpu, xo, bd):
             assert np.array_equal(Rc.download()[comp], exp_rec), (noise, tuple(b))
         for pic in (O, P, Rc):
             pic.destroy()
+
+
+@pytest.mark.parametrize("bd", [8, 10, 12])
+def test_transform_skip(gpu, xo, bd):
+    """X3: blocks <= 4x4 with cu.GetTransformSkip (tx_hor = XVC_TX_SKIP)."""
+    api, ctx = gpu
+    rng = np.random.default_rng(4300 + bd)
+    pw, ph = 64, 64
+    po = padded_planes(rng, bd, pw, ph, smooth=True)
+    amp = 40 << (bd - 8)
+    pp = [np.clip(p.astype(np.int32) + rng.integers(-amp, amp + 1, size=p.shape), 0,
+                  (1 << bd) - 1).astype(np.uint16) for p in po]
+    O, P, Rc = ctx.picture(pw, ph, bd), ctx.picture(pw, ph, bd), ctx.picture(pw, ph, bd)
+    O.upload(po, BL)
+    P.upload(pp, BL)
+    n = 0
+    for comp in range(3):
+        for (w, h) in [(4, 4), (2, 2), (2, 4), (4, 2)]:
+            if comp == 0 and min(w, h) < 4:
+                continue
+            for qp in (12, 27, 40):
+                cw = pw if comp == 0 else pw // 2
+                x = int(rng.integers(0, (cw - w) // 2 + 1)) * 2
+                y = int(rng.integers(0, (cw - h) // 2 + 1)) * 2
+                blk = np.array([(x, y, w, h, comp, 6, 6, 0, qp, int(rng.integers(0, 2)))],
+                               api.TX_DTYPE)
+                Rc.upload(pp, BL)
+                levels, off, nnz = ctx.residual_batch(O, P, Rc, blk)
+                ov, pv = view(po, comp), view(pp, comp)
+                exp_rec, exp_coeff, exp_n = xo.residual_pipeline(
+                    bd, to_tx_struct(blk[0]), np.ascontiguousarray(ov[:cw, :cw]),
+                    np.ascontiguousarray(pv[:cw, :cw]))
+                assert int(nnz[0]) == exp_n
+                assert np.array_equal(levels.reshape(h, w), exp_coeff)
+                assert np.array_equal(Rc.download()[comp], exp_rec), tuple(blk[0])
+                coeffs, _ = ctx.fwd_transform_batch(O, P, blk)
+                resi = (ov[y:y + h, x:x + w].astype(np.int32) -
+                        pv[y:y + h, x:x + w].astype(np.int32)).astype(np.int16)
+                assert np.array_equal(coeffs.reshape(h, w),
+                                      xo.fwd_transform_skip(bd, np.ascontiguousarray(resi)))
+                Rc.upload(pp, BL)
+                ctx.inv_transform_batch(P, Rc, blk, levels, off, nnz)
+                assert np.array_equal(Rc.download()[comp], exp_rec)
+                n += exp_n != 0
+    assert n > 5  # the inverse skip path is exercised too
+    for pic in (O, P, Rc):
+        pic.destroy()
 
 
 @pytest.mark.parametrize("bd", [8, 10])

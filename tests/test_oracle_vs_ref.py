@@ -384,3 +384,28 @@ def test_bipred_search(libs, bd):
             assert a == o, (x, y, w, h, a, o)
             n += 1
     assert n == 32
+
+
+@pytest.mark.parametrize("bd", [8, 10])
+def test_mc_metric(libs, bd):
+    """GetSubpelDist with every metric (T4's per-candidate step)."""
+    xo, xr = libs
+    rng = np.random.default_rng(97 + bd)
+    pw, ph, border = 128, 96, 96
+    orig, ref = make_pics(rng, bd, pw, ph, border, (2, -1))
+    n = 0
+    for i in range(60):
+        w = int(rng.choice([8, 16, 32, 64])); h = int(rng.choice([8, 16, 32, 64]))
+        x = int(rng.integers(0, (pw - w) // 8 + 1)) * 8
+        y = int(rng.integers(0, (ph - h) // 8 + 1)) * 8
+        lim = 3000 if i % 6 == 0 else 150
+        mv = (int(rng.integers(-lim, lim)), int(rng.integers(-lim, lim)))
+        metric = int(rng.integers(0, 8))
+        if metric in (4, 6) and h <= 8:
+            metric = 3
+        qp, strength = int(rng.integers(20, 45)), int(rng.choice([8, 16]))
+        a = xr.mc_metric(bd, metric, qp, strength, x, y, w, h, mv, pw, ph, orig, ref, border)
+        o = xo.mc_metric(bd, metric, qp, strength, x, y, w, h, mv, pw, ph, orig, ref, border)
+        assert a == o, (metric, x, y, w, h, mv, a, o)
+        n += 1
+    assert n == 60

@@ -79,8 +79,24 @@ def gen_bipred(xr):
         pp = np.zeros((64, 64), np.uint16)
         pp[:p.shape[0], :p.shape[1]] = p
         preds.append(pp)
+    # GetSubpelDist with every metric (T4's per-candidate step); orig vs ref_s
+    mcm = np.zeros(32, ol.MCM_DTYPE)
+    mcm_out = np.zeros(32, np.uint64)
+    for i, c in enumerate(mcm):
+        w = int(rng.choice([8, 16, 32, 64])); h = int(rng.choice([8, 16, 32, 64]))
+        c["w"], c["h"] = w, h
+        c["x"] = int(rng.integers(0, (pw - w) // 8 + 1)) * 8
+        c["y"] = int(rng.integers(0, (ph - h) // 8 + 1)) * 8
+        metric = i % 8
+        c["metric"] = 3 if metric in (4, 6) and h <= 8 else metric
+        c["qp"] = int(rng.integers(22, 42))
+        c["mv_x"], c["mv_y"] = int(rng.integers(-120, 120)), int(rng.integers(-120, 120))
+        mcm_out[i] = xr.mc_metric(bd, int(c["metric"]), int(c["qp"]), 16, int(c["x"]),
+                                  int(c["y"]), w, h, (int(c["mv_x"]), int(c["mv_y"])),
+                                  pw, ph, orig, ref_s, BL)
     np.savez_compressed(
         os.path.join(OUT, "bipred.npz"), dims=np.array([pw, ph, bd, keep], np.int32),
+        mcm=mcm, mcm_out=mcm_out,
         orig=orig[BL:BL + ph, BL:BL + pw], ref_s=crop(ref_s, BL, keep),
         ref_o=crop(ref_o, BL, keep), c_s=crop(c_s, BC, keep // 2),
         c_o=crop(c_o, BC, keep // 2), jobs=jobs, results=res,

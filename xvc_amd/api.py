@@ -49,6 +49,9 @@ MCBI_DTYPE = np.dtype([("x", "<i2"), ("y", "<i2"), ("w", "u1"), ("h", "u1"),
                        ("comp", "u1"), ("reserved", "u1"), ("mv0_x", "<i4"),
                        ("mv0_y", "<i4"), ("mv1_x", "<i4"), ("mv1_y", "<i4")])
 assert BI_DTYPE.itemsize == 48 and MCBI_DTYPE.itemsize == 24
+MCM_DTYPE = np.dtype([("x", "<i2"), ("y", "<i2"), ("w", "u1"), ("h", "u1"),
+                      ("metric", "u1"), ("qp", "i1"), ("mv_x", "<i4"), ("mv_y", "<i4")])
+assert MCM_DTYPE.itemsize == 16
 CAND_DTYPE = np.dtype([("x", "<i2"), ("y", "<i2"), ("w", "u1"), ("h", "u1"),
                        ("metric", "u1"), ("qp", "i1"), ("mv_x", "<i2"),
                        ("mv_y", "<i2")])
@@ -66,7 +69,7 @@ SYMBOLS = [
     "xvcgpu_picture_wrap", "xvcgpu_picture_destroy", "xvcgpu_picture_upload",
     "xvcgpu_picture_download", "xvcgpu_picture_upload_padded",
     "xvcgpu_picture_download_padded", "xvcgpu_picture_plane",
-    "xvcgpu_picture_copy", "xvcgpu_pad_border", "xvcgpu_metric_batch",
+    "xvcgpu_picture_copy", "xvcgpu_pad_border", "xvcgpu_metric_batch", "xvcgpu_mc_metric_batch",
     "xvcgpu_me_search", "xvcgpu_me_search_sized", "xvcgpu_mc_batch", "xvcgpu_mc_from_me",
     "xvcgpu_mc_bipred_batch", "xvcgpu_bipred_search",
     "xvcgpu_cu_info_from_me", "xvcgpu_recon_from_me", "xvcgpu_residual_batch",
@@ -139,6 +142,7 @@ def load_library():
         "xvcgpu_pad_border": [_vp, _vp],
         "xvcgpu_metric_batch": [_vp, _vp, _vp, C.c_int, C.c_double, C.c_int, _vp,
                                 C.c_int, _vp],
+        "xvcgpu_mc_metric_batch": [_vp, _vp, _vp, C.c_int, _vp, C.c_int, _vp],
         "xvcgpu_me_search": [_vp, _vp, _vp, C.c_int, _vp, C.c_int, _vp],
         "xvcgpu_me_search_sized": [_vp, _vp, _vp, C.c_int, _vp, C.c_int, _vp, C.c_int],
         "xvcgpu_mc_batch": [_vp, _vp, _vp, _vp, C.c_int],
@@ -436,6 +440,17 @@ class Context:
         self.mc_batch_dev(ref, pred, db.ptr, len(blocks))
         self.sync()
         db.free()
+
+    def mc_metric_batch(self, orig, ref, cands, strength=16):
+        cands = np.ascontiguousarray(cands, MCM_DTYPE)
+        dc = self.buffer(cands)
+        do = self.alloc(8 * max(1, len(cands)))
+        self._check(self.lib.xvcgpu_mc_metric_batch(self.h, orig.h_pic, ref.h_pic,
+                                                    strength, dc.ptr, len(cands), do.ptr))
+        out = do.to_array(np.uint64, len(cands))
+        dc.free()
+        do.free()
+        return out
 
     def mc_bipred_batch(self, ref0, ref1, pred, blocks):
         blocks = np.ascontiguousarray(blocks, MCBI_DTYPE)

@@ -261,4 +261,32 @@ mc_bipred_kernel(PicView ref0, PicView ref1, PicView pred,
         d_clip_bd(((int)p[0][i] + (int)p[1][i] + off) >> sh, smax);
 }
 
+// T4 building block (GetSubpelDist / EvalStartMvp / SearchMergeCandidates per
+// candidate): MotionCompensationMv of the luma block into LDS, then
+// SampleMetric::CompareSample(orig, pred).  One wave per candidate, two per
+// workgroup.  grid: ceil(n/2); block: 128.
+__global__ void __launch_bounds__(128)
+mc_metric_kernel(PlaneView orig, PlaneView ref, int bd, int strength,
+                 const xvcgpu_mc_metric_cand *cands, int n, uint64_t *out) {
+  __shared__ struct {
+    int16_t tmp[64 * 71];
+    uint16_t pred[64 * 64];
+  } sh[2];
+  const int wave = threadIdx.x >> 6;
+  const int ci = blockIdx.x * 2 + wave;
+  if (ci >= n) return;
+  const xvcgpu_mc_metric_cand cd = cands[ci];
+  xvcgpu_me_block b;
+  b.x = cd.x;
+  b.y = cd.y;
+  b.w = cd.w;
+  b.h = cd.h;
+  bi_mc_luma(bd, b, ref, cd.mv_x, cd.mv_y, sh[wave].tmp, sh[wave].pred);
+  wave_sync();
+  const uint16_t *o = orig.p + (ptrdiff_t)cd.y * orig.stride + cd.x;
+  const uint64_t dist = wave_compare(cd.metric, bd, cd.qp, strength, cd.w, cd.h, o,
+                                     orig.stride, sh[wave].pred, cd.w);
+  if ((threadIdx.x & 63) == 0) out[ci] = dist;
+}
+
 #endif  // XVCGPU_K_BIPRED_H_

@@ -117,7 +117,7 @@ __device__ __forceinline__ void tx_inv_dst4(int shift, const int16_t *in,
 __device__ __forceinline__ bool tx_small_job(const xvcgpu_tx_block &b) {
   const bool okw = b.w == 4 || b.w == 8 || b.w == 16;
   const bool okh = b.h == 4 || b.h == 8 || b.h == 16;
-  return okw && okh && !(b.dst4x4 && b.w == 4 && b.h == 4);
+  return okw && okh && !(b.dst4x4 && b.w == 4 && b.h == 4) && b.tx_hor != XVC_TX_SKIP;
 }
 
 // One workgroup (256 threads) = one job: the general path (blocks above
@@ -135,11 +135,12 @@ __device__ __forceinline__ void residual_job(TxShared &s, int bi, const PicView 
   const int lw = 31 - __clz(w);
   const int lgw = d_log2_size(w), lgh = d_log2_size(h);
   const PlaneView pp = pred.c[b.comp];
-  const bool dst4 = b.dst4x4 && w == 4 && h == 4;
+  const bool skip = b.tx_hor == XVC_TX_SKIP;  // TransformSkip, blocks <= 4x4
+  const bool dst4 = b.dst4x4 && w == 4 && h == 4 && !skip;
   int16_t *lv = (levels && level_off) ? levels + level_off[bi] : nullptr;
 
   // matrices
-  if (!dst4) {
+  if (!dst4 && !skip) {
     const int16_t *gh = tx_tables + tx_table_off(lay, b.tx_hor, w);
     const int16_t *gv = tx_tables + tx_table_off(lay, b.tx_ver, h);
     for (int i = threadIdx.x; i < w * w; i += TX_THREADS) s.mh[i] = gh[i];
@@ -166,7 +167,14 @@ __device__ __forceinline__ void residual_job(TxShared &s, int bi, const PicView 
     __syncthreads();
     // forward transform (transform.cc:869-961, high precision)
     const int shift1 = lgw + bd - 9 + 2, shift2 = lgh + 6 + 2;
-    if (dst4) {
+    if (skip) {  // ForwardTransform::TransformSkip, transform.cc:963-995
+      const int sh = tshift + (bias ? -8 : 0), sc = bias ? 181 : 1;
+      for (int i = threadIdx.x; i < w * h; i += TX_THREADS) {
+        const int k = (i >> lw) * TX_S + (i & (w - 1));
+        const int v = (int)s.a[k] * sc;
+        s.a[k] = sh > 0 ? (int16_t)(v * (1 << sh)) : (int16_t)((v + (1 << (-sh - 1))) >> -sh);
+      }
+    } else if (dst4) {
       tx_fwd_dst4(shift1 - 2, s.a, s.b);
       __syncthreads();
       tx_fwd_dst4(shift2 - 2, s.b, s.a);
@@ -246,7 +254,15 @@ __device__ __forceinline__ void residual_job(TxShared &s, int bi, const PicView 
     const bool dct2_both =
         (b.tx_ver == XVC_TX_DEFAULT || b.tx_ver == XVC_TX_DCT2) &&
         (b.tx_hor == XVC_TX_DEFAULT || b.tx_hor == XVC_TX_DCT2);
-    if (dst4) {
+    if (skip) {  // InverseTransform::TransformSkip, transform.cc:184-215
+      const int sh = tshift + (bias ? 7 : 0), sc = bias ? 181 : 1;
+      for (int i = threadIdx.x; i < w * h; i += TX_THREADS) {
+        const int k = (i >> lw) * TX_S + (i & (w - 1));
+        const int v = (int)s.a[k] * sc;
+        s.a[k] = sh > 0 ? (int16_t)((v + (1 << (sh - 1))) >> sh)
+                        : (int16_t)((uint32_t)v << -sh);
+      }
+    } else if (dst4) {
       tx_inv_dst4(shift1 - 2, s.a, s.b);
       __syncthreads();
       tx_inv_dst4(shift2 - 2, s.b, s.a);

@@ -486,6 +486,23 @@ xvcgpu_status xvcgpu_metric_batch(xvcgpu_ctx *ctx, const xvcgpu_picture *a,
   return XVCGPU_OK;
 }
 
+xvcgpu_status xvcgpu_mc_metric_batch(xvcgpu_ctx *ctx, const xvcgpu_picture *orig,
+                                     const xvcgpu_picture *ref,
+                                     int structural_strength,
+                                     const xvcgpu_mc_metric_cand *d_cands, int n,
+                                     uint64_t *d_out) {
+  if (!ctx || !orig || !ref || n < 0 || (n && (!d_cands || !d_out)))
+    return XVCGPU_INVALID_ARGUMENT;
+  if (orig->w != ref->w || orig->h != ref->h || orig->bd != ref->bd)
+    return fail(ctx, XVCGPU_INVALID_ARGUMENT, "picture mismatch");
+  if (n == 0) return XVCGPU_OK;
+  hipLaunchKernelGGL(mc_metric_kernel, dim3((n + 1) / 2), dim3(128), 0, ctx->stream,
+                     orig->v.c[0], ref->v.c[0], orig->bd, structural_strength, d_cands,
+                     n, d_out);
+  CHECK_LAUNCH(ctx, "mc_metric_batch");
+  return XVCGPU_OK;
+}
+
 static dim3 me2_grid(int n, int waves) {
   const int n_wg = (n + waves - 1) / waves;
   return dim3((n_wg + 7) / 8 * 8);

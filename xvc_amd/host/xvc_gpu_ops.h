@@ -142,6 +142,19 @@ class InterSearch {
                                 static_cast<int>(blocks.size()), r.data()));
     return r.ToHost();
   }
+  // InterSearch::GetSubpelDist per candidate MV (the step EvalStartMvp and
+  // SearchMergeCandidates repeat): motion-compensate the luma block, Compare.
+  std::vector<uint64_t> GetSubpelDistBatch(
+      const Picture &orig_pic, const Picture &ref_pic,
+      const std::vector<xvcgpu_mc_metric_cand> &cands,
+      int structural_strength = 16) const {
+    DeviceArray<xvcgpu_mc_metric_cand> d(ctx_, cands);
+    DeviceArray<uint64_t> r(ctx_, cands.size());
+    ctx_.Check(xvcgpu_mc_metric_batch(ctx_.get(), orig_pic.get(), ref_pic.get(),
+                                      structural_strength, d.data(),
+                                      static_cast<int>(cands.size()), r.data()));
+    return r.ToHost();
+  }
   // One SearchBiIterative refinement step per job (inter_search.cc:392-433):
   // ref_other = picture of the list whose MV is fixed (job.other_mv),
   // ref_search = picture of the list being refined.
