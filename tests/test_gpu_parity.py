@@ -676,6 +676,45 @@ def test_frame_pass(gpu, xo, size, fused):
         p.destroy()
 
 
+@pytest.mark.parametrize("size", [(352, 288), (1920, 1080)])
+def test_decode_pass_equals_encoder_reconstruction(gpu, xo, size):
+    """N1: the decoder-side reconstruction (MVs + levels -> MC, dequant,
+    inverse transform, deblock, pad) reproduces the encoder's reconstruction
+    and the oracle's - the reference's own enc-rec == dec-out invariant."""
+    api, ctx = gpu
+    from xvc_amd import pipeline, synth
+    import oracle_frame
+    pw, ph = size
+    bd = 10
+    clip = synth.SyntheticClip(pw, ph, bd)
+    enc = pipeline.FramePass(ctx, pw, ph, bd, qp=32, keep_levels=True)
+    dec = pipeline.DecodePass(ctx, enc.desc, bd)
+    ref_host = pad_planes(clip.frame(0), bd)
+    O, R, Renc, Rdec = (ctx.picture(pw, ph, bd) for _ in range(4))
+    R.upload(ref_host, BL)
+    for n in (1, 2):
+        orig_host = pad_planes(clip.frame(n), bd)
+        O.upload(orig_host, BL)
+        enc.run(O, R, Renc, ref_poc=n - 1)
+        dec.run(R, Rdec, enc.d_res.ptr, enc.d_levels.ptr, enc.d_level_off.ptr,
+                enc.d_nnz.ptr, ref_poc=n - 1)
+        ctx.sync()
+        a, b = Renc.download(BL), Rdec.download(BL)
+        e_rec = oracle_frame.frame_pass(enc.desc, bd, orig_host, ref_host, BL,
+                                        ref_poc=n - 1, lib=xo)[0]
+        for c in range(3):
+            assert np.array_equal(a[c], b[c]), (n, c)
+            assert np.array_equal(b[c], e_rec[c]), (n, c)
+        levels = enc.d_levels.to_array(np.int16, enc.n_levels)
+        assert np.any(levels != 0)
+        ref_host = e_rec
+        R.upload(ref_host, BL)
+    enc.destroy()
+    dec.destroy()
+    for p in (O, R, Renc, Rdec):
+        p.destroy()
+
+
 def test_recorded_frame_pass_replay(gpu, xo):
     """xvcgpu_record_* / xvcgpu_replay: the recorded frame pass replayed as one
     HIP graph gives the same bytes as the oracle, on every replay."""

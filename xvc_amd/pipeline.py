@@ -109,9 +109,11 @@ class FramePass:
     (or of one CTU-row shard of it)."""
 
     def __init__(self, ctx, width, height, bitdepth=10, qp=32, cu=16,
-                 search_range=96, row_range=None, fused=True):
+                 search_range=96, row_range=None, fused=True, keep_levels=False):
         self.ctx = ctx
-        self.fused = fused and width % 8 == 0 and height % 8 == 0
+        # keep_levels: also store the quantised coefficients of every TU (what
+        # the entropy coder - or DecodePass - consumes); needs the unfused path
+        self.fused = fused and width % 8 == 0 and height % 8 == 0 and not keep_levels
         self.w, self.h, self.bd = width, height, bitdepth
         self.desc = d = FrameDescriptors(width, height, qp, cu, search_range,
                                          row_range)
@@ -126,6 +128,12 @@ class FramePass:
                                          api.CU_DTYPE.itemsize * d.n_cus_total))
         self.d_ssd = ctx.alloc(16)
         self.pred = ctx.picture(width, height, bitdepth)
+        self.d_levels = self.d_level_off = None
+        if keep_levels:
+            off, total = ctx.level_offsets(d.tx)
+            self.d_level_off = ctx.buffer(off)
+            self.d_levels = ctx.alloc(2 * max(1, total))
+            self.n_levels = total
 
     @property
     def d_cus_own(self):
@@ -147,7 +155,9 @@ class FramePass:
             return
         ctx.mc_from_me_dev(ref, self.pred, self.d_me.ptr, self.d_res.ptr, n)
         ctx.residual_batch_dev(orig, self.pred, rec, self.d_tx.ptr, len(d.tx),
-                               None, None, self.d_nnz.ptr)
+                               self.d_levels.ptr if self.d_levels else None,
+                               self.d_level_off.ptr if self.d_level_off else None,
+                               self.d_nnz.ptr)
         ctx.cu_info_from_me_dev(self.d_me.ptr, self.d_res.ptr, self.d_nnz.ptr,
                                 self.d_luma_idx.ptr, n, d.qp, d.qp_c, ref_poc,
                                 self.d_cus_own)
@@ -178,7 +188,53 @@ class FramePass:
 
     def destroy(self):
         for b in (self.d_me, self.d_tx, self.d_luma_idx, self.d_map, self.d_res,
-                  self.d_nnz, self.d_cus, self.d_ssd):
+                  self.d_nnz, self.d_cus, self.d_ssd, self.d_levels, self.d_level_off):
+            if b is not None:
+                b.free()
+        self.pred.destroy()
+
+
+class DecodePass:
+    """The decoder's reconstruction of one inter picture from parsed syntax
+    (SURVEY section 8f row N1; PictureDecoder::Decode, picture_decoder.cc:
+    168-200, and CuDecoder::DecompressInter / DecompressComponent,
+    cu_decoder.cc:102-138): per CU the MV, per TU the levels and the cbf;
+    motion compensation -> Quantize::Inverse + InverseTransform + AddClip
+    (or CopyFrom when cbf == 0) -> deblocking -> PadBorder.  Same kernels as
+    the encoder's reconstruction, so encoder rec == decoder output by
+    construction - which the tests check."""
+
+    def __init__(self, ctx, desc, bitdepth=10):
+        self.ctx, self.desc, self.bd = ctx, desc, bitdepth
+        d = desc
+        self.d_me = ctx.buffer(d.me)
+        self.d_tx = ctx.buffer(d.tx)
+        self.d_luma_idx = ctx.buffer(d.luma_idx)
+        self.d_map = ctx.buffer(d.cu_map)
+        self.d_cus = ctx.alloc(api.CU_DTYPE.itemsize * d.n_cus_total)
+        ctx._check(ctx.lib.xvcgpu_memset(ctx.h, self.d_cus.ptr, 0,
+                                         api.CU_DTYPE.itemsize * d.n_cus_total))
+        self.pred = ctx.picture(d.w, d.h, bitdepth)
+
+    def run(self, ref, rec, d_mvs, d_levels, d_level_off, d_nnz, ref_poc=0,
+            deblock=True, pad=True):
+        """d_mvs: xvcgpu_me_result per CU (mv_x / mv_y used); d_levels /
+        d_level_off / d_nnz: per TU, as xvcgpu_residual_batch lays them out."""
+        ctx, d = self.ctx, self.desc
+        ctx.mc_from_me_dev(ref, self.pred, self.d_me.ptr, d_mvs, d.n_cus)
+        ctx._check(ctx.lib.xvcgpu_inv_transform_batch(
+            ctx.h, self.pred.h_pic, rec.h_pic, self.d_tx.ptr, len(d.tx), d_levels,
+            d_level_off, d_nnz))
+        ctx.cu_info_from_me_dev(self.d_me.ptr, d_mvs, d_nnz, self.d_luma_idx.ptr,
+                                d.n_cus, d.qp, d.qp_c, ref_poc, self.d_cus.ptr)
+        if deblock:
+            ctx.deblock_dev(rec, self.d_cus.ptr, d.n_cus_total, self.d_map.ptr,
+                            d.cu_map.shape[1], 0, 0, 0, 4)
+        if pad:
+            ctx.pad_border(rec)
+
+    def destroy(self):
+        for b in (self.d_me, self.d_tx, self.d_luma_idx, self.d_map, self.d_cus):
             b.free()
         self.pred.destroy()
 
