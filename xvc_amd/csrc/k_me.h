@@ -28,24 +28,25 @@ struct __attribute__((packed, aligned(2))) U16x4 {
 // ss samples, any 2-byte alignment) to LDS (row stride ds samples, 16-byte
 // aligned rows) by one wave.  The loads of a batch (up to 8 per lane) are all
 // issued before the first store, so the copy costs one memory round trip per
-// batch rather than one per loop iteration.
+// batch (B loads per lane) rather than one per loop iteration.
+template <int B = 8>
 __device__ __forceinline__ void wave_copy_chunks(uint16_t *dst, int ds, const uint16_t *src,
                                                  int ss, int rows, int cpr) {
   const int lane = threadIdx.x & 63;
   const int n = rows * cpr;
   const uint32_t inv = (65536u + (uint32_t)cpr - 1u) / (uint32_t)cpr;  // exact for n < 4096
-  for (int base = lane; base < n; base += 64 * 8) {
-    U16x8 v[8];
-    int off[8];
+  for (int base = lane; base < n; base += 64 * B) {
+    U16x8 v[B];
+    int off[B];
 #pragma unroll
-    for (int u = 0; u < 8; u++) {
+    for (int u = 0; u < B; u++) {
       const int i = base + 64 * u;
       const int r = (int)(((uint32_t)i * inv) >> 16), ch = i - r * cpr;
       off[u] = r * ds + ch * 8;
       if (i < n) v[u] = *reinterpret_cast<const U16x8 *>(src + (ptrdiff_t)r * ss + ch * 8);
     }
 #pragma unroll
-    for (int u = 0; u < 8; u++)
+    for (int u = 0; u < B; u++)
       if (base + 64 * u < n)
         *reinterpret_cast<uint4 *>(dst + off[u]) =
             make_uint4(v[u].v[0], v[u].v[1], v[u].v[2], v[u].v[3]);

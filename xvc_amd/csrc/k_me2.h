@@ -271,23 +271,36 @@ __device__ __forceinline__ void me2_pattern_at(const Me2Pattern &p, int idx, int
 template <class SH>
 __device__ __forceinline__ void me2_eval_diamonds(const MeCtx &c, SH &s,
                                                   const Me2Pattern &p, int bx, int by,
-                                                  int lo, int total, uint32_t &key0,
-                                                  uint32_t &key1) {
+                                                  int lo, int total, uint32_t best,
+                                                  uint32_t &key0, uint32_t &key1) {
   const int lane = ME2_LANE;
   const int x0 = bx + p.dx0, y0 = by + p.dy0, x1 = bx + p.dx1, y1 = by + p.dy1;
   const bool v0 = lane >= lo && lane < total && tz_inside(c, p.d10, x0, y0) &&
                   (p.d20 == 0 || tz_inside(c, p.d20, x0, y0));
   const bool v1 = lane + 64 >= lo && lane + 64 < total && tz_inside(c, p.d11, x1, y1) &&
                   (p.d21 == 0 || tz_inside(c, p.d21, x1, y1));
+  // cost = dist + rate >= rate: a candidate whose rate term alone is not below
+  // `best` (the running best when the sweep starts; it only decreases) can
+  // never pass the strict `cost < best` test of the fold, so its SAD is not
+  // needed.  Far diamonds (|mvd| >= 32 pel) mostly fall out here.
+  const uint32_t r0 = (c.lambda * d_mvd_bits_fullpel(c.mvp_x, c.mvp_y, x0, y0, c.down)) >> 16;
+  const uint32_t r1 = (c.lambda * d_mvd_bits_fullpel(c.mvp_x, c.mvp_y, x1, y1, c.down)) >> 16;
+  const bool e0 = v0 && r0 < best, e1 = v1 && r1 < best;
+  // survivors packed densely so that the 16-candidate passes stay full
+  const unsigned long long m0 = __ballot(e0), m1 = __ballot(e1);
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  const int n0 = __popcll(m0);
+  const int i0 = __popcll(m0 & lt), i1 = n0 + __popcll(m1 & lt);
+  const int n = n0 + __popcll(m1);
   wave_sync();
-  s.cost[lane] = v0 ? me2_pack_pos(x0, y0) : ME2_NOPOS;
-  s.cost[lane + 64] = v1 ? me2_pack_pos(x1, y1) : ME2_NOPOS;
+  if (e0) s.cost[i0] = me2_pack_pos(x0, y0);
+  if (e1) s.cost[i1] = me2_pack_pos(x1, y1);
   wave_sync();
-  me2_eval_positions(c, s.cost, s.orig, total);
+  me2_eval_positions(c, s.cost, s.orig, n);
   wave_sync();
   key0 = key1 = ME2_NOKEY;
-  if (v0) key0 = (me_cost(c, s.cost[lane], x0, y0) << 7) | (uint32_t)lane;
-  if (v1) key1 = (me_cost(c, s.cost[lane + 64], x1, y1) << 7) | (uint32_t)(lane + 64);
+  if (e0) key0 = ((s.cost[i0] + r0) << 7) | (uint32_t)lane;
+  if (e1) key1 = ((s.cost[i1] + r1) << 7) | (uint32_t)(lane + 64);
 }
 
 // ---- sub-pel ---------------------------------------------------------------
@@ -612,10 +625,13 @@ me_search_wave_kernel(PicView orig, PicView ref,
     reinterpret_cast<uint32_t *>(&s.taps[0][0])[lane] =
         reinterpret_cast<const uint32_t *>(&kLumaTaps[0][0])[lane];
   {  // stage the original block
-    const int lw = 31 - __clz(c.w);
     const uint16_t *o = po.p + (ptrdiff_t)b.y * po.stride + b.x;
-    for (int i = lane; i < c.w * c.h; i += 64)
-      s.orig[i] = o[(ptrdiff_t)(i >> lw) * po.stride + (i & (c.w - 1))];
+    if (c.w >= 8) {
+      wave_copy_chunks<2>(s.orig, c.w, o, po.stride, c.h, c.w >> 3);
+    } else {
+      for (int i = lane; i < 4 * c.h; i += 64)
+        s.orig[i] = o[(ptrdiff_t)(i >> 2) * po.stride + (i & 3)];
+    }
   }
 
   ME2_TRACE(1);  // block descriptor read, original block loads issued
@@ -677,13 +693,13 @@ me_search_wave_kernel(PicView orig, PicView ref,
       // is the common case: evaluate rounds 0..2 (ranges 1,2,4 = 20 nearby
       // candidates) first and the far rounds only if the search goes on.
       const int near_total = total < 20 ? total : 20;
-      me2_eval_diamonds(c, s, pat, bx, by, 0, near_total, k0, k1);
+      me2_eval_diamonds(c, s, pat, bx, by, 0, near_total, st.cost, k0, k1);
       int no_match = 0;
       bool far_done = near_total == total;
       for (int r = 0; r < n_rounds; r++) {
         if (r == 3 && !far_done) {
           uint32_t f0, f1;
-          me2_eval_diamonds(c, s, pat, bx, by, near_total, total, f0, f1);
+          me2_eval_diamonds(c, s, pat, bx, by, near_total, total, st.cost, f0, f1);
           if (f0 != ME2_NOKEY) k0 = f0;
           if (f1 != ME2_NOKEY) k1 = f1;
           far_done = true;
@@ -757,6 +773,11 @@ me_search_wave_kernel(PicView orig, PicView ref,
       const int segw = c.w >= 8 ? 8 : 4, spr = c.w / segw, nsg = c.rows * spr;
       for (int i = lane; i < tot; i += 64) {
         const int gx = fs_min_x + (i % nx) * 5, gy = fs_min_y + (i / nx) * 5;
+        // rate-only lower bound (see me2_eval_diamonds): cannot beat the
+        // running best nor this lane's own best so far
+        const uint32_t rate =
+            (c.lambda * d_mvd_bits_fullpel(c.mvp_x, c.mvp_y, gx, gy, c.down)) >> 16;
+        if (rate >= st.cost || rate >= best) continue;
         const uint16_t *r = c.ref + (ptrdiff_t)gy * c.rs + gx;
         uint32_t sum = 0;
         if (segw == 8 && (nsg & 7) == 0) {
@@ -817,7 +838,7 @@ me_search_wave_kernel(PicView orig, PicView ref,
       st.last_range = 0;
       uint32_t k0, k1;
       const int bx = st.bx, by = st.by;
-      me2_eval_diamonds(c, s, pat, bx, by, 0, total, k0, k1);
+      me2_eval_diamonds(c, s, pat, bx, by, 0, total, st.cost, k0, k1);
       const uint32_t k = wave_min_key(k0 < k1 ? k0 : k1);
       if (k != ME2_NOKEY && (k >> 7) < st.cost) {
         int x, y, pos, rng;
@@ -849,13 +870,7 @@ me_search_wave_kernel(PicView orig, PicView ref,
       const uint16_t *r0 = pr.p + (ptrdiff_t)(b.y + fpy - 4) * pr.stride + b.x + fpx - 8;
       const int cpr = ws >> 3;  // 8-sample chunks per row (ws is 12..80: w+16)
       if ((ws & 7) == 0) {
-        const int nchunk = (h + 8) * cpr;
-        for (int i = lane; i < nchunk; i += 64) {
-          const int r = i / cpr, ch = i - r * cpr;
-          const U16x8 v = *reinterpret_cast<const U16x8 *>(r0 + (ptrdiff_t)r * pr.stride + ch * 8);
-          *reinterpret_cast<uint4 *>(s.win + r * ws + ch * 8) =
-              make_uint4(v.v[0], v.v[1], v.v[2], v.v[3]);
-        }
+        wave_copy_chunks<2>(s.win, ws, r0, pr.stride, h + 8, cpr);
       } else {  // w == 4: ws = 20
         for (int i = lane; i < (h + 8) * ws; i += 64) {
           const int r = i / ws, x = i - r * ws;

@@ -158,9 +158,20 @@ picture_ssd_sum_kernel(const unsigned long long *part_in, int items,
                        unsigned long long *out) {
   __shared__ unsigned long long red[2][4];
   unsigned long long s0 = 0, s1 = 0;
-  for (int i = threadIdx.x; i < items; i += 256) {
-    s0 += part_in[2 * i];
-    s1 += part_in[2 * i + 1];
+  // batches of four independent loads per thread (one round trip per batch)
+  for (int base = threadIdx.x; base < items; base += 4 * 256) {
+    ulonglong2 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int i = base + 256 * u;
+      v[u] = i < items ? reinterpret_cast<const ulonglong2 *>(part_in)[i]
+                       : make_ulonglong2(0ull, 0ull);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      s0 += v[u].x;
+      s1 += v[u].y;
+    }
   }
   s0 = group_sum<64>(s0);
   s1 = group_sum<64>(s1);
