@@ -23,6 +23,22 @@ def xo():
 
 
 # --------------------------------------------------------------------- oracle
+def test_golden_manifest():
+    """The committed vectors are the ones tools/gen_golden.py captured from the
+    reference build (MD5 manifest written at capture time)."""
+    import hashlib
+    lines = open(os.path.join(G, "MANIFEST.md5")).read().split("\n")
+    seen = 0
+    for line in lines:
+        if not line.strip():
+            continue
+        digest, name = line.split()
+        data = open(os.path.join(G, name), "rb").read()
+        assert hashlib.md5(data).hexdigest() == digest, name
+        seen += 1
+    assert seen == len([f for f in os.listdir(G) if f.endswith(".npz")])
+
+
 def test_oracle_metrics(xo):
     g = load("metrics")
     for i, (bd, w, h, metric, qp) in enumerate(g["cases"]):

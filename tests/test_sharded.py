@@ -226,3 +226,26 @@ def test_sharded_gloo_two_ranks():
             for c in range(3):
                 assert np.array_equal(rec[c], expect[n][0][c]), (rank, n, c)
             assert ssd == expect[n][1]
+
+
+def test_synthetic_clip_c_mirror_matches_python():
+    """the clip generator exists in C (oracle/xvc_synth.c) and in
+    Python (xvc_amd/synth.py) and both produce identical bytes."""
+    import ctypes as C
+    import oracle_lib as ol
+    from xvc_amd import synth
+    dll = ol.Lib("xo").dll
+    dll.xo_synth_frame.restype = None
+    dll.xo_synth_frame.argtypes = [C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_int, C.c_int,
+                                   ol.u16p, ol.pd, ol.u16p, ol.pd, ol.u16p, ol.pd]
+    for (w, h, bd, square) in [(136, 72, 10, True), (352, 288, 8, True), (64, 48, 12, False)]:
+        clip = synth.SyntheticClip(w, h, bd, square=square)
+        for n in (0, 1, 7, 33, 70):
+            exp = clip.frame(n)
+            y = np.zeros((h, w), np.uint16)
+            u = np.zeros((h // 2, w // 2), np.uint16)
+            v = np.zeros((h // 2, w // 2), np.uint16)
+            dll.xo_synth_frame(w, h, bd, 1234, int(square), n, ol.ptr(y, ol.u16p), w,
+                               ol.ptr(u, ol.u16p), w // 2, ol.ptr(v, ol.u16p), w // 2)
+            assert np.array_equal(y, exp[0]) and np.array_equal(u, exp[1]) and \
+                np.array_equal(v, exp[2]), (w, h, bd, n)

@@ -103,12 +103,22 @@ def gen_bipred(xr):
         mc=np.array(mc, ol.MCBI_DTYPE), preds=np.array(preds))
 
 
+def write_manifest():
+    import hashlib
+    with open(os.path.join(OUT, "MANIFEST.md5"), "w") as f:
+        for name in sorted(os.listdir(OUT)):
+            if name.endswith(".npz"):
+                f.write("%s  %s\n" % (hashlib.md5(open(os.path.join(OUT, name), "rb").read())
+                                      .hexdigest(), name))
+
+
 def main():
     assert ol.have_ref(), "build the reference harness first: make -C oracle ref"
     xr = ol.Lib("xr")
     os.makedirs(OUT, exist_ok=True)
     if sys.argv[1:] == ["bipred"]:
         gen_bipred(xr)
+        write_manifest()
         return
     rng = np.random.default_rng(20260928)
 
@@ -254,6 +264,7 @@ def main():
     np.savez_compressed(os.path.join(OUT, "picture_ssd.npz"),
                         cases=np.array(cases, np.int64), a=np.array(a_l), b=np.array(b_l))
     gen_bipred(xr)
+    write_manifest()
     total = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))
     print("golden fixtures written to", OUT, "total bytes", total)
 
