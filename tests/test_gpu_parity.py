@@ -635,18 +635,22 @@ def pad_planes(planes, bd):
             for c, p in enumerate(planes)]
 
 
+# BASELINE.json configs: CIF QP32, 1080p QP32, 2160p QP27 (+ a ragged size)
 @pytest.mark.parametrize("fused", [True, False])
-@pytest.mark.parametrize("size", [(352, 288), (136, 72), (1920, 1080)])
+@pytest.mark.parametrize("size", [(352, 288, 32), (136, 72, 32), (1920, 1080, 32),
+                                  (3840, 2160, 27)])
 def test_frame_pass(gpu, xo, size, fused):
     """Whole frame pass (ME -> MC -> residual -> deblock -> pad -> SSD) on the
     GPU against the oracle's frame pass, two chained frames."""
     api, ctx = gpu
     from xvc_amd import pipeline, synth
     import oracle_frame
-    pw, ph = size
+    pw, ph, qp = size
+    if pw > 2000 and not fused:
+        pytest.skip("the 2160p case runs the production (fused) path only")
     bd = 10
     clip = synth.SyntheticClip(pw, ph, bd)
-    fp = pipeline.FramePass(ctx, pw, ph, bd, qp=32, fused=fused)
+    fp = pipeline.FramePass(ctx, pw, ph, bd, qp=qp, fused=fused)
     ref_host = pad_planes(clip.frame(0), bd)
     O, R, Rec = ctx.picture(pw, ph, bd), ctx.picture(pw, ph, bd), ctx.picture(pw, ph, bd)
     R.upload(ref_host, BL)
@@ -755,7 +759,46 @@ def test_recorded_frame_pass_replay(gpu, xo):
         p.destroy()
 
 
-@pytest.mark.parametrize("world", [2, 3])
+def test_frame_pass_8k_10bit_qp37(gpu, xo):
+    """BASELINE config 5 (7680x4320 10-bit, QP 37) at full size: one frame pass
+    against the oracle, and the decoder-side pass reproduces it."""
+    api, ctx = gpu
+    from xvc_amd import pipeline, synth
+    import oracle_frame
+    pw, ph, bd, qp = 7680, 4320, 10, 37
+    clip = synth.SyntheticClip(pw, ph, bd)
+    ref_host, orig_host = pad_planes(clip.frame(0), bd), pad_planes(clip.frame(1), bd)
+    O, R, Renc, Rdec = (ctx.picture(pw, ph, bd) for _ in range(4))
+    R.upload(ref_host, BL)
+    O.upload(orig_host, BL)
+    fp = pipeline.FramePass(ctx, pw, ph, bd, qp=qp)
+    fp.run(O, R, Renc)
+    ctx.sync()
+    e_rec, e_res, _, _, e_ssd = oracle_frame.frame_pass(fp.desc, bd, orig_host, ref_host,
+                                                        BL, lib=xo)
+    res, _, _, ssd = fp.results()
+    assert np.array_equal(res, e_res)
+    got = Renc.download(BL)
+    for c in range(3):
+        assert np.array_equal(got[c], e_rec[c]), c
+    assert (int(ssd[0]), int(ssd[1])) == e_ssd
+    fp.destroy()
+    enc = pipeline.FramePass(ctx, pw, ph, bd, qp=qp, keep_levels=True)
+    dec = pipeline.DecodePass(ctx, enc.desc, bd)
+    enc.run(O, R, Renc)
+    dec.run(R, Rdec, enc.d_res.ptr, enc.d_levels.ptr, enc.d_level_off.ptr, enc.d_nnz.ptr)
+    ctx.sync()
+    a = Rdec.download(BL)
+    for c in range(3):
+        assert np.array_equal(a[c], e_rec[c]), c
+    enc.destroy()
+    dec.destroy()
+    for p in (O, R, Renc, Rdec):
+        p.destroy()
+
+
+# (208x112, 2/3 shards) small; (3840x2160 QP32, 8 shards) = BASELINE config 4
+@pytest.mark.parametrize("world", [2, 3, 8])
 def test_sharded_gpu_engine_loopback(gpu, xo, world):
     """The multi-GPU orchestration with the real HIP engine: `world` shards of
     one picture handled by separate GpuEngine instances on this one GPU, data
@@ -766,7 +809,7 @@ def test_sharded_gpu_engine_loopback(gpu, xo, world):
     from test_sharded import LoopbackComm
     from xvc_amd import pipeline, sharded, synth
     api, ctx = gpu
-    pw, ph, bd, qp = 208, 112, 10, 32
+    pw, ph, bd, qp = (3840, 2160, 10, 32) if world == 8 else (208, 112, 10, 32)
     dev = torch.device("cuda", 0)
     clip = synth.SyntheticClip(pw, ph, bd)
     desc = pipeline.FrameDescriptors(pw, ph, qp)
@@ -778,7 +821,7 @@ def test_sharded_gpu_engine_loopback(gpu, xo, world):
         ranks.append(sharded.ShardedFramePass(e, LoopbackComm(), r, world))
     O = ctx.picture(pw, ph, bd)
     ref_host = pad_planes(clip.frame(0), bd)
-    for n in (1, 2):
+    for n in ((1,) if world == 8 else (1, 2)):
         orig_host = pad_planes(clip.frame(n), bd)
         O.upload(orig_host, BL)
         ref_idx, rec_idx = (n - 1) % 2, n % 2
