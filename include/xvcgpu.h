@@ -209,6 +209,16 @@ xvcgpu_status xvcgpu_mc_batch(xvcgpu_ctx *ctx, const xvcgpu_picture *ref,
                               xvcgpu_picture *pred,
                               const xvcgpu_mc_block *d_blocks, int n);
 
+/* ---- I3 (affine half): MotionCompAffine -> Sample ------------------------- *
+ * (inter_prediction.cc:1044-1136): the CU is cut into sub-blocks whose size
+ * follows from the corner-MV differences, each sub-block gets its own MV
+ * (8-bit-fraction interpolation of the corner MVs, clipped) and is
+ * motion-compensated with the ordinary luma / chroma filters.  Chroma follows
+ * the reference's C kernels (its SSE2 kernels differ on 2-wide blocks). */
+xvcgpu_status xvcgpu_mc_affine_batch(xvcgpu_ctx *ctx, const xvcgpu_picture *ref,
+                                     xvcgpu_picture *pred,
+                                     const xvcgpu_mc_affine_block *d_blocks, int n);
+
 /* ---- I2: MotionCompensation of bi-predicted CUs --------------------------- *
  * (inter_prediction.cc:710-738: MotionCompUniPred -> int16 for both lists,
  * :1156-1172, then AddAvgBi :1545-1547).  ref0 / ref1 are the list-0 / list-1

@@ -117,6 +117,17 @@ typedef struct xvcgpu_mc_bi_block {
   int32_t mv1_x, mv1_y; /* list-1 MV                                       */
 } xvcgpu_mc_bi_block;
 
+/* One affine motion-compensation job (InterPrediction::MotionCompAffine,
+ * inter_prediction.cc:1044-1136) for one component of one uni-pred CU:
+ * mv[0] top-left, mv[1] top-right, mv[2] bottom-left corner, 1/16 pel. */
+typedef struct xvcgpu_mc_affine_block {
+  int16_t x, y;        /* luma position of the CU                          */
+  uint8_t w, h;        /* luma size of the CU                              */
+  uint8_t comp;        /* 0 = Y, 1 = U, 2 = V                              */
+  uint8_t reserved;
+  int32_t mv[3][2];    /* [corner][x,y]                                    */
+} xvcgpu_mc_affine_block;
+
 /* One residual-pipeline job = one (CU, component) pair, i.e. one call of
  * TransformEncoder::TransformAndReconstruct (transform_encoder.cc:203-285)
  * with the non-RDO quantiser. Positions/sizes are in samples of `comp`. */

@@ -237,6 +237,25 @@ void xr_mc_block(int bd, int comp, int x, int y, int w, int h, int mv_x,
                           MotionVector(mv_x, mv_y), false, &pb);
 }
 
+void xr_mc_affine_block(int bd, int comp, int x, int y, int w, int h,
+                        const int mv[3][2], int pic_w, int pic_h,
+                        const uint16_t *ref_plane, ptrdiff_t rs, uint16_t *pred,
+                        ptrdiff_t ps) {
+  PictureData pic_data(ChromaFormat::k420, pic_w, pic_h, bd);
+  CodingUnit *cu = pic_data.CreateCu(CuTree::Primary, 1, x, y, w, h);
+  YuvPicture ref_pic(ChromaFormat::k420, pic_w, pic_h, bd, true, 0, 0);
+  const uint16_t *planes[3] = {nullptr, nullptr, nullptr};
+  ptrdiff_t strides[3] = {0, 0, 0};
+  planes[comp] = ref_plane;
+  strides[comp] = rs;
+  FillPic(&ref_pic, planes, strides);
+  InterPrediction ip(Simd(bd).inter_prediction, ref_pic, bd);
+  SampleBuffer pb(pred, ps);
+  MotionVector3 mv3;
+  for (int i = 0; i < 3; i++) mv3[i] = MotionVector(mv[i][0], mv[i][1]);
+  ip.MotionCompAffine(*cu, YuvComponent(comp), ref_pic, mv3, &pb);
+}
+
 void xr_clip_mv(int pos_x, int pos_y, int pic_w, int pic_h, int *mv_x,
                 int *mv_y) {
   PictureData pic_data(ChromaFormat::k420, pic_w, pic_h, 8);

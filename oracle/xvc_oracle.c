@@ -491,6 +491,69 @@ void xo_mc_block(int bd, int comp, int x, int y, int w, int h, int mv_x,
   xo_mc_uni(bd, comp != 0, cw, ch, frac_x, frac_y, ref, rs, pred, ps);
 }
 
+static int xo_affine_subblock(int ref_x, int ref_y, int mv_x, int mv_y, int size,
+                              int scale) {
+  /* get_subblock_size lambda, inter_prediction.cc:1071-1086 */
+  const int dx = abs(mv_x - ref_x), dy = abs(mv_y - ref_y);
+  const int max_len = dx > dy ? dx : dy;
+  if (!max_len) return size;
+  int sb = (size >> 2) / max_len;
+  if (sb < 1) sb = 1;
+  while (size % sb) sb--;
+  return (sb > 4 ? sb : 4) >> scale;
+}
+
+void xo_mc_affine_block(int bd, int comp, int x, int y, int w, int h,
+                        const int mv_in[3][2], int pic_w, int pic_h,
+                        const uint16_t *ref_plane, ptrdiff_t rs, uint16_t *pred,
+                        ptrdiff_t ps) {
+  /* InterPrediction::MotionCompAffine -> Sample (inter_prediction.cc:1044-1136);
+   * x,y,w,h: luma position / size of the CU; 4:2:0 */
+  int mv[3][2];
+  for (int i = 0; i < 3; i++) { /* ClipMv(MotionVector3), :784-799 */
+    mv[i][0] = mv_in[i][0];
+    mv[i][1] = mv_in[i][1];
+    xo_clip_mv(x, y, pic_w, pic_h, &mv[i][0], &mv[i][1]);
+  }
+  const int cs = comp ? 1 : 0, shift = 4 + cs;
+  const int cx = x >> cs, cy = y >> cs, cw = w >> cs, ch = h >> cs;
+  if (mv[0][0] == mv[1][0] && mv[0][1] == mv[1][1]) { /* :1063-1069 */
+    const uint16_t *r = ref_plane + (ptrdiff_t)(cy + (mv[0][1] >> shift)) * rs + cx +
+                        (mv[0][0] >> shift);
+    xo_mc_uni(bd, comp != 0, cw, ch, mv[0][0] & ((1 << shift) - 1),
+              mv[0][1] & ((1 << shift) - 1), r, rs, pred, ps);
+    return;
+  }
+  /* note: sizes passed are the COMPONENT's width / height (:1087-1090) */
+  const int sbw = xo_affine_subblock(mv[0][0], mv[0][1], mv[1][0], mv[1][1], cw, cs);
+  const int sbh = xo_affine_subblock(mv[0][0], mv[0][1], mv[2][0], mv[2][1], ch, cs);
+  const int mv_max_x = (pic_w - x + 8 - 1) * 16, mv_min_x = (-64 - x - 8 + 1) * 16;
+  const int mv_max_y = (pic_h - y + 8 - 1) * 16, mv_min_y = (-64 - y - 8 + 1) * 16;
+  const int dhx = ((mv[1][0] - mv[0][0]) * 256) / cw; /* C division, :1101-1102 */
+  const int dhy = ((mv[1][1] - mv[0][1]) * 256) / cw;
+  const int dvx = -dhy, dvy = dhx;
+  int hor_x = mv[0][0] * 256, hor_y = mv[0][1] * 256;
+  int ver_x = hor_x, ver_y = hor_y;
+  for (int sy = 0; sy < ch; sy += sbh) {
+    for (int sx = 0; sx < cw; sx += sbw) {
+      int mx = (hor_x + dhx * (sbw >> 1) + dvx * (sbh >> 1)) >> 8;
+      int my = (hor_y + dhy * (sbw >> 1) + dvy * (sbh >> 1)) >> 8;
+      mx = xo_clip3(mx, mv_min_x, mv_max_x);
+      my = xo_clip3(my, mv_min_y, mv_max_y);
+      const uint16_t *r = ref_plane + (ptrdiff_t)(cy + sy + (my >> shift)) * rs + cx + sx +
+                          (mx >> shift);
+      xo_mc_uni(bd, comp != 0, sbw, sbh, mx & ((1 << shift) - 1),
+                my & ((1 << shift) - 1), r, rs, pred + (ptrdiff_t)sy * ps + sx, ps);
+      hor_x += dhx * sbw;
+      hor_y += dhy * sbw;
+    }
+    ver_x += dvx * sbh;
+    ver_y += dvy * sbh;
+    hor_x = ver_x;
+    hor_y = ver_y;
+  }
+}
+
 /* ========================================================================= *
  *  Transforms                                                               *
  * ========================================================================= */

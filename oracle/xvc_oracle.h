@@ -166,6 +166,13 @@ void xo_bipred_search(int bitdepth, const xvcgpu_bi_block *job, int pic_w,
                       const uint16_t *ref_other, ptrdiff_t other_stride,
                       const uint16_t *ref_search, ptrdiff_t search_stride,
                       xvcgpu_me_result *out);
+/* I3 (affine half): InterPrediction::MotionCompAffine -> Sample
+ * (inter_prediction.cc:1044-1136): per-sub-block MVs from the three corner
+ * MVs mv[0..2] = {x,y} in 1/16 pel; x,y,w,h = luma geometry of the CU. */
+void xo_mc_affine_block(int bitdepth, int comp, int x, int y, int w, int h,
+                        const int mv[3][2], int pic_w, int pic_h,
+                        const uint16_t *ref_plane, ptrdiff_t ref_stride,
+                        uint16_t *pred, ptrdiff_t pred_stride);
 /* InterSearch::GetSubpelDist (inter_search.cc:951-964): MotionCompensationMv
  * of a luma block, then CompareSample(orig, prediction). */
 uint64_t xo_mc_metric(int bitdepth, int metric, int qp_raw_y, int strength, int x,

@@ -92,6 +92,8 @@ BI_DTYPE = np.dtype([("blk", ME_DTYPE), ("other_mv_x", "<i4"),
 MCBI_DTYPE = np.dtype([("x", "<i2"), ("y", "<i2"), ("w", "u1"), ("h", "u1"),
                        ("comp", "u1"), ("reserved", "u1"), ("mv0_x", "<i4"),
                        ("mv0_y", "<i4"), ("mv1_x", "<i4"), ("mv1_y", "<i4")])
+MCAFF_DTYPE = np.dtype([("x", "<i2"), ("y", "<i2"), ("w", "u1"), ("h", "u1"),
+                        ("comp", "u1"), ("reserved", "u1"), ("mv", "<i4", (3, 2))])
 MCM_DTYPE = np.dtype([("x", "<i2"), ("y", "<i2"), ("w", "u1"), ("h", "u1"),
                       ("metric", "u1"), ("qp", "i1"), ("mv_x", "<i4"), ("mv_y", "<i4")])
 TX_DTYPE = np.dtype([("x", "<i2"), ("y", "<i2"), ("w", "u1"), ("h", "u1"),
@@ -187,6 +189,8 @@ class Lib:
         sig("bipred_search", None,
             [C.c_int, C.POINTER(BiBlock), C.c_int, C.c_int, u16p, pd, u16p, pd,
              u16p, pd, C.POINTER(MeResult)])
+        sig("mc_affine_block", None,
+            [C.c_int] * 6 + [i32p, C.c_int, C.c_int, u16p, pd, u16p, pd])
         sig("mc_metric", C.c_uint64,
             [C.c_int] * 12 + [u16p, pd, u16p, pd])
         sig("mc_bipred_block", None,
@@ -367,6 +371,16 @@ class Lib:
                               ptr(target, i16p), self._s(target), ptr(r, u16p),
                               self._s(ref_pad), pw, ph, ptr(mv, i32p))
         return int(mv[0]), int(mv[1])
+
+    def mc_affine_block(self, bd, comp, x, y, w, h, mv3, pw, ph, padded, border):
+        """mv3: three (x, y) corner MVs in 1/16 pel."""
+        sh = 1 if comp else 0
+        out = np.zeros((h >> sh, w >> sh), np.uint16)
+        mv = np.ascontiguousarray(mv3, np.int32).reshape(3, 2)
+        r = padded[border:, border:]
+        self._mc_affine_block(bd, comp, x, y, w, h, ptr(mv, i32p), pw, ph,
+                              ptr(r, u16p), self._s(padded), ptr(out, u16p), self._s(out))
+        return out
 
     def mc_metric(self, bd, metric, qp, strength, x, y, w, h, mv, pw, ph, orig_pad,
                   ref_pad, border):

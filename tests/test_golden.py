@@ -159,6 +159,13 @@ def test_oracle_bipred(xo):
     for j, r in zip(g["jobs"], g["results"]):
         mv, d = xo.bipred_search(bd, bi_struct(j), pw, ph, orig, luma[1], luma[0], BL)
         assert (mv, d) == ((int(r["mv_x"]), int(r["mv_y"])), int(r["subpel_dist"]))
+    for b, exp in zip(g["aff"], g["aff_out"]):
+        comp = int(b["comp"]); cs = 1 if comp else 0
+        mv3 = [tuple(int(v) for v in m) for m in b["mv"]]
+        p = xo.mc_affine_block(bd, comp, int(b["x"]), int(b["y"]), int(b["w"]), int(b["h"]),
+                               mv3, pw, ph, luma[0] if comp == 0 else chroma[0],
+                               BL if comp == 0 else BC)
+        assert np.array_equal(p, exp[:int(b["h"]) >> cs, :int(b["w"]) >> cs]), tuple(b)
     for c, exp in zip(g["mcm"], g["mcm_out"]):
         got = xo.mc_metric(bd, int(c["metric"]), int(c["qp"]), 16, int(c["x"]), int(c["y"]),
                            int(c["w"]), int(c["h"]), (int(c["mv_x"]), int(c["mv_y"])),
@@ -311,6 +318,12 @@ def test_gpu_bipred(gpu):
     for name in ("mv_x", "mv_y", "subpel_dist"):
         assert np.array_equal(res[name], g["results"][name]), name
     assert np.array_equal(ctx.mc_metric_batch(O, RS, g["mcm"], strength=16), g["mcm_out"])
+    for b, exp in zip(g["aff"], g["aff_out"]):
+        ctx.mc_affine_batch(RS, P, np.array([b], api.MCAFF_DTYPE))
+        comp = int(b["comp"]); cs = 1 if comp else 0
+        x, y, w, h = int(b["x"]), int(b["y"]), int(b["w"]), int(b["h"])
+        got = P.download()[comp][y >> cs:(y + h) >> cs, x >> cs:(x + w) >> cs]
+        assert np.array_equal(got, exp[:h >> cs, :w >> cs]), tuple(b)
     for b, exp in zip(g["mc"], g["preds"]):
         ctx.mc_bipred_batch(RS, RO, P, np.array([b], api.MCBI_DTYPE))
         comp = int(b["comp"]); cs = 1 if comp else 0

@@ -291,6 +291,46 @@ def test_mc_metric_batch(gpu, xo, bd):
 
 
 @pytest.mark.parametrize("bd", [8, 10, 12])
+def test_mc_affine_batch(gpu, xo, bd):
+    """I3 (affine half): MotionCompAffine for all three components."""
+    from test_oracle_vs_ref import affine_mvs
+    api, ctx = gpu
+    rng = np.random.default_rng(3800 + bd)
+    pw, ph = 256, 192
+    pr = padded_planes(rng, bd, pw, ph, smooth=True)
+    R, P = ctx.picture(pw, ph, bd), ctx.picture(pw, ph, bd)
+    R.upload(pr, BL)
+    grid = []
+    i = 0
+    y = 0
+    for (w, h) in [(64, 64), (32, 64), (64, 32), (32, 32), (16, 16)]:
+        if y + h > ph:
+            break
+        for x in range(0, pw - w + 1, w):
+            mv3 = affine_mvs(rng, w, i)
+            i += 1
+            for comp in range(3):
+                grid.append((x, y, w, h, comp, 0, mv3))
+        y += h
+    grid = np.array(grid, api.MCAFF_DTYPE)
+    ctx.mc_affine_batch(R, P, grid)
+    got = P.download()
+    n_sub = 0
+    for b in grid:
+        comp = int(b["comp"]); cs = 1 if comp else 0
+        x, y, w, h = int(b["x"]), int(b["y"]), int(b["w"]), int(b["h"])
+        mv3 = [tuple(int(v) for v in m) for m in b["mv"]]
+        exp = xo.mc_affine_block(bd, comp, x, y, w, h, mv3, pw, ph, pr[comp],
+                                 BL if comp == 0 else BC)
+        g = got[comp][y >> cs:(y + h) >> cs, x >> cs:(x + w) >> cs]
+        assert np.array_equal(g, exp), (tuple(b), mv3)
+        n_sub += mv3[0] != mv3[1]
+    assert n_sub > 30
+    R.destroy()
+    P.destroy()
+
+
+@pytest.mark.parametrize("bd", [8, 10, 12])
 def test_mc_bipred_batch(gpu, xo, bd):
     """I2: two 14-bit predictions + AddAvg vs the oracle."""
     api, ctx = gpu

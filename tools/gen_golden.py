@@ -94,9 +94,30 @@ def gen_bipred(xr):
         mcm_out[i] = xr.mc_metric(bd, int(c["metric"]), int(c["qp"]), 16, int(c["x"]),
                                   int(c["y"]), w, h, (int(c["mv_x"]), int(c["mv_y"])),
                                   pw, ph, orig, ref_s, BL)
+    # affine MC (luma: reference default kernels; chroma: its C kernels, the SSE2
+    # ones differ on 2-wide sub-blocks in this build)
+    aff, aff_out = [], []
+    for i in range(18):
+        w = int(rng.choice([16, 32, 64])); h = int(rng.choice([16, 32, 64]))
+        x = int(rng.integers(0, (pw - w) // 8 + 1)) * 8
+        y = int(rng.integers(0, (ph - h) // 8 + 1)) * 8
+        base = (int(rng.integers(-100, 100)), int(rng.integers(-100, 100)))
+        span = int(rng.choice([2, 6, 30]))
+        mv3 = [base,
+               (base[0] + int(rng.integers(-span, span + 1)), base[1] + int(rng.integers(-span, span + 1))),
+               (base[0] + int(rng.integers(-span, span + 1)), base[1] + int(rng.integers(-span, span + 1)))]
+        comp = i % 3
+        xr._set_simd(1 if comp == 0 else 0)
+        p = xr.mc_affine_block(bd, comp, x, y, w, h, mv3, pw, ph,
+                               ref_s if comp == 0 else c_s, BL if comp == 0 else BC)
+        aff.append((x, y, w, h, comp, 0, mv3))
+        pp = np.zeros((64, 64), np.uint16)
+        pp[:p.shape[0], :p.shape[1]] = p
+        aff_out.append(pp)
+    xr._set_simd(1)
     np.savez_compressed(
         os.path.join(OUT, "bipred.npz"), dims=np.array([pw, ph, bd, keep], np.int32),
-        mcm=mcm, mcm_out=mcm_out,
+        mcm=mcm, mcm_out=mcm_out, aff=np.array(aff, ol.MCAFF_DTYPE), aff_out=np.array(aff_out),
         orig=orig[BL:BL + ph, BL:BL + pw], ref_s=crop(ref_s, BL, keep),
         ref_o=crop(ref_o, BL, keep), c_s=crop(c_s, BC, keep // 2),
         c_o=crop(c_o, BC, keep // 2), jobs=jobs, results=res,

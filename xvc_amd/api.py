@@ -49,6 +49,9 @@ MCBI_DTYPE = np.dtype([("x", "<i2"), ("y", "<i2"), ("w", "u1"), ("h", "u1"),
                        ("comp", "u1"), ("reserved", "u1"), ("mv0_x", "<i4"),
                        ("mv0_y", "<i4"), ("mv1_x", "<i4"), ("mv1_y", "<i4")])
 assert BI_DTYPE.itemsize == 48 and MCBI_DTYPE.itemsize == 24
+MCAFF_DTYPE = np.dtype([("x", "<i2"), ("y", "<i2"), ("w", "u1"), ("h", "u1"),
+                        ("comp", "u1"), ("reserved", "u1"), ("mv", "<i4", (3, 2))])
+assert MCAFF_DTYPE.itemsize == 32
 MCM_DTYPE = np.dtype([("x", "<i2"), ("y", "<i2"), ("w", "u1"), ("h", "u1"),
                       ("metric", "u1"), ("qp", "i1"), ("mv_x", "<i4"), ("mv_y", "<i4")])
 assert MCM_DTYPE.itemsize == 16
@@ -71,7 +74,7 @@ SYMBOLS = [
     "xvcgpu_picture_download_padded", "xvcgpu_picture_plane",
     "xvcgpu_picture_copy", "xvcgpu_pad_border", "xvcgpu_metric_batch", "xvcgpu_mc_metric_batch",
     "xvcgpu_me_search", "xvcgpu_me_search_sized", "xvcgpu_mc_batch", "xvcgpu_mc_from_me",
-    "xvcgpu_mc_bipred_batch", "xvcgpu_bipred_search",
+    "xvcgpu_mc_bipred_batch", "xvcgpu_bipred_search", "xvcgpu_mc_affine_batch",
     "xvcgpu_cu_info_from_me", "xvcgpu_recon_from_me", "xvcgpu_residual_batch",
     "xvcgpu_fwd_transform_batch", "xvcgpu_inv_transform_batch",
     "xvcgpu_deblock", "xvcgpu_deblock_rows", "xvcgpu_picture_ssd", "xvcgpu_get_transform_matrix",
@@ -148,6 +151,7 @@ def load_library():
         "xvcgpu_mc_batch": [_vp, _vp, _vp, _vp, C.c_int],
         "xvcgpu_mc_from_me": [_vp, _vp, _vp, _vp, _vp, C.c_int],
         "xvcgpu_mc_bipred_batch": [_vp, _vp, _vp, _vp, _vp, C.c_int],
+        "xvcgpu_mc_affine_batch": [_vp, _vp, _vp, _vp, C.c_int],
         "xvcgpu_bipred_search": [_vp, _vp, _vp, _vp, _vp, C.c_int, _vp, C.c_int],
         "xvcgpu_cu_info_from_me": [_vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int,
                                    C.c_int, C.c_int, _vp],
@@ -451,6 +455,14 @@ class Context:
         dc.free()
         do.free()
         return out
+
+    def mc_affine_batch(self, ref, pred, blocks):
+        blocks = np.ascontiguousarray(blocks, MCAFF_DTYPE)
+        db = self.buffer(blocks)
+        self._check(self.lib.xvcgpu_mc_affine_batch(self.h, ref.h_pic, pred.h_pic, db.ptr,
+                                                    len(blocks)))
+        self.sync()
+        db.free()
 
     def mc_bipred_batch(self, ref0, ref1, pred, blocks):
         blocks = np.ascontiguousarray(blocks, MCBI_DTYPE)

@@ -20,6 +20,7 @@
 
 #include "dev_common.h"
 #include "dev_tables.h"
+#include "k_interp.h"
 #include "k_me.h"
 #include "k_metric.h"
 #include "k_recon.h"
@@ -259,6 +260,91 @@ mc_bipred_kernel(PicView ref0, PicView ref1, PicView pred,
   for (int i = threadIdx.x; i < cw * ch; i += 256)
     dst[(ptrdiff_t)(i >> lw) * pd.stride + (i & (cw - 1))] =
         d_clip_bd(((int)p[0][i] + (int)p[1][i] + off) >> sh, smax);
+}
+
+// I3 (affine half): MotionCompAffine -> Sample (inter_prediction.cc:1044-1136).
+// One workgroup per (CU, component); the sub-blocks are dealt to the 4 waves.
+__device__ __forceinline__ int d_affine_subblock(int rx, int ry, int mx, int my, int size,
+                                                 int scale) {
+  const int dx = d_abs(mx - rx), dy = d_abs(my - ry);
+  const int max_len = dx > dy ? dx : dy;
+  if (!max_len) return size;
+  int sb = (size >> 2) / max_len;
+  sb = sb < 1 ? 1 : sb;
+  while (size % sb) sb--;
+  return (sb > 4 ? sb : 4) >> scale;
+}
+
+__global__ void __launch_bounds__(256)
+mc_affine_kernel(PicView ref, PicView pred, const xvcgpu_mc_affine_block *blocks, int n) {
+  __shared__ union {
+    int16_t whole[64 * 71];  // mv[0] == mv[1]: plain MC of the block
+    struct {
+      int16_t tmp[16 * 71];
+      uint16_t dst[16 * 64];
+    } wv[4];
+  } sh;
+  const int bi = blockIdx.x;
+  if (bi >= n) return;
+  const xvcgpu_mc_affine_block b = blocks[bi];
+  const int bd = ref.bd, comp = b.comp;
+  const int pic_w = ref.c[0].w, pic_h = ref.c[0].h;
+  int mv[3][2];
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+    mv[i][0] = b.mv[i][0];
+    mv[i][1] = b.mv[i][1];
+    d_clip_mv(b.x, b.y, pic_w, pic_h, mv[i][0], mv[i][1]);
+  }
+  const int cs = comp ? 1 : 0, shift = 4 + cs, mask = (1 << shift) - 1;
+  const int cx = b.x >> cs, cy = b.y >> cs, cw = b.w >> cs, ch = b.h >> cs;
+  const PlaneView pr = ref.c[comp], pd = pred.c[comp];
+  uint16_t *out = pd.p + (ptrdiff_t)cy * pd.stride + cx;
+  if (mv[0][0] == mv[1][0] && mv[0][1] == mv[1][1]) {
+    const uint16_t *r =
+        pr.p + (ptrdiff_t)(cy + (mv[0][1] >> shift)) * pr.stride + cx + (mv[0][0] >> shift);
+    if (comp)
+      wg_interp_block<true>(bd, cw, ch, mv[0][0] & mask, mv[0][1] & mask, r, pr.stride,
+                            sh.whole, out, pd.stride);
+    else
+      wg_interp_block<false>(bd, cw, ch, mv[0][0] & mask, mv[0][1] & mask, r, pr.stride,
+                             sh.whole, out, pd.stride);
+    return;
+  }
+  const int sbw = d_affine_subblock(mv[0][0], mv[0][1], mv[1][0], mv[1][1], cw, cs);
+  const int sbh = d_affine_subblock(mv[0][0], mv[0][1], mv[2][0], mv[2][1], ch, cs);
+  const int mv_max_x = (pic_w - b.x + 8 - 1) * 16, mv_min_x = (-64 - b.x - 8 + 1) * 16;
+  const int mv_max_y = (pic_h - b.y + 8 - 1) * 16, mv_min_y = (-64 - b.y - 8 + 1) * 16;
+  const int dhx = ((mv[1][0] - mv[0][0]) * 256) / cw;  // C division
+  const int dhy = ((mv[1][1] - mv[0][1]) * 256) / cw;
+  const int dvx = -dhy, dvy = dhx;
+  const int nsx = cw / sbw, nsy = ch / sbh;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int lsw = 31 - __clz(sbw);
+  for (int k = wave; k < nsx * nsy; k += 4) {
+    const int iy = k / nsx, ix = k - iy * nsx;
+    // the reference's running sums, in closed form
+    const int hor_x = mv[0][0] * 256 + dvx * sbh * iy + dhx * sbw * ix;
+    const int hor_y = mv[0][1] * 256 + dvy * sbh * iy + dhy * sbw * ix;
+    int mx = (hor_x + dhx * (sbw >> 1) + dvx * (sbh >> 1)) >> 8;
+    int my = (hor_y + dhy * (sbw >> 1) + dvy * (sbh >> 1)) >> 8;
+    mx = d_clip3(mx, mv_min_x, mv_max_x);
+    my = d_clip3(my, mv_min_y, mv_max_y);
+    const int sx = ix * sbw, sy = iy * sbh;
+    const uint16_t *r =
+        pr.p + (ptrdiff_t)(cy + sy + (my >> shift)) * pr.stride + cx + sx + (mx >> shift);
+    wave_sync();  // previous sub-block of this wave copied out
+    if (comp)
+      wave_interp_block<true>(bd, sbw, sbh, mx & mask, my & mask, r, pr.stride,
+                              sh.wv[wave].tmp, sh.wv[wave].dst);
+    else
+      wave_interp_block<false>(bd, sbw, sbh, mx & mask, my & mask, r, pr.stride,
+                               sh.wv[wave].tmp, sh.wv[wave].dst);
+    wave_sync();
+    uint16_t *o = out + (ptrdiff_t)sy * pd.stride + sx;
+    for (int i = lane; i < sbw * sbh; i += 64)
+      o[(ptrdiff_t)(i >> lsw) * pd.stride + (i & (sbw - 1))] = sh.wv[wave].dst[i];
+  }
 }
 
 // T4 building block (GetSubpelDist / EvalStartMvp / SearchMergeCandidates per

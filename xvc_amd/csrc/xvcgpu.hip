@@ -578,6 +578,19 @@ xvcgpu_status xvcgpu_mc_batch(xvcgpu_ctx *ctx, const xvcgpu_picture *ref,
   return XVCGPU_OK;
 }
 
+xvcgpu_status xvcgpu_mc_affine_batch(xvcgpu_ctx *ctx, const xvcgpu_picture *ref,
+                                     xvcgpu_picture *pred,
+                                     const xvcgpu_mc_affine_block *d_blocks, int n) {
+  if (!ctx || !ref || !pred || n < 0 || (n && !d_blocks)) return XVCGPU_INVALID_ARGUMENT;
+  if (pred->w != ref->w || pred->h != ref->h)
+    return fail(ctx, XVCGPU_INVALID_ARGUMENT, "picture mismatch");
+  if (n == 0) return XVCGPU_OK;
+  hipLaunchKernelGGL(mc_affine_kernel, dim3(n), dim3(256), 0, ctx->stream, ref->v,
+                     pred->v, d_blocks, n);
+  CHECK_LAUNCH(ctx, "mc_affine_batch");
+  return XVCGPU_OK;
+}
+
 xvcgpu_status xvcgpu_mc_bipred_batch(xvcgpu_ctx *ctx, const xvcgpu_picture *ref0,
                                      const xvcgpu_picture *ref1, xvcgpu_picture *pred,
                                      const xvcgpu_mc_bi_block *d_blocks, int n) {

@@ -184,6 +184,14 @@ class InterPrediction {
                                static_cast<int>(blocks.size())));
     ctx_.Sync();
   }
+  // InterPrediction::MotionCompAffine (uni-pred, Sample output), batched.
+  void MotionCompAffineBatch(const Picture &ref_pic, Picture *pred,
+                             const std::vector<xvcgpu_mc_affine_block> &blocks) const {
+    DeviceArray<xvcgpu_mc_affine_block> d(ctx_, blocks);
+    ctx_.Check(xvcgpu_mc_affine_batch(ctx_.get(), ref_pic.get(), pred->get(), d.data(),
+                                      static_cast<int>(blocks.size())));
+    ctx_.Sync();
+  }
   // InterPrediction::MotionCompensation for bi-pred CUs (two lists + AddAvg).
   void MotionCompensationBiBatch(const Picture &ref_l0, const Picture &ref_l1,
                                  Picture *pred,
