@@ -266,7 +266,10 @@ xvcgpu_status xvcgpu_cu_info_from_me(xvcgpu_ctx *ctx,
 
 /* ---- X1 + Q + Q1 + X2 + R1: TransformAndReconstruct --------------------- *
  * (transform_encoder.cc:203-285) with the reference's non-RDO quantiser
- * RdoQuant::QuantFast (rdo_quant.cc:156-195, sign hiding off).  For block i:
+ * RdoQuant::QuantFast as shipped (rdo_quant.cc:156-201: sign-data hiding
+ * CoeffSignHideFast :448-573 included; XVC_TXF_* bits in
+ * xvcgpu_tx_block.intra_pic select the restricted mode / the coefficient scan
+ * of small intra CUs).  For block i:
  * resi = orig - pred; coeff = T(resi); level = Q(coeff) -> d_levels +
  * d_level_offsets[i] (w*h int16, row-major, stride w); d_nnz[i] = non-zero
  * count; rec = cbf ? clip(pred + T^-1(Q^-1(level))) : pred.

@@ -139,8 +139,20 @@ typedef struct xvcgpu_tx_block {
   uint8_t tx_ver;      /* xvcgpu_tx_type for the vertical 1-D pass         */
   uint8_t dst4x4;      /* can_dst_4x4 (intra luma 4x4 default)             */
   int8_t qp;           /* raw qp for this component (Qp::GetQpRaw)         */
-  uint8_t intra_pic;   /* pic_type == kIntra (quantiser rounding offset)   */
+  uint8_t intra_pic;   /* XVC_TXF_* flags; 0 / 1 = inter / intra picture
+                        * with the reference's defaults                    */
 } xvcgpu_tx_block;
+
+/* xvcgpu_tx_block.intra_pic bits.  The defaults (bits clear) are what the
+ * reference does out of the box for an inter CU: QuantFast applies
+ * sign-data hiding (CoeffSignHideFast, rdo_quant.cc:196-199, :448-573) over
+ * the diagonal coefficient scan. */
+#define XVC_TXF_INTRA_PIC 1       /* pic_type == kIntra: rounding offset 171/512 */
+#define XVC_TXF_NO_SIGN_HIDING 2  /* Restrictions::disable_transform_sign_hiding */
+#define XVC_TXF_SCAN_SHIFT 2      /* bits 2-3: ScanOrder of the CU, 0 diagonal,
+                                   * 1 horizontal, 2 vertical
+                                   * (TransformHelper::DetermineScanOrder,
+                                   * transform.cc:1614-1637)                  */
 
 /* One motion-compensation job (InterPrediction::MotionCompensationMv,
  * inter_prediction.cc:740-758) for one component of one uni-pred CU. */

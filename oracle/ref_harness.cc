@@ -42,6 +42,7 @@
 #include "xvc_common_lib/coding_unit.h"
 #include "xvc_common_lib/deblocking_filter.h"
 #include "xvc_common_lib/inter_prediction.h"
+#include "xvc_common_lib/intra_prediction.h"
 #include "xvc_common_lib/picture_data.h"
 #include "xvc_common_lib/quantize.h"
 #include "xvc_common_lib/restrictions.h"
@@ -550,6 +551,37 @@ void xr_subpel_search(int bd, const xvcgpu_me_block *b, int pic_w, int pic_h,
   out_mv[0] = mv.x;
   out_mv[1] = mv.y;
   if (out_dist) *out_dist = static_cast<uint32_t>(dist);
+}
+
+int xr_quant_fast2(int bd, int qp_raw, int intra_pic, int sign_hide, int scan_order,
+                   int w, int h, const int16_t *in, ptrdiff_t is, int16_t *out,
+                   ptrdiff_t os) {
+  /* RdoQuant::QuantFast as shipped (sign hiding follows the restriction flag).
+   * The scan order is a function of the CU (transform.cc:1614-1637): inter ->
+   * diagonal; intra below 16x16 with a near-vertical mode -> horizontal scan,
+   * near-horizontal mode -> vertical scan. */
+  PictureData pic_data(ChromaFormat::k420, 64, 64, bd);
+  CodingUnit *cu = pic_data.CreateCu(CuTree::Primary, 0, 0, 0, w, h);
+  if (scan_order == 0) {
+    cu->SetPredMode(PredictionMode::kInter);
+  } else {
+    cu->SetPredMode(PredictionMode::kIntra);
+    cu->SetIntraModeLuma(IntraPrediction::Convert(
+        scan_order == 1 ? IntraAngle::kVertical : IntraAngle::kHorizontal));
+  }
+  Qp qp = MakeQp(qp_raw, bd);
+  EncoderSettings es;
+  es.Initialize(SpeedMode::kSlow);
+  RdoQuant rq(bd, es);
+  Restrictions &r = Restrictions::GetRW();
+  bool saved = r.disable_transform_sign_hiding;
+  r.disable_transform_sign_hiding = !sign_hide;
+  int nnz = rq.QuantFast(*cu, YuvComponent::kY, qp,
+                         intra_pic ? PicturePredictionType::kIntra
+                                   : PicturePredictionType::kBi,
+                         in, is, out, os);
+  r.disable_transform_sign_hiding = saved;
+  return nnz;
 }
 
 uint64_t xr_mc_metric(int bd, int metric_type, int qp_raw, int strength, int x, int y,

@@ -809,15 +809,105 @@ void xo_dequant(int bd, int qp_raw, int w, int h, const int16_t *in,
     }
 }
 
-int xo_quant_fast(int bd, int qp_raw, int intra_pic, int w, int h,
-                  const int16_t *in, ptrdiff_t is, int16_t *out,
-                  ptrdiff_t os) {
-  /* rdo_quant.cc:156-195 (sign hiding not applied) */
+/* Coefficient scan of a 4x4 sub-block (position = y*4 + x) and of the grid of
+ * sub-blocks: diagonal = anti-diagonals walked from bottom-left to top-right
+ * (TransformHelper::kScanCoeff4x4 / DeriveSubblockScan, transform.cc:72-76,
+ * :1639-1683); horizontal = raster, vertical = column-major. */
+static void xo_scan_order(int order, int gw, int gh, uint16_t *tab) {
+  int n = 0;
+  if (order == 0) {
+    for (int s = 0; s < gw + gh - 1; s++)
+      for (int y = (s < gh ? s : gh - 1); y >= 0 && s - y < gw; y--)
+        tab[n++] = (uint16_t)(y * gw + (s - y));
+  } else if (order == 1) {
+    for (int y = 0; y < gh; y++)
+      for (int x = 0; x < gw; x++) tab[n++] = (uint16_t)(y * gw + x);
+  } else {
+    for (int x = 0; x < gw; x++)
+      for (int y = 0; y < gh; y++) tab[n++] = (uint16_t)(y * gw + x);
+  }
+}
+
+/* RdoQuant::CoeffSignHideFast (rdo_quant.cc:448-573): per 4x4 sub-block, when
+ * the first and last non-zero levels are more than 3 scan positions apart,
+ * the parity of the level sum must equal the sign bit of the first non-zero
+ * level; otherwise the level whose rounding was cheapest to flip moves by 1. */
+static int xo_sign_hide_fast(int scan_order, int w, int h, const int16_t *in,
+                             ptrdiff_t is, const int16_t *delta, ptrdiff_t ds,
+                             int16_t *out, ptrdiff_t os) {
+  uint16_t c4[16], sb[256];
+  xo_scan_order(scan_order, 4, 4, c4);
+  const int gw = w >> 2, gh = h >> 2;
+  xo_scan_order(scan_order, gw, gh, sb);
+  int nnz = 0, last_subblock = -1;
+  for (int i = gw * gh - 1; i >= 0; i--) {
+    const int px = (sb[i] % gw) << 2, py = (sb[i] / gw) << 2;
+#define AT(buf, stride, k) (buf)[(py + (c4[k] >> 2)) * (stride) + px + (c4[k] & 3)]
+    int last = -1, first = 16, sum = 0;
+    for (int k = 0; k < 16; k++) {
+      const int c = AT(out, os, k);
+      if (c) {
+        if (k < first) first = k;
+        if (k > last) last = k;
+        sum += c;
+        nnz++;
+      }
+    }
+    if (last >= 0 && last_subblock == -1) last_subblock = 1;
+    if (last - first > 3) {
+      const int sign = AT(out, os, first) > 0 ? 0 : 1;
+      if (sign != (sum & 1)) {
+        int16_t curr_cost = 32767, curr_change = 0, min_cost = 32767, min_change = 0;
+        int min_index = -1;
+        for (int k = (last_subblock == 1) ? last : 15; k >= 0; k--) {
+          if (AT(out, os, k) != 0) {
+            if (AT(delta, ds, k) > 0) {
+              curr_cost = (int16_t)-AT(delta, ds, k);
+              curr_change = 1;
+            } else if (k == first && abs(AT(out, os, k)) == 1) {
+              curr_cost = 32767;
+            } else {
+              curr_cost = AT(delta, ds, k);
+              curr_change = -1;
+            }
+          } else if (k < first && (AT(in, is, k) >= 0 ? 0 : 1) != sign) {
+            curr_cost = 32767;
+          } else {
+            curr_cost = (int16_t)-AT(delta, ds, k);
+            curr_change = 1;
+          }
+          if (curr_cost < min_cost) {
+            min_cost = curr_cost;
+            min_change = curr_change;
+            min_index = k;
+          }
+        }
+        if (AT(out, os, min_index) == -32768 || AT(out, os, min_index) == 32767)
+          min_change = -1;
+        if (!AT(out, os, min_index)) nnz++;
+        if (AT(in, is, min_index) >= 0)
+          AT(out, os, min_index) = (int16_t)(AT(out, os, min_index) + min_change);
+        else
+          AT(out, os, min_index) = (int16_t)(AT(out, os, min_index) - min_change);
+        if (!AT(out, os, min_index)) nnz--;
+      }
+    }
+#undef AT
+    if (last_subblock == 1) last_subblock = 0;
+  }
+  return nnz;
+}
+
+int xo_quant_fast2(int bd, int qp_raw, int intra_pic, int sign_hide, int scan_order,
+                   int w, int h, const int16_t *in, ptrdiff_t is, int16_t *out,
+                   ptrdiff_t os) {
+  /* RdoQuant::QuantFast, rdo_quant.cc:156-201 */
   const int qpb = xo_qp_bitdepth(qp_raw, bd);
   const int bias = (xo_log2_size(w) + xo_log2_size(h)) % 2 != 0;
   const int shift = 14 + qpb / 6 + xo_transform_shift(w, h, bd) + (bias ? 7 : 0);
   const int scale = xo_fwd_scales[qpb % 6] * (bias ? 181 : 1);
   const int64_t offset = (int64_t)((intra_pic ? 171ull : 85ull) << (shift - 9));
+  static __thread int16_t delta[64 * 64];
   int nnz = 0;
   for (int y = 0; y < h; y++)
     for (int x = 0; x < w; x++) {
@@ -827,6 +917,17 @@ int xo_quant_fast(int bd, int qp_raw, int intra_pic, int w, int h,
       int level = (int)(((abs_coeff * scale) + offset) >> shift);
       nnz += level != 0;
       out[y * os + x] = (int16_t)xo_clip3(level * sign, -32768, 32767);
+      delta[y * 64 + x] =
+          (int16_t)(((abs_coeff * scale) - ((int64_t)level << shift)) >> (shift - 8));
     }
+  if (sign_hide && nnz > 1 && w >= 4 && h >= 4)
+    nnz = xo_sign_hide_fast(scan_order, w, h, in, is, delta, 64, out, os);
   return nnz;
+}
+
+int xo_quant_fast(int bd, int qp_raw, int intra_pic, int w, int h,
+                  const int16_t *in, ptrdiff_t is, int16_t *out,
+                  ptrdiff_t os) {
+  /* QuantFast with disable_transform_sign_hiding set */
+  return xo_quant_fast2(bd, qp_raw, intra_pic, 0, 0, w, h, in, is, out, os);
 }

@@ -97,9 +97,14 @@ void xo_inv_transform_skip(int bitdepth, int w, int h, const int16_t *coeff,
 /* Quantize::Inverse (quantize.cc:94-125). qp_raw = Qp::GetQpRaw(comp). */
 void xo_dequant(int bitdepth, int qp_raw, int w, int h, const int16_t *in,
                 ptrdiff_t in_stride, int16_t *out, ptrdiff_t out_stride);
-/* RdoQuant::QuantFast without sign hiding (rdo_quant.cc:156-195, the
- * disable_transform_sign_hiding / num_non_zero<=1 path). Returns the number
- * of non-zero levels. */
+/* RdoQuant::QuantFast (rdo_quant.cc:156-201); returns the number of non-zero
+ * levels.  xo_quant_fast = the disable_transform_sign_hiding path;
+ * xo_quant_fast2 = the reference's default QuantFast: with sign-data hiding
+ * (CoeffSignHideFast, rdo_quant.cc:448-573) when sign_hide != 0; scan_order
+ * 0 diagonal (every inter CU), 1 horizontal, 2 vertical (transform.cc:1614-1637) */
+int xo_quant_fast2(int bitdepth, int qp_raw, int intra_pic, int sign_hide,
+                   int scan_order, int w, int h, const int16_t *in, ptrdiff_t in_stride,
+                   int16_t *out, ptrdiff_t out_stride);
 int xo_quant_fast(int bitdepth, int qp_raw, int intra_pic, int w, int h,
                   const int16_t *in, ptrdiff_t in_stride, int16_t *out,
                   ptrdiff_t out_stride);

@@ -786,7 +786,10 @@ int xo_residual_pipeline(int bd, const xvcgpu_tx_block *b, const uint16_t *orig,
     xo_fwd_transform_skip(bd, w, h, resi, 64, coeff, 64);
   else
     xo_fwd_transform(bd, w, h, b->tx_hor, b->tx_ver, b->dst4x4, resi, 64, coeff, 64);
-  int nnz = xo_quant_fast(bd, b->qp, b->intra_pic, w, h, coeff, 64, coeff_out, w);
+  int nnz = xo_quant_fast2(bd, b->qp, b->intra_pic & XVC_TXF_INTRA_PIC,
+                           !(b->intra_pic & XVC_TXF_NO_SIGN_HIDING),
+                           (b->intra_pic >> XVC_TXF_SCAN_SHIFT) & 3, w, h, coeff, 64,
+                           coeff_out, w);
   if (nnz) {
     int dc_only = nnz == 1 && coeff_out[0] != 0;
     xo_dequant(bd, b->qp, w, h, coeff_out, w, deq, 64);

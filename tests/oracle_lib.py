@@ -189,6 +189,7 @@ class Lib:
         sig("bipred_search", None,
             [C.c_int, C.POINTER(BiBlock), C.c_int, C.c_int, u16p, pd, u16p, pd,
              u16p, pd, C.POINTER(MeResult)])
+        sig("quant_fast2", C.c_int, [C.c_int] * 7 + [i16p, pd, i16p, pd])
         sig("mc_affine_block", None,
             [C.c_int] * 6 + [i32p, C.c_int, C.c_int, u16p, pd, u16p, pd])
         sig("mc_metric", C.c_uint64,
@@ -317,6 +318,13 @@ class Lib:
         out = np.zeros((h, w), np.int16)
         n = self._quant_fast(bd, qp, intra_pic, w, h, ptr(coeff, i16p),
                              self._s(coeff), ptr(out, i16p), w)
+        return out, n
+
+    def quant_fast2(self, bd, qp, intra_pic, sign_hide, scan_order, coeff):
+        h, w = coeff.shape
+        out = np.zeros((h, w), np.int16)
+        n = self._quant_fast2(bd, qp, intra_pic, sign_hide, scan_order, w, h,
+                              ptr(coeff, i16p), self._s(coeff), ptr(out, i16p), self._s(out))
         return out, n
 
     def transform_matrix(self, tx, size):

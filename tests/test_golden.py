@@ -74,6 +74,27 @@ def test_oracle_transform_quant(xo):
         assert np.array_equal(inv, g["inverse"][i][:h, :w]), ("inv", bd, w, h, th, tv)
 
 
+def test_oracle_quant_sign_hiding(xo):
+    """QuantFast as the reference ships it (CoeffSignHideFast on)."""
+    g, q = load("transform"), load("quant_sh")
+    k = 0
+    changed = 0
+    for i, (bd, w, h, th, tv, qp, _) in enumerate(g["cases"]):
+        bd, w, h, qp = int(bd), int(w), int(h), int(qp)
+        if min(w, h) < 2:
+            continue
+        coeff = np.ascontiguousarray(g["coeff"][i][:h, :w])
+        lev, n = xo.quant_fast2(bd, qp, 0, 1, 0, coeff)
+        assert n == int(q["nnz_sh"][k]) and np.array_equal(lev, q["level_sh"][k][:h, :w])
+        changed += not np.array_equal(lev, g["level"][i][:h, :w])
+        k += 1
+    assert changed > 20
+    for (bd, w, h, scan, qp, intra, n), a, b in zip(q["xcases"], q["xin"], q["xout"]):
+        lev, nn = xo.quant_fast2(int(bd), int(qp), int(intra), 1, int(scan),
+                                 np.ascontiguousarray(a[:h, :w]))
+        assert nn == n and np.array_equal(lev, b[:h, :w]), (bd, w, h, scan)
+
+
 def padded_from(g, key, pw, ph):
     planes = []
     for c in range(3):
@@ -252,6 +273,18 @@ def test_gpu_transform_quant(gpu):
         O.upload(planes_o, BL)
         P.upload(planes_p, BL)
         coeffs, off = ctx.fwd_transform_batch(O, P, blocks)
+        # as shipped (sign-data hiding on): levels / counts of quant_sh.npz
+        q = load("quant_sh")
+        kq = {i: j for j, i in enumerate(
+            [i for i, c in enumerate(g["cases"]) if min(c[1], c[2]) >= 2])}
+        levels, off2, nnz = ctx.residual_batch(O, P, R, blocks)
+        for k, i in enumerate(idx):
+            _, w, h = (int(v) for v in g["cases"][i][:3])
+            assert np.array_equal(levels[off2[k]:off2[k] + w * h].reshape(h, w),
+                                  q["level_sh"][kq[i]][:h, :w]), tuple(g["cases"][i])
+            assert int(nnz[k]) == int(q["nnz_sh"][kq[i]])
+        # with the restriction flag set: the levels / reconstruction below
+        blocks["intra_pic"] = 2
         levels, off2, nnz = ctx.residual_batch(O, P, R, blocks)
         rec = R.download()[0]
         for k, i in enumerate(idx):

@@ -396,7 +396,14 @@ def tx_blocks(rng, api, pw, ph, n, with_types=True):
         if w == 4 and h == 4 and comp == 0 and b["tx_hor"] == 0 and rng.random() < 0.5:
             b["dst4x4"] = 1
         b["qp"] = int(rng.choice([12, 22, 27, 32, 37, 45]))
-        b["intra_pic"] = int(rng.integers(0, 2))
+        # XVC_TXF_*: intra picture, sign hiding off (1 in 5), coefficient scan
+        # order (non-diagonal only occurs below 16x16)
+        flags = int(rng.integers(0, 2))
+        if rng.random() < 0.2:
+            flags |= 2
+        if max(w, h) < 16 and rng.random() < 0.5:
+            flags |= int(rng.integers(1, 3)) << 2
+        b["intra_pic"] = flags
     return blocks
 
 

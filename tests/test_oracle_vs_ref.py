@@ -453,3 +453,29 @@ def test_mc_affine_block(libs, bd):
         n_sub += mv3[0] != mv3[1]
     xr._set_simd(1)
     assert n_sub > 60
+
+
+@pytest.mark.parametrize("bd", [8, 10, 12])
+def test_quant_fast_sign_hiding(libs, bd):
+    """QuantFast as shipped: CoeffSignHideFast on, all three scan orders."""
+    xo, xr = libs
+    rng = np.random.default_rng(131 + bd)
+    n_changed = 0
+    for i in range(400):
+        w = int(rng.choice([4, 8, 16, 32, 64])); h = int(rng.choice([4, 8, 16, 32, 64]))
+        scan = int(rng.integers(0, 3)) if max(w, h) < 16 else 0
+        amp = int(rng.choice([30, 300, 3000, 30000]))
+        coeff = rng.integers(-amp, amp + 1, size=(h, w)).astype(np.int16)
+        if i % 3 == 0:      # sparse, energy near DC like a real TU
+            yy, xx = np.mgrid[0:h, 0:w]
+            coeff = (coeff / (1 + 0.6 * (xx + yy))).astype(np.int16)
+        if i % 11 == 0:
+            coeff[rng.integers(0, h), rng.integers(0, w)] = 32767
+        qp = int(rng.integers(-6 * (bd - 8), 52))
+        intra = int(rng.integers(0, 2))
+        a, na = xr.quant_fast2(bd, qp, intra, 1, scan, coeff)
+        o, no = xo.quant_fast2(bd, qp, intra, 1, scan, coeff)
+        assert na == no and np.array_equal(a, o), (w, h, scan, qp, intra, i)
+        plain, _ = xo.quant_fast2(bd, qp, intra, 0, scan, coeff)
+        n_changed += not np.array_equal(plain, o)
+    assert n_changed > 100   # sign hiding did modify levels in many cases

@@ -124,6 +124,39 @@ def gen_bipred(xr):
         mc=np.array(mc, ol.MCBI_DTYPE), preds=np.array(preds))
 
 
+def gen_quant_sh(xr):
+    """quant_sh.npz: the reference's QuantFast as shipped (sign-data hiding on)
+    on the coefficient blocks of transform.npz, plus extra blocks under the
+    horizontal / vertical coefficient scans of small intra CUs."""
+    g = np.load(os.path.join(OUT, "transform.npz"))
+    lev, nnz = [], []
+    for i, (bd, w, h, th, tv, qp, _) in enumerate(g["cases"]):
+        coeff = np.ascontiguousarray(g["coeff"][i][:int(h), :int(w)])
+        if min(w, h) < 2:
+            continue
+        l, n = xr.quant_fast2(int(bd), int(qp), 0, 1, 0, coeff)
+        pp = np.zeros((64, 64), np.int16)
+        pp[:int(h), :int(w)] = l
+        lev.append(pp)
+        nnz.append(n)
+    rng = np.random.default_rng(20260930)
+    xc, xin, xout, xn = [], [], [], []
+    for i in range(48):
+        w = int(rng.choice([4, 8])); h = int(rng.choice([4, 8]))
+        scan, bd = 1 + i % 2, int(rng.choice([8, 10]))
+        qp, intra = int(rng.integers(10, 45)), int(rng.integers(0, 2))
+        amp = int(rng.choice([40, 400, 4000]))
+        yy, xx = np.mgrid[0:h, 0:w]
+        coeff = (rng.integers(-amp, amp + 1, size=(h, w)) / (1 + 0.5 * (xx + yy))).astype(np.int16)
+        l, n = xr.quant_fast2(bd, qp, intra, 1, scan, coeff)
+        a = np.zeros((8, 8), np.int16); a[:h, :w] = coeff
+        b = np.zeros((8, 8), np.int16); b[:h, :w] = l
+        xc.append((bd, w, h, scan, qp, intra, n)); xin.append(a); xout.append(b)
+    np.savez_compressed(os.path.join(OUT, "quant_sh.npz"), level_sh=np.array(lev),
+                        nnz_sh=np.array(nnz, np.int32), xcases=np.array(xc, np.int32),
+                        xin=np.array(xin), xout=np.array(xout))
+
+
 def write_manifest():
     import hashlib
     with open(os.path.join(OUT, "MANIFEST.md5"), "w") as f:
@@ -139,6 +172,10 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     if sys.argv[1:] == ["bipred"]:
         gen_bipred(xr)
+        write_manifest()
+        return
+    if sys.argv[1:] == ["quant_sh"]:
+        gen_quant_sh(xr)
         write_manifest()
         return
     rng = np.random.default_rng(20260928)
@@ -285,6 +322,7 @@ def main():
     np.savez_compressed(os.path.join(OUT, "picture_ssd.npz"),
                         cases=np.array(cases, np.int64), a=np.array(a_l), b=np.array(b_l))
     gen_bipred(xr)
+    gen_quant_sh(xr)
     write_manifest()
     total = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))
     print("golden fixtures written to", OUT, "total bytes", total)

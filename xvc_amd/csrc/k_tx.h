@@ -28,7 +28,9 @@ struct TxShared {
   int16_t b[64 * TX_S];
   int16_t mh[64 * 64];
   int16_t mv[64 * 64];
+  int16_t dl[64 * TX_S];  // QuantFast rounding remainders (sign-data hiding)
   int nnz;
+  int last_sb;
 };
 
 __device__ __forceinline__ int tx_table_off(const TxTableLayout &lay, int type,
@@ -113,6 +115,94 @@ __device__ __forceinline__ void tx_inv_dst4(int shift, const int16_t *in,
   }
 }
 
+// ---- sign-data hiding: RdoQuant::CoeffSignHideFast (rdo_quant.cc:448-573) --
+// Scan position k of a 4x4 sub-block as y*4 + x (TransformHelper::
+// kScanCoeff4x4, transform.cc:72-76): order 0 walks the anti-diagonals from
+// bottom-left to top-right, 1 is raster, 2 is column-major.
+constexpr unsigned long long tx_pack_scan4(int order) {
+  unsigned long long t = 0;
+  int k = 0;
+  if (order == 0) {
+    for (int s = 0; s < 7; s++)
+      for (int y = (s < 4 ? s : 3); y >= 0 && s - y < 4; y--, k++)
+        t |= (unsigned long long)((y << 2) | (s - y)) << (4 * k);
+  } else {
+    for (k = 0; k < 16; k++)
+      t |= (unsigned long long)(order == 1 ? k : (((k & 3) << 2) | (k >> 2))) << (4 * k);
+  }
+  return t;
+}
+// 16 nibbles: scan position k -> y*4 + x
+__device__ __forceinline__ unsigned long long d_scan4_table(int order) {
+  constexpr unsigned long long t0 = tx_pack_scan4(0), t1 = tx_pack_scan4(1),
+                               t2 = tx_pack_scan4(2);
+  return order == 0 ? t0 : (order == 1 ? t1 : t2);
+}
+// Index of sub-block (sx, sy) in the scan over a gw x gh grid of sub-blocks
+// (TransformHelper::DeriveSubblockScan, transform.cc:1639-1683).
+__device__ __forceinline__ int d_sb_scan_index(int order, int gw, int gh, int sx, int sy) {
+  if (order == 1) return sy * gw + sx;
+  if (order == 2) return sx * gh + sy;
+  const int s = sx + sy;
+  int idx = 0;
+  for (int d = 0; d < s; d++) {
+    int c = d < gw - 1 ? d : gw - 1;
+    c = c < gh - 1 ? c : gh - 1;
+    c = c < gw + gh - 2 - d ? c : gw + gh - 2 - d;
+    idx += c + 1;
+  }
+  return idx + ((s < gh - 1 ? s : gh - 1) - sy);
+}
+
+// One 4x4 sub-block, by one thread.  IDX(x, y) maps a coefficient position
+// to the index used by the three arrays (levels in/out, remainders, the
+// unquantised coefficients).  Returns the change of the non-zero count.
+template <typename IDX>
+__device__ __forceinline__ int d_sign_hide_subblock(int order, int px, int py,
+                                                    bool is_last_sb, int16_t *lev,
+                                                    const int16_t *dl, const int16_t *cf,
+                                                    IDX idx) {
+  const unsigned long long tab = d_scan4_table(order);
+  auto at = [&](int k) {
+    const int p = (int)((tab >> (4 * k)) & 15ull);
+    return idx(px + (p & 3), py + (p >> 2));
+  };
+  int last = -1, first = 16, sum = 0;
+  for (int k = 0; k < 16; k++) {
+    const int c = lev[at(k)];
+    if (c) {
+      first = k < first ? k : first;
+      last = k;
+      sum += c;
+    }
+  }
+  if (last - first <= 3) return 0;
+  const int sign = lev[at(first)] > 0 ? 0 : 1;
+  if (sign == (sum & 1)) return 0;
+  int curr_cost = 32767, curr_change = 0, min_cost = 32767, min_change = 0, min_index = 0;
+  for (int k = is_last_sb ? last : 15; k >= 0; k--) {
+    const int p = at(k);
+    const int l = lev[p], d = dl[p];
+    if (l != 0) {
+      if (d > 0) { curr_cost = -d; curr_change = 1; }
+      else if (k == first && d_abs(l) == 1) curr_cost = 32767;
+      else { curr_cost = d; curr_change = -1; }
+    } else if (k < first && (cf[p] >= 0 ? 0 : 1) != sign) {
+      curr_cost = 32767;
+    } else {
+      curr_cost = -d;
+      curr_change = 1;
+    }
+    if (curr_cost < min_cost) { min_cost = curr_cost; min_change = curr_change; min_index = k; }
+  }
+  const int p = at(min_index);
+  const int before = lev[p];
+  if (before == -32768 || before == 32767) min_change = -1;
+  const int after = (int16_t)(before + (cf[p] >= 0 ? min_change : -min_change));
+  lev[p] = (int16_t)after;
+  return (after != 0) - (before != 0);
+}
+
 // Jobs taken by the one-wave-per-job kernel (k_tx2.h); the rest stay here.
 __device__ __forceinline__ bool tx_small_job(const xvcgpu_tx_block &b) {
   const bool okw = b.w == 4 || b.w == 8 || b.w == 16;
@@ -136,6 +226,9 @@ __device__ __forceinline__ void residual_job(TxShared &s, int bi, const PicView 
   const int lgw = d_log2_size(w), lgh = d_log2_size(h);
   const PlaneView pp = pred.c[b.comp];
   const bool skip = b.tx_hor == XVC_TX_SKIP;  // TransformSkip, blocks <= 4x4
+  const bool intra_pic = (b.intra_pic & XVC_TXF_INTRA_PIC) != 0;
+  const bool sign_hide = !(b.intra_pic & XVC_TXF_NO_SIGN_HIDING);
+  const int scan_order = (b.intra_pic >> XVC_TXF_SCAN_SHIFT) & 3;
   const bool dst4 = b.dst4x4 && w == 4 && h == 4 && !skip;
   int16_t *lv = (levels && level_off) ? levels + level_off[bi] : nullptr;
 
@@ -194,7 +287,8 @@ __device__ __forceinline__ void residual_job(TxShared &s, int bi, const PicView 
     // QuantFast (rdo_quant.cc:156-195)
     const int qshift = 14 + qpb / 6 + tshift + (bias ? 7 : 0);
     const int qscale = kFwdQuantScales[qpb % 6] * (bias ? 181 : 1);
-    const long long qoff = (long long)((b.intra_pic ? 171ull : 85ull) << (qshift - 9));
+    const long long qoff = (long long)((intra_pic ? 171ull : 85ull) << (qshift - 9));
+    // levels -> s.b, rounding remainders -> s.dl, coefficients stay in s.a
     int local = 0;
     for (int i = threadIdx.x; i < w * h; i += TX_THREADS) {
       const int y = i >> lw, x = i & (w - 1);
@@ -203,20 +297,47 @@ __device__ __forceinline__ void residual_job(TxShared &s, int bi, const PicView 
       const long long abs_coeff = d_abs(v);
       const int level = (int)(((abs_coeff * qscale) + qoff) >> qshift);
       local += level != 0;
-      const int16_t q = (int16_t)d_clip3(level * sign, -32768, 32767);
-      s.a[y * TX_S + x] = q;
-      if (lv) lv[i] = q;
+      s.b[y * TX_S + x] = (int16_t)d_clip3(level * sign, -32768, 32767);
+      s.dl[y * TX_S + x] =
+          (int16_t)(((abs_coeff * qscale) - ((long long)level << qshift)) >> (qshift - 8));
     }
     local = group_sum<64>(local);
     if ((threadIdx.x & 63) == 0 && local) atomicAdd(&s.nnz, local);
+    if (threadIdx.x == 0) s.last_sb = -1;
     __syncthreads();
+    // CoeffSignHideFast (rdo_quant.cc:196-199, :448-573): thread = sub-block
+    if (sign_hide && s.nnz > 1 && w >= 4 && h >= 4) {
+      const int gw = w >> 2, gh = h >> 2;
+      auto idx = [](int x, int y) { return y * TX_S + x; };
+      // the "last" sub-block = highest scan index holding a non-zero level
+      for (int t = threadIdx.x; t < gw * gh; t += TX_THREADS) {
+        const int sx = t % gw, sy = t / gw;
+        bool any = false;
+        for (int k = 0; k < 16; k++) any |= s.b[idx(4 * sx + (k & 3), 4 * sy + (k >> 2))] != 0;
+        if (any) atomicMax(&s.last_sb, d_sb_scan_index(scan_order, gw, gh, sx, sy));
+      }
+      __syncthreads();
+      int dn = 0;
+      for (int t = threadIdx.x; t < gw * gh; t += TX_THREADS) {
+        const int sx = t % gw, sy = t / gw;
+        dn += d_sign_hide_subblock(
+            scan_order, 4 * sx, 4 * sy,
+            d_sb_scan_index(scan_order, gw, gh, sx, sy) == s.last_sb, s.b, s.dl, s.a, idx);
+      }
+      dn = group_sum<64>(dn);
+      if ((threadIdx.x & 63) == 0 && dn) atomicAdd(&s.nnz, dn);
+      __syncthreads();
+    }
     nnz = s.nnz;
     if (nnz_out && threadIdx.x == 0) nnz_out[bi] = nnz;
+    if (lv)
+      for (int i = threadIdx.x; i < w * h; i += TX_THREADS)
+        lv[i] = s.b[(i >> lw) * TX_S + (i & (w - 1))];
   } else {
     nnz = nnz_out[bi];
     if (nnz)
       for (int i = threadIdx.x; i < w * h; i += TX_THREADS)
-        s.a[(i >> lw) * TX_S + (i & (w - 1))] = lv[i];
+        s.b[(i >> lw) * TX_S + (i & (w - 1))] = lv[i];
     __syncthreads();
   }
 
@@ -229,16 +350,15 @@ __device__ __forceinline__ void residual_job(TxShared &s, int bi, const PicView 
     }
     return;
   }
-  const bool dc_only = nnz == 1 && s.a[0] != 0;  // transform_encoder.cc:241
+  const bool dc_only = nnz == 1 && s.b[0] != 0;  // transform_encoder.cc:241
 
-  // Quantize::Inverse (quantize.cc:94-125), in place in s.a
+  // Quantize::Inverse (quantize.cc:94-125): levels in s.b -> s.a
   {
     const int shift = 6 - tshift + (bias ? 8 : 0);
     const int scale = (kInvQuantScales[qpb % 6] << (qpb / 6)) * (bias ? 181 : 1);
-    __syncthreads();  // dc_only read s.a[0]
     for (int i = threadIdx.x; i < w * h; i += TX_THREADS) {
       const int y = i >> lw, x = i & (w - 1);
-      const int prod = (int)s.a[y * TX_S + x] * scale;
+      const int prod = (int)s.b[y * TX_S + x] * scale;
       int cf;
       if (shift > 0)
         cf = (prod + (1 << (shift - 1))) >> shift;

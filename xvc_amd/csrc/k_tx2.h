@@ -179,10 +179,14 @@ __device__ __forceinline__ int tx2_job(Tx2Shared &s, const xvcgpu_tx_block &b, i
         }
       return 0;
     }
-    // QuantFast (rdo_quant.cc:156-195) on C, in place
+    // QuantFast (rdo_quant.cc:156-201): levels -> s.r, rounding remainders
+    // -> s.t, the coefficients stay in s.c (same [x][k2] layout)
+    const bool intra_pic = (b.intra_pic & XVC_TXF_INTRA_PIC) != 0;
+    const bool sign_hide = !(b.intra_pic & XVC_TXF_NO_SIGN_HIDING);
+    const int scan_order = (b.intra_pic >> XVC_TXF_SCAN_SHIFT) & 3;
     const int qshift = 14 + qpb / 6 + tshift + (bias ? 7 : 0);
     const int qscale = kFwdQuantScales[qpb % 6] * (bias ? 181 : 1);
-    const long long qoff = (long long)((b.intra_pic ? 171ull : 85ull) << (qshift - 9));
+    const long long qoff = (long long)((intra_pic ? 171ull : 85ull) << (qshift - 9));
     int local = 0;
     for (int i = lane; i < n_el; i += 64) {
       const int v = s.c[i];
@@ -190,21 +194,48 @@ __device__ __forceinline__ int tx2_job(Tx2Shared &s, const xvcgpu_tx_block &b, i
       const long long abs_coeff = d_abs(v);
       const int level = (int)(((abs_coeff * qscale) + qoff) >> qshift);
       local += level != 0;
-      const int16_t q = (int16_t)d_clip3(level * sign, -32768, 32767);
-      s.c[i] = q;
-      if (lv) {
-        const int x = i / h, k2 = i - x * h;
-        lv[k2 * w + x] = q;
-      }
+      s.r[i] = (int16_t)d_clip3(level * sign, -32768, 32767);
+      s.t[i] = (int16_t)(((abs_coeff * qscale) - ((long long)level << qshift)) >> (qshift - 8));
     }
     nnz = wave_reduce_add_i32(local);
+    // CoeffSignHideFast (rdo_quant.cc:448-573): lane = 4x4 sub-block (<= 16)
+    if (sign_hide && nnz > 1 && w >= 4 && h >= 4) {
+      wave_sync();
+      const int gw = w >> 2, gh = h >> 2;
+      auto idx = [h](int x, int y) { return x * h + y; };
+      const bool mine = lane < gw * gh;
+      const int sx = mine ? lane % gw : 0, sy = mine ? lane / gw : 0;
+      bool any = false;
+      if (mine)
+        for (int k = 0; k < 16; k++) any |= s.r[idx(4 * sx + (k & 3), 4 * sy + (k >> 2))] != 0;
+      const int my_scan = d_sb_scan_index(scan_order, gw, gh, sx, sy);
+      // highest scan index among the sub-blocks that hold a level
+      int last_sb = any ? my_scan : -1;
+#pragma unroll
+      for (int sft = 1; sft < 16; sft <<= 1) {
+        const int o = __shfl_xor(last_sb, sft, 64);
+        last_sb = o > last_sb ? o : last_sb;
+      }
+      int dn = 0;
+      if (mine)
+        dn = d_sign_hide_subblock(scan_order, 4 * sx, 4 * sy, my_scan == last_sb, s.r, s.t,
+                                  s.c, idx);
+      nnz += wave_reduce_add_i32(dn);
+    }
     if (nnz_out && lane == 0) nnz_out[bi] = nnz;
+    if (lv) {
+      wave_sync();
+      for (int i = lane; i < n_el; i += 64) {
+        const int x = i / h, k2 = i - x * h;
+        lv[k2 * w + x] = s.r[i];
+      }
+    }
   } else {
     nnz = nnz_out[bi];
     if (nnz)
       for (int i = lane; i < n_el; i += 64) {
         const int x = i / h, k2 = i - x * h;
-        s.c[i] = lv[k2 * w + x];
+        s.r[i] = lv[k2 * w + x];
       }
   }
   wave_sync();
@@ -218,15 +249,15 @@ __device__ __forceinline__ int tx2_job(Tx2Shared &s, const xvcgpu_tx_block &b, i
     }
     return 0;
   }
-  const bool dc_only = nnz == 1 && s.c[0] != 0;
+  const bool dc_only = nnz == 1 && s.r[0] != 0;
   wave_sync();
   ME2_TRACE(5);
-  // Quantize::Inverse (quantize.cc:94-125), in place
+  // Quantize::Inverse (quantize.cc:94-125): levels in s.r -> s.c
   {
     const int shift = 6 - tshift + (bias ? 8 : 0);
     const int scale = (kInvQuantScales[qpb % 6] << (qpb / 6)) * (bias ? 181 : 1);
     for (int i = lane; i < n_el; i += 64) {
-      const int prod = (int)s.c[i] * scale;
+      const int prod = (int)s.r[i] * scale;
       int cf;
       if (shift > 0) cf = (prod + (1 << (shift - 1))) >> shift;
       else cf = (int)((unsigned)prod << -shift);
