@@ -806,6 +806,36 @@ def test_recorded_frame_pass_replay(gpu, xo):
         p.destroy()
 
 
+@pytest.mark.parametrize("cu", [8, 32, 64])
+def test_frame_pass_cu_sizes(gpu, xo, cu):
+    """Frame pass with other CU sizes (8: fused wave kernels; 32 / 64: the
+    32- and 64-class search instances and the workgroup residual kernel)."""
+    api, ctx = gpu
+    from xvc_amd import pipeline, synth
+    import oracle_frame
+    pw, ph, bd = 352, 288, 10
+    clip = synth.SyntheticClip(pw, ph, bd)
+    fp = pipeline.FramePass(ctx, pw, ph, bd, qp=30, cu=cu)
+    ref_host, orig_host = pad_planes(clip.frame(0), bd), pad_planes(clip.frame(2), bd)
+    O, R, Rec = (ctx.picture(pw, ph, bd) for _ in range(3))
+    R.upload(ref_host, BL)
+    O.upload(orig_host, BL)
+    fp.run(O, R, Rec)
+    ctx.sync()
+    res, nnz, cus, ssd = fp.results()
+    e_rec, e_res, e_nnz, e_cus, e_ssd = oracle_frame.frame_pass(fp.desc, bd, orig_host,
+                                                                ref_host, BL, lib=xo)
+    assert np.array_equal(res, e_res) and np.array_equal(nnz, e_nnz)
+    assert np.array_equal(cus, e_cus)
+    got = Rec.download(BL)
+    for c in range(3):
+        assert np.array_equal(got[c], e_rec[c]), c
+    assert (int(ssd[0]), int(ssd[1])) == e_ssd
+    fp.destroy()
+    for p in (O, R, Rec):
+        p.destroy()
+
+
 def test_frame_pass_8k_10bit_qp37(gpu, xo):
     """BASELINE config 5 (7680x4320 10-bit, QP 37) at full size: one frame pass
     against the oracle, and the decoder-side pass reproduces it."""
