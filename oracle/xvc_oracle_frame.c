@@ -43,11 +43,18 @@ typedef struct xo_frame_args {
   int cu_base;
   int encode_only;              /* stop before deblock / pad / SSD */
   uint64_t ssd[2];              /* out: luma SSD as ComputePsnr sums it, samples */
+  int threads;                  /* <= 1: serial; else OpenMP threads for the
+                                   per-CU loops (results do not depend on it) */
 } xo_frame_args;
 
 void xo_frame_pass(xo_frame_args *a) {
   const int bd = a->bd;
-  /* motion search + motion compensation */
+  const int nthreads = a->threads > 1 ? a->threads : 1;
+  (void)nthreads;
+  (void)xo_transform_matrix(XVC_TX_DCT2, 4); /* lazily built tables: before
+                                                 any parallel region */
+  /* motion search + motion compensation: CUs are independent */
+#pragma omp parallel for schedule(dynamic, 16) num_threads(nthreads)
   for (int i = 0; i < a->n_cus; i++) {
     const xvcgpu_me_block *b = &a->me_blocks[i];
     xvcgpu_me_result *r = &a->me_results[i];
@@ -77,8 +84,10 @@ void xo_frame_pass(xo_frame_args *a) {
     }
   }
   /* residual pipeline */
+#pragma omp parallel num_threads(nthreads)
   {
     int16_t *levels = (int16_t *)malloc(sizeof(int16_t) * 64 * 64);
+#pragma omp for schedule(dynamic, 48)
     for (int i = 0; i < a->n_tx; i++) {
       const xvcgpu_tx_block *t = &a->tx_blocks[i];
       const int c = t->comp;

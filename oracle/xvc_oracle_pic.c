@@ -374,7 +374,7 @@ void xo_min_max_mv(int pos_x, int pos_y, int pic_w, int pic_h, int center_x,
 
 /* debug counters (tests/tools only): [0] SAD evaluations, [1] grid searches,
  * [2] refinement iterations, [3] searches */
-uint64_t xo_dbg_counters[4];
+__thread uint64_t xo_dbg_counters[4]; /* per thread: no cache-line ping-pong under OpenMP */
 
 /* TZ search state, inter_tz_search.cc:66-82 */
 typedef struct {

@@ -27,10 +27,12 @@ class FrameArgs(C.Structure):
         ("me_results", C.c_void_p), ("nnz", C.c_void_p), ("cus", C.c_void_p),
         ("cu_base", C.c_int), ("encode_only", C.c_int),
         ("ssd", C.c_uint64 * 2),
+        ("threads", C.c_int),
     ]
 
 
-def frame_pass(desc, bd, orig, ref, border, ref_poc=0, lib=None, encode_only=False):
+def frame_pass(desc, bd, orig, ref, border, ref_poc=0, lib=None, encode_only=False,
+               threads=1):
     """desc: xvc_amd.pipeline.FrameDescriptors; orig/ref: [Y,U,V] padded uint16
     planes with `border` (luma) / border//2 (chroma) samples on each side.
     Returns (rec padded planes, me_results, nnz, cus, (ssd, samples))."""
@@ -67,5 +69,6 @@ def frame_pass(desc, bd, orig, ref, border, ref_poc=0, lib=None, encode_only=Fal
     a.me_results, a.nnz, a.cus = res.ctypes.data, nnz.ctypes.data, cus.ctypes.data
     a.cu_base = desc.cu_base
     a.encode_only = 1 if encode_only else 0
+    a.threads = threads
     f(C.byref(a))
     return rec, res, nnz, cus, (int(a.ssd[0]), int(a.ssd[1]))
