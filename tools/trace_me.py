@@ -18,6 +18,16 @@ R.upload(pad(clip.frame(0)), border); O.upload(pad(clip.frame(1)), border)
 fp = pipeline.FramePass(ctx, W, H, bd)
 d = fp.desc
 lib = api.load_library()
+chain = int(os.environ.get("CHAIN", "0"))   # run this many chained frame passes first
+if chain:
+    Rec = ctx.picture(W, H, bd)
+    for n_ in range(1, chain + 1):
+        k = (n_ - 1) % 14
+        O.upload(pad(clip.frame(1 + (k if k < 8 else 14 - k))), border)
+        fp.run(O, R, Rec)
+        R, Rec = Rec, R
+    k = chain % 14
+    O.upload(pad(clip.frame(1 + (k if k < 8 else 14 - k))), border)
 for _ in range(3):
     ctx.me_search_dev(O, R, 3, fp.d_me.ptr, d.n_cus, fp.d_res.ptr, 16)
 ctx.sync(); ctx.timer_begin()
@@ -37,3 +47,19 @@ for k, nm in enumerate(names):
     print("%-12s mean %7.0f  p50 %7.0f  p90 %7.0f  max %8d  share %5.1f%%" % (nm, dph.mean(), np.median(dph), np.percentile(dph, 90), dph.max(), 100.0 * dph.sum() / life.sum()))
 start = t[:, 0] - t0
 print("start time ticks: p10 %.0f p50 %.0f p90 %.0f max %d" % (np.percentile(start, 10), np.median(start), np.percentile(start, 90), start.max()))
+
+# ---- concurrency over time (s_memrealtime: 100 MHz, device-wide) ----
+rt = buf[:, 9:11].astype(np.int64)
+ok = (rt[:, 0] > 0) & (rt[:, 1] >= rt[:, 0])
+rt = rt[ok]
+a0 = rt[:, 0].min()
+st, en = (rt[:, 0] - a0) / 100.0, (rt[:, 1] - a0) / 100.0   # microseconds
+span = en.max()
+print("wall span %.1f us; wave lifetime mean %.1f us p90 %.1f max %.1f" %
+      (span, (en - st).mean(), np.percentile(en - st, 90), (en - st).max()))
+print("active waves every 5 us:", [int(((st <= x) & (en > x)).sum()) for x in np.arange(2.5, span, 5.0)])
+print("starts per 5 us:        ", np.histogram(st, bins=np.arange(0, span + 5, 5.0))[0].tolist())
+late = np.argsort(en)[-5:]
+grid = (t[:, 5] - t[:, 4]) > 4 * np.median(t[:, 5] - t[:, 4]) + 2000
+print("jobs that ran the step-5 grid:", int(grid.sum()))
+print("last 5 waves: start/end us", [(round(float(st[i]), 1), round(float(en[i]), 1)) for i in late])

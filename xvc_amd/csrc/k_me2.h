@@ -42,8 +42,15 @@ __device__ unsigned long long g_me2_trace[32768][16];
     if ((threadIdx.x & 63) == 0 && bi < 32768)                              \
       g_me2_trace[bi][k] = __builtin_amdgcn_s_memtime();                    \
   } while (0)
+// wall clock (100 MHz, common to the whole device) for cross-wave timelines
+#define ME2_TRACE_RT(k)                                                     \
+  do {                                                                      \
+    if ((threadIdx.x & 63) == 0 && bi < 32768)                              \
+      g_me2_trace[bi][k] = __builtin_amdgcn_s_memrealtime();                \
+  } while (0)
 #else
 #define ME2_TRACE(k) do {} while (0)
+#define ME2_TRACE_RT(k) do {} while (0)
 #endif
 
 // ---- cross-lane helpers (DPP / swizzle; no LDS traffic) ---------------------
@@ -576,26 +583,70 @@ __device__ __forceinline__ void me2_subpel_eval(Me2Shared<MS> &s, const MeCtx &c
   wave_sync();
 }
 
-// grid: n jobs; block: 64 threads (one wave).  Handles the jobs whose block
-// fits class MS (max(w,h) <= MS) and no smaller class.
+// Straggler-first scheduling.  A CU whose raster hit was >= 8 away runs the
+// step-5 grid: ~1500 extra candidates, ~28 us on top of a ~30 us job.  The
+// launch is two rounds of waves deep, so such a job starting in the second
+// round ends 20 us after everybody else - and a kernel ends with its slowest
+// wave (measured with s_memrealtime, tools/trace_me.py).  Content is coherent
+// in time and the job list is in picture raster order, so every job that runs
+// the grid records where it sits in its XCD's share of the list, and the NEXT
+// call rotates each XCD's dispatch order to start ME2_LEAD workgroups before
+// the earliest recorded one: the region around last picture's slow CUs runs
+// in the first round.  A rotation is a bijection of the job order: it changes
+// when a job runs, never whether it runs or what it computes.
+#define ME2_LEAD 64  // workgroups (~2 rows of 16x16 CUs at 1080p)
+struct Me2Rot {
+  int first[8];  // per XCD: workgroup (within the XCD's share) to start from
+};
+struct Me2Sched {
+  const Me2Rot *use;  // recorded by the previous call
+  Me2Rot *record;     // for the next call
+  Me2Rot *clear;      // the one after that: reset here
+};
+
+// XCD-aware job index with a per-XCD rotation (see xcd_job_index).
+__device__ __forceinline__ int me2_rotated_wg(int block, int n_wg, const Me2Rot *rot,
+                                              int &chunk, int &local, int &len) {
+  const int chunk_len = (n_wg + 7) >> 3;
+  chunk = block & 7;
+  const int pos = block >> 3;
+  const int base = chunk * chunk_len;
+  len = n_wg - base < chunk_len ? n_wg - base : chunk_len;
+  if (pos >= len) return -1;  // padding workgroup (or an empty share)
+  int r = rot ? rot->first[chunk] : 0;
+  r = (r < 0 || r >= len) ? 0 : r;
+  local = pos + r;
+  local = local >= len ? local - len : local;
+  return base + local;
+}
+
+// grid: ceil(n / waves) workgroups (padded to 8); block: ME2_WAVES(MS) waves, one
+// job per wave.  Handles the jobs whose block fits class MS (max(w,h) <= MS)
+// and no smaller class.
 // PH = phases compiled in.  (Forcing more waves per SIMD onto the full-pel
 // instance via a register cap spills and measured slower: 64 -> 88..149 us.)
 template <int MS, int PH>
 __global__ void __launch_bounds__(64 * ME2_WAVES(MS), ME2_MIN_WAVES(MS))
 me_search_wave_kernel(PicView orig, PicView ref,
                       const xvcgpu_me_block *blocks, int n,
-                      xvcgpu_me_result *results, const TzCand *tz_pattern) {
+                      xvcgpu_me_result *results, const TzCand *tz_pattern,
+                      Me2Sched sched) {
   constexpr int WPG = ME2_WAVES(MS);
+  constexpr bool kSched = (PH & XVCGPU_ME_FULLPEL) != 0;
   typedef Me2SharedT<MS, (PH & XVCGPU_ME_SUBPEL) != 0> Shared;
   __shared__ Shared s_all[WPG];
   Shared &s = s_all[threadIdx.x >> 6];
-  // job = (workgroup, wave); workgroups are XCD-swizzled, waves consecutive
+  // job = (workgroup, wave); workgroups are XCD-swizzled and rotated
   const int n_wg = (n + WPG - 1) / WPG;
-  const int wg = xcd_job_index(blockIdx.x, n_wg);
+  int chunk, local, len;
+  const int wg = me2_rotated_wg(blockIdx.x, n_wg, kSched ? sched.use : nullptr, chunk, local,
+                                len);
+  if (kSched && blockIdx.x == 0 && threadIdx.x < 8) sched.clear->first[threadIdx.x] = 0x7fffffff;
   if (wg < 0) return;
   const int bi = wg * WPG + (int)(threadIdx.x >> 6);
   if (bi >= n) return;
   ME2_TRACE(0);
+  ME2_TRACE_RT(9);
   const xvcgpu_me_block b = blocks[bi];
   {
     const int mx = b.w > b.h ? b.w : b.h;
@@ -685,24 +736,28 @@ me_search_wave_kernel(PicView orig, PicView ref,
     for (int r = 1; r <= range; r *= 2) { total += tz_pattern_count(r); n_rounds++; }
     const Me2Pattern pat = me2_load_pattern(tz_pattern);
 
-    // initial raster around the fixed base with per-round early termination
+    // initial raster around the fixed base with per-round early termination.
+    // The reference stops after 3 consecutive rounds without a hit, so at any
+    // point only the next (3 - dry) rounds are certain to be examined: exactly
+    // those are evaluated (one sweep), folded, and the horizon is extended only
+    // if one of them hit.  The common case is ranges 1,2,4 then 8,16 - the 32
+    // far candidates of ranges 32 and 64 (cold cache lines) are never read.
     {
-      uint32_t k0, k1;
+      uint32_t k0 = ME2_NOKEY, k1 = ME2_NOKEY;
       const int bx = st.bx, by = st.by;
-      // The reference stops the raster after 3 rounds without a hit, which
-      // is the common case: evaluate rounds 0..2 (ranges 1,2,4 = 20 nearby
-      // candidates) first and the far rounds only if the search goes on.
-      const int near_total = total < 20 ? total : 20;
-      me2_eval_diamonds(c, s, pat, bx, by, 0, near_total, st.cost, k0, k1);
-      int no_match = 0;
-      bool far_done = near_total == total;
+      int no_match = 0, r_eval = 0, idx_eval = 0;
       for (int r = 0; r < n_rounds; r++) {
-        if (r == 3 && !far_done) {
+        if (r >= r_eval) {
+          int hi = r + (3 - no_match);
+          hi = hi < n_rounds ? hi : n_rounds;
+          int idx_hi = idx_eval;
+          for (int q = r_eval; q < hi; q++) idx_hi += tz_pattern_count(1 << q);
           uint32_t f0, f1;
-          me2_eval_diamonds(c, s, pat, bx, by, near_total, total, st.cost, f0, f1);
+          me2_eval_diamonds(c, s, pat, bx, by, idx_eval, idx_hi, st.cost, f0, f1);
           if (f0 != ME2_NOKEY) k0 = f0;
           if (f1 != ME2_NOKEY) k1 = f1;
-          far_done = true;
+          r_eval = hi;
+          idx_eval = idx_hi;
         }
         uint32_t k = ME2_NOKEY;
         if (pat.round0 == r && k0 < k) k = k0;
@@ -761,6 +816,8 @@ me_search_wave_kernel(PicView orig, PicView ref,
     ME2_TRACE(4);  // neighbour
     // step-5 grid
     if (st.last_range > 5) {
+      if (kSched && lane == 0)  // slow job: ask the next call to start here
+        atomicMin(&sched.record->first[chunk], local > ME2_LEAD ? local - ME2_LEAD : 0);
       st.last_range = 5;
       const int nx = (fs_max_x - fs_min_x) / 5 + 1;
       const int ny = (fs_max_y - fs_min_y) / 5 + 1;
@@ -925,6 +982,7 @@ me_search_wave_kernel(PicView orig, PicView ref,
     }
   }
   ME2_TRACE(8);  // sub-pel passes
+  ME2_TRACE_RT(10);
   if (lane == 0) results[bi] = res;
 }
 

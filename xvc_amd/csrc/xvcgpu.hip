@@ -140,6 +140,8 @@ xvcgpu_status xvcgpu_create(int device, xvcgpu_ctx **out) {
   ctx->d_tz_pattern = nullptr;
   ctx->d_ssd_part = nullptr;
   ctx->ssd_part_cap = 0;
+  ctx->d_me_rot = nullptr;
+  ctx->me_epoch = 0;
   if (hipSetDevice(device) != hipSuccess ||
       hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
     delete ctx;
@@ -155,6 +157,11 @@ xvcgpu_status xvcgpu_create(int device, xvcgpu_ctx **out) {
       hipMalloc(&ctx->d_tx_tables_t, lay.total * sizeof(int16_t)) != hipSuccess ||
       hipMemcpy(ctx->d_tx_tables_t, xvcgpu_tx_host_tables_t(),
                 lay.total * sizeof(int16_t), hipMemcpyHostToDevice) != hipSuccess) {
+    xvcgpu_destroy(ctx);
+    return XVCGPU_OUT_OF_MEMORY;
+  }
+  if (hipMalloc(&ctx->d_me_rot, 3 * sizeof(Me2Rot)) != hipSuccess ||
+      hipMemset(ctx->d_me_rot, 0x7f, 3 * sizeof(Me2Rot)) != hipSuccess) {
     xvcgpu_destroy(ctx);
     return XVCGPU_OUT_OF_MEMORY;
   }
@@ -181,6 +188,7 @@ void xvcgpu_destroy(xvcgpu_ctx *ctx) {
   if (ctx->d_tx_tables_t) hipFree(ctx->d_tx_tables_t);
   if (ctx->d_tz_pattern) hipFree(ctx->d_tz_pattern);
   if (ctx->d_ssd_part) hipFree(ctx->d_ssd_part);
+  if (ctx->d_me_rot) hipFree(ctx->d_me_rot);
   hipEventDestroy(ctx->ev0);
   hipEventDestroy(ctx->ev1);
   if (ctx->own_stream && ctx->stream) hipStreamDestroy(ctx->stream);
@@ -527,10 +535,17 @@ xvcgpu_status xvcgpu_me_search_sized(xvcgpu_ctx *ctx, const xvcgpu_picture *orig
   // the fused instance (measured faster than two launches: waves in the
   // latency-bound full-pel search overlap waves in the VALU-bound sub-pel
   // search on the same SIMD).
+  Me2Sched sched = {nullptr, nullptr, nullptr};
+  if (flags & XVCGPU_ME_FULLPEL) {  // rotate the three records (k_me2.h)
+    const int e = ++ctx->me_epoch;
+    sched.use = ctx->d_me_rot + e % 3;
+    sched.record = ctx->d_me_rot + (e + 1) % 3;
+    sched.clear = ctx->d_me_rot + (e + 2) % 3;
+  }
 #define ME_LAUNCH(MS, PH)                                                          \
   hipLaunchKernelGGL((me_search_wave_kernel<MS, PH>), me2_grid(n, ME2_WAVES(MS)),  \
                      dim3(64 * ME2_WAVES(MS)), 0, ctx->stream, orig->v, ref->v,    \
-                     d_blocks, n, d_results, ctx->d_tz_pattern)
+                     d_blocks, n, d_results, ctx->d_tz_pattern, sched)
 #define ME_LAUNCH_CLASS(MS)                                \
   do {                                                     \
     if ((flags & 3) == 3) ME_LAUNCH(MS, 3);                \

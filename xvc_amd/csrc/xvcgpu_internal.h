@@ -36,6 +36,10 @@ struct xvcgpu_ctx {
   int16_t *d_tx_tables_t;  // transposed
   // TZ candidate pattern (tz_pattern.h), device copy
   TzCand *d_tz_pattern;
+  // straggler-first scheduling of the motion search (k_me2.h): three rotating
+  // records of where the slow jobs sat
+  struct Me2Rot *d_me_rot;
+  int me_epoch;
   // per-block partial results of xvcgpu_picture_ssd
   unsigned long long *d_ssd_part;
   int ssd_part_cap;  // in blocks
