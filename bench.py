@@ -48,6 +48,10 @@ def parse():
     ap.add_argument("--cpu-frames", type=int, default=12,
                     help="cap on the single-thread CPU oracle frame passes (rank 0, N=1)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--two-queue", action="store_true",
+                    help="N=1: issue the halves of every picture on a high- and a "
+                         "low-priority stream (pipeline.PipelinedFramePass; measured "
+                         "7 %% slower than one queue: 17 launches + events per step)")
     ap.add_argument("--graph", action="store_true",
                     help="N=1: replay one recorded HIP graph per step instead of "
                          "launching the kernels separately (measured ~3 %% slower: "
@@ -154,9 +158,18 @@ def main():
         p = ctx.picture(W, H, bd)
         p.upload(pad_planes(clip.frame(n), border), border)
         origs.append(p)
+    pipelined = runner is None and args.two_queue and not args.graph
+    ctx_lo = None
     if runner is None:
         recs = [ctx.picture(W, H, bd), ctx.picture(W, H, bd)]
         fp = pipeline.FramePass(ctx, W, H, bd, qp=args.qp)
+        if pipelined:
+            # two queues on the device: top half of every picture on a
+            # high-priority stream, bottom half on a low-priority one
+            ctx_lo = api.Context(local_rank)
+            ctx.use_priority_stream(True)
+            ctx_lo.use_priority_stream(False)
+            pfp = pipeline.PipelinedFramePass(ctx, ctx_lo, W, H, bd, qp=args.qp)
     else:
         recs = runner.e.pictures
         fp = runner.e.fp
@@ -174,6 +187,8 @@ def main():
         ref, rec = recs[i % 2], recs[(i + 1) % 2]
         if runner is not None:
             runner.run(o, i % 2, (i + 1) % 2, ref_poc=i)
+        elif pipelined:
+            pfp.run(o, ref, rec, ref_poc=i)
         elif not args.graph:
             fp.run(o, ref, rec, ref_poc=i)
         else:
@@ -188,6 +203,9 @@ def main():
 
     def barrier():
         ctx.sync()
+        if ctx_lo is not None:
+            ctx_lo.sync()
+            ctx.sync()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -203,6 +221,8 @@ def main():
     ctx.timer_begin()
     for i in range(args.warmup, args.warmup + args.steps):
         step(i)
+    if ctx_lo is not None:
+        ctx.wait_for(ctx_lo)  # the event timer sits on the high-priority queue
     gpu_ms = ctx.timer_end()
     barrier()
     dt = time.perf_counter() - t0
@@ -212,7 +232,7 @@ def main():
         dt = float(t.item())
 
     # PSNR-Y of the last reconstructed picture (sanity, not timed)
-    ssd = fp.d_ssd.to_array(np.uint64, 2)
+    ssd = (pfp if pipelined else fp).d_ssd.to_array(np.uint64, 2)
     psnr_y = pipeline.psnr_from_ssd(int(ssd[0]), int(ssd[1])) if ssd[1] else None
 
     # ---- roofline of the dominant kernel: HIP events around it on the
@@ -312,7 +332,8 @@ def main():
                                    "bitdepth 10, 16x16 CUs, TZ range 96, QuantFast" %
                                    (W, H, args.qp),
                        "cus_per_picture": fp.desc.n_cus_total,
-                       "parallelism": "single" if world == 1 else "cu-row-shard%d" % world},
+                       "parallelism": ("two-queue" if pipelined else "single") if world == 1
+                       else "cu-row-shard%d" % world},
             "roofline": roof, "cpu_baseline": cpu,
         }
         print(json.dumps(out))

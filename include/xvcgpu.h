@@ -59,6 +59,15 @@ const char *xvcgpu_version(void);
  * (the state after xvcgpu_create). */
 xvcgpu_status xvcgpu_set_stream(xvcgpu_ctx *ctx, void *hip_stream);
 xvcgpu_status xvcgpu_use_own_stream(xvcgpu_ctx *ctx);
+/* Several contexts on one device = several queues the GPU drains concurrently
+ * (the mirror of the reference's picture worker threads, thread_encoder.cc:
+ * 99-159).  xvcgpu_use_priority_stream gives the context a private stream of
+ * high (non-zero) or low priority: the low-priority queue fills the slots the
+ * high-priority one leaves idle while its kernels ramp up and drain.
+ * xvcgpu_wait_for(ctx, other): work queued on `ctx` after this call starts
+ * only when everything queued on `other` before it has finished (an event). */
+xvcgpu_status xvcgpu_use_priority_stream(xvcgpu_ctx *ctx, int high);
+xvcgpu_status xvcgpu_wait_for(xvcgpu_ctx *ctx, xvcgpu_ctx *other);
 xvcgpu_status xvcgpu_sync(xvcgpu_ctx *ctx);
 /* HIP-event stopwatch on the context's stream (bench.py's timed region). */
 xvcgpu_status xvcgpu_timer_begin(xvcgpu_ctx *ctx);

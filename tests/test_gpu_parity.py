@@ -806,6 +806,51 @@ def test_recorded_frame_pass_replay(gpu, xo):
         p.destroy()
 
 
+@pytest.mark.parametrize("size", [(352, 288), (1920, 1080)])
+def test_pipelined_frame_pass(gpu, xo, size):
+    """Two-queue issue of the frame pass (high / low priority streams, halves
+    of the picture): identical bytes, three chained pictures."""
+    api, ctx = gpu
+    from xvc_amd import pipeline, synth
+    import oracle_frame
+    pw, ph = size
+    bd = 10
+    lo = api.Context(0)
+    ctx.use_priority_stream(True)
+    lo.use_priority_stream(False)
+    clip = synth.SyntheticClip(pw, ph, bd)
+    fp = pipeline.PipelinedFramePass(ctx, lo, pw, ph, bd, qp=32)
+    ref_host = pad_planes(clip.frame(0), bd)
+    O = [ctx.picture(pw, ph, bd) for _ in range(3)]
+    recs = [ctx.picture(pw, ph, bd), ctx.picture(pw, ph, bd)]
+    recs[0].upload(ref_host, BL)
+    origs = [pad_planes(clip.frame(n), bd) for n in (1, 2, 3)]
+    for n in range(3):
+        O[n].upload(origs[n], BL)
+    ctx.sync()
+    # all three pictures queued back to back: cross-picture ordering is part of the test
+    for n in range(3):
+        fp.run(O[n], recs[n % 2], recs[(n + 1) % 2], ref_poc=n)
+    fp.sync()
+    exp_ref = ref_host
+    for n in range(3):
+        e_rec, e_res, e_nnz, e_cus, e_ssd = oracle_frame.frame_pass(
+            fp.desc, bd, origs[n], exp_ref, BL, ref_poc=n, lib=xo)
+        exp_ref = e_rec
+    got = recs[1].download(BL)        # picture 3 landed in recs[(2 + 1) % 2]
+    for c in range(3):
+        assert np.array_equal(got[c], e_rec[c]), c
+    res, nnz, cus, ssd = fp.results()
+    assert np.array_equal(res, e_res) and np.array_equal(nnz, e_nnz)
+    assert np.array_equal(cus, e_cus)
+    assert (int(ssd[0]), int(ssd[1])) == e_ssd
+    fp.destroy()
+    for p in O + recs:
+        p.destroy()
+    lo.close()
+    ctx.use_own_stream()
+
+
 @pytest.mark.parametrize("cu", [8, 32, 64])
 def test_frame_pass_cu_sizes(gpu, xo, cu):
     """Frame pass with other CU sizes (8: fused wave kernels; 32 / 64: the

@@ -65,7 +65,7 @@ assert MC_DTYPE.itemsize == 16 and CAND_DTYPE.itemsize == 12
 # every symbol include/xvcgpu.h declares
 SYMBOLS = [
     "xvcgpu_create", "xvcgpu_destroy", "xvcgpu_last_error", "xvcgpu_version",
-    "xvcgpu_set_stream", "xvcgpu_use_own_stream", "xvcgpu_sync", "xvcgpu_timer_begin", "xvcgpu_timer_end",
+    "xvcgpu_set_stream", "xvcgpu_use_own_stream", "xvcgpu_use_priority_stream", "xvcgpu_wait_for", "xvcgpu_sync", "xvcgpu_timer_begin", "xvcgpu_timer_end",
     "xvcgpu_record_begin", "xvcgpu_record_end", "xvcgpu_replay", "xvcgpu_recording_destroy",
     "xvcgpu_malloc", "xvcgpu_free", "xvcgpu_memcpy_h2d", "xvcgpu_memcpy_d2h",
     "xvcgpu_memset", "xvcgpu_picture_create", "xvcgpu_picture_bytes",
@@ -122,6 +122,8 @@ def load_library():
         "xvcgpu_create": [C.c_int, C.POINTER(_vp)],
         "xvcgpu_set_stream": [_vp, _vp],
         "xvcgpu_use_own_stream": [_vp],
+        "xvcgpu_use_priority_stream": [_vp, C.c_int],
+        "xvcgpu_wait_for": [_vp, _vp],
         "xvcgpu_sync": [_vp],
         "xvcgpu_timer_begin": [_vp],
         "xvcgpu_timer_end": [_vp, C.POINTER(C.c_float)],
@@ -331,6 +333,14 @@ class Context:
 
     def recording_destroy(self, recording):
         self.lib.xvcgpu_recording_destroy(recording)
+
+    def use_priority_stream(self, high):
+        self._check(self.lib.xvcgpu_use_priority_stream(self.h, 1 if high else 0))
+
+    def wait_for(self, other):
+        """Work queued on this context from now on starts after everything
+        already queued on `other`."""
+        self._check(self.lib.xvcgpu_wait_for(self.h, other.h))
 
     def use_own_stream(self):
         self._check(self.lib.xvcgpu_use_own_stream(self.h))

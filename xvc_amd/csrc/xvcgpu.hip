@@ -150,6 +150,7 @@ xvcgpu_status xvcgpu_create(int device, xvcgpu_ctx **out) {
   ctx->own_stream = true;
   hipEventCreate(&ctx->ev0);
   hipEventCreate(&ctx->ev1);
+  hipEventCreateWithFlags(&ctx->ev_sync, hipEventDisableTiming);
   const TxTableLayout &lay = xvcgpu_tx_layout();
   if (hipMalloc(&ctx->d_tx_tables, lay.total * sizeof(int16_t)) != hipSuccess ||
       hipMemcpy(ctx->d_tx_tables, xvcgpu_tx_host_tables(),
@@ -191,6 +192,7 @@ void xvcgpu_destroy(xvcgpu_ctx *ctx) {
   if (ctx->d_me_rot) hipFree(ctx->d_me_rot);
   hipEventDestroy(ctx->ev0);
   hipEventDestroy(ctx->ev1);
+  hipEventDestroy(ctx->ev_sync);
   if (ctx->own_stream && ctx->stream) hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -217,6 +219,27 @@ xvcgpu_status xvcgpu_use_own_stream(xvcgpu_ctx *ctx) {
   hipStreamSynchronize(ctx->stream);
   HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
   ctx->own_stream = true;
+  return XVCGPU_OK;
+}
+
+xvcgpu_status xvcgpu_use_priority_stream(xvcgpu_ctx *ctx, int high) {
+  if (!ctx) return XVCGPU_INVALID_ARGUMENT;
+  int lo = 0, hi = 0;  // numerically lower = higher priority
+  HIP_TRY(ctx, hipDeviceGetStreamPriorityRange(&lo, &hi));
+  hipStreamSynchronize(ctx->stream);
+  hipStream_t st = nullptr;
+  HIP_TRY(ctx, hipStreamCreateWithPriority(&st, hipStreamNonBlocking, high ? hi : lo));
+  if (ctx->own_stream && ctx->stream) hipStreamDestroy(ctx->stream);
+  ctx->stream = st;
+  ctx->own_stream = true;
+  return XVCGPU_OK;
+}
+
+xvcgpu_status xvcgpu_wait_for(xvcgpu_ctx *ctx, xvcgpu_ctx *other) {
+  if (!ctx || !other) return XVCGPU_INVALID_ARGUMENT;
+  if (ctx == other || ctx->stream == other->stream) return XVCGPU_OK;
+  HIP_TRY(ctx, hipEventRecord(other->ev_sync, other->stream));
+  HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, other->ev_sync, 0));
   return XVCGPU_OK;
 }
 

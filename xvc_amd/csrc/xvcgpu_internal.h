@@ -30,6 +30,7 @@ struct xvcgpu_ctx {
   hipStream_t stream;
   bool own_stream;
   hipEvent_t ev0, ev1;
+  hipEvent_t ev_sync;  // xvcgpu_wait_for
   std::string err;
   // transform matrices [type 1..5][log2 size 1..6], device copy
   int16_t *d_tx_tables;

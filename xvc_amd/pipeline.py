@@ -194,6 +194,71 @@ class FramePass:
         self.pred.destroy()
 
 
+class PipelinedFramePass:
+    """The frame pass issued on two queues so that kernels of one half of the
+    picture run while kernels of the other half ramp up or drain (a launch is
+    only ~2 rounds of waves deep, so each kernel spends a third of its time
+    partially filled - tools/trace_me.py).
+
+        ctx_hi (high priority): top CU rows    - search, recon, deblock V
+        ctx_lo (low priority):  bottom CU rows - search, recon, deblock V
+        ctx_hi: waits for ctx_lo, deblock H over the picture, pad
+        ctx_lo: waits for that, picture SSD (overlaps the next picture's search)
+
+    Same kernels, same results as FramePass; only the queueing differs."""
+
+    def __init__(self, ctx_hi, ctx_lo, width, height, bitdepth=10, qp=32, cu=16,
+                 search_range=96):
+        self.hi, self.lo = ctx_hi, ctx_lo
+        self.w, self.h, self.bd = width, height, bitdepth
+        rows = (height + cu - 1) // cu
+        self.y_mid = (rows // 2) * cu
+        self.top = FramePass(ctx_hi, width, height, bitdepth, qp, cu, search_range,
+                             row_range=(0, self.y_mid))
+        self.bot = FramePass(ctx_lo, width, height, bitdepth, qp, cu, search_range,
+                             row_range=(self.y_mid, height))
+        # one CU metadata array for the whole picture (the H pass reads both halves)
+        self.bot.d_cus.free()
+        self.bot.d_cus = self.top.d_cus
+        self.desc = FrameDescriptors(width, height, qp, cu, search_range)
+        self.d_ssd = self.bot.d_ssd
+
+    def run(self, orig, ref, rec, ref_poc=0):
+        hi, lo, top, bot = self.hi, self.lo, self.top, self.bot
+        top.encode(orig, ref, rec, ref_poc)
+        top.deblock_rows(rec, 0, 0, self.y_mid)
+        bot.encode(orig, ref, rec, ref_poc)
+        bot.deblock_rows(rec, 0, self.y_mid, self.h)
+        hi.wait_for(lo)
+        top.deblock_rows(rec, 1, 0, self.h)
+        hi.pad_border(rec)
+        lo.wait_for(hi)
+        lo.picture_ssd_dev(orig, rec, 0, self.bd, self.d_ssd.ptr)
+
+    def sync(self):
+        self.hi.sync()
+        self.lo.sync()
+
+    def results(self):
+        a, b = self.top, self.bot
+        res = np.concatenate([a.d_res.to_array(api.MERES_DTYPE, a.desc.n_cus),
+                              b.d_res.to_array(api.MERES_DTYPE, b.desc.n_cus)])
+        nnz = np.concatenate([a.d_nnz.to_array(np.int32, len(a.desc.tx)),
+                              b.d_nnz.to_array(np.int32, len(b.desc.tx))])
+        return (res, nnz, a.d_cus.to_array(api.CU_DTYPE, a.desc.n_cus_total),
+                self.d_ssd.to_array(np.uint64, 2))
+
+    def destroy(self):
+        self.sync()
+        self.bot.d_cus = None
+        for fp in (self.top, self.bot):
+            for b in (fp.d_me, fp.d_tx, fp.d_luma_idx, fp.d_map, fp.d_res, fp.d_nnz,
+                      fp.d_cus, fp.d_ssd, fp.d_levels, fp.d_level_off):
+                if b is not None:
+                    b.free()
+            fp.pred.destroy()
+
+
 class DecodePass:
     """The decoder's reconstruction of one inter picture from parsed syntax
     (SURVEY section 8f row N1; PictureDecoder::Decode, picture_decoder.cc:
