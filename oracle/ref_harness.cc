@@ -584,6 +584,18 @@ int xr_quant_fast2(int bd, int qp_raw, int intra_pic, int sign_hide, int scan_or
   return nnz;
 }
 
+void xr_qp_info(int qp_raw, int bd, int *qp_chroma, uint32_t *lambda16,
+                double *chroma_dist_weight) {
+  /* Y1: Qp as PictureData::Init builds it (picture_data.cc:91-106: lambda =
+   * 0.57 * 2^((qp-12)/3), chroma table 1, offsets 0) and the full-pel search's
+   * lambda16 = floor(65536 * sqrt(lambda)) (inter_tz_search.cc:98-99) */
+  const double lambda = 0.57 * pow(2.0, (qp_raw - 12) / 3.0);
+  Qp qp(qp_raw, ChromaFormat::k420, bd, lambda, 1, 0, 0);
+  *qp_chroma = qp.GetQpRaw(YuvComponent::kU);
+  *lambda16 = static_cast<uint32_t>(std::floor(65536.0 * qp.GetLambdaSqrt()));
+  *chroma_dist_weight = qp.GetDistortionWeight(YuvComponent::kU);
+}
+
 uint64_t xr_mc_metric(int bd, int metric_type, int qp_raw, int strength, int x, int y,
                       int w, int h,
                       int mv_x, int mv_y, int pic_w, int pic_h, const uint16_t *orig,

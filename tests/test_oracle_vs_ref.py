@@ -479,3 +479,21 @@ def test_quant_fast_sign_hiding(libs, bd):
         plain, _ = xo.quant_fast2(bd, qp, intra, 0, scan, coeff)
         n_changed += not np.array_equal(plain, o)
     assert n_changed > 100   # sign hiding did modify levels in many cases
+
+
+def test_qp_derivation(libs):
+    """Y1: the host-side Qp helpers (chroma qp table, lambda16) against Qp."""
+    import ctypes as C
+    from xvc_amd import pipeline
+    _, xr = libs
+    f = xr.dll.xr_qp_info
+    f.restype = None
+    f.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_uint32),
+                  C.POINTER(C.c_double)]
+    for bd in (8, 10):
+        for qp in range(0, 64):
+            qc, l16, w = C.c_int(), C.c_uint32(), C.c_double()
+            f(qp, bd, C.byref(qc), C.byref(l16), C.byref(w))
+            assert pipeline.chroma_qp(qp) == qc.value == ol.chroma_qp(qp), qp
+            assert pipeline.lambda16_for_qp(qp) == l16.value, qp
+            assert w.value == 2.0 ** (-(qc.value - min(qp, 57)) / 3.0)
