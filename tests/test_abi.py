@@ -112,3 +112,69 @@ def test_cpp_host_layer_runs_on_gpu(api, tmp_path):
     exe = _build_host_demo(str(tmp_path))
     r = subprocess.run([exe], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
+
+
+def _build_frame_pass_program(tmpdir):
+    import subprocess
+    host = os.path.join(ROOT, "xvc_amd", "host")
+    obj = os.path.join(tmpdir, "synth.o")
+    exe = os.path.join(tmpdir, "frame_pass")
+    subprocess.check_call(["gcc", "-O2", "-std=c99", "-Wall", "-Werror", "-c",
+                           os.path.join(host, "xvc_synth.c"), "-o", obj])
+    subprocess.check_call([
+        "g++", "-std=c++11", "-O2", "-Wall", "-Wextra", "-Werror",
+        "-I", os.path.join(ROOT, "include"), "-I", host,
+        os.path.join(host, "frame_pass_main.cc"), obj, "-o", exe,
+        "-L", os.path.join(ROOT, "xvc_amd"), "-lxvcgpu",
+        "-Wl,-rpath," + os.path.join(ROOT, "xvc_amd"), "-Wl,-rpath,/opt/rocm/lib"])
+    return exe
+
+
+def test_cpp_frame_pass_program_builds(api, tmp_path):
+    import subprocess
+    import torch
+    exe = _build_frame_pass_program(str(tmp_path))
+    if not torch.cuda.is_available():
+        r = subprocess.run([exe, "64", "32", "10", "32", "1"], capture_output=True, text=True)
+        assert r.returncode == 3, r.stdout + r.stderr
+
+
+@pytest.mark.gpu
+def test_cpp_frame_pass_program_matches_oracle(api, tmp_path):
+    """The C++ host driver (xvc_amd/host/xvc_frame_pass.h) end to end: three
+    chained pictures of the synthetic clip; SSD and a hash of every
+    reconstructed plane equal the oracle's."""
+    import subprocess
+    import numpy as np
+    import oracle_frame
+    from xvc_amd import pipeline, synth
+    exe = _build_frame_pass_program(str(tmp_path))
+    pw, ph, bd, qp, frames, BL = 352, 288, 10, 32, 3, 128
+    r = subprocess.run([exe, str(pw), str(ph), str(bd), str(qp), str(frames)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = [l.split() for l in r.stdout.splitlines() if l.startswith("frame ")]
+    assert len(lines) == frames
+
+    def fnv(planes):
+        h = 14695981039346656037
+        for p in planes:
+            for b in np.ascontiguousarray(p).astype("<u2").tobytes():
+                h = ((h ^ b) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+        return h
+
+    clip = synth.SyntheticClip(pw, ph, bd)
+    pad = lambda planes: [np.ascontiguousarray(np.pad(p, BL if c == 0 else BL // 2,
+                                                      mode="edge")) for c, p in enumerate(planes)]
+    desc = pipeline.FrameDescriptors(pw, ph, qp)
+    ref = pad(clip.frame(0))
+    xo = ol.Lib("xo")
+    for n in range(1, frames + 1):
+        rec, _, _, _, ssd = oracle_frame.frame_pass(desc, bd, pad(clip.frame(n)), ref, BL,
+                                                    ref_poc=n - 1, lib=xo)
+        inner = [rec[c][(BL >> (c > 0)):(BL >> (c > 0)) + (ph >> (c > 0)),
+                        (BL >> (c > 0)):(BL >> (c > 0)) + (pw >> (c > 0))] for c in range(3)]
+        got = lines[n - 1]
+        assert (int(got[3]), int(got[5])) == ssd, n
+        assert int(got[7], 16) == fnv(inner), n
+        ref = rec

@@ -1,7 +1,8 @@
 /* xvc_synth.c -- the deterministic integer-only synthetic clip generator of
  * xvc_amd/synth.py in plain C (shipped in both languages
- * so a C/C++ host and the Python harness feed identical bytes).  Test
- * infrastructure / tooling: the product library does not link it.
+ * so a C/C++ host and the Python harness feed identical bytes).  Input
+ * generation only: libxvcgpu.so does not link it; the oracle's shared object
+ * and the C++ host programs compile it in.
  *
  * frame n = crop of a static textured base plane at (2n mod 64, n mod 64) + one
  * 32x32 inverted-contrast square moving (5,3) px/frame + fresh +-2 noise from a
