@@ -766,6 +766,115 @@ def test_decode_pass_equals_encoder_reconstruction(gpu, xo, size):
         p.destroy()
 
 
+@pytest.mark.parametrize("bd", [8, 10])
+def test_bipicture_reconstruction(gpu, xo, bd):
+    """N1 for a B picture: CUs predicted from list 0, list 1 or both (random
+    partition into 8..64 CUs), residual coded with the device quantiser, then
+    decoded from MVs + levels: MC (uni / bi) -> dequant + inverse transform +
+    AddClip -> deblocking with two reference POCs per CU -> PadBorder.  The
+    encoder-side and decoder-side reconstructions and an oracle composite of
+    the pinned block functions must be the same bytes."""
+    api, ctx = gpu
+    rng = np.random.default_rng(6100 + bd)
+    pw, ph, qp = 256, 192, 30
+    po = padded_planes(rng, bd, pw, ph, smooth=True)
+    r0 = [np.clip(p.astype(np.int32) + rng.integers(-6, 7, size=p.shape), 0,
+                  (1 << bd) - 1).astype(np.uint16) for p in po]
+    r1 = [np.clip(p.astype(np.int32) + rng.integers(-6, 7, size=p.shape), 0,
+                  (1 << bd) - 1).astype(np.uint16) for p in po]
+    O, R0, R1, P, Renc, Rdec = (ctx.picture(pw, ph, bd) for _ in range(6))
+    O.upload(po, BL)
+    R0.upload(r0, BL)
+    R1.upload(r1, BL)
+    parts = random_partition(rng, pw, ph, 8)
+    n = len(parts)
+    cus = np.zeros(n, api.CU_DTYPE)
+    cmap = -np.ones((ph // 4, pw // 4), np.int32)
+    uni0, uni1, bi, tx = [], [], [], []
+    qpc = ol.chroma_qp(qp)
+    for i, (x, y, w, h) in enumerate(parts):
+        d = int(rng.integers(0, 3))               # 0: L0, 1: L1, 2: bi
+        mv0 = (int(rng.integers(-60, 60)), int(rng.integers(-60, 60)))
+        mv1 = (int(rng.integers(-60, 60)), int(rng.integers(-60, 60)))
+        c = cus[i]
+        c["x"], c["y"], c["w"], c["h"] = x, y, w, h
+        c["qp_y"], c["qp_c"] = qp, qpc
+        c["ref_poc"][0] = 0 if d != 1 else -1
+        c["ref_poc"][1] = 16 if d != 0 else -1
+        if d != 1:
+            c["mv"][0][:] = mv0
+        if d != 0:
+            c["mv"][1][:] = mv1
+        cmap[y // 4:(y + h) // 4, x // 4:(x + w) // 4] = i
+        for comp in range(3):
+            if d == 0:
+                uni0.append((x, y, w, h, comp, 0, *mv0))
+            elif d == 1:
+                uni1.append((x, y, w, h, comp, 0, *mv1))
+            else:
+                bi.append((x, y, w, h, comp, 0, *mv0, *mv1))
+            cs = 1 if comp else 0
+            tx.append((x >> cs, y >> cs, w >> cs, h >> cs, comp, 0, 0, 0,
+                       qpc if comp else qp, 0))
+    assert uni0 and uni1 and bi
+    tx = np.array(tx, api.TX_DTYPE)
+
+    def predict(dst):
+        ctx.mc_batch(R0, dst, np.array(uni0, api.MC_DTYPE))
+        ctx.mc_batch(R1, dst, np.array(uni1, api.MC_DTYPE))
+        ctx.mc_bipred_batch(R0, R1, dst, np.array(bi, api.MCBI_DTYPE))
+
+    # encoder side
+    predict(P)
+    levels, off, nnz = ctx.residual_batch(O, P, Renc, tx)
+    cus["cbf_luma"] = nnz[0::3] != 0
+    ctx.deblock(Renc, cus, cmap, bipred=1)
+    ctx.pad_border(Renc)
+    ctx.sync()
+    # decoder side: from MVs + levels only
+    predict(P)
+    ctx.inv_transform_batch(P, Rdec, tx, levels, off, nnz)
+    ctx.deblock(Rdec, cus, cmap, bipred=1)
+    ctx.pad_border(Rdec)
+    ctx.sync()
+    enc, dec = Renc.download(BL), Rdec.download(BL)
+    # oracle composite
+    pred = [np.zeros_like(p) for p in po]
+    for (x, y, w, h, comp, _, mx, my) in uni0:
+        b = BL if comp == 0 else BC
+        cs = 1 if comp else 0
+        view(pred, comp)[y >> cs:(y + h) >> cs, x >> cs:(x + w) >> cs] = \
+            xo.mc_block(bd, comp, x, y, w, h, mx, my, pw, ph, r0[comp], b)
+    for (x, y, w, h, comp, _, mx, my) in uni1:
+        b = BL if comp == 0 else BC
+        cs = 1 if comp else 0
+        view(pred, comp)[y >> cs:(y + h) >> cs, x >> cs:(x + w) >> cs] = \
+            xo.mc_block(bd, comp, x, y, w, h, mx, my, pw, ph, r1[comp], b)
+    for (x, y, w, h, comp, _, a0, a1, b0, b1) in bi:
+        b = BL if comp == 0 else BC
+        cs = 1 if comp else 0
+        view(pred, comp)[y >> cs:(y + h) >> cs, x >> cs:(x + w) >> cs] = \
+            xo.mc_bipred_block(bd, comp, x, y, w, h, (a0, a1), (b0, b1), pw, ph,
+                               r0[comp], r1[comp], b)
+    rec = [p.copy() for p in pred]
+    for k, t in enumerate(tx):
+        comp = int(t["comp"])
+        cw, ch = (pw, ph) if comp == 0 else (pw // 2, ph // 2)
+        r, coeff, nz = xo.residual_pipeline(
+            bd, to_tx_struct(t), np.ascontiguousarray(view(po, comp)[:ch, :cw]),
+            np.ascontiguousarray(view(pred, comp)[:ch, :cw]))
+        assert nz == int(nnz[k])
+        x, y, w, h = int(t["x"]), int(t["y"]), int(t["w"]), int(t["h"])
+        view(rec, comp)[y:y + h, x:x + w] = r[y:y + h, x:x + w]
+    xo.deblock(bd, pw, ph, 1, 0, 0, 4, cus, cmap, rec, [BL, BC, BC])
+    xo.pad_border(pw, ph, rec, [BL, BC, BC])
+    for c in range(3):
+        assert np.array_equal(enc[c], dec[c]), c
+        assert np.array_equal(dec[c], rec[c]), c
+    for p in (O, R0, R1, P, Renc, Rdec):
+        p.destroy()
+
+
 def test_recorded_frame_pass_replay(gpu, xo):
     """xvcgpu_record_* / xvcgpu_replay: the recorded frame pass replayed as one
     HIP graph gives the same bytes as the oracle, on every replay."""
