@@ -190,6 +190,8 @@ xvcgpu_status xvcgpu_mc_metric_batch(xvcgpu_ctx *ctx, const xvcgpu_picture *orig
  * (inter_search.cc:606-662, inter_tz_search.cc:84-171, inter_search.cc:
  * 893-964).  One result per xvcgpu_me_block, bit-identical to running the
  * reference search on that block with the same predictor inputs.
+ * Blocks: w, h in {4, 8, 16, 32, 64}, at least 32 samples (a job with any
+ * other size is left untouched); x, y multiples of 4 inside the picture.
  * flags: XVCGPU_ME_FULLPEL runs the TZ search; XVCGPU_ME_SUBPEL runs the
  * 9+8 point half/quarter-pel refinement starting from results[i].fullpel_*
  * (taken from the TZ search when both flags are set). */

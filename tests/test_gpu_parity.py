@@ -673,6 +673,40 @@ def test_error_paths(gpu):
     assert lib.xvcgpu_me_search(ctx.h, A.h_pic, A.h_pic, 0, None, 0, None) == 10
     assert lib.xvcgpu_me_search(ctx.h, A.h_pic, A.h_pic, 3, None, 0, None) == 0
     assert lib.xvcgpu_deblock(ctx.h, A.h_pic, None, 0, None, 16, 0, 0, 0, 4) == 10
+    # empty batches are accepted, null arrays with n > 0 and mismatching
+    # pictures are refused - for every batched entry point
+    B = ctx.picture(128, 64, 10)
+    d = ctx.alloc(256)
+    for name, pics, tail in [
+            ("xvcgpu_mc_batch", (A, A), ()),
+            ("xvcgpu_mc_affine_batch", (A, A), ()),
+            ("xvcgpu_mc_bipred_batch", (A, A, A), ()),
+            ("xvcgpu_mc_from_me", (A, A), None)]:
+        f = getattr(lib, name)
+        if tail is None:
+            assert f(ctx.h, A.h_pic, A.h_pic, None, None, 0) == 0
+            assert f(ctx.h, A.h_pic, A.h_pic, None, None, 4) == 10
+            assert f(ctx.h, A.h_pic, B.h_pic, d.ptr, d.ptr, 1) == 10
+            continue
+        hs = [p.h_pic for p in pics]
+        assert f(ctx.h, *hs, None, 0) == 0, name
+        assert f(ctx.h, *hs, None, 3) == 10, name
+        assert f(ctx.h, *(hs[:-1] + [B.h_pic]), d.ptr, 1) == 10, name
+    assert lib.xvcgpu_bipred_search(ctx.h, A.h_pic, A.h_pic, A.h_pic, None, 0, None, 64) == 0
+    assert lib.xvcgpu_bipred_search(ctx.h, A.h_pic, A.h_pic, A.h_pic, None, 2, None, 64) == 10
+    assert lib.xvcgpu_bipred_search(ctx.h, A.h_pic, B.h_pic, A.h_pic, d.ptr, 1, d.ptr, 64) == 10
+    assert lib.xvcgpu_bipred_search(ctx.h, A.h_pic, A.h_pic, A.h_pic, d.ptr, 1, d.ptr, 3) == 10
+    assert lib.xvcgpu_mc_metric_batch(ctx.h, A.h_pic, A.h_pic, 16, None, 0, None) == 0
+    assert lib.xvcgpu_mc_metric_batch(ctx.h, A.h_pic, A.h_pic, 16, None, 1, None) == 10
+    assert lib.xvcgpu_mc_metric_batch(ctx.h, A.h_pic, B.h_pic, 16, d.ptr, 1, d.ptr) == 10
+    assert lib.xvcgpu_residual_batch(ctx.h, A.h_pic, A.h_pic, A.h_pic, None, 0, None, None,
+                                     None) == 0
+    assert lib.xvcgpu_picture_ssd(ctx.h, A.h_pic, B.h_pic, 0, 10, d.ptr) == 10
+    assert lib.xvcgpu_wait_for(ctx.h, None) == 10
+    assert lib.xvcgpu_replay(ctx.h, None) == 10
+    assert b"mismatch" in lib.xvcgpu_last_error(ctx.h)
+    d.free()
+    B.destroy()
     A.destroy()
 
 
