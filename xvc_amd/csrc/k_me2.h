@@ -103,7 +103,7 @@ __device__ __forceinline__ int wave_reduce_add_i32(int v) {
 #define ME2_WAVES(MS) ((MS) > 32 ? 2 : 4)
 // waves per SIMD the register allocator leaves room for: the 16-class fits 4
 // workgroups per CU by LDS, so cap its registers at 128 (measured +3 %)
-#define ME2_MIN_WAVES(MS) ((MS) <= 16 ? 4 : 1)
+#define ME2_MIN_WAVES(MS) ((MS) <= 16 ? 4 : 1)  // 5 (96 VGPRs) spills: 80 -> 147 us
 
 // Orders LDS traffic between the lanes of ONE wave (jobs never share data
 // across waves, so no workgroup barrier is ever needed): LDS requests of a
@@ -125,10 +125,14 @@ struct __attribute__((aligned(16))) Me2SharedT {
   uint32_t cost[128];
   // per sub-pel candidate: plane offset (int16 units from `orig`), stride,
   // rounding offset, shift, 8 taps
-  int cand_plane[12], cand_stride[12], cand_off[12], cand_shift[12];
-  int16_t cand_taps[12][8];
+  union {
+    struct {                                // row-major path
+      int cand_plane[12], cand_stride[12], cand_off[12], cand_shift[12];
+      int16_t cand_taps[12][8];
+    };
+    SpCand sp[SUB ? 10 : 1];                // fast path (k_subpel.h)
+  };
   uint32_t dist[12];
-  SpCand sp[SUB ? 10 : 1];                  // fast path (k_subpel.h)
   int16_t taps[SUB ? 16 : 1][8];            // LDS copy of kLumaTaps
 };
 template <int MS>
