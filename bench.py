@@ -232,7 +232,10 @@ def main():
         dt = float(t.item())
 
     # PSNR-Y of the last reconstructed picture (sanity, not timed)
-    ssd = (pfp if pipelined else fp).d_ssd.to_array(np.uint64, 2)
+    if runner is not None:
+        ssd = runner.total_ssd()   # per-shard parts, all-reduced once here
+    else:
+        ssd = (pfp if pipelined else fp).d_ssd.to_array(np.uint64, 2)
     psnr_y = pipeline.psnr_from_ssd(int(ssd[0]), int(ssd[1])) if ssd[1] else None
 
     # ---- roofline of the dominant kernel: HIP events around it on the

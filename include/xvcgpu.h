@@ -357,6 +357,13 @@ xvcgpu_status xvcgpu_deblock_rows(xvcgpu_ctx *ctx, xvcgpu_picture *rec,
 xvcgpu_status xvcgpu_picture_ssd(xvcgpu_ctx *ctx, const xvcgpu_picture *a,
                                  const xvcgpu_picture *b, int comp,
                                  int shift_bitdepth, uint64_t *d_out);
+/* The share of the blocks whose first row (in the component plane) lies in
+ * [y_begin, y_end): shares of disjoint row ranges covering the picture add up
+ * to xvcgpu_picture_ssd - what one CU-row shard contributes. */
+xvcgpu_status xvcgpu_picture_ssd_rows(xvcgpu_ctx *ctx, const xvcgpu_picture *a,
+                                      const xvcgpu_picture *b, int comp,
+                                      int shift_bitdepth, int y_begin, int y_end,
+                                      uint64_t *d_out);
 
 /* ---- tables (host side, no GPU needed) ---------------------------------- *
  * The 8-bit-fraction transform matrices the kernels use (transform_data.cc:

@@ -285,6 +285,17 @@ uint64_t xo_ssd_rr(int bitdepth, double weight, int w, int h,
 uint64_t xo_picture_ssd(int bitdepth, int w, int h, const uint16_t *p1,
                         ptrdiff_t st1, const uint16_t *p2, ptrdiff_t st2,
                         uint64_t *psnr_dist, uint64_t *psnr_samples) {
+  return xo_picture_ssd_rows(bitdepth, w, h, 0, h, p1, st1, p2, st2, psnr_dist,
+                             psnr_samples);
+}
+
+/* The same walk restricted to the blocks whose first row lies in
+ * [y_begin, y_end): the share of one CU-row shard (the shares of disjoint row
+ * ranges covering the picture add up to xo_picture_ssd). */
+uint64_t xo_picture_ssd_rows(int bitdepth, int w, int h, int y_begin, int y_end,
+                             const uint16_t *p1, ptrdiff_t st1, const uint16_t *p2,
+                             ptrdiff_t st2, uint64_t *psnr_dist,
+                             uint64_t *psnr_samples) {
   const int B = 64;
   const int mbx = w & ~(w - 1);
   const int mby = h & ~(h - 1);
@@ -292,11 +303,12 @@ uint64_t xo_picture_ssd(int bitdepth, int w, int h, const uint16_t *p1,
   uint64_t dist = 0, samples = 0;
   int y;
   for (y = 0; y < h - B; y += B) {
-    for (int x = 0; x < w - B; x += B) {
+    const int take = y >= y_begin && y < y_end;
+    for (int x = 0; take && x < w - B; x += B) {
       dist += xo_ssd_ss(B, B, p1 + x, st1, p2 + x, st2) >> sh;
       samples += (uint64_t)B * B;
     }
-    for (int x = w & ~(B - 1); x < w; x += mbx) {
+    for (int x = w & ~(B - 1); take && x < w; x += mbx) {
       dist += xo_ssd_ss(mbx, B, p1 + x, st1, p2 + x, st2) >> sh;
       samples += (uint64_t)mbx * B;
     }
@@ -304,11 +316,12 @@ uint64_t xo_picture_ssd(int bitdepth, int w, int h, const uint16_t *p1,
     p2 += st2 * B;
   }
   for (y = h & ~(B - 1); y < h; y += mby) {
-    for (int x = 0; x < w - B; x += B) {
+    const int take = y >= y_begin && y < y_end;
+    for (int x = 0; take && x < w - B; x += B) {
       dist += xo_ssd_ss(B, mby, p1 + x, st1, p2 + x, st2) >> sh;
       samples += (uint64_t)B * mby;
     }
-    for (int x = w & ~(B - 1); x < w; x += mbx) {
+    for (int x = w & ~(B - 1); take && x < w; x += mbx) {
       dist += xo_ssd_ss(mbx, mby, p1 + x, st1, p2 + x, st2) >> sh;
       samples += (uint64_t)mbx * mby;
     }

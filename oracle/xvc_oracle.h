@@ -52,6 +52,11 @@ uint64_t xo_picture_ssd(int bitdepth, int w, int h,
                         const uint16_t *p1, ptrdiff_t st1,
                         const uint16_t *p2, ptrdiff_t st2,
                         uint64_t *psnr_dist, uint64_t *psnr_samples);
+/* ... restricted to the blocks whose first row is in [y_begin, y_end). */
+uint64_t xo_picture_ssd_rows(int bitdepth, int w, int h, int y_begin, int y_end,
+                             const uint16_t *p1, ptrdiff_t st1, const uint16_t *p2,
+                             ptrdiff_t st2, uint64_t *psnr_dist,
+                             uint64_t *psnr_samples);
 
 /* ---- I1/I2 interpolation (xvc_common_lib/inter_prediction.cc) ---- */
 /* MotionCompUniPred -> Sample (inter_prediction.cc:1138-1154). `ref` points

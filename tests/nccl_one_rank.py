@@ -1,0 +1,56 @@
+"""Helper for test_gpu_parity.test_sharded_rccl_single_rank: the product
+multi-GPU path (GpuEngine + TorchComm over the RCCL backend) as a one-rank
+job on the one GPU a test box has.  Prints OK when the sharded frame pass and
+its all-reduced PSNR parts equal the oracle's."""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    import torch
+    import torch.distributed as dist
+    import oracle_frame
+    import oracle_lib as ol
+    from xvc_amd import api, pipeline, sharded, synth
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", sys.argv[1])
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    w, h, bd, qp, bl = 208, 112, 10, 32, api.BORDER_LUMA
+
+    def padded(planes):
+        return [np.ascontiguousarray(np.pad(p, bl >> (c > 0), mode="edge"))
+                for c, p in enumerate(planes)]
+
+    ctx = api.Context(0)
+    clip = synth.SyntheticClip(w, h, bd)
+    s = sharded.make_gpu_sharded(ctx, w, h, bd, qp, 0, 1, dev, dist)
+    s.e.pictures[0].upload(padded(clip.frame(0)), bl)
+    O = ctx.picture(w, h, bd)
+    xo = ol.Lib("xo")
+    desc = pipeline.FrameDescriptors(w, h, qp)
+    ref = padded(clip.frame(0))
+    for n in (1, 2):
+        orig = padded(clip.frame(n))
+        O.upload(orig, bl)
+        s.run(O, (n - 1) % 2, n % 2, n - 1)
+        got_ssd = s.total_ssd()
+        dist.barrier()
+        torch.cuda.synchronize()
+        rec, _, _, _, ssd = oracle_frame.frame_pass(desc, bd, orig, ref, bl, n - 1, lib=xo)
+        got = s.e.pictures[n % 2].download(bl)
+        assert all(np.array_equal(got[c], rec[c]) for c in range(3)), n
+        assert got_ssd == ssd, (got_ssd, ssd)
+        ref = rec
+    dist.destroy_process_group()
+    print("OK")
+
+
+if __name__ == "__main__":
+    main()

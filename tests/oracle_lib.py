@@ -163,6 +163,9 @@ class Lib:
             [C.c_int, C.c_double, C.c_int, C.c_int, i16p, pd, i16p, pd])
         sig("picture_ssd", C.c_uint64,
             [C.c_int, C.c_int, C.c_int, u16p, pd, u16p, pd, u64p, u64p])
+        if prefix == "xo":  # sharding helper; the reference only walks whole pictures
+            sig("picture_ssd_rows", C.c_uint64,
+                [C.c_int] * 5 + [u16p, pd, u16p, pd, u64p, u64p])
         fa = [C.c_int] * 6
         sig("mc_uni", None, fa + [u16p, pd, u16p, pd])
         sig("mc_uni_bipred", None, fa + [u16p, pd, i16p, pd])
@@ -240,12 +243,16 @@ class Lib:
         return self._ssd_rr(bd, 1.0, w, h, ptr(a, i16p), self._s(a),
                             ptr(b, i16p), self._s(b))
 
-    def picture_ssd(self, bd, a, b):
+    def picture_ssd(self, bd, a, b, y_begin=0, y_end=1 << 30):
         h, w = a.shape
         d = C.c_uint64(0)
         n = C.c_uint64(0)
-        r = self._picture_ssd(bd, w, h, ptr(a, u16p), self._s(a), ptr(b, u16p),
-                              self._s(b), C.byref(d), C.byref(n))
+        if y_begin <= 0 and y_end >= h:
+            r = self._picture_ssd(bd, w, h, ptr(a, u16p), self._s(a), ptr(b, u16p),
+                                  self._s(b), C.byref(d), C.byref(n))
+        else:
+            r = self._picture_ssd_rows(bd, w, h, y_begin, y_end, ptr(a, u16p), self._s(a),
+                                       ptr(b, u16p), self._s(b), C.byref(d), C.byref(n))
         return r, n.value
 
     def mc_uni(self, bd, is_chroma, w, h, fx, fy, plane, px, py, bipred=False):

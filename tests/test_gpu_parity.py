@@ -3,6 +3,7 @@ against the CPU oracle on the same seeded inputs.  Bit-exact: all of this path
 is integer / byte work (the few double steps are op-for-op identical).
 """
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -1062,7 +1063,8 @@ def test_frame_pass_8k_10bit_qp37(gpu, xo):
         p.destroy()
 
 
-# (208x112, 2/3 shards) small; (3840x2160 QP32, 8 shards) = BASELINE config 4
+# (208x112, 2/3 shards) small; (3840x2160 QP32, 8 shards) = BASELINE config 4:
+# there a shard keeps only the rows its next search can reach (no all-gather)
 @pytest.mark.parametrize("world", [2, 3, 8])
 def test_sharded_gpu_engine_loopback(gpu, xo, world):
     """The multi-GPU orchestration with the real HIP engine: `world` shards of
@@ -1071,7 +1073,7 @@ def test_sharded_gpu_engine_loopback(gpu, xo, world):
     unsharded oracle frame pass bit for bit."""
     import torch
     import oracle_frame
-    from test_sharded import LoopbackComm
+    from test_sharded import LoopbackComm, assert_valid_rows_equal
     from xvc_amd import pipeline, sharded, synth
     api, ctx = gpu
     pw, ph, bd, qp = (3840, 2160, 10, 32) if world == 8 else (208, 112, 10, 32)
@@ -1086,7 +1088,11 @@ def test_sharded_gpu_engine_loopback(gpu, xo, world):
         ranks.append(sharded.ShardedFramePass(e, LoopbackComm(), r, world))
     O = ctx.picture(pw, ph, bd)
     ref_host = pad_planes(clip.frame(0), bd)
-    for n in ((1,) if world == 8 else (1, 2)):
+    if world == 8:
+        assert ranks[0].valid_rows() != (0, ph)
+        sends, recvs = ranks[0].gather_ops(0)
+        assert {p for p, _ in sends} | {p for p, _ in recvs} == {1}
+    for n in (1, 2):
         orig_host = pad_planes(clip.frame(n), bd)
         O.upload(orig_host, BL)
         ref_idx, rec_idx = (n - 1) % 2, n % 2
@@ -1102,12 +1108,30 @@ def test_sharded_gpu_engine_loopback(gpu, xo, world):
         ctx.sync()
         e_rec, _, _, _, e_ssd = oracle_frame.frame_pass(desc, bd, orig_host, ref_host, BL,
                                                         n - 1, lib=xo)
+        total = [0, 0]
         for s in ranks:
             got = s.e.pictures[rec_idx].download(BL)
-            for c in range(3):
-                assert np.array_equal(got[c], e_rec[c]), (world, n, s.rank, c)
-            ssd = s.e.fp.d_ssd.to_array(np.uint64, 2)
-            assert (int(ssd[0]), int(ssd[1])) == e_ssd
+            assert_valid_rows_equal(s, got, e_rec, ph, (world, n))
+            part = s.e.ssd_tensor().cpu()
+            total[0] += int(part[0])
+            total[1] += int(part[1])
+        assert tuple(total) == e_ssd
         ref_host = e_rec
     ctx.use_own_stream()
     O.destroy()
+
+
+def test_sharded_rccl_single_rank(gpu):
+    """GpuEngine + TorchComm on the RCCL backend (process group init, barrier,
+    int64 all-reduce of the PSNR parts) as a one-rank job in its own process."""
+    import socket
+    import subprocess
+    import sys
+    so = socket.socket()
+    so.bind(("127.0.0.1", 0))
+    port = so.getsockname()[1]
+    so.close()
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, os.path.join(here, "nccl_one_rank.py"), str(port)],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "OK" in r.stdout.split(), r.stdout + r.stderr

@@ -27,17 +27,19 @@ class OracleEngine:
     """Same interface as sharded.GpuEngine, computed by the CPU oracle on numpy
     planes (shared with torch CPU tensors for the exchange)."""
 
-    def __init__(self, lib, width, height, bd, qp, row_range, cu=16):
+    def __init__(self, lib, width, height, bd, qp, row_range, cu=16, search_range=96):
         import torch
         self.torch = torch
         self.lib, self.w, self.h, self.bd, self.cu = lib, width, height, bd, cu
-        self.desc = pipeline.FrameDescriptors(width, height, qp, cu, row_range=row_range)
+        self.desc = pipeline.FrameDescriptors(width, height, qp, cu, search_range,
+                                              row_range=row_range)
         self.cus_per_row = self.desc.cus_per_row
         self.pics = [[np.zeros(((height >> (c > 0)) + 2 * (BL >> (c > 0)),
                                 (width >> (c > 0)) + 2 * (BL >> (c > 0))), np.uint16)
                       for c in range(3)] for _ in range(2)]
         self.cus = np.zeros(self.desc.n_cus_total, ol.CU_DTYPE)
         self.ssd_out = None
+        self.ssd_t = torch.zeros(2, dtype=torch.int64)
         self._parts = pipeline.cu_partition(width, height, cu)
 
     def min_cu_height_at(self, y):
@@ -84,10 +86,17 @@ class OracleEngine:
     def pad(self, rec_idx):
         self.lib.pad_border(self.w, self.h, self.pics[rec_idx], [BL, BC, BC])
 
-    def ssd(self, orig, rec_idx):
+    def search_reach(self):
+        return sharded.search_reach(self.desc)
+
+    def ssd(self, orig, rec_idx, ya=0, yb=1 << 30):
         o = np.ascontiguousarray(orig[0][BL:BL + self.h, BL:BL + self.w])
         r = np.ascontiguousarray(self.pics[rec_idx][0][BL:BL + self.h, BL:BL + self.w])
-        self.ssd_out = self.lib.picture_ssd(self.bd, o, r)
+        self.ssd_out = self.lib.picture_ssd(self.bd, o, r, ya, yb)
+        self.ssd_t[0], self.ssd_t[1] = self.ssd_out
+
+    def ssd_tensor(self):
+        return self.ssd_t
 
     def row_slab(self, rec_idx, comp, ya, yb):
         b = BL if comp == 0 else BC
@@ -121,10 +130,10 @@ class LoopbackComm:
         assert all(len(q) == 0 for q in queues.values())
 
 
-def reference_frames(lib, n_frames):
+def reference_frames(lib, n_frames, w=PW, h=PH, search_range=96):
     """Unsharded oracle chain: returns list of (rec planes, ssd)."""
-    clip = synth.SyntheticClip(PW, PH, BD)
-    desc = pipeline.FrameDescriptors(PW, PH, QP)
+    clip = synth.SyntheticClip(w, h, BD)
+    desc = pipeline.FrameDescriptors(w, h, QP, search_range=search_range)
     ref = pad_planes(clip.frame(0))
     out = []
     for n in range(1, n_frames + 1):
@@ -133,6 +142,18 @@ def reference_frames(lib, n_frames):
         out.append((rec, ssd))
         ref = rec
     return out
+
+
+def assert_valid_rows_equal(s, planes, expect, h, tag):
+    """A shard holds the reconstruction only as far as its next search can
+    reach (ShardedFramePass.valid_rows); those rows - and the top / bottom
+    border when they are picture edges - must match the unsharded result."""
+    ya, yb = s.valid_rows()
+    for c in range(3):
+        b, sh = (BL, 0) if c == 0 else (BC, 1)
+        lo = 0 if ya == 0 else b + (ya >> sh)
+        hi = planes[c].shape[0] if yb == h else b + (yb >> sh)
+        assert np.array_equal(planes[c][lo:hi], expect[c][lo:hi]), (tag, s.rank, c)
 
 
 def test_shard_rows():
@@ -146,19 +167,28 @@ def test_shard_rows():
         assert all(a[0] % 16 == 0 for a in r)
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_sharded_loopback_matches_unsharded(world):
+@pytest.mark.parametrize("w,h,search_range,world", [
+    (PW, PH, 96, 2), (PW, PH, 96, 3),
+    # tall picture, short search: only neighbouring shards exchange rows
+    (208, 320, 8, 4)])
+def test_sharded_loopback_matches_unsharded(w, h, search_range, world):
     lib = ol.Lib("xo")
-    expect = reference_frames(lib, 2)
-    clip = synth.SyntheticClip(PW, PH, BD)
-    rows = sharded.shard_rows(PH, world)
+    expect = reference_frames(lib, 3, w, h, search_range)
+    clip = synth.SyntheticClip(w, h, BD)
+    rows = sharded.shard_rows(h, world)
     ranks = []
     for r in range(world):
-        e = OracleEngine(lib, PW, PH, BD, QP, rows[r])
+        e = OracleEngine(lib, w, h, BD, QP, rows[r], search_range=search_range)
         for c, p in enumerate(pad_planes(clip.frame(0))):
             e.pics[0][c][:] = p
         ranks.append(sharded.ShardedFramePass(e, LoopbackComm(), r, world))
-    for n in (1, 2):
+    if h == 320:
+        # the point of the case: no traffic between non-adjacent shards
+        for s in ranks:
+            sends, recvs = s.gather_ops(0)
+            assert {p for p, _ in sends} | {p for p, _ in recvs} <= {s.rank - 1, s.rank + 1}
+            assert s.valid_rows() != (0, h)
+    for n in (1, 2, 3):
         orig = pad_planes(clip.frame(n))
         ref_idx, rec_idx = (n - 1) % 2, n % 2
         for s in ranks:
@@ -171,9 +201,9 @@ def test_sharded_loopback_matches_unsharded(world):
             s.phase_c(orig, rec_idx)
         exp_rec, exp_ssd = expect[n - 1]
         for s in ranks:
-            for c in range(3):
-                assert np.array_equal(s.e.pics[rec_idx][c], exp_rec[c]), (world, n, s.rank, c)
-            assert s.e.ssd_out == exp_ssd
+            assert_valid_rows_equal(s, s.e.pics[rec_idx], exp_rec, h, (world, n))
+        # the per-shard PSNR parts add up to the picture's
+        assert tuple(sum(s.e.ssd_out[k] for s in ranks) for k in (0, 1)) == exp_ssd
 
 
 def _free_port():
@@ -200,7 +230,7 @@ def _gloo_worker(rank, world, port, q):
     for n in (1, 2):
         orig = pad_planes(clip.frame(n))
         s.run(orig, (n - 1) % 2, n % 2, n - 1)
-        out.append(([p.copy() for p in e.pics[n % 2]], e.ssd_out))
+        out.append(([p.copy() for p in e.pics[n % 2]], s.total_ssd(), s.valid_rows()))
     q.put((rank, out))
     dist.barrier()
     dist.destroy_process_group()
@@ -222,10 +252,11 @@ def test_sharded_gloo_two_ranks():
         assert p.exitcode == 0
     for rank in range(2):
         for n in range(2):
-            rec, ssd = got[rank][n]
+            rec, ssd, valid = got[rank][n]
+            assert valid == (0, PH)   # search range 96 spans this small picture
             for c in range(3):
                 assert np.array_equal(rec[c], expect[n][0][c]), (rank, n, c)
-            assert ssd == expect[n][1]
+            assert ssd == expect[n][1]   # all-reduced over the two ranks
 
 
 def test_synthetic_clip_c_mirror_matches_python():

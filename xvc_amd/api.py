@@ -77,7 +77,7 @@ SYMBOLS = [
     "xvcgpu_mc_bipred_batch", "xvcgpu_bipred_search", "xvcgpu_mc_affine_batch",
     "xvcgpu_cu_info_from_me", "xvcgpu_recon_from_me", "xvcgpu_residual_batch",
     "xvcgpu_fwd_transform_batch", "xvcgpu_inv_transform_batch",
-    "xvcgpu_deblock", "xvcgpu_deblock_rows", "xvcgpu_picture_ssd", "xvcgpu_get_transform_matrix",
+    "xvcgpu_deblock", "xvcgpu_deblock_rows", "xvcgpu_picture_ssd", "xvcgpu_picture_ssd_rows", "xvcgpu_get_transform_matrix",
 ]
 
 _vp = C.c_void_p
@@ -167,6 +167,7 @@ def load_library():
         "xvcgpu_deblock_rows": [_vp, _vp, _vp, C.c_int, _vp, C.c_int, C.c_int, C.c_int,
                                 C.c_int, C.c_int, C.c_int, C.c_int, C.c_int],
         "xvcgpu_picture_ssd": [_vp, _vp, _vp, C.c_int, C.c_int, _vp],
+        "xvcgpu_picture_ssd_rows": [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp],
         "xvcgpu_get_transform_matrix": [C.c_int, C.c_int, _vp],
     }
     for name, args in sigs.items():
@@ -418,9 +419,9 @@ class Context:
                                                  d_map, map_stride, bipred, beta, tc,
                                                  sub, pass_, y0, y1))
 
-    def picture_ssd_dev(self, a, b, comp, shift_bd, d_out):
-        self._check(self.lib.xvcgpu_picture_ssd(self.h, a.h_pic, b.h_pic, comp,
-                                                shift_bd, d_out))
+    def picture_ssd_dev(self, a, b, comp, shift_bd, d_out, y_begin=0, y_end=1 << 30):
+        self._check(self.lib.xvcgpu_picture_ssd_rows(self.h, a.h_pic, b.h_pic, comp,
+                                                     shift_bd, y_begin, y_end, d_out))
 
     # ---- numpy conveniences (tests) ----
     def metric_batch(self, a, b, comp, cands, weight=1.0, strength=16):

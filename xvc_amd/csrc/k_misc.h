@@ -104,7 +104,8 @@ __global__ void cu_info_from_me_kernel(const xvcgpu_me_block *blocks,
 // block's sum): thread = 8 samples (one 16-byte load from each picture),
 // 256 / (bw / 8) rows per sweep.  grid: items; block 256.
 __global__ void __launch_bounds__(256)
-picture_ssd_kernel(PlaneView a, PlaneView b, int shift, unsigned long long *part_out) {
+picture_ssd_kernel(PlaneView a, PlaneView b, int shift, int y_begin, int y_end,
+                   unsigned long long *part_out) {
   __shared__ unsigned long long part[4];
   const int w = a.w, h = a.h;
   const int mbx = w & ~(w - 1), mby = h & ~(h - 1);
@@ -117,6 +118,10 @@ picture_ssd_kernel(PlaneView a, PlaneView b, int shift, unsigned long long *part
   int x, y, bw, bh;
   if (ix < nfx) { x = ix * 64; bw = 64; } else { x = (w & ~63) + (ix - nfx) * mbx; bw = mbx; }
   if (iy < nfy) { y = iy * 64; bh = 64; } else { y = (h & ~63) + (iy - nfy) * mby; bh = mby; }
+  if (y < y_begin || y >= y_end) {  // another shard's block (uniform per workgroup)
+    if (threadIdx.x == 0) part_out[2 * item] = part_out[2 * item + 1] = 0;
+    return;
+  }
   const uint16_t *pa = a.p + (ptrdiff_t)y * a.stride + x;
   const uint16_t *pb = b.p + (ptrdiff_t)y * b.stride + x;
   uint32_t acc = 0;  // <= 16 squares of 12-bit differences per thread

@@ -848,6 +848,13 @@ static xvcgpu_status ensure_ssd_part(xvcgpu_ctx *ctx, int items) {
 xvcgpu_status xvcgpu_picture_ssd(xvcgpu_ctx *ctx, const xvcgpu_picture *a,
                                  const xvcgpu_picture *b, int comp,
                                  int shift_bitdepth, uint64_t *d_out) {
+  return xvcgpu_picture_ssd_rows(ctx, a, b, comp, shift_bitdepth, 0, 1 << 30, d_out);
+}
+
+xvcgpu_status xvcgpu_picture_ssd_rows(xvcgpu_ctx *ctx, const xvcgpu_picture *a,
+                                      const xvcgpu_picture *b, int comp,
+                                      int shift_bitdepth, int y_begin, int y_end,
+                                      uint64_t *d_out) {
   if (!ctx || !a || !b || comp < 0 || comp > 2 || !d_out || shift_bitdepth < 8)
     return XVCGPU_INVALID_ARGUMENT;
   if (a->w != b->w || a->h != b->h)
@@ -860,7 +867,7 @@ xvcgpu_status xvcgpu_picture_ssd(xvcgpu_ctx *ctx, const xvcgpu_picture *a,
   }
   if (items > 0)
     hipLaunchKernelGGL(picture_ssd_kernel, dim3(items), dim3(256), 0, ctx->stream, pa,
-                       pb, 2 * (shift_bitdepth - 8), ctx->d_ssd_part);
+                       pb, 2 * (shift_bitdepth - 8), y_begin, y_end, ctx->d_ssd_part);
   hipLaunchKernelGGL(picture_ssd_sum_kernel, dim3(1), dim3(256), 0, ctx->stream,
                      ctx->d_ssd_part, items,
                      reinterpret_cast<unsigned long long *>(d_out));

@@ -15,9 +15,14 @@ CU rows (16 luma lines; CTU rows when they divide evenly).  Per picture:
              neighbours (SURVEY.md section 8e scheme B: no return traffic).
              Exact whenever no 4-tall CU touches a shard boundary (no deblock
              chain crosses it) - checked when the plan is built.
-  X2 gather  every rank sends its finished rows to every other rank so all of
-             them hold the complete reconstruction = next reference picture
-  C  local   border extension, PSNR parts
+  X2 gather  every rank sends finished rows to the ranks whose next search can
+             reach them: a shard's motion search reads the reference only
+             within `reach` luma rows of its own rows (search range + MV clip
+             margin + filter taps), so on a tall picture only neighbouring
+             shards exchange rows - not an all-gather
+  C  local   border extension; the PSNR walk over the 64-row blocks that
+             START in the own rows (their sum over the ranks is the picture's;
+             one all-reduce when the number is wanted, not per picture)
 
 The orchestration is engine-agnostic: `GpuEngine` (HIP kernels through the
 C-ABI, torch tensors as picture memory so RCCL can address row slabs) is the
@@ -26,6 +31,17 @@ product; tests drive the same plan with a CPU engine over gloo.
 import numpy as np
 
 from . import api, pipeline
+
+
+def search_reach(desc):
+    """Largest vertical distance (luma rows) from a CU of `desc` to a reference
+    row its motion search can touch before clipping/filter margins: the search
+    window around the farthest start candidate (quarter-pel predictors)."""
+    me = desc.me
+    if len(me) == 0:
+        return 0
+    start = max(int(np.abs(me["mvp_y"]).max()), int(np.abs(me["prev_y"]).max()))
+    return int(me["search_range"].max()) + (start + 3) // 4
 
 
 def shard_rows(height, world, cu=16):
@@ -60,14 +76,26 @@ class TorchComm:
         for req in d.batch_isend_irecv(ops):
             req.wait()
 
+    def allreduce_sum(self, t):
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+        return t
+
 
 class ShardedFramePass:
     HALO = 4  # luma rows on each side of a shard boundary
 
-    def __init__(self, engine, comm, rank, world):
+    def __init__(self, engine, comm, rank, world, reach=None):
         self.e, self.comm, self.rank, self.world = engine, comm, rank, world
         self.rows = shard_rows(engine.h, world, engine.cu)
         self.y0, self.y1 = self.rows[rank]
+        # rows of the reference a shard may read beyond its own: the search
+        # window (+ predictor offset), the 8-sample MV clip margin, 4 filter
+        # taps, one CU of slack; below also the 64-row PSNR blocks that start
+        # in the own rows.  Must be the same number on every rank.
+        if reach is None:
+            reach = engine.search_reach() + 8 + 4 + 16
+        self.reach_up = (reach + 15) // 16 * 16
+        self.reach_down = max(self.reach_up, 64)
         self.up = rank - 1 if rank > 0 else None
         self.down = rank + 1 if rank < world - 1 else None
         # exactness precondition of the redundant-halo scheme
@@ -111,20 +139,38 @@ class ShardedFramePass:
         y_end = self.y1 + self.HALO if self.down is not None else self.y1
         self.e.deblock_rows(rec_idx, 1, self.y0, y_end)
 
+    def needed_from(self, who, peer):
+        """Rows of `peer`'s shard that rank `who` must hold: [ya, yb) or None."""
+        y0, y1 = self.rows[who]
+        pa, pb = self.rows[peer]
+        ya, yb = max(pa, y0 - self.reach_up), min(pb, y1 + self.reach_down)
+        return (ya, yb) if ya < yb else None
+
+    def valid_rows(self):
+        """Rows of the local reconstruction that are up to date after run()."""
+        return (max(0, self.y0 - self.reach_up), min(self.e.h, self.y1 + self.reach_down))
+
     def gather_ops(self, rec_idx):
         sends, recvs = [], []
-        mine = self._plane_rows(rec_idx, self.y0, self.y1)
         for peer in range(self.world):
             if peer == self.rank:
                 continue
-            sends += [(peer, t) for t in mine]
-            ya, yb = self.rows[peer]
-            recvs += [(peer, t) for t in self._plane_rows(rec_idx, ya, yb)]
+            out = self.needed_from(peer, self.rank)   # my rows the peer needs
+            if out:
+                sends += [(peer, t) for t in self._plane_rows(rec_idx, *out)]
+            inc = self.needed_from(self.rank, peer)   # the peer's rows I need
+            if inc:
+                recvs += [(peer, t) for t in self._plane_rows(rec_idx, *inc)]
         return sends, recvs
 
     def phase_c(self, orig, rec_idx):
         self.e.pad(rec_idx)
-        self.e.ssd(orig, rec_idx)
+        self.e.ssd(orig, rec_idx, self.y0, self.y1)
+
+    def total_ssd(self):
+        """(ssd, samples) of the last picture over all shards (a collective)."""
+        t = self.comm.allreduce_sum(self.e.ssd_tensor())
+        return int(t[0]), int(t[1])
 
     def run(self, orig, ref_idx, rec_idx, ref_poc=0):
         self.phase_a(orig, ref_idx, rec_idx, ref_poc)
@@ -168,6 +214,8 @@ class GpuEngine:
         self.fp.d_cus.free()
         self.fp.d_cus = _ExternalBuffer(ctx, self.cu_mem.data_ptr())
         self._parts = pipeline.cu_partition(width, height, cu)
+        # PSNR parts of the own blocks, in a tensor so they can be all-reduced
+        self.ssd_mem = torch.zeros(2, dtype=torch.int64, device=device)
 
     def min_cu_height_at(self, y):
         if y <= 0 or y >= self.h:
@@ -184,9 +232,15 @@ class GpuEngine:
     def pad(self, rec_idx):
         self.ctx.pad_border(self.pictures[rec_idx])
 
-    def ssd(self, orig, rec_idx):
+    def search_reach(self):
+        return search_reach(self.fp.desc)
+
+    def ssd(self, orig, rec_idx, ya=0, yb=1 << 30):
         self.ctx.picture_ssd_dev(orig, self.pictures[rec_idx], 0, self.bd,
-                                 self.fp.d_ssd.ptr)
+                                 self.ssd_mem.data_ptr(), ya, yb)
+
+    def ssd_tensor(self):
+        return self.ssd_mem
 
     def row_slab(self, rec_idx, comp, ya, yb):
         off, stride, border = self.geom[rec_idx][comp]
