@@ -86,40 +86,60 @@ def usable_cpus():
 
 
 def cpu_baseline(args, clip, bd, border):
-    """Oracle (kind "port") on the host: whole frame passes of the same
-    workload, chained like the GPU steps (each reconstruction is the next
-    reference).  Timed twice: single thread, and with the per-CU loops spread
-    over the hardware threads this process may use (OpenMP; identical results) - the reported value
-    is the all-threads one, `cores` = threads used; ~10 s of CPU work in all."""
+    """The same frame passes on the host, chained like the GPU steps (each
+    reconstruction is the next reference).  Kind "reference" when the
+    reference build travels with the repo (oracle/_ref/libxvcref.so, compiled
+    by oracle/Makefile from the reference's own sources): its classes - TZ
+    search, sub-pel search, interpolation, transforms, QuantFast, deblocking,
+    PadBorder, ComparePicture, with its SSE2/AVX2 kernels - run the composition
+    (ref_harness.cc xr_frame_pass; tests pin it equal to the oracle's).
+    Otherwise kind "port": the plain-C oracle.  The per-CU loops are spread
+    over the CPUs this process may use (OpenMP, identical results); the
+    reported value is the all-threads one, `cores` = threads used.  About 15 s
+    of CPU work in all."""
     import oracle_frame
     import oracle_lib as ol
     from xvc_amd import pipeline
-    lib = ol.Lib("xo")
     desc = pipeline.FrameDescriptors(args.width, args.height, args.qp)
     frames = [pad_planes(clip.frame(i), border) for i in range(args.frames + 1)]
     F = len(frames) - 1
 
-    def run(n_max, seconds, threads):
+    def run(lib, reference, n_max, seconds, threads):
         ref, n = frames[0], 0
         t0 = time.perf_counter()
         while n < n_max and (n == 0 or time.perf_counter() - t0 < seconds):
             k = n % (2 * F - 2) if F > 1 else 0
             orig = frames[1 + (k if k < F else 2 * F - 2 - k)]
             ref = oracle_frame.frame_pass(desc, bd, orig, ref, border, lib=lib,
-                                          threads=threads)[0]
+                                          threads=threads, reference=reference)[0]
             n += 1
         return n, time.perf_counter() - t0
 
-    n1, dt1 = run(max(1, int(args.cpu_frames)), 4.0, 1)
     cores = usable_cpus()
-    nc, dtc = run(2000, 7.0, cores)
+    xo = ol.Lib("xo")
+    np1, dtp1 = run(xo, False, max(1, int(args.cpu_frames)), 4.0, 1)
+    if not ol.have_ref():
+        nc, dtc = run(xo, False, 2000, 7.0, cores)
+        return {
+            "value": nc / dtc, "unit": "frames/s", "cores": cores, "kind": "port",
+            "single_thread_value": np1 / dtp1,
+            "sample": "%dx%d workload, chained frame passes, C oracle (gcc -O2): %d passes "
+                      "in %.1f s on %d threads (OpenMP over the CUs; deblock/pad/SSD "
+                      "serial); %d passes in %.1f s on 1 thread" %
+                      (args.width, args.height, nc, dtc, cores, np1, dtp1),
+        }
+    xr = ol.Lib("xr")
+    n1, dt1 = run(xr, True, 2000, 4.0, 1)
+    nc, dtc = run(xr, True, 2000, 7.0, cores)
     return {
-        "value": nc / dtc, "unit": "frames/s", "cores": cores, "kind": "port",
-        "single_thread_value": n1 / dt1,
-        "sample": "%dx%d workload, chained frame passes, C oracle (gcc -O2): %d passes "
-                  "in %.1f s on %d threads (OpenMP over the CUs; deblock/pad/SSD serial); "
-                  "%d passes in %.1f s on 1 thread" %
-                  (args.width, args.height, nc, dtc, cores, n1, dt1),
+        "value": nc / dtc, "unit": "frames/s", "cores": cores, "kind": "reference",
+        "single_thread_value": n1 / dt1, "port_single_thread_value": np1 / dtp1,
+        "sample": "%dx%d workload, chained frame passes run by the reference's own classes "
+                  "with its SIMD kernels (g++ -O2, oracle/_ref): %d passes in %.1f s on %d "
+                  "threads (OpenMP over the CUs; deblock/pad/PSNR serial as in the "
+                  "reference), %d passes in %.1f s on 1 thread; plain-C oracle: %d passes "
+                  "in %.1f s on 1 thread" %
+                  (args.width, args.height, nc, dtc, cores, n1, dt1, np1, dtp1),
     }
 
 

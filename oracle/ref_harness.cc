@@ -60,6 +60,7 @@
 #undef protected
 
 #include "../include/xvcgpu_types.h"
+#include "xvc_oracle.h" /* xo_frame_args: the frame pass argument block */
 
 using namespace xvc;  // NOLINT
 
@@ -735,4 +736,225 @@ void xr_bipred_search(int bd, const xvcgpu_bi_block *j, int pic_w, int pic_h,
   out->subpel_dist = static_cast<uint32_t>(dist);
 }
 
+
+/* ---- the hot-path frame pass, executed by the reference's own classes ----
+ * Same composition and argument block as xo_frame_pass (xvc_oracle_frame.c):
+ * per CU TzSearch::Search + InterSearch::SubpelSearch +
+ * InterPrediction::MotionCompensationMv for Y,U,V; per transform block
+ * ResidualBuffer::Subtract -> ForwardTransform -> RdoQuant::QuantFast ->
+ * Quantize::Inverse -> InverseTransform -> SampleBuffer::AddClip; then
+ * DeblockingFilter::DeblockPicture, YuvPicture::PadBorder and
+ * SampleMetric::ComparePicture.  Used to pin the oracle's whole composition
+ * (tests/test_oracle_vs_ref.py) and as bench.py's cpu_baseline of kind
+ * "reference".  me_results[].fullpel_cost stays 0 (not observable through the
+ * reference API). */
+static void ExtendBorder(uint16_t *p, ptrdiff_t st, int w, int h, int have,
+                         int want) {
+  /* the reference pads 80 / 40 samples; the argument block's planes carry
+   * `want` >= that: continue the replication outwards */
+  if (want <= have) return;
+  for (int y = -have; y < h + have; y++) {
+    uint16_t *row = p + y * st;
+    for (int k = have + 1; k <= want; k++) {
+      row[-k] = row[-have];
+      row[w - 1 + k] = row[w - 1 + have];
+    }
+  }
+  const size_t bytes = sizeof(uint16_t) * (w + 2 * want);
+  for (int k = have + 1; k <= want; k++) {
+    std::memcpy(p - k * st - want, p - have * st - want, bytes);
+    std::memcpy(p + (h - 1 + k) * st - want, p + (h - 1 + have) * st - want,
+                bytes);
+  }
+}
+
+void xr_frame_pass(xo_frame_args *a) {
+  const int bd = a->bd, W = a->pic_w, H = a->pic_h;
+  const int nthreads = a->threads > 1 ? a->threads : 1;
+  (void)nthreads;
+  YuvPicture orig_pic(ChromaFormat::k420, W, H, bd, true, 0, 0);
+  YuvPicture ref_pic(ChromaFormat::k420, W, H, bd, true, 0, 0);
+  YuvPicture rec_pic(ChromaFormat::k420, W, H, bd, true, 0, 0);
+  for (int c = 0; c < 3; c++) {
+    const int cs = c ? 1 : 0;
+    for (int y = 0; y < (H >> cs); y++)
+      std::memcpy(orig_pic.GetSamplePtr(YuvComponent(c), 0, y),
+                  a->orig[c] + y * a->orig_stride[c], sizeof(Sample) * (W >> cs));
+  }
+  FillPic(&ref_pic, a->ref, a->ref_stride);
+  EncoderSettings settings;
+  settings.Initialize(SpeedMode::kSlow);
+  const EncoderSimdFunctions &simd = Simd(bd); /* cached before the threads start */
+
+  /* motion search + motion compensation: CUs are independent */
+#pragma omp parallel num_threads(nthreads)
+  {
+    PictureData pd(ChromaFormat::k420, W, H, bd);
+    pd.SetSubGopLength(16);
+    pd.SetPoc(8);
+    ReferencePictureLists rpl;
+    InterPrediction ip(simd.inter_prediction, rec_pic, bd);
+    InterSearch is(simd, pd, orig_pic, rec_pic, rpl, settings);
+    SampleBufferStorage pred_tmp(64, 64);
+#pragma omp for schedule(dynamic, 16)
+    for (int i = 0; i < a->n_cus; i++) {
+      const xvcgpu_me_block *b = &a->me_blocks[i];
+      xvcgpu_me_result *r = &a->me_results[i];
+      CodingUnit *cu = pd.CreateCu(CuTree::Primary, b->depth_nonzero ? 1 : 0,
+                                   b->x, b->y, b->w, b->h);
+      cu->SetFullpelMv(b->fullpel_mv != 0);
+      const double ls = (b->lambda16 + 0.5) / 65536.0;
+      Qp qp = MakeQp(32, bd, ls * ls);
+      const MotionVector mvp(b->mvp_x, b->mvp_y);
+      MvFullpel mn, mx;
+      ip.DetermineMinMaxMv(*cu, ref_pic, mvp, b->search_range, &mn, &mx);
+      SampleMetric sad(simd.sample_metric, bd,
+                       b->h > 8 ? MetricType::kSadFast : MetricType::kSad);
+      TzSearch tz(orig_pic, ip, settings, b->search_range);
+      const MvFullpel fp = tz.Search(*cu, qp, sad, mvp, ref_pic, mn, mx,
+                                     MvFullpel(b->prev_x, b->prev_y));
+      MotionVector mv(fp.x * 16, fp.y * 16);
+      Distortion dist = 0;
+      if (!b->fullpel_mv) {
+        SampleMetric satd(simd.sample_metric, bd, MetricType::kSatd);
+        SampleBufferConst orig_buffer =
+            orig_pic.GetSampleBuffer(YuvComponent::kY, b->x, b->y);
+        mv = is.SubpelSearch(*cu, qp, satd, ref_pic, mvp, fp, orig_buffer,
+                             &pred_tmp, &dist);
+      }
+      r->fullpel_x = fp.x;
+      r->fullpel_y = fp.y;
+      r->fullpel_cost = 0;
+      r->mv_x = mv.x;
+      r->mv_y = mv.y;
+      r->subpel_dist = static_cast<uint32_t>(dist);
+      for (int c = 0; c < 3; c++) {
+        const int cs = c ? 1 : 0;
+        SampleBuffer pb(a->pred[c] + (b->y >> cs) * a->pred_stride[c] + (b->x >> cs),
+                        a->pred_stride[c]);
+        ip.MotionCompensationMv(*cu, YuvComponent(c), ref_pic, mv, false, &pb);
+      }
+      pd.ReleaseCu(cu);
+    }
+  }
+
+  /* residual pipeline (transform_encoder.cc:203-285 with QuantFast) */
+#pragma omp parallel num_threads(nthreads)
+  {
+    PictureData pd(ChromaFormat::k420, 64, 64, bd);
+    ForwardTransform fwd(bd);
+    InverseTransform inv(bd);
+    Quantize quant;
+    RdoQuant rq(bd, settings);
+    std::vector<int16_t> resi(64 * 64), coeff(64 * 64), level(64 * 64), deq(64 * 64);
+    Restrictions &restr = Restrictions::GetRW(); /* thread-local in the reference */
+    const bool saved = restr.disable_transform_sign_hiding;
+#pragma omp for schedule(dynamic, 48)
+    for (int i = 0; i < a->n_tx; i++) {
+      const xvcgpu_tx_block *t = &a->tx_blocks[i];
+      const int c = t->comp, w = t->w, h = t->h;
+      const int scan = (t->intra_pic >> XVC_TXF_SCAN_SHIFT) & 3;
+      /* every block is run as the luma block of a CU of its own size with the
+       * block's qp - exactly how the block-level functions were pinned */
+      CodingUnit *cu = pd.CreateCu(CuTree::Primary, 0, 0, 0, w, h);
+      if (scan == 0 && !t->dst4x4) {
+        cu->SetPredMode(PredictionMode::kInter);
+      } else {
+        cu->SetPredMode(PredictionMode::kIntra);
+        cu->SetIntraModeLuma(IntraPrediction::Convert(
+            scan == 1 ? IntraAngle::kVertical
+                      : (scan == 2 ? IntraAngle::kHorizontal : IntraAngle::kDc)));
+      }
+      const bool skip = t->tx_hor == XVC_TX_SKIP;
+      if (!skip)
+        cu->SetTransformType(YuvComponent::kY, static_cast<TransformType>(t->tx_ver),
+                             static_cast<TransformType>(t->tx_hor));
+      const ptrdiff_t os = a->orig_stride[c], ps = a->pred_stride[c], rs = a->rec_stride[c];
+      SampleBufferConst ob(a->orig[c] + t->y * os + t->x, os);
+      SampleBufferConst pb(a->pred[c] + t->y * ps + t->x, ps);
+      SampleBuffer recb(a->rec[c] + t->y * rs + t->x, rs);
+      ResidualBuffer rb(resi.data(), 64);
+      CoeffBuffer cb(coeff.data(), 64);
+      rb.Subtract(w, h, ob, pb);
+      if (skip)
+        fwd.TransformSkip(w, h, rb, &cb);
+      else
+        fwd.Transform(*cu, YuvComponent::kY, rb, &cb);
+      Qp qp = MakeQp(t->qp, bd);
+      restr.disable_transform_sign_hiding = (t->intra_pic & XVC_TXF_NO_SIGN_HIDING) != 0;
+      const int nnz = rq.QuantFast(*cu, YuvComponent::kY, qp,
+                                   (t->intra_pic & XVC_TXF_INTRA_PIC)
+                                       ? PicturePredictionType::kIntra
+                                       : PicturePredictionType::kBi,
+                                   coeff.data(), 64, level.data(), w);
+      a->nnz[i] = nnz;
+      if (nnz) {
+        quant.Inverse(YuvComponent::kY, qp, w, h, bd, level.data(), w, deq.data(), 64);
+        CoeffBuffer db(deq.data(), 64);
+        if (skip) {
+          inv.TransformSkip(w, h, db, &rb);
+        } else {
+          cu->SetDcCoeffOnly(YuvComponent::kY, nnz == 1 && level[0] != 0);
+          inv.Transform(*cu, YuvComponent::kY, db, &rb);
+        }
+        recb.AddClip(w, h, pb, rb, 0, static_cast<Sample>((1 << bd) - 1));
+      } else {
+        recb.CopyFrom(w, h, pb);
+      }
+      pd.ReleaseCu(cu);
+    }
+    restr.disable_transform_sign_hiding = saved;
+  }
+
+  /* CU metadata for the in-loop filter (plain bookkeeping, as in xo_frame_pass) */
+  for (int i = 0; i < a->n_cus; i++) {
+    const xvcgpu_me_block *b = &a->me_blocks[i];
+    xvcgpu_cu_info *c = &a->cus[a->cu_base + i];
+    std::memset(c, 0, sizeof(*c));
+    c->x = static_cast<uint16_t>(b->x);
+    c->y = static_cast<uint16_t>(b->y);
+    c->w = b->w;
+    c->h = b->h;
+    c->cbf_luma = a->nnz[a->luma_tx_index ? a->luma_tx_index[i] : i] != 0;
+    c->qp_y = static_cast<int8_t>(a->qp_y);
+    c->qp_c = static_cast<int8_t>(a->qp_c);
+    c->ref_poc[0] = a->ref_poc;
+    c->ref_poc[1] = -1;
+    for (int k = 0; k < 4; k++) {
+      c->mv[0][k][0] = a->me_results[i].mv_x;
+      c->mv[0][k][1] = a->me_results[i].mv_y;
+    }
+  }
+  if (a->encode_only) return;
+
+  /* in-loop filter over the whole picture's CU list, border, PSNR parts */
+  int n_all = 0; /* the CU array covers the picture: count via the map */
+  for (int y = 0; y < (H + 3) / 4; y++)
+    for (int x = 0; x < (W + 3) / 4; x++)
+      n_all = std::max(n_all, a->cu_map[y * a->map_stride + x] + 1);
+  const int32_t l0[1] = {a->ref_poc};
+  xr_deblock_picture(bd, W, H, 0, a->beta_offset, a->tc_offset, a->subblock, a->cus,
+                     n_all, a->rec, a->rec_stride, l0, 1, nullptr, 0);
+  FillPic(&rec_pic, a->rec, a->rec_stride);  /* visible area matters only */
+  rec_pic.PadBorder();
+  ReadPic(rec_pic, a->rec, a->rec_stride, true);
+  for (int c = 0; c < 3; c++) {
+    const int cs = c ? 1 : 0;
+    const int have = static_cast<int>(
+        (rec_pic.GetStride(YuvComponent(c)) - (W >> cs)) >> 1);
+    ExtendBorder(a->rec[c], a->rec_stride[c], W >> cs, H >> cs, have, a->border[c]);
+  }
+  SampleMetric ssd(simd.sample_metric, bd, MetricType::kSsd);
+  Qp pqp = MakeQp(32, bd);
+  a->ssd[0] = ssd.ComparePicture(pqp, YuvComponent::kY, YuvComponent::kY, orig_pic,
+                                 rec_pic);
+  /* samples visited by the block walk: recovered from the reported PSNR */
+  a->ssd[1] = 0;
+  if (a->ssd[0]) {
+    const double psnr =
+        ssd.ComputePsnr(pqp, YuvComponent::kY, YuvComponent::kY, orig_pic, rec_pic);
+    const double mse = 255.0 * 255.0 / std::pow(10.0, psnr / 10.0);
+    a->ssd[1] = static_cast<uint64_t>(std::llround(a->ssd[0] / mse));
+  }
+}
 }  // extern "C"

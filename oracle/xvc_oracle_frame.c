@@ -8,7 +8,8 @@
  *   then: deblocking (D1-D4), border extension (P1), picture SSD (M6).
  *
  * TEST INFRASTRUCTURE ONLY (see xvc_oracle.h): used as the checker of the GPU
- * frame pass and as bench.py's `cpu_baseline` (kind "port").  Each step calls
+ * frame pass and as bench.py's `cpu_baseline` fallback (kind "port"; where the
+ * reference build is present bench.py times xr_frame_pass instead).  Each step calls
  * the pinned block-level oracle functions; nothing new is computed here.
  */
 #include <stdlib.h>
@@ -16,36 +17,6 @@
 
 #include "xvc_oracle.h"
 
-typedef struct xo_frame_args {
-  int bd, pic_w, pic_h;
-  int n_cus;
-  const xvcgpu_me_block *me_blocks; /* one per CU */
-  int n_tx;
-  const xvcgpu_tx_block *tx_blocks; /* luma + chroma blocks of all CUs */
-  const int32_t *luma_tx_index;     /* per CU: index of its luma tx block */
-  const int32_t *cu_map;
-  int map_stride;
-  int qp_y, qp_c, ref_poc;
-  int beta_offset, tc_offset, subblock;
-  int border[3]; /* border available around every plane (>= 80/40) */
-  const uint16_t *orig[3];
-  ptrdiff_t orig_stride[3];
-  const uint16_t *ref[3]; /* padded reference picture */
-  ptrdiff_t ref_stride[3];
-  uint16_t *pred[3]; /* work picture */
-  ptrdiff_t pred_stride[3];
-  uint16_t *rec[3]; /* output: reconstructed, deblocked, padded */
-  ptrdiff_t rec_stride[3];
-  xvcgpu_me_result *me_results; /* out, n_cus */
-  int32_t *nnz;                 /* out, n_tx */
-  xvcgpu_cu_info *cus;          /* in/out: whole picture's CU array; the own
-                                   CUs [cu_base, cu_base + n_cus) are written */
-  int cu_base;
-  int encode_only;              /* stop before deblock / pad / SSD */
-  uint64_t ssd[2];              /* out: luma SSD as ComputePsnr sums it, samples */
-  int threads;                  /* <= 1: serial; else OpenMP threads for the
-                                   per-CU loops (results do not depend on it) */
-} xo_frame_args;
 
 void xo_frame_pass(xo_frame_args *a) {
   const int bd = a->bd;

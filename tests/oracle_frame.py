@@ -32,12 +32,16 @@ class FrameArgs(C.Structure):
 
 
 def frame_pass(desc, bd, orig, ref, border, ref_poc=0, lib=None, encode_only=False,
-               threads=1):
+               threads=1, reference=False):
     """desc: xvc_amd.pipeline.FrameDescriptors; orig/ref: [Y,U,V] padded uint16
     planes with `border` (luma) / border//2 (chroma) samples on each side.
     Returns (rec padded planes, me_results, nnz, cus, (ssd, samples))."""
-    lib = lib or ol.Lib("xo")
-    f = lib.dll.xo_frame_pass
+    if reference:   # the same composition run by the reference's own classes
+        lib = lib or ol.Lib("xr")
+        f = lib.dll.xr_frame_pass
+    else:
+        lib = lib or ol.Lib("xo")
+        f = lib.dll.xo_frame_pass
     f.restype = None
     f.argtypes = [C.POINTER(FrameArgs)]
     a = FrameArgs()

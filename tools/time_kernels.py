@@ -1,16 +1,18 @@
-"""Isolated timings of the frame-pass kernels on the 1080p bench workload."""
+"""Isolated timings of the frame-pass kernels (env W, H, QP; default the 1080p
+bench workload), with the algorithmic GB/s of the HBM-bound ones."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np
 from xvc_amd import api, pipeline, synth
-W, H, bd, border = 1920, 1080, 10, 128
+W, H = int(os.environ.get("W", 1920)), int(os.environ.get("H", 1080))
+QP, bd, border = int(os.environ.get("QP", 32)), 10, 128
 ctx = api.Context(0)
 clip = synth.SyntheticClip(W, H, bd)
 pad = lambda planes: [np.ascontiguousarray(np.pad(p, border if c == 0 else border // 2, mode="edge")) for c, p in enumerate(planes)]
 O, R, Rec = (ctx.picture(W, H, bd) for _ in range(3))
 R.upload(pad(clip.frame(0)), border); O.upload(pad(clip.frame(1)), border)
-fp = pipeline.FramePass(ctx, W, H, bd)
+fp = pipeline.FramePass(ctx, W, H, bd, qp=QP)
 d = fp.desc
 fp.run(O, R, Rec); ctx.sync()
 def timed(fn, reps=50):
@@ -25,5 +27,9 @@ fns = {
     "pad": lambda: ctx.pad_border(Rec),
     "ssd": lambda: ctx.picture_ssd_dev(O, Rec, 0, bd, fp.d_ssd.ptr),
 }
+N = W * H
+alg = {"me": 4 * N, "recon": 9 * N + 16 * N // 16, "deblock": 6 * N + N,
+       "pad": 2 * (2 * 128 * (W + H + 256) + 4 * 64 * (W // 2 + H // 2 + 128)), "ssd": 4 * N}
 for k in which:
-    print("%-8s %7.2f us" % (k, timed(fns[k])))
+    us = timed(fns[k])
+    print("%-8s %8.2f us  %7.0f GB/s algorithmic" % (k, us, alg[k] / us / 1e3))
