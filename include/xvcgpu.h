@@ -365,6 +365,53 @@ xvcgpu_status xvcgpu_picture_ssd_rows(xvcgpu_ctx *ctx, const xvcgpu_picture *a,
                                       int shift_bitdepth, int y_begin, int y_end,
                                       uint64_t *d_out);
 
+/* ---- whole-picture passes around the hot path -------------------------- *
+ * Decision-free, HBM-bound passes the encoder / decoder run on whole pictures
+ * before and after the per-CU work; on the device so that planes never have to
+ * visit the host.  All on the context's stream.
+ *
+ * Resampler::ConvertFrom without resizing (resample.cc:32-63, :152-262): packed
+ * planar 4:2:0 input in device memory (Y, U, V back to back, rows tightly
+ * packed; 1 byte per sample when in_bitdepth == 8, else 2 little endian) ->
+ * the picture at its internal bit depth (samples << (bd - in_bitdepth)); when
+ * the picture is larger than the input (internal size rounded up to the
+ * minimum CU size) the last column / row is repeated.  Visible area only: call
+ * xvcgpu_pad_border afterwards if the picture is searched. */
+xvcgpu_status xvcgpu_picture_import(xvcgpu_ctx *ctx, xvcgpu_picture *pic,
+                                    const void *d_src, int in_width, int in_height,
+                                    int in_bitdepth);
+/* Resampler::ConvertTo without resizing (resample.cc:96-147,
+ * CopyToBytesWithShift :304-338 with the sample functions :475-551): the
+ * display_width x display_height top-left part of the picture -> packed planar
+ * bytes at out_bitdepth (same layout as above): copy / left shift when
+ * out_bitdepth >= bd, else the rounding down-shift or, with `dither`, the
+ * reference's error-feedback down-shift whose remainder runs through all
+ * samples of a plane in raster order (computed here as a parallel prefix
+ * sum). */
+xvcgpu_status xvcgpu_picture_export(xvcgpu_ctx *ctx, const xvcgpu_picture *pic,
+                                    void *d_dst, int display_width, int display_height,
+                                    int out_bitdepth, int dither);
+/* Checksum::CalculateCrc (checksum.cc:46-92): CRC-16 (0x1021, preset 0xffff,
+ * low byte of a sample first, 16 trailing zero bits).  mode 0 = kMinOverhead:
+ * one value over Y,U,V, d_hash[0..1]; mode 1 = kMaxRobust: one per plane,
+ * d_hash[0..5] (high byte first).  d_hash: 8 bytes of device memory.  (The
+ * reference's default, MD5, is a serial chain and stays on the host.) */
+xvcgpu_status xvcgpu_picture_crc(xvcgpu_ctx *ctx, const xvcgpu_picture *pic, int mode,
+                                 uint8_t *d_hash);
+/* CuEncoder::CalcDeltaQpFromVariance (cu_encoder.cc:308-357), the integer
+ * part: d_var16[by * ceil(w/16) + bx] = calc_variance of the 16x16 luma block
+ * (blocks that hang over the picture edge read the border); and, if d_ctu_var
+ * is not NULL, per ctu_size x ctu_size CTU in raster order the statistic the
+ * QP offset is computed from: 1 + sorted in-picture block variances[blocks/2].
+ * The host applies strength * (1.5 * log(v) - 15 - 2 * (bd - 8)). */
+xvcgpu_status xvcgpu_variance_map(xvcgpu_ctx *ctx, const xvcgpu_picture *pic,
+                                  uint64_t *d_var16, int ctu_size, uint64_t *d_ctu_var);
+/* PictureEncoder::DetermineAllowLic (picture_encoder.cc:230-281): *d_out = sum
+ * over the sample values of |histogram(luma of a) - histogram(luma of b)|; the
+ * caller compares with (int)(0.06 * w * h). */
+xvcgpu_status xvcgpu_histogram_distance(xvcgpu_ctx *ctx, const xvcgpu_picture *a,
+                                        const xvcgpu_picture *b, int64_t *d_out);
+
 /* ---- tables (host side, no GPU needed) ---------------------------------- *
  * The 8-bit-fraction transform matrices the kernels use (transform_data.cc:
  * 109-796), for table-equality tests. out: size*size int16 row-major. */

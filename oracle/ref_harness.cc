@@ -39,19 +39,23 @@
 
 #define private public
 #define protected public
+#include "xvc_common_lib/checksum.h"
 #include "xvc_common_lib/coding_unit.h"
 #include "xvc_common_lib/deblocking_filter.h"
 #include "xvc_common_lib/inter_prediction.h"
 #include "xvc_common_lib/intra_prediction.h"
 #include "xvc_common_lib/picture_data.h"
 #include "xvc_common_lib/quantize.h"
+#include "xvc_common_lib/resample.h"
 #include "xvc_common_lib/restrictions.h"
 #include "xvc_common_lib/segment_header.h"
 #include "xvc_common_lib/transform.h"
 #include "xvc_common_lib/yuv_pic.h"
+#include "xvc_enc_lib/cu_encoder.h"
 #include "xvc_enc_lib/encoder_settings.h"
 #include "xvc_enc_lib/encoder_simd_functions.h"
 #include "xvc_enc_lib/inter_tz_search.h"
+#include "xvc_enc_lib/picture_encoder.h"
 #include "xvc_enc_lib/rdo_quant.h"
 #include "xvc_enc_lib/sample_metric.h"
 /* member templates (SubpelSearch<>, ...) are defined only in the .cc */
@@ -956,5 +960,113 @@ void xr_frame_pass(xo_frame_args *a) {
     const double mse = 255.0 * 255.0 / std::pow(10.0, psnr / 10.0);
     a->ssd[1] = static_cast<uint64_t>(std::llround(a->ssd[0] / mse));
   }
+}
+
+/* ---- whole-picture passes around the hot path (oracle: xvc_oracle_stats.c) ---- */
+
+/* Resampler::ConvertFrom: tightly packed planar 4:2:0 input (in_w x in_h at
+ * in_bd) into an internal picture out_w x out_h at out_bd; returns the planes
+ * without border, tightly packed uint16. */
+void xr_import_picture(int in_bd, int out_bd, int in_w, int in_h, int out_w,
+                       int out_h, const uint8_t *bytes, uint16_t *out_planes) {
+  Resampler::SimdFunc rs;
+  Resampler resampler(rs);
+  PictureFormat fmt(in_w, in_h, in_bd, ChromaFormat::k420, ColorMatrix::kUndefined,
+                    false);
+  YuvPicture pic(ChromaFormat::k420, out_w, out_h, out_bd, true, out_w - in_w,
+                 out_h - in_h);
+  resampler.ConvertFrom(fmt, bytes, &pic);
+  for (int c = 0; c < 3; c++) {
+    const YuvComponent comp = YuvComponent(c);
+    for (int y = 0; y < pic.GetHeight(comp); y++) {
+      std::memcpy(out_planes, pic.GetSamplePtr(comp, 0, y),
+                  sizeof(Sample) * pic.GetWidth(comp));
+      out_planes += pic.GetWidth(comp);
+    }
+  }
+}
+
+/* Resampler::ConvertTo without resizing: picture (w x h internal, display
+ * size disp_w x disp_h) -> packed planar bytes at out_bd.  Returns bytes
+ * written. */
+size_t xr_export_picture(int bd, int out_bd, int dither, int w, int h, int disp_w,
+                         int disp_h, const uint16_t *const planes[3],
+                         const ptrdiff_t strides[3], uint8_t *out) {
+  Resampler::SimdFunc rs;
+  Resampler resampler(rs);
+  YuvPicture pic(ChromaFormat::k420, w, h, bd, true, w - disp_w, h - disp_h);
+  for (int c = 0; c < 3; c++) {
+    const YuvComponent comp = YuvComponent(c);
+    for (int y = 0; y < pic.GetHeight(comp); y++)
+      std::memcpy(pic.GetSamplePtr(comp, 0, y), planes[c] + y * strides[c],
+                  sizeof(Sample) * pic.GetWidth(comp));
+  }
+  PictureFormat fmt(disp_w, disp_h, out_bd, ChromaFormat::k420,
+                    ColorMatrix::kUndefined, dither != 0);
+  std::vector<uint8_t> bytes;
+  resampler.ConvertTo(pic, fmt, &bytes);
+  std::memcpy(out, bytes.data(), bytes.size());
+  return bytes.size();
+}
+
+/* Checksum(kCrc, mode).HashPicture */
+int xr_picture_crc(int bd, int mode, int w, int h, const uint16_t *const planes[3],
+                   const ptrdiff_t strides[3], uint8_t *hash) {
+  YuvPicture pic(ChromaFormat::k420, w, h, bd, true, 0, 0);
+  for (int c = 0; c < 3; c++) {
+    const YuvComponent comp = YuvComponent(c);
+    for (int y = 0; y < pic.GetHeight(comp); y++)
+      std::memcpy(pic.GetSamplePtr(comp, 0, y), planes[c] + y * strides[c],
+                  sizeof(Sample) * pic.GetWidth(comp));
+  }
+  Checksum cs(Checksum::Method::kCrc, mode ? Checksum::Mode::kMaxRobust
+                                           : Checksum::Mode::kMinOverhead);
+  cs.HashPicture(pic);
+  std::vector<uint8_t> hv = cs.GetHash();
+  std::memcpy(hash, hv.data(), hv.size());
+  return static_cast<int>(hv.size());
+}
+
+/* CuEncoder::CalcDeltaQpFromVariance for the CTU at (x, y); luma plane w x h
+ * (multiples of 16: the reference reads past the plane otherwise). */
+int xr_aqp_delta_qp(int bd, int w, int h, const uint16_t *luma, ptrdiff_t stride,
+                    int x, int y, int ctu_size, int aqp_strength) {
+  YuvPicture orig(ChromaFormat::k420, w, h, bd, false, 0, 0);
+  YuvPicture rec(ChromaFormat::k420, w, h, bd, true, 0, 0);
+  for (int yy = 0; yy < h; yy++)
+    std::memcpy(orig.GetSamplePtr(YuvComponent::kY, 0, yy), luma + yy * stride,
+                sizeof(Sample) * w);
+  PictureData pic_data(ChromaFormat::k420, w, h, bd);
+  EncoderSettings settings;
+  settings.Initialize(SpeedMode::kSlow);
+  settings.aqp_strength = aqp_strength;
+  CuEncoder enc(Simd(bd), orig, &rec, &pic_data, settings);
+  CodingUnit *cu = pic_data.CreateCu(CuTree::Primary, 0, x, y, ctu_size, ctu_size);
+  return enc.CalcDeltaQpFromVariance(cu);
+}
+
+/* PictureEncoder::DetermineAllowLic(kUni, one reference whose original is b) */
+int xr_allow_lic(int bd, int w, int h, const uint16_t *a, ptrdiff_t sa,
+                 const uint16_t *b, ptrdiff_t sb) {
+  PictureFormat fmt(w, h, bd, ChromaFormat::k420, ColorMatrix::kUndefined, false);
+  PictureEncoder enc(Simd(bd), fmt, 0, 0);
+  auto ref_orig = std::make_shared<YuvPicture>(ChromaFormat::k420, w, h, bd, false, 0, 0);
+  for (int y = 0; y < h; y++) {
+    std::memcpy(enc.orig_pic_->GetSamplePtr(YuvComponent::kY, 0, y), a + y * sa,
+                sizeof(Sample) * w);
+    std::memcpy(ref_orig->GetSamplePtr(YuvComponent::kY, 0, y), b + y * sb,
+                sizeof(Sample) * w);
+  }
+  ReferencePictureLists rpl;
+  rpl.Reset(8);
+  auto ref_data = std::make_shared<PictureData>(ChromaFormat::k420, 8, 8, bd);
+  ref_data->SetNalType(NalUnitType::kPredictedPicture);
+  rpl.SetRefPic(RefPicList::kL0, 0, 4, ref_data, nullptr, ref_orig);
+  Restrictions &r = Restrictions::GetRW();
+  const bool saved = r.disable_ext2_inter_local_illumination_comp;
+  r.disable_ext2_inter_local_illumination_comp = false;
+  const bool allow = enc.DetermineAllowLic(PicturePredictionType::kUni, rpl);
+  r.disable_ext2_inter_local_illumination_comp = saved;
+  return allow ? 1 : 0;
 }
 }  // extern "C"

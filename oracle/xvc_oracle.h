@@ -239,6 +239,28 @@ typedef struct xo_frame_args {
 } xo_frame_args;
 void xo_frame_pass(xo_frame_args *a);
 
+/* ---- whole-picture passes around the hot path (xvc_oracle_stats.c; SURVEY
+ * 8f N4): sample conversion in / out (resample.cc:152-262, :304-338,
+ * :475-551), CRC (checksum.cc:46-92), AQP variance (cu_encoder.cc:308-363),
+ * LIC histogram distance (picture_encoder.cc:230-281). ---- */
+void xo_import_plane(int in_bitdepth, int out_bitdepth, int in_w, int in_h,
+                     int out_w, int out_h, const uint8_t *src,
+                     ptrdiff_t src_stride_bytes, uint16_t *dst,
+                     ptrdiff_t dst_stride);
+void xo_export_plane(int src_bitdepth, int out_bitdepth, int dither, int w, int h,
+                     const uint16_t *src, ptrdiff_t src_stride, uint8_t *out);
+int xo_picture_crc(int bitdepth, int mode, int w, int h,
+                   const uint16_t *const planes[3], const ptrdiff_t strides[3],
+                   uint8_t *hash);
+void xo_variance_map(int w, int h, const uint16_t *luma, ptrdiff_t stride,
+                     uint64_t *out);
+uint64_t xo_ctu_variance(int w, int h, int x, int y, int ctu_size,
+                         const uint64_t *var_map);
+int xo_aqp_delta_qp(uint64_t ctu_variance, int bitdepth, int aqp_strength);
+int64_t xo_histogram_distance(int bitdepth, int w, int h, const uint16_t *a,
+                              ptrdiff_t sa, const uint16_t *b, ptrdiff_t sb);
+int xo_allow_lic(int64_t histogram_distance, int w, int h);
+
 /* Transform matrix access (transform_data.cc, high-precision tables) for
  * table-equality tests: returns pointer to N*N int16 row-major, or NULL. */
 const int16_t *xo_transform_matrix(int tx_type, int size);

@@ -538,3 +538,119 @@ def test_frame_pass_composition(libs, w, h, bd, qp, cu, threads):
         nz += int(np.count_nonzero(o_nnz))
         ref = o_rec
     assert nz > 0
+
+
+# ---- whole-picture passes around the hot path (SURVEY 8f N4 + I/O) ----
+def _rand_planes(rng, w, h, bd, smooth=True):
+    return [rnd_samples(rng, bd, hh, ww, smooth) for ww, hh in
+            ((w, h), (w // 2, h // 2), (w // 2, h // 2))]
+
+
+@pytest.mark.parametrize("in_bd,out_bd", [(8, 8), (8, 10), (10, 10), (10, 12), (8, 12)])
+def test_import_picture(libs, in_bd, out_bd):
+    import oracle_stats as st
+    xo, xr = libs
+    rng = np.random.default_rng(700 + in_bd + out_bd)
+    # same size (CopyFromBytesFast) and display sizes that are not multiples
+    # of 8 (CopyFromBytesWithPadding: internal size rounded up)
+    for (iw, ih, ow, oh) in [(64, 48, 64, 48), (50, 30, 56, 32), (36, 22, 40, 24),
+                             (350, 286, 352, 288)]:
+        data = st.pack_input(_rand_planes(rng, iw, ih, in_bd), in_bd)
+        exp = st.xr_import_picture(xr, in_bd, out_bd, iw, ih, ow, oh, data)
+        got = st.xo_import_picture(xo, in_bd, out_bd, iw, ih, ow, oh, data)
+        for c in range(3):
+            assert np.array_equal(got[c], exp[c]), (iw, ih, c)
+
+
+@pytest.mark.parametrize("bd,out_bd", [(8, 8), (10, 8), (10, 10), (12, 8), (12, 10),
+                                       (10, 12), (8, 10)])
+@pytest.mark.parametrize("dither", [0, 1])
+def test_export_picture(libs, bd, out_bd, dither):
+    import oracle_stats as st
+    xo, xr = libs
+    rng = np.random.default_rng(720 + bd + out_bd)
+    for (w, h, dw, dh) in [(64, 48, 64, 48), (56, 32, 50, 30), (352, 288, 350, 286)]:
+        planes = _rand_planes(rng, w, h, bd, smooth=bool(dither))
+        exp = st.xr_export_picture(xr, bd, out_bd, dither, planes, dw, dh)
+        got = st.xo_export_picture(xo, bd, out_bd, dither, planes, dw, dh)
+        assert len(exp) == dw * dh * 3 // 2 * (2 if out_bd > 8 else 1)
+        assert got == exp, (w, h, dw, dh)
+
+
+@pytest.mark.parametrize("bd", [8, 10, 12])
+@pytest.mark.parametrize("mode", [0, 1])
+def test_picture_crc(libs, bd, mode):
+    import oracle_stats as st
+    xo, xr = libs
+    rng = np.random.default_rng(740 + bd)
+    for (w, h) in [(8, 8), (64, 48), (136, 72), (352, 288)]:
+        planes = _rand_planes(rng, w, h, bd)
+        exp = st.xr_picture_crc(xr, bd, mode, w, h, planes)
+        assert len(exp) == (6 if mode else 2)
+        assert st.xo_picture_crc(xo, bd, mode, w, h, planes) == exp, (w, h)
+
+
+@pytest.mark.parametrize("bd", [8, 10, 12])
+def test_aqp_variance(libs, bd):
+    """CalcDeltaQpFromVariance is observable only through the clipped integer
+    QP offset: sweep the strength so that every variance lands on several
+    different offsets."""
+    import oracle_stats as st
+    xo, xr = libs
+    rng = np.random.default_rng(760 + bd)
+    w, h = 192, 128
+    hit = set()
+    for trial in range(3):
+        luma = rnd_samples(rng, bd, h, w, True)
+        # flat, textured and noisy regions
+        luma[:64, :64] = luma[0, 0]
+        luma[64:, 64:128] = rng.integers(0, 1 << bd, (64, 64), dtype=np.uint16)
+        luma[:32, 128:] = (luma[:32, 128:] & ~np.uint16(3)) | np.uint16(trial)
+        # graded noise: 16x16 tiles with amplitudes 2, 3, 4, 6, 8, 12, ... around mid grey
+        amp = [2, 3, 4, 6, 8, 12, 16, 24, 32, 48, 64, 96]
+        for k, a_ in enumerate(amp):
+            a_ = min(a_ << (bd - 8), (1 << (bd - 1)) - 1)
+            luma[64:80, 16 * k:16 * k + 16] = (1 << (bd - 1)) + rng.integers(
+                -a_, a_ + 1, (16, 16))
+        vm = st.xo_variance_map(xo, w, h, luma)
+        for ctu in (16, 32, 64):
+            for y in range(0, h, ctu):
+                for x in range(0, w, ctu):
+                    var = st.xo_ctu_variance(xo, w, h, x, y, ctu, vm)
+                    for strength in (2, 5, 13, 29, 60):
+                        exp = st.xr_aqp_delta_qp(xr, bd, luma, x, y, ctu, strength)
+                        assert st.xo_aqp_delta_qp(xo, var, bd, strength) == exp, \
+                            (x, y, ctu, strength, var)
+                        hit.add(exp)
+    assert len(hit) >= 8   # the sweep exercised most of the -3..7 range
+
+
+@pytest.mark.parametrize("bd", [8, 10])
+def test_lic_histogram_distance(libs, bd):
+    import oracle_stats as st
+    xo, xr = libs
+    rng = np.random.default_rng(780 + bd)
+    w, h = 64, 48
+    thr = int(0.06 * w * h)
+    a = rnd_samples(rng, bd, h, w, True)
+    a[a == 0] = 1
+    seen = set()
+    for k in list(range(thr // 2 - 3, thr // 2 + 4)) + [0, 5, w * h // 2]:
+        b = a.copy()
+        # move k samples to the (otherwise unused) value 0: distance = 2k
+        idx = rng.choice(w * h, k, replace=False)
+        b.reshape(-1)[idx] = 0
+        d = st.xo_histogram_distance(xo, bd, a, b)
+        assert d == 2 * k
+        allow = st.xo_allow_lic(xo, d, w, h)
+        assert allow == st.xr_allow_lic(xr, bd, a, b), k
+        seen.add(allow)
+    assert seen == {0, 1}
+    # general case
+    for _ in range(4):
+        b = rnd_samples(rng, bd, h, w, True)
+        d = st.xo_histogram_distance(xo, bd, a, b)
+        ha = np.bincount(a.reshape(-1), minlength=1 << bd).astype(np.int64)
+        hb = np.bincount(b.reshape(-1), minlength=1 << bd).astype(np.int64)
+        assert d == int(np.abs(ha - hb).sum())
+        assert st.xo_allow_lic(xo, d, w, h) == st.xr_allow_lic(xr, bd, a, b)

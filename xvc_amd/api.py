@@ -77,7 +77,9 @@ SYMBOLS = [
     "xvcgpu_mc_bipred_batch", "xvcgpu_bipred_search", "xvcgpu_mc_affine_batch",
     "xvcgpu_cu_info_from_me", "xvcgpu_recon_from_me", "xvcgpu_residual_batch",
     "xvcgpu_fwd_transform_batch", "xvcgpu_inv_transform_batch",
-    "xvcgpu_deblock", "xvcgpu_deblock_rows", "xvcgpu_picture_ssd", "xvcgpu_picture_ssd_rows", "xvcgpu_get_transform_matrix",
+    "xvcgpu_deblock", "xvcgpu_deblock_rows", "xvcgpu_picture_ssd", "xvcgpu_picture_ssd_rows",
+    "xvcgpu_picture_import", "xvcgpu_picture_export", "xvcgpu_picture_crc",
+    "xvcgpu_variance_map", "xvcgpu_histogram_distance", "xvcgpu_get_transform_matrix",
 ]
 
 _vp = C.c_void_p
@@ -168,6 +170,11 @@ def load_library():
                                 C.c_int, C.c_int, C.c_int, C.c_int, C.c_int],
         "xvcgpu_picture_ssd": [_vp, _vp, _vp, C.c_int, C.c_int, _vp],
         "xvcgpu_picture_ssd_rows": [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp],
+        "xvcgpu_picture_import": [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int],
+        "xvcgpu_picture_export": [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int],
+        "xvcgpu_picture_crc": [_vp, _vp, C.c_int, _vp],
+        "xvcgpu_variance_map": [_vp, _vp, _vp, C.c_int, _vp],
+        "xvcgpu_histogram_distance": [_vp, _vp, _vp, _vp],
         "xvcgpu_get_transform_matrix": [C.c_int, C.c_int, _vp],
     }
     for name, args in sigs.items():
@@ -551,6 +558,54 @@ class Context:
         self.sync()
         dc.free()
         dm.free()
+
+    # ---- whole-picture passes around the hot path ----
+    def picture_import(self, pic, data, in_w, in_h, in_bd):
+        """data: packed planar 4:2:0 bytes (Y,U,V) as the application holds
+        them; staged in device memory, converted on the device."""
+        src = np.frombuffer(data, np.uint8)
+        assert len(src) == in_w * in_h * 3 // 2 * (2 if in_bd > 8 else 1)
+        d = self.buffer(src)
+        self._check(self.lib.xvcgpu_picture_import(self.h, pic.h_pic, d.ptr, in_w, in_h,
+                                                   in_bd))
+        self.sync()
+        d.free()
+
+    def picture_export(self, pic, disp_w, disp_h, out_bd, dither=False):
+        n = disp_w * disp_h * 3 // 2 * (2 if out_bd > 8 else 1)
+        d = self.alloc(n)
+        self._check(self.lib.xvcgpu_picture_export(self.h, pic.h_pic, d.ptr, disp_w,
+                                                   disp_h, out_bd, int(dither)))
+        out = d.to_array(np.uint8, n).tobytes()
+        d.free()
+        return out
+
+    def picture_crc(self, pic, mode=0):
+        d = self.alloc(8)
+        self._check(self.lib.xvcgpu_picture_crc(self.h, pic.h_pic, mode, d.ptr))
+        out = d.to_array(np.uint8, 8)[:6 if mode else 2].tobytes()
+        d.free()
+        return out
+
+    def variance_map(self, pic, ctu_size=64):
+        """-> (16x16-block variances [rows, cols], per-CTU statistic [rows, cols])"""
+        bw, bh = (pic.w + 15) // 16, (pic.h + 15) // 16
+        cw, ch = -(-pic.w // ctu_size), -(-pic.h // ctu_size)
+        dv, dc = self.alloc(8 * bw * bh), self.alloc(8 * cw * ch)
+        self._check(self.lib.xvcgpu_variance_map(self.h, pic.h_pic, dv.ptr, ctu_size,
+                                                 dc.ptr))
+        v = dv.to_array(np.uint64, bw * bh).reshape(bh, bw)
+        c = dc.to_array(np.uint64, cw * ch).reshape(ch, cw)
+        dv.free()
+        dc.free()
+        return v, c
+
+    def histogram_distance(self, a, b):
+        d = self.alloc(8)
+        self._check(self.lib.xvcgpu_histogram_distance(self.h, a.h_pic, b.h_pic, d.ptr))
+        out = int(d.to_array(np.int64, 1)[0])
+        d.free()
+        return out
 
     def picture_ssd(self, a, b, comp=0, shift_bd=8):
         do = self.alloc(16)

@@ -17,6 +17,7 @@
 #include "k_tx2.h"
 #include "k_recon.h"
 #include "k_bipred.h"
+#include "k_stats.h"
 #include "xvcgpu_internal.h"
 
 namespace {
@@ -140,6 +141,8 @@ xvcgpu_status xvcgpu_create(int device, xvcgpu_ctx **out) {
   ctx->d_tz_pattern = nullptr;
   ctx->d_ssd_part = nullptr;
   ctx->ssd_part_cap = 0;
+  ctx->d_stats = nullptr;
+  ctx->stats_rows_cap = 0;
   ctx->d_me_rot = nullptr;
   ctx->me_epoch = 0;
   if (hipSetDevice(device) != hipSuccess ||
@@ -189,6 +192,7 @@ void xvcgpu_destroy(xvcgpu_ctx *ctx) {
   if (ctx->d_tx_tables_t) hipFree(ctx->d_tx_tables_t);
   if (ctx->d_tz_pattern) hipFree(ctx->d_tz_pattern);
   if (ctx->d_ssd_part) hipFree(ctx->d_ssd_part);
+  if (ctx->d_stats) hipFree(ctx->d_stats);
   if (ctx->d_me_rot) hipFree(ctx->d_me_rot);
   hipEventDestroy(ctx->ev0);
   hipEventDestroy(ctx->ev1);
@@ -355,6 +359,7 @@ xvcgpu_status xvcgpu_memset(xvcgpu_ctx *ctx, void *dst, int value, size_t bytes)
 }
 
 static xvcgpu_status ensure_ssd_part(xvcgpu_ctx *ctx, int items);
+static xvcgpu_status ensure_stats(xvcgpu_ctx *ctx, int rows);
 
 /* ---- pictures ---- */
 size_t xvcgpu_picture_bytes(int width, int height) {
@@ -382,7 +387,8 @@ xvcgpu_status xvcgpu_picture_wrap(xvcgpu_ctx *ctx, int width, int height,
   p->bytes = bytes;
   p->own = false;
   init_views(p);
-  const xvcgpu_status st = ensure_ssd_part(ctx, ssd_items(width, height));
+  xvcgpu_status st = ensure_ssd_part(ctx, ssd_items(width, height));
+  if (st == XVCGPU_OK) st = ensure_stats(ctx, 2 * height);
   if (st != XVCGPU_OK) {
     delete p;
     return st;
@@ -874,5 +880,145 @@ xvcgpu_status xvcgpu_picture_ssd_rows(xvcgpu_ctx *ctx, const xvcgpu_picture *a,
   CHECK_LAUNCH(ctx, "picture_ssd");
   return XVCGPU_OK;
 }
+
+/* ---- whole-picture passes around the hot path (k_stats.h) ---- */
+static const int kStatsHistWords = 4096;
+
+// Scratch of the statistics passes; like the SSD scratch it is sized when a
+// picture is created, never on a measurement path.
+static xvcgpu_status ensure_stats(xvcgpu_ctx *ctx, int rows) {
+  if (rows <= ctx->stats_rows_cap) return XVCGPU_OK;
+  if (ctx->d_stats) {
+    hipStreamSynchronize(ctx->stream);
+    hipFree(ctx->d_stats);
+    ctx->d_stats = nullptr;
+    ctx->stats_rows_cap = 0;
+  }
+  const size_t bytes = sizeof(uint32_t) * ((size_t)kStatsHistWords + rows);
+  hipError_t e = hipMalloc(&ctx->d_stats, bytes);
+  if (e != hipSuccess) return fail(ctx, XVCGPU_OUT_OF_MEMORY, "hipMalloc", e);
+  hipMemsetAsync(ctx->d_stats, 0, bytes, ctx->stream);
+  ctx->stats_rows_cap = rows;
+  return XVCGPU_OK;
+}
+
+xvcgpu_status xvcgpu_picture_import(xvcgpu_ctx *ctx, xvcgpu_picture *pic,
+                                    const void *d_src, int in_width, int in_height,
+                                    int in_bitdepth) {
+  if (!ctx || !pic || !d_src) return XVCGPU_INVALID_ARGUMENT;
+  if (in_width < 2 || in_height < 2 || (in_width & 1) || (in_height & 1) ||
+      in_width > pic->w || in_height > pic->h || in_bitdepth < 8 ||
+      in_bitdepth > pic->bd || in_bitdepth > 16)
+    return fail(ctx, XVCGPU_INVALID_ARGUMENT, "import: input size/bitdepth");
+  ImportArgs a;
+  const size_t bps = in_bitdepth > 8 ? 2 : 1;
+  const uint8_t *src = static_cast<const uint8_t *>(d_src);
+  for (int c = 0; c < 3; c++) {
+    a.src[c] = src;
+    a.in_w[c] = c ? in_width >> 1 : in_width;
+    a.in_h[c] = c ? in_height >> 1 : in_height;
+    src += (size_t)a.in_w[c] * a.in_h[c] * bps;
+  }
+  a.wide = in_bitdepth > 8;
+  a.upshift = pic->bd - in_bitdepth;
+  hipLaunchKernelGGL(picture_import_kernel, dim3(pic->h, 3), dim3(256), 0, ctx->stream,
+                     pic->v, a);
+  CHECK_LAUNCH(ctx, "picture_import");
+  return XVCGPU_OK;
+}
+
+xvcgpu_status xvcgpu_picture_export(xvcgpu_ctx *ctx, const xvcgpu_picture *pic,
+                                    void *d_dst, int display_width, int display_height,
+                                    int out_bitdepth, int dither) {
+  if (!ctx || !pic || !d_dst) return XVCGPU_INVALID_ARGUMENT;
+  if (display_width < 2 || display_height < 2 || (display_width & 1) ||
+      (display_height & 1) || display_width > pic->w || display_height > pic->h ||
+      out_bitdepth < 1 || out_bitdepth > 16)
+    return fail(ctx, XVCGPU_INVALID_ARGUMENT, "export: output size/bitdepth");
+  ExportArgs a;
+  a.wide = out_bitdepth > 8;
+  const size_t bps = a.wide ? 2 : 1;
+  uint8_t *dst = static_cast<uint8_t *>(d_dst);
+  int rows = 0;
+  for (int c = 0; c < 3; c++) {
+    a.dst[c] = dst;
+    a.w[c] = c ? display_width >> 1 : display_width;
+    a.h[c] = c ? display_height >> 1 : display_height;
+    a.row_base[c] = rows;
+    rows += a.h[c];
+    dst += (size_t)a.w[c] * a.h[c] * bps;
+  }
+  // CopyToBytesWithShift's dispatch (resample.cc:304-338)
+  a.smax = (1 << out_bitdepth) - 1;
+  if (out_bitdepth >= pic->bd || (!a.wide && pic->bd <= 8)) {
+    a.mode = 0;
+    a.shift = a.wide ? out_bitdepth - pic->bd : 0;
+  } else {
+    a.mode = dither ? 2 : 1;
+    a.shift = pic->bd - out_bitdepth;
+  }
+  uint32_t *row_words = ctx->d_stats + kStatsHistWords;
+  a.row_carry = row_words;
+  if (a.mode == 2) {
+    hipLaunchKernelGGL(export_row_sums_kernel, dim3(a.h[0], 3), dim3(256), 0, ctx->stream,
+                       pic->v, a, row_words);
+    hipLaunchKernelGGL(export_row_scan_kernel, dim3(3), dim3(256), 0, ctx->stream, a,
+                       row_words);
+  }
+  hipLaunchKernelGGL(picture_export_kernel, dim3(a.h[0], 3), dim3(256), 0, ctx->stream,
+                     pic->v, a);
+  CHECK_LAUNCH(ctx, "picture_export");
+  return XVCGPU_OK;
+}
+
+xvcgpu_status xvcgpu_picture_crc(xvcgpu_ctx *ctx, const xvcgpu_picture *pic, int mode,
+                                 uint8_t *d_hash) {
+  if (!ctx || !pic || !d_hash || mode < 0 || mode > 1) return XVCGPU_INVALID_ARGUMENT;
+  uint32_t *row_words = ctx->d_stats + kStatsHistWords;
+  const int wide = pic->bd > 8;
+  hipLaunchKernelGGL(crc_rows_kernel, dim3(pic->h, 3), dim3(64), 0, ctx->stream, pic->v,
+                     wide, row_words);
+  hipLaunchKernelGGL(crc_fold_kernel, dim3(1), dim3(256), 0, ctx->stream, pic->v, wide,
+                     mode, row_words, d_hash);
+  CHECK_LAUNCH(ctx, "picture_crc");
+  return XVCGPU_OK;
+}
+
+xvcgpu_status xvcgpu_variance_map(xvcgpu_ctx *ctx, const xvcgpu_picture *pic,
+                                  uint64_t *d_var16, int ctu_size, uint64_t *d_ctu_var) {
+  if (!ctx || !pic || !d_var16) return XVCGPU_INVALID_ARGUMENT;
+  if (d_ctu_var && ctu_size != 16 && ctu_size != 32 && ctu_size != 64 && ctu_size != 128)
+    return fail(ctx, XVCGPU_INVALID_ARGUMENT, "variance_map: ctu size");
+  const int bw = (pic->w + 15) / 16, bh = (pic->h + 15) / 16;
+  hipLaunchKernelGGL(variance_map_kernel, dim3((bw * bh + 3) / 4), dim3(256), 0,
+                     ctx->stream, pic->v.c[0], bw, bw * bh,
+                     reinterpret_cast<unsigned long long *>(d_var16));
+  if (d_ctu_var) {
+    const int n = ((pic->w + ctu_size - 1) / ctu_size) * ((pic->h + ctu_size - 1) / ctu_size);
+    hipLaunchKernelGGL(ctu_variance_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream,
+                       reinterpret_cast<const unsigned long long *>(d_var16), pic->w, pic->h,
+                       ctu_size, reinterpret_cast<unsigned long long *>(d_ctu_var));
+  }
+  CHECK_LAUNCH(ctx, "variance_map");
+  return XVCGPU_OK;
+}
+
+xvcgpu_status xvcgpu_histogram_distance(xvcgpu_ctx *ctx, const xvcgpu_picture *a,
+                                        const xvcgpu_picture *b, int64_t *d_out) {
+  if (!ctx || !a || !b || !d_out) return XVCGPU_INVALID_ARGUMENT;
+  if (a->w != b->w || a->h != b->h || a->bd != b->bd || a->bd > 12)
+    return fail(ctx, XVCGPU_INVALID_ARGUMENT, "picture mismatch");
+  const int buckets = 1 << a->bd;
+  const int rows_per_wg = (a->h + 511) / 512;
+  const int n_wg = (a->h + rows_per_wg - 1) / rows_per_wg;
+  int *hist = reinterpret_cast<int *>(ctx->d_stats);
+  hipLaunchKernelGGL(histogram_diff_kernel, dim3(n_wg), dim3(256), sizeof(int) * buckets,
+                     ctx->stream, a->v.c[0], b->v.c[0], buckets, rows_per_wg, hist);
+  hipLaunchKernelGGL(histogram_abs_sum_kernel, dim3(1), dim3(256), 0, ctx->stream, hist,
+                     buckets, reinterpret_cast<long long *>(d_out));
+  CHECK_LAUNCH(ctx, "histogram_distance");
+  return XVCGPU_OK;
+}
+
 
 }  // extern "C"

@@ -44,6 +44,11 @@ struct xvcgpu_ctx {
   // per-block partial results of xvcgpu_picture_ssd
   unsigned long long *d_ssd_part;
   int ssd_part_cap;  // in blocks
+  // scratch of the whole-picture statistics passes (k_stats.h): a signed
+  // histogram of 4096 buckets followed by one word per picture row (row CRCs /
+  // row remainders of the dithering export)
+  uint32_t *d_stats;
+  int stats_rows_cap;
 };
 
 struct xvcgpu_picture {
