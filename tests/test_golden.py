@@ -209,6 +209,73 @@ def test_oracle_picture_ssd(xo):
         assert xo.picture_ssd(int(bd), a, b) == (int(d), int(n)), (w, h, bd)
 
 
+def _stats_cases(g):
+    for i, (in_bd, bd, iw, ih, w, h) in enumerate(g["cases"]):
+        yield i, int(in_bd), int(bd), int(iw), int(ih), int(w), int(h)
+
+
+def test_oracle_stats(xo):
+    """Resampler / Checksum / AQP / LIC vectors of the reference (stats.npz)."""
+    import oracle_stats as st
+    g = load("stats")
+    for i, in_bd, bd, iw, ih, w, h in _stats_cases(g):
+        data = g["in%d" % i].tobytes()
+        imp = st.xo_import_picture(xo, in_bd, bd, iw, ih, w, h, data)
+        for c in range(3):
+            assert np.array_equal(imp[c], g["imp%d_%d" % (i, c)]), (i, c)
+        for out_bd in (8, 10):
+            for dither in (0, 1):
+                assert st.xo_export_picture(xo, bd, out_bd, dither, imp, iw, ih) == \
+                    g["exp%d_%d_%d" % (i, out_bd, dither)].tobytes(), (i, out_bd, dither)
+        for mode in (0, 1):
+            assert st.xo_picture_crc(xo, bd, mode, w, h, imp) == \
+                g["crc%d_%d" % (i, mode)].tobytes()
+    luma = np.ascontiguousarray(g["aqp_luma"])
+    h, w = luma.shape
+    vm = st.xo_variance_map(xo, w, h, luma)
+    for ctu, x, y, strength, dqp in g["aqp"]:
+        var = st.xo_ctu_variance(xo, w, h, int(x), int(y), int(ctu), vm)
+        assert st.xo_aqp_delta_qp(xo, var, 10, int(strength)) == dqp
+    a = np.ascontiguousarray(g["lic_a"])
+    for b, allow in zip(g["lic_b"], g["lic"]):
+        d = st.xo_histogram_distance(xo, 10, a, np.ascontiguousarray(b))
+        assert st.xo_allow_lic(xo, d, w, h) == allow
+    assert set(g["lic"].tolist()) == {0, 1}
+
+
+def _frame_inputs(g):
+    from xvc_amd import synth
+    w, h, bd = (int(v) for v in g["dims"])
+    clip = synth.SyntheticClip(w, h, bd)
+    pad = lambda pl: [np.ascontiguousarray(np.pad(p, BL >> (c > 0), mode="edge"))
+                      for c, p in enumerate(pl)]
+    return w, h, bd, clip, pad
+
+
+def test_oracle_frame_pass(xo):
+    """The whole composition as the reference's own classes ran it (frame.npz):
+    three chained pictures at two QPs."""
+    import oracle_frame
+    from xvc_amd import pipeline
+    g = load("frame")
+    w, h, bd, clip, pad = _frame_inputs(g)
+    for qp in (32, 22):
+        desc = pipeline.FrameDescriptors(w, h, qp)
+        ref = pad(clip.frame(0))
+        for n in (1, 2, 3):
+            rec, res, nnz, _, ssd = oracle_frame.frame_pass(desc, bd, pad(clip.frame(n)), ref,
+                                                            BL, n - 1, lib=xo)
+            k = "q%d_f%d_" % (qp, n)
+            mv = np.stack([res["fullpel_x"], res["fullpel_y"], res["mv_x"], res["mv_y"],
+                           res["subpel_dist"].astype(np.int32)], 1)
+            assert np.array_equal(mv, g[k + "mv"]) and np.array_equal(nnz, g[k + "nnz"])
+            for c in range(3):
+                b = BL >> (c > 0)
+                assert np.array_equal(rec[c][b:-b, b:-b], g[k + "rec%d" % c]), (qp, n, c)
+            assert ssd == tuple(int(v) for v in g[k + "ssd"])
+            ref = rec
+
+
 # ------------------------------------------------------------------------ GPU
 @pytest.fixture(scope="module")
 def gpu():
@@ -383,3 +450,70 @@ def test_gpu_picture_ssd(gpu):
         assert ctx.picture_ssd(A, B, 0, bd) == (int(d), int(n))
         A.destroy()
         B.destroy()
+
+
+@pytest.mark.gpu
+def test_gpu_stats(gpu, xo):
+    import oracle_stats as st
+    api, ctx = gpu
+    g = load("stats")
+    for i, in_bd, bd, iw, ih, w, h in _stats_cases(g):
+        P = ctx.picture(w, h, bd)
+        ctx.picture_import(P, g["in%d" % i].tobytes(), iw, ih, in_bd)
+        got = P.download()
+        for c in range(3):
+            assert np.array_equal(got[c], g["imp%d_%d" % (i, c)]), (i, c)
+        for out_bd in (8, 10):
+            for dither in (0, 1):
+                assert ctx.picture_export(P, iw, ih, out_bd, dither) == \
+                    g["exp%d_%d_%d" % (i, out_bd, dither)].tobytes(), (i, out_bd, dither)
+        for mode in (0, 1):
+            assert ctx.picture_crc(P, mode) == g["crc%d_%d" % (i, mode)].tobytes()
+        P.destroy()
+    luma = np.ascontiguousarray(g["aqp_luma"])
+    h, w = luma.shape
+    P = ctx.picture(w, h, 10)
+    P.upload([luma, None, None])
+    for ctu in (16, 32, 64):
+        _, cv = ctx.variance_map(P, ctu)
+        for c, x, y, strength, dqp in g["aqp"]:
+            if c == ctu:   # the log and the clip are host work (here: the oracle's)
+                assert st.xo_aqp_delta_qp(xo, int(cv[y // ctu, x // ctu]), 10,
+                                          int(strength)) == dqp
+    A = ctx.picture(w, h, 10)
+    A.upload([np.ascontiguousarray(g["lic_a"]), None, None])
+    for b, allow in zip(g["lic_b"], g["lic"]):
+        P.upload([np.ascontiguousarray(b), None, None])
+        assert int(ctx.histogram_distance(A, P) > int(0.06 * w * h)) == allow
+    A.destroy()
+    P.destroy()
+
+
+@pytest.mark.gpu
+def test_gpu_frame_pass(gpu):
+    """The GPU frame pass against what the reference's own classes produced."""
+    from xvc_amd import pipeline
+    api, ctx = gpu
+    g = load("frame")
+    w, h, bd, clip, pad = _frame_inputs(g)
+    O, pics = ctx.picture(w, h, bd), [ctx.picture(w, h, bd), ctx.picture(w, h, bd)]
+    for qp in (32, 22):
+        fp = pipeline.FramePass(ctx, w, h, bd, qp=qp)
+        pics[0].upload(pad(clip.frame(0)), BL)
+        for n in (1, 2, 3):
+            O.upload(pad(clip.frame(n)), BL)
+            ref, rec = pics[(n - 1) % 2], pics[n % 2]
+            fp.run(O, ref, rec, ref_poc=n - 1)
+            res, nnz, _, ssd = fp.results()
+            k = "q%d_f%d_" % (qp, n)
+            mv = np.stack([res["fullpel_x"], res["fullpel_y"], res["mv_x"], res["mv_y"],
+                           res["subpel_dist"].astype(np.int32)], 1)
+            assert np.array_equal(mv, g[k + "mv"]) and np.array_equal(nnz, g[k + "nnz"])
+            got = rec.download()
+            for c in range(3):
+                assert np.array_equal(got[c], g[k + "rec%d" % c]), (qp, n, c)
+            assert (int(ssd[0]), int(ssd[1])) == tuple(int(v) for v in g[k + "ssd"])
+        fp.destroy()
+    O.destroy()
+    for p in pics:
+        p.destroy()

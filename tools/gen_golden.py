@@ -157,6 +157,90 @@ def gen_quant_sh(xr):
                         xin=np.array(xin), xout=np.array(xout))
 
 
+def gen_stats(xr):
+    """stats.npz: the reference's Resampler (ConvertFrom / ConvertTo), Checksum
+    (CRC), CalcDeltaQpFromVariance and DetermineAllowLic on small seeded
+    pictures (the whole-picture passes around the hot path)."""
+    import oracle_stats as st
+    rng = np.random.default_rng(20261001)
+    out = {}
+    cases = []
+    for i, (in_bd, bd, iw, ih, w, h) in enumerate([(8, 10, 70, 38, 72, 40), (10, 10, 96, 64, 96, 64),
+                                                   (8, 8, 50, 30, 56, 32), (10, 12, 36, 22, 40, 24)]):
+        planes = [rnd_samples(rng, in_bd, hh, ww, True)
+                  for ww, hh in ((iw, ih), (iw // 2, ih // 2), (iw // 2, ih // 2))]
+        data = st.pack_input(planes, in_bd)
+        imp = st.xr_import_picture(xr, in_bd, bd, iw, ih, w, h, data)
+        out["in%d" % i] = np.frombuffer(data, np.uint8)
+        for c in range(3):
+            out["imp%d_%d" % (i, c)] = imp[c]
+        for out_bd in (8, 10):
+            for dither in (0, 1):
+                out["exp%d_%d_%d" % (i, out_bd, dither)] = np.frombuffer(
+                    st.xr_export_picture(xr, bd, out_bd, dither, imp, iw, ih), np.uint8)
+        for mode in (0, 1):
+            out["crc%d_%d" % (i, mode)] = np.frombuffer(
+                st.xr_picture_crc(xr, bd, mode, w, h, imp), np.uint8)
+        cases.append((in_bd, bd, iw, ih, w, h))
+    out["cases"] = np.array(cases, np.int32)
+    # AQP offsets and the LIC decision on a 96x64 10-bit picture pair
+    bd, w, h = 10, 96, 64
+    luma = rnd_samples(rng, bd, h, w, True)
+    luma[:32, :32] = rng.integers(0, 1 << bd, (32, 32), dtype=np.uint16)
+    luma[32:, 64:] = 512 + rng.integers(-20, 21, (32, 32))
+    out["aqp_luma"] = luma
+    dq = []
+    for ctu in (16, 32, 64):
+        for y in range(0, h, ctu):
+            for x in range(0, w, ctu):
+                if y + ctu > h or x + ctu > w:
+                    continue
+                for strength in (5, 13, 29):
+                    dq.append((ctu, x, y, strength,
+                               st.xr_aqp_delta_qp(xr, bd, luma, x, y, ctu, strength)))
+    out["aqp"] = np.array(dq, np.int32)
+    lic_b, lic = [], []
+    for k in (0, 150, 184, 185, 186, 400, 3000):
+        b = luma.copy()
+        b[b == 0] = 1
+        a = b.copy()
+        b.reshape(-1)[rng.choice(w * h, k, replace=False)] = 0
+        lic_b.append(b)
+        lic.append(st.xr_allow_lic(xr, bd, a, b))
+    out["lic_a"], out["lic_b"], out["lic"] = a, np.array(lic_b), np.array(lic, np.int32)
+    np.savez_compressed(os.path.join(OUT, "stats.npz"), **out)
+
+
+def gen_frame(xr):
+    """frame.npz: the hot-path frame pass run by the reference's own classes
+    (ref_harness.cc xr_frame_pass) on three chained 136x72 synthetic pictures
+    at QP 32 and 22: motion vectors, coefficient counts, reconstructions, PSNR
+    sums."""
+    import oracle_frame
+    from xvc_amd import pipeline, synth
+    w, h, bd = 136, 72, 10
+    clip = synth.SyntheticClip(w, h, bd)
+    pad = lambda pl: [np.ascontiguousarray(np.pad(p, BL >> (c > 0), mode="edge"))
+                      for c, p in enumerate(pl)]
+    out = {"dims": np.array([w, h, bd], np.int32)}
+    for qp in (32, 22):
+        desc = pipeline.FrameDescriptors(w, h, qp)
+        ref = pad(clip.frame(0))
+        for n in (1, 2, 3):
+            rec, res, nnz, cus, ssd = oracle_frame.frame_pass(
+                desc, bd, pad(clip.frame(n)), ref, BL, n - 1, lib=xr, reference=True)
+            k = "q%d_f%d_" % (qp, n)
+            out[k + "mv"] = np.stack([res["fullpel_x"], res["fullpel_y"], res["mv_x"],
+                                      res["mv_y"], res["subpel_dist"].astype(np.int32)], 1)
+            out[k + "nnz"] = nnz
+            for c in range(3):
+                b = BL >> (c > 0)
+                out[k + "rec%d" % c] = rec[c][b:-b, b:-b]
+            out[k + "ssd"] = np.array(ssd, np.uint64)
+            ref = rec
+    np.savez_compressed(os.path.join(OUT, "frame.npz"), **out)
+
+
 def write_manifest():
     import hashlib
     with open(os.path.join(OUT, "MANIFEST.md5"), "w") as f:
@@ -172,6 +256,14 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     if sys.argv[1:] == ["bipred"]:
         gen_bipred(xr)
+        write_manifest()
+        return
+    if sys.argv[1:] == ["stats"]:
+        gen_stats(xr)
+        write_manifest()
+        return
+    if sys.argv[1:] == ["frame"]:
+        gen_frame(xr)
         write_manifest()
         return
     if sys.argv[1:] == ["quant_sh"]:
