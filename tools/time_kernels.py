@@ -19,7 +19,7 @@ def timed(fn, reps=50):
     fn(); ctx.sync(); ctx.timer_begin()
     for _ in range(reps): fn()
     return 1e3 * ctx.timer_end() / reps
-which = sys.argv[1:] or ["me", "recon", "deblock", "pad", "ssd"]
+which = sys.argv[1:] or ["me", "recon", "deblock", "pad", "ssd", "import8", "export8", "export8d", "crc", "variance", "histogram"]
 fns = {
     "me": lambda: ctx.me_search_dev(O, R, 3, fp.d_me.ptr, d.n_cus, fp.d_res.ptr, 16),
     "recon": lambda: ctx.recon_from_me_dev(O, R, Rec, fp.d_me.ptr, fp.d_res.ptr, d.n_cus, d.qp, d.qp_c, 0, fp.d_nnz.ptr, fp.d_cus_own),
@@ -27,9 +27,23 @@ fns = {
     "pad": lambda: ctx.pad_border(Rec),
     "ssd": lambda: ctx.picture_ssd_dev(O, Rec, 0, bd, fp.d_ssd.ptr),
 }
+d_in = ctx.alloc(W * H * 3)
+d_out = ctx.alloc(W * H * 3)
+d_small = ctx.alloc(8 * (W // 16 + 1) * (H // 16 + 1) * 2)
+lib = ctx.lib
+fns.update({
+    "import8": lambda: lib.xvcgpu_picture_import(ctx.h, O.h_pic, d_in.ptr, W, H, 8),
+    "export8": lambda: lib.xvcgpu_picture_export(ctx.h, Rec.h_pic, d_out.ptr, W, H, 8, 0),
+    "export8d": lambda: lib.xvcgpu_picture_export(ctx.h, Rec.h_pic, d_out.ptr, W, H, 8, 1),
+    "crc": lambda: lib.xvcgpu_picture_crc(ctx.h, Rec.h_pic, 0, d_small.ptr),
+    "variance": lambda: lib.xvcgpu_variance_map(ctx.h, O.h_pic, d_small.ptr, 64, d_small.ptr + 8 * (W // 16 + 1) * (H // 16 + 1)),
+    "histogram": lambda: lib.xvcgpu_histogram_distance(ctx.h, O.h_pic, R.h_pic, d_small.ptr),
+})
 N = W * H
 alg = {"me": 4 * N, "recon": 9 * N + 16 * N // 16, "deblock": 6 * N + N,
-       "pad": 2 * (2 * 128 * (W + H + 256) + 4 * 64 * (W // 2 + H // 2 + 128)), "ssd": 4 * N}
+       "pad": 2 * (2 * 128 * (W + H + 256) + 4 * 64 * (W // 2 + H // 2 + 128)), "ssd": 4 * N,
+       "import8": 1.5 * N * 3, "export8": 1.5 * N * 3, "export8d": 1.5 * N * 3, "crc": 3 * N,
+       "variance": 2 * N, "histogram": 4 * N}
 for k in which:
     us = timed(fns[k])
     print("%-8s %8.2f us  %7.0f GB/s algorithmic" % (k, us, alg[k] / us / 1e3))

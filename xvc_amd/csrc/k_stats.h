@@ -35,28 +35,45 @@ picture_import_kernel(PicView dst, ImportArgs a) {
   const size_t bps = a.wide ? 2 : 1;
   const uint8_t *row = a.src[c] + (size_t)ys * in_w * bps;
   uint16_t *out = d.p + (ptrdiff_t)y * d.stride;
-  const uint32_t last =
-      a.wide ? (uint32_t)row[2 * (in_w - 1)] | ((uint32_t)row[2 * (in_w - 1) + 1] << 8)
-             : row[in_w - 1];
   for (int x0 = threadIdx.x * 8; x0 < d.w; x0 += 256 * 8) {
     uint16_t v[8];
     if (x0 + 8 <= in_w) {
+      const uint8_t *sp = row + bps * x0;
       if (a.wide) {
-        const StU16x8 s = *reinterpret_cast<const StU16x8 *>(row + 2 * x0);
+        uint32_t q[4];
+        if ((reinterpret_cast<uintptr_t>(sp) & 3) == 0) {  // the usual case: dword loads
+          const uint4 t = *reinterpret_cast<const uint4 *>(sp);
+          q[0] = t.x; q[1] = t.y; q[2] = t.z; q[3] = t.w;
+        } else {
+          const StU16x8 t = *reinterpret_cast<const StU16x8 *>(sp);
 #pragma unroll
-        for (int k = 0; k < 8; k++) v[k] = (uint16_t)(s.v[k] << a.upshift);
+          for (int k = 0; k < 4; k++) q[k] = (uint32_t)t.v[2 * k] | ((uint32_t)t.v[2 * k + 1] << 16);
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+          v[k] = (uint16_t)(((q[k >> 1] >> (16 * (k & 1))) & 0xffffu) << a.upshift);
       } else {
-        const StU8x8 s = *reinterpret_cast<const StU8x8 *>(row + x0);
+        uint32_t q[2];
+        if ((reinterpret_cast<uintptr_t>(sp) & 3) == 0) {
+          const uint2 t = *reinterpret_cast<const uint2 *>(sp);
+          q[0] = t.x; q[1] = t.y;
+        } else {
+          const StU8x8 t = *reinterpret_cast<const StU8x8 *>(sp);
 #pragma unroll
-        for (int k = 0; k < 8; k++) v[k] = (uint16_t)((uint32_t)s.v[k] << a.upshift);
+          for (int k = 0; k < 2; k++)
+            q[k] = (uint32_t)t.v[4 * k] | ((uint32_t)t.v[4 * k + 1] << 8) |
+                   ((uint32_t)t.v[4 * k + 2] << 16) | ((uint32_t)t.v[4 * k + 3] << 24);
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+          v[k] = (uint16_t)(((q[k >> 2] >> (8 * (k & 3))) & 0xffu) << a.upshift);
       }
-    } else {
+    } else {  // the chunk that holds the last input column, and the padding
 #pragma unroll
       for (int k = 0; k < 8; k++) {
-        const int x = x0 + k;
-        uint32_t s = last;
-        if (x < in_w)
-          s = a.wide ? (uint32_t)row[2 * x] | ((uint32_t)row[2 * x + 1] << 8) : row[x];
+        const int x = x0 + k < in_w ? x0 + k : in_w - 1;
+        const uint32_t s =
+            a.wide ? (uint32_t)row[2 * x] | ((uint32_t)row[2 * x + 1] << 8) : row[x];
         v[k] = (uint16_t)(s << a.upshift);
       }
     }
@@ -202,12 +219,16 @@ picture_export_kernel(PicView src, ExportArgs a) {
 
 // ---- CRC-16 (x^16 + x^12 + x^5 + 1), the reference's bit-serial register ----
 // The register after N message bits is (preset * x^N + M(x)) mod P, and the 16
-// trailing zero bits multiply by x^16: linear over GF(2), so a plane is cut into
-// pieces, each piece's M_k(x) mod P is computed independently and the pieces
-// are joined with multiplications by powers of x.
+// trailing zero bits multiply by x^16: linear over GF(2).  So every row's
+// M_row(x) mod P is computed by its own wave, multiplied by x^(number of
+// message bits that follow the row, + 16) and XOR-ed into the result word; the
+// preset term is added by the wave of the first row.  All powers of x come from
+// a table of x^(2^i) mod P passed with the launch (host-computed constants).
 #define XVC_CRC_POLY 0x1021u
 
-__device__ __forceinline__ uint32_t crc_mulmod(uint32_t a, uint32_t b) {
+struct CrcPow2 { uint16_t v[48]; };  // x^(2^i) mod P
+
+__host__ __device__ __forceinline__ uint32_t crc_mulmod(uint32_t a, uint32_t b) {
   uint32_t r = 0;
 #pragma unroll
   for (int i = 15; i >= 0; i--) {
@@ -218,43 +239,44 @@ __device__ __forceinline__ uint32_t crc_mulmod(uint32_t a, uint32_t b) {
   return r;
 }
 
-// x^n mod P
-__device__ __forceinline__ uint32_t crc_xpow(unsigned long long n) {
-  uint32_t r = 1, sq = 2;  // sq = x^(2^i)
-  while (n) {
-    if (n & 1ull) r = crc_mulmod(r, sq);
-    sq = crc_mulmod(sq, sq);
-    n >>= 1;
-  }
+// x^n mod P, computed by a whole wave: lane i contributes x^(2^i) if bit i of n
+// is set, then a 6-level product tree.  Every lane returns the result.
+__device__ __forceinline__ uint32_t crc_xpow_wave(unsigned long long n, const CrcPow2 &t,
+                                                  int lane) {
+  uint32_t r = (lane < 48 && ((n >> lane) & 1ull)) ? t.v[lane] : 1u;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) r = crc_mulmod(r, __shfl_xor(r, d, XVC_WAVE));
   return r;
 }
 
-// grid: (rows, 3); block 64 (one wave per row).  row_crc[row] = M_row(x) mod P.
-// Lane t of a 64-lane window owns 16 samples; windows are aligned to the END of
-// the row so that the incomplete one comes first, where missing samples are
-// leading zeros and change nothing.
-__global__ void __launch_bounds__(64)
-crc_rows_kernel(PicView pic, int wide, uint32_t *row_crc) {
+struct CrcArgs {
+  CrcPow2 pow2;
+  int wide;   // 16 message bits per sample (bit depth > 8), else 8
+  int mode;   // 0: one value over Y,U,V; 1: one per plane
+};
+
+// grid: (ceil(rows / 4), 3); block 256: one wave per row.  Lane t of a 64-lane
+// window owns 16 samples; windows are aligned to the END of the row so that
+// the incomplete one comes first, where missing samples are leading zeros and
+// change nothing.  acc[c or 0] ^= contribution of the row.
+__global__ void __launch_bounds__(256)
+crc_rows_kernel(PicView pic, CrcArgs a, uint32_t *acc_words) {
   __shared__ uint16_t tab[256];  // h * x^16 mod P
-  const int lane = threadIdx.x;
-  for (int i = lane; i < 256; i += 64) {
-    uint32_t r = (uint32_t)i << 8;
-    for (int b = 0; b < 8; b++) r = (r & 0x8000u) ? ((r << 1) ^ XVC_CRC_POLY) & 0xffffu : (r << 1) & 0xffffu;
-    tab[i] = (uint16_t)r;
+  {
+    uint32_t r = (uint32_t)threadIdx.x << 8;
+#pragma unroll
+    for (int b = 0; b < 8; b++)
+      r = (r & 0x8000u) ? ((r << 1) ^ XVC_CRC_POLY) & 0xffffu : (r << 1) & 0xffffu;
+    tab[threadIdx.x] = (uint16_t)r;
   }
   __syncthreads();
-  const int c = blockIdx.y, y = blockIdx.x;
+  const int lane = threadIdx.x & 63;
+  const int c = blockIdx.y, y = blockIdx.x * 4 + (threadIdx.x >> 6);
   const PlaneView p = pic.c[c];
   if (y >= p.h) return;
   const uint16_t *row = p.p + (ptrdiff_t)y * p.stride;
   const int w = p.w;
-  const int bits_lane = 16 * (wide ? 16 : 8);
-  // joining constants of the butterfly: x^(bits_lane << level)
-  uint32_t mul[6];
-  mul[0] = crc_xpow(bits_lane);
-#pragma unroll
-  for (int l = 1; l < 6; l++) mul[l] = crc_mulmod(mul[l - 1], mul[l - 1]);
-  const uint32_t mul_window = crc_mulmod(mul[5], mul[5]);  // x^(64 * bits_lane)
+  const int lb = a.wide ? 8 : 7;  // log2 of the message bits per lane (16 samples)
   const int n_win = (w + 1023) / 1024;
   uint32_t acc = 0;
   for (int k = 0; k < n_win; k++) {
@@ -274,82 +296,43 @@ crc_rows_kernel(PicView pic, int wide, uint32_t *row_crc) {
 #pragma unroll
       for (int i = 0; i < 16; i++) {
         r = tab[r >> 8] ^ ((r & 0xffu) << 8) ^ (v[i] & 0xffu);
-        if (wide) r = tab[r >> 8] ^ ((r & 0xffu) << 8) ^ (uint32_t)(v[i] >> 8);
+        if (a.wide) r = tab[r >> 8] ^ ((r & 0xffu) << 8) ^ (uint32_t)(v[i] >> 8);
       }
     }
     // butterfly: after level l lane t (t % 2^(l+1) == 0) holds the piece of
-    // 2^(l+1) lanes
+    // 2^(l+1) lanes; the right half is x^(lane bits << l) = pow2[lb + l] shorter
 #pragma unroll
     for (int l = 0; l < 6; l++) {
       const uint32_t right = __shfl_down(r, 1 << l, XVC_WAVE);
-      r = crc_mulmod(r, mul[l]) ^ right;
+      r = crc_mulmod(r, a.pow2.v[lb + l]) ^ right;
     }
-    acc = crc_mulmod(acc, mul_window) ^ r;  // meaningful in lane 0
+    acc = crc_mulmod(acc, a.pow2.v[lb + 6]) ^ r;  // meaningful in lane 0
   }
-  if (lane == 0) row_crc[(c == 0 ? 0 : (c == 1 ? pic.c[0].h : pic.c[0].h + pic.c[1].h)) + y] = acc;
+  acc = __shfl(acc, 0, XVC_WAVE);
+  // message bits after this row (+ the 16 zero bits), and the preset term
+  const unsigned long long bps = a.wide ? 16 : 8;
+  unsigned long long after = (unsigned long long)w * (p.h - 1 - y) * bps + 16;
+  unsigned long long before = (unsigned long long)w * y * bps;
+  if (a.mode == 0) {
+    for (int q = c + 1; q < 3; q++) after += (unsigned long long)pic.c[q].w * pic.c[q].h * bps;
+    for (int q = 0; q < c; q++) before += (unsigned long long)pic.c[q].w * pic.c[q].h * bps;
+  }
+  uint32_t out = crc_mulmod(acc, crc_xpow_wave(after, a.pow2, lane));
+  if (before == 0)  // first row of the message: preset * x^(N + 16)
+    out ^= crc_mulmod(0xffffu, crc_xpow_wave(after + (unsigned long long)w * bps, a.pow2, lane));
+  if (lane == 0) atomicXor(&acc_words[a.mode ? c : 0], out);
 }
 
-// grid 1; block 256.  Joins the row values of each plane (rows are equally
-// long), then the planes, adds the preset term and the 16 trailing zero bits.
-// mode 0: one value over Y,U,V -> 2 bytes; mode 1: one per plane -> 6 bytes
-// (high byte first).
-__global__ void __launch_bounds__(256)
-crc_fold_kernel(PicView pic, int wide, int mode, const uint32_t *row_crc, uint8_t *hash) {
-  __shared__ uint32_t red[256];
-  __shared__ uint32_t plane_crc[3];
+// grid 1; block 64: the result words -> hash bytes (high byte first); the words
+// are cleared for the next call.
+__global__ void crc_finish_kernel(int mode, uint32_t *acc_words, uint8_t *hash) {
   const int t = threadIdx.x;
-  int base = 0;
-  for (int c = 0; c < 3; c++) {
-    const int h = pic.c[c].h;
-    const unsigned long long row_bits = (unsigned long long)pic.c[c].w * (wide ? 16 : 8);
-    uint32_t mul[8];
-    mul[0] = crc_xpow(row_bits);
-#pragma unroll
-    for (int l = 1; l < 8; l++) mul[l] = crc_mulmod(mul[l - 1], mul[l - 1]);
-    const uint32_t mul_window = crc_mulmod(mul[7], mul[7]);
-    const int n_win = (h + 255) / 256;
-    uint32_t acc = 0;
-    for (int k = 0; k < n_win; k++) {
-      const int y = h - (n_win - k) * 256 + t;
-      __syncthreads();
-      red[t] = y >= 0 ? row_crc[base + y] : 0;
-      __syncthreads();
-#pragma unroll
-      for (int l = 0; l < 8; l++) {
-        uint32_t r = 0;
-        const bool act = (t & ((2 << l) - 1)) == 0;
-        if (act) r = crc_mulmod(red[t], mul[l]) ^ red[t + (1 << l)];
-        __syncthreads();
-        if (act) red[t] = r;
-        __syncthreads();
-      }
-      acc = crc_mulmod(acc, mul_window) ^ red[0];
-    }
-    if (t == 0) plane_crc[c] = acc;
-    base += h;
+  if (t < (mode ? 3 : 1)) {
+    const uint32_t r = acc_words[t];
+    hash[2 * t] = (uint8_t)(r >> 8);
+    hash[2 * t + 1] = (uint8_t)(r & 0xff);
   }
-  __syncthreads();
-  if (t == 0) {
-    unsigned long long bits[3];
-    for (int c = 0; c < 3; c++)
-      bits[c] = (unsigned long long)pic.c[c].w * pic.c[c].h * (wide ? 16 : 8);
-    const uint32_t x16 = crc_xpow(16);
-    if (mode == 1) {
-      for (int c = 0; c < 3; c++) {
-        uint32_t r = crc_mulmod(0xffffu, crc_xpow(bits[c])) ^ plane_crc[c];
-        r = crc_mulmod(r, x16);
-        hash[2 * c] = (uint8_t)(r >> 8);
-        hash[2 * c + 1] = (uint8_t)(r & 0xff);
-      }
-    } else {
-      uint32_t m = crc_mulmod(plane_crc[0], crc_xpow(bits[1])) ^ plane_crc[1];
-      m = crc_mulmod(m, crc_xpow(bits[2])) ^ plane_crc[2];
-      uint32_t r = crc_mulmod(0xffffu, crc_xpow(bits[0] + bits[1] + bits[2])) ^ m;
-      r = crc_mulmod(r, x16);
-      hash[0] = (uint8_t)(r >> 8);
-      hash[1] = (uint8_t)(r & 0xff);
-    }
-  }
+  if (t < 3) acc_words[t] = 0;
 }
 
 // ---- AQP variance statistic -------------------------------------------------

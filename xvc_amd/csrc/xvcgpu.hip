@@ -974,12 +974,25 @@ xvcgpu_status xvcgpu_picture_export(xvcgpu_ctx *ctx, const xvcgpu_picture *pic,
 xvcgpu_status xvcgpu_picture_crc(xvcgpu_ctx *ctx, const xvcgpu_picture *pic, int mode,
                                  uint8_t *d_hash) {
   if (!ctx || !pic || !d_hash || mode < 0 || mode > 1) return XVCGPU_INVALID_ARGUMENT;
-  uint32_t *row_words = ctx->d_stats + kStatsHistWords;
-  const int wide = pic->bd > 8;
-  hipLaunchKernelGGL(crc_rows_kernel, dim3(pic->h, 3), dim3(64), 0, ctx->stream, pic->v,
-                     wide, row_words);
-  hipLaunchKernelGGL(crc_fold_kernel, dim3(1), dim3(256), 0, ctx->stream, pic->v, wide,
-                     mode, row_words, d_hash);
+  static const CrcPow2 pow2 = [] {
+    CrcPow2 t;
+    uint32_t v = 2;  // x
+    for (int i = 0; i < 48; i++) {
+      t.v[i] = (uint16_t)v;
+      v = crc_mulmod(v, v);
+    }
+    return t;
+  }();
+  CrcArgs a;
+  a.pow2 = pow2;
+  a.wide = pic->bd > 8;
+  a.mode = mode;
+  // three result words at the start of the (always re-zeroed) histogram scratch
+  uint32_t *words = ctx->d_stats;
+  hipLaunchKernelGGL(crc_rows_kernel, dim3((pic->h + 3) / 4, 3), dim3(256), 0, ctx->stream,
+                     pic->v, a, words);
+  hipLaunchKernelGGL(crc_finish_kernel, dim3(1), dim3(64), 0, ctx->stream, mode, words,
+                     d_hash);
   CHECK_LAUNCH(ctx, "picture_crc");
   return XVCGPU_OK;
 }
