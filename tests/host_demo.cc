@@ -1,5 +1,6 @@
 // host_demo.cc -- compiles the C++ host layer (xvc_amd/host/xvc_gpu_ops.h)
-// against libxvcgpu.so and exercises it: PadBorder + SAD through the
+// against libxvcgpu.so and exercises it: PadBorder + SAD, the sample
+// conversions, the CRC, the AQP statistic and the LIC test through the
 // reference-named classes.  Exit 0 = OK, 3 = no gfx950 device (no fallback).
 #include <cstdio>
 #include <cstdlib>
@@ -36,7 +37,42 @@ int main() {
         sad += std::labs(static_cast<long>(y[yy * w + xx]) - y2[yy * w + xx]);
     const unsigned long long expect = static_cast<unsigned long long>(sad) >> (bd - 8);
     std::printf("sad %llu expect %llu\n", static_cast<unsigned long long>(d[0]), expect);
-    return d[0] == expect ? 0 : 1;
+    if (d[0] != expect) return 1;
+
+    // 8-bit application picture -> internal 10 bit -> back (both down-shifts)
+    std::vector<uint8_t> in8(w * h * 3 / 2), out8;
+    for (size_t i = 0; i < in8.size(); i++) in8[i] = static_cast<uint8_t>((i * 29 + 7) & 255);
+    xvc_gpu::Resampler resampler(ctx);
+    xvc_gpu::Picture p(ctx, w, h, bd);
+    resampler.ConvertFrom(w, h, 8, in8.data(), &p);
+    for (int dither = 0; dither < 2; dither++) {
+      resampler.ConvertTo(p, w, h, 8, dither != 0, &out8);
+      if (out8 != in8) return 4;
+    }
+    // CRC of the internal picture against the bit-serial definition
+    xvc_gpu::Checksum checksum(ctx, xvc_gpu::Checksum::Mode::kMinOverhead);
+    checksum.HashPicture(p);
+    unsigned crc = 0xffff;
+    for (size_t i = 0; i < in8.size() + 1; i++) {
+      const unsigned sample = i < in8.size() ? static_cast<unsigned>(in8[i]) << 2 : 0;
+      for (int bit = 0; bit < 16; bit++) {   // low byte first, each MSB first
+        const unsigned msb = (crc >> 15) & 1;
+        const unsigned b = i < in8.size() ? (sample >> ((bit < 8 ? 7 : 23) - bit)) & 1 : 0;
+        crc = (((crc << 1) + b) & 0xffff) ^ (msb * 0x1021);
+      }
+    }
+    const std::vector<uint8_t> hash = checksum.GetHash();
+    std::printf("crc %02x%02x expect %04x\n", hash[0], hash[1], crc);
+    if (hash.size() != 2 || hash[0] != (crc >> 8) || hash[1] != (crc & 0xff)) return 5;
+    // AQP offsets (one per 16x16 CTU here) and the LIC test
+    xvc_gpu::AdaptiveQp aqp(ctx, 13);
+    const std::vector<int> dqp = aqp.CalcDeltaQpFromVariance(p, w, h, bd, 16);
+    if (dqp.size() != static_cast<size_t>((w / 16) * (h / 16))) return 6;
+    for (size_t i = 0; i < dqp.size(); i++)
+      if (dqp[i] < -3 || dqp[i] > 7) return 6;
+    if (xvc_gpu::DetermineAllowLic(ctx, p, p, w, h)) return 7;
+    if (!xvc_gpu::DetermineAllowLic(ctx, p, a, w, h)) return 7;
+    return 0;
   } catch (const xvc_gpu::Error &e) {
     std::printf("xvc_gpu error %d: %s\n", static_cast<int>(e.status), e.what());
     return e.status == XVCGPU_NO_DEVICE ? 3 : 2;

@@ -12,6 +12,14 @@
 //     (transform_encoder.cc:203)
 //   DeblockingFilter::DeblockPicture                xvc_gpu::DeblockingFilter::DeblockPicture
 //     (deblocking_filter.cc:56)
+//   Resampler::ConvertFrom / ConvertTo              xvc_gpu::Resampler::ConvertFrom / ConvertTo
+//     (resample.cc:32, :96; no resizing)
+//   Checksum(kCrc, mode)::HashPicture               xvc_gpu::Checksum::HashPicture
+//     (checksum.cc:30-92)
+//   CuEncoder::CalcDeltaQpFromVariance              xvc_gpu::AdaptiveQp::CalcDeltaQpFromVariance
+//     (cu_encoder.cc:308-363)
+//   PictureEncoder::DetermineAllowLic               xvc_gpu::DetermineAllowLic
+//     (picture_encoder.cc:230-281)
 //
 // Errors: the reference asserts internally and returns enum codes at its C API
 // (xvcenc.h:34-45); here every failing xvcgpu call throws xvc_gpu::Error inside
@@ -19,6 +27,7 @@
 #ifndef XVC_AMD_HOST_XVC_GPU_OPS_H_
 #define XVC_AMD_HOST_XVC_GPU_OPS_H_
 
+#include <cmath>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -266,6 +275,99 @@ class DeblockingFilter {
   Picture *rec_;
   int beta_, tc_, sub_;
 };
+
+// Resampler::ConvertFrom / ConvertTo for the cases without resizing: packed
+// planar 4:2:0 bytes <-> the device picture at its internal bit depth.
+class Resampler {
+ public:
+  explicit Resampler(const Context &ctx) : ctx_(ctx) {}
+  // src_bytes: Y,U,V back to back, rows tightly packed (xvc_enc_pic_buffer
+  // layout); the picture may be larger (internal size rounded up): padded by
+  // repetition as CopyFromBytesWithPadding does.
+  void ConvertFrom(int src_width, int src_height, int src_bitdepth,
+                   const uint8_t *src_bytes, Picture *out_pic) const {
+    const size_t n = static_cast<size_t>(src_width) * src_height * 3 / 2 *
+                     (src_bitdepth > 8 ? 2 : 1);
+    DeviceArray<uint8_t> d(ctx_, n);
+    ctx_.Check(xvcgpu_memcpy_h2d(ctx_.get(), d.data(), src_bytes, n));
+    ctx_.Check(xvcgpu_picture_import(ctx_.get(), out_pic->get(), d.data(), src_width,
+                                     src_height, src_bitdepth));
+    ctx_.Sync();
+  }
+  void ConvertTo(const Picture &src_pic, int out_width, int out_height,
+                 int out_bitdepth, bool dither, std::vector<uint8_t> *out_bytes) const {
+    const size_t n = static_cast<size_t>(out_width) * out_height * 3 / 2 *
+                     (out_bitdepth > 8 ? 2 : 1);
+    DeviceArray<uint8_t> d(ctx_, n);
+    ctx_.Check(xvcgpu_picture_export(ctx_.get(), src_pic.get(), d.data(), out_width,
+                                     out_height, out_bitdepth, dither ? 1 : 0));
+    *out_bytes = d.ToHost();
+  }
+
+ private:
+  const Context &ctx_;
+};
+
+// Checksum(Method::kCrc, mode)::HashPicture + GetHash.  (Method::kMd5, the
+// reference's default, is a serial chain: it stays on the host.)
+class Checksum {
+ public:
+  enum class Mode { kMinOverhead = 0, kMaxRobust = 1 };
+  Checksum(const Context &ctx, Mode mode) : ctx_(ctx), mode_(mode) {}
+  void HashPicture(const Picture &pic) {
+    DeviceArray<uint8_t> d(ctx_, 8);
+    ctx_.Check(xvcgpu_picture_crc(ctx_.get(), pic.get(), static_cast<int>(mode_), d.data()));
+    const std::vector<uint8_t> h = d.ToHost();
+    hash_.assign(h.begin(), h.begin() + (mode_ == Mode::kMaxRobust ? 6 : 2));
+  }
+  std::vector<uint8_t> GetHash() const { return hash_; }
+
+ private:
+  const Context &ctx_;
+  Mode mode_;
+  std::vector<uint8_t> hash_;
+};
+
+// CuEncoder::CalcDeltaQpFromVariance for all CTUs of a picture at once: the
+// device computes the per-CTU block-variance statistic, the host the
+// floating-point part (cu_encoder.cc:359-363).
+class AdaptiveQp {
+ public:
+  AdaptiveQp(const Context &ctx, int aqp_strength) : ctx_(ctx), strength_(aqp_strength) {}
+  // -> one QP offset per CTU in raster order
+  std::vector<int> CalcDeltaQpFromVariance(const Picture &orig_pic, int width, int height,
+                                           int bitdepth, int ctu_size) const {
+    const size_t nb = static_cast<size_t>((width + 15) / 16) * ((height + 15) / 16);
+    const size_t nc = static_cast<size_t>((width + ctu_size - 1) / ctu_size) *
+                      ((height + ctu_size - 1) / ctu_size);
+    DeviceArray<uint64_t> var16(ctx_, nb), ctu_var(ctx_, nc);
+    ctx_.Check(xvcgpu_variance_map(ctx_.get(), orig_pic.get(), var16.data(), ctu_size,
+                                   ctu_var.data()));
+    const std::vector<uint64_t> v = ctu_var.ToHost();
+    std::vector<int> dqp(nc);
+    const double k = 1.0 * strength_ / 10;
+    for (size_t i = 0; i < nc; i++) {
+      const double d = k * (1.5 * std::log(static_cast<double>(v[i])) - 15 - 2 * (bitdepth - 8));
+      const int q = static_cast<int>(d);
+      dqp[i] = q < -3 ? -3 : (q > 7 ? 7 : q);
+    }
+    return dqp;
+  }
+
+ private:
+  const Context &ctx_;
+  int strength_;
+};
+
+// PictureEncoder::DetermineAllowLic for one reference picture: the histogram
+// distance comes from the device, the threshold test is the reference's.
+inline bool DetermineAllowLic(const Context &ctx, const Picture &orig_pic,
+                              const Picture &ref_orig_pic, int width, int height) {
+  DeviceArray<int64_t> d(ctx, 1);
+  ctx.Check(xvcgpu_histogram_distance(ctx.get(), orig_pic.get(), ref_orig_pic.get(),
+                                      d.data()));
+  return d.ToHost()[0] > static_cast<int>(0.06 * width * height);
+}
 
 // Walks a reference-style CU map (anything exposing the PictureData /
 // CodingUnit accessors named below; picture_data.h:102-107,
