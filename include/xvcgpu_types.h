@@ -128,6 +128,27 @@ typedef struct xvcgpu_mc_affine_block {
   int32_t mv[3][2];    /* [corner][x,y]                                    */
 } xvcgpu_mc_affine_block;
 
+/* One intra prediction job = IntraPrediction::FillReferenceState + Predict
+ * (intra_prediction.cc:81-147) for one component of one CU, 67-mode set.
+ * Positions / sizes are in samples of `comp`.  The neighbour fields are what
+ * IntraPrediction::DetermineNeighbors (:688-705) derives from the CU map:
+ * which already reconstructed neighbours exist (the prediction reads the
+ * reconstruction picture around the block). */
+#define XVC_INTRA_HAS_ABOVE_LEFT 1
+#define XVC_INTRA_HAS_ABOVE 2
+#define XVC_INTRA_HAS_LEFT 4
+#define XVC_INTRA_NUM_MODES 67 /* 0 planar, 1 DC, 2..66 angular (18 hor, 50 ver) */
+typedef struct xvcgpu_intra_block {
+  int16_t x, y;        /* position in the component plane                  */
+  uint8_t w, h;        /* size in the component plane, {4,...,64}          */
+  uint8_t comp;        /* 0 = Y (reference filtering / edge filters), 1, 2 */
+  uint8_t mode;        /* IntraMode 0..66 (ignored by the all-modes search) */
+  uint8_t neighbors;   /* XVC_INTRA_HAS_* bits                              */
+  uint8_t above_right; /* GetCuSizeAboveRight: available samples, 0..h     */
+  uint8_t below_left;  /* GetCuSizeBelowLeft: available samples, 0..w      */
+  uint8_t reserved;
+} xvcgpu_intra_block;
+
 /* One residual-pipeline job = one (CU, component) pair, i.e. one call of
  * TransformEncoder::TransformAndReconstruct (transform_encoder.cc:203-285)
  * with the non-RDO quantiser. Positions/sizes are in samples of `comp`. */

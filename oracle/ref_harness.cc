@@ -60,6 +60,8 @@
 #include "xvc_enc_lib/sample_metric.h"
 /* member templates (SubpelSearch<>, ...) are defined only in the .cc */
 #include "xvc_enc_lib/inter_search.cc"
+/* IntraPrediction::NeighborState (argument of ComputeRefSamples) likewise */
+#include "xvc_common_lib/intra_prediction.cc"
 #undef private
 #undef protected
 
@@ -1068,5 +1070,78 @@ int xr_allow_lic(int bd, int w, int h, const uint16_t *a, ptrdiff_t sa,
   const bool allow = enc.DetermineAllowLic(PicturePredictionType::kUni, rpl);
   r.disable_ext2_inter_local_illumination_comp = saved;
   return allow ? 1 : 0;
+}
+
+/* ---- intra prediction (oracle: xvc_oracle_intra.c) ---- */
+static void IntraRefState(IntraPrediction *ip, int bd, const xvcgpu_intra_block *b,
+                          const uint16_t *rec, ptrdiff_t rs,
+                          IntraPrediction::RefState *state) {
+  IntraPrediction::NeighborState nb;
+  nb.has_above_left = (b->neighbors & XVC_INTRA_HAS_ABOVE_LEFT) != 0;
+  nb.has_above = (b->neighbors & XVC_INTRA_HAS_ABOVE) != 0;
+  nb.has_left = (b->neighbors & XVC_INTRA_HAS_LEFT) != 0;
+  nb.has_above_right = b->above_right;
+  nb.has_below_left = b->below_left;
+  state->ref_samples.fill(0);
+  state->ref_filtered.fill(0);
+  ip->ComputeRefSamples(b->w, b->h, nb, rec + b->y * rs + b->x, rs,
+                        &state->ref_samples[0], IntraPrediction::kRefSampleStride_);
+  if (b->comp == 0)
+    ip->FilterRefSamples(b->w, b->h, &state->ref_samples[0], &state->ref_filtered[0],
+                         IntraPrediction::kRefSampleStride_);
+  (void)bd;
+}
+
+/* IntraPrediction::ComputeRefSamples (+ FilterRefSamples for luma) + Predict for
+ * one block; the neighbour availability comes from the job (the reference
+ * derives it from its CU map in DetermineNeighbors). */
+void xr_intra_pred_block(int bd, const xvcgpu_intra_block *b, int pic_w, int pic_h,
+                         const uint16_t *rec, ptrdiff_t rs, uint16_t *pred, ptrdiff_t ps) {
+  const int cs = b->comp ? 1 : 0;
+  PictureData pic_data(ChromaFormat::k420, pic_w, pic_h, bd);
+  CodingUnit *cu = pic_data.CreateCu(CuTree::Primary, 1, b->x << cs, b->y << cs,
+                                     b->w << cs, b->h << cs);
+  YuvPicture rec_pic(ChromaFormat::k420, 8, 8, bd, false, 0, 0);
+  IntraPrediction ip(bd);
+  IntraPrediction::RefState state;
+  IntraRefState(&ip, bd, b, rec, rs, &state);
+  /* into a 64x64 scratch buffer, as the reference's callers do: horizontal
+   * modes of non-square blocks are first written transposed, i.e. beyond the
+   * block's h rows (intra_prediction.cc:447-451) */
+  SampleBufferStorage tmp(64, 64);
+  ip.Predict(static_cast<IntraMode>(b->mode), *cu, YuvComponent(b->comp), state, rec_pic,
+             &tmp);
+  for (int y = 0; y < b->h; y++)
+    std::memcpy(pred + (b->y + y) * ps + b->x, tmp.GetDataPtr() + y * tmp.GetStride(),
+                sizeof(Sample) * b->w);
+}
+
+/* The prediction + SATD loop of IntraSearch::DetermineSlowIntraModes for all 67
+ * luma modes (no bits, no sorting). */
+void xr_intra_satd_modes(int bd, const xvcgpu_intra_block *b, int pic_w, int pic_h,
+                         const uint16_t *orig, ptrdiff_t os, const uint16_t *rec,
+                         ptrdiff_t rs, uint32_t *dist) {
+  PictureData pic_data(ChromaFormat::k420, pic_w, pic_h, bd);
+  CodingUnit *cu = pic_data.CreateCu(CuTree::Primary, 1, b->x, b->y, b->w, b->h);
+  YuvPicture rec_pic(ChromaFormat::k420, 8, 8, bd, false, 0, 0);
+  YuvPicture orig_pic(ChromaFormat::k420, pic_w, pic_h, bd, false, 0, 0);
+  for (int y = 0; y < pic_h; y++)
+    std::memcpy(orig_pic.GetSamplePtr(YuvComponent::kY, 0, y), orig + y * os,
+                sizeof(Sample) * pic_w);
+  IntraPrediction ip(bd);
+  IntraPrediction::RefState state;
+  IntraRefState(&ip, bd, b, rec, rs, &state);
+  SampleMetric satd(Simd(bd).sample_metric, bd, MetricType::kSatd);
+  SampleBufferStorage pred(64, 64);
+  Qp qp = MakeQp(32, bd);
+  for (int m = 0; m < XVC_INTRA_NUM_MODES; m++) {
+    ip.Predict(static_cast<IntraMode>(m), *cu, YuvComponent::kY, state, rec_pic, &pred);
+    /* CompareSample(cu, comp, orig_pic, pred) minus the CU's Qp object (the
+     * SATD does not use it) */
+    dist[m] = static_cast<uint32_t>(satd.CompareSample(
+        qp, YuvComponent::kY, b->w, b->h,
+        orig_pic.GetSamplePtr(YuvComponent::kY, b->x, b->y),
+        orig_pic.GetStride(YuvComponent::kY), pred.GetDataPtr(), pred.GetStride()));
+  }
 }
 }  // extern "C"

@@ -261,6 +261,24 @@ int64_t xo_histogram_distance(int bitdepth, int w, int h, const uint16_t *a,
                               ptrdiff_t sa, const uint16_t *b, ptrdiff_t sb);
 int xo_allow_lic(int64_t histogram_distance, int w, int h);
 
+/* ---- intra prediction + SATD mode pre-selection (xvc_oracle_intra.c; SURVEY
+ * 8f N3): IntraPrediction (xvc_common_lib/intra_prediction.cc:81-147,
+ * :342-558, :688-871) and the distortions of
+ * IntraSearch::DetermineSlowIntraModes (xvc_enc_lib/intra_search.cc:189-305),
+ * 67-mode set. ---- */
+#define XO_INTRA_REF_STRIDE 129
+void xo_intra_ref_samples(int bitdepth, int w, int h, int neighbors, int above_right,
+                          int below_left, const uint16_t *src, ptrdiff_t stride,
+                          uint16_t *ref, uint16_t *ref_filtered);
+int xo_intra_use_filtered(int w, int h, int mode);
+void xo_intra_predict(int bitdepth, int is_luma, int mode, int w, int h,
+                      const uint16_t *ref, const uint16_t *ref_filtered, uint16_t *out,
+                      ptrdiff_t os);
+void xo_intra_pred_block(int bitdepth, const xvcgpu_intra_block *b, const uint16_t *rec,
+                         ptrdiff_t rs, uint16_t *pred, ptrdiff_t ps);
+void xo_intra_satd_modes(int bitdepth, const xvcgpu_intra_block *b, const uint16_t *orig,
+                         ptrdiff_t os, const uint16_t *rec, ptrdiff_t rs, uint32_t *dist);
+
 /* Transform matrix access (transform_data.cc, high-precision tables) for
  * table-equality tests: returns pointer to N*N int16 row-major, or NULL. */
 const int16_t *xo_transform_matrix(int tx_type, int size);

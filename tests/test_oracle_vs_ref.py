@@ -654,3 +654,59 @@ def test_lic_histogram_distance(libs, bd):
         hb = np.bincount(b.reshape(-1), minlength=1 << bd).astype(np.int64)
         assert d == int(np.abs(ha - hb).sum())
         assert st.xo_allow_lic(xo, d, w, h) == st.xr_allow_lic(xr, bd, a, b)
+
+
+# ---- intra prediction + SATD mode pre-selection ----
+@pytest.mark.parametrize("bd", [8, 10, 12])
+@pytest.mark.parametrize("comp", [0, 1])
+def test_intra_prediction(libs, bd, comp):
+    """IntraPrediction::ComputeRefSamples / FilterRefSamples / Predict for all
+    67 modes on blocks with every neighbour configuration."""
+    import oracle_intra as oi
+    xo, xr = libs
+    rng = np.random.default_rng(800 + bd + comp)
+    pw, ph = (160, 128) if comp == 0 else (80, 64)
+    rec = rnd_samples(rng, bd, ph, pw, True)
+    sizes = (4, 8, 16, 32, 64) if comp == 0 else (2, 4, 8, 16, 32)
+    jobs = oi.random_jobs(rng, pw, ph, comp, 60, sizes)
+    n = 0
+    for j in jobs:
+        for mode in ([0, 1, 2, 18, 34, 50, 66] + list(rng.integers(2, 67, 10))):
+            j["mode"] = mode
+            exp = oi.pred_block(xr, "xr", bd, j, rec, pw << (comp > 0), ph << (comp > 0))
+            got = oi.pred_block(xo, "xo", bd, j, rec, pw, ph)
+            assert np.array_equal(got, exp), (j, mode)
+            n += 1
+    assert n == 60 * 17
+
+
+def test_intra_prediction_all_modes_all_sizes(libs):
+    import oracle_intra as oi
+    xo, xr = libs
+    rng = np.random.default_rng(830)
+    bd, pw, ph = 10, 192, 192
+    rec = rnd_samples(rng, bd, ph, pw, False)
+    for w in (4, 8, 16, 32, 64):
+        for h in (4, 8, 16, 32, 64):
+            j = np.zeros(1, oi.INTRA_DTYPE)[0]
+            j["x"], j["y"], j["w"], j["h"] = 64, 64, w, h
+            j["neighbors"], j["above_right"], j["below_left"] = 7, h, w
+            for mode in range(67):
+                j["mode"] = mode
+                assert np.array_equal(oi.pred_block(xo, "xo", bd, j, rec, pw, ph),
+                                      oi.pred_block(xr, "xr", bd, j, rec, pw, ph)), (w, h, mode)
+
+
+@pytest.mark.parametrize("bd", [8, 10])
+def test_intra_satd_modes(libs, bd):
+    import oracle_intra as oi
+    xo, xr = libs
+    rng = np.random.default_rng(840 + bd)
+    pw, ph = 160, 128
+    orig, rec = make_pics(rng, bd, pw, ph, 0, motion=(1, 0), noise=6)
+    for j in oi.random_jobs(rng, pw, ph, 0, 40):
+        exp = oi.satd_modes(xr, "xr", bd, j, orig, rec)
+        got = oi.satd_modes(xo, "xo", bd, j, orig, rec)
+        assert np.array_equal(got, exp), j
+        if j["neighbors"] == 7:
+            assert len(set(exp.tolist())) > 8   # the modes really differ
