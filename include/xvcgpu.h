@@ -412,6 +412,29 @@ xvcgpu_status xvcgpu_variance_map(xvcgpu_ctx *ctx, const xvcgpu_picture *pic,
 xvcgpu_status xvcgpu_histogram_distance(xvcgpu_ctx *ctx, const xvcgpu_picture *a,
                                         const xvcgpu_picture *b, int64_t *d_out);
 
+/* ---- intra prediction and SATD mode pre-selection ----------------------- *
+ * IntraPrediction::FillReferenceState + Predict (intra_prediction.cc:81-147;
+ * ComputeRefSamples :707-848, FilterRefSamples :850-871, planar / DC / angular
+ * with the edge filters :365-558), 67-mode set with the default restriction
+ * flags, for a batch of independent blocks: each job reads its reference
+ * samples from `rec` (the neighbours it declares available must already be
+ * reconstructed there) and writes the prediction of job.mode into `pred` at
+ * the block's position.  Any component; comp 0 applies the luma rules
+ * (filtered references, edge filters up to 16x16).  LM chroma is not covered. */
+xvcgpu_status xvcgpu_intra_pred_batch(xvcgpu_ctx *ctx, const xvcgpu_picture *rec,
+                                      xvcgpu_picture *pred,
+                                      const xvcgpu_intra_block *d_jobs, int n);
+/* The prediction + SATD loop of IntraSearch::DetermineSlowIntraModes
+ * (intra_search.cc:189-305) for luma blocks, all 67 modes per job (the reference
+ * evaluates the even modes, then the odd neighbours of the best ones: any
+ * subset it asks for is in the table): d_dist[job * 67 + mode] =
+ * SampleMetric(kSatd)::CompareSample(original block, prediction).  The host
+ * adds bits * lambda_sqrt from its entropy coder state and sorts. */
+xvcgpu_status xvcgpu_intra_satd_batch(xvcgpu_ctx *ctx, const xvcgpu_picture *orig,
+                                      const xvcgpu_picture *rec,
+                                      const xvcgpu_intra_block *d_jobs, int n,
+                                      uint32_t *d_dist);
+
 /* ---- tables (host side, no GPU needed) ---------------------------------- *
  * The 8-bit-fraction transform matrices the kernels use (transform_data.cc:
  * 109-796), for table-equality tests. out: size*size int16 row-major. */

@@ -1,0 +1,167 @@
+"""GPU parity of intra prediction and the SATD mode pre-selection pass
+(k_intra.h) against the oracle, through the C-ABI.  Bit exact."""
+import numpy as np
+import pytest
+
+import oracle_intra as oi
+import oracle_lib as ol
+from helpers import make_pics, rnd_samples
+
+pytestmark = pytest.mark.gpu
+BL, BC = 128, 64
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    from xvc_amd import api
+    ctx = api.Context(0)
+    yield api, ctx
+    ctx.close()
+
+
+@pytest.fixture(scope="module")
+def xo():
+    return ol.Lib("xo")
+
+
+def upload(ctx, planes, w, h, bd):
+    P = ctx.picture(w, h, bd)
+    P.upload(planes)
+    return P
+
+
+@pytest.mark.parametrize("bd", [8, 10, 12])
+def test_intra_pred_batch(gpu, xo, bd):
+    """Random blocks of all sizes / neighbour configurations / modes in all
+    three components, one batch per component (blocks may overlap: compare
+    job by job in separate launches of non-overlapping subsets)."""
+    api, ctx = gpu
+    rng = np.random.default_rng(1000 + bd)
+    w, h = 320, 256
+    planes = [rnd_samples(rng, bd, hh, ww, True)
+              for ww, hh in ((w, h), (w // 2, h // 2), (w // 2, h // 2))]
+    R = upload(ctx, planes, w, h, bd)
+    P = ctx.picture(w, h, bd)
+    total = 0
+    for comp in (0, 1, 2):
+        pw, ph = planes[comp].shape[1], planes[comp].shape[0]
+        sizes = (4, 8, 16, 32, 64) if comp == 0 else (2, 4, 8, 16, 32)
+        jobs = oi.random_jobs(rng, pw, ph, comp, 160, sizes)
+        # greedy split into batches of mutually disjoint blocks
+        batches = []
+        def box(j):
+            return int(j["x"]), int(j["y"]), int(j["x"]) + int(j["w"]), int(j["y"]) + int(j["h"])
+
+        for j in jobs:
+            a = box(j)
+            for bt in batches:
+                if all(a[2] <= b[0] or b[2] <= a[0] or a[3] <= b[1] or b[3] <= a[1]
+                       for b in map(box, bt)):
+                    bt.append(j)
+                    break
+            else:
+                batches.append([j])
+        for bt in batches:
+            arr = np.array(bt, oi.INTRA_DTYPE)
+            ctx.intra_pred_batch(R, P, arr)
+            got = P.download()[comp]
+            for j in arr:
+                exp = oi.pred_block(xo, "xo", bd, j, planes[comp], pw, ph)
+                x0, y0, x1, y1 = box(j)
+                assert np.array_equal(got[y0:y1, x0:x1], exp), (comp, j)
+                total += 1
+    assert total == 480
+    R.destroy()
+    P.destroy()
+
+
+def test_intra_pred_all_modes_all_sizes(gpu, xo):
+    api, ctx = gpu
+    rng = np.random.default_rng(1030)
+    bd, w, h = 10, 256, 256
+    planes = [rnd_samples(rng, bd, hh, ww, False)
+              for ww, hh in ((w, h), (w // 2, h // 2), (w // 2, h // 2))]
+    R = upload(ctx, planes, w, h, bd)
+    P = ctx.picture(w, h, bd)
+    for bw in (4, 8, 16, 32, 64):
+        for bh in (4, 8, 16, 32, 64):
+            for (nb, ar, bl) in ((7, bh, bw), (7, 0, 0), (6, bh // 2, 0), (5, 0, bw // 2),
+                                 (0, 0, 0)):
+                for m0 in range(0, 67, 9):
+                    jobs = np.zeros(9, oi.INTRA_DTYPE)
+                    for k, j in enumerate(jobs):   # a 3x3 grid of disjoint blocks
+                        j["x"], j["y"] = 64 * (k % 3) + 8, 64 * (k // 3) + 8
+                        j["w"], j["h"], j["mode"] = bw, bh, min(66, m0 + k)
+                        j["neighbors"], j["above_right"], j["below_left"] = nb, ar, bl
+                        if int(j["x"]) + bw + ar > w or int(j["y"]) + bh + bl > h:
+                            j["above_right"], j["below_left"] = 0, 0
+                    ctx.intra_pred_batch(R, P, jobs)
+                    got = P.download()[0]
+                    for j in jobs:
+                        exp = oi.pred_block(xo, "xo", bd, j, planes[0], w, h)
+                        x, y = int(j["x"]), int(j["y"])
+                        assert np.array_equal(got[y:y + bh, x:x + bw], exp), j
+    R.destroy()
+    P.destroy()
+
+
+@pytest.mark.parametrize("bd", [8, 10])
+def test_intra_satd_batch(gpu, xo, bd):
+    api, ctx = gpu
+    rng = np.random.default_rng(1040 + bd)
+    w, h = 320, 256
+    orig, rec = make_pics(rng, bd, w, h, 0, motion=(1, 0), noise=6)
+    chroma = np.full((h // 2, w // 2), 1 << (bd - 1), np.uint16)
+    O = upload(ctx, [orig, chroma, chroma], w, h, bd)
+    R = upload(ctx, [rec, chroma, chroma], w, h, bd)
+    jobs = oi.random_jobs(rng, w, h, 0, 120)
+    got = ctx.intra_satd_batch(O, R, jobs)
+    assert got.shape == (120, 67)
+    for j, g in zip(jobs, got):
+        assert np.array_equal(g, oi.satd_modes(xo, "xo", bd, j, orig, rec)), j
+    O.destroy()
+    R.destroy()
+
+
+def test_intra_picture_of_ctus(gpu, xo):
+    """1080p: every 16x16 block of the picture as an intra job against the
+    previous reconstruction (full neighbours away from the edges): the table
+    of 8160 x 67 distortions equals the oracle's on a sample of rows, and the
+    best mode's prediction equals the original where the picture is flat."""
+    api, ctx = gpu
+    from xvc_amd import synth
+    w, h, bd = 1920, 1080, 10
+    clip = synth.SyntheticClip(w, h, bd)
+    f0, f1 = clip.frame(0), clip.frame(1)
+    O, R = upload(ctx, f1, w, h, bd), upload(ctx, f0, w, h, bd)
+    jobs = []
+    for y in range(0, h - 8, 16):
+        for x in range(0, w, 16):
+            bh = min(16, h - y)
+            nb = (oi.HAS_LEFT if x else 0) | (oi.HAS_ABOVE if y else 0) | \
+                (oi.HAS_ABOVE_LEFT if x and y else 0)
+            ar = min(bh, w - x - 16) if y else 0
+            bl = 0          # raster coding order: below-left not yet coded
+            jobs.append((x, y, 16, bh, 0, 0, nb, ar, bl, 0))
+    jobs = np.array(jobs, oi.INTRA_DTYPE)
+    got = ctx.intra_satd_batch(O, R, jobs)
+    assert got.shape == (len(jobs), 67)
+    rng = np.random.default_rng(3)
+    for k in rng.choice(len(jobs), 150, replace=False):
+        assert np.array_equal(got[k], oi.satd_modes(xo, "xo", bd, jobs[k], f1[0], f0[0])), k
+    O.destroy()
+    R.destroy()
+
+
+def test_intra_error_paths(gpu):
+    api, ctx = gpu
+    P, Q = ctx.picture(64, 48, 10), ctx.picture(64, 64, 10)
+    d = ctx.alloc(1024)
+    lib = ctx.lib
+    assert lib.xvcgpu_intra_pred_batch(ctx.h, P.h_pic, Q.h_pic, d.ptr, 1) == 10
+    assert lib.xvcgpu_intra_satd_batch(ctx.h, P.h_pic, Q.h_pic, d.ptr, 1, d.ptr) == 10
+    assert lib.xvcgpu_intra_satd_batch(ctx.h, P.h_pic, P.h_pic, None, 1, d.ptr) == 10
+    assert lib.xvcgpu_intra_pred_batch(ctx.h, P.h_pic, P.h_pic, None, 0) == 0
+    d.free()
+    P.destroy()
+    Q.destroy()

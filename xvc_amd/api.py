@@ -55,6 +55,11 @@ assert MCAFF_DTYPE.itemsize == 32
 MCM_DTYPE = np.dtype([("x", "<i2"), ("y", "<i2"), ("w", "u1"), ("h", "u1"),
                       ("metric", "u1"), ("qp", "i1"), ("mv_x", "<i4"), ("mv_y", "<i4")])
 assert MCM_DTYPE.itemsize == 16
+INTRA_DTYPE = np.dtype([("x", "<i2"), ("y", "<i2"), ("w", "u1"), ("h", "u1"),
+                        ("comp", "u1"), ("mode", "u1"), ("neighbors", "u1"),
+                        ("above_right", "u1"), ("below_left", "u1"), ("reserved", "u1")])
+assert INTRA_DTYPE.itemsize == 12
+INTRA_NUM_MODES = 67
 CAND_DTYPE = np.dtype([("x", "<i2"), ("y", "<i2"), ("w", "u1"), ("h", "u1"),
                        ("metric", "u1"), ("qp", "i1"), ("mv_x", "<i2"),
                        ("mv_y", "<i2")])
@@ -79,7 +84,8 @@ SYMBOLS = [
     "xvcgpu_fwd_transform_batch", "xvcgpu_inv_transform_batch",
     "xvcgpu_deblock", "xvcgpu_deblock_rows", "xvcgpu_picture_ssd", "xvcgpu_picture_ssd_rows",
     "xvcgpu_picture_import", "xvcgpu_picture_export", "xvcgpu_picture_crc",
-    "xvcgpu_variance_map", "xvcgpu_histogram_distance", "xvcgpu_get_transform_matrix",
+    "xvcgpu_variance_map", "xvcgpu_histogram_distance",
+    "xvcgpu_intra_pred_batch", "xvcgpu_intra_satd_batch", "xvcgpu_get_transform_matrix",
 ]
 
 _vp = C.c_void_p
@@ -175,6 +181,8 @@ def load_library():
         "xvcgpu_picture_crc": [_vp, _vp, C.c_int, _vp],
         "xvcgpu_variance_map": [_vp, _vp, _vp, C.c_int, _vp],
         "xvcgpu_histogram_distance": [_vp, _vp, _vp, _vp],
+        "xvcgpu_intra_pred_batch": [_vp, _vp, _vp, _vp, C.c_int],
+        "xvcgpu_intra_satd_batch": [_vp, _vp, _vp, _vp, C.c_int, _vp],
         "xvcgpu_get_transform_matrix": [C.c_int, C.c_int, _vp],
     }
     for name, args in sigs.items():
@@ -605,6 +613,27 @@ class Context:
         self._check(self.lib.xvcgpu_histogram_distance(self.h, a.h_pic, b.h_pic, d.ptr))
         out = int(d.to_array(np.int64, 1)[0])
         d.free()
+        return out
+
+    # ---- intra prediction ----
+    def intra_pred_batch(self, rec, pred, jobs):
+        jobs = np.ascontiguousarray(jobs, INTRA_DTYPE)
+        d = self.buffer(jobs)
+        self._check(self.lib.xvcgpu_intra_pred_batch(self.h, rec.h_pic, pred.h_pic, d.ptr,
+                                                     len(jobs)))
+        self.sync()
+        d.free()
+
+    def intra_satd_batch(self, orig, rec, jobs):
+        """-> uint32 [len(jobs), 67]: SATD of every luma mode's prediction"""
+        jobs = np.ascontiguousarray(jobs, INTRA_DTYPE)
+        d = self.buffer(jobs)
+        do = self.alloc(4 * INTRA_NUM_MODES * max(1, len(jobs)))
+        self._check(self.lib.xvcgpu_intra_satd_batch(self.h, orig.h_pic, rec.h_pic, d.ptr,
+                                                     len(jobs), do.ptr))
+        out = do.to_array(np.uint32, INTRA_NUM_MODES * len(jobs)).reshape(-1, INTRA_NUM_MODES)
+        d.free()
+        do.free()
         return out
 
     def picture_ssd(self, a, b, comp=0, shift_bd=8):

@@ -18,6 +18,7 @@
 #include "k_recon.h"
 #include "k_bipred.h"
 #include "k_stats.h"
+#include "k_intra.h"
 #include "xvcgpu_internal.h"
 
 namespace {
@@ -1033,5 +1034,34 @@ xvcgpu_status xvcgpu_histogram_distance(xvcgpu_ctx *ctx, const xvcgpu_picture *a
   return XVCGPU_OK;
 }
 
+
+/* ---- intra prediction / SATD mode pre-selection (k_intra.h) ---- */
+xvcgpu_status xvcgpu_intra_pred_batch(xvcgpu_ctx *ctx, const xvcgpu_picture *rec,
+                                      xvcgpu_picture *pred,
+                                      const xvcgpu_intra_block *d_jobs, int n) {
+  if (!ctx || !rec || !pred || (!d_jobs && n > 0) || n < 0) return XVCGPU_INVALID_ARGUMENT;
+  if (rec->w != pred->w || rec->h != pred->h || rec->bd != pred->bd)
+    return fail(ctx, XVCGPU_INVALID_ARGUMENT, "picture mismatch");
+  if (n == 0) return XVCGPU_OK;
+  hipLaunchKernelGGL(intra_pred_kernel, dim3(n), dim3(256), 0, ctx->stream, rec->v, pred->v,
+                     d_jobs, n);
+  CHECK_LAUNCH(ctx, "intra_pred_batch");
+  return XVCGPU_OK;
+}
+
+xvcgpu_status xvcgpu_intra_satd_batch(xvcgpu_ctx *ctx, const xvcgpu_picture *orig,
+                                      const xvcgpu_picture *rec,
+                                      const xvcgpu_intra_block *d_jobs, int n,
+                                      uint32_t *d_dist) {
+  if (!ctx || !orig || !rec || (!d_jobs && n > 0) || n < 0 || (!d_dist && n > 0))
+    return XVCGPU_INVALID_ARGUMENT;
+  if (rec->w != orig->w || rec->h != orig->h || rec->bd != orig->bd)
+    return fail(ctx, XVCGPU_INVALID_ARGUMENT, "picture mismatch");
+  if (n == 0) return XVCGPU_OK;
+  hipLaunchKernelGGL(intra_satd_kernel, dim3(n), dim3(256), 0, ctx->stream, orig->v, rec->v,
+                     d_jobs, n, d_dist);
+  CHECK_LAUNCH(ctx, "intra_satd_batch");
+  return XVCGPU_OK;
+}
 
 }  // extern "C"
