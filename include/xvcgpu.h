@@ -429,11 +429,14 @@ xvcgpu_status xvcgpu_intra_pred_batch(xvcgpu_ctx *ctx, const xvcgpu_picture *rec
  * evaluates the even modes, then the odd neighbours of the best ones: any
  * subset it asks for is in the table): d_dist[job * 67 + mode] =
  * SampleMetric(kSatd)::CompareSample(original block, prediction).  The host
- * adds bits * lambda_sqrt from its entropy coder state and sorts. */
+ * adds bits * lambda_sqrt from its entropy coder state and sorts.
+ * max_block_size: an upper bound (4..64) of the block sides in the batch; it
+ * sizes the on-chip tiles (batches of small blocks run at higher occupancy).
+ * Jobs with a larger side are not evaluated. */
 xvcgpu_status xvcgpu_intra_satd_batch(xvcgpu_ctx *ctx, const xvcgpu_picture *orig,
                                       const xvcgpu_picture *rec,
                                       const xvcgpu_intra_block *d_jobs, int n,
-                                      uint32_t *d_dist);
+                                      uint32_t *d_dist, int max_block_size);
 
 /* ---- tables (host side, no GPU needed) ---------------------------------- *
  * The 8-bit-fraction transform matrices the kernels use (transform_data.cc:

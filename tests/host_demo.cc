@@ -72,6 +72,22 @@ int main() {
       if (dqp[i] < -3 || dqp[i] > 7) return 6;
     if (xvc_gpu::DetermineAllowLic(ctx, p, p, w, h)) return 7;
     if (!xvc_gpu::DetermineAllowLic(ctx, p, a, w, h)) return 7;
+    // intra: the vertical mode (50) copies the row above the block; the SATD
+    // table of a block whose original equals that prediction is 0 at mode 50
+    std::vector<xvcgpu_intra_block> ib(1);
+    ib[0].x = 16; ib[0].y = 8; ib[0].w = 8; ib[0].h = 8; ib[0].comp = 0; ib[0].mode = 50;
+    ib[0].neighbors = XVC_INTRA_HAS_ABOVE | XVC_INTRA_HAS_LEFT | XVC_INTRA_HAS_ABOVE_LEFT;
+    ib[0].above_right = 8; ib[0].below_left = 8; ib[0].reserved = 0;
+    xvc_gpu::Picture pred(ctx, w, h, bd);
+    xvc_gpu::IntraPrediction(ctx).PredictBatch(a, &pred, ib);
+    std::vector<uint16_t> py(w * h), pu(w * h / 4), pv(w * h / 4);
+    uint16_t *pp[3] = {py.data(), pu.data(), pv.data()};
+    pred.Download(pp, st);
+    for (int yy = 8; yy < 16; yy++)       // (column 16 carries the edge filter)
+      for (int xx = 17; xx < 24; xx++)
+        if (py[yy * w + xx] != y[7 * w + xx]) return 8;
+    const std::vector<uint32_t> dist = xvc_gpu::IntraSearch(ctx).SatdAllModesBatch(pred, a, ib);
+    if (dist.size() != XVC_INTRA_NUM_MODES || dist[50] != 0 || dist[18] == 0) return 9;
     return 0;
   } catch (const xvc_gpu::Error &e) {
     std::printf("xvc_gpu error %d: %s\n", static_cast<int>(e.status), e.what());

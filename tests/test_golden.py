@@ -276,6 +276,21 @@ def test_oracle_frame_pass(xo):
             ref = rec
 
 
+def test_oracle_intra(xo):
+    """IntraPrediction / SATD-per-mode vectors of the reference (intra.npz)."""
+    import oracle_intra as oi
+    g = load("intra")
+    bd = 10
+    for j, exp in zip(g["jobs"], g["pred"]):
+        plane = g["rec"] if j["comp"] == 0 else g["chroma"]
+        got = oi.pred_block(xo, "xo", bd, j, np.ascontiguousarray(plane), plane.shape[1],
+                            plane.shape[0])
+        assert np.array_equal(got, exp[:int(j["h"]), :int(j["w"])]), j
+    orig, rec = np.ascontiguousarray(g["orig"]), np.ascontiguousarray(g["rec"])
+    for j, exp in zip(g["satd_jobs"], g["satd"]):
+        assert np.array_equal(oi.satd_modes(xo, "xo", bd, j, orig, rec), exp), j
+
+
 # ------------------------------------------------------------------------ GPU
 @pytest.fixture(scope="module")
 def gpu():
@@ -516,4 +531,25 @@ def test_gpu_frame_pass(gpu):
         fp.destroy()
     O.destroy()
     for p in pics:
+        p.destroy()
+
+
+@pytest.mark.gpu
+def test_gpu_intra(gpu):
+    api, ctx = gpu
+    g = load("intra")
+    bd = 10
+    h, w = g["rec"].shape
+    chroma = np.ascontiguousarray(g["chroma"])
+    R, O, P = ctx.picture(w, h, bd), ctx.picture(w, h, bd), ctx.picture(w, h, bd)
+    R.upload([np.ascontiguousarray(g["rec"]), chroma, chroma])
+    O.upload([np.ascontiguousarray(g["orig"]), chroma, chroma])
+    for j, exp in zip(g["jobs"], g["pred"]):      # one job per launch: blocks overlap
+        ctx.intra_pred_batch(R, P, np.array([j], api.INTRA_DTYPE))
+        x, y, bw, bh = (int(j[k]) for k in "xywh")
+        got = P.download()[int(j["comp"])][y:y + bh, x:x + bw]
+        assert np.array_equal(got, exp[:bh, :bw]), j
+    got = ctx.intra_satd_batch(O, R, g["satd_jobs"])
+    assert np.array_equal(got, g["satd"])
+    for p in (R, O, P):
         p.destroy()

@@ -114,11 +114,12 @@ def test_intra_satd_batch(gpu, xo, bd):
     chroma = np.full((h // 2, w // 2), 1 << (bd - 1), np.uint16)
     O = upload(ctx, [orig, chroma, chroma], w, h, bd)
     R = upload(ctx, [rec, chroma, chroma], w, h, bd)
-    jobs = oi.random_jobs(rng, w, h, 0, 120)
-    got = ctx.intra_satd_batch(O, R, jobs)
-    assert got.shape == (120, 67)
-    for j, g in zip(jobs, got):
-        assert np.array_equal(g, oi.satd_modes(xo, "xo", bd, j, orig, rec)), j
+    for sizes in ((4, 8, 16, 32, 64), (4, 8, 16, 32), (4, 8, 16)):   # the three tile sizes
+        jobs = oi.random_jobs(rng, w, h, 0, 120, sizes)
+        got = ctx.intra_satd_batch(O, R, jobs)
+        assert got.shape == (120, 67)
+        for j, g in zip(jobs, got):
+            assert np.array_equal(g, oi.satd_modes(xo, "xo", bd, j, orig, rec)), j
     O.destroy()
     R.destroy()
 
@@ -159,8 +160,9 @@ def test_intra_error_paths(gpu):
     d = ctx.alloc(1024)
     lib = ctx.lib
     assert lib.xvcgpu_intra_pred_batch(ctx.h, P.h_pic, Q.h_pic, d.ptr, 1) == 10
-    assert lib.xvcgpu_intra_satd_batch(ctx.h, P.h_pic, Q.h_pic, d.ptr, 1, d.ptr) == 10
-    assert lib.xvcgpu_intra_satd_batch(ctx.h, P.h_pic, P.h_pic, None, 1, d.ptr) == 10
+    assert lib.xvcgpu_intra_satd_batch(ctx.h, P.h_pic, Q.h_pic, d.ptr, 1, d.ptr, 64) == 10
+    assert lib.xvcgpu_intra_satd_batch(ctx.h, P.h_pic, P.h_pic, None, 1, d.ptr, 64) == 10
+    assert lib.xvcgpu_intra_satd_batch(ctx.h, P.h_pic, P.h_pic, d.ptr, 1, d.ptr, 128) == 10
     assert lib.xvcgpu_intra_pred_batch(ctx.h, P.h_pic, P.h_pic, None, 0) == 0
     d.free()
     P.destroy()

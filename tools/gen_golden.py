@@ -211,6 +211,34 @@ def gen_stats(xr):
     np.savez_compressed(os.path.join(OUT, "stats.npz"), **out)
 
 
+def gen_intra(xr):
+    """intra.npz: the reference's IntraPrediction (reference samples + Predict)
+    for seeded blocks of every size / neighbour configuration / component, and
+    the SATD of all 67 luma modes (the distortions of DetermineSlowIntraModes)."""
+    import oracle_intra as oi
+    rng = np.random.default_rng(20261002)
+    bd, w, h = 10, 160, 128
+    orig, rec = make_pics(rng, bd, w, h, 0, motion=(1, 0), noise=6)
+    chroma = rnd_samples(rng, bd, h // 2, w // 2, True)
+    out = {"orig": orig, "rec": rec, "chroma": chroma}
+    jobs, preds = [], []
+    for comp in (0, 1):
+        plane = rec if comp == 0 else chroma
+        ph, pw = plane.shape
+        sizes = (4, 8, 16, 32, 64) if comp == 0 else (2, 4, 8, 16, 32)
+        for j in oi.random_jobs(rng, pw, ph, comp, 90, sizes):
+            p = oi.pred_block(xr, "xr", bd, j, plane, pw << comp, ph << comp)
+            pp = np.zeros((64, 64), np.uint16)
+            pp[:p.shape[0], :p.shape[1]] = p
+            jobs.append(j)
+            preds.append(pp)
+    out["jobs"], out["pred"] = np.array(jobs, oi.INTRA_DTYPE), np.array(preds)
+    sj = oi.random_jobs(rng, w, h, 0, 40)
+    out["satd_jobs"] = sj
+    out["satd"] = np.array([oi.satd_modes(xr, "xr", bd, j, orig, rec) for j in sj])
+    np.savez_compressed(os.path.join(OUT, "intra.npz"), **out)
+
+
 def gen_frame(xr):
     """frame.npz: the hot-path frame pass run by the reference's own classes
     (ref_harness.cc xr_frame_pass) on three chained 136x72 synthetic pictures
@@ -260,6 +288,10 @@ def main():
         return
     if sys.argv[1:] == ["stats"]:
         gen_stats(xr)
+        write_manifest()
+        return
+    if sys.argv[1:] == ["intra"]:
+        gen_intra(xr)
         write_manifest()
         return
     if sys.argv[1:] == ["frame"]:

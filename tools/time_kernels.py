@@ -19,7 +19,7 @@ def timed(fn, reps=50):
     fn(); ctx.sync(); ctx.timer_begin()
     for _ in range(reps): fn()
     return 1e3 * ctx.timer_end() / reps
-which = sys.argv[1:] or ["me", "recon", "deblock", "pad", "ssd", "import8", "export8", "export8d", "crc", "variance", "histogram"]
+which = sys.argv[1:] or ["me", "recon", "deblock", "pad", "ssd", "import8", "export8", "export8d", "crc", "variance", "histogram", "intra_satd", "intra_pred"]
 fns = {
     "me": lambda: ctx.me_search_dev(O, R, 3, fp.d_me.ptr, d.n_cus, fp.d_res.ptr, 16),
     "recon": lambda: ctx.recon_from_me_dev(O, R, Rec, fp.d_me.ptr, fp.d_res.ptr, d.n_cus, d.qp, d.qp_c, 0, fp.d_nnz.ptr, fp.d_cus_own),
@@ -39,11 +39,24 @@ fns.update({
     "variance": lambda: lib.xvcgpu_variance_map(ctx.h, O.h_pic, d_small.ptr, 64, d_small.ptr + 8 * (W // 16 + 1) * (H // 16 + 1)),
     "histogram": lambda: lib.xvcgpu_histogram_distance(ctx.h, O.h_pic, R.h_pic, d_small.ptr),
 })
+ij = np.zeros((H // 16) * (W // 16), api.INTRA_DTYPE)
+k = 0
+for y in range(0, H - 15, 16):
+    for x in range(0, W, 16):
+        ij[k] = (x, y, 16, 16, 0, 34, (4 if x else 0) | (2 if y else 0) | (1 if x and y else 0),
+                 16 if y and x + 32 <= W else 0, 0, 0)
+        k += 1
+d_ij = ctx.buffer(ij)
+d_id = ctx.alloc(4 * 67 * len(ij))
+fns.update({
+    "intra_satd": lambda: lib.xvcgpu_intra_satd_batch(ctx.h, O.h_pic, R.h_pic, d_ij.ptr, len(ij), d_id.ptr, 16),
+    "intra_pred": lambda: lib.xvcgpu_intra_pred_batch(ctx.h, R.h_pic, Rec.h_pic, d_ij.ptr, len(ij)),
+})
 N = W * H
 alg = {"me": 4 * N, "recon": 9 * N + 16 * N // 16, "deblock": 6 * N + N,
        "pad": 2 * (2 * 128 * (W + H + 256) + 4 * 64 * (W // 2 + H // 2 + 128)), "ssd": 4 * N,
        "import8": 1.5 * N * 3, "export8": 1.5 * N * 3, "export8d": 1.5 * N * 3, "crc": 3 * N,
-       "variance": 2 * N, "histogram": 4 * N}
+       "variance": 2 * N, "histogram": 4 * N, "intra_satd": 4 * N, "intra_pred": 4 * N}
 for k in which:
     us = timed(fns[k])
     print("%-8s %8.2f us  %7.0f GB/s algorithmic" % (k, us, alg[k] / us / 1e3))

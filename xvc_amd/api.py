@@ -182,7 +182,7 @@ def load_library():
         "xvcgpu_variance_map": [_vp, _vp, _vp, C.c_int, _vp],
         "xvcgpu_histogram_distance": [_vp, _vp, _vp, _vp],
         "xvcgpu_intra_pred_batch": [_vp, _vp, _vp, _vp, C.c_int],
-        "xvcgpu_intra_satd_batch": [_vp, _vp, _vp, _vp, C.c_int, _vp],
+        "xvcgpu_intra_satd_batch": [_vp, _vp, _vp, _vp, C.c_int, _vp, C.c_int],
         "xvcgpu_get_transform_matrix": [C.c_int, C.c_int, _vp],
     }
     for name, args in sigs.items():
@@ -629,8 +629,9 @@ class Context:
         jobs = np.ascontiguousarray(jobs, INTRA_DTYPE)
         d = self.buffer(jobs)
         do = self.alloc(4 * INTRA_NUM_MODES * max(1, len(jobs)))
+        ms = int(max(jobs["w"].max(), jobs["h"].max())) if len(jobs) else 4
         self._check(self.lib.xvcgpu_intra_satd_batch(self.h, orig.h_pic, rec.h_pic, d.ptr,
-                                                     len(jobs), do.ptr))
+                                                     len(jobs), do.ptr, ms))
         out = do.to_array(np.uint32, INTRA_NUM_MODES * len(jobs)).reshape(-1, INTRA_NUM_MODES)
         d.free()
         do.free()

@@ -196,22 +196,27 @@ intra_pred_kernel(PicView rec, PicView pred, const xvcgpu_intra_block *jobs, int
                       pp.p + (ptrdiff_t)b.y * pp.stride + b.x, pp.stride, threadIdx.x, 256);
 }
 
+template <int MS>
 struct IntraSatdShared {
   IntraRefs refs;
   uint16_t line[4][132];
-  uint16_t orig[64 * 64];
-  uint16_t pred[4][64 * 64];
+  uint16_t orig[MS * MS];
+  uint16_t pred[4][MS * MS];
 };
 
 // grid: n jobs; block 256 = 4 waves.  Luma: the 67 modes are dealt to the waves;
 // a wave predicts into its own LDS tile and takes the SATD against the
-// original block.  dist[job * 67 + mode].
+// original block.  dist[job * 67 + mode].  MS = largest block side of the batch
+// (sizes the LDS tiles, i.e. how many workgroups share a CU); larger jobs are
+// skipped.
+template <int MS>
 __global__ void __launch_bounds__(256)
 intra_satd_kernel(PicView orig, PicView rec, const xvcgpu_intra_block *jobs, int n,
                   uint32_t *dist) {
-  __shared__ IntraSatdShared s;
+  __shared__ IntraSatdShared<MS> s;
   if ((int)blockIdx.x >= n) return;
   const xvcgpu_intra_block b = jobs[blockIdx.x];
+  if (b.w > MS || b.h > MS) return;
   const PlaneView po = orig.c[0], pr = rec.c[0];
   const int w = b.w, h = b.h, wl = 31 - __clz(w);
   for (int p = threadIdx.x; p < w * h; p += 256) {

@@ -1052,14 +1052,22 @@ xvcgpu_status xvcgpu_intra_pred_batch(xvcgpu_ctx *ctx, const xvcgpu_picture *rec
 xvcgpu_status xvcgpu_intra_satd_batch(xvcgpu_ctx *ctx, const xvcgpu_picture *orig,
                                       const xvcgpu_picture *rec,
                                       const xvcgpu_intra_block *d_jobs, int n,
-                                      uint32_t *d_dist) {
-  if (!ctx || !orig || !rec || (!d_jobs && n > 0) || n < 0 || (!d_dist && n > 0))
+                                      uint32_t *d_dist, int max_block_size) {
+  if (!ctx || !orig || !rec || (!d_jobs && n > 0) || n < 0 || (!d_dist && n > 0) ||
+      max_block_size < 4 || max_block_size > 64)
     return XVCGPU_INVALID_ARGUMENT;
   if (rec->w != orig->w || rec->h != orig->h || rec->bd != orig->bd)
     return fail(ctx, XVCGPU_INVALID_ARGUMENT, "picture mismatch");
   if (n == 0) return XVCGPU_OK;
-  hipLaunchKernelGGL(intra_satd_kernel, dim3(n), dim3(256), 0, ctx->stream, orig->v, rec->v,
-                     d_jobs, n, d_dist);
+  if (max_block_size <= 16)
+    hipLaunchKernelGGL(intra_satd_kernel<16>, dim3(n), dim3(256), 0, ctx->stream, orig->v,
+                       rec->v, d_jobs, n, d_dist);
+  else if (max_block_size <= 32)
+    hipLaunchKernelGGL(intra_satd_kernel<32>, dim3(n), dim3(256), 0, ctx->stream, orig->v,
+                       rec->v, d_jobs, n, d_dist);
+  else
+    hipLaunchKernelGGL(intra_satd_kernel<64>, dim3(n), dim3(256), 0, ctx->stream, orig->v,
+                       rec->v, d_jobs, n, d_dist);
   CHECK_LAUNCH(ctx, "intra_satd_batch");
   return XVCGPU_OK;
 }

@@ -20,6 +20,10 @@
 //     (cu_encoder.cc:308-363)
 //   PictureEncoder::DetermineAllowLic               xvc_gpu::DetermineAllowLic
 //     (picture_encoder.cc:230-281)
+//   IntraPrediction::FillReferenceState + Predict   xvc_gpu::IntraPrediction::PredictBatch
+//     (intra_prediction.cc:81-147)
+//   IntraSearch::DetermineSlowIntraModes, the       xvc_gpu::IntraSearch::SatdAllModesBatch
+//     prediction + SATD loop (intra_search.cc:189-305)
 //
 // Errors: the reference asserts internally and returns enum codes at its C API
 // (xvcenc.h:34-45); here every failing xvcgpu call throws xvc_gpu::Error inside
@@ -368,6 +372,47 @@ inline bool DetermineAllowLic(const Context &ctx, const Picture &orig_pic,
                                       d.data()));
   return d.ToHost()[0] > static_cast<int>(0.06 * width * height);
 }
+
+// IntraPrediction::FillReferenceState + Predict for a batch of independent
+// blocks (decoder reconstruction of intra CUs whose neighbours are done; the
+// encoder's final prediction).
+class IntraPrediction {
+ public:
+  explicit IntraPrediction(const Context &ctx) : ctx_(ctx) {}
+  void PredictBatch(const Picture &rec_pic, Picture *pred_pic,
+                    const std::vector<xvcgpu_intra_block> &blocks) const {
+    DeviceArray<xvcgpu_intra_block> d(ctx_, blocks);
+    ctx_.Check(xvcgpu_intra_pred_batch(ctx_.get(), rec_pic.get(), pred_pic->get(), d.data(),
+                                       static_cast<int>(blocks.size())));
+    ctx_.Sync();
+  }
+
+ private:
+  const Context &ctx_;
+};
+
+// The fast pass of IntraSearch::DetermineSlowIntraModes: SATD of every luma
+// mode's prediction, [block][mode]; the caller adds the mode bits and sorts.
+class IntraSearch {
+ public:
+  explicit IntraSearch(const Context &ctx) : ctx_(ctx) {}
+  std::vector<uint32_t> SatdAllModesBatch(const Picture &orig_pic, const Picture &rec_pic,
+                                          const std::vector<xvcgpu_intra_block> &blocks) const {
+    int max_size = 4;
+    for (size_t i = 0; i < blocks.size(); i++) {
+      if (blocks[i].w > max_size) max_size = blocks[i].w;
+      if (blocks[i].h > max_size) max_size = blocks[i].h;
+    }
+    DeviceArray<xvcgpu_intra_block> d(ctx_, blocks);
+    DeviceArray<uint32_t> r(ctx_, blocks.size() * XVC_INTRA_NUM_MODES);
+    ctx_.Check(xvcgpu_intra_satd_batch(ctx_.get(), orig_pic.get(), rec_pic.get(), d.data(),
+                                       static_cast<int>(blocks.size()), r.data(), max_size));
+    return r.ToHost();
+  }
+
+ private:
+  const Context &ctx_;
+};
 
 // Walks a reference-style CU map (anything exposing the PictureData /
 // CodingUnit accessors named below; picture_data.h:102-107,
