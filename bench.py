@@ -332,7 +332,11 @@ def main():
                 "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic,
                 "algorithmic_bytes": alg[dom],
                 "ms_per_launch": times[dom],
-                "all_kernels_ms": {k: round(v, 4) for k, v in times.items()}}
+                "all_kernels_ms": {k: round(v, 4) for k, v in times.items()},
+                # algorithmic GB/s of every kernel of the pass (the whole-picture
+                # ones - deblock, pad, SSD - are the HBM-bound ones)
+                "all_kernels_gbps": {k: round(alg[k] / (v * 1e-3) / 1e9, 1)
+                                     for k, v in times.items() if v > 0}}
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu:
