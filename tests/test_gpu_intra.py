@@ -167,3 +167,40 @@ def test_intra_error_paths(gpu):
     d.free()
     P.destroy()
     Q.destroy()
+
+
+@pytest.mark.parametrize("w,h,bd,qp,cu", [(352, 288, 10, 32, 16), (136, 72, 8, 27, 8),
+                                          (256, 192, 10, 37, 32), (1920, 1080, 10, 32, 16)])
+def test_intra_picture_pass(gpu, xo, w, h, bd, qp, cu):
+    """An all-intra picture on the device, wave by wave (anti-diagonals of the
+    CU raster), against the CU-by-CU oracle composition: chosen modes, levels,
+    coefficient counts and the reconstruction; then the decoder's side from the
+    same syntax (no host round trips) reproduces the reconstruction."""
+    import oracle_intra_picture
+    from xvc_amd import pipeline, synth
+    api, ctx = gpu
+    clip = synth.SyntheticClip(w, h, bd)
+    orig = clip.frame(3)
+    O = upload(ctx, orig, w, h, bd)
+    R, D = ctx.picture(w, h, bd), ctx.picture(w, h, bd)
+    ip = pipeline.IntraPicturePass(ctx, w, h, bd, qp, cu)
+    ip.encode(O, R)
+    modes, levels, nnz = ip.results()
+    e_desc = pipeline.IntraPictureDescriptors(w, h, qp, cu)
+    e_rec, e_modes, e_levels, e_nnz = oracle_intra_picture.run(xo, e_desc, bd, orig)
+    assert np.array_equal(modes, e_modes)
+    assert np.array_equal(nnz, e_nnz) and np.array_equal(levels, e_levels)
+    got = R.download()
+    for c in range(3):
+        assert np.array_equal(got[c], e_rec[c]), c
+    assert len(set(modes.tolist())) > 5 and np.count_nonzero(nnz) > 0
+    # decoder side
+    ip.load(modes, levels, nnz)
+    ip.decode(D)
+    ctx.sync()
+    dec = D.download()
+    for c in range(3):
+        assert np.array_equal(dec[c], e_rec[c]), c
+    ip.destroy()
+    for p in (O, R, D):
+        p.destroy()

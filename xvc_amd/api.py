@@ -60,6 +60,9 @@ INTRA_DTYPE = np.dtype([("x", "<i2"), ("y", "<i2"), ("w", "u1"), ("h", "u1"),
                         ("above_right", "u1"), ("below_left", "u1"), ("reserved", "u1")])
 assert INTRA_DTYPE.itemsize == 12
 INTRA_NUM_MODES = 67
+INTRA_HAS_ABOVE_LEFT, INTRA_HAS_ABOVE, INTRA_HAS_LEFT = 1, 2, 4
+# xvcgpu_tx_block.intra_pic flag bits (include/xvcgpu_types.h XVC_TXF_*)
+TXF_INTRA_PIC, TXF_NO_SIGN_HIDING, TXF_SCAN_SHIFT = 1, 2, 2
 CAND_DTYPE = np.dtype([("x", "<i2"), ("y", "<i2"), ("w", "u1"), ("h", "u1"),
                        ("metric", "u1"), ("qp", "i1"), ("mv_x", "<i2"),
                        ("mv_y", "<i2")])
@@ -377,6 +380,12 @@ class Context:
 
     def alloc(self, nbytes):
         return DeviceBuffer(self, nbytes)
+
+    def h2d(self, dev_ptr, arr):
+        arr = np.ascontiguousarray(arr)
+        if arr.nbytes:
+            self._check(self.lib.xvcgpu_memcpy_h2d(self.h, dev_ptr, arr.ctypes.data,
+                                                   arr.nbytes))
 
     # ---- device-pointer level calls (bench) ----
     def pad_border(self, pic):

@@ -308,3 +308,154 @@ def psnr_from_ssd(dist, samples):
     """SampleMetric::ComputePsnr tail (sample_metric.cc:143-154)."""
     mse = dist / samples if samples else 0.0
     return 10.0 * math.log10(255.0 * 255.0 / mse) if mse > 0 else 99.999
+
+
+class IntraPictureDescriptors:
+    """Host-side plan of an all-intra picture pass: a
+    raster of cu x cu CUs coded in raster order.  A CU's prediction reads the
+    reconstruction of its left / above-left / above / above-right neighbours,
+    so CU (cx, cy) can run once wave cx + 2*cy - 1 is done: the CUs are
+    grouped into those anti-diagonal waves, and every wave is one batch per
+    kernel.  Jobs and transform blocks are stored wave by wave."""
+
+    def __init__(self, width, height, qp=32, cu=16):
+        assert cu in (8, 16, 32)
+        self.w, self.h, self.qp, self.cu = width, height, qp, cu
+        self.qp_c = chroma_qp(qp)
+        parts = cu_partition(width, height, cu)
+        order = sorted(range(len(parts)),
+                       key=lambda i: (parts[i][0] // cu + 2 * (parts[i][1] // cu), i))
+        self.parts = [parts[i] for i in order]
+        n = len(parts)
+        self.n_cus = n
+        self.luma = np.zeros(n, api.INTRA_DTYPE)
+        self.chroma = np.zeros(2 * n, api.INTRA_DTYPE)      # U then V of each CU
+        self.tx = np.zeros(3 * n, api.TX_DTYPE)              # Y, U, V of each CU
+        wave_of = []
+        for i, (x, y, w, h) in enumerate(self.parts):
+            nb = (api.INTRA_HAS_LEFT if x else 0) | (api.INTRA_HAS_ABOVE if y else 0) | \
+                (api.INTRA_HAS_ABOVE_LEFT if x and y else 0)
+            # GetCuSizeAboveRight: the row above is complete; GetCuSizeBelowLeft: 0
+            ar = max(0, min(h, width - (x + w))) if y else 0
+            self.luma[i] = (x, y, w, h, 0, 0, nb, ar, 0, 0)
+            for c in (1, 2):
+                self.chroma[2 * i + c - 1] = (x // 2, y // 2, w // 2, h // 2, c, 0, nb,
+                                              ar // 2, 0, 0)
+            for c in range(3):
+                t = self.tx[3 * i + c]
+                s = 1 if c else 0
+                t["x"], t["y"], t["w"], t["h"] = x >> s, y >> s, w >> s, h >> s
+                t["comp"], t["qp"] = c, (self.qp_c if c else qp)
+                t["intra_pic"] = api.TXF_INTRA_PIC
+            wave_of.append(x // cu + 2 * (y // cu))
+        wave_of = np.array(wave_of)
+        self.wave_start = np.searchsorted(wave_of, np.arange(wave_of.max() + 2))
+        self.level_off, self.level_total = api.Context.level_offsets(self.tx)
+
+    def waves(self):
+        for k in range(len(self.wave_start) - 1):
+            a, b = int(self.wave_start[k]), int(self.wave_start[k + 1])
+            if b > a:
+                yield a, b
+
+    def set_modes(self, a, b, modes):
+        """Modes of CUs [a, b): luma jobs, chroma jobs (DM: the luma mode) and
+        the coefficient scan of small CUs (TransformHelper::DetermineScanOrder,
+        transform.cc:1614-1637)."""
+        for i, m in zip(range(a, b), modes):
+            m = int(m)
+            self.luma[i]["mode"] = m
+            self.chroma[2 * i]["mode"] = self.chroma[2 * i + 1]["mode"] = m
+            _, _, w, h = self.parts[i]
+            scan = 0
+            if w < 16 and h < 16:
+                scan = 1 if abs(m - 50) < 10 else (2 if abs(m - 18) < 10 else 0)
+            for c in range(3):
+                self.tx[3 * i + c]["intra_pic"] = api.TXF_INTRA_PIC | (scan << api.TXF_SCAN_SHIFT)
+
+
+class IntraPicturePass:
+    """All-intra picture on the device, wave by wave (IntraPictureDescriptors).
+
+    encode(): per wave the SATD of all 67 luma modes (xvcgpu_intra_satd_batch),
+    the mode with the smallest SATD (first on ties; chosen on the host - the
+    reference adds CABAC-state dependent mode bits there, which this
+    composition leaves out), prediction of Y,U,V (xvcgpu_intra_pred_batch) and
+    TransformAndReconstruct with QuantFast (xvcgpu_residual_batch).
+    decode(): the decoder's side - modes and levels given, prediction +
+    xvcgpu_inv_transform_batch per wave, no host round trip.
+    Neither is the reference's intra encoder (no RDO over modes / transforms,
+    raster CU order instead of the CTU quad-tree order); the oracle's twin in
+    tests/oracle_intra_picture.py is the same composition on the CPU."""
+
+    def __init__(self, ctx, width, height, bitdepth=10, qp=32, cu=16):
+        self.ctx, self.bd = ctx, bitdepth
+        self.desc = d = IntraPictureDescriptors(width, height, qp, cu)
+        self.pred = ctx.picture(width, height, bitdepth)
+        self.d_luma = ctx.buffer(d.luma)
+        self.d_chroma = ctx.buffer(d.chroma)
+        self.d_tx = ctx.buffer(d.tx)
+        self.d_off = ctx.buffer(d.level_off)
+        self.d_levels = ctx.alloc(2 * max(1, d.level_total))
+        self.d_nnz = ctx.alloc(4 * len(d.tx))
+        self.d_dist = ctx.alloc(4 * api.INTRA_NUM_MODES * d.n_cus)
+
+    def _upload_range(self, buf, arr, a, b):
+        sz = arr.dtype.itemsize
+        self.ctx.h2d(buf.ptr + a * sz, arr[a:b])
+
+    def encode(self, orig, rec):
+        ctx, d, lib = self.ctx, self.desc, self.ctx.lib
+        J, T = api.INTRA_DTYPE.itemsize, api.TX_DTYPE.itemsize
+        for a, b in d.waves():
+            n = b - a
+            ctx._check(lib.xvcgpu_intra_satd_batch(ctx.h, orig.h_pic, rec.h_pic,
+                                                   self.d_luma.ptr + a * J, n,
+                                                   self.d_dist.ptr, d.cu))
+            dist = self.d_dist.to_array(np.uint32, n * api.INTRA_NUM_MODES) \
+                .reshape(n, api.INTRA_NUM_MODES)
+            d.set_modes(a, b, dist.argmin(axis=1))
+            self._upload_range(self.d_luma, d.luma, a, b)
+            self._upload_range(self.d_chroma, d.chroma, 2 * a, 2 * b)
+            self._upload_range(self.d_tx, d.tx, 3 * a, 3 * b)
+            self._wave(rec, a, b)
+            ctx.residual_batch_dev(orig, self.pred, rec, self.d_tx.ptr + 3 * a * T, 3 * n,
+                                   self.d_levels.ptr, self.d_off.ptr + 3 * a * 4,
+                                   self.d_nnz.ptr + 3 * a * 4)
+        ctx.sync()
+
+    def _wave(self, rec, a, b):
+        ctx, lib, J = self.ctx, self.ctx.lib, api.INTRA_DTYPE.itemsize
+        ctx._check(lib.xvcgpu_intra_pred_batch(ctx.h, rec.h_pic, self.pred.h_pic,
+                                               self.d_luma.ptr + a * J, b - a))
+        ctx._check(lib.xvcgpu_intra_pred_batch(ctx.h, rec.h_pic, self.pred.h_pic,
+                                               self.d_chroma.ptr + 2 * a * J, 2 * (b - a)))
+
+    def load(self, modes, levels, nnz):
+        """Parsed syntax of a picture: mode per CU (wave order), levels / nnz as
+        results() returned them."""
+        d = self.desc
+        d.set_modes(0, d.n_cus, modes)
+        for buf, arr in ((self.d_luma, d.luma), (self.d_chroma, d.chroma), (self.d_tx, d.tx)):
+            self._upload_range(buf, arr, 0, len(arr))
+        self.ctx.h2d(self.d_levels.ptr, np.ascontiguousarray(levels, np.int16))
+        self.ctx.h2d(self.d_nnz.ptr, np.ascontiguousarray(nnz, np.int32))
+
+    def decode(self, rec):
+        ctx, d, T = self.ctx, self.desc, api.TX_DTYPE.itemsize
+        for a, b in d.waves():
+            self._wave(rec, a, b)
+            ctx._check(ctx.lib.xvcgpu_inv_transform_batch(
+                ctx.h, self.pred.h_pic, rec.h_pic, self.d_tx.ptr + 3 * a * T, 3 * (b - a),
+                self.d_levels.ptr, self.d_off.ptr + 3 * a * 4, self.d_nnz.ptr + 3 * a * 4))
+
+    def results(self):
+        d = self.desc
+        return (d.luma["mode"].copy(), self.d_levels.to_array(np.int16, d.level_total),
+                self.d_nnz.to_array(np.int32, len(d.tx)))
+
+    def destroy(self):
+        for b in (self.d_luma, self.d_chroma, self.d_tx, self.d_off, self.d_levels,
+                  self.d_nnz, self.d_dist):
+            b.free()
+        self.pred.destroy()
