@@ -438,6 +438,39 @@ xvcgpu_status xvcgpu_intra_satd_batch(xvcgpu_ctx *ctx, const xvcgpu_picture *ori
                                       const xvcgpu_intra_block *d_jobs, int n,
                                       uint32_t *d_dist, int max_block_size);
 
+/* The fold of the fast pass kept on the device, for pipelines that do not want a
+ * host round trip per batch: mode[cu] = first arg min over the 67 modes of
+ * d_dist[cu][mode] (+ d_mode_cost[cu][mode] when not NULL: the caller's rate
+ * term, e.g. bits * lambda_sqrt rounded).  Written to d_modes[cu] (may be NULL)
+ * and, when given, into the `per_cu` (1..3) consecutive prediction jobs of the
+ * CU (every component takes the luma mode, i.e. DM chroma) and into the scan
+ * bits (XVC_TXF_SCAN_SHIFT) of its `per_cu` consecutive transform blocks, luma
+ * block first, by TransformHelper::DetermineScanOrder (transform.cc:1614-1637).
+ * The reference's own decision (stable sort by double cost, N best to the slow
+ * RDO pass, intra_search.cc:236-303) remains host work on d_dist. */
+xvcgpu_status xvcgpu_intra_select_modes(xvcgpu_ctx *ctx, const uint32_t *d_dist,
+                                        const uint32_t *d_mode_cost, int n,
+                                        int32_t *d_modes, xvcgpu_intra_block *d_jobs,
+                                        xvcgpu_tx_block *d_blocks, int per_cu);
+
+/* Predict + TransformAndReconstruct in one launch for intra blocks up to 16x16
+ * (IntraSearch::PredictAndTransform, intra_search.cc:172-187, with QuantFast;
+ * the decoder's CuDecoder::DecompressIntra when `orig` is NULL): job i =
+ * d_jobs[i] (the prediction) + d_blocks[i] (its transform block: same
+ * component, position and size).  The prediction never leaves the chip.
+ * orig != NULL: levels / nnz are written as by xvcgpu_residual_batch (the three
+ * arrays may be NULL); orig == NULL: they are read as by
+ * xvcgpu_inv_transform_batch.  In place on `rec`; the jobs of one call must not
+ * depend on each other.  Larger blocks, 2-wide blocks, the 4x4 DST and
+ * transform skip are not taken (use xvcgpu_intra_pred_batch +
+ * xvcgpu_residual_batch / xvcgpu_inv_transform_batch). */
+xvcgpu_status xvcgpu_intra_recon_batch(xvcgpu_ctx *ctx, const xvcgpu_picture *orig,
+                                       xvcgpu_picture *rec,
+                                       const xvcgpu_intra_block *d_jobs,
+                                       const xvcgpu_tx_block *d_blocks, int n,
+                                       int16_t *d_levels, const uint32_t *d_level_offsets,
+                                       int32_t *d_nnz);
+
 /* ---- tables (host side, no GPU needed) ---------------------------------- *
  * The 8-bit-fraction transform matrices the kernels use (transform_data.cc:
  * 109-796), for table-equality tests. out: size*size int16 row-major. */

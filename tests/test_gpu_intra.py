@@ -164,14 +164,20 @@ def test_intra_error_paths(gpu):
     assert lib.xvcgpu_intra_satd_batch(ctx.h, P.h_pic, P.h_pic, None, 1, d.ptr, 64) == 10
     assert lib.xvcgpu_intra_satd_batch(ctx.h, P.h_pic, P.h_pic, d.ptr, 1, d.ptr, 128) == 10
     assert lib.xvcgpu_intra_pred_batch(ctx.h, P.h_pic, P.h_pic, None, 0) == 0
+    # decoder form of the fused entry point needs the levels
+    assert lib.xvcgpu_intra_recon_batch(ctx.h, None, P.h_pic, d.ptr, d.ptr, 1, None, None,
+                                        None) == 10
+    assert lib.xvcgpu_intra_recon_batch(ctx.h, Q.h_pic, P.h_pic, d.ptr, d.ptr, 1, None, None,
+                                        None) == 10
     d.free()
     P.destroy()
     Q.destroy()
 
 
-@pytest.mark.parametrize("w,h,bd,qp,cu", [(352, 288, 10, 32, 16), (136, 72, 8, 27, 8),
-                                          (256, 192, 10, 37, 32), (1920, 1080, 10, 32, 16)])
-def test_intra_picture_pass(gpu, xo, w, h, bd, qp, cu):
+@pytest.mark.parametrize("w,h,bd,qp,cu,fused", [
+    (352, 288, 10, 32, 16, True), (352, 288, 10, 32, 16, False), (136, 72, 8, 27, 8, True),
+    (136, 72, 12, 27, 8, False), (256, 192, 10, 37, 32, False), (1920, 1080, 10, 32, 16, True)])
+def test_intra_picture_pass(gpu, xo, w, h, bd, qp, cu, fused):
     """An all-intra picture on the device, wave by wave (anti-diagonals of the
     CU raster), against the CU-by-CU oracle composition: chosen modes, levels,
     coefficient counts and the reconstruction; then the decoder's side from the
@@ -183,9 +189,14 @@ def test_intra_picture_pass(gpu, xo, w, h, bd, qp, cu):
     orig = clip.frame(3)
     O = upload(ctx, orig, w, h, bd)
     R, D = ctx.picture(w, h, bd), ctx.picture(w, h, bd)
-    ip = pipeline.IntraPicturePass(ctx, w, h, bd, qp, cu)
+    ip = pipeline.IntraPicturePass(ctx, w, h, bd, qp, cu, fused=fused)
+    if fused:   # the host fold and the device fold choose the same modes
+        ip.encode(O, R, host_select=True)
+        host_modes = ip.results()[0]
     ip.encode(O, R)
     modes, levels, nnz = ip.results()
+    if fused:
+        assert np.array_equal(modes, host_modes)
     e_desc = pipeline.IntraPictureDescriptors(w, h, qp, cu)
     e_rec, e_modes, e_levels, e_nnz = oracle_intra_picture.run(xo, e_desc, bd, orig)
     assert np.array_equal(modes, e_modes)

@@ -88,7 +88,8 @@ SYMBOLS = [
     "xvcgpu_deblock", "xvcgpu_deblock_rows", "xvcgpu_picture_ssd", "xvcgpu_picture_ssd_rows",
     "xvcgpu_picture_import", "xvcgpu_picture_export", "xvcgpu_picture_crc",
     "xvcgpu_variance_map", "xvcgpu_histogram_distance",
-    "xvcgpu_intra_pred_batch", "xvcgpu_intra_satd_batch", "xvcgpu_get_transform_matrix",
+    "xvcgpu_intra_pred_batch", "xvcgpu_intra_satd_batch", "xvcgpu_intra_recon_batch",
+    "xvcgpu_intra_select_modes", "xvcgpu_get_transform_matrix",
 ]
 
 _vp = C.c_void_p
@@ -186,6 +187,8 @@ def load_library():
         "xvcgpu_histogram_distance": [_vp, _vp, _vp, _vp],
         "xvcgpu_intra_pred_batch": [_vp, _vp, _vp, _vp, C.c_int],
         "xvcgpu_intra_satd_batch": [_vp, _vp, _vp, _vp, C.c_int, _vp, C.c_int],
+        "xvcgpu_intra_recon_batch": [_vp, _vp, _vp, _vp, _vp, C.c_int, _vp, _vp, _vp],
+        "xvcgpu_intra_select_modes": [_vp, _vp, _vp, C.c_int, _vp, _vp, _vp, C.c_int],
         "xvcgpu_get_transform_matrix": [C.c_int, C.c_int, _vp],
     }
     for name, args in sigs.items():

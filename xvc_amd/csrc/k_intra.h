@@ -8,6 +8,7 @@
 
 #include "dev_common.h"
 #include "k_metric.h"
+#include "k_tx2.h"
 #include "xvcgpu_internal.h"
 
 __constant__ int8_t kIntraAngle[33] = {-32, -29, -26, -23, -21, -19, -17, -15, -13, -11, -9,
@@ -28,7 +29,9 @@ struct IntraRefs {
 // original): every entry is either a reconstructed neighbour sample or the
 // nearest available one in the order below-left <- left <- corner <- above <-
 // above-right, or the mid value when nothing is available.  All threads of the
-// workgroup; ends with a barrier.
+// group (a workgroup with WG_SYNC, else one wave - whose LDS operations complete
+// in order, so no barrier is needed); the entries are complete on return.
+template <bool WG_SYNC>
 __device__ __forceinline__ void intra_build_refs(IntraRefs &r, const xvcgpu_intra_block &b,
                                                  const uint16_t *src, int stride, int bd,
                                                  bool filter, int tid, int nthreads) {
@@ -65,7 +68,7 @@ __device__ __forceinline__ void intra_build_refs(IntraRefs &r, const xvcgpu_intr
     r.above[0][1 + i] = (uint16_t)a;
   }
   if (tid == 0) r.above[0][0] = r.left[0][0] = (uint16_t)corner;
-  __syncthreads();
+  if (WG_SYNC) __syncthreads();
   if (!filter) return;
   // FilterRefSamples: [1 2 1] along the L-shaped line, the two ends copied
   for (int i = tid; i < n; i += nthreads) {
@@ -79,7 +82,7 @@ __device__ __forceinline__ void intra_build_refs(IntraRefs &r, const xvcgpu_intr
   if (tid == 0)
     r.above[1][0] = r.left[1][0] =
         (uint16_t)(((corner << 1) + r.above[0][1] + r.left[0][1] + 2) >> 2);
-  __syncthreads();
+  if (WG_SYNC) __syncthreads();
 }
 
 __device__ __forceinline__ bool intra_use_filtered(int w, int h, int mode) {
@@ -190,8 +193,8 @@ intra_pred_kernel(PicView rec, PicView pred, const xvcgpu_intra_block *jobs, int
   const xvcgpu_intra_block b = jobs[blockIdx.x];
   const PlaneView pr = rec.c[b.comp], pp = pred.c[b.comp];
   const bool is_luma = b.comp == 0;
-  intra_build_refs(s.refs, b, pr.p + (ptrdiff_t)b.y * pr.stride + b.x, pr.stride, rec.bd,
-                   is_luma, threadIdx.x, 256);
+  intra_build_refs<true>(s.refs, b, pr.p + (ptrdiff_t)b.y * pr.stride + b.x, pr.stride,
+                         rec.bd, is_luma, threadIdx.x, 256);
   intra_predict<true>(s.refs, s.line, rec.bd, is_luma, b.mode, b.w, b.h,
                       pp.p + (ptrdiff_t)b.y * pp.stride + b.x, pp.stride, threadIdx.x, 256);
 }
@@ -204,9 +207,11 @@ struct IntraSatdShared {
   uint16_t pred[4][MS * MS];
 };
 
-// grid: n jobs; block 256 = 4 waves.  Luma: the 67 modes are dealt to the waves;
-// a wave predicts into its own LDS tile and takes the SATD against the
-// original block.  dist[job * 67 + mode].  MS = largest block side of the batch
+// grid: (n jobs, S); block 256 = 4 waves.  Luma: the 67 modes are dealt to the
+// 4 * S waves that work on a job (S = 1 for big batches; up to 17 - one mode
+// per wave - when the batch alone cannot fill the chip, e.g. one anti-diagonal
+// of a picture); a wave predicts into its own LDS tile and takes the SATD
+// against the original block.  dist[job * 67 + mode].  MS = largest block side of the batch
 // (sizes the LDS tiles, i.e. how many workgroups share a CU); larger jobs are
 // skipped.
 template <int MS>
@@ -223,14 +228,102 @@ intra_satd_kernel(PicView orig, PicView rec, const xvcgpu_intra_block *jobs, int
     const int y = p >> wl, x = p & (w - 1);
     s.orig[y * w + x] = po.p[(ptrdiff_t)(b.y + y) * po.stride + b.x + x];
   }
-  intra_build_refs(s.refs, b, pr.p + (ptrdiff_t)b.y * pr.stride + b.x, pr.stride, rec.bd, true,
-                   threadIdx.x, 256);  // ends with a barrier: orig is complete too
+  intra_build_refs<true>(s.refs, b, pr.p + (ptrdiff_t)b.y * pr.stride + b.x, pr.stride, rec.bd,
+                         true, threadIdx.x, 256);  // ends with a barrier: orig is complete too
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  for (int m = wave; m < XVC_INTRA_NUM_MODES; m += 4) {
+  for (int m = blockIdx.y * 4 + wave; m < XVC_INTRA_NUM_MODES; m += 4 * gridDim.y) {
     intra_predict<false>(s.refs, s.line[wave], rec.bd, true, m, w, h, s.pred[wave], w, lane, 64);
     const uint64_t d = wave_satd(rec.bd, w, h, 0, s.orig, w, s.pred[wave], w);
     if (lane == 0) dist[(size_t)blockIdx.x * XVC_INTRA_NUM_MODES + m] = (uint32_t)d;
   }
+}
+
+// ---- mode selection on the device --------------------------------------------
+// grid: ceil(n / 4); block 256: wave per CU.  mode = arg min over the 67
+// entries of dist[cu] (+ cost[cu], the caller's rate term, when given); first
+// minimum wins.  The choice is written to modes[cu] and - when given - into the
+// `per_cu` prediction jobs of the CU (all components use it: DM chroma) and
+// into the coefficient-scan bits of its `per_cu` transform blocks
+// (TransformHelper::DetermineScanOrder, transform.cc:1614-1637: CUs below
+// 16x16, horizontal scan within 10 modes of vertical, vertical scan within 10
+// of horizontal).
+__global__ void __launch_bounds__(256)
+intra_select_kernel(const uint32_t *dist, const uint32_t *cost, int n, int32_t *modes,
+                    xvcgpu_intra_block *jobs, xvcgpu_tx_block *blocks, int per_cu) {
+  // one wave per CU: two entries per lane, keyed wave minimum (value, mode)
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (i >= n) return;
+  const uint32_t *d = dist + (size_t)i * XVC_INTRA_NUM_MODES;
+  const uint32_t *c = cost ? cost + (size_t)i * XVC_INTRA_NUM_MODES : nullptr;
+  unsigned long long key = ~0ull;
+#pragma unroll
+  for (int k = lane; k < XVC_INTRA_NUM_MODES; k += 64) {
+    const unsigned long long v = (unsigned long long)d[k] + (c ? c[k] : 0u);
+    const unsigned long long kk = (v << 7) | (unsigned)k;   // first minimum wins
+    key = kk < key ? kk : key;
+  }
+#pragma unroll
+  for (int s = 1; s < 64; s <<= 1) {
+    const unsigned long long o = __shfl_xor(key, s, XVC_WAVE);
+    key = o < key ? o : key;
+  }
+  const int m = (int)(key & 127);
+  if (lane == 0 && modes) modes[i] = m;
+  if (lane < per_cu) {
+    const int k = lane;
+    if (jobs) jobs[(size_t)i * per_cu + k].mode = (uint8_t)m;
+    if (blocks) {
+      xvcgpu_tx_block &t = blocks[(size_t)i * per_cu + k];
+      // the CU's luma size decides (block 0 of the CU is its luma block)
+      const xvcgpu_tx_block &l = blocks[(size_t)i * per_cu];
+      int scan = 0;
+      if (l.w < 16 && l.h < 16) {
+        const int dv = m > 50 ? m - 50 : 50 - m, dh = m > 18 ? m - 18 : 18 - m;
+        scan = dv < 10 ? 1 : (dh < 10 ? 2 : 0);
+      }
+      t.intra_pic = (uint8_t)((t.intra_pic & ~(3 << XVC_TXF_SCAN_SHIFT)) |
+                              (scan << XVC_TXF_SCAN_SHIFT));
+    }
+  }
+}
+
+// ---- prediction + TransformAndReconstruct fused -----------------------------
+struct IntraWaveShared {
+  IntraRefs refs;
+  uint16_t line[132];
+  uint16_t pred[16 * 16];
+};
+
+// grid: ceil(n / TX2_WAVES); block: TX2_WAVES waves, one job per wave: the
+// block's prediction (jobs[i]) goes to an LDS tile and straight into the
+// one-wave residual pipeline of blocks[i] (k_tx2.h): MODE = TX_MODE_FULL
+// (encoder: levels / nnz written) or TX_MODE_INV (decoder: levels / nnz read).
+// Blocks up to 16x16 (tx_small_job); others are left to the unfused entry
+// points.  In-place on `rec`: the jobs of one batch are mutually independent.
+template <int MODE>
+__global__ void __launch_bounds__(64 * TX2_WAVES)
+intra_recon_wave_kernel(PicView orig, PicView rec, const xvcgpu_intra_block *jobs,
+                        const xvcgpu_tx_block *blocks, int n, int16_t *levels,
+                        const uint32_t *level_off, int32_t *nnz_out,
+                        const int16_t *tx_tables, const int16_t *tx_tables_t,
+                        TxTableLayout lay) {
+  __shared__ Tx2Shared s_all[TX2_WAVES];
+  __shared__ IntraWaveShared i_all[TX2_WAVES];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int bi = blockIdx.x * TX2_WAVES + wave;
+  if (bi >= n) return;
+  const xvcgpu_tx_block b = blocks[bi];
+  if (!tx_small_job(b)) return;
+  const xvcgpu_intra_block j = jobs[bi];
+  IntraWaveShared &iw = i_all[wave];
+  const PlaneView pr = rec.c[b.comp];
+  const bool is_luma = b.comp == 0;
+  intra_build_refs<false>(iw.refs, j, pr.p + (ptrdiff_t)j.y * pr.stride + j.x, pr.stride,
+                          rec.bd, is_luma, lane, 64);
+  intra_predict<false>(iw.refs, iw.line, rec.bd, is_luma, j.mode, j.w, j.h, iw.pred, j.w,
+                       lane, 64);
+  tx2_job<MODE>(s_all[wave], b, bi, rec.bd, orig.c[b.comp], iw.pred, j.w, pr, levels,
+                level_off, nnz_out, tx_tables, tx_tables_t, lay);
 }
 
 #endif  // XVCGPU_K_INTRA_H_

@@ -1059,16 +1059,60 @@ xvcgpu_status xvcgpu_intra_satd_batch(xvcgpu_ctx *ctx, const xvcgpu_picture *ori
   if (rec->w != orig->w || rec->h != orig->h || rec->bd != orig->bd)
     return fail(ctx, XVCGPU_INVALID_ARGUMENT, "picture mismatch");
   if (n == 0) return XVCGPU_OK;
+  // workgroups per job: enough to put ~2 workgroups on every CU, at most one
+  // mode per wave (67 modes / 4 waves -> 17)
+  int split = (2 * 256 + n - 1) / n;
+  split = split < 1 ? 1 : (split > 17 ? 17 : split);
+  const dim3 grid(n, split);
   if (max_block_size <= 16)
-    hipLaunchKernelGGL(intra_satd_kernel<16>, dim3(n), dim3(256), 0, ctx->stream, orig->v,
+    hipLaunchKernelGGL(intra_satd_kernel<16>, grid, dim3(256), 0, ctx->stream, orig->v,
                        rec->v, d_jobs, n, d_dist);
   else if (max_block_size <= 32)
-    hipLaunchKernelGGL(intra_satd_kernel<32>, dim3(n), dim3(256), 0, ctx->stream, orig->v,
+    hipLaunchKernelGGL(intra_satd_kernel<32>, grid, dim3(256), 0, ctx->stream, orig->v,
                        rec->v, d_jobs, n, d_dist);
   else
-    hipLaunchKernelGGL(intra_satd_kernel<64>, dim3(n), dim3(256), 0, ctx->stream, orig->v,
+    hipLaunchKernelGGL(intra_satd_kernel<64>, grid, dim3(256), 0, ctx->stream, orig->v,
                        rec->v, d_jobs, n, d_dist);
   CHECK_LAUNCH(ctx, "intra_satd_batch");
+  return XVCGPU_OK;
+}
+
+xvcgpu_status xvcgpu_intra_recon_batch(xvcgpu_ctx *ctx, const xvcgpu_picture *orig,
+                                       xvcgpu_picture *rec,
+                                       const xvcgpu_intra_block *d_jobs,
+                                       const xvcgpu_tx_block *d_blocks, int n,
+                                       int16_t *d_levels, const uint32_t *d_level_offsets,
+                                       int32_t *d_nnz) {
+  if (!ctx || !rec || n < 0 || (n && (!d_jobs || !d_blocks))) return XVCGPU_INVALID_ARGUMENT;
+  // decoder form (no original): the levels are an input and must be there
+  if (!orig && n && (!d_levels || !d_level_offsets || !d_nnz)) return XVCGPU_INVALID_ARGUMENT;
+  if (orig && (orig->w != rec->w || orig->h != rec->h || orig->bd != rec->bd))
+    return fail(ctx, XVCGPU_INVALID_ARGUMENT, "picture mismatch");
+  if (n == 0) return XVCGPU_OK;
+  const dim3 grid((n + TX2_WAVES - 1) / TX2_WAVES), block(64 * TX2_WAVES);
+  if (orig)
+    hipLaunchKernelGGL(intra_recon_wave_kernel<TX_MODE_FULL>, grid, block, 0, ctx->stream,
+                       orig->v, rec->v, d_jobs, d_blocks, n, d_levels, d_level_offsets, d_nnz,
+                       ctx->d_tx_tables, ctx->d_tx_tables_t, xvcgpu_tx_layout());
+  else
+    hipLaunchKernelGGL(intra_recon_wave_kernel<TX_MODE_INV>, grid, block, 0, ctx->stream,
+                       rec->v, rec->v, d_jobs, d_blocks, n, d_levels, d_level_offsets, d_nnz,
+                       ctx->d_tx_tables, ctx->d_tx_tables_t, xvcgpu_tx_layout());
+  CHECK_LAUNCH(ctx, "intra_recon_batch");
+  return XVCGPU_OK;
+}
+
+xvcgpu_status xvcgpu_intra_select_modes(xvcgpu_ctx *ctx, const uint32_t *d_dist,
+                                        const uint32_t *d_mode_cost, int n,
+                                        int32_t *d_modes, xvcgpu_intra_block *d_jobs,
+                                        xvcgpu_tx_block *d_blocks, int per_cu) {
+  if (!ctx || n < 0 || (n && !d_dist) || per_cu < 0 || per_cu > 3 ||
+      ((d_jobs || d_blocks) && per_cu == 0))
+    return XVCGPU_INVALID_ARGUMENT;
+  if (n == 0) return XVCGPU_OK;
+  hipLaunchKernelGGL(intra_select_kernel, dim3((n + 3) / 4), dim3(256), 0, ctx->stream,
+                     d_dist, d_mode_cost, n, d_modes, d_jobs, d_blocks, per_cu);
+  CHECK_LAUNCH(ctx, "intra_select_modes");
   return XVCGPU_OK;
 }
 

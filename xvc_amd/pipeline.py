@@ -330,6 +330,7 @@ class IntraPictureDescriptors:
         self.n_cus = n
         self.luma = np.zeros(n, api.INTRA_DTYPE)
         self.chroma = np.zeros(2 * n, api.INTRA_DTYPE)      # U then V of each CU
+        self.jobs3 = np.zeros(3 * n, api.INTRA_DTYPE)       # Y, U, V of each CU (= tx order)
         self.tx = np.zeros(3 * n, api.TX_DTYPE)              # Y, U, V of each CU
         wave_of = []
         for i, (x, y, w, h) in enumerate(self.parts):
@@ -348,6 +349,9 @@ class IntraPictureDescriptors:
                 t["comp"], t["qp"] = c, (self.qp_c if c else qp)
                 t["intra_pic"] = api.TXF_INTRA_PIC
             wave_of.append(x // cu + 2 * (y // cu))
+        self.jobs3[0::3] = self.luma
+        self.jobs3[1::3] = self.chroma[0::2]
+        self.jobs3[2::3] = self.chroma[1::2]
         wave_of = np.array(wave_of)
         self.wave_start = np.searchsorted(wave_of, np.arange(wave_of.max() + 2))
         self.level_off, self.level_total = api.Context.level_offsets(self.tx)
@@ -362,16 +366,16 @@ class IntraPictureDescriptors:
         """Modes of CUs [a, b): luma jobs, chroma jobs (DM: the luma mode) and
         the coefficient scan of small CUs (TransformHelper::DetermineScanOrder,
         transform.cc:1614-1637)."""
-        for i, m in zip(range(a, b), modes):
-            m = int(m)
-            self.luma[i]["mode"] = m
-            self.chroma[2 * i]["mode"] = self.chroma[2 * i + 1]["mode"] = m
-            _, _, w, h = self.parts[i]
-            scan = 0
-            if w < 16 and h < 16:
-                scan = 1 if abs(m - 50) < 10 else (2 if abs(m - 18) < 10 else 0)
-            for c in range(3):
-                self.tx[3 * i + c]["intra_pic"] = api.TXF_INTRA_PIC | (scan << api.TXF_SCAN_SHIFT)
+        m = np.asarray(modes, np.int64).reshape(-1)
+        assert len(m) == b - a
+        self.luma["mode"][a:b] = m
+        self.chroma["mode"][2 * a:2 * b] = np.repeat(m, 2)
+        self.jobs3["mode"][3 * a:3 * b] = np.repeat(m, 3)
+        small = (self.luma["w"][a:b] < 16) & (self.luma["h"][a:b] < 16)
+        scan = np.where(np.abs(m - 50) < 10, 1, np.where(np.abs(m - 18) < 10, 2, 0))
+        scan = np.where(small, scan, 0)
+        self.tx["intra_pic"][3 * a:3 * b] = np.repeat(
+            api.TXF_INTRA_PIC | (scan << api.TXF_SCAN_SHIFT), 3)
 
 
 class IntraPicturePass:
@@ -388,25 +392,47 @@ class IntraPicturePass:
     raster CU order instead of the CTU quad-tree order); the oracle's twin in
     tests/oracle_intra_picture.py is the same composition on the CPU."""
 
-    def __init__(self, ctx, width, height, bitdepth=10, qp=32, cu=16):
+    def __init__(self, ctx, width, height, bitdepth=10, qp=32, cu=16, fused=None):
         self.ctx, self.bd = ctx, bitdepth
         self.desc = d = IntraPictureDescriptors(width, height, qp, cu)
+        # CUs up to 16x16: prediction + residual pipeline in one launch per wave
+        # (xvcgpu_intra_recon_batch); else prediction picture + separate launches
+        self.fused = (cu <= 16) if fused is None else fused
         self.pred = ctx.picture(width, height, bitdepth)
         self.d_luma = ctx.buffer(d.luma)
         self.d_chroma = ctx.buffer(d.chroma)
+        self.d_jobs3 = ctx.buffer(d.jobs3)
         self.d_tx = ctx.buffer(d.tx)
         self.d_off = ctx.buffer(d.level_off)
         self.d_levels = ctx.alloc(2 * max(1, d.level_total))
         self.d_nnz = ctx.alloc(4 * len(d.tx))
         self.d_dist = ctx.alloc(4 * api.INTRA_NUM_MODES * d.n_cus)
+        self.d_modes = ctx.alloc(4 * d.n_cus)
 
     def _upload_range(self, buf, arr, a, b):
         sz = arr.dtype.itemsize
         self.ctx.h2d(buf.ptr + a * sz, arr[a:b])
 
-    def encode(self, orig, rec):
+    def encode(self, orig, rec, host_select=False):
+        """host_select: fold the SATD table on the host (one round trip per
+        wave, the reference's division of labour); default: on the device
+        (xvcgpu_intra_select_modes), the whole picture enqueued without a sync."""
         ctx, d, lib = self.ctx, self.desc, self.ctx.lib
         J, T = api.INTRA_DTYPE.itemsize, api.TX_DTYPE.itemsize
+        if not host_select and self.fused:
+            M = 4 * api.INTRA_NUM_MODES
+            for a, b in d.waves():
+                n = b - a
+                ctx._check(lib.xvcgpu_intra_satd_batch(
+                    ctx.h, orig.h_pic, rec.h_pic, self.d_luma.ptr + a * J, n,
+                    self.d_dist.ptr + a * M, d.cu))
+                ctx._check(lib.xvcgpu_intra_select_modes(
+                    ctx.h, self.d_dist.ptr + a * M, None, n, self.d_modes.ptr + 4 * a,
+                    self.d_jobs3.ptr + 3 * a * J, self.d_tx.ptr + 3 * a * T, 3))
+                self._recon(orig, rec, a, b)
+            modes = self.d_modes.to_array(np.int32, d.n_cus)    # synchronises
+            d.set_modes(0, d.n_cus, modes)
+            return
         for a, b in d.waves():
             n = b - a
             ctx._check(lib.xvcgpu_intra_satd_batch(ctx.h, orig.h_pic, rec.h_pic,
@@ -415,14 +441,25 @@ class IntraPicturePass:
             dist = self.d_dist.to_array(np.uint32, n * api.INTRA_NUM_MODES) \
                 .reshape(n, api.INTRA_NUM_MODES)
             d.set_modes(a, b, dist.argmin(axis=1))
+            self._upload_range(self.d_tx, d.tx, 3 * a, 3 * b)
+            if self.fused:
+                self._upload_range(self.d_jobs3, d.jobs3, 3 * a, 3 * b)
+                self._recon(orig, rec, a, b)
+                continue
             self._upload_range(self.d_luma, d.luma, a, b)
             self._upload_range(self.d_chroma, d.chroma, 2 * a, 2 * b)
-            self._upload_range(self.d_tx, d.tx, 3 * a, 3 * b)
             self._wave(rec, a, b)
             ctx.residual_batch_dev(orig, self.pred, rec, self.d_tx.ptr + 3 * a * T, 3 * n,
                                    self.d_levels.ptr, self.d_off.ptr + 3 * a * 4,
                                    self.d_nnz.ptr + 3 * a * 4)
         ctx.sync()
+
+    def _recon(self, orig, rec, a, b):
+        ctx, J, T = self.ctx, api.INTRA_DTYPE.itemsize, api.TX_DTYPE.itemsize
+        ctx._check(ctx.lib.xvcgpu_intra_recon_batch(
+            ctx.h, orig.h_pic if orig is not None else None, rec.h_pic,
+            self.d_jobs3.ptr + 3 * a * J, self.d_tx.ptr + 3 * a * T, 3 * (b - a),
+            self.d_levels.ptr, self.d_off.ptr + 3 * a * 4, self.d_nnz.ptr + 3 * a * 4))
 
     def _wave(self, rec, a, b):
         ctx, lib, J = self.ctx, self.ctx.lib, api.INTRA_DTYPE.itemsize
@@ -436,7 +473,8 @@ class IntraPicturePass:
         results() returned them."""
         d = self.desc
         d.set_modes(0, d.n_cus, modes)
-        for buf, arr in ((self.d_luma, d.luma), (self.d_chroma, d.chroma), (self.d_tx, d.tx)):
+        for buf, arr in ((self.d_luma, d.luma), (self.d_chroma, d.chroma), (self.d_tx, d.tx),
+                         (self.d_jobs3, d.jobs3)):
             self._upload_range(buf, arr, 0, len(arr))
         self.ctx.h2d(self.d_levels.ptr, np.ascontiguousarray(levels, np.int16))
         self.ctx.h2d(self.d_nnz.ptr, np.ascontiguousarray(nnz, np.int32))
@@ -444,6 +482,9 @@ class IntraPicturePass:
     def decode(self, rec):
         ctx, d, T = self.ctx, self.desc, api.TX_DTYPE.itemsize
         for a, b in d.waves():
+            if self.fused:
+                self._recon(None, rec, a, b)
+                continue
             self._wave(rec, a, b)
             ctx._check(ctx.lib.xvcgpu_inv_transform_batch(
                 ctx.h, self.pred.h_pic, rec.h_pic, self.d_tx.ptr + 3 * a * T, 3 * (b - a),
@@ -455,7 +496,7 @@ class IntraPicturePass:
                 self.d_nnz.to_array(np.int32, len(d.tx)))
 
     def destroy(self):
-        for b in (self.d_luma, self.d_chroma, self.d_tx, self.d_off, self.d_levels,
-                  self.d_nnz, self.d_dist):
+        for b in (self.d_luma, self.d_chroma, self.d_jobs3, self.d_tx, self.d_off,
+                  self.d_levels, self.d_nnz, self.d_dist, self.d_modes):
             b.free()
         self.pred.destroy()
