@@ -420,7 +420,10 @@ xvcgpu_status xvcgpu_histogram_distance(xvcgpu_ctx *ctx, const xvcgpu_picture *a
  * samples from `rec` (the neighbours it declares available must already be
  * reconstructed there) and writes the prediction of job.mode into `pred` at
  * the block's position.  Any component; comp 0 applies the luma rules
- * (filtered references, edge filters up to 16x16).  LM chroma is not covered. */
+ * (filtered references, edge filters up to 16x16).  Chroma jobs may also ask for
+ * mode XVC_INTRA_MODE_LM_CHROMA (PredLmChroma, :560-686, :873-906): the linear
+ * model from the CU's own reconstructed luma, which must be in `rec` already
+ * (availability = picture edges only, as in the reference). */
 xvcgpu_status xvcgpu_intra_pred_batch(xvcgpu_ctx *ctx, const xvcgpu_picture *rec,
                                       xvcgpu_picture *pred,
                                       const xvcgpu_intra_block *d_jobs, int n);

@@ -138,6 +138,9 @@ typedef struct xvcgpu_mc_affine_block {
 #define XVC_INTRA_HAS_ABOVE 2
 #define XVC_INTRA_HAS_LEFT 4
 #define XVC_INTRA_NUM_MODES 67 /* 0 planar, 1 DC, 2..66 angular (18 hor, 50 ver) */
+/* chroma only: the linear model from the CU's reconstructed luma
+ * (IntraMode::kLmChroma; prediction entry points, not the SATD table) */
+#define XVC_INTRA_MODE_LM_CHROMA 67
 typedef struct xvcgpu_intra_block {
   int16_t x, y;        /* position in the component plane                  */
   uint8_t w, h;        /* size in the component plane, {4,...,64}          */

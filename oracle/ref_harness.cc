@@ -1144,4 +1144,30 @@ void xr_intra_satd_modes(int bd, const xvcgpu_intra_block *b, int pic_w, int pic
         orig_pic.GetStride(YuvComponent::kY), pred.GetDataPtr(), pred.GetStride()));
   }
 }
+
+/* IntraPrediction::Predict(kLmChroma) for the U or V block of a CU: needs the
+ * whole reconstruction picture (luma of the CU, neighbouring rows / columns). */
+void xr_intra_lm_chroma(int bd, int comp, int x, int y, int w, int h, int pic_w, int pic_h,
+                        const uint16_t *const planes[3], const ptrdiff_t strides[3],
+                        uint16_t *out, ptrdiff_t os) {
+  PictureData pic_data(ChromaFormat::k420, pic_w, pic_h, bd);
+  CodingUnit *cu = pic_data.CreateCu(CuTree::Primary, 1, 2 * x, 2 * y, 2 * w, 2 * h);
+  YuvPicture rec_pic(ChromaFormat::k420, pic_w, pic_h, bd, true, 0, 0);
+  for (int c = 0; c < 3; c++) {
+    const YuvComponent cc = YuvComponent(c);
+    for (int yy = 0; yy < rec_pic.GetHeight(cc); yy++)
+      std::memcpy(rec_pic.GetSamplePtr(cc, 0, yy), planes[c] + yy * strides[c],
+                  sizeof(Sample) * rec_pic.GetWidth(cc));
+  }
+  IntraPrediction ip(bd);
+  IntraPrediction::RefState state;   /* not used by the LM mode */
+  SampleBufferStorage tmp(64, 64);
+  /* the down-scaled luma is produced by the first chroma component's call and
+   * reused by the second (intra_prediction.cc:574-580) */
+  if (comp == 2)
+    ip.Predict(IntraMode::kLmChroma, *cu, YuvComponent::kU, state, rec_pic, &tmp);
+  ip.Predict(IntraMode::kLmChroma, *cu, YuvComponent(comp), state, rec_pic, &tmp);
+  for (int yy = 0; yy < h; yy++)
+    std::memcpy(out + yy * os, tmp.GetDataPtr() + yy * tmp.GetStride(), sizeof(Sample) * w);
+}
 }  // extern "C"

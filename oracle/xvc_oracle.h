@@ -274,6 +274,9 @@ int xo_intra_use_filtered(int w, int h, int mode);
 void xo_intra_predict(int bitdepth, int is_luma, int mode, int w, int h,
                       const uint16_t *ref, const uint16_t *ref_filtered, uint16_t *out,
                       ptrdiff_t os);
+void xo_intra_lm_chroma(int bitdepth, int x, int y, int w, int h, const uint16_t *luma,
+                        ptrdiff_t ls, const uint16_t *chroma, ptrdiff_t cs, uint16_t *out,
+                        ptrdiff_t os);
 void xo_intra_pred_block(int bitdepth, const xvcgpu_intra_block *b, const uint16_t *rec,
                          ptrdiff_t rs, uint16_t *pred, ptrdiff_t ps);
 void xo_intra_satd_modes(int bitdepth, const xvcgpu_intra_block *b, const uint16_t *orig,

@@ -228,8 +228,109 @@ void xo_intra_predict(int bitdepth, int is_luma, int mode, int w, int h,
   }
 }
 
+static int log2_floor(int x) { /* util::Log2Floor */
+  int n = 0;
+  while (x > 1) {
+    n++;
+    x >>= 1;
+  }
+  return n;
+}
+
+/* PredLmChroma (intra_prediction.cc:560-585) for 4:2:0: RescaleLuma (:873-906,
+ * the CU's reconstructed luma and its row above / column to the left, [1 2 1;
+ * 1 2 1] / 8), DeriveLmParams (:587-686, a least-squares line through the
+ * neighbouring (down-scaled luma, chroma) pairs in integer arithmetic) and
+ * AddLinearModel (sample_buffer.h:108-122).  (x, y, w, h) in chroma samples;
+ * `luma` / `chroma` point at sample (0,0) of the reconstruction planes. */
+void xo_intra_lm_chroma(int bitdepth, int x, int y, int w, int h, const uint16_t *luma,
+                        ptrdiff_t ls, const uint16_t *chroma, ptrdiff_t cs, uint16_t *out,
+                        ptrdiff_t os) {
+  const int has_above = y > 0, has_left = x > 0;
+  uint16_t sub_buf[(64 + 1) * (64 + 1)];
+  const int ss = 65;
+  uint16_t *sub = sub_buf + ss + 1; /* (0,0) of the block; row -1 / column -1 exist */
+  const uint16_t *src0 = luma + (ptrdiff_t)(2 * y) * ls + 2 * x;
+  const uint16_t *src = src0 + (has_above ? -2 * ls : 0);
+  const int start_x = has_left ? 0 : 1, start_y = has_above ? -1 : 0;
+  for (int yy = start_y; yy < h; yy++) {
+    if (has_left) {
+      const int sum = src[-3] + 2 * src[-2] + src[-1] + src[-3 + ls] + 2 * src[-2 + ls] + src[-1 + ls];
+      sub[yy * ss - 1] = (uint16_t)((sum + 4) >> 3);
+    } else {
+      sub[yy * ss] = (uint16_t)((src[0] + src[ls] + 1) >> 1);
+    }
+    for (int xx = start_x; xx < w; xx++) {
+      const int sum = src[2 * xx - 1] + 2 * src[2 * xx] + src[2 * xx + 1] + src[2 * xx - 1 + ls] +
+                      2 * src[2 * xx + ls] + src[2 * xx + 1 + ls];
+      sub[yy * ss + xx] = (uint16_t)((sum + 4) >> 3);
+    }
+    src += 2 * ls;
+  }
+  /* DeriveLmParams */
+  int scale = 0, shift = 0, offset = 1 << (bitdepth - 1);
+  if (has_above || has_left) {
+    const uint16_t *cb = chroma + (ptrdiff_t)y * cs + x;
+    int sum_x = 0, sum_y = 0, sum_xx = 0, sum_xy = 0, nbr = 0;
+    if (has_above) {
+      const int dx = has_left ? (w / h > 1 ? w / h : 1) : 1;
+      for (int xx = 0; xx < w; xx += dx) {
+        const int r = sub[-ss + xx], c = cb[-cs + xx];
+        sum_x += r; sum_y += c; sum_xx += r * r; sum_xy += r * c; nbr++;
+      }
+    }
+    if (has_left) {
+      const int dy = has_above ? (h / w > 1 ? h / w : 1) : 1;
+      for (int yy = 0; yy < h; yy += dy) {
+        const int r = sub[yy * ss - 1], c = cb[yy * cs - 1];
+        sum_x += r; sum_y += c; sum_xx += r * r; sum_xy += r * c; nbr++;
+      }
+    }
+    int size_shift = 1; /* util::SizeToLog2 starts at 1 */
+    while ((1 << size_shift) < nbr) size_shift++;
+    if (size_shift > 15 - bitdepth) {
+      const int sh = size_shift + bitdepth - 15;
+      sum_x = (sum_x + (1 << (sh - 1))) >> sh;
+      sum_y = (sum_y + (1 << (sh - 1))) >> sh;
+      sum_xx = (sum_xx + (1 << (sh - 1))) >> sh;
+      sum_xy = (sum_xy + (1 << (sh - 1))) >> sh;
+      size_shift -= sh;
+    }
+    const int avg_x = sum_x >> size_shift, avg_y = sum_y >> size_shift;
+    const int x_frac = sum_x & ((1 << size_shift) - 1), y_frac = sum_y & ((1 << size_shift) - 1);
+    const int sxy = sum_xy - ((avg_x * avg_y) << size_shift) - (avg_x * y_frac) - (avg_y * x_frac);
+    const int sxx = sum_xx - ((avg_x * avg_x) << size_shift) - 2 * avg_x * x_frac;
+    int shift_xy = sxy == 0 ? 0 : log2_floor(abs(sxy)) - bitdepth + 2;
+    if (shift_xy < 0) shift_xy = 0;
+    int shift_xx = sxx == 0 ? 0 : log2_floor(abs(sxx)) - 5;
+    if (shift_xx < 0) shift_xx = 0;
+    const int sxy_s = sxy >> shift_xy, sxx_s = sxx >> shift_xx;
+    const int total_shift = bitdepth + shift_xx + 4 + 7 - 13 - shift_xy;
+    if (sxx_s < 32) {
+      scale = 0; offset = avg_y; shift = 0;
+    } else {
+      int sc = (int)((uint32_t)sxy_s *
+                     (uint32_t)(((1 << (bitdepth + 4)) + (sxx_s / 2)) / sxx_s));
+      sc = sc >> total_shift;
+      sc = sc < -256 ? -256 : (sc > 255 ? 255 : sc);
+      scale = 128 * sc;
+      const int base_shift = log2_floor(abs(scale) + (scale < 0 ? -1 : 0)) - (scale ? 5 : 0);
+      shift = 13 - base_shift;
+      scale >>= base_shift;
+      offset = avg_y - ((scale * avg_x) >> shift);
+    }
+  }
+  const int max = (1 << bitdepth) - 1;
+  for (int yy = 0; yy < h; yy++)
+    for (int xx = 0; xx < w; xx++) {
+      const int v = ((scale * sub[yy * ss + xx]) >> shift) + offset;
+      out[yy * os + xx] = (uint16_t)(v < 0 ? 0 : (v > max ? max : v));
+    }
+}
+
 /* One job of the prediction batch: reference samples from the reconstruction
- * plane, then the block's prediction. */
+ * plane, then the block's prediction.  (XVC_INTRA_MODE_LM_CHROMA jobs need the
+ * luma plane too: xo_intra_lm_chroma.) */
 void xo_intra_pred_block(int bitdepth, const xvcgpu_intra_block *b, const uint16_t *rec,
                          ptrdiff_t rs, uint16_t *pred, ptrdiff_t ps) {
   uint16_t ref[RS * 2], filt[RS * 2];

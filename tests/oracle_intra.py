@@ -97,3 +97,27 @@ def random_jobs(rng, pic_w, pic_h, comp, n, sizes=(4, 8, 16, 32, 64)):
         j["neighbors"], j["above_right"], j["below_left"] = nb, ar, bl
         j["mode"] = int(rng.integers(0, NUM_MODES))
     return jobs
+
+
+def lm_chroma(lib, prefix, bd, comp, x, y, w, h, planes):
+    """LM chroma prediction of the (x, y, w, h) block (chroma samples) of
+    component comp from the reconstruction planes [Y, U, V]."""
+    out = np.zeros((h, w), np.uint16)
+    if prefix == "xo":
+        f = lib.dll.xo_intra_lm_chroma
+        f.restype = None
+        f.argtypes = [C.c_int] * 5 + [u16p, pd, u16p, pd, u16p, pd]
+        lp, ls = _p(planes[0])
+        cp, cs = _p(planes[comp])
+        f(bd, x, y, w, h, lp, ls, cp, cs, C.cast(out.ctypes.data, u16p), w)
+    else:
+        f = lib.dll.xr_intra_lm_chroma
+        f.restype = None
+        f.argtypes = [C.c_int] * 8 + [C.POINTER(u16p), C.POINTER(pd), u16p, pd]
+        pp = (u16p * 3)()
+        ss = (pd * 3)()
+        for c in range(3):
+            pp[c], ss[c] = _p(planes[c])
+        ph, pw = planes[0].shape
+        f(bd, comp, x, y, w, h, pw, ph, pp, ss, C.cast(out.ctypes.data, u16p), w)
+    return out

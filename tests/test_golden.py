@@ -289,6 +289,11 @@ def test_oracle_intra(xo):
     orig, rec = np.ascontiguousarray(g["orig"]), np.ascontiguousarray(g["rec"])
     for j, exp in zip(g["satd_jobs"], g["satd"]):
         assert np.array_equal(oi.satd_modes(xo, "xo", bd, j, orig, rec), exp), j
+    planes = [rec, np.ascontiguousarray(g["lm_u"]), np.ascontiguousarray(g["lm_v"])]
+    for j, exp in zip(g["lm_jobs"], g["lm_pred"]):
+        x, y, bw, bh, comp = (int(j[k]) for k in ("x", "y", "w", "h", "comp"))
+        assert np.array_equal(oi.lm_chroma(xo, "xo", bd, comp, x, y, bw, bh, planes),
+                              exp[:bh, :bw]), j
 
 
 # ------------------------------------------------------------------------ GPU
@@ -551,5 +556,11 @@ def test_gpu_intra(gpu):
         assert np.array_equal(got, exp[:bh, :bw]), j
     got = ctx.intra_satd_batch(O, R, g["satd_jobs"])
     assert np.array_equal(got, g["satd"])
+    R.upload([np.ascontiguousarray(g["rec"]), np.ascontiguousarray(g["lm_u"]),
+              np.ascontiguousarray(g["lm_v"])])
+    for j, exp in zip(g["lm_jobs"], g["lm_pred"]):
+        ctx.intra_pred_batch(R, P, np.array([j], api.INTRA_DTYPE))
+        x, y, bw, bh, comp = (int(j[k]) for k in ("x", "y", "w", "h", "comp"))
+        assert np.array_equal(P.download()[comp][y:y + bh, x:x + bw], exp[:bh, :bw]), j
     for p in (R, O, P):
         p.destroy()

@@ -215,3 +215,41 @@ def test_intra_picture_pass(gpu, xo, w, h, bd, qp, cu, fused):
     ip.destroy()
     for p in (O, R, D):
         p.destroy()
+
+
+@pytest.mark.parametrize("bd", [8, 10, 12])
+def test_intra_lm_chroma(gpu, xo, bd):
+    """LM chroma jobs (mode 67) of the prediction batch against the oracle."""
+    api, ctx = gpu
+    rng = np.random.default_rng(1060 + bd)
+    w, h = 320, 256
+    mx = (1 << bd) - 1
+    luma = rnd_samples(rng, bd, h, w, True)
+    base = luma[0::2, 0::2].astype(np.int64)
+    u = np.clip(base * 3 // 4 + 40 + rng.integers(-6, 7, base.shape), 0, mx).astype(np.uint16)
+    v = rng.integers(0, mx + 1, base.shape).astype(np.uint16)
+    v[:40, :60] = 99 % mx
+    planes = [luma, np.ascontiguousarray(u), np.ascontiguousarray(v)]
+    R = upload(ctx, planes, w, h, bd)
+    P = ctx.picture(w, h, bd)
+    total = 0
+    for trial in range(6):
+        jobs = []
+        for gy in range(4):          # disjoint blocks on a 40 x 32 grid (chroma units)
+            for gx in range(4):
+                bw, bh = int(rng.choice([2, 4, 8, 16, 32])), int(rng.choice([2, 4, 8, 16, 32]))
+                x = gx * 40 + (0 if trial % 2 == 0 and gx == 0 else 2 * int(rng.integers(0, 4)))
+                y = gy * 32 + (0 if trial % 3 == 0 and gy == 0 else 0)
+                for comp in (1, 2):
+                    jobs.append((x, y, bw, bh, comp, 67, 0, 0, 0, 0))
+        jobs = np.array(jobs, oi.INTRA_DTYPE)
+        ctx.intra_pred_batch(R, P, jobs)
+        got = P.download()
+        for j in jobs:
+            x, y, bw, bh, comp = (int(j[k]) for k in ("x", "y", "w", "h", "comp"))
+            exp = oi.lm_chroma(xo, "xo", bd, comp, x, y, bw, bh, planes)
+            assert np.array_equal(got[comp][y:y + bh, x:x + bw], exp), j
+            total += 1
+    assert total == 6 * 32
+    R.destroy()
+    P.destroy()

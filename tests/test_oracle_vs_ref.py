@@ -710,3 +710,48 @@ def test_intra_satd_modes(libs, bd):
         assert np.array_equal(got, exp), j
         if j["neighbors"] == 7:
             assert len(set(exp.tolist())) > 8   # the modes really differ
+
+
+@pytest.mark.parametrize("bd", [8, 10, 12])
+def test_intra_lm_chroma(libs, bd):
+    """IntraPrediction::PredLmChroma: luma down-scaling, the integer
+    least-squares model and its application, for blocks at the picture edges
+    and inside, square and not, on correlated, flat and noisy content."""
+    import oracle_intra as oi
+    xo, xr = libs
+    rng = np.random.default_rng(860 + bd)
+    pw, ph = 160, 128
+    n = 0
+    for content in range(4):
+        luma = rnd_samples(rng, bd, ph, pw, content != 3)
+        base = luma[0::2, 0::2].astype(np.int64)
+        mx = (1 << bd) - 1
+        if content == 0:      # chroma = a line through luma + noise
+            u = np.clip(base * 3 // 4 + 40 + rng.integers(-6, 7, base.shape), 0, mx)
+            v = np.clip(mx - base // 2 + rng.integers(-3, 4, base.shape), 0, mx)
+        elif content == 1:    # flat chroma
+            u = np.full_like(base, 1 << (bd - 1))
+            v = np.full_like(base, 17)
+        elif content == 2:    # flat luma neighbourhoods
+            luma[:] = 300 % mx
+            u = rng.integers(0, mx + 1, base.shape)
+            v = np.clip(base + rng.integers(-20, 21, base.shape), 0, mx)
+        else:
+            u = rng.integers(0, mx + 1, base.shape)
+            v = rng.integers(0, mx + 1, base.shape)
+        planes = [luma, np.ascontiguousarray(u.astype(np.uint16)),
+                  np.ascontiguousarray(v.astype(np.uint16))]
+        for _ in range(30):
+            w, h = int(rng.choice([2, 4, 8, 16, 32])), int(rng.choice([2, 4, 8, 16, 32]))
+            x = int(rng.integers(0, (pw // 2 - w) // 2 + 1)) * 2
+            y = int(rng.integers(0, (ph // 2 - h) // 2 + 1)) * 2
+            if rng.random() < 0.25:
+                x = 0
+            if rng.random() < 0.25:
+                y = 0
+            for comp in (1, 2):
+                exp = oi.lm_chroma(xr, "xr", bd, comp, x, y, w, h, planes)
+                got = oi.lm_chroma(xo, "xo", bd, comp, x, y, w, h, planes)
+                assert np.array_equal(got, exp), (content, comp, x, y, w, h)
+                n += 1
+    assert n == 240

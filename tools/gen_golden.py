@@ -233,6 +233,23 @@ def gen_intra(xr):
             jobs.append(j)
             preds.append(pp)
     out["jobs"], out["pred"] = np.array(jobs, oi.INTRA_DTYPE), np.array(preds)
+    # LM chroma: chroma planes correlated with the luma reconstruction
+    base = rec[0::2, 0::2].astype(np.int64)
+    u = np.clip(base * 3 // 4 + 40 + rng.integers(-6, 7, base.shape), 0, 1023).astype(np.uint16)
+    v = np.clip(1023 - base // 2 + rng.integers(-30, 31, base.shape), 0, 1023).astype(np.uint16)
+    out["lm_u"], out["lm_v"] = u, v
+    lm_jobs, lm_pred = [], []
+    for k in range(40):
+        bw, bh = int(rng.choice([2, 4, 8, 16, 32])), int(rng.choice([2, 4, 8, 16, 32]))
+        x = 0 if k % 5 == 0 else int(rng.integers(0, (w // 2 - bw) // 2 + 1)) * 2
+        y = 0 if k % 7 == 0 else int(rng.integers(0, (h // 2 - bh) // 2 + 1)) * 2
+        comp = 1 + k % 2
+        p = oi.lm_chroma(xr, "xr", bd, comp, x, y, bw, bh, [rec, u, v])
+        pp = np.zeros((32, 32), np.uint16)
+        pp[:bh, :bw] = p
+        lm_jobs.append((x, y, bw, bh, comp, 67, 0, 0, 0, 0))
+        lm_pred.append(pp)
+    out["lm_jobs"], out["lm_pred"] = np.array(lm_jobs, oi.INTRA_DTYPE), np.array(lm_pred)
     sj = oi.random_jobs(rng, w, h, 0, 40)
     out["satd_jobs"] = sj
     out["satd"] = np.array([oi.satd_modes(xr, "xr", bd, j, orig, rec) for j in sj])

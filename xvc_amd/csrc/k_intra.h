@@ -179,9 +179,121 @@ __device__ __forceinline__ void intra_predict(const IntraRefs &r, uint16_t *line
   if (WG_SYNC) __syncthreads();  // `line` may be rebuilt by the caller's next mode
 }
 
+// PredLmChroma (intra_prediction.cc:560-585), 4:2:0, by one workgroup of 256:
+// RescaleLuma (:873-906) of the CU's reconstructed luma plus the row above /
+// column to the left into LDS, DeriveLmParams (:587-686: the neighbour sums by
+// the first wave, the integer model by one thread), AddLinearModel.
+struct IntraLmShared {
+  uint16_t sub[33 * 33];  // (h + 1) x (w + 1), block origin at [1][1]
+  int scale, shift, offset;
+};
+
+__device__ __forceinline__ int d_log2_floor(int x) { return x > 1 ? 31 - __clz(x) : 0; }
+
+__device__ __forceinline__ void intra_lm_chroma(IntraLmShared &s, const xvcgpu_intra_block &b,
+                                                const PlaneView &luma, const PlaneView &chroma,
+                                                int bd, uint16_t *out, int os) {
+  const int w = b.w, h = b.h, tid = threadIdx.x;
+  const bool has_above = b.y > 0, has_left = b.x > 0;
+  constexpr int SS = 33;
+  uint16_t *sub = s.sub + SS + 1;
+  const int ls = luma.stride;
+  const uint16_t *src0 = luma.p + (ptrdiff_t)(2 * b.y) * ls + 2 * b.x;
+  const int x0 = has_left ? -1 : 0, y0 = has_above ? -1 : 0;
+  const int cols = w - x0, rows = h - y0;
+  for (int p = tid; p < cols * rows; p += 256) {
+    const int yy = y0 + p / cols, xx = x0 + p % cols;
+    const uint16_t *r = src0 + (ptrdiff_t)(2 * yy) * ls;
+    int v;
+    if (xx == 0 && !has_left) {
+      v = (r[0] + r[ls] + 1) >> 1;
+    } else {  // column -1 uses the same taps at 2 * (-1) = -2: src[-3], src[-2], src[-1]
+      const uint16_t *q = r + 2 * xx;
+      v = (q[-1] + 2 * q[0] + q[1] + q[-1 + ls] + 2 * q[ls] + q[1 + ls] + 4) >> 3;
+    }
+    sub[yy * SS + xx] = (uint16_t)v;
+  }
+  __syncthreads();
+  if (tid < 64) {
+    int sx = 0, sy = 0, sxx = 0, sxy = 0, nbr = 0;
+    if (has_above || has_left) {
+      const uint16_t *cb = chroma.p + (ptrdiff_t)b.y * chroma.stride + b.x;
+      const int cs = chroma.stride;
+      const int dx = has_left ? (w / h > 1 ? w / h : 1) : 1;
+      const int dy = has_above ? (h / w > 1 ? h / w : 1) : 1;
+      const int na = has_above ? w / dx : 0, nl = has_left ? h / dy : 0;
+      nbr = na + nl;
+      for (int i = tid; i < nbr; i += 64) {  // nbr <= 64: one step
+        int r, c;
+        if (i < na) {
+          r = sub[-SS + i * dx];
+          c = cb[-cs + i * dx];
+        } else {
+          const int yy = (i - na) * dy;
+          r = sub[yy * SS - 1];
+          c = cb[(ptrdiff_t)yy * cs - 1];
+        }
+        sx += r; sy += c; sxx += r * r; sxy += r * c;
+      }
+      sx = group_sum<64>(sx);
+      sy = group_sum<64>(sy);
+      sxx = group_sum<64>(sxx);
+      sxy = group_sum<64>(sxy);
+    }
+    if (tid == 0) {
+      int scale = 0, shift = 0, offset = 1 << (bd - 1);
+      if (nbr > 0) {
+        int size_shift = 1;
+        while ((1 << size_shift) < nbr) size_shift++;
+        if (size_shift > 15 - bd) {
+          const int sh = size_shift + bd - 15;
+          sx = (sx + (1 << (sh - 1))) >> sh;
+          sy = (sy + (1 << (sh - 1))) >> sh;
+          sxx = (sxx + (1 << (sh - 1))) >> sh;
+          sxy = (sxy + (1 << (sh - 1))) >> sh;
+          size_shift -= sh;
+        }
+        const int avg_x = sx >> size_shift, avg_y = sy >> size_shift;
+        const int x_frac = sx & ((1 << size_shift) - 1), y_frac = sy & ((1 << size_shift) - 1);
+        const int vxy = sxy - ((avg_x * avg_y) << size_shift) - avg_x * y_frac - avg_y * x_frac;
+        const int vxx = sxx - ((avg_x * avg_x) << size_shift) - 2 * avg_x * x_frac;
+        int shift_xy = vxy == 0 ? 0 : d_log2_floor(d_abs(vxy)) - bd + 2;
+        shift_xy = shift_xy < 0 ? 0 : shift_xy;
+        int shift_xx = vxx == 0 ? 0 : d_log2_floor(d_abs(vxx)) - 5;
+        shift_xx = shift_xx < 0 ? 0 : shift_xx;
+        const int vxy_s = vxy >> shift_xy, vxx_s = vxx >> shift_xx;
+        const int total_shift = bd + shift_xx + 4 + 7 - 13 - shift_xy;
+        if (vxx_s < 32) {
+          offset = avg_y;
+        } else {
+          int sc = (int)((uint32_t)vxy_s * (uint32_t)(((1 << (bd + 4)) + (vxx_s / 2)) / vxx_s));
+          sc >>= total_shift;
+          sc = d_clip3(sc, -256, 255);
+          scale = 128 * sc;
+          const int base_shift =
+              d_log2_floor(d_abs(scale) + (scale < 0 ? -1 : 0)) - (scale ? 5 : 0);
+          shift = 13 - base_shift;
+          scale >>= base_shift;
+          offset = avg_y - ((scale * avg_x) >> shift);
+        }
+      }
+      s.scale = scale;
+      s.shift = shift;
+      s.offset = offset;
+    }
+  }
+  __syncthreads();
+  const int scale = s.scale, shift = s.shift, offset = s.offset, smax = (1 << bd) - 1;
+  for (int p = tid; p < w * h; p += 256) {
+    const int yy = p / w, xx = p - yy * w;
+    out[yy * os + xx] = (uint16_t)d_clip3(((scale * sub[yy * SS + xx]) >> shift) + offset, 0, smax);
+  }
+}
+
 struct IntraPredShared {
   IntraRefs refs;
   uint16_t line[132];
+  IntraLmShared lm;
 };
 
 // grid: n jobs; block 256.  One prediction (job.mode) per job, any component,
@@ -193,6 +305,12 @@ intra_pred_kernel(PicView rec, PicView pred, const xvcgpu_intra_block *jobs, int
   const xvcgpu_intra_block b = jobs[blockIdx.x];
   const PlaneView pr = rec.c[b.comp], pp = pred.c[b.comp];
   const bool is_luma = b.comp == 0;
+  if (b.mode == XVC_INTRA_MODE_LM_CHROMA) {
+    if (!is_luma && b.w <= 32 && b.h <= 32)
+      intra_lm_chroma(s.lm, b, rec.c[0], pr, rec.bd, pp.p + (ptrdiff_t)b.y * pp.stride + b.x,
+                      pp.stride);
+    return;
+  }
   intra_build_refs<true>(s.refs, b, pr.p + (ptrdiff_t)b.y * pr.stride + b.x, pr.stride,
                          rec.bd, is_luma, threadIdx.x, 256);
   intra_predict<true>(s.refs, s.line, rec.bd, is_luma, b.mode, b.w, b.h,
