@@ -321,7 +321,7 @@ def main():
             prof = json.load(open(os.path.join(ROOT, "profiles", "r01_v3_traffic.json")))
             kname = {"me_search": "void me_search_wave_kernel<16, 3>",
                      "recon_from_me": "recon_from_me_kernel",
-                     "picture_ssd": "picture_ssd_kernel", "pad_border": "pad_tb_kernel",
+                     "picture_ssd": "picture_ssd_kernel", "pad_border": "pad_border_kernel",
                      "deblock": "void deblock_pass_kernel<true>"}[dom]
             if W == 1920 and H == 1080 and world == 1:
                 traffic = prof[kname]["hbm_bytes_per_launch"]
