@@ -35,8 +35,9 @@ picture_import_kernel(PicView dst, ImportArgs a) {
   const size_t bps = a.wide ? 2 : 1;
   const uint8_t *row = a.src[c] + (size_t)ys * in_w * bps;
   uint16_t *out = d.p + (ptrdiff_t)y * d.stride;
-  for (int x0 = threadIdx.x * 8; x0 < d.w; x0 += 256 * 8) {
-    uint16_t v[8];
+  for (int x0 = threadIdx.x * 8; x0 < d.w; x0 += blockDim.x * 8) {
+    uint32_t o[4];  // 8 output samples, packed pairs (kept in registers: no local array
+                    // whose address is taken - that one the compiler moves to LDS)
     if (x0 + 8 <= in_w) {
       const uint8_t *sp = row + bps * x0;
       if (a.wide) {
@@ -50,8 +51,8 @@ picture_import_kernel(PicView dst, ImportArgs a) {
           for (int k = 0; k < 4; k++) q[k] = (uint32_t)t.v[2 * k] | ((uint32_t)t.v[2 * k + 1] << 16);
         }
 #pragma unroll
-        for (int k = 0; k < 8; k++)
-          v[k] = (uint16_t)(((q[k >> 1] >> (16 * (k & 1))) & 0xffffu) << a.upshift);
+        for (int k = 0; k < 4; k++)
+          o[k] = (((q[k] & 0xffffu) << a.upshift) & 0xffffu) | ((q[k] >> 16) << (16 + a.upshift));
       } else {
         uint32_t q[2];
         if ((reinterpret_cast<uintptr_t>(sp) & 3) == 0) {
@@ -65,24 +66,32 @@ picture_import_kernel(PicView dst, ImportArgs a) {
                    ((uint32_t)t.v[4 * k + 2] << 16) | ((uint32_t)t.v[4 * k + 3] << 24);
         }
 #pragma unroll
-        for (int k = 0; k < 8; k++)
-          v[k] = (uint16_t)(((q[k >> 2] >> (8 * (k & 3))) & 0xffu) << a.upshift);
+        for (int k = 0; k < 4; k++) {
+          const uint32_t lo = (q[k >> 1] >> (16 * (k & 1))) & 0xffu;
+          const uint32_t hi = (q[k >> 1] >> (16 * (k & 1) + 8)) & 0xffu;
+          o[k] = (lo << a.upshift) | (hi << (16 + a.upshift));
+        }
       }
     } else {  // the chunk that holds the last input column, and the padding
 #pragma unroll
-      for (int k = 0; k < 8; k++) {
-        const int x = x0 + k < in_w ? x0 + k : in_w - 1;
-        const uint32_t s =
-            a.wide ? (uint32_t)row[2 * x] | ((uint32_t)row[2 * x + 1] << 8) : row[x];
-        v[k] = (uint16_t)(s << a.upshift);
+      for (int k = 0; k < 4; k++) {
+        uint32_t pair = 0;
+#pragma unroll
+        for (int e = 0; e < 2; e++) {
+          const int x = x0 + 2 * k + e < in_w ? x0 + 2 * k + e : in_w - 1;
+          const uint32_t sv =
+              a.wide ? (uint32_t)row[2 * x] | ((uint32_t)row[2 * x + 1] << 8) : row[x];
+          pair |= ((sv << a.upshift) & 0xffffu) << (16 * e);
+        }
+        o[k] = pair;
       }
     }
     // plane widths are multiples of 4 (picture widths of 8): x0 + 8 may only
     // exceed the row by 4
     if (x0 + 8 <= d.w) {
-      *reinterpret_cast<uint4 *>(out + x0) = *reinterpret_cast<const uint4 *>(v);
+      *reinterpret_cast<uint4 *>(out + x0) = make_uint4(o[0], o[1], o[2], o[3]);
     } else {
-      for (int k = 0; x0 + k < d.w; k++) out[x0 + k] = v[k];
+      *reinterpret_cast<uint2 *>(out + x0) = make_uint2(o[0], o[1]);
     }
   }
 }
