@@ -32,6 +32,13 @@ def main():
     clip = synth.SyntheticClip(w, h, bd)
     s = sharded.make_gpu_sharded(ctx, w, h, bd, qp, 0, 1, dev, dist)
     s.e.pictures[0].upload(padded(clip.frame(0)), bl)
+    # a second chain on its own stream, context and process group (bench.py --chains)
+    ctx2, ts = api.Context(0), torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(ts):
+        s2 = sharded.make_gpu_sharded(ctx2, w, h, bd, qp, 0, 1, dev, dist,
+                                      group=dist.new_group())
+    s2.e.pictures[0].upload(padded(clip.frame(0)), bl)
+    O2 = ctx2.picture(w, h, bd)
     O = ctx.picture(w, h, bd)
     xo = ol.Lib("xo")
     desc = pipeline.FrameDescriptors(w, h, qp)
@@ -40,6 +47,10 @@ def main():
         orig = padded(clip.frame(n))
         O.upload(orig, bl)
         s.run(O, (n - 1) % 2, n % 2, n - 1)
+        O2.upload(orig, bl)
+        with torch.cuda.stream(ts):
+            s2.run(O2, (n - 1) % 2, n % 2, n - 1)
+            ssd2 = s2.total_ssd()
         got_ssd = s.total_ssd()
         dist.barrier()
         torch.cuda.synchronize()
@@ -47,6 +58,9 @@ def main():
         got = s.e.pictures[n % 2].download(bl)
         assert all(np.array_equal(got[c], rec[c]) for c in range(3)), n
         assert got_ssd == ssd, (got_ssd, ssd)
+        got2 = s2.e.pictures[n % 2].download(bl)
+        assert all(np.array_equal(got2[c], rec[c]) for c in range(3)), n
+        assert ssd2 == ssd
         ref = rec
     dist.destroy_process_group()
     print("OK")

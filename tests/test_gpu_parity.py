@@ -1135,3 +1135,48 @@ def test_sharded_rccl_single_rank(gpu):
     r = subprocess.run([sys.executable, os.path.join(here, "nccl_one_rank.py"), str(port)],
                        capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "OK" in r.stdout.split(), r.stdout + r.stderr
+
+
+def test_concurrent_chains(gpu, xo):
+    """bench.py --chains: independent picture chains issued round-robin on
+    their own contexts / streams run concurrently on the device; every chain's
+    reconstructions and PSNR sums equal the oracle's for that chain (no
+    cross-talk through scratch buffers or scheduling records)."""
+    import oracle_frame
+    from xvc_amd import pipeline, synth
+    api, _ = gpu
+    pw, ph, bd, qp, n_chains, n_frames = 352, 288, 10, 32, 3, 4
+    clip = synth.SyntheticClip(pw, ph, bd)
+    desc = pipeline.FrameDescriptors(pw, ph, qp)
+    ctxs = [api.Context(0) for _ in range(n_chains)]
+    chains = []
+    for c, ctx in enumerate(ctxs):
+        frames = [pad_planes(clip.frame(3 * c + n), bd) for n in range(n_frames + 1)]
+        origs = []
+        for f in frames[1:]:
+            p = ctx.picture(pw, ph, bd)
+            p.upload(f, BL)
+            origs.append(p)
+        recs = [ctx.picture(pw, ph, bd) for _ in range(n_frames + 1)]
+        recs[0].upload(frames[0], BL)
+        chains.append((ctx, pipeline.FramePass(ctx, pw, ph, bd, qp=qp), origs, recs, frames))
+    for rep in range(3):       # several rounds so that the launches really interleave
+        for n in range(n_frames):
+            for ctx, fp, origs, recs, _ in chains:
+                fp.run(origs[n], recs[n], recs[n + 1], ref_poc=n)
+    for ctx in ctxs:
+        ctx.sync()
+    for ctx, fp, origs, recs, frames in chains:
+        ref = frames[0]
+        for n in range(n_frames):
+            e_rec, _, _, _, e_ssd = oracle_frame.frame_pass(desc, bd, frames[n + 1], ref, BL, n,
+                                                            lib=xo, threads=4)
+            got = recs[n + 1].download(BL)
+            for c in range(3):
+                assert np.array_equal(got[c], e_rec[c]), (n, c)
+            ref = e_rec
+        ssd = fp.d_ssd.to_array(np.uint64, 2)
+        assert (int(ssd[0]), int(ssd[1])) == e_ssd
+        fp.destroy()
+    for ctx in ctxs:
+        ctx.close()

@@ -226,11 +226,21 @@ def _gloo_worker(rank, world, port, q):
     for c, p in enumerate(pad_planes(clip.frame(0))):
         e.pics[0][c][:] = p
     s = sharded.ShardedFramePass(e, sharded.TorchComm(dist, rank, world), rank, world)
+    # a second, independent chain with its own process group, interleaved with
+    # the first (bench.py --chains): same pictures, so the same results
+    e2 = OracleEngine(lib, PW, PH, BD, QP, rows[rank])
+    for c, p in enumerate(pad_planes(clip.frame(0))):
+        e2.pics[0][c][:] = p
+    s2 = sharded.ShardedFramePass(e2, sharded.TorchComm(dist, rank, world, dist.new_group()),
+                                  rank, world)
     out = []
     for n in (1, 2):
         orig = pad_planes(clip.frame(n))
         s.run(orig, (n - 1) % 2, n % 2, n - 1)
+        s2.run(orig, (n - 1) % 2, n % 2, n - 1)
         out.append(([p.copy() for p in e.pics[n % 2]], s.total_ssd(), s.valid_rows()))
+        assert all(np.array_equal(a, b) for a, b in zip(e.pics[n % 2], e2.pics[n % 2]))
+        assert s2.total_ssd() == out[-1][1]
     q.put((rank, out))
     dist.barrier()
     dist.destroy_process_group()

@@ -65,22 +65,25 @@ class TorchComm:
     """Batched point-to-point exchange over torch.distributed (RCCL on GPUs,
     gloo in the CPU tests)."""
 
-    def __init__(self, dist, rank, world):
-        self.dist, self.rank, self.world = dist, rank, world
+    def __init__(self, dist, rank, world, group=None):
+        # group: a process group of all ranks dedicated to one picture chain, so
+        # that the exchanges of concurrent chains do not queue behind each other
+        self.dist, self.rank, self.world, self.group = dist, rank, world, group
 
     def exchange(self, sends, recvs):
         """sends / recvs: lists of (peer, 1-D tensor); per peer the order of
         sends on one side matches the order of recvs on the other."""
         d = self.dist
-        ops = [d.P2POp(d.isend, t, p) for p, t in sends] + \
-              [d.P2POp(d.irecv, t, p) for p, t in recvs]
+        g = self.group
+        ops = [d.P2POp(d.isend, t, p, group=g) for p, t in sends] + \
+              [d.P2POp(d.irecv, t, p, group=g) for p, t in recvs]
         if not ops:
             return
         for req in d.batch_isend_irecv(ops):
             req.wait()
 
     def allreduce_sum(self, t):
-        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
         return t
 
 
@@ -272,7 +275,11 @@ class _ExternalBuffer:
         self.ptr = None
 
 
-def make_gpu_sharded(ctx, width, height, bitdepth, qp, rank, world, device, dist):
+def make_gpu_sharded(ctx, width, height, bitdepth, qp, rank, world, device, dist,
+                     group=None):
+    """The engine's kernels run on torch's current stream at the time of this
+    call (use `with torch.cuda.stream(s)` here and around run() for a chain of
+    its own); `group`: the chain's own process group, if any."""
     rows = shard_rows(height, world)
     engine = GpuEngine(ctx, width, height, bitdepth, qp, rows[rank], device)
-    return ShardedFramePass(engine, TorchComm(dist, rank, world), rank, world)
+    return ShardedFramePass(engine, TorchComm(dist, rank, world, group), rank, world)
