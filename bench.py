@@ -353,6 +353,30 @@ def main():
             fp.run(o, ref, rec, ref_poc=i)
         times = {k: v / cycle for k, v in times.items()}
         dom = max(times, key=times.get)
+
+        # The same kernel with the other chains in flight (what a kernel trace
+        # of this command shows): one more cycle of the round-robin, chain 0's
+        # launch of the search bracketed by two events per step, read afterwards.
+        in_flight = None
+        if n_chains > 1 and world == 1 and cycle <= 31:
+            start = (base + cycle) * n_chains
+            for i in range(start, start + cycle * n_chains):
+                if i % n_chains:
+                    step(i)
+                    continue
+                j = i // n_chains
+                o = orig_at(j)
+                ref, rec = recs[j % 2], recs[(j + 1) % 2]
+                slot = 2 * (j - base - cycle)
+                ctx.timer_mark(slot)
+                ctx.me_search_dev(o, ref, api.ME_FULLPEL | api.ME_SUBPEL, fp.d_me.ptr,
+                                  d.n_cus, fp.d_res.ptr, d.cu_size)
+                ctx.timer_mark(slot + 1)
+                fp.run(o, ref, rec, ref_poc=j)     # the whole pass (search repeated)
+            barrier()
+            ms = [ctx.timer_between(2 * q, 2 * q + 1) for q in range(cycle)]
+            in_flight = {"kernel": "me_search", "chains": n_chains,
+                         "ms_per_launch": sum(ms) / len(ms)}
         # algorithmic bytes per launch
         S = 2
         n_luma = sum(int(b["w"]) * int(b["h"]) for b in d.me)
@@ -370,7 +394,7 @@ def main():
         # MI355X_MICROARCH.md prescribes; tools/pmc_traffic.py)
         traffic = None
         try:
-            prof = json.load(open(os.path.join(ROOT, "profiles", "r01_v3_traffic.json")))
+            prof = json.load(open(os.path.join(ROOT, "profiles", "r01_v4_traffic.json")))
             kname = {"me_search": "void me_search_wave_kernel<16, 3>",
                      "recon_from_me": "recon_from_me_kernel",
                      "picture_ssd": "picture_ssd_kernel", "pad_border": "pad_border_kernel",
@@ -384,6 +408,10 @@ def main():
                 "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic,
                 "algorithmic_bytes": alg[dom],
                 "ms_per_launch": times[dom],
+                # per launch with the device to itself (chain 0, others idle):
+                # the kernel's own figure; `in_flight`: the same launch while the
+                # other chains run (agrees with a kernel trace of this command)
+                "measured": "alone", "in_flight": in_flight,
                 "all_kernels_ms": {k: round(v, 4) for k, v in times.items()},
                 # algorithmic GB/s of every kernel of the pass (the whole-picture
                 # ones - deblock, pad, SSD - are the HBM-bound ones)

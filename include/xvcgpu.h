@@ -72,6 +72,13 @@ xvcgpu_status xvcgpu_sync(xvcgpu_ctx *ctx);
 /* HIP-event stopwatch on the context's stream (bench.py's timed region). */
 xvcgpu_status xvcgpu_timer_begin(xvcgpu_ctx *ctx);
 xvcgpu_status xvcgpu_timer_end(xvcgpu_ctx *ctx, float *elapsed_ms);
+/* Several intervals in flight: record event `slot` (0..63) on the context's
+ * stream now; later ask for the time between two recorded slots (waits for
+ * slot_b only).  For timing one kernel while other streams keep the device
+ * busy (bench.py's in-flight roofline figures). */
+xvcgpu_status xvcgpu_timer_mark(xvcgpu_ctx *ctx, int slot);
+xvcgpu_status xvcgpu_timer_between(xvcgpu_ctx *ctx, int slot_a, int slot_b,
+                                   float *elapsed_ms);
 
 /* ---- recorded call sequences (HIP graphs) --------------------------------- *
  * The per-picture sequence of launches is short kernels (8-110 us each), so

@@ -73,7 +73,7 @@ assert MC_DTYPE.itemsize == 16 and CAND_DTYPE.itemsize == 12
 # every symbol include/xvcgpu.h declares
 SYMBOLS = [
     "xvcgpu_create", "xvcgpu_destroy", "xvcgpu_last_error", "xvcgpu_version",
-    "xvcgpu_set_stream", "xvcgpu_use_own_stream", "xvcgpu_use_priority_stream", "xvcgpu_wait_for", "xvcgpu_sync", "xvcgpu_timer_begin", "xvcgpu_timer_end",
+    "xvcgpu_set_stream", "xvcgpu_use_own_stream", "xvcgpu_use_priority_stream", "xvcgpu_wait_for", "xvcgpu_sync", "xvcgpu_timer_begin", "xvcgpu_timer_end", "xvcgpu_timer_mark", "xvcgpu_timer_between",
     "xvcgpu_record_begin", "xvcgpu_record_end", "xvcgpu_replay", "xvcgpu_recording_destroy",
     "xvcgpu_malloc", "xvcgpu_free", "xvcgpu_memcpy_h2d", "xvcgpu_memcpy_d2h",
     "xvcgpu_memset", "xvcgpu_picture_create", "xvcgpu_picture_bytes",
@@ -139,6 +139,8 @@ def load_library():
         "xvcgpu_sync": [_vp],
         "xvcgpu_timer_begin": [_vp],
         "xvcgpu_timer_end": [_vp, C.POINTER(C.c_float)],
+        "xvcgpu_timer_mark": [_vp, C.c_int],
+        "xvcgpu_timer_between": [_vp, C.c_int, C.c_int, C.POINTER(C.c_float)],
         "xvcgpu_record_begin": [_vp],
         "xvcgpu_record_end": [_vp, C.POINTER(_vp)],
         "xvcgpu_replay": [_vp, _vp],
@@ -373,6 +375,14 @@ class Context:
     def timer_end(self):
         ms = C.c_float(0)
         self._check(self.lib.xvcgpu_timer_end(self.h, C.byref(ms)))
+        return ms.value
+
+    def timer_mark(self, slot):
+        self._check(self.lib.xvcgpu_timer_mark(self.h, slot))
+
+    def timer_between(self, slot_a, slot_b):
+        ms = C.c_float(0)
+        self._check(self.lib.xvcgpu_timer_between(self.h, slot_a, slot_b, C.byref(ms)))
         return ms.value
 
     def picture(self, w, h, bd=10):

@@ -144,6 +144,7 @@ xvcgpu_status xvcgpu_create(int device, xvcgpu_ctx **out) {
   ctx->ssd_part_cap = 0;
   ctx->d_stats = nullptr;
   ctx->stats_rows_cap = 0;
+  for (int i = 0; i < 64; i++) ctx->ev_pool[i] = nullptr;
   ctx->d_me_rot = nullptr;
   ctx->me_epoch = 0;
   if (hipSetDevice(device) != hipSuccess ||
@@ -198,6 +199,8 @@ void xvcgpu_destroy(xvcgpu_ctx *ctx) {
   hipEventDestroy(ctx->ev0);
   hipEventDestroy(ctx->ev1);
   hipEventDestroy(ctx->ev_sync);
+  for (int i = 0; i < 64; i++)
+    if (ctx->ev_pool[i]) hipEventDestroy(ctx->ev_pool[i]);
   if (ctx->own_stream && ctx->stream) hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -265,6 +268,23 @@ xvcgpu_status xvcgpu_timer_end(xvcgpu_ctx *ctx, float *elapsed_ms) {
   HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
   HIP_TRY(ctx, hipEventSynchronize(ctx->ev1));
   HIP_TRY(ctx, hipEventElapsedTime(elapsed_ms, ctx->ev0, ctx->ev1));
+  return XVCGPU_OK;
+}
+
+xvcgpu_status xvcgpu_timer_mark(xvcgpu_ctx *ctx, int slot) {
+  if (!ctx || slot < 0 || slot >= 64) return XVCGPU_INVALID_ARGUMENT;
+  if (!ctx->ev_pool[slot]) HIP_TRY(ctx, hipEventCreate(&ctx->ev_pool[slot]));
+  HIP_TRY(ctx, hipEventRecord(ctx->ev_pool[slot], ctx->stream));
+  return XVCGPU_OK;
+}
+
+xvcgpu_status xvcgpu_timer_between(xvcgpu_ctx *ctx, int slot_a, int slot_b,
+                                   float *elapsed_ms) {
+  if (!ctx || !elapsed_ms || slot_a < 0 || slot_a >= 64 || slot_b < 0 || slot_b >= 64 ||
+      !ctx->ev_pool[slot_a] || !ctx->ev_pool[slot_b])
+    return XVCGPU_INVALID_ARGUMENT;
+  HIP_TRY(ctx, hipEventSynchronize(ctx->ev_pool[slot_b]));
+  HIP_TRY(ctx, hipEventElapsedTime(elapsed_ms, ctx->ev_pool[slot_a], ctx->ev_pool[slot_b]));
   return XVCGPU_OK;
 }
 

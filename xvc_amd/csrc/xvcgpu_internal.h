@@ -31,6 +31,7 @@ struct xvcgpu_ctx {
   bool own_stream;
   hipEvent_t ev0, ev1;
   hipEvent_t ev_sync;  // xvcgpu_wait_for
+  hipEvent_t ev_pool[64];  // xvcgpu_timer_mark slots, created on first use
   std::string err;
   // transform matrices [type 1..5][log2 size 1..6], device copy
   int16_t *d_tx_tables;
