@@ -227,6 +227,18 @@ xvcgpu_status xvcgpu_mc_batch(xvcgpu_ctx *ctx, const xvcgpu_picture *ref,
                               xvcgpu_picture *pred,
                               const xvcgpu_mc_block *d_blocks, int n);
 
+/* I3 (LIC half): InterPrediction::MotionCompensationMv for uni-pred CUs that
+ * use local illumination compensation (inter_prediction.cc:740-758,
+ * LocalIlluminationComp :1555-1575, DeriveLicParams :1577-1663): the ordinary
+ * prediction, then scale / offset from a linear model fitted to the block's
+ * row above / column left: `rec` (the current picture's reconstruction, which
+ * must hold the neighbouring CUs) against `ref` displaced by the rounded
+ * full-pel vector.  Written into `pred` at the block's position.  The wave of
+ * CUs of one call must not depend on each other's reconstruction. */
+xvcgpu_status xvcgpu_mc_lic_batch(xvcgpu_ctx *ctx, const xvcgpu_picture *ref,
+                                  const xvcgpu_picture *rec, xvcgpu_picture *pred,
+                                  const xvcgpu_mc_lic_block *d_blocks, int n);
+
 /* ---- I3 (affine half): MotionCompAffine -> Sample ------------------------- *
  * (inter_prediction.cc:1044-1136): the CU is cut into sub-blocks whose size
  * follows from the corner-MV differences, each sub-block gets its own MV

@@ -128,6 +128,25 @@ typedef struct xvcgpu_mc_affine_block {
   int32_t mv[3][2];    /* [corner][x,y]                                    */
 } xvcgpu_mc_affine_block;
 
+/* One uni-pred motion compensation job with local illumination compensation
+ * (InterPrediction::MotionCompensationMv with cu.GetUseLic(),
+ * inter_prediction.cc:740-758 -> LocalIlluminationComp :1555-1575 ->
+ * DeriveLicParams :1577-1663): the prediction is scaled / offset by a linear
+ * model fitted to the row above and the column left of the block - samples of
+ * the current reconstruction against the reference picture displaced by the
+ * rounded full-pel MV.  The model needs the neighbouring CUs' reconstruction. */
+#define XVC_LIC_HAS_ABOVE 1 /* cu.GetCodingUnitAbove() != nullptr */
+#define XVC_LIC_HAS_LEFT 2  /* cu.GetCodingUnitLeft() != nullptr  */
+typedef struct xvcgpu_mc_lic_block {
+  int16_t x, y;        /* luma position of the CU                          */
+  uint8_t w, h;        /* luma size of the CU                              */
+  uint8_t comp;        /* 0 = Y, 1 = U, 2 = V                              */
+  uint8_t neighbors;   /* XVC_LIC_HAS_* bits                                */
+  int32_t mv_x, mv_y;  /* 1/16 pel, before ClipMv                          */
+  int16_t above_x, above_y; /* luma position of the CU above (its ClipMv)  */
+  int16_t left_x, left_y;   /* luma position of the CU to the left         */
+} xvcgpu_mc_lic_block;
+
 /* One intra prediction job = IntraPrediction::FillReferenceState + Predict
  * (intra_prediction.cc:81-147) for one component of one CU, 67-mode set.
  * Positions / sizes are in samples of `comp`.  The neighbour fields are what

@@ -1170,4 +1170,45 @@ void xr_intra_lm_chroma(int bd, int comp, int x, int y, int w, int h, int pic_w,
   for (int yy = 0; yy < h; yy++)
     std::memcpy(out + yy * os, tmp.GetDataPtr() + yy * tmp.GetStride(), sizeof(Sample) * w);
 }
+
+/* InterPrediction::MotionCompensationMv(post_filter = true) of a CU with
+ * use_lic: neighbouring CUs above / left are created in the CU map at the
+ * positions the job names (their position enters through ClipMv). */
+void xr_mc_lic_block(int bd, const xvcgpu_mc_lic_block *b, int above_w, int above_h,
+                     int left_w, int left_h, int pic_w, int pic_h,
+                     const uint16_t *const ref_planes[3], const ptrdiff_t ref_strides[3],
+                     const uint16_t *const rec_planes[3], const ptrdiff_t rec_strides[3],
+                     uint16_t *pred, ptrdiff_t ps) {
+  PictureData pic_data(ChromaFormat::k420, pic_w, pic_h, bd);
+  if (b->neighbors & XVC_LIC_HAS_ABOVE) {
+    CodingUnit *a = pic_data.CreateCu(CuTree::Primary, 1, b->above_x, b->above_y,
+                                      above_w, above_h);
+    pic_data.MarkUsedInPic(a);
+  }
+  if (b->neighbors & XVC_LIC_HAS_LEFT) {
+    CodingUnit *l = pic_data.CreateCu(CuTree::Primary, 1, b->left_x, b->left_y, left_w,
+                                      left_h);
+    pic_data.MarkUsedInPic(l);
+  }
+  CodingUnit *cu = pic_data.CreateCu(CuTree::Primary, 1, b->x, b->y, b->w, b->h);
+  cu->SetUseLic(true);
+  YuvPicture ref_pic(ChromaFormat::k420, pic_w, pic_h, bd, true, 0, 0);
+  YuvPicture rec_pic(ChromaFormat::k420, pic_w, pic_h, bd, true, 0, 0);
+  FillPic(&ref_pic, ref_planes, ref_strides);
+  for (int c = 0; c < 3; c++) {
+    const YuvComponent cc = YuvComponent(c);
+    for (int y = 0; y < rec_pic.GetHeight(cc); y++)
+      std::memcpy(rec_pic.GetSamplePtr(cc, 0, y), rec_planes[c] + y * rec_strides[c],
+                  sizeof(Sample) * rec_pic.GetWidth(cc));
+  }
+  InterPrediction ip(Simd(bd).inter_prediction, rec_pic, bd);
+  const int cs = b->comp ? 1 : 0;
+  SampleBuffer pb(pred + (b->y >> cs) * ps + (b->x >> cs), ps);
+  Restrictions &r = Restrictions::GetRW();
+  const bool saved = r.disable_ext2_inter_local_illumination_comp;
+  r.disable_ext2_inter_local_illumination_comp = false;
+  ip.MotionCompensationMv(*cu, YuvComponent(b->comp), ref_pic,
+                          MotionVector(b->mv_x, b->mv_y), true, &pb);
+  r.disable_ext2_inter_local_illumination_comp = saved;
+}
 }  // extern "C"

@@ -196,6 +196,11 @@ void xo_mc_bipred_block(int bitdepth, int comp, int x, int y, int w, int h,
                         int pic_h, const uint16_t *ref0, ptrdiff_t rs0,
                         const uint16_t *ref1, ptrdiff_t rs1, uint16_t *pred,
                         ptrdiff_t pred_stride);
+/* MotionCompensationMv of a CU with local illumination compensation
+ * (inter_prediction.cc:740-758, :1555-1663). */
+void xo_mc_lic_block(int bitdepth, const xvcgpu_mc_lic_block *b, int pic_w, int pic_h,
+                     const uint16_t *ref, ptrdiff_t rs, const uint16_t *rec, ptrdiff_t cs,
+                     uint16_t *pred, ptrdiff_t ps);
 /* GetMvdBitsFullpel / GetMvdBits / GetNumExpGolombBits
  * (inter_search.cc:1150-1188). */
 uint32_t xo_mvd_bits_fullpel(int mvp_x, int mvp_y, int fx, int fy,

@@ -809,3 +809,86 @@ int xo_residual_pipeline(int bd, const xvcgpu_tx_block *b, const uint16_t *orig,
   }
   return nnz;
 }
+
+/* =========================================================================
+ *  Local illumination compensation
+ * ========================================================================= */
+
+/* MotionCompensationMv(post_filter = true) of a CU with use_lic
+ * (inter_prediction.cc:740-758): the ordinary uni-pred prediction, then
+ * LocalIlluminationComp (:1555-1575) with the model of DeriveLicParams
+ * (:1577-1663).  `ref` = padded reference plane of the component, `rec` = the
+ * current reconstruction plane (neighbours of the block must be there); both
+ * pointers at sample (0,0). */
+void xo_mc_lic_block(int bitdepth, const xvcgpu_mc_lic_block *b, int pic_w, int pic_h,
+                     const uint16_t *ref, ptrdiff_t rs, const uint16_t *rec, ptrdiff_t cs,
+                     uint16_t *pred, ptrdiff_t ps) {
+  const int c = b->comp, sub = c ? 1 : 0;
+  xo_mc_block(bitdepth, c, b->x, b->y, b->w, b->h, b->mv_x, b->mv_y, pic_w, pic_h, ref, rs,
+              pred + (ptrdiff_t)(b->y >> sub) * ps + (b->x >> sub), ps);
+  int mx = b->mv_x, my = b->mv_y;
+  xo_clip_mv(b->x, b->y, pic_w, pic_h, &mx, &my);
+  const int shift = 4 + sub;
+  const int fx = (mx + (1 << (shift - 1))) >> shift, fy = (my + (1 << (shift - 1))) >> shift;
+  const int w = b->w >> sub, h = b->h >> sub, x = b->x >> sub, y = b->y >> sub;
+  const int has_above = b->neighbors & XVC_LIC_HAS_ABOVE, has_left = b->neighbors & XVC_LIC_HAS_LEFT;
+  int scale = 32, offset = 0;
+  if (has_above || has_left) {
+    const int step = (w < h ? w : h) > 8 ? 2 : 1;
+    const uint16_t *rb = ref + (ptrdiff_t)y * rs + x, *sb = rec + (ptrdiff_t)y * cs + x;
+    int sum_x = 0, sum_y = 0, sum_xx = 0, sum_xy = 0, nbr = 0;
+    if (has_above) {
+      int cx = fx, cy = fy; /* the full-pel vector goes through ClipMv as it is */
+      xo_clip_mv(b->above_x, b->above_y, pic_w, pic_h, &cx, &cy);
+      const uint16_t *r = rb + cx + (ptrdiff_t)cy * rs - rs, *s2 = sb - cs;
+      const int dx = step * (w / h > 1 ? w / h : 1);
+      for (int i = 0; i < w; i += dx) {
+        sum_x += r[i]; sum_y += s2[i]; sum_xx += r[i] * r[i]; sum_xy += r[i] * s2[i]; nbr++;
+      }
+    }
+    if (has_left) {
+      int cx = fx, cy = fy;
+      xo_clip_mv(b->left_x, b->left_y, pic_w, pic_h, &cx, &cy);
+      const uint16_t *r = rb + cx + (ptrdiff_t)cy * rs - 1, *s2 = sb - 1;
+      const int dy = step * (h / w > 1 ? h / w : 1);
+      for (int i = 0; i < h; i += dy) {
+        const int a = r[i * rs], d = s2[i * cs];
+        sum_x += a; sum_y += d; sum_xx += a * a; sum_xy += a * d; nbr++;
+      }
+    }
+    int size_shift = 1; /* util::SizeToLog2 */
+    while ((1 << size_shift) < nbr) size_shift++;
+    int base_shift = bitdepth + size_shift - 15;
+    if (base_shift < 0) base_shift = 0;
+    const int avg_x = sum_x >> base_shift, avg_y = sum_y >> base_shift;
+    const int xx_offset = sum_xx >> 7;
+    const int avg_xy = ((sum_xy + xx_offset) >> (2 * base_shift)) << size_shift;
+    const int avg_xx = ((sum_xx + xx_offset) >> (2 * base_shift)) << size_shift;
+    const int sxy = avg_xy - avg_x * avg_y, sxx = avg_xx - avg_x * avg_x;
+    int msb = 0;
+    for (unsigned v = (unsigned)abs(sxx); v; v >>= 1) msb++;
+    int shift_xx = msb - 6;
+    if (shift_xx < 0) shift_xx = 0;
+    int shift_xy = shift_xx - 12;
+    if (shift_xy < 0) shift_xy = 0;
+    const int total_shift = 15 - 5 + shift_xx - shift_xy;
+    const int sxy_s = sxy >> shift_xy;
+    int sxx_s = sxx >> shift_xx;
+    sxx_s = sxx_s < 0 ? 0 : (sxx_s > 63 ? 63 : sxx_s);
+    if (sxx_s != 0) {
+      const int sxx_scaled = ((1 << 15) + (sxx_s / 2)) / sxx_s;
+      int sc = (int)((int64_t)sxy_s * sxx_scaled) >> total_shift;
+      scale = sc < 0 ? 0 : (sc > 128 ? 128 : sc);
+      int off = (sum_y - ((scale * sum_x) >> 5) + (1 << (size_shift - 1))) >> size_shift;
+      const int lo = -(1 << (bitdepth - 1)), hi = (1 << (bitdepth - 1)) - 1;
+      offset = off < lo ? lo : (off > hi ? hi : off);
+    }
+  }
+  const int max = (1 << bitdepth) - 1;
+  uint16_t *p = pred + (ptrdiff_t)y * ps + x;
+  for (int yy = 0; yy < h; yy++)
+    for (int xx = 0; xx < w; xx++) {
+      const int v = ((scale * p[yy * ps + xx]) >> 5) + offset;
+      p[yy * ps + xx] = (uint16_t)(v < 0 ? 0 : (v > max ? max : v));
+    }
+}

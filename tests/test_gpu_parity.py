@@ -1180,3 +1180,42 @@ def test_concurrent_chains(gpu, xo):
         fp.destroy()
     for ctx in ctxs:
         ctx.close()
+
+
+@pytest.mark.parametrize("bd", [8, 10, 12])
+def test_mc_lic_batch(gpu, xo, bd):
+    """Motion compensation with local illumination compensation (I3, LIC
+    half) against the oracle: random CUs / neighbours / vectors, all three
+    components, gain and offset changes between reference and current picture."""
+    import oracle_lic as ol_
+    api, ctx = gpu
+    rng = np.random.default_rng(1100 + bd)
+    pw, ph = 256, 192
+    mx = (1 << bd) - 1
+    total = 0
+    for content in range(3):
+        cur, ref = make_pics(rng, bd, pw, ph, BL, motion=(2, 1), noise=3)
+        gain = [1.0, 0.8, 1.3][content]
+        rec_y = np.clip(cur[BL:BL + ph, BL:BL + pw].astype(np.float64) * gain + 9 * content,
+                        0, mx).astype(np.uint16)
+        chroma_ref = [rnd_samples(rng, bd, ph // 2 + 2 * BC, pw // 2 + 2 * BC, True)
+                      for _ in range(2)]
+        rec_c = [np.clip(c[BC:BC + ph // 2, BC:BC + pw // 2].astype(np.int64) * 7 // 8 + 30, 0,
+                         mx).astype(np.uint16) for c in chroma_ref]
+        ref_planes = [np.ascontiguousarray(ref)] + chroma_ref
+        rec_planes = [np.ascontiguousarray(rec_y)] + [np.ascontiguousarray(c) for c in rec_c]
+        R, C_, P = ctx.picture(pw, ph, bd), ctx.picture(pw, ph, bd), ctx.picture(pw, ph, bd)
+        R.upload(ref_planes, BL)
+        C_.upload(rec_planes)
+        jobs = [j for j, _, _ in ol_.random_jobs(rng, pw, ph, 80)]
+        for j in jobs:           # blocks overlap: one launch per job
+            ctx.mc_lic_batch(R, C_, P, np.array([j], api.LIC_DTYPE))
+            c, s = int(j["comp"]), 1 if j["comp"] else 0
+            x, y, w, h = int(j["x"]) >> s, int(j["y"]) >> s, int(j["w"]) >> s, int(j["h"]) >> s
+            exp = ol_.xo_mc_lic(xo, bd, j, pw, ph, ref_planes, [BL, BC, BC], rec_planes)
+            got = P.download()[c]
+            assert np.array_equal(got[y:y + h, x:x + w], exp[y:y + h, x:x + w]), (content, j)
+            total += 1
+        for p in (R, C_, P):
+            p.destroy()
+    assert total == 240

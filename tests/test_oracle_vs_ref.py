@@ -755,3 +755,36 @@ def test_intra_lm_chroma(libs, bd):
                 assert np.array_equal(got, exp), (content, comp, x, y, w, h)
                 n += 1
     assert n == 240
+
+
+@pytest.mark.parametrize("bd", [8, 10])
+def test_mc_lic_block(libs, bd):
+    """InterPrediction::MotionCompensationMv with local illumination
+    compensation (LocalIlluminationComp / DeriveLicParams)."""
+    import oracle_lic as ol_
+    BL, BC = 128, 64
+    xo, xr = libs
+    xr._set_simd(0)     # 2-wide / narrow chroma: pin against the C kernels
+    rng = np.random.default_rng(880 + bd)
+    pw, ph = 192, 128
+    n = 0
+    for content in range(3):
+        cur, ref = make_pics(rng, bd, pw, ph, BL, motion=(2, 1), noise=3)
+        gain = [1.0, 0.8, 1.3][content]
+        mx = (1 << bd) - 1
+        rec_y = np.clip(cur[BL:BL + ph, BL:BL + pw].astype(np.float64) * gain + 9 * content,
+                        0, mx).astype(np.uint16)
+        chroma_ref = [rnd_samples(rng, bd, ph // 2 + 2 * BC, pw // 2 + 2 * BC, True)
+                      for _ in range(2)]
+        rec_c = [np.clip(c[BC:BC + ph // 2, BC:BC + pw // 2].astype(np.int64) + 12, 0, mx)
+                 .astype(np.uint16) for c in chroma_ref]
+        ref_planes = [np.ascontiguousarray(ref)] + chroma_ref
+        rec_planes = [np.ascontiguousarray(rec_y)] + [np.ascontiguousarray(c) for c in rec_c]
+        for j, above, left in ol_.random_jobs(rng, pw, ph, 60):
+            exp = ol_.xr_mc_lic(xr, bd, j, above, left, pw, ph, ref_planes, [BL, BC, BC],
+                                rec_planes)
+            got = ol_.xo_mc_lic(xo, bd, j, pw, ph, ref_planes, [BL, BC, BC], rec_planes)
+            assert np.array_equal(got, exp), (content, j)
+            n += 1
+    xr._set_simd(1)
+    assert n == 180

@@ -55,6 +55,11 @@ assert MCAFF_DTYPE.itemsize == 32
 MCM_DTYPE = np.dtype([("x", "<i2"), ("y", "<i2"), ("w", "u1"), ("h", "u1"),
                       ("metric", "u1"), ("qp", "i1"), ("mv_x", "<i4"), ("mv_y", "<i4")])
 assert MCM_DTYPE.itemsize == 16
+LIC_DTYPE = np.dtype([("x", "<i2"), ("y", "<i2"), ("w", "u1"), ("h", "u1"), ("comp", "u1"),
+                      ("neighbors", "u1"), ("mv_x", "<i4"), ("mv_y", "<i4"),
+                      ("above_x", "<i2"), ("above_y", "<i2"), ("left_x", "<i2"),
+                      ("left_y", "<i2")])
+assert LIC_DTYPE.itemsize == 24
 INTRA_DTYPE = np.dtype([("x", "<i2"), ("y", "<i2"), ("w", "u1"), ("h", "u1"),
                         ("comp", "u1"), ("mode", "u1"), ("neighbors", "u1"),
                         ("above_right", "u1"), ("below_left", "u1"), ("reserved", "u1")])
@@ -82,7 +87,7 @@ SYMBOLS = [
     "xvcgpu_picture_download_padded", "xvcgpu_picture_plane",
     "xvcgpu_picture_copy", "xvcgpu_pad_border", "xvcgpu_metric_batch", "xvcgpu_mc_metric_batch",
     "xvcgpu_me_search", "xvcgpu_me_search_sized", "xvcgpu_mc_batch", "xvcgpu_mc_from_me",
-    "xvcgpu_mc_bipred_batch", "xvcgpu_bipred_search", "xvcgpu_mc_affine_batch",
+    "xvcgpu_mc_bipred_batch", "xvcgpu_bipred_search", "xvcgpu_mc_affine_batch", "xvcgpu_mc_lic_batch",
     "xvcgpu_cu_info_from_me", "xvcgpu_recon_from_me", "xvcgpu_residual_batch",
     "xvcgpu_fwd_transform_batch", "xvcgpu_inv_transform_batch",
     "xvcgpu_deblock", "xvcgpu_deblock_rows", "xvcgpu_picture_ssd", "xvcgpu_picture_ssd_rows",
@@ -187,6 +192,7 @@ def load_library():
         "xvcgpu_picture_crc": [_vp, _vp, C.c_int, _vp],
         "xvcgpu_variance_map": [_vp, _vp, _vp, C.c_int, _vp],
         "xvcgpu_histogram_distance": [_vp, _vp, _vp, _vp],
+        "xvcgpu_mc_lic_batch": [_vp, _vp, _vp, _vp, _vp, C.c_int],
         "xvcgpu_intra_pred_batch": [_vp, _vp, _vp, _vp, C.c_int],
         "xvcgpu_intra_satd_batch": [_vp, _vp, _vp, _vp, C.c_int, _vp, C.c_int],
         "xvcgpu_intra_recon_batch": [_vp, _vp, _vp, _vp, _vp, C.c_int, _vp, _vp, _vp],
@@ -636,6 +642,14 @@ class Context:
         out = int(d.to_array(np.int64, 1)[0])
         d.free()
         return out
+
+    def mc_lic_batch(self, ref, rec, pred, jobs):
+        jobs = np.ascontiguousarray(jobs, LIC_DTYPE)
+        d = self.buffer(jobs)
+        self._check(self.lib.xvcgpu_mc_lic_batch(self.h, ref.h_pic, rec.h_pic, pred.h_pic,
+                                                 d.ptr, len(jobs)))
+        self.sync()
+        d.free()
 
     # ---- intra prediction ----
     def intra_pred_batch(self, rec, pred, jobs):

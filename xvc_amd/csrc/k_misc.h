@@ -33,6 +33,112 @@ mc_batch_kernel(PicView ref, PicView pred, const xvcgpu_mc_block *blocks, int n)
     wg_interp_block<false>(ref.bd, cw, ch, fx, fy, r, pr.stride, tmp, dst, pd.stride);
 }
 
+// MotionCompensationMv of a CU with local illumination compensation
+// (inter_prediction.cc:740-758 -> LocalIlluminationComp :1555-1575 ->
+// DeriveLicParams :1577-1663).  One workgroup per job: the ordinary prediction
+// into `pred`, then the linear model from the row above / column left of the
+// block (current reconstruction `rec` against the reference displaced by the
+// rounded full-pel vector, which - as in the reference - passes through ClipMv
+// of the neighbouring CU unchanged in units), applied in place.
+// grid: n; block: 256.
+__global__ void __launch_bounds__(256)
+mc_lic_kernel(PicView ref, PicView rec, PicView pred, const xvcgpu_mc_lic_block *blocks,
+              int n) {
+  __shared__ int16_t tmp[64 * 71];
+  __shared__ int s_scale, s_offset;
+  const int bi = blockIdx.x;
+  if (bi >= n) return;
+  const xvcgpu_mc_lic_block b = blocks[bi];
+  const int pic_w = ref.c[0].w, pic_h = ref.c[0].h, bd = ref.bd;
+  int mx = b.mv_x, my = b.mv_y;
+  d_clip_mv(b.x, b.y, pic_w, pic_h, mx, my);
+  const int cs = b.comp ? 1 : 0;
+  const int shift = 4 + cs;
+  const int pel_x = mx >> shift, pel_y = my >> shift;
+  const int fx = mx & ((1 << shift) - 1), fy = my & ((1 << shift) - 1);
+  const PlaneView pr = ref.c[b.comp], pd = pred.c[b.comp], pc = rec.c[b.comp];
+  const int cx = b.x >> cs, cy = b.y >> cs, cw = b.w >> cs, ch = b.h >> cs;
+  uint16_t *dst = pd.p + (ptrdiff_t)cy * pd.stride + cx;
+  {
+    const uint16_t *r = pr.p + (ptrdiff_t)(cy + pel_y) * pr.stride + cx + pel_x;
+    if (b.comp)
+      wg_interp_block<true>(bd, cw, ch, fx, fy, r, pr.stride, tmp, dst, pd.stride);
+    else
+      wg_interp_block<false>(bd, cw, ch, fx, fy, r, pr.stride, tmp, dst, pd.stride);
+  }
+  // model: the first wave sums the (<= 64) neighbour pairs, lane 0 solves
+  if (threadIdx.x < 64) {
+    const int lane = threadIdx.x;
+    const bool has_above = b.neighbors & XVC_LIC_HAS_ABOVE, has_left = b.neighbors & XVC_LIC_HAS_LEFT;
+    const int full_x = (mx + (1 << (shift - 1))) >> shift, full_y = (my + (1 << (shift - 1))) >> shift;
+    const int step = (cw < ch ? cw : ch) > 8 ? 2 : 1;
+    const int dx = step * (cw / ch > 1 ? cw / ch : 1), dy = step * (ch / cw > 1 ? ch / cw : 1);
+    const int na = has_above ? cw / dx : 0, nl = has_left ? ch / dy : 0;
+    const int nbr = na + nl;
+    const uint16_t *rb = pr.p + (ptrdiff_t)cy * pr.stride + cx;
+    const uint16_t *sb = pc.p + (ptrdiff_t)cy * pc.stride + cx;
+    int sx = 0, sy = 0, sxx = 0, sxy = 0;
+    for (int i = lane; i < nbr; i += 64) {
+      int a, d;
+      if (i < na) {
+        int vx = full_x, vy = full_y;
+        d_clip_mv(b.above_x, b.above_y, pic_w, pic_h, vx, vy);
+        a = rb[(ptrdiff_t)(vy - 1) * pr.stride + vx + i * dx];
+        d = sb[-(ptrdiff_t)pc.stride + i * dx];
+      } else {
+        int vx = full_x, vy = full_y;
+        d_clip_mv(b.left_x, b.left_y, pic_w, pic_h, vx, vy);
+        const int yy = (i - na) * dy;
+        a = rb[(ptrdiff_t)(vy + yy) * pr.stride + vx - 1];
+        d = sb[(ptrdiff_t)yy * pc.stride - 1];
+      }
+      sx += a; sy += d; sxx += a * a; sxy += a * d;
+    }
+    sx = group_sum<64>(sx);
+    sy = group_sum<64>(sy);
+    sxx = group_sum<64>(sxx);
+    sxy = group_sum<64>(sxy);
+    if (lane == 0) {
+      int scale = 32, offset = 0;
+      if (nbr > 0) {
+        int size_shift = 1;
+        while ((1 << size_shift) < nbr) size_shift++;
+        int base_shift = bd + size_shift - 15;
+        base_shift = base_shift < 0 ? 0 : base_shift;
+        const int avg_x = sx >> base_shift, avg_y = sy >> base_shift;
+        const int xx_offset = sxx >> 7;
+        const int avg_xy = ((sxy + xx_offset) >> (2 * base_shift)) << size_shift;
+        const int avg_xx = ((sxx + xx_offset) >> (2 * base_shift)) << size_shift;
+        const int vxy = avg_xy - avg_x * avg_y, vxx = avg_xx - avg_x * avg_x;
+        const int msb = vxx == 0 ? 0 : 32 - __clz(d_abs(vxx));
+        int shift_xx = msb - 6;
+        shift_xx = shift_xx < 0 ? 0 : shift_xx;
+        int shift_xy = shift_xx - 12;
+        shift_xy = shift_xy < 0 ? 0 : shift_xy;
+        const int total_shift = 15 - 5 + shift_xx - shift_xy;
+        const int vxy_s = vxy >> shift_xy;
+        const int vxx_s = d_clip3(vxx >> shift_xx, 0, 63);
+        if (vxx_s != 0) {
+          const int vxx_scaled = ((1 << 15) + (vxx_s / 2)) / vxx_s;
+          const int sc = (int)((long long)vxy_s * vxx_scaled) >> total_shift;
+          scale = d_clip3(sc, 0, 128);
+          const int off = (sy - ((scale * sx) >> 5) + (1 << (size_shift - 1))) >> size_shift;
+          offset = d_clip3(off, -(1 << (bd - 1)), (1 << (bd - 1)) - 1);
+        }
+      }
+      s_scale = scale;
+      s_offset = offset;
+    }
+  }
+  __syncthreads();  // also orders the prediction stores before the reads below
+  const int scale = s_scale, offset = s_offset, smax = (1 << bd) - 1;
+  const int lw = 31 - __clz(cw);
+  for (int i = threadIdx.x; i < cw * ch; i += 256) {
+    uint16_t *p = dst + (ptrdiff_t)(i >> lw) * pd.stride + (i & (cw - 1));
+    *p = (uint16_t)d_clip3(((scale * (int)*p) >> 5) + offset, 0, smax);
+  }
+}
+
 // Same, with the MV taken from the motion search result of the CU: one
 // workgroup per (CU, component) = InterPrediction::MotionCompensation for a
 // uni-pred CU (inter_prediction.cc:710-722).  grid: (n, 3); block: 256.

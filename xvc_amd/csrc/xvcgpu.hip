@@ -643,6 +643,21 @@ xvcgpu_status xvcgpu_mc_batch(xvcgpu_ctx *ctx, const xvcgpu_picture *ref,
   return XVCGPU_OK;
 }
 
+xvcgpu_status xvcgpu_mc_lic_batch(xvcgpu_ctx *ctx, const xvcgpu_picture *ref,
+                                  const xvcgpu_picture *rec, xvcgpu_picture *pred,
+                                  const xvcgpu_mc_lic_block *d_blocks, int n) {
+  if (!ctx || !ref || !rec || !pred || n < 0 || (n && !d_blocks))
+    return XVCGPU_INVALID_ARGUMENT;
+  if (pred->w != ref->w || pred->h != ref->h || rec->w != ref->w || rec->h != ref->h ||
+      rec->bd != ref->bd || pred->bd != ref->bd)
+    return fail(ctx, XVCGPU_INVALID_ARGUMENT, "picture mismatch");
+  if (n == 0) return XVCGPU_OK;
+  hipLaunchKernelGGL(mc_lic_kernel, dim3(n), dim3(256), 0, ctx->stream, ref->v, rec->v,
+                     pred->v, d_blocks, n);
+  CHECK_LAUNCH(ctx, "mc_lic_batch");
+  return XVCGPU_OK;
+}
+
 xvcgpu_status xvcgpu_mc_affine_batch(xvcgpu_ctx *ctx, const xvcgpu_picture *ref,
                                      xvcgpu_picture *pred,
                                      const xvcgpu_mc_affine_block *d_blocks, int n) {
