@@ -296,6 +296,30 @@ def test_oracle_intra(xo):
                               exp[:bh, :bw]), j
 
 
+def _lic_planes(g):
+    """Re-pad the stored reference planes (80 / 40 border samples kept) to the
+    128 / 64 border layout; far vectors clip inside what was kept."""
+    ref = []
+    for c in range(3):
+        keep, b = (80, BL) if c == 0 else (40, BC)
+        ref.append(np.ascontiguousarray(np.pad(g["ref%d" % c], b - keep, mode="edge")))
+    rec = [np.ascontiguousarray(g["rec%d" % c]) for c in range(3)]
+    return ref, rec
+
+
+def test_oracle_lic(xo):
+    """MotionCompensationMv + LocalIlluminationComp vectors of the reference."""
+    import oracle_lic as ol_
+    g = load("lic")
+    ref, rec = _lic_planes(g)
+    ph, pw = rec[0].shape
+    for j, exp in zip(g["jobs"], g["pred"]):
+        s = 1 if j["comp"] else 0
+        x, y, w, h = int(j["x"]) >> s, int(j["y"]) >> s, int(j["w"]) >> s, int(j["h"]) >> s
+        got = ol_.xo_mc_lic(xo, 10, j, pw, ph, ref, [BL, BC, BC], rec)
+        assert np.array_equal(got[y:y + h, x:x + w], exp[:h, :w]), j
+
+
 # ------------------------------------------------------------------------ GPU
 @pytest.fixture(scope="module")
 def gpu():
@@ -563,4 +587,22 @@ def test_gpu_intra(gpu):
         x, y, bw, bh, comp = (int(j[k]) for k in ("x", "y", "w", "h", "comp"))
         assert np.array_equal(P.download()[comp][y:y + bh, x:x + bw], exp[:bh, :bw]), j
     for p in (R, O, P):
+        p.destroy()
+
+
+@pytest.mark.gpu
+def test_gpu_lic(gpu):
+    api, ctx = gpu
+    g = load("lic")
+    ref, rec = _lic_planes(g)
+    ph, pw = rec[0].shape
+    R, C_, P = ctx.picture(pw, ph, 10), ctx.picture(pw, ph, 10), ctx.picture(pw, ph, 10)
+    R.upload(ref, BL)
+    C_.upload(rec)
+    for j, exp in zip(g["jobs"], g["pred"]):
+        ctx.mc_lic_batch(R, C_, P, np.array([j], api.LIC_DTYPE))
+        c, s = int(j["comp"]), 1 if j["comp"] else 0
+        x, y, w, h = int(j["x"]) >> s, int(j["y"]) >> s, int(j["w"]) >> s, int(j["h"]) >> s
+        assert np.array_equal(P.download()[c][y:y + h, x:x + w], exp[:h, :w]), j
+    for p in (R, C_, P):
         p.destroy()

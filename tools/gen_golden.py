@@ -256,6 +256,39 @@ def gen_intra(xr):
     np.savez_compressed(os.path.join(OUT, "intra.npz"), **out)
 
 
+def gen_lic(xr):
+    """lic.npz: InterPrediction::MotionCompensationMv with local illumination
+    compensation on seeded CUs (all components, assorted neighbours)."""
+    import oracle_lic as ol_
+    rng = np.random.default_rng(20261003)
+    bd, pw, ph = 10, 128, 96
+    cur, ref = make_pics(rng, bd, pw, ph, BL, motion=(2, 1), noise=3)
+    rec_y = np.clip(cur[BL:BL + ph, BL:BL + pw].astype(np.float64) * 0.85 + 20, 0, 1023) \
+        .astype(np.uint16)
+    chroma_ref = [rnd_samples(rng, bd, ph // 2 + 2 * BC, pw // 2 + 2 * BC, True) for _ in range(2)]
+    rec_c = [np.clip(c[BC:BC + ph // 2, BC:BC + pw // 2].astype(np.int64) * 7 // 8 + 30, 0, 1023)
+             .astype(np.uint16) for c in chroma_ref]
+    ref_planes = [np.ascontiguousarray(ref)] + chroma_ref
+    rec_planes = [np.ascontiguousarray(rec_y)] + [np.ascontiguousarray(c) for c in rec_c]
+    xr._set_simd(0)
+    jobs, preds = [], []
+    for j, above, left in ol_.random_jobs(rng, pw, ph, 60):
+        p = ol_.xr_mc_lic(xr, bd, j, above, left, pw, ph, ref_planes, [BL, BC, BC], rec_planes)
+        s = 1 if j["comp"] else 0
+        x, y, w, h = int(j["x"]) >> s, int(j["y"]) >> s, int(j["w"]) >> s, int(j["h"]) >> s
+        pp = np.zeros((64, 64), np.uint16)
+        pp[:h, :w] = p[y:y + h, x:x + w]
+        jobs.append(j)
+        preds.append(pp)
+    xr._set_simd(1)
+    keep = 80   # border actually reachable: 64 + 8 + taps
+    out = {"jobs": np.array(jobs, ol_.LIC_DTYPE), "pred": np.array(preds),
+           "ref0": crop(ref_planes[0], BL, keep), "ref1": crop(ref_planes[1], BC, keep // 2),
+           "ref2": crop(ref_planes[2], BC, keep // 2), "rec0": rec_planes[0],
+           "rec1": rec_planes[1], "rec2": rec_planes[2]}
+    np.savez_compressed(os.path.join(OUT, "lic.npz"), **out)
+
+
 def gen_frame(xr):
     """frame.npz: the hot-path frame pass run by the reference's own classes
     (ref_harness.cc xr_frame_pass) on three chained 136x72 synthetic pictures
@@ -309,6 +342,10 @@ def main():
         return
     if sys.argv[1:] == ["intra"]:
         gen_intra(xr)
+        write_manifest()
+        return
+    if sys.argv[1:] == ["lic"]:
+        gen_lic(xr)
         write_manifest()
         return
     if sys.argv[1:] == ["frame"]:

@@ -216,6 +216,19 @@ class InterPrediction {
     ctx_.Sync();
   }
 
+  // MotionCompensationMv for CUs with GetUseLic(): the prediction with the local
+  // illumination model (LocalIlluminationComp / DeriveLicParams) applied;
+  // rec_pic = the current reconstruction (neighbouring CUs already there).
+  void MotionCompensationLicBatch(const Picture &ref_pic, const Picture &rec_pic,
+                                  Picture *pred_pic,
+                                  const std::vector<xvcgpu_mc_lic_block> &blocks) const {
+    DeviceArray<xvcgpu_mc_lic_block> d(ctx_, blocks);
+    ctx_.Check(xvcgpu_mc_lic_batch(ctx_.get(), ref_pic.get(), rec_pic.get(),
+                                   pred_pic->get(), d.data(),
+                                   static_cast<int>(blocks.size())));
+    ctx_.Sync();
+  }
+
  private:
   const Context &ctx_;
 };
