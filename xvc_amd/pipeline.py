@@ -500,3 +500,144 @@ class IntraPicturePass:
                   self.d_levels, self.d_nnz, self.d_dist, self.d_modes):
             b.free()
         self.pred.destroy()
+
+
+class MixedPictureDecoder:
+    """Decoder-side reconstruction of an inter picture whose CUs are a mix of
+    uni-pred, bi-pred, LIC and intra CUs: what
+    CuDecoder::DecompressInter / DecompressIntra (cu_decoder.cc) do CU by CU,
+    scheduled as dependency waves over a raster of cu x cu CUs.  Plain inter
+    CUs need no neighbour: wave 0 (prediction + inverse path for all of them).
+    A LIC CU reads the reconstruction of its left / above CU, an intra CU that
+    of left, above-left, above and above-right: wave = 1 + the latest of those.
+    Per wave: xvcgpu_mc_lic_batch + xvcgpu_inv_transform_batch for the LIC CUs,
+    one fused xvcgpu_intra_recon_batch for the intra CUs.
+
+    syntax (numpy, CUs in raster order): kind[n] (0 uni L0, 1 bi, 2 LIC, 3 intra),
+    mv0[n,2], mv1[n,2] (1/16 pel), intra_mode[n], levels / nnz per (CU, comp)."""
+
+    UNI, BI, LIC, INTRA = 0, 1, 2, 3
+
+    def __init__(self, ctx, width, height, bitdepth, qp, kind, mv0, mv1, intra_mode, cu=16):
+        assert cu <= 16
+        self.ctx, self.bd, self.w, self.h = ctx, bitdepth, width, height
+        parts = cu_partition(width, height, cu)
+        n = len(parts)
+        per_row = (width + cu - 1) // cu
+        qpc = chroma_qp(qp)
+        wave = np.zeros(n, np.int64)
+        for i, (x, y, w, h) in enumerate(parts):
+            if kind[i] in (self.UNI, self.BI):
+                continue
+            deps = []
+            if x:
+                deps.append(i - 1)
+            if y:
+                deps.append(i - per_row)
+            if kind[i] == self.INTRA:
+                if x and y:
+                    deps.append(i - per_row - 1)
+                if y and x + w < width:
+                    deps.append(i - per_row + 1)
+            wave[i] = 1 + max([wave[d] for d in deps], default=0)
+        # CUs ordered by (wave, kind): every (wave, kind) group is one batch
+        self.order = order = sorted(range(n), key=lambda i: (wave[i], kind[i], i))
+        self.parts = [parts[i] for i in order]
+        self.kind = np.asarray(kind)[order]
+        self.wave = wave[order]
+        tx = np.zeros(3 * n, api.TX_DTYPE)
+        jobs3 = np.zeros(3 * n, api.INTRA_DTYPE)
+        uni, bi, lic = [], [], []
+        for k, i in enumerate(order):
+            x, y, w, h = parts[i]
+            for c in range(3):
+                s = 1 if c else 0
+                tx[3 * k + c] = (x >> s, y >> s, w >> s, h >> s, c, 0, 0, 0,
+                                 qpc if c else qp, 0)
+            if kind[i] == self.UNI:
+                uni += [(x, y, w, h, c, 0, *mv0[i]) for c in range(3)]
+            elif kind[i] == self.BI:
+                bi += [(x, y, w, h, c, 0, *mv0[i], *mv1[i]) for c in range(3)]
+            elif kind[i] == self.LIC:
+                nb = (1 if y else 0) | (2 if x else 0)
+                lic += [(x, y, w, h, c, nb, *mv0[i], x, max(0, y - cu), max(0, x - cu), y)
+                        for c in range(3)]
+            else:
+                nb = (api.INTRA_HAS_LEFT if x else 0) | (api.INTRA_HAS_ABOVE if y else 0) | \
+                    (api.INTRA_HAS_ABOVE_LEFT if x and y else 0)
+                ar = max(0, min(h, width - (x + w))) if y else 0
+                for c in range(3):
+                    s = 1 if c else 0
+                    jobs3[3 * k + c] = (x >> s, y >> s, w >> s, h >> s, c, intra_mode[i], nb,
+                                        ar >> s, 0, 0)
+        self.tx = tx
+        self.level_off, self.level_total = api.Context.level_offsets(tx)
+        self.d_tx, self.d_off = ctx.buffer(tx), ctx.buffer(self.level_off)
+        self.d_jobs3 = ctx.buffer(jobs3)
+        self.d_uni = ctx.buffer(np.array(uni, api.MC_DTYPE)) if uni else None
+        self.d_bi = ctx.buffer(np.array(bi, api.MCBI_DTYPE)) if bi else None
+        self.d_lic = ctx.buffer(np.array(lic, api.LIC_DTYPE)) if lic else None
+        self.n_uni, self.n_bi = len(uni), len(bi)
+        self.d_levels = ctx.alloc(2 * max(1, self.level_total))
+        self.d_nnz = ctx.alloc(4 * 3 * n)
+        self.pred = ctx.picture(width, height, bitdepth)
+        # batches: (first CU, last CU) in the new order per (wave, kind)
+        self.groups = []
+        k = 0
+        while k < n:
+            e = k
+            while e < n and self.wave[e] == self.wave[k] and self.kind[e] == self.kind[k]:
+                e += 1
+            self.groups.append((int(self.wave[k]), int(self.kind[k]), k, e))
+            k = e
+        self.n_inter = sum(e - a for wv, kd, a, e in self.groups if kd in (self.UNI, self.BI))
+
+    def load(self, levels_per_tx, nnz_per_tx):
+        """levels_per_tx[3 * i + c]: w*h int16 of CU i (raster order), comp c."""
+        lv = np.zeros(self.level_total, np.int16)
+        nz = np.zeros(len(self.tx), np.int32)
+        for k, i in enumerate(self.order):
+            for c in range(3):
+                a = np.asarray(levels_per_tx[3 * i + c], np.int16).reshape(-1)
+                off = int(self.level_off[3 * k + c])
+                lv[off:off + len(a)] = a
+                nz[3 * k + c] = nnz_per_tx[3 * i + c]
+        self.ctx.h2d(self.d_levels.ptr, lv)
+        self.ctx.h2d(self.d_nnz.ptr, nz)
+
+    def _inverse(self, rec, a, e):
+        ctx, T = self.ctx, api.TX_DTYPE.itemsize
+        ctx._check(ctx.lib.xvcgpu_inv_transform_batch(
+            ctx.h, self.pred.h_pic, rec.h_pic, self.d_tx.ptr + 3 * a * T, 3 * (e - a),
+            self.d_levels.ptr, self.d_off.ptr + 3 * a * 4, self.d_nnz.ptr + 3 * a * 4))
+
+    def decode(self, ref0, ref1, rec):
+        ctx, lib = self.ctx, self.ctx.lib
+        J, T, L = api.INTRA_DTYPE.itemsize, api.TX_DTYPE.itemsize, api.LIC_DTYPE.itemsize
+        if self.n_uni:
+            ctx.mc_batch_dev(ref0, self.pred, self.d_uni.ptr, self.n_uni)
+        if self.n_bi:
+            ctx._check(lib.xvcgpu_mc_bipred_batch(ctx.h, ref0.h_pic, ref1.h_pic,
+                                                  self.pred.h_pic, self.d_bi.ptr, self.n_bi))
+        if self.n_inter:
+            self._inverse(rec, 0, self.n_inter)     # all plain inter CUs come first
+        lic_done = 0
+        for wv, kd, a, e in self.groups:
+            if kd == self.LIC:
+                ctx._check(lib.xvcgpu_mc_lic_batch(ctx.h, ref0.h_pic, rec.h_pic, self.pred.h_pic,
+                                                   self.d_lic.ptr + 3 * lic_done * L,
+                                                   3 * (e - a)))
+                lic_done += e - a
+                self._inverse(rec, a, e)
+            elif kd == self.INTRA:
+                ctx._check(lib.xvcgpu_intra_recon_batch(
+                    ctx.h, None, rec.h_pic, self.d_jobs3.ptr + 3 * a * J,
+                    self.d_tx.ptr + 3 * a * T, 3 * (e - a), self.d_levels.ptr,
+                    self.d_off.ptr + 3 * a * 4, self.d_nnz.ptr + 3 * a * 4))
+
+    def destroy(self):
+        for b in (self.d_tx, self.d_off, self.d_jobs3, self.d_uni, self.d_bi, self.d_lic,
+                  self.d_levels, self.d_nnz):
+            if b is not None:
+                b.free()
+        self.pred.destroy()
