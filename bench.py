@@ -63,6 +63,10 @@ def parse():
                          "kernels (1080p: 6870 / 8030 / 8740 frame passes/s with 1 / 2 / 3 "
                          "chains, tools/two_chains.py); with N > 1 also hides the RCCL "
                          "exchanges of one chain behind the kernels of the others")
+    ap.add_argument("--force-sharded", action="store_true",
+                    help="testing aid: take the multi-GPU code path (row-sharded engine, "
+                         "process groups, RCCL exchanges) even with one rank; launch "
+                         "through torch.distributed.run --nproc-per-node 1")
     ap.add_argument("--kernel-times", action="store_true", default=True)
     return ap.parse_args()
 
@@ -152,13 +156,19 @@ def cpu_baseline(args, clip, bd, border):
 
 def main():
     args = parse()
+    # HIP maps streams onto 4 hardware queues by default; torch / RCCL take
+    # some, and two chains whose streams land on one queue run one after the
+    # other (3 chains beside RCCL: 7530 -> 8650 frame passes/s with 8 queues).
+    # Must be set before the runtime starts.
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     import torch
     from xvc_amd import api, pipeline, synth
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    multi = world > 1 or args.force_sharded     # row-sharded engine + process groups
+    if multi:
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
@@ -172,10 +182,15 @@ def main():
     ctx = api.Context(local_rank)
     clip = synth.SyntheticClip(W, H, bd)
 
-    if world > 1:
+    ts0 = None
+    if multi:
         from xvc_amd import sharded
+        # every chain on its context's own stream (handed to torch so that the
+        # RCCL operations are ordered on it) - not torch's default stream
         runner = sharded.make_gpu_sharded(ctx, W, H, bd, args.qp, rank, world,
-                                          torch.device("cuda", local_rank), dist)
+                                          torch.device("cuda", local_rank), dist,
+                                          own_stream=True)
+        ts0 = runner.e.stream
     else:
         runner = None
 
@@ -214,12 +229,11 @@ def main():
         cctx = api.Context(local_rank)
         phase = (c * cycle_len) // n_chains
         first = pad_planes(clip.frame(phase if phase < F else 2 * F - 2 - phase), border)
-        if world > 1:
-            ts = torch.cuda.Stream(device=torch.device("cuda", local_rank))
-            with torch.cuda.stream(ts):
-                crun = sharded.make_gpu_sharded(cctx, W, H, bd, args.qp, rank, world,
-                                                torch.device("cuda", local_rank), dist,
-                                                group=dist.new_group())
+        if multi:
+            crun = sharded.make_gpu_sharded(cctx, W, H, bd, args.qp, rank, world,
+                                            torch.device("cuda", local_rank), dist,
+                                            group=dist.new_group(), own_stream=True)
+            ts = crun.e.stream
             crecs, cfp = crun.e.pictures, crun.e.fp
         else:
             ts, crun = None, None
@@ -255,7 +269,8 @@ def main():
         o = origs[k if k < F else 2 * F - 2 - k]
         ref, rec = recs[i % 2], recs[(i + 1) % 2]
         if runner is not None:
-            runner.run(o, i % 2, (i + 1) % 2, ref_poc=i)
+            with torch.cuda.stream(ts0):
+                runner.run(o, i % 2, (i + 1) % 2, ref_poc=i)
         elif pipelined:
             pfp.run(o, ref, rec, ref_poc=i)
         elif not args.graph:
@@ -278,7 +293,7 @@ def main():
             ctx_lo.sync()
             ctx.sync()
         torch.cuda.synchronize()
-        if world > 1:
+        if multi:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -297,7 +312,7 @@ def main():
     gpu_ms = ctx.timer_end()
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if multi:
         t = torch.tensor([dt], device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -358,7 +373,7 @@ def main():
         # of this command shows): one more cycle of the round-robin, chain 0's
         # launch of the search bracketed by two events per step, read afterwards.
         in_flight = None
-        if n_chains > 1 and world == 1 and cycle <= 31:
+        if n_chains > 1 and not multi and cycle <= 31:
             start = (base + cycle) * n_chains
             for i in range(start, start + cycle * n_chains):
                 if i % n_chains:
@@ -399,7 +414,7 @@ def main():
                      "recon_from_me": "recon_from_me_kernel",
                      "picture_ssd": "picture_ssd_kernel", "pad_border": "pad_border_kernel",
                      "deblock": "void deblock_pass_kernel<true>"}[dom]
-            if W == 1920 and H == 1080 and world == 1:
+            if W == 1920 and H == 1080 and not multi:
                 traffic = prof[kname]["hbm_bytes_per_launch"]
         except (OSError, KeyError, ValueError):
             traffic = None
@@ -419,7 +434,7 @@ def main():
                                      for k, v in times.items() if v > 0}}
 
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu:
+    if rank == 0 and not multi and not args.no_cpu:
         cpu = cpu_baseline(args, clip, bd, border)
 
     if rank == 0:
@@ -443,12 +458,12 @@ def main():
                        "parallelism": (("two-queue" if pipelined else
                                         "single" if n_chains == 1 else
                                         "%d independent picture chains in flight" % n_chains)
-                                       if world == 1 else
+                                       if not multi else
                                        "cu-row-shard%d x %d chains in flight" % (world, n_chains))},
             "roofline": roof, "cpu_baseline": cpu,
         }
         print(json.dumps(out))
-    if world > 1:
+    if multi:
         dist.destroy_process_group()
 
 

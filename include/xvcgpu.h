@@ -53,6 +53,11 @@ void xvcgpu_destroy(xvcgpu_ctx *ctx);
 const char *xvcgpu_last_error(const xvcgpu_ctx *ctx);
 /* Version string "xvcgpu <major>.<minor> gfx950". Callable without a GPU. */
 const char *xvcgpu_version(void);
+/* The hipStream_t the context launches on (its own stream unless
+ * xvcgpu_set_stream replaced it) - for callers that must order other work
+ * after it, e.g. wrap it as torch.cuda.ExternalStream so that RCCL operations
+ * are issued on the same stream as the kernels. */
+void *xvcgpu_get_stream(const xvcgpu_ctx *ctx);
 /* Launch on an external hipStream_t (e.g. torch's current stream, so kernels
  * order with torch copies and RCCL collectives); NULL = the device's default
  * stream.  xvcgpu_use_own_stream() returns to a private non-blocking stream
@@ -492,6 +497,17 @@ xvcgpu_status xvcgpu_intra_recon_batch(xvcgpu_ctx *ctx, const xvcgpu_picture *or
                                        const xvcgpu_tx_block *d_blocks, int n,
                                        int16_t *d_levels, const uint32_t *d_level_offsets,
                                        int32_t *d_nnz);
+
+/* ---- a picture per call ------------------------------------------------- *
+ * The per-picture sequence of the entry points above behind one call (host
+ * cost of one call instead of six; nothing new is computed): the phases set in
+ * a->phases run in the order ENCODE (InterSearch::SearchMotion +
+ * CompressAndEvalCbf for the uni-pred CUs of a->d_me), DEBLOCK_V, DEBLOCK_H
+ * (DeblockingFilter::DeblockPicture, by rows so that a row shard can exchange
+ * its halo in between), PAD (YuvPicture::PadBorder), SSD (ComparePicture parts).
+ * Asynchronous on the context's stream like its parts. */
+xvcgpu_status xvcgpu_frame_pass(xvcgpu_ctx *ctx, const xvcgpu_frame_pass_args *a,
+                                int phases);
 
 /* ---- tables (host side, no GPU needed) ---------------------------------- *
  * The 8-bit-fraction transform matrices the kernels use (transform_data.cc:

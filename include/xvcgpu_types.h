@@ -210,4 +210,34 @@ typedef struct xvcgpu_mc_block {
 #ifdef __cplusplus
 }
 #endif
+/* One picture's worth of the hot path in a single call (xvcgpu_frame_pass):
+ * the launches a host issues per picture - search, CompressAndEvalCbf,
+ * deblocking, PadBorder, PSNR parts - selected by `phases`, in this order.
+ * All pointers are device memory laid out as for the individual entry points. */
+#define XVC_FP_ENCODE 1     /* xvcgpu_me_search_sized + xvcgpu_recon_from_me    */
+#define XVC_FP_DEBLOCK_V 2  /* xvcgpu_deblock_rows pass 0 on [db_y_begin, db_y_end) */
+#define XVC_FP_DEBLOCK_H 4  /* xvcgpu_deblock_rows pass 1 on [db_y_begin, dbh_y_end) */
+#define XVC_FP_PAD 8        /* xvcgpu_pad_border(rec)                           */
+#define XVC_FP_SSD 16       /* xvcgpu_picture_ssd_rows(orig, rec, luma)         */
+typedef struct xvcgpu_frame_pass_args {
+  const struct xvcgpu_picture *orig, *ref;
+  struct xvcgpu_picture *rec;
+  const xvcgpu_me_block *d_me;   /* the own CUs' search jobs (CUs <= 16x16)     */
+  xvcgpu_me_result *d_results;
+  int32_t n_cus;                 /* own CUs                                     */
+  int32_t max_block_size;
+  int32_t qp_y, qp_c, ref_poc;
+  int32_t *d_nnz;                /* 3 per own CU                                */
+  xvcgpu_cu_info *d_cus_own;     /* metadata of the own CUs (inside d_cus)      */
+  const xvcgpu_cu_info *d_cus;   /* whole picture's CU array                    */
+  int32_t n_cus_total;
+  const int32_t *d_cu_map;
+  int32_t map_stride;
+  int32_t db_y_begin, db_y_end;  /* luma rows of the vertical-edge pass         */
+  int32_t dbh_y_end;             /* end row of the horizontal-edge pass         */
+  int32_t ssd_y_begin, ssd_y_end;
+  int32_t shift_bitdepth;        /* xvcgpu_picture_ssd_rows                     */
+  uint64_t *d_ssd;
+} xvcgpu_frame_pass_args;
+
 #endif /* XVCGPU_TYPES_H_ */

@@ -75,10 +75,26 @@ assert CU_DTYPE.itemsize == 84 and ME_DTYPE.itemsize == 32
 assert MERES_DTYPE.itemsize == 24 and TX_DTYPE.itemsize == 12
 assert MC_DTYPE.itemsize == 16 and CAND_DTYPE.itemsize == 12
 
+class FramePassArgs(C.Structure):
+    """xvcgpu_frame_pass_args (include/xvcgpu_types.h)"""
+    _fields_ = [("orig", C.c_void_p), ("ref", C.c_void_p), ("rec", C.c_void_p),
+                ("d_me", C.c_void_p), ("d_results", C.c_void_p),
+                ("n_cus", C.c_int32), ("max_block_size", C.c_int32),
+                ("qp_y", C.c_int32), ("qp_c", C.c_int32), ("ref_poc", C.c_int32),
+                ("d_nnz", C.c_void_p), ("d_cus_own", C.c_void_p), ("d_cus", C.c_void_p),
+                ("n_cus_total", C.c_int32), ("d_cu_map", C.c_void_p),
+                ("map_stride", C.c_int32), ("db_y_begin", C.c_int32),
+                ("db_y_end", C.c_int32), ("dbh_y_end", C.c_int32),
+                ("ssd_y_begin", C.c_int32), ("ssd_y_end", C.c_int32),
+                ("shift_bitdepth", C.c_int32), ("d_ssd", C.c_void_p)]
+
+
+FP_ENCODE, FP_DEBLOCK_V, FP_DEBLOCK_H, FP_PAD, FP_SSD = 1, 2, 4, 8, 16
+
 # every symbol include/xvcgpu.h declares
 SYMBOLS = [
     "xvcgpu_create", "xvcgpu_destroy", "xvcgpu_last_error", "xvcgpu_version",
-    "xvcgpu_set_stream", "xvcgpu_use_own_stream", "xvcgpu_use_priority_stream", "xvcgpu_wait_for", "xvcgpu_sync", "xvcgpu_timer_begin", "xvcgpu_timer_end", "xvcgpu_timer_mark", "xvcgpu_timer_between",
+    "xvcgpu_set_stream", "xvcgpu_get_stream", "xvcgpu_use_own_stream", "xvcgpu_use_priority_stream", "xvcgpu_wait_for", "xvcgpu_sync", "xvcgpu_timer_begin", "xvcgpu_timer_end", "xvcgpu_timer_mark", "xvcgpu_timer_between",
     "xvcgpu_record_begin", "xvcgpu_record_end", "xvcgpu_replay", "xvcgpu_recording_destroy",
     "xvcgpu_malloc", "xvcgpu_free", "xvcgpu_memcpy_h2d", "xvcgpu_memcpy_d2h",
     "xvcgpu_memset", "xvcgpu_picture_create", "xvcgpu_picture_bytes",
@@ -94,7 +110,7 @@ SYMBOLS = [
     "xvcgpu_picture_import", "xvcgpu_picture_export", "xvcgpu_picture_crc",
     "xvcgpu_variance_map", "xvcgpu_histogram_distance",
     "xvcgpu_intra_pred_batch", "xvcgpu_intra_satd_batch", "xvcgpu_intra_recon_batch",
-    "xvcgpu_intra_select_modes", "xvcgpu_get_transform_matrix",
+    "xvcgpu_intra_select_modes", "xvcgpu_frame_pass", "xvcgpu_get_transform_matrix",
 ]
 
 _vp = C.c_void_p
@@ -197,6 +213,7 @@ def load_library():
         "xvcgpu_intra_satd_batch": [_vp, _vp, _vp, _vp, C.c_int, _vp, C.c_int],
         "xvcgpu_intra_recon_batch": [_vp, _vp, _vp, _vp, _vp, C.c_int, _vp, _vp, _vp],
         "xvcgpu_intra_select_modes": [_vp, _vp, _vp, C.c_int, _vp, _vp, _vp, C.c_int],
+        "xvcgpu_frame_pass": [_vp, C.POINTER(FramePassArgs), C.c_int],
         "xvcgpu_get_transform_matrix": [C.c_int, C.c_int, _vp],
     }
     for name, args in sigs.items():
@@ -371,6 +388,11 @@ class Context:
         """Work queued on this context from now on starts after everything
         already queued on `other`."""
         self._check(self.lib.xvcgpu_wait_for(self.h, other.h))
+
+    def stream_ptr(self):
+        f = self.lib.xvcgpu_get_stream
+        f.restype, f.argtypes = C.c_void_p, [_vp]
+        return f(self.h) or 0
 
     def use_own_stream(self):
         self._check(self.lib.xvcgpu_use_own_stream(self.h))

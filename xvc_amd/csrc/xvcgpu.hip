@@ -221,6 +221,10 @@ xvcgpu_status xvcgpu_set_stream(xvcgpu_ctx *ctx, void *hip_stream) {
   return XVCGPU_OK;
 }
 
+void *xvcgpu_get_stream(const xvcgpu_ctx *ctx) {
+  return ctx ? static_cast<void *>(ctx->stream) : nullptr;
+}
+
 xvcgpu_status xvcgpu_use_own_stream(xvcgpu_ctx *ctx) {
   if (!ctx) return XVCGPU_INVALID_ARGUMENT;
   if (ctx->own_stream) return XVCGPU_OK;
@@ -1149,6 +1153,39 @@ xvcgpu_status xvcgpu_intra_select_modes(xvcgpu_ctx *ctx, const uint32_t *d_dist,
                      d_dist, d_mode_cost, n, d_modes, d_jobs, d_blocks, per_cu);
   CHECK_LAUNCH(ctx, "intra_select_modes");
   return XVCGPU_OK;
+}
+
+/* ---- a picture per call ---- */
+xvcgpu_status xvcgpu_frame_pass(xvcgpu_ctx *ctx, const xvcgpu_frame_pass_args *a,
+                                int phases) {
+  if (!ctx || !a || !a->rec) return XVCGPU_INVALID_ARGUMENT;
+  xvcgpu_status st = XVCGPU_OK;
+  if ((phases & XVC_FP_ENCODE) && a->n_cus > 0) {
+    st = xvcgpu_me_search_sized(ctx, a->orig, a->ref, XVCGPU_ME_FULLPEL | XVCGPU_ME_SUBPEL,
+                                a->d_me, a->n_cus, a->d_results, a->max_block_size);
+    if (st != XVCGPU_OK) return st;
+    st = xvcgpu_recon_from_me(ctx, a->orig, a->ref, a->rec, a->d_me, a->d_results, a->n_cus,
+                              a->qp_y, a->qp_c, 0, a->ref_poc, a->d_nnz, a->d_cus_own);
+    if (st != XVCGPU_OK) return st;
+  }
+  if (phases & XVC_FP_DEBLOCK_V) {
+    st = xvcgpu_deblock_rows(ctx, a->rec, a->d_cus, a->n_cus_total, a->d_cu_map, a->map_stride,
+                             0, 0, 0, 4, 0, a->db_y_begin, a->db_y_end);
+    if (st != XVCGPU_OK) return st;
+  }
+  if (phases & XVC_FP_DEBLOCK_H) {
+    st = xvcgpu_deblock_rows(ctx, a->rec, a->d_cus, a->n_cus_total, a->d_cu_map, a->map_stride,
+                             0, 0, 0, 4, 1, a->db_y_begin, a->dbh_y_end);
+    if (st != XVCGPU_OK) return st;
+  }
+  if (phases & XVC_FP_PAD) {
+    st = xvcgpu_pad_border(ctx, a->rec);
+    if (st != XVCGPU_OK) return st;
+  }
+  if (phases & XVC_FP_SSD)
+    st = xvcgpu_picture_ssd_rows(ctx, a->orig, a->rec, 0, a->shift_bitdepth, a->ssd_y_begin,
+                                 a->ssd_y_end, a->d_ssd);
+  return st;
 }
 
 }  // extern "C"

@@ -19,6 +19,8 @@ the quantiser is the reference's non-RDO QuantFast (scope).
 """
 import math
 
+import ctypes as C
+
 import numpy as np
 
 from . import api
@@ -139,6 +141,39 @@ class FramePass:
     def d_cus_own(self):
         return self.d_cus.ptr + api.CU_DTYPE.itemsize * self.desc.cu_base
 
+    def _args(self):
+        """The picture-per-call argument block (xvcgpu_frame_pass), built once;
+        only the picture handles, the reference POC and row ranges change."""
+        if getattr(self, "_fp_args", None) is None:
+            d, a = self.desc, api.FramePassArgs()
+            a.d_me, a.d_results, a.n_cus = self.d_me.ptr, self.d_res.ptr, d.n_cus
+            a.max_block_size, a.qp_y, a.qp_c = d.cu_size, d.qp, d.qp_c
+            a.d_nnz, a.d_cus_own, a.d_cus = self.d_nnz.ptr, self.d_cus_own, self.d_cus.ptr
+            a.n_cus_total, a.d_cu_map = d.n_cus_total, self.d_map.ptr
+            a.map_stride = d.cu_map.shape[1]
+            a.db_y_begin, a.db_y_end, a.dbh_y_end = 0, d.h, d.h
+            a.ssd_y_begin, a.ssd_y_end = 0, 1 << 30
+            a.shift_bitdepth, a.d_ssd = self.bd, self.d_ssd.ptr
+            self._fp_args = a
+        return self._fp_args
+
+    def run_phases(self, orig, ref, rec, phases, ref_poc=0, rows=None, dbh_end=None,
+                   ssd_rows=None, d_ssd=None):
+        """One call for the selected phases (api.FP_*).  Needs the fused
+        CompressAndEvalCbf kernel (CUs up to 16x16) for FP_ENCODE."""
+        a = self._args()
+        a.orig = orig.h_pic if orig is not None else None
+        a.ref = ref.h_pic if ref is not None else None
+        a.rec, a.ref_poc = rec.h_pic, ref_poc
+        if rows is not None:
+            a.db_y_begin, a.db_y_end = rows
+            a.dbh_y_end = dbh_end if dbh_end is not None else rows[1]
+        if ssd_rows is not None:
+            a.ssd_y_begin, a.ssd_y_end = ssd_rows
+        if d_ssd is not None:
+            a.d_ssd = d_ssd
+        self.ctx._check(self.ctx.lib.xvcgpu_frame_pass(self.ctx.h, C.byref(a), phases))
+
     def encode(self, orig, ref, rec, ref_poc=0):
         """ME -> MC -> residual -> CU metadata for the own CUs (asynchronous)."""
         ctx, d = self.ctx, self.desc
@@ -170,6 +205,12 @@ class FramePass:
     def run(self, orig, ref, rec, ref_poc=0, deblock=True, pad=True, ssd=True):
         """Enqueue one whole-picture frame pass (asynchronous)."""
         ctx, d = self.ctx, self.desc
+        if self.fused and d.cu_size <= 16 and d.row_range == (0, d.h):
+            # the whole sequence behind one C call (xvcgpu_frame_pass)
+            self.run_phases(orig, ref, rec, api.FP_ENCODE |
+                            (api.FP_DEBLOCK_V | api.FP_DEBLOCK_H if deblock else 0) |
+                            (api.FP_PAD if pad else 0) | (api.FP_SSD if ssd else 0), ref_poc)
+            return
         self.encode(orig, ref, rec, ref_poc)
         if deblock:
             ctx.deblock_dev(rec, self.d_cus.ptr, d.n_cus_total, self.d_map.ptr,

@@ -102,6 +102,7 @@ class ShardedFramePass:
             reach = engine.search_reach() + 8 + 4 + 16
         self.reach_up = (reach + 15) // 16 * 16
         self.reach_down = max(self.reach_up, 64)
+        self._ops = {}
         self.up = rank - 1 if rank > 0 else None
         self.down = rank + 1 if rank < world - 1 else None
         # exactness precondition of the redundant-halo scheme
@@ -123,10 +124,20 @@ class ShardedFramePass:
 
     # ---- phases ----
     def phase_a(self, orig, ref_idx, rec_idx, ref_poc):
+        if getattr(self.e, "one_call_phases", False):
+            self.e.phase_a(orig, ref_idx, rec_idx, ref_poc, self.y0, self.y1)
+            return
         self.e.encode(orig, ref_idx, rec_idx, ref_poc)
         self.e.deblock_rows(rec_idx, 0, self.y0, self.y1)
 
     def halo_ops(self, rec_idx):
+        # the slabs are fixed views of the picture memory: built once per buffer
+        key = ("halo", rec_idx)
+        if key not in self._ops:
+            self._ops[key] = self._halo_ops(rec_idx)
+        return self._ops[key]
+
+    def _halo_ops(self, rec_idx):
         H = self.HALO
         sends, recvs = [], []
         if self.up is not None:
@@ -143,6 +154,9 @@ class ShardedFramePass:
 
     def phase_b(self, rec_idx):
         y_end = self.y1 + self.HALO if self.down is not None else self.y1
+        if getattr(self.e, "one_call_phases", False):
+            self.e.phase_b(rec_idx, self.y0, y_end)
+            return
         self.e.deblock_rows(rec_idx, 1, self.y0, y_end)
 
     def needed_from(self, who, peer):
@@ -157,6 +171,12 @@ class ShardedFramePass:
         return (max(0, self.y0 - self.reach_up), min(self.e.h, self.y1 + self.reach_down))
 
     def gather_ops(self, rec_idx):
+        key = ("gather", rec_idx)
+        if key not in self._ops:
+            self._ops[key] = self._gather_ops(rec_idx)
+        return self._ops[key]
+
+    def _gather_ops(self, rec_idx):
         sends, recvs = [], []
         for peer in range(self.world):
             if peer == self.rank:
@@ -170,6 +190,9 @@ class ShardedFramePass:
         return sends, recvs
 
     def phase_c(self, orig, rec_idx):
+        if getattr(self.e, "one_call_phases", False):
+            self.e.phase_c(orig, rec_idx, self.y0, self.y1)
+            return
         self.e.pad(rec_idx)
         self.e.ssd(orig, rec_idx, self.y0, self.y1)
 
@@ -191,11 +214,18 @@ class GpuEngine:
     wrapped as xvcgpu pictures; kernels run on torch's current stream."""
 
     def __init__(self, ctx, width, height, bitdepth, qp, row_range, device,
-                 n_pictures=2, cu=16):
+                 n_pictures=2, cu=16, own_stream=False):
         import torch
         self.torch = torch
         self.ctx, self.w, self.h, self.bd, self.cu = ctx, width, height, bitdepth, cu
-        ctx.set_stream(torch.cuda.current_stream(device).cuda_stream)
+        if own_stream:
+            # keep the context's own stream and hand it to torch: RCCL operations
+            # issued under `with torch.cuda.stream(engine.stream)` are ordered on
+            # the very stream the kernels run on
+            self.stream = torch.cuda.ExternalStream(ctx.stream_ptr(), device=device)
+        else:
+            self.stream = torch.cuda.current_stream(device)
+            ctx.set_stream(self.stream.cuda_stream)
         nbytes = ctx.lib.xvcgpu_picture_bytes(width, height)
         self.mem, self.pictures, self.geom = [], [], []
         for _ in range(n_pictures):
@@ -238,6 +268,23 @@ class GpuEngine:
     def pad(self, rec_idx):
         self.ctx.pad_border(self.pictures[rec_idx])
 
+    # each phase of the sharded pass behind one C call (xvcgpu_frame_pass)
+    @property
+    def one_call_phases(self):
+        return self.fp.fused and self.cu <= 16 and self.fp.desc.n_cus > 0
+
+    def phase_a(self, orig, ref_idx, rec_idx, ref_poc, y0, y1):
+        self.fp.run_phases(orig, self.pictures[ref_idx], self.pictures[rec_idx],
+                           api.FP_ENCODE | api.FP_DEBLOCK_V, ref_poc, rows=(y0, y1))
+
+    def phase_b(self, rec_idx, y0, y_end):
+        self.fp.run_phases(None, None, self.pictures[rec_idx], api.FP_DEBLOCK_H,
+                           rows=(y0, y_end), dbh_end=y_end)
+
+    def phase_c(self, orig, rec_idx, y0, y1):
+        self.fp.run_phases(orig, None, self.pictures[rec_idx], api.FP_PAD | api.FP_SSD,
+                           ssd_rows=(y0, y1), d_ssd=self.ssd_mem.data_ptr())
+
     def search_reach(self):
         return search_reach(self.fp.desc)
 
@@ -259,6 +306,16 @@ class GpuEngine:
         return self.cu_mem[first_cu * s:(first_cu + n) * s]
 
 
+def torch_stream_of(ctx, device, own_stream):
+    """Context manager: torch allocations / ops inside belong to the stream the
+    engine will use."""
+    import contextlib
+    import torch
+    if not own_stream:
+        return contextlib.nullcontext()
+    return torch.cuda.stream(torch.cuda.ExternalStream(ctx.stream_ptr(), device=device))
+
+
 class _ExternalBuffer:
     """DeviceBuffer look-alike over memory owned by a torch tensor."""
 
@@ -276,10 +333,14 @@ class _ExternalBuffer:
 
 
 def make_gpu_sharded(ctx, width, height, bitdepth, qp, rank, world, device, dist,
-                     group=None):
+                     group=None, own_stream=False):
     """The engine's kernels run on torch's current stream at the time of this
-    call (use `with torch.cuda.stream(s)` here and around run() for a chain of
-    its own); `group`: the chain's own process group, if any."""
+    call, or - own_stream - on the context's own stream, exposed to torch as
+    `runner.e.stream`; either way call run() under `with torch.cuda.stream(
+    runner.e.stream)` for a chain of its own.  `group`: the chain's own process
+    group, if any."""
     rows = shard_rows(height, world)
-    engine = GpuEngine(ctx, width, height, bitdepth, qp, rows[rank], device)
+    with torch_stream_of(ctx, device, own_stream):
+        engine = GpuEngine(ctx, width, height, bitdepth, qp, rows[rank], device,
+                           own_stream=own_stream)
     return ShardedFramePass(engine, TorchComm(dist, rank, world, group), rank, world)
