@@ -56,8 +56,10 @@ def parse():
                     help="N=1: replay one recorded HIP graph per step instead of "
                          "launching the kernels separately (measured ~3 %% slower: "
                          "the steps are GPU-bound, not launch-bound)")
-    ap.add_argument("--chains", type=int, default=3,
-                    help="independent picture chains in flight, issued round-robin on "
+    ap.add_argument("--chains", type=int, default=0,
+                    help="(0 = automatic: 3, or 1 when one rank's share of a picture "
+                         "exceeds 3840x2160, where a picture fills the chip by itself) "
+                         "independent picture chains in flight, issued round-robin on "
                          "their own HIP streams (like the reference's picture-level "
                          "threads): a picture of one chain fills the drain of another's "
                          "kernels (1080p: 6870 / 8030 / 8740 frame passes/s with 1 / 2 / 3 "
@@ -221,7 +223,8 @@ def main():
     # ---- further independent chains (own context = own stream, own
     # reconstructions and job buffers; the originals are shared, each chain
     # starts at another phase of the frame cycle) ----
-    n_chains = 1 if (pipelined or args.graph) else max(1, args.chains)
+    auto_chains = 3 if W * H // world <= 3840 * 2160 else 1
+    n_chains = 1 if (pipelined or args.graph) else (args.chains or auto_chains)
     extra = []          # (ctx, runner-or-None, frame pass, recs, phase, torch stream)
     F = len(origs)
     cycle_len = 2 * F - 2 if F > 1 else 1
