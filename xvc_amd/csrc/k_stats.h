@@ -231,7 +231,9 @@ picture_export_kernel(PicView src, ExportArgs a) {
 // trailing zero bits multiply by x^16: linear over GF(2).  So every row's
 // M_row(x) mod P is computed by its own wave, multiplied by x^(number of
 // message bits that follow the row, + 16) and XOR-ed into the result word; the
-// preset term is added by the wave of the first row.  All powers of x come from
+// preset term is added by the wave of the first row (in mode 0 every plane's
+// pieces already carry the bits of the planes after it, so the three plane
+// words simply XOR together).  All powers of x come from
 // a table of x^(2^i) mod P passed with the launch (host-computed constants).
 #define XVC_CRC_POLY 0x1021u
 
@@ -268,25 +270,51 @@ struct CrcArgs {
 // window owns 16 samples; windows are aligned to the END of the row so that
 // the incomplete one comes first, where missing samples are leading zeros and
 // change nothing.  acc[c or 0] ^= contribution of the row.
-__global__ void __launch_bounds__(256)
-crc_rows_kernel(PicView pic, CrcArgs a, uint32_t *acc_words) {
-  __shared__ uint16_t tab[256];  // h * x^16 mod P
-  {
-    uint32_t r = (uint32_t)threadIdx.x << 8;
-#pragma unroll
+// Byte-indexed tables, built once on the host for each sample width (they depend
+// on nothing else): tab = h * x^16 mod P (the byte step of the register);
+// mul_lo / mul_hi[l] = multiplication by a joining constant split by operand
+// byte (GF(2)-linear: c * v = c * hi(v) * x^8 + c * lo(v)) - 2 LDS reads per
+// product instead of a 16-step shift-and-xor loop.  l = 0..6: x^(lane bits << l),
+// l = 7: x^(bits of 4 samples).
+struct CrcTables {
+  uint16_t tab[256];
+  uint16_t mul_lo[8][256], mul_hi[8][256];
+};
+
+inline void crc_build_tables(CrcTables &t, const CrcPow2 &pow2, int wide) {
+  for (uint32_t i = 0; i < 256; i++) {
+    uint32_t r = i << 8;
     for (int b = 0; b < 8; b++)
       r = (r & 0x8000u) ? ((r << 1) ^ XVC_CRC_POLY) & 0xffffu : (r << 1) & 0xffffu;
-    tab[threadIdx.x] = (uint16_t)r;
+    t.tab[i] = (uint16_t)r;
+    const int lb0 = wide ? 8 : 7;
+    for (int l = 0; l < 8; l++) {
+      const uint32_t c = pow2.v[l < 7 ? lb0 + l : lb0 - 2];
+      t.mul_lo[l][i] = (uint16_t)crc_mulmod(c, i);
+      t.mul_hi[l][i] = (uint16_t)crc_mulmod(c, i << 8);
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256)
+crc_rows_kernel(PicView pic, CrcArgs a, const CrcTables *tables, uint32_t *acc_words) {
+  __shared__ CrcTables t;
+  {
+    const uint4 *src = reinterpret_cast<const uint4 *>(tables);
+    uint4 *dst = reinterpret_cast<uint4 *>(&t);
+    for (int i = threadIdx.x; i < (int)(sizeof(CrcTables) / 16); i += 256) dst[i] = src[i];
   }
   __syncthreads();
+  const uint16_t *tab = t.tab;
+  const uint16_t (*mul_lo)[256] = t.mul_lo, (*mul_hi)[256] = t.mul_hi;
   const int lane = threadIdx.x & 63;
   const int c = blockIdx.y, y = blockIdx.x * 4 + (threadIdx.x >> 6);
   const PlaneView p = pic.c[c];
-  if (y >= p.h) return;
-  const uint16_t *row = p.p + (ptrdiff_t)y * p.stride;
+  if ((int)(blockIdx.x * 4) >= p.h) return;   // whole workgroup beyond the plane
+  const bool live = y < p.h;
+  const uint16_t *row = p.p + (ptrdiff_t)(live ? y : 0) * p.stride;
   const int w = p.w;
-  const int lb = a.wide ? 8 : 7;  // log2 of the message bits per lane (16 samples)
-  const int n_win = (w + 1023) / 1024;
+  const int n_win = live ? (w + 1023) / 1024 : 0;
   uint32_t acc = 0;
   for (int k = 0; k < n_win; k++) {
     const int x0 = w - (n_win - k) * 1024 + lane * 16;
@@ -302,20 +330,30 @@ crc_rows_kernel(PicView pic, CrcArgs a, uint32_t *acc_words) {
 #pragma unroll
         for (int i = 0; i < 16; i++) v[i] = x0 + i >= 0 ? row[x0 + i] : 0;
       }
+      // four independent chains of four samples (the table walk is a chain of
+      // dependent LDS reads), joined with x^(bits of 4 samples)
+      uint32_t q[4] = {0, 0, 0, 0};
 #pragma unroll
-      for (int i = 0; i < 16; i++) {
-        r = tab[r >> 8] ^ ((r & 0xffu) << 8) ^ (v[i] & 0xffu);
-        if (a.wide) r = tab[r >> 8] ^ ((r & 0xffu) << 8) ^ (uint32_t)(v[i] >> 8);
+      for (int i = 0; i < 4; i++) {
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+          const uint32_t sv = v[4 * c + i];
+          q[c] = tab[q[c] >> 8] ^ ((q[c] & 0xffu) << 8) ^ (sv & 0xffu);
+          if (a.wide) q[c] = tab[q[c] >> 8] ^ ((q[c] & 0xffu) << 8) ^ (sv >> 8);
+        }
       }
+      r = q[0];
+#pragma unroll
+      for (int c = 1; c < 4; c++) r = (uint32_t)(mul_hi[7][r >> 8] ^ mul_lo[7][r & 0xff]) ^ q[c];
     }
     // butterfly: after level l lane t (t % 2^(l+1) == 0) holds the piece of
     // 2^(l+1) lanes; the right half is x^(lane bits << l) = pow2[lb + l] shorter
 #pragma unroll
     for (int l = 0; l < 6; l++) {
       const uint32_t right = __shfl_down(r, 1 << l, XVC_WAVE);
-      r = crc_mulmod(r, a.pow2.v[lb + l]) ^ right;
+      r = (uint32_t)(mul_hi[l][r >> 8] ^ mul_lo[l][r & 0xff]) ^ right;
     }
-    acc = crc_mulmod(acc, a.pow2.v[lb + 6]) ^ r;  // meaningful in lane 0
+    acc = (uint32_t)(mul_hi[6][acc >> 8] ^ mul_lo[6][acc & 0xff]) ^ r;  // lane 0's counts
   }
   acc = __shfl(acc, 0, XVC_WAVE);
   // message bits after this row (+ the 16 zero bits), and the preset term
@@ -329,19 +367,42 @@ crc_rows_kernel(PicView pic, CrcArgs a, uint32_t *acc_words) {
   uint32_t out = crc_mulmod(acc, crc_xpow_wave(after, a.pow2, lane));
   if (before == 0)  // first row of the message: preset * x^(N + 16)
     out ^= crc_mulmod(0xffffu, crc_xpow_wave(after + (unsigned long long)w * bps, a.pow2, lane));
-  if (lane == 0) atomicXor(&acc_words[a.mode ? c : 0], out);
+  // one word per workgroup and plane (no same-address atomics: a few thousand
+  // of those cost more than the whole computation); crc_finish_kernel XORs them
+  __shared__ uint32_t wg_part[4];
+  if (lane == 0) wg_part[threadIdx.x >> 6] = out;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t v = 0;
+    for (int q = 0; q < 4; q++)
+      if ((int)(blockIdx.x * 4 + q) < p.h) v ^= wg_part[q];
+    acc_words[c * gridDim.x + blockIdx.x] = v;
+  }
 }
 
-// grid 1; block 64: the result words -> hash bytes (high byte first); the words
-// are cleared for the next call.
-__global__ void crc_finish_kernel(int mode, uint32_t *acc_words, uint8_t *hash) {
-  const int t = threadIdx.x;
-  if (t < (mode ? 3 : 1)) {
-    const uint32_t r = acc_words[t];
-    hash[2 * t] = (uint8_t)(r >> 8);
-    hash[2 * t + 1] = (uint8_t)(r & 0xff);
+// grid 1; block 256: XOR of the per-workgroup words of each plane -> hash bytes
+// (high byte first).  n_wg = gridDim.x of crc_rows_kernel.
+__global__ void __launch_bounds__(256)
+crc_finish_kernel(PicView pic, int mode, int n_wg, const uint32_t *acc_words, uint8_t *hash) {
+  __shared__ uint32_t red[3][4];
+  for (int c = 0; c < 3; c++) {
+    const int live = (pic.c[c].h + 3) / 4;   // workgroups that wrote a word for plane c
+    uint32_t v = 0;
+    for (int i = threadIdx.x; i < live; i += 256) v ^= acc_words[c * n_wg + i];
+#pragma unroll
+    for (int s2 = 1; s2 < 64; s2 <<= 1) v ^= __shfl_xor(v, s2, XVC_WAVE);
+    if ((threadIdx.x & 63) == 0) red[c][threadIdx.x >> 6] = v;
   }
-  if (t < 3) acc_words[t] = 0;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t r[3];
+    for (int c = 0; c < 3; c++) r[c] = red[c][0] ^ red[c][1] ^ red[c][2] ^ red[c][3];
+    if (mode == 0) r[0] ^= r[1] ^ r[2];
+    for (int k = 0; k < (mode ? 3 : 1); k++) {
+      hash[2 * k] = (uint8_t)(r[k] >> 8);
+      hash[2 * k + 1] = (uint8_t)(r[k] & 0xff);
+    }
+  }
 }
 
 // ---- AQP variance statistic -------------------------------------------------

@@ -144,6 +144,7 @@ xvcgpu_status xvcgpu_create(int device, xvcgpu_ctx **out) {
   ctx->ssd_part_cap = 0;
   ctx->d_stats = nullptr;
   ctx->stats_rows_cap = 0;
+  ctx->d_crc_tables = nullptr;
   for (int i = 0; i < 64; i++) ctx->ev_pool[i] = nullptr;
   ctx->d_me_rot = nullptr;
   ctx->me_epoch = 0;
@@ -195,6 +196,7 @@ void xvcgpu_destroy(xvcgpu_ctx *ctx) {
   if (ctx->d_tz_pattern) hipFree(ctx->d_tz_pattern);
   if (ctx->d_ssd_part) hipFree(ctx->d_ssd_part);
   if (ctx->d_stats) hipFree(ctx->d_stats);
+  if (ctx->d_crc_tables) hipFree(ctx->d_crc_tables);
   if (ctx->d_me_rot) hipFree(ctx->d_me_rot);
   hipEventDestroy(ctx->ev0);
   hipEventDestroy(ctx->ev1);
@@ -1027,12 +1029,21 @@ xvcgpu_status xvcgpu_picture_crc(xvcgpu_ctx *ctx, const xvcgpu_picture *pic, int
   a.pow2 = pow2;
   a.wide = pic->bd > 8;
   a.mode = mode;
-  // three result words at the start of the (always re-zeroed) histogram scratch
-  uint32_t *words = ctx->d_stats;
-  hipLaunchKernelGGL(crc_rows_kernel, dim3((pic->h + 3) / 4, 3), dim3(256), 0, ctx->stream,
-                     pic->v, a, words);
-  hipLaunchKernelGGL(crc_finish_kernel, dim3(1), dim3(64), 0, ctx->stream, mode, words,
-                     d_hash);
+  if (!ctx->d_crc_tables) {
+    static CrcTables host[2];
+    crc_build_tables(host[0], pow2, 0);
+    crc_build_tables(host[1], pow2, 1);
+    hipError_t e = hipMalloc(&ctx->d_crc_tables, sizeof(host));
+    if (e != hipSuccess) return fail(ctx, XVCGPU_OUT_OF_MEMORY, "hipMalloc", e);
+    HIP_TRY(ctx, hipMemcpy(ctx->d_crc_tables, host, sizeof(host), hipMemcpyHostToDevice));
+  }
+  // one word per workgroup and plane in the row scratch (3 * ceil(h / 4) <= 2 * h)
+  uint32_t *words = ctx->d_stats + kStatsHistWords;
+  const int n_wg = (pic->h + 3) / 4;
+  hipLaunchKernelGGL(crc_rows_kernel, dim3(n_wg, 3), dim3(256), 0, ctx->stream, pic->v, a,
+                     ctx->d_crc_tables + a.wide, words);
+  hipLaunchKernelGGL(crc_finish_kernel, dim3(1), dim3(256), 0, ctx->stream, pic->v, mode,
+                     n_wg, words, d_hash);
   CHECK_LAUNCH(ctx, "picture_crc");
   return XVCGPU_OK;
 }

@@ -50,6 +50,7 @@ struct xvcgpu_ctx {
   // row remainders of the dithering export)
   uint32_t *d_stats;
   int stats_rows_cap;
+  struct CrcTables *d_crc_tables;  // [0]: 8-bit samples, [1]: wider; built on first use
 };
 
 struct xvcgpu_picture {
