@@ -168,8 +168,10 @@ __device__ __forceinline__ void wave_interp_block_lds(int bd, int w, int h, int 
   }
 }
 
-// grid: XCD-swizzled workgroups of 4 waves; job = (CU, component), component
-// fastest, so the three planes of a CU share a workgroup.
+// grid: XCD-swizzled workgroups of 4 waves; two waves per CU: one for the luma
+// block, one for the U and V blocks side by side (32 lanes each: a chroma
+// block of a CU up to 16x16 has at most 64 samples, which would leave three
+// quarters of a wave of its own idle through the whole pipeline).
 __global__ void __launch_bounds__(256)
 recon_from_me_kernel(PicView orig, PicView ref, PicView rec,
                      const xvcgpu_me_block *blocks, const xvcgpu_me_result *results,
@@ -179,13 +181,14 @@ recon_from_me_kernel(PicView orig, PicView ref, PicView rec,
                      TxTableLayout lay) {
   __shared__ ReconShared s_all[4];
   ReconShared &s = s_all[threadIdx.x >> 6];
-  const int n = n_cus * 3;
+  const int n = n_cus * 2;
   const int n_wg = (n + 3) / 4;
   const int wg = xcd_job_index(blockIdx.x, n_wg);
   if (wg < 0) return;
   const int job = wg * 4 + (int)(threadIdx.x >> 6);
   if (job >= n) return;
-  const int ci = job / 3, comp = job - ci * 3;
+  const int ci = job >> 1;
+  const bool chroma = (job & 1) != 0;
 #ifdef XVCGPU_TRACE
   const int bi = job;
 #endif
@@ -196,10 +199,53 @@ recon_from_me_kernel(PicView orig, PicView ref, PicView rec,
   // MotionCompensationMv: clip, split (GetFullpelRef, 4:2:0)
   int mx = mr.mv_x, my = mr.mv_y;
   d_clip_mv(mb.x, mb.y, ref.c[0].w, ref.c[0].h, mx, my);
-  const int cs = comp ? 1 : 0, shift = 4 + cs;
+  const int cs = chroma ? 1 : 0, shift = 4 + cs;
   const int fx = mx & ((1 << shift) - 1), fy = my & ((1 << shift) - 1);
-  const PlaneView prf = ref.c[comp];
   const int cx = mb.x >> cs, cy = mb.y >> cs, cw = mb.w >> cs, ch = mb.h >> cs;
+  xvcgpu_tx_block tb;
+  tb.x = (int16_t)cx;
+  tb.y = (int16_t)cy;
+  tb.w = (uint8_t)cw;
+  tb.h = (uint8_t)ch;
+  tb.tx_hor = XVC_TX_DEFAULT;
+  tb.tx_ver = XVC_TX_DEFAULT;
+  tb.dst4x4 = 0;
+  tb.intra_pic = (uint8_t)intra_pic;
+  if (chroma) {
+    // this lane's half: lanes 0-31 the U block, 32-63 the V block
+    const int g = ME2_LANE >> 5, comp = 1 + g;
+    const PlaneView po = g ? orig.c[2] : orig.c[1];
+    const PlaneView pc = g ? rec.c[2] : rec.c[1];
+    U16x4 orig_pre = {{0u, 0u}};
+    {
+      const int i = (ME2_LANE & 31) * 4;
+      if (i < cw * ch) {
+        const int lw = 31 - __clz(cw);
+        orig_pre = *reinterpret_cast<const U16x4 *>(
+            po.p + (ptrdiff_t)(cy + (i >> lw)) * po.stride + cx + (i & (cw - 1)));
+      }
+    }
+    // the two predictions one after the other by the whole wave (the window
+    // and the intermediate rows are reused), then both blocks together
+#pragma unroll
+    for (int c = 1; c <= 2; c++) {
+      const PlaneView prf = ref.c[c];
+      const uint16_t *r =
+          prf.p + (ptrdiff_t)(cy + (my >> shift)) * prf.stride + cx + (mx >> shift);
+      wave_interp_block_lds<true>(bd, cw, ch, fx, fy, r, prf.stride, s.win, s.tmp,
+                                  s.pred + (c - 1) * 64);
+      wave_sync();
+    }
+    ME2_TRACE(1);
+    tb.comp = (uint8_t)comp;
+    tb.qp = (int8_t)qp_c;
+    tx2_job<TX_MODE_FULL, 32>(s.tx, tb, 3 * ci + comp, bd, po, s.pred + g * 64, cw, pc,
+                              nullptr, nullptr, nnz_out, tx_tables, tx_tables_t, lay,
+                              &orig_pre, g * 128);
+    ME2_TRACE(8);
+    return;
+  }
+  const PlaneView prf = ref.c[0];
   const uint16_t *r = prf.p + (ptrdiff_t)(cy + (my >> shift)) * prf.stride + cx + (mx >> shift);
   // this lane's four original samples for the residual: fetched now, together
   // with the reference window, instead of after the interpolation
@@ -208,33 +254,21 @@ recon_from_me_kernel(PicView orig, PicView ref, PicView rec,
     const int i = ME2_LANE * 4;
     if (i < cw * ch) {
       const int lw = 31 - __clz(cw);
-      const PlaneView po = orig.c[comp];
+      const PlaneView po = orig.c[0];
       orig_pre = *reinterpret_cast<const U16x4 *>(
           po.p + (ptrdiff_t)(cy + (i >> lw)) * po.stride + cx + (i & (cw - 1)));
     }
   }
-  if (comp)
-    wave_interp_block_lds<true>(bd, cw, ch, fx, fy, r, prf.stride, s.win, s.tmp, s.pred);
-  else
-    wave_interp_block_lds<false>(bd, cw, ch, fx, fy, r, prf.stride, s.win, s.tmp, s.pred);
+  wave_interp_block_lds<false>(bd, cw, ch, fx, fy, r, prf.stride, s.win, s.tmp, s.pred);
   wave_sync();
   ME2_TRACE(1);
-  xvcgpu_tx_block tb;
-  tb.x = (int16_t)cx;
-  tb.y = (int16_t)cy;
-  tb.w = (uint8_t)cw;
-  tb.h = (uint8_t)ch;
-  tb.comp = (uint8_t)comp;
-  tb.tx_hor = XVC_TX_DEFAULT;
-  tb.tx_ver = XVC_TX_DEFAULT;
-  tb.dst4x4 = 0;
-  tb.qp = (int8_t)(comp ? qp_c : qp_y);
-  tb.intra_pic = (uint8_t)intra_pic;
-  const int nnz = tx2_job<TX_MODE_FULL>(s.tx, tb, job, bd, orig.c[comp], s.pred, cw,
-                                        rec.c[comp], nullptr, nullptr, nnz_out,
+  tb.comp = 0;
+  tb.qp = (int8_t)qp_y;
+  const int nnz = tx2_job<TX_MODE_FULL>(s.tx, tb, 3 * ci, bd, orig.c[0], s.pred, cw,
+                                        rec.c[0], nullptr, nullptr, nnz_out,
                                         tx_tables, tx_tables_t, lay, &orig_pre);
   ME2_TRACE(8);
-  if (comp == 0 && cus && ME2_LANE == 0) {
+  if (cus && ME2_LANE == 0) {
     xvcgpu_cu_info c;
     c.x = (uint16_t)mb.x;
     c.y = (uint16_t)mb.y;

@@ -58,11 +58,11 @@ __device__ __forceinline__ void tx2_load_row(const int16_t *p, uint32_t *d) {
 
 // out[a][b] = f((sum_j A[a][j]*B[b][j] + add) >> shift), a < na, b < nb;
 // rows of A / B / out are contiguous (strides NJ, NJ, nb).  OPL outputs/lane.
-template <int NJ, int OPL, bool CLIP>
+template <int NJ, int OPL, bool CLIP, int G = 64>
 __device__ __forceinline__ void tx2_stage(const int16_t *A, const int16_t *B,
                                           int na, int nb, int add, int shift,
                                           int16_t *out) {
-  const int lane = ME2_LANE;
+  const int lane = ME2_LANE & (G - 1);
   const int gb = nb / OPL;
   const int a = lane / gb, b0 = (lane - a * gb) * OPL;
   if (a >= na) return;
@@ -93,40 +93,55 @@ __device__ __forceinline__ void tx2_stage(const int16_t *A, const int16_t *B,
   }
 }
 
-template <bool CLIP>
+// G = lanes that work on one block: 64 (a wave per block) or 32 (two blocks of at
+// most 8x8 side by side in one wave, e.g. the U and V blocks of a CU).
+template <bool CLIP, int G = 64>
 __device__ __forceinline__ void tx2_stage_dispatch(int nj, const int16_t *A,
                                                    const int16_t *B, int na, int nb,
                                                    int add, int shift, int16_t *out) {
-  // outputs per lane so that na*nb/OPL <= 64 lanes
+  // outputs per lane so that na*nb/OPL <= G lanes
   const int total = na * nb;
   if (nj == 16) {
-    if (total > 128) tx2_stage<16, 4, CLIP>(A, B, na, nb, add, shift, out);
-    else if (total > 64) tx2_stage<16, 2, CLIP>(A, B, na, nb, add, shift, out);
-    else tx2_stage<16, 1, CLIP>(A, B, na, nb, add, shift, out);
+    if (total > 2 * G) tx2_stage<16, 4, CLIP, G>(A, B, na, nb, add, shift, out);
+    else if (total > G) tx2_stage<16, 2, CLIP, G>(A, B, na, nb, add, shift, out);
+    else tx2_stage<16, 1, CLIP, G>(A, B, na, nb, add, shift, out);
   } else if (nj == 8) {
-    if (total > 128) tx2_stage<8, 4, CLIP>(A, B, na, nb, add, shift, out);
-    else if (total > 64) tx2_stage<8, 2, CLIP>(A, B, na, nb, add, shift, out);
-    else tx2_stage<8, 1, CLIP>(A, B, na, nb, add, shift, out);
+    if (total > 2 * G) tx2_stage<8, 4, CLIP, G>(A, B, na, nb, add, shift, out);
+    else if (total > G) tx2_stage<8, 2, CLIP, G>(A, B, na, nb, add, shift, out);
+    else tx2_stage<8, 1, CLIP, G>(A, B, na, nb, add, shift, out);
   } else {
-    if (total > 128) tx2_stage<4, 4, CLIP>(A, B, na, nb, add, shift, out);
-    else if (total > 64) tx2_stage<4, 2, CLIP>(A, B, na, nb, add, shift, out);
-    else tx2_stage<4, 1, CLIP>(A, B, na, nb, add, shift, out);
+    if (total > 2 * G) tx2_stage<4, 4, CLIP, G>(A, B, na, nb, add, shift, out);
+    else if (total > G) tx2_stage<4, 2, CLIP, G>(A, B, na, nb, add, shift, out);
+    else tx2_stage<4, 1, CLIP, G>(A, B, na, nb, add, shift, out);
   }
+}
+
+// Sum over the G lanes that share a block, returned to all of them.
+template <int G>
+__device__ __forceinline__ int tx2_group_add(int v) {
+  if (G == 64) return wave_reduce_add_i32(v);
+  v = dpp_group_sum<16>(v);
+  return v + __shfl_xor(v, 16, 64);
 }
 
 // One TransformAndReconstruct job by one wave.  pred_p / pred_stride address
 // the predicted block (a picture plane in global memory, or an LDS buffer when
 // the caller has just motion-compensated it).
-template <int MODE>
-__device__ __forceinline__ int tx2_job(Tx2Shared &s, const xvcgpu_tx_block &b, int bi,
+// G = 32: the two halves of the wave run two blocks (each at most 64 samples,
+// same size) side by side; `b`, `bi`, `po`, `pred_p`, `pr`, `orig_pre` are then
+// per-lane values of the lane's own half and `soff` places the half's working
+// set inside the shared arrays.
+template <int MODE, int G = 64>
+__device__ __forceinline__ int tx2_job(Tx2Shared &sh, const xvcgpu_tx_block &b, int bi,
                                        int bd, const PlaneView &po, const uint16_t *pred_p,
                                        int pred_stride, const PlaneView &pr,
                                        int16_t *levels, const uint32_t *level_off,
                                        int32_t *nnz_out, const int16_t *tx_tables,
                                        const int16_t *tx_tables_t,
                                        const TxTableLayout &lay,
-                                       const U16x4 *orig_pre = nullptr) {
-  const int lane = ME2_LANE;
+                                       const U16x4 *orig_pre = nullptr, int soff = 0) {
+  struct { int16_t *r, *t, *c; } s = {sh.r + soff, sh.t + soff, sh.c + soff};
+  const int lane = ME2_LANE & (G - 1);
   const int w = b.w, h = b.h;
   const int lw = 31 - __clz(w);
   const int lgw = d_log2_size(w), lgh = d_log2_size(h);
@@ -144,7 +159,7 @@ __device__ __forceinline__ int tx2_job(Tx2Shared &s, const xvcgpu_tx_block &b, i
   int nnz;
   if (MODE != TX_MODE_INV) {
     // residual, 4 samples per lane along a row
-    for (int i = lane * 4; i < n_el; i += 256) {
+    for (int i = lane * 4; i < n_el; i += 4 * G) {
       const int y = i >> lw, x = i & (w - 1);
       // blocks are <= 256 samples: one iteration, so a caller may have
       // fetched this lane's four original samples ahead of time
@@ -165,15 +180,15 @@ __device__ __forceinline__ int tx2_job(Tx2Shared &s, const xvcgpu_tx_block &b, i
     ME2_TRACE(2);
     const int shift1 = lgw + bd - 9 + 2, shift2 = lgh + 6 + 2;
     // fwd 1: T[k][y] (w rows of h), fwd 2: C[x][k2] (w rows of h)
-    tx2_stage_dispatch<false>(w, Mh, s.r, w, h, 1 << (shift1 - 1), shift1, s.t);
+    tx2_stage_dispatch<false, G>(w, Mh, s.r, w, h, 1 << (shift1 - 1), shift1, s.t);
     wave_sync();
     ME2_TRACE(3);
-    tx2_stage_dispatch<false>(h, s.t, Mv, w, h, 1 << (shift2 - 1), shift2, s.c);
+    tx2_stage_dispatch<false, G>(h, s.t, Mv, w, h, 1 << (shift2 - 1), shift2, s.c);
     wave_sync();
     ME2_TRACE(4);
     if (MODE == TX_MODE_FWD) {
       if (lv)
-        for (int i = lane; i < n_el; i += 64) {
+        for (int i = lane; i < n_el; i += G) {
           const int x = i / h, k2 = i - x * h;  // C[x][k2]
           lv[k2 * w + x] = s.c[i];
         }
@@ -188,7 +203,7 @@ __device__ __forceinline__ int tx2_job(Tx2Shared &s, const xvcgpu_tx_block &b, i
     const int qscale = kFwdQuantScales[qpb % 6] * (bias ? 181 : 1);
     const long long qoff = (long long)((intra_pic ? 171ull : 85ull) << (qshift - 9));
     int local = 0;
-    for (int i = lane; i < n_el; i += 64) {
+    for (int i = lane; i < n_el; i += G) {
       const int v = s.c[i];
       const int sign = v < 0 ? -1 : 1;
       const long long abs_coeff = d_abs(v);
@@ -197,7 +212,7 @@ __device__ __forceinline__ int tx2_job(Tx2Shared &s, const xvcgpu_tx_block &b, i
       s.r[i] = (int16_t)d_clip3(level * sign, -32768, 32767);
       s.t[i] = (int16_t)(((abs_coeff * qscale) - ((long long)level << qshift)) >> (qshift - 8));
     }
-    nnz = wave_reduce_add_i32(local);
+    nnz = tx2_group_add<G>(local);
     // CoeffSignHideFast (rdo_quant.cc:448-573): lane = 4x4 sub-block (<= 16)
     if (sign_hide && nnz > 1 && w >= 4 && h >= 4) {
       wave_sync();
@@ -220,12 +235,12 @@ __device__ __forceinline__ int tx2_job(Tx2Shared &s, const xvcgpu_tx_block &b, i
       if (mine)
         dn = d_sign_hide_subblock(scan_order, 4 * sx, 4 * sy, my_scan == last_sb, s.r, s.t,
                                   s.c, idx);
-      nnz += wave_reduce_add_i32(dn);
+      nnz += tx2_group_add<G>(dn);
     }
     if (nnz_out && lane == 0) nnz_out[bi] = nnz;
     if (lv) {
       wave_sync();
-      for (int i = lane; i < n_el; i += 64) {
+      for (int i = lane; i < n_el; i += G) {
         const int x = i / h, k2 = i - x * h;
         lv[k2 * w + x] = s.r[i];
       }
@@ -233,7 +248,7 @@ __device__ __forceinline__ int tx2_job(Tx2Shared &s, const xvcgpu_tx_block &b, i
   } else {
     nnz = nnz_out[bi];
     if (nnz)
-      for (int i = lane; i < n_el; i += 64) {
+      for (int i = lane; i < n_el; i += G) {
         const int x = i / h, k2 = i - x * h;
         s.r[i] = lv[k2 * w + x];
       }
@@ -241,7 +256,7 @@ __device__ __forceinline__ int tx2_job(Tx2Shared &s, const xvcgpu_tx_block &b, i
   wave_sync();
 
   if (nnz == 0) {  // cbf == 0: rec = pred
-    for (int i = lane * 4; i < n_el; i += 256) {
+    for (int i = lane * 4; i < n_el; i += 4 * G) {
       const int y = i >> lw, x = i & (w - 1);
       const U16x4 p = *reinterpret_cast<const U16x4 *>(
           pred_p + (ptrdiff_t)y * pred_stride + x);
@@ -256,7 +271,7 @@ __device__ __forceinline__ int tx2_job(Tx2Shared &s, const xvcgpu_tx_block &b, i
   {
     const int shift = 6 - tshift + (bias ? 8 : 0);
     const int scale = (kInvQuantScales[qpb % 6] << (qpb / 6)) * (bias ? 181 : 1);
-    for (int i = lane; i < n_el; i += 64) {
+    for (int i = lane; i < n_el; i += G) {
       const int prod = (int)s.r[i] * scale;
       int cf;
       if (shift > 0) cf = (prod + (1 << (shift - 1))) >> shift;
@@ -272,7 +287,7 @@ __device__ __forceinline__ int tx2_job(Tx2Shared &s, const xvcgpu_tx_block &b, i
   if (dc_only && dct2_both) {  // InvDct2Dc, transform.cc:279-291
     const int sh = 14 - bd, add = 1 << (sh - 1);
     const int cf = (int16_t)(((((int)s.c[0] + 1) >> 1) + add) >> sh);
-    for (int i = lane * 4; i < n_el; i += 256) {
+    for (int i = lane * 4; i < n_el; i += 4 * G) {
       const int y = i >> lw, x = i & (w - 1);
       const U16x4 p = *reinterpret_cast<const U16x4 *>(
           pred_p + (ptrdiff_t)y * pred_stride + x);
@@ -288,14 +303,14 @@ __device__ __forceinline__ int tx2_job(Tx2Shared &s, const xvcgpu_tx_block &b, i
   // inverse: U[r][x] (h rows of w) into s.r, then residual rows into s.t
   {
     const int shift1 = 7 + 2, shift2 = 20 - bd + 2;
-    tx2_stage_dispatch<true>(h, MvT, s.c, h, w, 1 << (shift1 - 1), shift1, s.r);
+    tx2_stage_dispatch<true, G>(h, MvT, s.c, h, w, 1 << (shift1 - 1), shift1, s.r);
     wave_sync();
-    tx2_stage_dispatch<true>(w, s.r, MhT, h, w, 1 << (shift2 - 1), shift2, s.t);
+    tx2_stage_dispatch<true, G>(w, s.r, MhT, h, w, 1 << (shift2 - 1), shift2, s.t);
     wave_sync();
     ME2_TRACE(7);
   }
   // SampleBuffer::AddClip
-  for (int i = lane * 4; i < n_el; i += 256) {
+  for (int i = lane * 4; i < n_el; i += 4 * G) {
     const int y = i >> lw, x = i & (w - 1);
     const U16x4 p = *reinterpret_cast<const U16x4 *>(
         pred_p + (ptrdiff_t)y * pred_stride + x);

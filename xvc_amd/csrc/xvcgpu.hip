@@ -764,7 +764,7 @@ xvcgpu_status xvcgpu_recon_from_me(xvcgpu_ctx *ctx, const xvcgpu_picture *orig,
   if (orig->w != ref->w || orig->h != ref->h || rec->w != ref->w || rec->h != ref->h)
     return fail(ctx, XVCGPU_INVALID_ARGUMENT, "picture mismatch");
   if (n == 0) return XVCGPU_OK;
-  const int n_wg = (3 * n + 3) / 4;
+  const int n_wg = (2 * n + 3) / 4;
   hipLaunchKernelGGL(recon_from_me_kernel, dim3((n_wg + 7) / 8 * 8), dim3(256), 0,
                      ctx->stream, orig->v, ref->v, rec->v, d_blocks, d_results, n, qp_y,
                      qp_c, intra_pic, ref_poc, d_nnz, d_cus, ctx->d_tx_tables,
