@@ -1219,3 +1219,29 @@ def test_mc_lic_batch(gpu, xo, bd):
         for p in (R, C_, P):
             p.destroy()
     assert total == 240
+
+
+def test_timer_slots_and_stream_handle(gpu):
+    """xvcgpu_timer_mark / _between (several intervals in flight) and
+    xvcgpu_get_stream."""
+    api, ctx = gpu
+    P = ctx.picture(1920, 1080, 10)
+    for rep in range(2):        # the first round creates the events and warms up
+        for k in range(4):
+            ctx.timer_mark(2 * k)
+            for _ in range(4 * k + 1):
+                ctx.pad_border(P)
+            ctx.timer_mark(2 * k + 1)
+        ctx.sync()
+    ms = [ctx.timer_between(2 * k, 2 * k + 1) for k in range(4)]
+    assert all(m > 0 for m in ms) and ms[3] > ms[0]
+    assert ctx.timer_between(0, 7) >= sum(ms) * 0.9
+    lib = ctx.lib
+    f = C.c_float(0)
+    assert lib.xvcgpu_timer_mark(ctx.h, 64) == 10
+    assert lib.xvcgpu_timer_between(ctx.h, 0, 40, C.byref(f)) == 10   # slot never recorded
+    assert ctx.stream_ptr() != 0
+    ctx2 = api.Context(0)
+    assert ctx2.stream_ptr() not in (0, ctx.stream_ptr())
+    ctx2.close()
+    P.destroy()
