@@ -11,6 +11,9 @@ clip = synth.SyntheticClip(W, H, bd)
 F = 8
 for K in [int(v) for v in os.environ.get("CHAINS", "1,2,3").split(",")]:
     ctxs = [api.Context(0) for _ in range(K)]
+    if os.environ.get("PRIO") == "1" and K >= 2:   # stagger: first chain high, last low
+        ctxs[0].use_priority_stream(True)
+        ctxs[-1].use_priority_stream(False)
     chains = []
     for k, ctx in enumerate(ctxs):
         origs = []
