@@ -318,12 +318,51 @@ intra_pred_kernel(PicView rec, PicView pred, const xvcgpu_intra_block *jobs, int
 }
 
 template <int MS>
-struct IntraSatdShared {
+struct alignas(16) IntraSatdShared {
   IntraRefs refs;
-  uint16_t line[4][132];
+  uint16_t line[4][MS <= 16 ? 8 : 1][132];  // small blocks: up to 8 modes per wave
   uint16_t orig[MS * MS];
-  uint16_t pred[4][MS * MS];
+  uint16_t pred[4][MS <= 16 ? 512 : MS * MS];
 };
+
+// SATD of one 8x8 tile by the 8 lanes of a slot (lane = tile row): the
+// normalised tile value ((sum |H d H^T| + 2) >> 2, sample_metric.cc:403-641) in
+// all 8 lanes.  Sums of absolute values do not depend on the butterfly order.
+__device__ __forceinline__ int intra_satd8_slot(const uint16_t *po, const uint16_t *pp) {
+  const uint4 a = *reinterpret_cast<const uint4 *>(po), b = *reinterpret_cast<const uint4 *>(pp);
+  const uint32_t ua[4] = {a.x, a.y, a.z, a.w}, ub[4] = {b.x, b.y, b.z, b.w};
+  int m[8];
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    m[2 * k] = (int)(ua[k] & 0xffff) - (int)(ub[k] & 0xffff);
+    m[2 * k + 1] = (int)(ua[k] >> 16) - (int)(ub[k] >> 16);
+  }
+#pragma unroll
+  for (int len = 1; len < 8; len <<= 1)
+#pragma unroll
+    for (int i = 0; i < 8; i += len << 1)
+#pragma unroll
+      for (int j = i; j < i + len; j++) {
+        const int u = m[j], v = m[j + len];
+        m[j] = u + v;
+        m[j + len] = u - v;
+      }
+  const int row = threadIdx.x & 7;
+#pragma unroll
+  for (int st = 1; st < 8; st <<= 1) {
+    const bool upper = (row & st) != 0;
+#pragma unroll
+    for (int x = 0; x < 8; x++) {
+      const int o = __shfl_xor(m[x], st, XVC_WAVE);
+      m[x] = upper ? o - m[x] : m[x] + o;
+    }
+  }
+  int sum = 0;
+#pragma unroll
+  for (int x = 0; x < 8; x++) sum += d_abs(m[x]);
+  sum = group_sum<8>(sum);
+  return (sum + 2) >> 2;
+}
 
 // grid: (n jobs, S); block 256 = 4 waves.  Luma: the 67 modes are dealt to the
 // 4 * S waves that work on a job (S = 1 for big batches; up to 17 - one mode
@@ -349,8 +388,35 @@ intra_satd_kernel(PicView orig, PicView rec, const xvcgpu_intra_block *jobs, int
   intra_build_refs<true>(s.refs, b, pr.p + (ptrdiff_t)b.y * pr.stride + b.x, pr.stride, rec.bd,
                          true, threadIdx.x, 256);  // ends with a barrier: orig is complete too
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (MS <= 16 && w == h && (w == 8 || w == 16)) {
+    // K modes side by side in one wave (a 16x16 SATD keeps 32 lanes busy, an
+    // 8x8 one 8): K = 2 / 8 groups of 32 / 8 lanes, each predicting its own
+    // mode into its own tile; one 8x8 tile per 8-lane slot in the SATD
+    const int K = w == 16 ? 2 : 8, gl = 64 / K, g = lane / gl, sub = lane - g * gl;
+    const int slot = lane >> 3, row = lane & 7;
+    const int q = w == 16 ? slot & 3 : 0;                  // tile inside the block
+    const int tx = (q & 1) * 8, ty = (q >> 1) * 8 + row;
+    uint16_t *tile = s.pred[wave] + g * w * h;
+    for (int m0 = (blockIdx.y * 4 + wave) * K; m0 < XVC_INTRA_NUM_MODES;
+         m0 += 4 * gridDim.y * K) {
+      const int m = m0 + g;
+      if (m < XVC_INTRA_NUM_MODES)
+        intra_predict<false>(s.refs, s.line[wave][MS <= 16 ? g : 0], rec.bd, true, m, w, h, tile,
+                             w, sub, gl);
+      wave_sync();
+      int v = intra_satd8_slot(s.orig + ty * w + tx, tile + ty * w + tx);
+      if (w == 16) {
+        v += __shfl_xor(v, 8, XVC_WAVE);
+        v += __shfl_xor(v, 16, XVC_WAVE);
+      }
+      if (sub == 0 && m < XVC_INTRA_NUM_MODES)
+        dist[(size_t)blockIdx.x * XVC_INTRA_NUM_MODES + m] = (uint32_t)(v >> (rec.bd - 8));
+      wave_sync();
+    }
+    return;
+  }
   for (int m = blockIdx.y * 4 + wave; m < XVC_INTRA_NUM_MODES; m += 4 * gridDim.y) {
-    intra_predict<false>(s.refs, s.line[wave], rec.bd, true, m, w, h, s.pred[wave], w, lane, 64);
+    intra_predict<false>(s.refs, s.line[wave][0], rec.bd, true, m, w, h, s.pred[wave], w, lane, 64);
     const uint64_t d = wave_satd(rec.bd, w, h, 0, s.orig, w, s.pred[wave], w);
     if (lane == 0) dist[(size_t)blockIdx.x * XVC_INTRA_NUM_MODES + m] = (uint32_t)d;
   }
