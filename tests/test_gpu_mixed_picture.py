@@ -1,5 +1,5 @@
 """Decoder-side reconstruction of an inter picture with a mix of uni-pred,
-bi-pred, LIC and intra CUs (pipeline.MixedPictureDecoder: dependency waves over
+bi-pred, affine, LIC and intra CUs (pipeline.MixedPictureDecoder: dependency waves over
 the CU raster) against a CU-by-CU composition of the pinned oracle functions in
 coding order, including deblocking and border extension."""
 import ctypes as C
@@ -24,7 +24,8 @@ def gpu():
     ctx.close()
 
 
-def oracle_picture(xo, api, pipeline, bd, qp, pw, ph, cu, orig, r0, r1, kind, mv0, mv1, imode):
+def oracle_picture(xo, api, pipeline, bd, qp, pw, ph, cu, orig, r0, r1, kind, mv0, mv1, imode,
+                   mva):
     """orig: unpadded planes; r0 / r1: padded reference planes.  Raster order."""
     parts = pipeline.cu_partition(pw, ph, cu)
     qpc = pipeline.chroma_qp(qp)
@@ -52,6 +53,8 @@ def oracle_picture(xo, api, pipeline, bd, qp, pw, ph, cu, orig, r0, r1, kind, mv
             elif kind[i] == 1:
                 p = xo.mc_bipred_block(bd, c, x, y, w, h, mv0[i], mv1[i], pw, ph, r0[c], r1[c],
                                        borders[c])
+            elif kind[i] == 4:
+                p = xo.mc_affine_block(bd, c, x, y, w, h, mva[i], pw, ph, r0[c], borders[c])
             elif kind[i] == 2:
                 j = np.zeros(1, oracle_lic.LIC_DTYPE)[0]
                 j["x"], j["y"], j["w"], j["h"], j["comp"] = x, y, w, h, c
@@ -102,13 +105,14 @@ def test_mixed_picture_decode(gpu, pw, ph, bd, qp):
                  .astype(np.uint16) for p in base])
     parts = pipeline.cu_partition(pw, ph, cu)
     n = len(parts)
-    kind = rng.choice(4, n, p=[0.45, 0.15, 0.2, 0.2])
+    kind = rng.choice(5, n, p=[0.35, 0.15, 0.2, 0.2, 0.1])
     mv0 = rng.integers(-70, 71, (n, 2))
+    mva = mv0[:, None, :] + rng.integers(-12, 13, (n, 3, 2))   # corner vectors
     mv1 = rng.integers(-70, 71, (n, 2))
     imode = rng.integers(0, 67, n)
     e_rec, levels, nnz = oracle_picture(xo, api, pipeline, bd, qp, pw, ph, cu, orig, r0, r1,
-                                        kind, mv0, mv1, imode)
-    assert np.count_nonzero(nnz) > n // 4 and len(set(kind.tolist())) == 4
+                                        kind, mv0, mv1, imode, mva)
+    assert np.count_nonzero(nnz) > n // 4 and len(set(kind.tolist())) == 5
     # in-loop filter + border on the oracle side
     cus = np.zeros(n, api.CU_DTYPE)
     cmap = -np.ones(((ph + 3) // 4, (pw + 3) // 4), np.int32)
@@ -120,7 +124,10 @@ def test_mixed_picture_decode(gpu, pw, ph, bd, qp):
         c["cbf_luma"] = int(nnz[3 * i] != 0)
         c["ref_poc"][0] = -1 if kind[i] == 3 else 0
         c["ref_poc"][1] = 16 if kind[i] == 1 else -1
-        if kind[i] != 3:
+        if kind[i] == 4:    # corner vectors: top-left, top-right, bottom-left, bottom-right
+            tl, tr, bl = mva[i]
+            c["mv"][0][:] = [tl, tr, bl, tr + bl - tl]
+        elif kind[i] != 3:
             c["mv"][0][:] = mv0[i]
         if kind[i] == 1:
             c["mv"][1][:] = mv1[i]
@@ -132,7 +139,8 @@ def test_mixed_picture_decode(gpu, pw, ph, bd, qp):
     R0, R1, D = ctx.picture(pw, ph, bd), ctx.picture(pw, ph, bd), ctx.picture(pw, ph, bd)
     R0.upload(r0, BL)
     R1.upload(r1, BL)
-    dec = pipeline.MixedPictureDecoder(ctx, pw, ph, bd, qp, kind, mv0, mv1, imode, cu)
+    dec = pipeline.MixedPictureDecoder(ctx, pw, ph, bd, qp, kind, mv0, mv1, imode, cu,
+                                       mv_affine=mva)
     assert max(g[0] for g in dec.groups) >= 3          # real dependency chains
     dec.load(levels, nnz)
     dec.decode(R0, R1, D)

@@ -554,12 +554,14 @@ class MixedPictureDecoder:
     Per wave: xvcgpu_mc_lic_batch + xvcgpu_inv_transform_batch for the LIC CUs,
     one fused xvcgpu_intra_recon_batch for the intra CUs.
 
-    syntax (numpy, CUs in raster order): kind[n] (0 uni L0, 1 bi, 2 LIC, 3 intra),
-    mv0[n,2], mv1[n,2] (1/16 pel), intra_mode[n], levels / nnz per (CU, comp)."""
+    syntax (numpy, CUs in raster order): kind[n] (0 uni L0, 1 bi, 2 LIC, 3 intra,
+    4 affine L0), mv0[n,2], mv1[n,2] (1/16 pel), intra_mode[n], mv_affine[n,3,2]
+    (corner vectors of the affine CUs), levels / nnz per (CU, comp)."""
 
-    UNI, BI, LIC, INTRA = 0, 1, 2, 3
+    UNI, BI, LIC, INTRA, AFFINE = 0, 1, 2, 3, 4
 
-    def __init__(self, ctx, width, height, bitdepth, qp, kind, mv0, mv1, intra_mode, cu=16):
+    def __init__(self, ctx, width, height, bitdepth, qp, kind, mv0, mv1, intra_mode, cu=16,
+                 mv_affine=None):
         assert cu <= 16
         self.ctx, self.bd, self.w, self.h = ctx, bitdepth, width, height
         parts = cu_partition(width, height, cu)
@@ -568,7 +570,7 @@ class MixedPictureDecoder:
         qpc = chroma_qp(qp)
         wave = np.zeros(n, np.int64)
         for i, (x, y, w, h) in enumerate(parts):
-            if kind[i] in (self.UNI, self.BI):
+            if kind[i] in (self.UNI, self.BI, self.AFFINE):
                 continue
             deps = []
             if x:
@@ -588,7 +590,7 @@ class MixedPictureDecoder:
         self.wave = wave[order]
         tx = np.zeros(3 * n, api.TX_DTYPE)
         jobs3 = np.zeros(3 * n, api.INTRA_DTYPE)
-        uni, bi, lic = [], [], []
+        uni, bi, lic, aff = [], [], [], []
         for k, i in enumerate(order):
             x, y, w, h = parts[i]
             for c in range(3):
@@ -599,6 +601,8 @@ class MixedPictureDecoder:
                 uni += [(x, y, w, h, c, 0, *mv0[i]) for c in range(3)]
             elif kind[i] == self.BI:
                 bi += [(x, y, w, h, c, 0, *mv0[i], *mv1[i]) for c in range(3)]
+            elif kind[i] == self.AFFINE:
+                aff += [(x, y, w, h, c, 0, np.asarray(mv_affine[i], np.int32)) for c in range(3)]
             elif kind[i] == self.LIC:
                 nb = (1 if y else 0) | (2 if x else 0)
                 lic += [(x, y, w, h, c, nb, *mv0[i], x, max(0, y - cu), max(0, x - cu), y)
@@ -618,7 +622,8 @@ class MixedPictureDecoder:
         self.d_uni = ctx.buffer(np.array(uni, api.MC_DTYPE)) if uni else None
         self.d_bi = ctx.buffer(np.array(bi, api.MCBI_DTYPE)) if bi else None
         self.d_lic = ctx.buffer(np.array(lic, api.LIC_DTYPE)) if lic else None
-        self.n_uni, self.n_bi = len(uni), len(bi)
+        self.d_aff = ctx.buffer(np.array(aff, api.MCAFF_DTYPE)) if aff else None
+        self.n_uni, self.n_bi, self.n_aff = len(uni), len(bi), len(aff)
         self.d_levels = ctx.alloc(2 * max(1, self.level_total))
         self.d_nnz = ctx.alloc(4 * 3 * n)
         self.pred = ctx.picture(width, height, bitdepth)
@@ -631,7 +636,8 @@ class MixedPictureDecoder:
                 e += 1
             self.groups.append((int(self.wave[k]), int(self.kind[k]), k, e))
             k = e
-        self.n_inter = sum(e - a for wv, kd, a, e in self.groups if kd in (self.UNI, self.BI))
+        self.n_inter = sum(e - a for wv, kd, a, e in self.groups
+                           if kd in (self.UNI, self.BI, self.AFFINE))
 
     def load(self, levels_per_tx, nnz_per_tx):
         """levels_per_tx[3 * i + c]: w*h int16 of CU i (raster order), comp c."""
@@ -660,6 +666,9 @@ class MixedPictureDecoder:
         if self.n_bi:
             ctx._check(lib.xvcgpu_mc_bipred_batch(ctx.h, ref0.h_pic, ref1.h_pic,
                                                   self.pred.h_pic, self.d_bi.ptr, self.n_bi))
+        if self.n_aff:
+            ctx._check(lib.xvcgpu_mc_affine_batch(ctx.h, ref0.h_pic, self.pred.h_pic,
+                                                  self.d_aff.ptr, self.n_aff))
         if self.n_inter:
             self._inverse(rec, 0, self.n_inter)     # all plain inter CUs come first
         lic_done = 0
@@ -678,7 +687,7 @@ class MixedPictureDecoder:
 
     def destroy(self):
         for b in (self.d_tx, self.d_off, self.d_jobs3, self.d_uni, self.d_bi, self.d_lic,
-                  self.d_levels, self.d_nnz):
+                  self.d_aff, self.d_levels, self.d_nnz):
             if b is not None:
                 b.free()
         self.pred.destroy()
