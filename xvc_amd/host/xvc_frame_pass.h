@@ -67,18 +67,35 @@ class FramePass {
   }
 
   // Enqueues one picture (asynchronous): rec becomes the padded reconstruction.
+  // The whole sequence - search, CompressAndEvalCbf, deblocking, PadBorder,
+  // PSNR parts - goes through one C call (xvcgpu_frame_pass).
   void Run(const Picture &orig, const Picture &ref, Picture *rec, int ref_poc = 0) {
-    xvcgpu_ctx *c = ctx_.get();
-    ctx_.Check(xvcgpu_me_search_sized(c, orig.get(), ref.get(),
-                                      XVCGPU_ME_FULLPEL | XVCGPU_ME_SUBPEL, d_me_->data(),
-                                      n_cus_, d_res_->data(), max_cu_));
-    ctx_.Check(xvcgpu_recon_from_me(c, orig.get(), ref.get(), rec->get(), d_me_->data(),
-                                    d_res_->data(), n_cus_, qp_, qp_c_, 0, ref_poc,
-                                    d_nnz_->data(), d_cus_->data()));
-    ctx_.Check(xvcgpu_deblock(c, rec->get(), d_cus_->data(), n_cus_, d_map_->data(),
-                              map_stride_, 0, 0, 0, 4));
-    ctx_.Check(xvcgpu_pad_border(c, rec->get()));
-    ctx_.Check(xvcgpu_picture_ssd(c, orig.get(), rec->get(), 0, bd_, d_ssd_->data()));
+    xvcgpu_frame_pass_args a = xvcgpu_frame_pass_args();
+    a.orig = orig.get();
+    a.ref = ref.get();
+    a.rec = rec->get();
+    a.d_me = d_me_->data();
+    a.d_results = d_res_->data();
+    a.n_cus = n_cus_;
+    a.max_block_size = max_cu_;
+    a.qp_y = qp_;
+    a.qp_c = qp_c_;
+    a.ref_poc = ref_poc;
+    a.d_nnz = d_nnz_->data();
+    a.d_cus_own = d_cus_->data();
+    a.d_cus = d_cus_->data();
+    a.n_cus_total = n_cus_;
+    a.d_cu_map = d_map_->data();
+    a.map_stride = map_stride_;
+    a.db_y_begin = 0;
+    a.db_y_end = a.dbh_y_end = h_;
+    a.ssd_y_begin = 0;
+    a.ssd_y_end = 1 << 30;
+    a.shift_bitdepth = bd_;
+    a.d_ssd = d_ssd_->data();
+    ctx_.Check(xvcgpu_frame_pass(ctx_.get(), &a,
+                                 XVC_FP_ENCODE | XVC_FP_DEBLOCK_V | XVC_FP_DEBLOCK_H |
+                                     XVC_FP_PAD | XVC_FP_SSD));
   }
 
   // SampleMetric::ComputePsnr parts of the last Run (synchronises).
