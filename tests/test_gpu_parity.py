@@ -762,6 +762,40 @@ def test_frame_pass(gpu, xo, size, fused):
         p.destroy()
 
 
+@pytest.mark.parametrize("bd,qp,size", [(8, 22, (352, 288)), (8, 37, (200, 120)),
+                                        (12, 32, (352, 288)), (12, 17, (136, 72))])
+def test_frame_pass_bitdepths(gpu, xo, bd, qp, size):
+    """The frame pass at internal bit depths 8 and 12 (the packed sub-pel
+    sweep takes bd <= 10; 12 runs the row-major path) and other QPs."""
+    api, ctx = gpu
+    from xvc_amd import pipeline, synth
+    import oracle_frame
+    pw, ph = size
+    clip = synth.SyntheticClip(pw, ph, bd)
+    fp = pipeline.FramePass(ctx, pw, ph, bd, qp=qp)
+    ref_host = pad_planes(clip.frame(0), bd)
+    O, R, Rec = ctx.picture(pw, ph, bd), ctx.picture(pw, ph, bd), ctx.picture(pw, ph, bd)
+    R.upload(ref_host, BL)
+    for n in (1, 2, 3):
+        orig_host = pad_planes(clip.frame(n), bd)
+        O.upload(orig_host, BL)
+        fp.run(O, R, Rec, ref_poc=n - 1)
+        res, nnz, cus, ssd = fp.results()
+        e_rec, e_res, e_nnz, e_cus, e_ssd = oracle_frame.frame_pass(
+            fp.desc, bd, orig_host, ref_host, BL, ref_poc=n - 1, lib=xo, threads=4)
+        assert np.array_equal(res, e_res) and np.array_equal(nnz, e_nnz), n
+        assert np.array_equal(cus, e_cus), n
+        got = Rec.download(BL)
+        for c in range(3):
+            assert np.array_equal(got[c], e_rec[c]), (n, c)
+        assert (int(ssd[0]), int(ssd[1])) == e_ssd
+        ref_host = e_rec
+        R, Rec = Rec, R
+    fp.destroy()
+    for p in (O, R, Rec):
+        p.destroy()
+
+
 @pytest.mark.parametrize("size", [(352, 288), (1920, 1080)])
 def test_decode_pass_equals_encoder_reconstruction(gpu, xo, size):
     """N1: the decoder-side reconstruction (MVs + levels -> MC, dequant,
