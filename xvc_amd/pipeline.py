@@ -562,8 +562,8 @@ class MixedPictureDecoder:
 
     def __init__(self, ctx, width, height, bitdepth, qp, kind, mv0, mv1, intra_mode, cu=16,
                  mv_affine=None):
-        assert cu <= 16
         self.ctx, self.bd, self.w, self.h = ctx, bitdepth, width, height
+        self.fused_intra = cu <= 16     # else prediction picture + inverse path
         parts = cu_partition(width, height, cu)
         n = len(parts)
         per_row = (width + cu - 1) // cu
@@ -678,6 +678,10 @@ class MixedPictureDecoder:
                                                    self.d_lic.ptr + 3 * lic_done * L,
                                                    3 * (e - a)))
                 lic_done += e - a
+                self._inverse(rec, a, e)
+            elif kd == self.INTRA and not self.fused_intra:
+                ctx._check(lib.xvcgpu_intra_pred_batch(ctx.h, rec.h_pic, self.pred.h_pic,
+                                                       self.d_jobs3.ptr + 3 * a * J, 3 * (e - a)))
                 self._inverse(rec, a, e)
             elif kd == self.INTRA:
                 ctx._check(lib.xvcgpu_intra_recon_batch(
