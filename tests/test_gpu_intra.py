@@ -176,7 +176,8 @@ def test_intra_error_paths(gpu):
 
 @pytest.mark.parametrize("w,h,bd,qp,cu,fused", [
     (352, 288, 10, 32, 16, True), (352, 288, 10, 32, 16, False), (136, 72, 8, 27, 8, True),
-    (136, 72, 12, 27, 8, False), (256, 192, 10, 37, 32, False), (1920, 1080, 10, 32, 16, True)])
+    (136, 72, 12, 27, 8, False), (256, 192, 10, 37, 32, False), (512, 320, 10, 32, 64, False),
+    (1920, 1080, 10, 32, 16, True)])
 def test_intra_picture_pass(gpu, xo, w, h, bd, qp, cu, fused):
     """An all-intra picture on the device, wave by wave (anti-diagonals of the
     CU raster), against the CU-by-CU oracle composition: chosen modes, levels,

@@ -360,7 +360,7 @@ class IntraPictureDescriptors:
     kernel.  Jobs and transform blocks are stored wave by wave."""
 
     def __init__(self, width, height, qp=32, cu=16):
-        assert cu in (8, 16, 32)
+        assert cu in (8, 16, 32, 64)
         self.w, self.h, self.qp, self.cu = width, height, qp, cu
         self.qp_c = chroma_qp(qp)
         parts = cu_partition(width, height, cu)
