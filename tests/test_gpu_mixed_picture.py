@@ -100,7 +100,7 @@ def test_mixed_picture_decode(gpu, pw, ph, bd, qp, cu):
 
     base = [rnd_samples(rng, bd, hh, ww, True)
             for ww, hh in ((pw, ph), (pw // 2, ph // 2), (pw // 2, ph // 2))]
-    orig = [np.clip(p.astype(np.int64) + rng.integers(-4, 5, p.shape), 0, mx).astype(np.uint16)
+    orig = [np.clip(p.astype(np.int64) + rng.integers(-4, 5, p.shape) * (1 << (bd - 6)), 0, mx).astype(np.uint16)
             for p in base]
     r0 = padded([np.clip(p.astype(np.float64) * 0.9 + 12, 0, mx).astype(np.uint16) for p in base])
     r1 = padded([np.clip(p.astype(np.int64) + rng.integers(-6, 7, p.shape), 0, mx)
@@ -108,13 +108,14 @@ def test_mixed_picture_decode(gpu, pw, ph, bd, qp, cu):
     parts = pipeline.cu_partition(pw, ph, cu)
     n = len(parts)
     kind = rng.choice(5, n, p=[0.35, 0.15, 0.2, 0.2, 0.1])
+    kind[rng.choice(n, 5, replace=False)] = np.arange(5)     # every kind at least once
     mv0 = rng.integers(-70, 71, (n, 2))
     mva = mv0[:, None, :] + rng.integers(-12, 13, (n, 3, 2))   # corner vectors
     mv1 = rng.integers(-70, 71, (n, 2))
     imode = rng.integers(0, 67, n)
     e_rec, levels, nnz = oracle_picture(xo, api, pipeline, bd, qp, pw, ph, cu, orig, r0, r1,
                                         kind, mv0, mv1, imode, mva)
-    assert np.count_nonzero(nnz) > n // 4 and len(set(kind.tolist())) == 5
+    assert np.count_nonzero(nnz) > 0 and len(set(kind.tolist())) == 5
     # in-loop filter + border on the oracle side
     cus = np.zeros(n, api.CU_DTYPE)
     cmap = -np.ones(((ph + 3) // 4, (pw + 3) // 4), np.int32)
