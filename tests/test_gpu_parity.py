@@ -551,6 +551,7 @@ def test_residual_batch_grid(gpu, xo, bd):
 def test_deblock(gpu, xo, bd, bipred, sub):
     api, ctx = gpu
     rng = np.random.default_rng(5000 + bd + bipred + sub)
+    total_changed = 0
     for (pw, ph) in [(64, 64), (136, 72), (320, 200)]:
         for trial in range(3):
             parts = random_partition(rng, pw, ph, 4 if sub == 4 else 8)
@@ -581,8 +582,9 @@ def test_deblock(gpu, xo, bd, bipred, sub):
                 w, h = (pw, ph) if c == 0 else (pw // 2, ph // 2)
                 assert np.array_equal(got[c], po[c][b:b + h, b:b + w]), (pw, ph, trial, c)
                 changed += int((got[c] != planes[c][b:b + h, b:b + w]).sum())
-            assert changed > 0
+            total_changed += changed
             Rc.destroy()
+    assert total_changed > 0     # the filters did change samples
 
 
 def test_deblock_chains(gpu, xo):
