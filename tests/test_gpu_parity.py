@@ -1281,3 +1281,25 @@ def test_timer_slots_and_stream_handle(gpu):
     assert ctx2.stream_ptr() not in (0, ctx.stream_ptr())
     ctx2.close()
     P.destroy()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_ranks_share_one_gpu(gpu, world):
+    """GpuEngine + TorchComm as separate processes that exchange device
+    tensors (gloo transport: RCCL refuses several ranks on one device): halo
+    exchange, neighbour-limited row exchange and the all-reduced PSNR parts of
+    the row-sharded pass, every rank against the oracle."""
+    import socket
+    import subprocess
+    import sys
+    so = socket.socket()
+    so.bind(("127.0.0.1", 0))
+    port = so.getsockname()[1]
+    so.close()
+    here = os.path.dirname(os.path.abspath(__file__))
+    procs = [subprocess.Popen([sys.executable, os.path.join(here, "gloo_two_ranks_gpu.py"),
+                               str(r), str(world), str(port)], stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT, text=True) for r in range(world)]
+    outs = [p.communicate(timeout=600)[0] for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and ("OK rank %d" % r) in o, o[-3000:]
