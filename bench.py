@@ -169,11 +169,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # testing aids: all ranks on one GPU (XVC_BENCH_DEVICE=0) need a transport that
+    # accepts that (XVC_BENCH_BACKEND=gloo; RCCL refuses duplicate devices)
+    backend = os.environ.get("XVC_BENCH_BACKEND", "nccl")
+    if "XVC_BENCH_DEVICE" in os.environ:
+        local_rank = int(os.environ["XVC_BENCH_DEVICE"])
     multi = world > 1 or args.force_sharded     # row-sharded engine + process groups
     if multi:
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     if args.gpus != world and world > 1:
         raise SystemExit("--gpus must equal WORLD_SIZE")
     if not torch.cuda.is_available():

@@ -1303,3 +1303,32 @@ def test_sharded_ranks_share_one_gpu(gpu, world):
     outs = [p.communicate(timeout=600)[0] for p in procs]
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0 and ("OK rank %d" % r) in o, o[-3000:]
+
+
+def test_bench_multi_rank_path_runs(gpu):
+    """bench.py's N > 1 branch end to end (row shards, three picture chains
+    with their own process groups and streams, exchanges, all-reduced PSNR,
+    max-over-ranks timing) as two ranks on this one GPU over gloo - the
+    functional check of what the driver launches on a multi-GPU node."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    so = socket.socket()
+    so.bind(("127.0.0.1", 0))
+    port = so.getsockname()[1]
+    so.close()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, XVC_BENCH_DEVICE="0", XVC_BENCH_BACKEND="gloo")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+                        "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(root, "bench.py"),
+                        "--gpus", "2", "--steps", "24", "--warmup", "6", "--no-cpu",
+                        "--width", "352", "--height", "288"],
+                       capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["steps"] == 24 and d["scaling"] == "strong"
+    assert d["pictures_in_flight"] == 3 and 25.0 < d["psnr_y"] < 60.0
+    assert "cu-row-shard2" in d["config"]["parallelism"]
