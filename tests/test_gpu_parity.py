@@ -1101,7 +1101,7 @@ def test_frame_pass_8k_10bit_qp37(gpu, xo):
 
 # (208x112, 2/3 shards) small; (3840x2160 QP32, 8 shards) = BASELINE config 4:
 # there a shard keeps only the rows its next search can reach (no all-gather)
-@pytest.mark.parametrize("world", [2, 3, 8])
+@pytest.mark.parametrize("world", [2, 3, 8, 108])
 def test_sharded_gpu_engine_loopback(gpu, xo, world):
     """The multi-GPU orchestration with the real HIP engine: `world` shards of
     one picture handled by separate GpuEngine instances on this one GPU, data
@@ -1113,6 +1113,8 @@ def test_sharded_gpu_engine_loopback(gpu, xo, world):
     from xvc_amd import pipeline, sharded, synth
     api, ctx = gpu
     pw, ph, bd, qp = (3840, 2160, 10, 32) if world == 8 else (208, 112, 10, 32)
+    if world == 108:        # 8 shards of 1080p: the driver's 8-GPU run
+        world, pw, ph = 8, 1920, 1080
     dev = torch.device("cuda", 0)
     clip = synth.SyntheticClip(pw, ph, bd)
     desc = pipeline.FrameDescriptors(pw, ph, qp)
@@ -1128,7 +1130,7 @@ def test_sharded_gpu_engine_loopback(gpu, xo, world):
         assert ranks[0].valid_rows() != (0, ph)
         sends, recvs = ranks[0].gather_ops(0)
         assert {p for p, _ in sends} | {p for p, _ in recvs} == {1}
-    for n in (1, 2):
+    for n in ((1, 2, 3) if ph == 1080 else (1, 2)):
         orig_host = pad_planes(clip.frame(n), bd)
         O.upload(orig_host, BL)
         ref_idx, rec_idx = (n - 1) % 2, n % 2
@@ -1283,8 +1285,10 @@ def test_timer_slots_and_stream_handle(gpu):
     P.destroy()
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_sharded_ranks_share_one_gpu(gpu, world):
+# (8 ranks at 1080p = the shard plan of the driver's 8-GPU run: 128 / 144-row shards,
+# rows exchanged with up to two neighbours on each side)
+@pytest.mark.parametrize("world,size", [(2, (352, 288)), (3, (352, 288)), (8, (1920, 1080))])
+def test_sharded_ranks_share_one_gpu(gpu, world, size):
     """GpuEngine + TorchComm as separate processes that exchange device
     tensors (gloo transport: RCCL refuses several ranks on one device): halo
     exchange, neighbour-limited row exchange and the all-reduced PSNR parts of
@@ -1298,7 +1302,8 @@ def test_sharded_ranks_share_one_gpu(gpu, world):
     so.close()
     here = os.path.dirname(os.path.abspath(__file__))
     procs = [subprocess.Popen([sys.executable, os.path.join(here, "gloo_two_ranks_gpu.py"),
-                               str(r), str(world), str(port)], stdout=subprocess.PIPE,
+                               str(r), str(world), str(port), str(size[0]), str(size[1])],
+                              stdout=subprocess.PIPE,
                               stderr=subprocess.STDOUT, text=True) for r in range(world)]
     outs = [p.communicate(timeout=600)[0] for p in procs]
     for r, (p, o) in enumerate(zip(procs, outs)):

@@ -69,6 +69,11 @@ class TorchComm:
         # group: a process group of all ranks dedicated to one picture chain, so
         # that the exchanges of concurrent chains do not queue behind each other
         self.dist, self.rank, self.world, self.group = dist, rank, world, group
+        # RCCL orders its operations on the issuing stream.  A host transport
+        # (gloo, used by tests that put several ranks on one GPU) touches the
+        # device buffers from the CPU as soon as it is called: the stream has to
+        # be drained first.
+        self.host_transport = dist.get_backend(group) != "nccl"
 
     def exchange(self, sends, recvs):
         """sends / recvs: lists of (peer, 1-D tensor); per peer the order of
@@ -79,10 +84,17 @@ class TorchComm:
               [d.P2POp(d.irecv, t, p, group=g) for p, t in recvs]
         if not ops:
             return
+        self._drain(ops[0].tensor)
         for req in d.batch_isend_irecv(ops):
             req.wait()
 
+    def _drain(self, t):
+        if self.host_transport and t.is_cuda:
+            import torch
+            torch.cuda.current_stream(t.device).synchronize()
+
     def allreduce_sum(self, t):
+        self._drain(t)
         self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
         return t
 
