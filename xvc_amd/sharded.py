@@ -74,14 +74,23 @@ class TorchComm:
         # device buffers from the CPU as soon as it is called: the stream has to
         # be drained first.
         self.host_transport = dist.get_backend(group) != "nccl"
+        self._p2p = {}
 
     def exchange(self, sends, recvs):
         """sends / recvs: lists of (peer, 1-D tensor); per peer the order of
         sends on one side matches the order of recvs on the other."""
         d = self.dist
         g = self.group
-        ops = [d.P2POp(d.isend, t, p, group=g) for p, t in sends] + \
-              [d.P2POp(d.irecv, t, p, group=g) for p, t in recvs]
+        # the callers hand in the same (cached) lists for every picture: build
+        # the operation objects once per list pair
+        key = (id(sends), id(recvs))
+        hit = self._p2p.get(key)
+        if hit is None or hit[0] is not sends or hit[1] is not recvs:
+            ops = [d.P2POp(d.isend, t, p, group=g) for p, t in sends] + \
+                  [d.P2POp(d.irecv, t, p, group=g) for p, t in recvs]
+            self._p2p[key] = (sends, recvs, ops)
+        else:
+            ops = hit[2]
         if not ops:
             return
         self._drain(ops[0].tensor)
