@@ -498,6 +498,16 @@ xvcgpu_status xvcgpu_intra_recon_batch(xvcgpu_ctx *ctx, const xvcgpu_picture *or
                                        int16_t *d_levels, const uint32_t *d_level_offsets,
                                        int32_t *d_nnz);
 
+/* ---- multi-GPU staging --------------------------------------------------- *
+ * n device-to-device copies (descriptors in device memory) in one launch: packs
+ * the row slabs / CU metadata rows a rank exchanges with its neighbours into
+ * one contiguous buffer per exchange and unpacks what arrived, so that an
+ * exchange is a single collective instead of a dozen point-to-point
+ * operations (each of which costs ~10 us of host time through
+ * torch.distributed).  Segments must not overlap each other. */
+xvcgpu_status xvcgpu_copy_segments(xvcgpu_ctx *ctx, const xvcgpu_copy_segment *d_segments,
+                                   int n);
+
 /* ---- a picture per call ------------------------------------------------- *
  * The per-picture sequence of the entry points above behind one call (host
  * cost of one call instead of six; nothing new is computed): the phases set in

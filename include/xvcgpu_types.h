@@ -240,4 +240,12 @@ typedef struct xvcgpu_frame_pass_args {
   uint64_t *d_ssd;
 } xvcgpu_frame_pass_args;
 
+/* One device-to-device copy of xvcgpu_copy_segments (row slabs of a picture
+ * to / from the staging buffer of a multi-GPU exchange). */
+typedef struct xvcgpu_copy_segment {
+  const void *src;
+  void *dst;
+  uint64_t bytes;
+} xvcgpu_copy_segment;
+
 #endif /* XVCGPU_TYPES_H_ */

@@ -62,6 +62,38 @@ def main():
         assert all(np.array_equal(got2[c], rec[c]) for c in range(3)), n
         assert ssd2 == ssd
         ref = rec
+    # the exchange itself, rank 0 to rank 0 (RCCL copies): row slabs of picture 0
+    # into other rows of picture 1 and a CU metadata row, once packed (one
+    # all_to_all_single with staging copies), once as point-to-point operations.
+    # Catches tensor types the backend rejects (16-bit integers) and layout slips.
+    for packed in (True, False):
+        comm = sharded.TorchComm(dist, 0, 1, packed=packed)
+        e = s.e
+        e.cu_mem[:] = torch.arange(e.cu_mem.numel(), device=dev).to(torch.uint8)
+        before = [m.clone() for m in e.mem] + [e.cu_mem.clone()]
+        sends = [(0, e.row_slab(0, 0, 16, 20)), (0, e.row_slab(0, 1, 8, 10)),
+                 (0, e.row_slab(0, 2, 8, 10)), (0, e.cu_slab(0, e.cus_per_row)),
+                 (0, e.row_slab(0, 0, 33, 36))]
+        recvs = [(0, e.row_slab(1, 0, 48, 52)), (0, e.row_slab(1, 1, 30, 32)),
+                 (0, e.row_slab(1, 2, 2, 4)), (0, e.cu_slab(2 * e.cus_per_row, e.cus_per_row)),
+                 (0, e.row_slab(1, 0, 97, 100))]
+        exp = [t.clone() for _, t in sends]
+        comm.exchange(sends, recvs, e.make_copier)
+        comm.exchange(sends, recvs, e.make_copier)   # cached plan
+        torch.cuda.synchronize()
+        for (_, r), x in zip(recvs, exp):
+            assert torch.equal(r, x), packed
+        # nothing else moved
+        touched = torch.zeros_like(e.mem[1].view(torch.uint8), dtype=torch.bool)
+        for (_, r) in recvs[:3] + recvs[4:]:
+            o = r.data_ptr() - e.mem[1].data_ptr()
+            touched[o:o + r.numel()] = True
+        same = e.mem[1].view(torch.uint8) == before[1].view(torch.uint8)
+        assert bool((same | touched).all()), packed
+        assert torch.equal(e.mem[0], before[0])
+        e.mem[1].copy_(before[1])
+        e.cu_mem.copy_(before[2])
+        torch.cuda.synchronize()
     dist.destroy_process_group()
     print("OK")
 

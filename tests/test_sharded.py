@@ -101,7 +101,7 @@ class OracleEngine:
     def row_slab(self, rec_idx, comp, ya, yb):
         b = BL if comp == 0 else BC
         a = self.pics[rec_idx][comp]
-        return self.torch.from_numpy(a[b + ya:b + yb, :].view(np.int16)).reshape(-1)
+        return self.torch.from_numpy(a[b + ya:b + yb, :].view(np.uint8)).reshape(-1)
 
     def cu_slab(self, first_cu, n):
         return self.torch.from_numpy(self.cus[first_cu:first_cu + n].view(np.uint8)) \
@@ -214,25 +214,27 @@ def _free_port():
     return p
 
 
-def _gloo_worker(rank, world, port, q):
+def _gloo_worker(rank, world, port, q, w=PW, h=PH, search_range=96):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     lib = ol.Lib("xo")
-    clip = synth.SyntheticClip(PW, PH, BD)
-    rows = sharded.shard_rows(PH, world)
-    e = OracleEngine(lib, PW, PH, BD, QP, rows[rank])
+    clip = synth.SyntheticClip(w, h, BD)
+    rows = sharded.shard_rows(h, world)
+    e = OracleEngine(lib, w, h, BD, QP, rows[rank], search_range=search_range)
     for c, p in enumerate(pad_planes(clip.frame(0))):
         e.pics[0][c][:] = p
+    # packed: one all_to_all_single per exchange (what runs over RCCL)
     s = sharded.ShardedFramePass(e, sharded.TorchComm(dist, rank, world), rank, world)
     # a second, independent chain with its own process group, interleaved with
-    # the first (bench.py --chains): same pictures, so the same results
-    e2 = OracleEngine(lib, PW, PH, BD, QP, rows[rank])
+    # the first (bench.py --chains): same pictures, so the same results; this
+    # one with a point-to-point operation per slab
+    e2 = OracleEngine(lib, w, h, BD, QP, rows[rank], search_range=search_range)
     for c, p in enumerate(pad_planes(clip.frame(0))):
         e2.pics[0][c][:] = p
-    s2 = sharded.ShardedFramePass(e2, sharded.TorchComm(dist, rank, world, dist.new_group()),
-                                  rank, world)
+    s2 = sharded.ShardedFramePass(e2, sharded.TorchComm(dist, rank, world, dist.new_group(),
+                                                        packed=False), rank, world)
     out = []
     for n in (1, 2):
         orig = pad_planes(clip.frame(n))
@@ -267,6 +269,36 @@ def test_sharded_gloo_two_ranks():
             for c in range(3):
                 assert np.array_equal(rec[c], expect[n][0][c]), (rank, n, c)
             assert ssd == expect[n][1]   # all-reduced over the two ranks
+
+
+def test_sharded_gloo_four_ranks_neighbours_only():
+    """Tall picture, short search: a rank exchanges rows with its neighbours
+    only, so the all-to-all has empty segments for everybody else."""
+    import torch.multiprocessing as mp
+    w, h, sr, world = 208, 320, 8, 4
+    lib = ol.Lib("xo")
+    expect = reference_frames(lib, 2, w, h, sr)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gloo_worker, args=(r, world, port, q, w, h, sr))
+             for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=300) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert any(got[r][0][2] != (0, h) for r in range(world))
+    for rank in range(world):
+        for n in range(2):
+            rec, ssd, (ya, yb) = got[rank][n]
+            for c in range(3):
+                b = BL if c == 0 else BC   # plane border rows
+                lo, hi = (ya, yb) if c == 0 else (ya // 2, yb // 2)
+                assert np.array_equal(rec[c][b + lo:b + hi], expect[n][0][c][b + lo:b + hi]), \
+                    (rank, n, c)
+            assert ssd == expect[n][1]
 
 
 def test_synthetic_clip_c_mirror_matches_python():

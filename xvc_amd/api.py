@@ -55,6 +55,7 @@ assert MCAFF_DTYPE.itemsize == 32
 MCM_DTYPE = np.dtype([("x", "<i2"), ("y", "<i2"), ("w", "u1"), ("h", "u1"),
                       ("metric", "u1"), ("qp", "i1"), ("mv_x", "<i4"), ("mv_y", "<i4")])
 assert MCM_DTYPE.itemsize == 16
+SEG_DTYPE = np.dtype([("src", "<u8"), ("dst", "<u8"), ("bytes", "<u8")])
 LIC_DTYPE = np.dtype([("x", "<i2"), ("y", "<i2"), ("w", "u1"), ("h", "u1"), ("comp", "u1"),
                       ("neighbors", "u1"), ("mv_x", "<i4"), ("mv_y", "<i4"),
                       ("above_x", "<i2"), ("above_y", "<i2"), ("left_x", "<i2"),
@@ -110,7 +111,8 @@ SYMBOLS = [
     "xvcgpu_picture_import", "xvcgpu_picture_export", "xvcgpu_picture_crc",
     "xvcgpu_variance_map", "xvcgpu_histogram_distance",
     "xvcgpu_intra_pred_batch", "xvcgpu_intra_satd_batch", "xvcgpu_intra_recon_batch",
-    "xvcgpu_intra_select_modes", "xvcgpu_frame_pass", "xvcgpu_get_transform_matrix",
+    "xvcgpu_intra_select_modes", "xvcgpu_frame_pass", "xvcgpu_copy_segments",
+    "xvcgpu_get_transform_matrix",
 ]
 
 _vp = C.c_void_p
@@ -214,6 +216,7 @@ def load_library():
         "xvcgpu_intra_recon_batch": [_vp, _vp, _vp, _vp, _vp, C.c_int, _vp, _vp, _vp],
         "xvcgpu_intra_select_modes": [_vp, _vp, _vp, C.c_int, _vp, _vp, _vp, C.c_int],
         "xvcgpu_frame_pass": [_vp, C.POINTER(FramePassArgs), C.c_int],
+        "xvcgpu_copy_segments": [_vp, _vp, C.c_int],
         "xvcgpu_get_transform_matrix": [C.c_int, C.c_int, _vp],
     }
     for name, args in sigs.items():

@@ -297,4 +297,22 @@ picture_ssd_sum_kernel(const unsigned long long *part_in, int items,
   }
 }
 
+// grid: (32, n segments); block 256: segment blockIdx.y, 16 bytes per thread and
+// step when source, destination and length allow it, else bytes.
+__global__ void __launch_bounds__(256)
+copy_segments_kernel(const xvcgpu_copy_segment *segs, int n) {
+  const xvcgpu_copy_segment sg = segs[blockIdx.y];
+  const unsigned long long tid = blockIdx.x * 256ull + threadIdx.x, nthr = gridDim.x * 256ull;
+  const uintptr_t a = reinterpret_cast<uintptr_t>(sg.src), b = reinterpret_cast<uintptr_t>(sg.dst);
+  if (((a | b | sg.bytes) & 15) == 0) {
+    const uint4 *s4 = static_cast<const uint4 *>(sg.src);
+    uint4 *d4 = static_cast<uint4 *>(sg.dst);
+    for (unsigned long long i = tid; i < sg.bytes / 16; i += nthr) d4[i] = s4[i];
+  } else {
+    const uint8_t *s1 = static_cast<const uint8_t *>(sg.src);
+    uint8_t *d1 = static_cast<uint8_t *>(sg.dst);
+    for (unsigned long long i = tid; i < sg.bytes; i += nthr) d1[i] = s1[i];
+  }
+}
+
 #endif  // XVCGPU_K_MISC_H_

@@ -1199,4 +1199,14 @@ xvcgpu_status xvcgpu_frame_pass(xvcgpu_ctx *ctx, const xvcgpu_frame_pass_args *a
   return st;
 }
 
+xvcgpu_status xvcgpu_copy_segments(xvcgpu_ctx *ctx, const xvcgpu_copy_segment *d_segments,
+                                   int n) {
+  if (!ctx || n < 0 || (n && !d_segments)) return XVCGPU_INVALID_ARGUMENT;
+  if (n == 0) return XVCGPU_OK;
+  hipLaunchKernelGGL(copy_segments_kernel, dim3(32, n), dim3(256), 0, ctx->stream, d_segments,
+                     n);
+  CHECK_LAUNCH(ctx, "copy_segments");
+  return XVCGPU_OK;
+}
+
 }  // extern "C"

@@ -61,11 +61,63 @@ def shard_rows(height, world, cu=16):
     return out
 
 
-class TorchComm:
-    """Batched point-to-point exchange over torch.distributed (RCCL on GPUs,
-    gloo in the CPU tests)."""
+class _PackedPlan:
+    """One exchange as a single collective: every slab bound for a peer sits in
+    one segment of a staging buffer (16-byte aligned pieces, in list order, so
+    that both ends lay a peer's segment out alike)."""
 
-    def __init__(self, dist, rank, world, group=None):
+    ALIGN = 16
+
+    def __init__(self, sends, recvs, world, make_copier):
+        import torch
+        dev = (sends or recvs)[0][1].device
+        self.send_buf, self.send_splits, pack = self._layout(sends, world, dev, torch)
+        self.recv_buf, self.recv_splits, unpack = self._layout(recvs, world, dev, torch)
+        unpack = [(stage, slab) for slab, stage in unpack]
+        self.pack = make_copier(pack) if make_copier else _TorchCopier(pack)
+        self.unpack = make_copier(unpack) if make_copier else _TorchCopier(unpack)
+        self.peers = [p for p in range(world) if self.send_splits[p] or self.recv_splits[p]]
+
+    @classmethod
+    def _layout(cls, ops, world, dev, torch):
+        splits, pieces, total = [0] * world, [], 0
+        for peer in range(world):
+            for p, t in ops:
+                if p != peer:
+                    continue
+                assert t.dtype == torch.uint8 and t.dim() == 1
+                n = (t.numel() + cls.ALIGN - 1) // cls.ALIGN * cls.ALIGN
+                pieces.append((t, total, t.numel()))
+                total += n
+                splits[peer] += n
+        buf = torch.zeros(total, dtype=torch.uint8, device=dev)
+        return buf, splits, [(t, buf[off:off + n]) for t, off, n in pieces]
+
+    def segment(self, buf, splits, peer):
+        off = sum(splits[:peer])
+        return buf[off:off + splits[peer]]
+
+
+class _TorchCopier:
+    """(source, destination) tensor pairs copied one by one (CPU engines)."""
+
+    def __init__(self, pairs):
+        self.pairs = pairs
+
+    def __call__(self):
+        for src, dst in self.pairs:
+            dst.copy_(src)
+
+
+class TorchComm:
+    """Neighbour exchange over torch.distributed (RCCL on GPUs, gloo in the CPU
+    tests): the slabs of one exchange are packed per peer and travel in ONE
+    all_to_all_single (RCCL: a grouped send/recv per peer with data).  A batched
+    point-to-point group per slab costs ~10 us of host time per operation
+    through torch.distributed - 100-300 us per picture at 8 ranks, more than
+    the picture's kernels (tools/p2p_host_cost.py)."""
+
+    def __init__(self, dist, rank, world, group=None, packed=True):
         # group: a process group of all ranks dedicated to one picture chain, so
         # that the exchanges of concurrent chains do not queue behind each other
         self.dist, self.rank, self.world, self.group = dist, rank, world, group
@@ -74,15 +126,56 @@ class TorchComm:
         # device buffers from the CPU as soon as it is called: the stream has to
         # be drained first.
         self.host_transport = dist.get_backend(group) != "nccl"
+        self.packed = packed
         self._p2p = {}
+        self._plans = {}
 
-    def exchange(self, sends, recvs):
-        """sends / recvs: lists of (peer, 1-D tensor); per peer the order of
-        sends on one side matches the order of recvs on the other."""
+    def exchange(self, sends, recvs, make_copier=None):
+        """sends / recvs: lists of (peer, 1-D byte tensor); per peer the order
+        of sends on one side matches the order of recvs on the other.  Every
+        rank of the group calls this (a collective), with or without data.
+        make_copier(pairs) -> callable: the engine's batched device copy."""
+        if self.world == 1 and not sends and not recvs:
+            return
+        if not self.packed:
+            return self._exchange_p2p(sends, recvs)
+        # the callers hand in the same (cached) lists for every picture: lay the
+        # staging buffers out once per list pair
+        key = (id(sends), id(recvs))
+        hit = self._plans.get(key)
+        if hit is None or hit[0] is not sends or hit[1] is not recvs:
+            plan = _PackedPlan(sends, recvs, self.world, make_copier) \
+                if (sends or recvs) else None
+            self._plans[key] = (sends, recvs, plan)
+        else:
+            plan = hit[2]
+        d, g = self.dist, self.group
+        # with more than one rank every shard has a neighbour
+        assert plan is not None, "a rank without neighbours in a group of %d" % self.world
+        plan.pack()
+        if self.host_transport and plan.send_buf.is_cuda:
+            # gloo with device tensors (several ranks on one GPU in tests): the
+            # per-peer segments point to point, same layout as the collective
+            self._drain(plan.send_buf)
+            ops = []
+            for p in plan.peers:
+                if plan.send_splits[p]:
+                    ops.append(d.P2POp(d.isend, plan.segment(plan.send_buf, plan.send_splits, p),
+                                       p, group=g))
+                if plan.recv_splits[p]:
+                    ops.append(d.P2POp(d.irecv, plan.segment(plan.recv_buf, plan.recv_splits, p),
+                                       p, group=g))
+            for req in d.batch_isend_irecv(ops):
+                req.wait()
+        else:
+            d.all_to_all_single(plan.recv_buf, plan.send_buf, plan.recv_splits,
+                                plan.send_splits, group=g)
+        plan.unpack()
+
+    def _exchange_p2p(self, sends, recvs):
+        """One point-to-point operation per slab, no staging copies."""
         d = self.dist
         g = self.group
-        # the callers hand in the same (cached) lists for every picture: build
-        # the operation objects once per list pair
         key = (id(sends), id(recvs))
         hit = self._p2p.get(key)
         if hit is None or hit[0] is not sends or hit[1] is not recvs:
@@ -224,9 +317,10 @@ class ShardedFramePass:
 
     def run(self, orig, ref_idx, rec_idx, ref_poc=0):
         self.phase_a(orig, ref_idx, rec_idx, ref_poc)
-        self.comm.exchange(*self.halo_ops(rec_idx))
+        copier = getattr(self.e, "make_copier", None)
+        self.comm.exchange(*self.halo_ops(rec_idx), copier)
         self.phase_b(rec_idx)
-        self.comm.exchange(*self.gather_ops(rec_idx))
+        self.comm.exchange(*self.gather_ops(rec_idx), copier)
         self.phase_c(orig, rec_idx)
 
 
@@ -320,11 +414,28 @@ class GpuEngine:
         off, stride, border = self.geom[rec_idx][comp]
         # full padded rows: from the left border of row ya to the end of row yb-1
         start = off + ya * stride - border
-        return self.mem[rec_idx][start:start + (yb - ya) * stride]
+        # as bytes: torch's NCCL / RCCL backend does not take 16-bit integer tensors
+        return self.mem[rec_idx][start:start + (yb - ya) * stride].view(self.torch.uint8)
 
     def cu_slab(self, first_cu, n):
         s = api.CU_DTYPE.itemsize
         return self.cu_mem[first_cu * s:(first_cu + n) * s]
+
+    def make_copier(self, pairs):
+        """(source, destination) device tensor pairs -> a callable that copies
+        them all in one launch on the engine's stream (xvcgpu_copy_segments)."""
+        segs = np.zeros(len(pairs), api.SEG_DTYPE)
+        for i, (src, dst) in enumerate(pairs):
+            assert src.numel() == dst.numel() or dst.numel() >= src.numel()
+            segs[i] = (src.data_ptr(), dst.data_ptr(), src.numel() * src.element_size())
+        d_segs = self.torch.zeros(max(1, segs.nbytes), dtype=self.torch.uint8,
+                                  device=self.mem[0].device)
+        self.ctx.h2d(d_segs.data_ptr(), segs)
+        ctx, n, keep = self.ctx, len(pairs), (d_segs, pairs)
+
+        def run():
+            ctx._check(ctx.lib.xvcgpu_copy_segments(ctx.h, keep[0].data_ptr(), n))
+        return run
 
 
 def torch_stream_of(ctx, device, own_stream):
