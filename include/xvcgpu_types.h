@@ -240,6 +240,26 @@ typedef struct xvcgpu_frame_pass_args {
   uint64_t *d_ssd;
 } xvcgpu_frame_pass_args;
 
+/* One job of xvcgpu_affine_me_batch: InterSearch::MotionEstAffine for a
+ * uni-predicted CU (inter_search.cc:664-749).  Vectors are {x, y} in 1/16 pel;
+ * mvp / bootstrap are MotionVector3 (top-left, top-right, bottom-left corner). */
+#define XVC_AFFINE_ME_HAS_BOOTSTRAP 1
+typedef struct xvcgpu_affine_me_block {
+  int16_t x, y;        /* luma position of the CU */
+  uint8_t w, h;        /* 16, 32 or 64 each (CodingUnit::CanUseAffine: > 8) */
+  uint8_t flags;       /* XVC_AFFINE_ME_HAS_BOOTSTRAP */
+  uint8_t reserved;
+  uint32_t lambda16;   /* floor(65536 * sqrt(lambda)) */
+  int32_t mvp[3][2];
+  int32_t bootstrap[3][2];
+} xvcgpu_affine_me_block;
+
+typedef struct xvcgpu_affine_me_result {
+  int32_t mv[3][2];    /* best_mv */
+  uint32_t dist;       /* *out_dist: SATD of the best prediction */
+  uint32_t iterations; /* gradient iterations that produced a non-zero update */
+} xvcgpu_affine_me_result;
+
 /* One device-to-device copy of xvcgpu_copy_segments (row slabs of a picture
  * to / from the staging buffer of a multi-GPU exchange). */
 typedef struct xvcgpu_copy_segment {

@@ -560,6 +560,54 @@ void xr_subpel_search(int bd, const xvcgpu_me_block *b, int pic_w, int pic_h,
   if (out_dist) *out_dist = static_cast<uint32_t>(dist);
 }
 
+/* T5: InterSearch::AffineGradientSearch / MotionEstAffine (uni-pred) */
+void xr_affine_gradient_search(int bd, int width, int height, const uint16_t *pred,
+                               ptrdiff_t ps, const int16_t *err, ptrdiff_t es, int mvd[4]) {
+  std::vector<uint16_t> dummy(64 * 64, 0);
+  MeEnv env(bd, 64, 64, dummy.data(), 64, dummy.data(), 64);
+  InterSearch is(Simd(bd), env.pic_data, env.orig_pic, env.rec_pic, env.rpl,
+                 env.settings);
+  SampleBuffer pb(const_cast<uint16_t *>(pred), ps);
+  ResidualBuffer eb(const_cast<int16_t *>(err), es);
+  MvDelta2 r = is.AffineGradientSearch(width, height, pb, eb);
+  mvd[0] = r[0].x;
+  mvd[1] = r[0].y;
+  mvd[2] = r[1].x;
+  mvd[3] = r[1].y;
+}
+
+void xr_affine_me(int bd, const xvcgpu_affine_me_block *b, int pic_w, int pic_h,
+                  const uint16_t *orig, ptrdiff_t os, const uint16_t *ref, ptrdiff_t rs,
+                  xvcgpu_affine_me_result *out) {
+  MeEnv env(bd, pic_w, pic_h, orig, os, ref, rs);
+  std::shared_ptr<const YuvPicture> refp(&env.ref_pic, [](const YuvPicture *) {});
+  env.pic_data.GetRefPicLists()->SetRefPic(RefPicList::kL0, 0, 0, nullptr, refp, refp);
+  CodingUnit *cu = env.pic_data.CreateCu(CuTree::Primary, 1, b->x, b->y, b->w, b->h);
+  cu->SetUseAffine(true);
+  InterSearch is(Simd(bd), env.pic_data, env.orig_pic, env.rec_pic, env.rpl,
+                 env.settings);
+  double ls = (b->lambda16 + 0.5) / 65536.0;
+  Qp qp = MakeQp(32, bd, ls * ls);
+  assert(static_cast<uint32_t>(std::floor(65536.0 * qp.GetLambdaSqrt())) == b->lambda16);
+  SampleBufferConst orig_buffer = env.orig_pic.GetSampleBuffer(YuvComponent::kY, b->x, b->y);
+  SampleBufferStorage pred(64, 64);
+  MotionVector3 mvp, boot;
+  for (int i = 0; i < 3; i++) {
+    mvp[i] = MotionVector(b->mvp[i][0], b->mvp[i][1]);
+    boot[i] = MotionVector(b->bootstrap[i][0], b->bootstrap[i][1]);
+  }
+  Distortion dist = 0;
+  MotionVector3 mv = is.MotionEstAffine(
+      *cu, qp, InterSearch::SearchMethod::kTzSearch, RefPicList::kL0, 0, false, orig_buffer, mvp,
+      (b->flags & XVC_AFFINE_ME_HAS_BOOTSTRAP) ? &boot : nullptr, &pred, &dist);
+  for (int i = 0; i < 3; i++) {
+    out->mv[i][0] = mv[i].x;
+    out->mv[i][1] = mv[i].y;
+  }
+  out->dist = static_cast<uint32_t>(dist);
+  out->iterations = 0; /* not observable through the reference API */
+}
+
 int xr_quant_fast2(int bd, int qp_raw, int intra_pic, int sign_hide, int scan_order,
                    int w, int h, const int16_t *in, ptrdiff_t is, int16_t *out,
                    ptrdiff_t os) {

@@ -790,3 +790,62 @@ def test_mc_lic_block(libs, bd):
             n += 1
     xr._set_simd(1)
     assert n == 180
+
+
+# ---- T5: affine motion estimation ---------------------------------------------
+@pytest.mark.parametrize("bd", [8, 10, 12])
+def test_affine_gradient_search(libs, bd):
+    """InterSearch::AffineGradientSearch: Sobel gradients, the 4x5 normal
+    equations, elimination, lround - including flat and extreme inputs."""
+    import oracle_affine_me as oa
+    xo, xr = libs
+    rng = np.random.default_rng(1500 + bd)
+    mx = (1 << bd) - 1
+    nonzero = 0
+    for i in range(150):
+        w, h = int(rng.choice([16, 32, 64])), int(rng.choice([16, 32, 64]))
+        kind = i % 6
+        if kind == 0:
+            pred = rng.integers(0, mx + 1, size=(h, w))
+        elif kind == 1:
+            pred = np.full((h, w), int(rng.integers(0, mx + 1)))   # flat: singular system
+        elif kind == 2:
+            pred = np.tile(rng.integers(0, mx + 1, size=(1, w)), (h, 1))   # no vertical gradient
+        elif kind == 3:
+            pred = ((np.indices((h, w)).sum(0) % 2) * mx)          # extreme checkerboard
+        else:
+            yy, xx = np.mgrid[0:h, 0:w]
+            pred = (np.sin(xx / 5.0 + i) * np.cos(yy / 7.0) * 0.4 + 0.5) * mx + \
+                rng.integers(-3, 4, size=(h, w))
+        pred = np.clip(pred, 0, mx).astype(np.uint16)
+        amp = int(rng.choice([2, 30, mx]))
+        err = rng.integers(-amp, amp + 1, size=(h, w)).astype(np.int16)
+        if kind == 4:   # the error a small shift would produce
+            err = (np.roll(pred.astype(np.int32), 1, axis=1) - pred).astype(np.int16)
+        a = oa.gradient_search(xo, bd, pred, err)
+        b = oa.gradient_search(xr, bd, pred, err)
+        assert a == b, (i, w, h, kind)
+        nonzero += any(a)
+    assert nonzero > 40
+
+
+@pytest.mark.parametrize("bd", [8, 10])
+def test_affine_me(libs, bd):
+    """InterSearch::MotionEstAffine (uni-pred) on zooming / rotating content."""
+    import oracle_affine_me as oa
+    xo, xr = libs
+    rng = np.random.default_rng(1600 + bd)
+    pw, ph, border = 192, 128, 128
+    moved = iters = boot = 0
+    for (zoom, rot, shift) in [(1.0, 0.0, (1.5, -0.75)), (1.02, 0.0, (0, 0)),
+                               (1.0, 0.015, (0.5, 0.5)), (0.985, -0.01, (-2.0, 1.0))]:
+        orig, ref = oa.warped_pics(rng, bd, pw, ph, border, zoom, rot, shift)
+        blocks = oa.random_blocks(rng, pw, ph, 24)
+        for b in blocks:
+            exp = oa.affine_me(xr, bd, b, pw, ph, orig, ref, border)
+            got = oa.affine_me(xo, bd, b, pw, ph, orig, ref, border)
+            assert np.array_equal(got["mv"], exp["mv"]) and got["dist"] == exp["dist"], b
+            moved += not np.array_equal(got["mv"], b["mvp"])
+            iters += int(got["iterations"])
+            boot += bool(b["flags"]) and np.array_equal(got["mv"], b["bootstrap"])
+    assert moved > 60 and iters > 200
