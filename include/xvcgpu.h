@@ -498,6 +498,21 @@ xvcgpu_status xvcgpu_intra_recon_batch(xvcgpu_ctx *ctx, const xvcgpu_picture *or
                                        int16_t *d_levels, const uint32_t *d_level_offsets,
                                        int32_t *d_nnz);
 
+/* ---- T5: affine motion estimation ------------------------------------------ *
+ * InterSearch::MotionEstAffine (inter_search.cc:664-749) for n uni-predicted
+ * CUs (bipred == false: orig is the original picture, 7 iterations at most):
+ * prediction from the affine predictor (and the optional bootstrap vector),
+ * then per iteration AffineGradientSearch (:751-851: Sobel gradients, the 4x5
+ * normal equations, elimination with partial pivoting, lround), DeriveMvAffine
+ * (inter_prediction.cc:615-630), MotionCompAffine and the SATD / mvd-bit cost.
+ * The reference's float / double arithmetic is reproduced exactly (every sum of
+ * the normal equations is an exact multiple of 1/64 below 2^53, so its order
+ * does not matter; the elimination is the same IEEE double sequence). */
+xvcgpu_status xvcgpu_affine_me_batch(xvcgpu_ctx *ctx, const xvcgpu_picture *orig,
+                                     const xvcgpu_picture *ref,
+                                     const xvcgpu_affine_me_block *d_blocks, int n,
+                                     xvcgpu_affine_me_result *d_results);
+
 /* ---- multi-GPU staging --------------------------------------------------- *
  * n device-to-device copies (descriptors in device memory) in one launch: packs
  * the row slabs / CU metadata rows a rank exchanges with its neighbours into

@@ -55,6 +55,12 @@ assert MCAFF_DTYPE.itemsize == 32
 MCM_DTYPE = np.dtype([("x", "<i2"), ("y", "<i2"), ("w", "u1"), ("h", "u1"),
                       ("metric", "u1"), ("qp", "i1"), ("mv_x", "<i4"), ("mv_y", "<i4")])
 assert MCM_DTYPE.itemsize == 16
+AFFINE_ME_DTYPE = np.dtype([("x", "<i2"), ("y", "<i2"), ("w", "u1"), ("h", "u1"),
+                            ("flags", "u1"), ("reserved", "u1"), ("lambda16", "<u4"),
+                            ("mvp", "<i4", (3, 2)), ("bootstrap", "<i4", (3, 2))])
+AFFINE_ME_RESULT_DTYPE = np.dtype([("mv", "<i4", (3, 2)), ("dist", "<u4"),
+                                   ("iterations", "<u4")])
+AFFINE_ME_HAS_BOOTSTRAP = 1
 SEG_DTYPE = np.dtype([("src", "<u8"), ("dst", "<u8"), ("bytes", "<u8")])
 LIC_DTYPE = np.dtype([("x", "<i2"), ("y", "<i2"), ("w", "u1"), ("h", "u1"), ("comp", "u1"),
                       ("neighbors", "u1"), ("mv_x", "<i4"), ("mv_y", "<i4"),
@@ -105,6 +111,7 @@ SYMBOLS = [
     "xvcgpu_picture_copy", "xvcgpu_pad_border", "xvcgpu_metric_batch", "xvcgpu_mc_metric_batch",
     "xvcgpu_me_search", "xvcgpu_me_search_sized", "xvcgpu_mc_batch", "xvcgpu_mc_from_me",
     "xvcgpu_mc_bipred_batch", "xvcgpu_bipred_search", "xvcgpu_mc_affine_batch", "xvcgpu_mc_lic_batch",
+    "xvcgpu_affine_me_batch",
     "xvcgpu_cu_info_from_me", "xvcgpu_recon_from_me", "xvcgpu_residual_batch",
     "xvcgpu_fwd_transform_batch", "xvcgpu_inv_transform_batch",
     "xvcgpu_deblock", "xvcgpu_deblock_rows", "xvcgpu_picture_ssd", "xvcgpu_picture_ssd_rows",
@@ -211,6 +218,7 @@ def load_library():
         "xvcgpu_variance_map": [_vp, _vp, _vp, C.c_int, _vp],
         "xvcgpu_histogram_distance": [_vp, _vp, _vp, _vp],
         "xvcgpu_mc_lic_batch": [_vp, _vp, _vp, _vp, _vp, C.c_int],
+        "xvcgpu_affine_me_batch": [_vp, _vp, _vp, _vp, C.c_int, _vp],
         "xvcgpu_intra_pred_batch": [_vp, _vp, _vp, _vp, C.c_int],
         "xvcgpu_intra_satd_batch": [_vp, _vp, _vp, _vp, C.c_int, _vp, C.c_int],
         "xvcgpu_intra_recon_batch": [_vp, _vp, _vp, _vp, _vp, C.c_int, _vp, _vp, _vp],
@@ -675,6 +683,19 @@ class Context:
                                                  d.ptr, len(jobs)))
         self.sync()
         d.free()
+
+    def affine_me_batch(self, orig, ref, blocks):
+        """InterSearch::MotionEstAffine per block -> AFFINE_ME_RESULT_DTYPE array"""
+        blocks = np.ascontiguousarray(blocks, AFFINE_ME_DTYPE)
+        assert all(int(v) in (16, 32, 64) for v in np.concatenate([blocks["w"], blocks["h"]]))
+        d = self.buffer(blocks)
+        do = self.alloc(AFFINE_ME_RESULT_DTYPE.itemsize * max(1, len(blocks)))
+        self._check(self.lib.xvcgpu_affine_me_batch(self.h, orig.h_pic, ref.h_pic, d.ptr,
+                                                    len(blocks), do.ptr))
+        out = do.to_array(AFFINE_ME_RESULT_DTYPE, len(blocks))
+        d.free()
+        do.free()
+        return out
 
     # ---- intra prediction ----
     def intra_pred_batch(self, rec, pred, jobs):

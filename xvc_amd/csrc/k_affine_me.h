@@ -1,0 +1,273 @@
+// k_affine_me.h -- T5: InterSearch::MotionEstAffine of a uni-predicted CU
+// (inter_search.cc:664-749) with AffineGradientSearch (:751-851) and
+// DeriveMvAffine (inter_prediction.cc:615-630), the whole iteration on the
+// device.  One wave per CU.
+//
+// The reference keeps the gradients in float and the 4x5 normal equations in
+// double, summed in raster order.  Every term is a multiple of 1/64 (1/8 for
+// the right-hand side) and the totals stay below 2^53 for 8..12-bit samples
+// and blocks up to 64x64 (|8c| < 2^21, 4096 samples), so each of those
+// double sums is exact and therefore independent of the order: the lanes
+// accumulate the same sums as 64-bit integers and the matrix handed to the
+// elimination is bit-identical.  The elimination itself is a fixed sequence
+// of IEEE double operations (no contraction), evaluated the same on every lane.
+#ifndef XVCGPU_K_AFFINE_ME_H_
+#define XVCGPU_K_AFFINE_ME_H_
+
+#include "k_bipred.h"
+
+struct __attribute__((aligned(16))) AffineMeShared {
+  int16_t tmp[64 * 71];   // separable filter intermediate (whole block or sub-block)
+  uint16_t sub[16 * 64];  // one sub-block's prediction
+  uint16_t pred[64 * 64]; // the CU's prediction, row stride w
+};
+
+// InterPrediction::MotionCompAffine (inter_prediction.cc:1044-1136), luma, into
+// s.pred; the sub-blocks one after the other by the one wave.
+__device__ __forceinline__ void affine_me_mc(int bd, int bx, int by, int w, int h,
+                                             const PlaneView &pr, const int mvin[3][2],
+                                             AffineMeShared &s) {
+  int mv[3][2];
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+    mv[i][0] = mvin[i][0];
+    mv[i][1] = mvin[i][1];
+    d_clip_mv(bx, by, pr.w, pr.h, mv[i][0], mv[i][1]);
+  }
+  wave_sync();  // earlier readers of s.pred are done
+  if (mv[0][0] == mv[1][0] && mv[0][1] == mv[1][1]) {
+    const uint16_t *r =
+        pr.p + (ptrdiff_t)(by + (mv[0][1] >> 4)) * pr.stride + bx + (mv[0][0] >> 4);
+    wave_interp_block<false>(bd, w, h, mv[0][0] & 15, mv[0][1] & 15, r, pr.stride, s.tmp,
+                             s.pred);
+    wave_sync();
+    return;
+  }
+  const int sbw = d_affine_subblock(mv[0][0], mv[0][1], mv[1][0], mv[1][1], w, 0);
+  const int sbh = d_affine_subblock(mv[0][0], mv[0][1], mv[2][0], mv[2][1], h, 0);
+  const int mv_max_x = (pr.w - bx + 8 - 1) * 16, mv_min_x = (-64 - bx - 8 + 1) * 16;
+  const int mv_max_y = (pr.h - by + 8 - 1) * 16, mv_min_y = (-64 - by - 8 + 1) * 16;
+  const int dhx = ((mv[1][0] - mv[0][0]) * 256) / w;
+  const int dhy = ((mv[1][1] - mv[0][1]) * 256) / w;
+  const int dvx = -dhy, dvy = dhx;
+  const int nsx = w / sbw, nsy = h / sbh;
+  const int lane = ME2_LANE, lsw = 31 - __clz(sbw);
+  for (int k = 0; k < nsx * nsy; k++) {
+    const int iy = k / nsx, ix = k - iy * nsx;
+    const int hor_x = mv[0][0] * 256 + dvx * sbh * iy + dhx * sbw * ix;
+    const int hor_y = mv[0][1] * 256 + dvy * sbh * iy + dhy * sbw * ix;
+    int mx = (hor_x + dhx * (sbw >> 1) + dvx * (sbh >> 1)) >> 8;
+    int my = (hor_y + dhy * (sbw >> 1) + dvy * (sbh >> 1)) >> 8;
+    mx = d_clip3(mx, mv_min_x, mv_max_x);
+    my = d_clip3(my, mv_min_y, mv_max_y);
+    const int sx = ix * sbw, sy = iy * sbh;
+    const uint16_t *r =
+        pr.p + (ptrdiff_t)(by + sy + (my >> 4)) * pr.stride + bx + sx + (mx >> 4);
+    wave_interp_block<false>(bd, sbw, sbh, mx & 15, my & 15, r, pr.stride, s.tmp, s.sub);
+    wave_sync();
+    uint16_t *o = s.pred + sy * w + sx;
+    for (int i = lane; i < sbw * sbh; i += 64) o[(i >> lsw) * w + (i & (sbw - 1))] = s.sub[i];
+    wave_sync();
+  }
+}
+
+// ::lround into MvDelta's int members as the reference's x86-64 build does it:
+// out of range gives the "integer indefinite" value whose low 32 bits are 0.
+__device__ __forceinline__ int affine_lround(double v) {
+  if (!(fabs(v) < 9.2e18)) return 0;
+  return (int)lround(v);
+}
+
+// The elimination, back substitution and rounding of AffineGradientSearch
+// (inter_search.cc:805-850) on the exact sums: S = 64 * matrix[r][c] for
+// r <= c in the order 00 01 02 03 11 12 13 22 23 33, R = 8 * matrix[r][4].
+__device__ __noinline__ void affine_solve(const long long S[10], const long long R[4],
+                                          int width, int mvd[4]) {
+#pragma clang fp contract(off)
+  double m[4][5];
+  {
+    int k = 0;
+    for (int r = 0; r < 4; r++)
+      for (int c = r; c < 4; c++, k++) m[r][c] = m[c][r] = (double)S[k] / 64.0;
+    for (int r = 0; r < 4; r++) m[r][4] = (double)R[r] / 8.0;
+  }
+  for (int i = 0; i < 3; i++) {
+    int best = i;
+    double best_val = fabs(m[i][i]);
+    for (int j = i + 1; j < 4; j++)
+      if (fabs(m[j][i]) > best_val) {
+        best = j;
+        best_val = fabs(m[j][i]);
+      }
+    if (best != i)
+      for (int col = 0; col < 5; col++) {
+        const double t = m[i][col];
+        m[i][col] = m[best][col];
+        m[best][col] = t;
+      }
+    for (int j = i + 1; j < 4; j++)
+      for (int k = i + 1; k < 5; k++)
+        if (m[i][i] != 0.0) {
+          const double prod = m[i][k] * m[j][i];
+          const double q = prod / m[i][i];
+          m[j][k] = m[j][k] - q;
+        }
+  }
+  double params[4] = {0, 0, 0, 0};
+  if (m[3][3] != 0.0) params[3] = m[3][4] / m[3][3];
+  for (int row = 2; row >= 0; row--) {
+    double sum = 0;
+    for (int col = row + 1; col < 4; col++) {
+      const double prod = m[row][col] * params[col];
+      sum = sum + prod;
+    }
+    if (m[row][row] != 0.0) params[row] = (m[row][4] - sum) / m[row][row];
+  }
+  const double p1w = params[1] * (double)width;
+  const double p3w = -params[3] * (double)width;
+  mvd[0] = affine_lround(4.0 * params[0]);
+  mvd[1] = affine_lround(4.0 * params[2]);
+  mvd[2] = affine_lround(4.0 * (p1w + params[0]));
+  mvd[3] = affine_lround(4.0 * (p3w + params[2]));
+}
+
+// AffineGradientSearch on the prediction in s.pred and err = orig - pred.
+__device__ __forceinline__ void affine_gradient_search(int w, int h, const uint16_t *o,
+                                                       int os, const AffineMeShared &s,
+                                                       int mvd[4]) {
+  const int lane = ME2_LANE, lw = 31 - __clz(w);
+  long long S[10], R[4];
+#pragma unroll
+  for (int k = 0; k < 10; k++) S[k] = 0;
+#pragma unroll
+  for (int k = 0; k < 4; k++) R[k] = 0;
+  for (int i = lane; i < w * h; i += 64) {
+    const int x = i & (w - 1), y = i >> lw;
+    // border gradients are copies of the nearest interior one (:772-783)
+    const int xc = d_clip3(x, 1, w - 2), yc = d_clip3(y, 1, h - 2);
+    const uint16_t *p = s.pred + yc * w + xc;
+    const int a0 = p[-w - 1], a1 = p[-w], a2 = p[-w + 1];
+    const int b0 = p[-1], b2 = p[1];
+    const int c0 = p[w - 1], c1 = p[w], c2 = p[w + 1];
+    const int kh = -a0 + a2 - 2 * b0 + 2 * b2 - c0 + c2;  // 8 * affine_delta_hor_
+    const int kv = -a0 - 2 * a1 - a2 + c0 + 2 * c1 + c2;  // 8 * affine_delta_ver_
+    const long long c[4] = {kh, (long long)x * kh + (long long)y * kv, kv,
+                            (long long)y * kh - (long long)x * kv};
+    const long long e = (int)o[(ptrdiff_t)y * os + x] - (int)s.pred[i];
+    int k = 0;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+#pragma unroll
+      for (int cc = r; cc < 4; cc++, k++) S[k] += c[r] * c[cc];
+      R[r] += e * c[r];
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 10; k++) S[k] = group_sum<64>(S[k]);
+#pragma unroll
+  for (int k = 0; k < 4; k++) R[k] = group_sum<64>(R[k]);
+  affine_solve(S, R, w, mvd);
+}
+
+// grid: n CUs; block: 64.
+__global__ void __launch_bounds__(64)
+affine_me_kernel(PlaneView orig, PlaneView ref, int bd, const xvcgpu_affine_me_block *blocks,
+                 int n, xvcgpu_affine_me_result *out) {
+  __shared__ AffineMeShared s;
+  const int bi = blockIdx.x;
+  if (bi >= n) return;
+  const xvcgpu_affine_me_block b = blocks[bi];
+  const int w = b.w, h = b.h, bx = b.x, by = b.y;
+  const uint32_t lambda = b.lambda16;
+  const uint16_t *o = orig.p + (ptrdiff_t)by * orig.stride + bx;
+  const int os = (int)orig.stride;
+  int mvp[3][2], best_mv[3][2], mv[3][2];
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+    mvp[i][0] = best_mv[i][0] = b.mvp[i][0];
+    mvp[i][1] = best_mv[i][1] = b.mvp[i][1];
+  }
+  auto bits3 = [&](const int v[3][2]) -> uint32_t {
+    return d_mvd_bits(mvp[0][0], mvp[0][1], v[0][0], v[0][1], 0) +
+           d_mvd_bits(mvp[1][0], mvp[1][1], v[1][0], v[1][1], 0);
+  };
+  auto dist_of = [&](int metric) -> uint64_t {
+    return wave_compare(metric, bd, 0, 0, w, h, o, os, s.pred, w);
+  };
+  affine_me_mc(bd, bx, by, w, h, ref, mvp, s);
+  uint64_t best_dist = dist_of(XVC_METRIC_SAD);
+  uint64_t best_cost = best_dist + ((uint32_t)(lambda * bits3(best_mv)) >> 16);
+  if (b.flags & XVC_AFFINE_ME_HAS_BOOTSTRAP) {
+    int boot[3][2];
+    bool same = true;
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+      boot[i][0] = b.bootstrap[i][0];
+      boot[i][1] = b.bootstrap[i][1];
+      same = same && boot[i][0] == mvp[i][0] && boot[i][1] == mvp[i][1];
+    }
+    if (!same) {
+      affine_me_mc(bd, bx, by, w, h, ref, boot, s);
+      const uint64_t dist = dist_of(XVC_METRIC_SAD);
+      const uint64_t cost = dist + ((uint32_t)(lambda * bits3(boot)) >> 16);
+      if (cost < best_cost) {
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+          best_mv[i][0] = boot[i][0];
+          best_mv[i][1] = boot[i][1];
+        }
+      } else {
+        affine_me_mc(bd, bx, by, w, h, ref, best_mv, s);
+      }
+    }
+  }
+  best_dist = dist_of(XVC_METRIC_SATD);
+  best_cost = best_dist + ((uint32_t)(lambda * bits3(best_mv)) >> 16);
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+    mv[i][0] = best_mv[i][0];
+    mv[i][1] = best_mv[i][1];
+  }
+  uint32_t iterations = 0;
+  for (int iter = 0; iter < 7; iter++) {
+    int mvd[4];
+    affine_gradient_search(w, h, o, os, s, mvd);
+    if (!(mvd[0] | mvd[1] | mvd[2] | mvd[3])) break;
+    iterations++;
+    mv[0][0] += mvd[0] * 4;  // MotionVector += MvDelta (1/4 -> 1/16 pel)
+    mv[0][1] += mvd[1] * 4;
+    mv[1][0] += mvd[2] * 4;
+    mv[1][1] += mvd[3] * 4;
+    // DeriveMvAffine
+    d_clip_mv(bx, by, ref.w, ref.h, mv[0][0], mv[0][1]);
+    d_clip_mv(bx, by, ref.w, ref.h, mv[1][0], mv[1][1]);
+    mv[2][0] = mv[0][0] - (mv[1][1] - mv[0][1]) * h / w;
+    mv[2][1] = mv[0][1] + (mv[1][0] - mv[0][0]) * h / w;
+    d_clip_mv(bx, by, ref.w, ref.h, mv[2][0], mv[2][1]);
+    affine_me_mc(bd, bx, by, w, h, ref, mv, s);
+    const uint64_t dist = dist_of(XVC_METRIC_SATD);
+    const uint64_t cost = dist + ((uint32_t)(lambda * bits3(mv)) >> 16);
+    if (cost < best_cost) {
+      best_cost = cost;
+      best_dist = dist;
+#pragma unroll
+      for (int i = 0; i < 3; i++) {
+        best_mv[i][0] = mv[i][0];
+        best_mv[i][1] = mv[i][1];
+      }
+    }
+  }
+  if (ME2_LANE == 0) {
+    xvcgpu_affine_me_result r;
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+      r.mv[i][0] = best_mv[i][0];
+      r.mv[i][1] = best_mv[i][1];
+    }
+    r.dist = (uint32_t)best_dist;
+    r.iterations = iterations;
+    out[bi] = r;
+  }
+}
+
+#endif  // XVCGPU_K_AFFINE_ME_H_

@@ -19,6 +19,7 @@
 #include "k_bipred.h"
 #include "k_stats.h"
 #include "k_intra.h"
+#include "k_affine_me.h"
 #include "xvcgpu_internal.h"
 
 namespace {
@@ -1197,6 +1198,22 @@ xvcgpu_status xvcgpu_frame_pass(xvcgpu_ctx *ctx, const xvcgpu_frame_pass_args *a
     st = xvcgpu_picture_ssd_rows(ctx, a->orig, a->rec, 0, a->shift_bitdepth, a->ssd_y_begin,
                                  a->ssd_y_end, a->d_ssd);
   return st;
+}
+
+xvcgpu_status xvcgpu_affine_me_batch(xvcgpu_ctx *ctx, const xvcgpu_picture *orig,
+                                     const xvcgpu_picture *ref,
+                                     const xvcgpu_affine_me_block *d_blocks, int n,
+                                     xvcgpu_affine_me_result *d_results) {
+  if (!ctx || !orig || !ref || n < 0 || (n && (!d_blocks || !d_results)))
+    return XVCGPU_INVALID_ARGUMENT;
+  if (orig->v.bd != ref->v.bd || orig->v.c[0].w != ref->v.c[0].w ||
+      orig->v.c[0].h != ref->v.c[0].h)
+    return XVCGPU_INVALID_ARGUMENT;
+  if (n == 0) return XVCGPU_OK;
+  hipLaunchKernelGGL(affine_me_kernel, dim3(n), dim3(64), 0, ctx->stream, orig->v.c[0],
+                     ref->v.c[0], ref->v.bd, d_blocks, n, d_results);
+  CHECK_LAUNCH(ctx, "affine_me_batch");
+  return XVCGPU_OK;
 }
 
 xvcgpu_status xvcgpu_copy_segments(xvcgpu_ctx *ctx, const xvcgpu_copy_segment *d_segments,
