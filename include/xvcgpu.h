@@ -499,8 +499,11 @@ xvcgpu_status xvcgpu_intra_recon_batch(xvcgpu_ctx *ctx, const xvcgpu_picture *or
                                        int32_t *d_nnz);
 
 /* ---- T5: affine motion estimation ------------------------------------------ *
- * InterSearch::MotionEstAffine (inter_search.cc:664-749) for n uni-predicted
- * CUs (bipred == false: orig is the original picture, 7 iterations at most):
+ * InterSearch::MotionEstAffine (inter_search.cc:664-749) for n (CU, list,
+ * ref_idx) jobs on one reference picture - uni-pred (orig is the original
+ * picture, 7 iterations at most) or, XVC_AFFINE_ME_BIPRED, the refinement
+ * search of SearchBiIterative (:394-435) against 2 * orig - the other list's
+ * affine prediction from `ref_other` (may be NULL when no job has the flag):
  * prediction from the affine predictor (and the optional bootstrap vector),
  * then per iteration AffineGradientSearch (:751-851: Sobel gradients, the 4x5
  * normal equations, elimination with partial pivoting, lround), DeriveMvAffine
@@ -510,6 +513,7 @@ xvcgpu_status xvcgpu_intra_recon_batch(xvcgpu_ctx *ctx, const xvcgpu_picture *or
  * does not matter; the elimination is the same IEEE double sequence). */
 xvcgpu_status xvcgpu_affine_me_batch(xvcgpu_ctx *ctx, const xvcgpu_picture *orig,
                                      const xvcgpu_picture *ref,
+                                     const xvcgpu_picture *ref_other,
                                      const xvcgpu_affine_me_block *d_blocks, int n,
                                      xvcgpu_affine_me_result *d_results);
 

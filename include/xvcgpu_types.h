@@ -240,23 +240,29 @@ typedef struct xvcgpu_frame_pass_args {
   uint64_t *d_ssd;
 } xvcgpu_frame_pass_args;
 
-/* One job of xvcgpu_affine_me_batch: InterSearch::MotionEstAffine for a
- * uni-predicted CU (inter_search.cc:664-749).  Vectors are {x, y} in 1/16 pel;
- * mvp / bootstrap are MotionVector3 (top-left, top-right, bottom-left corner). */
+/* One job of xvcgpu_affine_me_batch: InterSearch::MotionEstAffine for one
+ * (list, ref_idx) of a CU (inter_search.cc:664-749).  Vectors are {x, y} in
+ * 1/16 pel; mvp / bootstrap / other_mv are MotionVector3 (top-left, top-right,
+ * bottom-left corner).  XVC_AFFINE_ME_BIPRED: the search of SearchBiIterative
+ * (:394-435) - the target is 2 * orig - the affine prediction of the other
+ * list (other_mv on the `ref_other` picture; SubtractWeighted), distortions
+ * are halved, 5 iterations, the bootstrap vector always wins. */
 #define XVC_AFFINE_ME_HAS_BOOTSTRAP 1
+#define XVC_AFFINE_ME_BIPRED 2
 typedef struct xvcgpu_affine_me_block {
   int16_t x, y;        /* luma position of the CU */
   uint8_t w, h;        /* 16, 32 or 64 each (CodingUnit::CanUseAffine: > 8) */
-  uint8_t flags;       /* XVC_AFFINE_ME_HAS_BOOTSTRAP */
+  uint8_t flags;       /* XVC_AFFINE_ME_HAS_BOOTSTRAP | XVC_AFFINE_ME_BIPRED */
   uint8_t reserved;
   uint32_t lambda16;   /* floor(65536 * sqrt(lambda)) */
   int32_t mvp[3][2];
   int32_t bootstrap[3][2];
+  int32_t other_mv[3][2]; /* XVC_AFFINE_ME_BIPRED: the other list's vectors */
 } xvcgpu_affine_me_block;
 
 typedef struct xvcgpu_affine_me_result {
   int32_t mv[3][2];    /* best_mv */
-  uint32_t dist;       /* *out_dist: SATD of the best prediction */
+  uint32_t dist;       /* *out_dist: SATD of the best prediction (>> 1 with BIPRED) */
   uint32_t iterations; /* gradient iterations that produced a non-zero update */
 } xvcgpu_affine_me_result;
 

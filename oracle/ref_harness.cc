@@ -578,7 +578,7 @@ void xr_affine_gradient_search(int bd, int width, int height, const uint16_t *pr
 
 void xr_affine_me(int bd, const xvcgpu_affine_me_block *b, int pic_w, int pic_h,
                   const uint16_t *orig, ptrdiff_t os, const uint16_t *ref, ptrdiff_t rs,
-                  xvcgpu_affine_me_result *out) {
+                  const uint16_t *ref_other, ptrdiff_t ros, xvcgpu_affine_me_result *out) {
   MeEnv env(bd, pic_w, pic_h, orig, os, ref, rs);
   std::shared_ptr<const YuvPicture> refp(&env.ref_pic, [](const YuvPicture *) {});
   env.pic_data.GetRefPicLists()->SetRefPic(RefPicList::kL0, 0, 0, nullptr, refp, refp);
@@ -591,15 +591,32 @@ void xr_affine_me(int bd, const xvcgpu_affine_me_block *b, int pic_w, int pic_h,
   assert(static_cast<uint32_t>(std::floor(65536.0 * qp.GetLambdaSqrt())) == b->lambda16);
   SampleBufferConst orig_buffer = env.orig_pic.GetSampleBuffer(YuvComponent::kY, b->x, b->y);
   SampleBufferStorage pred(64, 64);
-  MotionVector3 mvp, boot;
+  MotionVector3 mvp, boot, other;
   for (int i = 0; i < 3; i++) {
     mvp[i] = MotionVector(b->mvp[i][0], b->mvp[i][1]);
     boot[i] = MotionVector(b->bootstrap[i][0], b->bootstrap[i][1]);
+    other[i] = MotionVector(b->other_mv[i][0], b->other_mv[i][1]);
   }
+  const MotionVector3 *bootp = (b->flags & XVC_AFFINE_ME_HAS_BOOTSTRAP) ? &boot : nullptr;
   Distortion dist = 0;
-  MotionVector3 mv = is.MotionEstAffine(
-      *cu, qp, InterSearch::SearchMethod::kTzSearch, RefPicList::kL0, 0, false, orig_buffer, mvp,
-      (b->flags & XVC_AFFINE_ME_HAS_BOOTSTRAP) ? &boot : nullptr, &pred, &dist);
+  MotionVector3 mv;
+  if (b->flags & XVC_AFFINE_ME_BIPRED) {
+    /* SearchBiIterative :415-420: prediction of the other list, then
+     * bipred_orig_buffer_.SubtractWeighted */
+    YuvPicture other_pic(ChromaFormat::k420, pic_w, pic_h, bd, true, 0, 0);
+    const uint16_t *pr[3] = {ref_other, nullptr, nullptr};
+    ptrdiff_t sr[3] = {ros, 0, 0};
+    FillPic(&other_pic, pr, sr);
+    SampleBufferStorage other_pred(64, 64);
+    is.MotionCompensationMv(*cu, YuvComponent::kY, other_pic, other, false, &other_pred);
+    ResidualBufferStorage target(64, 64);
+    target.SubtractWeighted(b->w, b->h, orig_buffer, other_pred);
+    mv = is.MotionEstAffine(*cu, qp, InterSearch::SearchMethod::kTzSearch, RefPicList::kL0, 0,
+                            true, target, mvp, bootp, &pred, &dist);
+  } else {
+    mv = is.MotionEstAffine(*cu, qp, InterSearch::SearchMethod::kTzSearch, RefPicList::kL0, 0,
+                            false, orig_buffer, mvp, bootp, &pred, &dist);
+  }
   for (int i = 0; i < 3; i++) {
     out->mv[i][0] = mv[i].x;
     out->mv[i][1] = mv[i].y;

@@ -202,12 +202,13 @@ void xo_mc_lic_block(int bitdepth, const xvcgpu_mc_lic_block *b, int pic_w, int 
                      const uint16_t *ref, ptrdiff_t rs, const uint16_t *rec, ptrdiff_t cs,
                      uint16_t *pred, ptrdiff_t ps);
 /* T5: InterSearch::AffineGradientSearch (inter_search.cc:751-851) and
- * MotionEstAffine for a uni-predicted CU (:664-749); xvc_oracle_affine_me.c. */
+ * MotionEstAffine (:664-749; uni-pred and the bi-pred refinement search);
+ * xvc_oracle_affine_me.c. */
 void xo_affine_gradient_search(int width, int height, const uint16_t *pred, ptrdiff_t ps,
                                const int16_t *err, ptrdiff_t es, int mvd[4]);
 void xo_affine_me(int bd, const xvcgpu_affine_me_block *b, int pic_w, int pic_h,
                   const uint16_t *orig, ptrdiff_t os, const uint16_t *ref, ptrdiff_t rs,
-                  xvcgpu_affine_me_result *out);
+                  const uint16_t *ref_other, ptrdiff_t ros, xvcgpu_affine_me_result *out);
 /* GetMvdBitsFullpel / GetMvdBits / GetNumExpGolombBits
  * (inter_search.cc:1150-1188). */
 uint32_t xo_mvd_bits_fullpel(int mvp_x, int mvp_y, int fx, int fy,

@@ -113,22 +113,35 @@ static uint32_t mvd_bits3(const int mvp[3][2], const int mv[3][2]) {
          xo_mvd_bits(mvp[1][0], mvp[1][1], mv[1][0], mv[1][1], 0);
 }
 
-/* inter_search.cc:664-749, bipred == false.  orig / ref point at sample (0,0)
- * of the luma planes (ref padded). */
+/* inter_search.cc:664-749.  orig / ref / ref_other point at sample (0,0) of
+ * the luma planes (references padded); ref_other only with XVC_AFFINE_ME_BIPRED:
+ * the target is then 2 * orig - MotionCompAffine(ref_other, other_mv)
+ * (SearchBiIterative, :394-435; SubtractWeighted, sample_buffer.h:147-161). */
 void xo_affine_me(int bd, const xvcgpu_affine_me_block *b, int pic_w, int pic_h,
                   const uint16_t *orig, ptrdiff_t os, const uint16_t *ref, ptrdiff_t rs,
-                  xvcgpu_affine_me_result *out) {
+                  const uint16_t *ref_other, ptrdiff_t ros, xvcgpu_affine_me_result *out) {
   const int w = b->w, h = b->h;
   const uint32_t lambda = b->lambda16;
+  const int bipred = (b->flags & XVC_AFFINE_ME_BIPRED) != 0;
+  const int bi_shift = bipred ? 1 : 0, max_iterations = bipred ? 5 : 7;
   uint16_t pred[64 * 64];
-  int16_t err[64 * 64];
+  int16_t err[64 * 64], target[64 * 64];
   const uint16_t *o = orig + (ptrdiff_t)b->y * os + b->x;
   int mvp[3][2], best_mv[3][2], mv[3][2];
   memcpy(mvp, b->mvp, sizeof(mvp));
   memcpy(best_mv, mvp, sizeof(mvp));
 #define MC(v) xo_mc_affine_block(bd, 0, b->x, b->y, w, h, (const int (*)[2])(v), pic_w, pic_h, \
                                  ref, rs, pred, 64)
-#define DIST(metric) xo_metric_ss(metric, bd, 0, 0, 1.0, w, h, o, os, pred, 64)
+#define DIST(metric)                                                                 \
+  ((bipred ? xo_metric_rs(metric, bd, 0, 0, 1.0, w, h, target, 64, pred, 64)         \
+           : xo_metric_ss(metric, bd, 0, 0, 1.0, w, h, o, os, pred, 64)) >> bi_shift)
+  if (bipred) {
+    xo_mc_affine_block(bd, 0, b->x, b->y, w, h, (const int (*)[2])b->other_mv, pic_w, pic_h,
+                       ref_other, ros, pred, 64);
+    for (int y = 0; y < h; y++)
+      for (int x = 0; x < w; x++)
+        target[y * 64 + x] = (int16_t)(2 * (int)o[y * os + x] - (int)pred[y * 64 + x]);
+  }
   MC(mvp);
   uint64_t best_dist = DIST(XVC_METRIC_SAD);
   uint64_t best_cost = best_dist + ((uint32_t)(lambda * mvd_bits3(mvp, best_mv)) >> 16);
@@ -139,7 +152,7 @@ void xo_affine_me(int bd, const xvcgpu_affine_me_block *b, int pic_w, int pic_h,
     MC(boot);
     uint64_t dist = DIST(XVC_METRIC_SAD);
     uint64_t cost = dist + ((uint32_t)(lambda * mvd_bits3(mvp, boot)) >> 16);
-    if (cost < best_cost)
+    if (cost < best_cost || bipred) /* force_mv_bootstrap */
       memcpy(best_mv, boot, sizeof(boot));
     else
       MC(best_mv);
@@ -148,10 +161,11 @@ void xo_affine_me(int bd, const xvcgpu_affine_me_block *b, int pic_w, int pic_h,
   best_cost = best_dist + ((uint32_t)(lambda * mvd_bits3(mvp, best_mv)) >> 16);
   memcpy(mv, best_mv, sizeof(mv));
   uint32_t iterations = 0;
-  for (int iter = 0; iter < 7; iter++) {
+  for (int iter = 0; iter < max_iterations; iter++) {
     for (int y = 0; y < h; y++)
       for (int x = 0; x < w; x++)
-        err[y * 64 + x] = (int16_t)((int)o[y * os + x] - (int)pred[y * 64 + x]);
+        err[y * 64 + x] = (int16_t)((bipred ? (int)target[y * 64 + x] : (int)o[y * os + x]) -
+                                    (int)pred[y * 64 + x]);
     int mvd[4];
     xo_affine_gradient_search(w, h, pred, 64, err, 64, mvd);
     if (!mvd[0] && !mvd[1] && !mvd[2] && !mvd[3]) break;

@@ -10,10 +10,10 @@ i32p = C.POINTER(C.c_int32)
 pd = C.c_ssize_t
 BLOCK_DTYPE = np.dtype([("x", "<i2"), ("y", "<i2"), ("w", "u1"), ("h", "u1"), ("flags", "u1"),
                         ("reserved", "u1"), ("lambda16", "<u4"), ("mvp", "<i4", (3, 2)),
-                        ("bootstrap", "<i4", (3, 2))])
+                        ("bootstrap", "<i4", (3, 2)), ("other_mv", "<i4", (3, 2))])
 RESULT_DTYPE = np.dtype([("mv", "<i4", (3, 2)), ("dist", "<u4"), ("iterations", "<u4")])
-assert BLOCK_DTYPE.itemsize == 60 and RESULT_DTYPE.itemsize == 32
-HAS_BOOTSTRAP = 1
+assert BLOCK_DTYPE.itemsize == 84 and RESULT_DTYPE.itemsize == 32
+HAS_BOOTSTRAP, BIPRED = 1, 2
 
 
 def gradient_search(lib, bd, pred, err):
@@ -37,17 +37,24 @@ def gradient_search(lib, bd, pred, err):
     return [int(v) for v in mvd]
 
 
-def affine_me(lib, bd, block, pic_w, pic_h, orig_pad, ref_pad, border):
-    """orig_pad / ref_pad: padded luma planes.  Returns a RESULT_DTYPE scalar."""
+def affine_me(lib, bd, block, pic_w, pic_h, orig_pad, ref_pad, border, other_pad=None):
+    """orig_pad / ref_pad / other_pad: padded luma planes (other_pad: the other
+    list's reference, for BIPRED jobs).  Returns a RESULT_DTYPE scalar."""
     f = getattr(lib.dll, lib.prefix + "_affine_me")
     f.restype = None
-    f.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_int, u16p, pd, u16p, pd, C.c_void_p]
+    f.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_int, u16p, pd, u16p, pd, u16p, pd,
+                  C.c_void_p]
     b = np.ascontiguousarray(block, BLOCK_DTYPE).reshape(1)
     out = np.zeros(1, RESULT_DTYPE)
     o = orig_pad[border:, border:]
     r = ref_pad[border:, border:]
+    if other_pad is None:
+        assert not int(b[0]["flags"]) & BIPRED
+        other_pad = ref_pad
+    t = other_pad[border:, border:]
     f(bd, b.ctypes.data, pic_w, pic_h, C.cast(o.ctypes.data, u16p), orig_pad.strides[0] // 2,
-      C.cast(r.ctypes.data, u16p), ref_pad.strides[0] // 2, out.ctypes.data)
+      C.cast(r.ctypes.data, u16p), ref_pad.strides[0] // 2,
+      C.cast(t.ctypes.data, u16p), other_pad.strides[0] // 2, out.ctypes.data)
     return out[0]
 
 
@@ -71,7 +78,7 @@ def warped_pics(rng, bd, pw, ph, border, zoom=1.0, rot=0.0, shift=(0.0, 0.0), no
     return orig.astype(np.uint16), ref.astype(np.uint16)
 
 
-def random_blocks(rng, pic_w, pic_h, n, qp_lambda16=(9000, 60000, 400000)):
+def random_blocks(rng, pic_w, pic_h, n, qp_lambda16=(9000, 60000, 400000), bipred=False):
     out = np.zeros(n, BLOCK_DTYPE)
     for i in range(n):
         w, h = int(rng.choice([16, 32, 64])), int(rng.choice([16, 32, 64]))
@@ -94,4 +101,10 @@ def random_blocks(rng, pic_w, pic_h, n, qp_lambda16=(9000, 60000, 400000)):
             else:
                 t = base + rng.integers(-6, 7, size=2)    # translational bootstrap
                 b["bootstrap"] = np.stack([t, t, t])
+        if bipred and i % 2:
+            b["flags"] |= BIPRED
+            o0 = -base + rng.integers(-8, 9, size=2)      # roughly mirrored motion
+            o1 = o0 + (rng.integers(-12, 13, size=2) if i % 3 else 0)
+            o2 = np.array([o0[0] - (o1[1] - o0[1]) * h // w, o0[1] + (o1[0] - o0[0]) * h // w])
+            b["other_mv"] = np.stack([o0, o1, o2])
     return out

@@ -38,16 +38,19 @@ def test_affine_me_batch(gpu, xo, bd):
     assert api.AFFINE_ME_DTYPE == oa.BLOCK_DTYPE and api.AFFINE_ME_RESULT_DTYPE == oa.RESULT_DTYPE
     rng = np.random.default_rng(5200 + bd)
     pw, ph = 192, 128
-    moved = iters = best_boot = 0
+    moved = iters = best_boot = nbi = 0
     for (zoom, rot, shift) in [(1.0, 0.0, (1.5, -0.75)), (1.02, 0.0, (0, 0)),
                                (1.0, 0.015, (0.5, 0.5)), (0.985, -0.01, (-2.0, 1.0)),
                                (1.0, 0.0, (0, 0))]:
         orig, ref = oa.warped_pics(rng, bd, pw, ph, BL, zoom, rot, shift)
+        _, other = oa.warped_pics(rng, bd, pw, ph, BL, 2 - zoom, -rot, (-shift[0], -shift[1]))
         O, R = upload(ctx, orig, pw, ph, bd), upload(ctx, ref, pw, ph, bd)
-        blocks = oa.random_blocks(rng, pw, ph, 48)
-        got = ctx.affine_me_batch(O, R, blocks)
+        T = upload(ctx, other, pw, ph, bd)
+        blocks = oa.random_blocks(rng, pw, ph, 48, bipred=True)
+        nbi += int((blocks["flags"] & oa.BIPRED != 0).sum())
+        got = ctx.affine_me_batch(O, R, blocks, T)
         for b, g in zip(blocks, got):
-            e = oa.affine_me(xo, bd, b, pw, ph, orig, ref, BL)
+            e = oa.affine_me(xo, bd, b, pw, ph, orig, ref, BL, other)
             assert np.array_equal(g["mv"], e["mv"]) and g["dist"] == e["dist"] and \
                 g["iterations"] == e["iterations"], (b, g, e)
             moved += not np.array_equal(g["mv"], b["mvp"])
@@ -55,7 +58,8 @@ def test_affine_me_batch(gpu, xo, bd):
             best_boot += bool(b["flags"]) and np.array_equal(g["mv"], b["bootstrap"])
         O.destroy()
         R.destroy()
-    assert moved > 150 and iters > 500
+        T.destroy()
+    assert moved > 150 and iters > 500 and nbi > 100
 
 
 def test_affine_me_flat_and_extreme(gpu, xo):

@@ -831,21 +831,25 @@ def test_affine_gradient_search(libs, bd):
 
 @pytest.mark.parametrize("bd", [8, 10])
 def test_affine_me(libs, bd):
-    """InterSearch::MotionEstAffine (uni-pred) on zooming / rotating content."""
+    """InterSearch::MotionEstAffine on zooming / rotating content: uni-pred and
+    the bi-pred refinement search (target 2 * orig - other prediction)."""
     import oracle_affine_me as oa
     xo, xr = libs
     rng = np.random.default_rng(1600 + bd)
     pw, ph, border = 192, 128, 128
-    moved = iters = boot = 0
+    moved = iters = boot = nbi = 0
     for (zoom, rot, shift) in [(1.0, 0.0, (1.5, -0.75)), (1.02, 0.0, (0, 0)),
                                (1.0, 0.015, (0.5, 0.5)), (0.985, -0.01, (-2.0, 1.0))]:
         orig, ref = oa.warped_pics(rng, bd, pw, ph, border, zoom, rot, shift)
-        blocks = oa.random_blocks(rng, pw, ph, 24)
+        _, other = oa.warped_pics(rng, bd, pw, ph, border, 2 - zoom, -rot,
+                                  (-shift[0], -shift[1]))
+        blocks = oa.random_blocks(rng, pw, ph, 30, bipred=True)
         for b in blocks:
-            exp = oa.affine_me(xr, bd, b, pw, ph, orig, ref, border)
-            got = oa.affine_me(xo, bd, b, pw, ph, orig, ref, border)
+            exp = oa.affine_me(xr, bd, b, pw, ph, orig, ref, border, other)
+            got = oa.affine_me(xo, bd, b, pw, ph, orig, ref, border, other)
             assert np.array_equal(got["mv"], exp["mv"]) and got["dist"] == exp["dist"], b
             moved += not np.array_equal(got["mv"], b["mvp"])
             iters += int(got["iterations"])
             boot += bool(b["flags"]) and np.array_equal(got["mv"], b["bootstrap"])
-    assert moved > 60 and iters > 200
+            nbi += bool(int(b["flags"]) & oa.BIPRED)
+    assert moved > 60 and iters > 200 and nbi > 40

@@ -57,10 +57,11 @@ MCM_DTYPE = np.dtype([("x", "<i2"), ("y", "<i2"), ("w", "u1"), ("h", "u1"),
 assert MCM_DTYPE.itemsize == 16
 AFFINE_ME_DTYPE = np.dtype([("x", "<i2"), ("y", "<i2"), ("w", "u1"), ("h", "u1"),
                             ("flags", "u1"), ("reserved", "u1"), ("lambda16", "<u4"),
-                            ("mvp", "<i4", (3, 2)), ("bootstrap", "<i4", (3, 2))])
+                            ("mvp", "<i4", (3, 2)), ("bootstrap", "<i4", (3, 2)),
+                            ("other_mv", "<i4", (3, 2))])
 AFFINE_ME_RESULT_DTYPE = np.dtype([("mv", "<i4", (3, 2)), ("dist", "<u4"),
                                    ("iterations", "<u4")])
-AFFINE_ME_HAS_BOOTSTRAP = 1
+AFFINE_ME_HAS_BOOTSTRAP, AFFINE_ME_BIPRED = 1, 2
 SEG_DTYPE = np.dtype([("src", "<u8"), ("dst", "<u8"), ("bytes", "<u8")])
 LIC_DTYPE = np.dtype([("x", "<i2"), ("y", "<i2"), ("w", "u1"), ("h", "u1"), ("comp", "u1"),
                       ("neighbors", "u1"), ("mv_x", "<i4"), ("mv_y", "<i4"),
@@ -218,7 +219,7 @@ def load_library():
         "xvcgpu_variance_map": [_vp, _vp, _vp, C.c_int, _vp],
         "xvcgpu_histogram_distance": [_vp, _vp, _vp, _vp],
         "xvcgpu_mc_lic_batch": [_vp, _vp, _vp, _vp, _vp, C.c_int],
-        "xvcgpu_affine_me_batch": [_vp, _vp, _vp, _vp, C.c_int, _vp],
+        "xvcgpu_affine_me_batch": [_vp, _vp, _vp, _vp, _vp, C.c_int, _vp],
         "xvcgpu_intra_pred_batch": [_vp, _vp, _vp, _vp, C.c_int],
         "xvcgpu_intra_satd_batch": [_vp, _vp, _vp, _vp, C.c_int, _vp, C.c_int],
         "xvcgpu_intra_recon_batch": [_vp, _vp, _vp, _vp, _vp, C.c_int, _vp, _vp, _vp],
@@ -684,14 +685,17 @@ class Context:
         self.sync()
         d.free()
 
-    def affine_me_batch(self, orig, ref, blocks):
-        """InterSearch::MotionEstAffine per block -> AFFINE_ME_RESULT_DTYPE array"""
+    def affine_me_batch(self, orig, ref, blocks, ref_other=None):
+        """InterSearch::MotionEstAffine per block -> AFFINE_ME_RESULT_DTYPE array
+        (ref_other: the other list's reference for AFFINE_ME_BIPRED jobs)"""
         blocks = np.ascontiguousarray(blocks, AFFINE_ME_DTYPE)
         assert all(int(v) in (16, 32, 64) for v in np.concatenate([blocks["w"], blocks["h"]]))
         d = self.buffer(blocks)
         do = self.alloc(AFFINE_ME_RESULT_DTYPE.itemsize * max(1, len(blocks)))
-        self._check(self.lib.xvcgpu_affine_me_batch(self.h, orig.h_pic, ref.h_pic, d.ptr,
-                                                    len(blocks), do.ptr))
+        assert ref_other is not None or not (blocks["flags"] & AFFINE_ME_BIPRED).any()
+        self._check(self.lib.xvcgpu_affine_me_batch(
+            self.h, orig.h_pic, ref.h_pic, ref_other.h_pic if ref_other else None, d.ptr,
+            len(blocks), do.ptr))
         out = do.to_array(AFFINE_ME_RESULT_DTYPE, len(blocks))
         d.free()
         do.free()

@@ -1,7 +1,8 @@
-// k_affine_me.h -- T5: InterSearch::MotionEstAffine of a uni-predicted CU
-// (inter_search.cc:664-749) with AffineGradientSearch (:751-851) and
-// DeriveMvAffine (inter_prediction.cc:615-630), the whole iteration on the
-// device.  One wave per CU.
+// k_affine_me.h -- T5: InterSearch::MotionEstAffine (inter_search.cc:664-749;
+// uni-pred and the bi-pred refinement search of SearchBiIterative :394-435)
+// with AffineGradientSearch (:751-851) and DeriveMvAffine
+// (inter_prediction.cc:615-630), the whole iteration on the device.  One wave
+// per CU.
 //
 // The reference keeps the gradients in float and the 4x5 normal equations in
 // double, summed in raster order.  Every term is a multiple of 1/64 (1/8 for
@@ -20,6 +21,7 @@ struct __attribute__((aligned(16))) AffineMeShared {
   int16_t tmp[64 * 71];   // separable filter intermediate (whole block or sub-block)
   uint16_t sub[16 * 64];  // one sub-block's prediction
   uint16_t pred[64 * 64]; // the CU's prediction, row stride w
+  int16_t target[64 * 64]; // bi-pred: 2 * orig - the other list's prediction
 };
 
 // InterPrediction::MotionCompAffine (inter_prediction.cc:1044-1136), luma, into
@@ -132,7 +134,8 @@ __device__ __noinline__ void affine_solve(const long long S[10], const long long
 }
 
 // AffineGradientSearch on the prediction in s.pred and err = orig - pred.
-__device__ __forceinline__ void affine_gradient_search(int w, int h, const uint16_t *o,
+template <typename TOrig>
+__device__ __forceinline__ void affine_gradient_search(int w, int h, const TOrig *o,
                                                        int os, const AffineMeShared &s,
                                                        int mvd[4]) {
   const int lane = ME2_LANE, lw = 31 - __clz(w);
@@ -169,18 +172,16 @@ __device__ __forceinline__ void affine_gradient_search(int w, int h, const uint1
   affine_solve(S, R, w, mvd);
 }
 
-// grid: n CUs; block: 64.
-__global__ void __launch_bounds__(64)
-affine_me_kernel(PlaneView orig, PlaneView ref, int bd, const xvcgpu_affine_me_block *blocks,
-                 int n, xvcgpu_affine_me_result *out) {
-  __shared__ AffineMeShared s;
-  const int bi = blockIdx.x;
-  if (bi >= n) return;
-  const xvcgpu_affine_me_block b = blocks[bi];
+// The search proper on a target of samples (uni) or residuals (bi).
+template <typename TOrig>
+__device__ __forceinline__ void affine_me_search(int bd, const xvcgpu_affine_me_block &b,
+                                                 const PlaneView &ref, const TOrig *o, int os,
+                                                 AffineMeShared &s,
+                                                 xvcgpu_affine_me_result *out) {
   const int w = b.w, h = b.h, bx = b.x, by = b.y;
   const uint32_t lambda = b.lambda16;
-  const uint16_t *o = orig.p + (ptrdiff_t)by * orig.stride + bx;
-  const int os = (int)orig.stride;
+  const bool bipred = (b.flags & XVC_AFFINE_ME_BIPRED) != 0;
+  const int bi_shift = bipred ? 1 : 0, max_iterations = bipred ? 5 : 7;
   int mvp[3][2], best_mv[3][2], mv[3][2];
 #pragma unroll
   for (int i = 0; i < 3; i++) {
@@ -192,7 +193,7 @@ affine_me_kernel(PlaneView orig, PlaneView ref, int bd, const xvcgpu_affine_me_b
            d_mvd_bits(mvp[1][0], mvp[1][1], v[1][0], v[1][1], 0);
   };
   auto dist_of = [&](int metric) -> uint64_t {
-    return wave_compare(metric, bd, 0, 0, w, h, o, os, s.pred, w);
+    return wave_compare(metric, bd, 0, 0, w, h, o, os, s.pred, w) >> bi_shift;
   };
   affine_me_mc(bd, bx, by, w, h, ref, mvp, s);
   uint64_t best_dist = dist_of(XVC_METRIC_SAD);
@@ -210,7 +211,7 @@ affine_me_kernel(PlaneView orig, PlaneView ref, int bd, const xvcgpu_affine_me_b
       affine_me_mc(bd, bx, by, w, h, ref, boot, s);
       const uint64_t dist = dist_of(XVC_METRIC_SAD);
       const uint64_t cost = dist + ((uint32_t)(lambda * bits3(boot)) >> 16);
-      if (cost < best_cost) {
+      if (cost < best_cost || bipred) {  // force_mv_bootstrap
 #pragma unroll
         for (int i = 0; i < 3; i++) {
           best_mv[i][0] = boot[i][0];
@@ -229,7 +230,7 @@ affine_me_kernel(PlaneView orig, PlaneView ref, int bd, const xvcgpu_affine_me_b
     mv[i][1] = best_mv[i][1];
   }
   uint32_t iterations = 0;
-  for (int iter = 0; iter < 7; iter++) {
+  for (int iter = 0; iter < max_iterations; iter++) {
     int mvd[4];
     affine_gradient_search(w, h, o, os, s, mvd);
     if (!(mvd[0] | mvd[1] | mvd[2] | mvd[3])) break;
@@ -266,7 +267,36 @@ affine_me_kernel(PlaneView orig, PlaneView ref, int bd, const xvcgpu_affine_me_b
     }
     r.dist = (uint32_t)best_dist;
     r.iterations = iterations;
-    out[bi] = r;
+    *out = r;
+  }
+}
+
+// grid: n CUs; block: 64.
+__global__ void __launch_bounds__(64)
+affine_me_kernel(PlaneView orig, PlaneView ref, PlaneView ref_other, int bd,
+                 const xvcgpu_affine_me_block *blocks, int n, xvcgpu_affine_me_result *out) {
+  __shared__ AffineMeShared s;
+  const int bi = blockIdx.x;
+  if (bi >= n) return;
+  const xvcgpu_affine_me_block b = blocks[bi];
+  const uint16_t *o = orig.p + (ptrdiff_t)b.y * orig.stride + b.x;
+  if (b.flags & XVC_AFFINE_ME_BIPRED) {
+    // SearchBiIterative :415-420: the other list's prediction, SubtractWeighted
+    int other[3][2];
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+      other[i][0] = b.other_mv[i][0];
+      other[i][1] = b.other_mv[i][1];
+    }
+    affine_me_mc(bd, b.x, b.y, b.w, b.h, ref_other, other, s);
+    const int w = b.w, lw = 31 - __clz(w);
+    for (int i = ME2_LANE; i < w * b.h; i += 64)
+      s.target[i] = (int16_t)(2 * (int)o[(ptrdiff_t)(i >> lw) * orig.stride + (i & (w - 1))] -
+                              (int)s.pred[i]);
+    wave_sync();
+    affine_me_search<int16_t>(bd, b, ref, s.target, w, s, out + bi);
+  } else {
+    affine_me_search<uint16_t>(bd, b, ref, o, (int)orig.stride, s, out + bi);
   }
 }
 

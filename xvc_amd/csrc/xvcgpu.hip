@@ -1202,16 +1202,19 @@ xvcgpu_status xvcgpu_frame_pass(xvcgpu_ctx *ctx, const xvcgpu_frame_pass_args *a
 
 xvcgpu_status xvcgpu_affine_me_batch(xvcgpu_ctx *ctx, const xvcgpu_picture *orig,
                                      const xvcgpu_picture *ref,
+                                     const xvcgpu_picture *ref_other,
                                      const xvcgpu_affine_me_block *d_blocks, int n,
                                      xvcgpu_affine_me_result *d_results) {
   if (!ctx || !orig || !ref || n < 0 || (n && (!d_blocks || !d_results)))
     return XVCGPU_INVALID_ARGUMENT;
+  if (!ref_other) ref_other = ref;
   if (orig->v.bd != ref->v.bd || orig->v.c[0].w != ref->v.c[0].w ||
-      orig->v.c[0].h != ref->v.c[0].h)
+      orig->v.c[0].h != ref->v.c[0].h || ref_other->v.bd != ref->v.bd ||
+      ref_other->v.c[0].w != ref->v.c[0].w || ref_other->v.c[0].h != ref->v.c[0].h)
     return XVCGPU_INVALID_ARGUMENT;
   if (n == 0) return XVCGPU_OK;
   hipLaunchKernelGGL(affine_me_kernel, dim3(n), dim3(64), 0, ctx->stream, orig->v.c[0],
-                     ref->v.c[0], ref->v.bd, d_blocks, n, d_results);
+                     ref->v.c[0], ref_other->v.c[0], ref->v.bd, d_blocks, n, d_results);
   CHECK_LAUNCH(ctx, "affine_me_batch");
   return XVCGPU_OK;
 }
