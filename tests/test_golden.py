@@ -320,6 +320,32 @@ def test_oracle_lic(xo):
         assert np.array_equal(got[y:y + h, x:x + w], exp[:h, :w]), j
 
 
+def _affine_me_cases(g):
+    """(blocks, mv, dist, orig, ref, other) per content, planes re-padded to the
+    128-sample border (80 kept: far vectors clip inside that)."""
+    for k in range(2):
+        pad = lambda a, kept: np.ascontiguousarray(np.pad(a, BL - kept, mode="edge"))
+        yield (g["c%d_blocks" % k], g["c%d_mv" % k], g["c%d_dist" % k],
+               pad(g["c%d_orig" % k], 0), pad(g["c%d_ref" % k], 80), pad(g["c%d_other" % k], 80))
+
+
+def test_oracle_affine_me(xo):
+    """MotionEstAffine / AffineGradientSearch vectors of the reference."""
+    import oracle_affine_me as oa
+    g = load("affine_me")
+    n = 0
+    for blocks, mv, dist, orig, ref, other in _affine_me_cases(g):
+        ph, pw = orig.shape[0] - 2 * BL, orig.shape[1] - 2 * BL
+        for b, m, d in zip(blocks, mv, dist):
+            got = oa.affine_me(xo, 10, b, pw, ph, orig, ref, BL, other)
+            assert np.array_equal(got["mv"], m) and got["dist"] == d, b
+            n += not np.array_equal(m, b["mvp"])
+    assert n > 40
+    for pred, err, rec in zip(g["gs_pred"], g["gs_err"], g["gs_mvd"]):
+        w, h = int(rec[0]), int(rec[1])
+        assert oa.gradient_search(xo, 10, pred[:h, :w], err[:h, :w]) == rec[2:].tolist()
+
+
 # ------------------------------------------------------------------------ GPU
 @pytest.fixture(scope="module")
 def gpu():
@@ -606,3 +632,21 @@ def test_gpu_lic(gpu):
         assert np.array_equal(P.download()[c][y:y + h, x:x + w], exp[:h, :w]), j
     for p in (R, C_, P):
         p.destroy()
+
+
+@pytest.mark.gpu
+def test_gpu_affine_me(gpu):
+    api, ctx = gpu
+    g = load("affine_me")
+    for blocks, mv, dist, orig, ref, other in _affine_me_cases(g):
+        ph, pw = orig.shape[0] - 2 * BL, orig.shape[1] - 2 * BL
+        pics = []
+        for luma in (orig, ref, other):
+            chroma = np.full((ph // 2 + 2 * BC, pw // 2 + 2 * BC), 512, np.uint16)
+            p = ctx.picture(pw, ph, 10)
+            p.upload([luma, chroma, chroma], BL)
+            pics.append(p)
+        got = ctx.affine_me_batch(pics[0], pics[1], np.ascontiguousarray(blocks), pics[2])
+        assert np.array_equal(got["mv"], mv) and np.array_equal(got["dist"], dist)
+        for p in pics:
+            p.destroy()

@@ -289,6 +289,45 @@ def gen_lic(xr):
     np.savez_compressed(os.path.join(OUT, "lic.npz"), **out)
 
 
+def gen_affine_me(xr):
+    """affine_me.npz: InterSearch::MotionEstAffine (uni-pred and the bi-pred
+    refinement search) and AffineGradientSearch of the reference on seeded
+    zooming / rotating content."""
+    import oracle_affine_me as oa
+    rng = np.random.default_rng(20261004)
+    bd, pw, ph = 10, 128, 96
+    keep = 80
+    out = {}
+    for k, (zoom, rot, shift) in enumerate([(1.02, 0.0, (1.0, -0.5)), (0.99, 0.012, (0.5, 0.75))]):
+        orig, ref = oa.warped_pics(rng, bd, pw, ph, BL, zoom, rot, shift)
+        _, other = oa.warped_pics(rng, bd, pw, ph, BL, 2 - zoom, -rot, (-shift[0], -shift[1]))
+        blocks = oa.random_blocks(rng, pw, ph, 40, bipred=True)
+        res = np.array([oa.affine_me(xr, bd, b, pw, ph, orig, ref, BL, other) for b in blocks],
+                       oa.RESULT_DTYPE)
+        out["c%d_blocks" % k] = blocks
+        out["c%d_mv" % k] = res["mv"]
+        out["c%d_dist" % k] = res["dist"]
+        out["c%d_orig" % k] = orig[BL:BL + ph, BL:BL + pw]
+        out["c%d_ref" % k] = crop(ref, BL, keep)
+        out["c%d_other" % k] = crop(other, BL, keep)
+    preds, errs, mvds = [], [], []
+    for i in range(24):
+        w, h = int(rng.choice([16, 32, 64])), int(rng.choice([16, 32, 64]))
+        yy, xx = np.mgrid[0:h, 0:w]
+        pred = np.clip((np.sin(xx / 5.0 + i) * np.cos(yy / 7.0) * 0.4 + 0.5) * 1023 +
+                       rng.integers(-3, 4, size=(h, w)), 0, 1023).astype(np.uint16)
+        err = (np.roll(pred.astype(np.int32), 1, axis=i % 2) - pred +
+               rng.integers(-2, 3, size=(h, w))).astype(np.int16)
+        pp, ee = np.zeros((64, 64), np.uint16), np.zeros((64, 64), np.int16)
+        pp[:h, :w], ee[:h, :w] = pred, err
+        preds.append(pp)
+        errs.append(ee)
+        mvds.append([w, h] + oa.gradient_search(xr, bd, pred, err))
+    out["gs_pred"], out["gs_err"], out["gs_mvd"] = np.array(preds), np.array(errs), \
+        np.array(mvds, np.int32)
+    np.savez_compressed(os.path.join(OUT, "affine_me.npz"), **out)
+
+
 def gen_frame(xr):
     """frame.npz: the hot-path frame pass run by the reference's own classes
     (ref_harness.cc xr_frame_pass) on three chained 136x72 synthetic pictures
@@ -346,6 +385,10 @@ def main():
         return
     if sys.argv[1:] == ["lic"]:
         gen_lic(xr)
+        write_manifest()
+        return
+    if sys.argv[1:] == ["affine_me"]:
+        gen_affine_me(xr)
         write_manifest()
         return
     if sys.argv[1:] == ["frame"]:

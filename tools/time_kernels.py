@@ -19,7 +19,7 @@ def timed(fn, reps=50):
     fn(); ctx.sync(); ctx.timer_begin()
     for _ in range(reps): fn()
     return 1e3 * ctx.timer_end() / reps
-which = sys.argv[1:] or ["me", "recon", "deblock", "pad", "ssd", "import8", "export8", "export8d", "crc", "variance", "histogram", "intra_satd", "intra_pred"]
+which = sys.argv[1:] or ["me", "recon", "deblock", "pad", "ssd", "import8", "export8", "export8d", "crc", "variance", "histogram", "intra_satd", "intra_pred", "affine_me16", "affine_me32", "affine_me64"]
 fns = {
     "me": lambda: ctx.me_search_dev(O, R, 3, fp.d_me.ptr, d.n_cus, fp.d_res.ptr, 16),
     "recon": lambda: ctx.recon_from_me_dev(O, R, Rec, fp.d_me.ptr, fp.d_res.ptr, d.n_cus, d.qp, d.qp_c, 0, fp.d_nnz.ptr, fp.d_cus_own),
@@ -52,11 +52,35 @@ fns.update({
     "intra_satd": lambda: lib.xvcgpu_intra_satd_batch(ctx.h, O.h_pic, R.h_pic, d_ij.ptr, len(ij), d_id.ptr, 16),
     "intra_pred": lambda: lib.xvcgpu_intra_pred_batch(ctx.h, R.h_pic, Rec.h_pic, d_ij.ptr, len(ij)),
 })
+# affine ME over the whole picture in CUs of one size, the predictor = the
+# translational search result of the co-located 16x16 CU (as SearchRefIdx's
+# mv_bootstrap does)
+res = fp.d_res.to_array(api.MERES_DTYPE, d.n_cus)
+def affine_jobs(cu):
+    jobs = np.zeros((H // cu) * (W // cu), api.AFFINE_ME_DTYPE)
+    k = 0
+    for y in range(0, H - cu + 1, cu):
+        for x in range(0, W - cu + 1, cu):
+            b = jobs[k]
+            b["x"], b["y"], b["w"], b["h"] = x, y, cu, cu
+            b["lambda16"] = 200000
+            if res is not None:
+                r = res[(y // 16) * d.cus_per_row + x // 16]
+                b["mvp"][:] = (int(r["mv_x"]), int(r["mv_y"]))
+            k += 1
+    return jobs[:k]
+d_ar = ctx.alloc(api.AFFINE_ME_RESULT_DTYPE.itemsize * (H // 16) * (W // 16))
+for cu in (16, 32, 64):
+    aj = affine_jobs(cu)
+    d_aj = ctx.buffer(aj)
+    fns["affine_me%d" % cu] = (lambda d_aj=d_aj, n=len(aj): lib.xvcgpu_affine_me_batch(
+        ctx.h, O.h_pic, R.h_pic, None, d_aj.ptr, n, d_ar.ptr))
 N = W * H
 alg = {"me": 4 * N, "recon": 9 * N + 16 * N // 16, "deblock": 6 * N + N,
        "pad": 2 * (2 * 128 * (W + H + 256) + 4 * 64 * (W // 2 + H // 2 + 128)), "ssd": 4 * N,
        "import8": 1.5 * N * 3, "export8": 1.5 * N * 3, "export8d": 1.5 * N * 3, "crc": 3 * N,
-       "variance": 2 * N, "histogram": 4 * N, "intra_satd": 4 * N, "intra_pred": 4 * N}
+       "variance": 2 * N, "histogram": 4 * N, "intra_satd": 4 * N, "intra_pred": 4 * N,
+       "affine_me16": 4 * N, "affine_me32": 4 * N, "affine_me64": 4 * N}
 for k in which:
     us = timed(fns[k])
     print("%-8s %8.2f us  %7.0f GB/s algorithmic" % (k, us, alg[k] / us / 1e3))

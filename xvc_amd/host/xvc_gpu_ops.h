@@ -181,6 +181,20 @@ class InterSearch {
                                     static_cast<int>(jobs.size()), r.data(), 64));
     return r.ToHost();
   }
+  // InterSearch::MotionEstAffine (inter_search.cc:664-749) per job: the gradient
+  // iteration from the affine predictor / bootstrap vector on ref_pic; jobs
+  // with XVC_AFFINE_ME_BIPRED search against 2 * orig - the other list's affine
+  // prediction from ref_other (pass ref_pic when no job has the flag).
+  std::vector<xvcgpu_affine_me_result> MotionEstAffineBatch(
+      const Picture &orig_pic, const Picture &ref_pic, const Picture &ref_other,
+      const std::vector<xvcgpu_affine_me_block> &jobs) const {
+    DeviceArray<xvcgpu_affine_me_block> d(ctx_, jobs);
+    DeviceArray<xvcgpu_affine_me_result> r(ctx_, jobs.size());
+    ctx_.Check(xvcgpu_affine_me_batch(ctx_.get(), orig_pic.get(), ref_pic.get(),
+                                      ref_other.get(), d.data(),
+                                      static_cast<int>(jobs.size()), r.data()));
+    return r.ToHost();
+  }
 
  private:
   const Context &ctx_;
