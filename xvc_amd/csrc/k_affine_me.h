@@ -17,18 +17,29 @@
 
 #include "k_bipred.h"
 
+// NW = h / 16 waves per CU: every wave owns a 16-row slab of the block for the
+// plain-MC case, the distortions and the gradient sums, and a share of the
+// sub-blocks of the affine MC; the vectors, costs and the elimination are
+// carried redundantly (and identically) by all lanes.
+template <int NW>
 struct __attribute__((aligned(16))) AffineMeShared {
-  int16_t tmp[64 * 71];   // separable filter intermediate (whole block or sub-block)
-  uint16_t sub[16 * 64];  // one sub-block's prediction
-  uint16_t pred[64 * 64]; // the CU's prediction, row stride w
-  int16_t target[64 * 64]; // bi-pred: 2 * orig - the other list's prediction
+  struct {
+    int16_t tmp[64 * 23];   // filter intermediate: a 64x16 slab or a 16x64 sub-block
+    uint16_t sub[16 * 64];  // one sub-block's prediction
+  } wv[NW];
+  uint16_t pred[64 * 64];   // the CU's prediction, row stride w
+  int16_t target[64 * 64];  // bi-pred: 2 * orig - the other list's prediction
+  long long part[NW][14];   // per-wave partial sums of the normal equations
+  unsigned long long dpart[NW];
 };
 
 // InterPrediction::MotionCompAffine (inter_prediction.cc:1044-1136), luma, into
-// s.pred; the sub-blocks one after the other by the one wave.
+// s.pred.
+template <int NW>
 __device__ __forceinline__ void affine_me_mc(int bd, int bx, int by, int w, int h,
                                              const PlaneView &pr, const int mvin[3][2],
-                                             AffineMeShared &s) {
+                                             AffineMeShared<NW> &s) {
+  const int wave = threadIdx.x >> 6;
   int mv[3][2];
 #pragma unroll
   for (int i = 0; i < 3; i++) {
@@ -36,13 +47,14 @@ __device__ __forceinline__ void affine_me_mc(int bd, int bx, int by, int w, int 
     mv[i][1] = mvin[i][1];
     d_clip_mv(bx, by, pr.w, pr.h, mv[i][0], mv[i][1]);
   }
-  wave_sync();  // earlier readers of s.pred are done
+  __syncthreads();  // earlier readers of s.pred are done
   if (mv[0][0] == mv[1][0] && mv[0][1] == mv[1][1]) {
-    const uint16_t *r =
-        pr.p + (ptrdiff_t)(by + (mv[0][1] >> 4)) * pr.stride + bx + (mv[0][0] >> 4);
-    wave_interp_block<false>(bd, w, h, mv[0][0] & 15, mv[0][1] & 15, r, pr.stride, s.tmp,
-                             s.pred);
-    wave_sync();
+    // plain MC: the wave's 16-row slab as a block of its own
+    const uint16_t *r = pr.p + (ptrdiff_t)(by + wave * 16 + (mv[0][1] >> 4)) * pr.stride + bx +
+                        (mv[0][0] >> 4);
+    wave_interp_block<false>(bd, w, 16, mv[0][0] & 15, mv[0][1] & 15, r, pr.stride,
+                             s.wv[wave].tmp, s.pred + wave * 16 * w);
+    __syncthreads();
     return;
   }
   const int sbw = d_affine_subblock(mv[0][0], mv[0][1], mv[1][0], mv[1][1], w, 0);
@@ -54,7 +66,7 @@ __device__ __forceinline__ void affine_me_mc(int bd, int bx, int by, int w, int 
   const int dvx = -dhy, dvy = dhx;
   const int nsx = w / sbw, nsy = h / sbh;
   const int lane = ME2_LANE, lsw = 31 - __clz(sbw);
-  for (int k = 0; k < nsx * nsy; k++) {
+  for (int k = wave; k < nsx * nsy; k += NW) {
     const int iy = k / nsx, ix = k - iy * nsx;
     const int hor_x = mv[0][0] * 256 + dvx * sbh * iy + dhx * sbw * ix;
     const int hor_y = mv[0][1] * 256 + dvy * sbh * iy + dhy * sbw * ix;
@@ -65,12 +77,43 @@ __device__ __forceinline__ void affine_me_mc(int bd, int bx, int by, int w, int 
     const int sx = ix * sbw, sy = iy * sbh;
     const uint16_t *r =
         pr.p + (ptrdiff_t)(by + sy + (my >> 4)) * pr.stride + bx + sx + (mx >> 4);
-    wave_interp_block<false>(bd, sbw, sbh, mx & 15, my & 15, r, pr.stride, s.tmp, s.sub);
+    wave_interp_block<false>(bd, sbw, sbh, mx & 15, my & 15, r, pr.stride, s.wv[wave].tmp,
+                             s.wv[wave].sub);
     wave_sync();
     uint16_t *o = s.pred + sy * w + sx;
-    for (int i = lane; i < sbw * sbh; i += 64) o[(i >> lsw) * w + (i & (sbw - 1))] = s.sub[i];
+    for (int i = lane; i < sbw * sbh; i += 64)
+      o[(i >> lsw) * w + (i & (sbw - 1))] = s.wv[wave].sub[i];
     wave_sync();
   }
+  __syncthreads();
+}
+
+// SampleMetric::CompareSample with kSad / kSatd over the whole block: the
+// waves' slab parts summed, then the bit-depth normalisation of Compare().
+template <int NW, typename TOrig>
+__device__ __forceinline__ uint64_t affine_me_dist(int metric, int bd, int w, int h,
+                                                   const TOrig *o, int os,
+                                                   AffineMeShared<NW> &s) {
+  const int wave = threadIdx.x >> 6;
+  const TOrig *oo = o + (ptrdiff_t)wave * 16 * os;
+  const uint16_t *pp = s.pred + wave * 16 * w;
+  uint64_t part;
+  if (metric == XVC_METRIC_SAD)
+    part = (uint64_t)(int64_t)wave_sad(w, 16, 1, oo, os, pp, w);
+  else if (w == h)
+    part = wave_satd_tiles<8, 8>(w, 16, 0, oo, os, pp, w);
+  else if (w > h)
+    part = wave_satd_tiles<16, 8>(w, 16, 0, oo, os, pp, w);
+  else
+    part = wave_satd_tiles<8, 16>(w, 16, 0, oo, os, pp, w);
+  if (NW == 1) return part >> (bd - 8);
+  s.dpart[wave] = part;
+  __syncthreads();
+  uint64_t total = 0;
+#pragma unroll
+  for (int k = 0; k < NW; k++) total += s.dpart[k];
+  __syncthreads();
+  return total >> (bd - 8);
 }
 
 // ::lround into MvDelta's int members as the reference's x86-64 build does it:
@@ -134,17 +177,17 @@ __device__ __noinline__ void affine_solve(const long long S[10], const long long
 }
 
 // AffineGradientSearch on the prediction in s.pred and err = orig - pred.
-template <typename TOrig>
+template <int NW, typename TOrig>
 __device__ __forceinline__ void affine_gradient_search(int w, int h, const TOrig *o,
-                                                       int os, const AffineMeShared &s,
+                                                       int os, AffineMeShared<NW> &s,
                                                        int mvd[4]) {
-  const int lane = ME2_LANE, lw = 31 - __clz(w);
+  const int lane = ME2_LANE, wave = threadIdx.x >> 6, lw = 31 - __clz(w);
   long long S[10], R[4];
 #pragma unroll
   for (int k = 0; k < 10; k++) S[k] = 0;
 #pragma unroll
   for (int k = 0; k < 4; k++) R[k] = 0;
-  for (int i = lane; i < w * h; i += 64) {
+  for (int i = wave * 16 * w + lane; i < (wave + 1) * 16 * w; i += 64) {
     const int x = i & (w - 1), y = i >> lw;
     // border gradients are copies of the nearest interior one (:772-783)
     const int xc = d_clip3(x, 1, w - 2), yc = d_clip3(y, 1, h - 2);
@@ -169,14 +212,36 @@ __device__ __forceinline__ void affine_gradient_search(int w, int h, const TOrig
   for (int k = 0; k < 10; k++) S[k] = group_sum<64>(S[k]);
 #pragma unroll
   for (int k = 0; k < 4; k++) R[k] = group_sum<64>(R[k]);
+  if (NW > 1) {
+    if (lane == 0) {
+#pragma unroll
+      for (int k = 0; k < 10; k++) s.part[wave][k] = S[k];
+#pragma unroll
+      for (int k = 0; k < 4; k++) s.part[wave][10 + k] = R[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 10; k++) {
+      S[k] = 0;
+#pragma unroll
+      for (int v = 0; v < NW; v++) S[k] += s.part[v][k];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      R[k] = 0;
+#pragma unroll
+      for (int v = 0; v < NW; v++) R[k] += s.part[v][10 + k];
+    }
+    __syncthreads();
+  }
   affine_solve(S, R, w, mvd);
 }
 
 // The search proper on a target of samples (uni) or residuals (bi).
-template <typename TOrig>
+template <int NW, typename TOrig>
 __device__ __forceinline__ void affine_me_search(int bd, const xvcgpu_affine_me_block &b,
                                                  const PlaneView &ref, const TOrig *o, int os,
-                                                 AffineMeShared &s,
+                                                 AffineMeShared<NW> &s,
                                                  xvcgpu_affine_me_result *out) {
   const int w = b.w, h = b.h, bx = b.x, by = b.y;
   const uint32_t lambda = b.lambda16;
@@ -193,7 +258,7 @@ __device__ __forceinline__ void affine_me_search(int bd, const xvcgpu_affine_me_
            d_mvd_bits(mvp[1][0], mvp[1][1], v[1][0], v[1][1], 0);
   };
   auto dist_of = [&](int metric) -> uint64_t {
-    return wave_compare(metric, bd, 0, 0, w, h, o, os, s.pred, w) >> bi_shift;
+    return affine_me_dist(metric, bd, w, h, o, os, s) >> bi_shift;
   };
   affine_me_mc(bd, bx, by, w, h, ref, mvp, s);
   uint64_t best_dist = dist_of(XVC_METRIC_SAD);
@@ -258,7 +323,7 @@ __device__ __forceinline__ void affine_me_search(int bd, const xvcgpu_affine_me_
       }
     }
   }
-  if (ME2_LANE == 0) {
+  if (threadIdx.x == 0) {
     xvcgpu_affine_me_result r;
 #pragma unroll
     for (int i = 0; i < 3; i++) {
@@ -271,14 +336,17 @@ __device__ __forceinline__ void affine_me_search(int bd, const xvcgpu_affine_me_
   }
 }
 
-// grid: n CUs; block: 64.
-__global__ void __launch_bounds__(64)
+// grid: n CUs; block: 64 * NW.  The instance with NW waves takes the jobs
+// whose height is 16 * NW and leaves the others to its siblings.
+template <int NW>
+__global__ void __launch_bounds__(64 * NW)
 affine_me_kernel(PlaneView orig, PlaneView ref, PlaneView ref_other, int bd,
                  const xvcgpu_affine_me_block *blocks, int n, xvcgpu_affine_me_result *out) {
-  __shared__ AffineMeShared s;
+  __shared__ AffineMeShared<NW> s;
   const int bi = blockIdx.x;
   if (bi >= n) return;
   const xvcgpu_affine_me_block b = blocks[bi];
+  if (b.h != 16 * NW) return;
   const uint16_t *o = orig.p + (ptrdiff_t)b.y * orig.stride + b.x;
   if (b.flags & XVC_AFFINE_ME_BIPRED) {
     // SearchBiIterative :415-420: the other list's prediction, SubtractWeighted
@@ -290,13 +358,13 @@ affine_me_kernel(PlaneView orig, PlaneView ref, PlaneView ref_other, int bd,
     }
     affine_me_mc(bd, b.x, b.y, b.w, b.h, ref_other, other, s);
     const int w = b.w, lw = 31 - __clz(w);
-    for (int i = ME2_LANE; i < w * b.h; i += 64)
+    for (int i = threadIdx.x; i < w * b.h; i += 64 * NW)
       s.target[i] = (int16_t)(2 * (int)o[(ptrdiff_t)(i >> lw) * orig.stride + (i & (w - 1))] -
                               (int)s.pred[i]);
-    wave_sync();
-    affine_me_search<int16_t>(bd, b, ref, s.target, w, s, out + bi);
+    __syncthreads();
+    affine_me_search<NW, int16_t>(bd, b, ref, s.target, w, s, out + bi);
   } else {
-    affine_me_search<uint16_t>(bd, b, ref, o, (int)orig.stride, s, out + bi);
+    affine_me_search<NW, uint16_t>(bd, b, ref, o, (int)orig.stride, s, out + bi);
   }
 }
 

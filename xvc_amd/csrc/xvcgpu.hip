@@ -1213,7 +1213,12 @@ xvcgpu_status xvcgpu_affine_me_batch(xvcgpu_ctx *ctx, const xvcgpu_picture *orig
       ref_other->v.c[0].w != ref->v.c[0].w || ref_other->v.c[0].h != ref->v.c[0].h)
     return XVCGPU_INVALID_ARGUMENT;
   if (n == 0) return XVCGPU_OK;
-  hipLaunchKernelGGL(affine_me_kernel, dim3(n), dim3(64), 0, ctx->stream, orig->v.c[0],
+  // one instance per CU height (16 rows of the block per wave)
+  hipLaunchKernelGGL(affine_me_kernel<1>, dim3(n), dim3(64), 0, ctx->stream, orig->v.c[0],
+                     ref->v.c[0], ref_other->v.c[0], ref->v.bd, d_blocks, n, d_results);
+  hipLaunchKernelGGL(affine_me_kernel<2>, dim3(n), dim3(128), 0, ctx->stream, orig->v.c[0],
+                     ref->v.c[0], ref_other->v.c[0], ref->v.bd, d_blocks, n, d_results);
+  hipLaunchKernelGGL(affine_me_kernel<4>, dim3(n), dim3(256), 0, ctx->stream, orig->v.c[0],
                      ref->v.c[0], ref_other->v.c[0], ref->v.bd, d_blocks, n, d_results);
   CHECK_LAUNCH(ctx, "affine_me_batch");
   return XVCGPU_OK;
