@@ -90,7 +90,9 @@ class _PackedPlan:
                 pieces.append((t, total, t.numel()))
                 total += n
                 splits[peer] += n
-        buf = torch.zeros(total, dtype=torch.uint8, device=dev)
+        # empty, not zeros: a fill kernel on torch's current stream could race
+        # with the pack kernel on the engine's stream (padding bytes are never read)
+        buf = torch.empty(total, dtype=torch.uint8, device=dev)
         return buf, splits, [(t, buf[off:off + n]) for t, off, n in pieces]
 
     def segment(self, buf, splits, peer):
@@ -428,7 +430,7 @@ class GpuEngine:
         for i, (src, dst) in enumerate(pairs):
             assert src.numel() == dst.numel() or dst.numel() >= src.numel()
             segs[i] = (src.data_ptr(), dst.data_ptr(), src.numel() * src.element_size())
-        d_segs = self.torch.zeros(max(1, segs.nbytes), dtype=self.torch.uint8,
+        d_segs = self.torch.empty(max(1, segs.nbytes), dtype=self.torch.uint8,
                                   device=self.mem[0].device)
         self.ctx.h2d(d_segs.data_ptr(), segs)
         ctx, n, keep = self.ctx, len(pairs), (d_segs, pairs)
