@@ -23,12 +23,12 @@
 // carried redundantly (and identically) by all lanes.
 template <int NW>
 struct __attribute__((aligned(16))) AffineMeShared {
-  struct {
-    int16_t tmp[64 * 23];   // filter intermediate: a 64x16 slab or a 16x64 sub-block
-    uint16_t sub[16 * 64];  // one sub-block's prediction
-  } wv[NW];
-  uint16_t pred[64 * 64];   // the CU's prediction, row stride w
-  int16_t target[64 * 64];  // bi-pred: 2 * orig - the other list's prediction
+  // filter intermediates: per wave a 64x16 slab (plain MC: 64 x 23), or for all
+  // sub-blocks of the CU together (w x h x (sbh + 7) / sbh <= 2.75 w h)
+  int16_t tmp[NW * 16 * 64 * 11 / 4];
+  int sbmv[NW * 64][2];          // clipped vector of each (>= 4x4) sub-block
+  uint16_t pred[NW * 16 * 64];   // the CU's prediction, row stride w
+  int16_t target[NW * 16 * 64];  // bi-pred: 2 * orig - the other list's prediction
   long long part[NW][14];   // per-wave partial sums of the normal equations
   unsigned long long dpart[NW];
 };
@@ -53,37 +53,88 @@ __device__ __forceinline__ void affine_me_mc(int bd, int bx, int by, int w, int 
     const uint16_t *r = pr.p + (ptrdiff_t)(by + wave * 16 + (mv[0][1] >> 4)) * pr.stride + bx +
                         (mv[0][0] >> 4);
     wave_interp_block<false>(bd, w, 16, mv[0][0] & 15, mv[0][1] & 15, r, pr.stride,
-                             s.wv[wave].tmp, s.pred + wave * 16 * w);
+                             s.tmp + wave * (16 * 64 * 11 / 4), s.pred + wave * 16 * w);
     __syncthreads();
     return;
   }
+  // All sub-blocks at once (they are 4x4 ... 16x16: one at a time would leave
+  // most of a wave idle): the arithmetic per sample is MotionCompUniPred's
+  // (wave_interp_block), with the sub-block's own phase.
   const int sbw = d_affine_subblock(mv[0][0], mv[0][1], mv[1][0], mv[1][1], w, 0);
   const int sbh = d_affine_subblock(mv[0][0], mv[0][1], mv[2][0], mv[2][1], h, 0);
-  const int mv_max_x = (pr.w - bx + 8 - 1) * 16, mv_min_x = (-64 - bx - 8 + 1) * 16;
-  const int mv_max_y = (pr.h - by + 8 - 1) * 16, mv_min_y = (-64 - by - 8 + 1) * 16;
-  const int dhx = ((mv[1][0] - mv[0][0]) * 256) / w;
-  const int dhy = ((mv[1][1] - mv[0][1]) * 256) / w;
-  const int dvx = -dhy, dvy = dhx;
-  const int nsx = w / sbw, nsy = h / sbh;
-  const int lane = ME2_LANE, lsw = 31 - __clz(sbw);
-  for (int k = wave; k < nsx * nsy; k += NW) {
-    const int iy = k / nsx, ix = k - iy * nsx;
-    const int hor_x = mv[0][0] * 256 + dvx * sbh * iy + dhx * sbw * ix;
-    const int hor_y = mv[0][1] * 256 + dvy * sbh * iy + dhy * sbw * ix;
-    int mx = (hor_x + dhx * (sbw >> 1) + dvx * (sbh >> 1)) >> 8;
-    int my = (hor_y + dhy * (sbw >> 1) + dvy * (sbh >> 1)) >> 8;
-    mx = d_clip3(mx, mv_min_x, mv_max_x);
-    my = d_clip3(my, mv_min_y, mv_max_y);
-    const int sx = ix * sbw, sy = iy * sbh;
-    const uint16_t *r =
-        pr.p + (ptrdiff_t)(by + sy + (my >> 4)) * pr.stride + bx + sx + (mx >> 4);
-    wave_interp_block<false>(bd, sbw, sbh, mx & 15, my & 15, r, pr.stride, s.wv[wave].tmp,
-                             s.wv[wave].sub);
-    wave_sync();
-    uint16_t *o = s.pred + sy * w + sx;
-    for (int i = lane; i < sbw * sbh; i += 64)
-      o[(i >> lsw) * w + (i & (sbw - 1))] = s.wv[wave].sub[i];
-    wave_sync();
+  const int nsx = w / sbw, nsy = h / sbh, n_sub = nsx * nsy;
+  const int lsw = 31 - __clz(sbw), lsh = 31 - __clz(sbh), lnx = 31 - __clz(nsx);
+  const int T = 64 * NW, tid = threadIdx.x;
+  {
+    const int mv_max_x = (pr.w - bx + 8 - 1) * 16, mv_min_x = (-64 - bx - 8 + 1) * 16;
+    const int mv_max_y = (pr.h - by + 8 - 1) * 16, mv_min_y = (-64 - by - 8 + 1) * 16;
+    const int dhx = ((mv[1][0] - mv[0][0]) * 256) / w;
+    const int dhy = ((mv[1][1] - mv[0][1]) * 256) / w;
+    const int dvx = -dhy, dvy = dhx;
+    for (int k = tid; k < n_sub; k += T) {
+      const int iy = k >> lnx, ix = k & (nsx - 1);
+      const int hor_x = mv[0][0] * 256 + dvx * sbh * iy + dhx * sbw * ix;
+      const int hor_y = mv[0][1] * 256 + dvy * sbh * iy + dhy * sbw * ix;
+      const int mx = (hor_x + dhx * (sbw >> 1) + dvx * (sbh >> 1)) >> 8;
+      const int my = (hor_y + dhy * (sbw >> 1) + dvy * (sbh >> 1)) >> 8;
+      s.sbmv[k][0] = d_clip3(mx, mv_min_x, mv_max_x);
+      s.sbmv[k][1] = d_clip3(my, mv_min_y, mv_max_y);
+    }
+  }
+  __syncthreads();
+  const int rows = sbh + 7;  // intermediate rows of a sub-block
+  {
+    // horizontal pass of the sub-blocks with a fractional phase in both directions
+    const int shift = 6 - (14 - bd), offset = -(8192 << shift);
+    for (int j = tid; j < rows * n_sub * sbw; j += T) {
+      const int c = j & (sbw - 1), k = (j >> lsw) & (n_sub - 1), r = j >> (lsw + lnx + (31 - __clz(nsy)));
+      const int mx = s.sbmv[k][0], my = s.sbmv[k][1];
+      if (!(mx & 15) || !(my & 15)) continue;
+      const int sx = (k & (nsx - 1)) << lsw, sy = (k >> lnx) << lsh;
+      const uint16_t *p = pr.p + (ptrdiff_t)(by + sy + (my >> 4) + r - 3) * pr.stride + bx + sx +
+                          (mx >> 4) + c - 3;
+      const int16_t *fh = kLumaTaps[mx & 15];
+      int sum = 0;
+#pragma unroll
+      for (int t = 0; t < 8; t++) sum += (int)p[t] * fh[t];
+      s.tmp[(k * rows + r) * sbw + c] = (int16_t)((sum + offset) >> shift);
+    }
+  }
+  __syncthreads();
+  {
+    const int smax = (1 << bd) - 1, lw = 31 - __clz(w);
+    const int shift2 = 6 + (14 - bd), offset2 = (8192 << 6) + (1 << (shift2 - 1));
+    for (int i = tid; i < w * h; i += T) {
+      const int x = i & (w - 1), y = i >> lw;
+      const int k = ((y >> lsh) << lnx) + (x >> lsw), c = x & (sbw - 1), r = y & (sbh - 1);
+      const int mx = s.sbmv[k][0], my = s.sbmv[k][1];
+      const int fx = mx & 15, fy = my & 15;
+      const uint16_t *p = pr.p + (ptrdiff_t)(by + y + (my >> 4)) * pr.stride + bx + x + (mx >> 4);
+      int v;
+      if (fx == 0 && fy == 0) {
+        v = p[0];
+      } else if (fy == 0) {
+        const int16_t *fh = kLumaTaps[fx];
+        int sum = 0;
+#pragma unroll
+        for (int t = 0; t < 8; t++) sum += (int)p[t - 3] * fh[t];
+        v = d_clip_bd((sum + 32) >> 6, smax);
+      } else if (fx == 0) {
+        const int16_t *fv = kLumaTaps[fy];
+        int sum = 0;
+#pragma unroll
+        for (int t = 0; t < 8; t++) sum += (int)p[(ptrdiff_t)(t - 3) * pr.stride] * fv[t];
+        v = d_clip_bd((int16_t)((sum + 32) >> 6), smax);
+      } else {
+        const int16_t *fv = kLumaTaps[fy];
+        const int16_t *q = s.tmp + (k * rows + r) * sbw + c;
+        int sum = 0;
+#pragma unroll
+        for (int t = 0; t < 8; t++) sum += (int)q[t * sbw] * fv[t];
+        v = d_clip_bd((int16_t)((sum + offset2) >> shift2), smax);
+      }
+      s.pred[i] = (uint16_t)v;
+    }
   }
   __syncthreads();
 }
@@ -197,15 +248,15 @@ __device__ __forceinline__ void affine_gradient_search(int w, int h, const TOrig
     const int c0 = p[w - 1], c1 = p[w], c2 = p[w + 1];
     const int kh = -a0 + a2 - 2 * b0 + 2 * b2 - c0 + c2;  // 8 * affine_delta_hor_
     const int kv = -a0 - 2 * a1 - a2 + c0 + 2 * c1 + c2;  // 8 * affine_delta_ver_
-    const long long c[4] = {kh, (long long)x * kh + (long long)y * kv, kv,
-                            (long long)y * kh - (long long)x * kv};
-    const long long e = (int)o[(ptrdiff_t)y * os + x] - (int)s.pred[i];
+    // |c| < 2^21: 32 x 32 -> 64-bit multiply-adds
+    const int c[4] = {kh, x * kh + y * kv, kv, y * kh - x * kv};
+    const int e = (int)o[(ptrdiff_t)y * os + x] - (int)s.pred[i];
     int k = 0;
 #pragma unroll
     for (int r = 0; r < 4; r++) {
 #pragma unroll
-      for (int cc = r; cc < 4; cc++, k++) S[k] += c[r] * c[cc];
-      R[r] += e * c[r];
+      for (int cc = r; cc < 4; cc++, k++) S[k] += (long long)c[r] * c[cc];
+      R[r] += (long long)e * c[r];
     }
   }
 #pragma unroll
