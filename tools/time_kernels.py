@@ -27,12 +27,13 @@ fns = {
     "pad": lambda: ctx.pad_border(Rec),
     "ssd": lambda: ctx.picture_ssd_dev(O, Rec, 0, bd, fp.d_ssd.ptr),
 }
+Imp = ctx.picture(W, H, bd)   # import target: O stays the original for the kernels after it
 d_in = ctx.alloc(W * H * 3)
 d_out = ctx.alloc(W * H * 3)
 d_small = ctx.alloc(8 * (W // 16 + 1) * (H // 16 + 1) * 2)
 lib = ctx.lib
 fns.update({
-    "import8": lambda: lib.xvcgpu_picture_import(ctx.h, O.h_pic, d_in.ptr, W, H, 8),
+    "import8": lambda: lib.xvcgpu_picture_import(ctx.h, Imp.h_pic, d_in.ptr, W, H, 8),
     "export8": lambda: lib.xvcgpu_picture_export(ctx.h, Rec.h_pic, d_out.ptr, W, H, 8, 0),
     "export8d": lambda: lib.xvcgpu_picture_export(ctx.h, Rec.h_pic, d_out.ptr, W, H, 8, 1),
     "crc": lambda: lib.xvcgpu_picture_crc(ctx.h, Rec.h_pic, 0, d_small.ptr),
