@@ -420,7 +420,7 @@ def main():
         # MI355X_MICROARCH.md prescribes; tools/pmc_traffic.py)
         traffic = None
         try:
-            prof = json.load(open(os.path.join(ROOT, "profiles", "r01_v5_traffic.json")))
+            prof = json.load(open(os.path.join(ROOT, "profiles", "r01_v6_traffic.json")))
             kname = {"me_search": "void me_search_wave_kernel<16, 3>",
                      "recon_from_me": "recon_from_me_kernel",
                      "picture_ssd": "picture_ssd_kernel", "pad_border": "pad_border_kernel",
