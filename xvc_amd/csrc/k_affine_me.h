@@ -177,47 +177,75 @@ __device__ __forceinline__ int affine_lround(double v) {
 // The elimination, back substitution and rounding of AffineGradientSearch
 // (inter_search.cc:805-850) on the exact sums: S = 64 * matrix[r][c] for
 // r <= c in the order 00 01 02 03 11 12 13 22 23 33, R = 8 * matrix[r][4].
+// Lane 5 r + c of the wave holds matrix[r][c]: the updates of one pivot step
+// are independent of each other (each element sees the reference's own
+// multiply, divide, subtract, in that order), so a step costs one division
+// instead of twelve; the back substitution is serial and carried by all lanes.
+__device__ __forceinline__ double affine_lane_f64(double v, int src_lane) {
+  return __shfl(v, src_lane, XVC_WAVE);
+}
+
 __device__ __noinline__ void affine_solve(const long long S[10], const long long R[4],
                                           int width, int mvd[4]) {
 #pragma clang fp contract(off)
-  double m[4][5];
+  const int lane = ME2_LANE;
+  const int r = lane < 20 ? lane / 5 : 0, c = lane < 20 ? lane - 5 * (lane / 5) : 0;
+  double m;
   {
-    int k = 0;
-    for (int r = 0; r < 4; r++)
-      for (int c = r; c < 4; c++, k++) m[r][c] = m[c][r] = (double)S[k] / 64.0;
-    for (int r = 0; r < 4; r++) m[r][4] = (double)R[r] / 8.0;
+    // S index of (min, max): row starts 0, 4, 7, 9
+    const int lo = r < c ? r : c, hi = r < c ? c : r;
+    const int start = lo == 0 ? 0 : (lo == 1 ? 4 : (lo == 2 ? 7 : 9));
+    long long sv = 0;
+#pragma unroll
+    for (int k = 0; k < 10; k++) sv = (c < 4 && k == start + hi - lo) ? S[k] : sv;
+    long long rv = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) rv = k == r ? R[k] : rv;
+    m = c < 4 ? (double)sv / 64.0 : (double)rv / 8.0;
   }
+#pragma unroll
   for (int i = 0; i < 3; i++) {
     int best = i;
-    double best_val = fabs(m[i][i]);
-    for (int j = i + 1; j < 4; j++)
-      if (fabs(m[j][i]) > best_val) {
+    double best_val = fabs(affine_lane_f64(m, 5 * i + i));
+#pragma unroll
+    for (int j = i + 1; j < 4; j++) {
+      const double v = fabs(affine_lane_f64(m, 5 * j + i));
+      if (v > best_val) {
         best = j;
-        best_val = fabs(m[j][i]);
+        best_val = v;
       }
-    if (best != i)
-      for (int col = 0; col < 5; col++) {
-        const double t = m[i][col];
-        m[i][col] = m[best][col];
-        m[best][col] = t;
-      }
-    for (int j = i + 1; j < 4; j++)
-      for (int k = i + 1; k < 5; k++)
-        if (m[i][i] != 0.0) {
-          const double prod = m[i][k] * m[j][i];
-          const double q = prod / m[i][i];
-          m[j][k] = m[j][k] - q;
-        }
+    }
+    // swap rows i and best (uniform decision)
+    {
+      const int other = r == i ? best : (r == best ? i : r);
+      m = affine_lane_f64(m, 5 * other + c);
+    }
+    const double pivot = affine_lane_f64(m, 5 * i + i);
+    const double mik = affine_lane_f64(m, 5 * i + c);
+    const double mji = affine_lane_f64(m, 5 * r + i);
+    if (r > i && c > i && pivot != 0.0) {
+      const double prod = mik * mji;
+      const double q = prod / pivot;
+      m = m - q;
+    }
   }
+  // back substitution, identically on every lane
+  double u[4][5];
+#pragma unroll
+  for (int rr = 0; rr < 4; rr++)
+#pragma unroll
+    for (int cc = rr; cc < 5; cc++) u[rr][cc] = affine_lane_f64(m, 5 * rr + cc);
   double params[4] = {0, 0, 0, 0};
-  if (m[3][3] != 0.0) params[3] = m[3][4] / m[3][3];
+  if (u[3][3] != 0.0) params[3] = u[3][4] / u[3][3];
+#pragma unroll
   for (int row = 2; row >= 0; row--) {
     double sum = 0;
+#pragma unroll
     for (int col = row + 1; col < 4; col++) {
-      const double prod = m[row][col] * params[col];
+      const double prod = u[row][col] * params[col];
       sum = sum + prod;
     }
-    if (m[row][row] != 0.0) params[row] = (m[row][4] - sum) / m[row][row];
+    if (u[row][row] != 0.0) params[row] = (u[row][4] - sum) / u[row][row];
   }
   const double p1w = params[1] * (double)width;
   const double p3w = -params[3] * (double)width;
