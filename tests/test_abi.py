@@ -41,15 +41,20 @@ def test_struct_layouts_match_header(api):
     import oracle_lic
     assert api.INTRA_DTYPE == oracle_intra.INTRA_DTYPE
     assert api.LIC_DTYPE == oracle_lic.LIC_DTYPE
+    import oracle_affine_me
+    assert api.AFFINE_ME_DTYPE == oracle_affine_me.BLOCK_DTYPE
+    assert api.AFFINE_ME_RESULT_DTYPE == oracle_affine_me.RESULT_DTYPE
     src = ("#include <stdio.h>\n#include <stddef.h>\n#include \"xvcgpu.h\"\nint main(){"
-           "printf(\"%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n\", sizeof(xvcgpu_cu_info),"
+           "printf(\"%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n\", sizeof(xvcgpu_cu_info),"
            "sizeof(xvcgpu_me_block), sizeof(xvcgpu_me_result), sizeof(xvcgpu_tx_block),"
            "sizeof(xvcgpu_mc_block), sizeof(xvcgpu_metric_cand),"
            "offsetof(xvcgpu_cu_info, mv), offsetof(xvcgpu_me_block, lambda16),"
            "sizeof(xvcgpu_bi_block), sizeof(xvcgpu_mc_bi_block),"
            "offsetof(xvcgpu_bi_block, boot_mv_x), sizeof(xvcgpu_intra_block),"
            "offsetof(xvcgpu_intra_block, below_left), sizeof(xvcgpu_mc_lic_block),"
-           "offsetof(xvcgpu_mc_lic_block, left_x));return 0;}")
+           "offsetof(xvcgpu_mc_lic_block, left_x), sizeof(xvcgpu_affine_me_block),"
+           "offsetof(xvcgpu_affine_me_block, other_mv), sizeof(xvcgpu_affine_me_result),"
+           "sizeof(xvcgpu_copy_segment), sizeof(xvcgpu_frame_pass_args));return 0;}")
     import subprocess
     import tempfile
     with tempfile.TemporaryDirectory() as d:
@@ -57,7 +62,10 @@ def test_struct_layouts_match_header(api):
         subprocess.check_call(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"),
                                os.path.join(d, "t.c"), "-o", os.path.join(d, "t")])
         out = subprocess.check_output([os.path.join(d, "t")]).decode().split()
-    assert [int(v) for v in out] == [84, 32, 24, 12, 16, 12, 20, 24, 48, 24, 40, 12, 10, 24, 20]
+    assert [int(v) for v in out] == [84, 32, 24, 12, 16, 12, 20, 24, 48, 24, 40, 12, 10, 24, 20,
+                                       api.AFFINE_ME_DTYPE.itemsize, 60, api.AFFINE_ME_RESULT_DTYPE.itemsize,
+                                       api.SEG_DTYPE.itemsize, 144]
+    assert api.AFFINE_ME_DTYPE.itemsize == 84 and api.AFFINE_ME_RESULT_DTYPE.itemsize == 32
 
 
 def test_transform_tables_match_oracle(api):
