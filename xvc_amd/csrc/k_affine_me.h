@@ -29,7 +29,7 @@ struct __attribute__((aligned(16))) AffineMeShared {
   int sbmv[NW * 64][2];          // clipped vector of each (>= 4x4) sub-block
   uint16_t pred[NW * 16 * 64];   // the CU's prediction, row stride w
   int16_t target[NW * 16 * 64];  // bi-pred: 2 * orig - the other list's prediction
-  long long part[NW][14];   // per-wave partial sums of the normal equations
+  long long part[NW][16];   // per-wave partial sums of the normal equations
   unsigned long long dpart[NW];
 };
 
@@ -185,23 +185,34 @@ __device__ __forceinline__ double affine_lane_f64(double v, int src_lane) {
   return __shfl(v, src_lane, XVC_WAVE);
 }
 
-__device__ __noinline__ void affine_solve(const long long S[10], const long long R[4],
+__device__ __forceinline__ int affine_bitrev4(int v) {
+  return ((v & 1) << 3) | ((v & 2) << 1) | ((v & 4) >> 1) | ((v & 8) >> 3);
+}
+
+// `held`: the lane's share of the 14 totals after affine_reduce16 (lane & 15 =
+// bit-reversed index); with several waves the per-wave totals are in `part`.
+template <int NW>
+__device__ __noinline__ void affine_solve(long long held, const long long (*part)[16],
                                           int width, int mvd[4]) {
 #pragma clang fp contract(off)
   const int lane = ME2_LANE;
   const int r = lane < 20 ? lane / 5 : 0, c = lane < 20 ? lane - 5 * (lane / 5) : 0;
   double m;
   {
-    // S index of (min, max): row starts 0, 4, 7, 9
+    // index of matrix[r][c] among the totals: S at (min, max) with row starts
+    // 0, 4, 7, 9; the right-hand side at 10 + r
     const int lo = r < c ? r : c, hi = r < c ? c : r;
     const int start = lo == 0 ? 0 : (lo == 1 ? 4 : (lo == 2 ? 7 : 9));
-    long long sv = 0;
+    const int kk = c < 4 ? start + hi - lo : 10 + r;
+    long long val;
+    if (NW == 1) {
+      val = __shfl(held, affine_bitrev4(kk), XVC_WAVE);
+    } else {
+      val = 0;
 #pragma unroll
-    for (int k = 0; k < 10; k++) sv = (c < 4 && k == start + hi - lo) ? S[k] : sv;
-    long long rv = 0;
-#pragma unroll
-    for (int k = 0; k < 4; k++) rv = k == r ? R[k] : rv;
-    m = c < 4 ? (double)sv / 64.0 : (double)rv / 8.0;
+      for (int v = 0; v < NW; v++) val += part[v][kk];
+    }
+    m = c < 4 ? (double)val / 64.0 : (double)val / 8.0;
   }
 #pragma unroll
   for (int i = 0; i < 3; i++) {
@@ -287,33 +298,32 @@ __device__ __forceinline__ void affine_gradient_search(int w, int h, const TOrig
       R[r] += (long long)e * c[r];
     }
   }
+  // reduce-scatter butterfly: 17 shuffles instead of 84 - after it the lane
+  // whose low four bits are the bit-reversed index k holds total k
+  long long v[16];
 #pragma unroll
-  for (int k = 0; k < 10; k++) S[k] = group_sum<64>(S[k]);
+  for (int k = 0; k < 10; k++) v[k] = S[k];
 #pragma unroll
-  for (int k = 0; k < 4; k++) R[k] = group_sum<64>(R[k]);
+  for (int k = 0; k < 4; k++) v[10 + k] = R[k];
+  v[14] = v[15] = 0;
+#pragma unroll
+  for (int half = 8, bit = 1; half >= 1; half >>= 1, bit <<= 1) {
+    const bool upper = (lane & bit) != 0;
+#pragma unroll
+    for (int j = 0; j < half; j++) {
+      const long long keep = upper ? v[j + half] : v[j];
+      const long long send = upper ? v[j] : v[j + half];
+      v[j] = keep + __shfl_xor(send, bit, XVC_WAVE);
+    }
+  }
+  long long held = v[0];
+  held += __shfl_xor(held, 16, XVC_WAVE);
+  held += __shfl_xor(held, 32, XVC_WAVE);
   if (NW > 1) {
-    if (lane == 0) {
-#pragma unroll
-      for (int k = 0; k < 10; k++) s.part[wave][k] = S[k];
-#pragma unroll
-      for (int k = 0; k < 4; k++) s.part[wave][10 + k] = R[k];
-    }
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < 10; k++) {
-      S[k] = 0;
-#pragma unroll
-      for (int v = 0; v < NW; v++) S[k] += s.part[v][k];
-    }
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-      R[k] = 0;
-#pragma unroll
-      for (int v = 0; v < NW; v++) R[k] += s.part[v][10 + k];
-    }
+    if (lane < 16) s.part[wave][affine_bitrev4(lane)] = held;
     __syncthreads();
   }
-  affine_solve(S, R, w, mvd);
+  affine_solve<NW>(held, s.part, w, mvd);
 }
 
 // The search proper on a target of samples (uni) or residuals (bi).
