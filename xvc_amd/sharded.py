@@ -9,7 +9,7 @@ CU rows (16 luma lines; CTU rows when they divide evenly).  Per picture:
              cross rows) on the own rows
   X1 halo    neighbour ranks swap the 4 luma / 2 chroma rows on each side of
              the shard boundary (pass-0 output) and the metadata of the
-             boundary CU rows - point-to-point, one batched RCCL group
+             boundary CU rows - packed per neighbour, one RCCL all-to-all
   B  local   deblocking pass 1 (horizontal edges) on the own rows plus the
              first edge row of the shard below, computed redundantly by both
              neighbours (SURVEY.md section 8e scheme B: no return traffic).
@@ -19,7 +19,8 @@ CU rows (16 luma lines; CTU rows when they divide evenly).  Per picture:
              reach them: a shard's motion search reads the reference only
              within `reach` luma rows of its own rows (search range + MV clip
              margin + filter taps), so on a tall picture only neighbouring
-             shards exchange rows - not an all-gather
+             shards exchange rows - not an all-gather (packed per peer, one
+             all-to-all whose segments to everybody else are empty)
   C  local   border extension; the PSNR walk over the 64-row blocks that
              START in the own rows (their sum over the ranks is the picture's;
              one all-reduce when the number is wanted, not per picture)
