@@ -16,6 +16,8 @@
 #define XVCGPU_K_AFFINE_ME_H_
 
 #include "k_bipred.h"
+#include "k_me.h"
+#include "k_subpel.h"
 
 // NW = h / 16 waves per CU: every wave owns a 16-row slab of the block for the
 // plain-MC case, the distortions and the gradient sums, and a share of the
@@ -84,7 +86,9 @@ __device__ __forceinline__ void affine_me_mc(int bd, int bx, int by, int w, int 
   __syncthreads();
   const int rows = sbh + 7;  // intermediate rows of a sub-block
   {
-    // horizontal pass of the sub-blocks with a fractional phase in both directions
+    // horizontal pass of the sub-blocks with a fractional phase in both
+    // directions: the 8 samples in one (2-byte aligned) 16-byte load, the taps
+    // as packed pairs, four dot2
     const int shift = 6 - (14 - bd), offset = -(8192 << shift);
     for (int j = tid; j < rows * n_sub * sbw; j += T) {
       const int c = j & (sbw - 1), k = (j >> lsw) & (n_sub - 1), r = j >> (lsw + lnx + (31 - __clz(nsy)));
@@ -93,10 +97,12 @@ __device__ __forceinline__ void affine_me_mc(int bd, int bx, int by, int w, int 
       const int sx = (k & (nsx - 1)) << lsw, sy = (k >> lnx) << lsh;
       const uint16_t *p = pr.p + (ptrdiff_t)(by + sy + (my >> 4) + r - 3) * pr.stride + bx + sx +
                           (mx >> 4) + c - 3;
-      const int16_t *fh = kLumaTaps[mx & 15];
-      int sum = 0;
-#pragma unroll
-      for (int t = 0; t < 8; t++) sum += (int)p[t] * fh[t];
+      const U16x8 v = *reinterpret_cast<const U16x8 *>(p);
+      const uint4 t = *reinterpret_cast<const uint4 *>(kLumaTaps[mx & 15]);
+      int sum = sp_dot2(v.v[0], t.x, 0);  // samples < 2^15: exact as signed pairs
+      sum = sp_dot2(v.v[1], t.y, sum);
+      sum = sp_dot2(v.v[2], t.z, sum);
+      sum = sp_dot2(v.v[3], t.w, sum);
       s.tmp[(k * rows + r) * sbw + c] = (int16_t)((sum + offset) >> shift);
     }
   }
