@@ -71,11 +71,22 @@ def affine_jobs(cu):
             k += 1
     return jobs[:k]
 d_ar = ctx.alloc(api.AFFINE_ME_RESULT_DTYPE.itemsize * (H // 16) * (W // 16))
+AO, AR = O, R
+if os.environ.get("AFFINE_CONTENT") == "1":
+    # zooming / rotating content (every CU iterates, sub-block MC) instead of the
+    # translational clip
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_affine_me as oa
+    o_, r_ = oa.warped_pics(np.random.default_rng(1), bd, W, H, border, 1.01, 0.004, (0.5, -0.25))
+    chroma = np.full((H // 2 + border, W // 2 + border), 512, np.uint16)
+    AO, AR = ctx.picture(W, H, bd), ctx.picture(W, H, bd)
+    AO.upload([o_, chroma, chroma], border); AR.upload([r_, chroma, chroma], border)
+    res = None
 for cu in (16, 32, 64):
     aj = affine_jobs(cu)
     d_aj = ctx.buffer(aj)
     fns["affine_me%d" % cu] = (lambda d_aj=d_aj, n=len(aj): lib.xvcgpu_affine_me_batch(
-        ctx.h, O.h_pic, R.h_pic, None, d_aj.ptr, n, d_ar.ptr))
+        ctx.h, AO.h_pic, AR.h_pic, None, d_aj.ptr, n, d_ar.ptr))
 N = W * H
 alg = {"me": 4 * N, "recon": 9 * N + 16 * N // 16, "deblock": 6 * N + N,
        "pad": 2 * (2 * 128 * (W + H + 256) + 4 * 64 * (W // 2 + H // 2 + 128)), "ssd": 4 * N,
