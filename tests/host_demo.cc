@@ -88,6 +88,17 @@ int main() {
         if (py[yy * w + xx] != y[7 * w + xx]) return 8;
     const std::vector<uint32_t> dist = xvc_gpu::IntraSearch(ctx).SatdAllModesBatch(pred, a, ib);
     if (dist.size() != XVC_INTRA_NUM_MODES || dist[50] != 0 || dist[18] == 0) return 9;
+    // affine ME of a picture against itself from the zero predictor: the
+    // prediction equals the original, the normal equations have a zero
+    // right-hand side, the first gradient step is zero and the search stops
+    std::vector<xvcgpu_affine_me_block> aj(1);
+    aj[0] = xvcgpu_affine_me_block();
+    aj[0].x = 16; aj[0].y = 8; aj[0].w = 16; aj[0].h = 16; aj[0].lambda16 = 100000;
+    const std::vector<xvcgpu_affine_me_result> ar =
+        xvc_gpu::InterSearch(ctx).MotionEstAffineBatch(a, a, a, aj);
+    if (ar.size() != 1 || ar[0].dist != 0 || ar[0].iterations != 0) return 10;
+    for (int i = 0; i < 3; i++)
+      if (ar[0].mv[i][0] != 0 || ar[0].mv[i][1] != 0) return 10;
     return 0;
   } catch (const xvc_gpu::Error &e) {
     std::printf("xvc_gpu error %d: %s\n", static_cast<int>(e.status), e.what());
