@@ -147,6 +147,29 @@ typedef struct xvcgpu_mc_lic_block {
   int16_t left_x, left_y;   /* luma position of the CU to the left         */
 } xvcgpu_mc_lic_block;
 
+/* One inter prediction job of the decoder = InterPrediction::MotionCompensation
+ * (inter_prediction.cc:710-738) for one component of any inter CU: uni- or
+ * bi-prediction (ref[list] >= 0 selects the lists: an index into the array of
+ * reference pictures passed with the batch), translational (mv[list][0]) or
+ * affine (XVC_INTER_AFFINE: the three corner vectors, MotionCompAffine
+ * :1044-1136), with local illumination compensation (XVC_INTER_LIC: applied
+ * to each list's Sample prediction, the bi-pred average then starts from the
+ * compensated samples, :725-731; never together with affine, :1021-1041). */
+#define XVC_INTER_AFFINE 1
+#define XVC_INTER_LIC 2
+typedef struct xvcgpu_inter_block {
+  int16_t x, y;        /* luma position of the CU                          */
+  uint8_t w, h;        /* luma size of the CU                              */
+  uint8_t comp;        /* 0 = Y, 1 = U, 2 = V                              */
+  uint8_t flags;       /* XVC_INTER_*                                      */
+  int8_t ref[2];       /* reference picture slot per list, -1 = unused     */
+  uint8_t neighbors;   /* XVC_LIC_HAS_* (LIC only)                         */
+  uint8_t reserved;
+  int16_t above_x, above_y; /* LIC: luma position of the CU above / left   */
+  int16_t left_x, left_y;   /*      (their ClipMv, see xvcgpu_mc_lic_block)*/
+  int32_t mv[2][3][2]; /* [list][corner][x,y], 1/16 pel, before ClipMv     */
+} xvcgpu_inter_block;
+
 /* One intra prediction job = IntraPrediction::FillReferenceState + Predict
  * (intra_prediction.cc:81-147) for one component of one CU, 67-mode set.
  * Positions / sizes are in samples of `comp`.  The neighbour fields are what

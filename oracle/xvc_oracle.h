@@ -132,6 +132,12 @@ void xo_deblock_picture(int bitdepth, int pic_w, int pic_h, int pic_is_bipred,
                         int map_stride, uint16_t *const planes[3],
                         const ptrdiff_t strides[3]);
 
+void xo_deblock_picture_planes(int bitdepth, int pic_w, int pic_h, int pic_is_bipred,
+                               int beta_offset, int tc_offset, int subblock_size,
+                               const xvcgpu_cu_info *cus, const int32_t *cu_map,
+                               int map_stride, uint16_t *const planes[3],
+                               const ptrdiff_t strides[3], int comp_mask);
+
 void xo_deblock_rows(int bitdepth, int pic_w, int pic_h, int pic_is_bipred,
                      int beta_offset, int tc_offset, int subblock_size,
                      const xvcgpu_cu_info *cus, const int32_t *cu_map,
@@ -294,6 +300,19 @@ void xo_intra_pred_block(int bitdepth, const xvcgpu_intra_block *b, const uint16
                          ptrdiff_t rs, uint16_t *pred, ptrdiff_t ps);
 void xo_intra_satd_modes(int bitdepth, const xvcgpu_intra_block *b, const uint16_t *orig,
                          ptrdiff_t os, const uint16_t *rec, ptrdiff_t rs, uint32_t *dist);
+
+/* ---- decoder reconstruction (xvc_oracle_dec.c) ---- */
+#include "../include/xvc_syntax.h"
+void xo_inter_pred_block(int bd, const xvcgpu_inter_block *b, int pic_w, int pic_h,
+                         const uint16_t *const *ref_planes, const uint16_t *const *rec_planes,
+                         uint16_t *const *pred_planes, const ptrdiff_t *strides);
+void xo_intra_neighbors(const int32_t *cells, int stride, int rows, const xvc_cu_syntax *cu,
+                        int comp, uint8_t *flags, uint8_t *above_right, uint8_t *below_left);
+void xo_decode_picture(const xvc_picture_syntax *ps, const xvc_cu_syntax *cus,
+                       const int16_t *levels, const uint16_t *const *ref_planes,
+                       const int32_t ref_slot[2][5], uint16_t *const planes[3],
+                       const ptrdiff_t strides[3], int border, uint8_t *nb_out,
+                       uint16_t *const pre_planes[3]);
 
 /* Transform matrix access (transform_data.cc, high-precision tables) for
  * table-equality tests: returns pointer to N*N int16 row-major, or NULL. */

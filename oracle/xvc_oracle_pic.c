@@ -39,6 +39,8 @@ typedef struct {
   const xvcgpu_cu_info *cus;
   const int32_t *map;
   int map_stride, map_rows;
+  int comp_mask; /* 1: filter luma, 2: filter chroma (DeblockCtu's deblock_luma /
+                  * deblock_chroma, deblocking_filter.cc:88-91) */
   uint16_t *const *planes;
   const ptrdiff_t *strides;
 } xp_db;
@@ -223,8 +225,8 @@ static void xp_deblock_ctu(const xp_db *d, int ctu_x, int ctu_y, int vertical) {
       int bs = xp_bs(d, p, q, x, y, vertical);
       if (!bs) continue;
       int qp = (p->qp_y + q->qp_y + 1) >> 1;
-      xp_filter_luma(d, x, y, vertical, bs, qp);
-      if (bs == 2) {
+      if (d->comp_mask & 1) xp_filter_luma(d, x, y, vertical, bs, qp);
+      if (bs == 2 && (d->comp_mask & 2)) {
         int cqp = (p->qp_c + q->qp_c + 1) >> 1;
         int cx = x >> 1, cy = y >> 1;
         if (vertical ? ((cx & 7) == 0) : ((cy & 7) == 0))
@@ -239,8 +241,22 @@ void xo_deblock_picture(int bd, int pic_w, int pic_h, int bipred,
                         const xvcgpu_cu_info *cus, const int32_t *cu_map,
                         int map_stride, uint16_t *const planes[3],
                         const ptrdiff_t strides[3]) {
+  xo_deblock_picture_planes(bd, pic_w, pic_h, bipred, beta_offset, tc_offset, subblock_size,
+                            cus, cu_map, map_stride, planes, strides, 3);
+}
+
+/* One CU tree's share of DeblockPicture (deblocking_filter.cc:56-77): with two
+ * CU trees (intra pictures) the primary tree filters luma on the 4-sample
+ * grid, the secondary tree chroma on the 8-sample grid; the two touch
+ * disjoint planes, so the CTU interleaving of the reference is immaterial. */
+void xo_deblock_picture_planes(int bd, int pic_w, int pic_h, int bipred,
+                               int beta_offset, int tc_offset, int subblock_size,
+                               const xvcgpu_cu_info *cus, const int32_t *cu_map,
+                               int map_stride, uint16_t *const planes[3],
+                               const ptrdiff_t strides[3], int comp_mask) {
   /* DeblockPicture, deblocking_filter.cc:56-77 */
   xp_db d;
+  d.comp_mask = comp_mask;
   d.bd = bd;
   d.pic_w = pic_w;
   d.pic_h = pic_h;
@@ -283,6 +299,7 @@ void xo_deblock_rows(int bd, int pic_w, int pic_h, int bipred, int beta_offset,
   d.map_rows = (pic_h + 3) / 4;
   d.planes = planes;
   d.strides = strides;
+  d.comp_mask = 3;
   const int vertical = pass == 0;
   if (y_end > pic_h) y_end = pic_h;
   for (int y = y_begin; y < y_end; y += subblock_size)
