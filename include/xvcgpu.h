@@ -244,6 +244,20 @@ xvcgpu_status xvcgpu_mc_lic_batch(xvcgpu_ctx *ctx, const xvcgpu_picture *ref,
                                   const xvcgpu_picture *rec, xvcgpu_picture *pred,
                                   const xvcgpu_mc_lic_block *d_blocks, int n);
 
+/* ---- N1: the decoder's inter prediction, any inter CU ---------------------- *
+ * InterPrediction::MotionCompensation (inter_prediction.cc:710-738) for n
+ * (CU, component) jobs: uni- or bi-prediction from any of the picture's
+ * reference pictures (refs[0..n_refs): the job names a slot per list),
+ * translational or affine (MotionCompAffine :1044-1136, for either output
+ * precision), with or without local illumination compensation (:1555-1663; the
+ * model reads the neighbouring reconstruction from `rec`, so the CUs of one
+ * call must not depend on each other).  Written into `pred` at the CU's
+ * position.  n_refs <= 10 (two lists of kMaxNumRefPics, common.h:144). */
+xvcgpu_status xvcgpu_inter_pred_batch(xvcgpu_ctx *ctx, const xvcgpu_picture *const *refs,
+                                      int n_refs, const xvcgpu_picture *rec,
+                                      xvcgpu_picture *pred,
+                                      const xvcgpu_inter_block *d_blocks, int n);
+
 /* ---- I3 (affine half): MotionCompAffine -> Sample ------------------------- *
  * (inter_prediction.cc:1044-1136): the CU is cut into sub-blocks whose size
  * follows from the corner-MV differences, each sub-block gets its own MV
@@ -373,6 +387,18 @@ xvcgpu_status xvcgpu_deblock_rows(xvcgpu_ctx *ctx, xvcgpu_picture *rec,
                                   int pic_is_bipred, int beta_offset,
                                   int tc_offset, int subblock_size, int pass,
                                   int y_begin, int y_end);
+
+/* One CU tree's share of DeblockPicture (deblocking_filter.cc:56-77): both
+ * passes over the whole picture, filtering only the planes in comp_mask (1 =
+ * luma, 2 = chroma, 3 = both).  An intra picture codes luma and chroma in two
+ * CU trees (picture_data.cc:71-76): the primary tree filters luma on the
+ * 4-sample grid, the secondary tree chroma on the 8-sample grid (:63-75).
+ * xvcgpu_deblock() == comp_mask 3. */
+xvcgpu_status xvcgpu_deblock_tree(xvcgpu_ctx *ctx, xvcgpu_picture *rec,
+                                  const xvcgpu_cu_info *d_cus, int n_cus,
+                                  const int32_t *d_cu_map, int map_stride,
+                                  int pic_is_bipred, int beta_offset, int tc_offset,
+                                  int subblock_size, int comp_mask);
 
 /* ---- picture SSD / PSNR parts ------------------------------------------- *
  * SampleMetric::ComparePicture / ComputePsnr block walk (sample_metric.cc:

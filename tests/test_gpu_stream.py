@@ -1,0 +1,97 @@
+"""Reconstruction of REAL reference streams on the device: the
+parsed syntax of every picture of streams the reference encoder produced
+(tests/golden/stream_*.npz, captured from the reference decoder) goes through
+the C++ host decoder (xvc_gpu::PictureDecoder, libxvchost.so) and the C-ABI;
+every picture must equal what the reference decoder output - the committed
+planes where the fixture holds them, the picture MD5 (the value the stream
+itself carries for its reference pictures) everywhere, and the oracle decoder's
+planes (which localise a mismatch)."""
+import time
+
+import numpy as np
+import pytest
+
+import stream_fixture as sf
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    from xvc_amd import api
+    ctx = api.Context(0)
+    yield api, ctx
+    ctx.close()
+
+
+def decode_stream_on_gpu(api, ctx, fx, check):
+    from xvc_amd import decoder
+    w, h, bd = (int(fx.info[0][k]) for k in ("width", "height", "bitdepth"))
+    dec = decoder.PictureDecoder(ctx, w, h, bd)
+    done = {}
+    try:
+        for i in range(fx.n):
+            info = fx.info[i]
+            ps, cs = sf.to_syntax(info, fx.cus(i))
+            refs = [[done[int(info["ref_poc"][l][k])] for k in range(int(info["num_ref"][l]))]
+                    for l in range(2)]
+            rec = ctx.picture(w, h, bd)
+            dec.decode(ps, cs, fx.levels(i), refs, rec)
+            ctx.sync()
+            done[int(info["poc"])] = rec
+            check(i, rec, dec)
+    finally:
+        dec.destroy()
+        for p in done.values():
+            p.destroy()
+
+
+@pytest.mark.parametrize("name", ["tiny", "c0", "c1"])
+def test_gpu_reconstructs_reference_stream(gpu, name):
+    api, ctx = gpu
+    fx = sf.StreamFixture(name)
+    oracle = sf.oracle_decode_stream([(fx.info[i], fx.cus(i), fx.levels(i))
+                                      for i in range(fx.n)])
+
+    def check(i, rec, dec):
+        info = fx.info[i]
+        got = rec.download(0)
+        opic = oracle[i][0]
+        for c in range(3):
+            if not np.array_equal(got[c], opic.planes[c]):
+                bad = np.argwhere(got[c] != opic.planes[c])
+                raise AssertionError("%s pic %d (poc %d) comp %d: %d samples differ from the "
+                                     "oracle, first at (y, x) = %s" %
+                                     (name, i, info["poc"], c, len(bad), bad[0]))
+        if fx.has_planes(i):
+            for c, e in enumerate(fx.planes(i)):
+                assert np.array_equal(got[c], e), (name, i, c)
+        md5 = sf.picture_md5(got, int(info["bitdepth"]))
+        assert np.array_equal(md5, info["md5"]), "%s pic %d MD5" % (name, i)
+        if info["padded"]:      # the border a later picture's motion vectors reach into
+            gp = rec.download(80)
+            for c in range(3):
+                b = 80 >> (1 if c else 0)
+                full = opic.full[c]
+                ob = opic.border >> (1 if c else 0)
+                assert np.array_equal(gp[c], full[ob - b:full.shape[0] - ob + b,
+                                                  ob - b:full.shape[1] - ob + b]), (name, i, c)
+
+    decode_stream_on_gpu(api, ctx, fx, check)
+
+
+def test_gpu_stream_decode_rate(gpu):
+    """Not a parity test: prints pictures/s of the 1080p stream (device + host
+    planning, syntax already parsed) for the record."""
+    api, ctx = gpu
+    fx = sf.StreamFixture("c1")
+    t0 = time.time()
+    info = []
+
+    def check(i, rec, dec):
+        info.append((dec.waves, dec.launches))
+
+    decode_stream_on_gpu(api, ctx, fx, check)
+    dt = time.time() - t0
+    print("\n1080p stream: %d pictures in %.3f s (%.1f pictures/s incl. python marshalling); "
+          "waves / launches per picture: %s" % (fx.n, dt, fx.n / dt, info))

@@ -108,6 +108,17 @@ def main(names):
                    *kinds, len(lv), bytes(info["md5"]).hex()))
         np.savez_compressed(path, **arrays)
         print("  -> %s (%.1f KB)" % (path, os.path.getsize(path) / 1024))
+        update_manifest("stream_%s.npz" % name)
+
+
+def update_manifest(fname):
+    """tests/golden/MANIFEST.md5: one line per fixture (test_golden_manifest)."""
+    import hashlib
+    mpath = os.path.join(sf.GOLDEN, "MANIFEST.md5")
+    lines = [l for l in open(mpath).read().split("\n") if l.strip() and l.split()[1] != fname]
+    digest = hashlib.md5(open(os.path.join(sf.GOLDEN, fname), "rb").read()).hexdigest()
+    lines.append("%s  %s" % (digest, fname))
+    open(mpath, "w").write("\n".join(sorted(lines, key=lambda l: l.split()[1])) + "\n")
 
 
 if __name__ == "__main__":

@@ -72,6 +72,12 @@ INTRA_DTYPE = np.dtype([("x", "<i2"), ("y", "<i2"), ("w", "u1"), ("h", "u1"),
                         ("comp", "u1"), ("mode", "u1"), ("neighbors", "u1"),
                         ("above_right", "u1"), ("below_left", "u1"), ("reserved", "u1")])
 assert INTRA_DTYPE.itemsize == 12
+INTER_DTYPE = np.dtype([("x", "<i2"), ("y", "<i2"), ("w", "u1"), ("h", "u1"), ("comp", "u1"),
+                        ("flags", "u1"), ("ref", "i1", (2,)), ("neighbors", "u1"),
+                        ("reserved", "u1"), ("above_x", "<i2"), ("above_y", "<i2"),
+                        ("left_x", "<i2"), ("left_y", "<i2"), ("mv", "<i4", (2, 3, 2))])
+assert INTER_DTYPE.itemsize == 68
+INTER_AFFINE, INTER_LIC = 1, 2
 INTRA_NUM_MODES = 67
 INTRA_HAS_ABOVE_LEFT, INTRA_HAS_ABOVE, INTRA_HAS_LEFT = 1, 2, 4
 # xvcgpu_tx_block.intra_pic flag bits (include/xvcgpu_types.h XVC_TXF_*)
@@ -120,7 +126,7 @@ SYMBOLS = [
     "xvcgpu_variance_map", "xvcgpu_histogram_distance",
     "xvcgpu_intra_pred_batch", "xvcgpu_intra_satd_batch", "xvcgpu_intra_recon_batch",
     "xvcgpu_intra_select_modes", "xvcgpu_frame_pass", "xvcgpu_copy_segments",
-    "xvcgpu_get_transform_matrix",
+    "xvcgpu_get_transform_matrix", "xvcgpu_inter_pred_batch", "xvcgpu_deblock_tree",
 ]
 
 _vp = C.c_void_p
@@ -227,6 +233,9 @@ def load_library():
         "xvcgpu_frame_pass": [_vp, C.POINTER(FramePassArgs), C.c_int],
         "xvcgpu_copy_segments": [_vp, _vp, C.c_int],
         "xvcgpu_get_transform_matrix": [C.c_int, C.c_int, _vp],
+        "xvcgpu_inter_pred_batch": [_vp, C.POINTER(_vp), C.c_int, _vp, _vp, _vp, C.c_int],
+        "xvcgpu_deblock_tree": [_vp, _vp, _vp, C.c_int, _vp, C.c_int, C.c_int, C.c_int,
+                                C.c_int, C.c_int, C.c_int],
     }
     for name, args in sigs.items():
         f = getattr(lib, name)

@@ -35,6 +35,31 @@ def deps():
     return files
 
 
+HOST_OUT = os.path.join(HERE, "libxvchost.so")
+HOST_SOURCES = ["xvc_picture_decoder.cc"]
+
+
+def build_host(force=False, verbose=False):
+    """libxvchost.so: the C++ host layer above the C-ABI (xvc_amd/host/*.cc:
+    picture-level drivers named after the reference's classes), plain g++,
+    linked against libxvcgpu.so next to it."""
+    host = os.path.join(HERE, "host")
+    inc = os.path.join(os.path.dirname(HERE), "include")
+    srcs = [os.path.join(host, f) for f in HOST_SOURCES]
+    dep = srcs + [os.path.join(host, f) for f in os.listdir(host) if f.endswith(".h")] + \
+        [os.path.join(inc, f) for f in os.listdir(inc)]
+    if not force and os.path.exists(HOST_OUT):
+        m = os.path.getmtime(HOST_OUT)
+        if all(os.path.getmtime(f) <= m for f in dep):
+            return HOST_OUT
+    cmd = ["g++", "-std=c++11", "-O2", "-fPIC", "-shared", "-Wall", "-Wextra", "-I", inc,
+           "-I", host] + srcs + ["-o", HOST_OUT, "-L", HERE, "-lxvcgpu", "-Wl,-rpath,$ORIGIN"]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return HOST_OUT
+
+
 def build(force=False, verbose=False):
     if not force and os.path.exists(OUT):
         m = os.path.getmtime(OUT)
@@ -49,3 +74,4 @@ def build(force=False, verbose=False):
 
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
+    print(build_host(force="--force" in sys.argv, verbose=True))

@@ -31,6 +31,8 @@ struct DbParams {
   const xvcgpu_cu_info *cus;
   const int32_t *map;
   int map_stride, map_rows;
+  int comp_mask;  // 1: filter luma, 2: filter chroma (DeblockCtu's deblock_luma /
+                  // deblock_chroma, deblocking_filter.cc:88-91)
 };
 
 __device__ __forceinline__ int db_cu_index(const DbParams &d, int x, int y) {
@@ -183,7 +185,7 @@ __device__ __forceinline__ void db_filter_edge(const DbParams &d,
                                                const PicView &pic, int x, int y,
                                                int bs, int qp, int cqp) {
   const PlaneView pl = pic.c[0];
-  for (int g = 0; g < d.sub / 4; g++) {
+  for (int g = 0; g < ((d.comp_mask & 1) ? d.sub / 4 : 0); g++) {
     int s[4][8];
     if (VERTICAL) {
       uint16_t *base = pl.p + (ptrdiff_t)(y + 4 * g) * pl.stride + x - 4;
@@ -218,7 +220,7 @@ __device__ __forceinline__ void db_filter_edge(const DbParams &d,
       }
     }
   }
-  if (bs != 2) return;
+  if (bs != 2 || !(d.comp_mask & 2)) return;
   const int cx = x >> 1, cy = y >> 1;
   if (VERTICAL ? (cx & 7) != 0 : (cy & 7) != 0) return;
   const int bsh = d.bd - 8, smax = (1 << d.bd) - 1;

@@ -20,6 +20,7 @@
 #include "k_stats.h"
 #include "k_intra.h"
 #include "k_affine_me.h"
+#include "k_inter_pred.h"
 #include "xvcgpu_internal.h"
 
 namespace {
@@ -594,7 +595,9 @@ xvcgpu_status xvcgpu_me_search_sized(xvcgpu_ctx *ctx, const xvcgpu_picture *orig
   // search on the same SIMD).
   Me2Sched sched = {nullptr, nullptr, nullptr};
   if (flags & XVCGPU_ME_FULLPEL) {  // rotate the three records (k_me2.h)
-    const int e = ++ctx->me_epoch;
+    // the epoch only ever matters modulo 3: keep it there (no overflow after
+    // 2^31 searches, slot indices always 0..2)
+    const int e = ctx->me_epoch = (ctx->me_epoch + 1) % 3;
     sched.use = ctx->d_me_rot + e % 3;
     sched.record = ctx->d_me_rot + (e + 1) % 3;
     sched.clear = ctx->d_me_rot + (e + 2) % 3;
@@ -662,6 +665,30 @@ xvcgpu_status xvcgpu_mc_lic_batch(xvcgpu_ctx *ctx, const xvcgpu_picture *ref,
   hipLaunchKernelGGL(mc_lic_kernel, dim3(n), dim3(256), 0, ctx->stream, ref->v, rec->v,
                      pred->v, d_blocks, n);
   CHECK_LAUNCH(ctx, "mc_lic_batch");
+  return XVCGPU_OK;
+}
+
+xvcgpu_status xvcgpu_inter_pred_batch(xvcgpu_ctx *ctx, const xvcgpu_picture *const *refs,
+                                      int n_refs, const xvcgpu_picture *rec,
+                                      xvcgpu_picture *pred,
+                                      const xvcgpu_inter_block *d_blocks, int n) {
+  if (!ctx || !refs || n_refs < 1 || n_refs > XVC_MAX_REF_SLOTS || !rec || !pred || n < 0 ||
+      (n && !d_blocks))
+    return XVCGPU_INVALID_ARGUMENT;
+  if (rec->w != pred->w || rec->h != pred->h || rec->bd != pred->bd)
+    return fail(ctx, XVCGPU_INVALID_ARGUMENT, "picture mismatch");
+  RefTable t;
+  memset(&t, 0, sizeof(t));
+  for (int i = 0; i < n_refs; i++) {
+    if (!refs[i]) return XVCGPU_INVALID_ARGUMENT;
+    if (refs[i]->w != pred->w || refs[i]->h != pred->h || refs[i]->bd != pred->bd)
+      return fail(ctx, XVCGPU_INVALID_ARGUMENT, "reference picture mismatch");
+    t.pic[i] = refs[i]->v;
+  }
+  if (n == 0) return XVCGPU_OK;
+  hipLaunchKernelGGL(inter_pred_kernel, dim3(n), dim3(256), 0, ctx->stream, t, rec->v,
+                     pred->v, d_blocks, n);
+  CHECK_LAUNCH(ctx, "inter_pred_batch");
   return XVCGPU_OK;
 }
 
@@ -824,12 +851,12 @@ xvcgpu_status xvcgpu_inv_transform_batch(xvcgpu_ctx *ctx,
   return XVCGPU_OK;
 }
 
-xvcgpu_status xvcgpu_deblock_rows(xvcgpu_ctx *ctx, xvcgpu_picture *rec,
-                                  const xvcgpu_cu_info *d_cus, int n_cus,
-                                  const int32_t *d_cu_map, int map_stride,
-                                  int pic_is_bipred, int beta_offset,
-                                  int tc_offset, int subblock_size, int pass,
-                                  int y_begin, int y_end) {
+static xvcgpu_status deblock_rows_masked(xvcgpu_ctx *ctx, xvcgpu_picture *rec,
+                                         const xvcgpu_cu_info *d_cus, int n_cus,
+                                         const int32_t *d_cu_map, int map_stride,
+                                         int pic_is_bipred, int beta_offset,
+                                         int tc_offset, int subblock_size, int pass,
+                                         int y_begin, int y_end, int comp_mask) {
   if (!ctx || !rec || !d_cus || n_cus <= 0 || !d_cu_map ||
       map_stride < (rec->w + 3) / 4 || (subblock_size != 4 && subblock_size != 8) ||
       (pass != 0 && pass != 1) || y_begin < 0 || (y_begin % subblock_size) != 0)
@@ -850,6 +877,7 @@ xvcgpu_status xvcgpu_deblock_rows(xvcgpu_ctx *ctx, xvcgpu_picture *rec,
   d.map = d_cu_map;
   d.map_stride = map_stride;
   d.map_rows = (rec->h + 3) / 4;
+  d.comp_mask = comp_mask;
   const int nx = (rec->w + subblock_size - 1) / subblock_size;
   const int ny = (y_end - y_begin + subblock_size - 1) / subblock_size;
   const dim3 grid((nx + 63) / 64, ny);
@@ -861,6 +889,30 @@ xvcgpu_status xvcgpu_deblock_rows(xvcgpu_ctx *ctx, xvcgpu_picture *rec,
                        rec->v);
   CHECK_LAUNCH(ctx, "deblock_rows");
   return XVCGPU_OK;
+}
+
+xvcgpu_status xvcgpu_deblock_rows(xvcgpu_ctx *ctx, xvcgpu_picture *rec,
+                                  const xvcgpu_cu_info *d_cus, int n_cus,
+                                  const int32_t *d_cu_map, int map_stride,
+                                  int pic_is_bipred, int beta_offset,
+                                  int tc_offset, int subblock_size, int pass,
+                                  int y_begin, int y_end) {
+  return deblock_rows_masked(ctx, rec, d_cus, n_cus, d_cu_map, map_stride, pic_is_bipred,
+                             beta_offset, tc_offset, subblock_size, pass, y_begin, y_end, 3);
+}
+
+xvcgpu_status xvcgpu_deblock_tree(xvcgpu_ctx *ctx, xvcgpu_picture *rec,
+                                  const xvcgpu_cu_info *d_cus, int n_cus,
+                                  const int32_t *d_cu_map, int map_stride,
+                                  int pic_is_bipred, int beta_offset, int tc_offset,
+                                  int subblock_size, int comp_mask) {
+  if (!rec || comp_mask < 1 || comp_mask > 3) return XVCGPU_INVALID_ARGUMENT;
+  xvcgpu_status st = deblock_rows_masked(ctx, rec, d_cus, n_cus, d_cu_map, map_stride,
+                                         pic_is_bipred, beta_offset, tc_offset,
+                                         subblock_size, 0, 0, rec->h, comp_mask);
+  if (st != XVCGPU_OK) return st;
+  return deblock_rows_masked(ctx, rec, d_cus, n_cus, d_cu_map, map_stride, pic_is_bipred,
+                             beta_offset, tc_offset, subblock_size, 1, 0, rec->h, comp_mask);
 }
 
 xvcgpu_status xvcgpu_deblock(xvcgpu_ctx *ctx, xvcgpu_picture *rec,

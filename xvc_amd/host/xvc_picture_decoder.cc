@@ -1,0 +1,451 @@
+// xvc_picture_decoder.cc -- see xvc_picture_decoder.h.
+#include "xvc_picture_decoder.h"
+
+#include <algorithm>
+#include <cstring>
+#include <new>
+
+namespace xvc_gpu {
+
+namespace {
+
+// The 4x4 cell table of PictureData (picture_data.cc:52-62: one extra column /
+// row beyond the CTU-aligned picture), one per CU tree, holding coding-order
+// indices.  Cells are marked as the walk over the CU list proceeds, so a lookup
+// sees exactly the CUs decoded before the current one - PictureData::GetCuAt at
+// the time the reference decompresses that CU.
+struct CellMap {
+  int stride, rows;
+  std::vector<int32_t> *cell;
+  int At(int tree, int x, int y) const {
+    if (x < 0 || y < 0) return -1;
+    const int cx = x >> 2, cy = y >> 2;
+    if (cx >= stride || cy >= rows) return -1;
+    return cell[tree][static_cast<size_t>(cy) * stride + cx];
+  }
+};
+
+inline int Max(int a, int b) { return a > b ? a : b; }
+
+}  // namespace
+
+void PictureDecoder::Plan(const xvc_picture_syntax &ps, const xvc_cu_syntax *cus,
+                          const int16_t *levels, PicturePlan *plan) {
+  const int n = ps.n_cus;
+  PicturePlan &p = *plan;
+  p.map_stride = (ps.width + 63) / 4 + 1;
+  p.map_rows = (ps.height + 63) / 4 + 1;
+  const size_t cells = static_cast<size_t>(p.map_stride) * p.map_rows;
+  p.cell[0].assign(cells, -1);
+  p.cell[1].assign(cells, -1);
+  p.wave.assign(n, 0);
+  p.neighbors.assign(n, CuNeighbors());
+  p.cu_info.assign(n, xvcgpu_cu_info());
+  p.two_trees = false;
+  CellMap map = {p.map_stride, p.map_rows, p.cell};
+  // wave in which the CU's luma / chroma reconstruction is complete
+  std::vector<int32_t> wl(n, 0), wc(n, 0);
+  const bool intra_pic = ps.pic_type == XVC_PIC_INTRA;
+
+  // reference table: one slot per distinct (list, idx); the caller's pictures
+  // are matched to slots in Decode
+  p.n_ref_slots = 0;
+  for (int l = 0; l < 2; l++)
+    for (int k = 0; k < 5; k++) p.ref_slot[l][k] = k < ps.num_ref[l] ? p.n_ref_slots++ : -1;
+
+  struct Unit {  // one schedulable piece: the luma or the chroma of a CU
+    int cu, wave, c0, c1;
+  };
+  std::vector<Unit> units;
+  units.reserve(2 * n);
+
+  for (int i = 0; i < n; i++) {
+    const xvc_cu_syntax &cu = cus[i];
+    const int tree = cu.tree;
+    if (tree) p.two_trees = true;
+    // PictureData::MarkUsedInPic (picture_data.cc:191-210), before the lookups
+    for (int yy = 0; yy < cu.h; yy += 4) {
+      int32_t *row = &p.cell[tree][static_cast<size_t>((cu.y + yy) >> 2) * p.map_stride +
+                                   (cu.x >> 2)];
+      std::fill(row, row + (cu.w >> 2), i);
+    }
+    const bool has_luma = tree == 0;
+    const bool has_chroma = tree == 1 || !intra_pic;
+    const bool intra = cu.pred_mode == 0;
+    int dep_l = -1, dep_c = -1;  // latest wave this CU's luma / chroma waits for
+    auto need = [&](int j) {
+      if (j < 0) return;
+      if (has_luma) dep_l = Max(dep_l, wl[j]);
+      if (has_chroma) dep_c = Max(dep_c, wc[j]);
+    };
+    if (intra) {
+      // IntraPrediction::DetermineNeighbors (intra_prediction.cc:688-705) with
+      // GetCuSizeAboveRight / GetCuSizeBelowLeft (coding_unit.cc:304-336)
+      int ar = 0, bl = 0;  // in luma samples
+      if (cu.x > 0)
+        for (int k = cu.w; k >= 0; k -= 4)
+          if (map.At(tree, cu.x - 4, cu.y + cu.h - 4 + k) >= 0) {
+            bl = k;
+            break;
+          }
+      if (cu.y > 0)
+        for (int k = cu.h; k >= 0; k -= 4)
+          if (map.At(tree, cu.x + cu.w - 4 + k, cu.y - 4) >= 0) {
+            ar = k;
+            break;
+          }
+      CuNeighbors &nb = p.neighbors[i];
+      for (int c = 0; c < 3; c++) {
+        const int cs = c ? 1 : 0;
+        int f = 0;
+        if ((cu.x >> cs) > 0) f |= XVC_INTRA_HAS_LEFT;
+        if ((cu.y >> cs) > 0) f |= XVC_INTRA_HAS_ABOVE;
+        if ((cu.x >> cs) > 0 && (cu.y >> cs) > 0) f |= XVC_INTRA_HAS_ABOVE_LEFT;
+        nb.flags[c] = static_cast<uint8_t>(f);
+        nb.above_right[c] = static_cast<uint8_t>(ar >> cs);
+        nb.below_left[c] = static_cast<uint8_t>(bl >> cs);
+      }
+      // the CUs whose reconstruction the reference samples come from
+      if (cu.x > 0 && cu.y > 0) need(map.At(tree, cu.x - 4, cu.y - 4));
+      if (cu.y > 0)
+        for (int xx = 0; xx < cu.w + ar; xx += 4) need(map.At(tree, cu.x + xx, cu.y - 4));
+      if (cu.x > 0)
+        for (int yy = 0; yy < cu.h + bl; yy += 4) need(map.At(tree, cu.x - 4, cu.y + yy));
+      // LM chroma (PredLmChroma, intra_prediction.cc:560-686): the co-located
+      // luma with its row above / column to the left, from the luma tree
+      if (has_chroma &&
+          (cu.intra_mode[1] == XVC_CU_INTRA_LM || cu.intra_mode[2] == XVC_CU_INTRA_LM)) {
+        for (int yy = -4; yy < cu.h; yy += 4)
+          for (int xx = -4; xx < cu.w; xx += 4) {
+            const int j = map.At(0, cu.x + xx, cu.y + yy);
+            if (j >= 0 && j != i) dep_c = Max(dep_c, wl[j]);
+          }
+      }
+    } else if (cu.flags & XVC_CU_LIC) {
+      // DeriveLicParams reads the row above and the column left of the block
+      if (cu.y > 0)
+        for (int xx = 0; xx < cu.w; xx += 4) need(map.At(tree, cu.x + xx, cu.y - 4));
+      if (cu.x > 0)
+        for (int yy = 0; yy < cu.h; yy += 4) need(map.At(tree, cu.x - 4, cu.y + yy));
+    }
+    if (has_luma) wl[i] = dep_l + 1;
+    if (has_chroma) {
+      wc[i] = dep_c + 1;
+      // one tree: the CU's own luma comes first (DecompressCu's component order)
+      if (has_luma && intra &&
+          (cu.intra_mode[1] == XVC_CU_INTRA_LM || cu.intra_mode[2] == XVC_CU_INTRA_LM))
+        wc[i] = Max(wc[i], wl[i] + 1);
+    }
+    p.wave[i] = Max(has_luma ? wl[i] : 0, has_chroma ? wc[i] : 0);
+    if (has_luma) units.push_back(Unit{i, wl[i], 0, 1});
+    if (has_chroma) units.push_back(Unit{i, wc[i], 1, 3});
+
+    // what the in-loop filter reads (deblocking_filter.cc:79-241)
+    xvcgpu_cu_info &o = p.cu_info[i];
+    o.x = static_cast<uint16_t>(cu.x);
+    o.y = static_cast<uint16_t>(cu.y);
+    o.w = cu.w;
+    o.h = cu.h;
+    o.intra = intra;
+    o.cbf_luma = cu.cbf[0];
+    o.qp_y = cu.qp[0];
+    o.qp_c = cu.qp[1];
+    o.ref_idx0 = cu.ref_idx[0];
+    for (int l = 0; l < 2; l++) {
+      const bool used = !intra && (cu.inter_dir == 2 || cu.inter_dir == l);
+      o.ref_poc[l] = used ? ps.ref_poc[l][cu.ref_idx[l]] : -1;
+      const bool affine = cu.flags & XVC_CU_AFFINE;
+      for (int k = 0; k < 3; k++) {
+        o.mv[l][k][0] = cu.mv[l][affine ? k : 0][0];
+        o.mv[l][k][1] = cu.mv[l][affine ? k : 0][1];
+      }
+      // CodingUnit::SetMv(MotionVector3) (coding_unit.h:268-275)
+      o.mv[l][3][0] = affine ? cu.mv[l][1][0] + cu.mv[l][2][0] - cu.mv[l][0][0] : cu.mv[l][0][0];
+      o.mv[l][3][1] = affine ? cu.mv[l][1][1] + cu.mv[l][2][1] - cu.mv[l][0][1] : cu.mv[l][0][1];
+    }
+  }
+
+  // job lists grouped by wave (stable: coding order inside a wave)
+  int n_waves = 0;
+  for (const Unit &u : units) n_waves = Max(n_waves, u.wave + 1);
+  p.n_waves = n_waves;
+  std::vector<int32_t> n_inter(n_waves + 1, 0), n_intra(n_waves + 1, 0), n_tx(n_waves + 1, 0);
+  for (const Unit &u : units) {
+    const int k = u.c1 - u.c0;
+    (cus[u.cu].pred_mode == 0 ? n_intra : n_inter)[u.wave + 1] += k;
+    n_tx[u.wave + 1] += k;
+  }
+  for (int w = 0; w < n_waves; w++) {
+    n_inter[w + 1] += n_inter[w];
+    n_intra[w + 1] += n_intra[w];
+    n_tx[w + 1] += n_tx[w];
+  }
+  p.inter_first = n_inter;
+  p.intra_first = n_intra;
+  p.tx_first = n_tx;
+  p.inter.assign(n_inter[n_waves], xvcgpu_inter_block());
+  p.intra.assign(n_intra[n_waves], xvcgpu_intra_block());
+  p.tx.assign(n_tx[n_waves], xvcgpu_tx_block());
+  p.tx_level_off.assign(n_tx[n_waves], 0);
+  p.tx_nnz.assign(n_tx[n_waves], 0);
+  std::vector<int32_t> at_inter(n_inter.begin(), n_inter.end() - 1),
+      at_intra(n_intra.begin(), n_intra.end() - 1), at_tx(n_tx.begin(), n_tx.end() - 1);
+  // the final map answers "which CU is above / left" for the LIC model
+  for (const Unit &u : units) {
+    const xvc_cu_syntax &cu = cus[u.cu];
+    const bool intra = cu.pred_mode == 0;
+    for (int c = u.c0; c < u.c1; c++) {
+      const int cs = c ? 1 : 0;
+      const int x = cu.x >> cs, y = cu.y >> cs, w = cu.w >> cs, h = cu.h >> cs;
+      if (intra) {
+        xvcgpu_intra_block &j = p.intra[at_intra[u.wave]++];
+        j.x = static_cast<int16_t>(x);
+        j.y = static_cast<int16_t>(y);
+        j.w = static_cast<uint8_t>(w);
+        j.h = static_cast<uint8_t>(h);
+        j.comp = static_cast<uint8_t>(c);
+        j.mode = cu.intra_mode[c] == XVC_CU_INTRA_LM ? XVC_INTRA_MODE_LM_CHROMA
+                                                     : static_cast<uint8_t>(cu.intra_mode[c]);
+        j.neighbors = p.neighbors[u.cu].flags[c];
+        j.above_right = p.neighbors[u.cu].above_right[c];
+        j.below_left = p.neighbors[u.cu].below_left[c];
+        j.reserved = 0;
+      } else {
+        xvcgpu_inter_block &j = p.inter[at_inter[u.wave]++];
+        std::memset(&j, 0, sizeof(j));
+        j.x = cu.x;
+        j.y = cu.y;
+        j.w = cu.w;
+        j.h = cu.h;
+        j.comp = static_cast<uint8_t>(c);
+        j.flags = static_cast<uint8_t>(((cu.flags & XVC_CU_AFFINE) ? XVC_INTER_AFFINE : 0) |
+                                       ((cu.flags & XVC_CU_LIC) ? XVC_INTER_LIC : 0));
+        for (int l = 0; l < 2; l++) {
+          const bool used = cu.inter_dir == 2 || cu.inter_dir == l;
+          j.ref[l] = static_cast<int8_t>(used ? p.ref_slot[l][cu.ref_idx[l]] : -1);
+          std::memcpy(j.mv[l], cu.mv[l], sizeof(j.mv[l]));
+        }
+        if (cu.flags & XVC_CU_LIC) {
+          // GetCodingUnitAbove / Left (coding_unit.cc:227-234, :275-282): always
+          // earlier in coding order, so the final map gives the same answer
+          const int ia = cu.y > 0 ? map.At(cu.tree, cu.x, cu.y - 4) : -1;
+          const int il = cu.x > 0 ? map.At(cu.tree, cu.x - 4, cu.y) : -1;
+          if (ia >= 0) {
+            j.neighbors |= XVC_LIC_HAS_ABOVE;
+            j.above_x = cus[ia].x;
+            j.above_y = cus[ia].y;
+          }
+          if (il >= 0) {
+            j.neighbors |= XVC_LIC_HAS_LEFT;
+            j.left_x = cus[il].x;
+            j.left_y = cus[il].y;
+          }
+        }
+      }
+      const int t = at_tx[u.wave]++;
+      xvcgpu_tx_block &b = p.tx[t];
+      b.x = static_cast<int16_t>(x);
+      b.y = static_cast<int16_t>(y);
+      b.w = static_cast<uint8_t>(w);
+      b.h = static_cast<uint8_t>(h);
+      b.comp = static_cast<uint8_t>(c);
+      b.tx_hor = cu.tx_skip[c] ? static_cast<uint8_t>(XVC_TX_SKIP) : cu.tx_type[c][1];
+      b.tx_ver = cu.tx_type[c][0];
+      // can_dst_4x4 (transform.cc:88-90)
+      b.dst4x4 = c == 0 && intra && cu.tx_type[c][0] == XVC_TX_DEFAULT &&
+                 cu.tx_type[c][1] == XVC_TX_DEFAULT;
+      b.qp = cu.qp[c];
+      b.intra_pic = 0;
+      int nnz = 0;
+      if (cu.cbf[c]) {
+        const int16_t *lv = levels + cu.level_off[c];
+        for (int k = 0; k < w * h; k++) nnz += lv[k] != 0;
+        p.tx_level_off[t] = cu.level_off[c];
+      }
+      p.tx_nnz[t] = nnz;
+    }
+  }
+}
+
+PictureDecoder::PictureDecoder(xvcgpu_ctx *ctx, int width, int height, int bitdepth)
+    : ctx_(ctx), width_(width), height_(height), bitdepth_(bitdepth), pred_(nullptr),
+      d_staging_(nullptr), staging_cap_(0), last_waves_(0), last_launches_(0) {
+  xvcgpu_picture_create(ctx_, width, height, bitdepth, &pred_);
+}
+
+PictureDecoder::~PictureDecoder() {
+  if (d_staging_) xvcgpu_free(ctx_, d_staging_);
+  if (pred_) xvcgpu_picture_destroy(pred_);
+}
+
+xvcgpu_status PictureDecoder::EnsureStaging(size_t bytes) {
+  if (bytes <= staging_cap_) return XVCGPU_OK;
+  if (d_staging_) xvcgpu_free(ctx_, d_staging_);
+  d_staging_ = nullptr;
+  staging_cap_ = 0;
+  const size_t cap = bytes + bytes / 4;
+  xvcgpu_status st = xvcgpu_malloc(ctx_, cap, &d_staging_);
+  if (st == XVCGPU_OK) staging_cap_ = cap;
+  return st;
+}
+
+xvcgpu_status PictureDecoder::Decode(const xvc_picture_syntax &ps, const xvc_cu_syntax *cus,
+                                     const int16_t *levels,
+                                     const xvcgpu_picture *const ref_pics[2][5],
+                                     xvcgpu_picture *rec) {
+  if (!pred_ || !rec || !cus || ps.width != width_ || ps.height != height_ ||
+      ps.bitdepth != bitdepth_ || ps.n_cus <= 0 || (ps.n_levels > 0 && !levels))
+    return XVCGPU_INVALID_ARGUMENT;
+  Plan(ps, cus, levels, &plan_);
+  const PicturePlan &p = plan_;
+
+  // one packed upload: job lists, cell maps, CU records, levels
+  struct Piece {
+    const void *src;
+    size_t bytes, off;
+  };
+  Piece pc[9] = {
+      {p.inter.data(), p.inter.size() * sizeof(xvcgpu_inter_block), 0},
+      {p.intra.data(), p.intra.size() * sizeof(xvcgpu_intra_block), 0},
+      {p.tx.data(), p.tx.size() * sizeof(xvcgpu_tx_block), 0},
+      {p.tx_level_off.data(), p.tx_level_off.size() * sizeof(uint32_t), 0},
+      {p.tx_nnz.data(), p.tx_nnz.size() * sizeof(int32_t), 0},
+      {p.cu_info.data(), p.cu_info.size() * sizeof(xvcgpu_cu_info), 0},
+      {p.cell[0].data(), p.cell[0].size() * sizeof(int32_t), 0},
+      {p.cell[1].data(), p.cell[1].size() * sizeof(int32_t), 0},
+      {levels, static_cast<size_t>(ps.n_levels > 0 ? ps.n_levels : 1) * sizeof(int16_t), 0}};
+  static const int16_t kNoLevels[1] = {0};
+  if (ps.n_levels <= 0) pc[8].src = kNoLevels;
+  size_t total = 0;
+  for (Piece &q : pc) {
+    q.off = total;
+    total += (q.bytes + 255) & ~static_cast<size_t>(255);
+  }
+  xvcgpu_status st = EnsureStaging(total);
+  if (st != XVCGPU_OK) return st;
+  if (h_staging_.size() < total) h_staging_.resize(total);
+  for (const Piece &q : pc)
+    if (q.bytes) std::memcpy(h_staging_.data() + q.off, q.src, q.bytes);
+  st = xvcgpu_memcpy_h2d(ctx_, d_staging_, h_staging_.data(), total);
+  if (st != XVCGPU_OK) return st;
+  uint8_t *base = static_cast<uint8_t *>(d_staging_);
+  const xvcgpu_inter_block *d_inter = reinterpret_cast<const xvcgpu_inter_block *>(base + pc[0].off);
+  const xvcgpu_intra_block *d_intra = reinterpret_cast<const xvcgpu_intra_block *>(base + pc[1].off);
+  const xvcgpu_tx_block *d_tx = reinterpret_cast<const xvcgpu_tx_block *>(base + pc[2].off);
+  const uint32_t *d_off = reinterpret_cast<const uint32_t *>(base + pc[3].off);
+  const int32_t *d_nnz = reinterpret_cast<const int32_t *>(base + pc[4].off);
+  const xvcgpu_cu_info *d_cus = reinterpret_cast<const xvcgpu_cu_info *>(base + pc[5].off);
+  const int32_t *d_cell0 = reinterpret_cast<const int32_t *>(base + pc[6].off);
+  const int32_t *d_cell1 = reinterpret_cast<const int32_t *>(base + pc[7].off);
+  const int16_t *d_levels = reinterpret_cast<const int16_t *>(base + pc[8].off);
+
+  const xvcgpu_picture *refs[10];
+  for (int l = 0; l < 2; l++)
+    for (int k = 0; k < 5; k++)
+      if (p.ref_slot[l][k] >= 0) {
+        if (!ref_pics || !ref_pics[l][k]) return XVCGPU_INVALID_ARGUMENT;
+        refs[p.ref_slot[l][k]] = ref_pics[l][k];
+      }
+
+  int launches = 0;
+  for (int w = 0; w < p.n_waves; w++) {
+    const int i0 = p.inter_first[w], i1 = p.inter_first[w + 1];
+    if (i1 > i0) {
+      st = xvcgpu_inter_pred_batch(ctx_, refs, p.n_ref_slots, rec, pred_, d_inter + i0, i1 - i0);
+      if (st != XVCGPU_OK) return st;
+      launches++;
+    }
+    const int a0 = p.intra_first[w], a1 = p.intra_first[w + 1];
+    if (a1 > a0) {
+      st = xvcgpu_intra_pred_batch(ctx_, rec, pred_, d_intra + a0, a1 - a0);
+      if (st != XVCGPU_OK) return st;
+      launches++;
+    }
+    const int t0 = p.tx_first[w], t1 = p.tx_first[w + 1];
+    if (t1 > t0) {
+      st = xvcgpu_inv_transform_batch(ctx_, pred_, rec, d_tx + t0, t1 - t0, d_levels, d_off + t0,
+                                      d_nnz + t0);
+      if (st != XVCGPU_OK) return st;
+      launches += 2;
+    }
+  }
+  if (ps.deblock) {
+    const int bipic = ps.pic_type == XVC_PIC_BI;
+    if (p.two_trees) {
+      // deblocking_filter.cc:63-75: the primary tree filters luma on the
+      // 4-sample grid, the secondary tree chroma on the 8-sample grid
+      st = xvcgpu_deblock_tree(ctx_, rec, d_cus, ps.n_cus, d_cell0, p.map_stride, bipic,
+                               ps.beta_offset, ps.tc_offset, 4, 1);
+      if (st != XVCGPU_OK) return st;
+      st = xvcgpu_deblock_tree(ctx_, rec, d_cus, ps.n_cus, d_cell1, p.map_stride, bipic,
+                               ps.beta_offset, ps.tc_offset, 8, 2);
+    } else {
+      st = xvcgpu_deblock_tree(ctx_, rec, d_cus, ps.n_cus, d_cell0, p.map_stride, bipic,
+                               ps.beta_offset, ps.tc_offset, 4, 3);
+    }
+    if (st != XVCGPU_OK) return st;
+    launches += p.two_trees ? 4 : 2;
+  }
+  if (ps.pad_border) {
+    st = xvcgpu_pad_border(ctx_, rec);
+    if (st != XVCGPU_OK) return st;
+    launches++;
+  }
+  last_waves_ = p.n_waves;
+  last_launches_ = launches;
+  return XVCGPU_OK;
+}
+
+}  // namespace xvc_gpu
+
+struct xvc_host_picture_decoder {
+  xvc_gpu::PictureDecoder dec;
+  xvc_host_picture_decoder(xvcgpu_ctx *c, int w, int h, int bd) : dec(c, w, h, bd) {}
+};
+
+extern "C" {
+
+xvc_host_picture_decoder *xvc_host_picture_decoder_create(xvcgpu_ctx *ctx, int width, int height,
+                                                          int bitdepth) {
+  if (!ctx) return nullptr;
+  return new (std::nothrow) xvc_host_picture_decoder(ctx, width, height, bitdepth);
+}
+
+void xvc_host_picture_decoder_destroy(xvc_host_picture_decoder *d) { delete d; }
+
+int xvc_host_picture_decoder_decode(xvc_host_picture_decoder *d, const xvc_picture_syntax *ps,
+                                    const xvc_cu_syntax *cus, const int16_t *levels,
+                                    const xvcgpu_picture *const *ref_pics, xvcgpu_picture *rec) {
+  if (!d || !ps) return XVCGPU_INVALID_ARGUMENT;
+  const xvcgpu_picture *refs[2][5];
+  for (int l = 0; l < 2; l++)
+    for (int k = 0; k < 5; k++) refs[l][k] = ref_pics ? ref_pics[l * 5 + k] : nullptr;
+  return d->dec.Decode(*ps, cus, levels, refs, rec);
+}
+
+int xvc_host_picture_decoder_waves(const xvc_host_picture_decoder *d) {
+  return d ? d->dec.last_num_waves() : 0;
+}
+int xvc_host_picture_decoder_launches(const xvc_host_picture_decoder *d) {
+  return d ? d->dec.last_num_launches() : 0;
+}
+
+int xvc_host_plan_picture(const xvc_picture_syntax *ps, const xvc_cu_syntax *cus,
+                          const int16_t *levels, uint8_t *neighbors_out, int32_t *wave_out) {
+  if (!ps || !cus) return -1;
+  xvc_gpu::PicturePlan plan;
+  xvc_gpu::PictureDecoder::Plan(*ps, cus, levels, &plan);
+  for (int i = 0; i < ps->n_cus; i++) {
+    if (neighbors_out) {
+      for (int c = 0; c < 3; c++) {
+        neighbors_out[9 * i + c] = plan.neighbors[i].flags[c];
+        neighbors_out[9 * i + 3 + c] = plan.neighbors[i].above_right[c];
+        neighbors_out[9 * i + 6 + c] = plan.neighbors[i].below_left[c];
+      }
+    }
+    if (wave_out) wave_out[i] = plan.wave[i];
+  }
+  return plan.n_waves;
+}
+
+}  // extern "C"

@@ -1,0 +1,128 @@
+// xvc_picture_decoder.h -- the reconstruction half of xvc::PictureDecoder
+// (xvc_dec_lib/picture_decoder.cc:169-210) and xvc::CuDecoder::DecompressCu
+// (xvc_dec_lib/cu_decoder.cc:84-138) on the device, behind the C-ABI
+// (include/xvcgpu.h).  C++11 host code; the only thing it calls is xvcgpu_*.
+//
+// The reference decodes a picture CTU by CTU: parse a CTU (CABAC), then
+// reconstruct its CUs one after the other.  Parsing is bit-serial and stays
+// where it is; its result - the leaf CUs in coding order with their modes,
+// final vectors, transform types and levels (include/xvc_syntax.h) - is the
+// input here, and everything after it is decision-free:
+//
+//   reference (per CU, serial)                       here (per picture)
+//   -----------------------------------------------  ------------------------------------
+//   PictureData::MarkUsedInPic + neighbour lookups    one pass over the CU list builds the
+//     (picture_data.cc:191-210, coding_unit.cc)       4x4 cell map and every CU's
+//                                                     neighbour state at its coding time
+//   InterPrediction::MotionCompensation               wave 0: one xvcgpu_inter_pred_batch
+//     (inter_prediction.cc:710-738)                   over all inter CUs without LIC
+//   IntraPrediction::FillReferenceState + Predict,    dependency waves over the real CU
+//     LIC model (needs neighbouring reconstruction)   tree: wave(cu) = 1 + max(wave of the
+//                                                     CUs whose samples it reads)
+//   Quantize::Inverse, InverseTransform, AddClip      xvcgpu_inv_transform_batch per wave
+//   DeblockingFilter::DeblockPicture (two CU trees    xvcgpu_deblock_tree (luma by the
+//     in intra pictures, deblocking_filter.cc:56-77)  primary tree, chroma by the secondary)
+//   YuvPicture::PadBorder                             xvcgpu_pad_border
+//
+// One host -> device copy per picture carries all job lists, the cell maps and
+// the levels (a single packed staging buffer); the launches of a picture are
+// 2 + 3 * waves, enqueued without any synchronisation.
+#ifndef XVC_AMD_HOST_XVC_PICTURE_DECODER_H_
+#define XVC_AMD_HOST_XVC_PICTURE_DECODER_H_
+
+#include <cstdint>
+#include <vector>
+
+#include "xvc_syntax.h"
+#include "xvcgpu.h"
+
+namespace xvc_gpu {
+
+// What a CU reads from its neighbourhood, evaluated at its place in coding
+// order (exposed for the host-side tests: compared with what the reference's
+// IntraPrediction::DetermineNeighbors reported).
+struct CuNeighbors {
+  uint8_t flags[3];        // XVC_INTRA_HAS_* per component
+  uint8_t above_right[3];  // CodingUnit::GetCuSizeAboveRight(comp)
+  uint8_t below_left[3];   // CodingUnit::GetCuSizeBelowLeft(comp)
+};
+
+// The schedule of one picture (pure host data, no device work): exposed so the
+// planning step can be tested without a GPU.
+struct PicturePlan {
+  int map_stride = 0, map_rows = 0;
+  std::vector<int32_t> cell[2];       // per CU tree: coding index of the CU per 4x4 cell
+  std::vector<int32_t> wave;          // per CU
+  std::vector<CuNeighbors> neighbors; // per CU (intra CUs)
+  int n_waves = 0;
+  // jobs grouped by wave: wave w owns [first[w], first[w + 1]) of each list
+  std::vector<xvcgpu_inter_block> inter;
+  std::vector<int32_t> inter_first;
+  std::vector<xvcgpu_intra_block> intra;
+  std::vector<int32_t> intra_first;
+  std::vector<xvcgpu_tx_block> tx;
+  std::vector<uint32_t> tx_level_off;
+  std::vector<int32_t> tx_nnz;
+  std::vector<int32_t> tx_first;
+  std::vector<xvcgpu_cu_info> cu_info;
+  bool two_trees = false;
+  int n_ref_slots = 0;
+  int ref_slot[2][5];                 // [list][ref_idx] -> slot in the reference table
+};
+
+class PictureDecoder {
+ public:
+  PictureDecoder(xvcgpu_ctx *ctx, int width, int height, int bitdepth);
+  ~PictureDecoder();
+  PictureDecoder(const PictureDecoder &) = delete;
+  PictureDecoder &operator=(const PictureDecoder &) = delete;
+
+  // Host-only: the schedule and job lists for a picture.
+  static void Plan(const xvc_picture_syntax &ps, const xvc_cu_syntax *cus, const int16_t *levels,
+                   PicturePlan *plan);
+
+  // PictureDecoder::Decode after the parse (picture_decoder.cc:178-196): all CUs
+  // of the picture into `rec`, in-loop filter, border extension.  ref_pics[l][i]
+  // = the picture ReferencePictureLists::GetRefPic(l, i) names.  Asynchronous on
+  // the context's stream; returns the status of the first failing call.
+  xvcgpu_status Decode(const xvc_picture_syntax &ps, const xvc_cu_syntax *cus,
+                       const int16_t *levels, const xvcgpu_picture *const ref_pics[2][5],
+                       xvcgpu_picture *rec);
+
+  int last_num_waves() const { return last_waves_; }
+  int last_num_launches() const { return last_launches_; }
+
+ private:
+  xvcgpu_status EnsureStaging(size_t bytes);
+  xvcgpu_ctx *ctx_;
+  int width_, height_, bitdepth_;
+  xvcgpu_picture *pred_;   // the prediction of the wave in flight (CuDecoder::temp_pred_)
+  void *d_staging_;
+  size_t staging_cap_;
+  std::vector<uint8_t> h_staging_;
+  PicturePlan plan_;
+  int last_waves_, last_launches_;
+};
+
+}  // namespace xvc_gpu
+
+// C entry points over the class (for bindings that cannot take C++ types, e.g.
+// the ctypes tests): thin, no logic.
+extern "C" {
+typedef struct xvc_host_picture_decoder xvc_host_picture_decoder;
+xvc_host_picture_decoder *xvc_host_picture_decoder_create(xvcgpu_ctx *ctx, int width, int height,
+                                                          int bitdepth);
+void xvc_host_picture_decoder_destroy(xvc_host_picture_decoder *d);
+int xvc_host_picture_decoder_decode(xvc_host_picture_decoder *d, const xvc_picture_syntax *ps,
+                                    const xvc_cu_syntax *cus, const int16_t *levels,
+                                    const xvcgpu_picture *const *ref_pics /* [2][5] */,
+                                    xvcgpu_picture *rec);
+int xvc_host_picture_decoder_waves(const xvc_host_picture_decoder *d);
+int xvc_host_picture_decoder_launches(const xvc_host_picture_decoder *d);
+// Host-only planning check: neighbour state per CU (9 bytes: flags[3],
+// above_right[3], below_left[3]) and the wave of every CU.
+int xvc_host_plan_picture(const xvc_picture_syntax *ps, const xvc_cu_syntax *cus,
+                          const int16_t *levels, uint8_t *neighbors_out, int32_t *wave_out);
+}
+
+#endif  // XVC_AMD_HOST_XVC_PICTURE_DECODER_H_
