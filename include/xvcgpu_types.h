@@ -215,10 +215,53 @@ typedef struct xvcgpu_tx_block {
  * the diagonal coefficient scan. */
 #define XVC_TXF_INTRA_PIC 1       /* pic_type == kIntra: rounding offset 171/512 */
 #define XVC_TXF_NO_SIGN_HIDING 2  /* Restrictions::disable_transform_sign_hiding */
+#define XVC_TXF_RDOQ 16           /* quantise with RdoQuant::QuantRdo (needs the
+                                   * batch's xvcgpu_rdoq_params / contexts)   */
 #define XVC_TXF_SCAN_SHIFT 2      /* bits 2-3: ScanOrder of the CU, 0 diagonal,
                                    * 1 horizontal, 2 vertical
                                    * (TransformHelper::DetermineScanOrder,
                                    * transform.cc:1614-1637)                  */
+
+/* ---- RDOQ (RdoQuant::QuantRdo, rdo_quant.cc:203-446) ---------------------- *
+ * The quantiser the reference's encoder always runs (encoder_settings.h:59,
+ * transform_encoder.cc:230).  It reads the entropy coder only through
+ * ContextModel::GetEntropyBits of the coefficient-coding contexts of
+ * writer.GetContexts() (rdo_quant.cc:254): the host snapshots those context
+ * states (ContextModel::state_: (state << 1) | mps, 0..127) once per batch -
+ * the extended residual context set (Contexts::coeff_ext, cabac.h:158-166;
+ * the reference's default: disable_ext2_cabac_alt_residual_ctx == false). */
+typedef struct xvcgpu_rdoq_contexts {
+  uint8_t csbf[2][2];        /* coeff_ext.csbf_luma / csbf_chroma              */
+  uint8_t sig_luma[54];      /* coeff_ext.sig_luma                             */
+  uint8_t sig_chroma[12];    /* coeff_ext.sig_chroma                           */
+  uint8_t greater1_luma[16]; /* coeff_ext.greater1_luma (also the greater2
+                              * contexts in this set, cabac.cc:641-665)        */
+  uint8_t greater1_chroma[6];
+  uint8_t last_x_luma[25];   /* coeff_last_pos_x_luma                          */
+  uint8_t last_y_luma[25];
+  uint8_t last_x_chroma[3];
+  uint8_t last_y_chroma[3];
+  uint8_t cbf_luma;          /* cu_cbf_luma[0]   (intra CU, luma)              */
+  uint8_t cbf_chroma;        /* cu_cbf_chroma[0] (chroma)                      */
+  uint8_t root_cbf;          /* cu_root_cbf[0]   (inter CU, luma)              */
+  uint8_t reserved;
+} xvcgpu_rdoq_contexts;
+
+/* Per (CU, component) inputs of QuantRdo that are double arithmetic in the
+ * reference and therefore computed by the host:
+ *   lambda    = (int64)(qp.GetLambdaScaled(comp) * 65536 + 0.5)   (:251-252)
+ *   rd_factor = (int64)(inv_scale * inv_scale / lambda / 16 /
+ *               (1 << 2 * (bitdepth - 8)) + 0.5)                  (:590-594) */
+#define XVC_RDOQ_INTRA_CU 1   /* cu.IsIntra(): the luma cbf context (:756-758) */
+#define XVC_RDOQ_NO_2X2 2     /* !encoder_settings.rdo_quant_2x2: 2-wide blocks
+                               * take QuantFast (:208-216)                     */
+typedef struct xvcgpu_rdoq_params {
+  int64_t lambda;
+  int64_t rd_factor;
+  uint16_t ctx_index;        /* which xvcgpu_rdoq_contexts of the batch        */
+  uint8_t flags;             /* XVC_RDOQ_*                                     */
+  uint8_t reserved[5];
+} xvcgpu_rdoq_params;
 
 /* One motion-compensation job (InterPrediction::MotionCompensationMv,
  * inter_prediction.cc:740-758) for one component of one uni-pred CU. */

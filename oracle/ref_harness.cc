@@ -1276,4 +1276,109 @@ void xr_mc_lic_block(int bd, const xvcgpu_mc_lic_block *b, int above_w, int abov
                           MotionVector(b->mv_x, b->mv_y), true, &pb);
   r.disable_ext2_inter_local_illumination_comp = saved;
 }
+
+/* ---- Q2: RdoQuant::QuantRdo (rdo_quant.cc:203-446) ------------------------- */
+namespace {
+void LoadContexts(const xvcgpu_rdoq_contexts &c, Contexts *ctx) {
+  for (int i = 0; i < 2; i++) {
+    ctx->coeff_ext.csbf_luma[i].state_ = c.csbf[0][i];
+    ctx->coeff_ext.csbf_chroma[i].state_ = c.csbf[1][i];
+  }
+  for (int i = 0; i < 54; i++) ctx->coeff_ext.sig_luma[i].state_ = c.sig_luma[i];
+  for (int i = 0; i < 12; i++) ctx->coeff_ext.sig_chroma[i].state_ = c.sig_chroma[i];
+  for (int i = 0; i < 16; i++) ctx->coeff_ext.greater1_luma[i].state_ = c.greater1_luma[i];
+  for (int i = 0; i < 6; i++) ctx->coeff_ext.greater1_chroma[i].state_ = c.greater1_chroma[i];
+  for (int i = 0; i < 25; i++) {
+    ctx->coeff_last_pos_x_luma[i].state_ = c.last_x_luma[i];
+    ctx->coeff_last_pos_y_luma[i].state_ = c.last_y_luma[i];
+  }
+  for (int i = 0; i < 3; i++) {
+    ctx->coeff_last_pos_x_chroma[i].state_ = c.last_x_chroma[i];
+    ctx->coeff_last_pos_y_chroma[i].state_ = c.last_y_chroma[i];
+  }
+  ctx->cu_cbf_luma[0].state_ = c.cbf_luma;
+  ctx->cu_cbf_chroma[0].state_ = c.cbf_chroma;
+  ctx->cu_root_cbf[0].state_ = c.root_cbf;
+}
+void StoreContexts(const Contexts &ctx, xvcgpu_rdoq_contexts *c) {
+  std::memset(c, 0, sizeof(*c));
+  for (int i = 0; i < 2; i++) {
+    c->csbf[0][i] = ctx.coeff_ext.csbf_luma[i].state_;
+    c->csbf[1][i] = ctx.coeff_ext.csbf_chroma[i].state_;
+  }
+  for (int i = 0; i < 54; i++) c->sig_luma[i] = ctx.coeff_ext.sig_luma[i].state_;
+  for (int i = 0; i < 12; i++) c->sig_chroma[i] = ctx.coeff_ext.sig_chroma[i].state_;
+  for (int i = 0; i < 16; i++) c->greater1_luma[i] = ctx.coeff_ext.greater1_luma[i].state_;
+  for (int i = 0; i < 6; i++) c->greater1_chroma[i] = ctx.coeff_ext.greater1_chroma[i].state_;
+  for (int i = 0; i < 25; i++) {
+    c->last_x_luma[i] = ctx.coeff_last_pos_x_luma[i].state_;
+    c->last_y_luma[i] = ctx.coeff_last_pos_y_luma[i].state_;
+  }
+  for (int i = 0; i < 3; i++) {
+    c->last_x_chroma[i] = ctx.coeff_last_pos_x_chroma[i].state_;
+    c->last_y_chroma[i] = ctx.coeff_last_pos_y_chroma[i].state_;
+  }
+  c->cbf_luma = ctx.cu_cbf_luma[0].state_;
+  c->cbf_chroma = ctx.cu_cbf_chroma[0].state_;
+  c->root_cbf = ctx.cu_root_cbf[0].state_;
+}
+}  // namespace
+
+const uint32_t *xr_entropy_bits_table(void) { return &ContextModel::kEntropyBits_[0]; }
+
+/* The context states a fresh SyntaxWriter starts a picture with
+ * (CabacContexts::ResetStates for the picture qp / type). */
+void xr_rdoq_init_contexts(int bd, int qp_raw, int pic_type, xvcgpu_rdoq_contexts *out) {
+  Qp qp = MakeQp(qp_raw, bd);
+  BitWriter bw;
+  SyntaxWriter writer(qp, static_cast<PicturePredictionType>(pic_type), &bw);
+  StoreContexts(writer.GetContexts(), out);
+}
+
+/* RdoQuant::QuantRdo for component `comp` of a CU whose component block is
+ * w x h, with the given context states.  qp_raw_luma / lambda build the Qp as
+ * PictureData::Init does; the component's raw qp and the two host-side
+ * constants of xvcgpu_rdoq_params (as the reference's doubles give them) are
+ * returned so that the oracle can be fed the same inputs.  prm_io->flags in;
+ * lambda / rd_factor out. */
+int xr_quant_rdo(int bd, int qp_raw_luma, double lambda, int comp, int scan_order, int sign_hide,
+                 int w, int h, const xvcgpu_rdoq_contexts *ctx, xvcgpu_rdoq_params *prm_io,
+                 int *comp_qp_raw, const int16_t *src, ptrdiff_t is, int16_t *out,
+                 ptrdiff_t os) {
+  PictureData pic_data(ChromaFormat::k420, 64, 64, bd);
+  const int s = comp ? 1 : 0;
+  CodingUnit *cu = pic_data.CreateCu(CuTree::Primary, 0, 0, 0, w << s, h << s);
+  const bool intra = (prm_io->flags & XVC_RDOQ_INTRA_CU) != 0;
+  cu->SetPredMode(intra ? PredictionMode::kIntra : PredictionMode::kInter);
+  if (intra) {
+    cu->SetIntraModeLuma(scan_order == 1   ? IntraPrediction::Convert(IntraAngle::kVertical)
+                         : scan_order == 2 ? IntraPrediction::Convert(IntraAngle::kHorizontal)
+                                           : IntraMode::kDc);
+    cu->SetIntraModeChroma(IntraChromaMode::kDmChroma);
+  }
+  Qp qp(qp_raw_luma, ChromaFormat::k420, bd, lambda, 1, 0, 0);
+  const YuvComponent yc = YuvComponent(comp);
+  *comp_qp_raw = qp.GetQpRaw(yc);
+  prm_io->lambda = static_cast<int64_t>(qp.GetLambdaScaled(yc) * (1 << 16) + 0.5);
+  {
+    const double lam = qp.GetLambdaScaled(yc);
+    const double inv_scale = qp.GetInvScale(yc);
+    prm_io->rd_factor = static_cast<int64_t>(inv_scale * inv_scale / lam / 16 /
+                                             (1ull << (2 * (bd - 8))) + 0.5);
+  }
+  BitWriter bw;
+  SyntaxWriter writer(qp, PicturePredictionType::kBi, &bw);
+  LoadContexts(*ctx, &writer.ctx_);
+  EncoderSettings es;
+  es.Initialize(SpeedMode::kSlow);
+  es.rdo_quant_2x2 = (prm_io->flags & XVC_RDOQ_NO_2X2) ? 0 : 1;
+  RdoQuant rq(bd, es);
+  Restrictions &r = Restrictions::GetRW();
+  const bool saved = r.disable_transform_sign_hiding;
+  r.disable_transform_sign_hiding = !sign_hide;
+  assert(static_cast<int>(TransformHelper::DetermineScanOrder(*cu, yc)) == scan_order);
+  const int nnz = rq.QuantRdo(*cu, yc, qp, PicturePredictionType::kBi, writer, src, is, out, os);
+  r.disable_transform_sign_hiding = saved;
+  return nnz;
+}
 }  // extern "C"

@@ -301,6 +301,13 @@ void xo_intra_pred_block(int bitdepth, const xvcgpu_intra_block *b, const uint16
 void xo_intra_satd_modes(int bitdepth, const xvcgpu_intra_block *b, const uint16_t *orig,
                          ptrdiff_t os, const uint16_t *rec, ptrdiff_t rs, uint32_t *dist);
 
+/* ---- Q2: RdoQuant::QuantRdo + CoeffSignHideRdo (xvc_oracle_rdoq.c;
+ * rdo_quant.cc:203-446, :575-687) with the extended residual context set. ---- */
+int xo_quant_rdo(int bd, int qp_raw, int comp, int scan_order, int sign_hide, int w, int h,
+                 const xvcgpu_rdoq_contexts *ctx, const xvcgpu_rdoq_params *prm,
+                 const int16_t *src, ptrdiff_t is, int16_t *out, ptrdiff_t os);
+const uint32_t *xo_entropy_bits_table(void);
+
 /* ---- decoder reconstruction (xvc_oracle_dec.c) ---- */
 #include "../include/xvc_syntax.h"
 void xo_inter_pred_block(int bd, const xvcgpu_inter_block *b, int pic_w, int pic_h,

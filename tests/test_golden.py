@@ -39,6 +39,22 @@ def test_golden_manifest():
     assert seen == len([f for f in os.listdir(G) if f.endswith(".npz")])
 
 
+def test_oracle_rdoq(xo):
+    """RdoQuant::QuantRdo + CoeffSignHideRdo: the reference's levels for 432
+    coefficient blocks (every shape 2..64, luma / chroma, three scans, bit
+    depths 8 / 10 / 12, initialised and arbitrary context states)."""
+    import oracle_rdoq as oq
+    g = load("rdoq")
+    for i, (bd, cqp, comp, scan, sign_hide, w, h, nnz) in enumerate(g["cases"]):
+        ctx = g["contexts"][i].view(oq.RDOQ_CTX_DTYPE)
+        prm = g["params"][i].view(oq.RDOQ_PARAMS_DTYPE)
+        src = np.ascontiguousarray(g["src"][i][:h, :w])
+        got_nnz, got = oq.quant_rdo_oracle(xo, int(bd), int(cqp), int(comp), int(scan),
+                                           int(sign_hide), ctx, prm, src)
+        assert got_nnz == nnz and np.array_equal(got, g["levels"][i][:h, :w]), (i, bd, w, h)
+    assert len(g["cases"]) == 432
+
+
 def test_oracle_metrics(xo):
     g = load("metrics")
     for i, (bd, w, h, metric, qp) in enumerate(g["cases"]):

@@ -853,3 +853,48 @@ def test_affine_me(libs, bd):
             boot += bool(b["flags"]) and np.array_equal(got["mv"], b["bootstrap"])
             nbi += bool(int(b["flags"]) & oa.BIPRED)
     assert moved > 60 and iters > 200 and nbi > 40
+
+
+# ---- Q2: RdoQuant::QuantRdo + CoeffSignHideRdo ---------------------------------
+def test_entropy_bits_table(libs):
+    xo, xr = libs
+    xo.dll.xo_entropy_bits_table.restype = C.POINTER(C.c_uint32 * 128)
+    xr.dll.xr_entropy_bits_table.restype = C.POINTER(C.c_uint32 * 128)
+    assert list(xo.dll.xo_entropy_bits_table().contents) == \
+        list(xr.dll.xr_entropy_bits_table().contents)
+
+
+@pytest.mark.parametrize("bd", [8, 10, 12])
+def test_quant_rdo(libs, bd):
+    """The oracle's RDOQ == RdoQuant::QuantRdo for every block shape 2..64 x
+    2..64, luma and chroma, the three scans, sign hiding on / off, random and
+    freshly initialised context states, a range of qp / lambda."""
+    import oracle_rdoq as oq
+    xo, xr = libs
+    rng = np.random.default_rng(4100 + bd)
+    sizes = [2, 4, 8, 16, 32, 64]
+    n = 0
+    for w in sizes:
+        for h in sizes:
+            for rep in range(8):
+                comp = int(rng.integers(0, 3)) if max(w, h) <= 32 else 0
+                intra = bool(rng.integers(0, 2))
+                scan = 0
+                if intra and (w << (1 if comp else 0)) < 16 and (h << (1 if comp else 0)) < 16:
+                    scan = int(rng.integers(0, 3))
+                flags = (oq.RDOQ_INTRA_CU if intra else 0) | \
+                    (oq.RDOQ_NO_2X2 if rng.integers(0, 4) == 0 else 0)
+                qp = int(rng.integers(12, 46))
+                lam = 0.57 * 2.0 ** ((qp - 12) / 3.0) * float(rng.uniform(0.5, 2.0))
+                ctx = oq.random_contexts(rng) if rep % 2 else \
+                    oq.init_contexts(xr, bd, qp, int(rng.integers(0, 3)))
+                sign_hide = int(rng.integers(0, 4) != 0)
+                src = oq.random_coeffs(rng, w, h, bd, rep, qp)
+                e_nnz, e_out, prm, cqp = oq.quant_rdo_reference(
+                    xr, bd, qp, lam, comp, scan, sign_hide, ctx, flags, src)
+                g_nnz, g_out = oq.quant_rdo_oracle(xo, bd, cqp, comp, scan, sign_hide, ctx, prm,
+                                                   src)
+                assert g_nnz == e_nnz and np.array_equal(g_out, e_out), \
+                    (bd, w, h, comp, scan, sign_hide, flags, qp, rep)
+                n += e_nnz > 1
+    assert n > 140      # most of the 288 cases code several levels

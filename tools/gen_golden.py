@@ -358,6 +358,46 @@ def gen_frame(xr):
     np.savez_compressed(os.path.join(OUT, "frame.npz"), **out)
 
 
+def gen_rdoq(xr):
+    """RdoQuant::QuantRdo (rdo_quant.cc:203-446) with CoeffSignHideRdo: the
+    reference's levels for coefficient blocks of every shape, luma / chroma,
+    all scans, with freshly initialised and arbitrary context states."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_rdoq as oq
+    rng = np.random.default_rng(20260929)
+    cases, ctxs, prms, srcs, outs = [], [], [], [], []
+    sizes = [2, 4, 8, 16, 32, 64]
+    for bd in (8, 10, 12):
+        for w in sizes:
+            for h in sizes:
+                for rep in range(3 if bd != 10 else 6):
+                    comp = int(rng.integers(0, 3)) if max(w, h) <= 32 else 0
+                    intra = bool(rng.integers(0, 2))
+                    s = 1 if comp else 0
+                    scan = int(rng.integers(0, 3)) if intra and (w << s) < 16 and (h << s) < 16 \
+                        else 0
+                    flags = (oq.RDOQ_INTRA_CU if intra else 0) | \
+                        (oq.RDOQ_NO_2X2 if rng.integers(0, 4) == 0 else 0)
+                    qp = int(rng.integers(12, 46))
+                    lam = 0.57 * 2.0 ** ((qp - 12) / 3.0) * float(rng.uniform(0.5, 2.0))
+                    ctx = oq.random_contexts(rng) if rep % 2 else \
+                        oq.init_contexts(xr, bd, qp, int(rng.integers(0, 3)))
+                    sign_hide = int(rng.integers(0, 4) != 0)
+                    src = oq.random_coeffs(rng, w, h, bd, rep, qp)
+                    nnz, out, prm, cqp = oq.quant_rdo_reference(xr, bd, qp, lam, comp, scan,
+                                                                sign_hide, ctx, flags, src)
+                    cases.append((bd, cqp, comp, scan, sign_hide, w, h, nnz))
+                    ctxs.append(ctx.view(np.uint8).reshape(-1))
+                    prms.append(prm.view(np.uint8).reshape(-1))
+                    ps = np.zeros((64, 64), np.int16); ps[:h, :w] = src
+                    po = np.zeros((64, 64), np.int16); po[:h, :w] = out
+                    srcs.append(ps); outs.append(po)
+    np.savez_compressed(os.path.join(OUT, "rdoq.npz"), cases=np.array(cases, np.int32),
+                        contexts=np.array(ctxs), params=np.array(prms), src=np.array(srcs),
+                        levels=np.array(outs))
+    print("rdoq: %d cases, %d with levels" % (len(cases), sum(c[7] > 0 for c in cases)))
+
+
 def write_manifest():
     import hashlib
     with open(os.path.join(OUT, "MANIFEST.md5"), "w") as f:
@@ -393,6 +433,10 @@ def main():
         return
     if sys.argv[1:] == ["frame"]:
         gen_frame(xr)
+        write_manifest()
+        return
+    if sys.argv[1:] == ["rdoq"]:
+        gen_rdoq(xr)
         write_manifest()
         return
     if sys.argv[1:] == ["quant_sh"]:
@@ -544,6 +588,7 @@ def main():
                         cases=np.array(cases, np.int64), a=np.array(a_l), b=np.array(b_l))
     gen_bipred(xr)
     gen_quant_sh(xr)
+    gen_rdoq(xr)
     write_manifest()
     total = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))
     print("golden fixtures written to", OUT, "total bytes", total)
