@@ -330,6 +330,40 @@ xvcgpu_status xvcgpu_residual_batch(xvcgpu_ctx *ctx, const xvcgpu_picture *orig,
                                     int16_t *d_levels,
                                     const uint32_t *d_level_offsets,
                                     int32_t *d_nnz);
+/* The same with the quantiser the reference's encoder always runs (Q2:
+ * RdoQuant::QuantRdo with CoeffSignHideRdo, rdo_quant.cc:203-446, :575-687;
+ * selected by transform_encoder.cc:230 because encoder_settings.h:59 is
+ * rdo_quant = true) for the blocks whose intra_pic field carries XVC_TXF_RDOQ;
+ * the others take QuantFast as above.  d_params[i] belongs to d_blocks[i]
+ * (lambda and rd_factor in fixed point, computed by the host from the
+ * reference's doubles; which context snapshot; intra / inter CU);
+ * d_contexts[d_params[i].ctx_index] = the CABAC context states of the syntax
+ * writer the reference would pass (rdo_quant.cc:254), read through
+ * ContextModel::GetEntropyBits only.  Levels, non-zero counts and the
+ * reconstruction are bit-identical to the reference's for any block size
+ * 2..64 x 2..64 and any transform type pair. */
+xvcgpu_status xvcgpu_residual_rdoq_batch(xvcgpu_ctx *ctx, const xvcgpu_picture *orig,
+                                         const xvcgpu_picture *pred, xvcgpu_picture *rec,
+                                         const xvcgpu_tx_block *d_blocks, int n,
+                                         int16_t *d_levels, const uint32_t *d_level_offsets,
+                                         int32_t *d_nnz,
+                                         const xvcgpu_rdoq_contexts *d_contexts,
+                                         const xvcgpu_rdoq_params *d_params);
+
+/* Q2 alone: RdoQuant::QuantRdo on coefficients the caller holds (the output
+ * of xvcgpu_fwd_transform_batch; the levels go to xvcgpu_inv_transform_batch):
+ * block i reads w*h int16 at d_coeffs + d_offsets[i] and writes its levels at
+ * d_levels + d_offsets[i], d_nnz[i] = RdoQuant::QuantRdo's return value.  Only
+ * w, h, comp, qp and the XVC_TXF_NO_SIGN_HIDING / scan bits of a block are
+ * read.  Blocks whose XVC_RDOQ_NO_2X2 case applies (2-wide, rdo_quant_2x2
+ * off) are NOT taken here: route them to xvcgpu_residual_batch. */
+xvcgpu_status xvcgpu_quant_rdo_batch(xvcgpu_ctx *ctx, int bitdepth,
+                                     const xvcgpu_tx_block *d_blocks, int n,
+                                     const int16_t *d_coeffs, const uint32_t *d_offsets,
+                                     int16_t *d_levels, int32_t *d_nnz,
+                                     const xvcgpu_rdoq_contexts *d_contexts,
+                                     const xvcgpu_rdoq_params *d_params);
+
 /* I1 + the above fused, for the uni-pred inter CUs of a motion search batch
  * (InterSearch::CompressAndEvalCbf without the RD bookkeeping,
  * inter_search.cc:261-365): for CU i and each component, motion-compensate

@@ -307,6 +307,10 @@ int xo_quant_rdo(int bd, int qp_raw, int comp, int scan_order, int sign_hide, in
                  const xvcgpu_rdoq_contexts *ctx, const xvcgpu_rdoq_params *prm,
                  const int16_t *src, ptrdiff_t is, int16_t *out, ptrdiff_t os);
 const uint32_t *xo_entropy_bits_table(void);
+int xo_residual_pipeline_rdoq(int bd, const xvcgpu_tx_block *b, const xvcgpu_rdoq_contexts *ctx,
+                              const xvcgpu_rdoq_params *prm, const uint16_t *orig, ptrdiff_t os,
+                              const uint16_t *pred, ptrdiff_t ps, uint16_t *rec, ptrdiff_t rs,
+                              int16_t *coeff_out);
 
 /* ---- decoder reconstruction (xvc_oracle_dec.c) ---- */
 #include "../include/xvc_syntax.h"

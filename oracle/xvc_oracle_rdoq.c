@@ -569,3 +569,46 @@ int xo_quant_rdo(int bd, int qp_raw, int comp, int scan_order, int sign_hide, in
   }
   return nnz;
 }
+
+/* TransformEncoder::TransformAndReconstruct (transform_encoder.cc:203-285) with
+ * the quantiser it really calls, QuantRdo (:230); blocks without XVC_TXF_RDOQ
+ * go through xo_residual_pipeline (QuantFast).  Same conventions. */
+int xo_residual_pipeline_rdoq(int bd, const xvcgpu_tx_block *b, const xvcgpu_rdoq_contexts *ctx,
+                              const xvcgpu_rdoq_params *prm, const uint16_t *orig, ptrdiff_t os,
+                              const uint16_t *pred, ptrdiff_t ps, uint16_t *rec, ptrdiff_t rs,
+                              int16_t *coeff_out) {
+  if (!(b->intra_pic & XVC_TXF_RDOQ))
+    return xo_residual_pipeline(bd, b, orig, os, pred, ps, rec, rs, coeff_out);
+  static __thread int16_t resi[64 * 64], coeff[64 * 64], deq[64 * 64];
+  const int w = b->w, h = b->h;
+  memset(resi, 0, sizeof(resi));
+  const uint16_t *o = orig + (ptrdiff_t)b->y * os + b->x;
+  const uint16_t *p = pred + (ptrdiff_t)b->y * ps + b->x;
+  uint16_t *r = rec + (ptrdiff_t)b->y * rs + b->x;
+  for (int y = 0; y < h; y++)
+    for (int x = 0; x < w; x++) resi[y * 64 + x] = (int16_t)((int)o[y * os + x] - (int)p[y * ps + x]);
+  const int skip = b->tx_hor == XVC_TX_SKIP;
+  if (skip)
+    xo_fwd_transform_skip(bd, w, h, resi, 64, coeff, 64);
+  else
+    xo_fwd_transform(bd, w, h, b->tx_hor, b->tx_ver, b->dst4x4, resi, 64, coeff, 64);
+  const int nnz = xo_quant_rdo(bd, b->qp, b->comp, (b->intra_pic >> XVC_TXF_SCAN_SHIFT) & 3,
+                               !(b->intra_pic & XVC_TXF_NO_SIGN_HIDING), w, h,
+                               &ctx[prm->ctx_index], prm, coeff, 64, coeff_out, w);
+  if (nnz) {
+    const int dc_only = nnz == 1 && coeff_out[0] != 0;
+    xo_dequant(bd, b->qp, w, h, coeff_out, w, deq, 64);
+    if (skip)
+      xo_inv_transform_skip(bd, w, h, deq, 64, resi, 64);
+    else
+      xo_inv_transform(bd, w, h, b->tx_hor, b->tx_ver, b->dst4x4, dc_only, deq, 64, resi, 64);
+    const int smax = (1 << bd) - 1;
+    for (int y = 0; y < h; y++)
+      for (int x = 0; x < w; x++)
+        r[y * rs + x] = (uint16_t)xo_clip3((int)p[y * ps + x] + resi[y * 64 + x], 0, smax);
+  } else {
+    for (int y = 0; y < h; y++)
+      for (int x = 0; x < w; x++) r[y * rs + x] = p[y * ps + x];
+  }
+  return nnz;
+}

@@ -78,6 +78,17 @@ INTER_DTYPE = np.dtype([("x", "<i2"), ("y", "<i2"), ("w", "u1"), ("h", "u1"), ("
                         ("left_x", "<i2"), ("left_y", "<i2"), ("mv", "<i4", (2, 3, 2))])
 assert INTER_DTYPE.itemsize == 68
 INTER_AFFINE, INTER_LIC = 1, 2
+RDOQ_CTX_DTYPE = np.dtype([
+    ("csbf", "u1", (2, 2)), ("sig_luma", "u1", (54,)), ("sig_chroma", "u1", (12,)),
+    ("greater1_luma", "u1", (16,)), ("greater1_chroma", "u1", (6,)),
+    ("last_x_luma", "u1", (25,)), ("last_y_luma", "u1", (25,)), ("last_x_chroma", "u1", (3,)),
+    ("last_y_chroma", "u1", (3,)), ("cbf_luma", "u1"), ("cbf_chroma", "u1"), ("root_cbf", "u1"),
+    ("reserved", "u1")])
+RDOQ_PARAMS_DTYPE = np.dtype([("lambda", "<i8"), ("rd_factor", "<i8"), ("ctx_index", "<u2"),
+                              ("flags", "u1"), ("reserved", "u1", (5,))])
+assert RDOQ_CTX_DTYPE.itemsize == 152 and RDOQ_PARAMS_DTYPE.itemsize == 24
+RDOQ_INTRA_CU, RDOQ_NO_2X2 = 1, 2
+TXF_RDOQ = 16
 INTRA_NUM_MODES = 67
 INTRA_HAS_ABOVE_LEFT, INTRA_HAS_ABOVE, INTRA_HAS_LEFT = 1, 2, 4
 # xvcgpu_tx_block.intra_pic flag bits (include/xvcgpu_types.h XVC_TXF_*)
@@ -127,6 +138,7 @@ SYMBOLS = [
     "xvcgpu_intra_pred_batch", "xvcgpu_intra_satd_batch", "xvcgpu_intra_recon_batch",
     "xvcgpu_intra_select_modes", "xvcgpu_frame_pass", "xvcgpu_copy_segments",
     "xvcgpu_get_transform_matrix", "xvcgpu_inter_pred_batch", "xvcgpu_deblock_tree",
+    "xvcgpu_residual_rdoq_batch", "xvcgpu_quant_rdo_batch",
 ]
 
 _vp = C.c_void_p
@@ -234,6 +246,8 @@ def load_library():
         "xvcgpu_copy_segments": [_vp, _vp, C.c_int],
         "xvcgpu_get_transform_matrix": [C.c_int, C.c_int, _vp],
         "xvcgpu_inter_pred_batch": [_vp, C.POINTER(_vp), C.c_int, _vp, _vp, _vp, C.c_int],
+        "xvcgpu_residual_rdoq_batch": [_vp, _vp, _vp, _vp, _vp, C.c_int, _vp, _vp, _vp, _vp, _vp],
+        "xvcgpu_quant_rdo_batch": [_vp, C.c_int, _vp, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp],
         "xvcgpu_deblock_tree": [_vp, _vp, _vp, C.c_int, _vp, C.c_int, C.c_int, C.c_int,
                                 C.c_int, C.c_int, C.c_int],
     }
@@ -600,6 +614,44 @@ class Context:
         for b in (db, dof, dl, dn):
             b.free()
         return levels, off, nnz
+
+    def residual_rdoq_batch(self, orig, pred, rec, blocks, contexts, params):
+        """TransformAndReconstruct with RdoQuant::QuantRdo for the blocks flagged
+        TXF_RDOQ.  contexts: RDOQ_CTX_DTYPE[]; params: RDOQ_PARAMS_DTYPE[n]."""
+        blocks = np.ascontiguousarray(blocks, TX_DTYPE)
+        off, total = self.level_offsets(blocks)
+        db, dof = self.buffer(blocks), self.buffer(off)
+        dc = self.buffer(np.ascontiguousarray(contexts, RDOQ_CTX_DTYPE))
+        dp = self.buffer(np.ascontiguousarray(params, RDOQ_PARAMS_DTYPE))
+        dl = self.alloc(2 * max(1, total))
+        dn = self.alloc(4 * max(1, len(blocks)))
+        self._check(self.lib.xvcgpu_residual_rdoq_batch(
+            self.h, orig.h_pic, pred.h_pic, rec.h_pic, db.ptr, len(blocks), dl.ptr, dof.ptr,
+            dn.ptr, dc.ptr, dp.ptr))
+        levels = dl.to_array(np.int16, total)
+        nnz = dn.to_array(np.int32, len(blocks))
+        for b in (db, dof, dl, dn, dc, dp):
+            b.free()
+        return levels, off, nnz
+
+    def quant_rdo_batch(self, bitdepth, blocks, coeffs, off, contexts, params):
+        """RdoQuant::QuantRdo on coefficient blocks (w*h int16 at off[i])."""
+        blocks = np.ascontiguousarray(blocks, TX_DTYPE)
+        db = self.buffer(blocks)
+        dof = self.buffer(np.ascontiguousarray(off, np.uint32))
+        dcf = self.buffer(np.ascontiguousarray(coeffs, np.int16))
+        dc = self.buffer(np.ascontiguousarray(contexts, RDOQ_CTX_DTYPE))
+        dp = self.buffer(np.ascontiguousarray(params, RDOQ_PARAMS_DTYPE))
+        dl = self.alloc(2 * max(1, len(coeffs)))
+        dn = self.alloc(4 * max(1, len(blocks)))
+        self._check(self.lib.xvcgpu_quant_rdo_batch(
+            self.h, bitdepth, db.ptr, len(blocks), dcf.ptr, dof.ptr, dl.ptr, dn.ptr, dc.ptr,
+            dp.ptr))
+        levels = dl.to_array(np.int16, len(coeffs))
+        nnz = dn.to_array(np.int32, len(blocks))
+        for b in (db, dof, dcf, dl, dn, dc, dp):
+            b.free()
+        return levels, nnz
 
     def fwd_transform_batch(self, orig, pred, blocks):
         blocks = np.ascontiguousarray(blocks, TX_DTYPE)

@@ -1,0 +1,610 @@
+// k_rdoq.h -- Q2 / N2: RdoQuant::QuantRdo with CoeffSignHideRdo
+// (xvc_enc_lib/rdo_quant.cc:203-446, :575-687; QuantCoeffRdo :689-720,
+// EvalZeroSubblock :722-760, EvalLastPos :762-832, GetAbsLevelBits :834-878,
+// UpdateCodeState :880-898, GetLastPosBits :900-947) and the context selection
+// it calls (xvc_common_lib/cabac.cc:491-770, extended residual context set) -
+// the quantiser the reference's encoder always runs (encoder_settings.h:59).
+//
+// One WAVE per transform block.  The reference walks the coefficients in
+// reverse scan order, one at a time; what that order really constrains is:
+//   * a coefficient's contexts read the decided levels of five neighbours to
+//     its right / below (cabac.cc:535-552): up to 2 samples away, i.e. inside
+//     its own 4x4 sub-block or the sub-blocks right / below / diagonal;
+//   * the sub-block's coded flag context reads the flags of the sub-blocks to
+//     its right and below (cabac.cc:491-518);
+//   * inside a sub-block the greater1 / greater2 flag budget (c1_idx, c2_idx)
+//     runs along the scan;
+//   * the "last position" is the first non-zero quantised value in reverse
+//     scan - a function of the input alone.
+// With the extended context set nothing else crosses sub-blocks (ctx_set / c1
+// only feed the non-extended contexts).  So: lane = 4x4 sub-block; the
+// sub-blocks of one anti-diagonal of the sub-block grid are independent and
+// run together, each lane walking its 16 coefficients in scan order - 7 steps
+// for a 16x16 block instead of 16 - and every sum the reference accumulates
+// along the way (int64) is formed by an order-free reduction afterwards.
+// EvalLastPos is a short serial walk (it stops at the first level above 1) on
+// lane 0; zero-out, re-signing and the sign-data hiding (independent per
+// sub-block) are lane-parallel again.
+//
+// 64-point transforms only have coefficients in their 32x32 low-frequency
+// corner (transform.cc:1458): the other sub-blocks matter only through the
+// cost of their (zero) coded flags, which is added in closed form.
+#ifndef XVCGPU_K_RDOQ_H_
+#define XVCGPU_K_RDOQ_H_
+
+#include "dev_common.h"
+#include "dev_tables.h"
+#include "k_me.h"
+#include "k_me2.h"
+#include "xvcgpu_internal.h"
+
+// ContextModel::kEntropyBits_ (context_model.cc:75-93): bits = table[state ^ bin]
+__constant__ uint32_t kEntropyBits[128] = {
+    0x07b23, 0x085f9, 0x074a0, 0x08cbc, 0x06ee4, 0x09354, 0x067f4, 0x09c1b, 0x060b0, 0x0a62a,
+    0x05a9c, 0x0af5b, 0x0548d, 0x0b955, 0x04f56, 0x0c2a9, 0x04a87, 0x0cbf7, 0x045d6, 0x0d5c3,
+    0x04144, 0x0e01b, 0x03d88, 0x0e937, 0x039e0, 0x0f2cd, 0x03663, 0x0fc9e, 0x03347, 0x10600,
+    0x03050, 0x10f95, 0x02d4d, 0x11a02, 0x02ad3, 0x12333, 0x0286e, 0x12cad, 0x02604, 0x136df,
+    0x02425, 0x13f48, 0x021f4, 0x149c4, 0x0203e, 0x1527b, 0x01e4d, 0x15d00, 0x01c99, 0x166de,
+    0x01b18, 0x17017, 0x019a5, 0x17988, 0x01841, 0x18327, 0x016df, 0x18d50, 0x015d9, 0x19547,
+    0x0147c, 0x1a083, 0x0138e, 0x1a8a3, 0x01251, 0x1b418, 0x01166, 0x1bd27, 0x01068, 0x1c77b,
+    0x00f7f, 0x1d18e, 0x00eda, 0x1d91a, 0x00e19, 0x1e254, 0x00d4f, 0x1ec9a, 0x00c90, 0x1f6e0,
+    0x00c01, 0x1fef8, 0x00b5f, 0x208b1, 0x00ab6, 0x21362, 0x00a15, 0x21e46, 0x00988, 0x2285d,
+    0x00934, 0x22ea8, 0x008a8, 0x239b2, 0x0081d, 0x24577, 0x007c9, 0x24ce6, 0x00763, 0x25663,
+    0x00710, 0x25e8f, 0x006a0, 0x26a26, 0x00672, 0x26f23, 0x005e8, 0x27ef8, 0x005ba, 0x284b5,
+    0x0055e, 0x29057, 0x0050c, 0x29bab, 0x004c1, 0x2a674, 0x004a7, 0x2aa5e, 0x0046f, 0x2b32f,
+    0x0041f, 0x2c0ad, 0x003e7, 0x2ca8d, 0x003ba, 0x2d323, 0x0010c, 0x3bfbb};
+__constant__ uint8_t kGolombRiceRangeExt[10] = {6, 5, 6, 3, 3, 3, 3, 3, 3, 3};
+
+#define RQ_BYPASS 32768u  // ContextModel::kEntropyBypassBits
+
+// Per-block scratch: N = coefficients of the (at most 32x32) low-frequency
+// region; arrays indexed by position y * rw + x.
+template <int N>
+struct RdoqShared {
+  long long cost_to_zero[N];   // coeff_cost_to_zero_
+  unsigned sig_bits[N];        // coeff_sig_bits_
+  int sig_rate[N], rate_up[N], rate_down[N];
+  short err_dist[N];
+  long long sb_code_cost[64], sb_zero_dist[64];
+  unsigned csbf_bits[64];      // csbf_bits_to_zero
+  unsigned char csbf[64];
+  unsigned char sb_of_scan[256];  // sub-block scan index -> sy * gw + sx
+};
+
+__device__ __forceinline__ unsigned rq_bits(unsigned char state, int bin) {
+  return kEntropyBits[state ^ bin];
+}
+__device__ __forceinline__ long long rq_bit_cost(unsigned bits, long long lambda) {
+  return ((long long)bits * lambda) >> 16;
+}
+__device__ __forceinline__ int rq_log2(int size) {  // util::SizeToLog2, powers of two
+  return 31 - __clz(size);
+}
+__device__ __forceinline__ int rq_last_pos_group(int pos) {  // kLastPosGroupIdx
+  if (pos < 4) return pos;
+  const int l = 31 - __clz(pos);                // 4..7 -> 2, 8..15 -> 3, ...
+  return 2 * l + ((pos >> (l - 1)) & 1);
+}
+__device__ __forceinline__ int rq_wave_max_i32(int v) {
+#pragma unroll
+  for (int s = 1; s < 64; s <<= 1) {
+    const int o = __shfl_xor(v, s, 64);
+    v = o > v ? o : v;
+  }
+  return v;
+}
+__device__ __forceinline__ long long rq_wave_sum_i64(long long v) {
+#pragma unroll
+  for (int s = 1; s < 64; s <<= 1) v += __shfl_xor(v, s, 64);
+  return v;
+}
+
+struct RdoqCoeffState {  // RdoQuant::CoeffCodingState, the part the extended set reads
+  int c1_idx, c2_idx;
+  unsigned golomb_rice_k;
+};
+
+__device__ __forceinline__ unsigned rq_abs_level_bits(int level, unsigned char c1_ctx,
+                                                      unsigned char c2_ctx,
+                                                      const RdoqCoeffState &s) {
+  const int base_level = s.c1_idx < 8 ? (2 + (s.c2_idx < 1)) : 1;
+  const unsigned threshold = kGolombRiceRangeExt[s.golomb_rice_k];
+  unsigned bits = RQ_BYPASS;
+  if (level >= base_level) {
+    unsigned code = (unsigned)(level - base_level);
+    if (code < (threshold << s.golomb_rice_k)) {
+      bits += ((code >> s.golomb_rice_k) + 1 + s.golomb_rice_k) * RQ_BYPASS;
+    } else {
+      int length = (int)s.golomb_rice_k;
+      code -= threshold << s.golomb_rice_k;
+      while (code >= (1u << length)) code -= 1u << (length++);
+      bits += (unsigned)(length + (int)threshold + length + 1 - (int)s.golomb_rice_k) * RQ_BYPASS;
+    }
+    if (s.c1_idx < 8) {
+      bits += rq_bits(c1_ctx, 1);
+      if (s.c2_idx < 1) bits += rq_bits(c2_ctx, 1);
+    }
+  } else if (level == 1) {
+    bits += rq_bits(c1_ctx, 0);
+  } else if (level == 2) {
+    bits += rq_bits(c1_ctx, 1) + rq_bits(c2_ctx, 0);
+  } else {
+    return 0;
+  }
+  return bits;
+}
+
+// GetCoeffLastPosCtx (cabac.cc:727-770) + GetLastPosBits (rdo_quant.cc:900-947)
+__device__ __forceinline__ unsigned char rq_last_pos_ctx(const xvcgpu_rdoq_contexts &c, bool luma,
+                                                         int w, int h, int pos, bool is_x) {
+  const int size = is_x ? w : h;
+  if (luma) {
+    const int l2 = rq_log2(size);
+    const int off = l2 < 3 ? 0 : (l2 == 3 ? 3 : (l2 == 4 ? 6 : (l2 == 5 ? 10 : (l2 == 6 ? 15 : 21))));
+    const int idx = off + (pos >> ((l2 + 1) >> 2));
+    return is_x ? c.last_x_luma[idx] : c.last_y_luma[idx];
+  }
+  const int shift = d_clip3(size >> 3, 0, 2);
+  return is_x ? c.last_x_chroma[pos >> shift] : c.last_y_chroma[pos >> shift];
+}
+__device__ __forceinline__ unsigned rq_last_pos_bits(const xvcgpu_rdoq_contexts &c, bool luma,
+                                                     int w, int h, int scan_order, int lx,
+                                                     int ly) {
+  if (scan_order == 2) {
+    int t = lx; lx = ly; ly = t;
+    t = w; w = h; h = t;
+  }
+  const int gx = rq_last_pos_group(lx), gy = rq_last_pos_group(ly);
+  unsigned bits = 0;
+  int k;
+  for (k = 0; k < gx; k++) bits += rq_bits(rq_last_pos_ctx(c, luma, w, h, k, true), 1);
+  if (gx < rq_last_pos_group(w - 1)) bits += rq_bits(rq_last_pos_ctx(c, luma, w, h, k, true), 0);
+  for (k = 0; k < gy; k++) bits += rq_bits(rq_last_pos_ctx(c, luma, w, h, k, false), 1);
+  if (gy < rq_last_pos_group(h - 1)) bits += rq_bits(rq_last_pos_ctx(c, luma, w, h, k, false), 0);
+  if (gx > 3) bits += (unsigned)((gx - 2) >> 1) * RQ_BYPASS;
+  if (gy > 3) bits += (unsigned)((gy - 2) >> 1) * RQ_BYPASS;
+  return bits;
+}
+
+// Position of scan offset k inside a sub-block: (x, y) packed as y << 2 | x.
+__device__ __forceinline__ int rq_scan_pos(int sbs, int order, int k) {
+  if (sbs == 2) return (int)((d_scan4_table(order) >> (4 * k)) & 15ull);
+  // TransformHelper::kScanCoeff2x2 (transform.cc:65-69): {0,2,1,3} / raster / {0,2,1,3}
+  const int p = order == 1 ? k : (((k & 1) << 1) | (k >> 1));
+  return ((p >> 1) << 2) | (p & 1);
+}
+
+// One wave quantises one block.  cf(x, y) reads a transform coefficient,
+// lev(x, y) addresses the level array (both only inside the region); `lane` is
+// 0..63 and all 64 lanes must call.  Returns the number of non-zero levels (to
+// every lane); levels outside the region are NOT written (they are zero: the
+// caller clears what its layout needs).
+template <int N, typename CF, typename LEV>
+__device__ __forceinline__ int wave_rdoq(RdoqShared<N> &s, int lane, int bd, int w, int h,
+                                         int comp_qp, bool luma, int scan_order, bool sign_hide,
+                                         const xvcgpu_rdoq_contexts &ctx,
+                                         const xvcgpu_rdoq_params &prm, CF cf, LEV lev) {
+  const int sbs = (w == 2 || h == 2) ? 1 : 2;
+  const int sb_size = 1 << (2 * sbs);
+  const int gw = w >> sbs, gh = h >> sbs;                   // the whole grid (scan indices)
+  const int rw = w < 32 ? w : 32, rh = h < 32 ? h : 32;     // coefficients exist here
+  const int rgw = rw >> sbs, rgh = rh >> sbs;
+  const int lw = rq_log2(w), lh = rq_log2(h);
+  int qpb = comp_qp + 6 * (bd - 8);
+  qpb = qpb > 0 ? qpb : 0;
+  const int tshift = 15 - bd - ((lw + lh) >> 1);
+  const bool bias = ((lw + lh) & 1) != 0;
+  const int shift = 14 + qpb / 6 + tshift;
+  const int size_bias_shift = bias ? 7 : 0, size_bias_offset = bias ? 64 : 0;
+  const int scale = kFwdQuantScales[qpb % 6] * (bias ? 181 : 1);
+  const int cost_scale = 15 - 2 * tshift - 2 * (bd - 8) + 2 * (bias ? 1 : 0);
+  const long long lambda = prm.lambda;
+  const int fq_shift = shift + (bias ? 7 : 0);
+  const long long fq_offset = 1ll << (fq_shift - 1);
+  const int iq_shift = 6 - tshift + (bias ? 8 : 0);
+  const int iq_scale = (kInvQuantScales[qpb % 6] << (qpb / 6)) * (bias ? 181 : 1);
+
+  const bool mine = lane < rgw * rgh;
+  const int sx = mine ? lane % rgw : 0, sy = mine ? lane / rgw : 0;
+  const int my_scan = d_sb_scan_index(scan_order, gw, gh, sx, sy);
+  const int sb_index = my_scan << (2 * sbs);
+  const int px = sx << sbs, py = sy << sbs;
+  auto coeff_xy = [&](int k, int &x, int &y) {
+    const int p = rq_scan_pos(sbs, scan_order, k);
+    x = px + (p & 3);
+    y = py + (p >> 2);
+  };
+
+  // scan index -> sub-block (whole grid), and the last position: the first
+  // non-zero quantised value in reverse scan
+  for (int t = lane; t < gw * gh; t += 64)
+    s.sb_of_scan[d_sb_scan_index(scan_order, gw, gh, t % gw, t / gw)] = (unsigned char)t;
+  int last = -1;
+  if (mine)
+    for (int k = sb_size - 1; k >= 0; k--) {
+      int x, y;
+      coeff_xy(k, x, y);
+      const int a = (short)d_abs(cf(x, y));
+      const int q = (short)(int)((((long long)a * scale) + fq_offset) >> fq_shift);
+      if (q) {
+        last = sb_index + k;
+        break;
+      }
+    }
+  const int last_pos_index = (int)rq_wave_max_i32(last);
+  if (last_pos_index < 0) {  // nothing quantises to a level
+    if (mine)
+      for (int k = 0; k < sb_size; k++) {
+        int x, y;
+        coeff_xy(k, x, y);
+        *lev(x, y) = 0;
+      }
+    return 0;
+  }
+  if (mine) s.csbf[lane] = 0;
+  wave_sync();
+
+  // ---- the per-coefficient decisions, one anti-diagonal of sub-blocks at a time
+  for (int d = rgw + rgh - 2; d >= 0; d--) {
+    if (mine && sx + sy == d) {
+      RdoqCoeffState st = {0, 0, 0};
+      long long sb_zero_dist = 0, sb_code_cost = 0;
+      // GetSubblockCsbfCtx (cabac.cc:491-518); sub-blocks beyond the region are zero
+      const bool right = sx < rgw - 1 ? s.csbf[lane + 1] != 0 : false;
+      const bool below = sy < rgh - 1 ? s.csbf[lane + rgw] != 0 : false;
+      const unsigned char csbf_ctx = ctx.csbf[luma ? 0 : 1][(right || below) ? 1 : 0];
+      int num_non_zero = 0;
+      bool any = false;
+      for (int k = sb_size - 1; k >= 0; k--) {
+        const int index = sb_index + k;
+        int x, y;
+        coeff_xy(k, x, y);
+        const int pos = y * rw + x;
+        const int abs_coeff = (short)d_abs(cf(x, y));
+        const long long zero_cost = ((long long)(abs_coeff * abs_coeff)) << cost_scale;
+        sb_zero_dist += zero_cost;
+        short *out = lev(x, y);
+        if (index > last_pos_index) {  // rdo_quant.cc:303-307 (+ the memsets :262-265)
+          *out = 0;
+          sb_code_cost += zero_cost;
+          s.err_dist[pos] = 0;
+          s.sig_rate[pos] = s.rate_up[pos] = s.rate_down[pos] = 0;
+          continue;
+        }
+        const int q = (short)(int)((((long long)abs_coeff * scale) + fq_offset) >> fq_shift);
+        const bool is_last = index == last_pos_index;
+        // the template of decided neighbours (all inside the region: beyond it
+        // every level is zero)
+        int n_sig = 0, n_g1 = 0, n_g2 = 0, sum_abs = 0;
+        {
+          auto nb = [&](int xx, int yy) {
+            if (xx >= rw || yy >= rh) return;
+            const int v = d_abs((int)*lev(xx, yy));
+            n_sig += v != 0;
+            n_g1 += v > 1;
+            n_g2 += v > 2;
+            sum_abs += v;
+          };
+          if (x < w - 1) {
+            nb(x + 1, y);
+            if (x < w - 2) nb(x + 2, y);
+            if (y < h - 1) nb(x + 1, y + 1);
+          }
+          if (y < h - 1) {
+            nb(x, y + 1);
+            if (y < h - 2) nb(x, y + 2);
+          }
+        }
+        const int posxy = x + y;
+        unsigned char sig_ctx, c1_ctx, c2_ctx;
+        {  // GetCoeffSigCtx (cabac.cc:520-560)
+          const int size = (lw + lh) >> 1;
+          int start = posxy < 2 ? 6 : 0;
+          start += luma && posxy < 5 ? 6 : 0;
+          start += size > 2 && luma ? 18 << (size - 3 < 1 ? size - 3 : 1) : 0;
+          const int off = n_sig < 5 ? n_sig : 5;
+          sig_ctx = luma ? ctx.sig_luma[start + off] : ctx.sig_chroma[start + off];
+        }
+        if (is_last) {  // GetCoeffGreater1Ctx / Greater2Ctx (cabac.cc:594-684)
+          c1_ctx = c2_ctx = luma ? ctx.greater1_luma[0] : ctx.greater1_chroma[0];
+        } else {
+          const int start = luma ? (posxy < 3 ? 10 : (posxy < 10 ? 5 : 0)) : 0;
+          const int o1 = (n_g1 < 4 ? n_g1 : 4) + 1, o2 = (n_g2 < 4 ? n_g2 : 4) + 1;
+          c1_ctx = luma ? ctx.greater1_luma[start + o1] : ctx.greater1_chroma[start + o1];
+          c2_ctx = luma ? ctx.greater1_luma[start + o2] : ctx.greater1_chroma[start + o2];
+        }
+        {  // GetCoeffGolombRiceK (cabac.cc:686-725)
+          const unsigned threshold = 4u + (unsigned)(sum_abs - n_sig);
+          unsigned kk = 9;
+          for (unsigned t = 0; t < 10; t++)
+            if ((1u << (t + 3)) > threshold) {
+              kk = t;
+              break;
+            }
+          st.golomb_rice_k = kk;
+        }
+        const unsigned sig0 = rq_bits(sig_ctx, 0);
+        unsigned sig1 = rq_bits(sig_ctx, 1);
+        if (is_last || (sb_index > 0 && k == 0 && num_non_zero == 0)) sig1 = 0;
+
+        long long best_cost = 0x7fffffffffffffffll;
+        unsigned best_sig = 0;
+        int best_level = q;
+        if (q > 0) {  // QuantCoeffRdo (rdo_quant.cc:689-720)
+          best_sig = sig1;
+          for (int lvl = q > 1 ? q - 1 : q; lvl <= q; lvl++) {
+            const unsigned bits = sig1 + rq_abs_level_bits(lvl, c1_ctx, c2_ctx, st);
+            int deq;
+            if (iq_shift > 0) deq = (lvl * iq_scale + (1 << (iq_shift - 1))) >> iq_shift;
+            else deq = (lvl * iq_scale) << -iq_shift;
+            deq = (short)d_clip3(deq, -32768, 32767);
+            const long long err = abs_coeff - deq;
+            const long long cost = ((err * err) << cost_scale) + rq_bit_cost(bits, lambda);
+            if (lvl == q - 1 || cost <= best_cost) {
+              best_cost = cost;
+              best_level = lvl;
+            }
+          }
+        }
+        if (!is_last && q < 3) {
+          const long long cost = zero_cost + rq_bit_cost(sig0, lambda);
+          if (cost <= best_cost) {
+            best_cost = cost;
+            best_sig = sig0;
+            best_level = 0;
+          }
+        }
+        *out = (short)best_level;
+        s.cost_to_zero[pos] = zero_cost - best_cost;
+        s.sig_bits[pos] = best_sig;
+        sb_code_cost += best_cost;
+        const long long orig_scaled =
+            (((long long)abs_coeff * scale) + size_bias_offset) >> size_bias_shift;
+        const long long quant_err = orig_scaled - ((long long)best_level << shift);
+        s.err_dist[pos] = (short)(quant_err >> (shift - 8));
+        s.sig_rate[pos] = !is_last ? (int)(sig1 - sig0) : 0;
+        if (best_level) {
+          any = true;
+          num_non_zero++;
+          const int lvl_rate = (int)rq_abs_level_bits(best_level, c1_ctx, c2_ctx, st);
+          s.rate_up[pos] = -lvl_rate + (int)rq_abs_level_bits(best_level + 1, c1_ctx, c2_ctx, st);
+          s.rate_down[pos] = -lvl_rate + (int)rq_abs_level_bits(best_level - 1, c1_ctx, c2_ctx, st);
+        } else {
+          s.rate_up[pos] = (int)rq_bits(c1_ctx, 0);
+          s.rate_down[pos] = 0;
+        }
+        {  // UpdateCodeState (rdo_quant.cc:880-898); golomb_rice_k is re-derived
+          if (best_level >= 1) st.c1_idx++;
+          if (best_level >= 2) st.c2_idx++;
+        }
+      }
+      // EvalZeroSubblock (rdo_quant.cc:722-760)
+      unsigned bits_to_zero = 0;
+      bool zero_sb = false;
+      if (!(sb_index == 0 || sb_index + sb_size > last_pos_index)) {
+        const unsigned z_bits = rq_bits(csbf_ctx, 0), c_bits = rq_bits(csbf_ctx, 1);
+        const long long zero_cost = sb_zero_dist + rq_bit_cost(z_bits, lambda);
+        if (any) {
+          const long long code_cost = sb_code_cost + rq_bit_cost(c_bits, lambda);
+          if (zero_cost < code_cost) {
+            sb_code_cost = zero_cost;
+            bits_to_zero = z_bits;
+            zero_sb = true;
+          } else {
+            sb_code_cost = code_cost;
+            bits_to_zero = c_bits;
+          }
+        } else {
+          sb_code_cost = zero_cost;
+          bits_to_zero = z_bits;
+        }
+      }
+      if (zero_sb) {
+        any = false;
+        for (int k = 0; k < sb_size; k++) {
+          int x, y;
+          coeff_xy(k, x, y);
+          *lev(x, y) = 0;
+          s.cost_to_zero[y * rw + x] = 0;
+        }
+      }
+      s.csbf[lane] = any ? 1 : 0;
+      s.csbf_bits[lane] = bits_to_zero;
+      s.sb_code_cost[lane] = sb_code_cost;
+      s.sb_zero_dist[lane] = sb_zero_dist;
+    }
+    wave_sync();
+  }
+  long long comp_code_cost = rq_wave_sum_i64(mine ? s.sb_code_cost[lane] : 0ll);
+  const long long comp_zero_dist = rq_wave_sum_i64(mine ? s.sb_zero_dist[lane] : 0ll);
+  // sub-blocks outside the region (64-point transforms): all zero, never the
+  // last one, no coded neighbour to the right / below: the cost of a zero flag
+  // each (EvalZeroSubblock's csbf == 0 branch)
+  const unsigned outside_bits = rq_bits(ctx.csbf[luma ? 0 : 1][0], 0);
+  if (gw * gh > rgw * rgh) {
+    int n_out = 0;
+    for (int t = lane; t < gw * gh; t += 64) {
+      const int tx = t % gw, ty = t / gw;
+      if (tx < rgw && ty < rgh) continue;
+      const int idx = d_sb_scan_index(scan_order, gw, gh, tx, ty) << (2 * sbs);
+      n_out += idx > 0 && idx + sb_size <= last_pos_index;
+    }
+    comp_code_cost += (long long)wave_reduce_add_i32(n_out) * rq_bit_cost(outside_bits, lambda);
+  }
+
+  // ---- EvalLastPos (rdo_quant.cc:762-832): lane 0, result broadcast
+  int new_last = 0;
+  if (lane == 0) {
+    const unsigned char cbf_ctx =
+        !luma ? ctx.cbf_chroma : ((prm.flags & XVC_RDOQ_INTRA_CU) ? ctx.cbf_luma : ctx.root_cbf);
+    long long code_cost = comp_code_cost + rq_bit_cost(rq_bits(cbf_ctx, 1), lambda);
+    int start = last_pos_index & (sb_size - 1);
+    long long best_cost = 0x7fffffffffffffffll;
+    int best_last_plus1 = 0;
+    bool stop = false;
+    for (int sbi = last_pos_index >> (2 * sbs); sbi >= 0 && !stop; sbi--) {
+      const int t = s.sb_of_scan[sbi];
+      const int tx = t % gw, ty = t / gw;
+      const int idx = sbi << (2 * sbs);
+      if (tx >= rgw || ty >= rgh) {
+        if (idx > 0 && idx + sb_size <= last_pos_index) code_cost -= rq_bit_cost(outside_bits, lambda);
+        continue;
+      }
+      const int l = ty * rgw + tx;
+      code_cost -= rq_bit_cost(s.csbf_bits[l], lambda);
+      if (!s.csbf[l]) continue;
+      for (int k = start; k >= 0; k--) {
+        const int p = rq_scan_pos(sbs, scan_order, k);
+        const int x = (tx << sbs) + (p & 3), y = (ty << sbs) + (p >> 2);
+        const int pos = y * rw + x;
+        const int v = *lev(x, y);
+        if (!v) {
+          code_cost += s.cost_to_zero[pos];
+          continue;
+        }
+        const unsigned lp_bits = rq_last_pos_bits(ctx, luma, w, h, scan_order, x, y);
+        const long long cost =
+            code_cost + rq_bit_cost(lp_bits, lambda) - rq_bit_cost(s.sig_bits[pos], lambda);
+        if (cost < best_cost) {
+          best_cost = cost;
+          best_last_plus1 = idx + k + 1;
+        }
+        if (v > 1) {
+          stop = true;
+          break;
+        }
+        code_cost += s.cost_to_zero[pos];
+      }
+      start = sb_size - 1;
+    }
+    const long long comp_zero_cost = comp_zero_dist + rq_bit_cost(rq_bits(cbf_ctx, 0), lambda);
+    new_last = comp_zero_cost < best_cost ? -1 : best_last_plus1;
+  }
+  new_last = __shfl(new_last, 0, 64);
+
+  // ---- zero what lies at / beyond the new last position, re-apply the signs
+  int nnz = 0;
+  bool has = false;
+  if (mine)
+    for (int k = 0; k < sb_size; k++) {
+      int x, y;
+      coeff_xy(k, x, y);
+      short *out = lev(x, y);
+      int level = *out;
+      if (new_last < 0 || sb_index + k >= new_last) level = 0;
+      nnz += level != 0;
+      has |= level != 0;
+      *out = (short)(cf(x, y) < 0 ? -level : level);
+    }
+  nnz = wave_reduce_add_i32(nnz);
+  if (new_last < 0) return 0;
+  if (!(sign_hide && nnz > 1 && sbs > 1)) return nnz;
+
+  // ---- CoeffSignHideRdo (rdo_quant.cc:575-687): lane = sub-block
+  const int last_sb_scan = (int)rq_wave_max_i32(has ? my_scan : -1);
+  int dn = 0;
+  if (mine && has) {
+    const bool is_last_sb = my_scan == last_sb_scan;
+    int first = 16, lastk = -1, sum = 0;
+    for (int k = 15; k >= 0; k--) {
+      int x, y;
+      coeff_xy(k, x, y);
+      const int v = *lev(x, y);
+      if (v) {
+        first = k < first ? k : first;
+        lastk = lastk > k ? lastk : k;
+        sum += v;
+      }
+    }
+    int fx, fy;
+    coeff_xy(first, fx, fy);
+    const int first_sign = *lev(fx, fy) > 0 ? 0 : 1;
+    if (lastk - first >= 4 && first_sign != (sum & 1)) {
+      const long long rd_factor = prm.rd_factor;
+      long long best_cost = 0x7fffffffffffffffll;
+      int best_delta = 0, best_k = 0;
+      for (int k = is_last_sb ? lastk : 15; k >= 0; k--) {
+        int x, y;
+        coeff_xy(k, x, y);
+        const int pos = y * rw + x;
+        const int lvl = *lev(x, y);
+        long long cost;
+        int delta;
+        if (lvl != 0) {
+          const long long cost_inc = rd_factor * (-(int)s.err_dist[pos]) + s.rate_up[pos];
+          long long cost_dec = rd_factor * (int)s.err_dist[pos] + s.rate_down[pos] -
+                               (d_abs(lvl) == 1 ? s.sig_rate[pos] : 0);
+          if (is_last_sb && k == lastk && d_abs(lvl) == 1) cost_dec -= 4ll * RQ_BYPASS;
+          if (cost_inc < cost_dec) {
+            cost = cost_inc;
+            delta = 1;
+          } else {
+            delta = -1;
+            cost = (k == first && d_abs(lvl) == 1) ? 0x7fffffffll : cost_dec;
+          }
+        } else {
+          cost = rd_factor * -(long long)d_abs((int)s.err_dist[pos]) + s.rate_up[pos] +
+                 s.sig_rate[pos] + (long long)RQ_BYPASS;
+          delta = 1;
+          if (k < first && (cf(x, y) >= 0 ? 0 : 1) != first_sign) cost = 0x7fffffffll;
+        }
+        if (cost < best_cost) {
+          best_cost = cost;
+          best_delta = delta;
+          best_k = k;
+        }
+      }
+      int x, y;
+      coeff_xy(best_k, x, y);
+      short *o = lev(x, y);
+      const int before = *o;
+      if (before == 32767 || before == -32768) best_delta = -1;
+      const int after = (short)(cf(x, y) >= 0 ? before + best_delta : before - best_delta);
+      *o = (short)after;
+      dn = (after != 0) - (before != 0);
+    }
+  }
+  return nnz + wave_reduce_add_i32(dn);
+}
+
+// The quantiser alone, for flows that hold the transform coefficients
+// (xvcgpu_fwd_transform_batch -> here -> xvcgpu_inv_transform_batch): one wave
+// per block; coefficients / levels as w*h int16 row-major at d_off[i].
+// grid: n; block: 64.
+__global__ void __launch_bounds__(64)
+quant_rdo_kernel(int bd, const xvcgpu_tx_block *blocks, int n, const int16_t *coeffs,
+                 const uint32_t *d_off, int16_t *levels, int32_t *nnz_out,
+                 const xvcgpu_rdoq_contexts *rq_ctx, const xvcgpu_rdoq_params *rq_prm) {
+  __shared__ RdoqShared<1024> rq;
+  __shared__ int16_t cf[32 * 32], lv[32 * 32];
+  const int bi = blockIdx.x;
+  if (bi >= n) return;
+  const xvcgpu_tx_block b = blocks[bi];
+  const xvcgpu_rdoq_params prm = rq_prm[bi];
+  const int w = b.w, h = b.h, lane = threadIdx.x;
+  const int rw = w < 32 ? w : 32, rh = h < 32 ? h : 32;
+  const int16_t *src = coeffs + d_off[bi];
+  int16_t *dst = levels + d_off[bi];
+  for (int i = lane; i < rw * rh; i += 64) {
+    const int y = i / rw, x = i - y * rw;
+    cf[i] = src[y * w + x];
+    lv[i] = 0;
+  }
+  wave_sync();
+  const bool sign_hide = !(b.intra_pic & XVC_TXF_NO_SIGN_HIDING);
+  const int scan_order = (b.intra_pic >> XVC_TXF_SCAN_SHIFT) & 3;
+  const int16_t *cfp = cf;
+  int16_t *lvp = lv;
+  const int nnz = wave_rdoq<1024>(
+      rq, lane, bd, w, h, b.qp, b.comp == 0, scan_order, sign_hide, rq_ctx[prm.ctx_index], prm,
+      [cfp, rw](int x, int y) { return (int)cfp[y * rw + x]; },
+      [lvp, rw](int x, int y) { return lvp + y * rw + x; });
+  wave_sync();
+  for (int i = lane; i < w * h; i += 64) {
+    const int y = i / w, x = i - y * w;
+    dst[i] = (x < rw && y < rh) ? lv[y * rw + x] : (int16_t)0;
+  }
+  if (lane == 0 && nnz_out) nnz_out[bi] = nnz;
+}
+
+#endif  // XVCGPU_K_RDOQ_H_

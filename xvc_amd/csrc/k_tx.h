@@ -203,6 +203,8 @@ __device__ __forceinline__ int d_sign_hide_subblock(int order, int px, int py,
   return (after != 0) - (before != 0);
 }
 
+#include "k_rdoq.h"  // needs the scan helpers above
+
 // Jobs taken by the one-wave-per-job kernel (k_tx2.h); the rest stay here.
 __device__ __forceinline__ bool tx_small_job(const xvcgpu_tx_block &b) {
   const bool okw = b.w == 4 || b.w == 8 || b.w == 16;
@@ -212,13 +214,16 @@ __device__ __forceinline__ bool tx_small_job(const xvcgpu_tx_block &b) {
 
 // One workgroup (256 threads) = one job: the general path (blocks above
 // 16x16, 2-wide blocks, the 4x4 DST).
-template <int MODE>
+template <int MODE, int RQN = 4>
 __device__ __forceinline__ void residual_job(TxShared &s, int bi, const PicView &orig,
                                              const PicView &pred, const PicView &rec,
                                              const xvcgpu_tx_block *blocks,
                                              int16_t *levels, const uint32_t *level_off,
                                              int32_t *nnz_out, const int16_t *tx_tables,
-                                             const TxTableLayout &lay) {
+                                             const TxTableLayout &lay,
+                                             RdoqShared<RQN> *rq = nullptr,
+                                             const xvcgpu_rdoq_contexts *rq_ctx = nullptr,
+                                             const xvcgpu_rdoq_params *rq_prm = nullptr) {
   __syncthreads();  // previous job of this workgroup is done with s
   const xvcgpu_tx_block b = blocks[bi];
   const int w = b.w, h = b.h, bd = pred.bd;
@@ -289,7 +294,28 @@ __device__ __forceinline__ void residual_job(TxShared &s, int bi, const PicView 
     const int qscale = kFwdQuantScales[qpb % 6] * (bias ? 181 : 1);
     const long long qoff = (long long)((intra_pic ? 171ull : 85ull) << (qshift - 9));
     // levels -> s.b, rounding remainders -> s.dl, coefficients stay in s.a
+    bool use_rdoq = RQN > 4 && (b.intra_pic & XVC_TXF_RDOQ) != 0;
+    if (use_rdoq && (w == 2 || h == 2) && (rq_prm[bi].flags & XVC_RDOQ_NO_2X2))
+      use_rdoq = false;  // rdo_quant.cc:208-216: 2-wide blocks fall back to QuantFast
+    if (RQN > 4 && use_rdoq) {
+      // RdoQuant::QuantRdo (rdo_quant.cc:203-446) by the first wave
+      for (int i = threadIdx.x; i < w * h; i += TX_THREADS)
+        s.b[(i >> lw) * TX_S + (i & (w - 1))] = 0;  // levels beyond the 32x32 corner
+      __syncthreads();
+      if (threadIdx.x < 64) {
+        const xvcgpu_rdoq_params prm = rq_prm[bi];
+        const int16_t *cfp = s.a;
+        int16_t *lvp = s.b;
+        const int n_rq = wave_rdoq<RQN>(
+            *rq, (int)threadIdx.x, bd, w, h, b.qp, b.comp == 0, scan_order, sign_hide,
+            rq_ctx[prm.ctx_index], prm, [cfp](int x, int y) { return (int)cfp[y * TX_S + x]; },
+            [lvp](int x, int y) { return lvp + y * TX_S + x; });
+        if (threadIdx.x == 0) s.nnz = n_rq;
+      }
+      __syncthreads();
+    }
     int local = 0;
+    if (!use_rdoq)
     for (int i = threadIdx.x; i < w * h; i += TX_THREADS) {
       const int y = i >> lw, x = i & (w - 1);
       const int v = s.a[y * TX_S + x];
@@ -306,7 +332,7 @@ __device__ __forceinline__ void residual_job(TxShared &s, int bi, const PicView 
     if (threadIdx.x == 0) s.last_sb = -1;
     __syncthreads();
     // CoeffSignHideFast (rdo_quant.cc:196-199, :448-573): thread = sub-block
-    if (sign_hide && s.nnz > 1 && w >= 4 && h >= 4) {
+    if (!use_rdoq && sign_hide && s.nnz > 1 && w >= 4 && h >= 4) {
       const int gw = w >> 2, gh = h >> 2;
       auto idx = [](int x, int y) { return y * TX_S + x; };
       // the "last" sub-block = highest scan index holding a non-zero level
@@ -412,13 +438,16 @@ __device__ __forceinline__ void residual_job(TxShared &s, int bi, const PicView 
 // grid: ceil(n/256) workgroups of 256 threads.  Each workgroup scans 256
 // descriptors, collects the jobs that need the general path and runs them one
 // after the other (normally none: every job of a 16x16-CU picture is "small").
-template <int MODE>
+template <int MODE, bool RDOQ = false>
 __global__ void __launch_bounds__(TX_THREADS)
 residual_kernel(PicView orig, PicView pred, PicView rec,
                 const xvcgpu_tx_block *blocks, int n, int16_t *levels,
                 const uint32_t *level_off, int32_t *nnz_out,
-                const int16_t *tx_tables, TxTableLayout lay) {
+                const int16_t *tx_tables, TxTableLayout lay,
+                const xvcgpu_rdoq_contexts *rq_ctx = nullptr,
+                const xvcgpu_rdoq_params *rq_prm = nullptr) {
   __shared__ __attribute__((aligned(16))) TxShared s;
+  __shared__ RdoqShared<RDOQ ? 1024 : 4> rq;
   __shared__ int jobs[TX_THREADS];
   __shared__ int n_jobs;
   if (threadIdx.x == 0) n_jobs = 0;
@@ -428,8 +457,8 @@ residual_kernel(PicView orig, PicView pred, PicView rec,
   __syncthreads();
   const int nj = n_jobs;
   for (int k = 0; k < nj; k++)
-    residual_job<MODE>(s, jobs[k], orig, pred, rec, blocks, levels, level_off, nnz_out,
-                       tx_tables, lay);
+    residual_job<MODE, RDOQ ? 1024 : 4>(s, jobs[k], orig, pred, rec, blocks, levels, level_off,
+                                        nnz_out, tx_tables, lay, &rq, rq_ctx, rq_prm);
 }
 
 #endif  // XVCGPU_K_TX_H_

@@ -131,7 +131,7 @@ __device__ __forceinline__ int tx2_group_add(int v) {
 // same size) side by side; `b`, `bi`, `po`, `pred_p`, `pr`, `orig_pre` are then
 // per-lane values of the lane's own half and `soff` places the half's working
 // set inside the shared arrays.
-template <int MODE, int G = 64>
+template <int MODE, int G = 64, bool RDOQ = false>
 __device__ __forceinline__ int tx2_job(Tx2Shared &sh, const xvcgpu_tx_block &b, int bi,
                                        int bd, const PlaneView &po, const uint16_t *pred_p,
                                        int pred_stride, const PlaneView &pr,
@@ -139,7 +139,10 @@ __device__ __forceinline__ int tx2_job(Tx2Shared &sh, const xvcgpu_tx_block &b, 
                                        int32_t *nnz_out, const int16_t *tx_tables,
                                        const int16_t *tx_tables_t,
                                        const TxTableLayout &lay,
-                                       const U16x4 *orig_pre = nullptr, int soff = 0) {
+                                       const U16x4 *orig_pre = nullptr, int soff = 0,
+                                       RdoqShared<256> *rq = nullptr,
+                                       const xvcgpu_rdoq_contexts *rq_ctx = nullptr,
+                                       const xvcgpu_rdoq_params *rq_prm = nullptr) {
   struct { int16_t *r, *t, *c; } s = {sh.r + soff, sh.t + soff, sh.c + soff};
   const int lane = ME2_LANE & (G - 1);
   const int w = b.w, h = b.h;
@@ -202,7 +205,20 @@ __device__ __forceinline__ int tx2_job(Tx2Shared &sh, const xvcgpu_tx_block &b, 
     const int qshift = 14 + qpb / 6 + tshift + (bias ? 7 : 0);
     const int qscale = kFwdQuantScales[qpb % 6] * (bias ? 181 : 1);
     const long long qoff = (long long)((intra_pic ? 171ull : 85ull) << (qshift - 9));
+    const bool use_rdoq = RDOQ && G == 64 && (b.intra_pic & XVC_TXF_RDOQ) != 0;
+    if (RDOQ && use_rdoq) {
+      // RdoQuant::QuantRdo (rdo_quant.cc:203-446): levels -> s.r, same layout
+      const xvcgpu_rdoq_params prm = rq_prm[bi];
+      const int16_t *cfp = s.c;
+      int16_t *lvp = s.r;
+      nnz = wave_rdoq<256>(
+          *rq, lane, bd, w, h, b.qp, b.comp == 0, scan_order, sign_hide, rq_ctx[prm.ctx_index],
+          prm, [cfp, h](int x, int y) { return (int)cfp[x * h + y]; },
+          [lvp, h](int x, int y) { return lvp + x * h + y; });
+      wave_sync();
+    }
     int local = 0;
+    if (!use_rdoq) {
     for (int i = lane; i < n_el; i += G) {
       const int v = s.c[i];
       const int sign = v < 0 ? -1 : 1;
@@ -213,8 +229,9 @@ __device__ __forceinline__ int tx2_job(Tx2Shared &sh, const xvcgpu_tx_block &b, 
       s.t[i] = (int16_t)(((abs_coeff * qscale) - ((long long)level << qshift)) >> (qshift - 8));
     }
     nnz = tx2_group_add<G>(local);
+    }
     // CoeffSignHideFast (rdo_quant.cc:448-573): lane = 4x4 sub-block (<= 16)
-    if (sign_hide && nnz > 1 && w >= 4 && h >= 4) {
+    if (!use_rdoq && sign_hide && nnz > 1 && w >= 4 && h >= 4) {
       wave_sync();
       const int gw = w >> 2, gh = h >> 2;
       auto idx = [h](int x, int y) { return x * h + y; };
@@ -327,14 +344,16 @@ __device__ __forceinline__ int tx2_job(Tx2Shared &sh, const xvcgpu_tx_block &b, 
 
 // grid: XCD-swizzled workgroups of TX2_WAVES waves; one job per wave.
 // tx_tables_t: the same matrices transposed (same layout offsets).
-template <int MODE>
+template <int MODE, bool RDOQ = false>
 __global__ void __launch_bounds__(64 * TX2_WAVES)
 residual_wave_kernel(PicView orig, PicView pred, PicView rec,
                      const xvcgpu_tx_block *blocks, int n, int16_t *levels,
                      const uint32_t *level_off, int32_t *nnz_out,
                      const int16_t *tx_tables, const int16_t *tx_tables_t,
-                     TxTableLayout lay) {
+                     TxTableLayout lay, const xvcgpu_rdoq_contexts *rq_ctx = nullptr,
+                     const xvcgpu_rdoq_params *rq_prm = nullptr) {
   __shared__ Tx2Shared s_all[TX2_WAVES];
+  __shared__ RdoqShared<256> rq_all[RDOQ ? TX2_WAVES : 1];
   Tx2Shared &s = s_all[threadIdx.x >> 6];
   const int n_wg = (n + TX2_WAVES - 1) / TX2_WAVES;
   const int wg = xcd_job_index(blockIdx.x, n_wg);
@@ -344,9 +363,10 @@ residual_wave_kernel(PicView orig, PicView pred, PicView rec,
   const xvcgpu_tx_block b = blocks[bi];
   if (!tx_small_job(b)) return;  // general path: residual_kernel<>
   const PlaneView pp = pred.c[b.comp];
-  tx2_job<MODE>(s, b, bi, pred.bd, orig.c[b.comp],
-                pp.p + (ptrdiff_t)b.y * pp.stride + b.x, pp.stride, rec.c[b.comp], levels,
-                level_off, nnz_out, tx_tables, tx_tables_t, lay);
+  tx2_job<MODE, 64, RDOQ>(s, b, bi, pred.bd, orig.c[b.comp],
+                          pp.p + (ptrdiff_t)b.y * pp.stride + b.x, pp.stride, rec.c[b.comp],
+                          levels, level_off, nnz_out, tx_tables, tx_tables_t, lay, nullptr, 0,
+                          &rq_all[RDOQ ? (threadIdx.x >> 6) : 0], rq_ctx, rq_prm);
 }
 
 #endif  // XVCGPU_K_TX2_H_

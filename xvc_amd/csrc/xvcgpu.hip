@@ -112,10 +112,26 @@ void launch_residual(xvcgpu_ctx *ctx, const PicView &o, const PicView &p,
   hipLaunchKernelGGL(residual_wave_kernel<MODE>, dim3((n_wg + 7) / 8 * 8),
                      dim3(64 * TX2_WAVES), 0, ctx->stream, o, p, r, d_blocks, n,
                      d_levels, d_off, d_nnz, ctx->d_tx_tables, ctx->d_tx_tables_t,
-                     xvcgpu_tx_layout());
+                     xvcgpu_tx_layout(), nullptr, nullptr);
   hipLaunchKernelGGL(residual_kernel<MODE>, dim3((n + TX_THREADS - 1) / TX_THREADS),
                      dim3(TX_THREADS), 0, ctx->stream, o, p, r, d_blocks, n, d_levels,
-                     d_off, d_nnz, ctx->d_tx_tables, xvcgpu_tx_layout());
+                     d_off, d_nnz, ctx->d_tx_tables, xvcgpu_tx_layout(), nullptr, nullptr);
+}
+
+// TransformAndReconstruct with the RDO quantiser for the blocks that ask for it
+void launch_residual_rdoq(xvcgpu_ctx *ctx, const PicView &o, const PicView &p,
+                          const PicView &r, const xvcgpu_tx_block *d_blocks, int n,
+                          int16_t *d_levels, const uint32_t *d_off, int32_t *d_nnz,
+                          const xvcgpu_rdoq_contexts *d_ctx, const xvcgpu_rdoq_params *d_prm) {
+  const int n_wg = (n + TX2_WAVES - 1) / TX2_WAVES;
+  hipLaunchKernelGGL((residual_wave_kernel<TX_MODE_FULL, true>), dim3((n_wg + 7) / 8 * 8),
+                     dim3(64 * TX2_WAVES), 0, ctx->stream, o, p, r, d_blocks, n,
+                     d_levels, d_off, d_nnz, ctx->d_tx_tables, ctx->d_tx_tables_t,
+                     xvcgpu_tx_layout(), d_ctx, d_prm);
+  hipLaunchKernelGGL((residual_kernel<TX_MODE_FULL, true>),
+                     dim3((n + TX_THREADS - 1) / TX_THREADS), dim3(TX_THREADS), 0, ctx->stream,
+                     o, p, r, d_blocks, n, d_levels, d_off, d_nnz, ctx->d_tx_tables,
+                     xvcgpu_tx_layout(), d_ctx, d_prm);
 }
 
 }  // namespace
@@ -814,6 +830,41 @@ xvcgpu_status xvcgpu_residual_batch(xvcgpu_ctx *ctx, const xvcgpu_picture *orig,
   launch_residual<TX_MODE_FULL>(ctx, orig->v, pred->v, rec->v, d_blocks, n, d_levels,
                                 d_level_offsets, d_nnz);
   CHECK_LAUNCH(ctx, "residual_batch");
+  return XVCGPU_OK;
+}
+
+xvcgpu_status xvcgpu_residual_rdoq_batch(xvcgpu_ctx *ctx, const xvcgpu_picture *orig,
+                                         const xvcgpu_picture *pred, xvcgpu_picture *rec,
+                                         const xvcgpu_tx_block *d_blocks, int n,
+                                         int16_t *d_levels, const uint32_t *d_level_offsets,
+                                         int32_t *d_nnz,
+                                         const xvcgpu_rdoq_contexts *d_contexts,
+                                         const xvcgpu_rdoq_params *d_params) {
+  if (!ctx || !orig || !pred || !rec || n < 0 || (n && (!d_blocks || !d_contexts || !d_params)))
+    return XVCGPU_INVALID_ARGUMENT;
+  if (orig->w != pred->w || orig->h != pred->h || rec->w != pred->w || rec->h != pred->h ||
+      orig->bd != pred->bd || rec->bd != pred->bd)
+    return fail(ctx, XVCGPU_INVALID_ARGUMENT, "picture mismatch");
+  if (n == 0) return XVCGPU_OK;
+  launch_residual_rdoq(ctx, orig->v, pred->v, rec->v, d_blocks, n, d_levels, d_level_offsets,
+                       d_nnz, d_contexts, d_params);
+  CHECK_LAUNCH(ctx, "residual_rdoq_batch");
+  return XVCGPU_OK;
+}
+
+xvcgpu_status xvcgpu_quant_rdo_batch(xvcgpu_ctx *ctx, int bitdepth,
+                                     const xvcgpu_tx_block *d_blocks, int n,
+                                     const int16_t *d_coeffs, const uint32_t *d_offsets,
+                                     int16_t *d_levels, int32_t *d_nnz,
+                                     const xvcgpu_rdoq_contexts *d_contexts,
+                                     const xvcgpu_rdoq_params *d_params) {
+  if (!ctx || n < 0 || bitdepth < 8 || bitdepth > 12 ||
+      (n && (!d_blocks || !d_coeffs || !d_offsets || !d_levels || !d_contexts || !d_params)))
+    return XVCGPU_INVALID_ARGUMENT;
+  if (n == 0) return XVCGPU_OK;
+  hipLaunchKernelGGL(quant_rdo_kernel, dim3(n), dim3(64), 0, ctx->stream, bitdepth, d_blocks, n,
+                     d_coeffs, d_offsets, d_levels, d_nnz, d_contexts, d_params);
+  CHECK_LAUNCH(ctx, "quant_rdo_batch");
   return XVCGPU_OK;
 }
 
