@@ -379,6 +379,18 @@ xvcgpu_status xvcgpu_recon_from_me(xvcgpu_ctx *ctx, const xvcgpu_picture *orig,
                                    int qp_y, int qp_c, int intra_pic, int ref_poc,
                                    int32_t *d_nnz, xvcgpu_cu_info *d_cus);
 
+/* The same with RdoQuant::QuantRdo (see xvcgpu_residual_rdoq_batch):
+ * d_params[3 * i + comp] belongs to component comp of CU i; tx_flags = the
+ * XVC_TXF_* bits common to all blocks (XVC_TXF_RDOQ is implied). */
+xvcgpu_status xvcgpu_recon_from_me_rdoq(xvcgpu_ctx *ctx, const xvcgpu_picture *orig,
+                                        const xvcgpu_picture *ref, xvcgpu_picture *rec,
+                                        const xvcgpu_me_block *d_blocks,
+                                        const xvcgpu_me_result *d_results, int n,
+                                        int qp_y, int qp_c, int tx_flags, int ref_poc,
+                                        int32_t *d_nnz, xvcgpu_cu_info *d_cus,
+                                        const xvcgpu_rdoq_contexts *d_contexts,
+                                        const xvcgpu_rdoq_params *d_params);
+
 /* X1 only: coefficients of (orig - pred) for a host-side quantiser (RDOQ stays
  * on the host). Output layout as d_levels. */
 xvcgpu_status xvcgpu_fwd_transform_batch(xvcgpu_ctx *ctx,

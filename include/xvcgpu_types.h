@@ -304,6 +304,10 @@ typedef struct xvcgpu_frame_pass_args {
   int32_t ssd_y_begin, ssd_y_end;
   int32_t shift_bitdepth;        /* xvcgpu_picture_ssd_rows                     */
   uint64_t *d_ssd;
+  /* quantiser of XVC_FP_ENCODE: NULL = QuantFast; else RdoQuant::QuantRdo with
+   * d_rdoq_params[3 * cu + comp] and the context snapshots they index */
+  const struct xvcgpu_rdoq_contexts *d_rdoq_contexts;
+  const struct xvcgpu_rdoq_params *d_rdoq_params;
 } xvcgpu_frame_pass_args;
 
 /* One job of xvcgpu_affine_me_batch: InterSearch::MotionEstAffine for one

@@ -839,6 +839,8 @@ static void ExtendBorder(uint16_t *p, ptrdiff_t st, int w, int h, int have,
   }
 }
 
+void XrLoadContexts(const xvcgpu_rdoq_contexts &c, Contexts *ctx);
+
 void xr_frame_pass(xo_frame_args *a) {
   const int bd = a->bd, W = a->pic_w, H = a->pic_h;
   const int nthreads = a->threads > 1 ? a->threads : 1;
@@ -953,11 +955,37 @@ void xr_frame_pass(xo_frame_args *a) {
         fwd.Transform(*cu, YuvComponent::kY, rb, &cb);
       Qp qp = MakeQp(t->qp, bd);
       restr.disable_transform_sign_hiding = (t->intra_pic & XVC_TXF_NO_SIGN_HIDING) != 0;
-      const int nnz = rq.QuantFast(*cu, YuvComponent::kY, qp,
-                                   (t->intra_pic & XVC_TXF_INTRA_PIC)
-                                       ? PicturePredictionType::kIntra
-                                       : PicturePredictionType::kBi,
-                                   coeff.data(), 64, level.data(), w);
+      int nnz;
+      if (a->rdoq_params && (t->intra_pic & XVC_TXF_RDOQ)) {
+        /* the quantiser the encoder really runs (transform_encoder.cc:230), on
+         * the block's own component of a CU of the matching luma size, with the
+         * Qp PictureData::Init would build from the picture qp and lambda */
+        const xvcgpu_rdoq_params &prm = a->rdoq_params[i];
+        const int cs = c ? 1 : 0;
+        CodingUnit *rcu = pd.CreateCu(CuTree::Primary, 0, 0, 0, w << cs, h << cs);
+        rcu->SetPredMode((prm.flags & XVC_RDOQ_INTRA_CU) ? PredictionMode::kIntra
+                                                         : PredictionMode::kInter);
+        Qp pic_qp(a->qp_y, ChromaFormat::k420, bd, a->rdoq_lambda, 1, 0, 0);
+        const YuvComponent yc = YuvComponent(c);
+        assert(pic_qp.GetQpRaw(yc) == t->qp);
+        assert(static_cast<int64_t>(pic_qp.GetLambdaScaled(yc) * (1 << 16) + 0.5) == prm.lambda);
+        {
+          const double inv_scale = pic_qp.GetInvScale(yc);
+          assert(static_cast<int64_t>(inv_scale * inv_scale / pic_qp.GetLambdaScaled(yc) / 16 /
+                                      (1ull << (2 * (bd - 8))) + 0.5) == prm.rd_factor);
+        }
+        BitWriter bw;
+        SyntaxWriter writer(pic_qp, PicturePredictionType::kUni, &bw);
+        XrLoadContexts(a->rdoq_contexts[prm.ctx_index], &writer.ctx_);
+        nnz = rq.QuantRdo(*rcu, yc, pic_qp, PicturePredictionType::kUni, writer, coeff.data(),
+                          64, level.data(), w);
+        pd.ReleaseCu(rcu);
+      } else {
+        nnz = rq.QuantFast(*cu, YuvComponent::kY, qp,
+                           (t->intra_pic & XVC_TXF_INTRA_PIC) ? PicturePredictionType::kIntra
+                                                              : PicturePredictionType::kBi,
+                           coeff.data(), 64, level.data(), w);
+      }
       a->nnz[i] = nnz;
       if (nnz) {
         quant.Inverse(YuvComponent::kY, qp, w, h, bd, level.data(), w, deq.data(), 64);
@@ -1278,8 +1306,11 @@ void xr_mc_lic_block(int bd, const xvcgpu_mc_lic_block *b, int above_w, int abov
 }
 
 /* ---- Q2: RdoQuant::QuantRdo (rdo_quant.cc:203-446) ------------------------- */
+void XrLoadContexts(const xvcgpu_rdoq_contexts &c, Contexts *ctx);
 namespace {
-void LoadContexts(const xvcgpu_rdoq_contexts &c, Contexts *ctx) {
+void LoadContexts(const xvcgpu_rdoq_contexts &c, Contexts *ctx) { XrLoadContexts(c, ctx); }
+}  // namespace
+void XrLoadContexts(const xvcgpu_rdoq_contexts &c, Contexts *ctx) {
   for (int i = 0; i < 2; i++) {
     ctx->coeff_ext.csbf_luma[i].state_ = c.csbf[0][i];
     ctx->coeff_ext.csbf_chroma[i].state_ = c.csbf[1][i];
@@ -1300,6 +1331,7 @@ void LoadContexts(const xvcgpu_rdoq_contexts &c, Contexts *ctx) {
   ctx->cu_cbf_chroma[0].state_ = c.cbf_chroma;
   ctx->cu_root_cbf[0].state_ = c.root_cbf;
 }
+namespace {
 void StoreContexts(const Contexts &ctx, xvcgpu_rdoq_contexts *c) {
   std::memset(c, 0, sizeof(*c));
   for (int i = 0; i < 2; i++) {

@@ -255,6 +255,13 @@ typedef struct xo_frame_args {
   uint64_t ssd[2];              /* out: luma SSD as ComputePsnr sums it, samples */
   int threads;                  /* <= 1: serial; else OpenMP threads for the
                                    per-CU loops (results do not depend on it) */
+  /* quantiser: NULL = QuantFast for every block; else the blocks flagged
+   * XVC_TXF_RDOQ take RdoQuant::QuantRdo with rdoq_params[tx index] */
+  const xvcgpu_rdoq_contexts *rdoq_contexts;
+  const xvcgpu_rdoq_params *rdoq_params;
+  double rdoq_lambda;           /* the luma lambda the host derived the params
+                                   from (xr_frame_pass builds its Qp with it and
+                                   checks the fixed-point params against its own) */
 } xo_frame_args;
 void xo_frame_pass(xo_frame_args *a);
 

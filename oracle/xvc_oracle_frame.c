@@ -62,9 +62,15 @@ void xo_frame_pass(xo_frame_args *a) {
     for (int i = 0; i < a->n_tx; i++) {
       const xvcgpu_tx_block *t = &a->tx_blocks[i];
       const int c = t->comp;
-      a->nnz[i] = xo_residual_pipeline(bd, t, a->orig[c], a->orig_stride[c],
-                                       a->pred[c], a->pred_stride[c], a->rec[c],
-                                       a->rec_stride[c], levels);
+      if (a->rdoq_params)
+        a->nnz[i] = xo_residual_pipeline_rdoq(bd, t, a->rdoq_contexts, &a->rdoq_params[i],
+                                              a->orig[c], a->orig_stride[c], a->pred[c],
+                                              a->pred_stride[c], a->rec[c], a->rec_stride[c],
+                                              levels);
+      else
+        a->nnz[i] = xo_residual_pipeline(bd, t, a->orig[c], a->orig_stride[c],
+                                         a->pred[c], a->pred_stride[c], a->rec[c],
+                                         a->rec_stride[c], levels);
     }
     free(levels);
   }

@@ -28,6 +28,8 @@ class FrameArgs(C.Structure):
         ("cu_base", C.c_int), ("encode_only", C.c_int),
         ("ssd", C.c_uint64 * 2),
         ("threads", C.c_int),
+        ("rdoq_contexts", C.c_void_p), ("rdoq_params", C.c_void_p),
+        ("rdoq_lambda", C.c_double),
     ]
 
 
@@ -74,5 +76,10 @@ def frame_pass(desc, bd, orig, ref, border, ref_poc=0, lib=None, encode_only=Fal
     a.cu_base = desc.cu_base
     a.encode_only = 1 if encode_only else 0
     a.threads = threads
+    if getattr(desc, "rdoq", False):    # RdoQuant::QuantRdo with the descriptors' inputs
+        rc = np.ascontiguousarray(desc.rdoq_contexts)
+        rp = np.ascontiguousarray(desc.rdoq_params)
+        a.rdoq_contexts, a.rdoq_params = rc.ctypes.data, rp.ctypes.data
+        a.rdoq_lambda = desc.rdoq_lambda
     f(C.byref(a))
     return rec, res, nnz, cus, (int(a.ssd[0]), int(a.ssd[1]))

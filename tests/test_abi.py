@@ -64,8 +64,34 @@ def test_struct_layouts_match_header(api):
         out = subprocess.check_output([os.path.join(d, "t")]).decode().split()
     assert [int(v) for v in out] == [84, 32, 24, 12, 16, 12, 20, 24, 48, 24, 40, 12, 10, 24, 20,
                                        api.AFFINE_ME_DTYPE.itemsize, 60, api.AFFINE_ME_RESULT_DTYPE.itemsize,
-                                       api.SEG_DTYPE.itemsize, 144]
+                                       api.SEG_DTYPE.itemsize, C.sizeof(api.FramePassArgs)]
+    assert C.sizeof(api.FramePassArgs) == 160
     assert api.AFFINE_ME_DTYPE.itemsize == 84 and api.AFFINE_ME_RESULT_DTYPE.itemsize == 32
+
+
+def test_new_struct_layouts_match_header(api):
+    """xvcgpu_inter_block, the RDOQ records and the parsed-syntax records
+    (include/xvc_syntax.h) as the C compiler lays them out."""
+    import subprocess
+    import tempfile
+    from xvc_amd import decoder
+    src = ("#include <stdio.h>\n#include <stddef.h>\n#include \"xvcgpu.h\"\n"
+           "#include \"xvc_syntax.h\"\nint main(){"
+           "printf(\"%zu %zu %zu %zu %zu %zu %zu %zu\\n\", sizeof(xvcgpu_inter_block),"
+           "offsetof(xvcgpu_inter_block, mv), sizeof(xvcgpu_rdoq_contexts),"
+           "sizeof(xvcgpu_rdoq_params), offsetof(xvcgpu_rdoq_params, ctx_index),"
+           "sizeof(xvc_cu_syntax), offsetof(xvc_cu_syntax, mv), sizeof(xvc_picture_syntax));"
+           "return 0;}")
+    with tempfile.TemporaryDirectory() as d:
+        open(os.path.join(d, "t.c"), "w").write(src)
+        subprocess.check_call(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"),
+                               os.path.join(d, "t.c"), "-o", os.path.join(d, "t")])
+        out = [int(v) for v in subprocess.check_output([os.path.join(d, "t")]).decode().split()]
+    assert out == [api.INTER_DTYPE.itemsize, api.INTER_DTYPE.fields["mv"][1],
+                   api.RDOQ_CTX_DTYPE.itemsize, api.RDOQ_PARAMS_DTYPE.itemsize,
+                   api.RDOQ_PARAMS_DTYPE.fields["ctx_index"][1],
+                   decoder.CU_SYNTAX_DTYPE.itemsize, decoder.CU_SYNTAX_DTYPE.fields["mv"][1],
+                   decoder.PICTURE_SYNTAX_DTYPE.itemsize]
 
 
 def test_transform_tables_match_oracle(api):

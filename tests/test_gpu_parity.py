@@ -720,12 +720,14 @@ def pad_planes(planes, bd):
 
 
 # BASELINE.json configs: CIF QP32, 1080p QP32, 2160p QP27 (+ a ragged size)
+@pytest.mark.parametrize("rdoq", [True, False])
 @pytest.mark.parametrize("fused", [True, False])
 @pytest.mark.parametrize("size", [(352, 288, 32), (136, 72, 32), (1920, 1080, 32),
                                   (3840, 2160, 27)])
-def test_frame_pass(gpu, xo, size, fused):
+def test_frame_pass(gpu, xo, size, fused, rdoq):
     """Whole frame pass (ME -> MC -> residual -> deblock -> pad -> SSD) on the
-    GPU against the oracle's frame pass, two chained frames."""
+    GPU against the oracle's frame pass, two chained frames; with the
+    reference encoder's quantiser (RDOQ) and with QuantFast."""
     api, ctx = gpu
     from xvc_amd import pipeline, synth
     import oracle_frame
@@ -734,7 +736,7 @@ def test_frame_pass(gpu, xo, size, fused):
         pytest.skip("the 2160p case runs the production (fused) path only")
     bd = 10
     clip = synth.SyntheticClip(pw, ph, bd)
-    fp = pipeline.FramePass(ctx, pw, ph, bd, qp=qp, fused=fused)
+    fp = pipeline.FramePass(ctx, pw, ph, bd, qp=qp, fused=fused, rdoq=rdoq)
     ref_host = pad_planes(clip.frame(0), bd)
     O, R, Rec = ctx.picture(pw, ph, bd), ctx.picture(pw, ph, bd), ctx.picture(pw, ph, bd)
     R.upload(ref_host, BL)

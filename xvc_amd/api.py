@@ -111,7 +111,8 @@ class FramePassArgs(C.Structure):
                 ("map_stride", C.c_int32), ("db_y_begin", C.c_int32),
                 ("db_y_end", C.c_int32), ("dbh_y_end", C.c_int32),
                 ("ssd_y_begin", C.c_int32), ("ssd_y_end", C.c_int32),
-                ("shift_bitdepth", C.c_int32), ("d_ssd", C.c_void_p)]
+                ("shift_bitdepth", C.c_int32), ("d_ssd", C.c_void_p),
+                ("d_rdoq_contexts", C.c_void_p), ("d_rdoq_params", C.c_void_p)]
 
 
 FP_ENCODE, FP_DEBLOCK_V, FP_DEBLOCK_H, FP_PAD, FP_SSD = 1, 2, 4, 8, 16
@@ -138,7 +139,7 @@ SYMBOLS = [
     "xvcgpu_intra_pred_batch", "xvcgpu_intra_satd_batch", "xvcgpu_intra_recon_batch",
     "xvcgpu_intra_select_modes", "xvcgpu_frame_pass", "xvcgpu_copy_segments",
     "xvcgpu_get_transform_matrix", "xvcgpu_inter_pred_batch", "xvcgpu_deblock_tree",
-    "xvcgpu_residual_rdoq_batch", "xvcgpu_quant_rdo_batch",
+    "xvcgpu_residual_rdoq_batch", "xvcgpu_quant_rdo_batch", "xvcgpu_recon_from_me_rdoq",
 ]
 
 _vp = C.c_void_p
@@ -247,6 +248,8 @@ def load_library():
         "xvcgpu_get_transform_matrix": [C.c_int, C.c_int, _vp],
         "xvcgpu_inter_pred_batch": [_vp, C.POINTER(_vp), C.c_int, _vp, _vp, _vp, C.c_int],
         "xvcgpu_residual_rdoq_batch": [_vp, _vp, _vp, _vp, _vp, C.c_int, _vp, _vp, _vp, _vp, _vp],
+        "xvcgpu_recon_from_me_rdoq": [_vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int,
+                                      C.c_int, C.c_int, _vp, _vp, _vp, _vp],
         "xvcgpu_quant_rdo_batch": [_vp, C.c_int, _vp, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp],
         "xvcgpu_deblock_tree": [_vp, _vp, _vp, C.c_int, _vp, C.c_int, C.c_int, C.c_int,
                                 C.c_int, C.c_int, C.c_int],
@@ -501,6 +504,18 @@ class Context:
         self._check(self.lib.xvcgpu_recon_from_me(
             self.h, orig.h_pic, ref.h_pic, rec.h_pic, d_blocks, d_results, n, qp_y,
             qp_c, intra_pic, ref_poc, d_nnz, d_cus))
+
+    def recon_from_me_rdoq_dev(self, orig, ref, rec, d_blocks, d_results, n, qp_y, qp_c,
+                               ref_poc, d_nnz, d_cus, d_contexts, d_params, tx_flags=0):
+        self._check(self.lib.xvcgpu_recon_from_me_rdoq(
+            self.h, orig.h_pic, ref.h_pic, rec.h_pic, d_blocks, d_results, n, qp_y,
+            qp_c, tx_flags, ref_poc, d_nnz, d_cus, d_contexts, d_params))
+
+    def residual_rdoq_batch_dev(self, orig, pred, rec, d_blocks, n, d_levels, d_offsets, d_nnz,
+                                d_contexts, d_params):
+        self._check(self.lib.xvcgpu_residual_rdoq_batch(
+            self.h, orig.h_pic, pred.h_pic, rec.h_pic, d_blocks, n, d_levels, d_offsets,
+            d_nnz, d_contexts, d_params))
 
     def residual_batch_dev(self, orig, pred, rec, d_blocks, n, d_levels=None,
                            d_offsets=None, d_nnz=None):

@@ -85,17 +85,26 @@ __device__ __forceinline__ int rq_last_pos_group(int pos) {  // kLastPosGroupIdx
   const int l = 31 - __clz(pos);                // 4..7 -> 2, 8..15 -> 3, ...
   return 2 * l + ((pos >> (l - 1)) & 1);
 }
+// reductions over the G (64 or 32) lanes that share a block
+template <int G>
 __device__ __forceinline__ int rq_wave_max_i32(int v) {
 #pragma unroll
-  for (int s = 1; s < 64; s <<= 1) {
+  for (int s = 1; s < G; s <<= 1) {
     const int o = __shfl_xor(v, s, 64);
     v = o > v ? o : v;
   }
   return v;
 }
+template <int G>
 __device__ __forceinline__ long long rq_wave_sum_i64(long long v) {
 #pragma unroll
-  for (int s = 1; s < 64; s <<= 1) v += __shfl_xor(v, s, 64);
+  for (int s = 1; s < G; s <<= 1) v += __shfl_xor(v, s, 64);
+  return v;
+}
+template <int G>
+__device__ __forceinline__ int rq_wave_sum_i32(int v) {
+#pragma unroll
+  for (int s = 1; s < G; s <<= 1) v += __shfl_xor(v, s, 64);
   return v;
 }
 
@@ -174,12 +183,14 @@ __device__ __forceinline__ int rq_scan_pos(int sbs, int order, int k) {
   return ((p >> 1) << 2) | (p & 1);
 }
 
-// One wave quantises one block.  cf(x, y) reads a transform coefficient,
-// lev(x, y) addresses the level array (both only inside the region); `lane` is
-// 0..63 and all 64 lanes must call.  Returns the number of non-zero levels (to
+// One wave quantises one block (G = 64), or its two halves one block each (G =
+// 32: two blocks of at most 32 sub-blocks, same size, side by side - `s`, cf,
+// lev, the contexts and parameters are then per-lane values of the lane's own
+// half).  cf(x, y) reads a transform coefficient, lev(x, y) addresses the level
+// array (both only inside the region); `lane` is 0..G-1 and all lanes must call.  Returns the number of non-zero levels (to
 // every lane); levels outside the region are NOT written (they are zero: the
 // caller clears what its layout needs).
-template <int N, typename CF, typename LEV>
+template <int N, int G = 64, typename CF, typename LEV>
 __device__ __forceinline__ int wave_rdoq(RdoqShared<N> &s, int lane, int bd, int w, int h,
                                          int comp_qp, bool luma, int scan_order, bool sign_hide,
                                          const xvcgpu_rdoq_contexts &ctx,
@@ -217,7 +228,7 @@ __device__ __forceinline__ int wave_rdoq(RdoqShared<N> &s, int lane, int bd, int
 
   // scan index -> sub-block (whole grid), and the last position: the first
   // non-zero quantised value in reverse scan
-  for (int t = lane; t < gw * gh; t += 64)
+  for (int t = lane; t < gw * gh; t += G)
     s.sb_of_scan[d_sb_scan_index(scan_order, gw, gh, t % gw, t / gw)] = (unsigned char)t;
   int last = -1;
   if (mine)
@@ -231,7 +242,7 @@ __device__ __forceinline__ int wave_rdoq(RdoqShared<N> &s, int lane, int bd, int
         break;
       }
     }
-  const int last_pos_index = (int)rq_wave_max_i32(last);
+  const int last_pos_index = rq_wave_max_i32<G>(last);
   if (last_pos_index < 0) {  // nothing quantises to a level
     if (mine)
       for (int k = 0; k < sb_size; k++) {
@@ -415,21 +426,21 @@ __device__ __forceinline__ int wave_rdoq(RdoqShared<N> &s, int lane, int bd, int
     }
     wave_sync();
   }
-  long long comp_code_cost = rq_wave_sum_i64(mine ? s.sb_code_cost[lane] : 0ll);
-  const long long comp_zero_dist = rq_wave_sum_i64(mine ? s.sb_zero_dist[lane] : 0ll);
+  long long comp_code_cost = rq_wave_sum_i64<G>(mine ? s.sb_code_cost[lane] : 0ll);
+  const long long comp_zero_dist = rq_wave_sum_i64<G>(mine ? s.sb_zero_dist[lane] : 0ll);
   // sub-blocks outside the region (64-point transforms): all zero, never the
   // last one, no coded neighbour to the right / below: the cost of a zero flag
   // each (EvalZeroSubblock's csbf == 0 branch)
   const unsigned outside_bits = rq_bits(ctx.csbf[luma ? 0 : 1][0], 0);
   if (gw * gh > rgw * rgh) {
     int n_out = 0;
-    for (int t = lane; t < gw * gh; t += 64) {
+    for (int t = lane; t < gw * gh; t += G) {
       const int tx = t % gw, ty = t / gw;
       if (tx < rgw && ty < rgh) continue;
       const int idx = d_sb_scan_index(scan_order, gw, gh, tx, ty) << (2 * sbs);
       n_out += idx > 0 && idx + sb_size <= last_pos_index;
     }
-    comp_code_cost += (long long)wave_reduce_add_i32(n_out) * rq_bit_cost(outside_bits, lambda);
+    comp_code_cost += (long long)rq_wave_sum_i32<G>(n_out) * rq_bit_cost(outside_bits, lambda);
   }
 
   // ---- EvalLastPos (rdo_quant.cc:762-832): lane 0, result broadcast
@@ -480,7 +491,7 @@ __device__ __forceinline__ int wave_rdoq(RdoqShared<N> &s, int lane, int bd, int
     const long long comp_zero_cost = comp_zero_dist + rq_bit_cost(rq_bits(cbf_ctx, 0), lambda);
     new_last = comp_zero_cost < best_cost ? -1 : best_last_plus1;
   }
-  new_last = __shfl(new_last, 0, 64);
+  new_last = __shfl(new_last, (int)(ME2_LANE & ~(G - 1)), 64);
 
   // ---- zero what lies at / beyond the new last position, re-apply the signs
   int nnz = 0;
@@ -496,12 +507,12 @@ __device__ __forceinline__ int wave_rdoq(RdoqShared<N> &s, int lane, int bd, int
       has |= level != 0;
       *out = (short)(cf(x, y) < 0 ? -level : level);
     }
-  nnz = wave_reduce_add_i32(nnz);
+  nnz = rq_wave_sum_i32<G>(nnz);
   if (new_last < 0) return 0;
   if (!(sign_hide && nnz > 1 && sbs > 1)) return nnz;
 
   // ---- CoeffSignHideRdo (rdo_quant.cc:575-687): lane = sub-block
-  const int last_sb_scan = (int)rq_wave_max_i32(has ? my_scan : -1);
+  const int last_sb_scan = rq_wave_max_i32<G>(has ? my_scan : -1);
   int dn = 0;
   if (mine && has) {
     const bool is_last_sb = my_scan == last_sb_scan;
@@ -564,7 +575,7 @@ __device__ __forceinline__ int wave_rdoq(RdoqShared<N> &s, int lane, int bd, int
       dn = (after != 0) - (before != 0);
     }
   }
-  return nnz + wave_reduce_add_i32(dn);
+  return nnz + rq_wave_sum_i32<G>(dn);
 }
 
 // The quantiser alone, for flows that hold the transform coefficients

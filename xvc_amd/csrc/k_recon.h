@@ -172,14 +172,21 @@ __device__ __forceinline__ void wave_interp_block_lds(int bd, int w, int h, int 
 // block, one for the U and V blocks side by side (32 lanes each: a chroma
 // block of a CU up to 16x16 has at most 64 samples, which would leave three
 // quarters of a wave of its own idle through the whole pipeline).
+// RDOQ: quantise with RdoQuant::QuantRdo (k_rdoq.h); rq_prm[3 * cu + comp].
+template <bool RDOQ = false>
 __global__ void __launch_bounds__(256)
 recon_from_me_kernel(PicView orig, PicView ref, PicView rec,
                      const xvcgpu_me_block *blocks, const xvcgpu_me_result *results,
                      int n_cus, int qp_y, int qp_c, int intra_pic, int ref_poc,
                      int32_t *nnz_out, xvcgpu_cu_info *cus,
                      const int16_t *tx_tables, const int16_t *tx_tables_t,
-                     TxTableLayout lay) {
+                     TxTableLayout lay, const xvcgpu_rdoq_contexts *rq_ctx = nullptr,
+                     const xvcgpu_rdoq_params *rq_prm = nullptr) {
   __shared__ ReconShared s_all[4];
+  // one scratch per wave; a chroma wave splits it between its two halves
+  __shared__ RdoqShared<256> rq_all[RDOQ ? 4 : 1];
+  static_assert(2 * sizeof(RdoqShared<64>) <= sizeof(RdoqShared<256>), "scratch split");
+  RdoqShared<256> *rq_wave = &rq_all[RDOQ ? (threadIdx.x >> 6) : 0];
   ReconShared &s = s_all[threadIdx.x >> 6];
   const int n = n_cus * 2;
   const int n_wg = (n + 3) / 4;
@@ -239,9 +246,10 @@ recon_from_me_kernel(PicView orig, PicView ref, PicView rec,
     ME2_TRACE(1);
     tb.comp = (uint8_t)comp;
     tb.qp = (int8_t)qp_c;
-    tx2_job<TX_MODE_FULL, 32>(s.tx, tb, 3 * ci + comp, bd, po, s.pred + g * 64, cw, pc,
-                              nullptr, nullptr, nnz_out, tx_tables, tx_tables_t, lay,
-                              &orig_pre, g * 128);
+    tx2_job<TX_MODE_FULL, 32, RDOQ>(
+        s.tx, tb, 3 * ci + comp, bd, po, s.pred + g * 64, cw, pc, nullptr, nullptr, nnz_out,
+        tx_tables, tx_tables_t, lay, &orig_pre, g * 128,
+        reinterpret_cast<RdoqShared<64> *>(rq_wave) + g, rq_ctx, rq_prm);
     ME2_TRACE(8);
     return;
   }
@@ -264,9 +272,10 @@ recon_from_me_kernel(PicView orig, PicView ref, PicView rec,
   ME2_TRACE(1);
   tb.comp = 0;
   tb.qp = (int8_t)qp_y;
-  const int nnz = tx2_job<TX_MODE_FULL>(s.tx, tb, 3 * ci, bd, orig.c[0], s.pred, cw,
-                                        rec.c[0], nullptr, nullptr, nnz_out,
-                                        tx_tables, tx_tables_t, lay, &orig_pre);
+  const int nnz = tx2_job<TX_MODE_FULL, 64, RDOQ>(s.tx, tb, 3 * ci, bd, orig.c[0], s.pred, cw,
+                                                  rec.c[0], nullptr, nullptr, nnz_out,
+                                                  tx_tables, tx_tables_t, lay, &orig_pre, 0,
+                                                  rq_wave, rq_ctx, rq_prm);
   ME2_TRACE(8);
   if (cus && ME2_LANE == 0) {
     xvcgpu_cu_info c;

@@ -140,7 +140,7 @@ __device__ __forceinline__ int tx2_job(Tx2Shared &sh, const xvcgpu_tx_block &b, 
                                        const int16_t *tx_tables_t,
                                        const TxTableLayout &lay,
                                        const U16x4 *orig_pre = nullptr, int soff = 0,
-                                       RdoqShared<256> *rq = nullptr,
+                                       RdoqShared<(G == 32 ? 64 : 256)> *rq = nullptr,
                                        const xvcgpu_rdoq_contexts *rq_ctx = nullptr,
                                        const xvcgpu_rdoq_params *rq_prm = nullptr) {
   struct { int16_t *r, *t, *c; } s = {sh.r + soff, sh.t + soff, sh.c + soff};
@@ -205,13 +205,15 @@ __device__ __forceinline__ int tx2_job(Tx2Shared &sh, const xvcgpu_tx_block &b, 
     const int qshift = 14 + qpb / 6 + tshift + (bias ? 7 : 0);
     const int qscale = kFwdQuantScales[qpb % 6] * (bias ? 181 : 1);
     const long long qoff = (long long)((intra_pic ? 171ull : 85ull) << (qshift - 9));
-    const bool use_rdoq = RDOQ && G == 64 && (b.intra_pic & XVC_TXF_RDOQ) != 0;
+    // (with G = 32 both halves of the wave take the same branch: the caller
+    // gives the two blocks the same flags)
+    const bool use_rdoq = RDOQ && (b.intra_pic & XVC_TXF_RDOQ) != 0;
     if (RDOQ && use_rdoq) {
       // RdoQuant::QuantRdo (rdo_quant.cc:203-446): levels -> s.r, same layout
       const xvcgpu_rdoq_params prm = rq_prm[bi];
       const int16_t *cfp = s.c;
       int16_t *lvp = s.r;
-      nnz = wave_rdoq<256>(
+      nnz = wave_rdoq<(G == 32 ? 64 : 256), G>(
           *rq, lane, bd, w, h, b.qp, b.comp == 0, scan_order, sign_hide, rq_ctx[prm.ctx_index],
           prm, [cfp, h](int x, int y) { return (int)cfp[x * h + y]; },
           [lvp, h](int x, int y) { return lvp + x * h + y; });

@@ -809,11 +809,34 @@ xvcgpu_status xvcgpu_recon_from_me(xvcgpu_ctx *ctx, const xvcgpu_picture *orig,
     return fail(ctx, XVCGPU_INVALID_ARGUMENT, "picture mismatch");
   if (n == 0) return XVCGPU_OK;
   const int n_wg = (2 * n + 3) / 4;
-  hipLaunchKernelGGL(recon_from_me_kernel, dim3((n_wg + 7) / 8 * 8), dim3(256), 0,
+  hipLaunchKernelGGL(recon_from_me_kernel<false>, dim3((n_wg + 7) / 8 * 8), dim3(256), 0,
                      ctx->stream, orig->v, ref->v, rec->v, d_blocks, d_results, n, qp_y,
                      qp_c, intra_pic, ref_poc, d_nnz, d_cus, ctx->d_tx_tables,
-                     ctx->d_tx_tables_t, xvcgpu_tx_layout());
+                     ctx->d_tx_tables_t, xvcgpu_tx_layout(), nullptr, nullptr);
   CHECK_LAUNCH(ctx, "recon_from_me");
+  return XVCGPU_OK;
+}
+
+xvcgpu_status xvcgpu_recon_from_me_rdoq(xvcgpu_ctx *ctx, const xvcgpu_picture *orig,
+                                        const xvcgpu_picture *ref, xvcgpu_picture *rec,
+                                        const xvcgpu_me_block *d_blocks,
+                                        const xvcgpu_me_result *d_results, int n,
+                                        int qp_y, int qp_c, int tx_flags, int ref_poc,
+                                        int32_t *d_nnz, xvcgpu_cu_info *d_cus,
+                                        const xvcgpu_rdoq_contexts *d_contexts,
+                                        const xvcgpu_rdoq_params *d_params) {
+  if (!ctx || !orig || !ref || !rec || n < 0 ||
+      (n && (!d_blocks || !d_results || !d_contexts || !d_params)))
+    return XVCGPU_INVALID_ARGUMENT;
+  if (orig->w != ref->w || orig->h != ref->h || rec->w != ref->w || rec->h != ref->h)
+    return fail(ctx, XVCGPU_INVALID_ARGUMENT, "picture mismatch");
+  if (n == 0) return XVCGPU_OK;
+  const int n_wg = (2 * n + 3) / 4;
+  hipLaunchKernelGGL(recon_from_me_kernel<true>, dim3((n_wg + 7) / 8 * 8), dim3(256), 0,
+                     ctx->stream, orig->v, ref->v, rec->v, d_blocks, d_results, n, qp_y,
+                     qp_c, tx_flags | XVC_TXF_RDOQ, ref_poc, d_nnz, d_cus, ctx->d_tx_tables,
+                     ctx->d_tx_tables_t, xvcgpu_tx_layout(), d_contexts, d_params);
+  CHECK_LAUNCH(ctx, "recon_from_me_rdoq");
   return XVCGPU_OK;
 }
 
@@ -1279,8 +1302,13 @@ xvcgpu_status xvcgpu_frame_pass(xvcgpu_ctx *ctx, const xvcgpu_frame_pass_args *a
     st = xvcgpu_me_search_sized(ctx, a->orig, a->ref, XVCGPU_ME_FULLPEL | XVCGPU_ME_SUBPEL,
                                 a->d_me, a->n_cus, a->d_results, a->max_block_size);
     if (st != XVCGPU_OK) return st;
-    st = xvcgpu_recon_from_me(ctx, a->orig, a->ref, a->rec, a->d_me, a->d_results, a->n_cus,
-                              a->qp_y, a->qp_c, 0, a->ref_poc, a->d_nnz, a->d_cus_own);
+    if (a->d_rdoq_params)
+      st = xvcgpu_recon_from_me_rdoq(ctx, a->orig, a->ref, a->rec, a->d_me, a->d_results,
+                                     a->n_cus, a->qp_y, a->qp_c, 0, a->ref_poc, a->d_nnz,
+                                     a->d_cus_own, a->d_rdoq_contexts, a->d_rdoq_params);
+    else
+      st = xvcgpu_recon_from_me(ctx, a->orig, a->ref, a->rec, a->d_me, a->d_results, a->n_cus,
+                                a->qp_y, a->qp_c, 0, a->ref_poc, a->d_nnz, a->d_cus_own);
     if (st != XVCGPU_OK) return st;
   }
   if (phases & XVC_FP_DEBLOCK_V) {

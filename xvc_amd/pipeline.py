@@ -18,6 +18,7 @@ is an INPUT of the batched kernels: here the predictor is the zero vector and
 the quantiser is the reference's non-RDO QuantFast (scope).
 """
 import math
+import os
 
 import ctypes as C
 
@@ -43,6 +44,47 @@ def lambda16_for_qp(qp):
     return int(math.floor(65536.0 * math.sqrt(lam)))
 
 
+_INV_QUANT_SCALES = (40, 45, 51, 57, 64, 72)       # quantize.cc:44-46
+_DATA = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data")
+_init_ctx_table = None
+
+
+def rdoq_init_contexts(qp, pic_type=1):
+    """The coefficient-coding context states a syntax writer starts a picture of
+    this qp / type with (CabacContexts::ResetStates, cabac.cc:311-358), as one
+    xvcgpu_rdoq_contexts record.  RDOQ reads the entropy coder's states
+    (rdo_quant.cc:254): an integration snapshots its live CABAC contexts per
+    batch; this repo's frame pass has no entropy coder and feeds the
+    picture-initial states (data/rdoq_init_contexts.npy, captured from the
+    reference by tools/gen_rdoq_contexts.py).  pic_type: 0 bi, 1 uni, 2 intra."""
+    global _init_ctx_table
+    if _init_ctx_table is None:
+        _init_ctx_table = np.load(os.path.join(_DATA, "rdoq_init_contexts.npy"))
+    raw = _init_ctx_table[max(0, min(63, qp)), pic_type]
+    return np.ascontiguousarray(raw).view(api.RDOQ_CTX_DTYPE).copy()
+
+
+def rdoq_host_params(qp, bitdepth, lam=None):
+    """The two double-arithmetic constants of QuantRdo per component, as the
+    reference computes them on the host (rdo_quant.cc:251-252, :590-594; Qp,
+    quantize.cc:48-92): returns [(lambda_fix, rd_factor)] for Y, U, V.  `lam` =
+    the luma lambda (default: PictureData::Init's 0.57 * 2^((qp - 12) / 3))."""
+    if lam is None:
+        lam = 0.57 * math.pow(2.0, (qp - 12) / 3.0)
+    qpc = chroma_qp(qp)
+    # Qp::GetChromaDistWeight with table 1, offset 0 (quantize.cc:82-92)
+    weight_c = math.pow(2.0, -(qpc - max(0, min(57, qp))) / 3.0)
+    out = []
+    for c in range(3):
+        lam_c = lam if c == 0 else lam / weight_c
+        qpb = max(0, (qp if c == 0 else qpc) + 6 * (bitdepth - 8))
+        inv_scale = float(_INV_QUANT_SCALES[qpb % 6] << (qpb // 6))
+        lambda_fix = int(lam_c * 65536 + 0.5)
+        rd_factor = int(inv_scale * inv_scale / lam_c / 16 / (1 << (2 * (bitdepth - 8))) + 0.5)
+        out.append((lambda_fix, rd_factor))
+    return out
+
+
 def cu_partition(width, height, cu=16):
     """Raster list of (x, y, w, h): cu x cu CUs, smaller at right/bottom edge."""
     parts = []
@@ -64,8 +106,9 @@ class FrameDescriptors:
     because the in-loop filter looks across the shard boundary."""
 
     def __init__(self, width, height, qp=32, cu=16, search_range=96,
-                 row_range=None):
+                 row_range=None, rdoq=False, bitdepth=10):
         self.w, self.h, self.qp = width, height, qp
+        self.rdoq = rdoq
         parts_all = cu_partition(width, height, cu)
         self.n_cus_total = len(parts_all)
         if row_range is None:
@@ -101,6 +144,17 @@ class FrameDescriptors:
                 t["comp"], t["qp"] = c, qpc
         self.me, self.tx, self.luma_idx, self.cu_map = me, tx, luma_idx, cmap
         self.qp_c = qpc
+        self.rdoq_contexts = self.rdoq_params = None
+        self.rdoq_lambda = 0.57 * math.pow(2.0, (qp - 12) / 3.0)
+        if rdoq:
+            # the quantiser the reference's encoder runs (transform_encoder.cc:230)
+            tx["intra_pic"] |= api.TXF_RDOQ
+            self.rdoq_contexts = rdoq_init_contexts(qp, 1)
+            prm = np.zeros(3 * n, api.RDOQ_PARAMS_DTYPE)
+            for c, (lf, rf) in enumerate(rdoq_host_params(qp, bitdepth, self.rdoq_lambda)):
+                prm["lambda"][c::3] = lf
+                prm["rd_factor"][c::3] = rf
+            self.rdoq_params = prm
         self.cu_rows = (height + cu - 1) // cu
         self.cus_per_row = (width + cu - 1) // cu
         self.cu_size = cu
@@ -111,14 +165,18 @@ class FramePass:
     (or of one CTU-row shard of it)."""
 
     def __init__(self, ctx, width, height, bitdepth=10, qp=32, cu=16,
-                 search_range=96, row_range=None, fused=True, keep_levels=False):
+                 search_range=96, row_range=None, fused=True, keep_levels=False,
+                 rdoq=False):
         self.ctx = ctx
+        self.rdoq = rdoq
         # keep_levels: also store the quantised coefficients of every TU (what
         # the entropy coder - or DecodePass - consumes); needs the unfused path
         self.fused = fused and width % 8 == 0 and height % 8 == 0 and not keep_levels
         self.w, self.h, self.bd = width, height, bitdepth
         self.desc = d = FrameDescriptors(width, height, qp, cu, search_range,
-                                         row_range)
+                                         row_range, rdoq, bitdepth)
+        self.d_rdoq_ctx = ctx.buffer(d.rdoq_contexts) if rdoq else None
+        self.d_rdoq_prm = ctx.buffer(d.rdoq_params) if rdoq else None
         self.d_me = ctx.buffer(d.me)
         self.d_tx = ctx.buffer(d.tx)
         self.d_luma_idx = ctx.buffer(d.luma_idx)
@@ -154,6 +212,8 @@ class FramePass:
             a.db_y_begin, a.db_y_end, a.dbh_y_end = 0, d.h, d.h
             a.ssd_y_begin, a.ssd_y_end = 0, 1 << 30
             a.shift_bitdepth, a.d_ssd = self.bd, self.d_ssd.ptr
+            if self.rdoq:
+                a.d_rdoq_contexts, a.d_rdoq_params = self.d_rdoq_ctx.ptr, self.d_rdoq_prm.ptr
             self._fp_args = a
         return self._fp_args
 
@@ -185,14 +245,26 @@ class FramePass:
         if self.fused and d.cu_size <= 16:
             # MC + transform/quant/recon + CU metadata in one launch; the
             # prediction never leaves LDS
-            ctx.recon_from_me_dev(orig, ref, rec, self.d_me.ptr, self.d_res.ptr, n,
-                                  d.qp, d.qp_c, ref_poc, self.d_nnz.ptr, self.d_cus_own)
+            if self.rdoq:
+                ctx.recon_from_me_rdoq_dev(orig, ref, rec, self.d_me.ptr, self.d_res.ptr, n,
+                                           d.qp, d.qp_c, ref_poc, self.d_nnz.ptr,
+                                           self.d_cus_own, self.d_rdoq_ctx.ptr,
+                                           self.d_rdoq_prm.ptr)
+            else:
+                ctx.recon_from_me_dev(orig, ref, rec, self.d_me.ptr, self.d_res.ptr, n,
+                                      d.qp, d.qp_c, ref_poc, self.d_nnz.ptr, self.d_cus_own)
             return
         ctx.mc_from_me_dev(ref, self.pred, self.d_me.ptr, self.d_res.ptr, n)
-        ctx.residual_batch_dev(orig, self.pred, rec, self.d_tx.ptr, len(d.tx),
-                               self.d_levels.ptr if self.d_levels else None,
-                               self.d_level_off.ptr if self.d_level_off else None,
-                               self.d_nnz.ptr)
+        if self.rdoq:
+            ctx.residual_rdoq_batch_dev(orig, self.pred, rec, self.d_tx.ptr, len(d.tx),
+                                        self.d_levels.ptr if self.d_levels else None,
+                                        self.d_level_off.ptr if self.d_level_off else None,
+                                        self.d_nnz.ptr, self.d_rdoq_ctx.ptr, self.d_rdoq_prm.ptr)
+        else:
+            ctx.residual_batch_dev(orig, self.pred, rec, self.d_tx.ptr, len(d.tx),
+                                   self.d_levels.ptr if self.d_levels else None,
+                                   self.d_level_off.ptr if self.d_level_off else None,
+                                   self.d_nnz.ptr)
         ctx.cu_info_from_me_dev(self.d_me.ptr, self.d_res.ptr, self.d_nnz.ptr,
                                 self.d_luma_idx.ptr, n, d.qp, d.qp_c, ref_poc,
                                 self.d_cus_own)
@@ -229,7 +301,8 @@ class FramePass:
 
     def destroy(self):
         for b in (self.d_me, self.d_tx, self.d_luma_idx, self.d_map, self.d_res,
-                  self.d_nnz, self.d_cus, self.d_ssd, self.d_levels, self.d_level_off):
+                  self.d_nnz, self.d_cus, self.d_ssd, self.d_levels, self.d_level_off,
+                  self.d_rdoq_ctx, self.d_rdoq_prm):
             if b is not None:
                 b.free()
         self.pred.destroy()
