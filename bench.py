@@ -48,6 +48,13 @@ def parse():
     ap.add_argument("--cpu-frames", type=int, default=12,
                     help="cap on the single-thread CPU oracle frame passes (rank 0, N=1)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--quant", choices=["rdoq", "fast"], default="rdoq",
+                    help="quantiser of the transform stage: rdoq = RdoQuant::QuantRdo with "
+                         "CoeffSignHideRdo, what the reference's encoder always runs "
+                         "(encoder_settings.h:59); fast = its non-RDO QuantFast")
+    ap.add_argument("--no-decode", action="store_true",
+                    help="skip the stream-decode figure (reconstruction of the committed "
+                         "1080p reference stream, tests/golden/stream_c1.npz)")
     ap.add_argument("--two-queue", action="store_true",
                     help="N=1: issue the halves of every picture on a high- and a "
                          "low-priority stream (pipeline.PipelinedFramePass; measured "
@@ -71,6 +78,74 @@ def parse():
                          "through torch.distributed.run --nproc-per-node 1")
     ap.add_argument("--kernel-times", action="store_true", default=True)
     return ap.parse_args()
+
+
+def kernel_source_md5():
+    """MD5 over the HIP sources (xvc_amd/csrc): ties a PMC traffic profile to
+    the kernels it was measured on."""
+    import hashlib
+    m = hashlib.md5()
+    d = os.path.join(ROOT, "xvc_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        m.update(open(os.path.join(d, f), "rb").read())
+    return m.hexdigest()
+
+
+def stream_decode_figure(ctx, api):
+    """Reconstruction of the committed 1080p reference stream (the first five
+    pictures of BASELINE config 1 as the reference encoder coded them: CU trees,
+    modes, vectors, levels parsed by the reference decoder) through the C++ host
+    decoder + the C-ABI, and - where the reference build travels with the repo -
+    the reference decoder on the same stream on one host core.  Every picture's
+    MD5 is checked against the stream's."""
+    import stream_fixture as sf
+    from xvc_amd import decoder
+    fx = sf.StreamFixture("c1")
+    w, h, bd = (int(fx.info[0][k]) for k in ("width", "height", "bitdepth"))
+    syn = [sf.to_syntax(fx.info[i], fx.cus(i)) for i in range(fx.n)]
+    dec = decoder.PictureDecoder(ctx, w, h, bd)
+    pics = [ctx.picture(w, h, bd) for _ in range(fx.n)]
+
+    def run():
+        done = {}
+        for i in range(fx.n):
+            info = fx.info[i]
+            refs = [[done[int(info["ref_poc"][l][k])] for k in range(int(info["num_ref"][l]))]
+                    for l in range(2)]
+            dec.decode(syn[i][0], syn[i][1], fx.levels(i), refs, pics[i])
+            done[int(info["poc"])] = pics[i]
+        ctx.sync()
+
+    run()
+    ok = all(np.array_equal(sf.picture_md5(pics[i].download(0), bd), fx.info[i]["md5"])
+             for i in range(fx.n))
+    reps = 10
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        run()
+    dt = (time.perf_counter() - t0) / reps
+    out = {"stream": "1920x1080 QP 32, 1 intra + 4 hierarchical-B pictures coded by the "
+                     "reference encoder (tests/golden/stream_c1.npz)",
+           "pictures_per_s": fx.n / dt, "ms_per_picture": 1e3 * dt / fx.n,
+           "md5_match": bool(ok), "includes": "host planning + upload of the parsed syntax"}
+    dec.destroy()
+    for p in pics:
+        p.destroy()
+    import oracle_lib as ol
+    if ol.have_ref():
+        import ctypes as C
+        lib = C.CDLL(ol.REF_SO)
+        lib.xr_stream_decode.argtypes = [C.c_void_p, C.c_long, C.c_int]
+        buf = np.ascontiguousarray(fx.stream, np.uint8)
+        t0 = time.perf_counter()
+        n = 0
+        while n < 3 or time.perf_counter() - t0 < 2.0:
+            assert lib.xr_stream_decode(buf.ctypes.data, len(buf), 0) == fx.n
+            n += 1
+        out["cpu_reference_pictures_per_s"] = n * fx.n / (time.perf_counter() - t0)
+        out["cpu_reference"] = "the reference decoder (parse + reconstruct), 1 thread"
+        lib.xr_stream_release()
+    return out
 
 
 def pad_planes(planes, border):
@@ -103,7 +178,7 @@ def cpu_baseline(args, clip, bd, border):
     reconstruction is the next reference).  Kind "reference" when the
     reference build travels with the repo (oracle/_ref/libxvcref.so, compiled
     by oracle/Makefile from the reference's own sources): its classes - TZ
-    search, sub-pel search, interpolation, transforms, QuantFast, deblocking,
+    search, sub-pel search, interpolation, transforms, QuantRdo (or QuantFast), deblocking,
     PadBorder, ComparePicture, with its SSE2/AVX2 kernels - run the composition
     (ref_harness.cc xr_frame_pass; tests pin it equal to the oracle's).
     Otherwise kind "port": the plain-C oracle.  The per-CU loops are spread
@@ -113,7 +188,8 @@ def cpu_baseline(args, clip, bd, border):
     import oracle_frame
     import oracle_lib as ol
     from xvc_amd import pipeline
-    desc = pipeline.FrameDescriptors(args.width, args.height, args.qp)
+    desc = pipeline.FrameDescriptors(args.width, args.height, args.qp,
+                                     rdoq=args.quant == "rdoq", bitdepth=bd)
     frames = [pad_planes(clip.frame(i), border) for i in range(args.frames + 1)]
     F = len(frames) - 1
 
@@ -134,7 +210,7 @@ def cpu_baseline(args, clip, bd, border):
     if not ol.have_ref():
         nc, dtc = run(xo, False, 2000, 7.0, cores)
         return {
-            "value": nc / dtc, "unit": "frames/s", "cores": cores, "kind": "port",
+            "value": nc / dtc, "unit": "frame passes/s", "cores": cores, "kind": "port",
             "single_thread_value": np1 / dtp1,
             "sample": "%dx%d workload, chained frame passes, C oracle (gcc -O2): %d passes "
                       "in %.1f s on %d threads (OpenMP over the CUs; deblock/pad/SSD "
@@ -145,7 +221,7 @@ def cpu_baseline(args, clip, bd, border):
     n1, dt1 = run(xr, True, 2000, 4.0, 1)
     nc, dtc = run(xr, True, 2000, 7.0, cores)
     return {
-        "value": nc / dtc, "unit": "frames/s", "cores": cores, "kind": "reference",
+        "value": nc / dtc, "unit": "frame passes/s", "cores": cores, "kind": "reference",
         "single_thread_value": n1 / dt1, "port_single_thread_value": np1 / dtp1,
         "sample": "%dx%d workload, chained frame passes run by the reference's own classes "
                   "with its SIMD kernels (g++ -O2, oracle/_ref): %d passes in %.1f s on %d "
@@ -189,6 +265,7 @@ def main():
 
     bd, border = 10, api.BORDER_LUMA
     W, H = args.width, args.height
+    rdoq = args.quant == "rdoq"
     ctx = api.Context(local_rank)
     clip = synth.SyntheticClip(W, H, bd)
 
@@ -199,7 +276,7 @@ def main():
         # RCCL operations are ordered on it) - not torch's default stream
         runner = sharded.make_gpu_sharded(ctx, W, H, bd, args.qp, rank, world,
                                           torch.device("cuda", local_rank), dist,
-                                          own_stream=True)
+                                          own_stream=True, rdoq=rdoq)
         ts0 = runner.e.stream
     else:
         runner = None
@@ -214,7 +291,7 @@ def main():
     ctx_lo = None
     if runner is None:
         recs = [ctx.picture(W, H, bd), ctx.picture(W, H, bd)]
-        fp = pipeline.FramePass(ctx, W, H, bd, qp=args.qp)
+        fp = pipeline.FramePass(ctx, W, H, bd, qp=args.qp, rdoq=rdoq)
         if pipelined:
             # two queues on the device: top half of every picture on a
             # high-priority stream, bottom half on a low-priority one
@@ -243,13 +320,14 @@ def main():
         if multi:
             crun = sharded.make_gpu_sharded(cctx, W, H, bd, args.qp, rank, world,
                                             torch.device("cuda", local_rank), dist,
-                                            group=dist.new_group(), own_stream=True)
+                                            group=dist.new_group(), own_stream=True,
+                                            rdoq=rdoq)
             ts = crun.e.stream
             crecs, cfp = crun.e.pictures, crun.e.fp
         else:
             ts, crun = None, None
             crecs = [cctx.picture(W, H, bd), cctx.picture(W, H, bd)]
-            cfp = pipeline.FramePass(cctx, W, H, bd, qp=args.qp)
+            cfp = pipeline.FramePass(cctx, W, H, bd, qp=args.qp, rdoq=rdoq)
         crecs[0].upload(first, border)
         cctx.sync()
         extra.append((cctx, crun, cfp, crecs, phase, ts))
@@ -368,9 +446,14 @@ def main():
             times["me_search"] += timed(lambda: ctx.me_search_dev(
                 o, ref, api.ME_FULLPEL | api.ME_SUBPEL, fp.d_me.ptr, d.n_cus,
                 fp.d_res.ptr, d.cu_size))
-            times["recon_from_me"] += timed(lambda: ctx.recon_from_me_dev(
-                o, ref, rec, fp.d_me.ptr, fp.d_res.ptr, d.n_cus, d.qp, d.qp_c, 0,
-                fp.d_nnz.ptr, fp.d_cus_own))
+            if rdoq:
+                times["recon_from_me"] += timed(lambda: ctx.recon_from_me_rdoq_dev(
+                    o, ref, rec, fp.d_me.ptr, fp.d_res.ptr, d.n_cus, d.qp, d.qp_c, 0,
+                    fp.d_nnz.ptr, fp.d_cus_own, fp.d_rdoq_ctx.ptr, fp.d_rdoq_prm.ptr))
+            else:
+                times["recon_from_me"] += timed(lambda: ctx.recon_from_me_dev(
+                    o, ref, rec, fp.d_me.ptr, fp.d_res.ptr, d.n_cus, d.qp, d.qp_c, 0,
+                    fp.d_nnz.ptr, fp.d_cus_own))
             times["deblock"] += timed(lambda: ctx.deblock_dev(
                 rec, fp.d_cus.ptr, d.n_cus_total, fp.d_map.ptr, d.cu_map.shape[1]))
             times["pad_border"] += timed(lambda: ctx.pad_border(rec))
@@ -418,15 +501,20 @@ def main():
         # HBM bytes per launch from the committed PMC profile (rocprofv3 --pmc
         # FETCH_SIZE / WRITE_SIZE passes of this same command, corrected as
         # MI355X_MICROARCH.md prescribes; tools/pmc_traffic.py)
+        # The profile carries the MD5 of the kernel sources it was taken from:
+        # a figure from other kernels than the ones running now is not reported.
         traffic = None
         try:
-            prof = json.load(open(os.path.join(ROOT, "profiles", "r01_v6_traffic.json")))
-            kname = {"me_search": "void me_search_wave_kernel<16, 3>",
+            prof = json.load(open(os.path.join(ROOT, "profiles", "traffic_current.json")))
+            kname = {"me_search": "me_search_wave_kernel<16, 3>",
                      "recon_from_me": "recon_from_me_kernel",
                      "picture_ssd": "picture_ssd_kernel", "pad_border": "pad_border_kernel",
-                     "deblock": "void deblock_pass_kernel<true>"}[dom]
-            if W == 1920 and H == 1080 and not multi:
-                traffic = prof[kname]["hbm_bytes_per_launch"]
+                     "deblock": "deblock_pass_kernel<true>"}[dom]
+            if (W == 1920 and H == 1080 and not multi and
+                    prof.get("kernel_source_md5") == kernel_source_md5() and
+                    prof.get("quant") == args.quant):
+                hit = [v for k, v in prof["kernels"].items() if kname in k]
+                traffic = hit[0]["hbm_bytes_per_launch"] if hit else None
         except (OSError, KeyError, ValueError):
             traffic = None
         achieved = alg[dom] / (times[dom] * 1e-3) / 1e9
@@ -447,13 +535,17 @@ def main():
     cpu = None
     if rank == 0 and not multi and not args.no_cpu:
         cpu = cpu_baseline(args, clip, bd, border)
+    decode = None
+    if rank == 0 and not multi and not args.no_decode:
+        decode = stream_decode_figure(ctx, api)
 
     if rank == 0:
         value = args.steps / dt
         out = {
-            "metric": "hot-path encoded frames/sec (ME+MC+transform/quant+deblock+pad), "
-                      "bit-exact recon vs oracle",
-            "value": value, "unit": "frames/s", "n_gpus": world,
+            "metric": "hot-path frame passes/s (TZ + sub-pel ME, MC, transform + %s + "
+                      "dequant + inverse, deblock, pad, PSNR parts), bit-exact vs the "
+                      "reference's classes" % ("RDOQ" if rdoq else "QuantFast"),
+            "value": value, "unit": "frame passes/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps,
             "gpu_ms_per_step_events": gpu_ms / args.steps if n_chains == 1 else None,
@@ -463,15 +555,18 @@ def main():
             "vs_baseline": None, "dtype": "u16", "data": "synthetic",
             "psnr_y": psnr_y,
             "config": {"workload": "%dx%d yuv420p 30fps synthetic, QP %d, internal "
-                                   "bitdepth 10, 16x16 CUs, TZ range 96, QuantFast" %
-                                   (W, H, args.qp),
+                                   "bitdepth 10, 16x16 CUs, TZ range 96, %s" %
+                                   (W, H, args.qp,
+                                    "RDOQ (RdoQuant::QuantRdo + CoeffSignHideRdo, "
+                                    "picture-initial CABAC contexts)" if rdoq else
+                                    "QuantFast"),
                        "cus_per_picture": fp.desc.n_cus_total,
                        "parallelism": (("two-queue" if pipelined else
                                         "single" if n_chains == 1 else
                                         "%d independent picture chains in flight" % n_chains)
                                        if not multi else
                                        "cu-row-shard%d x %d chains in flight" % (world, n_chains))},
-            "roofline": roof, "cpu_baseline": cpu,
+            "roofline": roof, "cpu_baseline": cpu, "stream_decode": decode,
         }
         print(json.dumps(out))
     if multi:

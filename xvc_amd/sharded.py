@@ -332,7 +332,7 @@ class GpuEngine:
     wrapped as xvcgpu pictures; kernels run on torch's current stream."""
 
     def __init__(self, ctx, width, height, bitdepth, qp, row_range, device,
-                 n_pictures=2, cu=16, own_stream=False):
+                 n_pictures=2, cu=16, own_stream=False, rdoq=False):
         import torch
         self.torch = torch
         self.ctx, self.w, self.h, self.bd, self.cu = ctx, width, height, bitdepth, cu
@@ -359,7 +359,7 @@ class GpuEngine:
                           api.BORDER_LUMA if c == 0 else api.BORDER_CHROMA))
             self.geom.append(g)
         self.fp = pipeline.FramePass(ctx, width, height, bitdepth, qp=qp, cu=cu,
-                                     row_range=row_range)
+                                     row_range=row_range, rdoq=rdoq)
         d = self.fp.desc
         self.cus_per_row = d.cus_per_row
         # CU metadata in a torch tensor so boundary rows can be exchanged
@@ -468,7 +468,7 @@ class _ExternalBuffer:
 
 
 def make_gpu_sharded(ctx, width, height, bitdepth, qp, rank, world, device, dist,
-                     group=None, own_stream=False):
+                     group=None, own_stream=False, rdoq=False):
     """The engine's kernels run on torch's current stream at the time of this
     call, or - own_stream - on the context's own stream, exposed to torch as
     `runner.e.stream`; either way call run() under `with torch.cuda.stream(
@@ -477,5 +477,5 @@ def make_gpu_sharded(ctx, width, height, bitdepth, qp, rank, world, device, dist
     rows = shard_rows(height, world)
     with torch_stream_of(ctx, device, own_stream):
         engine = GpuEngine(ctx, width, height, bitdepth, qp, rows[rank], device,
-                           own_stream=own_stream)
+                           own_stream=own_stream, rdoq=rdoq)
     return ShardedFramePass(engine, TorchComm(dist, rank, world, group), rank, world)
