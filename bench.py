@@ -426,8 +426,7 @@ def main():
         F = len(origs)
         cycle = 2 * F - 2 if F > 1 else 1
         reps = 5
-        times = dict.fromkeys(["me_search", "recon_from_me", "deblock", "pad_border",
-                               "picture_ssd"], 0.0)
+        times = {}
 
         def timed(fn):
             fn()
@@ -443,22 +442,10 @@ def main():
             k = i % cycle
             o = origs[k if k < F else 2 * F - 2 - k]
             ref, rec = recs[i % 2], recs[(i + 1) % 2]
-            times["me_search"] += timed(lambda: ctx.me_search_dev(
-                o, ref, api.ME_FULLPEL | api.ME_SUBPEL, fp.d_me.ptr, d.n_cus,
-                fp.d_res.ptr, d.cu_size))
-            if rdoq:
-                times["recon_from_me"] += timed(lambda: ctx.recon_from_me_rdoq_dev(
-                    o, ref, rec, fp.d_me.ptr, fp.d_res.ptr, d.n_cus, d.qp, d.qp_c, 0,
-                    fp.d_nnz.ptr, fp.d_cus_own, fp.d_rdoq_ctx.ptr, fp.d_rdoq_prm.ptr))
-            else:
-                times["recon_from_me"] += timed(lambda: ctx.recon_from_me_dev(
-                    o, ref, rec, fp.d_me.ptr, fp.d_res.ptr, d.n_cus, d.qp, d.qp_c, 0,
-                    fp.d_nnz.ptr, fp.d_cus_own))
-            times["deblock"] += timed(lambda: ctx.deblock_dev(
-                rec, fp.d_cus.ptr, d.n_cus_total, fp.d_map.ptr, d.cu_map.shape[1]))
-            times["pad_border"] += timed(lambda: ctx.pad_border(rec))
-            times["picture_ssd"] += timed(lambda: ctx.picture_ssd_dev(o, rec, 0, bd,
-                                                                      fp.d_ssd.ptr))
+            # every launch of the pass in issue order (each leaves what the next
+            # one reads), then the pass itself to advance the chain
+            for name, fn in fp.kernel_steps(o, ref, rec, ref_poc=i):
+                times[name] = times.get(name, 0.0) + timed(fn)
             fp.run(o, ref, rec, ref_poc=i)
         times = {k: v / cycle for k, v in times.items()}
         dom = max(times, key=times.get)
@@ -489,27 +476,33 @@ def main():
         # algorithmic bytes per launch
         S = 2
         n_luma = sum(int(b["w"]) * int(b["h"]) for b in d.me)
+        n_all = int(1.5 * n_luma)
         alg = {
             # each plane read once: original + reference luma of the CUs
             "me_search": 2 * n_luma * S,
             # orig + reference read, reconstruction written, all three planes
-            "recon_from_me": 3 * int(1.5 * n_luma) * S,
-            "deblock": 2 * int(1.5 * n_luma) * S + 16 * (n_luma // 16),
+            "recon_from_me": 3 * n_all * S,
+            "mc_from_me": 2 * n_all * S,                 # reference read, prediction written
+            "fwd_transform": 3 * n_all * S,              # orig + pred read, coefficients written
+            "quant_rdo": 2 * n_all * S,                  # coefficients read, levels written
+            "inv_transform": 3 * n_all * S,              # levels + pred read, rec written
+            "residual_rdoq": 3 * n_all * S, "residual": 3 * n_all * S,
+            "cu_info": 84 * d.n_cus,
+            "deblock": 2 * n_all * S + 16 * (n_luma // 16),
             "pad_border": 2 * 80 * (W + H + 160) * S * 2,
             "picture_ssd": 2 * n_luma * S,
         }
-        # HBM bytes per launch from the committed PMC profile (rocprofv3 --pmc
-        # FETCH_SIZE / WRITE_SIZE passes of this same command, corrected as
-        # MI355X_MICROARCH.md prescribes; tools/pmc_traffic.py)
         # The profile carries the MD5 of the kernel sources it was taken from:
         # a figure from other kernels than the ones running now is not reported.
         traffic = None
         try:
             prof = json.load(open(os.path.join(ROOT, "profiles", "traffic_current.json")))
             kname = {"me_search": "me_search_wave_kernel<16, 3>",
-                     "recon_from_me": "recon_from_me_kernel",
+                     "recon_from_me": "recon_from_me_kernel", "quant_rdo": "quant_rdo_packed_kernel<16>",
+                     "fwd_transform": "residual_wave_kernel<1", "inv_transform": "residual_wave_kernel<2",
+                     "mc_from_me": "mc_from_me_kernel",
                      "picture_ssd": "picture_ssd_kernel", "pad_border": "pad_border_kernel",
-                     "deblock": "deblock_pass_kernel<true>"}[dom]
+                     "deblock": "deblock_pass_kernel<true>"}.get(dom, dom)
             if (W == 1920 and H == 1080 and not multi and
                     prof.get("kernel_source_md5") == kernel_source_md5() and
                     prof.get("quant") == args.quant):

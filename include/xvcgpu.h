@@ -353,14 +353,17 @@ xvcgpu_status xvcgpu_residual_rdoq_batch(xvcgpu_ctx *ctx, const xvcgpu_picture *
 /* Q2 alone: RdoQuant::QuantRdo on coefficients the caller holds (the output
  * of xvcgpu_fwd_transform_batch; the levels go to xvcgpu_inv_transform_batch):
  * block i reads w*h int16 at d_coeffs + d_offsets[i] and writes its levels at
- * d_levels + d_offsets[i], d_nnz[i] = RdoQuant::QuantRdo's return value.  Only
- * w, h, comp, qp and the XVC_TXF_NO_SIGN_HIDING / scan bits of a block are
- * read.  Blocks whose XVC_RDOQ_NO_2X2 case applies (2-wide, rdo_quant_2x2
+ * d_levels + d_offsets[i], d_nnz[i] = RdoQuant::QuantRdo's return value (all
+ * levels zero when it is 0).  n_coeffs = the number of int16 in d_coeffs
+ * (sizes the per-coefficient scratch).  Only w, h, comp, qp and the
+ * XVC_TXF_NO_SIGN_HIDING / scan bits of a block are read.  This is the
+ * throughput form: several blocks share a wave (16 blocks up to 8x8, 4 up to
+ * 16x16).  Blocks whose XVC_RDOQ_NO_2X2 case applies (2-wide, rdo_quant_2x2
  * off) are NOT taken here: route them to xvcgpu_residual_batch. */
 xvcgpu_status xvcgpu_quant_rdo_batch(xvcgpu_ctx *ctx, int bitdepth,
                                      const xvcgpu_tx_block *d_blocks, int n,
                                      const int16_t *d_coeffs, const uint32_t *d_offsets,
-                                     int16_t *d_levels, int32_t *d_nnz,
+                                     size_t n_coeffs, int16_t *d_levels, int32_t *d_nnz,
                                      const xvcgpu_rdoq_contexts *d_contexts,
                                      const xvcgpu_rdoq_params *d_params);
 

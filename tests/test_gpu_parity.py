@@ -720,6 +720,34 @@ def pad_planes(planes, bd):
 
 
 # BASELINE.json configs: CIF QP32, 1080p QP32, 2160p QP27 (+ a ragged size)
+def test_frame_pass_rdoq_fused_kernel(gpu, xo):
+    """The one-launch form (RDOQ inside recon_from_me: luma wave + U/V half-waves)
+    stays available and exact."""
+    api, ctx = gpu
+    from xvc_amd import pipeline, synth
+    import oracle_frame
+    pw, ph, bd, qp = 352, 288, 10, 32
+    clip = synth.SyntheticClip(pw, ph, bd)
+    fp = pipeline.FramePass(ctx, pw, ph, bd, qp=qp, fused=True, rdoq=True, rdoq_packed=False)
+    assert fp.fused
+    ref_host, orig_host = pad_planes(clip.frame(0), bd), pad_planes(clip.frame(1), bd)
+    O, R, Rec = ctx.picture(pw, ph, bd), ctx.picture(pw, ph, bd), ctx.picture(pw, ph, bd)
+    R.upload(ref_host, BL)
+    O.upload(orig_host, BL)
+    fp.run(O, R, Rec)
+    ctx.sync()
+    res, nnz, cus, ssd = fp.results()
+    e_rec, e_res, e_nnz, e_cus, e_ssd = oracle_frame.frame_pass(fp.desc, bd, orig_host, ref_host,
+                                                               BL, lib=xo)
+    assert np.array_equal(nnz, e_nnz) and np.array_equal(cus, e_cus)
+    got = Rec.download(BL)
+    for c in range(3):
+        assert np.array_equal(got[c], e_rec[c]), c
+    fp.destroy()
+    for p in (O, R, Rec):
+        p.destroy()
+
+
 @pytest.mark.parametrize("rdoq", [True, False])
 @pytest.mark.parametrize("fused", [True, False])
 @pytest.mark.parametrize("size", [(352, 288, 32), (136, 72, 32), (1920, 1080, 32),
@@ -736,6 +764,8 @@ def test_frame_pass(gpu, xo, size, fused, rdoq):
         pytest.skip("the 2160p case runs the production (fused) path only")
     bd = 10
     clip = synth.SyntheticClip(pw, ph, bd)
+    # fused + rdoq: the packed RDOQ kernel between the two halves of the pipeline
+    # (the production path); unfused + rdoq: the quantiser inside the residual kernel
     fp = pipeline.FramePass(ctx, pw, ph, bd, qp=qp, fused=fused, rdoq=rdoq)
     ref_host = pad_planes(clip.frame(0), bd)
     O, R, Rec = ctx.picture(pw, ph, bd), ctx.picture(pw, ph, bd), ctx.picture(pw, ph, bd)

@@ -250,7 +250,8 @@ def load_library():
         "xvcgpu_residual_rdoq_batch": [_vp, _vp, _vp, _vp, _vp, C.c_int, _vp, _vp, _vp, _vp, _vp],
         "xvcgpu_recon_from_me_rdoq": [_vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int,
                                       C.c_int, C.c_int, _vp, _vp, _vp, _vp],
-        "xvcgpu_quant_rdo_batch": [_vp, C.c_int, _vp, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp],
+        "xvcgpu_quant_rdo_batch": [_vp, C.c_int, _vp, C.c_int, _vp, _vp, C.c_size_t, _vp, _vp,
+                                   _vp, _vp],
         "xvcgpu_deblock_tree": [_vp, _vp, _vp, C.c_int, _vp, C.c_int, C.c_int, C.c_int,
                                 C.c_int, C.c_int, C.c_int],
     }
@@ -660,8 +661,8 @@ class Context:
         dl = self.alloc(2 * max(1, len(coeffs)))
         dn = self.alloc(4 * max(1, len(blocks)))
         self._check(self.lib.xvcgpu_quant_rdo_batch(
-            self.h, bitdepth, db.ptr, len(blocks), dcf.ptr, dof.ptr, dl.ptr, dn.ptr, dc.ptr,
-            dp.ptr))
+            self.h, bitdepth, db.ptr, len(blocks), dcf.ptr, dof.ptr, len(coeffs), dl.ptr,
+            dn.ptr, dc.ptr, dp.ptr))
         levels = dl.to_array(np.int16, len(coeffs))
         nnz = dn.to_array(np.int32, len(blocks))
         for b in (db, dof, dcf, dl, dn, dc, dp):

@@ -53,7 +53,6 @@ __constant__ uint32_t kEntropyBits[128] = {
     0x00710, 0x25e8f, 0x006a0, 0x26a26, 0x00672, 0x26f23, 0x005e8, 0x27ef8, 0x005ba, 0x284b5,
     0x0055e, 0x29057, 0x0050c, 0x29bab, 0x004c1, 0x2a674, 0x004a7, 0x2aa5e, 0x0046f, 0x2b32f,
     0x0041f, 0x2c0ad, 0x003e7, 0x2ca8d, 0x003ba, 0x2d323, 0x0010c, 0x3bfbb};
-__constant__ uint8_t kGolombRiceRangeExt[10] = {6, 5, 6, 3, 3, 3, 3, 3, 3, 3};
 
 #define RQ_BYPASS 32768u  // ContextModel::kEntropyBypassBits
 
@@ -69,7 +68,30 @@ struct RdoqShared {
   unsigned csbf_bits[64];      // csbf_bits_to_zero
   unsigned char csbf[64];
   unsigned char sb_of_scan[256];  // sub-block scan index -> sy * gw + sx
+  // GetEntropyBits(bin) of every context of the snapshot: [2 * i + bin] for the
+  // context at byte offset i of xvcgpu_rdoq_contexts.  The walk looks a dozen
+  // of these up per coefficient, each depending on the previous decision: from
+  // global / constant memory that is a dozen dependent ~1 us round trips per
+  // coefficient (the first version ran 0.86 ms per 1080p picture that way).
+  alignas(8) unsigned ctx_bits[2 * sizeof(xvcgpu_rdoq_contexts)];
 };
+
+// The same members as pointers (packed kernel: per-coefficient arrays in
+// global memory, the rest in LDS).
+struct RdoqView {
+  long long *cost_to_zero;
+  unsigned *sig_bits;
+  int *sig_rate, *rate_up, *rate_down;
+  short *err_dist;
+  long long *sb_code_cost, *sb_zero_dist;
+  unsigned *csbf_bits;
+  unsigned char *csbf;
+  unsigned char *sb_of_scan;
+  unsigned *ctx_bits;
+};
+
+// byte offsets of the context groups inside xvcgpu_rdoq_contexts
+#define RQ_OFF(field) ((int)__builtin_offsetof(xvcgpu_rdoq_contexts, field))
 
 __device__ __forceinline__ unsigned rq_bits(unsigned char state, int bin) {
   return kEntropyBits[state ^ bin];
@@ -113,11 +135,18 @@ struct RdoqCoeffState {  // RdoQuant::CoeffCodingState, the part the extended se
   unsigned golomb_rice_k;
 };
 
-__device__ __forceinline__ unsigned rq_abs_level_bits(int level, unsigned char c1_ctx,
-                                                      unsigned char c2_ctx,
+// The greater1 / greater2 flag costs of the coefficient's two contexts, loaded
+// once per coefficient (c1[bin], c2[bin]); the function itself touches no memory.
+struct RdoqFlagBits {
+  unsigned c1_0, c1_1, c2_0, c2_1;
+};
+__device__ __forceinline__ unsigned rq_abs_level_bits(const RdoqFlagBits &f, int level,
                                                       const RdoqCoeffState &s) {
   const int base_level = s.c1_idx < 8 ? (2 + (s.c2_idx < 1)) : 1;
-  const unsigned threshold = kGolombRiceRangeExt[s.golomb_rice_k];
+  // TransformHelper::kGolombRiceRangeExt = {6, 5, 6, 3, 3, ...} (transform.cc:61-63), as
+  // arithmetic: a divergent lookup in constant memory costs a ~1 us round trip
+  const unsigned threshold =
+      s.golomb_rice_k < 3 ? (s.golomb_rice_k == 1 ? 5u : 6u) : 3u;
   unsigned bits = RQ_BYPASS;
   if (level >= base_level) {
     unsigned code = (unsigned)(level - base_level);
@@ -130,35 +159,34 @@ __device__ __forceinline__ unsigned rq_abs_level_bits(int level, unsigned char c
       bits += (unsigned)(length + (int)threshold + length + 1 - (int)s.golomb_rice_k) * RQ_BYPASS;
     }
     if (s.c1_idx < 8) {
-      bits += rq_bits(c1_ctx, 1);
-      if (s.c2_idx < 1) bits += rq_bits(c2_ctx, 1);
+      bits += f.c1_1;
+      if (s.c2_idx < 1) bits += f.c2_1;
     }
   } else if (level == 1) {
-    bits += rq_bits(c1_ctx, 0);
+    bits += f.c1_0;
   } else if (level == 2) {
-    bits += rq_bits(c1_ctx, 1) + rq_bits(c2_ctx, 0);
+    bits += f.c1_1 + f.c2_0;
   } else {
     return 0;
   }
   return bits;
 }
 
-// GetCoeffLastPosCtx (cabac.cc:727-770) + GetLastPosBits (rdo_quant.cc:900-947)
-__device__ __forceinline__ unsigned char rq_last_pos_ctx(const xvcgpu_rdoq_contexts &c, bool luma,
-                                                         int w, int h, int pos, bool is_x) {
+// GetCoeffLastPosCtx (cabac.cc:727-770) + GetLastPosBits (rdo_quant.cc:900-947);
+// returns the table index of the context
+__device__ __forceinline__ int rq_last_pos_ctx(bool luma, int w, int h, int pos, bool is_x) {
   const int size = is_x ? w : h;
   if (luma) {
     const int l2 = rq_log2(size);
     const int off = l2 < 3 ? 0 : (l2 == 3 ? 3 : (l2 == 4 ? 6 : (l2 == 5 ? 10 : (l2 == 6 ? 15 : 21))));
     const int idx = off + (pos >> ((l2 + 1) >> 2));
-    return is_x ? c.last_x_luma[idx] : c.last_y_luma[idx];
+    return 2 * ((is_x ? RQ_OFF(last_x_luma) : RQ_OFF(last_y_luma)) + idx);
   }
   const int shift = d_clip3(size >> 3, 0, 2);
-  return is_x ? c.last_x_chroma[pos >> shift] : c.last_y_chroma[pos >> shift];
+  return 2 * ((is_x ? RQ_OFF(last_x_chroma) : RQ_OFF(last_y_chroma)) + (pos >> shift));
 }
-__device__ __forceinline__ unsigned rq_last_pos_bits(const xvcgpu_rdoq_contexts &c, bool luma,
-                                                     int w, int h, int scan_order, int lx,
-                                                     int ly) {
+__device__ __forceinline__ unsigned rq_last_pos_bits(const unsigned *cb, bool luma, int w, int h,
+                                                     int scan_order, int lx, int ly) {
   if (scan_order == 2) {
     int t = lx; lx = ly; ly = t;
     t = w; w = h; h = t;
@@ -166,10 +194,10 @@ __device__ __forceinline__ unsigned rq_last_pos_bits(const xvcgpu_rdoq_contexts 
   const int gx = rq_last_pos_group(lx), gy = rq_last_pos_group(ly);
   unsigned bits = 0;
   int k;
-  for (k = 0; k < gx; k++) bits += rq_bits(rq_last_pos_ctx(c, luma, w, h, k, true), 1);
-  if (gx < rq_last_pos_group(w - 1)) bits += rq_bits(rq_last_pos_ctx(c, luma, w, h, k, true), 0);
-  for (k = 0; k < gy; k++) bits += rq_bits(rq_last_pos_ctx(c, luma, w, h, k, false), 1);
-  if (gy < rq_last_pos_group(h - 1)) bits += rq_bits(rq_last_pos_ctx(c, luma, w, h, k, false), 0);
+  for (k = 0; k < gx; k++) bits += cb[rq_last_pos_ctx(luma, w, h, k, true) + 1];
+  if (gx < rq_last_pos_group(w - 1)) bits += cb[rq_last_pos_ctx(luma, w, h, k, true)];
+  for (k = 0; k < gy; k++) bits += cb[rq_last_pos_ctx(luma, w, h, k, false) + 1];
+  if (gy < rq_last_pos_group(h - 1)) bits += cb[rq_last_pos_ctx(luma, w, h, k, false)];
   if (gx > 3) bits += (unsigned)((gx - 2) >> 1) * RQ_BYPASS;
   if (gy > 3) bits += (unsigned)((gy - 2) >> 1) * RQ_BYPASS;
   return bits;
@@ -190,11 +218,14 @@ __device__ __forceinline__ int rq_scan_pos(int sbs, int order, int k) {
 // array (both only inside the region); `lane` is 0..G-1 and all lanes must call.  Returns the number of non-zero levels (to
 // every lane); levels outside the region are NOT written (they are zero: the
 // caller clears what its layout needs).
-template <int N, int G = 64, typename CF, typename LEV>
-__device__ __forceinline__ int wave_rdoq(RdoqShared<N> &s, int lane, int bd, int w, int h,
+// S: the scratch - RdoqShared<N> (all of it in LDS) or RdoqView (pointers: the
+// per-coefficient arrays in global memory, a context table that may be shared).
+template <int G = 64, typename S, typename CF, typename LEV>
+__device__ __forceinline__ int wave_rdoq(S &s, int lane, int bd, int w, int h,
                                          int comp_qp, bool luma, int scan_order, bool sign_hide,
                                          const xvcgpu_rdoq_contexts &ctx,
-                                         const xvcgpu_rdoq_params &prm, CF cf, LEV lev) {
+                                         const xvcgpu_rdoq_params &prm, CF cf, LEV lev,
+                                         bool stage_ctx = true) {
   const int sbs = (w == 2 || h == 2) ? 1 : 2;
   const int sb_size = 1 << (2 * sbs);
   const int gw = w >> sbs, gh = h >> sbs;                   // the whole grid (scan indices)
@@ -226,44 +257,61 @@ __device__ __forceinline__ int wave_rdoq(RdoqShared<N> &s, int lane, int bd, int
     y = py + (p >> 2);
   };
 
-  // scan index -> sub-block (whole grid), and the last position: the first
-  // non-zero quantised value in reverse scan
-  for (int t = lane; t < gw * gh; t += G)
-    s.sb_of_scan[d_sb_scan_index(scan_order, gw, gh, t % gw, t / gw)] = (unsigned char)t;
+  // The last position: the first non-zero quantised value in reverse scan; and
+  // every sub-block's sum of zero costs (what a sub-block beyond the last
+  // position contributes - to both totals, rdo_quant.cc:295-307 - and all it
+  // needs: its levels are zero and nothing reads its per-coefficient records).
   int last = -1;
+  long long my_zero_dist = 0;
   if (mine)
     for (int k = sb_size - 1; k >= 0; k--) {
       int x, y;
       coeff_xy(k, x, y);
       const int a = (short)d_abs(cf(x, y));
+      my_zero_dist += ((long long)(a * a)) << cost_scale;
       const int q = (short)(int)((((long long)a * scale) + fq_offset) >> fq_shift);
-      if (q) {
-        last = sb_index + k;
-        break;
-      }
+      if (q && last < 0) last = sb_index + k;
+      *lev(x, y) = 0;
     }
   const int last_pos_index = rq_wave_max_i32<G>(last);
-  if (last_pos_index < 0) {  // nothing quantises to a level
-    if (mine)
-      for (int k = 0; k < sb_size; k++) {
-        int x, y;
-        coeff_xy(k, x, y);
-        *lev(x, y) = 0;
-      }
-    return 0;
+  if (last_pos_index < 0) return 0;  // nothing quantises to a level (most blocks)
+
+  // every context's two bin costs into LDS
+  if (stage_ctx) {
+    const unsigned char *cbytes = reinterpret_cast<const unsigned char *>(&ctx);
+    for (int i = lane; i < (int)sizeof(xvcgpu_rdoq_contexts); i += G) {
+      const unsigned char st8 = cbytes[i] & 127;
+      s.ctx_bits[2 * i] = kEntropyBits[st8];
+      s.ctx_bits[2 * i + 1] = kEntropyBits[st8 ^ 1];
+    }
   }
-  if (mine) s.csbf[lane] = 0;
+  const unsigned *cb = s.ctx_bits;
+  // scan index -> sub-block (whole grid), for EvalLastPos
+  for (int t = lane; t < gw * gh; t += G)
+    s.sb_of_scan[d_sb_scan_index(scan_order, gw, gh, t % gw, t / gw)] = (unsigned char)t;
+  // a sub-block is "live" when the walk reaches it at or before the last position
+  const bool live = mine && sb_index <= last_pos_index;
+  if (mine) {
+    s.csbf[lane] = 0;
+    if (!live) {
+      s.csbf_bits[lane] = 0;
+      s.sb_code_cost[lane] = my_zero_dist;
+      s.sb_zero_dist[lane] = my_zero_dist;
+    }
+  }
+  // the wavefront starts at the highest anti-diagonal that holds a live sub-block
+  const int d_first = rq_wave_max_i32<G>(live ? sx + sy : -1);
   wave_sync();
 
   // ---- the per-coefficient decisions, one anti-diagonal of sub-blocks at a time
-  for (int d = rgw + rgh - 2; d >= 0; d--) {
-    if (mine && sx + sy == d) {
+  for (int d = d_first; d >= 0; d--) {
+    if (live && sx + sy == d) {
       RdoqCoeffState st = {0, 0, 0};
       long long sb_zero_dist = 0, sb_code_cost = 0;
       // GetSubblockCsbfCtx (cabac.cc:491-518); sub-blocks beyond the region are zero
       const bool right = sx < rgw - 1 ? s.csbf[lane + 1] != 0 : false;
       const bool below = sy < rgh - 1 ? s.csbf[lane + rgw] != 0 : false;
-      const unsigned char csbf_ctx = ctx.csbf[luma ? 0 : 1][(right || below) ? 1 : 0];
+      const int csbf_ctx = 2 * (RQ_OFF(csbf) + (luma ? 0 : 2) + ((right || below) ? 1 : 0));
       int num_non_zero = 0;
       bool any = false;
       for (int k = sb_size - 1; k >= 0; k--) {
@@ -284,58 +332,54 @@ __device__ __forceinline__ int wave_rdoq(RdoqShared<N> &s, int lane, int bd, int
         }
         const int q = (short)(int)((((long long)abs_coeff * scale) + fq_offset) >> fq_shift);
         const bool is_last = index == last_pos_index;
-        // the template of decided neighbours (all inside the region: beyond it
-        // every level is zero)
+        // the template of decided neighbours: five reads issued together (clamped
+        // addresses, masked values) - inside the region; beyond it every level is 0
         int n_sig = 0, n_g1 = 0, n_g2 = 0, sum_abs = 0;
         {
-          auto nb = [&](int xx, int yy) {
-            if (xx >= rw || yy >= rh) return;
-            const int v = d_abs((int)*lev(xx, yy));
+          const int x1 = x + 1 < rw ? x + 1 : x, x2 = x + 2 < rw ? x + 2 : x;
+          const int y1 = y + 1 < rh ? y + 1 : y, y2 = y + 2 < rh ? y + 2 : y;
+          const int v0 = *lev(x1, y), v1 = *lev(x2, y), v2 = *lev(x1, y1), v3 = *lev(x, y1),
+                    v4 = *lev(x, y2);
+          const bool m0 = x + 1 < rw, m1 = x + 2 < rw, m2 = m0 && y + 1 < rh, m3 = y + 1 < rh,
+                     m4 = y + 2 < rh;
+          auto nb = [&](int v, bool m) {
+            v = m ? d_abs(v) : 0;
             n_sig += v != 0;
             n_g1 += v > 1;
             n_g2 += v > 2;
             sum_abs += v;
           };
-          if (x < w - 1) {
-            nb(x + 1, y);
-            if (x < w - 2) nb(x + 2, y);
-            if (y < h - 1) nb(x + 1, y + 1);
-          }
-          if (y < h - 1) {
-            nb(x, y + 1);
-            if (y < h - 2) nb(x, y + 2);
-          }
+          nb(v0, m0); nb(v1, m1); nb(v2, m2); nb(v3, m3); nb(v4, m4);
         }
         const int posxy = x + y;
-        unsigned char sig_ctx, c1_ctx, c2_ctx;
+        int sig_ctx, c1_ctx, c2_ctx;  // table indices
         {  // GetCoeffSigCtx (cabac.cc:520-560)
           const int size = (lw + lh) >> 1;
           int start = posxy < 2 ? 6 : 0;
           start += luma && posxy < 5 ? 6 : 0;
           start += size > 2 && luma ? 18 << (size - 3 < 1 ? size - 3 : 1) : 0;
           const int off = n_sig < 5 ? n_sig : 5;
-          sig_ctx = luma ? ctx.sig_luma[start + off] : ctx.sig_chroma[start + off];
+          sig_ctx = 2 * ((luma ? RQ_OFF(sig_luma) : RQ_OFF(sig_chroma)) + start + off);
         }
-        if (is_last) {  // GetCoeffGreater1Ctx / Greater2Ctx (cabac.cc:594-684)
-          c1_ctx = c2_ctx = luma ? ctx.greater1_luma[0] : ctx.greater1_chroma[0];
-        } else {
+        {  // GetCoeffGreater1Ctx / Greater2Ctx (cabac.cc:594-684)
+          const int g1 = luma ? RQ_OFF(greater1_luma) : RQ_OFF(greater1_chroma);
           const int start = luma ? (posxy < 3 ? 10 : (posxy < 10 ? 5 : 0)) : 0;
           const int o1 = (n_g1 < 4 ? n_g1 : 4) + 1, o2 = (n_g2 < 4 ? n_g2 : 4) + 1;
-          c1_ctx = luma ? ctx.greater1_luma[start + o1] : ctx.greater1_chroma[start + o1];
-          c2_ctx = luma ? ctx.greater1_luma[start + o2] : ctx.greater1_chroma[start + o2];
+          c1_ctx = is_last ? 2 * g1 : 2 * (g1 + start + o1);
+          c2_ctx = is_last ? 2 * g1 : 2 * (g1 + start + o2);
         }
-        {  // GetCoeffGolombRiceK (cabac.cc:686-725)
+        {  // GetCoeffGolombRiceK (cabac.cc:686-725): smallest k with 2^(k+3) > threshold
           const unsigned threshold = 4u + (unsigned)(sum_abs - n_sig);
-          unsigned kk = 9;
-          for (unsigned t = 0; t < 10; t++)
-            if ((1u << (t + 3)) > threshold) {
-              kk = t;
-              break;
-            }
-          st.golomb_rice_k = kk;
+          const int kk = 29 - __clz((int)threshold);  // floor(log2) - 2
+          st.golomb_rice_k = (unsigned)(kk < 0 ? 0 : (kk > 9 ? 9 : kk));
         }
-        const unsigned sig0 = rq_bits(sig_ctx, 0);
-        unsigned sig1 = rq_bits(sig_ctx, 1);
+        // the six context costs of this coefficient: three 8-byte reads, together
+        const uint2 sig_b = *reinterpret_cast<const uint2 *>(cb + sig_ctx);
+        const uint2 c1_b = *reinterpret_cast<const uint2 *>(cb + c1_ctx);
+        const uint2 c2_b = *reinterpret_cast<const uint2 *>(cb + c2_ctx);
+        const RdoqFlagBits fb = {c1_b.x, c1_b.y, c2_b.x, c2_b.y};
+        const unsigned sig0 = sig_b.x;
+        unsigned sig1 = sig_b.y;
         if (is_last || (sb_index > 0 && k == 0 && num_non_zero == 0)) sig1 = 0;
 
         long long best_cost = 0x7fffffffffffffffll;
@@ -344,7 +388,7 @@ __device__ __forceinline__ int wave_rdoq(RdoqShared<N> &s, int lane, int bd, int
         if (q > 0) {  // QuantCoeffRdo (rdo_quant.cc:689-720)
           best_sig = sig1;
           for (int lvl = q > 1 ? q - 1 : q; lvl <= q; lvl++) {
-            const unsigned bits = sig1 + rq_abs_level_bits(lvl, c1_ctx, c2_ctx, st);
+            const unsigned bits = sig1 + rq_abs_level_bits(fb, lvl, st);
             int deq;
             if (iq_shift > 0) deq = (lvl * iq_scale + (1 << (iq_shift - 1))) >> iq_shift;
             else deq = (lvl * iq_scale) << -iq_shift;
@@ -377,11 +421,11 @@ __device__ __forceinline__ int wave_rdoq(RdoqShared<N> &s, int lane, int bd, int
         if (best_level) {
           any = true;
           num_non_zero++;
-          const int lvl_rate = (int)rq_abs_level_bits(best_level, c1_ctx, c2_ctx, st);
-          s.rate_up[pos] = -lvl_rate + (int)rq_abs_level_bits(best_level + 1, c1_ctx, c2_ctx, st);
-          s.rate_down[pos] = -lvl_rate + (int)rq_abs_level_bits(best_level - 1, c1_ctx, c2_ctx, st);
+          const int lvl_rate = (int)rq_abs_level_bits(fb, best_level, st);
+          s.rate_up[pos] = -lvl_rate + (int)rq_abs_level_bits(fb, best_level + 1, st);
+          s.rate_down[pos] = -lvl_rate + (int)rq_abs_level_bits(fb, best_level - 1, st);
         } else {
-          s.rate_up[pos] = (int)rq_bits(c1_ctx, 0);
+          s.rate_up[pos] = (int)fb.c1_0;
           s.rate_down[pos] = 0;
         }
         {  // UpdateCodeState (rdo_quant.cc:880-898); golomb_rice_k is re-derived
@@ -393,7 +437,7 @@ __device__ __forceinline__ int wave_rdoq(RdoqShared<N> &s, int lane, int bd, int
       unsigned bits_to_zero = 0;
       bool zero_sb = false;
       if (!(sb_index == 0 || sb_index + sb_size > last_pos_index)) {
-        const unsigned z_bits = rq_bits(csbf_ctx, 0), c_bits = rq_bits(csbf_ctx, 1);
+        const unsigned z_bits = cb[csbf_ctx], c_bits = cb[csbf_ctx + 1];
         const long long zero_cost = sb_zero_dist + rq_bit_cost(z_bits, lambda);
         if (any) {
           const long long code_cost = sb_code_cost + rq_bit_cost(c_bits, lambda);
@@ -431,7 +475,7 @@ __device__ __forceinline__ int wave_rdoq(RdoqShared<N> &s, int lane, int bd, int
   // sub-blocks outside the region (64-point transforms): all zero, never the
   // last one, no coded neighbour to the right / below: the cost of a zero flag
   // each (EvalZeroSubblock's csbf == 0 branch)
-  const unsigned outside_bits = rq_bits(ctx.csbf[luma ? 0 : 1][0], 0);
+  const unsigned outside_bits = cb[2 * (RQ_OFF(csbf) + (luma ? 0 : 2))];
   if (gw * gh > rgw * rgh) {
     int n_out = 0;
     for (int t = lane; t < gw * gh; t += G) {
@@ -446,9 +490,10 @@ __device__ __forceinline__ int wave_rdoq(RdoqShared<N> &s, int lane, int bd, int
   // ---- EvalLastPos (rdo_quant.cc:762-832): lane 0, result broadcast
   int new_last = 0;
   if (lane == 0) {
-    const unsigned char cbf_ctx =
-        !luma ? ctx.cbf_chroma : ((prm.flags & XVC_RDOQ_INTRA_CU) ? ctx.cbf_luma : ctx.root_cbf);
-    long long code_cost = comp_code_cost + rq_bit_cost(rq_bits(cbf_ctx, 1), lambda);
+    const int cbf_ctx = 2 * (!luma ? RQ_OFF(cbf_chroma)
+                                   : ((prm.flags & XVC_RDOQ_INTRA_CU) ? RQ_OFF(cbf_luma)
+                                                                      : RQ_OFF(root_cbf)));
+    long long code_cost = comp_code_cost + rq_bit_cost(cb[cbf_ctx + 1], lambda);
     int start = last_pos_index & (sb_size - 1);
     long long best_cost = 0x7fffffffffffffffll;
     int best_last_plus1 = 0;
@@ -473,7 +518,7 @@ __device__ __forceinline__ int wave_rdoq(RdoqShared<N> &s, int lane, int bd, int
           code_cost += s.cost_to_zero[pos];
           continue;
         }
-        const unsigned lp_bits = rq_last_pos_bits(ctx, luma, w, h, scan_order, x, y);
+        const unsigned lp_bits = rq_last_pos_bits(cb, luma, w, h, scan_order, x, y);
         const long long cost =
             code_cost + rq_bit_cost(lp_bits, lambda) - rq_bit_cost(s.sig_bits[pos], lambda);
         if (cost < best_cost) {
@@ -488,7 +533,7 @@ __device__ __forceinline__ int wave_rdoq(RdoqShared<N> &s, int lane, int bd, int
       }
       start = sb_size - 1;
     }
-    const long long comp_zero_cost = comp_zero_dist + rq_bit_cost(rq_bits(cbf_ctx, 0), lambda);
+    const long long comp_zero_cost = comp_zero_dist + rq_bit_cost(cb[cbf_ctx], lambda);
     new_last = comp_zero_cost < best_cost ? -1 : best_last_plus1;
   }
   new_last = __shfl(new_last, (int)(ME2_LANE & ~(G - 1)), 64);
@@ -578,44 +623,155 @@ __device__ __forceinline__ int wave_rdoq(RdoqShared<N> &s, int lane, int bd, int
   return nnz + rq_wave_sum_i32<G>(dn);
 }
 
-// The quantiser alone, for flows that hold the transform coefficients
-// (xvcgpu_fwd_transform_batch -> here -> xvcgpu_inv_transform_batch): one wave
-// per block; coefficients / levels as w*h int16 row-major at d_off[i].
-// grid: n; block: 64.
-__global__ void __launch_bounds__(64)
-quant_rdo_kernel(int bd, const xvcgpu_tx_block *blocks, int n, const int16_t *coeffs,
-                 const uint32_t *d_off, int16_t *levels, int32_t *nnz_out,
-                 const xvcgpu_rdoq_contexts *rq_ctx, const xvcgpu_rdoq_params *rq_prm) {
-  __shared__ RdoqShared<1024> rq;
-  __shared__ int16_t cf[32 * 32], lv[32 * 32];
-  const int bi = blockIdx.x;
-  if (bi >= n) return;
-  const xvcgpu_tx_block b = blocks[bi];
+// ---- the quantiser alone, packed ------------------------------------------------
+// For flows that hold the transform coefficients (xvcgpu_fwd_transform_batch ->
+// here -> xvcgpu_inv_transform_batch).  A block keeps <= 4 lanes of a wave busy
+// per wavefront step, so one block per wave wastes the machine: 0.86 ms per
+// 1080p picture.  Here G lanes take a block, G = its sub-block count rounded up
+// to 4 / 16 / 64: a wave runs 16 blocks of up to 8x8, 4 blocks of up to 16x16 or
+// one larger block, every block on its own wavefront.  A classification pass
+// sorts the block indices into the three lists; the per-coefficient scratch
+// (26 bytes each, written once, read by the short tail phases) lives in global
+// memory, what the serial walk reads - coefficients, levels, context costs - in
+// LDS.
+struct RdoqLists {
+  int *list[3];   // block indices per class (4 / 16 / 64 lanes)
+  int *count;     // [3]
+};
+
+__device__ __forceinline__ int rq_class_of(const xvcgpu_tx_block &b) {
+  const int sbs = (b.w == 2 || b.h == 2) ? 1 : 2;
+  const int rw = b.w < 32 ? b.w : 32, rh = b.h < 32 ? b.h : 32;
+  const int n_sb = (rw >> sbs) * (rh >> sbs);
+  return n_sb <= 4 ? 0 : (n_sb <= 16 ? 1 : 2);
+}
+
+// grid: ceil(n / 256); block 256.  counts must be zero on entry.  One atomic per
+// wave and class (same-address atomics serialise: one per block took 186 us for
+// the 24480 blocks of a 1080p picture).
+__global__ void __launch_bounds__(256)
+rdoq_classify_kernel(const xvcgpu_tx_block *blocks, int n, RdoqLists l) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const int c = i < n ? rq_class_of(blocks[i]) : -1;
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    const unsigned long long m = __ballot(c == k);
+    if (!m) continue;  // uniform
+    int base = 0;
+    if (lane == 0) base = atomicAdd(&l.count[k], __popcll(m));
+    base = __shfl(base, 0, 64);
+    if (c == k) l.list[k][base + __popcll(m & ((1ull << lane) - 1ull))] = i;
+  }
+}
+
+struct RdoqGlobalScratch {  // total = number of coefficients of the batch
+  long long *cost_to_zero;
+  unsigned *sig_bits;
+  int *sig_rate, *rate_up, *rate_down;
+  short *err_dist;
+};
+
+// LDS of one wave of class G, carved from one buffer so that the three classes
+// can share a launch.
+template <int G>
+struct RdoqPackedLds {
+  static constexpr int GROUPS = 64 / G;
+  static constexpr int MAXC = G == 4 ? 64 : (G == 16 ? 256 : 1024);  // region coefficients
+  static constexpr int MAXSB = G;                                      // region sub-blocks
+  alignas(8) long long sb_code_cost[GROUPS][MAXSB];
+  long long sb_zero_dist[GROUPS][MAXSB];
+  alignas(8) unsigned ctx_bits[GROUPS][2 * sizeof(xvcgpu_rdoq_contexts)];
+  unsigned csbf_bits[GROUPS][MAXSB];
+  int16_t cf[GROUPS][MAXC], lv[GROUPS][MAXC];
+  unsigned char csbf[GROUPS][MAXSB];
+  unsigned char sb_of_scan[GROUPS][G == 64 ? 256 : MAXSB * 4];
+};
+
+// G lanes per block; `wave`: index of this wave inside its class.
+template <int G>
+__device__ __forceinline__ void quant_rdo_packed_body(
+    RdoqPackedLds<G> &sm, int wave, int bd, const xvcgpu_tx_block *blocks, const int *list,
+    const int *count, const int16_t *coeffs, const uint32_t *d_off, int16_t *levels,
+    int32_t *nnz_out, const xvcgpu_rdoq_contexts *rq_ctx, const xvcgpu_rdoq_params *rq_prm,
+    const RdoqGlobalScratch &gs) {
+  constexpr int GROUPS = 64 / G;
+  const int g = threadIdx.x / G, lane = threadIdx.x % G;
+  const int slot = wave * GROUPS + g;
+  const int n_list = *count;
+  if (wave * GROUPS >= n_list) return;  // the launch is an upper bound
+  const bool active = slot < n_list;
+  // the groups of a wave walk independently (their shuffles stay inside the
+  // group); an unused group takes a 4x4 block of zeros, which ends at the first
+  // reduction
+  const int bi = active ? list[slot] : 0;
+  xvcgpu_tx_block b = blocks[bi];
+  if (!active) b.w = b.h = 4;
   const xvcgpu_rdoq_params prm = rq_prm[bi];
-  const int w = b.w, h = b.h, lane = threadIdx.x;
+  const int w = b.w, h = b.h;
   const int rw = w < 32 ? w : 32, rh = h < 32 ? h : 32;
-  const int16_t *src = coeffs + d_off[bi];
-  int16_t *dst = levels + d_off[bi];
-  for (int i = lane; i < rw * rh; i += 64) {
+  const uint32_t off = d_off[bi];
+  const int16_t *src = coeffs + off;
+  int16_t *cf = sm.cf[g], *lv = sm.lv[g];
+  for (int i = lane; i < rw * rh; i += G) {
     const int y = i / rw, x = i - y * rw;
-    cf[i] = src[y * w + x];
+    cf[i] = active ? src[y * w + x] : (int16_t)0;
     lv[i] = 0;
   }
+  RdoqView v;
+  v.cost_to_zero = gs.cost_to_zero + off;
+  v.sig_bits = gs.sig_bits + off;
+  v.sig_rate = gs.sig_rate + off;
+  v.rate_up = gs.rate_up + off;
+  v.rate_down = gs.rate_down + off;
+  v.err_dist = gs.err_dist + off;
+  v.sb_code_cost = sm.sb_code_cost[g];
+  v.sb_zero_dist = sm.sb_zero_dist[g];
+  v.csbf_bits = sm.csbf_bits[g];
+  v.csbf = sm.csbf[g];
+  v.sb_of_scan = sm.sb_of_scan[g];
+  v.ctx_bits = sm.ctx_bits[g];
   wave_sync();
   const bool sign_hide = !(b.intra_pic & XVC_TXF_NO_SIGN_HIDING);
   const int scan_order = (b.intra_pic >> XVC_TXF_SCAN_SHIFT) & 3;
-  const int16_t *cfp = cf;
-  int16_t *lvp = lv;
-  const int nnz = wave_rdoq<1024>(
-      rq, lane, bd, w, h, b.qp, b.comp == 0, scan_order, sign_hide, rq_ctx[prm.ctx_index], prm,
-      [cfp, rw](int x, int y) { return (int)cfp[y * rw + x]; },
-      [lvp, rw](int x, int y) { return lvp + y * rw + x; });
+  const int nnz = wave_rdoq<G>(
+      v, lane, bd, w, h, b.qp, b.comp == 0, scan_order, sign_hide, rq_ctx[prm.ctx_index], prm,
+      [cf, rw](int x, int y) { return (int)cf[y * rw + x]; },
+      [lv, rw](int x, int y) { return lv + y * rw + x; });
   wave_sync();
-  for (int i = lane; i < w * h; i += 64) {
+  if (!active) return;
+  int16_t *dst = levels + off;
+  for (int i = lane; i < w * h; i += G) {
     const int y = i / w, x = i - y * w;
     dst[i] = (x < rw && y < rh) ? lv[y * rw + x] : (int16_t)0;
   }
   if (lane == 0 && nnz_out) nnz_out[bi] = nnz;
+}
+
+// One launch for the three classes (they are independent: side by side the
+// batch lasts as long as its slowest class instead of the sum).  grid: nb0 + nb1
+// + nb2 waves (upper bounds ceil(n/16), ceil(n/4), n); block: 64.
+__global__ void __launch_bounds__(64)
+quant_rdo_packed_kernel(int bd, const xvcgpu_tx_block *blocks, RdoqLists l, int nb0, int nb1,
+                        const int16_t *coeffs, const uint32_t *d_off, int16_t *levels,
+                        int32_t *nnz_out, const xvcgpu_rdoq_contexts *rq_ctx,
+                        const xvcgpu_rdoq_params *rq_prm, RdoqGlobalScratch gs) {
+  __shared__ union {
+    RdoqPackedLds<4> a;
+    RdoqPackedLds<16> b;
+    RdoqPackedLds<64> c;
+  } sm;
+  const int wv = blockIdx.x;
+  // the long walks first: the large blocks, then the 16-lane class
+  if (wv < nb1)
+    quant_rdo_packed_body<16>(sm.b, wv, bd, blocks, l.list[1], l.count + 1, coeffs, d_off, levels,
+                              nnz_out, rq_ctx, rq_prm, gs);
+  else if (wv < nb1 + nb0)
+    quant_rdo_packed_body<4>(sm.a, wv - nb1, bd, blocks, l.list[0], l.count + 0, coeffs, d_off,
+                             levels, nnz_out, rq_ctx, rq_prm, gs);
+  else
+    quant_rdo_packed_body<64>(sm.c, wv - nb1 - nb0, bd, blocks, l.list[2], l.count + 2, coeffs,
+                              d_off, levels, nnz_out, rq_ctx, rq_prm, gs);
 }
 
 #endif  // XVCGPU_K_RDOQ_H_

@@ -306,7 +306,7 @@ __device__ __forceinline__ void residual_job(TxShared &s, int bi, const PicView 
         const xvcgpu_rdoq_params prm = rq_prm[bi];
         const int16_t *cfp = s.a;
         int16_t *lvp = s.b;
-        const int n_rq = wave_rdoq<RQN>(
+        const int n_rq = wave_rdoq<64>(
             *rq, (int)threadIdx.x, bd, w, h, b.qp, b.comp == 0, scan_order, sign_hide,
             rq_ctx[prm.ctx_index], prm, [cfp](int x, int y) { return (int)cfp[y * TX_S + x]; },
             [lvp](int x, int y) { return lvp + y * TX_S + x; });

@@ -213,7 +213,7 @@ __device__ __forceinline__ int tx2_job(Tx2Shared &sh, const xvcgpu_tx_block &b, 
       const xvcgpu_rdoq_params prm = rq_prm[bi];
       const int16_t *cfp = s.c;
       int16_t *lvp = s.r;
-      nnz = wave_rdoq<(G == 32 ? 64 : 256), G>(
+      nnz = wave_rdoq<G>(
           *rq, lane, bd, w, h, b.qp, b.comp == 0, scan_order, sign_hide, rq_ctx[prm.ctx_index],
           prm, [cfp, h](int x, int y) { return (int)cfp[x * h + y]; },
           [lvp, h](int x, int y) { return lvp + x * h + y; });

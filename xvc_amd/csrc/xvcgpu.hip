@@ -162,6 +162,10 @@ xvcgpu_status xvcgpu_create(int device, xvcgpu_ctx **out) {
   ctx->ssd_part_cap = 0;
   ctx->d_stats = nullptr;
   ctx->stats_rows_cap = 0;
+  ctx->d_rdoq_lists = nullptr;
+  ctx->rdoq_lists_cap = 0;
+  ctx->d_rdoq_scratch = nullptr;
+  ctx->rdoq_scratch_cap = 0;
   ctx->d_crc_tables = nullptr;
   for (int i = 0; i < 64; i++) ctx->ev_pool[i] = nullptr;
   ctx->d_me_rot = nullptr;
@@ -214,6 +218,8 @@ void xvcgpu_destroy(xvcgpu_ctx *ctx) {
   if (ctx->d_tz_pattern) hipFree(ctx->d_tz_pattern);
   if (ctx->d_ssd_part) hipFree(ctx->d_ssd_part);
   if (ctx->d_stats) hipFree(ctx->d_stats);
+  if (ctx->d_rdoq_lists) hipFree(ctx->d_rdoq_lists);
+  if (ctx->d_rdoq_scratch) hipFree(ctx->d_rdoq_scratch);
   if (ctx->d_crc_tables) hipFree(ctx->d_crc_tables);
   if (ctx->d_me_rot) hipFree(ctx->d_me_rot);
   hipEventDestroy(ctx->ev0);
@@ -878,15 +884,63 @@ xvcgpu_status xvcgpu_residual_rdoq_batch(xvcgpu_ctx *ctx, const xvcgpu_picture *
 xvcgpu_status xvcgpu_quant_rdo_batch(xvcgpu_ctx *ctx, int bitdepth,
                                      const xvcgpu_tx_block *d_blocks, int n,
                                      const int16_t *d_coeffs, const uint32_t *d_offsets,
-                                     int16_t *d_levels, int32_t *d_nnz,
+                                     size_t n_coeffs, int16_t *d_levels, int32_t *d_nnz,
                                      const xvcgpu_rdoq_contexts *d_contexts,
                                      const xvcgpu_rdoq_params *d_params) {
   if (!ctx || n < 0 || bitdepth < 8 || bitdepth > 12 ||
-      (n && (!d_blocks || !d_coeffs || !d_offsets || !d_levels || !d_contexts || !d_params)))
+      (n && (!d_blocks || !d_coeffs || !d_offsets || !d_levels || !d_contexts || !d_params ||
+             !n_coeffs)))
     return XVCGPU_INVALID_ARGUMENT;
   if (n == 0) return XVCGPU_OK;
-  hipLaunchKernelGGL(quant_rdo_kernel, dim3(n), dim3(64), 0, ctx->stream, bitdepth, d_blocks, n,
-                     d_coeffs, d_offsets, d_levels, d_nnz, d_contexts, d_params);
+  // scratch: class lists (3 x n) + counters; 26 bytes per coefficient
+  if (n > ctx->rdoq_lists_cap) {
+    if (ctx->d_rdoq_lists) {
+      hipStreamSynchronize(ctx->stream);
+      hipFree(ctx->d_rdoq_lists);
+      ctx->d_rdoq_lists = nullptr;
+      ctx->rdoq_lists_cap = 0;
+    }
+    const int cap = n + n / 4;
+    if (hipMalloc(&ctx->d_rdoq_lists, sizeof(int) * (3 * (size_t)cap + 4)) != hipSuccess)
+      return fail(ctx, XVCGPU_OUT_OF_MEMORY, "rdoq lists");
+    ctx->rdoq_lists_cap = cap;
+  }
+  if (n_coeffs > ctx->rdoq_scratch_cap) {
+    if (ctx->d_rdoq_scratch) {
+      hipStreamSynchronize(ctx->stream);
+      hipFree(ctx->d_rdoq_scratch);
+      ctx->d_rdoq_scratch = nullptr;
+      ctx->rdoq_scratch_cap = 0;
+    }
+    const size_t cap = n_coeffs + n_coeffs / 4 + 64;
+    if (hipMalloc(&ctx->d_rdoq_scratch, 26 * cap) != hipSuccess)
+      return fail(ctx, XVCGPU_OUT_OF_MEMORY, "rdoq scratch");
+    ctx->rdoq_scratch_cap = cap;
+  }
+  const int cap = ctx->rdoq_lists_cap;
+  RdoqLists l;
+  l.count = ctx->d_rdoq_lists;
+  for (int c = 0; c < 3; c++) l.list[c] = ctx->d_rdoq_lists + 4 + (size_t)c * cap;
+  RdoqGlobalScratch gs;
+  {
+    const size_t m = ctx->rdoq_scratch_cap;
+    char *p = static_cast<char *>(ctx->d_rdoq_scratch);
+    gs.cost_to_zero = reinterpret_cast<long long *>(p);
+    gs.sig_bits = reinterpret_cast<unsigned *>(p + 8 * m);
+    gs.sig_rate = reinterpret_cast<int *>(p + 12 * m);
+    gs.rate_up = reinterpret_cast<int *>(p + 16 * m);
+    gs.rate_down = reinterpret_cast<int *>(p + 20 * m);
+    gs.err_dist = reinterpret_cast<short *>(p + 24 * m);
+  }
+  HIP_TRY(ctx, hipMemsetAsync(l.count, 0, 4 * sizeof(int), ctx->stream));
+  hipLaunchKernelGGL(rdoq_classify_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream,
+                     d_blocks, n, l);
+  // the class sizes are only known on the device: launch the upper bounds, waves
+  // beyond a list's count retire at once
+  const int nb0 = (n + 15) / 16, nb1 = (n + 3) / 4;
+  hipLaunchKernelGGL(quant_rdo_packed_kernel, dim3(nb0 + nb1 + n), dim3(64), 0, ctx->stream,
+                     bitdepth, d_blocks, l, nb0, nb1, d_coeffs, d_offsets, d_levels, d_nnz,
+                     d_contexts, d_params, gs);
   CHECK_LAUNCH(ctx, "quant_rdo_batch");
   return XVCGPU_OK;
 }

@@ -51,6 +51,12 @@ struct xvcgpu_ctx {
   uint32_t *d_stats;
   int stats_rows_cap;
   struct CrcTables *d_crc_tables;  // [0]: 8-bit samples, [1]: wider; built on first use
+  // scratch of xvcgpu_quant_rdo_batch (k_rdoq.h): the three class lists + their
+  // counters, and 26 bytes per coefficient of the batch
+  int *d_rdoq_lists;
+  int rdoq_lists_cap;      // in blocks
+  void *d_rdoq_scratch;
+  size_t rdoq_scratch_cap; // in coefficients
 };
 
 struct xvcgpu_picture {

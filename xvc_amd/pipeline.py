@@ -166,12 +166,20 @@ class FramePass:
 
     def __init__(self, ctx, width, height, bitdepth=10, qp=32, cu=16,
                  search_range=96, row_range=None, fused=True, keep_levels=False,
-                 rdoq=False):
+                 rdoq=False, rdoq_packed=None):
         self.ctx = ctx
         self.rdoq = rdoq
+        # RDOQ keeps only a few lanes of a wave busy per block, so its own kernel
+        # packs several blocks into a wave (xvcgpu_quant_rdo_batch) between the
+        # forward and the inverse half of the residual pipeline: 5 launches instead
+        # of the one fused launch, an order of magnitude less time
+        self.rdoq_packed = rdoq and (fused if rdoq_packed is None else rdoq_packed)
+        if self.rdoq_packed:
+            keep_levels = True
         # keep_levels: also store the quantised coefficients of every TU (what
         # the entropy coder - or DecodePass - consumes); needs the unfused path
-        self.fused = fused and width % 8 == 0 and height % 8 == 0 and not keep_levels
+        self.fused = fused and width % 8 == 0 and height % 8 == 0 and not keep_levels \
+            and not self.rdoq_packed
         self.w, self.h, self.bd = width, height, bitdepth
         self.desc = d = FrameDescriptors(width, height, qp, cu, search_range,
                                          row_range, rdoq, bitdepth)
@@ -189,11 +197,13 @@ class FramePass:
         self.d_ssd = ctx.alloc(16)
         self.pred = ctx.picture(width, height, bitdepth)
         self.d_levels = self.d_level_off = None
+        self.n_levels = 0
         if keep_levels:
             off, total = ctx.level_offsets(d.tx)
             self.d_level_off = ctx.buffer(off)
             self.d_levels = ctx.alloc(2 * max(1, total))
             self.n_levels = total
+        self.d_coeffs = ctx.alloc(2 * max(1, self.n_levels)) if self.rdoq_packed else None
 
     @property
     def d_cus_own(self):
@@ -255,7 +265,19 @@ class FramePass:
                                       d.qp, d.qp_c, ref_poc, self.d_nnz.ptr, self.d_cus_own)
             return
         ctx.mc_from_me_dev(ref, self.pred, self.d_me.ptr, self.d_res.ptr, n)
-        if self.rdoq:
+        if self.rdoq_packed:
+            lib, T = ctx.lib, len(d.tx)
+            ctx._check(lib.xvcgpu_fwd_transform_batch(
+                ctx.h, orig.h_pic, self.pred.h_pic, self.d_tx.ptr, T, self.d_coeffs.ptr,
+                self.d_level_off.ptr))
+            ctx._check(lib.xvcgpu_quant_rdo_batch(
+                ctx.h, self.bd, self.d_tx.ptr, T, self.d_coeffs.ptr, self.d_level_off.ptr,
+                self.n_levels, self.d_levels.ptr, self.d_nnz.ptr, self.d_rdoq_ctx.ptr,
+                self.d_rdoq_prm.ptr))
+            ctx._check(lib.xvcgpu_inv_transform_batch(
+                ctx.h, self.pred.h_pic, rec.h_pic, self.d_tx.ptr, T, self.d_levels.ptr,
+                self.d_level_off.ptr, self.d_nnz.ptr))
+        elif self.rdoq:
             ctx.residual_rdoq_batch_dev(orig, self.pred, rec, self.d_tx.ptr, len(d.tx),
                                         self.d_levels.ptr if self.d_levels else None,
                                         self.d_level_off.ptr if self.d_level_off else None,
@@ -268,6 +290,56 @@ class FramePass:
         ctx.cu_info_from_me_dev(self.d_me.ptr, self.d_res.ptr, self.d_nnz.ptr,
                                 self.d_luma_idx.ptr, n, d.qp, d.qp_c, ref_poc,
                                 self.d_cus_own)
+
+    def kernel_steps(self, orig, ref, rec, ref_poc=0):
+        """The launches of one frame pass as (name, callable) in issue order - for
+        per-kernel timing (bench.py); run in order they are a frame pass."""
+        ctx, d, lib = self.ctx, self.desc, self.ctx.lib
+        n, T = d.n_cus, len(d.tx)
+        steps = [("me_search", lambda: ctx.me_search_dev(
+            orig, ref, api.ME_FULLPEL | api.ME_SUBPEL, self.d_me.ptr, n, self.d_res.ptr,
+            d.cu_size))]
+        if self.fused and d.cu_size <= 16:
+            if self.rdoq:
+                steps.append(("recon_from_me", lambda: ctx.recon_from_me_rdoq_dev(
+                    orig, ref, rec, self.d_me.ptr, self.d_res.ptr, n, d.qp, d.qp_c, ref_poc,
+                    self.d_nnz.ptr, self.d_cus_own, self.d_rdoq_ctx.ptr, self.d_rdoq_prm.ptr)))
+            else:
+                steps.append(("recon_from_me", lambda: ctx.recon_from_me_dev(
+                    orig, ref, rec, self.d_me.ptr, self.d_res.ptr, n, d.qp, d.qp_c, ref_poc,
+                    self.d_nnz.ptr, self.d_cus_own)))
+        else:
+            steps.append(("mc_from_me", lambda: ctx.mc_from_me_dev(
+                ref, self.pred, self.d_me.ptr, self.d_res.ptr, n)))
+            lv = self.d_levels.ptr if self.d_levels else None
+            lo = self.d_level_off.ptr if self.d_level_off else None
+            if self.rdoq_packed:
+                steps += [
+                    ("fwd_transform", lambda: ctx._check(lib.xvcgpu_fwd_transform_batch(
+                        ctx.h, orig.h_pic, self.pred.h_pic, self.d_tx.ptr, T,
+                        self.d_coeffs.ptr, lo))),
+                    ("quant_rdo", lambda: ctx._check(lib.xvcgpu_quant_rdo_batch(
+                        ctx.h, self.bd, self.d_tx.ptr, T, self.d_coeffs.ptr, lo, self.n_levels,
+                        lv, self.d_nnz.ptr, self.d_rdoq_ctx.ptr, self.d_rdoq_prm.ptr))),
+                    ("inv_transform", lambda: ctx._check(lib.xvcgpu_inv_transform_batch(
+                        ctx.h, self.pred.h_pic, rec.h_pic, self.d_tx.ptr, T, lv, lo,
+                        self.d_nnz.ptr)))]
+            elif self.rdoq:
+                steps.append(("residual_rdoq", lambda: ctx.residual_rdoq_batch_dev(
+                    orig, self.pred, rec, self.d_tx.ptr, T, lv, lo, self.d_nnz.ptr,
+                    self.d_rdoq_ctx.ptr, self.d_rdoq_prm.ptr)))
+            else:
+                steps.append(("residual", lambda: ctx.residual_batch_dev(
+                    orig, self.pred, rec, self.d_tx.ptr, T, lv, lo, self.d_nnz.ptr)))
+            steps.append(("cu_info", lambda: ctx.cu_info_from_me_dev(
+                self.d_me.ptr, self.d_res.ptr, self.d_nnz.ptr, self.d_luma_idx.ptr, n, d.qp,
+                d.qp_c, ref_poc, self.d_cus_own)))
+        steps += [
+            ("deblock", lambda: ctx.deblock_dev(rec, self.d_cus.ptr, d.n_cus_total,
+                                                self.d_map.ptr, d.cu_map.shape[1], 0, 0, 0, 4)),
+            ("pad_border", lambda: ctx.pad_border(rec)),
+            ("picture_ssd", lambda: ctx.picture_ssd_dev(orig, rec, 0, self.bd, self.d_ssd.ptr))]
+        return steps
 
     def deblock_rows(self, rec, pass_, y0, y1):
         d = self.desc
@@ -302,7 +374,7 @@ class FramePass:
     def destroy(self):
         for b in (self.d_me, self.d_tx, self.d_luma_idx, self.d_map, self.d_res,
                   self.d_nnz, self.d_cus, self.d_ssd, self.d_levels, self.d_level_off,
-                  self.d_rdoq_ctx, self.d_rdoq_prm):
+                  self.d_rdoq_ctx, self.d_rdoq_prm, self.d_coeffs):
             if b is not None:
                 b.free()
         self.pred.destroy()
