@@ -309,7 +309,7 @@ def main():
     # reconstructions and job buffers; the originals are shared, each chain
     # starts at another phase of the frame cycle) ----
     auto_chains = 3 if W * H // world <= 3840 * 2160 else 1
-    n_chains = 1 if (pipelined or args.graph) else (args.chains or auto_chains)
+    n_chains = 1 if pipelined else (args.chains or auto_chains)
     extra = []          # (ctx, runner-or-None, frame pass, recs, phase, torch stream)
     F = len(origs)
     cycle_len = 2 * F - 2 if F > 1 else 1
@@ -349,6 +349,15 @@ def main():
                 if crun is not None:
                     with torch.cuda.stream(ts):
                         crun.run(o, j % 2, (j + 1) % 2, ref_poc=j)
+                elif args.graph:
+                    kk = (j + phase) % cycle_len
+                    key = (c, kk, j % 2)
+                    if key not in recordings:
+                        ref_c, rec_c = crecs[j % 2], crecs[(j + 1) % 2]
+                        recordings[key] = cctx.record(
+                            lambda: cfp.run(o, ref_c, rec_c, ref_poc=kk))
+                    if not record_only:
+                        cctx.replay(recordings[key])
                 else:
                     cfp.run(o, crecs[j % 2], crecs[(j + 1) % 2], ref_poc=j)
                 return
@@ -368,7 +377,7 @@ def main():
             # one frame pass = one HIP graph launch: the sequence of launches
             # for (this original, this ping-pong parity) is recorded once,
             # before the warmup, and replayed (all kernels run every step)
-            key = (k, i % 2)
+            key = (0, k, i % 2)
             if key not in recordings:
                 recordings[key] = ctx.record(lambda: fp.run(o, ref, rec, ref_poc=k))
             if not record_only:
@@ -387,7 +396,7 @@ def main():
             torch.cuda.synchronize()
 
     if runner is None and args.graph:
-        for i in range(2 * len(origs)):
+        for i in range(2 * cycle_len * n_chains):
             step(i, record_only=True)
     for i in range(args.warmup):
         step(i)

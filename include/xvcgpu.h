@@ -367,6 +367,11 @@ xvcgpu_status xvcgpu_quant_rdo_batch(xvcgpu_ctx *ctx, int bitdepth,
                                      const xvcgpu_rdoq_contexts *d_contexts,
                                      const xvcgpu_rdoq_params *d_params);
 
+/* Sizes the context's scratch for batches of up to n blocks / n_coeffs
+ * coefficients now, so that later xvcgpu_quant_rdo_batch calls never allocate
+ * (required before recording them, xvcgpu_record_begin). */
+xvcgpu_status xvcgpu_quant_rdo_reserve(xvcgpu_ctx *ctx, int n, size_t n_coeffs);
+
 /* I1 + the above fused, for the uni-pred inter CUs of a motion search batch
  * (InterSearch::CompressAndEvalCbf without the RD bookkeeping,
  * inter_search.cc:261-365): for CU i and each component, motion-compensate

@@ -308,6 +308,18 @@ typedef struct xvcgpu_frame_pass_args {
    * d_rdoq_params[3 * cu + comp] and the context snapshots they index */
   const struct xvcgpu_rdoq_contexts *d_rdoq_contexts;
   const struct xvcgpu_rdoq_params *d_rdoq_params;
+  /* RDOQ, throughput form (pred != NULL): the residual pipeline split around
+   * the packed quantiser - xvcgpu_mc_from_me -> xvcgpu_fwd_transform_batch ->
+   * xvcgpu_quant_rdo_batch -> xvcgpu_inv_transform_batch ->
+   * xvcgpu_cu_info_from_me - with these work buffers (3 transform blocks per
+   * own CU: Y, U, V; d_rdoq_params indexed like d_tx) */
+  struct xvcgpu_picture *pred;
+  const xvcgpu_tx_block *d_tx;
+  const uint32_t *d_level_off;
+  const int32_t *d_luma_tx_index;
+  int16_t *d_coeffs, *d_levels;
+  int32_t n_tx;
+  uint32_t n_coeffs;
 } xvcgpu_frame_pass_args;
 
 /* One job of xvcgpu_affine_me_batch: InterSearch::MotionEstAffine for one

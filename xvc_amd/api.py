@@ -112,7 +112,10 @@ class FramePassArgs(C.Structure):
                 ("db_y_end", C.c_int32), ("dbh_y_end", C.c_int32),
                 ("ssd_y_begin", C.c_int32), ("ssd_y_end", C.c_int32),
                 ("shift_bitdepth", C.c_int32), ("d_ssd", C.c_void_p),
-                ("d_rdoq_contexts", C.c_void_p), ("d_rdoq_params", C.c_void_p)]
+                ("d_rdoq_contexts", C.c_void_p), ("d_rdoq_params", C.c_void_p),
+                ("pred", C.c_void_p), ("d_tx", C.c_void_p), ("d_level_off", C.c_void_p),
+                ("d_luma_tx_index", C.c_void_p), ("d_coeffs", C.c_void_p),
+                ("d_levels", C.c_void_p), ("n_tx", C.c_int32), ("n_coeffs", C.c_uint32)]
 
 
 FP_ENCODE, FP_DEBLOCK_V, FP_DEBLOCK_H, FP_PAD, FP_SSD = 1, 2, 4, 8, 16
@@ -140,6 +143,7 @@ SYMBOLS = [
     "xvcgpu_intra_select_modes", "xvcgpu_frame_pass", "xvcgpu_copy_segments",
     "xvcgpu_get_transform_matrix", "xvcgpu_inter_pred_batch", "xvcgpu_deblock_tree",
     "xvcgpu_residual_rdoq_batch", "xvcgpu_quant_rdo_batch", "xvcgpu_recon_from_me_rdoq",
+    "xvcgpu_quant_rdo_reserve",
 ]
 
 _vp = C.c_void_p
@@ -250,6 +254,7 @@ def load_library():
         "xvcgpu_residual_rdoq_batch": [_vp, _vp, _vp, _vp, _vp, C.c_int, _vp, _vp, _vp, _vp, _vp],
         "xvcgpu_recon_from_me_rdoq": [_vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int,
                                       C.c_int, C.c_int, _vp, _vp, _vp, _vp],
+        "xvcgpu_quant_rdo_reserve": [_vp, C.c_int, C.c_size_t],
         "xvcgpu_quant_rdo_batch": [_vp, C.c_int, _vp, C.c_int, _vp, _vp, C.c_size_t, _vp, _vp,
                                    _vp, _vp],
         "xvcgpu_deblock_tree": [_vp, _vp, _vp, C.c_int, _vp, C.c_int, C.c_int, C.c_int,

@@ -635,8 +635,9 @@ __device__ __forceinline__ int wave_rdoq(S &s, int lane, int bd, int w, int h,
 // memory, what the serial walk reads - coefficients, levels, context costs - in
 // LDS.
 struct RdoqLists {
-  int *list[3];   // block indices per class (4 / 16 / 64 lanes)
-  int *count;     // [3]
+  int *list[3];       // block indices per class (4 / 16 / 64 lanes)
+  int *count;         // [3]
+  signed char *cls;   // per block: class, -1 = nothing to code
 };
 
 __device__ __forceinline__ int rq_class_of(const xvcgpu_tx_block &b) {
@@ -646,23 +647,83 @@ __device__ __forceinline__ int rq_class_of(const xvcgpu_tx_block &b) {
   return n_sb <= 4 ? 0 : (n_sb <= 16 ? 1 : 2);
 }
 
-// grid: ceil(n / 256); block 256.  counts must be zero on entry.  One atomic per
-// wave and class (same-address atomics serialise: one per block took 186 us for
-// the 24480 blocks of a 1080p picture).
+// Classification + the trivial case.  One wave per block: does any coefficient
+// quantise to a non-zero value at all (GetFwdQuantFunc, rdo_quant.cc:949-964)?
+// If not, QuantRdo returns 0 right after its scan (:387-390) - on real content
+// that is most blocks (1080p QP 32: 3 of 4 luma blocks, nearly every chroma
+// block): they get their zero levels and count here and never reach the serial
+// walk; the others are appended to their class list.  counts must be zero on
+// entry.  grid: ceil(n / 4); block: 256.
 __global__ void __launch_bounds__(256)
-rdoq_classify_kernel(const xvcgpu_tx_block *blocks, int n, RdoqLists l) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  const int c = i < n ? rq_class_of(blocks[i]) : -1;
+rdoq_classify_kernel(int bd, const xvcgpu_tx_block *blocks, int n, const int16_t *coeffs,
+                     const uint32_t *d_off, int16_t *levels, int32_t *nnz_out, RdoqLists l) {
+  const int bi = blockIdx.x * 4 + (int)(threadIdx.x >> 6);
+  if (bi >= n) return;
   const int lane = threadIdx.x & 63;
-#pragma unroll
-  for (int k = 0; k < 3; k++) {
-    const unsigned long long m = __ballot(c == k);
-    if (!m) continue;  // uniform
-    int base = 0;
-    if (lane == 0) base = atomicAdd(&l.count[k], __popcll(m));
-    base = __shfl(base, 0, 64);
-    if (c == k) l.list[k][base + __popcll(m & ((1ull << lane) - 1ull))] = i;
+  const xvcgpu_tx_block b = blocks[bi];
+  const int w = b.w, h = b.h;
+  const int lw = rq_log2(w), lh = rq_log2(h);
+  int qpb = b.qp + 6 * (bd - 8);
+  qpb = qpb > 0 ? qpb : 0;
+  const bool bias = ((lw + lh) & 1) != 0;
+  const int fq_shift = 14 + qpb / 6 + (15 - bd - ((lw + lh) >> 1)) + (bias ? 7 : 0);
+  const int scale = kFwdQuantScales[qpb % 6] * (bias ? 181 : 1);
+  const long long fq_offset = 1ll << (fq_shift - 1);
+  const int16_t *src = coeffs + d_off[bi];
+  int16_t *dst = levels + d_off[bi];
+  bool any = false;
+  for (int i = lane; i < w * h; i += 64) {
+    const int a = (short)d_abs((int)src[i]);
+    any |= (short)(int)((((long long)a * scale) + fq_offset) >> fq_shift) != 0;
   }
+  if (__ballot(any)) {
+    if (lane == 0) l.cls[bi] = (signed char)rq_class_of(b);
+    return;
+  }
+  if (lane == 0) l.cls[bi] = -1;
+  for (int i = lane; i < w * h; i += 64) dst[i] = 0;
+  if (lane == 0 && nnz_out) nnz_out[bi] = 0;
+}
+
+// The class lists from the per-block classes, without atomics (a few thousand
+// atomicAdds on three addresses took 150 us): one workgroup, every thread
+// counts its contiguous chunk, an LDS scan gives the chunk's place in each list.
+// grid: 1; block: 1024.
+__global__ void __launch_bounds__(1024)
+rdoq_compact_kernel(int n, RdoqLists l) {
+  __shared__ int part[3][1024];
+  const int t = threadIdx.x;
+  const int per = (n + 1023) / 1024;
+  const int a = t * per, e = a + per < n ? a + per : n;
+  int cnt[3] = {0, 0, 0};
+  for (int i = a; i < e; i++) {
+    const int c = l.cls[i];
+    cnt[0] += c == 0;
+    cnt[1] += c == 1;
+    cnt[2] += c == 2;
+  }
+#pragma unroll
+  for (int k = 0; k < 3; k++) part[k][t] = cnt[k];
+  __syncthreads();
+  // inclusive Hillis-Steele scan over the 1024 partial counts, three at once
+  for (int d = 1; d < 1024; d <<= 1) {
+    int v[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) v[k] = t >= d ? part[k][t - d] : 0;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 3; k++) part[k][t] += v[k];
+    __syncthreads();
+  }
+  int pos[3];
+#pragma unroll
+  for (int k = 0; k < 3; k++) pos[k] = part[k][t] - cnt[k];
+  for (int i = a; i < e; i++) {
+    const int c = l.cls[i];
+    if (c >= 0) l.list[c][pos[c]++] = i;
+  }
+  if (t == 1023)
+    for (int k = 0; k < 3; k++) l.count[k] = part[k][1023];
 }
 
 struct RdoqGlobalScratch {  // total = number of coefficients of the batch
@@ -672,8 +733,11 @@ struct RdoqGlobalScratch {  // total = number of coefficients of the batch
   short *err_dist;
 };
 
-// LDS of one wave of class G, carved from one buffer so that the three classes
-// can share a launch.
+// LDS of one wave of class G.  One table of context costs per wave: the groups
+// of a wave nearly always name the same snapshot; when they do not, the wave
+// serves one snapshot after the other (a table per group cost 19 KB of LDS per
+// wave in the 4-lane class - enough, with the walk's long-lived waves, to keep
+// other kernels off the CUs).
 template <int G>
 struct RdoqPackedLds {
   static constexpr int GROUPS = 64 / G;
@@ -681,43 +745,43 @@ struct RdoqPackedLds {
   static constexpr int MAXSB = G;                                      // region sub-blocks
   alignas(8) long long sb_code_cost[GROUPS][MAXSB];
   long long sb_zero_dist[GROUPS][MAXSB];
-  alignas(8) unsigned ctx_bits[GROUPS][2 * sizeof(xvcgpu_rdoq_contexts)];
+  alignas(8) unsigned ctx_bits[2 * sizeof(xvcgpu_rdoq_contexts)];
   unsigned csbf_bits[GROUPS][MAXSB];
   int16_t cf[GROUPS][MAXC], lv[GROUPS][MAXC];
   unsigned char csbf[GROUPS][MAXSB];
   unsigned char sb_of_scan[GROUPS][G == 64 ? 256 : MAXSB * 4];
 };
 
-// G lanes per block; `wave`: index of this wave inside its class.
+// G lanes per block; grid: an upper bound on ceil(count / (64 / G)) waves (the
+// list's count is read on the device); block: 64.
 template <int G>
-__device__ __forceinline__ void quant_rdo_packed_body(
-    RdoqPackedLds<G> &sm, int wave, int bd, const xvcgpu_tx_block *blocks, const int *list,
-    const int *count, const int16_t *coeffs, const uint32_t *d_off, int16_t *levels,
-    int32_t *nnz_out, const xvcgpu_rdoq_contexts *rq_ctx, const xvcgpu_rdoq_params *rq_prm,
-    const RdoqGlobalScratch &gs) {
+__global__ void __launch_bounds__(64)
+quant_rdo_packed_kernel(int bd, const xvcgpu_tx_block *blocks, const int *list,
+                        const int *count, const int16_t *coeffs, const uint32_t *d_off,
+                        int16_t *levels, int32_t *nnz_out, const xvcgpu_rdoq_contexts *rq_ctx,
+                        const xvcgpu_rdoq_params *rq_prm, RdoqGlobalScratch gs) {
   constexpr int GROUPS = 64 / G;
+  __shared__ RdoqPackedLds<G> sm;
+  const int wave = blockIdx.x;
   const int g = threadIdx.x / G, lane = threadIdx.x % G;
   const int slot = wave * GROUPS + g;
   const int n_list = *count;
   if (wave * GROUPS >= n_list) return;  // the launch is an upper bound
   const bool active = slot < n_list;
-  // the groups of a wave walk independently (their shuffles stay inside the
-  // group); an unused group takes a 4x4 block of zeros, which ends at the first
-  // reduction
   const int bi = active ? list[slot] : 0;
-  xvcgpu_tx_block b = blocks[bi];
-  if (!active) b.w = b.h = 4;
+  const xvcgpu_tx_block b = blocks[bi];
   const xvcgpu_rdoq_params prm = rq_prm[bi];
   const int w = b.w, h = b.h;
   const int rw = w < 32 ? w : 32, rh = h < 32 ? h : 32;
   const uint32_t off = d_off[bi];
   const int16_t *src = coeffs + off;
   int16_t *cf = sm.cf[g], *lv = sm.lv[g];
-  for (int i = lane; i < rw * rh; i += G) {
-    const int y = i / rw, x = i - y * rw;
-    cf[i] = active ? src[y * w + x] : (int16_t)0;
-    lv[i] = 0;
-  }
+  if (active)
+    for (int i = lane; i < rw * rh; i += G) {
+      const int y = i / rw, x = i - y * rw;
+      cf[i] = src[y * w + x];
+      lv[i] = 0;
+    }
   RdoqView v;
   v.cost_to_zero = gs.cost_to_zero + off;
   v.sig_bits = gs.sig_bits + off;
@@ -730,14 +794,36 @@ __device__ __forceinline__ void quant_rdo_packed_body(
   v.csbf_bits = sm.csbf_bits[g];
   v.csbf = sm.csbf[g];
   v.sb_of_scan = sm.sb_of_scan[g];
-  v.ctx_bits = sm.ctx_bits[g];
-  wave_sync();
+  v.ctx_bits = sm.ctx_bits;
   const bool sign_hide = !(b.intra_pic & XVC_TXF_NO_SIGN_HIDING);
   const int scan_order = (b.intra_pic >> XVC_TXF_SCAN_SHIFT) & 3;
-  const int nnz = wave_rdoq<G>(
-      v, lane, bd, w, h, b.qp, b.comp == 0, scan_order, sign_hide, rq_ctx[prm.ctx_index], prm,
-      [cf, rw](int x, int y) { return (int)cf[y * rw + x]; },
-      [lv, rw](int x, int y) { return lv + y * rw + x; });
+  // one context snapshot at a time (normally one round)
+  bool pending = active;
+  int nnz = 0;
+  for (;;) {
+    const unsigned long long todo = __ballot(pending);
+    if (!todo) break;
+    const int leader = __ffsll((long long)todo) - 1;
+    const int cur = __shfl((int)prm.ctx_index, leader, 64);
+    wave_sync();  // the previous round's readers are done with the table
+    {
+      const unsigned char *cbytes = reinterpret_cast<const unsigned char *>(&rq_ctx[cur]);
+      for (int i = threadIdx.x; i < (int)sizeof(xvcgpu_rdoq_contexts); i += 64) {
+        const unsigned char st8 = cbytes[i] & 127;
+        sm.ctx_bits[2 * i] = kEntropyBits[st8];
+        sm.ctx_bits[2 * i + 1] = kEntropyBits[st8 ^ 1];
+      }
+    }
+    wave_sync();
+    if (pending && (int)prm.ctx_index == cur) {
+      // the groups walk independently (their shuffles stay inside the group)
+      nnz = wave_rdoq<G>(
+          v, lane, bd, w, h, b.qp, b.comp == 0, scan_order, sign_hide, rq_ctx[cur], prm,
+          [cf, rw](int x, int y) { return (int)cf[y * rw + x]; },
+          [lv, rw](int x, int y) { return lv + y * rw + x; }, false);
+      pending = false;
+    }
+  }
   wave_sync();
   if (!active) return;
   int16_t *dst = levels + off;
@@ -746,32 +832,6 @@ __device__ __forceinline__ void quant_rdo_packed_body(
     dst[i] = (x < rw && y < rh) ? lv[y * rw + x] : (int16_t)0;
   }
   if (lane == 0 && nnz_out) nnz_out[bi] = nnz;
-}
-
-// One launch for the three classes (they are independent: side by side the
-// batch lasts as long as its slowest class instead of the sum).  grid: nb0 + nb1
-// + nb2 waves (upper bounds ceil(n/16), ceil(n/4), n); block: 64.
-__global__ void __launch_bounds__(64)
-quant_rdo_packed_kernel(int bd, const xvcgpu_tx_block *blocks, RdoqLists l, int nb0, int nb1,
-                        const int16_t *coeffs, const uint32_t *d_off, int16_t *levels,
-                        int32_t *nnz_out, const xvcgpu_rdoq_contexts *rq_ctx,
-                        const xvcgpu_rdoq_params *rq_prm, RdoqGlobalScratch gs) {
-  __shared__ union {
-    RdoqPackedLds<4> a;
-    RdoqPackedLds<16> b;
-    RdoqPackedLds<64> c;
-  } sm;
-  const int wv = blockIdx.x;
-  // the long walks first: the large blocks, then the 16-lane class
-  if (wv < nb1)
-    quant_rdo_packed_body<16>(sm.b, wv, bd, blocks, l.list[1], l.count + 1, coeffs, d_off, levels,
-                              nnz_out, rq_ctx, rq_prm, gs);
-  else if (wv < nb1 + nb0)
-    quant_rdo_packed_body<4>(sm.a, wv - nb1, bd, blocks, l.list[0], l.count + 0, coeffs, d_off,
-                             levels, nnz_out, rq_ctx, rq_prm, gs);
-  else
-    quant_rdo_packed_body<64>(sm.c, wv - nb1 - nb0, bd, blocks, l.list[2], l.count + 2, coeffs,
-                              d_off, levels, nnz_out, rq_ctx, rq_prm, gs);
 }
 
 #endif  // XVCGPU_K_RDOQ_H_

@@ -881,17 +881,7 @@ xvcgpu_status xvcgpu_residual_rdoq_batch(xvcgpu_ctx *ctx, const xvcgpu_picture *
   return XVCGPU_OK;
 }
 
-xvcgpu_status xvcgpu_quant_rdo_batch(xvcgpu_ctx *ctx, int bitdepth,
-                                     const xvcgpu_tx_block *d_blocks, int n,
-                                     const int16_t *d_coeffs, const uint32_t *d_offsets,
-                                     size_t n_coeffs, int16_t *d_levels, int32_t *d_nnz,
-                                     const xvcgpu_rdoq_contexts *d_contexts,
-                                     const xvcgpu_rdoq_params *d_params) {
-  if (!ctx || n < 0 || bitdepth < 8 || bitdepth > 12 ||
-      (n && (!d_blocks || !d_coeffs || !d_offsets || !d_levels || !d_contexts || !d_params ||
-             !n_coeffs)))
-    return XVCGPU_INVALID_ARGUMENT;
-  if (n == 0) return XVCGPU_OK;
+static xvcgpu_status ensure_rdoq_scratch(xvcgpu_ctx *ctx, int n, size_t n_coeffs) {
   // scratch: class lists (3 x n) + counters; 26 bytes per coefficient
   if (n > ctx->rdoq_lists_cap) {
     if (ctx->d_rdoq_lists) {
@@ -901,7 +891,7 @@ xvcgpu_status xvcgpu_quant_rdo_batch(xvcgpu_ctx *ctx, int bitdepth,
       ctx->rdoq_lists_cap = 0;
     }
     const int cap = n + n / 4;
-    if (hipMalloc(&ctx->d_rdoq_lists, sizeof(int) * (3 * (size_t)cap + 4)) != hipSuccess)
+    if (hipMalloc(&ctx->d_rdoq_lists, sizeof(int) * (4 * (size_t)cap + 4)) != hipSuccess)
       return fail(ctx, XVCGPU_OUT_OF_MEMORY, "rdoq lists");
     ctx->rdoq_lists_cap = cap;
   }
@@ -917,10 +907,34 @@ xvcgpu_status xvcgpu_quant_rdo_batch(xvcgpu_ctx *ctx, int bitdepth,
       return fail(ctx, XVCGPU_OUT_OF_MEMORY, "rdoq scratch");
     ctx->rdoq_scratch_cap = cap;
   }
+  return XVCGPU_OK;
+}
+
+xvcgpu_status xvcgpu_quant_rdo_reserve(xvcgpu_ctx *ctx, int n, size_t n_coeffs) {
+  if (!ctx || n < 0) return XVCGPU_INVALID_ARGUMENT;
+  return ensure_rdoq_scratch(ctx, n, n_coeffs);
+}
+
+xvcgpu_status xvcgpu_quant_rdo_batch(xvcgpu_ctx *ctx, int bitdepth,
+                                     const xvcgpu_tx_block *d_blocks, int n,
+                                     const int16_t *d_coeffs, const uint32_t *d_offsets,
+                                     size_t n_coeffs, int16_t *d_levels, int32_t *d_nnz,
+                                     const xvcgpu_rdoq_contexts *d_contexts,
+                                     const xvcgpu_rdoq_params *d_params) {
+  if (!ctx || n < 0 || bitdepth < 8 || bitdepth > 12 ||
+      (n && (!d_blocks || !d_coeffs || !d_offsets || !d_levels || !d_contexts || !d_params ||
+             !n_coeffs)))
+    return XVCGPU_INVALID_ARGUMENT;
+  if (n == 0) return XVCGPU_OK;
+  {
+    const xvcgpu_status st_ = ensure_rdoq_scratch(ctx, n, n_coeffs);
+    if (st_ != XVCGPU_OK) return st_;
+  }
   const int cap = ctx->rdoq_lists_cap;
   RdoqLists l;
   l.count = ctx->d_rdoq_lists;
   for (int c = 0; c < 3; c++) l.list[c] = ctx->d_rdoq_lists + 4 + (size_t)c * cap;
+  l.cls = reinterpret_cast<signed char *>(ctx->d_rdoq_lists + 4 + 3 * (size_t)cap);
   RdoqGlobalScratch gs;
   {
     const size_t m = ctx->rdoq_scratch_cap;
@@ -932,14 +946,20 @@ xvcgpu_status xvcgpu_quant_rdo_batch(xvcgpu_ctx *ctx, int bitdepth,
     gs.rate_down = reinterpret_cast<int *>(p + 20 * m);
     gs.err_dist = reinterpret_cast<short *>(p + 24 * m);
   }
-  HIP_TRY(ctx, hipMemsetAsync(l.count, 0, 4 * sizeof(int), ctx->stream));
-  hipLaunchKernelGGL(rdoq_classify_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream,
-                     d_blocks, n, l);
-  // the class sizes are only known on the device: launch the upper bounds, waves
-  // beyond a list's count retire at once
-  const int nb0 = (n + 15) / 16, nb1 = (n + 3) / 4;
-  hipLaunchKernelGGL(quant_rdo_packed_kernel, dim3(nb0 + nb1 + n), dim3(64), 0, ctx->stream,
-                     bitdepth, d_blocks, l, nb0, nb1, d_coeffs, d_offsets, d_levels, d_nnz,
+  hipLaunchKernelGGL(rdoq_classify_kernel, dim3((n + 3) / 4), dim3(256), 0, ctx->stream,
+                     bitdepth, d_blocks, n, d_coeffs, d_offsets, d_levels, d_nnz, l);
+  hipLaunchKernelGGL(rdoq_compact_kernel, dim3(1), dim3(1024), 0, ctx->stream, n, l);
+  // the class sizes are only known on the device: launch upper bounds, waves
+  // beyond a list's count retire at once.  The 16-lane class (the long walks of
+  // 16x16 blocks) first.
+  hipLaunchKernelGGL(quant_rdo_packed_kernel<16>, dim3((n + 3) / 4), dim3(64), 0, ctx->stream,
+                     bitdepth, d_blocks, l.list[1], l.count + 1, d_coeffs, d_offsets, d_levels,
+                     d_nnz, d_contexts, d_params, gs);
+  hipLaunchKernelGGL(quant_rdo_packed_kernel<4>, dim3((n + 15) / 16), dim3(64), 0, ctx->stream,
+                     bitdepth, d_blocks, l.list[0], l.count + 0, d_coeffs, d_offsets, d_levels,
+                     d_nnz, d_contexts, d_params, gs);
+  hipLaunchKernelGGL(quant_rdo_packed_kernel<64>, dim3(n), dim3(64), 0, ctx->stream, bitdepth,
+                     d_blocks, l.list[2], l.count + 2, d_coeffs, d_offsets, d_levels, d_nnz,
                      d_contexts, d_params, gs);
   CHECK_LAUNCH(ctx, "quant_rdo_batch");
   return XVCGPU_OK;
@@ -1356,7 +1376,22 @@ xvcgpu_status xvcgpu_frame_pass(xvcgpu_ctx *ctx, const xvcgpu_frame_pass_args *a
     st = xvcgpu_me_search_sized(ctx, a->orig, a->ref, XVCGPU_ME_FULLPEL | XVCGPU_ME_SUBPEL,
                                 a->d_me, a->n_cus, a->d_results, a->max_block_size);
     if (st != XVCGPU_OK) return st;
-    if (a->d_rdoq_params)
+    if (a->d_rdoq_params && a->pred) {
+      st = xvcgpu_mc_from_me(ctx, a->ref, a->pred, a->d_me, a->d_results, a->n_cus);
+      if (st == XVCGPU_OK)
+        st = xvcgpu_fwd_transform_batch(ctx, a->orig, a->pred, a->d_tx, a->n_tx, a->d_coeffs,
+                                        a->d_level_off);
+      if (st == XVCGPU_OK)
+        st = xvcgpu_quant_rdo_batch(ctx, a->rec->bd, a->d_tx, a->n_tx, a->d_coeffs,
+                                    a->d_level_off, a->n_coeffs, a->d_levels, a->d_nnz,
+                                    a->d_rdoq_contexts, a->d_rdoq_params);
+      if (st == XVCGPU_OK)
+        st = xvcgpu_inv_transform_batch(ctx, a->pred, a->rec, a->d_tx, a->n_tx, a->d_levels,
+                                        a->d_level_off, a->d_nnz);
+      if (st == XVCGPU_OK)
+        st = xvcgpu_cu_info_from_me(ctx, a->d_me, a->d_results, a->d_nnz, a->d_luma_tx_index,
+                                    a->n_cus, a->qp_y, a->qp_c, a->ref_poc, a->d_cus_own);
+    } else if (a->d_rdoq_params)
       st = xvcgpu_recon_from_me_rdoq(ctx, a->orig, a->ref, a->rec, a->d_me, a->d_results,
                                      a->n_cus, a->qp_y, a->qp_c, 0, a->ref_poc, a->d_nnz,
                                      a->d_cus_own, a->d_rdoq_contexts, a->d_rdoq_params);

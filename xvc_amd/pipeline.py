@@ -204,6 +204,8 @@ class FramePass:
             self.d_levels = ctx.alloc(2 * max(1, total))
             self.n_levels = total
         self.d_coeffs = ctx.alloc(2 * max(1, self.n_levels)) if self.rdoq_packed else None
+        if self.rdoq_packed:    # no allocation inside the passes (they may be recorded)
+            ctx._check(ctx.lib.xvcgpu_quant_rdo_reserve(ctx.h, len(d.tx), self.n_levels))
 
     @property
     def d_cus_own(self):
@@ -224,6 +226,11 @@ class FramePass:
             a.shift_bitdepth, a.d_ssd = self.bd, self.d_ssd.ptr
             if self.rdoq:
                 a.d_rdoq_contexts, a.d_rdoq_params = self.d_rdoq_ctx.ptr, self.d_rdoq_prm.ptr
+            if self.rdoq_packed:
+                a.pred, a.d_tx, a.n_tx = self.pred.h_pic, self.d_tx.ptr, len(d.tx)
+                a.d_level_off, a.d_luma_tx_index = self.d_level_off.ptr, self.d_luma_idx.ptr
+                a.d_coeffs, a.d_levels = self.d_coeffs.ptr, self.d_levels.ptr
+                a.n_coeffs = self.n_levels
             self._fp_args = a
         return self._fp_args
 
@@ -349,7 +356,7 @@ class FramePass:
     def run(self, orig, ref, rec, ref_poc=0, deblock=True, pad=True, ssd=True):
         """Enqueue one whole-picture frame pass (asynchronous)."""
         ctx, d = self.ctx, self.desc
-        if self.fused and d.cu_size <= 16 and d.row_range == (0, d.h):
+        if (self.fused or self.rdoq_packed) and d.cu_size <= 16 and d.row_range == (0, d.h):
             # the whole sequence behind one C call (xvcgpu_frame_pass)
             self.run_phases(orig, ref, rec, api.FP_ENCODE |
                             (api.FP_DEBLOCK_V | api.FP_DEBLOCK_H if deblock else 0) |
