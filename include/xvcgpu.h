@@ -202,13 +202,18 @@ xvcgpu_status xvcgpu_mc_metric_batch(xvcgpu_ctx *ctx, const xvcgpu_picture *orig
  * (inter_search.cc:606-662, inter_tz_search.cc:84-171, inter_search.cc:
  * 893-964).  One result per xvcgpu_me_block, bit-identical to running the
  * reference search on that block with the same predictor inputs.
- * Blocks: w, h in {4, 8, 16, 32, 64}, at least 32 samples (a job with any
- * other size is left untouched); x, y multiples of 4 inside the picture.
+ * Blocks: w, h in {4, 8, 16, 32, 64}, at least 32 samples; x, y multiples of 4
+ * inside the picture.  The descriptors live in device memory, so a job the
+ * search cannot take (any other size, or larger than max_block_size of
+ * xvcgpu_me_search_sized) is reported in its result slot instead of an error
+ * code: the XVCGPU_ME_UNSUPPORTED record - fullpel_cost = subpel_dist =
+ * 0xffffffff, vectors 0 (no real result has cost 0xffffffff).
  * flags: XVCGPU_ME_FULLPEL runs the TZ search; XVCGPU_ME_SUBPEL runs the
  * 9+8 point half/quarter-pel refinement starting from results[i].fullpel_*
  * (taken from the TZ search when both flags are set). */
 #define XVCGPU_ME_FULLPEL 1
 #define XVCGPU_ME_SUBPEL 2
+#define XVCGPU_ME_UNSUPPORTED 0xffffffffu /* fullpel_cost / subpel_dist of a job not taken */
 xvcgpu_status xvcgpu_me_search(xvcgpu_ctx *ctx, const xvcgpu_picture *orig,
                                const xvcgpu_picture *ref, int flags,
                                const xvcgpu_me_block *d_blocks, int n,
@@ -286,7 +291,8 @@ xvcgpu_status xvcgpu_mc_bipred_batch(xvcgpu_ctx *ctx, const xvcgpu_picture *ref0
  * on the target (:853-891) and SubpelSearch with SATD on the target
  * (:893-964).  d_results[i]: fullpel_x/y = FullSearch result, mv_x/y = final
  * MV, subpel_dist = the function's *out_dist (SATD >> 1, :660),
- * fullpel_cost = 0.  max_block_size as in xvcgpu_me_search_sized. */
+ * fullpel_cost = 0.  max_block_size as in xvcgpu_me_search_sized; jobs that
+ * cannot be taken get the XVCGPU_ME_UNSUPPORTED record. */
 xvcgpu_status xvcgpu_bipred_search(xvcgpu_ctx *ctx, const xvcgpu_picture *orig,
                                    const xvcgpu_picture *ref_other,
                                    const xvcgpu_picture *ref_search,
@@ -539,7 +545,9 @@ xvcgpu_status xvcgpu_intra_pred_batch(xvcgpu_ctx *ctx, const xvcgpu_picture *rec
  * adds bits * lambda_sqrt from its entropy coder state and sorts.
  * max_block_size: an upper bound (4..64) of the block sides in the batch; it
  * sizes the on-chip tiles (batches of small blocks run at higher occupancy).
- * Jobs with a larger side are not evaluated. */
+ * A job with a larger side is answered with d_dist[job][mode] = 0xffffffff for
+ * every mode (XVCGPU_INTRA_SATD_UNSUPPORTED). */
+#define XVCGPU_INTRA_SATD_UNSUPPORTED 0xffffffffu
 xvcgpu_status xvcgpu_intra_satd_batch(xvcgpu_ctx *ctx, const xvcgpu_picture *orig,
                                       const xvcgpu_picture *rec,
                                       const xvcgpu_intra_block *d_jobs, int n,
@@ -590,7 +598,10 @@ xvcgpu_status xvcgpu_intra_recon_batch(xvcgpu_ctx *ctx, const xvcgpu_picture *or
  * (inter_prediction.cc:615-630), MotionCompAffine and the SATD / mvd-bit cost.
  * The reference's float / double arithmetic is reproduced exactly (every sum of
  * the normal equations is an exact multiple of 1/64 below 2^53, so its order
- * does not matter; the elimination is the same IEEE double sequence). */
+ * does not matter; the elimination is the same IEEE double sequence).
+ * w, h in {16, 32, 64} (CodingUnit::CanUseAffine); any other shape is answered
+ * with dist = iterations = 0xffffffff (XVCGPU_AFFINE_ME_UNSUPPORTED). */
+#define XVCGPU_AFFINE_ME_UNSUPPORTED 0xffffffffu
 xvcgpu_status xvcgpu_affine_me_batch(xvcgpu_ctx *ctx, const xvcgpu_picture *orig,
                                      const xvcgpu_picture *ref,
                                      const xvcgpu_picture *ref_other,

@@ -213,6 +213,65 @@ def test_me_search(gpu, xo, bd):
         R.destroy()
 
 
+def test_unsupported_jobs_are_reported(gpu):
+    """Job descriptors live in device memory, so a job a kernel cannot take is
+    reported in its result slot (the *_UNSUPPORTED records of xvcgpu.h), never
+    left as stale memory; the valid jobs beside it are unaffected."""
+    api, ctx = gpu
+    rng = np.random.default_rng(77)
+    pw, ph, bd = 192, 128, 10
+    orig, ref = make_pics(rng, bd, pw, ph, BL, (2, 1))
+    O, R = ctx.picture(pw, ph, bd), ctx.picture(pw, ph, bd)
+    O.upload([orig, None, None], BL)
+    R.upload([ref, None, None], BL)
+    blocks = np.zeros(6, api.ME_DTYPE)
+    shapes = [(16, 16), (2, 8), (4, 4), (12, 16), (64, 64), (8, 8)]
+    for b, (w, h) in zip(blocks, shapes):
+        b["x"], b["y"], b["w"], b["h"] = 64, 32, w, h
+        b["lambda16"], b["search_range"] = 90000, 96
+    stale = np.zeros(6, api.MERES_DTYPE)
+    stale["fullpel_cost"] = 12345
+    db, dr = ctx.buffer(blocks), ctx.buffer(stale)
+    ctx.me_search_dev(O, R, api.ME_FULLPEL | api.ME_SUBPEL, db.ptr, 6, dr.ptr, 16)
+    res = dr.to_array(api.MERES_DTYPE, 6)
+    for i, ok in enumerate([True, False, False, False, False, True]):   # 64x64 > max 16
+        if ok:
+            assert res[i]["fullpel_cost"] not in (12345, 0xffffffff), i
+        else:
+            assert res[i]["fullpel_cost"] == 0xffffffff and res[i]["subpel_dist"] == 0xffffffff, i
+    ctx.me_search_dev(O, R, api.ME_FULLPEL | api.ME_SUBPEL, db.ptr, 6, dr.ptr, 64)
+    assert dr.to_array(api.MERES_DTYPE, 6)[4]["fullpel_cost"] != 0xffffffff
+    # bi-pred refinement: a 32x32 job in a call sized for 16
+    jobs = np.zeros(2, api.BI_DTYPE)
+    jobs["blk"] = blocks[[0, 4]]
+    jobs["blk"]["w"][1] = jobs["blk"]["h"][1] = 32
+    dj, dr2 = ctx.buffer(jobs), ctx.buffer(stale[:2])
+    ctx.bipred_search_dev(O, R, R, dj.ptr, 2, dr2.ptr, 16)
+    r2 = dr2.to_array(api.MERES_DTYPE, 2)
+    assert r2[0]["subpel_dist"] != 0xffffffff and r2[1]["subpel_dist"] == 0xffffffff
+    # affine ME: an 8-tall block (CanUseAffine needs > 8)
+    ab = np.zeros(2, api.AFFINE_ME_DTYPE)
+    ab["x"], ab["y"], ab["w"], ab["lambda16"] = 64, 32, 16, 90000
+    ab["h"] = [16, 8]
+    da, do = ctx.buffer(ab), ctx.alloc(api.AFFINE_ME_RESULT_DTYPE.itemsize * 2)
+    ctx._check(ctx.lib.xvcgpu_affine_me_batch(ctx.h, O.h_pic, R.h_pic, None, da.ptr, 2, do.ptr))
+    ra = do.to_array(api.AFFINE_ME_RESULT_DTYPE, 2)
+    assert ra[0]["dist"] != 0xffffffff and ra[1]["dist"] == 0xffffffff \
+        and ra[1]["iterations"] == 0xffffffff
+    # intra SATD: a 32x32 job in a call sized for 16
+    ij = np.zeros(2, api.INTRA_DTYPE)
+    ij["x"], ij["y"], ij["neighbors"] = 64, 32, 7
+    ij["w"], ij["h"] = [16, 32], [16, 32]
+    di, dd = ctx.buffer(ij), ctx.alloc(4 * api.INTRA_NUM_MODES * 2)
+    ctx._check(ctx.lib.xvcgpu_intra_satd_batch(ctx.h, O.h_pic, R.h_pic, di.ptr, 2, dd.ptr, 16))
+    dist = dd.to_array(np.uint32, 2 * api.INTRA_NUM_MODES).reshape(2, -1)
+    assert (dist[0] != 0xffffffff).all() and (dist[1] == 0xffffffff).all()
+    for b in (db, dr, dj, dr2, da, do, di, dd):
+        b.free()
+    O.destroy()
+    R.destroy()
+
+
 @pytest.mark.parametrize("bd", [8, 10])
 def test_bipred_search(gpu, xo, bd):
     """M2/T2/T7: one SearchBiIterative step per job vs the oracle."""

@@ -441,6 +441,22 @@ affine_me_kernel(PlaneView orig, PlaneView ref, PlaneView ref_other, int bd,
   const int bi = blockIdx.x;
   if (bi >= n) return;
   const xvcgpu_affine_me_block b = blocks[bi];
+  {
+    // CodingUnit::CanUseAffine: width, height > 8 (coding_unit.h:308): 16, 32, 64
+    const bool valid = (b.w == 16 || b.w == 32 || b.w == 64) &&
+                       (b.h == 16 || b.h == 32 || b.h == 64);
+    if (NW == 1 && !valid) {  // nobody takes it: the XVCGPU_AFFINE_ME_UNSUPPORTED record
+      if (threadIdx.x == 0) {
+        xvcgpu_affine_me_result r;
+        for (int i = 0; i < 3; i++) r.mv[i][0] = r.mv[i][1] = 0;
+        r.dist = 0xffffffffu;
+        r.iterations = 0xffffffffu;
+        out[bi] = r;
+      }
+      return;
+    }
+    if (!valid) return;
+  }
   if (b.h != 16 * NW) return;
   const uint16_t *o = orig.p + (ptrdiff_t)b.y * orig.stride + b.x;
   if (b.flags & XVC_AFFINE_ME_BIPRED) {

@@ -52,7 +52,7 @@ template <int MS>
 __global__ void __launch_bounds__(64 * BI_WAVES(MS))
 bipred_search_kernel(PlaneView orig, PlaneView ref_other, PlaneView ref_search,
                      int bd, const xvcgpu_bi_block *jobs, int n,
-                     xvcgpu_me_result *out) {
+                     xvcgpu_me_result *out, int max_launched) {
   constexpr int NW = BI_WAVES(MS);
   __shared__ BiShared<MS> s;
   const int ji = xcd_job_index(blockIdx.x, n);
@@ -61,7 +61,19 @@ bipred_search_kernel(PlaneView orig, PlaneView ref_other, PlaneView ref_search,
   const xvcgpu_me_block &b = job.blk;
   {  // block-size class of this kernel instance (LDS footprint)
     const int m = b.w > b.h ? b.w : b.h;
-    if ((MS == 16 && m > 16) || (MS == 32 && (m <= 16 || m > 32)) || (MS == 64 && m <= 32))
+    const bool pow2 = (b.w & (b.w - 1)) == 0 && (b.h & (b.h - 1)) == 0;
+    const bool valid = pow2 && b.w >= 4 && b.h >= 4 && m <= 64 && m <= max_launched;
+    if (MS == 16 && !valid) {  // nobody takes it: the XVCGPU_ME_UNSUPPORTED record
+      if (threadIdx.x == 0) {
+        xvcgpu_me_result r;
+        r.fullpel_x = r.fullpel_y = r.mv_x = r.mv_y = 0;
+        r.fullpel_cost = r.subpel_dist = 0xffffffffu;
+        out[ji] = r;
+      }
+      return;
+    }
+    if (!valid || (MS == 16 && m > 16) || (MS == 32 && (m <= 16 || m > 32)) ||
+        (MS == 64 && m <= 32))
       return;
   }
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;

@@ -378,7 +378,14 @@ intra_satd_kernel(PicView orig, PicView rec, const xvcgpu_intra_block *jobs, int
   __shared__ IntraSatdShared<MS> s;
   if ((int)blockIdx.x >= n) return;
   const xvcgpu_intra_block b = jobs[blockIdx.x];
-  if (b.w > MS || b.h > MS) return;
+  if (b.w > MS || b.h > MS) {
+    // larger than the caller's max_block_size: every mode's distortion all ones
+    // (XVCGPU_INTRA_SATD_UNSUPPORTED) instead of stale memory
+    if (blockIdx.y == 0)
+      for (int m = threadIdx.x; m < XVC_INTRA_NUM_MODES; m += blockDim.x)
+        dist[(size_t)blockIdx.x * XVC_INTRA_NUM_MODES + m] = 0xffffffffu;
+    return;
+  }
   const PlaneView po = orig.c[0], pr = rec.c[0];
   const int w = b.w, h = b.h, wl = 31 - __clz(w);
   for (int p = threadIdx.x; p < w * h; p += 256) {

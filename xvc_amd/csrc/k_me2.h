@@ -634,7 +634,7 @@ __global__ void __launch_bounds__(64 * ME2_WAVES(MS), ME2_MIN_WAVES(MS))
 me_search_wave_kernel(PicView orig, PicView ref,
                       const xvcgpu_me_block *blocks, int n,
                       xvcgpu_me_result *results, const TzCand *tz_pattern,
-                      Me2Sched sched) {
+                      Me2Sched sched, int max_launched) {
   constexpr int WPG = ME2_WAVES(MS);
   constexpr bool kSched = (PH & XVCGPU_ME_FULLPEL) != 0;
   typedef Me2SharedT<MS, (PH & XVCGPU_ME_SUBPEL) != 0> Shared;
@@ -654,7 +654,22 @@ me_search_wave_kernel(PicView orig, PicView ref,
   const xvcgpu_me_block b = blocks[bi];
   {
     const int mx = b.w > b.h ? b.w : b.h;
-    if (mx > MS || (MS > 16 && mx <= MS / 2)) return;  // other class
+    // a job no instance of this call takes (a size the search does not have, or
+    // larger than the caller's max_block_size) is answered with the
+    // XVCGPU_ME_UNSUPPORTED record instead of being left as it was
+    const bool pow2 = (b.w & (b.w - 1)) == 0 && (b.h & (b.h - 1)) == 0;
+    const bool valid = pow2 && b.w >= 4 && b.h >= 4 && b.w <= 64 && b.h <= 64 &&
+                       b.w * b.h >= 32 && mx <= max_launched;
+    if (MS == 16 && !valid) {
+      if (ME2_LANE == 0) {
+        xvcgpu_me_result r;
+        r.fullpel_x = r.fullpel_y = r.mv_x = r.mv_y = 0;
+        r.fullpel_cost = r.subpel_dist = 0xffffffffu;
+        results[bi] = r;
+      }
+      return;
+    }
+    if (!valid || mx > MS || (MS > 16 && mx <= MS / 2)) return;  // other class
   }
   const int lane = ME2_LANE;
   const PlaneView po = orig.c[0], pr = ref.c[0];

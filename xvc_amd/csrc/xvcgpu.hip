@@ -627,7 +627,8 @@ xvcgpu_status xvcgpu_me_search_sized(xvcgpu_ctx *ctx, const xvcgpu_picture *orig
 #define ME_LAUNCH(MS, PH)                                                          \
   hipLaunchKernelGGL((me_search_wave_kernel<MS, PH>), me2_grid(n, ME2_WAVES(MS)),  \
                      dim3(64 * ME2_WAVES(MS)), 0, ctx->stream, orig->v, ref->v,    \
-                     d_blocks, n, d_results, ctx->d_tz_pattern, sched)
+                     d_blocks, n, d_results, ctx->d_tz_pattern, sched,             \
+                     max_block_size > 32 ? 64 : (max_block_size > 16 ? 32 : 16))
 #define ME_LAUNCH_CLASS(MS)                                \
   do {                                                     \
     if ((flags & 3) == 3) ME_LAUNCH(MS, 3);                \
@@ -756,17 +757,18 @@ xvcgpu_status xvcgpu_bipred_search(xvcgpu_ctx *ctx, const xvcgpu_picture *orig,
     return fail(ctx, XVCGPU_INVALID_ARGUMENT, "picture mismatch");
   if (n == 0) return XVCGPU_OK;
   const dim3 grid((n + 7) / 8 * 8);
+  const int bi_max = max_block_size > 32 ? 64 : (max_block_size > 16 ? 32 : 16);
   hipLaunchKernelGGL(bipred_search_kernel<16>, grid, dim3(64 * BI_WAVES(16)), 0,
                      ctx->stream, orig->v.c[0], ref_other->v.c[0], ref_search->v.c[0],
-                     orig->bd, d_jobs, n, d_results);
+                     orig->bd, d_jobs, n, d_results, bi_max);
   if (max_block_size > 16)
     hipLaunchKernelGGL(bipred_search_kernel<32>, grid, dim3(64 * BI_WAVES(32)), 0,
                        ctx->stream, orig->v.c[0], ref_other->v.c[0],
-                       ref_search->v.c[0], orig->bd, d_jobs, n, d_results);
+                       ref_search->v.c[0], orig->bd, d_jobs, n, d_results, bi_max);
   if (max_block_size > 32)
     hipLaunchKernelGGL(bipred_search_kernel<64>, grid, dim3(64 * BI_WAVES(64)), 0,
                        ctx->stream, orig->v.c[0], ref_other->v.c[0],
-                       ref_search->v.c[0], orig->bd, d_jobs, n, d_results);
+                       ref_search->v.c[0], orig->bd, d_jobs, n, d_results, bi_max);
   CHECK_LAUNCH(ctx, "bipred_search");
   return XVCGPU_OK;
 }
@@ -1174,6 +1176,11 @@ xvcgpu_status xvcgpu_picture_export(xvcgpu_ctx *ctx, const xvcgpu_picture *pic,
                                     void *d_dst, int display_width, int display_height,
                                     int out_bitdepth, int dither) {
   if (!ctx || !pic || !d_dst) return XVCGPU_INVALID_ARGUMENT;
+  {  // the scratch is sized by the pictures created on THIS context; a picture of
+     // another context (or a larger one) must not run into it
+    const xvcgpu_status st_ = ensure_stats(ctx, 2 * pic->h);
+    if (st_ != XVCGPU_OK) return st_;
+  }
   if (display_width < 2 || display_height < 2 || (display_width & 1) ||
       (display_height & 1) || display_width > pic->w || display_height > pic->h ||
       out_bitdepth < 1 || out_bitdepth > 16)
@@ -1217,6 +1224,11 @@ xvcgpu_status xvcgpu_picture_export(xvcgpu_ctx *ctx, const xvcgpu_picture *pic,
 xvcgpu_status xvcgpu_picture_crc(xvcgpu_ctx *ctx, const xvcgpu_picture *pic, int mode,
                                  uint8_t *d_hash) {
   if (!ctx || !pic || !d_hash || mode < 0 || mode > 1) return XVCGPU_INVALID_ARGUMENT;
+  {  // the scratch is sized by the pictures created on THIS context; a picture of
+     // another context (or a larger one) must not run into it
+    const xvcgpu_status st_ = ensure_stats(ctx, 2 * pic->h);
+    if (st_ != XVCGPU_OK) return st_;
+  }
   static const CrcPow2 pow2 = [] {
     CrcPow2 t;
     uint32_t v = 2;  // x
@@ -1271,6 +1283,11 @@ xvcgpu_status xvcgpu_variance_map(xvcgpu_ctx *ctx, const xvcgpu_picture *pic,
 xvcgpu_status xvcgpu_histogram_distance(xvcgpu_ctx *ctx, const xvcgpu_picture *a,
                                         const xvcgpu_picture *b, int64_t *d_out) {
   if (!ctx || !a || !b || !d_out) return XVCGPU_INVALID_ARGUMENT;
+  {  // the scratch is sized by the pictures created on THIS context; a picture of
+     // another context (or a larger one) must not run into it
+    const xvcgpu_status st_ = ensure_stats(ctx, 2 * a->h);
+    if (st_ != XVCGPU_OK) return st_;
+  }
   if (a->w != b->w || a->h != b->h || a->bd != b->bd || a->bd > 12)
     return fail(ctx, XVCGPU_INVALID_ARGUMENT, "picture mismatch");
   const int buckets = 1 << a->bd;

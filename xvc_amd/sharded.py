@@ -37,14 +37,15 @@ from . import api, pipeline
 def search_reach(desc):
     """Largest vertical distance (luma rows) from a CU of `desc` to a reference
     row its motion search can touch before clipping/filter margins.  The
-    window is centred on the predictor (quarter-pel), but the previous CU's
+    window is centred on the predictor (1/16 pel, MotionVector::kPrecisionShift = 4),
+    but the previous CU's
     full-pel vector is a start candidate that is only clipped to the picture
     and the diamond steps test one bound each (inter_tz_search.cc:117-123,
     :283-316), so both offsets are added to the range."""
     me = desc.me
     if len(me) == 0:
         return 0
-    return int(me["search_range"].max()) + (int(np.abs(me["mvp_y"]).max()) + 3) // 4 + \
+    return int(me["search_range"].max()) + (int(np.abs(me["mvp_y"]).max()) + 15) // 16 + \
         int(np.abs(me["prev_y"]).max())
 
 
