@@ -196,7 +196,7 @@ inter_pred_kernel(RefTable refs, PicView rec, PicView pred, const xvcgpu_inter_b
   __shared__ int s_scale, s_offset;
   const int bi_ = blockIdx.x;
   if (bi_ >= n) return;
-  const xvcgpu_inter_block b = blocks[bi_];
+  const xvcgpu_inter_block &b = blocks[bi_];
   const int bd = pred.bd, comp = b.comp;
   const int pic_w = pred.c[0].w, pic_h = pred.c[0].h;
   const int cs = comp ? 1 : 0, shift = 4 + cs, mask = (1 << shift) - 1;
@@ -211,12 +211,15 @@ inter_pred_kernel(RefTable refs, PicView rec, PicView pred, const xvcgpu_inter_b
   for (int l = 0; l < 2; l++) {
     if (b.ref[l] < 0) continue;  // uniform over the workgroup
     const PlaneView pr = refs.pic[b.ref[l]].c[comp];
+    // the list's vectors straight from the descriptor in global memory (indexing a
+    // register copy by the run-time list puts it in scratch)
+    const int32_t (*mvl)[2] = blocks[bi_].mv[l];
     if (bi && !lic) {  // normal bi-prediction: the list at 14 bit
       if (affine) {
-        wg_affine_block<true>(bd, comp, b.x, b.y, b.w, b.h, b.mv[l], pic_w, pic_h, pr,
+        wg_affine_block<true>(bd, comp, b.x, b.y, b.w, b.h, mvl, pic_w, pic_h, pr,
                               reinterpret_cast<uint16_t *>(p16[l]), cw);
       } else {
-        int mx = b.mv[l][0][0], my = b.mv[l][0][1];
+        int mx = mvl[0][0], my = mvl[0][1];
         d_clip_mv(b.x, b.y, pic_w, pic_h, mx, my);
         const uint16_t *r = pr.p + (ptrdiff_t)(cy + (my >> shift)) * pr.stride + cx + (mx >> shift);
         __syncthreads();  // tmp reuse
@@ -232,10 +235,10 @@ inter_pred_kernel(RefTable refs, PicView rec, PicView pred, const xvcgpu_inter_b
     uint16_t *dst = bi ? smp : out;
     const int ds = bi ? cw : pd.stride;
     if (affine) {
-      wg_affine_block<false>(bd, comp, b.x, b.y, b.w, b.h, b.mv[l], pic_w, pic_h, pr, dst, ds);
+      wg_affine_block<false>(bd, comp, b.x, b.y, b.w, b.h, mvl, pic_w, pic_h, pr, dst, ds);
       continue;
     }
-    int mx = b.mv[l][0][0], my = b.mv[l][0][1];
+    int mx = mvl[0][0], my = mvl[0][1];
     d_clip_mv(b.x, b.y, pic_w, pic_h, mx, my);
     const uint16_t *r = pr.p + (ptrdiff_t)(cy + (my >> shift)) * pr.stride + cx + (mx >> shift);
     __syncthreads();  // tmp / smp reuse

@@ -647,7 +647,10 @@ me_search_wave_kernel(PicView orig, PicView ref,
                                 len);
   if (kSched && blockIdx.x == 0 && threadIdx.x < 8) sched.clear->first[threadIdx.x] = 0x7fffffff;
   if (wg < 0) return;
-  const int bi = wg * WPG + (int)(threadIdx.x >> 6);
+  // the job index is the same in all lanes of the wave: tell the compiler, so
+  // that the descriptor and everything derived from it sits in scalar registers
+  // (it cost a dozen VGPRs and, under the 128-register cap, five spilled dwords)
+  const int bi = __builtin_amdgcn_readfirstlane(wg * WPG + (int)(threadIdx.x >> 6));
   if (bi >= n) return;
   ME2_TRACE(0);
   ME2_TRACE_RT(9);

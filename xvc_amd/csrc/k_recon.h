@@ -192,7 +192,7 @@ recon_from_me_kernel(PicView orig, PicView ref, PicView rec,
   const int n_wg = (n + 3) / 4;
   const int wg = xcd_job_index(blockIdx.x, n_wg);
   if (wg < 0) return;
-  const int job = wg * 4 + (int)(threadIdx.x >> 6);
+  const int job = __builtin_amdgcn_readfirstlane(wg * 4 + (int)(threadIdx.x >> 6));  // wave-uniform
   if (job >= n) return;
   const int ci = job >> 1;
   const bool chroma = (job & 1) != 0;

@@ -360,7 +360,7 @@ residual_wave_kernel(PicView orig, PicView pred, PicView rec,
   const int n_wg = (n + TX2_WAVES - 1) / TX2_WAVES;
   const int wg = xcd_job_index(blockIdx.x, n_wg);
   if (wg < 0) return;
-  const int bi = wg * TX2_WAVES + (int)(threadIdx.x >> 6);
+  const int bi = __builtin_amdgcn_readfirstlane(wg * TX2_WAVES + (int)(threadIdx.x >> 6));
   if (bi >= n) return;
   const xvcgpu_tx_block b = blocks[bi];
   if (!tx_small_job(b)) return;  // general path: residual_kernel<>
