@@ -461,4 +461,22 @@ residual_kernel(PicView orig, PicView pred, PicView rec,
                                         nnz_out, tx_tables, lay, &rq, rq_ctx, rq_prm);
 }
 
+// The same path with one workgroup per descriptor (a workgroup whose block
+// belongs to the one-wave kernel retires at once): for batches made mostly of
+// large blocks - the dependency waves of a decoded picture hold a few dozen
+// 32x32 / 64x64 blocks each, which the scanning form above would run one after
+// the other in a single workgroup.  grid: n; block: TX_THREADS.
+template <int MODE>
+__global__ void __launch_bounds__(TX_THREADS)
+residual_per_job_kernel(PicView orig, PicView pred, PicView rec,
+                        const xvcgpu_tx_block *blocks, int n, int16_t *levels,
+                        const uint32_t *level_off, int32_t *nnz_out,
+                        const int16_t *tx_tables, TxTableLayout lay) {
+  __shared__ __attribute__((aligned(16))) TxShared s;
+  const int idx = blockIdx.x;
+  if (idx >= n || tx_small_job(blocks[idx])) return;
+  residual_job<MODE, 4>(s, idx, orig, pred, rec, blocks, levels, level_off, nnz_out, tx_tables,
+                        lay);
+}
+
 #endif  // XVCGPU_K_TX_H_

@@ -113,9 +113,16 @@ void launch_residual(xvcgpu_ctx *ctx, const PicView &o, const PicView &p,
                      dim3(64 * TX2_WAVES), 0, ctx->stream, o, p, r, d_blocks, n,
                      d_levels, d_off, d_nnz, ctx->d_tx_tables, ctx->d_tx_tables_t,
                      xvcgpu_tx_layout(), nullptr, nullptr);
-  hipLaunchKernelGGL(residual_kernel<MODE>, dim3((n + TX_THREADS - 1) / TX_THREADS),
-                     dim3(TX_THREADS), 0, ctx->stream, o, p, r, d_blocks, n, d_levels,
-                     d_off, d_nnz, ctx->d_tx_tables, xvcgpu_tx_layout(), nullptr, nullptr);
+  // general path: small batches (a decoder's dependency waves) one workgroup per
+  // block; picture-sized batches (mostly small blocks) the scanning form
+  if (n <= 2048)
+    hipLaunchKernelGGL(residual_per_job_kernel<MODE>, dim3(n), dim3(TX_THREADS), 0, ctx->stream,
+                       o, p, r, d_blocks, n, d_levels, d_off, d_nnz, ctx->d_tx_tables,
+                       xvcgpu_tx_layout());
+  else
+    hipLaunchKernelGGL(residual_kernel<MODE>, dim3((n + TX_THREADS - 1) / TX_THREADS),
+                       dim3(TX_THREADS), 0, ctx->stream, o, p, r, d_blocks, n, d_levels,
+                       d_off, d_nnz, ctx->d_tx_tables, xvcgpu_tx_layout(), nullptr, nullptr);
 }
 
 // TransformAndReconstruct with the RDO quantiser for the blocks that ask for it
@@ -635,9 +642,19 @@ xvcgpu_status xvcgpu_me_search_sized(xvcgpu_ctx *ctx, const xvcgpu_picture *orig
     else if (flags & XVCGPU_ME_FULLPEL) ME_LAUNCH(MS, 1);  \
     else ME_LAUNCH(MS, 2);                                 \
   } while (0)
+  // The larger classes run the two phases as two launches: their sub-pel
+  // instance holds 23 / 76 KB of LDS per wave (one workgroup per CU), and fused
+  // with it the full-pel search runs at that occupancy too (32x32: 36 + 64 us
+  // apart, 120 us fused; 32x16: 38 + 112 vs 198; tools/time_me_classes.py).
+#define ME_LAUNCH_SPLIT(MS)                                \
+  do {                                                     \
+    if (flags & XVCGPU_ME_FULLPEL) ME_LAUNCH(MS, 1);       \
+    if (flags & XVCGPU_ME_SUBPEL) ME_LAUNCH(MS, 2);        \
+  } while (0)
   ME_LAUNCH_CLASS(16);
-  if (max_block_size > 16) ME_LAUNCH_CLASS(32);
-  if (max_block_size > 32) ME_LAUNCH_CLASS(64);
+  if (max_block_size > 16) ME_LAUNCH_SPLIT(32);
+  if (max_block_size > 32) ME_LAUNCH_SPLIT(64);
+#undef ME_LAUNCH_SPLIT
 #undef ME_LAUNCH_CLASS
 #undef ME_LAUNCH
   CHECK_LAUNCH(ctx, "me_search");
