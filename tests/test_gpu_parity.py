@@ -213,6 +213,50 @@ def test_me_search(gpu, xo, bd):
         R.destroy()
 
 
+@pytest.mark.parametrize("bd", [8, 10])
+def test_me_search_extreme_residuals(gpu, xo, bd):
+    """Sub-pel SATD at the edge of the packed 16-bit budget (k_subpel.h): the
+    original and the reference are opposite Walsh patterns at full swing, so
+    every residual is +-(2^bd - 1) and one Hadamard coefficient of each tile
+    takes the whole energy, for every tile shape of the fast path."""
+    api, ctx = gpu
+    rng = np.random.default_rng(3100 + bd)
+    pw, ph = 256, 192
+    smax = (1 << bd) - 1
+    shapes = [(16, 8), (8, 16), (32, 16), (16, 32), (64, 32), (32, 64), (64, 16), (16, 64),
+              (8, 8), (16, 16), (32, 32), (64, 64), (32, 8), (8, 32)]
+    yy, xx = np.mgrid[0:ph, 0:pw]
+    for trial in range(6):
+        kx, ky = int(rng.integers(0, 16)), int(rng.integers(0, 16))
+        walsh = (np.bitwise_count((xx & kx).astype(np.uint8)).astype(np.int64) +
+                 np.bitwise_count((yy & ky).astype(np.uint8))) & 1
+        if trial == 5:      # plain sign pattern drawn at random
+            walsh = rng.integers(0, 2, (ph, pw))
+        orig_in = (walsh * smax).astype(np.uint16)
+        ref_in = ((1 - walsh) * smax).astype(np.uint16)
+        orig = np.ascontiguousarray(np.pad(orig_in, BL, mode="edge"))
+        ref = np.ascontiguousarray(np.pad(ref_in, BL, mode="edge"))
+        O, R = ctx.picture(pw, ph, bd), ctx.picture(pw, ph, bd)
+        O.upload([orig, None, None], BL)
+        R.upload([ref, None, None], BL)
+        blocks = np.zeros(len(shapes), api.ME_DTYPE)
+        for b, (w, h) in zip(blocks, shapes):
+            b["w"], b["h"] = w, h
+            b["x"] = int(rng.integers(0, (pw - w) // 16 + 1)) * 16
+            b["y"] = int(rng.integers(0, (ph - h) // 16 + 1)) * 16
+            b["lambda16"], b["search_range"] = 498000, 96
+        res = ctx.me_search(O, R, blocks)
+        for i, b in enumerate(blocks):
+            s = to_me_struct(b)
+            (fx, fy), cost = xo.tz_search(bd, s, pw, ph, orig, ref, BL)
+            assert (int(res[i]["fullpel_x"]), int(res[i]["fullpel_y"])) == (fx, fy)
+            (sx, sy), sd = xo.subpel_search(bd, s, pw, ph, orig, ref, BL, (fx, fy))
+            assert (int(res[i]["mv_x"]), int(res[i]["mv_y"])) == (sx, sy), (trial, tuple(b))
+            assert int(res[i]["subpel_dist"]) == sd, (trial, tuple(b))
+        O.destroy()
+        R.destroy()
+
+
 def test_unsupported_jobs_are_reported(gpu):
     """Job descriptors live in device memory, so a job a kernel cannot take is
     reported in its result slot (the *_UNSUPPORTED records of xvcgpu.h), never

@@ -485,7 +485,7 @@ __device__ __forceinline__ void me2_subpel_mv(int pass, int i, int base_x, int b
 }
 
 __device__ __forceinline__ bool me2_subpel_fast(int w, int h, int bd) {
-  return w == h && w >= 8 && bd <= 10;
+  return w >= 8 && h >= 8 && bd <= 10;
 }
 
 // Evaluate the SATD of the n = 9 - pass candidates of a sub-pel pass (or, with
@@ -508,7 +508,7 @@ __device__ __forceinline__ void me2_subpel_eval(Me2Shared<MS> &s, const MeCtx &c
   const int cfx = mx & 15, cfy = my & 15;
   // distinct horizontal phases with fx != 0 -> plane slots (<= 3)
   const int mykey = (cpx + 1) * 16 + cfx;
-  // fast path (k_subpel.h): square block, 8x8 tiles, 16-bit-safe residuals;
+  // fast path (k_subpel.h): both sides >= 8, 16-bit-safe residuals;
   // the caller has transposed s.orig to column-major for it
   const bool fastp = me2_subpel_fast(w, h, bd);
   const bool need = lane < n && (fastp || cfx != 0);
@@ -673,6 +673,8 @@ me_search_wave_kernel(PicView orig, PicView ref,
       return;
     }
     if (!valid || mx > MS || (MS > 16 && mx <= MS / 2)) return;  // other class
+    // me_subpel_team_kernel's jobs
+    if (MS == 64 && PH == XVCGPU_ME_SUBPEL && me2_subpel_fast(b.w, b.h, orig.bd)) return;
   }
   const int lane = ME2_LANE;
   const PlaneView po = orig.c[0], pr = ref.c[0];
@@ -962,13 +964,20 @@ me_search_wave_kernel(PicView orig, PicView ref,
       // column-major original for k_subpel.h: swap across the diagonal
       wave_sync();
       const int lw = 31 - __clz(w);
-      for (int i = lane; i < w * h; i += 64) {
-        const int y = i >> lw, x = i & (w - 1);
-        if (x < y) {
-          const uint16_t a = s.orig[i], bb = s.orig[x * w + y];
-          s.orig[i] = bb;
-          s.orig[x * w + y] = a;
+      if (w == h) {
+        for (int i = lane; i < w * h; i += 64) {
+          const int y = i >> lw, x = i & (w - 1);
+          if (x < y) {
+            const uint16_t a = s.orig[i], bb = s.orig[x * w + y];
+            s.orig[i] = bb;
+            s.orig[x * w + y] = a;
+          }
         }
+      } else {  // through the (not yet built) third plane
+        uint16_t *tmp = reinterpret_cast<uint16_t *>(s.hint[2]);
+        for (int i = lane; i < w * h; i += 64) tmp[(i & (w - 1)) * h + (i >> lw)] = s.orig[i];
+        wave_sync();
+        for (int i = lane; i < w * h; i += 64) s.orig[i] = tmp[i];
       }
     }
     if (b.fullpel_mv) {
@@ -1006,6 +1015,149 @@ me_search_wave_kernel(PicView orig, PicView ref,
   ME2_TRACE(8);  // sub-pel passes
   ME2_TRACE_RT(10);
   if (lane == 0) results[bi] = res;
+}
+
+// ---- sub-pel phase of the 64 class by a team of waves -------------------------
+// A 64-class job keeps ~75 KB of planes in LDS, so only two fit a CU: run by
+// one wave each (the kernel above) that is two waves on four SIMDs, and the
+// 64-class sub-pel phase cost 2.7x the 16 class per sample.  Here one
+// workgroup of NW waves works on one job: the window, the planes and the SATD
+// tiles are dealt over all its threads, the candidate set-up and the ordered
+// fold are computed by every wave alike (same inputs, same result).  Takes the
+// jobs of class MS that qualify for the packed path (me2_subpel_fast); the
+// others stay with me_search_wave_kernel<MS, SUBPEL>, which skips these.
+// grid: n workgroups padded to 8; block: 64 * NW.
+template <int MS, int NW>
+__device__ __forceinline__ void me2_team_eval(Me2Shared<MS> &s, const MeCtx &c,
+                                              const xvcgpu_me_block &b, int pic_w, int pic_h,
+                                              int fpx, int fpy, int pass, int base_x,
+                                              int base_y) {
+  const int w = c.w, h = c.h, bd = c.bd;
+  const int lane = ME2_LANE, tid = threadIdx.x;
+  const int n = pass < 0 ? 1 : 9 - pass;
+  int mx = base_x, my = base_y;
+  if (pass >= 0 && lane < n) me2_subpel_mv(pass, lane, base_x, base_y, mx, my);
+  d_clip_mv(b.x, b.y, pic_w, pic_h, mx, my);
+  const int cpx = (mx >> 4) - fpx, cpy = (my >> 4) - fpy;
+  const int cfx = mx & 15, cfy = my & 15;
+  const int mykey = (cpx + 1) * 16 + cfx;
+  const bool need = lane < n;
+  int myslot = -1, nslots = 0, slot_key[3] = {0, 0, 0};
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    const unsigned long long m = __ballot(need && myslot < 0);
+    if (m) {
+      const int leader = __ffsll((long long)m) - 1;
+      const int key = __builtin_amdgcn_readlane(mykey, leader);
+      if (need && mykey == key) myslot = k;
+      slot_key[k] = key;
+      nslots = k + 1;
+    }
+  }
+  __syncthreads();  // previous readers of the planes / tables are done
+#pragma unroll
+  for (int k = 0; k < 3; k++)
+    if (k < nslots)
+      sp_build_planes(s.win, s.hint[k], s.hh[k], s.taps, bd, w, h, (slot_key[k] >> 4) - 1,
+                      slot_key[k] & 15, tid, 64 * NW);
+  if (tid < n) {
+    const int16_t *base = reinterpret_cast<const int16_t *>(s.orig);
+    SpCand &cd = s.sp[lane];
+    const bool two_stage = cfx != 0 && cfy != 0;
+    cd.plane = (int)((two_stage ? s.hint[0] : s.hh[0]) - base) + myslot * (MS + 8) * MS;
+    cd.sh = two_stage ? 6 + (14 - bd) : 6;
+    cd.off = two_stage ? (8192 << 6) + (1 << (cd.sh - 1)) : 32;
+    sp_fill_taps(cd, s.taps, cfy, cpy + 1);
+    s.dist[lane] = 0;
+  }
+  __syncthreads();
+  sp_satd_pairs(reinterpret_cast<const int16_t *>(s.orig), s.sp, s.orig, s.dist, bd, w, h, n,
+                tid, 64 * NW);
+  __syncthreads();
+}
+
+template <int MS, int NW>
+__global__ void __launch_bounds__(64 * NW)
+me_subpel_team_kernel(PicView orig, PicView ref, const xvcgpu_me_block *blocks, int n,
+                      xvcgpu_me_result *results) {
+  __shared__ Me2Shared<MS> s;
+  const int bi = xcd_job_index(blockIdx.x, n);
+  if (bi < 0) return;
+  const xvcgpu_me_block b = blocks[bi];
+  {
+    const int mx = b.w > b.h ? b.w : b.h;
+    const bool pow2 = (b.w & (b.w - 1)) == 0 && (b.h & (b.h - 1)) == 0;
+    if (!pow2 || mx > MS || mx <= MS / 2 || !me2_subpel_fast(b.w, b.h, orig.bd)) return;
+  }
+  const int tid = threadIdx.x, lane = ME2_LANE;
+  const PlaneView po = orig.c[0], pr = ref.c[0];
+  const int pic_w = po.w, pic_h = po.h;
+  MeCtx c;
+  c.bd = orig.bd;
+  c.w = b.w;
+  c.h = b.h;
+  c.lambda = b.lambda16;
+  const int w = b.w, h = b.h, ws = w + 16;
+  xvcgpu_me_result res = results[bi];
+  const int fpx = res.fullpel_x, fpy = res.fullpel_y;
+  res.mv_x = fpx * 16;
+  res.mv_y = fpy * 16;
+  res.subpel_dist = 0;
+  if (tid < 64)
+    reinterpret_cast<uint32_t *>(&s.taps[0][0])[tid] =
+        reinterpret_cast<const uint32_t *>(&kLumaTaps[0][0])[tid];
+  {  // the original block, column-major (column stride h) as k_subpel.h reads it
+    const uint16_t *o = po.p + (ptrdiff_t)b.y * po.stride + b.x;
+    const int cpr = w >> 3, lc = 31 - __clz(cpr);
+    for (int i = tid; i < h * cpr; i += 64 * NW) {
+      const int y = i >> lc, x0 = (i & (cpr - 1)) << 3;
+      const U16x8 v = *reinterpret_cast<const U16x8 *>(o + (ptrdiff_t)y * po.stride + x0);
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        s.orig[(x0 + 2 * k) * h + y] = (uint16_t)(v.v[k] & 0xffff);
+        s.orig[(x0 + 2 * k + 1) * h + y] = (uint16_t)(v.v[k] >> 16);
+      }
+    }
+  }
+  {  // the reference window: rows -4..h+3, cols -8..w+7 around the full-pel position
+    const uint16_t *r0 = pr.p + (ptrdiff_t)(b.y + fpy - 4) * pr.stride + b.x + fpx - 8;
+    const int cpr = ws >> 3;
+    for (int i = tid; i < (h + 8) * cpr; i += 64 * NW) {
+      const int r = i / cpr, ch = i - r * cpr;
+      const U16x8 v = *reinterpret_cast<const U16x8 *>(r0 + (ptrdiff_t)r * pr.stride + ch * 8);
+      *reinterpret_cast<uint4 *>(s.win + r * ws + ch * 8) = make_uint4(v.v[0], v.v[1], v.v[2], v.v[3]);
+    }
+  }
+  if (b.fullpel_mv) {
+    me2_team_eval<MS, NW>(s, c, b, pic_w, pic_h, fpx, fpy, -1, res.mv_x, res.mv_y);
+    res.subpel_dist = s.dist[0] >> (c.bd - 8);
+  } else {
+    uint32_t best_cost = 0xffffffffu, best_dist = 0xffffffffu;
+    int best_x = res.mv_x, best_y = res.mv_y;
+    for (int pass = 0; pass < 2; pass++) {
+      const int base_x = best_x, base_y = best_y;
+      const int nc = 9 - pass;
+      me2_team_eval<MS, NW>(s, c, b, pic_w, pic_h, fpx, fpy, pass, base_x, base_y);
+      uint32_t my_cost = 0xffffffffu;
+      if (lane < nc) {
+        int mx, my;
+        me2_subpel_mv(pass, lane, base_x, base_y, mx, my);
+        my_cost = (s.dist[lane] >> (c.bd - 8)) +
+                  ((c.lambda * d_mvd_bits(b.mvp_x, b.mvp_y, mx, my, 0)) >> 16);
+      }
+      const uint32_t gmin = wave_min_key(my_cost);
+      const int gi = (int)wave_min_key(my_cost == gmin ? (uint32_t)lane : 64u);
+      if (gmin < best_cost) {
+        best_cost = gmin;
+        best_dist = s.dist[gi] >> (c.bd - 8);
+        me2_subpel_mv(pass, gi, base_x, base_y, best_x, best_y);
+      }
+    }
+    res.mv_x = best_x;
+    res.mv_y = best_y;
+    res.subpel_dist = best_dist;
+  }
+  if (tid == 0) results[bi] = res;
 }
 
 #endif  // XVCGPU_K_ME2_H_

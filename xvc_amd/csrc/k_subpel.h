@@ -1,5 +1,6 @@
-// k_subpel.h -- T3 fast path: the sub-pel SATD sweep for square blocks with
-// 8x8 SATD tiles (w == h >= 8) at bit depth <= 10, on packed 16-bit math.
+// k_subpel.h -- T3 fast path: the sub-pel SATD sweep for blocks with both
+// sides >= 8 (8x8, 16x8 or 8x16 SATD tiles) at bit depth <= 10, on packed
+// 16-bit math.
 // Same arithmetic as me2_build_hplanes / me2_satd_cands in k_me2.h
 // (inter_prediction.cc:1207-1448, sample_metric.cc:316-641), fewer VALU
 // instructions:
@@ -58,13 +59,14 @@ struct __attribute__((aligned(16))) SpCand {
 // position.  win: row-major window, cols -8..w+7 (row stride w + 16).
 __device__ __forceinline__ void sp_build_planes(const uint16_t *win, int16_t *p14,
                                                 int16_t *ps, const int16_t (*taps)[8],
-                                                int bd, int w, int h, int pel_x, int fx) {
-  const int lane = threadIdx.x & 63;
+                                                int bd, int w, int h, int pel_x, int fx,
+                                                int tid = threadIdx.x & 63, int nthr = 64) {
+  const int lane = tid;   // tid / nthr: this thread's place in the wave (or team of waves)
   const int ws = w + 16, rs = h + 8;
   const int hw = w >> 1, lhw = 31 - __clz(hw);
   const int n = rs * hw;  // units: (row, pair of columns)
   if (fx == 0) {
-    for (int i = lane; i < n; i += 64) {
+    for (int i = lane; i < n; i += nthr) {
       const int r = i >> lhw, x0 = (i & (hw - 1)) << 1;
       const uint16_t *src = win + r * ws + x0 + pel_x + 8;
       ps[x0 * rs + r] = (int16_t)src[0];
@@ -83,7 +85,7 @@ __device__ __forceinline__ void sp_build_planes(const uint16_t *win, int16_t *p1
   // first tap of output x0 sits at window column c0 = x0 + pel_x + 5
   const bool odd = ((pel_x + 5) & 1) != 0;
   const uint32_t *win32 = reinterpret_cast<const uint32_t *>(win);
-  for (int i = lane; i < n; i += 64) {
+  for (int i = lane; i < n; i += nthr) {
     const int r = i >> lhw, x0 = (i & (hw - 1)) << 1;
     const uint32_t *d = win32 + ((r * ws + x0 + pel_x + 5) >> 1);
     const uint32_t d0 = d[0], d1 = d[1], d2 = d[2], d3 = d[3], d4 = d[4];
@@ -148,103 +150,171 @@ __device__ __forceinline__ void sp_vfilter8(const int16_t *lds, const SpCand &c,
 }
 
 // SATD of `ncand` candidates (params in cand[]) against origc (the original
-// block, column-major, column stride h).  Adds the
-// normalised 8x8 tile sums (ComputeSatdNxM with the square rule (s+2)>>2,
-// sample_metric.cc:403-641) into dist[c].  w == h, multiple of 8; bd <= 10.
-__device__ __forceinline__ void sp_satd_pairs(const int16_t *lds, const SpCand *cand,
-                                              const uint16_t *origc, uint32_t *dist,
-                                              int bd, int w, int h, int ncand) {
+// block, column-major, column stride h) with TW x TH tiles: 8x8 (square
+// blocks), 16x8 (w > h) or 8x16 (w < h), ComputeSatdNxM's choice for blocks
+// with both sides >= 8 (sample_metric.cc:403-641).  Adds the normalised tile
+// sums into dist[c].  w, h multiples of TW, TH; bd <= 10.
+//
+// lane = one column of one tile for two candidates (one per 16-bit half); the
+// TH rows of the column are registers.  The vertical butterflies (log2 TH
+// stages) run in registers, the horizontal ones (log2 TW stages) across the TW
+// lanes of the tile through ds_swizzle.  16-bit budget at bd 10: a residual
+// is <= 1023, five formed stages reach 32736.  The 8x8 tile forms 3 + 2 stages
+// and folds the sixth (|a+b| + |a-b| = 2 max(|a|,|b|)).  The 128-sample tiles
+// have seven stages: five are formed, the sixth is taken in MAGNITUDE only -
+// for u, v of the fifth stage |u+v| and |u-v| are |u|+|v| and ||u|-|v||
+// (which is which follows from the signs), both < 2^16 unsigned - and the
+// seventh is the max fold on those magnitudes.
+template <int K>
+__device__ __forceinline__ uint32_t sp_swz_xor(uint32_t v) {
+  return sp_swizzle<(K << 10) | 0x1F>(v);
+}
+__device__ __forceinline__ uint32_t sp_pk_abs(uint32_t v) {
+  const sp_v2s x = sp_s2(v);
+  return sp_u(__builtin_elementwise_max(x, sp_s2(0u) - x));
+}
+
+template <int TW, int TH>
+__device__ __forceinline__ void sp_satd_pairs_t(const int16_t *lds, const SpCand *cand,
+                                                const uint16_t *origc, uint32_t *dist,
+                                                int bd, int w, int h, int ncand, int tid,
+                                                int nthr) {
+  static_assert((TW == 8 && TH == 8) || (TW == 16 && TH == 8) || (TW == 8 && TH == 16), "tile");
+  constexpr int LT = TW == 16 ? 4 : 3;          // stages across lanes
+  constexpr int HF = TH == 16 ? 1 : 2;          // of which formed as values
+  constexpr bool MAG = LT - HF == 2;            // one magnitude-only stage before the fold
   const int lane = threadIdx.x & 63;
   const int rs = h + 8;
-  const int tiles_x = w >> 3;
-  const int upp = tiles_x * (h >> 3) * 8;  // units (tile columns) per pair
+  const int tiles_x = w / TW;
+  const int upp = (w * h) / TH;                 // units (tile columns) per pair
   const int npairs = (ncand + 1) >> 1;
   const int total = upp * npairs;
   const uint32_t smax2 = (uint32_t)((1 << bd) - 1) * 0x10001u;
-  for (int g0 = 0; g0 < total; g0 += 64) {
+  for (int g0 = tid & ~63; g0 < total; g0 += nthr) {   // whole waves stay in step
     const int g = g0 + lane;
     const bool active = g < total;
     const int gg = active ? g : 0;
     const int pr = gg / upp, u = gg - pr * upp;
-    const int tile = u >> 3, col = u & 7;
+    const int tile = u / TW, col = u & (TW - 1);
     const int tx = tile % tiles_x, ty = tile / tiles_x;
-    const int x = tx * 8 + col;
+    const int x = tx * TW + col;
     const int ca = 2 * pr, cb = (2 * pr + 1 < ncand) ? 2 * pr + 1 : 2 * pr;
-    const int col_off = x * rs + ty * 8;
-    int va[8], vb[8];
-    sp_vfilter8(lds, cand[ca], col_off, va);
-    sp_vfilter8(lds, cand[cb], col_off, vb);
-    // 8 originals of the column, each replicated into both halves
-    const uint4 o4 = *reinterpret_cast<const uint4 *>(origc + x * h + ty * 8);
-    const uint32_t ow[4] = {o4.x, o4.y, o4.z, o4.w};
-    uint32_t ov[8];
+    const int col_off = x * rs + ty * TH;
+    uint32_t m[TH];
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-      ov[2 * j] = __builtin_amdgcn_perm(ow[j], ow[j], 0x01000100u);
-      ov[2 * j + 1] = __builtin_amdgcn_perm(ow[j], ow[j], 0x03020302u);
-    }
-    uint32_t m[8];
+    for (int r8 = 0; r8 < TH / 8; r8++) {
+      int va[8], vb[8];
+      sp_vfilter8(lds, cand[ca], col_off + 8 * r8, va);
+      sp_vfilter8(lds, cand[cb], col_off + 8 * r8, vb);
+      // 8 originals of the column, each replicated into both halves
+      const uint4 o4 = *reinterpret_cast<const uint4 *>(origc + x * h + ty * TH + 8 * r8);
+      const uint32_t ow[4] = {o4.x, o4.y, o4.z, o4.w};
 #pragma unroll
-    for (int j = 0; j < 8; j++) {
-      // narrow to int16 (pack keeps the low halves), clip to [0, smax]
-      sp_v2s pk;
-      pk.x = (short)va[j];
-      pk.y = (short)vb[j];
-      pk = __builtin_elementwise_min(__builtin_elementwise_max(pk, sp_s2(0u)), sp_s2(smax2));
-      m[j] = sp_u(sp_s2(ov[j]) - pk);
+      for (int j = 0; j < 8; j++) {
+        const uint32_t ov = __builtin_amdgcn_perm(ow[j >> 1], ow[j >> 1],
+                                                  (j & 1) ? 0x03020302u : 0x01000100u);
+        // narrow to int16 (pack keeps the low halves), clip to [0, smax]
+        sp_v2s pk;
+        pk.x = (short)va[j];
+        pk.y = (short)vb[j];
+        pk = __builtin_elementwise_min(__builtin_elementwise_max(pk, sp_s2(0u)), sp_s2(smax2));
+        m[8 * r8 + j] = sp_u(sp_s2(ov) - pk);
+      }
     }
     // vertical WHT (down the column) in registers
 #pragma unroll
-    for (int len = 1; len < 8; len <<= 1)
+    for (int len = 1; len < TH; len <<= 1)
 #pragma unroll
-      for (int i = 0; i < 8; i += len << 1)
+      for (int i = 0; i < TH; i += len << 1)
 #pragma unroll
         for (int j = i; j < i + len; j++) {
           const sp_v2s a = sp_s2(m[j]), b = sp_s2(m[j + len]);
           m[j] = sp_u(a + b);
           m[j + len] = sp_u(a - b);
         }
-    // horizontal WHT across the 8 lanes of the tile: stages xor 1, xor 2
+    // horizontal WHT across the TW lanes of the tile: formed stages
     {
       const uint32_t sg = (col & 1) ? 0xffffffffu : 0x00010001u;
 #pragma unroll
-      for (int j = 0; j < 8; j++) m[j] = sp_pk_mad(m[j], sg, sp_swizzle<0x041F>(m[j]));
+      for (int j = 0; j < TH; j++) m[j] = sp_pk_mad(m[j], sg, sp_swz_xor<1>(m[j]));
     }
-    {
+    if (HF == 2) {
       const uint32_t sg = (col & 2) ? 0xffffffffu : 0x00010001u;
 #pragma unroll
-      for (int j = 0; j < 8; j++) m[j] = sp_pk_mad(m[j], sg, sp_swizzle<0x081F>(m[j]));
-    }
-    // last stage (xor 4) folded into the absolute sum: 2 * max(|a|, |b|),
-    // counted once by each lane of the pair
-    uint32_t mx[8];
-#pragma unroll
-    for (int j = 0; j < 8; j++) {
-      const sp_v2s v = sp_s2(m[j]);
-      const sp_v2u av = __builtin_bit_cast(sp_v2u, __builtin_elementwise_max(v, sp_s2(0u) - v));
-      const sp_v2u ot = __builtin_bit_cast(
-          sp_v2u, sp_swizzle<0x101F>(__builtin_bit_cast(uint32_t, av)));
-      mx[j] = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(av, ot));
+      for (int j = 0; j < TH; j++) m[j] = sp_pk_mad(m[j], sg, sp_swz_xor<2>(m[j]));
     }
     uint32_t sa = 0, sb = 0;
+    if (!MAG) {
+      // last stage (xor 4) folded into the absolute sum: 2 * max(|a|, |b|),
+      // counted once by each lane of the pair
+      uint32_t mx[TH];
 #pragma unroll
-    for (int j = 0; j < 8; j += 2) {
-      const sp_v2u t2 = __builtin_bit_cast(sp_v2u, mx[j]) + __builtin_bit_cast(sp_v2u, mx[j + 1]);
-      sa = __builtin_amdgcn_udot2(t2, (sp_v2u){1, 0}, sa, false);
-      sb = __builtin_amdgcn_udot2(t2, (sp_v2u){0, 1}, sb, false);
+      for (int j = 0; j < TH; j++) {
+        const sp_v2u av = __builtin_bit_cast(sp_v2u, sp_pk_abs(m[j]));
+        const sp_v2u ot = __builtin_bit_cast(
+            sp_v2u, sp_swz_xor<4>(__builtin_bit_cast(uint32_t, av)));
+        mx[j] = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(av, ot));
+      }
+#pragma unroll
+      for (int j = 0; j < TH; j += 2) {
+        const sp_v2u t2 = __builtin_bit_cast(sp_v2u, mx[j]) + __builtin_bit_cast(sp_v2u, mx[j + 1]);
+        sa = __builtin_amdgcn_udot2(t2, (sp_v2u){1, 0}, sa, false);
+        sb = __builtin_amdgcn_udot2(t2, (sp_v2u){0, 1}, sb, false);
+      }
+    } else {
+      constexpr int KM = 1 << HF, KF = 2 << HF;   // magnitude stage, fold stage
+      // this lane forms u + v (bit clear) or v - u (bit set) of the pair
+      const uint32_t flip = (col & KM) ? 0xffffffffu : 0u;
+#pragma unroll
+      for (int j = 0; j < TH; j++) {
+        const uint32_t uu = m[j], vv = sp_swz_xor<KM>(uu);
+        const sp_v2u au = __builtin_bit_cast(sp_v2u, sp_pk_abs(uu));
+        const sp_v2u av = __builtin_bit_cast(sp_v2u, sp_pk_abs(vv));
+        const uint32_t sum = __builtin_bit_cast(uint32_t, au + av);
+        const uint32_t dif = __builtin_bit_cast(
+            uint32_t, __builtin_elementwise_max(au, av) - __builtin_elementwise_min(au, av));
+        // halves whose signs differ (all-ones), swapped for the subtracting lane
+        const sp_v2s sx = sp_s2(uu ^ vv) >> (sp_v2s){15, 15};
+        const uint32_t sel = sp_u(sx) ^ flip;
+        const uint32_t mag = (dif & sel) | (sum & ~sel);
+        const sp_v2u mg = __builtin_bit_cast(sp_v2u, mag);
+        const sp_v2u ot = __builtin_bit_cast(sp_v2u, sp_swz_xor<KF>(mag));
+        const sp_v2u mx = __builtin_elementwise_max(mg, ot);
+        sa = __builtin_amdgcn_udot2(mx, (sp_v2u){1, 0}, sa, false);
+        sb = __builtin_amdgcn_udot2(mx, (sp_v2u){0, 1}, sb, false);
+      }
     }
-    // tile totals over the 8 columns
+    // tile totals over the TW columns
     sa += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)sa, 0xB1, 0xF, 0xF, false);
     sb += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)sb, 0xB1, 0xF, 0xF, false);
     sa += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)sa, 0x4E, 0xF, 0xF, false);
     sb += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)sb, 0x4E, 0xF, 0xF, false);
     sa += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)sa, 0x141, 0xF, 0xF, false);
     sb += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)sb, 0x141, 0xF, 0xF, false);
+    if (TW == 16) {
+      sa += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)sa, 0x140, 0xF, 0xF, false);
+      sb += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)sb, 0x140, 0xF, 0xF, false);
+    }
     if (active && col == 0) {
-      atomicAdd(&dist[ca], (sa + 2) >> 2);
-      if (cb != ca) atomicAdd(&dist[cb], (sb + 2) >> 2);
+      if (TW == TH) {
+        atomicAdd(&dist[ca], (sa + 2) >> 2);
+        if (cb != ca) atomicAdd(&dist[cb], (sb + 2) >> 2);
+      } else {
+        const double nrm = sqrt((double)(TW * TH));
+        atomicAdd(&dist[ca], (uint32_t)(int)(2.0 * (double)sa / nrm));
+        if (cb != ca) atomicAdd(&dist[cb], (uint32_t)(int)(2.0 * (double)sb / nrm));
+      }
     }
   }
+}
+
+__device__ __forceinline__ void sp_satd_pairs(const int16_t *lds, const SpCand *cand,
+                                              const uint16_t *origc, uint32_t *dist,
+                                              int bd, int w, int h, int ncand,
+                                              int tid = threadIdx.x & 63, int nthr = 64) {
+  if (w == h) sp_satd_pairs_t<8, 8>(lds, cand, origc, dist, bd, w, h, ncand, tid, nthr);
+  else if (w > h) sp_satd_pairs_t<16, 8>(lds, cand, origc, dist, bd, w, h, ncand, tid, nthr);
+  else sp_satd_pairs_t<8, 16>(lds, cand, origc, dist, bd, w, h, ncand, tid, nthr);
 }
 
 #endif  // XVCGPU_K_SUBPEL_H_

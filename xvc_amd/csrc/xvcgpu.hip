@@ -653,7 +653,14 @@ xvcgpu_status xvcgpu_me_search_sized(xvcgpu_ctx *ctx, const xvcgpu_picture *orig
   } while (0)
   ME_LAUNCH_CLASS(16);
   if (max_block_size > 16) ME_LAUNCH_SPLIT(32);
-  if (max_block_size > 32) ME_LAUNCH_SPLIT(64);
+  if (max_block_size > 32) {
+    ME_LAUNCH_SPLIT(64);
+    // 64-class jobs on the packed sub-pel path: a team of four waves per job
+    // (the <64, SUBPEL> wave instance above leaves those to it)
+    if (flags & XVCGPU_ME_SUBPEL)
+      hipLaunchKernelGGL((me_subpel_team_kernel<64, 4>), dim3((n + 7) / 8 * 8), dim3(256), 0,
+                         ctx->stream, orig->v, ref->v, d_blocks, n, d_results);
+  }
 #undef ME_LAUNCH_SPLIT
 #undef ME_LAUNCH_CLASS
 #undef ME_LAUNCH
