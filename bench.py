@@ -232,6 +232,9 @@ def cpu_baseline(args, clip, bd, border):
     }
 
 
+RDOQ_PACKED = None if os.environ.get("RDOQ_FUSED") is None else False
+
+
 def main():
     args = parse()
     # HIP maps streams onto 4 hardware queues by default; torch / RCCL take
@@ -291,7 +294,7 @@ def main():
     ctx_lo = None
     if runner is None:
         recs = [ctx.picture(W, H, bd), ctx.picture(W, H, bd)]
-        fp = pipeline.FramePass(ctx, W, H, bd, qp=args.qp, rdoq=rdoq)
+        fp = pipeline.FramePass(ctx, W, H, bd, qp=args.qp, rdoq=rdoq, rdoq_packed=RDOQ_PACKED)
         if pipelined:
             # two queues on the device: top half of every picture on a
             # high-priority stream, bottom half on a low-priority one
@@ -327,7 +330,7 @@ def main():
         else:
             ts, crun = None, None
             crecs = [cctx.picture(W, H, bd), cctx.picture(W, H, bd)]
-            cfp = pipeline.FramePass(cctx, W, H, bd, qp=args.qp, rdoq=rdoq)
+            cfp = pipeline.FramePass(cctx, W, H, bd, qp=args.qp, rdoq=rdoq, rdoq_packed=RDOQ_PACKED)
         crecs[0].upload(first, border)
         cctx.sync()
         extra.append((cctx, crun, cfp, crecs, phase, ts))

@@ -9,10 +9,10 @@ clip = synth.SyntheticClip(W, H, bd)
 pad = lambda planes: [np.ascontiguousarray(np.pad(p, border if c == 0 else border // 2, mode="edge")) for c, p in enumerate(planes)]
 O, R, Rec = ctx.picture(W, H, bd), ctx.picture(W, H, bd), ctx.picture(W, H, bd)
 R.upload(pad(clip.frame(0)), border); O.upload(pad(clip.frame(1)), border)
-fp = pipeline.FramePass(ctx, W, H, bd)
+fp = pipeline.FramePass(ctx, W, H, bd, rdoq=os.environ.get("QUANT", "rdoq") == "rdoq")
 for _ in range(5): fp.run(O, R, Rec)
 ctx.sync()
-N = 50
+N = int(os.environ.get("N", "30"))
 t0 = time.perf_counter()
 for _ in range(N): fp.run(O, R, Rec)
 t1 = time.perf_counter()

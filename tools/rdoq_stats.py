@@ -41,7 +41,10 @@ for comp, name in ((0, "luma 16x16"), (1, "chroma 8x8")):
         live.append(int(sb.sum()))
         ys, xs = np.nonzero(sb)
         diag.append(int((ys + xs).max()) if len(ys) else -1)
-    print("%s: %d blocks, cbf %.1f%%, mean nnz %.2f, p50/p90/p99 nnz %d/%d/%d; live sub-blocks "
-          "mean %.2f; highest sub-block diagonal: %s" %
-          (name, len(sel), 100.0 * (nz > 0).mean(), nz.mean(), *np.percentile(nz, [50, 90, 99]),
+    print("%s: %d blocks, cbf %.1f%%, mean nnz %.2f, p50/p90/p99/p99.9/max nnz %d/%d/%d/%d/%d; "
+          "live sub-blocks mean %.2f; highest sub-block diagonal: %s" %
+          (name, len(sel), 100.0 * (nz > 0).mean(), nz.mean(),
+           *np.percentile(nz, [50, 90, 99, 99.9]), nz.max(),
            np.mean(live), np.bincount(np.array(diag) + 1)))
+    print("   nnz histogram (0, 1-2, 3-5, 6-10, 11-20, 21-40, >40):",
+          np.histogram(nz, [0, 1, 3, 6, 11, 21, 41, 100000])[0])

@@ -62,11 +62,13 @@ template <int N>
 struct RdoqShared {
   long long cost_to_zero[N];   // coeff_cost_to_zero_
   unsigned sig_bits[N];        // coeff_sig_bits_
-  int sig_rate[N], rate_up[N], rate_down[N];
+  int sig_rate[N];
+  int rate_up[N];              // level 0: the rate; else the decision-time state (RQ_STATE_PACK)
   short err_dist[N];
   long long sb_code_cost[64], sb_zero_dist[64];
   unsigned csbf_bits[64];      // csbf_bits_to_zero
   unsigned char csbf[64];
+  unsigned char sb_live[64];   // the walk reaches the sub-block
   unsigned char sb_of_scan[256];  // sub-block scan index -> sy * gw + sx
   // GetEntropyBits(bin) of every context of the snapshot: [2 * i + bin] for the
   // context at byte offset i of xvcgpu_rdoq_contexts.  The walk looks a dozen
@@ -81,11 +83,11 @@ struct RdoqShared {
 struct RdoqView {
   long long *cost_to_zero;
   unsigned *sig_bits;
-  int *sig_rate, *rate_up, *rate_down;
+  int *sig_rate, *rate_up;
   short *err_dist;
   long long *sb_code_cost, *sb_zero_dist;
   unsigned *csbf_bits;
-  unsigned char *csbf;
+  unsigned char *csbf, *sb_live;
   unsigned char *sb_of_scan;
   unsigned *ctx_bits;
 };
@@ -211,15 +213,40 @@ __device__ __forceinline__ int rq_scan_pos(int sbs, int order, int k) {
   return ((p >> 1) << 2) | (p & 1);
 }
 
-// One wave quantises one block (G = 64), or its two halves one block each (G =
-// 32: two blocks of at most 32 sub-blocks, same size, side by side - `s`, cf,
-// lev, the contexts and parameters are then per-lane values of the lane's own
-// half).  cf(x, y) reads a transform coefficient, lev(x, y) addresses the level
-// array (both only inside the region); `lane` is 0..G-1 and all lanes must call.  Returns the number of non-zero levels (to
-// every lane); levels outside the region are NOT written (they are zero: the
-// caller clears what its layout needs).
-// S: the scratch - RdoqShared<N> (all of it in LDS) or RdoqView (pointers: the
-// per-coefficient arrays in global memory, a context table that may be shared).
+// G lanes quantise one block: G = 64 (one block per wave), or 32 / 16 / 4 (the
+// blocks of a wave side by side - `s`, cf, lev, the contexts and parameters
+// are then per-lane values of the lane's own group).  cf(x, y) reads a
+// transform coefficient, lev(x, y) addresses the level array (both only inside
+// the region); `lane` is 0..G-1 and all G lanes must call.  Returns the number
+// of non-zero levels (to every lane); levels outside the region are NOT
+// written (they are zero: the caller clears what its layout needs).
+// S: the scratch - RdoqShared<N> or RdoqView (the same members as pointers).
+//
+// What is serial and what is not.  A coefficient whose plain quantised value q
+// is 0 has no choice to make (rdo_quant.cc:404-411 leaves it at level 0); it
+// adds nothing to a neighbour's template nor to the sub-block's c1 / c2 budget,
+// it only COSTS (its zero distortion + the bits of a zero significance flag in
+// the context its decided neighbours select) and leaves the records the later
+// passes read.  So a sub-block is done in three steps:
+//   1. its owner lane walks the q > 0 coefficients in scan order and decides
+//      them (on real content: one or two per block);
+//   2. all G lanes share out the q == 0 coefficients of the sub-blocks of the
+//      current anti-diagonal: costs (summed per sub-block with LDS atomics) and
+//      records, every template now final;
+//   3. the owner evaluates the zero-sub-block choice (EvalZeroSubblock).
+// The first version walked all 16 coefficients of a sub-block on its owner
+// lane, ~450 instructions each at the ~5 clocks per instruction of a lone wave
+// with four busy lanes: 0.1 ms for a 16x16 block and the slowest block is the
+// kernel's duration.
+//
+// The sign hiding's rate_up / rate_down of a coefficient with a non-zero level
+// (three GetAbsLevelBits evaluations) are formed when - and if - the sign
+// hiding asks for them: rate_up[] then holds the coefficient's decision-time
+// state (RQ_STATE_*), rate_down[] does not exist.
+#define RQ_STATE_PACK(c1_ctx, c2_ctx, c1_idx, c2_idx, k)                                   \
+  ((unsigned)(c1_ctx) | ((unsigned)(c2_ctx) << 9) | ((unsigned)(c1_idx) << 18) |           \
+   ((unsigned)((c2_idx) > 0) << 23) | ((unsigned)(k) << 24))
+
 template <int G = 64, typename S, typename CF, typename LEV>
 __device__ __forceinline__ int wave_rdoq(S &s, int lane, int bd, int w, int h,
                                          int comp_qp, bool luma, int scan_order, bool sign_hide,
@@ -256,12 +283,50 @@ __device__ __forceinline__ int wave_rdoq(S &s, int lane, int bd, int w, int h,
     x = px + (p & 3);
     y = py + (p >> 2);
   };
+  auto quant = [&](int a) {  // GetFwdQuantFunc on a magnitude (rdo_quant.cc:949-964)
+    return (int)(short)(int)((((long long)a * scale) + fq_offset) >> fq_shift);
+  };
+  // the template of decided neighbours (cabac.cc:535-552): five reads issued
+  // together (clamped addresses, masked values) - inside the region; beyond it
+  // every level is 0
+  auto neighbours = [&](int x, int y, int &n_sig, int &n_g1, int &n_g2, int &sum_abs) {
+    const int x1 = x + 1 < rw ? x + 1 : x, x2 = x + 2 < rw ? x + 2 : x;
+    const int y1 = y + 1 < rh ? y + 1 : y, y2 = y + 2 < rh ? y + 2 : y;
+    const int v0 = *lev(x1, y), v1 = *lev(x2, y), v2 = *lev(x1, y1), v3 = *lev(x, y1),
+              v4 = *lev(x, y2);
+    const bool m0 = x + 1 < rw, m1 = x + 2 < rw, m2 = m0 && y + 1 < rh, m3 = y + 1 < rh,
+               m4 = y + 2 < rh;
+    n_sig = n_g1 = n_g2 = sum_abs = 0;
+    auto nb = [&](int v, bool m) {
+      v = m ? d_abs(v) : 0;
+      n_sig += v != 0;
+      n_g1 += v > 1;
+      n_g2 += v > 2;
+      sum_abs += v;
+    };
+    nb(v0, m0); nb(v1, m1); nb(v2, m2); nb(v3, m3); nb(v4, m4);
+  };
+  auto sig_ctx_of = [&](int posxy, int n_sig) {  // GetCoeffSigCtx (cabac.cc:520-560)
+    const int size = (lw + lh) >> 1;
+    int start = posxy < 2 ? 6 : 0;
+    start += luma && posxy < 5 ? 6 : 0;
+    start += size > 2 && luma ? 18 << (size - 3 < 1 ? size - 3 : 1) : 0;
+    const int off = n_sig < 5 ? n_sig : 5;
+    return 2 * ((luma ? RQ_OFF(sig_luma) : RQ_OFF(sig_chroma)) + start + off);
+  };
+  auto greater_ctx_of = [&](int posxy, int n, bool is_last) {  // cabac.cc:594-684
+    const int g1 = luma ? RQ_OFF(greater1_luma) : RQ_OFF(greater1_chroma);
+    const int start = luma ? (posxy < 3 ? 10 : (posxy < 10 ? 5 : 0)) : 0;
+    return is_last ? 2 * g1 : 2 * (g1 + start + (n < 4 ? n : 4) + 1);
+  };
 
-  // The last position: the first non-zero quantised value in reverse scan; and
-  // every sub-block's sum of zero costs (what a sub-block beyond the last
-  // position contributes - to both totals, rdo_quant.cc:295-307 - and all it
-  // needs: its levels are zero and nothing reads its per-coefficient records).
+  // The last position: the first non-zero quantised value in reverse scan; every
+  // sub-block's sum of zero costs (what a sub-block beyond the last position
+  // contributes - to both totals, rdo_quant.cc:295-307 - and all it needs: its
+  // levels are zero and nothing reads its per-coefficient records); and the set
+  // of its coefficients that have a decision to make.
   int last = -1;
+  unsigned qmask = 0;
   long long my_zero_dist = 0;
   if (mine)
     for (int k = sb_size - 1; k >= 0; k--) {
@@ -269,8 +334,10 @@ __device__ __forceinline__ int wave_rdoq(S &s, int lane, int bd, int w, int h,
       coeff_xy(k, x, y);
       const int a = (short)d_abs(cf(x, y));
       my_zero_dist += ((long long)(a * a)) << cost_scale;
-      const int q = (short)(int)((((long long)a * scale) + fq_offset) >> fq_shift);
-      if (q && last < 0) last = sb_index + k;
+      if (quant(a)) {
+        qmask |= 1u << k;
+        if (last < 0) last = sb_index + k;
+      }
       *lev(x, y) = 0;
     }
   const int last_pos_index = rq_wave_max_i32<G>(last);
@@ -293,81 +360,48 @@ __device__ __forceinline__ int wave_rdoq(S &s, int lane, int bd, int w, int h,
   const bool live = mine && sb_index <= last_pos_index;
   if (mine) {
     s.csbf[lane] = 0;
+    s.sb_live[lane] = live ? 1 : 0;
     if (!live) {
       s.csbf_bits[lane] = 0;
       s.sb_code_cost[lane] = my_zero_dist;
       s.sb_zero_dist[lane] = my_zero_dist;
     }
   }
+  // the sub-block (region index) and offset of the last position
+  const int last_k = last_pos_index & (sb_size - 1);
+  const int last_l = rq_wave_max_i32<G>(mine && (last_pos_index >> (2 * sbs)) == my_scan ? lane
+                                                                                          : -1);
   // the wavefront starts at the highest anti-diagonal that holds a live sub-block
   const int d_first = rq_wave_max_i32<G>(live ? sx + sy : -1);
   wave_sync();
 
-  // ---- the per-coefficient decisions, one anti-diagonal of sub-blocks at a time
+  // ---- one anti-diagonal of sub-blocks at a time
   for (int d = d_first; d >= 0; d--) {
-    if (live && sx + sy == d) {
+    const bool act = live && sx + sy == d;
+    bool any = false;
+    // step 1: the owner decides the coefficients that have a choice
+    if (act) {
       RdoqCoeffState st = {0, 0, 0};
-      long long sb_zero_dist = 0, sb_code_cost = 0;
-      // GetSubblockCsbfCtx (cabac.cc:491-518); sub-blocks beyond the region are zero
-      const bool right = sx < rgw - 1 ? s.csbf[lane + 1] != 0 : false;
-      const bool below = sy < rgh - 1 ? s.csbf[lane + rgw] != 0 : false;
-      const int csbf_ctx = 2 * (RQ_OFF(csbf) + (luma ? 0 : 2) + ((right || below) ? 1 : 0));
+      long long code_cost = 0;
       int num_non_zero = 0;
-      bool any = false;
-      for (int k = sb_size - 1; k >= 0; k--) {
+      unsigned m = qmask;
+      while (m) {
+        const int k = 31 - __clz((int)m);
+        m ^= 1u << k;
         const int index = sb_index + k;
         int x, y;
         coeff_xy(k, x, y);
         const int pos = y * rw + x;
         const int abs_coeff = (short)d_abs(cf(x, y));
         const long long zero_cost = ((long long)(abs_coeff * abs_coeff)) << cost_scale;
-        sb_zero_dist += zero_cost;
-        short *out = lev(x, y);
-        if (index > last_pos_index) {  // rdo_quant.cc:303-307 (+ the memsets :262-265)
-          *out = 0;
-          sb_code_cost += zero_cost;
-          s.err_dist[pos] = 0;
-          s.sig_rate[pos] = s.rate_up[pos] = s.rate_down[pos] = 0;
-          continue;
-        }
-        const int q = (short)(int)((((long long)abs_coeff * scale) + fq_offset) >> fq_shift);
+        const int q = quant(abs_coeff);
         const bool is_last = index == last_pos_index;
-        // the template of decided neighbours: five reads issued together (clamped
-        // addresses, masked values) - inside the region; beyond it every level is 0
-        int n_sig = 0, n_g1 = 0, n_g2 = 0, sum_abs = 0;
-        {
-          const int x1 = x + 1 < rw ? x + 1 : x, x2 = x + 2 < rw ? x + 2 : x;
-          const int y1 = y + 1 < rh ? y + 1 : y, y2 = y + 2 < rh ? y + 2 : y;
-          const int v0 = *lev(x1, y), v1 = *lev(x2, y), v2 = *lev(x1, y1), v3 = *lev(x, y1),
-                    v4 = *lev(x, y2);
-          const bool m0 = x + 1 < rw, m1 = x + 2 < rw, m2 = m0 && y + 1 < rh, m3 = y + 1 < rh,
-                     m4 = y + 2 < rh;
-          auto nb = [&](int v, bool m) {
-            v = m ? d_abs(v) : 0;
-            n_sig += v != 0;
-            n_g1 += v > 1;
-            n_g2 += v > 2;
-            sum_abs += v;
-          };
-          nb(v0, m0); nb(v1, m1); nb(v2, m2); nb(v3, m3); nb(v4, m4);
-        }
+        int n_sig, n_g1, n_g2, sum_abs;
+        neighbours(x, y, n_sig, n_g1, n_g2, sum_abs);
         const int posxy = x + y;
-        int sig_ctx, c1_ctx, c2_ctx;  // table indices
-        {  // GetCoeffSigCtx (cabac.cc:520-560)
-          const int size = (lw + lh) >> 1;
-          int start = posxy < 2 ? 6 : 0;
-          start += luma && posxy < 5 ? 6 : 0;
-          start += size > 2 && luma ? 18 << (size - 3 < 1 ? size - 3 : 1) : 0;
-          const int off = n_sig < 5 ? n_sig : 5;
-          sig_ctx = 2 * ((luma ? RQ_OFF(sig_luma) : RQ_OFF(sig_chroma)) + start + off);
-        }
-        {  // GetCoeffGreater1Ctx / Greater2Ctx (cabac.cc:594-684)
-          const int g1 = luma ? RQ_OFF(greater1_luma) : RQ_OFF(greater1_chroma);
-          const int start = luma ? (posxy < 3 ? 10 : (posxy < 10 ? 5 : 0)) : 0;
-          const int o1 = (n_g1 < 4 ? n_g1 : 4) + 1, o2 = (n_g2 < 4 ? n_g2 : 4) + 1;
-          c1_ctx = is_last ? 2 * g1 : 2 * (g1 + start + o1);
-          c2_ctx = is_last ? 2 * g1 : 2 * (g1 + start + o2);
-        }
+        const int sig_ctx = sig_ctx_of(posxy, n_sig);
+        const int c1_ctx = greater_ctx_of(posxy, n_g1, is_last);
+        const int c2_ctx = greater_ctx_of(posxy, n_g2, is_last);
         {  // GetCoeffGolombRiceK (cabac.cc:686-725): smallest k with 2^(k+3) > threshold
           const unsigned threshold = 4u + (unsigned)(sum_abs - n_sig);
           const int kk = 29 - __clz((int)threshold);  // floor(log2) - 2
@@ -382,10 +416,13 @@ __device__ __forceinline__ int wave_rdoq(S &s, int lane, int bd, int w, int h,
         unsigned sig1 = sig_b.y;
         if (is_last || (sb_index > 0 && k == 0 && num_non_zero == 0)) sig1 = 0;
 
+        // QuantCoeffRdo (rdo_quant.cc:689-720)
+        // (a magnitude of 32768 wraps to a negative q, as in the reference: no
+        // candidate but zero)
         long long best_cost = 0x7fffffffffffffffll;
         unsigned best_sig = 0;
         int best_level = q;
-        if (q > 0) {  // QuantCoeffRdo (rdo_quant.cc:689-720)
+        if (q > 0) {
           best_sig = sig1;
           for (int lvl = q > 1 ? q - 1 : q; lvl <= q; lvl++) {
             const unsigned bits = sig1 + rq_abs_level_bits(fb, lvl, st);
@@ -393,8 +430,9 @@ __device__ __forceinline__ int wave_rdoq(S &s, int lane, int bd, int w, int h,
             if (iq_shift > 0) deq = (lvl * iq_scale + (1 << (iq_shift - 1))) >> iq_shift;
             else deq = (lvl * iq_scale) << -iq_shift;
             deq = (short)d_clip3(deq, -32768, 32767);
-            const long long err = abs_coeff - deq;
-            const long long cost = ((err * err) << cost_scale) + rq_bit_cost(bits, lambda);
+            const int err = abs_coeff - deq;
+            const long long cost =
+                (((long long)err * err) << cost_scale) + rq_bit_cost(bits, lambda);
             if (lvl == q - 1 || cost <= best_cost) {
               best_cost = cost;
               best_level = lvl;
@@ -409,10 +447,10 @@ __device__ __forceinline__ int wave_rdoq(S &s, int lane, int bd, int w, int h,
             best_level = 0;
           }
         }
-        *out = (short)best_level;
+        *lev(x, y) = (short)best_level;
         s.cost_to_zero[pos] = zero_cost - best_cost;
         s.sig_bits[pos] = best_sig;
-        sb_code_cost += best_cost;
+        code_cost += best_cost;
         const long long orig_scaled =
             (((long long)abs_coeff * scale) + size_bias_offset) >> size_bias_shift;
         const long long quant_err = orig_scaled - ((long long)best_level << shift);
@@ -421,19 +459,66 @@ __device__ __forceinline__ int wave_rdoq(S &s, int lane, int bd, int w, int h,
         if (best_level) {
           any = true;
           num_non_zero++;
-          const int lvl_rate = (int)rq_abs_level_bits(fb, best_level, st);
-          s.rate_up[pos] = -lvl_rate + (int)rq_abs_level_bits(fb, best_level + 1, st);
-          s.rate_down[pos] = -lvl_rate + (int)rq_abs_level_bits(fb, best_level - 1, st);
+          s.rate_up[pos] =
+              (int)RQ_STATE_PACK(c1_ctx, c2_ctx, st.c1_idx, st.c2_idx, st.golomb_rice_k);
         } else {
           s.rate_up[pos] = (int)fb.c1_0;
-          s.rate_down[pos] = 0;
         }
-        {  // UpdateCodeState (rdo_quant.cc:880-898); golomb_rice_k is re-derived
-          if (best_level >= 1) st.c1_idx++;
-          if (best_level >= 2) st.c2_idx++;
-        }
+        // UpdateCodeState (rdo_quant.cc:880-898); golomb_rice_k is re-derived
+        if (best_level >= 1) st.c1_idx++;
+        if (best_level >= 2) st.c2_idx++;
       }
-      // EvalZeroSubblock (rdo_quant.cc:722-760)
+      s.sb_code_cost[lane] = code_cost;
+    }
+    wave_sync();
+    // step 2: the coefficients without a choice, dealt over the group's lanes
+    {
+      const int ax0 = d > rgh - 1 ? d - (rgh - 1) : 0;
+      const int ax1 = d < rgw - 1 ? d : rgw - 1;
+      const int pairs = (ax1 - ax0 + 1) << (2 * sbs);
+      for (int t = lane; t < pairs; t += G) {
+        const int ax = ax0 + (t >> (2 * sbs)), ay = d - ax, k = t & (sb_size - 1);
+        const int l2 = ay * rgw + ax;
+        if (!s.sb_live[l2]) continue;
+        const int p = rq_scan_pos(sbs, scan_order, k);
+        const int x = (ax << sbs) + (p & 3), y = (ay << sbs) + (p >> 2);
+        const int pos = y * rw + x;
+        const int abs_coeff = (short)d_abs(cf(x, y));
+        if (quant(abs_coeff)) continue;  // decided in step 1
+        long long cost = ((long long)(abs_coeff * abs_coeff)) << cost_scale;
+        if (l2 == last_l && k > last_k) {  // rdo_quant.cc:303-307 (+ the memsets :262-265)
+          s.err_dist[pos] = 0;
+          s.sig_rate[pos] = s.rate_up[pos] = 0;
+        } else {
+          int n_sig, n_g1, n_g2, sum_abs;
+          neighbours(x, y, n_sig, n_g1, n_g2, sum_abs);
+          const uint2 sig_b = *reinterpret_cast<const uint2 *>(cb + sig_ctx_of(x + y, n_sig));
+          const unsigned c1_0 = cb[greater_ctx_of(x + y, n_g1, false)];
+          const long long sig_cost = rq_bit_cost(sig_b.x, lambda);
+          cost += sig_cost;
+          s.cost_to_zero[pos] = -sig_cost;
+          s.sig_bits[pos] = sig_b.x;
+          const long long orig_scaled =
+              (((long long)abs_coeff * scale) + size_bias_offset) >> size_bias_shift;
+          s.err_dist[pos] = (short)(orig_scaled >> (shift - 8));
+          // (the k == 0 coefficient of an otherwise empty sub-block codes no flag,
+          // sig1 = 0 at rdo_quant.cc:343; nothing reads the rate of such a sub-block)
+          s.sig_rate[pos] = (int)(sig_b.y - sig_b.x);
+          s.rate_up[pos] = (int)c1_0;
+        }
+        atomicAdd(reinterpret_cast<unsigned long long *>(&s.sb_code_cost[l2]),
+                  (unsigned long long)cost);
+      }
+    }
+    wave_sync();
+    // step 3: EvalZeroSubblock (rdo_quant.cc:722-760)
+    if (act) {
+      long long sb_code_cost = s.sb_code_cost[lane];
+      const long long sb_zero_dist = my_zero_dist;
+      // GetSubblockCsbfCtx (cabac.cc:491-518); sub-blocks beyond the region are zero
+      const bool right = sx < rgw - 1 ? s.csbf[lane + 1] != 0 : false;
+      const bool below = sy < rgh - 1 ? s.csbf[lane + rgw] != 0 : false;
+      const int csbf_ctx = 2 * (RQ_OFF(csbf) + (luma ? 0 : 2) + ((right || below) ? 1 : 0));
       unsigned bits_to_zero = 0;
       bool zero_sb = false;
       if (!(sb_index == 0 || sb_index + sb_size > last_pos_index)) {
@@ -494,7 +579,7 @@ __device__ __forceinline__ int wave_rdoq(S &s, int lane, int bd, int w, int h,
                                    : ((prm.flags & XVC_RDOQ_INTRA_CU) ? RQ_OFF(cbf_luma)
                                                                       : RQ_OFF(root_cbf)));
     long long code_cost = comp_code_cost + rq_bit_cost(cb[cbf_ctx + 1], lambda);
-    int start = last_pos_index & (sb_size - 1);
+    int start = last_k;
     long long best_cost = 0x7fffffffffffffffll;
     int best_last_plus1 = 0;
     bool stop = false;
@@ -587,16 +672,26 @@ __device__ __forceinline__ int wave_rdoq(S &s, int lane, int bd, int w, int h,
         long long cost;
         int delta;
         if (lvl != 0) {
-          const long long cost_inc = rd_factor * (-(int)s.err_dist[pos]) + s.rate_up[pos];
-          long long cost_dec = rd_factor * (int)s.err_dist[pos] + s.rate_down[pos] -
-                               (d_abs(lvl) == 1 ? s.sig_rate[pos] : 0);
-          if (is_last_sb && k == lastk && d_abs(lvl) == 1) cost_dec -= 4ll * RQ_BYPASS;
+          // rate_up / rate_down (rdo_quant.cc:367-374) from the decision-time state
+          const unsigned pk = (unsigned)s.rate_up[pos];
+          const uint2 c1_b = *reinterpret_cast<const uint2 *>(cb + (pk & 511u));
+          const uint2 c2_b = *reinterpret_cast<const uint2 *>(cb + ((pk >> 9) & 511u));
+          const RdoqFlagBits fb = {c1_b.x, c1_b.y, c2_b.x, c2_b.y};
+          const RdoqCoeffState st = {(int)((pk >> 18) & 31u), (int)((pk >> 23) & 1u), pk >> 24};
+          const int al = d_abs(lvl);
+          const int lvl_rate = (int)rq_abs_level_bits(fb, al, st);
+          const int rate_up = -lvl_rate + (int)rq_abs_level_bits(fb, al + 1, st);
+          const int rate_down = -lvl_rate + (int)rq_abs_level_bits(fb, al - 1, st);
+          const long long cost_inc = rd_factor * (-(int)s.err_dist[pos]) + rate_up;
+          long long cost_dec = rd_factor * (int)s.err_dist[pos] + rate_down -
+                               (al == 1 ? s.sig_rate[pos] : 0);
+          if (is_last_sb && k == lastk && al == 1) cost_dec -= 4ll * RQ_BYPASS;
           if (cost_inc < cost_dec) {
             cost = cost_inc;
             delta = 1;
           } else {
             delta = -1;
-            cost = (k == first && d_abs(lvl) == 1) ? 0x7fffffffll : cost_dec;
+            cost = (k == first && al == 1) ? 0x7fffffffll : cost_dec;
           }
         } else {
           cost = rd_factor * -(long long)d_abs((int)s.err_dist[pos]) + s.rate_up[pos] +
@@ -726,13 +821,6 @@ rdoq_compact_kernel(int n, RdoqLists l) {
     for (int k = 0; k < 3; k++) l.count[k] = part[k][1023];
 }
 
-struct RdoqGlobalScratch {  // total = number of coefficients of the batch
-  long long *cost_to_zero;
-  unsigned *sig_bits;
-  int *sig_rate, *rate_up, *rate_down;
-  short *err_dist;
-};
-
 // LDS of one wave of class G.  One table of context costs per wave: the groups
 // of a wave nearly always name the same snapshot; when they do not, the wave
 // serves one snapshot after the other (a table per group cost 19 KB of LDS per
@@ -743,12 +831,16 @@ struct RdoqPackedLds {
   static constexpr int GROUPS = 64 / G;
   static constexpr int MAXC = G == 4 ? 64 : (G == 16 ? 256 : 1024);  // region coefficients
   static constexpr int MAXSB = G;                                      // region sub-blocks
-  alignas(8) long long sb_code_cost[GROUPS][MAXSB];
+  alignas(8) long long cost_to_zero[GROUPS][MAXC];   // the per-coefficient records: 22 bytes each
+  long long sb_code_cost[GROUPS][MAXSB];
   long long sb_zero_dist[GROUPS][MAXSB];
+  unsigned sig_bits[GROUPS][MAXC];
+  int sig_rate[GROUPS][MAXC], rate_up[GROUPS][MAXC];
+  short err_dist[GROUPS][MAXC];
   alignas(8) unsigned ctx_bits[2 * sizeof(xvcgpu_rdoq_contexts)];
   unsigned csbf_bits[GROUPS][MAXSB];
   int16_t cf[GROUPS][MAXC], lv[GROUPS][MAXC];
-  unsigned char csbf[GROUPS][MAXSB];
+  unsigned char csbf[GROUPS][MAXSB], sb_live[GROUPS][MAXSB];
   unsigned char sb_of_scan[GROUPS][G == 64 ? 256 : MAXSB * 4];
 };
 
@@ -759,7 +851,7 @@ __global__ void __launch_bounds__(64)
 quant_rdo_packed_kernel(int bd, const xvcgpu_tx_block *blocks, const int *list,
                         const int *count, const int16_t *coeffs, const uint32_t *d_off,
                         int16_t *levels, int32_t *nnz_out, const xvcgpu_rdoq_contexts *rq_ctx,
-                        const xvcgpu_rdoq_params *rq_prm, RdoqGlobalScratch gs) {
+                        const xvcgpu_rdoq_params *rq_prm) {
   constexpr int GROUPS = 64 / G;
   __shared__ RdoqPackedLds<G> sm;
   const int wave = blockIdx.x;
@@ -783,12 +875,12 @@ quant_rdo_packed_kernel(int bd, const xvcgpu_tx_block *blocks, const int *list,
       lv[i] = 0;
     }
   RdoqView v;
-  v.cost_to_zero = gs.cost_to_zero + off;
-  v.sig_bits = gs.sig_bits + off;
-  v.sig_rate = gs.sig_rate + off;
-  v.rate_up = gs.rate_up + off;
-  v.rate_down = gs.rate_down + off;
-  v.err_dist = gs.err_dist + off;
+  v.cost_to_zero = sm.cost_to_zero[g];
+  v.sig_bits = sm.sig_bits[g];
+  v.sig_rate = sm.sig_rate[g];
+  v.rate_up = sm.rate_up[g];
+  v.err_dist = sm.err_dist[g];
+  v.sb_live = sm.sb_live[g];
   v.sb_code_cost = sm.sb_code_cost[g];
   v.sb_zero_dist = sm.sb_zero_dist[g];
   v.csbf_bits = sm.csbf_bits[g];

@@ -184,9 +184,13 @@ recon_from_me_kernel(PicView orig, PicView ref, PicView rec,
                      const xvcgpu_rdoq_params *rq_prm = nullptr) {
   __shared__ ReconShared s_all[4];
   // one scratch per wave; a chroma wave splits it between its two halves
-  __shared__ RdoqShared<256> rq_all[RDOQ ? 4 : 1];
-  static_assert(2 * sizeof(RdoqShared<64>) <= sizeof(RdoqShared<256>), "scratch split");
-  RdoqShared<256> *rq_wave = &rq_all[RDOQ ? (threadIdx.x >> 6) : 0];
+  // per wave: one 16x16 luma block, or two 8x8 chroma blocks side by side
+  union RqWave {
+    RdoqShared<256> one;
+    RdoqShared<64> two[2];
+  };
+  __shared__ RqWave rq_all[RDOQ ? 4 : 1];
+  RdoqShared<256> *rq_wave = &rq_all[RDOQ ? (threadIdx.x >> 6) : 0].one;
   ReconShared &s = s_all[threadIdx.x >> 6];
   const int n = n_cus * 2;
   const int n_wg = (n + 3) / 4;

@@ -171,8 +171,6 @@ xvcgpu_status xvcgpu_create(int device, xvcgpu_ctx **out) {
   ctx->stats_rows_cap = 0;
   ctx->d_rdoq_lists = nullptr;
   ctx->rdoq_lists_cap = 0;
-  ctx->d_rdoq_scratch = nullptr;
-  ctx->rdoq_scratch_cap = 0;
   ctx->d_crc_tables = nullptr;
   for (int i = 0; i < 64; i++) ctx->ev_pool[i] = nullptr;
   ctx->d_me_rot = nullptr;
@@ -226,7 +224,6 @@ void xvcgpu_destroy(xvcgpu_ctx *ctx) {
   if (ctx->d_ssd_part) hipFree(ctx->d_ssd_part);
   if (ctx->d_stats) hipFree(ctx->d_stats);
   if (ctx->d_rdoq_lists) hipFree(ctx->d_rdoq_lists);
-  if (ctx->d_rdoq_scratch) hipFree(ctx->d_rdoq_scratch);
   if (ctx->d_crc_tables) hipFree(ctx->d_crc_tables);
   if (ctx->d_me_rot) hipFree(ctx->d_me_rot);
   hipEventDestroy(ctx->ev0);
@@ -908,7 +905,7 @@ xvcgpu_status xvcgpu_residual_rdoq_batch(xvcgpu_ctx *ctx, const xvcgpu_picture *
 }
 
 static xvcgpu_status ensure_rdoq_scratch(xvcgpu_ctx *ctx, int n, size_t n_coeffs) {
-  // scratch: class lists (3 x n) + counters; 26 bytes per coefficient
+  // scratch: class lists (3 x n) + counters + the per-block classes
   if (n > ctx->rdoq_lists_cap) {
     if (ctx->d_rdoq_lists) {
       hipStreamSynchronize(ctx->stream);
@@ -921,18 +918,7 @@ static xvcgpu_status ensure_rdoq_scratch(xvcgpu_ctx *ctx, int n, size_t n_coeffs
       return fail(ctx, XVCGPU_OUT_OF_MEMORY, "rdoq lists");
     ctx->rdoq_lists_cap = cap;
   }
-  if (n_coeffs > ctx->rdoq_scratch_cap) {
-    if (ctx->d_rdoq_scratch) {
-      hipStreamSynchronize(ctx->stream);
-      hipFree(ctx->d_rdoq_scratch);
-      ctx->d_rdoq_scratch = nullptr;
-      ctx->rdoq_scratch_cap = 0;
-    }
-    const size_t cap = n_coeffs + n_coeffs / 4 + 64;
-    if (hipMalloc(&ctx->d_rdoq_scratch, 26 * cap) != hipSuccess)
-      return fail(ctx, XVCGPU_OUT_OF_MEMORY, "rdoq scratch");
-    ctx->rdoq_scratch_cap = cap;
-  }
+  (void)n_coeffs;  // the per-coefficient records live in LDS
   return XVCGPU_OK;
 }
 
@@ -961,17 +947,6 @@ xvcgpu_status xvcgpu_quant_rdo_batch(xvcgpu_ctx *ctx, int bitdepth,
   l.count = ctx->d_rdoq_lists;
   for (int c = 0; c < 3; c++) l.list[c] = ctx->d_rdoq_lists + 4 + (size_t)c * cap;
   l.cls = reinterpret_cast<signed char *>(ctx->d_rdoq_lists + 4 + 3 * (size_t)cap);
-  RdoqGlobalScratch gs;
-  {
-    const size_t m = ctx->rdoq_scratch_cap;
-    char *p = static_cast<char *>(ctx->d_rdoq_scratch);
-    gs.cost_to_zero = reinterpret_cast<long long *>(p);
-    gs.sig_bits = reinterpret_cast<unsigned *>(p + 8 * m);
-    gs.sig_rate = reinterpret_cast<int *>(p + 12 * m);
-    gs.rate_up = reinterpret_cast<int *>(p + 16 * m);
-    gs.rate_down = reinterpret_cast<int *>(p + 20 * m);
-    gs.err_dist = reinterpret_cast<short *>(p + 24 * m);
-  }
   hipLaunchKernelGGL(rdoq_classify_kernel, dim3((n + 3) / 4), dim3(256), 0, ctx->stream,
                      bitdepth, d_blocks, n, d_coeffs, d_offsets, d_levels, d_nnz, l);
   hipLaunchKernelGGL(rdoq_compact_kernel, dim3(1), dim3(1024), 0, ctx->stream, n, l);
@@ -980,13 +955,13 @@ xvcgpu_status xvcgpu_quant_rdo_batch(xvcgpu_ctx *ctx, int bitdepth,
   // 16x16 blocks) first.
   hipLaunchKernelGGL(quant_rdo_packed_kernel<16>, dim3((n + 3) / 4), dim3(64), 0, ctx->stream,
                      bitdepth, d_blocks, l.list[1], l.count + 1, d_coeffs, d_offsets, d_levels,
-                     d_nnz, d_contexts, d_params, gs);
+                     d_nnz, d_contexts, d_params);
   hipLaunchKernelGGL(quant_rdo_packed_kernel<4>, dim3((n + 15) / 16), dim3(64), 0, ctx->stream,
                      bitdepth, d_blocks, l.list[0], l.count + 0, d_coeffs, d_offsets, d_levels,
-                     d_nnz, d_contexts, d_params, gs);
+                     d_nnz, d_contexts, d_params);
   hipLaunchKernelGGL(quant_rdo_packed_kernel<64>, dim3(n), dim3(64), 0, ctx->stream, bitdepth,
                      d_blocks, l.list[2], l.count + 2, d_coeffs, d_offsets, d_levels, d_nnz,
-                     d_contexts, d_params, gs);
+                     d_contexts, d_params);
   CHECK_LAUNCH(ctx, "quant_rdo_batch");
   return XVCGPU_OK;
 }

@@ -55,8 +55,6 @@ struct xvcgpu_ctx {
   // counters, and 26 bytes per coefficient of the batch
   int *d_rdoq_lists;
   int rdoq_lists_cap;      // in blocks
-  void *d_rdoq_scratch;
-  size_t rdoq_scratch_cap; // in coefficients
 };
 
 struct xvcgpu_picture {
