@@ -1358,6 +1358,21 @@ void StoreContexts(const Contexts &ctx, xvcgpu_rdoq_contexts *c) {
 
 const uint32_t *xr_entropy_bits_table(void) { return &ContextModel::kEntropyBits_[0]; }
 
+/* Sub-GOP arithmetic (segment_header.cc:135-175) as the encoder calls it:
+ * sub_gop_start_poc = the POC the picture's sub-GOP starts after (encoder.cc:97). */
+static int XrSubGopStart(int n, int len) { return n < 1 ? 0 : (n - 1) / len * len; }
+int xr_doc_from_poc(int poc, int sub_gop_length) {
+  return static_cast<int>(
+      SegmentHeader::CalcDocFromPoc(poc, sub_gop_length, XrSubGopStart(poc, sub_gop_length)));
+}
+int xr_poc_from_doc(int doc, int sub_gop_length) {
+  return static_cast<int>(
+      SegmentHeader::CalcPocFromDoc(doc, sub_gop_length, XrSubGopStart(doc, sub_gop_length)));
+}
+int xr_tid_from_doc(int doc, int sub_gop_length) {
+  return SegmentHeader::CalcTidFromDoc(doc, sub_gop_length, XrSubGopStart(doc, sub_gop_length));
+}
+
 /* The context states a fresh SyntaxWriter starts a picture with
  * (CabacContexts::ResetStates for the picture qp / type). */
 void xr_rdoq_init_contexts(int bd, int qp_raw, int pic_type, xvcgpu_rdoq_contexts *out) {

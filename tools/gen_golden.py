@@ -398,6 +398,18 @@ def gen_rdoq(xr):
     print("rdoq: %d cases, %d with levels" % (len(cases), sum(c[7] > 0 for c in cases)))
 
 
+def gen_subgop(xr):
+    """SegmentHeader::CalcDocFromPoc / CalcPocFromDoc / CalcTidFromDoc for the
+    dyadic sub-GOP lengths: rows [length, n, doc_from_poc(n), poc_from_doc(n),
+    tid_from_doc(n)] for n = 0..130."""
+    rows = []
+    for length in (1, 2, 4, 8, 16, 32, 64):
+        for n in range(0, 131):
+            rows.append((length, n, xr.dll.xr_doc_from_poc(n, length),
+                         xr.dll.xr_poc_from_doc(n, length), xr.dll.xr_tid_from_doc(n, length)))
+    np.savez_compressed(os.path.join(OUT, "subgop.npz"), rows=np.array(rows, np.int32))
+
+
 def write_manifest():
     import hashlib
     with open(os.path.join(OUT, "MANIFEST.md5"), "w") as f:
@@ -437,6 +449,10 @@ def main():
         return
     if sys.argv[1:] == ["rdoq"]:
         gen_rdoq(xr)
+        write_manifest()
+        return
+    if sys.argv[1:] == ["subgop"]:
+        gen_subgop(xr)
         write_manifest()
         return
     if sys.argv[1:] == ["quant_sh"]:
