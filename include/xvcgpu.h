@@ -85,6 +85,59 @@ xvcgpu_status xvcgpu_timer_mark(xvcgpu_ctx *ctx, int slot);
 xvcgpu_status xvcgpu_timer_between(xvcgpu_ctx *ctx, int slot_a, int slot_b,
                                    float *elapsed_ms);
 
+/* ---- events and the RCCL exchange (xvc_amd/csrc/xvcgpu_comm.hip) ---------- *
+ * Multi-GPU: one process and one communicator per GPU.  The ranks either code
+ * independent pictures of a sub-GOP and ship each finished, padded reference
+ * picture to the ranks that list it (the reference's only parallelism,
+ * thread_encoder.cc:99-159; schedule: xvc_amd/host/xvc_picture_schedule.h), or
+ * own CTU rows of one picture and trade the rows around a shard boundary for
+ * the in-loop filter (deblocking_filter.cc:59-62).  Transfers are ncclSend /
+ * ncclRecv on the communicator's own stream; events order them with the
+ * kernels of the contexts:
+ *   xvcgpu_event_record(ctx, ev)        ev = everything queued on ctx so far
+ *   xvcgpu_comm_wait_event(comm, ev)    later transfers start after ev
+ *   xvcgpu_comm_record_event(comm, ev)  ev = every transfer queued so far
+ *   xvcgpu_event_wait(ctx, ev)          later kernels of ctx start after ev
+ * Sends and receives that are enqueued in one agreed order on all ranks pair
+ * up without deadlock; put transfers that may cross between
+ * xvcgpu_comm_group_begin / _end (ncclGroupStart / ncclGroupEnd).
+ * xvcgpu_comm_unique_id is called on one rank, its 128 bytes are handed to
+ * the others by whatever started the processes (bench.py: torch.distributed's
+ * store), then every rank calls xvcgpu_comm_create (collective). */
+typedef struct xvcgpu_event xvcgpu_event;
+typedef struct xvcgpu_comm xvcgpu_comm;
+#define XVCGPU_COMM_ID_BYTES 128
+xvcgpu_status xvcgpu_event_create(xvcgpu_ctx *ctx, xvcgpu_event **out);
+void xvcgpu_event_destroy(xvcgpu_event *ev);
+xvcgpu_status xvcgpu_event_record(xvcgpu_ctx *ctx, xvcgpu_event *ev);
+xvcgpu_status xvcgpu_event_wait(xvcgpu_ctx *ctx, xvcgpu_event *ev);
+xvcgpu_status xvcgpu_event_synchronize(xvcgpu_event *ev);
+xvcgpu_status xvcgpu_comm_unique_id(uint8_t id[XVCGPU_COMM_ID_BYTES]);
+xvcgpu_status xvcgpu_comm_create(xvcgpu_ctx *ctx, const uint8_t id[XVCGPU_COMM_ID_BYTES],
+                                 int world, int rank, xvcgpu_comm **out);
+void xvcgpu_comm_destroy(xvcgpu_comm *comm);
+int xvcgpu_comm_world(const xvcgpu_comm *comm);
+int xvcgpu_comm_rank(const xvcgpu_comm *comm);
+xvcgpu_status xvcgpu_comm_wait_event(xvcgpu_comm *comm, xvcgpu_event *ev);
+xvcgpu_status xvcgpu_comm_record_event(xvcgpu_comm *comm, xvcgpu_event *ev);
+xvcgpu_status xvcgpu_comm_sync(xvcgpu_comm *comm);
+xvcgpu_status xvcgpu_comm_group_begin(xvcgpu_comm *comm);
+xvcgpu_status xvcgpu_comm_group_end(xvcgpu_comm *comm);
+/* The whole padded picture (all three planes with their borders: 7.8 MB at
+ * 1080p, one message). */
+xvcgpu_status xvcgpu_comm_send_picture(xvcgpu_comm *comm, const xvcgpu_picture *pic, int dst);
+xvcgpu_status xvcgpu_comm_recv_picture(xvcgpu_comm *comm, xvcgpu_picture *pic, int src);
+/* Rows [y0, y1) in luma rows (even; chroma planes move rows y0/2 .. y1/2) of
+ * the components in comp_mask (bit c), with their horizontal borders: one
+ * message per plane. */
+xvcgpu_status xvcgpu_comm_send_rows(xvcgpu_comm *comm, const xvcgpu_picture *pic, int comp_mask,
+                                    int y0, int y1, int dst);
+xvcgpu_status xvcgpu_comm_recv_rows(xvcgpu_comm *comm, xvcgpu_picture *pic, int comp_mask, int y0,
+                                    int y1, int src);
+/* Sum over the ranks of n 64-bit counters in device memory (PSNR parts of row
+ * shards), in place. */
+xvcgpu_status xvcgpu_comm_all_reduce_sum_u64(xvcgpu_comm *comm, uint64_t *d_values, int n);
+
 /* ---- recorded call sequences (HIP graphs) --------------------------------- *
  * The per-picture sequence of launches is short kernels (8-110 us each), so
  * the launch path matters.  xvcgpu_record_begin() puts the context's private

@@ -144,6 +144,12 @@ SYMBOLS = [
     "xvcgpu_get_transform_matrix", "xvcgpu_inter_pred_batch", "xvcgpu_deblock_tree",
     "xvcgpu_residual_rdoq_batch", "xvcgpu_quant_rdo_batch", "xvcgpu_recon_from_me_rdoq",
     "xvcgpu_quant_rdo_reserve",
+    "xvcgpu_event_create", "xvcgpu_event_destroy", "xvcgpu_event_record", "xvcgpu_event_wait",
+    "xvcgpu_event_synchronize", "xvcgpu_comm_unique_id", "xvcgpu_comm_create",
+    "xvcgpu_comm_destroy", "xvcgpu_comm_world", "xvcgpu_comm_rank", "xvcgpu_comm_wait_event",
+    "xvcgpu_comm_record_event", "xvcgpu_comm_sync", "xvcgpu_comm_group_begin",
+    "xvcgpu_comm_group_end", "xvcgpu_comm_send_picture", "xvcgpu_comm_recv_picture",
+    "xvcgpu_comm_send_rows", "xvcgpu_comm_recv_rows", "xvcgpu_comm_all_reduce_sum_u64",
 ]
 
 _vp = C.c_void_p
@@ -259,7 +265,29 @@ def load_library():
                                    _vp, _vp],
         "xvcgpu_deblock_tree": [_vp, _vp, _vp, C.c_int, _vp, C.c_int, C.c_int, C.c_int,
                                 C.c_int, C.c_int, C.c_int],
+        "xvcgpu_event_create": [_vp, C.POINTER(_vp)],
+        "xvcgpu_event_record": [_vp, _vp],
+        "xvcgpu_event_wait": [_vp, _vp],
+        "xvcgpu_event_synchronize": [_vp],
+        "xvcgpu_comm_unique_id": [_vp],
+        "xvcgpu_comm_create": [_vp, _vp, C.c_int, C.c_int, C.POINTER(_vp)],
+        "xvcgpu_comm_world": [_vp],
+        "xvcgpu_comm_rank": [_vp],
+        "xvcgpu_comm_wait_event": [_vp, _vp],
+        "xvcgpu_comm_record_event": [_vp, _vp],
+        "xvcgpu_comm_sync": [_vp],
+        "xvcgpu_comm_group_begin": [_vp],
+        "xvcgpu_comm_group_end": [_vp],
+        "xvcgpu_comm_send_picture": [_vp, _vp, C.c_int],
+        "xvcgpu_comm_recv_picture": [_vp, _vp, C.c_int],
+        "xvcgpu_comm_send_rows": [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int],
+        "xvcgpu_comm_recv_rows": [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int],
+        "xvcgpu_comm_all_reduce_sum_u64": [_vp, _vp, C.c_int],
     }
+    lib.xvcgpu_event_destroy.restype = None
+    lib.xvcgpu_event_destroy.argtypes = [_vp]
+    lib.xvcgpu_comm_destroy.restype = None
+    lib.xvcgpu_comm_destroy.argtypes = [_vp]
     for name, args in sigs.items():
         f = getattr(lib, name)
         f.restype = C.c_int
@@ -308,6 +336,96 @@ class DeviceBuffer:
         if self.ptr:
             self.ctx.lib.xvcgpu_free(self.ctx.h, self.ptr)
             self.ptr = None
+
+
+class Event:
+    """An ordering point between streams (xvcgpu_event_*)."""
+
+    def __init__(self, ctx):
+        self.ctx = ctx
+        p = _vp()
+        ctx._check(ctx.lib.xvcgpu_event_create(ctx.h, C.byref(p)))
+        self.h = p.value
+
+    def record(self, ctx=None):
+        ctx = ctx or self.ctx
+        ctx._check(ctx.lib.xvcgpu_event_record(ctx.h, self.h))
+
+    def wait(self, ctx=None):
+        """Work queued on `ctx` from now on starts after the event."""
+        ctx = ctx or self.ctx
+        ctx._check(ctx.lib.xvcgpu_event_wait(ctx.h, self.h))
+
+    def synchronize(self):
+        self.ctx._check(self.ctx.lib.xvcgpu_event_synchronize(self.h))
+
+    def destroy(self):
+        if self.h:
+            self.ctx.lib.xvcgpu_event_destroy(self.h)
+            self.h = None
+
+
+COMM_ID_BYTES = 128
+
+
+def comm_unique_id():
+    """128 bytes for xvcgpu_comm_create, made on one rank (ncclGetUniqueId)."""
+    lib = load_library()
+    buf = (C.c_uint8 * COMM_ID_BYTES)()
+    st = lib.xvcgpu_comm_unique_id(buf)
+    if st != 0:
+        raise XvcGpuError("xvcgpu_comm_unique_id failed with status %d" % st)
+    return bytes(buf)
+
+
+class Comm:
+    """The RCCL communicator of this process (one per GPU) with its own stream:
+    point-to-point transfers of pictures and plane rows (xvcgpu_comm_*)."""
+
+    def __init__(self, ctx, unique_id, world, rank):
+        self.ctx, self.world, self.rank = ctx, world, rank
+        buf = (C.c_uint8 * COMM_ID_BYTES).from_buffer_copy(unique_id)
+        p = _vp()
+        ctx._check(ctx.lib.xvcgpu_comm_create(ctx.h, buf, world, rank, C.byref(p)))
+        self.h = p.value
+
+    def _c(self, st):
+        self.ctx._check(st)
+
+    def wait_event(self, ev):
+        self._c(self.ctx.lib.xvcgpu_comm_wait_event(self.h, ev.h))
+
+    def record_event(self, ev):
+        self._c(self.ctx.lib.xvcgpu_comm_record_event(self.h, ev.h))
+
+    def sync(self):
+        self._c(self.ctx.lib.xvcgpu_comm_sync(self.h))
+
+    def group_begin(self):
+        self._c(self.ctx.lib.xvcgpu_comm_group_begin(self.h))
+
+    def group_end(self):
+        self._c(self.ctx.lib.xvcgpu_comm_group_end(self.h))
+
+    def send_picture(self, pic, dst):
+        self._c(self.ctx.lib.xvcgpu_comm_send_picture(self.h, pic.h_pic, dst))
+
+    def recv_picture(self, pic, src):
+        self._c(self.ctx.lib.xvcgpu_comm_recv_picture(self.h, pic.h_pic, src))
+
+    def send_rows(self, pic, y0, y1, dst, comp_mask=7):
+        self._c(self.ctx.lib.xvcgpu_comm_send_rows(self.h, pic.h_pic, comp_mask, y0, y1, dst))
+
+    def recv_rows(self, pic, y0, y1, src, comp_mask=7):
+        self._c(self.ctx.lib.xvcgpu_comm_recv_rows(self.h, pic.h_pic, comp_mask, y0, y1, src))
+
+    def all_reduce_sum_u64(self, dev_ptr, n):
+        self._c(self.ctx.lib.xvcgpu_comm_all_reduce_sum_u64(self.h, dev_ptr, n))
+
+    def destroy(self):
+        if self.h:
+            self.ctx.lib.xvcgpu_comm_destroy(self.h)
+            self.h = None
 
 
 class Picture:
@@ -385,6 +503,7 @@ class Picture:
 class Context:
     def __init__(self, device=0):
         self.lib = load_library()
+        self.device = device
         h = _vp()
         st = self.lib.xvcgpu_create(device, C.byref(h))
         if st != 0:

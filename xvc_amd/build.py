@@ -11,7 +11,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libxvcgpu.so")
-SOURCES = ["xvcgpu.hip", "xvcgpu_tables.cpp"]
+SOURCES = ["xvcgpu.hip", "xvcgpu_comm.hip", "xvcgpu_tables.cpp"]
 FLAGS = [
     "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
     # the few double-precision metric steps must evaluate op-for-op like the
