@@ -63,6 +63,13 @@ def parse():
                     help="N=1: replay one recorded HIP graph per step instead of "
                          "launching the kernels separately (measured ~3 %% slower: "
                          "the steps are GPU-bound, not launch-bound)")
+    ap.add_argument("--schedule", choices=["auto", "chains", "subgop", "rows"], default="auto",
+                    help="chains: independent picture chains, each picture referencing the one "
+                         "before (N=1 default); subgop: hierarchical sub-GOP 16 coded with the "
+                         "reference's ThreadEncoder policy on ranks x picture slots, references "
+                         "shipped by RCCL (N>1 default up to 1080p); rows: CTU-row shards of "
+                         "every picture with RCCL halo exchange (N>1 default above 1080p)")
+    ap.add_argument("--slots", type=int, default=3, help="subgop: pictures in flight per GPU")
     ap.add_argument("--chains", type=int, default=0,
                     help="(0 = automatic: 3, or 1 when one rank's share of a picture "
                          "exceeds 3840x2160, where a picture fills the chip by itself) "
@@ -235,6 +242,202 @@ def cpu_baseline(args, clip, bd, border):
 RDOQ_PACKED = None if os.environ.get("RDOQ_FUSED") is None else False
 
 
+def algorithmic_bytes(d, W, H):
+    """Algorithmic bytes per launch of every kernel of the pass (DESIGN.md
+    section 4); d: the pass's FrameDescriptors."""
+    S = 2
+    n_luma = sum(int(b["w"]) * int(b["h"]) for b in d.me)
+    n_all = int(1.5 * n_luma)
+    return {
+        # each plane read once: original + reference luma of the CUs
+        "me_search": 2 * n_luma * S,
+        # orig + reference read, reconstruction written, all three planes
+        "recon_from_me": 3 * n_all * S,
+        "mc_from_me": 2 * n_all * S,                 # reference read, prediction written
+        "fwd_transform": 3 * n_all * S,              # orig + pred read, coefficients written
+        "quant_rdo": 2 * n_all * S,                  # coefficients read, levels written
+        "inv_transform": 3 * n_all * S,              # levels + pred read, rec written
+        "residual_rdoq": 3 * n_all * S, "residual": 3 * n_all * S,
+        "cu_info": 84 * d.n_cus,
+        "deblock": 2 * n_all * S + 16 * (n_luma // 16),
+        "pad_border": 2 * 80 * (W + H + 160) * S * 2,
+        "picture_ssd": 2 * n_luma * S,
+    }
+
+
+class HostStagedComm:
+    """TESTING AID (XVC_BENCH_BACKEND=gloo): the interface of api.Comm with the
+    picture going through host memory and torch.distributed gloo, so that several
+    ranks can share the one GPU of a test box (RCCL refuses that).  Never used
+    for a measurement."""
+
+    def __init__(self, ctx, dist, world, rank):
+        self.ctx, self.dist, self.world, self.rank, self.h = ctx, dist, world, rank, None
+
+    def wait_event(self, ev):
+        ev.synchronize()
+
+    def record_event(self, ev):
+        ev.record(self.ctx)
+
+    def send_picture(self, pic, dst):
+        import torch
+        for a in pic.download(128):
+            self.dist.send(torch.from_numpy(np.ascontiguousarray(a).view(np.int16)), dst)
+
+    def recv_picture(self, pic, src):
+        import torch
+        planes = []
+        for c in range(3):
+            b = 128 >> (c > 0)
+            a = np.zeros(((pic.h >> (c > 0)) + 2 * b, (pic.w >> (c > 0)) + 2 * b), np.uint16)
+            self.dist.recv(torch.from_numpy(a.view(np.int16)), src)
+            planes.append(a)
+        pic.upload(planes, 128)
+
+    def sync(self):
+        self.ctx.sync()
+
+    def destroy(self):
+        pass
+
+
+def main_pictures(args, torch, api, pipeline, synth, world, rank, local_rank):
+    """N ranks x `slots` picture slots code the pictures of hierarchical sub-GOPs
+    (length 16, two references per list as the reference configures itself) in
+    the order and on the workers the reference's ThreadEncoder policy gives
+    (xvc_amd/host/xvc_picture_schedule.h); each finished reference picture goes
+    by RCCL send / recv to the ranks that list it (libxvcgpu.so's communicator,
+    its own stream).  A step = one picture = one hot-path frame pass against its
+    nearest L0 reference.  Warm-up and timed part are two consecutive parts of
+    one timeline; the timed part codes exactly --steps pictures."""
+    from xvc_amd import picture_parallel, schedule
+    bd, border = 10, api.BORDER_LUMA
+    W, H = args.width, args.height
+    rdoq = args.quant == "rdoq"
+    ctx = api.Context(local_rank)
+    comm, dist = None, None
+    if world > 1:
+        import torch.distributed as dist      # control plane only: id hand-over, barrier, max
+        dist.init_process_group("gloo")
+        if os.environ.get("XVC_BENCH_BACKEND", "nccl") == "gloo":    # testing aid, see class
+            comm, rccl_world = HostStagedComm(ctx, dist, world, rank), 0
+        else:
+            ids = [api.comm_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(ids, src=0)
+            comm = api.Comm(ctx, ids[0], world, rank)
+            rccl_world = ctx.lib.xvcgpu_comm_world(comm.h)
+    else:
+        rccl_world = 1
+    n_pictures = 1 + args.warmup + args.steps
+    sched = schedule.Schedule(n_pictures, 16, 2, world, args.slots)
+    clip = synth.SyntheticClip(W, H, bd)
+    origs = []
+    for n in range(args.frames):
+        p = ctx.picture(W, H, bd)
+        p.upload(pad_planes(clip.frame(n), border), border)
+        origs.append(p)
+    eng = picture_parallel.GpuPictureEngine(ctx, sched, rank, W, H, bd, args.qp, origs, comm,
+                                            rdoq=rdoq)
+    # the timeline position where the timed part starts: just before the
+    # (1 + warmup + 1)-th encode
+    enc = [i for i, o in enumerate(sched.ops) if o["kind"] == schedule.ENCODE]
+    split = enc[1 + args.warmup]
+
+    def barrier():
+        eng.sync()
+        if dist is not None:
+            dist.barrier()
+
+    picture_parallel.run_rank(sched, rank, eng, 0, split)
+    barrier()
+    t0 = time.perf_counter()
+    picture_parallel.run_rank(sched, rank, eng, split, -1)
+    barrier()
+    dt = time.perf_counter() - t0
+    coded = eng.encoded
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        c = torch.tensor([coded], dtype=torch.int64)
+        dist.all_reduce(c)
+        coded = int(c.item())
+    assert coded == n_pictures, (coded, n_pictures)
+    # checksums of the last pictures (POC -> CRC of the three planes), from
+    # whichever rank holds them: equal for every N
+    tail = {}
+    for i, p in enumerate(sched.pictures):
+        if int(p["poc"]) >= n_pictures - 8 and int(p["rank"]) == rank:
+            tail[int(p["poc"])] = ctx.picture_crc(eng.recs[i % eng.ring], 1).hex()
+    if dist is not None:
+        parts = [None] * world
+        dist.all_gather_object(parts, tail)
+        tail = {k: v for part in parts for k, v in part.items()}
+
+    roof = cpu = None
+    fp = eng.fps[0]
+    if rank == 0:
+        # per-kernel launch durations of the pass alone on rank 0 (the other ranks idle)
+        recs = [ctx.picture(W, H, bd), ctx.picture(W, H, bd)]
+        recs[0].upload(pad_planes(clip.frame(0), border), border)
+        times, reps, F = {}, 5, len(origs)
+        for i in range(1, F):
+            ref, rec = recs[(i + 1) % 2], recs[i % 2]
+            for name, fn in fp.kernel_steps(origs[i], ref, rec, ref_poc=i - 1):
+                fn()
+                ctx.sync()
+                ctx.timer_begin()
+                for _ in range(reps):
+                    fn()
+                times[name] = times.get(name, 0.0) + ctx.timer_end() / reps
+            fp.run(origs[i], ref, rec, ref_poc=i - 1)
+        times = {k: v / (F - 1) for k, v in times.items()}
+        dom = max(times, key=times.get)
+        alg = algorithmic_bytes(fp.desc, W, H)
+        achieved = alg[dom] / (times[dom] * 1e-3) / 1e9
+        roof = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": 8000.0,
+                "unit": "GB/s", "frac": achieved / 8000.0, "traffic": None,
+                "algorithmic_bytes": alg[dom], "ms_per_launch": times[dom], "measured": "alone",
+                "all_kernels_ms": {k: round(v, 4) for k, v in times.items()}}
+        if world == 1 and not args.no_cpu:
+            cpu = cpu_baseline(args, clip, bd, border)
+    if dist is not None:
+        dist.barrier()
+    if rank == 0:
+        n_xfer = int((sched.ops["kind"] == schedule.TRANSFER).sum())
+        print(json.dumps({
+            "metric": "hot-path frame passes/s (TZ + sub-pel ME, MC, transform + %s + "
+                      "dequant + inverse, deblock, pad, PSNR parts), bit-exact vs the "
+                      "reference's classes" % ("RDOQ" if rdoq else "QuantFast"),
+            "value": args.steps / dt, "unit": "frame passes/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
+            "pictures_in_flight": world * args.slots, "higher_is_better": True,
+            "scaling": "strong" if world > 1 else "weak",
+            "vs_baseline": None, "dtype": "u16", "data": "synthetic",
+            "rccl_world_size": rccl_world,
+            "tail_crc": {str(k): tail[k] for k in sorted(tail)},
+            "config": {"workload": "%dx%d yuv420p 30fps synthetic, QP %d, internal bitdepth 10, "
+                                   "16x16 CUs, TZ range 96, %s" %
+                                   (W, H, args.qp, "RDOQ" if rdoq else "QuantFast"),
+                       "cus_per_picture": fp.desc.n_cus_total,
+                       "parallelism": "picture-level: sub-GOP 16 (layers of 1, 1, 2, 4, 8 "
+                                      "pictures), ThreadEncoder policy on %d rank(s) x %d picture "
+                                      "slots, each picture against its nearest L0 reference; "
+                                      "%d reference transfers of %.1f MB by %s for "
+                                      "%d pictures" % (world, args.slots, n_xfer,
+                                                       origs[0].nbytes() / 1e6,
+                                                       "RCCL send/recv" if rccl_world else
+                                                       "HOST STAGING (testing aid)", n_pictures),
+                       "schedule_makespan_pictures": int(sched.makespan)},
+            "roofline": roof, "cpu_baseline": cpu}))
+    if comm is not None:
+        comm.sync()
+        comm.destroy()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
 def main():
     args = parse()
     # HIP maps streams onto 4 hardware queues by default; torch / RCCL take
@@ -253,6 +456,20 @@ def main():
     backend = os.environ.get("XVC_BENCH_BACKEND", "nccl")
     if "XVC_BENCH_DEVICE" in os.environ:
         local_rank = int(os.environ["XVC_BENCH_DEVICE"])
+    mode = args.schedule
+    if mode == "auto":
+        mode = "chains" if world == 1 and not args.force_sharded else \
+            ("subgop" if args.width * args.height <= 1920 * 1088 and not args.force_sharded
+             else "rows")
+    if mode == "subgop":
+        if args.gpus != world and world > 1:
+            raise SystemExit("--gpus must equal WORLD_SIZE")
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a GPU (there is no CPU fallback)")
+        if "XVC_BENCH_DEVICE" in os.environ:
+            local_rank = int(os.environ["XVC_BENCH_DEVICE"])
+        torch.cuda.set_device(local_rank)
+        return main_pictures(args, torch, api, pipeline, synth, world, rank, local_rank)
     multi = world > 1 or args.force_sharded     # row-sharded engine + process groups
     if multi:
         import torch.distributed as dist
@@ -277,9 +494,22 @@ def main():
         from xvc_amd import sharded
         # every chain on its context's own stream (handed to torch so that the
         # RCCL operations are ordered on it) - not torch's default stream
+        # the exchange natively on RCCL (libxvcgpu.so's communicator, one per chain);
+        # XVC_BENCH_COMM=torch keeps torch.distributed's all_to_all_single on the data path
+        native = backend == "nccl" and os.environ.get("XVC_BENCH_COMM", "native") == "native"
+
+        def new_comm(c):
+            if not native:
+                return None
+            ids = [api.comm_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(ids, src=0)
+            return api.Comm(c, ids[0], world, rank)
+        comm0 = new_comm(ctx)
+        rccl_world = ctx.lib.xvcgpu_comm_world(comm0.h) if comm0 is not None else \
+            (dist.get_world_size() if backend == "nccl" else 0)
         runner = sharded.make_gpu_sharded(ctx, W, H, bd, args.qp, rank, world,
                                           torch.device("cuda", local_rank), dist,
-                                          own_stream=True, rdoq=rdoq)
+                                          own_stream=True, rdoq=rdoq, native_comm=comm0)
         ts0 = runner.e.stream
     else:
         runner = None
@@ -321,10 +551,11 @@ def main():
         phase = (c * cycle_len) // n_chains
         first = pad_planes(clip.frame(phase if phase < F else 2 * F - 2 - phase), border)
         if multi:
+            ccomm = new_comm(cctx)
             crun = sharded.make_gpu_sharded(cctx, W, H, bd, args.qp, rank, world,
                                             torch.device("cuda", local_rank), dist,
-                                            group=dist.new_group(), own_stream=True,
-                                            rdoq=rdoq)
+                                            group=None if native else dist.new_group(),
+                                            own_stream=True, rdoq=rdoq, native_comm=ccomm)
             ts = crun.e.stream
             crecs, cfp = crun.e.pictures, crun.e.fp
         else:
@@ -485,25 +716,7 @@ def main():
             ms = [ctx.timer_between(2 * q, 2 * q + 1) for q in range(cycle)]
             in_flight = {"kernel": "me_search", "chains": n_chains,
                          "ms_per_launch": sum(ms) / len(ms)}
-        # algorithmic bytes per launch
-        S = 2
-        n_luma = sum(int(b["w"]) * int(b["h"]) for b in d.me)
-        n_all = int(1.5 * n_luma)
-        alg = {
-            # each plane read once: original + reference luma of the CUs
-            "me_search": 2 * n_luma * S,
-            # orig + reference read, reconstruction written, all three planes
-            "recon_from_me": 3 * n_all * S,
-            "mc_from_me": 2 * n_all * S,                 # reference read, prediction written
-            "fwd_transform": 3 * n_all * S,              # orig + pred read, coefficients written
-            "quant_rdo": 2 * n_all * S,                  # coefficients read, levels written
-            "inv_transform": 3 * n_all * S,              # levels + pred read, rec written
-            "residual_rdoq": 3 * n_all * S, "residual": 3 * n_all * S,
-            "cu_info": 84 * d.n_cus,
-            "deblock": 2 * n_all * S + 16 * (n_luma // 16),
-            "pad_border": 2 * 80 * (W + H + 160) * S * 2,
-            "picture_ssd": 2 * n_luma * S,
-        }
+        alg = algorithmic_bytes(d, W, H)
         # The profile carries the MD5 of the kernel sources it was taken from:
         # a figure from other kernels than the ones running now is not reported.
         traffic = None
@@ -558,6 +771,7 @@ def main():
             "higher_is_better": True,
             "scaling": "strong" if world > 1 else "weak",
             "vs_baseline": None, "dtype": "u16", "data": "synthetic",
+            "rccl_world_size": rccl_world if multi else 1,
             "psnr_y": psnr_y,
             "config": {"workload": "%dx%d yuv420p 30fps synthetic, QP %d, internal "
                                    "bitdepth 10, 16x16 CUs, TZ range 96, %s" %
@@ -570,7 +784,10 @@ def main():
                                         "single" if n_chains == 1 else
                                         "%d independent picture chains in flight" % n_chains)
                                        if not multi else
-                                       "cu-row-shard%d x %d chains in flight" % (world, n_chains))},
+                                       "cu-row-shard%d x %d chains in flight, halo rows by %s" %
+                                       (world, n_chains,
+                                        "RCCL send/recv groups issued by libxvcgpu.so" if native
+                                        else "torch.distributed (%s)" % backend))},
             "roofline": roof, "cpu_baseline": cpu, "stream_decode": decode,
         }
         print(json.dumps(out))

@@ -134,6 +134,9 @@ xvcgpu_status xvcgpu_comm_send_rows(xvcgpu_comm *comm, const xvcgpu_picture *pic
                                     int y0, int y1, int dst);
 xvcgpu_status xvcgpu_comm_recv_rows(xvcgpu_comm *comm, xvcgpu_picture *pic, int comp_mask, int y0,
                                     int y1, int src);
+/* Any contiguous device range (CU metadata rows of a shard boundary). */
+xvcgpu_status xvcgpu_comm_send_bytes(xvcgpu_comm *comm, const void *d_src, size_t bytes, int dst);
+xvcgpu_status xvcgpu_comm_recv_bytes(xvcgpu_comm *comm, void *d_dst, size_t bytes, int src);
 /* Sum over the ranks of n 64-bit counters in device memory (PSNR parts of row
  * shards), in place. */
 xvcgpu_status xvcgpu_comm_all_reduce_sum_u64(xvcgpu_comm *comm, uint64_t *d_values, int n);

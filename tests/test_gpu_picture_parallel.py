@@ -146,3 +146,51 @@ def test_rccl_self_exchange(gpu):
     comm.destroy()
     for x in (A, B, Cc):
         x.destroy()
+
+
+def test_bench_picture_mode_same_pictures_for_any_world(tmp_path):
+    """bench.py's picture-level mode as real processes: 1 rank, and 2 ranks sharing
+    this GPU (pictures staged through the host - RCCL refuses two ranks on one
+    device): the checksums of the last pictures agree."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    common = ["bench.py", "--schedule", "subgop", "--no-cpu", "--width", "352", "--height",
+              "288", "--steps", "40", "--warmup", "17", "--frames", "5"]
+    one = subprocess.run([sys.executable] + common, cwd=root, capture_output=True, text=True)
+    assert one.returncode == 0, one.stderr[-2000:]
+    a = json.loads(one.stdout.strip().splitlines()[-1])
+    env = dict(os.environ, XVC_BENCH_BACKEND="gloo", XVC_BENCH_DEVICE="0")
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+                          "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", "29541"] + common + ["--gpus", "2"],
+                         cwd=root, capture_output=True, text=True, env=env)
+    assert two.returncode == 0, two.stderr[-2000:]
+    b = json.loads([l for l in two.stdout.splitlines() if l.startswith("{")][-1])
+    assert a["tail_crc"] == b["tail_crc"] and len(a["tail_crc"]) == 8
+    assert a["rccl_world_size"] == 1 and b["n_gpus"] == 2
+
+
+def test_native_row_comm_self_exchange(gpu):
+    """sharded.NativeComm (the row shards' exchange on libxvcgpu.so's
+    communicator): slabs sent to the own rank arrive, ordered after the
+    producing kernel and before the consuming copy."""
+    import torch
+    from xvc_amd import sharded
+    api, ctx = gpu
+    comm = api.Comm(ctx, api.comm_unique_id(), 1, 0)
+    nc = sharded.NativeComm(ctx, comm)
+    a = torch.arange(0, 1 << 16, dtype=torch.int32, device="cuda").view(torch.uint8)
+    b = torch.zeros_like(a)
+    c2 = torch.full((64,), 7, dtype=torch.uint8, device="cuda")
+    d = torch.zeros_like(c2)
+    torch.cuda.synchronize()
+    nc.exchange([(0, a), (0, c2)], [(0, b), (0, d)])
+    ctx.sync()
+    assert torch.equal(a, b) and torch.equal(c2, d)
+    t = torch.tensor([3, 9], dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()
+    assert nc.allreduce_sum(t).tolist() == [3, 9]
+    comm.destroy()

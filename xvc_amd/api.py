@@ -150,6 +150,7 @@ SYMBOLS = [
     "xvcgpu_comm_record_event", "xvcgpu_comm_sync", "xvcgpu_comm_group_begin",
     "xvcgpu_comm_group_end", "xvcgpu_comm_send_picture", "xvcgpu_comm_recv_picture",
     "xvcgpu_comm_send_rows", "xvcgpu_comm_recv_rows", "xvcgpu_comm_all_reduce_sum_u64",
+    "xvcgpu_comm_send_bytes", "xvcgpu_comm_recv_bytes",
 ]
 
 _vp = C.c_void_p
@@ -283,6 +284,8 @@ def load_library():
         "xvcgpu_comm_send_rows": [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int],
         "xvcgpu_comm_recv_rows": [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int],
         "xvcgpu_comm_all_reduce_sum_u64": [_vp, _vp, C.c_int],
+        "xvcgpu_comm_send_bytes": [_vp, _vp, C.c_size_t, C.c_int],
+        "xvcgpu_comm_recv_bytes": [_vp, _vp, C.c_size_t, C.c_int],
     }
     lib.xvcgpu_event_destroy.restype = None
     lib.xvcgpu_event_destroy.argtypes = [_vp]
@@ -419,6 +422,12 @@ class Comm:
     def recv_rows(self, pic, y0, y1, src, comp_mask=7):
         self._c(self.ctx.lib.xvcgpu_comm_recv_rows(self.h, pic.h_pic, comp_mask, y0, y1, src))
 
+    def send_bytes(self, dev_ptr, nbytes, dst):
+        self._c(self.ctx.lib.xvcgpu_comm_send_bytes(self.h, dev_ptr, nbytes, dst))
+
+    def recv_bytes(self, dev_ptr, nbytes, src):
+        self._c(self.ctx.lib.xvcgpu_comm_recv_bytes(self.h, dev_ptr, nbytes, src))
+
     def all_reduce_sum_u64(self, dev_ptr, n):
         self._c(self.ctx.lib.xvcgpu_comm_all_reduce_sum_u64(self.h, dev_ptr, n))
 
@@ -460,6 +469,10 @@ class Picture:
             ss[c] = a.strides[0] // 2
             keep.append(a)
         return pp, ss, keep
+
+    def nbytes(self):
+        """Device bytes of the padded picture (what one transfer moves)."""
+        return int(self.ctx.lib.xvcgpu_picture_bytes(self.w, self.h))
 
     def upload(self, planes, border=0):
         """planes: [Y,U,V] uint16 2-D arrays; with border>0 the arrays include

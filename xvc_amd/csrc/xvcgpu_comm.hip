@@ -276,6 +276,18 @@ xvcgpu_status xvcgpu_comm_recv_rows(xvcgpu_comm *comm, xvcgpu_picture *pic, int 
   return rows_xfer(comm, pic, comp_mask, y0, y1, src, false);
 }
 
+xvcgpu_status xvcgpu_comm_send_bytes(xvcgpu_comm *comm, const void *d_src, size_t bytes, int dst) {
+  if (!comm || !d_src || !bytes || dst < 0 || dst >= comm->world) return XVCGPU_INVALID_ARGUMENT;
+  NCCL_TRY(comm->ctx, rccl().Send(d_src, bytes, ncclUint8, dst, comm->comm, comm->stream));
+  return XVCGPU_OK;
+}
+
+xvcgpu_status xvcgpu_comm_recv_bytes(xvcgpu_comm *comm, void *d_dst, size_t bytes, int src) {
+  if (!comm || !d_dst || !bytes || src < 0 || src >= comm->world) return XVCGPU_INVALID_ARGUMENT;
+  NCCL_TRY(comm->ctx, rccl().Recv(d_dst, bytes, ncclUint8, src, comm->comm, comm->stream));
+  return XVCGPU_OK;
+}
+
 xvcgpu_status xvcgpu_comm_all_reduce_sum_u64(xvcgpu_comm *comm, uint64_t *d_values, int n) {
   if (!comm || !d_values || n < 1) return XVCGPU_INVALID_ARGUMENT;
   NCCL_TRY(comm->ctx, rccl().AllReduce(d_values, d_values, (size_t)n, ncclUint64, ncclSum,

@@ -229,8 +229,12 @@ void PictureSchedule::BuildTimeline() {
   });
 }
 
-int PictureSchedule::Run(int rank, const xvc_sched_callbacks &cb, void *user) const {
-  for (const xvc_sched_op &op : ops_) {
+int PictureSchedule::Run(int rank, const xvc_sched_callbacks &cb, void *user, int first_op,
+                         int end_op) const {
+  const int n = static_cast<int>(ops_.size());
+  if (end_op < 0 || end_op > n) end_op = n;
+  for (int k = first_op < 0 ? 0 : first_op; k < end_op; k++) {
+    const xvc_sched_op &op = ops_[k];
     const xvc_sched_picture &p = pics_[op.picture];
     int st = 0;
     if (op.kind == XVC_SCHED_ENCODE) {
@@ -295,6 +299,11 @@ int xvc_sched_tid_from_doc(int doc, int l) {
 int xvc_schedule_run(const xvc_schedule *s, int rank, const xvc_sched_callbacks *cb, void *user) {
   if (!s || !cb) return -1;
   return s->s.Run(rank, *cb, user);
+}
+int xvc_schedule_run_range(const xvc_schedule *s, int rank, const xvc_sched_callbacks *cb,
+                           void *user, int first_op, int end_op) {
+  if (!s || !cb) return -1;
+  return s->s.Run(rank, *cb, user, first_op, end_op);
 }
 
 }  // extern "C"

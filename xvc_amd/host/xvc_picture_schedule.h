@@ -99,6 +99,10 @@ typedef struct xvc_sched_callbacks {
 // every TRANSFER that names it as source (send) or destination (recv), in
 // timeline order.
 int xvc_schedule_run(const xvc_schedule *s, int rank, const xvc_sched_callbacks *cb, void *user);
+// The same over timeline entries [first_op, end_op) only (a warm-up part and a
+// timed part of one sequence).
+int xvc_schedule_run_range(const xvc_schedule *s, int rank, const xvc_sched_callbacks *cb,
+                           void *user, int first_op, int end_op);
 
 }  // extern "C"
 
@@ -125,7 +129,8 @@ class PictureSchedule {
   // one extra sub-GOP per additional worker, encoder.cc:245-260): no picture
   // starts while one more than `window` places before it is unfinished
   int window() const { return window_; }
-  int Run(int rank, const xvc_sched_callbacks &cb, void *user) const;
+  int Run(int rank, const xvc_sched_callbacks &cb, void *user, int first_op = 0,
+          int end_op = -1) const;
 
  private:
   void BuildSequence(int num_pictures, int sub_gop_length);

@@ -29,9 +29,10 @@ def ring_size(schedule):
     return schedule.window + 2 * schedule.sub_gop_length + 1
 
 
-def run_rank(schedule, rank, engine):
-    """Walks the timeline as `rank`.  engine.encode(p, index, ref_indices),
-    engine.send(p, index, dst), engine.recv(p, index, src)."""
+def run_rank(schedule, rank, engine, first_op=0, end_op=-1):
+    """Walks the timeline (or entries [first_op, end_op) of it) as `rank`.
+    engine.encode(p, index, ref_indices), engine.send(p, index, dst),
+    engine.recv(p, index, src)."""
     P = schedule.pictures
     idx = schedule.index_of_poc
 
@@ -47,7 +48,7 @@ def run_rank(schedule, rank, engine):
     schedule.run(rank,
                  lambda p, i: engine.encode(p, i, refs(p)),
                  lambda p, i, dst: engine.send(p, i, dst),
-                 lambda p, i, src: engine.recv(p, i, src))
+                 lambda p, i, src: engine.recv(p, i, src), first_op, end_op)
 
 
 class GpuPictureEngine:

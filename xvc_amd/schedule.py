@@ -49,6 +49,8 @@ def lib():
         L.xvc_schedule_ops.restype = C.c_void_p
         L.xvc_schedule_ops.argtypes = [C.c_void_p]
         L.xvc_schedule_run.argtypes = [C.c_void_p, C.c_int, C.POINTER(_Callbacks), C.c_void_p]
+        L.xvc_schedule_run_range.argtypes = [C.c_void_p, C.c_int, C.POINTER(_Callbacks),
+                                             C.c_void_p, C.c_int, C.c_int]
         _lib = L
     return _lib
 
@@ -90,9 +92,10 @@ class Schedule:
         self.sub_gop_length, self.ranks, self.slots_per_rank = sub_gop_length, ranks, slots_per_rank
         self.index_of_poc = {int(p["poc"]): i for i, p in enumerate(self.pictures)}
 
-    def run(self, rank, encode, send=None, recv=None):
+    def run(self, rank, encode, send=None, recv=None, first_op=0, end_op=-1):
         """encode(picture_record, index), send(record, index, dst), recv(record,
-        index, src); exceptions raised inside propagate after the walk stops."""
+        index, src); exceptions raised inside propagate after the walk stops.
+        first_op / end_op: a part of the timeline only."""
         err = []
 
         def guard(fn, *a):
@@ -106,7 +109,7 @@ class Schedule:
             _ENCODE_CB(lambda u, p, i: guard(encode, self.pictures[i], i)),
             _XFER_CB(lambda u, p, i, r: guard(send, self.pictures[i], i, r) if send else 0),
             _XFER_CB(lambda u, p, i, r: guard(recv, self.pictures[i], i, r) if recv else 0))
-        st = lib().xvc_schedule_run(self.h, rank, C.byref(cb), None)
+        st = lib().xvc_schedule_run_range(self.h, rank, C.byref(cb), None, first_op, end_op)
         if err:
             raise err[0]
         if st:

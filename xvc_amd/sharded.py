@@ -205,6 +205,43 @@ class TorchComm:
         return t
 
 
+class NativeComm:
+    """The same neighbour exchange issued natively: ncclSend / ncclRecv of every
+    slab inside one ncclGroup on libxvcgpu.so's communicator and its own stream
+    (xvcgpu_comm_*), ordered with the context's kernels by two events - no
+    staging copies, no torch.distributed on the data path.  ctx: the api.Context
+    whose stream produces / consumes the slabs; comm: an api.Comm."""
+
+    def __init__(self, ctx, comm):
+        from . import api
+        self.ctx, self.comm = ctx, comm
+        self.rank, self.world = comm.rank, comm.world
+        self.before, self.after = api.Event(ctx), api.Event(ctx)
+
+    def exchange(self, sends, recvs, make_copier=None):
+        if not sends and not recvs:
+            return
+        c = self.comm
+        self.before.record(self.ctx)        # the slabs are final / free to overwrite
+        c.wait_event(self.before)
+        c.group_begin()
+        for peer, t in sends:
+            c.send_bytes(t.data_ptr(), t.numel() * t.element_size(), peer)
+        for peer, t in recvs:
+            c.recv_bytes(t.data_ptr(), t.numel() * t.element_size(), peer)
+        c.group_end()
+        c.record_event(self.after)
+        self.after.wait(self.ctx)           # later kernels see the received rows
+
+    def allreduce_sum(self, t):
+        c = self.comm
+        self.before.record(self.ctx)
+        c.wait_event(self.before)
+        c.all_reduce_sum_u64(t.data_ptr(), t.numel())
+        c.sync()                            # the caller reads the sums on the host
+        return t
+
+
 class ShardedFramePass:
     HALO = 4  # luma rows on each side of a shard boundary
 
@@ -469,7 +506,7 @@ class _ExternalBuffer:
 
 
 def make_gpu_sharded(ctx, width, height, bitdepth, qp, rank, world, device, dist,
-                     group=None, own_stream=False, rdoq=False):
+                     group=None, own_stream=False, rdoq=False, native_comm=None):
     """The engine's kernels run on torch's current stream at the time of this
     call, or - own_stream - on the context's own stream, exposed to torch as
     `runner.e.stream`; either way call run() under `with torch.cuda.stream(
@@ -479,4 +516,6 @@ def make_gpu_sharded(ctx, width, height, bitdepth, qp, rank, world, device, dist
     with torch_stream_of(ctx, device, own_stream):
         engine = GpuEngine(ctx, width, height, bitdepth, qp, rows[rank], device,
                            own_stream=own_stream, rdoq=rdoq)
-    return ShardedFramePass(engine, TorchComm(dist, rank, world, group), rank, world)
+    comm = NativeComm(ctx, native_comm) if native_comm is not None else \
+        TorchComm(dist, rank, world, group)
+    return ShardedFramePass(engine, comm, rank, world)
