@@ -135,6 +135,7 @@ def stream_decode_figure(ctx, api):
                      "reference encoder (tests/golden/stream_c1.npz)",
            "pictures_per_s": fx.n / dt, "ms_per_picture": 1e3 * dt / fx.n,
            "md5_match": bool(ok), "includes": "host planning + upload of the parsed syntax"}
+    out["encoder_me_batches"] = encoder_me_figure(ctx, api, fx, pics, w, h)
     dec.destroy()
     for p in pics:
         p.destroy()
@@ -152,6 +153,77 @@ def stream_decode_figure(ctx, api):
         out["cpu_reference_pictures_per_s"] = n * fx.n / (time.perf_counter() - t0)
         out["cpu_reference"] = "the reference decoder (parse + reconstruct), 1 thread"
         lib.xr_stream_release()
+    return out
+
+
+def encoder_me_figure(ctx, api, fx, pics, w, h):
+    """Second workload: the motion searches the reference encoder actually made
+    for one 1080p picture of that stream (POC 2, both reference pictures: every
+    CU shape its RD search tried, 4x4 to 64x64, with the real AMVP predictors,
+    previous-CU vectors, fullpel-MV CUs; tests/golden/me_calls_c1.npz, captured
+    by tools/gen_me_golden.py) as two xvcgpu_me_search batches against the
+    decoded reference pictures.  Results are checked against the reference's."""
+    import test_me_calls as tmc
+    calls = tmc.load_calls("c1")
+    calls = calls[calls["use_lic"] == 0]
+    poc = int(calls["poc"][0])
+    by_poc = {int(fx.info[i]["poc"]): pics[i] for i in range(fx.n)}
+    O = ctx.picture(w, h, 10)
+    O.upload([tmc.original_luma(w, h, poc), None, None], tmc.BL)
+    batches, ok = [], True
+    for ref_poc in sorted(set(calls["ref_poc"].tolist())):
+        sel = calls[calls["ref_poc"] == ref_poc]
+        b = np.zeros(len(sel), api.ME_DTYPE)
+        for k in ("x", "y", "w", "h", "depth_nonzero", "fullpel_mv", "mvp_x", "mvp_y", "prev_x",
+                  "prev_y", "lambda16", "search_range"):
+            b[k] = sel[k]
+        db, dr = ctx.buffer(b), ctx.alloc(api.MERES_DTYPE.itemsize * len(sel))
+        batches.append((by_poc[ref_poc], db, dr, sel))
+    flags = api.ME_FULLPEL | api.ME_SUBPEL
+
+    def run():
+        for ref, db, dr, sel in batches:
+            ctx.me_search_dev(O, ref, flags, db.ptr, len(sel), dr.ptr, 64)
+    run()
+    ctx.sync()
+    for ref, db, dr, sel in batches:
+        res = dr.to_array(api.MERES_DTYPE, len(sel))
+        ok &= bool(np.array_equal(res["mv_x"], sel["mv_x"]) and
+                   np.array_equal(res["mv_y"], sel["mv_y"]) and
+                   np.array_equal(res["subpel_dist"], sel["dist"]))
+    reps = 10
+    ctx.timer_begin()
+    for _ in range(reps):
+        run()
+    ms = ctx.timer_end() / reps
+    n = int(len(calls))
+    samples = int((calls["w"].astype(np.int64) * calls["h"]).sum())
+    out = {"workload": "all %d uni-directional motion searches of the reference encoder's RD "
+                       "search for one 1080p B picture (POC %d vs POC %s), block shapes 4x4..64x64"
+                       % (n, poc, "/".join(str(int(r)) for r in sorted(set(calls["ref_poc"].tolist())))),
+           "ms": ms, "searches_per_s": n / (ms * 1e-3), "block_samples": samples,
+           "ns_per_block_sample": 1e6 * ms / samples, "matches_reference": ok}
+    for _, db, dr, _ in batches:
+        db.free()
+        dr.free()
+    O.destroy()
+    import oracle_lib as ol
+    if ol.have_ref():       # the reference's own classes on a bounded sample, one thread
+        xr = ol.Lib("xr")
+        rec = {p: np.ascontiguousarray(np.pad(pic.download(0)[0], tmc.BL, mode="edge"))
+               for p, pic in by_poc.items() if p in set(calls["ref_poc"].tolist())}
+        orig = tmc.original_luma(w, h, poc)
+        t0, k = time.perf_counter(), 0
+        for c in calls[::37]:
+            st = tmc.me_struct(c)
+            fp, _ = xr.tz_search(10, st, w, h, orig, rec[int(c["ref_poc"])], tmc.BL)
+            if not c["fullpel_mv"]:
+                xr.subpel_search(10, st, w, h, orig, rec[int(c["ref_poc"])], tmc.BL, fp)
+            k += 1
+            if time.perf_counter() - t0 > 3.0:
+                break
+        out["cpu_reference_searches_per_s"] = k / (time.perf_counter() - t0)
+        out["cpu_reference"] = "TzSearch::Search + SubpelSearch of oracle/_ref, 1 thread, every 37th call"
     return out
 
 

@@ -258,7 +258,8 @@ xvcgpu_status xvcgpu_mc_metric_batch(xvcgpu_ctx *ctx, const xvcgpu_picture *orig
  * (inter_search.cc:606-662, inter_tz_search.cc:84-171, inter_search.cc:
  * 893-964).  One result per xvcgpu_me_block, bit-identical to running the
  * reference search on that block with the same predictor inputs.
- * Blocks: w, h in {4, 8, 16, 32, 64}, at least 32 samples; x, y multiples of 4
+ * Blocks: w, h in {4, 8, 16, 32, 64} (4x4 included: the reference's RD search
+ * tries it); x, y multiples of 4
  * inside the picture.  The descriptors live in device memory, so a job the
  * search cannot take (any other size, or larger than max_block_size of
  * xvcgpu_me_search_sized) is reported in its result slot instead of an error

@@ -58,8 +58,55 @@
 #include "xvc_enc_lib/picture_encoder.h"
 #include "xvc_enc_lib/rdo_quant.h"
 #include "xvc_enc_lib/sample_metric.h"
+/* Observation hook for the uni-directional motion search of a real encoder run
+ * (tools/gen_me_golden.py): InterSearch::MotionEstNormal constructs a TzSearch
+ * and calls Search() on it (inter_search.cc:631-637); while inter_search.cc is
+ * compiled below the name resolves to this wrapper, which forwards to the
+ * reference's TzSearch and - when capturing - records the call's inputs, its
+ * full-pel result, and the sub-pel result the reference's own SubpelSearch /
+ * GetSubpelDist give from there (what MotionEstNormal does next, :645-657). */
+namespace xvc {
+class ObservedTzSearch;
+}
+namespace xr_me {
+struct Call {
+  int32_t poc, ref_poc;
+  int16_t x, y;
+  uint8_t w, h, depth_nonzero, fullpel_mv;
+  int32_t use_lic;   /* AC-only metrics (GetFullpelMetric / GetSubpelMetric) */
+  int32_t mvp_x, mvp_y, prev_x, prev_y;
+  uint32_t lambda16;
+  int32_t search_range;
+  int32_t fullpel_x, fullpel_y, mv_x, mv_y;
+  uint32_t dist;
+};
+extern bool g_capture;
+extern int g_only_poc;
+extern std::vector<Call> g_calls;
+}  // namespace xr_me
+namespace xvc {
+class ObservedTzSearch {
+public:
+  ObservedTzSearch(const YuvPicture &orig_pic, const InterPrediction &inter_pred,
+                   const EncoderSettings &encoder_settings, int search_range)
+    : real_(orig_pic, inter_pred, encoder_settings, search_range),
+    orig_pic_(orig_pic), inter_pred_(inter_pred), search_range_(search_range) {
+  }
+  MvFullpel Search(const CodingUnit &cu, const Qp &qp, const SampleMetric &metric,
+                   const MotionVector &mvp, const YuvPicture &ref_pic,
+                   const MvFullpel &mv_min, const MvFullpel &mv_max,
+                   const MvFullpel &prev_search);
+private:
+  TzSearch real_;
+  const YuvPicture &orig_pic_;
+  const InterPrediction &inter_pred_;
+  int search_range_;
+};
+}  // namespace xvc
+#define TzSearch ObservedTzSearch
 /* member templates (SubpelSearch<>, ...) are defined only in the .cc */
 #include "xvc_enc_lib/inter_search.cc"
+#undef TzSearch
 /* IntraPrediction::NeighborState (argument of ComputeRefSamples) likewise */
 #include "xvc_common_lib/intra_prediction.cc"
 #undef private
@@ -1357,6 +1404,89 @@ void StoreContexts(const Contexts &ctx, xvcgpu_rdoq_contexts *c) {
 }  // namespace
 
 const uint32_t *xr_entropy_bits_table(void) { return &ContextModel::kEntropyBits_[0]; }
+
+}  /* extern "C" (reopened below) */
+
+namespace xr_me {
+bool g_capture = false;
+int g_only_poc = -1;
+std::vector<Call> g_calls;
+}  // namespace xr_me
+
+namespace xvc {
+MvFullpel ObservedTzSearch::Search(const CodingUnit &cu, const Qp &qp, const SampleMetric &metric,
+                                   const MotionVector &mvp, const YuvPicture &ref_pic,
+                                   const MvFullpel &mv_min, const MvFullpel &mv_max,
+                                   const MvFullpel &prev_search) {
+  const MvFullpel best = real_.Search(cu, qp, metric, mvp, ref_pic, mv_min, mv_max, prev_search);
+  const int poc = static_cast<int>(cu.GetPicData()->GetPoc());
+  if (!xr_me::g_capture || (xr_me::g_only_poc >= 0 && poc != xr_me::g_only_poc)) return best;
+  const YuvComponent comp = YuvComponent::kY;
+  xr_me::Call c;
+  std::memset(&c, 0, sizeof(c));
+  c.poc = poc;
+  c.ref_poc = -1;
+  const ReferencePictureLists *rpl = cu.GetRefPicLists();
+  for (int l = 0; l < 2 && c.ref_poc < 0; l++) {
+    const RefPicList list = l ? RefPicList::kL1 : RefPicList::kL0;
+    for (int i = 0; i < rpl->GetNumRefPics(list); i++)
+      if (rpl->GetRefPic(list, i) == &ref_pic) {
+        c.ref_poc = static_cast<int>(rpl->GetRefPoc(list, i));
+        break;
+      }
+  }
+  c.x = static_cast<int16_t>(cu.GetPosX(comp));
+  c.y = static_cast<int16_t>(cu.GetPosY(comp));
+  c.w = static_cast<uint8_t>(cu.GetWidth(comp));
+  c.h = static_cast<uint8_t>(cu.GetHeight(comp));
+  c.depth_nonzero = cu.GetDepth() != 0;
+  c.fullpel_mv = cu.GetFullpelMv();
+  c.use_lic = cu.GetUseLic() ? 1 : 0;
+  c.mvp_x = mvp.x;
+  c.mvp_y = mvp.y;
+  c.prev_x = prev_search.x;
+  c.prev_y = prev_search.y;
+  c.lambda16 = static_cast<uint32_t>(std::floor(65536.0 * qp.GetLambdaSqrt()));
+  c.search_range = search_range_;
+  c.fullpel_x = best.x;
+  c.fullpel_y = best.y;
+  /* the sub-pel stage from this full-pel position, by the reference's own code */
+  InterSearch &is = const_cast<InterSearch &>(static_cast<const InterSearch &>(inter_pred_));
+  SampleMetric subpel_metric(is.simd_.sample_metric, is.bitdepth_, is.GetSubpelMetric(cu));
+  auto orig_buffer = orig_pic_.GetSampleBuffer(comp, cu.GetPosX(comp), cu.GetPosY(comp));
+  SampleBufferStorage pred_storage(constants::kMaxBlockSize, constants::kMaxBlockSize);
+  SampleBuffer &pred = pred_storage;
+  Distortion dist = 0;
+  MotionVector mv;
+  if (cu.GetFullpelMv()) {
+    mv = MotionVector(best);
+    dist = is.GetSubpelDist(cu, qp, ref_pic, subpel_metric, mv, orig_buffer, &pred);
+  } else {
+    mv = is.SubpelSearch(cu, qp, subpel_metric, ref_pic, mvp, best, orig_buffer, &pred, &dist);
+  }
+  c.mv_x = mv.x;
+  c.mv_y = mv.y;
+  c.dist = static_cast<uint32_t>(dist);
+  xr_me::g_calls.push_back(c);
+  return best;
+}
+}  // namespace xvc
+
+extern "C" {
+
+/* Capture control for the hook above: start (only_poc < 0: every picture),
+ * then run an encode (xr_stream_encode), then read the records. */
+void xr_me_capture_begin(int only_poc) {
+  xr_me::g_calls.clear();
+  xr_me::g_only_poc = only_poc;
+  xr_me::g_capture = true;
+}
+long xr_me_capture_end(void) {
+  xr_me::g_capture = false;
+  return static_cast<long>(xr_me::g_calls.size());
+}
+int xr_me_call_size(void) { return static_cast<int>(sizeof(xr_me::Call)); }
+const void *xr_me_calls(void) { return xr_me::g_calls.data(); }
 
 /* Sub-GOP arithmetic (segment_header.cc:135-175) as the encoder calls it:
  * sub_gop_start_poc = the POC the picture's sub-GOP starts after (encoder.cc:97). */

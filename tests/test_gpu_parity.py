@@ -153,8 +153,6 @@ def me_blocks(rng, api, pw, ph, n):
     blocks = np.zeros(n, api.ME_DTYPE)
     for i in range(n):
         w = int(rng.choice([4, 8, 16, 32, 64])); h = int(rng.choice([4, 8, 16, 32, 64]))
-        if w * h < 32:
-            w = 8
         b = blocks[i]
         b["w"], b["h"] = w, h
         b["x"] = int(rng.integers(0, (pw - w) // 4 + 1)) * 4
@@ -269,7 +267,7 @@ def test_unsupported_jobs_are_reported(gpu):
     O.upload([orig, None, None], BL)
     R.upload([ref, None, None], BL)
     blocks = np.zeros(6, api.ME_DTYPE)
-    shapes = [(16, 16), (2, 8), (4, 4), (12, 16), (64, 64), (8, 8)]
+    shapes = [(16, 16), (2, 8), (4, 2), (12, 16), (64, 64), (8, 8)]
     for b, (w, h) in zip(blocks, shapes):
         b["x"], b["y"], b["w"], b["h"] = 64, 32, w, h
         b["lambda16"], b["search_range"] = 90000, 96

@@ -662,7 +662,7 @@ me_search_wave_kernel(PicView orig, PicView ref,
     // XVCGPU_ME_UNSUPPORTED record instead of being left as it was
     const bool pow2 = (b.w & (b.w - 1)) == 0 && (b.h & (b.h - 1)) == 0;
     const bool valid = pow2 && b.w >= 4 && b.h >= 4 && b.w <= 64 && b.h <= 64 &&
-                       b.w * b.h >= 32 && mx <= max_launched;
+                       mx <= max_launched;
     if (MS == 16 && !valid) {
       if (ME2_LANE == 0) {
         xvcgpu_me_result r;
