@@ -607,6 +607,40 @@ void xr_subpel_search(int bd, const xvcgpu_me_block *b, int pic_w, int pic_h,
   if (out_dist) *out_dist = static_cast<uint32_t>(dist);
 }
 
+/* T6: InterSearch::EvalStartMvp / EvalFinalMvpIdx and the bit helpers */
+int xr_eval_start_mvp(int bd, const xvcgpu_me_block *b, int pic_w, int pic_h,
+                      const uint16_t *orig, ptrdiff_t os, const uint16_t *ref, ptrdiff_t rs,
+                      const int32_t mvp[4], uint32_t *out_cost) {
+  MeEnv env(bd, pic_w, pic_h, orig, os, ref, rs);
+  CodingUnit *cu = env.pic_data.CreateCu(CuTree::Primary, 1, b->x, b->y, b->w, b->h);
+  cu->SetFullpelMv(b->fullpel_mv != 0);
+  InterSearch is(Simd(bd), env.pic_data, env.orig_pic, env.rec_pic, env.rpl, env.settings);
+  double ls = (b->lambda16 + 0.5) / 65536.0;
+  Qp qp = MakeQp(32, bd, ls * ls);
+  cu->SetQp(qp);   /* CompareSample(cu, ...) reads the CU's qp (distortion weight) */
+  std::array<MotionVector, constants::kNumInterMvPredictors> list;
+  static_assert(constants::kNumInterMvPredictors == 2, "two predictors");
+  list[0] = MotionVector(mvp[0], mvp[1]);
+  list[1] = MotionVector(mvp[2], mvp[3]);
+  SampleBufferStorage pred(64, 64);
+  Distortion cost = 0;
+  int idx = is.EvalStartMvp<false>(*cu, qp, list, env.ref_pic, &pred, &cost);
+  if (out_cost) *out_cost = static_cast<uint32_t>(cost);
+  return idx;
+}
+
+int xr_eval_final_mvp_idx(int fullpel_mv, const int32_t mvp[4], int mv_x, int mv_y, int start) {
+  std::vector<uint16_t> dummy(64 * 64, 0);
+  MeEnv env(10, 64, 64, dummy.data(), 64, dummy.data(), 64);
+  CodingUnit *cu = env.pic_data.CreateCu(CuTree::Primary, 1, 0, 0, 16, 16);
+  cu->SetFullpelMv(fullpel_mv != 0);
+  InterSearch is(Simd(10), env.pic_data, env.orig_pic, env.rec_pic, env.rpl, env.settings);
+  std::array<MotionVector, constants::kNumInterMvPredictors> list;
+  list[0] = MotionVector(mvp[0], mvp[1]);
+  list[1] = MotionVector(mvp[2], mvp[3]);
+  return is.EvalFinalMvpIdx(*cu, list, MotionVector(mv_x, mv_y), start);
+}
+
 /* T5: InterSearch::AffineGradientSearch / MotionEstAffine (uni-pred) */
 void xr_affine_gradient_search(int bd, int width, int height, const uint16_t *pred,
                                ptrdiff_t ps, const int16_t *err, ptrdiff_t es, int mvd[4]) {

@@ -1,0 +1,130 @@
+"""The host control the C++ layer keeps around the motion-search batches
+(xvc_gpu::InterSearch in xvc_amd/host/xvc_gpu_ops.h: EvalStartMvp,
+EvalFinalMvpIdx, the bit prices, the per-list SearchRefIdx loop) against the
+reference's own member functions (oracle/_ref, xr_eval_start_mvp /
+xr_eval_final_mvp_idx / xr_mvd_bits), on random CUs and predictor pairs."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+from test_gpu_parity import BL, make_pics, me_blocks, to_me_struct
+from xvc_amd import decoder
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    from xvc_amd import api
+    ctx = api.Context(0)
+    yield api, ctx
+    ctx.close()
+
+
+def host_lib():
+    L = decoder.load_host_library()
+    L.xvc_host_eval_start_mvp_batch.argtypes = [C.c_void_p] * 4 + [C.c_int] + [C.c_void_p] * 3
+    L.xvc_host_eval_final_mvp_idx.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
+    L.xvc_host_mvd_bits.restype = C.c_uint32
+    L.xvc_host_search_ref_idx_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                                C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                                C.c_void_p]
+    return L
+
+
+@pytest.mark.skipif(not ol.have_ref(), reason="oracle/_ref not built")
+def test_bit_prices_and_final_mvp_vs_reference():
+    L, xr = host_lib(), ol.Lib("xr").dll
+    xr.xr_mvd_bits.restype = C.c_uint32
+    xr.xr_eval_final_mvp_idx.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int]
+    rng = np.random.default_rng(11)
+    for _ in range(3000):
+        a = [int(v) for v in rng.integers(-3000, 3000, 4)]
+        sh = int(rng.integers(0, 2)) * 2
+        assert L.xvc_host_mvd_bits(*a, sh) == xr.xr_mvd_bits(*a, sh)
+        mvp = np.array(rng.integers(-800, 800, 4), np.int32)
+        if rng.integers(0, 4) == 0:
+            mvp[2:] = mvp[:2]           # identical predictors: the start index breaks the tie
+        mv = [int(v) for v in (mvp[:2] if rng.integers(0, 3) == 0 else rng.integers(-800, 800, 2))]
+        fp, start = int(rng.integers(0, 2)), int(rng.integers(0, 2))
+        got = L.xvc_host_eval_final_mvp_idx(mvp.ctypes.data, mv[0], mv[1], start, fp)
+        exp = xr.xr_eval_final_mvp_idx(fp, mvp.ctypes.data, mv[0], mv[1], start)
+        assert got == exp, (mvp, mv, fp, start)
+
+
+@pytest.mark.skipif(not ol.have_ref(), reason="oracle/_ref not built")
+@pytest.mark.parametrize("bd", [8, 10])
+def test_eval_start_mvp_and_ref_loop_vs_reference(gpu, bd):
+    api, ctx = gpu
+    L, xr, xo = host_lib(), ol.Lib("xr"), ol.Lib("xo")
+    xr.dll.xr_eval_start_mvp.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
+                                         C.c_ssize_t, C.c_void_p, C.c_ssize_t, C.c_void_p,
+                                         C.c_void_p]
+    rng = np.random.default_rng(4200 + bd)
+    pw, ph = 256, 160
+    orig, ref0 = make_pics(rng, bd, pw, ph, BL, (5, -3))
+    _, ref1 = make_pics(rng, bd, pw, ph, BL, (-9, 4))
+    ref1 = np.ascontiguousarray(np.roll(ref0, (3, -7), (0, 1)))   # a second, shifted reference
+    O, R0, R1 = (ctx.picture(pw, ph, bd) for _ in range(3))
+    O.upload([orig, None, None], BL)
+    R0.upload([ref0, None, None], BL)
+    R1.upload([ref1, None, None], BL)
+    n = 60
+    blocks = me_blocks(rng, api, pw, ph, n)
+    mvp = np.array(rng.integers(-160, 160, (2, n, 4)), np.int32)
+    mvp[:, ::5, 2:] = mvp[:, ::5, :2]
+    side = np.array(rng.integers(1, 6, (2, n)), np.uint32)
+    idx, cost = np.zeros(n, np.int32), np.zeros(n, np.uint32)
+    b = np.ascontiguousarray(blocks)
+    refs = [(R0, ref0), (R1, ref1)]
+    start = []
+    for r, (R, ref) in enumerate(refs):
+        m = np.ascontiguousarray(mvp[r])
+        st = L.xvc_host_eval_start_mvp_batch(ctx.h, O.h_pic, R.h_pic, b.ctypes.data, n,
+                                             m.ctypes.data, idx.ctypes.data, cost.ctypes.data)
+        assert st == 0
+        o, rr = orig[BL:, BL:], ref[BL:, BL:]
+        for i in range(n):
+            s = to_me_struct(blocks[i])
+            c = C.c_uint32(0)
+            e = xr.dll.xr_eval_start_mvp(bd, C.byref(s), pw, ph, o.ctypes.data, orig.strides[0] // 2,
+                                         rr.ctypes.data, ref.strides[0] // 2, m[i].ctypes.data,
+                                         C.byref(c))
+            assert (int(idx[i]), int(cost[i])) == (e, c.value), (r, i, tuple(blocks[i]), m[i])
+        start.append(idx.copy())
+    # the per-list loop: its parts are pinned above / in test_gpu_parity (search); the fold
+    # here against the same steps composed in Python from the reference's functions
+    out = np.zeros((n, 6), np.int32)
+    handles = (C.c_void_p * 2)(R0.h_pic, R1.h_pic)
+    mv_flat, side_flat = np.ascontiguousarray(mvp), np.ascontiguousarray(side)
+    assert L.xvc_host_search_ref_idx_batch(ctx.h, O.h_pic, handles, 2, b.ctypes.data, n,
+                                           mv_flat.ctypes.data, side_flat.ctypes.data,
+                                           out.ctypes.data) == 0
+    xr.dll.xr_mvd_bits.restype = C.c_uint32
+    xr.dll.xr_eval_final_mvp_idx.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int]
+    for i in range(n):
+        best = None
+        for r, (R, ref) in enumerate(refs):
+            blk = blocks[i].copy()
+            k = int(start[r][i])
+            blk["mvp_x"], blk["mvp_y"] = mvp[r][i][2 * k], mvp[r][i][2 * k + 1]
+            s = to_me_struct(blk)
+            (fx, fy), _ = xo.tz_search(bd, s, pw, ph, orig, ref, BL)
+            if blk["fullpel_mv"]:
+                mv = (16 * fx, 16 * fy)
+                dist = xo.mc_metric(bd, 1, 32, 16, s.x, s.y, s.w, s.h, mv, pw, ph, orig, ref, BL)
+            else:
+                mv, dist = xo.subpel_search(bd, s, pw, ph, orig, ref, BL, (fx, fy))
+            fp = int(blk["fullpel_mv"])
+            m = np.ascontiguousarray(mvp[r][i])
+            fidx = xr.dll.xr_eval_final_mvp_idx(fp, m.ctypes.data, mv[0], mv[1], k)
+            bits = int(side[r][i]) + 1 + xr.dll.xr_mvd_bits(int(m[2 * fidx]), int(m[2 * fidx + 1]),
+                                                             mv[0], mv[1], 2 * fp)
+            c = dist + ((bits * int(blk["lambda16"])) >> 16)
+            if best is None or c < best[5]:
+                best = (r, fidx, mv[0], mv[1], dist, c)
+        assert tuple(int(v) for v in out[i]) == best, (i, tuple(blocks[i]))
+    for p in (O, R0, R1):
+        p.destroy()

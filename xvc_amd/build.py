@@ -36,7 +36,7 @@ def deps():
 
 
 HOST_OUT = os.path.join(HERE, "libxvchost.so")
-HOST_SOURCES = ["xvc_picture_decoder.cc", "xvc_picture_schedule.cc"]
+HOST_SOURCES = ["xvc_picture_decoder.cc", "xvc_picture_schedule.cc", "xvc_inter_search.cc"]
 
 
 def build_host(force=False, verbose=False):

@@ -48,11 +48,15 @@ struct Error : std::runtime_error {
 
 class Context {
  public:
-  explicit Context(int device = 0) : ctx_(nullptr) {
+  explicit Context(int device = 0) : ctx_(nullptr), owned_(true) {
     xvcgpu_status st = xvcgpu_create(device, &ctx_);
     if (st != XVCGPU_OK) throw Error(st, "xvcgpu_create: no gfx950 device");
   }
-  ~Context() { xvcgpu_destroy(ctx_); }
+  // a view of a context somebody else owns
+  explicit Context(xvcgpu_ctx *borrowed) : ctx_(borrowed), owned_(false) {}
+  ~Context() {
+    if (owned_) xvcgpu_destroy(ctx_);
+  }
   Context(const Context &) = delete;
   Context &operator=(const Context &) = delete;
   xvcgpu_ctx *get() const { return ctx_; }
@@ -63,6 +67,7 @@ class Context {
 
  private:
   xvcgpu_ctx *ctx_;
+  bool owned_;
 };
 
 // Typed device array (descriptors in, results out).
@@ -97,10 +102,15 @@ class DeviceArray {
 class Picture {
  public:
   Picture(const Context &ctx, int width, int height, int bitdepth)
-      : ctx_(ctx), pic_(nullptr) {
+      : ctx_(ctx), pic_(nullptr), owned_(true) {
     ctx_.Check(xvcgpu_picture_create(ctx_.get(), width, height, bitdepth, &pic_));
   }
-  ~Picture() { xvcgpu_picture_destroy(pic_); }
+  // a view of a picture somebody else owns
+  Picture(const Context &ctx, xvcgpu_picture *borrowed)
+      : ctx_(ctx), pic_(borrowed), owned_(false) {}
+  ~Picture() {
+    if (owned_) xvcgpu_picture_destroy(pic_);
+  }
   Picture(const Picture &) = delete;
   Picture &operator=(const Picture &) = delete;
   xvcgpu_picture *get() const { return pic_; }
@@ -117,6 +127,7 @@ class Picture {
  private:
   const Context &ctx_;
   xvcgpu_picture *pic_;
+  bool owned_;
 };
 
 // SampleMetric(simd, bitdepth, type, structural_strength) ::Compare, batched.
@@ -168,6 +179,136 @@ class InterSearch {
                                       static_cast<int>(cands.size()), r.data()));
     return r.ToHost();
   }
+  // ---- the host control around the batches (inter_search.cc:437-578) --------
+  // Bits of an MV difference as the search prices it (GetNumExpGolombBits,
+  // GetMvdBits, GetMvpBits: inter_search.cc:1139-1190).  Vectors in 1/16 pel,
+  // differences coded in 1/4 pel (MvDelta::kPrecisionShift = 2), or in whole
+  // samples for fullpel-MV CUs (mvd_down_shift = 2).
+  static uint32_t GetNumExpGolombBits(int mvd) {
+    uint32_t length = 1;
+    uint32_t v = mvd <= 0 ? (static_cast<uint32_t>(-mvd) << 1) + 1 : static_cast<uint32_t>(mvd) << 1;
+    while (v != 1) {
+      v >>= 1;
+      length += 2;
+    }
+    return length;
+  }
+  static uint32_t GetMvdBits(int mvp_x, int mvp_y, int mv_x, int mv_y, int mvd_down_shift) {
+    const int shift = 2 + mvd_down_shift;
+    return GetNumExpGolombBits((mv_x - mvp_x) >> shift) +
+           GetNumExpGolombBits((mv_y - mvp_y) >> shift);
+  }
+  static uint32_t GetMvpBits(int /*mvp_idx*/, int num_mvp) { return num_mvp == 1 ? 0 : 1; }
+
+  // InterSearch::EvalStartMvp (inter_search.cc:966-997) for a batch of CUs with
+  // kNumInterMvPredictors = 2 candidates each: SAD of the motion-compensated
+  // luma block at each (clipped) predictor + the predictor index bits, first
+  // strictly smaller cost wins.  mvp[i] = {x0, y0, x1, y1} in 1/16 pel.
+  struct StartMvp {
+    int idx;
+    uint32_t cost;
+  };
+  std::vector<StartMvp> EvalStartMvpBatch(const Picture &orig_pic, const Picture &ref_pic,
+                                          const std::vector<xvcgpu_me_block> &blocks,
+                                          const std::vector<std::array<int32_t, 4>> &mvp) const {
+    std::vector<xvcgpu_mc_metric_cand> cands;
+    cands.reserve(2 * blocks.size());
+    for (size_t i = 0; i < blocks.size(); i++)
+      for (int k = 0; k < 2; k++) {
+        xvcgpu_mc_metric_cand c = xvcgpu_mc_metric_cand();
+        c.x = blocks[i].x;
+        c.y = blocks[i].y;
+        c.w = blocks[i].w;
+        c.h = blocks[i].h;
+        c.metric = XVC_METRIC_SAD;       // GetMvpMetricType (inter_search.cc:1078)
+        c.mv_x = mvp[i][2 * k];
+        c.mv_y = mvp[i][2 * k + 1];
+        cands.push_back(c);
+      }
+    const std::vector<uint64_t> dist = GetSubpelDistBatch(orig_pic, ref_pic, cands);
+    std::vector<StartMvp> out(blocks.size());
+    for (size_t i = 0; i < blocks.size(); i++) {
+      StartMvp best = {0, 0xffffffffu};
+      for (int k = 0; k < 2; k++) {
+        const uint32_t bits = GetMvpBits(k, 2);
+        const uint32_t cost = static_cast<uint32_t>(dist[2 * i + k]) +
+                              (static_cast<uint32_t>(bits * blocks[i].lambda16 + 0.5) >> 16);
+        if (cost < best.cost) {
+          best.cost = cost;
+          best.idx = k;
+        }
+      }
+      out[i] = best;
+    }
+    return out;
+  }
+  // InterSearch::EvalFinalMvpIdx (inter_search.cc:1000-1019): the predictor that
+  // makes the found vector cheapest to code; the start predictor wins a tie.
+  static int EvalFinalMvpIdx(const std::array<int32_t, 4> &mvp, int mv_x, int mv_y,
+                             int mvp_idx_start, bool fullpel_mv) {
+    int best = 0;
+    uint32_t best_cost = 0xffffffffu;
+    for (int k = 0; k < 2; k++) {
+      const uint32_t cost =
+          GetMvpBits(k, 2) + GetMvdBits(mvp[2 * k], mvp[2 * k + 1], mv_x, mv_y, fullpel_mv ? 2 : 0);
+      if (cost < best_cost || (cost == best_cost && k == mvp_idx_start)) {
+        best_cost = cost;
+        best = k;
+      }
+    }
+    return best;
+  }
+  // The per-list loop of InterSearch::SearchRefIdx (uni-prediction, TZ search,
+  // inter_search.cc:458-578) over the reference pictures of one list, for a
+  // batch of CUs that all use the same `previous` vectors: per reference
+  // picture one EvalStartMvp batch, one motion search batch from the chosen
+  // predictor, EvalFinalMvpIdx, then cost = dist + ((bits * lambda) >> 16) with
+  // the first strictly smaller cost kept.  side_bits[r][i]: what
+  // GetInterPredBits adds besides the vector difference and predictor index
+  // for CU i with reference r (inter direction, reference index: they come from
+  // the caller's entropy-coder state, syntax_writer.cc); mvp[r][i] as above.
+  struct UniPredChoice {
+    int ref_idx, mvp_idx;
+    int mv_x, mv_y;
+    uint32_t dist, cost;
+  };
+  std::vector<UniPredChoice> SearchRefIdxBatch(
+      const Picture &orig_pic, const std::vector<const Picture *> &ref_pics,
+      const std::vector<xvcgpu_me_block> &blocks,
+      const std::vector<std::vector<std::array<int32_t, 4>>> &mvp,
+      const std::vector<std::vector<uint32_t>> &side_bits) const {
+    std::vector<UniPredChoice> best(blocks.size());
+    for (size_t i = 0; i < blocks.size(); i++) {
+      UniPredChoice c = {-1, 0, 0, 0, 0, 0xffffffffu};
+      best[i] = c;
+    }
+    for (size_t r = 0; r < ref_pics.size(); r++) {
+      const std::vector<StartMvp> start = EvalStartMvpBatch(orig_pic, *ref_pics[r], blocks, mvp[r]);
+      std::vector<xvcgpu_me_block> jobs(blocks);
+      for (size_t i = 0; i < jobs.size(); i++) {
+        jobs[i].mvp_x = mvp[r][i][2 * start[i].idx];
+        jobs[i].mvp_y = mvp[r][i][2 * start[i].idx + 1];
+      }
+      const std::vector<xvcgpu_me_result> res = MotionEstNormalBatch(orig_pic, *ref_pics[r], jobs);
+      for (size_t i = 0; i < jobs.size(); i++) {
+        const bool fp = jobs[i].fullpel_mv != 0;
+        const int idx = EvalFinalMvpIdx(mvp[r][i], res[i].mv_x, res[i].mv_y, start[i].idx, fp);
+        const uint32_t bits = side_bits[r][i] + GetMvpBits(idx, 2) +
+                              GetMvdBits(mvp[r][i][2 * idx], mvp[r][i][2 * idx + 1], res[i].mv_x,
+                                         res[i].mv_y, fp ? 2 : 0);
+        const uint32_t cost =
+            res[i].subpel_dist +
+            static_cast<uint32_t>((static_cast<uint64_t>(bits) * jobs[i].lambda16) >> 16);
+        if (cost < best[i].cost) {
+          UniPredChoice c = {static_cast<int>(r), idx, res[i].mv_x, res[i].mv_y,
+                             res[i].subpel_dist, cost};
+          best[i] = c;
+        }
+      }
+    }
+    return best;
+  }
+
   // One SearchBiIterative refinement step per job (inter_search.cc:392-433):
   // ref_other = picture of the list whose MV is fixed (job.other_mv),
   // ref_search = picture of the list being refined.

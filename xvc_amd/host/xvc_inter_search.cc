@@ -1,0 +1,96 @@
+// xvc_inter_search.cc -- C entry points (for ctypes / tests) of the host control
+// that xvc_gpu::InterSearch (xvc_gpu_ops.h) keeps around the motion-search
+// batches: EvalStartMvp, EvalFinalMvpIdx, the per-list SearchRefIdx loop
+// (inter_search.cc:437-578, :966-1019).  Handles are borrowed, never freed here.
+#include <array>
+#include <cstdint>
+#include <memory>
+#include <vector>
+
+#include "xvc_gpu_ops.h"
+
+namespace {
+typedef std::array<int32_t, 4> Mvp;
+std::vector<Mvp> MvpList(const int32_t *mvp, int n) {
+  std::vector<Mvp> out(n);
+  for (int i = 0; i < n; i++)
+    for (int k = 0; k < 4; k++) out[i][k] = mvp[4 * i + k];
+  return out;
+}
+}  // namespace
+
+extern "C" {
+
+// blocks: host array of n xvcgpu_me_block; mvp: n x {x0, y0, x1, y1};
+// out_idx / out_cost: n each.
+int xvc_host_eval_start_mvp_batch(xvcgpu_ctx *ctx, xvcgpu_picture *orig, xvcgpu_picture *ref,
+                                  const xvcgpu_me_block *blocks, int n, const int32_t *mvp,
+                                  int32_t *out_idx, uint32_t *out_cost) {
+  if (!ctx || !orig || !ref || !blocks || !mvp || n < 0) return XVCGPU_INVALID_ARGUMENT;
+  try {
+    xvc_gpu::Context c(ctx);
+    xvc_gpu::Picture o(c, orig), r(c, ref);
+    const std::vector<xvcgpu_me_block> b(blocks, blocks + n);
+    const std::vector<xvc_gpu::InterSearch::StartMvp> res =
+        xvc_gpu::InterSearch(c).EvalStartMvpBatch(o, r, b, MvpList(mvp, n));
+    for (int i = 0; i < n; i++) {
+      if (out_idx) out_idx[i] = res[i].idx;
+      if (out_cost) out_cost[i] = res[i].cost;
+    }
+    return XVCGPU_OK;
+  } catch (const xvc_gpu::Error &e) {
+    return e.status;
+  }
+}
+
+int xvc_host_eval_final_mvp_idx(const int32_t mvp[4], int mv_x, int mv_y, int start,
+                                int fullpel_mv) {
+  Mvp m = {{mvp[0], mvp[1], mvp[2], mvp[3]}};
+  return xvc_gpu::InterSearch::EvalFinalMvpIdx(m, mv_x, mv_y, start, fullpel_mv != 0);
+}
+
+uint32_t xvc_host_mvd_bits(int mvp_x, int mvp_y, int mv_x, int mv_y, int down_shift) {
+  return xvc_gpu::InterSearch::GetMvdBits(mvp_x, mvp_y, mv_x, mv_y, down_shift);
+}
+
+// The per-list loop over n_refs reference pictures: mvp[r * n + i][4],
+// side_bits[r * n + i]; out: per CU {ref_idx, mvp_idx, mv_x, mv_y, dist, cost}.
+int xvc_host_search_ref_idx_batch(xvcgpu_ctx *ctx, xvcgpu_picture *orig,
+                                  xvcgpu_picture *const *refs, int n_refs,
+                                  const xvcgpu_me_block *blocks, int n, const int32_t *mvp,
+                                  const uint32_t *side_bits, int32_t *out) {
+  if (!ctx || !orig || !refs || !blocks || !mvp || !side_bits || !out || n < 0 || n_refs < 1)
+    return XVCGPU_INVALID_ARGUMENT;
+  try {
+    xvc_gpu::Context c(ctx);
+    xvc_gpu::Picture o(c, orig);
+    std::vector<std::unique_ptr<xvc_gpu::Picture>> views;
+    std::vector<const xvc_gpu::Picture *> ref_pics;
+    std::vector<std::vector<Mvp>> lists;
+    std::vector<std::vector<uint32_t>> bits;
+    for (int r = 0; r < n_refs; r++) {
+      views.emplace_back(new xvc_gpu::Picture(c, refs[r]));
+      ref_pics.push_back(views.back().get());
+      lists.push_back(MvpList(mvp + 4 * static_cast<size_t>(r) * n, n));
+      bits.push_back(std::vector<uint32_t>(side_bits + static_cast<size_t>(r) * n,
+                                           side_bits + static_cast<size_t>(r + 1) * n));
+    }
+    const std::vector<xvcgpu_me_block> b(blocks, blocks + n);
+    const std::vector<xvc_gpu::InterSearch::UniPredChoice> res =
+        xvc_gpu::InterSearch(c).SearchRefIdxBatch(o, ref_pics, b, lists, bits);
+    for (int i = 0; i < n; i++) {
+      int32_t *q = out + 6 * i;
+      q[0] = res[i].ref_idx;
+      q[1] = res[i].mvp_idx;
+      q[2] = res[i].mv_x;
+      q[3] = res[i].mv_y;
+      q[4] = static_cast<int32_t>(res[i].dist);
+      q[5] = static_cast<int32_t>(res[i].cost);
+    }
+    return XVCGPU_OK;
+  } catch (const xvc_gpu::Error &e) {
+    return e.status;
+  }
+}
+
+}  // extern "C"
