@@ -481,6 +481,19 @@ xvcgpu_status xvcgpu_inv_transform_batch(xvcgpu_ctx *ctx,
                                          const int16_t *d_levels,
                                          const uint32_t *d_level_offsets,
                                          const int32_t *d_nnz);
+/* The same, and the RD loop's distortion of the coded block in the residual
+ * domain (M6 short-short: SampleMetric::CompareShort on temp_resi_orig_ /
+ * temp_resi_, transform_encoder.cc:69-77, sample_metric.cc:286-290):
+ * d_dist[i] = sum((orig - pred - T^-1(Q^-1(level)))^2) >> 2 (bitdepth - 8) over
+ * block i - what TransformAndReconstruct's caller prices an inter block with
+ * (fast_inter_transform_dist); the chroma distortion weight (:275-276) is the
+ * caller's.  For a block without levels the reconstructed residual is zero. */
+xvcgpu_status xvcgpu_inv_transform_dist_batch(xvcgpu_ctx *ctx, const xvcgpu_picture *orig,
+                                              const xvcgpu_picture *pred, xvcgpu_picture *rec,
+                                              const xvcgpu_tx_block *d_blocks, int n,
+                                              const int16_t *d_levels,
+                                              const uint32_t *d_level_offsets,
+                                              const int32_t *d_nnz, uint64_t *d_dist);
 
 /* ---- D1..D4: DeblockingFilter::DeblockPicture --------------------------- *
  * (deblocking_filter.cc:56-77). d_cu_map: one int32 per 4x4 luma cell,

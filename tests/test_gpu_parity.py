@@ -521,6 +521,7 @@ def test_residual_pipeline(gpu, xo, bd):
     api, ctx = gpu
     rng = np.random.default_rng(4000 + bd)
     pw, ph = 256, 128
+    n_dist = 0
     for noise in (2, 12, 200):
         po = padded_planes(rng, bd, pw, ph, smooth=True)
         pp = [np.clip(p.astype(np.int32) + rng.integers(-noise, noise + 1, size=p.shape),
@@ -555,8 +556,20 @@ def test_residual_pipeline(gpu, xo, bd):
             Rc.upload(pp, BL)
             ctx.inv_transform_batch(P, Rc, blk, levels, off, nnz)
             assert np.array_equal(Rc.download()[comp], exp_rec), (noise, tuple(b))
+            # M6: the residual-domain SSD of the coded block (CompareShort on the
+            # original and the reconstructed residual, transform_encoder.cc:69-77).
+            # Where nothing was clipped the reconstructed residual is rec - pred.
+            Rc.upload(pp, BL)
+            dist = ctx.inv_transform_dist_batch(O, P, Rc, blk, levels, off, nnz)
+            assert np.array_equal(Rc.download()[comp], exp_rec), (noise, tuple(b))
+            rb = exp_rec[y:y + h, x:x + w].astype(np.int64)
+            if rb.min() > 0 and rb.max() < (1 << bd) - 1:
+                d = ov[y:y + h, x:x + w].astype(np.int64) - rb
+                assert int(dist[0]) == int((d * d).sum()) >> (2 * (bd - 8)), (noise, tuple(b))
+                n_dist += 1
         for pic in (O, P, Rc):
             pic.destroy()
+    assert n_dist > 100
 
 
 @pytest.mark.parametrize("bd", [8, 10, 12])

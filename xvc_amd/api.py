@@ -150,7 +150,7 @@ SYMBOLS = [
     "xvcgpu_comm_record_event", "xvcgpu_comm_sync", "xvcgpu_comm_group_begin",
     "xvcgpu_comm_group_end", "xvcgpu_comm_send_picture", "xvcgpu_comm_recv_picture",
     "xvcgpu_comm_send_rows", "xvcgpu_comm_recv_rows", "xvcgpu_comm_all_reduce_sum_u64",
-    "xvcgpu_comm_send_bytes", "xvcgpu_comm_recv_bytes",
+    "xvcgpu_comm_send_bytes", "xvcgpu_comm_recv_bytes", "xvcgpu_inv_transform_dist_batch",
 ]
 
 _vp = C.c_void_p
@@ -285,6 +285,7 @@ def load_library():
         "xvcgpu_comm_recv_rows": [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int],
         "xvcgpu_comm_all_reduce_sum_u64": [_vp, _vp, C.c_int],
         "xvcgpu_comm_send_bytes": [_vp, _vp, C.c_size_t, C.c_int],
+        "xvcgpu_inv_transform_dist_batch": [_vp, _vp, _vp, _vp, _vp, C.c_int, _vp, _vp, _vp, _vp],
         "xvcgpu_comm_recv_bytes": [_vp, _vp, C.c_size_t, C.c_int],
     }
     lib.xvcgpu_event_destroy.restype = None
@@ -831,6 +832,22 @@ class Context:
         self.sync()
         for b in (db, dof, dl, dn):
             b.free()
+
+    def inv_transform_dist_batch(self, orig, pred, rec, blocks, levels, off, nnz):
+        """inv_transform_batch + the residual-domain SSD per block (uint64)."""
+        blocks = np.ascontiguousarray(blocks, TX_DTYPE)
+        db = self.buffer(blocks)
+        dof = self.buffer(np.ascontiguousarray(off, np.uint32))
+        dl = self.buffer(np.ascontiguousarray(levels, np.int16))
+        dn = self.buffer(np.ascontiguousarray(nnz, np.int32))
+        dd = self.alloc(8 * len(blocks))
+        self._check(self.lib.xvcgpu_inv_transform_dist_batch(
+            self.h, orig.h_pic, pred.h_pic, rec.h_pic, db.ptr, len(blocks), dl.ptr, dof.ptr,
+            dn.ptr, dd.ptr))
+        out = dd.to_array(np.uint64, len(blocks))
+        for b in (db, dof, dl, dn, dd):
+            b.free()
+        return out
 
     def deblock(self, rec, cus, cu_map, bipred=0, beta=0, tc=0, sub=4):
         cus = np.ascontiguousarray(cus, CU_DTYPE)

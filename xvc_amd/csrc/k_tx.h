@@ -223,7 +223,10 @@ __device__ __forceinline__ void residual_job(TxShared &s, int bi, const PicView 
                                              const TxTableLayout &lay,
                                              RdoqShared<RQN> *rq = nullptr,
                                              const xvcgpu_rdoq_contexts *rq_ctx = nullptr,
-                                             const xvcgpu_rdoq_params *rq_prm = nullptr) {
+                                             const xvcgpu_rdoq_params *rq_prm = nullptr,
+                                             unsigned long long *dist_out = nullptr) {
+  __shared__ unsigned long long s_dist;  // see tx2_job: the residual-domain SSD
+  if (threadIdx.x == 0) s_dist = 0;
   __syncthreads();  // previous job of this workgroup is done with s
   const xvcgpu_tx_block b = blocks[bi];
   const int w = b.w, h = b.h, bd = pred.bd;
@@ -368,12 +371,27 @@ __device__ __forceinline__ void residual_job(TxShared &s, int bi, const PicView 
   }
 
   const PlaneView pr = rec.c[b.comp];
+  const PlaneView pod = orig.c[b.comp];
+  unsigned long long dist_acc = 0;
+  auto dist_finish = [&]() {
+    unsigned long long v = dist_acc;
+#pragma unroll
+    for (int sft = 1; sft < 64; sft <<= 1) v += __shfl_xor(v, sft, 64);
+    if ((threadIdx.x & 63) == 0) atomicAdd(&s_dist, v);
+    __syncthreads();
+    if (threadIdx.x == 0) dist_out[bi] = s_dist >> (2 * (bd - 8));
+  };
   if (nnz == 0) {  // cbf == 0: rec = pred (CopyFrom, transform_encoder.cc:281)
     for (int i = threadIdx.x; i < w * h; i += TX_THREADS) {
       const int y = i >> lw, x = i & (w - 1);
-      pr.p[(ptrdiff_t)(b.y + y) * pr.stride + b.x + x] =
-          pp.p[(ptrdiff_t)(b.y + y) * pp.stride + b.x + x];
+      const int p = pp.p[(ptrdiff_t)(b.y + y) * pp.stride + b.x + x];
+      pr.p[(ptrdiff_t)(b.y + y) * pr.stride + b.x + x] = (uint16_t)p;
+      if (dist_out) {
+        const int d = (int)pod.p[(ptrdiff_t)(b.y + y) * pod.stride + b.x + x] - p;
+        dist_acc += (unsigned long long)((long long)d * d);
+      }
     }
+    if (dist_out) dist_finish();
     return;
   }
   const bool dc_only = nnz == 1 && s.b[0] != 0;  // transform_encoder.cc:241
@@ -432,7 +450,13 @@ __device__ __forceinline__ void residual_job(TxShared &s, int bi, const PicView 
     const int p = pp.p[(ptrdiff_t)(b.y + y) * pp.stride + b.x + x];
     pr.p[(ptrdiff_t)(b.y + y) * pr.stride + b.x + x] =
         (uint16_t)d_clip3(p + (int)s.a[y * TX_S + x], 0, smax);
+    if (dist_out) {
+      const int d = (int)pod.p[(ptrdiff_t)(b.y + y) * pod.stride + b.x + x] - p -
+                    (int)s.a[y * TX_S + x];
+      dist_acc += (unsigned long long)((long long)d * d);
+    }
   }
+  if (dist_out) dist_finish();
 }
 
 // grid: ceil(n/256) workgroups of 256 threads.  Each workgroup scans 256
@@ -445,7 +469,8 @@ residual_kernel(PicView orig, PicView pred, PicView rec,
                 const uint32_t *level_off, int32_t *nnz_out,
                 const int16_t *tx_tables, TxTableLayout lay,
                 const xvcgpu_rdoq_contexts *rq_ctx = nullptr,
-                const xvcgpu_rdoq_params *rq_prm = nullptr) {
+                const xvcgpu_rdoq_params *rq_prm = nullptr,
+                unsigned long long *dist_out = nullptr) {
   __shared__ __attribute__((aligned(16))) TxShared s;
   __shared__ RdoqShared<RDOQ ? 1024 : 4> rq;
   __shared__ int jobs[TX_THREADS];
@@ -458,7 +483,7 @@ residual_kernel(PicView orig, PicView pred, PicView rec,
   const int nj = n_jobs;
   for (int k = 0; k < nj; k++)
     residual_job<MODE, RDOQ ? 1024 : 4>(s, jobs[k], orig, pred, rec, blocks, levels, level_off,
-                                        nnz_out, tx_tables, lay, &rq, rq_ctx, rq_prm);
+                                        nnz_out, tx_tables, lay, &rq, rq_ctx, rq_prm, dist_out);
 }
 
 // The same path with one workgroup per descriptor (a workgroup whose block
@@ -471,12 +496,13 @@ __global__ void __launch_bounds__(TX_THREADS)
 residual_per_job_kernel(PicView orig, PicView pred, PicView rec,
                         const xvcgpu_tx_block *blocks, int n, int16_t *levels,
                         const uint32_t *level_off, int32_t *nnz_out,
-                        const int16_t *tx_tables, TxTableLayout lay) {
+                        const int16_t *tx_tables, TxTableLayout lay,
+                        unsigned long long *dist_out = nullptr) {
   __shared__ __attribute__((aligned(16))) TxShared s;
   const int idx = blockIdx.x;
   if (idx >= n || tx_small_job(blocks[idx])) return;
   residual_job<MODE, 4>(s, idx, orig, pred, rec, blocks, levels, level_off, nnz_out, tx_tables,
-                        lay);
+                        lay, nullptr, nullptr, nullptr, dist_out);
 }
 
 #endif  // XVCGPU_K_TX_H_

@@ -142,8 +142,30 @@ __device__ __forceinline__ int tx2_job(Tx2Shared &sh, const xvcgpu_tx_block &b, 
                                        const U16x4 *orig_pre = nullptr, int soff = 0,
                                        RdoqShared<(G == 32 ? 64 : 256)> *rq = nullptr,
                                        const xvcgpu_rdoq_contexts *rq_ctx = nullptr,
-                                       const xvcgpu_rdoq_params *rq_prm = nullptr) {
+                                       const xvcgpu_rdoq_params *rq_prm = nullptr,
+                                       unsigned long long *dist_out = nullptr) {
   struct { int16_t *r, *t, *c; } s = {sh.r + soff, sh.t + soff, sh.c + soff};
+  // dist_out: SSD between the original residual (orig - pred) and the
+  // reconstructed one, >> 2 (bd - 8): SampleMetric::CompareShort on
+  // temp_resi_orig_ / temp_resi_ (transform_encoder.cc:75-76, sample_metric.cc:
+  // 286-290) - the RD loop's distortion of a coded inter block
+  unsigned long long dist_acc = 0;
+  auto dist4 = [&](int y, int x, const U16x4 &p, int r0, int r1, int r2, int r3) {
+    const U16x4 o = *reinterpret_cast<const U16x4 *>(po.p + (ptrdiff_t)(b.y + y) * po.stride +
+                                                     b.x + x);
+    const int d0 = (int)(o.v[0] & 0xffff) - (int)(p.v[0] & 0xffff) - r0;
+    const int d1 = (int)(o.v[0] >> 16) - (int)(p.v[0] >> 16) - r1;
+    const int d2 = (int)(o.v[1] & 0xffff) - (int)(p.v[1] & 0xffff) - r2;
+    const int d3 = (int)(o.v[1] >> 16) - (int)(p.v[1] >> 16) - r3;
+    dist_acc += (unsigned long long)((long long)d0 * d0) + (unsigned long long)((long long)d1 * d1) +
+                (unsigned long long)((long long)d2 * d2) + (unsigned long long)((long long)d3 * d3);
+  };
+  auto dist_finish = [&]() {
+    unsigned long long v = dist_acc;
+#pragma unroll
+    for (int sft = 1; sft < G; sft <<= 1) v += __shfl_xor(v, sft, 64);
+    if ((ME2_LANE & (G - 1)) == 0) dist_out[bi] = v >> (2 * (bd - 8));
+  };
   const int lane = ME2_LANE & (G - 1);
   const int w = b.w, h = b.h;
   const int lw = 31 - __clz(w);
@@ -280,7 +302,9 @@ __device__ __forceinline__ int tx2_job(Tx2Shared &sh, const xvcgpu_tx_block &b, 
       const U16x4 p = *reinterpret_cast<const U16x4 *>(
           pred_p + (ptrdiff_t)y * pred_stride + x);
       *reinterpret_cast<U16x4 *>(pr.p + (ptrdiff_t)(b.y + y) * pr.stride + b.x + x) = p;
+      if (dist_out) dist4(y, x, p, 0, 0, 0, 0);
     }
+    if (dist_out) dist_finish();
     return 0;
   }
   const bool dc_only = nnz == 1 && s.r[0] != 0;
@@ -316,7 +340,9 @@ __device__ __forceinline__ int tx2_job(Tx2Shared &sh, const xvcgpu_tx_block &b, 
       o.v[1] = (uint32_t)d_clip3((int)(p.v[1] & 0xffff) + cf, 0, smax) |
                ((uint32_t)d_clip3((int)(p.v[1] >> 16) + cf, 0, smax) << 16);
       *reinterpret_cast<U16x4 *>(pr.p + (ptrdiff_t)(b.y + y) * pr.stride + b.x + x) = o;
+      if (dist_out) dist4(y, x, p, cf, cf, cf, cf);
     }
+    if (dist_out) dist_finish();
     return nnz;
   }
   // inverse: U[r][x] (h rows of w) into s.r, then residual rows into s.t
@@ -340,7 +366,11 @@ __device__ __forceinline__ int tx2_job(Tx2Shared &sh, const xvcgpu_tx_block &b, 
     o.v[1] = (uint32_t)d_clip3((int)(p.v[1] & 0xffff) + (int)(int16_t)(rs.y & 0xffff), 0, smax) |
              ((uint32_t)d_clip3((int)(p.v[1] >> 16) + ((int)rs.y >> 16), 0, smax) << 16);
     *reinterpret_cast<U16x4 *>(pr.p + (ptrdiff_t)(b.y + y) * pr.stride + b.x + x) = o;
+    if (dist_out)
+      dist4(y, x, p, (int)(int16_t)(rs.x & 0xffff), (int)rs.x >> 16, (int)(int16_t)(rs.y & 0xffff),
+            (int)rs.y >> 16);
   }
+  if (dist_out) dist_finish();
   return nnz;
 }
 
@@ -353,7 +383,8 @@ residual_wave_kernel(PicView orig, PicView pred, PicView rec,
                      const uint32_t *level_off, int32_t *nnz_out,
                      const int16_t *tx_tables, const int16_t *tx_tables_t,
                      TxTableLayout lay, const xvcgpu_rdoq_contexts *rq_ctx = nullptr,
-                     const xvcgpu_rdoq_params *rq_prm = nullptr) {
+                     const xvcgpu_rdoq_params *rq_prm = nullptr,
+                     unsigned long long *dist_out = nullptr) {
   __shared__ Tx2Shared s_all[TX2_WAVES];
   __shared__ RdoqShared<256> rq_all[RDOQ ? TX2_WAVES : 1];
   Tx2Shared &s = s_all[threadIdx.x >> 6];
@@ -368,7 +399,7 @@ residual_wave_kernel(PicView orig, PicView pred, PicView rec,
   tx2_job<MODE, 64, RDOQ>(s, b, bi, pred.bd, orig.c[b.comp],
                           pp.p + (ptrdiff_t)b.y * pp.stride + b.x, pp.stride, rec.c[b.comp],
                           levels, level_off, nnz_out, tx_tables, tx_tables_t, lay, nullptr, 0,
-                          &rq_all[RDOQ ? (threadIdx.x >> 6) : 0], rq_ctx, rq_prm);
+                          &rq_all[RDOQ ? (threadIdx.x >> 6) : 0], rq_ctx, rq_prm, dist_out);
 }
 
 #endif  // XVCGPU_K_TX2_H_

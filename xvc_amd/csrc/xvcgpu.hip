@@ -107,22 +107,24 @@ void init_views(xvcgpu_picture *p) {
 template <int MODE>
 void launch_residual(xvcgpu_ctx *ctx, const PicView &o, const PicView &p,
                             const PicView &r, const xvcgpu_tx_block *d_blocks, int n,
-                            int16_t *d_levels, const uint32_t *d_off, int32_t *d_nnz) {
+                            int16_t *d_levels, const uint32_t *d_off, int32_t *d_nnz,
+                            unsigned long long *d_dist = nullptr) {
   const int n_wg = (n + TX2_WAVES - 1) / TX2_WAVES;
   hipLaunchKernelGGL(residual_wave_kernel<MODE>, dim3((n_wg + 7) / 8 * 8),
                      dim3(64 * TX2_WAVES), 0, ctx->stream, o, p, r, d_blocks, n,
                      d_levels, d_off, d_nnz, ctx->d_tx_tables, ctx->d_tx_tables_t,
-                     xvcgpu_tx_layout(), nullptr, nullptr);
+                     xvcgpu_tx_layout(), nullptr, nullptr, d_dist);
   // general path: small batches (a decoder's dependency waves) one workgroup per
   // block; picture-sized batches (mostly small blocks) the scanning form
   if (n <= 2048)
     hipLaunchKernelGGL(residual_per_job_kernel<MODE>, dim3(n), dim3(TX_THREADS), 0, ctx->stream,
                        o, p, r, d_blocks, n, d_levels, d_off, d_nnz, ctx->d_tx_tables,
-                       xvcgpu_tx_layout());
+                       xvcgpu_tx_layout(), d_dist);
   else
     hipLaunchKernelGGL(residual_kernel<MODE>, dim3((n + TX_THREADS - 1) / TX_THREADS),
                        dim3(TX_THREADS), 0, ctx->stream, o, p, r, d_blocks, n, d_levels,
-                       d_off, d_nnz, ctx->d_tx_tables, xvcgpu_tx_layout(), nullptr, nullptr);
+                       d_off, d_nnz, ctx->d_tx_tables, xvcgpu_tx_layout(), nullptr, nullptr,
+                       d_dist);
 }
 
 // TransformAndReconstruct with the RDO quantiser for the blocks that ask for it
@@ -997,6 +999,26 @@ xvcgpu_status xvcgpu_inv_transform_batch(xvcgpu_ctx *ctx,
                                const_cast<int16_t *>(d_levels), d_level_offsets,
                                const_cast<int32_t *>(d_nnz));
   CHECK_LAUNCH(ctx, "inv_transform_batch");
+  return XVCGPU_OK;
+}
+
+xvcgpu_status xvcgpu_inv_transform_dist_batch(xvcgpu_ctx *ctx, const xvcgpu_picture *orig,
+                                              const xvcgpu_picture *pred, xvcgpu_picture *rec,
+                                              const xvcgpu_tx_block *d_blocks, int n,
+                                              const int16_t *d_levels,
+                                              const uint32_t *d_level_offsets,
+                                              const int32_t *d_nnz, uint64_t *d_dist) {
+  if (!ctx || !orig || !pred || !rec || n < 0 ||
+      (n && (!d_blocks || !d_levels || !d_level_offsets || !d_nnz || !d_dist)))
+    return XVCGPU_INVALID_ARGUMENT;
+  if (orig->w != pred->w || orig->h != pred->h || orig->bd != pred->bd)
+    return fail(ctx, XVCGPU_INVALID_ARGUMENT, "picture mismatch");
+  if (n == 0) return XVCGPU_OK;
+  launch_residual<TX_MODE_INV>(ctx, orig->v, pred->v, rec->v, d_blocks, n,
+                               const_cast<int16_t *>(d_levels), d_level_offsets,
+                               const_cast<int32_t *>(d_nnz),
+                               reinterpret_cast<unsigned long long *>(d_dist));
+  CHECK_LAUNCH(ctx, "inv_transform_dist_batch");
   return XVCGPU_OK;
 }
 

@@ -31,6 +31,7 @@
 #ifndef XVC_AMD_HOST_XVC_GPU_OPS_H_
 #define XVC_AMD_HOST_XVC_GPU_OPS_H_
 
+#include <array>
 #include <cmath>
 #include <stdexcept>
 #include <string>
