@@ -267,9 +267,14 @@ xvcgpu_status xvcgpu_mc_metric_batch(xvcgpu_ctx *ctx, const xvcgpu_picture *orig
  * 0xffffffff, vectors 0 (no real result has cost 0xffffffff).
  * flags: XVCGPU_ME_FULLPEL runs the TZ search; XVCGPU_ME_SUBPEL runs the
  * 9+8 point half/quarter-pel refinement starting from results[i].fullpel_*
- * (taken from the TZ search when both flags are set). */
+ * (taken from the TZ search when both flags are set).  XVCGPU_ME_LIC_JOBS: the
+ * batch holds jobs with XVC_ME_USE_LIC (xvcgpu_types.h: AC-only metrics,
+ * GetFullpelMetric / GetSubpelMetric inter_search.cc:1059-1076); their kernel
+ * instances are launched beside the plain ones.  Without the flag such a job
+ * is reported unsupported. */
 #define XVCGPU_ME_FULLPEL 1
 #define XVCGPU_ME_SUBPEL 2
+#define XVCGPU_ME_LIC_JOBS 4
 #define XVCGPU_ME_UNSUPPORTED 0xffffffffu /* fullpel_cost / subpel_dist of a job not taken */
 xvcgpu_status xvcgpu_me_search(xvcgpu_ctx *ctx, const xvcgpu_picture *orig,
                                const xvcgpu_picture *ref, int flags,

@@ -78,11 +78,22 @@ typedef struct xvcgpu_cu_info {
  * of InterSearch::MotionEstNormal (inter_search.cc:606-662) with the TZ
  * search method.  Everything the reference derives from neighbouring CUs
  * (AMVP predictor, previous CU's full-pel result) is an input here. */
+/* xvcgpu_me_block.fullpel_mv is a flag byte (0 / 1 as before: bit 0):
+ * XVC_ME_FULLPEL_MV  cu.GetFullpelMv(): vector differences priced and the
+ *                    result kept in whole samples (inter_tz_search.cc:96,
+ *                    inter_search.cc:645-650);
+ * XVC_ME_USE_LIC     cu.GetUseLic(): the CU tries local illumination
+ *                    compensation, so the search compares with the block
+ *                    means removed - kSadAcOnly[Fast] in the full-pel stage,
+ *                    kSatdAcOnly in the sub-pel stage (GetFullpelMetric /
+ *                    GetSubpelMetric, inter_search.cc:1059-1076). */
+#define XVC_ME_FULLPEL_MV 1
+#define XVC_ME_USE_LIC 2
 typedef struct xvcgpu_me_block {
   int16_t x, y;        /* luma position                                    */
   uint8_t w, h;        /* luma size, each in {4,8,16,32,64}                */
   uint8_t depth_nonzero; /* cu.GetDepth() != 0 (inter_tz_search.cc:117)    */
-  uint8_t fullpel_mv;  /* cu.GetFullpelMv() (mvd down-shift, :96)          */
+  uint8_t fullpel_mv;  /* XVC_ME_FULLPEL_MV | XVC_ME_USE_LIC                */
   int32_t mvp_x, mvp_y;   /* AMVP predictor, 1/16 pel (unclipped)          */
   int32_t prev_x, prev_y; /* previous_fullpel_ for this (list,ref_idx)     */
   uint32_t lambda16;   /* floor(65536*sqrt(lambda)) (inter_tz_search.cc:98)*/

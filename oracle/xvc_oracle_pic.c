@@ -534,14 +534,19 @@ void xo_tz_search(int bd, const xvcgpu_me_block *b, int pic_w, int pic_h,
   s.bd = bd;
   s.w = b->w;
   s.h = b->h;
-  s.metric = b->h > 8 ? XVC_METRIC_SAD_FAST : XVC_METRIC_SAD;
+  /* GetFullpelMetric (inter_search.cc:1059-1069): CUs that try local illumination
+   * compensation compare with the block means removed */
+  if (b->fullpel_mv & XVC_ME_USE_LIC)
+    s.metric = b->h > 8 ? XVC_METRIC_SAD_ACONLY_FAST : XVC_METRIC_SAD_ACONLY;
+  else
+    s.metric = b->h > 8 ? XVC_METRIC_SAD_FAST : XVC_METRIC_SAD;
   s.orig = orig + (ptrdiff_t)b->y * os + b->x;
   s.ref = ref + (ptrdiff_t)b->y * rs + b->x;
   s.os = os;
   s.rs = rs;
   s.mvp_x = b->mvp_x;
   s.mvp_y = b->mvp_y;
-  s.down = b->fullpel_mv ? 2 : 0;
+  s.down = (b->fullpel_mv & XVC_ME_FULLPEL_MV) ? 2 : 0;
   s.lambda = b->lambda16;
   s.cost_best = UINT64_MAX;
   const int range = b->search_range;
@@ -649,8 +654,10 @@ void xo_subpel_search(int bd, const xvcgpu_me_block *b, int pic_w, int pic_h,
       const int mx = base_x + d[0] * scale, my = base_y + d[1] * scale;
       xo_mc_block(bd, 0, b->x, b->y, b->w, b->h, mx, my, pic_w, pic_h, ref, rs,
                   pred, 64);
-      uint64_t dist = xo_metric_ss(XVC_METRIC_SATD, bd, 0, 1, 1.0, b->w, b->h, o,
-                                   os, pred, 64);
+      /* GetSubpelMetric (inter_search.cc:1071-1076) */
+      uint64_t dist = xo_metric_ss((b->fullpel_mv & XVC_ME_USE_LIC) ? XVC_METRIC_SATD_ACONLY
+                                                                    : XVC_METRIC_SATD,
+                                   bd, 0, 1, 1.0, b->w, b->h, o, os, pred, 64);
       if (dist >= best_cost) continue;
       uint32_t bits = xo_mvd_bits(b->mvp_x, b->mvp_y, mx, my, 0);
       uint64_t cost = dist + ((uint32_t)(b->lambda16 * bits) >> 16);

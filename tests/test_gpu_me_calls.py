@@ -44,6 +44,7 @@ def me_blocks(api, calls):
     for k in ("x", "y", "w", "h", "depth_nonzero", "fullpel_mv", "mvp_x", "mvp_y", "prev_x",
               "prev_y", "lambda16", "search_range"):
         b[k] = calls[k]
+    b["fullpel_mv"] |= np.where(calls["use_lic"] != 0, 2, 0).astype(np.uint8)   # XVC_ME_USE_LIC
     return b
 
 
@@ -53,14 +54,19 @@ def test_me_search_reproduces_encoder_motion_searches(gpu, name):
     fx = sf.StreamFixture(name)
     pics, w, h = decode_stream(ctx, fx)
     calls = tmc.load_calls(name)
-    calls = calls[calls["use_lic"] == 0]
     done = 0
     for poc in sorted(set(calls["poc"].tolist())):
         O = ctx.picture(w, h, 10)
         O.upload([tmc.original_luma(w, h, poc), None, None], tmc.BL)
         for ref_poc in sorted(set(calls["ref_poc"][calls["poc"] == poc].tolist())):
             sel = calls[(calls["poc"] == poc) & (calls["ref_poc"] == ref_poc)]
-            res = ctx.me_search(O, pics[ref_poc], me_blocks(api, sel))
+            res = ctx.me_search(O, pics[ref_poc], me_blocks(api, sel),
+                                flags=api.ME_FULLPEL | api.ME_SUBPEL | api.ME_LIC_JOBS)
+            if (sel["use_lic"] != 0).any():     # not announced: reported, not computed
+                r0 = ctx.me_search(O, pics[ref_poc], me_blocks(api, sel[:64]))
+                lic0 = sel["use_lic"][:64] != 0
+                assert (r0["subpel_dist"][lic0] == 0xffffffff).all()
+                assert (r0["subpel_dist"][~lic0] != 0xffffffff).all()
             for k_res, k_call in (("fullpel_x", "fullpel_x"), ("fullpel_y", "fullpel_y"),
                                   ("mv_x", "mv_x"), ("mv_y", "mv_y"), ("subpel_dist", "dist")):
                 bad = np.nonzero(res[k_res].astype(np.int64) != sel[k_call].astype(np.int64))[0]

@@ -149,7 +149,7 @@ def test_mc_batch(gpu, xo, bd):
     P.destroy()
 
 
-def me_blocks(rng, api, pw, ph, n):
+def me_blocks(rng, api, pw, ph, n, lic=False):
     blocks = np.zeros(n, api.ME_DTYPE)
     for i in range(n):
         w = int(rng.choice([4, 8, 16, 32, 64])); h = int(rng.choice([4, 8, 16, 32, 64]))
@@ -158,7 +158,8 @@ def me_blocks(rng, api, pw, ph, n):
         b["x"] = int(rng.integers(0, (pw - w) // 4 + 1)) * 4
         b["y"] = int(rng.integers(0, (ph - h) // 4 + 1)) * 4
         b["depth_nonzero"] = int(rng.integers(0, 2))
-        b["fullpel_mv"] = int(rng.integers(0, 5) == 0)
+        # XVC_ME_FULLPEL_MV | XVC_ME_USE_LIC (AC-only metrics) for a third of the jobs
+        b["fullpel_mv"] = int(rng.integers(0, 5) == 0) | (2 if lic and rng.integers(0, 3) == 0 else 0)
         b["mvp_x"] = int(rng.integers(-200, 200))
         b["mvp_y"] = int(rng.integers(-200, 200))
         b["prev_x"] = int(rng.integers(-20, 20))
@@ -185,8 +186,9 @@ def test_me_search(gpu, xo, bd):
         O, R = ctx.picture(pw, ph, bd), ctx.picture(pw, ph, bd)
         O.upload([orig, None, None], BL)
         R.upload([ref, None, None], BL)
-        blocks = me_blocks(rng, api, pw, ph, 40)
-        res = ctx.me_search(O, R, blocks)
+        blocks = me_blocks(rng, api, pw, ph, 40, lic=True)
+        all_flags = api.ME_FULLPEL | api.ME_SUBPEL | api.ME_LIC_JOBS
+        res = ctx.me_search(O, R, blocks, flags=all_flags)
         n_sub = 0
         for i, b in enumerate(blocks):
             s = to_me_struct(b)
@@ -194,7 +196,7 @@ def test_me_search(gpu, xo, bd):
             assert (int(res[i]["fullpel_x"]), int(res[i]["fullpel_y"])) == (fx, fy), \
                 (motion, tuple(b), tuple(res[i]), fx, fy)
             assert int(res[i]["fullpel_cost"]) == cost
-            if b["fullpel_mv"]:
+            if b["fullpel_mv"] & 1:
                 assert (int(res[i]["mv_x"]), int(res[i]["mv_y"])) == (fx * 16, fy * 16)
                 continue
             (sx, sy), sd = xo.subpel_search(bd, s, pw, ph, orig, ref, BL, (fx, fy))
@@ -204,8 +206,8 @@ def test_me_search(gpu, xo, bd):
             n_sub += 1
         assert n_sub > 20
         # the two phases run separately give the same answer
-        r1 = ctx.me_search(O, R, blocks, flags=api.ME_FULLPEL)
-        r2 = ctx.me_search(O, R, blocks, flags=api.ME_SUBPEL, results=r1)
+        r1 = ctx.me_search(O, R, blocks, flags=api.ME_FULLPEL | api.ME_LIC_JOBS)
+        r2 = ctx.me_search(O, R, blocks, flags=api.ME_SUBPEL | api.ME_LIC_JOBS, results=r1)
         assert np.array_equal(r2, res)
         O.destroy()
         R.destroy()

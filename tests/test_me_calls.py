@@ -30,7 +30,8 @@ def original_luma(w, h, poc, border=BL):
 def me_struct(c):
     s = ol.MeBlock()
     s.x, s.y, s.w, s.h = int(c["x"]), int(c["y"]), int(c["w"]), int(c["h"])
-    s.depth_nonzero, s.fullpel_mv = int(c["depth_nonzero"]), int(c["fullpel_mv"])
+    s.depth_nonzero = int(c["depth_nonzero"])
+    s.fullpel_mv = int(c["fullpel_mv"]) | (2 if c["use_lic"] else 0)    # XVC_ME_* flags
     s.mvp_x, s.mvp_y = int(c["mvp_x"]), int(c["mvp_y"])
     s.prev_x, s.prev_y = int(c["prev_x"]), int(c["prev_y"])
     s.lambda16, s.search_range = int(c["lambda16"]), int(c["search_range"])
@@ -48,14 +49,13 @@ def test_oracle_reproduces_encoder_motion_searches():
     assert len(calls) > 30000
     xo = ol.Lib("xo")
     orig = {}
-    # calls of CUs that try local illumination compensation use the AC-only
-    # metrics (GetFullpelMetric / GetSubpelMetric, inter_search.cc:1059-1076): not
-    # part of xvcgpu_me_search (DESIGN: out of scope this round)
+    # half of this stream's calls come from CUs that try local illumination
+    # compensation: AC-only metrics (GetFullpelMetric / GetSubpelMetric)
     lic = calls["use_lic"] != 0
     assert 0 < lic.sum() < len(calls)
     step = 1
     sizes = set()
-    for c in calls[~lic][::step]:
+    for c in calls[::step]:
         poc = int(c["poc"])
         if poc not in orig:
             orig[poc] = original_luma(w, h, poc)
@@ -66,8 +66,8 @@ def test_oracle_reproduces_encoder_motion_searches():
         if c["fullpel_mv"]:
             # GetSubpelDist at the full-pel vector (inter_search.cc:647-650)
             mx, my = 16 * fx_, 16 * fy_
-            dist = xo.mc_metric(10, 1, 32, 16, s.x, s.y, s.w, s.h, (mx, my), w, h, orig[poc],
-                                ref, BL)       # 1 = XVC_METRIC_SATD
+            dist = xo.mc_metric(10, 2 if c["use_lic"] else 1, 32, 16, s.x, s.y, s.w, s.h,
+                                (mx, my), w, h, orig[poc], ref, BL)    # SATD / SATD AC-only
         else:
             (mx, my), dist = xo.subpel_search(10, s, w, h, orig[poc], ref, BL, (fx_, fy_))
         assert (mx, my) == (int(c["mv_x"]), int(c["mv_y"])), tuple(c)

@@ -60,6 +60,11 @@ struct MeCtx {
   int mvp_x, mvp_y, down;
   uint32_t lambda;
   int min_x, min_y, max_x, max_y;  // TZ window (mv_min / mv_max)
+  // CUs that try local illumination compensation: kSadAcOnly[Fast]
+  // (GetFullpelMetric, inter_search.cc:1059-1069).  orig_sum = sum of the
+  // original block over the rows the metric visits.
+  bool ac;
+  int orig_sum;
 };
 
 // CheckCostBest's cost (inter_tz_search.cc:261-276).

@@ -133,6 +133,7 @@ struct __attribute__((aligned(16))) Me2SharedT {
     SpCand sp[SUB ? 10 : 1];                // fast path (k_subpel.h)
   };
   uint32_t dist[12];
+  int dsum[12];                             // AC-only: sum(orig - pred) per candidate
   int16_t taps[SUB ? 16 : 1][8];            // LDS copy of kLumaTaps
 };
 template <int MS>
@@ -225,9 +226,76 @@ __device__ __forceinline__ void me2_eval_quads_gen(const MeCtx &c, uint32_t *cos
   }
 }
 
+// ---- AC-only SAD (ComputeSadAcOnly / CalcMeanDiff, sample_metric.cc:686-703,
+// :770-783): sum |a - b - avg| over the visited rows, avg = the truncated mean
+// of a - b.  One candidate per LANE (the LIC instances of the kernel only: half
+// of the searches of a picture that allows LIC, none of the bench's): two
+// passes over the candidate's rows, the second as v_sad_u16 of the two blocks
+// biased so that the mean difference cancels.
+__device__ __forceinline__ uint32_t me2_sad_ac_lane(const MeCtx &c, const uint16_t *s_orig,
+                                                    const uint16_t *r) {
+  typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+  const int segw = c.w >= 8 ? 8 : 4, spr = c.w / segw, nsg = c.rows * spr;
+  uint32_t sb = 0;
+  for (int sg = 0; sg < nsg; sg++) {
+    const int y = (sg / spr) * c.row_step, x = (sg % spr) * segw;
+    const uint16_t *rp = r + (ptrdiff_t)y * c.rs + x;
+    if (segw == 8) {
+      const U16x8 bb = *reinterpret_cast<const U16x8 *>(rp);
+#pragma unroll
+      for (int k = 0; k < 4; k++) sb = __builtin_amdgcn_sad_u16(bb.v[k], 0u, sb);
+    } else {
+      const U16x4 bb = *reinterpret_cast<const U16x4 *>(rp);
+      sb = __builtin_amdgcn_sad_u16(bb.v[0], 0u, sb);
+      sb = __builtin_amdgcn_sad_u16(bb.v[1], 0u, sb);
+    }
+  }
+  // (delta_sum * (1 + SkipLines)) / (width * height), C division
+  const int num = (c.orig_sum - (int)sb) * c.sad_mul;
+  const int lwh = (31 - __clz(c.w)) + (31 - __clz(c.h));
+  const int avg = num >= 0 ? num >> lwh : -((-num) >> lwh);
+  const uint32_t ka = (uint32_t)(8192 - avg) * 0x10001u, kb = 0x20002000u;
+  auto bias = [](uint32_t v, uint32_t k) {
+    return __builtin_bit_cast(uint32_t, __builtin_bit_cast(us2, v) + __builtin_bit_cast(us2, k));
+  };
+  uint32_t sum = 0;
+  for (int sg = 0; sg < nsg; sg++) {
+    const int y = (sg / spr) * c.row_step, x = (sg % spr) * segw;
+    const uint16_t *rp = r + (ptrdiff_t)y * c.rs + x;
+    if (segw == 8) {
+      const uint4 a = *reinterpret_cast<const uint4 *>(s_orig + y * c.w + x);
+      const U16x8 bb = *reinterpret_cast<const U16x8 *>(rp);
+      sum = __builtin_amdgcn_sad_u16(bias(a.x, ka), bias(bb.v[0], kb), sum);
+      sum = __builtin_amdgcn_sad_u16(bias(a.y, ka), bias(bb.v[1], kb), sum);
+      sum = __builtin_amdgcn_sad_u16(bias(a.z, ka), bias(bb.v[2], kb), sum);
+      sum = __builtin_amdgcn_sad_u16(bias(a.w, ka), bias(bb.v[3], kb), sum);
+    } else {
+      const uint2 a = *reinterpret_cast<const uint2 *>(s_orig + y * 4);
+      const U16x4 bb = *reinterpret_cast<const U16x4 *>(rp);
+      sum = __builtin_amdgcn_sad_u16(bias(a.x, ka), bias(bb.v[0], kb), sum);
+      sum = __builtin_amdgcn_sad_u16(bias(a.y, ka), bias(bb.v[1], kb), sum);
+    }
+  }
+  return (sum * c.sad_mul) >> c.sad_shift;
+}
+
+__device__ __forceinline__ void me2_eval_positions_ac(const MeCtx &c, uint32_t *cost,
+                                                      const uint16_t *s_orig, int n) {
+  for (int i = ME2_LANE; i < n; i += 64) {
+    const uint32_t pk = cost[i];
+    if (pk == ME2_NOPOS) continue;
+    const int x = (int)(int16_t)(pk & 0xffffu), y = (int)pk >> 16;
+    cost[i] = me2_sad_ac_lane(c, s_orig, c.ref + (ptrdiff_t)y * c.rs + x);
+  }
+}
+
 // Dispatch on the (wave-uniform) block shape.  Callers wave_sync() around it.
 __device__ __forceinline__ void me2_eval_positions(const MeCtx &c, uint32_t *cost,
                                                    const uint16_t *s_orig, int n) {
+  if (c.ac) {
+    me2_eval_positions_ac(c, cost, s_orig, n);
+    return;
+  }
   const int nseg = c.w >= 8 ? c.rows * (c.w >> 3) : 0;
   if (nseg == 16) me2_eval_quads_reg<4>(c, cost, s_orig, n);
   else if (nseg == 8) me2_eval_quads_reg<2>(c, cost, s_orig, n);
@@ -344,7 +412,10 @@ __device__ __forceinline__ void me2_build_hplanes(Me2Shared<MS> &s, int bd, int 
 // One SATD pass over `ncand` candidates described in s.cand_*: lane = one tile
 // row (TW samples) of one TW x TH tile of one candidate; s.dist[c] accumulates
 // the normalised tile sums (ComputeSatdNxM, sample_metric.cc:403-641).
-template <int MS, int TW, int TH>
+// AC: kSatdAcOnly (ComputeSatdAcOnly, sample_metric.cc:391-401): s.dsum[c] holds
+// the truncated mean of orig - pred of candidate c, removed from every sample.
+// SUM: no transform, only s.dsum[c] += sum(orig - pred) (the pass before).
+template <int MS, int TW, int TH, bool AC = false, bool SUM = false>
 __device__ __forceinline__ void me2_satd_cands(Me2Shared<MS> &s, int bd, int w,
                                                int h, int ncand) {
   const int lane = ME2_LANE;
@@ -405,15 +476,24 @@ __device__ __forceinline__ void me2_satd_cands(Me2Shared<MS> &s, int bd, int w,
           ok[4 * q + 0] = v.x; ok[4 * q + 1] = v.y; ok[4 * q + 2] = v.z; ok[4 * q + 3] = v.w;
         }
       }
+      const int avg = AC && !SUM ? s.dsum[cnd] : 0;
 #pragma unroll
       for (int j = 0; j < TW; j++) {
         const int pred = d_clip_bd((int16_t)(acc[j] >> sh), smax);
         const int ov = (j & 1) ? (int)(ok[j / 2] >> 16) : (int)(ok[j / 2] & 0xffff);
-        m[j] = ov - pred;
+        m[j] = ov - pred - avg;
       }
     } else {
 #pragma unroll
       for (int j = 0; j < TW; j++) m[j] = 0;
+    }
+    if (SUM) {
+      int t = 0;
+#pragma unroll
+      for (int j = 0; j < TW; j++) t += m[j];
+      t = dpp_group_sum<TH>(t);
+      if (active && (lane % TH) == 0) atomicAdd(&s.dsum[cnd], t);
+      continue;
     }
     // horizontal WHT in registers
 #pragma unroll
@@ -459,15 +539,15 @@ __device__ __forceinline__ void me2_satd_cands(Me2Shared<MS> &s, int bd, int w,
   }
 }
 
-template <int MS>
+template <int MS, bool AC = false, bool SUM = false>
 __device__ __forceinline__ void me2_satd_dispatch(Me2Shared<MS> &s, int bd, int w,
                                                   int h, int ncand) {
-  if (w == 4 && h == 4) me2_satd_cands<MS, 4, 4>(s, bd, w, h, ncand);
-  else if (h == 4 && w > h) me2_satd_cands<MS, 8, 4>(s, bd, w, h, ncand);
-  else if (w == 4 && h > w) me2_satd_cands<MS, 4, 8>(s, bd, w, h, ncand);
-  else if (w > h) me2_satd_cands<MS, 16, 8>(s, bd, w, h, ncand);
-  else if (w < h) me2_satd_cands<MS, 8, 16>(s, bd, w, h, ncand);
-  else me2_satd_cands<MS, 8, 8>(s, bd, w, h, ncand);
+  if (w == 4 && h == 4) me2_satd_cands<MS, 4, 4, AC, SUM>(s, bd, w, h, ncand);
+  else if (h == 4 && w > h) me2_satd_cands<MS, 8, 4, AC, SUM>(s, bd, w, h, ncand);
+  else if (w == 4 && h > w) me2_satd_cands<MS, 4, 8, AC, SUM>(s, bd, w, h, ncand);
+  else if (w > h) me2_satd_cands<MS, 16, 8, AC, SUM>(s, bd, w, h, ncand);
+  else if (w < h) me2_satd_cands<MS, 8, 16, AC, SUM>(s, bd, w, h, ncand);
+  else me2_satd_cands<MS, 8, 8, AC, SUM>(s, bd, w, h, ncand);
 }
 
 // Offsets of the 9 half-pel / 8 quarter-pel candidates in issue order
@@ -484,8 +564,8 @@ __device__ __forceinline__ void me2_subpel_mv(int pass, int i, int base_x, int b
   my = base_y + kSubpelOff[pass][k][1] * scale;
 }
 
-__device__ __forceinline__ bool me2_subpel_fast(int w, int h, int bd) {
-  return w >= 8 && h >= 8 && bd <= 10;
+__device__ __forceinline__ bool me2_subpel_fast(int w, int h, int bd, bool ac = false) {
+  return w >= 8 && h >= 8 && bd <= 10 && !ac;   // AC-only SATD: the 32-bit path
 }
 
 // Evaluate the SATD of the n = 9 - pass candidates of a sub-pel pass (or, with
@@ -510,7 +590,7 @@ __device__ __forceinline__ void me2_subpel_eval(Me2Shared<MS> &s, const MeCtx &c
   const int mykey = (cpx + 1) * 16 + cfx;
   // fast path (k_subpel.h): both sides >= 8, 16-bit-safe residuals;
   // the caller has transposed s.orig to column-major for it
-  const bool fastp = me2_subpel_fast(w, h, bd);
+  const bool fastp = me2_subpel_fast(w, h, bd, c.ac);
   const bool need = lane < n && (fastp || cfx != 0);
   int myslot = -1, nslots = 0, slot_key[3] = {0, 0, 0};
 #pragma unroll
@@ -581,9 +661,22 @@ __device__ __forceinline__ void me2_subpel_eval(Me2Shared<MS> &s, const MeCtx &c
 #pragma unroll
     for (int k = 0; k < 8; k++) s.cand_taps[lane][k] = kLumaTaps[cfy][k];
     s.dist[lane] = 0;
+    s.dsum[lane] = 0;
   }
   wave_sync();
-  me2_satd_dispatch(s, bd, w, h, n);
+  if (c.ac) {
+    // CalcMeanDiff<0> (sample_metric.cc:770-783) per candidate, then the transform
+    me2_satd_dispatch<MS, true, true>(s, bd, w, h, n);
+    wave_sync();
+    if (lane < n) {
+      const int num = s.dsum[lane], lwh = (31 - __clz(w)) + (31 - __clz(h));
+      s.dsum[lane] = num >= 0 ? num >> lwh : -((-num) >> lwh);
+    }
+    wave_sync();
+    me2_satd_dispatch<MS, true, false>(s, bd, w, h, n);
+  } else {
+    me2_satd_dispatch(s, bd, w, h, n);
+  }
   wave_sync();
 }
 
@@ -629,14 +722,17 @@ __device__ __forceinline__ int me2_rotated_wg(int block, int n_wg, const Me2Rot 
 // and no smaller class.
 // PH = phases compiled in.  (Forcing more waves per SIMD onto the full-pel
 // instance via a register cap spills and measured slower: 64 -> 88..149 us.)
-template <int MS, int PH>
+// LIC = the instance for the jobs with XVC_ME_USE_LIC (AC-only metrics); the
+// plain instances leave those jobs alone (or, when the caller did not announce
+// any - lic_launched false - report them unsupported).
+template <int MS, int PH, bool LIC = false>
 __global__ void __launch_bounds__(64 * ME2_WAVES(MS), ME2_MIN_WAVES(MS))
 me_search_wave_kernel(PicView orig, PicView ref,
                       const xvcgpu_me_block *blocks, int n,
                       xvcgpu_me_result *results, const TzCand *tz_pattern,
-                      Me2Sched sched, int max_launched) {
+                      Me2Sched sched, int max_launched, bool lic_launched = false) {
   constexpr int WPG = ME2_WAVES(MS);
-  constexpr bool kSched = (PH & XVCGPU_ME_FULLPEL) != 0;
+  constexpr bool kSched = !LIC && (PH & XVCGPU_ME_FULLPEL) != 0;
   typedef Me2SharedT<MS, (PH & XVCGPU_ME_SUBPEL) != 0> Shared;
   __shared__ Shared s_all[WPG];
   Shared &s = s_all[threadIdx.x >> 6];
@@ -661,9 +757,11 @@ me_search_wave_kernel(PicView orig, PicView ref,
     // larger than the caller's max_block_size) is answered with the
     // XVCGPU_ME_UNSUPPORTED record instead of being left as it was
     const bool pow2 = (b.w & (b.w - 1)) == 0 && (b.h & (b.h - 1)) == 0;
+    const bool lic = (b.fullpel_mv & XVC_ME_USE_LIC) != 0;
     const bool valid = pow2 && b.w >= 4 && b.h >= 4 && b.w <= 64 && b.h <= 64 &&
-                       mx <= max_launched;
-    if (MS == 16 && !valid) {
+                       mx <= max_launched && (!lic || lic_launched);
+    if (lic != LIC && valid) return;  // the other set of instances
+    if (MS == 16 && !LIC && !valid) {
       if (ME2_LANE == 0) {
         xvcgpu_me_result r;
         r.fullpel_x = r.fullpel_y = r.mv_x = r.mv_y = 0;
@@ -674,7 +772,7 @@ me_search_wave_kernel(PicView orig, PicView ref,
     }
     if (!valid || mx > MS || (MS > 16 && mx <= MS / 2)) return;  // other class
     // me_subpel_team_kernel's jobs
-    if (MS == 64 && PH == XVCGPU_ME_SUBPEL && me2_subpel_fast(b.w, b.h, orig.bd)) return;
+    if (MS == 64 && PH == XVCGPU_ME_SUBPEL && me2_subpel_fast(b.w, b.h, orig.bd, LIC)) return;
   }
   const int lane = ME2_LANE;
   const PlaneView po = orig.c[0], pr = ref.c[0];
@@ -693,8 +791,10 @@ me_search_wave_kernel(PicView orig, PicView ref,
   c.ref = pr.p + (ptrdiff_t)b.y * pr.stride + b.x;
   c.mvp_x = b.mvp_x;
   c.mvp_y = b.mvp_y;
-  c.down = b.fullpel_mv ? 2 : 0;
+  c.down = (b.fullpel_mv & XVC_ME_FULLPEL_MV) ? 2 : 0;
   c.lambda = b.lambda16;
+  c.ac = LIC;
+  c.orig_sum = 0;
 
   if constexpr ((PH & XVCGPU_ME_SUBPEL) != 0)  // per-lane phase lookups come from LDS
     reinterpret_cast<uint32_t *>(&s.taps[0][0])[lane] =
@@ -709,6 +809,13 @@ me_search_wave_kernel(PicView orig, PicView ref,
     }
   }
 
+  if constexpr (LIC) {  // sum of the original over the rows the full-pel metric visits
+    wave_sync();
+    int t = 0;
+    for (int i = lane; i < c.rows * c.w; i += 64)
+      t += (int)s.orig[(i / c.w) * c.row_step * c.w + (i % c.w)];
+    c.orig_sum = wave_reduce_add_i32(t);
+  }
   ME2_TRACE(1);  // block descriptor read, original block loads issued
   xvcgpu_me_result res;
   if constexpr ((PH & XVCGPU_ME_FULLPEL) != 0) {
@@ -861,6 +968,11 @@ me_search_wave_kernel(PicView orig, PicView ref,
         if (rate >= st.cost || rate >= best) continue;
         const uint16_t *r = c.ref + (ptrdiff_t)gy * c.rs + gx;
         uint32_t sum = 0;
+        if (c.ac) {
+          const uint32_t cost = me_cost(c, me2_sad_ac_lane(c, s.orig, r), gx, gy);
+          if (cost < best) { best = cost; best_i = i; }
+          continue;
+        }
         if (segw == 8 && (nsg & 7) == 0) {
           // 8 independent 16-byte loads in flight per lane
           for (int sg0 = 0; sg0 < nsg; sg0 += 8) {
@@ -960,7 +1072,7 @@ me_search_wave_kernel(PicView orig, PicView ref,
       }
     }
     ME2_TRACE(7);  // sub-pel window loads issued
-    if (me2_subpel_fast(w, h, c.bd)) {
+    if (me2_subpel_fast(w, h, c.bd, c.ac)) {
       // column-major original for k_subpel.h: swap across the diagonal
       wave_sync();
       const int lw = 31 - __clz(w);
@@ -980,7 +1092,7 @@ me_search_wave_kernel(PicView orig, PicView ref,
         for (int i = lane; i < w * h; i += 64) s.orig[i] = tmp[i];
       }
     }
-    if (b.fullpel_mv) {
+    if (b.fullpel_mv & XVC_ME_FULLPEL_MV) {
       me2_subpel_eval(s, c, b, pic_w, pic_h, fpx, fpy, -1, res.mv_x, res.mv_y);
       res.subpel_dist = s.dist[0] >> (c.bd - 8);
     } else {
@@ -1087,7 +1199,9 @@ me_subpel_team_kernel(PicView orig, PicView ref, const xvcgpu_me_block *blocks, 
   {
     const int mx = b.w > b.h ? b.w : b.h;
     const bool pow2 = (b.w & (b.w - 1)) == 0 && (b.h & (b.h - 1)) == 0;
-    if (!pow2 || mx > MS || mx <= MS / 2 || !me2_subpel_fast(b.w, b.h, orig.bd)) return;
+    if (!pow2 || mx > MS || mx <= MS / 2 ||
+        !me2_subpel_fast(b.w, b.h, orig.bd, (b.fullpel_mv & XVC_ME_USE_LIC) != 0))
+      return;
   }
   const int tid = threadIdx.x, lane = ME2_LANE;
   const PlaneView po = orig.c[0], pr = ref.c[0];
@@ -1097,6 +1211,8 @@ me_subpel_team_kernel(PicView orig, PicView ref, const xvcgpu_me_block *blocks, 
   c.w = b.w;
   c.h = b.h;
   c.lambda = b.lambda16;
+  c.ac = false;
+  c.orig_sum = 0;
   const int w = b.w, h = b.h, ws = w + 16;
   xvcgpu_me_result res = results[bi];
   const int fpx = res.fullpel_x, fpy = res.fullpel_y;
@@ -1128,7 +1244,7 @@ me_subpel_team_kernel(PicView orig, PicView ref, const xvcgpu_me_block *blocks, 
       *reinterpret_cast<uint4 *>(s.win + r * ws + ch * 8) = make_uint4(v.v[0], v.v[1], v.v[2], v.v[3]);
     }
   }
-  if (b.fullpel_mv) {
+  if (b.fullpel_mv & XVC_ME_FULLPEL_MV) {
     me2_team_eval<MS, NW>(s, c, b, pic_w, pic_h, fpx, fpy, -1, res.mv_x, res.mv_y);
     res.subpel_dist = s.dist[0] >> (c.bd - 8);
   } else {

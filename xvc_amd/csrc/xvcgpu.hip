@@ -630,11 +630,20 @@ xvcgpu_status xvcgpu_me_search_sized(xvcgpu_ctx *ctx, const xvcgpu_picture *orig
     sched.record = ctx->d_me_rot + (e + 1) % 3;
     sched.clear = ctx->d_me_rot + (e + 2) % 3;
   }
-#define ME_LAUNCH(MS, PH)                                                          \
-  hipLaunchKernelGGL((me_search_wave_kernel<MS, PH>), me2_grid(n, ME2_WAVES(MS)),  \
-                     dim3(64 * ME2_WAVES(MS)), 0, ctx->stream, orig->v, ref->v,    \
-                     d_blocks, n, d_results, ctx->d_tz_pattern, sched,             \
-                     max_block_size > 32 ? 64 : (max_block_size > 16 ? 32 : 16))
+  const bool lic_jobs = (flags & XVCGPU_ME_LIC_JOBS) != 0;
+#define ME_LAUNCH_T(MS, PH, LIC)                                                        \
+  hipLaunchKernelGGL((me_search_wave_kernel<MS, PH, LIC>), me2_grid(n, ME2_WAVES(MS)),  \
+                     dim3(64 * ME2_WAVES(MS)), 0, ctx->stream, orig->v, ref->v,         \
+                     d_blocks, n, d_results, ctx->d_tz_pattern, sched,                  \
+                     max_block_size > 32 ? 64 : (max_block_size > 16 ? 32 : 16), lic_jobs)
+#define ME_LAUNCH(MS, PH) ME_LAUNCH_T(MS, PH, false)
+  // jobs of CUs that try local illumination compensation (XVC_ME_USE_LIC): their
+  // own instances, the two phases as two launches
+#define ME_LAUNCH_LIC(MS)                                        \
+  do {                                                           \
+    if (flags & XVCGPU_ME_FULLPEL) ME_LAUNCH_T(MS, 1, true);     \
+    if (flags & XVCGPU_ME_SUBPEL) ME_LAUNCH_T(MS, 2, true);      \
+  } while (0)
 #define ME_LAUNCH_CLASS(MS)                                \
   do {                                                     \
     if ((flags & 3) == 3) ME_LAUNCH(MS, 3);                \
@@ -660,9 +669,16 @@ xvcgpu_status xvcgpu_me_search_sized(xvcgpu_ctx *ctx, const xvcgpu_picture *orig
       hipLaunchKernelGGL((me_subpel_team_kernel<64, 4>), dim3((n + 7) / 8 * 8), dim3(256), 0,
                          ctx->stream, orig->v, ref->v, d_blocks, n, d_results);
   }
+  if (lic_jobs) {
+    ME_LAUNCH_LIC(16);
+    if (max_block_size > 16) ME_LAUNCH_LIC(32);
+    if (max_block_size > 32) ME_LAUNCH_LIC(64);
+  }
+#undef ME_LAUNCH_LIC
 #undef ME_LAUNCH_SPLIT
 #undef ME_LAUNCH_CLASS
 #undef ME_LAUNCH
+#undef ME_LAUNCH_T
   CHECK_LAUNCH(ctx, "me_search");
   return XVCGPU_OK;
 }
