@@ -1477,7 +1477,7 @@ def test_bench_multi_rank_path_runs(gpu):
                         "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                         "--master-port", str(port), os.path.join(root, "bench.py"),
                         "--gpus", "2", "--steps", "24", "--warmup", "6", "--no-cpu",
-                        "--width", "352", "--height", "288"],
+                        "--width", "352", "--height", "288", "--schedule", "rows"],
                        capture_output=True, text=True, timeout=600, env=env, cwd=root)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
