@@ -326,6 +326,7 @@ def algorithmic_bytes(d, W, H):
         # orig + reference read, reconstruction written, all three planes
         "recon_from_me": 3 * n_all * S,
         "mc_from_me": 2 * n_all * S,                 # reference read, prediction written
+        "fwd_from_me": 4 * n_all * S,                # orig + ref read, pred + coefficients written
         "fwd_transform": 3 * n_all * S,              # orig + pred read, coefficients written
         "quant_rdo": 2 * n_all * S,                  # coefficients read, levels written
         "inv_transform": 3 * n_all * S,              # levels + pred read, rec written

@@ -455,6 +455,17 @@ xvcgpu_status xvcgpu_recon_from_me(xvcgpu_ctx *ctx, const xvcgpu_picture *orig,
                                    int qp_y, int qp_c, int intra_pic, int ref_poc,
                                    int32_t *d_nnz, xvcgpu_cu_info *d_cus);
 
+/* The front half of that pipeline alone, for a quantiser that runs as its own
+ * kernel (xvcgpu_quant_rdo_batch): MotionCompensationMv of CU i into `pred`
+ * (TransformEncoder's prediction buffer) and the forward transform of orig -
+ * pred, coefficients of the CU's Y / U / V block at d_coeffs +
+ * d_coeff_offsets[3 * i + comp] (as xvcgpu_fwd_transform_batch writes them).
+ * CUs up to 16x16. */
+xvcgpu_status xvcgpu_fwd_from_me(xvcgpu_ctx *ctx, const xvcgpu_picture *orig,
+                                 const xvcgpu_picture *ref, xvcgpu_picture *pred,
+                                 const xvcgpu_me_block *d_blocks,
+                                 const xvcgpu_me_result *d_results, int n, int16_t *d_coeffs,
+                                 const uint32_t *d_coeff_offsets);
 /* The same with RdoQuant::QuantRdo (see xvcgpu_residual_rdoq_batch):
  * d_params[3 * i + comp] belongs to component comp of CU i; tx_flags = the
  * XVC_TXF_* bits common to all blocks (XVC_TXF_RDOQ is implied). */

@@ -152,6 +152,7 @@ SYMBOLS = [
     "xvcgpu_comm_group_end", "xvcgpu_comm_send_picture", "xvcgpu_comm_recv_picture",
     "xvcgpu_comm_send_rows", "xvcgpu_comm_recv_rows", "xvcgpu_comm_all_reduce_sum_u64",
     "xvcgpu_comm_send_bytes", "xvcgpu_comm_recv_bytes", "xvcgpu_inv_transform_dist_batch",
+    "xvcgpu_fwd_from_me",
 ]
 
 _vp = C.c_void_p
@@ -287,6 +288,7 @@ def load_library():
         "xvcgpu_comm_all_reduce_sum_u64": [_vp, _vp, C.c_int],
         "xvcgpu_comm_send_bytes": [_vp, _vp, C.c_size_t, C.c_int],
         "xvcgpu_inv_transform_dist_batch": [_vp, _vp, _vp, _vp, _vp, C.c_int, _vp, _vp, _vp, _vp],
+        "xvcgpu_fwd_from_me": [_vp, _vp, _vp, _vp, _vp, _vp, C.c_int, _vp, _vp],
         "xvcgpu_comm_recv_bytes": [_vp, _vp, C.c_size_t, C.c_int],
     }
     lib.xvcgpu_event_destroy.restype = None

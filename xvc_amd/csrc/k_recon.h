@@ -173,7 +173,11 @@ __device__ __forceinline__ void wave_interp_block_lds(int bd, int w, int h, int 
 // block of a CU up to 16x16 has at most 64 samples, which would leave three
 // quarters of a wave of its own idle through the whole pipeline).
 // RDOQ: quantise with RdoQuant::QuantRdo (k_rdoq.h); rq_prm[3 * cu + comp].
-template <bool RDOQ = false>
+// FWD: the front half only - prediction (also written to the picture `rec`,
+// which then plays TransformEncoder's prediction buffer) and forward transform,
+// coefficients to coeffs + coeff_off[3 * cu + comp]: what precedes a quantiser
+// that runs as its own kernel (xvcgpu_quant_rdo_batch).
+template <bool RDOQ = false, bool FWD = false>
 __global__ void __launch_bounds__(256)
 recon_from_me_kernel(PicView orig, PicView ref, PicView rec,
                      const xvcgpu_me_block *blocks, const xvcgpu_me_result *results,
@@ -181,7 +185,9 @@ recon_from_me_kernel(PicView orig, PicView ref, PicView rec,
                      int32_t *nnz_out, xvcgpu_cu_info *cus,
                      const int16_t *tx_tables, const int16_t *tx_tables_t,
                      TxTableLayout lay, const xvcgpu_rdoq_contexts *rq_ctx = nullptr,
-                     const xvcgpu_rdoq_params *rq_prm = nullptr) {
+                     const xvcgpu_rdoq_params *rq_prm = nullptr, int16_t *coeffs = nullptr,
+                     const uint32_t *coeff_off = nullptr) {
+  constexpr int TXM = FWD ? TX_MODE_FWD : TX_MODE_FULL;
   __shared__ ReconShared s_all[4];
   // one scratch per wave; a chroma wave splits it between its two halves
   // per wave: one 16x16 luma block, or two 8x8 chroma blocks side by side
@@ -250,9 +256,18 @@ recon_from_me_kernel(PicView orig, PicView ref, PicView rec,
     ME2_TRACE(1);
     tb.comp = (uint8_t)comp;
     tb.qp = (int8_t)qp_c;
-    tx2_job<TX_MODE_FULL, 32, RDOQ>(
-        s.tx, tb, 3 * ci + comp, bd, po, s.pred + g * 64, cw, pc, nullptr, nullptr, nnz_out,
-        tx_tables, tx_tables_t, lay, &orig_pre, g * 128,
+    if (FWD) {  // the prediction, for the inverse path later
+      const int i = (ME2_LANE & 31) * 4;
+      if (i < cw * ch) {
+        const int lw = 31 - __clz(cw);
+        *reinterpret_cast<U16x4 *>(pc.p + (ptrdiff_t)(cy + (i >> lw)) * pc.stride + cx +
+                                   (i & (cw - 1))) =
+            *reinterpret_cast<const U16x4 *>(s.pred + g * 64 + i);
+      }
+    }
+    tx2_job<TXM, 32, RDOQ>(
+        s.tx, tb, 3 * ci + comp, bd, po, s.pred + g * 64, cw, pc, FWD ? coeffs : nullptr,
+        FWD ? coeff_off : nullptr, nnz_out, tx_tables, tx_tables_t, lay, &orig_pre, g * 128,
         reinterpret_cast<RdoqShared<64> *>(rq_wave) + g, rq_ctx, rq_prm);
     ME2_TRACE(8);
     return;
@@ -276,12 +291,20 @@ recon_from_me_kernel(PicView orig, PicView ref, PicView rec,
   ME2_TRACE(1);
   tb.comp = 0;
   tb.qp = (int8_t)qp_y;
-  const int nnz = tx2_job<TX_MODE_FULL, 64, RDOQ>(s.tx, tb, 3 * ci, bd, orig.c[0], s.pred, cw,
-                                                  rec.c[0], nullptr, nullptr, nnz_out,
-                                                  tx_tables, tx_tables_t, lay, &orig_pre, 0,
-                                                  rq_wave, rq_ctx, rq_prm);
+  if (FWD) {
+    const PlaneView pc = rec.c[0];
+    const int lw = 31 - __clz(cw);
+    for (int i = ME2_LANE * 4; i < cw * ch; i += 256)
+      *reinterpret_cast<U16x4 *>(pc.p + (ptrdiff_t)(cy + (i >> lw)) * pc.stride + cx +
+                                 (i & (cw - 1))) = *reinterpret_cast<const U16x4 *>(s.pred + i);
+  }
+  const int nnz = tx2_job<TXM, 64, RDOQ>(s.tx, tb, 3 * ci, bd, orig.c[0], s.pred, cw,
+                                         rec.c[0], FWD ? coeffs : nullptr,
+                                         FWD ? coeff_off : nullptr, nnz_out,
+                                         tx_tables, tx_tables_t, lay, &orig_pre, 0,
+                                         rq_wave, rq_ctx, rq_prm);
   ME2_TRACE(8);
-  if (cus && ME2_LANE == 0) {
+  if (!FWD && cus && ME2_LANE == 0) {
     xvcgpu_cu_info c;
     c.x = (uint16_t)mb.x;
     c.y = (uint16_t)mb.y;

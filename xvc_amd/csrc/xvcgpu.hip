@@ -864,6 +864,26 @@ xvcgpu_status xvcgpu_recon_from_me(xvcgpu_ctx *ctx, const xvcgpu_picture *orig,
   return XVCGPU_OK;
 }
 
+xvcgpu_status xvcgpu_fwd_from_me(xvcgpu_ctx *ctx, const xvcgpu_picture *orig,
+                                 const xvcgpu_picture *ref, xvcgpu_picture *pred,
+                                 const xvcgpu_me_block *d_blocks,
+                                 const xvcgpu_me_result *d_results, int n, int16_t *d_coeffs,
+                                 const uint32_t *d_coeff_offsets) {
+  if (!ctx || !orig || !ref || !pred || n < 0 ||
+      (n && (!d_blocks || !d_results || !d_coeffs || !d_coeff_offsets)))
+    return XVCGPU_INVALID_ARGUMENT;
+  if (orig->w != ref->w || orig->h != ref->h || pred->w != ref->w || pred->h != ref->h)
+    return fail(ctx, XVCGPU_INVALID_ARGUMENT, "picture mismatch");
+  if (n == 0) return XVCGPU_OK;
+  const int n_wg = (2 * n + 3) / 4;
+  hipLaunchKernelGGL((recon_from_me_kernel<false, true>), dim3((n_wg + 7) / 8 * 8), dim3(256), 0,
+                     ctx->stream, orig->v, ref->v, pred->v, d_blocks, d_results, n, 0, 0, 0, 0,
+                     nullptr, nullptr, ctx->d_tx_tables, ctx->d_tx_tables_t, xvcgpu_tx_layout(),
+                     nullptr, nullptr, d_coeffs, d_coeff_offsets);
+  CHECK_LAUNCH(ctx, "fwd_from_me");
+  return XVCGPU_OK;
+}
+
 xvcgpu_status xvcgpu_recon_from_me_rdoq(xvcgpu_ctx *ctx, const xvcgpu_picture *orig,
                                         const xvcgpu_picture *ref, xvcgpu_picture *rec,
                                         const xvcgpu_me_block *d_blocks,
@@ -1431,10 +1451,17 @@ xvcgpu_status xvcgpu_frame_pass(xvcgpu_ctx *ctx, const xvcgpu_frame_pass_args *a
                                 a->d_me, a->n_cus, a->d_results, a->max_block_size);
     if (st != XVCGPU_OK) return st;
     if (a->d_rdoq_params && a->pred) {
-      st = xvcgpu_mc_from_me(ctx, a->ref, a->pred, a->d_me, a->d_results, a->n_cus);
-      if (st == XVCGPU_OK)
-        st = xvcgpu_fwd_transform_batch(ctx, a->orig, a->pred, a->d_tx, a->n_tx, a->d_coeffs,
-                                        a->d_level_off);
+      if (a->max_block_size <= 16 && a->n_tx == 3 * a->n_cus) {
+        // prediction + forward transform in one kernel (transform blocks in CU
+        // order, Y U V each: block 3 * cu + comp)
+        st = xvcgpu_fwd_from_me(ctx, a->orig, a->ref, a->pred, a->d_me, a->d_results, a->n_cus,
+                                a->d_coeffs, a->d_level_off);
+      } else {
+        st = xvcgpu_mc_from_me(ctx, a->ref, a->pred, a->d_me, a->d_results, a->n_cus);
+        if (st == XVCGPU_OK)
+          st = xvcgpu_fwd_transform_batch(ctx, a->orig, a->pred, a->d_tx, a->n_tx, a->d_coeffs,
+                                          a->d_level_off);
+      }
       if (st == XVCGPU_OK)
         st = xvcgpu_quant_rdo_batch(ctx, a->rec->bd, a->d_tx, a->n_tx, a->d_coeffs,
                                     a->d_level_off, a->n_coeffs, a->d_levels, a->d_nnz,

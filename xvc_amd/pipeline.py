@@ -271,12 +271,19 @@ class FramePass:
                 ctx.recon_from_me_dev(orig, ref, rec, self.d_me.ptr, self.d_res.ptr, n,
                                       d.qp, d.qp_c, ref_poc, self.d_nnz.ptr, self.d_cus_own)
             return
-        ctx.mc_from_me_dev(ref, self.pred, self.d_me.ptr, self.d_res.ptr, n)
+        front_fused = self.rdoq_packed and d.cu_size <= 16    # xvcgpu_fwd_from_me
+        if not front_fused:
+            ctx.mc_from_me_dev(ref, self.pred, self.d_me.ptr, self.d_res.ptr, n)
         if self.rdoq_packed:
             lib, T = ctx.lib, len(d.tx)
-            ctx._check(lib.xvcgpu_fwd_transform_batch(
-                ctx.h, orig.h_pic, self.pred.h_pic, self.d_tx.ptr, T, self.d_coeffs.ptr,
-                self.d_level_off.ptr))
+            if front_fused:
+                ctx._check(lib.xvcgpu_fwd_from_me(
+                    ctx.h, orig.h_pic, ref.h_pic, self.pred.h_pic, self.d_me.ptr,
+                    self.d_res.ptr, n, self.d_coeffs.ptr, self.d_level_off.ptr))
+            else:
+                ctx._check(lib.xvcgpu_fwd_transform_batch(
+                    ctx.h, orig.h_pic, self.pred.h_pic, self.d_tx.ptr, T, self.d_coeffs.ptr,
+                    self.d_level_off.ptr))
             ctx._check(lib.xvcgpu_quant_rdo_batch(
                 ctx.h, self.bd, self.d_tx.ptr, T, self.d_coeffs.ptr, self.d_level_off.ptr,
                 self.n_levels, self.d_levels.ptr, self.d_nnz.ptr, self.d_rdoq_ctx.ptr,
@@ -316,15 +323,22 @@ class FramePass:
                     orig, ref, rec, self.d_me.ptr, self.d_res.ptr, n, d.qp, d.qp_c, ref_poc,
                     self.d_nnz.ptr, self.d_cus_own)))
         else:
-            steps.append(("mc_from_me", lambda: ctx.mc_from_me_dev(
-                ref, self.pred, self.d_me.ptr, self.d_res.ptr, n)))
+            front_fused = self.rdoq_packed and d.cu_size <= 16
             lv = self.d_levels.ptr if self.d_levels else None
             lo = self.d_level_off.ptr if self.d_level_off else None
+            if front_fused:
+                steps.append(("fwd_from_me", lambda: ctx._check(lib.xvcgpu_fwd_from_me(
+                    ctx.h, orig.h_pic, ref.h_pic, self.pred.h_pic, self.d_me.ptr,
+                    self.d_res.ptr, n, self.d_coeffs.ptr, lo))))
+            else:
+                steps.append(("mc_from_me", lambda: ctx.mc_from_me_dev(
+                    ref, self.pred, self.d_me.ptr, self.d_res.ptr, n)))
             if self.rdoq_packed:
+                if not front_fused:
+                    steps.append(("fwd_transform", lambda: ctx._check(
+                        lib.xvcgpu_fwd_transform_batch(ctx.h, orig.h_pic, self.pred.h_pic,
+                                                       self.d_tx.ptr, T, self.d_coeffs.ptr, lo))))
                 steps += [
-                    ("fwd_transform", lambda: ctx._check(lib.xvcgpu_fwd_transform_batch(
-                        ctx.h, orig.h_pic, self.pred.h_pic, self.d_tx.ptr, T,
-                        self.d_coeffs.ptr, lo))),
                     ("quant_rdo", lambda: ctx._check(lib.xvcgpu_quant_rdo_batch(
                         ctx.h, self.bd, self.d_tx.ptr, T, self.d_coeffs.ptr, lo, self.n_levels,
                         lv, self.d_nnz.ptr, self.d_rdoq_ctx.ptr, self.d_rdoq_prm.ptr))),
