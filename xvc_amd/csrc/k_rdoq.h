@@ -847,14 +847,11 @@ struct RdoqPackedLds {
 // G lanes per block; grid: an upper bound on ceil(count / (64 / G)) waves (the
 // list's count is read on the device); block: 64.
 template <int G>
-__global__ void __launch_bounds__(64)
-quant_rdo_packed_kernel(int bd, const xvcgpu_tx_block *blocks, const int *list,
-                        const int *count, const int16_t *coeffs, const uint32_t *d_off,
-                        int16_t *levels, int32_t *nnz_out, const xvcgpu_rdoq_contexts *rq_ctx,
-                        const xvcgpu_rdoq_params *rq_prm) {
+__device__ __forceinline__ void quant_rdo_packed_wave(
+    RdoqPackedLds<G> &sm, int wave, int bd, const xvcgpu_tx_block *blocks, const int *list,
+    const int *count, const int16_t *coeffs, const uint32_t *d_off, int16_t *levels,
+    int32_t *nnz_out, const xvcgpu_rdoq_contexts *rq_ctx, const xvcgpu_rdoq_params *rq_prm) {
   constexpr int GROUPS = 64 / G;
-  __shared__ RdoqPackedLds<G> sm;
-  const int wave = blockIdx.x;
   const int g = threadIdx.x / G, lane = threadIdx.x % G;
   const int slot = wave * GROUPS + g;
   const int n_list = *count;
@@ -924,6 +921,35 @@ quant_rdo_packed_kernel(int bd, const xvcgpu_tx_block *blocks, const int *list,
     dst[i] = (x < rw && y < rh) ? lv[y * rw + x] : (int16_t)0;
   }
   if (lane == 0 && nnz_out) nnz_out[bi] = nnz;
+}
+
+// The three classes in ONE launch: their walks are independent and each is
+// bounded by its own slowest block, so one after the other they cost the sum of
+// three tails (180 + 53 + 7 us on the bench picture), together the longest.
+// Workgroups [0, n16) take the 16-lane class (the long walks first), then the
+// 4-lane class, then the 64-lane class; n16 / n4 / n64 are upper bounds (the
+// lists' counts are read on the device).  grid: n16 + n4 + n64; block: 64.
+__global__ void __launch_bounds__(64)
+quant_rdo_packed_kernel(int bd, const xvcgpu_tx_block *blocks, RdoqLists l, int n16, int n4,
+                        const int16_t *coeffs, const uint32_t *d_off, int16_t *levels,
+                        int32_t *nnz_out, const xvcgpu_rdoq_contexts *rq_ctx,
+                        const xvcgpu_rdoq_params *rq_prm) {
+  union Lds {
+    RdoqPackedLds<16> a;
+    RdoqPackedLds<4> b;
+    RdoqPackedLds<64> c;
+  };
+  __shared__ Lds sm;
+  const int wg = blockIdx.x;
+  if (wg < n16)
+    quant_rdo_packed_wave<16>(sm.a, wg, bd, blocks, l.list[1], l.count + 1, coeffs, d_off, levels,
+                              nnz_out, rq_ctx, rq_prm);
+  else if (wg < n16 + n4)
+    quant_rdo_packed_wave<4>(sm.b, wg - n16, bd, blocks, l.list[0], l.count + 0, coeffs, d_off,
+                             levels, nnz_out, rq_ctx, rq_prm);
+  else
+    quant_rdo_packed_wave<64>(sm.c, wg - n16 - n4, bd, blocks, l.list[2], l.count + 2, coeffs,
+                              d_off, levels, nnz_out, rq_ctx, rq_prm);
 }
 
 #endif  // XVCGPU_K_RDOQ_H_

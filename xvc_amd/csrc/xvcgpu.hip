@@ -988,17 +988,11 @@ xvcgpu_status xvcgpu_quant_rdo_batch(xvcgpu_ctx *ctx, int bitdepth,
   hipLaunchKernelGGL(rdoq_classify_kernel, dim3((n + 3) / 4), dim3(256), 0, ctx->stream,
                      bitdepth, d_blocks, n, d_coeffs, d_offsets, d_levels, d_nnz, l);
   hipLaunchKernelGGL(rdoq_compact_kernel, dim3(1), dim3(1024), 0, ctx->stream, n, l);
-  // the class sizes are only known on the device: launch upper bounds, waves
-  // beyond a list's count retire at once.  The 16-lane class (the long walks of
-  // 16x16 blocks) first.
-  hipLaunchKernelGGL(quant_rdo_packed_kernel<16>, dim3((n + 3) / 4), dim3(64), 0, ctx->stream,
-                     bitdepth, d_blocks, l.list[1], l.count + 1, d_coeffs, d_offsets, d_levels,
-                     d_nnz, d_contexts, d_params);
-  hipLaunchKernelGGL(quant_rdo_packed_kernel<4>, dim3((n + 15) / 16), dim3(64), 0, ctx->stream,
-                     bitdepth, d_blocks, l.list[0], l.count + 0, d_coeffs, d_offsets, d_levels,
-                     d_nnz, d_contexts, d_params);
-  hipLaunchKernelGGL(quant_rdo_packed_kernel<64>, dim3(n), dim3(64), 0, ctx->stream, bitdepth,
-                     d_blocks, l.list[2], l.count + 2, d_coeffs, d_offsets, d_levels, d_nnz,
+  // the class sizes are only known on the device: upper bounds, workgroups
+  // beyond a list's count retire at once
+  const int n16 = (n + 3) / 4, n4 = (n + 15) / 16;
+  hipLaunchKernelGGL(quant_rdo_packed_kernel, dim3(n16 + n4 + n), dim3(64), 0, ctx->stream,
+                     bitdepth, d_blocks, l, n16, n4, d_coeffs, d_offsets, d_levels, d_nnz,
                      d_contexts, d_params);
   CHECK_LAUNCH(ctx, "quant_rdo_batch");
   return XVCGPU_OK;
