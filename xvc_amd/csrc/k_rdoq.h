@@ -788,37 +788,67 @@ __global__ void __launch_bounds__(1024)
 rdoq_compact_kernel(int n, RdoqLists l) {
   __shared__ int part[3][1024];
   const int t = threadIdx.x;
-  const int per = (n + 1023) / 1024;
+  // a multiple of 4 blocks per thread: the classes are read four at a time
+  const int per = ((n + 1023) / 1024 + 3) & ~3;
   const int a = t * per, e = a + per < n ? a + per : n;
+  const uint32_t *cw = reinterpret_cast<const uint32_t *>(l.cls);
   int cnt[3] = {0, 0, 0};
-  for (int i = a; i < e; i++) {
-    const int c = l.cls[i];
-    cnt[0] += c == 0;
-    cnt[1] += c == 1;
-    cnt[2] += c == 2;
+  for (int i = a; i < e; i += 4) {
+    const uint32_t v = cw[i >> 2];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int c = (int)(signed char)(v >> (8 * k));
+      const bool in = i + k < e;
+      cnt[0] += in && c == 0;
+      cnt[1] += in && c == 1;
+      cnt[2] += in && c == 2;
+    }
   }
 #pragma unroll
   for (int k = 0; k < 3; k++) part[k][t] = cnt[k];
   __syncthreads();
-  // inclusive Hillis-Steele scan over the 1024 partial counts, three at once
-  for (int d = 1; d < 1024; d <<= 1) {
-    int v[3];
+  // inclusive scan over the 1024 partial counts, three at once: inside each
+  // wave by shuffles, then the 16 wave totals by the first wave
+  int inc[3];
 #pragma unroll
-    for (int k = 0; k < 3; k++) v[k] = t >= d ? part[k][t - d] : 0;
-    __syncthreads();
+  for (int k = 0; k < 3; k++) {
+    int v = cnt[k];
 #pragma unroll
-    for (int k = 0; k < 3; k++) part[k][t] += v[k];
-    __syncthreads();
+    for (int d = 1; d < 64; d <<= 1) {
+      const int o = __shfl_up(v, d, 64);
+      if ((t & 63) >= d) v += o;
+    }
+    inc[k] = v;
+    if ((t & 63) == 63) part[k][t >> 6] = v;  // wave totals (slots 0..15 reused after the sync)
   }
+  __syncthreads();
+  if (t < 64) {
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      int v = t < 16 ? part[k][t] : 0;
+#pragma unroll
+      for (int d = 1; d < 16; d <<= 1) {
+        const int o = __shfl_up(v, d, 64);
+        if (t >= d) v += o;
+      }
+      if (t < 16) part[k][16 + t] = v;  // inclusive totals of waves 0..t
+    }
+  }
+  __syncthreads();
   int pos[3];
 #pragma unroll
-  for (int k = 0; k < 3; k++) pos[k] = part[k][t] - cnt[k];
-  for (int i = a; i < e; i++) {
-    const int c = l.cls[i];
-    if (c >= 0) l.list[c][pos[c]++] = i;
+  for (int k = 0; k < 3; k++)
+    pos[k] = inc[k] - cnt[k] + ((t >> 6) ? part[k][16 + (t >> 6) - 1] : 0);
+  for (int i = a; i < e; i += 4) {
+    const uint32_t v = cw[i >> 2];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int c = (int)(signed char)(v >> (8 * k));
+      if (i + k < e && c >= 0) l.list[c][pos[c]++] = i + k;
+    }
   }
   if (t == 1023)
-    for (int k = 0; k < 3; k++) l.count[k] = part[k][1023];
+    for (int k = 0; k < 3; k++) l.count[k] = part[k][16 + 15];
 }
 
 // LDS of one wave of class G.  One table of context costs per wave: the groups
