@@ -82,6 +82,7 @@ struct Call {
 };
 extern bool g_capture;
 extern int g_only_poc;
+extern std::set<int> g_also_poc;
 extern std::vector<Call> g_calls;
 }  // namespace xr_me
 namespace xvc {
@@ -1444,6 +1445,7 @@ const uint32_t *xr_entropy_bits_table(void) { return &ContextModel::kEntropyBits
 namespace xr_me {
 bool g_capture = false;
 int g_only_poc = -1;
+std::set<int> g_also_poc;
 std::vector<Call> g_calls;
 }  // namespace xr_me
 
@@ -1454,7 +1456,9 @@ MvFullpel ObservedTzSearch::Search(const CodingUnit &cu, const Qp &qp, const Sam
                                    const MvFullpel &prev_search) {
   const MvFullpel best = real_.Search(cu, qp, metric, mvp, ref_pic, mv_min, mv_max, prev_search);
   const int poc = static_cast<int>(cu.GetPicData()->GetPoc());
-  if (!xr_me::g_capture || (xr_me::g_only_poc >= 0 && poc != xr_me::g_only_poc)) return best;
+  if (!xr_me::g_capture || (xr_me::g_only_poc >= 0 && poc != xr_me::g_only_poc &&
+                            !xr_me::g_also_poc.count(poc)))
+    return best;
   const YuvComponent comp = YuvComponent::kY;
   xr_me::Call c;
   std::memset(&c, 0, sizeof(c));
@@ -1512,9 +1516,11 @@ extern "C" {
  * then run an encode (xr_stream_encode), then read the records. */
 void xr_me_capture_begin(int only_poc) {
   xr_me::g_calls.clear();
+  xr_me::g_also_poc.clear();
   xr_me::g_only_poc = only_poc;
   xr_me::g_capture = true;
 }
+void xr_me_capture_also(int poc) { xr_me::g_also_poc.insert(poc); }
 long xr_me_capture_end(void) {
   xr_me::g_capture = false;
   return static_cast<long>(xr_me::g_calls.size());

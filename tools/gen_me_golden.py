@@ -35,8 +35,8 @@ CALL_DTYPE = np.dtype([
     ("fullpel_x", "<i4"), ("fullpel_y", "<i4"), ("mv_x", "<i4"), ("mv_y", "<i4"),
     ("dist", "<u4")])
 
-# clip -> POC whose calls are kept (None: all pictures)
-KEEP = {"tiny": None, "c1": 2}
+# clip -> POCs whose calls are kept (None: all pictures)
+KEEP = {"tiny": None, "c1": [2], "c0": None}
 
 
 def main():
@@ -45,9 +45,13 @@ def main():
     lib.xr_me_capture_end.restype = C.c_long
     lib.xr_me_calls.restype = C.c_void_p
     for name, only in KEEP.items():
+        if len(sys.argv) > 1 and name not in sys.argv[1:]:
+            continue
         c = gsg.CLIPS[name]
         clip = synth.SyntheticClip(c["w"], c["h"], 8)
-        lib.xr_me_capture_begin(-1 if only is None else only)
+        lib.xr_me_capture_begin(-1 if only is None else only[0])
+        for extra in (only or [])[1:]:
+            lib.xr_me_capture_also(extra)
         stream = gsg.encode(lib, clip, c["w"], c["h"], c["n"], c["qp"], c["sub_gop"], threads=0)
         n = lib.xr_me_capture_end()
         committed = np.load(os.path.join(sf.GOLDEN, "stream_%s.npz" % name))["stream"]
