@@ -448,6 +448,21 @@ def main_pictures(args, torch, api, pipeline, synth, world, rank, local_rank):
         dist.all_gather_object(parts, tail)
         tail = {k: v for part in parts for k, v in part.items()}
 
+    # the same workload on ONE GPU (rank 0 alone, the others wait): what the
+    # multi-GPU figure should be compared with - the N = 1 default of this
+    # script is the chain workload, whose references are one picture away
+    one_gpu = None
+    if world > 1 and rank == 0:
+        s1 = schedule.Schedule(n_pictures, 16, 2, 1, args.slots)
+        e1 = picture_parallel.GpuPictureEngine(ctx, s1, 0, W, H, bd, args.qp, origs, None,
+                                               rdoq=rdoq)
+        enc1 = [i for i, o in enumerate(s1.ops) if o["kind"] == schedule.ENCODE]
+        picture_parallel.run_rank(s1, 0, e1, 0, enc1[1 + args.warmup])
+        e1.sync()
+        t1 = time.perf_counter()
+        picture_parallel.run_rank(s1, 0, e1, enc1[1 + args.warmup], -1)
+        e1.sync()
+        one_gpu = args.steps / (time.perf_counter() - t1)
     roof = cpu = None
     fp = eng.fps[0]
     if rank == 0:
@@ -490,6 +505,7 @@ def main_pictures(args, torch, api, pipeline, synth, world, rank, local_rank):
             "vs_baseline": None, "dtype": "u16", "data": "synthetic",
             "rccl_world_size": rccl_world,
             "tail_crc": {str(k): tail[k] for k in sorted(tail)},
+            "same_workload_on_one_gpu": one_gpu,
             "config": {"workload": "%dx%d yuv420p 30fps synthetic, QP %d, internal bitdepth 10, "
                                    "16x16 CUs, TZ range 96, %s" %
                                    (W, H, args.qp, "RDOQ" if rdoq else "QuantFast"),
