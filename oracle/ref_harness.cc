@@ -642,6 +642,15 @@ int xr_eval_final_mvp_idx(int fullpel_mv, const int32_t mvp[4], int mv_x, int mv
   return is.EvalFinalMvpIdx(*cu, list, MotionVector(mv_x, mv_y), start);
 }
 
+/* T4: InterSearch::SearchMergeCandidates on a given candidate list (two
+ * reference pictures: L0 index 0 and L1 index 0).  cands[5][5] = {inter_dir,
+ * mv0_x, mv0_y, mv1_x, mv1_y}; returns the number to try, order in out_list. */
+int xr_search_merge_candidates(int bd, int x, int y, int w, int h, int pic_w, int pic_h,
+                               const uint16_t *orig, ptrdiff_t os, const uint16_t *ref0,
+                               ptrdiff_t rs0, const uint16_t *ref1, ptrdiff_t rs1,
+                               const int32_t *cands, double lambda_sqrt, int32_t *out_list,
+                               uint64_t *out_dist);
+
 /* T5: InterSearch::AffineGradientSearch / MotionEstAffine (uni-pred) */
 void xr_affine_gradient_search(int bd, int width, int height, const uint16_t *pred,
                                ptrdiff_t ps, const int16_t *err, ptrdiff_t es, int mvd[4]) {
@@ -842,6 +851,55 @@ void xr_mc_bipred_block(int bd, int comp, int x, int y, int w, int h, int mv0_x,
   InterPrediction ip(Simd(bd).inter_prediction, env.rec_pic, bd);
   SampleBuffer pb(pred, ps);
   ip.MotionCompensation(*cu, YuvComponent(comp), &pb);
+}
+
+int xr_search_merge_candidates(int bd, int x, int y, int w, int h, int pic_w, int pic_h,
+                               const uint16_t *orig, ptrdiff_t os, const uint16_t *ref0,
+                               ptrdiff_t rs0, const uint16_t *ref1, ptrdiff_t rs1,
+                               const int32_t *cands, double lambda_sqrt, int32_t *out_list,
+                               uint64_t *out_dist) {
+  BiEnv env(bd, pic_w, pic_h);
+  for (int yy = 0; yy < pic_h; yy++)
+    std::memcpy(env.orig_pic.GetSamplePtr(YuvComponent::kY, 0, yy), orig + yy * os,
+                sizeof(Sample) * pic_w);
+  const uint16_t *p0[3] = {ref0, nullptr, nullptr}, *p1[3] = {ref1, nullptr, nullptr};
+  ptrdiff_t s0[3] = {rs0, 0, 0}, s1[3] = {rs1, 0, 0};
+  FillPic(env.ref[0].get(), p0, s0);
+  FillPic(env.ref[1].get(), p1, s1);
+  CodingUnit *cu = env.pic_data.CreateCu(CuTree::Primary, 1, x, y, w, h);
+  cu->SetPredMode(PredictionMode::kInter);
+  Qp qp = MakeQp(32, bd, lambda_sqrt * lambda_sqrt);
+  cu->SetQp(qp);
+  InterSearch is(Simd(bd), env.pic_data, env.orig_pic, env.rec_pic, *env.pic_data.GetRefPicLists(),
+                 env.settings);
+  TransformEncoder enc(Simd(bd), bd, 1, env.orig_pic, env.settings);
+  BitWriter bw;
+  SyntaxWriter writer(qp, PicturePredictionType::kBi, &bw);
+  InterMergeCandidateList list;
+  list.num = constants::kNumInterMergeCandidates;
+  for (int m = 0; m < constants::kNumInterMergeCandidates; m++) {
+    const int32_t *c = cands + 5 * m;
+    list[m].inter_dir = c[0] == 2 ? InterDir::kBi : (c[0] == 1 ? InterDir::kL1 : InterDir::kL0);
+    list[m].mv[0] = MotionVector(c[1], c[2]);
+    list[m].mv[1] = MotionVector(c[3], c[4]);
+    list[m].ref_idx[0] = 0;
+    list[m].ref_idx[1] = 0;
+  }
+  InterSearch::MergeCandLookup lookup;
+  lookup.fill(-1);
+  const int num = is.SearchMergeCandidates(cu, qp, writer, list, &enc, &lookup);
+  for (int m = 0; m < constants::kNumInterMergeCandidates; m++) out_list[m] = lookup[m];
+  if (out_dist) {
+    /* the per-candidate distortions of the same loop (:173-178), for diagnosis */
+    SampleMetric metric(Simd(bd).sample_metric, bd, MetricType::kSatd);
+    SampleBuffer pred_buffer = enc.GetPredBuffer(YuvComponent::kY);
+    for (int m = 0; m < constants::kNumInterMergeCandidates; m++) {
+      is.ApplyMergeCand(cu, list[m]);
+      is.MotionCompensation(*cu, YuvComponent::kY, &pred_buffer);
+      out_dist[m] = metric.CompareSample(*cu, YuvComponent::kY, env.orig_pic, pred_buffer);
+    }
+  }
+  return num;
 }
 
 void xr_bipred_search(int bd, const xvcgpu_bi_block *j, int pic_w, int pic_h,

@@ -128,3 +128,65 @@ def test_eval_start_mvp_and_ref_loop_vs_reference(gpu, bd):
         assert tuple(int(v) for v in out[i]) == best, (i, tuple(blocks[i]))
     for p in (O, R0, R1):
         p.destroy()
+
+
+@pytest.mark.skipif(not ol.have_ref(), reason="oracle/_ref not built")
+@pytest.mark.parametrize("bd", [8, 10])
+def test_search_merge_candidates_vs_reference(gpu, bd):
+    """SearchMergeCandidates (inter_search.cc:165-197): per-candidate SATD on the
+    device (uni and bi-directional candidates), the double-precision fold, the
+    stable sort and the 1.25x cut on the host - against the reference's member
+    function on the same candidate lists."""
+    api, ctx = gpu
+    L, xr = host_lib(), ol.Lib("xr")
+    L.xvc_host_search_merge_candidates_batch.argtypes = [C.c_void_p] * 6 + [C.c_int] + \
+        [C.c_void_p] * 3
+    f = xr.dll.xr_search_merge_candidates
+    f.restype = C.c_int
+    f.argtypes = [C.c_int] * 7 + [C.c_void_p, C.c_ssize_t, C.c_void_p, C.c_ssize_t, C.c_void_p,
+                                  C.c_ssize_t, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p]
+    rng = np.random.default_rng(5100 + bd)
+    pw, ph = 256, 160
+    orig, ref0 = make_pics(rng, bd, pw, ph, BL, (4, -2))
+    ref1 = np.ascontiguousarray(np.roll(ref0, (2, 5), (0, 1)))
+    O, R0, R1, P = (ctx.picture(pw, ph, bd) for _ in range(4))
+    O.upload([orig, None, None], BL)
+    R0.upload([ref0, None, None], BL)
+    R1.upload([ref1, None, None], BL)
+    # non-overlapping CUs on a 64-grid, all sizes
+    blocks, n = [], 0
+    for gy in range(0, ph - 63, 64):
+        for gx in range(0, pw, 64):
+            w = int(rng.choice([8, 16, 32, 64]))
+            h = int(rng.choice([8, 16, 32, 64]))
+            blocks.append((gx, gy, w, h))
+    n = len(blocks)
+    b = np.zeros(n, api.ME_DTYPE)
+    for i, (x, y, w, h) in enumerate(blocks):
+        b[i]["x"], b[i]["y"], b[i]["w"], b[i]["h"] = x, y, w, h
+    K = 5                                    # constants::kNumInterMergeCandidates
+    cands = np.zeros((n, K, 5), np.int32)
+    cands[:, :, 0] = rng.integers(0, 3, (n, K))
+    cands[:, :, 1:] = rng.integers(-96, 96, (n, K, 4))
+    cands[::3, 2] = cands[::3, 1]            # equal candidates: the stable sort decides
+    lam = np.array(rng.choice([2.0, 7.6, 19.3, 60.0], n), np.float64)
+    out = np.zeros((n, K + 1), np.int32)
+    assert L.xvc_host_search_merge_candidates_batch(
+        ctx.h, O.h_pic, R0.h_pic, R1.h_pic, P.h_pic, b.ctypes.data, n, cands.ctypes.data,
+        lam.ctypes.data, out.ctypes.data) == 0
+    o, r0, r1 = orig[BL:, BL:], ref0[BL:, BL:], ref1[BL:, BL:]
+    nums = set()
+    for i, (x, y, w, h) in enumerate(blocks):
+        exp = np.zeros(K, np.int32)
+        c = np.ascontiguousarray(cands[i])
+        num = f(bd, x, y, w, h, pw, ph, o.ctypes.data, orig.strides[0] // 2, r0.ctypes.data,
+                ref0.strides[0] // 2, r1.ctypes.data, ref1.strides[0] // 2, c.ctypes.data,
+                float(lam[i]), exp.ctypes.data, None)
+        assert out[i][K] == num, (i, blocks[i], out[i].tolist(), exp.tolist(), num)
+        assert out[i][:K].tolist() == exp.tolist(), (i, blocks[i], out[i].tolist(), exp.tolist())
+        nums.add(num)
+    assert len(nums) >= 2
+    for p in (O, R0, R1, P):
+        p.destroy()
+    assert [L.xvc_host_choose_uni_or_bi(*t) for t in
+            [(5, 5, 5), (5, 4, 6), (4, 5, 6), (5, 5, 6), (7, 7, 6)]] == [0, 2, 1, 1, 0]

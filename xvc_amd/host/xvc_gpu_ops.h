@@ -31,10 +31,12 @@
 #ifndef XVC_AMD_HOST_XVC_GPU_OPS_H_
 #define XVC_AMD_HOST_XVC_GPU_OPS_H_
 
+#include <algorithm>
 #include <array>
 #include <cmath>
 #include <stdexcept>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "xvcgpu.h"
@@ -308,6 +310,107 @@ class InterSearch {
       }
     }
     return best;
+  }
+
+  // InterSearch::SearchMergeCandidates (inter_search.cc:165-197) for a batch of
+  // CUs: SATD of the prediction every one of the kNumInterMergeCandidates = 5
+  // merge candidates gives (uni- or bi-directional; reference index 0 of each
+  // list here: the pictures are arguments), cost = dist + bits * sqrt(lambda) in
+  // double with bits = idx + 1 (the last index one less), stable sort, and the
+  // cut: the first kFastMergeNumCand = 4, fewer if a candidate costs more than
+  // 1.25 x the best.  `pred` is scratch for the bi-directional candidates.
+  static constexpr int kNumMergeCand = 5;   // constants::kNumInterMergeCandidates (common.h:122)
+  struct MergeCand {
+    int inter_dir;            // 0: L0, 1: L1, 2: bi
+    int mv[2][2];             // [list][x, y], 1/16 pel
+  };
+  struct MergeChoice {
+    int order[kNumMergeCand];            // candidate indices, cheapest first
+    int num;                  // how many of them the RD search should try
+  };
+  std::vector<MergeChoice> SearchMergeCandidatesBatch(
+      const Picture &orig_pic, const Picture &ref_l0, const Picture &ref_l1, Picture *pred,
+      const std::vector<xvcgpu_me_block> &blocks,
+      const std::vector<std::array<MergeCand, kNumMergeCand>> &cands,
+      const std::vector<double> &lambda_sqrt) const {
+    const size_t n = blocks.size();
+    std::vector<std::array<uint64_t, kNumMergeCand>> dist(n);
+    for (int m = 0; m < kNumMergeCand; m++) {
+      std::vector<xvcgpu_mc_metric_cand> uni[2];
+      std::vector<size_t> uni_of[2], bi_of;
+      std::vector<xvcgpu_mc_bi_block> bi;
+      std::vector<xvcgpu_metric_cand> bi_metric;
+      for (size_t i = 0; i < n; i++) {
+        const MergeCand &c = cands[i][m];
+        if (c.inter_dir == 2) {
+          xvcgpu_mc_bi_block b = xvcgpu_mc_bi_block();
+          b.x = blocks[i].x; b.y = blocks[i].y; b.w = blocks[i].w; b.h = blocks[i].h;
+          b.comp = 0;
+          b.mv0_x = c.mv[0][0]; b.mv0_y = c.mv[0][1];
+          b.mv1_x = c.mv[1][0]; b.mv1_y = c.mv[1][1];
+          bi.push_back(b);
+          xvcgpu_metric_cand k = xvcgpu_metric_cand();
+          k.x = blocks[i].x; k.y = blocks[i].y; k.w = blocks[i].w; k.h = blocks[i].h;
+          k.metric = XVC_METRIC_SATD;
+          bi_metric.push_back(k);
+          bi_of.push_back(i);
+        } else {
+          const int l = c.inter_dir;
+          xvcgpu_mc_metric_cand k = xvcgpu_mc_metric_cand();
+          k.x = blocks[i].x; k.y = blocks[i].y; k.w = blocks[i].w; k.h = blocks[i].h;
+          k.metric = XVC_METRIC_SATD;
+          k.mv_x = c.mv[l][0]; k.mv_y = c.mv[l][1];
+          uni[l].push_back(k);
+          uni_of[l].push_back(i);
+        }
+      }
+      for (int l = 0; l < 2; l++)
+        if (!uni[l].empty()) {
+          const std::vector<uint64_t> d = GetSubpelDistBatch(orig_pic, l ? ref_l1 : ref_l0, uni[l]);
+          for (size_t k = 0; k < d.size(); k++) dist[uni_of[l][k]][m] = d[k];
+        }
+      if (!bi.empty()) {
+        // (the blocks of one batch may overlap in `pred` only if they overlap in
+        // the picture: the caller's CUs of one size class do not)
+        DeviceArray<xvcgpu_mc_bi_block> db(ctx_, bi);
+        ctx_.Check(xvcgpu_mc_bipred_batch(ctx_.get(), ref_l0.get(), ref_l1.get(), pred->get(),
+                                          db.data(), static_cast<int>(bi.size())));
+        DeviceArray<xvcgpu_metric_cand> dm(ctx_, bi_metric);
+        DeviceArray<uint64_t> out(ctx_, bi_metric.size());
+        ctx_.Check(xvcgpu_metric_batch(ctx_.get(), orig_pic.get(), pred->get(), 0, 1.0, 16,
+                                       dm.data(), static_cast<int>(bi_metric.size()),
+                                       out.data()));
+        const std::vector<uint64_t> d = out.ToHost();
+        for (size_t k = 0; k < d.size(); k++) dist[bi_of[k]][m] = d[k];
+      }
+    }
+    std::vector<MergeChoice> out(n);
+    for (size_t i = 0; i < n; i++) out[i] = FoldMergeCandidates(dist[i].data(), lambda_sqrt[i]);
+    return out;
+  }
+  // the fold alone (host arithmetic, exactly the reference's doubles)
+  static MergeChoice FoldMergeCandidates(const uint64_t dist[kNumMergeCand], double lambda_sqrt) {
+    std::pair<int, double> c[kNumMergeCand];
+    for (int m = 0; m < kNumMergeCand; m++) {
+      const uint32_t bits = static_cast<uint32_t>(m + 1 - (m < kNumMergeCand - 1 ? 0 : 1));
+      c[m] = std::make_pair(m, static_cast<double>(dist[m]) + bits * lambda_sqrt);
+    }
+    std::stable_sort(c, c + kNumMergeCand, [](const std::pair<int, double> &a, const std::pair<int, double> &b) {
+      return a.second < b.second;
+    });
+    MergeChoice r;
+    for (int m = 0; m < kNumMergeCand; m++) r.order[m] = c[m].first;
+    r.num = 4;
+    for (int m = 4; m >= 0; m--)
+      if (c[m].second > c[0].second * 1.25) r.num = m;
+    return r;
+  }
+  // SearchMotion's final choice between the best list-0 state, the best list-1
+  // state on a reference picture list 0 does not have, and the bi-directional
+  // state (inter_search.cc:247-257): 0 = bi, 1 = L0, 2 = L1
+  static int ChooseUniOrBi(uint32_t cost_l0, uint32_t cost_l1_unique, uint32_t cost_bi) {
+    if (cost_bi <= cost_l0 && cost_bi <= cost_l1_unique) return 0;
+    return cost_l0 <= cost_l1_unique ? 1 : 2;
   }
 
   // One SearchBiIterative refinement step per job (inter_search.cc:392-433):

@@ -93,4 +93,44 @@ int xvc_host_search_ref_idx_batch(xvcgpu_ctx *ctx, xvcgpu_picture *orig,
   }
 }
 
+// SearchMergeCandidates for n CUs: cands[n][5][5] = {inter_dir, mv0_x, mv0_y,
+// mv1_x, mv1_y}; out[n][6] = the five candidate indices cheapest first, then the
+// number to try.  `pred`: a scratch picture.
+int xvc_host_search_merge_candidates_batch(xvcgpu_ctx *ctx, xvcgpu_picture *orig,
+                                           xvcgpu_picture *ref_l0, xvcgpu_picture *ref_l1,
+                                           xvcgpu_picture *pred, const xvcgpu_me_block *blocks,
+                                           int n, const int32_t *cands,
+                                           const double *lambda_sqrt, int32_t *out) {
+  if (!ctx || !orig || !ref_l0 || !ref_l1 || !pred || !blocks || !cands || !lambda_sqrt || !out ||
+      n < 0)
+    return XVCGPU_INVALID_ARGUMENT;
+  try {
+    xvc_gpu::Context c(ctx);
+    xvc_gpu::Picture o(c, orig), r0(c, ref_l0), r1(c, ref_l1), p(c, pred);
+    constexpr int K = xvc_gpu::InterSearch::kNumMergeCand;
+    std::vector<std::array<xvc_gpu::InterSearch::MergeCand, K>> list(n);
+    for (int i = 0; i < n; i++)
+      for (int m = 0; m < K; m++) {
+        const int32_t *q = cands + 5 * K * static_cast<size_t>(i) + 5 * m;
+        xvc_gpu::InterSearch::MergeCand mc = {q[0], {{q[1], q[2]}, {q[3], q[4]}}};
+        list[i][m] = mc;
+      }
+    const std::vector<xvcgpu_me_block> b(blocks, blocks + n);
+    const std::vector<double> ls(lambda_sqrt, lambda_sqrt + n);
+    const std::vector<xvc_gpu::InterSearch::MergeChoice> res =
+        xvc_gpu::InterSearch(c).SearchMergeCandidatesBatch(o, r0, r1, &p, b, list, ls);
+    for (int i = 0; i < n; i++) {
+      for (int m = 0; m < K; m++) out[(K + 1) * i + m] = res[i].order[m];
+      out[(K + 1) * i + K] = res[i].num;
+    }
+    return XVCGPU_OK;
+  } catch (const xvc_gpu::Error &e) {
+    return e.status;
+  }
+}
+
+int xvc_host_choose_uni_or_bi(uint32_t cost_l0, uint32_t cost_l1_unique, uint32_t cost_bi) {
+  return xvc_gpu::InterSearch::ChooseUniOrBi(cost_l0, cost_l1_unique, cost_bi);
+}
+
 }  // extern "C"
