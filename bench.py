@@ -320,6 +320,8 @@ def algorithmic_bytes(d, W, H):
     S = 2
     n_luma = sum(int(b["w"]) * int(b["h"]) for b in d.me)
     n_all = int(1.5 * n_luma)
+    # samples PadBorder writes: 128 around luma, 64 around each chroma plane
+    border = ((W + 256) * (H + 256) - W * H) + 2 * ((W // 2 + 128) * (H // 2 + 128) - W * H // 4)
     return {
         # each plane read once: original + reference luma of the CUs
         "me_search": 2 * n_luma * S,
@@ -333,8 +335,11 @@ def algorithmic_bytes(d, W, H):
         "residual_rdoq": 3 * n_all * S, "residual": 3 * n_all * S,
         "cu_info": 84 * d.n_cus,
         "deblock": 2 * n_all * S + 16 * (n_luma // 16),
-        "pad_border": 2 * 80 * (W + H + 160) * S * 2,
+        "pad_border": border * S,
         "picture_ssd": 2 * n_luma * S,
+        # unfiltered reconstruction read, filtered picture + its border written,
+        # original luma read, CU map / records
+        "deblock_pad_ssd": 2 * n_all * S + n_luma * S + 16 * (n_luma // 16) + border * S,
     }
 
 

@@ -546,6 +546,25 @@ xvcgpu_status xvcgpu_deblock_tree(xvcgpu_ctx *ctx, xvcgpu_picture *rec,
                                   int pic_is_bipred, int beta_offset, int tc_offset,
                                   int subblock_size, int comp_mask);
 
+/* The tail of PictureEncoder::Encode in one pass over the picture
+ * (picture_encoder.cc:141-151; one launch + the fold of the SSD parts):
+ * DeblockPicture (deblocking_filter.cc:56-77, both passes, luma and chroma, the
+ * default 4-sample subblocks) of `src` -> `dst`, PadBorder of `dst`
+ * (yuv_pic.cc:118-150) and, when `orig` is given, the luma ComparePicture parts
+ * of xvcgpu_picture_ssd(orig, dst, 0, shift_bitdepth) in d_ssd[0..1].
+ * `src` (the unfiltered reconstruction; its border is not read for the result)
+ * and `dst` must be different pictures of the same size.  Only for pictures
+ * whose CUs are all at least 8x8 (every coding edge on the 8-sample grid, so no
+ * two edges interact): the caller knows its CU tree; other pictures take
+ * xvcgpu_deblock + xvcgpu_pad_border + xvcgpu_picture_ssd.  Width and height
+ * must be multiples of 8 (XVCGPU_INVALID_ARGUMENT otherwise). */
+xvcgpu_status xvcgpu_deblock_pad_ssd(xvcgpu_ctx *ctx, const xvcgpu_picture *src,
+                                     xvcgpu_picture *dst, const xvcgpu_picture *orig,
+                                     const xvcgpu_cu_info *d_cus, int n_cus,
+                                     const int32_t *d_cu_map, int map_stride,
+                                     int pic_is_bipred, int beta_offset, int tc_offset,
+                                     int shift_bitdepth, uint64_t *d_ssd);
+
 /* ---- picture SSD / PSNR parts ------------------------------------------- *
  * SampleMetric::ComparePicture / ComputePsnr block walk (sample_metric.cc:
  * 37-155): per-64x64-block SSD, each >> 2*(shift_bitdepth-8), summed.

@@ -331,6 +331,11 @@ typedef struct xvcgpu_frame_pass_args {
   int16_t *d_coeffs, *d_levels;
   int32_t n_tx;
   uint32_t n_coeffs;
+  /* optional, only for pictures whose CUs are all at least 8x8: a picture of
+   * rec's size.  A call that runs ENCODE, DEBLOCK_V, DEBLOCK_H, PAD and SSD
+   * over all rows then writes the unfiltered reconstruction here and ends with
+   * ONE launch, xvcgpu_deblock_pad_ssd(scratch_rec -> rec), instead of five */
+  struct xvcgpu_picture *scratch_rec;
 } xvcgpu_frame_pass_args;
 
 /* One job of xvcgpu_affine_me_batch: InterSearch::MotionEstAffine for one

@@ -741,6 +741,68 @@ def test_deblock_chains(gpu, xo):
         Rc.destroy()
 
 
+@pytest.mark.parametrize("bd", [8, 10])
+@pytest.mark.parametrize("bipred", [0, 1])
+def test_deblock_pad_ssd(gpu, xo, bd, bipred):
+    """The fused tail (k_tail.h): one launch = DeblockPicture (4-sample subblocks,
+    CUs >= 8x8) + PadBorder + the luma ComparePicture parts, against the oracle's
+    three separate steps; picture sizes with full, remainder and unvisited
+    ComparePicture blocks, all tile positions (corner, rim, interior)."""
+    api, ctx = gpu
+    rng = np.random.default_rng(5600 + bd + bipred)
+    total_changed = 0
+    for k, (pw, ph) in enumerate([(64, 64), (136, 72), (320, 200), (352, 288), (8, 8), (72, 200),
+                                  (640, 384)]):
+        trial = k % 3
+        parts = random_partition(rng, pw, ph, 8)
+        cus, cmap = make_cus(rng, parts, bipred, [8, 0, 16][:2 + trial % 2], [16, 8], pw, ph)
+        planes = []
+        for c in range(3):
+            w, h = (pw, ph) if c == 0 else (pw // 2, ph // 2)
+            b = BL if c == 0 else BC
+            base = rng.integers(0, 1 << bd, size=((h + 7) // 8, (w + 7) // 8))
+            p = np.kron(base, np.ones((8, 8), np.int64))[:h, :w]
+            amp = [2, 6, 30][trial]
+            p = np.clip(p // [16, 4, 1][trial] + (1 << (bd - 1)) +
+                        rng.integers(-amp, amp + 1, size=(h, w)), 0, (1 << bd) - 1)
+            # the border of the unfiltered picture holds anything: it must not matter
+            full = rng.integers(0, 1 << bd, size=(h + 2 * b, w + 2 * b)).astype(np.uint16)
+            full[b:b + h, b:b + w] = p
+            planes.append(full)
+        orig = padded_planes(rng, bd, pw, ph)
+        orig[0][BL:BL + ph, BL:BL + pw] = np.clip(
+            planes[0][BL:BL + ph, BL:BL + pw].astype(np.int32) +
+            rng.integers(-7, 8, size=(ph, pw)), 0, (1 << bd) - 1)
+        beta, tc = [(0, 0), (2, -2), (-4, 4)][trial]
+        exp = [p.copy() for p in planes]
+        xo.deblock(bd, pw, ph, bipred, beta, tc, 4, cus, cmap, exp, [BL, BC, BC])
+        xo.pad_border(pw, ph, exp, [BL, BC, BC])
+        S, D, O = (ctx.picture(pw, ph, bd) for _ in range(3))
+        S.upload(planes, BL)
+        O.upload(orig, BL)
+        for sbd in (8, bd):
+            D.upload([np.zeros_like(p) for p in planes], BL)
+            got_ssd = ctx.deblock_pad_ssd(S, D, O, cus, cmap, bipred, beta, tc, sbd)
+            got = D.download(BL)
+            for c in range(3):
+                assert np.array_equal(got[c], exp[c]), (pw, ph, c)
+            exp_ssd = xo.picture_ssd(sbd, np.ascontiguousarray(view(orig, 0)[:ph, :pw]),
+                                     np.ascontiguousarray(view(exp, 0)[:ph, :pw]))
+            assert got_ssd == exp_ssd, (pw, ph, sbd, got_ssd, exp_ssd)
+        # without an original: no SSD, same pictures
+        D.upload([np.zeros_like(p) for p in planes], BL)
+        assert ctx.deblock_pad_ssd(S, D, None, cus, cmap, bipred, beta, tc) is None
+        got = D.download(BL)
+        for c in range(3):
+            assert np.array_equal(got[c], exp[c]), (pw, ph, c)
+        total_changed += int((view(exp, 0)[:ph, :pw] != view(planes, 0)[:ph, :pw]).sum())
+        assert ctx.lib.xvcgpu_deblock_pad_ssd(ctx.h, S.h_pic, S.h_pic, None, None, 0, None, 0, 0,
+                                              0, 0, 8, None) == 10
+        for p in (S, D, O):
+            p.destroy()
+    assert total_changed > 0
+
+
 def test_pad_border(gpu, xo):
     api, ctx = gpu
     rng = np.random.default_rng(6000)

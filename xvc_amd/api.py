@@ -116,7 +116,8 @@ class FramePassArgs(C.Structure):
                 ("d_rdoq_contexts", C.c_void_p), ("d_rdoq_params", C.c_void_p),
                 ("pred", C.c_void_p), ("d_tx", C.c_void_p), ("d_level_off", C.c_void_p),
                 ("d_luma_tx_index", C.c_void_p), ("d_coeffs", C.c_void_p),
-                ("d_levels", C.c_void_p), ("n_tx", C.c_int32), ("n_coeffs", C.c_uint32)]
+                ("d_levels", C.c_void_p), ("n_tx", C.c_int32), ("n_coeffs", C.c_uint32),
+                ("scratch_rec", C.c_void_p)]
 
 
 FP_ENCODE, FP_DEBLOCK_V, FP_DEBLOCK_H, FP_PAD, FP_SSD = 1, 2, 4, 8, 16
@@ -137,7 +138,7 @@ SYMBOLS = [
     "xvcgpu_affine_me_batch",
     "xvcgpu_cu_info_from_me", "xvcgpu_recon_from_me", "xvcgpu_residual_batch",
     "xvcgpu_fwd_transform_batch", "xvcgpu_inv_transform_batch",
-    "xvcgpu_deblock", "xvcgpu_deblock_rows", "xvcgpu_picture_ssd", "xvcgpu_picture_ssd_rows",
+    "xvcgpu_deblock", "xvcgpu_deblock_rows", "xvcgpu_deblock_pad_ssd", "xvcgpu_picture_ssd", "xvcgpu_picture_ssd_rows",
     "xvcgpu_picture_import", "xvcgpu_picture_export", "xvcgpu_picture_crc",
     "xvcgpu_variance_map", "xvcgpu_histogram_distance",
     "xvcgpu_intra_pred_batch", "xvcgpu_intra_satd_batch", "xvcgpu_intra_recon_batch",
@@ -266,6 +267,8 @@ def load_library():
         "xvcgpu_quant_rdo_reserve": [_vp, C.c_int, C.c_size_t],
         "xvcgpu_quant_rdo_batch": [_vp, C.c_int, _vp, C.c_int, _vp, _vp, C.c_size_t, _vp, _vp,
                                    _vp, _vp],
+        "xvcgpu_deblock_pad_ssd": [_vp, _vp, _vp, _vp, _vp, C.c_int, _vp, C.c_int, C.c_int,
+                                   C.c_int, C.c_int, C.c_int, _vp],
         "xvcgpu_deblock_tree": [_vp, _vp, _vp, C.c_int, _vp, C.c_int, C.c_int, C.c_int,
                                 C.c_int, C.c_int, C.c_int],
         "xvcgpu_event_create": [_vp, C.POINTER(_vp)],
@@ -676,6 +679,14 @@ class Context:
                                                  d_map, map_stride, bipred, beta, tc,
                                                  sub, pass_, y0, y1))
 
+    def deblock_pad_ssd_dev(self, src, dst, orig, d_cus, n_cus, d_map, map_stride, bipred=0,
+                            beta=0, tc=0, shift_bd=8, d_ssd=None):
+        """xvcgpu_deblock_pad_ssd: deblocking src -> dst, PadBorder, luma SSD parts
+        against `orig` (None: no SSD) in one launch; CUs all >= 8x8."""
+        self._check(self.lib.xvcgpu_deblock_pad_ssd(
+            self.h, src.h_pic, dst.h_pic, orig.h_pic if orig is not None else None, d_cus,
+            n_cus, d_map, map_stride, bipred, beta, tc, shift_bd, d_ssd))
+
     def picture_ssd_dev(self, a, b, comp, shift_bd, d_out, y_begin=0, y_end=1 << 30):
         self._check(self.lib.xvcgpu_picture_ssd_rows(self.h, a.h_pic, b.h_pic, comp,
                                                      shift_bd, y_begin, y_end, d_out))
@@ -862,6 +873,18 @@ class Context:
         self.sync()
         dc.free()
         dm.free()
+
+    def deblock_pad_ssd(self, src, dst, orig, cus, cu_map, bipred=0, beta=0, tc=0, shift_bd=8):
+        cus = np.ascontiguousarray(cus, CU_DTYPE)
+        cu_map = np.ascontiguousarray(cu_map, np.int32)
+        dc, dm, do = self.buffer(cus), self.buffer(cu_map), self.alloc(16)
+        self.deblock_pad_ssd_dev(src, dst, orig, dc.ptr, len(cus), dm.ptr, cu_map.shape[1],
+                                 bipred, beta, tc, shift_bd, do.ptr if orig is not None else None)
+        self.sync()
+        out = do.to_array(np.uint64, 2)
+        for b in (dc, dm, do):
+            b.free()
+        return (int(out[0]), int(out[1])) if orig is not None else None
 
     # ---- whole-picture passes around the hot path ----
     def picture_import(self, pic, data, in_w, in_h, in_bd):

@@ -101,20 +101,15 @@ __device__ __forceinline__ int db_candidate(const DbParams &d, int x, int y,
 
 // One 4-line group of FilterEdgeLuma (deblocking_filter.cc:243-401).
 // s[line][0..7] = p3,p2,p1,p0,q0,q1,q2,q3.  Returns true when modified.
-__device__ __forceinline__ bool db_filter_luma_group(int s[4][8], int bd, int qp,
-                                                     int bs, int beta_off,
-                                                     int tc_off) {
-  const int bsh = bd - 8, smax = (1 << bd) - 1;
-  const int index_beta = d_clip3(qp + beta_off, 0, 64);
-  const int beta = (index_beta < 64 ? (int)kBetaTable[index_beta] : 0) << bsh;
+// (beta, tc: the table values already scaled to the bit depth)
+__device__ __forceinline__ bool db_filter_luma_group_bt(int s[4][8], int bd, int beta, int tc) {
+  const int smax = (1 << bd) - 1;
   const int dp0 = d_abs(s[0][1] - 2 * s[0][2] + s[0][3]);
   const int dq0 = d_abs(s[0][4] - 2 * s[0][5] + s[0][6]);
   const int dp3 = d_abs(s[3][1] - 2 * s[3][2] + s[3][3]);
   const int dq3 = d_abs(s[3][4] - 2 * s[3][5] + s[3][6]);
   const int d0 = dp0 + dq0, d3 = dp3 + dq3;
   if (d0 + d3 >= beta) return false;
-  const int index_tc = d_clip3(qp + tc_off + 2 * (bs - 1), 0, 53);
-  const int tc = (int)kTcTable[index_tc] << bsh;
   bool strong = (d0 << 1) < (beta >> 2) && (d3 << 1) < (beta >> 2);
 #pragma unroll
   for (int e = 0; e < 4; e += 3) {  // CheckStrongFilter on lines 0 and 3
@@ -168,6 +163,23 @@ __device__ __forceinline__ bool db_filter_luma_group(int s[4][8], int bd, int qp
     }
   }
   return true;
+}
+
+__device__ __forceinline__ int db_beta_index(int qp, int beta_off) {
+  return d_clip3(qp + beta_off, 0, 64);   // 64: beta = 0
+}
+__device__ __forceinline__ int db_tc_index(int qp, int tc_off, int bs) {
+  return d_clip3(qp + tc_off + 2 * (bs - 1), 0, 53);
+}
+
+__device__ __forceinline__ bool db_filter_luma_group(int s[4][8], int bd, int qp,
+                                                     int bs, int beta_off,
+                                                     int tc_off) {
+  const int bsh = bd - 8;
+  const int index_beta = db_beta_index(qp, beta_off);
+  const int beta = (index_beta < 64 ? (int)kBetaTable[index_beta] : 0) << bsh;
+  const int tc = (int)kTcTable[db_tc_index(qp, tc_off, bs)] << bsh;
+  return db_filter_luma_group_bt(s, bd, beta, tc);
 }
 
 __device__ __forceinline__ void db_unpack8(const uint2 a, const uint2 b, int *o) {

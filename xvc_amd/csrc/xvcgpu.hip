@@ -8,6 +8,7 @@
 #include <vector>
 
 #include "k_deblock.h"
+#include "k_tail.h"
 #include "k_me.h"
 #include "k_me2.h"
 #include "k_metric.h"
@@ -58,6 +59,9 @@ inline int ssd_items(int w, int h) {
   const int ncy = (h > 64 ? (h - 64 + 63) / 64 : 0) + (h - (h & ~63)) / mby;
   return ncx * ncy;
 }
+
+// 64x64 tiles of xvcgpu_deblock_pad_ssd (k_tail.h).
+inline int tail_tiles(int w, int h) { return ((w + 63) / 64) * ((h + 63) / 64); }
 
 // Plane geometry shared by create / wrap / bytes.
 struct Geometry {
@@ -168,6 +172,8 @@ xvcgpu_status xvcgpu_create(int device, xvcgpu_ctx **out) {
   ctx->d_tx_tables_t = nullptr;
   ctx->d_tz_pattern = nullptr;
   ctx->d_ssd_part = nullptr;
+  ctx->d_tail_part = nullptr;
+  ctx->tail_cap = 0;
   ctx->ssd_part_cap = 0;
   ctx->d_stats = nullptr;
   ctx->stats_rows_cap = 0;
@@ -224,6 +230,7 @@ void xvcgpu_destroy(xvcgpu_ctx *ctx) {
   if (ctx->d_tx_tables_t) hipFree(ctx->d_tx_tables_t);
   if (ctx->d_tz_pattern) hipFree(ctx->d_tz_pattern);
   if (ctx->d_ssd_part) hipFree(ctx->d_ssd_part);
+  if (ctx->d_tail_part) hipFree(ctx->d_tail_part);
   if (ctx->d_stats) hipFree(ctx->d_stats);
   if (ctx->d_rdoq_lists) hipFree(ctx->d_rdoq_lists);
   if (ctx->d_crc_tables) hipFree(ctx->d_crc_tables);
@@ -417,6 +424,7 @@ xvcgpu_status xvcgpu_memset(xvcgpu_ctx *ctx, void *dst, int value, size_t bytes)
 
 static xvcgpu_status ensure_ssd_part(xvcgpu_ctx *ctx, int items);
 static xvcgpu_status ensure_stats(xvcgpu_ctx *ctx, int rows);
+static xvcgpu_status ensure_tail(xvcgpu_ctx *ctx, int tiles);
 
 /* ---- pictures ---- */
 size_t xvcgpu_picture_bytes(int width, int height) {
@@ -446,6 +454,7 @@ xvcgpu_status xvcgpu_picture_wrap(xvcgpu_ctx *ctx, int width, int height,
   init_views(p);
   xvcgpu_status st = ensure_ssd_part(ctx, ssd_items(width, height));
   if (st == XVCGPU_OK) st = ensure_stats(ctx, 2 * height);
+  if (st == XVCGPU_OK) st = ensure_tail(ctx, tail_tiles(width, height));
   if (st != XVCGPU_OK) {
     delete p;
     return st;
@@ -1177,6 +1186,72 @@ xvcgpu_status xvcgpu_picture_ssd_rows(xvcgpu_ctx *ctx, const xvcgpu_picture *a,
   return XVCGPU_OK;
 }
 
+// Scratch of xvcgpu_deblock_pad_ssd: per-tile results; sized when a picture is
+// created.
+static xvcgpu_status ensure_tail(xvcgpu_ctx *ctx, int tiles) {
+  if (tiles <= ctx->tail_cap) return XVCGPU_OK;
+  if (ctx->d_tail_part) {
+    hipStreamSynchronize(ctx->stream);
+    hipFree(ctx->d_tail_part);
+    ctx->d_tail_part = nullptr;
+    ctx->tail_cap = 0;
+  }
+  const size_t bytes = sizeof(unsigned long long) * (2 * (size_t)tiles + 2);
+  hipError_t e = hipMalloc(&ctx->d_tail_part, bytes);
+  if (e != hipSuccess) return fail(ctx, XVCGPU_OUT_OF_MEMORY, "hipMalloc", e);
+  hipMemsetAsync(ctx->d_tail_part, 0, bytes, ctx->stream);
+  ctx->tail_cap = tiles;
+  return XVCGPU_OK;
+}
+
+xvcgpu_status xvcgpu_deblock_pad_ssd(xvcgpu_ctx *ctx, const xvcgpu_picture *src,
+                                     xvcgpu_picture *dst, const xvcgpu_picture *orig,
+                                     const xvcgpu_cu_info *d_cus, int n_cus,
+                                     const int32_t *d_cu_map, int map_stride,
+                                     int pic_is_bipred, int beta_offset, int tc_offset,
+                                     int shift_bitdepth, uint64_t *d_ssd) {
+  if (!ctx || !src || !dst || src == dst || src->base == dst->base || !d_cus || n_cus <= 0 ||
+      !d_cu_map || map_stride < (dst->w + 3) / 4 || (orig && (!d_ssd || shift_bitdepth < 8)))
+    return XVCGPU_INVALID_ARGUMENT;
+  if (src->w != dst->w || src->h != dst->h || src->bd != dst->bd ||
+      (orig && (orig->w != dst->w || orig->h != dst->h)))
+    return fail(ctx, XVCGPU_INVALID_ARGUMENT, "picture mismatch");
+  if ((dst->w & 7) || (dst->h & 7))
+    return fail(ctx, XVCGPU_INVALID_ARGUMENT, "deblock_pad_ssd: picture size not a multiple of 8");
+  const int tiles = tail_tiles(dst->w, dst->h);
+  {
+    const xvcgpu_status st = ensure_tail(ctx, tiles);
+    if (st != XVCGPU_OK) return st;
+  }
+  DbParams d;
+  d.bd = dst->bd;
+  d.pic_w = dst->w;
+  d.pic_h = dst->h;
+  d.bipred = pic_is_bipred;
+  d.beta_off = beta_offset;
+  d.tc_off = tc_offset;
+  d.sub = 4;
+  d.y_begin = 0;
+  d.y_end = dst->h;
+  d.cus = d_cus;
+  d.map = d_cu_map;
+  d.map_stride = map_stride;
+  d.map_rows = (dst->h + 3) / 4;
+  d.comp_mask = 3;
+  unsigned long long *part = ctx->d_tail_part;
+  if (orig) {
+    hipLaunchKernelGGL(deblock_tail_kernel<true>, dim3(tiles), dim3(256), 0, ctx->stream, d,
+                       src->v, dst->v, orig->v.c[0], 2 * (shift_bitdepth - 8), part);
+    hipLaunchKernelGGL(picture_ssd_sum_kernel, dim3(1), dim3(256), 0, ctx->stream, part, tiles,
+                       reinterpret_cast<unsigned long long *>(d_ssd));
+  } else {
+    hipLaunchKernelGGL(deblock_tail_kernel<false>, dim3(tiles), dim3(256), 0, ctx->stream, d,
+                       src->v, dst->v, dst->v.c[0], 0, part);
+  }
+  CHECK_LAUNCH(ctx, "deblock_pad_ssd");
+  return XVCGPU_OK;
+}
+
 /* ---- whole-picture passes around the hot path (k_stats.h) ---- */
 static const int kStatsHistWords = 4096;
 
@@ -1440,6 +1515,14 @@ xvcgpu_status xvcgpu_frame_pass(xvcgpu_ctx *ctx, const xvcgpu_frame_pass_args *a
                                 int phases) {
   if (!ctx || !a || !a->rec) return XVCGPU_INVALID_ARGUMENT;
   xvcgpu_status st = XVCGPU_OK;
+  // the five launches of the tail as one (k_tail.h)
+  const int kAll = XVC_FP_ENCODE | XVC_FP_DEBLOCK_V | XVC_FP_DEBLOCK_H | XVC_FP_PAD | XVC_FP_SSD;
+  const bool fused_tail = a->scratch_rec && (phases & kAll) == kAll && a->n_cus > 0 &&
+                          a->n_cus == a->n_cus_total &&
+                          a->db_y_begin == 0 && a->db_y_end >= a->rec->h &&
+                          a->dbh_y_end >= a->rec->h && a->ssd_y_begin == 0 &&
+                          a->ssd_y_end >= a->rec->h && !(a->rec->w & 7) && !(a->rec->h & 7);
+  xvcgpu_picture *const rec = fused_tail ? a->scratch_rec : a->rec;
   if ((phases & XVC_FP_ENCODE) && a->n_cus > 0) {
     st = xvcgpu_me_search_sized(ctx, a->orig, a->ref, XVCGPU_ME_FULLPEL | XVCGPU_ME_SUBPEL,
                                 a->d_me, a->n_cus, a->d_results, a->max_block_size);
@@ -1461,20 +1544,24 @@ xvcgpu_status xvcgpu_frame_pass(xvcgpu_ctx *ctx, const xvcgpu_frame_pass_args *a
                                     a->d_level_off, a->n_coeffs, a->d_levels, a->d_nnz,
                                     a->d_rdoq_contexts, a->d_rdoq_params);
       if (st == XVCGPU_OK)
-        st = xvcgpu_inv_transform_batch(ctx, a->pred, a->rec, a->d_tx, a->n_tx, a->d_levels,
+        st = xvcgpu_inv_transform_batch(ctx, a->pred, rec, a->d_tx, a->n_tx, a->d_levels,
                                         a->d_level_off, a->d_nnz);
       if (st == XVCGPU_OK)
         st = xvcgpu_cu_info_from_me(ctx, a->d_me, a->d_results, a->d_nnz, a->d_luma_tx_index,
                                     a->n_cus, a->qp_y, a->qp_c, a->ref_poc, a->d_cus_own);
     } else if (a->d_rdoq_params)
-      st = xvcgpu_recon_from_me_rdoq(ctx, a->orig, a->ref, a->rec, a->d_me, a->d_results,
+      st = xvcgpu_recon_from_me_rdoq(ctx, a->orig, a->ref, rec, a->d_me, a->d_results,
                                      a->n_cus, a->qp_y, a->qp_c, 0, a->ref_poc, a->d_nnz,
                                      a->d_cus_own, a->d_rdoq_contexts, a->d_rdoq_params);
     else
-      st = xvcgpu_recon_from_me(ctx, a->orig, a->ref, a->rec, a->d_me, a->d_results, a->n_cus,
+      st = xvcgpu_recon_from_me(ctx, a->orig, a->ref, rec, a->d_me, a->d_results, a->n_cus,
                                 a->qp_y, a->qp_c, 0, a->ref_poc, a->d_nnz, a->d_cus_own);
     if (st != XVCGPU_OK) return st;
   }
+  if (fused_tail)
+    return xvcgpu_deblock_pad_ssd(ctx, a->scratch_rec, a->rec, a->orig, a->d_cus, a->n_cus_total,
+                                  a->d_cu_map, a->map_stride, 0, 0, 0, a->shift_bitdepth,
+                                  a->d_ssd);
   if (phases & XVC_FP_DEBLOCK_V) {
     st = xvcgpu_deblock_rows(ctx, a->rec, a->d_cus, a->n_cus_total, a->d_cu_map, a->map_stride,
                              0, 0, 0, 4, 0, a->db_y_begin, a->db_y_end);

@@ -45,6 +45,9 @@ struct xvcgpu_ctx {
   // per-block partial results of xvcgpu_picture_ssd
   unsigned long long *d_ssd_part;
   int ssd_part_cap;  // in blocks
+  // xvcgpu_deblock_pad_ssd (k_tail.h): two words per 64x64 tile
+  unsigned long long *d_tail_part;
+  int tail_cap;      // in tiles
   // scratch of the whole-picture statistics passes (k_stats.h): a signed
   // histogram of 4096 buckets followed by one word per picture row (row CRCs /
   // row remainders of the dithering export)

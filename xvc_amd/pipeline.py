@@ -196,6 +196,13 @@ class FramePass:
                                          api.CU_DTYPE.itemsize * d.n_cus_total))
         self.d_ssd = ctx.alloc(16)
         self.pred = ctx.picture(width, height, bitdepth)
+        # whole pictures of CUs >= 8x8 end with ONE launch (xvcgpu_deblock_pad_ssd:
+        # unfiltered reconstruction in `scratch` -> deblocked, padded `rec` + SSD)
+        # instead of deblock V, H, pad, SSD, SSD fold
+        self.scratch = None
+        if cu >= 8 and width % 8 == 0 and height % 8 == 0 and d.row_range == (0, d.h) \
+                and os.environ.get("XVC_TAIL_FUSED", "1") != "0":
+            self.scratch = ctx.picture(width, height, bitdepth)
         self.d_levels = self.d_level_off = None
         self.n_levels = 0
         if keep_levels:
@@ -222,6 +229,7 @@ class FramePass:
             a.n_cus_total, a.d_cu_map = d.n_cus_total, self.d_map.ptr
             a.map_stride = d.cu_map.shape[1]
             a.db_y_begin, a.db_y_end, a.dbh_y_end = 0, d.h, d.h
+            a.scratch_rec = self.scratch.h_pic if self.scratch is not None else None
             a.ssd_y_begin, a.ssd_y_end = 0, 1 << 30
             a.shift_bitdepth, a.d_ssd = self.bd, self.d_ssd.ptr
             if self.rdoq:
@@ -310,6 +318,9 @@ class FramePass:
         per-kernel timing (bench.py); run in order they are a frame pass."""
         ctx, d, lib = self.ctx, self.desc, self.ctx.lib
         n, T = d.n_cus, len(d.tx)
+        final = rec
+        if self.scratch is not None:
+            rec = self.scratch
         steps = [("me_search", lambda: ctx.me_search_dev(
             orig, ref, api.ME_FULLPEL | api.ME_SUBPEL, self.d_me.ptr, n, self.d_res.ptr,
             d.cu_size))]
@@ -355,6 +366,11 @@ class FramePass:
             steps.append(("cu_info", lambda: ctx.cu_info_from_me_dev(
                 self.d_me.ptr, self.d_res.ptr, self.d_nnz.ptr, self.d_luma_idx.ptr, n, d.qp,
                 d.qp_c, ref_poc, self.d_cus_own)))
+        if self.scratch is not None:
+            steps.append(("deblock_pad_ssd", lambda: ctx.deblock_pad_ssd_dev(
+                rec, final, orig, self.d_cus.ptr, d.n_cus_total, self.d_map.ptr,
+                d.cu_map.shape[1], 0, 0, 0, self.bd, self.d_ssd.ptr)))
+            return steps
         steps += [
             ("deblock", lambda: ctx.deblock_dev(rec, self.d_cus.ptr, d.n_cus_total,
                                                 self.d_map.ptr, d.cu_map.shape[1], 0, 0, 0, 4)),
@@ -375,6 +391,12 @@ class FramePass:
             self.run_phases(orig, ref, rec, api.FP_ENCODE |
                             (api.FP_DEBLOCK_V | api.FP_DEBLOCK_H if deblock else 0) |
                             (api.FP_PAD if pad else 0) | (api.FP_SSD if ssd else 0), ref_poc)
+            return
+        if self.scratch is not None and deblock and pad and ssd:
+            self.encode(orig, ref, self.scratch, ref_poc)
+            ctx.deblock_pad_ssd_dev(self.scratch, rec, orig, self.d_cus.ptr, d.n_cus_total,
+                                    self.d_map.ptr, d.cu_map.shape[1], 0, 0, 0, self.bd,
+                                    self.d_ssd.ptr)
             return
         self.encode(orig, ref, rec, ref_poc)
         if deblock:
