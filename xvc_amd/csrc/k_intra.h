@@ -322,21 +322,37 @@ struct alignas(16) IntraSatdShared {
   IntraRefs refs;
   uint16_t line[4][MS <= 16 ? 8 : 1][132];  // small blocks: up to 8 modes per wave
   uint16_t orig[MS * MS];
+  uint16_t orig_t[MS <= 16 ? MS * MS : 8];  // square 8 / 16 blocks: the original transposed
   uint16_t pred[4][MS <= 16 ? 512 : MS * MS];
 };
 
-// SATD of one 8x8 tile by the 8 lanes of a slot (lane = tile row): the
-// normalised tile value ((sum |H d H^T| + 2) >> 2, sample_metric.cc:403-641) in
-// all 8 lanes.  Sums of absolute values do not depend on the butterfly order.
-__device__ __forceinline__ int intra_satd8_slot(const uint16_t *po, const uint16_t *pp) {
-  const uint4 a = *reinterpret_cast<const uint4 *>(po), b = *reinterpret_cast<const uint4 *>(pp);
-  const uint32_t ua[4] = {a.x, a.y, a.z, a.w}, ub[4] = {b.x, b.y, b.z, b.w};
-  int m[8];
-#pragma unroll
-  for (int k = 0; k < 4; k++) {
-    m[2 * k] = (int)(ua[k] & 0xffff) - (int)(ub[k] & 0xffff);
-    m[2 * k + 1] = (int)(ua[k] >> 16) - (int)(ub[k] >> 16);
-  }
+// ---- square 8x8 / 16x16 blocks: prediction straight into the SATD's registers ----
+// A lane owns one row of one 8x8 tile (8 lanes = a tile, 32 lanes = a 16x16
+// block) and computes the 8 predicted samples of that row itself - no
+// prediction tile in LDS, no per-sample index arithmetic: along a row of an
+// angular mode the offset and the weight are constants and the 8 samples come
+// from 9 consecutive reference samples.  The horizontal half of the modes
+// (2 .. 33) is the vertical half on swapped references producing the transposed
+// block: its lanes compare with the TRANSPOSED original instead - the sum of
+// |H d H^T| over the tiles does not change when d is transposed.
+template <int CTRL>
+__device__ __forceinline__ int intra_dpp(int v) {
+  return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true);
+}
+#define INTRA_DPP_XOR1 0xB1         // quad_perm [1,0,3,2]
+#define INTRA_DPP_XOR2 0x4E         // quad_perm [2,3,0,1]
+#define INTRA_DPP_HALF_MIRROR 0x141 // lane i <-> 7 - i inside each 8 lanes
+#define INTRA_DPP_ROR8 0x128        // row_ror:8: lane i <-> i ^ 8 inside each 16 lanes
+
+// SATD of an 8x8 tile whose row `row` (= lane & 7) this lane holds as 8
+// differences: rows butterflied in registers, columns across the 8 lanes with
+// DPP moves.  The three lane pairings are i^1, i^2 and 7-i (= i^7: what DPP
+// offers for 8 lanes); which lane of a pair keeps the sum is chosen so that the
+// partners of the later stages hold the same kind of term (stage 1: bit0^bit2,
+// stage 2: bit1^bit2, stage 3: bit2) - a Hadamard transform up to the order and
+// the signs of its outputs, which the sum of magnitudes does not see.
+// Returns the tile's (sum + 2) >> 2 in all 8 lanes.
+__device__ __forceinline__ int intra_satd8_rows(int m[8], int row) {
 #pragma unroll
   for (int len = 1; len < 8; len <<= 1)
 #pragma unroll
@@ -347,21 +363,95 @@ __device__ __forceinline__ int intra_satd8_slot(const uint16_t *po, const uint16
         m[j] = u + v;
         m[j + len] = u - v;
       }
-  const int row = threadIdx.x & 7;
+  const int s1 = ((row ^ (row >> 2)) & 1) ? -1 : 1;
+  const int s2 = (((row >> 1) ^ (row >> 2)) & 1) ? -1 : 1;
+  const int s3 = (row & 4) ? -1 : 1;
 #pragma unroll
-  for (int st = 1; st < 8; st <<= 1) {
-    const bool upper = (row & st) != 0;
+  for (int x = 0; x < 8; x++) m[x] = intra_dpp<INTRA_DPP_XOR1>(m[x]) + s1 * m[x];
 #pragma unroll
-    for (int x = 0; x < 8; x++) {
-      const int o = __shfl_xor(m[x], st, XVC_WAVE);
-      m[x] = upper ? o - m[x] : m[x] + o;
-    }
-  }
+  for (int x = 0; x < 8; x++) m[x] = intra_dpp<INTRA_DPP_XOR2>(m[x]) + s2 * m[x];
   int sum = 0;
 #pragma unroll
-  for (int x = 0; x < 8; x++) sum += d_abs(m[x]);
-  sum = group_sum<8>(sum);
+  for (int x = 0; x < 8; x++) sum += d_abs(intra_dpp<INTRA_DPP_HALF_MIRROR>(m[x]) + s3 * m[x]);
+  sum += intra_dpp<INTRA_DPP_XOR1>(sum);
+  sum += intra_dpp<INTRA_DPP_XOR2>(sum);
+  sum += intra_dpp<INTRA_DPP_HALF_MIRROR>(sum);
   return (sum + 2) >> 2;
+}
+
+// Row y, columns tx .. tx+7 of the W x W luma prediction of `mode` in the
+// mode's own frame (modes 2 .. 33: the swapped one, i.e. column y of the block).
+// `line`: the group's scratch for the projected reference line of the negative
+// angles, built here by the group's `gl` lanes (lane index `sub`).  dc: the
+// block's DC value.  Same arithmetic as intra_predict.
+template <int W>
+__device__ __forceinline__ void intra_row8(const IntraRefs &r, uint16_t *line, int bd, int mode,
+                                           int y, int tx, int dc, int sub, int gl, int v[8]) {
+  const int f = intra_use_filtered(W, W, mode) ? 1 : 0;
+  const int smax = (1 << bd) - 1;
+  constexpr int WL = W == 16 ? 4 : 3;
+  if (mode == 0) {  // PlanarPred
+    const uint16_t *above = r.above[f] + 1, *left = r.left[f] + 1;
+    const int top_right = above[W], bottom_left = left[W], ly = left[y];
+    constexpr int shift = 2 * WL + 1, offset = 1 << (shift - 1);
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      const int x = tx + k;
+      const int hor = (W - 1 - y) * above[x] + (y + 1) * bottom_left;
+      const int ver = (W - 1 - x) * ly + (x + 1) * top_right;
+      v[k] = ((hor << WL) + (ver << WL) + offset) >> shift;
+    }
+    return;
+  }
+  if (mode == 1) {  // PredIntraDC with its edge filter (blocks up to 16x16)
+    const uint16_t *above = r.above[0] + 1, *left = r.left[0] + 1;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      const int x = tx + k;
+      v[k] = y == 0 ? (above[x] + 3 * dc + 2) >> 2 : dc;
+    }
+    if (tx == 0) v[0] = y == 0 ? (above[0] + left[0] + 2 * dc + 2) >> 2 : (left[y] + 3 * dc + 2) >> 2;
+    return;
+  }
+  const bool hor = mode < 34;
+  const uint16_t *t1 = hor ? r.left[f] : r.above[f];
+  const uint16_t *t2 = hor ? r.above[f] : r.left[f];
+  const int angle_offset = hor ? 18 - mode : mode - 50;
+  const int angle = kIntraAngle[16 + angle_offset];
+  const uint16_t *ln = t1 + 1;
+  if (angle < 0) {
+    const int num_projected = -((W * angle) >> 5) - 1;
+    const int inv = kIntraInvAngle[-angle_offset - 1];
+    uint16_t *base = line + num_projected + 1;
+    for (int i = sub; i < W + 1 + num_projected; i += gl) {
+      if (i < W + 1) {
+        base[i - 1] = t1[i];
+      } else {
+        const int k = i - (W + 1);
+        base[-2 - k] = t2[1 + ((128 + (k + 1) * inv) >> 8) - 1];
+      }
+    }
+    wave_sync();
+    ln = base;
+  }
+  const int corner = t1[0];
+  if (angle == 0) {
+#pragma unroll
+    for (int k = 0; k < 8; k++) v[k] = t1[1 + tx + k];
+    if (tx == 0) v[0] = d_clip3((int)(int16_t)(t1[1] + ((t2[1 + y] - corner) >> 1)), 0, smax);
+    return;
+  }
+  const int asum = (y + 1) * angle, off = asum >> 5, wt = asum & 31;
+  const uint16_t *a = ln + off + tx;
+  int prev = a[0];
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    const int next = a[k + 1];
+    v[k] = ((32 - wt) * prev + wt * next + 16) >> 5;
+    prev = next;
+  }
+  if (tx == 0 && (angle == 1 || angle == -1))
+    v[0] = d_clip3((int)(int16_t)(v[0] + ((t2[1 + y] - corner) >> 2)), 0, smax);
 }
 
 // grid: (n jobs, S); block 256 = 4 waves.  Luma: the 67 modes are dealt to the
@@ -388,37 +478,60 @@ intra_satd_kernel(PicView orig, PicView rec, const xvcgpu_intra_block *jobs, int
   }
   const PlaneView po = orig.c[0], pr = rec.c[0];
   const int w = b.w, h = b.h, wl = 31 - __clz(w);
+  const bool rows_path = MS <= 16 && w == h && (w == 8 || w == 16);
   for (int p = threadIdx.x; p < w * h; p += 256) {
     const int y = p >> wl, x = p & (w - 1);
-    s.orig[y * w + x] = po.p[(ptrdiff_t)(b.y + y) * po.stride + b.x + x];
+    const uint16_t o = po.p[(ptrdiff_t)(b.y + y) * po.stride + b.x + x];
+    s.orig[y * w + x] = o;
+    if (MS <= 16 && rows_path) s.orig_t[x * w + y] = o;
   }
   intra_build_refs<true>(s.refs, b, pr.p + (ptrdiff_t)b.y * pr.stride + b.x, pr.stride, rec.bd,
                          true, threadIdx.x, 256);  // ends with a barrier: orig is complete too
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  if (MS <= 16 && w == h && (w == 8 || w == 16)) {
-    // K modes side by side in one wave (a 16x16 SATD keeps 32 lanes busy, an
-    // 8x8 one 8): K = 2 / 8 groups of 32 / 8 lanes, each predicting its own
-    // mode into its own tile; one 8x8 tile per 8-lane slot in the SATD
+  if (MS <= 16 && rows_path) {
+    // K modes side by side in one wave: K = 2 (16x16: four tiles of 8 lanes per
+    // mode) or 8 (8x8: one tile); lane = (mode slot, tile, row of the tile)
     const int K = w == 16 ? 2 : 8, gl = 64 / K, g = lane / gl, sub = lane - g * gl;
-    const int slot = lane >> 3, row = lane & 7;
-    const int q = w == 16 ? slot & 3 : 0;                  // tile inside the block
-    const int tx = (q & 1) * 8, ty = (q >> 1) * 8 + row;
-    uint16_t *tile = s.pred[wave] + g * w * h;
+    const int row = lane & 7, q = w == 16 ? (lane >> 3) & 3 : 0;
+    const int tx = (q & 1) * 8, y = (q >> 1) * 8 + row;
+    // the lane's row of the original, and of the transposed original
+    int od[2][8];
+    {
+      const uint4 a = *reinterpret_cast<const uint4 *>(s.orig + y * w + tx);
+      const uint4 t = *reinterpret_cast<const uint4 *>(s.orig_t + y * w + tx);
+      const uint32_t ua[4] = {a.x, a.y, a.z, a.w}, ut[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        od[0][2 * k] = ua[k] & 0xffff;
+        od[0][2 * k + 1] = ua[k] >> 16;
+        od[1][2 * k] = ut[k] & 0xffff;
+        od[1][2 * k + 1] = ut[k] >> 16;
+      }
+    }
+    // PredIntraDC's value, by the wave (unfiltered references)
+    int dc;
+    {
+      int t = lane < w ? s.refs.above[0][1 + lane] : (lane < 2 * w ? s.refs.left[0][1 + lane - w] : 0);
+      t = group_sum<64>(t);
+      dc = (t + w) / (2 * w);
+    }
     for (int m0 = (blockIdx.y * 4 + wave) * K; m0 < XVC_INTRA_NUM_MODES;
          m0 += 4 * gridDim.y * K) {
-      const int m = m0 + g;
-      if (m < XVC_INTRA_NUM_MODES)
-        intra_predict<false>(s.refs, s.line[wave][MS <= 16 ? g : 0], rec.bd, true, m, w, h, tile,
-                             w, sub, gl);
-      wave_sync();
-      int v = intra_satd8_slot(s.orig + ty * w + tx, tile + ty * w + tx);
+      const int m = m0 + g < XVC_INTRA_NUM_MODES ? m0 + g : XVC_INTRA_NUM_MODES - 1;
+      int v[8];
+      if (w == 16) intra_row8<16>(s.refs, s.line[wave][g], rec.bd, m, y, tx, dc, sub, gl, v);
+      else intra_row8<8>(s.refs, s.line[wave][g], rec.bd, m, y, tx, dc, sub, gl, v);
+      const int t = (m >= 2 && m < 34) ? 1 : 0;
+#pragma unroll
+      for (int k = 0; k < 8; k++) v[k] = od[t][k] - v[k];
+      int d = intra_satd8_rows(v, row);
       if (w == 16) {
-        v += __shfl_xor(v, 8, XVC_WAVE);
-        v += __shfl_xor(v, 16, XVC_WAVE);
+        d += intra_dpp<INTRA_DPP_ROR8>(d);
+        d += __shfl_xor(d, 16, XVC_WAVE);
       }
-      if (sub == 0 && m < XVC_INTRA_NUM_MODES)
-        dist[(size_t)blockIdx.x * XVC_INTRA_NUM_MODES + m] = (uint32_t)(v >> (rec.bd - 8));
-      wave_sync();
+      if (sub == 0 && m0 + g < XVC_INTRA_NUM_MODES)
+        dist[(size_t)blockIdx.x * XVC_INTRA_NUM_MODES + m] = (uint32_t)(d >> (rec.bd - 8));
+      wave_sync();   // the group's line buffer is rebuilt by its next mode
     }
     return;
   }
