@@ -821,7 +821,8 @@ def main():
                      "fwd_transform": "residual_wave_kernel<1", "inv_transform": "residual_wave_kernel<2",
                      "mc_from_me": "mc_from_me_kernel",
                      "picture_ssd": "picture_ssd_kernel", "pad_border": "pad_border_kernel",
-                     "deblock": "deblock_pass_kernel<true>"}.get(dom, dom)
+                     "deblock": "deblock_pass_kernel<true>",
+                     "deblock_pad_ssd": "deblock_tail_kernel"}.get(dom, dom)
             if (W == 1920 and H == 1080 and not multi and
                     prof.get("kernel_source_md5") == kernel_source_md5() and
                     prof.get("quant") == args.quant):
