@@ -440,6 +440,12 @@ xvcgpu_status xvcgpu_quant_rdo_batch(xvcgpu_ctx *ctx, int bitdepth,
  * (required before recording them, xvcgpu_record_begin). */
 xvcgpu_status xvcgpu_quant_rdo_reserve(xvcgpu_ctx *ctx, int n, size_t n_coeffs);
 
+/* Diagnostics: the number of blocks of the last xvcgpu_quant_rdo_batch that
+ * needed the walk, by lane class (out[0]: up to 8x8, out[1]: up to 16x16,
+ * out[2]: larger); blocks whose coefficients all quantise to zero are settled
+ * by the classification pass and not counted.  Synchronises the stream. */
+xvcgpu_status xvcgpu_quant_rdo_class_counts(xvcgpu_ctx *ctx, int32_t out[3]);
+
 /* I1 + the above fused, for the uni-pred inter CUs of a motion search batch
  * (InterSearch::CompressAndEvalCbf without the RD bookkeeping,
  * inter_search.cc:261-365): for CU i and each component, motion-compensate

@@ -145,7 +145,7 @@ SYMBOLS = [
     "xvcgpu_intra_select_modes", "xvcgpu_frame_pass", "xvcgpu_copy_segments",
     "xvcgpu_get_transform_matrix", "xvcgpu_inter_pred_batch", "xvcgpu_deblock_tree",
     "xvcgpu_residual_rdoq_batch", "xvcgpu_quant_rdo_batch", "xvcgpu_recon_from_me_rdoq",
-    "xvcgpu_quant_rdo_reserve",
+    "xvcgpu_quant_rdo_reserve", "xvcgpu_quant_rdo_class_counts",
     "xvcgpu_event_create", "xvcgpu_event_destroy", "xvcgpu_event_record", "xvcgpu_event_wait",
     "xvcgpu_event_synchronize", "xvcgpu_comm_unique_id", "xvcgpu_comm_create",
     "xvcgpu_comm_destroy", "xvcgpu_comm_world", "xvcgpu_comm_rank", "xvcgpu_comm_wait_event",
@@ -265,6 +265,7 @@ def load_library():
         "xvcgpu_recon_from_me_rdoq": [_vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int,
                                       C.c_int, C.c_int, _vp, _vp, _vp, _vp],
         "xvcgpu_quant_rdo_reserve": [_vp, C.c_int, C.c_size_t],
+        "xvcgpu_quant_rdo_class_counts": [_vp, _vp],
         "xvcgpu_quant_rdo_batch": [_vp, C.c_int, _vp, C.c_int, _vp, _vp, C.c_size_t, _vp, _vp,
                                    _vp, _vp],
         "xvcgpu_deblock_pad_ssd": [_vp, _vp, _vp, _vp, _vp, C.c_int, _vp, C.c_int, C.c_int,

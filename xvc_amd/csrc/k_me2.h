@@ -100,7 +100,10 @@ __device__ __forceinline__ int wave_reduce_add_i32(int v) {
 
 #define ME2_NOKEY 0xffffffffu
 // independent jobs (waves) per workgroup, by block-size class (LDS budget)
-#define ME2_WAVES(MS) ((MS) > 32 ? 2 : 4)
+#ifndef ME2_WAVES16
+#define ME2_WAVES16 1
+#endif
+#define ME2_WAVES(MS) ((MS) > 32 ? 2 : ((MS) > 16 ? 4 : ME2_WAVES16))
 // waves per SIMD the register allocator leaves room for: the 16-class fits 4
 // workgroups per CU by LDS, so cap its registers at 128 (measured +3 %)
 #define ME2_MIN_WAVES(MS) ((MS) <= 16 ? 4 : 1)  // 5 (96 VGPRs) spills: 80 -> 147 us

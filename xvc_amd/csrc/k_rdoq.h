@@ -956,11 +956,17 @@ __device__ __forceinline__ void quant_rdo_packed_wave(
 // The three classes in ONE launch: their walks are independent and each is
 // bounded by its own slowest block, so one after the other they cost the sum of
 // three tails (180 + 53 + 7 us on the bench picture), together the longest.
-// Workgroups [0, n16) take the 16-lane class (the long walks first), then the
-// 4-lane class, then the 64-lane class; n16 / n4 / n64 are upper bounds (the
-// lists' counts are read on the device).  grid: n16 + n4 + n64; block: 64.
+// Workgroups [0, g16) take the 16-lane class (the long walks first), then g4 for
+// the 4-lane class, the rest the 64-lane class.  The lists' counts are only known
+// on the device, and a workgroup holds 29.5 KB of LDS from the moment it starts -
+// five per CU -, so one workgroup per possible wave of blocks (32 130 for the
+// bench picture, 31 000 of them retiring at once after a 2 us look at the count,
+// in the few LDS slots the live ones leave free) made the launch last as long as
+// that churn: each class gets a bounded number of workgroups instead, which walk
+// their list with that stride - more than the live blocks of a picture need, so
+// a long walk still delays nobody.  grid: g16 + g4 + g64; block: 64.
 __global__ void __launch_bounds__(64)
-quant_rdo_packed_kernel(int bd, const xvcgpu_tx_block *blocks, RdoqLists l, int n16, int n4,
+quant_rdo_packed_kernel(int bd, const xvcgpu_tx_block *blocks, RdoqLists l, int g16, int g4,
                         const int16_t *coeffs, const uint32_t *d_off, int16_t *levels,
                         int32_t *nnz_out, const xvcgpu_rdoq_contexts *rq_ctx,
                         const xvcgpu_rdoq_params *rq_prm) {
@@ -970,16 +976,29 @@ quant_rdo_packed_kernel(int bd, const xvcgpu_tx_block *blocks, RdoqLists l, int 
     RdoqPackedLds<64> c;
   };
   __shared__ Lds sm;
-  const int wg = blockIdx.x;
-  if (wg < n16)
-    quant_rdo_packed_wave<16>(sm.a, wg, bd, blocks, l.list[1], l.count + 1, coeffs, d_off, levels,
-                              nnz_out, rq_ctx, rq_prm);
-  else if (wg < n16 + n4)
-    quant_rdo_packed_wave<4>(sm.b, wg - n16, bd, blocks, l.list[0], l.count + 0, coeffs, d_off,
-                             levels, nnz_out, rq_ctx, rq_prm);
-  else
-    quant_rdo_packed_wave<64>(sm.c, wg - n16 - n4, bd, blocks, l.list[2], l.count + 2, coeffs,
-                              d_off, levels, nnz_out, rq_ctx, rq_prm);
+  const int wg = blockIdx.x, g64 = (int)gridDim.x - g16 - g4;
+  if (wg < g16) {
+    const int waves = (l.count[1] + 3) >> 2;
+    for (int wv = wg; wv < waves; wv += g16) {
+      quant_rdo_packed_wave<16>(sm.a, wv, bd, blocks, l.list[1], l.count + 1, coeffs, d_off,
+                                levels, nnz_out, rq_ctx, rq_prm);
+      wave_sync();
+    }
+  } else if (wg < g16 + g4) {
+    const int waves = (l.count[0] + 15) >> 4;
+    for (int wv = wg - g16; wv < waves; wv += g4) {
+      quant_rdo_packed_wave<4>(sm.b, wv, bd, blocks, l.list[0], l.count + 0, coeffs, d_off,
+                               levels, nnz_out, rq_ctx, rq_prm);
+      wave_sync();
+    }
+  } else {
+    const int waves = l.count[2];
+    for (int wv = wg - g16 - g4; wv < waves; wv += g64) {
+      quant_rdo_packed_wave<64>(sm.c, wv, bd, blocks, l.list[2], l.count + 2, coeffs, d_off,
+                                levels, nnz_out, rq_ctx, rq_prm);
+      wave_sync();
+    }
+  }
 }
 
 #endif  // XVCGPU_K_RDOQ_H_

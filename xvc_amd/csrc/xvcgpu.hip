@@ -4,6 +4,7 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <algorithm>
 #include <new>
 #include <vector>
 
@@ -951,6 +952,17 @@ xvcgpu_status xvcgpu_residual_rdoq_batch(xvcgpu_ctx *ctx, const xvcgpu_picture *
   return XVCGPU_OK;
 }
 
+// workgroups per class of quant_rdo_packed_kernel (k_rdoq.h)
+#ifndef RDOQ_GRID16
+#define RDOQ_GRID16 2048
+#endif
+#ifndef RDOQ_GRID4
+#define RDOQ_GRID4 512
+#endif
+#ifndef RDOQ_GRID64
+#define RDOQ_GRID64 512
+#endif
+
 static xvcgpu_status ensure_rdoq_scratch(xvcgpu_ctx *ctx, int n, size_t n_coeffs) {
   // scratch: class lists (3 x n) + counters + the per-block classes
   if (n > ctx->rdoq_lists_cap) {
@@ -966,6 +978,15 @@ static xvcgpu_status ensure_rdoq_scratch(xvcgpu_ctx *ctx, int n, size_t n_coeffs
     ctx->rdoq_lists_cap = cap;
   }
   (void)n_coeffs;  // the per-coefficient records live in LDS
+  return XVCGPU_OK;
+}
+
+xvcgpu_status xvcgpu_quant_rdo_class_counts(xvcgpu_ctx *ctx, int32_t out[3]) {
+  if (!ctx || !out) return XVCGPU_INVALID_ARGUMENT;
+  out[0] = out[1] = out[2] = 0;
+  if (!ctx->d_rdoq_lists) return XVCGPU_OK;
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  HIP_TRY(ctx, hipMemcpy(out, ctx->d_rdoq_lists, 3 * sizeof(int32_t), hipMemcpyDeviceToHost));
   return XVCGPU_OK;
 }
 
@@ -997,11 +1018,12 @@ xvcgpu_status xvcgpu_quant_rdo_batch(xvcgpu_ctx *ctx, int bitdepth,
   hipLaunchKernelGGL(rdoq_classify_kernel, dim3((n + 3) / 4), dim3(256), 0, ctx->stream,
                      bitdepth, d_blocks, n, d_coeffs, d_offsets, d_levels, d_nnz, l);
   hipLaunchKernelGGL(rdoq_compact_kernel, dim3(1), dim3(1024), 0, ctx->stream, n, l);
-  // the class sizes are only known on the device: upper bounds, workgroups
-  // beyond a list's count retire at once
-  const int n16 = (n + 3) / 4, n4 = (n + 15) / 16;
-  hipLaunchKernelGGL(quant_rdo_packed_kernel, dim3(n16 + n4 + n), dim3(64), 0, ctx->stream,
-                     bitdepth, d_blocks, l, n16, n4, d_coeffs, d_offsets, d_levels, d_nnz,
+  // the class sizes are only known on the device: a bounded number of workgroups
+  // per class that walk their list (k_rdoq.h)
+  const int g16 = std::min((n + 3) / 4, RDOQ_GRID16), g4 = std::min((n + 15) / 16, RDOQ_GRID4),
+            g64 = std::min(n, RDOQ_GRID64);
+  hipLaunchKernelGGL(quant_rdo_packed_kernel, dim3(g16 + g4 + g64), dim3(64), 0, ctx->stream,
+                     bitdepth, d_blocks, l, g16, g4, d_coeffs, d_offsets, d_levels, d_nnz,
                      d_contexts, d_params);
   CHECK_LAUNCH(ctx, "quant_rdo_batch");
   return XVCGPU_OK;
