@@ -38,7 +38,7 @@ def rate(c, fn, n):
     return (time.perf_counter() - t0) / n * 1e6
 
 
-names = ["me_search", "fwd_from_me", "quant_rdo", "inv_transform", "deblock"]
+names = ["me_search", "fwd_from_me", "quant_rdo", "inv_transform", "deblock_pad_ssd"]
 for b in names:
     fb = state[1][1][b]
     alone = rate(ctxs[1], fb, 200)

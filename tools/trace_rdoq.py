@@ -1,0 +1,45 @@
+"""Section timeline of the RDOQ walk (developer build, -DXVCGPU_TRACE):
+
+    hipcc ... -DXVCGPU_TRACE -o xvc_amd/libxvcgpu_trace.so      (tools/trace_rdoq.sh)
+    XVCGPU_LIB=$PWD/xvc_amd/libxvcgpu_trace.so python tools/trace_rdoq.py
+"""
+import ctypes as C, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+from xvc_amd import api, pipeline, synth
+W, H, bd, border = 1920, 1080, 10, 128
+ctx = api.Context(0)
+clip = synth.SyntheticClip(W, H, bd)
+pad = lambda planes: [np.ascontiguousarray(np.pad(p, border if c == 0 else border // 2, mode="edge")) for c, p in enumerate(planes)]
+O, R, Rec = (ctx.picture(W, H, bd) for _ in range(3))
+R.upload(pad(clip.frame(0)), border); O.upload(pad(clip.frame(1)), border)
+fp = pipeline.FramePass(ctx, W, H, bd, qp=32, rdoq=True)
+for _ in range(3):
+    fp.run(O, R, Rec)
+ctx.sync()
+lib = api.load_library()
+counts = (C.c_int32 * 3)()
+lib.xvcgpu_quant_rdo_class_counts(ctx.h, counts)
+rows = (counts[1] + 3) // 4
+buf = np.zeros((4096, 16), np.uint64)
+lib.xvcgpu_debug_rdoq_trace(buf.ctypes.data_as(C.c_void_p), 4096)
+steps = buf[:rows, 11:15].astype(np.int64)
+t = buf[:rows, :11].astype(np.int64)
+ok = (t[:, 10] > t[:, 0]) & (t[:, 4] > 0)
+t = t[ok]
+steps = steps[ok]
+print("%d waves of the 16-lane class (%d blocks); clock ticks" % (len(t), counts[1]))
+names = ["count,list", "block,prm,off", "coefficients", "ctx costs", "quant+last", "setup",
+         "diagonals", "EvalLastPos", "zero+signs", "sign hide", "levels out"]
+life = t[:, 10] - t[:, 0]
+print("wave lifetime: mean %.0f p50 %.0f p90 %.0f max %d" % (life.mean(), np.median(life), np.percentile(life, 90), life.max()))
+prev = t[:, 0]
+for k in range(1, 11):
+    cur = np.where(t[:, k] > 0, t[:, k], prev)     # sections a wave skipped
+    d = cur - prev
+    print("%-14s mean %7.0f  p50 %7.0f  p90 %7.0f  max %8d  share %5.1f%%" %
+          (names[k], d.mean(), np.median(d), np.percentile(d, 90), d.max(), 100.0 * d.sum() / life.sum()))
+    prev = cur
+print("inside the diagonal loop (sums over the diagonals): step 1 (decisions) %.0f, step 2 (no choice) %.0f, "
+      "step 3 (zero sub-block) %.0f, loop head %.0f" % tuple(steps.mean(axis=0)[[0, 1, 2, 3]]))

@@ -58,6 +58,38 @@ __constant__ uint32_t kEntropyBits[128] = {
 
 // Per-block scratch: N = coefficients of the (at most 32x32) low-frequency
 // region; arrays indexed by position y * rw + x.
+// Developer build (-DXVCGPU_TRACE): clock readings of the walk's sections, one
+// row per workgroup of quant_rdo_packed_kernel (tools/trace_rdoq.py).
+#ifdef XVCGPU_TRACE
+__device__ unsigned long long g_rq_trace[4096][16];
+#define RQ_TRACE(k)                                                          \
+  do {                                                                       \
+    if (threadIdx.x == 0 && blockIdx.x < 4096)                               \
+      g_rq_trace[blockIdx.x][k] = __builtin_amdgcn_s_memtime();              \
+  } while (0)
+#else
+#define RQ_TRACE(k) do {} while (0)
+#endif
+// step times inside the diagonal loop, summed (rows' columns 11-13, 14 = diagonals)
+#ifdef XVCGPU_TRACE
+#define RQ_STEP_BEGIN() unsigned long long rq_t_ = __builtin_amdgcn_s_memtime(), rq_a_[4] = {0, 0, 0, 0}
+#define RQ_STEP(i)                                              \
+  do {                                                          \
+    const unsigned long long n_ = __builtin_amdgcn_s_memtime(); \
+    rq_a_[i] += n_ - rq_t_;                                     \
+    rq_t_ = n_;                                                 \
+  } while (0)
+#define RQ_STEP_END()                                                           \
+  do {                                                                          \
+    if (threadIdx.x == 0 && blockIdx.x < 4096)                                  \
+      for (int i_ = 0; i_ < 4; i_++) g_rq_trace[blockIdx.x][11 + i_] = rq_a_[i_]; \
+  } while (0)
+#else
+#define RQ_STEP_BEGIN() do {} while (0)
+#define RQ_STEP(i) do {} while (0)
+#define RQ_STEP_END() do {} while (0)
+#endif
+
 template <int N>
 struct RdoqShared {
   long long cost_to_zero[N];   // coeff_cost_to_zero_
@@ -341,6 +373,7 @@ __device__ __forceinline__ int wave_rdoq(S &s, int lane, int bd, int w, int h,
       *lev(x, y) = 0;
     }
   const int last_pos_index = rq_wave_max_i32<G>(last);
+  RQ_TRACE(4);
   if (last_pos_index < 0) return 0;  // nothing quantises to a level (most blocks)
 
   // every context's two bin costs into LDS
@@ -374,11 +407,14 @@ __device__ __forceinline__ int wave_rdoq(S &s, int lane, int bd, int w, int h,
   // the wavefront starts at the highest anti-diagonal that holds a live sub-block
   const int d_first = rq_wave_max_i32<G>(live ? sx + sy : -1);
   wave_sync();
+  RQ_TRACE(5);
 
   // ---- one anti-diagonal of sub-blocks at a time
+  RQ_STEP_BEGIN();
   for (int d = d_first; d >= 0; d--) {
     const bool act = live && sx + sy == d;
     bool any = false;
+    RQ_STEP(3);
     // step 1: the owner decides the coefficients that have a choice
     if (act) {
       RdoqCoeffState st = {0, 0, 0};
@@ -471,6 +507,7 @@ __device__ __forceinline__ int wave_rdoq(S &s, int lane, int bd, int w, int h,
       s.sb_code_cost[lane] = code_cost;
     }
     wave_sync();
+    RQ_STEP(0);
     // step 2: the coefficients without a choice, dealt over the group's lanes
     {
       const int ax0 = d > rgh - 1 ? d - (rgh - 1) : 0;
@@ -511,6 +548,7 @@ __device__ __forceinline__ int wave_rdoq(S &s, int lane, int bd, int w, int h,
       }
     }
     wave_sync();
+    RQ_STEP(1);
     // step 3: EvalZeroSubblock (rdo_quant.cc:722-760)
     if (act) {
       long long sb_code_cost = s.sb_code_cost[lane];
@@ -554,7 +592,9 @@ __device__ __forceinline__ int wave_rdoq(S &s, int lane, int bd, int w, int h,
       s.sb_zero_dist[lane] = sb_zero_dist;
     }
     wave_sync();
+    RQ_STEP(2);
   }
+  RQ_STEP_END();
   long long comp_code_cost = rq_wave_sum_i64<G>(mine ? s.sb_code_cost[lane] : 0ll);
   const long long comp_zero_dist = rq_wave_sum_i64<G>(mine ? s.sb_zero_dist[lane] : 0ll);
   // sub-blocks outside the region (64-point transforms): all zero, never the
@@ -572,57 +612,123 @@ __device__ __forceinline__ int wave_rdoq(S &s, int lane, int bd, int w, int h,
     comp_code_cost += (long long)rq_wave_sum_i32<G>(n_out) * rq_bit_cost(outside_bits, lambda);
   }
 
-  // ---- EvalLastPos (rdo_quant.cc:762-832): lane 0, result broadcast
+  RQ_TRACE(6);
+  // ---- EvalLastPos (rdo_quant.cc:762-832).  The reference walks back from the
+  // last position carrying a running cost: minus every visited sub-block's flag
+  // cost, plus cost_to_zero of every visited coefficient; a non-zero level is a
+  // candidate (running cost + last-position bits - its implicit sig bits), the
+  // first level above 1 ends the walk.  The running cost in front of a
+  // coefficient is a prefix sum in scan order: every lane sums its own
+  // sub-block, takes the sum of the sub-blocks behind it (64-bit integer adds:
+  // any order), evaluates its own candidates down to the stop position and the
+  // group keeps the cheapest - on equal cost the one met first, i.e. the
+  // highest index.  (One lane doing the walk alone cost 36 of a wave's 93 us.)
   int new_last = 0;
-  if (lane == 0) {
-    const int cbf_ctx = 2 * (!luma ? RQ_OFF(cbf_chroma)
-                                   : ((prm.flags & XVC_RDOQ_INTRA_CU) ? RQ_OFF(cbf_luma)
-                                                                      : RQ_OFF(root_cbf)));
-    long long code_cost = comp_code_cost + rq_bit_cost(cb[cbf_ctx + 1], lambda);
-    int start = last_k;
+  const int cbf_ctx = 2 * (!luma ? RQ_OFF(cbf_chroma)
+                                 : ((prm.flags & XVC_RDOQ_INTRA_CU) ? RQ_OFF(cbf_luma)
+                                                                    : RQ_OFF(root_cbf)));
+  const long long comp_zero_cost = comp_zero_dist + rq_bit_cost(cb[cbf_ctx], lambda);
+  if (gw * gh == rgw * rgh) {
+    const int last_sb = last_pos_index >> (2 * sbs);
+    const bool visited = mine && my_scan <= last_sb;
+    const bool coded = visited && s.csbf[lane] != 0;
+    const int start_k = my_scan == last_sb ? last_k : sb_size - 1;
+    const long long flag_cost = visited ? rq_bit_cost(s.csbf_bits[lane], lambda) : 0ll;
+    long long t = -flag_cost;
+    int stop_local = -1;
+    if (coded)
+      for (int k = start_k; k >= 0; k--) {
+        int x, y;
+        coeff_xy(k, x, y);
+        t += s.cost_to_zero[y * rw + x];
+        if (stop_local < 0 && *lev(x, y) > 1) stop_local = sb_index + k;
+      }
+    wave_sync();   // every lane has read its sb_code_cost entry (the sums above)
+    if (mine) s.sb_code_cost[my_scan] = visited ? t : 0ll;   // now indexed by scan position
+    wave_sync();
+    const int stop_idx = rq_wave_max_i32<G>(stop_local);
     long long best_cost = 0x7fffffffffffffffll;
     int best_last_plus1 = 0;
-    bool stop = false;
-    for (int sbi = last_pos_index >> (2 * sbs); sbi >= 0 && !stop; sbi--) {
-      const int t = s.sb_of_scan[sbi];
-      const int tx = t % gw, ty = t / gw;
-      const int idx = sbi << (2 * sbs);
-      if (tx >= rgw || ty >= rgh) {
-        if (idx > 0 && idx + sb_size <= last_pos_index) code_cost -= rq_bit_cost(outside_bits, lambda);
-        continue;
-      }
-      const int l = ty * rgw + tx;
-      code_cost -= rq_bit_cost(s.csbf_bits[l], lambda);
-      if (!s.csbf[l]) continue;
-      for (int k = start; k >= 0; k--) {
-        const int p = rq_scan_pos(sbs, scan_order, k);
-        const int x = (tx << sbs) + (p & 3), y = (ty << sbs) + (p >> 2);
+    if (coded && sb_index + start_k >= stop_idx) {
+      long long c = comp_code_cost + rq_bit_cost(cb[cbf_ctx + 1], lambda) - flag_cost;
+      for (int j = my_scan + 1; j <= last_sb; j++) c += s.sb_code_cost[j];
+      for (int k = start_k; k >= 0 && sb_index + k >= stop_idx; k--) {
+        int x, y;
+        coeff_xy(k, x, y);
         const int pos = y * rw + x;
-        const int v = *lev(x, y);
-        if (!v) {
-          code_cost += s.cost_to_zero[pos];
+        if (*lev(x, y)) {
+          const unsigned lp_bits = rq_last_pos_bits(cb, luma, w, h, scan_order, x, y);
+          const long long cost =
+              c + rq_bit_cost(lp_bits, lambda) - rq_bit_cost(s.sig_bits[pos], lambda);
+          if (cost < best_cost) {
+            best_cost = cost;
+            best_last_plus1 = sb_index + k + 1;
+          }
+        }
+        c += s.cost_to_zero[pos];
+      }
+    }
+#pragma unroll
+    for (int sh = 1; sh < G; sh <<= 1) {
+      const long long oc = __shfl_xor(best_cost, sh, 64);
+      const int oi = __shfl_xor(best_last_plus1, sh, 64);
+      if (oc < best_cost || (oc == best_cost && oi > best_last_plus1)) {
+        best_cost = oc;
+        best_last_plus1 = oi;
+      }
+    }
+    new_last = comp_zero_cost < best_cost ? -1 : best_last_plus1;
+  } else {
+    // 64-point transforms (sub-blocks beyond the coefficient region take part in
+    // the walk): lane 0, result broadcast
+    if (lane == 0) {
+      long long code_cost = comp_code_cost + rq_bit_cost(cb[cbf_ctx + 1], lambda);
+      int start = last_k;
+      long long best_cost = 0x7fffffffffffffffll;
+      int best_last_plus1 = 0;
+      bool stop = false;
+      for (int sbi = last_pos_index >> (2 * sbs); sbi >= 0 && !stop; sbi--) {
+        const int t = s.sb_of_scan[sbi];
+        const int tx = t % gw, ty = t / gw;
+        const int idx = sbi << (2 * sbs);
+        if (tx >= rgw || ty >= rgh) {
+          if (idx > 0 && idx + sb_size <= last_pos_index)
+            code_cost -= rq_bit_cost(outside_bits, lambda);
           continue;
         }
-        const unsigned lp_bits = rq_last_pos_bits(cb, luma, w, h, scan_order, x, y);
-        const long long cost =
-            code_cost + rq_bit_cost(lp_bits, lambda) - rq_bit_cost(s.sig_bits[pos], lambda);
-        if (cost < best_cost) {
-          best_cost = cost;
-          best_last_plus1 = idx + k + 1;
+        const int l = ty * rgw + tx;
+        code_cost -= rq_bit_cost(s.csbf_bits[l], lambda);
+        if (!s.csbf[l]) continue;
+        for (int k = start; k >= 0; k--) {
+          const int p = rq_scan_pos(sbs, scan_order, k);
+          const int x = (tx << sbs) + (p & 3), y = (ty << sbs) + (p >> 2);
+          const int pos = y * rw + x;
+          const int v = *lev(x, y);
+          if (!v) {
+            code_cost += s.cost_to_zero[pos];
+            continue;
+          }
+          const unsigned lp_bits = rq_last_pos_bits(cb, luma, w, h, scan_order, x, y);
+          const long long cost =
+              code_cost + rq_bit_cost(lp_bits, lambda) - rq_bit_cost(s.sig_bits[pos], lambda);
+          if (cost < best_cost) {
+            best_cost = cost;
+            best_last_plus1 = idx + k + 1;
+          }
+          if (v > 1) {
+            stop = true;
+            break;
+          }
+          code_cost += s.cost_to_zero[pos];
         }
-        if (v > 1) {
-          stop = true;
-          break;
-        }
-        code_cost += s.cost_to_zero[pos];
+        start = sb_size - 1;
       }
-      start = sb_size - 1;
+      new_last = comp_zero_cost < best_cost ? -1 : best_last_plus1;
     }
-    const long long comp_zero_cost = comp_zero_dist + rq_bit_cost(cb[cbf_ctx], lambda);
-    new_last = comp_zero_cost < best_cost ? -1 : best_last_plus1;
+    new_last = __shfl(new_last, (int)(ME2_LANE & ~(G - 1)), 64);
   }
-  new_last = __shfl(new_last, (int)(ME2_LANE & ~(G - 1)), 64);
 
+  RQ_TRACE(7);
   // ---- zero what lies at / beyond the new last position, re-apply the signs
   int nnz = 0;
   bool has = false;
@@ -641,6 +747,7 @@ __device__ __forceinline__ int wave_rdoq(S &s, int lane, int bd, int w, int h,
   if (new_last < 0) return 0;
   if (!(sign_hide && nnz > 1 && sbs > 1)) return nnz;
 
+  RQ_TRACE(8);
   // ---- CoeffSignHideRdo (rdo_quant.cc:575-687): lane = sub-block
   const int last_sb_scan = rq_wave_max_i32<G>(has ? my_scan : -1);
   int dn = 0;
@@ -884,6 +991,7 @@ __device__ __forceinline__ void quant_rdo_packed_wave(
   constexpr int GROUPS = 64 / G;
   const int g = threadIdx.x / G, lane = threadIdx.x % G;
   const int slot = wave * GROUPS + g;
+  RQ_TRACE(0);
   const int n_list = *count;
   if (wave * GROUPS >= n_list) return;  // the launch is an upper bound
   const bool active = slot < n_list;
@@ -895,6 +1003,7 @@ __device__ __forceinline__ void quant_rdo_packed_wave(
   const uint32_t off = d_off[bi];
   const int16_t *src = coeffs + off;
   int16_t *cf = sm.cf[g], *lv = sm.lv[g];
+  RQ_TRACE(1);
   if (active)
     for (int i = lane; i < rw * rh; i += G) {
       const int y = i / rw, x = i - y * rw;
@@ -916,6 +1025,7 @@ __device__ __forceinline__ void quant_rdo_packed_wave(
   v.ctx_bits = sm.ctx_bits;
   const bool sign_hide = !(b.intra_pic & XVC_TXF_NO_SIGN_HIDING);
   const int scan_order = (b.intra_pic >> XVC_TXF_SCAN_SHIFT) & 3;
+  RQ_TRACE(2);
   // one context snapshot at a time (normally one round)
   bool pending = active;
   int nnz = 0;
@@ -934,6 +1044,7 @@ __device__ __forceinline__ void quant_rdo_packed_wave(
       }
     }
     wave_sync();
+    RQ_TRACE(3);
     if (pending && (int)prm.ctx_index == cur) {
       // the groups walk independently (their shuffles stay inside the group)
       nnz = wave_rdoq<G>(
@@ -944,6 +1055,7 @@ __device__ __forceinline__ void quant_rdo_packed_wave(
     }
   }
   wave_sync();
+  RQ_TRACE(9);
   if (!active) return;
   int16_t *dst = levels + off;
   for (int i = lane; i < w * h; i += G) {
@@ -951,6 +1063,7 @@ __device__ __forceinline__ void quant_rdo_packed_wave(
     dst[i] = (x < rw && y < rh) ? lv[y * rw + x] : (int16_t)0;
   }
   if (lane == 0 && nnz_out) nnz_out[bi] = nnz;
+  RQ_TRACE(10);
 }
 
 // The three classes in ONE launch: their walks are independent and each is

@@ -704,6 +704,17 @@ xvcgpu_status xvcgpu_debug_me_trace(unsigned long long *out, int n_jobs) {
 }
 #endif
 
+#ifdef XVCGPU_TRACE
+// developer build only (tools/trace_rdoq.py): the walk's section clock readings
+xvcgpu_status xvcgpu_debug_rdoq_trace(unsigned long long *out, int n_rows) {
+  hipDeviceSynchronize();
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_rq_trace),
+                             sizeof(unsigned long long) * 16 * (size_t)n_rows) == hipSuccess
+             ? XVCGPU_OK
+             : XVCGPU_DEVICE_ERROR;
+}
+#endif
+
 xvcgpu_status xvcgpu_me_search(xvcgpu_ctx *ctx, const xvcgpu_picture *orig,
                                const xvcgpu_picture *ref, int flags,
                                const xvcgpu_me_block *d_blocks, int n,
