@@ -25,10 +25,12 @@ rows = (counts[1] + 3) // 4
 buf = np.zeros((4096, 16), np.uint64)
 lib.xvcgpu_debug_rdoq_trace(buf.ctypes.data_as(C.c_void_p), 4096)
 steps = buf[:rows, 11:15].astype(np.int64)
+steps2 = buf[2048:2048 + rows, 11:15].astype(np.int64)
 t = buf[:rows, :11].astype(np.int64)
 ok = (t[:, 10] > t[:, 0]) & (t[:, 4] > 0)
 t = t[ok]
 steps = steps[ok]
+steps2 = steps2[ok]
 print("%d waves of the 16-lane class (%d blocks); clock ticks" % (len(t), counts[1]))
 names = ["count,list", "block,prm,off", "coefficients", "ctx costs", "quant+last", "setup",
          "diagonals", "EvalLastPos", "zero+signs", "sign hide", "levels out"]
@@ -43,3 +45,5 @@ for k in range(1, 11):
     prev = cur
 print("inside the diagonal loop (sums over the diagonals): step 1 (decisions) %.0f, step 2 (no choice) %.0f, "
       "step 3 (zero sub-block) %.0f, loop head %.0f" % tuple(steps.mean(axis=0)[[0, 1, 2, 3]]))
+print("inside EvalLastPos: own sums %.0f, stop + table %.0f, prefix + candidates %.0f, reduce %.0f" %
+      tuple(steps2.mean(axis=0)))

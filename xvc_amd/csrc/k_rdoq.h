@@ -81,13 +81,22 @@ __device__ unsigned long long g_rq_trace[4096][16];
   } while (0)
 #define RQ_STEP_END()                                                           \
   do {                                                                          \
-    if (threadIdx.x == 0 && blockIdx.x < 4096)                                  \
+    if (threadIdx.x == 0 && blockIdx.x < 2048)                                  \
       for (int i_ = 0; i_ < 4; i_++) g_rq_trace[blockIdx.x][11 + i_] = rq_a_[i_]; \
+  } while (0)
+// a second set of four (EvalLastPos' parts): rows 2048 + workgroup
+#define RQ_STEP2_BEGIN() rq_t_ = __builtin_amdgcn_s_memtime(); rq_a_[0] = rq_a_[1] = rq_a_[2] = rq_a_[3] = 0
+#define RQ_STEP2_END()                                                          \
+  do {                                                                          \
+    if (threadIdx.x == 0 && blockIdx.x < 2048)                                  \
+      for (int i_ = 0; i_ < 4; i_++) g_rq_trace[2048 + blockIdx.x][11 + i_] = rq_a_[i_]; \
   } while (0)
 #else
 #define RQ_STEP_BEGIN() do {} while (0)
 #define RQ_STEP(i) do {} while (0)
 #define RQ_STEP_END() do {} while (0)
+#define RQ_STEP2_BEGIN() do {} while (0)
+#define RQ_STEP2_END() do {} while (0)
 #endif
 
 template <int N>
@@ -102,6 +111,7 @@ struct RdoqShared {
   unsigned char csbf[64];
   unsigned char sb_live[64];   // the walk reaches the sub-block
   unsigned char sb_of_scan[256];  // sub-block scan index -> sy * gw + sx
+  unsigned lp_bits[32];        // EvalLastPos: last-position bits by group of x [0..15], of y [16..31]
   // GetEntropyBits(bin) of every context of the snapshot: [2 * i + bin] for the
   // context at byte offset i of xvcgpu_rdoq_contexts.  The walk looks a dozen
   // of these up per coefficient, each depending on the previous decision: from
@@ -121,6 +131,7 @@ struct RdoqView {
   unsigned *csbf_bits;
   unsigned char *csbf, *sb_live;
   unsigned char *sb_of_scan;
+  unsigned *lp_bits;
   unsigned *ctx_bits;
 };
 
@@ -234,6 +245,27 @@ __device__ __forceinline__ unsigned rq_last_pos_bits(const unsigned *cb, bool lu
   if (gy < rq_last_pos_group(h - 1)) bits += cb[rq_last_pos_ctx(luma, w, h, k, false)];
   if (gx > 3) bits += (unsigned)((gx - 2) >> 1) * RQ_BYPASS;
   if (gy > 3) bits += (unsigned)((gy - 2) >> 1) * RQ_BYPASS;
+  return bits;
+}
+
+// One axis of GetLastPosBits for a whole position GROUP g (every position of a
+// group costs the same): the bits of the x (is_x) or y part in a block of
+// (already scan-swapped) size w x h - rq_last_pos_bits = axis(group(x)) +
+// axis(group(y)).  The context costs of all possible prefix bins are read
+// together.
+__device__ __forceinline__ unsigned rq_last_pos_group_bits(const unsigned *cb, bool luma, int w,
+                                                           int h, int g, bool is_x) {
+  const int gmax = rq_last_pos_group((is_x ? w : h) - 1);
+  const int gc = gmax > 0 ? gmax - 1 : 0;
+  unsigned one[10];
+#pragma unroll
+  for (int k = 0; k < 10; k++) one[k] = cb[rq_last_pos_ctx(luma, w, h, k < gc ? k : gc, is_x) + 1];
+  const unsigned zero_bits = cb[rq_last_pos_ctx(luma, w, h, g < gc ? g : gc, is_x)];
+  unsigned bits = 0;
+#pragma unroll
+  for (int k = 0; k < 10; k++) bits += k < g ? one[k] : 0u;
+  if (g < gmax) bits += zero_bits;
+  if (g > 3) bits += (unsigned)((g - 2) >> 1) * RQ_BYPASS;
   return bits;
 }
 
@@ -629,45 +661,87 @@ __device__ __forceinline__ int wave_rdoq(S &s, int lane, int bd, int w, int h,
                                                                     : RQ_OFF(root_cbf)));
   const long long comp_zero_cost = comp_zero_dist + rq_bit_cost(cb[cbf_ctx], lambda);
   if (gw * gh == rgw * rgh) {
+    RQ_STEP2_BEGIN();
     const int last_sb = last_pos_index >> (2 * sbs);
     const bool visited = mine && my_scan <= last_sb;
     const bool coded = visited && s.csbf[lane] != 0;
     const int start_k = my_scan == last_sb ? last_k : sb_size - 1;
     const long long flag_cost = visited ? rq_bit_cost(s.csbf_bits[lane], lambda) : 0ll;
-    long long t = -flag_cost;
+    // the last-position bits of every position group of the two axes, once per
+    // block: entries [g] for the (scan-swapped) x, [16 + g] for y - a candidate
+    // then costs two reads instead of up to eighteen
+    const bool lp_swap = scan_order == 2;
+    {
+      const int tw = lp_swap ? h : w, th = lp_swap ? w : h;
+      const int nx = rq_last_pos_group(tw - 1) + 1, ny = rq_last_pos_group(th - 1) + 1;
+      for (int i = lane; i < nx + ny; i += G) {
+        const bool is_x = i < nx;
+        const int g = is_x ? i : i - nx;
+        s.lp_bits[is_x ? g : 16 + g] = rq_last_pos_group_bits(cb, luma, tw, th, g, is_x);
+      }
+    }
+    // own sub-block, back from start_k: the running sum of zero costs in front of
+    // every coefficient replaces its cost_to_zero entry (nothing reads those
+    // after this), the non-zero levels are noted in a mask; four coefficients'
+    // reads in flight at a time
+    long long run = 0;
+    unsigned nz = 0;
     int stop_local = -1;
     if (coded)
-      for (int k = start_k; k >= 0; k--) {
-        int x, y;
-        coeff_xy(k, x, y);
-        t += s.cost_to_zero[y * rw + x];
-        if (stop_local < 0 && *lev(x, y) > 1) stop_local = sb_index + k;
+      for (int kb = (sb_size - 1) & ~3; kb >= 0; kb -= 4) {
+        long long z[4];
+        int v[4], pos[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          const int k = kb + 3 - i;
+          int x, y;
+          coeff_xy(k < sb_size ? k : 0, x, y);
+          pos[i] = y * rw + x;
+          const bool in = k < sb_size && k <= start_k;
+          z[i] = in ? s.cost_to_zero[pos[i]] : 0ll;
+          v[i] = in ? (int)*lev(x, y) : 0;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          const int k = kb + 3 - i;
+          if (k < sb_size && k <= start_k) {
+            s.cost_to_zero[pos[i]] = run;
+            run += z[i];
+            if (v[i]) nz |= 1u << k;
+            if (v[i] > 1 && stop_local < 0) stop_local = sb_index + k;
+          }
+        }
       }
+    const long long t = run - flag_cost;
+    RQ_STEP(0);
     wave_sync();   // every lane has read its sb_code_cost entry (the sums above)
     if (mine) s.sb_code_cost[my_scan] = visited ? t : 0ll;   // now indexed by scan position
     wave_sync();
     const int stop_idx = rq_wave_max_i32<G>(stop_local);
     long long best_cost = 0x7fffffffffffffffll;
     int best_last_plus1 = 0;
-    if (coded && sb_index + start_k >= stop_idx) {
+    RQ_STEP(1);
+    if (nz && sb_index + start_k >= stop_idx) {
       long long c = comp_code_cost + rq_bit_cost(cb[cbf_ctx + 1], lambda) - flag_cost;
       for (int j = my_scan + 1; j <= last_sb; j++) c += s.sb_code_cost[j];
-      for (int k = start_k; k >= 0 && sb_index + k >= stop_idx; k--) {
+      while (nz) {
+        const int k = 31 - __clz((int)nz);
+        nz ^= 1u << k;
+        if (sb_index + k < stop_idx) break;
         int x, y;
         coeff_xy(k, x, y);
         const int pos = y * rw + x;
-        if (*lev(x, y)) {
-          const unsigned lp_bits = rq_last_pos_bits(cb, luma, w, h, scan_order, x, y);
-          const long long cost =
-              c + rq_bit_cost(lp_bits, lambda) - rq_bit_cost(s.sig_bits[pos], lambda);
-          if (cost < best_cost) {
-            best_cost = cost;
-            best_last_plus1 = sb_index + k + 1;
-          }
+        const unsigned lp_bits = s.lp_bits[rq_last_pos_group(lp_swap ? y : x)] +
+                                 s.lp_bits[16 + rq_last_pos_group(lp_swap ? x : y)];
+        const long long cost = c + s.cost_to_zero[pos] + rq_bit_cost(lp_bits, lambda) -
+                               rq_bit_cost(s.sig_bits[pos], lambda);
+        if (cost < best_cost) {
+          best_cost = cost;
+          best_last_plus1 = sb_index + k + 1;
         }
-        c += s.cost_to_zero[pos];
       }
     }
+    RQ_STEP(2);
 #pragma unroll
     for (int sh = 1; sh < G; sh <<= 1) {
       const long long oc = __shfl_xor(best_cost, sh, 64);
@@ -678,6 +752,8 @@ __device__ __forceinline__ int wave_rdoq(S &s, int lane, int bd, int w, int h,
       }
     }
     new_last = comp_zero_cost < best_cost ? -1 : best_last_plus1;
+    RQ_STEP(3);
+    RQ_STEP2_END();
   } else {
     // 64-point transforms (sub-blocks beyond the coefficient region take part in
     // the walk): lane 0, result broadcast
@@ -979,6 +1055,7 @@ struct RdoqPackedLds {
   int16_t cf[GROUPS][MAXC], lv[GROUPS][MAXC];
   unsigned char csbf[GROUPS][MAXSB], sb_live[GROUPS][MAXSB];
   unsigned char sb_of_scan[GROUPS][G == 64 ? 256 : MAXSB * 4];
+  unsigned lp_bits[GROUPS][32];
 };
 
 // G lanes per block; grid: an upper bound on ceil(count / (64 / G)) waves (the
@@ -1022,6 +1099,7 @@ __device__ __forceinline__ void quant_rdo_packed_wave(
   v.csbf_bits = sm.csbf_bits[g];
   v.csbf = sm.csbf[g];
   v.sb_of_scan = sm.sb_of_scan[g];
+  v.lp_bits = sm.lp_bits[g];
   v.ctx_bits = sm.ctx_bits;
   const bool sign_hide = !(b.intra_pic & XVC_TXF_NO_SIGN_HIDING);
   const int scan_order = (b.intra_pic >> XVC_TXF_SCAN_SHIFT) & 3;
