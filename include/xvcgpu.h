@@ -740,6 +740,21 @@ xvcgpu_status xvcgpu_copy_segments(xvcgpu_ctx *ctx, const xvcgpu_copy_segment *d
 xvcgpu_status xvcgpu_frame_pass(xvcgpu_ctx *ctx, const xvcgpu_frame_pass_args *a,
                                 int phases);
 
+/* The frame passes of n independent pictures (the pictures the reference's
+ * picture-level worker threads code at the same time, thread_encoder.cc:99-159)
+ * with every kernel launched ONCE for all of them: the n motion searches run
+ * beside each other, then the n transforms, ... - kernels of one kind share the
+ * chip far better than kernels of different pictures' different stages do.
+ * Same results as n calls of xvcgpu_frame_pass(ctxs[i], args[i], phases).
+ * Everything is enqueued on ctxs[0]'s stream; ctxs[i] lends picture i its
+ * scratch (its own stream must be idle or the same stream).  Batched for
+ * 2 <= n <= 4 whole pictures of one size whose CUs are 8x8 ... 16x16
+ * (scratch_rec given), all phases, QuantFast or the packed RDOQ pipeline;
+ * anything else falls back to the n single calls, each on its own context. */
+xvcgpu_status xvcgpu_frame_pass_multi(xvcgpu_ctx *const *ctxs,
+                                      const xvcgpu_frame_pass_args *const *args, int n,
+                                      int phases);
+
 /* ---- tables (host side, no GPU needed) ---------------------------------- *
  * The 8-bit-fraction transform matrices the kernels use (transform_data.cc:
  * 109-796), for table-equality tests. out: size*size int16 row-major. */

@@ -974,6 +974,53 @@ def test_frame_pass(gpu, xo, size, fused, rdoq):
         p.destroy()
 
 
+@pytest.mark.parametrize("rdoq", [False, True])
+@pytest.mark.parametrize("n", [2, 3, 4])
+def test_frame_pass_multi(gpu, rdoq, n):
+    """xvcgpu_frame_pass_multi: n pictures per launch of every kernel = n single
+    frame passes (which are pinned against the oracle above): reconstructions
+    with their borders, search results, non-zero counts, CU records, SSD - two
+    chained rounds, different pictures in every slot."""
+    api, ctx = gpu
+    from xvc_amd import pipeline, synth
+    pw, ph, qp, bd = 352, 288, 32, 10
+    clip = synth.SyntheticClip(pw, ph, bd)
+    ctxs = [api.Context(0) for _ in range(n)]
+    passes = [pipeline.FramePass(c, pw, ph, bd, qp=qp, rdoq=rdoq) for c in ctxs]
+    pipeline.share_stream(passes)
+    single = pipeline.FramePass(ctx, pw, ph, bd, qp=qp, rdoq=rdoq)
+    pics = [[c.picture(pw, ph, bd) for _ in range(3)] for c in ctxs]      # orig, ref, rec
+    sO, sR, sRec = (ctx.picture(pw, ph, bd) for _ in range(3))
+    for i in range(n):
+        pics[i][1].upload(pad_planes(clip.frame(i), bd), BL)
+    for rnd in range(2):
+        for i in range(n):
+            pics[i][0].upload(pad_planes(clip.frame(i + 1 + rnd), bd), BL)
+        pipeline.run_multi(passes, [p[0] for p in pics], [p[1] for p in pics],
+                           [p[2] for p in pics], [rnd + i for i in range(n)])
+        ctxs[0].sync()
+        for i in range(n):
+            sO.upload(pics[i][0].download(BL), BL)
+            sR.upload(pics[i][1].download(BL), BL)
+            single.run(sO, sR, sRec, ref_poc=rnd + i)
+            ctx.sync()
+            got, exp = pics[i][2].download(BL), sRec.download(BL)
+            for c in range(3):
+                assert np.array_equal(got[c], exp[c]), (rnd, i, c)
+            for a, b in zip(passes[i].results(), single.results()):
+                assert np.array_equal(a, b), (rnd, i)
+        for p in pics:
+            p[1], p[2] = p[2], p[1]          # next round references this reconstruction
+    # a form the batched launches do not cover falls back to the single calls
+    lone = [passes[0]]
+    pipeline.run_multi(lone, [pics[0][0]], [pics[0][1]], [pics[0][2]])
+    ctxs[0].sync()
+    for p in passes + [single]:
+        p.destroy()
+    for c in ctxs:
+        c.close()
+
+
 @pytest.mark.parametrize("bd,qp,size", [(8, 22, (352, 288)), (8, 37, (200, 120)),
                                         (12, 32, (352, 288)), (12, 17, (136, 72))])
 def test_frame_pass_bitdepths(gpu, xo, bd, qp, size):

@@ -142,7 +142,7 @@ SYMBOLS = [
     "xvcgpu_picture_import", "xvcgpu_picture_export", "xvcgpu_picture_crc",
     "xvcgpu_variance_map", "xvcgpu_histogram_distance",
     "xvcgpu_intra_pred_batch", "xvcgpu_intra_satd_batch", "xvcgpu_intra_recon_batch",
-    "xvcgpu_intra_select_modes", "xvcgpu_frame_pass", "xvcgpu_copy_segments",
+    "xvcgpu_intra_select_modes", "xvcgpu_frame_pass", "xvcgpu_frame_pass_multi", "xvcgpu_copy_segments",
     "xvcgpu_get_transform_matrix", "xvcgpu_inter_pred_batch", "xvcgpu_deblock_tree",
     "xvcgpu_residual_rdoq_batch", "xvcgpu_quant_rdo_batch", "xvcgpu_recon_from_me_rdoq",
     "xvcgpu_quant_rdo_reserve", "xvcgpu_quant_rdo_class_counts",
@@ -258,6 +258,8 @@ def load_library():
         "xvcgpu_intra_recon_batch": [_vp, _vp, _vp, _vp, _vp, C.c_int, _vp, _vp, _vp],
         "xvcgpu_intra_select_modes": [_vp, _vp, _vp, C.c_int, _vp, _vp, _vp, C.c_int],
         "xvcgpu_frame_pass": [_vp, C.POINTER(FramePassArgs), C.c_int],
+        "xvcgpu_frame_pass_multi": [C.POINTER(_vp), C.POINTER(C.POINTER(FramePassArgs)), C.c_int,
+                                    C.c_int],
         "xvcgpu_copy_segments": [_vp, _vp, C.c_int],
         "xvcgpu_get_transform_matrix": [C.c_int, C.c_int, _vp],
         "xvcgpu_inter_pred_batch": [_vp, C.POINTER(_vp), C.c_int, _vp, _vp, _vp, C.c_int],

@@ -29,6 +29,16 @@ __device__ __forceinline__ T group_sum(T v) {
   return v;
 }
 
+// Arguments of one kernel for up to XVC_MULTI_MAX pictures, passed by value: a
+// "multi" kernel is the single-picture kernel's body run with the arguments of
+// picture blockIdx.y (xvcgpu_frame_pass_multi: kernels of the same kind run well
+// beside each other, kernels of different kinds do not - DESIGN.md section 6b).
+#define XVC_MULTI_MAX 4
+template <typename A>
+struct MultiArgs {
+  A a[XVC_MULTI_MAX];
+};
+
 // ClipMv, inter_prediction.cc:769-782 (1/16-pel units).
 __device__ __forceinline__ void d_clip_mv(int pos_x, int pos_y, int pic_w,
                                           int pic_h, int &mx, int &my) {

@@ -729,11 +729,11 @@ __device__ __forceinline__ int me2_rotated_wg(int block, int n_wg, const Me2Rot 
 // plain instances leave those jobs alone (or, when the caller did not announce
 // any - lic_launched false - report them unsupported).
 template <int MS, int PH, bool LIC = false>
-__global__ void __launch_bounds__(64 * ME2_WAVES(MS), ME2_MIN_WAVES(MS))
-me_search_wave_kernel(PicView orig, PicView ref,
-                      const xvcgpu_me_block *blocks, int n,
-                      xvcgpu_me_result *results, const TzCand *tz_pattern,
-                      Me2Sched sched, int max_launched, bool lic_launched = false) {
+__device__ __forceinline__ void
+me_search_wave_body(const PicView &orig, const PicView &ref,
+                    const xvcgpu_me_block *blocks, int n,
+                    xvcgpu_me_result *results, const TzCand *tz_pattern,
+                    Me2Sched sched, int max_launched, bool lic_launched) {
   constexpr int WPG = ME2_WAVES(MS);
   constexpr bool kSched = !LIC && (PH & XVCGPU_ME_FULLPEL) != 0;
   typedef Me2SharedT<MS, (PH & XVCGPU_ME_SUBPEL) != 0> Shared;
@@ -1130,6 +1130,32 @@ me_search_wave_kernel(PicView orig, PicView ref,
   ME2_TRACE(8);  // sub-pel passes
   ME2_TRACE_RT(10);
   if (lane == 0) results[bi] = res;
+}
+
+template <int MS, int PH, bool LIC = false>
+__global__ void __launch_bounds__(64 * ME2_WAVES(MS), ME2_MIN_WAVES(MS))
+me_search_wave_kernel(PicView orig, PicView ref,
+                      const xvcgpu_me_block *blocks, int n,
+                      xvcgpu_me_result *results, const TzCand *tz_pattern,
+                      Me2Sched sched, int max_launched, bool lic_launched = false) {
+  me_search_wave_body<MS, PH, LIC>(orig, ref, blocks, n, results, tz_pattern, sched, max_launched,
+                                   lic_launched);
+}
+
+// The searches of several pictures in one launch (grid y = picture): see
+// xvcgpu_frame_pass_multi.  16-class, both phases.
+struct MeMultiArgs {
+  PicView orig, ref;
+  const xvcgpu_me_block *blocks;
+  int n;
+  xvcgpu_me_result *results;
+  Me2Sched sched;
+};
+__global__ void __launch_bounds__(64 * ME2_WAVES(16), ME2_MIN_WAVES(16))
+me_search_multi_kernel(MultiArgs<MeMultiArgs> m, const TzCand *tz_pattern) {
+  const MeMultiArgs &a = m.a[blockIdx.y];
+  me_search_wave_body<16, 3, false>(a.orig, a.ref, a.blocks, a.n, a.results, tz_pattern, a.sched,
+                                    16, false);
 }
 
 // ---- sub-pel phase of the 64 class by a team of waves -------------------------

@@ -169,12 +169,7 @@ mc_from_me_kernel(PicView ref, PicView pred, const xvcgpu_me_block *blocks,
 // HBM: fills the deblocking metadata of uni-pred inter CUs from the motion
 // search results and the luma cbf of the residual pipeline (what the
 // reference's CuEncoder writes into CodingUnit, cu_encoder.cc:543-577).
-__global__ void cu_info_from_me_kernel(const xvcgpu_me_block *blocks,
-                                       const xvcgpu_me_result *results,
-                                       const int32_t *nnz,
-                                       const int32_t *luma_tx_index, int n,
-                                       int qp_y, int qp_c, int ref_poc,
-                                       xvcgpu_cu_info *cus) {
+__device__ __forceinline__ void cu_info_from_me_kernel_body(const xvcgpu_me_block *blocks, const xvcgpu_me_result *results, const int32_t *nnz, const int32_t *luma_tx_index, int n, int qp_y, int qp_c, int ref_poc, xvcgpu_cu_info *cus) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const xvcgpu_me_block b = blocks[i];
@@ -198,6 +193,11 @@ __global__ void cu_info_from_me_kernel(const xvcgpu_me_block *blocks,
     c.mv[1][k][1] = 0;
   }
   cus[i] = c;
+}
+
+__global__ void
+cu_info_from_me_kernel(const xvcgpu_me_block *blocks, const xvcgpu_me_result *results, const int32_t *nnz, const int32_t *luma_tx_index, int n, int qp_y, int qp_c, int ref_poc, xvcgpu_cu_info *cus) {
+  cu_info_from_me_kernel_body(blocks, results, nnz, luma_tx_index, n, qp_y, qp_c, ref_poc, cus);
 }
 
 // SampleMetric::ComparePicture / ComputePsnr block walk (sample_metric.cc:
@@ -264,9 +264,7 @@ picture_ssd_kernel(PlaneView a, PlaneView b, int shift, int y_begin, int y_end,
 }
 
 // grid: 1; block: 256.  out[0] = sum of block SSDs, out[1] = samples visited.
-__global__ void __launch_bounds__(256)
-picture_ssd_sum_kernel(const unsigned long long *part_in, int items,
-                       unsigned long long *out) {
+__device__ __forceinline__ void picture_ssd_sum_kernel_body(const unsigned long long *part_in, int items, unsigned long long *out) {
   __shared__ unsigned long long red[2][4];
   unsigned long long s0 = 0, s1 = 0;
   // batches of four independent loads per thread (one round trip per batch)
@@ -295,6 +293,11 @@ picture_ssd_sum_kernel(const unsigned long long *part_in, int items,
     out[0] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
     out[1] = red[1][0] + red[1][1] + red[1][2] + red[1][3];
   }
+}
+
+__global__ void __launch_bounds__(256)
+picture_ssd_sum_kernel(const unsigned long long *part_in, int items, unsigned long long *out) {
+  picture_ssd_sum_kernel_body(part_in, items, out);
 }
 
 // grid: (32, n segments); block 256: segment blockIdx.y, 16 bytes per thread and

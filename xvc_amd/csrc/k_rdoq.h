@@ -932,9 +932,7 @@ __device__ __forceinline__ int rq_class_of(const xvcgpu_tx_block &b) {
 // block): they get their zero levels and count here and never reach the serial
 // walk; the others are appended to their class list.  counts must be zero on
 // entry.  grid: ceil(n / 4); block: 256.
-__global__ void __launch_bounds__(256)
-rdoq_classify_kernel(int bd, const xvcgpu_tx_block *blocks, int n, const int16_t *coeffs,
-                     const uint32_t *d_off, int16_t *levels, int32_t *nnz_out, RdoqLists l) {
+__device__ __forceinline__ void rdoq_classify_kernel_body(int bd, const xvcgpu_tx_block *blocks, int n, const int16_t *coeffs, const uint32_t *d_off, int16_t *levels, int32_t *nnz_out, RdoqLists l) {
   const int bi = blockIdx.x * 4 + (int)(threadIdx.x >> 6);
   if (bi >= n) return;
   const int lane = threadIdx.x & 63;
@@ -963,12 +961,16 @@ rdoq_classify_kernel(int bd, const xvcgpu_tx_block *blocks, int n, const int16_t
   if (lane == 0 && nnz_out) nnz_out[bi] = 0;
 }
 
+__global__ void __launch_bounds__(256)
+rdoq_classify_kernel(int bd, const xvcgpu_tx_block *blocks, int n, const int16_t *coeffs, const uint32_t *d_off, int16_t *levels, int32_t *nnz_out, RdoqLists l) {
+  rdoq_classify_kernel_body(bd, blocks, n, coeffs, d_off, levels, nnz_out, l);
+}
+
 // The class lists from the per-block classes, without atomics (a few thousand
 // atomicAdds on three addresses took 150 us): one workgroup, every thread
 // counts its contiguous chunk, an LDS scan gives the chunk's place in each list.
 // grid: 1; block: 1024.
-__global__ void __launch_bounds__(1024)
-rdoq_compact_kernel(int n, RdoqLists l) {
+__device__ __forceinline__ void rdoq_compact_kernel_body(int n, RdoqLists l) {
   __shared__ int part[3][1024];
   const int t = threadIdx.x;
   // a multiple of 4 blocks per thread: the classes are read four at a time
@@ -1032,6 +1034,11 @@ rdoq_compact_kernel(int n, RdoqLists l) {
   }
   if (t == 1023)
     for (int k = 0; k < 3; k++) l.count[k] = part[k][16 + 15];
+}
+
+__global__ void __launch_bounds__(1024)
+rdoq_compact_kernel(int n, RdoqLists l) {
+  rdoq_compact_kernel_body(n, l);
 }
 
 // LDS of one wave of class G.  One table of context costs per wave: the groups
@@ -1156,11 +1163,7 @@ __device__ __forceinline__ void quant_rdo_packed_wave(
 // that churn: each class gets a bounded number of workgroups instead, which walk
 // their list with that stride - more than the live blocks of a picture need, so
 // a long walk still delays nobody.  grid: g16 + g4 + g64; block: 64.
-__global__ void __launch_bounds__(64)
-quant_rdo_packed_kernel(int bd, const xvcgpu_tx_block *blocks, RdoqLists l, int g16, int g4,
-                        const int16_t *coeffs, const uint32_t *d_off, int16_t *levels,
-                        int32_t *nnz_out, const xvcgpu_rdoq_contexts *rq_ctx,
-                        const xvcgpu_rdoq_params *rq_prm) {
+__device__ __forceinline__ void quant_rdo_packed_kernel_body(int bd, const xvcgpu_tx_block *blocks, RdoqLists l, int g16, int g4, const int16_t *coeffs, const uint32_t *d_off, int16_t *levels, int32_t *nnz_out, const xvcgpu_rdoq_contexts *rq_ctx, const xvcgpu_rdoq_params *rq_prm) {
   union Lds {
     RdoqPackedLds<16> a;
     RdoqPackedLds<4> b;
@@ -1190,6 +1193,11 @@ quant_rdo_packed_kernel(int bd, const xvcgpu_tx_block *blocks, RdoqLists l, int 
       wave_sync();
     }
   }
+}
+
+__global__ void __launch_bounds__(64)
+quant_rdo_packed_kernel(int bd, const xvcgpu_tx_block *blocks, RdoqLists l, int g16, int g4, const int16_t *coeffs, const uint32_t *d_off, int16_t *levels, int32_t *nnz_out, const xvcgpu_rdoq_contexts *rq_ctx, const xvcgpu_rdoq_params *rq_prm) {
+  quant_rdo_packed_kernel_body(bd, blocks, l, g16, g4, coeffs, d_off, levels, nnz_out, rq_ctx, rq_prm);
 }
 
 #endif  // XVCGPU_K_RDOQ_H_

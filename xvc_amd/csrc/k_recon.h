@@ -177,16 +177,8 @@ __device__ __forceinline__ void wave_interp_block_lds(int bd, int w, int h, int 
 // which then plays TransformEncoder's prediction buffer) and forward transform,
 // coefficients to coeffs + coeff_off[3 * cu + comp]: what precedes a quantiser
 // that runs as its own kernel (xvcgpu_quant_rdo_batch).
-template <bool RDOQ = false, bool FWD = false>
-__global__ void __launch_bounds__(256)
-recon_from_me_kernel(PicView orig, PicView ref, PicView rec,
-                     const xvcgpu_me_block *blocks, const xvcgpu_me_result *results,
-                     int n_cus, int qp_y, int qp_c, int intra_pic, int ref_poc,
-                     int32_t *nnz_out, xvcgpu_cu_info *cus,
-                     const int16_t *tx_tables, const int16_t *tx_tables_t,
-                     TxTableLayout lay, const xvcgpu_rdoq_contexts *rq_ctx = nullptr,
-                     const xvcgpu_rdoq_params *rq_prm = nullptr, int16_t *coeffs = nullptr,
-                     const uint32_t *coeff_off = nullptr) {
+template <bool RDOQ, bool FWD>
+__device__ __forceinline__ void recon_from_me_kernel_body(PicView orig, PicView ref, PicView rec, const xvcgpu_me_block *blocks, const xvcgpu_me_result *results, int n_cus, int qp_y, int qp_c, int intra_pic, int ref_poc, int32_t *nnz_out, xvcgpu_cu_info *cus, const int16_t *tx_tables, const int16_t *tx_tables_t, TxTableLayout lay, const xvcgpu_rdoq_contexts *rq_ctx, const xvcgpu_rdoq_params *rq_prm, int16_t *coeffs, const uint32_t *coeff_off) {
   constexpr int TXM = FWD ? TX_MODE_FWD : TX_MODE_FULL;
   __shared__ ReconShared s_all[4];
   // one scratch per wave; a chroma wave splits it between its two halves
@@ -326,6 +318,12 @@ recon_from_me_kernel(PicView orig, PicView ref, PicView rec,
     }
     cus[ci] = c;
   }
+}
+
+template <bool RDOQ = false, bool FWD = false>
+__global__ void __launch_bounds__(256)
+recon_from_me_kernel(PicView orig, PicView ref, PicView rec, const xvcgpu_me_block *blocks, const xvcgpu_me_result *results, int n_cus, int qp_y, int qp_c, int intra_pic, int ref_poc, int32_t *nnz_out, xvcgpu_cu_info *cus, const int16_t *tx_tables, const int16_t *tx_tables_t, TxTableLayout lay, const xvcgpu_rdoq_contexts *rq_ctx = nullptr, const xvcgpu_rdoq_params *rq_prm = nullptr, int16_t *coeffs = nullptr, const uint32_t *coeff_off = nullptr) {
+  recon_from_me_kernel_body<RDOQ, FWD>(orig, ref, rec, blocks, results, n_cus, qp_y, qp_c, intra_pic, ref_poc, nnz_out, cus, tx_tables, tx_tables_t, lay, rq_ctx, rq_prm, coeffs, coeff_off);
 }
 
 #endif  // XVCGPU_K_RECON_H_

@@ -196,9 +196,7 @@ __device__ __forceinline__ void tail_pad_plane(const uint16_t *lds, const PlaneV
 // one sums - cost 10 us of the launch: 510 release fences + same-address
 // returning atomics across the eight L2s; the second launch costs 3.)
 template <bool SSD>
-__global__ void __launch_bounds__(256)
-deblock_tail_kernel(DbParams d, PicView src, PicView dst, PlaneView orig, int shift,
-                    unsigned long long *part) {
+__device__ __forceinline__ void deblock_tail_kernel_body(DbParams d, PicView src, PicView dst, PlaneView orig, int shift, unsigned long long *part) {
   __shared__ TailShared s;
   const int tid = threadIdx.x;
   const int w = d.pic_w, h = d.pic_h;
@@ -442,6 +440,12 @@ deblock_tail_kernel(DbParams d, PicView src, PicView dst, PlaneView orig, int sh
     part[2 * blockIdx.x + 1] = vis ? (unsigned long long)ow * oh : 0ull;
   }
   TAIL_MARK(6);
+}
+
+template <bool SSD>
+__global__ void __launch_bounds__(256)
+deblock_tail_kernel(DbParams d, PicView src, PicView dst, PlaneView orig, int shift, unsigned long long *part) {
+  deblock_tail_kernel_body<SSD>(d, src, dst, orig, shift, part);
 }
 
 #endif  // XVCGPU_K_TAIL_H_

@@ -462,15 +462,8 @@ __device__ __forceinline__ void residual_job(TxShared &s, int bi, const PicView 
 // grid: ceil(n/256) workgroups of 256 threads.  Each workgroup scans 256
 // descriptors, collects the jobs that need the general path and runs them one
 // after the other (normally none: every job of a 16x16-CU picture is "small").
-template <int MODE, bool RDOQ = false>
-__global__ void __launch_bounds__(TX_THREADS)
-residual_kernel(PicView orig, PicView pred, PicView rec,
-                const xvcgpu_tx_block *blocks, int n, int16_t *levels,
-                const uint32_t *level_off, int32_t *nnz_out,
-                const int16_t *tx_tables, TxTableLayout lay,
-                const xvcgpu_rdoq_contexts *rq_ctx = nullptr,
-                const xvcgpu_rdoq_params *rq_prm = nullptr,
-                unsigned long long *dist_out = nullptr) {
+template <int MODE, bool RDOQ>
+__device__ __forceinline__ void residual_kernel_body(PicView orig, PicView pred, PicView rec, const xvcgpu_tx_block *blocks, int n, int16_t *levels, const uint32_t *level_off, int32_t *nnz_out, const int16_t *tx_tables, TxTableLayout lay, const xvcgpu_rdoq_contexts *rq_ctx, const xvcgpu_rdoq_params *rq_prm, unsigned long long *dist_out) {
   __shared__ __attribute__((aligned(16))) TxShared s;
   __shared__ RdoqShared<RDOQ ? 1024 : 4> rq;
   __shared__ int jobs[TX_THREADS];
@@ -484,6 +477,12 @@ residual_kernel(PicView orig, PicView pred, PicView rec,
   for (int k = 0; k < nj; k++)
     residual_job<MODE, RDOQ ? 1024 : 4>(s, jobs[k], orig, pred, rec, blocks, levels, level_off,
                                         nnz_out, tx_tables, lay, &rq, rq_ctx, rq_prm, dist_out);
+}
+
+template <int MODE, bool RDOQ = false>
+__global__ void __launch_bounds__(TX_THREADS)
+residual_kernel(PicView orig, PicView pred, PicView rec, const xvcgpu_tx_block *blocks, int n, int16_t *levels, const uint32_t *level_off, int32_t *nnz_out, const int16_t *tx_tables, TxTableLayout lay, const xvcgpu_rdoq_contexts *rq_ctx = nullptr, const xvcgpu_rdoq_params *rq_prm = nullptr, unsigned long long *dist_out = nullptr) {
+  residual_kernel_body<MODE, RDOQ>(orig, pred, rec, blocks, n, levels, level_off, nnz_out, tx_tables, lay, rq_ctx, rq_prm, dist_out);
 }
 
 // The same path with one workgroup per descriptor (a workgroup whose block

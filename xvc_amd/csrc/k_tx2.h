@@ -376,15 +376,8 @@ __device__ __forceinline__ int tx2_job(Tx2Shared &sh, const xvcgpu_tx_block &b, 
 
 // grid: XCD-swizzled workgroups of TX2_WAVES waves; one job per wave.
 // tx_tables_t: the same matrices transposed (same layout offsets).
-template <int MODE, bool RDOQ = false>
-__global__ void __launch_bounds__(64 * TX2_WAVES)
-residual_wave_kernel(PicView orig, PicView pred, PicView rec,
-                     const xvcgpu_tx_block *blocks, int n, int16_t *levels,
-                     const uint32_t *level_off, int32_t *nnz_out,
-                     const int16_t *tx_tables, const int16_t *tx_tables_t,
-                     TxTableLayout lay, const xvcgpu_rdoq_contexts *rq_ctx = nullptr,
-                     const xvcgpu_rdoq_params *rq_prm = nullptr,
-                     unsigned long long *dist_out = nullptr) {
+template <int MODE, bool RDOQ>
+__device__ __forceinline__ void residual_wave_kernel_body(PicView orig, PicView pred, PicView rec, const xvcgpu_tx_block *blocks, int n, int16_t *levels, const uint32_t *level_off, int32_t *nnz_out, const int16_t *tx_tables, const int16_t *tx_tables_t, TxTableLayout lay, const xvcgpu_rdoq_contexts *rq_ctx, const xvcgpu_rdoq_params *rq_prm, unsigned long long *dist_out) {
   __shared__ Tx2Shared s_all[TX2_WAVES];
   __shared__ RdoqShared<256> rq_all[RDOQ ? TX2_WAVES : 1];
   Tx2Shared &s = s_all[threadIdx.x >> 6];
@@ -400,6 +393,12 @@ residual_wave_kernel(PicView orig, PicView pred, PicView rec,
                           pp.p + (ptrdiff_t)b.y * pp.stride + b.x, pp.stride, rec.c[b.comp],
                           levels, level_off, nnz_out, tx_tables, tx_tables_t, lay, nullptr, 0,
                           &rq_all[RDOQ ? (threadIdx.x >> 6) : 0], rq_ctx, rq_prm, dist_out);
+}
+
+template <int MODE, bool RDOQ = false>
+__global__ void __launch_bounds__(64 * TX2_WAVES)
+residual_wave_kernel(PicView orig, PicView pred, PicView rec, const xvcgpu_tx_block *blocks, int n, int16_t *levels, const uint32_t *level_off, int32_t *nnz_out, const int16_t *tx_tables, const int16_t *tx_tables_t, TxTableLayout lay, const xvcgpu_rdoq_contexts *rq_ctx = nullptr, const xvcgpu_rdoq_params *rq_prm = nullptr, unsigned long long *dist_out = nullptr) {
+  residual_wave_kernel_body<MODE, RDOQ>(orig, pred, rec, blocks, n, levels, level_off, nnz_out, tx_tables, tx_tables_t, lay, rq_ctx, rq_prm, dist_out);
 }
 
 #endif  // XVCGPU_K_TX2_H_

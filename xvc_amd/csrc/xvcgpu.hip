@@ -23,6 +23,7 @@
 #include "k_intra.h"
 #include "k_affine_me.h"
 #include "k_inter_pred.h"
+#include "k_multi.h"
 #include "xvcgpu_internal.h"
 
 namespace {
@@ -1613,6 +1614,206 @@ xvcgpu_status xvcgpu_frame_pass(xvcgpu_ctx *ctx, const xvcgpu_frame_pass_args *a
     st = xvcgpu_picture_ssd_rows(ctx, a->orig, a->rec, 0, a->shift_bitdepth, a->ssd_y_begin,
                                  a->ssd_y_end, a->d_ssd);
   return st;
+}
+
+/* ---- several pictures per call: every kernel launched once for all of them ---- */
+xvcgpu_status xvcgpu_frame_pass_multi(xvcgpu_ctx *const *ctxs,
+                                      const xvcgpu_frame_pass_args *const *args, int n,
+                                      int phases) {
+  if (!ctxs || !args || n < 1 || !ctxs[0]) return XVCGPU_INVALID_ARGUMENT;
+  xvcgpu_ctx *ctx = ctxs[0];
+  const int kAll = XVC_FP_ENCODE | XVC_FP_DEBLOCK_V | XVC_FP_DEBLOCK_H | XVC_FP_PAD | XVC_FP_SSD;
+  // the form the launches below cover: whole pictures of CUs up to 16x16 (and at
+  // least 8x8: scratch_rec), all phases, the packed RDOQ pipeline or QuantFast;
+  // anything else runs picture by picture, each on its own context
+  bool batched = n >= 2 && n <= XVC_MULTI_MAX && (phases & kAll) == kAll;
+  for (int i = 0; i < n && batched; i++) {
+    const xvcgpu_frame_pass_args *a = args[i];
+    if (!ctxs[i] || !a || !a->orig || !a->ref || !a->rec) return XVCGPU_INVALID_ARGUMENT;
+    const bool rdoq_packed = a->d_rdoq_params && a->pred && a->n_tx == 3 * a->n_cus;
+    const bool fast = !a->d_rdoq_params;
+    batched = a->scratch_rec && a->n_cus > 0 && a->n_cus == a->n_cus_total &&
+              a->max_block_size <= 16 && (rdoq_packed || fast) &&
+              (rdoq_packed == (args[0]->d_rdoq_params != nullptr)) && a->db_y_begin == 0 &&
+              a->db_y_end >= a->rec->h && a->dbh_y_end >= a->rec->h && a->ssd_y_begin == 0 &&
+              a->ssd_y_end >= a->rec->h && !(a->rec->w & 7) && !(a->rec->h & 7) &&
+              a->rec->w == args[0]->rec->w && a->rec->h == args[0]->rec->h &&
+              a->rec->bd == args[0]->rec->bd && ctxs[i]->device == ctx->device;
+  }
+  if (!batched) {
+    for (int i = 0; i < n; i++) {
+      if (!ctxs[i] || !args[i]) return XVCGPU_INVALID_ARGUMENT;
+      const xvcgpu_status st = xvcgpu_frame_pass(ctxs[i], args[i], phases);
+      if (st != XVCGPU_OK) return st;
+    }
+    return XVCGPU_OK;
+  }
+  const bool rdoq = args[0]->d_rdoq_params != nullptr;
+  const dim3 one(1);
+  int max_cus = 0, max_tx = 0;
+  for (int i = 0; i < n; i++) {
+    max_cus = std::max(max_cus, (int)args[i]->n_cus);
+    max_tx = std::max(max_tx, (int)args[i]->n_tx);
+  }
+  const TxTableLayout lay = xvcgpu_tx_layout();
+  // 1. the motion searches
+  {
+    MultiArgs<MeMultiArgs> m;
+    for (int i = 0; i < n; i++) {
+      const xvcgpu_frame_pass_args *a = args[i];
+      xvcgpu_ctx *c = ctxs[i];
+      const int e = c->me_epoch = (c->me_epoch + 1) % 3;   // the picture's own rotation records
+      MeMultiArgs &k = m.a[i];
+      k.orig = a->orig->v;
+      k.ref = a->ref->v;
+      k.blocks = a->d_me;
+      k.n = a->n_cus;
+      k.results = a->d_results;
+      k.sched.use = c->d_me_rot + e % 3;
+      k.sched.record = c->d_me_rot + (e + 1) % 3;
+      k.sched.clear = c->d_me_rot + (e + 2) % 3;
+    }
+    hipLaunchKernelGGL(me_search_multi_kernel, dim3(me2_grid(max_cus, ME2_WAVES(16)).x, n),
+                       dim3(64 * ME2_WAVES(16)), 0, ctx->stream, m, ctx->d_tz_pattern);
+  }
+  // 2. prediction + transform (RDOQ: forward half only, the quantiser follows)
+  {
+    MultiArgs<ReconMultiArgs> m;
+    for (int i = 0; i < n; i++) {
+      const xvcgpu_frame_pass_args *a = args[i];
+      ReconMultiArgs &k = m.a[i];
+      k.orig = a->orig->v;
+      k.ref = a->ref->v;
+      k.rec = rdoq ? a->pred->v : a->scratch_rec->v;
+      k.blocks = a->d_me;
+      k.results = a->d_results;
+      k.n_cus = a->n_cus;
+      k.qp_y = rdoq ? 0 : a->qp_y;
+      k.qp_c = rdoq ? 0 : a->qp_c;
+      k.ref_poc = rdoq ? 0 : a->ref_poc;
+      k.nnz_out = rdoq ? nullptr : a->d_nnz;
+      k.cus = rdoq ? nullptr : a->d_cus_own;
+      k.coeffs = rdoq ? a->d_coeffs : nullptr;
+      k.coeff_off = rdoq ? a->d_level_off : nullptr;
+    }
+    const int n_wg = (2 * max_cus + 3) / 4;
+    const dim3 grid((n_wg + 7) / 8 * 8, n);
+    if (rdoq)
+      hipLaunchKernelGGL(recon_from_me_multi_kernel<true>, grid, dim3(256), 0, ctx->stream, m,
+                         ctx->d_tx_tables, ctx->d_tx_tables_t, lay);
+    else
+      hipLaunchKernelGGL(recon_from_me_multi_kernel<false>, grid, dim3(256), 0, ctx->stream, m,
+                         ctx->d_tx_tables, ctx->d_tx_tables_t, lay);
+  }
+  if (rdoq) {
+    // 3. the quantiser: classification, class lists, the walks
+    MultiArgs<RdoqMultiArgs> q;
+    for (int i = 0; i < n; i++) {
+      const xvcgpu_frame_pass_args *a = args[i];
+      xvcgpu_ctx *c = ctxs[i];
+      const xvcgpu_status st = ensure_rdoq_scratch(c, a->n_tx, a->n_coeffs);
+      if (st != XVCGPU_OK) return st;
+      const int cap = c->rdoq_lists_cap;
+      RdoqMultiArgs &k = q.a[i];
+      k.blocks = a->d_tx;
+      k.n = a->n_tx;
+      k.coeffs = a->d_coeffs;
+      k.d_off = a->d_level_off;
+      k.levels = a->d_levels;
+      k.nnz_out = a->d_nnz;
+      k.l.count = c->d_rdoq_lists;
+      for (int cl = 0; cl < 3; cl++) k.l.list[cl] = c->d_rdoq_lists + 4 + (size_t)cl * cap;
+      k.l.cls = reinterpret_cast<signed char *>(c->d_rdoq_lists + 4 + 3 * (size_t)cap);
+      k.rq_ctx = a->d_rdoq_contexts;
+      k.rq_prm = a->d_rdoq_params;
+    }
+    const int bd = args[0]->rec->bd;
+    hipLaunchKernelGGL(rdoq_classify_multi_kernel, dim3((max_tx + 3) / 4, n), dim3(256), 0,
+                       ctx->stream, q, bd);
+    hipLaunchKernelGGL(rdoq_compact_multi_kernel, dim3(1, n), dim3(1024), 0, ctx->stream, q);
+    const int g16 = std::min((max_tx + 3) / 4, RDOQ_GRID16),
+              g4 = std::min((max_tx + 15) / 16, RDOQ_GRID4), g64 = std::min(max_tx, RDOQ_GRID64);
+    hipLaunchKernelGGL(quant_rdo_packed_multi_kernel, dim3(g16 + g4 + g64, n), dim3(64), 0,
+                       ctx->stream, q, bd, g16, g4);
+    // 4. dequantisation + inverse transform + reconstruction
+    MultiArgs<InvMultiArgs> v;
+    for (int i = 0; i < n; i++) {
+      const xvcgpu_frame_pass_args *a = args[i];
+      InvMultiArgs &k = v.a[i];
+      k.pred = a->pred->v;
+      k.rec = a->scratch_rec->v;
+      k.blocks = a->d_tx;
+      k.n = a->n_tx;
+      k.levels = a->d_levels;
+      k.level_off = a->d_level_off;
+      k.nnz = a->d_nnz;
+    }
+    const int n_wg = (max_tx + TX2_WAVES - 1) / TX2_WAVES;
+    hipLaunchKernelGGL(inv_wave_multi_kernel, dim3((n_wg + 7) / 8 * 8, n), dim3(64 * TX2_WAVES), 0,
+                       ctx->stream, v, ctx->d_tx_tables, ctx->d_tx_tables_t, lay);
+    hipLaunchKernelGGL(inv_general_multi_kernel, dim3((max_tx + TX_THREADS - 1) / TX_THREADS, n),
+                       dim3(TX_THREADS), 0, ctx->stream, v, ctx->d_tx_tables, lay);
+    // 5. the CUs' deblocking records
+    MultiArgs<CuInfoMultiArgs> u;
+    for (int i = 0; i < n; i++) {
+      const xvcgpu_frame_pass_args *a = args[i];
+      CuInfoMultiArgs &k = u.a[i];
+      k.blocks = a->d_me;
+      k.results = a->d_results;
+      k.nnz = a->d_nnz;
+      k.luma_tx_index = a->d_luma_tx_index;
+      k.n = a->n_cus;
+      k.qp_y = a->qp_y;
+      k.qp_c = a->qp_c;
+      k.ref_poc = a->ref_poc;
+      k.cus = a->d_cus_own;
+    }
+    hipLaunchKernelGGL(cu_info_multi_kernel, dim3((max_cus + 255) / 256, n), dim3(256), 0,
+                       ctx->stream, u);
+  }
+  // 6. deblocking, border, SSD parts
+  {
+    MultiArgs<TailMultiArgs> t;
+    int max_tiles = 0;
+    for (int i = 0; i < n; i++) {
+      const xvcgpu_frame_pass_args *a = args[i];
+      xvcgpu_ctx *c = ctxs[i];
+      const int tiles = tail_tiles(a->rec->w, a->rec->h);
+      const xvcgpu_status st = ensure_tail(c, tiles);
+      if (st != XVCGPU_OK) return st;
+      if (a->orig->w != a->rec->w || a->orig->h != a->rec->h || !a->d_ssd || !a->d_cus ||
+          !a->d_cu_map || a->shift_bitdepth < 8)
+        return XVCGPU_INVALID_ARGUMENT;
+      TailMultiArgs &k = t.a[i];
+      k.d.bd = a->rec->bd;
+      k.d.pic_w = a->rec->w;
+      k.d.pic_h = a->rec->h;
+      k.d.bipred = 0;
+      k.d.beta_off = 0;
+      k.d.tc_off = 0;
+      k.d.sub = 4;
+      k.d.y_begin = 0;
+      k.d.y_end = a->rec->h;
+      k.d.cus = a->d_cus;
+      k.d.map = a->d_cu_map;
+      k.d.map_stride = a->map_stride;
+      k.d.map_rows = (a->rec->h + 3) / 4;
+      k.d.comp_mask = 3;
+      k.src = a->scratch_rec->v;
+      k.dst = a->rec->v;
+      k.orig = a->orig->v.c[0];
+      k.shift = 2 * (a->shift_bitdepth - 8);
+      k.tiles = tiles;
+      k.part = c->d_tail_part;
+      k.out = reinterpret_cast<unsigned long long *>(a->d_ssd);
+      max_tiles = std::max(max_tiles, tiles);
+    }
+    hipLaunchKernelGGL(deblock_tail_multi_kernel, dim3(max_tiles, n), dim3(256), 0, ctx->stream, t);
+    hipLaunchKernelGGL(picture_ssd_sum_multi_kernel, dim3(1, n), dim3(256), 0, ctx->stream, t);
+  }
+  (void)one;
+  CHECK_LAUNCH(ctx, "frame_pass_multi");
+  return XVCGPU_OK;
 }
 
 xvcgpu_status xvcgpu_affine_me_batch(xvcgpu_ctx *ctx, const xvcgpu_picture *orig,

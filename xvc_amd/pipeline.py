@@ -160,6 +160,33 @@ class FrameDescriptors:
         self.cu_size = cu
 
 
+def run_multi(passes, origs, refs, recs, ref_pocs=None):
+    """The frame passes of len(passes) independent pictures with every kernel
+    launched once for all of them (xvcgpu_frame_pass_multi).  passes: FramePass
+    objects of one picture size, each on its own Context - the contexts lend their
+    scratch, everything is enqueued on passes[0]'s stream (share_stream() puts the
+    other contexts on it)."""
+    n = len(passes)
+    lead = passes[0].ctx
+    ctxs = (C.c_void_p * n)(*[p.ctx.h for p in passes])
+    argv = (C.POINTER(api.FramePassArgs) * n)()
+    for i, p in enumerate(passes):
+        a = p._args()
+        a.orig, a.ref, a.rec = origs[i].h_pic, refs[i].h_pic, recs[i].h_pic
+        a.ref_poc = ref_pocs[i] if ref_pocs is not None else 0
+        argv[i] = C.pointer(a)
+    lead._check(lead.lib.xvcgpu_frame_pass_multi(
+        ctxs, argv, n, api.FP_ENCODE | api.FP_DEBLOCK_V | api.FP_DEBLOCK_H | api.FP_PAD |
+        api.FP_SSD))
+
+
+def share_stream(passes):
+    """Put the contexts of passes[1:] on passes[0]'s stream (see run_multi)."""
+    stream = passes[0].ctx.stream_ptr()
+    for p in passes[1:]:
+        p.ctx.set_stream(stream)
+
+
 class FramePass:
     """Device-resident state for running frame passes of one picture size
     (or of one CTU-row shard of it)."""
