@@ -751,8 +751,10 @@ def test_deblock_pad_ssd(gpu, xo, bd, bipred):
     api, ctx = gpu
     rng = np.random.default_rng(5600 + bd + bipred)
     total_changed = 0
-    for k, (pw, ph) in enumerate([(64, 64), (136, 72), (320, 200), (352, 288), (8, 8), (72, 200),
-                                  (640, 384)]):
+    sizes = [(64, 64), (136, 72), (320, 200), (352, 288), (8, 8), (72, 200), (640, 384)]
+    if bd == 10 and bipred:
+        sizes.append((1920, 1080))      # BASELINE config 1's picture: 510 tiles, 7 remainder rows
+    for k, (pw, ph) in enumerate(sizes):
         trial = k % 3
         parts = random_partition(rng, pw, ph, 8)
         cus, cmap = make_cus(rng, parts, bipred, [8, 0, 16][:2 + trial % 2], [16, 8], pw, ph)
