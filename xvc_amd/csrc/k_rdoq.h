@@ -611,12 +611,7 @@ __device__ __forceinline__ int wave_rdoq(S &s, int lane, int bd, int w, int h,
       }
       if (zero_sb) {
         any = false;
-        for (int k = 0; k < sb_size; k++) {
-          int x, y;
-          coeff_xy(k, x, y);
-          *lev(x, y) = 0;
-          s.cost_to_zero[y * rw + x] = 0;
-        }
+        s.sb_live[lane] = 2;   // its levels and zero costs are cleared by all lanes below
       }
       s.csbf[lane] = any ? 1 : 0;
       s.csbf_bits[lane] = bits_to_zero;
@@ -624,6 +619,23 @@ __device__ __forceinline__ int wave_rdoq(S &s, int lane, int bd, int w, int h,
       s.sb_zero_dist[lane] = sb_zero_dist;
     }
     wave_sync();
+    // the sub-blocks of this diagonal that were just zeroed: their 16 levels and
+    // zero costs, one coefficient per lane and step (the owner alone took 16
+    // steps of two writes)
+    {
+      const int ax0 = d > rgh - 1 ? d - (rgh - 1) : 0;
+      const int ax1 = d < rgw - 1 ? d : rgw - 1;
+      const int pairs = (ax1 - ax0 + 1) << (2 * sbs);
+      for (int t = lane; t < pairs; t += G) {
+        const int ax = ax0 + (t >> (2 * sbs)), ay = d - ax, k = t & (sb_size - 1);
+        if (s.sb_live[ay * rgw + ax] != 2) continue;
+        const int p = rq_scan_pos(sbs, scan_order, k);
+        const int x = (ax << sbs) + (p & 3), y = (ay << sbs) + (p >> 2);
+        *lev(x, y) = 0;
+        s.cost_to_zero[y * rw + x] = 0;
+      }
+      wave_sync();
+    }
     RQ_STEP(2);
   }
   RQ_STEP_END();
@@ -1088,12 +1100,25 @@ __device__ __forceinline__ void quant_rdo_packed_wave(
   const int16_t *src = coeffs + off;
   int16_t *cf = sm.cf[g], *lv = sm.lv[g];
   RQ_TRACE(1);
-  if (active)
-    for (int i = lane; i < rw * rh; i += G) {
-      const int y = i / rw, x = i - y * rw;
-      cf[i] = src[y * w + x];
-      lv[i] = 0;
+  // blocks that are their own region (no 64-point side), a multiple of 8
+  // coefficients, 16-byte aligned in both arrays: 16-byte copies in and out
+  int16_t *dst = levels + off;
+  const bool wide = w == rw && h == rh && ((w * h) & 7) == 0 &&
+                    ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15) == 0;
+  if (active) {
+    if (wide) {
+      for (int i = lane; i < (w * h) >> 3; i += G) {
+        reinterpret_cast<uint4 *>(cf)[i] = reinterpret_cast<const uint4 *>(src)[i];
+        reinterpret_cast<uint4 *>(lv)[i] = make_uint4(0, 0, 0, 0);
+      }
+    } else {
+      for (int i = lane; i < rw * rh; i += G) {
+        const int y = i / rw, x = i - y * rw;
+        cf[i] = src[y * w + x];
+        lv[i] = 0;
+      }
     }
+  }
   RdoqView v;
   v.cost_to_zero = sm.cost_to_zero[g];
   v.sig_bits = sm.sig_bits[g];
@@ -1121,11 +1146,26 @@ __device__ __forceinline__ void quant_rdo_packed_wave(
     const int cur = __shfl((int)prm.ctx_index, leader, 64);
     wave_sync();  // the previous round's readers are done with the table
     {
-      const unsigned char *cbytes = reinterpret_cast<const unsigned char *>(&rq_ctx[cur]);
-      for (int i = threadIdx.x; i < (int)sizeof(xvcgpu_rdoq_contexts); i += 64) {
-        const unsigned char st8 = cbytes[i] & 127;
-        sm.ctx_bits[2 * i] = kEntropyBits[st8];
-        sm.ctx_bits[2 * i + 1] = kEntropyBits[st8 ^ 1];
+      // two round trips in all: a word of four contexts per lane, then its eight
+      // table entries (byte by byte it was three dependent pairs of trips)
+      static_assert(sizeof(xvcgpu_rdoq_contexts) % 4 == 0 &&
+                        sizeof(xvcgpu_rdoq_contexts) / 4 <= 64,
+                    "one word of contexts per lane");
+      constexpr int kWords = (int)sizeof(xvcgpu_rdoq_contexts) / 4;
+      const uint32_t *cw = reinterpret_cast<const uint32_t *>(&rq_ctx[cur]);
+      const int wi = (int)threadIdx.x < kWords ? (int)threadIdx.x : kWords - 1;
+      const uint32_t word = cw[wi];
+      unsigned e[8];
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const unsigned st8 = (word >> (8 * k)) & 127;
+        e[2 * k] = kEntropyBits[st8];
+        e[2 * k + 1] = kEntropyBits[st8 ^ 1];
+      }
+      if ((int)threadIdx.x < kWords) {
+        uint4 *o = reinterpret_cast<uint4 *>(sm.ctx_bits + 8 * threadIdx.x);
+        o[0] = make_uint4(e[0], e[1], e[2], e[3]);
+        o[1] = make_uint4(e[4], e[5], e[6], e[7]);
       }
     }
     wave_sync();
@@ -1142,10 +1182,14 @@ __device__ __forceinline__ void quant_rdo_packed_wave(
   wave_sync();
   RQ_TRACE(9);
   if (!active) return;
-  int16_t *dst = levels + off;
-  for (int i = lane; i < w * h; i += G) {
-    const int y = i / w, x = i - y * w;
-    dst[i] = (x < rw && y < rh) ? lv[y * rw + x] : (int16_t)0;
+  if (wide) {
+    for (int i = lane; i < (w * h) >> 3; i += G)
+      reinterpret_cast<uint4 *>(dst)[i] = reinterpret_cast<const uint4 *>(lv)[i];
+  } else {
+    for (int i = lane; i < w * h; i += G) {
+      const int y = i / w, x = i - y * w;
+      dst[i] = (x < rw && y < rh) ? lv[y * rw + x] : (int16_t)0;
+    }
   }
   if (lane == 0 && nnz_out) nnz_out[bi] = nnz;
   RQ_TRACE(10);
