@@ -495,7 +495,9 @@ xvcgpu_status xvcgpu_fwd_transform_batch(xvcgpu_ctx *ctx,
 /* Q1 + X2 + R1: Quantize::Inverse -> InverseTransform -> AddClip for levels
  * chosen by the host (decoder reconstruction shares this entry point,
  * cu_decoder.cc:102-138). d_nnz[i] == 0 copies pred; dc-only shortcut applied
- * when d_nnz[i] == 1 and level[0] != 0 (transform_encoder.cc:241). */
+ * when d_nnz[i] == 1 and level[0] != 0 (transform_encoder.cc:241). 
+ * `pred` and `rec` may be the same picture (the prediction was written where
+ * the reconstruction goes): the blocks without levels then cost nothing. */
 xvcgpu_status xvcgpu_inv_transform_batch(xvcgpu_ctx *ctx,
                                          const xvcgpu_picture *pred,
                                          xvcgpu_picture *rec,

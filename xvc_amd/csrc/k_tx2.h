@@ -297,6 +297,12 @@ __device__ __forceinline__ int tx2_job(Tx2Shared &sh, const xvcgpu_tx_block &b, 
   wave_sync();
 
   if (nnz == 0) {  // cbf == 0: rec = pred
+    // in place (the prediction was written into the reconstruction's picture,
+    // xvcgpu_inv_transform_batch with pred == rec): nothing to do - at QP 32 that
+    // is 7 of 8 blocks of a picture
+    if (MODE == TX_MODE_INV && !dist_out &&
+        pred_p == pr.p + (ptrdiff_t)b.y * pr.stride + b.x)
+      return 0;
     for (int i = lane * 4; i < n_el; i += 4 * G) {
       const int y = i >> lw, x = i & (w - 1);
       const U16x4 p = *reinterpret_cast<const U16x4 *>(
@@ -386,6 +392,8 @@ __device__ __forceinline__ void residual_wave_kernel_body(PicView orig, PicView 
   if (wg < 0) return;
   const int bi = __builtin_amdgcn_readfirstlane(wg * TX2_WAVES + (int)(threadIdx.x >> 6));
   if (bi >= n) return;
+  // in place and nothing coded: the block is already what it will be
+  if (MODE == TX_MODE_INV && !dist_out && pred.c[0].p == rec.c[0].p && nnz_out[bi] == 0) return;
   const xvcgpu_tx_block b = blocks[bi];
   if (!tx_small_job(b)) return;  // general path: residual_kernel<>
   const PlaneView pp = pred.c[b.comp];

@@ -1562,11 +1562,15 @@ xvcgpu_status xvcgpu_frame_pass(xvcgpu_ctx *ctx, const xvcgpu_frame_pass_args *a
                                 a->d_me, a->n_cus, a->d_results, a->max_block_size);
     if (st != XVCGPU_OK) return st;
     if (a->d_rdoq_params && a->pred) {
+      bool in_place = false;
       if (a->max_block_size <= 16 && a->n_tx == 3 * a->n_cus) {
         // prediction + forward transform in one kernel (transform blocks in CU
         // order, Y U V each: block 3 * cu + comp)
-        st = xvcgpu_fwd_from_me(ctx, a->orig, a->ref, a->pred, a->d_me, a->d_results, a->n_cus,
+        // (the prediction goes straight into the reconstruction's picture: the
+        // inverse half then works in place and skips the blocks without levels)
+        st = xvcgpu_fwd_from_me(ctx, a->orig, a->ref, rec, a->d_me, a->d_results, a->n_cus,
                                 a->d_coeffs, a->d_level_off);
+        in_place = true;
       } else {
         st = xvcgpu_mc_from_me(ctx, a->ref, a->pred, a->d_me, a->d_results, a->n_cus);
         if (st == XVCGPU_OK)
@@ -1578,8 +1582,8 @@ xvcgpu_status xvcgpu_frame_pass(xvcgpu_ctx *ctx, const xvcgpu_frame_pass_args *a
                                     a->d_level_off, a->n_coeffs, a->d_levels, a->d_nnz,
                                     a->d_rdoq_contexts, a->d_rdoq_params);
       if (st == XVCGPU_OK)
-        st = xvcgpu_inv_transform_batch(ctx, a->pred, rec, a->d_tx, a->n_tx, a->d_levels,
-                                        a->d_level_off, a->d_nnz);
+        st = xvcgpu_inv_transform_batch(ctx, in_place ? rec : a->pred, rec, a->d_tx, a->n_tx,
+                                        a->d_levels, a->d_level_off, a->d_nnz);
       if (st == XVCGPU_OK)
         st = xvcgpu_cu_info_from_me(ctx, a->d_me, a->d_results, a->d_nnz, a->d_luma_tx_index,
                                     a->n_cus, a->qp_y, a->qp_c, a->ref_poc, a->d_cus_own);
@@ -1684,7 +1688,7 @@ xvcgpu_status xvcgpu_frame_pass_multi(xvcgpu_ctx *const *ctxs,
       ReconMultiArgs &k = m.a[i];
       k.orig = a->orig->v;
       k.ref = a->ref->v;
-      k.rec = rdoq ? a->pred->v : a->scratch_rec->v;
+      k.rec = a->scratch_rec->v;   // (RDOQ: the prediction; the inverse half works in place)
       k.blocks = a->d_me;
       k.results = a->d_results;
       k.n_cus = a->n_cus;
@@ -1740,7 +1744,7 @@ xvcgpu_status xvcgpu_frame_pass_multi(xvcgpu_ctx *const *ctxs,
     for (int i = 0; i < n; i++) {
       const xvcgpu_frame_pass_args *a = args[i];
       InvMultiArgs &k = v.a[i];
-      k.pred = a->pred->v;
+      k.pred = a->scratch_rec->v;
       k.rec = a->scratch_rec->v;
       k.blocks = a->d_tx;
       k.n = a->n_tx;

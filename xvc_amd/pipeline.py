@@ -311,9 +311,12 @@ class FramePass:
             ctx.mc_from_me_dev(ref, self.pred, self.d_me.ptr, self.d_res.ptr, n)
         if self.rdoq_packed:
             lib, T = ctx.lib, len(d.tx)
+            # fwd_from_me: the prediction goes into the reconstruction's picture, the
+            # inverse half then works in place (and skips the blocks without levels)
+            pred_pic = rec if front_fused else self.pred
             if front_fused:
                 ctx._check(lib.xvcgpu_fwd_from_me(
-                    ctx.h, orig.h_pic, ref.h_pic, self.pred.h_pic, self.d_me.ptr,
+                    ctx.h, orig.h_pic, ref.h_pic, rec.h_pic, self.d_me.ptr,
                     self.d_res.ptr, n, self.d_coeffs.ptr, self.d_level_off.ptr))
             else:
                 ctx._check(lib.xvcgpu_fwd_transform_batch(
@@ -324,7 +327,7 @@ class FramePass:
                 self.n_levels, self.d_levels.ptr, self.d_nnz.ptr, self.d_rdoq_ctx.ptr,
                 self.d_rdoq_prm.ptr))
             ctx._check(lib.xvcgpu_inv_transform_batch(
-                ctx.h, self.pred.h_pic, rec.h_pic, self.d_tx.ptr, T, self.d_levels.ptr,
+                ctx.h, pred_pic.h_pic, rec.h_pic, self.d_tx.ptr, T, self.d_levels.ptr,
                 self.d_level_off.ptr, self.d_nnz.ptr))
         elif self.rdoq:
             ctx.residual_rdoq_batch_dev(orig, self.pred, rec, self.d_tx.ptr, len(d.tx),
@@ -364,9 +367,12 @@ class FramePass:
             front_fused = self.rdoq_packed and d.cu_size <= 16
             lv = self.d_levels.ptr if self.d_levels else None
             lo = self.d_level_off.ptr if self.d_level_off else None
+            # fwd_from_me writes the prediction into the reconstruction's picture, the
+            # inverse half works in place (as xvcgpu_frame_pass does)
+            pred_pic = rec if front_fused else self.pred
             if front_fused:
                 steps.append(("fwd_from_me", lambda: ctx._check(lib.xvcgpu_fwd_from_me(
-                    ctx.h, orig.h_pic, ref.h_pic, self.pred.h_pic, self.d_me.ptr,
+                    ctx.h, orig.h_pic, ref.h_pic, rec.h_pic, self.d_me.ptr,
                     self.d_res.ptr, n, self.d_coeffs.ptr, lo))))
             else:
                 steps.append(("mc_from_me", lambda: ctx.mc_from_me_dev(
@@ -381,7 +387,7 @@ class FramePass:
                         ctx.h, self.bd, self.d_tx.ptr, T, self.d_coeffs.ptr, lo, self.n_levels,
                         lv, self.d_nnz.ptr, self.d_rdoq_ctx.ptr, self.d_rdoq_prm.ptr))),
                     ("inv_transform", lambda: ctx._check(lib.xvcgpu_inv_transform_batch(
-                        ctx.h, self.pred.h_pic, rec.h_pic, self.d_tx.ptr, T, lv, lo,
+                        ctx.h, pred_pic.h_pic, rec.h_pic, self.d_tx.ptr, T, lv, lo,
                         self.d_nnz.ptr)))]
             elif self.rdoq:
                 steps.append(("residual_rdoq", lambda: ctx.residual_rdoq_batch_dev(
