@@ -435,6 +435,31 @@ xvcgpu_status xvcgpu_quant_rdo_batch(xvcgpu_ctx *ctx, int bitdepth,
                                      const xvcgpu_rdoq_contexts *d_contexts,
                                      const xvcgpu_rdoq_params *d_params);
 
+/* The two calls above with the classification pass of the quantiser (which
+ * blocks hold a coefficient that quantises to a level at all - at QP 32 one in
+ * eight) done by the forward transform, on the coefficients it has at hand:
+ * xvcgpu_fwd_from_me_classify = xvcgpu_fwd_from_me + the blocks' classes into
+ * the context's scratch, zero levels and d_nnz = 0 for the blocks the quantiser
+ * has nothing to do for (their coefficients are not stored);
+ * xvcgpu_quant_rdo_classified_batch = xvcgpu_quant_rdo_batch over the SAME
+ * blocks (3 per CU: Y, U, V, in CU order) without its own pass over all
+ * coefficients.  Nothing else of the context's RDOQ entry points may run in
+ * between.  Same results as the plain pair. */
+xvcgpu_status xvcgpu_fwd_from_me_classify(xvcgpu_ctx *ctx, const xvcgpu_picture *orig,
+                                          const xvcgpu_picture *ref, xvcgpu_picture *pred,
+                                          const xvcgpu_me_block *d_blocks,
+                                          const xvcgpu_me_result *d_results, int n, int qp_y,
+                                          int qp_c, int16_t *d_coeffs,
+                                          const uint32_t *d_coeff_offsets, size_t n_coeffs,
+                                          int16_t *d_levels, int32_t *d_nnz);
+xvcgpu_status xvcgpu_quant_rdo_classified_batch(xvcgpu_ctx *ctx, int bitdepth,
+                                                const xvcgpu_tx_block *d_blocks, int n,
+                                                const int16_t *d_coeffs,
+                                                const uint32_t *d_offsets, size_t n_coeffs,
+                                                int16_t *d_levels, int32_t *d_nnz,
+                                                const xvcgpu_rdoq_contexts *d_contexts,
+                                                const xvcgpu_rdoq_params *d_params);
+
 /* Sizes the context's scratch for batches of up to n blocks / n_coeffs
  * coefficients now, so that later xvcgpu_quant_rdo_batch calls never allocate
  * (required before recording them, xvcgpu_record_begin). */

@@ -146,6 +146,7 @@ SYMBOLS = [
     "xvcgpu_get_transform_matrix", "xvcgpu_inter_pred_batch", "xvcgpu_deblock_tree",
     "xvcgpu_residual_rdoq_batch", "xvcgpu_quant_rdo_batch", "xvcgpu_recon_from_me_rdoq",
     "xvcgpu_quant_rdo_reserve", "xvcgpu_quant_rdo_class_counts",
+    "xvcgpu_fwd_from_me_classify", "xvcgpu_quant_rdo_classified_batch",
     "xvcgpu_event_create", "xvcgpu_event_destroy", "xvcgpu_event_record", "xvcgpu_event_wait",
     "xvcgpu_event_synchronize", "xvcgpu_comm_unique_id", "xvcgpu_comm_create",
     "xvcgpu_comm_destroy", "xvcgpu_comm_world", "xvcgpu_comm_rank", "xvcgpu_comm_wait_event",
@@ -295,6 +296,10 @@ def load_library():
         "xvcgpu_comm_send_bytes": [_vp, _vp, C.c_size_t, C.c_int],
         "xvcgpu_inv_transform_dist_batch": [_vp, _vp, _vp, _vp, _vp, C.c_int, _vp, _vp, _vp, _vp],
         "xvcgpu_fwd_from_me": [_vp, _vp, _vp, _vp, _vp, _vp, C.c_int, _vp, _vp],
+        "xvcgpu_fwd_from_me_classify": [_vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int,
+                                        _vp, _vp, C.c_size_t, _vp, _vp],
+        "xvcgpu_quant_rdo_classified_batch": [_vp, C.c_int, _vp, C.c_int, _vp, _vp, C.c_size_t,
+                                              _vp, _vp, _vp, _vp],
         "xvcgpu_comm_recv_bytes": [_vp, _vp, C.c_size_t, C.c_int],
     }
     lib.xvcgpu_event_destroy.restype = None

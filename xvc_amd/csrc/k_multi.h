@@ -38,7 +38,8 @@ recon_from_me_multi_kernel(MultiArgs<ReconMultiArgs> m, const int16_t *tx_tables
   const ReconMultiArgs &a = m.a[blockIdx.y];
   recon_from_me_kernel_body<false, FWD>(a.orig, a.ref, a.rec, a.blocks, a.results, a.n_cus,
                                         a.qp_y, a.qp_c, 0, a.ref_poc, a.nnz_out, a.cus, tx_tables,
-                                        tx_tables_t, lay, nullptr, nullptr, a.coeffs, a.coeff_off);
+                                        tx_tables_t, lay, nullptr, nullptr, a.coeffs, a.coeff_off,
+                                        FwdClassify());
 }
 
 // the three kernels of xvcgpu_quant_rdo_batch

@@ -178,7 +178,7 @@ __device__ __forceinline__ void wave_interp_block_lds(int bd, int w, int h, int 
 // coefficients to coeffs + coeff_off[3 * cu + comp]: what precedes a quantiser
 // that runs as its own kernel (xvcgpu_quant_rdo_batch).
 template <bool RDOQ, bool FWD>
-__device__ __forceinline__ void recon_from_me_kernel_body(PicView orig, PicView ref, PicView rec, const xvcgpu_me_block *blocks, const xvcgpu_me_result *results, int n_cus, int qp_y, int qp_c, int intra_pic, int ref_poc, int32_t *nnz_out, xvcgpu_cu_info *cus, const int16_t *tx_tables, const int16_t *tx_tables_t, TxTableLayout lay, const xvcgpu_rdoq_contexts *rq_ctx, const xvcgpu_rdoq_params *rq_prm, int16_t *coeffs, const uint32_t *coeff_off) {
+__device__ __forceinline__ void recon_from_me_kernel_body(PicView orig, PicView ref, PicView rec, const xvcgpu_me_block *blocks, const xvcgpu_me_result *results, int n_cus, int qp_y, int qp_c, int intra_pic, int ref_poc, int32_t *nnz_out, xvcgpu_cu_info *cus, const int16_t *tx_tables, const int16_t *tx_tables_t, TxTableLayout lay, const xvcgpu_rdoq_contexts *rq_ctx, const xvcgpu_rdoq_params *rq_prm, int16_t *coeffs, const uint32_t *coeff_off, FwdClassify fc) {
   constexpr int TXM = FWD ? TX_MODE_FWD : TX_MODE_FULL;
   __shared__ ReconShared s_all[4];
   // one scratch per wave; a chroma wave splits it between its two halves
@@ -260,7 +260,8 @@ __device__ __forceinline__ void recon_from_me_kernel_body(PicView orig, PicView 
     tx2_job<TXM, 32, RDOQ>(
         s.tx, tb, 3 * ci + comp, bd, po, s.pred + g * 64, cw, pc, FWD ? coeffs : nullptr,
         FWD ? coeff_off : nullptr, nnz_out, tx_tables, tx_tables_t, lay, &orig_pre, g * 128,
-        reinterpret_cast<RdoqShared<64> *>(rq_wave) + g, rq_ctx, rq_prm);
+        reinterpret_cast<RdoqShared<64> *>(rq_wave) + g, rq_ctx, rq_prm, nullptr,
+        FWD ? &fc : nullptr);
     ME2_TRACE(8);
     return;
   }
@@ -294,7 +295,7 @@ __device__ __forceinline__ void recon_from_me_kernel_body(PicView orig, PicView 
                                          rec.c[0], FWD ? coeffs : nullptr,
                                          FWD ? coeff_off : nullptr, nnz_out,
                                          tx_tables, tx_tables_t, lay, &orig_pre, 0,
-                                         rq_wave, rq_ctx, rq_prm);
+                                         rq_wave, rq_ctx, rq_prm, nullptr, FWD ? &fc : nullptr);
   ME2_TRACE(8);
   if (!FWD && cus && ME2_LANE == 0) {
     xvcgpu_cu_info c;
@@ -322,8 +323,8 @@ __device__ __forceinline__ void recon_from_me_kernel_body(PicView orig, PicView 
 
 template <bool RDOQ = false, bool FWD = false>
 __global__ void __launch_bounds__(256)
-recon_from_me_kernel(PicView orig, PicView ref, PicView rec, const xvcgpu_me_block *blocks, const xvcgpu_me_result *results, int n_cus, int qp_y, int qp_c, int intra_pic, int ref_poc, int32_t *nnz_out, xvcgpu_cu_info *cus, const int16_t *tx_tables, const int16_t *tx_tables_t, TxTableLayout lay, const xvcgpu_rdoq_contexts *rq_ctx = nullptr, const xvcgpu_rdoq_params *rq_prm = nullptr, int16_t *coeffs = nullptr, const uint32_t *coeff_off = nullptr) {
-  recon_from_me_kernel_body<RDOQ, FWD>(orig, ref, rec, blocks, results, n_cus, qp_y, qp_c, intra_pic, ref_poc, nnz_out, cus, tx_tables, tx_tables_t, lay, rq_ctx, rq_prm, coeffs, coeff_off);
+recon_from_me_kernel(PicView orig, PicView ref, PicView rec, const xvcgpu_me_block *blocks, const xvcgpu_me_result *results, int n_cus, int qp_y, int qp_c, int intra_pic, int ref_poc, int32_t *nnz_out, xvcgpu_cu_info *cus, const int16_t *tx_tables, const int16_t *tx_tables_t, TxTableLayout lay, const xvcgpu_rdoq_contexts *rq_ctx = nullptr, const xvcgpu_rdoq_params *rq_prm = nullptr, int16_t *coeffs = nullptr, const uint32_t *coeff_off = nullptr, FwdClassify fc = FwdClassify()) {
+  recon_from_me_kernel_body<RDOQ, FWD>(orig, ref, rec, blocks, results, n_cus, qp_y, qp_c, intra_pic, ref_poc, nnz_out, cus, tx_tables, tx_tables_t, lay, rq_ctx, rq_prm, coeffs, coeff_off, fc);
 }
 
 #endif  // XVCGPU_K_RECON_H_

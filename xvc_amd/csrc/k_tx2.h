@@ -124,6 +124,16 @@ __device__ __forceinline__ int tx2_group_add(int v) {
   return v + __shfl_xor(v, 16, 64);
 }
 
+// Forward-only jobs that feed the RDO quantiser can classify their block on the
+// way (xvcgpu_frame_pass: saves the separate pass over all coefficients): cls =
+// RdoqLists::cls, levels / nnz = the quantiser's outputs (zeros for a block in
+// which nothing quantises to a level).
+struct FwdClassify {
+  signed char *cls;
+  int16_t *levels;
+  int32_t *nnz;
+};
+
 // One TransformAndReconstruct job by one wave.  pred_p / pred_stride address
 // the predicted block (a picture plane in global memory, or an LDS buffer when
 // the caller has just motion-compensated it).
@@ -143,7 +153,8 @@ __device__ __forceinline__ int tx2_job(Tx2Shared &sh, const xvcgpu_tx_block &b, 
                                        RdoqShared<(G == 32 ? 64 : 256)> *rq = nullptr,
                                        const xvcgpu_rdoq_contexts *rq_ctx = nullptr,
                                        const xvcgpu_rdoq_params *rq_prm = nullptr,
-                                       unsigned long long *dist_out = nullptr) {
+                                       unsigned long long *dist_out = nullptr,
+                                       const FwdClassify *fc = nullptr) {
   struct { int16_t *r, *t, *c; } s = {sh.r + soff, sh.t + soff, sh.c + soff};
   // dist_out: SSD between the original residual (orig - pred) and the
   // reconstructed one, >> 2 (bd - 8): SampleMetric::CompareShort on
@@ -212,6 +223,28 @@ __device__ __forceinline__ int tx2_job(Tx2Shared &sh, const xvcgpu_tx_block &b, 
     wave_sync();
     ME2_TRACE(4);
     if (MODE == TX_MODE_FWD) {
+      if (fc && fc->cls) {
+        // the classification pass of the RDO quantiser (rdoq_classify_kernel, k_rdoq.h)
+        // on the coefficients at hand: does any of them quantise to a level at all?
+        const int fq_shift = 14 + qpb / 6 + tshift + (bias ? 7 : 0);
+        const int fq_scale = kFwdQuantScales[qpb % 6] * (bias ? 181 : 1);
+        const long long fq_offset = 1ll << (fq_shift - 1);
+        bool any = false;
+        for (int i = lane; i < n_el; i += G) {
+          const int a = (short)d_abs((int)s.c[i]);
+          any |= (short)(int)((((long long)a * fq_scale) + fq_offset) >> fq_shift) != 0;
+        }
+        const unsigned long long group =
+            G == 64 ? ~0ull : (((1ull << G) - 1) << (ME2_LANE & ~(G - 1)));
+        const bool live = (__ballot(any) & group) != 0;
+        if (lane == 0) fc->cls[bi] = live ? (signed char)rq_class_of(b) : (signed char)-1;
+        if (!live) {   // its levels are zeros; the coefficients are not needed again
+          int16_t *z = fc->levels + level_off[bi];
+          for (int i = lane; i < n_el; i += G) z[i] = 0;
+          if (lane == 0 && fc->nnz) fc->nnz[bi] = 0;
+          return 0;
+        }
+      }
       if (lv)
         for (int i = lane; i < n_el; i += G) {
           const int x = i / h, k2 = i - x * h;  // C[x][k2]

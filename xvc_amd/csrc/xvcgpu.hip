@@ -1007,12 +1007,23 @@ xvcgpu_status xvcgpu_quant_rdo_reserve(xvcgpu_ctx *ctx, int n, size_t n_coeffs) 
   return ensure_rdoq_scratch(ctx, n, n_coeffs);
 }
 
-xvcgpu_status xvcgpu_quant_rdo_batch(xvcgpu_ctx *ctx, int bitdepth,
-                                     const xvcgpu_tx_block *d_blocks, int n,
-                                     const int16_t *d_coeffs, const uint32_t *d_offsets,
-                                     size_t n_coeffs, int16_t *d_levels, int32_t *d_nnz,
-                                     const xvcgpu_rdoq_contexts *d_contexts,
-                                     const xvcgpu_rdoq_params *d_params) {
+static RdoqLists rdoq_lists_of(xvcgpu_ctx *ctx) {
+  const int cap = ctx->rdoq_lists_cap;
+  RdoqLists l;
+  l.count = ctx->d_rdoq_lists;
+  for (int c = 0; c < 3; c++) l.list[c] = ctx->d_rdoq_lists + 4 + (size_t)c * cap;
+  l.cls = reinterpret_cast<signed char *>(ctx->d_rdoq_lists + 4 + 3 * (size_t)cap);
+  return l;
+}
+
+// classified: the blocks' classes are already in the context's RdoqLists::cls
+// (written by the forward transform of xvcgpu_frame_pass, FwdClassify)
+static xvcgpu_status quant_rdo_launch(xvcgpu_ctx *ctx, int bitdepth,
+                                      const xvcgpu_tx_block *d_blocks, int n,
+                                      const int16_t *d_coeffs, const uint32_t *d_offsets,
+                                      size_t n_coeffs, int16_t *d_levels, int32_t *d_nnz,
+                                      const xvcgpu_rdoq_contexts *d_contexts,
+                                      const xvcgpu_rdoq_params *d_params, bool classified) {
   if (!ctx || n < 0 || bitdepth < 8 || bitdepth > 12 ||
       (n && (!d_blocks || !d_coeffs || !d_offsets || !d_levels || !d_contexts || !d_params ||
              !n_coeffs)))
@@ -1022,13 +1033,10 @@ xvcgpu_status xvcgpu_quant_rdo_batch(xvcgpu_ctx *ctx, int bitdepth,
     const xvcgpu_status st_ = ensure_rdoq_scratch(ctx, n, n_coeffs);
     if (st_ != XVCGPU_OK) return st_;
   }
-  const int cap = ctx->rdoq_lists_cap;
-  RdoqLists l;
-  l.count = ctx->d_rdoq_lists;
-  for (int c = 0; c < 3; c++) l.list[c] = ctx->d_rdoq_lists + 4 + (size_t)c * cap;
-  l.cls = reinterpret_cast<signed char *>(ctx->d_rdoq_lists + 4 + 3 * (size_t)cap);
-  hipLaunchKernelGGL(rdoq_classify_kernel, dim3((n + 3) / 4), dim3(256), 0, ctx->stream,
-                     bitdepth, d_blocks, n, d_coeffs, d_offsets, d_levels, d_nnz, l);
+  const RdoqLists l = rdoq_lists_of(ctx);
+  if (!classified)
+    hipLaunchKernelGGL(rdoq_classify_kernel, dim3((n + 3) / 4), dim3(256), 0, ctx->stream,
+                       bitdepth, d_blocks, n, d_coeffs, d_offsets, d_levels, d_nnz, l);
   hipLaunchKernelGGL(rdoq_compact_kernel, dim3(1), dim3(1024), 0, ctx->stream, n, l);
   // the class sizes are only known on the device: a bounded number of workgroups
   // per class that walk their list (k_rdoq.h)
@@ -1038,6 +1046,57 @@ xvcgpu_status xvcgpu_quant_rdo_batch(xvcgpu_ctx *ctx, int bitdepth,
                      bitdepth, d_blocks, l, g16, g4, d_coeffs, d_offsets, d_levels, d_nnz,
                      d_contexts, d_params);
   CHECK_LAUNCH(ctx, "quant_rdo_batch");
+  return XVCGPU_OK;
+}
+
+xvcgpu_status xvcgpu_quant_rdo_batch(xvcgpu_ctx *ctx, int bitdepth,
+                                     const xvcgpu_tx_block *d_blocks, int n,
+                                     const int16_t *d_coeffs, const uint32_t *d_offsets,
+                                     size_t n_coeffs, int16_t *d_levels, int32_t *d_nnz,
+                                     const xvcgpu_rdoq_contexts *d_contexts,
+                                     const xvcgpu_rdoq_params *d_params) {
+  return quant_rdo_launch(ctx, bitdepth, d_blocks, n, d_coeffs, d_offsets, n_coeffs, d_levels,
+                          d_nnz, d_contexts, d_params, false);
+}
+
+xvcgpu_status xvcgpu_quant_rdo_classified_batch(xvcgpu_ctx *ctx, int bitdepth,
+                                                const xvcgpu_tx_block *d_blocks, int n,
+                                                const int16_t *d_coeffs,
+                                                const uint32_t *d_offsets, size_t n_coeffs,
+                                                int16_t *d_levels, int32_t *d_nnz,
+                                                const xvcgpu_rdoq_contexts *d_contexts,
+                                                const xvcgpu_rdoq_params *d_params) {
+  return quant_rdo_launch(ctx, bitdepth, d_blocks, n, d_coeffs, d_offsets, n_coeffs, d_levels,
+                          d_nnz, d_contexts, d_params, true);
+}
+
+xvcgpu_status xvcgpu_fwd_from_me_classify(xvcgpu_ctx *ctx, const xvcgpu_picture *orig,
+                                          const xvcgpu_picture *ref, xvcgpu_picture *pred,
+                                          const xvcgpu_me_block *d_blocks,
+                                          const xvcgpu_me_result *d_results, int n, int qp_y,
+                                          int qp_c, int16_t *d_coeffs,
+                                          const uint32_t *d_coeff_offsets, size_t n_coeffs,
+                                          int16_t *d_levels, int32_t *d_nnz) {
+  if (!ctx || !orig || !ref || !pred || n < 0 ||
+      (n && (!d_blocks || !d_results || !d_coeffs || !d_coeff_offsets || !d_levels || !d_nnz)))
+    return XVCGPU_INVALID_ARGUMENT;
+  if (orig->w != ref->w || orig->h != ref->h || pred->w != ref->w || pred->h != ref->h)
+    return fail(ctx, XVCGPU_INVALID_ARGUMENT, "picture mismatch");
+  if (n == 0) return XVCGPU_OK;
+  {
+    const xvcgpu_status st = ensure_rdoq_scratch(ctx, 3 * n, n_coeffs);
+    if (st != XVCGPU_OK) return st;
+  }
+  FwdClassify fc;
+  fc.cls = rdoq_lists_of(ctx).cls;
+  fc.levels = d_levels;
+  fc.nnz = d_nnz;
+  const int n_wg = (2 * n + 3) / 4;
+  hipLaunchKernelGGL((recon_from_me_kernel<false, true>), dim3((n_wg + 7) / 8 * 8), dim3(256), 0,
+                     ctx->stream, orig->v, ref->v, pred->v, d_blocks, d_results, n, qp_y, qp_c, 0,
+                     0, nullptr, nullptr, ctx->d_tx_tables, ctx->d_tx_tables_t,
+                     xvcgpu_tx_layout(), nullptr, nullptr, d_coeffs, d_coeff_offsets, fc);
+  CHECK_LAUNCH(ctx, "fwd_from_me_classify");
   return XVCGPU_OK;
 }
 
@@ -1562,15 +1621,18 @@ xvcgpu_status xvcgpu_frame_pass(xvcgpu_ctx *ctx, const xvcgpu_frame_pass_args *a
                                 a->d_me, a->n_cus, a->d_results, a->max_block_size);
     if (st != XVCGPU_OK) return st;
     if (a->d_rdoq_params && a->pred) {
-      bool in_place = false;
+      bool in_place = false, classified = false;
       if (a->max_block_size <= 16 && a->n_tx == 3 * a->n_cus) {
         // prediction + forward transform in one kernel (transform blocks in CU
         // order, Y U V each: block 3 * cu + comp)
         // (the prediction goes straight into the reconstruction's picture: the
         // inverse half then works in place and skips the blocks without levels)
-        st = xvcgpu_fwd_from_me(ctx, a->orig, a->ref, rec, a->d_me, a->d_results, a->n_cus,
-                                a->d_coeffs, a->d_level_off);
-        in_place = true;
+        // and it classifies the blocks for the quantiser on the way (the
+        // coefficients are at hand: no separate pass over all of them)
+        st = xvcgpu_fwd_from_me_classify(ctx, a->orig, a->ref, rec, a->d_me, a->d_results,
+                                         a->n_cus, a->qp_y, a->qp_c, a->d_coeffs, a->d_level_off,
+                                         a->n_coeffs, a->d_levels, a->d_nnz);
+        in_place = classified = true;
       } else {
         st = xvcgpu_mc_from_me(ctx, a->ref, a->pred, a->d_me, a->d_results, a->n_cus);
         if (st == XVCGPU_OK)
@@ -1578,9 +1640,14 @@ xvcgpu_status xvcgpu_frame_pass(xvcgpu_ctx *ctx, const xvcgpu_frame_pass_args *a
                                           a->d_level_off);
       }
       if (st == XVCGPU_OK)
-        st = xvcgpu_quant_rdo_batch(ctx, a->rec->bd, a->d_tx, a->n_tx, a->d_coeffs,
-                                    a->d_level_off, a->n_coeffs, a->d_levels, a->d_nnz,
-                                    a->d_rdoq_contexts, a->d_rdoq_params);
+        st = classified
+                 ? xvcgpu_quant_rdo_classified_batch(ctx, a->rec->bd, a->d_tx, a->n_tx,
+                                                     a->d_coeffs, a->d_level_off, a->n_coeffs,
+                                                     a->d_levels, a->d_nnz, a->d_rdoq_contexts,
+                                                     a->d_rdoq_params)
+                 : xvcgpu_quant_rdo_batch(ctx, a->rec->bd, a->d_tx, a->n_tx, a->d_coeffs,
+                                          a->d_level_off, a->n_coeffs, a->d_levels, a->d_nnz,
+                                          a->d_rdoq_contexts, a->d_rdoq_params);
       if (st == XVCGPU_OK)
         st = xvcgpu_inv_transform_batch(ctx, in_place ? rec : a->pred, rec, a->d_tx, a->n_tx,
                                         a->d_levels, a->d_level_off, a->d_nnz);

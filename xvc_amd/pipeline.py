@@ -314,18 +314,21 @@ class FramePass:
             # fwd_from_me: the prediction goes into the reconstruction's picture, the
             # inverse half then works in place (and skips the blocks without levels)
             pred_pic = rec if front_fused else self.pred
-            if front_fused:
-                ctx._check(lib.xvcgpu_fwd_from_me(
+            if front_fused:     # ... which also classifies the blocks for the quantiser
+                ctx._check(lib.xvcgpu_fwd_from_me_classify(
                     ctx.h, orig.h_pic, ref.h_pic, rec.h_pic, self.d_me.ptr,
-                    self.d_res.ptr, n, self.d_coeffs.ptr, self.d_level_off.ptr))
+                    self.d_res.ptr, n, d.qp, d.qp_c, self.d_coeffs.ptr, self.d_level_off.ptr,
+                    C.c_size_t(self.n_levels), self.d_levels.ptr, self.d_nnz.ptr))
             else:
                 ctx._check(lib.xvcgpu_fwd_transform_batch(
                     ctx.h, orig.h_pic, self.pred.h_pic, self.d_tx.ptr, T, self.d_coeffs.ptr,
                     self.d_level_off.ptr))
-            ctx._check(lib.xvcgpu_quant_rdo_batch(
+            quant = lib.xvcgpu_quant_rdo_classified_batch if front_fused else \
+                lib.xvcgpu_quant_rdo_batch
+            ctx._check(quant(
                 ctx.h, self.bd, self.d_tx.ptr, T, self.d_coeffs.ptr, self.d_level_off.ptr,
-                self.n_levels, self.d_levels.ptr, self.d_nnz.ptr, self.d_rdoq_ctx.ptr,
-                self.d_rdoq_prm.ptr))
+                C.c_size_t(self.n_levels), self.d_levels.ptr, self.d_nnz.ptr,
+                self.d_rdoq_ctx.ptr, self.d_rdoq_prm.ptr))
             ctx._check(lib.xvcgpu_inv_transform_batch(
                 ctx.h, pred_pic.h_pic, rec.h_pic, self.d_tx.ptr, T, self.d_levels.ptr,
                 self.d_level_off.ptr, self.d_nnz.ptr))
@@ -371,9 +374,10 @@ class FramePass:
             # inverse half works in place (as xvcgpu_frame_pass does)
             pred_pic = rec if front_fused else self.pred
             if front_fused:
-                steps.append(("fwd_from_me", lambda: ctx._check(lib.xvcgpu_fwd_from_me(
+                steps.append(("fwd_from_me", lambda: ctx._check(lib.xvcgpu_fwd_from_me_classify(
                     ctx.h, orig.h_pic, ref.h_pic, rec.h_pic, self.d_me.ptr,
-                    self.d_res.ptr, n, self.d_coeffs.ptr, lo))))
+                    self.d_res.ptr, n, d.qp, d.qp_c, self.d_coeffs.ptr, lo,
+                    C.c_size_t(self.n_levels), lv, self.d_nnz.ptr))))
             else:
                 steps.append(("mc_from_me", lambda: ctx.mc_from_me_dev(
                     ref, self.pred, self.d_me.ptr, self.d_res.ptr, n)))
@@ -383,9 +387,12 @@ class FramePass:
                         lib.xvcgpu_fwd_transform_batch(ctx.h, orig.h_pic, self.pred.h_pic,
                                                        self.d_tx.ptr, T, self.d_coeffs.ptr, lo))))
                 steps += [
-                    ("quant_rdo", lambda: ctx._check(lib.xvcgpu_quant_rdo_batch(
-                        ctx.h, self.bd, self.d_tx.ptr, T, self.d_coeffs.ptr, lo, self.n_levels,
-                        lv, self.d_nnz.ptr, self.d_rdoq_ctx.ptr, self.d_rdoq_prm.ptr))),
+                    ("quant_rdo", lambda: ctx._check(
+                        (lib.xvcgpu_quant_rdo_classified_batch if front_fused else
+                         lib.xvcgpu_quant_rdo_batch)(
+                            ctx.h, self.bd, self.d_tx.ptr, T, self.d_coeffs.ptr, lo,
+                            C.c_size_t(self.n_levels), lv, self.d_nnz.ptr, self.d_rdoq_ctx.ptr,
+                            self.d_rdoq_prm.ptr))),
                     ("inv_transform", lambda: ctx._check(lib.xvcgpu_inv_transform_batch(
                         ctx.h, pred_pic.h_pic, rec.h_pic, self.d_tx.ptr, T, lv, lo,
                         self.d_nnz.ptr)))]
