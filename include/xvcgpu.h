@@ -444,21 +444,26 @@ xvcgpu_status xvcgpu_quant_rdo_batch(xvcgpu_ctx *ctx, int bitdepth,
  * xvcgpu_quant_rdo_classified_batch = xvcgpu_quant_rdo_batch over the SAME
  * blocks (3 per CU: Y, U, V, in CU order) without its own pass over all
  * coefficients.  Nothing else of the context's RDOQ entry points may run in
- * between.  Same results as the plain pair. */
+ * between.  Same results as the plain pair.  d_cus (optional, both calls): the
+ * CUs' deblocking records (xvcgpu_cu_info_from_me) written on the way - the
+ * forward call writes them with cbf_luma = 0, the quantiser sets the flag of
+ * the CUs whose luma block keeps a level. */
 xvcgpu_status xvcgpu_fwd_from_me_classify(xvcgpu_ctx *ctx, const xvcgpu_picture *orig,
                                           const xvcgpu_picture *ref, xvcgpu_picture *pred,
                                           const xvcgpu_me_block *d_blocks,
                                           const xvcgpu_me_result *d_results, int n, int qp_y,
-                                          int qp_c, int16_t *d_coeffs,
+                                          int qp_c, int ref_poc, int16_t *d_coeffs,
                                           const uint32_t *d_coeff_offsets, size_t n_coeffs,
-                                          int16_t *d_levels, int32_t *d_nnz);
+                                          int16_t *d_levels, int32_t *d_nnz,
+                                          xvcgpu_cu_info *d_cus);
 xvcgpu_status xvcgpu_quant_rdo_classified_batch(xvcgpu_ctx *ctx, int bitdepth,
                                                 const xvcgpu_tx_block *d_blocks, int n,
                                                 const int16_t *d_coeffs,
                                                 const uint32_t *d_offsets, size_t n_coeffs,
                                                 int16_t *d_levels, int32_t *d_nnz,
                                                 const xvcgpu_rdoq_contexts *d_contexts,
-                                                const xvcgpu_rdoq_params *d_params);
+                                                const xvcgpu_rdoq_params *d_params,
+                                                xvcgpu_cu_info *d_cus);
 
 /* Sizes the context's scratch for batches of up to n blocks / n_coeffs
  * coefficients now, so that later xvcgpu_quant_rdo_batch calls never allocate

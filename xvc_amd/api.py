@@ -297,9 +297,9 @@ def load_library():
         "xvcgpu_inv_transform_dist_batch": [_vp, _vp, _vp, _vp, _vp, C.c_int, _vp, _vp, _vp, _vp],
         "xvcgpu_fwd_from_me": [_vp, _vp, _vp, _vp, _vp, _vp, C.c_int, _vp, _vp],
         "xvcgpu_fwd_from_me_classify": [_vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int,
-                                        _vp, _vp, C.c_size_t, _vp, _vp],
+                                        C.c_int, _vp, _vp, C.c_size_t, _vp, _vp, _vp],
         "xvcgpu_quant_rdo_classified_batch": [_vp, C.c_int, _vp, C.c_int, _vp, _vp, C.c_size_t,
-                                              _vp, _vp, _vp, _vp],
+                                              _vp, _vp, _vp, _vp, _vp],
         "xvcgpu_comm_recv_bytes": [_vp, _vp, C.c_size_t, C.c_int],
     }
     lib.xvcgpu_event_destroy.restype = None

@@ -68,7 +68,7 @@ __global__ void __launch_bounds__(64)
 quant_rdo_packed_multi_kernel(MultiArgs<RdoqMultiArgs> m, int bd, int g16, int g4) {
   const RdoqMultiArgs &a = m.a[blockIdx.y];
   quant_rdo_packed_kernel_body(bd, a.blocks, a.l, g16, g4, a.coeffs, a.d_off, a.levels, a.nnz_out,
-                               a.rq_ctx, a.rq_prm);
+                               a.rq_ctx, a.rq_prm, nullptr);
 }
 
 // xvcgpu_inv_transform_batch (TX_MODE_INV): blocks up to 16x16 by the wave

@@ -1083,7 +1083,8 @@ template <int G>
 __device__ __forceinline__ void quant_rdo_packed_wave(
     RdoqPackedLds<G> &sm, int wave, int bd, const xvcgpu_tx_block *blocks, const int *list,
     const int *count, const int16_t *coeffs, const uint32_t *d_off, int16_t *levels,
-    int32_t *nnz_out, const xvcgpu_rdoq_contexts *rq_ctx, const xvcgpu_rdoq_params *rq_prm) {
+    int32_t *nnz_out, const xvcgpu_rdoq_contexts *rq_ctx, const xvcgpu_rdoq_params *rq_prm,
+    xvcgpu_cu_info *cu_patch = nullptr) {
   constexpr int GROUPS = 64 / G;
   const int g = threadIdx.x / G, lane = threadIdx.x % G;
   const int slot = wave * GROUPS + g;
@@ -1192,6 +1193,8 @@ __device__ __forceinline__ void quant_rdo_packed_wave(
     }
   }
   if (lane == 0 && nnz_out) nnz_out[bi] = nnz;
+  // blocks 3 * cu + comp (xvcgpu_fwd_from_me_classify wrote the CU's record with cbf_luma = 0)
+  if (lane == 0 && cu_patch && b.comp == 0 && nnz) cu_patch[bi / 3].cbf_luma = 1;
   RQ_TRACE(10);
 }
 
@@ -1207,7 +1210,7 @@ __device__ __forceinline__ void quant_rdo_packed_wave(
 // that churn: each class gets a bounded number of workgroups instead, which walk
 // their list with that stride - more than the live blocks of a picture need, so
 // a long walk still delays nobody.  grid: g16 + g4 + g64; block: 64.
-__device__ __forceinline__ void quant_rdo_packed_kernel_body(int bd, const xvcgpu_tx_block *blocks, RdoqLists l, int g16, int g4, const int16_t *coeffs, const uint32_t *d_off, int16_t *levels, int32_t *nnz_out, const xvcgpu_rdoq_contexts *rq_ctx, const xvcgpu_rdoq_params *rq_prm) {
+__device__ __forceinline__ void quant_rdo_packed_kernel_body(int bd, const xvcgpu_tx_block *blocks, RdoqLists l, int g16, int g4, const int16_t *coeffs, const uint32_t *d_off, int16_t *levels, int32_t *nnz_out, const xvcgpu_rdoq_contexts *rq_ctx, const xvcgpu_rdoq_params *rq_prm, xvcgpu_cu_info *cu_patch) {
   union Lds {
     RdoqPackedLds<16> a;
     RdoqPackedLds<4> b;
@@ -1219,29 +1222,29 @@ __device__ __forceinline__ void quant_rdo_packed_kernel_body(int bd, const xvcgp
     const int waves = (l.count[1] + 3) >> 2;
     for (int wv = wg; wv < waves; wv += g16) {
       quant_rdo_packed_wave<16>(sm.a, wv, bd, blocks, l.list[1], l.count + 1, coeffs, d_off,
-                                levels, nnz_out, rq_ctx, rq_prm);
+                                levels, nnz_out, rq_ctx, rq_prm, cu_patch);
       wave_sync();
     }
   } else if (wg < g16 + g4) {
     const int waves = (l.count[0] + 15) >> 4;
     for (int wv = wg - g16; wv < waves; wv += g4) {
       quant_rdo_packed_wave<4>(sm.b, wv, bd, blocks, l.list[0], l.count + 0, coeffs, d_off,
-                               levels, nnz_out, rq_ctx, rq_prm);
+                               levels, nnz_out, rq_ctx, rq_prm, cu_patch);
       wave_sync();
     }
   } else {
     const int waves = l.count[2];
     for (int wv = wg - g16 - g4; wv < waves; wv += g64) {
       quant_rdo_packed_wave<64>(sm.c, wv, bd, blocks, l.list[2], l.count + 2, coeffs, d_off,
-                                levels, nnz_out, rq_ctx, rq_prm);
+                                levels, nnz_out, rq_ctx, rq_prm, cu_patch);
       wave_sync();
     }
   }
 }
 
 __global__ void __launch_bounds__(64)
-quant_rdo_packed_kernel(int bd, const xvcgpu_tx_block *blocks, RdoqLists l, int g16, int g4, const int16_t *coeffs, const uint32_t *d_off, int16_t *levels, int32_t *nnz_out, const xvcgpu_rdoq_contexts *rq_ctx, const xvcgpu_rdoq_params *rq_prm) {
-  quant_rdo_packed_kernel_body(bd, blocks, l, g16, g4, coeffs, d_off, levels, nnz_out, rq_ctx, rq_prm);
+quant_rdo_packed_kernel(int bd, const xvcgpu_tx_block *blocks, RdoqLists l, int g16, int g4, const int16_t *coeffs, const uint32_t *d_off, int16_t *levels, int32_t *nnz_out, const xvcgpu_rdoq_contexts *rq_ctx, const xvcgpu_rdoq_params *rq_prm, xvcgpu_cu_info *cu_patch = nullptr) {
+  quant_rdo_packed_kernel_body(bd, blocks, l, g16, g4, coeffs, d_off, levels, nnz_out, rq_ctx, rq_prm, cu_patch);
 }
 
 #endif  // XVCGPU_K_RDOQ_H_

@@ -297,14 +297,16 @@ __device__ __forceinline__ void recon_from_me_kernel_body(PicView orig, PicView 
                                          tx_tables, tx_tables_t, lay, &orig_pre, 0,
                                          rq_wave, rq_ctx, rq_prm, nullptr, FWD ? &fc : nullptr);
   ME2_TRACE(8);
-  if (!FWD && cus && ME2_LANE == 0) {
+  // (FWD: the record with cbf_luma = 0; the quantiser's walk sets the flag of the
+  // blocks it codes a level for, quant_rdo_packed_wave's cu_patch)
+  if (cus && ME2_LANE == 0) {
     xvcgpu_cu_info c;
     c.x = (uint16_t)mb.x;
     c.y = (uint16_t)mb.y;
     c.w = mb.w;
     c.h = mb.h;
     c.intra = 0;
-    c.cbf_luma = nnz != 0;
+    c.cbf_luma = !FWD && nnz != 0;
     c.qp_y = (int8_t)qp_y;
     c.qp_c = (int8_t)qp_c;
     c.ref_idx0 = 0;

@@ -1023,7 +1023,8 @@ static xvcgpu_status quant_rdo_launch(xvcgpu_ctx *ctx, int bitdepth,
                                       const int16_t *d_coeffs, const uint32_t *d_offsets,
                                       size_t n_coeffs, int16_t *d_levels, int32_t *d_nnz,
                                       const xvcgpu_rdoq_contexts *d_contexts,
-                                      const xvcgpu_rdoq_params *d_params, bool classified) {
+                                      const xvcgpu_rdoq_params *d_params, bool classified,
+                                      xvcgpu_cu_info *d_cu_patch = nullptr) {
   if (!ctx || n < 0 || bitdepth < 8 || bitdepth > 12 ||
       (n && (!d_blocks || !d_coeffs || !d_offsets || !d_levels || !d_contexts || !d_params ||
              !n_coeffs)))
@@ -1044,7 +1045,7 @@ static xvcgpu_status quant_rdo_launch(xvcgpu_ctx *ctx, int bitdepth,
             g64 = std::min(n, RDOQ_GRID64);
   hipLaunchKernelGGL(quant_rdo_packed_kernel, dim3(g16 + g4 + g64), dim3(64), 0, ctx->stream,
                      bitdepth, d_blocks, l, g16, g4, d_coeffs, d_offsets, d_levels, d_nnz,
-                     d_contexts, d_params);
+                     d_contexts, d_params, d_cu_patch);
   CHECK_LAUNCH(ctx, "quant_rdo_batch");
   return XVCGPU_OK;
 }
@@ -1065,18 +1066,20 @@ xvcgpu_status xvcgpu_quant_rdo_classified_batch(xvcgpu_ctx *ctx, int bitdepth,
                                                 const uint32_t *d_offsets, size_t n_coeffs,
                                                 int16_t *d_levels, int32_t *d_nnz,
                                                 const xvcgpu_rdoq_contexts *d_contexts,
-                                                const xvcgpu_rdoq_params *d_params) {
+                                                const xvcgpu_rdoq_params *d_params,
+                                                xvcgpu_cu_info *d_cus) {
   return quant_rdo_launch(ctx, bitdepth, d_blocks, n, d_coeffs, d_offsets, n_coeffs, d_levels,
-                          d_nnz, d_contexts, d_params, true);
+                          d_nnz, d_contexts, d_params, true, d_cus);
 }
 
 xvcgpu_status xvcgpu_fwd_from_me_classify(xvcgpu_ctx *ctx, const xvcgpu_picture *orig,
                                           const xvcgpu_picture *ref, xvcgpu_picture *pred,
                                           const xvcgpu_me_block *d_blocks,
                                           const xvcgpu_me_result *d_results, int n, int qp_y,
-                                          int qp_c, int16_t *d_coeffs,
+                                          int qp_c, int ref_poc, int16_t *d_coeffs,
                                           const uint32_t *d_coeff_offsets, size_t n_coeffs,
-                                          int16_t *d_levels, int32_t *d_nnz) {
+                                          int16_t *d_levels, int32_t *d_nnz,
+                                          xvcgpu_cu_info *d_cus) {
   if (!ctx || !orig || !ref || !pred || n < 0 ||
       (n && (!d_blocks || !d_results || !d_coeffs || !d_coeff_offsets || !d_levels || !d_nnz)))
     return XVCGPU_INVALID_ARGUMENT;
@@ -1094,7 +1097,7 @@ xvcgpu_status xvcgpu_fwd_from_me_classify(xvcgpu_ctx *ctx, const xvcgpu_picture 
   const int n_wg = (2 * n + 3) / 4;
   hipLaunchKernelGGL((recon_from_me_kernel<false, true>), dim3((n_wg + 7) / 8 * 8), dim3(256), 0,
                      ctx->stream, orig->v, ref->v, pred->v, d_blocks, d_results, n, qp_y, qp_c, 0,
-                     0, nullptr, nullptr, ctx->d_tx_tables, ctx->d_tx_tables_t,
+                     ref_poc, nullptr, d_cus, ctx->d_tx_tables, ctx->d_tx_tables_t,
                      xvcgpu_tx_layout(), nullptr, nullptr, d_coeffs, d_coeff_offsets, fc);
   CHECK_LAUNCH(ctx, "fwd_from_me_classify");
   return XVCGPU_OK;
@@ -1630,8 +1633,9 @@ xvcgpu_status xvcgpu_frame_pass(xvcgpu_ctx *ctx, const xvcgpu_frame_pass_args *a
         // and it classifies the blocks for the quantiser on the way (the
         // coefficients are at hand: no separate pass over all of them)
         st = xvcgpu_fwd_from_me_classify(ctx, a->orig, a->ref, rec, a->d_me, a->d_results,
-                                         a->n_cus, a->qp_y, a->qp_c, a->d_coeffs, a->d_level_off,
-                                         a->n_coeffs, a->d_levels, a->d_nnz);
+                                         a->n_cus, a->qp_y, a->qp_c, a->ref_poc, a->d_coeffs,
+                                         a->d_level_off, a->n_coeffs, a->d_levels, a->d_nnz,
+                                         a->d_cus_own);
         in_place = classified = true;
       } else {
         st = xvcgpu_mc_from_me(ctx, a->ref, a->pred, a->d_me, a->d_results, a->n_cus);
@@ -1644,14 +1648,14 @@ xvcgpu_status xvcgpu_frame_pass(xvcgpu_ctx *ctx, const xvcgpu_frame_pass_args *a
                  ? xvcgpu_quant_rdo_classified_batch(ctx, a->rec->bd, a->d_tx, a->n_tx,
                                                      a->d_coeffs, a->d_level_off, a->n_coeffs,
                                                      a->d_levels, a->d_nnz, a->d_rdoq_contexts,
-                                                     a->d_rdoq_params)
+                                                     a->d_rdoq_params, a->d_cus_own)
                  : xvcgpu_quant_rdo_batch(ctx, a->rec->bd, a->d_tx, a->n_tx, a->d_coeffs,
                                           a->d_level_off, a->n_coeffs, a->d_levels, a->d_nnz,
                                           a->d_rdoq_contexts, a->d_rdoq_params);
       if (st == XVCGPU_OK)
         st = xvcgpu_inv_transform_batch(ctx, in_place ? rec : a->pred, rec, a->d_tx, a->n_tx,
                                         a->d_levels, a->d_level_off, a->d_nnz);
-      if (st == XVCGPU_OK)
+      if (st == XVCGPU_OK && !(classified && a->d_cus_own))   // (else written on the way)
         st = xvcgpu_cu_info_from_me(ctx, a->d_me, a->d_results, a->d_nnz, a->d_luma_tx_index,
                                     a->n_cus, a->qp_y, a->qp_c, a->ref_poc, a->d_cus_own);
     } else if (a->d_rdoq_params)

@@ -317,8 +317,9 @@ class FramePass:
             if front_fused:     # ... which also classifies the blocks for the quantiser
                 ctx._check(lib.xvcgpu_fwd_from_me_classify(
                     ctx.h, orig.h_pic, ref.h_pic, rec.h_pic, self.d_me.ptr,
-                    self.d_res.ptr, n, d.qp, d.qp_c, self.d_coeffs.ptr, self.d_level_off.ptr,
-                    C.c_size_t(self.n_levels), self.d_levels.ptr, self.d_nnz.ptr))
+                    self.d_res.ptr, n, d.qp, d.qp_c, ref_poc, self.d_coeffs.ptr,
+                    self.d_level_off.ptr, C.c_size_t(self.n_levels), self.d_levels.ptr,
+                    self.d_nnz.ptr, self.d_cus_own))
             else:
                 ctx._check(lib.xvcgpu_fwd_transform_batch(
                     ctx.h, orig.h_pic, self.pred.h_pic, self.d_tx.ptr, T, self.d_coeffs.ptr,
@@ -328,7 +329,8 @@ class FramePass:
             ctx._check(quant(
                 ctx.h, self.bd, self.d_tx.ptr, T, self.d_coeffs.ptr, self.d_level_off.ptr,
                 C.c_size_t(self.n_levels), self.d_levels.ptr, self.d_nnz.ptr,
-                self.d_rdoq_ctx.ptr, self.d_rdoq_prm.ptr))
+                self.d_rdoq_ctx.ptr, self.d_rdoq_prm.ptr,
+                *([self.d_cus_own] if front_fused else [])))
             ctx._check(lib.xvcgpu_inv_transform_batch(
                 ctx.h, pred_pic.h_pic, rec.h_pic, self.d_tx.ptr, T, self.d_levels.ptr,
                 self.d_level_off.ptr, self.d_nnz.ptr))
@@ -342,9 +344,10 @@ class FramePass:
                                    self.d_levels.ptr if self.d_levels else None,
                                    self.d_level_off.ptr if self.d_level_off else None,
                                    self.d_nnz.ptr)
-        ctx.cu_info_from_me_dev(self.d_me.ptr, self.d_res.ptr, self.d_nnz.ptr,
-                                self.d_luma_idx.ptr, n, d.qp, d.qp_c, ref_poc,
-                                self.d_cus_own)
+        if not front_fused:      # (front_fused: the records were written on the way)
+            ctx.cu_info_from_me_dev(self.d_me.ptr, self.d_res.ptr, self.d_nnz.ptr,
+                                    self.d_luma_idx.ptr, n, d.qp, d.qp_c, ref_poc,
+                                    self.d_cus_own)
 
     def kernel_steps(self, orig, ref, rec, ref_poc=0):
         """The launches of one frame pass as (name, callable) in issue order - for
@@ -376,8 +379,8 @@ class FramePass:
             if front_fused:
                 steps.append(("fwd_from_me", lambda: ctx._check(lib.xvcgpu_fwd_from_me_classify(
                     ctx.h, orig.h_pic, ref.h_pic, rec.h_pic, self.d_me.ptr,
-                    self.d_res.ptr, n, d.qp, d.qp_c, self.d_coeffs.ptr, lo,
-                    C.c_size_t(self.n_levels), lv, self.d_nnz.ptr))))
+                    self.d_res.ptr, n, d.qp, d.qp_c, ref_poc, self.d_coeffs.ptr, lo,
+                    C.c_size_t(self.n_levels), lv, self.d_nnz.ptr, self.d_cus_own))))
             else:
                 steps.append(("mc_from_me", lambda: ctx.mc_from_me_dev(
                     ref, self.pred, self.d_me.ptr, self.d_res.ptr, n)))
@@ -392,7 +395,7 @@ class FramePass:
                          lib.xvcgpu_quant_rdo_batch)(
                             ctx.h, self.bd, self.d_tx.ptr, T, self.d_coeffs.ptr, lo,
                             C.c_size_t(self.n_levels), lv, self.d_nnz.ptr, self.d_rdoq_ctx.ptr,
-                            self.d_rdoq_prm.ptr))),
+                            self.d_rdoq_prm.ptr, *([self.d_cus_own] if front_fused else [])))),
                     ("inv_transform", lambda: ctx._check(lib.xvcgpu_inv_transform_batch(
                         ctx.h, pred_pic.h_pic, rec.h_pic, self.d_tx.ptr, T, lv, lo,
                         self.d_nnz.ptr)))]
@@ -403,9 +406,10 @@ class FramePass:
             else:
                 steps.append(("residual", lambda: ctx.residual_batch_dev(
                     orig, self.pred, rec, self.d_tx.ptr, T, lv, lo, self.d_nnz.ptr)))
-            steps.append(("cu_info", lambda: ctx.cu_info_from_me_dev(
-                self.d_me.ptr, self.d_res.ptr, self.d_nnz.ptr, self.d_luma_idx.ptr, n, d.qp,
-                d.qp_c, ref_poc, self.d_cus_own)))
+            if not front_fused:
+                steps.append(("cu_info", lambda: ctx.cu_info_from_me_dev(
+                    self.d_me.ptr, self.d_res.ptr, self.d_nnz.ptr, self.d_luma_idx.ptr, n, d.qp,
+                    d.qp_c, ref_poc, self.d_cus_own)))
         if self.scratch is not None:
             steps.append(("deblock_pad_ssd", lambda: ctx.deblock_pad_ssd_dev(
                 rec, final, orig, self.d_cus.ptr, d.n_cus_total, self.d_map.ptr,
