@@ -114,12 +114,15 @@ template <int MODE>
 void launch_residual(xvcgpu_ctx *ctx, const PicView &o, const PicView &p,
                             const PicView &r, const xvcgpu_tx_block *d_blocks, int n,
                             int16_t *d_levels, const uint32_t *d_off, int32_t *d_nnz,
-                            unsigned long long *d_dist = nullptr) {
+                            unsigned long long *d_dist = nullptr, bool small_only = false) {
   const int n_wg = (n + TX2_WAVES - 1) / TX2_WAVES;
   hipLaunchKernelGGL(residual_wave_kernel<MODE>, dim3((n_wg + 7) / 8 * 8),
                      dim3(64 * TX2_WAVES), 0, ctx->stream, o, p, r, d_blocks, n,
                      d_levels, d_off, d_nnz, ctx->d_tx_tables, ctx->d_tx_tables_t,
                      xvcgpu_tx_layout(), nullptr, nullptr, d_dist);
+  // (the caller knows that every block is at most 16x16: the general-path kernel
+  // would find nothing to do - and still be a launch on the picture's critical path)
+  if (small_only) return;
   // general path: small batches (a decoder's dependency waves) one workgroup per
   // block; picture-sized batches (mostly small blocks) the scanning form
   if (n <= 2048)
@@ -1652,9 +1655,17 @@ xvcgpu_status xvcgpu_frame_pass(xvcgpu_ctx *ctx, const xvcgpu_frame_pass_args *a
                  : xvcgpu_quant_rdo_batch(ctx, a->rec->bd, a->d_tx, a->n_tx, a->d_coeffs,
                                           a->d_level_off, a->n_coeffs, a->d_levels, a->d_nnz,
                                           a->d_rdoq_contexts, a->d_rdoq_params);
-      if (st == XVCGPU_OK)
-        st = xvcgpu_inv_transform_batch(ctx, in_place ? rec : a->pred, rec, a->d_tx, a->n_tx,
-                                        a->d_levels, a->d_level_off, a->d_nnz);
+      if (st == XVCGPU_OK) {
+        if (!a->d_tx || !a->d_levels || !a->d_level_off || !a->d_nnz) {
+          st = XVCGPU_INVALID_ARGUMENT;
+        } else if (a->n_tx > 0) {
+          const PicView &pv = in_place ? rec->v : a->pred->v;
+          launch_residual<TX_MODE_INV>(ctx, pv, pv, rec->v, a->d_tx, a->n_tx, a->d_levels,
+                                       a->d_level_off, a->d_nnz, nullptr,
+                                       /*small_only=*/in_place);
+          CHECK_LAUNCH(ctx, "inv_transform_batch");
+        }
+      }
       if (st == XVCGPU_OK && !(classified && a->d_cus_own))   // (else written on the way)
         st = xvcgpu_cu_info_from_me(ctx, a->d_me, a->d_results, a->d_nnz, a->d_luma_tx_index,
                                     a->n_cus, a->qp_y, a->qp_c, a->ref_poc, a->d_cus_own);
