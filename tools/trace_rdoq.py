@@ -15,13 +15,21 @@ pad = lambda planes: [np.ascontiguousarray(np.pad(p, border if c == 0 else borde
 O, R, Rec = (ctx.picture(W, H, bd) for _ in range(3))
 R.upload(pad(clip.frame(0)), border); O.upload(pad(clip.frame(1)), border)
 fp = pipeline.FramePass(ctx, W, H, bd, qp=32, rdoq=True)
+# CHAIN=n: the state of a chain after n pictures (the bench's steady state is
+# reached after a few hundred: tools/chain_drift.py); default: a chain's first pictures
+chain = int(os.environ.get("CHAIN", "0"))
+for j in range(chain):
+    k = j % 14
+    O.upload(pad(clip.frame(k if k < 8 else 14 - k)), border)
+    fp.run(O, R, Rec)
+    R, Rec = Rec, R
 for _ in range(3):
     fp.run(O, R, Rec)
 ctx.sync()
 lib = api.load_library()
 counts = (C.c_int32 * 3)()
 lib.xvcgpu_quant_rdo_class_counts(ctx.h, counts)
-rows = (counts[1] + 3) // 4
+rows = min(2048, (counts[1] + 3) // 4)
 buf = np.zeros((4096, 16), np.uint64)
 lib.xvcgpu_debug_rdoq_trace(buf.ctypes.data_as(C.c_void_p), 4096)
 steps = buf[:rows, 11:15].astype(np.int64)
