@@ -102,14 +102,18 @@ __device__ unsigned long long g_rq_trace[4096][16];
 template <int N>
 struct RdoqShared {
   long long cost_to_zero[N];   // coeff_cost_to_zero_
-  unsigned sig_bits[N];        // coeff_sig_bits_
-  int sig_rate[N];
+  // coeff_sig_bits_ / the sig-flag rate as what they are made of: the index (in
+  // contexts, not table entries) of the coefficient's significance context - the
+  // two bin costs are ctx_bits[2 * i], [2 * i + 1] -, 1 byte instead of 8: with
+  // the records in LDS their size is what limits the waves per CU
+  unsigned char sig_ci[N];
   int rate_up[N];              // level 0: the rate; else the decision-time state (RQ_STATE_PACK)
   short err_dist[N];
   long long sb_code_cost[64], sb_zero_dist[64];
   unsigned csbf_bits[64];      // csbf_bits_to_zero
   unsigned char csbf[64];
   unsigned char sb_live[64];   // the walk reaches the sub-block
+  unsigned char sb_dcz[64];    // its k = 0 coefficient was decided with sig1 = 0 (rdo_quant.cc:343)
   unsigned char sb_of_scan[256];  // sub-block scan index -> sy * gw + sx
   unsigned lp_bits[32];        // EvalLastPos: last-position bits by group of x [0..15], of y [16..31]
   // GetEntropyBits(bin) of every context of the snapshot: [2 * i + bin] for the
@@ -124,12 +128,12 @@ struct RdoqShared {
 // global memory, the rest in LDS).
 struct RdoqView {
   long long *cost_to_zero;
-  unsigned *sig_bits;
-  int *sig_rate, *rate_up;
+  unsigned char *sig_ci;
+  int *rate_up;
   short *err_dist;
   long long *sb_code_cost, *sb_zero_dist;
   unsigned *csbf_bits;
-  unsigned char *csbf, *sb_live;
+  unsigned char *csbf, *sb_live, *sb_dcz;
   unsigned char *sb_of_scan;
   unsigned *lp_bits;
   unsigned *ctx_bits;
@@ -423,8 +427,24 @@ __device__ __forceinline__ int wave_rdoq(S &s, int lane, int bd, int w, int h,
     s.sb_of_scan[d_sb_scan_index(scan_order, gw, gh, t % gw, t / gw)] = (unsigned char)t;
   // a sub-block is "live" when the walk reaches it at or before the last position
   const bool live = mine && sb_index <= last_pos_index;
+  // the two costs of a coefficient's significance flag as the decision used them
+  // (sig1 = 0 for the last position and for the k = 0 coefficient of a sub-block
+  // that was empty up to it, rdo_quant.cc:343), and its rate sig1 - sig0 (0 at and
+  // beyond the last position: :303-307)
+  auto sig_pair = [&](int pos, int index, int k, bool dcz, unsigned &sig0, unsigned &sig1) {
+    const uint2 b2 = *reinterpret_cast<const uint2 *>(cb + 2 * (int)s.sig_ci[pos]);
+    sig0 = b2.x;
+    sig1 = (index == last_pos_index || (k == 0 && dcz)) ? 0u : b2.y;
+  };
+  auto sig_rate_of = [&](int pos, int index, int k, bool dcz) {
+    if (index >= last_pos_index) return 0;
+    unsigned sig0, sig1;
+    sig_pair(pos, index, k, dcz, sig0, sig1);
+    return (int)(sig1 - sig0);
+  };
   if (mine) {
     s.csbf[lane] = 0;
+    s.sb_dcz[lane] = 0;
     s.sb_live[lane] = live ? 1 : 0;
     if (!live) {
       s.csbf_bits[lane] = 0;
@@ -482,16 +502,15 @@ __device__ __forceinline__ int wave_rdoq(S &s, int lane, int bd, int w, int h,
         const RdoqFlagBits fb = {c1_b.x, c1_b.y, c2_b.x, c2_b.y};
         const unsigned sig0 = sig_b.x;
         unsigned sig1 = sig_b.y;
-        if (is_last || (sb_index > 0 && k == 0 && num_non_zero == 0)) sig1 = 0;
+        const bool dc_sig_zero = sb_index > 0 && k == 0 && num_non_zero == 0;
+        if (is_last || dc_sig_zero) sig1 = 0;
 
         // QuantCoeffRdo (rdo_quant.cc:689-720)
         // (a magnitude of 32768 wraps to a negative q, as in the reference: no
         // candidate but zero)
         long long best_cost = 0x7fffffffffffffffll;
-        unsigned best_sig = 0;
         int best_level = q;
         if (q > 0) {
-          best_sig = sig1;
           for (int lvl = q > 1 ? q - 1 : q; lvl <= q; lvl++) {
             const unsigned bits = sig1 + rq_abs_level_bits(fb, lvl, st);
             int deq;
@@ -511,19 +530,18 @@ __device__ __forceinline__ int wave_rdoq(S &s, int lane, int bd, int w, int h,
           const long long cost = zero_cost + rq_bit_cost(sig0, lambda);
           if (cost <= best_cost) {
             best_cost = cost;
-            best_sig = sig0;
             best_level = 0;
           }
         }
         *lev(x, y) = (short)best_level;
         s.cost_to_zero[pos] = zero_cost - best_cost;
-        s.sig_bits[pos] = best_sig;
+        s.sig_ci[pos] = (unsigned char)(sig_ctx >> 1);
+        if (dc_sig_zero) s.sb_dcz[lane] = 1;
         code_cost += best_cost;
         const long long orig_scaled =
             (((long long)abs_coeff * scale) + size_bias_offset) >> size_bias_shift;
         const long long quant_err = orig_scaled - ((long long)best_level << shift);
         s.err_dist[pos] = (short)(quant_err >> (shift - 8));
-        s.sig_rate[pos] = !is_last ? (int)(sig1 - sig0) : 0;
         if (best_level) {
           any = true;
           num_non_zero++;
@@ -557,22 +575,22 @@ __device__ __forceinline__ int wave_rdoq(S &s, int lane, int bd, int w, int h,
         long long cost = ((long long)(abs_coeff * abs_coeff)) << cost_scale;
         if (l2 == last_l && k > last_k) {  // rdo_quant.cc:303-307 (+ the memsets :262-265)
           s.err_dist[pos] = 0;
-          s.sig_rate[pos] = s.rate_up[pos] = 0;
+          s.rate_up[pos] = 0;
         } else {
           int n_sig, n_g1, n_g2, sum_abs;
           neighbours(x, y, n_sig, n_g1, n_g2, sum_abs);
-          const uint2 sig_b = *reinterpret_cast<const uint2 *>(cb + sig_ctx_of(x + y, n_sig));
+          const int sig_ctx2 = sig_ctx_of(x + y, n_sig);
+          const uint2 sig_b = *reinterpret_cast<const uint2 *>(cb + sig_ctx2);
           const unsigned c1_0 = cb[greater_ctx_of(x + y, n_g1, false)];
           const long long sig_cost = rq_bit_cost(sig_b.x, lambda);
           cost += sig_cost;
           s.cost_to_zero[pos] = -sig_cost;
-          s.sig_bits[pos] = sig_b.x;
+          s.sig_ci[pos] = (unsigned char)(sig_ctx2 >> 1);
           const long long orig_scaled =
               (((long long)abs_coeff * scale) + size_bias_offset) >> size_bias_shift;
           s.err_dist[pos] = (short)(orig_scaled >> (shift - 8));
           // (the k == 0 coefficient of an otherwise empty sub-block codes no flag,
           // sig1 = 0 at rdo_quant.cc:343; nothing reads the rate of such a sub-block)
-          s.sig_rate[pos] = (int)(sig_b.y - sig_b.x);
           s.rate_up[pos] = (int)c1_0;
         }
         atomicAdd(reinterpret_cast<unsigned long long *>(&s.sb_code_cost[l2]),
@@ -683,13 +701,14 @@ __device__ __forceinline__ int wave_rdoq(S &s, int lane, int bd, int w, int h,
     // block: entries [g] for the (scan-swapped) x, [16 + g] for y - a candidate
     // then costs two reads instead of up to eighteen
     const bool lp_swap = scan_order == 2;
+    constexpr int LPY = G == 4 ? 8 : 16;   // where the y groups' entries start
     {
       const int tw = lp_swap ? h : w, th = lp_swap ? w : h;
       const int nx = rq_last_pos_group(tw - 1) + 1, ny = rq_last_pos_group(th - 1) + 1;
       for (int i = lane; i < nx + ny; i += G) {
         const bool is_x = i < nx;
         const int g = is_x ? i : i - nx;
-        s.lp_bits[is_x ? g : 16 + g] = rq_last_pos_group_bits(cb, luma, tw, th, g, is_x);
+        s.lp_bits[is_x ? g : LPY + g] = rq_last_pos_group_bits(cb, luma, tw, th, g, is_x);
       }
     }
     // own sub-block, back from start_k: the running sum of zero costs in front of
@@ -744,9 +763,11 @@ __device__ __forceinline__ int wave_rdoq(S &s, int lane, int bd, int w, int h,
         coeff_xy(k, x, y);
         const int pos = y * rw + x;
         const unsigned lp_bits = s.lp_bits[rq_last_pos_group(lp_swap ? y : x)] +
-                                 s.lp_bits[16 + rq_last_pos_group(lp_swap ? x : y)];
+                                 s.lp_bits[LPY + rq_last_pos_group(lp_swap ? x : y)];
+        unsigned sg0, sg1;
+        sig_pair(pos, sb_index + k, k, s.sb_dcz[lane] != 0, sg0, sg1);
         const long long cost = c + s.cost_to_zero[pos] + rq_bit_cost(lp_bits, lambda) -
-                               rq_bit_cost(s.sig_bits[pos], lambda);
+                               rq_bit_cost(sg1, lambda);
         if (cost < best_cost) {
           best_cost = cost;
           best_last_plus1 = sb_index + k + 1;
@@ -797,8 +818,10 @@ __device__ __forceinline__ int wave_rdoq(S &s, int lane, int bd, int w, int h,
             continue;
           }
           const unsigned lp_bits = rq_last_pos_bits(cb, luma, w, h, scan_order, x, y);
+          unsigned sg0, sg1;
+          sig_pair(pos, idx + k, k, s.sb_dcz[l] != 0, sg0, sg1);
           const long long cost =
-              code_cost + rq_bit_cost(lp_bits, lambda) - rq_bit_cost(s.sig_bits[pos], lambda);
+              code_cost + rq_bit_cost(lp_bits, lambda) - rq_bit_cost(sg1, lambda);
           if (cost < best_cost) {
             best_cost = cost;
             best_last_plus1 = idx + k + 1;
@@ -879,7 +902,7 @@ __device__ __forceinline__ int wave_rdoq(S &s, int lane, int bd, int w, int h,
           const int rate_down = -lvl_rate + (int)rq_abs_level_bits(fb, al - 1, st);
           const long long cost_inc = rd_factor * (-(int)s.err_dist[pos]) + rate_up;
           long long cost_dec = rd_factor * (int)s.err_dist[pos] + rate_down -
-                               (al == 1 ? s.sig_rate[pos] : 0);
+                               (al == 1 ? sig_rate_of(pos, sb_index + k, k, s.sb_dcz[lane] != 0) : 0);
           if (is_last_sb && k == lastk && al == 1) cost_dec -= 4ll * RQ_BYPASS;
           if (cost_inc < cost_dec) {
             cost = cost_inc;
@@ -890,7 +913,7 @@ __device__ __forceinline__ int wave_rdoq(S &s, int lane, int bd, int w, int h,
           }
         } else {
           cost = rd_factor * -(long long)d_abs((int)s.err_dist[pos]) + s.rate_up[pos] +
-                 s.sig_rate[pos] + (long long)RQ_BYPASS;
+                 sig_rate_of(pos, sb_index + k, k, s.sb_dcz[lane] != 0) + (long long)RQ_BYPASS;
           delta = 1;
           if (k < first && (cf(x, y) >= 0 ? 0 : 1) != first_sign) cost = 0x7fffffffll;
         }
@@ -1066,15 +1089,15 @@ struct RdoqPackedLds {
   alignas(8) long long cost_to_zero[GROUPS][MAXC];   // the per-coefficient records: 22 bytes each
   long long sb_code_cost[GROUPS][MAXSB];
   long long sb_zero_dist[GROUPS][MAXSB];
-  unsigned sig_bits[GROUPS][MAXC];
-  int sig_rate[GROUPS][MAXC], rate_up[GROUPS][MAXC];
+  int rate_up[GROUPS][MAXC];
   short err_dist[GROUPS][MAXC];
   alignas(8) unsigned ctx_bits[2 * sizeof(xvcgpu_rdoq_contexts)];
   unsigned csbf_bits[GROUPS][MAXSB];
   int16_t cf[GROUPS][MAXC], lv[GROUPS][MAXC];
-  unsigned char csbf[GROUPS][MAXSB], sb_live[GROUPS][MAXSB];
-  unsigned char sb_of_scan[GROUPS][G == 64 ? 256 : MAXSB * 4];
-  unsigned lp_bits[GROUPS][32];
+  unsigned char csbf[GROUPS][MAXSB], sb_live[GROUPS][MAXSB], sb_dcz[GROUPS][MAXSB];
+  unsigned char sig_ci[GROUPS][MAXC];
+  unsigned char sb_of_scan[GROUPS][G == 64 ? 256 : (G == 4 ? MAXSB : MAXSB * 4)];   // (G = 4: grid = region)
+  unsigned lp_bits[GROUPS][G == 4 ? 16 : 32];   // (G = 4: a side is at most 16, 8 groups)
 };
 
 // G lanes per block; grid: an upper bound on ceil(count / (64 / G)) waves (the
@@ -1122,8 +1145,8 @@ __device__ __forceinline__ void quant_rdo_packed_wave(
   }
   RdoqView v;
   v.cost_to_zero = sm.cost_to_zero[g];
-  v.sig_bits = sm.sig_bits[g];
-  v.sig_rate = sm.sig_rate[g];
+  v.sig_ci = sm.sig_ci[g];
+  v.sb_dcz = sm.sb_dcz[g];
   v.rate_up = sm.rate_up[g];
   v.err_dist = sm.err_dist[g];
   v.sb_live = sm.sb_live[g];
