@@ -118,13 +118,29 @@ __device__ __forceinline__ void wave_sync() {
 }
 #define ME2_LANE ((int)(threadIdx.x & 63))
 
+// H-only sub-pel prediction from the 14-bit plane.  FilterHorSampleSample
+// (inter_prediction.cc) is clip((S + 32) >> 6) of the 8-tap sum S; the plane
+// holds v = (S - (8192 << t)) >> t with t = bd - 8, so (v << t) + (8192 << t)
+// = S - (S mod 2^t), and since 2^t divides 32 the dropped bits never carry
+// into bit 6: ((v << t) + (8192 << t) + 32) >> 6 == (S + 32) >> 6 exactly.
+// That is the candidate filter with a single centre tap 2^t (row 16 of
+// Me2SharedT::taps), offset 32 + (8192 << t), shift 6 - no second plane.
+__device__ __forceinline__ int me2_honly_off(int bd, int cfx) {
+  return cfx != 0 ? 32 + (8192 << (bd - 8)) : 32;
+}
+__device__ __forceinline__ int me2_vtaps_row(int cfx, int cfy) {
+  return (cfx != 0 && cfy == 0) ? 16 : cfy;
+}
+
 // SUB = false: layout of a full-pel-only kernel instance (orig + cost).
 template <int MS, bool SUB>
 struct __attribute__((aligned(16))) Me2SharedT {
   uint16_t orig[MS * MS];                   // row stride w
   uint16_t win[SUB ? (MS + 8) * (MS + 16) : 8];  // rows -4..h+3, cols -8..w+7
-  int16_t hint[3][SUB ? (MS + 8) * MS : 8];  // 14-bit H-filtered, rows -4..h+3
-  int16_t hh[3][SUB ? (MS + 8) * MS : 8];    // Sample-rounded H-filtered
+  // per x-phase slot: 14-bit H-filtered plane, rows -4..h+3 (the fast path keeps
+  // the unfiltered samples here for a phase-0 slot).  The Sample-rounded
+  // H-only prediction is derived from the 14-bit value, see me2_honly_taps.
+  int16_t hint[3][SUB ? (MS + 8) * MS : 8];
   uint32_t cost[128];
   // per sub-pel candidate: plane offset (int16 units from `orig`), stride,
   // rounding offset, shift, 8 taps
@@ -137,7 +153,7 @@ struct __attribute__((aligned(16))) Me2SharedT {
   };
   uint32_t dist[12];
   int dsum[12];                             // AC-only: sum(orig - pred) per candidate
-  int16_t taps[SUB ? 16 : 1][8];            // LDS copy of kLumaTaps
+  int16_t taps[SUB ? 17 : 1][8];            // LDS copy of kLumaTaps + the H-only row
 };
 template <int MS>
 using Me2Shared = Me2SharedT<MS, true>;
@@ -398,7 +414,6 @@ __device__ __forceinline__ void me2_build_hplanes(Me2Shared<MS> &s, int bd, int 
   const int f0 = f[0], f1 = f[1], f2 = f[2], f3 = f[3], f4 = f[4], f5 = f[5],
             f6 = f[6], f7 = f[7];
   const int shift = 6 - (14 - bd), offset = -(8192 << shift);
-  const int smax = (1 << bd) - 1;
   const int n = (h + 8) * w;
   for (int i = ME2_LANE; i < n; i += 64) {
     const int r = i >> lw, x = i & (w - 1);
@@ -408,7 +423,6 @@ __device__ __forceinline__ void me2_build_hplanes(Me2Shared<MS> &s, int bd, int 
                     (int)src[3] * f3 + (int)src[4] * f4 + (int)src[5] * f5 +
                     (int)src[6] * f6 + (int)src[7] * f7;
     s.hint[p][i] = (int16_t)((sum + offset) >> shift);
-    s.hh[p][i] = (int16_t)d_clip_bd((sum + 32) >> 6, smax);
   }
 }
 
@@ -612,16 +626,16 @@ __device__ __forceinline__ void me2_subpel_eval(Me2Shared<MS> &s, const MeCtx &c
 #pragma unroll
     for (int k = 0; k < 3; k++)
       if (k < nslots)
-        sp_build_planes(s.win, s.hint[k], s.hh[k], s.taps, bd, w, h,
+        sp_build_planes(s.win, s.hint[k], s.taps, bd, w, h,
                         (slot_key[k] >> 4) - 1, slot_key[k] & 15);
     if (lane < n) {
       const int16_t *base = reinterpret_cast<const int16_t *>(s.orig);
       SpCand &cd = s.sp[lane];
       const bool two_stage = cfx != 0 && cfy != 0;
-      cd.plane = (int)((two_stage ? s.hint[0] : s.hh[0]) - base) + myslot * (MS + 8) * MS;
+      cd.plane = (int)(s.hint[0] - base) + myslot * (MS + 8) * MS;
       cd.sh = two_stage ? 6 + (14 - bd) : 6;
-      cd.off = two_stage ? (8192 << 6) + (1 << (cd.sh - 1)) : 32;
-      sp_fill_taps(cd, s.taps, cfy, cpy + 1);
+      cd.off = two_stage ? (8192 << 6) + (1 << (cd.sh - 1)) : me2_honly_off(bd, cfx);
+      sp_fill_taps(cd, s.taps, me2_vtaps_row(cfx, cfy), cpy + 1);
       s.dist[lane] = 0;
     }
     wave_sync();
@@ -645,10 +659,10 @@ __device__ __forceinline__ void me2_subpel_eval(Me2Shared<MS> &s, const MeCtx &c
       off = 32;
       sh = 6;
     } else if (cfy == 0) {
-      // horizontal-only: Sample-rounded plane through identity taps
-      plane = (int)(s.hh[0] - base) + myslot * (MS + 8) * MS + (cpy + 1) * w;
+      // horizontal-only: the Sample-rounded value out of the 14-bit plane
+      plane = (int)(s.hint[0] - base) + myslot * (MS + 8) * MS + (cpy + 1) * w;
       stride = w;
-      off = 32;
+      off = me2_honly_off(bd, cfx);
       sh = 6;
     } else {
       // two-stage: FilterVerShortSample on the 14-bit plane
@@ -662,7 +676,10 @@ __device__ __forceinline__ void me2_subpel_eval(Me2Shared<MS> &s, const MeCtx &c
     s.cand_off[lane] = off;
     s.cand_shift[lane] = sh;
 #pragma unroll
-    for (int k = 0; k < 8; k++) s.cand_taps[lane][k] = kLumaTaps[cfy][k];
+    for (int k = 0; k < 8; k++)
+      s.cand_taps[lane][k] =
+          (cfx != 0 && cfy == 0) ? (k == 3 ? (int16_t)(1 << (bd - 8)) : (int16_t)0)
+                                 : kLumaTaps[cfy][k];
     s.dist[lane] = 0;
     s.dsum[lane] = 0;
   }
@@ -799,9 +816,11 @@ me_search_wave_body(const PicView &orig, const PicView &ref,
   c.ac = LIC;
   c.orig_sum = 0;
 
-  if constexpr ((PH & XVCGPU_ME_SUBPEL) != 0)  // per-lane phase lookups come from LDS
+  if constexpr ((PH & XVCGPU_ME_SUBPEL) != 0) {  // per-lane phase lookups come from LDS
     reinterpret_cast<uint32_t *>(&s.taps[0][0])[lane] =
         reinterpret_cast<const uint32_t *>(&kLumaTaps[0][0])[lane];
+    if (lane < 8) s.taps[16][lane] = lane == 3 ? (int16_t)(1 << (c.bd - 8)) : (int16_t)0;
+  }
   {  // stage the original block
     const uint16_t *o = po.p + (ptrdiff_t)b.y * po.stride + b.x;
     if (c.w >= 8) {
@@ -1199,16 +1218,16 @@ __device__ __forceinline__ void me2_team_eval(Me2Shared<MS> &s, const MeCtx &c,
 #pragma unroll
   for (int k = 0; k < 3; k++)
     if (k < nslots)
-      sp_build_planes(s.win, s.hint[k], s.hh[k], s.taps, bd, w, h, (slot_key[k] >> 4) - 1,
+      sp_build_planes(s.win, s.hint[k], s.taps, bd, w, h, (slot_key[k] >> 4) - 1,
                       slot_key[k] & 15, tid, 64 * NW);
   if (tid < n) {
     const int16_t *base = reinterpret_cast<const int16_t *>(s.orig);
     SpCand &cd = s.sp[lane];
     const bool two_stage = cfx != 0 && cfy != 0;
-    cd.plane = (int)((two_stage ? s.hint[0] : s.hh[0]) - base) + myslot * (MS + 8) * MS;
+    cd.plane = (int)(s.hint[0] - base) + myslot * (MS + 8) * MS;
     cd.sh = two_stage ? 6 + (14 - bd) : 6;
-    cd.off = two_stage ? (8192 << 6) + (1 << (cd.sh - 1)) : 32;
-    sp_fill_taps(cd, s.taps, cfy, cpy + 1);
+    cd.off = two_stage ? (8192 << 6) + (1 << (cd.sh - 1)) : me2_honly_off(bd, cfx);
+    sp_fill_taps(cd, s.taps, me2_vtaps_row(cfx, cfy), cpy + 1);
     s.dist[lane] = 0;
   }
   __syncthreads();
@@ -1251,6 +1270,7 @@ me_subpel_team_kernel(PicView orig, PicView ref, const xvcgpu_me_block *blocks, 
   if (tid < 64)
     reinterpret_cast<uint32_t *>(&s.taps[0][0])[tid] =
         reinterpret_cast<const uint32_t *>(&kLumaTaps[0][0])[tid];
+  if (tid < 8) s.taps[16][tid] = tid == 3 ? (int16_t)(1 << (orig.bd - 8)) : (int16_t)0;
   {  // the original block, column-major (column stride h) as k_subpel.h reads it
     const uint16_t *o = po.p + (ptrdiff_t)b.y * po.stride + b.x;
     const int cpr = w >> 3, lc = 31 - __clz(cpr);

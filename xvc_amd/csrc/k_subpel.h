@@ -53,12 +53,12 @@ struct __attribute__((aligned(16))) SpCand {
   int pad[3];
 };
 
-// Column-major planes of one x-phase: p14 = FilterHorSampleShort (14 bit),
-// ps = FilterHorSampleSample (or the unfiltered samples when fx == 0); column
+// Column-major plane of one x-phase: p14 = FilterHorSampleShort (14 bit), or
+// the unfiltered samples when fx == 0; column
 // stride h + 8, stored row r <-> picture row r - 4 relative to the full-pel
 // position.  win: row-major window, cols -8..w+7 (row stride w + 16).
 __device__ __forceinline__ void sp_build_planes(const uint16_t *win, int16_t *p14,
-                                                int16_t *ps, const int16_t (*taps)[8],
+                                                const int16_t (*taps)[8],
                                                 int bd, int w, int h, int pel_x, int fx,
                                                 int tid = threadIdx.x & 63, int nthr = 64) {
   const int lane = tid;   // tid / nthr: this thread's place in the wave (or team of waves)
@@ -69,8 +69,8 @@ __device__ __forceinline__ void sp_build_planes(const uint16_t *win, int16_t *p1
     for (int i = lane; i < n; i += nthr) {
       const int r = i >> lhw, x0 = (i & (hw - 1)) << 1;
       const uint16_t *src = win + r * ws + x0 + pel_x + 8;
-      ps[x0 * rs + r] = (int16_t)src[0];
-      ps[(x0 + 1) * rs + r] = (int16_t)src[1];
+      p14[x0 * rs + r] = (int16_t)src[0];
+      p14[(x0 + 1) * rs + r] = (int16_t)src[1];
     }
     return;
   }
@@ -81,7 +81,6 @@ __device__ __forceinline__ void sp_build_planes(const uint16_t *win, int16_t *p1
                  b2 = sp_pack_taps(f[3], f[4]), b3 = sp_pack_taps(f[5], f[6]),
                  b4 = sp_pack_taps(f[7], 0);
   const int shift = 6 - (14 - bd), offset = -(8192 << shift);
-  const int smax = (1 << bd) - 1;
   // first tap of output x0 sits at window column c0 = x0 + pel_x + 5
   const bool odd = ((pel_x + 5) & 1) != 0;
   const uint32_t *win32 = reinterpret_cast<const uint32_t *>(win);
@@ -103,8 +102,6 @@ __device__ __forceinline__ void sp_build_planes(const uint16_t *win, int16_t *p1
     }
     p14[x0 * rs + r] = (int16_t)((s0 + offset) >> shift);
     p14[(x0 + 1) * rs + r] = (int16_t)((s1 + offset) >> shift);
-    ps[x0 * rs + r] = (int16_t)d_clip_bd((s0 + 32) >> 6, smax);
-    ps[(x0 + 1) * rs + r] = (int16_t)d_clip_bd((s1 + 32) >> 6, smax);
   }
 }
 
