@@ -948,6 +948,93 @@ void xr_bipred_search(int bd, const xvcgpu_bi_block *j, int pic_w, int pic_h,
 }
 
 
+/* InterSearch::SearchMotion (inter_search.cc:198-259) for one CU of a
+ * bi-predicted picture with one reference per list: SearchRefIdx on L0 and L1,
+ * SearchBiIterative (`iterations` refinement steps at most) and the final choice.
+ * The closed-form bit costs (fast_inter_pred_bits, :1084-1130) are switched on so
+ * that the result does not depend on entropy-coder state.  nb[2][2][2]: MVs of an
+ * inter CU to the left (8 x h) and above (w x 8) [neighbour][list][x, y]; they
+ * give the AMVP lists (inter_prediction.cc:139-248).  flags: 1 = full-pel MVs.
+ * out[18]: cost, inter_dir (0 L0, 1 L1, 2 bi), mv0 x y, mv1 x y, mvp_idx0,
+ * mvp_idx1, search_range L0, search_range L1, mvp list L0 {x0,y0,x1,y1}, L1;
+ * out[18..25]: the uni-directional searches on their own (a second InterSearch):
+ * cost, mv x y, mvp_idx of L0, then of L1. */
+void xr_search_motion(int bd, int x, int y, int w, int h, int flags, uint32_t lambda16,
+                      int iterations, int pic_w, int pic_h, const uint16_t *orig,
+                      ptrdiff_t os, const uint16_t *ref0, ptrdiff_t rs0,
+                      const uint16_t *ref1, ptrdiff_t rs1, const int32_t *nb,
+                      int64_t *out) {
+  BiEnv env(bd, pic_w, pic_h);
+  env.settings.fast_inter_pred_bits = 1;
+  env.settings.bipred_refinement_iterations = iterations;
+  for (int yy = 0; yy < pic_h; yy++)
+    std::memcpy(env.orig_pic.GetSamplePtr(YuvComponent::kY, 0, yy), orig + yy * os,
+                sizeof(Sample) * pic_w);
+  const uint16_t *p0[3] = {ref0, nullptr, nullptr}, *p1[3] = {ref1, nullptr, nullptr};
+  ptrdiff_t s0[3] = {rs0, 0, 0}, s1[3] = {rs1, 0, 0};
+  FillPic(env.ref[0].get(), p0, s0);
+  FillPic(env.ref[1].get(), p1, s1);
+  for (int k = 0; k < 2; k++) {
+    if ((k == 0 && x < 8) || (k == 1 && y < 8)) continue;
+    CodingUnit *n = k == 0 ? env.pic_data.CreateCu(CuTree::Primary, 1, x - 8, y, 8, h)
+                           : env.pic_data.CreateCu(CuTree::Primary, 1, x, y - 8, w, 8);
+    n->SetPredMode(PredictionMode::kInter);
+    n->SetInterDir(InterDir::kBi);
+    for (int l = 0; l < 2; l++) {
+      n->SetRefIdx(0, static_cast<RefPicList>(l));
+      n->SetMv(MotionVector(nb[4 * k + 2 * l], nb[4 * k + 2 * l + 1]),
+               static_cast<RefPicList>(l));
+    }
+    env.pic_data.MarkUsedInPic(n);
+  }
+  CodingUnit *cu = env.pic_data.CreateCu(CuTree::Primary, 1, x, y, w, h);
+  const double ls = (lambda16 + 0.5) / 65536.0;
+  Qp qp = MakeQp(32, bd, ls * ls);
+  cu->SetQp(qp);
+  InterSearch is(Simd(bd), env.pic_data, env.orig_pic, env.rec_pic, *env.pic_data.GetRefPicLists(),
+                 env.settings);
+  BitWriter bw;
+  SyntaxWriter writer(qp, PicturePredictionType::kBi, &bw);
+  SampleBufferStorage pred(64, 64);
+  const InterSearchFlags sf =
+      (flags & 1) ? InterSearchFlags::kFullPelMv : InterSearchFlags::kDefault;
+  const Distortion cost = is.SearchMotion(cu, qp, writer, sf, &pred);
+  out[0] = static_cast<int64_t>(cost);
+  out[1] = cu->GetInterDir() == InterDir::kBi ? 2 : (cu->GetInterDir() == InterDir::kL1 ? 1 : 0);
+  for (int l = 0; l < 2; l++) {
+    const RefPicList rl = static_cast<RefPicList>(l);
+    const bool has = cu->HasMv(rl);
+    out[2 + 2 * l] = has ? cu->GetMv(rl, MvCorner::kDefault).x : 0;
+    out[3 + 2 * l] = has ? cu->GetMv(rl, MvCorner::kDefault).y : 0;
+    out[6 + l] = has ? cu->GetMvpIdx(rl) : 0;
+    out[8 + l] = is.GetSearchRangeUniPred(env.pic_data.GetRefPicLists()->GetRefPoc(rl, 0));
+    const InterPredictorList mvp = is.GetMvpList(*cu, rl, 0);
+    for (int k = 0; k < 2; k++) {
+      out[10 + 4 * l + 2 * k] = mvp[k].x;
+      out[11 + 4 * l + 2 * k] = mvp[k].y;
+    }
+  }
+  InterSearch is2(Simd(bd), env.pic_data, env.orig_pic, env.rec_pic,
+                  *env.pic_data.GetRefPicLists(), env.settings);
+  SampleBufferConst orig_luma = env.orig_pic.GetSampleBuffer(YuvComponent::kY, x, y);
+  for (int l = 0; l < 2; l++) {
+    const RefPicList rl = static_cast<RefPicList>(l);
+    cu->ResetPredictionState();
+    cu->SetPredMode(PredictionMode::kInter);
+    cu->SetFullpelMv((flags & 1) != 0);
+    cu->SetInterDir(l == 0 ? InterDir::kL0 : InterDir::kL1);
+    CodingUnit::InterState st;
+    const Distortion c = is2.SearchRefIdx(cu, qp, rl, writer, orig_luma,
+                                          std::numeric_limits<Distortion>::max(), &pred, &st,
+                                          nullptr);
+    out[18 + 4 * l] = static_cast<int64_t>(c);
+    out[19 + 4 * l] = cu->GetMv(rl, MvCorner::kDefault).x;
+    out[20 + 4 * l] = cu->GetMv(rl, MvCorner::kDefault).y;
+    out[21 + 4 * l] = cu->GetMvpIdx(rl);
+  }
+}
+
+
 /* ---- the hot-path frame pass, executed by the reference's own classes ----
  * Same composition and argument block as xo_frame_pass (xvc_oracle_frame.c):
  * per CU TzSearch::Search + InterSearch::SubpelSearch +

@@ -1,8 +1,9 @@
 """The host control the C++ layer keeps around the motion-search batches
 (xvc_gpu::InterSearch in xvc_amd/host/xvc_gpu_ops.h: EvalStartMvp,
-EvalFinalMvpIdx, the bit prices, the per-list SearchRefIdx loop) against the
-reference's own member functions (oracle/_ref, xr_eval_start_mvp /
-xr_eval_final_mvp_idx / xr_mvd_bits), on random CUs and predictor pairs."""
+EvalFinalMvpIdx, the bit prices, the per-list SearchRefIdx loop, the merge fold,
+SearchBiIterative / SearchMotion) against the reference's own member functions
+(oracle/_ref, xr_eval_start_mvp / xr_eval_final_mvp_idx / xr_mvd_bits /
+xr_search_merge_candidates / xr_search_motion), on random CUs and predictors."""
 import ctypes as C
 
 import numpy as np
@@ -190,3 +191,90 @@ def test_search_merge_candidates_vs_reference(gpu, bd):
         p.destroy()
     assert [L.xvc_host_choose_uni_or_bi(*t) for t in
             [(5, 5, 5), (5, 4, 6), (4, 5, 6), (5, 5, 6), (7, 7, 6)]] == [0, 2, 1, 1, 0]
+
+
+@pytest.mark.skipif(not ol.have_ref(), reason="oracle/_ref not built")
+@pytest.mark.parametrize("bd,iterations", [(8, 4), (10, 4), (10, 1)])
+def test_search_motion_vs_reference(gpu, bd, iterations):
+    """InterSearch::SearchMotion (inter_search.cc:198-259) as a whole - the
+    uni-directional searches of both lists, SearchBiIterative's loop around the
+    device steps (bootstrap vectors and predictors carried between iterations, the
+    stop rule) and the final choice - against the reference's member function on
+    the same CUs, neighbours (AMVP lists) and pictures."""
+    api, ctx = gpu
+    L, xr = host_lib(), ol.Lib("xr").dll
+    L.xvc_host_search_motion_batch.argtypes = [C.c_void_p] * 5 + [C.c_int] + [C.c_void_p] * 3 + \
+        [C.c_int, C.c_void_p]
+    xr.xr_search_motion.restype = None
+    xr.xr_search_motion.argtypes = [C.c_int] * 6 + [C.c_uint32] + [C.c_int] * 3 + \
+        [C.c_void_p, C.c_ssize_t] * 3 + [C.c_void_p, C.c_void_p]
+    rng = np.random.default_rng(9100 + bd + iterations)
+    pw, ph = 256, 160
+    _, ref0 = make_pics(rng, bd, pw, ph, BL, (0, 0))
+    _, ref1 = make_pics(rng, bd, pw, ph, BL, (0, 0), noise=5)
+    # the original: the mean of the two references displaced differently + noise, so
+    # that bi-prediction wins for many CUs and the refinement moves both vectors
+    a = np.roll(ref0, (2, -5), (0, 1)).astype(np.int32)
+    b2 = np.roll(ref1, (-3, 6), (0, 1)).astype(np.int32)
+    orig = np.clip((a + b2 + 1) // 2 + rng.integers(-2, 3, a.shape), 0,
+                   (1 << bd) - 1).astype(np.uint16)
+    O, R0, R1 = (ctx.picture(pw, ph, bd) for _ in range(3))
+    O.upload([orig, None, None], BL)
+    R0.upload([ref0, None, None], BL)
+    R1.upload([ref1, None, None], BL)
+    n = 40
+    blocks = np.zeros((2, n), api.ME_DTYPE)
+    mvp = np.zeros((2, n, 4), np.int32)
+    exp = np.zeros((n, 26), np.int64)
+    o, r0, r1 = orig[BL:, BL:], ref0[BL:, BL:], ref1[BL:, BL:]
+    for i in range(n):
+        w, h = int(rng.choice([8, 16, 32, 64])), int(rng.choice([8, 16, 32, 64]))
+        x = int(rng.integers(0, (pw - w) // 8 + 1)) * 8
+        y = int(rng.integers(0, (ph - h) // 8 + 1)) * 8
+        fp = int(rng.integers(0, 6) == 0)
+        lam = int(rng.choice([120000, 498000, 1500000]))
+        nb = np.array(rng.integers(-150, 150, 8), np.int32)
+        if i % 4 == 0:
+            nb[4:] = nb[:4]              # identical predictors
+        xr.xr_search_motion(bd, x, y, w, h, fp, lam, iterations, pw, ph, o.ctypes.data,
+                            orig.strides[0] // 2, r0.ctypes.data, ref0.strides[0] // 2,
+                            r1.ctypes.data, ref1.strides[0] // 2, nb.ctypes.data,
+                            exp[i].ctypes.data)
+        for l in range(2):
+            bk = blocks[l][i]
+            bk["x"], bk["y"], bk["w"], bk["h"] = x, y, w, h
+            bk["depth_nonzero"], bk["fullpel_mv"], bk["lambda16"] = 1, fp, lam
+            bk["search_range"] = exp[i][8 + l]
+            mvp[l][i] = exp[i][10 + 4 * l:14 + 4 * l]
+    assert len({tuple(m) for m in mvp.reshape(-1, 4)}) > n // 2     # real AMVP lists
+    side_uni = np.full((2, n), 3, np.uint32)    # fast_inter_pred_bits: 3 (bi picture), 5 (bi CU)
+    side_bi = np.full(n, 5, np.uint32)
+    out = np.zeros((n, 18), np.int64)
+    bl, mv = np.ascontiguousarray(blocks), np.ascontiguousarray(mvp)
+    assert L.xvc_host_search_motion_batch(ctx.h, O.h_pic, R0.h_pic, R1.h_pic, bl.ctypes.data, n,
+                                          mv.ctypes.data, side_uni.ctypes.data,
+                                          side_bi.ctypes.data, iterations, out.ctypes.data) == 0
+    n_bi = 0
+    for i in range(n):
+        e = exp[i]
+        d = int(e[1])
+        want = [d, 0, 0, 0, 0, 0, 0, int(e[0])]
+        got = [int(v) for v in out[i][:8]]
+        # the uni-directional halves first: {cost, mv, mvp_idx} per list
+        assert [int(v) for v in out[i][8:16]] == [int(v) for v in e[18:26]], \
+            (i, tuple(blocks[0][i]), mvp[:, i])
+        for l in range(2):
+            if d == 2 or d == l:
+                want[1 + 2 * l:3 + 2 * l] = [int(e[2 + 2 * l]), int(e[3 + 2 * l])]
+                want[5 + l] = int(e[6 + l])
+            else:                       # the unused list: the reference cleared it
+                got[1 + 2 * l:3 + 2 * l] = [0, 0]
+                got[5 + l] = 0
+        if got != want:
+            print("CU", i, "host", " ".join(str(int(v)) for v in out[i]))
+            print("CU", i, "ref ", " ".join(str(int(v)) for v in e))
+        assert got == want, (i, tuple(blocks[0][i]))
+        n_bi += d == 2
+    assert n_bi >= n // 4
+    for p in (O, R0, R1):
+        p.destroy()

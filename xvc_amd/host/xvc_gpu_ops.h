@@ -7,6 +7,8 @@
 //   YuvPicture + PadBorder (yuv_pic.cc:32-150)      xvc_gpu::Picture
 //   SampleMetric::Compare (sample_metric.cc:171)    xvc_gpu::SampleMetric::CompareBatch
 //   InterSearch::MotionEstNormal (inter_search.cc:606)  xvc_gpu::InterSearch::MotionEstNormalBatch
+//   InterSearch::SearchMotion (:198-259),           xvc_gpu::InterSearch::SearchMotionBatch,
+//     SearchBiIterative (:392-433)                    SearchBiIterativeBatch
 //   InterPrediction::MotionCompensationMv (:740)    xvc_gpu::InterPrediction::MotionCompensationBatch
 //   TransformEncoder::TransformAndReconstruct       xvc_gpu::TransformEncoder::TransformAndReconstructBatch
 //     (transform_encoder.cc:203)
@@ -425,6 +427,156 @@ class InterSearch {
                                     ref_search.get(), d.data(),
                                     static_cast<int>(jobs.size()), r.data(), 64));
     return r.ToHost();
+  }
+  // InterSearch::SearchBiIterative (inter_search.cc:392-433) around the device
+  // steps, for a batch of CUs with one reference picture per list.  Per CU the
+  // loop is the reference's: start with the list that lost the uni-directional
+  // comparison; predict from the other list with the CU's current vector, search
+  // +-4 around the searched list's best uni-directional vector with the predictor
+  // that search ended on (SearchRefIdx, bipred branch, :485-489), EvalFinalMvpIdx,
+  // remember vector and predictor as the list's new bootstrap when more than one
+  // iteration is configured (:550-554), price the pair
+  // cost = dist + ((bits * lambda) >> 16), keep it if strictly cheaper, go back to
+  // the best state, stop when an iteration did not improve, else swap lists.
+  // Every iteration is one SearchBiStepBatch per searched list over the CUs still
+  // iterating.  side_bits[i]: GetInterPredBits of the bi-directional CU without
+  // the two predictor indices and vector differences (5 with
+  // fast_inter_pred_bits, :1108).
+  struct ListState {
+    int mvp_idx;
+    int mv_x, mv_y;
+  };
+  struct BiPredChoice {
+    ListState list[2];
+    uint32_t cost;
+    int steps;                // device steps this CU took
+  };
+  std::vector<BiPredChoice> SearchBiIterativeBatch(
+      const Picture &orig_pic, const Picture &ref_l0, const Picture &ref_l1,
+      const std::vector<xvcgpu_me_block> &blocks,
+      const std::vector<std::array<int32_t, 4>> mvp[2], const std::vector<ListState> uni[2],
+      const std::vector<int> &best_uni_dir, const std::vector<uint32_t> &side_bits,
+      int num_iterations) const {
+    const size_t n = blocks.size();
+    std::vector<BiPredChoice> best(n);
+    std::vector<ListState> boot[2] = {uni[0], uni[1]};
+    std::vector<int> search_list(n);
+    std::vector<char> active(n, 1);
+    for (size_t i = 0; i < n; i++) {
+      BiPredChoice c = {{uni[0][i], uni[1][i]}, 0xffffffffu, 0};
+      best[i] = c;
+      search_list[i] = best_uni_dir[i] == 0 ? 1 : 0;
+    }
+    const Picture *ref[2] = {&ref_l0, &ref_l1};
+    for (int it = 0; it < num_iterations; it++) {
+      bool any = false;
+      const std::vector<int> searched(search_list);   // one step per CU and iteration
+      for (int l = 0; l < 2; l++) {
+        std::vector<xvcgpu_bi_block> jobs;
+        std::vector<size_t> of;
+        for (size_t i = 0; i < n; i++) {
+          if (!active[i] || searched[i] != l) continue;
+          xvcgpu_bi_block j = xvcgpu_bi_block();
+          j.blk = blocks[i];
+          j.blk.mvp_x = mvp[l][i][2 * boot[l][i].mvp_idx];
+          j.blk.mvp_y = mvp[l][i][2 * boot[l][i].mvp_idx + 1];
+          j.other_mv_x = best[i].list[1 - l].mv_x;
+          j.other_mv_y = best[i].list[1 - l].mv_y;
+          j.boot_mv_x = boot[l][i].mv_x;
+          j.boot_mv_y = boot[l][i].mv_y;
+          jobs.push_back(j);
+          of.push_back(i);
+        }
+        if (jobs.empty()) continue;
+        any = true;
+        const std::vector<xvcgpu_me_result> res =
+            SearchBiStepBatch(orig_pic, *ref[1 - l], *ref[l], jobs);
+        for (size_t k = 0; k < of.size(); k++) {
+          const size_t i = of[k];
+          const bool fp = (blocks[i].fullpel_mv & XVC_ME_FULLPEL_MV) != 0;
+          ListState cand = {EvalFinalMvpIdx(mvp[l][i], res[k].mv_x, res[k].mv_y,
+                                            boot[l][i].mvp_idx, fp),
+                            res[k].mv_x, res[k].mv_y};
+          if (num_iterations > 1) boot[l][i] = cand;
+          ListState st[2];
+          st[l] = cand;
+          st[1 - l] = best[i].list[1 - l];
+          uint32_t bits = side_bits[i];
+          for (int q = 0; q < 2; q++)
+            bits += GetMvpBits(st[q].mvp_idx, 2) +
+                    GetMvdBits(mvp[q][i][2 * st[q].mvp_idx], mvp[q][i][2 * st[q].mvp_idx + 1],
+                               st[q].mv_x, st[q].mv_y, fp ? 2 : 0);
+          const uint32_t cost =
+              res[k].subpel_dist +
+              static_cast<uint32_t>((static_cast<uint64_t>(bits) * blocks[i].lambda16) >> 16);
+          best[i].steps++;
+          if (cost < best[i].cost) {
+            best[i].cost = cost;
+            best[i].list[l] = cand;
+            search_list[i] = 1 - l;
+          } else {
+            active[i] = 0;  // cost_best == prev_best (:427)
+          }
+        }
+      }
+      if (!any) break;
+    }
+    return best;
+  }
+  // InterSearch::SearchMotion (inter_search.cc:198-259) for a batch of CUs of a
+  // bi-predicted picture with one reference per list (both "unique"): the
+  // uni-directional searches of both lists, SearchBiIterative, and the choice.
+  // side_bits_uni[l][i] / side_bits_bi[i]: what GetInterPredBits adds besides the
+  // predictor indices and vector differences.
+  struct MotionChoice {
+    int inter_dir;            // 0: L0, 1: L1, 2: bi
+    ListState list[2];
+    uint32_t cost;
+    ListState uni[2];         // the lists' uni-directional results
+    uint32_t cost_uni[2], cost_bi;
+    int bi_steps;
+  };
+  std::vector<MotionChoice> SearchMotionBatch(
+      const Picture &orig_pic, const Picture &ref_l0, const Picture &ref_l1,
+      const std::vector<xvcgpu_me_block> blocks[2],
+      const std::vector<std::array<int32_t, 4>> mvp[2],
+      const std::vector<uint32_t> side_bits_uni[2], const std::vector<uint32_t> &side_bits_bi,
+      int num_iterations) const {
+    const size_t n = blocks[0].size();
+    const Picture *ref[2] = {&ref_l0, &ref_l1};
+    std::vector<UniPredChoice> u[2];
+    std::vector<ListState> uni[2];
+    for (int l = 0; l < 2; l++) {
+      u[l] = SearchRefIdxBatch(orig_pic, std::vector<const Picture *>(1, ref[l]), blocks[l],
+                               std::vector<std::vector<std::array<int32_t, 4>>>(1, mvp[l]),
+                               std::vector<std::vector<uint32_t>>(1, side_bits_uni[l]));
+      uni[l].resize(n);
+      for (size_t i = 0; i < n; i++) {
+        ListState s = {u[l][i].mvp_idx, u[l][i].mv_x, u[l][i].mv_y};
+        uni[l][i] = s;
+      }
+    }
+    std::vector<int> best_uni_dir(n);
+    for (size_t i = 0; i < n; i++) best_uni_dir[i] = u[0][i].cost <= u[1][i].cost ? 0 : 1;
+    const std::vector<BiPredChoice> bi = SearchBiIterativeBatch(
+        orig_pic, ref_l0, ref_l1, blocks[0], mvp, uni, best_uni_dir, side_bits_bi, num_iterations);
+    std::vector<MotionChoice> out(n);
+    for (size_t i = 0; i < n; i++) {
+      const int pick = ChooseUniOrBi(u[0][i].cost, u[1][i].cost, bi[i].cost);
+      MotionChoice c;
+      c.inter_dir = pick == 0 ? 2 : pick - 1;
+      c.list[0] = pick == 0 ? bi[i].list[0] : uni[0][i];
+      c.list[1] = pick == 0 ? bi[i].list[1] : uni[1][i];
+      c.cost = pick == 0 ? bi[i].cost : u[pick - 1][i].cost;
+      for (int l = 0; l < 2; l++) {
+        c.uni[l] = uni[l][i];
+        c.cost_uni[l] = u[l][i].cost;
+      }
+      c.cost_bi = bi[i].cost;
+      c.bi_steps = bi[i].steps;
+      out[i] = c;
+    }
+    return out;
   }
   // InterSearch::MotionEstAffine (inter_search.cc:664-749) per job: the gradient
   // iteration from the affine predictor / bootstrap vector on ref_pic; jobs

@@ -1,7 +1,8 @@
 // xvc_inter_search.cc -- C entry points (for ctypes / tests) of the host control
 // that xvc_gpu::InterSearch (xvc_gpu_ops.h) keeps around the motion-search
-// batches: EvalStartMvp, EvalFinalMvpIdx, the per-list SearchRefIdx loop
-// (inter_search.cc:437-578, :966-1019).  Handles are borrowed, never freed here.
+// batches: EvalStartMvp, EvalFinalMvpIdx, the per-list SearchRefIdx loop, the merge
+// fold, SearchBiIterative and SearchMotion (inter_search.cc:165-259, :392-578,
+// :966-1019).  Handles are borrowed, never freed here.
 #include <array>
 #include <cstdint>
 #include <memory>
@@ -122,6 +123,60 @@ int xvc_host_search_merge_candidates_batch(xvcgpu_ctx *ctx, xvcgpu_picture *orig
     for (int i = 0; i < n; i++) {
       for (int m = 0; m < K; m++) out[(K + 1) * i + m] = res[i].order[m];
       out[(K + 1) * i + K] = res[i].num;
+    }
+    return XVCGPU_OK;
+  } catch (const xvc_gpu::Error &e) {
+    return e.status;
+  }
+}
+
+// InterSearch::SearchMotion for n CUs of a bi-predicted picture, one reference per
+// list: blocks[l * n + i] (the descriptor of CU i for list l: search range and
+// previous vector are per list), mvp[(l * n + i) * 4], side_bits_uni[l * n + i],
+// side_bits_bi[i]; out[n][18] = {inter_dir, mv0_x, mv0_y, mv1_x, mv1_y, mvp_idx0,
+// mvp_idx1, cost; then the parts: {cost, mv_x, mv_y, mvp_idx} of the L0 and of the
+// L1 uni-directional search, the bi-directional cost, the refinement steps taken}.
+int xvc_host_search_motion_batch(xvcgpu_ctx *ctx, xvcgpu_picture *orig, xvcgpu_picture *ref_l0,
+                                 xvcgpu_picture *ref_l1, const xvcgpu_me_block *blocks, int n,
+                                 const int32_t *mvp, const uint32_t *side_bits_uni,
+                                 const uint32_t *side_bits_bi, int num_iterations,
+                                 int64_t *out) {
+  if (!ctx || !orig || !ref_l0 || !ref_l1 || !blocks || !mvp || !side_bits_uni ||
+      !side_bits_bi || !out || n < 0 || num_iterations < 1)
+    return XVCGPU_INVALID_ARGUMENT;
+  try {
+    xvc_gpu::Context c(ctx);
+    xvc_gpu::Picture o(c, orig), r0(c, ref_l0), r1(c, ref_l1);
+    std::vector<xvcgpu_me_block> b[2];
+    std::vector<Mvp> m[2];
+    std::vector<uint32_t> su[2];
+    for (int l = 0; l < 2; l++) {
+      b[l].assign(blocks + static_cast<size_t>(l) * n, blocks + static_cast<size_t>(l + 1) * n);
+      m[l] = MvpList(mvp + 4 * static_cast<size_t>(l) * n, n);
+      su[l].assign(side_bits_uni + static_cast<size_t>(l) * n,
+                   side_bits_uni + static_cast<size_t>(l + 1) * n);
+    }
+    const std::vector<uint32_t> sb(side_bits_bi, side_bits_bi + n);
+    const std::vector<xvc_gpu::InterSearch::MotionChoice> res =
+        xvc_gpu::InterSearch(c).SearchMotionBatch(o, r0, r1, b, m, su, sb, num_iterations);
+    for (int i = 0; i < n; i++) {
+      int64_t *q = out + 18 * i;
+      q[0] = res[i].inter_dir;
+      q[1] = res[i].list[0].mv_x;
+      q[2] = res[i].list[0].mv_y;
+      q[3] = res[i].list[1].mv_x;
+      q[4] = res[i].list[1].mv_y;
+      q[5] = res[i].list[0].mvp_idx;
+      q[6] = res[i].list[1].mvp_idx;
+      q[7] = res[i].cost;
+      for (int l = 0; l < 2; l++) {
+        q[8 + 4 * l] = res[i].cost_uni[l];
+        q[9 + 4 * l] = res[i].uni[l].mv_x;
+        q[10 + 4 * l] = res[i].uni[l].mv_y;
+        q[11 + 4 * l] = res[i].uni[l].mvp_idx;
+      }
+      q[16] = res[i].cost_bi;
+      q[17] = res[i].bi_steps;
     }
     return XVCGPU_OK;
   } catch (const xvc_gpu::Error &e) {
