@@ -815,7 +815,9 @@ def main():
         # a figure from other kernels than the ones running now is not reported.
         traffic = None
         try:
-            prof = json.load(open(os.path.join(ROOT, "profiles", "traffic_current.json")))
+            prof = json.load(open(os.path.join(
+                ROOT, "profiles",
+                "traffic_current.json" if args.quant == "rdoq" else "traffic_current_fast.json")))
             kname = {"me_search": "me_search_wave_kernel<16, 3",
                      "recon_from_me": "recon_from_me_kernel", "quant_rdo": "quant_rdo_packed_kernel",
                      "fwd_transform": "residual_wave_kernel<1", "inv_transform": "residual_wave_kernel<2",

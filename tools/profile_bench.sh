@@ -3,7 +3,7 @@
 #   <tag>_bench.json               bench.py's line
 #   <tag>_bench_kernel_stats.csv   rocprofv3 --kernel-trace --stats of the same command
 #   <tag>_traffic.json             HBM bytes per launch from separate --pmc passes, stamped with
-#                                  the MD5 of the kernel sources (copy to profiles/traffic_current.json)
+#                                  the MD5 of the kernel sources (copy to profiles/traffic_current.json, the QuantFast one to traffic_current_fast.json)
 #   <tag>_sq_counters.txt          SQ / TCP / LDS counters of the pass's kernels (separate passes)
 # usage: tools/profile_bench.sh <tag> [rdoq|fast]  (outputs in gpurun_out/profile_<tag>/)
 tag=${1:-r02}
