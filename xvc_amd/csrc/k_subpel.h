@@ -202,7 +202,14 @@ __device__ __forceinline__ void sp_satd_pairs_t(const int16_t *lds, const SpCand
     for (int r8 = 0; r8 < TH / 8; r8++) {
       int va[8], vb[8];
       sp_vfilter8(lds, cand[ca], col_off + 8 * r8, va);
-      sp_vfilter8(lds, cand[cb], col_off + 8 * r8, vb);
+      // an odd candidate count leaves the last sweep with one candidate in both
+      // halves (the half-pel pass has nine): filter it once (wave-uniform test)
+      if (__builtin_amdgcn_ballot_w64(active && cb != ca) != 0) {
+        sp_vfilter8(lds, cand[cb], col_off + 8 * r8, vb);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; j++) vb[j] = va[j];
+      }
       // 8 originals of the column, each replicated into both halves
       const uint4 o4 = *reinterpret_cast<const uint4 *>(origc + x * h + ty * TH + 8 * r8);
       const uint32_t ow[4] = {o4.x, o4.y, o4.z, o4.w};
