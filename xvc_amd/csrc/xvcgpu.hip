@@ -1724,12 +1724,40 @@ xvcgpu_status xvcgpu_frame_pass_multi(xvcgpu_ctx *const *ctxs,
               a->db_y_end >= a->rec->h && a->dbh_y_end >= a->rec->h && a->ssd_y_begin == 0 &&
               a->ssd_y_end >= a->rec->h && !(a->rec->w & 7) && !(a->rec->h & 7) &&
               a->rec->w == args[0]->rec->w && a->rec->h == args[0]->rec->h &&
-              a->rec->bd == args[0]->rec->bd && ctxs[i]->device == ctx->device;
+              a->rec->bd == args[0]->rec->bd && ctxs[i]->device == ctx->device &&
+              // what the launches below dereference (the single-picture path
+              // validates the same pointers, so a picture missing one goes there)
+              a->d_me && a->d_results && a->d_cus && a->d_cu_map && a->d_ssd && a->d_nnz &&
+              a->d_cus_own &&
+              (!rdoq_packed || (a->d_tx && a->d_levels && a->d_coeffs && a->d_level_off &&
+                                a->d_luma_tx_index && a->d_rdoq_contexts));
   }
   if (!batched) {
+    // Picture by picture.  The batched form runs everything on ctxs[0]'s
+    // stream; so that a caller sees ONE ordering rule whichever form a call
+    // takes, a picture whose context has another stream is fenced into that
+    // stream: it starts after what ctxs[0]'s stream holds now, and ctxs[0]'s
+    // stream continues only after it.
     for (int i = 0; i < n; i++) {
       if (!ctxs[i] || !args[i]) return XVCGPU_INVALID_ARGUMENT;
+      const bool foreign = ctxs[i]->stream != ctx->stream;
+      hipEvent_t before = nullptr, after = nullptr;
+      if (foreign) {
+        HIP_TRY(ctx, hipSetDevice(ctx->device));
+        HIP_TRY(ctx, hipEventCreateWithFlags(&before, hipEventDisableTiming));
+        HIP_TRY(ctx, hipEventCreateWithFlags(&after, hipEventDisableTiming));
+        HIP_TRY(ctx, hipEventRecord(before, ctx->stream));
+        HIP_TRY(ctx, hipStreamWaitEvent(ctxs[i]->stream, before, 0));
+      }
       const xvcgpu_status st = xvcgpu_frame_pass(ctxs[i], args[i], phases);
+      if (foreign) {
+        if (st == XVCGPU_OK) {
+          HIP_TRY(ctx, hipEventRecord(after, ctxs[i]->stream));
+          HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, after, 0));
+        }
+        hipEventDestroy(before);   // released when the recorded work has passed them
+        hipEventDestroy(after);
+      }
       if (st != XVCGPU_OK) return st;
     }
     return XVCGPU_OK;

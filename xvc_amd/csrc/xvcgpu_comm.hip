@@ -41,9 +41,9 @@ struct Rccl {
   bool ok = false;
 };
 
-Rccl &rccl() {
-  static Rccl r;
-  if (r.dl || r.ok) return r;
+// loaded once; the initialisation of a function-local static is thread-safe
+Rccl load_rccl() {
+  Rccl r;
   for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
     r.dl = dlopen(name, RTLD_NOW | RTLD_LOCAL);
     if (r.dl) break;
@@ -65,6 +65,11 @@ Rccl &rccl() {
   return r;
 }
 
+Rccl &rccl() {
+  static Rccl r = load_rccl();
+  return r;
+}
+
 }  // namespace
 
 struct xvcgpu_event {
@@ -77,6 +82,7 @@ struct xvcgpu_comm {
   ncclComm_t comm;
   hipStream_t stream;
   int world, rank;
+  bool in_group;
 };
 
 namespace {
@@ -98,12 +104,24 @@ xvcgpu_status comm_fail(xvcgpu_ctx *ctx, xvcgpu_status st, const char *what, con
     if (e_ != hipSuccess)                                                                 \
       return comm_fail(ctx, XVCGPU_DEVICE_ERROR, #call, hipGetErrorString(e_));           \
   } while (0)
-#define NCCL_TRY(ctx, call)                                                               \
+// a failing call between xvcgpu_comm_group_begin / _end must not leave the
+// group open (everything enqueued later would silently join it): close it
+// before reporting
+#define NCCL_TRY(comm_or_null, ctx, call)                                                 \
   do {                                                                                    \
     ncclResult_t r_ = (call);                                                             \
-    if (r_ != ncclSuccess)                                                                \
+    if (r_ != ncclSuccess) {                                                              \
+      xvcgpu_comm *c_ = (comm_or_null);                                                   \
+      if (c_ && c_->in_group) {                                                           \
+        c_->in_group = false;                                                             \
+        rccl().GroupEnd();                                                                \
+      }                                                                                   \
       return comm_fail(ctx, XVCGPU_DEVICE_ERROR, #call, rccl().GetErrorString(r_));       \
+    }                                                                                     \
   } while (0)
+// every entry point runs on the context's device, whatever device the calling
+// thread had current (a process may hold contexts on several GPUs)
+#define ON_DEVICE(ctx) CHIP_TRY(ctx, hipSetDevice((ctx)->device))
 
 // the contiguous bytes of rows [y0, y1) of a plane, borders included
 void plane_rows(const PlaneView &p, int border, int y0, int y1, uint16_t **ptr, size_t *count) {
@@ -120,7 +138,8 @@ xvcgpu_status xvcgpu_event_create(xvcgpu_ctx *ctx, xvcgpu_event **out) {
   xvcgpu_event *e = new (std::nothrow) xvcgpu_event();
   if (!e) return XVCGPU_OUT_OF_MEMORY;
   e->ctx = ctx;
-  hipError_t r = hipEventCreateWithFlags(&e->ev, hipEventDisableTiming);
+  hipError_t r = hipSetDevice(ctx->device);
+  if (r == hipSuccess) r = hipEventCreateWithFlags(&e->ev, hipEventDisableTiming);
   if (r != hipSuccess) {
     delete e;
     return comm_fail(ctx, XVCGPU_DEVICE_ERROR, "hipEventCreateWithFlags", hipGetErrorString(r));
@@ -175,7 +194,9 @@ xvcgpu_status xvcgpu_comm_create(xvcgpu_ctx *ctx, const uint8_t id[XVCGPU_COMM_I
   c->rank = rank;
   c->comm = nullptr;
   c->stream = nullptr;
-  hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+  c->in_group = false;
+  hipError_t e = hipSetDevice(ctx->device);
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
   if (e != hipSuccess) {
     delete c;
     return comm_fail(ctx, XVCGPU_DEVICE_ERROR, "hipStreamCreateWithFlags", hipGetErrorString(e));
@@ -223,25 +244,31 @@ xvcgpu_status xvcgpu_comm_sync(xvcgpu_comm *comm) {
 
 xvcgpu_status xvcgpu_comm_group_begin(xvcgpu_comm *comm) {
   if (!comm) return XVCGPU_INVALID_ARGUMENT;
-  NCCL_TRY(comm->ctx, rccl().GroupStart());
+  ON_DEVICE(comm->ctx);
+  NCCL_TRY(nullptr, comm->ctx, rccl().GroupStart());
+  comm->in_group = true;
   return XVCGPU_OK;
 }
 
 xvcgpu_status xvcgpu_comm_group_end(xvcgpu_comm *comm) {
   if (!comm) return XVCGPU_INVALID_ARGUMENT;
-  NCCL_TRY(comm->ctx, rccl().GroupEnd());
+  ON_DEVICE(comm->ctx);
+  comm->in_group = false;
+  NCCL_TRY(nullptr, comm->ctx, rccl().GroupEnd());
   return XVCGPU_OK;
 }
 
 xvcgpu_status xvcgpu_comm_send_picture(xvcgpu_comm *comm, const xvcgpu_picture *pic, int dst) {
   if (!comm || !pic || dst < 0 || dst >= comm->world) return XVCGPU_INVALID_ARGUMENT;
-  NCCL_TRY(comm->ctx, rccl().Send(pic->base, pic->bytes, ncclUint8, dst, comm->comm, comm->stream));
+  ON_DEVICE(comm->ctx);
+  NCCL_TRY(comm, comm->ctx, rccl().Send(pic->base, pic->bytes, ncclUint8, dst, comm->comm, comm->stream));
   return XVCGPU_OK;
 }
 
 xvcgpu_status xvcgpu_comm_recv_picture(xvcgpu_comm *comm, xvcgpu_picture *pic, int src) {
   if (!comm || !pic || src < 0 || src >= comm->world) return XVCGPU_INVALID_ARGUMENT;
-  NCCL_TRY(comm->ctx, rccl().Recv(pic->base, pic->bytes, ncclUint8, src, comm->comm, comm->stream));
+  ON_DEVICE(comm->ctx);
+  NCCL_TRY(comm, comm->ctx, rccl().Recv(pic->base, pic->bytes, ncclUint8, src, comm->comm, comm->stream));
   return XVCGPU_OK;
 }
 
@@ -253,15 +280,16 @@ static xvcgpu_status rows_xfer(xvcgpu_comm *comm, const xvcgpu_picture *pic, int
     return XVCGPU_INVALID_ARGUMENT;
   const int bl = XVCGPU_BORDER_LUMA;
   if (y0 < -bl || y1 > pic->h + bl) return XVCGPU_INVALID_ARGUMENT;
+  ON_DEVICE(comm->ctx);
   for (int c = 0; c < 3; c++) {
     if (!(comp_mask & (1 << c))) continue;
     uint16_t *p;
     size_t n;
     plane_rows(pic->v.c[c], c ? bl / 2 : bl, c ? y0 / 2 : y0, c ? y1 / 2 : y1, &p, &n);
     if (send)
-      NCCL_TRY(comm->ctx, rccl().Send(p, 2 * n, ncclUint8, peer, comm->comm, comm->stream));
+      NCCL_TRY(comm, comm->ctx, rccl().Send(p, 2 * n, ncclUint8, peer, comm->comm, comm->stream));
     else
-      NCCL_TRY(comm->ctx, rccl().Recv(p, 2 * n, ncclUint8, peer, comm->comm, comm->stream));
+      NCCL_TRY(comm, comm->ctx, rccl().Recv(p, 2 * n, ncclUint8, peer, comm->comm, comm->stream));
   }
   return XVCGPU_OK;
 }
@@ -278,19 +306,22 @@ xvcgpu_status xvcgpu_comm_recv_rows(xvcgpu_comm *comm, xvcgpu_picture *pic, int 
 
 xvcgpu_status xvcgpu_comm_send_bytes(xvcgpu_comm *comm, const void *d_src, size_t bytes, int dst) {
   if (!comm || !d_src || !bytes || dst < 0 || dst >= comm->world) return XVCGPU_INVALID_ARGUMENT;
-  NCCL_TRY(comm->ctx, rccl().Send(d_src, bytes, ncclUint8, dst, comm->comm, comm->stream));
+  ON_DEVICE(comm->ctx);
+  NCCL_TRY(comm, comm->ctx, rccl().Send(d_src, bytes, ncclUint8, dst, comm->comm, comm->stream));
   return XVCGPU_OK;
 }
 
 xvcgpu_status xvcgpu_comm_recv_bytes(xvcgpu_comm *comm, void *d_dst, size_t bytes, int src) {
   if (!comm || !d_dst || !bytes || src < 0 || src >= comm->world) return XVCGPU_INVALID_ARGUMENT;
-  NCCL_TRY(comm->ctx, rccl().Recv(d_dst, bytes, ncclUint8, src, comm->comm, comm->stream));
+  ON_DEVICE(comm->ctx);
+  NCCL_TRY(comm, comm->ctx, rccl().Recv(d_dst, bytes, ncclUint8, src, comm->comm, comm->stream));
   return XVCGPU_OK;
 }
 
 xvcgpu_status xvcgpu_comm_all_reduce_sum_u64(xvcgpu_comm *comm, uint64_t *d_values, int n) {
   if (!comm || !d_values || n < 1) return XVCGPU_INVALID_ARGUMENT;
-  NCCL_TRY(comm->ctx, rccl().AllReduce(d_values, d_values, (size_t)n, ncclUint64, ncclSum,
+  ON_DEVICE(comm->ctx);
+  NCCL_TRY(comm, comm->ctx, rccl().AllReduce(d_values, d_values, (size_t)n, ncclUint64, ncclSum,
                                        comm->comm, comm->stream));
   return XVCGPU_OK;
 }

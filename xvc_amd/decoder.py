@@ -62,6 +62,8 @@ def plan_picture(ps, cus, levels):
     lv = np.ascontiguousarray(levels if len(levels) else np.zeros(1, np.int16), np.int16)
     n_waves = lib.xvc_host_plan_picture(ps.ctypes.data, cus.ctypes.data, lv.ctypes.data,
                                         nb.ctypes.data, wave.ctypes.data)
+    if n_waves < 0:
+        raise ValueError("malformed picture syntax (PictureDecoder::Validate)")
     return n_waves, nb, wave
 
 

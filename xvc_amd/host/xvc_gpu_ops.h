@@ -166,8 +166,13 @@ class InterSearch {
       const std::vector<xvcgpu_me_block> &blocks) const {
     DeviceArray<xvcgpu_me_block> d(ctx_, blocks);
     DeviceArray<xvcgpu_me_result> r(ctx_, blocks.size());
+    // CUs that try local illumination compensation search with the AC-only
+    // metrics (GetFullpelMetric / GetSubpelMetric): their own kernel instances
+    int lic = 0;
+    for (size_t i = 0; i < blocks.size(); i++)
+      if (blocks[i].fullpel_mv & XVC_ME_USE_LIC) lic = XVCGPU_ME_LIC_JOBS;
     ctx_.Check(xvcgpu_me_search(ctx_.get(), orig_pic.get(), ref_pic.get(),
-                                XVCGPU_ME_FULLPEL | XVCGPU_ME_SUBPEL, d.data(),
+                                XVCGPU_ME_FULLPEL | XVCGPU_ME_SUBPEL | lic, d.data(),
                                 static_cast<int>(blocks.size()), r.data()));
     return r.ToHost();
   }
@@ -225,7 +230,9 @@ class InterSearch {
         c.y = blocks[i].y;
         c.w = blocks[i].w;
         c.h = blocks[i].h;
-        c.metric = XVC_METRIC_SAD;       // GetMvpMetricType (inter_search.cc:1078)
+        // GetMvpMetricType (inter_search.cc:1078-1080): kSad for every CU, also
+        // one that tries local illumination compensation
+        c.metric = XVC_METRIC_SAD;
         c.mv_x = mvp[i][2 * k];
         c.mv_y = mvp[i][2 * k + 1];
         cands.push_back(c);
@@ -296,7 +303,9 @@ class InterSearch {
       }
       const std::vector<xvcgpu_me_result> res = MotionEstNormalBatch(orig_pic, *ref_pics[r], jobs);
       for (size_t i = 0; i < jobs.size(); i++) {
-        const bool fp = jobs[i].fullpel_mv != 0;
+        const bool fp = (jobs[i].fullpel_mv & XVC_ME_FULLPEL_MV) != 0;
+        if (res[i].subpel_dist == XVCGPU_ME_UNSUPPORTED)
+          throw Error(XVCGPU_UNSUPPORTED, "SearchRefIdxBatch: a job the device search does not take");
         const int idx = EvalFinalMvpIdx(mvp[r][i], res[i].mv_x, res[i].mv_y, start[i].idx, fp);
         const uint32_t bits = side_bits[r][i] + GetMvpBits(idx, 2) +
                               GetMvdBits(mvp[r][i][2 * idx], mvp[r][i][2 * idx + 1], res[i].mv_x,

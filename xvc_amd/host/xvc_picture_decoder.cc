@@ -27,7 +27,59 @@ struct CellMap {
 
 inline int Max(int a, int b) { return a > b ? a : b; }
 
+inline bool IsBlockSize(int v) { return v == 4 || v == 8 || v == 16 || v == 32 || v == 64; }
+
 }  // namespace
+
+// The syntax comes from a bitstream: nothing in it may index outside the cell
+// map, the reference table or the level array.  (The reference asserts the same
+// invariants while parsing - cu_reader.cc; here they are one check per CU
+// before anything is planned.)
+bool PictureDecoder::Validate(const xvc_picture_syntax &ps, const xvc_cu_syntax *cus,
+                              const int16_t *levels) {
+  if (ps.width <= 0 || ps.height <= 0 || ps.width > 16384 || ps.height > 16384 || ps.n_cus <= 0 ||
+      !cus || ps.n_levels < 0 || (ps.n_levels > 0 && !levels))
+    return false;
+  if (ps.pic_type != XVC_PIC_BI && ps.pic_type != XVC_PIC_UNI && ps.pic_type != XVC_PIC_INTRA)
+    return false;
+  for (int l = 0; l < 2; l++)
+    if (ps.num_ref[l] < 0 || ps.num_ref[l] > 5) return false;
+  // CTU-aligned picture (the cell map holds one more column / row than that)
+  const int aw = (ps.width + 63) & ~63, ah = (ps.height + 63) & ~63;
+  const bool intra_pic = ps.pic_type == XVC_PIC_INTRA;
+  for (int i = 0; i < ps.n_cus; i++) {
+    const xvc_cu_syntax &cu = cus[i];
+    if (cu.tree > 1 || (cu.tree == 1 && !intra_pic)) return false;
+    if (!IsBlockSize(cu.w) || !IsBlockSize(cu.h)) return false;
+    if (cu.x < 0 || cu.y < 0 || (cu.x & 3) || (cu.y & 3) || cu.x + cu.w > aw || cu.y + cu.h > ah)
+      return false;
+    if (cu.pred_mode > 1) return false;
+    const bool has_luma = cu.tree == 0, has_chroma = cu.tree == 1 || !intra_pic;
+    if (cu.pred_mode == 1) {
+      if (intra_pic || cu.inter_dir > 2) return false;
+      for (int l = 0; l < 2; l++) {
+        const bool used = cu.inter_dir == 2 || cu.inter_dir == l;
+        if (used && (cu.ref_idx[l] < 0 || cu.ref_idx[l] >= ps.num_ref[l])) return false;
+      }
+      if ((cu.flags & XVC_CU_AFFINE) && (cu.flags & XVC_CU_LIC)) return false;
+    } else {
+      for (int c = has_luma ? 0 : 1; c < (has_chroma ? 3 : 1); c++)
+        if (cu.intra_mode[c] != XVC_CU_INTRA_LM &&
+            (cu.intra_mode[c] < 0 || cu.intra_mode[c] >= XVC_INTRA_NUM_MODES))
+          return false;
+      if (has_luma && cu.intra_mode[0] == XVC_CU_INTRA_LM) return false;
+    }
+    for (int c = has_luma ? 0 : 1; c < (has_chroma ? 3 : 1); c++) {
+      if (cu.tx_type[c][0] > XVC_TX_DST7 || cu.tx_type[c][1] > XVC_TX_DST7) return false;
+      if (!cu.cbf[c]) continue;
+      const int cs = c ? 1 : 0;
+      const uint64_t end = static_cast<uint64_t>(cu.level_off[c]) +
+                           static_cast<uint64_t>(cu.w >> cs) * (cu.h >> cs);
+      if (end > static_cast<uint64_t>(ps.n_levels)) return false;
+    }
+  }
+  return true;
+}
 
 void PictureDecoder::Plan(const xvc_picture_syntax &ps, const xvc_cu_syntax *cus,
                           const int16_t *levels, PicturePlan *plan) {
@@ -296,6 +348,7 @@ xvcgpu_status PictureDecoder::Decode(const xvc_picture_syntax &ps, const xvc_cu_
   if (!pred_ || !rec || !cus || ps.width != width_ || ps.height != height_ ||
       ps.bitdepth != bitdepth_ || ps.n_cus <= 0 || (ps.n_levels > 0 && !levels))
     return XVCGPU_INVALID_ARGUMENT;
+  if (!Validate(ps, cus, levels)) return XVCGPU_INVALID_ARGUMENT;
   Plan(ps, cus, levels, &plan_);
   const PicturePlan &p = plan_;
 
@@ -433,6 +486,7 @@ int xvc_host_picture_decoder_launches(const xvc_host_picture_decoder *d) {
 int xvc_host_plan_picture(const xvc_picture_syntax *ps, const xvc_cu_syntax *cus,
                           const int16_t *levels, uint8_t *neighbors_out, int32_t *wave_out) {
   if (!ps || !cus) return -1;
+  if (!xvc_gpu::PictureDecoder::Validate(*ps, cus, levels)) return -1;
   xvc_gpu::PicturePlan plan;
   xvc_gpu::PictureDecoder::Plan(*ps, cus, levels, &plan);
   for (int i = 0; i < ps->n_cus; i++) {

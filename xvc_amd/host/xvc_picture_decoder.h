@@ -77,6 +77,11 @@ class PictureDecoder {
   PictureDecoder(const PictureDecoder &) = delete;
   PictureDecoder &operator=(const PictureDecoder &) = delete;
 
+  // Host-only: does every field of the parsed syntax stay inside the picture,
+  // the reference lists and the level array?  Decode refuses a picture that
+  // does not (XVCGPU_INVALID_ARGUMENT); Plan may only be given one that does.
+  static bool Validate(const xvc_picture_syntax &ps, const xvc_cu_syntax *cus,
+                       const int16_t *levels);
   // Host-only: the schedule and job lists for a picture.
   static void Plan(const xvc_picture_syntax &ps, const xvc_cu_syntax *cus, const int16_t *levels,
                    PicturePlan *plan);

@@ -465,6 +465,9 @@ class FramePass:
             if b is not None:
                 b.free()
         self.pred.destroy()
+        if self.scratch is not None:
+            self.scratch.destroy()
+            self.scratch = None
 
 
 class PipelinedFramePass:
@@ -526,10 +529,14 @@ class PipelinedFramePass:
         self.bot.d_cus = None
         for fp in (self.top, self.bot):
             for b in (fp.d_me, fp.d_tx, fp.d_luma_idx, fp.d_map, fp.d_res, fp.d_nnz,
-                      fp.d_cus, fp.d_ssd, fp.d_levels, fp.d_level_off):
+                      fp.d_cus, fp.d_ssd, fp.d_levels, fp.d_level_off,
+                      fp.d_rdoq_ctx, fp.d_rdoq_prm, fp.d_coeffs):
                 if b is not None:
                     b.free()
             fp.pred.destroy()
+            if fp.scratch is not None:
+                fp.scratch.destroy()
+                fp.scratch = None
 
 
 class DecodePass:
