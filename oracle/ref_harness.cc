@@ -104,10 +104,76 @@ private:
   int search_range_;
 };
 }  // namespace xvc
+/* Observation hooks for the REST of the RD search (tools/gen_rd_golden.py):
+ *  - SearchRefIdx (inter_search.cc:456-578) stores every search result with
+ *    cu->SetMvpIdx(mvp_idx, ref_list) (:556); with the function-like macro below
+ *    that statement is followed by xr_rd::AfterMotionEst(...), which sees the
+ *    loop's locals: the vector and distortion MotionEstimation returned, the
+ *    predictor list, the bootstrap vector.  It records the bi-prediction
+ *    refinement steps (FullSearch + sub-pel on the 2 * orig - other target) and
+ *    the affine searches (MotionEstAffine, uni and bi).  The one other
+ *    SetMvpIdx statement of the file (:510, the force_mvd_zero branch) has no
+ *    `mv` / `dist` in scope: there the names resolve to the two XrNone dummies
+ *    declared below and the overload for them does nothing.
+ *  - SearchMergeCandidates (:165-197) sorts its five candidates' costs with
+ *    std::stable_sort (:184); the macro appends xr_rd::AfterMergeSort(...),
+ *    which sees the candidate list and the sorted (index, cost) pairs.
+ *  - TransformEncoder::TransformAndReconstruct (transform_encoder.cc:203-285) is
+ *    compiled below as part of this file with two more macros (see there).
+ * Nothing of the reference's control flow is restated: the encoder runs its own
+ * code, the hooks only read. */
+#include "xvc_enc_lib/cu_writer.h"
+namespace xvc {
+struct XrNone {};
+static const XrNone mv = XrNone(), dist = XrNone();
+}  // namespace xvc
+namespace xr_rd {
+template <typename MV, size_t N>
+void AfterMotionEst(xvc::InterSearch *is, xvc::CodingUnit *cu, const xvc::Qp &qp,
+                    xvc::RefPicList ref_list, int ref_idx, bool bipred,
+                    const std::array<MV, N> &mvp_list, const MV *boot, const MV &mv,
+                    xvc::Distortion dist);
+template <typename MV, size_t N>
+inline void AfterMotionEst(xvc::InterSearch *, xvc::CodingUnit *, const xvc::Qp &,
+                           xvc::RefPicList, int, bool, const std::array<MV, N> &, const MV *,
+                           const xvc::XrNone &, const xvc::XrNone &) {}
+void AfterMergeSort(xvc::InterSearch *is, xvc::CodingUnit *cu, const xvc::Qp &qp,
+                    const xvc::InterMergeCandidateList &merge_list,
+                    const std::array<std::pair<int, double>, 5> &cand_cost);
+void AfterQuantRdo(xvc::TransformEncoder *te, xvc::CodingUnit *cu, xvc::YuvComponent comp,
+                   const xvc::Qp &qp, const xvc::SyntaxWriter &writer, int non_zero,
+                   const xvc::YuvPicture &rec_pic);
+xvc::Distortion AfterCompare(xvc::TransformEncoder *te, xvc::CodingUnit *cu,
+                             xvc::YuvComponent comp, const xvc::YuvPicture &orig_pic,
+                             const xvc::SampleBuffer &buffer, const char *func);
+}  // namespace xr_rd
+#define SetMvpIdx(i, l) \
+  SetMvpIdx(i, l);      \
+  xr_rd::AfterMotionEst(this, cu, qp, ref_list, ref_idx, bipred, mvp_list, mv_bootstrap, mv, dist)
+#define stable_sort(a, b, c) \
+  stable_sort(a, b, c);      \
+  xr_rd::AfterMergeSort(this, cu, qp, merge_list, cand_cost)
 #define TzSearch ObservedTzSearch
 /* member templates (SubpelSearch<>, ...) are defined only in the .cc */
 #include "xvc_enc_lib/inter_search.cc"
 #undef TzSearch
+#undef SetMvpIdx
+#undef stable_sort
+/* TransformEncoder::TransformAndReconstruct: after its quantiser call
+ * (fwd_quant_.QuantRdo(...), transform_encoder.cc:231-234) the hook records the
+ * call - CU, component, transform choice, the CU's motion state, the context
+ * states the quantiser read - and the levels it produced; the distortion
+ * comparison that ends the function (:284) completes the record with the
+ * reconstruction.  CompressAndEvalTransform's cbf-zero comparison (:116-117)
+ * goes through the same macro and is recorded as the component's dist_zero. */
+#define QuantRdo(a, b, c, d, e, f, g, h, i) \
+  QuantRdo(a, b, c, d, e, f, g, h, i);      \
+  xr_rd::AfterQuantRdo(this, cu, comp, qp, syntax_writer, non_zero, *rec_pic)
+#define CompareSample(a, b, c, d) \
+  CompareSample(a, b, c, d) + xr_rd::AfterCompare(this, cu, comp, c, d, __func__)
+#include "xvc_enc_lib/transform_encoder.cc"
+#undef QuantRdo
+#undef CompareSample
 /* IntraPrediction::NeighborState (argument of ComputeRefSamples) likewise */
 #include "xvc_common_lib/intra_prediction.cc"
 #undef private
@@ -1743,4 +1809,508 @@ int xr_quant_rdo(int bd, int qp_raw_luma, double lambda, int comp, int scan_orde
   r.disable_transform_sign_hiding = saved;
   return nnz;
 }
+}  // extern "C"
+
+/* ---- RD-search capture (tools/gen_rd_golden.py) ----------------------------
+ * Records, while the reference encoder codes a picture, every bi-prediction
+ * refinement step, affine motion search, merge-candidate ranking and inter-CU
+ * TransformAndReconstruct it makes - inputs and results - through the hooks
+ * declared at the top of this file.  Layouts mirrored by numpy dtypes in
+ * tools/gen_rd_golden.py (sizes checked). */
+namespace xr_rd {
+using namespace xvc;  // NOLINT
+
+enum { kBi = 1, kAffineUni = 2, kAffineBi = 3 };
+enum { kFlagFullpel = 1, kFlagLic = 2, kFlagHasBoot = 4, kFlagAffine = 8, kFlagMerge = 16,
+       kFlagSkip = 32 };
+
+struct MeStep {            /* one MotionEstimation call of SearchRefIdx */
+  int32_t poc;
+  int16_t x, y;
+  uint8_t w, h, kind, flags;
+  uint8_t list;            /* the searched list */
+  int8_t ref_idx, other_ref_idx;
+  uint8_t start_mvp_idx, final_mvp_idx, pad[3];
+  int32_t ref_poc, other_ref_poc;
+  uint32_t lambda16;
+  int32_t mvp[2][3][2];    /* the list's two predictors ([k][0] for a plain vector) */
+  int32_t boot[3][2];
+  int32_t other_mv[3][2];  /* the other list's vector(s) the target was formed with */
+  int32_t mv[3][2];        /* result */
+  uint32_t dist;           /* *out_dist */
+  int32_t nb_index;        /* LIC CUs: which Neighbours record (-1: none) */
+};
+
+struct MergeCall {         /* one SearchMergeCandidates */
+  int32_t poc;
+  int16_t x, y;
+  uint8_t w, h, pad[2];
+  double lambda_sqrt;
+  uint8_t inter_dir[5], use_lic[5];
+  int8_t ref_idx[5][2];
+  int32_t ref_poc[5][2];
+  int32_t mv[5][2][2];
+  int32_t order[5];        /* candidate indices after the stable sort */
+  double cost[5];          /* their costs, same order */
+  int32_t num;             /* the function's return value (:186-195) */
+  int32_t nb_index;        /* a candidate with use_lic: which Neighbours record (else -1) */
+};
+
+struct Eval {              /* the CU state a group of transform calls shares */
+  int32_t poc;
+  int16_t x, y;
+  uint8_t w, h, inter_dir, flags;
+  int8_t ref_idx[2];
+  int8_t qp[3];            /* qp.GetQpRaw(comp) */
+  uint8_t pad;
+  int32_t ref_poc[2];
+  int32_t mv[2][3][2];
+  int32_t ctx_index;       /* which context snapshot */
+  int32_t qp_index;        /* which QpParams */
+  int32_t nb_index;        /* LIC CUs: which Neighbours record (-1: none) */
+  int32_t pad2;
+  uint64_t dist_zero[3];   /* CompressAndEvalTransform's cbf-zero distortion (~0: not evaluated) */
+};
+
+struct QpParams {          /* what the quantiser / metrics take from the Qp */
+  int8_t qp_raw[3];
+  uint8_t pad[5];
+  int64_t lambda[3];       /* (int64)(GetLambdaScaled(comp) * 65536 + 0.5) */
+  int64_t rd_factor[3];    /* rdo_quant.cc:590-594 */
+  double dist_weight[3];   /* Qp::GetDistortionWeight(comp) */
+};
+
+/* What the local illumination model of a CU reads besides the reference
+ * picture (DeriveLicParams, inter_prediction.cc:1577-1663): the CUs above / left
+ * (their positions: ClipMv) and the CURRENT reconstruction's row above / column
+ * left of the block, per component - state of the RD search at that moment, not
+ * of the final picture.  samples: for comp 0,1,2: the row (w_c samples, if
+ * has_above) then the column (h_c samples, if has_left), at sample_off in the
+ * sample array. */
+struct Neighbours {
+  int16_t x, y;
+  uint8_t w, h, has_above, has_left;
+  int16_t above_x, above_y, left_x, left_y;
+  uint32_t sample_off, sample_count;
+};
+
+struct TxCall {            /* one TransformAndReconstruct */
+  int32_t eval;
+  uint8_t comp, tx_skip, tx_hor, tx_ver, scan, completed;
+  int8_t tx_select_idx;
+  uint8_t pad;
+  int32_t nnz;             /* QuantRdo's return value */
+  uint32_t levels_crc;     /* CRC-32 of the w x h levels, row-major */
+  uint32_t rec_crc;        /* CRC-32 of the reconstruction block (completed calls) */
+  uint32_t pad2;
+  uint64_t dist;           /* the returned distortion (completed calls) */
+};
+
+bool g_capture = false;
+int g_only_poc = -1;
+std::vector<MeStep> g_steps;
+std::vector<MergeCall> g_merges;
+std::vector<Eval> g_evals;
+std::vector<QpParams> g_qps;
+std::vector<TxCall> g_calls;
+std::vector<xvcgpu_rdoq_contexts> g_ctx;
+std::vector<Neighbours> g_nb;
+std::vector<uint16_t> g_nb_samples;
+std::unordered_map<std::string, int> g_ctx_index, g_qp_index, g_nb_index;
+long g_skipped_intra = 0;
+const CodingUnit *g_pending_cu = nullptr;
+int g_pending_call = -1;
+
+static bool Wanted(const CodingUnit &cu) {
+  return g_capture &&
+         (g_only_poc < 0 || static_cast<int>(cu.GetPicData()->GetPoc()) == g_only_poc);
+}
+
+static uint32_t Crc32(uint32_t crc, const void *data, size_t n) {
+  static uint32_t table[256];
+  static bool init = false;
+  if (!init) {
+    for (uint32_t i = 0; i < 256; i++) {
+      uint32_t c = i;
+      for (int k = 0; k < 8; k++) c = (c & 1) ? 0xedb88320u ^ (c >> 1) : c >> 1;
+      table[i] = c;
+    }
+    init = true;
+  }
+  const uint8_t *p = static_cast<const uint8_t *>(data);
+  crc = ~crc;
+  for (size_t i = 0; i < n; i++) crc = table[(crc ^ p[i]) & 255] ^ (crc >> 8);
+  return ~crc;
+}
+
+static void PutMv(int32_t out[3][2], const MotionVector &m) {
+  out[0][0] = m.x;
+  out[0][1] = m.y;
+}
+static void PutMv(int32_t out[3][2], const MotionVector3 &m) {
+  for (int k = 0; k < 3; k++) {
+    out[k][0] = m[k].x;
+    out[k][1] = m[k].y;
+  }
+}
+static void OtherMv(const CodingUnit &cu, RefPicList l, const MotionVector *, int32_t out[3][2]) {
+  PutMv(out, cu.GetMv(l, MvCorner::kDefault));
+}
+static void OtherMv(const CodingUnit &cu, RefPicList l, const MotionVector3 *, int32_t out[3][2]) {
+  PutMv(out, cu.GetMvAffine(l));
+}
+
+static int NeighbourIndex(const CodingUnit &cu, const YuvPicture &rec_pic, bool force = false) {
+  if (!cu.GetUseLic() && !force) return -1;
+  const YuvComponent luma = YuvComponent::kY;
+  Neighbours n;
+  std::memset(&n, 0, sizeof(n));
+  n.x = static_cast<int16_t>(cu.GetPosX(luma));
+  n.y = static_cast<int16_t>(cu.GetPosY(luma));
+  n.w = static_cast<uint8_t>(cu.GetWidth(luma));
+  n.h = static_cast<uint8_t>(cu.GetHeight(luma));
+  const CodingUnit *above = cu.GetCodingUnitAbove(), *left = cu.GetCodingUnitLeft();
+  n.has_above = above != nullptr;
+  n.has_left = left != nullptr;
+  if (above) {
+    n.above_x = static_cast<int16_t>(above->GetPosX(luma));
+    n.above_y = static_cast<int16_t>(above->GetPosY(luma));
+  }
+  if (left) {
+    n.left_x = static_cast<int16_t>(left->GetPosX(luma));
+    n.left_y = static_cast<int16_t>(left->GetPosY(luma));
+  }
+  std::vector<uint16_t> smp;
+  for (int c = 0; c < 3; c++) {
+    const YuvComponent comp = YuvComponent(c);
+    const int x = cu.GetPosX(comp), y = cu.GetPosY(comp);
+    const int w = cu.GetWidth(comp), h = cu.GetHeight(comp);
+    if (above)
+      for (int i = 0; i < w; i++) smp.push_back(*rec_pic.GetSamplePtr(comp, x + i, y - 1));
+    if (left)
+      for (int i = 0; i < h; i++) smp.push_back(*rec_pic.GetSamplePtr(comp, x - 1, y + i));
+  }
+  n.sample_count = static_cast<uint32_t>(smp.size());
+  std::string key(reinterpret_cast<const char *>(&n), sizeof(n));
+  key.append(reinterpret_cast<const char *>(smp.data()), smp.size() * sizeof(uint16_t));
+  auto it = g_nb_index.find(key);
+  if (it != g_nb_index.end()) return it->second;
+  n.sample_off = static_cast<uint32_t>(g_nb_samples.size());
+  g_nb_samples.insert(g_nb_samples.end(), smp.begin(), smp.end());
+  const int idx = static_cast<int>(g_nb.size());
+  g_nb.push_back(n);
+  g_nb_index.emplace(key, idx);
+  return idx;
+}
+
+template <typename MV, size_t N>
+void AfterMotionEst(InterSearch *is, CodingUnit *cu, const Qp &qp, RefPicList ref_list,
+                    int ref_idx, bool bipred, const std::array<MV, N> &mvp_list, const MV *boot,
+                    const MV &mv, Distortion dist) {
+  if (!Wanted(*cu)) return;
+  const bool affine = std::is_same<MV, MotionVector3>::value;
+  if (!bipred && !affine) return;   /* the TZ searches are tools/gen_me_golden.py's */
+  const int li = static_cast<int>(ref_list);
+  if (!bipred && ref_list == RefPicList::kL1 && is->same_poc_in_l0_mapping_[ref_idx] >= 0)
+    return;                         /* list 0's result reused (:536-542): no search */
+  assert(is->encoder_settings_.bipred_refinement_iterations == 1);
+  const YuvComponent luma = YuvComponent::kY;
+  MeStep s;
+  std::memset(&s, 0, sizeof(s));
+  s.poc = static_cast<int32_t>(cu->GetPicData()->GetPoc());
+  s.x = static_cast<int16_t>(cu->GetPosX(luma));
+  s.y = static_cast<int16_t>(cu->GetPosY(luma));
+  s.w = static_cast<uint8_t>(cu->GetWidth(luma));
+  s.h = static_cast<uint8_t>(cu->GetHeight(luma));
+  s.kind = static_cast<uint8_t>(affine ? (bipred ? kAffineBi : kAffineUni) : kBi);
+  s.flags = static_cast<uint8_t>((cu->GetFullpelMv() ? kFlagFullpel : 0) |
+                                 (cu->GetUseLic() ? kFlagLic : 0) | (boot ? kFlagHasBoot : 0));
+  s.list = static_cast<uint8_t>(li);
+  s.ref_idx = static_cast<int8_t>(ref_idx);
+  const ReferencePictureLists *rpl = cu->GetRefPicLists();
+  s.ref_poc = static_cast<int32_t>(rpl->GetRefPoc(ref_list, ref_idx));
+  s.other_ref_idx = -1;
+  s.other_ref_poc = -1;
+  if (bipred) {
+    const RefPicList other = ReferencePictureLists::Inverse(ref_list);
+    s.other_ref_idx = static_cast<int8_t>(cu->GetRefIdx(other));
+    s.other_ref_poc = static_cast<int32_t>(rpl->GetRefPoc(other, cu->GetRefIdx(other)));
+    OtherMv(*cu, other, static_cast<const MV *>(nullptr), s.other_mv);
+    /* the predictor the uni-directional search of this (list, picture) ended on
+     * (:485-489; untouched by this call with one refinement iteration) */
+    s.start_mvp_idx = static_cast<uint8_t>(is->unipred_best_mvp_idx_[li][ref_idx]);
+  } else {
+    /* the start predictor is EvalStartMvp's choice (:493-496); mvp_idx has been
+     * overwritten by EvalFinalMvpIdx since: ask the reference again (a pure
+     * function of CU, predictors and pictures; scratch prediction buffer) */
+    SampleBufferStorage scratch(constants::kMaxBlockSize, constants::kMaxBlockSize);
+    Distortion cost = 0;
+    s.start_mvp_idx = static_cast<uint8_t>(is->EvalStartMvp<std::is_same<MV, MotionVector3>::value>(
+        *cu, qp, mvp_list, *rpl->GetRefPic(ref_list, ref_idx), &scratch, &cost));
+  }
+  s.final_mvp_idx = static_cast<uint8_t>(cu->GetMvpIdx(ref_list));
+  s.lambda16 = static_cast<uint32_t>(std::floor(65536.0 * qp.GetLambdaSqrt()));
+  for (size_t k = 0; k < N && k < 2; k++) PutMv(s.mvp[k], mvp_list[k]);
+  if (boot) PutMv(s.boot, *boot);
+  PutMv(s.mv, mv);
+  s.dist = static_cast<uint32_t>(dist);
+  s.nb_index = bipred ? NeighbourIndex(*cu, is->rec_pic_) : -1;
+  g_steps.push_back(s);
+}
+template void AfterMotionEst<MotionVector, 2>(InterSearch *, CodingUnit *, const Qp &, RefPicList,
+                                              int, bool, const std::array<MotionVector, 2> &,
+                                              const MotionVector *, const MotionVector &,
+                                              Distortion);
+template void AfterMotionEst<MotionVector3, 2>(InterSearch *, CodingUnit *, const Qp &,
+                                               RefPicList, int, bool,
+                                               const std::array<MotionVector3, 2> &,
+                                               const MotionVector3 *, const MotionVector3 &,
+                                               Distortion);
+
+void AfterMergeSort(InterSearch *is, CodingUnit *cu, const Qp &qp,
+                    const InterMergeCandidateList &merge_list,
+                    const std::array<std::pair<int, double>, 5> &cand_cost) {
+  if (!Wanted(*cu)) return;
+  const YuvComponent luma = YuvComponent::kY;
+  MergeCall m;
+  std::memset(&m, 0, sizeof(m));
+  m.poc = static_cast<int32_t>(cu->GetPicData()->GetPoc());
+  m.x = static_cast<int16_t>(cu->GetPosX(luma));
+  m.y = static_cast<int16_t>(cu->GetPosY(luma));
+  m.w = static_cast<uint8_t>(cu->GetWidth(luma));
+  m.h = static_cast<uint8_t>(cu->GetHeight(luma));
+  m.lambda_sqrt = qp.GetLambdaSqrt();
+  const ReferencePictureLists *rpl = cu->GetRefPicLists();
+  for (int k = 0; k < 5; k++) {
+    const MergeCandidate &c = merge_list[k];
+    m.inter_dir[k] = static_cast<uint8_t>(c.inter_dir);
+    m.use_lic[k] = c.use_lic;
+    for (int l = 0; l < 2; l++) {
+      const bool used = c.inter_dir == InterDir::kBi || static_cast<int>(c.inter_dir) == l;
+      m.ref_idx[k][l] = static_cast<int8_t>(used ? c.ref_idx[l] : -1);
+      m.ref_poc[k][l] =
+          used ? static_cast<int32_t>(rpl->GetRefPoc(static_cast<RefPicList>(l), c.ref_idx[l])) : -1;
+      m.mv[k][l][0] = c.mv[l].x;
+      m.mv[k][l][1] = c.mv[l].y;
+    }
+    m.order[k] = cand_cost[k].first;
+    m.cost[k] = cand_cost[k].second;
+  }
+  /* the function's tail (:186-195) on the sorted costs */
+  m.num = InterSearch::kFastMergeNumCand;
+  for (int k = InterSearch::kFastMergeNumCand; k >= 0; k--)
+    if (cand_cost[k].second > cand_cost[0].second * InterSearch::kFastMergeCostFactor) m.num = k;
+  bool any_lic = false;
+  for (int k = 0; k < 5; k++) any_lic |= m.use_lic[k] != 0;
+  m.nb_index = any_lic ? NeighbourIndex(*cu, is->rec_pic_, true) : -1;
+  g_merges.push_back(m);
+}
+
+static int ContextIndex(const SyntaxWriter &writer) {
+  xvcgpu_rdoq_contexts c;
+  StoreContexts(writer.GetContexts(), &c);
+  std::string key(reinterpret_cast<const char *>(&c), sizeof(c));
+  auto it = g_ctx_index.find(key);
+  if (it != g_ctx_index.end()) return it->second;
+  const int idx = static_cast<int>(g_ctx.size());
+  g_ctx.push_back(c);
+  g_ctx_index.emplace(key, idx);
+  return idx;
+}
+
+static int QpIndex(const Qp &qp, int bd) {
+  QpParams q;
+  std::memset(&q, 0, sizeof(q));
+  for (int c = 0; c < 3; c++) {
+    const YuvComponent yc = YuvComponent(c);
+    q.qp_raw[c] = static_cast<int8_t>(qp.GetQpRaw(yc));
+    const double lam = qp.GetLambdaScaled(yc);
+    const double inv_scale = qp.GetInvScale(yc);
+    q.lambda[c] = static_cast<int64_t>(lam * (1 << 16) + 0.5);
+    q.rd_factor[c] = static_cast<int64_t>(inv_scale * inv_scale / lam / 16 /
+                                          (1ull << (2 * (bd - 8))) + 0.5);
+    q.dist_weight[c] = qp.GetDistortionWeight(yc);
+  }
+  std::string key(reinterpret_cast<const char *>(&q), sizeof(q));
+  auto it = g_qp_index.find(key);
+  if (it != g_qp_index.end()) return it->second;
+  const int idx = static_cast<int>(g_qps.size());
+  g_qps.push_back(q);
+  g_qp_index.emplace(key, idx);
+  return idx;
+}
+
+static int EvalIndex(const CodingUnit &cu, const Qp &qp, const SyntaxWriter &writer, int bd,
+                     const YuvPicture &rec_pic) {
+  const YuvComponent luma = YuvComponent::kY;
+  Eval e;
+  std::memset(&e, 0, sizeof(e));
+  e.poc = static_cast<int32_t>(cu.GetPicData()->GetPoc());
+  e.x = static_cast<int16_t>(cu.GetPosX(luma));
+  e.y = static_cast<int16_t>(cu.GetPosY(luma));
+  e.w = static_cast<uint8_t>(cu.GetWidth(luma));
+  e.h = static_cast<uint8_t>(cu.GetHeight(luma));
+  e.inter_dir = static_cast<uint8_t>(cu.GetInterDir());
+  e.flags = static_cast<uint8_t>((cu.GetFullpelMv() ? kFlagFullpel : 0) |
+                                 (cu.GetUseLic() ? kFlagLic : 0) |
+                                 (cu.GetUseAffine() ? kFlagAffine : 0) |
+                                 (cu.GetMergeFlag() ? kFlagMerge : 0));
+  const ReferencePictureLists *rpl = cu.GetRefPicLists();
+  for (int l = 0; l < 2; l++) {
+    const RefPicList rl = static_cast<RefPicList>(l);
+    const bool used = cu.GetInterDir() == InterDir::kBi || static_cast<int>(cu.GetInterDir()) == l;
+    e.ref_idx[l] = static_cast<int8_t>(used ? cu.GetRefIdx(rl) : -1);
+    e.ref_poc[l] = used ? static_cast<int32_t>(rpl->GetRefPoc(rl, cu.GetRefIdx(rl))) : -1;
+    if (!used) continue;
+    if (cu.GetUseAffine())
+      PutMv(e.mv[l], cu.GetMvAffine(rl));
+    else
+      PutMv(e.mv[l], cu.GetMv(rl, MvCorner::kDefault));
+  }
+  for (int c = 0; c < 3; c++) {
+    e.qp[c] = static_cast<int8_t>(qp.GetQpRaw(YuvComponent(c)));
+    e.dist_zero[c] = ~0ull;
+  }
+  e.ctx_index = ContextIndex(writer);
+  e.qp_index = QpIndex(qp, bd);
+  e.nb_index = NeighbourIndex(cu, rec_pic);
+  if (!g_evals.empty()) {
+    /* the calls of one CompressAndEvalCbf share the CU state: same record */
+    Eval last = g_evals.back();
+    for (int c = 0; c < 3; c++) last.dist_zero[c] = ~0ull;
+    if (std::memcmp(&last, &e, sizeof(e)) == 0) return static_cast<int>(g_evals.size()) - 1;
+  }
+  g_evals.push_back(e);
+  return static_cast<int>(g_evals.size()) - 1;
+}
+
+void AfterQuantRdo(TransformEncoder *te, CodingUnit *cu, YuvComponent comp, const Qp &qp,
+                   const SyntaxWriter &writer, int non_zero, const YuvPicture &rec_pic) {
+  g_pending_cu = nullptr;
+  if (!Wanted(*cu)) return;
+  if (!cu->IsInter()) {
+    g_skipped_intra++;
+    return;
+  }
+  const int bd = te->max_pel_ == 1023 ? 10 : (te->max_pel_ == 255 ? 8 : 12);
+  TxCall t;
+  std::memset(&t, 0, sizeof(t));
+  t.eval = EvalIndex(*cu, qp, writer, bd, rec_pic);
+  t.comp = static_cast<uint8_t>(comp);
+  t.tx_skip = cu->GetTransformSkip(comp);
+  t.tx_ver = static_cast<uint8_t>(cu->GetTransformType(comp, 0));
+  t.tx_hor = static_cast<uint8_t>(cu->GetTransformType(comp, 1));
+  t.scan = static_cast<uint8_t>(TransformHelper::DetermineScanOrder(*cu, comp));
+  t.tx_select_idx = static_cast<int8_t>(cu->GetTransformSelectIdx());
+  t.nnz = non_zero;
+  const int w = cu->GetWidth(comp), h = cu->GetHeight(comp);
+  CoeffBuffer coeff = cu->GetCoeff(comp);
+  uint32_t crc = 0;
+  for (int y = 0; y < h; y++)
+    crc = Crc32(crc, coeff.GetDataPtr() + y * coeff.GetStride(), sizeof(Coeff) * w);
+  t.levels_crc = crc;
+  g_calls.push_back(t);
+  g_pending_cu = cu;
+  g_pending_call = static_cast<int>(g_calls.size()) - 1;
+}
+
+Distortion AfterCompare(TransformEncoder *te, CodingUnit *cu, YuvComponent comp,
+                        const YuvPicture &orig_pic, const SampleBuffer &buffer, const char *func) {
+  if (!Wanted(*cu) || !cu->IsInter()) return 0;
+  const bool reconstruct = func[0] == 'T';   /* TransformAndReconstruct / CompressAndEvalTransform */
+  const Distortion d = te->cu_metric_.CompareSample(*cu, comp, orig_pic, buffer);
+  if (!reconstruct) {
+    /* cbf-zero distortion of the component: prediction against the original */
+    if (!g_evals.empty()) {
+      Eval &e = g_evals.back();
+      const YuvComponent luma = YuvComponent::kY;
+      if (e.x == cu->GetPosX(luma) && e.y == cu->GetPosY(luma) && e.w == cu->GetWidth(luma) &&
+          e.h == cu->GetHeight(luma))
+        e.dist_zero[static_cast<int>(comp)] = d;
+    }
+    return 0;
+  }
+  if (g_pending_cu != cu || g_pending_call < 0) return 0;
+  TxCall &t = g_calls[g_pending_call];
+  if (t.comp != static_cast<uint8_t>(comp)) return 0;
+  const int w = cu->GetWidth(comp), h = cu->GetHeight(comp);
+  uint32_t crc = 0;
+  for (int y = 0; y < h; y++)
+    crc = Crc32(crc, buffer.GetDataPtr() + y * buffer.GetStride(), sizeof(Sample) * w);
+  t.rec_crc = crc;
+  t.dist = d;
+  t.completed = 1;
+  g_pending_cu = nullptr;
+  return 0;
+}
+
+}  // namespace xr_rd
+
+extern "C" {
+
+void xr_rd_capture_begin(int only_poc) {
+  using namespace xr_rd;  // NOLINT
+  g_steps.clear();
+  g_merges.clear();
+  g_evals.clear();
+  g_qps.clear();
+  g_calls.clear();
+  g_ctx.clear();
+  g_nb.clear();
+  g_nb_samples.clear();
+  g_ctx_index.clear();
+  g_qp_index.clear();
+  g_nb_index.clear();
+  g_skipped_intra = 0;
+  g_pending_cu = nullptr;
+  g_only_poc = only_poc;
+  g_capture = true;
+}
+void xr_rd_capture_end(void) { xr_rd::g_capture = false; }
+/* which: 0 MeStep, 1 MergeCall, 2 Eval, 3 QpParams, 4 TxCall, 5 contexts, 6 Neighbours,
+ * 7 their samples, 8 (count only) transform calls of intra CUs, not kept */
+long xr_rd_count(int which) {
+  using namespace xr_rd;  // NOLINT
+  switch (which) {
+    case 0: return static_cast<long>(g_steps.size());
+    case 1: return static_cast<long>(g_merges.size());
+    case 2: return static_cast<long>(g_evals.size());
+    case 3: return static_cast<long>(g_qps.size());
+    case 4: return static_cast<long>(g_calls.size());
+    case 5: return static_cast<long>(g_ctx.size());
+    case 6: return static_cast<long>(g_nb.size());
+    case 7: return static_cast<long>(g_nb_samples.size());
+    case 8: return g_skipped_intra;
+  }
+  return -1;
+}
+int xr_rd_size(int which) {
+  using namespace xr_rd;  // NOLINT
+  switch (which) {
+    case 0: return sizeof(MeStep);
+    case 1: return sizeof(MergeCall);
+    case 2: return sizeof(Eval);
+    case 3: return sizeof(QpParams);
+    case 4: return sizeof(TxCall);
+    case 5: return sizeof(xvcgpu_rdoq_contexts);
+    case 6: return sizeof(Neighbours);
+    case 7: return sizeof(uint16_t);
+  }
+  return -1;
+}
+const void *xr_rd_data(int which) {
+  using namespace xr_rd;  // NOLINT
+  switch (which) {
+    case 0: return g_steps.data();
+    case 1: return g_merges.data();
+    case 2: return g_evals.data();
+    case 3: return g_qps.data();
+    case 4: return g_calls.data();
+    case 5: return g_ctx.data();
+    case 6: return g_nb.data();
+    case 7: return g_nb_samples.data();
+  }
+  return nullptr;
+}
+
 }  // extern "C"

@@ -1,0 +1,415 @@
+"""Replays the RD-search calls of a real encoder run (tests/golden/rd_calls_*.npz,
+tests/rd_fixture.py) as device batches through the C-ABI entry points and
+compares every call with what the reference encoder got.  Used by
+tests/test_gpu_rd_calls.py and by bench.py's `encoder_rd_batches` figure.
+
+Blocks of the RD search overlap (the CU recursion evaluates every size at every
+position, several modes each) while the entry points that write a prediction /
+reconstruction do so at the CU's own position in a picture: such calls are
+dealt into "layers" of non-overlapping blocks - a cell map holds, per 4x4 cell,
+the last layer that used it; a block goes into the layer after the highest one
+under its footprint (one numpy max + fill per block)."""
+import time
+
+import numpy as np
+
+import rd_fixture as rf
+from xvc_amd import synth
+
+BL = 128
+
+
+def original_planes(w, h, poc):
+    """The encoder's internal original: the 8-bit synthetic frame at the internal
+    bit depth of 10 (Resampler: plain left shift), padded."""
+    planes = synth.SyntheticClip(w, h, 8).frame(poc)
+    return [np.ascontiguousarray(np.pad(p.astype(np.uint16) << 2, BL if c == 0 else BL // 2,
+                                        mode="edge")) for c, p in enumerate(planes)]
+
+
+def assign_layers(x, y, w, h, grow=0):
+    """-> layer index per block (capture order).  grow = 1: the footprint also
+    covers one cell above and to the left (the row / column a local illumination
+    model reads from the current reconstruction)."""
+    x4 = np.asarray(x, np.int64) // 4
+    y4 = np.asarray(y, np.int64) // 4
+    x1 = (np.asarray(x, np.int64) + np.asarray(w, np.int64) + 3) // 4
+    y1 = (np.asarray(y, np.int64) + np.asarray(h, np.int64) + 3) // 4
+    if grow:
+        x4 = np.maximum(x4 - 1, 0)
+        y4 = np.maximum(y4 - 1, 0)
+    last = np.full((int(y1.max()) + 1, int(x1.max()) + 1), -1, np.int32)
+    out = np.zeros(len(x4), np.int32)
+    for i in range(len(x4)):
+        v = last[y4[i]:y1[i], x4[i]:x1[i]]
+        k = int(v.max()) + 1
+        v[...] = k
+        out[i] = k
+    return out
+
+
+class Replay:
+    def __init__(self, api, ctx, name, pics, width, height):
+        """pics: {poc: device picture} - the stream's reconstructions."""
+        self.api, self.ctx, self.pics = api, ctx, pics
+        self.w, self.h = width, height
+        self.rd = rf.load(name)
+        self._orig = {}
+        self.timing = {}
+
+    def orig(self, poc):
+        if poc not in self._orig:
+            planes = original_planes(self.w, self.h, poc)
+            p = self.ctx.picture(self.w, self.h, 10)
+            p.upload(planes, BL)
+            self._orig[poc] = (p, planes)
+        return self._orig[poc]
+
+    def destroy(self):
+        for p, _ in self._orig.values():
+            p.destroy()
+        self._orig = {}
+
+    def _time(self, key, t0):
+        self.ctx.sync()
+        self.timing[key] = self.timing.get(key, 0.0) + time.time() - t0
+
+    # ---- bi-prediction refinement steps (SearchBiIterative, :392-433) ----------
+    def bi_steps(self, include_lic=False):
+        """-> (compared, mismatches, skipped LIC steps)"""
+        api, ctx = self.api, self.ctx
+        st = self.rd["steps"]
+        st = st[st["kind"] == rf.KIND_BI]
+        lic = (st["flags"] & rf.FLAG_LIC) != 0
+        skipped = 0 if include_lic else int(lic.sum())
+        if not include_lic:
+            st = st[~lic]
+        done = bad = 0
+        keys = np.stack([st["poc"], st["other_ref_poc"], st["ref_poc"]], 1)
+        for poc, opoc, rpoc in np.unique(keys, axis=0):
+            sel = st[(st["poc"] == poc) & (st["other_ref_poc"] == opoc) & (st["ref_poc"] == rpoc)]
+            jobs = np.zeros(len(sel), api.BI_DTYPE)
+            b = jobs["blk"]
+            for k in ("x", "y", "w", "h", "lambda16"):
+                b[k] = sel[k]
+            b["fullpel_mv"] = (sel["flags"] & rf.FLAG_FULLPEL) != 0
+            i = np.arange(len(sel))
+            start = sel["start_mvp_idx"].astype(np.int64)
+            b["mvp_x"] = sel["mvp"][i, start, 0, 0]
+            b["mvp_y"] = sel["mvp"][i, start, 0, 1]
+            b["search_range"] = 4
+            jobs["blk"] = b
+            jobs["other_mv_x"], jobs["other_mv_y"] = sel["other_mv"][:, 0, 0], sel["other_mv"][:, 0, 1]
+            jobs["boot_mv_x"], jobs["boot_mv_y"] = sel["boot"][:, 0, 0], sel["boot"][:, 0, 1]
+            assert ((sel["flags"] & rf.FLAG_HAS_BOOT) != 0).all()
+            O = self.orig(int(poc))[0]
+            t0 = time.time()
+            res = ctx.bipred_search(O, self.pics[int(opoc)], self.pics[int(rpoc)], jobs)
+            self._time("bi_steps", t0)
+            ok = ((res["mv_x"] == sel["mv"][:, 0, 0]) & (res["mv_y"] == sel["mv"][:, 0, 1]) &
+                  (res["subpel_dist"] == sel["dist"]))
+            bad += int((~ok).sum())
+            done += len(sel)
+            if (~ok).any():
+                k = int(np.flatnonzero(~ok)[0])
+                self.first_bad = ("bi", tuple(sel[k]), tuple(res[k]))
+        return done, bad, skipped
+
+    # ---- affine motion searches (MotionEstAffine, :664-749) --------------------
+    def affine_steps(self):
+        api, ctx = self.api, self.ctx
+        st = self.rd["steps"]
+        st = st[st["kind"] != rf.KIND_BI]
+        done = bad = 0
+        if not len(st):
+            return 0, 0
+        keys = np.stack([st["poc"], st["ref_poc"], st["other_ref_poc"]], 1)
+        for poc, rpoc, opoc in np.unique(keys, axis=0):
+            sel = st[(st["poc"] == poc) & (st["ref_poc"] == rpoc) & (st["other_ref_poc"] == opoc)]
+            jobs = np.zeros(len(sel), api.AFFINE_ME_DTYPE)
+            for k in ("x", "y", "w", "h", "lambda16"):
+                jobs[k] = sel[k]
+            bipred = sel["kind"] == rf.KIND_AFFINE_BI
+            jobs["flags"] = (np.where((sel["flags"] & rf.FLAG_HAS_BOOT) != 0,
+                                      api.AFFINE_ME_HAS_BOOTSTRAP, 0) |
+                             np.where(bipred, api.AFFINE_ME_BIPRED, 0))
+            i = np.arange(len(sel))
+            jobs["mvp"] = sel["mvp"][i, sel["start_mvp_idx"].astype(np.int64)]
+            jobs["bootstrap"] = sel["boot"]
+            jobs["other_mv"] = sel["other_mv"]
+            O = self.orig(int(poc))[0]
+            other = self.pics[int(opoc)] if opoc >= 0 else self.pics[int(rpoc)]
+            t0 = time.time()
+            res = ctx.affine_me_batch(O, self.pics[int(rpoc)], jobs, ref_other=other)
+            self._time("affine_steps", t0)
+            ok = (res["mv"] == sel["mv"]).all(axis=(1, 2)) & (res["dist"] == sel["dist"])
+            bad += int((~ok).sum())
+            done += len(sel)
+            if (~ok).any():
+                k = int(np.flatnonzero(~ok)[0])
+                self.first_bad = ("affine", tuple(sel[k]), tuple(res[k]))
+        return done, bad
+
+    # ---- helpers for the calls that need a prediction picture ------------------
+    def _inter_jobs(self, x, y, w, h, inter_dir, affine, lic, ref_poc, mv, nb_index, slots):
+        """xvcgpu_inter_block for components 0..2 of n CU states -> [n, 3] jobs."""
+        api = self.api
+        n = len(x)
+        jobs = np.zeros((n, 3), api.INTER_DTYPE)
+        for c in range(3):
+            j = jobs[:, c]
+            j["x"], j["y"], j["w"], j["h"], j["comp"] = x, y, w, h, c
+            j["flags"] = np.where(affine, api.INTER_AFFINE, 0) | np.where(lic, api.INTER_LIC, 0)
+            for l in range(2):
+                used = (inter_dir == 2) | (inter_dir == l)
+                j["ref"][:, l] = np.where(used, [slots.get(int(p), -1) for p in ref_poc[:, l]], -1)
+            j["mv"] = mv
+            nb = self.rd["neighbours"]
+            has = (nb_index >= 0) & lic
+            if has.any():
+                k = np.where(has, nb_index, 0)
+                j["neighbors"] = np.where(has, nb["has_above"][k] * 1 + nb["has_left"][k] * 2, 0)
+                for f in ("above_x", "above_y", "left_x", "left_y"):
+                    j[f] = np.where(has, nb[f][k], 0)
+            jobs[:, c] = j
+        return jobs
+
+    def _write_neighbours(self, planes, nb_indices):
+        """The rows / columns the illumination models of these CUs read, into
+        host planes (unpadded views)."""
+        nb, smp = self.rd["neighbours"], self.rd["nb_samples"]
+        for k in np.unique(nb_indices[nb_indices >= 0]):
+            r = nb[k]
+            off = int(r["sample_off"])
+            for c in range(3):
+                s = 1 if c else 0
+                x, y, w, h = int(r["x"]) >> s, int(r["y"]) >> s, int(r["w"]) >> s, int(r["h"]) >> s
+                if r["has_above"]:
+                    planes[c][y - 1, x:x + w] = smp[off:off + w]
+                    off += w
+                if r["has_left"]:
+                    planes[c][y:y + h, x - 1] = smp[off:off + h]
+                    off += h
+
+    def _rec_for(self, poc, nb_indices, cache):
+        """A device picture holding the neighbour samples of one layer."""
+        if "rec" not in cache:
+            cache["rec"] = self.ctx.picture(self.w, self.h, 10)
+            cache["planes"] = [np.zeros((self.h + 2 * BL, self.w + 2 * BL), np.uint16),
+                               np.zeros((self.h // 2 + BL, self.w // 2 + BL), np.uint16),
+                               np.zeros((self.h // 2 + BL, self.w // 2 + BL), np.uint16)]
+        if (nb_indices >= 0).any():
+            views = [p[(BL >> (1 if c else 0)):, (BL >> (1 if c else 0)):]
+                     for c, p in enumerate(cache["planes"])]
+            self._write_neighbours(views, nb_indices)
+            cache["rec"].upload(cache["planes"], BL)
+        return cache["rec"]
+
+    # ---- merge-candidate rankings (SearchMergeCandidates, :165-197) ------------
+    def merges(self):
+        api, ctx = self.api, self.ctx
+        mg = self.rd["merges"]
+        done = bad = 0
+        cache = {}
+        pred = ctx.picture(self.w, self.h, 10)
+        for poc in np.unique(mg["poc"]):
+            m = mg[mg["poc"] == poc]
+            O, _ = self.orig(int(poc))
+            ref_pocs = sorted(set(int(p) for p in m["ref_poc"].reshape(-1) if p >= 0))
+            slots = {p: i for i, p in enumerate(ref_pocs)}
+            refs = [self.pics[p] for p in ref_pocs]
+            n = len(m)
+            # unit = (call, candidate); a call's five candidates take five layers
+            x, y = np.repeat(m["x"], 5), np.repeat(m["y"], 5)
+            w, h = np.repeat(m["w"], 5), np.repeat(m["h"], 5)
+            lic = m["use_lic"].reshape(-1) != 0
+            layer = assign_layers(x, y, w, h, grow=1)
+            mv = np.zeros((5 * n, 2, 3, 2), np.int32)
+            mv[:, :, 0, :] = m["mv"].reshape(5 * n, 2, 2)
+            jobs = self._inter_jobs(x, y, w, h, m["inter_dir"].reshape(-1), np.zeros(5 * n, bool),
+                                    lic, m["ref_poc"].reshape(5 * n, 2), mv,
+                                    np.repeat(m["nb_index"], 5), slots)[:, 0]
+            dist = np.zeros(5 * n, np.uint64)
+            for k in range(int(layer.max()) + 1):
+                idx = np.flatnonzero(layer == k)
+                nbi = np.where(lic[idx], np.repeat(m["nb_index"], 5)[idx], -1)
+                rec = self._rec_for(int(poc), nbi, cache)
+                cands = np.zeros(len(idx), api.CAND_DTYPE)
+                cands["x"], cands["y"], cands["w"], cands["h"] = x[idx], y[idx], w[idx], h[idx]
+                cands["metric"] = 1   # SATD
+                t0 = time.time()
+                ctx.inter_pred_batch(refs, rec, pred, jobs[idx])
+                dist[idx] = ctx.metric_batch(O, pred, 0, cands)
+                self._time("merges", t0)
+            dist = dist.reshape(n, 5)
+            # the fold: cost = dist + bits * sqrt(lambda) in double, stable sort, cut
+            bits = np.array([1, 2, 3, 4, 4], np.float64)
+            cost = dist.astype(np.float64) + bits[None, :] * m["lambda_sqrt"][:, None]
+            order = np.argsort(cost, axis=1, kind="stable")
+            scost = np.take_along_axis(cost, order, 1)
+            num = np.full(n, 4, np.int32)
+            for k in range(4, -1, -1):
+                num = np.where(scost[:, k] > scost[:, 0] * 1.25, k, num)
+            ok = (order == m["order"]).all(1) & (scost == m["cost"]).all(1) & (num == m["num"])
+            bad += int((~ok).sum())
+            done += n
+            if (~ok).any():
+                k = int(np.flatnonzero(~ok)[0])
+                self.first_bad = ("merge", tuple(m[k]), dist[k].tolist(), order[k].tolist())
+        pred.destroy()
+        if "rec" in cache:
+            cache["rec"].destroy()
+        return done, bad
+
+    # ---- TransformAndReconstruct of inter CUs (transform_encoder.cc:203-285) ---
+    def transform_calls(self, max_layers=None):
+        """-> (calls compared, mismatching calls, layers, dist_zero compared, dist_zero bad)"""
+        api, ctx = self.api, self.ctx
+        rd = self.rd
+        ev_all, calls_all, qps = rd["evals"], rd["calls"], rd["qps"]
+        contexts = rd["contexts"].view(api.RDOQ_CTX_DTYPE).reshape(-1)
+        done = bad = n_layers = dz_done = dz_bad = 0
+        cache = {}
+        pred = ctx.picture(self.w, self.h, 10)
+        rec_out = ctx.picture(self.w, self.h, 10)
+        for poc in np.unique(ev_all["poc"]):
+            O, _ = self.orig(int(poc))
+            e_idx = np.flatnonzero(ev_all["poc"] == poc)
+            ev = ev_all[e_idx]
+            first, last = int(e_idx[0]), int(e_idx[-1])
+            assert np.array_equal(e_idx, np.arange(first, last + 1))
+            cl = calls_all[(calls_all["eval"] >= first) & (calls_all["eval"] <= last)]
+            ce = cl["eval"] - first
+            # round of a call = how many calls of the same (eval, comp) came before
+            key = ce.astype(np.int64) * 3 + cl["comp"]
+            order = np.argsort(key, kind="stable")
+            ks = key[order]
+            start = np.r_[0, np.flatnonzero(ks[1:] != ks[:-1]) + 1]
+            rnd = np.zeros(len(cl), np.int32)
+            rnd[order] = np.arange(len(cl)) - np.repeat(start, np.diff(np.r_[start, len(cl)]))
+            n_rounds = int(rnd.max()) + 1 if len(cl) else 0
+            # unit = (eval, round); its footprint = the CU
+            rounds_of = np.zeros(len(ev), np.int32)
+            np.maximum.at(rounds_of, ce, rnd + 1)
+            u_eval = np.repeat(np.arange(len(ev)), rounds_of)
+            u_round = np.concatenate([np.arange(r) for r in rounds_of]) if len(ev) else np.zeros(0, int)
+            lic = (ev["flags"] & rf.FLAG_LIC) != 0
+            layer = assign_layers(ev["x"][u_eval], ev["y"][u_eval], ev["w"][u_eval],
+                                  ev["h"][u_eval], grow=1)
+            ref_pocs = sorted(set(int(p) for p in ev["ref_poc"].reshape(-1) if p >= 0))
+            slots = {p: i for i, p in enumerate(ref_pocs)}
+            refs = [self.pics[p] for p in ref_pocs]
+            ijobs = self._inter_jobs(ev["x"], ev["y"], ev["w"], ev["h"], ev["inter_dir"],
+                                     (ev["flags"] & rf.FLAG_AFFINE) != 0, lic, ev["ref_poc"],
+                                     ev["mv"], ev["nb_index"], slots)
+            # call -> unit
+            unit_first = np.r_[0, np.cumsum(rounds_of)[:-1]]
+            call_unit = unit_first[ce] + rnd
+            call_layer = layer[call_unit]
+            total_layers = int(layer.max()) + 1 if len(layer) else 0
+            for k in range(total_layers if max_layers is None else min(total_layers, max_layers)):
+                units = np.flatnonzero(layer == k)
+                evs = u_eval[units]
+                ci = np.flatnonzero(call_layer == k)
+                c = cl[ci]
+                e = ev[ce[ci]]
+                s = (c["comp"] != 0).astype(np.int64)
+                blocks = np.zeros(len(c), api.TX_DTYPE)
+                blocks["x"], blocks["y"] = e["x"] >> s, e["y"] >> s
+                blocks["w"], blocks["h"] = e["w"] >> s, e["h"] >> s
+                blocks["comp"] = c["comp"]
+                blocks["tx_hor"] = np.where(c["tx_skip"] != 0, 6, c["tx_hor"])
+                blocks["tx_ver"] = c["tx_ver"]
+                blocks["qp"] = e["qp"][np.arange(len(c)), c["comp"]]
+                blocks["intra_pic"] = api.TXF_RDOQ | (c["scan"].astype(np.int64) << api.TXF_SCAN_SHIFT)
+                uctx, inv = np.unique(e["ctx_index"], return_inverse=True)
+                prm = np.zeros(len(c), api.RDOQ_PARAMS_DTYPE)
+                q = qps[e["qp_index"]]
+                prm["lambda"] = q["lambda"][np.arange(len(c)), c["comp"]]
+                prm["rd_factor"] = q["rd_factor"][np.arange(len(c)), c["comp"]]
+                prm["ctx_index"] = inv
+                nbi = np.where(lic[evs], ev["nb_index"][evs], -1)
+                rec_nb = self._rec_for(int(poc), nbi, cache)
+                t0 = time.time()
+                ctx.inter_pred_batch(refs, rec_nb, pred, ijobs[evs].reshape(-1))
+                levels, off, nnz = ctx.residual_rdoq_batch(O, pred, rec_out, blocks, contexts[uctx], prm)
+                self._time("transform_calls", t0)
+                # distortion: structural SSD (luma, CU qp) / weighted SSD (chroma)
+                dist = np.zeros(len(c), np.uint64)
+                t0 = time.time()
+                for comp in range(3):
+                    m = np.flatnonzero(c["comp"] == comp)
+                    if not len(m):
+                        continue
+                    cands = np.zeros(len(m), api.CAND_DTYPE)
+                    for f in ("x", "y", "w", "h"):
+                        cands[f] = blocks[f][m]
+                    cands["metric"] = 7 if comp == 0 else 0
+                    cands["qp"] = e["qp"][m, 0]
+                    for qi in np.unique(e["qp_index"][m]):
+                        mm = np.flatnonzero(e["qp_index"][m] == qi)
+                        dist[m[mm]] = ctx.metric_batch(O, rec_out, comp, cands[mm],
+                                                       weight=float(qps["dist_weight"][qi, comp]))
+                self._time("transform_dist", t0)
+                planes = rec_out.download()
+                ok = nnz == c["nnz"]
+                for i in range(len(c)):
+                    w_, h_ = int(blocks["w"][i]), int(blocks["h"][i])
+                    lv = levels[int(off[i]):int(off[i]) + w_ * h_]
+                    # (QuantRdo returning 0 leaves its output block in an intermediate
+                    # state, rdo_quant.cc:397-408: nobody reads it - cbf = 0)
+                    good = c["nnz"][i] == 0 or rf.crc32_rows(lv) == int(c["levels_crc"][i])
+                    if good and c["completed"][i]:
+                        x_, y_ = int(blocks["x"][i]), int(blocks["y"][i])
+                        blk = planes[int(c["comp"][i])][y_:y_ + h_, x_:x_ + w_]
+                        good = ((rf.crc32_rows(blk) & 0xffff) == int(c["rec_crc"][i]) and
+                                int(dist[i]) == int(c["dist"][i]))
+                    if hasattr(self, "debug") and not (ok[i] and good):
+                        lv_ok = c["nnz"][i] == 0 or rf.crc32_rows(lv) == int(c["levels_crc"][i])
+                        self.debug[(int(c["comp"][i]), w_, h_, int(c["completed"][i]),
+                                    int(c["tx_hor"][i]), int(c["tx_ver"][i]), int(c["tx_skip"][i]),
+                                    int(e["flags"][i]), int(e["inter_dir"][i]),
+                                    "nnz" if nnz[i] != c["nnz"][i] else ("lv" if not lv_ok else "rec"))] += 1
+                        if len(self.debug_rows) < 20:
+                            self.debug_rows.append((tuple(c[i]), tuple(e[i]), int(nnz[i]), int(dist[i])))
+                    ok[i] &= good
+                bad += int((~ok).sum())
+                done += len(c)
+                if (~ok).any() and not hasattr(self, "first_bad"):
+                    i = int(np.flatnonzero(~ok)[0])
+                    self.first_bad = ("transform", tuple(c[i]), tuple(e[i]), int(nnz[i]), int(dist[i]))
+                n_layers += 1
+            # cbf-zero distortions: prediction against the original, once per CU state
+            has = (ev["dist_zero"] != np.uint64(0xffffffffffffffff)).any(1)
+            if max_layers is None and has.any():
+                lay0 = assign_layers(ev["x"], ev["y"], ev["w"], ev["h"], grow=1)
+                for k in range(int(lay0.max()) + 1):
+                    evs = np.flatnonzero((lay0 == k) & has)
+                    if not len(evs):
+                        continue
+                    nbi = np.where(lic[evs], ev["nb_index"][evs], -1)
+                    rec_nb = self._rec_for(int(poc), nbi, cache)
+                    t0 = time.time()
+                    ctx.inter_pred_batch(refs, rec_nb, pred, ijobs[evs].reshape(-1))
+                    for comp in range(3):
+                        s = 1 if comp else 0
+                        cands = np.zeros(len(evs), api.CAND_DTYPE)
+                        cands["x"], cands["y"] = ev["x"][evs] >> s, ev["y"][evs] >> s
+                        cands["w"], cands["h"] = ev["w"][evs] >> s, ev["h"][evs] >> s
+                        cands["metric"] = 7 if comp == 0 else 0
+                        cands["qp"] = ev["qp"][evs, 0]
+                        got = np.zeros(len(evs), np.uint64)
+                        for qi in np.unique(ev["qp_index"][evs]):
+                            mm = np.flatnonzero(ev["qp_index"][evs] == qi)
+                            got[mm] = ctx.metric_batch(O, pred, comp, cands[mm],
+                                                       weight=float(qps["dist_weight"][qi, comp]))
+                        want = ev["dist_zero"][evs, comp]
+                        valid = want != np.uint64(0xffffffffffffffff)
+                        dz_bad += int(((got != want) & valid).sum())
+                        dz_done += int(valid.sum())
+                    self._time("dist_zero", t0)
+        pred.destroy()
+        rec_out.destroy()
+        if "rec" in cache:
+            cache["rec"].destroy()
+        return done, bad, n_layers, dz_done, dz_bad

@@ -950,6 +950,17 @@ class Context:
         self.sync()
         d.free()
 
+    def inter_pred_batch(self, refs, rec, pred, jobs):
+        """InterPrediction::MotionCompensation per (CU, component) job - uni / bi,
+        affine, local illumination compensation (reads `rec` around the CU) -
+        from the reference pictures refs[job.ref[list]] into `pred`."""
+        jobs = np.ascontiguousarray(jobs, INTER_DTYPE)
+        arr = (_vp * max(1, len(refs)))(*[r.h_pic for r in refs])
+        d = self.buffer(jobs)
+        self._check(self.lib.xvcgpu_inter_pred_batch(self.h, arr, len(refs), rec.h_pic,
+                                                     pred.h_pic, d.ptr, len(jobs)))
+        d.free()
+
     def affine_me_batch(self, orig, ref, blocks, ref_other=None):
         """InterSearch::MotionEstAffine per block -> AFFINE_ME_RESULT_DTYPE array
         (ref_other: the other list's reference for AFFINE_ME_BIPRED jobs)"""
