@@ -136,6 +136,7 @@ def stream_decode_figure(ctx, api):
            "pictures_per_s": fx.n / dt, "ms_per_picture": 1e3 * dt / fx.n,
            "md5_match": bool(ok), "includes": "host planning + upload of the parsed syntax"}
     out["encoder_me_batches"] = encoder_me_figure(ctx, api, fx, pics, w, h)
+    out["encoder_rd_batches"] = encoder_rd_figure(ctx, api, fx, pics, w, h)
     dec.destroy()
     for p in pics:
         p.destroy()
@@ -224,6 +225,91 @@ def encoder_me_figure(ctx, api, fx, pics, w, h):
                 break
         out["cpu_reference_searches_per_s"] = k / (time.perf_counter() - t0)
         out["cpu_reference"] = "TzSearch::Search + SubpelSearch of oracle/_ref, 1 thread, every 37th call"
+    return out
+
+
+def encoder_rd_figure(ctx, api, fx, pics, w, h):
+    """Third workload: the REST of the reference encoder's RD search for that
+    1080p B picture (tests/golden/rd_calls_c1.npz, tools/gen_rd_golden.py): every
+    bi-prediction refinement step (FullSearch +-4 + sub-pel on the 2 * orig -
+    other-list target), every affine motion search, every merge-candidate
+    ranking and every inter-CU TransformAndReconstruct - the latter quantised
+    with the CABAC context states RdoQuant::QuantRdo really read at that moment
+    - as device batches (tests/rd_replay.py), every call compared with the
+    reference's result.  The searches are one batch per picture pair; the calls
+    that write a prediction / reconstruction at the CU's own position are dealt
+    into layers of non-overlapping blocks (the RD recursion revisits every
+    position at every size), so their figure is launch-bound, not throughput."""
+    import rd_fixture as rf
+    import rd_replay
+    if not os.path.exists(rf.path("c1")):
+        return None
+    by_poc = {int(fx.info[i]["poc"]): pics[i] for i in range(fx.n)}
+    r = rd_replay.Replay(api, ctx, "c1", by_poc, w, h)
+    r.bi_steps()        # warm-up (originals uploaded, kernels loaded)
+    r.timing = {}
+    bi_n, bi_bad, bi_skip = r.bi_steps()
+    af_n, af_bad = r.affine_steps()
+    mg_n, mg_bad = r.merges()
+    tx_n, tx_bad, layers, dz_n, dz_bad = r.transform_calls()
+    t = {k: 1e3 * v for k, v in r.timing.items()}
+    poc = int(r.rd["evals"]["poc"][0])
+    out = {"workload": "the rest of the reference encoder's RD search for the 1080p B picture "
+                       "POC %d: %d bi-prediction refinement steps, %d affine motion searches, "
+                       "%d merge rankings (x 5 candidates), %d TransformAndReconstruct calls of "
+                       "%d CU states (%d CABAC context snapshots)" %
+                       (poc, bi_n, af_n, mg_n, tx_n, len(r.rd["evals"]), len(r.rd["contexts"])),
+           "ms": {"bi_steps": t.get("bi_steps"), "affine_searches": t.get("affine_steps"),
+                  "merge_rankings": t.get("merges"),
+                  "transform_and_reconstruct": t.get("transform_calls"),
+                  "transform_distortions": t.get("transform_dist"),
+                  "cbf_zero_distortions": t.get("dist_zero")},
+           "ms_includes": "host job preparation excluded; descriptor upload, launches, result "
+                          "download included (wall clock around each batch)",
+           "transform_layers": layers,
+           "matches_reference": bool(bi_bad == 0 and af_bad == 0 and mg_bad == 0 and tx_bad == 0
+                                     and dz_bad == 0),
+           "mismatches": {"bi": bi_bad, "affine": af_bad, "merge": mg_bad, "transform": tx_bad,
+                          "dist_zero": dz_bad},
+           "bi_steps_of_lic_cus_not_replayed": bi_skip}
+    import oracle_lib as ol
+    if ol.have_ref():       # the reference's own MotionEstNormal(kFullSearch), one thread
+        import ctypes as C
+        st = r.rd["steps"]
+        st = st[(st["kind"] == rf.KIND_BI) & ((st["flags"] & rf.FLAG_LIC) == 0)]
+        key = (int(st["other_ref_poc"][0]), int(st["ref_poc"][0]))
+        sel = st[(st["other_ref_poc"] == key[0]) & (st["ref_poc"] == key[1])][:4000]
+        jobs = np.zeros(len(sel), api.BI_DTYPE)
+        b = jobs["blk"]
+        for k in ("x", "y", "w", "h", "lambda16"):
+            b[k] = sel[k]
+        b["fullpel_mv"] = (sel["flags"] & rf.FLAG_FULLPEL) != 0
+        i = np.arange(len(sel))
+        k0 = sel["start_mvp_idx"].astype(np.int64)
+        b["mvp_x"], b["mvp_y"] = sel["mvp"][i, k0, 0, 0], sel["mvp"][i, k0, 0, 1]
+        b["search_range"] = 4
+        jobs["blk"] = b
+        jobs["other_mv_x"], jobs["other_mv_y"] = sel["other_mv"][:, 0, 0], sel["other_mv"][:, 0, 1]
+        jobs["boot_mv_x"], jobs["boot_mv_y"] = sel["boot"][:, 0, 0], sel["boot"][:, 0, 1]
+        res = np.zeros(len(sel), api.MERES_DTYPE)
+        lib = C.CDLL(ol.REF_SO)
+        planes = [rd_replay.original_planes(w, h, poc)[0]] + [
+            np.ascontiguousarray(np.pad(by_poc[p].download(0)[0], rd_replay.BL, mode="edge"))
+            for p in key]
+        args = []
+        for a in planes:
+            args += [C.c_void_p(a.ctypes.data + 2 * rd_replay.BL * (a.shape[1] + 1)),
+                     C.c_ssize_t(a.shape[1])]
+        t0 = time.perf_counter()
+        lib.xr_bipred_search_many(10, C.c_void_p(jobs.ctypes.data), len(sel), w, h, *args,
+                                  C.c_void_p(res.ctypes.data))
+        dt = time.perf_counter() - t0
+        assert np.array_equal(res["mv_x"], sel["mv"][:, 0, 0])
+        out["cpu_reference_bi_steps_per_s"] = len(sel) / dt
+        out["cpu_reference"] = ("InterSearch::MotionEstNormal(kFullSearch, bipred) of oracle/_ref on "
+                                "the first %d steps, 1 thread (incl. one picture set-up)" % len(sel))
+        out["bi_steps_per_s"] = bi_n / (1e-3 * t["bi_steps"]) if t.get("bi_steps") else None
+    r.destroy()
     return out
 
 

@@ -968,12 +968,47 @@ int xr_search_merge_candidates(int bd, int x, int y, int w, int h, int pic_w, in
   return num;
 }
 
-void xr_bipred_search(int bd, const xvcgpu_bi_block *j, int pic_w, int pic_h,
-                      const uint16_t *orig, ptrdiff_t os, const uint16_t *ref_other,
-                      ptrdiff_t ros, const uint16_t *ref_search, ptrdiff_t rss,
-                      xvcgpu_me_result *out) {
-  /* searched list = L0 (ref[0] = ref_search), other list = L1 (ref[1]) */
+/* one step of SearchBiIterative on a prepared environment: searched list = L0
+ * (ref[0]), other list = L1 (ref[1]) */
+static void BipredStep(BiEnv *env, InterSearch *is, const xvcgpu_bi_block *j, int bd,
+                       xvcgpu_me_result *out) {
   const xvcgpu_me_block *b = &j->blk;
+  CodingUnit *cu = env->pic_data.CreateCu(CuTree::Primary, 1, b->x, b->y, b->w, b->h);
+  cu->SetPredMode(PredictionMode::kInter);
+  cu->SetFullpelMv(b->fullpel_mv != 0);
+  cu->SetRefIdx(0, RefPicList::kL0);
+  cu->SetRefIdx(0, RefPicList::kL1);
+  cu->SetMv(MotionVector(j->other_mv_x, j->other_mv_y), RefPicList::kL1);
+  const YuvComponent comp = YuvComponent::kY;
+  /* SearchBiIterative body, inter_search.cc:418-423 */
+  cu->SetInterDir(InterDir::kL1);
+  is->MotionCompensation(*cu, comp, &is->bipred_pred_buffer_);
+  SampleBufferConst orig_luma = env->orig_pic.GetSampleBuffer(comp, b->x, b->y);
+  is->bipred_orig_buffer_.SubtractWeighted(b->w, b->h, orig_luma, is->bipred_pred_buffer_);
+  cu->SetInterDir(InterDir::kBi);
+  double ls = (b->lambda16 + 0.5) / 65536.0;
+  Qp qp = MakeQp(32, bd, ls * ls);
+  MotionVector boot(j->boot_mv_x, j->boot_mv_y);
+  SampleBufferStorage pred(64, 64);
+  Distortion dist = 0;
+  MotionVector mv = is->MotionEstNormal(
+      *cu, qp, InterSearch::SearchMethod::kFullSearch, RefPicList::kL0, 0, true,
+      is->bipred_orig_buffer_, MotionVector(b->mvp_x, b->mvp_y), &boot, &pred, &dist);
+  out->fullpel_x = 0;
+  out->fullpel_y = 0;
+  out->mv_x = mv.x;
+  out->mv_y = mv.y;
+  out->fullpel_cost = 0;
+  out->subpel_dist = static_cast<uint32_t>(dist);
+  env->pic_data.ReleaseCu(cu);
+}
+
+/* n steps on the same three pictures (the environment is built once: what the
+ * timing leg of bench.py uses) */
+void xr_bipred_search_many(int bd, const xvcgpu_bi_block *jobs, int n, int pic_w, int pic_h,
+                           const uint16_t *orig, ptrdiff_t os, const uint16_t *ref_other,
+                           ptrdiff_t ros, const uint16_t *ref_search, ptrdiff_t rss,
+                           xvcgpu_me_result *out) {
   BiEnv env(bd, pic_w, pic_h);
   for (int y = 0; y < pic_h; y++)
     std::memcpy(env.orig_pic.GetSamplePtr(YuvComponent::kY, 0, y), orig + y * os,
@@ -982,35 +1017,16 @@ void xr_bipred_search(int bd, const xvcgpu_bi_block *j, int pic_w, int pic_h,
   ptrdiff_t ss[3] = {rss, 0, 0}, so[3] = {ros, 0, 0};
   FillPic(env.ref[0].get(), ps, ss);
   FillPic(env.ref[1].get(), po, so);
-  CodingUnit *cu = env.pic_data.CreateCu(CuTree::Primary, 1, b->x, b->y, b->w, b->h);
-  cu->SetPredMode(PredictionMode::kInter);
-  cu->SetFullpelMv(b->fullpel_mv != 0);
-  cu->SetRefIdx(0, RefPicList::kL0);
-  cu->SetRefIdx(0, RefPicList::kL1);
-  cu->SetMv(MotionVector(j->other_mv_x, j->other_mv_y), RefPicList::kL1);
   InterSearch is(Simd(bd), env.pic_data, env.orig_pic, env.rec_pic,
                  *env.pic_data.GetRefPicLists(), env.settings);
-  const YuvComponent comp = YuvComponent::kY;
-  /* SearchBiIterative body, inter_search.cc:418-423 */
-  cu->SetInterDir(InterDir::kL1);
-  is.MotionCompensation(*cu, comp, &is.bipred_pred_buffer_);
-  SampleBufferConst orig_luma = env.orig_pic.GetSampleBuffer(comp, b->x, b->y);
-  is.bipred_orig_buffer_.SubtractWeighted(b->w, b->h, orig_luma, is.bipred_pred_buffer_);
-  cu->SetInterDir(InterDir::kBi);
-  double ls = (b->lambda16 + 0.5) / 65536.0;
-  Qp qp = MakeQp(32, bd, ls * ls);
-  MotionVector boot(j->boot_mv_x, j->boot_mv_y);
-  SampleBufferStorage pred(64, 64);
-  Distortion dist = 0;
-  MotionVector mv = is.MotionEstNormal(
-      *cu, qp, InterSearch::SearchMethod::kFullSearch, RefPicList::kL0, 0, true,
-      is.bipred_orig_buffer_, MotionVector(b->mvp_x, b->mvp_y), &boot, &pred, &dist);
-  out->fullpel_x = 0;
-  out->fullpel_y = 0;
-  out->mv_x = mv.x;
-  out->mv_y = mv.y;
-  out->fullpel_cost = 0;
-  out->subpel_dist = static_cast<uint32_t>(dist);
+  for (int i = 0; i < n; i++) BipredStep(&env, &is, jobs + i, bd, out + i);
+}
+
+void xr_bipred_search(int bd, const xvcgpu_bi_block *j, int pic_w, int pic_h,
+                      const uint16_t *orig, ptrdiff_t os, const uint16_t *ref_other,
+                      ptrdiff_t ros, const uint16_t *ref_search, ptrdiff_t rss,
+                      xvcgpu_me_result *out) {
+  xr_bipred_search_many(bd, j, 1, pic_w, pic_h, orig, os, ref_other, ros, ref_search, rss, out);
 }
 
 
@@ -1097,6 +1113,140 @@ void xr_search_motion(int bd, int x, int y, int w, int h, int flags, uint32_t la
     out[19 + 4 * l] = cu->GetMv(rl, MvCorner::kDefault).x;
     out[20 + 4 * l] = cu->GetMv(rl, MvCorner::kDefault).y;
     out[21 + 4 * l] = cu->GetMvpIdx(rl);
+  }
+}
+
+
+/* InterSearch::SearchMotion as the reference configures itself: up to three
+ * reference pictures per list (default_num_ref_pics = 2, 3 in placebo;
+ * encoder_settings.cc:36, :48), lists that may name the same pictures (list 1
+ * then reuses list 0's search result, inter_search.cc:536-542), pictures with
+ * only back references (PictureData::DetermineForceBipredL1MvdZero: list 1 of a
+ * bi-directional CU carries no vector difference, :496-518, :410-413), the
+ * closed-form bit prices (fast_inter_pred_bits, :1084-1130).
+ *   pics: n_pics padded luma planes with their POCs; ref_pic[l][r] = index into
+ *   pics of reference r of list l (num_ref[l] of them); cur_poc = the picture's POC.
+ *   nb[2][2][3]: the inter CU to the left (8 x h) and above (w x 8):
+ *   [neighbour][list]{ref_idx, mv_x, mv_y} (ref_idx < 0: list unused there).
+ * out: [0] cost, [1] inter_dir, then per list {ref_idx, mv_x, mv_y, mvp_idx} at
+ *   [2 + 4 l]; [10] force_l1_mvd_zero as the picture derives it; per (l, r) at
+ *   [16 + 8 (3 l + r)]: search_range, the AMVP list {x0, y0, x1, y1}, same-POC index
+ *   in list 0 (list 1 entries; -1 unique), 2 spare;
+ *   [64 + 6 l]: the list's uni-directional search alone (a second InterSearch run
+ *   L0 then L1, so list 1 sees list 0's results): cost, ref_idx, mv_x, mv_y,
+ *   mvp_idx, cost of the best unique-POC reference (list 1). */
+void xr_search_motion_multi(int bd, int x, int y, int w, int h, int flags, uint32_t lambda16,
+                            int iterations, int pic_w, int pic_h, const uint16_t *orig,
+                            ptrdiff_t os, int n_pics, const uint16_t *const *pics,
+                            const ptrdiff_t *pic_strides, const int32_t *pic_pocs, int cur_poc,
+                            const int32_t *num_ref, const int32_t *ref_pic, const int32_t *nb,
+                            int64_t *out) {
+  PictureData pic_data(ChromaFormat::k420, pic_w, pic_h, bd);
+  YuvPicture orig_pic(ChromaFormat::k420, pic_w, pic_h, bd, true, 0, 0);
+  YuvPicture rec_pic(ChromaFormat::k420, pic_w, pic_h, bd, true, 0, 0);
+  std::vector<std::shared_ptr<YuvPicture>> store;
+  for (int i = 0; i < n_pics; i++) {
+    store.push_back(std::make_shared<YuvPicture>(ChromaFormat::k420, pic_w, pic_h, bd, true, 0, 0));
+    const uint16_t *p[3] = {pics[i], nullptr, nullptr};
+    ptrdiff_t st[3] = {pic_strides[i], 0, 0};
+    FillPic(store.back().get(), p, st);
+  }
+  auto ref_data = std::make_shared<PictureData>(ChromaFormat::k420, 8, 8, bd);
+  ref_data->SetNalType(NalUnitType::kPredictedPicture);
+  EncoderSettings settings;
+  settings.Initialize(SpeedMode::kSlow);
+  settings.fast_inter_pred_bits = 1;
+  settings.bipred_refinement_iterations = iterations;
+  pic_data.SetSubGopLength(16);
+  pic_data.SetPoc(cur_poc);
+  pic_data.SetNalType(NalUnitType::kBipredictedPicture);
+  ReferencePictureLists *rpl = pic_data.GetRefPicLists();
+  rpl->Reset(cur_poc);
+  for (int l = 0; l < 2; l++)
+    for (int r = 0; r < num_ref[l]; r++) {
+      const int k = ref_pic[3 * l + r];
+      rpl->SetRefPic(static_cast<RefPicList>(l), r, pic_pocs[k], ref_data, store[k], nullptr);
+    }
+  pic_data.force_bipred_l1_mvd_zero_ = pic_data.DetermineForceBipredL1MvdZero();
+  for (int yy = 0; yy < pic_h; yy++)
+    std::memcpy(orig_pic.GetSamplePtr(YuvComponent::kY, 0, yy), orig + yy * os,
+                sizeof(Sample) * pic_w);
+  for (int k = 0; k < 2; k++) {
+    if ((k == 0 && x < 8) || (k == 1 && y < 8)) continue;
+    const int32_t *q = nb + 6 * k;
+    if (q[0] < 0 && q[3] < 0) continue;
+    CodingUnit *n = k == 0 ? pic_data.CreateCu(CuTree::Primary, 1, x - 8, y, 8, h)
+                           : pic_data.CreateCu(CuTree::Primary, 1, x, y - 8, w, 8);
+    n->SetPredMode(PredictionMode::kInter);
+    n->SetInterDir(q[0] >= 0 && q[3] >= 0 ? InterDir::kBi
+                                          : (q[0] >= 0 ? InterDir::kL0 : InterDir::kL1));
+    for (int l = 0; l < 2; l++) {
+      if (q[3 * l] < 0) continue;
+      n->SetRefIdx(q[3 * l], static_cast<RefPicList>(l));
+      n->SetMv(MotionVector(q[3 * l + 1], q[3 * l + 2]), static_cast<RefPicList>(l));
+    }
+    pic_data.MarkUsedInPic(n);
+  }
+  CodingUnit *cu = pic_data.CreateCu(CuTree::Primary, 1, x, y, w, h);
+  const double ls = (lambda16 + 0.5) / 65536.0;
+  Qp qp = MakeQp(32, bd, ls * ls);
+  cu->SetQp(qp);
+  InterSearch is(Simd(bd), pic_data, orig_pic, rec_pic, *rpl, settings);
+  BitWriter bw;
+  SyntaxWriter writer(qp, PicturePredictionType::kBi, &bw);
+  SampleBufferStorage pred(64, 64);
+  const InterSearchFlags sf =
+      (flags & 1) ? InterSearchFlags::kFullPelMv : InterSearchFlags::kDefault;
+  std::memset(out, 0, sizeof(int64_t) * 80);
+  const Distortion cost = is.SearchMotion(cu, qp, writer, sf, &pred);
+  out[0] = static_cast<int64_t>(cost);
+  out[1] = cu->GetInterDir() == InterDir::kBi ? 2 : (cu->GetInterDir() == InterDir::kL1 ? 1 : 0);
+  for (int l = 0; l < 2; l++) {
+    const RefPicList rl = static_cast<RefPicList>(l);
+    const bool has = cu->HasMv(rl);
+    out[2 + 4 * l] = has ? cu->GetRefIdx(rl) : -1;
+    out[3 + 4 * l] = has ? cu->GetMv(rl, MvCorner::kDefault).x : 0;
+    out[4 + 4 * l] = has ? cu->GetMv(rl, MvCorner::kDefault).y : 0;
+    out[5 + 4 * l] = has ? cu->GetMvpIdx(rl) : 0;
+  }
+  out[10] = pic_data.GetForceBipredL1MvdZero();
+  const std::vector<int> same = rpl->GetSamePocMappingFor(RefPicList::kL1);
+  for (int l = 0; l < 2; l++)
+    for (int r = 0; r < num_ref[l]; r++) {
+      const RefPicList rl = static_cast<RefPicList>(l);
+      int64_t *q = out + 16 + 8 * (3 * l + r);
+      q[0] = is.GetSearchRangeUniPred(rpl->GetRefPoc(rl, r));
+      cu->SetRefIdx(r, rl);
+      const InterPredictorList mvp = is.GetMvpList(*cu, rl, r);
+      for (int k = 0; k < 2; k++) {
+        q[1 + 2 * k] = mvp[k].x;
+        q[2 + 2 * k] = mvp[k].y;
+      }
+      q[5] = l == 1 ? same[r] : -1;
+    }
+  InterSearch is2(Simd(bd), pic_data, orig_pic, rec_pic, *rpl, settings);
+  SampleBufferConst orig_luma = orig_pic.GetSampleBuffer(YuvComponent::kY, x, y);
+  for (int l = 0; l < 2; l++) {
+    const RefPicList rl = static_cast<RefPicList>(l);
+    if (l == 0) {
+      cu->ResetPredictionState();
+      cu->SetPredMode(PredictionMode::kInter);
+      cu->SetFullpelMv((flags & 1) != 0);
+    }
+    cu->SetInterDir(l == 0 ? InterDir::kL0 : InterDir::kL1);
+    CodingUnit::InterState st, st_unique;
+    Distortion cost_unique = 0;
+    const Distortion c = is2.SearchRefIdx(cu, qp, rl, writer, orig_luma,
+                                          std::numeric_limits<Distortion>::max(), &pred, &st,
+                                          l == 1 ? &st_unique : nullptr,
+                                          l == 1 ? &cost_unique : nullptr);
+    int64_t *q = out + 64 + 6 * l;
+    q[0] = static_cast<int64_t>(c);
+    q[1] = cu->GetRefIdx(rl);
+    q[2] = cu->GetMv(rl, MvCorner::kDefault).x;
+    q[3] = cu->GetMv(rl, MvCorner::kDefault).y;
+    q[4] = cu->GetMvpIdx(rl);
+    q[5] = l == 1 ? static_cast<int64_t>(cost_unique) : 0;
   }
 }
 

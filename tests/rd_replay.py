@@ -27,17 +27,17 @@ def original_planes(w, h, poc):
                                         mode="edge")) for c, p in enumerate(planes)]
 
 
-def assign_layers(x, y, w, h, grow=0):
-    """-> layer index per block (capture order).  grow = 1: the footprint also
+def assign_layers(x, y, w, h, grow=None):
+    """-> layer index per block (capture order).  grow[i]: the footprint also
     covers one cell above and to the left (the row / column a local illumination
     model reads from the current reconstruction)."""
     x4 = np.asarray(x, np.int64) // 4
     y4 = np.asarray(y, np.int64) // 4
     x1 = (np.asarray(x, np.int64) + np.asarray(w, np.int64) + 3) // 4
     y1 = (np.asarray(y, np.int64) + np.asarray(h, np.int64) + 3) // 4
-    if grow:
-        x4 = np.maximum(x4 - 1, 0)
-        y4 = np.maximum(y4 - 1, 0)
+    if grow is not None:
+        x4 = np.where(grow, np.maximum(x4 - 1, 0), x4)
+        y4 = np.where(grow, np.maximum(y4 - 1, 0), y4)
     last = np.full((int(y1.max()) + 1, int(x1.max()) + 1), -1, np.int32)
     out = np.zeros(len(x4), np.int32)
     for i in range(len(x4)):
@@ -223,7 +223,7 @@ class Replay:
             x, y = np.repeat(m["x"], 5), np.repeat(m["y"], 5)
             w, h = np.repeat(m["w"], 5), np.repeat(m["h"], 5)
             lic = m["use_lic"].reshape(-1) != 0
-            layer = assign_layers(x, y, w, h, grow=1)
+            layer = assign_layers(x, y, w, h, grow=np.repeat((m["use_lic"] != 0).any(1), 5))
             mv = np.zeros((5 * n, 2, 3, 2), np.int32)
             mv[:, :, 0, :] = m["mv"].reshape(5 * n, 2, 2)
             jobs = self._inter_jobs(x, y, w, h, m["inter_dir"].reshape(-1), np.zeros(5 * n, bool),
@@ -295,7 +295,7 @@ class Replay:
             u_round = np.concatenate([np.arange(r) for r in rounds_of]) if len(ev) else np.zeros(0, int)
             lic = (ev["flags"] & rf.FLAG_LIC) != 0
             layer = assign_layers(ev["x"][u_eval], ev["y"][u_eval], ev["w"][u_eval],
-                                  ev["h"][u_eval], grow=1)
+                                  ev["h"][u_eval], grow=lic[u_eval])
             ref_pocs = sorted(set(int(p) for p in ev["ref_poc"].reshape(-1) if p >= 0))
             slots = {p: i for i, p in enumerate(ref_pocs)}
             refs = [self.pics[p] for p in ref_pocs]
@@ -382,7 +382,7 @@ class Replay:
             # cbf-zero distortions: prediction against the original, once per CU state
             has = (ev["dist_zero"] != np.uint64(0xffffffffffffffff)).any(1)
             if max_layers is None and has.any():
-                lay0 = assign_layers(ev["x"], ev["y"], ev["w"], ev["h"], grow=1)
+                lay0 = assign_layers(ev["x"], ev["y"], ev["w"], ev["h"], grow=lic)
                 for k in range(int(lay0.max()) + 1):
                     evs = np.flatnonzero((lay0 == k) & has)
                     if not len(evs):

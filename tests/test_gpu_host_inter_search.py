@@ -278,3 +278,137 @@ def test_search_motion_vs_reference(gpu, bd, iterations):
     assert n_bi >= n // 4
     for p in (O, R0, R1):
         p.destroy()
+
+
+# (list 0 / list 1 as indices into the picture set, the picture set's POCs, current POC)
+_REF_CONFIGS = {
+    # hierarchical B, two pictures per list, the lists name the same two pictures:
+    # every list-1 entry reuses list 0's search (inter_search.cc:536-542)
+    "b2_shared": ([0, 1], [1, 0], [0, 16], 8),
+    # two per list, list 1 partly unique
+    "b2_mixed": ([0, 1], [2, 1], [4, 0, 16], 8),
+    # placebo: three per list (encoder_settings.cc:36), all of list 1 unique
+    "b3_unique": ([0, 1, 2], [3, 4, 5], [6, 4, 0, 10, 12, 16], 8),
+    # only back references: list 1 of a bi-directional CU carries no vector
+    # difference (PictureData::DetermineForceBipredL1MvdZero)
+    "back_only": ([0, 1], [0, 1], [12, 8], 16),
+}
+
+
+@pytest.mark.skipif(not ol.have_ref(), reason="oracle/_ref not built")
+@pytest.mark.parametrize("config,bd,iterations", [
+    ("b2_shared", 10, 1), ("b2_mixed", 10, 1), ("b2_mixed", 8, 4), ("b3_unique", 10, 4),
+    ("b3_unique", 8, 1), ("back_only", 10, 1), ("back_only", 8, 4)])
+def test_search_motion_multi_ref_vs_reference(gpu, config, bd, iterations):
+    """InterSearch::SearchMotion as the reference configures itself
+    (default_num_ref_pics 2, placebo 3; lists that share pictures; back-only
+    reference structures; closed-form bit prices): xvc_gpu::InterSearch::
+    SearchMotionMultiBatch against the reference's member function on the same
+    CUs, neighbours (real AMVP lists per reference picture) and pictures."""
+    api, ctx = gpu
+    L, xr = host_lib(), ol.Lib("xr").dll
+    l0, l1, pocs, cur = _REF_CONFIGS[config]
+    L.xvc_host_search_motion_multi_batch.argtypes = [C.c_void_p] * 5 + [C.c_int, C.c_int,
+                                                                         C.c_void_p, C.c_int,
+                                                                         C.c_void_p, C.c_int,
+                                                                         C.c_void_p]
+    xr.xr_search_motion_multi.restype = None
+    xr.xr_search_motion_multi.argtypes = [C.c_int] * 6 + [C.c_uint32] + [C.c_int] * 3 + \
+        [C.c_void_p, C.c_ssize_t, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    rng = np.random.default_rng(9900 + bd + iterations + len(pocs))
+    pw, ph = 256, 160
+    n_pics = len(pocs)
+    _, base = make_pics(rng, bd, pw, ph, BL, (0, 0))
+    # every reference = the base displaced in proportion to its POC distance + its
+    # own grain; the original = two of them blended, so uni- and bi-directional
+    # choices, and different pictures, all win somewhere
+    planes = []
+    for p in pocs:
+        d = p - cur
+        shifted = np.roll(base, (d // 3, -d // 2), (0, 1)).astype(np.int32)
+        planes.append(np.clip(shifted + rng.integers(-3, 4, base.shape), 0,
+                              (1 << bd) - 1).astype(np.uint16))
+    mix = (planes[l0[0]].astype(np.int32) + planes[l1[-1]].astype(np.int32) + 1) // 2
+    orig = np.clip(np.where(rng.integers(0, 3, (1, base.shape[1])) == 0, planes[l0[-1]], mix) +
+                   rng.integers(-2, 3, base.shape), 0, (1 << bd) - 1).astype(np.uint16)
+    O = ctx.picture(pw, ph, bd)
+    O.upload([orig, None, None], BL)
+    R = [ctx.picture(pw, ph, bd) for _ in range(n_pics)]
+    for pic, pl in zip(R, planes):
+        pic.upload([pl, None, None], BL)
+    num_ref = np.array([len(l0), len(l1)], np.int32)
+    ref_pic = np.full((2, 3), -1, np.int32)
+    ref_pic[0, :len(l0)], ref_pic[1, :len(l1)] = l0, l1
+    plane_ptrs = (C.c_void_p * n_pics)(*[pl[BL:, BL:].ctypes.data for pl in planes])
+    strides = np.array([pl.strides[0] // 2 for pl in planes], np.int64)
+    pocs_a = np.array(pocs, np.int32)
+    n = 36
+    blocks = np.zeros((2, 3, n), api.ME_DTYPE)
+    mvp = np.zeros((2, 3, n, 4), np.int32)
+    exp = np.zeros((n, 80), np.int64)
+    o = orig[BL:, BL:]
+    for i in range(n):
+        w, h = int(rng.choice([8, 16, 32, 64])), int(rng.choice([8, 16, 32, 64]))
+        x = int(rng.integers(0, (pw - w) // 8 + 1)) * 8
+        y = int(rng.integers(0, (ph - h) // 8 + 1)) * 8
+        fp = int(rng.integers(0, 6) == 0)
+        lam = int(rng.choice([120000, 498000, 1500000]))
+        nb = np.zeros((2, 2, 3), np.int32)
+        nb[:, :, 1:] = rng.integers(-150, 150, (2, 2, 2))
+        nb[:, 0, 0] = rng.integers(-1, len(l0), 2)
+        nb[:, 1, 0] = rng.integers(-1, len(l1), 2)
+        if i % 5 == 0:
+            nb[1] = nb[0]
+        xr.xr_search_motion_multi(bd, x, y, w, h, fp, lam, iterations, pw, ph, o.ctypes.data,
+                                  orig.strides[0] // 2, n_pics, plane_ptrs, strides.ctypes.data,
+                                  pocs_a.ctypes.data, cur, num_ref.ctypes.data,
+                                  ref_pic.ctypes.data, nb.ctypes.data, exp[i].ctypes.data)
+        for l in range(2):
+            for r in range(int(num_ref[l])):
+                q = exp[i][16 + 8 * (3 * l + r):]
+                bk = blocks[l][r][i]
+                bk["x"], bk["y"], bk["w"], bk["h"] = x, y, w, h
+                bk["depth_nonzero"], bk["fullpel_mv"], bk["lambda16"] = 1, fp, lam
+                bk["search_range"] = q[0]
+                mvp[l][r][i] = q[1:5]
+    same = np.array([exp[0][16 + 8 * (3 + r) + 5] if r < len(l1) else -1 for r in range(3)],
+                    np.int32)
+    force = int(exp[0][10])
+    assert force == (config == "back_only")
+    assert [int(v) for v in same[:len(l1)]] == [l0.index(k) if k in l0 else -1 for k in l1]
+    handles = (C.c_void_p * 6)(*[R[ref_pic[l][r]].h_pic if ref_pic[l][r] >= 0 else None
+                                 for l in range(2) for r in range(3)])
+    out = np.zeros((n, 32), np.int64)
+    bl, mv = np.ascontiguousarray(blocks), np.ascontiguousarray(mvp)
+    assert L.xvc_host_search_motion_multi_batch(
+        ctx.h, O.h_pic, handles, num_ref.ctypes.data, same.ctypes.data, 0, force, bl.ctypes.data,
+        n, mv.ctypes.data, iterations, out.ctypes.data) == 0
+    dirs, refs_used = set(), set()
+    for i in range(n):
+        e, g = exp[i], out[i]
+        d = int(e[1])
+        # the uni-directional halves first (cost, ref_idx, mv, mvp_idx per list)
+        for l in range(2):
+            u = e[64 + 6 * l:70 + 6 * l]
+            got = (int(g[10 + l]), int(g[14 + 4 * l]), int(g[16 + 4 * l]), int(g[17 + 4 * l]),
+                   int(g[15 + 4 * l]))
+            assert got == tuple(int(v) for v in u[:5]), (i, l, tuple(blocks[l][0][i]), got, u)
+        assert int(g[12]) == int(e[75]) & 0xffffffff, (i, g[12], e[75])
+        want = [d, int(e[0])]
+        have = [int(g[0]), int(g[1])]
+        for l in range(2):
+            if d == 2 or d == l:
+                want += [int(e[2 + 4 * l]), int(e[5 + 4 * l]), int(e[3 + 4 * l]), int(e[4 + 4 * l])]
+                have += [int(v) for v in g[2 + 4 * l:6 + 4 * l]]
+                refs_used.add((l, int(e[2 + 4 * l])))
+        if have != want:
+            print("CU", i, "host", " ".join(str(int(v)) for v in g[:24]))
+            print("CU", i, "ref ", " ".join(str(int(v)) for v in e[:16]), "|",
+                  " ".join(str(int(v)) for v in e[64:76]))
+        assert have == want, (i, tuple(blocks[0][0][i]))
+        dirs.add(d)
+    assert 2 in dirs and len(dirs) >= 2, dirs
+    assert len({r for _, r in refs_used}) >= 2, refs_used
+    for p in [O] + R:
+        p.destroy()

@@ -587,6 +587,258 @@ class InterSearch {
     }
     return out;
   }
+  // ---- SearchMotion as the reference configures itself -----------------------
+  // Up to kMaxRefs reference pictures per list (default_num_ref_pics = 2, 3 in
+  // placebo: encoder_settings.cc:36, :48), lists that may name the same pictures,
+  // pictures with only back references, closed-form bit prices.
+  static constexpr int kMaxRefs = 3;
+  // The picture-level inputs of SearchMotion (ReferencePictureLists + PictureData):
+  struct RefLists {
+    int num_ref[2];
+    const Picture *pic[2][kMaxRefs];
+    // ReferencePictureLists::GetSamePocMappingFor(L1) (reference_picture_lists.cc:
+    // 105-122): the list-0 index of the same picture, or -1 (a "unique" picture)
+    int same_poc_in_l0[kMaxRefs];
+    bool pic_is_uni;           // PicturePredictionType::kUni: inter_dir costs 1 bit, else 3
+    bool force_l1_mvd_zero;    // PictureData::GetForceBipredL1MvdZero (only back references)
+  };
+  // GetInterPredBits with fast_inter_pred_bits (inter_search.cc:1084-1130) without
+  // the vector differences: inter direction + reference index (truncated unary: the
+  // last index one bit less) + predictor index
+  static uint32_t RefIdxBits(int num_ref, int ref_idx) {
+    if (num_ref <= 1) return 0;
+    return static_cast<uint32_t>(ref_idx + 1 - (ref_idx == num_ref - 1 ? 1 : 0));
+  }
+  struct ListChoice {
+    int ref_idx, mvp_idx;
+    int mv_x, mv_y;
+  };
+  struct MotionChoiceMulti {
+    int inter_dir;             // 0: L0, 1: L1, 2: bi
+    ListChoice list[2];
+    uint32_t cost;
+    uint32_t cost_l0, cost_l1, cost_l1_unique, cost_bi;
+    ListChoice uni[2];         // the lists' uni-directional choices
+    int bi_steps;
+    // TzSearch's result per (list, picture) actually searched: the next CU's
+    // previous_fullpel_ (inter_search.cc:637); untouched where nothing was searched
+    int32_t fullpel[2][kMaxRefs][2];
+  };
+  // blocks[l][r][i]: CU i's descriptor for reference r of list l (previous vector
+  // and search range are per picture); mvp[l][r][i] = {x0, y0, x1, y1}.
+  std::vector<MotionChoiceMulti> SearchMotionMultiBatch(
+      const Picture &orig_pic, const RefLists &refs,
+      const std::vector<xvcgpu_me_block> blocks[2][kMaxRefs],
+      const std::vector<std::array<int32_t, 4>> mvp[2][kMaxRefs], int num_iterations) const {
+    const size_t n = blocks[0][0].size();
+    const uint32_t kNone = 0xffffffffu;
+    std::vector<MotionChoiceMulti> out(n);
+    // per (list, picture): what SearchRefIdx remembers for the bi-directional
+    // refinement (unipred_best_mv_ / _mvp_idx_ / _dist_, :550-554)
+    struct Uni {
+      int mvp_idx, mv_x, mv_y;
+      uint32_t dist;
+    };
+    std::vector<Uni> uni[2][kMaxRefs];
+    std::vector<ListChoice> best[2], best_unique(n);
+    std::vector<uint32_t> cost_best[2], cost_unique(n, kNone);
+    for (size_t i = 0; i < n; i++)
+      for (int l = 0; l < 2; l++)
+        for (int r = 0; r < kMaxRefs; r++) out[i].fullpel[l][r][0] = out[i].fullpel[l][r][1] = 0;
+    for (int l = 0; l < 2; l++) {
+      ListChoice none = {-1, 0, 0, 0};
+      best[l].assign(n, none);
+      cost_best[l].assign(n, kNone);
+      const uint32_t dir_bits = refs.pic_is_uni ? 1 : 3;
+      for (int r = 0; r < refs.num_ref[l]; r++) {
+        const std::vector<xvcgpu_me_block> &blk = blocks[l][r];
+        const std::vector<std::array<int32_t, 4>> &pl = mvp[l][r];
+        const bool unique = l == 1 && refs.same_poc_in_l0[r] < 0;
+        const bool reuse = l == 1 && !unique;
+        const bool force_zero = refs.force_l1_mvd_zero && l == 1;
+        const std::vector<StartMvp> start = EvalStartMvpBatch(orig_pic, *refs.pic[l][r], blk, pl);
+        uni[l][r].resize(n);
+        if (force_zero) {
+          // :496-518: the predictor itself is the candidate, priced by EvalStartMvp
+          for (size_t i = 0; i < n; i++)
+            if (start[i].cost < cost_best[l][i]) {
+              ListChoice c = {r, start[i].idx, pl[i][2 * start[i].idx], pl[i][2 * start[i].idx + 1]};
+              best[l][i] = c;
+              cost_best[l][i] = start[i].cost;
+            }
+          if (!unique) continue;
+        }
+        std::vector<xvcgpu_me_result> res;
+        if (!reuse) {
+          std::vector<xvcgpu_me_block> jobs(blk);
+          for (size_t i = 0; i < n; i++) {
+            jobs[i].mvp_x = pl[i][2 * start[i].idx];
+            jobs[i].mvp_y = pl[i][2 * start[i].idx + 1];
+          }
+          res = MotionEstNormalBatch(orig_pic, *refs.pic[l][r], jobs);
+        }
+        for (size_t i = 0; i < n; i++) {
+          const bool fp = (blk[i].fullpel_mv & XVC_ME_FULLPEL_MV) != 0;
+          int mv_x, mv_y;
+          uint32_t dist;
+          if (reuse) {                 // :536-542: list 0 searched this picture already
+            const Uni &u0 = uni[0][refs.same_poc_in_l0[r]][i];
+            mv_x = u0.mv_x;
+            mv_y = u0.mv_y;
+            dist = u0.dist;
+          } else {
+            if (res[i].subpel_dist == XVCGPU_ME_UNSUPPORTED)
+              throw Error(XVCGPU_UNSUPPORTED, "SearchMotionMultiBatch: job not taken by the search");
+            mv_x = res[i].mv_x;
+            mv_y = res[i].mv_y;
+            dist = res[i].subpel_dist;
+            out[i].fullpel[l][r][0] = res[i].fullpel_x;
+            out[i].fullpel[l][r][1] = res[i].fullpel_y;
+          }
+          const int idx = EvalFinalMvpIdx(pl[i], mv_x, mv_y, start[i].idx, fp);
+          Uni u = {idx, mv_x, mv_y, dist};
+          uni[l][r][i] = u;
+          const uint32_t bits = dir_bits + RefIdxBits(refs.num_ref[l], r) + GetMvpBits(idx, 2) +
+                                GetMvdBits(pl[i][2 * idx], pl[i][2 * idx + 1], mv_x, mv_y, fp ? 2 : 0);
+          const uint32_t cost =
+              dist + static_cast<uint32_t>((static_cast<uint64_t>(bits) * blk[i].lambda16) >> 16);
+          ListChoice c = {r, idx, mv_x, mv_y};
+          if (!force_zero && cost < cost_best[l][i]) {
+            cost_best[l][i] = cost;
+            best[l][i] = c;
+          }
+          if (unique && cost < cost_unique[i]) {
+            cost_unique[i] = cost;
+            best_unique[i] = c;
+          }
+        }
+      }
+    }
+    // ---- SearchBiIterative (:392-433) over (searched, other) picture pairs -----
+    struct BiState {
+      ListChoice list[2];
+      uint32_t cost;
+      int search_list;
+      bool active;
+    };
+    std::vector<BiState> bi(n);
+    int iterations = num_iterations;
+    for (size_t i = 0; i < n; i++) {
+      BiState b = {{best[0][i], best[1][i]}, kNone,
+                   cost_best[0][i] <= cost_best[1][i] ? 1 : 0, true};
+      if (refs.force_l1_mvd_zero) b.search_list = 0;
+      bi[i] = b;
+      out[i].bi_steps = 0;
+    }
+    if (refs.force_l1_mvd_zero) iterations = 1;
+    for (int it = 0; it < iterations; it++) {
+      bool any = false;
+      // this iteration's candidates: per CU every picture of its searched list
+      struct Cand {
+        size_t cu;
+        int r;
+      };
+      std::vector<std::vector<xvcgpu_bi_block>> jobs(2 * kMaxRefs * kMaxRefs);
+      std::vector<std::vector<Cand>> of(2 * kMaxRefs * kMaxRefs);
+      for (size_t i = 0; i < n; i++) {
+        if (!bi[i].active) continue;
+        const int l = bi[i].search_list, o = 1 - l;
+        const ListChoice &other = bi[i].list[o];
+        for (int r = 0; r < refs.num_ref[l]; r++) {
+          const Uni &u = uni[l][r][i];
+          xvcgpu_bi_block j = xvcgpu_bi_block();
+          j.blk = blocks[l][r][i];
+          j.blk.mvp_x = mvp[l][r][i][2 * u.mvp_idx];
+          j.blk.mvp_y = mvp[l][r][i][2 * u.mvp_idx + 1];
+          j.other_mv_x = other.mv_x;
+          j.other_mv_y = other.mv_y;
+          j.boot_mv_x = u.mv_x;
+          j.boot_mv_y = u.mv_y;
+          const int g = (l * kMaxRefs + r) * kMaxRefs + other.ref_idx;
+          jobs[g].push_back(j);
+          Cand c = {i, r};
+          of[g].push_back(c);
+        }
+      }
+      // every candidate of this iteration is evaluated against the state the CU
+      // had when the iteration began; the fold below walks them in picture order
+      std::vector<std::vector<xvcgpu_me_result>> res(jobs.size());
+      for (size_t g = 0; g < jobs.size(); g++) {
+        if (jobs[g].empty()) continue;
+        any = true;
+        const int l = static_cast<int>(g) / (kMaxRefs * kMaxRefs);
+        const int r = static_cast<int>(g) / kMaxRefs % kMaxRefs, ro = static_cast<int>(g) % kMaxRefs;
+        res[g] = SearchBiStepBatch(orig_pic, *refs.pic[1 - l][ro], *refs.pic[l][r], jobs[g]);
+      }
+      if (!any) break;
+      std::vector<uint32_t> prev_best(n);
+      std::vector<BiState> next(bi);
+      for (size_t i = 0; i < n; i++) prev_best[i] = bi[i].cost;
+      for (int l = 0; l < 2; l++)
+        for (int r = 0; r < kMaxRefs; r++)
+          for (int ro = 0; ro < kMaxRefs; ro++) {
+            const size_t g = static_cast<size_t>((l * kMaxRefs + r) * kMaxRefs + ro);
+            for (size_t k = 0; k < of[g].size(); k++) {
+              const size_t i = of[g][k].cu;
+              const xvcgpu_me_block &blk = blocks[l][r][i];
+              const bool fp = (blk.fullpel_mv & XVC_ME_FULLPEL_MV) != 0;
+              const std::array<int32_t, 4> &pl = mvp[l][r][i];
+              Uni &u = uni[l][r][i];
+              const int idx = EvalFinalMvpIdx(pl, res[g][k].mv_x, res[g][k].mv_y, u.mvp_idx, fp);
+              ListChoice cand = {r, idx, res[g][k].mv_x, res[g][k].mv_y};
+              if (num_iterations > 1) {     // :550-554
+                Uni nu = {idx, cand.mv_x, cand.mv_y, res[g][k].subpel_dist};
+                u = nu;
+              }
+              ListChoice st[2];
+              st[l] = cand;
+              st[1 - l] = bi[i].list[1 - l];
+              uint32_t bits = 5;
+              for (int q = 0; q < 2; q++) {
+                const std::array<int32_t, 4> &pq = mvp[q][st[q].ref_idx][i];
+                bits += RefIdxBits(refs.num_ref[q], st[q].ref_idx) + GetMvpBits(st[q].mvp_idx, 2);
+                if (refs.force_l1_mvd_zero && q == 1) continue;   // GetForceMvdZero
+                bits += GetMvdBits(pq[2 * st[q].mvp_idx], pq[2 * st[q].mvp_idx + 1], st[q].mv_x,
+                                   st[q].mv_y, fp ? 2 : 0);
+              }
+              const uint32_t cost =
+                  res[g][k].subpel_dist +
+                  static_cast<uint32_t>((static_cast<uint64_t>(bits) * blk.lambda16) >> 16);
+              out[i].bi_steps++;
+              if (cost < next[i].cost) {
+                next[i].cost = cost;
+                next[i].list[l] = cand;
+              }
+            }
+          }
+      for (size_t i = 0; i < n; i++) {
+        if (!bi[i].active) continue;
+        bi[i].cost = next[i].cost;
+        bi[i].list[0] = next[i].list[0];
+        bi[i].list[1] = next[i].list[1];
+        if (bi[i].cost == prev_best[i])
+          bi[i].active = false;        // :427
+        else
+          bi[i].search_list = 1 - bi[i].search_list;
+      }
+    }
+    for (size_t i = 0; i < n; i++) {
+      MotionChoiceMulti &c = out[i];
+      c.cost_l0 = cost_best[0][i];
+      c.cost_l1 = cost_best[1][i];
+      c.cost_l1_unique = cost_unique[i];
+      c.cost_bi = bi[i].cost;
+      c.uni[0] = best[0][i];
+      c.uni[1] = best[1][i];
+      const int pick = ChooseUniOrBi(c.cost_l0, c.cost_l1_unique, c.cost_bi);
+      c.inter_dir = pick == 0 ? 2 : pick - 1;
+      c.list[0] = pick == 0 ? bi[i].list[0] : best[0][i];
+      c.list[1] = pick == 0 ? bi[i].list[1] : (pick == 2 ? best_unique[i] : best[1][i]);
+      c.cost = pick == 0 ? c.cost_bi : (pick == 1 ? c.cost_l0 : c.cost_l1_unique);
+    }
+    return out;
+  }
+
   // InterSearch::MotionEstAffine (inter_search.cc:664-749) per job: the gradient
   // iteration from the affine predictor / bootstrap vector on ref_pic; jobs
   // with XVC_AFFINE_ME_BIPRED search against 2 * orig - the other list's affine

@@ -184,6 +184,78 @@ int xvc_host_search_motion_batch(xvcgpu_ctx *ctx, xvcgpu_picture *orig, xvcgpu_p
   }
 }
 
+// InterSearch::SearchMotion with up to three reference pictures per list
+// (xvc_gpu::InterSearch::SearchMotionMultiBatch): ref_pics[l * 3 + r] (NULL beyond
+// num_ref[l]), same_poc_in_l0[r] for the list-1 pictures, blocks[(l * 3 + r) * n + i],
+// mvp[((l * 3 + r) * n + i) * 4]; out[n][32] = {inter_dir, cost, then per list
+// {ref_idx, mvp_idx, mv_x, mv_y} at [2 + 4 l], cost_l0, cost_l1, cost_l1_unique,
+// cost_bi at [10..13], the lists' uni-directional choices {ref_idx, mvp_idx, mv_x,
+// mv_y} at [14 + 4 l], bi_steps at [22]}.
+int xvc_host_search_motion_multi_batch(xvcgpu_ctx *ctx, xvcgpu_picture *orig,
+                                       xvcgpu_picture *const *ref_pics, const int32_t *num_ref,
+                                       const int32_t *same_poc_in_l0, int pic_is_uni,
+                                       int force_l1_mvd_zero, const xvcgpu_me_block *blocks, int n,
+                                       const int32_t *mvp, int num_iterations, int64_t *out) {
+  typedef xvc_gpu::InterSearch IS;
+  if (!ctx || !orig || !ref_pics || !num_ref || !same_poc_in_l0 || !blocks || !mvp || !out ||
+      n < 0 || num_iterations < 1 || num_ref[0] < 1 || num_ref[0] > IS::kMaxRefs ||
+      num_ref[1] < 1 || num_ref[1] > IS::kMaxRefs)
+    return XVCGPU_INVALID_ARGUMENT;
+  try {
+    xvc_gpu::Context c(ctx);
+    xvc_gpu::Picture o(c, orig);
+    std::vector<std::unique_ptr<xvc_gpu::Picture>> views;
+    IS::RefLists refs;
+    std::vector<xvcgpu_me_block> b[2][IS::kMaxRefs];
+    std::vector<Mvp> m[2][IS::kMaxRefs];
+    for (int l = 0; l < 2; l++) {
+      refs.num_ref[l] = num_ref[l];
+      for (int r = 0; r < IS::kMaxRefs; r++) {
+        refs.pic[l][r] = nullptr;
+        if (r >= num_ref[l]) continue;
+        if (!ref_pics[l * IS::kMaxRefs + r]) return XVCGPU_INVALID_ARGUMENT;
+        views.emplace_back(new xvc_gpu::Picture(c, ref_pics[l * IS::kMaxRefs + r]));
+        refs.pic[l][r] = views.back().get();
+        const size_t at = static_cast<size_t>(l * IS::kMaxRefs + r) * n;
+        b[l][r].assign(blocks + at, blocks + at + n);
+        m[l][r] = MvpList(mvp + 4 * at, n);
+      }
+    }
+    for (int r = 0; r < IS::kMaxRefs; r++) {
+      refs.same_poc_in_l0[r] = r < num_ref[1] ? same_poc_in_l0[r] : -1;
+      if (refs.same_poc_in_l0[r] >= num_ref[0]) return XVCGPU_INVALID_ARGUMENT;
+    }
+    refs.pic_is_uni = pic_is_uni != 0;
+    refs.force_l1_mvd_zero = force_l1_mvd_zero != 0;
+    const std::vector<IS::MotionChoiceMulti> res =
+        IS(c).SearchMotionMultiBatch(o, refs, b, m, num_iterations);
+    for (int i = 0; i < n; i++) {
+      int64_t *q = out + 32 * i;
+      for (int k = 0; k < 32; k++) q[k] = 0;
+      q[0] = res[i].inter_dir;
+      q[1] = res[i].cost;
+      for (int l = 0; l < 2; l++) {
+        q[2 + 4 * l] = res[i].list[l].ref_idx;
+        q[3 + 4 * l] = res[i].list[l].mvp_idx;
+        q[4 + 4 * l] = res[i].list[l].mv_x;
+        q[5 + 4 * l] = res[i].list[l].mv_y;
+        q[14 + 4 * l] = res[i].uni[l].ref_idx;
+        q[15 + 4 * l] = res[i].uni[l].mvp_idx;
+        q[16 + 4 * l] = res[i].uni[l].mv_x;
+        q[17 + 4 * l] = res[i].uni[l].mv_y;
+      }
+      q[10] = res[i].cost_l0;
+      q[11] = res[i].cost_l1;
+      q[12] = res[i].cost_l1_unique;
+      q[13] = res[i].cost_bi;
+      q[22] = res[i].bi_steps;
+    }
+    return XVCGPU_OK;
+  } catch (const xvc_gpu::Error &e) {
+    return e.status;
+  }
+}
+
 int xvc_host_choose_uni_or_bi(uint32_t cost_l0, uint32_t cost_l1_unique, uint32_t cost_bi) {
   return xvc_gpu::InterSearch::ChooseUniOrBi(cost_l0, cost_l1_unique, cost_bi);
 }
