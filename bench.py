@@ -45,6 +45,14 @@ def parse():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--qp", type=int, default=32)
     ap.add_argument("--frames", type=int, default=8, help="distinct synthetic frames")
+    ap.add_argument("--settle", type=int, default=-1,
+                    help="untimed frame passes before the warmup so that the picture chains "
+                         "are in their steady state when the clock starts (a chain codes every "
+                         "picture against the previous RECONSTRUCTION: quantisation noise builds "
+                         "up over the first few hundred pictures - 2092 coded luma blocks in a "
+                         "chain's first picture, 8146 after 600 - and with it the quantiser's "
+                         "load; without this a 20-step and a 1000-step run time different "
+                         "workloads).  -1 = automatic: 1500 per chain on one GPU, 0 otherwise")
     ap.add_argument("--cpu-frames", type=int, default=12,
                     help="cap on the single-thread CPU oracle frame passes (rank 0, N=1)")
     ap.add_argument("--no-cpu", action="store_true")
@@ -601,6 +609,11 @@ def main_pictures(args, torch, api, pipeline, synth, world, rank, local_rank):
                                    "16x16 CUs, TZ range 96, %s" %
                                    (W, H, args.qp, "RDOQ" if rdoq else "QuantFast"),
                        "cus_per_picture": fp.desc.n_cus_total,
+                       "regime": ("steady state of open picture chains (every picture coded "
+                                  "against the previous reconstruction, no key-picture refresh), "
+                                  "reached by %d untimed settle passes per chain before the "
+                                  "warmup" % (settle // n_chains)) if settle else
+                                 "chains started from the original of the first picture",
                        "parallelism": "picture-level: sub-GOP 16 (layers of 1, 1, 2, 4, 8 "
                                       "pictures), ThreadEncoder policy on %d rank(s) x %d picture "
                                       "slots, each picture against its nearest L0 reference; "
@@ -812,12 +825,18 @@ def main():
     if runner is None and args.graph:
         for i in range(2 * cycle_len * n_chains):
             step(i, record_only=True)
-    for i in range(args.warmup):
+    settle = args.settle
+    if settle < 0:
+        settle = 1500 * n_chains if (runner is None and not args.graph and not pipelined) else 0
+    settle -= settle % (2 * n_chains)      # keep the ping-pong parity and the chains' turn
+    for i in range(settle):
+        step(i)
+    for i in range(settle, settle + args.warmup):
         step(i)
     barrier()
     t0 = time.perf_counter()
     ctx.timer_begin()
-    for i in range(args.warmup, args.warmup + args.steps):
+    for i in range(settle + args.warmup, settle + args.warmup + args.steps):
         step(i)
     if ctx_lo is not None:
         ctx.wait_for(ctx_lo)  # the event timer sits on the high-priority queue
@@ -860,7 +879,7 @@ def main():
             return ctx.timer_end() / reps
 
         # continue chain 0 where the timed region left it
-        base = -(-(args.warmup + args.steps) // n_chains)
+        base = -(-(settle + args.warmup + args.steps) // n_chains)
         for i in range(base, base + cycle):
             k = i % cycle
             o = origs[k if k < F else 2 * F - 2 - k]
@@ -963,6 +982,11 @@ def main():
                                     "picture-initial CABAC contexts)" if rdoq else
                                     "QuantFast"),
                        "cus_per_picture": fp.desc.n_cus_total,
+                       "regime": ("steady state of open picture chains (every picture coded "
+                                  "against the previous reconstruction, no key-picture refresh), "
+                                  "reached by %d untimed settle passes per chain before the "
+                                  "warmup" % (settle // n_chains)) if settle else
+                                 "chains started from the original of the first picture",
                        "parallelism": (("two-queue" if pipelined else
                                         "single" if n_chains == 1 else
                                         "%d independent picture chains in flight" % n_chains)

@@ -57,7 +57,7 @@ __constant__ uint32_t kEntropyBits[128] = {
 #define RQ_BYPASS 32768u  // ContextModel::kEntropyBypassBits
 
 // Per-block scratch: N = coefficients of the (at most 32x32) low-frequency
-// region; arrays indexed by position y * rw + x.
+// region; arrays indexed by rec_pos(x, y) (sub-block major, RQ_SB_STRIDE).
 // Developer build (-DXVCGPU_TRACE): clock readings of the walk's sections, one
 // row per workgroup of quant_rdo_packed_kernel (tools/trace_rdoq.py).
 #ifdef XVCGPU_TRACE
@@ -99,15 +99,32 @@ __device__ unsigned long long g_rq_trace[4096][16];
 #define RQ_STEP2_END() do {} while (0)
 #endif
 
-template <int N>
+// Per-coefficient records are laid out sub-block by sub-block with a stride of 17
+// entries (rq_pos): the lanes of a group address the SAME offset of DIFFERENT
+// sub-blocks together, and with the raster layout (stride 4 in x, 64 in y) the
+// 16 lanes of a 16x16 block - and the four blocks of a wave - fell onto the same
+// LDS banks (SQ_LDS_BANK_CONFLICT was 52 % of the LDS cycles).  17 is odd: any 16
+// consecutive sub-blocks land on distinct banks for 1-, 2-, 4- and 8-byte entries.
+#define RQ_SB_STRIDE 17
+#define RQ_PADDED(n) ((n) + (n) / 16)
+// the coefficient / level tiles of the packed kernel are copied 8 bytes at a
+// time: stride 20 keeps every sub-block row 8-byte aligned
+#define RQ_CF_STRIDE 20
+#define RQ_CF_PADDED(n) ((n) + (n) / 4)
+
+template <int N0>
 struct RdoqShared {
-  long long cost_to_zero[N];   // coeff_cost_to_zero_
+  static constexpr int N = RQ_PADDED(N0);
+  // coeff_cost_to_zero_ is not kept (8 of a coefficient's 19 bytes: the records'
+  // size is what limits the waves per CU): EvalLastPos recomputes a coefficient's
+  // entry from what is kept - its level, its decision-time state and contexts
+  // (rq ctz_of).
   // coeff_sig_bits_ / the sig-flag rate as what they are made of: the index (in
   // contexts, not table entries) of the coefficient's significance context - the
   // two bin costs are ctx_bits[2 * i], [2 * i + 1] -, 1 byte instead of 8: with
   // the records in LDS their size is what limits the waves per CU
   unsigned char sig_ci[N];
-  int rate_up[N];              // level 0: the rate; else the decision-time state (RQ_STATE_PACK)
+  unsigned short rate_up[N];   // the decision-time state, 16 bits (RQ_STATE_PACK)
   short err_dist[N];
   long long sb_code_cost[64], sb_zero_dist[64];
   unsigned csbf_bits[64];      // csbf_bits_to_zero
@@ -127,9 +144,8 @@ struct RdoqShared {
 // The same members as pointers (packed kernel: per-coefficient arrays in
 // global memory, the rest in LDS).
 struct RdoqView {
-  long long *cost_to_zero;
   unsigned char *sig_ci;
-  int *rate_up;
+  unsigned short *rate_up;
   short *err_dist;
   long long *sb_code_cost, *sb_zero_dist;
   unsigned *csbf_bits;
@@ -177,6 +193,19 @@ __device__ __forceinline__ int rq_wave_sum_i32(int v) {
 #pragma unroll
   for (int s = 1; s < G; s <<= 1) v += __shfl_xor(v, s, 64);
   return v;
+}
+
+// 64-bit sum over each aligned group of SEG (4 or 16) lanes without LDS traffic:
+// three 32-bit DPP sums (the high word, and the low word as two 16-bit halves so
+// that no partial sum can overflow); every lane of the group gets the total.
+template <int SEG>
+__device__ __forceinline__ long long rq_group_sum_i64(long long v) {
+  const unsigned lo = (unsigned)v;
+  const int hi = dpp_group_sum<SEG>((int)(v >> 32));
+  const int l0 = dpp_group_sum<SEG>((int)(lo & 0xffffu));
+  const int l1 = dpp_group_sum<SEG>((int)(lo >> 16));
+  return (long long)(((unsigned long long)(unsigned)hi << 32) +
+                     ((unsigned long long)(unsigned)l1 << 16) + (unsigned long long)(unsigned)l0);
 }
 
 struct RdoqCoeffState {  // RdoQuant::CoeffCodingState, the part the extended set reads
@@ -311,9 +340,16 @@ __device__ __forceinline__ int rq_scan_pos(int sbs, int order, int k) {
 // (three GetAbsLevelBits evaluations) are formed when - and if - the sign
 // hiding asks for them: rate_up[] then holds the coefficient's decision-time
 // state (RQ_STATE_*), rate_down[] does not exist.
-#define RQ_STATE_PACK(c1_ctx, c2_ctx, c1_idx, c2_idx, k)                                   \
-  ((unsigned)(c1_ctx) | ((unsigned)(c2_ctx) << 9) | ((unsigned)(c1_idx) << 18) |           \
-   ((unsigned)((c2_idx) > 0) << 23) | ((unsigned)(k) << 24))
+// 16 bits: the two greater-flag contexts as offsets inside their group (0..16),
+// what GetAbsLevelBits reads of the budget (c1_idx < 8, c2_idx < 1) and the
+// Golomb-Rice parameter (0..9).  A coefficient left at level 0 only needs the
+// first field (the cost of its greater1 flag's zero bin); RQ_STATE_NO_RATE marks
+// the tail of the last sub-block, whose rate is 0.
+#define RQ_STATE_PACK(c1_off, c2_off, c1_idx, c2_idx, k)                              \
+  ((unsigned short)((unsigned)(c1_off) | ((unsigned)(c2_off) << 5) |                   \
+                    ((unsigned)((c1_idx) >= 8) << 10) | ((unsigned)((c2_idx) > 0) << 11) | \
+                    ((unsigned)(k) << 12)))
+#define RQ_STATE_NO_RATE 31u
 
 template <int G = 64, typename S, typename CF, typename LEV>
 __device__ __forceinline__ int wave_rdoq(S &s, int lane, int bd, int w, int h,
@@ -351,6 +387,12 @@ __device__ __forceinline__ int wave_rdoq(S &s, int lane, int bd, int w, int h,
     x = px + (p & 3);
     y = py + (p >> 2);
   };
+  // where a coefficient's records live (RQ_SB_STRIDE): sub-block major
+  auto rec_pos = [&](int x, int y) {
+    return sbs == 2 ? ((y >> 2) * rgw + (x >> 2)) * RQ_SB_STRIDE + (((y & 3) << 2) | (x & 3))
+                    : y * rw + x;
+  };
+  const int g1_base = luma ? RQ_OFF(greater1_luma) : RQ_OFF(greater1_chroma);
   auto quant = [&](int a) {  // GetFwdQuantFunc on a magnitude (rdo_quant.cc:949-964)
     return (int)(short)(int)((((long long)a * scale) + fq_offset) >> fq_shift);
   };
@@ -442,6 +484,42 @@ __device__ __forceinline__ int wave_rdoq(S &s, int lane, int bd, int w, int h,
     sig_pair(pos, index, k, dcz, sig0, sig1);
     return (int)(sig1 - sig0);
   };
+  // the greater1 / greater2 flag costs and the budget state of a decided
+  // coefficient from its 16-bit record
+  auto state_of = [&](unsigned pk, RdoqFlagBits &fb, RdoqCoeffState &st) {
+    const uint2 c1_b = *reinterpret_cast<const uint2 *>(cb + 2 * (g1_base + (int)(pk & 31u)));
+    const uint2 c2_b =
+        *reinterpret_cast<const uint2 *>(cb + 2 * (g1_base + (int)((pk >> 5) & 31u)));
+    fb.c1_0 = c1_b.x; fb.c1_1 = c1_b.y; fb.c2_0 = c2_b.x; fb.c2_1 = c2_b.y;
+    st.c1_idx = (pk >> 10) & 1u ? 8 : 0;
+    st.c2_idx = (int)((pk >> 11) & 1u);
+    st.golomb_rice_k = pk >> 12;
+  };
+  auto dequant = [&](int lvl) {
+    int deq;
+    if (iq_shift > 0) deq = (lvl * iq_scale + (1 << (iq_shift - 1))) >> iq_shift;
+    else deq = (lvl * iq_scale) << -iq_shift;
+    return (int)(short)d_clip3(deq, -32768, 32767);
+  };
+  // coeff_cost_to_zero_[index] (rdo_quant.cc:350, :307) of a coefficient whose
+  // sub-block is coded, recomputed: zero_cost - best_cost of the decision that
+  // left it at level v.  A level of 0 - chosen, or without a choice - cost a zero
+  // significance flag: -sig0.  A non-zero level cost its distortion + sig1 + the
+  // level's bits in the state the decision saw.  (v < 0: a magnitude of 32768
+  // wrapped, no candidate was priced and best_cost stayed at its initial value.)
+  auto ctz_of = [&](int pos, int index, int k, bool dcz, int abs_coeff, int v) -> long long {
+    unsigned sig0, sig1;
+    sig_pair(pos, index, k, dcz, sig0, sig1);
+    if (v == 0) return -rq_bit_cost(sig0, lambda);
+    const long long zero_cost = ((long long)(abs_coeff * abs_coeff)) << cost_scale;
+    if (v < 0) return zero_cost - 0x7fffffffffffffffll;
+    RdoqFlagBits fb;
+    RdoqCoeffState st;
+    state_of((unsigned)s.rate_up[pos], fb, st);
+    const unsigned bits = sig1 + rq_abs_level_bits(fb, v, st);
+    const int err = abs_coeff - dequant(v);
+    return zero_cost - ((((long long)err * err) << cost_scale) + rq_bit_cost(bits, lambda));
+  };
   if (mine) {
     s.csbf[lane] = 0;
     s.sb_dcz[lane] = 0;
@@ -479,7 +557,7 @@ __device__ __forceinline__ int wave_rdoq(S &s, int lane, int bd, int w, int h,
         const int index = sb_index + k;
         int x, y;
         coeff_xy(k, x, y);
-        const int pos = y * rw + x;
+        const int pos = rec_pos(x, y);
         const int abs_coeff = (short)d_abs(cf(x, y));
         const long long zero_cost = ((long long)(abs_coeff * abs_coeff)) << cost_scale;
         const int q = quant(abs_coeff);
@@ -534,7 +612,6 @@ __device__ __forceinline__ int wave_rdoq(S &s, int lane, int bd, int w, int h,
           }
         }
         *lev(x, y) = (short)best_level;
-        s.cost_to_zero[pos] = zero_cost - best_cost;
         s.sig_ci[pos] = (unsigned char)(sig_ctx >> 1);
         if (dc_sig_zero) s.sb_dcz[lane] = 1;
         code_cost += best_cost;
@@ -545,56 +622,72 @@ __device__ __forceinline__ int wave_rdoq(S &s, int lane, int bd, int w, int h,
         if (best_level) {
           any = true;
           num_non_zero++;
-          s.rate_up[pos] =
-              (int)RQ_STATE_PACK(c1_ctx, c2_ctx, st.c1_idx, st.c2_idx, st.golomb_rice_k);
-        } else {
-          s.rate_up[pos] = (int)fb.c1_0;
         }
+        s.rate_up[pos] = RQ_STATE_PACK((c1_ctx >> 1) - g1_base, (c2_ctx >> 1) - g1_base, st.c1_idx,
+                                       st.c2_idx, st.golomb_rice_k);
         // UpdateCodeState (rdo_quant.cc:880-898); golomb_rice_k is re-derived
         if (best_level >= 1) st.c1_idx++;
         if (best_level >= 2) st.c2_idx++;
       }
       s.sb_code_cost[lane] = code_cost;
+      // EvalZeroSubblock replaces the code cost of a sub-block without a level by
+      // its zero cost (:745-749; not for the first and the last sub-block, :729),
+      // and nothing reads the records of such a sub-block afterwards (it is not
+      // coded): its coefficients without a choice need not be priced at all.  On
+      // real content that is most live sub-blocks.
+      if (!any && !(sb_index == 0 || sb_index + sb_size > last_pos_index)) s.sb_live[lane] = 4;
     }
     wave_sync();
     RQ_STEP(0);
-    // step 2: the coefficients without a choice, dealt over the group's lanes
+    // step 2: the coefficients without a choice, dealt over the group's lanes:
+    // SEG lanes share a sub-block in every round; their costs are summed by
+    // shuffles and added by the segment's first lane (16 lanes adding to one LDS
+    // word with 64-bit atomics serialised)
     {
       const int ax0 = d > rgh - 1 ? d - (rgh - 1) : 0;
       const int ax1 = d < rgw - 1 ? d : rgw - 1;
       const int pairs = (ax1 - ax0 + 1) << (2 * sbs);
-      for (int t = lane; t < pairs; t += G) {
-        const int ax = ax0 + (t >> (2 * sbs)), ay = d - ax, k = t & (sb_size - 1);
+      constexpr int SEG = G < 16 ? G : 16;
+      for (int t0 = 0; t0 < pairs; t0 += G) {
+        const int t = t0 + lane;
+        const bool in = t < pairs;
+        const int ax = ax0 + ((in ? t : 0) >> (2 * sbs)), ay = d - ax, k = t & (sb_size - 1);
         const int l2 = ay * rgw + ax;
-        if (!s.sb_live[l2]) continue;
-        const int p = rq_scan_pos(sbs, scan_order, k);
-        const int x = (ax << sbs) + (p & 3), y = (ay << sbs) + (p >> 2);
-        const int pos = y * rw + x;
-        const int abs_coeff = (short)d_abs(cf(x, y));
-        if (quant(abs_coeff)) continue;  // decided in step 1
-        long long cost = ((long long)(abs_coeff * abs_coeff)) << cost_scale;
-        if (l2 == last_l && k > last_k) {  // rdo_quant.cc:303-307 (+ the memsets :262-265)
-          s.err_dist[pos] = 0;
-          s.rate_up[pos] = 0;
-        } else {
-          int n_sig, n_g1, n_g2, sum_abs;
-          neighbours(x, y, n_sig, n_g1, n_g2, sum_abs);
-          const int sig_ctx2 = sig_ctx_of(x + y, n_sig);
-          const uint2 sig_b = *reinterpret_cast<const uint2 *>(cb + sig_ctx2);
-          const unsigned c1_0 = cb[greater_ctx_of(x + y, n_g1, false)];
-          const long long sig_cost = rq_bit_cost(sig_b.x, lambda);
-          cost += sig_cost;
-          s.cost_to_zero[pos] = -sig_cost;
-          s.sig_ci[pos] = (unsigned char)(sig_ctx2 >> 1);
-          const long long orig_scaled =
-              (((long long)abs_coeff * scale) + size_bias_offset) >> size_bias_shift;
-          s.err_dist[pos] = (short)(orig_scaled >> (shift - 8));
-          // (the k == 0 coefficient of an otherwise empty sub-block codes no flag,
-          // sig1 = 0 at rdo_quant.cc:343; nothing reads the rate of such a sub-block)
-          s.rate_up[pos] = (int)c1_0;
+        long long cost = 0;
+        if (in && s.sb_live[l2] == 1) {
+          const int p = rq_scan_pos(sbs, scan_order, k);
+          const int x = (ax << sbs) + (p & 3), y = (ay << sbs) + (p >> 2);
+          const int pos = rec_pos(x, y);
+          const int abs_coeff = (short)d_abs(cf(x, y));
+          if (!quant(abs_coeff)) {  // (else: decided in step 1)
+            cost = ((long long)(abs_coeff * abs_coeff)) << cost_scale;
+            if (l2 == last_l && k > last_k) {  // rdo_quant.cc:303-307 (+ the memsets :262-265)
+              s.err_dist[pos] = 0;
+              s.rate_up[pos] = (unsigned short)RQ_STATE_NO_RATE;
+            } else {
+              int n_sig, n_g1, n_g2, sum_abs;
+              neighbours(x, y, n_sig, n_g1, n_g2, sum_abs);
+              const int sig_ctx2 = sig_ctx_of(x + y, n_sig);
+              cost += rq_bit_cost(cb[sig_ctx2], lambda);
+              s.sig_ci[pos] = (unsigned char)(sig_ctx2 >> 1);
+              const long long orig_scaled =
+                  (((long long)abs_coeff * scale) + size_bias_offset) >> size_bias_shift;
+              s.err_dist[pos] = (short)(orig_scaled >> (shift - 8));
+              // (the k == 0 coefficient of an otherwise empty sub-block codes no flag,
+              // sig1 = 0 at rdo_quant.cc:343; nothing reads the rate of such a sub-block)
+              s.rate_up[pos] =
+                  (unsigned short)((greater_ctx_of(x + y, n_g1, false) >> 1) - g1_base);
+            }
+          }
         }
-        atomicAdd(reinterpret_cast<unsigned long long *>(&s.sb_code_cost[l2]),
-                  (unsigned long long)cost);
+        // (sb_size < SEG only for 2x2 sub-blocks: then a segment is one sub-block too)
+        if (sbs == 2) {
+          cost = rq_group_sum_i64<SEG>(cost);
+          if ((lane & (SEG - 1)) == 0 && in && cost) s.sb_code_cost[l2] += cost;
+        } else {
+          cost = rq_group_sum_i64<4>(cost);
+          if ((lane & 3) == 0 && in && cost) s.sb_code_cost[l2] += cost;
+        }
       }
     }
     wave_sync();
@@ -650,7 +743,6 @@ __device__ __forceinline__ int wave_rdoq(S &s, int lane, int bd, int w, int h,
         const int p = rq_scan_pos(sbs, scan_order, k);
         const int x = (ax << sbs) + (p & 3), y = (ay << sbs) + (p >> 2);
         *lev(x, y) = 0;
-        s.cost_to_zero[y * rw + x] = 0;
       }
       wave_sync();
     }
@@ -711,38 +803,57 @@ __device__ __forceinline__ int wave_rdoq(S &s, int lane, int bd, int w, int h,
         s.lp_bits[is_x ? g : LPY + g] = rq_last_pos_group_bits(cb, luma, tw, th, g, is_x);
       }
     }
-    // own sub-block, back from start_k: the running sum of zero costs in front of
-    // every coefficient replaces its cost_to_zero entry (nothing reads those
-    // after this), the non-zero levels are noted in a mask; four coefficients'
-    // reads in flight at a time
-    long long run = 0;
-    unsigned nz = 0;
-    int stop_local = -1;
-    if (coded)
-      for (int kb = (sb_size - 1) & ~3; kb >= 0; kb -= 4) {
-        long long z[4];
-        int v[4], pos[4];
+    // own sub-block, back from start_k, in ONE pass: the running sum of the
+    // coefficients' cost_to_zero (recomputed, ctz_of) and, at every non-zero
+    // level, the candidate's part that belongs to this sub-block (running sum +
+    // last-position bits - its implicit significance bits); the cheapest is kept,
+    // on equal cost the one met first.  The walk ends at the first level above 1:
+    // candidates behind it - in this sub-block or in the sub-blocks below the one
+    // that holds the highest such level - do not count.
+    long long run = 0, part_best = 0x7fffffffffffffffll;
+    int part_k = -1, stop_local = -1;
+    if (coded) {
+      const bool dcz = s.sb_dcz[lane] != 0;
+      // four coefficients' reads in flight at a time (the walk itself is serial:
+      // the running sum, and it ends at the first level above 1)
+      for (int kb = (sb_size - 1) & ~3; kb >= 0 && stop_local < 0; kb -= 4) {
+        int v[4], ac[4], pos[4], xs[4], ys[4];
+        unsigned sig0[4], sig1[4];
 #pragma unroll
         for (int i = 0; i < 4; i++) {
           const int k = kb + 3 - i;
           int x, y;
           coeff_xy(k < sb_size ? k : 0, x, y);
-          pos[i] = y * rw + x;
-          const bool in = k < sb_size && k <= start_k;
-          z[i] = in ? s.cost_to_zero[pos[i]] : 0ll;
-          v[i] = in ? (int)*lev(x, y) : 0;
+          xs[i] = x;
+          ys[i] = y;
+          pos[i] = rec_pos(x, y);
+          v[i] = (int)*lev(x, y);
+          ac[i] = (short)d_abs(cf(x, y));
+          sig_pair(pos[i], sb_index + k, k, dcz, sig0[i], sig1[i]);
         }
 #pragma unroll
         for (int i = 0; i < 4; i++) {
           const int k = kb + 3 - i;
-          if (k < sb_size && k <= start_k) {
-            s.cost_to_zero[pos[i]] = run;
-            run += z[i];
-            if (v[i]) nz |= 1u << k;
-            if (v[i] > 1 && stop_local < 0) stop_local = sb_index + k;
+          if (k >= sb_size || k > start_k || stop_local >= 0) continue;
+          long long ctz = -rq_bit_cost(sig0[i], lambda);
+          if (v[i]) {
+            const unsigned lp_bits = s.lp_bits[rq_last_pos_group(lp_swap ? ys[i] : xs[i])] +
+                                     s.lp_bits[LPY + rq_last_pos_group(lp_swap ? xs[i] : ys[i])];
+            const long long part =
+                run + rq_bit_cost(lp_bits, lambda) - rq_bit_cost(sig1[i], lambda);
+            if (part < part_best) {
+              part_best = part;
+              part_k = k;
+            }
+            if (v[i] > 1) stop_local = sb_index + k;
+            ctz = ctz_of(pos[i], sb_index + k, k, dcz, ac[i], v[i]);
           }
+          run += ctz;
         }
       }
+      // (the sum is only needed in full by the sub-blocks in FRONT of this one, and
+      // they only count when no level above 1 lies here: then the loop ran to k = 0)
+    }
     const long long t = run - flag_cost;
     RQ_STEP(0);
     wave_sync();   // every lane has read its sb_code_cost entry (the sums above)
@@ -752,27 +863,11 @@ __device__ __forceinline__ int wave_rdoq(S &s, int lane, int bd, int w, int h,
     long long best_cost = 0x7fffffffffffffffll;
     int best_last_plus1 = 0;
     RQ_STEP(1);
-    if (nz && sb_index + start_k >= stop_idx) {
+    if (part_k >= 0 && sb_index + start_k >= stop_idx && (stop_local < 0 || stop_local == stop_idx)) {
       long long c = comp_code_cost + rq_bit_cost(cb[cbf_ctx + 1], lambda) - flag_cost;
       for (int j = my_scan + 1; j <= last_sb; j++) c += s.sb_code_cost[j];
-      while (nz) {
-        const int k = 31 - __clz((int)nz);
-        nz ^= 1u << k;
-        if (sb_index + k < stop_idx) break;
-        int x, y;
-        coeff_xy(k, x, y);
-        const int pos = y * rw + x;
-        const unsigned lp_bits = s.lp_bits[rq_last_pos_group(lp_swap ? y : x)] +
-                                 s.lp_bits[LPY + rq_last_pos_group(lp_swap ? x : y)];
-        unsigned sg0, sg1;
-        sig_pair(pos, sb_index + k, k, s.sb_dcz[lane] != 0, sg0, sg1);
-        const long long cost = c + s.cost_to_zero[pos] + rq_bit_cost(lp_bits, lambda) -
-                               rq_bit_cost(sg1, lambda);
-        if (cost < best_cost) {
-          best_cost = cost;
-          best_last_plus1 = sb_index + k + 1;
-        }
-      }
+      best_cost = c + part_best;
+      best_last_plus1 = sb_index + part_k + 1;
     }
     RQ_STEP(2);
 #pragma unroll
@@ -811,10 +906,12 @@ __device__ __forceinline__ int wave_rdoq(S &s, int lane, int bd, int w, int h,
         for (int k = start; k >= 0; k--) {
           const int p = rq_scan_pos(sbs, scan_order, k);
           const int x = (tx << sbs) + (p & 3), y = (ty << sbs) + (p >> 2);
-          const int pos = y * rw + x;
+          const int pos = rec_pos(x, y);
           const int v = *lev(x, y);
+          const long long ctz =
+              ctz_of(pos, idx + k, k, s.sb_dcz[l] != 0, (int)(short)d_abs(cf(x, y)), v);
           if (!v) {
-            code_cost += s.cost_to_zero[pos];
+            code_cost += ctz;
             continue;
           }
           const unsigned lp_bits = rq_last_pos_bits(cb, luma, w, h, scan_order, x, y);
@@ -830,7 +927,7 @@ __device__ __forceinline__ int wave_rdoq(S &s, int lane, int bd, int w, int h,
             stop = true;
             break;
           }
-          code_cost += s.cost_to_zero[pos];
+          code_cost += ctz;
         }
         start = sb_size - 1;
       }
@@ -885,17 +982,15 @@ __device__ __forceinline__ int wave_rdoq(S &s, int lane, int bd, int w, int h,
       for (int k = is_last_sb ? lastk : 15; k >= 0; k--) {
         int x, y;
         coeff_xy(k, x, y);
-        const int pos = y * rw + x;
+        const int pos = rec_pos(x, y);
         const int lvl = *lev(x, y);
         long long cost;
         int delta;
         if (lvl != 0) {
           // rate_up / rate_down (rdo_quant.cc:367-374) from the decision-time state
-          const unsigned pk = (unsigned)s.rate_up[pos];
-          const uint2 c1_b = *reinterpret_cast<const uint2 *>(cb + (pk & 511u));
-          const uint2 c2_b = *reinterpret_cast<const uint2 *>(cb + ((pk >> 9) & 511u));
-          const RdoqFlagBits fb = {c1_b.x, c1_b.y, c2_b.x, c2_b.y};
-          const RdoqCoeffState st = {(int)((pk >> 18) & 31u), (int)((pk >> 23) & 1u), pk >> 24};
+          RdoqFlagBits fb;
+          RdoqCoeffState st;
+          state_of((unsigned)s.rate_up[pos], fb, st);
           const int al = d_abs(lvl);
           const int lvl_rate = (int)rq_abs_level_bits(fb, al, st);
           const int rate_up = -lvl_rate + (int)rq_abs_level_bits(fb, al + 1, st);
@@ -912,7 +1007,10 @@ __device__ __forceinline__ int wave_rdoq(S &s, int lane, int bd, int w, int h,
             cost = (k == first && al == 1) ? 0x7fffffffll : cost_dec;
           }
         } else {
-          cost = rd_factor * -(long long)d_abs((int)s.err_dist[pos]) + s.rate_up[pos] +
+          // the rate of a level that was left at 0: the zero bin of its greater1 flag
+          const unsigned c1_off = (unsigned)s.rate_up[pos] & 31u;
+          const int rate0 = c1_off == RQ_STATE_NO_RATE ? 0 : (int)cb[2 * (g1_base + (int)c1_off)];
+          cost = rd_factor * -(long long)d_abs((int)s.err_dist[pos]) + rate0 +
                  sig_rate_of(pos, sb_index + k, k, s.sb_dcz[lane] != 0) + (long long)RQ_BYPASS;
           delta = 1;
           if (k < first && (cf(x, y) >= 0 ? 0 : 1) != first_sign) cost = 0x7fffffffll;
@@ -951,7 +1049,9 @@ struct RdoqLists {
   int *list[3];       // block indices per class (4 / 16 / 64 lanes)
   int *count;         // [3]
   signed char *cls;   // per block: class, -1 = nothing to code
+  int *part;          // [chunks][4]: class counts per chunk of RDOQ_CHUNK blocks (compaction)
 };
+#define RDOQ_CHUNK 4096   // blocks per workgroup of the compaction kernels (4 per thread)
 
 __device__ __forceinline__ int rq_class_of(const xvcgpu_tx_block &b) {
   const int sbs = (b.w == 2 || b.h == 2) ? 1 : 2;
@@ -1076,6 +1176,124 @@ rdoq_compact_kernel(int n, RdoqLists l) {
   rdoq_compact_kernel_body(n, l);
 }
 
+// The same lists from many workgroups, still without atomics and in block order
+// (the single workgroup above takes 13 us for a 1080p picture but 90 / 300 us for
+// 2160p / 4320p - on every picture's critical path): a workgroup owns a chunk of
+// RDOQ_CHUNK blocks, four per thread.  Launch 1 counts the chunk's classes; launch
+// 2 sums the counts of the chunks in front of it (at most a few hundred), scans
+// its own threads' counts and scatters.  grid: ceil(n / RDOQ_CHUNK); block: 1024.
+__device__ __forceinline__ void rdoq_chunk_counts(int n, const RdoqLists &l, int cnt[3]) {
+  const int i = (int)blockIdx.x * RDOQ_CHUNK + 4 * (int)threadIdx.x;
+  cnt[0] = cnt[1] = cnt[2] = 0;
+  if (i < n) {
+    const uint32_t v = reinterpret_cast<const uint32_t *>(l.cls)[i >> 2];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int c = (int)(signed char)(v >> (8 * k));
+      const bool in = i + k < n;
+      cnt[0] += in && c == 0;
+      cnt[1] += in && c == 1;
+      cnt[2] += in && c == 2;
+    }
+  }
+}
+
+__global__ void __launch_bounds__(1024)
+rdoq_count_kernel(int n, RdoqLists l) {
+  __shared__ int wsum[3][16];
+  int cnt[3];
+  rdoq_chunk_counts(n, l, cnt);
+  const int t = threadIdx.x;
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    const int v = wave_reduce_add_i32(cnt[k]);
+    if ((t & 63) == 0) wsum[k][t >> 6] = v;
+  }
+  __syncthreads();
+  if (t < 3) {
+    int v = 0;
+    for (int w = 0; w < 16; w++) v += wsum[t][w];
+    l.part[4 * blockIdx.x + t] = v;
+  }
+}
+
+__global__ void __launch_bounds__(1024)
+rdoq_scatter_kernel(int n, RdoqLists l) {
+  __shared__ int part[3][1024];
+  __shared__ int base[3];
+  const int t = threadIdx.x, b = blockIdx.x;
+  // the chunks in front of this one
+  {
+    int v[3] = {0, 0, 0};
+    for (int j = t; j < b; j += 1024) {
+      v[0] += l.part[4 * j];
+      v[1] += l.part[4 * j + 1];
+      v[2] += l.part[4 * j + 2];
+    }
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      const int w = wave_reduce_add_i32(v[k]);
+      if ((t & 63) == 0) part[k][t >> 6] = w;
+    }
+    __syncthreads();
+    if (t < 3) {
+      int sum = 0;
+      for (int w = 0; w < 16; w++) sum += part[t][w];
+      base[t] = sum;
+    }
+    __syncthreads();
+  }
+  int cnt[3];
+  rdoq_chunk_counts(n, l, cnt);
+  int inc[3];
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    int v = cnt[k];
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int o = __shfl_up(v, d, 64);
+      if ((t & 63) >= d) v += o;
+    }
+    inc[k] = v;
+  }
+  __syncthreads();   // base[] read by everybody before part[] is reused
+  const int b0 = base[0], b1 = base[1], b2 = base[2];
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 3; k++)
+    if ((t & 63) == 63) part[k][t >> 6] = inc[k];
+  __syncthreads();
+  if (t < 64) {
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      int v = t < 16 ? part[k][t] : 0;
+#pragma unroll
+      for (int d = 1; d < 16; d <<= 1) {
+        const int o = __shfl_up(v, d, 64);
+        if (t >= d) v += o;
+      }
+      if (t < 16) part[k][16 + t] = v;
+    }
+  }
+  __syncthreads();
+  const int bs[3] = {b0, b1, b2};
+  int pos[3];
+#pragma unroll
+  for (int k = 0; k < 3; k++)
+    pos[k] = bs[k] + inc[k] - cnt[k] + ((t >> 6) ? part[k][16 + (t >> 6) - 1] : 0);
+  const int i = b * RDOQ_CHUNK + 4 * t;
+  if (i < n) {
+    const uint32_t v = reinterpret_cast<const uint32_t *>(l.cls)[i >> 2];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int c = (int)(signed char)(v >> (8 * k));
+      if (i + k < n && c >= 0) l.list[c][pos[c]++] = i + k;
+    }
+  }
+  if (b == (int)gridDim.x - 1 && t == 1023)
+    for (int k = 0; k < 3; k++) l.count[k] = bs[k] + part[k][16 + 15];
+}
+
 // LDS of one wave of class G.  One table of context costs per wave: the groups
 // of a wave nearly always name the same snapshot; when they do not, the wave
 // serves one snapshot after the other (a table per group cost 19 KB of LDS per
@@ -1086,16 +1304,18 @@ struct RdoqPackedLds {
   static constexpr int GROUPS = 64 / G;
   static constexpr int MAXC = G == 4 ? 64 : (G == 16 ? 256 : 1024);  // region coefficients
   static constexpr int MAXSB = G;                                      // region sub-blocks
-  alignas(8) long long cost_to_zero[GROUPS][MAXC];   // the per-coefficient records: 22 bytes each
-  long long sb_code_cost[GROUPS][MAXSB];
+  static constexpr int MAXR = RQ_PADDED(MAXC);     // records: RQ_SB_STRIDE per sub-block
+  static constexpr int MAXT = RQ_CF_PADDED(MAXC);  // coefficient / level tiles: RQ_CF_STRIDE
+  // the per-coefficient records: 5 bytes each (+ 4 of coefficient and level)
+  alignas(8) long long sb_code_cost[GROUPS][MAXSB];
   long long sb_zero_dist[GROUPS][MAXSB];
-  int rate_up[GROUPS][MAXC];
-  short err_dist[GROUPS][MAXC];
+  alignas(8) int16_t cf[GROUPS][MAXT], lv[GROUPS][MAXT];
+  unsigned short rate_up[GROUPS][MAXR];
+  short err_dist[GROUPS][MAXR];
   alignas(8) unsigned ctx_bits[2 * sizeof(xvcgpu_rdoq_contexts)];
   unsigned csbf_bits[GROUPS][MAXSB];
-  int16_t cf[GROUPS][MAXC], lv[GROUPS][MAXC];
   unsigned char csbf[GROUPS][MAXSB], sb_live[GROUPS][MAXSB], sb_dcz[GROUPS][MAXSB];
-  unsigned char sig_ci[GROUPS][MAXC];
+  unsigned char sig_ci[GROUPS][MAXR];
   unsigned char sb_of_scan[GROUPS][G == 64 ? 256 : (G == 4 ? MAXSB : MAXSB * 4)];   // (G = 4: grid = region)
   unsigned lp_bits[GROUPS][G == 4 ? 16 : 32];   // (G = 4: a side is at most 16, 8 groups)
 };
@@ -1129,22 +1349,36 @@ __device__ __forceinline__ void quant_rdo_packed_wave(
   int16_t *dst = levels + off;
   const bool wide = w == rw && h == rh && ((w * h) & 7) == 0 &&
                     ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15) == 0;
+  // the tiles are stored sub-block by sub-block (stride RQ_CF_STRIDE: the lanes
+  // of a group read the same offset of different sub-blocks - RQ_SB_STRIDE above);
+  // blocks with 2x2 sub-blocks (a side of 2) stay raster
+  const bool sb4 = !(w == 2 || h == 2);
+  const int rgw4 = rw >> 2;
+  auto tile_pos = [sb4, rgw4, rw](int x, int y) {
+    return sb4 ? ((y >> 2) * rgw4 + (x >> 2)) * RQ_CF_STRIDE + (((y & 3) << 2) | (x & 3))
+               : y * rw + x;
+  };
   if (active) {
-    if (wide) {
+    if (wide && sb4) {
+      // 8 coefficients = two sub-blocks' rows of 4 (a 4-wide block: two rows of one)
       for (int i = lane; i < (w * h) >> 3; i += G) {
-        reinterpret_cast<uint4 *>(cf)[i] = reinterpret_cast<const uint4 *>(src)[i];
-        reinterpret_cast<uint4 *>(lv)[i] = make_uint4(0, 0, 0, 0);
+        const uint4 v8 = reinterpret_cast<const uint4 *>(src)[i];
+        const int y = (8 * i) / rw, x = 8 * i - y * rw;
+        const int p0 = tile_pos(x, y), p1 = rw == 4 ? tile_pos(0, y + 1) : tile_pos(x + 4, y);
+        *reinterpret_cast<uint2 *>(cf + p0) = make_uint2(v8.x, v8.y);
+        *reinterpret_cast<uint2 *>(cf + p1) = make_uint2(v8.z, v8.w);
+        *reinterpret_cast<uint2 *>(lv + p0) = make_uint2(0, 0);
+        *reinterpret_cast<uint2 *>(lv + p1) = make_uint2(0, 0);
       }
     } else {
       for (int i = lane; i < rw * rh; i += G) {
         const int y = i / rw, x = i - y * rw;
-        cf[i] = src[y * w + x];
-        lv[i] = 0;
+        cf[tile_pos(x, y)] = src[y * w + x];
+        lv[tile_pos(x, y)] = 0;
       }
     }
   }
   RdoqView v;
-  v.cost_to_zero = sm.cost_to_zero[g];
   v.sig_ci = sm.sig_ci[g];
   v.sb_dcz = sm.sb_dcz[g];
   v.rate_up = sm.rate_up[g];
@@ -1198,21 +1432,26 @@ __device__ __forceinline__ void quant_rdo_packed_wave(
       // the groups walk independently (their shuffles stay inside the group)
       nnz = wave_rdoq<G>(
           v, lane, bd, w, h, b.qp, b.comp == 0, scan_order, sign_hide, rq_ctx[cur], prm,
-          [cf, rw](int x, int y) { return (int)cf[y * rw + x]; },
-          [lv, rw](int x, int y) { return lv + y * rw + x; }, false);
+          [cf, tile_pos](int x, int y) { return (int)cf[tile_pos(x, y)]; },
+          [lv, tile_pos](int x, int y) { return lv + tile_pos(x, y); }, false);
       pending = false;
     }
   }
   wave_sync();
   RQ_TRACE(9);
   if (!active) return;
-  if (wide) {
-    for (int i = lane; i < (w * h) >> 3; i += G)
-      reinterpret_cast<uint4 *>(dst)[i] = reinterpret_cast<const uint4 *>(lv)[i];
+  if (wide && sb4) {
+    for (int i = lane; i < (w * h) >> 3; i += G) {
+      const int y = (8 * i) / rw, x = 8 * i - y * rw;
+      const uint2 a = *reinterpret_cast<const uint2 *>(lv + tile_pos(x, y));
+      const uint2 b2 = *reinterpret_cast<const uint2 *>(
+          lv + (rw == 4 ? tile_pos(0, y + 1) : tile_pos(x + 4, y)));
+      reinterpret_cast<uint4 *>(dst)[i] = make_uint4(a.x, a.y, b2.x, b2.y);
+    }
   } else {
     for (int i = lane; i < w * h; i += G) {
       const int y = i / w, x = i - y * w;
-      dst[i] = (x < rw && y < rh) ? lv[y * rw + x] : (int16_t)0;
+      dst[i] = (x < rw && y < rh) ? lv[tile_pos(x, y)] : (int16_t)0;
     }
   }
   if (lane == 0 && nnz_out) nnz_out[bi] = nnz;
@@ -1265,7 +1504,7 @@ __device__ __forceinline__ void quant_rdo_packed_kernel_body(int bd, const xvcgp
   }
 }
 
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(64, 3)
 quant_rdo_packed_kernel(int bd, const xvcgpu_tx_block *blocks, RdoqLists l, int g16, int g4, const int16_t *coeffs, const uint32_t *d_off, int16_t *levels, int32_t *nnz_out, const xvcgpu_rdoq_contexts *rq_ctx, const xvcgpu_rdoq_params *rq_prm, xvcgpu_cu_info *cu_patch = nullptr) {
   quant_rdo_packed_kernel_body(bd, blocks, l, g16, g4, coeffs, d_off, levels, nnz_out, rq_ctx, rq_prm, cu_patch);
 }

@@ -988,7 +988,11 @@ static xvcgpu_status ensure_rdoq_scratch(xvcgpu_ctx *ctx, int n, size_t n_coeffs
       ctx->rdoq_lists_cap = 0;
     }
     const int cap = n + n / 4;
-    if (hipMalloc(&ctx->d_rdoq_lists, sizeof(int) * (4 * (size_t)cap + 4)) != hipSuccess)
+    // count[4], three lists and the classes (cap bytes = cap / 4 ints), then the
+    // compaction's per-chunk counts
+    if (hipMalloc(&ctx->d_rdoq_lists,
+                  sizeof(int) * (4 * (size_t)cap + 4 + 4 * ((size_t)cap / RDOQ_CHUNK + 2))) !=
+        hipSuccess)
       return fail(ctx, XVCGPU_OUT_OF_MEMORY, "rdoq lists");
     ctx->rdoq_lists_cap = cap;
   }
@@ -1016,6 +1020,7 @@ static RdoqLists rdoq_lists_of(xvcgpu_ctx *ctx) {
   l.count = ctx->d_rdoq_lists;
   for (int c = 0; c < 3; c++) l.list[c] = ctx->d_rdoq_lists + 4 + (size_t)c * cap;
   l.cls = reinterpret_cast<signed char *>(ctx->d_rdoq_lists + 4 + 3 * (size_t)cap);
+  l.part = ctx->d_rdoq_lists + 4 + 4 * (size_t)cap;
   return l;
 }
 
@@ -1041,7 +1046,11 @@ static xvcgpu_status quant_rdo_launch(xvcgpu_ctx *ctx, int bitdepth,
   if (!classified)
     hipLaunchKernelGGL(rdoq_classify_kernel, dim3((n + 3) / 4), dim3(256), 0, ctx->stream,
                        bitdepth, d_blocks, n, d_coeffs, d_offsets, d_levels, d_nnz, l);
-  hipLaunchKernelGGL(rdoq_compact_kernel, dim3(1), dim3(1024), 0, ctx->stream, n, l);
+  {
+    const int chunks = (n + RDOQ_CHUNK - 1) / RDOQ_CHUNK;
+    hipLaunchKernelGGL(rdoq_count_kernel, dim3(chunks), dim3(1024), 0, ctx->stream, n, l);
+    hipLaunchKernelGGL(rdoq_scatter_kernel, dim3(chunks), dim3(1024), 0, ctx->stream, n, l);
+  }
   // the class sizes are only known on the device: a bounded number of workgroups
   // per class that walk their list (k_rdoq.h)
   const int g16 = std::min((n + 3) / 4, RDOQ_GRID16), g4 = std::min((n + 15) / 16, RDOQ_GRID4),
