@@ -549,6 +549,24 @@ xvcgpu_status xvcgpu_inv_transform_dist_batch(xvcgpu_ctx *ctx, const xvcgpu_pict
                                               const uint32_t *d_level_offsets,
                                               const int32_t *d_nnz, uint64_t *d_dist);
 
+/* ---- C1, decision half ----------------------------------------------------- *
+ * TransformEncoder::CompressAndEvalTransform's choice among a component's
+ * alternatives (transform_encoder.cc:53-201: default transform, all-zero block,
+ * transform skip, the transform-select indices) and the tail of
+ * InterSearch::CompressAndEvalCbf (inter_search.cc:316-361: root-cbf-zero test,
+ * gate of the transform-select second pass), batched.  The distortions are the
+ * outputs of xvcgpu_residual_rdoq_batch + xvcgpu_metric_batch /
+ * xvcgpu_inv_transform_dist_batch (device arrays the caller gathers into the
+ * alternative records, or fills from the host); the bits are what the caller's
+ * RdoSyntaxWriter prices each alternative with.  Costs are formed and compared
+ * exactly as the reference does: dist + (Cost)(bits * lambda + 0.5), first
+ * strictly cheaper alternative wins.  One thread per job. */
+xvcgpu_status xvcgpu_tx_eval_batch(xvcgpu_ctx *ctx, const xvcgpu_tx_eval_job *d_jobs, int n,
+                                   const xvcgpu_tx_eval_alt *d_alts,
+                                   xvcgpu_tx_eval_result *d_out);
+xvcgpu_status xvcgpu_root_cbf_batch(xvcgpu_ctx *ctx, const xvcgpu_root_cbf_job *d_jobs, int n,
+                                    xvcgpu_root_cbf_result *d_out);
+
 /* ---- D1..D4: DeblockingFilter::DeblockPicture --------------------------- *
  * (deblocking_filter.cc:56-77). d_cu_map: one int32 per 4x4 luma cell,
  * row-major, `map_stride` entries per row, ceil(height/4) rows, value = index

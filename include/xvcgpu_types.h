@@ -364,6 +364,79 @@ typedef struct xvcgpu_affine_me_result {
   uint32_t iterations; /* gradient iterations that produced a non-zero update */
 } xvcgpu_affine_me_result;
 
+/* ---- C1, decision half: the folds of CompressAndEvalTransform and of
+ * CompressAndEvalCbf (transform_encoder.cc:53-201, inter_search.cc:261-365).
+ * Distortions come from the device's own kernels; the bits an alternative costs
+ * come from the caller's entropy coder (a per-alternative input).
+ *
+ * One xvcgpu_tx_eval_job = one CompressAndEvalTransform call for a (CU,
+ * component): its alternatives, in the reference's evaluation order, occupy
+ * [alt_first, alt_first + n_alt) of the batch's alternative arrays.  Every cost
+ * is dist_resi + (Cost)(bits * lambda + 0.5) in double as the reference forms it;
+ * an alternative replaces the best so far only when strictly cheaper. */
+#define XVC_TXE_KIND_NORMAL 0   /* default transform (:97-110)                     */
+#define XVC_TXE_KIND_TSKIP 1    /* transform skip (:146-162)                       */
+#define XVC_TXE_KIND_SELECT 2   /* a transform-select index (:164-194)             */
+#define XVC_TXE_CBF_ZERO 1      /* TxSearchFlags::kCbfZero: after the NORMAL
+                                 * alternative, if it kept a coefficient, the
+                                 * all-zero block competes (:112-144)              */
+#define XVC_TXE_FAST_SELECT 2   /* fast_transform_select_eval with kCbfZero: the
+                                 * SELECT alternatives are skipped when the best so
+                                 * far has no coefficient (:176-180)               */
+#define XVC_TXE_PREV_CBF 4      /* second pass: the state prev_cost belongs to has
+                                 * a coefficient                                   */
+#define XVC_TXE_DIST_INVALID 0xffffffffffffffffull /* TransformAndReconstruct returned
+                                 * max(): the alternative breaks a signalling
+                                 * invariant (:239-252)                            */
+typedef struct xvcgpu_tx_eval_alt {
+  uint64_t dist_reco;      /* TransformAndReconstruct's return value               */
+  uint64_t dist_resi;      /* the distortion the cost is formed with (= dist_reco
+                            * unless fast_inter_transform_dist applies, :71-83)     */
+  uint32_t bits;           /* rdo_writer.GetNumWrittenBits() for the alternative    */
+  uint8_t kind;            /* XVC_TXE_KIND_*                                        */
+  uint8_t cbf;             /* it kept a coefficient                                 */
+  uint8_t reserved[2];
+} xvcgpu_tx_eval_alt;
+typedef struct xvcgpu_tx_eval_job {
+  double lambda;           /* qp.GetLambda()                                        */
+  uint64_t prev_cost;      /* *prev_cost of the second pass; ~0: first pass         */
+  uint64_t dist_zero;      /* prediction against the original (XVC_TXE_CBF_ZERO)    */
+  uint32_t bits_zero;      /* WriteCbf(cu, comp, false)                             */
+  uint32_t alt_first;
+  uint8_t n_alt;
+  uint8_t flags;           /* XVC_TXE_*                                             */
+  uint8_t reserved[6];
+} xvcgpu_tx_eval_job;
+/* best: index of the winning alternative relative to alt_first; -1: the all-zero
+ * block; -2: nothing beat prev_cost (the previous state stays) */
+typedef struct xvcgpu_tx_eval_result {
+  uint64_t cost, dist_reco, dist_resi;
+  int32_t best;
+  uint8_t cbf;             /* the winning state has a coefficient                   */
+  uint8_t reserved[3];
+} xvcgpu_tx_eval_result;
+
+/* One CompressAndEvalCbf tail per CU (inter_search.cc:316-361): the root-cbf-zero
+ * test on the components' winning states and the gate of the transform-select
+ * second pass. */
+#define XVC_CBF_FAST_SELECT 1   /* encoder_settings.fast_transform_select_eval      */
+typedef struct xvcgpu_root_cbf_job {
+  double lambda;
+  uint64_t dist_resi[3], dist_reco[3], dist_zero[3];  /* per component              */
+  uint64_t best_cu_cost;   /* the RD search's best cost for this CU so far          */
+  uint32_t bits_non_zero;  /* GetCuBitsResidual of the winning states               */
+  uint32_t bits_root_zero; /* WriteRootCbf(false)                                   */
+  uint32_t bits_full;      /* GetCuBitsFull of the winning states                   */
+  uint8_t cbf[3];          /* the winning states' cbf                               */
+  uint8_t flags;           /* XVC_CBF_*                                             */
+} xvcgpu_root_cbf_job;
+typedef struct xvcgpu_root_cbf_result {
+  uint64_t sum_dist_final, sum_dist_resi;
+  uint8_t root_cbf;        /* 0: the zero-residual CU won (every cbf cleared)       */
+  uint8_t second_pass;     /* the transform-select pass is to be evaluated          */
+  uint8_t reserved[6];
+} xvcgpu_root_cbf_result;
+
 /* One device-to-device copy of xvcgpu_copy_segments (row slabs of a picture
  * to / from the staging buffer of a multi-GPU exchange). */
 typedef struct xvcgpu_copy_segment {

@@ -146,6 +146,7 @@ void AfterQuantRdo(xvc::TransformEncoder *te, xvc::CodingUnit *cu, xvc::YuvCompo
 xvc::Distortion AfterCompare(xvc::TransformEncoder *te, xvc::CodingUnit *cu,
                              xvc::YuvComponent comp, const xvc::YuvPicture &orig_pic,
                              const xvc::SampleBuffer &buffer, const char *func);
+uint32_t Crc32(uint32_t crc, const void *data, size_t n);
 }  // namespace xr_rd
 #define SetMvpIdx(i, l) \
   SetMvpIdx(i, l);      \
@@ -1251,6 +1252,176 @@ void xr_search_motion_multi(int bd, int x, int y, int w, int h, int flags, uint3
 }
 
 
+/* ---- C1, decision half: InterSearch::CompressAndEvalCbf on a prepared CU -------
+ * An environment (pictures, CU, motion, Qp, a SyntaxWriter in its picture-initial
+ * state) that (a) runs the reference's own CompressAndEvalCbf (inter_search.cc:
+ * 261-365) and reports every decision it made, and (b) answers the bit-price
+ * questions the function asks its entropy coder, for a residual state the caller
+ * describes (levels, cbf, transform choice) - the "bits" inputs of
+ * xvcgpu_tx_eval_batch / xvcgpu_root_cbf_batch. */
+struct XrC1Env {
+  int bd, x, y, w, h;
+  PictureData pic_data;
+  YuvPicture orig_pic, rec_pic;
+  std::shared_ptr<YuvPicture> ref[2];
+  std::shared_ptr<PictureData> ref_data;
+  EncoderSettings settings;
+  Qp qp;
+  int inter_dir, merge;
+  MotionVector mv[2];
+  XrC1Env(int bd_, int pic_w, int pic_h, int qp_raw, double lambda)
+      : bd(bd_), pic_data(ChromaFormat::k420, pic_w, pic_h, bd_),
+        orig_pic(ChromaFormat::k420, pic_w, pic_h, bd_, true, 0, 0),
+        rec_pic(ChromaFormat::k420, pic_w, pic_h, bd_, true, 0, 0),
+        qp(qp_raw, ChromaFormat::k420, bd_, lambda, 1, 0, 0) {
+    for (int l = 0; l < 2; l++)
+      ref[l] = std::make_shared<YuvPicture>(ChromaFormat::k420, pic_w, pic_h, bd_, true, 0, 0);
+    ref_data = std::make_shared<PictureData>(ChromaFormat::k420, 8, 8, bd_);
+    ref_data->SetNalType(NalUnitType::kPredictedPicture);
+    settings.Initialize(SpeedMode::kSlow);
+    pic_data.SetSubGopLength(16);
+    pic_data.SetPoc(8);
+    pic_data.SetNalType(NalUnitType::kBipredictedPicture);
+    ReferencePictureLists *rpl = pic_data.GetRefPicLists();
+    rpl->Reset(8);
+    rpl->SetRefPic(RefPicList::kL0, 0, 0, ref_data, ref[0], nullptr);
+    rpl->SetRefPic(RefPicList::kL1, 0, 16, ref_data, ref[1], nullptr);
+  }
+  CodingUnit *MakeCu() {
+    CodingUnit *cu = pic_data.CreateCu(CuTree::Primary, 1, x, y, w, h);
+    cu->SetQp(qp);
+    cu->ResetPredictionState();
+    cu->SetPredMode(PredictionMode::kInter);
+    cu->SetMergeFlag(merge != 0);
+    if (merge) cu->SetMergeIdx(0);
+    cu->SetInterDir(inter_dir == 2 ? InterDir::kBi : (inter_dir == 1 ? InterDir::kL1 : InterDir::kL0));
+    for (int l = 0; l < 2; l++) {
+      const bool used = inter_dir == 2 || inter_dir == l;
+      cu->SetRefIdx(used ? 0 : -1, static_cast<RefPicList>(l));
+      cu->SetMv(used ? mv[l] : MotionVector(), static_cast<RefPicList>(l));
+    }
+    return cu;
+  }
+};
+
+/* planes: orig, ref0, ref1 as [3] pointers at sample (0, 0) with strides (padded
+ * references, >= 80 / 40 samples of border) */
+void *xr_c1_create(int bd, int pic_w, int pic_h, int qp_raw, double lambda, int x, int y, int w,
+                   int h, int inter_dir, int merge, const int32_t *mv,
+                   const uint16_t *const *orig, const ptrdiff_t *orig_strides,
+                   const uint16_t *const *ref0, const ptrdiff_t *ref0_strides,
+                   const uint16_t *const *ref1, const ptrdiff_t *ref1_strides) {
+  XrC1Env *e = new XrC1Env(bd, pic_w, pic_h, qp_raw, lambda);
+  e->x = x; e->y = y; e->w = w; e->h = h;
+  e->inter_dir = inter_dir;
+  e->merge = merge;
+  e->mv[0] = MotionVector(mv[0], mv[1]);
+  e->mv[1] = MotionVector(mv[2], mv[3]);
+  for (int c = 0; c < 3; c++) {
+    const YuvComponent comp = YuvComponent(c);
+    for (int yy = 0; yy < e->orig_pic.GetHeight(comp); yy++)
+      std::memcpy(e->orig_pic.GetSamplePtr(comp, 0, yy), orig[c] + yy * orig_strides[c],
+                  sizeof(Sample) * e->orig_pic.GetWidth(comp));
+  }
+  FillPic(e->ref[0].get(), ref0, ref0_strides);
+  FillPic(e->ref[1].get(), ref1, ref1_strides);
+  return e;
+}
+void xr_c1_destroy(void *env) { delete static_cast<XrC1Env *>(env); }
+/* What the device's jobs take from the Qp: out[0..2] raw qp per component,
+ * [3..5] RdoQuant's lambda (fixed point), [6..8] its sign-hiding rd_factor
+ * (rdo_quant.cc:251-252, :590-594); weights[0..2] Qp::GetDistortionWeight. */
+void xr_c1_qp(void *env, int64_t *out, double *weights) {
+  XrC1Env *e = static_cast<XrC1Env *>(env);
+  for (int c = 0; c < 3; c++) {
+    const YuvComponent yc = YuvComponent(c);
+    out[c] = e->qp.GetQpRaw(yc);
+    const double lam = e->qp.GetLambdaScaled(yc);
+    const double inv_scale = e->qp.GetInvScale(yc);
+    out[3 + c] = static_cast<int64_t>(lam * (1 << 16) + 0.5);
+    out[6 + c] = static_cast<int64_t>(inv_scale * inv_scale / lam / 16 /
+                                      (1ull << (2 * (e->bd - 8))) + 0.5);
+    weights[c] = e->qp.GetDistortionWeight(yc);
+  }
+}
+
+/* The reference's own CompressAndEvalCbf.  out: [0] returned distortion, [1..3]
+ * cbf, [4] root_cbf, [5] transform select idx (-1 none), [6..8] transform skip,
+ * [9] skip flag, [10..12] CRC-32 of the component's reconstruction block. */
+void xr_c1_reference(void *env, uint64_t best_cu_cost, int fast_select, int64_t *out) {
+  XrC1Env *e = static_cast<XrC1Env *>(env);
+  e->settings.fast_transform_select_eval = fast_select;
+  CodingUnit *cu = e->MakeCu();
+  InterSearch is(Simd(e->bd), e->pic_data, e->orig_pic, e->rec_pic, *e->pic_data.GetRefPicLists(),
+                 e->settings);
+  TransformEncoder te(Simd(e->bd), e->bd, 3, e->orig_pic, e->settings);
+  BitWriter bw;
+  SyntaxWriter writer(e->qp, PicturePredictionType::kBi, &bw);
+  const Distortion d = is.CompressAndEvalCbf(cu, e->qp, writer, best_cu_cost, &te, &e->rec_pic);
+  out[0] = static_cast<int64_t>(d);
+  for (int c = 0; c < 3; c++) {
+    const YuvComponent comp = YuvComponent(c);
+    out[1 + c] = cu->GetCbf(comp);
+    out[6 + c] = cu->GetTransformSkip(comp);
+    uint32_t crc = 0;
+    for (int yy = 0; yy < cu->GetHeight(comp); yy++)
+      crc = xr_rd::Crc32(crc, e->rec_pic.GetSamplePtr(comp, cu->GetPosX(comp), cu->GetPosY(comp) + yy),
+                         sizeof(Sample) * cu->GetWidth(comp));
+    out[10 + c] = crc;
+  }
+  out[4] = cu->GetRootCbf();
+  out[5] = cu->GetTransformSelectIdx();
+  out[9] = cu->GetSkipFlag();
+  e->pic_data.ReleaseCu(cu);
+}
+
+/* A residual state described by the caller -> the bits the reference's entropy
+ * coder (picture-initial contexts, as in xr_c1_reference) prices it with.
+ *   state: [0..2] cbf, [3..5] transform skip, [6] transform select idx (-1 none),
+ *   [7] root cbf; levels[c]: the component's w_c x h_c levels, row-major (read
+ *   when cbf[c]).
+ *   kind 0: WriteResidualDataRdoCbf(comp)   (CompressAndEvalTransform, :84-88)
+ *        1: WriteCbf(comp, false)            (:121-123)
+ *        2: WriteRootCbf(false)              (inter_search.cc:270-275)
+ *        3: GetCuBitsResidual                (transform_encoder.cc:287-296)
+ *        4: GetCuBitsFull                    (:298-307) */
+uint32_t xr_c1_bits(void *env, int kind, int comp, const int32_t *state,
+                    const int16_t *const *levels) {
+  XrC1Env *e = static_cast<XrC1Env *>(env);
+  CodingUnit *cu = e->MakeCu();
+  for (int c = 0; c < 3; c++) {
+    const YuvComponent yc = YuvComponent(c);
+    cu->SetCbf(yc, state[c] != 0);
+    cu->SetTransformSkip(yc, state[3 + c] != 0);
+    if (state[c] && levels && levels[c]) {
+      CoeffBuffer dst = cu->GetCoeff(yc);
+      const int cw = cu->GetWidth(yc), ch = cu->GetHeight(yc);
+      for (int yy = 0; yy < ch; yy++)
+        std::memcpy(dst.GetDataPtr() + yy * dst.GetStride(), levels[c] + yy * cw, sizeof(Coeff) * cw);
+    }
+  }
+  cu->SetTransformFromSelectIdx(YuvComponent::kY, state[6]);
+  cu->SetRootCbf(state[7] != 0);
+  cu->SetSkipFlag(cu->GetMergeFlag() && !cu->GetHasAnyCbf());
+  TransformEncoder te(Simd(e->bd), e->bd, 3, e->orig_pic, e->settings);
+  CuWriter cu_writer(e->pic_data, nullptr);
+  BitWriter bw;
+  SyntaxWriter writer(e->qp, PicturePredictionType::kBi, &bw);
+  RdoSyntaxWriter rdo(writer, 0);
+  const YuvComponent yc = YuvComponent(comp);
+  uint32_t bits = 0;
+  switch (kind) {
+    case 0: cu_writer.WriteResidualDataRdoCbf(*cu, yc, &rdo); bits = rdo.GetNumWrittenBits(); break;
+    case 1: rdo.WriteCbf(*cu, yc, false); bits = rdo.GetNumWrittenBits(); break;
+    case 2: rdo.WriteRootCbf(false); bits = rdo.GetNumWrittenBits(); break;
+    case 3: bits = te.GetCuBitsResidual(*cu, writer, &cu_writer); break;
+    case 4: bits = te.GetCuBitsFull(*cu, writer, &cu_writer); break;
+  }
+  e->pic_data.ReleaseCu(cu);
+  return bits;
+}
+
+
 /* ---- the hot-path frame pass, executed by the reference's own classes ----
  * Same composition and argument block as xo_frame_pass (xvc_oracle_frame.c):
  * per CU TzSearch::Search + InterSearch::SubpelSearch +
@@ -2076,7 +2247,7 @@ static bool Wanted(const CodingUnit &cu) {
          (g_only_poc < 0 || static_cast<int>(cu.GetPicData()->GetPoc()) == g_only_poc);
 }
 
-static uint32_t Crc32(uint32_t crc, const void *data, size_t n) {
+uint32_t Crc32(uint32_t crc, const void *data, size_t n) {
   static uint32_t table[256];
   static bool init = false;
   if (!init) {

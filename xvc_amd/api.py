@@ -94,6 +94,26 @@ INTRA_NUM_MODES = 67
 INTRA_HAS_ABOVE_LEFT, INTRA_HAS_ABOVE, INTRA_HAS_LEFT = 1, 2, 4
 # xvcgpu_tx_block.intra_pic flag bits (include/xvcgpu_types.h XVC_TXF_*)
 TXF_INTRA_PIC, TXF_NO_SIGN_HIDING, TXF_SCAN_SHIFT = 1, 2, 2
+TXE_ALT_DTYPE = np.dtype([("dist_reco", "<u8"), ("dist_resi", "<u8"), ("bits", "<u4"),
+                          ("kind", "u1"), ("cbf", "u1"), ("reserved", "u1", (2,))])
+TXE_JOB_DTYPE = np.dtype([("lambda", "<f8"), ("prev_cost", "<u8"), ("dist_zero", "<u8"),
+                          ("bits_zero", "<u4"), ("alt_first", "<u4"), ("n_alt", "u1"),
+                          ("flags", "u1"), ("reserved", "u1", (6,))])
+TXE_RESULT_DTYPE = np.dtype([("cost", "<u8"), ("dist_reco", "<u8"), ("dist_resi", "<u8"),
+                             ("best", "<i4"), ("cbf", "u1"), ("reserved", "u1", (3,))])
+ROOT_CBF_JOB_DTYPE = np.dtype([("lambda", "<f8"), ("dist_resi", "<u8", (3,)),
+                               ("dist_reco", "<u8", (3,)), ("dist_zero", "<u8", (3,)),
+                               ("best_cu_cost", "<u8"), ("bits_non_zero", "<u4"),
+                               ("bits_root_zero", "<u4"), ("bits_full", "<u4"),
+                               ("cbf", "u1", (3,)), ("flags", "u1")])
+ROOT_CBF_RESULT_DTYPE = np.dtype([("sum_dist_final", "<u8"), ("sum_dist_resi", "<u8"),
+                                  ("root_cbf", "u1"), ("second_pass", "u1"),
+                                  ("reserved", "u1", (6,))])
+assert (TXE_ALT_DTYPE.itemsize, TXE_JOB_DTYPE.itemsize, TXE_RESULT_DTYPE.itemsize,
+        ROOT_CBF_JOB_DTYPE.itemsize, ROOT_CBF_RESULT_DTYPE.itemsize) == (24, 40, 32, 104, 24)
+TXE_KIND_NORMAL, TXE_KIND_TSKIP, TXE_KIND_SELECT = 0, 1, 2
+TXE_CBF_ZERO, TXE_FAST_SELECT, TXE_PREV_CBF = 1, 2, 4
+TXE_DIST_INVALID = 0xffffffffffffffff
 CAND_DTYPE = np.dtype([("x", "<i2"), ("y", "<i2"), ("w", "u1"), ("h", "u1"),
                        ("metric", "u1"), ("qp", "i1"), ("mv_x", "<i2"),
                        ("mv_y", "<i2")])
@@ -146,6 +166,7 @@ SYMBOLS = [
     "xvcgpu_get_transform_matrix", "xvcgpu_inter_pred_batch", "xvcgpu_deblock_tree",
     "xvcgpu_residual_rdoq_batch", "xvcgpu_quant_rdo_batch", "xvcgpu_recon_from_me_rdoq",
     "xvcgpu_quant_rdo_reserve", "xvcgpu_quant_rdo_class_counts",
+    "xvcgpu_tx_eval_batch", "xvcgpu_root_cbf_batch",
     "xvcgpu_fwd_from_me_classify", "xvcgpu_quant_rdo_classified_batch",
     "xvcgpu_event_create", "xvcgpu_event_destroy", "xvcgpu_event_record", "xvcgpu_event_wait",
     "xvcgpu_event_synchronize", "xvcgpu_comm_unique_id", "xvcgpu_comm_create",
@@ -269,6 +290,8 @@ def load_library():
                                       C.c_int, C.c_int, _vp, _vp, _vp, _vp],
         "xvcgpu_quant_rdo_reserve": [_vp, C.c_int, C.c_size_t],
         "xvcgpu_quant_rdo_class_counts": [_vp, _vp],
+        "xvcgpu_tx_eval_batch": [_vp, _vp, C.c_int, _vp, _vp],
+        "xvcgpu_root_cbf_batch": [_vp, _vp, C.c_int, _vp],
         "xvcgpu_quant_rdo_batch": [_vp, C.c_int, _vp, C.c_int, _vp, _vp, C.c_size_t, _vp, _vp,
                                    _vp, _vp],
         "xvcgpu_deblock_pad_ssd": [_vp, _vp, _vp, _vp, _vp, C.c_int, _vp, C.c_int, C.c_int,
@@ -949,6 +972,29 @@ class Context:
                                                  d.ptr, len(jobs)))
         self.sync()
         d.free()
+
+    def tx_eval_batch(self, jobs, alts):
+        """CompressAndEvalTransform's fold per job -> TXE_RESULT_DTYPE array."""
+        jobs = np.ascontiguousarray(jobs, TXE_JOB_DTYPE)
+        alts = np.ascontiguousarray(alts, TXE_ALT_DTYPE)
+        dj, da = self.buffer(jobs), self.buffer(alts if len(alts) else np.zeros(1, TXE_ALT_DTYPE))
+        do = self.alloc(TXE_RESULT_DTYPE.itemsize * max(1, len(jobs)))
+        self._check(self.lib.xvcgpu_tx_eval_batch(self.h, dj.ptr, len(jobs), da.ptr, do.ptr))
+        out = do.to_array(TXE_RESULT_DTYPE, len(jobs))
+        for b in (dj, da, do):
+            b.free()
+        return out
+
+    def root_cbf_batch(self, jobs):
+        """CompressAndEvalCbf's tail per CU -> ROOT_CBF_RESULT_DTYPE array."""
+        jobs = np.ascontiguousarray(jobs, ROOT_CBF_JOB_DTYPE)
+        dj = self.buffer(jobs)
+        do = self.alloc(ROOT_CBF_RESULT_DTYPE.itemsize * max(1, len(jobs)))
+        self._check(self.lib.xvcgpu_root_cbf_batch(self.h, dj.ptr, len(jobs), do.ptr))
+        out = do.to_array(ROOT_CBF_RESULT_DTYPE, len(jobs))
+        dj.free()
+        do.free()
+        return out
 
     def inter_pred_batch(self, refs, rec, pred, jobs):
         """InterPrediction::MotionCompensation per (CU, component) job - uni / bi,

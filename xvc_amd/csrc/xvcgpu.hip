@@ -24,6 +24,7 @@
 #include "k_affine_me.h"
 #include "k_inter_pred.h"
 #include "k_multi.h"
+#include "k_rd.h"
 #include "xvcgpu_internal.h"
 
 namespace {
@@ -1166,6 +1167,29 @@ xvcgpu_status xvcgpu_inv_transform_dist_batch(xvcgpu_ctx *ctx, const xvcgpu_pict
                                const_cast<int32_t *>(d_nnz),
                                reinterpret_cast<unsigned long long *>(d_dist));
   CHECK_LAUNCH(ctx, "inv_transform_dist_batch");
+  return XVCGPU_OK;
+}
+
+xvcgpu_status xvcgpu_tx_eval_batch(xvcgpu_ctx *ctx, const xvcgpu_tx_eval_job *d_jobs, int n,
+                                   const xvcgpu_tx_eval_alt *d_alts,
+                                   xvcgpu_tx_eval_result *d_out) {
+  if (!ctx || n < 0 || (n && (!d_jobs || !d_alts || !d_out))) return XVCGPU_INVALID_ARGUMENT;
+  if (n == 0) return XVCGPU_OK;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  hipLaunchKernelGGL(tx_eval_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, d_jobs, n,
+                     d_alts, d_out);
+  CHECK_LAUNCH(ctx, "tx_eval_batch");
+  return XVCGPU_OK;
+}
+
+xvcgpu_status xvcgpu_root_cbf_batch(xvcgpu_ctx *ctx, const xvcgpu_root_cbf_job *d_jobs, int n,
+                                    xvcgpu_root_cbf_result *d_out) {
+  if (!ctx || n < 0 || (n && (!d_jobs || !d_out))) return XVCGPU_INVALID_ARGUMENT;
+  if (n == 0) return XVCGPU_OK;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  hipLaunchKernelGGL(root_cbf_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, d_jobs, n,
+                     d_out);
+  CHECK_LAUNCH(ctx, "root_cbf_batch");
   return XVCGPU_OK;
 }
 
