@@ -46,7 +46,7 @@ def decode_stream_on_gpu(api, ctx, fx, check):
             p.destroy()
 
 
-@pytest.mark.parametrize("name", ["tiny", "c0", "c1"])
+@pytest.mark.parametrize("name", ["tiny", "c0", "c1", "c1x"])
 def test_gpu_reconstructs_reference_stream(gpu, name):
     api, ctx = gpu
     fx = sf.StreamFixture(name)

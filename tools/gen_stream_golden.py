@@ -38,6 +38,11 @@ CLIPS = {
     # BASELINE config 1 (1080p QP 32), the first pictures: one intra picture +
     # one sub-GOP of 4 (hierarchical B); planes are pinned by MD5 only
     "c1": dict(w=1920, h=1080, n=5, qp=32, sub_gop=4, planes=0, pre=0),
+    # BASELINE config 1 as SURVEY 8d specifies it: 33 pictures (two default
+    # sub-GOPs of 16 + 1), xvcenc's defaults; MD5 only.  The decoder figure of
+    # bench.py and tests/test_gpu_stream.py use it; the motion-search / RD-search
+    # captures stay on the short clip above.
+    "c1x": dict(w=1920, h=1080, n=33, qp=32, sub_gop=0, planes=0, pre=0),
     # small, for CPU-side checks of the host driver (oracle engine)
     "tiny": dict(w=136, h=72, n=5, qp=27, sub_gop=4, planes=5, pre=5),
 }

@@ -124,9 +124,13 @@ void launch_residual(xvcgpu_ctx *ctx, const PicView &o, const PicView &p,
   // (the caller knows that every block is at most 16x16: the general-path kernel
   // would find nothing to do - and still be a launch on the picture's critical path)
   if (small_only) return;
-  // general path: small batches (a decoder's dependency waves) one workgroup per
-  // block; picture-sized batches (mostly small blocks) the scanning form
-  if (n <= 2048)
+  // general path: one workgroup per block (a workgroup whose block the wave
+  // kernel took retires at once); only batches far beyond a picture's worth of a
+  // decoder's dependency wave take the scanning form, whose few workgroups each
+  // walk their share of the large blocks one after the other (it took 0.98 ms for
+  // the ~2800 blocks - 500 of them 32x32 / 64x64 - of a 1080p B picture's first
+  // wave: nearly all of that picture's 1.3 ms)
+  if (n <= 65536)
     hipLaunchKernelGGL(residual_per_job_kernel<MODE>, dim3(n), dim3(TX_THREADS), 0, ctx->stream,
                        o, p, r, d_blocks, n, d_levels, d_off, d_nnz, ctx->d_tx_tables,
                        xvcgpu_tx_layout(), d_dist);
