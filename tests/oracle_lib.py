@@ -129,8 +129,16 @@ def build_oracle():
         so_m = os.path.getmtime(ORACLE_SO)
         if all(os.path.getmtime(s) <= so_m for s in srcs):
             return ORACLE_SO
-    subprocess.check_call(["make", "-s", "-C", ORACLE_DIR],
-                          stdout=subprocess.DEVNULL)
+    # one builder at a time (pytest-xdist workers all arrive here together: a
+    # second make would rewrite the .so while the first worker is loading it)
+    import fcntl
+    os.makedirs(os.path.dirname(ORACLE_SO), exist_ok=True)
+    with open(ORACLE_SO + ".lock", "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        stale = not os.path.exists(ORACLE_SO) or \
+            any(os.path.getmtime(s) > os.path.getmtime(ORACLE_SO) for s in srcs)
+        if stale:
+            subprocess.check_call(["make", "-s", "-C", ORACLE_DIR], stdout=subprocess.DEVNULL)
     return ORACLE_SO
 
 
