@@ -201,3 +201,26 @@ def oracle_decode_stream(pictures, check=None):
         if check:
             check(i, pic, pre, nb)
     return results
+
+
+def deblock_metadata(info, cus):
+    """What the in-loop filter reads of a single-tree picture (deblocking_filter.cc:
+    79-241) from the fixture's leaf CUs: xvcgpu_cu_info records (api.CU_DTYPE layout)
+    and the 4x4 cell map - the arrays xvcgpu_deblock / xo_deblock_rows take."""
+    from xvc_amd import api
+    assert not int(info["two_trees"])
+    w, h = int(info["width"]), int(info["height"])
+    n = len(cus)
+    out = np.zeros(n, api.CU_DTYPE)
+    out["x"], out["y"], out["w"], out["h"] = cus["x"], cus["y"], cus["w"], cus["h"]
+    out["intra"] = cus["pred_mode"] == 0
+    out["cbf_luma"] = cus["cbf"][:, 0]
+    out["qp_y"], out["qp_c"] = cus["qp"][:, 0], cus["qp"][:, 1]
+    out["ref_idx0"] = cus["ref_idx"][:, 0]
+    out["ref_poc"] = cus["ref_poc"]
+    out["mv"] = cus["mv"]
+    cu_map = np.full(((h + 3) // 4, (w + 3) // 4), -1, np.int32)
+    for i in range(n):
+        x, y = int(cus["x"][i]) // 4, int(cus["y"][i]) // 4
+        cu_map[y:y + int(cus["h"][i]) // 4, x:x + int(cus["w"][i]) // 4] = i
+    return out, cu_map

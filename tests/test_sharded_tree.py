@@ -1,0 +1,178 @@
+"""The in-loop filter of pictures with REAL CU trees (quad + binary splits down to
+4-tall CUs, as the reference encoder coded them) sharded by CTU rows: SURVEY 8e
+scheme (A), the ordered hand-off (xvc_amd/host/xvc_shard_filter.h,
+sharded.ShardedTreeFilter).  Each rank holds only its rows of the unfiltered
+reconstruction; after the protocol its rows must equal the reference decoder's
+filtered picture - in one process (loop-back, 2 / 3 / 4 shards) and as real
+processes over gloo (world 2 and 4).  The B pictures of the CIF stream fixture
+put 4-tall CUs on the shard boundaries: deblocking chains cross them."""
+import ctypes as C
+import os
+import socket
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+import stream_fixture as sf
+from test_sharded import LoopbackComm
+from xvc_amd import sharded
+
+BL = 128
+
+
+class OracleTreeEngine:
+    """ShardedTreeFilter's engine on the CPU oracle (xo_deblock_rows)."""
+
+    def __init__(self, planes, cus, cu_map, bd, bipred, beta, tc):
+        import torch
+        self.torch = torch
+        self.h, self.w = planes[0].shape
+        self.bd, self.args = bd, (bipred, beta, tc)
+        self.cus = np.ascontiguousarray(cus)
+        self.cu_map = np.ascontiguousarray(cu_map, np.int32)
+        self.full = [np.ascontiguousarray(np.pad(p, BL >> (1 if c else 0), mode="edge"))
+                     for c, p in enumerate(planes)]
+        self.dll = C.CDLL(ol.build_oracle())
+
+    def view(self, c):
+        b = BL >> (1 if c else 0)
+        return self.full[c][b:-b, b:-b]
+
+    def deblock_rows(self, pass_, ya, yb):
+        if ya >= yb:
+            return
+        pp = (C.c_void_p * 3)(*[self.full[c].ctypes.data + 2 * ((BL >> (1 if c else 0)) *
+                                                               (self.full[c].shape[1] + 1))
+                                for c in range(3)])
+        ss = (C.c_ssize_t * 3)(*[self.full[c].shape[1] for c in range(3)])
+        self.dll.xo_deblock_rows(self.bd, self.w, self.h, self.args[0], self.args[1],
+                                 self.args[2], 4, C.c_void_p(self.cus.ctypes.data),
+                                 C.c_void_p(self.cu_map.ctypes.data), self.cu_map.shape[1], pp, ss,
+                                 pass_, ya, yb)
+
+    def row_slabs(self, ya, yb):
+        out = []
+        for c in range(3):
+            b = BL >> (1 if c else 0)
+            a0, a1 = (ya, yb) if c == 0 else (ya // 2, yb // 2)
+            out.append(self.torch.from_numpy(self.full[c][b + a0:b + a1, :].view(np.uint8))
+                       .reshape(-1))
+        return out
+
+
+def b_pictures(name="c0"):
+    """(info, cus, pre planes, post planes, cu records, cell map) of the fixture's
+    single-tree pictures, from the oracle's decode of the stream (pinned equal to
+    the reference decoder's planes / MD5 by tests/test_stream_oracle.py)."""
+    fx = sf.StreamFixture(name)
+    res = sf.oracle_decode_stream([(fx.info[i], fx.cus(i), fx.levels(i)) for i in range(fx.n)])
+    out = []
+    for i in range(fx.n):
+        info = fx.info[i]
+        if int(info["two_trees"]) or not int(info["deblock"]):
+            continue
+        pic, pre, _ = res[i]
+        post = [p.copy() for p in pic.planes]
+        assert np.array_equal(sf.picture_md5(post, int(info["bitdepth"])), info["md5"])
+        cus, cu_map = sf.deblock_metadata(info, fx.cus(i))
+        out.append((info, pre, post, cus, cu_map))
+    return out
+
+
+def boundaries(h, world):
+    """CTU-row shards: one row of CTUs (64 luma rows) per rank, the rest of the
+    picture to the last rank - for the CIF pictures that puts a boundary on rows
+    64 / 128 / 192, where the fixture has 4-tall CUs below the boundary (chains of
+    up to five edges: D = 24)."""
+    assert h > 64 * (world - 1) + 32
+    return [64 * r for r in range(world)] + [h]
+
+
+def own_rows_only(planes, y0, y1, seed):
+    """A rank's picture: its own rows of the unfiltered reconstruction, noise
+    everywhere else (whatever it needs from a neighbour has to arrive)."""
+    rng = np.random.default_rng(seed)
+    out = []
+    for c, p in enumerate(planes):
+        a, b = (y0, y1) if c == 0 else (y0 // 2, y1 // 2)
+        q = rng.integers(0, 1024, p.shape).astype(np.uint16)
+        q[a:b] = p[a:b]
+        out.append(q)
+    return out
+
+
+@pytest.mark.parametrize("world", [2, 3, 4])
+def test_ordered_handoff_loopback_matches_reference(world):
+    pics = b_pictures("c0")
+    assert len(pics) >= 6
+    chains = 0
+    for k, (info, pre, post, cus, cu_map) in enumerate(pics):
+        h, bd = int(info["height"]), int(info["bitdepth"])
+        rows = boundaries(h, world)
+        args = (int(info["pic_type"]) == 0, int(info["beta_offset"]), int(info["tc_offset"]))
+        ranks = []
+        for r in range(world):
+            e = OracleTreeEngine(own_rows_only(pre, rows[r], rows[r + 1], 100 * k + r), cus,
+                                 cu_map, bd, *args)
+            ranks.append(sharded.ShardedTreeFilter(e, LoopbackComm(), r, world, rows))
+        chains += sum(s.d_top > 8 for s in ranks)     # 8 = the boundary edge alone
+        for s in ranks:
+            s.step_local()
+        LoopbackComm.exchange_all({s.rank: s.ops_down() for s in ranks})
+        for s in ranks:
+            s.step_strip()
+        LoopbackComm.exchange_all({s.rank: s.ops_up() for s in ranks})
+        for s in ranks:
+            for c in range(3):
+                a, b = (s.y0, s.y1) if c == 0 else (s.y0 // 2, s.y1 // 2)
+                assert np.array_equal(s.e.view(c)[a:b], post[c][a:b]), (k, s.rank, c)
+    # real CU trees: some boundary carries a chain (scheme B would be wrong there)
+    assert chains >= 3, chains
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _gloo_worker(rank, world, port, q):
+    try:
+        import torch.distributed as dist
+        os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        comm = sharded.TorchComm(dist, rank, world)
+        bad = []
+        for k, (info, pre, post, cus, cu_map) in enumerate(b_pictures("c0")[:4]):
+            h, bd = int(info["height"]), int(info["bitdepth"])
+            rows = boundaries(h, world)
+            e = OracleTreeEngine(own_rows_only(pre, rows[rank], rows[rank + 1], 7 * k + rank), cus,
+                                 cu_map, bd, int(info["pic_type"]) == 0,
+                                 int(info["beta_offset"]), int(info["tc_offset"]))
+            s = sharded.ShardedTreeFilter(e, comm, rank, world, rows)
+            s.run()
+            for c in range(3):
+                a, b = (s.y0, s.y1) if c == 0 else (s.y0 // 2, s.y1 // 2)
+                if not np.array_equal(e.view(c)[a:b], post[c][a:b]):
+                    bad.append((k, c))
+        dist.barrier()
+        dist.destroy_process_group()
+        q.put((rank, bad))
+    except Exception as ex:  # noqa: BLE001
+        q.put((rank, repr(ex)))
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_ordered_handoff_gloo(world):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gloo_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(res) == [(r, []) for r in range(world)], res

@@ -36,7 +36,8 @@ def deps():
 
 
 HOST_OUT = os.path.join(HERE, "libxvchost.so")
-HOST_SOURCES = ["xvc_picture_decoder.cc", "xvc_picture_schedule.cc", "xvc_inter_search.cc"]
+HOST_SOURCES = ["xvc_picture_decoder.cc", "xvc_picture_schedule.cc", "xvc_inter_search.cc",
+                "xvc_shard_filter.cc"]
 
 
 def build_host(force=False, verbose=False):

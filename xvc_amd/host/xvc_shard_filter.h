@@ -1,0 +1,56 @@
+// xvc_shard_filter.h -- the in-loop filter of a picture sharded by CTU rows over
+// the GPUs of a node, for REAL CU trees (binary splits down to 4-tall CUs):
+// SURVEY 8e scheme (A), the ordered hand-off.
+//
+// deblocking_filter.cc:56-152 filters a picture in two passes.  Vertical edges
+// (pass 0) never cross rows: every rank filters its own rows.  Horizontal edges
+// (pass 1) sit on the 4-sample grid (:59-62); the edge at row y reads rows
+// y-4 .. y+3 and writes y-3 .. y+2, so two edges 4 rows apart in one 4-column band
+// interact and must be applied in increasing y (:243-312) - a CHAIN.  Chains only
+// form where CUs are 4 tall (common.h:99).  The edge ON a shard boundary y0 reads
+// four rows of each side, and a chain may run on from it into the lower shard.
+//
+//   rank r owns rows [y0, y1).  From the CU map it derives D = 4 * (m + 1), m =
+//   the longest run of candidate edges y0, y0 + 4, ... in any band (0 when the CUs
+//   at the boundary are at least 8 tall; ChainRows below).  Then:
+//     1. pass 0 on [y0, y1)
+//     2. pass 1 on the edges [y0 + D, y1): nothing they read or write is touched
+//        by the boundary edge's chain (rank 0: from row 0)
+//     3. rows [y1 - 4, y1) - final as far as this rank's own edges go - to rank
+//        r + 1;  rows [y0 - 4, y0) from rank r - 1
+//     4. pass 1 on the strip of edges [y0, y0 + D): the boundary edge and its
+//        chain, in order, on the rows just received
+//     5. rows [y0 - 4, y0) (the edge modified three of them; chroma: one of two)
+//        back to rank r - 1;  rows [y1 - 4, y1) back from rank r + 1
+//   Exact for every CU tree (no assumption on CU heights); two small exchanges
+//   per picture instead of scheme B's one; no rank waits for more than its upper
+//   neighbour's step 2.  Requires y0 + D <= y1 - 4 (a shard taller than its chain).
+//
+// ChainRows is host arithmetic on the CU map (also what the engine-agnostic
+// Python mirror xvc_amd/sharded.ShardedTreeFilter and its CPU tests use);
+// ShardedTreeFilter::Run issues the steps on xvcgpu_deblock_rows and the native
+// RCCL row transfers of xvcgpu_comm_* (no torch on the data path).
+#ifndef XVC_AMD_HOST_XVC_SHARD_FILTER_H_
+#define XVC_AMD_HOST_XVC_SHARD_FILTER_H_
+
+#include <cstdint>
+
+#include "xvcgpu.h"
+
+extern "C" {
+// D for the boundary at luma row y0 (a multiple of 4, 0 < y0 < pic_h): cu_map as
+// xvcgpu_deblock takes it (one int32 per 4x4 luma cell, -1 = no CU).
+int xvc_shard_chain_rows(const int32_t *cu_map, int map_stride, int pic_w, int pic_h, int y0);
+
+// Steps 1-5 for one picture on rank `rank` of `world` (comm may be NULL when world
+// == 1): rows[r] .. rows[r + 1] are rank r's rows (multiples of 16), d_* the
+// device copies of the CU records / map, cu_map the host copy (planning).
+// Asynchronous on the context's and the communicator's streams.
+int xvc_host_shard_filter_run(xvcgpu_ctx *ctx, xvcgpu_comm *comm, int rank, int world,
+                              const int32_t *rows, xvcgpu_picture *rec,
+                              const xvcgpu_cu_info *d_cus, int n_cus, const int32_t *d_cu_map,
+                              const int32_t *cu_map, int map_stride, int pic_is_bipred,
+                              int beta_offset, int tc_offset);
+}
+
+#endif  // XVC_AMD_HOST_XVC_SHARD_FILTER_H_

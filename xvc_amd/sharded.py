@@ -365,6 +365,115 @@ class ShardedFramePass:
         self.phase_c(orig, rec_idx)
 
 
+def chain_rows(cu_map, pic_w, pic_h, y0):
+    """D of the ordered hand-off at the shard boundary y0 (host planning in the
+    C++ layer: xvc_amd/host/xvc_shard_filter.cc, xvc_shard_chain_rows)."""
+    import ctypes as C
+    from . import decoder
+    lib = decoder.load_host_library()
+    m = np.ascontiguousarray(cu_map, np.int32)
+    lib.xvc_shard_chain_rows.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
+    return int(lib.xvc_shard_chain_rows(m.ctypes.data, m.shape[1], pic_w, pic_h, y0))
+
+
+class ShardedTreeFilter:
+    """The in-loop filter of a picture with a REAL CU tree (binary splits down to
+    4-tall CUs), sharded by CTU rows: SURVEY 8e scheme (A), the ordered hand-off -
+    xvc_amd/host/xvc_shard_filter.h describes the five steps; this is the
+    engine-agnostic mirror of xvc_host_shard_filter_run (the product path on
+    RCCL) that the CPU tests drive with an oracle engine over gloo and the GPU
+    test with the HIP engine in loop-back.
+
+    engine: deblock_rows(pass, ya, yb) on its picture, row_slabs(ya, yb) -> the
+    three planes' row slabs as byte tensors, cu_map (host), w, h.
+    rows: world + 1 boundaries (multiples of 16)."""
+
+    HALO = 4
+
+    def __init__(self, engine, comm, rank, world, rows):
+        self.e, self.comm, self.rank, self.world = engine, comm, rank, world
+        self.y0, self.y1 = rows[rank], rows[rank + 1]
+        self.up = rank - 1 if rank > 0 else None
+        self.down = rank + 1 if rank < world - 1 else None
+        self.d_top = chain_rows(engine.cu_map, engine.w, engine.h, self.y0) \
+            if self.up is not None else 0
+        assert self.down is None or self.y0 + self.d_top <= self.y1 - self.HALO, \
+            "a shard must be taller than the chain that enters it"
+
+    def step_local(self):
+        self.e.deblock_rows(0, self.y0, self.y1)
+        self.e.deblock_rows(1, self.y0 + self.d_top, self.y1)
+
+    def ops_down(self):
+        H = self.HALO
+        sends = [(self.down, t) for t in self.e.row_slabs(self.y1 - H, self.y1)] \
+            if self.down is not None else []
+        recvs = [(self.up, t) for t in self.e.row_slabs(self.y0 - H, self.y0)] \
+            if self.up is not None else []
+        return sends, recvs
+
+    def step_strip(self):
+        if self.up is not None:
+            self.e.deblock_rows(1, self.y0, self.y0 + self.d_top)
+
+    def ops_up(self):
+        H = self.HALO
+        sends = [(self.up, t) for t in self.e.row_slabs(self.y0 - H, self.y0)] \
+            if self.up is not None else []
+        recvs = [(self.down, t) for t in self.e.row_slabs(self.y1 - H, self.y1)] \
+            if self.down is not None else []
+        return sends, recvs
+
+    def run(self):
+        self.step_local()
+        self.comm.exchange(*self.ops_down())
+        self.step_strip()
+        self.comm.exchange(*self.ops_up())
+
+
+class GpuTreeEngine:
+    """ShardedTreeFilter's HIP engine: one picture in a torch tensor (so that row
+    slabs can be exchanged), the CU records / map of the whole picture on the
+    device; kernels through xvcgpu_deblock_rows."""
+
+    def __init__(self, ctx, width, height, bitdepth, cus, cu_map, bipred, beta, tc, device):
+        import torch
+        self.torch, self.ctx = torch, ctx
+        self.w, self.h, self.bd = width, height, bitdepth
+        self.cu_map = np.ascontiguousarray(cu_map, np.int32)
+        nbytes = ctx.lib.xvcgpu_picture_bytes(width, height)
+        self.mem = torch.zeros(nbytes // 2, dtype=torch.int16, device=device)
+        self.picture = api.Picture(ctx, width, height, bitdepth, wrap_ptr=self.mem.data_ptr(),
+                                   wrap_bytes=nbytes)
+        self.geom = []
+        for c in range(3):
+            ptr, stride = self.picture.plane_ptr(c)
+            self.geom.append(((ptr - self.mem.data_ptr()) // 2, stride,
+                              api.BORDER_LUMA if c == 0 else api.BORDER_CHROMA))
+        self.d_cus = ctx.buffer(np.ascontiguousarray(cus, api.CU_DTYPE))
+        self.d_map = ctx.buffer(self.cu_map)
+        self.n_cus, self.args = len(cus), (bipred, beta, tc)
+
+    def deblock_rows(self, pass_, ya, yb):
+        if ya < yb:
+            self.ctx.deblock_rows_dev(self.picture, self.d_cus.ptr, self.n_cus, self.d_map.ptr,
+                                      self.cu_map.shape[1], pass_, ya, yb, *self.args)
+
+    def row_slabs(self, ya, yb):
+        out = []
+        for c in range(3):
+            off, stride, border = self.geom[c]
+            a, b = (ya, yb) if c == 0 else (ya // 2, yb // 2)
+            start = off + a * stride - border
+            out.append(self.mem[start:start + (b - a) * stride].view(self.torch.uint8))
+        return out
+
+    def destroy(self):
+        self.d_cus.free()
+        self.d_map.free()
+        self.picture.destroy()
+
+
 class GpuEngine:
     """HIP engine: pictures live in torch tensors (so RCCL can send row slabs)
     wrapped as xvcgpu pictures; kernels run on torch's current stream."""
