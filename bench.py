@@ -270,10 +270,13 @@ def encoder_rd_figure(ctx, api, fx, pics, w, h):
     ranking and every inter-CU TransformAndReconstruct - the latter quantised
     with the CABAC context states RdoQuant::QuantRdo really read at that moment
     - as device batches (tests/rd_replay.py), every call compared with the
-    reference's result.  The searches are one batch per picture pair; the calls
-    that write a prediction / reconstruction at the CU's own position are dealt
-    into layers of non-overlapping blocks (the RD recursion revisits every
-    position at every size), so their figure is launch-bound, not throughput."""
+    reference's result.  The searches are one batch per picture pair; the
+    merge rankings write their candidates' predictions at the CU's own position
+    and are dealt into layers of non-overlapping blocks; the
+    TransformAndReconstruct calls are ONE batch - the RD recursion revisits every
+    position at every size, so each CU state predicts into its own slot of a
+    scratch picture (xvcgpu_inter_pred_batch_to) with its original copied beside
+    (xvcgpu_copy_blocks), as the reference's temp buffers are."""
     import rd_fixture as rf
     import rd_replay
     if not os.path.exists(rf.path("c1")):
@@ -285,7 +288,9 @@ def encoder_rd_figure(ctx, api, fx, pics, w, h):
     bi_n, bi_bad, bi_skip = r.bi_steps()
     af_n, af_bad = r.affine_steps()
     mg_n, mg_bad = r.merges()
-    tx_n, tx_bad, layers, dz_n, dz_bad = r.transform_calls()
+    r.dz_done = r.dz_bad = 0
+    tx_n, tx_bad = r.transform_calls_scratch()
+    dz_bad = r.dz_bad
     t = {k: 1e3 * v for k, v in r.timing.items()}
     poc = int(r.rd["evals"]["poc"][0])
     out = {"workload": "the rest of the reference encoder's RD search for the 1080p B picture "
@@ -295,17 +300,20 @@ def encoder_rd_figure(ctx, api, fx, pics, w, h):
                        (poc, bi_n, af_n, mg_n, tx_n, len(r.rd["evals"]), len(r.rd["contexts"])),
            "ms": {"bi_steps": t.get("bi_steps"), "affine_searches": t.get("affine_steps"),
                   "merge_rankings": t.get("merges"),
-                  "transform_and_reconstruct": t.get("transform_calls"),
-                  "transform_distortions": t.get("transform_dist"),
-                  "cbf_zero_distortions": t.get("dist_zero")},
+                  "transform_and_reconstruct": t.get("scratch_transform_calls"),
+                  "transform_distortions": t.get("scratch_transform_dist"),
+                  "cbf_zero_distortions": t.get("scratch_dist_zero")},
            "ms_includes": "host job preparation excluded; descriptor upload, launches, result "
                           "download included (wall clock around each batch)",
-           "transform_layers": layers,
+           "transform_scratch": {"cu_states_x_rounds": r.timing.get("scratch_units"),
+                                 "picture": "4096 x %d" % r.timing.get("scratch_rows", 0)},
            "matches_reference": bool(bi_bad == 0 and af_bad == 0 and mg_bad == 0 and tx_bad == 0
                                      and dz_bad == 0),
            "mismatches": {"bi": bi_bad, "affine": af_bad, "merge": mg_bad, "transform": tx_bad,
                           "dist_zero": dz_bad},
-           "bi_steps_of_lic_cus_not_replayed": bi_skip}
+           "bi_steps_of_lic_cus_not_replayed": bi_skip,
+           "transform_calls_per_s": (tx_n / (1e-3 * t["scratch_transform_calls"])
+                                     if t.get("scratch_transform_calls") else None)}
     import oracle_lib as ol
     if ol.have_ref():       # the reference's own MotionEstNormal(kFullSearch), one thread
         import ctypes as C

@@ -325,6 +325,30 @@ xvcgpu_status xvcgpu_inter_pred_batch(xvcgpu_ctx *ctx, const xvcgpu_picture *con
                                       xvcgpu_picture *pred,
                                       const xvcgpu_inter_block *d_blocks, int n);
 
+/* The same with the RD search's destination: InterPrediction::MotionCompensation
+ * writes into whatever SampleBuffer the caller passes (the encoder's
+ * temp_pred_ / bipred buffers, inter_search.cc:96-99, :417), not into the
+ * picture - overlapping candidate CUs of one CTU are then independent jobs.
+ * Block i goes to `scratch` at d_dst[i] (luma position; chroma at half of it);
+ * `scratch` is any picture of the same bit depth and chroma format, its size
+ * is unrelated to the references'.  `rec` is read at the CUs' own positions
+ * (LIC jobs only) and has the references' size. */
+xvcgpu_status xvcgpu_inter_pred_batch_to(xvcgpu_ctx *ctx, const xvcgpu_picture *const *refs,
+                                         int n_refs, const xvcgpu_picture *rec,
+                                         xvcgpu_picture *scratch,
+                                         const xvcgpu_inter_block *d_blocks,
+                                         const xvcgpu_block_pos *d_dst, int n);
+
+/* n block copies src -> dst (pictures of any two sizes): how the originals of
+ * candidate CUs are brought beside their scratch predictions, so that the
+ * residual / metric batches address one geometry (the reference passes
+ * orig_pic_ + the CU position and a temp buffer side by side,
+ * transform_encoder.cc:203-215).  Blocks must lie inside both pictures; the
+ * destination blocks of one call must not overlap. */
+xvcgpu_status xvcgpu_copy_blocks(xvcgpu_ctx *ctx, const xvcgpu_picture *src,
+                                 xvcgpu_picture *dst, const xvcgpu_copy_block *d_blocks,
+                                 int n);
+
 /* ---- I3 (affine half): MotionCompAffine -> Sample ------------------------- *
  * (inter_prediction.cc:1044-1136): the CU is cut into sub-blocks whose size
  * follows from the corner-MV differences, each sub-block gets its own MV
@@ -361,6 +385,22 @@ xvcgpu_status xvcgpu_bipred_search(xvcgpu_ctx *ctx, const xvcgpu_picture *orig,
                                    const xvcgpu_bi_block *d_jobs, int n,
                                    xvcgpu_me_result *d_results,
                                    int max_block_size);
+/* The same step for CUs that try local illumination compensation
+ * (cu.GetUseLic()): the other list's prediction is the compensated one
+ * (inter_prediction.cc:710-722 -> LocalIlluminationComp :1555-1575; the model
+ * reads the current reconstruction `rec` around the CU, d_neighbours[i] names
+ * the CUs above / left of job i - only x, y of the neighbours and the
+ * XVC_LIC_HAS_* bits of xvcgpu_mc_lic_block are read), the full-pel stage
+ * compares with kSadAcOnly[Fast] and the sub-pel stage with kSatdAcOnly
+ * (inter_search.cc:1059-1076), both on the int16 target. */
+xvcgpu_status xvcgpu_bipred_search_lic(xvcgpu_ctx *ctx, const xvcgpu_picture *orig,
+                                       const xvcgpu_picture *ref_other,
+                                       const xvcgpu_picture *ref_search,
+                                       const xvcgpu_picture *rec,
+                                       const xvcgpu_bi_block *d_jobs,
+                                       const xvcgpu_mc_lic_block *d_neighbours, int n,
+                                       xvcgpu_me_result *d_results, int max_block_size);
+
 
 /* Same for all three components of every CU of a motion search batch, taking
  * the MV from d_results[i].mv_* (InterPrediction::MotionCompensation for a

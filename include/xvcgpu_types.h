@@ -181,6 +181,23 @@ typedef struct xvcgpu_inter_block {
   int32_t mv[2][3][2]; /* [list][corner][x,y], 1/16 pel, before ClipMv     */
 } xvcgpu_inter_block;
 
+/* A luma position in a scratch picture (xvcgpu_inter_pred_batch_to): where the
+ * job's block goes instead of the CU's own position; chroma lands at (x >> 1,
+ * y >> 1), so x and y are even. */
+typedef struct xvcgpu_block_pos {
+  int16_t x, y;
+} xvcgpu_block_pos;
+
+/* One block copy between two pictures (xvcgpu_copy_blocks): w x h samples of
+ * component `comp`, positions in samples of that component. */
+typedef struct xvcgpu_copy_block {
+  int16_t sx, sy;      /* in the source picture                            */
+  int16_t dx, dy;      /* in the destination picture                       */
+  uint8_t w, h;
+  uint8_t comp;
+  uint8_t reserved;
+} xvcgpu_copy_block;
+
 /* One intra prediction job = IntraPrediction::FillReferenceState + Predict
  * (intra_prediction.cc:81-147) for one component of one CU, 67-mode set.
  * Positions / sizes are in samples of `comp`.  The neighbour fields are what

@@ -75,44 +75,91 @@ class Replay:
         self.timing[key] = self.timing.get(key, 0.0) + time.time() - t0
 
     # ---- bi-prediction refinement steps (SearchBiIterative, :392-433) ----------
-    def bi_steps(self, include_lic=False):
-        """-> (compared, mismatches, skipped LIC steps)"""
+    def _bi_jobs(self, sel):
+        api = self.api
+        jobs = np.zeros(len(sel), api.BI_DTYPE)
+        b = jobs["blk"]
+        for k in ("x", "y", "w", "h", "lambda16"):
+            b[k] = sel[k]
+        b["fullpel_mv"] = (sel["flags"] & rf.FLAG_FULLPEL) != 0
+        i = np.arange(len(sel))
+        start = sel["start_mvp_idx"].astype(np.int64)
+        b["mvp_x"] = sel["mvp"][i, start, 0, 0]
+        b["mvp_y"] = sel["mvp"][i, start, 0, 1]
+        b["search_range"] = 4
+        jobs["blk"] = b
+        jobs["other_mv_x"], jobs["other_mv_y"] = sel["other_mv"][:, 0, 0], sel["other_mv"][:, 0, 1]
+        jobs["boot_mv_x"], jobs["boot_mv_y"] = sel["boot"][:, 0, 0], sel["boot"][:, 0, 1]
+        assert ((sel["flags"] & rf.FLAG_HAS_BOOT) != 0).all()
+        return jobs
+
+    def _check_bi(self, sel, res):
+        ok = ((res["mv_x"] == sel["mv"][:, 0, 0]) & (res["mv_y"] == sel["mv"][:, 0, 1]) &
+              (res["subpel_dist"] == sel["dist"]))
+        if (~ok).any():
+            k = int(np.flatnonzero(~ok)[0])
+            self.first_bad = ("bi", tuple(sel[k]), tuple(res[k]))
+        return int((~ok).sum())
+
+    def bi_steps(self, include_lic=True):
+        """-> (compared, mismatches, skipped LIC steps).  Steps of CUs that try
+        local illumination compensation go through xvcgpu_bipred_search_lic, in
+        layers: the model reads the CURRENT reconstruction around the CU
+        (neighbours / nb_samples), which differs between the overlapping CUs the
+        RD search tries."""
         api, ctx = self.api, self.ctx
         st = self.rd["steps"]
         st = st[st["kind"] == rf.KIND_BI]
         lic = (st["flags"] & rf.FLAG_LIC) != 0
         skipped = 0 if include_lic else int(lic.sum())
-        if not include_lic:
-            st = st[~lic]
+        plain, st_lic = st[~lic], st[lic]
         done = bad = 0
-        keys = np.stack([st["poc"], st["other_ref_poc"], st["ref_poc"]], 1)
+        keys = np.stack([plain["poc"], plain["other_ref_poc"], plain["ref_poc"]], 1)
         for poc, opoc, rpoc in np.unique(keys, axis=0):
-            sel = st[(st["poc"] == poc) & (st["other_ref_poc"] == opoc) & (st["ref_poc"] == rpoc)]
-            jobs = np.zeros(len(sel), api.BI_DTYPE)
-            b = jobs["blk"]
-            for k in ("x", "y", "w", "h", "lambda16"):
-                b[k] = sel[k]
-            b["fullpel_mv"] = (sel["flags"] & rf.FLAG_FULLPEL) != 0
-            i = np.arange(len(sel))
-            start = sel["start_mvp_idx"].astype(np.int64)
-            b["mvp_x"] = sel["mvp"][i, start, 0, 0]
-            b["mvp_y"] = sel["mvp"][i, start, 0, 1]
-            b["search_range"] = 4
-            jobs["blk"] = b
-            jobs["other_mv_x"], jobs["other_mv_y"] = sel["other_mv"][:, 0, 0], sel["other_mv"][:, 0, 1]
-            jobs["boot_mv_x"], jobs["boot_mv_y"] = sel["boot"][:, 0, 0], sel["boot"][:, 0, 1]
-            assert ((sel["flags"] & rf.FLAG_HAS_BOOT) != 0).all()
+            sel = plain[(plain["poc"] == poc) & (plain["other_ref_poc"] == opoc) &
+                        (plain["ref_poc"] == rpoc)]
+            jobs = self._bi_jobs(sel)
             O = self.orig(int(poc))[0]
             t0 = time.time()
             res = ctx.bipred_search(O, self.pics[int(opoc)], self.pics[int(rpoc)], jobs)
             self._time("bi_steps", t0)
-            ok = ((res["mv_x"] == sel["mv"][:, 0, 0]) & (res["mv_y"] == sel["mv"][:, 0, 1]) &
-                  (res["subpel_dist"] == sel["dist"]))
-            bad += int((~ok).sum())
+            bad += self._check_bi(sel, res)
             done += len(sel)
-            if (~ok).any():
-                k = int(np.flatnonzero(~ok)[0])
-                self.first_bad = ("bi", tuple(sel[k]), tuple(res[k]))
+        if not include_lic or not len(st_lic):
+            return done, bad, skipped
+        nb = self.rd["neighbours"]
+        assert (st_lic["nb_index"] >= 0).all()
+        for poc in np.unique(st_lic["poc"]):
+            sp = st_lic[st_lic["poc"] == poc]
+            used = np.unique(sp["nb_index"])          # capture order
+            lay_of = np.zeros(len(nb), np.int32)
+            lay_of[used] = assign_layers(nb["x"][used], nb["y"][used], nb["w"][used], nb["h"][used],
+                                         grow=np.ones(len(used), bool))
+            lay = lay_of[sp["nb_index"]]
+            cache = {}
+            O = self.orig(int(poc))[0]
+            for L in range(int(lay.max()) + 1):
+                sl = sp[lay == L]
+                rec = self._rec_for(int(poc), sl["nb_index"], cache)
+                keys = np.stack([sl["other_ref_poc"], sl["ref_poc"]], 1)
+                for opoc, rpoc in np.unique(keys, axis=0):
+                    sel = sl[(sl["other_ref_poc"] == opoc) & (sl["ref_poc"] == rpoc)]
+                    jobs = self._bi_jobs(sel)
+                    q = np.zeros(len(sel), api.LIC_DTYPE)
+                    k = sel["nb_index"]
+                    q["x"], q["y"], q["w"], q["h"] = sel["x"], sel["y"], sel["w"], sel["h"]
+                    q["neighbors"] = nb["has_above"][k] * 1 + nb["has_left"][k] * 2
+                    for f in ("above_x", "above_y", "left_x", "left_y"):
+                        q[f] = nb[f][k]
+                    t0 = time.time()
+                    res = ctx.bipred_search_lic(O, self.pics[int(opoc)], self.pics[int(rpoc)], rec,
+                                                jobs, q)
+                    self._time("bi_steps_lic", t0)
+                    bad += self._check_bi(sel, res)
+                    done += len(sel)
+            self.timing["bi_lic_layers"] = self.timing.get("bi_lic_layers", 0) + int(lay.max()) + 1
+            if "rec" in cache:
+                cache["rec"].destroy()
         return done, bad, skipped
 
     # ---- affine motion searches (MotionEstAffine, :664-749) --------------------
@@ -259,6 +306,165 @@ class Replay:
         pred.destroy()
         if "rec" in cache:
             cache["rec"].destroy()
+        return done, bad
+
+    # ---- the same calls with scratch destinations --------------------------------
+    @staticmethod
+    def pack_slots(w, h, width=4096):
+        """Shelf packing of n luma blocks into a scratch picture `width` wide
+        -> (x, y, height): blocks of one size fill rows of slots."""
+        w, h = np.asarray(w, np.int64), np.asarray(h, np.int64)
+        x, y = np.zeros(len(w), np.int64), np.zeros(len(w), np.int64)
+        base = 0
+        for hh in np.unique(h):
+            for ww in np.unique(w[h == hh]):
+                idx = np.flatnonzero((h == hh) & (w == ww))
+                per_row = width // int(ww)
+                k = np.arange(len(idx))
+                x[idx] = (k % per_row) * ww
+                y[idx] = base + (k // per_row) * hh
+                base += ((len(idx) + per_row - 1) // per_row) * int(hh)
+        return x, y, int((base + 63) // 64 * 64)
+
+    def transform_calls_scratch(self, check=True):
+        """Every TransformAndReconstruct of the inter CUs without local
+        illumination compensation as ONE batch per picture: each CU state's
+        prediction goes to its own slot of a scratch picture
+        (xvcgpu_inter_pred_batch_to), the originals are copied beside
+        (xvcgpu_copy_blocks), and the residual / distortion batches address the
+        scratch geometry.  -> (calls compared, mismatching calls)"""
+        api, ctx = self.api, self.ctx
+        rd = self.rd
+        ev_all, calls_all, qps = rd["evals"], rd["calls"], rd["qps"]
+        contexts = rd["contexts"].view(api.RDOQ_CTX_DTYPE).reshape(-1)
+        done = bad = 0
+        for poc in np.unique(ev_all["poc"]):
+            O, _ = self.orig(int(poc))
+            e_idx = np.flatnonzero(ev_all["poc"] == poc)
+            ev = ev_all[e_idx]
+            first, last = int(e_idx[0]), int(e_idx[-1])
+            cl = calls_all[(calls_all["eval"] >= first) & (calls_all["eval"] <= last)]
+            lic_ev = (ev["flags"] & rf.FLAG_LIC) != 0
+            cl = cl[~lic_ev[cl["eval"] - first]]
+            if not len(cl):
+                continue
+            ce = cl["eval"] - first
+            key = ce.astype(np.int64) * 3 + cl["comp"]
+            order = np.argsort(key, kind="stable")
+            ks = key[order]
+            start = np.r_[0, np.flatnonzero(ks[1:] != ks[:-1]) + 1]
+            rnd = np.zeros(len(cl), np.int32)
+            rnd[order] = np.arange(len(cl)) - np.repeat(start, np.diff(np.r_[start, len(cl)]))
+            rounds_of = np.zeros(len(ev), np.int32)
+            np.maximum.at(rounds_of, ce, rnd + 1)
+            u_eval = np.repeat(np.arange(len(ev)), rounds_of)
+            unit_first = np.r_[0, np.cumsum(rounds_of)[:-1]]
+            call_unit = unit_first[ce] + rnd
+            ux, uy, height = self.pack_slots(ev["w"][u_eval], ev["h"][u_eval])
+            width = 4096
+            assert height <= 16384
+            ref_pocs = sorted(set(int(p) for p in ev["ref_poc"].reshape(-1) if p >= 0))
+            slots = {p: i for i, p in enumerate(ref_pocs)}
+            refs = [self.pics[p] for p in ref_pocs]
+            ijobs = self._inter_jobs(ev["x"], ev["y"], ev["w"], ev["h"], ev["inter_dir"],
+                                     (ev["flags"] & rf.FLAG_AFFINE) != 0,
+                                     np.zeros(len(ev), bool), ev["ref_poc"], ev["mv"],
+                                     ev["nb_index"], slots)[u_eval].reshape(-1)
+            dst = np.zeros((len(u_eval), 3), api.POS_DTYPE)
+            dst["x"], dst["y"] = ux[:, None], uy[:, None]
+            cp = np.zeros((len(u_eval), 3), api.COPY_BLOCK_DTYPE)
+            for c in range(3):
+                s_ = 1 if c else 0
+                cp["sx"][:, c], cp["sy"][:, c] = ev["x"][u_eval] >> s_, ev["y"][u_eval] >> s_
+                cp["dx"][:, c], cp["dy"][:, c] = ux >> s_, uy >> s_
+                cp["w"][:, c], cp["h"][:, c] = ev["w"][u_eval] >> s_, ev["h"][u_eval] >> s_
+                cp["comp"][:, c] = c
+            c, e = cl, ev[ce]
+            s = (c["comp"] != 0).astype(np.int64)
+            blocks = np.zeros(len(c), api.TX_DTYPE)
+            blocks["x"], blocks["y"] = ux[call_unit] >> s, uy[call_unit] >> s
+            blocks["w"], blocks["h"] = e["w"] >> s, e["h"] >> s
+            blocks["comp"] = c["comp"]
+            blocks["tx_hor"] = np.where(c["tx_skip"] != 0, 6, c["tx_hor"])
+            blocks["tx_ver"] = c["tx_ver"]
+            blocks["qp"] = e["qp"][np.arange(len(c)), c["comp"]]
+            blocks["intra_pic"] = api.TXF_RDOQ | (c["scan"].astype(np.int64) << api.TXF_SCAN_SHIFT)
+            uctx, inv = np.unique(e["ctx_index"], return_inverse=True)
+            prm = np.zeros(len(c), api.RDOQ_PARAMS_DTYPE)
+            q = qps[e["qp_index"]]
+            prm["lambda"] = q["lambda"][np.arange(len(c)), c["comp"]]
+            prm["rd_factor"] = q["rd_factor"][np.arange(len(c)), c["comp"]]
+            prm["ctx_index"] = inv
+            o_s = ctx.picture(width, height, 10)
+            p_s = ctx.picture(width, height, 10)
+            r_s = ctx.picture(width, height, 10)
+            ctx.sync()
+            t0 = time.time()
+            ctx.copy_blocks(O, o_s, cp.reshape(-1))
+            ctx.inter_pred_batch_to(refs, O, p_s, ijobs, dst.reshape(-1))
+            levels, off, nnz = ctx.residual_rdoq_batch(o_s, p_s, r_s, blocks, contexts[uctx], prm)
+            self._time("scratch_transform_calls", t0)
+            dist = np.zeros(len(c), np.uint64)
+            t0 = time.time()
+            for comp in range(3):
+                m = np.flatnonzero(c["comp"] == comp)
+                if not len(m):
+                    continue
+                cands = np.zeros(len(m), api.CAND_DTYPE)
+                for f in ("x", "y", "w", "h"):
+                    cands[f] = blocks[f][m]
+                cands["metric"] = 7 if comp == 0 else 0
+                cands["qp"] = e["qp"][m, 0]
+                for qi in np.unique(e["qp_index"][m]):
+                    mm = np.flatnonzero(e["qp_index"][m] == qi)
+                    dist[m[mm]] = ctx.metric_batch(o_s, r_s, comp, cands[mm],
+                                                   weight=float(qps["dist_weight"][qi, comp]))
+            self._time("scratch_transform_dist", t0)
+            # cbf-zero distortions: the prediction against the original, per CU state
+            has = ((ev["dist_zero"] != np.uint64(0xffffffffffffffff)).any(1) & ~lic_ev &
+                   (rounds_of > 0))
+            evs = np.flatnonzero(has)
+            t0 = time.time()
+            for comp in range(3):
+                s_ = 1 if comp else 0
+                cands = np.zeros(len(evs), api.CAND_DTYPE)
+                cands["x"], cands["y"] = ux[unit_first[evs]] >> s_, uy[unit_first[evs]] >> s_
+                cands["w"], cands["h"] = ev["w"][evs] >> s_, ev["h"][evs] >> s_
+                cands["metric"] = 7 if comp == 0 else 0
+                cands["qp"] = ev["qp"][evs, 0]
+                got = np.zeros(len(evs), np.uint64)
+                for qi in np.unique(ev["qp_index"][evs]):
+                    mm = np.flatnonzero(ev["qp_index"][evs] == qi)
+                    got[mm] = ctx.metric_batch(o_s, p_s, comp, cands[mm],
+                                               weight=float(qps["dist_weight"][qi, comp]))
+                want = ev["dist_zero"][evs, comp]
+                valid = want != np.uint64(0xffffffffffffffff)
+                self.dz_bad = getattr(self, "dz_bad", 0) + int(((got != want) & valid).sum())
+                self.dz_done = getattr(self, "dz_done", 0) + int(valid.sum())
+            self._time("scratch_dist_zero", t0)
+            self.timing["scratch_units"] = self.timing.get("scratch_units", 0) + len(u_eval)
+            self.timing["scratch_rows"] = max(self.timing.get("scratch_rows", 0), height)
+            ok = nnz == c["nnz"]
+            if check:
+                planes = r_s.download()
+                for i in range(len(c)):
+                    w_, h_ = int(blocks["w"][i]), int(blocks["h"][i])
+                    lv = levels[int(off[i]):int(off[i]) + w_ * h_]
+                    good = c["nnz"][i] == 0 or rf.crc32_rows(lv) == int(c["levels_crc"][i])
+                    if good and c["completed"][i]:
+                        x_, y_ = int(blocks["x"][i]), int(blocks["y"][i])
+                        blk = planes[int(c["comp"][i])][y_:y_ + h_, x_:x_ + w_]
+                        good = ((rf.crc32_rows(blk) & 0xffff) == int(c["rec_crc"][i]) and
+                                int(dist[i]) == int(c["dist"][i]))
+                    ok[i] &= good
+            bad += int((~ok).sum())
+            done += len(c)
+            if (~ok).any() and not hasattr(self, "first_bad"):
+                i = int(np.flatnonzero(~ok)[0])
+                self.first_bad = ("transform/scratch", tuple(c[i]), tuple(e[i]), int(nnz[i]),
+                                  int(dist[i]))
+            for p in (o_s, p_s, r_s):
+                p.destroy()
         return done, bad
 
     # ---- TransformAndReconstruct of inter CUs (transform_encoder.cc:203-285) ---

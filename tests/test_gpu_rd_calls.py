@@ -56,6 +56,13 @@ def test_merge_candidate_rankings(replay):
     assert done > 100 and bad == 0, (done, bad, getattr(replay, "first_bad", None))
 
 
+def test_transform_calls_with_scratch_destinations(replay):
+    replay.dz_done = replay.dz_bad = 0
+    done, bad = replay.transform_calls_scratch()
+    assert done > 1000 and bad == 0, (done, bad, getattr(replay, "first_bad", None))
+    assert replay.dz_done > 100 and replay.dz_bad == 0, (replay.dz_done, replay.dz_bad)
+
+
 def test_transform_and_reconstruct_calls(replay):
     done, bad, layers, dz_done, dz_bad = replay.transform_calls()
     assert done > 10000 and bad == 0, (done, bad, layers, getattr(replay, "first_bad", None))

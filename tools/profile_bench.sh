@@ -16,7 +16,7 @@ B="python $R/bench.py --quant $quant"
 $B > $out/${tag}_bench.json 2> $out/bench.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o st -- $B --no-cpu --no-decode > $out/stats.log 2>&1
 cp $(find $out/stats -name "*kernel_stats.csv" | head -1) $out/${tag}_bench_kernel_stats.csv
-S="--no-cpu --no-decode --steps 56 --warmup 14"
+S="--no-cpu --no-decode --steps 56 --warmup 14 --settle 0"
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/fetch -o f -- $B $S > $out/fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/write -o w -- $B $S > $out/write.log 2>&1
 md5=$(cd $R && python -c "import bench; print(bench.kernel_source_md5())")

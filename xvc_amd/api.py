@@ -79,6 +79,10 @@ INTER_DTYPE = np.dtype([("x", "<i2"), ("y", "<i2"), ("w", "u1"), ("h", "u1"), ("
                         ("left_x", "<i2"), ("left_y", "<i2"), ("mv", "<i4", (2, 3, 2))])
 assert INTER_DTYPE.itemsize == 68
 INTER_AFFINE, INTER_LIC = 1, 2
+POS_DTYPE = np.dtype([("x", "<i2"), ("y", "<i2")])
+COPY_BLOCK_DTYPE = np.dtype([("sx", "<i2"), ("sy", "<i2"), ("dx", "<i2"), ("dy", "<i2"),
+                             ("w", "u1"), ("h", "u1"), ("comp", "u1"), ("reserved", "u1")])
+assert COPY_BLOCK_DTYPE.itemsize == 12
 RDOQ_CTX_DTYPE = np.dtype([
     ("csbf", "u1", (2, 2)), ("sig_luma", "u1", (54,)), ("sig_chroma", "u1", (12,)),
     ("greater1_luma", "u1", (16,)), ("greater1_chroma", "u1", (6,)),
@@ -166,7 +170,8 @@ SYMBOLS = [
     "xvcgpu_get_transform_matrix", "xvcgpu_inter_pred_batch", "xvcgpu_deblock_tree",
     "xvcgpu_residual_rdoq_batch", "xvcgpu_quant_rdo_batch", "xvcgpu_recon_from_me_rdoq",
     "xvcgpu_quant_rdo_reserve", "xvcgpu_quant_rdo_class_counts",
-    "xvcgpu_tx_eval_batch", "xvcgpu_root_cbf_batch",
+    "xvcgpu_tx_eval_batch", "xvcgpu_root_cbf_batch", "xvcgpu_bipred_search_lic",
+    "xvcgpu_inter_pred_batch_to", "xvcgpu_copy_blocks",
     "xvcgpu_fwd_from_me_classify", "xvcgpu_quant_rdo_classified_batch",
     "xvcgpu_event_create", "xvcgpu_event_destroy", "xvcgpu_event_record", "xvcgpu_event_wait",
     "xvcgpu_event_synchronize", "xvcgpu_comm_unique_id", "xvcgpu_comm_create",
@@ -291,6 +296,9 @@ def load_library():
         "xvcgpu_quant_rdo_reserve": [_vp, C.c_int, C.c_size_t],
         "xvcgpu_quant_rdo_class_counts": [_vp, _vp],
         "xvcgpu_tx_eval_batch": [_vp, _vp, C.c_int, _vp, _vp],
+        "xvcgpu_inter_pred_batch_to": [_vp, _vp, C.c_int, _vp, _vp, _vp, _vp, C.c_int],
+        "xvcgpu_copy_blocks": [_vp, _vp, _vp, _vp, C.c_int],
+        "xvcgpu_bipred_search_lic": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, _vp, C.c_int],
         "xvcgpu_root_cbf_batch": [_vp, _vp, C.c_int, _vp],
         "xvcgpu_quant_rdo_batch": [_vp, C.c_int, _vp, C.c_int, _vp, _vp, C.c_size_t, _vp, _vp,
                                    _vp, _vp],
@@ -791,6 +799,21 @@ class Context:
         dr.free()
         return out
 
+    def bipred_search_lic(self, orig, ref_other, ref_search, rec, jobs, neighbours):
+        """xvcgpu_bipred_search_lic: jobs BI_DTYPE, neighbours LIC_DTYPE (one per job)."""
+        jobs = np.ascontiguousarray(jobs, BI_DTYPE)
+        nb = np.ascontiguousarray(neighbours, LIC_DTYPE)
+        assert len(nb) == len(jobs)
+        dj, dn = self.buffer(jobs), self.buffer(nb)
+        dr = self.buffer(np.zeros(len(jobs), MERES_DTYPE))
+        self._check(self.lib.xvcgpu_bipred_search_lic(
+            self.h, orig.h_pic, ref_other.h_pic, ref_search.h_pic, rec.h_pic, dj.ptr, dn.ptr,
+            len(jobs), dr.ptr, 64))
+        out = dr.to_array(MERES_DTYPE, len(jobs))
+        for b in (dj, dn, dr):
+            b.free()
+        return out
+
     @staticmethod
     def level_offsets(blocks):
         sizes = blocks["w"].astype(np.int64) * blocks["h"].astype(np.int64)
@@ -1005,6 +1028,25 @@ class Context:
         d = self.buffer(jobs)
         self._check(self.lib.xvcgpu_inter_pred_batch(self.h, arr, len(refs), rec.h_pic,
                                                      pred.h_pic, d.ptr, len(jobs)))
+        d.free()
+
+    def inter_pred_batch_to(self, refs, rec, scratch, jobs, dst):
+        """xvcgpu_inter_pred_batch_to: job i's block goes to `scratch` at the luma
+        position dst[i] (POS_DTYPE) instead of the CU's own."""
+        jobs = np.ascontiguousarray(jobs, INTER_DTYPE)
+        dst = np.ascontiguousarray(dst, POS_DTYPE)
+        assert len(dst) == len(jobs)
+        arr = (_vp * max(1, len(refs)))(*[r.h_pic for r in refs])
+        d, dd = self.buffer(jobs), self.buffer(dst)
+        self._check(self.lib.xvcgpu_inter_pred_batch_to(self.h, arr, len(refs), rec.h_pic,
+                                                        scratch.h_pic, d.ptr, dd.ptr, len(jobs)))
+        d.free()
+        dd.free()
+
+    def copy_blocks(self, src, dst, blocks):
+        blocks = np.ascontiguousarray(blocks, COPY_BLOCK_DTYPE)
+        d = self.buffer(blocks)
+        self._check(self.lib.xvcgpu_copy_blocks(self.h, src.h_pic, dst.h_pic, d.ptr, len(blocks)))
         d.free()
 
     def affine_me_batch(self, orig, ref, blocks, ref_other=None):

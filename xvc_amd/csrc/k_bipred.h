@@ -48,13 +48,96 @@ __device__ __forceinline__ void bi_mc_luma(int bd, const xvcgpu_me_block &b,
   wave_interp_block<false>(bd, b.w, b.h, mx & 15, my & 15, r, pr.stride, tmp, pred);
 }
 
-template <int MS>
+// DeriveLicParams (inter_prediction.cc:1577-1663) by the first wave of the
+// workgroup; scale / offset are left in *s_scale / *s_offset (LDS) and are
+// visible after the next __syncthreads().  mx, my: the CU's clipped vector.
+__device__ __forceinline__ void wg_lic_model(int bd, int comp, int bx, int by, int bw, int bh,
+                                             int mx, int my, int neighbors, int above_x,
+                                             int above_y, int left_x, int left_y, int pic_w,
+                                             int pic_h, const PlaneView &pr, const PlaneView &pc,
+                                             int *s_scale, int *s_offset) {
+  if (threadIdx.x >= 64) return;
+  const int lane = threadIdx.x;
+  const int cs = comp ? 1 : 0, shift = 4 + cs;
+  const int cx = bx >> cs, cy = by >> cs, cw = bw >> cs, ch = bh >> cs;
+  const bool has_above = neighbors & XVC_LIC_HAS_ABOVE, has_left = neighbors & XVC_LIC_HAS_LEFT;
+  const int full_x = (mx + (1 << (shift - 1))) >> shift, full_y = (my + (1 << (shift - 1))) >> shift;
+  const int step = (cw < ch ? cw : ch) > 8 ? 2 : 1;
+  const int dx = step * (cw / ch > 1 ? cw / ch : 1), dy = step * (ch / cw > 1 ? ch / cw : 1);
+  const int na = has_above ? cw / dx : 0, nl = has_left ? ch / dy : 0;
+  const int nbr = na + nl;
+  const uint16_t *rb = pr.p + (ptrdiff_t)cy * pr.stride + cx;
+  const uint16_t *sb = pc.p + (ptrdiff_t)cy * pc.stride + cx;
+  int sx = 0, sy = 0, sxx = 0, sxy = 0;
+  for (int i = lane; i < nbr; i += 64) {
+    int a, d;
+    if (i < na) {
+      int vx = full_x, vy = full_y;
+      d_clip_mv(above_x, above_y, pic_w, pic_h, vx, vy);
+      a = rb[(ptrdiff_t)(vy - 1) * pr.stride + vx + i * dx];
+      d = sb[-(ptrdiff_t)pc.stride + i * dx];
+    } else {
+      int vx = full_x, vy = full_y;
+      d_clip_mv(left_x, left_y, pic_w, pic_h, vx, vy);
+      const int yy = (i - na) * dy;
+      a = rb[(ptrdiff_t)(vy + yy) * pr.stride + vx - 1];
+      d = sb[(ptrdiff_t)yy * pc.stride - 1];
+    }
+    sx += a; sy += d; sxx += a * a; sxy += a * d;
+  }
+  sx = group_sum<64>(sx);
+  sy = group_sum<64>(sy);
+  sxx = group_sum<64>(sxx);
+  sxy = group_sum<64>(sxy);
+  if (lane != 0) return;
+  int scale = 32, offset = 0;
+  if (nbr > 0) {
+    int size_shift = 1;
+    while ((1 << size_shift) < nbr) size_shift++;
+    int base_shift = bd + size_shift - 15;
+    base_shift = base_shift < 0 ? 0 : base_shift;
+    const int avg_x = sx >> base_shift, avg_y = sy >> base_shift;
+    const int xx_offset = sxx >> 7;
+    const int avg_xy = ((sxy + xx_offset) >> (2 * base_shift)) << size_shift;
+    const int avg_xx = ((sxx + xx_offset) >> (2 * base_shift)) << size_shift;
+    const int vxy = avg_xy - avg_x * avg_y, vxx = avg_xx - avg_x * avg_x;
+    const int msb = vxx == 0 ? 0 : 32 - __clz(d_abs(vxx));
+    int shift_xx = msb - 6;
+    shift_xx = shift_xx < 0 ? 0 : shift_xx;
+    int shift_xy = shift_xx - 12;
+    shift_xy = shift_xy < 0 ? 0 : shift_xy;
+    const int total_shift = 15 - 5 + shift_xx - shift_xy;
+    const int vxy_s = vxy >> shift_xy;
+    const int vxx_s = d_clip3(vxx >> shift_xx, 0, 63);
+    if (vxx_s != 0) {
+      const int vxx_scaled = ((1 << 15) + (vxx_s / 2)) / vxx_s;
+      const int sc = (int)((long long)vxy_s * vxx_scaled) >> total_shift;
+      scale = d_clip3(sc, 0, 128);
+      const int off = (sy - ((scale * sx) >> 5) + (1 << (size_shift - 1))) >> size_shift;
+      offset = d_clip3(off, -(1 << (bd - 1)), (1 << (bd - 1)) - 1);
+    }
+  }
+  *s_scale = scale;
+  *s_offset = offset;
+}
+
+// LIC = true: the CU tries local illumination compensation (cu.GetUseLic()).  The
+// other list's prediction is then the compensated one (MotionCompensation ->
+// MotionCompRefList with post_filter, inter_prediction.cc:710-722 ->
+// LocalIlluminationComp :1555-1575: the model from the current reconstruction
+// `rec` around the CU, neighbours in nb[job]), the full-pel stage compares with
+// kSadAcOnly[Fast] and the sub-pel stage with kSatdAcOnly (GetFullpelMetric /
+// GetSubpelMetric, inter_search.cc:1059-1076) - both on the int16 target; the
+// candidates' own predictions stay plain (GetSubpelDist: post_filter = false).
+template <int MS, bool LIC = false>
 __global__ void __launch_bounds__(64 * BI_WAVES(MS))
 bipred_search_kernel(PlaneView orig, PlaneView ref_other, PlaneView ref_search,
                      int bd, const xvcgpu_bi_block *jobs, int n,
-                     xvcgpu_me_result *out, int max_launched) {
+                     xvcgpu_me_result *out, int max_launched, PlaneView rec = PlaneView(),
+                     const xvcgpu_mc_lic_block *nb = nullptr) {
   constexpr int NW = BI_WAVES(MS);
   __shared__ BiShared<MS> s;
+  __shared__ int s_scale, s_offset;
   const int ji = xcd_job_index(blockIdx.x, n);
   if (ji < 0) return;
   const xvcgpu_bi_block job = jobs[ji];
@@ -85,6 +168,19 @@ bipred_search_kernel(PlaneView orig, PlaneView ref_other, PlaneView ref_search,
   if (wave == 0)
     bi_mc_luma(bd, b, ref_other, job.other_mv_x, job.other_mv_y, tmp, pred);
   __syncthreads();
+  if (LIC) {
+    const xvcgpu_mc_lic_block q = nb[ji];
+    int cmx = job.other_mv_x, cmy = job.other_mv_y;
+    d_clip_mv(b.x, b.y, ref_other.w, ref_other.h, cmx, cmy);
+    wg_lic_model(bd, 0, b.x, b.y, w, h, cmx, cmy, q.neighbors, q.above_x, q.above_y, q.left_x,
+                 q.left_y, ref_other.w, ref_other.h, ref_other, rec, &s_scale, &s_offset);
+    __syncthreads();
+    const int scale = s_scale, offset = s_offset, smax = (1 << bd) - 1;
+    uint16_t *p0 = s.wv[0].pred;
+    for (int i = threadIdx.x; i < w * h; i += 64 * NW)
+      p0[i] = (uint16_t)d_clip3(((scale * (int)p0[i]) >> 5) + offset, 0, smax);
+    __syncthreads();
+  }
   {
     const uint16_t *o = orig.p + (ptrdiff_t)b.y * orig.stride + b.x;
     const uint16_t *p0 = s.wv[0].pred;
@@ -106,7 +202,9 @@ bipred_search_kernel(PlaneView orig, PlaneView ref_other, PlaneView ref_search,
     const int my = mny + c / nx, mx = mnx + c % nx;
     const uint16_t *r = rcu + (ptrdiff_t)my * ref_search.stride + mx;
     unsigned long long dist;
-    if (h > 8)  // kSadFast
+    if (LIC)    // kSadAcOnlyFast / kSadAcOnly
+      dist = wave_sad_ac(h > 8 ? 1 : 0, bd, w, h, s.target, w, r, ref_search.stride);
+    else if (h > 8)  // kSadFast
       dist = ((unsigned long long)(long long)wave_sad(w, h / 2, 2, s.target, w, r,
                                                       ref_search.stride) * 2) >> (bd - 8);
     else
@@ -131,7 +229,8 @@ bipred_search_kernel(PlaneView orig, PlaneView ref_other, PlaneView ref_search,
     if (wave == 0) {
       bi_mc_luma(bd, b, ref_search, bx, by, tmp, pred);
       wave_sync();
-      const uint32_t d = (uint32_t)wave_satd(bd, w, h, 0, s.target, w, pred, w);
+      const int avg = LIC ? wave_mean_diff(0, w, h, s.target, w, pred, w) : 0;
+      const uint32_t d = (uint32_t)wave_satd(bd, w, h, avg, s.target, w, pred, w);
       if (lane == 0) s.dist[0] = d;
     }
     __syncthreads();
@@ -146,7 +245,8 @@ bipred_search_kernel(PlaneView orig, PlaneView ref_other, PlaneView ref_search,
         const int mx = bx + d[0] * scale, my = by + d[1] * scale;
         bi_mc_luma(bd, b, ref_search, mx, my, tmp, pred);
         wave_sync();
-        const uint32_t dist = (uint32_t)wave_satd(bd, w, h, 0, s.target, w, pred, w);
+        const int avg = LIC ? wave_mean_diff(0, w, h, s.target, w, pred, w) : 0;
+        const uint32_t dist = (uint32_t)wave_satd(bd, w, h, avg, s.target, w, pred, w);
         wave_sync();
         const uint32_t bits = d_mvd_bits(b.mvp_x, b.mvp_y, mx, my, 0);
         const unsigned long long cost =

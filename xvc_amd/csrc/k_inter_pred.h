@@ -113,83 +113,12 @@ __device__ __forceinline__ void wg_affine_block(int bd, int comp, int bx, int by
   }
 }
 
-// DeriveLicParams (inter_prediction.cc:1577-1663) by the first wave of the
-// workgroup; scale / offset are left in *s_scale / *s_offset (LDS) and are
-// visible after the next __syncthreads().  mx, my: the CU's clipped vector.
-__device__ __forceinline__ void wg_lic_model(int bd, int comp, int bx, int by, int bw, int bh,
-                                             int mx, int my, int neighbors, int above_x,
-                                             int above_y, int left_x, int left_y, int pic_w,
-                                             int pic_h, const PlaneView &pr, const PlaneView &pc,
-                                             int *s_scale, int *s_offset) {
-  if (threadIdx.x >= 64) return;
-  const int lane = threadIdx.x;
-  const int cs = comp ? 1 : 0, shift = 4 + cs;
-  const int cx = bx >> cs, cy = by >> cs, cw = bw >> cs, ch = bh >> cs;
-  const bool has_above = neighbors & XVC_LIC_HAS_ABOVE, has_left = neighbors & XVC_LIC_HAS_LEFT;
-  const int full_x = (mx + (1 << (shift - 1))) >> shift, full_y = (my + (1 << (shift - 1))) >> shift;
-  const int step = (cw < ch ? cw : ch) > 8 ? 2 : 1;
-  const int dx = step * (cw / ch > 1 ? cw / ch : 1), dy = step * (ch / cw > 1 ? ch / cw : 1);
-  const int na = has_above ? cw / dx : 0, nl = has_left ? ch / dy : 0;
-  const int nbr = na + nl;
-  const uint16_t *rb = pr.p + (ptrdiff_t)cy * pr.stride + cx;
-  const uint16_t *sb = pc.p + (ptrdiff_t)cy * pc.stride + cx;
-  int sx = 0, sy = 0, sxx = 0, sxy = 0;
-  for (int i = lane; i < nbr; i += 64) {
-    int a, d;
-    if (i < na) {
-      int vx = full_x, vy = full_y;
-      d_clip_mv(above_x, above_y, pic_w, pic_h, vx, vy);
-      a = rb[(ptrdiff_t)(vy - 1) * pr.stride + vx + i * dx];
-      d = sb[-(ptrdiff_t)pc.stride + i * dx];
-    } else {
-      int vx = full_x, vy = full_y;
-      d_clip_mv(left_x, left_y, pic_w, pic_h, vx, vy);
-      const int yy = (i - na) * dy;
-      a = rb[(ptrdiff_t)(vy + yy) * pr.stride + vx - 1];
-      d = sb[(ptrdiff_t)yy * pc.stride - 1];
-    }
-    sx += a; sy += d; sxx += a * a; sxy += a * d;
-  }
-  sx = group_sum<64>(sx);
-  sy = group_sum<64>(sy);
-  sxx = group_sum<64>(sxx);
-  sxy = group_sum<64>(sxy);
-  if (lane != 0) return;
-  int scale = 32, offset = 0;
-  if (nbr > 0) {
-    int size_shift = 1;
-    while ((1 << size_shift) < nbr) size_shift++;
-    int base_shift = bd + size_shift - 15;
-    base_shift = base_shift < 0 ? 0 : base_shift;
-    const int avg_x = sx >> base_shift, avg_y = sy >> base_shift;
-    const int xx_offset = sxx >> 7;
-    const int avg_xy = ((sxy + xx_offset) >> (2 * base_shift)) << size_shift;
-    const int avg_xx = ((sxx + xx_offset) >> (2 * base_shift)) << size_shift;
-    const int vxy = avg_xy - avg_x * avg_y, vxx = avg_xx - avg_x * avg_x;
-    const int msb = vxx == 0 ? 0 : 32 - __clz(d_abs(vxx));
-    int shift_xx = msb - 6;
-    shift_xx = shift_xx < 0 ? 0 : shift_xx;
-    int shift_xy = shift_xx - 12;
-    shift_xy = shift_xy < 0 ? 0 : shift_xy;
-    const int total_shift = 15 - 5 + shift_xx - shift_xy;
-    const int vxy_s = vxy >> shift_xy;
-    const int vxx_s = d_clip3(vxx >> shift_xx, 0, 63);
-    if (vxx_s != 0) {
-      const int vxx_scaled = ((1 << 15) + (vxx_s / 2)) / vxx_s;
-      const int sc = (int)((long long)vxy_s * vxx_scaled) >> total_shift;
-      scale = d_clip3(sc, 0, 128);
-      const int off = (sy - ((scale * sx) >> 5) + (1 << (size_shift - 1))) >> size_shift;
-      offset = d_clip3(off, -(1 << (bd - 1)), (1 << (bd - 1)) - 1);
-    }
-  }
-  *s_scale = scale;
-  *s_offset = offset;
-}
+// (wg_lic_model: k_bipred.h)
 
 // grid: n; block: 256.
 __global__ void __launch_bounds__(256)
 inter_pred_kernel(RefTable refs, PicView rec, PicView pred, const xvcgpu_inter_block *blocks,
-                  int n) {
+                  int n, const xvcgpu_block_pos *dst_pos, int pic_w, int pic_h) {
   __shared__ int16_t tmp[64 * 71];
   __shared__ int16_t p16[2][64 * 64];
   __shared__ uint16_t smp[64 * 64];
@@ -198,14 +127,16 @@ inter_pred_kernel(RefTable refs, PicView rec, PicView pred, const xvcgpu_inter_b
   if (bi_ >= n) return;
   const xvcgpu_inter_block &b = blocks[bi_];
   const int bd = pred.bd, comp = b.comp;
-  const int pic_w = pred.c[0].w, pic_h = pred.c[0].h;
   const int cs = comp ? 1 : 0, shift = 4 + cs, mask = (1 << shift) - 1;
   const int cx = b.x >> cs, cy = b.y >> cs, cw = b.w >> cs, ch = b.h >> cs;
   const bool affine = b.flags & XVC_INTER_AFFINE;
   const bool lic = (b.flags & XVC_INTER_LIC) && !affine;
   const bool bi = b.ref[0] >= 0 && b.ref[1] >= 0;
   const PlaneView pd = pred.c[comp];
-  uint16_t *out = pd.p + (ptrdiff_t)cy * pd.stride + cx;
+  // the CU's position, or the caller's scratch position (pred is then not a picture
+  // of the sequence)
+  const int ox = dst_pos ? dst_pos[bi_].x >> cs : cx, oy = dst_pos ? dst_pos[bi_].y >> cs : cy;
+  uint16_t *out = pd.p + (ptrdiff_t)oy * pd.stride + ox;
   const int smax = (1 << bd) - 1, head = 14 - bd;
   const int lw = 31 - __clz(cw);
   for (int l = 0; l < 2; l++) {

@@ -318,4 +318,26 @@ copy_segments_kernel(const xvcgpu_copy_segment *segs, int n) {
   }
 }
 
+// xvcgpu_copy_blocks: one wave per block, rows of up to 64 samples.
+// grid: (n + 3) / 4; block: 256.
+__global__ void __launch_bounds__(256)
+copy_blocks_kernel(PicView src, PicView dst, const xvcgpu_copy_block *blocks, int n) {
+  const int bi = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (bi >= n) return;
+  const xvcgpu_copy_block b = blocks[bi];
+  const PlaneView ps = src.c[b.comp], pd = dst.c[b.comp];
+  const uint16_t *s = ps.p + (ptrdiff_t)b.sy * ps.stride + b.sx;
+  uint16_t *d = pd.p + (ptrdiff_t)b.dy * pd.stride + b.dx;
+  const int lw = 31 - __clz((int)b.w), total = b.w * b.h;
+  if ((b.w & (b.w - 1)) == 0) {
+    for (int i = lane; i < total; i += 64)
+      d[(ptrdiff_t)(i >> lw) * pd.stride + (i & (b.w - 1))] =
+          s[(ptrdiff_t)(i >> lw) * ps.stride + (i & (b.w - 1))];
+  } else {
+    for (int y = 0; y < b.h; y++)
+      for (int x = lane; x < b.w; x += 64)
+        d[(ptrdiff_t)y * pd.stride + x] = s[(ptrdiff_t)y * ps.stride + x];
+  }
+}
+
 #endif  // XVCGPU_K_MISC_H_

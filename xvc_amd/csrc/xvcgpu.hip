@@ -760,27 +760,56 @@ xvcgpu_status xvcgpu_mc_lic_batch(xvcgpu_ctx *ctx, const xvcgpu_picture *ref,
   return XVCGPU_OK;
 }
 
-xvcgpu_status xvcgpu_inter_pred_batch(xvcgpu_ctx *ctx, const xvcgpu_picture *const *refs,
-                                      int n_refs, const xvcgpu_picture *rec,
-                                      xvcgpu_picture *pred,
-                                      const xvcgpu_inter_block *d_blocks, int n) {
+static xvcgpu_status inter_pred_launch(xvcgpu_ctx *ctx, const xvcgpu_picture *const *refs,
+                                       int n_refs, const xvcgpu_picture *rec,
+                                       xvcgpu_picture *pred, const xvcgpu_inter_block *d_blocks,
+                                       const xvcgpu_block_pos *d_dst, int n) {
   if (!ctx || !refs || n_refs < 1 || n_refs > XVC_MAX_REF_SLOTS || !rec || !pred || n < 0 ||
       (n && !d_blocks))
     return XVCGPU_INVALID_ARGUMENT;
-  if (rec->w != pred->w || rec->h != pred->h || rec->bd != pred->bd)
+  // a scratch destination has its own size; the pictures of the sequence agree
+  if (rec->bd != pred->bd || (!d_dst && (rec->w != pred->w || rec->h != pred->h)))
     return fail(ctx, XVCGPU_INVALID_ARGUMENT, "picture mismatch");
   RefTable t;
   memset(&t, 0, sizeof(t));
   for (int i = 0; i < n_refs; i++) {
     if (!refs[i]) return XVCGPU_INVALID_ARGUMENT;
-    if (refs[i]->w != pred->w || refs[i]->h != pred->h || refs[i]->bd != pred->bd)
+    if (refs[i]->w != rec->w || refs[i]->h != rec->h || refs[i]->bd != rec->bd)
       return fail(ctx, XVCGPU_INVALID_ARGUMENT, "reference picture mismatch");
     t.pic[i] = refs[i]->v;
   }
   if (n == 0) return XVCGPU_OK;
   hipLaunchKernelGGL(inter_pred_kernel, dim3(n), dim3(256), 0, ctx->stream, t, rec->v,
-                     pred->v, d_blocks, n);
+                     pred->v, d_blocks, n, d_dst, rec->w, rec->h);
   CHECK_LAUNCH(ctx, "inter_pred_batch");
+  return XVCGPU_OK;
+}
+
+xvcgpu_status xvcgpu_inter_pred_batch(xvcgpu_ctx *ctx, const xvcgpu_picture *const *refs,
+                                      int n_refs, const xvcgpu_picture *rec,
+                                      xvcgpu_picture *pred,
+                                      const xvcgpu_inter_block *d_blocks, int n) {
+  return inter_pred_launch(ctx, refs, n_refs, rec, pred, d_blocks, nullptr, n);
+}
+
+xvcgpu_status xvcgpu_inter_pred_batch_to(xvcgpu_ctx *ctx, const xvcgpu_picture *const *refs,
+                                         int n_refs, const xvcgpu_picture *rec,
+                                         xvcgpu_picture *scratch,
+                                         const xvcgpu_inter_block *d_blocks,
+                                         const xvcgpu_block_pos *d_dst, int n) {
+  if (n && !d_dst) return XVCGPU_INVALID_ARGUMENT;
+  return inter_pred_launch(ctx, refs, n_refs, rec, scratch, d_blocks, d_dst, n);
+}
+
+xvcgpu_status xvcgpu_copy_blocks(xvcgpu_ctx *ctx, const xvcgpu_picture *src,
+                                 xvcgpu_picture *dst, const xvcgpu_copy_block *d_blocks,
+                                 int n) {
+  if (!ctx || !src || !dst || n < 0 || (n && !d_blocks)) return XVCGPU_INVALID_ARGUMENT;
+  if (src->bd != dst->bd) return fail(ctx, XVCGPU_INVALID_ARGUMENT, "picture mismatch");
+  if (n == 0) return XVCGPU_OK;
+  hipLaunchKernelGGL(copy_blocks_kernel, dim3((n + 3) / 4), dim3(256), 0, ctx->stream, src->v,
+                     dst->v, d_blocks, n);
+  CHECK_LAUNCH(ctx, "copy_blocks");
   return XVCGPU_OK;
 }
 
@@ -812,34 +841,63 @@ xvcgpu_status xvcgpu_mc_bipred_batch(xvcgpu_ctx *ctx, const xvcgpu_picture *ref0
   return XVCGPU_OK;
 }
 
+static xvcgpu_status bipred_search_launch(xvcgpu_ctx *ctx, const xvcgpu_picture *orig,
+                                          const xvcgpu_picture *ref_other,
+                                          const xvcgpu_picture *ref_search,
+                                          const xvcgpu_picture *rec,
+                                          const xvcgpu_bi_block *d_jobs,
+                                          const xvcgpu_mc_lic_block *d_nb, int n,
+                                          xvcgpu_me_result *d_results, int max_block_size) {
+  if (!ctx || !orig || !ref_other || !ref_search || n < 0 ||
+      (n && (!d_jobs || !d_results)) || max_block_size < 4 || max_block_size > 64 ||
+      ((rec != nullptr) != (d_nb != nullptr)))
+    return XVCGPU_INVALID_ARGUMENT;
+  if (orig->w != ref_other->w || orig->h != ref_other->h ||
+      orig->bd != ref_other->bd || orig->w != ref_search->w ||
+      orig->h != ref_search->h || orig->bd != ref_search->bd ||
+      (rec && (rec->w != orig->w || rec->h != orig->h || rec->bd != orig->bd)))
+    return fail(ctx, XVCGPU_INVALID_ARGUMENT, "picture mismatch");
+  if (n == 0) return XVCGPU_OK;
+  const dim3 grid((n + 7) / 8 * 8);
+  const int bi_max = max_block_size > 32 ? 64 : (max_block_size > 16 ? 32 : 16);
+#define BI_LAUNCH(MS)                                                                        \
+  do {                                                                                       \
+    if (rec)                                                                                 \
+      hipLaunchKernelGGL((bipred_search_kernel<MS, true>), grid, dim3(64 * BI_WAVES(MS)), 0, \
+                         ctx->stream, orig->v.c[0], ref_other->v.c[0], ref_search->v.c[0],   \
+                         orig->bd, d_jobs, n, d_results, bi_max, rec->v.c[0], d_nb);         \
+    else                                                                                     \
+      hipLaunchKernelGGL((bipred_search_kernel<MS, false>), grid, dim3(64 * BI_WAVES(MS)), 0,\
+                         ctx->stream, orig->v.c[0], ref_other->v.c[0], ref_search->v.c[0],   \
+                         orig->bd, d_jobs, n, d_results, bi_max, PlaneView(), nullptr);      \
+  } while (0)
+  BI_LAUNCH(16);
+  if (max_block_size > 16) BI_LAUNCH(32);
+  if (max_block_size > 32) BI_LAUNCH(64);
+#undef BI_LAUNCH
+  CHECK_LAUNCH(ctx, "bipred_search");
+  return XVCGPU_OK;
+}
+
 xvcgpu_status xvcgpu_bipred_search(xvcgpu_ctx *ctx, const xvcgpu_picture *orig,
                                    const xvcgpu_picture *ref_other,
                                    const xvcgpu_picture *ref_search,
                                    const xvcgpu_bi_block *d_jobs, int n,
                                    xvcgpu_me_result *d_results, int max_block_size) {
-  if (!ctx || !orig || !ref_other || !ref_search || n < 0 ||
-      (n && (!d_jobs || !d_results)) || max_block_size < 4 || max_block_size > 64)
-    return XVCGPU_INVALID_ARGUMENT;
-  if (orig->w != ref_other->w || orig->h != ref_other->h ||
-      orig->bd != ref_other->bd || orig->w != ref_search->w ||
-      orig->h != ref_search->h || orig->bd != ref_search->bd)
-    return fail(ctx, XVCGPU_INVALID_ARGUMENT, "picture mismatch");
-  if (n == 0) return XVCGPU_OK;
-  const dim3 grid((n + 7) / 8 * 8);
-  const int bi_max = max_block_size > 32 ? 64 : (max_block_size > 16 ? 32 : 16);
-  hipLaunchKernelGGL(bipred_search_kernel<16>, grid, dim3(64 * BI_WAVES(16)), 0,
-                     ctx->stream, orig->v.c[0], ref_other->v.c[0], ref_search->v.c[0],
-                     orig->bd, d_jobs, n, d_results, bi_max);
-  if (max_block_size > 16)
-    hipLaunchKernelGGL(bipred_search_kernel<32>, grid, dim3(64 * BI_WAVES(32)), 0,
-                       ctx->stream, orig->v.c[0], ref_other->v.c[0],
-                       ref_search->v.c[0], orig->bd, d_jobs, n, d_results, bi_max);
-  if (max_block_size > 32)
-    hipLaunchKernelGGL(bipred_search_kernel<64>, grid, dim3(64 * BI_WAVES(64)), 0,
-                       ctx->stream, orig->v.c[0], ref_other->v.c[0],
-                       ref_search->v.c[0], orig->bd, d_jobs, n, d_results, bi_max);
-  CHECK_LAUNCH(ctx, "bipred_search");
-  return XVCGPU_OK;
+  return bipred_search_launch(ctx, orig, ref_other, ref_search, nullptr, d_jobs, nullptr, n,
+                              d_results, max_block_size);
+}
+
+xvcgpu_status xvcgpu_bipred_search_lic(xvcgpu_ctx *ctx, const xvcgpu_picture *orig,
+                                       const xvcgpu_picture *ref_other,
+                                       const xvcgpu_picture *ref_search,
+                                       const xvcgpu_picture *rec,
+                                       const xvcgpu_bi_block *d_jobs,
+                                       const xvcgpu_mc_lic_block *d_neighbours, int n,
+                                       xvcgpu_me_result *d_results, int max_block_size) {
+  if (!rec || !d_neighbours) return XVCGPU_INVALID_ARGUMENT;
+  return bipred_search_launch(ctx, orig, ref_other, ref_search, rec, d_jobs, d_neighbours, n,
+                              d_results, max_block_size);
 }
 
 xvcgpu_status xvcgpu_mc_from_me(xvcgpu_ctx *ctx, const xvcgpu_picture *ref,

@@ -3,8 +3,9 @@
 // them as literal tables; they are the JEM definitions
 //   coef = (int)(256*sqrt(N)*v + (v > 0 ? 0.5 : -0.5)),
 // v = orthonormal DCT-2 / DCT-5 / DCT-8 / DST-1 / DST-7 basis).
-// tests/test_tables.py checks every entry against the oracle, the reference
-// build and a committed checksum.  Pure host code: no GPU needed.
+// tests/test_abi.py::test_transform_tables_match_oracle checks every entry
+// against the oracle, tests/test_oracle_vs_ref.py::test_transform_tables the
+// oracle against the reference build's literals.  Pure host code: no GPU needed.
 #include <math.h>
 #include <string.h>
 
