@@ -14,11 +14,11 @@ mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 B="python $R/bench.py --quant $quant"
 $B > $out/${tag}_bench.json 2> $out/bench.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o st -- $B --no-cpu --no-decode > $out/stats.log 2>&1
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o st -- $B --no-cpu --no-decode > $out/stats.log 2>&1
 cp $(find $out/stats -name "*kernel_stats.csv" | head -1) $out/${tag}_bench_kernel_stats.csv
 S="--no-cpu --no-decode --steps 56 --warmup 14 --settle 0"
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/fetch -o f -- $B $S > $out/fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/write -o w -- $B $S > $out/write.log 2>&1
+timeout 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/fetch -o f -- $B $S > $out/fetch.log 2>&1
+timeout 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/write -o w -- $B $S > $out/write.log 2>&1
 md5=$(cd $R && python -c "import bench; print(bench.kernel_source_md5())")
 python $R/tools/pmc_traffic.py $out/fetch $out/write $out/${tag}_traffic.json $md5 $quant
 i=0
@@ -28,7 +28,7 @@ for set in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS" \
            "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_THREAD_CYCLES_VALU GRBM_GUI_ACTIVE" \
            "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum TCC_HIT_sum"; do
   i=$((i+1))
-  rocprofv3 --pmc $set --kernel-trace --output-format csv -d $out/sq$i -o pmc -- $B $S > $out/sq$i.log 2>&1
+  timeout 300 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $out/sq$i -o pmc -- $B $S > $out/sq$i.log 2>&1
 done
 python - > $out/${tag}_sq_counters.txt <<PY
 import csv, glob, collections
