@@ -738,6 +738,24 @@ xvcgpu_status xvcgpu_histogram_distance(xvcgpu_ctx *ctx, const xvcgpu_picture *a
 xvcgpu_status xvcgpu_intra_pred_batch(xvcgpu_ctx *ctx, const xvcgpu_picture *rec,
                                       xvcgpu_picture *pred,
                                       const xvcgpu_intra_block *d_jobs, int n);
+/* The decoder's intra picture in ONE launch: all dependency waves of
+ * CuDecoder::DecompressCu for intra CUs (cu_decoder.cc:100-166: Predict,
+ * InverseTransform, AddClip).  Wave w = jobs d_wave_first[w] ..
+ * d_wave_first[w + 1] of BOTH lists - d_jobs[k] (the prediction, any size / mode,
+ * LM chroma included) and d_blocks[k] (the same block's transform job) - whose
+ * reference samples come from waves < w; levels / offsets / nnz as for
+ * xvcgpu_inv_transform_batch.  A cooperative launch (the workgroups meet at a
+ * grid barrier between waves): XVCGPU_UNSUPPORTED when the device refuses it -
+ * the caller then issues xvcgpu_intra_pred_batch + xvcgpu_inv_transform_batch
+ * per wave, the same result. */
+xvcgpu_status xvcgpu_intra_recon_waves(xvcgpu_ctx *ctx, xvcgpu_picture *rec,
+                                       xvcgpu_picture *pred,
+                                       const xvcgpu_intra_block *d_jobs,
+                                       const xvcgpu_tx_block *d_blocks,
+                                       const int32_t *d_wave_first, int n_waves,
+                                       const int16_t *d_levels,
+                                       const uint32_t *d_level_offsets,
+                                       const int32_t *d_nnz);
 /* The prediction + SATD loop of IntraSearch::DetermineSlowIntraModes
  * (intra_search.cc:189-305) for luma blocks, all 67 modes per job (the reference
  * evaluates the even modes, then the odd neighbours of the best ones: any

@@ -24,10 +24,11 @@ def gpu():
     ctx.close()
 
 
-def decode_stream_on_gpu(api, ctx, fx, check):
+def decode_stream_on_gpu(api, ctx, fx, check, one_launch_intra=True):
     from xvc_amd import decoder
     w, h, bd = (int(fx.info[0][k]) for k in ("width", "height", "bitdepth"))
     dec = decoder.PictureDecoder(ctx, w, h, bd)
+    dec.one_launch_intra(one_launch_intra)
     done = {}
     try:
         for i in range(fx.n):
@@ -46,8 +47,11 @@ def decode_stream_on_gpu(api, ctx, fx, check):
             p.destroy()
 
 
-@pytest.mark.parametrize("name", ["tiny", "c0", "c1", "c1x"])
-def test_gpu_reconstructs_reference_stream(gpu, name):
+@pytest.mark.parametrize("name,one_launch", [("tiny", True), ("c0", True), ("c1", True),
+                                             ("c1x", True), ("tiny", False), ("c1", False)])
+def test_gpu_reconstructs_reference_stream(gpu, name, one_launch):
+    """one_launch: the intra picture's dependency waves as ONE cooperative launch
+    (xvcgpu_intra_recon_waves, the default) or as a launch set per wave."""
     api, ctx = gpu
     fx = sf.StreamFixture(name)
     oracle = sf.oracle_decode_stream([(fx.info[i], fx.cus(i), fx.levels(i))
@@ -76,8 +80,10 @@ def test_gpu_reconstructs_reference_stream(gpu, name):
                 ob = opic.border >> (1 if c else 0)
                 assert np.array_equal(gp[c], full[ob - b:full.shape[0] - ob + b,
                                                   ob - b:full.shape[1] - ob + b]), (name, i, c)
+        if int(info["pic_type"]) == 2:      # an intra picture: its waves took one launch
+            assert (dec.launches < 10) == one_launch, (dec.waves, dec.launches)
 
-    decode_stream_on_gpu(api, ctx, fx, check)
+    decode_stream_on_gpu(api, ctx, fx, check, one_launch)
 
 
 def test_gpu_stream_decode_rate(gpu):

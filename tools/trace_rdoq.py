@@ -46,7 +46,9 @@ life = t[:, 10] - t[:, 0]
 print("wave lifetime: mean %.0f p50 %.0f p90 %.0f max %d" % (life.mean(), np.median(life), np.percentile(life, 90), life.max()))
 prev = t[:, 0]
 for k in range(1, 11):
-    cur = np.where(t[:, k] > 0, t[:, k], prev)     # sections a wave skipped
+    # a section the wave skipped keeps the stamp of an earlier block of the same
+    # workgroup (or none): only stamps inside [previous section, end] count
+    cur = np.where((t[:, k] >= prev) & (t[:, k] <= t[:, 10]), t[:, k], prev)
     d = cur - prev
     print("%-14s mean %7.0f  p50 %7.0f  p90 %7.0f  max %8d  share %5.1f%%" %
           (names[k], d.mean(), np.median(d), np.percentile(d, 90), d.max(), 100.0 * d.sum() / life.sum()))

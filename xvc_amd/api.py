@@ -171,7 +171,7 @@ SYMBOLS = [
     "xvcgpu_residual_rdoq_batch", "xvcgpu_quant_rdo_batch", "xvcgpu_recon_from_me_rdoq",
     "xvcgpu_quant_rdo_reserve", "xvcgpu_quant_rdo_class_counts",
     "xvcgpu_tx_eval_batch", "xvcgpu_root_cbf_batch", "xvcgpu_bipred_search_lic",
-    "xvcgpu_inter_pred_batch_to", "xvcgpu_copy_blocks",
+    "xvcgpu_inter_pred_batch_to", "xvcgpu_copy_blocks", "xvcgpu_intra_recon_waves",
     "xvcgpu_fwd_from_me_classify", "xvcgpu_quant_rdo_classified_batch",
     "xvcgpu_event_create", "xvcgpu_event_destroy", "xvcgpu_event_record", "xvcgpu_event_wait",
     "xvcgpu_event_synchronize", "xvcgpu_comm_unique_id", "xvcgpu_comm_create",
@@ -298,6 +298,7 @@ def load_library():
         "xvcgpu_tx_eval_batch": [_vp, _vp, C.c_int, _vp, _vp],
         "xvcgpu_inter_pred_batch_to": [_vp, _vp, C.c_int, _vp, _vp, _vp, _vp, C.c_int],
         "xvcgpu_copy_blocks": [_vp, _vp, _vp, _vp, C.c_int],
+        "xvcgpu_intra_recon_waves": [_vp, _vp, _vp, _vp, _vp, _vp, C.c_int, _vp, _vp, _vp],
         "xvcgpu_bipred_search_lic": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, _vp, C.c_int],
         "xvcgpu_root_cbf_batch": [_vp, _vp, C.c_int, _vp],
         "xvcgpu_quant_rdo_batch": [_vp, C.c_int, _vp, C.c_int, _vp, _vp, C.c_size_t, _vp, _vp,

@@ -231,9 +231,11 @@ __device__ __forceinline__ unsigned rq_abs_level_bits(const RdoqFlagBits &f, int
     if (code < (threshold << s.golomb_rice_k)) {
       bits += ((code >> s.golomb_rice_k) + 1 + s.golomb_rice_k) * RQ_BYPASS;
     } else {
-      int length = (int)s.golomb_rice_k;
+      // the escape's prefix: the reference subtracts 2^k, 2^(k+1), ... while the
+      // rest is not smaller (rdo_quant.cc:862-866); the sum of those powers is
+      // 2^length - 2^k, so length = floor(log2(rest + 2^k))
       code -= threshold << s.golomb_rice_k;
-      while (code >= (1u << length)) code -= 1u << (length++);
+      const int length = 31 - __clz((int)(code + (1u << s.golomb_rice_k)));
       bits += (unsigned)(length + (int)threshold + length + 1 - (int)s.golomb_rice_k) * RQ_BYPASS;
     }
     if (s.c1_idx < 8) {

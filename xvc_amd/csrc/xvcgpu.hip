@@ -25,6 +25,7 @@
 #include "k_inter_pred.h"
 #include "k_multi.h"
 #include "k_rd.h"
+#include "k_intra_waves.h"
 #include "xvcgpu_internal.h"
 
 namespace {
@@ -190,6 +191,8 @@ xvcgpu_status xvcgpu_create(int device, xvcgpu_ctx **out) {
   ctx->d_rdoq_lists = nullptr;
   ctx->rdoq_lists_cap = 0;
   ctx->d_crc_tables = nullptr;
+  ctx->d_intra_done = nullptr;
+  ctx->intra_done_cap = 0;
   for (int i = 0; i < 64; i++) ctx->ev_pool[i] = nullptr;
   ctx->d_me_rot = nullptr;
   ctx->me_epoch = 0;
@@ -244,6 +247,7 @@ void xvcgpu_destroy(xvcgpu_ctx *ctx) {
   if (ctx->d_stats) hipFree(ctx->d_stats);
   if (ctx->d_rdoq_lists) hipFree(ctx->d_rdoq_lists);
   if (ctx->d_crc_tables) hipFree(ctx->d_crc_tables);
+  if (ctx->d_intra_done) hipFree(ctx->d_intra_done);
   if (ctx->d_me_rot) hipFree(ctx->d_me_rot);
   hipEventDestroy(ctx->ev0);
   hipEventDestroy(ctx->ev1);
@@ -1634,6 +1638,68 @@ xvcgpu_status xvcgpu_intra_pred_batch(xvcgpu_ctx *ctx, const xvcgpu_picture *rec
   hipLaunchKernelGGL(intra_pred_kernel, dim3(n), dim3(256), 0, ctx->stream, rec->v, pred->v,
                      d_jobs, n);
   CHECK_LAUNCH(ctx, "intra_pred_batch");
+  return XVCGPU_OK;
+}
+
+#ifndef XVCGPU_INTRA_WAVES_GRID
+#define XVCGPU_INTRA_WAVES_GRID 128
+#endif
+xvcgpu_status xvcgpu_intra_recon_waves(xvcgpu_ctx *ctx, xvcgpu_picture *rec,
+                                       xvcgpu_picture *pred,
+                                       const xvcgpu_intra_block *d_jobs,
+                                       const xvcgpu_tx_block *d_blocks,
+                                       const int32_t *d_wave_first, int n_waves,
+                                       const int16_t *d_levels,
+                                       const uint32_t *d_level_offsets,
+                                       const int32_t *d_nnz) {
+  if (!ctx || !rec || !pred || n_waves < 0 ||
+      (n_waves && (!d_jobs || !d_blocks || !d_wave_first || !d_levels || !d_level_offsets ||
+                   !d_nnz)))
+    return XVCGPU_INVALID_ARGUMENT;
+  if (rec->w != pred->w || rec->h != pred->h || rec->bd != pred->bd)
+    return fail(ctx, XVCGPU_INVALID_ARGUMENT, "picture mismatch");
+  if (n_waves == 0) return XVCGPU_OK;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  // a wave of a 1080p picture holds a few dozen jobs: a fraction of the chip's
+  // workgroup slots is enough (all of them must be resident together)
+  static int s_grid[64];
+  int &grid = s_grid[ctx->device & 63];
+  if (grid == 0) {
+    int per_cu = 0, cus = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, intra_waves_kernel, 256, 0) !=
+            hipSuccess ||
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device) !=
+            hipSuccess ||
+        per_cu < 1 || cus < 1)
+      grid = -1;
+    else
+      grid = cus * per_cu < XVCGPU_INTRA_WAVES_GRID ? cus * per_cu : XVCGPU_INTRA_WAVES_GRID;
+  }
+  if (grid < 0) return XVCGPU_UNSUPPORTED;
+  // the waves' counters
+  if (ctx->intra_done_cap < n_waves) {
+    if (ctx->d_intra_done) hipFree(ctx->d_intra_done);
+    ctx->d_intra_done = nullptr;
+    ctx->intra_done_cap = 0;
+    if (hipMalloc(&ctx->d_intra_done, sizeof(int) * (size_t)(n_waves + 256)) != hipSuccess)
+      return XVCGPU_OUT_OF_MEMORY;
+    ctx->intra_done_cap = n_waves + 256;
+  }
+  HIP_TRY(ctx, hipMemsetAsync(ctx->d_intra_done, 0, sizeof(int) * (size_t)n_waves, ctx->stream));
+  int *done = ctx->d_intra_done;
+  PicView rv = rec->v, pv = pred->v;
+  int16_t *lv = const_cast<int16_t *>(d_levels);
+  int32_t *nz = const_cast<int32_t *>(d_nnz);
+  const int16_t *tables = ctx->d_tx_tables;
+  TxTableLayout lay = xvcgpu_tx_layout();
+  void *args[] = {&rv, &pv, &d_jobs, &d_blocks, &d_wave_first, &n_waves, &lv, &d_level_offsets,
+                  &nz, &tables, &lay, &done};
+  if (hipLaunchCooperativeKernel(reinterpret_cast<const void *>(intra_waves_kernel), dim3(grid),
+                                 dim3(256), args, 0, ctx->stream) != hipSuccess) {
+    (void)hipGetLastError();
+    return XVCGPU_UNSUPPORTED;
+  }
+  CHECK_LAUNCH(ctx, "intra_recon_waves");
   return XVCGPU_OK;
 }
 

@@ -48,6 +48,8 @@ def load_host_library():
     lib.xvc_host_picture_decoder_decode.argtypes = [vp, vp, vp, vp, C.POINTER(vp), vp]
     lib.xvc_host_picture_decoder_waves.argtypes = [vp]
     lib.xvc_host_picture_decoder_launches.argtypes = [vp]
+    lib.xvc_host_picture_decoder_one_launch_intra.argtypes = [vp, C.c_int]
+    lib.xvc_host_picture_decoder_one_launch_intra.restype = None
     lib.xvc_host_plan_picture.argtypes = [vp, vp, vp, vp, vp]
     _host = lib
     return lib
@@ -96,6 +98,11 @@ class PictureDecoder:
     @property
     def launches(self):
         return self.lib.xvc_host_picture_decoder_launches(self.h)
+
+    def one_launch_intra(self, on):
+        """Intra pictures: all dependency waves in one cooperative launch (default)
+        or one launch set per wave."""
+        self.lib.xvc_host_picture_decoder_one_launch_intra(self.h, int(bool(on)))
 
     def destroy(self):
         if self.h:

@@ -321,7 +321,8 @@ void PictureDecoder::Plan(const xvc_picture_syntax &ps, const xvc_cu_syntax *cus
 
 PictureDecoder::PictureDecoder(xvcgpu_ctx *ctx, int width, int height, int bitdepth)
     : ctx_(ctx), width_(width), height_(height), bitdepth_(bitdepth), pred_(nullptr),
-      d_staging_(nullptr), staging_cap_(0), last_waves_(0), last_launches_(0) {
+      d_staging_(nullptr), staging_cap_(0), last_waves_(0), last_launches_(0),
+      use_waves_kernel_(true) {
   xvcgpu_picture_create(ctx_, width, height, bitdepth, &pred_);
 }
 
@@ -357,7 +358,11 @@ xvcgpu_status PictureDecoder::Decode(const xvc_picture_syntax &ps, const xvc_cu_
     const void *src;
     size_t bytes, off;
   };
-  Piece pc[9] = {
+  // an intra picture (every wave holds intra jobs only, prediction job k and
+  // transform job k are the same block): all waves in one cooperative launch
+  const bool one_launch = use_waves_kernel_ && p.inter.empty() && !p.intra.empty() &&
+                          p.intra_first == p.tx_first;
+  Piece pc[10] = {
       {p.inter.data(), p.inter.size() * sizeof(xvcgpu_inter_block), 0},
       {p.intra.data(), p.intra.size() * sizeof(xvcgpu_intra_block), 0},
       {p.tx.data(), p.tx.size() * sizeof(xvcgpu_tx_block), 0},
@@ -366,7 +371,8 @@ xvcgpu_status PictureDecoder::Decode(const xvc_picture_syntax &ps, const xvc_cu_
       {p.cu_info.data(), p.cu_info.size() * sizeof(xvcgpu_cu_info), 0},
       {p.cell[0].data(), p.cell[0].size() * sizeof(int32_t), 0},
       {p.cell[1].data(), p.cell[1].size() * sizeof(int32_t), 0},
-      {levels, static_cast<size_t>(ps.n_levels > 0 ? ps.n_levels : 1) * sizeof(int16_t), 0}};
+      {levels, static_cast<size_t>(ps.n_levels > 0 ? ps.n_levels : 1) * sizeof(int16_t), 0},
+      {p.intra_first.data(), one_launch ? p.intra_first.size() * sizeof(int32_t) : 0, 0}};
   static const int16_t kNoLevels[1] = {0};
   if (ps.n_levels <= 0) pc[8].src = kNoLevels;
   size_t total = 0;
@@ -401,7 +407,19 @@ xvcgpu_status PictureDecoder::Decode(const xvc_picture_syntax &ps, const xvc_cu_
       }
 
   int launches = 0;
-  for (int w = 0; w < p.n_waves; w++) {
+  bool waves_done = false;
+  if (one_launch) {
+    const int32_t *d_first = reinterpret_cast<const int32_t *>(base + pc[9].off);
+    st = xvcgpu_intra_recon_waves(ctx_, rec, pred_, d_intra, d_tx, d_first, p.n_waves, d_levels,
+                                  d_off, d_nnz);
+    if (st == XVCGPU_OK) {
+      waves_done = true;
+      launches++;
+    } else if (st != XVCGPU_UNSUPPORTED) {
+      return st;
+    }
+  }
+  for (int w = 0; w < p.n_waves && !waves_done; w++) {
     const int i0 = p.inter_first[w], i1 = p.inter_first[w + 1];
     if (i1 > i0) {
       st = xvcgpu_inter_pred_batch(ctx_, refs, p.n_ref_slots, rec, pred_, d_inter + i0, i1 - i0);
@@ -474,6 +492,10 @@ int xvc_host_picture_decoder_decode(xvc_host_picture_decoder *d, const xvc_pictu
   for (int l = 0; l < 2; l++)
     for (int k = 0; k < 5; k++) refs[l][k] = ref_pics ? ref_pics[l * 5 + k] : nullptr;
   return d->dec.Decode(*ps, cus, levels, refs, rec);
+}
+
+void xvc_host_picture_decoder_one_launch_intra(xvc_host_picture_decoder *d, int on) {
+  if (d) d->dec.set_one_launch_intra(on != 0);
 }
 
 int xvc_host_picture_decoder_waves(const xvc_host_picture_decoder *d) {

@@ -96,6 +96,9 @@ class PictureDecoder {
 
   int last_num_waves() const { return last_waves_; }
   int last_num_launches() const { return last_launches_; }
+  // Intra pictures: all dependency waves in one cooperative launch
+  // (xvcgpu_intra_recon_waves; on by default) or a launch set per wave.
+  void set_one_launch_intra(bool on) { use_waves_kernel_ = on; }
 
  private:
   xvcgpu_status EnsureStaging(size_t bytes);
@@ -107,6 +110,7 @@ class PictureDecoder {
   std::vector<uint8_t> h_staging_;
   PicturePlan plan_;
   int last_waves_, last_launches_;
+  bool use_waves_kernel_;
 };
 
 }  // namespace xvc_gpu
@@ -124,6 +128,7 @@ int xvc_host_picture_decoder_decode(xvc_host_picture_decoder *d, const xvc_pictu
                                     xvcgpu_picture *rec);
 int xvc_host_picture_decoder_waves(const xvc_host_picture_decoder *d);
 int xvc_host_picture_decoder_launches(const xvc_host_picture_decoder *d);
+void xvc_host_picture_decoder_one_launch_intra(xvc_host_picture_decoder *d, int on);
 // Host-only planning check: neighbour state per CU (9 bytes: flags[3],
 // above_right[3], below_left[3]) and the wave of every CU.
 int xvc_host_plan_picture(const xvc_picture_syntax *ps, const xvc_cu_syntax *cus,
