@@ -270,13 +270,12 @@ def encoder_rd_figure(ctx, api, fx, pics, w, h):
     ranking and every inter-CU TransformAndReconstruct - the latter quantised
     with the CABAC context states RdoQuant::QuantRdo really read at that moment
     - as device batches (tests/rd_replay.py), every call compared with the
-    reference's result.  The searches are one batch per picture pair; the
-    merge rankings write their candidates' predictions at the CU's own position
-    and are dealt into layers of non-overlapping blocks; the
-    TransformAndReconstruct calls are ONE batch - the RD recursion revisits every
-    position at every size, so each CU state predicts into its own slot of a
-    scratch picture (xvcgpu_inter_pred_batch_to) with its original copied beside
-    (xvcgpu_copy_blocks), as the reference's temp buffers are."""
+    reference's result.  The searches are one batch per picture pair; the merge
+    candidates and the TransformAndReconstruct calls are ONE batch each - the RD
+    recursion revisits every position at every size, so each candidate / CU state
+    predicts into its own slot of a scratch picture (xvcgpu_inter_pred_batch_to)
+    with its original copied beside (xvcgpu_copy_blocks), as the reference's temp
+    buffers are."""
     import rd_fixture as rf
     import rd_replay
     if not os.path.exists(rf.path("c1")):

@@ -277,8 +277,33 @@ class Replay:
                                     lic, m["ref_poc"].reshape(5 * n, 2), mv,
                                     np.repeat(m["nb_index"], 5), slots)[:, 0]
             dist = np.zeros(5 * n, np.uint64)
+            # candidates of calls without a LIC candidate: one batch, every candidate
+            # predicted into its own slot of a scratch picture
+            plain = np.flatnonzero(~np.repeat((m["use_lic"] != 0).any(1), 5))
+            if len(plain):
+                ux, uy, height = self.pack_slots(w[plain], h[plain])
+                o_s, p_s = ctx.picture(4096, height, 10), ctx.picture(4096, height, 10)
+                cp = np.zeros(len(plain), api.COPY_BLOCK_DTYPE)
+                cp["sx"], cp["sy"], cp["dx"], cp["dy"] = x[plain], y[plain], ux, uy
+                cp["w"], cp["h"] = w[plain], h[plain]
+                dst = np.zeros(len(plain), api.POS_DTYPE)
+                dst["x"], dst["y"] = ux, uy
+                cands = np.zeros(len(plain), api.CAND_DTYPE)
+                cands["x"], cands["y"], cands["w"], cands["h"] = ux, uy, w[plain], h[plain]
+                cands["metric"] = 1   # SATD
+                ctx.sync()
+                t0 = time.time()
+                ctx.copy_blocks(O, o_s, cp)
+                ctx.inter_pred_batch_to(refs, O, p_s, jobs[plain], dst)
+                dist[plain] = ctx.metric_batch(o_s, p_s, 0, cands)
+                self._time("merges", t0)
+                o_s.destroy()
+                p_s.destroy()
+                layer = np.where(np.isin(np.arange(5 * n), plain), -1, layer)
             for k in range(int(layer.max()) + 1):
                 idx = np.flatnonzero(layer == k)
+                if not len(idx):
+                    continue
                 nbi = np.where(lic[idx], np.repeat(m["nb_index"], 5)[idx], -1)
                 rec = self._rec_for(int(poc), nbi, cache)
                 cands = np.zeros(len(idx), api.CAND_DTYPE)
