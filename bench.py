@@ -642,11 +642,8 @@ def main_pictures(args, torch, api, pipeline, synth, world, rank, local_rank):
                                    "16x16 CUs, TZ range 96, %s" %
                                    (W, H, args.qp, "RDOQ" if rdoq else "QuantFast"),
                        "cus_per_picture": fp.desc.n_cus_total,
-                       "regime": ("steady state of open picture chains (every picture coded "
-                                  "against the previous reconstruction, no key-picture refresh), "
-                                  "reached by %d untimed settle passes per chain before the "
-                                  "warmup" % (settle // n_chains)) if settle else
-                                 "chains started from the original of the first picture",
+                       "regime": "sub-GOPs of 16 in coding order, every sub-GOP's key picture "
+                                 "coded against the previous key picture's reconstruction",
                        "parallelism": "picture-level: sub-GOP 16 (layers of 1, 1, 2, 4, 8 "
                                       "pictures), ThreadEncoder policy on %d rank(s) x %d picture "
                                       "slots, each picture against its nearest L0 reference; "
