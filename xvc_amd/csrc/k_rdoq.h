@@ -125,8 +125,10 @@ struct RdoqShared {
   // the records in LDS their size is what limits the waves per CU
   unsigned char sig_ci[N];
   unsigned short rate_up[N];   // the decision-time state, 16 bits (RQ_STATE_PACK)
-  short err_dist[N];
-  long long sb_code_cost[64], sb_zero_dist[64];
+  // (delta_u - the quantisation error the sign hiding prices, rdo_quant.cc:360-365 - is
+  // a function of the coefficient and its level: re-derived there, err_of below;
+  // a sub-block's zero distortion stays in its owner lane's register)
+  long long sb_code_cost[64];
   unsigned csbf_bits[64];      // csbf_bits_to_zero
   unsigned char csbf[64];
   unsigned char sb_live[64];   // the walk reaches the sub-block
@@ -146,8 +148,7 @@ struct RdoqShared {
 struct RdoqView {
   unsigned char *sig_ci;
   unsigned short *rate_up;
-  short *err_dist;
-  long long *sb_code_cost, *sb_zero_dist;
+  long long *sb_code_cost;
   unsigned *csbf_bits;
   unsigned char *csbf, *sb_live, *sb_dcz;
   unsigned char *sb_of_scan;
@@ -503,6 +504,12 @@ __device__ __forceinline__ int wave_rdoq(S &s, int lane, int bd, int w, int h,
     else deq = (lvl * iq_scale) << -iq_shift;
     return (int)(short)d_clip3(deq, -32768, 32767);
   };
+  auto err_of = [&](int abs_coeff, int level) {
+    const long long orig_scaled =
+        (((long long)abs_coeff * scale) + size_bias_offset) >> size_bias_shift;
+    const long long quant_err = orig_scaled - ((long long)level << shift);
+    return (int)(short)(quant_err >> (shift - 8));
+  };
   // coeff_cost_to_zero_[index] (rdo_quant.cc:350, :307) of a coefficient whose
   // sub-block is coded, recomputed: zero_cost - best_cost of the decision that
   // left it at level v.  A level of 0 - chosen, or without a choice - cost a zero
@@ -529,7 +536,6 @@ __device__ __forceinline__ int wave_rdoq(S &s, int lane, int bd, int w, int h,
     if (!live) {
       s.csbf_bits[lane] = 0;
       s.sb_code_cost[lane] = my_zero_dist;
-      s.sb_zero_dist[lane] = my_zero_dist;
     }
   }
   // the sub-block (region index) and offset of the last position
@@ -617,10 +623,6 @@ __device__ __forceinline__ int wave_rdoq(S &s, int lane, int bd, int w, int h,
         s.sig_ci[pos] = (unsigned char)(sig_ctx >> 1);
         if (dc_sig_zero) s.sb_dcz[lane] = 1;
         code_cost += best_cost;
-        const long long orig_scaled =
-            (((long long)abs_coeff * scale) + size_bias_offset) >> size_bias_shift;
-        const long long quant_err = orig_scaled - ((long long)best_level << shift);
-        s.err_dist[pos] = (short)(quant_err >> (shift - 8));
         if (best_level) {
           any = true;
           num_non_zero++;
@@ -664,7 +666,6 @@ __device__ __forceinline__ int wave_rdoq(S &s, int lane, int bd, int w, int h,
           if (!quant(abs_coeff)) {  // (else: decided in step 1)
             cost = ((long long)(abs_coeff * abs_coeff)) << cost_scale;
             if (l2 == last_l && k > last_k) {  // rdo_quant.cc:303-307 (+ the memsets :262-265)
-              s.err_dist[pos] = 0;
               s.rate_up[pos] = (unsigned short)RQ_STATE_NO_RATE;
             } else {
               int n_sig, n_g1, n_g2, sum_abs;
@@ -672,9 +673,6 @@ __device__ __forceinline__ int wave_rdoq(S &s, int lane, int bd, int w, int h,
               const int sig_ctx2 = sig_ctx_of(x + y, n_sig);
               cost += rq_bit_cost(cb[sig_ctx2], lambda);
               s.sig_ci[pos] = (unsigned char)(sig_ctx2 >> 1);
-              const long long orig_scaled =
-                  (((long long)abs_coeff * scale) + size_bias_offset) >> size_bias_shift;
-              s.err_dist[pos] = (short)(orig_scaled >> (shift - 8));
               // (the k == 0 coefficient of an otherwise empty sub-block codes no flag,
               // sig1 = 0 at rdo_quant.cc:343; nothing reads the rate of such a sub-block)
               s.rate_up[pos] =
@@ -729,7 +727,6 @@ __device__ __forceinline__ int wave_rdoq(S &s, int lane, int bd, int w, int h,
       s.csbf[lane] = any ? 1 : 0;
       s.csbf_bits[lane] = bits_to_zero;
       s.sb_code_cost[lane] = sb_code_cost;
-      s.sb_zero_dist[lane] = sb_zero_dist;
     }
     wave_sync();
     // the sub-blocks of this diagonal that were just zeroed: their 16 levels and
@@ -752,7 +749,7 @@ __device__ __forceinline__ int wave_rdoq(S &s, int lane, int bd, int w, int h,
   }
   RQ_STEP_END();
   long long comp_code_cost = rq_wave_sum_i64<G>(mine ? s.sb_code_cost[lane] : 0ll);
-  const long long comp_zero_dist = rq_wave_sum_i64<G>(mine ? s.sb_zero_dist[lane] : 0ll);
+  const long long comp_zero_dist = rq_wave_sum_i64<G>(mine ? my_zero_dist : 0ll);
   // sub-blocks outside the region (64-point transforms): all zero, never the
   // last one, no coded neighbour to the right / below: the cost of a zero flag
   // each (EvalZeroSubblock's csbf == 0 branch)
@@ -986,6 +983,10 @@ __device__ __forceinline__ int wave_rdoq(S &s, int lane, int bd, int w, int h,
         coeff_xy(k, x, y);
         const int pos = rec_pos(x, y);
         const int lvl = *lev(x, y);
+        // delta_u (rdo_quant.cc:360-365) of the level as it was decided (the sign
+        // was re-applied above: undo it - a magnitude of 32768 keeps its wrapped value)
+        const int coeff = cf(x, y);
+        const int err_dist = err_of((short)d_abs(coeff), coeff < 0 ? -lvl : lvl);
         long long cost;
         int delta;
         if (lvl != 0) {
@@ -997,8 +998,8 @@ __device__ __forceinline__ int wave_rdoq(S &s, int lane, int bd, int w, int h,
           const int lvl_rate = (int)rq_abs_level_bits(fb, al, st);
           const int rate_up = -lvl_rate + (int)rq_abs_level_bits(fb, al + 1, st);
           const int rate_down = -lvl_rate + (int)rq_abs_level_bits(fb, al - 1, st);
-          const long long cost_inc = rd_factor * (-(int)s.err_dist[pos]) + rate_up;
-          long long cost_dec = rd_factor * (int)s.err_dist[pos] + rate_down -
+          const long long cost_inc = rd_factor * (-err_dist) + rate_up;
+          long long cost_dec = rd_factor * err_dist + rate_down -
                                (al == 1 ? sig_rate_of(pos, sb_index + k, k, s.sb_dcz[lane] != 0) : 0);
           if (is_last_sb && k == lastk && al == 1) cost_dec -= 4ll * RQ_BYPASS;
           if (cost_inc < cost_dec) {
@@ -1012,10 +1013,10 @@ __device__ __forceinline__ int wave_rdoq(S &s, int lane, int bd, int w, int h,
           // the rate of a level that was left at 0: the zero bin of its greater1 flag
           const unsigned c1_off = (unsigned)s.rate_up[pos] & 31u;
           const int rate0 = c1_off == RQ_STATE_NO_RATE ? 0 : (int)cb[2 * (g1_base + (int)c1_off)];
-          cost = rd_factor * -(long long)d_abs((int)s.err_dist[pos]) + rate0 +
+          cost = rd_factor * -(long long)d_abs(err_dist) + rate0 +
                  sig_rate_of(pos, sb_index + k, k, s.sb_dcz[lane] != 0) + (long long)RQ_BYPASS;
           delta = 1;
-          if (k < first && (cf(x, y) >= 0 ? 0 : 1) != first_sign) cost = 0x7fffffffll;
+          if (k < first && (coeff >= 0 ? 0 : 1) != first_sign) cost = 0x7fffffffll;
         }
         if (cost < best_cost) {
           best_cost = cost;
@@ -1310,10 +1311,8 @@ struct RdoqPackedLds {
   static constexpr int MAXT = RQ_CF_PADDED(MAXC);  // coefficient / level tiles: RQ_CF_STRIDE
   // the per-coefficient records: 5 bytes each (+ 4 of coefficient and level)
   alignas(8) long long sb_code_cost[GROUPS][MAXSB];
-  long long sb_zero_dist[GROUPS][MAXSB];
   alignas(8) int16_t cf[GROUPS][MAXT], lv[GROUPS][MAXT];
   unsigned short rate_up[GROUPS][MAXR];
-  short err_dist[GROUPS][MAXR];
   alignas(8) unsigned ctx_bits[2 * sizeof(xvcgpu_rdoq_contexts)];
   unsigned csbf_bits[GROUPS][MAXSB];
   unsigned char csbf[GROUPS][MAXSB], sb_live[GROUPS][MAXSB], sb_dcz[GROUPS][MAXSB];
@@ -1384,19 +1383,20 @@ __device__ __forceinline__ void quant_rdo_packed_wave(
   v.sig_ci = sm.sig_ci[g];
   v.sb_dcz = sm.sb_dcz[g];
   v.rate_up = sm.rate_up[g];
-  v.err_dist = sm.err_dist[g];
   v.sb_live = sm.sb_live[g];
   v.sb_code_cost = sm.sb_code_cost[g];
-  v.sb_zero_dist = sm.sb_zero_dist[g];
   v.csbf_bits = sm.csbf_bits[g];
   v.csbf = sm.csbf[g];
   v.sb_of_scan = sm.sb_of_scan[g];
   v.lp_bits = sm.lp_bits[g];
   v.ctx_bits = sm.ctx_bits;
-  const bool sign_hide = !(b.intra_pic & XVC_TXF_NO_SIGN_HIDING);
-  const int scan_order = (b.intra_pic >> XVC_TXF_SCAN_SHIFT) & 3;
   RQ_TRACE(2);
-  // one context snapshot at a time (normally one round)
+  // One (context snapshot, block shape, qp, component kind, flags, lambda) at a
+  // time - normally one round: a picture's blocks of one class share them.  What
+  // the walk derives from them (quantiser scales and shifts, grid sizes, context
+  // bases, the lambda it multiplies every rate with) then lives in SCALAR
+  // registers; as per-lane values - every group of a wave its own block - they
+  // cost the walk 70 of its 200 vector registers, i.e. a wave per SIMD.
   bool pending = active;
   int nnz = 0;
   for (;;) {
@@ -1404,6 +1404,13 @@ __device__ __forceinline__ void quant_rdo_packed_wave(
     if (!todo) break;
     const int leader = __ffsll((long long)todo) - 1;
     const int cur = __shfl((int)prm.ctx_index, leader, 64);
+    // the leader's key, as per-lane copies for the comparison
+    const int kw = __shfl(w, leader, 64), kh = __shfl(h, leader, 64);
+    const int kqp = __shfl((int)b.qp, leader, 64);
+    const int kluma = __shfl((int)(b.comp == 0), leader, 64);
+    const int kflags = __shfl((int)b.intra_pic, leader, 64);
+    const int kpf = __shfl((int)prm.flags, leader, 64);
+    const long long klambda = __shfl(prm.lambda, leader, 64);
     wave_sync();  // the previous round's readers are done with the table
     {
       // two round trips in all: a word of four contexts per lane, then its eight
@@ -1430,12 +1437,36 @@ __device__ __forceinline__ void quant_rdo_packed_wave(
     }
     wave_sync();
     RQ_TRACE(3);
-    if (pending && (int)prm.ctx_index == cur) {
+    const bool take = pending && (int)prm.ctx_index == cur && w == kw && h == kh &&
+                      (int)b.qp == kqp && (int)(b.comp == 0) == kluma &&
+                      (int)b.intra_pic == kflags && (int)prm.flags == kpf &&
+                      prm.lambda == klambda;
+    if (take) {
+      // every lane in here holds the same key: read it into scalar registers
+      const int uw = __builtin_amdgcn_readfirstlane(w), uh = __builtin_amdgcn_readfirstlane(h);
+      const int uqp = __builtin_amdgcn_readfirstlane((int)b.qp);
+      const int uluma = __builtin_amdgcn_readfirstlane((int)(b.comp == 0));
+      const int uflags = __builtin_amdgcn_readfirstlane((int)b.intra_pic);
+      const int upf = __builtin_amdgcn_readfirstlane((int)prm.flags);
+      const unsigned ulam_lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)prm.lambda);
+      const unsigned ulam_hi = (unsigned)__builtin_amdgcn_readfirstlane(
+          (int)(unsigned)((unsigned long long)prm.lambda >> 32));
+      const long long ulambda = (long long)(((unsigned long long)ulam_hi << 32) | ulam_lo);
       // the groups walk independently (their shuffles stay inside the group)
+      const bool usb4 = !(uw == 2 || uh == 2);
+      const int urw = uw < 32 ? uw : 32, urgw4 = urw >> 2;
+      auto utile = [usb4, urgw4, urw](int x, int y) {
+        return usb4 ? ((y >> 2) * urgw4 + (x >> 2)) * RQ_CF_STRIDE + (((y & 3) << 2) | (x & 3))
+                    : y * urw + x;
+      };
+      xvcgpu_rdoq_params uprm = prm;   // rd_factor stays the lane's own
+      uprm.lambda = ulambda;
+      uprm.flags = (uint8_t)upf;
       nnz = wave_rdoq<G>(
-          v, lane, bd, w, h, b.qp, b.comp == 0, scan_order, sign_hide, rq_ctx[cur], prm,
-          [cf, tile_pos](int x, int y) { return (int)cf[tile_pos(x, y)]; },
-          [lv, tile_pos](int x, int y) { return lv + tile_pos(x, y); }, false);
+          v, lane, bd, uw, uh, uqp, uluma != 0, (uflags >> XVC_TXF_SCAN_SHIFT) & 3,
+          !(uflags & XVC_TXF_NO_SIGN_HIDING), rq_ctx[cur], uprm,
+          [cf, utile](int x, int y) { return (int)cf[utile(x, y)]; },
+          [lv, utile](int x, int y) { return lv + utile(x, y); }, false);
       pending = false;
     }
   }
@@ -1506,7 +1537,7 @@ __device__ __forceinline__ void quant_rdo_packed_kernel_body(int bd, const xvcgp
   }
 }
 
-__global__ void __launch_bounds__(64, 3)
+__global__ void __launch_bounds__(64, 4)
 quant_rdo_packed_kernel(int bd, const xvcgpu_tx_block *blocks, RdoqLists l, int g16, int g4, const int16_t *coeffs, const uint32_t *d_off, int16_t *levels, int32_t *nnz_out, const xvcgpu_rdoq_contexts *rq_ctx, const xvcgpu_rdoq_params *rq_prm, xvcgpu_cu_info *cu_patch = nullptr) {
   quant_rdo_packed_kernel_body(bd, blocks, l, g16, g4, coeffs, d_off, levels, nnz_out, rq_ctx, rq_prm, cu_patch);
 }
