@@ -45,7 +45,16 @@ enum xvcgpu_tx_type {
   /* not a TransformType: in xvcgpu_tx_block.tx_hor it selects
    * Forward/InverseTransform::TransformSkip (cu.GetTransformSkip(comp),
    * transform_encoder.cc:213-227, :270-274; blocks <= 4x4 only) */
-  XVC_TX_SKIP = 6
+  XVC_TX_SKIP = 6,
+  /* not a TransformType either: DCT-2 of size 4 / 8 / 16 / 32 with the 6-bit
+   * matrices (TransformData::kDct2Transform4..32, transform_data.cc:26-107) and
+   * the stage's shift without kTransformHighPrecisionShift - what kDefault / kDct2
+   * mean for those sizes under Restrictions::disable_ext2_transform_high_precision
+   * (restricted mode; transform.cc:91-99, :458-605, :876-884).  The binding maps
+   * the type per direction; sizes 2 and 64 and the other four types keep their
+   * high-precision matrices in that mode (their shift absorbs the 2 bits), so
+   * they pass unchanged. */
+  XVC_TX_DCT2_LOW = 7
 };
 
 /* MvCorner order (cu_types.h / coding_unit.h:152-155 GetMvCorner). */

@@ -421,6 +421,29 @@ void xr_inv_transform(int bd, int w, int h, int tx_hor, int tx_ver, int dst4x4,
   inv.Transform(*cu, YuvComponent::kY, in, &out);
 }
 
+/* The same two under Restrictions::disable_ext2_transform_high_precision
+ * (restricted mode): thread-local state of the reference, flipped around the
+ * call.  tx_hor / tx_ver are the reference's TransformType values (0..5). */
+void xr_fwd_transform_restricted(int bd, int w, int h, int tx_hor, int tx_ver, int dst4x4,
+                                 const int16_t *resi, ptrdiff_t rs, int16_t *coeff,
+                                 ptrdiff_t cs) {
+  Restrictions &r = Restrictions::GetRW();
+  const bool saved = r.disable_ext2_transform_high_precision;
+  r.disable_ext2_transform_high_precision = true;
+  xr_fwd_transform(bd, w, h, tx_hor, tx_ver, dst4x4, resi, rs, coeff, cs);
+  r.disable_ext2_transform_high_precision = saved;
+}
+
+void xr_inv_transform_restricted(int bd, int w, int h, int tx_hor, int tx_ver, int dst4x4,
+                                 int dc_only, const int16_t *coeff, ptrdiff_t cs,
+                                 int16_t *resi, ptrdiff_t rs) {
+  Restrictions &r = Restrictions::GetRW();
+  const bool saved = r.disable_ext2_transform_high_precision;
+  r.disable_ext2_transform_high_precision = true;
+  xr_inv_transform(bd, w, h, tx_hor, tx_ver, dst4x4, dc_only, coeff, cs, resi, rs);
+  r.disable_ext2_transform_high_precision = saved;
+}
+
 void xr_fwd_transform_skip(int bd, int w, int h, const int16_t *resi,
                            ptrdiff_t rs, int16_t *coeff, ptrdiff_t cs) {
   ForwardTransform fwd(bd);
@@ -491,6 +514,14 @@ const int16_t *xr_transform_matrix(int tx_type, int size) {
     case 64: return T::k##NAME##Transform64High;      \
   }                                                   \
   return nullptr;
+    case XVC_TX_DCT2_LOW:
+      switch (size) {
+        case 4: return &T::kDct2Transform4[0][0];
+        case 8: return &T::kDct2Transform8[0][0];
+        case 16: return &T::kDct2Transform16[0][0];
+        case 32: return &T::kDct2Transform32[0][0];
+      }
+      return nullptr;
     case XVC_TX_DCT5: XR_TAB(Dct5)
     case XVC_TX_DCT8: XR_TAB(Dct8)
     case XVC_TX_DST1: XR_TAB(Dst1)

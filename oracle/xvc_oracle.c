@@ -621,13 +621,46 @@ static void xo_tx_init(void) {
   xo_tx_init_done = 1;
 }
 
+/* XVC_TX_DCT2_LOW: TransformData::kDct2Transform4 .. 32 (transform_data.cc:26-107),
+ * the 6-bit DCT-2 of HEVC - what kDefault / kDct2 select for those sizes under
+ * Restrictions::disable_ext2_transform_high_precision (transform.cc:458-605).
+ * The 32-point basis has 33 magnitudes, xo_dct2_low[j] ~ 64 sqrt(2) cos(j pi / 64)
+ * as the standard rounds them; smaller sizes take every (32 / N)-th row. */
+static const int16_t xo_dct2_low[33] = {64, 90, 90, 90, 89, 88, 87, 85, 83, 82, 80,
+                                        78, 75, 73, 70, 67, 64, 61, 57, 54, 50, 46,
+                                        43, 38, 36, 31, 25, 22, 18, 13, 9,  4,  0};
+static int16_t *xo_tx_low[7];
+static const int16_t *xo_low_matrix(int l) {
+  if (l < 2 || l > 5) return NULL;
+  if (!xo_tx_low[l]) {
+    const int N = 1 << l;
+    int16_t *m = (int16_t *)malloc(sizeof(int16_t) * N * N);
+    for (int k = 0; k < N; k++)
+      for (int n = 0; n < N; n++) {
+        const int a = (k * (2 * n + 1) * (32 / N)) & 127; /* units of pi / 64 */
+        m[k * N + n] = (int16_t)(a <= 32 ? xo_dct2_low[a] : a <= 64 ? -xo_dct2_low[64 - a]
+                                         : a <= 96 ? -xo_dct2_low[a - 64] : xo_dct2_low[128 - a]);
+      }
+    xo_tx_low[l] = m;
+  }
+  return xo_tx_low[l];
+}
+
 const int16_t *xo_transform_matrix(int tx_type, int size) {
   xo_tx_init();
   if (tx_type == XVC_TX_DEFAULT) tx_type = XVC_TX_DCT2;
-  if (tx_type < 1 || tx_type > 5) return NULL;
   int l = xo_log2_size(size);
   if ((1 << l) != size || l > 6) return NULL;
+  if (tx_type == XVC_TX_DCT2_LOW) return xo_low_matrix(l);
+  if (tx_type < 1 || tx_type > 5) return NULL;
   return xo_tx_tab[tx_type][l];
+}
+
+/* kTransformHighPrecisionShift of a 1-D stage (transform.cc:91-99, :876-884):
+ * absent only for the low-precision DCT-2 */
+static int xo_hp_shift(int tx_type) { return tx_type == XVC_TX_DCT2_LOW ? 0 : 2; }
+static int xo_is_dct2(int t) {
+  return t == XVC_TX_DEFAULT || t == XVC_TX_DCT2 || t == XVC_TX_DCT2_LOW;
 }
 
 /* One forward 1-D pass = transposing matrix product (SURVEY appendix C;
@@ -714,13 +747,13 @@ static void xo_inv_dst4(int shift, const int16_t *in, ptrdiff_t is,
 void xo_fwd_transform(int bd, int w, int h, int tx_hor, int tx_ver, int dst4x4,
                       const int16_t *resi, ptrdiff_t rs, int16_t *coeff,
                       ptrdiff_t cs) {
-  /* transform.cc:869-961 with default_high_precision == true */
+  /* transform.cc:869-961 */
   int16_t tmp[XO_MAX_BLK * XO_MAX_BLK];
-  const int shift1 = xo_log2_size(w) + bd - 9 + 2;
-  const int shift2 = xo_log2_size(h) + 6 + 2;
-  if (dst4x4 && w == 4 && h == 4) {
-    xo_fwd_dst4(shift1 - 2, resi, rs, tmp, XO_MAX_BLK);
-    xo_fwd_dst4(shift2 - 2, tmp, XO_MAX_BLK, coeff, cs);
+  const int shift1 = xo_log2_size(w) + bd - 9 + xo_hp_shift(tx_hor);
+  const int shift2 = xo_log2_size(h) + 6 + xo_hp_shift(tx_ver);
+  if (dst4x4 && w == 4 && h == 4) { /* no high precision for the 4x4 DST (:997-1000) */
+    xo_fwd_dst4(xo_log2_size(w) + bd - 9, resi, rs, tmp, XO_MAX_BLK);
+    xo_fwd_dst4(xo_log2_size(h) + 6, tmp, XO_MAX_BLK, coeff, cs);
     return;
   }
   xo_fwd_1d(xo_transform_matrix(tx_hor, w), w, shift1, h, 0, resi, rs, tmp,
@@ -734,15 +767,14 @@ void xo_inv_transform(int bd, int w, int h, int tx_hor, int tx_ver, int dst4x4,
                       int16_t *resi, ptrdiff_t rs) {
   /* transform.cc:83-182 */
   int16_t tmp[XO_MAX_BLK * XO_MAX_BLK];
-  const int shift1 = 7 + 2;
-  const int shift2 = 20 - bd + 2;
+  const int shift1 = 7 + xo_hp_shift(tx_ver);
+  const int shift2 = 20 - bd + xo_hp_shift(tx_hor);
   if (dst4x4 && w == 4 && h == 4) {
-    xo_inv_dst4(shift1 - 2, coeff, cs, tmp, XO_MAX_BLK);
-    xo_inv_dst4(shift2 - 2, tmp, XO_MAX_BLK, resi, rs);
+    xo_inv_dst4(7, coeff, cs, tmp, XO_MAX_BLK);
+    xo_inv_dst4(20 - bd, tmp, XO_MAX_BLK, resi, rs);
     return;
   }
-  if (dc_only && (tx_ver == XVC_TX_DEFAULT || tx_ver == XVC_TX_DCT2) &&
-      (tx_hor == XVC_TX_DEFAULT || tx_hor == XVC_TX_DCT2)) {
+  if (dc_only && xo_is_dct2(tx_ver) && xo_is_dct2(tx_hor)) {
     /* InvDct2Dc, transform.cc:279-291 */
     const int shift = 14 - bd;
     const int add = 1 << (shift - 1);

@@ -183,6 +183,9 @@ class Lib:
         sig("mc_block", None, [C.c_int] * 10 + [u16p, pd, u16p, pd])
         sig("fwd_transform", None, [C.c_int] * 6 + [i16p, pd, i16p, pd])
         sig("inv_transform", None, [C.c_int] * 7 + [i16p, pd, i16p, pd])
+        if prefix == "xr":  # restricted mode (disable_ext2_transform_high_precision)
+            sig("fwd_transform_restricted", None, [C.c_int] * 6 + [i16p, pd, i16p, pd])
+            sig("inv_transform_restricted", None, [C.c_int] * 7 + [i16p, pd, i16p, pd])
         sig("fwd_transform_skip", None, [C.c_int] * 3 + [i16p, pd, i16p, pd])
         sig("inv_transform_skip", None, [C.c_int] * 3 + [i16p, pd, i16p, pd])
         sig("dequant", None, [C.c_int] * 4 + [i16p, pd, i16p, pd])
@@ -305,6 +308,20 @@ class Lib:
         out = np.zeros((h, w), np.int16)
         self._inv_transform(bd, w, h, tx_hor, tx_ver, dst4x4, dc_only,
                             ptr(coeff, i16p), self._s(coeff), ptr(out, i16p), w)
+        return out
+
+    def fwd_transform_restricted(self, bd, resi, tx_hor=0, tx_ver=0, dst4x4=0):
+        h, w = resi.shape
+        out = np.zeros((h, w), np.int16)
+        self._fwd_transform_restricted(bd, w, h, tx_hor, tx_ver, dst4x4, ptr(resi, i16p),
+                                       self._s(resi), ptr(out, i16p), w)
+        return out
+
+    def inv_transform_restricted(self, bd, coeff, tx_hor=0, tx_ver=0, dst4x4=0, dc_only=0):
+        h, w = coeff.shape
+        out = np.zeros((h, w), np.int16)
+        self._inv_transform_restricted(bd, w, h, tx_hor, tx_ver, dst4x4, dc_only,
+                                       ptr(coeff, i16p), self._s(coeff), ptr(out, i16p), w)
         return out
 
     def fwd_transform_skip(self, bd, resi):

@@ -107,6 +107,10 @@ def test_transform_tables_match_oracle(api):
             assert np.array_equal(g, o), (tx, size)
             n += 1
     assert n == 26
+    for size in (4, 8, 16, 32):     # XVC_TX_DCT2_LOW: the 6-bit DCT-2 of restricted mode
+        assert np.array_equal(api.transform_matrix(7, size), xo.transform_matrix(7, size)), size
+    assert api.transform_matrix(7, 8)[1].tolist() == [89, 75, 50, 18, -18, -50, -75, -89]
+    assert api.transform_matrix(7, 64) is None and api.transform_matrix(7, 2) is None
     # a few landmark entries of the format (DCT-2 DC row = 256, 4-pt DCT-2)
     assert api.transform_matrix(1, 4).tolist() == [[256, 256, 256, 256],
                                                    [334, 139, -139, -334],

@@ -480,7 +480,7 @@ def test_mc_bipred_batch(gpu, xo, bd):
         p.destroy()
 
 
-def tx_blocks(rng, api, pw, ph, n, with_types=True):
+def tx_blocks(rng, api, pw, ph, n, with_types=True, restricted=False):
     blocks = np.zeros(n, api.TX_DTYPE)
     for i in range(n):
         comp = int(rng.integers(0, 3))
@@ -499,6 +499,13 @@ def tx_blocks(rng, api, pw, ph, n, with_types=True):
             b["tx_ver"] = int(rng.integers(1, 6))
         if w == 4 and h == 4 and comp == 0 and b["tx_hor"] == 0 and rng.random() < 0.5:
             b["dst4x4"] = 1
+        if restricted:
+            # what the binding passes under disable_ext2_transform_high_precision:
+            # XVC_TX_DCT2_LOW for kDefault / kDct2 of a side of 4..32
+            if b["tx_hor"] in (0, 1) and 4 <= w <= 32:
+                b["tx_hor"] = 7
+            if b["tx_ver"] in (0, 1) and 4 <= h <= 32:
+                b["tx_ver"] = 7
         b["qp"] = int(rng.choice([12, 22, 27, 32, 37, 45]))
         # XVC_TXF_*: intra picture, sign hiding off (1 in 5), coefficient scan
         # order (non-diagonal only occurs below 16x16)
@@ -520,8 +527,20 @@ def to_tx_struct(b):
 
 @pytest.mark.parametrize("bd", [8, 10, 12])
 def test_residual_pipeline(gpu, xo, bd):
+    _residual_pipeline(gpu, xo, bd, False)
+
+
+@pytest.mark.parametrize("bd", [8, 10])
+def test_residual_pipeline_restricted_mode(gpu, xo, bd):
+    """The 6-bit DCT-2 of restricted mode (XVC_TX_DCT2_LOW per direction; the
+    oracle's form is pinned to the reference with the restriction flag set in
+    test_oracle_vs_ref.py::test_transforms_restricted_mode)."""
+    _residual_pipeline(gpu, xo, bd, True)
+
+
+def _residual_pipeline(gpu, xo, bd, restricted):
     api, ctx = gpu
-    rng = np.random.default_rng(4000 + bd)
+    rng = np.random.default_rng(4000 + bd + (500 if restricted else 0))
     pw, ph = 256, 128
     n_dist = 0
     for noise in (2, 12, 200):
@@ -531,7 +550,8 @@ def test_residual_pipeline(gpu, xo, bd):
         O, P, Rc = ctx.picture(pw, ph, bd), ctx.picture(pw, ph, bd), ctx.picture(pw, ph, bd)
         O.upload(po, BL)
         P.upload(pp, BL)
-        blocks = tx_blocks(rng, api, pw, ph, 60)
+        blocks = tx_blocks(rng, api, pw, ph, 60, restricted=restricted)
+        assert not restricted or (blocks["tx_hor"] == 7).sum() > 10
         for i, b in enumerate(blocks):
             blk = blocks[i:i + 1]
             Rc.upload(pp, BL)

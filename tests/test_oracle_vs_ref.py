@@ -160,6 +160,61 @@ def test_transform_tables(libs):
             assert np.array_equal(r, o), (tx, size)
 
 
+TX_DCT2_LOW = 7
+
+
+def restricted_type(t, size):
+    """What the binding passes for TransformType t of a side `size` under
+    Restrictions::disable_ext2_transform_high_precision (xvcgpu_types.h,
+    XVC_TX_DCT2_LOW): the 6-bit DCT-2 for sizes 4..32, everything else unchanged."""
+    return TX_DCT2_LOW if t in (0, 1) and 4 <= size <= 32 else t
+
+
+def test_low_precision_tables(libs):
+    xo, xr = libs
+    for size in (4, 8, 16, 32):
+        r = xr.transform_matrix(TX_DCT2_LOW, size)
+        assert r is not None and np.array_equal(r, xo.transform_matrix(TX_DCT2_LOW, size)), size
+        assert int(r[0, 0]) == 64
+    for size in (2, 64):
+        assert xo.transform_matrix(TX_DCT2_LOW, size) is None
+
+
+@pytest.mark.parametrize("bd", [8, 10, 12])
+def test_transforms_restricted_mode(libs, bd):
+    """Restricted mode's transform precision: the reference with the restriction
+    flag set against the oracle given XVC_TX_DCT2_LOW where the binding would."""
+    xo, xr = libs
+    rng = np.random.default_rng(77 + bd)
+    for w in [2] + SIZES:
+        for h in [2] + SIZES:
+            types = [(0, 0), (1, 1)]
+            if w >= 4 and h >= 4:
+                types += [(3, 5), (1, 5), (5, 1), (0, 2), (4, 0), (2, 2)]
+            for tx_hor, tx_ver in types:
+                oh, ov = restricted_type(tx_hor, w), restricted_type(tx_ver, h)
+                resi = rng.integers(-(1 << bd) + 1, 1 << bd, size=(h, 64)).astype(np.int16)[:, :w]
+                r = xr.fwd_transform_restricted(bd, resi, tx_hor, tx_ver)
+                o = xo.fwd_transform(bd, resi, oh, ov)
+                assert np.array_equal(r, o), ("fwd", w, h, tx_hor, tx_ver)
+                if (oh, ov) != (tx_hor, tx_ver) and w * h >= 16:   # it is not the default path
+                    assert not np.array_equal(r, xr.fwd_transform(bd, resi, tx_hor, tx_ver))
+                coeff = (r.astype(np.int32) // 16 * 16).astype(np.int16)
+                ri = xr.inv_transform_restricted(bd, coeff, tx_hor, tx_ver)
+                oi = xo.inv_transform(bd, coeff, oh, ov)
+                assert np.array_equal(ri, oi), ("inv", w, h, tx_hor, tx_ver)
+                dc = np.zeros_like(coeff)
+                dc[0, 0] = coeff[0, 0] | 16
+                assert np.array_equal(xr.inv_transform_restricted(bd, dc, tx_hor, tx_ver, 0, 1),
+                                      xo.inv_transform(bd, dc, oh, ov, 0, 1)), ("dc", w, h)
+    # the 4x4 DST of intra luma keeps its own (always 6-bit) path
+    resi = rng.integers(-(1 << bd) + 1, 1 << bd, size=(4, 4)).astype(np.int16)
+    r = xr.fwd_transform_restricted(bd, resi, 0, 0, 1)
+    assert np.array_equal(r, xo.fwd_transform(bd, resi, TX_DCT2_LOW, TX_DCT2_LOW, 1))
+    assert np.array_equal(xr.inv_transform_restricted(bd, r, 0, 0, 1),
+                          xo.inv_transform(bd, r, TX_DCT2_LOW, TX_DCT2_LOW, 1))
+
+
 @pytest.mark.parametrize("bd", [8, 10, 12])
 def test_transforms(libs, bd):
     xo, xr = libs

@@ -266,8 +266,10 @@ __device__ __forceinline__ void residual_job(TxShared &s, int bi, const PicView 
       s.a[y * TX_S + x] = (int16_t)(o - p);
     }
     __syncthreads();
-    // forward transform (transform.cc:869-961, high precision)
-    const int shift1 = lgw + bd - 9 + 2, shift2 = lgh + 6 + 2;
+    // forward transform (transform.cc:869-961; a stage of XVC_TX_DCT2_LOW has the
+    // 6-bit matrix and no high-precision shift, :876-884)
+    const int shift1 = lgw + bd - 9 + (b.tx_hor == XVC_TX_DCT2_LOW ? 0 : 2);
+    const int shift2 = lgh + 6 + (b.tx_ver == XVC_TX_DCT2_LOW ? 0 : 2);
     if (skip) {  // ForwardTransform::TransformSkip, transform.cc:963-995
       const int sh = tshift + (bias ? -8 : 0), sc = bias ? 181 : 1;
       for (int i = threadIdx.x; i < w * h; i += TX_THREADS) {
@@ -276,9 +278,9 @@ __device__ __forceinline__ void residual_job(TxShared &s, int bi, const PicView 
         s.a[k] = sh > 0 ? (int16_t)(v * (1 << sh)) : (int16_t)((v + (1 << (-sh - 1))) >> -sh);
       }
     } else if (dst4) {
-      tx_fwd_dst4(shift1 - 2, s.a, s.b);
+      tx_fwd_dst4(lgw + bd - 9, s.a, s.b);
       __syncthreads();
-      tx_fwd_dst4(shift2 - 2, s.b, s.a);
+      tx_fwd_dst4(lgh + 6, s.b, s.a);
     } else {
       tx_fwd_1d(s.mh, w, shift1, h, false, s.a, s.b);
       __syncthreads();
@@ -414,10 +416,11 @@ __device__ __forceinline__ void residual_job(TxShared &s, int bi, const PicView 
   }
   // InverseTransform::Transform (transform.cc:83-182) -> residual in s.a
   {
-    const int shift1 = 7 + 2, shift2 = 20 - bd + 2;
+    const int shift1 = 7 + (b.tx_ver == XVC_TX_DCT2_LOW ? 0 : 2);
+    const int shift2 = 20 - bd + (b.tx_hor == XVC_TX_DCT2_LOW ? 0 : 2);
     const bool dct2_both =
-        (b.tx_ver == XVC_TX_DEFAULT || b.tx_ver == XVC_TX_DCT2) &&
-        (b.tx_hor == XVC_TX_DEFAULT || b.tx_hor == XVC_TX_DCT2);
+        (b.tx_ver == XVC_TX_DEFAULT || b.tx_ver == XVC_TX_DCT2 || b.tx_ver == XVC_TX_DCT2_LOW) &&
+        (b.tx_hor == XVC_TX_DEFAULT || b.tx_hor == XVC_TX_DCT2 || b.tx_hor == XVC_TX_DCT2_LOW);
     if (skip) {  // InverseTransform::TransformSkip, transform.cc:184-215
       const int sh = tshift + (bias ? 7 : 0), sc = bias ? 181 : 1;
       for (int i = threadIdx.x; i < w * h; i += TX_THREADS) {
@@ -427,9 +430,9 @@ __device__ __forceinline__ void residual_job(TxShared &s, int bi, const PicView 
                         : (int16_t)((uint32_t)v << -sh);
       }
     } else if (dst4) {
-      tx_inv_dst4(shift1 - 2, s.a, s.b);
+      tx_inv_dst4(7, s.a, s.b);
       __syncthreads();
-      tx_inv_dst4(shift2 - 2, s.b, s.a);
+      tx_inv_dst4(20 - bd, s.b, s.a);
     } else if (dc_only && dct2_both) {  // InvDct2Dc, transform.cc:279-291
       const int sh = 14 - bd, add = 1 << (sh - 1);
       const int16_t cf = (int16_t)(((((int)s.a[0] + 1) >> 1) + add) >> sh);

@@ -214,7 +214,8 @@ __device__ __forceinline__ int tx2_job(Tx2Shared &sh, const xvcgpu_tx_block &b, 
     }
     wave_sync();
     ME2_TRACE(2);
-    const int shift1 = lgw + bd - 9 + 2, shift2 = lgh + 6 + 2;
+    const int shift1 = lgw + bd - 9 + (b.tx_hor == XVC_TX_DCT2_LOW ? 0 : 2);
+    const int shift2 = lgh + 6 + (b.tx_ver == XVC_TX_DCT2_LOW ? 0 : 2);
     // fwd 1: T[k][y] (w rows of h), fwd 2: C[x][k2] (w rows of h)
     tx2_stage_dispatch<false, G>(w, Mh, s.r, w, h, 1 << (shift1 - 1), shift1, s.t);
     wave_sync();
@@ -364,8 +365,9 @@ __device__ __forceinline__ int tx2_job(Tx2Shared &sh, const xvcgpu_tx_block &b, 
   wave_sync();
   ME2_TRACE(6);
   const int smax = (1 << bd) - 1;
-  const bool dct2_both = (b.tx_ver == XVC_TX_DEFAULT || b.tx_ver == XVC_TX_DCT2) &&
-                         (b.tx_hor == XVC_TX_DEFAULT || b.tx_hor == XVC_TX_DCT2);
+  const bool dct2_both =
+      (b.tx_ver == XVC_TX_DEFAULT || b.tx_ver == XVC_TX_DCT2 || b.tx_ver == XVC_TX_DCT2_LOW) &&
+      (b.tx_hor == XVC_TX_DEFAULT || b.tx_hor == XVC_TX_DCT2 || b.tx_hor == XVC_TX_DCT2_LOW);
   if (dc_only && dct2_both) {  // InvDct2Dc, transform.cc:279-291
     const int sh = 14 - bd, add = 1 << (sh - 1);
     const int cf = (int16_t)(((((int)s.c[0] + 1) >> 1) + add) >> sh);
@@ -386,7 +388,8 @@ __device__ __forceinline__ int tx2_job(Tx2Shared &sh, const xvcgpu_tx_block &b, 
   }
   // inverse: U[r][x] (h rows of w) into s.r, then residual rows into s.t
   {
-    const int shift1 = 7 + 2, shift2 = 20 - bd + 2;
+    const int shift1 = 7 + (b.tx_ver == XVC_TX_DCT2_LOW ? 0 : 2);
+    const int shift2 = 20 - bd + (b.tx_hor == XVC_TX_DCT2_LOW ? 0 : 2);
     tx2_stage_dispatch<true, G>(h, MvT, s.c, h, w, 1 << (shift1 - 1), shift1, s.r);
     wave_sync();
     tx2_stage_dispatch<true, G>(w, s.r, MhT, h, w, 1 << (shift2 - 1), shift2, s.t);

@@ -74,7 +74,7 @@ struct xvcgpu_picture {
 // Offsets (in int16 entries) of the transform matrices inside the packed
 // table blob: index [type-1][log2 size]; filled by xvcgpu_tables.cpp.
 struct TxTableLayout {
-  int off[5][7];
+  int off[7][7];   // [type - 1][log2 size]; row 5 (XVC_TX_SKIP) unused, row 6 = XVC_TX_DCT2_LOW
   int total;
 };
 const TxTableLayout &xvcgpu_tx_layout();

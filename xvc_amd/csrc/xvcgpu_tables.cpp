@@ -63,9 +63,31 @@ struct Tables {
         total += N * N;
       }
     }
+    // XVC_TX_DCT2_LOW: the 6-bit DCT-2 of HEVC (reference literals
+    // transform_data.cc:26-107).  Its 32-point basis takes 33 magnitudes,
+    // kLow[j] ~ 64 * sqrt(2) * cos(j * pi / 64) as the standard rounds them; the
+    // N-point matrix is every (32 / N)-th row: M[k][n] = +-kLow at the angle
+    // k * (2n + 1) * (32 / N) folded into the first quadrant.
+    static const int16_t kLow[33] = {64, 90, 90, 90, 89, 88, 87, 85, 83, 82, 80,
+                                     78, 75, 73, 70, 67, 64, 61, 57, 54, 50, 46,
+                                     43, 38, 36, 31, 25, 22, 18, 13, 9,  4,  0};
+    for (int l = 2; l <= 5; l++) {
+      const int N = 1 << l;
+      total = (total + 7) & ~7;
+      layout.off[XVC_TX_DCT2_LOW - 1][l] = total;
+      data.resize(total + N * N);
+      int16_t *m = &data[total];
+      for (int k = 0; k < N; k++)
+        for (int n = 0; n < N; n++) {
+          const int a = (k * (2 * n + 1) * (32 / N)) & 127;   // units of pi / 64
+          m[k * N + n] = (int16_t)(a <= 32 ? kLow[a] : a <= 64 ? -kLow[64 - a]
+                                           : a <= 96 ? -kLow[a - 64] : kLow[128 - a]);
+        }
+      total += N * N;
+    }
     layout.total = total;
     data_t.assign(data.size(), 0);
-    for (int t = 0; t < 5; t++)
+    for (int t = 0; t < 7; t++)
       for (int l = 1; l <= 6; l++) {
         const int off = layout.off[t][l];
         if (off < 0) continue;
@@ -91,7 +113,7 @@ extern "C" xvcgpu_status xvcgpu_get_transform_matrix(int tx_type, int size,
                                                      int16_t *out) {
   if (!out) return XVCGPU_INVALID_ARGUMENT;
   if (tx_type == XVC_TX_DEFAULT) tx_type = XVC_TX_DCT2;
-  if (tx_type < XVC_TX_DCT2 || tx_type > XVC_TX_DST7)
+  if (tx_type != XVC_TX_DCT2_LOW && (tx_type < XVC_TX_DCT2 || tx_type > XVC_TX_DST7))
     return XVCGPU_INVALID_ARGUMENT;
   int l = 1;
   while ((1 << l) < size) l++;
