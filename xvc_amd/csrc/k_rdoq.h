@@ -119,11 +119,9 @@ struct RdoqShared {
   // size is what limits the waves per CU): EvalLastPos recomputes a coefficient's
   // entry from what is kept - its level, its decision-time state and contexts
   // (rq ctz_of).
-  // coeff_sig_bits_ / the sig-flag rate as what they are made of: the index (in
-  // contexts, not table entries) of the coefficient's significance context - the
-  // two bin costs are ctx_bits[2 * i], [2 * i + 1] -, 1 byte instead of 8: with
+  // coeff_sig_bits_ / the sig-flag rate as what they are made of: the count that
+  // selects the coefficient's significance context, 3 bits of its record - with
   // the records in LDS their size is what limits the waves per CU
-  unsigned char sig_ci[N];
   unsigned short rate_up[N];   // the decision-time state, 16 bits (RQ_STATE_PACK)
   // (delta_u - the quantisation error the sign hiding prices, rdo_quant.cc:360-365 - is
   // a function of the coefficient and its level: re-derived there, err_of below;
@@ -146,7 +144,6 @@ struct RdoqShared {
 // The same members as pointers (packed kernel: per-coefficient arrays in
 // global memory, the rest in LDS).
 struct RdoqView {
-  unsigned char *sig_ci;
   unsigned short *rate_up;
   long long *sb_code_cost;
   unsigned *csbf_bits;
@@ -343,16 +340,20 @@ __device__ __forceinline__ int rq_scan_pos(int sbs, int order, int k) {
 // (three GetAbsLevelBits evaluations) are formed when - and if - the sign
 // hiding asks for them: rate_up[] then holds the coefficient's decision-time
 // state (RQ_STATE_*), rate_down[] does not exist.
-// 16 bits: the two greater-flag contexts as offsets inside their group (0..16),
-// what GetAbsLevelBits reads of the budget (c1_idx < 8, c2_idx < 1) and the
-// Golomb-Rice parameter (0..9).  A coefficient left at level 0 only needs the
-// first field (the cost of its greater1 flag's zero bin); RQ_STATE_NO_RATE marks
-// the tail of the last sub-block, whose rate is 0.
-#define RQ_STATE_PACK(c1_off, c2_off, c1_idx, c2_idx, k)                              \
-  ((unsigned short)((unsigned)(c1_off) | ((unsigned)(c2_off) << 5) |                   \
-                    ((unsigned)((c1_idx) >= 8) << 10) | ((unsigned)((c2_idx) > 0) << 11) | \
-                    ((unsigned)(k) << 12)))
-#define RQ_STATE_NO_RATE 31u
+// 16 bits per coefficient, ALL that is kept of a decision: the template counts
+// that select its three contexts - n1 / n2 = 0 for the last position, else
+// min(greater-1 / greater-2 neighbours, 4) + 1 (cabac.cc:594-684), nsig =
+// min(significant neighbours, 5) (cabac.cc:520-560); the contexts' position
+// class is a function of x + y and is re-derived by the readers -, what
+// GetAbsLevelBits reads of the budget (c1_idx < 8, c2_idx < 1) and the
+// Golomb-Rice parameter (0..9).  A coefficient left at level 0 only needs n1 (the
+// cost of its greater1 flag's zero bin) and nsig; RQ_STATE_NO_RATE marks the tail
+// of the last sub-block, whose rate is 0.
+#define RQ_STATE_PACK(n1, n2, c1_idx, c2_idx, k, nsig)                                   \
+  ((unsigned short)((unsigned)(n1) | ((unsigned)(n2) << 3) |                              \
+                    ((unsigned)((c1_idx) >= 8) << 6) | ((unsigned)((c2_idx) > 0) << 7) | \
+                    ((unsigned)(k) << 8) | ((unsigned)(nsig) << 12)))
+#define RQ_STATE_NO_RATE 0x8000u
 
 template <int G = 64, typename S, typename CF, typename LEV>
 __device__ __forceinline__ int wave_rdoq(S &s, int lane, int bd, int w, int h,
@@ -395,7 +396,6 @@ __device__ __forceinline__ int wave_rdoq(S &s, int lane, int bd, int w, int h,
     return sbs == 2 ? ((y >> 2) * rgw + (x >> 2)) * RQ_SB_STRIDE + (((y & 3) << 2) | (x & 3))
                     : y * rw + x;
   };
-  const int g1_base = luma ? RQ_OFF(greater1_luma) : RQ_OFF(greater1_chroma);
   auto quant = [&](int a) {  // GetFwdQuantFunc on a magnitude (rdo_quant.cc:949-964)
     return (int)(short)(int)((((long long)a * scale) + fq_offset) >> fq_shift);
   };
@@ -427,11 +427,13 @@ __device__ __forceinline__ int wave_rdoq(S &s, int lane, int bd, int w, int h,
     const int off = n_sig < 5 ? n_sig : 5;
     return 2 * ((luma ? RQ_OFF(sig_luma) : RQ_OFF(sig_chroma)) + start + off);
   };
-  auto greater_ctx_of = [&](int posxy, int n, bool is_last) {  // cabac.cc:594-684
+  // greater-1 / greater-2 context from a record's count field nn (0: last position)
+  auto greater_ctx_nn = [&](int posxy, int nn) {  // cabac.cc:594-684
     const int g1 = luma ? RQ_OFF(greater1_luma) : RQ_OFF(greater1_chroma);
     const int start = luma ? (posxy < 3 ? 10 : (posxy < 10 ? 5 : 0)) : 0;
-    return is_last ? 2 * g1 : 2 * (g1 + start + (n < 4 ? n : 4) + 1);
+    return nn == 0 ? 2 * g1 : 2 * (g1 + start + nn);
   };
+  auto greater_nn = [](int n, bool is_last) { return is_last ? 0 : (n < 4 ? n : 4) + 1; };
 
   // The last position: the first non-zero quantised value in reverse scan; every
   // sub-block's sum of zero costs (what a sub-block beyond the last position
@@ -476,27 +478,30 @@ __device__ __forceinline__ int wave_rdoq(S &s, int lane, int bd, int w, int h,
   // (sig1 = 0 for the last position and for the k = 0 coefficient of a sub-block
   // that was empty up to it, rdo_quant.cc:343), and its rate sig1 - sig0 (0 at and
   // beyond the last position: :303-307)
-  auto sig_pair = [&](int pos, int index, int k, bool dcz, unsigned &sig0, unsigned &sig1) {
-    const uint2 b2 = *reinterpret_cast<const uint2 *>(cb + 2 * (int)s.sig_ci[pos]);
+  auto sig_pair = [&](unsigned pk, int posxy, int index, int k, bool dcz, unsigned &sig0,
+                      unsigned &sig1) {
+    const uint2 b2 =
+        *reinterpret_cast<const uint2 *>(cb + sig_ctx_of(posxy, (int)((pk >> 12) & 7u)));
     sig0 = b2.x;
     sig1 = (index == last_pos_index || (k == 0 && dcz)) ? 0u : b2.y;
   };
-  auto sig_rate_of = [&](int pos, int index, int k, bool dcz) {
+  auto sig_rate_of = [&](unsigned pk, int posxy, int index, int k, bool dcz) {
     if (index >= last_pos_index) return 0;
     unsigned sig0, sig1;
-    sig_pair(pos, index, k, dcz, sig0, sig1);
+    sig_pair(pk, posxy, index, k, dcz, sig0, sig1);
     return (int)(sig1 - sig0);
   };
   // the greater1 / greater2 flag costs and the budget state of a decided
   // coefficient from its 16-bit record
-  auto state_of = [&](unsigned pk, RdoqFlagBits &fb, RdoqCoeffState &st) {
-    const uint2 c1_b = *reinterpret_cast<const uint2 *>(cb + 2 * (g1_base + (int)(pk & 31u)));
+  auto state_of = [&](unsigned pk, int posxy, RdoqFlagBits &fb, RdoqCoeffState &st) {
+    const uint2 c1_b =
+        *reinterpret_cast<const uint2 *>(cb + greater_ctx_nn(posxy, (int)(pk & 7u)));
     const uint2 c2_b =
-        *reinterpret_cast<const uint2 *>(cb + 2 * (g1_base + (int)((pk >> 5) & 31u)));
+        *reinterpret_cast<const uint2 *>(cb + greater_ctx_nn(posxy, (int)((pk >> 3) & 7u)));
     fb.c1_0 = c1_b.x; fb.c1_1 = c1_b.y; fb.c2_0 = c2_b.x; fb.c2_1 = c2_b.y;
-    st.c1_idx = (pk >> 10) & 1u ? 8 : 0;
-    st.c2_idx = (int)((pk >> 11) & 1u);
-    st.golomb_rice_k = pk >> 12;
+    st.c1_idx = (pk >> 6) & 1u ? 8 : 0;
+    st.c2_idx = (int)((pk >> 7) & 1u);
+    st.golomb_rice_k = (pk >> 8) & 15u;
   };
   auto dequant = [&](int lvl) {
     int deq;
@@ -516,15 +521,16 @@ __device__ __forceinline__ int wave_rdoq(S &s, int lane, int bd, int w, int h,
   // significance flag: -sig0.  A non-zero level cost its distortion + sig1 + the
   // level's bits in the state the decision saw.  (v < 0: a magnitude of 32768
   // wrapped, no candidate was priced and best_cost stayed at its initial value.)
-  auto ctz_of = [&](int pos, int index, int k, bool dcz, int abs_coeff, int v) -> long long {
+  auto ctz_of = [&](unsigned pk, int posxy, int index, int k, bool dcz, int abs_coeff,
+                    int v) -> long long {
     unsigned sig0, sig1;
-    sig_pair(pos, index, k, dcz, sig0, sig1);
+    sig_pair(pk, posxy, index, k, dcz, sig0, sig1);
     if (v == 0) return -rq_bit_cost(sig0, lambda);
     const long long zero_cost = ((long long)(abs_coeff * abs_coeff)) << cost_scale;
     if (v < 0) return zero_cost - 0x7fffffffffffffffll;
     RdoqFlagBits fb;
     RdoqCoeffState st;
-    state_of((unsigned)s.rate_up[pos], fb, st);
+    state_of(pk, posxy, fb, st);
     const unsigned bits = sig1 + rq_abs_level_bits(fb, v, st);
     const int err = abs_coeff - dequant(v);
     return zero_cost - ((((long long)err * err) << cost_scale) + rq_bit_cost(bits, lambda));
@@ -574,8 +580,9 @@ __device__ __forceinline__ int wave_rdoq(S &s, int lane, int bd, int w, int h,
         neighbours(x, y, n_sig, n_g1, n_g2, sum_abs);
         const int posxy = x + y;
         const int sig_ctx = sig_ctx_of(posxy, n_sig);
-        const int c1_ctx = greater_ctx_of(posxy, n_g1, is_last);
-        const int c2_ctx = greater_ctx_of(posxy, n_g2, is_last);
+        const int nn1 = greater_nn(n_g1, is_last), nn2 = greater_nn(n_g2, is_last);
+        const int c1_ctx = greater_ctx_nn(posxy, nn1);
+        const int c2_ctx = greater_ctx_nn(posxy, nn2);
         {  // GetCoeffGolombRiceK (cabac.cc:686-725): smallest k with 2^(k+3) > threshold
           const unsigned threshold = 4u + (unsigned)(sum_abs - n_sig);
           const int kk = 29 - __clz((int)threshold);  // floor(log2) - 2
@@ -620,15 +627,14 @@ __device__ __forceinline__ int wave_rdoq(S &s, int lane, int bd, int w, int h,
           }
         }
         *lev(x, y) = (short)best_level;
-        s.sig_ci[pos] = (unsigned char)(sig_ctx >> 1);
         if (dc_sig_zero) s.sb_dcz[lane] = 1;
         code_cost += best_cost;
         if (best_level) {
           any = true;
           num_non_zero++;
         }
-        s.rate_up[pos] = RQ_STATE_PACK((c1_ctx >> 1) - g1_base, (c2_ctx >> 1) - g1_base, st.c1_idx,
-                                       st.c2_idx, st.golomb_rice_k);
+        s.rate_up[pos] = RQ_STATE_PACK(nn1, nn2, st.c1_idx, st.c2_idx, st.golomb_rice_k,
+                                       n_sig < 5 ? n_sig : 5);
         // UpdateCodeState (rdo_quant.cc:880-898); golomb_rice_k is re-derived
         if (best_level >= 1) st.c1_idx++;
         if (best_level >= 2) st.c2_idx++;
@@ -672,11 +678,10 @@ __device__ __forceinline__ int wave_rdoq(S &s, int lane, int bd, int w, int h,
               neighbours(x, y, n_sig, n_g1, n_g2, sum_abs);
               const int sig_ctx2 = sig_ctx_of(x + y, n_sig);
               cost += rq_bit_cost(cb[sig_ctx2], lambda);
-              s.sig_ci[pos] = (unsigned char)(sig_ctx2 >> 1);
               // (the k == 0 coefficient of an otherwise empty sub-block codes no flag,
               // sig1 = 0 at rdo_quant.cc:343; nothing reads the rate of such a sub-block)
-              s.rate_up[pos] =
-                  (unsigned short)((greater_ctx_of(x + y, n_g1, false) >> 1) - g1_base);
+              s.rate_up[pos] = RQ_STATE_PACK(greater_nn(n_g1, false), 0, 0, 0, 0,
+                                             n_sig < 5 ? n_sig : 5);
             }
           }
         }
@@ -816,8 +821,8 @@ __device__ __forceinline__ int wave_rdoq(S &s, int lane, int bd, int w, int h,
       // four coefficients' reads in flight at a time (the walk itself is serial:
       // the running sum, and it ends at the first level above 1)
       for (int kb = (sb_size - 1) & ~3; kb >= 0 && stop_local < 0; kb -= 4) {
-        int v[4], ac[4], pos[4], xs[4], ys[4];
-        unsigned sig0[4], sig1[4];
+        int v[4], ac[4], xs[4], ys[4];
+        unsigned pk[4], sig0[4], sig1[4];
 #pragma unroll
         for (int i = 0; i < 4; i++) {
           const int k = kb + 3 - i;
@@ -825,10 +830,10 @@ __device__ __forceinline__ int wave_rdoq(S &s, int lane, int bd, int w, int h,
           coeff_xy(k < sb_size ? k : 0, x, y);
           xs[i] = x;
           ys[i] = y;
-          pos[i] = rec_pos(x, y);
+          pk[i] = (unsigned)s.rate_up[rec_pos(x, y)];
           v[i] = (int)*lev(x, y);
           ac[i] = (short)d_abs(cf(x, y));
-          sig_pair(pos[i], sb_index + k, k, dcz, sig0[i], sig1[i]);
+          sig_pair(pk[i], x + y, sb_index + k, k, dcz, sig0[i], sig1[i]);
         }
 #pragma unroll
         for (int i = 0; i < 4; i++) {
@@ -845,7 +850,7 @@ __device__ __forceinline__ int wave_rdoq(S &s, int lane, int bd, int w, int h,
               part_k = k;
             }
             if (v[i] > 1) stop_local = sb_index + k;
-            ctz = ctz_of(pos[i], sb_index + k, k, dcz, ac[i], v[i]);
+            ctz = ctz_of(pk[i], xs[i] + ys[i], sb_index + k, k, dcz, ac[i], v[i]);
           }
           run += ctz;
         }
@@ -907,15 +912,16 @@ __device__ __forceinline__ int wave_rdoq(S &s, int lane, int bd, int w, int h,
           const int x = (tx << sbs) + (p & 3), y = (ty << sbs) + (p >> 2);
           const int pos = rec_pos(x, y);
           const int v = *lev(x, y);
+          const unsigned pk = (unsigned)s.rate_up[pos];
           const long long ctz =
-              ctz_of(pos, idx + k, k, s.sb_dcz[l] != 0, (int)(short)d_abs(cf(x, y)), v);
+              ctz_of(pk, x + y, idx + k, k, s.sb_dcz[l] != 0, (int)(short)d_abs(cf(x, y)), v);
           if (!v) {
             code_cost += ctz;
             continue;
           }
           const unsigned lp_bits = rq_last_pos_bits(cb, luma, w, h, scan_order, x, y);
           unsigned sg0, sg1;
-          sig_pair(pos, idx + k, k, s.sb_dcz[l] != 0, sg0, sg1);
+          sig_pair(pk, x + y, idx + k, k, s.sb_dcz[l] != 0, sg0, sg1);
           const long long cost =
               code_cost + rq_bit_cost(lp_bits, lambda) - rq_bit_cost(sg1, lambda);
           if (cost < best_cost) {
@@ -981,7 +987,7 @@ __device__ __forceinline__ int wave_rdoq(S &s, int lane, int bd, int w, int h,
       for (int k = is_last_sb ? lastk : 15; k >= 0; k--) {
         int x, y;
         coeff_xy(k, x, y);
-        const int pos = rec_pos(x, y);
+        const unsigned pk = (unsigned)s.rate_up[rec_pos(x, y)];
         const int lvl = *lev(x, y);
         // delta_u (rdo_quant.cc:360-365) of the level as it was decided (the sign
         // was re-applied above: undo it - a magnitude of 32768 keeps its wrapped value)
@@ -993,14 +999,14 @@ __device__ __forceinline__ int wave_rdoq(S &s, int lane, int bd, int w, int h,
           // rate_up / rate_down (rdo_quant.cc:367-374) from the decision-time state
           RdoqFlagBits fb;
           RdoqCoeffState st;
-          state_of((unsigned)s.rate_up[pos], fb, st);
+          state_of(pk, x + y, fb, st);
           const int al = d_abs(lvl);
           const int lvl_rate = (int)rq_abs_level_bits(fb, al, st);
           const int rate_up = -lvl_rate + (int)rq_abs_level_bits(fb, al + 1, st);
           const int rate_down = -lvl_rate + (int)rq_abs_level_bits(fb, al - 1, st);
           const long long cost_inc = rd_factor * (-err_dist) + rate_up;
           long long cost_dec = rd_factor * err_dist + rate_down -
-                               (al == 1 ? sig_rate_of(pos, sb_index + k, k, s.sb_dcz[lane] != 0) : 0);
+                               (al == 1 ? sig_rate_of(pk, x + y, sb_index + k, k, s.sb_dcz[lane] != 0) : 0);
           if (is_last_sb && k == lastk && al == 1) cost_dec -= 4ll * RQ_BYPASS;
           if (cost_inc < cost_dec) {
             cost = cost_inc;
@@ -1011,10 +1017,10 @@ __device__ __forceinline__ int wave_rdoq(S &s, int lane, int bd, int w, int h,
           }
         } else {
           // the rate of a level that was left at 0: the zero bin of its greater1 flag
-          const unsigned c1_off = (unsigned)s.rate_up[pos] & 31u;
-          const int rate0 = c1_off == RQ_STATE_NO_RATE ? 0 : (int)cb[2 * (g1_base + (int)c1_off)];
+          const int rate0 =
+              (pk & RQ_STATE_NO_RATE) ? 0 : (int)cb[greater_ctx_nn(x + y, (int)(pk & 7u))];
           cost = rd_factor * -(long long)d_abs(err_dist) + rate0 +
-                 sig_rate_of(pos, sb_index + k, k, s.sb_dcz[lane] != 0) + (long long)RQ_BYPASS;
+                 sig_rate_of(pk, x + y, sb_index + k, k, s.sb_dcz[lane] != 0) + (long long)RQ_BYPASS;
           delta = 1;
           if (k < first && (coeff >= 0 ? 0 : 1) != first_sign) cost = 0x7fffffffll;
         }
@@ -1316,9 +1322,9 @@ struct RdoqPackedLds {
   alignas(8) unsigned ctx_bits[2 * sizeof(xvcgpu_rdoq_contexts)];
   unsigned csbf_bits[GROUPS][MAXSB];
   unsigned char csbf[GROUPS][MAXSB], sb_live[GROUPS][MAXSB], sb_dcz[GROUPS][MAXSB];
-  unsigned char sig_ci[GROUPS][MAXR];
   unsigned char sb_of_scan[GROUPS][G == 64 ? 256 : (G == 4 ? MAXSB : MAXSB * 4)];   // (G = 4: grid = region)
-  unsigned lp_bits[GROUPS][G == 4 ? 16 : 32];   // (G = 4: a side is at most 16, 8 groups)
+  // one table per wave: the groups of a round share shape, scan and snapshot
+  unsigned lp_bits[G == 4 ? 16 : 32];   // (G = 4: a side is at most 16, 8 groups)
 };
 
 // G lanes per block; grid: an upper bound on ceil(count / (64 / G)) waves (the
@@ -1380,7 +1386,6 @@ __device__ __forceinline__ void quant_rdo_packed_wave(
     }
   }
   RdoqView v;
-  v.sig_ci = sm.sig_ci[g];
   v.sb_dcz = sm.sb_dcz[g];
   v.rate_up = sm.rate_up[g];
   v.sb_live = sm.sb_live[g];
@@ -1388,7 +1393,7 @@ __device__ __forceinline__ void quant_rdo_packed_wave(
   v.csbf_bits = sm.csbf_bits[g];
   v.csbf = sm.csbf[g];
   v.sb_of_scan = sm.sb_of_scan[g];
-  v.lp_bits = sm.lp_bits[g];
+  v.lp_bits = sm.lp_bits;
   v.ctx_bits = sm.ctx_bits;
   RQ_TRACE(2);
   // One (context snapshot, block shape, qp, component kind, flags, lambda) at a
