@@ -849,8 +849,24 @@ __device__ __forceinline__ int wave_rdoq(S &s, int lane, int bd, int w, int h,
               part_best = part;
               part_k = k;
             }
-            if (v[i] > 1) stop_local = sb_index + k;
-            ctz = ctz_of(pk[i], xs[i] + ys[i], sb_index + k, k, dcz, ac[i], v[i]);
+            // the walk ends at a level above 1: nothing behind it counts, its own
+            // cost_to_zero included.  What it passes on its way are levels of 1 (and
+            // zeros): a level of 1 costs its sign and either the zero bin of its
+            // greater-1 flag or, with the flag budget spent, a Golomb-Rice code of 0
+            // (GetAbsLevelBits, rdo_quant.cc:844-878, for quant_level = 1)
+            if (v[i] > 1) {
+              stop_local = sb_index + k;
+            } else if (v[i] == 1) {
+              const unsigned c1_0 = cb[greater_ctx_nn(xs[i] + ys[i], (int)(pk[i] & 7u))];
+              const unsigned bits1 =
+                  sig1[i] + (((pk[i] >> 6) & 1u) ? (2u + ((pk[i] >> 8) & 15u)) * RQ_BYPASS
+                                                 : RQ_BYPASS + c1_0);
+              const int err = ac[i] - dequant(1);
+              ctz = (((long long)(ac[i] * ac[i])) << cost_scale) -
+                    ((((long long)err * err) << cost_scale) + rq_bit_cost(bits1, lambda));
+            } else {
+              ctz = ctz_of(pk[i], xs[i] + ys[i], sb_index + k, k, dcz, ac[i], v[i]);
+            }
           }
           run += ctz;
         }
