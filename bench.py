@@ -125,12 +125,15 @@ def stream_decode_figure(ctx, api):
 
     def decoder_run(f, syn, pics, per_picture=None):
         done = {}
+        if not hasattr(f, "_levels"):   # out of the .npz once (every access inflates it again)
+            f._levels = [np.ascontiguousarray(f.levels(i)) for i in range(f.n)]
+            f._infos = [f.info[i] for i in range(f.n)]
         for i in range(f.n):
-            info = f.info[i]
+            info = f._infos[i]
             refs = [[done[int(info["ref_poc"][l][k])] for k in range(int(info["num_ref"][l]))]
                     for l in range(2)]
             t0 = time.perf_counter()
-            dec.decode(syn[i][0], syn[i][1], f.levels(i), refs, pics[i])
+            dec.decode(syn[i][0], syn[i][1], f._levels[i], refs, pics[i])
             if per_picture is not None:
                 ctx.sync()
                 per_picture[i] += time.perf_counter() - t0
