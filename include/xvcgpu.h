@@ -166,6 +166,15 @@ xvcgpu_status xvcgpu_memcpy_h2d(xvcgpu_ctx *ctx, void *dst, const void *src,
 xvcgpu_status xvcgpu_memcpy_d2h(xvcgpu_ctx *ctx, void *dst, const void *src,
                                 size_t bytes);
 xvcgpu_status xvcgpu_memset(xvcgpu_ctx *ctx, void *dst, int value, size_t bytes);
+/* Page-locked host memory and the copy that does not wait: the upload is queued
+ * on the context's stream (ordered with its kernels) and the call returns at
+ * once - `src` must stay untouched until an event recorded after the call has
+ * completed (xvcgpu_event_record / _synchronize).  With pageable `src` the
+ * runtime stages the bytes itself and the call may block. */
+xvcgpu_status xvcgpu_host_alloc(xvcgpu_ctx *ctx, size_t bytes, void **host_ptr);
+xvcgpu_status xvcgpu_host_free(xvcgpu_ctx *ctx, void *host_ptr);
+xvcgpu_status xvcgpu_memcpy_h2d_async(xvcgpu_ctx *ctx, void *dst, const void *src,
+                                      size_t bytes);
 
 /* ---- pictures ----------------------------------------------------------- *
  * Device twin of YuvPicture (yuv_pic.cc:32-68): planar Y,U,V of 16-bit

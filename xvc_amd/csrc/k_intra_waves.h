@@ -10,7 +10,7 @@
 //
 // Here the whole picture is one cooperative launch (G workgroups resident
 // together).  The jobs are sorted by wave; workgroup g takes jobs g, g + G, ...
-// in that order: prediction into `pred`, then the inverse transform +
+// in that order: prediction (kept in LDS), then the inverse transform +
 // reconstruction of the same block into `rec` (job k of the intra list and job k
 // of the transform list are the same block: xvc_gpu::PictureDecoder::Plan appends
 // both per unit).  A job of wave w starts when the counter of wave w - 1 has
@@ -27,24 +27,33 @@
 #include "k_intra.h"
 #include "k_tx.h"
 
-union IntraWavesShared {
-  IntraPredShared ip;
-  TxShared tx;
-};
-
 // grid: any number of workgroups that are resident together (cooperative
 // launch); block: 256 (= TX_THREADS).  wave_first[w] .. wave_first[w + 1]: the
 // jobs of wave w in both lists; done[n_waves]: zero on entry.
+//
+// What does not depend on the neighbours runs BEFORE the job waits for them: the
+// block's descriptor, levels, matrices, dequantisation and inverse transform
+// (the residual stays in LDS).  Behind the wait are only the reference samples,
+// the prediction and the add - the part of a job that really is on the picture's
+// critical path of 401 dependent steps.
 __global__ void __launch_bounds__(256)
 intra_waves_kernel(PicView rec, PicView pred, const xvcgpu_intra_block *jobs,
                    const xvcgpu_tx_block *blocks, const int32_t *wave_first, int n_waves,
                    int16_t *levels, const uint32_t *level_off, int32_t *nnz,
                    const int16_t *tx_tables, TxTableLayout lay, int *done) {
-  __shared__ __attribute__((aligned(16))) IntraWavesShared s;
+  __shared__ __attribute__((aligned(16))) TxShared tx;
+  __shared__ IntraPredShared ip;
+  __shared__ uint16_t pblk[64 * 64];
   const int n = wave_first[n_waves];
   int w = 0;
   for (int j = (int)blockIdx.x; j < n; j += (int)gridDim.x) {
     while (j >= wave_first[w + 1]) w++;
+    const xvcgpu_intra_block b = jobs[j];
+    // the residual of the block (0: none), in tx.a
+    const int has_resi =
+        residual_job<TX_MODE_INV, 4>(tx, j, pred, pred, rec, blocks, levels, level_off, nnz,
+                                     tx_tables, lay, nullptr, nullptr, nullptr, nullptr, nullptr,
+                                     0, /*defer_add=*/true);
     if (w > 0) {
       // relaxed polls, then ONE agent-scope acquire by one lane: it invalidates this
       // CU's L1 for the whole workgroup (a fence per thread is 3-4 us each)
@@ -56,26 +65,29 @@ intra_waves_kernel(PicView rec, PicView pred, const xvcgpu_intra_block *jobs,
       }
       __syncthreads();
     }
-    const xvcgpu_intra_block b = jobs[j];
-    const PlaneView pr = rec.c[b.comp], pp = pred.c[b.comp];
+    const PlaneView pr = rec.c[b.comp];
     const bool is_luma = b.comp == 0;
-    uint16_t *dst = pp.p + (ptrdiff_t)b.y * pp.stride + b.x;
+    // the prediction stays in LDS (pblk, row stride = the block's width)
     if (b.mode == XVC_INTRA_MODE_LM_CHROMA) {
       if (!is_luma && b.w <= 32 && b.h <= 32)
-        intra_lm_chroma(s.ip.lm, b, rec.c[0], pr, rec.bd, dst, pp.stride);
+        intra_lm_chroma(ip.lm, b, rec.c[0], pr, rec.bd, pblk, b.w);
     } else {
-      intra_build_refs<true>(s.ip.refs, b, pr.p + (ptrdiff_t)b.y * pr.stride + b.x, pr.stride,
+      intra_build_refs<true>(ip.refs, b, pr.p + (ptrdiff_t)b.y * pr.stride + b.x, pr.stride,
                              rec.bd, is_luma, threadIdx.x, 256);
-      intra_predict<true>(s.ip.refs, s.ip.line, rec.bd, is_luma, b.mode, b.w, b.h, dst,
-                          pp.stride, threadIdx.x, 256);
+      intra_predict<true>(ip.refs, ip.line, rec.bd, is_luma, b.mode, b.w, b.h, pblk, b.w,
+                          threadIdx.x, 256);
     }
-    // the prediction is read back from memory by other threads of this workgroup:
-    // the barrier drains the stores (to the XCD's L2), one lane drops the CU's L1
     __syncthreads();
-    if (threadIdx.x == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    __syncthreads();
-    residual_job<TX_MODE_INV, 4>(s.tx, j, pred, pred, rec, blocks, levels, level_off, nnz,
-                                 tx_tables, lay);
+    // SampleBuffer::AddClip (sample_buffer.h:72-87) / CopyFrom for a block without levels
+    {
+      const int bw = b.w, bh = b.h, lw = 31 - __clz(bw), smax = (1 << rec.bd) - 1;
+      for (int i = threadIdx.x; i < bw * bh; i += 256) {
+        const int y = i >> lw, x = i & (bw - 1);
+        const int r = has_resi ? (int)tx.a[y * TX_S + x] : 0;
+        pr.p[(ptrdiff_t)(b.y + y) * pr.stride + b.x + x] =
+            (uint16_t)d_clip3((int)pblk[y * bw + x] + r, 0, smax);
+      }
+    }
     // the block is in memory (one lane writes the L2's dirty lines back) before the
     // wave's counter says so
     __syncthreads();

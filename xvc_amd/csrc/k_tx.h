@@ -215,7 +215,7 @@ __device__ __forceinline__ bool tx_small_job(const xvcgpu_tx_block &b) {
 // One workgroup (256 threads) = one job: the general path (blocks above
 // 16x16, 2-wide blocks, the 4x4 DST).
 template <int MODE, int RQN = 4>
-__device__ __forceinline__ void residual_job(TxShared &s, int bi, const PicView &orig,
+__device__ __forceinline__ int residual_job(TxShared &s, int bi, const PicView &orig,
                                              const PicView &pred, const PicView &rec,
                                              const xvcgpu_tx_block *blocks,
                                              int16_t *levels, const uint32_t *level_off,
@@ -224,7 +224,16 @@ __device__ __forceinline__ void residual_job(TxShared &s, int bi, const PicView 
                                              RdoqShared<RQN> *rq = nullptr,
                                              const xvcgpu_rdoq_contexts *rq_ctx = nullptr,
                                              const xvcgpu_rdoq_params *rq_prm = nullptr,
-                                             unsigned long long *dist_out = nullptr) {
+                                             unsigned long long *dist_out = nullptr,
+                                             const uint16_t *pred_blk = nullptr,
+                                             int pred_blk_stride = 0,
+                                             bool defer_add = false) {
+  // pred_blk: the block's prediction handed over directly (row stride
+  // pred_blk_stride, e.g. in LDS) instead of read from the `pred` picture.
+  // defer_add (TX_MODE_INV): stop in front of AddClip and return the block's
+  // level count - 0: no residual; else the residual is s.a[y * TX_S + x] - so
+  // that a caller whose prediction is not ready yet adds it itself.  Returns -1
+  // otherwise.
   __shared__ unsigned long long s_dist;  // see tx2_job: the residual-domain SSD
   if (threadIdx.x == 0) s_dist = 0;
   __syncthreads();  // previous job of this workgroup is done with s
@@ -262,7 +271,8 @@ __device__ __forceinline__ void residual_job(TxShared &s, int bi, const PicView 
     for (int i = threadIdx.x; i < w * h; i += TX_THREADS) {
       const int y = i >> lw, x = i & (w - 1);
       const int o = po.p[(ptrdiff_t)(b.y + y) * po.stride + b.x + x];
-      const int p = pp.p[(ptrdiff_t)(b.y + y) * pp.stride + b.x + x];
+      const int p = pred_blk ? pred_blk[y * pred_blk_stride + x]
+                             : pp.p[(ptrdiff_t)(b.y + y) * pp.stride + b.x + x];
       s.a[y * TX_S + x] = (int16_t)(o - p);
     }
     __syncthreads();
@@ -292,7 +302,7 @@ __device__ __forceinline__ void residual_job(TxShared &s, int bi, const PicView 
       if (lv)
         for (int i = threadIdx.x; i < w * h; i += TX_THREADS)
           lv[i] = s.a[(i >> lw) * TX_S + (i & (w - 1))];
-      return;
+      return -1;
     }
     // QuantFast (rdo_quant.cc:156-195)
     const int qshift = 14 + qpb / 6 + tshift + (bias ? 7 : 0);
@@ -383,10 +393,12 @@ __device__ __forceinline__ void residual_job(TxShared &s, int bi, const PicView 
     __syncthreads();
     if (threadIdx.x == 0) dist_out[bi] = s_dist >> (2 * (bd - 8));
   };
+  if (defer_add && nnz == 0) return 0;
   if (nnz == 0) {  // cbf == 0: rec = pred (CopyFrom, transform_encoder.cc:281)
     for (int i = threadIdx.x; i < w * h; i += TX_THREADS) {
       const int y = i >> lw, x = i & (w - 1);
-      const int p = pp.p[(ptrdiff_t)(b.y + y) * pp.stride + b.x + x];
+      const int p = pred_blk ? pred_blk[y * pred_blk_stride + x]
+                             : pp.p[(ptrdiff_t)(b.y + y) * pp.stride + b.x + x];
       pr.p[(ptrdiff_t)(b.y + y) * pr.stride + b.x + x] = (uint16_t)p;
       if (dist_out) {
         const int d = (int)pod.p[(ptrdiff_t)(b.y + y) * pod.stride + b.x + x] - p;
@@ -394,7 +406,7 @@ __device__ __forceinline__ void residual_job(TxShared &s, int bi, const PicView 
       }
     }
     if (dist_out) dist_finish();
-    return;
+    return -1;
   }
   const bool dc_only = nnz == 1 && s.b[0] != 0;  // transform_encoder.cc:241
 
@@ -446,11 +458,13 @@ __device__ __forceinline__ void residual_job(TxShared &s, int bi, const PicView 
     }
     __syncthreads();
   }
+  if (defer_add) return nnz;
   // SampleBuffer::AddClip (sample_buffer.h:72-87)
   const int smax = (1 << bd) - 1;
   for (int i = threadIdx.x; i < w * h; i += TX_THREADS) {
     const int y = i >> lw, x = i & (w - 1);
-    const int p = pp.p[(ptrdiff_t)(b.y + y) * pp.stride + b.x + x];
+    const int p = pred_blk ? pred_blk[y * pred_blk_stride + x]
+                           : pp.p[(ptrdiff_t)(b.y + y) * pp.stride + b.x + x];
     pr.p[(ptrdiff_t)(b.y + y) * pr.stride + b.x + x] =
         (uint16_t)d_clip3(p + (int)s.a[y * TX_S + x], 0, smax);
     if (dist_out) {
@@ -460,6 +474,7 @@ __device__ __forceinline__ void residual_job(TxShared &s, int bi, const PicView 
     }
   }
   if (dist_out) dist_finish();
+  return -1;
 }
 
 // grid: ceil(n/256) workgroups of 256 threads.  Each workgroup scans 256

@@ -420,6 +420,32 @@ xvcgpu_status xvcgpu_memcpy_h2d(xvcgpu_ctx *ctx, void *dst, const void *src,
   return XVCGPU_OK;
 }
 
+xvcgpu_status xvcgpu_host_alloc(xvcgpu_ctx *ctx, size_t bytes, void **host_ptr) {
+  if (!ctx || !host_ptr || !bytes) return XVCGPU_INVALID_ARGUMENT;
+  *host_ptr = nullptr;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  if (hipHostMalloc(host_ptr, bytes, hipHostMallocDefault) != hipSuccess) {
+    (void)hipGetLastError();
+    *host_ptr = nullptr;
+    return XVCGPU_OUT_OF_MEMORY;
+  }
+  return XVCGPU_OK;
+}
+
+xvcgpu_status xvcgpu_host_free(xvcgpu_ctx *ctx, void *host_ptr) {
+  if (!ctx) return XVCGPU_INVALID_ARGUMENT;
+  if (host_ptr) HIP_TRY(ctx, hipHostFree(host_ptr));
+  return XVCGPU_OK;
+}
+
+xvcgpu_status xvcgpu_memcpy_h2d_async(xvcgpu_ctx *ctx, void *dst, const void *src,
+                                      size_t bytes) {
+  if (!ctx || (!dst && bytes) || (!src && bytes)) return XVCGPU_INVALID_ARGUMENT;
+  if (!bytes) return XVCGPU_OK;
+  HIP_TRY(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+  return XVCGPU_OK;
+}
+
 xvcgpu_status xvcgpu_memcpy_d2h(xvcgpu_ctx *ctx, void *dst, const void *src,
                                 size_t bytes) {
   if (!ctx || (!dst && bytes) || (!src && bytes)) return XVCGPU_INVALID_ARGUMENT;

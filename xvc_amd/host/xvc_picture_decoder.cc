@@ -322,11 +322,22 @@ void PictureDecoder::Plan(const xvc_picture_syntax &ps, const xvc_cu_syntax *cus
 PictureDecoder::PictureDecoder(xvcgpu_ctx *ctx, int width, int height, int bitdepth)
     : ctx_(ctx), width_(width), height_(height), bitdepth_(bitdepth), pred_(nullptr),
       d_staging_(nullptr), staging_cap_(0), last_waves_(0), last_launches_(0),
-      use_waves_kernel_(true) {
+      use_waves_kernel_(true), next_host_(0) {
   xvcgpu_picture_create(ctx_, width, height, bitdepth, &pred_);
+  for (HostSlot &h : host_) {
+    h.mem = nullptr;
+    h.cap = 0;
+    h.copied = nullptr;
+    h.in_flight = false;
+  }
 }
 
 PictureDecoder::~PictureDecoder() {
+  for (HostSlot &h : host_) {
+    if (h.in_flight) xvcgpu_event_synchronize(h.copied);
+    if (h.copied) xvcgpu_event_destroy(h.copied);
+    if (h.mem) xvcgpu_host_free(ctx_, h.mem);
+  }
   if (d_staging_) xvcgpu_free(ctx_, d_staging_);
   if (pred_) xvcgpu_picture_destroy(pred_);
 }
@@ -340,6 +351,32 @@ xvcgpu_status PictureDecoder::EnsureStaging(size_t bytes) {
   xvcgpu_status st = xvcgpu_malloc(ctx_, cap, &d_staging_);
   if (st == XVCGPU_OK) staging_cap_ = cap;
   return st;
+}
+
+xvcgpu_status PictureDecoder::AcquireHostSlot(size_t bytes, HostSlot **out) {
+  HostSlot &h = host_[next_host_];
+  next_host_ ^= 1;
+  xvcgpu_status st = XVCGPU_OK;
+  if (h.in_flight) {   // the upload queued two pictures ago
+    st = xvcgpu_event_synchronize(h.copied);
+    if (st != XVCGPU_OK) return st;
+    h.in_flight = false;
+  }
+  if (!h.copied) {
+    st = xvcgpu_event_create(ctx_, &h.copied);
+    if (st != XVCGPU_OK) return st;
+  }
+  if (bytes > h.cap) {
+    if (h.mem) xvcgpu_host_free(ctx_, h.mem);
+    h.mem = nullptr;
+    h.cap = 0;
+    const size_t cap = bytes + bytes / 4;
+    st = xvcgpu_host_alloc(ctx_, cap, &h.mem);
+    if (st != XVCGPU_OK) return st;
+    h.cap = cap;
+  }
+  *out = &h;
+  return XVCGPU_OK;
 }
 
 xvcgpu_status PictureDecoder::Decode(const xvc_picture_syntax &ps, const xvc_cu_syntax *cus,
@@ -382,11 +419,17 @@ xvcgpu_status PictureDecoder::Decode(const xvc_picture_syntax &ps, const xvc_cu_
   }
   xvcgpu_status st = EnsureStaging(total);
   if (st != XVCGPU_OK) return st;
-  if (h_staging_.size() < total) h_staging_.resize(total);
-  for (const Piece &q : pc)
-    if (q.bytes) std::memcpy(h_staging_.data() + q.off, q.src, q.bytes);
-  st = xvcgpu_memcpy_h2d(ctx_, d_staging_, h_staging_.data(), total);
+  HostSlot *slot = nullptr;
+  st = AcquireHostSlot(total, &slot);
   if (st != XVCGPU_OK) return st;
+  for (const Piece &q : pc)
+    if (q.bytes) std::memcpy(static_cast<uint8_t *>(slot->mem) + q.off, q.src, q.bytes);
+  // queued behind the previous picture's kernels (they read the device buffer)
+  st = xvcgpu_memcpy_h2d_async(ctx_, d_staging_, slot->mem, total);
+  if (st != XVCGPU_OK) return st;
+  st = xvcgpu_event_record(ctx_, slot->copied);
+  if (st != XVCGPU_OK) return st;
+  slot->in_flight = true;
   uint8_t *base = static_cast<uint8_t *>(d_staging_);
   const xvcgpu_inter_block *d_inter = reinterpret_cast<const xvcgpu_inter_block *>(base + pc[0].off);
   const xvcgpu_intra_block *d_intra = reinterpret_cast<const xvcgpu_intra_block *>(base + pc[1].off);

@@ -102,15 +102,27 @@ class PictureDecoder {
 
  private:
   xvcgpu_status EnsureStaging(size_t bytes);
+  // The picture's job lists, maps and levels go up in ONE queued copy from a
+  // page-locked buffer; two buffers take turns so that Decode() of the next
+  // picture can fill one while the copy of the previous is still in flight.
+  struct HostSlot {
+    void *mem;
+    size_t cap;
+    xvcgpu_event *copied;   // recorded behind the slot's upload
+    bool in_flight;
+  };
+  xvcgpu_status AcquireHostSlot(size_t bytes, HostSlot **out);
   xvcgpu_ctx *ctx_;
   int width_, height_, bitdepth_;
   xvcgpu_picture *pred_;   // the prediction of the wave in flight (CuDecoder::temp_pred_)
   void *d_staging_;
   size_t staging_cap_;
-  std::vector<uint8_t> h_staging_;
+
   PicturePlan plan_;
   int last_waves_, last_launches_;
   bool use_waves_kernel_;
+  HostSlot host_[2];
+  int next_host_;
 };
 
 }  // namespace xvc_gpu
