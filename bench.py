@@ -952,6 +952,7 @@ def main():
         # The profile carries the MD5 of the kernel sources it was taken from:
         # a figure from other kernels than the ones running now is not reported.
         traffic = None
+        kname = dom
         try:
             prof = json.load(open(os.path.join(
                 ROOT, "profiles",
@@ -970,9 +971,31 @@ def main():
                 traffic = hit[0]["hbm_bytes_per_launch"] if hit else None
         except (OSError, KeyError, ValueError):
             traffic = None
+        # What the kernel is really bound by: the vector instructions it issues.
+        # wave64 instructions per launch (SQ_INSTS_VALU, a separate --pmc pass of this
+        # command, profiles/issue_current.json, same MD5 rule) x the measured issue
+        # cost of the kernels' instruction mix (3.6 clocks per instruction and SIMD,
+        # profiles/r03_valu_rate.txt + tools/isa_mix.py) over 1024 SIMDs at 2.4 GHz.
+        issue = None
+        try:
+            prof = json.load(open(os.path.join(ROOT, "profiles", "issue_current.json")))
+            if (W == 1920 and H == 1080 and not multi and
+                    prof.get("kernel_source_md5") == kernel_source_md5() and
+                    prof.get("quant") == args.quant):
+                hit = [v for k, v in prof["kernels"].items() if kname in k]
+                if hit:
+                    floor_ms = hit[0]["valu"] * 3.6 / (1024 * 2.4e9) * 1e3
+                    issue = {"wave_instructions": hit[0]["valu"], "clocks_per_instruction": 3.6,
+                             "simds": 1024, "clock_ghz": 2.4, "floor_ms": floor_ms,
+                             "frac_alone": floor_ms / times[dom],
+                             "active_lanes": hit[0].get("active_lanes"),
+                             "lds_bank_conflict_share": hit[0].get("lds_bank_conflict_share")}
+        except (OSError, KeyError, ValueError, NameError):
+            issue = None
         achieved = alg[dom] / (times[dom] * 1e-3) / 1e9
         roof = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": 8000.0,
                 "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic,
+                "valu_issue": issue,
                 "algorithmic_bytes": alg[dom],
                 "ms_per_launch": times[dom],
                 # per launch with the device to itself (chain 0, others idle):
