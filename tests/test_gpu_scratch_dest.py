@@ -120,3 +120,57 @@ def test_scratch_destination_arguments(gpu):
     dd.free()
     a.destroy()
     b.destroy()
+
+
+def test_copy_blocks_any_width(gpu):
+    """Widths that are not powers of two take the row loop."""
+    api, ctx = gpu
+    rng = np.random.default_rng(9)
+    src = _picture(ctx, rng, 128, 64)
+    dst = ctx.picture(192, 96, 10)
+    jobs = np.zeros(3, api.COPY_BLOCK_DTYPE)
+    jobs["sx"], jobs["sy"] = [3, 10, 0], [5, 0, 2]
+    jobs["dx"], jobs["dy"] = [7, 60, 1], [9, 40, 3]
+    jobs["w"], jobs["h"] = [12, 24, 6], [5, 7, 3]
+    jobs["comp"] = [0, 0, 1]
+    ctx.copy_blocks(src, dst, jobs)
+    a, b = src.download(), dst.download()
+    for j in jobs:
+        c = int(j["comp"])
+        assert np.array_equal(b[c][j["dy"]:j["dy"] + j["h"], j["dx"]:j["dx"] + j["w"]],
+                              a[c][j["sy"]:j["sy"] + j["h"], j["sx"]:j["sx"] + j["w"]])
+    src.destroy()
+    dst.destroy()
+
+
+def test_page_locked_upload(gpu):
+    """xvcgpu_host_alloc + xvcgpu_memcpy_h2d_async + an event: the bytes arrive,
+    ordered with the stream."""
+    import ctypes as C
+    api, ctx = gpu
+    n = 1 << 20
+    hp = C.c_void_p()
+    assert ctx.lib.xvcgpu_host_alloc(ctx.h, n, C.byref(hp)) == 0 and hp.value
+    host = np.ctypeslib.as_array((C.c_uint8 * n).from_address(hp.value))
+    host[:] = np.arange(n, dtype=np.uint32).astype(np.uint8)
+    dev = ctx.alloc(n)
+    assert ctx.lib.xvcgpu_memcpy_h2d_async(ctx.h, dev.ptr, hp, n) == 0
+    ctx.sync()
+    assert np.array_equal(dev.to_array(np.uint8, n), host)
+    assert ctx.lib.xvcgpu_host_alloc(ctx.h, 0, C.byref(hp)) != 0
+    dev.free()
+    del host
+    assert ctx.lib.xvcgpu_host_free(ctx.h, hp) == 0
+
+
+def test_intra_recon_waves_arguments(gpu):
+    api, ctx = gpu
+    a, b = ctx.picture(64, 64, 10), ctx.picture(64, 64, 8)
+    f = ctx.lib.xvcgpu_intra_recon_waves
+    assert f(ctx.h, a.h_pic, a.h_pic, None, None, None, 0, None, None, None) == 0      # nothing to do
+    assert f(ctx.h, a.h_pic, a.h_pic, None, None, None, 3, None, None, None) != 0      # lists missing
+    d = ctx.alloc(256)
+    assert f(ctx.h, a.h_pic, b.h_pic, d.ptr, d.ptr, d.ptr, 1, d.ptr, d.ptr, d.ptr) != 0  # bit depths
+    d.free()
+    a.destroy()
+    b.destroy()
