@@ -358,6 +358,17 @@ xvcgpu_status xvcgpu_copy_blocks(xvcgpu_ctx *ctx, const xvcgpu_picture *src,
                                  xvcgpu_picture *dst, const xvcgpu_copy_block *d_blocks,
                                  int n);
 
+/* The same for the blocks of a picture's CU loop in CU order - block 3 * cu + comp,
+ * Y U V each, CUs up to 16x16 (what xvcgpu_fwd_from_me_classify leaves behind) -,
+ * in place on `rec`, which holds the prediction: the U and V blocks of a CU share
+ * a wave, blocks without levels cost a look at their count.  Same results as
+ * xvcgpu_inv_transform_batch(ctx, rec, rec, d_blocks, 3 * n_cus, ...). */
+xvcgpu_status xvcgpu_inv_transform_cu_order(xvcgpu_ctx *ctx, xvcgpu_picture *rec,
+                                            const xvcgpu_tx_block *d_blocks, int n_cus,
+                                            const int16_t *d_levels,
+                                            const uint32_t *d_level_offsets,
+                                            const int32_t *d_nnz);
+
 /* ---- I3 (affine half): MotionCompAffine -> Sample ------------------------- *
  * (inter_prediction.cc:1044-1136): the CU is cut into sub-blocks whose size
  * follows from the corner-MV differences, each sub-block gets its own MV

@@ -173,6 +173,7 @@ SYMBOLS = [
     "xvcgpu_tx_eval_batch", "xvcgpu_root_cbf_batch", "xvcgpu_bipred_search_lic",
     "xvcgpu_inter_pred_batch_to", "xvcgpu_copy_blocks", "xvcgpu_intra_recon_waves",
     "xvcgpu_host_alloc", "xvcgpu_host_free", "xvcgpu_memcpy_h2d_async",
+    "xvcgpu_inv_transform_cu_order",
     "xvcgpu_fwd_from_me_classify", "xvcgpu_quant_rdo_classified_batch",
     "xvcgpu_event_create", "xvcgpu_event_destroy", "xvcgpu_event_record", "xvcgpu_event_wait",
     "xvcgpu_event_synchronize", "xvcgpu_comm_unique_id", "xvcgpu_comm_create",
@@ -301,6 +302,7 @@ def load_library():
         "xvcgpu_copy_blocks": [_vp, _vp, _vp, _vp, C.c_int],
         "xvcgpu_host_alloc": [_vp, C.c_size_t, C.POINTER(_vp)],
         "xvcgpu_host_free": [_vp, _vp],
+        "xvcgpu_inv_transform_cu_order": [_vp, _vp, _vp, C.c_int, _vp, _vp, _vp],
         "xvcgpu_memcpy_h2d_async": [_vp, _vp, _vp, C.c_size_t],
         "xvcgpu_intra_recon_waves": [_vp, _vp, _vp, _vp, _vp, _vp, C.c_int, _vp, _vp, _vp],
         "xvcgpu_bipred_search_lic": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, _vp, C.c_int],

@@ -439,6 +439,47 @@ __device__ __forceinline__ void residual_wave_kernel_body(PicView orig, PicView 
                           &rq_all[RDOQ ? (threadIdx.x >> 6) : 0], rq_ctx, rq_prm, dist_out);
 }
 
+// The inverse half of a frame pass whose transform blocks come in CU order, Y U V
+// each (block 3 * cu + comp, CUs up to 16x16), in place on `rec` (which holds the
+// prediction): two waves per CU as in recon_from_me_kernel - one for the luma
+// block, one for the U and V blocks side by side, 32 lanes each.  One wave per
+// block is 24 480 waves for a 1080p picture, two thirds of them for 8x8 blocks
+// that leave three quarters of their wave idle; a wave whose blocks carry no
+// level retires after a look at their counts.  grid: XCD-swizzled workgroups of
+// TX2_WAVES waves over 2 * n_cus jobs.
+__global__ void __launch_bounds__(64 * TX2_WAVES)
+inv_cu_pairs_kernel(PicView rec, const xvcgpu_tx_block *blocks, int n_cus, int16_t *levels,
+                    const uint32_t *level_off, int32_t *nnz_out, const int16_t *tx_tables,
+                    const int16_t *tx_tables_t, TxTableLayout lay) {
+  __shared__ Tx2Shared s_all[TX2_WAVES];
+  Tx2Shared &s = s_all[threadIdx.x >> 6];
+  const int n = 2 * n_cus;
+  const int n_wg = (n + TX2_WAVES - 1) / TX2_WAVES;
+  const int wg = xcd_job_index(blockIdx.x, n_wg);
+  if (wg < 0) return;
+  const int job = __builtin_amdgcn_readfirstlane(wg * TX2_WAVES + (int)(threadIdx.x >> 6));
+  if (job >= n) return;
+  const int ci = job >> 1;
+  if (!(job & 1)) {
+    const int bi = 3 * ci;
+    if (nnz_out[bi] == 0) return;   // in place: the block is already what it will be
+    const xvcgpu_tx_block b = blocks[bi];
+    const PlaneView pc = rec.c[0];
+    tx2_job<TX_MODE_INV, 64, false>(s, b, bi, rec.bd, pc, pc.p + (ptrdiff_t)b.y * pc.stride + b.x,
+                                    pc.stride, pc, levels, level_off, nnz_out, tx_tables,
+                                    tx_tables_t, lay);
+    return;
+  }
+  if (nnz_out[3 * ci + 1] == 0 && nnz_out[3 * ci + 2] == 0) return;
+  // this lane's half: lanes 0-31 the U block, 32-63 the V block
+  const int g = ME2_LANE >> 5, bi = 3 * ci + 1 + g;
+  const xvcgpu_tx_block b = blocks[bi];
+  const PlaneView pc = g ? rec.c[2] : rec.c[1];
+  tx2_job<TX_MODE_INV, 32, false>(s, b, bi, rec.bd, pc, pc.p + (ptrdiff_t)b.y * pc.stride + b.x,
+                                  pc.stride, pc, levels, level_off, nnz_out, tx_tables,
+                                  tx_tables_t, lay, nullptr, g * 128);
+}
+
 template <int MODE, bool RDOQ = false>
 __global__ void __launch_bounds__(64 * TX2_WAVES)
 residual_wave_kernel(PicView orig, PicView pred, PicView rec, const xvcgpu_tx_block *blocks, int n, int16_t *levels, const uint32_t *level_off, int32_t *nnz_out, const int16_t *tx_tables, const int16_t *tx_tables_t, TxTableLayout lay, const xvcgpu_rdoq_contexts *rq_ctx = nullptr, const xvcgpu_rdoq_params *rq_prm = nullptr, unsigned long long *dist_out = nullptr) {

@@ -1242,6 +1242,24 @@ xvcgpu_status xvcgpu_inv_transform_batch(xvcgpu_ctx *ctx,
   return XVCGPU_OK;
 }
 
+xvcgpu_status xvcgpu_inv_transform_cu_order(xvcgpu_ctx *ctx, xvcgpu_picture *rec,
+                                            const xvcgpu_tx_block *d_blocks, int n_cus,
+                                            const int16_t *d_levels,
+                                            const uint32_t *d_level_offsets,
+                                            const int32_t *d_nnz) {
+  if (!ctx || !rec || n_cus < 0 ||
+      (n_cus && (!d_blocks || !d_levels || !d_level_offsets || !d_nnz)))
+    return XVCGPU_INVALID_ARGUMENT;
+  if (n_cus == 0) return XVCGPU_OK;
+  const int n_wg = (2 * n_cus + TX2_WAVES - 1) / TX2_WAVES;
+  hipLaunchKernelGGL(inv_cu_pairs_kernel, dim3((n_wg + 7) / 8 * 8), dim3(64 * TX2_WAVES), 0,
+                     ctx->stream, rec->v, d_blocks, n_cus, const_cast<int16_t *>(d_levels),
+                     d_level_offsets, const_cast<int32_t *>(d_nnz), ctx->d_tx_tables,
+                     ctx->d_tx_tables_t, xvcgpu_tx_layout());
+  CHECK_LAUNCH(ctx, "inv_transform_cu_order");
+  return XVCGPU_OK;
+}
+
 xvcgpu_status xvcgpu_inv_transform_dist_batch(xvcgpu_ctx *ctx, const xvcgpu_picture *orig,
                                               const xvcgpu_picture *pred, xvcgpu_picture *rec,
                                               const xvcgpu_tx_block *d_blocks, int n,
@@ -1847,9 +1865,15 @@ xvcgpu_status xvcgpu_frame_pass(xvcgpu_ctx *ctx, const xvcgpu_frame_pass_args *a
           st = XVCGPU_INVALID_ARGUMENT;
         } else if (a->n_tx > 0) {
           const PicView &pv = in_place ? rec->v : a->pred->v;
-          launch_residual<TX_MODE_INV>(ctx, pv, pv, rec->v, a->d_tx, a->n_tx, a->d_levels,
-                                       a->d_level_off, a->d_nnz, nullptr,
-                                       /*small_only=*/in_place);
+          if (in_place) {
+            // blocks 3 * cu + comp, CUs up to 16x16 (the condition of in_place): the
+            // U and V blocks of a CU share a wave
+            st = xvcgpu_inv_transform_cu_order(ctx, rec, a->d_tx, a->n_cus, a->d_levels,
+                                               a->d_level_off, a->d_nnz);
+          } else {
+            launch_residual<TX_MODE_INV>(ctx, pv, pv, rec->v, a->d_tx, a->n_tx, a->d_levels,
+                                         a->d_level_off, a->d_nnz, nullptr, false);
+          }
           CHECK_LAUNCH(ctx, "inv_transform_batch");
         }
       }

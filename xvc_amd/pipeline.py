@@ -331,9 +331,14 @@ class FramePass:
                 C.c_size_t(self.n_levels), self.d_levels.ptr, self.d_nnz.ptr,
                 self.d_rdoq_ctx.ptr, self.d_rdoq_prm.ptr,
                 *([self.d_cus_own] if front_fused else [])))
-            ctx._check(lib.xvcgpu_inv_transform_batch(
-                ctx.h, pred_pic.h_pic, rec.h_pic, self.d_tx.ptr, T, self.d_levels.ptr,
-                self.d_level_off.ptr, self.d_nnz.ptr))
+            if front_fused:   # blocks 3 * cu + comp, in place: U and V of a CU share a wave
+                ctx._check(lib.xvcgpu_inv_transform_cu_order(
+                    ctx.h, rec.h_pic, self.d_tx.ptr, n, self.d_levels.ptr, self.d_level_off.ptr,
+                    self.d_nnz.ptr))
+            else:
+                ctx._check(lib.xvcgpu_inv_transform_batch(
+                    ctx.h, pred_pic.h_pic, rec.h_pic, self.d_tx.ptr, T, self.d_levels.ptr,
+                    self.d_level_off.ptr, self.d_nnz.ptr))
         elif self.rdoq:
             ctx.residual_rdoq_batch_dev(orig, self.pred, rec, self.d_tx.ptr, len(d.tx),
                                         self.d_levels.ptr if self.d_levels else None,
@@ -396,9 +401,12 @@ class FramePass:
                             ctx.h, self.bd, self.d_tx.ptr, T, self.d_coeffs.ptr, lo,
                             C.c_size_t(self.n_levels), lv, self.d_nnz.ptr, self.d_rdoq_ctx.ptr,
                             self.d_rdoq_prm.ptr, *([self.d_cus_own] if front_fused else [])))),
-                    ("inv_transform", lambda: ctx._check(lib.xvcgpu_inv_transform_batch(
-                        ctx.h, pred_pic.h_pic, rec.h_pic, self.d_tx.ptr, T, lv, lo,
-                        self.d_nnz.ptr)))]
+                    ("inv_transform", lambda: ctx._check(
+                        lib.xvcgpu_inv_transform_cu_order(ctx.h, rec.h_pic, self.d_tx.ptr, n, lv,
+                                                          lo, self.d_nnz.ptr) if front_fused else
+                        lib.xvcgpu_inv_transform_batch(ctx.h, pred_pic.h_pic, rec.h_pic,
+                                                       self.d_tx.ptr, T, lv, lo,
+                                                       self.d_nnz.ptr)))]
             elif self.rdoq:
                 steps.append(("residual_rdoq", lambda: ctx.residual_rdoq_batch_dev(
                     orig, self.pred, rec, self.d_tx.ptr, T, lv, lo, self.d_nnz.ptr,
