@@ -757,7 +757,7 @@ def main():
             ctx_lo = api.Context(local_rank)
             ctx.use_priority_stream(True)
             ctx_lo.use_priority_stream(False)
-            pfp = pipeline.PipelinedFramePass(ctx, ctx_lo, W, H, bd, qp=args.qp)
+            pfp = pipeline.PipelinedFramePass(ctx, ctx_lo, W, H, bd, qp=args.qp, rdoq=rdoq)
     else:
         recs = runner.e.pictures
         fp = runner.e.fp

@@ -492,15 +492,15 @@ class PipelinedFramePass:
     Same kernels, same results as FramePass; only the queueing differs."""
 
     def __init__(self, ctx_hi, ctx_lo, width, height, bitdepth=10, qp=32, cu=16,
-                 search_range=96):
+                 search_range=96, rdoq=False):
         self.hi, self.lo = ctx_hi, ctx_lo
         self.w, self.h, self.bd = width, height, bitdepth
         rows = (height + cu - 1) // cu
         self.y_mid = (rows // 2) * cu
         self.top = FramePass(ctx_hi, width, height, bitdepth, qp, cu, search_range,
-                             row_range=(0, self.y_mid))
+                             row_range=(0, self.y_mid), rdoq=rdoq)
         self.bot = FramePass(ctx_lo, width, height, bitdepth, qp, cu, search_range,
-                             row_range=(self.y_mid, height))
+                             row_range=(self.y_mid, height), rdoq=rdoq)
         # one CU metadata array for the whole picture (the H pass reads both halves)
         self.bot.d_cus.free()
         self.bot.d_cus = self.top.d_cus
