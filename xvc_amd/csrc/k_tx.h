@@ -508,18 +508,21 @@ residual_kernel(PicView orig, PicView pred, PicView rec, const xvcgpu_tx_block *
 // large blocks - the dependency waves of a decoded picture hold a few dozen
 // 32x32 / 64x64 blocks each, which the scanning form above would run one after
 // the other in a single workgroup.  grid: n; block: TX_THREADS.
-template <int MODE>
+template <int MODE, bool RDOQ = false>
 __global__ void __launch_bounds__(TX_THREADS)
 residual_per_job_kernel(PicView orig, PicView pred, PicView rec,
                         const xvcgpu_tx_block *blocks, int n, int16_t *levels,
                         const uint32_t *level_off, int32_t *nnz_out,
                         const int16_t *tx_tables, TxTableLayout lay,
-                        unsigned long long *dist_out = nullptr) {
+                        unsigned long long *dist_out = nullptr,
+                        const xvcgpu_rdoq_contexts *rq_ctx = nullptr,
+                        const xvcgpu_rdoq_params *rq_prm = nullptr) {
   __shared__ __attribute__((aligned(16))) TxShared s;
+  __shared__ RdoqShared<RDOQ ? 1024 : 4> rq;
   const int idx = blockIdx.x;
   if (idx >= n || tx_small_job(blocks[idx])) return;
-  residual_job<MODE, 4>(s, idx, orig, pred, rec, blocks, levels, level_off, nnz_out, tx_tables,
-                        lay, nullptr, nullptr, nullptr, dist_out);
+  residual_job<MODE, RDOQ ? 1024 : 4>(s, idx, orig, pred, rec, blocks, levels, level_off, nnz_out,
+                                      tx_tables, lay, &rq, rq_ctx, rq_prm, dist_out);
 }
 
 #endif  // XVCGPU_K_TX_H_

@@ -152,10 +152,19 @@ void launch_residual_rdoq(xvcgpu_ctx *ctx, const PicView &o, const PicView &p,
                      dim3(64 * TX2_WAVES), 0, ctx->stream, o, p, r, d_blocks, n,
                      d_levels, d_off, d_nnz, ctx->d_tx_tables, ctx->d_tx_tables_t,
                      xvcgpu_tx_layout(), d_ctx, d_prm);
-  hipLaunchKernelGGL((residual_kernel<TX_MODE_FULL, true>),
-                     dim3((n + TX_THREADS - 1) / TX_THREADS), dim3(TX_THREADS), 0, ctx->stream,
-                     o, p, r, d_blocks, n, d_levels, d_off, d_nnz, ctx->d_tx_tables,
-                     xvcgpu_tx_layout(), d_ctx, d_prm);
+  // the blocks beyond 16x16 (and the 2-wide ones): a workgroup each - the scanning
+  // form runs the large blocks of its 256 descriptors one after the other, which a
+  // batch of RD-search candidates (a third of them 32x32 / 64x64) turns into the
+  // whole launch's duration
+  if (n <= 262144)
+    hipLaunchKernelGGL((residual_per_job_kernel<TX_MODE_FULL, true>), dim3(n), dim3(TX_THREADS),
+                       0, ctx->stream, o, p, r, d_blocks, n, d_levels, d_off, d_nnz,
+                       ctx->d_tx_tables, xvcgpu_tx_layout(), nullptr, d_ctx, d_prm);
+  else
+    hipLaunchKernelGGL((residual_kernel<TX_MODE_FULL, true>),
+                       dim3((n + TX_THREADS - 1) / TX_THREADS), dim3(TX_THREADS), 0, ctx->stream,
+                       o, p, r, d_blocks, n, d_levels, d_off, d_nnz, ctx->d_tx_tables,
+                       xvcgpu_tx_layout(), d_ctx, d_prm);
 }
 
 }  // namespace
