@@ -89,7 +89,14 @@ void PictureDecoder::Plan(const xvc_picture_syntax &ps, const xvc_cu_syntax *cus
   p.map_rows = (ps.height + 63) / 4 + 1;
   const size_t cells = static_cast<size_t>(p.map_stride) * p.map_rows;
   p.cell[0].assign(cells, -1);
-  p.cell[1].assign(cells, -1);
+  // the second tree's map only where a second tree exists (intra pictures): it is
+  // half a megabyte to clear and to upload at 1080p
+  bool second_tree = false;
+  for (int i = 0; i < n && !second_tree; i++) second_tree = cus[i].tree != 0;
+  if (second_tree)
+    p.cell[1].assign(cells, -1);
+  else
+    p.cell[1].clear();
   p.wave.assign(n, 0);
   p.neighbors.assign(n, CuNeighbors());
   p.cu_info.assign(n, xvcgpu_cu_info());
