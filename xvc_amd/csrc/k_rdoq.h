@@ -698,6 +698,7 @@ __device__ __forceinline__ int wave_rdoq(S &s, int lane, int bd, int w, int h,
     wave_sync();
     RQ_STEP(1);
     // step 3: EvalZeroSubblock (rdo_quant.cc:722-760)
+    bool zeroed = false;
     if (act) {
       long long sb_code_cost = s.sb_code_cost[lane];
       const long long sb_zero_dist = my_zero_dist;
@@ -727,6 +728,7 @@ __device__ __forceinline__ int wave_rdoq(S &s, int lane, int bd, int w, int h,
       }
       if (zero_sb) {
         any = false;
+        zeroed = true;
         s.sb_live[lane] = 2;   // its levels and zero costs are cleared by all lanes below
       }
       s.csbf[lane] = any ? 1 : 0;
@@ -736,8 +738,8 @@ __device__ __forceinline__ int wave_rdoq(S &s, int lane, int bd, int w, int h,
     wave_sync();
     // the sub-blocks of this diagonal that were just zeroed: their 16 levels and
     // zero costs, one coefficient per lane and step (the owner alone took 16
-    // steps of two writes)
-    {
+    // steps of two writes) - when a lane of the wave zeroed one at all
+    if (__ballot(zeroed)) {
       const int ax0 = d > rgh - 1 ? d - (rgh - 1) : 0;
       const int ax1 = d < rgw - 1 ? d : rgw - 1;
       const int pairs = (ax1 - ax0 + 1) << (2 * sbs);
