@@ -69,8 +69,8 @@ def parse():
                          "7 %% slower than one queue: 17 launches + events per step)")
     ap.add_argument("--graph", action="store_true",
                     help="N=1: replay one recorded HIP graph per step instead of "
-                         "launching the kernels separately (measured ~3 %% slower: "
-                         "the steps are GPU-bound, not launch-bound)")
+                         "launching the kernels separately (the same rate on the settled "
+                         "state: the steps are GPU-bound, not launch-bound)")
     ap.add_argument("--schedule", choices=["auto", "chains", "subgop", "rows"], default="auto",
                     help="chains: independent picture chains, each picture referencing the one "
                          "before (N=1 default); subgop: hierarchical sub-GOP 16 coded with the "
@@ -860,7 +860,7 @@ def main():
             step(i, record_only=True)
     settle = args.settle
     if settle < 0:
-        settle = 1500 * n_chains if (runner is None and not args.graph and not pipelined) else 0
+        settle = 1500 * n_chains if (runner is None and not pipelined) else 0
     settle -= settle % (2 * n_chains)      # keep the ping-pong parity and the chains' turn
     for i in range(settle):
         step(i)

@@ -115,10 +115,9 @@ __device__ unsigned long long g_rq_trace[4096][16];
 template <int N0>
 struct RdoqShared {
   static constexpr int N = RQ_PADDED(N0);
-  // coeff_cost_to_zero_ is not kept (8 of a coefficient's 19 bytes: the records'
-  // size is what limits the waves per CU): EvalLastPos recomputes a coefficient's
-  // entry from what is kept - its level, its decision-time state and contexts
-  // (rq ctz_of).
+  // coeff_cost_to_zero_ is not kept (8 bytes per coefficient: the records' size is
+  // what limits the waves per CU): EvalLastPos recomputes a coefficient's entry
+  // from what is kept - its level and its 16-bit decision record (rq ctz_of).
   // coeff_sig_bits_ / the sig-flag rate as what they are made of: the count that
   // selects the coefficient's significance context, 3 bits of its record - with
   // the records in LDS their size is what limits the waves per CU
@@ -328,7 +327,7 @@ __device__ __forceinline__ int rq_scan_pos(int sbs, int order, int k) {
 //   1. its owner lane walks the q > 0 coefficients in scan order and decides
 //      them (on real content: one or two per block);
 //   2. all G lanes share out the q == 0 coefficients of the sub-blocks of the
-//      current anti-diagonal: costs (summed per sub-block with LDS atomics) and
+//      current anti-diagonal: costs (summed per sub-block by DPP adds) and
 //      records, every template now final;
 //   3. the owner evaluates the zero-sub-block choice (EvalZeroSubblock).
 // The first version walked all 16 coefficients of a sub-block on its owner
@@ -1068,10 +1067,9 @@ __device__ __forceinline__ int wave_rdoq(S &s, int lane, int bd, int w, int h,
 // 1080p picture.  Here G lanes take a block, G = its sub-block count rounded up
 // to 4 / 16 / 64: a wave runs 16 blocks of up to 8x8, 4 blocks of up to 16x16 or
 // one larger block, every block on its own wavefront.  A classification pass
-// sorts the block indices into the three lists; the per-coefficient scratch
-// (26 bytes each, written once, read by the short tail phases) lives in global
-// memory, what the serial walk reads - coefficients, levels, context costs - in
-// LDS.
+// sorts the block indices into the three lists; everything the walk keeps per
+// coefficient - the coefficient, its level and a 16-bit decision record - and the
+// context costs live in LDS (9.9 KB per wave).
 struct RdoqLists {
   int *list[3];       // block indices per class (4 / 16 / 64 lanes)
   int *count;         // [3]
@@ -1521,8 +1519,8 @@ __device__ __forceinline__ void quant_rdo_packed_wave(
 // three tails (180 + 53 + 7 us on the bench picture), together the longest.
 // Workgroups [0, g16) take the 16-lane class (the long walks first), then g4 for
 // the 4-lane class, the rest the 64-lane class.  The lists' counts are only known
-// on the device, and a workgroup holds 29.5 KB of LDS from the moment it starts -
-// five per CU -, so one workgroup per possible wave of blocks (32 130 for the
+// on the device, and a workgroup holds its LDS from the moment it starts (29.5 KB
+// when this was measured, five per CU), so one workgroup per possible wave of blocks (32 130 for the
 // bench picture, 31 000 of them retiring at once after a 2 us look at the count,
 // in the few LDS slots the live ones leave free) made the launch last as long as
 // that churn: each class gets a bounded number of workgroups instead, which walk

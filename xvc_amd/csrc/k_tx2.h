@@ -464,6 +464,7 @@ inv_cu_pairs_kernel(PicView rec, const xvcgpu_tx_block *blocks, int n_cus, int16
     const int bi = 3 * ci;
     if (nnz_out[bi] == 0) return;   // in place: the block is already what it will be
     const xvcgpu_tx_block b = blocks[bi];
+    if (!tx_small_job(b)) return;   // (not a block of this layout: left as it is)
     const PlaneView pc = rec.c[0];
     tx2_job<TX_MODE_INV, 64, false>(s, b, bi, rec.bd, pc, pc.p + (ptrdiff_t)b.y * pc.stride + b.x,
                                     pc.stride, pc, levels, level_off, nnz_out, tx_tables,
@@ -474,6 +475,7 @@ inv_cu_pairs_kernel(PicView rec, const xvcgpu_tx_block *blocks, int n_cus, int16
   // this lane's half: lanes 0-31 the U block, 32-63 the V block
   const int g = ME2_LANE >> 5, bi = 3 * ci + 1 + g;
   const xvcgpu_tx_block b = blocks[bi];
+  if (!tx_small_job(b) || b.w * b.h > 64) return;   // a half-wave holds a block of <= 64 samples
   const PlaneView pc = g ? rec.c[2] : rec.c[1];
   tx2_job<TX_MODE_INV, 32, false>(s, b, bi, rec.bd, pc, pc.p + (ptrdiff_t)b.y * pc.stride + b.x,
                                   pc.stride, pc, levels, level_off, nnz_out, tx_tables,

@@ -202,6 +202,7 @@ xvcgpu_status xvcgpu_create(int device, xvcgpu_ctx **out) {
   ctx->d_crc_tables = nullptr;
   ctx->d_intra_done = nullptr;
   ctx->intra_done_cap = 0;
+  ctx->intra_waves_grid = 0;
   for (int i = 0; i < 64; i++) ctx->ev_pool[i] = nullptr;
   ctx->d_me_rot = nullptr;
   ctx->me_epoch = 0;
@@ -1715,8 +1716,7 @@ xvcgpu_status xvcgpu_intra_recon_waves(xvcgpu_ctx *ctx, xvcgpu_picture *rec,
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   // a wave of a 1080p picture holds a few dozen jobs: a fraction of the chip's
   // workgroup slots is enough (all of them must be resident together)
-  static int s_grid[64];
-  int &grid = s_grid[ctx->device & 63];
+  int &grid = ctx->intra_waves_grid;   // 0: not asked yet, < 0: refused
   if (grid == 0) {
     int per_cu = 0, cus = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, intra_waves_kernel, 256, 0) !=
