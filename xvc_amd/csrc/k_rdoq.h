@@ -359,7 +359,7 @@ __device__ __forceinline__ int wave_rdoq(S &s, int lane, int bd, int w, int h,
                                          int comp_qp, bool luma, int scan_order, bool sign_hide,
                                          const xvcgpu_rdoq_contexts &ctx,
                                          const xvcgpu_rdoq_params &prm, CF cf, LEV lev,
-                                         bool stage_ctx = true) {
+                                         bool stage_ctx = true, bool clear_levels = true) {
   const int sbs = (w == 2 || h == 2) ? 1 : 2;
   const int sb_size = 1 << (2 * sbs);
   const int gw = w >> sbs, gh = h >> sbs;                   // the whole grid (scan indices)
@@ -442,18 +442,23 @@ __device__ __forceinline__ int wave_rdoq(S &s, int lane, int bd, int w, int h,
   int last = -1;
   unsigned qmask = 0;
   long long my_zero_dist = 0;
-  if (mine)
+  if (mine) {
+    // sum of (a * a) << cost_scale = (sum of a * a) << cost_scale: cost_scale =
+    // 1 + 2 * ((lw + lh) / 2) + 2 * bias > 0, a * a < 2^31
+    unsigned long long sum_sq = 0;
     for (int k = sb_size - 1; k >= 0; k--) {
       int x, y;
       coeff_xy(k, x, y);
       const int a = (short)d_abs(cf(x, y));
-      my_zero_dist += ((long long)(a * a)) << cost_scale;
+      sum_sq += (unsigned)(a * a);
       if (quant(a)) {
         qmask |= 1u << k;
         if (last < 0) last = sb_index + k;
       }
-      *lev(x, y) = 0;
+      if (clear_levels) *lev(x, y) = 0;   // (a caller that staged zero levels says so)
     }
+    my_zero_dist = (long long)(sum_sq << cost_scale);
+  }
   const int last_pos_index = rq_wave_max_i32<G>(last);
   RQ_TRACE(4);
   if (last_pos_index < 0) return 0;  // nothing quantises to a level (most blocks)
@@ -1487,7 +1492,7 @@ __device__ __forceinline__ void quant_rdo_packed_wave(
           v, lane, bd, uw, uh, uqp, uluma != 0, (uflags >> XVC_TXF_SCAN_SHIFT) & 3,
           !(uflags & XVC_TXF_NO_SIGN_HIDING), rq_ctx[cur], uprm,
           [cf, utile](int x, int y) { return (int)cf[utile(x, y)]; },
-          [lv, utile](int x, int y) { return lv + utile(x, y); }, false);
+          [lv, utile](int x, int y) { return lv + utile(x, y); }, false, false);
       pending = false;
     }
   }
