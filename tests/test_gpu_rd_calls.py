@@ -26,7 +26,7 @@ def gpu():
     ctx.close()
 
 
-@pytest.fixture(scope="module", params=["tiny", "c0", "c1"])
+@pytest.fixture(scope="module", params=["tiny", "c0", "c1", "c0q22", "c0q37"])
 def replay(gpu, request):
     api, ctx = gpu
     name = request.param

@@ -48,7 +48,8 @@ def decode_stream_on_gpu(api, ctx, fx, check, one_launch_intra=True):
 
 
 @pytest.mark.parametrize("name,one_launch", [("tiny", True), ("c0", True), ("c1", True),
-                                             ("c1x", True), ("tiny", False), ("c1", False)])
+                                             ("c1x", True), ("tiny", False), ("c1", False),
+                                             ("c0q22", True), ("c0q37", True)])
 def test_gpu_reconstructs_reference_stream(gpu, name, one_launch):
     """one_launch: the intra picture's dependency waves as ONE cooperative launch
     (xvcgpu_intra_recon_waves, the default) or as a launch set per wave."""

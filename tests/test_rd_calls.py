@@ -25,7 +25,7 @@ def _pictures():
 
 
 def test_fixture_tables_are_consistent():
-    for name in ("tiny", "c0", "c1"):
+    for name in ("tiny", "c0", "c1", "c0q22", "c0q37"):
         rd = rf.load(name)
         calls, evals = rd["calls"], rd["evals"]
         assert len(calls) > 50000 and len(evals) > 10000

@@ -10,7 +10,7 @@ import stream_fixture as sf
 from xvc_amd import decoder
 
 
-@pytest.mark.parametrize("name", ["tiny", "c0", "c1", "c1x"])
+@pytest.mark.parametrize("name", ["tiny", "c0", "c1", "c1x", "c0q22", "c0q37"])
 def test_plan_neighbors_equal_reference(name):
     fx = sf.StreamFixture(name)
     for i in range(fx.n):

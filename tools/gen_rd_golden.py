@@ -56,7 +56,7 @@ from rd_fixture import (STEP_DTYPE, MERGE_DTYPE, EVAL_DTYPE, QP_DTYPE, CALL_DTYP
                         NB_DTYPE, CTX_BYTES)
 
 # clip -> the POC whose calls are kept (None: all pictures)
-KEEP = {"tiny": None, "c0": None, "c1": 2}
+KEEP = {"tiny": None, "c0": None, "c1": 2, "c0q22": None, "c0q37": None}
 DTYPES = [STEP_DTYPE, MERGE_DTYPE, EVAL_DTYPE, QP_DTYPE, CALL_DTYPE, None, NB_DTYPE,
           np.dtype("<u2")]
 NAMES = ["steps", "merges", "evals", "qps", "calls", "contexts", "neighbours", "nb_samples"]

@@ -43,6 +43,11 @@ CLIPS = {
     # bench.py and tests/test_gpu_stream.py use it; the motion-search / RD-search
     # captures stay on the short clip above.
     "c1x": dict(w=1920, h=1080, n=33, qp=32, sub_gop=0, planes=0, pre=0),
+    # CIF at the ends of the QP range (dense levels with escape codes / nearly empty
+    # blocks): the RD-search captures of tools/gen_rd_golden.py at other operating
+    # points than QP 32; MD5 only
+    "c0q22": dict(w=352, h=288, n=5, qp=22, sub_gop=4, planes=0, pre=0),
+    "c0q37": dict(w=352, h=288, n=5, qp=37, sub_gop=4, planes=0, pre=0),
     # small, for CPU-side checks of the host driver (oracle engine)
     "tiny": dict(w=136, h=72, n=5, qp=27, sub_gop=4, planes=5, pre=5),
 }
