@@ -48,7 +48,7 @@ def me_blocks(api, calls):
     return b
 
 
-@pytest.mark.parametrize("name", ["tiny", "c0", "c1"])
+@pytest.mark.parametrize("name", ["tiny", "c0", "c1", "c0q22", "c0q37"])
 def test_me_search_reproduces_encoder_motion_searches(gpu, name):
     api, ctx = gpu
     fx = sf.StreamFixture(name)

@@ -36,7 +36,7 @@ CALL_DTYPE = np.dtype([
     ("dist", "<u4")])
 
 # clip -> POCs whose calls are kept (None: all pictures)
-KEEP = {"tiny": None, "c1": [2], "c0": None}
+KEEP = {"tiny": None, "c1": [2], "c0": None, "c0q22": None, "c0q37": None}
 
 
 def main():
