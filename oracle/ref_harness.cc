@@ -177,6 +177,25 @@ uint32_t Crc32(uint32_t crc, const void *data, size_t n);
 #undef CompareSample
 /* IntraPrediction::NeighborState (argument of ComputeRefSamples) likewise */
 #include "xvc_common_lib/intra_prediction.cc"
+/* IntraSearch::DetermineSlowIntraModes (intra_search.cc:188-305), the SATD
+ * pre-selection of the intra search (tools/gen_intra_golden.py): the statement
+ * that fetches the predictor modes (:219, once per call) is followed by a hook
+ * that records the CU, what DetermineNeighbors says about its surroundings and
+ * the reconstruction's row above / column to the left at that moment of the RD
+ * search; every evaluated mode's cost statement (:237, :277) ends in a hook that
+ * records (mode, SATD).  The hooks only read. */
+namespace xr_intra {
+void OnCu(xvc::IntraSearch *is, xvc::CodingUnit *cu, const xvc::YuvPicture &rec_pic);
+double OnEval(xvc::CodingUnit *cu, int mode, uint64_t dist);
+}  // namespace xr_intra
+#define GetPredictorLuma(x) \
+  GetPredictorLuma(x);      \
+  xr_intra::OnCu(this, cu, *rec_pic)
+#define GetLambdaSqrt() \
+  GetLambdaSqrt() + xr_intra::OnEval(cu, static_cast<int>(intra_mode), dist)
+#include "xvc_enc_lib/intra_search.cc"
+#undef GetPredictorLuma
+#undef GetLambdaSqrt
 #undef private
 #undef protected
 
@@ -2598,7 +2617,110 @@ Distortion AfterCompare(TransformEncoder *te, CodingUnit *cu, YuvComponent comp,
 
 }  // namespace xr_rd
 
+/* ---- the intra search's SATD pre-selection, captured ------------------------ */
+namespace xr_intra {
+
+struct Call {                /* one DetermineSlowIntraModes */
+  int32_t poc;
+  int16_t x, y;              /* luma */
+  uint8_t w, h;
+  uint8_t neighbors;         /* XVC_INTRA_HAS_* */
+  uint8_t above_right, below_left;   /* samples (DetermineNeighbors) */
+  uint8_t pad[3];
+  int32_t sample_off;        /* into the sample array: [above-left] [above: w + above_right]
+                                [left: h + below_left], present parts only */
+  int32_t first_eval, n_eval;
+};
+struct Eval {
+  int32_t call;
+  uint32_t dist;             /* SampleMetric(kSatd)::CompareSample */
+  uint8_t mode;
+  uint8_t pad[3];
+};
+
+bool g_capture = false;
+int g_max_calls = 0, g_stride = 1;
+long g_seen = 0;             /* DetermineSlowIntraModes calls so far: every g_stride-th is kept */
+std::vector<Call> g_calls;
+std::vector<Eval> g_evals;
+std::vector<uint16_t> g_samples;
+bool g_open = false;         /* the evaluations that follow belong to g_calls.back() */
+
+void OnCu(xvc::IntraSearch *is, xvc::CodingUnit *cu, const xvc::YuvPicture &rec_pic) {
+  g_open = false;
+  if (!g_capture) return;
+  if ((g_seen++ % g_stride) != 0 || static_cast<int>(g_calls.size()) >= g_max_calls) return;
+  const xvc::YuvComponent comp = xvc::YuvComponent::kY;
+  const xvc::IntraPrediction::NeighborState nb = is->DetermineNeighbors(*cu, comp);
+  Call c;
+  std::memset(&c, 0, sizeof(c));
+  c.poc = static_cast<int32_t>(cu->GetPoc());
+  c.x = static_cast<int16_t>(cu->GetPosX(comp));
+  c.y = static_cast<int16_t>(cu->GetPosY(comp));
+  c.w = static_cast<uint8_t>(cu->GetWidth(comp));
+  c.h = static_cast<uint8_t>(cu->GetHeight(comp));
+  c.neighbors = static_cast<uint8_t>((nb.has_above_left ? XVC_INTRA_HAS_ABOVE_LEFT : 0) |
+                                     (nb.has_above ? XVC_INTRA_HAS_ABOVE : 0) |
+                                     (nb.has_left ? XVC_INTRA_HAS_LEFT : 0));
+  c.above_right = static_cast<uint8_t>(nb.has_above_right);
+  c.below_left = static_cast<uint8_t>(nb.has_below_left);
+  c.sample_off = static_cast<int32_t>(g_samples.size());
+  c.first_eval = static_cast<int32_t>(g_evals.size());
+  const xvc::Sample *p = rec_pic.GetSamplePtr(comp, c.x, c.y);
+  const ptrdiff_t st = rec_pic.GetStride(comp);
+  if (nb.has_above_left) g_samples.push_back(p[-st - 1]);
+  if (nb.has_above)
+    for (int i = 0; i < c.w + c.above_right; i++) g_samples.push_back(p[-st + i]);
+  if (nb.has_left)
+    for (int i = 0; i < c.h + c.below_left; i++) g_samples.push_back(p[i * st - 1]);
+  g_calls.push_back(c);
+  g_open = true;
+}
+
+double OnEval(xvc::CodingUnit *, int mode, uint64_t dist) {
+  if (g_open) {
+    Eval e;
+    std::memset(&e, 0, sizeof(e));
+    e.call = static_cast<int32_t>(g_calls.size()) - 1;
+    e.dist = static_cast<uint32_t>(dist);
+    e.mode = static_cast<uint8_t>(mode);
+    g_evals.push_back(e);
+    g_calls.back().n_eval++;
+  }
+  return 0.0;
+}
+
+}  // namespace xr_intra
+
 extern "C" {
+
+void xr_intra_capture_begin(int max_calls, int stride) {
+  xr_intra::g_stride = stride > 0 ? stride : 1;
+  xr_intra::g_seen = 0;
+  xr_intra::g_calls.clear();
+  xr_intra::g_evals.clear();
+  xr_intra::g_samples.clear();
+  xr_intra::g_max_calls = max_calls;
+  xr_intra::g_open = false;
+  xr_intra::g_capture = true;
+}
+void xr_intra_capture_end(void) { xr_intra::g_capture = false; xr_intra::g_open = false; }
+/* which: 0 calls, 1 evaluations, 2 samples, 3 (count only) all calls seen */
+long xr_intra_count(int which) {
+  if (which == 3) return xr_intra::g_seen;
+  return which == 0 ? static_cast<long>(xr_intra::g_calls.size())
+         : which == 1 ? static_cast<long>(xr_intra::g_evals.size())
+                      : static_cast<long>(xr_intra::g_samples.size());
+}
+int xr_intra_size(int which) {
+  return which == 0 ? static_cast<int>(sizeof(xr_intra::Call))
+         : which == 1 ? static_cast<int>(sizeof(xr_intra::Eval)) : 2;
+}
+const void *xr_intra_data(int which) {
+  return which == 0 ? static_cast<const void *>(xr_intra::g_calls.data())
+         : which == 1 ? static_cast<const void *>(xr_intra::g_evals.data())
+                      : static_cast<const void *>(xr_intra::g_samples.data());
+}
 
 void xr_rd_capture_begin(int only_poc) {
   using namespace xr_rd;  // NOLINT
