@@ -41,7 +41,7 @@ def _layers(calls):
     return out
 
 
-@pytest.mark.parametrize("name,width,height", [("tiny", 136, 72), ("c0", 352, 288)])
+@pytest.mark.parametrize("name,width,height", [("tiny", 136, 72), ("c0", 352, 288), ("c1", 1920, 1080)])
 def test_intra_satd_preselection_of_a_real_encode(gpu, name, width, height):
     api, ctx = gpu
     fx = ifx.load(name)

@@ -12,7 +12,7 @@ import oracle_lib as ol
 from xvc_amd import synth
 
 
-@pytest.mark.parametrize("name,width,height", [("tiny", 136, 72), ("c0", 352, 288)])
+@pytest.mark.parametrize("name,width,height", [("tiny", 136, 72), ("c0", 352, 288), ("c1", 1920, 1080)])
 def test_oracle_reproduces_encoder_intra_satd(name, width, height):
     xo = ol.Lib("xo")
     fx = ifx.load(name)

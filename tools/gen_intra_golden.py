@@ -30,7 +30,7 @@ from xvc_amd import synth  # noqa: E402
 from intra_fixture import CALL_DTYPE, EVAL_DTYPE  # noqa: E402
 
 # clip -> (calls kept at most, every n-th call)
-KEEP = {"tiny": (1500, 3), "c0": (3000, 11)}
+KEEP = {"tiny": (1500, 3), "c0": (3000, 11), "c1": (3000, 199)}
 
 
 def fetch(lib, which, dt):

@@ -10,12 +10,13 @@
 //
 // Here the whole picture is one cooperative launch (G workgroups resident
 // together).  The jobs are sorted by wave; workgroup g takes jobs g, g + G, ...
-// in that order: prediction (kept in LDS), then the inverse transform +
-// reconstruction of the same block into `rec` (job k of the intra list and job k
-// of the transform list are the same block: xvc_gpu::PictureDecoder::Plan appends
-// both per unit).  A job of wave w starts when the counter of wave w - 1 has
-// reached that wave's size, and adds itself to the counter of wave w when its
-// block is in memory - one atomic per JOB on a per-wave address.  (A grid barrier
+// in that order: the block's residual (inverse transform, in LDS), then - once
+// its neighbours are there - the prediction (in LDS) and the add into `rec` (job
+// k of the intra list and job k of the transform list are the same block:
+// xvc_gpu::PictureDecoder::Plan appends both per unit).  A job of wave w may read
+// its neighbours when the counter of wave w - 1 has reached that wave's size, and
+// adds itself to the counter of wave w when its block is in memory - one atomic
+// per JOB on a per-wave address.  (A grid barrier
 // per wave is one atomic per WORKGROUP on one address: with 512 workgroups that
 // alone took 60 us per wave, 27 ms per picture.)  No deadlock: a workgroup takes
 // its jobs in wave order and all workgroups are resident, so the jobs of wave
