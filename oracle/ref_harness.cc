@@ -142,7 +142,7 @@ void AfterMergeSort(xvc::InterSearch *is, xvc::CodingUnit *cu, const xvc::Qp &qp
                     const std::array<std::pair<int, double>, 5> &cand_cost);
 void AfterQuantRdo(xvc::TransformEncoder *te, xvc::CodingUnit *cu, xvc::YuvComponent comp,
                    const xvc::Qp &qp, const xvc::SyntaxWriter &writer, int non_zero,
-                   const xvc::YuvPicture &rec_pic);
+                   const xvc::YuvPicture &rec_pic, const xvc::SampleBuffer &pred_buffer);
 xvc::Distortion AfterCompare(xvc::TransformEncoder *te, xvc::CodingUnit *cu,
                              xvc::YuvComponent comp, const xvc::YuvPicture &orig_pic,
                              const xvc::SampleBuffer &buffer, const char *func);
@@ -169,7 +169,7 @@ uint32_t Crc32(uint32_t crc, const void *data, size_t n);
  * goes through the same macro and is recorded as the component's dist_zero. */
 #define QuantRdo(a, b, c, d, e, f, g, h, i) \
   QuantRdo(a, b, c, d, e, f, g, h, i);      \
-  xr_rd::AfterQuantRdo(this, cu, comp, qp, syntax_writer, non_zero, *rec_pic)
+  xr_rd::AfterQuantRdo(this, cu, comp, qp, syntax_writer, non_zero, *rec_pic, pred_buffer)
 #define CompareSample(a, b, c, d) \
   CompareSample(a, b, c, d) + xr_rd::AfterCompare(this, cu, comp, c, d, __func__)
 #include "xvc_enc_lib/transform_encoder.cc"
@@ -2292,6 +2292,32 @@ long g_skipped_intra = 0;
 const CodingUnit *g_pending_cu = nullptr;
 int g_pending_call = -1;
 
+/* TransformAndReconstruct of INTRA CUs, a sample (every g_itx_stride-th call; LM
+ * chroma left out: its prediction reads the co-located luma block): the block,
+ * its prediction mode, what DetermineNeighbors sees and the reconstruction's
+ * reference samples around it - the prediction is the caller's, but nothing
+ * outside the CU changes between FillReferenceState and this call -, the
+ * transform choice, the context snapshot, and the results. */
+struct IntraTx {
+  int32_t poc;
+  int16_t x, y;              /* in samples of comp */
+  uint8_t w, h, comp, mode;  /* mode: IntraMode of the component (0..66) */
+  uint8_t neighbors, above_right, below_left, tx_skip;
+  uint8_t tx_hor, tx_ver, scan, dst4x4;
+  uint8_t completed, intra_pic;
+  int8_t qp, qp_luma;        /* raw qp of the component / of luma (structural SSD) */
+  int32_t ctx_index, qp_index;
+  int32_t nnz;
+  uint32_t levels_crc, pred_crc, rec_crc;
+  int32_t sample_off;        /* [above-left] [above: w + above_right] [left: h + below_left] */
+  uint64_t dist;
+};
+std::vector<IntraTx> g_itx;
+std::vector<uint16_t> g_itx_samples;
+int g_itx_stride = 0, g_itx_cap = 0;
+long g_itx_seen = 0;
+int g_pending_itx = -1;
+
 static bool Wanted(const CodingUnit &cu) {
   return g_capture &&
          (g_only_poc < 0 || static_cast<int>(cu.GetPicData()->GetPoc()) == g_only_poc);
@@ -2555,12 +2581,71 @@ static int EvalIndex(const CodingUnit &cu, const Qp &qp, const SyntaxWriter &wri
   return static_cast<int>(g_evals.size()) - 1;
 }
 
+static void RecordIntraTx(TransformEncoder *te, CodingUnit *cu, YuvComponent comp, const Qp &qp,
+                          const SyntaxWriter &writer, int non_zero, const YuvPicture &rec_pic,
+                          const SampleBuffer &pred_buffer) {
+  const IntraMode mode = cu->GetIntraMode(comp);
+  if (static_cast<int>(mode) < 0 || static_cast<int>(mode) > 66) return;   /* LM chroma */
+  if ((g_itx_seen++ % g_itx_stride) != 0 || static_cast<int>(g_itx.size()) >= g_itx_cap) return;
+  const int bd = te->max_pel_ == 1023 ? 10 : (te->max_pel_ == 255 ? 8 : 12);
+  IntraTx t;
+  std::memset(&t, 0, sizeof(t));
+  t.poc = static_cast<int32_t>(cu->GetPicData()->GetPoc());
+  t.x = static_cast<int16_t>(cu->GetPosX(comp));
+  t.y = static_cast<int16_t>(cu->GetPosY(comp));
+  t.w = static_cast<uint8_t>(cu->GetWidth(comp));
+  t.h = static_cast<uint8_t>(cu->GetHeight(comp));
+  t.comp = static_cast<uint8_t>(comp);
+  t.mode = static_cast<uint8_t>(mode);
+  /* IntraPrediction::DetermineNeighbors (intra_prediction.cc:688-705) */
+  const bool has_left = t.x > 0, has_above = t.y > 0;
+  t.neighbors = static_cast<uint8_t>((has_left && has_above ? XVC_INTRA_HAS_ABOVE_LEFT : 0) |
+                                     (has_above ? XVC_INTRA_HAS_ABOVE : 0) |
+                                     (has_left ? XVC_INTRA_HAS_LEFT : 0));
+  t.above_right = static_cast<uint8_t>(has_above ? cu->GetCuSizeAboveRight(comp) : 0);
+  t.below_left = static_cast<uint8_t>(has_left ? cu->GetCuSizeBelowLeft(comp) : 0);
+  t.tx_skip = cu->GetTransformSkip(comp);
+  t.tx_ver = static_cast<uint8_t>(cu->GetTransformType(comp, 0));
+  t.tx_hor = static_cast<uint8_t>(cu->GetTransformType(comp, 1));
+  t.scan = static_cast<uint8_t>(TransformHelper::DetermineScanOrder(*cu, comp));
+  t.dst4x4 = util::IsLuma(comp) && t.tx_ver == 0 && t.tx_hor == 0;   /* transform.cc:88-90 */
+  t.intra_pic = cu->GetPicType() == PicturePredictionType::kIntra;
+  t.qp = static_cast<int8_t>(qp.GetQpRaw(comp));
+  t.qp_luma = static_cast<int8_t>(qp.GetQpRaw(YuvComponent::kY));
+  t.ctx_index = ContextIndex(writer);
+  t.qp_index = QpIndex(qp, bd);
+  t.nnz = non_zero;
+  CoeffBuffer coeff = cu->GetCoeff(comp);
+  uint32_t crc = 0, pcrc = 0;
+  for (int y = 0; y < t.h; y++) {
+    crc = Crc32(crc, coeff.GetDataPtr() + y * coeff.GetStride(), sizeof(Coeff) * t.w);
+    pcrc = Crc32(pcrc, pred_buffer.GetDataPtr() + y * pred_buffer.GetStride(),
+                 sizeof(Sample) * t.w);
+  }
+  t.levels_crc = crc;
+  t.pred_crc = pcrc;
+  t.sample_off = static_cast<int32_t>(g_itx_samples.size());
+  const Sample *p = rec_pic.GetSamplePtr(comp, t.x, t.y);
+  const ptrdiff_t st = rec_pic.GetStride(comp);
+  if (has_left && has_above) g_itx_samples.push_back(p[-st - 1]);
+  if (has_above)
+    for (int i = 0; i < t.w + t.above_right; i++) g_itx_samples.push_back(p[-st + i]);
+  if (has_left)
+    for (int i = 0; i < t.h + t.below_left; i++) g_itx_samples.push_back(p[i * st - 1]);
+  g_itx.push_back(t);
+  g_pending_cu = cu;
+  g_pending_itx = static_cast<int>(g_itx.size()) - 1;
+}
+
 void AfterQuantRdo(TransformEncoder *te, CodingUnit *cu, YuvComponent comp, const Qp &qp,
-                   const SyntaxWriter &writer, int non_zero, const YuvPicture &rec_pic) {
+                   const SyntaxWriter &writer, int non_zero, const YuvPicture &rec_pic,
+                   const SampleBuffer &pred_buffer) {
   g_pending_cu = nullptr;
+  g_pending_itx = -1;
   if (!Wanted(*cu)) return;
   if (!cu->IsInter()) {
     g_skipped_intra++;
+    if (g_itx_stride > 0) RecordIntraTx(te, cu, comp, qp, writer, non_zero, rec_pic, pred_buffer);
     return;
   }
   const int bd = te->max_pel_ == 1023 ? 10 : (te->max_pel_ == 255 ? 8 : 12);
@@ -2587,8 +2672,23 @@ void AfterQuantRdo(TransformEncoder *te, CodingUnit *cu, YuvComponent comp, cons
 
 Distortion AfterCompare(TransformEncoder *te, CodingUnit *cu, YuvComponent comp,
                         const YuvPicture &orig_pic, const SampleBuffer &buffer, const char *func) {
-  if (!Wanted(*cu) || !cu->IsInter()) return 0;
+  if (!Wanted(*cu)) return 0;
   const bool reconstruct = func[0] == 'T';   /* TransformAndReconstruct / CompressAndEvalTransform */
+  if (!cu->IsInter()) {
+    /* a sampled intra call: completed by its reconstruction and distortion */
+    if (!reconstruct || g_pending_cu != cu || g_pending_itx < 0) return 0;
+    IntraTx &t = g_itx[g_pending_itx];
+    if (t.comp != static_cast<uint8_t>(comp)) return 0;
+    uint32_t crc = 0;
+    for (int y = 0; y < t.h; y++)
+      crc = Crc32(crc, buffer.GetDataPtr() + y * buffer.GetStride(), sizeof(Sample) * t.w);
+    t.rec_crc = crc;
+    t.dist = te->cu_metric_.CompareSample(*cu, comp, orig_pic, buffer);
+    t.completed = 1;
+    g_pending_cu = nullptr;
+    g_pending_itx = -1;
+    return 0;
+  }
   const Distortion d = te->cu_metric_.CompareSample(*cu, comp, orig_pic, buffer);
   if (!reconstruct) {
     /* cbf-zero distortion of the component: prediction against the original */
@@ -2722,8 +2822,21 @@ const void *xr_intra_data(int which) {
                       : static_cast<const void *>(xr_intra::g_samples.data());
 }
 
+/* The intra-CU half of the capture: every `stride`-th TransformAndReconstruct of an
+ * intra CU (at most `cap`), in the same run as xr_rd_capture_begin (call after it).
+ * xr_rd_count / _size / _data: which 9 = IntraTx, 10 = their neighbour samples. */
+void xr_rd_capture_intra(int stride, int cap) {
+  xr_rd::g_itx_stride = stride;
+  xr_rd::g_itx_cap = cap;
+}
+
 void xr_rd_capture_begin(int only_poc) {
   using namespace xr_rd;  // NOLINT
+  g_itx.clear();
+  g_itx_samples.clear();
+  g_itx_stride = 0;
+  g_itx_seen = 0;
+  g_pending_itx = -1;
   g_steps.clear();
   g_merges.clear();
   g_evals.clear();
@@ -2755,6 +2868,8 @@ long xr_rd_count(int which) {
     case 6: return static_cast<long>(g_nb.size());
     case 7: return static_cast<long>(g_nb_samples.size());
     case 8: return g_skipped_intra;
+    case 9: return static_cast<long>(g_itx.size());
+    case 10: return static_cast<long>(g_itx_samples.size());
   }
   return -1;
 }
@@ -2769,6 +2884,8 @@ int xr_rd_size(int which) {
     case 5: return sizeof(xvcgpu_rdoq_contexts);
     case 6: return sizeof(Neighbours);
     case 7: return sizeof(uint16_t);
+    case 9: return sizeof(IntraTx);
+    case 10: return sizeof(uint16_t);
   }
   return -1;
 }
@@ -2783,6 +2900,8 @@ const void *xr_rd_data(int which) {
     case 5: return g_ctx.data();
     case 6: return g_nb.data();
     case 7: return g_nb_samples.data();
+    case 9: return g_itx.data();
+    case 10: return g_itx_samples.data();
   }
   return nullptr;
 }
