@@ -51,3 +51,30 @@ for comp, size in ((0, 16), (1, 8)):
           (comp, size, size, len(nsb), 100.0 * live.mean(),
            np.bincount(nsb[live], minlength=17).tolist(), nq[live].mean(),
            *np.percentile(nq[live], [50, 90, 99]), nq.max()))
+
+# EvalLastPos' walk: from the last non-zero level back to the first level above 1 -
+# how many sub-blocks does it pass (estimate by sub-block anti-diagonals)?
+lv = fp.d_levels.to_array(np.int16, fp.n_levels)
+for comp, size in ((0, 16), (1, 8)):
+    sel = np.flatnonzero((d.tx["comp"] == comp) & (d.tx["w"] == size) & (d.tx["h"] == size))
+    need, big, ones = [], [], []
+    g = size // 4
+    sy, sx = np.mgrid[0:g, 0:g]
+    diag = (sx + sy)
+    for i in sel[::3]:
+        a = np.abs(lv[off[i]:off[i] + size * size].astype(np.int64)).reshape(size, size)
+        if not a.any():
+            continue
+        nz = (a != 0).reshape(g, 4, g, 4).any(axis=(1, 3))
+        gt = (a > 1).reshape(g, 4, g, 4).any(axis=(1, 3))
+        d_last = diag[nz].max()
+        d_stop = diag[gt].max() if gt.any() else 0
+        need.append(int((nz & (diag >= d_stop) & (diag <= d_last)).sum()))
+        big.append(int((a > 1).sum()))
+        ones.append(int((a == 1).sum()))
+    need = np.array(need)
+    print("comp %d %dx%d: coded blocks %d; sub-blocks the EvalLastPos walk passes (coded ones between "
+          "the highest level > 1 and the last level): hist %s mean %.2f; levels > 1 per block mean %.1f, "
+          "levels == 1 mean %.1f" % (comp, size, size, len(need),
+                                     np.bincount(need, minlength=g * g + 1).tolist(), need.mean(),
+                                     np.mean(big), np.mean(ones)))

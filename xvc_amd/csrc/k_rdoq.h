@@ -205,6 +205,23 @@ __device__ __forceinline__ long long rq_group_sum_i64(long long v) {
                      ((unsigned long long)(unsigned)l1 << 16) + (unsigned long long)(unsigned)l0);
 }
 
+// Inclusive prefix sum of a 64-bit value over each aligned row of 16 lanes (lane
+// offsets ascending), by DPP row shifts - no LDS crossbar trips: four steps, both
+// halves moved with the same control, lanes in front of the row's start read 0.
+template <int N>
+__device__ __forceinline__ long long rq_row_shr_add_i64(long long v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)v, 0x110 + N, 0xF, 0xF, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, (int)(v >> 32), 0x110 + N, 0xF, 0xF, true);
+  return v + (long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
+}
+__device__ __forceinline__ long long rq_row_scan_i64(long long v) {
+  v = rq_row_shr_add_i64<1>(v);
+  v = rq_row_shr_add_i64<2>(v);
+  v = rq_row_shr_add_i64<4>(v);
+  v = rq_row_shr_add_i64<8>(v);
+  return v;
+}
+
 struct RdoqCoeffState {  // RdoQuant::CoeffCodingState, the part the extended set reads
   int c1_idx, c2_idx;
   unsigned golomb_rice_k;
@@ -820,80 +837,160 @@ __device__ __forceinline__ int wave_rdoq(S &s, int lane, int bd, int w, int h,
     // on equal cost the one met first.  The walk ends at the first level above 1:
     // candidates behind it - in this sub-block or in the sub-blocks below the one
     // that holds the highest such level - do not count.
-    long long run = 0, part_best = 0x7fffffffffffffffll;
-    int part_k = -1, stop_local = -1;
-    if (coded) {
-      const bool dcz = s.sb_dcz[lane] != 0;
-      // four coefficients' reads in flight at a time (the walk itself is serial:
-      // the running sum, and it ends at the first level above 1)
-      for (int kb = (sb_size - 1) & ~3; kb >= 0 && stop_local < 0; kb -= 4) {
-        int v[4], ac[4], xs[4], ys[4];
-        unsigned pk[4], sig0[4], sig1[4];
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-          const int k = kb + 3 - i;
-          int x, y;
-          coeff_xy(k < sb_size ? k : 0, x, y);
-          xs[i] = x;
-          ys[i] = y;
-          pk[i] = (unsigned)s.rate_up[rec_pos(x, y)];
-          v[i] = (int)*lev(x, y);
-          ac[i] = (short)d_abs(cf(x, y));
-          sig_pair(pk[i], x + y, sb_index + k, k, dcz, sig0[i], sig1[i]);
-        }
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-          const int k = kb + 3 - i;
-          if (k >= sb_size || k > start_k || stop_local >= 0) continue;
-          long long ctz = -rq_bit_cost(sig0[i], lambda);
-          if (v[i]) {
-            const unsigned lp_bits = s.lp_bits[rq_last_pos_group(lp_swap ? ys[i] : xs[i])] +
-                                     s.lp_bits[LPY + rq_last_pos_group(lp_swap ? xs[i] : ys[i])];
-            const long long part =
-                run + rq_bit_cost(lp_bits, lambda) - rq_bit_cost(sig1[i], lambda);
-            if (part < part_best) {
-              part_best = part;
-              part_k = k;
-            }
-            // the walk ends at a level above 1: nothing behind it counts, its own
-            // cost_to_zero included.  What it passes on its way are levels of 1 (and
-            // zeros): a level of 1 costs its sign and either the zero bin of its
-            // greater-1 flag or, with the flag budget spent, a Golomb-Rice code of 0
-            // (GetAbsLevelBits, rdo_quant.cc:844-878, for quant_level = 1)
-            if (v[i] > 1) {
-              stop_local = sb_index + k;
-            } else if (v[i] == 1) {
-              const unsigned c1_0 = cb[greater_ctx_nn(xs[i] + ys[i], (int)(pk[i] & 7u))];
-              const unsigned bits1 =
-                  sig1[i] + (((pk[i] >> 6) & 1u) ? (2u + ((pk[i] >> 8) & 15u)) * RQ_BYPASS
-                                                 : RQ_BYPASS + c1_0);
-              const int err = ac[i] - dequant(1);
-              ctz = (((long long)(ac[i] * ac[i])) << cost_scale) -
-                    ((((long long)err * err) << cost_scale) + rq_bit_cost(bits1, lambda));
-            } else {
-              ctz = ctz_of(pk[i], xs[i] + ys[i], sb_index + k, k, dcz, ac[i], v[i]);
-            }
-          }
-          run += ctz;
-        }
-      }
-      // (the sum is only needed in full by the sub-blocks in FRONT of this one, and
-      // they only count when no level above 1 lies here: then the loop ran to k = 0)
-    }
-    const long long t = run - flag_cost;
-    RQ_STEP(0);
-    wave_sync();   // every lane has read its sb_code_cost entry (the sums above)
-    if (mine) s.sb_code_cost[my_scan] = visited ? t : 0ll;   // now indexed by scan position
-    wave_sync();
-    const int stop_idx = rq_wave_max_i32<G>(stop_local);
     long long best_cost = 0x7fffffffffffffffll;
     int best_last_plus1 = 0;
-    RQ_STEP(1);
-    if (part_k >= 0 && sb_index + start_k >= stop_idx && (stop_local < 0 || stop_local == stop_idx)) {
-      long long c = comp_code_cost + rq_bit_cost(cb[cbf_ctx + 1], lambda) - flag_cost;
-      for (int j = my_scan + 1; j <= last_sb; j++) c += s.sb_code_cost[j];
-      best_cost = c + part_best;
-      best_last_plus1 = sb_index + part_k + 1;
+    if (sbs == 2 && G >= 16) {
+      // Sixteen lanes take the sixteen coefficients of ONE sub-block per round, from
+      // the last position's sub-block down to the one that holds the highest level
+      // above 1 (where the walk ends): on real content the walk passes one or two
+      // coded sub-blocks, while every owner lane walking its own sixteen
+      // coefficients cost sixteen serial steps whatever the content.  The running
+      // cost in front of a coefficient is an exclusive prefix sum over the lanes.
+      int stop_local = -1;
+      if (coded) {
+        // sixteen independent reads, then the highest offset with a level above 1
+        // (a loop that stops at the first one waits for every read in turn)
+        unsigned gt1 = 0;
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+          int x, y;
+          coeff_xy(k, x, y);
+          gt1 |= (unsigned)((int)*lev(x, y) > 1) << k;
+        }
+        gt1 &= (2u << start_k) - 1u;
+        if (gt1) stop_local = sb_index + 31 - __clz((int)gt1);
+      }
+      const int stop_idx = rq_wave_max_i32<G>(stop_local);
+      const int stop_sb = stop_idx >= 0 ? stop_idx >> 4 : 0;
+      RQ_STEP(0);
+      const int kk = lane & 15;
+      const bool worker = lane < 16;     // (G = 64: the first sixteen lanes of the wave)
+      const int p = rq_scan_pos(sbs, scan_order, kk);
+      const long long base = comp_code_cost + rq_bit_cost(cb[cbf_ctx + 1], lambda);
+      long long acc = 0;                 // sum of (run - flag cost) of the sub-blocks behind
+      for (int j = last_sb; j >= stop_sb; j--) {
+        const int t = (int)s.sb_of_scan[j];
+        const long long fcost = rq_bit_cost(s.csbf_bits[t], lambda);
+        if (!s.csbf[t]) {                // not coded: only its flag's cost leaves the total
+          acc -= fcost;
+          continue;
+        }
+        const bool dcz = s.sb_dcz[t] != 0;
+        const int x = ((t % rgw) << 2) + (p & 3), y = ((t / rgw) << 2) + (p >> 2);
+        const int index = (j << 4) + kk;
+        const int first_k = j == last_sb ? last_k : 15;
+        const bool in = worker && kk <= first_k && index >= stop_idx;
+        const unsigned pk = (unsigned)s.rate_up[rec_pos(x, y)];
+        const int v = (int)*lev(x, y);
+        const int ac = (short)d_abs(cf(x, y));
+        unsigned sig0, sig1;
+        sig_pair(pk, x + y, index, kk, dcz, sig0, sig1);
+        long long ctz = 0;
+        if (in && index != stop_idx) {   // (the level that ends the walk adds nothing)
+          ctz = -rq_bit_cost(sig0, lambda);
+          if (v == 1) {
+            // GetAbsLevelBits (rdo_quant.cc:844-878) for quant_level = 1
+            const unsigned c1_0 = cb[greater_ctx_nn(x + y, (int)(pk & 7u))];
+            const unsigned bits1 = sig1 + (((pk >> 6) & 1u) ? (2u + ((pk >> 8) & 15u)) * RQ_BYPASS
+                                                           : RQ_BYPASS + c1_0);
+            const int err = ac - dequant(1);
+            ctz = (((long long)(ac * ac)) << cost_scale) -
+                  ((((long long)err * err) << cost_scale) + rq_bit_cost(bits1, lambda));
+          } else if (v != 0) {
+            ctz = ctz_of(pk, x + y, index, kk, dcz, ac, v);
+          }
+        }
+        // inclusive prefix over the segment's lanes (scan offsets ascending), then
+        // the sum of the coefficients BEHIND this one = total - inclusive
+        const long long inc = rq_row_scan_i64(ctz);
+        const long long total = rq_group_sum_i64<16>(ctz);
+        if (in && v != 0) {
+          const unsigned lp_bits = s.lp_bits[rq_last_pos_group(lp_swap ? y : x)] +
+                                   s.lp_bits[LPY + rq_last_pos_group(lp_swap ? x : y)];
+          const long long cost = base - fcost + acc + (total - inc) +
+                                 rq_bit_cost(lp_bits, lambda) - rq_bit_cost(sig1, lambda);
+          if (cost < best_cost) {        // (equal cost: the one met first, the higher index)
+            best_cost = cost;
+            best_last_plus1 = index + 1;
+          }
+        }
+        acc += total - fcost;
+      }
+      RQ_STEP(1);
+    } else {
+      long long run = 0, part_best = 0x7fffffffffffffffll;
+      int part_k = -1, stop_local = -1;
+      if (coded) {
+        const bool dcz = s.sb_dcz[lane] != 0;
+        // four coefficients' reads in flight at a time (the walk itself is serial:
+        // the running sum, and it ends at the first level above 1)
+        for (int kb = (sb_size - 1) & ~3; kb >= 0 && stop_local < 0; kb -= 4) {
+          int v[4], ac[4], xs[4], ys[4];
+          unsigned pk[4], sig0[4], sig1[4];
+  #pragma unroll
+          for (int i = 0; i < 4; i++) {
+            const int k = kb + 3 - i;
+            int x, y;
+            coeff_xy(k < sb_size ? k : 0, x, y);
+            xs[i] = x;
+            ys[i] = y;
+            pk[i] = (unsigned)s.rate_up[rec_pos(x, y)];
+            v[i] = (int)*lev(x, y);
+            ac[i] = (short)d_abs(cf(x, y));
+            sig_pair(pk[i], x + y, sb_index + k, k, dcz, sig0[i], sig1[i]);
+          }
+  #pragma unroll
+          for (int i = 0; i < 4; i++) {
+            const int k = kb + 3 - i;
+            if (k >= sb_size || k > start_k || stop_local >= 0) continue;
+            long long ctz = -rq_bit_cost(sig0[i], lambda);
+            if (v[i]) {
+              const unsigned lp_bits = s.lp_bits[rq_last_pos_group(lp_swap ? ys[i] : xs[i])] +
+                                       s.lp_bits[LPY + rq_last_pos_group(lp_swap ? xs[i] : ys[i])];
+              const long long part =
+                  run + rq_bit_cost(lp_bits, lambda) - rq_bit_cost(sig1[i], lambda);
+              if (part < part_best) {
+                part_best = part;
+                part_k = k;
+              }
+              // the walk ends at a level above 1: nothing behind it counts, its own
+              // cost_to_zero included.  What it passes on its way are levels of 1 (and
+              // zeros): a level of 1 costs its sign and either the zero bin of its
+              // greater-1 flag or, with the flag budget spent, a Golomb-Rice code of 0
+              // (GetAbsLevelBits, rdo_quant.cc:844-878, for quant_level = 1)
+              if (v[i] > 1) {
+                stop_local = sb_index + k;
+              } else if (v[i] == 1) {
+                const unsigned c1_0 = cb[greater_ctx_nn(xs[i] + ys[i], (int)(pk[i] & 7u))];
+                const unsigned bits1 =
+                    sig1[i] + (((pk[i] >> 6) & 1u) ? (2u + ((pk[i] >> 8) & 15u)) * RQ_BYPASS
+                                                   : RQ_BYPASS + c1_0);
+                const int err = ac[i] - dequant(1);
+                ctz = (((long long)(ac[i] * ac[i])) << cost_scale) -
+                      ((((long long)err * err) << cost_scale) + rq_bit_cost(bits1, lambda));
+              } else {
+                ctz = ctz_of(pk[i], xs[i] + ys[i], sb_index + k, k, dcz, ac[i], v[i]);
+              }
+            }
+            run += ctz;
+          }
+        }
+        // (the sum is only needed in full by the sub-blocks in FRONT of this one, and
+        // they only count when no level above 1 lies here: then the loop ran to k = 0)
+      }
+      const long long t = run - flag_cost;
+      RQ_STEP(0);
+      wave_sync();   // every lane has read its sb_code_cost entry (the sums above)
+      if (mine) s.sb_code_cost[my_scan] = visited ? t : 0ll;   // now indexed by scan position
+      wave_sync();
+      const int stop_idx = rq_wave_max_i32<G>(stop_local);
+      RQ_STEP(1);
+      if (part_k >= 0 && sb_index + start_k >= stop_idx && (stop_local < 0 || stop_local == stop_idx)) {
+        long long c = comp_code_cost + rq_bit_cost(cb[cbf_ctx + 1], lambda) - flag_cost;
+        for (int j = my_scan + 1; j <= last_sb; j++) c += s.sb_code_cost[j];
+        best_cost = c + part_best;
+        best_last_plus1 = sb_index + part_k + 1;
+      }
     }
     RQ_STEP(2);
 #pragma unroll
