@@ -41,7 +41,8 @@ def _layers(calls):
     return out
 
 
-@pytest.mark.parametrize("name,width,height", [("tiny", 136, 72), ("c0", 352, 288), ("c1", 1920, 1080)])
+@pytest.mark.parametrize("name,width,height", [("tiny", 136, 72), ("c0", 352, 288), ("c1", 1920, 1080),
+                                               ("c0q22", 352, 288), ("c0q37", 352, 288)])
 def test_intra_satd_preselection_of_a_real_encode(gpu, name, width, height):
     api, ctx = gpu
     fx = ifx.load(name)
@@ -102,7 +103,8 @@ def test_intra_satd_preselection_of_a_real_encode(gpu, name, width, height):
 
 
 @pytest.mark.parametrize("name,width,height", [("tiny", 136, 72), ("c0", 352, 288),
-                                               ("c1", 1920, 1080)])
+                                               ("c1", 1920, 1080), ("c0q22", 352, 288),
+                                               ("c0q37", 352, 288)])
 def test_intra_transform_and_reconstruct_of_a_real_encode(gpu, name, width, height):
     """A sample of the TransformAndReconstruct calls the encoder made for INTRA CUs
     (transform_encoder.cc:203-285): prediction from the captured reference samples
@@ -119,7 +121,7 @@ def test_intra_transform_and_reconstruct_of_a_real_encode(gpu, name, width, heig
     itx, samples = fx["itx"], fx["itx_samples"]
     contexts = fx["contexts"].view(api.RDOQ_CTX_DTYPE).reshape(-1)
     qps = fx["qps"].view(rf.QP_DTYPE).reshape(-1)
-    assert len(itx) > 3000 and (itx["scan"] == 1).sum() > 100 and (itx["scan"] == 2).sum() > 100
+    assert len(itx) >= 3000 and (itx["scan"] == 1).sum() > 100 and (itx["scan"] == 2).sum() > 100
     rec_nb, pred, rec_out = (ctx.picture(width, height, 10) for _ in range(3))
     planes = [np.zeros((height + 2 * BL, width + 2 * BL), np.uint16),
               np.zeros((height // 2 + BL, width // 2 + BL), np.uint16),

@@ -12,7 +12,8 @@ import oracle_lib as ol
 from xvc_amd import synth
 
 
-@pytest.mark.parametrize("name,width,height", [("tiny", 136, 72), ("c0", 352, 288), ("c1", 1920, 1080)])
+@pytest.mark.parametrize("name,width,height", [("tiny", 136, 72), ("c0", 352, 288), ("c1", 1920, 1080),
+                                               ("c0q22", 352, 288), ("c0q37", 352, 288)])
 def test_oracle_reproduces_encoder_intra_satd(name, width, height):
     xo = ol.Lib("xo")
     fx = ifx.load(name)
@@ -51,7 +52,8 @@ def test_oracle_reproduces_encoder_intra_satd(name, width, height):
     assert done == len(evals) and done > 20000
 
 
-@pytest.mark.parametrize("name,width,height", [("tiny", 136, 72), ("c0", 352, 288)])
+@pytest.mark.parametrize("name,width,height", [("tiny", 136, 72), ("c0", 352, 288),
+                                               ("c0q22", 352, 288), ("c0q37", 352, 288)])
 def test_oracle_reproduces_encoder_intra_transform_calls(name, width, height):
     """The sampled TransformAndReconstruct calls of intra CUs: the oracle's intra
     prediction from the captured reference samples (CRC equal to the encoder's
@@ -118,4 +120,4 @@ def test_oracle_reproduces_encoder_intra_transform_calls(name, width, height):
         if t["completed"]:
             assert rf.crc32_rows(out[y:y + h, x:x + w]) == int(t["rec_crc"]), ("rec", name, tuple(t))
         done += 1
-    assert done > 1500
+    assert done >= 1500

@@ -31,9 +31,11 @@ from intra_fixture import CALL_DTYPE, EVAL_DTYPE, ITX_DTYPE  # noqa: E402
 from rd_fixture import QP_DTYPE, CTX_BYTES  # noqa: E402
 
 # clip -> (calls kept at most, every n-th call)
-KEEP = {"tiny": (1500, 3), "c0": (3000, 11), "c1": (3000, 199)}
+KEEP = {"tiny": (1500, 3), "c0": (3000, 11), "c1": (3000, 199), "c0q22": (1200, 17),
+        "c0q37": (1200, 13)}
 # clip -> (TransformAndReconstruct calls of intra CUs kept at most, every n-th, only this POC)
-KEEP_TX = {"tiny": (4000, 53, -1), "c0": (6000, 397, -1), "c1": (6000, 2003, 0)}
+KEEP_TX = {"tiny": (4000, 53, -1), "c0": (6000, 397, -1), "c1": (6000, 2003, 0),
+           "c0q22": (3000, 397, -1), "c0q37": (3000, 307, -1)}
 
 
 def fetch(lib, which, dt):
