@@ -80,7 +80,11 @@ def test_compress_and_eval_cbf_vs_reference(gpu):
             total[k] = total.get(k, 0) + v
     # every kind of outcome was exercised (transform skip is evaluated for the 4x4
     # chroma blocks of the 8-wide CUs; on this content it never wins)
-    assert total["cbf"] >= 20 and total["root0"] >= 10 and total["sel"] >= 2, total
+    # input coverage (the parity assertions are in _run): at the committed seed the content
+    # makes a transform-select pair win at least twice; a soak run's shifted seed need not
+    import os
+    soak = int(os.environ.get("XVC_SOAK", "0")) != 0
+    assert total["cbf"] >= 20 and total["root0"] >= 10 and (soak or total["sel"] >= 2), total
 
 
 def _run(gpu, bd, qp, fast_select):
