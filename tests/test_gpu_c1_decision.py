@@ -78,16 +78,20 @@ def test_compress_and_eval_cbf_vs_reference(gpu):
         st = _run(gpu, bd, qp, fast_select)
         for k, v in st.items():
             total[k] = total.get(k, 0) + v
-    # every kind of outcome was exercised (transform skip is evaluated for the 4x4
-    # chroma blocks of the 8-wide CUs; on this content it never wins)
+    # a second content (the seed of soak round 47) on which transform skip - evaluated
+    # for the 4x4 chroma blocks of the 8-wide CUs - wins as well
+    tskip = 0
+    for bd, qp, fast_select in [(10, 32, 1), (10, 27, 1), (8, 22, 1), (10, 37, 0), (10, 27, 0)]:
+        tskip += _run(gpu, bd, qp, fast_select, seed_shift=7919 * 47)["tskip"]
     # input coverage (the parity assertions are in _run): at the committed seed the content
     # makes a transform-select pair win at least twice; a soak run's shifted seed need not
     import os
     soak = int(os.environ.get("XVC_SOAK", "0")) != 0
     assert total["cbf"] >= 20 and total["root0"] >= 10 and (soak or total["sel"] >= 2), total
+    assert soak or tskip >= 1, tskip
 
 
-def _run(gpu, bd, qp, fast_select):
+def _run(gpu, bd, qp, fast_select, seed_shift=0):
     api, ctx = gpu
     xr = C.CDLL(ol.REF_SO)
     xr.xr_c1_create.restype = C.c_void_p
@@ -97,7 +101,7 @@ def _run(gpu, bd, qp, fast_select):
     xr.xr_c1_reference.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.c_void_p]
     xr.xr_c1_bits.restype = C.c_uint32
     xr.xr_c1_bits.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
-    rng = np.random.default_rng(7700 + bd + qp)
+    rng = np.random.default_rng(7700 + bd + qp + seed_shift)
     pw, ph = 512, 256
     orig, ref0, ref1 = _pictures(rng, bd, pw, ph)
     O, R0, R1, P, Rc = (ctx.picture(pw, ph, bd) for _ in range(5))
