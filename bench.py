@@ -875,6 +875,7 @@ def main():
         step(i)
     if ctx_lo is not None:
         ctx.wait_for(ctx_lo)  # the event timer sits on the high-priority queue
+    t_issued = time.perf_counter() - t0    # host time to issue every launch of the region
     gpu_ms = ctx.timer_end()
     barrier()
     dt = time.perf_counter() - t0
@@ -1028,6 +1029,7 @@ def main():
             "ms_per_step": 1e3 * dt / args.steps,
             "gpu_ms_per_step_events": gpu_ms / args.steps if n_chains == 1 else None,
             "pictures_in_flight": n_chains,
+            "host_issue_ms_per_step": 1e3 * t_issued / args.steps,
             "higher_is_better": True,
             "scaling": "strong" if world > 1 else "weak",
             "vs_baseline": None, "dtype": "u16", "data": "synthetic",

@@ -530,6 +530,18 @@ xvcgpu_status xvcgpu_quant_rdo_classified_batch(xvcgpu_ctx *ctx, int bitdepth,
  * (required before recording them, xvcgpu_record_begin). */
 xvcgpu_status xvcgpu_quant_rdo_reserve(xvcgpu_ctx *ctx, int n, size_t n_coeffs);
 
+/* The all-zero proof ahead of the quantiser's walk (k_rdoq.h, rdoq_prove_zero_kernel):
+ * blocks for which RdoQuant::QuantRdo (rdo_quant.cc:223-446) is bound to return 0 -
+ * provable from the plain quantised magnitudes and the context snapshot - get their
+ * zero levels from one more launch and never reach the walk.  Results are the same
+ * either way; the launch pays when the walk is throughput bound (large batches, few
+ * surviving levels) and costs a few percent when it is latency bound.
+ * mode: 0 never, 1 always, -1 (default) for batches of XVCGPU_PROVE_ZERO_AUTO_BLOCKS
+ * blocks or more.  The environment variable XVCGPU_PROVE_ZERO (0 / 1), read by
+ * xvcgpu_create, sets the initial mode. */
+#define XVCGPU_PROVE_ZERO_AUTO_BLOCKS 65536
+xvcgpu_status xvcgpu_quant_rdo_set_prove_zero(xvcgpu_ctx *ctx, int mode);
+
 /* Diagnostics: the number of blocks of the last xvcgpu_quant_rdo_batch that
  * needed the walk, by lane class (out[0]: up to 8x8, out[1]: up to 16x16,
  * out[2]: larger); blocks whose coefficients all quantise to zero are settled

@@ -351,6 +351,37 @@ class Replay:
                 base += ((len(idx) + per_row - 1) // per_row) * int(hh)
         return x, y, int((base + 63) // 64 * 64)
 
+    def _prove_zero_check(self, o_s, p_s, blocks, contexts, prm, levels, off, nnz):
+        """The same calls through the two-step path (xvcgpu_fwd_transform_batch ->
+        xvcgpu_quant_rdo_batch) with the all-zero proof off and forced on: levels and
+        counts equal to the fused path's (which the caller holds against the
+        reference's CRCs); the class lists tell how many blocks the proof took."""
+        import ctypes as C
+        api, ctx = self.api, self.ctx
+        coeffs, off2 = ctx.fwd_transform_batch(o_s, p_s, blocks)
+        assert np.array_equal(off, off2)
+        listed = []
+        for mode in (0, 1):
+            ctx.set_rdoq_prove_zero(mode)
+            lv, nz = ctx.quant_rdo_batch(10, blocks, coeffs, off2, contexts, prm)
+            cc = (C.c_int32 * 3)()
+            ctx._check(ctx.lib.xvcgpu_quant_rdo_class_counts(ctx.h, cc))
+            listed.append(sum(cc))
+            same = np.array_equal(lv, levels) and np.array_equal(nz, nnz)
+            if not same:
+                n_el = blocks["w"].astype(np.int64) * blocks["h"]
+                diff = np.add.reduceat((lv != levels).astype(np.int64), off.astype(np.int64)) \
+                    if len(levels) else np.zeros(0, np.int64)
+                bad = np.flatnonzero((diff != 0) | (nz != nnz))
+                self.pz_bad += len(bad)
+                self.first_bad = ("prove_zero mode %d" % mode, int(bad[0]) if len(bad) else -1,
+                                  blocks[bad[:1]], n_el[bad[:1]])
+        ctx.set_rdoq_prove_zero(-1)
+        self.pz_done += len(blocks)
+        self.pz_zero += int((nnz == 0).sum())
+        self.pz_walked += listed[0]
+        self.pz_proved += listed[0] - listed[1]
+
     def transform_calls_scratch(self, check=True):
         """Every TransformAndReconstruct of the inter CUs without local
         illumination compensation as ONE batch per picture: each CU state's
@@ -429,6 +460,8 @@ class Replay:
             ctx.inter_pred_batch_to(refs, O, p_s, ijobs, dst.reshape(-1))
             levels, off, nnz = ctx.residual_rdoq_batch(o_s, p_s, r_s, blocks, contexts[uctx], prm)
             self._time("scratch_transform_calls", t0)
+            if getattr(self, "check_prove_zero", False):
+                self._prove_zero_check(o_s, p_s, blocks, contexts[uctx], prm, levels, off, nnz)
             dist = np.zeros(len(c), np.uint64)
             t0 = time.time()
             for comp in range(3):

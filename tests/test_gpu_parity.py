@@ -996,6 +996,21 @@ def test_frame_pass(gpu, xo, size, fused, rdoq):
         p.destroy()
 
 
+@pytest.mark.parametrize("size", [(352, 288, 32), (1920, 1080, 32), (1920, 1080, 40),
+                                  (3840, 2160, 27)])
+@pytest.mark.parametrize("mode", [0, 1])
+def test_frame_pass_all_zero_proof(gpu, xo, size, mode):
+    """The same frame passes with the quantiser's all-zero proof
+    (xvcgpu_quant_rdo_set_prove_zero) forced on and forced off - by default the
+    batch size decides: on at 2160p, off below."""
+    api, ctx = gpu
+    ctx.set_rdoq_prove_zero(mode)
+    try:
+        test_frame_pass(gpu, xo, size, True, True)
+    finally:
+        ctx.set_rdoq_prove_zero(-1)
+
+
 @pytest.mark.parametrize("rdoq", [False, True])
 @pytest.mark.parametrize("n", [2, 3, 4])
 def test_frame_pass_multi(gpu, rdoq, n):

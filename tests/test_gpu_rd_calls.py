@@ -67,3 +67,21 @@ def test_transform_and_reconstruct_calls(replay):
     done, bad, layers, dz_done, dz_bad = replay.transform_calls()
     assert done > 10000 and bad == 0, (done, bad, layers, getattr(replay, "first_bad", None))
     assert dz_done > 1000 and dz_bad == 0, (dz_done, dz_bad)
+
+
+def test_all_zero_proof_on_captured_calls(replay):
+    """xvcgpu_quant_rdo_batch with the all-zero proof forced on / off over every
+    captured inter TransformAndReconstruct call (live context snapshots): the same
+    levels as the fused path - which test_transform_calls_with_scratch_destinations
+    holds against the reference - and the proof does take blocks off the walk."""
+    replay.check_prove_zero = True
+    replay.pz_done = replay.pz_bad = replay.pz_zero = replay.pz_walked = replay.pz_proved = 0
+    try:
+        done, bad = replay.transform_calls_scratch()
+    finally:
+        replay.check_prove_zero = False
+    assert bad == 0 and replay.pz_bad == 0, (done, bad, replay.pz_bad,
+                                             getattr(replay, "first_bad", None))
+    assert replay.pz_done > 1000 and replay.pz_proved > 0, (replay.pz_done, replay.pz_proved)
+    print("all-zero proof: %d calls, %d end all zero, %d walked without the proof, %d proved"
+          % (replay.pz_done, replay.pz_zero, replay.pz_walked, replay.pz_proved))

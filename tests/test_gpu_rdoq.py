@@ -23,10 +23,13 @@ def gpu():
     ctx.close()
 
 
-def test_gpu_rdoq_golden(gpu):
-    """Bit-exact levels and non-zero counts for the 432 reference vectors."""
+@pytest.mark.parametrize("prove_zero", [0, 1])
+def test_gpu_rdoq_golden(gpu, prove_zero):
+    """Bit-exact levels and non-zero counts for the 432 reference vectors, with the
+    all-zero proof ahead of the walk forced off and on."""
     import os
     api, ctx = gpu
+    ctx.set_rdoq_prove_zero(prove_zero)
     g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "rdoq.npz"))
     cases = g["cases"]
     done = 0
@@ -61,6 +64,7 @@ def test_gpu_rdoq_golden(gpu):
             assert nnz[k] == e_nnz and np.array_equal(got, exp), \
                 (bd, i, w, h, comp, scan, sign_hide)
             done += 1
+    ctx.set_rdoq_prove_zero(-1)
     assert done > 400
 
 

@@ -169,7 +169,7 @@ SYMBOLS = [
     "xvcgpu_intra_select_modes", "xvcgpu_frame_pass", "xvcgpu_frame_pass_multi", "xvcgpu_copy_segments",
     "xvcgpu_get_transform_matrix", "xvcgpu_inter_pred_batch", "xvcgpu_deblock_tree",
     "xvcgpu_residual_rdoq_batch", "xvcgpu_quant_rdo_batch", "xvcgpu_recon_from_me_rdoq",
-    "xvcgpu_quant_rdo_reserve", "xvcgpu_quant_rdo_class_counts",
+    "xvcgpu_quant_rdo_reserve", "xvcgpu_quant_rdo_class_counts", "xvcgpu_quant_rdo_set_prove_zero",
     "xvcgpu_tx_eval_batch", "xvcgpu_root_cbf_batch", "xvcgpu_bipred_search_lic",
     "xvcgpu_inter_pred_batch_to", "xvcgpu_copy_blocks", "xvcgpu_intra_recon_waves",
     "xvcgpu_host_alloc", "xvcgpu_host_free", "xvcgpu_memcpy_h2d_async",
@@ -297,6 +297,7 @@ def load_library():
                                       C.c_int, C.c_int, _vp, _vp, _vp, _vp],
         "xvcgpu_quant_rdo_reserve": [_vp, C.c_int, C.c_size_t],
         "xvcgpu_quant_rdo_class_counts": [_vp, _vp],
+        "xvcgpu_quant_rdo_set_prove_zero": [_vp, C.c_int],
         "xvcgpu_tx_eval_batch": [_vp, _vp, C.c_int, _vp, _vp],
         "xvcgpu_inter_pred_batch_to": [_vp, _vp, C.c_int, _vp, _vp, _vp, _vp, C.c_int],
         "xvcgpu_copy_blocks": [_vp, _vp, _vp, _vp, C.c_int],
@@ -622,6 +623,11 @@ class Context:
         f = self.lib.xvcgpu_get_stream
         f.restype, f.argtypes = C.c_void_p, [_vp]
         return f(self.h) or 0
+
+    def set_rdoq_prove_zero(self, mode):
+        """The all-zero proof ahead of the RDO quantiser's walk: 0 never, 1 always,
+        -1 by batch size (xvcgpu_quant_rdo_set_prove_zero; same results either way)."""
+        self._check(self.lib.xvcgpu_quant_rdo_set_prove_zero(self.h, int(mode)))
 
     def use_own_stream(self):
         self._check(self.lib.xvcgpu_use_own_stream(self.h))

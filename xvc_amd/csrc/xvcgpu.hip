@@ -1,6 +1,7 @@
 // xvcgpu.hip -- C-ABI implementation of libxvcgpu.so (see include/xvcgpu.h).
 // gfx950 only; no CPU fallback anywhere in this file.
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include <stdio.h>
 #include <string.h>
 
@@ -203,6 +204,10 @@ xvcgpu_status xvcgpu_create(int device, xvcgpu_ctx **out) {
   ctx->d_intra_done = nullptr;
   ctx->intra_done_cap = 0;
   ctx->intra_waves_grid = 0;
+  {
+    const char *e = getenv("XVCGPU_PROVE_ZERO");   // 0 / 1; default: by batch size
+    ctx->rdoq_prove_zero = (e && (e[0] == '0' || e[0] == '1') && !e[1]) ? e[0] - '0' : -1;
+  }
   for (int i = 0; i < 64; i++) ctx->ev_pool[i] = nullptr;
   ctx->d_me_rot = nullptr;
   ctx->me_epoch = 0;
@@ -229,6 +234,14 @@ xvcgpu_status xvcgpu_create(int device, xvcgpu_ctx **out) {
       hipMemset(ctx->d_me_rot, 0x7f, 3 * sizeof(Me2Rot)) != hipSuccess) {
     xvcgpu_destroy(ctx);
     return XVCGPU_OUT_OF_MEMORY;
+  }
+  {
+    uint32_t bits[128];
+    if (hipMemcpyFromSymbol(bits, HIP_SYMBOL(kEntropyBits), sizeof(bits)) != hipSuccess ||
+        hipMemcpyToSymbol(HIP_SYMBOL(gEntropyBits), bits, sizeof(bits)) != hipSuccess) {
+      xvcgpu_destroy(ctx);
+      return XVCGPU_DEVICE_ERROR;
+    }
   }
   {
     TzCand pattern[TZ_MAX_CANDS];
@@ -1112,6 +1125,12 @@ xvcgpu_status xvcgpu_quant_rdo_class_counts(xvcgpu_ctx *ctx, int32_t out[3]) {
   return XVCGPU_OK;
 }
 
+xvcgpu_status xvcgpu_quant_rdo_set_prove_zero(xvcgpu_ctx *ctx, int mode) {
+  if (!ctx || mode < -1 || mode > 1) return XVCGPU_INVALID_ARGUMENT;
+  ctx->rdoq_prove_zero = mode;
+  return XVCGPU_OK;
+}
+
 xvcgpu_status xvcgpu_quant_rdo_reserve(xvcgpu_ctx *ctx, int n, size_t n_coeffs) {
   if (!ctx || n < 0) return XVCGPU_INVALID_ARGUMENT;
   return ensure_rdoq_scratch(ctx, n, n_coeffs);
@@ -1149,6 +1168,12 @@ static xvcgpu_status quant_rdo_launch(xvcgpu_ctx *ctx, int bitdepth,
   if (!classified)
     hipLaunchKernelGGL(rdoq_classify_kernel, dim3((n + 3) / 4), dim3(256), 0, ctx->stream,
                        bitdepth, d_blocks, n, d_coeffs, d_offsets, d_levels, d_nnz, l);
+  // the blocks the walk is bound to return 0 for leave the lists here (k_rdoq.h)
+  if (ctx->rdoq_prove_zero > 0 ||
+      (ctx->rdoq_prove_zero < 0 && n >= XVCGPU_PROVE_ZERO_AUTO_BLOCKS))
+    hipLaunchKernelGGL(rdoq_prove_zero_kernel, dim3((n + 15) / 16), dim3(256), 0, ctx->stream,
+                       bitdepth, d_blocks, n, d_coeffs, d_offsets, d_levels, d_nnz, d_contexts,
+                       d_params, l);
   {
     const int chunks = (n + RDOQ_CHUNK - 1) / RDOQ_CHUNK;
     hipLaunchKernelGGL(rdoq_count_kernel, dim3(chunks), dim3(1024), 0, ctx->stream, n, l);
