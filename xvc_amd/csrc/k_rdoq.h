@@ -1255,8 +1255,8 @@ rdoq_classify_kernel(int bd, const xvcgpu_tx_block *blocks, int n, const int16_t
 // blocks and nearly all chroma blocks the walk zeroes are proved here
 // (tools/dbg/rdoq_zero_bound.py is the offline form of the bound).
 // Blocks with 2-wide sub-blocks, a 64-point side, a magnitude of 32768, more than
-// 16 candidates or another context snapshot than the workgroup's are left to the
-// walk.  Sixteen lanes per block, sixteen blocks per workgroup (one table of
+// 16 candidates, coefficients that do not start on 8 bytes or another context
+// snapshot than the workgroup's are left to the walk.  Sixteen lanes per block, sixteen blocks per workgroup (one table of
 // context costs for all of them); grid: ceil(n / 16); block: 256.
 __global__ void __launch_bounds__(256)
 rdoq_prove_zero_kernel(int bd, const xvcgpu_tx_block *blocks, int n, const int16_t *coeffs,
@@ -1305,7 +1305,11 @@ rdoq_prove_zero_kernel(int bd, const xvcgpu_tx_block *blocks, int n, const int16
     }
   }
   const int w = b.w, h = b.h;
-  const bool tried = live && (int)prm.ctx_index == wg_ctx && w >= 4 && h >= 4 && w <= 32 && h <= 32;
+  const int16_t *src = coeffs + d_off[live ? bi : 0];
+  // (coefficients are read four at a time: a block that does not start on 8 bytes
+  // is left to the walk)
+  const bool tried = live && (int)prm.ctx_index == wg_ctx && w >= 4 && h >= 4 && w <= 32 &&
+                     h <= 32 && (reinterpret_cast<uintptr_t>(src) & 7) == 0;
   const bool luma = b.comp == 0;
   const int scan_order = (b.intra_pic >> XVC_TXF_SCAN_SHIFT) & 3;
   const int lw = rq_log2(w), lh = rq_log2(h);
@@ -1320,7 +1324,6 @@ rdoq_prove_zero_kernel(int bd, const xvcgpu_tx_block *blocks, int n, const int16
   const int iq_shift = 6 - tshift + (bias ? 8 : 0);
   const int iq_scale = (kInvQuantScales[qpb % 6] << (qpb / 6)) * (bias ? 181 : 1);
   const long long lambda = prm.lambda;
-  const int16_t *src = coeffs + d_off[live ? bi : 0];
   auto quant = [&](int a) {
     return (int)(short)(int)((((long long)a * scale) + fq_offset) >> fq_shift);
   };
@@ -1328,15 +1331,27 @@ rdoq_prove_zero_kernel(int bd, const xvcgpu_tx_block *blocks, int n, const int16
     if (x >= w || y >= h) return 0;
     return quant((short)d_abs((int)src[y * w + x]));
   };
-  // the candidates: coefficients with q > 0 (a magnitude of 32768: no proof)
+  // the candidates: coefficients with q > 0, i.e. a * scale >= 2^(shift-1) - one
+  // compare against the smallest such magnitude, four coefficients per load
+  // (a magnitude of 32768: no proof)
   if (tried) {
+    long long t = (long long)((double)fq_offset / (double)scale);
+    while (t * scale < fq_offset) t++;
+    while (t > 0 && (t - 1) * scale >= fq_offset) t--;
+    const int thr = t > 32768 ? 32768 : (int)t;
     bool wrap = false;
-    for (int i = gl; i < w * h; i += 16) {
-      const int a = (short)d_abs((int)src[i]);
-      wrap |= a < 0;
-      if (quant(a) != 0) {
-        const int slot = atomicAdd(&s_n[g], 1);
-        if (slot < 16) s_xy[g][slot] = (unsigned short)(((i >> lw) << 8) | (i & (w - 1)));
+    for (int i = 4 * gl; i < w * h; i += 64) {
+      const uint2 v = *reinterpret_cast<const uint2 *>(src + i);
+      const int a4[4] = {d_abs((int)(short)(v.x & 0xffff)), d_abs((int)(short)(v.x >> 16)),
+                         d_abs((int)(short)(v.y & 0xffff)), d_abs((int)(short)(v.y >> 16))};
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        wrap |= a4[k] == 32768;
+        if (a4[k] >= thr) {
+          const int slot = atomicAdd(&s_n[g], 1);
+          const int ii = i + k;
+          if (slot < 16) s_xy[g][slot] = (unsigned short)(((ii >> lw) << 8) | (ii & (w - 1)));
+        }
       }
     }
     if (wrap) s_fail[g] = 1;

@@ -205,6 +205,7 @@ xvcgpu_status xvcgpu_create(int device, xvcgpu_ctx **out) {
   ctx->intra_done_cap = 0;
   ctx->intra_waves_grid = 0;
   {
+    ctx->rdoq_qp_hint = -1;
     const char *e = getenv("XVCGPU_PROVE_ZERO");   // 0 / 1; default: by batch size
     ctx->rdoq_prove_zero = (e && (e[0] == '0' || e[0] == '1') && !e[1]) ? e[0] - '0' : -1;
   }
@@ -1169,8 +1170,10 @@ static xvcgpu_status quant_rdo_launch(xvcgpu_ctx *ctx, int bitdepth,
     hipLaunchKernelGGL(rdoq_classify_kernel, dim3((n + 3) / 4), dim3(256), 0, ctx->stream,
                        bitdepth, d_blocks, n, d_coeffs, d_offsets, d_levels, d_nnz, l);
   // the blocks the walk is bound to return 0 for leave the lists here (k_rdoq.h)
+  const int qp_hint = classified ? ctx->rdoq_qp_hint : -1;
   if (ctx->rdoq_prove_zero > 0 ||
-      (ctx->rdoq_prove_zero < 0 && n >= XVCGPU_PROVE_ZERO_AUTO_BLOCKS))
+      (ctx->rdoq_prove_zero < 0 && n >= XVCGPU_PROVE_ZERO_AUTO_BLOCKS &&
+       (qp_hint < 0 || qp_hint >= XVCGPU_PROVE_ZERO_AUTO_QP)))
     hipLaunchKernelGGL(rdoq_prove_zero_kernel, dim3((n + 15) / 16), dim3(256), 0, ctx->stream,
                        bitdepth, d_blocks, n, d_coeffs, d_offsets, d_levels, d_nnz, d_contexts,
                        d_params, l);
@@ -1230,6 +1233,7 @@ xvcgpu_status xvcgpu_fwd_from_me_classify(xvcgpu_ctx *ctx, const xvcgpu_picture 
     const xvcgpu_status st = ensure_rdoq_scratch(ctx, 3 * n, n_coeffs);
     if (st != XVCGPU_OK) return st;
   }
+  ctx->rdoq_qp_hint = qp_y;
   FwdClassify fc;
   fc.cls = rdoq_lists_of(ctx).cls;
   fc.levels = d_levels;

@@ -15,8 +15,8 @@ The walk itself (which entries name this rank, in which order) is C++
 Ring of picture buffers per rank: entry = picture index modulo ring size,
 ring >= window + 2 sub-GOPs (a reference lives at most one sub-GOP either side
 of its consumers).  Before an entry is overwritten the writer waits for
-everything that read its previous content (the events of the pictures that
-listed it, the sends that shipped it).
+the picture that wrote its previous content and for everything that read it (the
+events of the pictures that listed it, the sends that shipped it).
 
 The engines used by tests/ (CPU oracle + torch.distributed gloo) implement the
 same three methods as GpuPictureEngine: encode, send, recv."""
@@ -89,6 +89,10 @@ class GpuPictureEngine:
         """Entry of picture `index`, safe to overwrite once `wait(ev)` has been
         applied to every reader of what it held."""
         e = index % self.ring
+        if self.holds[e] >= 0:
+            # ... and for whoever wrote it: a picture nobody referenced has no readers,
+            # and its slot may still be at work on the entry
+            wait(self.ready[e])
         for ev in self.readers[e]:
             wait(ev)
         self.readers[e] = []

@@ -443,6 +443,9 @@ class GpuTreeEngine:
         self.cu_map = np.ascontiguousarray(cu_map, np.int32)
         nbytes = ctx.lib.xvcgpu_picture_bytes(width, height)
         self.mem = torch.zeros(nbytes // 2, dtype=torch.int16, device=device)
+        # the fill runs on torch's stream, everything else on the context's: it must
+        # have landed before the first upload writes the same memory
+        torch.cuda.current_stream(device).synchronize()
         self.picture = api.Picture(ctx, width, height, bitdepth, wrap_ptr=self.mem.data_ptr(),
                                    wrap_bytes=nbytes)
         self.geom = []
@@ -517,6 +520,9 @@ class GpuEngine:
         self._parts = pipeline.cu_partition(width, height, cu)
         # PSNR parts of the own blocks, in a tensor so they can be all-reduced
         self.ssd_mem = torch.zeros(2, dtype=torch.int64, device=device)
+        # the tensors' zero fills ran on torch's current stream; with own_stream the
+        # kernels run on another one
+        torch.cuda.current_stream(device).synchronize()
 
     def min_cu_height_at(self, y):
         if y <= 0 or y >= self.h:
