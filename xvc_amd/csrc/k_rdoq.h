@@ -1256,8 +1256,10 @@ rdoq_classify_kernel(int bd, const xvcgpu_tx_block *blocks, int n, const int16_t
 // (tools/dbg/rdoq_zero_bound.py is the offline form of the bound).
 // Blocks with 2-wide sub-blocks, a 64-point side, a magnitude of 32768, more than
 // 16 candidates, coefficients that do not start on 8 bytes or another context
-// snapshot than the workgroup's are left to the walk.  Sixteen lanes per block, sixteen blocks per workgroup (one table of
-// context costs for all of them); grid: ceil(n / 16); block: 256.
+// snapshot than the workgroup's are left to the walk.  Sixteen lanes per block,
+// RQ_PROVE_BLOCKS blocks per workgroup in rounds of sixteen (one table of context
+// costs for all of them); grid: ceil(n / RQ_PROVE_BLOCKS); block: 256.
+#define RQ_PROVE_BLOCKS 16
 __global__ void __launch_bounds__(256)
 rdoq_prove_zero_kernel(int bd, const xvcgpu_tx_block *blocks, int n, const int16_t *coeffs,
                        const uint32_t *d_off, int16_t *levels, int32_t *nnz_out,
@@ -1271,18 +1273,14 @@ rdoq_prove_zero_kernel(int bd, const xvcgpu_tx_block *blocks, int n, const int16
   __shared__ int s_fail[16];
   __shared__ int s_ctx;
   const int g = threadIdx.x >> 4, gl = threadIdx.x & 15;
-  const int bi = blockIdx.x * 16 + g;
-  const bool live = bi < n && l.cls[bi < n ? bi : 0] >= 0;
-  const xvcgpu_tx_block b = blocks[live ? bi : 0];
-  const xvcgpu_rdoq_params prm = rq_prm[live ? bi : 0];
+  const int base = blockIdx.x * RQ_PROVE_BLOCKS;
   // the workgroup's snapshot: the largest index among its live blocks
   if (threadIdx.x == 0) s_ctx = -1;
-  if (gl == 0) {
-    s_n[g] = 0;
-    s_fail[g] = 0;
-  }
   __syncthreads();
-  if (live && gl == 0) atomicMax(&s_ctx, (int)prm.ctx_index);
+  if ((int)threadIdx.x < RQ_PROVE_BLOCKS) {
+    const int b2 = base + (int)threadIdx.x;
+    if (b2 < n && l.cls[b2] >= 0) atomicMax(&s_ctx, (int)rq_prm[b2].ctx_index);
+  }
   __syncthreads();
   const int wg_ctx = s_ctx;
   if (wg_ctx < 0) return;   // no live block (uniform)
@@ -1304,6 +1302,20 @@ rdoq_prove_zero_kernel(int bd, const xvcgpu_tx_block *blocks, int n, const int16
       o[1] = make_uint4(e[4], e[5], e[6], e[7]);
     }
   }
+  __syncthreads();   // the context costs are in place
+  // From here on a group of sixteen lanes works on its own block and its own rows
+  // of the shared arrays: groups never share data, a wave holds four of them, so
+  // ordering LDS traffic inside the wave is all that is needed.
+  for (int sub = 0; sub < RQ_PROVE_BLOCKS / 16; sub++) {
+  const int bi = base + sub * 16 + g;
+  const bool live = bi < n && l.cls[bi < n ? bi : 0] >= 0;
+  const xvcgpu_tx_block b = blocks[live ? bi : 0];
+  const xvcgpu_rdoq_params prm = rq_prm[live ? bi : 0];
+  if (gl == 0) {
+    s_n[g] = 0;
+    s_fail[g] = 0;
+  }
+  wave_sync();
   const int w = b.w, h = b.h;
   const int16_t *src = coeffs + d_off[live ? bi : 0];
   // (coefficients are read four at a time: a block that does not start on 8 bytes
@@ -1356,7 +1368,7 @@ rdoq_prove_zero_kernel(int bd, const xvcgpu_tx_block *blocks, int n, const int16
     }
     if (wrap) s_fail[g] = 1;
   }
-  __syncthreads();   // candidate lists and the context costs are in place
+  wave_sync();   // the group's candidate list is complete
   const unsigned *cb = s_cb;
   const int nq = s_n[g];
   const bool lp_swap = scan_order == 2;
@@ -1440,21 +1452,24 @@ rdoq_prove_zero_kernel(int bd, const xvcgpu_tx_block *blocks, int n, const int16
     s_idx[g][gl] = my_idx;
     s_gain[g][gl] = gain;
   }
-  __syncthreads();
+  wave_sync();
   if (cand) {
     long long before = 0;
     for (int j = 0; j < nq; j++)
       if (s_idx[g][j] < my_idx) before += s_gain[g][j];
     if (before + gain_last >= rhs) s_fail[g] = 1;
   }
-  __syncthreads();
-  if (!tried || s_fail[g]) return;
-  // QuantRdo would return 0: zero levels, no class
-  int16_t *dst = levels + d_off[bi];
-  for (int i = gl; i < w * h; i += 16) dst[i] = 0;
-  if (gl == 0) {
-    if (nnz_out) nnz_out[bi] = 0;
-    l.cls[bi] = -1;
+  wave_sync();
+  if (tried && !s_fail[g]) {
+    // QuantRdo would return 0: zero levels, no class
+    int16_t *dst = levels + d_off[bi];
+    for (int i = gl; i < w * h; i += 16) dst[i] = 0;
+    if (gl == 0) {
+      if (nnz_out) nnz_out[bi] = 0;
+      l.cls[bi] = -1;
+    }
+  }
+  wave_sync();   // the group's rows are free for its next block
   }
 }
 

@@ -1174,7 +1174,8 @@ static xvcgpu_status quant_rdo_launch(xvcgpu_ctx *ctx, int bitdepth,
   if (ctx->rdoq_prove_zero > 0 ||
       (ctx->rdoq_prove_zero < 0 && n >= XVCGPU_PROVE_ZERO_AUTO_BLOCKS &&
        (qp_hint < 0 || qp_hint >= XVCGPU_PROVE_ZERO_AUTO_QP)))
-    hipLaunchKernelGGL(rdoq_prove_zero_kernel, dim3((n + 15) / 16), dim3(256), 0, ctx->stream,
+    hipLaunchKernelGGL(rdoq_prove_zero_kernel, dim3((n + RQ_PROVE_BLOCKS - 1) / RQ_PROVE_BLOCKS),
+                       dim3(256), 0, ctx->stream,
                        bitdepth, d_blocks, n, d_coeffs, d_offsets, d_levels, d_nnz, d_contexts,
                        d_params, l);
   {
