@@ -516,6 +516,18 @@ xvcgpu_status xvcgpu_fwd_from_me_classify(xvcgpu_ctx *ctx, const xvcgpu_picture 
                                           const uint32_t *d_coeff_offsets, size_t n_coeffs,
                                           int16_t *d_levels, int32_t *d_nnz,
                                           xvcgpu_cu_info *d_cus);
+/* ... and with the quantiser's context snapshots and per-block parameters (the
+ * ones xvcgpu_quant_rdo_classified_batch will be given, blocks 3 * cu + comp):
+ * the forward transform then also runs the all-zero proof
+ * (xvcgpu_quant_rdo_set_prove_zero, below) on the coefficients it holds - no
+ * launch of its own, no second read - unless the proof is switched off (mode 0).
+ * Both null: xvcgpu_fwd_from_me_classify. */
+xvcgpu_status xvcgpu_fwd_from_me_classify_prove(
+    xvcgpu_ctx *ctx, const xvcgpu_picture *orig, const xvcgpu_picture *ref, xvcgpu_picture *pred,
+    const xvcgpu_me_block *d_blocks, const xvcgpu_me_result *d_results, int n, int qp_y, int qp_c,
+    int ref_poc, int16_t *d_coeffs, const uint32_t *d_coeff_offsets, size_t n_coeffs,
+    int16_t *d_levels, int32_t *d_nnz, xvcgpu_cu_info *d_cus,
+    const xvcgpu_rdoq_contexts *d_contexts, const xvcgpu_rdoq_params *d_params);
 xvcgpu_status xvcgpu_quant_rdo_classified_batch(xvcgpu_ctx *ctx, int bitdepth,
                                                 const xvcgpu_tx_block *d_blocks, int n,
                                                 const int16_t *d_coeffs,

@@ -174,7 +174,7 @@ SYMBOLS = [
     "xvcgpu_inter_pred_batch_to", "xvcgpu_copy_blocks", "xvcgpu_intra_recon_waves",
     "xvcgpu_host_alloc", "xvcgpu_host_free", "xvcgpu_memcpy_h2d_async",
     "xvcgpu_inv_transform_cu_order",
-    "xvcgpu_fwd_from_me_classify", "xvcgpu_quant_rdo_classified_batch",
+    "xvcgpu_fwd_from_me_classify", "xvcgpu_fwd_from_me_classify_prove", "xvcgpu_quant_rdo_classified_batch",
     "xvcgpu_event_create", "xvcgpu_event_destroy", "xvcgpu_event_record", "xvcgpu_event_wait",
     "xvcgpu_event_synchronize", "xvcgpu_comm_unique_id", "xvcgpu_comm_create",
     "xvcgpu_comm_destroy", "xvcgpu_comm_world", "xvcgpu_comm_rank", "xvcgpu_comm_wait_event",
@@ -337,6 +337,9 @@ def load_library():
         "xvcgpu_fwd_from_me": [_vp, _vp, _vp, _vp, _vp, _vp, C.c_int, _vp, _vp],
         "xvcgpu_fwd_from_me_classify": [_vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int,
                                         C.c_int, _vp, _vp, C.c_size_t, _vp, _vp, _vp],
+        "xvcgpu_fwd_from_me_classify_prove": [_vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int,
+                                              C.c_int, C.c_int, _vp, _vp, C.c_size_t, _vp, _vp,
+                                              _vp, _vp, _vp],
         "xvcgpu_quant_rdo_classified_batch": [_vp, C.c_int, _vp, C.c_int, _vp, _vp, C.c_size_t,
                                               _vp, _vp, _vp, _vp, _vp],
         "xvcgpu_comm_recv_bytes": [_vp, _vp, C.c_size_t, C.c_int],

@@ -1260,15 +1260,165 @@ rdoq_classify_kernel(int bd, const xvcgpu_tx_block *blocks, int n, const int16_t
 // RQ_PROVE_BLOCKS blocks per workgroup in rounds of sixteen (one table of context
 // costs for all of them); grid: ceil(n / RQ_PROVE_BLOCKS); block: 256.
 #define RQ_PROVE_BLOCKS 16
+#define RQ_PROVE_MAX_CANDS 16
+
+// a block's quantiser constants, as QuantRdo derives them (rdo_quant.cc:223-300)
+struct RqProveBlock {
+  int w, h, lw, lh, scale, fq_shift, cost_scale, iq_shift, iq_scale, scan_order;
+  long long fq_offset, lambda;
+  bool luma, intra_cu;
+};
+
+__device__ __forceinline__ RqProveBlock rq_prove_block(const xvcgpu_tx_block &b, int bd,
+                                                       const xvcgpu_rdoq_params &prm) {
+  RqProveBlock k;
+  k.w = b.w;
+  k.h = b.h;
+  k.luma = b.comp == 0;
+  k.intra_cu = (prm.flags & XVC_RDOQ_INTRA_CU) != 0;
+  k.scan_order = (b.intra_pic >> XVC_TXF_SCAN_SHIFT) & 3;
+  k.lw = rq_log2(k.w);
+  k.lh = rq_log2(k.h);
+  int qpb = b.qp + 6 * (bd - 8);
+  qpb = qpb > 0 ? qpb : 0;
+  const int tshift = 15 - bd - ((k.lw + k.lh) >> 1);
+  const bool bias = ((k.lw + k.lh) & 1) != 0;
+  k.scale = kFwdQuantScales[qpb % 6] * (bias ? 181 : 1);
+  k.fq_shift = 14 + qpb / 6 + tshift + (bias ? 7 : 0);
+  k.fq_offset = 1ll << (k.fq_shift - 1);
+  k.cost_scale = 15 - 2 * tshift - 2 * (bd - 8) + 2 * (bias ? 1 : 0);
+  k.iq_shift = 6 - tshift + (bias ? 8 : 0);
+  k.iq_scale = (kInvQuantScales[qpb % 6] << (qpb / 6)) * (bias ? 181 : 1);
+  k.lambda = prm.lambda;
+  return k;
+}
+
+__device__ __forceinline__ int rq_prove_quant(const RqProveBlock &k, int a) {
+  return (int)(short)(int)((((long long)a * k.scale) + k.fq_offset) >> k.fq_shift);
+}
+
+// the smallest magnitude that quantises to a level: a * scale >= 2^(shift - 1)
+__device__ __forceinline__ int rq_prove_threshold(const RqProveBlock &k) {
+  long long t = (long long)((double)k.fq_offset / (double)k.scale);
+  while (t * k.scale < k.fq_offset) t++;
+  while (t > 0 && (t - 1) * k.scale >= k.fq_offset) t--;
+  return t > 32768 ? 32768 : (int)t;
+}
+
+// One candidate (x, y) with magnitude a: what coding it can save at most as an
+// inner coefficient (gain) and as the last one (gain_last), what a last position
+// there costs on top (rhs), and its place in the scan (idx).  qat(x, y) = the
+// plain quantised magnitude at a position, 0 outside the block; cb = the
+// snapshot's bit costs (entry 2 * ctx + bin).
+template <class QAt>
+__device__ __forceinline__ void rq_prove_candidate(const RqProveBlock &k, const unsigned *cb,
+                                                   int x, int y, int a, QAt qat,
+                                                   long long &gain, long long &gain_last,
+                                                   long long &rhs, int &idx) {
+  const int w = k.w, h = k.h;
+  const bool luma = k.luma;
+  const int q = rq_prove_quant(k, a);
+  int cnt, cnt1;
+  {
+    const int q0 = qat(x + 1, y), q1 = qat(x + 2, y), q2 = qat(x + 1, y + 1), q3 = qat(x, y + 1),
+              q4 = qat(x, y + 2);
+    cnt = (q0 > 0) + (q1 > 0) + (q2 > 0) + (q3 > 0) + (q4 > 0);
+    cnt1 = (q0 > 1) + (q1 > 1) + (q2 > 1) + (q3 > 1) + (q4 > 1);
+  }
+  const int posxy = x + y, size = (k.lw + k.lh) >> 1;
+  // GetCoeffSigCtx (cabac.cc:520-560): the cheapest "1" bin the flag can meet
+  int start = posxy < 2 ? 6 : 0;
+  start += luma && posxy < 5 ? 6 : 0;
+  start += size > 2 && luma ? 18 << (size - 3 < 1 ? size - 3 : 1) : 0;
+  const int sig_base = (luma ? RQ_OFF(sig_luma) : RQ_OFF(sig_chroma)) + start;
+  unsigned sig1 = 0xffffffffu;
+  for (int nn = 0; nn <= cnt; nn++) {
+    const unsigned v = cb[2 * (sig_base + nn) + 1];
+    sig1 = v < sig1 ? v : sig1;
+  }
+  const bool sub_dc = ((x | y) & 3) == 0 && (x | y) != 0;   // k = 0 behind the first sub-block
+  if (sub_dc) sig1 = 0;
+  // the greater-1 contexts (cabac.cc:594-684): the last position's, or by the count
+  const int g1 = luma ? RQ_OFF(greater1_luma) : RQ_OFF(greater1_chroma);
+  const int gstart = luma ? (posxy < 3 ? 10 : (posxy < 10 ? 5 : 0)) : 0;
+  unsigned flag_min = RQ_BYPASS;   // (budget spent: a Golomb-Rice code of at least one bin)
+  {
+    const unsigned v0 = cb[2 * g1], v1 = cb[2 * g1 + 1];
+    flag_min = v0 < flag_min ? v0 : flag_min;
+    flag_min = v1 < flag_min ? v1 : flag_min;
+  }
+  for (int nn = 0; nn <= cnt1; nn++) {
+    const int c = 2 * (g1 + gstart + (nn < 4 ? nn : 4) + 1);
+    const unsigned v0 = cb[c], v1 = cb[c + 1];
+    flag_min = v0 < flag_min ? v0 : flag_min;
+    flag_min = v1 < flag_min ? v1 : flag_min;
+  }
+  const unsigned lvl_min = RQ_BYPASS + flag_min;   // sign + the cheapest continuation
+  auto dist_of = [&](int lvl) {
+    int deq;
+    if (k.iq_shift > 0) deq = (lvl * k.iq_scale + (1 << (k.iq_shift - 1))) >> k.iq_shift;
+    else deq = (lvl * k.iq_scale) << -k.iq_shift;
+    deq = (short)d_clip3(deq, -32768, 32767);
+    const int err = a - deq;
+    return ((long long)err * err) << k.cost_scale;
+  };
+  long long d_best = dist_of(q);
+  if (q > 1) {
+    const long long d1 = dist_of(q - 1);
+    d_best = d1 < d_best ? d1 : d_best;
+  }
+  const long long zd = ((long long)(a * a)) << k.cost_scale;
+  const long long coded = d_best + rq_bit_cost(sig1 + lvl_min, k.lambda);
+  const long long coded_last = d_best + rq_bit_cost(lvl_min, k.lambda);
+  gain = zd - (coded < zd ? coded : zd);
+  gain_last = zd - coded_last;
+  const bool lp_swap = k.scan_order == 2;
+  const int tw = lp_swap ? h : w, th = lp_swap ? w : h;
+  const unsigned lp =
+      rq_last_pos_group_bits(cb, luma, tw, th, rq_last_pos_group(lp_swap ? y : x), true) +
+      rq_last_pos_group_bits(cb, luma, tw, th, rq_last_pos_group(lp_swap ? x : y), false);
+  const int cbf_ctx = 2 * (!luma ? RQ_OFF(cbf_chroma)
+                                 : (k.intra_cu ? RQ_OFF(cbf_luma) : RQ_OFF(root_cbf)));
+  rhs = rq_bit_cost(cb[cbf_ctx + 1], k.lambda) - rq_bit_cost(cb[cbf_ctx], k.lambda) +
+        rq_bit_cost(lp, k.lambda);
+  // scan index: sub-block in the grid's scan, offset in the sub-block's
+  int kk = 0;
+  const int pp = ((y & 3) << 2) | (x & 3);
+  for (int t = 0; t < 16; t++)
+    if (rq_scan_pos(2, k.scan_order, t) == pp) kk = t;
+  idx = (d_sb_scan_index(k.scan_order, w >> 2, h >> 2, x >> 2, y >> 2) << 4) + kk;
+}
+
+// A snapshot's bit costs into cb[2 * 152] by the first `lanes` lanes (a word of
+// four contexts per lane and round, its eight entries).
+__device__ __forceinline__ void rq_prove_stage_costs(const xvcgpu_rdoq_contexts *snap,
+                                                     unsigned *cb, int lane, int lanes) {
+  constexpr int kWords = (int)sizeof(xvcgpu_rdoq_contexts) / 4;
+  const uint32_t *cw = reinterpret_cast<const uint32_t *>(snap);
+  for (int wi = lane; wi < kWords; wi += lanes) {
+    const uint32_t word = cw[wi];
+    unsigned e[8];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const unsigned st8 = (word >> (8 * k)) & 127;
+      e[2 * k] = gEntropyBits[st8];
+      e[2 * k + 1] = gEntropyBits[st8 ^ 1];
+    }
+    uint4 *o = reinterpret_cast<uint4 *>(cb + 8 * wi);
+    o[0] = make_uint4(e[0], e[1], e[2], e[3]);
+    o[1] = make_uint4(e[4], e[5], e[6], e[7]);
+  }
+}
+
 __global__ void __launch_bounds__(256)
 rdoq_prove_zero_kernel(int bd, const xvcgpu_tx_block *blocks, int n, const int16_t *coeffs,
                        const uint32_t *d_off, int16_t *levels, int32_t *nnz_out,
                        const xvcgpu_rdoq_contexts *rq_ctx, const xvcgpu_rdoq_params *rq_prm,
                        RdoqLists l) {
   __shared__ __attribute__((aligned(16))) unsigned s_cb[2 * sizeof(xvcgpu_rdoq_contexts)];
-  __shared__ unsigned short s_xy[16][16];
-  __shared__ int s_idx[16][16];
-  __shared__ long long s_gain[16][16];
+  __shared__ unsigned short s_xy[16][RQ_PROVE_MAX_CANDS];
+  __shared__ int s_idx[16][RQ_PROVE_MAX_CANDS];
+  __shared__ long long s_gain[16][RQ_PROVE_MAX_CANDS];
   __shared__ int s_n[16];
   __shared__ int s_fail[16];
   __shared__ int s_ctx;
@@ -1284,193 +1434,151 @@ rdoq_prove_zero_kernel(int bd, const xvcgpu_tx_block *blocks, int n, const int16
   __syncthreads();
   const int wg_ctx = s_ctx;
   if (wg_ctx < 0) return;   // no live block (uniform)
-  {
-    // the snapshot's bit costs: a word of four contexts per thread, its eight entries
-    constexpr int kWords = (int)sizeof(xvcgpu_rdoq_contexts) / 4;
-    const uint32_t *cw = reinterpret_cast<const uint32_t *>(&rq_ctx[wg_ctx]);
-    if ((int)threadIdx.x < kWords) {
-      const uint32_t word = cw[threadIdx.x];
-      unsigned e[8];
-#pragma unroll
-      for (int k = 0; k < 4; k++) {
-        const unsigned st8 = (word >> (8 * k)) & 127;
-        e[2 * k] = gEntropyBits[st8];
-        e[2 * k + 1] = gEntropyBits[st8 ^ 1];
-      }
-      uint4 *o = reinterpret_cast<uint4 *>(s_cb + 8 * threadIdx.x);
-      o[0] = make_uint4(e[0], e[1], e[2], e[3]);
-      o[1] = make_uint4(e[4], e[5], e[6], e[7]);
-    }
-  }
+  rq_prove_stage_costs(&rq_ctx[wg_ctx], s_cb, (int)threadIdx.x, 256);
   __syncthreads();   // the context costs are in place
   // From here on a group of sixteen lanes works on its own block and its own rows
   // of the shared arrays: groups never share data, a wave holds four of them, so
   // ordering LDS traffic inside the wave is all that is needed.
   for (int sub = 0; sub < RQ_PROVE_BLOCKS / 16; sub++) {
-  const int bi = base + sub * 16 + g;
-  const bool live = bi < n && l.cls[bi < n ? bi : 0] >= 0;
-  const xvcgpu_tx_block b = blocks[live ? bi : 0];
-  const xvcgpu_rdoq_params prm = rq_prm[live ? bi : 0];
-  if (gl == 0) {
-    s_n[g] = 0;
-    s_fail[g] = 0;
-  }
-  wave_sync();
-  const int w = b.w, h = b.h;
-  const int16_t *src = coeffs + d_off[live ? bi : 0];
-  // (coefficients are read four at a time: a block that does not start on 8 bytes
-  // is left to the walk)
-  const bool tried = live && (int)prm.ctx_index == wg_ctx && w >= 4 && h >= 4 && w <= 32 &&
-                     h <= 32 && (reinterpret_cast<uintptr_t>(src) & 7) == 0;
-  const bool luma = b.comp == 0;
-  const int scan_order = (b.intra_pic >> XVC_TXF_SCAN_SHIFT) & 3;
-  const int lw = rq_log2(w), lh = rq_log2(h);
-  int qpb = b.qp + 6 * (bd - 8);
-  qpb = qpb > 0 ? qpb : 0;
-  const int tshift = 15 - bd - ((lw + lh) >> 1);
-  const bool bias = ((lw + lh) & 1) != 0;
-  const int scale = kFwdQuantScales[qpb % 6] * (bias ? 181 : 1);
-  const int fq_shift = 14 + qpb / 6 + tshift + (bias ? 7 : 0);
-  const long long fq_offset = 1ll << (fq_shift - 1);
-  const int cost_scale = 15 - 2 * tshift - 2 * (bd - 8) + 2 * (bias ? 1 : 0);
-  const int iq_shift = 6 - tshift + (bias ? 8 : 0);
-  const int iq_scale = (kInvQuantScales[qpb % 6] << (qpb / 6)) * (bias ? 181 : 1);
-  const long long lambda = prm.lambda;
-  auto quant = [&](int a) {
-    return (int)(short)(int)((((long long)a * scale) + fq_offset) >> fq_shift);
-  };
-  auto qat = [&](int x, int y) {   // quantised magnitude at (x, y), 0 outside the block
-    if (x >= w || y >= h) return 0;
-    return quant((short)d_abs((int)src[y * w + x]));
-  };
-  // the candidates: coefficients with q > 0, i.e. a * scale >= 2^(shift-1) - one
-  // compare against the smallest such magnitude, four coefficients per load
-  // (a magnitude of 32768: no proof)
-  if (tried) {
-    long long t = (long long)((double)fq_offset / (double)scale);
-    while (t * scale < fq_offset) t++;
-    while (t > 0 && (t - 1) * scale >= fq_offset) t--;
-    const int thr = t > 32768 ? 32768 : (int)t;
-    bool wrap = false;
-    for (int i = 4 * gl; i < w * h; i += 64) {
-      const uint2 v = *reinterpret_cast<const uint2 *>(src + i);
-      const int a4[4] = {d_abs((int)(short)(v.x & 0xffff)), d_abs((int)(short)(v.x >> 16)),
-                         d_abs((int)(short)(v.y & 0xffff)), d_abs((int)(short)(v.y >> 16))};
+    const int bi = base + sub * 16 + g;
+    const bool live = bi < n && l.cls[bi < n ? bi : 0] >= 0;
+    const xvcgpu_tx_block b = blocks[live ? bi : 0];
+    const xvcgpu_rdoq_params prm = rq_prm[live ? bi : 0];
+    if (gl == 0) {
+      s_n[g] = 0;
+      s_fail[g] = 0;
+    }
+    wave_sync();
+    const RqProveBlock k = rq_prove_block(b, bd, prm);
+    const int w = k.w, h = k.h;
+    const int16_t *src = coeffs + d_off[live ? bi : 0];
+    // (coefficients are read four at a time: a block that does not start on 8 bytes
+    // is left to the walk)
+    const bool tried = live && (int)prm.ctx_index == wg_ctx && w >= 4 && h >= 4 && w <= 32 &&
+                       h <= 32 && (reinterpret_cast<uintptr_t>(src) & 7) == 0;
+    auto qat = [&](int x, int y) {
+      if (x >= w || y >= h) return 0;
+      return rq_prove_quant(k, (short)d_abs((int)src[y * w + x]));
+    };
+    // the candidates: coefficients with q > 0 - one compare against the smallest
+    // such magnitude, four coefficients per load (a magnitude of 32768: no proof)
+    if (tried) {
+      const int thr = rq_prove_threshold(k);
+      bool wrap = false;
+      for (int i = 4 * gl; i < w * h; i += 64) {
+        const uint2 v = *reinterpret_cast<const uint2 *>(src + i);
+        const int a4[4] = {d_abs((int)(short)(v.x & 0xffff)), d_abs((int)(short)(v.x >> 16)),
+                           d_abs((int)(short)(v.y & 0xffff)), d_abs((int)(short)(v.y >> 16))};
 #pragma unroll
-      for (int k = 0; k < 4; k++) {
-        wrap |= a4[k] == 32768;
-        if (a4[k] >= thr) {
-          const int slot = atomicAdd(&s_n[g], 1);
-          const int ii = i + k;
-          if (slot < 16) s_xy[g][slot] = (unsigned short)(((ii >> lw) << 8) | (ii & (w - 1)));
+        for (int t = 0; t < 4; t++) {
+          wrap |= a4[t] == 32768;
+          if (a4[t] >= thr) {
+            const int slot = atomicAdd(&s_n[g], 1);
+            const int ii = i + t;
+            if (slot < RQ_PROVE_MAX_CANDS)
+              s_xy[g][slot] = (unsigned short)(((ii >> k.lw) << 8) | (ii & (w - 1)));
+          }
         }
       }
+      if (wrap) s_fail[g] = 1;
     }
-    if (wrap) s_fail[g] = 1;
+    wave_sync();   // the group's candidate list is complete
+    const int nq = s_n[g];
+    long long gain_last = 0, rhs = 0;
+    int my_idx = 0;
+    const bool cand = tried && nq <= RQ_PROVE_MAX_CANDS && gl < nq && !s_fail[g];
+    if (tried && gl == 0 && (nq > RQ_PROVE_MAX_CANDS || nq == 0)) s_fail[g] = 1;
+    if (cand) {
+      const int x = s_xy[g][gl] & 255, y = s_xy[g][gl] >> 8;
+      const int a = (short)d_abs((int)src[y * w + x]);
+      long long gain;
+      rq_prove_candidate(k, s_cb, x, y, a, qat, gain, gain_last, rhs, my_idx);
+      s_idx[g][gl] = my_idx;
+      s_gain[g][gl] = gain;
+    }
+    wave_sync();
+    if (cand) {
+      long long before = 0;
+      for (int j = 0; j < nq; j++)
+        if (s_idx[g][j] < my_idx) before += s_gain[g][j];
+      if (before + gain_last >= rhs) s_fail[g] = 1;
+    }
+    wave_sync();
+    if (tried && !s_fail[g]) {
+      // QuantRdo would return 0: zero levels, no class
+      int16_t *dst = levels + d_off[bi];
+      for (int i = gl; i < w * h; i += 16) dst[i] = 0;
+      if (gl == 0) {
+        if (nnz_out) nnz_out[bi] = 0;
+        l.cls[bi] = -1;
+      }
+    }
+    wave_sync();   // the group's rows are free for its next block
   }
-  wave_sync();   // the group's candidate list is complete
-  const unsigned *cb = s_cb;
-  const int nq = s_n[g];
-  const bool lp_swap = scan_order == 2;
+}
+
+// The same proof where the coefficients of a block lie in LDS (the forward
+// transform of the frame pass, k_tx2.h: C[x][y] at c[x * h + y]): G lanes per
+// block, 64 / G blocks per wave; `cands` = the block's q > 0 coefficients already
+// collected by the caller (count n_c, positions (y << 8) | x), wrap = a magnitude
+// of 32768 was seen.  Returns true (to every lane of the group) when QuantRdo is
+// bound to return 0.  The wave's LDS: the snapshot's costs, staged on first use.
+struct RqProveLds {
+  __attribute__((aligned(16))) unsigned cb[2 * sizeof(xvcgpu_rdoq_contexts)];
+  long long gain[2][RQ_PROVE_MAX_CANDS];
+  int idx[2][RQ_PROVE_MAX_CANDS];
+  unsigned short xy[2][RQ_PROVE_MAX_CANDS];
+  int n[2];
+  int fail[2];
+  int staged_ctx;   // snapshot whose costs cb holds (-1: none yet)
+};
+
+template <int G>
+__device__ __forceinline__ bool rq_prove_zero_lds(RqProveLds &pv, const xvcgpu_tx_block &b, int bd,
+                                                  const xvcgpu_rdoq_contexts *rq_ctx,
+                                                  const xvcgpu_rdoq_params &prm,
+                                                  const int16_t *c, bool live) {
+  const int wl = (int)(threadIdx.x & 63), lane = wl & (G - 1), grp = wl / G;
+  const int w = b.w, h = b.h;
+  const int nq = pv.n[grp];
+  bool tried = live && nq >= 1 && nq <= RQ_PROVE_MAX_CANDS && !pv.fail[grp] && w >= 4 && h >= 4 &&
+               w <= 32 && h <= 32;
+  // the wave's snapshot: the first trying group's
+  const unsigned long long tm = __ballot(tried);
+  if (!tm) return false;
+  const int wave_ctx = __shfl((int)prm.ctx_index, __ffsll((long long)tm) - 1, 64);
+  tried = tried && (int)prm.ctx_index == wave_ctx;
+  if (pv.staged_ctx != wave_ctx) {
+    wave_sync();
+    rq_prove_stage_costs(&rq_ctx[wave_ctx], pv.cb, wl, 64);
+    if (wl == 0) pv.staged_ctx = wave_ctx;
+    wave_sync();
+  }
+  const RqProveBlock k = rq_prove_block(b, bd, prm);
+  auto qat = [&](int x, int y) {
+    if (x >= w || y >= h) return 0;
+    return rq_prove_quant(k, (short)d_abs((int)c[x * h + y]));
+  };
   long long gain_last = 0, rhs = 0;
   int my_idx = 0;
-  const bool cand = tried && nq <= 16 && gl < nq && !s_fail[g];
-  if (tried && gl == 0 && (nq > 16 || nq == 0)) s_fail[g] = 1;
+  const bool cand = tried && lane < nq;
   if (cand) {
-    const int x = s_xy[g][gl] & 255, y = s_xy[g][gl] >> 8;
-    const int a = (short)d_abs((int)src[y * w + x]);
-    const int q = quant(a);
-    int cnt, cnt1;
-    {
-      const int q0 = qat(x + 1, y), q1 = qat(x + 2, y), q2 = qat(x + 1, y + 1), q3 = qat(x, y + 1),
-                q4 = qat(x, y + 2);
-      cnt = (q0 > 0) + (q1 > 0) + (q2 > 0) + (q3 > 0) + (q4 > 0);
-      cnt1 = (q0 > 1) + (q1 > 1) + (q2 > 1) + (q3 > 1) + (q4 > 1);
-    }
-    const int posxy = x + y, size = (lw + lh) >> 1;
-    // GetCoeffSigCtx (cabac.cc:520-560): the cheapest "1" bin the flag can meet
-    int start = posxy < 2 ? 6 : 0;
-    start += luma && posxy < 5 ? 6 : 0;
-    start += size > 2 && luma ? 18 << (size - 3 < 1 ? size - 3 : 1) : 0;
-    const int sig_base = (luma ? RQ_OFF(sig_luma) : RQ_OFF(sig_chroma)) + start;
-    unsigned sig1 = 0xffffffffu;
-    for (int nn = 0; nn <= cnt; nn++) {
-      const unsigned v = cb[2 * (sig_base + nn) + 1];
-      sig1 = v < sig1 ? v : sig1;
-    }
-    const bool sub_dc = ((x | y) & 3) == 0 && (x | y) != 0;   // k = 0 behind the first sub-block
-    if (sub_dc) sig1 = 0;
-    // the greater-1 contexts (cabac.cc:594-684): the last position's, or by the count
-    const int g1 = luma ? RQ_OFF(greater1_luma) : RQ_OFF(greater1_chroma);
-    const int gstart = luma ? (posxy < 3 ? 10 : (posxy < 10 ? 5 : 0)) : 0;
-    unsigned flag_min = RQ_BYPASS;   // (budget spent: a Golomb-Rice code of at least one bin)
-    {
-      const unsigned v0 = cb[2 * g1], v1 = cb[2 * g1 + 1];
-      flag_min = v0 < flag_min ? v0 : flag_min;
-      flag_min = v1 < flag_min ? v1 : flag_min;
-    }
-    for (int nn = 0; nn <= cnt1; nn++) {
-      const int c = 2 * (g1 + gstart + (nn < 4 ? nn : 4) + 1);
-      const unsigned v0 = cb[c], v1 = cb[c + 1];
-      flag_min = v0 < flag_min ? v0 : flag_min;
-      flag_min = v1 < flag_min ? v1 : flag_min;
-    }
-    const unsigned lvl_min = RQ_BYPASS + flag_min;   // sign + the cheapest continuation
-    auto dist_of = [&](int lvl) {
-      int deq;
-      if (iq_shift > 0) deq = (lvl * iq_scale + (1 << (iq_shift - 1))) >> iq_shift;
-      else deq = (lvl * iq_scale) << -iq_shift;
-      deq = (short)d_clip3(deq, -32768, 32767);
-      const int err = a - deq;
-      return ((long long)err * err) << cost_scale;
-    };
-    long long d_best = dist_of(q);
-    if (q > 1) {
-      const long long d1 = dist_of(q - 1);
-      d_best = d1 < d_best ? d1 : d_best;
-    }
-    const long long zd = ((long long)(a * a)) << cost_scale;
-    const long long coded = d_best + rq_bit_cost(sig1 + lvl_min, lambda);
-    const long long coded_last = d_best + rq_bit_cost(lvl_min, lambda);
-    const long long gain = zd - (coded < zd ? coded : zd);
-    gain_last = zd - coded_last;
-    const int tw = lp_swap ? h : w, th = lp_swap ? w : h;
-    const unsigned lp =
-        rq_last_pos_group_bits(cb, luma, tw, th, rq_last_pos_group(lp_swap ? y : x), true) +
-        rq_last_pos_group_bits(cb, luma, tw, th, rq_last_pos_group(lp_swap ? x : y), false);
-    const int cbf_ctx = 2 * (!luma ? RQ_OFF(cbf_chroma)
-                                   : ((prm.flags & XVC_RDOQ_INTRA_CU) ? RQ_OFF(cbf_luma)
-                                                                      : RQ_OFF(root_cbf)));
-    rhs = rq_bit_cost(cb[cbf_ctx + 1], lambda) - rq_bit_cost(cb[cbf_ctx], lambda) +
-          rq_bit_cost(lp, lambda);
-    // scan index: sub-block in the grid's scan, offset in the sub-block's
-    int k = 0;
-    const int pp = ((y & 3) << 2) | (x & 3);
-    for (int t = 0; t < 16; t++)
-      if (rq_scan_pos(2, scan_order, t) == pp) k = t;
-    my_idx = (d_sb_scan_index(scan_order, w >> 2, h >> 2, x >> 2, y >> 2) << 4) + k;
-    s_idx[g][gl] = my_idx;
-    s_gain[g][gl] = gain;
+    const int x = pv.xy[grp][lane] & 255, y = pv.xy[grp][lane] >> 8;
+    const int a = (short)d_abs((int)c[x * h + y]);
+    long long gain;
+    rq_prove_candidate(k, pv.cb, x, y, a, qat, gain, gain_last, rhs, my_idx);
+    pv.idx[grp][lane] = my_idx;
+    pv.gain[grp][lane] = gain;
   }
   wave_sync();
   if (cand) {
     long long before = 0;
     for (int j = 0; j < nq; j++)
-      if (s_idx[g][j] < my_idx) before += s_gain[g][j];
-    if (before + gain_last >= rhs) s_fail[g] = 1;
+      if (pv.idx[grp][j] < my_idx) before += pv.gain[grp][j];
+    if (before + gain_last >= rhs) pv.fail[grp] = 1;
   }
   wave_sync();
-  if (tried && !s_fail[g]) {
-    // QuantRdo would return 0: zero levels, no class
-    int16_t *dst = levels + d_off[bi];
-    for (int i = gl; i < w * h; i += 16) dst[i] = 0;
-    if (gl == 0) {
-      if (nnz_out) nnz_out[bi] = 0;
-      l.cls[bi] = -1;
-    }
-  }
-  wave_sync();   // the group's rows are free for its next block
-  }
+  return tried && !pv.fail[grp];
 }
 
 // The class lists from the per-block classes, without atomics (a few thousand

@@ -190,6 +190,14 @@ __device__ __forceinline__ void recon_from_me_kernel_body(PicView orig, PicView 
   __shared__ RqWave rq_all[RDOQ ? 4 : 1];
   RdoqShared<256> *rq_wave = &rq_all[RDOQ ? (threadIdx.x >> 6) : 0].one;
   ReconShared &s = s_all[threadIdx.x >> 6];
+  // the forward half's classification can prove blocks all zero on the spot: a
+  // scratch per wave for it
+  FwdClassify fcl = fc;
+  if constexpr (FWD) {
+    __shared__ RqProveLds pv_all[4];
+    fcl.pv = (fc.cls && fc.rq_ctx && fc.rq_prm) ? &pv_all[threadIdx.x >> 6] : nullptr;
+    if (fcl.pv && (threadIdx.x & 63) == 0) fcl.pv->staged_ctx = -1;
+  }
   const int n = n_cus * 2;
   const int n_wg = (n + 3) / 4;
   const int wg = xcd_job_index(blockIdx.x, n_wg);
@@ -261,7 +269,7 @@ __device__ __forceinline__ void recon_from_me_kernel_body(PicView orig, PicView 
         s.tx, tb, 3 * ci + comp, bd, po, s.pred + g * 64, cw, pc, FWD ? coeffs : nullptr,
         FWD ? coeff_off : nullptr, nnz_out, tx_tables, tx_tables_t, lay, &orig_pre, g * 128,
         reinterpret_cast<RdoqShared<64> *>(rq_wave) + g, rq_ctx, rq_prm, nullptr,
-        FWD ? &fc : nullptr);
+        FWD ? &fcl : nullptr);
     ME2_TRACE(8);
     return;
   }
@@ -295,7 +303,7 @@ __device__ __forceinline__ void recon_from_me_kernel_body(PicView orig, PicView 
                                          rec.c[0], FWD ? coeffs : nullptr,
                                          FWD ? coeff_off : nullptr, nnz_out,
                                          tx_tables, tx_tables_t, lay, &orig_pre, 0,
-                                         rq_wave, rq_ctx, rq_prm, nullptr, FWD ? &fc : nullptr);
+                                         rq_wave, rq_ctx, rq_prm, nullptr, FWD ? &fcl : nullptr);
   ME2_TRACE(8);
   // (FWD: the record with cbf_luma = 0; the quantiser's walk sets the flag of the
   // blocks it codes a level for, quant_rdo_packed_wave's cu_patch)

@@ -132,6 +132,12 @@ struct FwdClassify {
   signed char *cls;
   int16_t *levels;
   int32_t *nnz;
+  // the all-zero proof on the spot (rq_prove_zero_lds, k_rdoq.h): the quantiser's
+  // context snapshots and per-block parameters, and the wave's scratch (set by the
+  // kernel); null: classification only
+  const xvcgpu_rdoq_contexts *rq_ctx;
+  const xvcgpu_rdoq_params *rq_prm;
+  RqProveLds *pv;
 };
 
 // One TransformAndReconstruct job by one wave.  pred_p / pred_stride address
@@ -231,13 +237,33 @@ __device__ __forceinline__ int tx2_job(Tx2Shared &sh, const xvcgpu_tx_block &b, 
         const int fq_scale = kFwdQuantScales[qpb % 6] * (bias ? 181 : 1);
         const long long fq_offset = 1ll << (fq_shift - 1);
         bool any = false;
+        RqProveLds *pv = fc->pv;
+        const int grp = ME2_LANE / G;
+        if (pv) {
+          if (lane == 0) {
+            pv->n[grp] = 0;
+            pv->fail[grp] = 0;
+          }
+          wave_sync();
+        }
         for (int i = lane; i < n_el; i += G) {
           const int a = (short)d_abs((int)s.c[i]);
-          any |= (short)(int)((((long long)a * fq_scale) + fq_offset) >> fq_shift) != 0;
+          const bool nz = (short)(int)((((long long)a * fq_scale) + fq_offset) >> fq_shift) != 0;
+          any |= nz;
+          if (pv && nz) {   // a candidate of the all-zero proof: C[x][y] at s.c[x * h + y]
+            const int slot = atomicAdd(&pv->n[grp], 1);
+            if (slot < RQ_PROVE_MAX_CANDS)
+              pv->xy[grp][slot] = (unsigned short)(((i & (h - 1)) << 8) | (i >> lgh));
+            if (a < 0) pv->fail[grp] = 1;   // a magnitude of 32768: no proof
+          }
         }
         const unsigned long long group =
             G == 64 ? ~0ull : (((1ull << G) - 1) << (ME2_LANE & ~(G - 1)));
-        const bool live = (__ballot(any) & group) != 0;
+        bool live = (__ballot(any) & group) != 0;
+        if (pv) {
+          wave_sync();
+          if (rq_prove_zero_lds<G>(*pv, b, bd, fc->rq_ctx, fc->rq_prm[bi], s.c, live)) live = false;
+        }
         if (lane == 0) fc->cls[bi] = live ? (signed char)rq_class_of(b) : (signed char)-1;
         if (!live) {   // its levels are zeros; the coefficients are not needed again
           int16_t *z = fc->levels + level_off[bi];

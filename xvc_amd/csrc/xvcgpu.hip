@@ -206,6 +206,7 @@ xvcgpu_status xvcgpu_create(int device, xvcgpu_ctx **out) {
   ctx->intra_waves_grid = 0;
   {
     ctx->rdoq_qp_hint = -1;
+    ctx->rdoq_classified_proved = false;
     const char *e = getenv("XVCGPU_PROVE_ZERO");   // 0 / 1; default: by batch size
     ctx->rdoq_prove_zero = (e && (e[0] == '0' || e[0] == '1') && !e[1]) ? e[0] - '0' : -1;
   }
@@ -1171,9 +1172,12 @@ static xvcgpu_status quant_rdo_launch(xvcgpu_ctx *ctx, int bitdepth,
                        bitdepth, d_blocks, n, d_coeffs, d_offsets, d_levels, d_nnz, l);
   // the blocks the walk is bound to return 0 for leave the lists here (k_rdoq.h)
   const int qp_hint = classified ? ctx->rdoq_qp_hint : -1;
-  if (ctx->rdoq_prove_zero > 0 ||
-      (ctx->rdoq_prove_zero < 0 && n >= XVCGPU_PROVE_ZERO_AUTO_BLOCKS &&
-       (qp_hint < 0 || qp_hint >= XVCGPU_PROVE_ZERO_AUTO_QP)))
+  // (the classes a proving forward call left behind stay proved until the next one)
+  const bool proved_already = classified && ctx->rdoq_classified_proved;
+  if (!proved_already &&
+      (ctx->rdoq_prove_zero > 0 ||
+       (ctx->rdoq_prove_zero < 0 && n >= XVCGPU_PROVE_ZERO_AUTO_BLOCKS &&
+        (qp_hint < 0 || qp_hint >= XVCGPU_PROVE_ZERO_AUTO_QP))))
     hipLaunchKernelGGL(rdoq_prove_zero_kernel, dim3((n + RQ_PROVE_BLOCKS - 1) / RQ_PROVE_BLOCKS),
                        dim3(256), 0, ctx->stream,
                        bitdepth, d_blocks, n, d_coeffs, d_offsets, d_levels, d_nnz, d_contexts,
@@ -1224,6 +1228,18 @@ xvcgpu_status xvcgpu_fwd_from_me_classify(xvcgpu_ctx *ctx, const xvcgpu_picture 
                                           const uint32_t *d_coeff_offsets, size_t n_coeffs,
                                           int16_t *d_levels, int32_t *d_nnz,
                                           xvcgpu_cu_info *d_cus) {
+  return xvcgpu_fwd_from_me_classify_prove(ctx, orig, ref, pred, d_blocks, d_results, n, qp_y, qp_c,
+                                           ref_poc, d_coeffs, d_coeff_offsets, n_coeffs, d_levels,
+                                           d_nnz, d_cus, nullptr, nullptr);
+}
+
+xvcgpu_status xvcgpu_fwd_from_me_classify_prove(
+    xvcgpu_ctx *ctx, const xvcgpu_picture *orig, const xvcgpu_picture *ref, xvcgpu_picture *pred,
+    const xvcgpu_me_block *d_blocks, const xvcgpu_me_result *d_results, int n, int qp_y, int qp_c,
+    int ref_poc, int16_t *d_coeffs, const uint32_t *d_coeff_offsets, size_t n_coeffs,
+    int16_t *d_levels, int32_t *d_nnz, xvcgpu_cu_info *d_cus,
+    const xvcgpu_rdoq_contexts *d_contexts, const xvcgpu_rdoq_params *d_params) {
+  if ((d_contexts == nullptr) != (d_params == nullptr)) return XVCGPU_INVALID_ARGUMENT;
   if (!ctx || !orig || !ref || !pred || n < 0 ||
       (n && (!d_blocks || !d_results || !d_coeffs || !d_coeff_offsets || !d_levels || !d_nnz)))
     return XVCGPU_INVALID_ARGUMENT;
@@ -1239,6 +1255,13 @@ xvcgpu_status xvcgpu_fwd_from_me_classify(xvcgpu_ctx *ctx, const xvcgpu_picture 
   fc.cls = rdoq_lists_of(ctx).cls;
   fc.levels = d_levels;
   fc.nnz = d_nnz;
+  // the all-zero proof where the coefficients are at hand, unless it is switched off;
+  // the quantiser's own launch of it is then not needed
+  const bool prove = d_contexts && ctx->rdoq_prove_zero != 0;
+  fc.rq_ctx = prove ? d_contexts : nullptr;
+  fc.rq_prm = prove ? d_params : nullptr;
+  fc.pv = nullptr;
+  ctx->rdoq_classified_proved = prove;
   const int n_wg = (2 * n + 3) / 4;
   hipLaunchKernelGGL((recon_from_me_kernel<false, true>), dim3((n_wg + 7) / 8 * 8), dim3(256), 0,
                      ctx->stream, orig->v, ref->v, pred->v, d_blocks, d_results, n, qp_y, qp_c, 0,
@@ -1879,10 +1902,12 @@ xvcgpu_status xvcgpu_frame_pass(xvcgpu_ctx *ctx, const xvcgpu_frame_pass_args *a
         // inverse half then works in place and skips the blocks without levels)
         // and it classifies the blocks for the quantiser on the way (the
         // coefficients are at hand: no separate pass over all of them)
-        st = xvcgpu_fwd_from_me_classify(ctx, a->orig, a->ref, rec, a->d_me, a->d_results,
-                                         a->n_cus, a->qp_y, a->qp_c, a->ref_poc, a->d_coeffs,
-                                         a->d_level_off, a->n_coeffs, a->d_levels, a->d_nnz,
-                                         a->d_cus_own);
+        // ... and proves the blocks it can all zero (k_rdoq.h)
+        st = xvcgpu_fwd_from_me_classify_prove(ctx, a->orig, a->ref, rec, a->d_me, a->d_results,
+                                               a->n_cus, a->qp_y, a->qp_c, a->ref_poc,
+                                               a->d_coeffs, a->d_level_off, a->n_coeffs,
+                                               a->d_levels, a->d_nnz, a->d_cus_own,
+                                               a->d_rdoq_contexts, a->d_rdoq_params);
         in_place = classified = true;
       } else {
         st = xvcgpu_mc_from_me(ctx, a->ref, a->pred, a->d_me, a->d_results, a->n_cus);

@@ -56,6 +56,7 @@ struct xvcgpu_ctx {
   struct CrcTables *d_crc_tables;  // [0]: 8-bit samples, [1]: wider; built on first use
   int *d_intra_done;               // xvcgpu_intra_recon_waves: finished jobs per dependency wave
   int intra_done_cap;
+  bool rdoq_classified_proved;     // the last xvcgpu_fwd_from_me_classify_prove ran the all-zero proof itself
   int rdoq_qp_hint;                // luma QP of the last xvcgpu_fwd_from_me_classify (-1: none)
   int rdoq_prove_zero;             // quant_rdo: the all-zero proof ahead of the walk: 0 / 1 / -1 by batch size
   int intra_waves_grid;            // workgroups of its cooperative launch (0: not determined yet)

@@ -315,11 +315,13 @@ class FramePass:
             # inverse half then works in place (and skips the blocks without levels)
             pred_pic = rec if front_fused else self.pred
             if front_fused:     # ... which also classifies the blocks for the quantiser
-                ctx._check(lib.xvcgpu_fwd_from_me_classify(
+                # (with the quantiser's contexts: blocks it can prove all zero on the
+                # spot never reach the walk - xvcgpu_quant_rdo_set_prove_zero)
+                ctx._check(lib.xvcgpu_fwd_from_me_classify_prove(
                     ctx.h, orig.h_pic, ref.h_pic, rec.h_pic, self.d_me.ptr,
                     self.d_res.ptr, n, d.qp, d.qp_c, ref_poc, self.d_coeffs.ptr,
                     self.d_level_off.ptr, C.c_size_t(self.n_levels), self.d_levels.ptr,
-                    self.d_nnz.ptr, self.d_cus_own))
+                    self.d_nnz.ptr, self.d_cus_own, self.d_rdoq_ctx.ptr, self.d_rdoq_prm.ptr))
             else:
                 ctx._check(lib.xvcgpu_fwd_transform_batch(
                     ctx.h, orig.h_pic, self.pred.h_pic, self.d_tx.ptr, T, self.d_coeffs.ptr,
@@ -382,10 +384,12 @@ class FramePass:
             # inverse half works in place (as xvcgpu_frame_pass does)
             pred_pic = rec if front_fused else self.pred
             if front_fused:
-                steps.append(("fwd_from_me", lambda: ctx._check(lib.xvcgpu_fwd_from_me_classify(
-                    ctx.h, orig.h_pic, ref.h_pic, rec.h_pic, self.d_me.ptr,
-                    self.d_res.ptr, n, d.qp, d.qp_c, ref_poc, self.d_coeffs.ptr, lo,
-                    C.c_size_t(self.n_levels), lv, self.d_nnz.ptr, self.d_cus_own))))
+                steps.append(("fwd_from_me", lambda: ctx._check(
+                    lib.xvcgpu_fwd_from_me_classify_prove(
+                        ctx.h, orig.h_pic, ref.h_pic, rec.h_pic, self.d_me.ptr,
+                        self.d_res.ptr, n, d.qp, d.qp_c, ref_poc, self.d_coeffs.ptr, lo,
+                        C.c_size_t(self.n_levels), lv, self.d_nnz.ptr, self.d_cus_own,
+                        self.d_rdoq_ctx.ptr, self.d_rdoq_prm.ptr))))
             else:
                 steps.append(("mc_from_me", lambda: ctx.mc_from_me_dev(
                     ref, self.pred, self.d_me.ptr, self.d_res.ptr, n)))
