@@ -1305,6 +1305,13 @@ __device__ __forceinline__ int rq_prove_threshold(const RqProveBlock &k) {
   return t > 32768 ? 32768 : (int)t;
 }
 
+constexpr unsigned long long rq_pack_scan4_inv(int order) {
+  const unsigned long long t = tx_pack_scan4(order);
+  unsigned long long r = 0;
+  for (int k = 0; k < 16; k++) r |= (unsigned long long)k << (4 * (int)((t >> (4 * k)) & 15ull));
+  return r;
+}
+
 // One candidate (x, y) with magnitude a: what coding it can save at most as an
 // inner coefficient (gain) and as the last one (gain_last), what a last position
 // there costs on top (rhs), and its place in the scan (idx).  qat(x, y) = the
@@ -1372,20 +1379,17 @@ __device__ __forceinline__ void rq_prove_candidate(const RqProveBlock &k, const 
   const long long coded_last = d_best + rq_bit_cost(lvl_min, k.lambda);
   gain = zd - (coded < zd ? coded : zd);
   gain_last = zd - coded_last;
-  const bool lp_swap = k.scan_order == 2;
-  const int tw = lp_swap ? h : w, th = lp_swap ? w : h;
-  const unsigned lp =
-      rq_last_pos_group_bits(cb, luma, tw, th, rq_last_pos_group(lp_swap ? y : x), true) +
-      rq_last_pos_group_bits(cb, luma, tw, th, rq_last_pos_group(lp_swap ? x : y), false);
+  const unsigned lp = rq_last_pos_bits(cb, luma, w, h, k.scan_order, x, y);
   const int cbf_ctx = 2 * (!luma ? RQ_OFF(cbf_chroma)
                                  : (k.intra_cu ? RQ_OFF(cbf_luma) : RQ_OFF(root_cbf)));
   rhs = rq_bit_cost(cb[cbf_ctx + 1], k.lambda) - rq_bit_cost(cb[cbf_ctx], k.lambda) +
         rq_bit_cost(lp, k.lambda);
-  // scan index: sub-block in the grid's scan, offset in the sub-block's
-  int kk = 0;
-  const int pp = ((y & 3) << 2) | (x & 3);
-  for (int t = 0; t < 16; t++)
-    if (rq_scan_pos(2, k.scan_order, t) == pp) kk = t;
+  // scan index: sub-block in the grid's scan, offset in the sub-block's (the
+  // inverse of the 4x4 scan: position y * 4 + x -> scan offset, 16 nibbles)
+  constexpr unsigned long long inv0 = rq_pack_scan4_inv(0), inv1 = rq_pack_scan4_inv(1),
+                               inv2 = rq_pack_scan4_inv(2);
+  const unsigned long long inv = k.scan_order == 0 ? inv0 : (k.scan_order == 1 ? inv1 : inv2);
+  const int kk = (int)((inv >> (4 * (((y & 3) << 2) | (x & 3)))) & 15ull);
   idx = (d_sb_scan_index(k.scan_order, w >> 2, h >> 2, x >> 2, y >> 2) << 4) + kk;
 }
 
