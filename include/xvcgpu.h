@@ -550,9 +550,11 @@ xvcgpu_status xvcgpu_quant_rdo_reserve(xvcgpu_ctx *ctx, int n, size_t n_coeffs);
  * surviving levels) and costs a few percent when it is latency bound.
  * mode: 0 never, 1 always, -1 (default) for batches of XVCGPU_PROVE_ZERO_AUTO_BLOCKS
  * blocks or more - and, where the batch follows xvcgpu_fwd_from_me_classify, which
- * knows the picture's QP, only from XVCGPU_PROVE_ZERO_AUTO_QP up (measured, frame
- * passes/s without -> with: 3840x2160 QP 27 1475 -> 1440, QP 32 1841 -> 2036;
- * 7680x4320 QP 37 525 -> 551; 1920x1080 QP 32 6811 -> 6696).  The environment
+ * knows the picture's QP, only from XVCGPU_PROVE_ZERO_AUTO_QP up (measured with the
+ * proof as its own launch, frame passes/s without -> with: 3840x2160 QP 27 1475 ->
+ * 1440, QP 32 1841 -> 2036; 7680x4320 QP 37 525 -> 551; 1920x1080 QP 32 6811 ->
+ * 6696).  A batch that follows xvcgpu_fwd_from_me_classify_prove needs no launch:
+ * that call has run the proof already, for any mode but 0.  The environment
  * variable XVCGPU_PROVE_ZERO (0 / 1), read by xvcgpu_create, sets the initial mode. */
 #define XVCGPU_PROVE_ZERO_AUTO_BLOCKS 65536
 #define XVCGPU_PROVE_ZERO_AUTO_QP 30
