@@ -3,6 +3,7 @@ CoeffSignHideRdo through the C-ABI against (1) the golden vectors captured from
 the reference build (tests/golden/rdoq.npz) and (2) the pinned oracle inside the
 whole TransformAndReconstruct pipeline on random pictures, every block shape."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -158,3 +159,50 @@ def test_gpu_residual_rdoq_pipeline(gpu, bd):
     assert n_coded > len(blocks) // 3
     for p in (O, P, R):
         p.destroy()
+
+
+def test_gpu_all_zero_proof_random_blocks(gpu):
+    """Random blocks around the quantiser's threshold (the generator of
+    tests/test_rdoq_zero_proof.py: sizes 4..32, three scan orders, random context
+    states) through xvcgpu_quant_rdo_batch with the all-zero proof off and forced on:
+    the same levels and counts, equal to the oracle's, and the proof takes blocks off
+    the class lists."""
+    import ctypes as C
+    import test_rdoq_zero_proof as zp
+    api, ctx = gpu
+    xo = ol.Lib("xo")
+    rng = np.random.default_rng(int(os.environ.get("XVC_SOAK", 0)) * 7919 + 4242)
+    for bd in (8, 10, 12):
+        cases = [c for c in zp._cases(rng, 4000) if c[0] == bd]
+        snaps = np.concatenate([oq.random_contexts(rng) for _ in range(8)]).view(api.RDOQ_CTX_DTYPE)
+        # blocks of one snapshot side by side (a workgroup of the proof shares one)
+        order = np.argsort(rng.integers(0, 8, len(cases)), kind="stable")
+        which = np.sort(rng.integers(0, 8, len(cases)))
+        blocks = np.zeros(len(cases), api.TX_DTYPE)
+        params = np.zeros(len(cases), api.RDOQ_PARAMS_DTYPE)
+        off, coeffs, expect = [], [], []
+        for k, j in enumerate(order):
+            _, qp, comp, scan, _, prm, src = cases[j]
+            h, w = src.shape
+            blocks[k] = (0, 0, w, h, comp, 0, 0, 0, qp, api.TXF_RDOQ | (scan << api.TXF_SCAN_SHIFT))
+            params[k] = prm[0]
+            params[k]["ctx_index"] = which[k]
+            off.append(sum(len(c) for c in coeffs))
+            coeffs.append(src.reshape(-1))
+            nnz, lv = oq.quant_rdo_oracle(xo, bd, qp, comp, scan, 1, snaps[which[k]:which[k] + 1],
+                                          params[k:k + 1], src)
+            expect.append((nnz, lv if nnz else np.zeros_like(lv)))
+        listed = []
+        for mode in (0, 1):
+            ctx.set_rdoq_prove_zero(mode)
+            levels, nnz = ctx.quant_rdo_batch(bd, blocks, np.concatenate(coeffs),
+                                              np.array(off, np.uint32), snaps, params)
+            cc = (C.c_int32 * 3)()
+            ctx._check(ctx.lib.xvcgpu_quant_rdo_class_counts(ctx.h, cc))
+            listed.append(sum(cc))
+            for k, (e_nnz, e_lv) in enumerate(expect):
+                h, w = e_lv.shape
+                assert nnz[k] == e_nnz and np.array_equal(
+                    levels[off[k]:off[k] + w * h].reshape(h, w), e_lv), (bd, mode, k, blocks[k])
+        ctx.set_rdoq_prove_zero(-1)
+        assert listed[1] < listed[0], listed
