@@ -1631,3 +1631,50 @@ def test_bench_multi_rank_path_runs(gpu):
     assert d["n_gpus"] == 2 and d["steps"] == 24 and d["scaling"] == "strong"
     assert d["pictures_in_flight"] == 3 and 25.0 < d["psnr_y"] < 60.0
     assert "cu-row-shard2" in d["config"]["parallelism"]
+
+
+@pytest.mark.parametrize("size,qp", [((352, 288), 30), ((1920, 1080), 36)])
+def test_frame_pass_proof_with_random_context_states(gpu, size, qp):
+    """The proof inside the forward kernel with context snapshots other than the
+    picture-initial ones: a frame pass whose quantiser reads random context states,
+    proof off against proof on - levels, counts, CU records and reconstruction equal
+    (the walk itself is held against the oracle with random states in test_gpu_rdoq.py)."""
+    api, ctx = gpu
+    from xvc_amd import pipeline, synth
+    import oracle_rdoq as oq
+    pw, ph = size
+    bd = 10
+    clip = synth.SyntheticClip(pw, ph, bd)
+    rng = np.random.default_rng(int(os.environ.get("XVC_SOAK", 0)) * 7919 + 99)
+    fp = pipeline.FramePass(ctx, pw, ph, bd, qp=qp, rdoq=True)
+    O, R = ctx.picture(pw, ph, bd), ctx.picture(pw, ph, bd)
+    recs = [ctx.picture(pw, ph, bd) for _ in range(2)]
+    R.upload(pad_planes(clip.frame(0), bd), BL)
+    O.upload(pad_planes(clip.frame(1), bd), BL)
+    proved_total = 0
+    for trial in range(3):
+        snap = oq.random_contexts(rng)
+        ctx._check(ctx.lib.xvcgpu_memcpy_h2d(ctx.h, fp.d_rdoq_ctx.ptr, snap.ctypes.data,
+                                             snap.nbytes))
+        out = []
+        for mode, rec in zip((0, -1), recs):
+            ctx.set_rdoq_prove_zero(mode)
+            fp.run(O, R, rec, ref_poc=0)
+            ctx.sync()
+            res, nnz, cus, ssd = fp.results()
+            lv = fp.d_levels.to_array(np.int16, fp.n_levels)
+            cc = (C.c_int32 * 3)()
+            ctx._check(ctx.lib.xvcgpu_quant_rdo_class_counts(ctx.h, cc))
+            out.append((nnz, cus, lv, rec.download(BL), tuple(int(v) for v in ssd), sum(cc)))
+        ctx.set_rdoq_prove_zero(-1)
+        a, b = out
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]), trial
+        assert np.array_equal(a[2], b[2]), trial
+        for c in range(3):
+            assert np.array_equal(a[3][c], b[3][c]), (trial, c)
+        assert a[4] == b[4]
+        proved_total += a[5] - b[5]
+    assert proved_total > 0
+    fp.destroy()
+    for p in [O, R] + recs:
+        p.destroy()
