@@ -136,3 +136,26 @@ def test_picture_parallel_gloo(world, slots, tmp_path):
                 received += 1
     assert len(coded) == 3 * N_PICTURES and received > 0
     assert len({r for r in coded.values()}) == world    # every rank coded something
+
+
+def test_ring_entry_reuse_waits_for_its_writer_and_readers():
+    """GpuPictureEngine._claim: before a ring entry is overwritten the new writer
+    waits for the picture that wrote its previous content - a picture nobody
+    referenced has no reader events, and its slot's stream may still be at work on
+    the entry - and for every reader of it (the ordering rules only; no device)."""
+    e = object.__new__(picture_parallel.GpuPictureEngine)
+    e.ring = 3
+    e.readers = [[] for _ in range(3)]
+    e.holds = [-1] * 3
+    e.ready = ["ready0", "ready1", "ready2"]
+    waited = []
+    assert e._claim(0, waited.append) == 0 and waited == [] and e.holds[0] == 0
+    # picture 3 reuses entry 0, which nobody read: it still waits for picture 0 itself
+    assert e._claim(3, waited.append) == 0 and waited == ["ready0"] and e.holds[0] == 3
+    # with readers: the writer first, then each of them; the list is cleared
+    e.readers[0] = ["reader_a", "send_b"]
+    waited.clear()
+    assert e._claim(6, waited.append) == 0
+    assert waited == ["ready0", "reader_a", "send_b"] and e.readers[0] == []
+    # another entry is untouched
+    assert e.holds[1] == -1 and e._claim(1, waited.append) == 1 and len(waited) == 3
