@@ -58,7 +58,7 @@ def run_shards(ctx, info, pre, post, cus, cu_map, rows, tag):
         for c in range(3):
             a, b = (s.y0, s.y1) if c == 0 else (s.y0 // 2, s.y1 // 2)
             assert np.array_equal(got[c][a:b], post[c][a:b]), (tag, s.rank, c)
-        chains += s.d_top > 8
+        chains += s.d_top > 4          # 4 = the boundary edge alone
         s.e.destroy()
     return chains
 
@@ -71,6 +71,41 @@ def test_ordered_handoff_cif(gpu, world):
         rows = tst.boundaries(int(info["height"]), world)
         chains += run_shards(ctx, info, pre, post, cus, cu_map, rows, ("c0", k))
     assert chains >= 3
+
+
+def test_cut_clears_every_band_gpu(gpu):
+    """The synthetic tree of test_sharded_tree.test_cut_clears_every_band on the HIP
+    engine: a band whose run ends early and starts again across the longest run's
+    end - the sharded filter equals xvcgpu_deblock of the whole picture."""
+    from helpers import make_cus
+    import oracle_lib as ol
+    import torch
+    api, ctx = gpu
+    pw, ph, y0, bd = 64, 128, 64, 10
+    parts = tst._column_tree([[4, 4, 8, 16], [8, 4, 4, 16]], 32, pw, ph, y0)
+    rows = [0, y0, ph]
+    for trial in range(6):
+        rng = np.random.default_rng(900 + trial)
+        cus, cu_map = make_cus(rng, parts, 0, [0], [8], pw, ph)
+        cus["intra"], cus["qp_y"], cus["qp_c"] = 1, 40, ol.chroma_qp(40)
+        pre = []
+        for c in range(3):
+            w, h = (pw, ph) if c == 0 else (pw // 2, ph // 2)
+            base = rng.integers(0, 1 << bd, size=((h + 3) // 4, (w + 3) // 4))
+            p = np.kron(base, np.ones((4, 4), np.int64))[:h, :w] // 8 + 400
+            pre.append(np.clip(p + rng.integers(-3, 4, size=(h, w)), 0, 1023).astype(np.uint16))
+        whole = sharded.GpuTreeEngine(ctx, pw, ph, bd, cus, cu_map, 0, 0, 0,
+                                      torch.device("cuda", 0))
+        whole.picture.upload(pad(pre), BL)
+        whole.deblock_rows(0, 0, ph)
+        whole.deblock_rows(1, 0, ph)
+        ctx.sync()
+        post = whole.picture.download(0)
+        whole.destroy()
+        assert not np.array_equal(post[0], pre[0])
+        info = {"width": pw, "height": ph, "bitdepth": bd, "pic_type": 1, "beta_offset": 0,
+                "tc_offset": 0}
+        assert run_shards(ctx, info, pre, post, cus, cu_map, rows, ("synthetic", trial)) == 1
 
 
 def _decode_variants(ctx, name):

@@ -84,7 +84,7 @@ def boundaries(h, world):
     """CTU-row shards: one row of CTUs (64 luma rows) per rank, the rest of the
     picture to the last rank - for the CIF pictures that puts a boundary on rows
     64 / 128 / 192, where the fixture has 4-tall CUs below the boundary (chains of
-    up to five edges: D = 24)."""
+    up to five interacting edges)."""
     assert h > 64 * (world - 1) + 32
     return [64 * r for r in range(world)] + [h]
 
@@ -116,7 +116,7 @@ def test_ordered_handoff_loopback_matches_reference(world):
             e = OracleTreeEngine(own_rows_only(pre, rows[r], rows[r + 1], 100 * k + r), cus,
                                  cu_map, bd, *args)
             ranks.append(sharded.ShardedTreeFilter(e, LoopbackComm(), r, world, rows))
-        chains += sum(s.d_top > 8 for s in ranks)     # 8 = the boundary edge alone
+        chains += sum(s.d_top > 4 for s in ranks)     # 4 = the boundary edge alone
         for s in ranks:
             s.step_local()
         LoopbackComm.exchange_all({s.rank: s.ops_down() for s in ranks})
@@ -176,3 +176,79 @@ def test_ordered_handoff_gloo(world):
     for p in procs:
         p.join(timeout=60)
     assert sorted(res) == [(r, []) for r in range(world)], res
+
+
+def _column_tree(heights_by_band, band_w, pic_w, pic_h, y0):
+    """CUs of a synthetic tree: above y0 one 64-tall row of 64-wide CUs, below it
+    every `band_w`-wide band is a stack of CUs with the given heights (the rest of
+    the band one CU)."""
+    parts = [(x, y, 64, 64) for y in range(0, y0, 64) for x in range(0, pic_w, 64)]
+    for b, x in enumerate(range(0, pic_w, band_w)):
+        y = y0
+        for hgt in heights_by_band[b % len(heights_by_band)]:
+            parts.append((x, y, band_w, hgt))
+            y += hgt
+        if y < pic_h:
+            parts.append((x, y, band_w, pic_h - y))
+    return parts
+
+
+def test_cut_clears_every_band():
+    """one band's run of 4-spaced edges ends (heights 4, 4, 8, 16:
+    edges 64, 68, 72 -> the old cut at 80) while another band's CUs of heights 8,
+    4, 4, 16 put edges at 72, 76 AND 80 - an interacting pair straddling that cut.
+    The cut has to be the first row no band straddles; with it the sharded filter
+    equals the unsharded one, sample for sample."""
+    from helpers import make_cus
+    pw, ph, y0, bd = 64, 128, 64, 10
+    parts = _column_tree([[4, 4, 8, 16], [8, 4, 4, 16]], 32, pw, ph, y0)
+    rows = [0, y0, ph]
+    for trial in range(20):
+        rng = np.random.default_rng(900 + trial)
+        cus, cu_map = make_cus(rng, parts, 0, [0], [8], pw, ph)
+        cus["intra"] = 1                      # BS 2 everywhere: every candidate edge filters
+        cus["qp_y"] = 40
+        cus["qp_c"] = ol.chroma_qp(40)
+        ok, d = sharded.shard_plan(cu_map, 2, rows)
+        assert ok and d == [0, 20], d         # edges 76 / 80 clash at 80, 84 is clear
+        pre = []
+        for c in range(3):
+            w, h = (pw, ph) if c == 0 else (pw // 2, ph // 2)
+            base = rng.integers(0, 1 << bd, size=((h + 3) // 4, (w + 3) // 4))
+            p = np.kron(base, np.ones((4, 4), np.int64))[:h, :w] // 8 + 400
+            pre.append(np.clip(p + rng.integers(-3, 4, size=(h, w)), 0, 1023).astype(np.uint16))
+        whole = OracleTreeEngine(pre, cus, cu_map, bd, 0, 0, 0)
+        whole.deblock_rows(0, 0, ph)
+        whole.deblock_rows(1, 0, ph)
+        assert any(not np.array_equal(whole.view(c), pre[c]) for c in range(3))
+        ranks = [sharded.ShardedTreeFilter(
+            OracleTreeEngine(own_rows_only(pre, rows[r], rows[r + 1], trial * 2 + r), cus, cu_map,
+                             bd, 0, 0, 0), LoopbackComm(), r, 2, rows) for r in range(2)]
+        for s in ranks:
+            s.step_local()
+        LoopbackComm.exchange_all({s.rank: s.ops_down() for s in ranks})
+        for s in ranks:
+            s.step_strip()
+        LoopbackComm.exchange_all({s.rank: s.ops_up() for s in ranks})
+        for s in ranks:
+            for c in range(3):
+                a, b = (s.y0, s.y1) if c == 0 else (s.y0 // 2, s.y1 // 2)
+                assert np.array_equal(s.e.view(c)[a:b], whole.view(c)[a:b]), (trial, s.rank, c)
+
+
+def test_plan_is_the_same_verdict_on_every_rank():
+    """A shard shorter than the chain entering it: every rank refuses (nobody is left
+    waiting in a send / receive group), and says so before any transfer."""
+    from helpers import make_cus
+    pw, ph = 64, 192
+    parts = _column_tree([[4] * 16], 64, pw, ph, 64)      # edges 64 ... 128: crosses row 128
+    rng = np.random.default_rng(5)
+    cus, cu_map = make_cus(rng, parts, 0, [0], [8], pw, ph)
+    ok, d = sharded.shard_plan(cu_map, 3, [0, 64, 128, 192])
+    assert not ok and d[1] == 68
+    for r in range(3):
+        with pytest.raises(ValueError):
+            sharded.ShardedTreeFilter(type("E", (), {"cu_map": cu_map, "w": pw, "h": ph})(),
+                                      LoopbackComm(), r, 3, [0, 64, 128, 192])
+    ok, d = sharded.shard_plan(cu_map, 2, [0, 64, 192])
+    assert ok and d == [0, 68]

@@ -89,8 +89,11 @@ intra_waves_kernel(PicView rec, PicView pred, const xvcgpu_intra_block *jobs,
             (uint16_t)d_clip3((int)pblk[y * bw + x] + r, 0, smax);
       }
     }
-    // the block is in memory (one lane writes the L2's dirty lines back) before the
-    // wave's counter says so
+    // the block is in memory before the wave's counter says so.  A workgroup
+    // barrier does not wait for the OTHER waves' outstanding stores: every wave
+    // drains its own (vmcnt counts per wave) in front of the barrier; behind it one
+    // lane writes the L2's dirty lines back for all of them
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");

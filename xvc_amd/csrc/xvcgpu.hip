@@ -2017,22 +2017,35 @@ xvcgpu_status xvcgpu_frame_pass_multi(xvcgpu_ctx *const *ctxs,
       if (!ctxs[i] || !args[i]) return XVCGPU_INVALID_ARGUMENT;
       const bool foreign = ctxs[i]->stream != ctx->stream;
       hipEvent_t before = nullptr, after = nullptr;
-      if (foreign) {
-        HIP_TRY(ctx, hipSetDevice(ctx->device));
-        HIP_TRY(ctx, hipEventCreateWithFlags(&before, hipEventDisableTiming));
-        HIP_TRY(ctx, hipEventCreateWithFlags(&after, hipEventDisableTiming));
-        HIP_TRY(ctx, hipEventRecord(before, ctx->stream));
-        HIP_TRY(ctx, hipStreamWaitEvent(ctxs[i]->stream, before, 0));
+      // an event belongs to the device that was current when it was created and
+      // can only be recorded on that device's streams: `before` is ctxs[0]'s,
+      // `after` the picture's own (contexts on another device are exactly what
+      // sends a call down this path); both are destroyed on every way out
+      auto fence_in = [&]() -> hipError_t {
+        hipError_t e = hipSetDevice(ctx->device);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&before, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventRecord(before, ctx->stream);
+        if (e == hipSuccess) e = hipSetDevice(ctxs[i]->device);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&after, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipStreamWaitEvent(ctxs[i]->stream, before, 0);
+        return e;
+      };
+      auto fence_out = [&]() -> hipError_t {
+        hipError_t e = hipSetDevice(ctxs[i]->device);
+        if (e == hipSuccess) e = hipEventRecord(after, ctxs[i]->stream);
+        if (e == hipSuccess) e = hipSetDevice(ctx->device);
+        if (e == hipSuccess) e = hipStreamWaitEvent(ctx->stream, after, 0);
+        return e;
+      };
+      hipError_t herr = foreign ? fence_in() : hipSuccess;
+      xvcgpu_status st = XVCGPU_OK;
+      if (herr == hipSuccess) {
+        st = xvcgpu_frame_pass(ctxs[i], args[i], phases);
+        if (foreign && st == XVCGPU_OK) herr = fence_out();
       }
-      const xvcgpu_status st = xvcgpu_frame_pass(ctxs[i], args[i], phases);
-      if (foreign) {
-        if (st == XVCGPU_OK) {
-          HIP_TRY(ctx, hipEventRecord(after, ctxs[i]->stream));
-          HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, after, 0));
-        }
-        hipEventDestroy(before);   // released when the recorded work has passed them
-        hipEventDestroy(after);
-      }
+      if (before) hipEventDestroy(before);   // released when the recorded work has passed them
+      if (after) hipEventDestroy(after);
+      HIP_TRY(ctx, herr);
       if (st != XVCGPU_OK) return st;
     }
     return XVCGPU_OK;

@@ -10,9 +10,14 @@
 // form where CUs are 4 tall (common.h:99).  The edge ON a shard boundary y0 reads
 // four rows of each side, and a chain may run on from it into the lower shard.
 //
-//   rank r owns rows [y0, y1).  From the CU map it derives D = 4 * (m + 1), m =
-//   the longest run of candidate edges y0, y0 + 4, ... in any band (0 when the CUs
-//   at the boundary are at least 8 tall; ChainRows below).  Then:
+//   rank r owns rows [y0, y1).  From the CU map it derives the cut S = y0 + D: the
+//   first multiple of 4 below y0 at which NO 4-column band has candidate edges at
+//   both S - 4 and S (D = 4 when the CUs under the boundary are at least 8 tall;
+//   xvc_shard_chain_rows below).  Edges further than 4 rows apart touch disjoint
+//   rows, so the edges >= S and the edges < S commute.  (The longest run of
+//   4-spaced edges starting AT y0 is not enough: a band whose run ends earlier can
+//   start a new one that straddles that cut - round 3's rule, found by the
+//   advisor, test_cut_clears_every_band.)  Then:
 //     1. pass 0 on [y0, y1)
 //     2. pass 1 on the edges [y0 + D, y1): nothing they read or write is touched
 //        by the boundary edge's chain (rank 0: from row 0)
@@ -24,7 +29,9 @@
 //        back to rank r - 1;  rows [y1 - 4, y1) back from rank r + 1
 //   Exact for every CU tree (no assumption on CU heights); two small exchanges
 //   per picture instead of scheme B's one; no rank waits for more than its upper
-//   neighbour's step 2.  Requires y0 + D <= y1 - 4 (a shard taller than its chain).
+//   neighbour's step 2.  Requires y0 + D <= y1 - 4 (a shard taller than its chain);
+//   every rank checks EVERY boundary (xvc_shard_plan: all ranks hold the CU map and
+//   reach the same verdict before the first transfer).
 //
 // ChainRows is host arithmetic on the CU map (also what the engine-agnostic
 // Python mirror xvc_amd/sharded.ShardedTreeFilter and its CPU tests use);
@@ -41,6 +48,12 @@ extern "C" {
 // D for the boundary at luma row y0 (a multiple of 4, 0 < y0 < pic_h): cu_map as
 // xvcgpu_deblock takes it (one int32 per 4x4 luma cell, -1 = no CU).
 int xvc_shard_chain_rows(const int32_t *cu_map, int map_stride, int pic_w, int pic_h, int y0);
+
+// D of every boundary (d_top[r] for rank r's upper boundary, d_top[0] = 0; d_top may
+// be NULL): XVCGPU_OK, or XVCGPU_UNSUPPORTED when some shard is shorter than the
+// chain entering it - the same answer on every rank.
+int xvc_shard_plan(const int32_t *cu_map, int map_stride, int world, const int32_t *rows,
+                   int32_t *d_top);
 
 // Steps 1-5 for one picture on rank `rank` of `world` (comm may be NULL when world
 // == 1): rows[r] .. rows[r + 1] are rank r's rows (multiples of 16), d_* the

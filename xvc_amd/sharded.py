@@ -376,6 +376,22 @@ def chain_rows(cu_map, pic_w, pic_h, y0):
     return int(lib.xvc_shard_chain_rows(m.ctypes.data, m.shape[1], pic_w, pic_h, y0))
 
 
+def shard_plan(cu_map, world, rows):
+    """(all shards taller than their chains?, [D of every rank's upper boundary])
+    - xvc_shard_plan of the C++ layer."""
+    import ctypes as C
+    from . import decoder
+    lib = decoder.load_host_library()
+    m = np.ascontiguousarray(cu_map, np.int32)
+    r = (C.c_int32 * (world + 1))(*[int(v) for v in rows])
+    d = (C.c_int32 * world)()
+    lib.xvc_shard_plan.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    st = int(lib.xvc_shard_plan(m.ctypes.data, m.shape[1], world, r, d))
+    if st not in (0, 50):               # XVCGPU_OK, XVCGPU_UNSUPPORTED (include/xvcgpu.h)
+        raise ValueError("xvc_shard_plan: status %d" % st)
+    return st == 0, list(d)
+
+
 class ShardedTreeFilter:
     """The in-loop filter of a picture with a REAL CU tree (binary splits down to
     4-tall CUs), sharded by CTU rows: SURVEY 8e scheme (A), the ordered hand-off -
@@ -395,10 +411,13 @@ class ShardedTreeFilter:
         self.y0, self.y1 = rows[rank], rows[rank + 1]
         self.up = rank - 1 if rank > 0 else None
         self.down = rank + 1 if rank < world - 1 else None
-        self.d_top = chain_rows(engine.cu_map, engine.w, engine.h, self.y0) \
-            if self.up is not None else 0
-        assert self.down is None or self.y0 + self.d_top <= self.y1 - self.HALO, \
-            "a shard must be taller than the chain that enters it"
+        # every rank plans every boundary: the same verdict everywhere, before the
+        # first transfer (xvc_shard_plan)
+        ok, d_all = shard_plan(engine.cu_map, world, rows)
+        if not ok:
+            raise ValueError("a shard must be taller than the chain that enters it "
+                             "(rows %r, chains %r)" % (list(rows), d_all))
+        self.d_top = d_all[rank]
 
     def step_local(self):
         self.e.deblock_rows(0, self.y0, self.y1)
