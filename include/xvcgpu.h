@@ -175,6 +175,12 @@ xvcgpu_status xvcgpu_host_alloc(xvcgpu_ctx *ctx, size_t bytes, void **host_ptr);
 xvcgpu_status xvcgpu_host_free(xvcgpu_ctx *ctx, void *host_ptr);
 xvcgpu_status xvcgpu_memcpy_h2d_async(xvcgpu_ctx *ctx, void *dst, const void *src,
                                       size_t bytes);
+/* The read-back that does not wait: queued on the context's stream behind the
+ * kernels that produce `src`; `dst` (page-locked, or the call may block) holds the
+ * bytes once xvcgpu_sync / an event recorded after the call has completed.  Several
+ * result arrays of one step are fetched with one wait. */
+xvcgpu_status xvcgpu_memcpy_d2h_async(xvcgpu_ctx *ctx, void *dst, const void *src,
+                                      size_t bytes);
 
 /* ---- pictures ----------------------------------------------------------- *
  * Device twin of YuvPicture (yuv_pic.cc:32-68): planar Y,U,V of 16-bit

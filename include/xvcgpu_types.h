@@ -300,6 +300,37 @@ typedef struct xvcgpu_rdoq_params {
   uint8_t reserved[5];
 } xvcgpu_rdoq_params;
 
+/* ---- the bits of a CU's inter prediction syntax ------------------------------ *
+ * InterSearch::GetInterPredBits as the encoder runs it by default
+ * (inter_search.cc:1131-1135, fast_inter_pred_bits == 0): the candidate's
+ * CuWriter::WriteInterPrediction (cu_writer.cc:122-172) through a throw-away
+ * RdoSyntaxWriter - every context-coded bin costs
+ * ContextModel::kEntropyBits_[state ^ bin] and moves its context on
+ * (entropy_encoder.cc:44-51), bypass bins cost 1 << 15, the result is the sum
+ * >> 15.  The entropy coder enters only through the states of the eleven contexts
+ * the syntax of ONE CU reads: the host snapshots them (ContextModel::state_) when
+ * it hands the CU over; the neighbour / size dependent selections
+ * (cabac.cc:361-371, :464-489) are made by the host. */
+#define XVC_ICTX_PIC_BI 1      /* bi-predictive picture: the inter direction is coded */
+#define XVC_ICTX_CAN_AFFINE 2  /* cu.CanUseAffine(): the affine flag is coded          */
+#define XVC_ICTX_PIC_LIC 4     /* the picture uses local illumination compensation    */
+typedef struct xvcgpu_inter_contexts {
+  uint8_t merge_flag;    /* inter_merge_flag[0]                                       */
+  uint8_t inter_dir_bi;  /* GetInterDirBiCtx(cu)                                      */
+  uint8_t inter_dir_l;   /* inter_dir[4]                                              */
+  uint8_t affine_flag;   /* GetAffineCtx(cu)                                          */
+  uint8_t ref_idx[2];    /* inter_ref_idx[0..1]                                       */
+  uint8_t mvd[2];        /* inter_mvd[0..1]                                           */
+  uint8_t mvp_idx;       /* inter_mvp_idx[0]                                          */
+  uint8_t fullpel_mv;    /* GetInterFullpelMvCtx(cu)                                  */
+  uint8_t lic_flag;      /* lic_flag[0]                                               */
+  uint8_t flags;         /* XVC_ICTX_*                                                */
+  uint8_t num_refs[2];   /* pictures per list                                         */
+  uint16_t frac_bits;    /* bitstream_writer.GetFractionalBits(): the throw-away writer
+                          * starts from the live coder's fraction of a bit
+                          * (syntax_writer.cc:861-865, entropy_encoder.cc:33-38)      */
+} xvcgpu_inter_contexts;
+
 /* One motion-compensation job (InterPrediction::MotionCompensationMv,
  * inter_prediction.cc:740-758) for one component of one uni-pred CU. */
 typedef struct xvcgpu_mc_block {

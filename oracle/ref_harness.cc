@@ -68,6 +68,14 @@
 namespace xvc {
 class ObservedTzSearch;
 }
+/* round 4: one counter over ALL capture tables (tools/gen_order_golden.py): the
+ * order in which the encoder's RD search issued the calls, across tables. */
+namespace xr_seq {
+extern uint32_t g_next;
+extern std::vector<uint32_t> g_of[7];   /* 0 me calls, 1 steps, 2 merges, 3 evals, 4 calls,
+                                          * 5 cands, 6 finals */
+inline void Stamp(int table) { g_of[table].push_back(g_next++); }
+}  // namespace xr_seq
 namespace xr_me {
 struct Call {
   int32_t poc, ref_poc;
@@ -132,11 +140,18 @@ template <typename MV, size_t N>
 void AfterMotionEst(xvc::InterSearch *is, xvc::CodingUnit *cu, const xvc::Qp &qp,
                     xvc::RefPicList ref_list, int ref_idx, bool bipred,
                     const std::array<MV, N> &mvp_list, const MV *boot, const MV &mv,
-                    xvc::Distortion dist);
+                    xvc::Distortion dist, const xvc::SyntaxWriter &writer, int mvp_idx);
 template <typename MV, size_t N>
 inline void AfterMotionEst(xvc::InterSearch *, xvc::CodingUnit *, const xvc::Qp &,
                            xvc::RefPicList, int, bool, const std::array<MV, N> &, const MV *,
-                           const xvc::XrNone &, const xvc::XrNone &) {}
+                           const xvc::XrNone &, const xvc::XrNone &, const xvc::SyntaxWriter &,
+                           int) {}
+/* round 4: the END of SearchMotion (inter_search.cc:247-257) - its three-way choice
+ * loads one of three saved states with cu->LoadStateFrom(state_bi / state_l0 /
+ * state_l1_unique_poc); the macro below follows every LoadStateFrom statement of
+ * the file with this hook, which looks at the argument's spelling and records the
+ * CU's motion state after those three. */
+void AfterLoadState(xvc::InterSearch *is, xvc::CodingUnit *cu, const char *what);
 void AfterMergeSort(xvc::InterSearch *is, xvc::CodingUnit *cu, const xvc::Qp &qp,
                     const xvc::InterMergeCandidateList &merge_list,
                     const std::array<std::pair<int, double>, 5> &cand_cost);
@@ -150,7 +165,11 @@ uint32_t Crc32(uint32_t crc, const void *data, size_t n);
 }  // namespace xr_rd
 #define SetMvpIdx(i, l) \
   SetMvpIdx(i, l);      \
-  xr_rd::AfterMotionEst(this, cu, qp, ref_list, ref_idx, bipred, mvp_list, mv_bootstrap, mv, dist)
+  xr_rd::AfterMotionEst(this, cu, qp, ref_list, ref_idx, bipred, mvp_list, mv_bootstrap, mv, dist, \
+                        bitstream_writer, mvp_idx)
+#define LoadStateFrom(...)      \
+  LoadStateFrom(__VA_ARGS__);   \
+  xr_rd::AfterLoadState(this, cu, #__VA_ARGS__)
 #define stable_sort(a, b, c) \
   stable_sort(a, b, c);      \
   xr_rd::AfterMergeSort(this, cu, qp, merge_list, cand_cost)
@@ -160,6 +179,7 @@ uint32_t Crc32(uint32_t crc, const void *data, size_t n);
 #undef TzSearch
 #undef SetMvpIdx
 #undef stable_sort
+#undef LoadStateFrom
 /* TransformEncoder::TransformAndReconstruct: after its quantiser call
  * (fwd_quant_.QuantRdo(...), transform_encoder.cc:231-234) the hook records the
  * call - CU, component, transform choice, the CU's motion state, the context
@@ -2024,6 +2044,11 @@ const uint32_t *xr_entropy_bits_table(void) { return &ContextModel::kEntropyBits
 
 }  /* extern "C" (reopened below) */
 
+namespace xr_seq {
+uint32_t g_next = 0;
+std::vector<uint32_t> g_of[7];
+}  // namespace xr_seq
+
 namespace xr_me {
 bool g_capture = false;
 int g_only_poc = -1;
@@ -2088,6 +2113,7 @@ MvFullpel ObservedTzSearch::Search(const CodingUnit &cu, const Qp &qp, const Sam
   c.mv_y = mv.y;
   c.dist = static_cast<uint32_t>(dist);
   xr_me::g_calls.push_back(c);
+  xr_seq::Stamp(0);
   return best;
 }
 }  // namespace xvc
@@ -2098,6 +2124,7 @@ extern "C" {
  * then run an encode (xr_stream_encode), then read the records. */
 void xr_me_capture_begin(int only_poc) {
   xr_me::g_calls.clear();
+  xr_seq::g_of[0].clear();
   xr_me::g_also_poc.clear();
   xr_me::g_only_poc = only_poc;
   xr_me::g_capture = true;
@@ -2277,6 +2304,48 @@ struct TxCall {            /* one TransformAndReconstruct */
   uint64_t dist;           /* the returned distortion (completed calls) */
 };
 
+/* round 4: every candidate SearchRefIdx prices (inter_search.cc:556-571) - uni
+ * searches, list 1's re-use of list 0's result, bi-prediction steps, affine - with
+ * the bits GetInterPredBits returned for it through the throw-away RdoSyntaxWriter
+ * (:1131-1135, the default: fast_inter_pred_bits == 0) and the context states
+ * CuWriter::WriteInterPrediction (cu_writer.cc:122-172) read for this CU. */
+struct Cand {
+  int32_t poc;
+  int16_t x, y;
+  uint8_t w, h, kind, flags;   /* kind: 0 uni, kBi, kAffineUni, kAffineBi; flags as MeStep */
+  uint8_t list;
+  int8_t ref_idx;
+  uint8_t reused;              /* list 1 took list 0's result (:536-542) */
+  uint8_t mvp_idx;             /* after EvalFinalMvpIdx */
+  uint8_t inter_dir;           /* cu->GetInterDir() while the bits were written */
+  int8_t other_ref_idx;        /* bi: the other list's picture */
+  uint8_t other_mvp_idx, force_mvd_zero_other;
+  int32_t mv[3][2];
+  int32_t mvp[2][3][2];        /* the list's two predictors (GetMvpList; [k][0] plain) */
+  uint8_t start_mvp_idx;       /* uni: EvalStartMvp's choice; bi: the uni search's final one */
+  uint8_t pad[3];
+  int32_t other_mvd[2][2];     /* bi: the other list's mvd(s) (affine: two corners) */
+  uint32_t dist;
+  uint32_t bits;               /* GetInterPredBits(*cu, bitstream_writer) */
+  uint32_t lambda16;
+  int32_t ictx_index;          /* which InterContexts snapshot */
+};
+struct Final {                 /* the CU's motion state as SearchMotion returns it */
+  int32_t poc;
+  int16_t x, y;
+  uint8_t w, h, which, flags;  /* which: 0 bi, 1 list 0, 2 list 1 (unique picture) */
+  uint8_t inter_dir;
+  int8_t ref_idx[2];
+  uint8_t mvp_idx[2];
+  uint8_t pad[3];
+  int32_t mv[2][3][2];
+  int32_t mvd[2][2][2];
+};
+std::vector<Cand> g_cands;
+std::vector<Final> g_finals;
+std::vector<xvcgpu_inter_contexts> g_ictx;
+std::unordered_map<std::string, int> g_ictx_index;
+
 bool g_capture = false;
 int g_only_poc = -1;
 std::vector<MeStep> g_steps;
@@ -2400,12 +2469,106 @@ static int NeighbourIndex(const CodingUnit &cu, const YuvPicture &rec_pic, bool 
   return idx;
 }
 
+static int InterContextIndex(const CodingUnit &cu, const SyntaxWriter &writer) {
+  Contexts &ctx = const_cast<Contexts &>(writer.GetContexts());
+  xvcgpu_inter_contexts c;
+  std::memset(&c, 0, sizeof(c));
+  c.merge_flag = ctx.inter_merge_flag[0].state_;
+  c.inter_dir_bi = ctx.GetInterDirBiCtx(cu).state_;
+  c.inter_dir_l = ctx.inter_dir[4].state_;
+  c.affine_flag = ctx.GetAffineCtx(cu).state_;
+  c.ref_idx[0] = ctx.inter_ref_idx[0].state_;
+  c.ref_idx[1] = ctx.inter_ref_idx[1].state_;
+  c.mvd[0] = ctx.inter_mvd[0].state_;
+  c.mvd[1] = ctx.inter_mvd[1].state_;
+  c.mvp_idx = ctx.inter_mvp_idx[0].state_;
+  c.fullpel_mv = ctx.GetInterFullpelMvCtx(cu).state_;
+  c.lic_flag = ctx.lic_flag[0].state_;
+  const PictureData *pd = cu.GetPicData();
+  c.flags = static_cast<uint8_t>(
+      (pd->GetPredictionType() == PicturePredictionType::kBi ? XVC_ICTX_PIC_BI : 0) |
+      (cu.CanUseAffine() ? XVC_ICTX_CAN_AFFINE : 0) |
+      (pd->GetUseLocalIlluminationCompensation() ? XVC_ICTX_PIC_LIC : 0));
+  c.num_refs[0] = static_cast<uint8_t>(pd->GetRefPicLists()->GetNumRefPics(RefPicList::kL0));
+  c.num_refs[1] = static_cast<uint8_t>(pd->GetRefPicLists()->GetNumRefPics(RefPicList::kL1));
+  c.frac_bits = static_cast<uint16_t>(writer.GetFractionalBits());
+  std::string key(reinterpret_cast<const char *>(&c), sizeof(c));
+  auto it = g_ictx_index.find(key);
+  if (it != g_ictx_index.end()) return it->second;
+  const int idx = static_cast<int>(g_ictx.size());
+  g_ictx.push_back(c);
+  g_ictx_index.emplace(key, idx);
+  return idx;
+}
+
+static void PutMvd(int32_t out[2][2], const CodingUnit &cu, RefPicList l) {
+  if (cu.GetUseAffine()) {
+    for (int k = 0; k < 2; k++) {
+      out[k][0] = cu.GetMvdAffine(k, l).x;
+      out[k][1] = cu.GetMvdAffine(k, l).y;
+    }
+  } else {
+    out[0][0] = cu.GetMvDelta(l).x;
+    out[0][1] = cu.GetMvDelta(l).y;
+  }
+}
+
 template <typename MV, size_t N>
 void AfterMotionEst(InterSearch *is, CodingUnit *cu, const Qp &qp, RefPicList ref_list,
                     int ref_idx, bool bipred, const std::array<MV, N> &mvp_list, const MV *boot,
-                    const MV &mv, Distortion dist) {
+                    const MV &mv, Distortion dist, const SyntaxWriter &writer, int mvp_idx) {
   if (!Wanted(*cu)) return;
   const bool affine = std::is_same<MV, MotionVector3>::value;
+  {
+    /* the candidate's price: the two statements that follow the hooked one
+     * (:557-558, SetMv and SetMvd) applied here first - the reference repeats them
+     * with the same arguments - then the reference's own GetInterPredBits, which
+     * works on a throw-away copy of the entropy coder */
+    cu->SetMv(mv, ref_list);
+    is->SetMvd(cu, ref_list, mvp_list[mvp_idx], mv);
+    const YuvComponent luma = YuvComponent::kY;
+    Cand c;
+    std::memset(&c, 0, sizeof(c));
+    c.poc = static_cast<int32_t>(cu->GetPicData()->GetPoc());
+    c.x = static_cast<int16_t>(cu->GetPosX(luma));
+    c.y = static_cast<int16_t>(cu->GetPosY(luma));
+    c.w = static_cast<uint8_t>(cu->GetWidth(luma));
+    c.h = static_cast<uint8_t>(cu->GetHeight(luma));
+    c.kind = static_cast<uint8_t>(affine ? (bipred ? kAffineBi : kAffineUni) : (bipred ? kBi : 0));
+    c.flags = static_cast<uint8_t>((cu->GetFullpelMv() ? kFlagFullpel : 0) |
+                                   (cu->GetUseLic() ? kFlagLic : 0));
+    c.list = static_cast<uint8_t>(ref_list);
+    c.ref_idx = static_cast<int8_t>(ref_idx);
+    c.reused = !bipred && ref_list == RefPicList::kL1 && is->same_poc_in_l0_mapping_[ref_idx] >= 0;
+    c.mvp_idx = static_cast<uint8_t>(mvp_idx);
+    c.inter_dir = static_cast<uint8_t>(cu->GetInterDir());
+    c.other_ref_idx = -1;
+    if (bipred) {
+      const RefPicList other = ReferencePictureLists::Inverse(ref_list);
+      c.other_ref_idx = static_cast<int8_t>(cu->GetRefIdx(other));
+      c.other_mvp_idx = static_cast<uint8_t>(cu->GetMvpIdx(other));
+      c.force_mvd_zero_other = cu->GetForceMvdZero(other);
+      PutMvd(c.other_mvd, *cu, other);
+    }
+    PutMv(c.mv, mv);
+    for (size_t k = 0; k < N && k < 2; k++) PutMv(c.mvp[k], mvp_list[k]);
+    if (bipred) {
+      c.start_mvp_idx = static_cast<uint8_t>(is->unipred_best_mvp_idx_[static_cast<int>(ref_list)][ref_idx]);
+    } else if (!c.reused) {
+      /* EvalStartMvp's choice (:493-496) asked again: a pure function of CU,
+       * predictors and pictures (scratch prediction buffer) */
+      SampleBufferStorage scratch(constants::kMaxBlockSize, constants::kMaxBlockSize);
+      Distortion cost = 0;
+      c.start_mvp_idx = static_cast<uint8_t>(is->EvalStartMvp<std::is_same<MV, MotionVector3>::value>(
+          *cu, qp, mvp_list, *cu->GetRefPicLists()->GetRefPic(ref_list, ref_idx), &scratch, &cost));
+    }
+    c.dist = static_cast<uint32_t>(dist);
+    c.bits = static_cast<uint32_t>(is->GetInterPredBits(*cu, writer));
+    c.lambda16 = static_cast<uint32_t>(std::floor(65536.0 * qp.GetLambdaSqrt()));
+    c.ictx_index = InterContextIndex(*cu, writer);
+    g_cands.push_back(c);
+    xr_seq::Stamp(5);
+  }
   if (!bipred && !affine) return;   /* the TZ searches are tools/gen_me_golden.py's */
   const int li = static_cast<int>(ref_list);
   if (!bipred && ref_list == RefPicList::kL1 && is->same_poc_in_l0_mapping_[ref_idx] >= 0)
@@ -2453,16 +2616,51 @@ void AfterMotionEst(InterSearch *is, CodingUnit *cu, const Qp &qp, RefPicList re
   s.dist = static_cast<uint32_t>(dist);
   s.nb_index = bipred ? NeighbourIndex(*cu, is->rec_pic_) : -1;
   g_steps.push_back(s);
+  xr_seq::Stamp(1);
+}
+
+void AfterLoadState(InterSearch *, CodingUnit *cu, const char *what) {
+  if (!Wanted(*cu)) return;
+  const int which = !std::strcmp(what, "state_bi") ? 0 : !std::strcmp(what, "state_l0") ? 1 :
+                    !std::strcmp(what, "state_l1_unique_poc") ? 2 : -1;
+  if (which < 0) return;
+  const YuvComponent luma = YuvComponent::kY;
+  Final f;
+  std::memset(&f, 0, sizeof(f));
+  f.poc = static_cast<int32_t>(cu->GetPicData()->GetPoc());
+  f.x = static_cast<int16_t>(cu->GetPosX(luma));
+  f.y = static_cast<int16_t>(cu->GetPosY(luma));
+  f.w = static_cast<uint8_t>(cu->GetWidth(luma));
+  f.h = static_cast<uint8_t>(cu->GetHeight(luma));
+  f.which = static_cast<uint8_t>(which);
+  f.flags = static_cast<uint8_t>((cu->GetFullpelMv() ? kFlagFullpel : 0) |
+                                 (cu->GetUseLic() ? kFlagLic : 0) |
+                                 (cu->GetUseAffine() ? kFlagAffine : 0));
+  f.inter_dir = static_cast<uint8_t>(cu->GetInterDir());
+  for (int l = 0; l < 2; l++) {
+    const RefPicList rl = static_cast<RefPicList>(l);
+    const bool used = cu->GetInterDir() == InterDir::kBi || static_cast<int>(cu->GetInterDir()) == l;
+    f.ref_idx[l] = static_cast<int8_t>(used ? cu->GetRefIdx(rl) : -1);
+    if (!used) continue;
+    f.mvp_idx[l] = static_cast<uint8_t>(cu->GetMvpIdx(rl));
+    if (cu->GetUseAffine())
+      PutMv(f.mv[l], cu->GetMvAffine(rl));
+    else
+      PutMv(f.mv[l], cu->GetMv(rl, MvCorner::kDefault));
+    PutMvd(f.mvd[l], *cu, rl);
+  }
+  g_finals.push_back(f);
+  xr_seq::Stamp(6);
 }
 template void AfterMotionEst<MotionVector, 2>(InterSearch *, CodingUnit *, const Qp &, RefPicList,
                                               int, bool, const std::array<MotionVector, 2> &,
                                               const MotionVector *, const MotionVector &,
-                                              Distortion);
+                                              Distortion, const SyntaxWriter &, int);
 template void AfterMotionEst<MotionVector3, 2>(InterSearch *, CodingUnit *, const Qp &,
                                                RefPicList, int, bool,
                                                const std::array<MotionVector3, 2> &,
                                                const MotionVector3 *, const MotionVector3 &,
-                                               Distortion);
+                                               Distortion, const SyntaxWriter &, int);
 
 void AfterMergeSort(InterSearch *is, CodingUnit *cu, const Qp &qp,
                     const InterMergeCandidateList &merge_list,
@@ -2501,6 +2699,7 @@ void AfterMergeSort(InterSearch *is, CodingUnit *cu, const Qp &qp,
   for (int k = 0; k < 5; k++) any_lic |= m.use_lic[k] != 0;
   m.nb_index = any_lic ? NeighbourIndex(*cu, is->rec_pic_, true) : -1;
   g_merges.push_back(m);
+  xr_seq::Stamp(2);
 }
 
 static int ContextIndex(const SyntaxWriter &writer) {
@@ -2578,6 +2777,7 @@ static int EvalIndex(const CodingUnit &cu, const Qp &qp, const SyntaxWriter &wri
     if (std::memcmp(&last, &e, sizeof(e)) == 0) return static_cast<int>(g_evals.size()) - 1;
   }
   g_evals.push_back(e);
+  xr_seq::Stamp(3);
   return static_cast<int>(g_evals.size()) - 1;
 }
 
@@ -2666,6 +2866,7 @@ void AfterQuantRdo(TransformEncoder *te, CodingUnit *cu, YuvComponent comp, cons
     crc = Crc32(crc, coeff.GetDataPtr() + y * coeff.GetStride(), sizeof(Coeff) * w);
   t.levels_crc = crc;
   g_calls.push_back(t);
+  xr_seq::Stamp(4);
   g_pending_cu = cu;
   g_pending_call = static_cast<int>(g_calls.size()) - 1;
 }
@@ -2837,6 +3038,11 @@ void xr_rd_capture_begin(int only_poc) {
   g_itx_stride = 0;
   g_itx_seen = 0;
   g_pending_itx = -1;
+  g_cands.clear();
+  g_finals.clear();
+  g_ictx.clear();
+  g_ictx_index.clear();
+  for (int t = 1; t < 7; t++) xr_seq::g_of[t].clear();
   g_steps.clear();
   g_merges.clear();
   g_evals.clear();
@@ -2855,7 +3061,9 @@ void xr_rd_capture_begin(int only_poc) {
 }
 void xr_rd_capture_end(void) { xr_rd::g_capture = false; }
 /* which: 0 MeStep, 1 MergeCall, 2 Eval, 3 QpParams, 4 TxCall, 5 contexts, 6 Neighbours,
- * 7 their samples, 8 (count only) transform calls of intra CUs, not kept */
+ * 7 their samples, 8 (count only) transform calls of intra CUs, not kept; round 4:
+ * 11 Cand, 12 Final, 13 inter-prediction context snapshots, 20 + t: the global
+ * sequence numbers of table t (xr_seq: 0 me calls ... 6 finals) */
 long xr_rd_count(int which) {
   using namespace xr_rd;  // NOLINT
   switch (which) {
@@ -2870,7 +3078,11 @@ long xr_rd_count(int which) {
     case 8: return g_skipped_intra;
     case 9: return static_cast<long>(g_itx.size());
     case 10: return static_cast<long>(g_itx_samples.size());
+    case 11: return static_cast<long>(g_cands.size());
+    case 12: return static_cast<long>(g_finals.size());
+    case 13: return static_cast<long>(g_ictx.size());
   }
+  if (which >= 20 && which < 27) return static_cast<long>(xr_seq::g_of[which - 20].size());
   return -1;
 }
 int xr_rd_size(int which) {
@@ -2886,7 +3098,11 @@ int xr_rd_size(int which) {
     case 7: return sizeof(uint16_t);
     case 9: return sizeof(IntraTx);
     case 10: return sizeof(uint16_t);
+    case 11: return sizeof(Cand);
+    case 12: return sizeof(Final);
+    case 13: return sizeof(xvcgpu_inter_contexts);
   }
+  if (which >= 20 && which < 27) return sizeof(uint32_t);
   return -1;
 }
 const void *xr_rd_data(int which) {
@@ -2902,8 +3118,18 @@ const void *xr_rd_data(int which) {
     case 7: return g_nb_samples.data();
     case 9: return g_itx.data();
     case 10: return g_itx_samples.data();
+    case 11: return g_cands.data();
+    case 12: return g_finals.data();
+    case 13: return g_ictx.data();
   }
+  if (which >= 20 && which < 27) return xr_seq::g_of[which - 20].data();
   return nullptr;
+}
+
+/* ContextModel's state transitions (context_model.cc:51-73): the product builds its
+ * own tables from the CABAC state machine's rule; the tests compare. */
+const uint8_t *xr_next_state_table(int lps) {
+  return lps ? &ContextModel::kNextStateLps_[0] : &ContextModel::kNextStateMps_[0];
 }
 
 }  // extern "C"

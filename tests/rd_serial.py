@@ -1,0 +1,407 @@
+"""A real picture's RD search in the ORDER the reference encoder issued it
+(tests/golden/rd_order_*.npz over me_calls_* / rd_calls_*), as CU STATES:
+
+  kind 0  merge ranking   SearchMergeCandidates (inter_search.cc:165-197)
+  kind 1  evaluation      CompressAndEvalCbf (:261-365) of a given motion: a merge
+                          candidate (CompressMergeCand :117-139)
+  kind 2  inter mode      CompressInter (:74-98): SearchMotion [+ the affine second
+                          pass] then CompressAndEvalCbf of what it chose
+  kind 3  motion only     a CompressInter that returned before its evaluation
+                          (whole-sample vectors with a zero difference, :94-96)
+
+State boundaries come from the capture's global sequence numbers: a state is what the
+reference computes between two points where CuEncoder (cu_encoder.cc:431-515, :598-...)
+reads a cost and decides what to try next.  This module turns the fixture records
+into the device job arrays of the C-ABI entry points (all states of a picture, in
+issue order, uploaded once) and a table of xvc_cs_state records; the C++ layer
+(xvc_amd/host/xvc_cu_state.cc) walks that table - serially with a read-back wherever
+the reference reads a result (the baseline), or as one device chain per state."""
+import ctypes as C
+
+import numpy as np
+
+import order_fixture as of
+import rd_fixture as rf
+from rd_replay import BL, original_planes
+
+KIND_MERGE_RANK, KIND_EVAL, KIND_INTER, KIND_MOTION = 0, 1, 2, 3
+SLOT = 64            # scratch geometry: slot k of a state at luma x = 64 * k
+MAX_SLOTS = 8        # slot 0 = the prediction, 1.. = the transform alternatives
+
+STATE_DTYPE = np.dtype([
+    ("kind", "<i4"), ("x", "<i2"), ("y", "<i2"), ("w", "u1"), ("h", "u1"), ("flags", "u1"),
+    ("supported", "u1"),
+    ("me_first", "<i4"), ("me_count", "<i4"),
+    ("bi_first", "<i4"), ("bi_count", "<i4"),
+    ("aff_first", "<i4"), ("aff_uni_count", "<i4"), ("aff_bi_count", "<i4"),
+    ("merge", "<i4"), ("ev", "<i4"),
+    ("call_first", "<i4"), ("call_pass0", "<i4"), ("call_pass1", "<i4"),
+    ("comp_count", "<i4", 3),           # pass-0 calls per component (Y.., U.., V..)
+    ("copy_first", "<i4"),              # originals: [3 (slot 0)] [pass 0 calls] [pass 1 calls]
+    ("cand_first", "<i4"), ("cand_count", "<i4"),
+    ("final_first", "<i4"), ("final_count", "<i4"),
+    ("level_first", "<i8"), ("level_count", "<i8")], align=True)
+
+
+def _stream(seq):
+    n = sum(len(s) for s in seq.values())
+    kind = np.zeros(n, np.int8)
+    idx = np.zeros(n, np.int64)
+    for k, t in enumerate(of.SEQ_TABLES):
+        kind[seq[t]] = k
+        idx[seq[t]] = np.arange(len(seq[t]))
+    return kind, idx
+
+
+class SerialPicture:
+    """The states of ONE picture of a clip and their device job arrays."""
+
+    def __init__(self, api, name, poc):
+        self.api, self.name, self.poc = api, name, poc
+        self.rd = rd = rf.load(name)
+        self.order = o = of.load(name)
+        self.me = np.load(rf.GOLDEN + "/me_calls_%s.npz" % name)["calls"]
+        self.tabs = {"me": self.me, "steps": rd["steps"], "merges": rd["merges"],
+                     "evals": rd["evals"], "calls": rd["calls"], "cands": o["cands"],
+                     "finals": o["finals"]}
+        self._group()
+        self._jobs()
+
+    # ---- state boundaries ---------------------------------------------------------
+    def _group(self):
+        kind, idx = _stream(self.order["seq"])
+        T = of.SEQ_TABLES
+        tabs = self.tabs
+        ev_tab, calls = tabs["evals"], tabs["calls"]
+        states = []
+        pending = None
+
+        def new_state(k, key):
+            return dict(kind=k, key=key, me=[], cands=[], steps=[], finals=[], merge=-1, ev=-1,
+                        calls=[])
+
+        def flush():
+            nonlocal pending
+            if pending is not None:
+                pending["kind"] = KIND_MOTION
+                states.append(pending)
+                pending = None
+
+        cur = None           # the evaluation state collecting calls
+        for k, i in zip(kind, idx):
+            t = T[k]
+            r = tabs[t][i]
+            if t == "calls":
+                e = ev_tab[r["eval"]]
+                if int(e["poc"]) != self.poc:
+                    continue
+                key = (int(e["x"]), int(e["y"]), int(e["w"]), int(e["h"]))
+                first = r["comp"] == 0 and r["tx_select_idx"] < 0 and not r["tx_skip"]
+                if first:
+                    merge = (e["flags"] & rf.FLAG_MERGE) != 0
+                    if pending is not None and pending["key"] == key and not merge:
+                        cur = pending
+                        cur["kind"] = KIND_INTER
+                        pending = None
+                    else:
+                        flush()
+                        cur = new_state(KIND_EVAL, key)
+                    cur["ev"] = int(r["eval"])
+                    states.append(cur)
+                assert cur is not None and cur["ev"] == int(r["eval"]), (i, cur)
+                cur["calls"].append(int(i))
+                continue
+            if int(r["poc"]) != self.poc:
+                continue
+            key = (int(r["x"]), int(r["y"]), int(r["w"]), int(r["h"]))
+            if t == "evals":
+                continue          # the record is created by the state's first call (next record)
+            if t == "merges":
+                flush()
+                s = new_state(KIND_MERGE_RANK, key)
+                s["merge"] = int(i)
+                states.append(s)
+                cur = None
+                continue
+            # me / cands / steps / finals: the motion search of a CompressInter
+            if pending is not None and pending["key"] != key:
+                flush()
+            if pending is None:
+                pending = new_state(KIND_MOTION, key)
+                cur = None
+            pending[{"me": "me", "cands": "cands", "steps": "steps", "finals": "finals"}[t]].append(int(i))
+        flush()
+        # a motion group that holds TWO CompressInter calls back to back (the first one
+        # returned before its evaluation): split at the finals / flag change
+        out = []
+        for s in states:
+            out.extend(self._split_motion(s))
+        self.state_list = out
+
+    def _split_motion(self, s):
+        """One state per SearchMotion chain: a CompressInter's records carry one value of
+        the whole-sample / illumination flags."""
+        if s["kind"] not in (KIND_INTER, KIND_MOTION) or not s["cands"]:
+            return [s]
+        cd = self.tabs["cands"]
+        fl = [int(cd[i]["flags"]) & 3 for i in s["cands"]]
+        if len(set(fl)) == 1:
+            return [s]
+        # leading chains without evaluation, then the one that was evaluated
+        parts, seen = [], []
+        for f in fl:
+            if not seen or seen[-1] != f:
+                seen.append(f)
+        for n, f in enumerate(seen):
+            last = n == len(seen) - 1
+            p = dict(s)
+            for t, tab in (("me", "me"), ("cands", "cands"), ("steps", "steps"), ("finals", "finals")):
+                src = self.tabs[tab]
+                if t == "me":
+                    keep = [i for i in s[t] if (int(src[i]["fullpel_mv"]) | (2 if src[i]["use_lic"] else 0)) == f]
+                else:
+                    keep = [i for i in s[t] if (int(src[i]["flags"]) & 3) == f]
+                p[t] = keep
+            if not last:
+                p["kind"], p["ev"], p["calls"] = KIND_MOTION, -1, []
+            parts.append(p)
+        return parts
+
+    # ---- job arrays ---------------------------------------------------------------
+    def _jobs(self):
+        api, rd = self.api, self.rd
+        me, steps, merges = self.me, rd["steps"], rd["merges"]
+        ev_tab, calls, qps = rd["evals"], rd["calls"], rd["qps"]
+        S = self.state_list
+        # reference pictures of this picture
+        pocs = set(int(p) for p in me["ref_poc"][me["poc"] == self.poc])
+        sp = steps[steps["poc"] == self.poc]
+        pocs |= set(int(p) for p in sp["ref_poc"]) | set(int(p) for p in sp["other_ref_poc"] if p >= 0)
+        mp = merges[merges["poc"] == self.poc]
+        pocs |= set(int(p) for p in mp["ref_poc"].reshape(-1) if p >= 0)
+        ep = ev_tab[ev_tab["poc"] == self.poc]
+        pocs |= set(int(p) for p in ep["ref_poc"].reshape(-1) if p >= 0)
+        self.ref_pocs = sorted(pocs)
+        slot = {p: i for i, p in enumerate(self.ref_pocs)}
+        slot[-1] = -1
+
+        st = np.zeros(len(S), STATE_DTYPE)
+        me_idx, bi_idx, aff_idx, mg_idx = [], [], [], []
+        ev_states = []          # (state index, eval index)
+        call_idx = []
+        n_copy = 0
+        level_pos = 0
+        for n, s in enumerate(S):
+            r = st[n]
+            r["kind"] = s["kind"]
+            r["x"], r["y"], r["w"], r["h"] = s["key"]
+            r["supported"] = 1
+            r["merge"], r["ev"] = -1, -1
+            r["me_first"], r["me_count"] = len(me_idx), len(s["me"])
+            me_idx += s["me"]
+            bi = [i for i in s["steps"] if steps[i]["kind"] == rf.KIND_BI]
+            au = [i for i in s["steps"] if steps[i]["kind"] == rf.KIND_AFFINE_UNI]
+            ab = [i for i in s["steps"] if steps[i]["kind"] == rf.KIND_AFFINE_BI]
+            r["bi_first"], r["bi_count"] = len(bi_idx), len(bi)
+            bi_idx += bi
+            r["aff_first"], r["aff_uni_count"], r["aff_bi_count"] = len(aff_idx), len(au), len(ab)
+            aff_idx += au + ab
+            lic = any(steps[i]["flags"] & rf.FLAG_LIC for i in s["steps"]) or \
+                any(me[i]["use_lic"] for i in s["me"])
+            if s["cands"]:
+                r["cand_first"], r["cand_count"] = s["cands"][0], len(s["cands"])
+                assert s["cands"] == list(range(s["cands"][0], s["cands"][0] + len(s["cands"])))
+                r["flags"] = int(self.tabs["cands"][s["cands"][0]]["flags"]) & 3
+            if s["finals"]:
+                r["final_first"], r["final_count"] = s["finals"][0], len(s["finals"])
+            if s["kind"] == KIND_MERGE_RANK:
+                r["merge"] = len(mg_idx)
+                mg_idx.append(s["merge"])
+                lic = lic or bool(merges[s["merge"]]["use_lic"].any())
+            if s["ev"] >= 0:
+                e = ev_tab[s["ev"]]
+                lic = lic or bool(e["flags"] & rf.FLAG_LIC)
+                r["ev"] = len(ev_states)
+                ev_states.append((n, s["ev"]))
+                cs = calls[s["calls"]]
+                p0 = [i for i, c in zip(s["calls"], cs) if not (c["comp"] == 0 and c["tx_select_idx"] >= 0)]
+                p1 = [i for i, c in zip(s["calls"], cs) if c["comp"] == 0 and c["tx_select_idx"] >= 0]
+                assert s["calls"] == p0 + p1, s          # pass 1 = the luma selections, last
+                comps = calls["comp"][p0]
+                assert (np.diff(comps.astype(int)) >= 0).all()
+                for c in range(3):
+                    r["comp_count"][c] = int((comps == c).sum())
+                r["call_first"], r["call_pass0"], r["call_pass1"] = len(call_idx), len(p0), len(p1)
+                call_idx += s["calls"]
+                r["copy_first"] = n_copy
+                n_copy += 3 + len(s["calls"])
+                sizes = [(int(e["w"]) >> (1 if calls[i]["comp"] else 0)) *
+                         (int(e["h"]) >> (1 if calls[i]["comp"] else 0)) for i in s["calls"]]
+                r["level_first"], r["level_count"] = level_pos, sum(sizes)
+                level_pos += sum(sizes)
+            if lic:
+                r["supported"] = 0      # local illumination compensation: not in this replay
+        self.states = st
+        self.n_levels = level_pos
+
+        i_ = np.asarray
+        # -- uni-directional searches
+        m = me[i_(me_idx, np.int64)] if me_idx else me[:0]
+        self.me_jobs = np.zeros(len(m), api.ME_DTYPE)
+        for k in ("x", "y", "w", "h", "depth_nonzero", "mvp_x", "mvp_y", "prev_x", "prev_y",
+                  "lambda16", "search_range"):
+            self.me_jobs[k] = m[k]
+        self.me_jobs["fullpel_mv"] = m["fullpel_mv"] | np.where(m["use_lic"] != 0, 2, 0)
+        self.me_ref = np.array([slot[int(p)] for p in m["ref_poc"]], np.int8)
+        self.me_want = m
+        # -- bi-prediction refinement steps
+        b = steps[i_(bi_idx, np.int64)] if bi_idx else steps[:0]
+        self.bi_jobs = np.zeros(len(b), api.BI_DTYPE)
+        blk = self.bi_jobs["blk"]
+        for k in ("x", "y", "w", "h", "lambda16"):
+            blk[k] = b[k]
+        blk["fullpel_mv"] = (b["flags"] & rf.FLAG_FULLPEL) != 0
+        ar = np.arange(len(b))
+        stt = b["start_mvp_idx"].astype(np.int64)
+        blk["mvp_x"], blk["mvp_y"] = b["mvp"][ar, stt, 0, 0], b["mvp"][ar, stt, 0, 1]
+        blk["search_range"] = 4
+        self.bi_jobs["blk"] = blk
+        self.bi_jobs["other_mv_x"], self.bi_jobs["other_mv_y"] = b["other_mv"][:, 0, 0], b["other_mv"][:, 0, 1]
+        self.bi_jobs["boot_mv_x"], self.bi_jobs["boot_mv_y"] = b["boot"][:, 0, 0], b["boot"][:, 0, 1]
+        self.bi_ref = np.array([[slot[int(p)], slot[int(q)]] for p, q in
+                                zip(b["ref_poc"], b["other_ref_poc"])], np.int8).reshape(-1, 2)
+        self.bi_want = b
+        # -- affine searches
+        a = steps[i_(aff_idx, np.int64)] if aff_idx else steps[:0]
+        self.aff_jobs = np.zeros(len(a), api.AFFINE_ME_DTYPE)
+        for k in ("x", "y", "w", "h", "lambda16"):
+            self.aff_jobs[k] = a[k]
+        self.aff_jobs["flags"] = (np.where((a["flags"] & rf.FLAG_HAS_BOOT) != 0, api.AFFINE_ME_HAS_BOOTSTRAP, 0) |
+                                  np.where(a["kind"] == rf.KIND_AFFINE_BI, api.AFFINE_ME_BIPRED, 0))
+        ar = np.arange(len(a))
+        self.aff_jobs["mvp"] = a["mvp"][ar, a["start_mvp_idx"].astype(np.int64)]
+        self.aff_jobs["bootstrap"] = a["boot"]
+        self.aff_jobs["other_mv"] = a["other_mv"]
+        self.aff_ref = np.array([[slot[int(p)], slot[int(q)] if q >= 0 else slot[int(p)]]
+                                 for p, q in zip(a["ref_poc"], a["other_ref_poc"])], np.int8).reshape(-1, 2)
+        self.aff_want = a
+        # -- merge rankings: five luma predictions + SATD per call
+        g = merges[i_(mg_idx, np.int64)] if mg_idx else merges[:0]
+        n = len(g)
+        self.mg_want = g
+        self.mg_inter = np.zeros((n, 5), api.INTER_DTYPE)
+        j = self.mg_inter
+        j["x"], j["y"], j["w"], j["h"] = g["x"][:, None], g["y"][:, None], g["w"][:, None], g["h"][:, None]
+        for l in range(2):
+            used = (g["inter_dir"] == 2) | (g["inter_dir"] == l)
+            j["ref"][:, :, l] = np.where(used, np.vectorize(lambda p: slot.get(int(p), -1))(g["ref_poc"][:, :, l]), -1)
+        j["mv"][:, :, :, 0, :] = g["mv"]
+        self.mg_dst = np.zeros((n, 5), api.POS_DTYPE)
+        self.mg_dst["x"] = SLOT * np.arange(5)[None, :]
+        self.mg_copy = np.zeros((n, 5), api.COPY_BLOCK_DTYPE)
+        c = self.mg_copy
+        c["sx"], c["sy"] = g["x"][:, None], g["y"][:, None]
+        c["dx"] = SLOT * np.arange(5)[None, :]
+        c["w"], c["h"] = g["w"][:, None], g["h"][:, None]
+        self.mg_cands = np.zeros((n, 5), api.CAND_DTYPE)
+        k = self.mg_cands
+        k["x"] = SLOT * np.arange(5)[None, :]
+        k["w"], k["h"], k["metric"] = g["w"][:, None], g["h"][:, None], 1
+        # -- evaluations
+        ne = len(ev_states)
+        e = ev_tab[i_([x[1] for x in ev_states], np.int64)] if ne else ev_tab[:0]
+        self.ev_want = e
+        self.ev_state = np.array([x[0] for x in ev_states], np.int64)
+        self.ev_inter = np.zeros((ne, 3), api.INTER_DTYPE)
+        j = self.ev_inter
+        for c in range(3):
+            jc = j[:, c]
+            jc["x"], jc["y"], jc["w"], jc["h"], jc["comp"] = e["x"], e["y"], e["w"], e["h"], c
+            jc["flags"] = np.where((e["flags"] & rf.FLAG_AFFINE) != 0, api.INTER_AFFINE, 0)
+            for l in range(2):
+                used = (e["inter_dir"] == 2) | (e["inter_dir"] == l)
+                jc["ref"][:, l] = np.where(used, [slot.get(int(p), -1) for p in e["ref_poc"][:, l]], -1)
+            jc["mv"] = e["mv"]
+            j[:, c] = jc
+        self.ev_dst = np.zeros((ne, 3), api.POS_DTYPE)      # slot 0
+        self.ev_weight = qps["dist_weight"][e["qp_index"]] if ne else np.zeros((0, 3))
+        self.ev_ctx = e["ctx_index"].astype(np.int32)
+        # dist_zero: prediction (slot 0) against the original (slot 0), per component
+        self.ev_dz = np.zeros((ne, 3), api.CAND_DTYPE)
+        for c in range(3):
+            d = self.ev_dz[:, c]
+            d["w"], d["h"] = e["w"] >> (1 if c else 0), e["h"] >> (1 if c else 0)
+            d["metric"], d["qp"] = (7 if c == 0 else 0), e["qp"][:, 0]
+            self.ev_dz[:, c] = d
+        # -- the transform calls
+        cl = calls[i_(call_idx, np.int64)] if call_idx else calls[:0]
+        nc = len(cl)
+        self.call_want = cl
+        # which evaluation state / slot each call belongs to
+        call_ev = np.zeros(nc, np.int64)
+        call_slot = np.zeros(nc, np.int64)
+        for n in np.flatnonzero(st["ev"] >= 0):
+            r = st[n]
+            f, p0, p1 = int(r["call_first"]), int(r["call_pass0"]), int(r["call_pass1"])
+            call_ev[f:f + p0 + p1] = r["ev"]
+            pos = f
+            for c in range(3):
+                k = int(r["comp_count"][c])
+                call_slot[pos:pos + k] = 1 + np.arange(k)
+                pos += k
+            call_slot[pos:pos + p1] = 1 + int(r["comp_count"][0]) + np.arange(p1)
+        assert nc == 0 or call_slot.max() < MAX_SLOTS
+        ce = e[call_ev]
+        sh = (cl["comp"] != 0).astype(np.int64)
+        self.call_tx = np.zeros(nc, api.TX_DTYPE)
+        t = self.call_tx
+        t["x"], t["y"] = (SLOT * call_slot) >> sh, 0
+        t["w"], t["h"] = ce["w"] >> sh, ce["h"] >> sh
+        t["comp"] = cl["comp"]
+        t["tx_hor"] = np.where(cl["tx_skip"] != 0, 6, cl["tx_hor"])
+        t["tx_ver"] = cl["tx_ver"]
+        t["qp"] = ce["qp"][np.arange(nc), cl["comp"]]
+        t["intra_pic"] = api.TXF_RDOQ | (cl["scan"].astype(np.int64) << api.TXF_SCAN_SHIFT)
+        self.call_prm = np.zeros(nc, api.RDOQ_PARAMS_DTYPE)
+        q = qps[ce["qp_index"]]
+        self.call_prm["lambda"] = q["lambda"][np.arange(nc), cl["comp"]]
+        self.call_prm["rd_factor"] = q["rd_factor"][np.arange(nc), cl["comp"]]
+        self.call_prm["ctx_index"] = 0                       # one snapshot per state
+        n_el = t["w"].astype(np.int64) * t["h"]
+        self.call_off = np.r_[0, np.cumsum(n_el)[:-1]].astype(np.uint32) if nc else np.zeros(0, np.uint32)
+        assert self.n_levels == int(n_el.sum())
+        self.call_cand = np.zeros(nc, api.CAND_DTYPE)
+        d = self.call_cand
+        d["x"], d["y"], d["w"], d["h"] = t["x"], t["y"], t["w"], t["h"]
+        d["metric"] = np.where(cl["comp"] == 0, 7, 0)
+        d["qp"] = ce["qp"][:, 0]
+        # prediction: slot 0 -> the call's slot (same picture)
+        self.call_copy_pred = np.zeros(nc, api.COPY_BLOCK_DTYPE)
+        p = self.call_copy_pred
+        p["dx"], p["w"], p["h"], p["comp"] = t["x"], t["w"], t["h"], cl["comp"]
+        # originals: per state [slot 0: Y U V] [pass-0 calls] [pass-1 calls]
+        self.copy_orig = np.zeros(n_copy, api.COPY_BLOCK_DTYPE)
+        for n in np.flatnonzero(st["ev"] >= 0):
+            r = st[n]
+            ev = e[int(r["ev"])]
+            f = int(r["copy_first"])
+            for c in range(3):
+                s_ = 1 if c else 0
+                self.copy_orig[f + c] = (int(ev["x"]) >> s_, int(ev["y"]) >> s_, 0, 0,
+                                         int(ev["w"]) >> s_, int(ev["h"]) >> s_, c, 0)
+            cf, k = int(r["call_first"]), int(r["call_pass0"]) + int(r["call_pass1"])
+            o = self.copy_orig[f + 3:f + 3 + k]
+            sh_ = sh[cf:cf + k]
+            o["sx"], o["sy"] = ev["x"] >> sh_, ev["y"] >> sh_
+            o["dx"], o["w"], o["h"], o["comp"] = t["x"][cf:cf + k], t["w"][cf:cf + k], t["h"][cf:cf + k], cl["comp"][cf:cf + k]
+            self.copy_orig[f + 3:f + 3 + k] = o
+        self.contexts = np.ascontiguousarray(rd["contexts"]).view(api.RDOQ_CTX_DTYPE).reshape(-1)
+
+    def summary(self):
+        st = self.states
+        return {"states": len(st), "merge_rank": int((st["kind"] == 0).sum()),
+                "eval": int((st["kind"] == 1).sum()), "inter": int((st["kind"] == 2).sum()),
+                "motion_only": int((st["kind"] == 3).sum()),
+                "unsupported": int((st["supported"] == 0).sum()),
+                "me": len(self.me_jobs), "bi": len(self.bi_jobs), "affine": len(self.aff_jobs),
+                "calls": len(self.call_tx)}

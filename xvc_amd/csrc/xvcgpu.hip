@@ -471,6 +471,14 @@ xvcgpu_status xvcgpu_memcpy_h2d_async(xvcgpu_ctx *ctx, void *dst, const void *sr
   return XVCGPU_OK;
 }
 
+xvcgpu_status xvcgpu_memcpy_d2h_async(xvcgpu_ctx *ctx, void *dst, const void *src,
+                                      size_t bytes) {
+  if (!ctx || (!dst && bytes) || (!src && bytes)) return XVCGPU_INVALID_ARGUMENT;
+  if (!bytes) return XVCGPU_OK;
+  HIP_TRY(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  return XVCGPU_OK;
+}
+
 xvcgpu_status xvcgpu_memcpy_d2h(xvcgpu_ctx *ctx, void *dst, const void *src,
                                 size_t bytes) {
   if (!ctx || (!dst && bytes) || (!src && bytes)) return XVCGPU_INVALID_ARGUMENT;

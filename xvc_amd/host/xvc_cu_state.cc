@@ -1,0 +1,209 @@
+// xvc_cu_state.cc -- see xvc_cu_state.h.
+#include "xvc_cu_state.h"
+
+#include <chrono>
+#include <cstring>
+
+namespace {
+const uint32_t kEntropyBits[128] = {
+#include "../csrc/entropy_bits.inc"
+};
+const uint8_t kTransIdxLps[64] = {XVC_TRANS_IDX_LPS_LIST};
+const xvc_bits_tables kTables = {kEntropyBits, kTransIdxLps};
+}  // namespace
+
+extern "C" {
+
+void xvc_host_inter_pred_bits(const xvcgpu_inter_contexts *snapshots, const int32_t *ictx_index,
+                              const xvc_inter_syntax *cands, int n, uint32_t *bits) {
+  for (int i = 0; i < n; i++)
+    bits[i] = xvc_inter_pred_bits(&snapshots[ictx_index ? ictx_index[i] : i], &cands[i], &kTables);
+}
+
+void xvc_host_next_state_table(int lps, uint8_t *out) {
+  for (int s = 0; s < 128; s++)
+    out[s] = xvc_ctx_next(static_cast<uint8_t>(s), lps ? !(s & 1) : (s & 1), kTransIdxLps);
+}
+
+const uint32_t *xvc_host_entropy_bits_table(void) { return kEntropyBits; }
+
+}  // extern "C"
+
+// ---- the serial walk ---------------------------------------------------------------
+namespace {
+
+struct Walk {
+  xvcgpu_ctx *ctx;
+  const xvc_cs_tables &t;
+  xvc_cs_stats *st;
+  int read_levels;
+  xvcgpu_status err;
+  Walk(xvcgpu_ctx *c, const xvc_cs_tables &tab, xvc_cs_stats *s, int rl)
+      : ctx(c), t(tab), st(s), read_levels(rl), err(XVCGPU_OK) {}
+
+  bool Ok(xvcgpu_status s) {
+    st->api_calls++;
+    if (s != XVCGPU_OK && err == XVCGPU_OK) err = s;
+    return s == XVCGPU_OK;
+  }
+  // queue a device -> host copy of n records; the wait is ReadBack()
+  template <typename T>
+  void Fetch(T *host, const T *dev, size_t first, size_t n) {
+    if (n && err == XVCGPU_OK) {
+      const xvcgpu_status s = xvcgpu_memcpy_d2h_async(ctx, host + first, dev + first, n * sizeof(T));
+      if (s != XVCGPU_OK) err = s;
+    }
+  }
+  void ReadBack() {
+    if (err != XVCGPU_OK) return;
+    const xvcgpu_status s = xvcgpu_sync(ctx);
+    if (s != XVCGPU_OK) err = s;
+    st->round_trips++;
+  }
+
+  // jobs [first, first + n) that name the same reference slot(s) go out as one batch
+  template <typename F>
+  void ByRef(const int8_t *ref, int stride, int first, int n, F launch) {
+    int a = first;
+    while (a < first + n) {
+      int b = a + 1;
+      while (b < first + n && !std::memcmp(ref + (size_t)b * stride, ref + (size_t)a * stride, stride)) b++;
+      launch(a, b - a, ref + (size_t)a * stride);
+      a = b;
+    }
+  }
+
+  void Motion(const xvc_cs_state &s) {
+    const int max_size = s.w > s.h ? s.w : s.h;
+    if (s.me_count) {            // SearchRefIdx, uni-directional: one TZ + sub-pel search per picture
+      ByRef(t.me_ref, 1, s.me_first, s.me_count, [&](int a, int n, const int8_t *r) {
+        Ok(xvcgpu_me_search_sized(ctx, t.orig, t.refs[r[0]], XVCGPU_ME_FULLPEL | XVCGPU_ME_SUBPEL,
+                                  t.d_me + a, n, t.d_me_res + a, max_size));
+      });
+      Fetch(t.h_me_res, t.d_me_res, s.me_first, s.me_count);
+      ReadBack();                // the fold over lists and pictures reads every result
+    }
+    if (s.bi_count) {            // SearchBiIterative: needs the uni-directional winners
+      ByRef(t.bi_ref, 2, s.bi_first, s.bi_count, [&](int a, int n, const int8_t *r) {
+        Ok(xvcgpu_bipred_search(ctx, t.orig, t.refs[r[1]], t.refs[r[0]], t.d_bi + a, n,
+                                t.d_bi_res + a, max_size));
+      });
+      Fetch(t.h_bi_res, t.d_bi_res, s.bi_first, s.bi_count);
+      ReadBack();
+    }
+    if (s.aff_uni_count) {       // second SearchMotion, affine: bootstrapped from the plain result
+      ByRef(t.aff_ref, 2, s.aff_first, s.aff_uni_count, [&](int a, int n, const int8_t *r) {
+        Ok(xvcgpu_affine_me_batch(ctx, t.orig, t.refs[r[0]], t.refs[r[1]], t.d_aff + a, n,
+                                  t.d_aff_res + a));
+      });
+      Fetch(t.h_aff_res, t.d_aff_res, s.aff_first, s.aff_uni_count);
+      ReadBack();
+    }
+    if (s.aff_bi_count) {
+      const int f = s.aff_first + s.aff_uni_count;
+      ByRef(t.aff_ref, 2, f, s.aff_bi_count, [&](int a, int n, const int8_t *r) {
+        Ok(xvcgpu_affine_me_batch(ctx, t.orig, t.refs[r[0]], t.refs[r[1]], t.d_aff + a, n,
+                                  t.d_aff_res + a));
+      });
+      Fetch(t.h_aff_res, t.d_aff_res, f, s.aff_bi_count);
+      ReadBack();
+    }
+  }
+
+  void MergeRank(const xvc_cs_state &s) {
+    const size_t m = (size_t)s.merge * 5;
+    Ok(xvcgpu_copy_blocks(ctx, t.orig, t.s_orig, t.d_mg_copy + m, 5));
+    Ok(xvcgpu_inter_pred_batch_to(ctx, t.refs, t.n_refs, t.orig, t.s_pred, t.d_mg_inter + m,
+                                  t.d_mg_dst + m, 5));
+    Ok(xvcgpu_metric_batch(ctx, t.s_orig, t.s_pred, 0, 1.0, 16, t.d_mg_cands + m, 5,
+                           t.d_mg_dist + m));
+    Fetch(t.h_mg_dist, t.d_mg_dist, m, 5);
+    ReadBack();                  // the stable sort and the cut decide which candidates are evaluated
+  }
+
+  // calls [first, first + n) of evaluation e: residual pipeline + distortions
+  void Calls(const xvc_cs_state &s, int first, int n, const int comp_count[3]) {
+    if (!n) return;
+    const size_t e = (size_t)s.ev;
+    Ok(xvcgpu_copy_blocks(ctx, t.s_pred, t.s_pred, t.d_call_copy_pred + first, n));
+    Ok(xvcgpu_residual_rdoq_batch(ctx, t.s_orig, t.s_pred, t.s_rec, t.d_call_tx + first, n,
+                                  t.d_levels, t.d_call_off + first, t.d_nnz + first,
+                                  t.d_contexts + t.ev_ctx[e], t.d_call_prm + first));
+    int a = first;
+    for (int c = 0; c < 3; c++) {
+      if (!comp_count[c]) continue;
+      Ok(xvcgpu_metric_batch(ctx, t.s_orig, t.s_rec, c, t.ev_weight[3 * e + c], 16,
+                             t.d_call_cand + a, comp_count[c], t.d_call_dist + a));
+      a += comp_count[c];
+    }
+    Fetch(t.h_nnz, t.d_nnz, first, n);
+    Fetch(t.h_call_dist, t.d_call_dist, first, n);
+  }
+
+  void Eval(const xvc_cs_state &s) {
+    const size_t e = (size_t)s.ev;
+    const int n0 = s.call_pass0, n1 = s.call_pass1;
+    // the originals beside the scratch predictions: slot 0 and the pass-0 slots
+    Ok(xvcgpu_copy_blocks(ctx, t.orig, t.s_orig, t.d_copy_orig + s.copy_first, 3 + n0));
+    Ok(xvcgpu_inter_pred_batch_to(ctx, t.refs, t.n_refs, t.orig, t.s_pred, t.d_ev_inter + 3 * e,
+                                  t.d_ev_dst + 3 * e, 3));
+    for (int c = 0; c < 3; c++)   // cbf-zero distortion: the prediction against the original
+      Ok(xvcgpu_metric_batch(ctx, t.s_orig, t.s_pred, c, t.ev_weight[3 * e + c], 16,
+                             t.d_ev_dz + 3 * e + c, 1, t.d_ev_dz_dist + 3 * e + c));
+    Calls(s, s.call_first, n0, s.comp_count);
+    Fetch(t.h_ev_dz_dist, t.d_ev_dz_dist, 3 * e, 3);
+    if (read_levels) Fetch(t.h_levels, t.d_levels, (size_t)s.level_first, LevelCount(s, 0));
+    ReadBack();                  // bits of every alternative, the folds, the gate of the second pass
+    if (n1) {
+      const int cc[3] = {n1, 0, 0};
+      Ok(xvcgpu_copy_blocks(ctx, t.orig, t.s_orig, t.d_copy_orig + s.copy_first + 3 + n0, n1));
+      Calls(s, s.call_first + n0, n1, cc);
+      if (read_levels)
+        Fetch(t.h_levels, t.d_levels, (size_t)s.level_first + LevelCount(s, 0), LevelCount(s, 1));
+      ReadBack();
+    }
+  }
+  // levels of a state's pass: the luma selections of pass 1 are w * h each
+  size_t LevelCount(const xvc_cs_state &s, int pass) const {
+    const size_t p1 = (size_t)s.call_pass1 * s.w * s.h;
+    return pass ? p1 : (size_t)s.level_count - p1;
+  }
+};
+
+double Now() {
+  using namespace std::chrono;
+  return duration<double>(steady_clock::now().time_since_epoch()).count();
+}
+
+}  // namespace
+
+extern "C" int xvc_host_cu_state_run_serial(xvcgpu_ctx *ctx, const xvc_cs_tables *t,
+                                            const xvc_cs_state *states, int first, int n,
+                                            int read_levels, xvc_cs_stats *stats) {
+  if (!ctx || !t || !states || !stats || n < 0) return XVCGPU_INVALID_ARGUMENT;
+  std::memset(stats, 0, sizeof(*stats));
+  Walk w(ctx, *t, stats, read_levels);
+  xvcgpu_status s0 = xvcgpu_sync(ctx);
+  if (s0 != XVCGPU_OK) return s0;
+  const double t0 = Now();
+  for (int i = first; i < first + n && w.err == XVCGPU_OK; i++) {
+    const xvc_cs_state &s = states[i];
+    if (!s.supported) {
+      stats->skipped++;
+      continue;
+    }
+    const double a = Now();
+    switch (s.kind) {
+      case XVC_CS_MERGE_RANK: w.MergeRank(s); break;
+      case XVC_CS_EVAL: w.Eval(s); break;
+      case XVC_CS_INTER: w.Motion(s); w.Eval(s); break;
+      case XVC_CS_MOTION: w.Motion(s); break;
+      default: return XVCGPU_INVALID_ARGUMENT;
+    }
+    stats->seconds_by_kind[s.kind] += Now() - a;
+    stats->states_by_kind[s.kind]++;
+    stats->states++;
+  }
+  stats->seconds = Now() - t0;
+  return w.err;
+}
