@@ -405,3 +405,175 @@ class SerialPicture:
                 "unsupported": int((st["supported"] == 0).sum()),
                 "me": len(self.me_jobs), "bi": len(self.bi_jobs), "affine": len(self.aff_jobs),
                 "calls": len(self.call_tx)}
+
+
+# ---- running the walk (needs the device) ----------------------------------------------
+class CsTables(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("orig", "refs")] + [("n_refs", C.c_int32)] + \
+        [(n, C.c_void_p) for n in (
+            "s_orig", "s_pred", "s_rec", "d_me", "d_me_res", "me_ref", "d_bi", "d_bi_res", "bi_ref",
+            "d_aff", "d_aff_res", "aff_ref", "d_mg_inter", "d_mg_dst", "d_mg_copy", "d_mg_cands",
+            "d_mg_dist", "d_ev_inter", "d_ev_dst", "d_ev_dz", "d_ev_dz_dist", "ev_weight", "ev_ctx",
+            "d_contexts", "d_copy_orig", "d_call_tx", "d_call_prm", "d_call_off",
+            "d_call_copy_pred", "d_call_cand", "d_levels", "d_nnz", "d_call_dist", "h_me_res",
+            "h_bi_res", "h_aff_res", "h_mg_dist", "h_ev_dz_dist", "h_call_dist", "h_nnz",
+            "h_levels")]
+
+
+class CsStats(C.Structure):
+    _fields_ = [("seconds", C.c_double), ("states", C.c_int64), ("skipped", C.c_int64),
+                ("api_calls", C.c_int64), ("round_trips", C.c_int64),
+                ("seconds_by_kind", C.c_double * 4), ("states_by_kind", C.c_int64 * 4)]
+
+
+class SerialRun:
+    """One chain: a context (its own stream), the picture's job arrays on the device,
+    scratch pictures and result arrays of its own."""
+
+    def __init__(self, api, ctx, sp, pics, width, height):
+        from xvc_amd import decoder
+        self.api, self.ctx, self.sp = api, ctx, sp
+        self.lib = decoder.load_host_library()
+        for f in ("xvc_host_cu_state_run_serial",):
+            getattr(self.lib, f).argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                             C.c_int, C.c_void_p]
+        self.orig = ctx.picture(width, height, 10)
+        self.orig.upload(original_planes(width, height, sp.poc), BL)
+        self.scratch = [ctx.picture(SLOT * MAX_SLOTS, 64, 10) for _ in range(3)]
+        self.refs = [pics[p] for p in sp.ref_pocs]
+        self._ref_arr = (C.c_void_p * len(self.refs))(*[r.h_pic for r in self.refs])
+        self._keep, self._pinned = [], []
+        t = self.t = CsTables()
+        t.orig, t.refs, t.n_refs = self.orig.h_pic, C.addressof(self._ref_arr), len(self.refs)
+        t.s_orig, t.s_pred, t.s_rec = (p.h_pic for p in self.scratch)
+        up = self._upload
+        t.d_me, t.me_ref = up(sp.me_jobs), self._host(sp.me_ref)
+        t.d_bi, t.bi_ref = up(sp.bi_jobs), self._host(sp.bi_ref)
+        t.d_aff, t.aff_ref = up(sp.aff_jobs), self._host(sp.aff_ref)
+        t.d_mg_inter, t.d_mg_dst = up(sp.mg_inter), up(sp.mg_dst)
+        t.d_mg_copy, t.d_mg_cands = up(sp.mg_copy), up(sp.mg_cands)
+        t.d_ev_inter, t.d_ev_dst, t.d_ev_dz = up(sp.ev_inter), up(sp.ev_dst), up(sp.ev_dz)
+        t.ev_weight = self._host(np.ascontiguousarray(sp.ev_weight, np.float64))
+        t.ev_ctx = self._host(np.ascontiguousarray(sp.ev_ctx, np.int32))
+        t.d_contexts, t.d_copy_orig = up(sp.contexts), up(sp.copy_orig)
+        t.d_call_tx, t.d_call_prm, t.d_call_off = up(sp.call_tx), up(sp.call_prm), up(sp.call_off)
+        t.d_call_copy_pred, t.d_call_cand = up(sp.call_copy_pred), up(sp.call_cand)
+        res = self.res = {}
+        for name, dt, n in (("me_res", api.MERES_DTYPE, len(sp.me_jobs)),
+                            ("bi_res", api.MERES_DTYPE, len(sp.bi_jobs)),
+                            ("aff_res", api.AFFINE_ME_RESULT_DTYPE, len(sp.aff_jobs)),
+                            ("mg_dist", np.dtype("<u8"), 5 * len(sp.mg_inter)),
+                            ("ev_dz_dist", np.dtype("<u8"), 3 * len(sp.ev_inter)),
+                            ("call_dist", np.dtype("<u8"), len(sp.call_tx)),
+                            ("nnz", np.dtype("<i4"), len(sp.call_tx)),
+                            ("levels", np.dtype("<i2"), sp.n_levels)):
+            nbytes = max(n, 1) * dt.itemsize
+            d = ctx.alloc(nbytes)
+            self._keep.append(d)
+            h = self._pin(nbytes)
+            C.memset(h, 0xff, nbytes)
+            res[name] = np.frombuffer((C.c_char * nbytes).from_address(h), dt)[:n]
+            setattr(t, "d_" + name if name not in ("levels", "nnz") else "d_" + name, d.ptr)
+            setattr(t, "h_" + name, h)
+        ctx.sync()
+
+    def _upload(self, arr):
+        a = np.ascontiguousarray(arr).reshape(-1)
+        if not len(a):
+            a = np.zeros(1, a.dtype)
+        b = self.ctx.buffer(a)
+        self._keep.append(b)
+        return b.ptr
+
+    def _host(self, arr):
+        a = np.ascontiguousarray(arr)
+        self._keep.append(a)
+        return a.ctypes.data
+
+    def _pin(self, nbytes):
+        p = C.c_void_p()
+        self.ctx._check(self.ctx.lib.xvcgpu_host_alloc(self.ctx.h, nbytes, C.byref(p)))
+        self._pinned.append(p)
+        return p.value
+
+    def run_serial(self, first=0, n=None, read_levels=True):
+        st = self.sp.states
+        n = len(st) - first if n is None else n
+        stats = CsStats()
+        rc = self.lib.xvc_host_cu_state_run_serial(self.ctx.h, C.addressof(self.t), st.ctypes.data,
+                                                   first, n, int(read_levels), C.addressof(stats))
+        if rc:
+            raise RuntimeError("xvc_host_cu_state_run_serial: %d (%s)" % (
+                rc, self.ctx.lib.xvcgpu_last_error(self.ctx.h)))
+        return stats
+
+    def check(self, first=0, n=None, levels=True):
+        """Every result the walk read back against what the reference encoder got.
+        -> dict of (compared, mismatching) per table."""
+        sp, res = self.sp, self.res
+        st = sp.states[first:None if n is None else first + n]
+        st = st[st["supported"] != 0]
+        out = {}
+
+        def rng(first_f, count_f):
+            idx = [np.arange(int(a), int(a) + int(b)) for a, b in zip(st[first_f], count_f) if b]
+            return np.concatenate(idx) if idx else np.zeros(0, np.int64)
+
+        i = rng("me_first", st["me_count"])
+        w, g = sp.me_want[i], res["me_res"][i]
+        out["me"] = (len(i), int(((g["fullpel_x"] != w["fullpel_x"]) | (g["fullpel_y"] != w["fullpel_y"]) |
+                                  (g["mv_x"] != w["mv_x"]) | (g["mv_y"] != w["mv_y"]) |
+                                  (g["subpel_dist"] != w["dist"])).sum()))
+        i = rng("bi_first", st["bi_count"])
+        w, g = sp.bi_want[i], res["bi_res"][i]
+        out["bi"] = (len(i), int(((g["mv_x"] != w["mv"][:, 0, 0]) | (g["mv_y"] != w["mv"][:, 0, 1]) |
+                                  (g["subpel_dist"] != w["dist"])).sum()))
+        i = rng("aff_first", st["aff_uni_count"] + st["aff_bi_count"])
+        w, g = sp.aff_want[i], res["aff_res"][i]
+        out["affine"] = (len(i), int((~((g["mv"] == w["mv"]).all(axis=(1, 2)) & (g["dist"] == w["dist"]))).sum()))
+        m = st["merge"][st["kind"] == KIND_MERGE_RANK].astype(np.int64)
+        if len(m):
+            g = sp.mg_want[m]
+            dist = res["mg_dist"].reshape(-1, 5)[m]
+            cost = dist.astype(np.float64) + np.array([1, 2, 3, 4, 4.0])[None, :] * g["lambda_sqrt"][:, None]
+            order = np.argsort(cost, axis=1, kind="stable")
+            scost = np.take_along_axis(cost, order, 1)
+            num = np.full(len(m), 4, np.int32)
+            for k in range(4, -1, -1):
+                num = np.where(scost[:, k] > scost[:, 0] * 1.25, k, num)
+            ok = (order == g["order"]).all(1) & (scost == g["cost"]).all(1) & (num == g["num"])
+            out["merge"] = (len(m), int((~ok).sum()))
+        e = st["ev"][st["ev"] >= 0].astype(np.int64)
+        if len(e):
+            want = sp.ev_want["dist_zero"][e]
+            got = res["ev_dz_dist"].reshape(-1, 3)[e]
+            valid = want != np.uint64(0xffffffffffffffff)
+            out["dist_zero"] = (int(valid.sum()), int(((got != want) & valid).sum()))
+        sel = st[st["ev"] >= 0]
+        i = rng("call_first", sel["call_pass0"] + sel["call_pass1"]) if len(sel) else np.zeros(0, np.int64)
+        if len(i):
+            # (rng() above iterates st; redo over the evaluation states)
+            i = np.concatenate([np.arange(int(a), int(a) + int(b) + int(c)) for a, b, c in
+                                zip(sel["call_first"], sel["call_pass0"], sel["call_pass1"])])
+            w = sp.call_want[i]
+            bad = res["nnz"][i] != w["nnz"]
+            done = w["completed"] != 0
+            bad |= done & (res["call_dist"][i] != w["dist"])
+            if levels:
+                lv = res["levels"]
+                off = sp.call_off[i].astype(np.int64)
+                ne = sp.call_tx["w"][i].astype(np.int64) * sp.call_tx["h"][i]
+                for k in np.flatnonzero((w["nnz"] != 0) & ~bad):
+                    if rf.crc32_rows(lv[off[k]:off[k] + ne[k]]) != int(w["levels_crc"][k]):
+                        bad[k] = True
+            out["calls"] = (len(i), int(bad.sum()))
+        return out
+
+    def destroy(self):
+        for p in self._pinned:
+            self.ctx.lib.xvcgpu_host_free(self.ctx.h, p)
+        for b in self._keep:
+            if hasattr(b, "free"):
+                b.free()
+        for p in self.scratch + [self.orig]:
+            p.destroy()

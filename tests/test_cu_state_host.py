@@ -1,0 +1,50 @@
+"""The CU-state tables of the serial RD replay without a device: the bindings' struct
+sizes, and the grouping of a captured encode into states (tests/rd_serial.py)."""
+import ctypes as C
+
+import numpy as np
+
+import rd_serial
+from xvc_amd import api, decoder
+
+
+def test_binding_sizes():
+    L = decoder.load_host_library()
+    out = (C.c_int32 * 3)()
+    L.xvc_host_cs_sizes(out)
+    assert list(out) == [rd_serial.STATE_DTYPE.itemsize, C.sizeof(rd_serial.CsTables),
+                         C.sizeof(rd_serial.CsStats)]
+
+
+def test_states_of_a_captured_picture():
+    sp = rd_serial.SerialPicture(api, "tiny", 2)
+    st, s = sp.states, sp.summary()
+    assert s["states"] > 5000 and s["inter"] > 1000 and s["merge_rank"] > 500
+    # every record of the picture sits in exactly one state, in capture order
+    assert s["me"] == int((sp.me["poc"] == 2).sum())
+    steps = sp.rd["steps"]
+    assert s["bi"] + s["affine"] == int((steps["poc"] == 2).sum())
+    ev = sp.rd["evals"]
+    calls = sp.rd["calls"]
+    assert s["calls"] == int((ev["poc"][calls["eval"]] == 2).sum())
+    for f, c in (("me_first", st["me_count"]), ("bi_first", st["bi_count"]),
+                 ("aff_first", st["aff_uni_count"] + st["aff_bi_count"]),
+                 ("call_first", st["call_pass0"] + st["call_pass1"])):
+        used = c > 0
+        assert np.array_equal(st[f][used], np.r_[0, np.cumsum(c[used])[:-1]])
+    # an inter state: searches, then an evaluation whose motion is one the search priced
+    inter = st[st["kind"] == rd_serial.KIND_INTER]
+    assert (inter["me_count"] > 0).all() and (inter["ev"] >= 0).all() and (inter["cand_count"] > 0).all()
+    # the state's vector is its SearchMotion's final choice (first pass, or the affine second)
+    fin = sp.order["finals"]
+    n_checked = 0
+    for r in inter[:400]:
+        e = sp.ev_want[r["ev"]]
+        fs = fin[int(r["final_first"]):int(r["final_first"]) + int(r["final_count"])]
+        assert len(fs) in (1, 2)
+        hit = [f for f in fs if f["inter_dir"] == e["inter_dir"] and
+               all(np.array_equal(f["mv"][l], e["mv"][l]) for l in range(2)
+                   if e["inter_dir"] == 2 or e["inter_dir"] == l)]
+        assert hit, (r, e, fs)
+        n_checked += 1
+    assert n_checked == 400

@@ -1,0 +1,49 @@
+"""A real picture's RD search walked one CU STATE at a time, in the order the reference
+encoder issued it (tests/rd_serial.py, xvc_amd/host/xvc_cu_state.cc): every step a batch
+of one with a read-back wherever the reference reads a result - the regime a bit-exact
+encoder can actually present.  Every result equals what the reference encoder got."""
+import numpy as np
+import pytest
+
+import rd_serial
+import stream_fixture as sf
+from test_gpu_me_calls import decode_stream
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    from xvc_amd import api
+    ctx = api.Context(0)
+    yield api, ctx
+    ctx.close()
+
+
+def _run(api, ctx, name, poc, n_states):
+    fx = sf.StreamFixture(name)
+    pics, w, h = decode_stream(ctx, fx)
+    sp = rd_serial.SerialPicture(api, name, poc)
+    run = rd_serial.SerialRun(api, ctx, sp, pics, w, h)
+    n = min(n_states, len(sp.states))
+    stats = run.run_serial(0, n)
+    res = run.check(0, n)
+    run.destroy()
+    for p in pics.values():
+        p.destroy()
+    return sp, stats, res
+
+
+@pytest.mark.parametrize("name,poc,n_states", [("tiny", 2, 1 << 30), ("c1", 2, 6000)])
+def test_serial_walk_equals_reference(gpu, name, poc, n_states):
+    api, ctx = gpu
+    sp, stats, res = _run(api, ctx, name, poc, n_states)
+    print(name, sp.summary(), res, "%.1f us / state, %.1f API calls, %.2f round trips per state" % (
+        1e6 * stats.seconds / max(stats.states, 1), stats.api_calls / max(stats.states, 1),
+        stats.round_trips / max(stats.states, 1)))
+    assert stats.states > 1000
+    for k in ("me", "bi", "merge", "calls", "dist_zero"):
+        assert res[k][0] > 100 and res[k][1] == 0, (k, res)
+    assert res["affine"][1] == 0, res
+    if name == "c1":
+        assert res["affine"][0] > 100

@@ -207,3 +207,9 @@ extern "C" int xvc_host_cu_state_run_serial(xvcgpu_ctx *ctx, const xvc_cs_tables
   stats->seconds = Now() - t0;
   return w.err;
 }
+
+extern "C" void xvc_host_cs_sizes(int32_t out[3]) {
+  out[0] = static_cast<int32_t>(sizeof(xvc_cs_state));
+  out[1] = static_cast<int32_t>(sizeof(xvc_cs_tables));
+  out[2] = static_cast<int32_t>(sizeof(xvc_cs_stats));
+}

@@ -122,6 +122,9 @@ int xvc_host_cu_state_run_serial(xvcgpu_ctx *ctx, const xvc_cs_tables *t,
                                  const xvc_cs_state *states, int first, int n, int read_levels,
                                  xvc_cs_stats *stats);
 
+// sizeof(xvc_cs_state), sizeof(xvc_cs_tables), sizeof(xvc_cs_stats): bindings check.
+void xvc_host_cs_sizes(int32_t out[3]);
+
 // InterSearch::GetInterPredBits with the encoder's default setting, for n motion
 // candidates: candidate i is priced against snapshots[ictx_index[i]] (ictx_index
 // NULL: snapshot i).  Host arithmetic (include/xvc_inter_bits.h).
