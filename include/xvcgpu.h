@@ -883,6 +883,52 @@ xvcgpu_status xvcgpu_affine_me_batch(xvcgpu_ctx *ctx, const xvcgpu_picture *orig
                                      const xvcgpu_affine_me_block *d_blocks, int n,
                                      xvcgpu_affine_me_result *d_results);
 
+/* ---- the folds of one SearchMotion chain --------------------------------------- *
+ * xvcgpu_cs_pass (include/xvcgpu_types.h) describes one SearchMotion of a CU; the three
+ * calls below run the host logic of InterSearch::SearchRefIdx / SearchBiIterative /
+ * SearchMotion (inter_search.cc:199-259, :392-578) between the batched searches, ON the
+ * device, each reading the previous step's results and writing the next step's jobs -
+ * a CU state is enqueued once and read back once (no host round trip inside):
+ *
+ *   xvcgpu_mc_metric_batch (SAD of both predictors)     -> d_start_dist
+ *   xvcgpu_cs_start_fold   EvalStartMvp's choice        -> the search jobs' predictor
+ *                          (+ previous_fullpel_, + the affine bootstrap vector)
+ *   xvcgpu_me_search / xvcgpu_affine_me_batch           -> d_me_res / d_aff_res
+ *   xvcgpu_cs_uni_fold     EvalFinalMvpIdx, SetMvd, GetInterPredBits (default bit
+ *                          prices, include/xvc_inter_bits.h), the cost fold per list,
+ *                          the list SearchBiIterative searches
+ *                                                       -> the refinement job slots
+ *   xvcgpu_bipred_search / xvcgpu_affine_me_batch       -> d_bi_res / d_aff_res
+ *   xvcgpu_cs_bi_fold      the refinement's costs, the three-way choice (:247-257),
+ *                          the affine pass against the plain one (:85-93),
+ *                          HasZeroMvd                   -> d_results, the evaluation's
+ *                                                          xvcgpu_inter_block jobs
+ *
+ * Refinement job slots of a pass: bi_job + (searched list * R + ref_idx) * R + other
+ * ref_idx, R = XVC_CS_MAX_REFS; the fold fills the slots this state searches and empties
+ * the others (block width 0: the search kernels return at once), so the host can issue
+ * one launch per slot that exists without knowing which list won.  The affine pass's
+ * slots and search jobs live in the xvcgpu_affine_me_block array.  A call folds the
+ * passes [first, first + n) of d_passes / d_results (an affine pass names its plain
+ * pass by absolute index). */
+xvcgpu_status xvcgpu_cs_start_fold(xvcgpu_ctx *ctx, const xvcgpu_cs_pass *d_passes, int first,
+    int n,
+                                   const uint64_t *d_start_dist, xvcgpu_me_block *d_me_jobs,
+                                   const xvcgpu_me_result *d_me_res,
+                                   xvcgpu_affine_me_block *d_aff_jobs,
+                                   xvcgpu_cs_result *d_results, int pic_w, int pic_h);
+xvcgpu_status xvcgpu_cs_uni_fold(xvcgpu_ctx *ctx, const xvcgpu_cs_pass *d_passes, int first,
+    int n,
+                                 const xvcgpu_me_result *d_me_res,
+                                 const xvcgpu_affine_me_result *d_aff_res,
+                                 xvcgpu_cs_result *d_results, xvcgpu_bi_block *d_bi_jobs,
+                                 xvcgpu_affine_me_block *d_aff_jobs);
+xvcgpu_status xvcgpu_cs_bi_fold(xvcgpu_ctx *ctx, const xvcgpu_cs_pass *d_passes, int first,
+    int n,
+                                const xvcgpu_me_result *d_bi_res,
+                                const xvcgpu_affine_me_result *d_aff_res,
+                                xvcgpu_cs_result *d_results, xvcgpu_inter_block *d_ev_inter);
+
 /* ---- multi-GPU staging --------------------------------------------------- *
  * n device-to-device copies (descriptors in device memory) in one launch: packs
  * the row slabs / CU metadata rows a rank exchanges with its neighbours into

@@ -331,6 +331,76 @@ typedef struct xvcgpu_inter_contexts {
                           * (syntax_writer.cc:861-865, entropy_encoder.cc:33-38)      */
 } xvcgpu_inter_contexts;
 
+/* ---- one SearchMotion of a CU, chained on the device --------------------------- *
+ * InterSearch::SearchMotion (inter_search.cc:199-259) is a chain: per list and
+ * picture EvalStartMvp -> search -> EvalFinalMvpIdx -> GetInterPredBits -> cost fold
+ * (SearchRefIdx :456-578), then SearchBiIterative (:392-433) from the two winners,
+ * then the three-way choice (:247-257); CompressInter (:74-98) runs it a second time
+ * with the affine model and keeps the cheaper result.  The searches are the batched
+ * entry points; what sits BETWEEN them - a few dozen integer operations on their
+ * results - are the three folds below, so that the chain needs no host round trip:
+ * each fold reads the previous step's results and writes the next step's jobs.
+ * A pass describes what the encoder's control code knows before the search. */
+#define XVC_CS_MAX_REFS 3      /* pictures per list (default_num_ref_pics 2, placebo 3) */
+#define XVC_CS_FULLPEL 1       /* cu.GetFullpelMv()                                   */
+#define XVC_CS_AFFINE 8        /* the affine pass (MotionVector3, MotionEstAffine)      */
+typedef struct xvcgpu_cs_pass {
+  int16_t x, y;                /* luma position of the CU                              */
+  uint8_t w, h;
+  uint8_t flags;               /* XVC_CS_*                                             */
+  uint8_t num_refs[2];         /* pictures per list                                    */
+  int8_t same_poc_in_l0[XVC_CS_MAX_REFS]; /* list-1 picture -> the list-0 ref_idx of the
+                                * same picture (its result is re-used, :536-542), -1   */
+  uint32_t lambda16;           /* floor(65536 * sqrt(lambda))                          */
+  xvcgpu_inter_contexts ictx;  /* what GetInterPredBits reads of the entropy coder      */
+  int32_t mvp[2][XVC_CS_MAX_REFS][2][3][2]; /* GetMvpList[Affine]: [list][ref_idx][predictor]
+                                * [corner][x, y]; a plain vector uses corner 0         */
+  int32_t uni_job[2][XVC_CS_MAX_REFS];   /* index of the search's job / result in the
+                                * xvcgpu_me_block (affine pass: xvcgpu_affine_me_block)
+                                * array; -1: no search (re-used picture)               */
+  int32_t start_dist[2][XVC_CS_MAX_REFS]; /* index of predictor 0's EvalStartMvp
+                                * distortion (SAD of its prediction); predictor 1's
+                                * follows                                             */
+  int32_t prev_job[2][XVC_CS_MAX_REFS];  /* plain pass: the earlier search job of the same
+                                * chain whose full-pel result is this search's
+                                * previous_fullpel_ (:640-641), -1: the job holds it   */
+  int32_t bi_job;              /* first of the pass's 2 * MAX_REFS * MAX_REFS refinement
+                                * job slots [searched list][ref_idx][other ref_idx]    */
+  int32_t plain_pass;          /* affine pass: the CU's plain pass (bootstrap vectors,
+                                * the result it has to beat), else -1                  */
+  int32_t eval;                /* the evaluation (3 xvcgpu_inter_block) that takes the
+                                * chosen motion, -1: none                              */
+  int8_t slot[2][XVC_CS_MAX_REFS]; /* reference picture slot per (list, ref_idx)       */
+  uint8_t reserved[2];
+} xvcgpu_cs_pass;
+
+/* What a pass computed: every intermediate the reference's loop holds (readable by
+ * the host for checking) and the motion state SearchMotion ends with. */
+typedef struct xvcgpu_cs_result {
+  uint8_t start_idx[2][XVC_CS_MAX_REFS];  /* EvalStartMvp                              */
+  uint8_t mvp_idx[2][XVC_CS_MAX_REFS];    /* EvalFinalMvpIdx                           */
+  int32_t mv[2][XVC_CS_MAX_REFS][3][2];   /* uni-directional result per picture        */
+  uint32_t dist[2][XVC_CS_MAX_REFS], bits[2][XVC_CS_MAX_REFS], cost[2][XVC_CS_MAX_REFS];
+  uint32_t cost_list[2], cost_l1_unique;
+  int8_t best_ref[2], best_ref_l1_unique; /* SearchRefIdx's winners (-1: none)         */
+  uint8_t search_list;                    /* the list SearchBiIterative searched        */
+  uint8_t bi_mvp_idx[XVC_CS_MAX_REFS];
+  uint8_t bi_valid;                       /* a refinement was run                       */
+  int32_t bi_mv[XVC_CS_MAX_REFS][3][2];
+  uint32_t bi_dist[XVC_CS_MAX_REFS], bi_bits[XVC_CS_MAX_REFS], bi_cost[XVC_CS_MAX_REFS];
+  /* SearchMotion's result (inter_search.cc:247-257) */
+  uint8_t which;               /* 0 bi, 1 list 0, 2 list 1 (unique picture)            */
+  uint8_t inter_dir;
+  int8_t ref_idx[2];
+  uint8_t out_mvp_idx[2];
+  uint8_t zero_mvd;            /* CodingUnit::HasZeroMvd()                              */
+  uint8_t chosen;              /* affine pass: 1 = this pass beat the plain one (:85-93);
+                                * plain pass: 1                                        */
+  uint32_t best_cost;
+  int32_t out_mv[2][3][2];
+  int32_t out_mvd[2][2][2];
+} xvcgpu_cs_result;
+
 /* One motion-compensation job (InterPrediction::MotionCompensationMv,
  * inter_prediction.cc:740-758) for one component of one uni-pred CU. */
 typedef struct xvcgpu_mc_block {

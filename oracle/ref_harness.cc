@@ -2554,9 +2554,10 @@ void AfterMotionEst(InterSearch *is, CodingUnit *cu, const Qp &qp, RefPicList re
     for (size_t k = 0; k < N && k < 2; k++) PutMv(c.mvp[k], mvp_list[k]);
     if (bipred) {
       c.start_mvp_idx = static_cast<uint8_t>(is->unipred_best_mvp_idx_[static_cast<int>(ref_list)][ref_idx]);
-    } else if (!c.reused) {
-      /* EvalStartMvp's choice (:493-496) asked again: a pure function of CU,
-       * predictors and pictures (scratch prediction buffer) */
+    } else {
+      /* EvalStartMvp's choice (:493-496; also made for list-1 pictures that then re-use
+       * list 0's result) asked again: a pure function of CU, predictors and pictures
+       * (scratch prediction buffer) */
       SampleBufferStorage scratch(constants::kMaxBlockSize, constants::kMaxBlockSize);
       Distortion cost = 0;
       c.start_mvp_idx = static_cast<uint8_t>(is->EvalStartMvp<std::is_same<MV, MotionVector3>::value>(

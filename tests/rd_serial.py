@@ -507,9 +507,10 @@ class SerialRun:
                 rc, self.ctx.lib.xvcgpu_last_error(self.ctx.h)))
         return stats
 
-    def check(self, first=0, n=None, levels=True):
+    def check(self, first=0, n=None, levels=True, searches=True):
         """Every result the walk read back against what the reference encoder got.
-        -> dict of (compared, mismatching) per table."""
+        -> dict of (compared, mismatching) per table.  searches=False: the chained form
+        keeps the searches' results in its own arrays (check_chained compares them)."""
         sp, res = self.sp, self.res
         st = sp.states[first:None if n is None else first + n]
         st = st[st["supported"] != 0]
@@ -519,16 +520,16 @@ class SerialRun:
             idx = [np.arange(int(a), int(a) + int(b)) for a, b in zip(st[first_f], count_f) if b]
             return np.concatenate(idx) if idx else np.zeros(0, np.int64)
 
-        i = rng("me_first", st["me_count"])
+        i = rng("me_first", st["me_count"] * (1 if searches else 0))
         w, g = sp.me_want[i], res["me_res"][i]
         out["me"] = (len(i), int(((g["fullpel_x"] != w["fullpel_x"]) | (g["fullpel_y"] != w["fullpel_y"]) |
                                   (g["mv_x"] != w["mv_x"]) | (g["mv_y"] != w["mv_y"]) |
                                   (g["subpel_dist"] != w["dist"])).sum()))
-        i = rng("bi_first", st["bi_count"])
+        i = rng("bi_first", st["bi_count"] * (1 if searches else 0))
         w, g = sp.bi_want[i], res["bi_res"][i]
         out["bi"] = (len(i), int(((g["mv_x"] != w["mv"][:, 0, 0]) | (g["mv_y"] != w["mv"][:, 0, 1]) |
                                   (g["subpel_dist"] != w["dist"])).sum()))
-        i = rng("aff_first", st["aff_uni_count"] + st["aff_bi_count"])
+        i = rng("aff_first", (st["aff_uni_count"] + st["aff_bi_count"]) * (1 if searches else 0))
         w, g = sp.aff_want[i], res["aff_res"][i]
         out["affine"] = (len(i), int((~((g["mv"] == w["mv"]).all(axis=(1, 2)) & (g["dist"] == w["dist"]))).sum()))
         m = st["merge"][st["kind"] == KIND_MERGE_RANK].astype(np.int64)
@@ -577,3 +578,441 @@ class SerialRun:
                 b.free()
         for p in self.scratch + [self.orig]:
             p.destroy()
+
+
+# ======================================================================================
+# The chained form: passes (xvcgpu_cs_pass), work arrays the device composes, programs.
+# ======================================================================================
+R3 = 3               # XVC_CS_MAX_REFS
+CS_FULLPEL, CS_AFFINE = 1, 8
+
+PASS_DTYPE = np.dtype([
+    ("x", "<i2"), ("y", "<i2"), ("w", "u1"), ("h", "u1"), ("flags", "u1"), ("num_refs", "u1", 2),
+    ("same_poc_in_l0", "i1", R3), ("lambda16", "<u4"), ("ictx", of.ICTX_DTYPE),
+    ("mvp", "<i4", (2, R3, 2, 3, 2)), ("uni_job", "<i4", (2, R3)), ("start_dist", "<i4", (2, R3)),
+    ("prev_job", "<i4", (2, R3)), ("bi_job", "<i4"), ("plain_pass", "<i4"), ("eval", "<i4"),
+    ("slot", "i1", (2, R3)), ("reserved", "u1", 2)], align=True)
+
+RESULT_DTYPE = np.dtype([
+    ("start_idx", "u1", (2, R3)), ("mvp_idx", "u1", (2, R3)), ("mv", "<i4", (2, R3, 3, 2)),
+    ("dist", "<u4", (2, R3)), ("bits", "<u4", (2, R3)), ("cost", "<u4", (2, R3)),
+    ("cost_list", "<u4", 2), ("cost_l1_unique", "<u4"), ("best_ref", "i1", 2),
+    ("best_ref_l1_unique", "i1"), ("search_list", "u1"), ("bi_mvp_idx", "u1", R3),
+    ("bi_valid", "u1"), ("bi_mv", "<i4", (R3, 3, 2)), ("bi_dist", "<u4", R3),
+    ("bi_bits", "<u4", R3), ("bi_cost", "<u4", R3), ("which", "u1"), ("inter_dir", "u1"),
+    ("ref_idx", "i1", 2), ("out_mvp_idx", "u1", 2), ("zero_mvd", "u1"), ("chosen", "u1"),
+    ("best_cost", "<u4"), ("out_mv", "<i4", (2, 3, 2)), ("out_mvd", "<i4", (2, 2, 2))], align=True)
+
+OP_DTYPE = np.dtype([("opcode", "<i4"), ("n", "<i4"), ("r0", "<i4"), ("r1", "<i4"), ("i0", "<i4"),
+                     ("reserved", "<i4"), ("f", "<f8"), ("p", "<u8", 5)], align=True)
+(OP_MC_METRIC, OP_METRIC, OP_ME, OP_BI, OP_AFFINE, OP_COPY, OP_INTER_PRED, OP_RESIDUAL,
+ OP_START_FOLD, OP_UNI_FOLD, OP_BI_FOLD, OP_FETCH, OP_SYNC) = range(13)
+PIC_ORIG, PIC_S_ORIG, PIC_S_PRED, PIC_S_REC = 0, 1, 2, 3
+BI_SLOTS = 2 * R3 * R3
+
+
+class CsEnv(C.Structure):
+    _fields_ = [("orig", C.c_void_p), ("refs", C.c_void_p), ("n_refs", C.c_int32),
+                ("pic_w", C.c_int32), ("pic_h", C.c_int32), ("reserved", C.c_int32),
+                ("s_orig", C.c_void_p), ("s_pred", C.c_void_p), ("s_rec", C.c_void_p),
+                ("d_levels", C.c_void_p), ("d_results", C.c_void_p)]
+
+
+def build_passes(sp, ref_lists):
+    """The passes of every inter / motion state of the picture and the arrays the chained
+    form works on.  ref_lists: ([poc per ref_idx of list 0], [... list 1]) of the picture.
+    Adds to sp: passes, pass_first / pass_count per state, start cands, work jobs."""
+    api = sp.api
+    cd_all, st = sp.tabs["cands"], sp.states
+    slot_of = {p: i for i, p in enumerate(sp.ref_pocs)}
+    nref = [len(ref_lists[0]), len(ref_lists[1])]
+    same = [-1] * R3
+    for r, poc in enumerate(ref_lists[1]):
+        same[r] = ref_lists[0].index(poc) if poc in ref_lists[0] else -1
+    passes, pass_first, pass_count = [], np.full(len(st), -1, np.int64), np.zeros(len(st), np.int64)
+    start_cands = []            # plain passes: mc_metric candidates, grouped per pass by slot
+    start_groups = {}           # pass -> [(slot, first, n)]
+    aff_start = {}              # affine pass -> (first candidate index, n)
+    aff_inter, aff_dst, aff_cands, aff_copy = [], [], [], []
+    n_start_dist = 0
+    me_work = sp.me_jobs.copy()
+    aff_work_rows = []          # (source: index into sp.aff_jobs or -1 for a slot)
+    n_bi_slots = 0
+    uni_groups, aff_uni_groups = {}, {}
+    for n in np.flatnonzero((st["kind"] >= KIND_INTER) & (st["supported"] != 0)):
+        s = st[n]
+        cds = cd_all[int(s["cand_first"]):int(s["cand_first"]) + int(s["cand_count"])]
+        plain = cds[cds["kind"] == 0]
+        aff = cds[cds["kind"] == 2]
+        pass_first[n] = len(passes)
+        me_next = int(s["me_first"])
+        aff_next = int(s["aff_first"])
+        for which, cu in ((0, plain), (1, aff)):
+            if not len(cu):
+                continue
+            assert len(cu) == nref[0] + nref[1], (n, len(cu), nref)
+            p = np.zeros((), PASS_DTYPE)
+            p["x"], p["y"], p["w"], p["h"] = s["x"], s["y"], s["w"], s["h"]
+            p["flags"] = (int(cu[0]["flags"]) & 1) | (CS_AFFINE if which else 0)
+            p["num_refs"] = nref
+            p["same_poc_in_l0"] = same
+            p["lambda16"] = cu[0]["lambda16"]
+            p["ictx"] = sp.order["ictx"][int(cu[0]["ictx_index"])]
+            p["uni_job"], p["start_dist"], p["prev_job"] = -1, -1, -1
+            p["plain_pass"], p["eval"] = -1, -1
+            pi = len(passes)
+            entries = []
+            for c in cu:
+                l, r = int(c["list"]), int(c["ref_idx"])
+                p["mvp"][l, r] = c["mvp"]
+                p["slot"][l, r] = slot_of[ref_lists[l][r]]
+                entries.append((l, r, bool(c["reused"])))
+            if which == 0:
+                # EvalStartMvp: two luma predictions + SAD per (list, picture), re-used ones too
+                order = sorted(range(len(entries)), key=lambda k: int(p["slot"][entries[k][0], entries[k][1]]))
+                groups = []
+                for k in order:
+                    l, r, _ = entries[k]
+                    sl = int(p["slot"][l, r])
+                    p["start_dist"][l, r] = n_start_dist
+                    for cand in range(2):
+                        start_cands.append((int(s["x"]), int(s["y"]), int(s["w"]), int(s["h"]), 3, 0,
+                                            int(p["mvp"][l, r, cand, 0, 0]), int(p["mvp"][l, r, cand, 0, 1])))
+                    if groups and groups[-1][0] == sl:
+                        groups[-1][2] += 2
+                    else:        # (slot, first distortion, count, first candidate)
+                        groups.append([sl, n_start_dist, 2, len(start_cands) - 2])
+                    n_start_dist += 2
+                start_groups[pi] = groups
+                ug = []
+                for l, r, reused in entries:
+                    if reused:
+                        continue
+                    p["uni_job"][l, r] = me_next
+                    assert sp.me_ref[me_next] == p["slot"][l, r], (n, l, r)
+                    me_work["mvp_x"][me_next] = me_work["mvp_y"][me_next] = 0x7fffff
+                    ug.append((int(p["slot"][l, r]), me_next))
+                    me_next += 1
+                uni_groups[pi] = ug
+                p["bi_job"] = n_bi_slots
+                n_bi_slots += BI_SLOTS
+            else:
+                p["plain_pass"] = pi - 1
+                first = len(aff_inter)
+                for l, r, _ in entries:
+                    p["start_dist"][l, r] = n_start_dist
+                    for cand in range(2):
+                        k = len(aff_inter) - first
+                        ib = np.zeros((), api.INTER_DTYPE)
+                        ib["x"], ib["y"], ib["w"], ib["h"] = s["x"], s["y"], s["w"], s["h"]
+                        ib["flags"] = api.INTER_AFFINE
+                        ib["ref"] = (int(p["slot"][l, r]), -1)
+                        ib["mv"][0] = p["mvp"][l, r, cand]
+                        aff_inter.append(ib)
+                        aff_dst.append((SLOT * k, 0))
+                        aff_cands.append((SLOT * k, 0, int(s["w"]), int(s["h"]), 3, 0, 0, 0))
+                        aff_copy.append((int(s["x"]), int(s["y"]), SLOT * k, 0, int(s["w"]), int(s["h"]), 0, 0))
+                        n_start_dist += 1
+                assert len(aff_inter) - first <= MAX_SLOTS
+                aff_start[pi] = (first, len(aff_inter) - first, int(p["start_dist"][entries[0][0], entries[0][1]]))
+                ug = []
+                for l, r, reused in entries:
+                    if reused:
+                        continue
+                    p["uni_job"][l, r] = len(aff_work_rows)
+                    assert sp.aff_ref[aff_next][0] == p["slot"][l, r]
+                    ug.append((int(p["slot"][l, r]), len(aff_work_rows)))
+                    aff_work_rows.append(aff_next)
+                    aff_next += 1
+                aff_uni_groups[pi] = ug
+                p["bi_job"] = len(aff_work_rows)
+                aff_work_rows += [-1] * BI_SLOTS
+            passes.append(p)
+        if len(plain):
+            assert me_next == int(s["me_first"]) + int(s["me_count"]), (n, me_next, s)
+        if len(aff):
+            assert aff_next == int(s["aff_first"]) + int(s["aff_uni_count"]), (n, aff_next, s)
+        pass_count[n] = len(passes) - pass_first[n]
+        if s["kind"] == KIND_INTER:
+            passes[-1]["eval"] = s["ev"]
+    sp.passes = np.array(passes, PASS_DTYPE) if passes else np.zeros(0, PASS_DTYPE)
+    sp.pass_first, sp.pass_count = pass_first, pass_count
+    sp.start_cands = np.array(start_cands, api.MCM_DTYPE) if start_cands else np.zeros(0, api.MCM_DTYPE)
+    sp.start_groups, sp.uni_groups, sp.aff_uni_groups, sp.aff_start = start_groups, uni_groups, aff_uni_groups, aff_start
+    sp.n_start_dist = n_start_dist
+    sp.aff_start_inter = np.array(aff_inter, api.INTER_DTYPE) if aff_inter else np.zeros(0, api.INTER_DTYPE)
+    sp.aff_start_dst = np.array(aff_dst, api.POS_DTYPE) if aff_dst else np.zeros(0, api.POS_DTYPE)
+    sp.aff_start_cands = np.array(aff_cands, api.CAND_DTYPE) if aff_cands else np.zeros(0, api.CAND_DTYPE)
+    sp.aff_start_copy = np.array(aff_copy, api.COPY_BLOCK_DTYPE) if aff_copy else np.zeros(0, api.COPY_BLOCK_DTYPE)
+    sp.me_work = me_work
+    sp.n_bi_slots = n_bi_slots
+    aw = np.zeros(len(aff_work_rows), api.AFFINE_ME_DTYPE)
+    rows = np.array(aff_work_rows, np.int64) if aff_work_rows else np.zeros(0, np.int64)
+    src = rows >= 0
+    if src.any():
+        aw[src] = sp.aff_jobs[rows[src]]
+        aw["mvp"][src] = 0x7fffff           # composed on the device
+        aw["bootstrap"][src] = 0x7fffff
+    sp.aff_work, sp.aff_work_src = aw, rows
+    # the evaluations' prediction jobs: motion composed on the device for inter states
+    ei = sp.ev_inter.copy()
+    for n in np.flatnonzero((st["kind"] == KIND_INTER) & (st["supported"] != 0)):
+        e = int(st["ev"][n])
+        ei["ref"][e], ei["mv"][e], ei["flags"][e] = (0, -1), 12345, 0    # overwritten by the fold
+    sp.ev_inter_work = ei
+
+
+class ChainedRun(SerialRun):
+    """SerialRun + the arrays and the program of the chained form."""
+
+    def __init__(self, api, ctx, sp, pics, width, height, ref_lists):
+        super().__init__(api, ctx, sp, pics, width, height)
+        if not hasattr(sp, "passes"):
+            build_passes(sp, ref_lists)
+        self.lib.xvc_host_cs_run_program.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
+                                                     C.c_void_p]
+        up = self._upload
+        self.d = d = {}
+        d["passes"], d["start_cands"] = up(sp.passes), up(sp.start_cands)
+        d["aff_start_inter"], d["aff_start_dst"] = up(sp.aff_start_inter), up(sp.aff_start_dst)
+        d["aff_start_cands"], d["aff_start_copy"] = up(sp.aff_start_cands), up(sp.aff_start_copy)
+        d["me_work"], d["aff_work"] = up(sp.me_work), up(sp.aff_work)
+        d["bi_work"] = up(np.zeros(max(sp.n_bi_slots, 1), api.BI_DTYPE))
+        d["ev_inter_work"] = up(sp.ev_inter_work)
+        self.cres = {}
+        for name, dt, n in (("start_dist", np.dtype("<u8"), sp.n_start_dist),
+                            ("me_res_c", api.MERES_DTYPE, len(sp.me_work)),
+                            ("bi_res_c", api.MERES_DTYPE, sp.n_bi_slots),
+                            ("aff_res_c", api.AFFINE_ME_RESULT_DTYPE, len(sp.aff_work)),
+                            ("results", RESULT_DTYPE, len(sp.passes)),
+                            ("ev_inter_out", api.INTER_DTYPE, 3 * len(sp.ev_inter))):
+            nbytes = max(n, 1) * dt.itemsize
+            if name != "ev_inter_out":
+                buf = self.ctx.alloc(nbytes)
+                self._keep.append(buf)
+                self.ctx._check(self.ctx.lib.xvcgpu_memset(self.ctx.h, buf.ptr, 0xee, nbytes))
+                d[name] = buf.ptr
+            h = self._pin(nbytes)
+            C.memset(h, 0xff, nbytes)
+            self.cres[name] = (np.frombuffer((C.c_char * nbytes).from_address(h), dt)[:n], h)
+        self.env = e = CsEnv()
+        e.orig, e.refs, e.n_refs = self.t.orig, self.t.refs, self.t.n_refs
+        e.pic_w, e.pic_h = width, height
+        e.s_orig, e.s_pred, e.s_rec = self.t.s_orig, self.t.s_pred, self.t.s_rec
+        e.d_levels, e.d_results = self.t.d_levels, d["results"]
+        self.ctx.sync()
+
+    # ---- program ---------------------------------------------------------------
+    def program(self, first, n, by_position=True):
+        """Ops of the states [first, first + n): one chain (ending in a SYNC) per state,
+        or per visit of a CU position (consecutive states of one CU)."""
+        sp, api, t, d = self.sp, self.api, self.t, self.d
+        st = sp.states
+        ops = []
+        I = {k: v.itemsize for k, v in (("me", api.ME_DTYPE), ("res", api.MERES_DTYPE),
+                                        ("bi", api.BI_DTYPE), ("aff", api.AFFINE_ME_DTYPE),
+                                        ("affr", api.AFFINE_ME_RESULT_DTYPE), ("pass", PASS_DTYPE),
+                                        ("mcm", api.MCM_DTYPE), ("inter", api.INTER_DTYPE),
+                                        ("pos", api.POS_DTYPE), ("cand", api.CAND_DTYPE),
+                                        ("copy", api.COPY_BLOCK_DTYPE), ("tx", api.TX_DTYPE),
+                                        ("prm", api.RDOQ_PARAMS_DTYPE), ("ctx", api.RDOQ_CTX_DTYPE),
+                                        ("result", RESULT_DTYPE))}
+
+        def op(code, n_=0, r0=0, r1=0, i0=0, f=0.0, p=()):
+            ops.append((code, n_, r0, r1, i0, 0, f, tuple(int(x) for x in p) + (0,) * (5 - len(p))))
+
+        def fetch(dev, host, nbytes):
+            if nbytes:
+                op(OP_FETCH, nbytes, p=(dev, host))
+
+        def motion(s, n_state):
+            ms = max(int(s["w"]), int(s["h"]))
+            pf, pc = int(sp.pass_first[n_state]), int(sp.pass_count[n_state])
+            for pi in range(pf, pf + pc):
+                p = sp.passes[pi]
+                affine = bool(p["flags"] & CS_AFFINE)
+                P = d["passes"]                  # the folds index the arrays absolutely (i0 = pass)
+                if not affine:
+                    for sl, a, k, ca in sp.start_groups[pi]:
+                        op(OP_MC_METRIC, k, r0=sl, p=(d["start_cands"] + ca * I["mcm"], d["start_dist"] + 8 * a))
+                else:
+                    a, k, sd = sp.aff_start[pi]
+                    op(OP_COPY, k, r0=PIC_ORIG, r1=PIC_S_ORIG, p=(d["aff_start_copy"] + a * I["copy"],))
+                    op(OP_INTER_PRED, k, r1=PIC_S_PRED, p=(d["aff_start_inter"] + a * I["inter"],
+                                                           d["aff_start_dst"] + a * I["pos"]))
+                    op(OP_METRIC, k, r0=PIC_S_ORIG, r1=PIC_S_PRED, i0=0, f=1.0,
+                       p=(d["aff_start_cands"] + a * I["cand"], d["start_dist"] + 8 * sd))
+                op(OP_START_FOLD, 1, i0=pi, p=(P, d["start_dist"], d["me_work"], d["me_res_c"], d["aff_work"]))
+                if not affine:
+                    for sl, j in sp.uni_groups[pi]:
+                        op(OP_ME, 1, r0=sl, i0=ms, p=(d["me_work"] + j * I["me"], d["me_res_c"] + j * I["res"]))
+                else:
+                    for sl, j in sp.aff_uni_groups[pi]:
+                        op(OP_AFFINE, 1, r0=sl, r1=sl, p=(d["aff_work"] + j * I["aff"], d["aff_res_c"] + j * I["affr"]))
+                op(OP_UNI_FOLD, 1, i0=pi, p=(P, d["me_res_c"], d["aff_res_c"], d["bi_work"], d["aff_work"]))
+                if p["num_refs"][1]:
+                    bj = int(p["bi_job"])
+                    for sl_ in range(2):
+                        for r in range(int(p["num_refs"][sl_])):
+                            for o in range(int(p["num_refs"][1 - sl_])):
+                                k = bj + (sl_ * R3 + r) * R3 + o
+                                rs, ro = int(p["slot"][sl_, r]), int(p["slot"][1 - sl_, o])
+                                if not affine:
+                                    op(OP_BI, 1, r0=rs, r1=ro, i0=ms,
+                                       p=(d["bi_work"] + k * I["bi"], d["bi_res_c"] + k * I["res"]))
+                                else:
+                                    op(OP_AFFINE, 1, r0=rs, r1=ro,
+                                       p=(d["aff_work"] + k * I["aff"], d["aff_res_c"] + k * I["affr"]))
+                op(OP_BI_FOLD, 1, i0=pi, p=(P, d["bi_res_c"], d["aff_res_c"], d["ev_inter_work"]))
+            fetch(d["results"] + pf * I["result"], self.cres["results"][1] + pf * I["result"], pc * I["result"])
+
+        def evaluation(s):
+            e = int(s["ev"])
+            n0, n1 = int(s["call_pass0"]), int(s["call_pass1"])
+            cf, k = int(s["call_first"]), n0 + n1
+            op(OP_COPY, 3 + k, r0=PIC_ORIG, r1=PIC_S_ORIG, p=(t.d_copy_orig + int(s["copy_first"]) * I["copy"],))
+            op(OP_INTER_PRED, 3, r1=PIC_S_PRED, p=(d["ev_inter_work"] + 3 * e * I["inter"],
+                                                   t.d_ev_dst + 3 * e * I["pos"]))
+            for c in range(3):
+                op(OP_METRIC, 1, r0=PIC_S_ORIG, r1=PIC_S_PRED, i0=c, f=float(sp.ev_weight[e, c]),
+                   p=(t.d_ev_dz + (3 * e + c) * I["cand"], t.d_ev_dz_dist + 8 * (3 * e + c)))
+            op(OP_COPY, k, r0=PIC_S_PRED, r1=PIC_S_PRED, p=(t.d_call_copy_pred + cf * I["copy"],))
+            op(OP_RESIDUAL, k, p=(t.d_call_tx + cf * I["tx"], t.d_call_off + 4 * cf, t.d_nnz + 4 * cf,
+                                  t.d_contexts + int(sp.ev_ctx[e]) * I["ctx"], t.d_call_prm + cf * I["prm"]))
+            a = cf
+            for c, cnt in list(enumerate(int(x) for x in s["comp_count"])) + [(0, n1)]:
+                if cnt:
+                    op(OP_METRIC, cnt, r0=PIC_S_ORIG, r1=PIC_S_REC, i0=c, f=float(sp.ev_weight[e, c]),
+                       p=(t.d_call_cand + a * I["cand"], t.d_call_dist + 8 * a))
+                a += cnt
+            fetch(t.d_nnz + 4 * cf, t.h_nnz + 4 * cf, 4 * k)
+            fetch(t.d_call_dist + 8 * cf, t.h_call_dist + 8 * cf, 8 * k)
+            fetch(t.d_ev_dz_dist + 24 * e, t.h_ev_dz_dist + 24 * e, 24)
+            fetch(t.d_levels + 2 * int(s["level_first"]), t.h_levels + 2 * int(s["level_first"]),
+                  2 * int(s["level_count"]))
+            fetch(d["ev_inter_work"] + 3 * e * I["inter"], self.cres["ev_inter_out"][1] + 3 * e * I["inter"],
+                  3 * I["inter"])
+
+        chain_states, chain_kind, prev_key = 0, 0, None
+        for n_state in range(first, first + n):
+            s = st[n_state]
+            if not s["supported"]:
+                continue
+            key = (int(s["x"]), int(s["y"]), int(s["w"]), int(s["h"]))
+            if chain_states and (not by_position or key != prev_key):
+                op(OP_SYNC, i0=chain_states, r0=chain_kind)
+                chain_states = 0
+            prev_key = key
+            kind = int(s["kind"])
+            if kind == KIND_MERGE_RANK:
+                m = int(s["merge"]) * 5
+                op(OP_COPY, 5, r0=PIC_ORIG, r1=PIC_S_ORIG, p=(t.d_mg_copy + m * I["copy"],))
+                op(OP_INTER_PRED, 5, r1=PIC_S_PRED, p=(t.d_mg_inter + m * I["inter"], t.d_mg_dst + m * I["pos"]))
+                op(OP_METRIC, 5, r0=PIC_S_ORIG, r1=PIC_S_PRED, i0=0, f=1.0,
+                   p=(t.d_mg_cands + m * I["cand"], t.d_mg_dist + 8 * m))
+                fetch(t.d_mg_dist + 8 * m, t.h_mg_dist + 8 * m, 40)
+            else:
+                if kind in (KIND_INTER, KIND_MOTION):
+                    motion(s, n_state)
+                if kind in (KIND_EVAL, KIND_INTER):
+                    evaluation(s)
+            chain_kind = max(chain_kind, kind) if chain_states else kind
+            chain_states += 1
+        if chain_states:
+            op(OP_SYNC, i0=chain_states, r0=chain_kind)
+        return np.array(ops, OP_DTYPE)
+
+    def run_program(self, ops):
+        stats = CsStats()
+        ops = np.ascontiguousarray(ops)
+        rc = self.lib.xvc_host_cs_run_program(self.ctx.h, C.addressof(self.env), ops.ctypes.data,
+                                              len(ops), C.addressof(stats))
+        if rc:
+            raise RuntimeError("xvc_host_cs_run_program: %d (%s)" % (
+                rc, self.ctx.lib.xvcgpu_last_error(self.ctx.h)))
+        return stats
+
+    def run_chained(self, first=0, n=None, by_position=True):
+        n = len(self.sp.states) - first if n is None else n
+        key = (first, n, by_position)
+        if getattr(self, "_prog_key", None) != key:
+            self._prog, self._prog_key = self.program(first, n, by_position), key
+        return self.run_program(self._prog)
+
+    def run_chained_state(self, first=0, n=None):
+        return self.run_chained(first, n, by_position=False)
+
+    def check_chained(self, first=0, n=None):
+        """The folds' intermediates and choices against the capture: every priced
+        candidate's final predictor, distortion, bits; SearchMotion's result; the motion
+        the evaluation was run with.  -> dict of (compared, mismatching)."""
+        sp = self.sp
+        st = sp.states
+        n = len(st) - first if n is None else n
+        R = self.cres["results"][0]
+        cd_all, fin = sp.tabs["cands"], sp.order["finals"]
+        out = {"cands": [0, 0], "finals": [0, 0], "eval_motion": [0, 0]}
+        for ns in range(first, first + n):
+            s = st[ns]
+            if not s["supported"] or s["kind"] < KIND_INTER or sp.pass_count[ns] == 0:
+                continue
+            pf = int(sp.pass_first[ns])
+            cds = cd_all[int(s["cand_first"]):int(s["cand_first"]) + int(s["cand_count"])]
+            for c in cds:
+                pi = pf + (1 if c["kind"] >= 2 else 0)
+                r, l, k = R[pi], int(c["list"]), int(c["ref_idx"])
+                out["cands"][0] += 1
+                if c["kind"] in (0, 2):
+                    ok = (r["dist"][l, k] == c["dist"] and r["bits"][l, k] == c["bits"] and
+                          r["mvp_idx"][l, k] == c["mvp_idx"] and r["start_idx"][l, k] == c["start_mvp_idx"] and
+                          np.array_equal(r["mv"][l, k][:3 if c["kind"] == 2 else 1], c["mv"][:3 if c["kind"] == 2 else 1]))
+                else:
+                    ok = (r["search_list"] == l and r["bi_dist"][k] == c["dist"] and r["bi_bits"][k] == c["bits"] and
+                          r["bi_mvp_idx"][k] == c["mvp_idx"] and
+                          np.array_equal(r["bi_mv"][k][:3 if c["kind"] == 3 else 1], c["mv"][:3 if c["kind"] == 3 else 1]))
+                if not ok:
+                    out["cands"][1] += 1
+                    self.first_bad = getattr(self, "first_bad", ("cand", ns, tuple(c), tuple(r)))
+            fs = fin[int(s["final_first"]):int(s["final_first"]) + int(s["final_count"])]
+            for k, f in enumerate(fs):
+                r = R[pf + k]
+                out["finals"][0] += 1
+                ok = r["which"] == f["which"] and r["inter_dir"] == f["inter_dir"]
+                for l in range(2):
+                    if f["inter_dir"] == 2 or f["inter_dir"] == l:
+                        nc = 3 if (f["flags"] & 8) else 1
+                        ok = ok and r["ref_idx"][l] == f["ref_idx"][l] and r["out_mvp_idx"][l] == f["mvp_idx"][l] and \
+                            np.array_equal(r["out_mv"][l][:nc], f["mv"][l][:nc]) and \
+                            np.array_equal(r["out_mvd"][l][:2 if nc == 3 else 1], f["mvd"][l][:2 if nc == 3 else 1])
+                if not ok:
+                    out["finals"][1] += 1
+                    self.first_bad = getattr(self, "first_bad", ("final", ns, tuple(f), tuple(r)))
+            if s["kind"] == KIND_INTER:
+                e = int(s["ev"])
+                got = self.cres["ev_inter_out"][0].reshape(-1, 3)[e]
+                want = sp.ev_inter[e]
+                out["eval_motion"][0] += 1
+                ok = True
+                for c in range(3):
+                    ok = ok and got[c]["flags"] == want[c]["flags"] and np.array_equal(got[c]["ref"], want[c]["ref"])
+                    for l in range(2):
+                        if want[c]["ref"][l] >= 0:
+                            nc = 3 if want[c]["flags"] & 1 else 1
+                            ok = ok and np.array_equal(got[c]["mv"][l][:nc], want[c]["mv"][l][:nc])
+                if not ok:
+                    out["eval_motion"][1] += 1
+                    self.first_bad = getattr(self, "first_bad", ("eval_motion", ns, got, want))
+        return {k: tuple(v) for k, v in out.items()}
+
+
+def ref_lists_of(name, poc):
+    """([picture per ref_idx of list 0], [... of list 1]) of the clip's picture `poc`
+    (stream fixture: the reference encoder's own lists)."""
+    import stream_fixture as sf
+    fx = sf.StreamFixture(name)
+    for i in range(fx.n):
+        info = fx.info[i]
+        if int(info["poc"]) == poc:
+            return tuple([int(info["ref_poc"][l][k]) for k in range(int(info["num_ref"][l]))]
+                         for l in range(2))
+    raise KeyError(poc)

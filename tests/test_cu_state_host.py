@@ -10,10 +10,12 @@ from xvc_amd import api, decoder
 
 def test_binding_sizes():
     L = decoder.load_host_library()
-    out = (C.c_int32 * 3)()
+    out = (C.c_int32 * 7)()
     L.xvc_host_cs_sizes(out)
     assert list(out) == [rd_serial.STATE_DTYPE.itemsize, C.sizeof(rd_serial.CsTables),
-                         C.sizeof(rd_serial.CsStats)]
+                         C.sizeof(rd_serial.CsStats), rd_serial.PASS_DTYPE.itemsize,
+                         rd_serial.RESULT_DTYPE.itemsize, rd_serial.OP_DTYPE.itemsize,
+                         C.sizeof(rd_serial.CsEnv)]
 
 
 def test_states_of_a_captured_picture():
@@ -48,3 +50,23 @@ def test_states_of_a_captured_picture():
         assert hit, (r, e, fs)
         n_checked += 1
     assert n_checked == 400
+
+
+def test_passes_of_a_captured_picture():
+    """Every SearchMotion of the picture becomes a pass whose entries are the (list,
+    picture) pairs SearchRefIdx walked; the affine pass follows its plain pass."""
+    sp = rd_serial.SerialPicture(api, "tiny", 2)
+    rd_serial.build_passes(sp, rd_serial.ref_lists_of("tiny", 2))
+    st, ps = sp.states, sp.passes
+    motion = (st["kind"] >= rd_serial.KIND_INTER) & (st["supported"] != 0)
+    assert (sp.pass_count[motion] >= 1).all() and (sp.pass_count[~motion] == 0).all()
+    assert len(ps) == int(sp.pass_count.sum()) > 1000
+    aff = (ps["flags"] & rd_serial.CS_AFFINE) != 0
+    assert aff.any() and (ps["plain_pass"][aff] == np.flatnonzero(aff) - 1).all()
+    assert (ps["plain_pass"][~aff] == -1).all()
+    # the searches of a pass are the state's jobs, each once
+    used = ps["uni_job"][~aff]
+    used = np.sort(used[used >= 0])
+    sup = st[motion]
+    want = np.concatenate([np.arange(a, a + c) for a, c in zip(sup["me_first"], sup["me_count"])])
+    assert np.array_equal(used, want)

@@ -47,3 +47,40 @@ def test_serial_walk_equals_reference(gpu, name, poc, n_states):
     assert res["affine"][1] == 0, res
     if name == "c1":
         assert res["affine"][0] > 100
+
+
+def _run_chained(api, ctx, name, poc, n_states, by_position):
+    fx = sf.StreamFixture(name)
+    pics, w, h = decode_stream(ctx, fx)
+    sp = rd_serial.SerialPicture(api, name, poc)
+    run = rd_serial.ChainedRun(api, ctx, sp, pics, w, h, rd_serial.ref_lists_of(name, poc))
+    n = min(n_states, len(sp.states))
+    stats = run.run_chained(0, n, by_position)
+    res = run.check(0, n, searches=False)
+    res.update(run.check_chained(0, n))
+    bad = repr(getattr(run, "first_bad", None))     # (views of pinned memory: before destroy)
+    run.destroy()
+    for p in pics.values():
+        p.destroy()
+    return sp, stats, res, bad
+
+
+@pytest.mark.parametrize("name,poc,n_states,by_position", [
+    ("tiny", 2, 1 << 30, False), ("tiny", 2, 1 << 30, True), ("c1", 2, 6000, True)])
+def test_chained_states_equal_reference(gpu, name, poc, n_states, by_position):
+    """The same states as ONE enqueue each (or per visit of a CU position), the folds
+    between the searches on the device (xvcgpu_cs_*_fold): no read-back inside a chain.
+    The searches' jobs are composed by the folds - the predictor EvalStartMvp picks, the
+    refinement's jobs, the affine bootstrap, the evaluation's motion - so every result
+    below depends on them: all equal to the reference's, and so are the folds' own
+    intermediates (final predictor, bits with the default prices, costs, choices)."""
+    api, ctx = gpu
+    sp, stats, res, bad = _run_chained(api, ctx, name, poc, n_states, by_position)
+    print(name, by_position, res, "%.1f us / state, %.1f API calls, %.2f round trips per state" % (
+        1e6 * stats.seconds / max(stats.states, 1), stats.api_calls / max(stats.states, 1),
+        stats.round_trips / max(stats.states, 1)))
+    for k, (done, wrong) in res.items():
+        assert wrong == 0, (k, res, bad)
+    assert stats.round_trips <= stats.states
+    for k in ("cands", "finals", "eval_motion", "calls", "merge"):
+        assert res[k][0] > 100, (k, res)

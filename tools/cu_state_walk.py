@@ -1,0 +1,96 @@
+#!/usr/bin/env python3
+"""The RD search of one real 1080p B picture (stream fixture c1, POC 2) walked CU state
+by CU state in the reference's issue order on k contexts at once (k independent
+pictures in flight, here k replays of the same picture on their own streams and
+buffers): microseconds per state, entry-point calls and read-backs per state,
+pictures per second.
+
+    python tools/cu_state_walk.py [--clip c1] [--poc 2] [--states 6000] [--k 1,4,8,16]
+                                  [--mode serial|chained]"""
+import argparse
+import json
+import os
+import sys
+import threading
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def walk(api, clip, poc, n_states, ks, mode="serial", check=True):
+    import rd_serial
+    import stream_fixture as sf
+    from test_gpu_me_calls import decode_stream
+    base = api.Context(0)
+    fx = sf.StreamFixture(clip)
+    pics, w, h = decode_stream(base, fx)
+    sp = rd_serial.SerialPicture(api, clip, poc)
+    n = min(n_states, len(sp.states))
+    out = {"clip": clip, "poc": poc, "states_in_picture": len(sp.states), "states_walked": n,
+           "mode": mode, "summary": sp.summary(), "chains": {}}
+    for k in ks:
+        ctxs = [api.Context(0) for _ in range(k)]
+        for c in ctxs:
+            c.use_own_stream()
+        if mode == "serial":
+            runs = [rd_serial.SerialRun(api, c, sp, pics, w, h) for c in ctxs]
+        else:
+            lists = rd_serial.ref_lists_of(clip, poc)
+            runs = [rd_serial.ChainedRun(api, c, sp, pics, w, h, lists) for c in ctxs]
+        stats = [None] * k
+
+        def work(i):
+            stats[i] = getattr(runs[i], "run_" + mode)(0, n)
+
+        for r in runs[:1]:          # warm-up (module load, scratch allocation)
+            getattr(r, "run_" + mode)(0, min(n, 200))
+        th = [threading.Thread(target=work, args=(i,)) for i in range(k)]
+        t0 = time.time()
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        wall = time.time() - t0
+        s0 = stats[0]
+        done = sum(s.states for s in stats)
+        per_pic = len(sp.states) / max(s0.states + s0.skipped, 1)      # scale to the whole picture
+        entry = {
+            "us_per_cu_state": 1e6 * sum(s.seconds for s in stats) / done,
+            "api_calls_per_state": s0.api_calls / s0.states,
+            "states_per_chain": s0.states / max(s0.round_trips, 1),
+            "round_trips_per_state": s0.round_trips / s0.states,
+            "states_per_s": done / wall,
+            "pictures_per_s": done / wall / (s0.states * per_pic),
+            "us_by_kind": {name: 1e6 * s0.seconds_by_kind[i] / max(s0.states_by_kind[i], 1)
+                           for i, name in enumerate(("merge_rank", "eval", "inter", "motion_only"))},
+        }
+        if check:
+            res = runs[-1].check(0, n, searches=(mode == "serial"))
+            if mode != "serial":
+                res.update(runs[-1].check_chained(0, n))
+            entry["matches_reference"] = all(v[1] == 0 for v in res.values())
+            entry["compared"] = {a: v[0] for a, v in res.items()}
+        out["chains"][str(k)] = entry
+        for r in runs:
+            r.destroy()
+        for c in ctxs:
+            c.close()
+    for p in pics.values():
+        p.destroy()
+    base.close()
+    return out
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--clip", default="c1")
+    ap.add_argument("--poc", type=int, default=2)
+    ap.add_argument("--states", type=int, default=6000)
+    ap.add_argument("--k", default="1,4,8,16")
+    ap.add_argument("--mode", default="serial")
+    a = ap.parse_args()
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+    from xvc_amd import api
+    print(json.dumps(walk(api, a.clip, a.poc, a.states, [int(x) for x in a.k.split(",")], a.mode)))

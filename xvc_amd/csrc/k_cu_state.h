@@ -1,0 +1,376 @@
+// k_cu_state.h -- the folds BETWEEN the searches of one SearchMotion, on the device.
+//
+// InterSearch::SearchMotion (xvc_enc_lib/inter_search.cc:199-259) as the reference
+// runs it for one CU is a chain of dependent steps; the expensive ones are the
+// batched kernels of this library (k_me2.h, k_bipred.h, k_affine_me.h).  Between them
+// the reference does a few dozen integer operations per candidate: EvalStartMvp's
+// two-way choice (:966-997), EvalFinalMvpIdx (:999-1020), the vector difference
+// (SetMvd :1022-1048), GetInterPredBits (:1082-1137, default setting: the candidate's
+// syntax through a throw-away entropy coder - include/xvc_inter_bits.h), cost =
+// dist + ((bits * lambda) >> 16), first strictly cheaper wins (:563-571), the
+// choice of the list SearchBiIterative searches (:243-245, :406-407) and the
+// three-way choice (:247-257).  Done on the host that is one read-back per step
+// (xvc_host_cu_state_run_serial measures it); here each fold is a launch of one
+// thread per pass that reads the previous step's results and WRITES THE NEXT STEP'S
+// JOBS, so a CU state is enqueued once and read back once.
+//
+// One thread per pass on purpose: the work is ~200 dependent scalar operations on a
+// handful of candidates - there is nothing to spread over lanes; its cost is the
+// launch (a few microseconds in a chain of searches of 30-100 us each).
+#ifndef XVCGPU_K_CU_STATE_H_
+#define XVCGPU_K_CU_STATE_H_
+
+#include "dev_common.h"
+#include "xvcgpu_internal.h"
+
+#define XVC_BITS_FN __device__ __forceinline__
+#include "../../include/xvc_inter_bits.h"
+
+__constant__ uint8_t kTransIdxLps[64] = {XVC_TRANS_IDX_LPS_LIST};
+
+#define CS_R XVC_CS_MAX_REFS
+#define CS_MAXCOST 0xffffffffu
+
+__device__ __forceinline__ bool cs_affine(const xvcgpu_cs_pass &p) {
+  return (p.flags & XVC_CS_AFFINE) != 0;
+}
+__device__ __forceinline__ bool cs_fullpel(const xvcgpu_cs_pass &p) {
+  return (p.flags & XVC_CS_FULLPEL) != 0;
+}
+
+// InterSearch::GetMvdBits (inter_search.cc:1149-1164): two corners for MotionVector3
+__device__ __forceinline__ uint32_t cs_mvd_bits(const int32_t mvp[3][2], const int32_t mv[3][2],
+                                                int down, bool affine) {
+  uint32_t b = d_eg_bits((mv[0][0] - mvp[0][0]) >> (2 + down)) +
+               d_eg_bits((mv[0][1] - mvp[0][1]) >> (2 + down));
+  if (affine)
+    b += d_eg_bits((mv[1][0] - mvp[1][0]) >> (2 + down)) +
+         d_eg_bits((mv[1][1] - mvp[1][1]) >> (2 + down));
+  return b;
+}
+
+// InterSearch::EvalFinalMvpIdx (:999-1020)
+__device__ __forceinline__ int cs_final_mvp_idx(const int32_t mvp[2][3][2], const int32_t mv[3][2],
+                                                int start, bool fullpel, bool affine) {
+  const int down = fullpel ? 2 : 0;
+  int best = 0;
+  uint32_t best_cost = CS_MAXCOST;
+  for (int i = 0; i < 2; i++) {
+    const uint32_t cost = 1u + cs_mvd_bits(mvp[i], mv, down, affine);   // GetMvpBits(i, 2) = 1
+    if (cost < best_cost || (cost == best_cost && i == start)) {
+      best_cost = cost;
+      best = i;
+    }
+  }
+  return best;
+}
+
+// InterSearch::SetMvd (:1022-1048): MvDelta = (mv - mvp) in quarter samples
+// (cu_types.h:192-194), whole-sample vectors shifted down again
+__device__ __forceinline__ void cs_set_mvd(int32_t out[2][2], const int32_t mvp[3][2],
+                                           const int32_t mv[3][2], bool fullpel, bool affine) {
+  for (int k = 0; k < 2; k++)
+    for (int c = 0; c < 2; c++) {
+      int d = (k == 0 || affine) ? ((mv[k][c] - mvp[k][c]) >> 2) : 0;
+      if (fullpel) d >>= 2;
+      out[k][c] = d;
+    }
+}
+
+__device__ __forceinline__ uint32_t cs_price(const xvcgpu_cs_pass &p, const xvc_inter_syntax &syn,
+                                             uint32_t dist, uint32_t *bits_out) {
+  const xvc_bits_tables t = {kEntropyBits, kTransIdxLps};
+  const uint32_t bits = xvc_inter_pred_bits(&p.ictx, &syn, &t);
+  *bits_out = bits;
+  return dist + ((bits * p.lambda16) >> 16);   // Bits and lambda are uint32_t (:563)
+}
+
+__device__ __forceinline__ void cs_copy_mv(int32_t dst[3][2], const int32_t src[3][2]) {
+  for (int k = 0; k < 3; k++) {
+    dst[k][0] = src[k][0];
+    dst[k][1] = src[k][1];
+  }
+}
+
+// ---- fold 1: EvalStartMvp's choice -> the searches' start predictors ---------------
+// start_dist: SampleMetric(kSad) of the two predictors' predictions (GetMvpMetricType,
+// :1078-1080), as xvcgpu_mc_metric_batch / xvcgpu_metric_batch return them.  Both
+// candidates pay the same GetMvpBits, so the first strictly smaller distortion wins.
+__global__ void cs_start_fold_kernel(const xvcgpu_cs_pass *passes, int first, int n,
+                                     const uint64_t *start_dist, xvcgpu_me_block *me_jobs,
+                                     const xvcgpu_me_result *me_res,
+                                     xvcgpu_affine_me_block *aff_jobs, xvcgpu_cs_result *results,
+                                     int pic_w, int pic_h) {
+  // passes [first, first + n) of the arrays (plain_pass indexes them absolutely)
+  const int ti = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ti >= n) return;
+  const int pi = first + ti;
+  const xvcgpu_cs_pass &p = passes[pi];
+  xvcgpu_cs_result &R = results[pi];
+  const bool affine = cs_affine(p);
+  for (int l = 0; l < 2; l++)
+    for (int r = 0; r < p.num_refs[l] && r < CS_R; r++) {
+      const int sd = p.start_dist[l][r];
+      const int start = sd >= 0 && start_dist[sd + 1] < start_dist[sd] ? 1 : 0;
+      R.start_idx[l][r] = (uint8_t)start;
+      const int j = p.uni_job[l][r];
+      if (j < 0) continue;
+      if (!affine) {
+        xvcgpu_me_block &b = me_jobs[j];
+        b.mvp_x = p.mvp[l][r][start][0][0];
+        b.mvp_y = p.mvp[l][r][start][0][1];
+        const int pj = p.prev_job[l][r];
+        if (pj >= 0) {                       // previous_fullpel_[list][ref_idx] (:640-641)
+          b.prev_x = me_res[pj].fullpel_x;
+          b.prev_y = me_res[pj].fullpel_y;
+        }
+      } else {
+        xvcgpu_affine_me_block &b = aff_jobs[j];
+        cs_copy_mv(b.mvp, p.mvp[l][r][start]);
+        // bootstrap: DeriveMvAffine(cu, ref, mv_normal, mv_normal) (:523-528,
+        // inter_prediction.cc:615-630) = the plain pass's vector, clipped, at all corners
+        int mx = results[p.plain_pass].mv[l][r][0][0], my = results[p.plain_pass].mv[l][r][0][1];
+        d_clip_mv(p.x, p.y, pic_w, pic_h, mx, my);
+        for (int k = 0; k < 3; k++) {
+          b.bootstrap[k][0] = mx;
+          b.bootstrap[k][1] = my;
+        }
+      }
+    }
+}
+
+// ---- fold 2: SearchRefIdx over both lists -> the refinement jobs --------------------
+__global__ void cs_uni_fold_kernel(const xvcgpu_cs_pass *passes, int first, int n,
+                                   const xvcgpu_me_result *me_res,
+                                   const xvcgpu_affine_me_result *aff_res,
+                                   xvcgpu_cs_result *results, xvcgpu_bi_block *bi_jobs,
+                                   xvcgpu_affine_me_block *aff_jobs) {
+  // passes [first, first + n) of the arrays (plain_pass indexes them absolutely)
+  const int ti = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ti >= n) return;
+  const int pi = first + ti;
+  const xvcgpu_cs_pass &p = passes[pi];
+  xvcgpu_cs_result &R = results[pi];
+  const bool affine = cs_affine(p), fullpel = cs_fullpel(p);
+  R.cost_l1_unique = CS_MAXCOST;
+  R.best_ref_l1_unique = -1;
+  for (int l = 0; l < 2; l++) {
+    uint32_t cost_best = CS_MAXCOST;
+    int best = -1;
+    for (int r = 0; r < p.num_refs[l] && r < CS_R; r++) {
+      const int m = l == 1 ? p.same_poc_in_l0[r] : -1;
+      if (m >= 0) {                          // list 0 searched this picture already (:536-542)
+        cs_copy_mv(R.mv[l][r], R.mv[0][m]);
+        R.dist[l][r] = R.dist[0][m];
+      } else if (!affine) {
+        const xvcgpu_me_result &s = me_res[p.uni_job[l][r]];
+        R.mv[l][r][0][0] = s.mv_x;
+        R.mv[l][r][0][1] = s.mv_y;
+        for (int k = 1; k < 3; k++) R.mv[l][r][k][0] = R.mv[l][r][k][1] = 0;
+        R.dist[l][r] = s.subpel_dist;
+      } else {
+        const xvcgpu_affine_me_result &s = aff_res[p.uni_job[l][r]];
+        cs_copy_mv(R.mv[l][r], s.mv);
+        R.dist[l][r] = s.dist;
+      }
+      const int idx = cs_final_mvp_idx(p.mvp[l][r], R.mv[l][r], R.start_idx[l][r], fullpel, affine);
+      R.mvp_idx[l][r] = (uint8_t)idx;
+      xvc_inter_syntax syn = {};
+      syn.inter_dir = (uint8_t)l;
+      syn.use_affine = affine;
+      syn.fullpel_mv = fullpel;
+      syn.ref_idx[l] = (int8_t)r;
+      syn.mvp_idx[l] = (uint8_t)idx;
+      cs_set_mvd(syn.mvd[l], p.mvp[l][r][idx], R.mv[l][r], fullpel, affine);
+      const uint32_t cost = cs_price(p, syn, R.dist[l][r], &R.bits[l][r]);
+      R.cost[l][r] = cost;
+      if (cost < cost_best) {
+        cost_best = cost;
+        best = r;
+      }
+      if (l == 1 && m < 0 && cost < R.cost_l1_unique) {
+        R.cost_l1_unique = cost;
+        R.best_ref_l1_unique = (int8_t)r;
+      }
+    }
+    R.cost_list[l] = cost_best;
+    R.best_ref[l] = (int8_t)best;
+  }
+  // the refinement job slots of the pass: all empty, then the ones this state runs
+  const int slots = 2 * CS_R * CS_R;
+  for (int i = 0; i < slots; i++) {
+    if (!affine)
+      bi_jobs[p.bi_job + i].blk.w = 0;     // not a block size: the kernels skip it
+    else
+      aff_jobs[p.bi_job + i].w = 0;
+  }
+  R.bi_valid = 0;
+  if (!p.num_refs[1]) return;              // kUniPredOnly (:228-230)
+  // SearchBiIterative (:392-433), one iteration: searches the list that lost
+  const int best_dir = R.cost_list[0] <= R.cost_list[1] ? 0 : 1;
+  const int s = 1 - best_dir, o = R.best_ref[best_dir];
+  R.search_list = (uint8_t)s;
+  R.bi_valid = 1;
+  for (int r = 0; r < p.num_refs[s] && r < CS_R; r++) {
+    const int slot = p.bi_job + (s * CS_R + r) * CS_R + o;
+    const int idx = R.mvp_idx[s][r];       // unipred_best_mvp_idx_ (:497-499)
+    if (!affine) {
+      xvcgpu_bi_block &j = bi_jobs[slot];
+      j.blk.x = p.x;
+      j.blk.y = p.y;
+      j.blk.w = p.w;
+      j.blk.h = p.h;
+      j.blk.depth_nonzero = 0;
+      j.blk.fullpel_mv = fullpel ? XVC_ME_FULLPEL_MV : 0;
+      j.blk.mvp_x = p.mvp[s][r][idx][0][0];
+      j.blk.mvp_y = p.mvp[s][r][idx][0][1];
+      j.blk.prev_x = j.blk.prev_y = 0;
+      j.blk.lambda16 = p.lambda16;
+      j.blk.search_range = 4;              // inter_search_range_bi
+      j.other_mv_x = R.mv[best_dir][o][0][0];
+      j.other_mv_y = R.mv[best_dir][o][0][1];
+      j.boot_mv_x = R.mv[s][r][0][0];      // GetBestUniPredMv (:499)
+      j.boot_mv_y = R.mv[s][r][0][1];
+    } else {
+      xvcgpu_affine_me_block &j = aff_jobs[slot];
+      j.x = p.x;
+      j.y = p.y;
+      j.w = p.w;
+      j.h = p.h;
+      j.flags = XVC_AFFINE_ME_HAS_BOOTSTRAP | XVC_AFFINE_ME_BIPRED;
+      j.reserved = 0;
+      j.lambda16 = p.lambda16;
+      cs_copy_mv(j.mvp, p.mvp[s][r][idx]);
+      cs_copy_mv(j.bootstrap, R.mv[s][r]);
+      cs_copy_mv(j.other_mv, R.mv[best_dir][o]);
+    }
+  }
+}
+
+// ---- fold 3: the refinement's costs, the three-way choice, the evaluation's jobs ----
+__global__ void cs_bi_fold_kernel(const xvcgpu_cs_pass *passes, int first, int n,
+                                  const xvcgpu_me_result *bi_res,
+                                  const xvcgpu_affine_me_result *aff_res,
+                                  xvcgpu_cs_result *results, xvcgpu_inter_block *ev_inter) {
+  // passes [first, first + n) of the arrays (plain_pass indexes them absolutely)
+  const int ti = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ti >= n) return;
+  const int pi = first + ti;
+  const xvcgpu_cs_pass &p = passes[pi];
+  xvcgpu_cs_result &R = results[pi];
+  const bool affine = cs_affine(p), fullpel = cs_fullpel(p);
+  uint32_t cost_bi = CS_MAXCOST;
+  int bi_ref = -1;
+  const int s = R.search_list, od = 1 - s;
+  const int o = R.bi_valid ? R.best_ref[od] : -1;
+  int32_t other_mvd[2][2] = {};
+  if (R.bi_valid) {
+    cs_set_mvd(other_mvd, p.mvp[od][o][R.mvp_idx[od][o]], R.mv[od][o], fullpel, affine);
+    for (int r = 0; r < p.num_refs[s] && r < CS_R; r++) {
+      const int slot = p.bi_job + (s * CS_R + r) * CS_R + o;
+      if (!affine) {
+        R.bi_mv[r][0][0] = bi_res[slot].mv_x;
+        R.bi_mv[r][0][1] = bi_res[slot].mv_y;
+        for (int k = 1; k < 3; k++) R.bi_mv[r][k][0] = R.bi_mv[r][k][1] = 0;
+        R.bi_dist[r] = bi_res[slot].subpel_dist;
+      } else {
+        cs_copy_mv(R.bi_mv[r], aff_res[slot].mv);
+        R.bi_dist[r] = aff_res[slot].dist;
+      }
+      const int idx = cs_final_mvp_idx(p.mvp[s][r], R.bi_mv[r], R.mvp_idx[s][r], fullpel, affine);
+      R.bi_mvp_idx[r] = (uint8_t)idx;
+      xvc_inter_syntax syn = {};
+      syn.inter_dir = 2;
+      syn.use_affine = affine;
+      syn.fullpel_mv = fullpel;
+      syn.ref_idx[s] = (int8_t)r;
+      syn.mvp_idx[s] = (uint8_t)idx;
+      cs_set_mvd(syn.mvd[s], p.mvp[s][r][idx], R.bi_mv[r], fullpel, affine);
+      syn.ref_idx[od] = (int8_t)o;
+      syn.mvp_idx[od] = R.mvp_idx[od][o];
+      for (int k = 0; k < 2; k++)
+        for (int c = 0; c < 2; c++) syn.mvd[od][k][c] = other_mvd[k][c];
+      const uint32_t cost = cs_price(p, syn, R.bi_dist[r], &R.bi_bits[r]);
+      R.bi_cost[r] = cost;
+      if (cost < cost_bi) {
+        cost_bi = cost;
+        bi_ref = r;
+      }
+    }
+  }
+  // the three-way choice (:247-257); a picture with one list returns list 0's result
+  const uint32_t c0 = R.cost_list[0], c1u = R.cost_l1_unique;
+  int which;
+  if (!p.num_refs[1])
+    which = 1;
+  else if (cost_bi <= c0 && cost_bi <= c1u)
+    which = 0;
+  else if (c0 <= c1u)
+    which = 1;
+  else
+    which = 2;
+  R.which = (uint8_t)which;
+  for (int l = 0; l < 2; l++) {
+    R.ref_idx[l] = -1;
+    R.out_mvp_idx[l] = 0;
+    for (int k = 0; k < 3; k++) R.out_mv[l][k][0] = R.out_mv[l][k][1] = 0;
+    for (int k = 0; k < 2; k++) R.out_mvd[l][k][0] = R.out_mvd[l][k][1] = 0;
+  }
+  auto take_uni = [&](int l, int r) {
+    R.ref_idx[l] = (int8_t)r;
+    R.out_mvp_idx[l] = R.mvp_idx[l][r];
+    cs_copy_mv(R.out_mv[l], R.mv[l][r]);
+    cs_set_mvd(R.out_mvd[l], p.mvp[l][r][R.mvp_idx[l][r]], R.mv[l][r], fullpel, affine);
+  };
+  if (which == 0) {
+    R.inter_dir = 2;
+    R.best_cost = cost_bi;
+    take_uni(od, o);
+    R.ref_idx[s] = (int8_t)bi_ref;
+    R.out_mvp_idx[s] = R.bi_mvp_idx[bi_ref];
+    cs_copy_mv(R.out_mv[s], R.bi_mv[bi_ref]);
+    cs_set_mvd(R.out_mvd[s], p.mvp[s][bi_ref][R.bi_mvp_idx[bi_ref]], R.bi_mv[bi_ref], fullpel, affine);
+  } else if (which == 1) {
+    R.inter_dir = 0;
+    R.best_cost = c0;
+    take_uni(0, R.best_ref[0]);
+  } else {
+    R.inter_dir = 1;
+    R.best_cost = c1u;
+    take_uni(1, R.best_ref_l1_unique);
+  }
+  // CodingUnit::HasZeroMvd (coding_unit.cc:445-453)
+  if (R.inter_dir == 2)
+    R.zero_mvd = !(R.out_mvd[0][0][0] | R.out_mvd[0][0][1] | R.out_mvd[1][0][0] | R.out_mvd[1][0][1]);
+  else
+    R.zero_mvd = !(R.out_mvd[R.inter_dir][0][0] | R.out_mvd[R.inter_dir][0][1]);
+  // CompressInter (:80-93): the affine pass replaces the plain result only when cheaper
+  R.chosen = 1;
+  const xvcgpu_cs_result *final = &R;
+  const xvcgpu_cs_pass *fp = &p;
+  if (affine && p.plain_pass >= 0) {
+    if (results[p.plain_pass].best_cost <= R.best_cost) {
+      R.chosen = 0;
+      final = &results[p.plain_pass];
+      fp = &passes[p.plain_pass];
+    } else {
+      results[p.plain_pass].chosen = 0;
+    }
+  }
+  if (p.eval < 0) return;
+  const bool fa = cs_affine(*fp);
+  for (int c = 0; c < 3; c++) {
+    xvcgpu_inter_block &b = ev_inter[3 * p.eval + c];
+    b.flags = fa ? XVC_INTER_AFFINE : 0;
+    for (int l = 0; l < 2; l++) {
+      const bool used = final->inter_dir == 2 || final->inter_dir == l;
+      b.ref[l] = used ? fp->slot[l][final->ref_idx[l]] : -1;
+      for (int k = 0; k < 3; k++) {
+        b.mv[l][k][0] = used ? final->out_mv[l][k][0] : 0;
+        b.mv[l][k][1] = used ? final->out_mv[l][k][1] : 0;
+      }
+    }
+  }
+}
+
+#endif  // XVCGPU_K_CU_STATE_H_

@@ -27,6 +27,7 @@
 #include "k_multi.h"
 #include "k_rd.h"
 #include "k_intra_waves.h"
+#include "k_cu_state.h"
 #include "xvcgpu_internal.h"
 
 namespace {
@@ -2257,6 +2258,50 @@ xvcgpu_status xvcgpu_copy_segments(xvcgpu_ctx *ctx, const xvcgpu_copy_segment *d
   hipLaunchKernelGGL(copy_segments_kernel, dim3(32, n), dim3(256), 0, ctx->stream, d_segments,
                      n);
   CHECK_LAUNCH(ctx, "copy_segments");
+  return XVCGPU_OK;
+}
+
+
+/* ---- the folds of one SearchMotion chain (k_cu_state.h) ----------------------- */
+xvcgpu_status xvcgpu_cs_start_fold(xvcgpu_ctx *ctx, const xvcgpu_cs_pass *d_passes, int first,
+    int n,
+                                   const uint64_t *d_start_dist, xvcgpu_me_block *d_me_jobs,
+                                   const xvcgpu_me_result *d_me_res,
+                                   xvcgpu_affine_me_block *d_aff_jobs,
+                                   xvcgpu_cs_result *d_results, int pic_w, int pic_h) {
+  if (!ctx || n < 0 || first < 0 || (n && (!d_passes || !d_start_dist || !d_results)))
+    return XVCGPU_INVALID_ARGUMENT;
+  if (!n) return XVCGPU_OK;
+  hipLaunchKernelGGL(cs_start_fold_kernel, dim3((n + 63) / 64), dim3(64), 0, ctx->stream, d_passes,
+                     first, n, d_start_dist, d_me_jobs, d_me_res, d_aff_jobs, d_results, pic_w, pic_h);
+  CHECK_LAUNCH(ctx, "cs_start_fold");
+  return XVCGPU_OK;
+}
+
+xvcgpu_status xvcgpu_cs_uni_fold(xvcgpu_ctx *ctx, const xvcgpu_cs_pass *d_passes, int first,
+    int n,
+                                 const xvcgpu_me_result *d_me_res,
+                                 const xvcgpu_affine_me_result *d_aff_res,
+                                 xvcgpu_cs_result *d_results, xvcgpu_bi_block *d_bi_jobs,
+                                 xvcgpu_affine_me_block *d_aff_jobs) {
+  if (!ctx || n < 0 || (n && (!d_passes || !d_results))) return XVCGPU_INVALID_ARGUMENT;
+  if (!n) return XVCGPU_OK;
+  hipLaunchKernelGGL(cs_uni_fold_kernel, dim3((n + 63) / 64), dim3(64), 0, ctx->stream, d_passes, first, n,
+                     d_me_res, d_aff_res, d_results, d_bi_jobs, d_aff_jobs);
+  CHECK_LAUNCH(ctx, "cs_uni_fold");
+  return XVCGPU_OK;
+}
+
+xvcgpu_status xvcgpu_cs_bi_fold(xvcgpu_ctx *ctx, const xvcgpu_cs_pass *d_passes, int first,
+    int n,
+                                const xvcgpu_me_result *d_bi_res,
+                                const xvcgpu_affine_me_result *d_aff_res,
+                                xvcgpu_cs_result *d_results, xvcgpu_inter_block *d_ev_inter) {
+  if (!ctx || n < 0 || (n && (!d_passes || !d_results))) return XVCGPU_INVALID_ARGUMENT;
+  if (!n) return XVCGPU_OK;
+  hipLaunchKernelGGL(cs_bi_fold_kernel, dim3((n + 63) / 64), dim3(64), 0, ctx->stream, d_passes, first, n,
+                     d_bi_res, d_aff_res, d_results, d_ev_inter);
+  CHECK_LAUNCH(ctx, "cs_bi_fold");
   return XVCGPU_OK;
 }
 

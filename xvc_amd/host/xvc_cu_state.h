@@ -111,7 +111,33 @@ typedef struct xvc_cs_stats {
   int64_t states_by_kind[4];
 } xvc_cs_stats;
 
+// The chained form's program: one op = one C-ABI call on arrays the host filled before
+// (p[]: device pointers; FETCH: p[0] device -> p[1] host, n bytes).  r0 / r1: reference
+// picture slots, or picture selectors 0 original, 1 scratch originals, 2 scratch
+// predictions, 3 scratch reconstructions (METRIC, COPY, INTER_PRED).
+enum {
+  XVC_OP_MC_METRIC = 0, XVC_OP_METRIC, XVC_OP_ME, XVC_OP_BI, XVC_OP_AFFINE, XVC_OP_COPY,
+  XVC_OP_INTER_PRED, XVC_OP_RESIDUAL, XVC_OP_START_FOLD, XVC_OP_UNI_FOLD, XVC_OP_BI_FOLD,
+  XVC_OP_FETCH, XVC_OP_SYNC
+};
+typedef struct xvc_cs_op {
+  int32_t opcode, n, r0, r1, i0, reserved;
+  double f;
+  uint64_t p[5];
+} xvc_cs_op;
+typedef struct xvc_cs_env {
+  const xvcgpu_picture *orig;
+  const xvcgpu_picture *const *refs;
+  int32_t n_refs, pic_w, pic_h, reserved;
+  xvcgpu_picture *s_orig, *s_pred, *s_rec;
+  int16_t *d_levels;
+  xvcgpu_cs_result *d_results;
+} xvc_cs_env;
+
 extern "C" {
+int xvc_host_cs_run_program(xvcgpu_ctx *ctx, const xvc_cs_env *env, const xvc_cs_op *ops,
+                            int64_t n_ops, xvc_cs_stats *stats);
+
 // The states [first, first + n) walked ONE AT A TIME with the batched entry points as
 // they are: every step a batch of one CU, a read-back (copy + wait) wherever the
 // reference reads a result before it can go on - after the uni-directional searches,
@@ -122,8 +148,9 @@ int xvc_host_cu_state_run_serial(xvcgpu_ctx *ctx, const xvc_cs_tables *t,
                                  const xvc_cs_state *states, int first, int n, int read_levels,
                                  xvc_cs_stats *stats);
 
-// sizeof(xvc_cs_state), sizeof(xvc_cs_tables), sizeof(xvc_cs_stats): bindings check.
-void xvc_host_cs_sizes(int32_t out[3]);
+// sizeof of xvc_cs_state, xvc_cs_tables, xvc_cs_stats, xvcgpu_cs_pass, xvcgpu_cs_result,
+// xvc_cs_op, xvc_cs_env: bindings check.
+void xvc_host_cs_sizes(int32_t out[7]);
 
 // InterSearch::GetInterPredBits with the encoder's default setting, for n motion
 // candidates: candidate i is priced against snapshots[ictx_index[i]] (ictx_index
