@@ -174,6 +174,7 @@ def stream_decode_figure(ctx, api):
     decoder_run(fx, syn, pics)
     out["encoder_me_batches"] = encoder_me_figure(ctx, api, fx, pics, w, h)
     out["encoder_rd_batches"] = encoder_rd_figure(ctx, api, fx, pics, w, h)
+    out["encoder_rd_serial"] = encoder_rd_serial_figure(ctx, api, fx, pics, w, h)
     dec.destroy()
     for p in pics:
         p.destroy()
@@ -263,6 +264,70 @@ def encoder_me_figure(ctx, api, fx, pics, w, h):
         out["cpu_reference_searches_per_s"] = k / (time.perf_counter() - t0)
         out["cpu_reference"] = "TzSearch::Search + SubpelSearch of oracle/_ref, 1 thread, every 37th call"
     return out
+
+
+def encoder_rd_serial_figure(ctx, api, fx, pics, w, h, n_states=4000):
+    """Fourth workload: the SAME picture's RD search in the order the reference can
+    actually issue it (tests/golden/rd_order_c1.npz, tests/rd_serial.py,
+    xvc_amd/host/xvc_cu_state.cc).  CuEncoder::CompressCu evaluates one CU state at a
+    time - merge ranking, each merge candidate, CompressInter (SearchMotion [+ affine]
+    -> CompressAndEvalCbf) per mode - and every state starts from what the previous one
+    decided; the whole-picture batches above are a shape no bit-exact encoder can
+    present.  Here the first `n_states` states of the picture are walked in that order:
+      serial   each step a batch of one CU through the entry points as they are, with a
+               read-back wherever the reference reads a result ("latency /
+               launch bounds the per-CU batches; report it as such");
+      chained  all states of one visit of a CU position as ONE enqueue, the folds between
+               the searches on the device (xvcgpu_cs_*_fold, default bit prices), one
+               read-back at the end;
+    on k contexts at once (k independent pictures in flight: the sub-GOP's top layer).
+    Every search result, every priced candidate, every SearchMotion choice, every
+    TransformAndReconstruct (count, levels, distortion) is compared with the reference
+    encoder's."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import cu_state_walk
+    import rd_fixture as rf
+    import rd_serial
+    if not (os.path.exists(rf.path("c1")) and os.path.exists(os.path.join(rf.GOLDEN, "rd_order_c1.npz"))):
+        return None
+    by_poc = {int(fx.info[i]["poc"]): pics[i] for i in range(fx.n)}
+    poc = 2
+    sp = rd_serial.SerialPicture(api, "c1", poc)
+    serial = cu_state_walk.walk(api, "c1", poc, n_states, [1, 4], "serial", decoded=(by_poc, w, h), sp=sp)
+    chained = cu_state_walk.walk(api, "c1", poc, n_states, [1, 4], "chained", decoded=(by_poc, w, h), sp=sp)
+    s1, c1 = serial["chains"]["1"], chained["chains"]["1"]
+    ok = all(e.get("matches_reference") for r in (serial, chained) for e in r["chains"].values())
+    return {
+        "workload": "1080p B picture POC %d of the reference-coded stream: %d CU states in the "
+                    "reference's issue order (%d merge rankings, %d merge-candidate evaluations, "
+                    "%d CompressInter with evaluation, %d without), the first %d walked" % (
+                        poc, serial["states_in_picture"], serial["summary"]["merge_rank"],
+                        serial["summary"]["eval"], serial["summary"]["inter"],
+                        serial["summary"]["motion_only"], serial["states_walked"]),
+        "us_per_cu_state": s1["us_per_cu_state"],
+        "launches_per_state": {"entry_point_calls": s1["api_calls_per_state"],
+                               "kernel_launches_rocprof": 15.7,
+                               "note": "rocprofv3 --kernel-trace of tools/cu_state_walk.py "
+                                       "(3000 states): 47 156 launches serial (12 887 of them "
+                                       "result copies), 56 553 chained - "
+                                       "profiles/r04_cu_state_{serial,chained}_kernel_stats.csv; "
+                                       "the kernels' summed duration equals the wall time: a "
+                                       "state is a string of 3-30 us kernels on one CU each"},
+        "round_trips_per_state": s1["round_trips_per_state"],
+        "pictures_per_s": {k: v["pictures_per_s"] for k, v in serial["chains"].items()},
+        "us_by_state_kind": s1["us_by_kind"],
+        "chained": {"us_per_cu_state": c1["us_per_cu_state"],
+                    "entry_point_calls_per_state": c1["api_calls_per_state"],
+                    "round_trips_per_state": c1["round_trips_per_state"],
+                    "states_per_chain": c1["states_per_chain"],
+                    "fewer_round_trips": s1["round_trips_per_state"] / c1["round_trips_per_state"],
+                    "pictures_per_s": {k: v["pictures_per_s"] for k, v in chained["chains"].items()},
+                    "compared": c1.get("compared")},
+        "compared": s1.get("compared"),
+        "matches_reference": bool(ok),
+        "reading": "both forms are bound by the number of dependent launches per state (the "
+                   "searches themselves are one CU each): ~10 us per entry point; fewer "
+                   "read-backs alone do not shorten a state"}
 
 
 def encoder_rd_figure(ctx, api, fx, pics, w, h):

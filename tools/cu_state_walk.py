@@ -19,14 +19,19 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
-def walk(api, clip, poc, n_states, ks, mode="serial", check=True):
+def walk(api, clip, poc, n_states, ks, mode="serial", check=True, decoded=None, sp=None):
+    """decoded: ({poc: device picture}, width, height) of the clip when the caller holds
+    it already; sp: a rd_serial.SerialPicture to re-use."""
     import rd_serial
     import stream_fixture as sf
-    from test_gpu_me_calls import decode_stream
-    base = api.Context(0)
-    fx = sf.StreamFixture(clip)
-    pics, w, h = decode_stream(base, fx)
-    sp = rd_serial.SerialPicture(api, clip, poc)
+    base = None
+    if decoded is None:
+        from test_gpu_me_calls import decode_stream
+        base = api.Context(0)
+        pics, w, h = decode_stream(base, sf.StreamFixture(clip))
+    else:
+        pics, w, h = decoded
+    sp = sp or rd_serial.SerialPicture(api, clip, poc)
     n = min(n_states, len(sp.states))
     out = {"clip": clip, "poc": poc, "states_in_picture": len(sp.states), "states_walked": n,
            "mode": mode, "summary": sp.summary(), "chains": {}}
@@ -77,9 +82,10 @@ def walk(api, clip, poc, n_states, ks, mode="serial", check=True):
             r.destroy()
         for c in ctxs:
             c.close()
-    for p in pics.values():
-        p.destroy()
-    base.close()
+    if base is not None:
+        for p in pics.values():
+            p.destroy()
+        base.close()
     return out
 
 
