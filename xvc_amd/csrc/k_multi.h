@@ -121,8 +121,7 @@ struct TailMultiArgs {
 };
 __global__ void __launch_bounds__(256)
 deblock_tail_multi_kernel(MultiArgs<TailMultiArgs> m) {
-  const TailMultiArgs &a = m.a[blockIdx.y];
-  if ((int)blockIdx.x >= a.tiles) return;
+  const TailMultiArgs &a = m.a[blockIdx.y];   // (grid x padded to 8: the body drops the rest)
   deblock_tail_kernel_body<true>(a.d, a.src, a.dst, a.orig, a.shift, a.part);
 }
 __global__ void __launch_bounds__(256)

@@ -201,7 +201,16 @@ __device__ __forceinline__ void deblock_tail_kernel_body(DbParams d, PicView src
   const int tid = threadIdx.x;
   const int w = d.pic_w, h = d.pic_h;
   const int ntx = (w + 63) >> 6;
-  const int tx = blockIdx.x % ntx, ty = blockIdx.x / ntx;
+  // Tiles in raster order, XCD k takes the k-th contiguous eighth of them (the grid is
+  // padded to a multiple of 8): a tile's halo - 4 rows / 8 columns of its neighbours'
+  // samples, and the 128-byte lines they drag in: a row of 80 samples starting 16
+  // bytes in front of a line boundary touches three lines for 160 bytes - then sits
+  // in the L2 that serves those neighbours too.  With tile b on XCD b % 8 every
+  // neighbour is on another XCD and each of the eight L2s fetches the shared lines
+  // from memory for itself: 1.8x the algorithmic bytes (profiles/r03_traffic*.json).
+  const int tile = xcd_job_index(blockIdx.x, ntx * ((h + 63) >> 6));
+  if (tile < 0) return;
+  const int tx = tile % ntx, ty = tile / ntx;
   const int X0 = tx << 6, Y0 = ty << 6, CX0 = X0 >> 1, CY0 = Y0 >> 1;
   const int ow = min(64, w - X0), oh = min(64, h - Y0);
   TAIL_MARK(0);
@@ -436,8 +445,8 @@ __device__ __forceinline__ void deblock_tail_kernel_body(DbParams d, PicView src
       for (int by = 0; by < nby; by++)
         for (int bx = 0; bx < nbx; bx++) sum += s.sub[(by << 3) + bx] >> shift;
     }
-    part[2 * blockIdx.x] = sum;
-    part[2 * blockIdx.x + 1] = vis ? (unsigned long long)ow * oh : 0ull;
+    part[2 * tile] = sum;
+    part[2 * tile + 1] = vis ? (unsigned long long)ow * oh : 0ull;
   }
   TAIL_MARK(6);
 }

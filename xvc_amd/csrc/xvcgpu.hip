@@ -1554,12 +1554,12 @@ xvcgpu_status xvcgpu_deblock_pad_ssd(xvcgpu_ctx *ctx, const xvcgpu_picture *src,
   d.comp_mask = 3;
   unsigned long long *part = ctx->d_tail_part;
   if (orig) {
-    hipLaunchKernelGGL(deblock_tail_kernel<true>, dim3(tiles), dim3(256), 0, ctx->stream, d,
+    hipLaunchKernelGGL(deblock_tail_kernel<true>, dim3((tiles + 7) / 8 * 8), dim3(256), 0, ctx->stream, d,
                        src->v, dst->v, orig->v.c[0], 2 * (shift_bitdepth - 8), part);
     hipLaunchKernelGGL(picture_ssd_sum_kernel, dim3(1), dim3(256), 0, ctx->stream, part, tiles,
                        reinterpret_cast<unsigned long long *>(d_ssd));
   } else {
-    hipLaunchKernelGGL(deblock_tail_kernel<false>, dim3(tiles), dim3(256), 0, ctx->stream, d,
+    hipLaunchKernelGGL(deblock_tail_kernel<false>, dim3((tiles + 7) / 8 * 8), dim3(256), 0, ctx->stream, d,
                        src->v, dst->v, dst->v.c[0], 0, part);
   }
   CHECK_LAUNCH(ctx, "deblock_pad_ssd");
@@ -2219,7 +2219,8 @@ xvcgpu_status xvcgpu_frame_pass_multi(xvcgpu_ctx *const *ctxs,
       k.out = reinterpret_cast<unsigned long long *>(a->d_ssd);
       max_tiles = std::max(max_tiles, tiles);
     }
-    hipLaunchKernelGGL(deblock_tail_multi_kernel, dim3(max_tiles, n), dim3(256), 0, ctx->stream, t);
+    hipLaunchKernelGGL(deblock_tail_multi_kernel, dim3((max_tiles + 7) / 8 * 8, n), dim3(256), 0,
+                       ctx->stream, t);
     hipLaunchKernelGGL(picture_ssd_sum_multi_kernel, dim3(1, n), dim3(256), 0, ctx->stream, t);
   }
   (void)one;
