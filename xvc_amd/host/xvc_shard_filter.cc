@@ -58,6 +58,74 @@ int xvc_shard_plan(const int32_t *cu_map, int map_stride, int world, const int32
   return verdict;
 }
 
+int xvc_shard_filter_run(const int32_t *cu_map, int map_stride, int rank, int world,
+                         const int32_t *rows, const xvc_shard_filter_callbacks *cb) {
+  if (!cu_map || !rows || !cb || !cb->pass || !cb->exchange || world < 1 || rank < 0 ||
+      rank >= world || world > 64)
+    return XVCGPU_INVALID_ARGUMENT;
+  // Every rank holds the whole CU map: all of them plan ALL boundaries and reach
+  // the same verdict before anything is sent (a rank that backed out alone would
+  // leave its neighbours waiting in their send / receive groups).
+  int32_t d_all[64];
+  {
+    const int st = xvc_shard_plan(cu_map, map_stride, world, rows, d_all);
+    if (st != XVCGPU_OK) return st;
+  }
+  const int y0 = rows[rank], y1 = rows[rank + 1], d_top = d_all[rank];
+  int st;
+  if ((st = cb->pass(cb->user, 0, y0, y1)) != 0) return st;                    // 1
+  if (y0 + d_top < y1 && (st = cb->pass(cb->user, 1, y0 + d_top, y1)) != 0) return st;   // 2
+  if (world == 1) return XVCGPU_OK;
+  if ((st = cb->exchange(cb->user, 1)) != 0) return st;                        // 3
+  // 4: the boundary edge and its chain, in order, on the rows just received
+  if (rank > 0 && d_top > 0 && (st = cb->pass(cb->user, 1, y0, y0 + d_top)) != 0) return st;
+  return cb->exchange(cb->user, 0);                                            // 5
+}
+
+namespace {
+struct GpuFilter {
+  xvcgpu_ctx *ctx;
+  xvcgpu_comm *comm;
+  int rank, world, y0, y1;
+  xvcgpu_picture *rec;
+  const xvcgpu_cu_info *d_cus;
+  int n_cus;
+  const int32_t *d_cu_map;
+  int map_stride, bipred, beta, tc;
+  xvcgpu_event *a, *b;
+};
+int GpuFilterPass(void *user, int which, int ya, int yb) {
+  GpuFilter *g = static_cast<GpuFilter *>(user);
+  if (ya >= yb) return XVCGPU_OK;
+  return xvcgpu_deblock_rows(g->ctx, g->rec, g->d_cus, g->n_cus, g->d_cu_map, g->map_stride,
+                             g->bipred, g->beta, g->tc, 4, which, ya, yb);
+}
+// an error between group_begin and group_end must not leave the RCCL group open
+int GpuFilterExchange(void *user, int send_down) {
+  GpuFilter *g = static_cast<GpuFilter *>(user);
+  const bool up = g->rank > 0, down = g->rank < g->world - 1;
+  xvcgpu_status st;
+  if ((st = xvcgpu_event_record(g->ctx, g->a)) != XVCGPU_OK) return st;
+  if ((st = xvcgpu_comm_wait_event(g->comm, g->a)) != XVCGPU_OK) return st;
+  if ((st = xvcgpu_comm_group_begin(g->comm)) != XVCGPU_OK) return st;
+  st = XVCGPU_OK;
+  if (send_down) {  // 3: rows down / rows from above
+    if (down) st = xvcgpu_comm_send_rows(g->comm, g->rec, 7, g->y1 - 4, g->y1, g->rank + 1);
+    if (st == XVCGPU_OK && up)
+      st = xvcgpu_comm_recv_rows(g->comm, g->rec, 7, g->y0 - 4, g->y0, g->rank - 1);
+  } else {  // 5: the rows the boundary edge changed go back up / come back from below
+    if (up) st = xvcgpu_comm_send_rows(g->comm, g->rec, 7, g->y0 - 4, g->y0, g->rank - 1);
+    if (st == XVCGPU_OK && down)
+      st = xvcgpu_comm_recv_rows(g->comm, g->rec, 7, g->y1 - 4, g->y1, g->rank + 1);
+  }
+  const xvcgpu_status end = xvcgpu_comm_group_end(g->comm);
+  if (st != XVCGPU_OK) return st;
+  if (end != XVCGPU_OK) return end;
+  if ((st = xvcgpu_comm_record_event(g->comm, g->b)) != XVCGPU_OK) return st;
+  return xvcgpu_event_wait(g->ctx, g->b);
+}
+}  // namespace
+
 int xvc_host_shard_filter_run(xvcgpu_ctx *ctx, xvcgpu_comm *comm, int rank, int world,
                               const int32_t *rows, xvcgpu_picture *rec,
                               const xvcgpu_cu_info *d_cus, int n_cus, const int32_t *d_cu_map,
@@ -66,62 +134,20 @@ int xvc_host_shard_filter_run(xvcgpu_ctx *ctx, xvcgpu_comm *comm, int rank, int 
   if (!ctx || !rows || !rec || !d_cus || !d_cu_map || !cu_map || world < 1 || rank < 0 ||
       rank >= world || (world > 1 && !comm))
     return XVCGPU_INVALID_ARGUMENT;
-  const int y0 = rows[rank], y1 = rows[rank + 1];
-  // Every rank holds the whole CU map: all of them plan ALL boundaries and reach
-  // the same verdict before anything is sent (a rank that backed out alone would
-  // leave its neighbours waiting in their send / receive groups).
-  int32_t d_all[64];
-  if (world > 64) return XVCGPU_INVALID_ARGUMENT;
-  {
-    const int st = xvc_shard_plan(cu_map, map_stride, world, rows, d_all);
-    if (st != XVCGPU_OK) return st;
-  }
-  const int d_top = d_all[rank];
-#define TRY(call)                                  \
-  do {                                             \
-    const xvcgpu_status st_ = (call);              \
-    if (st_ != XVCGPU_OK) return st_;              \
-  } while (0)
-  auto pass = [&](int which, int ya, int yb) -> xvcgpu_status {
-    if (ya >= yb) return XVCGPU_OK;
-    return xvcgpu_deblock_rows(ctx, rec, d_cus, n_cus, d_cu_map, map_stride, pic_is_bipred,
-                               beta_offset, tc_offset, 4, which, ya, yb);
-  };
-  TRY(pass(0, y0, y1));                    // 1
-  TRY(pass(1, y0 + d_top, y1));            // 2
-  if (world == 1) return XVCGPU_OK;
   Events ev(ctx);
-  TRY(xvcgpu_event_create(ctx, &ev.a));
-  TRY(xvcgpu_event_create(ctx, &ev.b));
-  const bool up = rank > 0, down = rank < world - 1;
-  // an error between group_begin and group_end must not leave the RCCL group open
-  auto exchange = [&](bool send_down) -> xvcgpu_status {
-    TRY(xvcgpu_event_record(ctx, ev.a));
-    TRY(xvcgpu_comm_wait_event(comm, ev.a));
-    TRY(xvcgpu_comm_group_begin(comm));
-    xvcgpu_status st = XVCGPU_OK;
-    if (send_down) {  // 3: rows down / rows from above
-      if (down) st = xvcgpu_comm_send_rows(comm, rec, 7, y1 - 4, y1, rank + 1);
-      if (st == XVCGPU_OK && up) st = xvcgpu_comm_recv_rows(comm, rec, 7, y0 - 4, y0, rank - 1);
-    } else {  // 5: the rows the boundary edge changed go back up / come back from below
-      if (up) st = xvcgpu_comm_send_rows(comm, rec, 7, y0 - 4, y0, rank - 1);
-      if (st == XVCGPU_OK && down) st = xvcgpu_comm_recv_rows(comm, rec, 7, y1 - 4, y1, rank + 1);
-    }
-    const xvcgpu_status end = xvcgpu_comm_group_end(comm);
-    if (st != XVCGPU_OK) return st;
-    TRY(end);
-    TRY(xvcgpu_comm_record_event(comm, ev.b));
-    return xvcgpu_event_wait(ctx, ev.b);
-  };
-  TRY(exchange(true));
-  // 4: the boundary edge and its chain
-  if (up) TRY(pass(1, y0, y0 + d_top));
-  TRY(exchange(false));
+  if (world > 1) {
+    xvcgpu_status st;
+    if ((st = xvcgpu_event_create(ctx, &ev.a)) != XVCGPU_OK) return st;
+    if ((st = xvcgpu_event_create(ctx, &ev.b)) != XVCGPU_OK) return st;
+  }
+  GpuFilter g = {ctx, comm, rank, world, rows[rank], rows[rank + 1], rec, d_cus, n_cus, d_cu_map,
+                 map_stride, pic_is_bipred, beta_offset, tc_offset, ev.a, ev.b};
+  const xvc_shard_filter_callbacks cb = {&g, GpuFilterPass, GpuFilterExchange};
+  const int st = xvc_shard_filter_run(cu_map, map_stride, rank, world, rows, &cb);
+  if (st != XVCGPU_OK || world == 1) return st;
   // the events may be destroyed once enqueued work has passed them; keep the
   // host in step with the two short exchanges (a picture's worth of filtering)
-  TRY(xvcgpu_comm_sync(comm));
-#undef TRY
-  return XVCGPU_OK;
+  return xvcgpu_comm_sync(comm);
 }
 
 }  // extern "C"

@@ -55,6 +55,20 @@ int xvc_shard_chain_rows(const int32_t *cu_map, int map_stride, int pic_w, int p
 int xvc_shard_plan(const int32_t *cu_map, int map_stride, int world, const int32_t *rows,
                    int32_t *d_top);
 
+// Steps 1-5 on callbacks: pass(which, ya, yb) filters the edges of direction `which`
+// (0 vertical, 1 horizontal) in rows [ya, yb); exchange(send_down) is step 3
+// (send_down = 1: the last four rows go down, the four rows above the shard arrive)
+// or step 5 (0: they travel back).  The plan (every boundary, on every rank) and the
+// order of the steps are this function's; the CPU tests run the oracle over gloo
+// through it, xvc_host_shard_filter_run the HIP kernels over RCCL.
+typedef struct xvc_shard_filter_callbacks {
+  void *user;
+  int (*pass)(void *user, int which, int ya, int yb);
+  int (*exchange)(void *user, int send_down);
+} xvc_shard_filter_callbacks;
+int xvc_shard_filter_run(const int32_t *cu_map, int map_stride, int rank, int world,
+                         const int32_t *rows, const xvc_shard_filter_callbacks *cb);
+
 // Steps 1-5 for one picture on rank `rank` of `world` (comm may be NULL when world
 // == 1): rows[r] .. rows[r + 1] are rank r's rows (multiples of 16), d_* the
 // device copies of the CU records / map, cu_map the host copy (planning).

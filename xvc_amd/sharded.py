@@ -49,17 +49,43 @@ def search_reach(desc):
         int(np.abs(me["prev_y"]).max())
 
 
+def _host():
+    import ctypes as C
+    from . import decoder
+    L = decoder.load_host_library()
+    if not getattr(L, "_shard_engine_bound", False):
+        L.xvc_shard_rows.argtypes = [C.c_int] * 4 + [C.c_void_p] * 2
+        L.xvc_shard_plan_create.restype = C.c_void_p
+        L.xvc_shard_plan_create.argtypes = [C.c_int] * 8
+        L.xvc_shard_plan_destroy.argtypes = [C.c_void_p]
+        L.xvc_shard_plan_destroy.restype = None
+        L.xvc_shard_plan_rows.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        L.xvc_shard_plan_rows.restype = None
+        L.xvc_shard_plan_valid_rows.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.xvc_shard_plan_valid_rows.restype = None
+        L.xvc_shard_plan_slabs.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        L.xvc_shard_plan_traffic.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        L.xvc_shard_plan_traffic.restype = None
+        L.xvc_shard_run.argtypes = [C.c_void_p, C.c_void_p]
+        L.xvc_host_sharded_frame_pass.argtypes = [C.c_void_p, C.c_void_p]
+        L.xvc_host_sharded_total_ssd.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L._shard_engine_bound = True
+    return L
+
+
 def shard_rows(height, world, cu=16):
     """Split the CU rows of a picture into `world` contiguous shards.
-    Returns [(y0, y1)] in luma lines (y1 clipped to height)."""
+    Returns [(y0, y1)] in luma lines (y1 clipped to height).  (xvc_shard_rows,
+    xvc_amd/host/xvc_shard_engine.cc)"""
+    import ctypes as C
+    L = _host()
     n_rows = (height + cu - 1) // cu
     assert world <= n_rows, "more ranks than CU rows"
-    base, extra = divmod(n_rows, world)
-    out, r = [], 0
-    for k in range(world):
-        n = base + (1 if k < extra else 0)
-        out.append((r * cu, min(height, (r + n) * cu)))
-        r += n
+    out = []
+    for r in range(world):
+        y0, y1 = C.c_int32(), C.c_int32()
+        assert L.xvc_shard_rows(height, world, cu, r, C.byref(y0), C.byref(y1)) == 0
+        out.append((y0.value, y1.value))
     return out
 
 
@@ -242,42 +268,102 @@ class NativeComm:
         return t
 
 
+class _Slab(__import__("ctypes").Structure):
+    _fields_ = [("peer", __import__("ctypes").c_int32), ("kind", __import__("ctypes").c_int32),
+                ("a", __import__("ctypes").c_int32), ("b", __import__("ctypes").c_int32)]
+
+
 class ShardedFramePass:
+    """Binding of the C++ shard engine (xvc_amd/host/xvc_shard_engine.{h,cc}): the plan
+    - rows per rank, which rows / CU records travel in the halo and the gather exchange,
+    scheme B's exactness precondition - and the five-step control (xvc_shard_run) live
+    there.  This class turns the plan's slabs into the engine's memory views, hands the
+    steps to the engine / transport it was given (the CPU tests: an oracle engine over
+    gloo, driven by the same C++ control through callbacks) and, for a GpuEngine with a
+    native communicator, calls the product path xvc_host_sharded_frame_pass (frame-pass
+    phases on row ranges + ncclSend / ncclRecv groups; no Python between the steps)."""
+
     HALO = 4  # luma rows on each side of a shard boundary
 
     def __init__(self, engine, comm, rank, world, reach=None):
+        import ctypes as C
         self.e, self.comm, self.rank, self.world = engine, comm, rank, world
+        self.L = _host()
         self.rows = shard_rows(engine.h, world, engine.cu)
         self.y0, self.y1 = self.rows[rank]
         # rows of the reference a shard may read beyond its own: the search
         # window (+ predictor offset), the 8-sample MV clip margin, 4 filter
-        # taps, one CU of slack; below also the 64-row PSNR blocks that start
-        # in the own rows.  Must be the same number on every rank.
+        # taps, one CU of slack.  Must be the same number on every rank.
         if reach is None:
             reach = engine.search_reach() + 8 + 4 + 16
-        self.reach_up = (reach + 15) // 16 * 16
-        self.reach_down = max(self.reach_up, 64)
+        self.plan = self.L.xvc_shard_plan_create(engine.w, engine.h, engine.cu, world, rank, reach,
+                                                 engine.min_cu_height_at(self.y0),
+                                                 engine.min_cu_height_at(self.y1))
+        # exactness precondition of the redundant-halo scheme
+        assert self.plan, "4-tall CUs at a shard boundary need the ordered hand-off protocol"
         self._ops = {}
         self.up = rank - 1 if rank > 0 else None
         self.down = rank + 1 if rank < world - 1 else None
-        # exactness precondition of the redundant-halo scheme
-        assert engine.min_cu_height_at(self.y0) >= 8 and \
-            engine.min_cu_height_at(self.y1) >= 8, \
-            "4-tall CUs at a shard boundary need the ordered hand-off protocol"
+        self._cb_type = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int)
+        self._ex_type = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
+                                    C.c_int)
+        self._gpu = None
 
-    # ---- slabs ----
-    def _plane_rows(self, rec_idx, ya, yb):
-        """Row slabs [ya, yb) (luma lines) of the three planes."""
-        return [self.e.row_slab(rec_idx, 0, ya, yb),
-                self.e.row_slab(rec_idx, 1, ya // 2, yb // 2),
-                self.e.row_slab(rec_idx, 2, ya // 2, yb // 2)]
+    def __del__(self):
+        if getattr(self, "plan", None):
+            self.L.xvc_shard_plan_destroy(self.plan)
+            self.plan = None
 
-    def _cu_row_slab(self, y):
-        """Metadata of the CU row that starts at luma line y."""
-        first = (y // self.e.cu) * self.e.cus_per_row
-        return self.e.cu_slab(first, self.e.cus_per_row)
+    # ---- the plan's slabs as views of the engine's memory ----
+    def _slabs(self, which, direction):
+        import ctypes as C
+        ptr = C.POINTER(_Slab)()
+        n = self.L.xvc_shard_plan_slabs(self.plan, which, direction, C.byref(ptr))
+        return [(ptr[i].peer, ptr[i].kind, ptr[i].a, ptr[i].b) for i in range(n)]
 
-    # ---- phases ----
+    def _views(self, rec_idx, slabs):
+        out = []
+        for peer, kind, a, b in slabs:
+            if kind == 0:
+                out += [(peer, self.e.row_slab(rec_idx, 0, a, b)),
+                        (peer, self.e.row_slab(rec_idx, 1, a // 2, b // 2)),
+                        (peer, self.e.row_slab(rec_idx, 2, a // 2, b // 2))]
+            else:
+                out.append((peer, self.e.cu_slab(a, b)))
+        return out
+
+    def _exchange_ops(self, which, rec_idx):
+        # the slabs are fixed views of the picture memory: built once per buffer
+        key = (which, rec_idx)
+        if key not in self._ops:
+            self._ops[key] = (self._views(rec_idx, self._slabs(which, 0)),
+                              self._views(rec_idx, self._slabs(which, 1)))
+        return self._ops[key]
+
+    def halo_ops(self, rec_idx):
+        return self._exchange_ops(0, rec_idx)
+
+    def gather_ops(self, rec_idx):
+        return self._exchange_ops(1, rec_idx)
+
+    def traffic(self):
+        """{exchange: (RCCL operations, bytes) this rank sends per picture}."""
+        import ctypes as C
+        out = {}
+        for which, name in ((0, "halo"), (1, "gather")):
+            m, b = C.c_int64(), C.c_int64()
+            self.L.xvc_shard_plan_traffic(self.plan, which, C.byref(m), C.byref(b))
+            out[name] = (m.value, b.value)
+        return out
+
+    def valid_rows(self):
+        """Rows of the local reconstruction that are up to date after run()."""
+        import ctypes as C
+        a, b = C.c_int32(), C.c_int32()
+        self.L.xvc_shard_plan_valid_rows(self.plan, C.byref(a), C.byref(b))
+        return (a.value, b.value)
+
+    # ---- one step each (the loop-back tests interleave the ranks by hand) ----
     def phase_a(self, orig, ref_idx, rec_idx, ref_poc):
         if getattr(self.e, "one_call_phases", False):
             self.e.phase_a(orig, ref_idx, rec_idx, ref_poc, self.y0, self.y1)
@@ -285,64 +371,13 @@ class ShardedFramePass:
         self.e.encode(orig, ref_idx, rec_idx, ref_poc)
         self.e.deblock_rows(rec_idx, 0, self.y0, self.y1)
 
-    def halo_ops(self, rec_idx):
-        # the slabs are fixed views of the picture memory: built once per buffer
-        key = ("halo", rec_idx)
-        if key not in self._ops:
-            self._ops[key] = self._halo_ops(rec_idx)
-        return self._ops[key]
-
-    def _halo_ops(self, rec_idx):
-        H = self.HALO
-        sends, recvs = [], []
-        if self.up is not None:
-            sends += [(self.up, t) for t in self._plane_rows(rec_idx, self.y0, self.y0 + H)]
-            sends.append((self.up, self._cu_row_slab(self.y0)))
-            recvs += [(self.up, t) for t in self._plane_rows(rec_idx, self.y0 - H, self.y0)]
-            recvs.append((self.up, self._cu_row_slab(self.y0 - self.e.cu)))
-        if self.down is not None:
-            sends += [(self.down, t) for t in self._plane_rows(rec_idx, self.y1 - H, self.y1)]
-            sends.append((self.down, self._cu_row_slab(self.y1 - self.e.cu)))
-            recvs += [(self.down, t) for t in self._plane_rows(rec_idx, self.y1, self.y1 + H)]
-            recvs.append((self.down, self._cu_row_slab(self.y1)))
-        return sends, recvs
-
-    def phase_b(self, rec_idx):
-        y_end = self.y1 + self.HALO if self.down is not None else self.y1
+    def phase_b(self, rec_idx, y_end=None):
+        if y_end is None:
+            y_end = self.y1 + self.HALO if self.down is not None else self.y1
         if getattr(self.e, "one_call_phases", False):
             self.e.phase_b(rec_idx, self.y0, y_end)
             return
         self.e.deblock_rows(rec_idx, 1, self.y0, y_end)
-
-    def needed_from(self, who, peer):
-        """Rows of `peer`'s shard that rank `who` must hold: [ya, yb) or None."""
-        y0, y1 = self.rows[who]
-        pa, pb = self.rows[peer]
-        ya, yb = max(pa, y0 - self.reach_up), min(pb, y1 + self.reach_down)
-        return (ya, yb) if ya < yb else None
-
-    def valid_rows(self):
-        """Rows of the local reconstruction that are up to date after run()."""
-        return (max(0, self.y0 - self.reach_up), min(self.e.h, self.y1 + self.reach_down))
-
-    def gather_ops(self, rec_idx):
-        key = ("gather", rec_idx)
-        if key not in self._ops:
-            self._ops[key] = self._gather_ops(rec_idx)
-        return self._ops[key]
-
-    def _gather_ops(self, rec_idx):
-        sends, recvs = [], []
-        for peer in range(self.world):
-            if peer == self.rank:
-                continue
-            out = self.needed_from(peer, self.rank)   # my rows the peer needs
-            if out:
-                sends += [(peer, t) for t in self._plane_rows(rec_idx, *out)]
-            inc = self.needed_from(self.rank, peer)   # the peer's rows I need
-            if inc:
-                recvs += [(peer, t) for t in self._plane_rows(rec_idx, *inc)]
-        return sends, recvs
 
     def phase_c(self, orig, rec_idx):
         if getattr(self.e, "one_call_phases", False):
@@ -356,13 +391,63 @@ class ShardedFramePass:
         t = self.comm.allreduce_sum(self.e.ssd_tensor())
         return int(t[0]), int(t[1])
 
+    # ---- one picture: the C++ control ----
     def run(self, orig, ref_idx, rec_idx, ref_poc=0):
-        self.phase_a(orig, ref_idx, rec_idx, ref_poc)
+        import ctypes as C
+        if isinstance(self.comm, NativeComm) and getattr(self.e, "one_call_phases", False):
+            return self._run_native(orig, ref_idx, rec_idx, ref_poc)
         copier = getattr(self.e, "make_copier", None)
-        self.comm.exchange(*self.halo_ops(rec_idx), copier)
-        self.phase_b(rec_idx)
-        self.comm.exchange(*self.gather_ops(rec_idx), copier)
-        self.phase_c(orig, rec_idx)
+        err = []
+
+        def phase(_, which, y0, y1, y_end):
+            try:
+                assert (y0, y1) == (self.y0, self.y1)
+                if which == 0:
+                    self.phase_a(orig, ref_idx, rec_idx, ref_poc)
+                elif which == 1:
+                    self.phase_b(rec_idx, y_end)
+                else:
+                    self.phase_c(orig, rec_idx)
+                return 0
+            except BaseException as ex:  # noqa: BLE001 (must not cross the C frame)
+                err.append(ex)
+                return 1
+
+        def exchange(_, which, sends, ns, recvs, nr):
+            try:
+                ops = self._exchange_ops(which, rec_idx)
+                assert (len(self._slabs(which, 0)), len(self._slabs(which, 1))) == (ns, nr)
+                if copier is not None:
+                    self.comm.exchange(*ops, copier)
+                else:
+                    self.comm.exchange(*ops)
+                return 0
+            except BaseException as ex:  # noqa: BLE001
+                err.append(ex)
+                return 1
+
+        class Cb(C.Structure):
+            _fields_ = [("user", C.c_void_p), ("phase", self._cb_type), ("exchange", self._ex_type)]
+        cb = Cb(None, self._cb_type(phase), self._ex_type(exchange))
+        rc = self.L.xvc_shard_run(self.plan, C.byref(cb))
+        if err:
+            raise err[0]
+        assert rc == 0, rc
+
+    def _run_native(self, orig, ref_idx, rec_idx, ref_poc):
+        import ctypes as C
+        e = self.e
+        if self._gpu is None:
+            class Gpu(C.Structure):
+                _fields_ = [("ctx", C.c_void_p), ("comm", C.c_void_p), ("args", C.c_void_p),
+                            ("d_cus", C.c_void_p), ("before", C.c_void_p), ("after", C.c_void_p)]
+            self._gpu = Gpu(e.ctx.h, self.comm.comm.h, None, e.cu_mem.data_ptr(),
+                            self.comm.before.h, self.comm.after.h)
+        a = e.frame_pass_args(orig, ref_idx, rec_idx, ref_poc)
+        self._gpu.args = C.addressof(a)
+        rc = self.L.xvc_host_sharded_frame_pass(self.plan, C.byref(self._gpu))
+        if rc:
+            raise api.XvcGpuError("xvc_host_sharded_frame_pass: %d" % rc)
 
 
 def chain_rows(cu_map, pic_w, pic_h, y0):
@@ -408,6 +493,7 @@ class ShardedTreeFilter:
 
     def __init__(self, engine, comm, rank, world, rows):
         self.e, self.comm, self.rank, self.world = engine, comm, rank, world
+        self._rows = list(rows)
         self.y0, self.y1 = rows[rank], rows[rank + 1]
         self.up = rank - 1 if rank > 0 else None
         self.down = rank + 1 if rank < world - 1 else None
@@ -444,10 +530,43 @@ class ShardedTreeFilter:
         return sends, recvs
 
     def run(self):
-        self.step_local()
-        self.comm.exchange(*self.ops_down())
-        self.step_strip()
-        self.comm.exchange(*self.ops_up())
+        """The five steps under the C++ control (xvc_shard_filter_run): it plans every
+        boundary and orders the steps; passes and exchanges come back here."""
+        import ctypes as C
+        from . import decoder
+        L = decoder.load_host_library()
+        pass_t = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int)
+        ex_t = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int)
+        err = []
+
+        def do_pass(_, which, ya, yb):
+            try:
+                self.e.deblock_rows(which, ya, yb)
+                return 0
+            except BaseException as ex:  # noqa: BLE001 (must not cross the C frame)
+                err.append(ex)
+                return 1
+
+        def do_exchange(_, send_down):
+            try:
+                self.comm.exchange(*(self.ops_down() if send_down else self.ops_up()))
+                return 0
+            except BaseException as ex:  # noqa: BLE001
+                err.append(ex)
+                return 1
+
+        class Cb(C.Structure):
+            _fields_ = [("user", C.c_void_p), ("do_pass", pass_t), ("exchange", ex_t)]
+        cb = Cb(None, pass_t(do_pass), ex_t(do_exchange))
+        m = np.ascontiguousarray(self.e.cu_map, np.int32)
+        rows = (C.c_int32 * (self.world + 1))(*[int(v) for v in self._rows])
+        L.xvc_shard_filter_run.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                           C.c_void_p]
+        rc = L.xvc_shard_filter_run(m.ctypes.data, m.shape[1], self.rank, self.world, rows,
+                                    C.byref(cb))
+        if err:
+            raise err[0]
+        assert rc == 0, rc
 
 
 class GpuTreeEngine:
@@ -577,6 +696,15 @@ class GpuEngine:
 
     def search_reach(self):
         return search_reach(self.fp.desc)
+
+    def frame_pass_args(self, orig, ref_idx, rec_idx, ref_poc):
+        """The picture's xvcgpu_frame_pass_args (row ranges are the shard engine's)."""
+        a = self.fp._args()
+        a.orig = orig.h_pic
+        a.ref = self.pictures[ref_idx].h_pic
+        a.rec, a.ref_poc = self.pictures[rec_idx].h_pic, ref_poc
+        a.d_ssd = self.ssd_mem.data_ptr()
+        return a
 
     def ssd(self, orig, rec_idx, ya=0, yb=1 << 30):
         self.ctx.picture_ssd_dev(orig, self.pictures[rec_idx], 0, self.bd,
