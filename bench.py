@@ -1099,6 +1099,13 @@ def main():
             "scaling": "strong" if world > 1 else "weak",
             "vs_baseline": None, "dtype": "u16", "data": "synthetic",
             "rccl_world_size": rccl_world if multi else 1,
+            # what this rank's exchanges move per picture, from the C++ plan
+            # (xvc_shard_plan_traffic): {exchange: [RCCL operations, bytes sent]}
+            "shard_exchange_per_picture": ({k: list(v) for k, v in runner.traffic().items()}
+                                           if runner is not None else None),
+            "shard_control": ("xvc_host_sharded_frame_pass (C++: frame-pass phases on row ranges "
+                              "+ ncclSend / ncclRecv groups)" if runner is not None and
+                              isinstance(runner.comm, sharded.NativeComm) else None) if multi else None,
             "psnr_y": psnr_y,
             "config": {"workload": "%dx%d yuv420p 30fps synthetic, QP %d, internal "
                                    "bitdepth 10, 16x16 CUs, TZ range 96, %s" %

@@ -94,6 +94,31 @@ def main():
         e.mem[1].copy_(before[1])
         e.cu_mem.copy_(before[2])
         torch.cuda.synchronize()
+    # the product path: libxvcgpu.so's own communicator and the C++ shard engine
+    # (xvc_host_sharded_frame_pass: frame-pass phases on row ranges, RCCL groups
+    # between them - none with one rank -, the PSNR parts all-reduced natively)
+    ctx3 = api.Context(0)
+    comm3 = api.Comm(ctx3, api.comm_unique_id(), 1, 0)
+    s3 = sharded.make_gpu_sharded(ctx3, w, h, bd, qp, 0, 1, dev, dist, own_stream=True,
+                                  native_comm=comm3)
+    assert isinstance(s3.comm, sharded.NativeComm) and s3.e.one_call_phases
+    assert ctx3.lib.xvcgpu_comm_world(comm3.h) == 1
+    s3.e.pictures[0].upload(padded(clip.frame(0)), bl)
+    O3 = ctx3.picture(w, h, bd)
+    ref = padded(clip.frame(0))
+    for n in (1, 2):
+        orig = padded(clip.frame(n))
+        O3.upload(orig, bl)
+        with torch.cuda.stream(s3.e.stream):
+            s3.run(O3, (n - 1) % 2, n % 2, n - 1)
+            ssd3 = s3.total_ssd()
+        ctx3.sync()
+        rec, _, _, _, ssd = oracle_frame.frame_pass(desc, bd, orig, ref, bl, n - 1, lib=xo)
+        got = s3.e.pictures[n % 2].download(bl)
+        assert all(np.array_equal(got[c], rec[c]) for c in range(3)), ("native", n)
+        assert ssd3 == ssd, (ssd3, ssd)
+        ref = rec
+    assert s3.traffic() == {"halo": (0, 0), "gather": (0, 0)}
     dist.destroy_process_group()
     print("OK")
 
