@@ -56,6 +56,10 @@ def parse():
     ap.add_argument("--cpu-frames", type=int, default=12,
                     help="cap on the single-thread CPU oracle frame passes (rank 0, N=1)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--tail-priority", choices=["auto", "on", "off"], default="auto",
+                    help="the short kernels that end a pass (inverse transform, fused tail) "
+                         "on a high-priority stream of their chain "
+                         "(xvcgpu_set_short_kernel_priority); auto: on with several chains")
     ap.add_argument("--quant", choices=["rdoq", "fast"], default="rdoq",
                     help="quantiser of the transform stage: rdoq = RdoQuant::QuantRdo with "
                          "CoeffSignHideRdo, what the reference's encoder always runs "
@@ -859,6 +863,12 @@ def main():
         cctx.sync()
         extra.append((cctx, crun, cfp, crecs, phase, ts))
 
+    tail_priority = args.tail_priority == "on" or (
+        args.tail_priority == "auto" and n_chains > 1 and not multi and not args.graph)
+    if tail_priority:
+        for c in [ctx] + [e[0] for e in extra]:
+            c.set_short_kernel_priority(True)
+
     recordings = {}
 
     def orig_at(j):
@@ -1061,9 +1071,30 @@ def main():
         except (OSError, KeyError, ValueError, NameError):
             issue = None
         achieved = alg[dom] / (times[dom] * 1e-3) / 1e9
-        roof = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": 8000.0,
+        # `bound` names the roofline the harness prices the kernel against (these are
+        # byte / integer paths: HBM); `limited_by` is what the counters say holds it
+        # back in fact
+        if achieved / 8000.0 >= 0.5:
+            limited = "hbm bandwidth"
+        elif issue is not None and issue["frac_alone"] >= 0.6:
+            limited = "VALU issue (%.0f %% of the instruction-issue floor)" % (100 * issue["frac_alone"])
+        elif issue is not None:
+            limited = ("latency: the launch lasts as long as its longest wave - dependent LDS / "
+                       "L2 round trips of one wave, %.0f %% of the VALU-issue floor, %.0f %% of "
+                       "the lanes active" % (100 * issue["frac_alone"],
+                                             100 * (issue.get("active_lanes") or 0)))
+        else:
+            limited = "latency / instruction issue (no counter profile for these kernel sources)"
+        pass_bytes = sum(alg[k] for k in times if k in alg)
+        roof = {"bound": "hbm", "limited_by": limited, "kernel": dom, "achieved": achieved,
+                "peak": 8000.0,
                 "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic,
                 "valu_issue": issue,
+                # the whole pass: the algorithmic bytes of all its kernels over the time a
+                # pass takes with the chains in flight
+                "whole_pass": {"algorithmic_bytes": pass_bytes,
+                               "gbps": pass_bytes / (dt / args.steps) / 1e9,
+                               "frac": pass_bytes / (dt / args.steps) / 1e9 / 8000.0},
                 "algorithmic_bytes": alg[dom],
                 "ms_per_launch": times[dom],
                 # per launch with the device to itself (chain 0, others idle):
@@ -1094,6 +1125,7 @@ def main():
             "ms_per_step": 1e3 * dt / args.steps,
             "gpu_ms_per_step_events": gpu_ms / args.steps if n_chains == 1 else None,
             "pictures_in_flight": n_chains,
+            "tail_on_priority_stream": bool(tail_priority),
             "host_issue_ms_per_step": 1e3 * t_issued / args.steps,
             "higher_is_better": True,
             "scaling": "strong" if world > 1 else "weak",

@@ -74,6 +74,12 @@ xvcgpu_status xvcgpu_use_own_stream(xvcgpu_ctx *ctx);
 xvcgpu_status xvcgpu_use_priority_stream(xvcgpu_ctx *ctx, int high);
 xvcgpu_status xvcgpu_wait_for(xvcgpu_ctx *ctx, xvcgpu_ctx *other);
 xvcgpu_status xvcgpu_sync(xvcgpu_ctx *ctx);
+/* on != 0: the short kernels that end a whole-picture xvcgpu_frame_pass (inverse
+ * transform, the fused deblock / pad / PSNR tail) run on a second, high-priority
+ * stream of the context, ordered with the rest of the pass by events - for several
+ * picture chains in flight on one device, whose searches otherwise keep every CU
+ * busy while another chain's 100-us tail waits.  Results do not depend on it. */
+xvcgpu_status xvcgpu_set_short_kernel_priority(xvcgpu_ctx *ctx, int on);
 /* HIP-event stopwatch on the context's stream (bench.py's timed region). */
 xvcgpu_status xvcgpu_timer_begin(xvcgpu_ctx *ctx);
 xvcgpu_status xvcgpu_timer_end(xvcgpu_ctx *ctx, float *elapsed_ms);

@@ -149,7 +149,7 @@ FP_ENCODE, FP_DEBLOCK_V, FP_DEBLOCK_H, FP_PAD, FP_SSD = 1, 2, 4, 8, 16
 # every symbol include/xvcgpu.h declares
 SYMBOLS = [
     "xvcgpu_create", "xvcgpu_destroy", "xvcgpu_last_error", "xvcgpu_version",
-    "xvcgpu_set_stream", "xvcgpu_get_stream", "xvcgpu_use_own_stream", "xvcgpu_use_priority_stream", "xvcgpu_wait_for", "xvcgpu_sync", "xvcgpu_timer_begin", "xvcgpu_timer_end", "xvcgpu_timer_mark", "xvcgpu_timer_between",
+    "xvcgpu_set_stream", "xvcgpu_get_stream", "xvcgpu_use_own_stream", "xvcgpu_use_priority_stream", "xvcgpu_set_short_kernel_priority", "xvcgpu_wait_for", "xvcgpu_sync", "xvcgpu_timer_begin", "xvcgpu_timer_end", "xvcgpu_timer_mark", "xvcgpu_timer_between",
     "xvcgpu_record_begin", "xvcgpu_record_end", "xvcgpu_replay", "xvcgpu_recording_destroy",
     "xvcgpu_malloc", "xvcgpu_free", "xvcgpu_memcpy_h2d", "xvcgpu_memcpy_d2h", "xvcgpu_memcpy_d2h_async", "xvcgpu_cs_start_fold", "xvcgpu_cs_uni_fold", "xvcgpu_cs_bi_fold",
     "xvcgpu_memset", "xvcgpu_picture_create", "xvcgpu_picture_bytes",
@@ -228,6 +228,7 @@ def load_library():
         "xvcgpu_set_stream": [_vp, _vp],
         "xvcgpu_use_own_stream": [_vp],
         "xvcgpu_use_priority_stream": [_vp, C.c_int],
+        "xvcgpu_set_short_kernel_priority": [_vp, C.c_int],
         "xvcgpu_wait_for": [_vp, _vp],
         "xvcgpu_sync": [_vp],
         "xvcgpu_timer_begin": [_vp],
@@ -620,6 +621,9 @@ class Context:
 
     def use_priority_stream(self, high):
         self._check(self.lib.xvcgpu_use_priority_stream(self.h, 1 if high else 0))
+
+    def set_short_kernel_priority(self, on=True):
+        self._check(self.lib.xvcgpu_set_short_kernel_priority(self.h, int(on)))
 
     def wait_for(self, other):
         """Work queued on this context from now on starts after everything

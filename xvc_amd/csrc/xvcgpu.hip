@@ -189,6 +189,7 @@ xvcgpu_status xvcgpu_create(int device, xvcgpu_ctx **out) {
   if (!ctx) return XVCGPU_OUT_OF_MEMORY;
   ctx->device = device;
   ctx->stream = nullptr;
+  ctx->hi_stream = nullptr;
   ctx->own_stream = false;
   ctx->d_tx_tables = nullptr;
   ctx->d_tx_tables_t = nullptr;
@@ -278,6 +279,11 @@ void xvcgpu_destroy(xvcgpu_ctx *ctx) {
   hipEventDestroy(ctx->ev0);
   hipEventDestroy(ctx->ev1);
   hipEventDestroy(ctx->ev_sync);
+  if (ctx->hi_stream) {
+    hipStreamDestroy(ctx->hi_stream);
+    hipEventDestroy(ctx->ev_hi_in);
+    hipEventDestroy(ctx->ev_hi_out);
+  }
   for (int i = 0; i < 64; i++)
     if (ctx->ev_pool[i]) hipEventDestroy(ctx->ev_pool[i]);
   if (ctx->own_stream && ctx->stream) hipStreamDestroy(ctx->stream);
@@ -323,6 +329,28 @@ xvcgpu_status xvcgpu_use_priority_stream(xvcgpu_ctx *ctx, int high) {
   if (ctx->own_stream && ctx->stream) hipStreamDestroy(ctx->stream);
   ctx->stream = st;
   ctx->own_stream = true;
+  return XVCGPU_OK;
+}
+
+xvcgpu_status xvcgpu_set_short_kernel_priority(xvcgpu_ctx *ctx, int on) {
+  if (!ctx) return XVCGPU_INVALID_ARGUMENT;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  if (!on) {
+    if (ctx->hi_stream) {
+      hipStreamSynchronize(ctx->hi_stream);
+      hipStreamDestroy(ctx->hi_stream);
+      hipEventDestroy(ctx->ev_hi_in);
+      hipEventDestroy(ctx->ev_hi_out);
+      ctx->hi_stream = nullptr;
+    }
+    return XVCGPU_OK;
+  }
+  if (ctx->hi_stream) return XVCGPU_OK;
+  int lo = 0, hi = 0;  // numerically lower = higher priority
+  HIP_TRY(ctx, hipDeviceGetStreamPriorityRange(&lo, &hi));
+  HIP_TRY(ctx, hipStreamCreateWithPriority(&ctx->hi_stream, hipStreamNonBlocking, hi));
+  HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_hi_in, hipEventDisableTiming));
+  HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_hi_out, hipEventDisableTiming));
   return XVCGPU_OK;
 }
 
@@ -1898,6 +1926,17 @@ xvcgpu_status xvcgpu_frame_pass(xvcgpu_ctx *ctx, const xvcgpu_frame_pass_args *a
                           a->dbh_y_end >= a->rec->h && a->ssd_y_begin == 0 &&
                           a->ssd_y_end >= a->rec->h && !(a->rec->w & 7) && !(a->rec->h & 7);
   xvcgpu_picture *const rec = fused_tail ? a->scratch_rec : a->rec;
+  hipStream_t main_stream = nullptr;   // set while the pass runs on ctx->hi_stream
+  struct Back {
+    xvcgpu_ctx *c;
+    hipStream_t *m;
+    ~Back() {   // every way out: the chain continues on its own stream, after the tail
+      if (!*m) return;
+      hipEventRecord(c->ev_hi_out, c->hi_stream);
+      c->stream = *m;
+      hipStreamWaitEvent(c->stream, c->ev_hi_out, 0);
+    }
+  } back = {ctx, &main_stream};
   if ((phases & XVC_FP_ENCODE) && a->n_cus > 0) {
     st = xvcgpu_me_search_sized(ctx, a->orig, a->ref, XVCGPU_ME_FULLPEL | XVCGPU_ME_SUBPEL,
                                 a->d_me, a->n_cus, a->d_results, a->max_block_size);
@@ -1938,6 +1977,17 @@ xvcgpu_status xvcgpu_frame_pass(xvcgpu_ctx *ctx, const xvcgpu_frame_pass_args *a
           st = XVCGPU_INVALID_ARGUMENT;
         } else if (a->n_tx > 0) {
           const PicView &pv = in_place ? rec->v : a->pred->v;
+          if (ctx->hi_stream && fused_tail && in_place) {
+            // the rest of the pass - inverse transform and the fused tail, two short
+            // kernels - on the high-priority stream: beside other pictures' searches
+            // (long-lived waves on every CU) their workgroups otherwise wait for slots
+            // many times their own duration (profiles/r03_bench_4320p_kernel_stats.csv:
+            // the tail 2152 us in flight against 118 alone)
+            HIP_TRY(ctx, hipEventRecord(ctx->ev_hi_in, ctx->stream));
+            HIP_TRY(ctx, hipStreamWaitEvent(ctx->hi_stream, ctx->ev_hi_in, 0));
+            main_stream = ctx->stream;
+            ctx->stream = ctx->hi_stream;
+          }
           if (in_place) {
             // blocks 3 * cu + comp, CUs up to 16x16 (the condition of in_place): the
             // U and V blocks of a CU share a wave

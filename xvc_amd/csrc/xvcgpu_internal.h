@@ -31,6 +31,11 @@ struct xvcgpu_ctx {
   bool own_stream;
   hipEvent_t ev0, ev1;
   hipEvent_t ev_sync;  // xvcgpu_wait_for
+  // xvcgpu_set_short_kernel_priority: a second, high-priority stream for the short
+  // kernels at the end of a frame pass (inverse transform, the fused tail) and the two
+  // events that hand the chain over and back
+  hipStream_t hi_stream;
+  hipEvent_t ev_hi_in, ev_hi_out;
   hipEvent_t ev_pool[64];  // xvcgpu_timer_mark slots, created on first use
   std::string err;
   // transform matrices [type 1..5][log2 size 1..6], device copy
