@@ -59,7 +59,10 @@ def parse():
     ap.add_argument("--tail-priority", choices=["auto", "on", "off"], default="auto",
                     help="the short kernels that end a pass (inverse transform, fused tail) "
                          "on a high-priority stream of their chain "
-                         "(xvcgpu_set_short_kernel_priority); auto: on with several chains")
+                         "(xvcgpu_set_short_kernel_priority); auto = off: measured in round 4 it "
+                         "LOSES - 7124 -> 3726 passes/s at 1080p, 1542 -> 1305 at 2160p, 583 -> "
+                         "522 at 4320p (three chains): the two event hand-overs per pass cost "
+                         "more than the earlier start of the short kernels gains")
     ap.add_argument("--quant", choices=["rdoq", "fast"], default="rdoq",
                     help="quantiser of the transform stage: rdoq = RdoQuant::QuantRdo with "
                          "CoeffSignHideRdo, what the reference's encoder always runs "
@@ -863,8 +866,7 @@ def main():
         cctx.sync()
         extra.append((cctx, crun, cfp, crecs, phase, ts))
 
-    tail_priority = args.tail_priority == "on" or (
-        args.tail_priority == "auto" and n_chains > 1 and not multi and not args.graph)
+    tail_priority = args.tail_priority == "on"
     if tail_priority:
         for c in [ctx] + [e[0] for e in extra]:
             c.set_short_kernel_priority(True)
