@@ -177,6 +177,9 @@ xvcgpu_status xvcgpu_memset(xvcgpu_ctx *ctx, void *dst, int value, size_t bytes)
  * once - `src` must stay untouched until an event recorded after the call has
  * completed (xvcgpu_event_record / _synchronize).  With pageable `src` the
  * runtime stages the bytes itself and the call may block. */
+/* (hipHostMalloc: the memory is also addressable by the device under the same pointer -
+ * a kernel's small results can be written straight into it, visible to the host once
+ * the stream has been synchronised: no copy kernel, no separate read-back.) */
 xvcgpu_status xvcgpu_host_alloc(xvcgpu_ctx *ctx, size_t bytes, void **host_ptr);
 xvcgpu_status xvcgpu_host_free(xvcgpu_ctx *ctx, void *host_ptr);
 xvcgpu_status xvcgpu_memcpy_h2d_async(xvcgpu_ctx *ctx, void *dst, const void *src,
@@ -890,7 +893,7 @@ xvcgpu_status xvcgpu_affine_me_batch(xvcgpu_ctx *ctx, const xvcgpu_picture *orig
                                      xvcgpu_affine_me_result *d_results);
 
 /* ---- the folds of one SearchMotion chain --------------------------------------- *
- * xvcgpu_cs_pass (include/xvcgpu_types.h) describes one SearchMotion of a CU; the three
+ * A pass record - xvcgpu_cs_pass, include/xvcgpu_types.h - describes one SearchMotion of a CU; the three
  * calls below run the host logic of InterSearch::SearchRefIdx / SearchBiIterative /
  * SearchMotion (inter_search.cc:199-259, :392-578) between the batched searches, ON the
  * device, each reading the previous step's results and writing the next step's jobs -
@@ -934,6 +937,18 @@ xvcgpu_status xvcgpu_cs_bi_fold(xvcgpu_ctx *ctx, const xvcgpu_cs_pass *d_passes,
                                 const xvcgpu_me_result *d_bi_res,
                                 const xvcgpu_affine_me_result *d_aff_res,
                                 xvcgpu_cs_result *d_results, xvcgpu_inter_block *d_ev_inter);
+
+/* All distortions of an evaluation (CompressAndEvalCbf, inter_search.cc:261-365) in one
+ * launch: candidate i compares its block of `orig` with the same block of `pred`
+ * (versus = 0: the cbf-zero distortion) or of `rec` (versus = 1: an alternative's
+ * reconstruction) in component comp with `metric`, times its weight -
+ * out[i] = (uint64)(dist * weight) as SampleMetric::CompareSample returns it
+ * (sample_metric.cc:221-222).  xvcgpu_metric_batch is one component, one picture pair
+ * and one weight per launch. */
+xvcgpu_status xvcgpu_eval_dist_batch(xvcgpu_ctx *ctx, const xvcgpu_picture *orig,
+                                     const xvcgpu_picture *pred, const xvcgpu_picture *rec,
+                                     int structural_strength, const xvcgpu_eval_cand *d_cands,
+                                     int n, uint64_t *d_out);
 
 /* ---- multi-GPU staging --------------------------------------------------- *
  * n device-to-device copies (descriptors in device memory) in one launch: packs

@@ -401,6 +401,22 @@ typedef struct xvcgpu_cs_result {
   int32_t out_mvd[2][2][2];
 } xvcgpu_cs_result;
 
+/* One distortion of an evaluation (xvcgpu_eval_dist_batch): what CompressAndEvalCbf /
+ * CompressAndEvalTransform compare per component and alternative - the prediction
+ * against the original (the cbf-zero distortion, transform_encoder.cc:116-117) or a
+ * reconstruction against it (:284) - with the component's distortion weight.  One
+ * launch prices all of them, whatever their component. */
+typedef struct xvcgpu_eval_cand {
+  int16_t x, y;        /* block position in the component plane (all three pictures) */
+  uint8_t w, h;
+  uint8_t metric;      /* xvcgpu_metric                                               */
+  int8_t qp;           /* raw luma qp (structural SSD)                                */
+  uint8_t comp;        /* 0 = Y, 1 = U, 2 = V                                         */
+  uint8_t versus;      /* 0: the prediction picture, 1: the reconstruction picture    */
+  uint8_t reserved[6];
+  double weight;       /* Qp::GetDistortionWeight(comp)                               */
+} xvcgpu_eval_cand;
+
 /* One motion-compensation job (InterPrediction::MotionCompensationMv,
  * inter_prediction.cc:740-758) for one component of one uni-pred CU. */
 typedef struct xvcgpu_mc_block {

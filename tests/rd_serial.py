@@ -606,7 +606,7 @@ RESULT_DTYPE = np.dtype([
 OP_DTYPE = np.dtype([("opcode", "<i4"), ("n", "<i4"), ("r0", "<i4"), ("r1", "<i4"), ("i0", "<i4"),
                      ("reserved", "<i4"), ("f", "<f8"), ("p", "<u8", 5)], align=True)
 (OP_MC_METRIC, OP_METRIC, OP_ME, OP_BI, OP_AFFINE, OP_COPY, OP_INTER_PRED, OP_RESIDUAL,
- OP_START_FOLD, OP_UNI_FOLD, OP_BI_FOLD, OP_FETCH, OP_SYNC) = range(13)
+ OP_START_FOLD, OP_UNI_FOLD, OP_BI_FOLD, OP_FETCH, OP_SYNC, OP_EVAL_DIST) = range(14)
 PIC_ORIG, PIC_S_ORIG, PIC_S_PRED, PIC_S_REC = 0, 1, 2, 3
 BI_SLOTS = 2 * R3 * R3
 
@@ -795,6 +795,43 @@ class ChainedRun(SerialRun):
             h = self._pin(nbytes)
             C.memset(h, 0xff, nbytes)
             self.cres[name] = (np.frombuffer((C.c_char * nbytes).from_address(h), dt)[:n], h)
+        # Small results land in page-locked host memory the device writes directly
+        # (xvcgpu_host_alloc): no copy kernel, no read-back call - they are there when
+        # the chain's one wait returns.  Per evaluation state one block of distortions:
+        # [3 cbf-zero (Y, U, V)] [one per TransformAndReconstruct call].
+        st = sp.states
+        evs = np.flatnonzero(st["ev"] >= 0)
+        self.edist_first = np.full(len(st), -1, np.int64)
+        n_ed = 0
+        cands = []
+        for ns in evs:
+            r = st[ns]
+            ev, cf = int(r["ev"]), int(r["call_first"])
+            k = int(r["call_pass0"]) + int(r["call_pass1"])
+            self.edist_first[ns] = n_ed
+            blk = np.zeros(3 + k, api.EVAL_CAND_DTYPE)
+            for c in range(3):
+                d_ = sp.ev_dz[ev, c]
+                blk[c] = (d_["x"], d_["y"], d_["w"], d_["h"], d_["metric"], d_["qp"], c, 0, 0,
+                          sp.ev_weight[ev, c])
+            cc = sp.call_cand[cf:cf + k]
+            comp = sp.call_tx["comp"][cf:cf + k]
+            b = blk[3:]
+            for f in ("x", "y", "w", "h", "metric", "qp"):
+                b[f] = cc[f]
+            b["comp"], b["versus"] = comp, 1
+            b["weight"] = sp.ev_weight[ev][comp]
+            blk[3:] = b
+            cands.append(blk)
+            n_ed += 3 + k
+        d["ev_cands"] = up(np.concatenate(cands) if cands else np.zeros(0, api.EVAL_CAND_DTYPE))
+        self.z = {}
+        for name, dt, n in (("nnz", np.dtype("<i4"), len(sp.call_tx)), ("edist", np.dtype("<u8"), n_ed),
+                            ("mg_dist", np.dtype("<u8"), 5 * len(sp.mg_inter))):
+            nbytes = max(n, 1) * dt.itemsize
+            h = self._pin(nbytes)
+            C.memset(h, 0xff, nbytes)
+            self.z[name] = (np.frombuffer((C.c_char * nbytes).from_address(h), dt)[:n], h)
         self.env = e = CsEnv()
         e.orig, e.refs, e.n_refs = self.t.orig, self.t.refs, self.t.n_refs
         e.pic_w, e.pic_h = width, height
@@ -803,7 +840,7 @@ class ChainedRun(SerialRun):
         self.ctx.sync()
 
     # ---- program ---------------------------------------------------------------
-    def program(self, first, n, by_position=True):
+    def program(self, first, n, by_position=True, verify=True):
         """Ops of the states [first, first + n): one chain (ending in a SYNC) per state,
         or per visit of a CU position (consecutive states of one CU)."""
         sp, api, t, d = self.sp, self.api, self.t, self.d
@@ -866,32 +903,25 @@ class ChainedRun(SerialRun):
                 op(OP_BI_FOLD, 1, i0=pi, p=(P, d["bi_res_c"], d["aff_res_c"], d["ev_inter_work"]))
             fetch(d["results"] + pf * I["result"], self.cres["results"][1] + pf * I["result"], pc * I["result"])
 
-        def evaluation(s):
+        def evaluation(s, n_state):
             e = int(s["ev"])
             n0, n1 = int(s["call_pass0"]), int(s["call_pass1"])
             cf, k = int(s["call_first"]), n0 + n1
+            ed = int(self.edist_first[n_state])
+            z_nnz, z_ed = self.z["nnz"][1], self.z["edist"][1]
             op(OP_COPY, 3 + k, r0=PIC_ORIG, r1=PIC_S_ORIG, p=(t.d_copy_orig + int(s["copy_first"]) * I["copy"],))
             op(OP_INTER_PRED, 3, r1=PIC_S_PRED, p=(d["ev_inter_work"] + 3 * e * I["inter"],
                                                    t.d_ev_dst + 3 * e * I["pos"]))
-            for c in range(3):
-                op(OP_METRIC, 1, r0=PIC_S_ORIG, r1=PIC_S_PRED, i0=c, f=float(sp.ev_weight[e, c]),
-                   p=(t.d_ev_dz + (3 * e + c) * I["cand"], t.d_ev_dz_dist + 8 * (3 * e + c)))
             op(OP_COPY, k, r0=PIC_S_PRED, r1=PIC_S_PRED, p=(t.d_call_copy_pred + cf * I["copy"],))
-            op(OP_RESIDUAL, k, p=(t.d_call_tx + cf * I["tx"], t.d_call_off + 4 * cf, t.d_nnz + 4 * cf,
+            op(OP_RESIDUAL, k, p=(t.d_call_tx + cf * I["tx"], t.d_call_off + 4 * cf, z_nnz + 4 * cf,
                                   t.d_contexts + int(sp.ev_ctx[e]) * I["ctx"], t.d_call_prm + cf * I["prm"]))
-            a = cf
-            for c, cnt in list(enumerate(int(x) for x in s["comp_count"])) + [(0, n1)]:
-                if cnt:
-                    op(OP_METRIC, cnt, r0=PIC_S_ORIG, r1=PIC_S_REC, i0=c, f=float(sp.ev_weight[e, c]),
-                       p=(t.d_call_cand + a * I["cand"], t.d_call_dist + 8 * a))
-                a += cnt
-            fetch(t.d_nnz + 4 * cf, t.h_nnz + 4 * cf, 4 * k)
-            fetch(t.d_call_dist + 8 * cf, t.h_call_dist + 8 * cf, 8 * k)
-            fetch(t.d_ev_dz_dist + 24 * e, t.h_ev_dz_dist + 24 * e, 24)
+            # the three cbf-zero distortions and every alternative's, one launch
+            op(OP_EVAL_DIST, 3 + k, p=(d["ev_cands"] + ed * 24, z_ed + 8 * ed))
             fetch(t.d_levels + 2 * int(s["level_first"]), t.h_levels + 2 * int(s["level_first"]),
                   2 * int(s["level_count"]))
-            fetch(d["ev_inter_work"] + 3 * e * I["inter"], self.cres["ev_inter_out"][1] + 3 * e * I["inter"],
-                  3 * I["inter"])
+            if verify and s["kind"] == KIND_INTER:   # (an encoder reads the motion from `results`)
+                fetch(d["ev_inter_work"] + 3 * e * I["inter"],
+                      self.cres["ev_inter_out"][1] + 3 * e * I["inter"], 3 * I["inter"])
 
         chain_states, chain_kind, prev_key = 0, 0, None
         for n_state in range(first, first + n):
@@ -909,13 +939,12 @@ class ChainedRun(SerialRun):
                 op(OP_COPY, 5, r0=PIC_ORIG, r1=PIC_S_ORIG, p=(t.d_mg_copy + m * I["copy"],))
                 op(OP_INTER_PRED, 5, r1=PIC_S_PRED, p=(t.d_mg_inter + m * I["inter"], t.d_mg_dst + m * I["pos"]))
                 op(OP_METRIC, 5, r0=PIC_S_ORIG, r1=PIC_S_PRED, i0=0, f=1.0,
-                   p=(t.d_mg_cands + m * I["cand"], t.d_mg_dist + 8 * m))
-                fetch(t.d_mg_dist + 8 * m, t.h_mg_dist + 8 * m, 40)
+                   p=(t.d_mg_cands + m * I["cand"], self.z["mg_dist"][1] + 8 * m))
             else:
                 if kind in (KIND_INTER, KIND_MOTION):
                     motion(s, n_state)
                 if kind in (KIND_EVAL, KIND_INTER):
-                    evaluation(s)
+                    evaluation(s, n_state)
             chain_kind = max(chain_kind, kind) if chain_states else kind
             chain_states += 1
         if chain_states:
@@ -932,12 +961,27 @@ class ChainedRun(SerialRun):
                 rc, self.ctx.lib.xvcgpu_last_error(self.ctx.h)))
         return stats
 
-    def run_chained(self, first=0, n=None, by_position=True):
+    def run_chained(self, first=0, n=None, by_position=True, verify=True):
         n = len(self.sp.states) - first if n is None else n
-        key = (first, n, by_position)
+        key = (first, n, by_position, verify)
         if getattr(self, "_prog_key", None) != key:
-            self._prog, self._prog_key = self.program(first, n, by_position), key
-        return self.run_program(self._prog)
+            self._prog, self._prog_key = self.program(first, n, by_position, verify), key
+        stats = self.run_program(self._prog)
+        self.collect()
+        return stats
+
+    def collect(self):
+        """The device-written host arrays into the result arrays check() reads."""
+        st, res = self.sp.states, self.res
+        res["nnz"][:] = self.z["nnz"][0]
+        res["mg_dist"][:] = self.z["mg_dist"][0]
+        ed = self.z["edist"][0]
+        for ns in np.flatnonzero(self.edist_first >= 0):
+            r = st[ns]
+            a, ev, cf = int(self.edist_first[ns]), int(r["ev"]), int(r["call_first"])
+            k = int(r["call_pass0"]) + int(r["call_pass1"])
+            res["ev_dz_dist"][3 * ev:3 * ev + 3] = ed[a:a + 3]
+            res["call_dist"][cf:cf + k] = ed[a + 3:a + 3 + k]
 
     def run_chained_state(self, first=0, n=None):
         return self.run_chained(first, n, by_position=False)

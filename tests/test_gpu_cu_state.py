@@ -66,7 +66,8 @@ def _run_chained(api, ctx, name, poc, n_states, by_position):
 
 
 @pytest.mark.parametrize("name,poc,n_states,by_position", [
-    ("tiny", 2, 1 << 30, False), ("tiny", 2, 1 << 30, True), ("c1", 2, 6000, True)])
+    ("tiny", 2, 1 << 30, False), ("tiny", 2, 1 << 30, True), ("c0", 4, 1 << 30, True),
+    ("c1", 2, 20000, True)])
 def test_chained_states_equal_reference(gpu, name, poc, n_states, by_position):
     """The same states as ONE enqueue each (or per visit of a CU position), the folds
     between the searches on the device (xvcgpu_cs_*_fold): no read-back inside a chain.

@@ -3,7 +3,7 @@
 RdoSyntaxWriter on the live CABAC state, inter_search.cc:1131-1135) as the product
 computes it from a snapshot of eleven context states (include/xvc_inter_bits.h):
 every candidate SearchRefIdx priced while the reference encoder coded the tiny clip
-(all pictures) and one 1080p B picture - uni-directional, list-1 re-use,
+(all pictures), the CIF clip = BASELINE config 0 (all pictures) and one 1080p B picture - uni-directional, list-1 re-use,
 bi-directional, affine (tests/golden/rd_order_*.npz) - gets the reference's bits."""
 import ctypes as C
 
@@ -62,7 +62,7 @@ def host():
     return L
 
 
-@pytest.mark.parametrize("name", ["tiny", "c1"])
+@pytest.mark.parametrize("name", ["tiny", "c0", "c1"])
 def test_bits_of_every_priced_candidate(host, name):
     o = of.load(name)
     cd, ictx = o["cands"], np.ascontiguousarray(o["ictx"])
@@ -77,7 +77,7 @@ def test_bits_of_every_priced_candidate(host, name):
     # the closed form of restricted mode (:1084-1130) is NOT what the default run pays
     kinds = {int(k): int((cd["kind"] == k).sum()) for k in np.unique(cd["kind"])}
     assert kinds.get(0, 0) and kinds.get(1, 0)
-    if name == "c1":
+    if name != "tiny":
         assert kinds.get(2, 0) and kinds.get(3, 0)          # affine, uni and bi
     assert (cd["reused"] != 0).any() and ((cd["flags"] & 1) != 0).any()
 

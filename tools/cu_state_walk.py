@@ -46,11 +46,18 @@ def walk(api, clip, poc, n_states, ks, mode="serial", check=True, decoded=None, 
             runs = [rd_serial.ChainedRun(api, c, sp, pics, w, h, lists) for c in ctxs]
         stats = [None] * k
 
+        def go(r, count, verify=False):
+            if mode == "serial":
+                return r.run_serial(0, count)
+            # timed without the read-back of the composed prediction jobs, which only the
+            # check below wants (an encoder takes the motion from the pass results)
+            return r.run_chained(0, count, by_position=(mode == "chained"), verify=verify)
+
         def work(i):
-            stats[i] = getattr(runs[i], "run_" + mode)(0, n)
+            stats[i] = go(runs[i], n)
 
         for r in runs[:1]:          # warm-up (module load, scratch allocation)
-            getattr(r, "run_" + mode)(0, min(n, 200))
+            go(r, min(n, 200))
         th = [threading.Thread(target=work, args=(i,)) for i in range(k)]
         t0 = time.time()
         for t in th:
@@ -72,6 +79,8 @@ def walk(api, clip, poc, n_states, ks, mode="serial", check=True, decoded=None, 
                            for i, name in enumerate(("merge_rank", "eval", "inter", "motion_only"))},
         }
         if check:
+            if mode != "serial":
+                go(runs[-1], n, verify=True)
             res = runs[-1].check(0, n, searches=(mode == "serial"))
             if mode != "serial":
                 res.update(runs[-1].check_chained(0, n))

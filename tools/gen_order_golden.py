@@ -2,7 +2,7 @@
 """The ORDER of a real encoder run's RD search, and the motion searches' prices
 (authoring container only: needs oracle/_ref/libxvcref.so).
 
-    python tools/gen_order_golden.py [tiny] [c1]
+    python tools/gen_order_golden.py [tiny] [c0] [c1]
 
 tools/gen_me_golden.py and tools/gen_rd_golden.py record WHAT the reference
 encoder's RD search computes on the hot path - each table in its own capture
@@ -44,7 +44,7 @@ import rd_fixture as rf  # noqa: E402
 import stream_fixture as sf  # noqa: E402
 from xvc_amd import synth  # noqa: E402
 
-KEEP = {"tiny": None, "c1": 2}
+KEEP = {"tiny": None, "c0": None, "c1": 2}
 SEQ_TABLES = ["me", "steps", "merges", "evals", "calls", "cands", "finals"]
 
 

@@ -14,9 +14,13 @@
 // thread per pass that reads the previous step's results and WRITES THE NEXT STEP'S
 // JOBS, so a CU state is enqueued once and read back once.
 //
-// One thread per pass on purpose: the work is ~200 dependent scalar operations on a
-// handful of candidates - there is nothing to spread over lanes; its cost is the
-// launch (a few microseconds in a chain of searches of 30-100 us each).
+// One thread per pass does the arithmetic on purpose: ~200 dependent scalar operations
+// on a handful of candidates - nothing to spread over lanes.  What does cost time is
+// memory latency: read field by field from global memory the pass record (412 bytes)
+// and the running result (448 bytes) are a chain of ~1 us round trips (13.7 / 11.9 us
+// per launch, profiles/r04_cu_state_chained_kernel_stats.csv).  So a wave per pass
+// copies both records into LDS in one round trip, lane 0 works there, and the wave
+// writes the result back.
 #ifndef XVCGPU_K_CU_STATE_H_
 #define XVCGPU_K_CU_STATE_H_
 
@@ -92,6 +96,37 @@ __device__ __forceinline__ void cs_copy_mv(int32_t dst[3][2], const int32_t src[
   }
 }
 
+// one wave: n_words dwords global <-> LDS, all loads of a lane issued before its stores
+__device__ __forceinline__ void cs_wave_copy(void *dst, const void *src, int n_words) {
+  const uint32_t *s = static_cast<const uint32_t *>(src);
+  uint32_t *d = static_cast<uint32_t *>(dst);
+  const int lane = threadIdx.x;
+  uint32_t v[2];
+#pragma unroll
+  for (int k = 0; k < 2; k++) v[k] = s[min(lane + 64 * k, n_words - 1)];
+#pragma unroll
+  for (int k = 0; k < 2; k++)
+    if (lane + 64 * k < n_words) d[lane + 64 * k] = v[k];
+}
+static_assert(sizeof(xvcgpu_cs_pass) % 4 == 0 && sizeof(xvcgpu_cs_pass) <= 512, "two rounds of 64 lanes");
+static_assert(sizeof(xvcgpu_cs_result) % 4 == 0 && sizeof(xvcgpu_cs_result) <= 512, "two rounds of 64 lanes");
+
+// grid: n passes; block: one wave.  `first`: the fold works on passes [first, first + n)
+// of the arrays (an affine pass names its plain pass by absolute index).
+#define CS_FOLD_PROLOGUE                                                         \
+  __shared__ xvcgpu_cs_pass s_pass;                                              \
+  __shared__ xvcgpu_cs_result s_res;                                             \
+  if ((int)blockIdx.x >= n) return;                                              \
+  const int pi = first + blockIdx.x;                                             \
+  cs_wave_copy(&s_pass, &passes[pi], sizeof(xvcgpu_cs_pass) / 4);                \
+  cs_wave_copy(&s_res, &results[pi], sizeof(xvcgpu_cs_result) / 4);              \
+  __syncthreads();                                                               \
+  const xvcgpu_cs_pass &p = s_pass;                                              \
+  xvcgpu_cs_result &R = s_res;
+#define CS_FOLD_EPILOGUE \
+  __syncthreads();       \
+  cs_wave_copy(&results[pi], &s_res, sizeof(xvcgpu_cs_result) / 4);
+
 // ---- fold 1: EvalStartMvp's choice -> the searches' start predictors ---------------
 // start_dist: SampleMetric(kSad) of the two predictors' predictions (GetMvpMetricType,
 // :1078-1080), as xvcgpu_mc_metric_batch / xvcgpu_metric_batch return them.  Both
@@ -101,12 +136,8 @@ __global__ void cs_start_fold_kernel(const xvcgpu_cs_pass *passes, int first, in
                                      const xvcgpu_me_result *me_res,
                                      xvcgpu_affine_me_block *aff_jobs, xvcgpu_cs_result *results,
                                      int pic_w, int pic_h) {
-  // passes [first, first + n) of the arrays (plain_pass indexes them absolutely)
-  const int ti = blockIdx.x * blockDim.x + threadIdx.x;
-  if (ti >= n) return;
-  const int pi = first + ti;
-  const xvcgpu_cs_pass &p = passes[pi];
-  xvcgpu_cs_result &R = results[pi];
+  CS_FOLD_PROLOGUE
+  auto body = [&]() {
   const bool affine = cs_affine(p);
   for (int l = 0; l < 2; l++)
     for (int r = 0; r < p.num_refs[l] && r < CS_R; r++) {
@@ -137,6 +168,9 @@ __global__ void cs_start_fold_kernel(const xvcgpu_cs_pass *passes, int first, in
         }
       }
     }
+  };
+  if (threadIdx.x == 0) body();
+  CS_FOLD_EPILOGUE
 }
 
 // ---- fold 2: SearchRefIdx over both lists -> the refinement jobs --------------------
@@ -145,12 +179,8 @@ __global__ void cs_uni_fold_kernel(const xvcgpu_cs_pass *passes, int first, int 
                                    const xvcgpu_affine_me_result *aff_res,
                                    xvcgpu_cs_result *results, xvcgpu_bi_block *bi_jobs,
                                    xvcgpu_affine_me_block *aff_jobs) {
-  // passes [first, first + n) of the arrays (plain_pass indexes them absolutely)
-  const int ti = blockIdx.x * blockDim.x + threadIdx.x;
-  if (ti >= n) return;
-  const int pi = first + ti;
-  const xvcgpu_cs_pass &p = passes[pi];
-  xvcgpu_cs_result &R = results[pi];
+  CS_FOLD_PROLOGUE
+  auto body = [&]() {
   const bool affine = cs_affine(p), fullpel = cs_fullpel(p);
   R.cost_l1_unique = CS_MAXCOST;
   R.best_ref_l1_unique = -1;
@@ -245,6 +275,9 @@ __global__ void cs_uni_fold_kernel(const xvcgpu_cs_pass *passes, int first, int 
       cs_copy_mv(j.other_mv, R.mv[best_dir][o]);
     }
   }
+  };
+  if (threadIdx.x == 0) body();
+  CS_FOLD_EPILOGUE
 }
 
 // ---- fold 3: the refinement's costs, the three-way choice, the evaluation's jobs ----
@@ -252,12 +285,8 @@ __global__ void cs_bi_fold_kernel(const xvcgpu_cs_pass *passes, int first, int n
                                   const xvcgpu_me_result *bi_res,
                                   const xvcgpu_affine_me_result *aff_res,
                                   xvcgpu_cs_result *results, xvcgpu_inter_block *ev_inter) {
-  // passes [first, first + n) of the arrays (plain_pass indexes them absolutely)
-  const int ti = blockIdx.x * blockDim.x + threadIdx.x;
-  if (ti >= n) return;
-  const int pi = first + ti;
-  const xvcgpu_cs_pass &p = passes[pi];
-  xvcgpu_cs_result &R = results[pi];
+  CS_FOLD_PROLOGUE
+  auto body = [&]() {
   const bool affine = cs_affine(p), fullpel = cs_fullpel(p);
   uint32_t cost_bi = CS_MAXCOST;
   int bi_ref = -1;
@@ -371,6 +400,28 @@ __global__ void cs_bi_fold_kernel(const xvcgpu_cs_pass *passes, int first, int n
       }
     }
   }
+  };
+  if (threadIdx.x == 0) body();
+  CS_FOLD_EPILOGUE
+}
+
+// ---- the distortions of an evaluation in one launch ----------------------------------
+// metric_batch_kernel (k_metric.h) with the planes chosen per candidate: an evaluation
+// compares three components against two pictures with three weights - seven launches
+// of 5 us each through xvcgpu_metric_batch, a fifth of a CU state's time.
+// grid: ceil(n/4); block: 256 = 4 waves, one candidate per wave.
+__global__ void __launch_bounds__(256)
+eval_dist_kernel(PicView orig, PicView pred, PicView rec, int strength,
+                 const xvcgpu_eval_cand *cands, int n, uint64_t *out) {
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (c >= n) return;
+  const xvcgpu_eval_cand cd = cands[c];
+  const PlaneView pa = orig.c[cd.comp], pb = cd.versus ? rec.c[cd.comp] : pred.c[cd.comp];
+  const uint16_t *a = pa.p + (ptrdiff_t)cd.y * pa.stride + cd.x;
+  const uint16_t *b = pb.p + (ptrdiff_t)cd.y * pb.stride + cd.x;
+  const uint64_t dist = wave_compare(cd.metric, orig.bd, cd.qp, strength, cd.w, cd.h, a,
+                                     pa.stride, b, pb.stride);
+  if ((threadIdx.x & 63) == 0) out[c] = (uint64_t)((double)dist * cd.weight);
 }
 
 #endif  // XVCGPU_K_CU_STATE_H_

@@ -2323,7 +2323,7 @@ xvcgpu_status xvcgpu_cs_start_fold(xvcgpu_ctx *ctx, const xvcgpu_cs_pass *d_pass
   if (!ctx || n < 0 || first < 0 || (n && (!d_passes || !d_start_dist || !d_results)))
     return XVCGPU_INVALID_ARGUMENT;
   if (!n) return XVCGPU_OK;
-  hipLaunchKernelGGL(cs_start_fold_kernel, dim3((n + 63) / 64), dim3(64), 0, ctx->stream, d_passes,
+  hipLaunchKernelGGL(cs_start_fold_kernel, dim3(n), dim3(64), 0, ctx->stream, d_passes,
                      first, n, d_start_dist, d_me_jobs, d_me_res, d_aff_jobs, d_results, pic_w, pic_h);
   CHECK_LAUNCH(ctx, "cs_start_fold");
   return XVCGPU_OK;
@@ -2337,7 +2337,7 @@ xvcgpu_status xvcgpu_cs_uni_fold(xvcgpu_ctx *ctx, const xvcgpu_cs_pass *d_passes
                                  xvcgpu_affine_me_block *d_aff_jobs) {
   if (!ctx || n < 0 || (n && (!d_passes || !d_results))) return XVCGPU_INVALID_ARGUMENT;
   if (!n) return XVCGPU_OK;
-  hipLaunchKernelGGL(cs_uni_fold_kernel, dim3((n + 63) / 64), dim3(64), 0, ctx->stream, d_passes, first, n,
+  hipLaunchKernelGGL(cs_uni_fold_kernel, dim3(n), dim3(64), 0, ctx->stream, d_passes, first, n,
                      d_me_res, d_aff_res, d_results, d_bi_jobs, d_aff_jobs);
   CHECK_LAUNCH(ctx, "cs_uni_fold");
   return XVCGPU_OK;
@@ -2350,9 +2350,24 @@ xvcgpu_status xvcgpu_cs_bi_fold(xvcgpu_ctx *ctx, const xvcgpu_cs_pass *d_passes,
                                 xvcgpu_cs_result *d_results, xvcgpu_inter_block *d_ev_inter) {
   if (!ctx || n < 0 || (n && (!d_passes || !d_results))) return XVCGPU_INVALID_ARGUMENT;
   if (!n) return XVCGPU_OK;
-  hipLaunchKernelGGL(cs_bi_fold_kernel, dim3((n + 63) / 64), dim3(64), 0, ctx->stream, d_passes, first, n,
+  hipLaunchKernelGGL(cs_bi_fold_kernel, dim3(n), dim3(64), 0, ctx->stream, d_passes, first, n,
                      d_bi_res, d_aff_res, d_results, d_ev_inter);
   CHECK_LAUNCH(ctx, "cs_bi_fold");
+  return XVCGPU_OK;
+}
+
+xvcgpu_status xvcgpu_eval_dist_batch(xvcgpu_ctx *ctx, const xvcgpu_picture *orig,
+                                     const xvcgpu_picture *pred, const xvcgpu_picture *rec,
+                                     int structural_strength, const xvcgpu_eval_cand *d_cands,
+                                     int n, uint64_t *d_out) {
+  if (!ctx || !orig || !pred || !rec || n < 0 || (n && (!d_cands || !d_out)))
+    return XVCGPU_INVALID_ARGUMENT;
+  if (orig->bd != pred->bd || orig->bd != rec->bd)
+    return fail(ctx, XVCGPU_INVALID_ARGUMENT, "picture mismatch");
+  if (n == 0) return XVCGPU_OK;
+  hipLaunchKernelGGL(eval_dist_kernel, dim3((n + 3) / 4), dim3(256), 0, ctx->stream, orig->v,
+                     pred->v, rec->v, structural_strength, d_cands, n, d_out);
+  CHECK_LAUNCH(ctx, "eval_dist_batch");
   return XVCGPU_OK;
 }
 

@@ -303,6 +303,11 @@ extern "C" int xvc_host_cs_run_program(xvcgpu_ctx *ctx, const xvc_cs_env *env,
                                static_cast<const xvcgpu_affine_me_result *>(p[2]),
                                env->d_results, static_cast<xvcgpu_inter_block *>(p[3]));
         break;
+      case XVC_OP_EVAL_DIST:
+        st = xvcgpu_eval_dist_batch(ctx, env->s_orig, env->s_pred, env->s_rec, 16,
+                                    static_cast<const xvcgpu_eval_cand *>(p[0]), o.n,
+                                    static_cast<uint64_t *>(p[1]));
+        break;
       case XVC_OP_FETCH:
         st = xvcgpu_memcpy_d2h_async(ctx, p[1], p[0], static_cast<size_t>(o.n));
         stats->api_calls--;          // a copy, not a launch
