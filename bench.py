@@ -135,15 +135,28 @@ def stream_decode_figure(ctx, api):
         if not hasattr(f, "_levels"):   # out of the .npz once (every access inflates it again)
             f._levels = [np.ascontiguousarray(f.levels(i)) for i in range(f.n)]
             f._infos = [f.info[i] for i in range(f.n)]
+            pos = {int(f._infos[i]["poc"]): i for i in range(f.n)}
+            f._ref_index = np.full((f.n, 2, 5), -1, np.int32)
+            for i in range(f.n):
+                info = f._infos[i]
+                for l in range(2):
+                    for k in range(int(info["num_ref"][l])):
+                        f._ref_index[i, l, k] = pos[int(info["ref_poc"][l][k])]
+        if per_picture is None:
+            # the whole sequence in one call: the C++ layer plans picture i + 1 on a
+            # worker thread while picture i is uploaded and launched
+            dec.decode_sequence([(syn[i][0], syn[i][1], f._levels[i]) for i in range(f.n)],
+                                f._ref_index, pics)
+            ctx.sync()
+            return
         for i in range(f.n):
             info = f._infos[i]
             refs = [[done[int(info["ref_poc"][l][k])] for k in range(int(info["num_ref"][l]))]
                     for l in range(2)]
             t0 = time.perf_counter()
             dec.decode(syn[i][0], syn[i][1], f._levels[i], refs, pics[i])
-            if per_picture is not None:
-                ctx.sync()
-                per_picture[i] += time.perf_counter() - t0
+            ctx.sync()
+            per_picture[i] += time.perf_counter() - t0
             done[int(info["poc"])] = pics[i]
         ctx.sync()
 
@@ -172,7 +185,9 @@ def stream_decode_figure(ctx, api):
            "ms_by_picture_type": {k: {"pictures": len(v), "mean_ms": sum(v) / len(v),
                                       "pictures_per_s": 1e3 * len(v) / sum(v)}
                                   for k, v in kinds.items()},
-           "md5_match": bool(ok), "includes": "host planning + upload of the parsed syntax"}
+           "md5_match": bool(ok), "includes": "host planning + upload of the parsed syntax; the "
+                                              "planning of picture i + 1 on a worker thread while "
+                                              "picture i is issued (PictureDecoder::DecodeSequence)"}
     for p in dpics:
         p.destroy()
     # the short stream, decoded for the search replays

@@ -118,6 +118,13 @@ void xvcgpu_event_destroy(xvcgpu_event *ev);
 xvcgpu_status xvcgpu_event_record(xvcgpu_ctx *ctx, xvcgpu_event *ev);
 xvcgpu_status xvcgpu_event_wait(xvcgpu_ctx *ctx, xvcgpu_event *ev);
 xvcgpu_status xvcgpu_event_synchronize(xvcgpu_event *ev);
+/* An upload that does not queue behind the context's kernels: on the context's COPY
+ * stream (created on first use), after `after` (may be NULL: at once) - `done` is
+ * recorded behind it; xvcgpu_event_wait(ctx, done) makes later kernels see the bytes.
+ * The next picture's job lists go up while this picture's kernels run
+ * (xvc_gpu::PictureDecoder, two device staging buffers taking turns). */
+xvcgpu_status xvcgpu_upload_ahead(xvcgpu_ctx *ctx, void *d_dst, const void *h_src, size_t bytes,
+                                  xvcgpu_event *after, xvcgpu_event *done);
 xvcgpu_status xvcgpu_comm_unique_id(uint8_t id[XVCGPU_COMM_ID_BYTES]);
 xvcgpu_status xvcgpu_comm_create(xvcgpu_ctx *ctx, const uint8_t id[XVCGPU_COMM_ID_BYTES],
                                  int world, int rank, xvcgpu_comm **out);

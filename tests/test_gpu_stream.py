@@ -12,6 +12,7 @@ import numpy as np
 import pytest
 
 import stream_fixture as sf
+from xvc_amd import decoder
 
 pytestmark = pytest.mark.gpu
 
@@ -102,3 +103,41 @@ def test_gpu_stream_decode_rate(gpu):
     dt = time.time() - t0
     print("\n1080p stream: %d pictures in %.3f s (%.1f pictures/s incl. python marshalling); "
           "waves / launches per picture: %s" % (fx.n, dt, fx.n / dt, info))
+
+
+@pytest.mark.parametrize("name", ["tiny", "c1x"])
+def test_decode_sequence_equals_stream_md5(gpu, name):
+    """The whole stream through ONE call (PictureDecoder::DecodeSequence: the plan of
+    picture i + 1 made on a worker thread while picture i is uploaded and launched; in
+    inter pictures the trailing waves of intra CUs in one cooperative launch): every
+    picture's MD5 equals the stream's."""
+    api, ctx = gpu
+    fx = sf.StreamFixture(name)
+    w, h, bd = (int(fx.info[0][k]) for k in ("width", "height", "bitdepth"))
+    dec = decoder.PictureDecoder(ctx, w, h, bd)
+    infos = [fx.info[i] for i in range(fx.n)]
+    pos = {int(infos[i]["poc"]): i for i in range(fx.n)}
+    ref_index = np.full((fx.n, 2, 5), -1, np.int32)
+    pictures = []
+    for i, info in enumerate(infos):
+        ps, cs = sf.to_syntax(info, fx.cus(i))
+        pictures.append((ps, cs, np.ascontiguousarray(fx.levels(i))))
+        for l in range(2):
+            for k in range(int(info["num_ref"][l])):
+                ref_index[i, l, k] = pos[int(info["ref_poc"][l][k])]
+    recs = [ctx.picture(w, h, bd) for _ in range(fx.n)]
+    for _ in range(2):       # twice: the second run re-uses every buffer
+        dec.decode_sequence(pictures, ref_index, recs)
+        ctx.sync()
+        for i, info in enumerate(infos):
+            got = recs[i].download(0)
+            assert np.array_equal(sf.picture_md5(got, bd), info["md5"]), (name, i)
+    # a reference that is not decoded yet is refused
+    bad = ref_index.copy()
+    bad[1, 0, 0] = fx.n - 1
+    with pytest.raises(api.XvcGpuError):
+        dec.decode_sequence(pictures, bad, recs)
+    ctx.sync()
+    dec.destroy()
+    for p in recs:
+        p.destroy()

@@ -54,7 +54,7 @@ def build_host(force=False, verbose=False):
         if all(os.path.getmtime(f) <= m for f in dep):
             return HOST_OUT
     cmd = ["g++", "-std=c++11", "-O2", "-fPIC", "-shared", "-Wall", "-Wextra", "-I", inc,
-           "-I", host] + srcs + ["-o", HOST_OUT, "-L", HERE, "-lxvcgpu", "-Wl,-rpath,$ORIGIN"]
+           "-I", host] + srcs + ["-o", HOST_OUT, "-L", HERE, "-lxvcgpu", "-lpthread", "-Wl,-rpath,$ORIGIN"]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

@@ -190,6 +190,7 @@ xvcgpu_status xvcgpu_create(int device, xvcgpu_ctx **out) {
   ctx->device = device;
   ctx->stream = nullptr;
   ctx->hi_stream = nullptr;
+  ctx->copy_stream = nullptr;
   ctx->own_stream = false;
   ctx->d_tx_tables = nullptr;
   ctx->d_tx_tables_t = nullptr;
@@ -279,6 +280,7 @@ void xvcgpu_destroy(xvcgpu_ctx *ctx) {
   hipEventDestroy(ctx->ev0);
   hipEventDestroy(ctx->ev1);
   hipEventDestroy(ctx->ev_sync);
+  if (ctx->copy_stream) hipStreamDestroy(ctx->copy_stream);
   if (ctx->hi_stream) {
     hipStreamDestroy(ctx->hi_stream);
     hipEventDestroy(ctx->ev_hi_in);

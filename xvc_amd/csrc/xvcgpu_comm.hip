@@ -166,6 +166,20 @@ xvcgpu_status xvcgpu_event_wait(xvcgpu_ctx *ctx, xvcgpu_event *ev) {
   return XVCGPU_OK;
 }
 
+xvcgpu_status xvcgpu_upload_ahead(xvcgpu_ctx *ctx, void *d_dst, const void *h_src, size_t bytes,
+                                  xvcgpu_event *after, xvcgpu_event *done) {
+  if (!ctx || (!d_dst && bytes) || (!h_src && bytes) || !done) return XVCGPU_INVALID_ARGUMENT;
+  if (!ctx->copy_stream) {
+    CHIP_TRY(ctx, hipSetDevice(ctx->device));
+    CHIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+  }
+  if (after) CHIP_TRY(ctx, hipStreamWaitEvent(ctx->copy_stream, after->ev, 0));
+  if (bytes)
+    CHIP_TRY(ctx, hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, ctx->copy_stream));
+  CHIP_TRY(ctx, hipEventRecord(done->ev, ctx->copy_stream));
+  return XVCGPU_OK;
+}
+
 xvcgpu_status xvcgpu_event_synchronize(xvcgpu_event *ev) {
   if (!ev) return XVCGPU_INVALID_ARGUMENT;
   CHIP_TRY(ev->ctx, hipEventSynchronize(ev->ev));

@@ -46,6 +46,7 @@ def load_host_library():
     lib.xvc_host_picture_decoder_destroy.restype = None
     lib.xvc_host_picture_decoder_destroy.argtypes = [vp]
     lib.xvc_host_picture_decoder_decode.argtypes = [vp, vp, vp, vp, C.POINTER(vp), vp]
+    lib.xvc_host_picture_decoder_decode_sequence.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp]
     lib.xvc_host_picture_decoder_waves.argtypes = [vp]
     lib.xvc_host_picture_decoder_launches.argtypes = [vp]
     lib.xvc_host_picture_decoder_one_launch_intra.argtypes = [vp, C.c_int]
@@ -89,6 +90,24 @@ class PictureDecoder:
         lv = np.ascontiguousarray(levels if len(levels) else np.zeros(1, np.int16), np.int16)
         st = self.lib.xvc_host_picture_decoder_decode(
             self.h, ps.ctypes.data, cus.ctypes.data, lv.ctypes.data, refs, rec.h_pic)
+        self.ctx._check(st)
+
+    def decode_sequence(self, pictures, ref_index, recs):
+        """pictures: [(ps, cus, levels)] in decoding order; ref_index[i][list][k]: the
+        position in this sequence of picture i's reference (list, k), -1 = unused; recs:
+        [api.Picture] outputs.  The C++ layer plans picture i + 1 on a worker thread
+        while it uploads and launches picture i (xvc_gpu::PictureDecoder::DecodeSequence)."""
+        n = len(pictures)
+        keep = []
+        ps_p, cu_p, lv_p = (C.c_void_p * n)(), (C.c_void_p * n)(), (C.c_void_p * n)()
+        for i, (ps, cus, levels) in enumerate(pictures):
+            lv = np.ascontiguousarray(levels if len(levels) else np.zeros(1, np.int16), np.int16)
+            keep.append(lv)
+            ps_p[i], cu_p[i], lv_p[i] = ps.ctypes.data, cus.ctypes.data, lv.ctypes.data
+        ri = np.ascontiguousarray(ref_index, np.int32).reshape(n, 2, 5)
+        rp = (C.c_void_p * n)(*[r.h_pic for r in recs])
+        st = self.lib.xvc_host_picture_decoder_decode_sequence(self.h, n, ps_p, cu_p, lv_p,
+                                                               ri.ctypes.data, rp)
         self.ctx._check(st)
 
     @property

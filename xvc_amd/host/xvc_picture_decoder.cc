@@ -1,7 +1,14 @@
 // xvc_picture_decoder.cc -- see xvc_picture_decoder.h.
 #include "xvc_picture_decoder.h"
 
+#include <chrono>
+#include <condition_variable>
+#include <cstdio>
+#include <mutex>
+#include <thread>
+
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 
@@ -328,9 +335,17 @@ void PictureDecoder::Plan(const xvc_picture_syntax &ps, const xvc_cu_syntax *cus
 
 PictureDecoder::PictureDecoder(xvcgpu_ctx *ctx, int width, int height, int bitdepth)
     : ctx_(ctx), width_(width), height_(height), bitdepth_(bitdepth), pred_(nullptr),
-      d_staging_(nullptr), staging_cap_(0), last_waves_(0), last_launches_(0),
-      use_waves_kernel_(true), next_host_(0) {
+      last_waves_(0), last_launches_(0),
+      use_waves_kernel_(true), tail_min_waves_(6), next_host_(0) {
+  if (const char *e = std::getenv("XVC_DEC_TAIL_MIN_WAVES")) tail_min_waves_ = std::atoi(e);
   xvcgpu_picture_create(ctx_, width, height, bitdepth, &pred_);
+  for (int k = 0; k < 2; k++) {
+    d_staging_[k] = nullptr;
+    staging_cap_[k] = 0;
+    kernels_done_[k] = nullptr;
+    staging_used_[k] = false;
+  }
+  next_staging_ = 0;
   for (HostSlot &h : host_) {
     h.mem = nullptr;
     h.cap = 0;
@@ -345,18 +360,32 @@ PictureDecoder::~PictureDecoder() {
     if (h.copied) xvcgpu_event_destroy(h.copied);
     if (h.mem) xvcgpu_host_free(ctx_, h.mem);
   }
-  if (d_staging_) xvcgpu_free(ctx_, d_staging_);
+  xvcgpu_sync(ctx_);
+  for (int k = 0; k < 2; k++) {
+    if (d_staging_[k]) xvcgpu_free(ctx_, d_staging_[k]);
+    if (kernels_done_[k]) xvcgpu_event_destroy(kernels_done_[k]);
+  }
   if (pred_) xvcgpu_picture_destroy(pred_);
 }
 
-xvcgpu_status PictureDecoder::EnsureStaging(size_t bytes) {
-  if (bytes <= staging_cap_) return XVCGPU_OK;
-  if (d_staging_) xvcgpu_free(ctx_, d_staging_);
-  d_staging_ = nullptr;
-  staging_cap_ = 0;
+xvcgpu_status PictureDecoder::EnsureStaging(int k, size_t bytes) {
+  xvcgpu_status st = XVCGPU_OK;
+  if (!kernels_done_[k]) {
+    st = xvcgpu_event_create(ctx_, &kernels_done_[k]);
+    if (st != XVCGPU_OK) return st;
+  }
+  if (bytes <= staging_cap_[k]) return XVCGPU_OK;
+  if (d_staging_[k]) {
+    // (kernels of the picture two back may still read it)
+    if (staging_used_[k]) xvcgpu_event_synchronize(kernels_done_[k]);
+    xvcgpu_free(ctx_, d_staging_[k]);
+  }
+  d_staging_[k] = nullptr;
+  staging_cap_[k] = 0;
+  staging_used_[k] = false;
   const size_t cap = bytes + bytes / 4;
-  xvcgpu_status st = xvcgpu_malloc(ctx_, cap, &d_staging_);
-  if (st == XVCGPU_OK) staging_cap_ = cap;
+  st = xvcgpu_malloc(ctx_, cap, &d_staging_[k]);
+  if (st == XVCGPU_OK) staging_cap_[k] = cap;
   return st;
 }
 
@@ -395,8 +424,13 @@ xvcgpu_status PictureDecoder::Decode(const xvc_picture_syntax &ps, const xvc_cu_
     return XVCGPU_INVALID_ARGUMENT;
   if (!Validate(ps, cus, levels)) return XVCGPU_INVALID_ARGUMENT;
   Plan(ps, cus, levels, &plan_);
-  const PicturePlan &p = plan_;
+  return Issue(plan_, ps, levels, ref_pics, rec);
+}
 
+xvcgpu_status PictureDecoder::Issue(const PicturePlan &p, const xvc_picture_syntax &ps,
+                                    const int16_t *levels,
+                                    const xvcgpu_picture *const ref_pics[2][5],
+                                    xvcgpu_picture *rec) {
   // one packed upload: job lists, cell maps, CU records, levels
   struct Piece {
     const void *src;
@@ -406,6 +440,17 @@ xvcgpu_status PictureDecoder::Decode(const xvc_picture_syntax &ps, const xvc_cu_
   // transform job k are the same block): all waves in one cooperative launch
   const bool one_launch = use_waves_kernel_ && p.inter.empty() && !p.intra.empty() &&
                           p.intra_first == p.tx_first;
+  // an inter picture with intra CUs: from wave t0 on every job is an intra job (the
+  // waves behind the inter CUs: intra CUs reading their neighbours' reconstruction) -
+  // that tail goes into ONE cooperative launch too, instead of three launches per
+  // wave (B pictures of the 1080p stream: 27-33 launches)
+  int t0 = p.n_waves;
+  while (t0 > 0 && p.inter_first[t0 - 1] == p.inter_first[p.n_waves]) t0--;
+  const bool tail_launch = use_waves_kernel_ && !one_launch && t0 > 0 &&
+                           p.n_waves - t0 >= tail_min_waves_;
+  std::vector<int32_t> tail_first;
+  if (tail_launch)
+    for (int w = t0; w <= p.n_waves; w++) tail_first.push_back(p.intra_first[w] - p.intra_first[t0]);
   Piece pc[10] = {
       {p.inter.data(), p.inter.size() * sizeof(xvcgpu_inter_block), 0},
       {p.intra.data(), p.intra.size() * sizeof(xvcgpu_intra_block), 0},
@@ -416,7 +461,8 @@ xvcgpu_status PictureDecoder::Decode(const xvc_picture_syntax &ps, const xvc_cu_
       {p.cell[0].data(), p.cell[0].size() * sizeof(int32_t), 0},
       {p.cell[1].data(), p.cell[1].size() * sizeof(int32_t), 0},
       {levels, static_cast<size_t>(ps.n_levels > 0 ? ps.n_levels : 1) * sizeof(int16_t), 0},
-      {p.intra_first.data(), one_launch ? p.intra_first.size() * sizeof(int32_t) : 0, 0}};
+      {one_launch ? p.intra_first.data() : tail_first.data(),
+       one_launch ? p.intra_first.size() * sizeof(int32_t) : tail_first.size() * sizeof(int32_t), 0}};
   static const int16_t kNoLevels[1] = {0};
   if (ps.n_levels <= 0) pc[8].src = kNoLevels;
   size_t total = 0;
@@ -424,20 +470,24 @@ xvcgpu_status PictureDecoder::Decode(const xvc_picture_syntax &ps, const xvc_cu_
     q.off = total;
     total += (q.bytes + 255) & ~static_cast<size_t>(255);
   }
-  xvcgpu_status st = EnsureStaging(total);
+  const int sk = next_staging_;
+  next_staging_ ^= 1;
+  xvcgpu_status st = EnsureStaging(sk, total);
   if (st != XVCGPU_OK) return st;
   HostSlot *slot = nullptr;
   st = AcquireHostSlot(total, &slot);
   if (st != XVCGPU_OK) return st;
   for (const Piece &q : pc)
     if (q.bytes) std::memcpy(static_cast<uint8_t *>(slot->mem) + q.off, q.src, q.bytes);
-  // queued behind the previous picture's kernels (they read the device buffer)
-  st = xvcgpu_memcpy_h2d_async(ctx_, d_staging_, slot->mem, total);
-  if (st != XVCGPU_OK) return st;
-  st = xvcgpu_event_record(ctx_, slot->copied);
+  // on the copy stream, behind the kernels of the picture two back (they read this
+  // device buffer) - beside, not behind, the previous picture's kernels
+  st = xvcgpu_upload_ahead(ctx_, d_staging_[sk], slot->mem, total,
+                           staging_used_[sk] ? kernels_done_[sk] : nullptr, slot->copied);
   if (st != XVCGPU_OK) return st;
   slot->in_flight = true;
-  uint8_t *base = static_cast<uint8_t *>(d_staging_);
+  st = xvcgpu_event_wait(ctx_, slot->copied);   // this picture's kernels: after its upload
+  if (st != XVCGPU_OK) return st;
+  uint8_t *base = static_cast<uint8_t *>(d_staging_[sk]);
   const xvcgpu_inter_block *d_inter = reinterpret_cast<const xvcgpu_inter_block *>(base + pc[0].off);
   const xvcgpu_intra_block *d_intra = reinterpret_cast<const xvcgpu_intra_block *>(base + pc[1].off);
   const xvcgpu_tx_block *d_tx = reinterpret_cast<const xvcgpu_tx_block *>(base + pc[2].off);
@@ -469,7 +519,9 @@ xvcgpu_status PictureDecoder::Decode(const xvc_picture_syntax &ps, const xvc_cu_
       return st;
     }
   }
-  for (int w = 0; w < p.n_waves && !waves_done; w++) {
+  int n_sep = p.n_waves;   // waves issued as separate launches
+  if (tail_launch) n_sep = t0;
+  for (int w = 0; w < n_sep && !waves_done; w++) {
     const int i0 = p.inter_first[w], i1 = p.inter_first[w + 1];
     if (i1 > i0) {
       st = xvcgpu_inter_pred_batch(ctx_, refs, p.n_ref_slots, rec, pred_, d_inter + i0, i1 - i0);
@@ -488,6 +540,30 @@ xvcgpu_status PictureDecoder::Decode(const xvc_picture_syntax &ps, const xvc_cu_
                                       d_nnz + t0);
       if (st != XVCGPU_OK) return st;
       launches += 2;
+    }
+  }
+  if (tail_launch) {
+    // (in these waves job k of the intra list and job tx_first[t0] + k of the
+    // transform list are the same block: every unit is an intra unit)
+    const int32_t *d_first = reinterpret_cast<const int32_t *>(base + pc[9].off);
+    const int a = p.intra_first[t0], t = p.tx_first[t0];
+    st = xvcgpu_intra_recon_waves(ctx_, rec, pred_, d_intra + a, d_tx + t, d_first,
+                                  p.n_waves - t0, d_levels, d_off + t, d_nnz + t);
+    if (st == XVCGPU_OK) {
+      launches++;
+    } else if (st == XVCGPU_UNSUPPORTED) {
+      for (int w = t0; w < p.n_waves; w++) {
+        const int a0 = p.intra_first[w], a1 = p.intra_first[w + 1];
+        const int t0w = p.tx_first[w], t1w = p.tx_first[w + 1];
+        st = xvcgpu_intra_pred_batch(ctx_, rec, pred_, d_intra + a0, a1 - a0);
+        if (st != XVCGPU_OK) return st;
+        st = xvcgpu_inv_transform_batch(ctx_, pred_, rec, d_tx + t0w, t1w - t0w, d_levels,
+                                        d_off + t0w, d_nnz + t0w);
+        if (st != XVCGPU_OK) return st;
+        launches += 3;
+      }
+    } else {
+      return st;
     }
   }
   if (ps.deblock) {
@@ -512,9 +588,110 @@ xvcgpu_status PictureDecoder::Decode(const xvc_picture_syntax &ps, const xvc_cu_
     if (st != XVCGPU_OK) return st;
     launches++;
   }
+  st = xvcgpu_event_record(ctx_, kernels_done_[sk]);
+  if (st != XVCGPU_OK) return st;
+  staging_used_[sk] = true;
   last_waves_ = p.n_waves;
   last_launches_ = launches;
   return XVCGPU_OK;
+}
+
+// The pictures of a sequence, planning one ahead of issuing: while this thread uploads
+// and launches picture i, a worker validates and plans picture i + 1 (pure host work,
+// 0.1 ms per 1080p B picture - as long as the device takes for the picture).
+xvcgpu_status PictureDecoder::DecodeSequence(int n, const xvc_picture_syntax *const *ps,
+                                             const xvc_cu_syntax *const *cus,
+                                             const int16_t *const *levels,
+                                             const int32_t *ref_index,
+                                             xvcgpu_picture *const *recs) {
+  if (n < 0 || (n && (!ps || !cus || !levels || !ref_index || !recs)))
+    return XVCGPU_INVALID_ARGUMENT;
+  if (!n) return XVCGPU_OK;
+  // kWorkers planners, each taking every kWorkers-th picture, kRing plan slots: a plan
+  // costs about as much host time as a B picture takes on the device, and more when
+  // its thread shares the memory system with the issuing thread - several in flight
+  // keep the issuing thread from waiting
+  enum { kWorkers = 4, kRing = 8 };
+  if (seq_plans_.size() != kRing) seq_plans_.resize(kRing);
+  std::vector<PicturePlan> &plans = seq_plans_;
+  bool valid[kRing] = {};
+  bool ready[kRing] = {};
+  auto prepare = [&](int i) {
+    const xvc_picture_syntax &s = *ps[i];
+    const int k = i % kRing;
+    valid[k] = cus[i] && s.width == width_ && s.height == height_ &&
+               s.bitdepth == bitdepth_ && s.n_cus > 0 && (s.n_levels <= 0 || levels[i]) &&
+               Validate(s, cus[i], levels[i]);
+    if (valid[k]) Plan(s, cus[i], levels[i], &plans[k]);
+  };
+  // slot i % kRing may be written once picture i - kRing (its previous user) has been
+  // issued; picture i is issued once its plan is there
+  std::mutex mu;
+  std::condition_variable cv;
+  int issued = 0;
+  bool stop = false;
+  std::vector<std::thread> workers;
+  for (int wk = 0; wk < kWorkers && wk < n; wk++)
+    workers.emplace_back([&, wk]() {
+      for (int i = wk; i < n; i += kWorkers) {
+        {
+          std::unique_lock<std::mutex> lk(mu);
+          cv.wait(lk, [&]() { return stop || issued > i - kRing; });
+          if (stop) return;
+        }
+        prepare(i);
+        {
+          std::lock_guard<std::mutex> lk(mu);
+          ready[i % kRing] = true;
+        }
+        cv.notify_all();
+      }
+    });
+  xvcgpu_status st = XVCGPU_OK;
+  const bool trace = std::getenv("XVC_DEC_TRACE") != nullptr;
+  double t_wait = 0, t_issue = 0;
+  auto now = []() {
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+  };
+  for (int i = 0; i < n && st == XVCGPU_OK; i++) {
+    const double ta = now();
+    {
+      std::unique_lock<std::mutex> lk(mu);
+      cv.wait(lk, [&]() { return ready[i % kRing]; });
+      ready[i % kRing] = false;
+    }
+    const double tb = now();
+    t_wait += tb - ta;
+    if (!valid[i % kRing] || !recs[i]) {
+      st = XVCGPU_INVALID_ARGUMENT;
+    } else {
+      const xvcgpu_picture *refs[2][5];
+      for (int l = 0; l < 2 && st == XVCGPU_OK; l++)
+        for (int k = 0; k < 5; k++) {
+          const int j = ref_index[(i * 2 + l) * 5 + k];
+          if (j >= i) st = XVCGPU_INVALID_ARGUMENT;   // only pictures decoded before this one
+          refs[l][k] = j >= 0 && j < i ? recs[j] : nullptr;
+        }
+      if (st == XVCGPU_OK) st = Issue(plans[i % kRing], *ps[i], levels[i], refs, recs[i]);
+    }
+    t_issue += now() - tb;
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      issued = i + 1;
+      if (st != XVCGPU_OK) stop = true;
+    }
+    cv.notify_all();
+  }
+  {
+    std::lock_guard<std::mutex> lk(mu);
+    stop = stop || st != XVCGPU_OK;
+  }
+  cv.notify_all();
+  for (std::thread &w : workers) w.join();
+  if (trace)
+    std::fprintf(stderr, "DecodeSequence: %d pictures, waiting for plans %.3f ms, issuing %.3f ms\n",
+                 n, 1e3 * t_wait, 1e3 * t_issue);
+  return st;
 }
 
 }  // namespace xvc_gpu
@@ -542,6 +719,16 @@ int xvc_host_picture_decoder_decode(xvc_host_picture_decoder *d, const xvc_pictu
   for (int l = 0; l < 2; l++)
     for (int k = 0; k < 5; k++) refs[l][k] = ref_pics ? ref_pics[l * 5 + k] : nullptr;
   return d->dec.Decode(*ps, cus, levels, refs, rec);
+}
+
+int xvc_host_picture_decoder_decode_sequence(xvc_host_picture_decoder *d, int n,
+                                             const xvc_picture_syntax *const *ps,
+                                             const xvc_cu_syntax *const *cus,
+                                             const int16_t *const *levels,
+                                             const int32_t *ref_index,
+                                             xvcgpu_picture *const *recs) {
+  if (!d) return XVCGPU_INVALID_ARGUMENT;
+  return d->dec.DecodeSequence(n, ps, cus, levels, ref_index, recs);
 }
 
 void xvc_host_picture_decoder_one_launch_intra(xvc_host_picture_decoder *d, int on) {

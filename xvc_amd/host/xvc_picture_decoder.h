@@ -94,6 +94,16 @@ class PictureDecoder {
                        const int16_t *levels, const xvcgpu_picture *const ref_pics[2][5],
                        xvcgpu_picture *rec);
 
+  // The same with the planning done: Decode = Validate + Plan + Issue.
+  xvcgpu_status Issue(const PicturePlan &plan, const xvc_picture_syntax &ps, const int16_t *levels,
+                      const xvcgpu_picture *const ref_pics[2][5], xvcgpu_picture *rec);
+  // n pictures in decoding order; ref_index[(i * 2 + list) * 5 + k] = the position in
+  // this sequence of picture i's reference (list, k), -1 = unused.  Planning of
+  // picture i + 1 runs on a worker thread while picture i is uploaded and launched.
+  xvcgpu_status DecodeSequence(int n, const xvc_picture_syntax *const *ps,
+                               const xvc_cu_syntax *const *cus, const int16_t *const *levels,
+                               const int32_t *ref_index, xvcgpu_picture *const *recs);
+
   int last_num_waves() const { return last_waves_; }
   int last_num_launches() const { return last_launches_; }
   // Intra pictures: all dependency waves in one cooperative launch
@@ -101,7 +111,7 @@ class PictureDecoder {
   void set_one_launch_intra(bool on) { use_waves_kernel_ = on; }
 
  private:
-  xvcgpu_status EnsureStaging(size_t bytes);
+  xvcgpu_status EnsureStaging(int k, size_t bytes);
   // The picture's job lists, maps and levels go up in ONE queued copy from a
   // page-locked buffer; two buffers take turns so that Decode() of the next
   // picture can fill one while the copy of the previous is still in flight.
@@ -115,12 +125,19 @@ class PictureDecoder {
   xvcgpu_ctx *ctx_;
   int width_, height_, bitdepth_;
   xvcgpu_picture *pred_;   // the prediction of the wave in flight (CuDecoder::temp_pred_)
-  void *d_staging_;
-  size_t staging_cap_;
+  // device staging: two buffers take turns, the upload of picture i + 1 runs on the
+  // context's copy stream while the kernels of picture i read the other one
+  void *d_staging_[2];
+  size_t staging_cap_[2];
+  xvcgpu_event *kernels_done_[2];   // behind the last kernel that read d_staging_[k]
+  bool staging_used_[2];
+  int next_staging_;
 
   PicturePlan plan_;
+  std::vector<PicturePlan> seq_plans_;   // DecodeSequence's ring (buffers kept between calls)
   int last_waves_, last_launches_;
   bool use_waves_kernel_;
+  int tail_min_waves_;     // inter pictures: trailing all-intra waves in one launch from this many
   HostSlot host_[2];
   int next_host_;
 };
@@ -138,6 +155,12 @@ int xvc_host_picture_decoder_decode(xvc_host_picture_decoder *d, const xvc_pictu
                                     const xvc_cu_syntax *cus, const int16_t *levels,
                                     const xvcgpu_picture *const *ref_pics /* [2][5] */,
                                     xvcgpu_picture *rec);
+int xvc_host_picture_decoder_decode_sequence(xvc_host_picture_decoder *d, int n,
+                                             const xvc_picture_syntax *const *ps,
+                                             const xvc_cu_syntax *const *cus,
+                                             const int16_t *const *levels,
+                                             const int32_t *ref_index,
+                                             xvcgpu_picture *const *recs);
 int xvc_host_picture_decoder_waves(const xvc_host_picture_decoder *d);
 int xvc_host_picture_decoder_launches(const xvc_host_picture_decoder *d);
 void xvc_host_picture_decoder_one_launch_intra(xvc_host_picture_decoder *d, int on);
