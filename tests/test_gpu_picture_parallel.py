@@ -44,12 +44,10 @@ def test_gpu_engine_matches_oracle_engine(gpu, slots, rdoq):
     # keep every picture: download right after its entry was written (the ring
     # is smaller than the sequence when several sub-GOPs are in flight)
     got = {}
-    enc = e.encode
 
-    def encode_and_keep(p, index, refs):
-        enc(p, index, refs)
-        got[int(p["poc"])] = e.download(index)
-    e.encode = encode_and_keep
+    def keep(index):
+        got[int(s.pictures[index]["poc"])] = e.download(index)
+    e.after_encode = keep
     picture_parallel.run_rank(s, 0, e)
     assert len(got) == tpp.N_PICTURES
     for poc, planes in got.items():

@@ -139,23 +139,26 @@ def test_picture_parallel_gloo(world, slots, tmp_path):
 
 
 def test_ring_entry_reuse_waits_for_its_writer_and_readers():
-    """GpuPictureEngine._claim: before a ring entry is overwritten the new writer
-    waits for the picture that wrote its previous content - a picture nobody
-    referenced has no reader events, and its slot's stream may still be at work on
-    the entry - and for every reader of it (the ordering rules only; no device)."""
-    e = object.__new__(picture_parallel.GpuPictureEngine)
-    e.ring = 3
-    e.readers = [[] for _ in range(3)]
-    e.holds = [-1] * 3
-    e.ready = ["ready0", "ready1", "ready2"]
-    waited = []
-    assert e._claim(0, waited.append) == 0 and waited == [] and e.holds[0] == 0
+    """The picture engine's ring rule (xvc_amd/host/xvc_picture_engine.cc, ClaimEntry):
+    before a ring entry is overwritten the new writer waits for the picture that wrote
+    its previous content - a picture nobody referenced has no reader events, and its
+    slot's stream may still be at work on the entry - and for every reader of it (the
+    ordering rule only; no device)."""
+    import ctypes as C
+    L = schedule.lib()
+    idx = np.array([0, 3, 6, 1], np.int32)
+    # before the third claim entry 0 has two readers (ids 7 and 9)
+    rd = np.zeros((4, 4), np.int32)
+    rd[2, :2] = (7, 9)
+    ent = np.zeros(4, np.int32)
+    waited = np.zeros((4, 8), np.int32)
+    L.xvc_host_picture_ring_claims.argtypes = [C.c_int, C.c_int] + [C.c_void_p] * 4
+    assert L.xvc_host_picture_ring_claims(3, 4, idx.ctypes.data, rd.ctypes.data, ent.ctypes.data,
+                                          waited.ctypes.data) == 0
+    assert ent.tolist() == [0, 0, 0, 1]
+    assert waited[0].tolist() == [0] * 8                       # a fresh entry: nothing to wait for
     # picture 3 reuses entry 0, which nobody read: it still waits for picture 0 itself
-    assert e._claim(3, waited.append) == 0 and waited == ["ready0"] and e.holds[0] == 3
+    assert waited[1].tolist() == [100] + [0] * 7
     # with readers: the writer first, then each of them; the list is cleared
-    e.readers[0] = ["reader_a", "send_b"]
-    waited.clear()
-    assert e._claim(6, waited.append) == 0
-    assert waited == ["ready0", "reader_a", "send_b"] and e.readers[0] == []
-    # another entry is untouched
-    assert e.holds[1] == -1 and e._claim(1, waited.append) == 1 and len(waited) == 3
+    assert waited[2].tolist() == [100, 7, 9] + [0] * 5
+    assert waited[3].tolist() == [0] * 8                       # another entry is untouched

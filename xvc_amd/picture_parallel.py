@@ -18,8 +18,10 @@ of its consumers).  Before an entry is overwritten the writer waits for
 the picture that wrote its previous content and for everything that read it (the
 events of the pictures that listed it, the sends that shipped it).
 
-The engines used by tests/ (CPU oracle + torch.distributed gloo) implement the
-same three methods as GpuPictureEngine: encode, send, recv."""
+The device engine is C++ (xvc_amd/host/xvc_picture_engine.cc; GpuPictureEngine below is
+its binding).  The engines used by tests/ (CPU oracle + torch.distributed gloo) implement
+encode, send, recv in Python and are driven by the same C++ timeline walk
+(xvc_schedule_run) through run_rank."""
 import numpy as np
 
 from . import api, pipeline
@@ -33,6 +35,8 @@ def run_rank(schedule, rank, engine, first_op=0, end_op=-1):
     """Walks the timeline (or entries [first_op, end_op) of it) as `rank`.
     engine.encode(p, index, ref_indices), engine.send(p, index, dst),
     engine.recv(p, index, src)."""
+    if hasattr(engine, "eng"):          # the C++ engine walks the timeline itself
+        return engine.run(first_op, end_op)
     P = schedule.pictures
     idx = schedule.index_of_poc
 
@@ -52,12 +56,19 @@ def run_rank(schedule, rank, engine, first_op=0, end_op=-1):
 
 
 class GpuPictureEngine:
-    """The device side of one rank: `slots` contexts (streams) each with a
-    FramePass, a ring of reconstructed pictures, the synthetic originals, and -
-    when there is more than one rank - the RCCL communicator."""
+    """Binding of the C++ picture engine (xvc_amd/host/xvc_picture_engine.{h,cc}): this
+    class allocates what a rank needs - `slots` contexts (streams) each with a
+    FramePass's buffers, a ring of reconstructed pictures, the synthetic originals, the
+    RCCL communicator when there is more than one rank - and hands it over; the walk
+    (ring entries, events, frame passes, transfers) is C++.
+
+    after_encode(picture_index): optional hook called once a picture's encode has been
+    enqueued (tests download the ring entry before it is re-used)."""
 
     def __init__(self, ctx, schedule, rank, width, height, bitdepth, qp, origs, comm=None,
                  rdoq=True, border=128):
+        import ctypes as C
+        from . import schedule as sched_mod
         self.ctx, self.s, self.rank, self.comm = ctx, schedule, rank, comm
         self.w, self.h, self.bd = width, height, bitdepth
         self.ring = ring_size(schedule)
@@ -67,16 +78,47 @@ class GpuPictureEngine:
                     for c in self.ctxs]
         self.origs = origs                       # padded device pictures, cycled by POC
         self.recs = [ctx.picture(width, height, bitdepth) for _ in range(self.ring)]
-        self.ready = [api.Event(ctx) for _ in range(self.ring)]
-        self.readers = [[] for _ in range(self.ring)]   # events to wait for before overwriting
-        self.holds = [-1] * self.ring
-        self._pool, self._pool_i = [api.Event(ctx) for _ in range(4 * self.ring)], 0
-        self.encoded = 0
+        self.after_encode = None
+        self._err = []
+        L = self.L = sched_mod.lib()
 
-    def _event(self):
-        e = self._pool[self._pool_i % len(self._pool)]
-        self._pool_i += 1
-        return e
+        class Desc(C.Structure):
+            _fields_ = [("schedule", C.c_void_p), ("rank", C.c_int32), ("n_slots", C.c_int32),
+                        ("ctxs", C.c_void_p), ("slot_args", C.c_void_p), ("comm", C.c_void_p),
+                        ("orig_of_picture", C.c_void_p), ("ring", C.c_int32),
+                        ("recs", C.c_void_p), ("after_encode", C.c_void_p), ("user", C.c_void_p)]
+        self._cb_type = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int)
+
+        def hook(_, index):
+            try:
+                if self.after_encode is not None:
+                    self.after_encode(index)
+                return 0
+            except BaseException as ex:  # noqa: BLE001 (must not cross the C frame)
+                self._err.append(ex)
+                return 1
+        self._hook = self._cb_type(hook)
+        n = len(schedule.pictures)
+        self._keep = [
+            (C.c_void_p * self.slots)(*[c.h for c in self.ctxs]),
+            [fp._args() for fp in self.fps],
+            (C.c_void_p * n)(*[self._orig(int(p["poc"])).h_pic for p in schedule.pictures]),
+            (C.c_void_p * self.ring)(*[r.h_pic for r in self.recs])]
+        args = (C.c_void_p * self.slots)(*[C.addressof(a) for a in self._keep[1]])
+        self._keep.append(args)
+        d = Desc(schedule.h, rank, self.slots, C.addressof(self._keep[0]), C.addressof(args),
+                 comm.h if comm is not None else None, C.addressof(self._keep[2]), self.ring,
+                 C.addressof(self._keep[3]), C.cast(self._hook, C.c_void_p), None)
+        L.xvc_host_picture_engine_create.restype = C.c_void_p
+        L.xvc_host_picture_engine_create.argtypes = [C.c_void_p]
+        L.xvc_host_picture_engine_run.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.xvc_host_picture_engine_destroy.argtypes = [C.c_void_p]
+        L.xvc_host_picture_engine_destroy.restype = None
+        L.xvc_host_picture_engine_holds.argtypes = [C.c_void_p, C.c_int]
+        L.xvc_host_picture_engine_encoded.argtypes = [C.c_void_p]
+        self.eng = L.xvc_host_picture_engine_create(C.byref(d))
+        if not self.eng:
+            raise api.XvcGpuError("xvc_host_picture_engine_create failed")
 
     def _orig(self, poc):
         F = len(self.origs)
@@ -85,52 +127,23 @@ class GpuPictureEngine:
         k = poc % (2 * F - 2)
         return self.origs[k if k < F else 2 * F - 2 - k]
 
-    def _claim(self, index, wait):
-        """Entry of picture `index`, safe to overwrite once `wait(ev)` has been
-        applied to every reader of what it held."""
-        e = index % self.ring
-        if self.holds[e] >= 0:
-            # ... and for whoever wrote it: a picture nobody referenced has no readers,
-            # and its slot may still be at work on the entry
-            wait(self.ready[e])
-        for ev in self.readers[e]:
-            wait(ev)
-        self.readers[e] = []
-        self.holds[e] = index
-        return e
+    @property
+    def holds(self):
+        """Picture index held by every ring entry (-1: none)."""
+        return [self.L.xvc_host_picture_engine_holds(self.eng, e) for e in range(self.ring)]
 
-    def encode(self, p, index, ref_indices):
-        c, fp = self.ctxs[int(p["slot"])], self.fps[int(p["slot"])]
-        e = self._claim(index, lambda ev: ev.wait(c))
-        if p["intra"]:
-            # stands in for the intra picture of the segment: the padded original
-            c._check(c.lib.xvcgpu_picture_copy(c.h, self.recs[e].h_pic,
-                                               self._orig(int(p["poc"])).h_pic))
-        else:
-            for j in ref_indices:
-                assert self.holds[j % self.ring] == j, (index, j)
-                self.ready[j % self.ring].wait(c)
-            r = ref_indices[0] % self.ring      # nearest L0 picture: the frame pass's reference
-            fp.run(self._orig(int(p["poc"])), self.recs[r], self.recs[e],
-                   ref_poc=int(self.s.pictures[ref_indices[0]]["poc"]))
-        self.ready[e].record(c)
-        for j in ref_indices:
-            self.readers[j % self.ring].append(self.ready[e])
-        self.encoded += 1
+    @property
+    def encoded(self):
+        return self.L.xvc_host_picture_engine_encoded(self.eng)
 
-    def send(self, p, index, dst):
-        e = index % self.ring
-        assert self.holds[e] == index
-        self.comm.wait_event(self.ready[e])
-        self.comm.send_picture(self.recs[e], dst)
-        ev = self._event()
-        self.comm.record_event(ev)
-        self.readers[e].append(ev)
-
-    def recv(self, p, index, src):
-        e = self._claim(index, self.comm.wait_event)
-        self.comm.recv_picture(self.recs[e], src)
-        self.comm.record_event(self.ready[e])
+    def run(self, first_op=0, end_op=-1):
+        """Timeline entries [first_op, end_op) as this rank (asynchronous on the slots'
+        and the communicator's streams)."""
+        st = self.L.xvc_host_picture_engine_run(self.eng, first_op, end_op)
+        if self._err:
+            raise self._err.pop(0)
+        if st:
+            raise api.XvcGpuError("xvc_host_picture_engine_run: %d" % st)
 
     def sync(self):
         for c in self.ctxs:
@@ -140,6 +153,11 @@ class GpuPictureEngine:
 
     def download(self, index, border=128):
         e = index % self.ring
-        assert self.holds[e] == index
+        assert self.L.xvc_host_picture_engine_holds(self.eng, e) == index
         self.sync()
         return self.recs[e].download(border)
+
+    def __del__(self):
+        if getattr(self, "eng", None):
+            self.L.xvc_host_picture_engine_destroy(self.eng)
+            self.eng = None
