@@ -87,6 +87,14 @@ struct xvc_picture_engine {
   }
   int Send(int index, int dst) {
     const int e = index % d.ring;
+    if (!d.comm && d.host_send && holds[e] == index) {
+      Ok(xvcgpu_event_wait(d.ctxs[0], ready[e]));
+      if (err == XVCGPU_OK && d.host_send(d.user, e, dst)) return XVCGPU_DEVICE_ERROR;
+      xvcgpu_event *ev = pool[pool_next++ % pool.size()];
+      Ok(xvcgpu_event_record(d.ctxs[0], ev));
+      readers[e].push_back(ev);
+      return err;
+    }
     if (!d.comm || holds[e] != index) return XVCGPU_INVALID_ARGUMENT;
     Ok(xvcgpu_comm_wait_event(d.comm, ready[e]));
     Ok(xvcgpu_comm_send_picture(d.comm, d.recs[e], dst));
@@ -96,6 +104,12 @@ struct xvc_picture_engine {
     return err;
   }
   int Recv(int index, int src) {
+    if (!d.comm && d.host_recv) {
+      const int e = Claim(index, [&](xvcgpu_event *ev) { Ok(xvcgpu_event_wait(d.ctxs[0], ev)); });
+      if (err == XVCGPU_OK && d.host_recv(d.user, e, src)) return XVCGPU_DEVICE_ERROR;
+      Ok(xvcgpu_event_record(d.ctxs[0], ready[e]));
+      return err;
+    }
     if (!d.comm) return XVCGPU_INVALID_ARGUMENT;
     const int e = Claim(index, [&](xvcgpu_event *ev) { Ok(xvcgpu_comm_wait_event(d.comm, ev)); });
     Ok(xvcgpu_comm_recv_picture(d.comm, d.recs[e], src));

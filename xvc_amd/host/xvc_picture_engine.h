@@ -39,6 +39,11 @@ typedef struct xvc_picture_engine_desc {
   // optional: called after the encode of a picture has been enqueued (tests read the
   // ring entry back before it is overwritten)
   int (*after_encode)(void *user, int picture_index);
+  // optional, used when comm == NULL on more than one rank: a host transport for tests
+  // that put several ranks on one GPU (RCCL refuses that) - the picture of ring entry
+  // `entry` shipped / received by the caller, ordered on ctxs[0]'s stream
+  int (*host_send)(void *user, int entry, int dst_rank);
+  int (*host_recv)(void *user, int entry, int src_rank);
   void *user;
 } xvc_picture_engine_desc;
 

@@ -86,7 +86,8 @@ class GpuPictureEngine:
             _fields_ = [("schedule", C.c_void_p), ("rank", C.c_int32), ("n_slots", C.c_int32),
                         ("ctxs", C.c_void_p), ("slot_args", C.c_void_p), ("comm", C.c_void_p),
                         ("orig_of_picture", C.c_void_p), ("ring", C.c_int32),
-                        ("recs", C.c_void_p), ("after_encode", C.c_void_p), ("user", C.c_void_p)]
+                        ("recs", C.c_void_p), ("after_encode", C.c_void_p),
+                        ("host_send", C.c_void_p), ("host_recv", C.c_void_p), ("user", C.c_void_p)]
         self._cb_type = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int)
 
         def hook(_, index):
@@ -98,6 +99,21 @@ class GpuPictureEngine:
                 self._err.append(ex)
                 return 1
         self._hook = self._cb_type(hook)
+        # a communicator without a native handle: a host transport (testing aid)
+        native = getattr(comm, "h", None) is not None
+        xfer_type = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int)
+
+        def xfer(fn):
+            def call(_, entry, peer):
+                try:
+                    fn(self.recs[entry], peer)
+                    return 0
+                except BaseException as ex:  # noqa: BLE001
+                    self._err.append(ex)
+                    return 1
+            return xfer_type(call)
+        self._xfer = (xfer(comm.send_picture), xfer(comm.recv_picture)) \
+            if comm is not None and not native else (None, None)
         n = len(schedule.pictures)
         self._keep = [
             (C.c_void_p * self.slots)(*[c.h for c in self.ctxs]),
@@ -107,8 +123,10 @@ class GpuPictureEngine:
         args = (C.c_void_p * self.slots)(*[C.addressof(a) for a in self._keep[1]])
         self._keep.append(args)
         d = Desc(schedule.h, rank, self.slots, C.addressof(self._keep[0]), C.addressof(args),
-                 comm.h if comm is not None else None, C.addressof(self._keep[2]), self.ring,
-                 C.addressof(self._keep[3]), C.cast(self._hook, C.c_void_p), None)
+                 comm.h if native else None, C.addressof(self._keep[2]), self.ring,
+                 C.addressof(self._keep[3]), C.cast(self._hook, C.c_void_p),
+                 C.cast(self._xfer[0], C.c_void_p) if self._xfer[0] else None,
+                 C.cast(self._xfer[1], C.c_void_p) if self._xfer[1] else None, None)
         L.xvc_host_picture_engine_create.restype = C.c_void_p
         L.xvc_host_picture_engine_create.argtypes = [C.c_void_p]
         L.xvc_host_picture_engine_run.argtypes = [C.c_void_p, C.c_int, C.c_int]
