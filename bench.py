@@ -56,6 +56,10 @@ def parse():
     ap.add_argument("--cpu-frames", type=int, default=12,
                     help="cap on the single-thread CPU oracle frame passes (rank 0, N=1)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--cu-order", choices=["tiles", "raster"], default="tiles",
+                    help="order of the CU list of the (unsharded) frame pass: region-major over "
+                         "a 4 x 2 tiling of the picture, so that each XCD's eighth of every "
+                         "job list is one compact region (pipeline.cu_partition), or raster")
     ap.add_argument("--tail-priority", choices=["auto", "on", "off"], default="auto",
                     help="the short kernels that end a pass (inverse transform, fused tail) "
                          "on a high-priority stream of their chain "
@@ -837,7 +841,8 @@ def main():
     ctx_lo = None
     if runner is None:
         recs = [ctx.picture(W, H, bd), ctx.picture(W, H, bd)]
-        fp = pipeline.FramePass(ctx, W, H, bd, qp=args.qp, rdoq=rdoq, rdoq_packed=RDOQ_PACKED)
+        fp = pipeline.FramePass(ctx, W, H, bd, qp=args.qp, rdoq=rdoq, rdoq_packed=RDOQ_PACKED,
+                                xcd_tiles=args.cu_order == "tiles")
         if pipelined:
             # two queues on the device: top half of every picture on a
             # high-priority stream, bottom half on a low-priority one
@@ -876,7 +881,8 @@ def main():
         else:
             ts, crun = None, None
             crecs = [cctx.picture(W, H, bd), cctx.picture(W, H, bd)]
-            cfp = pipeline.FramePass(cctx, W, H, bd, qp=args.qp, rdoq=rdoq, rdoq_packed=RDOQ_PACKED)
+            cfp = pipeline.FramePass(cctx, W, H, bd, qp=args.qp, rdoq=rdoq, rdoq_packed=RDOQ_PACKED,
+                                     xcd_tiles=args.cu_order == "tiles")
         crecs[0].upload(first, border)
         cctx.sync()
         extra.append((cctx, crun, cfp, crecs, phase, ts))

@@ -996,6 +996,53 @@ def test_frame_pass(gpu, xo, size, fused, rdoq):
         p.destroy()
 
 
+@pytest.mark.parametrize("size", [(136, 72, 32), (1920, 1080, 32)])
+def test_frame_pass_region_major_cu_order(gpu, xo, size):
+    """The CU list region by region of a 4 x 2 tiling (pipeline.cu_partition xcd_tiles:
+    what bench.py runs, so that an XCD's share of every job list is one compact region):
+    the same picture as with the raster list - the order of the jobs changes where a CU's
+    results sit, never what they are - and equal to the oracle run on that list."""
+    api, ctx = gpu
+    from xvc_amd import pipeline, synth
+    import oracle_frame
+    pw, ph, qp = size
+    bd = 10
+    clip = synth.SyntheticClip(pw, ph, bd)
+    ref_host, orig_host = pad_planes(clip.frame(0), bd), pad_planes(clip.frame(1), bd)
+    O, R = ctx.picture(pw, ph, bd), ctx.picture(pw, ph, bd)
+    R.upload(ref_host, BL)
+    O.upload(orig_host, BL)
+    out = {}
+    for tiles in (False, True):
+        fp = pipeline.FramePass(ctx, pw, ph, bd, qp=qp, rdoq=True, xcd_tiles=tiles)
+        Rec = ctx.picture(pw, ph, bd)
+        fp.run(O, R, Rec)
+        ctx.sync()
+        res, nnz, cus, ssd = fp.results()
+        out[tiles] = (Rec.download(BL), (int(ssd[0]), int(ssd[1])), fp.desc.me.copy(), res)
+        if tiles:
+            e_rec, e_res, e_nnz, e_cus, e_ssd = oracle_frame.frame_pass(
+                fp.desc, bd, orig_host, ref_host, BL, lib=xo)
+            assert np.array_equal(res, e_res) and np.array_equal(nnz, e_nnz)
+            assert np.array_equal(cus, e_cus) and out[True][1] == e_ssd
+            for c in range(3):
+                assert np.array_equal(out[True][0][c], e_rec[c]), c
+        fp.destroy()
+        Rec.destroy()
+    assert out[False][1] == out[True][1]
+    for c in range(3):
+        assert np.array_equal(out[False][0][c], out[True][0][c]), c
+    # a permutation of the same CUs, each with the same vectors
+    key = lambda m: (m["y"].astype(np.int64) << 16) | m["x"]
+    a, b = np.argsort(key(out[False][2])), np.argsort(key(out[True][2]))
+    assert np.array_equal(out[False][2][a], out[True][2][b])
+    assert np.array_equal(out[False][3][a], out[True][3][b])
+    if pw > 1000:
+        assert not np.array_equal(out[False][2], out[True][2])
+    for p in (O, R):
+        p.destroy()
+
+
 @pytest.mark.parametrize("size", [(352, 288, 32), (1920, 1080, 32), (1920, 1080, 40),
                                   (3840, 2160, 27)])
 @pytest.mark.parametrize("mode", [0, 1])

@@ -85,14 +85,29 @@ def rdoq_host_params(qp, bitdepth, lam=None):
     return out
 
 
-def cu_partition(width, height, cu=16):
-    """Raster list of (x, y, w, h): cu x cu CUs, smaller at right/bottom edge."""
+def cu_partition(width, height, cu=16, xcd_tiles=False):
+    """List of (x, y, w, h): cu x cu CUs, smaller at right/bottom edge - in raster
+    order, or (xcd_tiles) region by region of a 4 x 2 tiling of the picture, raster
+    inside a region.  The kernels give XCD k the k-th contiguous eighth of a job
+    list (dev_common.h: xcd_job_index), and an XCD's L2 then holds what its jobs
+    read: with raster order that is a band 1/8 of the picture tall plus the rows the
+    TZ search's far diamonds (+-64) and the filters reach above and below it -
+    (135 + 128) / 135 = 1.95 x the band at 1080p; a quarter-by-half region has the
+    shorter boundary: (480 + 128)(540 + 128) / (480 * 540) = 1.57 x."""
+    cols, rows = (width + cu - 1) // cu, (height + cu - 1) // cu
+
+    def cell(cx, cy):
+        x, y = cx * cu, cy * cu
+        return (x, y, min(cu, width - x), min(cu, height - y))
+    if not xcd_tiles:
+        return [cell(cx, cy) for cy in range(rows) for cx in range(cols)]
     parts = []
-    for y in range(0, height, cu):
-        h = min(cu, height - y)
-        for x in range(0, width, cu):
-            w = min(cu, width - x)
-            parts.append((x, y, w, h))
+    xb = [round(k * cols / 4) for k in range(5)]
+    yb = [round(k * rows / 2) for k in range(3)]
+    for ty in range(2):
+        for tx in range(4):
+            parts += [cell(cx, cy) for cy in range(yb[ty], yb[ty + 1])
+                      for cx in range(xb[tx], xb[tx + 1])]
     return parts
 
 
@@ -106,10 +121,13 @@ class FrameDescriptors:
     because the in-loop filter looks across the shard boundary."""
 
     def __init__(self, width, height, qp=32, cu=16, search_range=96,
-                 row_range=None, rdoq=False, bitdepth=10):
+                 row_range=None, rdoq=False, bitdepth=10, xcd_tiles=False):
         self.w, self.h, self.qp = width, height, qp
         self.rdoq = rdoq
-        parts_all = cu_partition(width, height, cu)
+        # (region-major CU order only for a whole picture: a row shard's CUs have to be
+        # a contiguous run of the raster list)
+        assert not xcd_tiles or row_range is None or tuple(row_range) == (0, height)
+        parts_all = cu_partition(width, height, cu, xcd_tiles)
         self.n_cus_total = len(parts_all)
         if row_range is None:
             row_range = (0, height)
@@ -193,7 +211,7 @@ class FramePass:
 
     def __init__(self, ctx, width, height, bitdepth=10, qp=32, cu=16,
                  search_range=96, row_range=None, fused=True, keep_levels=False,
-                 rdoq=False, rdoq_packed=None):
+                 rdoq=False, rdoq_packed=None, xcd_tiles=False):
         self.ctx = ctx
         self.rdoq = rdoq
         # RDOQ keeps only a few lanes of a wave busy per block, so its own kernel
@@ -209,7 +227,7 @@ class FramePass:
             and not self.rdoq_packed
         self.w, self.h, self.bd = width, height, bitdepth
         self.desc = d = FrameDescriptors(width, height, qp, cu, search_range,
-                                         row_range, rdoq, bitdepth)
+                                         row_range, rdoq, bitdepth, xcd_tiles)
         self.d_rdoq_ctx = ctx.buffer(d.rdoq_contexts) if rdoq else None
         self.d_rdoq_prm = ctx.buffer(d.rdoq_params) if rdoq else None
         self.d_me = ctx.buffer(d.me)
