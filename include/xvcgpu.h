@@ -899,6 +899,43 @@ xvcgpu_status xvcgpu_affine_me_batch(xvcgpu_ctx *ctx, const xvcgpu_picture *orig
                                      const xvcgpu_affine_me_block *d_blocks, int n,
                                      xvcgpu_affine_me_result *d_results);
 
+/* ---- one step of a CU state's SearchMotion into all its reference pictures -------- *
+ * InterSearch::SearchMotion (inter_search.cc:199-259) runs every step once per (list,
+ * reference picture) of the CU: SearchRefIdx's EvalStartMvp and MotionEstNormal
+ * (:536-578), SearchBiIterative's refinement per pair of pictures (:392-433), the affine
+ * searches (:664-749).  With the single-picture entry points above that is one launch per
+ * picture with one job each, one after the other.  The *_refs forms take the CU's
+ * reference pictures as a table (refs[0 .. n_refs), n_refs <= 10 = 2 lists x
+ * kMaxNumRefPics) and per job the slot(s) of the picture(s) it works on, so one step is
+ * ONE launch whose jobs run side by side.  d_slots: one byte per job
+ * (xvcgpu_me_search_refs, xvcgpu_mc_metric_batch_refs) or two (the searched picture, then
+ * the other list's: xvcgpu_bipred_search_refs, xvcgpu_affine_me_batch_refs; a uni-pred
+ * affine job may name 255 as its second); a first slot >= n_refs marks "no job": its
+ * result is left as it was.
+ * The jobs of a CU state all have the CU's size: block_class (16, 32 or 64 = the class of
+ * max(w, h) as xvcgpu_me_search_sized forms it) / cu_height name the one set of kernel
+ * instances that is launched; a job of another class is not searched (16: it is
+ * answered XVCGPU_ME_UNSUPPORTED).  Results are those of the single-picture calls, job
+ * for job.  No LIC jobs (XVCGPU_ME_LIC_JOBS is refused). */
+xvcgpu_status xvcgpu_me_search_refs(xvcgpu_ctx *ctx, const xvcgpu_picture *orig,
+                                    const xvcgpu_picture *const *refs, int n_refs, int flags,
+                                    const xvcgpu_me_block *d_blocks, const uint8_t *d_slots,
+                                    int n, xvcgpu_me_result *d_results, int block_class);
+xvcgpu_status xvcgpu_bipred_search_refs(xvcgpu_ctx *ctx, const xvcgpu_picture *orig,
+                                        const xvcgpu_picture *const *refs, int n_refs,
+                                        const xvcgpu_bi_block *d_jobs, const uint8_t *d_slots,
+                                        int n, xvcgpu_me_result *d_results, int block_class);
+xvcgpu_status xvcgpu_mc_metric_batch_refs(xvcgpu_ctx *ctx, const xvcgpu_picture *orig,
+                                          const xvcgpu_picture *const *refs, int n_refs,
+                                          int structural_strength,
+                                          const xvcgpu_mc_metric_cand *d_cands,
+                                          const uint8_t *d_slots, int n, uint64_t *d_out);
+xvcgpu_status xvcgpu_affine_me_batch_refs(xvcgpu_ctx *ctx, const xvcgpu_picture *orig,
+                                          const xvcgpu_picture *const *refs, int n_refs,
+                                          const xvcgpu_affine_me_block *d_blocks,
+                                          const uint8_t *d_slots, int n,
+                                          xvcgpu_affine_me_result *d_results, int cu_height);
+
 /* ---- the folds of one SearchMotion chain --------------------------------------- *
  * A pass record - xvcgpu_cs_pass, include/xvcgpu_types.h - describes one SearchMotion of a CU; the three
  * calls below run the host logic of InterSearch::SearchRefIdx / SearchBiIterative /

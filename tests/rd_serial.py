@@ -606,7 +606,8 @@ RESULT_DTYPE = np.dtype([
 OP_DTYPE = np.dtype([("opcode", "<i4"), ("n", "<i4"), ("r0", "<i4"), ("r1", "<i4"), ("i0", "<i4"),
                      ("reserved", "<i4"), ("f", "<f8"), ("p", "<u8", 5)], align=True)
 (OP_MC_METRIC, OP_METRIC, OP_ME, OP_BI, OP_AFFINE, OP_COPY, OP_INTER_PRED, OP_RESIDUAL,
- OP_START_FOLD, OP_UNI_FOLD, OP_BI_FOLD, OP_FETCH, OP_SYNC, OP_EVAL_DIST) = range(14)
+ OP_START_FOLD, OP_UNI_FOLD, OP_BI_FOLD, OP_FETCH, OP_SYNC, OP_EVAL_DIST, OP_MC_METRIC_REFS,
+ OP_ME_REFS, OP_BI_REFS, OP_AFFINE_REFS) = range(18)
 PIC_ORIG, PIC_S_ORIG, PIC_S_PRED, PIC_S_REC = 0, 1, 2, 3
 BI_SLOTS = 2 * R3 * R3
 
@@ -754,6 +755,27 @@ def build_passes(sp, ref_lists):
         aw["mvp"][src] = 0x7fffff           # composed on the device
         aw["bootstrap"][src] = 0x7fffff
     sp.aff_work, sp.aff_work_src = aw, rows
+    # the *_refs forms: per job the slot(s) of the picture(s) it works on (255: no job)
+    sp.start_slots = np.full(len(sp.start_cands), 255, np.uint8)
+    for groups in start_groups.values():
+        for sl, a, k, ca in groups:
+            sp.start_slots[ca:ca + k] = sl
+    sp.me_slots = np.asarray(sp.me_ref, np.uint8).copy()
+    sp.bi_slots = np.full((max(n_bi_slots, 1), 2), 255, np.uint8)
+    sp.aff_slots = np.full((max(len(aw), 1), 2), 255, np.uint8)
+    for pi, p in enumerate(sp.passes):
+        affine = bool(p["flags"] & CS_AFFINE)
+        if affine:
+            for sl, j in aff_uni_groups[pi]:
+                sp.aff_slots[j] = (sl, sl)
+        if p["num_refs"][1]:
+            bj = int(p["bi_job"])
+            for sl_ in range(2):
+                for r in range(int(p["num_refs"][sl_])):
+                    for o in range(int(p["num_refs"][1 - sl_])):
+                        k = bj + (sl_ * R3 + r) * R3 + o
+                        pair = (int(p["slot"][sl_, r]), int(p["slot"][1 - sl_, o]))
+                        (sp.aff_slots if affine else sp.bi_slots)[k] = pair
     # the evaluations' prediction jobs: motion composed on the device for inter states
     ei = sp.ev_inter.copy()
     for n in np.flatnonzero((st["kind"] == KIND_INTER) & (st["supported"] != 0)):
@@ -764,6 +786,8 @@ def build_passes(sp, ref_lists):
 
 class ChainedRun(SerialRun):
     """SerialRun + the arrays and the program of the chained form."""
+
+    refs_form = True      # a SearchMotion step into all reference pictures as one launch
 
     def __init__(self, api, ctx, sp, pics, width, height, ref_lists):
         super().__init__(api, ctx, sp, pics, width, height)
@@ -779,6 +803,8 @@ class ChainedRun(SerialRun):
         d["me_work"], d["aff_work"] = up(sp.me_work), up(sp.aff_work)
         d["bi_work"] = up(np.zeros(max(sp.n_bi_slots, 1), api.BI_DTYPE))
         d["ev_inter_work"] = up(sp.ev_inter_work)
+        d["start_slots"], d["me_slots"] = up(sp.start_slots), up(sp.me_slots)
+        d["bi_slots"], d["aff_slots"] = up(sp.bi_slots), up(sp.aff_slots)
         self.cres = {}
         for name, dt, n in (("start_dist", np.dtype("<u8"), sp.n_start_dist),
                             ("me_res_c", api.MERES_DTYPE, len(sp.me_work)),
@@ -840,9 +866,13 @@ class ChainedRun(SerialRun):
         self.ctx.sync()
 
     # ---- program ---------------------------------------------------------------
-    def program(self, first, n, by_position=True, verify=True):
+    def program(self, first, n, by_position=True, verify=True, refs_form=None):
         """Ops of the states [first, first + n): one chain (ending in a SYNC) per state,
-        or per visit of a CU position (consecutive states of one CU)."""
+        or per visit of a CU position (consecutive states of one CU).  refs_form: a step
+        of SearchMotion into all the CU's reference pictures as ONE launch
+        (xvcgpu_*_refs) instead of one launch per picture; the read-backs of a chain
+        merged where their ranges touch (one copy per result array and chain)."""
+        refs_form = self.refs_form if refs_form is None else refs_form
         sp, api, t, d = self.sp, self.api, self.t, self.d
         st = sp.states
         ops = []
@@ -858,18 +888,48 @@ class ChainedRun(SerialRun):
         def op(code, n_=0, r0=0, r1=0, i0=0, f=0.0, p=()):
             ops.append((code, n_, r0, r1, i0, 0, f, tuple(int(x) for x in p) + (0,) * (5 - len(p))))
 
+        pending = []                   # (device, host, bytes) read-backs of the open chain
+
+        def flush_fetches():
+            pending.sort()
+            merged = []
+            for dev, host, nb in pending:
+                if merged and merged[-1][0] + merged[-1][2] >= dev and \
+                        host - merged[-1][1] == dev - merged[-1][0]:
+                    merged[-1][2] = max(merged[-1][2], dev + nb - merged[-1][0])
+                else:
+                    merged.append([dev, host, nb])
+            for dev, host, nb in merged:
+                fetch_now(dev, host, nb)
+            del pending[:]
+
         def fetch(dev, host, nbytes):
+            if nbytes <= 0:
+                return
+            if refs_form:
+                pending.append((int(dev), int(host), int(nbytes)))
+            else:
+                fetch_now(dev, host, nbytes)
+
+        def fetch_now(dev, host, nbytes):
             if nbytes:
                 op(OP_FETCH, nbytes, p=(dev, host))
 
         def motion(s, n_state):
             ms = max(int(s["w"]), int(s["h"]))
+            cls = 16 if ms <= 16 else (32 if ms <= 32 else 64)
             pf, pc = int(sp.pass_first[n_state]), int(sp.pass_count[n_state])
             for pi in range(pf, pf + pc):
                 p = sp.passes[pi]
                 affine = bool(p["flags"] & CS_AFFINE)
                 P = d["passes"]                  # the folds index the arrays absolutely (i0 = pass)
-                if not affine:
+                if not affine and refs_form:
+                    g = sp.start_groups[pi]
+                    a0, ca0, kk = g[0][1], g[0][3], sum(x[2] for x in g)
+                    assert all(x[1] - a0 == x[3] - ca0 for x in g) and g[-1][3] + g[-1][2] == ca0 + kk
+                    op(OP_MC_METRIC_REFS, kk, p=(d["start_cands"] + ca0 * I["mcm"], d["start_dist"] + 8 * a0,
+                                                 d["start_slots"] + ca0))
+                elif not affine:
                     for sl, a, k, ca in sp.start_groups[pi]:
                         op(OP_MC_METRIC, k, r0=sl, p=(d["start_cands"] + ca * I["mcm"], d["start_dist"] + 8 * a))
                 else:
@@ -880,14 +940,32 @@ class ChainedRun(SerialRun):
                     op(OP_METRIC, k, r0=PIC_S_ORIG, r1=PIC_S_PRED, i0=0, f=1.0,
                        p=(d["aff_start_cands"] + a * I["cand"], d["start_dist"] + 8 * sd))
                 op(OP_START_FOLD, 1, i0=pi, p=(P, d["start_dist"], d["me_work"], d["me_res_c"], d["aff_work"]))
-                if not affine:
-                    for sl, j in sp.uni_groups[pi]:
+                ug = sp.aff_uni_groups[pi] if affine else sp.uni_groups[pi]
+                if refs_form and ug:
+                    j0 = ug[0][1]
+                    assert [j for _, j in ug] == list(range(j0, j0 + len(ug)))
+                    if not affine:
+                        op(OP_ME_REFS, len(ug), i0=cls, p=(d["me_work"] + j0 * I["me"], d["me_res_c"] + j0 * I["res"],
+                                                           d["me_slots"] + j0))
+                    else:
+                        op(OP_AFFINE_REFS, len(ug), i0=int(s["h"]),
+                           p=(d["aff_work"] + j0 * I["aff"], d["aff_res_c"] + j0 * I["affr"], d["aff_slots"] + 2 * j0))
+                elif not affine:
+                    for sl, j in ug:
                         op(OP_ME, 1, r0=sl, i0=ms, p=(d["me_work"] + j * I["me"], d["me_res_c"] + j * I["res"]))
                 else:
-                    for sl, j in sp.aff_uni_groups[pi]:
+                    for sl, j in ug:
                         op(OP_AFFINE, 1, r0=sl, r1=sl, p=(d["aff_work"] + j * I["aff"], d["aff_res_c"] + j * I["affr"]))
                 op(OP_UNI_FOLD, 1, i0=pi, p=(P, d["me_res_c"], d["aff_res_c"], d["bi_work"], d["aff_work"]))
-                if p["num_refs"][1]:
+                if p["num_refs"][1] and refs_form:
+                    bj = int(p["bi_job"])
+                    if not affine:
+                        op(OP_BI_REFS, BI_SLOTS, i0=cls, p=(d["bi_work"] + bj * I["bi"], d["bi_res_c"] + bj * I["res"],
+                                                            d["bi_slots"] + 2 * bj))
+                    else:
+                        op(OP_AFFINE_REFS, BI_SLOTS, i0=int(s["h"]),
+                           p=(d["aff_work"] + bj * I["aff"], d["aff_res_c"] + bj * I["affr"], d["aff_slots"] + 2 * bj))
+                elif p["num_refs"][1]:
                     bj = int(p["bi_job"])
                     for sl_ in range(2):
                         for r in range(int(p["num_refs"][sl_])):
@@ -930,6 +1008,7 @@ class ChainedRun(SerialRun):
                 continue
             key = (int(s["x"]), int(s["y"]), int(s["w"]), int(s["h"]))
             if chain_states and (not by_position or key != prev_key):
+                flush_fetches()
                 op(OP_SYNC, i0=chain_states, r0=chain_kind)
                 chain_states = 0
             prev_key = key
@@ -948,6 +1027,7 @@ class ChainedRun(SerialRun):
             chain_kind = max(chain_kind, kind) if chain_states else kind
             chain_states += 1
         if chain_states:
+            flush_fetches()
             op(OP_SYNC, i0=chain_states, r0=chain_kind)
         return np.array(ops, OP_DTYPE)
 
@@ -961,13 +1041,44 @@ class ChainedRun(SerialRun):
                 rc, self.ctx.lib.xvcgpu_last_error(self.ctx.h)))
         return stats
 
-    def run_chained(self, first=0, n=None, by_position=True, verify=True):
+    def prepare(self, first=0, n=None, by_position=True, verify=True):
+        """Record the program (what an encoder emits as it walks its CU tree; here a
+        Python loop over the state table - keep it out of a timed region)."""
         n = len(self.sp.states) - first if n is None else n
-        key = (first, n, by_position, verify)
+        key = (first, n, by_position, verify, self.refs_form)
         if getattr(self, "_prog_key", None) != key:
-            self._prog, self._prog_key = self.program(first, n, by_position, verify), key
+            self._prog = np.ascontiguousarray(self.program(first, n, by_position, verify))
+            self._prog_key = key
+        return self._prog
+
+    def run_chained(self, first=0, n=None, by_position=True, verify=True):
+        self.prepare(first, n, by_position, verify)
         stats = self.run_program(self._prog)
         self.collect()
+        return stats
+
+    @staticmethod
+    def run_interleaved(runs, first=0, n=None, by_position=True):
+        """k runs (their own contexts) driven by one thread,
+        xvc_host_cs_run_programs_interleaved: a chain of one run is issued while the
+        others' are executing."""
+        k = len(runs)
+        for r in runs:
+            r.prepare(first, n, by_position, False)
+        lib = runs[0].lib
+        lib.xvc_host_cs_run_programs_interleaved.argtypes = [C.c_int, C.c_void_p, C.c_void_p,
+                                                             C.c_void_p, C.c_void_p, C.c_void_p]
+        lib.xvc_host_cs_run_programs_interleaved.restype = C.c_int
+        ctxs = (C.c_void_p * k)(*[r.ctx.h for r in runs])
+        envs = (C.c_void_p * k)(*[C.addressof(r.env) for r in runs])
+        ops = (C.c_void_p * k)(*[r._prog.ctypes.data for r in runs])
+        n_ops = (C.c_int64 * k)(*[len(r._prog) for r in runs])
+        stats = CsStats()
+        rc = lib.xvc_host_cs_run_programs_interleaved(k, ctxs, envs, ops, n_ops, C.addressof(stats))
+        if rc:
+            raise RuntimeError("xvc_host_cs_run_programs_interleaved: %d" % rc)
+        for r in runs:
+            r.collect()
         return stats
 
     def collect(self):

@@ -18,6 +18,17 @@ def test_binding_sizes():
                          C.sizeof(rd_serial.CsEnv)]
 
 
+def test_host_library_exports_the_cu_state_entry_points():
+    L = decoder.load_host_library()
+    for name in ("xvc_host_cu_state_run_serial", "xvc_host_cs_run_program",
+                 "xvc_host_cs_run_programs_interleaved", "xvc_host_inter_pred_bits",
+                 "xvc_host_next_state_table"):
+        assert getattr(L, name) is not None
+    # argument checks need no device
+    L.xvc_host_cs_run_programs_interleaved.restype = C.c_int
+    assert L.xvc_host_cs_run_programs_interleaved(0, None, None, None, None, None) != 0
+
+
 def test_states_of_a_captured_picture():
     sp = rd_serial.SerialPicture(api, "tiny", 2)
     st, s = sp.states, sp.summary()

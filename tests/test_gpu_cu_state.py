@@ -49,11 +49,12 @@ def test_serial_walk_equals_reference(gpu, name, poc, n_states):
         assert res["affine"][0] > 100
 
 
-def _run_chained(api, ctx, name, poc, n_states, by_position):
+def _run_chained(api, ctx, name, poc, n_states, by_position, refs_form=True):
     fx = sf.StreamFixture(name)
     pics, w, h = decode_stream(ctx, fx)
     sp = rd_serial.SerialPicture(api, name, poc)
     run = rd_serial.ChainedRun(api, ctx, sp, pics, w, h, rd_serial.ref_lists_of(name, poc))
+    run.refs_form = refs_form
     n = min(n_states, len(sp.states))
     stats = run.run_chained(0, n, by_position)
     res = run.check(0, n, searches=False)
@@ -65,18 +66,21 @@ def _run_chained(api, ctx, name, poc, n_states, by_position):
     return sp, stats, res, bad
 
 
-@pytest.mark.parametrize("name,poc,n_states,by_position", [
-    ("tiny", 2, 1 << 30, False), ("tiny", 2, 1 << 30, True), ("c0", 4, 1 << 30, True),
-    ("c1", 2, 20000, True)])
-def test_chained_states_equal_reference(gpu, name, poc, n_states, by_position):
+@pytest.mark.parametrize("name,poc,n_states,by_position,refs_form", [
+    ("tiny", 2, 1 << 30, False, True), ("tiny", 2, 1 << 30, True, True),
+    ("tiny", 2, 1 << 30, True, False), ("c0", 4, 1 << 30, True, True),
+    ("c1", 2, 20000, True, True), ("c1", 2, 4000, True, False)])
+def test_chained_states_equal_reference(gpu, name, poc, n_states, by_position, refs_form):
     """The same states as ONE enqueue each (or per visit of a CU position), the folds
     between the searches on the device (xvcgpu_cs_*_fold): no read-back inside a chain.
     The searches' jobs are composed by the folds - the predictor EvalStartMvp picks, the
     refinement's jobs, the affine bootstrap, the evaluation's motion - so every result
     below depends on them: all equal to the reference's, and so are the folds' own
-    intermediates (final predictor, bits with the default prices, costs, choices)."""
+    intermediates (final predictor, bits with the default prices, costs, choices).
+    refs_form: every step of SearchMotion into all the CU's reference pictures as one
+    launch (xvcgpu_*_refs, the jobs side by side) instead of one launch per picture."""
     api, ctx = gpu
-    sp, stats, res, bad = _run_chained(api, ctx, name, poc, n_states, by_position)
+    sp, stats, res, bad = _run_chained(api, ctx, name, poc, n_states, by_position, refs_form)
     print(name, by_position, res, "%.1f us / state, %.1f API calls, %.2f round trips per state" % (
         1e6 * stats.seconds / max(stats.states, 1), stats.api_calls / max(stats.states, 1),
         stats.round_trips / max(stats.states, 1)))
@@ -85,3 +89,31 @@ def test_chained_states_equal_reference(gpu, name, poc, n_states, by_position):
     assert stats.round_trips <= stats.states
     for k in ("cands", "finals", "eval_motion", "calls", "merge"):
         assert res[k][0] > 100, (k, res)
+
+
+def test_interleaved_chains_equal_reference(gpu):
+    """Three replays of the picture on their own contexts driven by one host thread
+    (xvc_host_cs_run_programs_interleaved: a chain issued while the others execute):
+    each run's results equal the reference's."""
+    api, ctx = gpu
+    fx = sf.StreamFixture("tiny")
+    pics, w, h = decode_stream(ctx, fx)
+    sp = rd_serial.SerialPicture(api, "tiny", 2)
+    ctxs = [api.Context(0) for _ in range(3)]
+    for c in ctxs:
+        c.use_own_stream()
+    lists = rd_serial.ref_lists_of("tiny", 2)
+    runs = [rd_serial.ChainedRun(api, c, sp, pics, w, h, lists) for c in ctxs]
+    stats = rd_serial.ChainedRun.run_interleaved(runs)
+    assert stats.states > 1000 and stats.states % 3 == 0 and stats.round_trips < stats.states
+    for r in runs:
+        res = r.check(0, len(sp.states), searches=False)
+        for k, (done, wrong) in res.items():
+            assert wrong == 0, (k, res)
+        assert res["calls"][0] > 100
+    for r in runs:
+        r.destroy()
+    for c in ctxs:
+        c.close()
+    for p in pics.values():
+        p.destroy()

@@ -58,6 +58,9 @@ def walk(api, clip, poc, n_states, ks, mode="serial", check=True, decoded=None, 
 
         for r in runs[:1]:          # warm-up (module load, scratch allocation)
             go(r, min(n, 200))
+        if mode != "serial":        # the programs are recorded before the clock starts
+            for r in runs:
+                r.prepare(0, n, mode == "chained", False)
         th = [threading.Thread(target=work, args=(i,)) for i in range(k)]
         t0 = time.time()
         for t in th:
@@ -78,6 +81,17 @@ def walk(api, clip, poc, n_states, ks, mode="serial", check=True, decoded=None, 
             "us_by_kind": {name: 1e6 * s0.seconds_by_kind[i] / max(s0.states_by_kind[i], 1)
                            for i, name in enumerate(("merge_rank", "eval", "inter", "motion_only"))},
         }
+        if mode == "chained" and k > 1:
+            # the same k chains driven by ONE host thread, a chain issued while the
+            # others execute (xvc_host_cs_run_programs_interleaved)
+            t0 = time.time()
+            si = rd_serial.ChainedRun.run_interleaved(runs, 0, n)
+            wall_i = time.time() - t0
+            entry["one_thread"] = {"states_per_s": si.states / wall_i,
+                                   "pictures_per_s": si.states / wall_i / (s0.states * per_pic)}
+            if check:
+                ri = runs[0].check(0, n, searches=False)
+                entry["one_thread"]["matches_reference"] = all(v[1] == 0 for v in ri.values())
         if check:
             if mode != "serial":
                 go(runs[-1], n, verify=True)
@@ -105,7 +119,10 @@ if __name__ == "__main__":
     ap.add_argument("--states", type=int, default=6000)
     ap.add_argument("--k", default="1,4,8,16")
     ap.add_argument("--mode", default="serial")
+    ap.add_argument("--no-check", action="store_true",
+                    help="skip the comparison (and its second, verifying run): for kernel traces")
     a = ap.parse_args()
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     from xvc_amd import api
-    print(json.dumps(walk(api, a.clip, a.poc, a.states, [int(x) for x in a.k.split(",")], a.mode)))
+    print(json.dumps(walk(api, a.clip, a.poc, a.states, [int(x) for x in a.k.split(",")], a.mode,
+                          check=not a.no_check)))

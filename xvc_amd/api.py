@@ -164,6 +164,10 @@ SYMBOLS = [
     "xvcgpu_me_search", "xvcgpu_me_search_sized", "xvcgpu_mc_batch", "xvcgpu_mc_from_me",
     "xvcgpu_mc_bipred_batch", "xvcgpu_bipred_search", "xvcgpu_mc_affine_batch", "xvcgpu_mc_lic_batch",
     "xvcgpu_affine_me_batch",
+    "xvcgpu_me_search_refs",
+    "xvcgpu_bipred_search_refs",
+    "xvcgpu_mc_metric_batch_refs",
+    "xvcgpu_affine_me_batch_refs",
     "xvcgpu_cu_info_from_me", "xvcgpu_recon_from_me", "xvcgpu_residual_batch",
     "xvcgpu_fwd_transform_batch", "xvcgpu_inv_transform_batch",
     "xvcgpu_deblock", "xvcgpu_deblock_rows", "xvcgpu_deblock_pad_ssd", "xvcgpu_picture_ssd", "xvcgpu_picture_ssd_rows",
@@ -287,6 +291,10 @@ def load_library():
         "xvcgpu_histogram_distance": [_vp, _vp, _vp, _vp],
         "xvcgpu_mc_lic_batch": [_vp, _vp, _vp, _vp, _vp, C.c_int],
         "xvcgpu_affine_me_batch": [_vp, _vp, _vp, _vp, _vp, C.c_int, _vp],
+        "xvcgpu_me_search_refs": [_vp, _vp, _vp, C.c_int, C.c_int, _vp, _vp, C.c_int, _vp, C.c_int],
+        "xvcgpu_bipred_search_refs": [_vp, _vp, _vp, C.c_int, _vp, _vp, C.c_int, _vp, C.c_int],
+        "xvcgpu_mc_metric_batch_refs": [_vp, _vp, _vp, C.c_int, C.c_int, _vp, _vp, C.c_int, _vp],
+        "xvcgpu_affine_me_batch_refs": [_vp, _vp, _vp, C.c_int, _vp, _vp, C.c_int, _vp, C.c_int],
         "xvcgpu_intra_pred_batch": [_vp, _vp, _vp, _vp, C.c_int],
         "xvcgpu_intra_satd_batch": [_vp, _vp, _vp, _vp, C.c_int, _vp, C.c_int],
         "xvcgpu_intra_recon_batch": [_vp, _vp, _vp, _vp, _vp, C.c_int, _vp, _vp, _vp],

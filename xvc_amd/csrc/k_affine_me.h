@@ -434,12 +434,23 @@ __device__ __forceinline__ void affine_me_search(int bd, const xvcgpu_affine_me_
 // grid: n CUs; block: 64 * NW.  The instance with NW waves takes the jobs
 // whose height is 16 * NW and leaves the others to its siblings.
 template <int NW>
-__global__ void __launch_bounds__(64 * NW)
-affine_me_kernel(PlaneView orig, PlaneView ref, PlaneView ref_other, int bd,
-                 const xvcgpu_affine_me_block *blocks, int n, xvcgpu_affine_me_result *out) {
+__device__ __forceinline__ void
+affine_me_body(const PlaneView &orig, const PlaneView &ref_arg, const PlaneView &ref_other_arg,
+               int bd, const xvcgpu_affine_me_block *blocks, int n, xvcgpu_affine_me_result *out,
+               const RefTable *refs = nullptr, const uint8_t *slots = nullptr) {
   __shared__ AffineMeShared<NW> s;
   const int bi = blockIdx.x;
   if (bi >= n) return;
+  // (the *_refs form: slots[2 * job] = the searched picture, [2 * job + 1] = the other list's)
+  int slot_s = 0, slot_o = 0;
+  if (slots) {
+    slot_s = __builtin_amdgcn_readfirstlane((int)slots[2 * bi]);
+    slot_o = __builtin_amdgcn_readfirstlane((int)slots[2 * bi + 1]);
+    if (slot_s >= XVC_MAX_REF_SLOTS) return;
+    if (slot_o >= XVC_MAX_REF_SLOTS) slot_o = slot_s;   // (uni-prediction: not read)
+  }
+  const PlaneView ref = slots ? refs->pic[slot_s].c[0] : ref_arg;
+  const PlaneView ref_other = slots ? refs->pic[slot_o].c[0] : ref_other_arg;
   const xvcgpu_affine_me_block b = blocks[bi];
   {
     // CodingUnit::CanUseAffine: width, height > 8 (coding_unit.h:308): 16, 32, 64
@@ -477,6 +488,23 @@ affine_me_kernel(PlaneView orig, PlaneView ref, PlaneView ref_other, int bd,
   } else {
     affine_me_search<NW, uint16_t>(bd, b, ref, o, (int)orig.stride, s, out + bi);
   }
+}
+
+template <int NW>
+__global__ void __launch_bounds__(64 * NW)
+affine_me_kernel(PlaneView orig, PlaneView ref, PlaneView ref_other, int bd,
+                 const xvcgpu_affine_me_block *blocks, int n, xvcgpu_affine_me_result *out) {
+  affine_me_body<NW>(orig, ref, ref_other, bd, blocks, n, out);
+}
+
+// The affine searches of one CU state into several reference pictures in one launch
+// (xvcgpu_affine_me_batch_refs).
+template <int NW>
+__global__ void __launch_bounds__(64 * NW)
+affine_me_refs_kernel(PlaneView orig, RefTable refs, const uint8_t *slots, int bd,
+                      const xvcgpu_affine_me_block *blocks, int n,
+                      xvcgpu_affine_me_result *out) {
+  affine_me_body<NW>(orig, orig, orig, bd, blocks, n, out, &refs, slots);
 }
 
 #endif  // XVCGPU_K_AFFINE_ME_H_

@@ -130,16 +130,26 @@ __device__ __forceinline__ void wg_lic_model(int bd, int comp, int bx, int by, i
 // GetSubpelMetric, inter_search.cc:1059-1076) - both on the int16 target; the
 // candidates' own predictions stay plain (GetSubpelDist: post_filter = false).
 template <int MS, bool LIC = false>
-__global__ void __launch_bounds__(64 * BI_WAVES(MS))
-bipred_search_kernel(PlaneView orig, PlaneView ref_other, PlaneView ref_search,
-                     int bd, const xvcgpu_bi_block *jobs, int n,
-                     xvcgpu_me_result *out, int max_launched, PlaneView rec = PlaneView(),
-                     const xvcgpu_mc_lic_block *nb = nullptr) {
+__device__ __forceinline__ void
+bipred_search_body(const PlaneView &orig, const PlaneView &ref_other_arg,
+                   const PlaneView &ref_search_arg, int bd, const xvcgpu_bi_block *jobs, int n,
+                   xvcgpu_me_result *out, int max_launched, const PlaneView &rec,
+                   const xvcgpu_mc_lic_block *nb, const RefTable *refs = nullptr,
+                   const uint8_t *slots = nullptr) {
   constexpr int NW = BI_WAVES(MS);
   __shared__ BiShared<MS> s;
   __shared__ int s_scale, s_offset;
   const int ji = xcd_job_index(blockIdx.x, n);
   if (ji < 0) return;
+  // (the *_refs form: slots[2 * job] = the searched picture, [2 * job + 1] = the other)
+  int slot_s = 0, slot_o = 0;
+  if (slots) {
+    slot_s = __builtin_amdgcn_readfirstlane((int)slots[2 * ji]);
+    slot_o = __builtin_amdgcn_readfirstlane((int)slots[2 * ji + 1]);
+    if (slot_s >= XVC_MAX_REF_SLOTS || slot_o >= XVC_MAX_REF_SLOTS) return;
+  }
+  const PlaneView ref_other = slots ? refs->pic[slot_o].c[0] : ref_other_arg;
+  const PlaneView ref_search = slots ? refs->pic[slot_s].c[0] : ref_search_arg;
   const xvcgpu_bi_block job = jobs[ji];
   const xvcgpu_me_block &b = job.blk;
   {  // block-size class of this kernel instance (LDS footprint)
@@ -281,6 +291,27 @@ bipred_search_kernel(PlaneView orig, PlaneView ref_other, PlaneView ref_search,
     r.subpel_dist = bdist >> 1;  // inter_search.cc:660
     out[ji] = r;
   }
+}
+
+template <int MS, bool LIC = false>
+__global__ void __launch_bounds__(64 * BI_WAVES(MS))
+bipred_search_kernel(PlaneView orig, PlaneView ref_other, PlaneView ref_search,
+                     int bd, const xvcgpu_bi_block *jobs, int n,
+                     xvcgpu_me_result *out, int max_launched, PlaneView rec = PlaneView(),
+                     const xvcgpu_mc_lic_block *nb = nullptr) {
+  bipred_search_body<MS, LIC>(orig, ref_other, ref_search, bd, jobs, n, out, max_launched, rec, nb);
+}
+
+// The refinement steps of one CU state into several pairs of reference pictures in
+// one launch (xvcgpu_bipred_search_refs): job i searches refs.pic[slots[2 i]] against
+// the prediction from refs.pic[slots[2 i + 1]]; a slot beyond the table: no job.
+template <int MS>
+__global__ void __launch_bounds__(64 * BI_WAVES(MS))
+bipred_search_refs_kernel(PlaneView orig, RefTable refs, const uint8_t *slots, int bd,
+                          const xvcgpu_bi_block *jobs, int n, xvcgpu_me_result *out,
+                          int max_launched) {
+  bipred_search_body<MS, false>(orig, orig, orig, bd, jobs, n, out, max_launched, PlaneView(),
+                                nullptr, &refs, slots);
 }
 
 // MotionCompUniPred -> int16 (14-bit, offset removed) by the workgroup
@@ -463,9 +494,10 @@ mc_affine_kernel(PicView ref, PicView pred, const xvcgpu_mc_affine_block *blocks
 // candidate): MotionCompensationMv of the luma block into LDS, then
 // SampleMetric::CompareSample(orig, pred).  One wave per candidate, two per
 // workgroup.  grid: ceil(n/2); block: 128.
-__global__ void __launch_bounds__(128)
-mc_metric_kernel(PlaneView orig, PlaneView ref, int bd, int strength,
-                 const xvcgpu_mc_metric_cand *cands, int n, uint64_t *out) {
+__device__ __forceinline__ void
+mc_metric_body(const PlaneView &orig, const PlaneView &ref_arg, int bd, int strength,
+               const xvcgpu_mc_metric_cand *cands, int n, uint64_t *out,
+               const RefTable *refs = nullptr, const uint8_t *slots = nullptr) {
   __shared__ struct {
     int16_t tmp[64 * 71];
     uint16_t pred[64 * 64];
@@ -473,6 +505,12 @@ mc_metric_kernel(PlaneView orig, PlaneView ref, int bd, int strength,
   const int wave = threadIdx.x >> 6;
   const int ci = blockIdx.x * 2 + wave;
   if (ci >= n) return;
+  int slot = 0;
+  if (slots) {
+    slot = __builtin_amdgcn_readfirstlane((int)slots[ci]);   // (one candidate per wave)
+    if (slot >= XVC_MAX_REF_SLOTS) return;
+  }
+  const PlaneView ref = slots ? refs->pic[slot].c[0] : ref_arg;
   const xvcgpu_mc_metric_cand cd = cands[ci];
   xvcgpu_me_block b;
   b.x = cd.x;
@@ -485,6 +523,19 @@ mc_metric_kernel(PlaneView orig, PlaneView ref, int bd, int strength,
   const uint64_t dist = wave_compare(cd.metric, bd, cd.qp, strength, cd.w, cd.h, o,
                                      orig.stride, sh[wave].pred, cd.w);
   if ((threadIdx.x & 63) == 0) out[ci] = dist;
+}
+
+__global__ void __launch_bounds__(128)
+mc_metric_kernel(PlaneView orig, PlaneView ref, int bd, int strength,
+                 const xvcgpu_mc_metric_cand *cands, int n, uint64_t *out) {
+  mc_metric_body(orig, ref, bd, strength, cands, n, out);
+}
+
+// candidate i predicted from refs.pic[slots[i]] (xvcgpu_mc_metric_batch_refs)
+__global__ void __launch_bounds__(128)
+mc_metric_refs_kernel(PlaneView orig, RefTable refs, const uint8_t *slots, int bd, int strength,
+                      const xvcgpu_mc_metric_cand *cands, int n, uint64_t *out) {
+  mc_metric_body(orig, orig, bd, strength, cands, n, out, &refs, slots);
 }
 
 #endif  // XVCGPU_K_BIPRED_H_

@@ -82,8 +82,8 @@ __device__ __forceinline__ void cs_set_mvd(int32_t out[2][2], const int32_t mvp[
 }
 
 __device__ __forceinline__ uint32_t cs_price(const xvcgpu_cs_pass &p, const xvc_inter_syntax &syn,
-                                             uint32_t dist, uint32_t *bits_out) {
-  const xvc_bits_tables t = {kEntropyBits, kTransIdxLps};
+                                             uint32_t dist, uint32_t *bits_out,
+                                             const xvc_bits_tables &t) {
   const uint32_t bits = xvc_inter_pred_bits(&p.ictx, &syn, &t);
   *bits_out = bits;
   return dist + ((bits * p.lambda16) >> 16);   // Bits and lambda are uint32_t (:563)
@@ -123,6 +123,18 @@ static_assert(sizeof(xvcgpu_cs_result) % 4 == 0 && sizeof(xvcgpu_cs_result) <= 5
   __syncthreads();                                                               \
   const xvcgpu_cs_pass &p = s_pass;                                              \
   xvcgpu_cs_result &R = s_res;
+// The two tables of the bit prices in LDS: a candidate's price is a chain of some twenty
+// dependent look-ups by one lane (context state -> bits, -> next state), each a trip to
+// the vector cache out of constant memory - most of a fold's 10 us.
+#define CS_FOLD_TABLES                                                                   \
+  __shared__ uint32_t s_bits[128];                                                       \
+  __shared__ __attribute__((aligned(4))) uint8_t s_lps[64];                              \
+  s_bits[threadIdx.x] = kEntropyBits[threadIdx.x];                                       \
+  s_bits[threadIdx.x + 64] = kEntropyBits[threadIdx.x + 64];                             \
+  if (threadIdx.x < 16)                                                                  \
+    reinterpret_cast<uint32_t *>(s_lps)[threadIdx.x] =                                   \
+        reinterpret_cast<const uint32_t *>(kTransIdxLps)[threadIdx.x];                   \
+  const xvc_bits_tables tabs = {s_bits, s_lps};
 #define CS_FOLD_EPILOGUE \
   __syncthreads();       \
   cs_wave_copy(&results[pi], &s_res, sizeof(xvcgpu_cs_result) / 4);
@@ -179,7 +191,20 @@ __global__ void cs_uni_fold_kernel(const xvcgpu_cs_pass *passes, int first, int 
                                    const xvcgpu_affine_me_result *aff_res,
                                    xvcgpu_cs_result *results, xvcgpu_bi_block *bi_jobs,
                                    xvcgpu_affine_me_block *aff_jobs) {
+  CS_FOLD_TABLES
   CS_FOLD_PROLOGUE
+  // the searches' results: one lane per (list, picture), the reads in flight together
+  __shared__ xvcgpu_me_result s_me[2 * CS_R];
+  __shared__ xvcgpu_affine_me_result s_aff[2 * CS_R];
+  if (threadIdx.x < 2 * CS_R) {
+    const int l = threadIdx.x / CS_R, r = threadIdx.x % CS_R;
+    const int j = r < p.num_refs[l] ? p.uni_job[l][r] : -1;
+    if (j >= 0) {
+      if (!cs_affine(p)) s_me[threadIdx.x] = me_res[j];
+      else s_aff[threadIdx.x] = aff_res[j];
+    }
+  }
+  __syncthreads();
   auto body = [&]() {
   const bool affine = cs_affine(p), fullpel = cs_fullpel(p);
   R.cost_l1_unique = CS_MAXCOST;
@@ -193,13 +218,13 @@ __global__ void cs_uni_fold_kernel(const xvcgpu_cs_pass *passes, int first, int 
         cs_copy_mv(R.mv[l][r], R.mv[0][m]);
         R.dist[l][r] = R.dist[0][m];
       } else if (!affine) {
-        const xvcgpu_me_result &s = me_res[p.uni_job[l][r]];
+        const xvcgpu_me_result &s = s_me[l * CS_R + r];
         R.mv[l][r][0][0] = s.mv_x;
         R.mv[l][r][0][1] = s.mv_y;
         for (int k = 1; k < 3; k++) R.mv[l][r][k][0] = R.mv[l][r][k][1] = 0;
         R.dist[l][r] = s.subpel_dist;
       } else {
-        const xvcgpu_affine_me_result &s = aff_res[p.uni_job[l][r]];
+        const xvcgpu_affine_me_result &s = s_aff[l * CS_R + r];
         cs_copy_mv(R.mv[l][r], s.mv);
         R.dist[l][r] = s.dist;
       }
@@ -212,7 +237,7 @@ __global__ void cs_uni_fold_kernel(const xvcgpu_cs_pass *passes, int first, int 
       syn.ref_idx[l] = (int8_t)r;
       syn.mvp_idx[l] = (uint8_t)idx;
       cs_set_mvd(syn.mvd[l], p.mvp[l][r][idx], R.mv[l][r], fullpel, affine);
-      const uint32_t cost = cs_price(p, syn, R.dist[l][r], &R.bits[l][r]);
+      const uint32_t cost = cs_price(p, syn, R.dist[l][r], &R.bits[l][r], tabs);
       R.cost[l][r] = cost;
       if (cost < cost_best) {
         cost_best = cost;
@@ -285,7 +310,19 @@ __global__ void cs_bi_fold_kernel(const xvcgpu_cs_pass *passes, int first, int n
                                   const xvcgpu_me_result *bi_res,
                                   const xvcgpu_affine_me_result *aff_res,
                                   xvcgpu_cs_result *results, xvcgpu_inter_block *ev_inter) {
+  CS_FOLD_TABLES
   CS_FOLD_PROLOGUE
+  __shared__ xvcgpu_me_result s_bi[CS_R];
+  __shared__ xvcgpu_affine_me_result s_abi[CS_R];
+  if (threadIdx.x < CS_R && R.bi_valid) {
+    const int s = R.search_list, r = threadIdx.x;
+    if (r < p.num_refs[s]) {
+      const int slot = p.bi_job + (s * CS_R + r) * CS_R + R.best_ref[1 - s];
+      if (!cs_affine(p)) s_bi[r] = bi_res[slot];
+      else s_abi[r] = aff_res[slot];
+    }
+  }
+  __syncthreads();
   auto body = [&]() {
   const bool affine = cs_affine(p), fullpel = cs_fullpel(p);
   uint32_t cost_bi = CS_MAXCOST;
@@ -296,15 +333,14 @@ __global__ void cs_bi_fold_kernel(const xvcgpu_cs_pass *passes, int first, int n
   if (R.bi_valid) {
     cs_set_mvd(other_mvd, p.mvp[od][o][R.mvp_idx[od][o]], R.mv[od][o], fullpel, affine);
     for (int r = 0; r < p.num_refs[s] && r < CS_R; r++) {
-      const int slot = p.bi_job + (s * CS_R + r) * CS_R + o;
       if (!affine) {
-        R.bi_mv[r][0][0] = bi_res[slot].mv_x;
-        R.bi_mv[r][0][1] = bi_res[slot].mv_y;
+        R.bi_mv[r][0][0] = s_bi[r].mv_x;
+        R.bi_mv[r][0][1] = s_bi[r].mv_y;
         for (int k = 1; k < 3; k++) R.bi_mv[r][k][0] = R.bi_mv[r][k][1] = 0;
-        R.bi_dist[r] = bi_res[slot].subpel_dist;
+        R.bi_dist[r] = s_bi[r].subpel_dist;
       } else {
-        cs_copy_mv(R.bi_mv[r], aff_res[slot].mv);
-        R.bi_dist[r] = aff_res[slot].dist;
+        cs_copy_mv(R.bi_mv[r], s_abi[r].mv);
+        R.bi_dist[r] = s_abi[r].dist;
       }
       const int idx = cs_final_mvp_idx(p.mvp[s][r], R.bi_mv[r], R.mvp_idx[s][r], fullpel, affine);
       R.bi_mvp_idx[r] = (uint8_t)idx;
@@ -319,7 +355,7 @@ __global__ void cs_bi_fold_kernel(const xvcgpu_cs_pass *passes, int first, int n
       syn.mvp_idx[od] = R.mvp_idx[od][o];
       for (int k = 0; k < 2; k++)
         for (int c = 0; c < 2; c++) syn.mvd[od][k][c] = other_mvd[k][c];
-      const uint32_t cost = cs_price(p, syn, R.bi_dist[r], &R.bi_bits[r]);
+      const uint32_t cost = cs_price(p, syn, R.bi_dist[r], &R.bi_bits[r], tabs);
       R.bi_cost[r] = cost;
       if (cost < cost_bi) {
         cost_bi = cost;

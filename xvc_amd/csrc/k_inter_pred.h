@@ -21,12 +21,6 @@
 #include "k_interp.h"
 #include "xvcgpu_internal.h"
 
-#define XVC_MAX_REF_SLOTS 10  // 2 lists x kMaxNumRefPics (common.h:144)
-
-struct RefTable {
-  PicView pic[XVC_MAX_REF_SLOTS];
-};
-
 // One output sample of MotionCompUniPred at full-pel pointer `s` (the sample's
 // own position displaced by the integer vector): BIPRED = false -> Sample
 // (FilterLuma / FilterChroma, :1387-1448), true -> the 14-bit int16

@@ -750,7 +750,8 @@ __device__ __forceinline__ void
 me_search_wave_body(const PicView &orig, const PicView &ref,
                     const xvcgpu_me_block *blocks, int n,
                     xvcgpu_me_result *results, const TzCand *tz_pattern,
-                    Me2Sched sched, int max_launched, bool lic_launched) {
+                    Me2Sched sched, int max_launched, bool lic_launched,
+                    const RefTable *refs = nullptr, const uint8_t *slots = nullptr) {
   constexpr int WPG = ME2_WAVES(MS);
   constexpr bool kSched = !LIC && (PH & XVCGPU_ME_FULLPEL) != 0;
   typedef Me2SharedT<MS, (PH & XVCGPU_ME_SUBPEL) != 0> Shared;
@@ -795,7 +796,13 @@ me_search_wave_body(const PicView &orig, const PicView &ref,
     if (MS == 64 && PH == XVCGPU_ME_SUBPEL && me2_subpel_fast(b.w, b.h, orig.bd, LIC)) return;
   }
   const int lane = ME2_LANE;
-  const PlaneView po = orig.c[0], pr = ref.c[0];
+  // (the *_refs form: the job's own reference picture out of the launch's table)
+  int slot = 0;
+  if (slots) {
+    slot = __builtin_amdgcn_readfirstlane((int)slots[bi]);
+    if (slot >= XVC_MAX_REF_SLOTS) return;
+  }
+  const PlaneView po = orig.c[0], pr = slots ? refs->pic[slot].c[0] : ref.c[0];
   const int pic_w = po.w, pic_h = po.h;
 
   MeCtx c;
@@ -1161,6 +1168,18 @@ me_search_wave_kernel(PicView orig, PicView ref,
                                    lic_launched);
 }
 
+// The searches of one CU state into several reference pictures in one launch: job i
+// searches refs.pic[slots[i]] (a slot beyond the table: no job).  See
+// xvcgpu_me_search_refs.
+template <int MS, int PH>
+__global__ void __launch_bounds__(64 * ME2_WAVES(MS), ME2_MIN_WAVES(MS))
+me_search_refs_kernel(PicView orig, RefTable refs, const uint8_t *slots,
+                      const xvcgpu_me_block *blocks, int n, xvcgpu_me_result *results,
+                      const TzCand *tz_pattern, Me2Sched sched, int max_launched) {
+  me_search_wave_body<MS, PH, false>(orig, orig, blocks, n, results, tz_pattern, sched,
+                                     max_launched, false, &refs, slots);
+}
+
 // The searches of several pictures in one launch (grid y = picture): see
 // xvcgpu_frame_pass_multi.  16-class, both phases.
 struct MeMultiArgs {
@@ -1237,9 +1256,10 @@ __device__ __forceinline__ void me2_team_eval(Me2Shared<MS> &s, const MeCtx &c,
 }
 
 template <int MS, int NW>
-__global__ void __launch_bounds__(64 * NW)
-me_subpel_team_kernel(PicView orig, PicView ref, const xvcgpu_me_block *blocks, int n,
-                      xvcgpu_me_result *results) {
+__device__ __forceinline__ void
+me_subpel_team_body(const PicView &orig, const PicView &ref, const xvcgpu_me_block *blocks, int n,
+                    xvcgpu_me_result *results, const RefTable *refs = nullptr,
+                    const uint8_t *slots = nullptr) {
   __shared__ Me2Shared<MS> s;
   const int bi = xcd_job_index(blockIdx.x, n);
   if (bi < 0) return;
@@ -1252,7 +1272,12 @@ me_subpel_team_kernel(PicView orig, PicView ref, const xvcgpu_me_block *blocks, 
       return;
   }
   const int tid = threadIdx.x, lane = ME2_LANE;
-  const PlaneView po = orig.c[0], pr = ref.c[0];
+  int slot = 0;
+  if (slots) {
+    slot = __builtin_amdgcn_readfirstlane((int)slots[bi]);
+    if (slot >= XVC_MAX_REF_SLOTS) return;
+  }
+  const PlaneView po = orig.c[0], pr = slots ? refs->pic[slot].c[0] : ref.c[0];
   const int pic_w = po.w, pic_h = po.h;
   MeCtx c;
   c.bd = orig.bd;
@@ -1323,6 +1348,20 @@ me_subpel_team_kernel(PicView orig, PicView ref, const xvcgpu_me_block *blocks, 
     res.subpel_dist = best_dist;
   }
   if (tid == 0) results[bi] = res;
+}
+
+template <int MS, int NW>
+__global__ void __launch_bounds__(64 * NW)
+me_subpel_team_kernel(PicView orig, PicView ref, const xvcgpu_me_block *blocks, int n,
+                      xvcgpu_me_result *results) {
+  me_subpel_team_body<MS, NW>(orig, ref, blocks, n, results);
+}
+
+template <int MS, int NW>
+__global__ void __launch_bounds__(64 * NW)
+me_subpel_team_refs_kernel(PicView orig, RefTable refs, const uint8_t *slots,
+                           const xvcgpu_me_block *blocks, int n, xvcgpu_me_result *results) {
+  me_subpel_team_body<MS, NW>(orig, orig, blocks, n, results, &refs, slots);
 }
 
 #endif  // XVCGPU_K_ME2_H_

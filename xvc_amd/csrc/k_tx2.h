@@ -514,4 +514,44 @@ residual_wave_kernel(PicView orig, PicView pred, PicView rec, const xvcgpu_tx_bl
   residual_wave_kernel_body<MODE, RDOQ>(orig, pred, rec, blocks, n, levels, level_off, nnz_out, tx_tables, tx_tables_t, lay, rq_ctx, rq_prm, dist_out);
 }
 
+// The transform blocks of ONE CU state's evaluation (a handful, small and large mixed)
+// in one launch: a workgroup per block, which takes the one-wave path (tx2_job) or the
+// workgroup path (residual_job) as residual_wave_kernel / residual_per_job_kernel
+// would - the same functions, so the same results.  The two kernels one after the
+// other are two wave lives (16 + 25 us with RDOQ) for a batch that fills neither.
+// grid: n; block: TX_THREADS.
+template <int MODE, bool RDOQ>
+__global__ void __launch_bounds__(TX_THREADS)
+residual_cu_kernel(PicView orig, PicView pred, PicView rec, const xvcgpu_tx_block *blocks, int n,
+                   int16_t *levels, const uint32_t *level_off, int32_t *nnz_out,
+                   const int16_t *tx_tables, const int16_t *tx_tables_t, TxTableLayout lay,
+                   const xvcgpu_rdoq_contexts *rq_ctx, const xvcgpu_rdoq_params *rq_prm) {
+  struct Big {
+    TxShared s;
+    RdoqShared<RDOQ ? 1024 : 4> rq;
+  };
+  struct Small {
+    Tx2Shared s;
+    RdoqShared<256> rq;
+  };
+  constexpr size_t kBytes = sizeof(Big) > sizeof(Small) ? sizeof(Big) : sizeof(Small);
+  __shared__ __attribute__((aligned(16))) unsigned char raw[kBytes];
+  const int idx = blockIdx.x;
+  if (idx >= n) return;
+  const xvcgpu_tx_block b = blocks[idx];
+  if (tx_small_job(b)) {
+    if (threadIdx.x >= 64) return;
+    Small &u = *reinterpret_cast<Small *>(raw);
+    const PlaneView pp = pred.c[b.comp];
+    tx2_job<MODE, 64, RDOQ>(u.s, b, idx, pred.bd, orig.c[b.comp],
+                            pp.p + (ptrdiff_t)b.y * pp.stride + b.x, pp.stride, rec.c[b.comp],
+                            levels, level_off, nnz_out, tx_tables, tx_tables_t, lay, nullptr, 0,
+                            &u.rq, rq_ctx, rq_prm, nullptr);
+  } else {
+    Big &u = *reinterpret_cast<Big *>(raw);
+    residual_job<MODE, RDOQ ? 1024 : 4>(u.s, idx, orig, pred, rec, blocks, levels, level_off,
+                                        nnz_out, tx_tables, lay, &u.rq, rq_ctx, rq_prm, nullptr);
+  }
+}
+
 #endif  // XVCGPU_K_TX2_H_

@@ -149,6 +149,13 @@ void launch_residual_rdoq(xvcgpu_ctx *ctx, const PicView &o, const PicView &p,
                           const PicView &r, const xvcgpu_tx_block *d_blocks, int n,
                           int16_t *d_levels, const uint32_t *d_off, int32_t *d_nnz,
                           const xvcgpu_rdoq_contexts *d_ctx, const xvcgpu_rdoq_params *d_prm) {
+  // a CU state's evaluation: its few blocks as one launch, a workgroup each
+  if (n <= 64) {
+    hipLaunchKernelGGL((residual_cu_kernel<TX_MODE_FULL, true>), dim3(n), dim3(TX_THREADS), 0,
+                       ctx->stream, o, p, r, d_blocks, n, d_levels, d_off, d_nnz,
+                       ctx->d_tx_tables, ctx->d_tx_tables_t, xvcgpu_tx_layout(), d_ctx, d_prm);
+    return;
+  }
   const int n_wg = (n + TX2_WAVES - 1) / TX2_WAVES;
   hipLaunchKernelGGL((residual_wave_kernel<TX_MODE_FULL, true>), dim3((n_wg + 7) / 8 * 8),
                      dim3(64 * TX2_WAVES), 0, ctx->stream, o, p, r, d_blocks, n,
@@ -2301,6 +2308,135 @@ xvcgpu_status xvcgpu_affine_me_batch(xvcgpu_ctx *ctx, const xvcgpu_picture *orig
   hipLaunchKernelGGL(affine_me_kernel<4>, dim3(n), dim3(256), 0, ctx->stream, orig->v.c[0],
                      ref->v.c[0], ref_other->v.c[0], ref->v.bd, d_blocks, n, d_results);
   CHECK_LAUNCH(ctx, "affine_me_batch");
+  return XVCGPU_OK;
+}
+
+/* ---- the searches of one CU state into several reference pictures, one launch each ---
+ * A CU state's SearchMotion runs the same step for every (list, picture) of the CU:
+ * with the single-picture entry points that is one launch per picture, each with one
+ * job, one after the other.  Here the pictures come as a table and every job names its
+ * slot, so the step is ONE launch whose jobs run side by side; and the caller says
+ * which block-size class its jobs are (a CU state's jobs all have the CU's size), so
+ * only that class's instances are launched. */
+static xvcgpu_status ref_table_of(xvcgpu_ctx *ctx, const xvcgpu_picture *orig,
+                                  const xvcgpu_picture *const *refs, int n_refs, RefTable *t) {
+  if (!refs || n_refs < 1 || n_refs > XVC_MAX_REF_SLOTS) return XVCGPU_INVALID_ARGUMENT;
+  memset(t, 0, sizeof(*t));
+  for (int i = 0; i < n_refs; i++) {
+    if (!refs[i]) return XVCGPU_INVALID_ARGUMENT;
+    if (refs[i]->w != orig->w || refs[i]->h != orig->h || refs[i]->bd != orig->bd)
+      return fail(ctx, XVCGPU_INVALID_ARGUMENT, "reference picture mismatch");
+    t->pic[i] = refs[i]->v;
+  }
+  return XVCGPU_OK;
+}
+
+xvcgpu_status xvcgpu_me_search_refs(xvcgpu_ctx *ctx, const xvcgpu_picture *orig,
+                                    const xvcgpu_picture *const *refs, int n_refs, int flags,
+                                    const xvcgpu_me_block *d_blocks, const uint8_t *d_slots,
+                                    int n, xvcgpu_me_result *d_results, int block_class) {
+  if (!ctx || !orig || n < 0 || (n && (!d_blocks || !d_slots || !d_results)) ||
+      !(flags & (XVCGPU_ME_FULLPEL | XVCGPU_ME_SUBPEL)) || (flags & XVCGPU_ME_LIC_JOBS) ||
+      (block_class != 16 && block_class != 32 && block_class != 64))
+    return XVCGPU_INVALID_ARGUMENT;
+  RefTable t;
+  const xvcgpu_status st = ref_table_of(ctx, orig, refs, n_refs, &t);
+  if (st != XVCGPU_OK) return st;
+  if (n == 0) return XVCGPU_OK;
+  Me2Sched sched = {nullptr, nullptr, nullptr};
+  if (flags & XVCGPU_ME_FULLPEL) {
+    const int e = ctx->me_epoch = (ctx->me_epoch + 1) % 3;
+    sched.use = ctx->d_me_rot + e % 3;
+    sched.record = ctx->d_me_rot + (e + 1) % 3;
+    sched.clear = ctx->d_me_rot + (e + 2) % 3;
+  }
+#define ME_REFS(MS, PH)                                                                      \
+  hipLaunchKernelGGL((me_search_refs_kernel<MS, PH>), me2_grid(n, ME2_WAVES(MS)),            \
+                     dim3(64 * ME2_WAVES(MS)), 0, ctx->stream, orig->v, t, d_slots, d_blocks, \
+                     n, d_results, ctx->d_tz_pattern, sched, block_class)
+#define ME_REFS_SPLIT(MS)                            \
+  do {                                               \
+    if (flags & XVCGPU_ME_FULLPEL) ME_REFS(MS, 1);   \
+    if (flags & XVCGPU_ME_SUBPEL) ME_REFS(MS, 2);    \
+  } while (0)
+  if (block_class == 16) {
+    if ((flags & 3) == 3) ME_REFS(16, 3);
+    else ME_REFS_SPLIT(16);
+  } else if (block_class == 32) {
+    ME_REFS_SPLIT(32);
+  } else {
+    ME_REFS_SPLIT(64);
+    if (flags & XVCGPU_ME_SUBPEL)
+      hipLaunchKernelGGL((me_subpel_team_refs_kernel<64, 4>), dim3((n + 7) / 8 * 8), dim3(256), 0,
+                         ctx->stream, orig->v, t, d_slots, d_blocks, n, d_results);
+  }
+#undef ME_REFS_SPLIT
+#undef ME_REFS
+  CHECK_LAUNCH(ctx, "me_search_refs");
+  return XVCGPU_OK;
+}
+
+xvcgpu_status xvcgpu_bipred_search_refs(xvcgpu_ctx *ctx, const xvcgpu_picture *orig,
+                                        const xvcgpu_picture *const *refs, int n_refs,
+                                        const xvcgpu_bi_block *d_jobs, const uint8_t *d_slots,
+                                        int n, xvcgpu_me_result *d_results, int block_class) {
+  if (!ctx || !orig || n < 0 || (n && (!d_jobs || !d_slots || !d_results)) ||
+      (block_class != 16 && block_class != 32 && block_class != 64))
+    return XVCGPU_INVALID_ARGUMENT;
+  RefTable t;
+  const xvcgpu_status st = ref_table_of(ctx, orig, refs, n_refs, &t);
+  if (st != XVCGPU_OK) return st;
+  if (n == 0) return XVCGPU_OK;
+  const dim3 grid((n + 7) / 8 * 8);
+#define BI_REFS(MS)                                                                          \
+  hipLaunchKernelGGL((bipred_search_refs_kernel<MS>), grid, dim3(64 * BI_WAVES(MS)), 0,      \
+                     ctx->stream, orig->v.c[0], t, d_slots, orig->bd, d_jobs, n, d_results,  \
+                     block_class)
+  if (block_class == 16) BI_REFS(16);
+  else if (block_class == 32) BI_REFS(32);
+  else BI_REFS(64);
+#undef BI_REFS
+  CHECK_LAUNCH(ctx, "bipred_search_refs");
+  return XVCGPU_OK;
+}
+
+xvcgpu_status xvcgpu_mc_metric_batch_refs(xvcgpu_ctx *ctx, const xvcgpu_picture *orig,
+                                          const xvcgpu_picture *const *refs, int n_refs,
+                                          int structural_strength,
+                                          const xvcgpu_mc_metric_cand *d_cands,
+                                          const uint8_t *d_slots, int n, uint64_t *d_out) {
+  if (!ctx || !orig || n < 0 || (n && (!d_cands || !d_slots || !d_out)))
+    return XVCGPU_INVALID_ARGUMENT;
+  RefTable t;
+  const xvcgpu_status st = ref_table_of(ctx, orig, refs, n_refs, &t);
+  if (st != XVCGPU_OK) return st;
+  if (n == 0) return XVCGPU_OK;
+  hipLaunchKernelGGL(mc_metric_refs_kernel, dim3((n + 1) / 2), dim3(128), 0, ctx->stream,
+                     orig->v.c[0], t, d_slots, orig->bd, structural_strength, d_cands, n, d_out);
+  CHECK_LAUNCH(ctx, "mc_metric_batch_refs");
+  return XVCGPU_OK;
+}
+
+xvcgpu_status xvcgpu_affine_me_batch_refs(xvcgpu_ctx *ctx, const xvcgpu_picture *orig,
+                                          const xvcgpu_picture *const *refs, int n_refs,
+                                          const xvcgpu_affine_me_block *d_blocks,
+                                          const uint8_t *d_slots, int n,
+                                          xvcgpu_affine_me_result *d_results, int cu_height) {
+  if (!ctx || !orig || n < 0 || (n && (!d_blocks || !d_slots || !d_results)) ||
+      (cu_height != 16 && cu_height != 32 && cu_height != 64))
+    return XVCGPU_INVALID_ARGUMENT;
+  RefTable t;
+  const xvcgpu_status st = ref_table_of(ctx, orig, refs, n_refs, &t);
+  if (st != XVCGPU_OK) return st;
+  if (n == 0) return XVCGPU_OK;
+#define AFF_REFS(NW)                                                                      \
+  hipLaunchKernelGGL(affine_me_refs_kernel<NW>, dim3(n), dim3(64 * NW), 0, ctx->stream,   \
+                     orig->v.c[0], t, d_slots, orig->bd, d_blocks, n, d_results)
+  if (cu_height == 16) AFF_REFS(1);
+  else if (cu_height == 32) AFF_REFS(2);
+  else AFF_REFS(4);
+#undef AFF_REFS
+  CHECK_LAUNCH(ctx, "affine_me_batch_refs");
   return XVCGPU_OK;
 }
 

@@ -25,6 +25,14 @@ struct PicView {
   int bd;
 };
 
+// The reference pictures of a batch as a table indexed by a job's slot: one launch
+// covers the pictures of both lists (k_inter_pred.h, the *_refs searches).
+#define XVC_MAX_REF_SLOTS 10  // 2 lists x kMaxNumRefPics (common.h:144)
+
+struct RefTable {
+  PicView pic[XVC_MAX_REF_SLOTS];
+};
+
 struct xvcgpu_ctx {
   int device;
   hipStream_t stream;

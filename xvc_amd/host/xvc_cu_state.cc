@@ -225,108 +225,170 @@ extern "C" void xvc_host_cs_sizes(int32_t out[7]) {
 // (tests/rd_serial.py writes it from the state table; an encoder would emit the same
 // ops as it walks its CU tree).  No op looks at a result: the only wait is the SYNC that
 // ends a chain.
+namespace {
+// one op of a chain program (SYNC is the caller's)
+xvcgpu_status IssueOp(xvcgpu_ctx *ctx, const xvc_cs_env *env, const xvc_cs_op &o) {
+  const xvcgpu_picture *pics[4] = {env->orig, env->s_orig, env->s_pred, env->s_rec};
+  void *const *p = reinterpret_cast<void *const *>(o.p);
+  switch (o.opcode) {
+    case XVC_OP_MC_METRIC:
+      return xvcgpu_mc_metric_batch(ctx, env->orig, env->refs[o.r0], 16,
+                                    static_cast<const xvcgpu_mc_metric_cand *>(p[0]), o.n,
+                                    static_cast<uint64_t *>(p[1]));
+    case XVC_OP_METRIC:
+      return xvcgpu_metric_batch(ctx, pics[o.r0], pics[o.r1], o.i0, o.f, 16,
+                                 static_cast<const xvcgpu_metric_cand *>(p[0]), o.n,
+                                 static_cast<uint64_t *>(p[1]));
+    case XVC_OP_ME:
+      return xvcgpu_me_search_sized(ctx, env->orig, env->refs[o.r0],
+                                    XVCGPU_ME_FULLPEL | XVCGPU_ME_SUBPEL,
+                                    static_cast<const xvcgpu_me_block *>(p[0]), o.n,
+                                    static_cast<xvcgpu_me_result *>(p[1]), o.i0);
+    case XVC_OP_BI:
+      return xvcgpu_bipred_search(ctx, env->orig, env->refs[o.r1], env->refs[o.r0],
+                                  static_cast<const xvcgpu_bi_block *>(p[0]), o.n,
+                                  static_cast<xvcgpu_me_result *>(p[1]), o.i0);
+    case XVC_OP_AFFINE:
+      return xvcgpu_affine_me_batch(ctx, env->orig, env->refs[o.r0], env->refs[o.r1],
+                                    static_cast<const xvcgpu_affine_me_block *>(p[0]), o.n,
+                                    static_cast<xvcgpu_affine_me_result *>(p[1]));
+    case XVC_OP_COPY:
+      return xvcgpu_copy_blocks(ctx, pics[o.r0], const_cast<xvcgpu_picture *>(pics[o.r1]),
+                                static_cast<const xvcgpu_copy_block *>(p[0]), o.n);
+    case XVC_OP_INTER_PRED:
+      return xvcgpu_inter_pred_batch_to(ctx, env->refs, env->n_refs, env->orig,
+                                        const_cast<xvcgpu_picture *>(pics[o.r1]),
+                                        static_cast<const xvcgpu_inter_block *>(p[0]),
+                                        static_cast<const xvcgpu_block_pos *>(p[1]), o.n);
+    case XVC_OP_RESIDUAL:
+      return xvcgpu_residual_rdoq_batch(ctx, env->s_orig, env->s_pred, env->s_rec,
+                                        static_cast<const xvcgpu_tx_block *>(p[0]), o.n,
+                                        env->d_levels, static_cast<const uint32_t *>(p[1]),
+                                        static_cast<int32_t *>(p[2]),
+                                        static_cast<const xvcgpu_rdoq_contexts *>(p[3]),
+                                        static_cast<const xvcgpu_rdoq_params *>(p[4]));
+    case XVC_OP_START_FOLD:
+      return xvcgpu_cs_start_fold(ctx, static_cast<const xvcgpu_cs_pass *>(p[0]), o.i0, o.n,
+                                  static_cast<const uint64_t *>(p[1]),
+                                  static_cast<xvcgpu_me_block *>(p[2]),
+                                  static_cast<const xvcgpu_me_result *>(p[3]),
+                                  static_cast<xvcgpu_affine_me_block *>(p[4]), env->d_results,
+                                  env->pic_w, env->pic_h);
+    case XVC_OP_UNI_FOLD:
+      return xvcgpu_cs_uni_fold(ctx, static_cast<const xvcgpu_cs_pass *>(p[0]), o.i0, o.n,
+                                static_cast<const xvcgpu_me_result *>(p[1]),
+                                static_cast<const xvcgpu_affine_me_result *>(p[2]),
+                                env->d_results, static_cast<xvcgpu_bi_block *>(p[3]),
+                                static_cast<xvcgpu_affine_me_block *>(p[4]));
+    case XVC_OP_BI_FOLD:
+      return xvcgpu_cs_bi_fold(ctx, static_cast<const xvcgpu_cs_pass *>(p[0]), o.i0, o.n,
+                               static_cast<const xvcgpu_me_result *>(p[1]),
+                               static_cast<const xvcgpu_affine_me_result *>(p[2]),
+                               env->d_results, static_cast<xvcgpu_inter_block *>(p[3]));
+    case XVC_OP_EVAL_DIST:
+      return xvcgpu_eval_dist_batch(ctx, env->s_orig, env->s_pred, env->s_rec, 16,
+                                    static_cast<const xvcgpu_eval_cand *>(p[0]), o.n,
+                                    static_cast<uint64_t *>(p[1]));
+    case XVC_OP_FETCH:
+      return xvcgpu_memcpy_d2h_async(ctx, p[1], p[0], static_cast<size_t>(o.n));
+    case XVC_OP_MC_METRIC_REFS:
+      return xvcgpu_mc_metric_batch_refs(ctx, env->orig, env->refs, env->n_refs, 16,
+                                         static_cast<const xvcgpu_mc_metric_cand *>(p[0]),
+                                         static_cast<const uint8_t *>(p[2]), o.n,
+                                         static_cast<uint64_t *>(p[1]));
+    case XVC_OP_ME_REFS:
+      return xvcgpu_me_search_refs(ctx, env->orig, env->refs, env->n_refs,
+                                   XVCGPU_ME_FULLPEL | XVCGPU_ME_SUBPEL,
+                                   static_cast<const xvcgpu_me_block *>(p[0]),
+                                   static_cast<const uint8_t *>(p[2]), o.n,
+                                   static_cast<xvcgpu_me_result *>(p[1]), o.i0);
+    case XVC_OP_BI_REFS:
+      return xvcgpu_bipred_search_refs(ctx, env->orig, env->refs, env->n_refs,
+                                       static_cast<const xvcgpu_bi_block *>(p[0]),
+                                       static_cast<const uint8_t *>(p[2]), o.n,
+                                       static_cast<xvcgpu_me_result *>(p[1]), o.i0);
+    case XVC_OP_AFFINE_REFS:
+      return xvcgpu_affine_me_batch_refs(ctx, env->orig, env->refs, env->n_refs,
+                                         static_cast<const xvcgpu_affine_me_block *>(p[0]),
+                                         static_cast<const uint8_t *>(p[2]), o.n,
+                                         static_cast<xvcgpu_affine_me_result *>(p[1]), o.i0);
+    default:
+      return XVCGPU_INVALID_ARGUMENT;
+  }
+}
+}  // namespace
+
 extern "C" int xvc_host_cs_run_program(xvcgpu_ctx *ctx, const xvc_cs_env *env,
                                        const xvc_cs_op *ops, int64_t n_ops, xvc_cs_stats *stats) {
   if (!ctx || !env || !ops || !stats || n_ops < 0) return XVCGPU_INVALID_ARGUMENT;
   std::memset(stats, 0, sizeof(*stats));
   xvcgpu_status st = xvcgpu_sync(ctx);
   if (st != XVCGPU_OK) return st;
-  const xvcgpu_picture *pics[4] = {env->orig, env->s_orig, env->s_pred, env->s_rec};
   const double t0 = Now();
   double chain_t0 = t0;
   for (int64_t i = 0; i < n_ops && st == XVCGPU_OK; i++) {
     const xvc_cs_op &o = ops[i];
-    void *const *p = reinterpret_cast<void *const *>(o.p);
-    switch (o.opcode) {
-      case XVC_OP_MC_METRIC:
-        st = xvcgpu_mc_metric_batch(ctx, env->orig, env->refs[o.r0], 16,
-                                    static_cast<const xvcgpu_mc_metric_cand *>(p[0]), o.n,
-                                    static_cast<uint64_t *>(p[1]));
-        break;
-      case XVC_OP_METRIC:
-        st = xvcgpu_metric_batch(ctx, pics[o.r0], pics[o.r1], o.i0, o.f, 16,
-                                 static_cast<const xvcgpu_metric_cand *>(p[0]), o.n,
-                                 static_cast<uint64_t *>(p[1]));
-        break;
-      case XVC_OP_ME:
-        st = xvcgpu_me_search_sized(ctx, env->orig, env->refs[o.r0],
-                                    XVCGPU_ME_FULLPEL | XVCGPU_ME_SUBPEL,
-                                    static_cast<const xvcgpu_me_block *>(p[0]), o.n,
-                                    static_cast<xvcgpu_me_result *>(p[1]), o.i0);
-        break;
-      case XVC_OP_BI:
-        st = xvcgpu_bipred_search(ctx, env->orig, env->refs[o.r1], env->refs[o.r0],
-                                  static_cast<const xvcgpu_bi_block *>(p[0]), o.n,
-                                  static_cast<xvcgpu_me_result *>(p[1]), o.i0);
-        break;
-      case XVC_OP_AFFINE:
-        st = xvcgpu_affine_me_batch(ctx, env->orig, env->refs[o.r0], env->refs[o.r1],
-                                    static_cast<const xvcgpu_affine_me_block *>(p[0]), o.n,
-                                    static_cast<xvcgpu_affine_me_result *>(p[1]));
-        break;
-      case XVC_OP_COPY:
-        st = xvcgpu_copy_blocks(ctx, pics[o.r0], const_cast<xvcgpu_picture *>(pics[o.r1]),
-                                static_cast<const xvcgpu_copy_block *>(p[0]), o.n);
-        break;
-      case XVC_OP_INTER_PRED:
-        st = xvcgpu_inter_pred_batch_to(ctx, env->refs, env->n_refs, env->orig,
-                                        const_cast<xvcgpu_picture *>(pics[o.r1]),
-                                        static_cast<const xvcgpu_inter_block *>(p[0]),
-                                        static_cast<const xvcgpu_block_pos *>(p[1]), o.n);
-        break;
-      case XVC_OP_RESIDUAL:
-        st = xvcgpu_residual_rdoq_batch(ctx, env->s_orig, env->s_pred, env->s_rec,
-                                        static_cast<const xvcgpu_tx_block *>(p[0]), o.n,
-                                        env->d_levels, static_cast<const uint32_t *>(p[1]),
-                                        static_cast<int32_t *>(p[2]),
-                                        static_cast<const xvcgpu_rdoq_contexts *>(p[3]),
-                                        static_cast<const xvcgpu_rdoq_params *>(p[4]));
-        break;
-      case XVC_OP_START_FOLD:
-        st = xvcgpu_cs_start_fold(ctx, static_cast<const xvcgpu_cs_pass *>(p[0]), o.i0, o.n,
-                                  static_cast<const uint64_t *>(p[1]),
-                                  static_cast<xvcgpu_me_block *>(p[2]),
-                                  static_cast<const xvcgpu_me_result *>(p[3]),
-                                  static_cast<xvcgpu_affine_me_block *>(p[4]),
-                                  env->d_results, env->pic_w, env->pic_h);
-        break;
-      case XVC_OP_UNI_FOLD:
-        st = xvcgpu_cs_uni_fold(ctx, static_cast<const xvcgpu_cs_pass *>(p[0]), o.i0, o.n,
-                                static_cast<const xvcgpu_me_result *>(p[1]),
-                                static_cast<const xvcgpu_affine_me_result *>(p[2]),
-                                env->d_results, static_cast<xvcgpu_bi_block *>(p[3]),
-                                static_cast<xvcgpu_affine_me_block *>(p[4]));
-        break;
-      case XVC_OP_BI_FOLD:
-        st = xvcgpu_cs_bi_fold(ctx, static_cast<const xvcgpu_cs_pass *>(p[0]), o.i0, o.n,
-                               static_cast<const xvcgpu_me_result *>(p[1]),
-                               static_cast<const xvcgpu_affine_me_result *>(p[2]),
-                               env->d_results, static_cast<xvcgpu_inter_block *>(p[3]));
-        break;
-      case XVC_OP_EVAL_DIST:
-        st = xvcgpu_eval_dist_batch(ctx, env->s_orig, env->s_pred, env->s_rec, 16,
-                                    static_cast<const xvcgpu_eval_cand *>(p[0]), o.n,
-                                    static_cast<uint64_t *>(p[1]));
-        break;
-      case XVC_OP_FETCH:
-        st = xvcgpu_memcpy_d2h_async(ctx, p[1], p[0], static_cast<size_t>(o.n));
-        stats->api_calls--;          // a copy, not a launch
-        break;
-      case XVC_OP_SYNC: {            // the end of a chain: i0 = states it held, r0 = kind
-        st = xvcgpu_sync(ctx);
-        stats->round_trips++;
-        stats->states += o.i0;
-        const double now = Now();
-        const int k = o.r0 >= 0 && o.r0 < 4 ? o.r0 : 0;
-        stats->seconds_by_kind[k] += now - chain_t0;
-        stats->states_by_kind[k] += o.i0;
-        chain_t0 = now;
-        stats->api_calls--;
-        break;
-      }
-      default: return XVCGPU_INVALID_ARGUMENT;
+    if (o.opcode == XVC_OP_SYNC) {   // the end of a chain: i0 = states it held, r0 = kind
+      st = xvcgpu_sync(ctx);
+      stats->round_trips++;
+      stats->states += o.i0;
+      const double now = Now();
+      const int k = o.r0 >= 0 && o.r0 < 4 ? o.r0 : 0;
+      stats->seconds_by_kind[k] += now - chain_t0;
+      stats->states_by_kind[k] += o.i0;
+      chain_t0 = now;
+      continue;
     }
-    stats->api_calls++;
+    st = IssueOp(ctx, env, o);
+    if (o.opcode != XVC_OP_FETCH) stats->api_calls++;   // (a copy is not a launch)
+  }
+  stats->seconds = Now() - t0;
+  return st;
+}
+
+// k independent programs (k pictures in flight, each with its own context = stream,
+// arrays and scratch) driven by ONE thread: a chain's next state sequence is issued
+// while the other chains' run, and the thread comes back to wait for a chain only after
+// it has issued work for all the others.  (One thread per chain contends for the
+// runtime's submission path: four threads reach 2.5x of one, not 4x.)
+extern "C" int xvc_host_cs_run_programs_interleaved(int k, xvcgpu_ctx *const *ctxs,
+                                                    const xvc_cs_env *const *envs,
+                                                    const xvc_cs_op *const *ops,
+                                                    const int64_t *n_ops, xvc_cs_stats *stats) {
+  if (k < 1 || k > 64 || !ctxs || !envs || !ops || !n_ops || !stats)
+    return XVCGPU_INVALID_ARGUMENT;
+  std::memset(stats, 0, sizeof(*stats));
+  int64_t at[64];
+  int64_t waiting[64];               // states of the chain whose results are awaited, or -1
+  for (int c = 0; c < k; c++) {
+    at[c] = 0;
+    waiting[c] = -1;
+    const xvcgpu_status st = xvcgpu_sync(ctxs[c]);
+    if (st != XVCGPU_OK) return st;
+  }
+  const double t0 = Now();
+  int live = k;
+  xvcgpu_status st = XVCGPU_OK;
+  while (live > 0 && st == XVCGPU_OK) {
+    live = 0;
+    for (int c = 0; c < k && st == XVCGPU_OK; c++) {
+      if (waiting[c] >= 0) {         // issued a round ago: its results
+        st = xvcgpu_sync(ctxs[c]);
+        stats->round_trips++;
+        stats->states += waiting[c];
+        waiting[c] = -1;
+      }
+      while (at[c] < n_ops[c] && st == XVCGPU_OK) {
+        const xvc_cs_op &o = ops[c][at[c]++];
+        if (o.opcode == XVC_OP_SYNC) {
+          waiting[c] = o.i0;
+          break;
+        }
+        st = IssueOp(ctxs[c], envs[c], o);
+        if (o.opcode != XVC_OP_FETCH) stats->api_calls++;
+      }
+      if (waiting[c] >= 0 || at[c] < n_ops[c]) live++;
+    }
   }
   stats->seconds = Now() - t0;
   return st;

@@ -114,11 +114,14 @@ typedef struct xvc_cs_stats {
 // The chained form's program: one op = one C-ABI call on arrays the host filled before
 // (p[]: device pointers; FETCH: p[0] device -> p[1] host, n bytes).  r0 / r1: reference
 // picture slots, or picture selectors 0 original, 1 scratch originals, 2 scratch
-// predictions, 3 scratch reconstructions (METRIC, COPY, INTER_PRED).
+// predictions, 3 scratch reconstructions (METRIC, COPY, INTER_PRED).  The *_REFS ops are
+// a step into all the CU's reference pictures as one launch (xvcgpu_*_refs): p[0] jobs,
+// p[1] results, p[2] the jobs' slot bytes, i0 = block class / CU height.
 enum {
   XVC_OP_MC_METRIC = 0, XVC_OP_METRIC, XVC_OP_ME, XVC_OP_BI, XVC_OP_AFFINE, XVC_OP_COPY,
   XVC_OP_INTER_PRED, XVC_OP_RESIDUAL, XVC_OP_START_FOLD, XVC_OP_UNI_FOLD, XVC_OP_BI_FOLD,
-  XVC_OP_FETCH, XVC_OP_SYNC, XVC_OP_EVAL_DIST
+  XVC_OP_FETCH, XVC_OP_SYNC, XVC_OP_EVAL_DIST, XVC_OP_MC_METRIC_REFS, XVC_OP_ME_REFS,
+  XVC_OP_BI_REFS, XVC_OP_AFFINE_REFS
 };
 typedef struct xvc_cs_op {
   int32_t opcode, n, r0, r1, i0, reserved;
@@ -137,6 +140,12 @@ typedef struct xvc_cs_env {
 extern "C" {
 int xvc_host_cs_run_program(xvcgpu_ctx *ctx, const xvc_cs_env *env, const xvc_cs_op *ops,
                             int64_t n_ops, xvc_cs_stats *stats);
+// k chains (their own contexts, environments, programs) driven by one thread, a chain's
+// next sequence issued while the others' run.
+int xvc_host_cs_run_programs_interleaved(int k, xvcgpu_ctx *const *ctxs,
+                                         const xvc_cs_env *const *envs,
+                                         const xvc_cs_op *const *ops, const int64_t *n_ops,
+                                         xvc_cs_stats *stats);
 
 // The states [first, first + n) walked ONE AT A TIME with the batched entry points as
 // they are: every step a batch of one CU, a read-back (copy + wait) wherever the
