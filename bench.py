@@ -332,13 +332,13 @@ def encoder_rd_serial_figure(ctx, api, fx, pics, w, h, n_states=4000):
                         serial["summary"]["motion_only"], serial["states_walked"]),
         "us_per_cu_state": s1["us_per_cu_state"],
         "launches_per_state": {"entry_point_calls": s1["api_calls_per_state"],
-                               "kernel_launches_rocprof": 15.7,
-                               "note": "rocprofv3 --kernel-trace of tools/cu_state_walk.py "
-                                       "(3000 states): 47 156 launches serial (12 887 of them "
-                                       "result copies), 56 553 chained - "
+                               "kernel_launches_rocprof": {"serial": 13.96, "chained": 7.17},
+                               "note": "rocprofv3 --kernel-trace of tools/cu_state_walk.py --no-check "
+                                       "(3000 + 200 warm-up states): 44 660 launches serial (12 887 of "
+                                       "them result copies), 22 947 chained (1 502 copies) - "
                                        "profiles/r04_cu_state_{serial,chained}_kernel_stats.csv; "
-                                       "the kernels' summed duration equals the wall time: a "
-                                       "state is a string of 3-30 us kernels on one CU each"},
+                                       "the kernels' summed duration is the wall time: a state is a "
+                                       "string of dependent 4-30 us kernels on a few CUs each"},
         "round_trips_per_state": s1["round_trips_per_state"],
         "pictures_per_s": {k: v["pictures_per_s"] for k, v in serial["chains"].items()},
         "us_by_state_kind": s1["us_by_kind"],
@@ -348,12 +348,20 @@ def encoder_rd_serial_figure(ctx, api, fx, pics, w, h, n_states=4000):
                     "states_per_chain": c1["states_per_chain"],
                     "fewer_round_trips": s1["round_trips_per_state"] / c1["round_trips_per_state"],
                     "pictures_per_s": {k: v["pictures_per_s"] for k, v in chained["chains"].items()},
+                    "pictures_per_s_one_host_thread": {
+                        k: v["one_thread"]["pictures_per_s"] for k, v in chained["chains"].items()
+                        if "one_thread" in v},
+                    "form": "every step of SearchMotion into all the CU's reference pictures as one "
+                            "launch (xvcgpu_*_refs), a state's transform blocks as one launch, "
+                            "one read-back per result array and chain",
                     "compared": c1.get("compared")},
         "compared": s1.get("compared"),
         "matches_reference": bool(ok),
-        "reading": "both forms are bound by the number of dependent launches per state (the "
-                   "searches themselves are one CU each): ~10 us per entry point; fewer "
-                   "read-backs alone do not shorten a state"}
+        "reading": "both forms are bound by the chain of dependent kernels per state (each "
+                   "search is one CU's worth of work: 4-30 us, RDOQ's and the refinement's wave "
+                   "lives the longest): read-backs removed, the steps of the pictures of a list "
+                   "side by side and half the launches take a state from ~130 us to ~70 us; more "
+                   "than four chains in flight do not add up (tools/cu_state_walk.py --threads)"}
 
 
 def encoder_rd_figure(ctx, api, fx, pics, w, h):

@@ -19,7 +19,8 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
-def walk(api, clip, poc, n_states, ks, mode="serial", check=True, decoded=None, sp=None):
+def walk(api, clip, poc, n_states, ks, mode="serial", check=True, decoded=None, sp=None,
+         threads_list=()):
     """decoded: ({poc: device picture}, width, height) of the clip when the caller holds
     it already; sp: a rd_serial.SerialPicture to re-use."""
     import rd_serial
@@ -81,6 +82,28 @@ def walk(api, clip, poc, n_states, ks, mode="serial", check=True, decoded=None, 
             "us_by_kind": {name: 1e6 * s0.seconds_by_kind[i] / max(s0.states_by_kind[i], 1)
                            for i, name in enumerate(("merge_rank", "eval", "inter", "motion_only"))},
         }
+        if mode == "chained" and k > 1 and threads_list:
+            # T host threads, each driving k / T chains interleaved
+            entry["threads_x_chains"] = {}
+            for T in threads_list:
+                if T >= k or k % T:
+                    continue
+                groups = [runs[i::T] for i in range(T)]
+                out_t = [None] * T
+
+                def work_t(i):
+                    out_t[i] = rd_serial.ChainedRun.run_interleaved(groups[i], 0, n)
+                th = [threading.Thread(target=work_t, args=(i,)) for i in range(T)]
+                t0 = time.time()
+                for t in th:
+                    t.start()
+                for t in th:
+                    t.join()
+                wall_t = time.time() - t0
+                done_t = sum(x.states for x in out_t)
+                entry["threads_x_chains"]["%dx%d" % (T, k // T)] = {
+                    "states_per_s": done_t / wall_t,
+                    "pictures_per_s": done_t / wall_t / (s0.states * per_pic)}
         if mode == "chained" and k > 1:
             # the same k chains driven by ONE host thread, a chain issued while the
             # others execute (xvc_host_cs_run_programs_interleaved)
@@ -119,10 +142,12 @@ if __name__ == "__main__":
     ap.add_argument("--states", type=int, default=6000)
     ap.add_argument("--k", default="1,4,8,16")
     ap.add_argument("--mode", default="serial")
+    ap.add_argument("--threads", default="", help="also: T threads x k/T interleaved chains, e.g. 2,4")
     ap.add_argument("--no-check", action="store_true",
                     help="skip the comparison (and its second, verifying run): for kernel traces")
     a = ap.parse_args()
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     from xvc_amd import api
     print(json.dumps(walk(api, a.clip, a.poc, a.states, [int(x) for x in a.k.split(",")], a.mode,
-                          check=not a.no_check)))
+                          check=not a.no_check,
+                          threads_list=[int(x) for x in a.threads.split(",") if x])))

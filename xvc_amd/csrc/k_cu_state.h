@@ -205,28 +205,26 @@ __global__ void cs_uni_fold_kernel(const xvcgpu_cs_pass *passes, int first, int 
     }
   }
   __syncthreads();
-  auto body = [&]() {
-  const bool affine = cs_affine(p), fullpel = cs_fullpel(p);
-  R.cost_l1_unique = CS_MAXCOST;
-  R.best_ref_l1_unique = -1;
-  for (int l = 0; l < 2; l++) {
-    uint32_t cost_best = CS_MAXCOST;
-    int best = -1;
-    for (int r = 0; r < p.num_refs[l] && r < CS_R; r++) {
+  // SearchRefIdx's candidates, one lane per (list, picture): final predictor, syntax,
+  // price (a candidate is ~800 dependent instructions of one lane: side by side they
+  // cost one candidate's time)
+  if (threadIdx.x < 2 * CS_R) {
+    const bool affine = cs_affine(p), fullpel = cs_fullpel(p);
+    const int l = threadIdx.x / CS_R, r = threadIdx.x % CS_R;
+    if (r < p.num_refs[l]) {
       const int m = l == 1 ? p.same_poc_in_l0[r] : -1;
-      if (m >= 0) {                          // list 0 searched this picture already (:536-542)
-        cs_copy_mv(R.mv[l][r], R.mv[0][m]);
-        R.dist[l][r] = R.dist[0][m];
-      } else if (!affine) {
-        const xvcgpu_me_result &s = s_me[l * CS_R + r];
-        R.mv[l][r][0][0] = s.mv_x;
-        R.mv[l][r][0][1] = s.mv_y;
+      // list 0 searched this picture already (:536-542): its result
+      const int src = m >= 0 ? m : l * CS_R + r;
+      if (!affine) {
+        const xvcgpu_me_result &sr = s_me[src];
+        R.mv[l][r][0][0] = sr.mv_x;
+        R.mv[l][r][0][1] = sr.mv_y;
         for (int k = 1; k < 3; k++) R.mv[l][r][k][0] = R.mv[l][r][k][1] = 0;
-        R.dist[l][r] = s.subpel_dist;
+        R.dist[l][r] = sr.subpel_dist;
       } else {
-        const xvcgpu_affine_me_result &s = s_aff[l * CS_R + r];
-        cs_copy_mv(R.mv[l][r], s.mv);
-        R.dist[l][r] = s.dist;
+        const xvcgpu_affine_me_result &sr = s_aff[src];
+        cs_copy_mv(R.mv[l][r], sr.mv);
+        R.dist[l][r] = sr.dist;
       }
       const int idx = cs_final_mvp_idx(p.mvp[l][r], R.mv[l][r], R.start_idx[l][r], fullpel, affine);
       R.mvp_idx[l][r] = (uint8_t)idx;
@@ -237,8 +235,20 @@ __global__ void cs_uni_fold_kernel(const xvcgpu_cs_pass *passes, int first, int 
       syn.ref_idx[l] = (int8_t)r;
       syn.mvp_idx[l] = (uint8_t)idx;
       cs_set_mvd(syn.mvd[l], p.mvp[l][r][idx], R.mv[l][r], fullpel, affine);
-      const uint32_t cost = cs_price(p, syn, R.dist[l][r], &R.bits[l][r], tabs);
-      R.cost[l][r] = cost;
+      R.cost[l][r] = cs_price(p, syn, R.dist[l][r], &R.bits[l][r], tabs);
+    }
+  }
+  __syncthreads();
+  auto body = [&]() {
+  const bool affine = cs_affine(p), fullpel = cs_fullpel(p);
+  R.cost_l1_unique = CS_MAXCOST;
+  R.best_ref_l1_unique = -1;
+  for (int l = 0; l < 2; l++) {          // the folds over the candidates, in the reference's order
+    uint32_t cost_best = CS_MAXCOST;
+    int best = -1;
+    for (int r = 0; r < p.num_refs[l] && r < CS_R; r++) {
+      const int m = l == 1 ? p.same_poc_in_l0[r] : -1;
+      const uint32_t cost = R.cost[l][r];
       if (cost < cost_best) {
         cost_best = cost;
         best = r;
@@ -323,16 +333,13 @@ __global__ void cs_bi_fold_kernel(const xvcgpu_cs_pass *passes, int first, int n
     }
   }
   __syncthreads();
-  auto body = [&]() {
-  const bool affine = cs_affine(p), fullpel = cs_fullpel(p);
-  uint32_t cost_bi = CS_MAXCOST;
-  int bi_ref = -1;
-  const int s = R.search_list, od = 1 - s;
-  const int o = R.bi_valid ? R.best_ref[od] : -1;
-  int32_t other_mvd[2][2] = {};
-  if (R.bi_valid) {
-    cs_set_mvd(other_mvd, p.mvp[od][o][R.mvp_idx[od][o]], R.mv[od][o], fullpel, affine);
-    for (int r = 0; r < p.num_refs[s] && r < CS_R; r++) {
+  // the refinement's candidates, one lane per searched picture
+  if (threadIdx.x < CS_R && R.bi_valid) {
+    const bool affine = cs_affine(p), fullpel = cs_fullpel(p);
+    const int s = R.search_list, od = 1 - s, o = R.best_ref[od], r = threadIdx.x;
+    if (r < p.num_refs[s]) {
+      int32_t other_mvd[2][2];
+      cs_set_mvd(other_mvd, p.mvp[od][o][R.mvp_idx[od][o]], R.mv[od][o], fullpel, affine);
       if (!affine) {
         R.bi_mv[r][0][0] = s_bi[r].mv_x;
         R.bi_mv[r][0][1] = s_bi[r].mv_y;
@@ -355,14 +362,22 @@ __global__ void cs_bi_fold_kernel(const xvcgpu_cs_pass *passes, int first, int n
       syn.mvp_idx[od] = R.mvp_idx[od][o];
       for (int k = 0; k < 2; k++)
         for (int c = 0; c < 2; c++) syn.mvd[od][k][c] = other_mvd[k][c];
-      const uint32_t cost = cs_price(p, syn, R.bi_dist[r], &R.bi_bits[r], tabs);
-      R.bi_cost[r] = cost;
-      if (cost < cost_bi) {
-        cost_bi = cost;
-        bi_ref = r;
-      }
+      R.bi_cost[r] = cs_price(p, syn, R.bi_dist[r], &R.bi_bits[r], tabs);
     }
   }
+  __syncthreads();
+  auto body = [&]() {
+  const bool affine = cs_affine(p), fullpel = cs_fullpel(p);
+  uint32_t cost_bi = CS_MAXCOST;
+  int bi_ref = -1;
+  const int s = R.search_list, od = 1 - s;
+  const int o = R.bi_valid ? R.best_ref[od] : -1;
+  if (R.bi_valid)
+    for (int r = 0; r < p.num_refs[s] && r < CS_R; r++)
+      if (R.bi_cost[r] < cost_bi) {
+        cost_bi = R.bi_cost[r];
+        bi_ref = r;
+      }
   // the three-way choice (:247-257); a picture with one list returns list 0's result
   const uint32_t c0 = R.cost_list[0], c1u = R.cost_l1_unique;
   int which;
