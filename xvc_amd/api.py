@@ -1103,6 +1103,73 @@ class Context:
         do.free()
         return out
 
+    # ---- one SearchMotion step into all reference pictures of a CU (xvcgpu_*_refs) ----
+    def _ref_array(self, refs):
+        return (C.c_void_p * len(refs))(*[r.h_pic for r in refs])
+
+    def me_search_refs(self, orig, refs, blocks, slots, block_class, flags=ME_FULLPEL | ME_SUBPEL,
+                       results=None):
+        """job i searches refs[slots[i]] (255: no job) -> MERES_DTYPE array"""
+        blocks = np.ascontiguousarray(blocks, ME_DTYPE)
+        slots = np.ascontiguousarray(slots, np.uint8)
+        assert len(slots) == len(blocks)
+        db, ds = self.buffer(blocks), self.buffer(slots)
+        if results is None:
+            results = np.zeros(len(blocks), MERES_DTYPE)
+        dr = self.buffer(np.ascontiguousarray(results, MERES_DTYPE))
+        self._check(self.lib.xvcgpu_me_search_refs(self.h, orig.h_pic, self._ref_array(refs),
+                                                   len(refs), flags, db.ptr, ds.ptr, len(blocks),
+                                                   dr.ptr, block_class))
+        out = dr.to_array(MERES_DTYPE, len(blocks))
+        for b in (db, ds, dr):
+            b.free()
+        return out
+
+    def bipred_search_refs(self, orig, refs, jobs, slots, block_class, results=None):
+        """slots[i] = (searched picture, the other list's picture) of job i"""
+        jobs = np.ascontiguousarray(jobs, BI_DTYPE)
+        slots = np.ascontiguousarray(slots, np.uint8).reshape(-1, 2)
+        assert len(slots) == len(jobs)
+        dj, ds = self.buffer(jobs), self.buffer(slots)
+        if results is None:
+            results = np.zeros(len(jobs), MERES_DTYPE)
+        dr = self.buffer(np.ascontiguousarray(results, MERES_DTYPE))
+        self._check(self.lib.xvcgpu_bipred_search_refs(self.h, orig.h_pic, self._ref_array(refs),
+                                                       len(refs), dj.ptr, ds.ptr, len(jobs), dr.ptr,
+                                                       block_class))
+        out = dr.to_array(MERES_DTYPE, len(jobs))
+        for b in (dj, ds, dr):
+            b.free()
+        return out
+
+    def mc_metric_batch_refs(self, orig, refs, cands, slots, strength=16):
+        cands = np.ascontiguousarray(cands, MCM_DTYPE)
+        slots = np.ascontiguousarray(slots, np.uint8)
+        assert len(slots) == len(cands)
+        dc, ds = self.buffer(cands), self.buffer(slots)
+        do = self.buffer(np.full(max(1, len(cands)), 0xffffffffffffffff, np.uint64))
+        self._check(self.lib.xvcgpu_mc_metric_batch_refs(self.h, orig.h_pic, self._ref_array(refs),
+                                                         len(refs), strength, dc.ptr, ds.ptr,
+                                                         len(cands), do.ptr))
+        out = do.to_array(np.uint64, len(cands))
+        for b in (dc, ds, do):
+            b.free()
+        return out
+
+    def affine_me_batch_refs(self, orig, refs, blocks, slots, cu_height):
+        blocks = np.ascontiguousarray(blocks, AFFINE_ME_DTYPE)
+        slots = np.ascontiguousarray(slots, np.uint8).reshape(-1, 2)
+        assert len(slots) == len(blocks)
+        d, ds = self.buffer(blocks), self.buffer(slots)
+        do = self.buffer(np.zeros(max(1, len(blocks)), AFFINE_ME_RESULT_DTYPE))
+        self._check(self.lib.xvcgpu_affine_me_batch_refs(self.h, orig.h_pic, self._ref_array(refs),
+                                                         len(refs), d.ptr, ds.ptr, len(blocks),
+                                                         do.ptr, cu_height))
+        out = do.to_array(AFFINE_ME_RESULT_DTYPE, len(blocks))
+        for b in (d, ds, do):
+            b.free()
+        return out
+
     # ---- intra prediction ----
     def intra_pred_batch(self, rec, pred, jobs):
         jobs = np.ascontiguousarray(jobs, INTRA_DTYPE)
