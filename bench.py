@@ -192,6 +192,11 @@ def stream_decode_figure(ctx, api):
            "md5_match": bool(ok), "includes": "host planning + upload of the parsed syntax; the "
                                               "planning of picture i + 1 on a worker thread while "
                                               "picture i is issued (PictureDecoder::DecodeSequence)"}
+    # an inter picture inside the pipelined run: what the sequence takes beyond its
+    # intra picture (ms_by_picture_type waits after every picture)
+    if "I" in kinds and any(k != "I" for k in kinds):
+        n_inter = sum(len(v) for k, v in kinds.items() if k != "I")
+        out["ms_per_inter_picture_pipelined"] = max(1e3 * dt - sum(kinds["I"]), 0.0) / n_inter
     for p in dpics:
         p.destroy()
     # the short stream, decoded for the search replays
@@ -1143,7 +1148,13 @@ def main():
         cpu = cpu_baseline(args, clip, bd, border)
     decode = None
     if rank == 0 and not multi and not args.no_decode:
-        decode = stream_decode_figure(ctx, api)
+        # its own context and stream: on the process's null stream every launch is
+        # ordered against all the other streams that exist (the chains': the runtime
+        # walks them per launch - the host-bound decoder ran at half its rate there)
+        dctx = api.Context(local_rank)
+        dctx.use_own_stream()
+        decode = stream_decode_figure(dctx, api)
+        dctx.close()
 
     if rank == 0:
         value = args.steps / dt
