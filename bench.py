@@ -1148,9 +1148,12 @@ def main():
         cpu = cpu_baseline(args, clip, bd, border)
     decode = None
     if rank == 0 and not multi and not args.no_decode:
-        # its own context and stream: on the process's null stream every launch is
-        # ordered against all the other streams that exist (the chains': the runtime
-        # walks them per launch - the host-bound decoder ran at half its rate there)
+        # its own context: the process holds more streams than the runtime has hardware
+        # queues by now (the chains', the main context's), streams share queues in
+        # creation order, and the host-bound decoder on the main context's stream ran at
+        # half its rate (tools/dbg/dec_rate2.py: 4500 -> 3500 pictures/s beside three
+        # idle contexts with 4 queues, 4440 with GPU_MAX_HW_QUEUES=8 as main() sets it -
+        # but this process holds more than eight streams by now)
         dctx = api.Context(local_rank)
         dctx.use_own_stream()
         decode = stream_decode_figure(dctx, api)

@@ -13,6 +13,9 @@ from xvc_amd import api, decoder
 import stream_fixture as sf
 ctx = api.Context(0)
 extra = []
+if "early" in what:         # the context's copy stream right behind its main stream
+    ev = api.Event(ctx)
+    ctx._check(ctx.lib.xvcgpu_upload_ahead(ctx.h, None, None, 0, None, ev.h))
 if "ctxs" in what:
     for _ in range(3):
         c = api.Context(0); c.use_own_stream(); extra.append(c)
