@@ -11,7 +11,8 @@ clip = synth.SyntheticClip(W, H, bd)
 pad = lambda planes: [np.ascontiguousarray(np.pad(p, border if c == 0 else border // 2, mode="edge")) for c, p in enumerate(planes)]
 O, R = ctx.picture(W, H, bd), ctx.picture(W, H, bd)
 R.upload(pad(clip.frame(0)), border); O.upload(pad(clip.frame(1)), border)
-fp = pipeline.FramePass(ctx, W, H, bd)
+# XCD_TILES=1: the CU list region-major (bench.py's default order)
+fp = pipeline.FramePass(ctx, W, H, bd, xcd_tiles=os.environ.get("XCD_TILES", "0") == "1")
 d = fp.desc
 if flags != 3:  # real full-pel results for a sub-pel-only run
     ctx.me_search_dev(O, R, 3, fp.d_me.ptr, d.n_cus, fp.d_res.ptr, 16)
