@@ -151,6 +151,23 @@ def test_affine_me_batch_refs(gpu, cu_height):
     assert (got[none]["dist"] == 0).all()
 
 
+def test_slot_beyond_the_table_is_no_job(gpu):
+    """A slot >= n_refs (here 2 of a table of 2) is not searched, whatever lies behind
+    the table's entries in use."""
+    api, ctx, orig, refs = gpu
+    rng = np.random.default_rng(7)
+    blocks = _me_blocks(api, rng, 16, 12)
+    slots = np.array([0, 1, 2, 9, 255, 0, 1, 2, 0, 1, 3, 0], np.uint8)
+    before = np.zeros(12, api.MERES_DTYPE)
+    before["fullpel_cost"] = 0x5a5a5a5a
+    got = ctx.me_search_refs(orig, refs[:2], blocks, slots, 16, results=before)
+    for s_ in range(2):
+        idx = np.flatnonzero(slots == s_)
+        assert np.array_equal(got[idx], ctx.me_search(orig, refs[s_], blocks[idx]))
+    none = slots >= 2
+    assert np.array_equal(got[none], before[none])
+
+
 def test_refs_forms_refuse_bad_arguments(gpu):
     api, ctx, orig, refs = gpu
     arr = ctx._ref_array(refs)

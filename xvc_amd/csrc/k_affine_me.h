@@ -446,8 +446,8 @@ affine_me_body(const PlaneView &orig, const PlaneView &ref_arg, const PlaneView 
   if (slots) {
     slot_s = __builtin_amdgcn_readfirstlane((int)slots[2 * bi]);
     slot_o = __builtin_amdgcn_readfirstlane((int)slots[2 * bi + 1]);
-    if (slot_s >= XVC_MAX_REF_SLOTS) return;
-    if (slot_o >= XVC_MAX_REF_SLOTS) slot_o = slot_s;   // (uni-prediction: not read)
+    if (slot_s >= refs->n) return;
+    if (slot_o >= refs->n) slot_o = slot_s;   // (uni-prediction: not read)
   }
   const PlaneView ref = slots ? refs->pic[slot_s].c[0] : ref_arg;
   const PlaneView ref_other = slots ? refs->pic[slot_o].c[0] : ref_other_arg;

@@ -146,7 +146,7 @@ bipred_search_body(const PlaneView &orig, const PlaneView &ref_other_arg,
   if (slots) {
     slot_s = __builtin_amdgcn_readfirstlane((int)slots[2 * ji]);
     slot_o = __builtin_amdgcn_readfirstlane((int)slots[2 * ji + 1]);
-    if (slot_s >= XVC_MAX_REF_SLOTS || slot_o >= XVC_MAX_REF_SLOTS) return;
+    if (slot_s >= refs->n || slot_o >= refs->n) return;
   }
   const PlaneView ref_other = slots ? refs->pic[slot_o].c[0] : ref_other_arg;
   const PlaneView ref_search = slots ? refs->pic[slot_s].c[0] : ref_search_arg;
@@ -508,7 +508,7 @@ mc_metric_body(const PlaneView &orig, const PlaneView &ref_arg, int bd, int stre
   int slot = 0;
   if (slots) {
     slot = __builtin_amdgcn_readfirstlane((int)slots[ci]);   // (one candidate per wave)
-    if (slot >= XVC_MAX_REF_SLOTS) return;
+    if (slot >= refs->n) return;
   }
   const PlaneView ref = slots ? refs->pic[slot].c[0] : ref_arg;
   const xvcgpu_mc_metric_cand cd = cands[ci];

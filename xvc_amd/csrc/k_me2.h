@@ -800,7 +800,7 @@ me_search_wave_body(const PicView &orig, const PicView &ref,
   int slot = 0;
   if (slots) {
     slot = __builtin_amdgcn_readfirstlane((int)slots[bi]);
-    if (slot >= XVC_MAX_REF_SLOTS) return;
+    if (slot >= refs->n) return;
   }
   const PlaneView po = orig.c[0], pr = slots ? refs->pic[slot].c[0] : ref.c[0];
   const int pic_w = po.w, pic_h = po.h;
@@ -1275,7 +1275,7 @@ me_subpel_team_body(const PicView &orig, const PicView &ref, const xvcgpu_me_blo
   int slot = 0;
   if (slots) {
     slot = __builtin_amdgcn_readfirstlane((int)slots[bi]);
-    if (slot >= XVC_MAX_REF_SLOTS) return;
+    if (slot >= refs->n) return;
   }
   const PlaneView po = orig.c[0], pr = slots ? refs->pic[slot].c[0] : ref.c[0];
   const int pic_w = po.w, pic_h = po.h;

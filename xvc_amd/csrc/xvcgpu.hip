@@ -879,6 +879,7 @@ static xvcgpu_status inter_pred_launch(xvcgpu_ctx *ctx, const xvcgpu_picture *co
       return fail(ctx, XVCGPU_INVALID_ARGUMENT, "reference picture mismatch");
     t.pic[i] = refs[i]->v;
   }
+  t.n = n_refs;
   if (n == 0) return XVCGPU_OK;
   hipLaunchKernelGGL(inter_pred_kernel, dim3(n), dim3(256), 0, ctx->stream, t, rec->v,
                      pred->v, d_blocks, n, d_dst, rec->w, rec->h);
@@ -2328,6 +2329,7 @@ static xvcgpu_status ref_table_of(xvcgpu_ctx *ctx, const xvcgpu_picture *orig,
       return fail(ctx, XVCGPU_INVALID_ARGUMENT, "reference picture mismatch");
     t->pic[i] = refs[i]->v;
   }
+  t->n = n_refs;
   return XVCGPU_OK;
 }
 

@@ -31,6 +31,7 @@ struct PicView {
 
 struct RefTable {
   PicView pic[XVC_MAX_REF_SLOTS];
+  int n;   // entries in use (the *_refs searches: a job whose slot is >= n is no job)
 };
 
 struct xvcgpu_ctx {

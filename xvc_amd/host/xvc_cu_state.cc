@@ -390,6 +390,9 @@ extern "C" int xvc_host_cs_run_programs_interleaved(int k, xvcgpu_ctx *const *ct
       if (waiting[c] >= 0 || at[c] < n_ops[c]) live++;
     }
   }
+  // (an error in one chain: the others' work is waited for, the device is left idle)
+  if (st != XVCGPU_OK)
+    for (int c = 0; c < k; c++) xvcgpu_sync(ctxs[c]);
   stats->seconds = Now() - t0;
   return st;
 }
