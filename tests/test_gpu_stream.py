@@ -105,16 +105,25 @@ def test_gpu_stream_decode_rate(gpu):
           "waves / launches per picture: %s" % (fx.n, dt, fx.n / dt, info))
 
 
-@pytest.mark.parametrize("name", ["tiny", "c1x"])
-def test_decode_sequence_equals_stream_md5(gpu, name):
+@pytest.mark.parametrize("name,lanes", [("tiny", 1), ("c1x", 1), ("tiny", 3), ("c0", 2), ("c1x", 3),
+                                        ("c1x", 4)])
+def test_decode_sequence_equals_stream_md5(gpu, name, lanes):
     """The whole stream through ONE call (PictureDecoder::DecodeSequence: the plan of
     picture i + 1 made on a worker thread while picture i is uploaded and launched; in
     inter pictures the trailing waves of intra CUs in one cooperative launch): every
-    picture's MD5 equals the stream's."""
+    picture's MD5 equals the stream's.  lanes > 1: the pictures dealt over that many
+    contexts (PictureDecoder::AddLane) - a picture's kernels wait for the pictures it
+    references by events, the B pictures of a temporal layer run side by side."""
     api, ctx = gpu
     fx = sf.StreamFixture(name)
     w, h, bd = (int(fx.info[0][k]) for k in ("width", "height", "bitdepth"))
     dec = decoder.PictureDecoder(ctx, w, h, bd)
+    lane_ctxs = [api.Context(0) for _ in range(lanes - 1)]
+    for c in lane_ctxs:
+        dec.add_lane(c)
+    if lanes > 1:
+        with pytest.raises(api.XvcGpuError):
+            dec.add_lane(ctx)                 # the decoder's own context is lane 0
     infos = [fx.info[i] for i in range(fx.n)]
     pos = {int(infos[i]["poc"]): i for i in range(fx.n)}
     ref_index = np.full((fx.n, 2, 5), -1, np.int32)
@@ -126,12 +135,12 @@ def test_decode_sequence_equals_stream_md5(gpu, name):
             for k in range(int(info["num_ref"][l])):
                 ref_index[i, l, k] = pos[int(info["ref_poc"][l][k])]
     recs = [ctx.picture(w, h, bd) for _ in range(fx.n)]
-    for _ in range(2):       # twice: the second run re-uses every buffer
+    for _ in range(2 if lanes == 1 else 4):       # again: the later runs re-use every buffer
         dec.decode_sequence(pictures, ref_index, recs)
         ctx.sync()
         for i, info in enumerate(infos):
             got = recs[i].download(0)
-            assert np.array_equal(sf.picture_md5(got, bd), info["md5"]), (name, i)
+            assert np.array_equal(sf.picture_md5(got, bd), info["md5"]), (name, lanes, i)
     # a reference that is not decoded yet is refused
     bad = ref_index.copy()
     bad[1, 0, 0] = fx.n - 1
@@ -139,5 +148,7 @@ def test_decode_sequence_equals_stream_md5(gpu, name):
         dec.decode_sequence(pictures, bad, recs)
     ctx.sync()
     dec.destroy()
+    for c in lane_ctxs:
+        c.close()
     for p in recs:
         p.destroy()

@@ -34,6 +34,10 @@ for i, info in enumerate(infos):
     for l in range(2):
         for k in range(int(info["num_ref"][l])):
             ri[i, l, k] = pos[int(info["ref_poc"][l][k])]
+for k in range(2, 9):           # lanesK: K picture lanes
+    if "lanes%d" % k in what:
+        for _ in range(k - 1):
+            c = api.Context(0); extra.append(c); dec.add_lane(c)
 recs = [ctx.picture(w, h, bd) for _ in range(fx.n)]
 def seq():
     dec.decode_sequence(pics, ri, recs); ctx.sync()

@@ -92,6 +92,14 @@ class PictureDecoder:
             self.h, ps.ctypes.data, cus.ctypes.data, lv.ctypes.data, refs, rec.h_pic)
         self.ctx._check(st)
 
+    def add_lane(self, ctx):
+        """A further picture lane (PictureDecoder::AddLane): decode_sequence deals the
+        pictures over the lanes, pictures that do not reference each other run side
+        by side.  `ctx`: another api.Context on the same device (kept by the caller)."""
+        self.lib.xvc_host_picture_decoder_add_lane.argtypes = [C.c_void_p, C.c_void_p]
+        self.ctx._check(self.lib.xvc_host_picture_decoder_add_lane(self.h, ctx.h))
+        self._lanes = getattr(self, "_lanes", []) + [ctx]
+
     def decode_sequence(self, pictures, ref_index, recs):
         """pictures: [(ps, cus, levels)] in decoding order; ref_index[i][list][k]: the
         position in this sequence of picture i's reference (list, k), -1 = unused; recs:

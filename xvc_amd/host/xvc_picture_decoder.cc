@@ -14,6 +14,11 @@
 
 namespace xvc_gpu {
 
+static double NowSeconds() {
+  return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+
 namespace {
 
 // The 4x4 cell table of PictureData (picture_data.cc:52-62: one extra column /
@@ -355,6 +360,14 @@ PictureDecoder::PictureDecoder(xvcgpu_ctx *ctx, int width, int height, int bitde
 }
 
 PictureDecoder::~PictureDecoder() {
+  lanes_.clear();
+  for (SeqSlot &q : seq_slots_) {
+    if (q.in_flight) xvcgpu_event_synchronize(q.copied);
+    if (q.copied) xvcgpu_event_destroy(q.copied);
+    if (q.mem) xvcgpu_host_free(ctx_, q.mem);
+  }
+  for (xvcgpu_event *e : pic_done_)
+    if (e) xvcgpu_event_destroy(e);
   for (HostSlot &h : host_) {
     if (h.in_flight) xvcgpu_event_synchronize(h.copied);
     if (h.copied) xvcgpu_event_destroy(h.copied);
@@ -366,6 +379,16 @@ PictureDecoder::~PictureDecoder() {
     if (kernels_done_[k]) xvcgpu_event_destroy(kernels_done_[k]);
   }
   if (pred_) xvcgpu_picture_destroy(pred_);
+}
+
+xvcgpu_status PictureDecoder::AddLane(xvcgpu_ctx *ctx) {
+  if (!ctx || ctx == ctx_) return XVCGPU_INVALID_ARGUMENT;
+  for (const auto &l : lanes_)
+    if (l->ctx_ == ctx) return XVCGPU_INVALID_ARGUMENT;
+  std::unique_ptr<PictureDecoder> d(new (std::nothrow) PictureDecoder(ctx, width_, height_, bitdepth_));
+  if (!d || !d->pred_) return XVCGPU_OUT_OF_MEMORY;
+  lanes_.push_back(std::move(d));
+  return XVCGPU_OK;
 }
 
 xvcgpu_status PictureDecoder::EnsureStaging(int k, size_t bytes) {
@@ -427,76 +450,106 @@ xvcgpu_status PictureDecoder::Decode(const xvc_picture_syntax &ps, const xvc_cu_
   return Issue(plan_, ps, levels, ref_pics, rec);
 }
 
-xvcgpu_status PictureDecoder::Issue(const PicturePlan &p, const xvc_picture_syntax &ps,
-                                    const int16_t *levels,
-                                    const xvcgpu_picture *const ref_pics[2][5],
-                                    xvcgpu_picture *rec) {
-  // one packed upload: job lists, cell maps, CU records, levels
-  struct Piece {
-    const void *src;
-    size_t bytes, off;
-  };
+// What a picture sends to the device in one piece - job lists, cell maps, CU records,
+// levels, the wave table of its cooperative launch - and where each part lies in it.
+void PictureDecoder::Layout(const PicturePlan &p, const xvc_picture_syntax &ps,
+                            PackedPicture *L) const {
   // an intra picture (every wave holds intra jobs only, prediction job k and
   // transform job k are the same block): all waves in one cooperative launch
-  const bool one_launch = use_waves_kernel_ && p.inter.empty() && !p.intra.empty() &&
-                          p.intra_first == p.tx_first;
+  L->one_launch = use_waves_kernel_ && p.inter.empty() && !p.intra.empty() &&
+                  p.intra_first == p.tx_first;
   // an inter picture with intra CUs: from wave t0 on every job is an intra job (the
   // waves behind the inter CUs: intra CUs reading their neighbours' reconstruction) -
   // that tail goes into ONE cooperative launch too, instead of three launches per
   // wave (B pictures of the 1080p stream: 27-33 launches)
   int t0 = p.n_waves;
   while (t0 > 0 && p.inter_first[t0 - 1] == p.inter_first[p.n_waves]) t0--;
-  const bool tail_launch = use_waves_kernel_ && !one_launch && t0 > 0 &&
-                           p.n_waves - t0 >= tail_min_waves_;
-  std::vector<int32_t> tail_first;
-  if (tail_launch)
-    for (int w = t0; w <= p.n_waves; w++) tail_first.push_back(p.intra_first[w] - p.intra_first[t0]);
-  Piece pc[10] = {
-      {p.inter.data(), p.inter.size() * sizeof(xvcgpu_inter_block), 0},
-      {p.intra.data(), p.intra.size() * sizeof(xvcgpu_intra_block), 0},
-      {p.tx.data(), p.tx.size() * sizeof(xvcgpu_tx_block), 0},
-      {p.tx_level_off.data(), p.tx_level_off.size() * sizeof(uint32_t), 0},
-      {p.tx_nnz.data(), p.tx_nnz.size() * sizeof(int32_t), 0},
-      {p.cu_info.data(), p.cu_info.size() * sizeof(xvcgpu_cu_info), 0},
-      {p.cell[0].data(), p.cell[0].size() * sizeof(int32_t), 0},
-      {p.cell[1].data(), p.cell[1].size() * sizeof(int32_t), 0},
-      {levels, static_cast<size_t>(ps.n_levels > 0 ? ps.n_levels : 1) * sizeof(int16_t), 0},
-      {one_launch ? p.intra_first.data() : tail_first.data(),
-       one_launch ? p.intra_first.size() * sizeof(int32_t) : tail_first.size() * sizeof(int32_t), 0}};
-  static const int16_t kNoLevels[1] = {0};
-  if (ps.n_levels <= 0) pc[8].src = kNoLevels;
+  L->t0 = t0;
+  L->tail_launch = use_waves_kernel_ && !L->one_launch && t0 > 0 &&
+                   p.n_waves - t0 >= tail_min_waves_;
+  L->tail_first.clear();
+  if (L->tail_launch)
+    for (int w = t0; w <= p.n_waves; w++)
+      L->tail_first.push_back(p.intra_first[w] - p.intra_first[t0]);
+  const size_t bytes[10] = {
+      p.inter.size() * sizeof(xvcgpu_inter_block),
+      p.intra.size() * sizeof(xvcgpu_intra_block),
+      p.tx.size() * sizeof(xvcgpu_tx_block),
+      p.tx_level_off.size() * sizeof(uint32_t),
+      p.tx_nnz.size() * sizeof(int32_t),
+      p.cu_info.size() * sizeof(xvcgpu_cu_info),
+      p.cell[0].size() * sizeof(int32_t),
+      p.cell[1].size() * sizeof(int32_t),
+      static_cast<size_t>(ps.n_levels > 0 ? ps.n_levels : 1) * sizeof(int16_t),
+      (L->one_launch ? p.intra_first.size() : L->tail_first.size()) * sizeof(int32_t)};
   size_t total = 0;
-  for (Piece &q : pc) {
-    q.off = total;
-    total += (q.bytes + 255) & ~static_cast<size_t>(255);
+  for (int k = 0; k < 10; k++) {
+    L->bytes[k] = bytes[k];
+    L->off[k] = total;
+    total += (bytes[k] + 255) & ~static_cast<size_t>(255);
   }
+  L->total = total;
+}
+
+void PictureDecoder::PackInto(const PicturePlan &p, const xvc_picture_syntax &ps,
+                              const int16_t *levels, const PackedPicture &L, void *dst) {
+  static const int16_t kNoLevels[1] = {0};
+  const void *src[10] = {p.inter.data(), p.intra.data(), p.tx.data(), p.tx_level_off.data(),
+                         p.tx_nnz.data(), p.cu_info.data(), p.cell[0].data(), p.cell[1].data(),
+                         ps.n_levels > 0 ? static_cast<const void *>(levels) : kNoLevels,
+                         L.one_launch ? p.intra_first.data() : L.tail_first.data()};
+  for (int k = 0; k < 10; k++)
+    if (L.bytes[k]) std::memcpy(static_cast<uint8_t *>(dst) + L.off[k], src[k], L.bytes[k]);
+}
+
+xvcgpu_status PictureDecoder::Issue(const PicturePlan &p, const xvc_picture_syntax &ps,
+                                    const int16_t *levels,
+                                    const xvcgpu_picture *const ref_pics[2][5],
+                                    xvcgpu_picture *rec) {
+  PackedPicture L;
+  Layout(p, ps, &L);
+  HostSlot *slot = nullptr;
+  xvcgpu_status st = AcquireHostSlot(L.total, &slot);
+  if (st != XVCGPU_OK) return st;
+  PackInto(p, ps, levels, L, slot->mem);
+  st = IssuePacked(p, ps, L, slot->mem, slot->copied, ref_pics, rec);
+  slot->in_flight = true;
+  return st;
+}
+
+// The picture's upload (from page-locked memory the caller filled: PackInto) and its
+// launches.  `copied` is recorded behind the upload: the memory may be written again
+// once it has passed.
+xvcgpu_status PictureDecoder::IssuePacked(const PicturePlan &p, const xvc_picture_syntax &ps,
+                                          const PackedPicture &L, const void *host_mem,
+                                          xvcgpu_event *copied,
+                                          const xvcgpu_picture *const ref_pics[2][5],
+                                          xvcgpu_picture *rec) {
+  const size_t *off = L.off;
+  const bool one_launch = L.one_launch, tail_launch = L.tail_launch;
+  const int t0 = L.t0;
+  const size_t total = L.total;
   const int sk = next_staging_;
   next_staging_ ^= 1;
   xvcgpu_status st = EnsureStaging(sk, total);
   if (st != XVCGPU_OK) return st;
-  HostSlot *slot = nullptr;
-  st = AcquireHostSlot(total, &slot);
-  if (st != XVCGPU_OK) return st;
-  for (const Piece &q : pc)
-    if (q.bytes) std::memcpy(static_cast<uint8_t *>(slot->mem) + q.off, q.src, q.bytes);
   // on the copy stream, behind the kernels of the picture two back (they read this
   // device buffer) - beside, not behind, the previous picture's kernels
-  st = xvcgpu_upload_ahead(ctx_, d_staging_[sk], slot->mem, total,
-                           staging_used_[sk] ? kernels_done_[sk] : nullptr, slot->copied);
+  st = xvcgpu_upload_ahead(ctx_, d_staging_[sk], host_mem, total,
+                           staging_used_[sk] ? kernels_done_[sk] : nullptr, copied);
   if (st != XVCGPU_OK) return st;
-  slot->in_flight = true;
-  st = xvcgpu_event_wait(ctx_, slot->copied);   // this picture's kernels: after its upload
+  st = xvcgpu_event_wait(ctx_, copied);   // this picture's kernels: after its upload
   if (st != XVCGPU_OK) return st;
   uint8_t *base = static_cast<uint8_t *>(d_staging_[sk]);
-  const xvcgpu_inter_block *d_inter = reinterpret_cast<const xvcgpu_inter_block *>(base + pc[0].off);
-  const xvcgpu_intra_block *d_intra = reinterpret_cast<const xvcgpu_intra_block *>(base + pc[1].off);
-  const xvcgpu_tx_block *d_tx = reinterpret_cast<const xvcgpu_tx_block *>(base + pc[2].off);
-  const uint32_t *d_off = reinterpret_cast<const uint32_t *>(base + pc[3].off);
-  const int32_t *d_nnz = reinterpret_cast<const int32_t *>(base + pc[4].off);
-  const xvcgpu_cu_info *d_cus = reinterpret_cast<const xvcgpu_cu_info *>(base + pc[5].off);
-  const int32_t *d_cell0 = reinterpret_cast<const int32_t *>(base + pc[6].off);
-  const int32_t *d_cell1 = reinterpret_cast<const int32_t *>(base + pc[7].off);
-  const int16_t *d_levels = reinterpret_cast<const int16_t *>(base + pc[8].off);
+  const xvcgpu_inter_block *d_inter = reinterpret_cast<const xvcgpu_inter_block *>(base + off[0]);
+  const xvcgpu_intra_block *d_intra = reinterpret_cast<const xvcgpu_intra_block *>(base + off[1]);
+  const xvcgpu_tx_block *d_tx = reinterpret_cast<const xvcgpu_tx_block *>(base + off[2]);
+  const uint32_t *d_off = reinterpret_cast<const uint32_t *>(base + off[3]);
+  const int32_t *d_nnz = reinterpret_cast<const int32_t *>(base + off[4]);
+  const xvcgpu_cu_info *d_cus = reinterpret_cast<const xvcgpu_cu_info *>(base + off[5]);
+  const int32_t *d_cell0 = reinterpret_cast<const int32_t *>(base + off[6]);
+  const int32_t *d_cell1 = reinterpret_cast<const int32_t *>(base + off[7]);
+  const int16_t *d_levels = reinterpret_cast<const int16_t *>(base + off[8]);
 
   const xvcgpu_picture *refs[10];
   for (int l = 0; l < 2; l++)
@@ -509,7 +562,7 @@ xvcgpu_status PictureDecoder::Issue(const PicturePlan &p, const xvc_picture_synt
   int launches = 0;
   bool waves_done = false;
   if (one_launch) {
-    const int32_t *d_first = reinterpret_cast<const int32_t *>(base + pc[9].off);
+    const int32_t *d_first = reinterpret_cast<const int32_t *>(base + off[9]);
     st = xvcgpu_intra_recon_waves(ctx_, rec, pred_, d_intra, d_tx, d_first, p.n_waves, d_levels,
                                   d_off, d_nnz);
     if (st == XVCGPU_OK) {
@@ -545,7 +598,7 @@ xvcgpu_status PictureDecoder::Issue(const PicturePlan &p, const xvc_picture_synt
   if (tail_launch) {
     // (in these waves job k of the intra list and job tx_first[t0] + k of the
     // transform list are the same block: every unit is an intra unit)
-    const int32_t *d_first = reinterpret_cast<const int32_t *>(base + pc[9].off);
+    const int32_t *d_first = reinterpret_cast<const int32_t *>(base + off[9]);
     const int a = p.intra_first[t0], t = p.tx_first[t0];
     st = xvcgpu_intra_recon_waves(ctx_, rec, pred_, d_intra + a, d_tx + t, d_first,
                                   p.n_waves - t0, d_levels, d_off + t, d_nnz + t);
@@ -616,13 +669,57 @@ xvcgpu_status PictureDecoder::DecodeSequence(int n, const xvc_picture_syntax *co
   std::vector<PicturePlan> &plans = seq_plans_;
   bool valid[kRing] = {};
   bool ready[kRing] = {};
+  const bool trace_workers = std::getenv("XVC_DEC_TRACE") != nullptr;
+  std::mutex trace_mu;
+  double w_plan = 0, w_wait = 0, w_pack = 0;
+  if (seq_slots_.size() != kRing) {
+    SeqSlot empty = {};
+    empty.mem = nullptr;
+    empty.cap = 0;
+    empty.copied = nullptr;
+    empty.in_flight = false;
+    seq_slots_.assign(kRing, empty);
+  }
+  for (SeqSlot &q : seq_slots_)
+    if (!q.copied && xvcgpu_event_create(ctx_, &q.copied) != XVCGPU_OK) return XVCGPU_DEVICE_ERROR;
+  // a planner validates, plans and PACKS its picture: the parts of the upload go into
+  // the ring slot's page-locked memory on the planner's thread
   auto prepare = [&](int i) {
     const xvc_picture_syntax &s = *ps[i];
     const int k = i % kRing;
     valid[k] = cus[i] && s.width == width_ && s.height == height_ &&
                s.bitdepth == bitdepth_ && s.n_cus > 0 && (s.n_levels <= 0 || levels[i]) &&
                Validate(s, cus[i], levels[i]);
-    if (valid[k]) Plan(s, cus[i], levels[i], &plans[k]);
+    if (!valid[k]) return;
+    const double tp0 = trace_workers ? NowSeconds() : 0;
+    Plan(s, cus[i], levels[i], &plans[k]);
+    SeqSlot &q = seq_slots_[k];
+    Layout(plans[k], s, &q.lay);
+    const double tp1 = trace_workers ? NowSeconds() : 0;
+    if (q.in_flight) {          // the upload of the slot's previous picture
+      xvcgpu_event_synchronize(q.copied);
+      q.in_flight = false;
+    }
+    const double tp2 = trace_workers ? NowSeconds() : 0;
+    if (q.lay.total > q.cap) {
+      if (q.mem) xvcgpu_host_free(ctx_, q.mem);
+      q.mem = nullptr;
+      q.cap = 0;
+      const size_t cap = q.lay.total + q.lay.total / 4;
+      if (xvcgpu_host_alloc(ctx_, cap, &q.mem) != XVCGPU_OK) {
+        valid[k] = false;
+        return;
+      }
+      q.cap = cap;
+    }
+    PackInto(plans[k], s, levels[i], q.lay, q.mem);
+    if (trace_workers) {
+      const double tp3 = NowSeconds();
+      std::lock_guard<std::mutex> lk(trace_mu);
+      w_plan += tp1 - tp0;
+      w_wait += tp2 - tp1;
+      w_pack += tp3 - tp2;
+    }
   };
   // slot i % kRing may be written once picture i - kRing (its previous user) has been
   // issued; picture i is issued once its plan is there
@@ -648,6 +745,18 @@ xvcgpu_status PictureDecoder::DecodeSequence(int n, const xvc_picture_syntax *co
       }
     });
   xvcgpu_status st = XVCGPU_OK;
+  const int n_lanes = num_lanes();
+  if (n_lanes > 1) {
+    for (auto &l : lanes_) {
+      l->use_waves_kernel_ = use_waves_kernel_;
+      l->tail_min_waves_ = tail_min_waves_;
+    }
+    while (static_cast<int>(pic_done_.size()) < n && st == XVCGPU_OK) {
+      xvcgpu_event *e = nullptr;
+      st = xvcgpu_event_create(ctx_, &e);
+      if (st == XVCGPU_OK) pic_done_.push_back(e);
+    }
+  }
   const bool trace = std::getenv("XVC_DEC_TRACE") != nullptr;
   double t_wait = 0, t_issue = 0;
   auto now = []() {
@@ -672,7 +781,21 @@ xvcgpu_status PictureDecoder::DecodeSequence(int n, const xvc_picture_syntax *co
           if (j >= i) st = XVCGPU_INVALID_ARGUMENT;   // only pictures decoded before this one
           refs[l][k] = j >= 0 && j < i ? recs[j] : nullptr;
         }
-      if (st == XVCGPU_OK) st = Issue(plans[i % kRing], *ps[i], levels[i], refs, recs[i]);
+      // the picture's lane; its kernels behind the pictures it reads that ran elsewhere
+      const int lane = i % n_lanes;
+      PictureDecoder *pd = lane ? lanes_[lane - 1].get() : this;
+      if (n_lanes > 1)
+        for (int l = 0; l < 2 && st == XVCGPU_OK; l++)
+          for (int k = 0; k < 5 && st == XVCGPU_OK; k++) {
+            const int j = ref_index[(i * 2 + l) * 5 + k];
+            if (j >= 0 && j % n_lanes != lane) st = xvcgpu_event_wait(pd->ctx_, pic_done_[j]);
+          }
+      if (st == XVCGPU_OK) {
+        SeqSlot &q = seq_slots_[i % kRing];
+        st = pd->IssuePacked(plans[i % kRing], *ps[i], q.lay, q.mem, q.copied, refs, recs[i]);
+        q.in_flight = true;
+      }
+      if (st == XVCGPU_OK && n_lanes > 1) st = xvcgpu_event_record(pd->ctx_, pic_done_[i]);
     }
     t_issue += now() - tb;
     {
@@ -688,9 +811,19 @@ xvcgpu_status PictureDecoder::DecodeSequence(int n, const xvc_picture_syntax *co
   }
   cv.notify_all();
   for (std::thread &w : workers) w.join();
+  // the caller waits on this decoder's context: it is behind every lane's last picture
+  if (n_lanes > 1 && st == XVCGPU_OK)
+    for (int lane = 1; lane < n_lanes && st == XVCGPU_OK; lane++) {
+      const int last = ((n - 1 - lane) / n_lanes) * n_lanes + lane;
+      if (last >= 0 && last < n && n - 1 >= lane) st = xvcgpu_event_wait(ctx_, pic_done_[last]);
+    }
+  else if (n_lanes > 1)
+    for (auto &l : lanes_) xvcgpu_sync(l->ctx_);   // (an error: leave no lane running)
   if (trace)
-    std::fprintf(stderr, "DecodeSequence: %d pictures, waiting for plans %.3f ms, issuing %.3f ms\n",
-                 n, 1e3 * t_wait, 1e3 * t_issue);
+    std::fprintf(stderr, "DecodeSequence: %d pictures, waiting for plans %.3f ms, issuing %.3f ms; "
+                 "planners (summed): plan %.3f ms, waiting for their slot's upload %.3f ms, "
+                 "packing %.3f ms\n",
+                 n, 1e3 * t_wait, 1e3 * t_issue, 1e3 * w_plan, 1e3 * w_wait, 1e3 * w_pack);
   return st;
 }
 
@@ -733,6 +866,10 @@ int xvc_host_picture_decoder_decode_sequence(xvc_host_picture_decoder *d, int n,
 
 void xvc_host_picture_decoder_one_launch_intra(xvc_host_picture_decoder *d, int on) {
   if (d) d->dec.set_one_launch_intra(on != 0);
+}
+
+int xvc_host_picture_decoder_add_lane(xvc_host_picture_decoder *d, xvcgpu_ctx *ctx) {
+  return d ? d->dec.AddLane(ctx) : XVCGPU_INVALID_ARGUMENT;
 }
 
 int xvc_host_picture_decoder_waves(const xvc_host_picture_decoder *d) {

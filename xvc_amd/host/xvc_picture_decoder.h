@@ -31,6 +31,7 @@
 #define XVC_AMD_HOST_XVC_PICTURE_DECODER_H_
 
 #include <cstdint>
+#include <memory>
 #include <vector>
 
 #include "xvc_syntax.h"
@@ -97,12 +98,36 @@ class PictureDecoder {
   // The same with the planning done: Decode = Validate + Plan + Issue.
   xvcgpu_status Issue(const PicturePlan &plan, const xvc_picture_syntax &ps, const int16_t *levels,
                       const xvcgpu_picture *const ref_pics[2][5], xvcgpu_picture *rec);
+  // Issue in its parts: the layout of the picture's one upload, the copy of its parts
+  // into page-locked memory (any thread), and the upload + launches.
+  struct PackedPicture {
+    size_t off[10], bytes[10], total;
+    bool one_launch, tail_launch;
+    int t0;
+    std::vector<int32_t> tail_first;
+  };
+  void Layout(const PicturePlan &plan, const xvc_picture_syntax &ps, PackedPicture *L) const;
+  static void PackInto(const PicturePlan &plan, const xvc_picture_syntax &ps,
+                       const int16_t *levels, const PackedPicture &L, void *dst);
+  xvcgpu_status IssuePacked(const PicturePlan &plan, const xvc_picture_syntax &ps,
+                            const PackedPicture &L, const void *host_mem, xvcgpu_event *copied,
+                            const xvcgpu_picture *const ref_pics[2][5], xvcgpu_picture *rec);
   // n pictures in decoding order; ref_index[(i * 2 + list) * 5 + k] = the position in
   // this sequence of picture i's reference (list, k), -1 = unused.  Planning of
   // picture i + 1 runs on a worker thread while picture i is uploaded and launched.
   xvcgpu_status DecodeSequence(int n, const xvc_picture_syntax *const *ps,
                                const xvc_cu_syntax *const *cus, const int16_t *const *levels,
                                const int32_t *ref_index, xvcgpu_picture *const *recs);
+
+  // Picture-level parallelism (the reference decoder's picture threads,
+  // xvc_dec_lib/thread_decoder.cc): a further lane = another context (its own stream)
+  // with its own prediction scratch and staging buffers.  DecodeSequence deals the
+  // pictures over the lanes in decoding order; a picture's kernels wait for the
+  // pictures it references (events), so pictures that do not depend on each other -
+  // the B pictures of one temporal layer - run side by side.  The context must be on
+  // this decoder's device and stays the caller's.
+  xvcgpu_status AddLane(xvcgpu_ctx *ctx);
+  int num_lanes() const { return 1 + static_cast<int>(lanes_.size()); }
 
   int last_num_waves() const { return last_waves_; }
   int last_num_launches() const { return last_launches_; }
@@ -135,11 +160,24 @@ class PictureDecoder {
 
   PicturePlan plan_;
   std::vector<PicturePlan> seq_plans_;   // DecodeSequence's ring (buffers kept between calls)
+  // ... and the ring's page-locked memory: the planning threads pack the picture's
+  // upload themselves (0.6 - 1.1 MB of maps and records per 1080p picture: 60 - 110 us
+  // of copying that the issuing thread no longer does)
+  struct SeqSlot {
+    PackedPicture lay;
+    void *mem;
+    size_t cap;
+    xvcgpu_event *copied;
+    bool in_flight;
+  };
+  std::vector<SeqSlot> seq_slots_;
   int last_waves_, last_launches_;
   bool use_waves_kernel_;
   int tail_min_waves_;     // inter pictures: trailing all-intra waves in one launch from this many
   HostSlot host_[2];
   int next_host_;
+  std::vector<std::unique_ptr<PictureDecoder>> lanes_;   // lanes 1 .. (this is lane 0)
+  std::vector<xvcgpu_event *> pic_done_;                  // per position of a sequence
 };
 
 }  // namespace xvc_gpu
@@ -161,6 +199,8 @@ int xvc_host_picture_decoder_decode_sequence(xvc_host_picture_decoder *d, int n,
                                              const int16_t *const *levels,
                                              const int32_t *ref_index,
                                              xvcgpu_picture *const *recs);
+// a further picture lane on `ctx` (PictureDecoder::AddLane)
+int xvc_host_picture_decoder_add_lane(xvc_host_picture_decoder *d, xvcgpu_ctx *ctx);
 int xvc_host_picture_decoder_waves(const xvc_host_picture_decoder *d);
 int xvc_host_picture_decoder_launches(const xvc_host_picture_decoder *d);
 void xvc_host_picture_decoder_one_launch_intra(xvc_host_picture_decoder *d, int on);
