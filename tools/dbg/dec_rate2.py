@@ -9,6 +9,9 @@ if "torch" in what:
     import torch
     torch.cuda.init()
     x = torch.zeros(16, device="cuda")
+if "affinity" in what:
+    print("affinity before:", len(os.sched_getaffinity(0)))
+    os.sched_setaffinity(0, range(os.cpu_count()))
 from xvc_amd import api, decoder
 import stream_fixture as sf
 ctx = api.Context(0)

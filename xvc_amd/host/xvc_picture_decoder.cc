@@ -670,6 +670,9 @@ xvcgpu_status PictureDecoder::DecodeSequence(int n, const xvc_picture_syntax *co
   bool valid[kRing] = {};
   bool ready[kRing] = {};
   const bool trace_workers = std::getenv("XVC_DEC_TRACE") != nullptr;
+  // XVC_DEC_PACK_ON_ISSUE=1: the issuing thread copies a picture's parts into its own two
+  // page-locked slots (the form before the planners packed: for comparisons)
+  const bool pack_on_issue = std::getenv("XVC_DEC_PACK_ON_ISSUE") != nullptr;
   std::mutex trace_mu;
   double w_plan = 0, w_wait = 0, w_pack = 0;
   if (seq_slots_.size() != kRing) {
@@ -680,8 +683,13 @@ xvcgpu_status PictureDecoder::DecodeSequence(int n, const xvc_picture_syntax *co
     empty.in_flight = false;
     seq_slots_.assign(kRing, empty);
   }
-  for (SeqSlot &q : seq_slots_)
+  for (SeqSlot &q : seq_slots_) {
     if (!q.copied && xvcgpu_event_create(ctx_, &q.copied) != XVCGPU_OK) return XVCGPU_DEVICE_ERROR;
+    if (q.in_flight) {          // an earlier sequence's upload
+      xvcgpu_event_synchronize(q.copied);
+      q.in_flight = false;
+    }
+  }
   // a planner validates, plans and PACKS its picture: the parts of the upload go into
   // the ring slot's page-locked memory on the planner's thread
   auto prepare = [&](int i) {
@@ -693,14 +701,14 @@ xvcgpu_status PictureDecoder::DecodeSequence(int n, const xvc_picture_syntax *co
     if (!valid[k]) return;
     const double tp0 = trace_workers ? NowSeconds() : 0;
     Plan(s, cus[i], levels[i], &plans[k]);
+    if (pack_on_issue) return;
     SeqSlot &q = seq_slots_[k];
     Layout(plans[k], s, &q.lay);
+    // (the slot's previous upload has passed: the issuing thread said so - `uploaded` -
+    // before this planner was let at the slot; planners make no runtime calls but the
+    // occasional allocation)
     const double tp1 = trace_workers ? NowSeconds() : 0;
-    if (q.in_flight) {          // the upload of the slot's previous picture
-      xvcgpu_event_synchronize(q.copied);
-      q.in_flight = false;
-    }
-    const double tp2 = trace_workers ? NowSeconds() : 0;
+    const double tp2 = tp1;
     if (q.lay.total > q.cap) {
       if (q.mem) xvcgpu_host_free(ctx_, q.mem);
       q.mem = nullptr;
@@ -726,6 +734,7 @@ xvcgpu_status PictureDecoder::DecodeSequence(int n, const xvc_picture_syntax *co
   std::mutex mu;
   std::condition_variable cv;
   int issued = 0;
+  int uploaded = -1;     // the uploads of the pictures up to this one have passed
   bool stop = false;
   std::vector<std::thread> workers;
   for (int wk = 0; wk < kWorkers && wk < n; wk++)
@@ -733,7 +742,7 @@ xvcgpu_status PictureDecoder::DecodeSequence(int n, const xvc_picture_syntax *co
       for (int i = wk; i < n; i += kWorkers) {
         {
           std::unique_lock<std::mutex> lk(mu);
-          cv.wait(lk, [&]() { return stop || issued > i - kRing; });
+          cv.wait(lk, [&]() { return stop || (issued > i - kRing && uploaded >= i - kRing); });
           if (stop) return;
         }
         prepare(i);
@@ -762,7 +771,21 @@ xvcgpu_status PictureDecoder::DecodeSequence(int n, const xvc_picture_syntax *co
   auto now = []() {
     return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
   };
+  enum { kUploadsAhead = 4 };   // uploads in flight at most; the planners' slots behind them
   for (int i = 0; i < n && st == XVCGPU_OK; i++) {
+    if (i >= kUploadsAhead) {
+      // (the only wait for the device, and on this thread: usually long passed)
+      SeqSlot &o = seq_slots_[(i - kUploadsAhead) % kRing];
+      if (o.in_flight) {
+        xvcgpu_event_synchronize(o.copied);
+        o.in_flight = false;
+      }
+      {
+        std::lock_guard<std::mutex> lk(mu);
+        uploaded = i - kUploadsAhead;
+      }
+      cv.notify_all();
+    }
     const double ta = now();
     {
       std::unique_lock<std::mutex> lk(mu);
@@ -790,7 +813,9 @@ xvcgpu_status PictureDecoder::DecodeSequence(int n, const xvc_picture_syntax *co
             const int j = ref_index[(i * 2 + l) * 5 + k];
             if (j >= 0 && j % n_lanes != lane) st = xvcgpu_event_wait(pd->ctx_, pic_done_[j]);
           }
-      if (st == XVCGPU_OK) {
+      if (st == XVCGPU_OK && pack_on_issue) {
+        st = pd->Issue(plans[i % kRing], *ps[i], levels[i], refs, recs[i]);
+      } else if (st == XVCGPU_OK) {
         SeqSlot &q = seq_slots_[i % kRing];
         st = pd->IssuePacked(plans[i % kRing], *ps[i], q.lay, q.mem, q.copied, refs, recs[i]);
         q.in_flight = true;
