@@ -538,6 +538,8 @@ residual_cu_kernel(PicView orig, PicView pred, PicView rec, const xvcgpu_tx_bloc
   __shared__ __attribute__((aligned(16))) unsigned char raw[kBytes];
   const int idx = blockIdx.x;
   if (idx >= n) return;
+  // in place and nothing coded: the block is already what it will be
+  if (MODE == TX_MODE_INV && pred.c[0].p == rec.c[0].p && nnz_out[idx] == 0) return;
   const xvcgpu_tx_block b = blocks[idx];
   if (tx_small_job(b)) {
     if (threadIdx.x >= 64) return;

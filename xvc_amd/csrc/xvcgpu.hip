@@ -114,11 +114,24 @@ void init_views(xvcgpu_picture *p) {
 
 // Both residual kernels over one batch: the one-wave-per-job kernel takes the
 // blocks up to 16x16, the scanning general-path kernel the rest.
+#ifndef XVCGPU_INV_ONE_LAUNCH_MAX
+#define XVCGPU_INV_ONE_LAUNCH_MAX 16384
+#endif
 template <int MODE>
 void launch_residual(xvcgpu_ctx *ctx, const PicView &o, const PicView &p,
                             const PicView &r, const xvcgpu_tx_block *d_blocks, int n,
                             int16_t *d_levels, const uint32_t *d_off, int32_t *d_nnz,
                             unsigned long long *d_dist = nullptr, bool small_only = false) {
+  // a decoded picture's dependency wave (a few thousand blocks, small and large mixed):
+  // one launch, a workgroup per block - the two kernels below one behind the other are
+  // two launches on the picture's critical path (5 + 12 us and the gap between them)
+  if (MODE == TX_MODE_INV && !d_dist && !small_only && n <= XVCGPU_INV_ONE_LAUNCH_MAX &&
+      ctx->inv_one_launch) {
+    hipLaunchKernelGGL((residual_cu_kernel<MODE, false>), dim3(n), dim3(TX_THREADS), 0,
+                       ctx->stream, o, p, r, d_blocks, n, d_levels, d_off, d_nnz,
+                       ctx->d_tx_tables, ctx->d_tx_tables_t, xvcgpu_tx_layout(), nullptr, nullptr);
+    return;
+  }
   const int n_wg = (n + TX2_WAVES - 1) / TX2_WAVES;
   hipLaunchKernelGGL(residual_wave_kernel<MODE>, dim3((n_wg + 7) / 8 * 8),
                      dim3(64 * TX2_WAVES), 0, ctx->stream, o, p, r, d_blocks, n,
@@ -223,6 +236,10 @@ xvcgpu_status xvcgpu_create(int device, xvcgpu_ctx **out) {
   for (int i = 0; i < 64; i++) ctx->ev_pool[i] = nullptr;
   ctx->d_me_rot = nullptr;
   ctx->me_epoch = 0;
+  {
+    const char *e = getenv("XVCGPU_INV_ONE_LAUNCH");   // 0: the two-kernel form (comparisons)
+    ctx->inv_one_launch = !(e && e[0] == '0' && !e[1]);
+  }
   if (hipSetDevice(device) != hipSuccess ||
       hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
     delete ctx;

@@ -44,6 +44,7 @@ struct xvcgpu_ctx {
   // kernels at the end of a frame pass (inverse transform, the fused tail) and the two
   // events that hand the chain over and back
   hipStream_t copy_stream;   // xvcgpu_upload_ahead: created on first use
+  bool inv_one_launch;       // xvcgpu_inv_transform_batch: one workgroup-per-block launch
   hipStream_t hi_stream;
   hipEvent_t ev_hi_in, ev_hi_out;
   hipEvent_t ev_pool[64];  // xvcgpu_timer_mark slots, created on first use
