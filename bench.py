@@ -1154,6 +1154,11 @@ def main():
         # half its rate (tools/dbg/dec_rate2.py: 4500 -> 3500 pictures/s beside three
         # idle contexts with 4 queues, 4440 with GPU_MAX_HW_QUEUES=8 as main() sets it -
         # but this process holds more than eight streams by now)
+        # ... so the chains' contexts (their streams) go first: the frame-pass figures are
+        # taken
+        for e in extra:
+            e[0].close()
+        extra = []
         dctx = api.Context(local_rank)
         dctx.use_own_stream()
         decode = stream_decode_figure(dctx, api)
