@@ -674,7 +674,7 @@ xvcgpu_status PictureDecoder::DecodeSequence(int n, const xvc_picture_syntax *co
   // page-locked slots (the form before the planners packed: for comparisons)
   const bool pack_on_issue = std::getenv("XVC_DEC_PACK_ON_ISSUE") != nullptr;
   std::mutex trace_mu;
-  double w_plan = 0, w_wait = 0, w_pack = 0;
+  double w_plan = 0, w_pack = 0;
   if (seq_slots_.size() != kRing) {
     SeqSlot empty = {};
     empty.mem = nullptr;
@@ -708,7 +708,6 @@ xvcgpu_status PictureDecoder::DecodeSequence(int n, const xvc_picture_syntax *co
     // before this planner was let at the slot; planners make no runtime calls but the
     // occasional allocation)
     const double tp1 = trace_workers ? NowSeconds() : 0;
-    const double tp2 = tp1;
     if (q.lay.total > q.cap) {
       if (q.mem) xvcgpu_host_free(ctx_, q.mem);
       q.mem = nullptr;
@@ -725,8 +724,7 @@ xvcgpu_status PictureDecoder::DecodeSequence(int n, const xvc_picture_syntax *co
       const double tp3 = NowSeconds();
       std::lock_guard<std::mutex> lk(trace_mu);
       w_plan += tp1 - tp0;
-      w_wait += tp2 - tp1;
-      w_pack += tp3 - tp2;
+      w_pack += tp3 - tp1;
     }
   };
   // slot i % kRing may be written once picture i - kRing (its previous user) has been
@@ -846,9 +844,8 @@ xvcgpu_status PictureDecoder::DecodeSequence(int n, const xvc_picture_syntax *co
     for (auto &l : lanes_) xvcgpu_sync(l->ctx_);   // (an error: leave no lane running)
   if (trace)
     std::fprintf(stderr, "DecodeSequence: %d pictures, waiting for plans %.3f ms, issuing %.3f ms; "
-                 "planners (summed): plan %.3f ms, waiting for their slot's upload %.3f ms, "
-                 "packing %.3f ms\n",
-                 n, 1e3 * t_wait, 1e3 * t_issue, 1e3 * w_plan, 1e3 * w_wait, 1e3 * w_pack);
+                 "planners (summed): plan %.3f ms, packing %.3f ms\n",
+                 n, 1e3 * t_wait, 1e3 * t_issue, 1e3 * w_plan, 1e3 * w_pack);
   return st;
 }
 
