@@ -5,6 +5,7 @@ SearchBiIterative / SearchMotion) against the reference's own member functions
 (oracle/_ref, xr_eval_start_mvp / xr_eval_final_mvp_idx / xr_mvd_bits /
 xr_search_merge_candidates / xr_search_motion), on random CUs and predictors."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -408,7 +409,9 @@ def test_search_motion_multi_ref_vs_reference(gpu, config, bd, iterations):
                   " ".join(str(int(v)) for v in e[64:76]))
         assert have == want, (i, tuple(blocks[0][0][i]))
         dirs.add(d)
-    assert 2 in dirs and len(dirs) >= 2, dirs
-    assert len({r for _, r in refs_used}) >= 2, refs_used
+    # (input coverage, for the committed seed: a soak seed may make every CU choose bi)
+    if not int(os.environ.get("XVC_SOAK", "0")):
+        assert 2 in dirs and len(dirs) >= 2, dirs
+        assert len({r for _, r in refs_used}) >= 2, refs_used
     for p in [O] + R:
         p.destroy()
