@@ -343,7 +343,17 @@ typedef struct xvcgpu_inter_contexts {
  * A pass describes what the encoder's control code knows before the search. */
 #define XVC_CS_MAX_REFS 3      /* pictures per list (default_num_ref_pics 2, placebo 3) */
 #define XVC_CS_FULLPEL 1       /* cu.GetFullpelMv()                                   */
+#define XVC_CS_FORCE_L1_MVD_ZERO 2 /* pic_data.GetForceBipredL1MvdZero() (only-back-reference
+                                * pictures, inter_search.cc:410-413, :496-518): the folds
+                                * do NOT run this variant - such a pass is answered
+                                * XVC_CS_WHICH_UNSUPPORTED (InterSearch::SearchMotionMultiBatch
+                                * of the C++ host layer handles it)                      */
 #define XVC_CS_AFFINE 8        /* the affine pass (MotionVector3, MotionEstAffine)      */
+/* xvcgpu_cs_result::which of a pass the folds do not run: XVC_CS_FORCE_L1_MVD_ZERO, or
+ * bi_iterations > 1 (the folds run ONE SearchBiIterative iteration on the list that lost,
+ * encoder_settings.cc:58-96 default / faster / slow; placebo's 4, :34, is the host
+ * layer's loop).  No refinement or evaluation job of such a pass is filled in. */
+#define XVC_CS_WHICH_UNSUPPORTED 255
 typedef struct xvcgpu_cs_pass {
   int16_t x, y;                /* luma position of the CU                              */
   uint8_t w, h;
@@ -371,7 +381,9 @@ typedef struct xvcgpu_cs_pass {
   int32_t eval;                /* the evaluation (3 xvcgpu_inter_block) that takes the
                                 * chosen motion, -1: none                              */
   int8_t slot[2][XVC_CS_MAX_REFS]; /* reference picture slot per (list, ref_idx)       */
-  uint8_t reserved[2];
+  uint8_t bi_iterations;       /* encoder_settings.bipred_refinement_iterations; 0 or 1:
+                                * one iteration, more: XVC_CS_WHICH_UNSUPPORTED          */
+  uint8_t reserved;
 } xvcgpu_cs_pass;
 
 /* What a pass computed: every intermediate the reference's loop holds (readable by

@@ -584,14 +584,15 @@ class SerialRun:
 # The chained form: passes (xvcgpu_cs_pass), work arrays the device composes, programs.
 # ======================================================================================
 R3 = 3               # XVC_CS_MAX_REFS
-CS_FULLPEL, CS_AFFINE = 1, 8
+CS_FULLPEL, CS_FORCE_L1_MVD_ZERO, CS_AFFINE = 1, 2, 8
+CS_WHICH_UNSUPPORTED = 255
 
 PASS_DTYPE = np.dtype([
     ("x", "<i2"), ("y", "<i2"), ("w", "u1"), ("h", "u1"), ("flags", "u1"), ("num_refs", "u1", 2),
     ("same_poc_in_l0", "i1", R3), ("lambda16", "<u4"), ("ictx", of.ICTX_DTYPE),
     ("mvp", "<i4", (2, R3, 2, 3, 2)), ("uni_job", "<i4", (2, R3)), ("start_dist", "<i4", (2, R3)),
     ("prev_job", "<i4", (2, R3)), ("bi_job", "<i4"), ("plain_pass", "<i4"), ("eval", "<i4"),
-    ("slot", "i1", (2, R3)), ("reserved", "u1", 2)], align=True)
+    ("slot", "i1", (2, R3)), ("bi_iterations", "u1"), ("reserved", "u1")], align=True)
 
 RESULT_DTYPE = np.dtype([
     ("start_idx", "u1", (2, R3)), ("mvp_idx", "u1", (2, R3)), ("mv", "<i4", (2, R3, 3, 2)),
@@ -661,6 +662,14 @@ def build_passes(sp, ref_lists):
             p["ictx"] = sp.order["ictx"][int(cu[0]["ictx_index"])]
             p["uni_job"], p["start_dist"], p["prev_job"] = -1, -1, -1
             p["plain_pass"], p["eval"] = -1, -1
+            # the folds run the default SearchMotion (one refinement iteration, no forced
+            # zero L1 vector difference: xvcgpu_types.h); the captured encodes are such
+            assert not cds["force_mvd_zero_other"].any(), \
+                "a pass the folds would answer XVC_CS_WHICH_UNSUPPORTED (forced zero L1 mvd)"
+            for kind_bi in (1, 3):   # one refinement iteration: a candidate per searched picture
+                assert (cds["kind"] == kind_bi).sum() <= max(nref), \
+                    "a pass the folds would answer XVC_CS_WHICH_UNSUPPORTED (iterations > 1)"
+            p["bi_iterations"] = 1
             pi = len(passes)
             entries = []
             for c in cu:

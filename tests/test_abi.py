@@ -158,6 +158,27 @@ def test_cpp_host_layer_runs_on_gpu(api, tmp_path):
     assert r.returncode == 0, r.stdout + r.stderr
 
 
+
+def test_host_headers_compile_together(tmp_path):
+    """Every header of the C++ host layer and of include/ in ONE translation unit
+    (an integrator following INTEGRATION.md's row-shard snippet includes
+    xvc_shard_engine.h and xvc_shard_filter.h together: a name that is a type in
+    one and a function in the other would not compile)."""
+    import subprocess
+    host = os.path.join(ROOT, "xvc_amd", "host")
+    inc = os.path.join(ROOT, "include")
+    names = sorted(f for f in os.listdir(inc) if f.endswith(".h")) + \
+        sorted(f for f in os.listdir(host) if f.endswith(".h"))
+    assert "xvc_shard_engine.h" in names and "xvc_shard_filter.h" in names
+    src = tmp_path / "all_headers.cc"
+    src.write_text("".join('#include "%s"\n' % n for n in names) +
+                   "int main() { xvc_shard_plan *p = nullptr; (void)p;\n"
+                   "  int (*f)(const int32_t *, int, int, const int32_t *, int32_t *) = "
+                   "xvc_shard_filter_plan; (void)f; return 0; }\n")
+    subprocess.check_call(["g++", "-std=c++11", "-Wall", "-Wextra", "-Werror", "-fsyntax-only",
+                           "-I", inc, "-I", host, str(src)])
+
+
 def _build_frame_pass_program(tmpdir):
     import subprocess
     host = os.path.join(ROOT, "xvc_amd", "host")

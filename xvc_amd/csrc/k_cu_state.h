@@ -41,6 +41,12 @@ __device__ __forceinline__ bool cs_affine(const xvcgpu_cs_pass &p) {
 __device__ __forceinline__ bool cs_fullpel(const xvcgpu_cs_pass &p) {
   return (p.flags & XVC_CS_FULLPEL) != 0;
 }
+// The variants of SearchMotion the folds do not run (xvcgpu_types.h): the L1 vector
+// difference forced to zero (inter_search.cc:410-413, :496-518), more than one
+// refinement iteration (:394).  Answered, never computed as if they were the default.
+__device__ __forceinline__ bool cs_unsupported(const xvcgpu_cs_pass &p) {
+  return (p.flags & XVC_CS_FORCE_L1_MVD_ZERO) != 0 || p.bi_iterations > 1;
+}
 
 // InterSearch::GetMvdBits (inter_search.cc:1149-1164): two corners for MotionVector3
 __device__ __forceinline__ uint32_t cs_mvd_bits(const int32_t mvp[3][2], const int32_t mv[3][2],
@@ -270,6 +276,10 @@ __global__ void cs_uni_fold_kernel(const xvcgpu_cs_pass *passes, int first, int 
       aff_jobs[p.bi_job + i].w = 0;
   }
   R.bi_valid = 0;
+  if (cs_unsupported(p)) {                 // no refinement job: the bi fold answers
+    R.which = XVC_CS_WHICH_UNSUPPORTED;
+    return;
+  }
   if (!p.num_refs[1]) return;              // kUniPredOnly (:228-230)
   // SearchBiIterative (:392-433), one iteration: searches the list that lost
   const int best_dir = R.cost_list[0] <= R.cost_list[1] ? 0 : 1;
@@ -368,6 +378,20 @@ __global__ void cs_bi_fold_kernel(const xvcgpu_cs_pass *passes, int first, int n
   __syncthreads();
   auto body = [&]() {
   const bool affine = cs_affine(p), fullpel = cs_fullpel(p);
+  if (cs_unsupported(p)) {
+    // answered, not computed: no motion, never chosen, the evaluation gets no reference
+    R.which = XVC_CS_WHICH_UNSUPPORTED;
+    R.chosen = 0;
+    R.best_cost = CS_MAXCOST;
+    R.inter_dir = 0;
+    R.ref_idx[0] = R.ref_idx[1] = -1;
+    if (p.eval >= 0)
+      for (int c = 0; c < 3; c++) {
+        xvcgpu_inter_block &b = ev_inter[3 * p.eval + c];
+        b.ref[0] = b.ref[1] = -1;
+      }
+    return;
+  }
   uint32_t cost_bi = CS_MAXCOST;
   int bi_ref = -1;
   const int s = R.search_list, od = 1 - s;

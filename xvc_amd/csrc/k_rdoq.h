@@ -1154,6 +1154,40 @@ __device__ __forceinline__ int wave_rdoq(S &s, int lane, int bd, int w, int h,
   return nnz + rq_wave_sum_i32<G>(dn);
 }
 
+// the inverse of the 4x4 scan: position y * 4 + x -> scan offset, 16 nibbles
+constexpr unsigned long long rq_pack_scan4_inv(int order) {
+  const unsigned long long t = tx_pack_scan4(order);
+  unsigned long long r = 0;
+  for (int k = 0; k < 16; k++) r |= (unsigned long long)k << (4 * (int)((t >> (4 * k)) & 15ull));
+  return r;
+}
+
+// A snapshot's bit costs into cb[2 * sizeof(xvcgpu_rdoq_contexts)] by `lanes` lanes
+// (lane = 0 .. lanes - 1): a word of four contexts per lane and round, then its eight
+// table entries - two round trips (byte by byte: three dependent pairs).
+__device__ __forceinline__ void rq_stage_costs(const xvcgpu_rdoq_contexts *snap, unsigned *cb,
+                                               int lane, int lanes) {
+  static_assert(sizeof(xvcgpu_rdoq_contexts) % 4 == 0, "whole words of contexts");
+  constexpr int kWords = (int)sizeof(xvcgpu_rdoq_contexts) / 4;
+  const uint32_t *cw = reinterpret_cast<const uint32_t *>(snap);
+  for (int wi = lane; wi < kWords; wi += lanes) {
+    const uint32_t word = cw[wi];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const unsigned st8 = (word >> (8 * k)) & 127;
+      *reinterpret_cast<uint2 *>(cb + 8 * wi + 2 * k) =
+          make_uint2(kEntropyBits[st8], kEntropyBits[st8 ^ 1]);
+    }
+  }
+}
+
+// Blocks wave_rdoq4 (k_rdoq4.h: four lanes per sub-block) takes with G lanes
+__device__ __forceinline__ bool rq4_takes(int G, int w, int h, int scan_order) {
+  return scan_order == 0 && w >= 4 && h >= 4 && w <= 32 && h <= 32 && (w >> 2) * (h >> 2) * 4 <= G;
+}
+
+#include "k_rdoq4.h"
+
 // ---- the quantiser alone, packed ------------------------------------------------
 // For flows that hold the transform coefficients (xvcgpu_fwd_transform_batch ->
 // here -> xvcgpu_inv_transform_batch).  A block keeps <= 4 lanes of a wave busy
@@ -1292,13 +1326,6 @@ __device__ __forceinline__ int rq_prove_threshold(const RqProveBlock &k) {
   while (t * k.scale < k.fq_offset) t++;
   while (t > 0 && (t - 1) * k.scale >= k.fq_offset) t--;
   return t > 32768 ? 32768 : (int)t;
-}
-
-constexpr unsigned long long rq_pack_scan4_inv(int order) {
-  const unsigned long long t = tx_pack_scan4(order);
-  unsigned long long r = 0;
-  for (int k = 0; k < 16; k++) r |= (unsigned long long)k << (4 * (int)((t >> (4 * k)) & 15ull));
-  return r;
 }
 
 // One candidate (x, y) with magnitude a: what coding it can save at most as an
@@ -1767,16 +1794,17 @@ rdoq_scatter_kernel(int n, RdoqLists l) {
     for (int k = 0; k < 3; k++) l.count[k] = bs[k] + part[k][16 + 15];
 }
 
-// LDS of one wave of class G.  One table of context costs per wave: the groups
-// of a wave nearly always name the same snapshot; when they do not, the wave
-// serves one snapshot after the other (a table per group cost 19 KB of LDS per
-// wave in the 4-lane class - enough, with the walk's long-lived waves, to keep
-// other kernels off the CUs).
-template <int G>
+// LDS of one wave: G lanes per block (64 / G blocks per wave), blocks of at most NSB
+// region sub-blocks.  One table of context costs per wave: the groups of a wave
+// nearly always name the same snapshot; when they do not, the wave serves one
+// snapshot after the other (a table per group cost 19 KB of LDS per wave in the
+// 4-lane class - enough, with the walk's long-lived waves, to keep other kernels
+// off the CUs).
+template <int G, int NSB>
 struct RdoqPackedLds {
   static constexpr int GROUPS = 64 / G;
-  static constexpr int MAXC = G == 4 ? 64 : (G == 16 ? 256 : 1024);  // region coefficients
-  static constexpr int MAXSB = G;                                      // region sub-blocks
+  static constexpr int MAXC = 16 * NSB;                                // region coefficients
+  static constexpr int MAXSB = NSB;                                    // region sub-blocks
   static constexpr int MAXR = RQ_PADDED(MAXC);     // records: RQ_SB_STRIDE per sub-block
   static constexpr int MAXT = RQ_CF_PADDED(MAXC);  // coefficient / level tiles: RQ_CF_STRIDE
   // the per-coefficient records: 5 bytes each (+ 4 of coefficient and level)
@@ -1786,16 +1814,17 @@ struct RdoqPackedLds {
   alignas(8) unsigned ctx_bits[2 * sizeof(xvcgpu_rdoq_contexts)];
   unsigned csbf_bits[GROUPS][MAXSB];
   unsigned char csbf[GROUPS][MAXSB], sb_live[GROUPS][MAXSB], sb_dcz[GROUPS][MAXSB];
-  unsigned char sb_of_scan[GROUPS][G == 64 ? 256 : (G == 4 ? MAXSB : MAXSB * 4)];   // (G = 4: grid = region)
+  // the whole grid's scan (64-point sides: up to four times the region; NSB = 4: grid = region)
+  unsigned char sb_of_scan[GROUPS][NSB == 4 ? MAXSB : MAXSB * 4];
   // one table per wave: the groups of a round share shape, scan and snapshot
-  unsigned lp_bits[G == 4 ? 16 : 32];   // (G = 4: a side is at most 16, 8 groups)
+  unsigned lp_bits[32];
 };
 
 // G lanes per block; grid: an upper bound on ceil(count / (64 / G)) waves (the
 // list's count is read on the device); block: 64.
-template <int G>
+template <int G, int NSB>
 __device__ __forceinline__ void quant_rdo_packed_wave(
-    RdoqPackedLds<G> &sm, int wave, int bd, const xvcgpu_tx_block *blocks, const int *list,
+    RdoqPackedLds<G, NSB> &sm, int wave, int bd, const xvcgpu_tx_block *blocks, const int *list,
     const int *count, const int16_t *coeffs, const uint32_t *d_off, int16_t *levels,
     int32_t *nnz_out, const xvcgpu_rdoq_contexts *rq_ctx, const xvcgpu_rdoq_params *rq_prm,
     xvcgpu_cu_info *cu_patch = nullptr) {
@@ -1931,11 +1960,17 @@ __device__ __forceinline__ void quant_rdo_packed_wave(
       xvcgpu_rdoq_params uprm = prm;   // rd_factor stays the lane's own
       uprm.lambda = ulambda;
       uprm.flags = (uint8_t)upf;
-      nnz = wave_rdoq<G>(
-          v, lane, bd, uw, uh, uqp, uluma != 0, (uflags >> XVC_TXF_SCAN_SHIFT) & 3,
-          !(uflags & XVC_TXF_NO_SIGN_HIDING), rq_ctx[cur], uprm,
-          [cf, utile](int x, int y) { return (int)cf[utile(x, y)]; },
-          [lv, utile](int x, int y) { return lv + utile(x, y); }, false, false);
+      const int uscan = (uflags >> XVC_TXF_SCAN_SHIFT) & 3;
+      auto cf_at = [cf, utile](int x, int y) { return (int)cf[utile(x, y)]; };
+      auto lv_at = [lv, utile](int x, int y) { return lv + utile(x, y); };
+      // four lanes per sub-block where the block fits the group that way (k_rdoq4.h)
+      if (G == 4 * NSB && rq4_takes(G, uw, uh, uscan))
+        nnz = wave_rdoq4<G>(v, lane, bd, uw, uh, uqp, uluma != 0,
+                            !(uflags & XVC_TXF_NO_SIGN_HIDING), uprm, cf_at, lv_at);
+      else
+        nnz = wave_rdoq<G>(v, lane, bd, uw, uh, uqp, uluma != 0, uscan,
+                           !(uflags & XVC_TXF_NO_SIGN_HIDING), rq_ctx[cur], uprm, cf_at, lv_at,
+                           false, false);
       pending = false;
     }
   }
@@ -1976,37 +2011,42 @@ __device__ __forceinline__ void quant_rdo_packed_wave(
 // a long walk still delays nobody.  grid: g16 + g4 + g64; block: 64.
 __device__ __forceinline__ void quant_rdo_packed_kernel_body(int bd, const xvcgpu_tx_block *blocks, RdoqLists l, int g16, int g4, const int16_t *coeffs, const uint32_t *d_off, int16_t *levels, int32_t *nnz_out, const xvcgpu_rdoq_contexts *rq_ctx, const xvcgpu_rdoq_params *rq_prm, xvcgpu_cu_info *cu_patch) {
   union Lds {
-    RdoqPackedLds<16> a;
-    RdoqPackedLds<4> b;
-    RdoqPackedLds<64> c;
+    RdoqPackedLds<64, 16> a;
+    RdoqPackedLds<16, 4> b;
+    RdoqPackedLds<64, 64> c;
   };
   __shared__ Lds sm;
   const int wg = blockIdx.x, g64 = (int)gridDim.x - g16 - g4;
   if (wg < g16) {
-    const int waves = (l.count[1] + 3) >> 2;
+    // up to sixteen sub-blocks: a block per wave, four lanes per sub-block
+    const int waves = l.count[1];
     for (int wv = wg; wv < waves; wv += g16) {
-      quant_rdo_packed_wave<16>(sm.a, wv, bd, blocks, l.list[1], l.count + 1, coeffs, d_off,
-                                levels, nnz_out, rq_ctx, rq_prm, cu_patch);
+      quant_rdo_packed_wave<64, 16>(sm.a, wv, bd, blocks, l.list[1], l.count + 1, coeffs, d_off,
+                                    levels, nnz_out, rq_ctx, rq_prm, cu_patch);
       wave_sync();
     }
   } else if (wg < g16 + g4) {
-    const int waves = (l.count[0] + 15) >> 4;
+    // up to four sub-blocks: four blocks per wave
+    const int waves = (l.count[0] + 3) >> 2;
     for (int wv = wg - g16; wv < waves; wv += g4) {
-      quant_rdo_packed_wave<4>(sm.b, wv, bd, blocks, l.list[0], l.count + 0, coeffs, d_off,
-                               levels, nnz_out, rq_ctx, rq_prm, cu_patch);
+      quant_rdo_packed_wave<16, 4>(sm.b, wv, bd, blocks, l.list[0], l.count + 0, coeffs, d_off,
+                                   levels, nnz_out, rq_ctx, rq_prm, cu_patch);
       wave_sync();
     }
   } else {
     const int waves = l.count[2];
     for (int wv = wg - g16 - g4; wv < waves; wv += g64) {
-      quant_rdo_packed_wave<64>(sm.c, wv, bd, blocks, l.list[2], l.count + 2, coeffs, d_off,
-                                levels, nnz_out, rq_ctx, rq_prm, cu_patch);
+      quant_rdo_packed_wave<64, 64>(sm.c, wv, bd, blocks, l.list[2], l.count + 2, coeffs, d_off,
+                                    levels, nnz_out, rq_ctx, rq_prm, cu_patch);
       wave_sync();
     }
   }
 }
 
-__global__ void __launch_bounds__(64, 4)
+#ifndef RDOQ_MIN_WAVES
+#define RDOQ_MIN_WAVES 2   // per SIMD: 256 vector registers
+#endif
+__global__ void __launch_bounds__(64, RDOQ_MIN_WAVES)
 quant_rdo_packed_kernel(int bd, const xvcgpu_tx_block *blocks, RdoqLists l, int g16, int g4, const int16_t *coeffs, const uint32_t *d_off, int16_t *levels, int32_t *nnz_out, const xvcgpu_rdoq_contexts *rq_ctx, const xvcgpu_rdoq_params *rq_prm, xvcgpu_cu_info *cu_patch = nullptr) {
   quant_rdo_packed_kernel_body(bd, blocks, l, g16, g4, coeffs, d_off, levels, nnz_out, rq_ctx, rq_prm, cu_patch);
 }

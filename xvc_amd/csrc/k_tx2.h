@@ -295,10 +295,17 @@ __device__ __forceinline__ int tx2_job(Tx2Shared &sh, const xvcgpu_tx_block &b, 
       const xvcgpu_rdoq_params prm = rq_prm[bi];
       const int16_t *cfp = s.c;
       int16_t *lvp = s.r;
-      nnz = wave_rdoq<G>(
-          *rq, lane, bd, w, h, b.qp, b.comp == 0, scan_order, sign_hide, rq_ctx[prm.ctx_index],
-          prm, [cfp, h](int x, int y) { return (int)cfp[x * h + y]; },
-          [lvp, h](int x, int y) { return lvp + x * h + y; });
+      auto cf_at = [cfp, h](int x, int y) { return (int)cfp[x * h + y]; };
+      auto lv_at = [lvp, h](int x, int y) { return lvp + x * h + y; };
+      if (G == 64 && rq4_takes(64, w, h, scan_order)) {
+        // four lanes per sub-block (k_rdoq4.h): the whole wave on this block's walk
+        rq_stage_costs(&rq_ctx[prm.ctx_index], rq->ctx_bits, lane, 64);
+        wave_sync();
+        nnz = wave_rdoq4<64>(*rq, lane, bd, w, h, b.qp, b.comp == 0, sign_hide, prm, cf_at, lv_at);
+      } else {
+        nnz = wave_rdoq<G>(*rq, lane, bd, w, h, b.qp, b.comp == 0, scan_order, sign_hide,
+                           rq_ctx[prm.ctx_index], prm, cf_at, lv_at);
+      }
       wave_sync();
     }
     int local = 0;

@@ -1151,10 +1151,10 @@ xvcgpu_status xvcgpu_residual_rdoq_batch(xvcgpu_ctx *ctx, const xvcgpu_picture *
 
 // workgroups per class of quant_rdo_packed_kernel (k_rdoq.h)
 #ifndef RDOQ_GRID16
-#define RDOQ_GRID16 2048
+#define RDOQ_GRID16 8192   // blocks of up to sixteen sub-blocks: one per wave
 #endif
 #ifndef RDOQ_GRID4
-#define RDOQ_GRID4 512
+#define RDOQ_GRID4 2048    // blocks of up to four sub-blocks: four per wave
 #endif
 #ifndef RDOQ_GRID64
 #define RDOQ_GRID64 512
@@ -1253,7 +1253,7 @@ static xvcgpu_status quant_rdo_launch(xvcgpu_ctx *ctx, int bitdepth,
   }
   // the class sizes are only known on the device: a bounded number of workgroups
   // per class that walk their list (k_rdoq.h)
-  const int g16 = std::min((n + 3) / 4, RDOQ_GRID16), g4 = std::min((n + 15) / 16, RDOQ_GRID4),
+  const int g16 = std::min(n, RDOQ_GRID16), g4 = std::min((n + 3) / 4, RDOQ_GRID4),
             g64 = std::min(n, RDOQ_GRID64);
   hipLaunchKernelGGL(quant_rdo_packed_kernel, dim3(g16 + g4 + g64), dim3(64), 0, ctx->stream,
                      bitdepth, d_blocks, l, g16, g4, d_coeffs, d_offsets, d_levels, d_nnz,
@@ -2219,8 +2219,8 @@ xvcgpu_status xvcgpu_frame_pass_multi(xvcgpu_ctx *const *ctxs,
     hipLaunchKernelGGL(rdoq_classify_multi_kernel, dim3((max_tx + 3) / 4, n), dim3(256), 0,
                        ctx->stream, q, bd);
     hipLaunchKernelGGL(rdoq_compact_multi_kernel, dim3(1, n), dim3(1024), 0, ctx->stream, q);
-    const int g16 = std::min((max_tx + 3) / 4, RDOQ_GRID16),
-              g4 = std::min((max_tx + 15) / 16, RDOQ_GRID4), g64 = std::min(max_tx, RDOQ_GRID64);
+    const int g16 = std::min(max_tx, RDOQ_GRID16),
+              g4 = std::min((max_tx + 3) / 4, RDOQ_GRID4), g64 = std::min(max_tx, RDOQ_GRID64);
     hipLaunchKernelGGL(quant_rdo_packed_multi_kernel, dim3(g16 + g4 + g64, n), dim3(64), 0,
                        ctx->stream, q, bd, g16, g4);
     // 4. dequantisation + inverse transform + reconstruction

@@ -41,7 +41,7 @@ int xvc_shard_chain_rows(const int32_t *cu_map, int map_stride, int pic_w, int p
   return 4 * rows - y0;
 }
 
-int xvc_shard_plan(const int32_t *cu_map, int map_stride, int world, const int32_t *rows,
+int xvc_shard_filter_plan(const int32_t *cu_map, int map_stride, int world, const int32_t *rows,
                    int32_t *d_top) {
   if (!cu_map || !rows || world < 1) return XVCGPU_INVALID_ARGUMENT;
   const int pic_h = rows[world], pic_w = map_stride * 4;
@@ -68,7 +68,7 @@ int xvc_shard_filter_run(const int32_t *cu_map, int map_stride, int rank, int wo
   // leave its neighbours waiting in their send / receive groups).
   int32_t d_all[64];
   {
-    const int st = xvc_shard_plan(cu_map, map_stride, world, rows, d_all);
+    const int st = xvc_shard_filter_plan(cu_map, map_stride, world, rows, d_all);
     if (st != XVCGPU_OK) return st;
   }
   const int y0 = rows[rank], y1 = rows[rank + 1], d_top = d_all[rank];

@@ -30,7 +30,7 @@
 //   Exact for every CU tree (no assumption on CU heights); two small exchanges
 //   per picture instead of scheme B's one; no rank waits for more than its upper
 //   neighbour's step 2.  Requires y0 + D <= y1 - 4 (a shard taller than its chain);
-//   every rank checks EVERY boundary (xvc_shard_plan: all ranks hold the CU map and
+//   every rank checks EVERY boundary (xvc_shard_filter_plan: all ranks hold the CU map and
 //   reach the same verdict before the first transfer).
 //
 // ChainRows is host arithmetic on the CU map (also what the engine-agnostic
@@ -52,7 +52,7 @@ int xvc_shard_chain_rows(const int32_t *cu_map, int map_stride, int pic_w, int p
 // D of every boundary (d_top[r] for rank r's upper boundary, d_top[0] = 0; d_top may
 // be NULL): XVCGPU_OK, or XVCGPU_UNSUPPORTED when some shard is shorter than the
 // chain entering it - the same answer on every rank.
-int xvc_shard_plan(const int32_t *cu_map, int map_stride, int world, const int32_t *rows,
+int xvc_shard_filter_plan(const int32_t *cu_map, int map_stride, int world, const int32_t *rows,
                    int32_t *d_top);
 
 // Steps 1-5 on callbacks: pass(which, ya, yb) filters the edges of direction `which`

@@ -463,17 +463,17 @@ def chain_rows(cu_map, pic_w, pic_h, y0):
 
 def shard_plan(cu_map, world, rows):
     """(all shards taller than their chains?, [D of every rank's upper boundary])
-    - xvc_shard_plan of the C++ layer."""
+    - xvc_shard_filter_plan of the C++ layer."""
     import ctypes as C
     from . import decoder
     lib = decoder.load_host_library()
     m = np.ascontiguousarray(cu_map, np.int32)
     r = (C.c_int32 * (world + 1))(*[int(v) for v in rows])
     d = (C.c_int32 * world)()
-    lib.xvc_shard_plan.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
-    st = int(lib.xvc_shard_plan(m.ctypes.data, m.shape[1], world, r, d))
+    lib.xvc_shard_filter_plan.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    st = int(lib.xvc_shard_filter_plan(m.ctypes.data, m.shape[1], world, r, d))
     if st not in (0, 50):               # XVCGPU_OK, XVCGPU_UNSUPPORTED (include/xvcgpu.h)
-        raise ValueError("xvc_shard_plan: status %d" % st)
+        raise ValueError("xvc_shard_filter_plan: status %d" % st)
     return st == 0, list(d)
 
 
@@ -498,7 +498,7 @@ class ShardedTreeFilter:
         self.up = rank - 1 if rank > 0 else None
         self.down = rank + 1 if rank < world - 1 else None
         # every rank plans every boundary: the same verdict everywhere, before the
-        # first transfer (xvc_shard_plan)
+        # first transfer (xvc_shard_filter_plan)
         ok, d_all = shard_plan(engine.cu_map, world, rows)
         if not ok:
             raise ValueError("a shard must be taller than the chain that enters it "
