@@ -18,18 +18,21 @@ fp = pipeline.FramePass(ctx, W, H, bd, qp=32, rdoq=True)
 # CHAIN=n: the state of a chain after n pictures (the bench's steady state is
 # reached after a few hundred: tools/chain_drift.py); default: a chain's first pictures
 chain = int(os.environ.get("CHAIN", "0"))
+steady = os.environ.get("STATE", "") == "steady"   # the chain of tools/run_rdoq_steady.py / throughput_cost.py
 for j in range(chain):
     k = j % 14
-    O.upload(pad(clip.frame(k if k < 8 else 14 - k)), border)
+    O.upload(pad(clip.frame(j % 7 + 1 if steady else (k if k < 8 else 14 - k))), border)
     fp.run(O, R, Rec)
     R, Rec = Rec, R
+if steady:
+    O.upload(pad(clip.frame(chain % 7 + 1)), border)
 for _ in range(3):
     fp.run(O, R, Rec)
 ctx.sync()
 lib = api.load_library()
 counts = (C.c_int32 * 3)()
 lib.xvcgpu_quant_rdo_class_counts(ctx.h, counts)
-rows = min(2048, (counts[1] + 3) // 4)
+rows = min(2048, counts[1])   # a block per workgroup (k_rdoq4.h)
 buf = np.zeros((4096, 16), np.uint64)
 lib.xvcgpu_debug_rdoq_trace(buf.ctypes.data_as(C.c_void_p), 4096)
 steps = buf[:rows, 11:15].astype(np.int64)
@@ -39,10 +42,23 @@ ok = (t[:, 10] > t[:, 0]) & (t[:, 4] > 0)
 t = t[ok]
 steps = steps[ok]
 steps2 = steps2[ok]
-print("%d waves of the 16-lane class (%d blocks); clock ticks" % (len(t), counts[1]))
+print("%d waves of the class of up to sixteen sub-blocks, a block each (%d blocks); clock ticks" % (len(t), counts[1]))
 names = ["count,list", "block,prm,off", "coefficients", "ctx costs", "quant+last", "setup",
          "diagonals", "EvalLastPos", "zero+signs", "sign hide", "levels out"]
 life = t[:, 10] - t[:, 0]
+rt = buf[2048:2048 + rows, :2].astype(np.int64)[ok]
+rt_us = (rt[:, 1] - rt[:, 0]) / 100.0          # s_memrealtime: 100 MHz
+good = rt_us > 0
+print("wall clock per wave life: mean %.1f us p50 %.1f p90 %.1f max %.1f; s_memtime ticks per us: %.0f" %
+      (rt_us[good].mean(), np.median(rt_us[good]), np.percentile(rt_us[good], 90), rt_us[good].max(),
+       (life[good] / rt_us[good]).mean()))
+g = good
+st0 = rt[g, 0].min()
+print("wall clock, relative to the first wave's start: wave starts p50 %.1f p90 %.1f max %.1f us; "
+      "wave ends p50 %.1f p90 %.1f max %.1f us" %
+      (np.median(rt[g, 0] - st0) / 100.0, np.percentile(rt[g, 0] - st0, 90) / 100.0,
+       (rt[g, 0] - st0).max() / 100.0, np.median(rt[g, 1] - st0) / 100.0,
+       np.percentile(rt[g, 1] - st0, 90) / 100.0, (rt[g, 1] - st0).max() / 100.0))
 print("wave lifetime: mean %.0f p50 %.0f p90 %.0f max %d" % (life.mean(), np.median(life), np.percentile(life, 90), life.max()))
 prev = t[:, 0]
 for k in range(1, 11):

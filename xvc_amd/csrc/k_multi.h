@@ -64,10 +64,16 @@ rdoq_compact_multi_kernel(MultiArgs<RdoqMultiArgs> m) {
   const RdoqMultiArgs &a = m.a[blockIdx.y];
   rdoq_compact_kernel_body(a.n, a.l);
 }
-__global__ void __launch_bounds__(64)
-quant_rdo_packed_multi_kernel(MultiArgs<RdoqMultiArgs> m, int bd, int g16, int g4) {
+__global__ void __launch_bounds__(64, RDOQ4_MIN_WAVES)
+quant_rdo_packed4_multi_kernel(MultiArgs<RdoqMultiArgs> m, int bd, int g16) {
   const RdoqMultiArgs &a = m.a[blockIdx.y];
-  quant_rdo_packed_kernel_body(bd, a.blocks, a.l, g16, g4, a.coeffs, a.d_off, a.levels, a.nnz_out,
+  quant_rdo_packed4_kernel_body(bd, a.blocks, a.l, g16, a.coeffs, a.d_off, a.levels, a.nnz_out,
+                                a.rq_ctx, a.rq_prm, nullptr);
+}
+__global__ void __launch_bounds__(64, RDOQ_MIN_WAVES)
+quant_rdo_packed_multi_kernel(MultiArgs<RdoqMultiArgs> m, int bd) {
+  const RdoqMultiArgs &a = m.a[blockIdx.y];
+  quant_rdo_packed_kernel_body(bd, a.blocks, a.l, a.coeffs, a.d_off, a.levels, a.nnz_out,
                                a.rq_ctx, a.rq_prm, nullptr);
 }
 

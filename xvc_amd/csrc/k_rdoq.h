@@ -59,8 +59,16 @@ __device__ unsigned long long g_rq_trace[4096][16];
     if (threadIdx.x == 0 && blockIdx.x < 4096)                               \
       g_rq_trace[blockIdx.x][k] = __builtin_amdgcn_s_memtime();              \
   } while (0)
+// the 100 MHz wall clock beside it (rows 2048 + workgroup, columns 0 / 1): what a
+// tick of s_memtime is worth at the clock the chip runs this kernel at
+#define RQ_TRACE_RT(k)                                                       \
+  do {                                                                       \
+    if (threadIdx.x == 0 && blockIdx.x < 2048)                               \
+      g_rq_trace[2048 + blockIdx.x][k] = __builtin_amdgcn_s_memrealtime();   \
+  } while (0)
 #else
 #define RQ_TRACE(k) do {} while (0)
+#define RQ_TRACE_RT(k) do {} while (0)
 #endif
 // step times inside the diagonal loop, summed (rows' columns 11-13, 14 = diagonals)
 #ifdef XVCGPU_TRACE
@@ -1206,11 +1214,12 @@ struct RdoqLists {
 };
 #define RDOQ_CHUNK 4096   // blocks per workgroup of the compaction kernels (4 per thread)
 
+// 0 / 1: diagonal scan, 4x4 sub-blocks, at most four / sixteen of them - four lanes
+// per sub-block (wave_rdoq4); 2: everything else (the other scans, 2-wide blocks,
+// more than sixteen sub-blocks, 64-point sides) - a lane per sub-block (wave_rdoq)
 __device__ __forceinline__ int rq_class_of(const xvcgpu_tx_block &b) {
-  const int sbs = (b.w == 2 || b.h == 2) ? 1 : 2;
-  const int rw = b.w < 32 ? b.w : 32, rh = b.h < 32 ? b.h : 32;
-  const int n_sb = (rw >> sbs) * (rh >> sbs);
-  return n_sb <= 4 ? 0 : (n_sb <= 16 ? 1 : 2);
+  if (!rq4_takes(64, b.w, b.h, (b.intra_pic >> XVC_TXF_SCAN_SHIFT) & 3)) return 2;
+  return (b.w >> 2) * (b.h >> 2) <= 4 ? 0 : 1;
 }
 
 // Classification + the trivial case.  One wave per block: does any coefficient
@@ -1822,7 +1831,7 @@ struct RdoqPackedLds {
 
 // G lanes per block; grid: an upper bound on ceil(count / (64 / G)) waves (the
 // list's count is read on the device); block: 64.
-template <int G, int NSB>
+template <int G, int NSB, bool FOUR>
 __device__ __forceinline__ void quant_rdo_packed_wave(
     RdoqPackedLds<G, NSB> &sm, int wave, int bd, const xvcgpu_tx_block *blocks, const int *list,
     const int *count, const int16_t *coeffs, const uint32_t *d_off, int16_t *levels,
@@ -1832,6 +1841,7 @@ __device__ __forceinline__ void quant_rdo_packed_wave(
   const int g = threadIdx.x / G, lane = threadIdx.x % G;
   const int slot = wave * GROUPS + g;
   RQ_TRACE(0);
+  RQ_TRACE_RT(0);
   const int n_list = *count;
   if (wave * GROUPS >= n_list) return;  // the launch is an upper bound
   const bool active = slot < n_list;
@@ -1843,6 +1853,11 @@ __device__ __forceinline__ void quant_rdo_packed_wave(
   const uint32_t off = d_off[bi];
   const int16_t *src = coeffs + off;
   int16_t *cf = sm.cf[g], *lv = sm.lv[g];
+  // this lane's word of its own block's snapshot, fetched beside the coefficients (the
+  // round below nearly always serves that snapshot: one global round trip less)
+  constexpr int kCtxWords = (int)sizeof(xvcgpu_rdoq_contexts) / 4;
+  const int ctx_wi = (int)threadIdx.x < kCtxWords ? (int)threadIdx.x : kCtxWords - 1;
+  const uint32_t word_own = reinterpret_cast<const uint32_t *>(&rq_ctx[prm.ctx_index])[ctx_wi];
   RQ_TRACE(1);
   // blocks that are their own region (no 64-point side), a multiple of 8
   // coefficients, 16-byte aligned in both arrays: 16-byte copies in and out
@@ -1918,8 +1933,7 @@ __device__ __forceinline__ void quant_rdo_packed_wave(
                     "one word of contexts per lane");
       constexpr int kWords = (int)sizeof(xvcgpu_rdoq_contexts) / 4;
       const uint32_t *cw = reinterpret_cast<const uint32_t *>(&rq_ctx[cur]);
-      const int wi = (int)threadIdx.x < kWords ? (int)threadIdx.x : kWords - 1;
-      const uint32_t word = cw[wi];
+      const uint32_t word = (int)prm.ctx_index == cur ? word_own : cw[ctx_wi];
       unsigned e[8];
 #pragma unroll
       for (int k = 0; k < 4; k++) {
@@ -1963,8 +1977,7 @@ __device__ __forceinline__ void quant_rdo_packed_wave(
       const int uscan = (uflags >> XVC_TXF_SCAN_SHIFT) & 3;
       auto cf_at = [cf, utile](int x, int y) { return (int)cf[utile(x, y)]; };
       auto lv_at = [lv, utile](int x, int y) { return lv + utile(x, y); };
-      // four lanes per sub-block where the block fits the group that way (k_rdoq4.h)
-      if (G == 4 * NSB && rq4_takes(G, uw, uh, uscan))
+      if (FOUR)   // four lanes per sub-block (k_rdoq4.h): the class lists hold what it takes
         nnz = wave_rdoq4<G>(v, lane, bd, uw, uh, uqp, uluma != 0,
                             !(uflags & XVC_TXF_NO_SIGN_HIDING), uprm, cf_at, lv_at);
       else
@@ -1995,60 +2008,69 @@ __device__ __forceinline__ void quant_rdo_packed_wave(
   // blocks 3 * cu + comp (xvcgpu_fwd_from_me_classify wrote the CU's record with cbf_luma = 0)
   if (lane == 0 && cu_patch && b.comp == 0 && nnz) cu_patch[bi / 3].cbf_luma = 1;
   RQ_TRACE(10);
+  RQ_TRACE_RT(1);
 }
 
-// The three classes in ONE launch: their walks are independent and each is
-// bounded by its own slowest block, so one after the other they cost the sum of
-// three tails (180 + 53 + 7 us on the bench picture), together the longest.
-// Workgroups [0, g16) take the 16-lane class (the long walks first), then g4 for
-// the 4-lane class, the rest the 64-lane class.  The lists' counts are only known
-// on the device, and a workgroup holds its LDS from the moment it starts (29.5 KB
-// when this was measured, five per CU), so one workgroup per possible wave of blocks (32 130 for the
-// bench picture, 31 000 of them retiring at once after a 2 us look at the count,
-// in the few LDS slots the live ones leave free) made the launch last as long as
-// that churn: each class gets a bounded number of workgroups instead, which walk
-// their list with that stride - more than the live blocks of a picture need, so
-// a long walk still delays nobody.  grid: g16 + g4 + g64; block: 64.
-__device__ __forceinline__ void quant_rdo_packed_kernel_body(int bd, const xvcgpu_tx_block *blocks, RdoqLists l, int g16, int g4, const int16_t *coeffs, const uint32_t *d_off, int16_t *levels, int32_t *nnz_out, const xvcgpu_rdoq_contexts *rq_ctx, const xvcgpu_rdoq_params *rq_prm, xvcgpu_cu_info *cu_patch) {
+// The classes' walks are independent and each is bounded by its own slowest block.
+// Two launches: the two classes of wave_rdoq4 together (quant_rdo_packed4_kernel:
+// workgroups [0, g16) take the blocks of up to sixteen sub-blocks, a block per wave,
+// the rest the blocks of up to four, four per wave), and the general class
+// (quant_rdo_packed_kernel, a lane per sub-block) - in one kernel the general walk's
+// 198 vector registers were every wave's: two waves per SIMD, 2048 wave slots on the
+// chip for the 2300 - 7600 blocks of a 1080p picture, i.e. a second round of waves
+// behind the first (66 us for walks of at most 45).  The lists' counts are only known
+// on the device, and one workgroup per possible block made the launch last as long as
+// the churn of workgroups retiring after a look at the count: each class gets a bounded
+// number of workgroups instead, which walk their list with that stride.
+// grid: g16 + g4 (packed4) / g64 (general); block: 64.
+__device__ __forceinline__ void quant_rdo_packed4_kernel_body(int bd, const xvcgpu_tx_block *blocks, RdoqLists l, int g16, const int16_t *coeffs, const uint32_t *d_off, int16_t *levels, int32_t *nnz_out, const xvcgpu_rdoq_contexts *rq_ctx, const xvcgpu_rdoq_params *rq_prm, xvcgpu_cu_info *cu_patch) {
   union Lds {
     RdoqPackedLds<64, 16> a;
     RdoqPackedLds<16, 4> b;
-    RdoqPackedLds<64, 64> c;
   };
   __shared__ Lds sm;
-  const int wg = blockIdx.x, g64 = (int)gridDim.x - g16 - g4;
+  const int wg = blockIdx.x, g4 = (int)gridDim.x - g16;
   if (wg < g16) {
-    // up to sixteen sub-blocks: a block per wave, four lanes per sub-block
     const int waves = l.count[1];
     for (int wv = wg; wv < waves; wv += g16) {
-      quant_rdo_packed_wave<64, 16>(sm.a, wv, bd, blocks, l.list[1], l.count + 1, coeffs, d_off,
-                                    levels, nnz_out, rq_ctx, rq_prm, cu_patch);
-      wave_sync();
-    }
-  } else if (wg < g16 + g4) {
-    // up to four sub-blocks: four blocks per wave
-    const int waves = (l.count[0] + 3) >> 2;
-    for (int wv = wg - g16; wv < waves; wv += g4) {
-      quant_rdo_packed_wave<16, 4>(sm.b, wv, bd, blocks, l.list[0], l.count + 0, coeffs, d_off,
-                                   levels, nnz_out, rq_ctx, rq_prm, cu_patch);
+      quant_rdo_packed_wave<64, 16, true>(sm.a, wv, bd, blocks, l.list[1], l.count + 1, coeffs,
+                                          d_off, levels, nnz_out, rq_ctx, rq_prm, cu_patch);
       wave_sync();
     }
   } else {
-    const int waves = l.count[2];
-    for (int wv = wg - g16 - g4; wv < waves; wv += g64) {
-      quant_rdo_packed_wave<64, 64>(sm.c, wv, bd, blocks, l.list[2], l.count + 2, coeffs, d_off,
-                                    levels, nnz_out, rq_ctx, rq_prm, cu_patch);
+    const int waves = (l.count[0] + 3) >> 2;
+    for (int wv = wg - g16; wv < waves; wv += g4) {
+      quant_rdo_packed_wave<16, 4, true>(sm.b, wv, bd, blocks, l.list[0], l.count + 0, coeffs,
+                                         d_off, levels, nnz_out, rq_ctx, rq_prm, cu_patch);
       wave_sync();
     }
   }
+}
+
+__device__ __forceinline__ void quant_rdo_packed_kernel_body(int bd, const xvcgpu_tx_block *blocks, RdoqLists l, const int16_t *coeffs, const uint32_t *d_off, int16_t *levels, int32_t *nnz_out, const xvcgpu_rdoq_contexts *rq_ctx, const xvcgpu_rdoq_params *rq_prm, xvcgpu_cu_info *cu_patch) {
+  __shared__ RdoqPackedLds<64, 64> sm;
+  const int waves = l.count[2];
+  for (int wv = blockIdx.x; wv < waves; wv += (int)gridDim.x) {
+    quant_rdo_packed_wave<64, 64, false>(sm, wv, bd, blocks, l.list[2], l.count + 2, coeffs, d_off,
+                                         levels, nnz_out, rq_ctx, rq_prm, cu_patch);
+    wave_sync();
+  }
+}
+
+#ifndef RDOQ4_MIN_WAVES
+#define RDOQ4_MIN_WAVES 3   // per SIMD: 168 vector registers (the walk holds 156 - 167)
+#endif
+__global__ void __launch_bounds__(64, RDOQ4_MIN_WAVES)
+quant_rdo_packed4_kernel(int bd, const xvcgpu_tx_block *blocks, RdoqLists l, int g16, const int16_t *coeffs, const uint32_t *d_off, int16_t *levels, int32_t *nnz_out, const xvcgpu_rdoq_contexts *rq_ctx, const xvcgpu_rdoq_params *rq_prm, xvcgpu_cu_info *cu_patch = nullptr) {
+  quant_rdo_packed4_kernel_body(bd, blocks, l, g16, coeffs, d_off, levels, nnz_out, rq_ctx, rq_prm, cu_patch);
 }
 
 #ifndef RDOQ_MIN_WAVES
 #define RDOQ_MIN_WAVES 2   // per SIMD: 256 vector registers
 #endif
 __global__ void __launch_bounds__(64, RDOQ_MIN_WAVES)
-quant_rdo_packed_kernel(int bd, const xvcgpu_tx_block *blocks, RdoqLists l, int g16, int g4, const int16_t *coeffs, const uint32_t *d_off, int16_t *levels, int32_t *nnz_out, const xvcgpu_rdoq_contexts *rq_ctx, const xvcgpu_rdoq_params *rq_prm, xvcgpu_cu_info *cu_patch = nullptr) {
-  quant_rdo_packed_kernel_body(bd, blocks, l, g16, g4, coeffs, d_off, levels, nnz_out, rq_ctx, rq_prm, cu_patch);
+quant_rdo_packed_kernel(int bd, const xvcgpu_tx_block *blocks, RdoqLists l, const int16_t *coeffs, const uint32_t *d_off, int16_t *levels, int32_t *nnz_out, const xvcgpu_rdoq_contexts *rq_ctx, const xvcgpu_rdoq_params *rq_prm, xvcgpu_cu_info *cu_patch = nullptr) {
+  quant_rdo_packed_kernel_body(bd, blocks, l, coeffs, d_off, levels, nnz_out, rq_ctx, rq_prm, cu_patch);
 }
 
 #endif  // XVCGPU_K_RDOQ_H_

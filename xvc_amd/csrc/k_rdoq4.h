@@ -55,6 +55,67 @@ __device__ __forceinline__ int rq4_quad_max(int v) {
   o = lane_xor<2>(v);
   return o > v ? o : v;
 }
+// Reductions over the G (16 or 64) lanes of a block without the LDS crossbar
+// (__shfl_xor is ds_bpermute: six dependent LDS round trips per 64-lane reduction, and
+// the walk had fifteen of them): quad_perm, row_half_mirror and row_mirror inside a
+// row of sixteen, the four rows through v_readlane - the result is wave-uniform
+// (G = 64) or equal on the row's sixteen lanes (G = 16).
+__device__ __forceinline__ int rq4_row_mirror(int v) {
+  return __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, false);
+}
+__device__ __forceinline__ int rq4_row_half_mirror(int v) {
+  return __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, false);
+}
+template <int G>
+__device__ __forceinline__ int rq4_max(int v) {
+  int o = lane_xor<1>(v);
+  v = o > v ? o : v;
+  o = lane_xor<2>(v);
+  v = o > v ? o : v;
+  o = rq4_row_half_mirror(v);
+  v = o > v ? o : v;
+  o = rq4_row_mirror(v);
+  v = o > v ? o : v;
+  if (G == 64) {
+    const int a = __builtin_amdgcn_readlane(v, 0), b = __builtin_amdgcn_readlane(v, 16),
+              c = __builtin_amdgcn_readlane(v, 32), d = __builtin_amdgcn_readlane(v, 48);
+    const int ab = a > b ? a : b, cd = c > d ? c : d;
+    v = ab > cd ? ab : cd;
+  }
+  return v;
+}
+template <int G>
+__device__ __forceinline__ int rq4_sum(int v) {
+  v = dpp_group_sum<16>(v);
+  if (G == 64)
+    v = __builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16) +
+        __builtin_amdgcn_readlane(v, 32) + __builtin_amdgcn_readlane(v, 48);
+  return v;
+}
+template <int G>
+__device__ __forceinline__ long long rq4_sum_i64(long long v) {
+  v = rq_group_sum_i64<16>(v);
+  if (G == 64) {
+    unsigned long long t = 0;
+#pragma unroll
+    for (int r = 0; r < 64; r += 16) {
+      const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, r);
+      const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(v >> 32), r);
+      t += ((unsigned long long)hi << 32) | lo;
+    }
+    v = (long long)t;
+  }
+  return v;
+}
+
+// inclusive prefix sum over each row of sixteen lanes (lanes ascending), row_shr
+__device__ __forceinline__ unsigned rq4_row_scan_u32(unsigned v) {
+  v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, true);
+  v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, true);
+  v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, true);
+  v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, true);
+  return v;
+}
 template <int S>
 __device__ __forceinline__ long long rq4_xor_i64(long long v) {
   const int lo = lane_xor<S>((int)(unsigned)v), hi = lane_xor<S>((int)(v >> 32));
@@ -167,15 +228,14 @@ __device__ __forceinline__ int wave_rdoq4(S &s, int lane, int bd, int w, int h, 
   const long long my_zero_dist = (long long)((unsigned long long)rq_group_sum_i64<4>((long long)sum_sq)
                                              << cost_scale);
   const int last = mine && qmask ? sb_index + 31 - __clz((int)qmask) : -1;
-  const int last_pos_index = rq_wave_max_i32<G>(last);
+  const int last_pos_index = rq4_max<G>(last);
   RQ_TRACE(4);
   if (last_pos_index < 0) return 0;  // nothing quantises to a level
 
   const bool owner = mine && j == 0;   // the sub-block's per-sub-block records
-  for (int t = lane; t < nsb; t += G)
-    s.sb_of_scan[d_sb_scan_index(0, gw, gh, t & (gw - 1), t >> lgw)] = (unsigned char)t;
   const bool live = mine && sb_index <= last_pos_index;
   if (owner) {
+    s.sb_of_scan[my_scan] = (unsigned char)sbi;
     s.csbf[sbi] = 0;
     s.sb_dcz[sbi] = 0;
     s.sb_live[sbi] = live ? 1 : 0;
@@ -185,17 +245,34 @@ __device__ __forceinline__ int wave_rdoq4(S &s, int lane, int bd, int w, int h, 
     }
   }
   const int last_k = last_pos_index & 15;
-  const int last_l = rq_wave_max_i32<G>(mine && (last_pos_index >> 4) == my_scan ? sbi : -1);
-  const int d_first = rq_wave_max_i32<G>(live ? sx + sy : -1);
-  // the last-position bits of every position group of the two axes ([g] for x,
-  // [LPY + g] for y; diagonal scan: no swap)
+  const int last_l = rq4_max<G>(mine && (last_pos_index >> 4) == my_scan ? sbi : -1);
+  const int d_first = rq4_max<G>(live ? sx + sy : -1);
+  // The last-position bits (GetLastPosBits, rdo_quant.cc:918-965) of every position
+  // GROUP of the two axes ([g] for x, [LPY + g] for y; diagonal scan: no swap): group g
+  // costs the "1" bins of the groups in front of it - a prefix sum over the lanes, a
+  // lane per group -, its own "0" bin unless it is the axis' last, and its suffix bits.
   constexpr int LPY = 16;
   {
-    const int nx = rq_last_pos_group(w - 1) + 1, ny = rq_last_pos_group(h - 1) + 1;
-    for (int i = lane; i < nx + ny; i += G) {
-      const bool is_x = i < nx;
-      const int g = is_x ? i : i - nx;
-      s.lp_bits[is_x ? g : LPY + g] = rq_last_pos_group_bits(cb, luma, w, h, g, is_x);
+    const int r16 = lane & 15;
+    auto axis = [&](bool is_x, int &gmax) {
+      gmax = rq_last_pos_group((is_x ? w : h) - 1);
+      const bool inr = r16 < gmax;
+      const int gc = gmax > 0 ? gmax - 1 : 0;
+      const uint2 zb = *reinterpret_cast<const uint2 *>(
+          cb + rq_last_pos_ctx(luma, w, h, r16 < gc ? r16 : gc, is_x));
+      const unsigned one = inr ? zb.y : 0u, zero = inr ? zb.x : 0u;
+      return rq4_row_scan_u32(one) - one + zero +
+             (r16 > 3 ? (unsigned)((r16 - 2) >> 1) * RQ_BYPASS : 0u);
+    };
+    if (G == 64) {   // x on the wave's first row, y on the second
+      int gmax;
+      const unsigned v = axis(lane < 16, gmax);
+      if (lane < 32 && r16 <= gmax) s.lp_bits[(lane < 16 ? 0 : LPY) + r16] = v;
+    } else {         // (the groups of a wave share the table: same shape, same snapshot)
+      int gx, gy;
+      const unsigned vx = axis(true, gx), vy = axis(false, gy);
+      if (r16 <= gx) s.lp_bits[r16] = vx;
+      if (r16 <= gy) s.lp_bits[LPY + r16] = vy;
     }
   }
   // the two costs of a coefficient's significance flag as the decision used them
@@ -358,8 +435,10 @@ __device__ __forceinline__ int wave_rdoq4(S &s, int lane, int bd, int w, int h, 
         const bool in = t < pairs;
         const int ax = ax0 + ((in ? t : 0) >> 4), ay = d - ax, k = t & 15;
         const int l2 = ay * gw + ax;
+        const bool work = in && s.sb_live[l2] == 1;
+        if (!__ballot(work)) continue;   // no sub-block of the diagonal is priced at all
         long long cost = 0;
-        if (in && s.sb_live[l2] == 1) {
+        if (work) {
           const int p = rq_scan_pos(2, 0, k);
           const int x = (ax << 2) + (p & 3), y = (ay << 2) + (p >> 2);
           const int pos = rec_pos(x, y);
@@ -431,13 +510,19 @@ __device__ __forceinline__ int wave_rdoq4(S &s, int lane, int bd, int w, int h, 
     RQ_STEP(2);
   }
   RQ_STEP_END();
-  const long long comp_code_cost = rq_wave_sum_i64<G>(owner ? s.sb_code_cost[sbi] : 0ll);
-  const long long comp_zero_dist = rq_wave_sum_i64<G>(owner ? my_zero_dist : 0ll);
+  const long long comp_code_cost = rq4_sum_i64<G>(owner ? s.sb_code_cost[sbi] : 0ll);
+  const long long comp_zero_dist = rq4_sum_i64<G>(owner ? my_zero_dist : 0ll);
 
   RQ_TRACE(6);
-  // ---- EvalLastPos (rdo_quant.cc:777-850): sixteen lanes take the sixteen
-  // coefficients of one sub-block per round, from the last position's sub-block down
-  // to the one that holds the highest level above 1 (k_rdoq.h)
+  // ---- EvalLastPos (rdo_quant.cc:777-850).  The reference walks back from the last
+  // position carrying a running cost: minus every visited sub-block's flag cost, plus
+  // cost_to_zero of every visited coefficient; a non-zero level is a candidate, the
+  // first level above 1 ends the walk.  Here: the flag costs of the sub-blocks at or
+  // behind a scan position as one suffix sum (sixteen lanes, one per scan position);
+  // then only the CODED sub-blocks between the last position's and the one that holds
+  // the highest level above 1 are visited, sixteen lanes on the sixteen coefficients
+  // of one sub-block per round (on real content one or two rounds; walking the
+  // uncoded ones too was 4 of this section's 7 k clocks).
   int new_last = 0;
   const int cbf_ctx = 2 * (!luma ? RQ_OFF(cbf_chroma)
                                  : ((prm.flags & XVC_RDOQ_INTRA_CU) ? RQ_OFF(cbf_luma)
@@ -459,28 +544,38 @@ __device__ __forceinline__ int wave_rdoq4(S &s, int lane, int bd, int w, int h, 
     }
     gt1 = (unsigned)rq4_quad_or((int)gt1) & ((2u << start_k) - 1u);
     const int stop_local = coded && gt1 ? sb_index + 31 - __clz((int)gt1) : -1;
-    const int stop_idx = rq_wave_max_i32<G>(stop_local);
+    const int stop_idx = rq4_max<G>(stop_local);
     const int stop_sb = stop_idx >= 0 ? stop_idx >> 4 : 0;
-    RQ_STEP(0);
     const int kk = lane & 15;
     const bool worker = lane < 16;
+    // by scan position kk: the sub-block's flag cost, summed over the positions at or
+    // behind it (up to the last position's sub-block); the coded ones as a bit set
+    const int tj = kk < nsb ? (int)s.sb_of_scan[kk] : 0;
+    const bool vis = worker && kk < nsb && kk <= last_sb;
+    const long long fc = vis ? rq_bit_cost(s.csbf_bits[tj], lambda) : 0ll;
+    const bool cd = vis && kk >= stop_sb && s.csbf[tj] != 0;
+    const long long fc_behind = rq_group_sum_i64<16>(fc) - rq_row_scan_i64(fc) + fc;
+    unsigned todo = (unsigned)((__ballot(cd) >> (ME2_LANE & ~(G - 1) & 63)) & 0xffffull);
+    wave_sync();   // (sb_code_cost was read for the sums above)
+    if (vis) s.sb_code_cost[kk] = fc_behind;
+    wave_sync();
+    RQ_STEP(0);
     const int p = rq_scan_pos(2, 0, kk);
     const long long base = comp_code_cost + rq_bit_cost(cb[cbf_ctx + 1], lambda);
     long long best_cost = 0x7fffffffffffffffll;
     int best_last_plus1 = 0;
-    long long acc = 0;                 // sum of (run - flag cost) of the sub-blocks behind
-    for (int jj = last_sb; jj >= stop_sb; jj--) {
+    long long acc = 0;                 // sum of the visited coded sub-blocks' cost_to_zero
+    while (__ballot(todo != 0)) {
+      const bool on = todo != 0;
+      const int jj = on ? 31 - __clz((int)todo) : 0;
+      todo &= ~(1u << jj);
       const int t = (int)s.sb_of_scan[jj];
-      const long long fcost = rq_bit_cost(s.csbf_bits[t], lambda);
-      if (!s.csbf[t]) {                // not coded: only its flag's cost leaves the total
-        acc -= fcost;
-        continue;
-      }
+      const long long flags_behind = s.sb_code_cost[jj];
       const bool dcz = s.sb_dcz[t] != 0;
       const int x = ((t & (gw - 1)) << 2) + (p & 3), y = ((t >> lgw) << 2) + (p >> 2);
       const int index = (jj << 4) + kk;
       const int first_k = jj == last_sb ? last_k : 15;
-      const bool in = worker && kk <= first_k && index >= stop_idx;
+      const bool in = on && worker && kk <= first_k && index >= stop_idx;
       const unsigned pk = (unsigned)s.rate_up[rec_pos(x, y)];
       const int v = (int)*lev(x, y);
       const int ac = (short)d_abs(cf(x, y));
@@ -508,29 +603,43 @@ __device__ __forceinline__ int wave_rdoq4(S &s, int lane, int bd, int w, int h, 
       if (in && v != 0) {
         const unsigned lp_bits = s.lp_bits[rq_last_pos_group(x)] +
                                  s.lp_bits[LPY + rq_last_pos_group(y)];
-        const long long cost = base - fcost + acc + (total - inc) +
+        const long long cost = base - flags_behind + acc + (total - inc) +
                                rq_bit_cost(lp_bits, lambda) - rq_bit_cost(sig1, lambda);
         if (cost < best_cost) {        // (equal cost: the one met first, the higher index)
           best_cost = cost;
           best_last_plus1 = index + 1;
         }
       }
-      acc += total - fcost;
+      acc += total;
     }
     RQ_STEP(1);
-    // the workers are the first sixteen lanes of the group
-#pragma unroll
-    for (int sh = 1; sh < 16; sh <<= 1) {
-      const long long oc = __shfl_xor(best_cost, sh, 64);
-      const int oi = __shfl_xor(best_last_plus1, sh, 64);
+    // the cheapest candidate of the sixteen workers (on equal cost the higher index),
+    // then to every lane of the block
+    auto keep_better = [&](long long oc, int oi) {
       if (oc < best_cost || (oc == best_cost && oi > best_last_plus1)) {
         best_cost = oc;
         best_last_plus1 = oi;
       }
+    };
+    keep_better(rq4_xor_i64<1>(best_cost), lane_xor<1>(best_last_plus1));
+    keep_better(rq4_xor_i64<2>(best_cost), lane_xor<2>(best_last_plus1));
+    {
+      const int lo = rq4_row_half_mirror((int)(unsigned)best_cost),
+                hi = rq4_row_half_mirror((int)(best_cost >> 32));
+      keep_better((long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo),
+                  rq4_row_half_mirror(best_last_plus1));
     }
-    if (G > 16) {   // to every lane of the block
-      best_cost = __shfl(best_cost, 0, 64);
-      best_last_plus1 = __shfl(best_last_plus1, 0, 64);
+    {
+      const int lo = rq4_row_mirror((int)(unsigned)best_cost),
+                hi = rq4_row_mirror((int)(best_cost >> 32));
+      keep_better((long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo),
+                  rq4_row_mirror(best_last_plus1));
+    }
+    if (G == 64) {   // the workers are the wave's first row
+      const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)best_cost, 0);
+      const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(best_cost >> 32), 0);
+      best_cost = (long long)(((unsigned long long)hi << 32) | lo);
+      best_last_plus1 = __builtin_amdgcn_readlane(best_last_plus1, 0);
     }
     new_last = comp_zero_cost < best_cost ? -1 : best_last_plus1;
     RQ_STEP(3);
@@ -550,13 +659,13 @@ __device__ __forceinline__ int wave_rdoq4(S &s, int lane, int bd, int w, int h, 
     if (mine) *lev(px + i, Y) = (short)lv4[i];
   }
   const bool has_sb = rq4_quad_or(nnz) != 0;
-  nnz = rq_wave_sum_i32<G>(nnz);
+  nnz = rq4_sum<G>(nnz);
   if (new_last < 0) return 0;
   if (!(sign_hide && nnz > 1)) return nnz;
 
   RQ_TRACE(8);
   // ---- CoeffSignHideRdo (rdo_quant.cc:575-705): four lanes per sub-block
-  const int last_sb_scan = rq_wave_max_i32<G>(mine && has_sb ? my_scan : -1);
+  const int last_sb_scan = rq4_max<G>(mine && has_sb ? my_scan : -1);
   int first = 16, lastk = -1, sum = 0;
 #pragma unroll
   for (int i = 0; i < 4; i++) {
@@ -656,7 +765,7 @@ __device__ __forceinline__ int wave_rdoq4(S &s, int lane, int bd, int w, int h, 
         }
     }
   }
-  return nnz + rq_wave_sum_i32<G>(dn);
+  return nnz + rq4_sum<G>(dn);
 }
 
 #endif  // XVCGPU_K_RDOQ4_H_

@@ -1255,8 +1255,11 @@ static xvcgpu_status quant_rdo_launch(xvcgpu_ctx *ctx, int bitdepth,
   // per class that walk their list (k_rdoq.h)
   const int g16 = std::min(n, RDOQ_GRID16), g4 = std::min((n + 3) / 4, RDOQ_GRID4),
             g64 = std::min(n, RDOQ_GRID64);
-  hipLaunchKernelGGL(quant_rdo_packed_kernel, dim3(g16 + g4 + g64), dim3(64), 0, ctx->stream,
-                     bitdepth, d_blocks, l, g16, g4, d_coeffs, d_offsets, d_levels, d_nnz,
+  hipLaunchKernelGGL(quant_rdo_packed4_kernel, dim3(g16 + g4), dim3(64), 0, ctx->stream,
+                     bitdepth, d_blocks, l, g16, d_coeffs, d_offsets, d_levels, d_nnz,
+                     d_contexts, d_params, d_cu_patch);
+  hipLaunchKernelGGL(quant_rdo_packed_kernel, dim3(g64), dim3(64), 0, ctx->stream,
+                     bitdepth, d_blocks, l, d_coeffs, d_offsets, d_levels, d_nnz,
                      d_contexts, d_params, d_cu_patch);
   CHECK_LAUNCH(ctx, "quant_rdo_batch");
   return XVCGPU_OK;
@@ -2221,8 +2224,10 @@ xvcgpu_status xvcgpu_frame_pass_multi(xvcgpu_ctx *const *ctxs,
     hipLaunchKernelGGL(rdoq_compact_multi_kernel, dim3(1, n), dim3(1024), 0, ctx->stream, q);
     const int g16 = std::min(max_tx, RDOQ_GRID16),
               g4 = std::min((max_tx + 3) / 4, RDOQ_GRID4), g64 = std::min(max_tx, RDOQ_GRID64);
-    hipLaunchKernelGGL(quant_rdo_packed_multi_kernel, dim3(g16 + g4 + g64, n), dim3(64), 0,
-                       ctx->stream, q, bd, g16, g4);
+    hipLaunchKernelGGL(quant_rdo_packed4_multi_kernel, dim3(g16 + g4, n), dim3(64), 0,
+                       ctx->stream, q, bd, g16);
+    hipLaunchKernelGGL(quant_rdo_packed_multi_kernel, dim3(g64, n), dim3(64), 0,
+                       ctx->stream, q, bd);
     // 4. dequantisation + inverse transform + reconstruction
     MultiArgs<InvMultiArgs> v;
     for (int i = 0; i < n; i++) {
