@@ -112,6 +112,11 @@ __device__ unsigned long long g_rq_trace[4096][16];
 #define RQ_CF_STRIDE 20
 #define RQ_CF_PADDED(n) ((n) + (n) / 4)
 
+// wave_rdoq4's working levels (k_rdoq4.h): the corner's raster with two zero columns /
+// rows to the right / below; its largest shape per coefficient budget: 4x16 / 8x32 /
+// 32x32 ((w + 2) x (h + 2))
+#define RQ_WL(n) ((n) + 2 * ((n) >= 1024 ? 64 : ((n) >= 256 ? 40 : 20)) + 4)
+
 template <int N0>
 struct RdoqShared {
   static constexpr int N = RQ_PADDED(N0);
@@ -138,11 +143,21 @@ struct RdoqShared {
   // global / constant memory that is a dozen dependent ~1 us round trips per
   // coefficient (the first version ran 0.86 ms per 1080p picture that way).
   alignas(8) unsigned ctx_bits[2 * sizeof(xvcgpu_rdoq_contexts)];
+  alignas(8) int16_t wl[RQ_WL(N0)];
+  // wave_rdoq4: the flag costs at / behind a scan position (blocks with a 64-point
+  // side: up to 256 positions; the others re-use sb_code_cost)
+  long long fcs_store[N0 >= 1024 ? 256 : 1];
 };
+template <int N0>
+__device__ __forceinline__ long long *rq_fcs(RdoqShared<N0> &s) {
+  return N0 >= 1024 ? s.fcs_store : s.sb_code_cost;
+}
 
 // The same members as pointers (packed kernel: per-coefficient arrays in
 // global memory, the rest in LDS).
 struct RdoqView {
+  int16_t *wl;
+  long long *fcs;
   unsigned short *rate_up;
   long long *sb_code_cost;
   unsigned *csbf_bits;
@@ -221,6 +236,8 @@ __device__ __forceinline__ long long rq_row_scan_i64(long long v) {
   v = rq_row_shr_add_i64<8>(v);
   return v;
 }
+
+__device__ __forceinline__ long long *rq_fcs(RdoqView &v) { return v.fcs; }
 
 struct RdoqCoeffState {  // RdoQuant::CoeffCodingState, the part the extended set reads
   int c1_idx, c2_idx;
@@ -1189,11 +1206,6 @@ __device__ __forceinline__ void rq_stage_costs(const xvcgpu_rdoq_contexts *snap,
   }
 }
 
-// Blocks wave_rdoq4 (k_rdoq4.h: four lanes per sub-block) takes with G lanes
-__device__ __forceinline__ bool rq4_takes(int G, int w, int h, int scan_order) {
-  return scan_order == 0 && w >= 4 && h >= 4 && w <= 32 && h <= 32 && (w >> 2) * (h >> 2) * 4 <= G;
-}
-
 #include "k_rdoq4.h"
 
 // ---- the quantiser alone, packed ------------------------------------------------
@@ -1218,8 +1230,10 @@ struct RdoqLists {
 // per sub-block (wave_rdoq4); 2: everything else (the other scans, 2-wide blocks,
 // more than sixteen sub-blocks, 64-point sides) - a lane per sub-block (wave_rdoq)
 __device__ __forceinline__ int rq_class_of(const xvcgpu_tx_block &b) {
-  if (!rq4_takes(64, b.w, b.h, (b.intra_pic >> XVC_TXF_SCAN_SHIFT) & 3)) return 2;
-  return (b.w >> 2) * (b.h >> 2) <= 4 ? 0 : 1;
+  if (!rq4_takes(64, b.w, b.h, (b.intra_pic >> XVC_TXF_SCAN_SHIFT) & 3) || b.w > 32 || b.h > 32)
+    return 2;
+  const int n_sb = (b.w >> 2) * (b.h >> 2);
+  return n_sb <= 4 ? 0 : (n_sb <= 16 ? 1 : 2);
 }
 
 // Classification + the trivial case.  One wave per block: does any coefficient
@@ -1819,6 +1833,8 @@ struct RdoqPackedLds {
   // the per-coefficient records: 5 bytes each (+ 4 of coefficient and level)
   alignas(8) long long sb_code_cost[GROUPS][MAXSB];
   alignas(8) int16_t cf[GROUPS][MAXT], lv[GROUPS][MAXT];
+  alignas(8) int16_t wl[GROUPS][RQ_WL(MAXC)];          // wave_rdoq4's working levels
+  long long fcs[NSB == 64 ? 256 : 1];                  // (64-point sides; else sb_code_cost)
   unsigned short rate_up[GROUPS][MAXR];
   alignas(8) unsigned ctx_bits[2 * sizeof(xvcgpu_rdoq_contexts)];
   unsigned csbf_bits[GROUPS][MAXSB];
@@ -1831,6 +1847,40 @@ struct RdoqPackedLds {
 
 // G lanes per block; grid: an upper bound on ceil(count / (64 / G)) waves (the
 // list's count is read on the device); block: 64.
+// wave_rdoq4's accessors in the packed kernel: the coefficient tile (sub-block major,
+// RQ_CF_STRIDE: a sub-block's row is 8 contiguous bytes) and the block's levels in
+// global memory (row-major, the block's own width): a unit's row is one access.
+struct RqTileCf {
+  const int16_t *p;
+  int rgw;
+  __device__ __forceinline__ int pos(int x, int y) const {
+    return ((y >> 2) * rgw + (x >> 2)) * RQ_CF_STRIDE + (((y & 3) << 2) | (x & 3));
+  }
+  __device__ __forceinline__ int operator()(int x, int y) const { return (int)p[pos(x, y)]; }
+  __device__ __forceinline__ void row4(int px, int y, int c[4]) const {
+    const uint2 v = *reinterpret_cast<const uint2 *>(p + pos(px, y));
+    c[0] = (int)(short)(v.x & 0xffffu);
+    c[1] = (int)(short)(v.x >> 16);
+    c[2] = (int)(short)(v.y & 0xffffu);
+    c[3] = (int)(short)(v.y >> 16);
+  }
+};
+struct RqGlobalLev {
+  int16_t *p;
+  int w;
+  __device__ __forceinline__ int16_t *operator()(int x, int y) const { return p + y * w + x; }
+  __device__ __forceinline__ void store4(int px, int y, const int v[4]) const {
+    int16_t *o = p + y * w + px;
+    if ((reinterpret_cast<uintptr_t>(o) & 7) == 0) {
+      *reinterpret_cast<uint2 *>(o) =
+          make_uint2((unsigned)(v[0] & 0xffff) | ((unsigned)v[1] << 16),
+                     (unsigned)(v[2] & 0xffff) | ((unsigned)v[3] << 16));
+    } else {
+      o[0] = (int16_t)v[0]; o[1] = (int16_t)v[1]; o[2] = (int16_t)v[2]; o[3] = (int16_t)v[3];
+    }
+  }
+};
+
 template <int G, int NSB, bool FOUR>
 __device__ __forceinline__ void quant_rdo_packed_wave(
     RdoqPackedLds<G, NSB> &sm, int wave, int bd, const xvcgpu_tx_block *blocks, const int *list,
@@ -1882,18 +1932,22 @@ __device__ __forceinline__ void quant_rdo_packed_wave(
         const int p0 = tile_pos(x, y), p1 = rw == 4 ? tile_pos(0, y + 1) : tile_pos(x + 4, y);
         *reinterpret_cast<uint2 *>(cf + p0) = make_uint2(v8.x, v8.y);
         *reinterpret_cast<uint2 *>(cf + p1) = make_uint2(v8.z, v8.w);
-        *reinterpret_cast<uint2 *>(lv + p0) = make_uint2(0, 0);
-        *reinterpret_cast<uint2 *>(lv + p1) = make_uint2(0, 0);
+        if (!FOUR) {   // (wave_rdoq4 writes its levels to global memory itself)
+          *reinterpret_cast<uint2 *>(lv + p0) = make_uint2(0, 0);
+          *reinterpret_cast<uint2 *>(lv + p1) = make_uint2(0, 0);
+        }
       }
     } else {
       for (int i = lane; i < rw * rh; i += G) {
         const int y = i / rw, x = i - y * rw;
         cf[tile_pos(x, y)] = src[y * w + x];
-        lv[tile_pos(x, y)] = 0;
+        if (!FOUR) lv[tile_pos(x, y)] = 0;
       }
     }
   }
   RdoqView v;
+  v.wl = sm.wl[g];
+  v.fcs = NSB == 64 ? sm.fcs : sm.sb_code_cost[g];
   v.sb_dcz = sm.sb_dcz[g];
   v.rate_up = sm.rate_up[g];
   v.sb_live = sm.sb_live[g];
@@ -1977,20 +2031,29 @@ __device__ __forceinline__ void quant_rdo_packed_wave(
       const int uscan = (uflags >> XVC_TXF_SCAN_SHIFT) & 3;
       auto cf_at = [cf, utile](int x, int y) { return (int)cf[utile(x, y)]; };
       auto lv_at = [lv, utile](int x, int y) { return lv + utile(x, y); };
-      if (FOUR)   // four lanes per sub-block (k_rdoq4.h): the class lists hold what it takes
-        nnz = wave_rdoq4<G>(v, lane, bd, uw, uh, uqp, uluma != 0,
-                            !(uflags & XVC_TXF_NO_SIGN_HIDING), uprm, cf_at, lv_at);
-      else
-        nnz = wave_rdoq<G>(v, lane, bd, uw, uh, uqp, uluma != 0, uscan,
-                           !(uflags & XVC_TXF_NO_SIGN_HIDING), rq_ctx[cur], uprm, cf_at, lv_at,
-                           false, false);
+      const bool ush = !(uflags & XVC_TXF_NO_SIGN_HIDING);
+      if (FOUR) {
+        // four lanes per sub-block (k_rdoq4.h): the class lists hold what it takes; the
+        // levels go straight to the block's place in global memory
+        const RqTileCf cf4 = {cf, urgw4};
+        const RqGlobalLev lv4 = {dst, uw};
+        nnz = wave_rdoq4<G, 1>(v, lane, bd, uw, uh, uqp, uluma != 0, ush, uprm, cf4, lv4);
+      } else if (NSB == 64 && rq4_takes(64, uw, uh, uscan)) {
+        // (more than sixteen sub-blocks or a 64-point side: four units per lane)
+        nnz = wave_rdoq4<64, 4>(v, lane, bd, uw, uh, uqp, uluma != 0, ush, uprm, cf_at, lv_at);
+      } else {
+        nnz = wave_rdoq<G>(v, lane, bd, uw, uh, uqp, uluma != 0, uscan, ush, rq_ctx[cur], uprm,
+                           cf_at, lv_at, false, false);
+      }
       pending = false;
     }
   }
   wave_sync();
   RQ_TRACE(9);
   if (!active) return;
-  if (wide && sb4) {
+  if (FOUR) {
+    // (the walk wrote the levels)
+  } else if (wide && sb4) {
     for (int i = lane; i < (w * h) >> 3; i += G) {
       const int y = (8 * i) / rw, x = 8 * i - y * rw;
       const uint2 a = *reinterpret_cast<const uint2 *>(lv + tile_pos(x, y));

@@ -321,10 +321,23 @@ __device__ __forceinline__ int residual_job(TxShared &s, int bi, const PicView &
         const xvcgpu_rdoq_params prm = rq_prm[bi];
         const int16_t *cfp = s.a;
         int16_t *lvp = s.b;
-        const int n_rq = wave_rdoq<64>(
-            *rq, (int)threadIdx.x, bd, w, h, b.qp, b.comp == 0, scan_order, sign_hide,
-            rq_ctx[prm.ctx_index], prm, [cfp](int x, int y) { return (int)cfp[y * TX_S + x]; },
-            [lvp](int x, int y) { return lvp + y * TX_S + x; });
+        auto cf_at = [cfp](int x, int y) { return (int)cfp[y * TX_S + x]; };
+        auto lv_at = [lvp](int x, int y) { return lvp + y * TX_S + x; };
+        int n_rq;
+        if (RQN >= 1024 && rq4_takes(64, w, h, scan_order)) {
+          // four lanes per sub-block (k_rdoq4.h), four units per lane beyond sixteen sub-blocks
+          rq_stage_costs(&rq_ctx[prm.ctx_index], rq->ctx_bits, (int)threadIdx.x, 64);
+          wave_sync();
+          if (rq4_needs_nr4(w, h))
+            n_rq = wave_rdoq4<64, 4>(*rq, (int)threadIdx.x, bd, w, h, b.qp, b.comp == 0, sign_hide,
+                                     prm, cf_at, lv_at);
+          else
+            n_rq = wave_rdoq4<64, 1>(*rq, (int)threadIdx.x, bd, w, h, b.qp, b.comp == 0, sign_hide,
+                                     prm, cf_at, lv_at);
+        } else {
+          n_rq = wave_rdoq<64>(*rq, (int)threadIdx.x, bd, w, h, b.qp, b.comp == 0, scan_order,
+                               sign_hide, rq_ctx[prm.ctx_index], prm, cf_at, lv_at);
+        }
         if (threadIdx.x == 0) s.nnz = n_rq;
       }
       __syncthreads();

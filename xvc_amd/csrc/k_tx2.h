@@ -301,7 +301,8 @@ __device__ __forceinline__ int tx2_job(Tx2Shared &sh, const xvcgpu_tx_block &b, 
         // four lanes per sub-block (k_rdoq4.h): the whole wave on this block's walk
         rq_stage_costs(&rq_ctx[prm.ctx_index], rq->ctx_bits, lane, 64);
         wave_sync();
-        nnz = wave_rdoq4<64>(*rq, lane, bd, w, h, b.qp, b.comp == 0, sign_hide, prm, cf_at, lv_at);
+        nnz = wave_rdoq4<64, 1>(*rq, lane, bd, w, h, b.qp, b.comp == 0, sign_hide, prm, cf_at,
+                                lv_at);
       } else {
         nnz = wave_rdoq<G>(*rq, lane, bd, w, h, b.qp, b.comp == 0, scan_order, sign_hide,
                            rq_ctx[prm.ctx_index], prm, cf_at, lv_at);
