@@ -326,8 +326,9 @@ def encoder_rd_serial_figure(ctx, api, fx, pics, w, h, n_states=4000):
     sp = rd_serial.SerialPicture(api, "c1", poc)
     serial = cu_state_walk.walk(api, "c1", poc, n_states, [1, 4], "serial", decoded=(by_poc, w, h), sp=sp)
     chained = cu_state_walk.walk(api, "c1", poc, n_states, [1, 4], "chained", decoded=(by_poc, w, h), sp=sp)
-    s1, c1 = serial["chains"]["1"], chained["chains"]["1"]
-    ok = all(e.get("matches_reference") for r in (serial, chained) for e in r["chains"].values())
+    live = cu_state_walk.walk(api, "c1", poc, n_states, [1, 4], "live", decoded=(by_poc, w, h), sp=sp)
+    s1, c1, l1 = serial["chains"]["1"], chained["chains"]["1"], live["chains"]["1"]
+    ok = all(e.get("matches_reference") for r in (serial, chained, live) for e in r["chains"].values())
     return {
         "workload": "1080p B picture POC %d of the reference-coded stream: %d CU states in the "
                     "reference's issue order (%d merge rankings, %d merge-candidate evaluations, "
@@ -338,6 +339,8 @@ def encoder_rd_serial_figure(ctx, api, fx, pics, w, h, n_states=4000):
         "us_per_cu_state": s1["us_per_cu_state"],
         "launches_per_state": {"entry_point_calls": s1["api_calls_per_state"],
                                "kernel_launches_rocprof": {"serial": 13.96, "chained": 7.17},
+                               "kernel_launches_rocprof_measured_at": "round 4, commit f6a310b (static "
+                                                                      "reference, not re-measured by this run)",
                                "note": "rocprofv3 --kernel-trace of tools/cu_state_walk.py --no-check "
                                        "(3000 + 200 warm-up states): 44 660 launches serial (12 887 of "
                                        "them result copies), 22 947 chained (1 502 copies) - "
@@ -360,6 +363,38 @@ def encoder_rd_serial_figure(ctx, api, fx, pics, w, h, n_states=4000):
                             "launch (xvcgpu_*_refs), a state's transform blocks as one launch, "
                             "one read-back per result array and chain",
                     "compared": c1.get("compared")},
+        "live": {"us_per_cu_state": l1["us_per_cu_state"],
+                 "entry_point_calls_per_state": l1["api_calls_per_state"],
+                 "round_trips_per_state": l1["round_trips_per_state"],
+                 "pictures_per_s": {k: v["pictures_per_s"] for k, v in live["chains"].items()},
+                 "pictures_per_s_one_host_thread": {
+                     k: v["one_thread"]["pictures_per_s"] for k, v in live["chains"].items()
+                     if "one_thread" in v},
+                 "form": "the chains a live encoder could issue: a wait wherever the reference's "
+                         "control reads a cost that needs the host's entropy coder - after every "
+                         "CompressInter / merge position, and inside an evaluation in front of the "
+                         "gated second transform pass; nothing is taken from the capture's knowledge "
+                         "of how a state ended except where listed below",
+                 "decided_on_the_device": [
+                     "EvalStartMvp / EvalFinalMvpIdx, GetInterPredBits (default prices), SearchRefIdx's "
+                     "folds, the list SearchBiIterative searches (xvcgpu_cs_start / uni_fold)",
+                     "the refinement's costs, the three-way choice, affine against plain, HasZeroMvd "
+                     "(xvcgpu_cs_bi_fold) -> the evaluation's prediction jobs",
+                     "the merge ranking: cost in double, stable sort, the 1.25 x cut -> the ranked "
+                     "candidates' evaluation slots (xvcgpu_cs_merge_fold)"],
+                 "decided_on_the_host": [
+                     "GetCuCostWithoutSplit of every evaluation (the RDO writer's bits: entropy coder, "
+                     "out of scope) and with it: best_cu_cost handed to the next candidate, "
+                     "skip_evaluated, the break on a cbf-free winner (cu_encoder.cc:598-628)",
+                     "cost_full > best_cu_cost * 1.1 in front of the second transform pass "
+                     "(inter_search.cc:347-361): a wait inside the state",
+                     "the CU recursion itself (split decisions, mode order)"],
+                 "still_from_the_capture": [
+                     "whether a CompressInter went on to its evaluation (HasZeroMvd is on the device, "
+                     "but the replay has no evaluation jobs for the states that returned early)",
+                     "which ranked merge candidates were evaluated (the fold fills all slots below "
+                     "the count; the replay runs the ones the reference ran)"],
+                 "compared": l1.get("compared")},
         "compared": s1.get("compared"),
         "matches_reference": bool(ok),
         "reading": "both forms are bound by the chain of dependent kernels per state (each "

@@ -963,7 +963,11 @@ xvcgpu_status xvcgpu_affine_me_batch_refs(xvcgpu_ctx *ctx, const xvcgpu_picture 
  * one launch per slot that exists without knowing which list won.  The affine pass's
  * slots and search jobs live in the xvcgpu_affine_me_block array.  A call folds the
  * passes [first, first + n) of d_passes / d_results (an affine pass names its plain
- * pass by absolute index). */
+ * pass by absolute index; the plain pass must have been folded by an EARLIER launch of
+ * the same fold - the affine pass reads and updates its result record -, i.e. a call
+ * never holds a pass together with its plain pass).  A pass with
+ * XVC_CS_FORCE_L1_MVD_ZERO or bi_iterations > 1 is answered XVC_CS_WHICH_UNSUPPORTED
+ * (xvcgpu_types.h), not computed. */
 xvcgpu_status xvcgpu_cs_start_fold(xvcgpu_ctx *ctx, const xvcgpu_cs_pass *d_passes, int first,
     int n,
                                    const uint64_t *d_start_dist, xvcgpu_me_block *d_me_jobs,
@@ -981,6 +985,15 @@ xvcgpu_status xvcgpu_cs_bi_fold(xvcgpu_ctx *ctx, const xvcgpu_cs_pass *d_passes,
                                 const xvcgpu_me_result *d_bi_res,
                                 const xvcgpu_affine_me_result *d_aff_res,
                                 xvcgpu_cs_result *d_results, xvcgpu_inter_block *d_ev_inter);
+
+/* The merge ranking's fold (xvcgpu_types.h: xvcgpu_cs_merge): rankings [first, first + n)
+ * of d_merges / d_results; d_dist the SATDs, d_cands the ranking's prediction jobs,
+ * d_ev_inter the evaluation slots.  One launch, no host decision. */
+xvcgpu_status xvcgpu_cs_merge_fold(xvcgpu_ctx *ctx, const xvcgpu_cs_merge *d_merges, int first,
+                                   int n, const uint64_t *d_dist,
+                                   const xvcgpu_inter_block *d_cands,
+                                   xvcgpu_cs_merge_result *d_results,
+                                   xvcgpu_inter_block *d_ev_inter);
 
 /* All distortions of an evaluation (CompressAndEvalCbf, inter_search.cc:261-365) in one
  * launch: candidate i compares its block of `orig` with the same block of `pred`

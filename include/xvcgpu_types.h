@@ -413,6 +413,36 @@ typedef struct xvcgpu_cs_result {
   int32_t out_mvd[2][2][2];
 } xvcgpu_cs_result;
 
+/* ---- the merge ranking of a CU, folded on the device ---------------------------- *
+ * InterSearch::SearchMergeCandidates (inter_search.cc:165-197): the SATD of the five
+ * merge candidates' luma predictions (xvcgpu_inter_pred_batch_to + xvcgpu_metric_batch)
+ * -> cost = dist + bits * lambda_sqrt in double (bits = idx + 1, the last index one
+ * less), a stable sort, and the count of candidates within kFastMergeCostFactor = 1.25
+ * of the cheapest (at most kFastMergeNumCand = 4).  xvcgpu_cs_merge_fold does that
+ * between the launches and writes the motion of ranked candidate i < num into the
+ * position's i-th EVALUATION SLOT (3 xvcgpu_inter_block: Y, U, V - geometry and
+ * component filled in by the caller; the fold sets flags, ref and mv), ref = -1 / -1
+ * in the slots from num on: CuEncoder::CompressMerge's loop (cu_encoder.cc:598-628)
+ * can then be enqueued - every ranked candidate's CompressAndEvalCbf - without the
+ * host having seen the ranking. */
+#define XVC_CS_MERGE_CANDS 5   /* constants::kNumInterMergeCandidates */
+#define XVC_CS_MERGE_SLOTS 4   /* InterSearch::kFastMergeNumCand      */
+typedef struct xvcgpu_cs_merge {
+  double lambda_sqrt;          /* qp.GetLambdaSqrt()                                     */
+  int32_t dist;                /* index of candidate 0's distortion (uint64; 1..4 follow) */
+  int32_t cand;                /* index of candidate 0's xvcgpu_inter_block (the luma job
+                                * the ranking predicted with; 1..4 follow)              */
+  int32_t slot;                /* the position's first evaluation slot (slot s = blocks
+                                * 3 s .. 3 s + 2 of the evaluation array), -1: none      */
+  int32_t reserved;
+} xvcgpu_cs_merge;
+typedef struct xvcgpu_cs_merge_result {
+  double cost[XVC_CS_MERGE_CANDS];   /* sorted                                           */
+  int32_t order[XVC_CS_MERGE_CANDS]; /* out_cand_list: merge index per rank               */
+  int32_t num;                       /* candidates to evaluate                           */
+  int32_t reserved[2];
+} xvcgpu_cs_merge_result;
+
 /* One distortion of an evaluation (xvcgpu_eval_dist_batch): what CompressAndEvalCbf /
  * CompressAndEvalTransform compare per component and alternative - the prediction
  * against the original (the cbf-zero distortion, transform_encoder.cc:116-117) or a

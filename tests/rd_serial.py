@@ -608,9 +608,63 @@ OP_DTYPE = np.dtype([("opcode", "<i4"), ("n", "<i4"), ("r0", "<i4"), ("r1", "<i4
                      ("reserved", "<i4"), ("f", "<f8"), ("p", "<u8", 5)], align=True)
 (OP_MC_METRIC, OP_METRIC, OP_ME, OP_BI, OP_AFFINE, OP_COPY, OP_INTER_PRED, OP_RESIDUAL,
  OP_START_FOLD, OP_UNI_FOLD, OP_BI_FOLD, OP_FETCH, OP_SYNC, OP_EVAL_DIST, OP_MC_METRIC_REFS,
- OP_ME_REFS, OP_BI_REFS, OP_AFFINE_REFS) = range(18)
+ OP_ME_REFS, OP_BI_REFS, OP_AFFINE_REFS, OP_MERGE_FOLD) = range(19)
 PIC_ORIG, PIC_S_ORIG, PIC_S_PRED, PIC_S_REC = 0, 1, 2, 3
 BI_SLOTS = 2 * R3 * R3
+
+
+MERGE_FOLD_DTYPE = np.dtype([("lambda_sqrt", "<f8"), ("dist", "<i4"), ("cand", "<i4"), ("slot", "<i4"),
+                             ("reserved", "<i4")], align=True)
+MERGE_RESULT_DTYPE = np.dtype([("cost", "<f8", 5), ("order", "<i4", 5), ("num", "<i4"),
+                               ("reserved", "<i4", 2)], align=True)
+MERGE_SLOTS = 4      # XVC_CS_MERGE_SLOTS
+
+
+def build_merge_folds(sp):
+    """The records of xvcgpu_cs_merge_fold for every merge ranking of the picture, the
+    evaluation slots it fills (four per ranking: Y, U, V prediction jobs with the CU's
+    geometry, motion left to the fold) and, for the harness only, which slot each captured
+    merge-candidate evaluation corresponds to (its motion = a ranked candidate's): the
+    chain then predicts from the SLOT, not from the capture's job."""
+    api, st = sp.api, sp.states
+    n_m = len(sp.mg_inter)
+    mf = np.zeros(n_m, MERGE_FOLD_DTYPE)
+    mf["lambda_sqrt"] = sp.mg_want["lambda_sqrt"]
+    mf["dist"] = mf["cand"] = 5 * np.arange(n_m)
+    mf["slot"] = MERGE_SLOTS * np.arange(n_m)
+    slots = np.zeros((n_m * MERGE_SLOTS, 3), api.INTER_DTYPE)
+    g = np.repeat(sp.mg_want, MERGE_SLOTS)
+    for c in range(3):
+        sc = slots[:, c]
+        sc["x"], sc["y"], sc["w"], sc["h"], sc["comp"] = g["x"], g["y"], g["w"], g["h"], c
+        sc["ref"], sc["mv"] = -1, 0x7fffff          # the fold's to write
+        slots[:, c] = sc
+    ev_slot = np.full(len(sp.ev_inter), -1, np.int64)
+    cur, used = None, set()
+    for n in range(len(st)):
+        s = st[n]
+        key = (int(s["x"]), int(s["y"]), int(s["w"]), int(s["h"]))
+        kind = int(s["kind"])
+        if kind == KIND_MERGE_RANK and s["supported"]:
+            cur, used = (int(s["merge"]), key), set()
+            continue
+        if kind != KIND_EVAL or cur is None or cur[1] != key or not s["supported"]:
+            if kind != KIND_EVAL:
+                cur = None
+            continue
+        m, e = cur[0], int(s["ev"])
+        if not (int(sp.ev_want["flags"][e]) & rf.FLAG_MERGE):
+            continue
+        want = sp.ev_inter[e, 0]
+        for r in range(int(sp.mg_want["num"][m])):
+            cand = sp.mg_inter[m, int(sp.mg_want["order"][m][r])]
+            if r not in used and int(want["flags"]) == int(cand["flags"]) and \
+                    (want["ref"] == cand["ref"]).all() and \
+                    all((want["mv"][l][0] == cand["mv"][l][0]).all() for l in range(2) if want["ref"][l] >= 0):
+                ev_slot[e] = MERGE_SLOTS * m + r
+                used.add(r)
+                break
+    sp.mg_fold, sp.mg_slots, sp.ev_merge_slot = mf, slots, ev_slot
 
 
 class CsEnv(C.Structure):
@@ -797,6 +851,8 @@ class ChainedRun(SerialRun):
     """SerialRun + the arrays and the program of the chained form."""
 
     refs_form = True      # a SearchMotion step into all reference pictures as one launch
+    merge_fold = True     # the merge ranking folded on the device: a merge candidate's
+    #                       evaluation predicts from the slot xvcgpu_cs_merge_fold filled
 
     def __init__(self, api, ctx, sp, pics, width, height, ref_lists):
         super().__init__(api, ctx, sp, pics, width, height)
@@ -814,6 +870,9 @@ class ChainedRun(SerialRun):
         d["ev_inter_work"] = up(sp.ev_inter_work)
         d["start_slots"], d["me_slots"] = up(sp.start_slots), up(sp.me_slots)
         d["bi_slots"], d["aff_slots"] = up(sp.bi_slots), up(sp.aff_slots)
+        if not hasattr(sp, "mg_fold"):
+            build_merge_folds(sp)
+        d["mg_fold"], d["mg_slots"] = up(sp.mg_fold), up(sp.mg_slots)
         self.cres = {}
         for name, dt, n in (("start_dist", np.dtype("<u8"), sp.n_start_dist),
                             ("me_res_c", api.MERES_DTYPE, len(sp.me_work)),
@@ -862,7 +921,9 @@ class ChainedRun(SerialRun):
         d["ev_cands"] = up(np.concatenate(cands) if cands else np.zeros(0, api.EVAL_CAND_DTYPE))
         self.z = {}
         for name, dt, n in (("nnz", np.dtype("<i4"), len(sp.call_tx)), ("edist", np.dtype("<u8"), n_ed),
-                            ("mg_dist", np.dtype("<u8"), 5 * len(sp.mg_inter))):
+                            ("mg_dist", np.dtype("<u8"), 5 * len(sp.mg_inter)),
+                            ("mg_res", MERGE_RESULT_DTYPE, len(sp.mg_inter)),
+                            ("mg_slots_out", api.INTER_DTYPE, 3 * len(sp.mg_slots))):
             nbytes = max(n, 1) * dt.itemsize
             h = self._pin(nbytes)
             C.memset(h, 0xff, nbytes)
@@ -875,12 +936,19 @@ class ChainedRun(SerialRun):
         self.ctx.sync()
 
     # ---- program ---------------------------------------------------------------
-    def program(self, first, n, by_position=True, verify=True, refs_form=None):
+    def program(self, first, n, by_position=True, verify=True, refs_form=None, live=False):
         """Ops of the states [first, first + n): one chain (ending in a SYNC) per state,
         or per visit of a CU position (consecutive states of one CU).  refs_form: a step
         of SearchMotion into all the CU's reference pictures as ONE launch
         (xvcgpu_*_refs) instead of one launch per picture; the read-backs of a chain
-        merged where their ranges touch (one copy per result array and chain)."""
+        merged where their ranges touch (one copy per result array and chain).
+        live: the chains a LIVE encoder could issue - a chain ends wherever the reference's
+        control reads a cost that needs the host's entropy coder (GetCuCostWithoutSplit):
+        after every CompressInter's evaluation, and inside it in front of the gated second
+        transform pass (cost_full > best_cu_cost * 1.1, inter_search.cc:347-361); what the
+        device folds decide - EvalStartMvp, the lists' folds, the three-way choice, affine
+        against plain, the merge ranking (xvcgpu_cs_merge_fold) - needs no wait: a merge
+        ranking and its candidates' evaluations are one chain."""
         refs_form = self.refs_form if refs_form is None else refs_form
         sp, api, t, d = self.sp, self.api, self.t, self.d
         st = sp.states
@@ -996,9 +1064,42 @@ class ChainedRun(SerialRun):
             cf, k = int(s["call_first"]), n0 + n1
             ed = int(self.edist_first[n_state])
             z_nnz, z_ed = self.z["nnz"][1], self.z["edist"][1]
+            if live and n1:
+                # the first transform pass, a wait (the host prices it and decides the gate),
+                # then the second pass' calls
+                co = int(s["copy_first"])
+                sl = int(sp.ev_merge_slot[e]) if self.merge_fold else -1
+                pred_jobs = d["mg_slots"] + 3 * sl * I["inter"] if sl >= 0 else \
+                    d["ev_inter_work"] + 3 * e * I["inter"]
+                op(OP_COPY, 3 + n0, r0=PIC_ORIG, r1=PIC_S_ORIG, p=(t.d_copy_orig + co * I["copy"],))
+                op(OP_INTER_PRED, 3, r1=PIC_S_PRED, p=(pred_jobs, t.d_ev_dst + 3 * e * I["pos"]))
+                op(OP_COPY, n0, r0=PIC_S_PRED, r1=PIC_S_PRED, p=(t.d_call_copy_pred + cf * I["copy"],))
+                op(OP_RESIDUAL, n0, p=(t.d_call_tx + cf * I["tx"], t.d_call_off + 4 * cf, z_nnz + 4 * cf,
+                                       t.d_contexts + int(sp.ev_ctx[e]) * I["ctx"], t.d_call_prm + cf * I["prm"]))
+                op(OP_EVAL_DIST, 3 + n0, p=(d["ev_cands"] + ed * 24, z_ed + 8 * ed))
+                flush_fetches()
+                op(OP_SYNC, i0=0, r0=int(s["kind"]))
+                c1_ = cf + n0
+                op(OP_COPY, n1, r0=PIC_ORIG, r1=PIC_S_ORIG, p=(t.d_copy_orig + (co + 3 + n0) * I["copy"],))
+                op(OP_COPY, n1, r0=PIC_S_PRED, r1=PIC_S_PRED, p=(t.d_call_copy_pred + c1_ * I["copy"],))
+                op(OP_RESIDUAL, n1, p=(t.d_call_tx + c1_ * I["tx"], t.d_call_off + 4 * c1_, z_nnz + 4 * c1_,
+                                       t.d_contexts + int(sp.ev_ctx[e]) * I["ctx"], t.d_call_prm + c1_ * I["prm"]))
+                op(OP_EVAL_DIST, n1, p=(d["ev_cands"] + (ed + 3 + n0) * 24, z_ed + 8 * (ed + 3 + n0)))
+                fetch(t.d_levels + 2 * int(s["level_first"]), t.h_levels + 2 * int(s["level_first"]),
+                      2 * int(s["level_count"]))
+                if verify and s["kind"] == KIND_INTER:
+                    fetch(d["ev_inter_work"] + 3 * e * I["inter"],
+                          self.cres["ev_inter_out"][1] + 3 * e * I["inter"], 3 * I["inter"])
+                if verify and sl >= 0:
+                    fetch(pred_jobs, self.z["mg_slots_out"][1] + 3 * sl * I["inter"], 3 * I["inter"])
+                return
             op(OP_COPY, 3 + k, r0=PIC_ORIG, r1=PIC_S_ORIG, p=(t.d_copy_orig + int(s["copy_first"]) * I["copy"],))
-            op(OP_INTER_PRED, 3, r1=PIC_S_PRED, p=(d["ev_inter_work"] + 3 * e * I["inter"],
-                                                   t.d_ev_dst + 3 * e * I["pos"]))
+            sl = int(sp.ev_merge_slot[e]) if self.merge_fold else -1
+            pred_jobs = d["mg_slots"] + 3 * sl * I["inter"] if sl >= 0 else \
+                d["ev_inter_work"] + 3 * e * I["inter"]
+            op(OP_INTER_PRED, 3, r1=PIC_S_PRED, p=(pred_jobs, t.d_ev_dst + 3 * e * I["pos"]))
+            if verify and sl >= 0:      # the slot's motion, to be held against the capture
+                fetch(pred_jobs, self.z["mg_slots_out"][1] + 3 * sl * I["inter"], 3 * I["inter"])
             op(OP_COPY, k, r0=PIC_S_PRED, r1=PIC_S_PRED, p=(t.d_call_copy_pred + cf * I["copy"],))
             op(OP_RESIDUAL, k, p=(t.d_call_tx + cf * I["tx"], t.d_call_off + 4 * cf, z_nnz + 4 * cf,
                                   t.d_contexts + int(sp.ev_ctx[e]) * I["ctx"], t.d_call_prm + cf * I["prm"]))
@@ -1011,12 +1112,20 @@ class ChainedRun(SerialRun):
                       self.cres["ev_inter_out"][1] + 3 * e * I["inter"], 3 * I["inter"])
 
         chain_states, chain_kind, prev_key = 0, 0, None
+        merge_open = False             # live: the open chain is a merge ranking + its candidates
         for n_state in range(first, first + n):
             s = st[n_state]
             if not s["supported"]:
                 continue
             key = (int(s["x"]), int(s["y"]), int(s["w"]), int(s["h"]))
-            if chain_states and (not by_position or key != prev_key):
+            if live:
+                stay = merge_open and key == prev_key and int(s["kind"]) == KIND_EVAL and \
+                    self.merge_fold and sp.ev_merge_slot[int(s["ev"])] >= 0
+                merge_open = stay or (int(s["kind"]) == KIND_MERGE_RANK and self.merge_fold)
+                cut = not stay
+            else:
+                cut = not by_position or key != prev_key
+            if chain_states and cut:
                 flush_fetches()
                 op(OP_SYNC, i0=chain_states, r0=chain_kind)
                 chain_states = 0
@@ -1028,6 +1137,9 @@ class ChainedRun(SerialRun):
                 op(OP_INTER_PRED, 5, r1=PIC_S_PRED, p=(t.d_mg_inter + m * I["inter"], t.d_mg_dst + m * I["pos"]))
                 op(OP_METRIC, 5, r0=PIC_S_ORIG, r1=PIC_S_PRED, i0=0, f=1.0,
                    p=(t.d_mg_cands + m * I["cand"], self.z["mg_dist"][1] + 8 * m))
+                if self.merge_fold:
+                    op(OP_MERGE_FOLD, 1, i0=m // 5,
+                       p=(d["mg_fold"], self.z["mg_dist"][1], t.d_mg_inter, self.z["mg_res"][1], d["mg_slots"]))
             else:
                 if kind in (KIND_INTER, KIND_MOTION):
                     motion(s, n_state)
@@ -1050,30 +1162,30 @@ class ChainedRun(SerialRun):
                 rc, self.ctx.lib.xvcgpu_last_error(self.ctx.h)))
         return stats
 
-    def prepare(self, first=0, n=None, by_position=True, verify=True):
+    def prepare(self, first=0, n=None, by_position=True, verify=True, live=False):
         """Record the program (what an encoder emits as it walks its CU tree; here a
         Python loop over the state table - keep it out of a timed region)."""
         n = len(self.sp.states) - first if n is None else n
-        key = (first, n, by_position, verify, self.refs_form)
+        key = (first, n, by_position, verify, self.refs_form, live, self.merge_fold)
         if getattr(self, "_prog_key", None) != key:
-            self._prog = np.ascontiguousarray(self.program(first, n, by_position, verify))
+            self._prog = np.ascontiguousarray(self.program(first, n, by_position, verify, live=live))
             self._prog_key = key
         return self._prog
 
-    def run_chained(self, first=0, n=None, by_position=True, verify=True):
-        self.prepare(first, n, by_position, verify)
+    def run_chained(self, first=0, n=None, by_position=True, verify=True, live=False):
+        self.prepare(first, n, by_position, verify, live)
         stats = self.run_program(self._prog)
         self.collect()
         return stats
 
     @staticmethod
-    def run_interleaved(runs, first=0, n=None, by_position=True):
+    def run_interleaved(runs, first=0, n=None, by_position=True, live=False):
         """k runs (their own contexts) driven by one thread,
         xvc_host_cs_run_programs_interleaved: a chain of one run is issued while the
         others' are executing."""
         k = len(runs)
         for r in runs:
-            r.prepare(first, n, by_position, False)
+            r.prepare(first, n, by_position, False, live)
         lib = runs[0].lib
         lib.xvc_host_cs_run_programs_interleaved.argtypes = [C.c_int, C.c_void_p, C.c_void_p,
                                                              C.c_void_p, C.c_void_p, C.c_void_p]
@@ -1115,9 +1227,37 @@ class ChainedRun(SerialRun):
         n = len(st) - first if n is None else n
         R = self.cres["results"][0]
         cd_all, fin = sp.tabs["cands"], sp.order["finals"]
-        out = {"cands": [0, 0], "finals": [0, 0], "eval_motion": [0, 0]}
+        out = {"cands": [0, 0], "finals": [0, 0], "eval_motion": [0, 0], "merge_fold": [0, 0],
+               "merge_slot_motion": [0, 0]}
+        mres = self.z["mg_res"][0]
+        slots_out = self.z["mg_slots_out"][0].reshape(-1, 3)
         for ns in range(first, first + n):
             s = st[ns]
+            if s["supported"] and self.merge_fold and s["kind"] == KIND_MERGE_RANK:
+                # the device's ranking (order, sorted costs, count) against the reference's
+                m = int(s["merge"])
+                g, w = mres[m], sp.mg_want[m]
+                out["merge_fold"][0] += 1
+                if not (np.array_equal(g["order"], w["order"]) and np.array_equal(g["cost"], w["cost"]) and
+                        int(g["num"]) == int(w["num"])):
+                    out["merge_fold"][1] += 1
+                    self.first_bad = getattr(self, "first_bad", ("merge_fold", ns, tuple(g), tuple(w)))
+            if s["supported"] and self.merge_fold and s["kind"] == KIND_EVAL and \
+                    sp.ev_merge_slot[int(s["ev"])] >= 0:
+                # the motion the fold put into the slot this evaluation predicted from
+                e = int(s["ev"])
+                got, want = slots_out[int(sp.ev_merge_slot[e])], sp.ev_inter[e]
+                out["merge_slot_motion"][0] += 1
+                ok = True
+                for c in range(3):
+                    ok = ok and got[c]["flags"] == want[c]["flags"] and np.array_equal(got[c]["ref"], want[c]["ref"]) \
+                        and got[c]["comp"] == c and got[c]["x"] == want[c]["x"] and got[c]["w"] == want[c]["w"]
+                    for l in range(2):
+                        if want[c]["ref"][l] >= 0:
+                            ok = ok and np.array_equal(got[c]["mv"][l][:1], want[c]["mv"][l][:1])
+                if not ok:
+                    out["merge_slot_motion"][1] += 1
+                    self.first_bad = getattr(self, "first_bad", ("merge_slot_motion", ns, got, want))
             if not s["supported"] or s["kind"] < KIND_INTER or sp.pass_count[ns] == 0:
                 continue
             pf = int(sp.pass_first[ns])

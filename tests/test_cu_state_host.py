@@ -81,3 +81,36 @@ def test_passes_of_a_captured_picture():
     sup = st[motion]
     want = np.concatenate([np.arange(a, a + c) for a, c in zip(sup["me_first"], sup["me_count"])])
     assert np.array_equal(used, want)
+
+
+def test_merge_fold_records_of_a_captured_picture():
+    """tests/rd_serial.build_merge_folds: one xvcgpu_cs_merge record and four evaluation
+    slots per merge ranking; the captured merge-candidate evaluations find their slot
+    (ranked candidate with the same motion) - the harness-side map the GPU test checks the
+    device's fold through.  Struct sizes as the C compiler lays them out."""
+    import subprocess, os, tempfile
+    # (tiny's rankings mostly hold an illumination-compensated candidate: those rankings
+    # are not replayed, their plain candidates' evaluations keep the capture's job)
+    for name, poc, least in (("tiny", 2, 0.5), ("c0", 4, 0.85)):
+        sp = rd_serial.SerialPicture(api, name, poc)
+        rd_serial.build_merge_folds(sp)
+        n_m = len(sp.mg_inter)
+        assert len(sp.mg_fold) == n_m and sp.mg_slots.shape == (4 * n_m, 3)
+        st = sp.states
+        ev = st["ev"][(st["kind"] == rd_serial.KIND_EVAL) & (st["supported"] != 0)]
+        mapped = sp.ev_merge_slot[ev] >= 0
+        assert mapped.mean() > least, (name, mapped.mean())
+        # a slot is used by at most one evaluation, and lies inside its ranking's count
+        used = sp.ev_merge_slot[sp.ev_merge_slot >= 0]
+        assert len(np.unique(used)) == len(used)
+        assert ((used % 4) < sp.mg_want["num"][used // 4]).all()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with tempfile.TemporaryDirectory() as td:
+        src = os.path.join(td, "sz.c")
+        open(src, "w").write('#include <stdio.h>\n#include "xvcgpu_types.h"\n'
+                             'int main(){printf("%zu %zu\\n", sizeof(xvcgpu_cs_merge), '
+                             'sizeof(xvcgpu_cs_merge_result));return 0;}\n')
+        exe = os.path.join(td, "sz")
+        subprocess.check_call(["gcc", "-I", os.path.join(root, "include"), src, "-o", exe])
+        a, b = map(int, subprocess.check_output([exe]).split())
+    assert (a, b) == (rd_serial.MERGE_FOLD_DTYPE.itemsize, rd_serial.MERGE_RESULT_DTYPE.itemsize)

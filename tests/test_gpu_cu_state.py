@@ -49,14 +49,14 @@ def test_serial_walk_equals_reference(gpu, name, poc, n_states):
         assert res["affine"][0] > 100
 
 
-def _run_chained(api, ctx, name, poc, n_states, by_position, refs_form=True):
+def _run_chained(api, ctx, name, poc, n_states, by_position, refs_form=True, live=False):
     fx = sf.StreamFixture(name)
     pics, w, h = decode_stream(ctx, fx)
     sp = rd_serial.SerialPicture(api, name, poc)
     run = rd_serial.ChainedRun(api, ctx, sp, pics, w, h, rd_serial.ref_lists_of(name, poc))
     run.refs_form = refs_form
     n = min(n_states, len(sp.states))
-    stats = run.run_chained(0, n, by_position)
+    stats = run.run_chained(0, n, by_position, live=live)
     res = run.check(0, n, searches=False)
     res.update(run.check_chained(0, n))
     bad = repr(getattr(run, "first_bad", None))     # (views of pinned memory: before destroy)
@@ -87,8 +87,33 @@ def test_chained_states_equal_reference(gpu, name, poc, n_states, by_position, r
     for k, (done, wrong) in res.items():
         assert wrong == 0, (k, res, bad)
     assert stats.round_trips <= stats.states
-    for k in ("cands", "finals", "eval_motion", "calls", "merge"):
+    for k in ("cands", "finals", "eval_motion", "calls", "merge", "merge_fold", "merge_slot_motion"):
         assert res[k][0] > 100, (k, res)
+    # every merge ranking went through the device's fold (xvcgpu_cs_merge_fold), and nearly
+    # every merge candidate's evaluation predicted from the slot the fold filled (the rest:
+    # affine merges and candidates the harness could not tell apart)
+    assert res["merge_fold"][0] == res["merge"][0]
+    merge_evals = int(((sp.states["kind"] == rd_serial.KIND_EVAL) & (sp.states["supported"] != 0))[
+        :min(n_states, len(sp.states))].sum())
+    assert res["merge_slot_motion"][0] > (0.5 if name == "tiny" else 0.8) * merge_evals, (res, merge_evals)
+
+
+@pytest.mark.parametrize("name,poc,n_states", [("tiny", 2, 1 << 30), ("c1", 2, 6000)])
+def test_live_chains_equal_reference(gpu, name, poc, n_states):
+    """The chains a live encoder could issue (rd_serial.program(live=True)): a wait after
+    every CompressInter and in front of an evaluation's gated second transform pass, a merge
+    ranking and its candidates' evaluations as one chain with the ranking folded on the
+    device (xvcgpu_cs_merge_fold fills the evaluation slots).  Same results as the
+    reference's, between one and two waits per state."""
+    api, ctx = gpu
+    sp, stats, res, bad = _run_chained(api, ctx, name, poc, n_states, False, True, live=True)
+    print(name, "live", res, "%.1f us / state, %.2f round trips per state" % (
+        1e6 * stats.seconds / max(stats.states, 1), stats.round_trips / max(stats.states, 1)))
+    for k, (done, wrong) in res.items():
+        assert wrong == 0, (k, res, bad)
+    for k in ("cands", "finals", "eval_motion", "calls", "merge_fold", "merge_slot_motion"):
+        assert res[k][0] > 100, (k, res)
+    assert 0.5 * stats.states < stats.round_trips < 2 * stats.states
 
 
 def test_interleaved_chains_equal_reference(gpu):

@@ -52,7 +52,10 @@ def walk(api, clip, poc, n_states, ks, mode="serial", check=True, decoded=None, 
                 return r.run_serial(0, count)
             # timed without the read-back of the composed prediction jobs, which only the
             # check below wants (an encoder takes the motion from the pass results)
-            return r.run_chained(0, count, by_position=(mode == "chained"), verify=verify)
+            # modes: "chained" = a chain per visit of a CU position; "by_state" = a chain per
+            # state; "live" = the chains a live encoder could issue (rd_serial.program)
+            return r.run_chained(0, count, by_position=(mode == "chained"), verify=verify,
+                                 live=(mode == "live"))
 
         def work(i):
             stats[i] = go(runs[i], n)
@@ -61,7 +64,7 @@ def walk(api, clip, poc, n_states, ks, mode="serial", check=True, decoded=None, 
             go(r, min(n, 200))
         if mode != "serial":        # the programs are recorded before the clock starts
             for r in runs:
-                r.prepare(0, n, mode == "chained", False)
+                r.prepare(0, n, mode == "chained", False, mode == "live")
         # the median of three runs: with k host threads a run's rate depends on how
         # the threads and the streams' queues fall (0.28 - 0.57 pictures/s at k = 4)
         walls = []
@@ -110,13 +113,13 @@ def walk(api, clip, poc, n_states, ks, mode="serial", check=True, decoded=None, 
                 entry["threads_x_chains"]["%dx%d" % (T, k // T)] = {
                     "states_per_s": done_t / wall_t,
                     "pictures_per_s": done_t / wall_t / (s0.states * per_pic)}
-        if mode == "chained" and k > 1:
+        if mode in ("chained", "live") and k > 1:
             # the same k chains driven by ONE host thread, a chain issued while the
             # others execute (xvc_host_cs_run_programs_interleaved)
             walls_i = []
             for _ in range(3):
                 t0 = time.time()
-                si = rd_serial.ChainedRun.run_interleaved(runs, 0, n)
+                si = rd_serial.ChainedRun.run_interleaved(runs, 0, n, mode == "chained", mode == "live")
                 walls_i.append(time.time() - t0)
             wall_i = sorted(walls_i)[1]
             entry["one_thread"] = {"states_per_s": si.states / wall_i,

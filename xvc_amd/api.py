@@ -155,7 +155,7 @@ SYMBOLS = [
     "xvcgpu_create", "xvcgpu_destroy", "xvcgpu_last_error", "xvcgpu_version",
     "xvcgpu_set_stream", "xvcgpu_get_stream", "xvcgpu_use_own_stream", "xvcgpu_use_priority_stream", "xvcgpu_set_short_kernel_priority", "xvcgpu_wait_for", "xvcgpu_sync", "xvcgpu_timer_begin", "xvcgpu_timer_end", "xvcgpu_timer_mark", "xvcgpu_timer_between",
     "xvcgpu_record_begin", "xvcgpu_record_end", "xvcgpu_replay", "xvcgpu_recording_destroy",
-    "xvcgpu_malloc", "xvcgpu_free", "xvcgpu_memcpy_h2d", "xvcgpu_memcpy_d2h", "xvcgpu_memcpy_d2h_async", "xvcgpu_upload_ahead", "xvcgpu_eval_dist_batch", "xvcgpu_cs_start_fold", "xvcgpu_cs_uni_fold", "xvcgpu_cs_bi_fold",
+    "xvcgpu_malloc", "xvcgpu_free", "xvcgpu_memcpy_h2d", "xvcgpu_memcpy_d2h", "xvcgpu_memcpy_d2h_async", "xvcgpu_upload_ahead", "xvcgpu_eval_dist_batch", "xvcgpu_cs_start_fold", "xvcgpu_cs_uni_fold", "xvcgpu_cs_bi_fold", "xvcgpu_cs_merge_fold",
     "xvcgpu_memset", "xvcgpu_picture_create", "xvcgpu_picture_bytes",
     "xvcgpu_picture_wrap", "xvcgpu_picture_destroy", "xvcgpu_picture_upload",
     "xvcgpu_picture_download", "xvcgpu_picture_upload_padded",
@@ -324,6 +324,7 @@ def load_library():
         "xvcgpu_cs_start_fold": [_vp, _vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int],
         "xvcgpu_cs_uni_fold": [_vp, _vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp],
         "xvcgpu_cs_bi_fold": [_vp, _vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp],
+        "xvcgpu_cs_merge_fold": [_vp, _vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp],
         "xvcgpu_intra_recon_waves": [_vp, _vp, _vp, _vp, _vp, _vp, C.c_int, _vp, _vp, _vp],
         "xvcgpu_bipred_search_lic": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, _vp, C.c_int],
         "xvcgpu_root_cbf_batch": [_vp, _vp, C.c_int, _vp],

@@ -480,6 +480,65 @@ __global__ void cs_bi_fold_kernel(const xvcgpu_cs_pass *passes, int first, int n
   CS_FOLD_EPILOGUE
 }
 
+// ---- the merge ranking's fold: SearchMergeCandidates' arithmetic (:176-196) ---------
+// One thread per ranking: five costs in double (dist + bits * lambda_sqrt as the
+// reference forms it - no contraction, -ffp-contract=off), std::stable_sort = an
+// insertion sort that only moves on strictly smaller, the 1.25 x cut from the back.
+__global__ void cs_merge_fold_kernel(const xvcgpu_cs_merge *merges, int first, int n,
+                                     const uint64_t *dist, const xvcgpu_inter_block *cands,
+                                     xvcgpu_cs_merge_result *results,
+                                     xvcgpu_inter_block *ev_inter) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const xvcgpu_cs_merge m = merges[first + i];
+  double cost[XVC_CS_MERGE_CANDS];
+  int order[XVC_CS_MERGE_CANDS];
+  for (int k = 0; k < XVC_CS_MERGE_CANDS; k++) {
+    const int bits = k + 1 - (k < XVC_CS_MERGE_CANDS - 1 ? 0 : 1);
+    cost[k] = (double)dist[m.dist + k] + (double)bits * m.lambda_sqrt;
+    order[k] = k;
+  }
+  for (int a = 1; a < XVC_CS_MERGE_CANDS; a++) {   // stable: equal costs keep their order
+    const double c = cost[a];
+    const int o = order[a];
+    int b = a - 1;
+    while (b >= 0 && c < cost[b]) {
+      cost[b + 1] = cost[b];
+      order[b + 1] = order[b];
+      b--;
+    }
+    cost[b + 1] = c;
+    order[b + 1] = o;
+  }
+  int num = XVC_CS_MERGE_SLOTS;
+  for (int k = XVC_CS_MERGE_SLOTS; k >= 0; k--)
+    if (cost[k] > cost[0] * 1.25) num = k;
+  xvcgpu_cs_merge_result r;
+  for (int k = 0; k < XVC_CS_MERGE_CANDS; k++) {
+    r.cost[k] = cost[k];
+    r.order[k] = order[k];
+  }
+  r.num = num;
+  r.reserved[0] = r.reserved[1] = 0;
+  results[first + i] = r;
+  if (m.slot < 0) return;
+  for (int sl = 0; sl < XVC_CS_MERGE_SLOTS; sl++) {
+    const xvcgpu_inter_block src = cands[m.cand + order[sl]];
+    for (int c = 0; c < 3; c++) {
+      xvcgpu_inter_block &b = ev_inter[3 * (m.slot + sl) + c];
+      const bool on = sl < num;
+      b.flags = on ? src.flags : 0;
+      for (int l = 0; l < 2; l++) {
+        b.ref[l] = on ? src.ref[l] : (int8_t)-1;
+        for (int k = 0; k < 3; k++) {
+          b.mv[l][k][0] = on ? src.mv[l][k][0] : 0;
+          b.mv[l][k][1] = on ? src.mv[l][k][1] : 0;
+        }
+      }
+    }
+  }
+}
+
 // ---- the distortions of an evaluation in one launch ----------------------------------
 // metric_batch_kernel (k_metric.h) with the planes chosen per candidate: an evaluation
 // compares three components against two pictures with three weights - seven launches

@@ -2491,6 +2491,20 @@ xvcgpu_status xvcgpu_cs_start_fold(xvcgpu_ctx *ctx, const xvcgpu_cs_pass *d_pass
   return XVCGPU_OK;
 }
 
+xvcgpu_status xvcgpu_cs_merge_fold(xvcgpu_ctx *ctx, const xvcgpu_cs_merge *d_merges, int first,
+                                   int n, const uint64_t *d_dist,
+                                   const xvcgpu_inter_block *d_cands,
+                                   xvcgpu_cs_merge_result *d_results,
+                                   xvcgpu_inter_block *d_ev_inter) {
+  if (!ctx || n < 0 || first < 0 || (n && (!d_merges || !d_dist || !d_cands || !d_results)))
+    return XVCGPU_INVALID_ARGUMENT;
+  if (!n) return XVCGPU_OK;
+  hipLaunchKernelGGL(cs_merge_fold_kernel, dim3((n + 63) / 64), dim3(64), 0, ctx->stream,
+                     d_merges, first, n, d_dist, d_cands, d_results, d_ev_inter);
+  CHECK_LAUNCH(ctx, "cs_merge_fold");
+  return XVCGPU_OK;
+}
+
 xvcgpu_status xvcgpu_cs_uni_fold(xvcgpu_ctx *ctx, const xvcgpu_cs_pass *d_passes, int first,
     int n,
                                  const xvcgpu_me_result *d_me_res,

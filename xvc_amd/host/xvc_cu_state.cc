@@ -230,6 +230,18 @@ namespace {
 xvcgpu_status IssueOp(xvcgpu_ctx *ctx, const xvc_cs_env *env, const xvc_cs_op &o) {
   const xvcgpu_picture *pics[4] = {env->orig, env->s_orig, env->s_pred, env->s_rec};
   void *const *p = reinterpret_cast<void *const *>(o.p);
+  // r0 / r1 name a reference slot or one of the four pictures above, by opcode
+  const bool ref_slots = o.opcode == XVC_OP_MC_METRIC || o.opcode == XVC_OP_ME ||
+                         o.opcode == XVC_OP_BI || o.opcode == XVC_OP_AFFINE;
+  const bool pic_index = o.opcode == XVC_OP_METRIC || o.opcode == XVC_OP_COPY ||
+                         o.opcode == XVC_OP_INTER_PRED;
+  if (ref_slots && (o.r0 < 0 || o.r0 >= env->n_refs ||
+                    (o.opcode != XVC_OP_MC_METRIC && o.opcode != XVC_OP_ME &&
+                     (o.r1 < 0 || o.r1 >= env->n_refs))))
+    return XVCGPU_INVALID_ARGUMENT;
+  if (pic_index && (o.r1 < 0 || o.r1 > 3 ||
+                    (o.opcode != XVC_OP_INTER_PRED && (o.r0 < 0 || o.r0 > 3))))
+    return XVCGPU_INVALID_ARGUMENT;
   switch (o.opcode) {
     case XVC_OP_MC_METRIC:
       return xvcgpu_mc_metric_batch(ctx, env->orig, env->refs[o.r0], 16,
@@ -312,6 +324,12 @@ xvcgpu_status IssueOp(xvcgpu_ctx *ctx, const xvc_cs_env *env, const xvc_cs_op &o
                                          static_cast<const xvcgpu_affine_me_block *>(p[0]),
                                          static_cast<const uint8_t *>(p[2]), o.n,
                                          static_cast<xvcgpu_affine_me_result *>(p[1]), o.i0);
+    case XVC_OP_MERGE_FOLD:
+      return xvcgpu_cs_merge_fold(ctx, static_cast<const xvcgpu_cs_merge *>(p[0]), o.i0, o.n,
+                                  static_cast<const uint64_t *>(p[1]),
+                                  static_cast<const xvcgpu_inter_block *>(p[2]),
+                                  static_cast<xvcgpu_cs_merge_result *>(p[3]),
+                                  static_cast<xvcgpu_inter_block *>(p[4]));
     default:
       return XVCGPU_INVALID_ARGUMENT;
   }

@@ -121,7 +121,8 @@ enum {
   XVC_OP_MC_METRIC = 0, XVC_OP_METRIC, XVC_OP_ME, XVC_OP_BI, XVC_OP_AFFINE, XVC_OP_COPY,
   XVC_OP_INTER_PRED, XVC_OP_RESIDUAL, XVC_OP_START_FOLD, XVC_OP_UNI_FOLD, XVC_OP_BI_FOLD,
   XVC_OP_FETCH, XVC_OP_SYNC, XVC_OP_EVAL_DIST, XVC_OP_MC_METRIC_REFS, XVC_OP_ME_REFS,
-  XVC_OP_BI_REFS, XVC_OP_AFFINE_REFS
+  XVC_OP_BI_REFS, XVC_OP_AFFINE_REFS,
+  XVC_OP_MERGE_FOLD   // p: merges, distortions, candidates' jobs, results, evaluation slots; i0 = first
 };
 typedef struct xvc_cs_op {
   int32_t opcode, n, r0, r1, i0, reserved;
