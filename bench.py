@@ -649,6 +649,24 @@ class HostStagedComm:
         pass
 
 
+def quoted_cpu_baseline():
+    """The N > 1 lines carry the CPU baseline of the N = 1 run (it is measured on rank 0 at
+    N = 1 only, as the contract asks): quoted from the newest committed bench line under
+    profiles/, with its source named."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_bench.json")), reverse=True):
+        try:
+            with open(path) as f:
+                cpu = json.load(f).get("cpu_baseline")
+        except (OSError, ValueError):
+            continue
+        if cpu:
+            cpu = dict(cpu)
+            cpu["quoted_from"] = os.path.relpath(path, ROOT) + " (the N = 1 run; not re-measured here)"
+            return cpu
+    return None
+
+
 def main_pictures(args, torch, api, pipeline, synth, world, rank, local_rank):
     """N ranks x `slots` picture slots code the pictures of hierarchical sub-GOPs
     (length 16, two references per list as the reference configures itself) in
@@ -780,6 +798,10 @@ def main_pictures(args, torch, api, pipeline, synth, world, rank, local_rank):
             "rccl_world_size": rccl_world,
             "tail_crc": {str(k): tail[k] for k in sorted(tail)},
             "same_workload_on_one_gpu": one_gpu,
+            # the N = 1 point of THIS curve is `bench.py --gpus 1 --schedule subgop` (the
+            # default N = 1 run times the three-chain workload); efficiency against it:
+            "efficiency_vs_same_workload_on_one_gpu":
+                (args.steps / dt) / (world * one_gpu) if one_gpu else None,
             "config": {"workload": "%dx%d yuv420p 30fps synthetic, QP %d, internal bitdepth 10, "
                                    "16x16 CUs, TZ range 96, %s" %
                                    (W, H, args.qp, "RDOQ" if rdoq else "QuantFast"),
@@ -795,7 +817,8 @@ def main_pictures(args, torch, api, pipeline, synth, world, rank, local_rank):
                                                        "RCCL send/recv" if rccl_world else
                                                        "HOST STAGING (testing aid)", n_pictures),
                        "schedule_makespan_pictures": int(sched.makespan)},
-            "roofline": roof, "cpu_baseline": cpu}))
+            "roofline": roof,
+            "cpu_baseline": cpu if cpu is not None or world == 1 else quoted_cpu_baseline()}))
     if comm is not None:
         comm.sync()
         comm.destroy()
@@ -1244,7 +1267,9 @@ def main():
                                        (world, n_chains,
                                         "RCCL send/recv groups issued by libxvcgpu.so" if native
                                         else "torch.distributed (%s)" % backend))},
-            "roofline": roof, "cpu_baseline": cpu, "stream_decode": decode,
+            "roofline": roof,
+            "cpu_baseline": cpu if cpu is not None or world == 1 else quoted_cpu_baseline(),
+            "stream_decode": decode,
         }
         print(json.dumps(out))
     if multi:

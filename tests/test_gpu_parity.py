@@ -1678,6 +1678,11 @@ def test_bench_multi_rank_path_runs(gpu):
     assert d["n_gpus"] == 2 and d["steps"] == 24 and d["scaling"] == "strong"
     assert d["pictures_in_flight"] == 3 and 25.0 < d["psnr_y"] < 60.0
     assert "cu-row-shard2" in d["config"]["parallelism"]
+    # what makes the line readable on its own: the exchanges' RCCL operations and bytes per
+    # picture from the C++ plan, and the CPU baseline quoted from the N = 1 run
+    ex = d["shard_exchange_per_picture"]
+    assert ex and all(len(v) == 2 and v[1] > 0 for v in ex.values())
+    assert d["cpu_baseline"] is None or "quoted_from" in d["cpu_baseline"]
 
 
 @pytest.mark.parametrize("size,qp", [((352, 288), 30), ((1920, 1080), 36)])

@@ -660,6 +660,13 @@ xvcgpu_status PictureDecoder::DecodeSequence(int n, const xvc_picture_syntax *co
   if (n < 0 || (n && (!ps || !cus || !levels || !ref_index || !recs)))
     return XVCGPU_INVALID_ARGUMENT;
   if (!n) return XVCGPU_OK;
+  // With lanes a picture is ordered behind the pictures it REFERENCES only: a buffer
+  // handed in twice (a recycled DPB entry) would be written on one lane while another
+  // lane still reads what it held - refused (one lane keeps stream order and takes it)
+  if (num_lanes() > 1)
+    for (int i = 0; i < n; i++)
+      for (int j = 0; j < i; j++)
+        if (recs[i] && recs[i] == recs[j]) return XVCGPU_INVALID_ARGUMENT;
   // kWorkers planners, each taking every kWorkers-th picture, kRing plan slots: a plan
   // costs about as much host time as a B picture takes on the device, and more when
   // its thread shares the memory system with the issuing thread - several in flight

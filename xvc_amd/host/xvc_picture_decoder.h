@@ -125,7 +125,9 @@ class PictureDecoder {
   // pictures over the lanes in decoding order; a picture's kernels wait for the
   // pictures it references (events), so pictures that do not depend on each other -
   // the B pictures of one temporal layer - run side by side.  The context must be on
-  // this decoder's device and stays the caller's.
+  // this decoder's device and stays the caller's.  With lanes the recs[] entries of a
+  // DecodeSequence call must be distinct buffers (nothing orders a picture behind the
+  // READERS of what its buffer held before): a repeated entry is XVCGPU_INVALID_ARGUMENT.
   xvcgpu_status AddLane(xvcgpu_ctx *ctx);
   int num_lanes() const { return 1 + static_cast<int>(lanes_.size()); }
 
