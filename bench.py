@@ -1130,7 +1130,7 @@ def main():
                 ROOT, "profiles",
                 "traffic_current.json" if args.quant == "rdoq" else "traffic_current_fast.json")))
             kname = {"me_search": "me_search_wave_kernel<16, 3",
-                     "recon_from_me": "recon_from_me_kernel", "quant_rdo": "quant_rdo_packed_kernel",
+                     "recon_from_me": "recon_from_me_kernel", "quant_rdo": "quant_rdo_packed4_kernel",
                      "fwd_transform": "residual_wave_kernel<1", "inv_transform": "residual_wave_kernel<2",
                      "mc_from_me": "mc_from_me_kernel",
                      "picture_ssd": "picture_ssd_kernel", "pad_border": "pad_border_kernel",

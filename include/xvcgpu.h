@@ -499,6 +499,23 @@ xvcgpu_status xvcgpu_residual_rdoq_batch(xvcgpu_ctx *ctx, const xvcgpu_picture *
                                          int32_t *d_nnz,
                                          const xvcgpu_rdoq_contexts *d_contexts,
                                          const xvcgpu_rdoq_params *d_params);
+/* The same for the blocks of ONE CU state (n <= 64) whose original and prediction lie
+ * elsewhere: block i reads its original at d_src_pos[2 i] of `orig` and its prediction
+ * at d_src_pos[2 i + 1] of `pred` (positions in the plane of the block's component) and
+ * writes its reconstruction at its own (x, y) of `rec` - the RD search's alternatives
+ * of a CU (CompressAndEvalTransform's default / transform-select / skip candidates)
+ * each reconstruct into their own slot of a scratch picture from the one prediction
+ * and the original picture itself, without the two block copies that put them side by
+ * side.  orig may have another size than pred / rec. */
+xvcgpu_status xvcgpu_residual_rdoq_batch_at(xvcgpu_ctx *ctx, const xvcgpu_picture *orig,
+                                            const xvcgpu_picture *pred, xvcgpu_picture *rec,
+                                            const xvcgpu_tx_block *d_blocks, int n,
+                                            int16_t *d_levels, const uint32_t *d_level_offsets,
+                                            int32_t *d_nnz,
+                                            const xvcgpu_rdoq_contexts *d_contexts,
+                                            const xvcgpu_rdoq_params *d_params,
+                                            const xvcgpu_block_pos *d_src_pos);
+
 
 /* Q2 alone: RdoQuant::QuantRdo on coefficients the caller holds (the output
  * of xvcgpu_fwd_transform_batch; the levels go to xvcgpu_inv_transform_batch):

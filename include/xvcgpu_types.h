@@ -455,7 +455,11 @@ typedef struct xvcgpu_eval_cand {
   int8_t qp;           /* raw luma qp (structural SSD)                                */
   uint8_t comp;        /* 0 = Y, 1 = U, 2 = V                                         */
   uint8_t versus;      /* 0: the prediction picture, 1: the reconstruction picture    */
-  uint8_t reserved[6];
+  int16_t ox, oy;      /* orig_at != 0: the block's position in `orig` (component
+                        * plane) - the original picture itself instead of a copy of
+                        * the block beside the candidate's slot                       */
+  uint8_t orig_at;
+  uint8_t reserved;
   double weight;       /* Qp::GetDistortionWeight(comp)                               */
 } xvcgpu_eval_cand;
 

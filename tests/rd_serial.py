@@ -352,6 +352,7 @@ class SerialPicture:
             call_slot[pos:pos + p1] = 1 + int(r["comp_count"][0]) + np.arange(p1)
         assert nc == 0 or call_slot.max() < MAX_SLOTS
         ce = e[call_ev]
+        self.call_ev = call_ev
         sh = (cl["comp"] != 0).astype(np.int64)
         self.call_tx = np.zeros(nc, api.TX_DTYPE)
         t = self.call_tx
@@ -605,7 +606,7 @@ RESULT_DTYPE = np.dtype([
     ("best_cost", "<u4"), ("out_mv", "<i4", (2, 3, 2)), ("out_mvd", "<i4", (2, 2, 2))], align=True)
 
 OP_DTYPE = np.dtype([("opcode", "<i4"), ("n", "<i4"), ("r0", "<i4"), ("r1", "<i4"), ("i0", "<i4"),
-                     ("reserved", "<i4"), ("f", "<f8"), ("p", "<u8", 5)], align=True)
+                     ("reserved", "<i4"), ("f", "<f8"), ("p", "<u8", 6)], align=True)
 (OP_MC_METRIC, OP_METRIC, OP_ME, OP_BI, OP_AFFINE, OP_COPY, OP_INTER_PRED, OP_RESIDUAL,
  OP_START_FOLD, OP_UNI_FOLD, OP_BI_FOLD, OP_FETCH, OP_SYNC, OP_EVAL_DIST, OP_MC_METRIC_REFS,
  OP_ME_REFS, OP_BI_REFS, OP_AFFINE_REFS, OP_MERGE_FOLD) = range(19)
@@ -851,6 +852,9 @@ class ChainedRun(SerialRun):
     """SerialRun + the arrays and the program of the chained form."""
 
     refs_form = True      # a SearchMotion step into all reference pictures as one launch
+    no_copies = True      # originals read from the picture itself, an evaluation's alternatives
+    #                       from its one prediction (xvcgpu_residual_rdoq_batch_at, the
+    #                       candidates' orig_at): no block copies inside a chain
     merge_fold = True     # the merge ranking folded on the device: a merge candidate's
     #                       evaluation predicts from the slot xvcgpu_cs_merge_fold filled
 
@@ -904,9 +908,11 @@ class ChainedRun(SerialRun):
             k = int(r["call_pass0"]) + int(r["call_pass1"])
             self.edist_first[ns] = n_ed
             blk = np.zeros(3 + k, api.EVAL_CAND_DTYPE)
+            evr = sp.ev_want[ev]
             for c in range(3):
                 d_ = sp.ev_dz[ev, c]
-                blk[c] = (d_["x"], d_["y"], d_["w"], d_["h"], d_["metric"], d_["qp"], c, 0, 0,
+                blk[c] = (d_["x"], d_["y"], d_["w"], d_["h"], d_["metric"], d_["qp"], c, 0,
+                          int(evr["x"]) >> (1 if c else 0), int(evr["y"]) >> (1 if c else 0), 1, 0,
                           sp.ev_weight[ev, c])
             cc = sp.call_cand[cf:cf + k]
             comp = sp.call_tx["comp"][cf:cf + k]
@@ -914,11 +920,37 @@ class ChainedRun(SerialRun):
             for f in ("x", "y", "w", "h", "metric", "qp"):
                 b[f] = cc[f]
             b["comp"], b["versus"] = comp, 1
+            b["ox"], b["oy"], b["orig_at"] = int(evr["x"]) >> (comp != 0), int(evr["y"]) >> (comp != 0), 1
             b["weight"] = sp.ev_weight[ev][comp]
             blk[3:] = b
             cands.append(blk)
             n_ed += 3 + k
-        d["ev_cands"] = up(np.concatenate(cands) if cands else np.zeros(0, api.EVAL_CAND_DTYPE))
+        allc = np.concatenate(cands) if cands else np.zeros(0, api.EVAL_CAND_DTYPE)
+        d["ev_cands"] = up(allc)
+        allc = allc.copy()
+        allc["orig_at"] = 0           # the form with the originals copied beside the slots
+        d["ev_cands_copy"] = up(allc)
+        # per TransformAndReconstruct call: where its original lies in the picture and its
+        # prediction in the scratch picture (the evaluation's slot 0), component planes
+        ce = sp.ev_want[sp.call_ev] if len(sp.call_tx) else sp.ev_want[:0]
+        sh = (sp.call_tx["comp"] != 0).astype(np.int64)
+        pos = np.zeros((len(sp.call_tx), 2), api.POS_DTYPE)
+        pos["x"][:, 0], pos["y"][:, 0] = ce["x"] >> sh, ce["y"] >> sh
+        d["call_pos"] = up(pos)
+        # the merge rankings' and the affine start predictors' distortions as evaluation
+        # candidates against the original picture (weight 1: the distortion itself)
+        mc = np.zeros((len(sp.mg_inter), 5), api.EVAL_CAND_DTYPE)
+        for f in ("x", "y", "w", "h", "metric"):
+            mc[f] = sp.mg_cands[f]
+        mc["ox"], mc["oy"], mc["orig_at"], mc["weight"] = sp.mg_want["x"][:, None], sp.mg_want["y"][:, None], 1, 1.0
+        d["mg_ecands"] = up(mc)
+        ac = np.zeros(len(sp.aff_start_cands), api.EVAL_CAND_DTYPE)
+        for f in ("x", "y", "w", "h", "metric"):
+            ac[f] = sp.aff_start_cands[f]
+        if len(ac):
+            ac["ox"], ac["oy"] = sp.aff_start_copy["sx"], sp.aff_start_copy["sy"]
+        ac["orig_at"], ac["weight"] = 1, 1.0
+        d["aff_start_ecands"] = up(ac)
         self.z = {}
         for name, dt, n in (("nnz", np.dtype("<i4"), len(sp.call_tx)), ("edist", np.dtype("<u8"), n_ed),
                             ("mg_dist", np.dtype("<u8"), 5 * len(sp.mg_inter)),
@@ -963,7 +995,7 @@ class ChainedRun(SerialRun):
                                         ("result", RESULT_DTYPE))}
 
         def op(code, n_=0, r0=0, r1=0, i0=0, f=0.0, p=()):
-            ops.append((code, n_, r0, r1, i0, 0, f, tuple(int(x) for x in p) + (0,) * (5 - len(p))))
+            ops.append((code, n_, r0, r1, i0, 0, f, tuple(int(x) for x in p) + (0,) * (6 - len(p))))
 
         pending = []                   # (device, host, bytes) read-backs of the open chain
 
@@ -1011,11 +1043,15 @@ class ChainedRun(SerialRun):
                         op(OP_MC_METRIC, k, r0=sl, p=(d["start_cands"] + ca * I["mcm"], d["start_dist"] + 8 * a))
                 else:
                     a, k, sd = sp.aff_start[pi]
-                    op(OP_COPY, k, r0=PIC_ORIG, r1=PIC_S_ORIG, p=(d["aff_start_copy"] + a * I["copy"],))
+                    if not self.no_copies:
+                        op(OP_COPY, k, r0=PIC_ORIG, r1=PIC_S_ORIG, p=(d["aff_start_copy"] + a * I["copy"],))
                     op(OP_INTER_PRED, k, r1=PIC_S_PRED, p=(d["aff_start_inter"] + a * I["inter"],
                                                            d["aff_start_dst"] + a * I["pos"]))
-                    op(OP_METRIC, k, r0=PIC_S_ORIG, r1=PIC_S_PRED, i0=0, f=1.0,
-                       p=(d["aff_start_cands"] + a * I["cand"], d["start_dist"] + 8 * sd))
+                    if self.no_copies:
+                        op(OP_EVAL_DIST, k, r0=1, p=(d["aff_start_ecands"] + a * 24, d["start_dist"] + 8 * sd))
+                    else:
+                        op(OP_METRIC, k, r0=PIC_S_ORIG, r1=PIC_S_PRED, i0=0, f=1.0,
+                           p=(d["aff_start_cands"] + a * I["cand"], d["start_dist"] + 8 * sd))
                 op(OP_START_FOLD, 1, i0=pi, p=(P, d["start_dist"], d["me_work"], d["me_res_c"], d["aff_work"]))
                 ug = sp.aff_uni_groups[pi] if affine else sp.uni_groups[pi]
                 if refs_form and ug:
@@ -1071,20 +1107,28 @@ class ChainedRun(SerialRun):
                 sl = int(sp.ev_merge_slot[e]) if self.merge_fold else -1
                 pred_jobs = d["mg_slots"] + 3 * sl * I["inter"] if sl >= 0 else \
                     d["ev_inter_work"] + 3 * e * I["inter"]
-                op(OP_COPY, 3 + n0, r0=PIC_ORIG, r1=PIC_S_ORIG, p=(t.d_copy_orig + co * I["copy"],))
+                nc_ = self.no_copies
+                ecands = d["ev_cands"] if nc_ else d["ev_cands_copy"]
+                if not nc_:
+                    op(OP_COPY, 3 + n0, r0=PIC_ORIG, r1=PIC_S_ORIG, p=(t.d_copy_orig + co * I["copy"],))
                 op(OP_INTER_PRED, 3, r1=PIC_S_PRED, p=(pred_jobs, t.d_ev_dst + 3 * e * I["pos"]))
-                op(OP_COPY, n0, r0=PIC_S_PRED, r1=PIC_S_PRED, p=(t.d_call_copy_pred + cf * I["copy"],))
+                if not nc_:
+                    op(OP_COPY, n0, r0=PIC_S_PRED, r1=PIC_S_PRED, p=(t.d_call_copy_pred + cf * I["copy"],))
                 op(OP_RESIDUAL, n0, p=(t.d_call_tx + cf * I["tx"], t.d_call_off + 4 * cf, z_nnz + 4 * cf,
-                                       t.d_contexts + int(sp.ev_ctx[e]) * I["ctx"], t.d_call_prm + cf * I["prm"]))
-                op(OP_EVAL_DIST, 3 + n0, p=(d["ev_cands"] + ed * 24, z_ed + 8 * ed))
+                                       t.d_contexts + int(sp.ev_ctx[e]) * I["ctx"], t.d_call_prm + cf * I["prm"],
+                                       d["call_pos"] + 2 * cf * I["pos"] if nc_ else 0))
+                op(OP_EVAL_DIST, 3 + n0, r0=1 if nc_ else 0, p=(ecands + ed * 24, z_ed + 8 * ed))
                 flush_fetches()
                 op(OP_SYNC, i0=0, r0=int(s["kind"]))
                 c1_ = cf + n0
-                op(OP_COPY, n1, r0=PIC_ORIG, r1=PIC_S_ORIG, p=(t.d_copy_orig + (co + 3 + n0) * I["copy"],))
-                op(OP_COPY, n1, r0=PIC_S_PRED, r1=PIC_S_PRED, p=(t.d_call_copy_pred + c1_ * I["copy"],))
+                if not nc_:
+                    op(OP_COPY, n1, r0=PIC_ORIG, r1=PIC_S_ORIG, p=(t.d_copy_orig + (co + 3 + n0) * I["copy"],))
+                    op(OP_COPY, n1, r0=PIC_S_PRED, r1=PIC_S_PRED, p=(t.d_call_copy_pred + c1_ * I["copy"],))
                 op(OP_RESIDUAL, n1, p=(t.d_call_tx + c1_ * I["tx"], t.d_call_off + 4 * c1_, z_nnz + 4 * c1_,
-                                       t.d_contexts + int(sp.ev_ctx[e]) * I["ctx"], t.d_call_prm + c1_ * I["prm"]))
-                op(OP_EVAL_DIST, n1, p=(d["ev_cands"] + (ed + 3 + n0) * 24, z_ed + 8 * (ed + 3 + n0)))
+                                       t.d_contexts + int(sp.ev_ctx[e]) * I["ctx"], t.d_call_prm + c1_ * I["prm"],
+                                       d["call_pos"] + 2 * c1_ * I["pos"] if nc_ else 0))
+                op(OP_EVAL_DIST, n1, r0=1 if nc_ else 0,
+                   p=(ecands + (ed + 3 + n0) * 24, z_ed + 8 * (ed + 3 + n0)))
                 fetch(t.d_levels + 2 * int(s["level_first"]), t.h_levels + 2 * int(s["level_first"]),
                       2 * int(s["level_count"]))
                 if verify and s["kind"] == KIND_INTER:
@@ -1093,18 +1137,23 @@ class ChainedRun(SerialRun):
                 if verify and sl >= 0:
                     fetch(pred_jobs, self.z["mg_slots_out"][1] + 3 * sl * I["inter"], 3 * I["inter"])
                 return
-            op(OP_COPY, 3 + k, r0=PIC_ORIG, r1=PIC_S_ORIG, p=(t.d_copy_orig + int(s["copy_first"]) * I["copy"],))
+            nc_ = self.no_copies
+            if not nc_:
+                op(OP_COPY, 3 + k, r0=PIC_ORIG, r1=PIC_S_ORIG, p=(t.d_copy_orig + int(s["copy_first"]) * I["copy"],))
             sl = int(sp.ev_merge_slot[e]) if self.merge_fold else -1
             pred_jobs = d["mg_slots"] + 3 * sl * I["inter"] if sl >= 0 else \
                 d["ev_inter_work"] + 3 * e * I["inter"]
             op(OP_INTER_PRED, 3, r1=PIC_S_PRED, p=(pred_jobs, t.d_ev_dst + 3 * e * I["pos"]))
             if verify and sl >= 0:      # the slot's motion, to be held against the capture
                 fetch(pred_jobs, self.z["mg_slots_out"][1] + 3 * sl * I["inter"], 3 * I["inter"])
-            op(OP_COPY, k, r0=PIC_S_PRED, r1=PIC_S_PRED, p=(t.d_call_copy_pred + cf * I["copy"],))
+            if not nc_:
+                op(OP_COPY, k, r0=PIC_S_PRED, r1=PIC_S_PRED, p=(t.d_call_copy_pred + cf * I["copy"],))
             op(OP_RESIDUAL, k, p=(t.d_call_tx + cf * I["tx"], t.d_call_off + 4 * cf, z_nnz + 4 * cf,
-                                  t.d_contexts + int(sp.ev_ctx[e]) * I["ctx"], t.d_call_prm + cf * I["prm"]))
+                                  t.d_contexts + int(sp.ev_ctx[e]) * I["ctx"], t.d_call_prm + cf * I["prm"],
+                                  d["call_pos"] + 2 * cf * I["pos"] if nc_ else 0))
             # the three cbf-zero distortions and every alternative's, one launch
-            op(OP_EVAL_DIST, 3 + k, p=(d["ev_cands"] + ed * 24, z_ed + 8 * ed))
+            op(OP_EVAL_DIST, 3 + k, r0=1 if nc_ else 0,
+               p=((d["ev_cands"] if nc_ else d["ev_cands_copy"]) + ed * 24, z_ed + 8 * ed))
             fetch(t.d_levels + 2 * int(s["level_first"]), t.h_levels + 2 * int(s["level_first"]),
                   2 * int(s["level_count"]))
             if verify and s["kind"] == KIND_INTER:   # (an encoder reads the motion from `results`)
@@ -1133,10 +1182,14 @@ class ChainedRun(SerialRun):
             kind = int(s["kind"])
             if kind == KIND_MERGE_RANK:
                 m = int(s["merge"]) * 5
-                op(OP_COPY, 5, r0=PIC_ORIG, r1=PIC_S_ORIG, p=(t.d_mg_copy + m * I["copy"],))
+                if not self.no_copies:
+                    op(OP_COPY, 5, r0=PIC_ORIG, r1=PIC_S_ORIG, p=(t.d_mg_copy + m * I["copy"],))
                 op(OP_INTER_PRED, 5, r1=PIC_S_PRED, p=(t.d_mg_inter + m * I["inter"], t.d_mg_dst + m * I["pos"]))
-                op(OP_METRIC, 5, r0=PIC_S_ORIG, r1=PIC_S_PRED, i0=0, f=1.0,
-                   p=(t.d_mg_cands + m * I["cand"], self.z["mg_dist"][1] + 8 * m))
+                if self.no_copies:
+                    op(OP_EVAL_DIST, 5, r0=1, p=(d["mg_ecands"] + m * 24, self.z["mg_dist"][1] + 8 * m))
+                else:
+                    op(OP_METRIC, 5, r0=PIC_S_ORIG, r1=PIC_S_PRED, i0=0, f=1.0,
+                       p=(t.d_mg_cands + m * I["cand"], self.z["mg_dist"][1] + 8 * m))
                 if self.merge_fold:
                     op(OP_MERGE_FOLD, 1, i0=m // 5,
                        p=(d["mg_fold"], self.z["mg_dist"][1], t.d_mg_inter, self.z["mg_res"][1], d["mg_slots"]))
@@ -1166,7 +1219,7 @@ class ChainedRun(SerialRun):
         """Record the program (what an encoder emits as it walks its CU tree; here a
         Python loop over the state table - keep it out of a timed region)."""
         n = len(self.sp.states) - first if n is None else n
-        key = (first, n, by_position, verify, self.refs_form, live, self.merge_fold)
+        key = (first, n, by_position, verify, self.refs_form, live, self.merge_fold, self.no_copies)
         if getattr(self, "_prog_key", None) != key:
             self._prog = np.ascontiguousarray(self.program(first, n, by_position, verify, live=live))
             self._prog_key = key

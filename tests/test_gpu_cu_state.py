@@ -55,6 +55,7 @@ def _run_chained(api, ctx, name, poc, n_states, by_position, refs_form=True, liv
     sp = rd_serial.SerialPicture(api, name, poc)
     run = rd_serial.ChainedRun(api, ctx, sp, pics, w, h, rd_serial.ref_lists_of(name, poc))
     run.refs_form = refs_form
+    run.no_copies = refs_form      # (the older form keeps the block copies too)
     n = min(n_states, len(sp.states))
     stats = run.run_chained(0, n, by_position, live=live)
     res = run.check(0, n, searches=False)

@@ -119,8 +119,8 @@ TXE_KIND_NORMAL, TXE_KIND_TSKIP, TXE_KIND_SELECT = 0, 1, 2
 TXE_CBF_ZERO, TXE_FAST_SELECT, TXE_PREV_CBF = 1, 2, 4
 TXE_DIST_INVALID = 0xffffffffffffffff
 EVAL_CAND_DTYPE = np.dtype([("x", "<i2"), ("y", "<i2"), ("w", "u1"), ("h", "u1"), ("metric", "u1"),
-                            ("qp", "i1"), ("comp", "u1"), ("versus", "u1"), ("reserved", "u1", 6),
-                            ("weight", "<f8")])
+                            ("qp", "i1"), ("comp", "u1"), ("versus", "u1"), ("ox", "<i2"),
+                            ("oy", "<i2"), ("orig_at", "u1"), ("reserved", "u1"), ("weight", "<f8")])
 assert EVAL_CAND_DTYPE.itemsize == 24
 CAND_DTYPE = np.dtype([("x", "<i2"), ("y", "<i2"), ("w", "u1"), ("h", "u1"),
                        ("metric", "u1"), ("qp", "i1"), ("mv_x", "<i2"),
@@ -155,7 +155,7 @@ SYMBOLS = [
     "xvcgpu_create", "xvcgpu_destroy", "xvcgpu_last_error", "xvcgpu_version",
     "xvcgpu_set_stream", "xvcgpu_get_stream", "xvcgpu_use_own_stream", "xvcgpu_use_priority_stream", "xvcgpu_set_short_kernel_priority", "xvcgpu_wait_for", "xvcgpu_sync", "xvcgpu_timer_begin", "xvcgpu_timer_end", "xvcgpu_timer_mark", "xvcgpu_timer_between",
     "xvcgpu_record_begin", "xvcgpu_record_end", "xvcgpu_replay", "xvcgpu_recording_destroy",
-    "xvcgpu_malloc", "xvcgpu_free", "xvcgpu_memcpy_h2d", "xvcgpu_memcpy_d2h", "xvcgpu_memcpy_d2h_async", "xvcgpu_upload_ahead", "xvcgpu_eval_dist_batch", "xvcgpu_cs_start_fold", "xvcgpu_cs_uni_fold", "xvcgpu_cs_bi_fold", "xvcgpu_cs_merge_fold",
+    "xvcgpu_malloc", "xvcgpu_free", "xvcgpu_memcpy_h2d", "xvcgpu_memcpy_d2h", "xvcgpu_memcpy_d2h_async", "xvcgpu_upload_ahead", "xvcgpu_eval_dist_batch", "xvcgpu_cs_start_fold", "xvcgpu_cs_uni_fold", "xvcgpu_cs_bi_fold", "xvcgpu_cs_merge_fold", "xvcgpu_residual_rdoq_batch_at",
     "xvcgpu_memset", "xvcgpu_picture_create", "xvcgpu_picture_bytes",
     "xvcgpu_picture_wrap", "xvcgpu_picture_destroy", "xvcgpu_picture_upload",
     "xvcgpu_picture_download", "xvcgpu_picture_upload_padded",
@@ -325,6 +325,7 @@ def load_library():
         "xvcgpu_cs_uni_fold": [_vp, _vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp],
         "xvcgpu_cs_bi_fold": [_vp, _vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp],
         "xvcgpu_cs_merge_fold": [_vp, _vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp],
+        "xvcgpu_residual_rdoq_batch_at": [_vp, _vp, _vp, _vp, _vp, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp],
         "xvcgpu_intra_recon_waves": [_vp, _vp, _vp, _vp, _vp, _vp, C.c_int, _vp, _vp, _vp],
         "xvcgpu_bipred_search_lic": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, _vp, C.c_int],
         "xvcgpu_root_cbf_batch": [_vp, _vp, C.c_int, _vp],

@@ -551,7 +551,8 @@ eval_dist_kernel(PicView orig, PicView pred, PicView rec, int strength,
   if (c >= n) return;
   const xvcgpu_eval_cand cd = cands[c];
   const PlaneView pa = orig.c[cd.comp], pb = cd.versus ? rec.c[cd.comp] : pred.c[cd.comp];
-  const uint16_t *a = pa.p + (ptrdiff_t)cd.y * pa.stride + cd.x;
+  const uint16_t *a = cd.orig_at ? pa.p + (ptrdiff_t)cd.oy * pa.stride + cd.ox
+                                 : pa.p + (ptrdiff_t)cd.y * pa.stride + cd.x;
   const uint16_t *b = pb.p + (ptrdiff_t)cd.y * pb.stride + cd.x;
   const uint64_t dist = wave_compare(cd.metric, orig.bd, cd.qp, strength, cd.w, cd.h, a,
                                      pa.stride, b, pb.stride);

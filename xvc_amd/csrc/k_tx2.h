@@ -533,7 +533,11 @@ __global__ void __launch_bounds__(TX_THREADS)
 residual_cu_kernel(PicView orig, PicView pred, PicView rec, const xvcgpu_tx_block *blocks, int n,
                    int16_t *levels, const uint32_t *level_off, int32_t *nnz_out,
                    const int16_t *tx_tables, const int16_t *tx_tables_t, TxTableLayout lay,
-                   const xvcgpu_rdoq_contexts *rq_ctx, const xvcgpu_rdoq_params *rq_prm) {
+                   const xvcgpu_rdoq_contexts *rq_ctx, const xvcgpu_rdoq_params *rq_prm,
+                   const xvcgpu_block_pos *src_pos = nullptr) {
+  // src_pos (xvcgpu_residual_rdoq_batch_at): block i reads its original at src_pos[2 i]
+  // of `orig` and its prediction at src_pos[2 i + 1] of `pred` (positions in the plane of
+  // the block's component); the reconstruction goes to the block's own (x, y) of `rec`
   struct Big {
     TxShared s;
     RdoqShared<RDOQ ? 1024 : 4> rq;
@@ -549,18 +553,27 @@ residual_cu_kernel(PicView orig, PicView pred, PicView rec, const xvcgpu_tx_bloc
   // in place and nothing coded: the block is already what it will be
   if (MODE == TX_MODE_INV && pred.c[0].p == rec.c[0].p && nnz_out[idx] == 0) return;
   const xvcgpu_tx_block b = blocks[idx];
+  const PlaneView pp = pred.c[b.comp];
+  // the original as if it lay at the block's own position, the prediction by pointer
+  PicView orig_v = orig;
+  const uint16_t *pred_p = pp.p + (ptrdiff_t)b.y * pp.stride + b.x;
+  if (src_pos) {
+    const xvcgpu_block_pos so = src_pos[2 * idx], sp = src_pos[2 * idx + 1];
+    PlaneView &po = orig_v.c[b.comp];
+    po.p += (ptrdiff_t)(so.y - b.y) * po.stride + (so.x - b.x);
+    pred_p = pp.p + (ptrdiff_t)sp.y * pp.stride + sp.x;
+  }
   if (tx_small_job(b)) {
     if (threadIdx.x >= 64) return;
     Small &u = *reinterpret_cast<Small *>(raw);
-    const PlaneView pp = pred.c[b.comp];
-    tx2_job<MODE, 64, RDOQ>(u.s, b, idx, pred.bd, orig.c[b.comp],
-                            pp.p + (ptrdiff_t)b.y * pp.stride + b.x, pp.stride, rec.c[b.comp],
-                            levels, level_off, nnz_out, tx_tables, tx_tables_t, lay, nullptr, 0,
-                            &u.rq, rq_ctx, rq_prm, nullptr);
+    tx2_job<MODE, 64, RDOQ>(u.s, b, idx, pred.bd, orig_v.c[b.comp], pred_p, pp.stride,
+                            rec.c[b.comp], levels, level_off, nnz_out, tx_tables, tx_tables_t,
+                            lay, nullptr, 0, &u.rq, rq_ctx, rq_prm, nullptr);
   } else {
     Big &u = *reinterpret_cast<Big *>(raw);
-    residual_job<MODE, RDOQ ? 1024 : 4>(u.s, idx, orig, pred, rec, blocks, levels, level_off,
-                                        nnz_out, tx_tables, lay, &u.rq, rq_ctx, rq_prm, nullptr);
+    residual_job<MODE, RDOQ ? 1024 : 4>(u.s, idx, orig_v, pred, rec, blocks, levels, level_off,
+                                        nnz_out, tx_tables, lay, &u.rq, rq_ctx, rq_prm, nullptr,
+                                        src_pos ? pred_p : nullptr, pp.stride);
   }
 }
 

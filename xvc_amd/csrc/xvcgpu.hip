@@ -161,12 +161,14 @@ void launch_residual(xvcgpu_ctx *ctx, const PicView &o, const PicView &p,
 void launch_residual_rdoq(xvcgpu_ctx *ctx, const PicView &o, const PicView &p,
                           const PicView &r, const xvcgpu_tx_block *d_blocks, int n,
                           int16_t *d_levels, const uint32_t *d_off, int32_t *d_nnz,
-                          const xvcgpu_rdoq_contexts *d_ctx, const xvcgpu_rdoq_params *d_prm) {
+                          const xvcgpu_rdoq_contexts *d_ctx, const xvcgpu_rdoq_params *d_prm,
+                          const xvcgpu_block_pos *d_src_pos = nullptr) {
   // a CU state's evaluation: its few blocks as one launch, a workgroup each
   if (n <= 64) {
     hipLaunchKernelGGL((residual_cu_kernel<TX_MODE_FULL, true>), dim3(n), dim3(TX_THREADS), 0,
                        ctx->stream, o, p, r, d_blocks, n, d_levels, d_off, d_nnz,
-                       ctx->d_tx_tables, ctx->d_tx_tables_t, xvcgpu_tx_layout(), d_ctx, d_prm);
+                       ctx->d_tx_tables, ctx->d_tx_tables_t, xvcgpu_tx_layout(), d_ctx, d_prm,
+                       d_src_pos);
     return;
   }
   const int n_wg = (n + TX2_WAVES - 1) / TX2_WAVES;
@@ -1127,6 +1129,27 @@ xvcgpu_status xvcgpu_residual_batch(xvcgpu_ctx *ctx, const xvcgpu_picture *orig,
   launch_residual<TX_MODE_FULL>(ctx, orig->v, pred->v, rec->v, d_blocks, n, d_levels,
                                 d_level_offsets, d_nnz);
   CHECK_LAUNCH(ctx, "residual_batch");
+  return XVCGPU_OK;
+}
+
+xvcgpu_status xvcgpu_residual_rdoq_batch_at(xvcgpu_ctx *ctx, const xvcgpu_picture *orig,
+                                            const xvcgpu_picture *pred, xvcgpu_picture *rec,
+                                            const xvcgpu_tx_block *d_blocks, int n,
+                                            int16_t *d_levels, const uint32_t *d_level_offsets,
+                                            int32_t *d_nnz,
+                                            const xvcgpu_rdoq_contexts *d_contexts,
+                                            const xvcgpu_rdoq_params *d_params,
+                                            const xvcgpu_block_pos *d_src_pos) {
+  if (!ctx || !orig || !pred || !rec || n < 0 ||
+      (n && (!d_blocks || !d_contexts || !d_params || !d_src_pos)))
+    return XVCGPU_INVALID_ARGUMENT;
+  if (orig->bd != pred->bd || rec->bd != pred->bd || rec->w != pred->w || rec->h != pred->h)
+    return fail(ctx, XVCGPU_INVALID_ARGUMENT, "picture mismatch");
+  if (n > 64) return fail(ctx, XVCGPU_UNSUPPORTED, "residual_rdoq_batch_at: a CU state's blocks (<= 64)");
+  if (n == 0) return XVCGPU_OK;
+  launch_residual_rdoq(ctx, orig->v, pred->v, rec->v, d_blocks, n, d_levels, d_level_offsets,
+                       d_nnz, d_contexts, d_params, d_src_pos);
+  CHECK_LAUNCH(ctx, "residual_rdoq_batch_at");
   return XVCGPU_OK;
 }
 

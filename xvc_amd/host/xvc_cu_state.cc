@@ -273,6 +273,14 @@ xvcgpu_status IssueOp(xvcgpu_ctx *ctx, const xvc_cs_env *env, const xvc_cs_op &o
                                         static_cast<const xvcgpu_inter_block *>(p[0]),
                                         static_cast<const xvcgpu_block_pos *>(p[1]), o.n);
     case XVC_OP_RESIDUAL:
+      if (p[5])   // originals from the picture itself, the prediction from its one slot
+        return xvcgpu_residual_rdoq_batch_at(ctx, env->orig, env->s_pred, env->s_rec,
+                                             static_cast<const xvcgpu_tx_block *>(p[0]), o.n,
+                                             env->d_levels, static_cast<const uint32_t *>(p[1]),
+                                             static_cast<int32_t *>(p[2]),
+                                             static_cast<const xvcgpu_rdoq_contexts *>(p[3]),
+                                             static_cast<const xvcgpu_rdoq_params *>(p[4]),
+                                             static_cast<const xvcgpu_block_pos *>(p[5]));
       return xvcgpu_residual_rdoq_batch(ctx, env->s_orig, env->s_pred, env->s_rec,
                                         static_cast<const xvcgpu_tx_block *>(p[0]), o.n,
                                         env->d_levels, static_cast<const uint32_t *>(p[1]),
@@ -297,8 +305,9 @@ xvcgpu_status IssueOp(xvcgpu_ctx *ctx, const xvc_cs_env *env, const xvc_cs_op &o
                                static_cast<const xvcgpu_me_result *>(p[1]),
                                static_cast<const xvcgpu_affine_me_result *>(p[2]),
                                env->d_results, static_cast<xvcgpu_inter_block *>(p[3]));
-    case XVC_OP_EVAL_DIST:
-      return xvcgpu_eval_dist_batch(ctx, env->s_orig, env->s_pred, env->s_rec, 16,
+    case XVC_OP_EVAL_DIST:   // r0 = 1: the candidates name their original's place in env->orig
+      return xvcgpu_eval_dist_batch(ctx, o.r0 == 1 ? env->orig : env->s_orig, env->s_pred,
+                                    env->s_rec, 16,
                                     static_cast<const xvcgpu_eval_cand *>(p[0]), o.n,
                                     static_cast<uint64_t *>(p[1]));
     case XVC_OP_FETCH:
