@@ -506,7 +506,13 @@ xvcgpu_status xvcgpu_residual_rdoq_batch(xvcgpu_ctx *ctx, const xvcgpu_picture *
  * of a CU (CompressAndEvalTransform's default / transform-select / skip candidates)
  * each reconstruct into their own slot of a scratch picture from the one prediction
  * and the original picture itself, without the two block copies that put them side by
- * side.  orig may have another size than pred / rec. */
+ * side.  orig may have another size than pred / rec.
+ * d_eval_cands != NULL: the evaluation's distortions in the same launch
+ * (xvcgpu_eval_dist_batch's arithmetic, xvcgpu_eval_cand): candidates [0, n_eval_head)
+ * - the prediction against the original, the cbf-zero distortions - and candidate
+ * n_eval_head + i, priced by the workgroup that has just reconstructed block i;
+ * d_eval_out[c] for every candidate.  With it a CompressAndEvalCbf is two launches:
+ * the prediction, and this. */
 xvcgpu_status xvcgpu_residual_rdoq_batch_at(xvcgpu_ctx *ctx, const xvcgpu_picture *orig,
                                             const xvcgpu_picture *pred, xvcgpu_picture *rec,
                                             const xvcgpu_tx_block *d_blocks, int n,
@@ -514,7 +520,10 @@ xvcgpu_status xvcgpu_residual_rdoq_batch_at(xvcgpu_ctx *ctx, const xvcgpu_pictur
                                             int32_t *d_nnz,
                                             const xvcgpu_rdoq_contexts *d_contexts,
                                             const xvcgpu_rdoq_params *d_params,
-                                            const xvcgpu_block_pos *d_src_pos);
+                                            const xvcgpu_block_pos *d_src_pos,
+                                            int structural_strength,
+                                            const xvcgpu_eval_cand *d_eval_cands, int n_eval_head,
+                                            uint64_t *d_eval_out);
 
 
 /* Q2 alone: RdoQuant::QuantRdo on coefficients the caller holds (the output

@@ -606,7 +606,7 @@ RESULT_DTYPE = np.dtype([
     ("best_cost", "<u4"), ("out_mv", "<i4", (2, 3, 2)), ("out_mvd", "<i4", (2, 2, 2))], align=True)
 
 OP_DTYPE = np.dtype([("opcode", "<i4"), ("n", "<i4"), ("r0", "<i4"), ("r1", "<i4"), ("i0", "<i4"),
-                     ("reserved", "<i4"), ("f", "<f8"), ("p", "<u8", 6)], align=True)
+                     ("reserved", "<i4"), ("f", "<f8"), ("p", "<u8", 8)], align=True)
 (OP_MC_METRIC, OP_METRIC, OP_ME, OP_BI, OP_AFFINE, OP_COPY, OP_INTER_PRED, OP_RESIDUAL,
  OP_START_FOLD, OP_UNI_FOLD, OP_BI_FOLD, OP_FETCH, OP_SYNC, OP_EVAL_DIST, OP_MC_METRIC_REFS,
  OP_ME_REFS, OP_BI_REFS, OP_AFFINE_REFS, OP_MERGE_FOLD) = range(19)
@@ -855,6 +855,8 @@ class ChainedRun(SerialRun):
     no_copies = True      # originals read from the picture itself, an evaluation's alternatives
     #                       from its one prediction (xvcgpu_residual_rdoq_batch_at, the
     #                       candidates' orig_at): no block copies inside a chain
+    fused_eval = True     # an evaluation's distortions priced by the launch that reconstructs
+    #                       its alternatives (xvcgpu_residual_rdoq_batch_at's candidates)
     merge_fold = True     # the merge ranking folded on the device: a merge candidate's
     #                       evaluation predicts from the slot xvcgpu_cs_merge_fold filled
 
@@ -995,7 +997,7 @@ class ChainedRun(SerialRun):
                                         ("result", RESULT_DTYPE))}
 
         def op(code, n_=0, r0=0, r1=0, i0=0, f=0.0, p=()):
-            ops.append((code, n_, r0, r1, i0, 0, f, tuple(int(x) for x in p) + (0,) * (6 - len(p))))
+            ops.append((code, n_, r0, r1, i0, 0, f, tuple(int(x) for x in p) + (0,) * (8 - len(p))))
 
         pending = []                   # (device, host, bytes) read-backs of the open chain
 
@@ -1114,21 +1116,28 @@ class ChainedRun(SerialRun):
                 op(OP_INTER_PRED, 3, r1=PIC_S_PRED, p=(pred_jobs, t.d_ev_dst + 3 * e * I["pos"]))
                 if not nc_:
                     op(OP_COPY, n0, r0=PIC_S_PRED, r1=PIC_S_PRED, p=(t.d_call_copy_pred + cf * I["copy"],))
-                op(OP_RESIDUAL, n0, p=(t.d_call_tx + cf * I["tx"], t.d_call_off + 4 * cf, z_nnz + 4 * cf,
-                                       t.d_contexts + int(sp.ev_ctx[e]) * I["ctx"], t.d_call_prm + cf * I["prm"],
-                                       d["call_pos"] + 2 * cf * I["pos"] if nc_ else 0))
-                op(OP_EVAL_DIST, 3 + n0, r0=1 if nc_ else 0, p=(ecands + ed * 24, z_ed + 8 * ed))
+                fe_ = nc_ and self.fused_eval
+                op(OP_RESIDUAL, n0, r0=3 if fe_ else 0,
+                   p=(t.d_call_tx + cf * I["tx"], t.d_call_off + 4 * cf, z_nnz + 4 * cf,
+                      t.d_contexts + int(sp.ev_ctx[e]) * I["ctx"], t.d_call_prm + cf * I["prm"],
+                      d["call_pos"] + 2 * cf * I["pos"] if nc_ else 0) +
+                   ((ecands + ed * 24, z_ed + 8 * ed) if fe_ else ()))
+                if not fe_:
+                    op(OP_EVAL_DIST, 3 + n0, r0=1 if nc_ else 0, p=(ecands + ed * 24, z_ed + 8 * ed))
                 flush_fetches()
                 op(OP_SYNC, i0=0, r0=int(s["kind"]))
                 c1_ = cf + n0
                 if not nc_:
                     op(OP_COPY, n1, r0=PIC_ORIG, r1=PIC_S_ORIG, p=(t.d_copy_orig + (co + 3 + n0) * I["copy"],))
                     op(OP_COPY, n1, r0=PIC_S_PRED, r1=PIC_S_PRED, p=(t.d_call_copy_pred + c1_ * I["copy"],))
-                op(OP_RESIDUAL, n1, p=(t.d_call_tx + c1_ * I["tx"], t.d_call_off + 4 * c1_, z_nnz + 4 * c1_,
-                                       t.d_contexts + int(sp.ev_ctx[e]) * I["ctx"], t.d_call_prm + c1_ * I["prm"],
-                                       d["call_pos"] + 2 * c1_ * I["pos"] if nc_ else 0))
-                op(OP_EVAL_DIST, n1, r0=1 if nc_ else 0,
-                   p=(ecands + (ed + 3 + n0) * 24, z_ed + 8 * (ed + 3 + n0)))
+                op(OP_RESIDUAL, n1, r0=0,
+                   p=(t.d_call_tx + c1_ * I["tx"], t.d_call_off + 4 * c1_, z_nnz + 4 * c1_,
+                      t.d_contexts + int(sp.ev_ctx[e]) * I["ctx"], t.d_call_prm + c1_ * I["prm"],
+                      d["call_pos"] + 2 * c1_ * I["pos"] if nc_ else 0) +
+                   ((ecands + (ed + 3 + n0) * 24, z_ed + 8 * (ed + 3 + n0)) if fe_ else ()))
+                if not fe_:
+                    op(OP_EVAL_DIST, n1, r0=1 if nc_ else 0,
+                       p=(ecands + (ed + 3 + n0) * 24, z_ed + 8 * (ed + 3 + n0)))
                 fetch(t.d_levels + 2 * int(s["level_first"]), t.h_levels + 2 * int(s["level_first"]),
                       2 * int(s["level_count"]))
                 if verify and s["kind"] == KIND_INTER:
@@ -1148,12 +1157,20 @@ class ChainedRun(SerialRun):
                 fetch(pred_jobs, self.z["mg_slots_out"][1] + 3 * sl * I["inter"], 3 * I["inter"])
             if not nc_:
                 op(OP_COPY, k, r0=PIC_S_PRED, r1=PIC_S_PRED, p=(t.d_call_copy_pred + cf * I["copy"],))
-            op(OP_RESIDUAL, k, p=(t.d_call_tx + cf * I["tx"], t.d_call_off + 4 * cf, z_nnz + 4 * cf,
-                                  t.d_contexts + int(sp.ev_ctx[e]) * I["ctx"], t.d_call_prm + cf * I["prm"],
-                                  d["call_pos"] + 2 * cf * I["pos"] if nc_ else 0))
-            # the three cbf-zero distortions and every alternative's, one launch
-            op(OP_EVAL_DIST, 3 + k, r0=1 if nc_ else 0,
-               p=((d["ev_cands"] if nc_ else d["ev_cands_copy"]) + ed * 24, z_ed + 8 * ed))
+            if nc_ and self.fused_eval:
+                # the alternatives' reconstruction and all of the evaluation's distortions
+                # (three cbf-zero ones in front) in ONE launch
+                op(OP_RESIDUAL, k, r0=3,
+                   p=(t.d_call_tx + cf * I["tx"], t.d_call_off + 4 * cf, z_nnz + 4 * cf,
+                      t.d_contexts + int(sp.ev_ctx[e]) * I["ctx"], t.d_call_prm + cf * I["prm"],
+                      d["call_pos"] + 2 * cf * I["pos"], d["ev_cands"] + ed * 24, z_ed + 8 * ed))
+            else:
+                op(OP_RESIDUAL, k, p=(t.d_call_tx + cf * I["tx"], t.d_call_off + 4 * cf, z_nnz + 4 * cf,
+                                      t.d_contexts + int(sp.ev_ctx[e]) * I["ctx"], t.d_call_prm + cf * I["prm"],
+                                      d["call_pos"] + 2 * cf * I["pos"] if nc_ else 0))
+                # the three cbf-zero distortions and every alternative's, one launch
+                op(OP_EVAL_DIST, 3 + k, r0=1 if nc_ else 0,
+                   p=((d["ev_cands"] if nc_ else d["ev_cands_copy"]) + ed * 24, z_ed + 8 * ed))
             fetch(t.d_levels + 2 * int(s["level_first"]), t.h_levels + 2 * int(s["level_first"]),
                   2 * int(s["level_count"]))
             if verify and s["kind"] == KIND_INTER:   # (an encoder reads the motion from `results`)
@@ -1219,7 +1236,8 @@ class ChainedRun(SerialRun):
         """Record the program (what an encoder emits as it walks its CU tree; here a
         Python loop over the state table - keep it out of a timed region)."""
         n = len(self.sp.states) - first if n is None else n
-        key = (first, n, by_position, verify, self.refs_form, live, self.merge_fold, self.no_copies)
+        key = (first, n, by_position, verify, self.refs_form, live, self.merge_fold, self.no_copies,
+               self.fused_eval)
         if getattr(self, "_prog_key", None) != key:
             self._prog = np.ascontiguousarray(self.program(first, n, by_position, verify, live=live))
             self._prog_key = key

@@ -325,7 +325,8 @@ def load_library():
         "xvcgpu_cs_uni_fold": [_vp, _vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp],
         "xvcgpu_cs_bi_fold": [_vp, _vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp],
         "xvcgpu_cs_merge_fold": [_vp, _vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp],
-        "xvcgpu_residual_rdoq_batch_at": [_vp, _vp, _vp, _vp, _vp, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp],
+        "xvcgpu_residual_rdoq_batch_at": [_vp, _vp, _vp, _vp, _vp, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp,
+                                          C.c_int, _vp, C.c_int, _vp],
         "xvcgpu_intra_recon_waves": [_vp, _vp, _vp, _vp, _vp, _vp, C.c_int, _vp, _vp, _vp],
         "xvcgpu_bipred_search_lic": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, _vp, C.c_int],
         "xvcgpu_root_cbf_batch": [_vp, _vp, C.c_int, _vp],

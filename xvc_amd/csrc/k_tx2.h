@@ -534,10 +534,15 @@ residual_cu_kernel(PicView orig, PicView pred, PicView rec, const xvcgpu_tx_bloc
                    int16_t *levels, const uint32_t *level_off, int32_t *nnz_out,
                    const int16_t *tx_tables, const int16_t *tx_tables_t, TxTableLayout lay,
                    const xvcgpu_rdoq_contexts *rq_ctx, const xvcgpu_rdoq_params *rq_prm,
-                   const xvcgpu_block_pos *src_pos = nullptr) {
+                   const xvcgpu_block_pos *src_pos = nullptr,
+                   const xvcgpu_eval_cand *ecands = nullptr, int n_head = 0,
+                   uint64_t *eout = nullptr, int strength = 0) {
   // src_pos (xvcgpu_residual_rdoq_batch_at): block i reads its original at src_pos[2 i]
   // of `orig` and its prediction at src_pos[2 i + 1] of `pred` (positions in the plane of
-  // the block's component); the reconstruction goes to the block's own (x, y) of `rec`
+  // the block's component); the reconstruction goes to the block's own (x, y) of `rec`.
+  // ecands: the evaluation's distortions in the same launch (xvcgpu_eval_dist_batch's
+  // arithmetic): candidates [0, n_head) - prediction against original - by workgroups
+  // n .. n + n_head - 1, candidate n_head + i by the workgroup that reconstructed block i.
   struct Big {
     TxShared s;
     RdoqShared<RDOQ ? 1024 : 4> rq;
@@ -549,7 +554,20 @@ residual_cu_kernel(PicView orig, PicView pred, PicView rec, const xvcgpu_tx_bloc
   constexpr size_t kBytes = sizeof(Big) > sizeof(Small) ? sizeof(Big) : sizeof(Small);
   __shared__ __attribute__((aligned(16))) unsigned char raw[kBytes];
   const int idx = blockIdx.x;
-  if (idx >= n) return;
+  auto price = [&](int c) {   // (one wave)
+    const xvcgpu_eval_cand cd = ecands[c];
+    const PlaneView pa = orig.c[cd.comp], pb = cd.versus ? rec.c[cd.comp] : pred.c[cd.comp];
+    const uint16_t *a = cd.orig_at ? pa.p + (ptrdiff_t)cd.oy * pa.stride + cd.ox
+                                   : pa.p + (ptrdiff_t)cd.y * pa.stride + cd.x;
+    const uint16_t *bq = pb.p + (ptrdiff_t)cd.y * pb.stride + cd.x;
+    const uint64_t dist = wave_compare(cd.metric, orig.bd, cd.qp, strength, cd.w, cd.h, a,
+                                       pa.stride, bq, pb.stride);
+    if ((threadIdx.x & 63) == 0) eout[c] = (uint64_t)((double)dist * cd.weight);
+  };
+  if (idx >= n) {
+    if (ecands && idx - n < n_head && threadIdx.x < 64) price(idx - n);
+    return;
+  }
   // in place and nothing coded: the block is already what it will be
   if (MODE == TX_MODE_INV && pred.c[0].p == rec.c[0].p && nnz_out[idx] == 0) return;
   const xvcgpu_tx_block b = blocks[idx];
@@ -574,6 +592,15 @@ residual_cu_kernel(PicView orig, PicView pred, PicView rec, const xvcgpu_tx_bloc
     residual_job<MODE, RDOQ ? 1024 : 4>(u.s, idx, orig_v, pred, rec, blocks, levels, level_off,
                                         nnz_out, tx_tables, lay, &u.rq, rq_ctx, rq_prm, nullptr,
                                         src_pos ? pred_p : nullptr, pp.stride);
+  }
+  if (ecands) {
+    // the block's reconstruction was written by this workgroup: visible to its first
+    // wave behind a workgroup-scope release / acquire around the barrier (the waves that
+    // left early are not waited for)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    if (threadIdx.x < 64) price(n_head + idx);
   }
 }
 

@@ -162,13 +162,16 @@ void launch_residual_rdoq(xvcgpu_ctx *ctx, const PicView &o, const PicView &p,
                           const PicView &r, const xvcgpu_tx_block *d_blocks, int n,
                           int16_t *d_levels, const uint32_t *d_off, int32_t *d_nnz,
                           const xvcgpu_rdoq_contexts *d_ctx, const xvcgpu_rdoq_params *d_prm,
-                          const xvcgpu_block_pos *d_src_pos = nullptr) {
+                          const xvcgpu_block_pos *d_src_pos = nullptr,
+                          const xvcgpu_eval_cand *d_ecands = nullptr, int n_head = 0,
+                          uint64_t *d_eout = nullptr, int strength = 0) {
   // a CU state's evaluation: its few blocks as one launch, a workgroup each
   if (n <= 64) {
-    hipLaunchKernelGGL((residual_cu_kernel<TX_MODE_FULL, true>), dim3(n), dim3(TX_THREADS), 0,
+    hipLaunchKernelGGL((residual_cu_kernel<TX_MODE_FULL, true>), dim3(n + (d_ecands ? n_head : 0)),
+                       dim3(TX_THREADS), 0,
                        ctx->stream, o, p, r, d_blocks, n, d_levels, d_off, d_nnz,
                        ctx->d_tx_tables, ctx->d_tx_tables_t, xvcgpu_tx_layout(), d_ctx, d_prm,
-                       d_src_pos);
+                       d_src_pos, d_ecands, n_head, d_eout, strength);
     return;
   }
   const int n_wg = (n + TX2_WAVES - 1) / TX2_WAVES;
@@ -1139,16 +1142,21 @@ xvcgpu_status xvcgpu_residual_rdoq_batch_at(xvcgpu_ctx *ctx, const xvcgpu_pictur
                                             int32_t *d_nnz,
                                             const xvcgpu_rdoq_contexts *d_contexts,
                                             const xvcgpu_rdoq_params *d_params,
-                                            const xvcgpu_block_pos *d_src_pos) {
-  if (!ctx || !orig || !pred || !rec || n < 0 ||
-      (n && (!d_blocks || !d_contexts || !d_params || !d_src_pos)))
+                                            const xvcgpu_block_pos *d_src_pos,
+                                            int structural_strength,
+                                            const xvcgpu_eval_cand *d_eval_cands, int n_eval_head,
+                                            uint64_t *d_eval_out) {
+  if (!ctx || !orig || !pred || !rec || n < 0 || n_eval_head < 0 || n_eval_head > 64 ||
+      (n && (!d_blocks || !d_contexts || !d_params || !d_src_pos)) ||
+      ((d_eval_cands != nullptr) != (d_eval_out != nullptr)))
     return XVCGPU_INVALID_ARGUMENT;
   if (orig->bd != pred->bd || rec->bd != pred->bd || rec->w != pred->w || rec->h != pred->h)
     return fail(ctx, XVCGPU_INVALID_ARGUMENT, "picture mismatch");
   if (n > 64) return fail(ctx, XVCGPU_UNSUPPORTED, "residual_rdoq_batch_at: a CU state's blocks (<= 64)");
   if (n == 0) return XVCGPU_OK;
   launch_residual_rdoq(ctx, orig->v, pred->v, rec->v, d_blocks, n, d_levels, d_level_offsets,
-                       d_nnz, d_contexts, d_params, d_src_pos);
+                       d_nnz, d_contexts, d_params, d_src_pos, d_eval_cands, n_eval_head,
+                       d_eval_out, structural_strength);
   CHECK_LAUNCH(ctx, "residual_rdoq_batch_at");
   return XVCGPU_OK;
 }

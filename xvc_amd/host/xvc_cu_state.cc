@@ -280,7 +280,12 @@ xvcgpu_status IssueOp(xvcgpu_ctx *ctx, const xvc_cs_env *env, const xvc_cs_op &o
                                              static_cast<int32_t *>(p[2]),
                                              static_cast<const xvcgpu_rdoq_contexts *>(p[3]),
                                              static_cast<const xvcgpu_rdoq_params *>(p[4]),
-                                             static_cast<const xvcgpu_block_pos *>(p[5]));
+                                             static_cast<const xvcgpu_block_pos *>(p[5]), 16,
+                                             // p[6] / p[7]: the evaluation's candidates and their
+                                             // distortions, priced by the same launch (r0 = the
+                                             // prediction-against-original candidates in front)
+                                             static_cast<const xvcgpu_eval_cand *>(p[6]), o.r0,
+                                             static_cast<uint64_t *>(p[7]));
       return xvcgpu_residual_rdoq_batch(ctx, env->s_orig, env->s_pred, env->s_rec,
                                         static_cast<const xvcgpu_tx_block *>(p[0]), o.n,
                                         env->d_levels, static_cast<const uint32_t *>(p[1]),

@@ -127,7 +127,7 @@ enum {
 typedef struct xvc_cs_op {
   int32_t opcode, n, r0, r1, i0, reserved;
   double f;
-  uint64_t p[6];
+  uint64_t p[8];
 } xvc_cs_op;
 typedef struct xvc_cs_env {
   const xvcgpu_picture *orig;
