@@ -397,11 +397,11 @@ def encoder_rd_serial_figure(ctx, api, fx, pics, w, h, n_states=4000):
                  "compared": l1.get("compared")},
         "compared": s1.get("compared"),
         "matches_reference": bool(ok),
-        "reading": "both forms are bound by the chain of dependent kernels per state (each "
-                   "search is one CU's worth of work: 4-30 us, RDOQ's and the refinement's wave "
-                   "lives the longest): read-backs removed, the steps of the pictures of a list "
-                   "side by side and half the launches take a state from ~130 us to ~70 us; more "
-                   "than four chains in flight do not add up (tools/cu_state_walk.py --threads)"}
+        "reading": "every form is bound by the chain of dependent kernels per state (each search is "
+                   "one CU's worth of work: 4-30 us on a few CUs); what the forms differ in is how "
+                   "often the host waits (round_trips_per_state) and how many launches a state takes "
+                   "(entry_point_calls_per_state); more than four chains in flight do not add up "
+                   "(tools/cu_state_walk.py --k 1,4,8,16: the launch path, not the device, is full)"}
 
 
 def encoder_rd_figure(ctx, api, fx, pics, w, h):

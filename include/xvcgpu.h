@@ -609,10 +609,22 @@ xvcgpu_status xvcgpu_quant_rdo_reserve(xvcgpu_ctx *ctx, int n, size_t n_coeffs);
 xvcgpu_status xvcgpu_quant_rdo_set_prove_zero(xvcgpu_ctx *ctx, int mode);
 
 /* Diagnostics: the number of blocks of the last xvcgpu_quant_rdo_batch that
- * needed the walk, by lane class (out[0]: up to 8x8, out[1]: up to 16x16,
- * out[2]: larger); blocks whose coefficients all quantise to zero are settled
- * by the classification pass and not counted.  Synchronises the stream. */
+ * needed the walk, by class (out[0]: diagonal scan, up to four 4x4 sub-blocks;
+ * out[1]: diagonal scan, up to sixteen, sides up to 32 - both walked with four
+ * lanes per sub-block; out[2]: everything else - more sub-blocks, 64-point sides,
+ * the horizontal / vertical scans, 2-wide blocks); blocks whose coefficients all
+ * quantise to zero are settled by the classification pass and not counted.
+ * Synchronises the stream. */
 xvcgpu_status xvcgpu_quant_rdo_class_counts(xvcgpu_ctx *ctx, int32_t out[3]);
+/* The walk is two launches: the four-lane classes (out[0], out[1] above) and the
+ * general class (out[2]), whose waves hold 255 vector registers - even with an empty
+ * list that launch waits for room beside other streams' kernels (190 us in flight
+ * per 2160p picture with three picture chains).  A caller whose batches only hold
+ * diagonal-scan blocks with 4x4 sub-blocks, sides up to 32 and at most sixteen
+ * sub-blocks (a frame pass of CUs up to 16x16, say) sets on = 1 and the general
+ * launch is not made.  A block outside that promise is not quantised; the next
+ * xvcgpu_sync reports it as XVCGPU_INVALID_ARGUMENT (xvcgpu_last_error says why). */
+xvcgpu_status xvcgpu_quant_rdo_set_four_lane_only(xvcgpu_ctx *ctx, int on);
 
 /* I1 + the above fused, for the uni-pred inter CUs of a motion search batch
  * (InterSearch::CompressAndEvalCbf without the RD bookkeeping,

@@ -525,6 +525,11 @@ typedef struct xvcgpu_frame_pass_args {
    * over all rows then writes the unfiltered reconstruction here and ends with
    * ONE launch, xvcgpu_deblock_pad_ssd(scratch_rec -> rec), instead of five */
   struct xvcgpu_picture *scratch_rec;
+  /* RDOQ, throughput form: the caller's word that d_tx holds no block of the quantiser's
+   * general class (xvcgpu_quant_rdo_set_four_lane_only, for this call's batch): pictures
+   * of CUs 8x8 .. 16x16 coded with the diagonal scan, say */
+  int32_t tx_four_lane_only;
+  int32_t reserved2;
 } xvcgpu_frame_pass_args;
 
 /* One job of xvcgpu_affine_me_batch: InterSearch::MotionEstAffine for one

@@ -65,7 +65,7 @@ def test_struct_layouts_match_header(api):
     assert [int(v) for v in out] == [84, 32, 24, 12, 16, 12, 20, 24, 48, 24, 40, 12, 10, 24, 20,
                                        api.AFFINE_ME_DTYPE.itemsize, 60, api.AFFINE_ME_RESULT_DTYPE.itemsize,
                                        api.SEG_DTYPE.itemsize, C.sizeof(api.FramePassArgs)]
-    assert C.sizeof(api.FramePassArgs) == 224
+    assert C.sizeof(api.FramePassArgs) == 232
     assert api.AFFINE_ME_DTYPE.itemsize == 84 and api.AFFINE_ME_RESULT_DTYPE.itemsize == 32
 
 

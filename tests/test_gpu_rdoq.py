@@ -206,3 +206,37 @@ def test_gpu_all_zero_proof_random_blocks(gpu):
                     levels[off[k]:off[k] + w * h].reshape(h, w), e_lv), (bd, mode, k, blocks[k])
         ctx.set_rdoq_prove_zero(-1)
         assert listed[1] < listed[0], listed
+
+
+def test_four_lane_only_promise_is_checked(gpu):
+    """xvcgpu_quant_rdo_set_four_lane_only leaves the general class's launch out; a block of
+    that class in such a batch is reported by the next xvcgpu_sync instead of being dropped
+    silently, and the same batch without the promise is quantised."""
+    api, ctx = gpu
+    rng = np.random.default_rng(5)
+    bd, qp = 10, 30
+    from xvc_amd import pipeline
+    ctxs = pipeline.rdoq_init_contexts(qp, 1)
+    lam, rdf = pipeline.rdoq_host_params(qp, bd)[0]
+    shapes = [(16, 16), (8, 8), (64, 64)]          # the last one: general class
+    blocks = np.zeros(len(shapes), api.TX_DTYPE)
+    for i, (w, h) in enumerate(shapes):
+        blocks[i]["w"], blocks[i]["h"], blocks[i]["qp"], blocks[i]["intra_pic"] = w, h, qp, api.TXF_RDOQ
+    prm = np.zeros(len(shapes), api.RDOQ_PARAMS_DTYPE)
+    prm["lambda"], prm["rd_factor"] = lam, rdf
+    cf = [np.clip(np.rint(rng.laplace(0, 1, (h, w)) * 300), -32768, 32767).astype(np.int16).reshape(-1)
+          for w, h in shapes]
+    off = np.r_[0, np.cumsum([len(c) for c in cf])[:-1]].astype(np.uint32)
+    want_lv, want_nnz = ctx.quant_rdo_batch(bd, blocks, np.concatenate(cf), off, ctxs, prm)
+    assert (want_nnz > 0).all()
+    ctx.set_rdoq_four_lane_only(True)
+    try:
+        with pytest.raises(api.XvcGpuError):
+            ctx.quant_rdo_batch(bd, blocks, np.concatenate(cf), off, ctxs, prm)
+        # the promise kept: the two four-lane blocks alone
+        lv, nnz = ctx.quant_rdo_batch(bd, blocks[:2], np.concatenate(cf[:2]), off[:2], ctxs, prm[:2])
+        assert np.array_equal(nnz, want_nnz[:2]) and np.array_equal(lv, want_lv[:len(lv)])
+    finally:
+        ctx.set_rdoq_four_lane_only(False)
+    lv, nnz = ctx.quant_rdo_batch(bd, blocks, np.concatenate(cf), off, ctxs, prm)
+    assert np.array_equal(nnz, want_nnz) and np.array_equal(lv, want_lv)

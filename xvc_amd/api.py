@@ -145,7 +145,7 @@ class FramePassArgs(C.Structure):
                 ("pred", C.c_void_p), ("d_tx", C.c_void_p), ("d_level_off", C.c_void_p),
                 ("d_luma_tx_index", C.c_void_p), ("d_coeffs", C.c_void_p),
                 ("d_levels", C.c_void_p), ("n_tx", C.c_int32), ("n_coeffs", C.c_uint32),
-                ("scratch_rec", C.c_void_p)]
+                ("scratch_rec", C.c_void_p), ("tx_four_lane_only", C.c_int32), ("reserved2", C.c_int32)]
 
 
 FP_ENCODE, FP_DEBLOCK_V, FP_DEBLOCK_H, FP_PAD, FP_SSD = 1, 2, 4, 8, 16
@@ -155,7 +155,7 @@ SYMBOLS = [
     "xvcgpu_create", "xvcgpu_destroy", "xvcgpu_last_error", "xvcgpu_version",
     "xvcgpu_set_stream", "xvcgpu_get_stream", "xvcgpu_use_own_stream", "xvcgpu_use_priority_stream", "xvcgpu_set_short_kernel_priority", "xvcgpu_wait_for", "xvcgpu_sync", "xvcgpu_timer_begin", "xvcgpu_timer_end", "xvcgpu_timer_mark", "xvcgpu_timer_between",
     "xvcgpu_record_begin", "xvcgpu_record_end", "xvcgpu_replay", "xvcgpu_recording_destroy",
-    "xvcgpu_malloc", "xvcgpu_free", "xvcgpu_memcpy_h2d", "xvcgpu_memcpy_d2h", "xvcgpu_memcpy_d2h_async", "xvcgpu_upload_ahead", "xvcgpu_eval_dist_batch", "xvcgpu_cs_start_fold", "xvcgpu_cs_uni_fold", "xvcgpu_cs_bi_fold", "xvcgpu_cs_merge_fold", "xvcgpu_residual_rdoq_batch_at",
+    "xvcgpu_malloc", "xvcgpu_free", "xvcgpu_memcpy_h2d", "xvcgpu_memcpy_d2h", "xvcgpu_memcpy_d2h_async", "xvcgpu_upload_ahead", "xvcgpu_eval_dist_batch", "xvcgpu_cs_start_fold", "xvcgpu_cs_uni_fold", "xvcgpu_cs_bi_fold", "xvcgpu_cs_merge_fold", "xvcgpu_residual_rdoq_batch_at", "xvcgpu_quant_rdo_set_four_lane_only",
     "xvcgpu_memset", "xvcgpu_picture_create", "xvcgpu_picture_bytes",
     "xvcgpu_picture_wrap", "xvcgpu_picture_destroy", "xvcgpu_picture_upload",
     "xvcgpu_picture_download", "xvcgpu_picture_upload_padded",
@@ -311,6 +311,7 @@ def load_library():
         "xvcgpu_quant_rdo_reserve": [_vp, C.c_int, C.c_size_t],
         "xvcgpu_quant_rdo_class_counts": [_vp, _vp],
         "xvcgpu_quant_rdo_set_prove_zero": [_vp, C.c_int],
+        "xvcgpu_quant_rdo_set_four_lane_only": [_vp, C.c_int],
         "xvcgpu_tx_eval_batch": [_vp, _vp, C.c_int, _vp, _vp],
         "xvcgpu_inter_pred_batch_to": [_vp, _vp, C.c_int, _vp, _vp, _vp, _vp, C.c_int],
         "xvcgpu_copy_blocks": [_vp, _vp, _vp, _vp, C.c_int],
@@ -652,6 +653,10 @@ class Context:
         f.restype, f.argtypes = C.c_void_p, [_vp]
         return f(self.h) or 0
 
+    def set_rdoq_four_lane_only(self, on):
+        """xvcgpu_quant_rdo_set_four_lane_only: the batches hold no block of the general class."""
+        self._check(self.lib.xvcgpu_quant_rdo_set_four_lane_only(self.h, 1 if on else 0))
+
     def set_rdoq_prove_zero(self, mode):
         """The all-zero proof ahead of the RDO quantiser's walk: 0 never, 1 always,
         -1 by batch size (xvcgpu_quant_rdo_set_prove_zero; same results either way)."""
@@ -910,10 +915,13 @@ class Context:
         self._check(self.lib.xvcgpu_quant_rdo_batch(
             self.h, bitdepth, db.ptr, len(blocks), dcf.ptr, dof.ptr, len(coeffs), dl.ptr,
             dn.ptr, dc.ptr, dp.ptr))
-        levels = dl.to_array(np.int16, len(coeffs))
-        nnz = dn.to_array(np.int32, len(blocks))
-        for b in (db, dof, dcf, dl, dn, dc, dp):
-            b.free()
+        try:
+            self.sync()      # (reports a broken xvcgpu_quant_rdo_set_four_lane_only promise)
+            levels = dl.to_array(np.int16, len(coeffs))
+            nnz = dn.to_array(np.int32, len(blocks))
+        finally:
+            for b in (db, dof, dcf, dl, dn, dc, dp):
+                b.free()
         return levels, nnz
 
     def fwd_transform_batch(self, orig, pred, blocks):

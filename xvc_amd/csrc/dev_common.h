@@ -32,7 +32,7 @@ __device__ __forceinline__ T group_sum(T v) {
 // Arguments of one kernel for up to XVC_MULTI_MAX pictures, passed by value: a
 // "multi" kernel is the single-picture kernel's body run with the arguments of
 // picture blockIdx.y (xvcgpu_frame_pass_multi: kernels of the same kind run well
-// beside each other, kernels of different kinds do not - DESIGN.md section 6b).
+// beside each other, kernels of different kinds do not - profiles/ARCHIVE_r01_r04_design_measured.md section 6b).
 #define XVC_MULTI_MAX 4
 template <typename A>
 struct MultiArgs {

@@ -2086,16 +2086,35 @@ __device__ __forceinline__ void quant_rdo_packed_wave(
 // the churn of workgroups retiring after a look at the count: each class gets a bounded
 // number of workgroups instead, which walk their list with that stride.
 // grid: g16 + g4 (packed4) / g64 (general); block: 64.
+#ifndef RDOQ4_LATENCY_BLOCKS
+#define RDOQ4_LATENCY_BLOCKS 4096   // a block per wave up to this many blocks of the class
+#endif
 __device__ __forceinline__ void quant_rdo_packed4_kernel_body(int bd, const xvcgpu_tx_block *blocks, RdoqLists l, int g16, const int16_t *coeffs, const uint32_t *d_off, int16_t *levels, int32_t *nnz_out, const xvcgpu_rdoq_contexts *rq_ctx, const xvcgpu_rdoq_params *rq_prm, xvcgpu_cu_info *cu_patch) {
   union Lds {
     RdoqPackedLds<64, 16> a;
     RdoqPackedLds<16, 4> b;
+    RdoqPackedLds<16, 16> t;
   };
   __shared__ Lds sm;
   const int wg = blockIdx.x, g4 = (int)gridDim.x - g16;
   if (wg < g16) {
-    const int waves = l.count[1];
-    for (int wv = wg; wv < waves; wv += g16) {
+    const int n1 = l.count[1];
+    if (n1 > RDOQ4_LATENCY_BLOCKS) {
+      // More blocks than the chip has wave slots: waves queue behind each other whatever
+      // their shape, and what the launch costs - alone and beside the other pictures'
+      // kernels - is its total instruction count.  A block per wave spends about twice
+      // the wave instructions per block of the lane-per-sub-block walk with four blocks
+      // side by side (2160p QP 27, 25 000 blocks, three chains: 1290 against 1550 frame
+      // passes/s): the long lists take that walk.
+      const int waves = (n1 + 3) >> 2;
+      for (int wv = wg; wv < waves; wv += g16) {
+        quant_rdo_packed_wave<16, 16, false>(sm.t, wv, bd, blocks, l.list[1], l.count + 1, coeffs,
+                                             d_off, levels, nnz_out, rq_ctx, rq_prm, cu_patch);
+        wave_sync();
+      }
+      return;
+    }
+    for (int wv = wg; wv < n1; wv += g16) {
       quant_rdo_packed_wave<64, 16, true>(sm.a, wv, bd, blocks, l.list[1], l.count + 1, coeffs,
                                           d_off, levels, nnz_out, rq_ctx, rq_prm, cu_patch);
       wave_sync();
@@ -2124,7 +2143,10 @@ __device__ __forceinline__ void quant_rdo_packed_kernel_body(int bd, const xvcgp
 #define RDOQ4_MIN_WAVES 3   // per SIMD: 168 vector registers (the walk holds 156 - 167)
 #endif
 __global__ void __launch_bounds__(64, RDOQ4_MIN_WAVES)
-quant_rdo_packed4_kernel(int bd, const xvcgpu_tx_block *blocks, RdoqLists l, int g16, const int16_t *coeffs, const uint32_t *d_off, int16_t *levels, int32_t *nnz_out, const xvcgpu_rdoq_contexts *rq_ctx, const xvcgpu_rdoq_params *rq_prm, xvcgpu_cu_info *cu_patch = nullptr) {
+quant_rdo_packed4_kernel(int bd, const xvcgpu_tx_block *blocks, RdoqLists l, int g16, const int16_t *coeffs, const uint32_t *d_off, int16_t *levels, int32_t *nnz_out, const xvcgpu_rdoq_contexts *rq_ctx, const xvcgpu_rdoq_params *rq_prm, xvcgpu_cu_info *cu_patch = nullptr, int *misuse = nullptr) {
+  // misuse: the general class's launch was left out on the caller's word
+  // (xvcgpu_quant_rdo_set_four_lane_only); a block on its list is reported, not dropped
+  if (misuse && blockIdx.x == 0 && threadIdx.x == 0 && l.count[2] != 0) *misuse = 1;
   quant_rdo_packed4_kernel_body(bd, blocks, l, g16, coeffs, d_off, levels, nnz_out, rq_ctx, rq_prm, cu_patch);
 }
 

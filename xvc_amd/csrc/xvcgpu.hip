@@ -232,6 +232,8 @@ xvcgpu_status xvcgpu_create(int device, xvcgpu_ctx **out) {
   ctx->d_intra_done = nullptr;
   ctx->intra_done_cap = 0;
   ctx->intra_waves_grid = 0;
+  ctx->rdoq_four_lane_only = 0;
+  ctx->h_rdoq_misuse = nullptr;
   {
     ctx->rdoq_qp_hint = -1;
     ctx->rdoq_classified_proved = false;
@@ -303,6 +305,7 @@ void xvcgpu_destroy(xvcgpu_ctx *ctx) {
   if (ctx->d_tail_part) hipFree(ctx->d_tail_part);
   if (ctx->d_stats) hipFree(ctx->d_stats);
   if (ctx->d_rdoq_lists) hipFree(ctx->d_rdoq_lists);
+  if (ctx->h_rdoq_misuse) hipHostFree(ctx->h_rdoq_misuse);
   if (ctx->d_crc_tables) hipFree(ctx->d_crc_tables);
   if (ctx->d_intra_done) hipFree(ctx->d_intra_done);
   if (ctx->d_me_rot) hipFree(ctx->d_me_rot);
@@ -396,6 +399,12 @@ xvcgpu_status xvcgpu_wait_for(xvcgpu_ctx *ctx, xvcgpu_ctx *other) {
 xvcgpu_status xvcgpu_sync(xvcgpu_ctx *ctx) {
   if (!ctx) return XVCGPU_INVALID_ARGUMENT;
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  if (ctx->h_rdoq_misuse && *ctx->h_rdoq_misuse) {
+    *ctx->h_rdoq_misuse = 0;
+    return fail(ctx, XVCGPU_INVALID_ARGUMENT,
+                "quant_rdo: a block outside the four-lane classes in a batch declared "
+                "xvcgpu_quant_rdo_set_four_lane_only (its levels were not computed)");
+  }
   return XVCGPU_OK;
 }
 
@@ -1228,6 +1237,19 @@ xvcgpu_status xvcgpu_quant_rdo_set_prove_zero(xvcgpu_ctx *ctx, int mode) {
   return XVCGPU_OK;
 }
 
+xvcgpu_status xvcgpu_quant_rdo_set_four_lane_only(xvcgpu_ctx *ctx, int on) {
+  if (!ctx) return XVCGPU_INVALID_ARGUMENT;
+  if (on && !ctx->h_rdoq_misuse) {
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (hipHostMalloc(reinterpret_cast<void **>(&ctx->h_rdoq_misuse), sizeof(int),
+                      hipHostMallocMapped) != hipSuccess)
+      return fail(ctx, XVCGPU_OUT_OF_MEMORY, "quant_rdo misuse flag");
+    *ctx->h_rdoq_misuse = 0;
+  }
+  ctx->rdoq_four_lane_only = on ? 1 : 0;
+  return XVCGPU_OK;
+}
+
 xvcgpu_status xvcgpu_quant_rdo_reserve(xvcgpu_ctx *ctx, int n, size_t n_coeffs) {
   if (!ctx || n < 0) return XVCGPU_INVALID_ARGUMENT;
   return ensure_rdoq_scratch(ctx, n, n_coeffs);
@@ -1284,14 +1306,24 @@ static xvcgpu_status quant_rdo_launch(xvcgpu_ctx *ctx, int bitdepth,
   }
   // the class sizes are only known on the device: a bounded number of workgroups
   // per class that walk their list (k_rdoq.h)
-  const int g16 = std::min(n, RDOQ_GRID16), g4 = std::min((n + 3) / 4, RDOQ_GRID4),
+  static const int grid16 = [] {
+    const char *e = getenv("XVCGPU_RDOQ_GRID16");
+    const int v = e ? atoi(e) : 0;
+    return v > 0 ? v : RDOQ_GRID16;
+  }();
+  const int g16 = std::min(n, grid16), g4 = std::min((n + 3) / 4, RDOQ_GRID4),
             g64 = std::min(n, RDOQ_GRID64);
+  // (the general class's launch holds 255 vector registers a wave: even with an empty list
+  // it waits for room beside other streams' kernels - 190 us in flight at 2160p; a caller
+  // that knows its blocks says so and the launch is not made)
+  const bool four_only = ctx->rdoq_four_lane_only != 0;
   hipLaunchKernelGGL(quant_rdo_packed4_kernel, dim3(g16 + g4), dim3(64), 0, ctx->stream,
                      bitdepth, d_blocks, l, g16, d_coeffs, d_offsets, d_levels, d_nnz,
-                     d_contexts, d_params, d_cu_patch);
-  hipLaunchKernelGGL(quant_rdo_packed_kernel, dim3(g64), dim3(64), 0, ctx->stream,
-                     bitdepth, d_blocks, l, d_coeffs, d_offsets, d_levels, d_nnz,
-                     d_contexts, d_params, d_cu_patch);
+                     d_contexts, d_params, d_cu_patch, four_only ? ctx->h_rdoq_misuse : nullptr);
+  if (!four_only)
+    hipLaunchKernelGGL(quant_rdo_packed_kernel, dim3(g64), dim3(64), 0, ctx->stream,
+                       bitdepth, d_blocks, l, d_coeffs, d_offsets, d_levels, d_nnz,
+                       d_contexts, d_params, d_cu_patch);
   CHECK_LAUNCH(ctx, "quant_rdo_batch");
   return XVCGPU_OK;
 }
@@ -2024,6 +2056,10 @@ xvcgpu_status xvcgpu_frame_pass(xvcgpu_ctx *ctx, const xvcgpu_frame_pass_args *a
           st = xvcgpu_fwd_transform_batch(ctx, a->orig, a->pred, a->d_tx, a->n_tx, a->d_coeffs,
                                           a->d_level_off);
       }
+      // the caller's word about its blocks holds for this call's batch
+      const int four_before = ctx->rdoq_four_lane_only;
+      if (st == XVCGPU_OK && a->tx_four_lane_only && !four_before)
+        st = xvcgpu_quant_rdo_set_four_lane_only(ctx, 1);
       if (st == XVCGPU_OK)
         st = classified
                  ? xvcgpu_quant_rdo_classified_batch(ctx, a->rec->bd, a->d_tx, a->n_tx,
@@ -2033,6 +2069,7 @@ xvcgpu_status xvcgpu_frame_pass(xvcgpu_ctx *ctx, const xvcgpu_frame_pass_args *a
                  : xvcgpu_quant_rdo_batch(ctx, a->rec->bd, a->d_tx, a->n_tx, a->d_coeffs,
                                           a->d_level_off, a->n_coeffs, a->d_levels, a->d_nnz,
                                           a->d_rdoq_contexts, a->d_rdoq_params);
+      ctx->rdoq_four_lane_only = four_before;
       if (st == XVCGPU_OK) {
         if (!a->d_tx || !a->d_levels || !a->d_level_off || !a->d_nnz) {
           st = XVCGPU_INVALID_ARGUMENT;

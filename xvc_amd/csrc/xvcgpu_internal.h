@@ -76,6 +76,8 @@ struct xvcgpu_ctx {
   int rdoq_qp_hint;                // luma QP of the last xvcgpu_fwd_from_me_classify (-1: none)
   int rdoq_prove_zero;             // quant_rdo: the all-zero proof ahead of the walk: 0 / 1 / -1 by batch size
   int intra_waves_grid;            // workgroups of its cooperative launch (0: not determined yet)
+  int rdoq_four_lane_only;         // xvcgpu_quant_rdo_set_four_lane_only: the general class's launch is skipped
+  int *h_rdoq_misuse;              // page-locked: set by the walk when such a batch held a general-class block
   // scratch of xvcgpu_quant_rdo_batch (k_rdoq.h): the three class lists + their
   // counters, and 26 bytes per coefficient of the batch
   int *d_rdoq_lists;

@@ -219,6 +219,7 @@ class FramePass:
         # forward and the inverse half of the residual pipeline: 5 launches instead
         # of the one fused launch, an order of magnitude less time
         self.rdoq_packed = rdoq and (fused if rdoq_packed is None else rdoq_packed)
+        self.tx_four_lane_only = False       # set below, from the transform blocks
         if self.rdoq_packed:
             keep_levels = True
         # keep_levels: also store the quantised coefficients of every TU (what
@@ -232,6 +233,13 @@ class FramePass:
         self.d_rdoq_prm = ctx.buffer(d.rdoq_params) if rdoq else None
         self.d_me = ctx.buffer(d.me)
         self.d_tx = ctx.buffer(d.tx)
+        # no block of the quantiser's general class (diagonal scan, 4x4 sub-blocks, sides up
+        # to 32, at most sixteen sub-blocks): its launch can be left out (xvcgpu.h)
+        t = d.tx
+        self.tx_four_lane_only = bool(len(t)) and bool(
+            ((t["w"] >= 4) & (t["h"] >= 4) & (t["w"] <= 32) & (t["h"] <= 32) &
+             ((t["w"].astype(int) >> 2) * (t["h"].astype(int) >> 2) <= 16) &
+             (((t["intra_pic"].astype(int) >> api.TXF_SCAN_SHIFT) & 3) == 0)).all())
         self.d_luma_idx = ctx.buffer(d.luma_idx)
         self.d_map = ctx.buffer(d.cu_map)
         self.d_res = ctx.alloc(api.MERES_DTYPE.itemsize * max(1, d.n_cus))
@@ -295,6 +303,7 @@ class FramePass:
         a.orig = orig.h_pic if orig is not None else None
         a.ref = ref.h_pic if ref is not None else None
         a.rec, a.ref_poc = rec.h_pic, ref_poc
+        a.tx_four_lane_only = 1 if self.tx_four_lane_only else 0
         if rows is not None:
             a.db_y_begin, a.db_y_end = rows
             a.dbh_y_end = dbh_end if dbh_end is not None else rows[1]
