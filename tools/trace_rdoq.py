@@ -48,7 +48,7 @@ names = ["count,list", "block,prm,off", "coefficients", "ctx costs", "quant+last
 life = t[:, 10] - t[:, 0]
 rt = buf[2048:2048 + rows, :2].astype(np.int64)[ok]
 rt_us = (rt[:, 1] - rt[:, 0]) / 100.0          # s_memrealtime: 100 MHz
-good = rt_us > 0
+good = (rt_us > 0) & (rt[:, 0] > 0) & (rt_us < 1e6)   # (rows the kernel did not stamp)
 print("wall clock per wave life: mean %.1f us p50 %.1f p90 %.1f max %.1f; s_memtime ticks per us: %.0f" %
       (rt_us[good].mean(), np.median(rt_us[good]), np.percentile(rt_us[good], 90), rt_us[good].max(),
        (life[good] / rt_us[good]).mean()))
