@@ -1033,6 +1033,28 @@ xvcgpu_status xvcgpu_cs_merge_fold(xvcgpu_ctx *ctx, const xvcgpu_cs_merge *d_mer
                                    xvcgpu_cs_merge_result *d_results,
                                    xvcgpu_inter_block *d_ev_inter);
 
+/* ---- many chains, one launch per step kind ---------------------------------------- *
+ * The pictures of one chain (the picture being coded, its reference pictures, the three
+ * scratch pictures of its evaluations, its level and result arrays) as a device-resident
+ * record; xvcgpu_cs_segs_launch then runs n_segs segments of one kind - the same kernel
+ * bodies as the single-chain entry points named in xvcgpu_types.h, grid y = segment - on
+ * ctx's stream.  Segments of one call must not depend on each other (they are the
+ * current steps of DIFFERENT chains); a chain's next step goes into a later call.
+ * All segments of a call share i0 where it selects a kernel instance (ME / BI / AFFINE).
+ * The kernels read the segment records from page-locked memory of the context (a ring of
+ * two 4 MiB halves; a half is written again only after the launches that read it have
+ * passed), so a call takes any number of segments. */
+xvcgpu_status xvcgpu_cs_env_create(xvcgpu_ctx *ctx, const xvcgpu_picture *orig,
+                                   const xvcgpu_picture *const *refs, int n_refs,
+                                   xvcgpu_picture *s_orig, xvcgpu_picture *s_pred,
+                                   xvcgpu_picture *s_rec, int16_t *d_levels,
+                                   xvcgpu_cs_result *d_results, xvcgpu_cs_env **out);
+void xvcgpu_cs_env_destroy(xvcgpu_cs_env *env);
+xvcgpu_status xvcgpu_cs_segs_launch(xvcgpu_ctx *ctx, int kind, const xvcgpu_cs_seg *segs,
+                                    int n_segs);
+/* 1 in *done when everything recorded into ev has completed, without waiting */
+xvcgpu_status xvcgpu_event_query(xvcgpu_event *ev, int *done);
+
 /* All distortions of an evaluation (CompressAndEvalCbf, inter_search.cc:261-365) in one
  * launch: candidate i compares its block of `orig` with the same block of `pred`
  * (versus = 0: the cbf-zero distortion) or of `rec` (versus = 1: an alternative's

@@ -443,6 +443,35 @@ typedef struct xvcgpu_cs_merge_result {
   int32_t reserved[2];
 } xvcgpu_cs_merge_result;
 
+/* ---- the steps of many pictures' CU-state chains in one launch -------------------- *
+ * xvcgpu_cs_segs_launch (xvcgpu.h): a SEGMENT is the argument list of one of the batched
+ * entry points a chain issues - p[] in that entry point's own order, the pictures from
+ * the chain's environment (xvcgpu_cs_env_create) - and a launch runs up to hundreds of
+ * segments of one kind, grid y = segment. */
+#define XVC_CS_SEG_MC_METRIC_REFS 0  /* p: cands, out, slots                  n jobs          */
+#define XVC_CS_SEG_START_FOLD 1      /* p: passes, start_dist, me_jobs, me_res, aff_jobs; i0 = first pass, n passes */
+#define XVC_CS_SEG_UNI_FOLD 2        /* p: passes, me_res, aff_res, bi_jobs, aff_jobs; i0, n     */
+#define XVC_CS_SEG_BI_FOLD 3         /* p: passes, bi_res, aff_res, ev_inter; i0, n              */
+#define XVC_CS_SEG_MERGE_FOLD 4      /* p: merges, dist, cands, results, ev_inter; i0, n         */
+#define XVC_CS_SEG_ME_REFS 5         /* p: blocks, results, slots; i0 = block class (16/32/64)  */
+#define XVC_CS_SEG_BI_REFS 6         /* p: jobs, results, slots; i0 = block class               */
+#define XVC_CS_SEG_AFFINE_REFS 7     /* p: blocks, results, slots; i0 = CU height (16/32/64)    */
+#define XVC_CS_SEG_INTER_PRED 8      /* p: blocks, dst positions (into the env's s_pred)        */
+#define XVC_CS_SEG_RESIDUAL_AT 9     /* p: tx blocks, level offsets, nnz, contexts, params, source
+                                      * positions, evaluation candidates (or 0), their output;
+                                      * r0 = candidates in front (xvcgpu_residual_rdoq_batch_at) */
+#define XVC_CS_SEG_EVAL_DIST 10      /* p: candidates (orig_at), out                            */
+#define XVC_CS_SEG_FETCH 11          /* p: source (device), destination (page-locked host memory
+                                      * the device can write: xvcgpu_host_alloc); n bytes, a
+                                      * multiple of 4, both 4-byte aligned                      */
+#define XVC_CS_SEG_KINDS 12
+typedef struct xvcgpu_cs_env xvcgpu_cs_env;
+typedef struct xvcgpu_cs_seg {
+  int32_t n, i0, r0, r1;
+  uint64_t p[8];               /* device addresses                                        */
+  const xvcgpu_cs_env *env;
+} xvcgpu_cs_seg;
+
 /* One distortion of an evaluation (xvcgpu_eval_dist_batch): what CompressAndEvalCbf /
  * CompressAndEvalTransform compare per component and alternative - the prediction
  * against the original (the cbf-zero distortion, transform_encoder.cc:116-117) or a

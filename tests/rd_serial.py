@@ -398,6 +398,15 @@ class SerialPicture:
             self.copy_orig[f + 3:f + 3 + k] = o
         self.contexts = np.ascontiguousarray(rd["contexts"]).view(api.RDOQ_CTX_DTYPE).reshape(-1)
 
+    def position_start(self, i):
+        """The first state at or behind i that opens a visit of a CU position (a stretch of
+        states cut anywhere else would start inside a chain: its first states read what
+        states in front of the cut computed)."""
+        st = self.states
+        while 0 < i < len(st) and tuple(st[i][["x", "y", "w", "h"]]) == tuple(st[i - 1][["x", "y", "w", "h"]]):
+            i += 1
+        return min(i, len(st) - 1)
+
     def summary(self):
         st = self.states
         return {"states": len(st), "merge_rank": int((st["kind"] == 0).sum()),
@@ -666,6 +675,9 @@ def build_merge_folds(sp):
                 used.add(r)
                 break
     sp.mg_fold, sp.mg_slots, sp.ev_merge_slot = mf, slots, ev_slot
+    sp.merge_state = np.full(n_m, -1, np.int64)       # ranking -> its state
+    for n in np.flatnonzero(st["kind"] == KIND_MERGE_RANK):
+        sp.merge_state[int(st["merge"][n])] = n
 
 
 class CsEnv(C.Structure):
@@ -1096,6 +1108,13 @@ class ChainedRun(SerialRun):
                 op(OP_BI_FOLD, 1, i0=pi, p=(P, d["bi_res_c"], d["aff_res_c"], d["ev_inter_work"]))
             fetch(d["results"] + pf * I["result"], self.cres["results"][1] + pf * I["result"], pc * I["result"])
 
+        def slot_of(e):
+            """the evaluation's slot, when its ranking is folded by THIS program"""
+            sl = int(sp.ev_merge_slot[e]) if self.merge_fold else -1
+            if sl >= 0 and not (first <= sp.merge_state[sl // MERGE_SLOTS] < first + n):
+                sl = -1
+            return sl
+
         def evaluation(s, n_state):
             e = int(s["ev"])
             n0, n1 = int(s["call_pass0"]), int(s["call_pass1"])
@@ -1106,7 +1125,7 @@ class ChainedRun(SerialRun):
                 # the first transform pass, a wait (the host prices it and decides the gate),
                 # then the second pass' calls
                 co = int(s["copy_first"])
-                sl = int(sp.ev_merge_slot[e]) if self.merge_fold else -1
+                sl = slot_of(e)
                 pred_jobs = d["mg_slots"] + 3 * sl * I["inter"] if sl >= 0 else \
                     d["ev_inter_work"] + 3 * e * I["inter"]
                 nc_ = self.no_copies
@@ -1149,7 +1168,7 @@ class ChainedRun(SerialRun):
             nc_ = self.no_copies
             if not nc_:
                 op(OP_COPY, 3 + k, r0=PIC_ORIG, r1=PIC_S_ORIG, p=(t.d_copy_orig + int(s["copy_first"]) * I["copy"],))
-            sl = int(sp.ev_merge_slot[e]) if self.merge_fold else -1
+            sl = slot_of(e)
             pred_jobs = d["mg_slots"] + 3 * sl * I["inter"] if sl >= 0 else \
                 d["ev_inter_work"] + 3 * e * I["inter"]
             op(OP_INTER_PRED, 3, r1=PIC_S_PRED, p=(pred_jobs, t.d_ev_dst + 3 * e * I["pos"]))
@@ -1186,7 +1205,7 @@ class ChainedRun(SerialRun):
             key = (int(s["x"]), int(s["y"]), int(s["w"]), int(s["h"]))
             if live:
                 stay = merge_open and key == prev_key and int(s["kind"]) == KIND_EVAL and \
-                    self.merge_fold and sp.ev_merge_slot[int(s["ev"])] >= 0
+                    slot_of(int(s["ev"])) >= 0
                 merge_open = stay or (int(s["kind"]) == KIND_MERGE_RANK and self.merge_fold)
                 cut = not stay
             else:
@@ -1273,6 +1292,65 @@ class ChainedRun(SerialRun):
             r.collect()
         return stats
 
+    @staticmethod
+    def run_engine(runs, firsts, n, by_position=True, live=False, verify=False, streams=(), threads=1):
+        """k runs through xvc_host_cs_run_programs_engine: every round the chains' next steps
+        grouped by kind, one launch per kind with the chains' jobs side by side.  firsts[c]:
+        the first state of run c's stretch of n states (the chains walk different parts of the
+        picture: their steps do not line up).  streams: further contexts of the device.
+        threads = 1: one engine, a round's groups dealt over the contexts; threads = T: T
+        engines on T host threads, each with its own context and every T-th chain."""
+        import threading
+        import time
+        k = len(runs)
+        ctx = runs[0].ctx
+        assert all(r.ctx is ctx for r in runs)
+        progs = [np.ascontiguousarray(r.program(f, n, by_position, verify, live=live))
+                 for r, f in zip(runs, firsts)]
+        lib = runs[0].lib
+        lib.xvc_host_cs_run_programs_engine.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p,
+                                                        C.c_void_p, C.c_void_p, C.c_void_p]
+        lib.xvc_host_cs_run_programs_engine.restype = C.c_int
+        all_ctx = [ctx] + list(streams)
+
+        def one(ctxs, which, stats, err):
+            kk = len(which)
+            envs = (C.c_void_p * kk)(*[C.addressof(runs[c].env) for c in which])
+            ops = (C.c_void_p * kk)(*[progs[c].ctypes.data for c in which])
+            n_ops = (C.c_int64 * kk)(*[len(progs[c]) for c in which])
+            hs = (C.c_void_p * len(ctxs))(*[c.h for c in ctxs])
+            rc = lib.xvc_host_cs_run_programs_engine(hs, len(ctxs), kk, envs, ops, n_ops,
+                                                     C.addressof(stats))
+            if rc:
+                err.append("xvc_host_cs_run_programs_engine: %d (%s)" % (
+                    rc, ctxs[0].lib.xvcgpu_last_error(ctxs[0].h)))
+
+        err = []
+        if threads <= 1:
+            stats = CsStats()
+            one(all_ctx, list(range(k)), stats, err)
+        else:
+            assert len(all_ctx) >= threads and k >= threads
+            ctx.sync()                       # the runs' uploads, before other streams read them
+            parts = [CsStats() for _ in range(threads)]
+            ths = [threading.Thread(target=one, args=([all_ctx[t]], list(range(t, k, threads)), parts[t], err))
+                   for t in range(threads)]
+            t0 = time.perf_counter()
+            for t in ths:
+                t.start()
+            for t in ths:
+                t.join()
+            stats = CsStats()
+            stats.seconds = time.perf_counter() - t0
+            for pt in parts:
+                for f in ("states", "round_trips", "api_calls"):
+                    setattr(stats, f, getattr(stats, f) + getattr(pt, f))
+        if err:
+            raise RuntimeError(err[0])
+        for r in runs:
+            r.collect()
+        return stats
+
     def collect(self):
         """The device-written host arrays into the result arrays check() reads."""
         st, res = self.sp.states, self.res
@@ -1314,7 +1392,8 @@ class ChainedRun(SerialRun):
                     out["merge_fold"][1] += 1
                     self.first_bad = getattr(self, "first_bad", ("merge_fold", ns, tuple(g), tuple(w)))
             if s["supported"] and self.merge_fold and s["kind"] == KIND_EVAL and \
-                    sp.ev_merge_slot[int(s["ev"])] >= 0:
+                    sp.ev_merge_slot[int(s["ev"])] >= 0 and \
+                    first <= sp.merge_state[int(sp.ev_merge_slot[int(s["ev"])]) // MERGE_SLOTS] < first + n:
                 # the motion the fold put into the slot this evaluation predicted from
                 e = int(s["ev"])
                 got, want = slots_out[int(sp.ev_merge_slot[e])], sp.ev_inter[e]

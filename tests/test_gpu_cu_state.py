@@ -117,6 +117,51 @@ def test_live_chains_equal_reference(gpu, name, poc, n_states):
     assert 0.5 * stats.states < stats.round_trips < 2 * stats.states
 
 
+@pytest.mark.parametrize("name,poc,k,n,threads", [("tiny", 2, 5, 1500, 1), ("c1", 2, 8, 1500, 1),
+                                                  ("c1", 2, 9, 1200, 3)])
+def test_engine_chains_equal_reference(gpu, name, poc, k, n, threads):
+    """k chains on ONE context through the engine (xvc_host_cs_run_programs_engine): every
+    round the chains' next steps grouped by kind, one launch per kind with the chains' jobs
+    side by side in the grid (xvcgpu_cs_segs_launch) - each chain walks its own stretch of
+    the picture, so their steps do not line up.  threads = 1: a round's groups dealt over
+    three streams; threads = 3: three engines on three host threads, a stream and every
+    third chain each.  Every chain's results equal the reference's, and the launches are
+    fewer than the steps."""
+    api, ctx = gpu
+    fx = sf.StreamFixture(name)
+    pics, w, h = decode_stream(ctx, fx)
+    sp = rd_serial.SerialPicture(api, name, poc)
+    ectx = api.Context(0)
+    ectx.use_own_stream()
+    lists = rd_serial.ref_lists_of(name, poc)
+    runs = [rd_serial.ChainedRun(api, ectx, sp, pics, w, h, lists) for _ in range(k)]
+    n = min(n, len(sp.states) // k)
+    firsts = [sp.position_start(c * (len(sp.states) - n - 64) // max(k - 1, 1)) for c in range(k)]
+    more = [api.Context(0) for _ in range(2)]        # two further streams for the rounds' groups
+    for c in more:
+        c.use_own_stream()
+    stats = rd_serial.ChainedRun.run_engine(runs, firsts, n, by_position=True, verify=True, streams=more,
+                                            threads=threads)
+    steps = sum(int((r.program(f, n, True, True)["opcode"] != rd_serial.OP_SYNC).sum())
+                for r, f in zip(runs, firsts))
+    print(name, "engine k=%d: %d states, %d launches for %d steps, %.1f us per state" % (
+        k, stats.states, stats.api_calls, steps, 1e6 * stats.seconds / max(stats.states, 1)))
+    assert stats.states > 0.3 * k * n and stats.api_calls < 0.8 * steps
+    for r, f in zip(runs, firsts):
+        res = r.check(f, n, searches=False)
+        res.update(r.check_chained(f, n))
+        bad = repr(getattr(r, "first_bad", None))
+        for key, (done, wrong) in res.items():
+            assert wrong == 0, (key, res, bad)
+    for r in runs:
+        r.destroy()
+    for c in more:
+        c.close()
+    ectx.close()
+    for p in pics.values():
+        p.destroy()
+
+
 def test_interleaved_chains_equal_reference(gpu):
     """Three replays of the picture on their own contexts driven by one host thread
     (xvc_host_cs_run_programs_interleaved: a chain issued while the others execute):

@@ -36,6 +36,58 @@ def walk(api, clip, poc, n_states, ks, mode="serial", check=True, decoded=None, 
     n = min(n_states, len(sp.states))
     out = {"clip": clip, "poc": poc, "states_in_picture": len(sp.states), "states_walked": n,
            "mode": mode, "summary": sp.summary(), "chains": {}}
+    if mode == "engine":
+        # k chains on ONE context: every round the chains' next steps grouped by kind, one
+        # launch per kind (xvc_host_cs_run_programs_engine); each chain walks its own
+        # stretch of the picture, so the steps do not line up
+        lists = rd_serial.ref_lists_of(clip, poc)
+        for k in ks:
+            ectx = api.Context(0)
+            ectx.use_own_stream()
+            runs = [rd_serial.ChainedRun(api, ectx, sp, pics, w, h, lists) for _ in range(k)]
+            # ENGINE_THREADS engines on as many host threads and streams, every T-th chain each;
+            # with one thread ENGINE_STREAMS deals a round's groups over that many streams
+            threads = int(os.environ.get("ENGINE_THREADS", "1"))
+            extra = [api.Context(0) for _ in range(max(int(os.environ.get("ENGINE_STREAMS", "1")), threads) - 1)]
+            for c in extra:
+                c.use_own_stream()
+            firsts = [sp.position_start(c * (len(sp.states) - n - 64) // max(k - 1, 1)) for c in range(k)]
+            rd_serial.ChainedRun.run_engine(runs[:min(k, 2)], firsts[:min(k, 2)], min(n, 300), streams=extra)   # warm-up
+            walls, stats = [], None
+            for _ in range(3):
+                t0 = time.time()
+                stats = rd_serial.ChainedRun.run_engine(runs, firsts, n, streams=extra, threads=min(threads, k))
+                walls.append(time.time() - t0)
+            # (the wall time holds the Python loop that records the programs; the engine's own
+            # clock starts when the first step is issued)
+            entry = {"us_per_cu_state_aggregate": 1e6 * stats.seconds / stats.states,
+                     "states_per_s": stats.states / stats.seconds,
+                     "pictures_per_s": stats.states / stats.seconds / len(sp.states),
+                     "launches_per_state": stats.api_calls / stats.states,
+                     "round_trips_per_state": stats.round_trips / stats.states,
+                     "states": int(stats.states)}
+            if check:
+                runs_c = runs[:min(k, 4)]
+                rd_serial.ChainedRun.run_engine(runs, firsts, n, verify=True, streams=extra, threads=min(threads, k))
+                ok = True
+                for r, f in zip(runs_c, firsts):
+                    res = r.check(f, n, searches=False)
+                    res.update(r.check_chained(f, n))
+                    ok = ok and all(v[1] == 0 for v in res.values())
+                entry["matches_reference"] = ok
+            out["chains"][str(k)] = entry
+            entry["streams"] = 1 + len(extra)
+            entry["host_threads"] = min(threads, k)
+            for r in runs:
+                r.destroy()
+            for c in extra:
+                c.close()
+            ectx.close()
+        if base is not None:
+            for p in pics.values():
+                p.destroy()
+            base.close()
+        return out
     for k in ks:
         ctxs = [api.Context(0) for _ in range(k)]
         for c in ctxs:

@@ -155,7 +155,7 @@ SYMBOLS = [
     "xvcgpu_create", "xvcgpu_destroy", "xvcgpu_last_error", "xvcgpu_version",
     "xvcgpu_set_stream", "xvcgpu_get_stream", "xvcgpu_use_own_stream", "xvcgpu_use_priority_stream", "xvcgpu_set_short_kernel_priority", "xvcgpu_wait_for", "xvcgpu_sync", "xvcgpu_timer_begin", "xvcgpu_timer_end", "xvcgpu_timer_mark", "xvcgpu_timer_between",
     "xvcgpu_record_begin", "xvcgpu_record_end", "xvcgpu_replay", "xvcgpu_recording_destroy",
-    "xvcgpu_malloc", "xvcgpu_free", "xvcgpu_memcpy_h2d", "xvcgpu_memcpy_d2h", "xvcgpu_memcpy_d2h_async", "xvcgpu_upload_ahead", "xvcgpu_eval_dist_batch", "xvcgpu_cs_start_fold", "xvcgpu_cs_uni_fold", "xvcgpu_cs_bi_fold", "xvcgpu_cs_merge_fold", "xvcgpu_residual_rdoq_batch_at", "xvcgpu_quant_rdo_set_four_lane_only",
+    "xvcgpu_malloc", "xvcgpu_free", "xvcgpu_memcpy_h2d", "xvcgpu_memcpy_d2h", "xvcgpu_memcpy_d2h_async", "xvcgpu_upload_ahead", "xvcgpu_eval_dist_batch", "xvcgpu_cs_start_fold", "xvcgpu_cs_uni_fold", "xvcgpu_cs_bi_fold", "xvcgpu_cs_merge_fold", "xvcgpu_residual_rdoq_batch_at", "xvcgpu_quant_rdo_set_four_lane_only", "xvcgpu_cs_env_create", "xvcgpu_cs_env_destroy", "xvcgpu_cs_segs_launch", "xvcgpu_event_query",
     "xvcgpu_memset", "xvcgpu_picture_create", "xvcgpu_picture_bytes",
     "xvcgpu_picture_wrap", "xvcgpu_picture_destroy", "xvcgpu_picture_upload",
     "xvcgpu_picture_download", "xvcgpu_picture_upload_padded",

@@ -149,7 +149,7 @@ static_assert(sizeof(xvcgpu_cs_result) % 4 == 0 && sizeof(xvcgpu_cs_result) <= 5
 // start_dist: SampleMetric(kSad) of the two predictors' predictions (GetMvpMetricType,
 // :1078-1080), as xvcgpu_mc_metric_batch / xvcgpu_metric_batch return them.  Both
 // candidates pay the same GetMvpBits, so the first strictly smaller distortion wins.
-__global__ void cs_start_fold_kernel(const xvcgpu_cs_pass *passes, int first, int n,
+__device__ __forceinline__ void cs_start_fold_body(const xvcgpu_cs_pass *passes, int first, int n,
                                      const uint64_t *start_dist, xvcgpu_me_block *me_jobs,
                                      const xvcgpu_me_result *me_res,
                                      xvcgpu_affine_me_block *aff_jobs, xvcgpu_cs_result *results,
@@ -191,8 +191,17 @@ __global__ void cs_start_fold_kernel(const xvcgpu_cs_pass *passes, int first, in
   CS_FOLD_EPILOGUE
 }
 
+__global__ void
+cs_start_fold_kernel(const xvcgpu_cs_pass *passes, int first, int n,
+                                     const uint64_t *start_dist, xvcgpu_me_block *me_jobs,
+                                     const xvcgpu_me_result *me_res,
+                                     xvcgpu_affine_me_block *aff_jobs, xvcgpu_cs_result *results,
+                                     int pic_w, int pic_h) {
+  cs_start_fold_body(passes, first, n, start_dist, me_jobs, me_res, aff_jobs, results, pic_w, pic_h);
+}
+
 // ---- fold 2: SearchRefIdx over both lists -> the refinement jobs --------------------
-__global__ void cs_uni_fold_kernel(const xvcgpu_cs_pass *passes, int first, int n,
+__device__ __forceinline__ void cs_uni_fold_body(const xvcgpu_cs_pass *passes, int first, int n,
                                    const xvcgpu_me_result *me_res,
                                    const xvcgpu_affine_me_result *aff_res,
                                    xvcgpu_cs_result *results, xvcgpu_bi_block *bi_jobs,
@@ -325,8 +334,17 @@ __global__ void cs_uni_fold_kernel(const xvcgpu_cs_pass *passes, int first, int 
   CS_FOLD_EPILOGUE
 }
 
+__global__ void
+cs_uni_fold_kernel(const xvcgpu_cs_pass *passes, int first, int n,
+                                   const xvcgpu_me_result *me_res,
+                                   const xvcgpu_affine_me_result *aff_res,
+                                   xvcgpu_cs_result *results, xvcgpu_bi_block *bi_jobs,
+                                   xvcgpu_affine_me_block *aff_jobs) {
+  cs_uni_fold_body(passes, first, n, me_res, aff_res, results, bi_jobs, aff_jobs);
+}
+
 // ---- fold 3: the refinement's costs, the three-way choice, the evaluation's jobs ----
-__global__ void cs_bi_fold_kernel(const xvcgpu_cs_pass *passes, int first, int n,
+__device__ __forceinline__ void cs_bi_fold_body(const xvcgpu_cs_pass *passes, int first, int n,
                                   const xvcgpu_me_result *bi_res,
                                   const xvcgpu_affine_me_result *aff_res,
                                   xvcgpu_cs_result *results, xvcgpu_inter_block *ev_inter) {
@@ -480,11 +498,19 @@ __global__ void cs_bi_fold_kernel(const xvcgpu_cs_pass *passes, int first, int n
   CS_FOLD_EPILOGUE
 }
 
+__global__ void
+cs_bi_fold_kernel(const xvcgpu_cs_pass *passes, int first, int n,
+                                  const xvcgpu_me_result *bi_res,
+                                  const xvcgpu_affine_me_result *aff_res,
+                                  xvcgpu_cs_result *results, xvcgpu_inter_block *ev_inter) {
+  cs_bi_fold_body(passes, first, n, bi_res, aff_res, results, ev_inter);
+}
+
 // ---- the merge ranking's fold: SearchMergeCandidates' arithmetic (:176-196) ---------
 // One thread per ranking: five costs in double (dist + bits * lambda_sqrt as the
 // reference forms it - no contraction, -ffp-contract=off), std::stable_sort = an
 // insertion sort that only moves on strictly smaller, the 1.25 x cut from the back.
-__global__ void cs_merge_fold_kernel(const xvcgpu_cs_merge *merges, int first, int n,
+__device__ __forceinline__ void cs_merge_fold_body(const xvcgpu_cs_merge *merges, int first, int n,
                                      const uint64_t *dist, const xvcgpu_inter_block *cands,
                                      xvcgpu_cs_merge_result *results,
                                      xvcgpu_inter_block *ev_inter) {
@@ -539,13 +565,20 @@ __global__ void cs_merge_fold_kernel(const xvcgpu_cs_merge *merges, int first, i
   }
 }
 
+__global__ void
+cs_merge_fold_kernel(const xvcgpu_cs_merge *merges, int first, int n,
+                                     const uint64_t *dist, const xvcgpu_inter_block *cands,
+                                     xvcgpu_cs_merge_result *results,
+                                     xvcgpu_inter_block *ev_inter) {
+  cs_merge_fold_body(merges, first, n, dist, cands, results, ev_inter);
+}
+
 // ---- the distortions of an evaluation in one launch ----------------------------------
 // metric_batch_kernel (k_metric.h) with the planes chosen per candidate: an evaluation
 // compares three components against two pictures with three weights - seven launches
 // of 5 us each through xvcgpu_metric_batch, a fifth of a CU state's time.
 // grid: ceil(n/4); block: 256 = 4 waves, one candidate per wave.
-__global__ void __launch_bounds__(256)
-eval_dist_kernel(PicView orig, PicView pred, PicView rec, int strength,
+__device__ __forceinline__ void eval_dist_body(PicView orig, PicView pred, PicView rec, int strength,
                  const xvcgpu_eval_cand *cands, int n, uint64_t *out) {
   const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (c >= n) return;
@@ -557,6 +590,12 @@ eval_dist_kernel(PicView orig, PicView pred, PicView rec, int strength,
   const uint64_t dist = wave_compare(cd.metric, orig.bd, cd.qp, strength, cd.w, cd.h, a,
                                      pa.stride, b, pb.stride);
   if ((threadIdx.x & 63) == 0) out[c] = (uint64_t)((double)dist * cd.weight);
+}
+
+__global__ void __launch_bounds__(256)
+eval_dist_kernel(PicView orig, PicView pred, PicView rec, int strength,
+                 const xvcgpu_eval_cand *cands, int n, uint64_t *out) {
+  eval_dist_body(orig, pred, rec, strength, cands, n, out);
 }
 
 #endif  // XVCGPU_K_CU_STATE_H_

@@ -110,9 +110,10 @@ __device__ __forceinline__ void wg_affine_block(int bd, int comp, int bx, int by
 // (wg_lic_model: k_bipred.h)
 
 // grid: n; block: 256.
-__global__ void __launch_bounds__(256)
-inter_pred_kernel(RefTable refs, PicView rec, PicView pred, const xvcgpu_inter_block *blocks,
-                  int n, const xvcgpu_block_pos *dst_pos, int pic_w, int pic_h) {
+__device__ __forceinline__ void
+inter_pred_body(const RefTable &refs, const PicView &rec, const PicView &pred,
+                const xvcgpu_inter_block *blocks, int n, const xvcgpu_block_pos *dst_pos,
+                int pic_w, int pic_h) {
   __shared__ int16_t tmp[64 * 71];
   __shared__ int16_t p16[2][64 * 64];
   __shared__ uint16_t smp[64 * 64];
@@ -193,6 +194,12 @@ inter_pred_kernel(RefTable refs, PicView rec, PicView pred, const xvcgpu_inter_b
   for (int i = threadIdx.x; i < cw * ch; i += 256)
     out[(ptrdiff_t)(i >> lw) * pd.stride + (i & (cw - 1))] =
         d_clip_bd(((int)p16[0][i] + (int)p16[1][i] + off) >> sh, smax);
+}
+
+__global__ void __launch_bounds__(256)
+inter_pred_kernel(RefTable refs, PicView rec, PicView pred, const xvcgpu_inter_block *blocks,
+                  int n, const xvcgpu_block_pos *dst_pos, int pic_w, int pic_h) {
+  inter_pred_body(refs, rec, pred, blocks, n, dst_pos, pic_w, pic_h);
 }
 
 #endif  // XVCGPU_K_INTER_PRED_H_

@@ -529,14 +529,13 @@ residual_wave_kernel(PicView orig, PicView pred, PicView rec, const xvcgpu_tx_bl
 // other are two wave lives (16 + 25 us with RDOQ) for a batch that fills neither.
 // grid: n; block: TX_THREADS.
 template <int MODE, bool RDOQ>
-__global__ void __launch_bounds__(TX_THREADS)
-residual_cu_kernel(PicView orig, PicView pred, PicView rec, const xvcgpu_tx_block *blocks, int n,
+__device__ __forceinline__ void
+residual_cu_body(const PicView &orig, const PicView &pred, const PicView &rec, const xvcgpu_tx_block *blocks, int n,
                    int16_t *levels, const uint32_t *level_off, int32_t *nnz_out,
                    const int16_t *tx_tables, const int16_t *tx_tables_t, TxTableLayout lay,
                    const xvcgpu_rdoq_contexts *rq_ctx, const xvcgpu_rdoq_params *rq_prm,
-                   const xvcgpu_block_pos *src_pos = nullptr,
-                   const xvcgpu_eval_cand *ecands = nullptr, int n_head = 0,
-                   uint64_t *eout = nullptr, int strength = 0) {
+                   const xvcgpu_block_pos *src_pos, const xvcgpu_eval_cand *ecands, int n_head,
+                   uint64_t *eout, int strength) {
   // src_pos (xvcgpu_residual_rdoq_batch_at): block i reads its original at src_pos[2 i]
   // of `orig` and its prediction at src_pos[2 i + 1] of `pred` (positions in the plane of
   // the block's component); the reconstruction goes to the block's own (x, y) of `rec`.
@@ -602,6 +601,20 @@ residual_cu_kernel(PicView orig, PicView pred, PicView rec, const xvcgpu_tx_bloc
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     if (threadIdx.x < 64) price(n_head + idx);
   }
+}
+
+template <int MODE, bool RDOQ>
+__global__ void __launch_bounds__(TX_THREADS)
+residual_cu_kernel(PicView orig, PicView pred, PicView rec, const xvcgpu_tx_block *blocks, int n,
+                   int16_t *levels, const uint32_t *level_off, int32_t *nnz_out,
+                   const int16_t *tx_tables, const int16_t *tx_tables_t, TxTableLayout lay,
+                   const xvcgpu_rdoq_contexts *rq_ctx, const xvcgpu_rdoq_params *rq_prm,
+                   const xvcgpu_block_pos *src_pos = nullptr,
+                   const xvcgpu_eval_cand *ecands = nullptr, int n_head = 0,
+                   uint64_t *eout = nullptr, int strength = 0) {
+  residual_cu_body<MODE, RDOQ>(orig, pred, rec, blocks, n, levels, level_off, nnz_out, tx_tables,
+                               tx_tables_t, lay, rq_ctx, rq_prm, src_pos, ecands, n_head, eout,
+                               strength);
 }
 
 #endif  // XVCGPU_K_TX2_H_

@@ -28,6 +28,7 @@
 #include "k_rd.h"
 #include "k_intra_waves.h"
 #include "k_cu_state.h"
+#include "k_cs_engine.h"
 #include "xvcgpu_internal.h"
 
 namespace {
@@ -234,6 +235,11 @@ xvcgpu_status xvcgpu_create(int device, xvcgpu_ctx **out) {
   ctx->intra_waves_grid = 0;
   ctx->rdoq_four_lane_only = 0;
   ctx->h_rdoq_misuse = nullptr;
+  ctx->h_seg_ring = nullptr;
+  ctx->seg_ring_pos = 0;
+  ctx->seg_ring_half = 0;
+  ctx->seg_ring_ev[0] = ctx->seg_ring_ev[1] = nullptr;
+  ctx->seg_ring_used[0] = ctx->seg_ring_used[1] = false;
   {
     ctx->rdoq_qp_hint = -1;
     ctx->rdoq_classified_proved = false;
@@ -306,6 +312,11 @@ void xvcgpu_destroy(xvcgpu_ctx *ctx) {
   if (ctx->d_stats) hipFree(ctx->d_stats);
   if (ctx->d_rdoq_lists) hipFree(ctx->d_rdoq_lists);
   if (ctx->h_rdoq_misuse) hipHostFree(ctx->h_rdoq_misuse);
+  if (ctx->h_seg_ring) {
+    hipHostFree(ctx->h_seg_ring);
+    hipEventDestroy(ctx->seg_ring_ev[0]);
+    hipEventDestroy(ctx->seg_ring_ev[1]);
+  }
   if (ctx->d_crc_tables) hipFree(ctx->d_crc_tables);
   if (ctx->d_intra_done) hipFree(ctx->d_intra_done);
   if (ctx->d_me_rot) hipFree(ctx->d_me_rot);
@@ -2542,6 +2553,200 @@ xvcgpu_status xvcgpu_copy_segments(xvcgpu_ctx *ctx, const xvcgpu_copy_segment *d
   return XVCGPU_OK;
 }
 
+
+/* ---- many chains' steps in one launch (k_cs_engine.h) --------------------------- */
+struct xvcgpu_cs_env {
+  xvcgpu_ctx *ctx;
+  CsEnvDev *dev;
+};
+
+xvcgpu_status xvcgpu_cs_env_create(xvcgpu_ctx *ctx, const xvcgpu_picture *orig,
+                                   const xvcgpu_picture *const *refs, int n_refs,
+                                   xvcgpu_picture *s_orig, xvcgpu_picture *s_pred,
+                                   xvcgpu_picture *s_rec, int16_t *d_levels,
+                                   xvcgpu_cs_result *d_results, xvcgpu_cs_env **out) {
+  if (!ctx || !orig || !s_orig || !s_pred || !s_rec || !out) return XVCGPU_INVALID_ARGUMENT;
+  if (s_pred->bd != orig->bd || s_rec->bd != orig->bd || s_orig->bd != orig->bd ||
+      s_rec->w != s_pred->w || s_rec->h != s_pred->h)
+    return fail(ctx, XVCGPU_INVALID_ARGUMENT, "picture mismatch");
+  CsEnvDev h;
+  memset(&h, 0, sizeof(h));
+  const xvcgpu_status st = ref_table_of(ctx, orig, refs, n_refs, &h.refs);
+  if (st != XVCGPU_OK) return st;
+  h.orig = orig->v;
+  h.s_orig = s_orig->v;
+  h.s_pred = s_pred->v;
+  h.s_rec = s_rec->v;
+  h.levels = d_levels;
+  h.results = d_results;
+  h.pic_w = orig->w;
+  h.pic_h = orig->h;
+  xvcgpu_cs_env *e = new (std::nothrow) xvcgpu_cs_env();
+  if (!e) return XVCGPU_OUT_OF_MEMORY;
+  e->ctx = ctx;
+  e->dev = nullptr;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  if (hipMalloc(reinterpret_cast<void **>(&e->dev), sizeof(CsEnvDev)) != hipSuccess) {
+    delete e;
+    return fail(ctx, XVCGPU_OUT_OF_MEMORY, "cs_env");
+  }
+  if (hipMemcpy(e->dev, &h, sizeof(h), hipMemcpyHostToDevice) != hipSuccess) {
+    hipFree(e->dev);
+    delete e;
+    return fail(ctx, XVCGPU_DEVICE_ERROR, "cs_env upload");
+  }
+  *out = e;
+  return XVCGPU_OK;
+}
+
+void xvcgpu_cs_env_destroy(xvcgpu_cs_env *env) {
+  if (!env) return;
+  if (env->dev) hipFree(env->dev);
+  delete env;
+}
+
+#define CS_SEG_RING_HALF (4u << 20)
+// room for n segment records in the context's ring (see xvcgpu_internal.h)
+static CsSegDev *seg_ring_take(xvcgpu_ctx *ctx, int n) {
+  const size_t bytes = (sizeof(CsSegDev) * (size_t)n + 255) & ~(size_t)255;
+  if (bytes > CS_SEG_RING_HALF) return nullptr;
+  if (!ctx->h_seg_ring) {
+    if (hipHostMalloc(reinterpret_cast<void **>(&ctx->h_seg_ring), 2 * CS_SEG_RING_HALF,
+                      hipHostMallocDefault) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->seg_ring_ev[0], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->seg_ring_ev[1], hipEventDisableTiming) != hipSuccess) {
+      (void)hipGetLastError();
+      ctx->h_seg_ring = nullptr;
+      return nullptr;
+    }
+  }
+  if (ctx->seg_ring_pos + bytes > CS_SEG_RING_HALF) {
+    // this half is full: what read it is behind this event; the other half is free once
+    // the launches that read IT have passed
+    const int h = ctx->seg_ring_half;
+    hipEventRecord(ctx->seg_ring_ev[h], ctx->stream);
+    ctx->seg_ring_used[h] = true;
+    ctx->seg_ring_half = 1 - h;
+    if (ctx->seg_ring_used[1 - h]) hipEventSynchronize(ctx->seg_ring_ev[1 - h]);
+    ctx->seg_ring_pos = 0;
+  }
+  CsSegDev *out = reinterpret_cast<CsSegDev *>(ctx->h_seg_ring + ctx->seg_ring_half * CS_SEG_RING_HALF +
+                                              ctx->seg_ring_pos);
+  ctx->seg_ring_pos += bytes;
+  return out;
+}
+
+xvcgpu_status xvcgpu_cs_segs_launch(xvcgpu_ctx *ctx, int kind, const xvcgpu_cs_seg *segs,
+                                    int n_segs) {
+  if (!ctx || n_segs < 0 || (n_segs && !segs) || kind < 0 || kind >= XVC_CS_SEG_KINDS)
+    return XVCGPU_INVALID_ARGUMENT;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  const int kChunk = 16384;          // segments per launch (grid y)
+  for (int first = 0; first < n_segs; first += kChunk) {
+    const int cnt = std::min(kChunk, n_segs - first);
+    CsSegDev *a = seg_ring_take(ctx, cnt);
+    if (!a) return fail(ctx, XVCGPU_OUT_OF_MEMORY, "cs_segs_launch: segment ring");
+    int max_n = 0, max_nh = 0;
+    const int key = segs[first].i0;
+    for (int i = 0; i < cnt; i++) {
+      const xvcgpu_cs_seg &g = segs[first + i];
+      if (g.n < 0 || (kind != XVC_CS_SEG_FETCH && (!g.env || g.env->ctx->device != ctx->device)))
+        return XVCGPU_INVALID_ARGUMENT;
+      if ((kind == XVC_CS_SEG_ME_REFS || kind == XVC_CS_SEG_BI_REFS ||
+           kind == XVC_CS_SEG_AFFINE_REFS) && g.i0 != key)
+        return fail(ctx, XVCGPU_INVALID_ARGUMENT, "cs_segs_launch: one kernel instance per call");
+      CsSegDev &d = a[i];
+      d.n = g.n;
+      d.i0 = g.i0;
+      d.r0 = g.r0;
+      d.r1 = g.r1;
+      for (int k = 0; k < 8; k++) d.p[k] = reinterpret_cast<const void *>(g.p[k]);
+      d.env = g.env ? g.env->dev : nullptr;
+      max_n = std::max(max_n, g.n);
+      max_nh = std::max(max_nh, g.n + (g.p[6] ? g.r0 : 0));
+    }
+    if (max_n == 0) continue;
+    const unsigned gy = (unsigned)cnt;
+    hipStream_t st = ctx->stream;
+    switch (kind) {
+      case XVC_CS_SEG_MC_METRIC_REFS:
+        hipLaunchKernelGGL(cs_seg_mc_metric_kernel, dim3((max_n + 1) / 2, gy), dim3(128), 0, st, a);
+        break;
+      case XVC_CS_SEG_START_FOLD:
+        hipLaunchKernelGGL(cs_seg_start_fold_kernel, dim3(max_n, gy), dim3(64), 0, st, a);
+        break;
+      case XVC_CS_SEG_UNI_FOLD:
+        hipLaunchKernelGGL(cs_seg_uni_fold_kernel, dim3(max_n, gy), dim3(64), 0, st, a);
+        break;
+      case XVC_CS_SEG_BI_FOLD:
+        hipLaunchKernelGGL(cs_seg_bi_fold_kernel, dim3(max_n, gy), dim3(64), 0, st, a);
+        break;
+      case XVC_CS_SEG_MERGE_FOLD:
+        hipLaunchKernelGGL(cs_seg_merge_fold_kernel, dim3((max_n + 63) / 64, gy), dim3(64), 0, st, a);
+        break;
+      case XVC_CS_SEG_ME_REFS: {
+        const int ep = ctx->me_epoch = (ctx->me_epoch + 1) % 3;
+        Me2Sched sched;
+        sched.use = ctx->d_me_rot + ep % 3;
+        sched.record = ctx->d_me_rot + (ep + 1) % 3;
+        sched.clear = ctx->d_me_rot + (ep + 2) % 3;
+#define SEG_ME(MS, PH)                                                                      \
+  hipLaunchKernelGGL((cs_seg_me_kernel<MS, PH>), dim3(me2_grid(max_n, ME2_WAVES(MS)).x, gy), \
+                     dim3(64 * ME2_WAVES(MS)), 0, st, a, ctx->d_tz_pattern, sched)
+        if (key == 16) {
+          SEG_ME(16, 3);
+        } else if (key == 32) {
+          SEG_ME(32, 1);
+          SEG_ME(32, 2);
+        } else if (key == 64) {
+          SEG_ME(64, 1);
+          SEG_ME(64, 2);
+          hipLaunchKernelGGL(cs_seg_me_team_kernel, dim3((max_n + 7) / 8 * 8, gy), dim3(256), 0, st, a);
+        } else {
+          return XVCGPU_INVALID_ARGUMENT;
+        }
+#undef SEG_ME
+        break;
+      }
+      case XVC_CS_SEG_BI_REFS: {
+        const dim3 grid((max_n + 7) / 8 * 8, gy);
+        if (key == 16) hipLaunchKernelGGL(cs_seg_bi_kernel<16>, grid, dim3(64 * BI_WAVES(16)), 0, st, a);
+        else if (key == 32) hipLaunchKernelGGL(cs_seg_bi_kernel<32>, grid, dim3(64 * BI_WAVES(32)), 0, st, a);
+        else if (key == 64) hipLaunchKernelGGL(cs_seg_bi_kernel<64>, grid, dim3(64 * BI_WAVES(64)), 0, st, a);
+        else return XVCGPU_INVALID_ARGUMENT;
+        break;
+      }
+      case XVC_CS_SEG_AFFINE_REFS:
+        if (key == 16) hipLaunchKernelGGL(cs_seg_affine_kernel<1>, dim3(max_n, gy), dim3(64), 0, st, a);
+        else if (key == 32) hipLaunchKernelGGL(cs_seg_affine_kernel<2>, dim3(max_n, gy), dim3(128), 0, st, a);
+        else if (key == 64) hipLaunchKernelGGL(cs_seg_affine_kernel<4>, dim3(max_n, gy), dim3(256), 0, st, a);
+        else return XVCGPU_INVALID_ARGUMENT;
+        break;
+      case XVC_CS_SEG_INTER_PRED:
+        hipLaunchKernelGGL(cs_seg_inter_pred_kernel, dim3(max_n, gy), dim3(256), 0, st, a);
+        break;
+      case XVC_CS_SEG_RESIDUAL_AT:
+        for (int i = 0; i < cnt; i++)
+          if (segs[first + i].n > 64 || !segs[first + i].p[5]) return XVCGPU_INVALID_ARGUMENT;
+        hipLaunchKernelGGL(cs_seg_residual_kernel, dim3(max_nh, gy), dim3(TX_THREADS), 0, st, a,
+                           ctx->d_tx_tables, ctx->d_tx_tables_t, xvcgpu_tx_layout());
+        break;
+      case XVC_CS_SEG_EVAL_DIST:
+        hipLaunchKernelGGL(cs_seg_eval_dist_kernel, dim3((max_n + 3) / 4, gy), dim3(256), 0, st, a);
+        break;
+      case XVC_CS_SEG_FETCH:
+        for (int i = 0; i < cnt; i++)
+          if ((segs[first + i].n & 3) || ((segs[first + i].p[0] | segs[first + i].p[1]) & 3))
+            return XVCGPU_INVALID_ARGUMENT;
+        hipLaunchKernelGGL(cs_seg_fetch_kernel, dim3(8, gy), dim3(256), 0, st, a);
+        break;
+      default:
+        return XVCGPU_INVALID_ARGUMENT;
+    }
+    CHECK_LAUNCH(ctx, "cs_segs_launch");
+  }
+  return XVCGPU_OK;
+}
 
 /* ---- the folds of one SearchMotion chain (k_cu_state.h) ----------------------- */
 xvcgpu_status xvcgpu_cs_start_fold(xvcgpu_ctx *ctx, const xvcgpu_cs_pass *d_passes, int first,

@@ -186,6 +186,22 @@ xvcgpu_status xvcgpu_event_synchronize(xvcgpu_event *ev) {
   return XVCGPU_OK;
 }
 
+xvcgpu_status xvcgpu_event_query(xvcgpu_event *ev, int *done) {
+  if (!ev || !done) return XVCGPU_INVALID_ARGUMENT;
+  const hipError_t e = hipEventQuery(ev->ev);
+  if (e == hipSuccess) {
+    *done = 1;
+    return XVCGPU_OK;
+  }
+  if (e == hipErrorNotReady) {
+    (void)hipGetLastError();
+    *done = 0;
+    return XVCGPU_OK;
+  }
+  CHIP_TRY(ev->ctx, e);
+  return XVCGPU_OK;
+}
+
 xvcgpu_status xvcgpu_comm_unique_id(uint8_t id[XVCGPU_COMM_ID_BYTES]) {
   if (!id) return XVCGPU_INVALID_ARGUMENT;
   static_assert(XVCGPU_COMM_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "id size");

@@ -76,6 +76,13 @@ struct xvcgpu_ctx {
   int rdoq_qp_hint;                // luma QP of the last xvcgpu_fwd_from_me_classify (-1: none)
   int rdoq_prove_zero;             // quant_rdo: the all-zero proof ahead of the walk: 0 / 1 / -1 by batch size
   int intra_waves_grid;            // workgroups of its cooperative launch (0: not determined yet)
+  // xvcgpu_cs_segs_launch: the launches' segment records, page-locked, two halves used in
+  // turn (a half is re-used once the launches that read it have passed: seg_ring_ev)
+  unsigned char *h_seg_ring;
+  size_t seg_ring_pos;
+  int seg_ring_half;
+  hipEvent_t seg_ring_ev[2];
+  bool seg_ring_used[2];
   int rdoq_four_lane_only;         // xvcgpu_quant_rdo_set_four_lane_only: the general class's launch is skipped
   int *h_rdoq_misuse;              // page-locked: set by the walk when such a batch held a general-class block
   // scratch of xvcgpu_quant_rdo_batch (k_rdoq.h): the three class lists + their

@@ -3,6 +3,8 @@
 
 #include <chrono>
 #include <cstring>
+#include <utility>
+#include <vector>
 
 namespace {
 const uint32_t kEntropyBits[128] = {
@@ -426,5 +428,256 @@ extern "C" int xvc_host_cs_run_programs_interleaved(int k, xvcgpu_ctx *const *ct
   if (st != XVCGPU_OK)
     for (int c = 0; c < k; c++) xvcgpu_sync(ctxs[c]);
   stats->seconds = Now() - t0;
+  return st;
+}
+
+// ---- the engine: many chains, one launch per step kind -----------------------------------
+// k recorded programs on ONE context (one stream).  A round takes every chain's next step,
+// groups the steps by kind (and kernel instance) and issues one xvcgpu_cs_segs_launch per
+// group - the chains' jobs side by side in the grid's y - so the launch path carries
+// (kinds per round) launches for k chain steps instead of k.  A chain's steps stay in order
+// because a round issues at most one launch-step per chain and the stream is in order; a
+// chain that reaches its SYNC records an event and sits out until the event has passed
+// (the others keep the device busy).  Steps without a batched form are issued as they are.
+namespace {
+int SegKindOf(const xvc_cs_op &o) {
+  switch (o.opcode) {
+    case XVC_OP_MC_METRIC_REFS: return XVC_CS_SEG_MC_METRIC_REFS;
+    case XVC_OP_START_FOLD: return XVC_CS_SEG_START_FOLD;
+    case XVC_OP_UNI_FOLD: return XVC_CS_SEG_UNI_FOLD;
+    case XVC_OP_BI_FOLD: return XVC_CS_SEG_BI_FOLD;
+    case XVC_OP_MERGE_FOLD: return XVC_CS_SEG_MERGE_FOLD;
+    case XVC_OP_ME_REFS: return XVC_CS_SEG_ME_REFS;
+    case XVC_OP_BI_REFS: return XVC_CS_SEG_BI_REFS;
+    case XVC_OP_AFFINE_REFS: return XVC_CS_SEG_AFFINE_REFS;
+    case XVC_OP_INTER_PRED: return o.r1 == 2 ? XVC_CS_SEG_INTER_PRED : -1;   // into s_pred
+    case XVC_OP_RESIDUAL: return o.p[5] ? XVC_CS_SEG_RESIDUAL_AT : -1;
+    case XVC_OP_EVAL_DIST: return o.r0 == 1 ? XVC_CS_SEG_EVAL_DIST : -1;
+    default: return -1;
+  }
+}
+}  // namespace
+
+// how long a kind's launch lasts, roughly (to deal the groups of a round over the streams)
+static int SegWeight(int kind, int key) {
+  switch (kind) {
+    case XVC_CS_SEG_BI_REFS: return key >= 64 ? 80 : (key >= 32 ? 36 : 22);
+    case XVC_CS_SEG_AFFINE_REFS: return 60;
+    case XVC_CS_SEG_RESIDUAL_AT: return 45;
+    case XVC_CS_SEG_ME_REFS: return key >= 64 ? 50 : (key >= 32 ? 30 : 13);
+    default: return 9;
+  }
+}
+
+extern "C" int xvc_host_cs_run_programs_engine(xvcgpu_ctx *const *ctxs, int n_ctx, int k,
+                                               const xvc_cs_env *const *envs,
+                                               const xvc_cs_op *const *ops, const int64_t *n_ops,
+                                               xvc_cs_stats *stats) {
+  if (!ctxs || n_ctx < 1 || n_ctx > 8 || k < 1 || k > 256 || !envs || !ops || !n_ops || !stats)
+    return XVCGPU_INVALID_ARGUMENT;
+  for (int i = 0; i < n_ctx; i++)
+    if (!ctxs[i]) return XVCGPU_INVALID_ARGUMENT;
+  xvcgpu_ctx *ctx = ctxs[0];
+  std::memset(stats, 0, sizeof(*stats));
+  std::vector<xvcgpu_cs_env *> denv(k, nullptr);
+  std::vector<xvcgpu_event *> round_ev(n_ctx, nullptr);
+  xvcgpu_status st = XVCGPU_OK;
+  for (int c = 0; c < k && st == XVCGPU_OK; c++) {
+    const xvc_cs_env *e = envs[c];
+    st = xvcgpu_cs_env_create(ctx, e->orig, e->refs, e->n_refs, e->s_orig, e->s_pred, e->s_rec,
+                              e->d_levels, e->d_results, &denv[c]);
+  }
+  for (int i = 0; i < n_ctx && st == XVCGPU_OK; i++) {
+    st = xvcgpu_event_create(ctxs[i], &round_ev[i]);
+    if (st == XVCGPU_OK) st = xvcgpu_sync(ctxs[i]);
+  }
+  std::vector<int64_t> at(k, 0), wait_states(k, -1);
+  // groups of a round: kind x kernel instance (i0 of the searches)
+  struct Group {
+    int kind, key;
+    std::vector<xvcgpu_cs_seg> segs;
+  };
+  std::vector<Group> groups;
+  std::vector<int> order, syncs;
+  std::vector<xvcgpu_cs_seg> fetches;
+  std::vector<char> fetched(k, 0);
+  const double t0 = Now();
+  int live = k;
+  bool used_last[8] = {false}, used_now[8] = {false}, met[8] = {false};
+  // the chains that reach their SYNC in one round share its event (one record, one query)
+  const int kSyncEvents = 64;
+  std::vector<xvcgpu_event *> sync_ev(kSyncEvents, nullptr);
+  std::vector<int> sync_waiters(kSyncEvents, 0), qcache(kSyncEvents, -1), ev_of(k, -1);
+  for (int i = 0; i < kSyncEvents && st == XVCGPU_OK; i++) st = xvcgpu_event_create(ctx, &sync_ev[i]);
+  int qcache_round = 0, sync_next = 0;
+  std::vector<int> qcache_at(kSyncEvents, -1);
+  auto Meet = [&](int t) -> xvcgpu_status {
+    if (met[t]) return XVCGPU_OK;
+    met[t] = true;
+    for (int sidx = 0; sidx < n_ctx; sidx++)
+      if (sidx != t && used_last[sidx]) {
+        const xvcgpu_status r = xvcgpu_event_wait(ctxs[t], round_ev[sidx]);
+        if (r != XVCGPU_OK) return r;
+      }
+    return XVCGPU_OK;
+  };
+  while (live > 0 && st == XVCGPU_OK) {
+    live = 0;
+    bool issued = false;
+    int first_waiting = -1;
+    for (Group &g : groups) g.segs.clear();
+    fetches.clear();
+    syncs.clear();
+    // The streams meet between rounds: a chain's step of this round may run on another
+    // stream than its step of the last one (a round's groups are dealt over the streams so
+    // that a long search does not hold the others up)
+    // (a stream waits for the streams that had work in the last round when it gets its first
+    // launch of this one: Meet below)
+    for (int t = 0; t < n_ctx; t++) {
+      used_last[t] = used_now[t];
+      used_now[t] = false;
+      met[t] = false;
+    }
+    qcache_round++;
+    for (int c = 0; c < k && st == XVCGPU_OK; c++) {
+      if (wait_states[c] >= 0) {           // at its SYNC: has the event passed?
+        int done = 0;
+        const int e = ev_of[c];
+        if (qcache_at[e] != qcache_round) {
+          st = xvcgpu_event_query(sync_ev[e], &qcache[e]);
+          if (st != XVCGPU_OK) break;
+          qcache_at[e] = qcache_round;
+        }
+        done = qcache[e];
+        if (!done) {
+          if (first_waiting < 0) first_waiting = c;
+          live++;
+          continue;
+        }
+        stats->round_trips++;
+        stats->states += wait_states[c];
+        wait_states[c] = -1;
+        sync_waiters[e]--;
+      }
+      while (at[c] < n_ops[c] && st == XVCGPU_OK) {
+        const xvc_cs_op &o = ops[c][at[c]];
+        if (o.opcode == XVC_OP_SYNC) {     // (behind the chain's read-backs: stream 0, below)
+          syncs.push_back(c);
+          wait_states[c] = o.i0;
+          at[c]++;
+          issued = true;
+          break;
+        }
+        if (o.opcode == XVC_OP_FETCH) {
+          // behind the chain's last launch (an earlier round).  The round's read-backs are
+          // one launch of their own, on stream 0 in front of the SYNC events
+          if ((o.n & 3) || ((o.p[0] | o.p[1]) & 3)) {
+            st = IssueOp(ctx, envs[c], o);
+          } else {
+            xvcgpu_cs_seg sg;
+            std::memset(&sg, 0, sizeof(sg));
+            sg.n = o.n;
+            sg.p[0] = o.p[0];
+            sg.p[1] = o.p[1];
+            fetches.push_back(sg);
+          }
+          at[c]++;
+          fetched[c] = true;
+          continue;
+        }
+        const int kind = SegKindOf(o);
+        if (kind < 0) {                    // no batched form: as it is
+          st = IssueOp(ctxs[c % n_ctx], envs[c], o);
+          stats->api_calls++;
+        } else {
+          const int key = (kind == XVC_CS_SEG_ME_REFS || kind == XVC_CS_SEG_BI_REFS ||
+                           kind == XVC_CS_SEG_AFFINE_REFS) ? o.i0 : 0;
+          Group *grp = nullptr;
+          for (Group &g : groups)
+            if (g.kind == kind && g.key == key) grp = &g;
+          if (!grp) {
+            groups.push_back(Group());
+            grp = &groups.back();
+            grp->kind = kind;
+            grp->key = key;
+          }
+          xvcgpu_cs_seg sg;
+          sg.n = o.n;
+          sg.i0 = o.i0;
+          sg.r0 = o.r0;
+          sg.r1 = o.r1;
+          for (int q = 0; q < 8; q++) sg.p[q] = o.p[q];
+          sg.env = denv[c];
+          grp->segs.push_back(sg);
+        }
+        at[c]++;
+        issued = true;
+        break;                             // one launch step per chain and round
+      }
+      if (wait_states[c] >= 0 || at[c] < n_ops[c]) live++;
+    }
+    // the round's read-backs, then the events of the chains that wait for them
+    if ((!fetches.empty() || !syncs.empty()) && st == XVCGPU_OK) st = Meet(0);
+    if (!fetches.empty() && st == XVCGPU_OK) {
+      st = xvcgpu_cs_segs_launch(ctx, XVC_CS_SEG_FETCH, fetches.data(), static_cast<int>(fetches.size()));
+      stats->api_calls++;
+      used_now[0] = true;
+    }
+    if (!syncs.empty() && st == XVCGPU_OK) {
+      int e = -1;
+      for (int tries = 0; tries < kSyncEvents && e < 0; tries++) {
+        const int cand = (sync_next + tries) % kSyncEvents;
+        if (sync_waiters[cand] == 0) e = cand;
+      }
+      if (e < 0) {
+        st = XVCGPU_DEVICE_ERROR;          // (k <= 256 chains can hold 64 events only if they
+      } else {                             //  all wait, and then nothing reaches a SYNC)
+        sync_next = (e + 1) % kSyncEvents;
+        st = xvcgpu_event_record(ctx, sync_ev[e]);
+        qcache_at[e] = -1;
+        for (size_t i = 0; i < syncs.size(); i++) ev_of[syncs[i]] = e;
+        sync_waiters[e] = static_cast<int>(syncs.size());
+      }
+    }
+    // the round's groups, the long ones first, dealt over the streams (least loaded next)
+    order.clear();
+    for (size_t i = 0; i < groups.size(); i++)
+      if (!groups[i].segs.empty()) order.push_back(static_cast<int>(i));
+    for (size_t i = 1; i < order.size(); i++)
+      for (size_t j2 = i; j2 > 0 && SegWeight(groups[order[j2]].kind, groups[order[j2]].key) >
+                                      SegWeight(groups[order[j2 - 1]].kind, groups[order[j2 - 1]].key);
+           j2--)
+        std::swap(order[j2], order[j2 - 1]);
+    int load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (size_t i = 0; i < order.size() && st == XVCGPU_OK; i++) {
+      Group &g = groups[order[i]];
+      int s_min = 0;
+      for (int t = 1; t < n_ctx; t++)
+        if (load[t] < load[s_min]) s_min = t;
+      load[s_min] += SegWeight(g.kind, g.key);
+      st = Meet(s_min);
+      used_now[s_min] = true;
+      if (st == XVCGPU_OK) st = xvcgpu_cs_segs_launch(ctxs[s_min], g.kind, g.segs.data(), static_cast<int>(g.segs.size()));
+      stats->api_calls++;
+    }
+    if (n_ctx > 1)
+      for (int t = 0; t < n_ctx && st == XVCGPU_OK; t++)
+        if (used_now[t]) st = xvcgpu_event_record(ctxs[t], round_ev[t]);
+    // every chain waits for the device: wait for one of them instead of spinning
+    if (!issued && first_waiting >= 0 && st == XVCGPU_OK)
+      st = xvcgpu_event_synchronize(sync_ev[ev_of[first_waiting]]);
+  }
+  for (int i = 0; i < n_ctx; i++) {
+    const xvcgpu_status s2 = xvcgpu_sync(ctxs[i]);
+    if (st == XVCGPU_OK) st = s2;
+  }
+  stats->seconds = Now() - t0;
+  for (int c = 0; c < k; c++) {
+    if (denv[c]) xvcgpu_cs_env_destroy(denv[c]);
+  }
+  for (int i = 0; i < n_ctx; i++)
+    if (round_ev[i]) xvcgpu_event_destroy(round_ev[i]);
+  for (int i = 0; i < kSyncEvents; i++)
+    if (sync_ev[i]) xvcgpu_event_destroy(sync_ev[i]);
   return st;
 }

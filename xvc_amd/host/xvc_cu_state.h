@@ -147,6 +147,13 @@ int xvc_host_cs_run_programs_interleaved(int k, xvcgpu_ctx *const *ctxs,
                                          const xvc_cs_env *const *envs,
                                          const xvc_cs_op *const *ops, const int64_t *n_ops,
                                          xvc_cs_stats *stats);
+// k recorded programs through the engine: every round the chains' next steps grouped by
+// kind, one xvcgpu_cs_segs_launch per kind, the round's groups dealt over the n_ctx streams
+// (contexts on one device; they meet between rounds by events); k <= 256, n_ctx <= 8
+int xvc_host_cs_run_programs_engine(xvcgpu_ctx *const *ctxs, int n_ctx, int k,
+                                    const xvc_cs_env *const *envs,
+                                    const xvc_cs_op *const *ops, const int64_t *n_ops,
+                                    xvc_cs_stats *stats);
 
 // The states [first, first + n) walked ONE AT A TIME with the batched entry points as
 // they are: every step a batch of one CU, a read-back (copy + wait) wherever the
