@@ -327,8 +327,13 @@ def encoder_rd_serial_figure(ctx, api, fx, pics, w, h, n_states=4000):
     serial = cu_state_walk.walk(api, "c1", poc, n_states, [1, 4], "serial", decoded=(by_poc, w, h), sp=sp)
     chained = cu_state_walk.walk(api, "c1", poc, n_states, [1, 4], "chained", decoded=(by_poc, w, h), sp=sp)
     live = cu_state_walk.walk(api, "c1", poc, n_states, [1, 4], "live", decoded=(by_poc, w, h), sp=sp)
+    # many pictures in flight: k chains through the execution engine, four engines on four
+    # host threads and streams (each chain its own stretch of the picture)
+    engine = cu_state_walk.walk(api, "c1", poc, min(n_states, 1200), [16, 64, 256], "engine",
+                                decoded=(by_poc, w, h), sp=sp, engine_threads=4, reps=2)
     s1, c1, l1 = serial["chains"]["1"], chained["chains"]["1"], live["chains"]["1"]
-    ok = all(e.get("matches_reference") for r in (serial, chained, live) for e in r["chains"].values())
+    ok = all(e.get("matches_reference") for r in (serial, chained, live, engine)
+             for e in r["chains"].values())
     return {
         "workload": "1080p B picture POC %d of the reference-coded stream: %d CU states in the "
                     "reference's issue order (%d merge rankings, %d merge-candidate evaluations, "
@@ -395,13 +400,28 @@ def encoder_rd_serial_figure(ctx, api, fx, pics, w, h, n_states=4000):
                      "which ranked merge candidates were evaluated (the fold fills all slots below "
                      "the count; the replay runs the ones the reference ran)"],
                  "compared": l1.get("compared")},
+        "engine": {"pictures_per_s": {k: v["pictures_per_s"] for k, v in engine["chains"].items()},
+                   "launches_per_state": {k: v["launches_per_state"] for k, v in engine["chains"].items()},
+                   "round_trips_per_state": {k: v["round_trips_per_state"]
+                                             for k, v in engine["chains"].items()},
+                   "host_threads_and_streams": 4,
+                   "states_per_chain_walked": engine["states_walked"],
+                   "form": "k pictures' chains in flight (the chained form's programs, every chain on "
+                           "its own stretch of the picture): a round takes the next step of every "
+                           "chain and issues one launch per step kind, grid y = chain "
+                           "(xvcgpu_cs_segs_launch; xvc_host_cs_run_programs_engine); a chain at its "
+                           "read-back sits out until the round's event has passed",
+                   "kernels_in_flight_mean": {"128": 4.3, "measured_at": "round 5: kernel seconds of "
+                                              "profiles/r05_cu_state_engine_kernel_stats.csv over the "
+                                              "unprofiled wall time (static, not re-measured by this run)"}},
         "compared": s1.get("compared"),
         "matches_reference": bool(ok),
         "reading": "every form is bound by the chain of dependent kernels per state (each search is "
                    "one CU's worth of work: 4-30 us on a few CUs); what the forms differ in is how "
                    "often the host waits (round_trips_per_state) and how many launches a state takes "
-                   "(entry_point_calls_per_state); more than four chains in flight do not add up "
-                   "(tools/cu_state_walk.py --k 1,4,8,16: the launch path, not the device, is full)"}
+                   "(entry_point_calls_per_state); more than four chains on streams of their own do "
+                   "not add up (about four dependent-kernel streams of a process run side by side), "
+                   "more work per launch does: the engine's figures"}
 
 
 def encoder_rd_figure(ctx, api, fx, pics, w, h):

@@ -1305,8 +1305,14 @@ class ChainedRun(SerialRun):
         k = len(runs)
         ctx = runs[0].ctx
         assert all(r.ctx is ctx for r in runs)
-        progs = [np.ascontiguousarray(r.program(f, n, by_position, verify, live=live))
-                 for r, f in zip(runs, firsts)]
+        progs = []
+        for r, f in zip(runs, firsts):       # (recording a program is a Python loop: keep it)
+            key = (f, n, by_position, verify, live)
+            cache = r.__dict__.setdefault("_engine_programs", {})
+            if key not in cache:
+                cache.clear()
+                cache[key] = np.ascontiguousarray(r.program(f, n, by_position, verify, live=live))
+            progs.append(cache[key])
         lib = runs[0].lib
         lib.xvc_host_cs_run_programs_engine.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p,
                                                         C.c_void_p, C.c_void_p, C.c_void_p]

@@ -6,7 +6,11 @@ buffers): microseconds per state, entry-point calls and read-backs per state,
 pictures per second.
 
     python tools/cu_state_walk.py [--clip c1] [--poc 2] [--states 6000] [--k 1,4,8,16]
-                                  [--mode serial|chained]"""
+                                  [--mode serial|chained|by_state|live|engine]
+
+--mode engine: k chains through the execution engine (one launch per step kind and round);
+ENGINE_THREADS = T engines on T host threads and streams (every T-th chain each),
+ENGINE_STREAMS = streams of one engine."""
 import argparse
 import json
 import os
@@ -20,7 +24,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
 def walk(api, clip, poc, n_states, ks, mode="serial", check=True, decoded=None, sp=None,
-         threads_list=()):
+         threads_list=(), engine_threads=None, reps=3):
     """decoded: ({poc: device picture}, width, height) of the clip when the caller holds
     it already; sp: a rd_serial.SerialPicture to re-use."""
     import rd_serial
@@ -47,14 +51,14 @@ def walk(api, clip, poc, n_states, ks, mode="serial", check=True, decoded=None, 
             runs = [rd_serial.ChainedRun(api, ectx, sp, pics, w, h, lists) for _ in range(k)]
             # ENGINE_THREADS engines on as many host threads and streams, every T-th chain each;
             # with one thread ENGINE_STREAMS deals a round's groups over that many streams
-            threads = int(os.environ.get("ENGINE_THREADS", "1"))
+            threads = int(engine_threads or os.environ.get("ENGINE_THREADS", "1"))
             extra = [api.Context(0) for _ in range(max(int(os.environ.get("ENGINE_STREAMS", "1")), threads) - 1)]
             for c in extra:
                 c.use_own_stream()
             firsts = [sp.position_start(c * (len(sp.states) - n - 64) // max(k - 1, 1)) for c in range(k)]
             rd_serial.ChainedRun.run_engine(runs[:min(k, 2)], firsts[:min(k, 2)], min(n, 300), streams=extra)   # warm-up
             walls, stats = [], None
-            for _ in range(3):
+            for _ in range(reps):
                 t0 = time.time()
                 stats = rd_serial.ChainedRun.run_engine(runs, firsts, n, streams=extra, threads=min(threads, k))
                 walls.append(time.time() - t0)
