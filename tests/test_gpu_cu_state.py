@@ -117,16 +117,19 @@ def test_live_chains_equal_reference(gpu, name, poc, n_states):
     assert 0.5 * stats.states < stats.round_trips < 2 * stats.states
 
 
-@pytest.mark.parametrize("name,poc,k,n,threads", [("tiny", 2, 5, 1500, 1), ("c1", 2, 8, 1500, 1),
-                                                  ("c1", 2, 9, 1200, 3)])
-def test_engine_chains_equal_reference(gpu, name, poc, k, n, threads):
+@pytest.mark.parametrize("name,poc,k,n,threads,live", [("tiny", 2, 5, 1500, 1, False),
+                                                       ("c1", 2, 8, 1500, 1, False),
+                                                       ("c1", 2, 9, 1200, 3, False),
+                                                       ("c1", 2, 8, 1000, 2, True)])
+def test_engine_chains_equal_reference(gpu, name, poc, k, n, threads, live):
     """k chains on ONE context through the engine (xvc_host_cs_run_programs_engine): every
     round the chains' next steps grouped by kind, one launch per kind with the chains' jobs
     side by side in the grid (xvcgpu_cs_segs_launch) - each chain walks its own stretch of
     the picture, so their steps do not line up.  threads = 1: a round's groups dealt over
     three streams; threads = 3: three engines on three host threads, a stream and every
-    third chain each.  Every chain's results equal the reference's, and the launches are
-    fewer than the steps."""
+    third chain each.  live: the chains a live encoder could issue (a wait wherever the host's
+    entropy coder decides).  Every chain's results equal the reference's, and the launches
+    are fewer than the steps."""
     api, ctx = gpu
     fx = sf.StreamFixture(name)
     pics, w, h = decode_stream(ctx, fx)
@@ -141,8 +144,8 @@ def test_engine_chains_equal_reference(gpu, name, poc, k, n, threads):
     for c in more:
         c.use_own_stream()
     stats = rd_serial.ChainedRun.run_engine(runs, firsts, n, by_position=True, verify=True, streams=more,
-                                            threads=threads)
-    steps = sum(int((r.program(f, n, True, True)["opcode"] != rd_serial.OP_SYNC).sum())
+                                            threads=threads, live=live)
+    steps = sum(int((r.program(f, n, True, True, live=live)["opcode"] != rd_serial.OP_SYNC).sum())
                 for r, f in zip(runs, firsts))
     print(name, "engine k=%d: %d states, %d launches for %d steps, %.1f us per state" % (
         k, stats.states, stats.api_calls, steps, 1e6 * stats.seconds / max(stats.states, 1)))

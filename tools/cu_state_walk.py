@@ -24,7 +24,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
 def walk(api, clip, poc, n_states, ks, mode="serial", check=True, decoded=None, sp=None,
-         threads_list=(), engine_threads=None, reps=3):
+         threads_list=(), engine_threads=None, reps=3, engine_live=None):
     """decoded: ({poc: device picture}, width, height) of the clip when the caller holds
     it already; sp: a rd_serial.SerialPicture to re-use."""
     import rd_serial
@@ -52,15 +52,18 @@ def walk(api, clip, poc, n_states, ks, mode="serial", check=True, decoded=None, 
             # ENGINE_THREADS engines on as many host threads and streams, every T-th chain each;
             # with one thread ENGINE_STREAMS deals a round's groups over that many streams
             threads = int(engine_threads or os.environ.get("ENGINE_THREADS", "1"))
+            # ENGINE_LIVE: the chains a live encoder could issue (a wait wherever the host's
+            # entropy coder decides) instead of one chain per visit of a CU position
+            elive = bool(int(os.environ.get("ENGINE_LIVE", "0"))) if engine_live is None else bool(engine_live)
             extra = [api.Context(0) for _ in range(max(int(os.environ.get("ENGINE_STREAMS", "1")), threads) - 1)]
             for c in extra:
                 c.use_own_stream()
             firsts = [sp.position_start(c * (len(sp.states) - n - 64) // max(k - 1, 1)) for c in range(k)]
-            rd_serial.ChainedRun.run_engine(runs[:min(k, 2)], firsts[:min(k, 2)], min(n, 300), streams=extra)   # warm-up
+            rd_serial.ChainedRun.run_engine(runs[:min(k, 2)], firsts[:min(k, 2)], min(n, 300), streams=extra, live=elive)   # warm-up
             walls, stats = [], None
             for _ in range(reps):
                 t0 = time.time()
-                stats = rd_serial.ChainedRun.run_engine(runs, firsts, n, streams=extra, threads=min(threads, k))
+                stats = rd_serial.ChainedRun.run_engine(runs, firsts, n, streams=extra, threads=min(threads, k), live=elive)
                 walls.append(time.time() - t0)
             # (the wall time holds the Python loop that records the programs; the engine's own
             # clock starts when the first step is issued)
@@ -72,7 +75,8 @@ def walk(api, clip, poc, n_states, ks, mode="serial", check=True, decoded=None, 
                      "states": int(stats.states)}
             if check:
                 runs_c = runs[:min(k, 4)]
-                rd_serial.ChainedRun.run_engine(runs, firsts, n, verify=True, streams=extra, threads=min(threads, k))
+                rd_serial.ChainedRun.run_engine(runs, firsts, n, verify=True, streams=extra, threads=min(threads, k),
+                                                live=elive)
                 ok = True
                 for r, f in zip(runs_c, firsts):
                     res = r.check(f, n, searches=False)
@@ -82,6 +86,7 @@ def walk(api, clip, poc, n_states, ks, mode="serial", check=True, decoded=None, 
             out["chains"][str(k)] = entry
             entry["streams"] = 1 + len(extra)
             entry["host_threads"] = min(threads, k)
+            entry["live"] = elive
             for r in runs:
                 r.destroy()
             for c in extra:
