@@ -40,7 +40,10 @@ STATE_DTYPE = np.dtype([
     ("copy_first", "<i4"),              # originals: [3 (slot 0)] [pass 0 calls] [pass 1 calls]
     ("cand_first", "<i4"), ("cand_count", "<i4"),
     ("final_first", "<i4"), ("final_count", "<i4"),
+    ("nb_first", "<i4"), ("nb_count", "<i4"),   # LIC: block copies staging the neighbours
     ("level_first", "<i8"), ("level_count", "<i8")], align=True)
+STATE_LIC = 2        # flags: the CU tries local illumination compensation
+NB_WIDTH = 1024      # luma width of the neighbour staging picture
 
 
 def _stream(seq):
@@ -187,6 +190,7 @@ class SerialPicture:
 
         st = np.zeros(len(S), STATE_DTYPE)
         me_idx, bi_idx, aff_idx, mg_idx = [], [], [], []
+        nb_of_state = {}        # LIC state -> neighbour records (capture order)
         ev_states = []          # (state index, eval index)
         call_idx = []
         n_copy = 0
@@ -240,8 +244,18 @@ class SerialPicture:
                 r["level_first"], r["level_count"] = level_pos, sum(sizes)
                 level_pos += sum(sizes)
             if lic:
-                r["supported"] = 0      # local illumination compensation: not in this replay
+                # local illumination compensation: the model reads the reconstruction of
+                # THAT MOMENT above / left of the CU (the capture's neighbour records)
+                r["flags"] = int(r["flags"]) | STATE_LIC
+                ks = [int(steps[i]["nb_index"]) for i in s["steps"] if steps[i]["flags"] & rf.FLAG_LIC]
+                if s["kind"] == KIND_MERGE_RANK and merges[s["merge"]]["use_lic"].any():
+                    ks.append(int(merges[s["merge"]]["nb_index"]))
+                if s["ev"] >= 0 and (ev_tab[s["ev"]]["flags"] & rf.FLAG_LIC):
+                    ks.append(int(ev_tab[s["ev"]]["nb_index"]))
+                assert all(k >= 0 for k in ks), (n, ks)
+                nb_of_state[n] = list(dict.fromkeys(ks))
         self.states = st
+        self._stage_neighbours(nb_of_state)
         self.n_levels = level_pos
 
         i_ = np.asarray
@@ -271,6 +285,8 @@ class SerialPicture:
         self.bi_ref = np.array([[slot[int(p)], slot[int(q)]] for p, q in
                                 zip(b["ref_poc"], b["other_ref_poc"])], np.int8).reshape(-1, 2)
         self.bi_want = b
+        self.bi_lic = self._lic_blocks(b["x"], b["y"], b["w"], b["h"],
+                                       np.where((b["flags"] & rf.FLAG_LIC) != 0, b["nb_index"], -1))
         # -- affine searches
         a = steps[i_(aff_idx, np.int64)] if aff_idx else steps[:0]
         self.aff_jobs = np.zeros(len(a), api.AFFINE_ME_DTYPE)
@@ -296,6 +312,7 @@ class SerialPicture:
             used = (g["inter_dir"] == 2) | (g["inter_dir"] == l)
             j["ref"][:, :, l] = np.where(used, np.vectorize(lambda p: slot.get(int(p), -1))(g["ref_poc"][:, :, l]), -1)
         j["mv"][:, :, :, 0, :] = g["mv"]
+        self._lic_fields(j, g["use_lic"] != 0, np.repeat(g["nb_index"][:, None], 5, 1))
         self.mg_dst = np.zeros((n, 5), api.POS_DTYPE)
         self.mg_dst["x"] = SLOT * np.arange(5)[None, :]
         self.mg_copy = np.zeros((n, 5), api.COPY_BLOCK_DTYPE)
@@ -323,6 +340,8 @@ class SerialPicture:
                 jc["ref"][:, l] = np.where(used, [slot.get(int(p), -1) for p in e["ref_poc"][:, l]], -1)
             jc["mv"] = e["mv"]
             j[:, c] = jc
+        self._lic_fields(j, np.repeat(((e["flags"] & rf.FLAG_LIC) != 0)[:, None], 3, 1),
+                         np.repeat(e["nb_index"][:, None], 3, 1))
         self.ev_dst = np.zeros((ne, 3), api.POS_DTYPE)      # slot 0
         self.ev_weight = qps["dist_weight"][e["qp_index"]] if ne else np.zeros((0, 3))
         self.ev_ctx = e["ctx_index"].astype(np.int32)
@@ -398,6 +417,100 @@ class SerialPicture:
             self.copy_orig[f + 3:f + 3 + k] = o
         self.contexts = np.ascontiguousarray(rd["contexts"]).view(api.RDOQ_CTX_DTYPE).reshape(-1)
 
+    # ---- local illumination compensation ----------------------------------------------
+    def _nb_table(self):
+        nb = self.rd["neighbours"]
+        return nb if len(nb) else np.zeros(1, nb.dtype)      # (a clip without LIC CUs)
+
+    def _lic_fields(self, jobs, lic, nb_index):
+        """XVC_INTER_LIC + the neighbour fields of xvcgpu_inter_block for the jobs with lic
+        (arrays of the jobs' shape)."""
+        nb = self._nb_table()
+        has = lic & (nb_index >= 0)
+        k = np.where(has, nb_index, 0)
+        jobs["flags"] = jobs["flags"] | np.where(lic, self.api.INTER_LIC, 0).astype(np.uint8)
+        jobs["neighbors"] = np.where(has, nb["has_above"][k] * 1 + nb["has_left"][k] * 2, 0)
+        for f in ("above_x", "above_y", "left_x", "left_y"):
+            jobs[f] = np.where(has, nb[f][k], 0)
+
+    def _lic_blocks(self, x, y, w, h, nb_index):
+        """xvcgpu_mc_lic_block per job (xvcgpu_bipred_search_lic's d_neighbours)."""
+        nb = self._nb_table()
+        q = np.zeros(len(x), self.api.LIC_DTYPE)
+        has = nb_index >= 0
+        k = np.where(has, nb_index, 0)
+        q["x"], q["y"], q["w"], q["h"] = x, y, w, h
+        q["neighbors"] = np.where(has, nb["has_above"][k] * 1 + nb["has_left"][k] * 2, 0)
+        for f in ("above_x", "above_y", "left_x", "left_y"):
+            q[f] = np.where(has, nb[f][k], 0)
+        return q
+
+    def _stage_neighbours(self, nb_of_state):
+        """The rows above / columns left of the LIC states' CUs as the capture holds them,
+        laid out in a staging picture (rows as rows, columns as columns: every strip one
+        xvcgpu_copy_block into the chain's reconstruction picture at the CU's place), and
+        per state the range of its block copies."""
+        api, st = self.api, self.states
+        nb, smp = self.rd["neighbours"], self.rd["nb_samples"]
+        used = sorted(set(k for ks in nb_of_state.values() for k in ks))
+        W = [NB_WIDTH, NB_WIDTH // 2]
+        row_cur = [[0, 0], [0, 0]]          # [luma / chroma] -> (x, y) of the next row strip
+        col_cur = [[0, 0], [0, 0]]          # -> (column, band) of the next column strip
+        place = {}                          # record -> [(comp, above?, px, py, n)]  (py of columns: band)
+        for k in used:
+            r = nb[k]
+            out = []
+            for cls in range(2):
+                w, h = int(r["w"]) >> cls, int(r["h"]) >> cls
+                if r["has_above"]:
+                    if row_cur[cls][0] + w > W[cls]:
+                        row_cur[cls] = [0, row_cur[cls][1] + 1]
+                    out.append((cls, True, row_cur[cls][0], row_cur[cls][1], w))
+                    row_cur[cls][0] += w
+                if r["has_left"]:
+                    if col_cur[cls][0] >= W[cls]:
+                        col_cur[cls] = [0, col_cur[cls][1] + 1]
+                    out.append((cls, False, col_cur[cls][0], col_cur[cls][1], h))
+                    col_cur[cls][0] += 1
+            place[k] = out
+        rows = [row_cur[c][1] + 1 for c in range(2)]
+        bands = [col_cur[c][1] + 1 for c in range(2)]
+        band_h = [64, 32]
+        height = max(rows[0] + 64 * bands[0], 2 * (rows[1] + 32 * bands[1]))
+        height = (height + 63) // 64 * 64
+        planes = [np.zeros((height, NB_WIDTH), np.uint16), np.zeros((height // 2, NB_WIDTH // 2), np.uint16),
+                  np.zeros((height // 2, NB_WIDTH // 2), np.uint16)]
+        copies = {}
+        for k in used:
+            r = nb[k]
+            off = int(r["sample_off"])
+            pl = {(cls, ab): (px, py, n) for cls, ab, px, py, n in place[k]}
+            jobs = []
+            for c in range(3):
+                cls = 1 if c else 0
+                x, y = int(r["x"]) >> cls, int(r["y"]) >> cls
+                if r["has_above"]:
+                    px, py, n = pl[(cls, True)]
+                    planes[c][py, px:px + n] = smp[off:off + n]
+                    off += n
+                    jobs.append((px, py, x, y - 1, n, 1, c, 0))
+                if r["has_left"]:
+                    px, band, n = pl[(cls, False)]
+                    py = rows[cls] + band_h[cls] * band
+                    planes[c][py:py + n, px] = smp[off:off + n]
+                    off += n
+                    jobs.append((px, py, x - 1, y, 1, n, c, 0))
+            assert off - int(r["sample_off"]) == int(r["sample_count"]), (k, off, r)
+            copies[k] = jobs
+        all_jobs = []
+        for n in sorted(nb_of_state):
+            st["nb_first"][n] = len(all_jobs)
+            for k in nb_of_state[n]:
+                all_jobs += copies[k]
+            st["nb_count"][n] = len(all_jobs) - st["nb_first"][n]
+        self.nb_copy = np.array(all_jobs, api.COPY_BLOCK_DTYPE) if all_jobs else np.zeros(0, api.COPY_BLOCK_DTYPE)
+        self.nb_planes, self.nb_height = planes, height
+
     def position_start(self, i):
         """The first state at or behind i that opens a visit of a CU position (a stretch of
         states cut anywhere else would start inside a chain: its first states read what
@@ -427,7 +540,7 @@ class CsTables(C.Structure):
             "d_contexts", "d_copy_orig", "d_call_tx", "d_call_prm", "d_call_off",
             "d_call_copy_pred", "d_call_cand", "d_levels", "d_nnz", "d_call_dist", "h_me_res",
             "h_bi_res", "h_aff_res", "h_mg_dist", "h_ev_dz_dist", "h_call_dist", "h_nnz",
-            "h_levels")]
+            "h_levels", "rec", "nb", "d_nb_copy", "d_bi_lic")]
 
 
 class CsStats(C.Structure):
@@ -450,6 +563,11 @@ class SerialRun:
         self.orig = ctx.picture(width, height, 10)
         self.orig.upload(original_planes(width, height, sp.poc), BL)
         self.scratch = [ctx.picture(SLOT * MAX_SLOTS, 64, 10) for _ in range(3)]
+        # LIC states: the chain's reconstruction picture (only the rows above / columns left
+        # of such CUs are ever written: staged from `nb` in front of the state's jobs)
+        self.rec = ctx.picture(width, height, 10)
+        self.nb = ctx.picture(NB_WIDTH, sp.nb_height, 10)
+        self.nb.upload(sp.nb_planes)
         self.refs = [pics[p] for p in sp.ref_pocs]
         self._ref_arr = (C.c_void_p * len(self.refs))(*[r.h_pic for r in self.refs])
         self._keep, self._pinned = [], []
@@ -468,6 +586,8 @@ class SerialRun:
         t.d_contexts, t.d_copy_orig = up(sp.contexts), up(sp.copy_orig)
         t.d_call_tx, t.d_call_prm, t.d_call_off = up(sp.call_tx), up(sp.call_prm), up(sp.call_off)
         t.d_call_copy_pred, t.d_call_cand = up(sp.call_copy_pred), up(sp.call_cand)
+        t.rec, t.nb = self.rec.h_pic, self.nb.h_pic
+        t.d_nb_copy, t.d_bi_lic = up(sp.nb_copy), up(sp.bi_lic)
         res = self.res = {}
         for name, dt, n in (("me_res", api.MERES_DTYPE, len(sp.me_jobs)),
                             ("bi_res", api.MERES_DTYPE, len(sp.bi_jobs)),
@@ -530,12 +650,13 @@ class SerialRun:
             idx = [np.arange(int(a), int(a) + int(b)) for a, b in zip(st[first_f], count_f) if b]
             return np.concatenate(idx) if idx else np.zeros(0, np.int64)
 
-        i = rng("me_first", st["me_count"] * (1 if searches else 0))
+        rb = 1 if searches else ((st["flags"] & STATE_LIC) != 0)    # LIC states: the serial form
+        i = rng("me_first", st["me_count"] * rb)
         w, g = sp.me_want[i], res["me_res"][i]
         out["me"] = (len(i), int(((g["fullpel_x"] != w["fullpel_x"]) | (g["fullpel_y"] != w["fullpel_y"]) |
                                   (g["mv_x"] != w["mv_x"]) | (g["mv_y"] != w["mv_y"]) |
                                   (g["subpel_dist"] != w["dist"])).sum()))
-        i = rng("bi_first", st["bi_count"] * (1 if searches else 0))
+        i = rng("bi_first", st["bi_count"] * rb)
         w, g = sp.bi_want[i], res["bi_res"][i]
         out["bi"] = (len(i), int(((g["mv_x"] != w["mv"][:, 0, 0]) | (g["mv_y"] != w["mv"][:, 0, 1]) |
                                   (g["subpel_dist"] != w["dist"])).sum()))
@@ -586,7 +707,7 @@ class SerialRun:
         for b in self._keep:
             if hasattr(b, "free"):
                 b.free()
-        for p in self.scratch + [self.orig]:
+        for p in self.scratch + [self.orig, self.rec, self.nb]:
             p.destroy()
 
 
@@ -618,8 +739,8 @@ OP_DTYPE = np.dtype([("opcode", "<i4"), ("n", "<i4"), ("r0", "<i4"), ("r1", "<i4
                      ("reserved", "<i4"), ("f", "<f8"), ("p", "<u8", 8)], align=True)
 (OP_MC_METRIC, OP_METRIC, OP_ME, OP_BI, OP_AFFINE, OP_COPY, OP_INTER_PRED, OP_RESIDUAL,
  OP_START_FOLD, OP_UNI_FOLD, OP_BI_FOLD, OP_FETCH, OP_SYNC, OP_EVAL_DIST, OP_MC_METRIC_REFS,
- OP_ME_REFS, OP_BI_REFS, OP_AFFINE_REFS, OP_MERGE_FOLD) = range(19)
-PIC_ORIG, PIC_S_ORIG, PIC_S_PRED, PIC_S_REC = 0, 1, 2, 3
+ OP_ME_REFS, OP_BI_REFS, OP_AFFINE_REFS, OP_MERGE_FOLD, OP_BI_LIC) = range(20)
+PIC_ORIG, PIC_S_ORIG, PIC_S_PRED, PIC_S_REC, PIC_NB, PIC_REC = 0, 1, 2, 3, 4, 5
 BI_SLOTS = 2 * R3 * R3
 
 
@@ -647,8 +768,12 @@ def build_merge_folds(sp):
     for c in range(3):
         sc = slots[:, c]
         sc["x"], sc["y"], sc["w"], sc["h"], sc["comp"] = g["x"], g["y"], g["w"], g["h"], c
-        sc["ref"], sc["mv"] = -1, 0x7fffff          # the fold's to write
+        sc["ref"], sc["mv"] = -1, 0x7fffff          # the fold's to write (and XVC_INTER_LIC)
         slots[:, c] = sc
+    # what a LIC candidate's prediction reads besides its motion: the CU's neighbours
+    any_lic = np.repeat((sp.mg_want["use_lic"] != 0).any(1), MERGE_SLOTS)
+    sp._lic_fields(slots, np.repeat(any_lic[:, None], 3, 1), np.repeat(g["nb_index"][:, None], 3, 1))
+    slots["flags"] = 0
     ev_slot = np.full(len(sp.ev_inter), -1, np.int64)
     cur, used = None, set()
     for n in range(len(st)):
@@ -684,7 +809,8 @@ class CsEnv(C.Structure):
     _fields_ = [("orig", C.c_void_p), ("refs", C.c_void_p), ("n_refs", C.c_int32),
                 ("pic_w", C.c_int32), ("pic_h", C.c_int32), ("reserved", C.c_int32),
                 ("s_orig", C.c_void_p), ("s_pred", C.c_void_p), ("s_rec", C.c_void_p),
-                ("d_levels", C.c_void_p), ("d_results", C.c_void_p)]
+                ("d_levels", C.c_void_p), ("d_results", C.c_void_p),
+                ("rec", C.c_void_p), ("nb", C.c_void_p)]
 
 
 def build_passes(sp, ref_lists):
@@ -708,7 +834,8 @@ def build_passes(sp, ref_lists):
     aff_work_rows = []          # (source: index into sp.aff_jobs or -1 for a slot)
     n_bi_slots = 0
     uni_groups, aff_uni_groups = {}, {}
-    for n in np.flatnonzero((st["kind"] >= KIND_INTER) & (st["supported"] != 0)):
+    folded = (st["kind"] >= KIND_INTER) & (st["supported"] != 0) & ((st["flags"] & STATE_LIC) == 0)
+    for n in np.flatnonzero(folded):
         s = st[n]
         cds = cd_all[int(s["cand_first"]):int(s["cand_first"]) + int(s["cand_count"])]
         plain = cds[cds["kind"] == 0]
@@ -854,7 +981,7 @@ def build_passes(sp, ref_lists):
                         (sp.aff_slots if affine else sp.bi_slots)[k] = pair
     # the evaluations' prediction jobs: motion composed on the device for inter states
     ei = sp.ev_inter.copy()
-    for n in np.flatnonzero((st["kind"] == KIND_INTER) & (st["supported"] != 0)):
+    for n in np.flatnonzero((st["kind"] == KIND_INTER) & folded):
         e = int(st["ev"][n])
         ei["ref"][e], ei["mv"][e], ei["flags"][e] = (0, -1), 12345, 0    # overwritten by the fold
     sp.ev_inter_work = ei
@@ -979,6 +1106,7 @@ class ChainedRun(SerialRun):
         e.pic_w, e.pic_h = width, height
         e.s_orig, e.s_pred, e.s_rec = self.t.s_orig, self.t.s_pred, self.t.s_rec
         e.d_levels, e.d_results = self.t.d_levels, d["results"]
+        e.rec, e.nb = self.t.rec, self.t.nb
         self.ctx.sync()
 
     # ---- program ---------------------------------------------------------------
@@ -1038,7 +1166,36 @@ class ChainedRun(SerialRun):
             if nbytes:
                 op(OP_FETCH, nbytes, p=(dev, host))
 
+        def stage(s):
+            if int(s["nb_count"]):   # the reconstruction of that moment around a LIC state's CU
+                op(OP_COPY, int(s["nb_count"]), r0=PIC_NB, r1=PIC_REC,
+                   p=(t.d_nb_copy + int(s["nb_first"]) * I["copy"],))
+
+        def motion_lic(s):
+            """A LIC state's SearchMotion in the serial form (the searches' inputs from the
+            capture, no device folds: EvalStartMvp's compensated predictions and the LIC
+            syntax bit have no fold): AC-only searches, then the refinement against the
+            compensated prediction of the other list."""
+            ms = max(int(s["w"]), int(s["h"]))
+            mf, mc = int(s["me_first"]), int(s["me_count"])
+            for j in range(mf, mf + mc):
+                op(OP_ME, 1, r0=int(sp.me_ref[j]), i0=ms, p=(t.d_me + j * I["me"], t.d_me_res + j * I["res"]))
+            fetch(t.d_me_res + mf * I["res"], t.h_me_res + mf * I["res"], mc * I["res"])
+            bf, bc = int(s["bi_first"]), int(s["bi_count"])
+            if bc and live:           # the host's fold over lists and pictures picks the bootstrap
+                flush_fetches()
+                op(OP_SYNC, i0=0, r0=int(s["kind"]))
+            for j in range(bf, bf + bc):
+                op(OP_BI_LIC, 1, r0=int(sp.bi_ref[j][0]), r1=int(sp.bi_ref[j][1]), i0=ms,
+                   p=(t.d_bi + j * I["bi"], t.d_bi_res + j * I["res"], t.d_bi_lic + j * 24))
+            fetch(t.d_bi_res + bf * I["res"], t.h_bi_res + bf * I["res"], bc * I["res"])
+            if live and int(s["kind"]) == KIND_INTER:      # the three-way choice is the host's
+                flush_fetches()
+                op(OP_SYNC, i0=0, r0=int(s["kind"]))
+
         def motion(s, n_state):
+            if int(s["flags"]) & STATE_LIC:
+                return motion_lic(s)
             ms = max(int(s["w"]), int(s["h"]))
             cls = 16 if ms <= 16 else (32 if ms <= 32 else 64)
             pf, pc = int(sp.pass_first[n_state]), int(sp.pass_count[n_state])
@@ -1116,6 +1273,7 @@ class ChainedRun(SerialRun):
             return sl
 
         def evaluation(s, n_state):
+            lic_ = 1 if int(s["flags"]) & STATE_LIC else 0   # INTER_PRED: neighbours from the reconstruction
             e = int(s["ev"])
             n0, n1 = int(s["call_pass0"]), int(s["call_pass1"])
             cf, k = int(s["call_first"]), n0 + n1
@@ -1132,7 +1290,7 @@ class ChainedRun(SerialRun):
                 ecands = d["ev_cands"] if nc_ else d["ev_cands_copy"]
                 if not nc_:
                     op(OP_COPY, 3 + n0, r0=PIC_ORIG, r1=PIC_S_ORIG, p=(t.d_copy_orig + co * I["copy"],))
-                op(OP_INTER_PRED, 3, r1=PIC_S_PRED, p=(pred_jobs, t.d_ev_dst + 3 * e * I["pos"]))
+                op(OP_INTER_PRED, 3, r0=lic_, r1=PIC_S_PRED, p=(pred_jobs, t.d_ev_dst + 3 * e * I["pos"]))
                 if not nc_:
                     op(OP_COPY, n0, r0=PIC_S_PRED, r1=PIC_S_PRED, p=(t.d_call_copy_pred + cf * I["copy"],))
                 fe_ = nc_ and self.fused_eval
@@ -1171,7 +1329,7 @@ class ChainedRun(SerialRun):
             sl = slot_of(e)
             pred_jobs = d["mg_slots"] + 3 * sl * I["inter"] if sl >= 0 else \
                 d["ev_inter_work"] + 3 * e * I["inter"]
-            op(OP_INTER_PRED, 3, r1=PIC_S_PRED, p=(pred_jobs, t.d_ev_dst + 3 * e * I["pos"]))
+            op(OP_INTER_PRED, 3, r0=lic_, r1=PIC_S_PRED, p=(pred_jobs, t.d_ev_dst + 3 * e * I["pos"]))
             if verify and sl >= 0:      # the slot's motion, to be held against the capture
                 fetch(pred_jobs, self.z["mg_slots_out"][1] + 3 * sl * I["inter"], 3 * I["inter"])
             if not nc_:
@@ -1216,11 +1374,13 @@ class ChainedRun(SerialRun):
                 chain_states = 0
             prev_key = key
             kind = int(s["kind"])
+            stage(s)
             if kind == KIND_MERGE_RANK:
                 m = int(s["merge"]) * 5
                 if not self.no_copies:
                     op(OP_COPY, 5, r0=PIC_ORIG, r1=PIC_S_ORIG, p=(t.d_mg_copy + m * I["copy"],))
-                op(OP_INTER_PRED, 5, r1=PIC_S_PRED, p=(t.d_mg_inter + m * I["inter"], t.d_mg_dst + m * I["pos"]))
+                op(OP_INTER_PRED, 5, r0=1 if int(s["flags"]) & STATE_LIC else 0, r1=PIC_S_PRED,
+                   p=(t.d_mg_inter + m * I["inter"], t.d_mg_dst + m * I["pos"]))
                 if self.no_copies:
                     op(OP_EVAL_DIST, 5, r0=1, p=(d["mg_ecands"] + m * 24, self.z["mg_dist"][1] + 8 * m))
                 else:

@@ -75,6 +75,15 @@ struct Walk {
     }
   }
 
+  // LIC states: the reconstruction of that moment around the CU (a live encoder's own
+  // reconstruction picture holds it already)
+  void Stage(const xvc_cs_state &s) {
+    if (s.nb_count) Ok(xvcgpu_copy_blocks(ctx, t.nb, t.rec, t.d_nb_copy + s.nb_first, s.nb_count));
+  }
+  const xvcgpu_picture *Rec(const xvc_cs_state &s) const {
+    return (s.flags & XVC_CS_STATE_LIC) ? t.rec : t.orig;
+  }
+
   void Motion(const xvc_cs_state &s) {
     const int max_size = s.w > s.h ? s.w : s.h;
     if (s.me_count) {            // SearchRefIdx, uni-directional: one TZ + sub-pel search per picture
@@ -87,8 +96,12 @@ struct Walk {
     }
     if (s.bi_count) {            // SearchBiIterative: needs the uni-directional winners
       ByRef(t.bi_ref, 2, s.bi_first, s.bi_count, [&](int a, int n, const int8_t *r) {
-        Ok(xvcgpu_bipred_search(ctx, t.orig, t.refs[r[1]], t.refs[r[0]], t.d_bi + a, n,
-                                t.d_bi_res + a, max_size));
+        if (s.flags & XVC_CS_STATE_LIC)
+          Ok(xvcgpu_bipred_search_lic(ctx, t.orig, t.refs[r[1]], t.refs[r[0]], t.rec, t.d_bi + a,
+                                      t.d_bi_lic + a, n, t.d_bi_res + a, max_size));
+        else
+          Ok(xvcgpu_bipred_search(ctx, t.orig, t.refs[r[1]], t.refs[r[0]], t.d_bi + a, n,
+                                  t.d_bi_res + a, max_size));
       });
       Fetch(t.h_bi_res, t.d_bi_res, s.bi_first, s.bi_count);
       ReadBack();
@@ -115,7 +128,7 @@ struct Walk {
   void MergeRank(const xvc_cs_state &s) {
     const size_t m = (size_t)s.merge * 5;
     Ok(xvcgpu_copy_blocks(ctx, t.orig, t.s_orig, t.d_mg_copy + m, 5));
-    Ok(xvcgpu_inter_pred_batch_to(ctx, t.refs, t.n_refs, t.orig, t.s_pred, t.d_mg_inter + m,
+    Ok(xvcgpu_inter_pred_batch_to(ctx, t.refs, t.n_refs, Rec(s), t.s_pred, t.d_mg_inter + m,
                                   t.d_mg_dst + m, 5));
     Ok(xvcgpu_metric_batch(ctx, t.s_orig, t.s_pred, 0, 1.0, 16, t.d_mg_cands + m, 5,
                            t.d_mg_dist + m));
@@ -147,7 +160,7 @@ struct Walk {
     const int n0 = s.call_pass0, n1 = s.call_pass1;
     // the originals beside the scratch predictions: slot 0 and the pass-0 slots
     Ok(xvcgpu_copy_blocks(ctx, t.orig, t.s_orig, t.d_copy_orig + s.copy_first, 3 + n0));
-    Ok(xvcgpu_inter_pred_batch_to(ctx, t.refs, t.n_refs, t.orig, t.s_pred, t.d_ev_inter + 3 * e,
+    Ok(xvcgpu_inter_pred_batch_to(ctx, t.refs, t.n_refs, Rec(s), t.s_pred, t.d_ev_inter + 3 * e,
                                   t.d_ev_dst + 3 * e, 3));
     for (int c = 0; c < 3; c++)   // cbf-zero distortion: the prediction against the original
       Ok(xvcgpu_metric_batch(ctx, t.s_orig, t.s_pred, c, t.ev_weight[3 * e + c], 16,
@@ -195,6 +208,7 @@ extern "C" int xvc_host_cu_state_run_serial(xvcgpu_ctx *ctx, const xvc_cs_tables
       continue;
     }
     const double a = Now();
+    w.Stage(s);
     switch (s.kind) {
       case XVC_CS_MERGE_RANK: w.MergeRank(s); break;
       case XVC_CS_EVAL: w.Eval(s); break;
@@ -230,19 +244,22 @@ extern "C" void xvc_host_cs_sizes(int32_t out[7]) {
 namespace {
 // one op of a chain program (SYNC is the caller's)
 xvcgpu_status IssueOp(xvcgpu_ctx *ctx, const xvc_cs_env *env, const xvc_cs_op &o) {
-  const xvcgpu_picture *pics[4] = {env->orig, env->s_orig, env->s_pred, env->s_rec};
+  const xvcgpu_picture *pics[6] = {env->orig, env->s_orig, env->s_pred, env->s_rec, env->nb, env->rec};
   void *const *p = reinterpret_cast<void *const *>(o.p);
   // r0 / r1 name a reference slot or one of the four pictures above, by opcode
   const bool ref_slots = o.opcode == XVC_OP_MC_METRIC || o.opcode == XVC_OP_ME ||
-                         o.opcode == XVC_OP_BI || o.opcode == XVC_OP_AFFINE;
+                         o.opcode == XVC_OP_BI || o.opcode == XVC_OP_AFFINE ||
+                         o.opcode == XVC_OP_BI_LIC;
   const bool pic_index = o.opcode == XVC_OP_METRIC || o.opcode == XVC_OP_COPY ||
                          o.opcode == XVC_OP_INTER_PRED;
   if (ref_slots && (o.r0 < 0 || o.r0 >= env->n_refs ||
                     (o.opcode != XVC_OP_MC_METRIC && o.opcode != XVC_OP_ME &&
                      (o.r1 < 0 || o.r1 >= env->n_refs))))
     return XVCGPU_INVALID_ARGUMENT;
-  if (pic_index && (o.r1 < 0 || o.r1 > 3 ||
-                    (o.opcode != XVC_OP_INTER_PRED && (o.r0 < 0 || o.r0 > 3))))
+  if (pic_index && (o.r1 < 0 || o.r1 > 5 || !pics[o.r1] ||
+                    (o.opcode != XVC_OP_INTER_PRED && (o.r0 < 0 || o.r0 > 5 || !pics[o.r0]))))
+    return XVCGPU_INVALID_ARGUMENT;
+  if ((o.opcode == XVC_OP_BI_LIC || (o.opcode == XVC_OP_INTER_PRED && o.r0 == 1)) && !env->rec)
     return XVCGPU_INVALID_ARGUMENT;
   switch (o.opcode) {
     case XVC_OP_MC_METRIC:
@@ -262,6 +279,11 @@ xvcgpu_status IssueOp(xvcgpu_ctx *ctx, const xvc_cs_env *env, const xvc_cs_op &o
       return xvcgpu_bipred_search(ctx, env->orig, env->refs[o.r1], env->refs[o.r0],
                                   static_cast<const xvcgpu_bi_block *>(p[0]), o.n,
                                   static_cast<xvcgpu_me_result *>(p[1]), o.i0);
+    case XVC_OP_BI_LIC:
+      return xvcgpu_bipred_search_lic(ctx, env->orig, env->refs[o.r1], env->refs[o.r0], env->rec,
+                                      static_cast<const xvcgpu_bi_block *>(p[0]),
+                                      static_cast<const xvcgpu_mc_lic_block *>(p[2]), o.n,
+                                      static_cast<xvcgpu_me_result *>(p[1]), o.i0);
     case XVC_OP_AFFINE:
       return xvcgpu_affine_me_batch(ctx, env->orig, env->refs[o.r0], env->refs[o.r1],
                                     static_cast<const xvcgpu_affine_me_block *>(p[0]), o.n,
@@ -270,7 +292,9 @@ xvcgpu_status IssueOp(xvcgpu_ctx *ctx, const xvc_cs_env *env, const xvc_cs_op &o
       return xvcgpu_copy_blocks(ctx, pics[o.r0], const_cast<xvcgpu_picture *>(pics[o.r1]),
                                 static_cast<const xvcgpu_copy_block *>(p[0]), o.n);
     case XVC_OP_INTER_PRED:
-      return xvcgpu_inter_pred_batch_to(ctx, env->refs, env->n_refs, env->orig,
+      // r0 = 1: XVC_INTER_LIC jobs among them - the neighbours from the reconstruction
+      return xvcgpu_inter_pred_batch_to(ctx, env->refs, env->n_refs,
+                                        o.r0 == 1 ? env->rec : env->orig,
                                         const_cast<xvcgpu_picture *>(pics[o.r1]),
                                         static_cast<const xvcgpu_inter_block *>(p[0]),
                                         static_cast<const xvcgpu_block_pos *>(p[1]), o.n);
@@ -450,7 +474,8 @@ int SegKindOf(const xvc_cs_op &o) {
     case XVC_OP_ME_REFS: return XVC_CS_SEG_ME_REFS;
     case XVC_OP_BI_REFS: return XVC_CS_SEG_BI_REFS;
     case XVC_OP_AFFINE_REFS: return XVC_CS_SEG_AFFINE_REFS;
-    case XVC_OP_INTER_PRED: return o.r1 == 2 ? XVC_CS_SEG_INTER_PRED : -1;   // into s_pred
+    // into s_pred; LIC jobs (r0 = 1: neighbours from the chain's reconstruction) as they are
+    case XVC_OP_INTER_PRED: return (o.r1 == 2 && o.r0 != 1) ? XVC_CS_SEG_INTER_PRED : -1;
     case XVC_OP_RESIDUAL: return o.p[5] ? XVC_CS_SEG_RESIDUAL_AT : -1;
     case XVC_OP_EVAL_DIST: return o.r0 == 1 ? XVC_CS_SEG_EVAL_DIST : -1;
     default: return -1;

@@ -46,8 +46,15 @@ typedef struct xvc_cs_state {
   int32_t comp_count[3];                    // pass-0 calls per component
   int32_t copy_first;                       // originals: [3 (slot 0)] [pass 0] [pass 1]
   int32_t cand_first, cand_count, final_first, final_count;
+  // XVC_CS_STATE_LIC: the block copies that stage the reconstruction of that moment above /
+  // left of the CU (tables.nb -> tables.rec), issued in front of the state's jobs
+  int32_t nb_first, nb_count;
   int64_t level_first, level_count;
 } xvc_cs_state;
+// flags of a state: the whole-sample search (1) and local illumination compensation (2):
+// cu.GetUseLic() - AC-only metrics in the searches, the other list's prediction compensated
+// in the refinement (xvcgpu_bipred_search_lic), XVC_INTER_LIC prediction jobs
+enum { XVC_CS_STATE_FULLPEL = 1, XVC_CS_STATE_LIC = 2 };
 
 // Device job / result arrays of one picture's states, in issue order (all device
 // memory unless marked host).  Scratch geometry: slot k of a state at luma x = 64 k of
@@ -99,6 +106,13 @@ typedef struct xvc_cs_tables {
   uint64_t *h_mg_dist, *h_ev_dz_dist, *h_call_dist;
   int32_t *h_nnz;
   int16_t *h_levels;
+  // local illumination compensation: the chain's reconstruction picture (the references'
+  // size; a live encoder's own reconstruction), the staging picture the captured neighbour
+  // rows / columns are copied from, the copies, and per bi-prediction job its neighbours
+  xvcgpu_picture *rec;
+  const xvcgpu_picture *nb;
+  const xvcgpu_copy_block *d_nb_copy;
+  const xvcgpu_mc_lic_block *d_bi_lic;
 } xvc_cs_tables;
 
 typedef struct xvc_cs_stats {
@@ -122,7 +136,10 @@ enum {
   XVC_OP_INTER_PRED, XVC_OP_RESIDUAL, XVC_OP_START_FOLD, XVC_OP_UNI_FOLD, XVC_OP_BI_FOLD,
   XVC_OP_FETCH, XVC_OP_SYNC, XVC_OP_EVAL_DIST, XVC_OP_MC_METRIC_REFS, XVC_OP_ME_REFS,
   XVC_OP_BI_REFS, XVC_OP_AFFINE_REFS,
-  XVC_OP_MERGE_FOLD   // p: merges, distortions, candidates' jobs, results, evaluation slots; i0 = first
+  XVC_OP_MERGE_FOLD,  // p: merges, distortions, candidates' jobs, results, evaluation slots; i0 = first
+  // LIC states (picture selectors 4 = the neighbour staging picture, 5 = the chain's
+  // reconstruction; INTER_PRED with r0 = 1 reads the neighbours from the reconstruction):
+  XVC_OP_BI_LIC       // xvcgpu_bipred_search_lic: r0 searched / r1 other slot, p: jobs, results, neighbours
 };
 typedef struct xvc_cs_op {
   int32_t opcode, n, r0, r1, i0, reserved;
@@ -136,6 +153,8 @@ typedef struct xvc_cs_env {
   xvcgpu_picture *s_orig, *s_pred, *s_rec;
   int16_t *d_levels;
   xvcgpu_cs_result *d_results;
+  xvcgpu_picture *rec;          // LIC states only (may be NULL without them)
+  const xvcgpu_picture *nb;
 } xvc_cs_env;
 
 extern "C" {
