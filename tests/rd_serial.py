@@ -1179,7 +1179,8 @@ class ChainedRun(SerialRun):
             ms = max(int(s["w"]), int(s["h"]))
             mf, mc = int(s["me_first"]), int(s["me_count"])
             for j in range(mf, mf + mc):
-                op(OP_ME, 1, r0=int(sp.me_ref[j]), i0=ms, p=(t.d_me + j * I["me"], t.d_me_res + j * I["res"]))
+                op(OP_ME, 1, r0=int(sp.me_ref[j]), r1=1, i0=ms,
+                   p=(t.d_me + j * I["me"], t.d_me_res + j * I["res"]))
             fetch(t.d_me_res + mf * I["res"], t.h_me_res + mf * I["res"], mc * I["res"])
             bf, bc = int(s["bi_first"]), int(s["bi_count"])
             if bc and live:           # the host's fold over lists and pictures picks the bootstrap

@@ -42,6 +42,11 @@ def test_serial_walk_equals_reference(gpu, name, poc, n_states):
         1e6 * stats.seconds / max(stats.states, 1), stats.api_calls / max(stats.states, 1),
         stats.round_trips / max(stats.states, 1)))
     assert stats.states > 1000
+    # every state of the picture is walked: the LIC states too (tiny: 3648 of 8151; the
+    # neighbouring reconstruction of that moment staged in front of each)
+    assert sp.summary()["unsupported"] == 0 and stats.skipped == 0 and stats.states == min(n_states, len(sp.states))
+    lic = (sp.states["flags"] & rd_serial.STATE_LIC) != 0
+    assert lic.sum() == (3648 if name == "tiny" else 0)
     for k in ("me", "bi", "merge", "calls", "dist_zero"):
         assert res[k][0] > 100 and res[k][1] == 0, (k, res)
     assert res["affine"][1] == 0, res
@@ -88,15 +93,18 @@ def test_chained_states_equal_reference(gpu, name, poc, n_states, by_position, r
     for k, (done, wrong) in res.items():
         assert wrong == 0, (k, res, bad)
     assert stats.round_trips <= stats.states
+    assert sp.summary()["unsupported"] == 0 and stats.states == min(n_states, len(sp.states))
     for k in ("cands", "finals", "eval_motion", "calls", "merge", "merge_fold", "merge_slot_motion"):
         assert res[k][0] > 100, (k, res)
+    if name == "tiny":       # the LIC states' searches (serial form inside the chains) are compared too
+        assert res["me"][0] == 5140 and res["bi"][0] > 4000
     # every merge ranking went through the device's fold (xvcgpu_cs_merge_fold), and nearly
     # every merge candidate's evaluation predicted from the slot the fold filled (the rest:
     # affine merges and candidates the harness could not tell apart)
     assert res["merge_fold"][0] == res["merge"][0]
     merge_evals = int(((sp.states["kind"] == rd_serial.KIND_EVAL) & (sp.states["supported"] != 0))[
         :min(n_states, len(sp.states))].sum())
-    assert res["merge_slot_motion"][0] > (0.5 if name == "tiny" else 0.8) * merge_evals, (res, merge_evals)
+    assert res["merge_slot_motion"][0] > 0.8 * merge_evals, (res, merge_evals)
 
 
 @pytest.mark.parametrize("name,poc,n_states", [("tiny", 2, 1 << 30), ("c1", 2, 6000)])

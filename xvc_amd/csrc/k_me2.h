@@ -588,11 +588,14 @@ __device__ __forceinline__ bool me2_subpel_fast(int w, int h, int bd, bool ac = 
 // Evaluate the SATD of the n = 9 - pass candidates of a sub-pel pass (or, with
 // pass < 0, of the single MV (base_x, base_y)) around the staged full-pel
 // position (fpx,fpy); raw tile sums in s.dist[0..n).  Arguments wave-uniform.
+// held[k]: the x-phase key of the plane slot k still holds from the job's previous pass
+// (-1: none) - the quarter-pel pass's centre column of candidates has the x-phase of the
+// half-pel winner, whose plane is therefore not built a second time.
 template <int MS>
 __device__ __forceinline__ void me2_subpel_eval(Me2Shared<MS> &s, const MeCtx &c,
                                                 const xvcgpu_me_block &b, int pic_w,
                                                 int pic_h, int fpx, int fpy, int pass,
-                                                int base_x, int base_y) {
+                                                int base_x, int base_y, int (&held)[3]) {
   const int w = c.w, h = c.h, bd = c.bd;
   const int ws = w + 16;
   const int lane = ME2_LANE;
@@ -609,23 +612,35 @@ __device__ __forceinline__ void me2_subpel_eval(Me2Shared<MS> &s, const MeCtx &c
   // the caller has transposed s.orig to column-major for it
   const bool fastp = me2_subpel_fast(w, h, bd, c.ac);
   const bool need = lane < n && (fastp || cfx != 0);
-  int myslot = -1, nslots = 0, slot_key[3] = {0, 0, 0};
+  int myslot = -1, slot_key[3] = {-1, -1, -1};
+  bool build[3] = {false, false, false};
+#pragma unroll
+  for (int k = 0; k < 3; k++) {   // planes of the previous pass that this one reads again
+    if (held[k] >= 0 && __ballot(need && mykey == held[k]) != 0) {
+      if (need && mykey == held[k]) myslot = k;
+      slot_key[k] = held[k];
+    }
+  }
 #pragma unroll
   for (int k = 0; k < 3; k++) {
     const unsigned long long m = __ballot(need && myslot < 0);
     if (m) {
       const int leader = __ffsll((long long)m) - 1;
       const int key = __builtin_amdgcn_readlane(mykey, leader);
-      if (need && mykey == key) myslot = k;
-      slot_key[k] = key;
-      nslots = k + 1;
+      const int f = slot_key[0] < 0 ? 0 : (slot_key[1] < 0 ? 1 : 2);   // a free slot (<= 3 keys)
+      if (need && mykey == key) myslot = f;
+      if (f == 0) { slot_key[0] = key; build[0] = true; }
+      else if (f == 1) { slot_key[1] = key; build[1] = true; }
+      else { slot_key[2] = key; build[2] = true; }
     }
   }
+#pragma unroll
+  for (int k = 0; k < 3; k++) held[k] = slot_key[k];
   wave_sync();  // previous readers of the planes / tables are done
   if (fastp) {
 #pragma unroll
     for (int k = 0; k < 3; k++)
-      if (k < nslots)
+      if (build[k])
         sp_build_planes(s.win, s.hint[k], s.taps, bd, w, h,
                         (slot_key[k] >> 4) - 1, slot_key[k] & 15);
     if (lane < n) {
@@ -645,7 +660,7 @@ __device__ __forceinline__ void me2_subpel_eval(Me2Shared<MS> &s, const MeCtx &c
   }
 #pragma unroll
   for (int k = 0; k < 3; k++)
-    if (k < nslots)
+    if (build[k])
       me2_build_hplanes(s, bd, w, h, k, (slot_key[k] >> 4) - 1, slot_key[k] & 15);
   if (lane < n) {
     const int16_t *base = reinterpret_cast<const int16_t *>(s.orig);
@@ -1121,8 +1136,9 @@ me_search_wave_body(const PicView &orig, const PicView &ref,
         for (int i = lane; i < w * h; i += 64) s.orig[i] = tmp[i];
       }
     }
+    int held[3] = {-1, -1, -1};   // x-phase planes a pass leaves for the next one
     if (b.fullpel_mv & XVC_ME_FULLPEL_MV) {
-      me2_subpel_eval(s, c, b, pic_w, pic_h, fpx, fpy, -1, res.mv_x, res.mv_y);
+      me2_subpel_eval(s, c, b, pic_w, pic_h, fpx, fpy, -1, res.mv_x, res.mv_y, held);
       res.subpel_dist = s.dist[0] >> (c.bd - 8);
     } else {
       uint32_t best_cost = 0xffffffffu, best_dist = 0xffffffffu;
@@ -1130,7 +1146,7 @@ me_search_wave_body(const PicView &orig, const PicView &ref,
       for (int pass = 0; pass < 2; pass++) {
         const int base_x = best_x, base_y = best_y;
         const int n = 9 - pass;
-        me2_subpel_eval(s, c, b, pic_w, pic_h, fpx, fpy, pass, base_x, base_y);
+        me2_subpel_eval(s, c, b, pic_w, pic_h, fpx, fpy, pass, base_x, base_y, held);
         // the reference's ordered strict-< fold = (lowest cost, lowest index),
         // one candidate per lane
         uint32_t my_cost = 0xffffffffu;

@@ -88,7 +88,10 @@ struct Walk {
     const int max_size = s.w > s.h ? s.w : s.h;
     if (s.me_count) {            // SearchRefIdx, uni-directional: one TZ + sub-pel search per picture
       ByRef(t.me_ref, 1, s.me_first, s.me_count, [&](int a, int n, const int8_t *r) {
-        Ok(xvcgpu_me_search_sized(ctx, t.orig, t.refs[r[0]], XVCGPU_ME_FULLPEL | XVCGPU_ME_SUBPEL,
+        // (LIC states: the AC-only metrics, announced per call)
+        Ok(xvcgpu_me_search_sized(ctx, t.orig, t.refs[r[0]],
+                                  XVCGPU_ME_FULLPEL | XVCGPU_ME_SUBPEL |
+                                      ((s.flags & XVC_CS_STATE_LIC) ? XVCGPU_ME_LIC_JOBS : 0),
                                   t.d_me + a, n, t.d_me_res + a, max_size));
       });
       Fetch(t.h_me_res, t.d_me_res, s.me_first, s.me_count);
@@ -271,8 +274,9 @@ xvcgpu_status IssueOp(xvcgpu_ctx *ctx, const xvc_cs_env *env, const xvc_cs_op &o
                                  static_cast<const xvcgpu_metric_cand *>(p[0]), o.n,
                                  static_cast<uint64_t *>(p[1]));
     case XVC_OP_ME:
-      return xvcgpu_me_search_sized(ctx, env->orig, env->refs[o.r0],
-                                    XVCGPU_ME_FULLPEL | XVCGPU_ME_SUBPEL,
+      return xvcgpu_me_search_sized(ctx, env->orig, env->refs[o.r0],   // r1 = 1: LIC jobs
+                                    XVCGPU_ME_FULLPEL | XVCGPU_ME_SUBPEL |
+                                        (o.r1 == 1 ? XVCGPU_ME_LIC_JOBS : 0),
                                     static_cast<const xvcgpu_me_block *>(p[0]), o.n,
                                     static_cast<xvcgpu_me_result *>(p[1]), o.i0);
     case XVC_OP_BI:
@@ -611,8 +615,11 @@ extern "C" int xvc_host_cs_run_programs_engine(xvcgpu_ctx *const *ctxs, int n_ct
           continue;
         }
         const int kind = SegKindOf(o);
-        if (kind < 0) {                    // no batched form: as it is
-          st = IssueOp(ctxs[c % n_ctx], envs[c], o);
+        if (kind < 0) {                    // no batched form (a LIC state's steps): as it is,
+          const int t = c % n_ctx;         // behind the last round's launches of every stream
+          st = Meet(t);
+          used_now[t] = true;
+          if (st == XVCGPU_OK) st = IssueOp(ctxs[t], envs[c], o);
           stats->api_calls++;
         } else {
           const int key = (kind == XVC_CS_SEG_ME_REFS || kind == XVC_CS_SEG_BI_REFS ||

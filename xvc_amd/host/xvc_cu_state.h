@@ -138,7 +138,8 @@ enum {
   XVC_OP_BI_REFS, XVC_OP_AFFINE_REFS,
   XVC_OP_MERGE_FOLD,  // p: merges, distortions, candidates' jobs, results, evaluation slots; i0 = first
   // LIC states (picture selectors 4 = the neighbour staging picture, 5 = the chain's
-  // reconstruction; INTER_PRED with r0 = 1 reads the neighbours from the reconstruction):
+  // reconstruction; INTER_PRED with r0 = 1 reads the neighbours from the reconstruction; ME
+  // with r1 = 1 announces XVCGPU_ME_LIC_JOBS):
   XVC_OP_BI_LIC       // xvcgpu_bipred_search_lic: r0 searched / r1 other slot, p: jobs, results, neighbours
 };
 typedef struct xvc_cs_op {
