@@ -334,6 +334,28 @@ def encoder_rd_serial_figure(ctx, api, fx, pics, w, h, n_states=4000):
     s1, c1, l1 = serial["chains"]["1"], chained["chains"]["1"], live["chains"]["1"]
     ok = all(e.get("matches_reference") for r in (serial, chained, live, engine)
              for e in r["chains"].values())
+    # the clip whose encode allows local illumination compensation (136x72, POC 2): nearly
+    # half of its states are LIC states - walked with the neighbouring reconstruction of that
+    # moment staged in front of each (xvcgpu_bipred_search_lic, XVC_INTER_LIC predictions)
+    lic_fig = None
+    if os.path.exists(rf.path("tiny")) and os.path.exists(os.path.join(rf.GOLDEN, "rd_order_tiny.npz")):
+        spl = rd_serial.SerialPicture(api, "tiny", 2)
+        forms = {m: cu_state_walk.walk(api, "tiny", 2, 1 << 30, [1], m, sp=spl)
+                 for m in ("serial", "chained", "live")}
+        ok = ok and all(f["chains"]["1"].get("matches_reference") for f in forms.values())
+        lic_fig = {
+            "workload": "136x72 B picture POC 2 of the reference-coded LIC clip: all %d CU states" %
+                        forms["serial"]["states_in_picture"],
+            "lic_states": int(((spl.states["flags"] & rd_serial.STATE_LIC) != 0).sum()),
+            "unsupported_states": forms["serial"]["summary"]["unsupported"],
+            "us_per_cu_state": {m: f["chains"]["1"]["us_per_cu_state"] for m, f in forms.items()},
+            "round_trips_per_state": {m: f["chains"]["1"]["round_trips_per_state"] for m, f in forms.items()},
+            "form": "a LIC state's SearchMotion keeps the serial form inside its chain (captured "
+                    "inputs; a live chain waits after the uni-directional searches and after the "
+                    "refinement): EvalStartMvp on compensated predictions, LIC jobs in the *_refs "
+                    "searches and use_lic in the folds' syntax have no device form yet; its merge "
+                    "ranking is folded on the device",
+            "matches_reference": all(f["chains"]["1"].get("matches_reference") for f in forms.values())}
     return {
         "workload": "1080p B picture POC %d of the reference-coded stream: %d CU states in the "
                     "reference's issue order (%d merge rankings, %d merge-candidate evaluations, "
@@ -411,9 +433,11 @@ def encoder_rd_serial_figure(ctx, api, fx, pics, w, h, n_states=4000):
                            "chain and issues one launch per step kind, grid y = chain "
                            "(xvcgpu_cs_segs_launch; xvc_host_cs_run_programs_engine); a chain at its "
                            "read-back sits out until the round's event has passed",
-                   "kernels_in_flight_mean": {"128": 4.3, "measured_at": "round 5: kernel seconds of "
-                                              "profiles/r05_cu_state_engine_kernel_stats.csv over the "
-                                              "unprofiled wall time (static, not re-measured by this run)"}},
+                   "kernels_in_flight_mean": {"128": 2.5, "measured_at": "round 5: kernel seconds of "
+                                              "profiles/r05_cu_state_engine_kernel_stats.csv over that "
+                                              "(profiled) run's wall time, four streams (static, not "
+                                              "re-measured by this run)"}},
+        "lic_picture": lic_fig,
         "compared": s1.get("compared"),
         "matches_reference": bool(ok),
         "reading": "every form is bound by the chain of dependent kernels per state (each search is "

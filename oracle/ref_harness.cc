@@ -72,8 +72,9 @@ class ObservedTzSearch;
  * order in which the encoder's RD search issued the calls, across tables. */
 namespace xr_seq {
 extern uint32_t g_next;
-extern std::vector<uint32_t> g_of[7];   /* 0 me calls, 1 steps, 2 merges, 3 evals, 4 calls,
-                                          * 5 cands, 6 finals */
+extern std::vector<uint32_t> g_of[9];   /* 0 me calls, 1 steps, 2 merges, 3 evals, 4 calls,
+                                          * 5 cands, 6 finals; round 5: 7 intra SATD calls
+                                          * (xr_intra::Call), 8 intra transform calls (IntraTx) */
 inline void Stamp(int table) { g_of[table].push_back(g_next++); }
 }  // namespace xr_seq
 namespace xr_me {
@@ -2046,7 +2047,7 @@ const uint32_t *xr_entropy_bits_table(void) { return &ContextModel::kEntropyBits
 
 namespace xr_seq {
 uint32_t g_next = 0;
-std::vector<uint32_t> g_of[7];
+std::vector<uint32_t> g_of[9];
 }  // namespace xr_seq
 
 namespace xr_me {
@@ -2386,6 +2387,17 @@ std::vector<uint16_t> g_itx_samples;
 int g_itx_stride = 0, g_itx_cap = 0;
 long g_itx_seen = 0;
 int g_pending_itx = -1;
+/* round 5 (tools/gen_order_golden.py): EVERY such call of the wanted picture, in the global
+ * order (xr_seq table 8), LM chroma included - after its reference samples the luma
+ * rectangle RescaleLuma reads (intra_prediction.cc:873-906: rows y - 2 .. y + h - 1 when
+ * there is a row above, columns x - 3 .. x + w - 1 when there is a column left; luma
+ * units) -, with context / QP tables of their own so that the inter tables' indices do
+ * not move */
+bool g_itx_walk = false;
+int g_itx_poc = -1;
+std::vector<xvcgpu_rdoq_contexts> g_itx_ctx;
+std::vector<QpParams> g_itx_qps;
+std::unordered_map<std::string, int> g_itx_ctx_index, g_itx_qp_index;
 
 static bool Wanted(const CodingUnit &cu) {
   return g_capture &&
@@ -2703,19 +2715,27 @@ void AfterMergeSort(InterSearch *is, CodingUnit *cu, const Qp &qp,
   xr_seq::Stamp(2);
 }
 
-static int ContextIndex(const SyntaxWriter &writer) {
+static int ContextIndexIn(const SyntaxWriter &writer, std::vector<xvcgpu_rdoq_contexts> *tab,
+                          std::unordered_map<std::string, int> *index) {
   xvcgpu_rdoq_contexts c;
   StoreContexts(writer.GetContexts(), &c);
   std::string key(reinterpret_cast<const char *>(&c), sizeof(c));
-  auto it = g_ctx_index.find(key);
-  if (it != g_ctx_index.end()) return it->second;
-  const int idx = static_cast<int>(g_ctx.size());
-  g_ctx.push_back(c);
-  g_ctx_index.emplace(key, idx);
+  auto it = index->find(key);
+  if (it != index->end()) return it->second;
+  const int idx = static_cast<int>(tab->size());
+  tab->push_back(c);
+  index->emplace(key, idx);
   return idx;
 }
+static int ContextIndex(const SyntaxWriter &writer) {
+  return ContextIndexIn(writer, &g_ctx, &g_ctx_index);
+}
 
-static int QpIndex(const Qp &qp, int bd) {
+static int QpIndexIn(const Qp &qp, int bd, std::vector<QpParams> *tab,
+                     std::unordered_map<std::string, int> *index);
+static int QpIndex(const Qp &qp, int bd) { return QpIndexIn(qp, bd, &g_qps, &g_qp_index); }
+static int QpIndexIn(const Qp &qp, int bd, std::vector<QpParams> *tab,
+                     std::unordered_map<std::string, int> *index) {
   QpParams q;
   std::memset(&q, 0, sizeof(q));
   for (int c = 0; c < 3; c++) {
@@ -2729,11 +2749,11 @@ static int QpIndex(const Qp &qp, int bd) {
     q.dist_weight[c] = qp.GetDistortionWeight(yc);
   }
   std::string key(reinterpret_cast<const char *>(&q), sizeof(q));
-  auto it = g_qp_index.find(key);
-  if (it != g_qp_index.end()) return it->second;
-  const int idx = static_cast<int>(g_qps.size());
-  g_qps.push_back(q);
-  g_qp_index.emplace(key, idx);
+  auto it = index->find(key);
+  if (it != index->end()) return it->second;
+  const int idx = static_cast<int>(tab->size());
+  tab->push_back(q);
+  index->emplace(key, idx);
   return idx;
 }
 
@@ -2785,8 +2805,12 @@ static int EvalIndex(const CodingUnit &cu, const Qp &qp, const SyntaxWriter &wri
 static void RecordIntraTx(TransformEncoder *te, CodingUnit *cu, YuvComponent comp, const Qp &qp,
                           const SyntaxWriter &writer, int non_zero, const YuvPicture &rec_pic,
                           const SampleBuffer &pred_buffer) {
-  const IntraMode mode = cu->GetIntraMode(comp);
-  if (static_cast<int>(mode) < 0 || static_cast<int>(mode) > 66) return;   /* LM chroma */
+  IntraMode mode = cu->GetIntraMode(comp);
+  const bool lm = mode == IntraMode::kLmChroma;
+  if (lm && g_itx_walk) mode = static_cast<IntraMode>(67);   /* XVC_INTRA_MODE_LM_CHROMA */
+  if (static_cast<int>(mode) < 0 || static_cast<int>(mode) > (g_itx_walk ? 67 : 66)) return;
+  if (g_itx_walk && g_itx_poc >= 0 && static_cast<int>(cu->GetPicData()->GetPoc()) != g_itx_poc)
+    return;
   if ((g_itx_seen++ % g_itx_stride) != 0 || static_cast<int>(g_itx.size()) >= g_itx_cap) return;
   const int bd = te->max_pel_ == 1023 ? 10 : (te->max_pel_ == 255 ? 8 : 12);
   IntraTx t;
@@ -2813,8 +2837,9 @@ static void RecordIntraTx(TransformEncoder *te, CodingUnit *cu, YuvComponent com
   t.intra_pic = cu->GetPicType() == PicturePredictionType::kIntra;
   t.qp = static_cast<int8_t>(qp.GetQpRaw(comp));
   t.qp_luma = static_cast<int8_t>(qp.GetQpRaw(YuvComponent::kY));
-  t.ctx_index = ContextIndex(writer);
-  t.qp_index = QpIndex(qp, bd);
+  t.ctx_index = g_itx_walk ? ContextIndexIn(writer, &g_itx_ctx, &g_itx_ctx_index)
+                           : ContextIndex(writer);
+  t.qp_index = g_itx_walk ? QpIndexIn(qp, bd, &g_itx_qps, &g_itx_qp_index) : QpIndex(qp, bd);
   t.nnz = non_zero;
   CoeffBuffer coeff = cu->GetCoeff(comp);
   uint32_t crc = 0, pcrc = 0;
@@ -2833,7 +2858,17 @@ static void RecordIntraTx(TransformEncoder *te, CodingUnit *cu, YuvComponent com
     for (int i = 0; i < t.w + t.above_right; i++) g_itx_samples.push_back(p[-st + i]);
   if (has_left)
     for (int i = 0; i < t.h + t.below_left; i++) g_itx_samples.push_back(p[i * st - 1]);
+  if (lm) {   /* the luma rectangle of the linear model (the CU's own luma reconstruction) */
+    const YuvComponent luma = YuvComponent::kY;
+    const int lx = cu->GetPosX(luma), ly = cu->GetPosY(luma);
+    const int lw = cu->GetWidth(luma), lh = cu->GetHeight(luma);
+    const Sample *q = rec_pic.GetSamplePtr(luma, lx, ly);
+    const ptrdiff_t ls = rec_pic.GetStride(luma);
+    for (int y = (ly > 0 ? -2 : 0); y < lh; y++)
+      for (int x = (lx > 0 ? -3 : 0); x < lw; x++) g_itx_samples.push_back(q[y * ls + x]);
+  }
   g_itx.push_back(t);
+  if (g_itx_walk) xr_seq::Stamp(8);
   g_pending_cu = cu;
   g_pending_itx = static_cast<int>(g_itx.size()) - 1;
 }
@@ -2942,6 +2977,7 @@ struct Eval {
 
 bool g_capture = false;
 int g_max_calls = 0, g_stride = 1;
+int g_only_poc = -1;         /* round 5: only this picture's calls, stamped (xr_seq table 7) */
 long g_seen = 0;             /* DetermineSlowIntraModes calls so far: every g_stride-th is kept */
 std::vector<Call> g_calls;
 std::vector<Eval> g_evals;
@@ -2951,6 +2987,7 @@ bool g_open = false;         /* the evaluations that follow belong to g_calls.ba
 void OnCu(xvc::IntraSearch *is, xvc::CodingUnit *cu, const xvc::YuvPicture &rec_pic) {
   g_open = false;
   if (!g_capture) return;
+  if (g_only_poc >= 0 && static_cast<int>(cu->GetPoc()) != g_only_poc) return;
   if ((g_seen++ % g_stride) != 0 || static_cast<int>(g_calls.size()) >= g_max_calls) return;
   const xvc::YuvComponent comp = xvc::YuvComponent::kY;
   const xvc::IntraPrediction::NeighborState nb = is->DetermineNeighbors(*cu, comp);
@@ -2976,6 +3013,7 @@ void OnCu(xvc::IntraSearch *is, xvc::CodingUnit *cu, const xvc::YuvPicture &rec_
   if (nb.has_left)
     for (int i = 0; i < c.h + c.below_left; i++) g_samples.push_back(p[i * st - 1]);
   g_calls.push_back(c);
+  if (g_only_poc >= 0) xr_seq::Stamp(7);
   g_open = true;
 }
 
@@ -3006,7 +3044,16 @@ void xr_intra_capture_begin(int max_calls, int stride) {
   xr_intra::g_open = false;
   xr_intra::g_capture = true;
 }
-void xr_intra_capture_end(void) { xr_intra::g_capture = false; xr_intra::g_open = false; }
+void xr_intra_capture_end(void) {
+  xr_intra::g_capture = false;
+  xr_intra::g_open = false;
+  xr_intra::g_only_poc = -1;
+}
+/* after xr_intra_capture_begin: every call of picture `poc` only, in the global order */
+void xr_intra_capture_poc(int poc) {
+  xr_intra::g_only_poc = poc;
+  xr_seq::g_of[7].clear();
+}
 /* which: 0 calls, 1 evaluations, 2 samples, 3 (count only) all calls seen */
 long xr_intra_count(int which) {
   if (which == 3) return xr_intra::g_seen;
@@ -3031,11 +3078,25 @@ void xr_rd_capture_intra(int stride, int cap) {
   xr_rd::g_itx_stride = stride;
   xr_rd::g_itx_cap = cap;
 }
+/* the walk's capture (after xr_rd_capture_begin(poc)): every TransformAndReconstruct of
+ * the picture's intra CUs, LM chroma too, tables of their own (which 14 contexts, 15 QPs) */
+void xr_rd_capture_intra_walk(int cap, int poc) {
+  xr_rd::g_itx_stride = 1;
+  xr_rd::g_itx_cap = cap;
+  xr_rd::g_itx_walk = true;
+  xr_rd::g_itx_poc = poc;
+}
 
 void xr_rd_capture_begin(int only_poc) {
   using namespace xr_rd;  // NOLINT
   g_itx.clear();
   g_itx_samples.clear();
+  g_itx_walk = false;
+  g_itx_poc = -1;
+  g_itx_ctx.clear();
+  g_itx_qps.clear();
+  g_itx_ctx_index.clear();
+  g_itx_qp_index.clear();
   g_itx_stride = 0;
   g_itx_seen = 0;
   g_pending_itx = -1;
@@ -3043,7 +3104,7 @@ void xr_rd_capture_begin(int only_poc) {
   g_finals.clear();
   g_ictx.clear();
   g_ictx_index.clear();
-  for (int t = 1; t < 7; t++) xr_seq::g_of[t].clear();
+  for (int t = 1; t < 9; t++) xr_seq::g_of[t].clear();
   g_steps.clear();
   g_merges.clear();
   g_evals.clear();
@@ -3082,8 +3143,10 @@ long xr_rd_count(int which) {
     case 11: return static_cast<long>(g_cands.size());
     case 12: return static_cast<long>(g_finals.size());
     case 13: return static_cast<long>(g_ictx.size());
+    case 14: return static_cast<long>(g_itx_ctx.size());
+    case 15: return static_cast<long>(g_itx_qps.size());
   }
-  if (which >= 20 && which < 27) return static_cast<long>(xr_seq::g_of[which - 20].size());
+  if (which >= 20 && which < 29) return static_cast<long>(xr_seq::g_of[which - 20].size());
   return -1;
 }
 int xr_rd_size(int which) {
@@ -3102,8 +3165,10 @@ int xr_rd_size(int which) {
     case 11: return sizeof(Cand);
     case 12: return sizeof(Final);
     case 13: return sizeof(xvcgpu_inter_contexts);
+    case 14: return sizeof(xvcgpu_rdoq_contexts);
+    case 15: return sizeof(QpParams);
   }
-  if (which >= 20 && which < 27) return sizeof(uint32_t);
+  if (which >= 20 && which < 29) return sizeof(uint32_t);
   return -1;
 }
 const void *xr_rd_data(int which) {
@@ -3122,8 +3187,10 @@ const void *xr_rd_data(int which) {
     case 11: return g_cands.data();
     case 12: return g_finals.data();
     case 13: return g_ictx.data();
+    case 14: return g_itx_ctx.data();
+    case 15: return g_itx_qps.data();
   }
-  if (which >= 20 && which < 27) return xr_seq::g_of[which - 20].data();
+  if (which >= 20 && which < 29) return xr_seq::g_of[which - 20].data();
   return nullptr;
 }
 

@@ -47,3 +47,32 @@ def load(name):
                 a[f] = z[t + "/" + f]
         out[t] = a
     return out
+
+
+def order_path(name):
+    return os.path.join(GOLDEN, "intra_order_%s.npz" % name)
+
+
+def load_order(name):
+    """tests/golden/intra_order_<clip>.npz (tools/gen_order_golden.py, round 5): EVERY
+    DetermineSlowIntraModes call and every TransformAndReconstruct of an intra CU of the
+    picture tests/rd_serial.py walks, LM chroma included (mode 67: behind the call's
+    reference samples lies the luma rectangle RescaleLuma reads - rows y - 2 .., columns
+    x - 3 .. where the picture has them), and where each lies in the order of
+    rd_order_<clip>.npz: pos = inter records of that order in front of it, stamp = its
+    order among the intra records.  None when the clip has no such fixture."""
+    if not os.path.exists(order_path(name)):
+        return None
+    z = np.load(order_path(name))
+    out = {k: z[k] for k in ("samples", "itx_samples")}
+    out["contexts"] = z["contexts"]
+    out["qps"] = z["qps"]
+    for t, dt in (("calls", CALL_DTYPE), ("evals", EVAL_DTYPE), ("itx", ITX_DTYPE)):
+        names = [f for f in dt.names if not f.startswith("pad")]
+        a = np.zeros(len(z[t + "/" + names[0]]), dt)
+        for f in names:
+            a[f] = z[t + "/" + f]
+        out[t] = a
+    out["pos"] = {"calls": z["pos/calls"], "itx": z["pos/itx"]}
+    out["stamp"] = {"calls": z["stamp/calls"], "itx": z["stamp/itx"]}
+    return out

@@ -8,6 +8,13 @@
                           pass] then CompressAndEvalCbf of what it chose
   kind 3  motion only     a CompressInter that returned before its evaluation
                           (whole-sample vectors with a zero difference, :94-96)
+  kind 4  intra mode      CompressIntra (cu_encoder.cc:518-541): the SATD pre-selection
+                          over the 67 luma modes (DetermineSlowIntraModes,
+                          intra_search.cc:188-305), then PredictAndTransform of every
+                          kept luma mode and every chroma mode (:61-82, :118-150) - each
+                          a prediction from the reconstruction of that moment around
+                          the CU + the TransformAndReconstruct alternatives
+                          (tests/golden/intra_order_*.npz)
 
 State boundaries come from the capture's global sequence numbers: a state is what the
 reference computes between two points where CuEncoder (cu_encoder.cc:431-515, :598-...)
@@ -20,11 +27,12 @@ import ctypes as C
 
 import numpy as np
 
+import intra_fixture as ifx
 import order_fixture as of
 import rd_fixture as rf
 from rd_replay import BL, original_planes
 
-KIND_MERGE_RANK, KIND_EVAL, KIND_INTER, KIND_MOTION = 0, 1, 2, 3
+KIND_MERGE_RANK, KIND_EVAL, KIND_INTER, KIND_MOTION, KIND_INTRA = 0, 1, 2, 3, 4
 SLOT = 64            # scratch geometry: slot k of a state at luma x = 64 * k
 MAX_SLOTS = 8        # slot 0 = the prediction, 1.. = the transform alternatives
 
@@ -40,7 +48,8 @@ STATE_DTYPE = np.dtype([
     ("copy_first", "<i4"),              # originals: [3 (slot 0)] [pass 0 calls] [pass 1 calls]
     ("cand_first", "<i4"), ("cand_count", "<i4"),
     ("final_first", "<i4"), ("final_count", "<i4"),
-    ("nb_first", "<i4"), ("nb_count", "<i4"),   # LIC: block copies staging the neighbours
+    ("nb_first", "<i4"), ("nb_count", "<i4"),   # LIC / intra: block copies staging the neighbours
+    ("in_satd", "<i4"), ("in_first", "<i4"), ("in_count", "<i4"), ("in_reserved", "<i4"),
     ("level_first", "<i8"), ("level_count", "<i8")], align=True)
 STATE_LIC = 2        # flags: the CU tries local illumination compensation
 NB_WIDTH = 1024      # luma width of the neighbour staging picture
@@ -56,10 +65,66 @@ def _stream(seq):
     return kind, idx
 
 
+class Stager:
+    """Sample strips of a capture (rows above, columns left, LM's luma rectangles) laid out
+    in a staging picture, each copied to its place in the chain's reconstruction picture
+    by one xvcgpu_copy_block.  Rows go to one-row shelves, everything taller to shelves of
+    the tallest strip's height; equal content is stored once."""
+    TALL = (130, 66)                    # shelf heights of the luma / chroma planes
+
+    def __init__(self, api, width=NB_WIDTH):
+        self.api, self.W = api, (width, width // 2)
+        self.row = [[0, 0], [0, 0]]       # next free (x, shelf) of the one-row shelves
+        self.tall = [[0, 0], [0, 0]]
+        self.placed = {}                  # (cls, h, w, bytes) -> (is_row, px, shelf)
+        self.data = []                    # (cls, is_row, px, shelf, array)
+        self.jobs = []                    # (comp, is_row, px, shelf, dx, dy, w, h)
+
+    def add(self, comp, dx, dy, arr):
+        """arr [h, w] -> component comp at (dx, dy) of the destination; returns the job's index"""
+        arr = np.ascontiguousarray(arr, np.uint16)
+        h, w = arr.shape
+        cls = 1 if comp else 0
+        key = (cls, h, w, arr.tobytes())
+        if key not in self.placed:
+            is_row = h == 1
+            cur = self.row[cls] if is_row else self.tall[cls]
+            assert w <= self.W[cls] and h <= self.TALL[cls], (w, h)
+            if cur[0] + w > self.W[cls]:
+                cur[0], cur[1] = 0, cur[1] + 1
+            self.placed[key] = (is_row, cur[0], cur[1])
+            self.data.append((cls, is_row, cur[0], cur[1], arr))
+            cur[0] += w
+        is_row, px, shelf = self.placed[key]
+        self.jobs.append((comp, is_row, px, shelf, dx, dy, w, h))
+        return len(self.jobs) - 1
+
+    def finish(self):
+        """-> (planes of the staging picture, its height, the copy jobs)"""
+        rows = [self.row[c][1] + 1 for c in range(2)]
+        talls = [self.tall[c][1] + 1 for c in range(2)]
+        height = max(rows[0] + self.TALL[0] * talls[0], 2 * (rows[1] + self.TALL[1] * talls[1]))
+        height = (height + 63) // 64 * 64
+        W = self.W[0]
+        planes = [np.zeros((height, W), np.uint16), np.zeros((height // 2, W // 2), np.uint16),
+                  np.zeros((height // 2, W // 2), np.uint16)]
+
+        def sy(cls, is_row, shelf):
+            return shelf if is_row else rows[cls] + self.TALL[cls] * shelf
+        for cls, is_row, px, shelf, arr in self.data:
+            y = sy(cls, is_row, shelf)
+            for c in ((0,) if cls == 0 else (1, 2)):       # (U and V share the chroma layout)
+                planes[c][y:y + arr.shape[0], px:px + arr.shape[1]] = arr
+        jobs = np.zeros(len(self.jobs), self.api.COPY_BLOCK_DTYPE)
+        for i, (comp, is_row, px, shelf, dx, dy, w, h) in enumerate(self.jobs):
+            jobs[i] = (px, sy(1 if comp else 0, is_row, shelf), dx, dy, w, h, comp, 0)
+        return planes, height, jobs
+
+
 class SerialPicture:
     """The states of ONE picture of a clip and their device job arrays."""
 
-    def __init__(self, api, name, poc):
+    def __init__(self, api, name, poc, intra=True):
         self.api, self.name, self.poc = api, name, poc
         self.rd = rd = rf.load(name)
         self.order = o = of.load(name)
@@ -67,6 +132,8 @@ class SerialPicture:
         self.tabs = {"me": self.me, "steps": rd["steps"], "merges": rd["merges"],
                      "evals": rd["evals"], "calls": rd["calls"], "cands": o["cands"],
                      "finals": o["finals"]}
+        # (intra=False: the inter states only, as rounds 4 - 5 walked them)
+        self.intra = ifx.load_order(name) if intra else None
         self._group()
         self._jobs()
 
@@ -91,13 +158,53 @@ class SerialPicture:
                 pending = None
 
         cur = None           # the evaluation state collecting calls
-        for k, i in zip(kind, idx):
+        # the picture's intra records, merged into the order by the number of inter records
+        # in front of each
+        io = self.intra
+        iev = []
+        if io is not None:
+            iev = sorted([(int(io["pos"]["calls"][i]), int(io["stamp"]["calls"][i]), 0, i)
+                          for i in range(len(io["calls"]))] +
+                         [(int(io["pos"]["itx"][i]), int(io["stamp"]["itx"][i]), 1, i)
+                          for i in range(len(io["itx"]))])
+        inext = 0
+        cur_intra = None
+
+        def intra_until(p):
+            """the intra records in front of inter record p of the order"""
+            nonlocal inext, cur_intra, cur
+            while inext < len(iev) and iev[inext][0] <= p:
+                _, _, which, i = iev[inext]
+                inext += 1
+                if which == 0:
+                    c = io["calls"][i]
+                    key = (int(c["x"]), int(c["y"]), int(c["w"]), int(c["h"]))
+                    flush()
+                    cur = None
+                    cur_intra = new_state(KIND_INTRA, key)
+                    cur_intra.update(satd=i, itx=[])
+                    states.append(cur_intra)
+                else:
+                    t_ = io["itx"][i]
+                    sh_ = 1 if t_["comp"] else 0
+                    key = (int(t_["x"]) << sh_, int(t_["y"]) << sh_, int(t_["w"]) << sh_, int(t_["h"]) << sh_)
+                    if cur_intra is None or cur_intra["key"] != key:
+                        flush()
+                        cur = None
+                        cur_intra = new_state(KIND_INTRA, key)
+                        cur_intra.update(satd=-1, itx=[])
+                        states.append(cur_intra)
+                    cur_intra["itx"].append(i)
+
+        for p_, (k, i) in enumerate(zip(kind, idx)):
+            intra_until(p_)
             t = T[k]
             r = tabs[t][i]
             if t == "calls":
                 e = ev_tab[r["eval"]]
                 if int(e["poc"]) != self.poc:
                     continue
+                cur_intra = None
                 key = (int(e["x"]), int(e["y"]), int(e["w"]), int(e["h"]))
                 first = r["comp"] == 0 and r["tx_select_idx"] < 0 and not r["tx_skip"]
                 if first:
@@ -116,6 +223,7 @@ class SerialPicture:
                 continue
             if int(r["poc"]) != self.poc:
                 continue
+            cur_intra = None
             key = (int(r["x"]), int(r["y"]), int(r["w"]), int(r["h"]))
             if t == "evals":
                 continue          # the record is created by the state's first call (next record)
@@ -133,6 +241,7 @@ class SerialPicture:
                 pending = new_state(KIND_MOTION, key)
                 cur = None
             pending[{"me": "me", "cands": "cands", "steps": "steps", "finals": "finals"}[t]].append(int(i))
+        intra_until(1 << 62)
         flush()
         # a motion group that holds TWO CompressInter calls back to back (the first one
         # returned before its evaluation): split at the finals / flag change
@@ -200,7 +309,7 @@ class SerialPicture:
             r["kind"] = s["kind"]
             r["x"], r["y"], r["w"], r["h"] = s["key"]
             r["supported"] = 1
-            r["merge"], r["ev"] = -1, -1
+            r["merge"], r["ev"], r["in_satd"] = -1, -1, -1
             r["me_first"], r["me_count"] = len(me_idx), len(s["me"])
             me_idx += s["me"]
             bi = [i for i in s["steps"] if steps[i]["kind"] == rf.KIND_BI]
@@ -446,70 +555,159 @@ class SerialPicture:
         return q
 
     def _stage_neighbours(self, nb_of_state):
-        """The rows above / columns left of the LIC states' CUs as the capture holds them,
-        laid out in a staging picture (rows as rows, columns as columns: every strip one
-        xvcgpu_copy_block into the chain's reconstruction picture at the CU's place), and
-        per state the range of its block copies."""
-        api, st = self.api, self.states
+        """The rows above / columns left of the LIC states' CUs as the capture holds them, and
+        the reference samples of the intra states' predictions, laid out in a staging picture
+        (Stager): every strip one xvcgpu_copy_block into the chain's reconstruction picture at
+        the CU's place; per state (and per intra call) the range of its block copies."""
+        st = self.states
         nb, smp = self.rd["neighbours"], self.rd["nb_samples"]
-        used = sorted(set(k for ks in nb_of_state.values() for k in ks))
-        W = [NB_WIDTH, NB_WIDTH // 2]
-        row_cur = [[0, 0], [0, 0]]          # [luma / chroma] -> (x, y) of the next row strip
-        col_cur = [[0, 0], [0, 0]]          # -> (column, band) of the next column strip
-        place = {}                          # record -> [(comp, above?, px, py, n)]  (py of columns: band)
-        for k in used:
-            r = nb[k]
-            out = []
-            for cls in range(2):
-                w, h = int(r["w"]) >> cls, int(r["h"]) >> cls
-                if r["has_above"]:
-                    if row_cur[cls][0] + w > W[cls]:
-                        row_cur[cls] = [0, row_cur[cls][1] + 1]
-                    out.append((cls, True, row_cur[cls][0], row_cur[cls][1], w))
-                    row_cur[cls][0] += w
-                if r["has_left"]:
-                    if col_cur[cls][0] >= W[cls]:
-                        col_cur[cls] = [0, col_cur[cls][1] + 1]
-                    out.append((cls, False, col_cur[cls][0], col_cur[cls][1], h))
-                    col_cur[cls][0] += 1
-            place[k] = out
-        rows = [row_cur[c][1] + 1 for c in range(2)]
-        bands = [col_cur[c][1] + 1 for c in range(2)]
-        band_h = [64, 32]
-        height = max(rows[0] + 64 * bands[0], 2 * (rows[1] + 32 * bands[1]))
-        height = (height + 63) // 64 * 64
-        planes = [np.zeros((height, NB_WIDTH), np.uint16), np.zeros((height // 2, NB_WIDTH // 2), np.uint16),
-                  np.zeros((height // 2, NB_WIDTH // 2), np.uint16)]
-        copies = {}
-        for k in used:
-            r = nb[k]
-            off = int(r["sample_off"])
-            pl = {(cls, ab): (px, py, n) for cls, ab, px, py, n in place[k]}
-            jobs = []
-            for c in range(3):
-                cls = 1 if c else 0
-                x, y = int(r["x"]) >> cls, int(r["y"]) >> cls
-                if r["has_above"]:
-                    px, py, n = pl[(cls, True)]
-                    planes[c][py, px:px + n] = smp[off:off + n]
-                    off += n
-                    jobs.append((px, py, x, y - 1, n, 1, c, 0))
-                if r["has_left"]:
-                    px, band, n = pl[(cls, False)]
-                    py = rows[cls] + band_h[cls] * band
-                    planes[c][py:py + n, px] = smp[off:off + n]
-                    off += n
-                    jobs.append((px, py, x - 1, y, 1, n, c, 0))
-            assert off - int(r["sample_off"]) == int(r["sample_count"]), (k, off, r)
-            copies[k] = jobs
-        all_jobs = []
+        sg = Stager(self.api)
+        done = {}                       # LIC neighbour record -> its jobs' indices
+        ranges = {}
         for n in sorted(nb_of_state):
-            st["nb_first"][n] = len(all_jobs)
+            first = len(sg.jobs)
             for k in nb_of_state[n]:
-                all_jobs += copies[k]
-            st["nb_count"][n] = len(all_jobs) - st["nb_first"][n]
-        self.nb_copy = np.array(all_jobs, api.COPY_BLOCK_DTYPE) if all_jobs else np.zeros(0, api.COPY_BLOCK_DTYPE)
-        self.nb_planes, self.nb_height = planes, height
+                r = nb[k]
+                off = int(r["sample_off"])
+                for c in range(3):
+                    cls = 1 if c else 0
+                    x, y = int(r["x"]) >> cls, int(r["y"]) >> cls
+                    w, h = int(r["w"]) >> cls, int(r["h"]) >> cls
+                    if r["has_above"]:
+                        sg.add(c, x, y - 1, smp[off:off + w].reshape(1, w))
+                        off += w
+                    if r["has_left"]:
+                        sg.add(c, x - 1, y, smp[off:off + h].reshape(h, 1))
+                        off += h
+                assert off - int(r["sample_off"]) == int(r["sample_count"]), (k, off, r)
+            st["nb_first"][n], st["nb_count"][n] = first, len(sg.jobs) - first
+        self._intra_jobs(sg)
+        self.nb_planes, self.nb_height, self.nb_copy = sg.finish()
+
+    @staticmethod
+    def _intra_strips(sg, comp, x, y, w, h, nbits, above_right, below_left, smp, off, api):
+        """the reference samples of an intra prediction ([above-left] [above: w +
+        above_right] [left: h + below_left], present parts only) as strips; -> samples used"""
+        o = off
+        if nbits & api.INTRA_HAS_ABOVE_LEFT:
+            sg.add(comp, x - 1, y - 1, smp[o:o + 1].reshape(1, 1))
+            o += 1
+        if nbits & api.INTRA_HAS_ABOVE:
+            n = w + above_right
+            sg.add(comp, x, y - 1, smp[o:o + n].reshape(1, n))
+            o += n
+        if nbits & api.INTRA_HAS_LEFT:
+            n = h + below_left
+            sg.add(comp, x - 1, y, smp[o:o + n].reshape(n, 1))
+            o += n
+        return o - off
+
+    def _intra_jobs(self, sg):
+        """Job arrays of the intra states (kind 4): one xvcgpu_intra_block per SATD
+        pre-selection, and per TransformAndReconstruct call the prediction job, the
+        transform block, the quantiser's parameters and the distortion candidate."""
+        api, st, io = self.api, self.states, self.intra
+        S = self.state_list
+        intra_states = [n for n, s_ in enumerate(S) if s_["kind"] == KIND_INTRA]
+        n_satd = sum(1 for n in intra_states if S[n]["satd"] >= 0)
+        call_idx = [i for n in intra_states for i in S[n]["itx"]]
+        nc = len(call_idx)
+        self.in_satd_jobs = np.zeros(n_satd, api.INTRA_DTYPE)
+        self.in_satd_call = np.zeros(n_satd, np.int64)
+        self.in_pred = np.zeros(nc, api.INTRA_DTYPE)
+        self.in_tx = np.zeros(nc, api.TX_DTYPE)
+        self.in_prm = np.zeros(nc, api.RDOQ_PARAMS_DTYPE)
+        self.in_cand = np.zeros(nc, api.CAND_DTYPE)
+        self.in_off = np.zeros(nc, np.uint32)
+        self.in_ctx = np.zeros(nc, np.int32)
+        self.in_weight = np.zeros(nc, np.float64)
+        self.in_comp = np.zeros(nc, np.int32)
+        self.in_stage = np.zeros((nc, 2), np.int32)      # per call: first / count of its block copies
+        self.in_wait = np.zeros(nc, np.int32)            # a read-back behind the call (end of a mode)
+        self.in_want = io["itx"][np.asarray(call_idx, np.int64)] if nc else (io["itx"][:0] if io is not None else None)
+        self.n_in_levels = 0
+        if io is None or not intra_states:
+            self.in_contexts = np.zeros(1, api.RDOQ_CTX_DTYPE)
+            return
+        calls, itx = io["calls"], io["itx"]
+        qps = io["qps"].view(rf.QP_DTYPE).reshape(-1)
+        self.in_contexts = np.ascontiguousarray(io["contexts"]).view(api.RDOQ_CTX_DTYPE).reshape(-1)
+        k_satd = k_call = 0
+        for n in intra_states:
+            s_ = S[n]
+            r = st[n]
+            r["in_satd"], r["in_first"], r["in_count"] = -1, k_call, len(s_["itx"])
+            staged = {}                 # component -> the samples staged last (bytes)
+            if s_["satd"] >= 0:
+                c = calls[s_["satd"]]
+                x, y, w, h = int(c["x"]), int(c["y"]), int(c["w"]), int(c["h"])
+                first = len(sg.jobs)
+                used = self._intra_strips(sg, 0, x, y, w, h, int(c["neighbors"]), int(c["above_right"]),
+                                          int(c["below_left"]), io["samples"], int(c["sample_off"]), api)
+                staged[0] = io["samples"][int(c["sample_off"]):int(c["sample_off"]) + used].tobytes()
+                r["nb_first"], r["nb_count"] = first, len(sg.jobs) - first
+                jb = self.in_satd_jobs[k_satd]
+                jb["x"], jb["y"], jb["w"], jb["h"], jb["comp"] = x, y, w, h, 0
+                jb["neighbors"], jb["above_right"], jb["below_left"] = c["neighbors"], c["above_right"], c["below_left"]
+                self.in_satd_jobs[k_satd] = jb
+                self.in_satd_call[k_satd] = s_["satd"]
+                r["in_satd"] = k_satd
+                k_satd += 1
+            for pos_, i in enumerate(s_["itx"]):
+                t = itx[i]
+                comp = int(t["comp"])
+                x, y, w, h = int(t["x"]), int(t["y"]), int(t["w"]), int(t["h"])
+                off = int(t["sample_off"])
+                nbits = int(t["neighbors"])
+                n_ref = ((1 if nbits & api.INTRA_HAS_ABOVE_LEFT else 0) +
+                         (w + int(t["above_right"]) if nbits & api.INTRA_HAS_ABOVE else 0) +
+                         (h + int(t["below_left"]) if nbits & api.INTRA_HAS_LEFT else 0))
+                lm = int(t["mode"]) == 67
+                n_lm = 0
+                if lm:
+                    lx, ly = x << 1, y << 1
+                    x0, y0 = (lx - 3 if lx > 0 else lx), (ly - 2 if ly > 0 else ly)
+                    rw, rh = lx + 2 * w - x0, ly + 2 * h - y0
+                    n_lm = rw * rh
+                blob = io["itx_samples"][off:off + n_ref + n_lm]
+                first = len(sg.jobs)
+                if staged.get(comp) != blob[:n_ref].tobytes():
+                    self._intra_strips(sg, comp, x, y, w, h, nbits, int(t["above_right"]),
+                                       int(t["below_left"]), io["itx_samples"], off, api)
+                    staged[comp] = blob[:n_ref].tobytes()
+                if lm and staged.get("lm") != blob[n_ref:].tobytes():
+                    sg.add(0, x0, y0, blob[n_ref:].reshape(rh, rw))
+                    staged["lm"] = blob[n_ref:].tobytes()
+                    staged.pop(0, None)        # (the rectangle overwrote the luma strips)
+                self.in_stage[k_call] = (first, len(sg.jobs) - first)
+                jb = self.in_pred[k_call]
+                for f in ("x", "y", "w", "h", "comp", "mode", "neighbors", "above_right", "below_left"):
+                    jb[f] = t[f]
+                self.in_pred[k_call] = jb
+                b = self.in_tx[k_call]
+                for f in ("x", "y", "w", "h", "comp", "tx_ver", "qp", "dst4x4"):
+                    b[f] = t[f]
+                b["tx_hor"] = 6 if t["tx_skip"] else t["tx_hor"]
+                b["intra_pic"] = api.TXF_RDOQ | (int(t["scan"]) << api.TXF_SCAN_SHIFT) | (1 if t["intra_pic"] else 0)
+                self.in_tx[k_call] = b
+                q = qps[int(t["qp_index"])]
+                pr = self.in_prm[k_call]
+                pr["lambda"], pr["rd_factor"] = q["lambda"][comp], q["rd_factor"][comp]
+                pr["ctx_index"], pr["flags"] = 0, api.RDOQ_INTRA_CU
+                self.in_prm[k_call] = pr
+                cd = self.in_cand[k_call]
+                cd["x"], cd["y"], cd["w"], cd["h"] = x, y, w, h
+                cd["metric"], cd["qp"] = (7 if comp == 0 else 0), t["qp_luma"]
+                self.in_cand[k_call] = cd
+                self.in_off[k_call] = self.n_in_levels
+                self.n_in_levels += w * h
+                self.in_ctx[k_call] = t["ctx_index"]
+                self.in_weight[k_call] = q["dist_weight"][comp]
+                self.in_comp[k_call] = comp
+                nxt = itx[s_["itx"][pos_ + 1]] if pos_ + 1 < len(s_["itx"]) else None
+                self.in_wait[k_call] = int(nxt is None or int(nxt["comp"]) < comp or
+                                           (comp == 0 and (int(nxt["comp"]) != 0 or int(nxt["mode"]) != int(t["mode"]))))
+                k_call += 1
 
     def position_start(self, i):
         """The first state at or behind i that opens a visit of a CU position (a stretch of
@@ -540,13 +738,18 @@ class CsTables(C.Structure):
             "d_contexts", "d_copy_orig", "d_call_tx", "d_call_prm", "d_call_off",
             "d_call_copy_pred", "d_call_cand", "d_levels", "d_nnz", "d_call_dist", "h_me_res",
             "h_bi_res", "h_aff_res", "h_mg_dist", "h_ev_dz_dist", "h_call_dist", "h_nnz",
-            "h_levels", "rec", "nb", "d_nb_copy", "d_bi_lic")]
+            "h_levels", "rec", "nb", "d_nb_copy", "d_bi_lic",
+            # intra states
+            "ipred", "irec", "d_in_satd_jobs", "d_in_satd", "h_in_satd", "d_in_pred", "d_in_tx",
+            "d_in_prm", "d_in_off", "d_in_cand", "d_in_contexts", "in_ctx", "in_weight", "in_comp",
+            "in_stage", "in_wait", "in_off_h", "d_in_levels", "d_in_nnz", "d_in_dist", "h_in_nnz", "h_in_dist",
+            "h_in_levels")]
 
 
 class CsStats(C.Structure):
     _fields_ = [("seconds", C.c_double), ("states", C.c_int64), ("skipped", C.c_int64),
                 ("api_calls", C.c_int64), ("round_trips", C.c_int64),
-                ("seconds_by_kind", C.c_double * 4), ("states_by_kind", C.c_int64 * 4)]
+                ("seconds_by_kind", C.c_double * 5), ("states_by_kind", C.c_int64 * 5)]
 
 
 class SerialRun:
@@ -588,6 +791,15 @@ class SerialRun:
         t.d_call_copy_pred, t.d_call_cand = up(sp.call_copy_pred), up(sp.call_cand)
         t.rec, t.nb = self.rec.h_pic, self.nb.h_pic
         t.d_nb_copy, t.d_bi_lic = up(sp.nb_copy), up(sp.bi_lic)
+        # intra states: prediction and reconstruction at the CU's own place
+        self.ipred, self.irec = ctx.picture(width, height, 10), ctx.picture(width, height, 10)
+        t.ipred, t.irec = self.ipred.h_pic, self.irec.h_pic
+        t.d_in_satd_jobs, t.d_in_pred, t.d_in_tx = up(sp.in_satd_jobs), up(sp.in_pred), up(sp.in_tx)
+        t.d_in_prm, t.d_in_off, t.d_in_cand = up(sp.in_prm), up(sp.in_off), up(sp.in_cand)
+        t.d_in_contexts = up(sp.in_contexts)
+        t.in_ctx, t.in_weight, t.in_comp = self._host(sp.in_ctx), self._host(sp.in_weight), self._host(sp.in_comp)
+        t.in_stage, t.in_wait = self._host(sp.in_stage), self._host(sp.in_wait)
+        t.in_off_h = self._host(np.r_[sp.in_off, sp.n_in_levels].astype(np.uint32))
         res = self.res = {}
         for name, dt, n in (("me_res", api.MERES_DTYPE, len(sp.me_jobs)),
                             ("bi_res", api.MERES_DTYPE, len(sp.bi_jobs)),
@@ -596,14 +808,18 @@ class SerialRun:
                             ("ev_dz_dist", np.dtype("<u8"), 3 * len(sp.ev_inter)),
                             ("call_dist", np.dtype("<u8"), len(sp.call_tx)),
                             ("nnz", np.dtype("<i4"), len(sp.call_tx)),
-                            ("levels", np.dtype("<i2"), sp.n_levels)):
+                            ("levels", np.dtype("<i2"), sp.n_levels),
+                            ("in_satd", np.dtype("<u4"), 67 * len(sp.in_satd_jobs)),
+                            ("in_nnz", np.dtype("<i4"), len(sp.in_tx)),
+                            ("in_dist", np.dtype("<u8"), len(sp.in_tx)),
+                            ("in_levels", np.dtype("<i2"), sp.n_in_levels)):
             nbytes = max(n, 1) * dt.itemsize
             d = ctx.alloc(nbytes)
             self._keep.append(d)
             h = self._pin(nbytes)
             C.memset(h, 0xff, nbytes)
             res[name] = np.frombuffer((C.c_char * nbytes).from_address(h), dt)[:n]
-            setattr(t, "d_" + name if name not in ("levels", "nnz") else "d_" + name, d.ptr)
+            setattr(t, "d_" + name, d.ptr)
             setattr(t, "h_" + name, h)
         ctx.sync()
 
@@ -699,6 +915,34 @@ class SerialRun:
                     if rf.crc32_rows(lv[off[k]:off[k] + ne[k]]) != int(w["levels_crc"][k]):
                         bad[k] = True
             out["calls"] = (len(i), int(bad.sum()))
+        # intra states: every evaluated mode's SATD, every TransformAndReconstruct
+        it = st[st["kind"] == KIND_INTRA]
+        if len(it) and sp.intra is not None:
+            io = sp.intra
+            sat = res["in_satd"].reshape(-1, 67)
+            done = wrong = 0
+            for k in it["in_satd"][it["in_satd"] >= 0]:
+                c = io["calls"][int(sp.in_satd_call[k])]
+                e = io["evals"][int(c["first_eval"]):int(c["first_eval"]) + int(c["n_eval"])]
+                done += len(e)
+                wrong += int((sat[k, e["mode"]] != e["dist"]).sum())
+            out["intra_satd"] = (done, wrong)
+            i = np.concatenate([np.arange(int(a), int(a) + int(b)) for a, b in zip(it["in_first"], it["in_count"])]) \
+                if it["in_count"].sum() else np.zeros(0, np.int64)
+            w = sp.in_want[i]
+            bad = res["in_nnz"][i] != w["nnz"]
+            bad |= (w["completed"] != 0) & (res["in_dist"][i] != w["dist"])
+            if levels:
+                lv = res["in_levels"]
+                off = sp.in_off[i].astype(np.int64)
+                ne = sp.in_tx["w"][i].astype(np.int64) * sp.in_tx["h"][i]
+                for k in np.flatnonzero((w["nnz"] != 0) & ~bad):
+                    if rf.crc32_rows(lv[off[k]:off[k] + ne[k]].reshape(int(sp.in_tx["h"][i[k]]), -1)) != int(w["levels_crc"][k]):
+                        bad[k] = True
+            out["intra_calls"] = (len(i), int(bad.sum()))
+            if bad.any():
+                k = int(np.flatnonzero(bad)[0])
+                self.first_bad_intra = (int(i[k]), tuple(w[k]), int(res["in_nnz"][i[k]]), int(res["in_dist"][i[k]]))
         return out
 
     def destroy(self):
@@ -707,7 +951,7 @@ class SerialRun:
         for b in self._keep:
             if hasattr(b, "free"):
                 b.free()
-        for p in self.scratch + [self.orig, self.rec, self.nb]:
+        for p in self.scratch + [self.orig, self.rec, self.nb, self.ipred, self.irec]:
             p.destroy()
 
 
@@ -739,8 +983,9 @@ OP_DTYPE = np.dtype([("opcode", "<i4"), ("n", "<i4"), ("r0", "<i4"), ("r1", "<i4
                      ("reserved", "<i4"), ("f", "<f8"), ("p", "<u8", 8)], align=True)
 (OP_MC_METRIC, OP_METRIC, OP_ME, OP_BI, OP_AFFINE, OP_COPY, OP_INTER_PRED, OP_RESIDUAL,
  OP_START_FOLD, OP_UNI_FOLD, OP_BI_FOLD, OP_FETCH, OP_SYNC, OP_EVAL_DIST, OP_MC_METRIC_REFS,
- OP_ME_REFS, OP_BI_REFS, OP_AFFINE_REFS, OP_MERGE_FOLD, OP_BI_LIC) = range(20)
-PIC_ORIG, PIC_S_ORIG, PIC_S_PRED, PIC_S_REC, PIC_NB, PIC_REC = 0, 1, 2, 3, 4, 5
+ OP_ME_REFS, OP_BI_REFS, OP_AFFINE_REFS, OP_MERGE_FOLD, OP_BI_LIC, OP_INTRA_SATD, OP_INTRA_PRED,
+ OP_RESIDUAL_INTRA) = range(23)
+PIC_ORIG, PIC_S_ORIG, PIC_S_PRED, PIC_S_REC, PIC_NB, PIC_REC, PIC_IPRED, PIC_IREC = 0, 1, 2, 3, 4, 5, 6, 7
 BI_SLOTS = 2 * R3 * R3
 
 
@@ -810,7 +1055,8 @@ class CsEnv(C.Structure):
                 ("pic_w", C.c_int32), ("pic_h", C.c_int32), ("reserved", C.c_int32),
                 ("s_orig", C.c_void_p), ("s_pred", C.c_void_p), ("s_rec", C.c_void_p),
                 ("d_levels", C.c_void_p), ("d_results", C.c_void_p),
-                ("rec", C.c_void_p), ("nb", C.c_void_p)]
+                ("rec", C.c_void_p), ("nb", C.c_void_p), ("ipred", C.c_void_p), ("irec", C.c_void_p),
+                ("d_in_levels", C.c_void_p)]
 
 
 def build_passes(sp, ref_lists):
@@ -834,7 +1080,8 @@ def build_passes(sp, ref_lists):
     aff_work_rows = []          # (source: index into sp.aff_jobs or -1 for a slot)
     n_bi_slots = 0
     uni_groups, aff_uni_groups = {}, {}
-    folded = (st["kind"] >= KIND_INTER) & (st["supported"] != 0) & ((st["flags"] & STATE_LIC) == 0)
+    folded = ((st["kind"] == KIND_INTER) | (st["kind"] == KIND_MOTION)) & (st["supported"] != 0) & \
+        ((st["flags"] & STATE_LIC) == 0)
     for n in np.flatnonzero(folded):
         s = st[n]
         cds = cd_all[int(s["cand_first"]):int(s["cand_first"]) + int(s["cand_count"])]
@@ -1107,6 +1354,7 @@ class ChainedRun(SerialRun):
         e.s_orig, e.s_pred, e.s_rec = self.t.s_orig, self.t.s_pred, self.t.s_rec
         e.d_levels, e.d_results = self.t.d_levels, d["results"]
         e.rec, e.nb = self.t.rec, self.t.nb
+        e.ipred, e.irec, e.d_in_levels = self.t.ipred, self.t.irec, self.t.d_in_levels
         self.ctx.sync()
 
     # ---- program ---------------------------------------------------------------
@@ -1134,7 +1382,7 @@ class ChainedRun(SerialRun):
                                         ("pos", api.POS_DTYPE), ("cand", api.CAND_DTYPE),
                                         ("copy", api.COPY_BLOCK_DTYPE), ("tx", api.TX_DTYPE),
                                         ("prm", api.RDOQ_PARAMS_DTYPE), ("ctx", api.RDOQ_CTX_DTYPE),
-                                        ("result", RESULT_DTYPE))}
+                                        ("result", RESULT_DTYPE), ("intra", api.INTRA_DTYPE))}
 
         def op(code, n_=0, r0=0, r1=0, i0=0, f=0.0, p=()):
             ops.append((code, n_, r0, r1, i0, 0, f, tuple(int(x) for x in p) + (0,) * (8 - len(p))))
@@ -1193,6 +1441,41 @@ class ChainedRun(SerialRun):
             if live and int(s["kind"]) == KIND_INTER:      # the three-way choice is the host's
                 flush_fetches()
                 op(OP_SYNC, i0=0, r0=int(s["kind"]))
+
+        def intra(s):
+            """CompressIntra: the SATD pre-selection, a wait (the host sorts with the mode
+            bits), then the kept luma modes' and the chroma modes' PredictAndTransform
+            alternatives one behind the other at the CU's place.  The mode loops decide
+            nothing between the modes (intra_search.cc:61-82, :118-150): a chain by
+            position / state waits once more at the end, a live chain behind the luma modes
+            and behind the chroma modes (CompressIntra prices luma before chroma starts)."""
+            ms = max(int(s["w"]), int(s["h"]))
+            k = int(s["in_satd"])
+            if k >= 0:
+                op(OP_INTRA_SATD, 1, i0=ms, p=(t.d_in_satd_jobs + k * I["intra"], t.d_in_satd + 4 * 67 * k))
+                fetch(t.d_in_satd + 4 * 67 * k, t.h_in_satd + 4 * 67 * k, 4 * 67)
+                flush_fetches()
+                op(OP_SYNC, i0=0, r0=KIND_INTRA)
+            a, nc_ = int(s["in_first"]), int(s["in_count"])
+            for c in range(a, a + nc_):
+                sf_, sc_ = int(sp.in_stage[c][0]), int(sp.in_stage[c][1])
+                if sc_:
+                    op(OP_COPY, sc_, r0=PIC_NB, r1=PIC_REC, p=(t.d_nb_copy + sf_ * I["copy"],))
+                op(OP_INTRA_PRED, 1, p=(t.d_in_pred + c * I["intra"],))
+                op(OP_RESIDUAL_INTRA, 1, p=(t.d_in_tx + c * I["tx"], t.d_in_off + 4 * c, t.d_in_nnz + 4 * c,
+                                            t.d_in_contexts + int(sp.in_ctx[c]) * I["ctx"], t.d_in_prm + c * I["prm"]))
+                op(OP_METRIC, 1, r0=PIC_ORIG, r1=PIC_IREC, i0=int(sp.in_comp[c]), f=float(sp.in_weight[c]),
+                   p=(t.d_in_cand + c * I["cand"], t.d_in_dist + 8 * c))
+                if live and c + 1 < a + nc_ and int(sp.in_comp[c]) == 0 and int(sp.in_comp[c + 1]) != 0:
+                    fetch(t.d_in_nnz + 4 * a, t.h_in_nnz + 4 * a, 4 * (c + 1 - a))
+                    fetch(t.d_in_dist + 8 * a, t.h_in_dist + 8 * a, 8 * (c + 1 - a))
+                    flush_fetches()
+                    op(OP_SYNC, i0=0, r0=KIND_INTRA)
+            fetch(t.d_in_nnz + 4 * a, t.h_in_nnz + 4 * a, 4 * nc_)
+            fetch(t.d_in_dist + 8 * a, t.h_in_dist + 8 * a, 8 * nc_)
+            if nc_:
+                la, lb = int(sp.in_off[a]), (int(sp.in_off[a + nc_]) if a + nc_ < len(sp.in_off) else sp.n_in_levels)
+                fetch(t.d_in_levels + 2 * la, t.h_in_levels + 2 * la, 2 * (lb - la))
 
         def motion(s, n_state):
             if int(s["flags"]) & STATE_LIC:
@@ -1390,6 +1673,8 @@ class ChainedRun(SerialRun):
                 if self.merge_fold:
                     op(OP_MERGE_FOLD, 1, i0=m // 5,
                        p=(d["mg_fold"], self.z["mg_dist"][1], t.d_mg_inter, self.z["mg_res"][1], d["mg_slots"]))
+            elif kind == KIND_INTRA:
+                intra(s)
             else:
                 if kind in (KIND_INTER, KIND_MOTION):
                     motion(s, n_state)

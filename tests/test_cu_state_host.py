@@ -70,7 +70,7 @@ def test_passes_of_a_captured_picture():
     rd_serial.build_passes(sp, rd_serial.ref_lists_of("tiny", 2))
     st, ps = sp.states, sp.passes
     # (LIC states walk in the serial form: no passes)
-    motion = (st["kind"] >= rd_serial.KIND_INTER) & (st["supported"] != 0) & \
+    motion = ((st["kind"] == rd_serial.KIND_INTER) | (st["kind"] == rd_serial.KIND_MOTION)) & (st["supported"] != 0) & \
         ((st["flags"] & rd_serial.STATE_LIC) == 0)
     assert (sp.pass_count[motion] >= 1).all() and (sp.pass_count[~motion] == 0).all()
     assert len(ps) == int(sp.pass_count.sum()) > 1000

@@ -150,7 +150,7 @@ def walk(api, clip, poc, n_states, ks, mode="serial", check=True, decoded=None, 
             "pictures_per_s": done / wall / (s0.states * per_pic),
             "pictures_per_s_runs": [done / x / (s0.states * per_pic) for x in walls],
             "us_by_kind": {name: 1e6 * s0.seconds_by_kind[i] / max(s0.states_by_kind[i], 1)
-                           for i, name in enumerate(("merge_rank", "eval", "inter", "motion_only"))},
+                           for i, name in enumerate(("merge_rank", "eval", "inter", "motion_only", "intra"))},
         }
         if mode == "chained" and k > 1 and threads_list:
             # T host threads, each driving k / T chains interleaved

@@ -20,7 +20,18 @@ print(sp.summary(), "LIC states", int(((sp.states["flags"] & 2) != 0).sum()))
 run = rd_serial.SerialRun(api, ctx, sp, pics, w, h)
 stats = run.run_serial(0, len(sp.states))
 res = run.check(0, len(sp.states))
-print("serial", res, "%.1f us / state" % (1e6 * stats.seconds / stats.states))
+print("serial", res, "%.1f us / state" % (1e6 * stats.seconds / stats.states), getattr(run, "first_bad_intra", None))
+print("by kind us", [round(1e6 * stats.seconds_by_kind[i] / max(stats.states_by_kind[i], 1), 1) for i in range(5)],
+      [stats.states_by_kind[i] for i in range(5)])
+if res.get("intra_calls", (0, 0))[1]:
+    w = sp.in_want
+    g_n, g_d = run.res["in_nnz"], run.res["in_dist"]
+    bad = (g_n != w["nnz"]) | ((w["completed"] != 0) & (g_d != w["dist"]))
+    print("intra calls bad by comp", [int((bad & (w["comp"] == c)).sum()) for c in range(3)],
+          "LM", int((bad & (w["mode"] == 67)).sum()), "of", int((w["mode"] == 67).sum()),
+          "nnz-only", int((g_n != w["nnz"]).sum()))
+    for k in np.flatnonzero(bad)[:6]:
+        print("  itx", k, tuple(w[k][["x", "y", "w", "h", "comp", "mode", "tx_skip", "tx_hor", "tx_ver", "nnz", "dist"]]), int(g_n[k]), int(g_d[k]))
 st = sp.states
 lic = (st["flags"] & 2) != 0
 # bi mismatches by state
@@ -46,5 +57,6 @@ for label, kw in (("by position", dict(by_position=True)), ("by state", dict(by_
     res = run.check(0, len(sp.states), searches=False)
     res.update(run.check_chained(0, len(sp.states)))
     print(label, res, "%.1f us / state, %.2f round trips per state" % (
-        1e6 * stats.seconds / stats.states, stats.round_trips / stats.states), getattr(run, "first_bad", None))
+        1e6 * stats.seconds / stats.states, stats.round_trips / stats.states), getattr(run, "first_bad", None),
+        getattr(run, "first_bad_intra", None))
     run.destroy()

@@ -45,6 +45,13 @@ import stream_fixture as sf  # noqa: E402
 from xvc_amd import synth  # noqa: E402
 
 KEEP = {"tiny": None, "c0": None, "c1": 2}
+# round 5: the INTRA states of the picture tests/rd_serial.py walks (CompressIntra,
+# cu_encoder.cc:518-541): every DetermineSlowIntraModes call and every
+# TransformAndReconstruct of its intra CUs, stamped with the same sequence counter ->
+# tests/golden/intra_order_<clip>.npz.  clip -> (picture, at most this many inter records
+# of the order in front of a kept intra record: the 1080p picture's capture is cut to the
+# stretch the tests walk)
+INTRA_WALK = {"tiny": (2, None), "c0": (4, None), "c1": (2, None)}
 SEQ_TABLES = ["me", "steps", "merges", "evals", "calls", "cands", "finals"]
 
 
@@ -55,6 +62,80 @@ def fetch(lib, which, dt):
         return np.zeros(0, dt)
     buf = (C.c_char * (n * dt.itemsize)).from_address(lib.xr_rd_data(which))
     return np.frombuffer(buf, dt).copy()
+
+
+def write_intra(lib, name, poc, cut, pos, stamp):
+    """tests/golden/intra_order_<clip>.npz: calls / evals / samples (intra_fixture.CALL_DTYPE,
+    EVAL_DTYPE), itx / itx_samples / contexts / qps (ITX_DTYPE; LM chroma = mode 67, its luma
+    rectangle behind its reference samples), pos/<table>: inter records of the order in front
+    of each record, stamp/<table>: the records' own order among the intra records."""
+    import ctypes as C
+    import intra_fixture as ifx
+    lib.xr_intra_count.restype = C.c_long
+    lib.xr_intra_data.restype = C.c_void_p
+
+    def ifetch(which, dt):
+        n = lib.xr_intra_count(which)
+        assert lib.xr_intra_size(which) == dt.itemsize
+        if n == 0:
+            return np.zeros(0, dt)
+        return np.frombuffer((C.c_char * (n * dt.itemsize)).from_address(lib.xr_intra_data(which)), dt).copy()
+
+    calls, evals, samples = ifetch(0, ifx.CALL_DTYPE), ifetch(1, ifx.EVAL_DTYPE), ifetch(2, np.dtype("<u2"))
+    itx, itx_samples = fetch(lib, 9, ifx.ITX_DTYPE), fetch(lib, 10, np.dtype("<u2"))
+    ctx = fetch(lib, 14, np.dtype(("u1", rf.CTX_BYTES)))
+    qps = fetch(lib, 15, rf.QP_DTYPE)
+    assert len(calls) == len(pos[0]) and len(itx) == len(pos[1]), (len(calls), len(pos[0]), len(itx), len(pos[1]))
+    assert (calls["poc"] == poc).all() and (itx["poc"] == poc).all()
+    rank = np.argsort(np.argsort(np.concatenate(stamp)))      # own order among the intra records
+    st = [rank[:len(calls)], rank[len(calls):]]
+    if cut is not None:          # keep the leading stretch only (sample arrays re-packed)
+        kc, kt = pos[0] < cut, pos[1] < cut
+        new_off, chunks = [], []
+        total = 0
+        ends = np.r_[calls["sample_off"][1:], len(samples)]
+        for i in np.flatnonzero(kc):
+            a, b = int(calls["sample_off"][i]), int(ends[i])
+            new_off.append(total)
+            chunks.append(samples[a:b])
+            total += b - a
+        ev_keep = kc[evals["call"]]
+        remap = np.cumsum(kc) - 1
+        evals = evals[ev_keep].copy()
+        evals["call"] = remap[evals["call"]]
+        calls = calls[kc].copy()
+        calls["sample_off"] = new_off
+        calls["first_eval"] = np.r_[0, np.cumsum(calls["n_eval"])[:-1]]
+        samples = np.concatenate(chunks) if chunks else samples[:0]
+        ends = np.r_[itx["sample_off"][1:], len(itx_samples)]
+        new_off, chunks, total = [], [], 0
+        for i in np.flatnonzero(kt):
+            a, b = int(itx["sample_off"][i]), int(ends[i])
+            new_off.append(total)
+            chunks.append(itx_samples[a:b])
+            total += b - a
+        itx = itx[kt].copy()
+        itx["sample_off"] = new_off
+        itx_samples = np.concatenate(chunks) if chunks else itx_samples[:0]
+        pos = [pos[0][kc], pos[1][kt]]
+        st = [st[0][kc], st[1][kt]]
+        uc, inv = np.unique(itx["ctx_index"], return_inverse=True)      # the snapshots still used
+        ctx, itx["ctx_index"] = ctx[uc], inv
+    cols = {}
+    for t, a in (("calls", calls), ("evals", evals), ("itx", itx)):
+        for f in a.dtype.names:
+            if not f.startswith("pad"):
+                cols["%s/%s" % (t, f)] = np.ascontiguousarray(a[f])
+    cols.update({"samples": samples, "itx_samples": itx_samples, "contexts": ctx, "qps": qps.view("u1"),
+                 "pos/calls": pos[0].astype(np.int64), "pos/itx": pos[1].astype(np.int64),
+                 "stamp/calls": st[0].astype(np.int64), "stamp/itx": st[1].astype(np.int64)})
+    path = os.path.join(sf.GOLDEN, "intra_order_%s.npz" % name)
+    np.savez_compressed(path, **cols)
+    print("  %s: %d DetermineSlowIntraModes calls (%d mode evaluations), %d TransformAndReconstruct "
+          "calls of intra CUs (%d LM chroma), %d context snapshots -> %s (%.1f KB)" % (
+              name, len(calls), len(evals), len(itx), int((itx["mode"] == 67).sum()), len(ctx), path,
+              os.path.getsize(path) / 1024))
+    gsg.update_manifest("intra_order_%s.npz" % name)
 
 
 def main():
@@ -70,9 +151,14 @@ def main():
         clip = synth.SyntheticClip(c["w"], c["h"], 8)
         lib.xr_me_capture_begin(-1 if only is None else only)
         lib.xr_rd_capture_begin(-1 if only is None else only)
+        ipoc, icut = INTRA_WALK[name]
+        lib.xr_intra_capture_begin(1 << 30, 1)
+        lib.xr_intra_capture_poc(ipoc)
+        lib.xr_rd_capture_intra_walk(1 << 30, ipoc)
         stream = gsg.encode(lib, clip, c["w"], c["h"], c["n"], c["qp"], c["sub_gop"], threads=0)
         n_me = lib.xr_me_capture_end()
         lib.xr_rd_capture_end()
+        lib.xr_intra_capture_end()
         committed = np.load(os.path.join(sf.GOLDEN, "stream_%s.npz" % name))["stream"]
         assert np.array_equal(stream, committed), "stream differs from the committed fixture"
         # the tables of this run = the committed fixtures
@@ -95,7 +181,15 @@ def main():
                  len(out["cands"]), len(out["finals"])]
         assert [len(s) for s in seqs] == sizes, ([len(s) for s in seqs], sizes)
         allseq = np.sort(np.concatenate(seqs))
-        assert np.array_equal(allseq, np.arange(len(allseq), dtype=np.uint32) + allseq[0])
+        # the intra records share the counter: the seven tables' numbers are made dense
+        # again (rd_order_<clip>.npz as before), an intra record is placed by the number of
+        # inter records in front of it
+        iseq = [fetch(lib, 27, np.dtype("<u4")), fetch(lib, 28, np.dtype("<u4"))]
+        both = np.sort(np.concatenate(seqs + iseq))
+        assert np.array_equal(both, np.arange(len(both), dtype=np.uint32) + both[0])
+        seqs = [np.searchsorted(allseq, q).astype(np.uint32) for q in seqs]
+        write_intra(lib, name, ipoc, icut, [np.searchsorted(allseq, q) for q in iseq], iseq)
+        allseq = np.arange(len(allseq), dtype=np.uint32)
         cols = of.to_columns(out)
         for t, s in zip(SEQ_TABLES, seqs):
             cols["seq/" + t] = np.diff(s.astype(np.int64) - int(allseq[0]), prepend=0).astype(np.int32)

@@ -181,6 +181,40 @@ struct Walk {
       ReadBack();
     }
   }
+  // CompressIntra: the SATD of the 67 luma modes, a wait (the host sorts with the mode
+  // bits and keeps a few), then every PredictAndTransform alternative one behind the other
+  // at the CU's own place - prediction from the staged reconstruction, transform + RDOQ +
+  // reconstruction, distortion - with a wait wherever the reference reads a mode's cost
+  void Intra(const xvc_cs_state &s) {
+    const int max_size = s.w > s.h ? s.w : s.h;
+    if (s.in_satd >= 0) {
+      Ok(xvcgpu_intra_satd_batch(ctx, t.orig, t.rec, t.d_in_satd_jobs + s.in_satd, 1,
+                                 t.d_in_satd + (size_t)67 * s.in_satd, max_size));
+      Fetch(t.h_in_satd, t.d_in_satd, (size_t)67 * s.in_satd, 67);
+      ReadBack();
+    }
+    int fetched = s.in_first;
+    for (int c = s.in_first; c < s.in_first + s.in_count; c++) {
+      if (t.in_stage[2 * c + 1])
+        Ok(xvcgpu_copy_blocks(ctx, t.nb, t.rec, t.d_nb_copy + t.in_stage[2 * c], t.in_stage[2 * c + 1]));
+      Ok(xvcgpu_intra_pred_batch(ctx, t.rec, t.ipred, t.d_in_pred + c, 1));
+      Ok(xvcgpu_residual_rdoq_batch(ctx, t.orig, t.ipred, t.irec, t.d_in_tx + c, 1, t.d_in_levels,
+                                    t.d_in_off + c, t.d_in_nnz + c, t.d_in_contexts + t.in_ctx[c],
+                                    t.d_in_prm + c));
+      Ok(xvcgpu_metric_batch(ctx, t.orig, t.irec, t.in_comp[c], t.in_weight[c], 16, t.d_in_cand + c, 1,
+                             t.d_in_dist + c));
+      if (t.in_wait[c]) {
+        Fetch(t.h_in_nnz, t.d_in_nnz, fetched, c + 1 - fetched);
+        Fetch(t.h_in_dist, t.d_in_dist, fetched, c + 1 - fetched);
+        if (read_levels) {
+          const size_t a = t.in_off_h[fetched], b = t.in_off_h[c + 1];   // (consecutive)
+          Fetch(t.h_in_levels, t.d_in_levels, a, b - a);
+        }
+        ReadBack();
+        fetched = c + 1;
+      }
+    }
+  }
   // levels of a state's pass: the luma selections of pass 1 are w * h each
   size_t LevelCount(const xvc_cs_state &s, int pass) const {
     const size_t p1 = (size_t)s.call_pass1 * s.w * s.h;
@@ -217,6 +251,7 @@ extern "C" int xvc_host_cu_state_run_serial(xvcgpu_ctx *ctx, const xvc_cs_tables
       case XVC_CS_EVAL: w.Eval(s); break;
       case XVC_CS_INTER: w.Motion(s); w.Eval(s); break;
       case XVC_CS_MOTION: w.Motion(s); break;
+      case XVC_CS_INTRA: w.Intra(s); break;
       default: return XVCGPU_INVALID_ARGUMENT;
     }
     stats->seconds_by_kind[s.kind] += Now() - a;
@@ -247,7 +282,8 @@ extern "C" void xvc_host_cs_sizes(int32_t out[7]) {
 namespace {
 // one op of a chain program (SYNC is the caller's)
 xvcgpu_status IssueOp(xvcgpu_ctx *ctx, const xvc_cs_env *env, const xvc_cs_op &o) {
-  const xvcgpu_picture *pics[6] = {env->orig, env->s_orig, env->s_pred, env->s_rec, env->nb, env->rec};
+  const xvcgpu_picture *pics[8] = {env->orig, env->s_orig, env->s_pred, env->s_rec,
+                                   env->nb,   env->rec,    env->ipred,  env->irec};
   void *const *p = reinterpret_cast<void *const *>(o.p);
   // r0 / r1 name a reference slot or one of the four pictures above, by opcode
   const bool ref_slots = o.opcode == XVC_OP_MC_METRIC || o.opcode == XVC_OP_ME ||
@@ -259,8 +295,11 @@ xvcgpu_status IssueOp(xvcgpu_ctx *ctx, const xvc_cs_env *env, const xvc_cs_op &o
                     (o.opcode != XVC_OP_MC_METRIC && o.opcode != XVC_OP_ME &&
                      (o.r1 < 0 || o.r1 >= env->n_refs))))
     return XVCGPU_INVALID_ARGUMENT;
-  if (pic_index && (o.r1 < 0 || o.r1 > 5 || !pics[o.r1] ||
-                    (o.opcode != XVC_OP_INTER_PRED && (o.r0 < 0 || o.r0 > 5 || !pics[o.r0]))))
+  if (pic_index && (o.r1 < 0 || o.r1 > 7 || !pics[o.r1] ||
+                    (o.opcode != XVC_OP_INTER_PRED && (o.r0 < 0 || o.r0 > 7 || !pics[o.r0]))))
+    return XVCGPU_INVALID_ARGUMENT;
+  if ((o.opcode == XVC_OP_INTRA_SATD || o.opcode == XVC_OP_INTRA_PRED ||
+       o.opcode == XVC_OP_RESIDUAL_INTRA) && (!env->rec || !env->ipred || !env->irec))
     return XVCGPU_INVALID_ARGUMENT;
   if ((o.opcode == XVC_OP_BI_LIC || (o.opcode == XVC_OP_INTER_PRED && o.r0 == 1)) && !env->rec)
     return XVCGPU_INVALID_ARGUMENT;
@@ -368,6 +407,20 @@ xvcgpu_status IssueOp(xvcgpu_ctx *ctx, const xvc_cs_env *env, const xvc_cs_op &o
                                          static_cast<const xvcgpu_affine_me_block *>(p[0]),
                                          static_cast<const uint8_t *>(p[2]), o.n,
                                          static_cast<xvcgpu_affine_me_result *>(p[1]), o.i0);
+    case XVC_OP_INTRA_SATD:
+      return xvcgpu_intra_satd_batch(ctx, env->orig, env->rec,
+                                     static_cast<const xvcgpu_intra_block *>(p[0]), o.n,
+                                     static_cast<uint32_t *>(p[1]), o.i0);
+    case XVC_OP_INTRA_PRED:
+      return xvcgpu_intra_pred_batch(ctx, env->rec, env->ipred,
+                                     static_cast<const xvcgpu_intra_block *>(p[0]), o.n);
+    case XVC_OP_RESIDUAL_INTRA:
+      return xvcgpu_residual_rdoq_batch(ctx, env->orig, env->ipred, env->irec,
+                                        static_cast<const xvcgpu_tx_block *>(p[0]), o.n,
+                                        env->d_in_levels, static_cast<const uint32_t *>(p[1]),
+                                        static_cast<int32_t *>(p[2]),
+                                        static_cast<const xvcgpu_rdoq_contexts *>(p[3]),
+                                        static_cast<const xvcgpu_rdoq_params *>(p[4]));
     case XVC_OP_MERGE_FOLD:
       return xvcgpu_cs_merge_fold(ctx, static_cast<const xvcgpu_cs_merge *>(p[0]), o.i0, o.n,
                                   static_cast<const uint64_t *>(p[1]),
@@ -395,7 +448,7 @@ extern "C" int xvc_host_cs_run_program(xvcgpu_ctx *ctx, const xvc_cs_env *env,
       stats->round_trips++;
       stats->states += o.i0;
       const double now = Now();
-      const int k = o.r0 >= 0 && o.r0 < 4 ? o.r0 : 0;
+      const int k = o.r0 >= 0 && o.r0 < XVC_CS_KINDS ? o.r0 : 0;
       stats->seconds_by_kind[k] += now - chain_t0;
       stats->states_by_kind[k] += o.i0;
       chain_t0 = now;

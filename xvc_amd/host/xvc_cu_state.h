@@ -32,7 +32,11 @@
 // One CU state (tests/rd_serial.py builds the table from a captured encode; an
 // encoder's control code would fill one record as it goes).  Ranges index the job
 // arrays of xvc_cs_tables.
-enum { XVC_CS_MERGE_RANK = 0, XVC_CS_EVAL = 1, XVC_CS_INTER = 2, XVC_CS_MOTION = 3 };
+//   CompressIntra (cu_encoder.cc:518-541): DetermineSlowIntraModes (the SATD of the 67 luma
+//     modes, intra_search.cc:188-305) -> the host sorts with the mode bits -> every kept
+//     luma mode's and every chroma mode's PredictAndTransform (:61-82, :118-150)
+enum { XVC_CS_MERGE_RANK = 0, XVC_CS_EVAL = 1, XVC_CS_INTER = 2, XVC_CS_MOTION = 3,
+       XVC_CS_INTRA = 4, XVC_CS_KINDS = 5 };
 typedef struct xvc_cs_state {
   int32_t kind;
   int16_t x, y;
@@ -49,6 +53,9 @@ typedef struct xvc_cs_state {
   // XVC_CS_STATE_LIC: the block copies that stage the reconstruction of that moment above /
   // left of the CU (tables.nb -> tables.rec), issued in front of the state's jobs
   int32_t nb_first, nb_count;
+  // XVC_CS_INTRA: the SATD pre-selection's job (-1: none) and the state's
+  // TransformAndReconstruct calls (ranges of the in_* arrays)
+  int32_t in_satd, in_first, in_count, in_reserved;
   int64_t level_first, level_count;
 } xvc_cs_state;
 // flags of a state: the whole-sample search (1) and local illumination compensation (2):
@@ -113,6 +120,31 @@ typedef struct xvc_cs_tables {
   const xvcgpu_picture *nb;
   const xvcgpu_copy_block *d_nb_copy;
   const xvcgpu_mc_lic_block *d_bi_lic;
+  // intra states: prediction and reconstruction pictures (the references' size: an intra
+  // block lies at its own place), the SATD jobs and their 67 distortions each, and per
+  // TransformAndReconstruct call the prediction job, transform block, quantiser parameters,
+  // level offset, distortion candidate; host: context snapshot, distortion weight,
+  // component, [first, count] of the call's block copies (its reference samples when they
+  // changed), whether the reference reads a cost behind the call
+  xvcgpu_picture *ipred, *irec;
+  const xvcgpu_intra_block *d_in_satd_jobs;
+  uint32_t *d_in_satd, *h_in_satd;
+  const xvcgpu_intra_block *d_in_pred;
+  const xvcgpu_tx_block *d_in_tx;
+  const xvcgpu_rdoq_params *d_in_prm;
+  const uint32_t *d_in_off;
+  const xvcgpu_metric_cand *d_in_cand;
+  const xvcgpu_rdoq_contexts *d_in_contexts;
+  const int32_t *in_ctx;
+  const double *in_weight;
+  const int32_t *in_comp, *in_stage, *in_wait;
+  const uint32_t *in_off_h;                 // host: d_in_off and the total behind it
+  int16_t *d_in_levels;
+  int32_t *d_in_nnz;
+  uint64_t *d_in_dist;
+  int32_t *h_in_nnz;
+  uint64_t *h_in_dist;
+  int16_t *h_in_levels;
 } xvc_cs_tables;
 
 typedef struct xvc_cs_stats {
@@ -121,8 +153,8 @@ typedef struct xvc_cs_stats {
   int64_t skipped;
   int64_t api_calls;       // C-ABI entry points called
   int64_t round_trips;     // device -> host read-backs the walk waited for
-  double seconds_by_kind[4];
-  int64_t states_by_kind[4];
+  double seconds_by_kind[XVC_CS_KINDS];
+  int64_t states_by_kind[XVC_CS_KINDS];
 } xvc_cs_stats;
 
 // The chained form's program: one op = one C-ABI call on arrays the host filled before
@@ -140,7 +172,12 @@ enum {
   // LIC states (picture selectors 4 = the neighbour staging picture, 5 = the chain's
   // reconstruction; INTER_PRED with r0 = 1 reads the neighbours from the reconstruction; ME
   // with r1 = 1 announces XVCGPU_ME_LIC_JOBS):
-  XVC_OP_BI_LIC       // xvcgpu_bipred_search_lic: r0 searched / r1 other slot, p: jobs, results, neighbours
+  XVC_OP_BI_LIC,      // xvcgpu_bipred_search_lic: r0 searched / r1 other slot, p: jobs, results, neighbours
+  // intra states (picture selectors 6 = the intra prediction picture, 7 = the intra
+  // reconstruction picture):
+  XVC_OP_INTRA_SATD,  // xvcgpu_intra_satd_batch(orig, rec): p: jobs, distortions; i0 = block size
+  XVC_OP_INTRA_PRED,  // xvcgpu_intra_pred_batch(rec -> ipred): p: jobs
+  XVC_OP_RESIDUAL_INTRA  // xvcgpu_residual_rdoq_batch(orig, ipred, irec): p as RESIDUAL's first five
 };
 typedef struct xvc_cs_op {
   int32_t opcode, n, r0, r1, i0, reserved;
@@ -154,8 +191,10 @@ typedef struct xvc_cs_env {
   xvcgpu_picture *s_orig, *s_pred, *s_rec;
   int16_t *d_levels;
   xvcgpu_cs_result *d_results;
-  xvcgpu_picture *rec;          // LIC states only (may be NULL without them)
+  xvcgpu_picture *rec;          // LIC / intra states only (may be NULL without them)
   const xvcgpu_picture *nb;
+  xvcgpu_picture *ipred, *irec; // intra states only
+  int16_t *d_in_levels;
 } xvc_cs_env;
 
 extern "C" {
