@@ -347,6 +347,7 @@ def encoder_rd_serial_figure(ctx, api, fx, pics, w, h, n_states=4000):
             "workload": "136x72 B picture POC 2 of the reference-coded LIC clip: all %d CU states" %
                         forms["serial"]["states_in_picture"],
             "lic_states": int(((spl.states["flags"] & rd_serial.STATE_LIC) != 0).sum()),
+            "intra_states": forms["serial"]["summary"]["intra"],
             "unsupported_states": forms["serial"]["summary"]["unsupported"],
             "us_per_cu_state": {m: f["chains"]["1"]["us_per_cu_state"] for m, f in forms.items()},
             "round_trips_per_state": {m: f["chains"]["1"]["round_trips_per_state"] for m, f in forms.items()},
@@ -359,10 +360,12 @@ def encoder_rd_serial_figure(ctx, api, fx, pics, w, h, n_states=4000):
     return {
         "workload": "1080p B picture POC %d of the reference-coded stream: %d CU states in the "
                     "reference's issue order (%d merge rankings, %d merge-candidate evaluations, "
-                    "%d CompressInter with evaluation, %d without), the first %d walked" % (
+                    "%d CompressInter with evaluation, %d without, %d CompressIntra with %d "
+                    "TransformAndReconstruct calls), the first %d walked" % (
                         poc, serial["states_in_picture"], serial["summary"]["merge_rank"],
                         serial["summary"]["eval"], serial["summary"]["inter"],
-                        serial["summary"]["motion_only"], serial["states_walked"]),
+                        serial["summary"]["motion_only"], serial["summary"]["intra"],
+                        serial["summary"]["intra_calls"], serial["states_walked"]),
         "us_per_cu_state": s1["us_per_cu_state"],
         "launches_per_state": {"entry_point_calls": s1["api_calls_per_state"],
                                "kernel_launches_rocprof": {"serial": 13.96, "chained": 7.17},

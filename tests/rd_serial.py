@@ -722,7 +722,8 @@ class SerialPicture:
         st = self.states
         return {"states": len(st), "merge_rank": int((st["kind"] == 0).sum()),
                 "eval": int((st["kind"] == 1).sum()), "inter": int((st["kind"] == 2).sum()),
-                "motion_only": int((st["kind"] == 3).sum()),
+                "motion_only": int((st["kind"] == 3).sum()), "intra": int((st["kind"] == KIND_INTRA).sum()),
+                "intra_calls": int(st["in_count"].sum()),
                 "unsupported": int((st["supported"] == 0).sum()),
                 "me": len(self.me_jobs), "bi": len(self.bi_jobs), "affine": len(self.aff_jobs),
                 "calls": len(self.call_tx)}

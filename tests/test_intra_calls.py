@@ -15,8 +15,18 @@ from xvc_amd import synth
 @pytest.mark.parametrize("name,width,height", [("tiny", 136, 72), ("c0", 352, 288), ("c1", 1920, 1080),
                                                ("c0q22", 352, 288), ("c0q37", 352, 288)])
 def test_oracle_reproduces_encoder_intra_satd(name, width, height):
+    _satd_calls_against_oracle(ifx.load(name), name, width, height, 20000)
+
+
+@pytest.mark.parametrize("name,width,height", [("tiny", 136, 72), ("c0", 352, 288), ("c1", 1920, 1080)])
+def test_oracle_reproduces_the_walked_pictures_intra_satd(name, width, height):
+    """tests/golden/intra_order_*.npz (round 5): EVERY DetermineSlowIntraModes call of the
+    picture the CU-state walk covers (tests/rd_serial.py kind 4), pinned the same way."""
+    _satd_calls_against_oracle(ifx.load_order(name), name, width, height, 9000)
+
+
+def _satd_calls_against_oracle(fx, name, width, height, least):
     xo = ol.Lib("xo")
-    fx = ifx.load(name)
     calls, evals, samples = fx["calls"], fx["evals"], fx["samples"]
     assert (np.diff(calls["first_eval"]) == calls["n_eval"][:-1]).all()
     done = 0
@@ -49,7 +59,7 @@ def test_oracle_reproduces_encoder_intra_satd(name, width, height):
         e = evals[int(c["first_eval"]):int(c["first_eval"]) + int(c["n_eval"])]
         assert np.array_equal(dist[e["mode"]], e["dist"]), (name, tuple(c))
         done += len(e)
-    assert done == len(evals) and done > 20000
+    assert done == len(evals) and done > least
 
 
 @pytest.mark.parametrize("name,width,height", [("tiny", 136, 72), ("c0", 352, 288),
@@ -59,19 +69,31 @@ def test_oracle_reproduces_encoder_intra_transform_calls(name, width, height):
     prediction from the captured reference samples (CRC equal to the encoder's
     prediction), then xo_residual_pipeline_rdoq with the captured context snapshot:
     count, levels (CRC) and reconstruction (CRC) equal to the encoder's."""
+    _itx_calls_against_oracle(ifx.load(name), name, width, height, 2, 1500)
+
+
+@pytest.mark.parametrize("name,width,height", [("tiny", 136, 72), ("c0", 352, 288)])
+def test_oracle_reproduces_the_walked_pictures_intra_transform_calls(name, width, height):
+    """tests/golden/intra_order_*.npz: every 5th TransformAndReconstruct call of the walked
+    picture's intra CUs (the LM chroma calls' prediction needs the luma rectangle: the GPU
+    walk covers them against the capture's counts, levels and distortions)."""
+    _itx_calls_against_oracle(ifx.load_order(name), name, width, height, 5, 2000)
+
+
+def _itx_calls_against_oracle(fx, name, width, height, step, least):
     import ctypes as C
     import oracle_rdoq as orq
     import rd_fixture as rf
     xo = ol.Lib("xo")
-    fx = ifx.load(name)
     itx, samples = fx["itx"], fx["itx_samples"]
+    itx = itx[itx["mode"] <= 66]
     contexts = np.ascontiguousarray(fx["contexts"]).view(orq.RDOQ_CTX_DTYPE).reshape(-1)
     qps = fx["qps"].view(rf.QP_DTYPE).reshape(-1)
     f = xo.dll.xo_residual_pipeline_rdoq
     f.restype = C.c_int
     origs = {}
     done = 0
-    for t in itx[::2]:
+    for t in itx[::step]:
         poc, comp = int(t["poc"]), int(t["comp"])
         if poc not in origs:
             origs[poc] = [np.ascontiguousarray(p.astype(np.uint16) << 2)
@@ -120,4 +142,4 @@ def test_oracle_reproduces_encoder_intra_transform_calls(name, width, height):
         if t["completed"]:
             assert rf.crc32_rows(out[y:y + h, x:x + w]) == int(t["rec_crc"]), ("rec", name, tuple(t))
         done += 1
-    assert done >= 1500
+    assert done >= least
