@@ -351,21 +351,25 @@ def encoder_rd_serial_figure(ctx, api, fx, pics, w, h, n_states=4000):
             "unsupported_states": forms["serial"]["summary"]["unsupported"],
             "us_per_cu_state": {m: f["chains"]["1"]["us_per_cu_state"] for m, f in forms.items()},
             "round_trips_per_state": {m: f["chains"]["1"]["round_trips_per_state"] for m, f in forms.items()},
-            "form": "a LIC state's SearchMotion keeps the serial form inside its chain (captured "
-                    "inputs; a live chain waits after the uni-directional searches and after the "
-                    "refinement): EvalStartMvp on compensated predictions, LIC jobs in the *_refs "
-                    "searches and use_lic in the folds' syntax have no device form yet; its merge "
-                    "ranking is folded on the device",
+            "form": "a LIC state's SearchMotion runs through the device folds (XVC_CS_LIC): "
+                    "EvalStartMvp on compensated predictions (XVC_INTER_LIC jobs + SAD), the searches "
+                    "per picture with the AC-only metrics, xvcgpu_bipred_search_lic per refinement "
+                    "slot, use_lic in the folds' syntax; its merge ranking is folded on the device; "
+                    "the neighbouring reconstruction of that moment is staged from the capture",
             "matches_reference": all(f["chains"]["1"].get("matches_reference") for f in forms.values())}
     return {
         "workload": "1080p B picture POC %d of the reference-coded stream: %d CU states in the "
                     "reference's issue order (%d merge rankings, %d merge-candidate evaluations, "
                     "%d CompressInter with evaluation, %d without, %d CompressIntra with %d "
-                    "TransformAndReconstruct calls), the first %d walked" % (
+                    "TransformAndReconstruct calls); walked: the %d states from state %d on - the "
+                    "stretch whose mix of state kinds is closest to the picture's (%d CompressIntra "
+                    "with %d calls: the picture's first states hold most of its intra states)" % (
                         poc, serial["states_in_picture"], serial["summary"]["merge_rank"],
                         serial["summary"]["eval"], serial["summary"]["inter"],
                         serial["summary"]["motion_only"], serial["summary"]["intra"],
-                        serial["summary"]["intra_calls"], serial["states_walked"]),
+                        serial["summary"]["intra_calls"], serial["states_walked"],
+                        serial["first_state_walked"], serial["stretch"]["intra"],
+                        serial["stretch"]["intra_calls"]),
         "us_per_cu_state": s1["us_per_cu_state"],
         "launches_per_state": {"entry_point_calls": s1["api_calls_per_state"],
                                "kernel_launches_rocprof": {"serial": 13.96, "chained": 7.17},
@@ -423,7 +427,10 @@ def encoder_rd_serial_figure(ctx, api, fx, pics, w, h, n_states=4000):
                      "whether a CompressInter went on to its evaluation (HasZeroMvd is on the device, "
                      "but the replay has no evaluation jobs for the states that returned early)",
                      "which ranked merge candidates were evaluated (the fold fills all slots below "
-                     "the count; the replay runs the ones the reference ran)"],
+                     "the count; the replay runs the ones the reference ran)",
+                     "an intra state's kept luma modes and chroma mode list (the SATD sort adds the "
+                     "host's mode bits; the walk runs the PredictAndTransform calls the reference ran)",
+                     "a LIC state's neighbouring reconstruction (lic_picture: a live encoder's own picture)"],
                  "compared": l1.get("compared")},
         "engine": {"pictures_per_s": {k: v["pictures_per_s"] for k, v in engine["chains"].items()},
                    "launches_per_state": {k: v["launches_per_state"] for k, v in engine["chains"].items()},

@@ -348,6 +348,14 @@ typedef struct xvcgpu_inter_contexts {
                                 * do NOT run this variant - such a pass is answered
                                 * XVC_CS_WHICH_UNSUPPORTED (InterSearch::SearchMotionMultiBatch
                                 * of the C++ host layer handles it)                      */
+#define XVC_CS_LIC 4           /* cu.GetUseLic() (never with XVC_CS_AFFINE): the flag in the
+                                * candidates' syntax, the refinement jobs the uni fold writes
+                                * are to be searched with xvcgpu_bipred_search_lic (the CU's
+                                * xvcgpu_mc_lic_block per slot), XVC_INTER_LIC in the evaluation's
+                                * prediction jobs (their neighbour fields are the caller's).
+                                * EvalStartMvp's distortions of such a pass are those of
+                                * COMPENSATED predictions (inter_search.cc:980: XVC_INTER_LIC
+                                * jobs of xvcgpu_inter_pred_batch_to + xvcgpu_eval_dist_batch) */
 #define XVC_CS_AFFINE 8        /* the affine pass (MotionVector3, MotionEstAffine)      */
 /* xvcgpu_cs_result::which of a pass the folds do not run: XVC_CS_FORCE_L1_MVD_ZERO, or
  * bi_iterations > 1 (the folds run ONE SearchBiIterative iteration on the list that lost,

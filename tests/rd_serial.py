@@ -364,6 +364,7 @@ class SerialPicture:
                 assert all(k >= 0 for k in ks), (n, ks)
                 nb_of_state[n] = list(dict.fromkeys(ks))
         self.states = st
+        self.nb_of_state = nb_of_state
         self._stage_neighbours(nb_of_state)
         self.n_levels = level_pos
 
@@ -718,8 +719,32 @@ class SerialPicture:
             i += 1
         return min(i, len(st) - 1)
 
-    def summary(self):
+    def representative_start(self, n, step=97):
+        """The first state (one that opens a visit of a CU position) of the stretch of n
+        states whose mix of state kinds - and of intra transform calls - is closest to the
+        whole picture's."""
         st = self.states
+        N = len(st)
+        if n >= N:
+            return 0
+        feat = np.zeros((N, 6))
+        for k in range(5):
+            feat[:, k] = st["kind"] == k
+        feat[:, 5] = st["in_count"] / 8.0          # (an intra state is its calls)
+        cs = np.vstack([np.zeros(6), np.cumsum(feat, 0)])
+        want = cs[-1] / N
+        best, best_d = 0, None
+        for f in range(0, N - n, step):
+            a = self.position_start(f)
+            if a + n > N:
+                break
+            d = float(np.abs((cs[a + n] - cs[a]) / n - want).sum())
+            if best_d is None or d < best_d:
+                best, best_d = a, d
+        return best
+
+    def summary(self, first=0, n=None):
+        st = self.states[first:None if n is None else first + n]
         return {"states": len(st), "merge_rank": int((st["kind"] == 0).sum()),
                 "eval": int((st["kind"] == 1).sum()), "inter": int((st["kind"] == 2).sum()),
                 "motion_only": int((st["kind"] == 3).sum()), "intra": int((st["kind"] == KIND_INTRA).sum()),
@@ -859,15 +884,20 @@ class SerialRun:
         -> dict of (compared, mismatching) per table.  searches=False: the chained form
         keeps the searches' results in its own arrays (check_chained compares them)."""
         sp, res = self.sp, self.res
-        st = sp.states[first:None if n is None else first + n]
-        st = st[st["supported"] != 0]
+        sl_ = slice(first, None if n is None else first + n)
+        st = sp.states[sl_]
+        keep_ = st["supported"] != 0
+        st = st[keep_]
         out = {}
 
         def rng(first_f, count_f):
             idx = [np.arange(int(a), int(a) + int(b)) for a, b in zip(st[first_f], count_f) if b]
             return np.concatenate(idx) if idx else np.zeros(0, np.int64)
 
-        rb = 1 if searches else ((st["flags"] & STATE_LIC) != 0)    # LIC states: the serial form
+        # (searches=False: only the LIC states that kept the serial form read their searches back)
+        rb = 1 if searches else ((st["flags"] & STATE_LIC) != 0)
+        if not searches and hasattr(sp, "folded"):
+            rb = rb & ~sp.folded[sl_][keep_]
         i = rng("me_first", st["me_count"] * rb)
         w, g = sp.me_want[i], res["me_res"][i]
         out["me"] = (len(i), int(((g["fullpel_x"] != w["fullpel_x"]) | (g["fullpel_y"] != w["fullpel_y"]) |
@@ -960,7 +990,7 @@ class SerialRun:
 # The chained form: passes (xvcgpu_cs_pass), work arrays the device composes, programs.
 # ======================================================================================
 R3 = 3               # XVC_CS_MAX_REFS
-CS_FULLPEL, CS_FORCE_L1_MVD_ZERO, CS_AFFINE = 1, 2, 8
+CS_FULLPEL, CS_FORCE_L1_MVD_ZERO, CS_LIC, CS_AFFINE = 1, 2, 4, 8
 CS_WHICH_UNSUPPORTED = 255
 
 PASS_DTYPE = np.dtype([
@@ -1060,7 +1090,7 @@ class CsEnv(C.Structure):
                 ("d_in_levels", C.c_void_p)]
 
 
-def build_passes(sp, ref_lists):
+def build_passes(sp, ref_lists, lic_folds=True):
     """The passes of every inter / motion state of the picture and the arrays the chained
     form works on.  ref_lists: ([poc per ref_idx of list 0], [... list 1]) of the picture.
     Adds to sp: passes, pass_first / pass_count per state, start cands, work jobs."""
@@ -1081,10 +1111,19 @@ def build_passes(sp, ref_lists):
     aff_work_rows = []          # (source: index into sp.aff_jobs or -1 for a slot)
     n_bi_slots = 0
     uni_groups, aff_uni_groups = {}, {}
+    # a LIC state's SearchMotion is folded on the device too (XVC_CS_LIC) when the capture
+    # holds its neighbour record (the refinement's or the evaluation's: EvalStartMvp's
+    # compensated predictions read the same rows / columns); lic_folds=False: the serial form
+    lic = (st["flags"] & STATE_LIC) != 0
+    has_nb = np.array([bool(sp.nb_of_state.get(n)) for n in range(len(st))])
     folded = ((st["kind"] == KIND_INTER) | (st["kind"] == KIND_MOTION)) & (st["supported"] != 0) & \
-        ((st["flags"] & STATE_LIC) == 0)
+        (~lic | (has_nb & bool(lic_folds)))
+    sp.folded = folded
+    bi_lic_rows = {}            # first refinement slot of a LIC pass -> the CU's xvcgpu_mc_lic_block
     for n in np.flatnonzero(folded):
         s = st[n]
+        s_lic = bool(lic[n])
+        nbr = sp._nb_table()[sp.nb_of_state[n][0]] if s_lic else None
         cds = cd_all[int(s["cand_first"]):int(s["cand_first"]) + int(s["cand_count"])]
         plain = cds[cds["kind"] == 0]
         aff = cds[cds["kind"] == 2]
@@ -1097,7 +1136,8 @@ def build_passes(sp, ref_lists):
             assert len(cu) == nref[0] + nref[1], (n, len(cu), nref)
             p = np.zeros((), PASS_DTYPE)
             p["x"], p["y"], p["w"], p["h"] = s["x"], s["y"], s["w"], s["h"]
-            p["flags"] = (int(cu[0]["flags"]) & 1) | (CS_AFFINE if which else 0)
+            p["flags"] = (int(cu[0]["flags"]) & 1) | (CS_AFFINE if which else 0) | (CS_LIC if s_lic else 0)
+            assert not (s_lic and which)        # (never together: inter_search.cc:215-219)
             p["num_refs"] = nref
             p["same_poc_in_l0"] = same
             p["lambda16"] = cu[0]["lambda16"]
@@ -1119,7 +1159,50 @@ def build_passes(sp, ref_lists):
                 p["mvp"][l, r] = c["mvp"]
                 p["slot"][l, r] = slot_of[ref_lists[l][r]]
                 entries.append((l, r, bool(c["reused"])))
-            if which == 0:
+            if which == 0 and s_lic:
+                # EvalStartMvp of a LIC CU compares COMPENSATED predictions
+                # (MotionCompensationMv(..., post_filter = true), inter_search.cc:980): XVC_INTER_LIC
+                # jobs into the scratch slots + their SAD against the original, as the affine
+                # pass's start does
+                first = len(aff_inter)
+                for l, r, _ in entries:
+                    p["start_dist"][l, r] = n_start_dist
+                    for cand in range(2):
+                        k = len(aff_inter) - first
+                        ib = np.zeros((), api.INTER_DTYPE)
+                        ib["x"], ib["y"], ib["w"], ib["h"] = s["x"], s["y"], s["w"], s["h"]
+                        ib["flags"] = api.INTER_LIC
+                        ib["neighbors"] = int(nbr["has_above"]) * 1 + int(nbr["has_left"]) * 2
+                        for f in ("above_x", "above_y", "left_x", "left_y"):
+                            ib[f] = nbr[f]
+                        ib["ref"] = (int(p["slot"][l, r]), -1)
+                        ib["mv"][0][0] = p["mvp"][l, r, cand][0]
+                        aff_inter.append(ib)
+                        aff_dst.append((SLOT * k, 0))
+                        aff_cands.append((SLOT * k, 0, int(s["w"]), int(s["h"]), 3, 0, 0, 0))
+                        aff_copy.append((int(s["x"]), int(s["y"]), SLOT * k, 0, int(s["w"]), int(s["h"]), 0, 0))
+                        n_start_dist += 1
+                assert len(aff_inter) - first <= MAX_SLOTS, "more start candidates than scratch slots"
+                aff_start[pi] = (first, len(aff_inter) - first, int(p["start_dist"][entries[0][0], entries[0][1]]))
+                ug = []
+                for l, r, reused in entries:
+                    if reused:
+                        continue
+                    p["uni_job"][l, r] = me_next
+                    assert sp.me_ref[me_next] == p["slot"][l, r], (n, l, r)
+                    me_work["mvp_x"][me_next] = me_work["mvp_y"][me_next] = 0x7fffff
+                    ug.append((int(p["slot"][l, r]), me_next))
+                    me_next += 1
+                uni_groups[pi] = ug
+                p["bi_job"] = n_bi_slots
+                q = np.zeros((), api.LIC_DTYPE)
+                q["x"], q["y"], q["w"], q["h"] = s["x"], s["y"], s["w"], s["h"]
+                q["neighbors"] = int(nbr["has_above"]) * 1 + int(nbr["has_left"]) * 2
+                for f in ("above_x", "above_y", "left_x", "left_y"):
+                    q[f] = nbr[f]
+                bi_lic_rows[n_bi_slots] = q
+                n_bi_slots += BI_SLOTS
+            elif which == 0:
                 # EvalStartMvp: two luma predictions + SAD per (list, picture), re-used ones too
                 order = sorted(range(len(entries)), key=lambda k: int(p["slot"][entries[k][0], entries[k][1]]))
                 groups = []
@@ -1198,6 +1281,9 @@ def build_passes(sp, ref_lists):
     sp.aff_start_copy = np.array(aff_copy, api.COPY_BLOCK_DTYPE) if aff_copy else np.zeros(0, api.COPY_BLOCK_DTYPE)
     sp.me_work = me_work
     sp.n_bi_slots = n_bi_slots
+    sp.bi_lic_work = np.zeros(max(n_bi_slots, 1), api.LIC_DTYPE)
+    for a_, q in bi_lic_rows.items():
+        sp.bi_lic_work[a_:a_ + BI_SLOTS] = q
     aw = np.zeros(len(aff_work_rows), api.AFFINE_ME_DTYPE)
     rows = np.array(aff_work_rows, np.int64) if aff_work_rows else np.zeros(0, np.int64)
     src = rows >= 0
@@ -1231,7 +1317,8 @@ def build_passes(sp, ref_lists):
     ei = sp.ev_inter.copy()
     for n in np.flatnonzero((st["kind"] == KIND_INTER) & folded):
         e = int(st["ev"][n])
-        ei["ref"][e], ei["mv"][e], ei["flags"][e] = (0, -1), 12345, 0    # overwritten by the fold
+        # overwritten by the fold (a LIC CU's neighbour fields stay: they are the caller's)
+        ei["ref"][e], ei["mv"][e], ei["flags"][e] = (0, -1), 12345, 0
     sp.ev_inter_work = ei
 
 
@@ -1246,11 +1333,13 @@ class ChainedRun(SerialRun):
     #                       its alternatives (xvcgpu_residual_rdoq_batch_at's candidates)
     merge_fold = True     # the merge ranking folded on the device: a merge candidate's
     #                       evaluation predicts from the slot xvcgpu_cs_merge_fold filled
+    lic_folds = True      # a LIC state's SearchMotion through the folds too (XVC_CS_LIC) instead
+    #                       of the serial form with the capture's inputs
 
     def __init__(self, api, ctx, sp, pics, width, height, ref_lists):
         super().__init__(api, ctx, sp, pics, width, height)
         if not hasattr(sp, "passes"):
-            build_passes(sp, ref_lists)
+            build_passes(sp, ref_lists, self.lic_folds)
         self.lib.xvc_host_cs_run_program.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                                      C.c_void_p]
         up = self._upload
@@ -1260,6 +1349,7 @@ class ChainedRun(SerialRun):
         d["aff_start_cands"], d["aff_start_copy"] = up(sp.aff_start_cands), up(sp.aff_start_copy)
         d["me_work"], d["aff_work"] = up(sp.me_work), up(sp.aff_work)
         d["bi_work"] = up(np.zeros(max(sp.n_bi_slots, 1), api.BI_DTYPE))
+        d["bi_lic_work"] = up(sp.bi_lic_work)
         d["ev_inter_work"] = up(sp.ev_inter_work)
         d["start_slots"], d["me_slots"] = up(sp.start_slots), up(sp.me_slots)
         d["bi_slots"], d["aff_slots"] = up(sp.bi_slots), up(sp.aff_slots)
@@ -1479,7 +1569,7 @@ class ChainedRun(SerialRun):
                 fetch(t.d_in_levels + 2 * la, t.h_in_levels + 2 * la, 2 * (lb - la))
 
         def motion(s, n_state):
-            if int(s["flags"]) & STATE_LIC:
+            if (int(s["flags"]) & STATE_LIC) and not sp.folded[n_state]:
                 return motion_lic(s)
             ms = max(int(s["w"]), int(s["h"]))
             cls = 16 if ms <= 16 else (32 if ms <= 32 else 64)
@@ -1487,8 +1577,19 @@ class ChainedRun(SerialRun):
             for pi in range(pf, pf + pc):
                 p = sp.passes[pi]
                 affine = bool(p["flags"] & CS_AFFINE)
+                licp = bool(p["flags"] & CS_LIC)  # XVC_INTER_LIC start predictions, LIC searches per picture
                 P = d["passes"]                  # the folds index the arrays absolutely (i0 = pass)
-                if not affine and refs_form:
+                if licp:
+                    a, k, sd = sp.aff_start[pi]
+                    op(OP_INTER_PRED, k, r0=1, r1=PIC_S_PRED, p=(d["aff_start_inter"] + a * I["inter"],
+                                                                 d["aff_start_dst"] + a * I["pos"]))
+                    if self.no_copies:
+                        op(OP_EVAL_DIST, k, r0=1, p=(d["aff_start_ecands"] + a * 24, d["start_dist"] + 8 * sd))
+                    else:
+                        op(OP_COPY, k, r0=PIC_ORIG, r1=PIC_S_ORIG, p=(d["aff_start_copy"] + a * I["copy"],))
+                        op(OP_METRIC, k, r0=PIC_S_ORIG, r1=PIC_S_PRED, i0=0, f=1.0,
+                           p=(d["aff_start_cands"] + a * I["cand"], d["start_dist"] + 8 * sd))
+                elif not affine and refs_form:
                     g = sp.start_groups[pi]
                     a0, ca0, kk = g[0][1], g[0][3], sum(x[2] for x in g)
                     assert all(x[1] - a0 == x[3] - ca0 for x in g) and g[-1][3] + g[-1][2] == ca0 + kk
@@ -1510,7 +1611,10 @@ class ChainedRun(SerialRun):
                            p=(d["aff_start_cands"] + a * I["cand"], d["start_dist"] + 8 * sd))
                 op(OP_START_FOLD, 1, i0=pi, p=(P, d["start_dist"], d["me_work"], d["me_res_c"], d["aff_work"]))
                 ug = sp.aff_uni_groups[pi] if affine else sp.uni_groups[pi]
-                if refs_form and ug:
+                if licp:
+                    for sl, j in ug:
+                        op(OP_ME, 1, r0=sl, r1=1, i0=ms, p=(d["me_work"] + j * I["me"], d["me_res_c"] + j * I["res"]))
+                elif refs_form and ug:
                     j0 = ug[0][1]
                     assert [j for _, j in ug] == list(range(j0, j0 + len(ug)))
                     if not affine:
@@ -1526,7 +1630,17 @@ class ChainedRun(SerialRun):
                     for sl, j in ug:
                         op(OP_AFFINE, 1, r0=sl, r1=sl, p=(d["aff_work"] + j * I["aff"], d["aff_res_c"] + j * I["affr"]))
                 op(OP_UNI_FOLD, 1, i0=pi, p=(P, d["me_res_c"], d["aff_res_c"], d["bi_work"], d["aff_work"]))
-                if p["num_refs"][1] and refs_form:
+                if p["num_refs"][1] and licp:
+                    bj = int(p["bi_job"])
+                    for sl_ in range(2):
+                        for r in range(int(p["num_refs"][sl_])):
+                            for o in range(int(p["num_refs"][1 - sl_])):
+                                k = bj + (sl_ * R3 + r) * R3 + o
+                                rs, ro = int(p["slot"][sl_, r]), int(p["slot"][1 - sl_, o])
+                                op(OP_BI_LIC, 1, r0=rs, r1=ro, i0=ms,
+                                   p=(d["bi_work"] + k * I["bi"], d["bi_res_c"] + k * I["res"],
+                                      d["bi_lic_work"] + k * 24))
+                elif p["num_refs"][1] and refs_form:
                     bj = int(p["bi_job"])
                     if not affine:
                         op(OP_BI_REFS, BI_SLOTS, i0=cls, p=(d["bi_work"] + bj * I["bi"], d["bi_res_c"] + bj * I["res"],

@@ -69,9 +69,10 @@ def test_passes_of_a_captured_picture():
     sp = rd_serial.SerialPicture(api, "tiny", 2)
     rd_serial.build_passes(sp, rd_serial.ref_lists_of("tiny", 2))
     st, ps = sp.states, sp.passes
-    # (LIC states walk in the serial form: no passes)
-    motion = ((st["kind"] == rd_serial.KIND_INTER) | (st["kind"] == rd_serial.KIND_MOTION)) & (st["supported"] != 0) & \
-        ((st["flags"] & rd_serial.STATE_LIC) == 0)
+    # (the LIC states too: XVC_CS_LIC passes, their neighbour records are in the capture)
+    motion = ((st["kind"] == rd_serial.KIND_INTER) | (st["kind"] == rd_serial.KIND_MOTION)) & (st["supported"] != 0)
+    assert np.array_equal(motion, sp.folded)
+    assert ((ps["flags"] & rd_serial.CS_LIC) != 0).sum() == ((st["flags"] & rd_serial.STATE_LIC) != 0)[motion].sum() > 2000
     assert (sp.pass_count[motion] >= 1).all() and (sp.pass_count[~motion] == 0).all()
     assert len(ps) == int(sp.pass_count.sum()) > 1000
     aff = (ps["flags"] & rd_serial.CS_AFFINE) != 0

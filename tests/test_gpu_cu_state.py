@@ -81,7 +81,7 @@ def _run_chained(api, ctx, name, poc, n_states, by_position, refs_form=True, liv
 @pytest.mark.parametrize("name,poc,n_states,by_position,refs_form", [
     ("tiny", 2, 1 << 30, False, True), ("tiny", 2, 1 << 30, True, True),
     ("tiny", 2, 1 << 30, True, False), ("c0", 4, 1 << 30, True, True),
-    ("c1", 2, 20000, True, True), ("c1", 2, 4000, True, False)])
+    ("c1", 2, 1 << 30, True, True), ("c1", 2, 4000, True, False)])      # (c1: the whole 1080p picture)
 def test_chained_states_equal_reference(gpu, name, poc, n_states, by_position, refs_form):
     """The same states as ONE enqueue each (or per visit of a CU position), the folds
     between the searches on the device (xvcgpu_cs_*_fold): no read-back inside a chain.
@@ -105,8 +105,8 @@ def test_chained_states_equal_reference(gpu, name, poc, n_states, by_position, r
     for k in ("cands", "finals", "eval_motion", "calls", "merge", "merge_fold", "merge_slot_motion",
               "intra_satd", "intra_calls"):
         assert res[k][0] > 100, (k, res)
-    if name == "tiny":       # the LIC states' searches (serial form inside the chains) are compared too
-        assert res["me"][0] == 5140 and res["bi"][0] > 4000
+    if name == "tiny":       # the LIC states' SearchMotion runs through the folds too (XVC_CS_LIC)
+        assert res["cands"][0] == 24412 and res["finals"][0] == 5253 and res["me"][0] == 0, res
     # every merge ranking went through the device's fold (xvcgpu_cs_merge_fold), and nearly
     # every merge candidate's evaluation predicted from the slot the fold filled (the rest:
     # affine merges and candidates the harness could not tell apart)

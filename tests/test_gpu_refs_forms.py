@@ -2,7 +2,8 @@
 (xvcgpu_me_search_refs / _bipred_search_refs / _mc_metric_batch_refs /
 _affine_me_batch_refs: the pictures as a table, a slot byte per job, only the CU's
 block class launched) against the single-picture entry points job by job - which the
-other tests hold against the oracle and the reference's captured calls."""
+other tests hold against the oracle and the reference's captured calls - and, for the
+uni-directional search, directly against the oracle."""
 import numpy as np
 import pytest
 
@@ -26,6 +27,7 @@ def gpu():
     pics = []
     for k in range(4):
         p = ctx.picture(W, H, BD)
+        p.host_luma = pad(clip.frame(k))[0]       # (for the oracle)
         p.upload(pad(clip.frame(k)), BL)
         pics.append(p)
     yield api, ctx, pics[3], pics[:3]
@@ -72,6 +74,20 @@ def test_me_search_refs(gpu, cls):
         assert (exp["fullpel_cost"] != 0xffffffff).all()
     none = slots == 255
     assert none.any() and np.array_equal(got[none], before[none])
+    # and directly against the oracle (TzSearch::Search + SubpelSearch on the job's picture)
+    import oracle_lib as ol
+    from test_gpu_parity import to_me_struct
+    xo = ol.Lib("xo")
+    for i in np.flatnonzero(slots != 255):
+        st = to_me_struct(blocks[i])
+        rp = refs[int(slots[i])].host_luma
+        (fx, fy), cost = xo.tz_search(BD, st, W, H, orig.host_luma, rp, BL)
+        assert (int(got[i]["fullpel_x"]), int(got[i]["fullpel_y"]), int(got[i]["fullpel_cost"])) == (fx, fy, cost), \
+            (cls, i, tuple(blocks[i]), tuple(got[i]))
+        if not (blocks[i]["fullpel_mv"] & 1):
+            (sx, sy), sd = xo.subpel_search(BD, st, W, H, orig.host_luma, rp, BL, (fx, fy))
+            assert (int(got[i]["mv_x"]), int(got[i]["mv_y"]), int(got[i]["subpel_dist"])) == (sx, sy, sd), \
+                (cls, i, tuple(blocks[i]), tuple(got[i]))
 
 
 @pytest.mark.parametrize("cls", [16, 32, 64])

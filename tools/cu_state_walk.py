@@ -38,7 +38,13 @@ def walk(api, clip, poc, n_states, ks, mode="serial", check=True, decoded=None, 
         pics, w, h = decoded
     sp = sp or rd_serial.SerialPicture(api, clip, poc)
     n = min(n_states, len(sp.states))
+    # the stretch walked: the one whose mix of state kinds is closest to the whole picture's
+    # (the 1080p picture's first states hold most of its intra states - 58
+    # TransformAndReconstruct calls each: its first 4000 states would read 2.3 x the picture's
+    # mean time per state)
+    first = sp.representative_start(n)
     out = {"clip": clip, "poc": poc, "states_in_picture": len(sp.states), "states_walked": n,
+           "first_state_walked": int(first), "stretch": sp.summary(first, n),
            "mode": mode, "summary": sp.summary(), "chains": {}}
     if mode == "engine":
         # k chains on ONE context: every round the chains' next steps grouped by kind, one
@@ -110,12 +116,12 @@ def walk(api, clip, poc, n_states, ks, mode="serial", check=True, decoded=None, 
 
         def go(r, count, verify=False):
             if mode == "serial":
-                return r.run_serial(0, count)
+                return r.run_serial(first, count)
             # timed without the read-back of the composed prediction jobs, which only the
             # check below wants (an encoder takes the motion from the pass results)
             # modes: "chained" = a chain per visit of a CU position; "by_state" = a chain per
             # state; "live" = the chains a live encoder could issue (rd_serial.program)
-            return r.run_chained(0, count, by_position=(mode == "chained"), verify=verify,
+            return r.run_chained(first, count, by_position=(mode == "chained"), verify=verify,
                                  live=(mode == "live"))
 
         def work(i):
@@ -125,7 +131,7 @@ def walk(api, clip, poc, n_states, ks, mode="serial", check=True, decoded=None, 
             go(r, min(n, 200))
         if mode != "serial":        # the programs are recorded before the clock starts
             for r in runs:
-                r.prepare(0, n, mode == "chained", False, mode == "live")
+                r.prepare(first, n, mode == "chained", False, mode == "live")
         # the median of three runs: with k host threads a run's rate depends on how
         # the threads and the streams' queues fall (0.28 - 0.57 pictures/s at k = 4)
         walls = []
@@ -162,7 +168,7 @@ def walk(api, clip, poc, n_states, ks, mode="serial", check=True, decoded=None, 
                 out_t = [None] * T
 
                 def work_t(i):
-                    out_t[i] = rd_serial.ChainedRun.run_interleaved(groups[i], 0, n)
+                    out_t[i] = rd_serial.ChainedRun.run_interleaved(groups[i], first, n)
                 th = [threading.Thread(target=work_t, args=(i,)) for i in range(T)]
                 t0 = time.time()
                 for t in th:
@@ -180,20 +186,20 @@ def walk(api, clip, poc, n_states, ks, mode="serial", check=True, decoded=None, 
             walls_i = []
             for _ in range(3):
                 t0 = time.time()
-                si = rd_serial.ChainedRun.run_interleaved(runs, 0, n, mode == "chained", mode == "live")
+                si = rd_serial.ChainedRun.run_interleaved(runs, first, n, mode == "chained", mode == "live")
                 walls_i.append(time.time() - t0)
             wall_i = sorted(walls_i)[1]
             entry["one_thread"] = {"states_per_s": si.states / wall_i,
                                    "pictures_per_s": si.states / wall_i / (s0.states * per_pic)}
             if check:
-                ri = runs[0].check(0, n, searches=False)
+                ri = runs[0].check(first, n, searches=False)
                 entry["one_thread"]["matches_reference"] = all(v[1] == 0 for v in ri.values())
         if check:
             if mode != "serial":
                 go(runs[-1], n, verify=True)
-            res = runs[-1].check(0, n, searches=(mode == "serial"))
+            res = runs[-1].check(first, n, searches=(mode == "serial"))
             if mode != "serial":
-                res.update(runs[-1].check_chained(0, n))
+                res.update(runs[-1].check_chained(first, n))
             entry["matches_reference"] = all(v[1] == 0 for v in res.values())
             entry["compared"] = {a: v[0] for a, v in res.items()}
         out["chains"][str(k)] = entry

@@ -41,6 +41,9 @@ __device__ __forceinline__ bool cs_affine(const xvcgpu_cs_pass &p) {
 __device__ __forceinline__ bool cs_fullpel(const xvcgpu_cs_pass &p) {
   return (p.flags & XVC_CS_FULLPEL) != 0;
 }
+__device__ __forceinline__ bool cs_lic(const xvcgpu_cs_pass &p) {
+  return (p.flags & XVC_CS_LIC) != 0;
+}
 // The variants of SearchMotion the folds do not run (xvcgpu_types.h): the L1 vector
 // difference forced to zero (inter_search.cc:410-413, :496-518), more than one
 // refinement iteration (:394).  Answered, never computed as if they were the default.
@@ -247,6 +250,7 @@ __device__ __forceinline__ void cs_uni_fold_body(const xvcgpu_cs_pass *passes, i
       syn.inter_dir = (uint8_t)l;
       syn.use_affine = affine;
       syn.fullpel_mv = fullpel;
+      syn.use_lic = cs_lic(p);
       syn.ref_idx[l] = (int8_t)r;
       syn.mvp_idx[l] = (uint8_t)idx;
       cs_set_mvd(syn.mvd[l], p.mvp[l][r][idx], R.mv[l][r], fullpel, affine);
@@ -305,7 +309,7 @@ __device__ __forceinline__ void cs_uni_fold_body(const xvcgpu_cs_pass *passes, i
       j.blk.w = p.w;
       j.blk.h = p.h;
       j.blk.depth_nonzero = 0;
-      j.blk.fullpel_mv = fullpel ? XVC_ME_FULLPEL_MV : 0;
+      j.blk.fullpel_mv = fullpel ? XVC_ME_FULLPEL_MV : 0;   // (a LIC pass: xvcgpu_bipred_search_lic)
       j.blk.mvp_x = p.mvp[s][r][idx][0][0];
       j.blk.mvp_y = p.mvp[s][r][idx][0][1];
       j.blk.prev_x = j.blk.prev_y = 0;
@@ -383,6 +387,7 @@ __device__ __forceinline__ void cs_bi_fold_body(const xvcgpu_cs_pass *passes, in
       syn.inter_dir = 2;
       syn.use_affine = affine;
       syn.fullpel_mv = fullpel;
+      syn.use_lic = cs_lic(p);
       syn.ref_idx[s] = (int8_t)r;
       syn.mvp_idx[s] = (uint8_t)idx;
       cs_set_mvd(syn.mvd[s], p.mvp[s][r][idx], R.bi_mv[r], fullpel, affine);
@@ -483,7 +488,7 @@ __device__ __forceinline__ void cs_bi_fold_body(const xvcgpu_cs_pass *passes, in
   const bool fa = cs_affine(*fp);
   for (int c = 0; c < 3; c++) {
     xvcgpu_inter_block &b = ev_inter[3 * p.eval + c];
-    b.flags = fa ? XVC_INTER_AFFINE : 0;
+    b.flags = fa ? XVC_INTER_AFFINE : (cs_lic(*fp) ? XVC_INTER_LIC : 0);
     for (int l = 0; l < 2; l++) {
       const bool used = final->inter_dir == 2 || final->inter_dir == l;
       b.ref[l] = used ? fp->slot[l][final->ref_idx[l]] : -1;
