@@ -117,3 +117,22 @@ def test_merge_fold_records_of_a_captured_picture():
         subprocess.check_call(["gcc", "-I", os.path.join(root, "include"), src, "-o", exe])
         a, b = map(int, subprocess.check_output([exe]).split())
     assert (a, b) == (rd_serial.MERGE_FOLD_DTYPE.itemsize, rd_serial.MERGE_RESULT_DTYPE.itemsize)
+
+
+def test_walked_stretch_has_the_pictures_mix_of_states():
+    """tools/cu_state_walk.py and bench.py walk the stretch SerialPicture.representative_start
+    picks: the 1080p picture's first 4000 states hold 184 of its 220 intra states (58
+    TransformAndReconstruct calls each), the picked stretch the picture's share of them."""
+    sp = rd_serial.SerialPicture(api, "c1", 2)
+    st = sp.states
+    n = 4000
+    intra = st["kind"] == rd_serial.KIND_INTRA
+    assert intra.sum() == 220 and intra[:n].sum() > 150
+    a = sp.representative_start(n)
+    want = intra.sum() * n / len(st)
+    assert 0.5 * want <= intra[a:a + n].sum() <= 2 * want, (a, intra[a:a + n].sum(), want)
+    # a stretch starts where a visit of a CU position starts
+    assert a == sp.position_start(a)
+    for k in range(4):
+        share, whole = (st["kind"][a:a + n] == k).mean(), (st["kind"] == k).mean()
+        assert abs(share - whole) < 0.03, (k, share, whole)
