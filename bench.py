@@ -323,14 +323,25 @@ def encoder_rd_serial_figure(ctx, api, fx, pics, w, h, n_states=4000):
         return None
     by_poc = {int(fx.info[i]["poc"]): pics[i] for i in range(fx.n)}
     poc = 2
+    spent = {}
+    t_ = time.perf_counter()
     sp = rd_serial.SerialPicture(api, "c1", poc)
-    serial = cu_state_walk.walk(api, "c1", poc, n_states, [1, 4], "serial", decoded=(by_poc, w, h), sp=sp)
-    chained = cu_state_walk.walk(api, "c1", poc, n_states, [1, 4], "chained", decoded=(by_poc, w, h), sp=sp)
-    live = cu_state_walk.walk(api, "c1", poc, n_states, [1, 4], "live", decoded=(by_poc, w, h), sp=sp)
+    spent["state_table"] = time.perf_counter() - t_
+
+    def timed_walk(label, *a, **kw):
+        t0_ = time.perf_counter()
+        r = cu_state_walk.walk(*a, **kw)
+        spent[label] = time.perf_counter() - t0_
+        return r
+    serial = timed_walk("serial", api, "c1", poc, n_states, [1, 4], "serial", decoded=(by_poc, w, h), sp=sp)
+    chained = timed_walk("chained", api, "c1", poc, n_states, [1, 4], "chained", decoded=(by_poc, w, h), sp=sp)
+    live = timed_walk("live", api, "c1", poc, n_states, [1, 4], "live", decoded=(by_poc, w, h), sp=sp)
     # many pictures in flight: k chains through the execution engine, four engines on four
     # host threads and streams (each chain its own stretch of the picture)
-    engine = cu_state_walk.walk(api, "c1", poc, min(n_states, 1200), [16, 64, 256], "engine",
-                                decoded=(by_poc, w, h), sp=sp, engine_threads=4, reps=2)
+    # (k = 128 / 256: profiles/r05_cu_state_walk_engine.json - building 256 chains' device
+    # arrays takes longer than the rest of this figure)
+    engine = timed_walk("engine", api, "c1", poc, min(n_states, 1200), [16, 64], "engine",
+                        decoded=(by_poc, w, h), sp=sp, engine_threads=4, reps=1)
     s1, c1, l1 = serial["chains"]["1"], chained["chains"]["1"], live["chains"]["1"]
     ok = all(e.get("matches_reference") for r in (serial, chained, live, engine)
              for e in r["chains"].values())
@@ -340,7 +351,7 @@ def encoder_rd_serial_figure(ctx, api, fx, pics, w, h, n_states=4000):
     lic_fig = None
     if os.path.exists(rf.path("tiny")) and os.path.exists(os.path.join(rf.GOLDEN, "rd_order_tiny.npz")):
         spl = rd_serial.SerialPicture(api, "tiny", 2)
-        forms = {m: cu_state_walk.walk(api, "tiny", 2, 1 << 30, [1], m, sp=spl)
+        forms = {m: timed_walk("lic_" + m, api, "tiny", 2, 1 << 30, [1], m, sp=spl)
                  for m in ("serial", "chained", "live")}
         ok = ok and all(f["chains"]["1"].get("matches_reference") for f in forms.values())
         lic_fig = {
@@ -448,6 +459,7 @@ def encoder_rd_serial_figure(ctx, api, fx, pics, w, h, n_states=4000):
                                               "(profiled) run's wall time, four streams (static, not "
                                               "re-measured by this run)"}},
         "lic_picture": lic_fig,
+        "seconds_spent_measuring": {k: round(v, 1) for k, v in spent.items()},
         "compared": s1.get("compared"),
         "matches_reference": bool(ok),
         "reading": "every form is bound by the chain of dependent kernels per state (each search is "
