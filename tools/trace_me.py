@@ -34,7 +34,7 @@ ctx.sync(); ctx.timer_begin()
 ctx.me_search_dev(O, R, flags, fp.d_me.ptr, d.n_cus, fp.d_res.ptr, 16)
 ms = ctx.timer_end()
 n = d.n_cus
-buf = np.zeros((n, 16), np.uint64)
+buf = np.zeros((n, 24), np.uint64)
 lib.xvcgpu_debug_me_trace(buf.ctypes.data_as(C.c_void_p), n)
 t = buf[:, :9].astype(np.int64)
 t0 = t[:, 0].min()
@@ -63,3 +63,14 @@ late = np.argsort(en)[-5:]
 grid = (t[:, 5] - t[:, 4]) > 4 * np.median(t[:, 5] - t[:, 4]) + 2000
 print("jobs that ran the step-5 grid:", int(grid.sum()))
 print("last 5 waves: start/end us", [(round(float(st[i]), 1), round(float(en[i]), 1)) for i in late])
+
+cnt = buf[:, 11:16].astype(np.int64)
+clk = buf[:, 16:24].astype(np.int64)
+for k, nm in enumerate(["diamond sweeps", "16-cand passes", "refine iters", "neighbour steps", "candidates"]):
+    v = cnt[:, k]
+    print("%-16s mean %6.2f p50 %4d p90 %4d max %5d" % (nm, v.mean(), np.median(v), np.percentile(v, 90), v.max()))
+print("sweeps histogram", np.bincount(cnt[:, 0].clip(0, 12)).tolist())
+print("refine histogram", np.bincount(cnt[:, 2].clip(0, 12)).tolist())
+for k, nm in enumerate(["sp setup", "sp planes", "sp records", "sp sweep"]):
+    v = clk[:, k]
+    print("%-12s mean %7.0f  p50 %7.0f  p90 %7.0f" % (nm, v.mean(), np.median(v), np.percentile(v, 90)))

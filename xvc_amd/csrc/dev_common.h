@@ -53,8 +53,10 @@ __device__ __forceinline__ void d_clip_mv(int pos_x, int pos_y, int pic_w,
 // GetNumExpGolombBits, inter_search.cc:1179-1188 (closed form: the loop adds
 // 2 per halving until 1 => 2*floor(log2(u)) + 1).
 __device__ __forceinline__ uint32_t d_eg_bits(int mvd) {
-  uint32_t u = mvd <= 0 ? ((uint32_t)(-mvd) << 1) + 1u : ((uint32_t)mvd << 1);
-  return 2u * (31u - (uint32_t)__clz((int)u)) + 1u;
+  // u = mvd <= 0 ? (-mvd << 1) + 1 : mvd << 1; for mvd > 0, 2 mvd and 2 mvd + 1 have the
+  // same leading bit, so (|mvd| << 1) | 1 serves both signs
+  const uint32_t u = ((uint32_t)(mvd < 0 ? -mvd : mvd) << 1) | 1u;
+  return 63u - 2u * (uint32_t)__clz((int)u);
 }
 // GetMvdBitsFullpel, inter_search.cc:1166-1177
 __device__ __forceinline__ uint32_t d_mvd_bits_fullpel(int mvp_x, int mvp_y,

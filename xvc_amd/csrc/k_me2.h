@@ -36,7 +36,7 @@
 // Developer build (-DXVCGPU_TRACE): per-job phase timestamps (s_memtime) of
 // the ME kernel, one row per job, plain stores (tools/trace_me.py).
 #ifdef XVCGPU_TRACE
-__device__ unsigned long long g_me2_trace[32768][16];
+__device__ unsigned long long g_me2_trace[32768][24];
 #define ME2_TRACE(k)                                                        \
   do {                                                                      \
     if ((threadIdx.x & 63) == 0 && bi < 32768)                              \
@@ -48,9 +48,35 @@ __device__ unsigned long long g_me2_trace[32768][16];
     if ((threadIdx.x & 63) == 0 && bi < 32768)                              \
       g_me2_trace[bi][k] = __builtin_amdgcn_s_memrealtime();                \
   } while (0)
+// event counters of a job (columns 11..15): diamond sweeps, 16-candidate passes,
+// refinement iterations, neighbour steps, candidates evaluated
+// columns 16..23: clocks spent in the sections of the sub-pel passes (ME2_CLK)
+#define ME2_COUNT_DECL int me2_cnt[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
+#define ME2_COUNT(k, v) me2_cnt[k] += (v)
+#define ME2_COUNT_STORE()                                                   \
+  do {                                                                      \
+    if ((threadIdx.x & 63) == 0 && bi < 32768)                              \
+      for (int q_ = 0; q_ < 13; q_++) g_me2_trace[bi][11 + q_] = (unsigned long long)me2_cnt[q_]; \
+  } while (0)
+#define ME2_CLK_ARG , int *me2_cnt
+#define ME2_CLK_PASS , me2_cnt
+#define ME2_CLK_BEGIN unsigned long long me2_t0 = __builtin_amdgcn_s_memtime()
+#define ME2_CLK(k)                                                          \
+  do {                                                                      \
+    const unsigned long long t_ = __builtin_amdgcn_s_memtime();             \
+    me2_cnt[5 + (k)] += (int)(t_ - me2_t0);                                 \
+    me2_t0 = t_;                                                            \
+  } while (0)
 #else
 #define ME2_TRACE(k) do {} while (0)
 #define ME2_TRACE_RT(k) do {} while (0)
+#define ME2_COUNT_DECL do {} while (0)
+#define ME2_COUNT(k, v) do {} while (0)
+#define ME2_COUNT_STORE() do {} while (0)
+#define ME2_CLK_ARG
+#define ME2_CLK_PASS
+#define ME2_CLK_BEGIN do {} while (0)
+#define ME2_CLK(k) do {} while (0)
 #endif
 
 // ---- cross-lane helpers (DPP / swizzle; no LDS traffic) ---------------------
@@ -140,7 +166,9 @@ struct __attribute__((aligned(16))) Me2SharedT {
   // per x-phase slot: 14-bit H-filtered plane, rows -4..h+3 (the fast path keeps
   // the unfiltered samples here for a phase-0 slot).  The Sample-rounded
   // H-only prediction is derived from the 14-bit value, see me2_honly_taps.
-  int16_t hint[3][SUB ? (MS + 8) * MS : 8];
+  // (a slot is two columns wider than the block: the half-pel pass's x phase 8 is needed from
+  // one column to the left AND from the block's own column - one plane of w + 2 columns)
+  int16_t hint[3][SUB ? (MS + 8) * (MS + 2) : 8];
   uint32_t cost[128];
   // per sub-pel candidate: plane offset (int16 units from `orig`), stride,
   // rounding offset, shift, 8 taps
@@ -149,7 +177,10 @@ struct __attribute__((aligned(16))) Me2SharedT {
       int cand_plane[12], cand_stride[12], cand_off[12], cand_shift[12];
       int16_t cand_taps[12][8];
     };
-    SpCand sp[SUB ? 10 : 1];                // fast path (k_subpel.h)
+    struct {                                // fast path (k_subpel.h)
+      SpCand sp[SUB ? 10 : 1];
+      SpUnit un[SUB ? SP_MAX_UNITS : 1];
+    };
   };
   uint32_t dist[12];
   int dsum[12];                             // AC-only: sum(orig - pred) per candidate
@@ -169,36 +200,62 @@ using Me2Shared = Me2SharedT<MS, true>;
 // quad_perm DPP adds and a pass costs ~2 instructions per candidate.
 #define ME2_NOPOS 0x80008000u
 
-template <int SPL>  // segments per lane, original segments kept in registers
-__device__ __forceinline__ void me2_eval_quads_reg(const MeCtx &c, uint32_t *cost,
-                                                   const uint16_t *s_orig, int n) {
-  const int lane = ME2_LANE, qd = lane >> 2, q = lane & 3;
-  const int spr = c.w >> 3, lspr = 31 - __clz(spr);
+// Candidate rows are addressed as (uniform base) + (32-bit unsigned byte offset): one
+// scalar base per job, one multiply-add per candidate and one add per load instead of
+// 64-bit address arithmetic per load.  The base is the CU's position in the reference
+// plane moved down by ME2_ADDR_BIAS bytes, so that offsets of positions left of / above
+// the CU stay positive (a plane is far smaller than the bias).
+#define ME2_ADDR_BIAS (1u << 28)
+__device__ __forceinline__ const char *me2_ref_base(const MeCtx &c) {
+  return reinterpret_cast<const char *>(c.ref) - ME2_ADDR_BIAS;
+}
+__device__ __forceinline__ uint32_t me2_pos_off(const MeCtx &c, int x, int y) {
+  return (uint32_t)((y * c.rs + x) * 2) + ME2_ADDR_BIAS;
+}
+
+// This lane's share of the original block for the quad evaluation (SPL segments of 8
+// samples) and the byte offsets of those segments in a candidate block.
+template <int SPL>
+struct Me2Quad {
   uint4 a[SPL];
-  int goff[SPL];
+  uint32_t goff[SPL];
+};
+template <int SPL>
+__device__ __forceinline__ void me2_quad_load(const MeCtx &c, const uint16_t *s_orig,
+                                              Me2Quad<SPL> &qd) {
+  const int q = ME2_LANE & 3;
+  const int spr = c.w >> 3, lspr = 31 - __clz(spr);
 #pragma unroll
   for (int u = 0; u < SPL; u++) {
     const int sg = q + 4 * u;
     const int y = (sg >> lspr) * c.row_step, x = (sg & (spr - 1)) << 3;
-    a[u] = *reinterpret_cast<const uint4 *>(s_orig + y * c.w + x);
-    goff[u] = y * c.rs + x;
+    qd.a[u] = *reinterpret_cast<const uint4 *>(s_orig + y * c.w + x);
+    qd.goff[u] = (uint32_t)((y * c.rs + x) * 2);
   }
+}
+
+template <int SPL>  // segments per lane, original segments kept in registers
+__device__ __forceinline__ void me2_eval_quads_reg(const MeCtx &c, uint32_t *cost,
+                                                   const Me2Quad<SPL> &qd, int n) {
+  const int lane = ME2_LANE, qi = lane >> 2, q = lane & 3;
+  const char *base = me2_ref_base(c);
   for (int i0 = 0; i0 < n; i0 += 16) {
-    const int i = i0 + qd;
+    const int i = i0 + qi;
     const uint32_t pk = i < n ? cost[i] : ME2_NOPOS;
     if (pk == ME2_NOPOS) continue;  // uniform within the quad
     const int x = (int)(int16_t)(pk & 0xffffu), y = (int)pk >> 16;
-    const uint16_t *r = c.ref + (ptrdiff_t)y * c.rs + x;
+    const uint32_t vo = me2_pos_off(c, x, y);
     U16x8 b[SPL];
 #pragma unroll
-    for (int u = 0; u < SPL; u++) b[u] = *reinterpret_cast<const U16x8 *>(r + goff[u]);
+    for (int u = 0; u < SPL; u++)
+      b[u] = *reinterpret_cast<const U16x8 *>(base + (size_t)(vo + qd.goff[u]));
     uint32_t sum = 0;
 #pragma unroll
     for (int u = 0; u < SPL; u++) {
-      sum = __builtin_amdgcn_sad_u16(a[u].x, b[u].v[0], sum);
-      sum = __builtin_amdgcn_sad_u16(a[u].y, b[u].v[1], sum);
-      sum = __builtin_amdgcn_sad_u16(a[u].z, b[u].v[2], sum);
-      sum = __builtin_amdgcn_sad_u16(a[u].w, b[u].v[3], sum);
+      sum = __builtin_amdgcn_sad_u16(qd.a[u].x, b[u].v[0], sum);
+      sum = __builtin_amdgcn_sad_u16(qd.a[u].y, b[u].v[1], sum);
+      sum = __builtin_amdgcn_sad_u16(qd.a[u].z, b[u].v[2], sum);
+      sum = __builtin_amdgcn_sad_u16(qd.a[u].w, b[u].v[3], sum);
     }
     sum += (uint32_t)lane_xor<1>((int)sum);
     sum += (uint32_t)lane_xor<2>((int)sum);
@@ -213,18 +270,20 @@ __device__ __forceinline__ void me2_eval_quads_gen(const MeCtx &c, uint32_t *cos
   const bool wide = c.w >= 8;
   const int spr = wide ? c.w >> 3 : 1, lspr = 31 - __clz(spr);
   const int nseg = c.rows * spr;
+  const char *base = me2_ref_base(c);
   for (int i0 = 0; i0 < n; i0 += 16) {
     const int i = i0 + qd;
     const uint32_t pk = i < n ? cost[i] : ME2_NOPOS;
     if (pk == ME2_NOPOS) continue;
     const int x = (int)(int16_t)(pk & 0xffffu), y = (int)pk >> 16;
-    const uint16_t *r = c.ref + (ptrdiff_t)y * c.rs + x;
+    const uint32_t vo = me2_pos_off(c, x, y);
     uint32_t sum = 0;
     if (wide) {
       for (int sg = q; sg < nseg; sg += 4) {
         const int yy = (sg >> lspr) * c.row_step, xx = (sg & (spr - 1)) << 3;
         const uint4 a = *reinterpret_cast<const uint4 *>(s_orig + yy * c.w + xx);
-        const U16x8 b = *reinterpret_cast<const U16x8 *>(r + (ptrdiff_t)yy * c.rs + xx);
+        const U16x8 b = *reinterpret_cast<const U16x8 *>(
+            base + (size_t)(vo + (uint32_t)((yy * c.rs + xx) * 2)));
         sum = __builtin_amdgcn_sad_u16(a.x, b.v[0], sum);
         sum = __builtin_amdgcn_sad_u16(a.y, b.v[1], sum);
         sum = __builtin_amdgcn_sad_u16(a.z, b.v[2], sum);
@@ -234,7 +293,8 @@ __device__ __forceinline__ void me2_eval_quads_gen(const MeCtx &c, uint32_t *cos
       for (int sg = q; sg < nseg; sg += 4) {
         const int yy = sg * c.row_step;
         const uint2 a = *reinterpret_cast<const uint2 *>(s_orig + yy * 4);
-        const U16x4 b = *reinterpret_cast<const U16x4 *>(r + (ptrdiff_t)yy * c.rs);
+        const U16x4 b = *reinterpret_cast<const U16x4 *>(
+            base + (size_t)(vo + (uint32_t)(yy * c.rs * 2)));
         sum = __builtin_amdgcn_sad_u16(a.x, b.v[0], sum);
         sum = __builtin_amdgcn_sad_u16(a.y, b.v[1], sum);
       }
@@ -309,17 +369,27 @@ __device__ __forceinline__ void me2_eval_positions_ac(const MeCtx &c, uint32_t *
 }
 
 // Dispatch on the (wave-uniform) block shape.  Callers wave_sync() around it.
+// q16: the lane's original segments of a 16-segment block (16x16, 16x8 ... whatever visits
+// 16 segments), loaded once per job (me2_quad_load) - the shape of nearly every job of the
+// 16 class; the other shapes fetch theirs per call.
 __device__ __forceinline__ void me2_eval_positions(const MeCtx &c, uint32_t *cost,
-                                                   const uint16_t *s_orig, int n) {
+                                                   const uint16_t *s_orig, int n,
+                                                   const Me2Quad<4> &q16) {
   if (c.ac) {
     me2_eval_positions_ac(c, cost, s_orig, n);
     return;
   }
   const int nseg = c.w >= 8 ? c.rows * (c.w >> 3) : 0;
-  if (nseg == 16) me2_eval_quads_reg<4>(c, cost, s_orig, n);
-  else if (nseg == 8) me2_eval_quads_reg<2>(c, cost, s_orig, n);
-  else if (nseg == 4) me2_eval_quads_reg<1>(c, cost, s_orig, n);
-  else me2_eval_quads_gen(c, cost, s_orig, n);
+  if (nseg == 16) me2_eval_quads_reg<4>(c, cost, q16, n);
+  else if (nseg == 8) {
+    Me2Quad<2> qd;
+    me2_quad_load<2>(c, s_orig, qd);
+    me2_eval_quads_reg<2>(c, cost, qd, n);
+  } else if (nseg == 4) {
+    Me2Quad<1> qd;
+    me2_quad_load<1>(c, s_orig, qd);
+    me2_eval_quads_reg<1>(c, cost, qd, n);
+  } else me2_eval_quads_gen(c, cost, s_orig, n);
 }
 
 __device__ __forceinline__ uint32_t me2_pack_pos(int x, int y) {
@@ -327,25 +397,40 @@ __device__ __forceinline__ uint32_t me2_pack_pos(int x, int y) {
 }
 
 // This lane's two pattern entries (indices lane and lane + 64 of the TZ
-// candidate pattern, tz_pattern.h), unpacked once per job.
+// candidate pattern, tz_pattern.h), unpacked once per job.  The window tests of an
+// entry (IsInside<Dir> for its one or two directions, inter_tz_search.cc:278-336) are
+// kept as a packed box: the tested bounds of the job's window, the widest int16 values
+// for the untested ones - an entry is inside iff clamping its packed position to the box
+// leaves it unchanged (two v_pk instructions and a compare instead of a branch per
+// direction).  Full-pel positions are far inside int16 (|mv| < 8192 + the range).
 struct Me2Pattern {
-  int dx0, dy0, d10, d20, dx1, dy1, d11, d21;
   int meta0, meta1;  // (rng << 8) | ((d1 + d2) & 0xff), for winner look-up
   int off0, off1;    // (dy << 16) | (dx & 0xffff)
+  uint32_t lo0, hi0, lo1, hi1;   // (y bound << 16) | (x bound & 0xffff)
   int round0, round1;
 };
 
-__device__ __forceinline__ Me2Pattern me2_load_pattern(const TzCand *tzp) {
+__device__ __forceinline__ void me2_pattern_box(const MeCtx &c, const TzCand &a, uint32_t &lo,
+                                                uint32_t &hi) {
+  const bool l = a.d1 == TZ_LEFT || a.d2 == TZ_LEFT, r = a.d1 == TZ_RIGHT || a.d2 == TZ_RIGHT;
+  const bool u = a.d1 == TZ_UP || a.d2 == TZ_UP, d = a.d1 == TZ_DOWN || a.d2 == TZ_DOWN;
+  lo = me2_pack_pos(l ? c.min_x : -32768, u ? c.min_y : -32768);
+  hi = me2_pack_pos(r ? c.max_x : 32767, d ? c.max_y : 32767);
+}
+
+__device__ __forceinline__ Me2Pattern me2_load_pattern(const MeCtx &c, const TzCand *tzp) {
   const int lane = ME2_LANE;
   const TzCand a = tzp[lane];
   const TzCand b = tzp[lane + 64 < TZ_MAX_CANDS ? lane + 64 : 0];
   Me2Pattern p;
-  p.dx0 = a.dx; p.dy0 = a.dy; p.d10 = a.d1; p.d20 = a.d2; p.round0 = a.round;
-  p.dx1 = b.dx; p.dy1 = b.dy; p.d11 = b.d1; p.d21 = b.d2; p.round1 = b.round;
+  p.round0 = a.round;
+  p.round1 = b.round;
   p.meta0 = ((int)a.rng << 8) | ((a.d1 + a.d2) & 0xff);
   p.meta1 = ((int)b.rng << 8) | ((b.d1 + b.d2) & 0xff);
   p.off0 = ((int)a.dy << 16) | ((int)a.dx & 0xffff);
   p.off1 = ((int)b.dy << 16) | ((int)b.dx & 0xffff);
+  me2_pattern_box(c, a, p.lo0, p.hi0);
+  me2_pattern_box(c, b, p.lo1, p.hi1);
   return p;
 }
 
@@ -367,16 +452,24 @@ __device__ __forceinline__ void me2_pattern_at(const Me2Pattern &p, int idx, int
 // afterwards lane l holds the keys of candidates l and l+64
 // ((cost << 7) | index, or ME2_NOKEY when outside the window).
 template <class SH>
-__device__ __forceinline__ void me2_eval_diamonds(const MeCtx &c, SH &s,
+__device__ __forceinline__ int me2_eval_diamonds(const MeCtx &c, SH &s,
                                                   const Me2Pattern &p, int bx, int by,
                                                   int lo, int total, uint32_t best,
-                                                  uint32_t &key0, uint32_t &key1) {
+                                                  uint32_t &key0, uint32_t &key1,
+                                                  const Me2Quad<4> &q16) {
   const int lane = ME2_LANE;
-  const int x0 = bx + p.dx0, y0 = by + p.dy0, x1 = bx + p.dx1, y1 = by + p.dy1;
-  const bool v0 = lane >= lo && lane < total && tz_inside(c, p.d10, x0, y0) &&
-                  (p.d20 == 0 || tz_inside(c, p.d20, x0, y0));
-  const bool v1 = lane + 64 >= lo && lane + 64 < total && tz_inside(c, p.d11, x1, y1) &&
-                  (p.d21 == 0 || tz_inside(c, p.d21, x1, y1));
+  // packed positions of the two entries, and their window tests (Me2Pattern)
+  const sp_v2s ctr = sp_s2(me2_pack_pos(bx, by));
+  const sp_v2s q0 = ctr + sp_s2((uint32_t)p.off0), q1 = ctr + sp_s2((uint32_t)p.off1);
+  const uint32_t pk0 = sp_u(q0), pk1 = sp_u(q1);
+  const bool in0 = sp_u(__builtin_elementwise_min(__builtin_elementwise_max(q0, sp_s2(p.lo0)),
+                                                  sp_s2(p.hi0))) == pk0;
+  const bool in1 = sp_u(__builtin_elementwise_min(__builtin_elementwise_max(q1, sp_s2(p.lo1)),
+                                                  sp_s2(p.hi1))) == pk1;
+  const int x0 = (int)(int16_t)(pk0 & 0xffffu), y0 = (int)pk0 >> 16;
+  const int x1 = (int)(int16_t)(pk1 & 0xffffu), y1 = (int)pk1 >> 16;
+  const bool v0 = (unsigned)(lane - lo) < (unsigned)(total - lo) && in0;
+  const bool v1 = (unsigned)(lane + 64 - lo) < (unsigned)(total - lo) && in1;
   // cost = dist + rate >= rate: a candidate whose rate term alone is not below
   // `best` (the running best when the sweep starts; it only decreases) can
   // never pass the strict `cost < best` test of the fold, so its SAD is not
@@ -391,14 +484,15 @@ __device__ __forceinline__ void me2_eval_diamonds(const MeCtx &c, SH &s,
   const int i0 = __popcll(m0 & lt), i1 = n0 + __popcll(m1 & lt);
   const int n = n0 + __popcll(m1);
   wave_sync();
-  if (e0) s.cost[i0] = me2_pack_pos(x0, y0);
-  if (e1) s.cost[i1] = me2_pack_pos(x1, y1);
+  if (e0) s.cost[i0] = pk0;
+  if (e1) s.cost[i1] = pk1;
   wave_sync();
-  me2_eval_positions(c, s.cost, s.orig, n);
+  me2_eval_positions(c, s.cost, s.orig, n, q16);
   wave_sync();
   key0 = key1 = ME2_NOKEY;
   if (e0) key0 = ((s.cost[i0] + r0) << 7) | (uint32_t)lane;
   if (e1) key1 = ((s.cost[i1] + r1) << 7) | (uint32_t)(lane + 64);
+  return n;
 }
 
 // ---- sub-pel ---------------------------------------------------------------
@@ -585,17 +679,129 @@ __device__ __forceinline__ bool me2_subpel_fast(int w, int h, int bd, bool ac = 
   return w >= 8 && h >= 8 && bd <= 10 && !ac;   // AC-only SATD: the 32-bit path
 }
 
+// The x-phase planes a pass leaves in the three slots for the next one (fx < 0: none):
+// plane k holds x phase fx[k] for nc[k] columns from picture column pel0[k] on.
+struct SpSlots {
+  int fx[3], pel0[3], nc[3];
+};
+#define ME2_SLOT(MS) ((MS + 8) * (MS + 2))   // int16 entries of a plane slot
+
+// Fast path of a sub-pel pass (k_subpel.h; both sides >= 8, bd <= 10, plain SATD), by one
+// wave (NW = 1) or a team of NW waves: s.orig is column-major, the window is staged.
+// Raw tile sums of the n = 9 - pass candidates (pass < 0: of the single MV
+// (base_x, base_y)) in s.dist[0..n).  Arguments wave-uniform.
+template <int MS, int NW>
+__device__ __forceinline__ void me2_subpel_fast_pass(Me2Shared<MS> &s, const MeCtx &c,
+                                                     const xvcgpu_me_block &b, int pic_w,
+                                                     int pic_h, int fpx, int fpy, int pass,
+                                                     int base_x, int base_y, SpSlots &held
+                                                     ME2_CLK_ARG) {
+  const int w = c.w, h = c.h, bd = c.bd;
+  const int lane = ME2_LANE;
+  const int tid = NW == 1 ? lane : (int)threadIdx.x;
+  ME2_CLK_BEGIN;
+  auto sync = [] {
+    if (NW == 1) wave_sync();
+    else __syncthreads();
+  };
+  const int n = pass < 0 ? 1 : 9 - pass;
+  // this lane's candidate (lanes >= n idle; every wave of a team computes the same)
+  int mx = base_x, my = base_y;
+  if (pass >= 0 && lane < n) me2_subpel_mv(pass, lane, base_x, base_y, mx, my);
+  d_clip_mv(b.x, b.y, pic_w, pic_h, mx, my);  // MotionCompensationMv, :749
+  const int cpx = (mx >> 4) - fpx, cpy = (my >> 4) - fpy;   // -1 or 0 each
+  const int cfx = mx & 15, cfy = my & 15;
+  const bool need = lane < n;
+  // the distinct x phases (<= 3) and the columns each is needed from
+  int gfx[3] = {-1, -1, -1}, gpel[3] = {0, 0, 0}, gnc[3] = {0, 0, 0}, gslot[3] = {-1, -1, -1};
+  int mygroup = 0;
+  {
+    unsigned long long rem = __ballot(need);
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      if (rem) {
+        const int leader = __ffsll((long long)rem) - 1;
+        const int fxg = __builtin_amdgcn_readlane(cfx, leader);
+        const bool mem = need && cfx == fxg;
+        rem &= ~__ballot(mem);
+        const int lo = (__ballot(mem && cpx < 0) != 0) ? -1 : 0;
+        const bool both = lo < 0 && __ballot(mem && cpx >= 0) != 0;
+        gfx[k] = fxg; gpel[k] = lo; gnc[k] = both ? w + 2 : w;
+        if (mem) mygroup = k;
+      }
+    }
+  }
+  // a plane of the previous pass that covers a group is read again, the others are built
+  // (slot sets as bit masks: small arrays indexed by a computed slot end up in scratch)
+  int used = 0, build = 0;
+#pragma unroll
+  for (int g = 0; g < 3; g++) {
+    const int hi = gpel[g] + (gnc[g] > w ? w + 1 : w);
+#pragma unroll
+    for (int j = 0; j < 3; j++)
+      if (gfx[g] >= 0 && gslot[g] < 0 && !(used & (1 << j)) && held.fx[j] == gfx[g] &&
+          held.pel0[j] <= gpel[g] && held.pel0[j] + held.nc[j] >= hi) {
+        gslot[g] = j;
+        used |= 1 << j;
+      }
+  }
+#pragma unroll
+  for (int g = 0; g < 3; g++) {
+    if (gfx[g] >= 0 && gslot[g] < 0) {
+      const int j = !(used & 1) ? 0 : (!(used & 2) ? 1 : 2);
+      gslot[g] = j;
+      used |= 1 << j;
+      build |= 1 << j;
+#pragma unroll
+      for (int k = 0; k < 3; k++)
+        if (k == j) { held.fx[k] = gfx[g]; held.pel0[k] = gpel[g]; held.nc[k] = gnc[g]; }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 3; j++)
+    if (!(used & (1 << j))) held.fx[j] = -1;   // (overwritten or not: no longer tracked)
+  sync();  // previous readers of the planes / tables are done
+  ME2_CLK(0);   // candidates, plane slots
+#pragma unroll
+  for (int j = 0; j < 3; j++)
+    if (build & (1 << j))
+      sp_build_planes(s.win, s.hint[j], s.taps, bd, w, h, held.pel0[j], held.fx[j], held.nc[j],
+                      tid, 64 * NW);
+  ME2_CLK(1);   // planes
+  if (tid < n) {
+    const int16_t *base = reinterpret_cast<const int16_t *>(s.orig);
+    SpCand &cd = s.sp[lane];
+    const int slot = mygroup == 0 ? gslot[0] : (mygroup == 1 ? gslot[1] : gslot[2]);
+    const int pel0 = slot == 0 ? held.pel0[0] : (slot == 1 ? held.pel0[1] : held.pel0[2]);
+    const bool honly = cfx != 0 && cfy == 0, two_stage = cfx != 0 && cfy != 0;
+    const int sh = 20 - bd;   // FilterVerShortSample's shift
+    cd.plane = (int)(s.hint[0] - base) + slot * ME2_SLOT(MS) + (cpx - pel0) * (h + 8);
+    cd.off = two_stage ? ((8192 << 6) + (1 << (sh - 1))) << (16 - sh)
+                       : me2_honly_off(bd, cfx) << 10;
+    sp_fill_taps(cd, s.taps, me2_vtaps_row(cfx, cfy), cpy + 1,
+                 cfx == 0 ? 6 : (honly ? 10 : bd - 4));
+    cd.ident = cfy == 0;
+    s.dist[lane] = 0;
+  }
+  sync();
+  const int nunits = sp_make_units(s.sp, s.un, pass, tid);
+  sync();
+  ME2_CLK(2);   // candidate and unit records
+  sp_satd_units(reinterpret_cast<const int16_t *>(s.orig), s.sp, s.un, nunits, s.orig, s.dist, bd,
+                w, h, tid, 64 * NW);
+  sync();
+  ME2_CLK(3);   // the sweep
+}
+
 // Evaluate the SATD of the n = 9 - pass candidates of a sub-pel pass (or, with
 // pass < 0, of the single MV (base_x, base_y)) around the staged full-pel
 // position (fpx,fpy); raw tile sums in s.dist[0..n).  Arguments wave-uniform.
-// held[k]: the x-phase key of the plane slot k still holds from the job's previous pass
-// (-1: none) - the quarter-pel pass's centre column of candidates has the x-phase of the
-// half-pel winner, whose plane is therefore not built a second time.
+// The 32-bit row-major path: 4-wide blocks, bd 12, the AC-only metric.
 template <int MS>
 __device__ __forceinline__ void me2_subpel_eval(Me2Shared<MS> &s, const MeCtx &c,
                                                 const xvcgpu_me_block &b, int pic_w,
                                                 int pic_h, int fpx, int fpy, int pass,
-                                                int base_x, int base_y, int (&held)[3]) {
+                                                int base_x, int base_y) {
   const int w = c.w, h = c.h, bd = c.bd;
   const int ws = w + 16;
   const int lane = ME2_LANE;
@@ -608,56 +814,20 @@ __device__ __forceinline__ void me2_subpel_eval(Me2Shared<MS> &s, const MeCtx &c
   const int cfx = mx & 15, cfy = my & 15;
   // distinct horizontal phases with fx != 0 -> plane slots (<= 3)
   const int mykey = (cpx + 1) * 16 + cfx;
-  // fast path (k_subpel.h): both sides >= 8, 16-bit-safe residuals;
-  // the caller has transposed s.orig to column-major for it
-  const bool fastp = me2_subpel_fast(w, h, bd, c.ac);
-  const bool need = lane < n && (fastp || cfx != 0);
+  const bool need = lane < n && cfx != 0;
   int myslot = -1, slot_key[3] = {-1, -1, -1};
   bool build[3] = {false, false, false};
-#pragma unroll
-  for (int k = 0; k < 3; k++) {   // planes of the previous pass that this one reads again
-    if (held[k] >= 0 && __ballot(need && mykey == held[k]) != 0) {
-      if (need && mykey == held[k]) myslot = k;
-      slot_key[k] = held[k];
-    }
-  }
 #pragma unroll
   for (int k = 0; k < 3; k++) {
     const unsigned long long m = __ballot(need && myslot < 0);
     if (m) {
       const int leader = __ffsll((long long)m) - 1;
       const int key = __builtin_amdgcn_readlane(mykey, leader);
-      const int f = slot_key[0] < 0 ? 0 : (slot_key[1] < 0 ? 1 : 2);   // a free slot (<= 3 keys)
-      if (need && mykey == key) myslot = f;
-      if (f == 0) { slot_key[0] = key; build[0] = true; }
-      else if (f == 1) { slot_key[1] = key; build[1] = true; }
-      else { slot_key[2] = key; build[2] = true; }
+      if (need && mykey == key) myslot = k;
+      slot_key[k] = key; build[k] = true;
     }
   }
-#pragma unroll
-  for (int k = 0; k < 3; k++) held[k] = slot_key[k];
   wave_sync();  // previous readers of the planes / tables are done
-  if (fastp) {
-#pragma unroll
-    for (int k = 0; k < 3; k++)
-      if (build[k])
-        sp_build_planes(s.win, s.hint[k], s.taps, bd, w, h,
-                        (slot_key[k] >> 4) - 1, slot_key[k] & 15);
-    if (lane < n) {
-      const int16_t *base = reinterpret_cast<const int16_t *>(s.orig);
-      SpCand &cd = s.sp[lane];
-      const bool two_stage = cfx != 0 && cfy != 0;
-      cd.plane = (int)(s.hint[0] - base) + myslot * (MS + 8) * MS;
-      cd.sh = two_stage ? 6 + (14 - bd) : 6;
-      cd.off = two_stage ? (8192 << 6) + (1 << (cd.sh - 1)) : me2_honly_off(bd, cfx);
-      sp_fill_taps(cd, s.taps, me2_vtaps_row(cfx, cfy), cpy + 1);
-      s.dist[lane] = 0;
-    }
-    wave_sync();
-    sp_satd_pairs(reinterpret_cast<const int16_t *>(s.orig), s.sp, s.orig, s.dist, bd, w, h, n);
-    wave_sync();
-    return;
-  }
 #pragma unroll
   for (int k = 0; k < 3; k++)
     if (build[k])
@@ -675,13 +845,13 @@ __device__ __forceinline__ void me2_subpel_eval(Me2Shared<MS> &s, const MeCtx &c
       sh = 6;
     } else if (cfy == 0) {
       // horizontal-only: the Sample-rounded value out of the 14-bit plane
-      plane = (int)(s.hint[0] - base) + myslot * (MS + 8) * MS + (cpy + 1) * w;
+      plane = (int)(s.hint[0] - base) + myslot * ME2_SLOT(MS) + (cpy + 1) * w;
       stride = w;
       off = me2_honly_off(bd, cfx);
       sh = 6;
     } else {
       // two-stage: FilterVerShortSample on the 14-bit plane
-      plane = (int)(s.hint[0] - base) + myslot * (MS + 8) * MS + (cpy + 1) * w;
+      plane = (int)(s.hint[0] - base) + myslot * ME2_SLOT(MS) + (cpy + 1) * w;
       stride = w;
       sh = 6 + (14 - bd);
       off = (8192 << 6) + (1 << (sh - 1));
@@ -861,6 +1031,7 @@ me_search_wave_body(const PicView &orig, const PicView &ref,
     c.orig_sum = wave_reduce_add_i32(t);
   }
   ME2_TRACE(1);  // block descriptor read, original block loads issued
+  ME2_COUNT_DECL;
   xvcgpu_me_result res;
   if constexpr ((PH & XVCGPU_ME_FULLPEL) != 0) {
     const int range = b.search_range;
@@ -870,6 +1041,11 @@ me_search_wave_body(const PicView &orig, const PicView &ref,
         fs_max_y = c.max_y;
     TzState st;
     st.bx = 0; st.by = 0; st.cost = 0xffffffffu; st.last_pos = 0; st.last_range = 0;
+    Me2Quad<4> q16;
+    if (!LIC && c.w >= 8 && c.rows * (c.w >> 3) == 16) {
+      wave_sync();   // the staged original is visible
+      me2_quad_load<4>(c, s.orig, q16);
+    }
 
     // predictor, zero MV and previous CU's MV in one pass (groups 0..2)
     {
@@ -883,7 +1059,7 @@ me_search_wave_body(const PicView &orig, const PicView &ref,
         s.cost[lane] = me2_pack_pos(lane == 0 ? ax : (lane == 1 ? 0 : zx),
                                     lane == 0 ? ay : (lane == 1 ? 0 : zy));
       wave_sync();
-      me2_eval_positions(c, s.cost, s.orig, 3);
+      me2_eval_positions(c, s.cost, s.orig, 3, q16);
       wave_sync();
       if (lane < 3) {
         const int px_ = lane == 0 ? ax : (lane == 1 ? 0 : zx);
@@ -891,7 +1067,10 @@ me_search_wave_body(const PicView &orig, const PicView &ref,
         s.cost[lane] = me_cost(c, s.cost[lane], px_, py_);
       }
       wave_sync();
-      const uint32_t c0 = s.cost[0], c1 = s.cost[1], c2 = s.cost[2];
+      // (the same in every lane: said so, the search state and the loops it steers stay scalar)
+      const uint32_t c0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)s.cost[0]);
+      const uint32_t c1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)s.cost[1]);
+      const uint32_t c2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)s.cost[2]);
       st.cost = c0; st.bx = ax; st.by = ay;
       bool change = false;
       if (st.bx != 0 || st.by != 0) {
@@ -909,7 +1088,7 @@ me_search_wave_body(const PicView &orig, const PicView &ref,
     ME2_TRACE(2);  // predictor pass
     int total = 0, n_rounds = 0;
     for (int r = 1; r <= range; r *= 2) { total += tz_pattern_count(r); n_rounds++; }
-    const Me2Pattern pat = me2_load_pattern(tz_pattern);
+    const Me2Pattern pat = me2_load_pattern(c, tz_pattern);
 
     // initial raster around the fixed base with per-round early termination.
     // The reference stops after 3 consecutive rounds without a hit, so at any
@@ -928,7 +1107,9 @@ me_search_wave_body(const PicView &orig, const PicView &ref,
           int idx_hi = idx_eval;
           for (int q = r_eval; q < hi; q++) idx_hi += tz_pattern_count(1 << q);
           uint32_t f0, f1;
-          me2_eval_diamonds(c, s, pat, bx, by, idx_eval, idx_hi, st.cost, f0, f1);
+          const int ne = me2_eval_diamonds(c, s, pat, bx, by, idx_eval, idx_hi, st.cost, f0, f1, q16);
+          (void)ne;
+          ME2_COUNT(0, 1); ME2_COUNT(1, (ne + 15) >> 4); ME2_COUNT(4, ne);
           if (f0 != ME2_NOKEY) k0 = f0;
           if (f1 != ME2_NOKEY) k1 = f1;
           r_eval = hi;
@@ -966,23 +1147,24 @@ me_search_wave_body(const PicView &orig, const PicView &ref,
         default: any = false; break;
       }
       if (!any) return;
+      ME2_COUNT(3, 1);
       const bool v0 = tz_inside(c, d1[0], x[0], y[0]) && (d2[0] == 0 || tz_inside(c, d2[0], x[0], y[0]));
       const bool v1 = tz_inside(c, d1[1], x[1], y[1]) && (d2[1] == 0 || tz_inside(c, d2[1], x[1], y[1]));
       wave_sync();
       if (lane == 0) s.cost[0] = v0 ? me2_pack_pos(x[0], y[0]) : ME2_NOPOS;
       if (lane == 1) s.cost[1] = v1 ? me2_pack_pos(x[1], y[1]) : ME2_NOPOS;
       wave_sync();
-      me2_eval_positions(c, s.cost, s.orig, 2);
+      me2_eval_positions(c, s.cost, s.orig, 2, q16);
       wave_sync();
       if (lane == 0 && v0) s.cost[0] = me_cost(c, s.cost[0], x[0], y[0]);
       if (lane == 1 && v1) s.cost[1] = me_cost(c, s.cost[1], x[1], y[1]);
       wave_sync();
       if (v0) {
-        const uint32_t cc = s.cost[0];
+        const uint32_t cc = (uint32_t)__builtin_amdgcn_readfirstlane((int)s.cost[0]);
         if (cc < st.cost) { st.cost = cc; st.bx = x[0]; st.by = y[0]; st.last_pos = d1[0] + d2[0]; st.last_range = r; }
       }
       if (v1) {
-        const uint32_t cc = s.cost[1];
+        const uint32_t cc = (uint32_t)__builtin_amdgcn_readfirstlane((int)s.cost[1]);
         if (cc < st.cost) { st.cost = cc; st.bx = x[1]; st.by = y[1]; st.last_pos = d1[1] + d2[1]; st.last_range = r; }
       }
     };
@@ -1075,7 +1257,9 @@ me_search_wave_body(const PicView &orig, const PicView &ref,
       st.last_range = 0;
       uint32_t k0, k1;
       const int bx = st.bx, by = st.by;
-      me2_eval_diamonds(c, s, pat, bx, by, 0, total, st.cost, k0, k1);
+      const int ne = me2_eval_diamonds(c, s, pat, bx, by, 0, total, st.cost, k0, k1, q16);
+      (void)ne;
+      ME2_COUNT(0, 1); ME2_COUNT(1, (ne + 15) >> 4); ME2_COUNT(4, ne); ME2_COUNT(2, 1);
       const uint32_t k = wave_min_key(k0 < k1 ? k0 : k1);
       if (k != ME2_NOKEY && (k >> 7) < st.cost) {
         int x, y, pos, rng;
@@ -1136,41 +1320,47 @@ me_search_wave_body(const PicView &orig, const PicView &ref,
         for (int i = lane; i < w * h; i += 64) s.orig[i] = tmp[i];
       }
     }
-    int held[3] = {-1, -1, -1};   // x-phase planes a pass leaves for the next one
-    if (b.fullpel_mv & XVC_ME_FULLPEL_MV) {
-      me2_subpel_eval(s, c, b, pic_w, pic_h, fpx, fpy, -1, res.mv_x, res.mv_y, held);
-      res.subpel_dist = s.dist[0] >> (c.bd - 8);
-    } else {
-      uint32_t best_cost = 0xffffffffu, best_dist = 0xffffffffu;
-      int best_x = res.mv_x, best_y = res.mv_y;
-      for (int pass = 0; pass < 2; pass++) {
-        const int base_x = best_x, base_y = best_y;
-        const int n = 9 - pass;
-        me2_subpel_eval(s, c, b, pic_w, pic_h, fpx, fpy, pass, base_x, base_y, held);
-        // the reference's ordered strict-< fold = (lowest cost, lowest index),
-        // one candidate per lane
-        uint32_t my_cost = 0xffffffffu;
-        if (lane < n) {
-          int mx, my;
-          me2_subpel_mv(pass, lane, base_x, base_y, mx, my);
-          my_cost = (s.dist[lane] >> (c.bd - 8)) +
-                    ((c.lambda * d_mvd_bits(b.mvp_x, b.mvp_y, mx, my, 0)) >> 16);
-        }
-        const uint32_t gmin = wave_min_key(my_cost);
-        const int gi = (int)wave_min_key(my_cost == gmin ? (uint32_t)lane : 64u);
-        if (gmin < best_cost) {
-          best_cost = gmin;
-          best_dist = s.dist[gi] >> (c.bd - 8);
-          me2_subpel_mv(pass, gi, base_x, base_y, best_x, best_y);
-        }
+    // one loop for the single-MV form (pass -1) and the two passes: the sweep is inlined once
+    const bool fastp = me2_subpel_fast(w, h, c.bd, c.ac);
+    const bool single = (b.fullpel_mv & XVC_ME_FULLPEL_MV) != 0;
+    SpSlots held = {{-1, -1, -1}, {0, 0, 0}, {0, 0, 0}};   // planes a pass leaves for the next one
+    uint32_t best_cost = 0xffffffffu, best_dist = 0xffffffffu;
+    int best_x = res.mv_x, best_y = res.mv_y;
+    for (int pass = single ? -1 : 0; pass < (single ? 0 : 2); pass++) {
+      const int base_x = best_x, base_y = best_y;
+      const int n = pass < 0 ? 1 : 9 - pass;
+      if (fastp)
+        me2_subpel_fast_pass<MS, 1>(s, c, b, pic_w, pic_h, fpx, fpy, pass, base_x, base_y,
+                                    held ME2_CLK_PASS);
+      else me2_subpel_eval(s, c, b, pic_w, pic_h, fpx, fpy, pass, base_x, base_y);
+      if (pass < 0) {
+        best_dist = s.dist[0] >> (c.bd - 8);
+        break;
       }
-      res.mv_x = best_x;
-      res.mv_y = best_y;
-      res.subpel_dist = best_dist;
+      // the reference's ordered strict-< fold = (lowest cost, lowest index),
+      // one candidate per lane
+      uint32_t my_cost = 0xffffffffu;
+      if (lane < n) {
+        int mx, my;
+        me2_subpel_mv(pass, lane, base_x, base_y, mx, my);
+        my_cost = (s.dist[lane] >> (c.bd - 8)) +
+                  ((c.lambda * d_mvd_bits(b.mvp_x, b.mvp_y, mx, my, 0)) >> 16);
+      }
+      const uint32_t gmin = wave_min_key(my_cost);
+      const int gi = (int)wave_min_key(my_cost == gmin ? (uint32_t)lane : 64u);
+      if (gmin < best_cost) {
+        best_cost = gmin;
+        best_dist = s.dist[gi] >> (c.bd - 8);
+        me2_subpel_mv(pass, gi, base_x, base_y, best_x, best_y);
+      }
     }
+    res.mv_x = best_x;
+    res.mv_y = best_y;
+    res.subpel_dist = best_dist;
   }
   ME2_TRACE(8);  // sub-pel passes
   ME2_TRACE_RT(10);
+  ME2_COUNT_STORE();
   if (lane == 0) results[bi] = res;
 }
 
@@ -1222,55 +1412,6 @@ me_search_multi_kernel(MultiArgs<MeMultiArgs> m, const TzCand *tz_pattern) {
 // jobs of class MS that qualify for the packed path (me2_subpel_fast); the
 // others stay with me_search_wave_kernel<MS, SUBPEL>, which skips these.
 // grid: n workgroups padded to 8; block: 64 * NW.
-template <int MS, int NW>
-__device__ __forceinline__ void me2_team_eval(Me2Shared<MS> &s, const MeCtx &c,
-                                              const xvcgpu_me_block &b, int pic_w, int pic_h,
-                                              int fpx, int fpy, int pass, int base_x,
-                                              int base_y) {
-  const int w = c.w, h = c.h, bd = c.bd;
-  const int lane = ME2_LANE, tid = threadIdx.x;
-  const int n = pass < 0 ? 1 : 9 - pass;
-  int mx = base_x, my = base_y;
-  if (pass >= 0 && lane < n) me2_subpel_mv(pass, lane, base_x, base_y, mx, my);
-  d_clip_mv(b.x, b.y, pic_w, pic_h, mx, my);
-  const int cpx = (mx >> 4) - fpx, cpy = (my >> 4) - fpy;
-  const int cfx = mx & 15, cfy = my & 15;
-  const int mykey = (cpx + 1) * 16 + cfx;
-  const bool need = lane < n;
-  int myslot = -1, nslots = 0, slot_key[3] = {0, 0, 0};
-#pragma unroll
-  for (int k = 0; k < 3; k++) {
-    const unsigned long long m = __ballot(need && myslot < 0);
-    if (m) {
-      const int leader = __ffsll((long long)m) - 1;
-      const int key = __builtin_amdgcn_readlane(mykey, leader);
-      if (need && mykey == key) myslot = k;
-      slot_key[k] = key;
-      nslots = k + 1;
-    }
-  }
-  __syncthreads();  // previous readers of the planes / tables are done
-#pragma unroll
-  for (int k = 0; k < 3; k++)
-    if (k < nslots)
-      sp_build_planes(s.win, s.hint[k], s.taps, bd, w, h, (slot_key[k] >> 4) - 1,
-                      slot_key[k] & 15, tid, 64 * NW);
-  if (tid < n) {
-    const int16_t *base = reinterpret_cast<const int16_t *>(s.orig);
-    SpCand &cd = s.sp[lane];
-    const bool two_stage = cfx != 0 && cfy != 0;
-    cd.plane = (int)(s.hint[0] - base) + myslot * (MS + 8) * MS;
-    cd.sh = two_stage ? 6 + (14 - bd) : 6;
-    cd.off = two_stage ? (8192 << 6) + (1 << (cd.sh - 1)) : me2_honly_off(bd, cfx);
-    sp_fill_taps(cd, s.taps, me2_vtaps_row(cfx, cfy), cpy + 1);
-    s.dist[lane] = 0;
-  }
-  __syncthreads();
-  sp_satd_pairs(reinterpret_cast<const int16_t *>(s.orig), s.sp, s.orig, s.dist, bd, w, h, n,
-                tid, 64 * NW);
-  __syncthreads();
-}
-
 template <int MS, int NW>
 __device__ __forceinline__ void
 me_subpel_team_body(const PicView &orig, const PicView &ref, const xvcgpu_me_block *blocks, int n,
@@ -1334,8 +1475,11 @@ me_subpel_team_body(const PicView &orig, const PicView &ref, const xvcgpu_me_blo
       *reinterpret_cast<uint4 *>(s.win + r * ws + ch * 8) = make_uint4(v.v[0], v.v[1], v.v[2], v.v[3]);
     }
   }
+  SpSlots held = {{-1, -1, -1}, {0, 0, 0}, {0, 0, 0}};
+  ME2_COUNT_DECL;
   if (b.fullpel_mv & XVC_ME_FULLPEL_MV) {
-    me2_team_eval<MS, NW>(s, c, b, pic_w, pic_h, fpx, fpy, -1, res.mv_x, res.mv_y);
+    me2_subpel_fast_pass<MS, NW>(s, c, b, pic_w, pic_h, fpx, fpy, -1, res.mv_x, res.mv_y,
+                                 held ME2_CLK_PASS);
     res.subpel_dist = s.dist[0] >> (c.bd - 8);
   } else {
     uint32_t best_cost = 0xffffffffu, best_dist = 0xffffffffu;
@@ -1343,7 +1487,8 @@ me_subpel_team_body(const PicView &orig, const PicView &ref, const xvcgpu_me_blo
     for (int pass = 0; pass < 2; pass++) {
       const int base_x = best_x, base_y = best_y;
       const int nc = 9 - pass;
-      me2_team_eval<MS, NW>(s, c, b, pic_w, pic_h, fpx, fpy, pass, base_x, base_y);
+      me2_subpel_fast_pass<MS, NW>(s, c, b, pic_w, pic_h, fpx, fpy, pass, base_x, base_y,
+                                   held ME2_CLK_PASS);
       uint32_t my_cost = 0xffffffffu;
       if (lane < nc) {
         int mx, my;

@@ -6,13 +6,20 @@
 // instructions:
 //   * the filtered planes are kept COLUMN-major in LDS, so the vertical 8-tap
 //     filter of 8 outputs of one column reads 16 consecutive int16 (two
-//     ds_read_b128) and is 5 v_dot2c_i32_i16 per output: rows are consumed as
+//     ds_read_b128) and is <= 5 v_dot2_i32_i16 per output: rows are consumed as
 //     aligned pairs, an odd start uses the tap set shifted by one
 //     ((0,t0),(t1,t2),(t3,t4),(t5,t6),(t7,0));
+//   * taps (and the unfiltered plane) are pre-scaled by powers of two so that
+//     the rounded, shifted prediction is the accumulator's UPPER half: no shift
+//     per output, and two candidates' outputs are packed by one v_perm_b32;
 //   * lane = one column of one 8x8 tile for TWO candidates, one in each
 //     16-bit half: clip, residual and the Hadamard butterflies are v_pk_*;
 //     the vertical WHT is in registers, the horizontal one goes through
 //     ds_swizzle (LDS crossbar, no VALU);
+//   * the candidates of a pass are paired by what they share (sp_make_units):
+//     the two half-pel candidates above / below a position are ONE filtered
+//     column read at two row offsets (9 outputs instead of 16), a candidate
+//     whose vertical phase is zero is one tap, not eight;
 //   * the last butterfly stage is never formed: |a+b| + |a-b| = 2 max(|a|,|b|).
 // 16-bit safety: |orig - pred| <= 1023 (bd <= 10); after k stages <= 1023*2^k;
 // five stages = 32736 < 2^15; the sum of two maxima 65472 < 2^16.
@@ -30,6 +37,13 @@ __device__ __forceinline__ uint32_t sp_u(sp_v2s v) { return __builtin_bit_cast(u
 __device__ __forceinline__ int sp_dot2(uint32_t a, uint32_t b, int c) {
   return __builtin_amdgcn_sdot2(sp_s2(a), sp_s2(b), c, false);
 }
+// the same with the addend in a register of its own: the compiler's two-address
+// form (v_dot2c) would copy a live addend (the rounding offset) first
+__device__ __forceinline__ int sp_dot2_from(uint32_t a, uint32_t b, int c) {
+  int d;
+  asm("v_dot2_i32_i16 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  return d;
+}
 __device__ __forceinline__ uint32_t sp_pack_taps(int lo, int hi) {
   return ((uint32_t)lo & 0xffffu) | ((uint32_t)hi << 16);
 }
@@ -39,82 +53,132 @@ __device__ __forceinline__ uint32_t sp_pk_mad(uint32_t a, uint32_t b, uint32_t c
   asm("v_pk_mad_i16 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
   return d;
 }
+// (a.lo - b.lo, a.lo - b.hi) / (a.hi - b.lo, a.hi - b.hi): one original sample
+// against the two candidates' predictions, the replication done by op_sel
+__device__ __forceinline__ uint32_t sp_pk_sub_lo(uint32_t a, uint32_t b) {
+  uint32_t d;
+  asm("v_pk_sub_i16 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b));
+  return d;
+}
+__device__ __forceinline__ uint32_t sp_pk_sub_hi(uint32_t a, uint32_t b) {
+  uint32_t d;
+  asm("v_pk_sub_i16 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1]" : "=v"(d) : "v"(a), "v"(b));
+  return d;
+}
+// upper halves of two accumulators side by side: (a >> 16) | (b & 0xffff0000)
+__device__ __forceinline__ uint32_t sp_pack_hi(int a, int b) {
+  return __builtin_amdgcn_perm((uint32_t)b, (uint32_t)a, 0x07060302u);
+}
 template <int PATTERN>
 __device__ __forceinline__ uint32_t sp_swizzle(uint32_t v) {
   return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, PATTERN);
 }
 
-// Per-candidate parameters of the vertical stage, 16 dwords.
+// Per-candidate parameters of the vertical stage, 16 dwords.  The taps are scaled by
+// 2^k, k chosen per kind of candidate so that (sum + off) >> 16 is the prediction:
+//   unfiltered plane (x phase 0; the plane holds sample << 4): k = 6, off = 32 << 10
+//     (FilterVerSampleSample: (sum + 32) >> 6, identity taps for y phase 0);
+//   horizontal only (one tap 2^(bd - 8) on the 14-bit plane, me2_honly_off): k = 10;
+//   two-stage (FilterVerShortSample, shift 20 - bd): k = bd - 4.
 struct __attribute__((aligned(16))) SpCand {
   uint32_t e[5];   // tap pairs for even outputs of the column
   uint32_t o[5];   // tap pairs for odd outputs
-  int off, sh;     // rounding offset, shift
-  int plane;       // int16 index of the plane's (x = 0, stored row 0)
-  int pad[3];
+  int off;         // rounding offset, scaled like the taps
+  int plane;       // int16 index of the plane's (this candidate's x = 0, stored row 0)
+  int q;           // stored row of the first tap for output row 0: 0 or 1
+  int ident;       // vertical phase 0 (or horizontal only): one tap, at index 3
+  int pad[2];
 };
 
+// A unit of the sweep: two candidates (cb == ca: one) that share each lane, with all the
+// sweep needs of them in one record (a lane reads its unit's record in one round trip).
+enum { SP_GENERIC = 0, SP_ROWSHARED = 1, SP_IDENT = 2 };
+struct __attribute__((aligned(16))) SpUnit {
+  int ca, cb, kind, pad;
+  int plane_a, plane_b, off_a, off_b;
+  uint32_t ta[12];   // candidate a: e[0..4], o[0..4]
+  uint32_t tb[12];   // candidate b
+};
+#define SP_MAX_UNITS 5
+
 // Column-major plane of one x-phase: p14 = FilterHorSampleShort (14 bit), or
-// the unfiltered samples when fx == 0; column
-// stride h + 8, stored row r <-> picture row r - 4 relative to the full-pel
-// position.  win: row-major window, cols -8..w+7 (row stride w + 16).
+// the unfiltered samples << 4 when fx == 0; `ncols` (even) columns from picture
+// column pel_x on; column stride h + 8, stored row r <-> picture row r - 4
+// relative to the full-pel position.  win: row-major window, cols -8..w+7
+// (row stride w + 16).
 __device__ __forceinline__ void sp_build_planes(const uint16_t *win, int16_t *p14,
                                                 const int16_t (*taps)[8],
                                                 int bd, int w, int h, int pel_x, int fx,
-                                                int tid = threadIdx.x & 63, int nthr = 64) {
-  const int lane = tid;   // tid / nthr: this thread's place in the wave (or team of waves)
+                                                int ncols, int tid = threadIdx.x & 63,
+                                                int nthr = 64) {
+  // tid / nthr: this thread's place in the wave (or team of waves).  A thread keeps its pair
+  // of columns and walks down the rows (the threads cover nthr / (w / 2) rows at a time): the
+  // window and plane addresses advance by constants.  The two extra columns of a wide plane
+  // (ncols = w + 2) are a second walk, one row per thread.
   const int ws = w + 16, rs = h + 8;
   const int hw = w >> 1, lhw = 31 - __clz(hw);
-  const int n = rs * hw;  // units: (row, pair of columns)
-  if (fx == 0) {
-    for (int i = lane; i < n; i += nthr) {
-      const int r = i >> lhw, x0 = (i & (hw - 1)) << 1;
-      const uint16_t *src = win + r * ws + x0 + pel_x + 8;
-      p14[x0 * rs + r] = (int16_t)src[0];
-      p14[(x0 + 1) * rs + r] = (int16_t)src[1];
-    }
-    return;
-  }
-  const int16_t *f = taps[fx];  // LDS copy of kLumaTaps
-  const uint32_t a0 = sp_pack_taps(f[0], f[1]), a1 = sp_pack_taps(f[2], f[3]),
-                 a2 = sp_pack_taps(f[4], f[5]), a3 = sp_pack_taps(f[6], f[7]);
-  const uint32_t b0 = sp_pack_taps(0, f[0]), b1 = sp_pack_taps(f[1], f[2]),
-                 b2 = sp_pack_taps(f[3], f[4]), b3 = sp_pack_taps(f[5], f[6]),
-                 b4 = sp_pack_taps(f[7], 0);
+  const int rstep = nthr >> lhw;                       // w <= 64: hw <= 32 <= nthr
   const int shift = 6 - (14 - bd), offset = -(8192 << shift);
-  // first tap of output x0 sits at window column c0 = x0 + pel_x + 5
-  const bool odd = ((pel_x + 5) & 1) != 0;
-  const uint32_t *win32 = reinterpret_cast<const uint32_t *>(win);
-  for (int i = lane; i < n; i += nthr) {
-    const int r = i >> lhw, x0 = (i & (hw - 1)) << 1;
-    const uint32_t *d = win32 + ((r * ws + x0 + pel_x + 5) >> 1);
+  const bool odd = ((pel_x + 5) & 1) != 0;             // parity of the first tap's window column
+  uint32_t a0 = 0, a1 = 0, a2 = 0, a3 = 0, b0 = 0, b1 = 0, b2 = 0, b3 = 0, b4 = 0;
+  if (fx != 0) {
+    const int16_t *f = taps[fx];  // LDS copy of kLumaTaps
+    a0 = sp_pack_taps(f[0], f[1]); a1 = sp_pack_taps(f[2], f[3]);
+    a2 = sp_pack_taps(f[4], f[5]); a3 = sp_pack_taps(f[6], f[7]);
+    b0 = sp_pack_taps(0, f[0]); b1 = sp_pack_taps(f[1], f[2]); b2 = sp_pack_taps(f[3], f[4]);
+    b3 = sp_pack_taps(f[5], f[6]); b4 = sp_pack_taps(f[7], 0);
+  }
+  // one (row, pair of columns x0, x0 + 1): src = the window row
+  auto unit = [&](const uint16_t *wrow, int x0, int16_t *dst) {
+    if (fx == 0) {
+      const uint16_t *src = wrow + x0 + pel_x + 8;
+      dst[0] = (int16_t)(src[0] << 4);
+      dst[rs] = (int16_t)(src[1] << 4);
+      return;
+    }
+    // first tap of output x0 sits at window column c0 = x0 + pel_x + 5
+    const uint32_t *d = reinterpret_cast<const uint32_t *>(wrow) + ((x0 + pel_x + 5) >> 1);
     const uint32_t d0 = d[0], d1 = d[1], d2 = d[2], d3 = d[3], d4 = d[4];
     int s0, s1;
     if (!odd) {
-      s0 = sp_dot2(d0, a0, 0); s0 = sp_dot2(d1, a1, s0); s0 = sp_dot2(d2, a2, s0);
+      s0 = sp_dot2_from(d0, a0, offset); s0 = sp_dot2(d1, a1, s0); s0 = sp_dot2(d2, a2, s0);
       s0 = sp_dot2(d3, a3, s0);
-      s1 = sp_dot2(d0, b0, 0); s1 = sp_dot2(d1, b1, s1); s1 = sp_dot2(d2, b2, s1);
+      s1 = sp_dot2_from(d0, b0, offset); s1 = sp_dot2(d1, b1, s1); s1 = sp_dot2(d2, b2, s1);
       s1 = sp_dot2(d3, b3, s1); s1 = sp_dot2(d4, b4, s1);
     } else {
-      s0 = sp_dot2(d0, b0, 0); s0 = sp_dot2(d1, b1, s0); s0 = sp_dot2(d2, b2, s0);
+      s0 = sp_dot2_from(d0, b0, offset); s0 = sp_dot2(d1, b1, s0); s0 = sp_dot2(d2, b2, s0);
       s0 = sp_dot2(d3, b3, s0); s0 = sp_dot2(d4, b4, s0);
-      s1 = sp_dot2(d1, a0, 0); s1 = sp_dot2(d2, a1, s1); s1 = sp_dot2(d3, a2, s1);
+      s1 = sp_dot2_from(d1, a0, offset); s1 = sp_dot2(d2, a1, s1); s1 = sp_dot2(d3, a2, s1);
       s1 = sp_dot2(d4, a3, s1);
     }
-    p14[x0 * rs + r] = (int16_t)((s0 + offset) >> shift);
-    p14[(x0 + 1) * rs + r] = (int16_t)((s1 + offset) >> shift);
+    dst[0] = (int16_t)(s0 >> shift);
+    dst[rs] = (int16_t)(s1 >> shift);
+  };
+  {
+    const int x0 = (tid & (hw - 1)) << 1;
+    const uint16_t *wrow = win + (tid >> lhw) * ws;
+    int16_t *dst = p14 + x0 * rs + (tid >> lhw);
+    for (int r = tid >> lhw; r < rs; r += rstep, wrow += rstep * ws, dst += rstep)
+      unit(wrow, x0, dst);
   }
+  if (ncols > w)
+    for (int r = tid; r < rs; r += nthr) unit(win + r * ws, w, p14 + w * rs + r);
 }
 
 // Tap sets of a candidate: q = (stored row of its first tap for output row 0)
-// in {0, 1}; fy = vertical phase (0 -> identity taps).
+// in {0, 1}; fy = row of `taps` (vertical phase; 0 -> identity taps; 16 -> the
+// horizontal-only tap); ks = log2 of the scale.
 __device__ __forceinline__ void sp_fill_taps(SpCand &c, const int16_t (*taps)[8], int fy,
-                                             int q) {
+                                             int q, int ks) {
   const int16_t *t = taps[fy];
-  const uint32_t a0 = sp_pack_taps(t[0], t[1]), a1 = sp_pack_taps(t[2], t[3]),
-                 a2 = sp_pack_taps(t[4], t[5]), a3 = sp_pack_taps(t[6], t[7]);
-  const uint32_t b0 = sp_pack_taps(0, t[0]), b1 = sp_pack_taps(t[1], t[2]),
-                 b2 = sp_pack_taps(t[3], t[4]), b3 = sp_pack_taps(t[5], t[6]),
-                 b4 = sp_pack_taps(t[7], 0);
+  int s[8];
+#pragma unroll
+  for (int i = 0; i < 8; i++) s[i] = (int)t[i] << ks;
+  const uint32_t a0 = sp_pack_taps(s[0], s[1]), a1 = sp_pack_taps(s[2], s[3]),
+                 a2 = sp_pack_taps(s[4], s[5]), a3 = sp_pack_taps(s[6], s[7]);
+  const uint32_t b0 = sp_pack_taps(0, s[0]), b1 = sp_pack_taps(s[1], s[2]),
+                 b2 = sp_pack_taps(s[3], s[4]), b3 = sp_pack_taps(s[5], s[6]),
+                 b4 = sp_pack_taps(s[7], 0);
   if (q == 0) {
     c.e[0] = a0; c.e[1] = a1; c.e[2] = a2; c.e[3] = a3; c.e[4] = 0;
     c.o[0] = b0; c.o[1] = b1; c.o[2] = b2; c.o[3] = b3; c.o[4] = b4;
@@ -122,35 +186,58 @@ __device__ __forceinline__ void sp_fill_taps(SpCand &c, const int16_t (*taps)[8]
     c.e[0] = b0; c.e[1] = b1; c.e[2] = b2; c.e[3] = b3; c.e[4] = b4;
     c.o[0] = 0; c.o[1] = a0; c.o[2] = a1; c.o[3] = a2; c.o[4] = a3;
   }
+  c.q = q;
 }
 
-// Vertical filter of one tile column (8 outputs) of one candidate: raw
-// (acc >> sh) values, not yet narrowed / clipped.
-__device__ __forceinline__ void sp_vfilter8(const int16_t *lds, const SpCand &c, int col_off,
-                                            int out[8]) {
-  const uint4 *src = reinterpret_cast<const uint4 *>(lds + c.plane + col_off);
-  const uint4 lo = src[0], hi = src[1];
-  const uint32_t p[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-#pragma unroll
-  for (int m = 0; m < 4; m++) {
-    int e = c.off, o = c.off;
+// The units of a pass, by what its candidates share (lanes 0.. of a wave, `lane`
+// = unit index; cand[] filled and visible).  The 9 / 8 candidates of a pass are a
+// 3 x 3 square of offsets (dx, dy) in issue order (kSubpelOff, k_me2.h): the
+// candidates (dx, -1) and (dx, +1) have one x phase - one plane column -, the
+// candidates (-1, 0) and (+1, 0) one y phase.  pass -1: the one candidate.
+//   SP_ROWSHARED: same column, same taps, rows one apart (the half-pel pass's
+//     above / below: one filtered column of nine outputs read at two offsets);
+//   SP_IDENT: both candidates' vertical phase is zero (one tap each);
+//   SP_GENERIC: two independent vertical filters.
+__device__ __forceinline__ int sp_make_units(const SpCand *cand, SpUnit *units, int pass,
+                                             int lane) {
+  // candidate indices of (VP(-1), VP(+1), VP(0), HP, C)
+  const int nunits = pass < 0 ? 1 : (pass == 0 ? 5 : 4);
+  if (lane < nunits) {
+    int ca, cb;
+    bool vp;
+    if (pass < 0) { ca = cb = 0; vp = false; }
+    else if (pass == 0) {
+      ca = lane == 0 ? 5 : (lane == 1 ? 6 : (lane == 2 ? 1 : (lane == 3 ? 3 : 0)));
+      cb = lane == 0 ? 7 : (lane == 1 ? 8 : (lane == 2 ? 2 : (lane == 3 ? 4 : 0)));
+      vp = lane < 3;
+    } else {
+      ca = lane == 0 ? 2 : (lane == 1 ? 3 : (lane == 2 ? 0 : 4));
+      cb = lane == 0 ? 6 : (lane == 1 ? 7 : (lane == 2 ? 1 : 5));
+      vp = lane < 3;
+    }
+    const SpCand A = cand[ca], B = cand[cb];
+    int kind = SP_GENERIC;
+    if (A.ident && B.ident) kind = SP_IDENT;
+    else if (vp && !A.ident && A.plane == B.plane && A.q == 0 && B.q == 1 && A.off == B.off &&
+             A.e[0] == B.o[1] && A.e[1] == B.o[2] && A.e[2] == B.o[3] && A.e[3] == B.o[4])
+      kind = SP_ROWSHARED;
+    SpUnit &u = units[lane];
+    u.ca = ca; u.cb = cb; u.kind = kind; u.pad = 0;
+    u.plane_a = A.plane; u.plane_b = B.plane; u.off_a = A.off; u.off_b = B.off;
 #pragma unroll
     for (int i = 0; i < 5; i++) {
-      if (m + i < 8) {
-        e = sp_dot2(p[m + i], c.e[i], e);
-        o = sp_dot2(p[m + i], c.o[i], o);
-      }
+      u.ta[i] = A.e[i]; u.ta[5 + i] = A.o[i];
+      u.tb[i] = B.e[i]; u.tb[5 + i] = B.o[i];
     }
-    out[2 * m] = e >> c.sh;
-    out[2 * m + 1] = o >> c.sh;
   }
+  return nunits;
 }
 
-// SATD of `ncand` candidates (params in cand[]) against origc (the original
-// block, column-major, column stride h) with TW x TH tiles: 8x8 (square
+// SATD of the candidates of `nunits` units (params in cand[]) against origc (the
+// original block, column-major, column stride h) with TW x TH tiles: 8x8 (square
 // blocks), 16x8 (w > h) or 8x16 (w < h), ComputeSatdNxM's choice for blocks
 // with both sides >= 8 (sample_metric.cc:403-641).  Adds the normalised tile
-// sums into dist[c].  w, h multiples of TW, TH; bd <= 10.
+// sums into dist[c].  w, h powers of two, multiples of TW, TH; bd <= 10.
 //
 // lane = one column of one tile for two candidates (one per 16-bit half); the
 // TH rows of the column are registers.  The vertical butterflies (log2 TH
@@ -171,58 +258,125 @@ __device__ __forceinline__ uint32_t sp_pk_abs(uint32_t v) {
   return sp_u(__builtin_elementwise_max(x, sp_s2(0u) - x));
 }
 
+// 16 stored rows (8 aligned pairs) of one plane column
+__device__ __forceinline__ void sp_load_col(const int16_t *lds, int idx, uint32_t p[8]) {
+  const uint4 *src = reinterpret_cast<const uint4 *>(lds + idx);
+  const uint4 lo = src[0], hi = src[1];
+  p[0] = lo.x; p[1] = lo.y; p[2] = lo.z; p[3] = lo.w;
+  p[4] = hi.x; p[5] = hi.y; p[6] = hi.z; p[7] = hi.w;
+}
+
+// the three ways to the packed predictions pk[8] (low half: candidate a) of a tile column;
+// pa / pb: the 16 stored rows of the candidates' plane columns, ta / tb: their e[5], o[5]
+__device__ __forceinline__ void sp_pred_generic(const uint32_t pa[8], const uint32_t pb[8],
+                                                const uint32_t *ta, const uint32_t *tb,
+                                                int off_a, int off_b, uint32_t pk[8]) {
+#pragma unroll
+  for (int m = 0; m < 4; m++) {
+    int ea = sp_dot2_from(pa[m], ta[0], off_a), oa = sp_dot2_from(pa[m], ta[5], off_a);
+    int eb = sp_dot2_from(pb[m], tb[0], off_b), ob = sp_dot2_from(pb[m], tb[5], off_b);
+#pragma unroll
+    for (int i = 1; i < 5; i++) {
+      ea = sp_dot2(pa[m + i], ta[i], ea);
+      oa = sp_dot2(pa[m + i], ta[5 + i], oa);
+      eb = sp_dot2(pb[m + i], tb[i], eb);
+      ob = sp_dot2(pb[m + i], tb[5 + i], ob);
+    }
+    pk[2 * m] = sp_pack_hi(ea, eb);
+    pk[2 * m + 1] = sp_pack_hi(oa, ob);
+  }
+}
+// candidate b = candidate a one row further down the same filtered column
+// (q_a = 0: e = the aligned tap pairs, e[4] = 0; o = the shifted ones)
+__device__ __forceinline__ void sp_pred_rowshared(const uint32_t pa[8], const uint32_t *ta,
+                                                  int off_a, uint32_t pk[8]) {
+  int out[9];
+#pragma unroll
+  for (int m = 0; m < 5; m++) {
+    int e = sp_dot2_from(pa[m], ta[0], off_a);
+#pragma unroll
+    for (int i = 1; i < 4; i++) e = sp_dot2(pa[m + i], ta[i], e);
+    out[2 * m] = e;
+    if (m < 4) {
+      int o = sp_dot2_from(pa[m], ta[5], off_a);
+#pragma unroll
+      for (int i = 1; i < 5; i++) o = sp_dot2(pa[m + i], ta[5 + i], o);
+      out[2 * m + 1] = o;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 8; j++) pk[j] = sp_pack_hi(out[j], out[j + 1]);
+}
+// one tap each, at index 3: output j reads stored row j + q + 3 - pair m + 1 (q = 0) or
+// m + 2 (q = 1) for the even outputs (the other set's tap pair is zero), pair m + 2 for the
+// odd ones
+__device__ __forceinline__ void sp_pred_ident(const uint32_t pa[8], const uint32_t pb[8],
+                                              const uint32_t *ta, const uint32_t *tb, int off_a,
+                                              int off_b, uint32_t pk[8]) {
+#pragma unroll
+  for (int m = 0; m < 4; m++) {
+    const int ea = sp_dot2(pa[m + 2], ta[2], sp_dot2_from(pa[m + 1], ta[1], off_a));
+    const int eb = sp_dot2(pb[m + 2], tb[2], sp_dot2_from(pb[m + 1], tb[1], off_b));
+    const int oa = sp_dot2_from(pa[m + 2], ta[7], off_a);
+    const int ob = sp_dot2_from(pb[m + 2], tb[7], off_b);
+    pk[2 * m] = sp_pack_hi(ea, eb);
+    pk[2 * m + 1] = sp_pack_hi(oa, ob);
+  }
+}
+
 template <int TW, int TH>
-__device__ __forceinline__ void sp_satd_pairs_t(const int16_t *lds, const SpCand *cand,
+__device__ __forceinline__ void sp_satd_units_t(const int16_t *lds, const SpCand *cand,
+                                                const SpUnit *units, int nunits,
                                                 const uint16_t *origc, uint32_t *dist,
-                                                int bd, int w, int h, int ncand, int tid,
-                                                int nthr) {
+                                                int bd, int w, int h, int tid, int nthr) {
   static_assert((TW == 8 && TH == 8) || (TW == 16 && TH == 8) || (TW == 8 && TH == 16), "tile");
   constexpr int LT = TW == 16 ? 4 : 3;          // stages across lanes
   constexpr int HF = TH == 16 ? 1 : 2;          // of which formed as values
   constexpr bool MAG = LT - HF == 2;            // one magnitude-only stage before the fold
   const int lane = threadIdx.x & 63;
   const int rs = h + 8;
-  const int tiles_x = w / TW;
-  const int upp = (w * h) / TH;                 // units (tile columns) per pair
-  const int npairs = (ncand + 1) >> 1;
-  const int total = upp * npairs;
+  const int tiles_x = w / TW, ltx = 31 - __clz(tiles_x);
+  const int upp = (w * h) / TH, lupp = 31 - __clz(upp);   // lanes (tile columns) per unit
+  const int total = upp * nunits;
   const uint32_t smax2 = (uint32_t)((1 << bd) - 1) * 0x10001u;
   for (int g0 = tid & ~63; g0 < total; g0 += nthr) {   // whole waves stay in step
     const int g = g0 + lane;
     const bool active = g < total;
     const int gg = active ? g : 0;
-    const int pr = gg / upp, u = gg - pr * upp;
+    const int un = gg >> lupp, u = gg & (upp - 1);
     const int tile = u / TW, col = u & (TW - 1);
-    const int tx = tile % tiles_x, ty = tile / tiles_x;
+    const int tx = tile & (tiles_x - 1), ty = tile >> ltx;
     const int x = tx * TW + col;
-    const int ca = 2 * pr, cb = (2 * pr + 1 < ncand) ? 2 * pr + 1 : 2 * pr;
+    // round trip 1: the unit's record; round trip 2: the two plane columns and the originals
+    const uint4 *up = reinterpret_cast<const uint4 *>(units + un);
+    const uint4 h0 = up[0], h1 = up[1];
+    uint32_t ta[12], tb[12];
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+      const uint4 va = up[2 + i], vb = up[5 + i];
+      ta[4 * i] = va.x; ta[4 * i + 1] = va.y; ta[4 * i + 2] = va.z; ta[4 * i + 3] = va.w;
+      tb[4 * i] = vb.x; tb[4 * i + 1] = vb.y; tb[4 * i + 2] = vb.z; tb[4 * i + 3] = vb.w;
+    }
+    const int ca = (int)h0.x, cb = (int)h0.y, kind = (int)h0.z;
+    const int plane_a = (int)h1.x, plane_b = (int)h1.y, off_a = (int)h1.z, off_b = (int)h1.w;
     const int col_off = x * rs + ty * TH;
     uint32_t m[TH];
 #pragma unroll
     for (int r8 = 0; r8 < TH / 8; r8++) {
-      int va[8], vb[8];
-      sp_vfilter8(lds, cand[ca], col_off + 8 * r8, va);
-      // an odd candidate count leaves the last sweep with one candidate in both
-      // halves (the half-pel pass has nine): filter it once (wave-uniform test)
-      if (__builtin_amdgcn_ballot_w64(active && cb != ca) != 0) {
-        sp_vfilter8(lds, cand[cb], col_off + 8 * r8, vb);
-      } else {
-#pragma unroll
-        for (int j = 0; j < 8; j++) vb[j] = va[j];
-      }
-      // 8 originals of the column, each replicated into both halves
+      uint32_t pa[8], pb[8], pk[8];
+      sp_load_col(lds, plane_a + col_off + 8 * r8, pa);
+      sp_load_col(lds, plane_b + col_off + 8 * r8, pb);
       const uint4 o4 = *reinterpret_cast<const uint4 *>(origc + x * h + ty * TH + 8 * r8);
-      const uint32_t ow[4] = {o4.x, o4.y, o4.z, o4.w};
+      if (kind == SP_ROWSHARED) sp_pred_rowshared(pa, ta, off_a, pk);
+      else if (kind == SP_IDENT) sp_pred_ident(pa, pb, ta, tb, off_a, off_b, pk);
+      else sp_pred_generic(pa, pb, ta, tb, off_a, off_b, pk);
+      const uint32_t ow[4] = {o4.x, o4.y, o4.z, o4.w};   // 8 originals of the column
 #pragma unroll
       for (int j = 0; j < 8; j++) {
-        const uint32_t ov = __builtin_amdgcn_perm(ow[j >> 1], ow[j >> 1],
-                                                  (j & 1) ? 0x03020302u : 0x01000100u);
-        // narrow to int16 (pack keeps the low halves), clip to [0, smax]
-        sp_v2s pk;
-        pk.x = (short)va[j];
-        pk.y = (short)vb[j];
-        pk = __builtin_elementwise_min(__builtin_elementwise_max(pk, sp_s2(0u)), sp_s2(smax2));
-        m[8 * r8 + j] = sp_u(sp_s2(ov) - pk);
+        // clip to [0, smax], residual of both candidates
+        const sp_v2s c2 = __builtin_elementwise_min(
+            __builtin_elementwise_max(sp_s2(pk[j]), sp_s2(0u)), sp_s2(smax2));
+        m[8 * r8 + j] = (j & 1) ? sp_pk_sub_hi(ow[j >> 1], sp_u(c2)) : sp_pk_sub_lo(ow[j >> 1], sp_u(c2));
       }
     }
     // vertical WHT (down the column) in registers
@@ -312,13 +466,14 @@ __device__ __forceinline__ void sp_satd_pairs_t(const int16_t *lds, const SpCand
   }
 }
 
-__device__ __forceinline__ void sp_satd_pairs(const int16_t *lds, const SpCand *cand,
+__device__ __forceinline__ void sp_satd_units(const int16_t *lds, const SpCand *cand,
+                                              const SpUnit *units, int nunits,
                                               const uint16_t *origc, uint32_t *dist,
-                                              int bd, int w, int h, int ncand,
+                                              int bd, int w, int h,
                                               int tid = threadIdx.x & 63, int nthr = 64) {
-  if (w == h) sp_satd_pairs_t<8, 8>(lds, cand, origc, dist, bd, w, h, ncand, tid, nthr);
-  else if (w > h) sp_satd_pairs_t<16, 8>(lds, cand, origc, dist, bd, w, h, ncand, tid, nthr);
-  else sp_satd_pairs_t<8, 16>(lds, cand, origc, dist, bd, w, h, ncand, tid, nthr);
+  if (w == h) sp_satd_units_t<8, 8>(lds, cand, units, nunits, origc, dist, bd, w, h, tid, nthr);
+  else if (w > h) sp_satd_units_t<16, 8>(lds, cand, units, nunits, origc, dist, bd, w, h, tid, nthr);
+  else sp_satd_units_t<8, 16>(lds, cand, units, nunits, origc, dist, bd, w, h, tid, nthr);
 }
 
 #endif  // XVCGPU_K_SUBPEL_H_

@@ -850,7 +850,7 @@ xvcgpu_status xvcgpu_me_search_sized(xvcgpu_ctx *ctx, const xvcgpu_picture *orig
 xvcgpu_status xvcgpu_debug_me_trace(unsigned long long *out, int n_jobs) {
   hipDeviceSynchronize();
   return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_me2_trace),
-                             sizeof(unsigned long long) * 16 * (size_t)n_jobs) == hipSuccess
+                             sizeof(unsigned long long) * 24 * (size_t)n_jobs) == hipSuccess
              ? XVCGPU_OK
              : XVCGPU_DEVICE_ERROR;
 }
