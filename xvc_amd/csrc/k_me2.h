@@ -168,7 +168,8 @@ struct __attribute__((aligned(16))) Me2SharedT {
   // H-only prediction is derived from the 14-bit value, see me2_honly_taps.
   // (a slot is two columns wider than the block: the half-pel pass's x phase 8 is needed from
   // one column to the left AND from the block's own column - one plane of w + 2 columns)
-  int16_t hint[3][SUB ? (MS + 8) * (MS + 2) : 8];
+  // slot k holds x phase 4 k (the phases of a search are multiples of a quarter pel)
+  int16_t hint[4][SUB ? (MS + 8) * (MS + 2) : 8];
   uint32_t cost[128];
   // per sub-pel candidate: plane offset (int16 units from `orig`), stride,
   // rounding offset, shift, 8 taps
@@ -177,10 +178,7 @@ struct __attribute__((aligned(16))) Me2SharedT {
       int cand_plane[12], cand_stride[12], cand_off[12], cand_shift[12];
       int16_t cand_taps[12][8];
     };
-    struct {                                // fast path (k_subpel.h)
-      SpCand sp[SUB ? 10 : 1];
-      SpUnit un[SUB ? SP_MAX_UNITS : 1];
-    };
+    uint32_t rec[SUB ? 10 * SP_REC : 4];    // fast path (k_subpel.h): a record per candidate
   };
   uint32_t dist[12];
   int dsum[12];                             // AC-only: sum(orig - pred) per candidate
@@ -234,6 +232,32 @@ __device__ __forceinline__ void me2_quad_load(const MeCtx &c, const uint16_t *s_
   }
 }
 
+// SAD of the candidate at packed position pk against this lane's segments, summed over the
+// quad (valid in all four lanes).  pk == ME2_NOPOS: nothing is read, 0.
+template <int SPL>
+__device__ __forceinline__ uint32_t me2_quad_sad(const MeCtx &c, const Me2Quad<SPL> &qd,
+                                                 const char *base, uint32_t pk) {
+  uint32_t sum = 0;
+  if (pk != ME2_NOPOS) {  // uniform within the quad
+    const int x = (int)(int16_t)(pk & 0xffffu), y = (int)pk >> 16;
+    const uint32_t vo = me2_pos_off(c, x, y);
+    U16x8 b[SPL];
+#pragma unroll
+    for (int u = 0; u < SPL; u++)
+      b[u] = *reinterpret_cast<const U16x8 *>(base + (size_t)(vo + qd.goff[u]));
+#pragma unroll
+    for (int u = 0; u < SPL; u++) {
+      sum = __builtin_amdgcn_sad_u16(qd.a[u].x, b[u].v[0], sum);
+      sum = __builtin_amdgcn_sad_u16(qd.a[u].y, b[u].v[1], sum);
+      sum = __builtin_amdgcn_sad_u16(qd.a[u].z, b[u].v[2], sum);
+      sum = __builtin_amdgcn_sad_u16(qd.a[u].w, b[u].v[3], sum);
+    }
+  }
+  sum += (uint32_t)lane_xor<1>((int)sum);
+  sum += (uint32_t)lane_xor<2>((int)sum);
+  return (sum * c.sad_mul) >> c.sad_shift;
+}
+
 template <int SPL>  // segments per lane, original segments kept in registers
 __device__ __forceinline__ void me2_eval_quads_reg(const MeCtx &c, uint32_t *cost,
                                                    const Me2Quad<SPL> &qd, int n) {
@@ -243,23 +267,8 @@ __device__ __forceinline__ void me2_eval_quads_reg(const MeCtx &c, uint32_t *cos
     const int i = i0 + qi;
     const uint32_t pk = i < n ? cost[i] : ME2_NOPOS;
     if (pk == ME2_NOPOS) continue;  // uniform within the quad
-    const int x = (int)(int16_t)(pk & 0xffffu), y = (int)pk >> 16;
-    const uint32_t vo = me2_pos_off(c, x, y);
-    U16x8 b[SPL];
-#pragma unroll
-    for (int u = 0; u < SPL; u++)
-      b[u] = *reinterpret_cast<const U16x8 *>(base + (size_t)(vo + qd.goff[u]));
-    uint32_t sum = 0;
-#pragma unroll
-    for (int u = 0; u < SPL; u++) {
-      sum = __builtin_amdgcn_sad_u16(qd.a[u].x, b[u].v[0], sum);
-      sum = __builtin_amdgcn_sad_u16(qd.a[u].y, b[u].v[1], sum);
-      sum = __builtin_amdgcn_sad_u16(qd.a[u].z, b[u].v[2], sum);
-      sum = __builtin_amdgcn_sad_u16(qd.a[u].w, b[u].v[3], sum);
-    }
-    sum += (uint32_t)lane_xor<1>((int)sum);
-    sum += (uint32_t)lane_xor<2>((int)sum);
-    if (q == 0) cost[i] = (sum * c.sad_mul) >> c.sad_shift;
+    const uint32_t sad = me2_quad_sad<SPL>(c, qd, base, pk);
+    if (q == 0) cost[i] = sad;
   }
 }
 
@@ -679,23 +688,27 @@ __device__ __forceinline__ bool me2_subpel_fast(int w, int h, int bd, bool ac = 
   return w >= 8 && h >= 8 && bd <= 10 && !ac;   // AC-only SATD: the 32-bit path
 }
 
-// The x-phase planes a pass leaves in the three slots for the next one (fx < 0: none):
-// plane k holds x phase fx[k] for nc[k] columns from picture column pel0[k] on.
-struct SpSlots {
-  int fx[3], pel0[3], nc[3];
-};
 #define ME2_SLOT(MS) ((MS + 8) * (MS + 2))   // int16 entries of a plane slot
+
+// Order in which a pass's candidates are stored for the sweep (k_subpel.h takes them two at
+// a time): the pairs above / below a position first - (-1,-+1), (+1,-+1), (0,-+1) in units
+// of the pass's step -, then left / right of the centre, then (half-pel pass) the centre.
+// Entry = index in issue order (kSubpelOff with the pass's skip of the centre).
+__constant__ int8_t kSubpelOrder[2][9] = {{5, 7, 6, 8, 1, 2, 3, 4, 0}, {2, 6, 3, 7, 0, 1, 4, 5, 0}};
 
 // Fast path of a sub-pel pass (k_subpel.h; both sides >= 8, bd <= 10, plain SATD), by one
 // wave (NW = 1) or a team of NW waves: s.orig is column-major, the window is staged.
 // Raw tile sums of the n = 9 - pass candidates (pass < 0: of the single MV
-// (base_x, base_y)) in s.dist[0..n).  Arguments wave-uniform.
+// (base_x, base_y)) in s.dist[i], i = the candidate's place in kSubpelOrder; returns
+// this lane's candidate in issue order (lanes >= n: 64).  Arguments wave-uniform.
+// held: what the four plane slots hold, a byte per slot (0x80 built, 1 from column -1 on,
+// 2 two columns wider than the block), carried from pass to pass.
 template <int MS, int NW>
-__device__ __forceinline__ void me2_subpel_fast_pass(Me2Shared<MS> &s, const MeCtx &c,
-                                                     const xvcgpu_me_block &b, int pic_w,
-                                                     int pic_h, int fpx, int fpy, int pass,
-                                                     int base_x, int base_y, SpSlots &held
-                                                     ME2_CLK_ARG) {
+__device__ __forceinline__ int me2_subpel_fast_pass(Me2Shared<MS> &s, const MeCtx &c,
+                                                    const xvcgpu_me_block &b, int pic_w,
+                                                    int pic_h, int fpx, int fpy, int pass,
+                                                    int base_x, int base_y, uint32_t &held
+                                                    ME2_CLK_ARG) {
   const int w = c.w, h = c.h, bd = c.bd;
   const int lane = ME2_LANE;
   const int tid = NW == 1 ? lane : (int)threadIdx.x;
@@ -705,92 +718,74 @@ __device__ __forceinline__ void me2_subpel_fast_pass(Me2Shared<MS> &s, const MeC
     else __syncthreads();
   };
   const int n = pass < 0 ? 1 : 9 - pass;
+  const bool need = lane < n;
   // this lane's candidate (lanes >= n idle; every wave of a team computes the same)
+  const int oi = (pass >= 0 && need) ? kSubpelOrder[pass][lane] : 0;
   int mx = base_x, my = base_y;
-  if (pass >= 0 && lane < n) me2_subpel_mv(pass, lane, base_x, base_y, mx, my);
+  if (pass >= 0 && need) me2_subpel_mv(pass, oi, base_x, base_y, mx, my);
   d_clip_mv(b.x, b.y, pic_w, pic_h, mx, my);  // MotionCompensationMv, :749
   const int cpx = (mx >> 4) - fpx, cpy = (my >> 4) - fpy;   // -1 or 0 each
   const int cfx = mx & 15, cfy = my & 15;
-  const bool need = lane < n;
-  // the distinct x phases (<= 3) and the columns each is needed from
-  int gfx[3] = {-1, -1, -1}, gpel[3] = {0, 0, 0}, gnc[3] = {0, 0, 0}, gslot[3] = {-1, -1, -1};
-  int mygroup = 0;
-  {
-    unsigned long long rem = __ballot(need);
+  const int myslot = cfx >> 2;
+  // per x phase in use: a plane of an earlier pass that covers the columns wanted is read
+  // again, otherwise the slot is (re)built
+  int build = 0;
 #pragma unroll
-    for (int k = 0; k < 3; k++) {
-      if (rem) {
-        const int leader = __ffsll((long long)rem) - 1;
-        const int fxg = __builtin_amdgcn_readlane(cfx, leader);
-        const bool mem = need && cfx == fxg;
-        rem &= ~__ballot(mem);
-        const int lo = (__ballot(mem && cpx < 0) != 0) ? -1 : 0;
-        const bool both = lo < 0 && __ballot(mem && cpx >= 0) != 0;
-        gfx[k] = fxg; gpel[k] = lo; gnc[k] = both ? w + 2 : w;
-        if (mem) mygroup = k;
+  for (int k = 0; k < 4; k++) {
+    const bool mem = need && myslot == k;
+    if (__ballot(mem) != 0) {
+      const uint32_t m1 = __ballot(mem && cpx < 0) != 0 ? 1u : 0u;
+      const uint32_t both = (m1 && __ballot(mem && cpx >= 0) != 0) ? 2u : 0u;
+      const uint32_t st = (held >> (8 * k)) & 0xffu;
+      const bool reuse = (st & 0x80u) && ((st & 2u) || (!both && (st & 1u) == m1));
+      if (!reuse) {
+        build |= 1 << k;
+        held = (held & ~(0xffu << (8 * k))) | ((0x80u | m1 | both) << (8 * k));
       }
     }
   }
-  // a plane of the previous pass that covers a group is read again, the others are built
-  // (slot sets as bit masks: small arrays indexed by a computed slot end up in scratch)
-  int used = 0, build = 0;
-#pragma unroll
-  for (int g = 0; g < 3; g++) {
-    const int hi = gpel[g] + (gnc[g] > w ? w + 1 : w);
-#pragma unroll
-    for (int j = 0; j < 3; j++)
-      if (gfx[g] >= 0 && gslot[g] < 0 && !(used & (1 << j)) && held.fx[j] == gfx[g] &&
-          held.pel0[j] <= gpel[g] && held.pel0[j] + held.nc[j] >= hi) {
-        gslot[g] = j;
-        used |= 1 << j;
-      }
-  }
-#pragma unroll
-  for (int g = 0; g < 3; g++) {
-    if (gfx[g] >= 0 && gslot[g] < 0) {
-      const int j = !(used & 1) ? 0 : (!(used & 2) ? 1 : 2);
-      gslot[g] = j;
-      used |= 1 << j;
-      build |= 1 << j;
-#pragma unroll
-      for (int k = 0; k < 3; k++)
-        if (k == j) { held.fx[k] = gfx[g]; held.pel0[k] = gpel[g]; held.nc[k] = gnc[g]; }
-    }
-  }
-#pragma unroll
-  for (int j = 0; j < 3; j++)
-    if (!(used & (1 << j))) held.fx[j] = -1;   // (overwritten or not: no longer tracked)
-  sync();  // previous readers of the planes / tables are done
+  sync();  // previous readers of the planes / records are done
   ME2_CLK(0);   // candidates, plane slots
-#pragma unroll
-  for (int j = 0; j < 3; j++)
-    if (build & (1 << j))
-      sp_build_planes(s.win, s.hint[j], s.taps, bd, w, h, held.pel0[j], held.fx[j], held.nc[j],
-                      tid, 64 * NW);
-  ME2_CLK(1);   // planes
   if (tid < n) {
     const int16_t *base = reinterpret_cast<const int16_t *>(s.orig);
-    SpCand &cd = s.sp[lane];
-    const int slot = mygroup == 0 ? gslot[0] : (mygroup == 1 ? gslot[1] : gslot[2]);
-    const int pel0 = slot == 0 ? held.pel0[0] : (slot == 1 ? held.pel0[1] : held.pel0[2]);
+    const int pel0 = ((held >> (8 * myslot)) & 1u) ? -1 : 0;
     const bool honly = cfx != 0 && cfy == 0, two_stage = cfx != 0 && cfy != 0;
     const int sh = 20 - bd;   // FilterVerShortSample's shift
-    cd.plane = (int)(s.hint[0] - base) + slot * ME2_SLOT(MS) + (cpx - pel0) * (h + 8);
+    SpCand cd;
+    cd.plane = (int)(s.hint[0] - base) + myslot * ME2_SLOT(MS) + (cpx - pel0) * (h + 8);
     cd.off = two_stage ? ((8192 << 6) + (1 << (sh - 1))) << (16 - sh)
                        : me2_honly_off(bd, cfx) << 10;
     sp_fill_taps(cd, s.taps, me2_vtaps_row(cfx, cfy), cpy + 1,
                  cfx == 0 ? 6 : (honly ? 10 : bd - 4));
-    cd.ident = cfy == 0;
+    // what this candidate shares with the next one (the even lanes' records say)
+    const int mine = (cfy << 4) | ((cpy + 1) << 1) | (cfy == 0 ? 1 : 0);
+    const int o_mine = __builtin_amdgcn_update_dpp(0, mine, 0xB1, 0xF, 0xF, false);
+    const int o_plane = __builtin_amdgcn_update_dpp(0, cd.plane, 0xB1, 0xF, 0xF, false);
+    const int o_off = __builtin_amdgcn_update_dpp(0, cd.off, 0xB1, 0xF, 0xF, false);
+    int kind = SP_GENERIC;
+    if (lane + 1 >= n) kind = (mine & 1) ? SP_IDENT : SP_GENERIC;   // the pair is this candidate twice
+    else if ((mine & 1) && (o_mine & 1)) kind = SP_IDENT;
+    else if (!((mine | o_mine) & 1) && o_plane == cd.plane && o_off == cd.off &&
+             (mine >> 4) == (o_mine >> 4) && (mine & 2) == 0 && (o_mine & 2) != 0)
+      kind = SP_ROWSHARED;
+    sp_store_cand(s.rec + lane * SP_REC, cd, kind);
     s.dist[lane] = 0;
   }
+  ME2_CLK(2);   // candidate records
+#pragma unroll 1
+  for (int k = 0; k < 4; k++)
+    if (build & (1 << k)) {
+      const uint32_t st = (held >> (8 * k)) & 0xffu;
+      sp_build_planes(s.win, s.hint[0] + k * ME2_SLOT(MS), s.taps, bd, w, h, (st & 1u) ? -1 : 0,
+                      4 * k, (st & 2u) ? w + 2 : w, tid, 64 * NW);
+    }
   sync();
-  const int nunits = sp_make_units(s.sp, s.un, pass, tid);
-  sync();
-  ME2_CLK(2);   // candidate and unit records
-  sp_satd_units(reinterpret_cast<const int16_t *>(s.orig), s.sp, s.un, nunits, s.orig, s.dist, bd,
-                w, h, tid, 64 * NW);
+  ME2_CLK(1);   // planes
+  sp_satd_pairs(reinterpret_cast<const int16_t *>(s.orig), s.rec, n, s.orig, s.dist, bd, w, h,
+                tid, 64 * NW);
   sync();
   ME2_CLK(3);   // the sweep
+  return need ? oi : 64;
 }
 
 // Evaluate the SATD of the n = 9 - pass candidates of a sub-pel pass (or, with
@@ -1042,7 +1037,8 @@ me_search_wave_body(const PicView &orig, const PicView &ref,
     TzState st;
     st.bx = 0; st.by = 0; st.cost = 0xffffffffu; st.last_pos = 0; st.last_range = 0;
     Me2Quad<4> q16;
-    if (!LIC && c.w >= 8 && c.rows * (c.w >> 3) == 16) {
+    const bool use_q16 = !LIC && c.w >= 8 && c.rows * (c.w >> 3) == 16;
+    if (use_q16) {
       wave_sync();   // the staged original is visible
       me2_quad_load<4>(c, s.orig, q16);
     }
@@ -1054,23 +1050,35 @@ me_search_wave_body(const PicView &orig, const PicView &ref,
       int qx = b.prev_x * 16, qy = b.prev_y * 16;
       d_clip_mv(b.x, b.y, pic_w, pic_h, qx, qy);
       const int ax = px >> 4, ay = py >> 4, zx = qx >> 4, zy = qy >> 4;
-      wave_sync();
-      if (lane < 3)
-        s.cost[lane] = me2_pack_pos(lane == 0 ? ax : (lane == 1 ? 0 : zx),
-                                    lane == 0 ? ay : (lane == 1 ? 0 : zy));
-      wave_sync();
-      me2_eval_positions(c, s.cost, s.orig, 3, q16);
-      wave_sync();
-      if (lane < 3) {
-        const int px_ = lane == 0 ? ax : (lane == 1 ? 0 : zx);
-        const int py_ = lane == 0 ? ay : (lane == 1 ? 0 : zy);
-        s.cost[lane] = me_cost(c, s.cost[lane], px_, py_);
+      uint32_t c0, c1, c2;
+      if (use_q16) {
+        // quads 0..2 take a candidate each: no LDS at all
+        const int qi = lane >> 2;
+        const int px_ = qi == 0 ? ax : (qi == 1 ? 0 : zx), py_ = qi == 0 ? ay : (qi == 1 ? 0 : zy);
+        const uint32_t pk = qi < 3 ? me2_pack_pos(px_, py_) : ME2_NOPOS;
+        const uint32_t cc = me_cost(c, me2_quad_sad<4>(c, q16, me2_ref_base(c), pk), px_, py_);
+        c0 = (uint32_t)__builtin_amdgcn_readlane((int)cc, 0);
+        c1 = (uint32_t)__builtin_amdgcn_readlane((int)cc, 4);
+        c2 = (uint32_t)__builtin_amdgcn_readlane((int)cc, 8);
+      } else {
+        wave_sync();
+        if (lane < 3)
+          s.cost[lane] = me2_pack_pos(lane == 0 ? ax : (lane == 1 ? 0 : zx),
+                                      lane == 0 ? ay : (lane == 1 ? 0 : zy));
+        wave_sync();
+        me2_eval_positions(c, s.cost, s.orig, 3, q16);
+        wave_sync();
+        if (lane < 3) {
+          const int px_ = lane == 0 ? ax : (lane == 1 ? 0 : zx);
+          const int py_ = lane == 0 ? ay : (lane == 1 ? 0 : zy);
+          s.cost[lane] = me_cost(c, s.cost[lane], px_, py_);
+        }
+        wave_sync();
+        // (the same in every lane: said so, the search state and the loops it steers stay scalar)
+        c0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)s.cost[0]);
+        c1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)s.cost[1]);
+        c2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)s.cost[2]);
       }
-      wave_sync();
-      // (the same in every lane: said so, the search state and the loops it steers stay scalar)
-      const uint32_t c0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)s.cost[0]);
-      const uint32_t c1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)s.cost[1]);
-      const uint32_t c2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)s.cost[2]);
       st.cost = c0; st.bx = ax; st.by = ay;
       bool change = false;
       if (st.bx != 0 || st.by != 0) {
@@ -1150,23 +1158,30 @@ me_search_wave_body(const PicView &orig, const PicView &ref,
       ME2_COUNT(3, 1);
       const bool v0 = tz_inside(c, d1[0], x[0], y[0]) && (d2[0] == 0 || tz_inside(c, d2[0], x[0], y[0]));
       const bool v1 = tz_inside(c, d1[1], x[1], y[1]) && (d2[1] == 0 || tz_inside(c, d2[1], x[1], y[1]));
-      wave_sync();
-      if (lane == 0) s.cost[0] = v0 ? me2_pack_pos(x[0], y[0]) : ME2_NOPOS;
-      if (lane == 1) s.cost[1] = v1 ? me2_pack_pos(x[1], y[1]) : ME2_NOPOS;
-      wave_sync();
-      me2_eval_positions(c, s.cost, s.orig, 2, q16);
-      wave_sync();
-      if (lane == 0 && v0) s.cost[0] = me_cost(c, s.cost[0], x[0], y[0]);
-      if (lane == 1 && v1) s.cost[1] = me_cost(c, s.cost[1], x[1], y[1]);
-      wave_sync();
-      if (v0) {
-        const uint32_t cc = (uint32_t)__builtin_amdgcn_readfirstlane((int)s.cost[0]);
-        if (cc < st.cost) { st.cost = cc; st.bx = x[0]; st.by = y[0]; st.last_pos = d1[0] + d2[0]; st.last_range = r; }
+      uint32_t n0, n1;
+      if (use_q16) {
+        const int qi = lane >> 2;
+        const bool mine = qi == 0 ? v0 : (qi == 1 ? v1 : false);
+        const int nx = qi == 0 ? x[0] : x[1], ny = qi == 0 ? y[0] : y[1];
+        const uint32_t pk = mine ? me2_pack_pos(nx, ny) : ME2_NOPOS;
+        const uint32_t cc = me_cost(c, me2_quad_sad<4>(c, q16, me2_ref_base(c), pk), nx, ny);
+        n0 = (uint32_t)__builtin_amdgcn_readlane((int)cc, 0);
+        n1 = (uint32_t)__builtin_amdgcn_readlane((int)cc, 4);
+      } else {
+        wave_sync();
+        if (lane == 0) s.cost[0] = v0 ? me2_pack_pos(x[0], y[0]) : ME2_NOPOS;
+        if (lane == 1) s.cost[1] = v1 ? me2_pack_pos(x[1], y[1]) : ME2_NOPOS;
+        wave_sync();
+        me2_eval_positions(c, s.cost, s.orig, 2, q16);
+        wave_sync();
+        if (lane == 0 && v0) s.cost[0] = me_cost(c, s.cost[0], x[0], y[0]);
+        if (lane == 1 && v1) s.cost[1] = me_cost(c, s.cost[1], x[1], y[1]);
+        wave_sync();
+        n0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)s.cost[0]);
+        n1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)s.cost[1]);
       }
-      if (v1) {
-        const uint32_t cc = (uint32_t)__builtin_amdgcn_readfirstlane((int)s.cost[1]);
-        if (cc < st.cost) { st.cost = cc; st.bx = x[1]; st.by = y[1]; st.last_pos = d1[1] + d2[1]; st.last_range = r; }
-      }
+      if (v0 && n0 < st.cost) { st.cost = n0; st.bx = x[0]; st.by = y[0]; st.last_pos = d1[0] + d2[0]; st.last_range = r; }
+      if (v1 && n1 < st.cost) { st.cost = n1; st.bx = x[1]; st.by = y[1]; st.last_pos = d1[1] + d2[1]; st.last_range = r; }
     };
     ME2_TRACE(3);  // raster
     if (st.last_range == 1) { st.last_range = 0; neighbor(); }
@@ -1323,35 +1338,36 @@ me_search_wave_body(const PicView &orig, const PicView &ref,
     // one loop for the single-MV form (pass -1) and the two passes: the sweep is inlined once
     const bool fastp = me2_subpel_fast(w, h, c.bd, c.ac);
     const bool single = (b.fullpel_mv & XVC_ME_FULLPEL_MV) != 0;
-    SpSlots held = {{-1, -1, -1}, {0, 0, 0}, {0, 0, 0}};   // planes a pass leaves for the next one
+    uint32_t held = 0;   // plane slots a pass leaves for the next one
     uint32_t best_cost = 0xffffffffu, best_dist = 0xffffffffu;
     int best_x = res.mv_x, best_y = res.mv_y;
     for (int pass = single ? -1 : 0; pass < (single ? 0 : 2); pass++) {
       const int base_x = best_x, base_y = best_y;
       const int n = pass < 0 ? 1 : 9 - pass;
+      int oi = lane < n ? lane : 64;   // this lane's candidate, in issue order
       if (fastp)
-        me2_subpel_fast_pass<MS, 1>(s, c, b, pic_w, pic_h, fpx, fpy, pass, base_x, base_y,
-                                    held ME2_CLK_PASS);
+        oi = me2_subpel_fast_pass<MS, 1>(s, c, b, pic_w, pic_h, fpx, fpy, pass, base_x, base_y,
+                                         held ME2_CLK_PASS);
       else me2_subpel_eval(s, c, b, pic_w, pic_h, fpx, fpy, pass, base_x, base_y);
       if (pass < 0) {
         best_dist = s.dist[0] >> (c.bd - 8);
         break;
       }
-      // the reference's ordered strict-< fold = (lowest cost, lowest index),
+      // the reference's ordered strict-< fold = (lowest cost, lowest index in issue order),
       // one candidate per lane
-      uint32_t my_cost = 0xffffffffu;
+      uint32_t my_cost = 0xffffffffu, my_dist = 0;
       if (lane < n) {
         int mx, my;
-        me2_subpel_mv(pass, lane, base_x, base_y, mx, my);
-        my_cost = (s.dist[lane] >> (c.bd - 8)) +
-                  ((c.lambda * d_mvd_bits(b.mvp_x, b.mvp_y, mx, my, 0)) >> 16);
+        me2_subpel_mv(pass, oi, base_x, base_y, mx, my);
+        my_dist = s.dist[lane] >> (c.bd - 8);
+        my_cost = my_dist + ((c.lambda * d_mvd_bits(b.mvp_x, b.mvp_y, mx, my, 0)) >> 16);
       }
       const uint32_t gmin = wave_min_key(my_cost);
-      const int gi = (int)wave_min_key(my_cost == gmin ? (uint32_t)lane : 64u);
+      const uint32_t gk = wave_min_key(my_cost == gmin ? ((uint32_t)oi << 8) | (uint32_t)lane : 0xffffu);
       if (gmin < best_cost) {
         best_cost = gmin;
-        best_dist = s.dist[gi] >> (c.bd - 8);
-        me2_subpel_mv(pass, gi, base_x, base_y, best_x, best_y);
+        best_dist = (uint32_t)__builtin_amdgcn_readlane((int)my_dist, (int)(gk & 63u));
+        me2_subpel_mv(pass, (int)(gk >> 8), base_x, base_y, best_x, best_y);
       }
     }
     res.mv_x = best_x;
@@ -1475,7 +1491,7 @@ me_subpel_team_body(const PicView &orig, const PicView &ref, const xvcgpu_me_blo
       *reinterpret_cast<uint4 *>(s.win + r * ws + ch * 8) = make_uint4(v.v[0], v.v[1], v.v[2], v.v[3]);
     }
   }
-  SpSlots held = {{-1, -1, -1}, {0, 0, 0}, {0, 0, 0}};
+  uint32_t held = 0;
   ME2_COUNT_DECL;
   if (b.fullpel_mv & XVC_ME_FULLPEL_MV) {
     me2_subpel_fast_pass<MS, NW>(s, c, b, pic_w, pic_h, fpx, fpy, -1, res.mv_x, res.mv_y,
@@ -1487,21 +1503,21 @@ me_subpel_team_body(const PicView &orig, const PicView &ref, const xvcgpu_me_blo
     for (int pass = 0; pass < 2; pass++) {
       const int base_x = best_x, base_y = best_y;
       const int nc = 9 - pass;
-      me2_subpel_fast_pass<MS, NW>(s, c, b, pic_w, pic_h, fpx, fpy, pass, base_x, base_y,
-                                   held ME2_CLK_PASS);
-      uint32_t my_cost = 0xffffffffu;
+      const int oi = me2_subpel_fast_pass<MS, NW>(s, c, b, pic_w, pic_h, fpx, fpy, pass, base_x,
+                                                  base_y, held ME2_CLK_PASS);
+      uint32_t my_cost = 0xffffffffu, my_dist = 0;
       if (lane < nc) {
         int mx, my;
-        me2_subpel_mv(pass, lane, base_x, base_y, mx, my);
-        my_cost = (s.dist[lane] >> (c.bd - 8)) +
-                  ((c.lambda * d_mvd_bits(b.mvp_x, b.mvp_y, mx, my, 0)) >> 16);
+        me2_subpel_mv(pass, oi, base_x, base_y, mx, my);
+        my_dist = s.dist[lane] >> (c.bd - 8);
+        my_cost = my_dist + ((c.lambda * d_mvd_bits(b.mvp_x, b.mvp_y, mx, my, 0)) >> 16);
       }
       const uint32_t gmin = wave_min_key(my_cost);
-      const int gi = (int)wave_min_key(my_cost == gmin ? (uint32_t)lane : 64u);
+      const uint32_t gk = wave_min_key(my_cost == gmin ? ((uint32_t)oi << 8) | (uint32_t)lane : 0xffffu);
       if (gmin < best_cost) {
         best_cost = gmin;
-        best_dist = s.dist[gi] >> (c.bd - 8);
-        me2_subpel_mv(pass, gi, base_x, base_y, best_x, best_y);
+        best_dist = (uint32_t)__builtin_amdgcn_readlane((int)my_dist, (int)(gk & 63u));
+        me2_subpel_mv(pass, (int)(gk >> 8), base_x, base_y, best_x, best_y);
       }
     }
     res.mv_x = best_x;

@@ -16,7 +16,7 @@
 //     16-bit half: clip, residual and the Hadamard butterflies are v_pk_*;
 //     the vertical WHT is in registers, the horizontal one goes through
 //     ds_swizzle (LDS crossbar, no VALU);
-//   * the candidates of a pass are paired by what they share (sp_make_units):
+//   * the candidates of a pass are paired by what they share (kSubpelOrder, k_me2.h):
 //     the two half-pel candidates above / below a position are ONE filtered
 //     column read at two row offsets (9 outputs instead of 16), a candidate
 //     whose vertical phase is zero is one tap, not eight;
@@ -90,16 +90,22 @@ struct __attribute__((aligned(16))) SpCand {
   int pad[2];
 };
 
-// A unit of the sweep: two candidates (cb == ca: one) that share each lane, with all the
-// sweep needs of them in one record (a lane reads its unit's record in one round trip).
+// The sweep takes the candidates two at a time, (2 p, 2 p + 1) of the order their records
+// are stored in (me2_subpel_fast_pass stores them so that candidates which share work are
+// neighbours), and record 2 p says what the pair shares:
+//   SP_ROWSHARED: same column, same taps, rows one apart (the half-pel pass's
+//     above / below: one filtered column of nine outputs read at two offsets);
+//   SP_IDENT: both candidates' vertical phase is zero (one tap each);
+//   SP_GENERIC: two independent vertical filters.
+// A record is 12 dwords: e[0..4], o[0..4], off, plane | kind << 24.
 enum { SP_GENERIC = 0, SP_ROWSHARED = 1, SP_IDENT = 2 };
-struct __attribute__((aligned(16))) SpUnit {
-  int ca, cb, kind, pad;
-  int plane_a, plane_b, off_a, off_b;
-  uint32_t ta[12];   // candidate a: e[0..4], o[0..4]
-  uint32_t tb[12];   // candidate b
-};
-#define SP_MAX_UNITS 5
+#define SP_REC 12
+__device__ __forceinline__ void sp_store_cand(uint32_t *rec, const SpCand &c, int kind) {
+  uint4 *r = reinterpret_cast<uint4 *>(rec);
+  r[0] = make_uint4(c.e[0], c.e[1], c.e[2], c.e[3]);
+  r[1] = make_uint4(c.e[4], c.o[0], c.o[1], c.o[2]);
+  r[2] = make_uint4(c.o[3], c.o[4], (uint32_t)c.off, (uint32_t)c.plane | ((uint32_t)kind << 24));
+}
 
 // Column-major plane of one x-phase: p14 = FilterHorSampleShort (14 bit), or
 // the unfiltered samples << 4 when fx == 0; `ncols` (even) columns from picture
@@ -156,10 +162,43 @@ __device__ __forceinline__ void sp_build_planes(const uint16_t *win, int16_t *p1
   };
   {
     const int x0 = (tid & (hw - 1)) << 1;
-    const uint16_t *wrow = win + (tid >> lhw) * ws;
-    int16_t *dst = p14 + x0 * rs + (tid >> lhw);
-    for (int r = tid >> lhw; r < rs; r += rstep, wrow += rstep * ws, dst += rstep)
-      unit(wrow, x0, dst);
+    int r = tid >> lhw;
+    const uint16_t *wrow = win + r * ws;
+    int16_t *dst = p14 + x0 * rs + r;
+    if (fx != 0) {
+      // three rows per trip, their window reads issued together (a 16x16 block's plane is
+      // one trip of a wave)
+      const int cw = (x0 + pel_x + 5) >> 1;
+      for (; r + 2 * rstep < rs; r += 3 * rstep, wrow += 3 * rstep * ws, dst += 3 * rstep) {
+        uint32_t d[3][5];
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+          const uint32_t *dp = reinterpret_cast<const uint32_t *>(wrow + k * rstep * ws) + cw;
+#pragma unroll
+          for (int j = 0; j < 5; j++) d[k][j] = dp[j];
+        }
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+          int s0, s1;
+          if (!odd) {
+            s0 = sp_dot2_from(d[k][0], a0, offset); s0 = sp_dot2(d[k][1], a1, s0);
+            s0 = sp_dot2(d[k][2], a2, s0); s0 = sp_dot2(d[k][3], a3, s0);
+            s1 = sp_dot2_from(d[k][0], b0, offset); s1 = sp_dot2(d[k][1], b1, s1);
+            s1 = sp_dot2(d[k][2], b2, s1); s1 = sp_dot2(d[k][3], b3, s1);
+            s1 = sp_dot2(d[k][4], b4, s1);
+          } else {
+            s0 = sp_dot2_from(d[k][0], b0, offset); s0 = sp_dot2(d[k][1], b1, s0);
+            s0 = sp_dot2(d[k][2], b2, s0); s0 = sp_dot2(d[k][3], b3, s0);
+            s0 = sp_dot2(d[k][4], b4, s0);
+            s1 = sp_dot2_from(d[k][1], a0, offset); s1 = sp_dot2(d[k][2], a1, s1);
+            s1 = sp_dot2(d[k][3], a2, s1); s1 = sp_dot2(d[k][4], a3, s1);
+          }
+          dst[k * rstep] = (int16_t)(s0 >> shift);
+          dst[k * rstep + rs] = (int16_t)(s1 >> shift);
+        }
+      }
+    }
+    for (; r < rs; r += rstep, wrow += rstep * ws, dst += rstep) unit(wrow, x0, dst);
   }
   if (ncols > w)
     for (int r = tid; r < rs; r += nthr) unit(win + r * ws, w, p14 + w * rs + r);
@@ -189,51 +228,7 @@ __device__ __forceinline__ void sp_fill_taps(SpCand &c, const int16_t (*taps)[8]
   c.q = q;
 }
 
-// The units of a pass, by what its candidates share (lanes 0.. of a wave, `lane`
-// = unit index; cand[] filled and visible).  The 9 / 8 candidates of a pass are a
-// 3 x 3 square of offsets (dx, dy) in issue order (kSubpelOff, k_me2.h): the
-// candidates (dx, -1) and (dx, +1) have one x phase - one plane column -, the
-// candidates (-1, 0) and (+1, 0) one y phase.  pass -1: the one candidate.
-//   SP_ROWSHARED: same column, same taps, rows one apart (the half-pel pass's
-//     above / below: one filtered column of nine outputs read at two offsets);
-//   SP_IDENT: both candidates' vertical phase is zero (one tap each);
-//   SP_GENERIC: two independent vertical filters.
-__device__ __forceinline__ int sp_make_units(const SpCand *cand, SpUnit *units, int pass,
-                                             int lane) {
-  // candidate indices of (VP(-1), VP(+1), VP(0), HP, C)
-  const int nunits = pass < 0 ? 1 : (pass == 0 ? 5 : 4);
-  if (lane < nunits) {
-    int ca, cb;
-    bool vp;
-    if (pass < 0) { ca = cb = 0; vp = false; }
-    else if (pass == 0) {
-      ca = lane == 0 ? 5 : (lane == 1 ? 6 : (lane == 2 ? 1 : (lane == 3 ? 3 : 0)));
-      cb = lane == 0 ? 7 : (lane == 1 ? 8 : (lane == 2 ? 2 : (lane == 3 ? 4 : 0)));
-      vp = lane < 3;
-    } else {
-      ca = lane == 0 ? 2 : (lane == 1 ? 3 : (lane == 2 ? 0 : 4));
-      cb = lane == 0 ? 6 : (lane == 1 ? 7 : (lane == 2 ? 1 : 5));
-      vp = lane < 3;
-    }
-    const SpCand A = cand[ca], B = cand[cb];
-    int kind = SP_GENERIC;
-    if (A.ident && B.ident) kind = SP_IDENT;
-    else if (vp && !A.ident && A.plane == B.plane && A.q == 0 && B.q == 1 && A.off == B.off &&
-             A.e[0] == B.o[1] && A.e[1] == B.o[2] && A.e[2] == B.o[3] && A.e[3] == B.o[4])
-      kind = SP_ROWSHARED;
-    SpUnit &u = units[lane];
-    u.ca = ca; u.cb = cb; u.kind = kind; u.pad = 0;
-    u.plane_a = A.plane; u.plane_b = B.plane; u.off_a = A.off; u.off_b = B.off;
-#pragma unroll
-    for (int i = 0; i < 5; i++) {
-      u.ta[i] = A.e[i]; u.ta[5 + i] = A.o[i];
-      u.tb[i] = B.e[i]; u.tb[5 + i] = B.o[i];
-    }
-  }
-  return nunits;
-}
-
-// SATD of the candidates of `nunits` units (params in cand[]) against origc (the
+// SATD of `ncand` candidates (records in cand[]) against origc (the
 // original block, column-major, column stride h) with TW x TH tiles: 8x8 (square
 // blocks), 16x8 (w > h) or 8x16 (w < h), ComputeSatdNxM's choice for blocks
 // with both sides >= 8 (sample_metric.cc:403-641).  Adds the normalised tile
@@ -325,10 +320,10 @@ __device__ __forceinline__ void sp_pred_ident(const uint32_t pa[8], const uint32
 }
 
 template <int TW, int TH>
-__device__ __forceinline__ void sp_satd_units_t(const int16_t *lds, const SpCand *cand,
-                                                const SpUnit *units, int nunits,
-                                                const uint16_t *origc, uint32_t *dist,
-                                                int bd, int w, int h, int tid, int nthr) {
+__device__ __forceinline__ void sp_satd_pairs_t(const int16_t *lds, const uint32_t *cand,
+                                                int ncand, const uint16_t *origc,
+                                                uint32_t *dist, int bd, int w, int h, int tid,
+                                                int nthr) {
   static_assert((TW == 8 && TH == 8) || (TW == 16 && TH == 8) || (TW == 8 && TH == 16), "tile");
   constexpr int LT = TW == 16 ? 4 : 3;          // stages across lanes
   constexpr int HF = TH == 16 ? 1 : 2;          // of which formed as values
@@ -336,29 +331,33 @@ __device__ __forceinline__ void sp_satd_units_t(const int16_t *lds, const SpCand
   const int lane = threadIdx.x & 63;
   const int rs = h + 8;
   const int tiles_x = w / TW, ltx = 31 - __clz(tiles_x);
-  const int upp = (w * h) / TH, lupp = 31 - __clz(upp);   // lanes (tile columns) per unit
-  const int total = upp * nunits;
+  const int upp = (w * h) / TH, lupp = 31 - __clz(upp);   // lanes (tile columns) per pair
+  const int total = upp * ((ncand + 1) >> 1);
   const uint32_t smax2 = (uint32_t)((1 << bd) - 1) * 0x10001u;
   for (int g0 = tid & ~63; g0 < total; g0 += nthr) {   // whole waves stay in step
     const int g = g0 + lane;
     const bool active = g < total;
     const int gg = active ? g : 0;
-    const int un = gg >> lupp, u = gg & (upp - 1);
+    const int pr = gg >> lupp, u = gg & (upp - 1);
     const int tile = u / TW, col = u & (TW - 1);
     const int tx = tile & (tiles_x - 1), ty = tile >> ltx;
     const int x = tx * TW + col;
-    // round trip 1: the unit's record; round trip 2: the two plane columns and the originals
-    const uint4 *up = reinterpret_cast<const uint4 *>(units + un);
-    const uint4 h0 = up[0], h1 = up[1];
+    const int ca = 2 * pr, cb = (2 * pr + 1 < ncand) ? 2 * pr + 1 : 2 * pr;
+    // round trip 1: the two records; round trip 2: the two plane columns and the originals
     uint32_t ta[12], tb[12];
+    {
+      const uint4 *ra = reinterpret_cast<const uint4 *>(cand + ca * SP_REC);
+      const uint4 *rb = reinterpret_cast<const uint4 *>(cand + cb * SP_REC);
 #pragma unroll
-    for (int i = 0; i < 3; i++) {
-      const uint4 va = up[2 + i], vb = up[5 + i];
-      ta[4 * i] = va.x; ta[4 * i + 1] = va.y; ta[4 * i + 2] = va.z; ta[4 * i + 3] = va.w;
-      tb[4 * i] = vb.x; tb[4 * i + 1] = vb.y; tb[4 * i + 2] = vb.z; tb[4 * i + 3] = vb.w;
+      for (int i = 0; i < 3; i++) {
+        const uint4 va = ra[i], vb = rb[i];
+        ta[4 * i] = va.x; ta[4 * i + 1] = va.y; ta[4 * i + 2] = va.z; ta[4 * i + 3] = va.w;
+        tb[4 * i] = vb.x; tb[4 * i + 1] = vb.y; tb[4 * i + 2] = vb.z; tb[4 * i + 3] = vb.w;
+      }
     }
-    const int ca = (int)h0.x, cb = (int)h0.y, kind = (int)h0.z;
-    const int plane_a = (int)h1.x, plane_b = (int)h1.y, off_a = (int)h1.z, off_b = (int)h1.w;
+    const int kind = (int)(ta[11] >> 24);
+    const int plane_a = (int)(ta[11] & 0xffffffu), plane_b = (int)(tb[11] & 0xffffffu);
+    const int off_a = (int)ta[10], off_b = (int)tb[10];
     const int col_off = x * rs + ty * TH;
     uint32_t m[TH];
 #pragma unroll
@@ -390,32 +389,50 @@ __device__ __forceinline__ void sp_satd_units_t(const int16_t *lds, const SpCand
           m[j] = sp_u(a + b);
           m[j + len] = sp_u(a - b);
         }
-    // horizontal WHT across the TW lanes of the tile: formed stages
+    // horizontal WHT across the TW lanes of the tile: formed stages.  The exchanges of a
+    // stage are issued together and waited for once (left to itself the compiler, short of
+    // registers, pairs every ds_swizzle with its own wait: a crossbar round trip per value).
+#define SP_STAGE_FENCE() __builtin_amdgcn_sched_barrier(0)
+#define SP_WAIT_LGKM() __builtin_amdgcn_s_waitcnt(0xc07f)
     {
       const uint32_t sg = (col & 1) ? 0xffffffffu : 0x00010001u;
+      uint32_t t[TH];
+      SP_STAGE_FENCE();
 #pragma unroll
-      for (int j = 0; j < TH; j++) m[j] = sp_pk_mad(m[j], sg, sp_swz_xor<1>(m[j]));
+      for (int j = 0; j < TH; j++) t[j] = sp_swz_xor<1>(m[j]);
+      SP_WAIT_LGKM();
+      SP_STAGE_FENCE();
+#pragma unroll
+      for (int j = 0; j < TH; j++) m[j] = sp_pk_mad(m[j], sg, t[j]);
     }
     if (HF == 2) {
       const uint32_t sg = (col & 2) ? 0xffffffffu : 0x00010001u;
+      uint32_t t[TH];
+      SP_STAGE_FENCE();
 #pragma unroll
-      for (int j = 0; j < TH; j++) m[j] = sp_pk_mad(m[j], sg, sp_swz_xor<2>(m[j]));
+      for (int j = 0; j < TH; j++) t[j] = sp_swz_xor<2>(m[j]);
+      SP_WAIT_LGKM();
+      SP_STAGE_FENCE();
+#pragma unroll
+      for (int j = 0; j < TH; j++) m[j] = sp_pk_mad(m[j], sg, t[j]);
     }
     uint32_t sa = 0, sb = 0;
     if (!MAG) {
       // last stage (xor 4) folded into the absolute sum: 2 * max(|a|, |b|),
       // counted once by each lane of the pair
-      uint32_t mx[TH];
+      uint32_t av[TH], ot[TH];
 #pragma unroll
-      for (int j = 0; j < TH; j++) {
-        const sp_v2u av = __builtin_bit_cast(sp_v2u, sp_pk_abs(m[j]));
-        const sp_v2u ot = __builtin_bit_cast(
-            sp_v2u, sp_swz_xor<4>(__builtin_bit_cast(uint32_t, av)));
-        mx[j] = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(av, ot));
-      }
+      for (int j = 0; j < TH; j++) av[j] = sp_pk_abs(m[j]);
+      SP_STAGE_FENCE();
+#pragma unroll
+      for (int j = 0; j < TH; j++) ot[j] = sp_swz_xor<4>(av[j]);
+      SP_WAIT_LGKM();
+      SP_STAGE_FENCE();
 #pragma unroll
       for (int j = 0; j < TH; j += 2) {
-        const sp_v2u t2 = __builtin_bit_cast(sp_v2u, mx[j]) + __builtin_bit_cast(sp_v2u, mx[j + 1]);
+        const sp_v2u t2 =
+            __builtin_elementwise_max(__builtin_bit_cast(sp_v2u, av[j]), __builtin_bit_cast(sp_v2u, ot[j])) +
+            __builtin_elementwise_max(__builtin_bit_cast(sp_v2u, av[j + 1]), __builtin_bit_cast(sp_v2u, ot[j + 1]));
         sa = __builtin_amdgcn_udot2(t2, (sp_v2u){1, 0}, sa, false);
         sb = __builtin_amdgcn_udot2(t2, (sp_v2u){0, 1}, sb, false);
       }
@@ -423,25 +440,40 @@ __device__ __forceinline__ void sp_satd_units_t(const int16_t *lds, const SpCand
       constexpr int KM = 1 << HF, KF = 2 << HF;   // magnitude stage, fold stage
       // this lane forms u + v (bit clear) or v - u (bit set) of the pair
       const uint32_t flip = (col & KM) ? 0xffffffffu : 0u;
+      uint32_t vv[TH], mag[TH], ot[TH];
+      SP_STAGE_FENCE();
+#pragma unroll
+      for (int j = 0; j < TH; j++) vv[j] = sp_swz_xor<KM>(m[j]);
+      SP_WAIT_LGKM();
+      SP_STAGE_FENCE();
 #pragma unroll
       for (int j = 0; j < TH; j++) {
-        const uint32_t uu = m[j], vv = sp_swz_xor<KM>(uu);
+        const uint32_t uu = m[j];
         const sp_v2u au = __builtin_bit_cast(sp_v2u, sp_pk_abs(uu));
-        const sp_v2u av = __builtin_bit_cast(sp_v2u, sp_pk_abs(vv));
+        const sp_v2u av = __builtin_bit_cast(sp_v2u, sp_pk_abs(vv[j]));
         const uint32_t sum = __builtin_bit_cast(uint32_t, au + av);
         const uint32_t dif = __builtin_bit_cast(
             uint32_t, __builtin_elementwise_max(au, av) - __builtin_elementwise_min(au, av));
         // halves whose signs differ (all-ones), swapped for the subtracting lane
-        const sp_v2s sx = sp_s2(uu ^ vv) >> (sp_v2s){15, 15};
+        const sp_v2s sx = sp_s2(uu ^ vv[j]) >> (sp_v2s){15, 15};
         const uint32_t sel = sp_u(sx) ^ flip;
-        const uint32_t mag = (dif & sel) | (sum & ~sel);
-        const sp_v2u mg = __builtin_bit_cast(sp_v2u, mag);
-        const sp_v2u ot = __builtin_bit_cast(sp_v2u, sp_swz_xor<KF>(mag));
-        const sp_v2u mx = __builtin_elementwise_max(mg, ot);
+        mag[j] = (dif & sel) | (sum & ~sel);
+      }
+      SP_STAGE_FENCE();
+#pragma unroll
+      for (int j = 0; j < TH; j++) ot[j] = sp_swz_xor<KF>(mag[j]);
+      SP_WAIT_LGKM();
+      SP_STAGE_FENCE();
+#pragma unroll
+      for (int j = 0; j < TH; j++) {
+        const sp_v2u mx = __builtin_elementwise_max(__builtin_bit_cast(sp_v2u, mag[j]),
+                                                    __builtin_bit_cast(sp_v2u, ot[j]));
         sa = __builtin_amdgcn_udot2(mx, (sp_v2u){1, 0}, sa, false);
         sb = __builtin_amdgcn_udot2(mx, (sp_v2u){0, 1}, sb, false);
       }
     }
+#undef SP_STAGE_FENCE
+#undef SP_WAIT_LGKM
     // tile totals over the TW columns
     sa += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)sa, 0xB1, 0xF, 0xF, false);
     sb += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)sb, 0xB1, 0xF, 0xF, false);
@@ -466,14 +498,13 @@ __device__ __forceinline__ void sp_satd_units_t(const int16_t *lds, const SpCand
   }
 }
 
-__device__ __forceinline__ void sp_satd_units(const int16_t *lds, const SpCand *cand,
-                                              const SpUnit *units, int nunits,
-                                              const uint16_t *origc, uint32_t *dist,
+__device__ __forceinline__ void sp_satd_pairs(const int16_t *lds, const uint32_t *cand,
+                                              int ncand, const uint16_t *origc, uint32_t *dist,
                                               int bd, int w, int h,
                                               int tid = threadIdx.x & 63, int nthr = 64) {
-  if (w == h) sp_satd_units_t<8, 8>(lds, cand, units, nunits, origc, dist, bd, w, h, tid, nthr);
-  else if (w > h) sp_satd_units_t<16, 8>(lds, cand, units, nunits, origc, dist, bd, w, h, tid, nthr);
-  else sp_satd_units_t<8, 16>(lds, cand, units, nunits, origc, dist, bd, w, h, tid, nthr);
+  if (w == h) sp_satd_pairs_t<8, 8>(lds, cand, ncand, origc, dist, bd, w, h, tid, nthr);
+  else if (w > h) sp_satd_pairs_t<16, 8>(lds, cand, ncand, origc, dist, bd, w, h, tid, nthr);
+  else sp_satd_pairs_t<8, 16>(lds, cand, ncand, origc, dist, bd, w, h, tid, nthr);
 }
 
 #endif  // XVCGPU_K_SUBPEL_H_
