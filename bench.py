@@ -382,16 +382,9 @@ def encoder_rd_serial_figure(ctx, api, fx, pics, w, h, n_states=4000):
                         serial["first_state_walked"], serial["stretch"]["intra"],
                         serial["stretch"]["intra_calls"]),
         "us_per_cu_state": s1["us_per_cu_state"],
-        "launches_per_state": {"entry_point_calls": s1["api_calls_per_state"],
-                               "kernel_launches_rocprof": {"serial": 13.96, "chained": 7.17},
-                               "kernel_launches_rocprof_measured_at": "round 4, commit f6a310b (static "
-                                                                      "reference, not re-measured by this run)",
-                               "note": "rocprofv3 --kernel-trace of tools/cu_state_walk.py --no-check "
-                                       "(3000 + 200 warm-up states): 44 660 launches serial (12 887 of "
-                                       "them result copies), 22 947 chained (1 502 copies) - "
-                                       "profiles/r04_cu_state_{serial,chained}_kernel_stats.csv; "
-                                       "the kernels' summed duration is the wall time: a state is a "
-                                       "string of dependent 4-30 us kernels on a few CUs each"},
+        "launches_per_state": {"entry_point_calls": s1["api_calls_per_state"]},
+        # not of this run: read from the committed profiles, labelled with their file
+        "quoted": quoted_walk_profiles(),
         "round_trips_per_state": s1["round_trips_per_state"],
         "pictures_per_s": {k: v["pictures_per_s"] for k, v in serial["chains"].items()},
         "us_by_state_kind": s1["us_by_kind"],
@@ -453,11 +446,7 @@ def encoder_rd_serial_figure(ctx, api, fx, pics, w, h, n_states=4000):
                            "its own stretch of the picture): a round takes the next step of every "
                            "chain and issues one launch per step kind, grid y = chain "
                            "(xvcgpu_cs_segs_launch; xvc_host_cs_run_programs_engine); a chain at its "
-                           "read-back sits out until the round's event has passed",
-                   "kernels_in_flight_mean": {"128": 2.5, "measured_at": "round 5: kernel seconds of "
-                                              "profiles/r05_cu_state_engine_kernel_stats.csv over that "
-                                              "(profiled) run's wall time, four streams (static, not "
-                                              "re-measured by this run)"}},
+                           "read-back sits out until the round's event has passed"},
         "lic_picture": lic_fig,
         "seconds_spent_measuring": {k: round(v, 1) for k, v in spent.items()},
         "compared": s1.get("compared"),
@@ -713,6 +702,27 @@ class HostStagedComm:
 
     def destroy(self):
         pass
+
+
+
+def quoted_walk_profiles():
+    """Kernel launches per CU state of the serial / chained walks, from the NEWEST committed
+    rocprofv3 --kernel-trace --stats summaries (profiles/rNN_cu_state_<form>_kernel_stats.csv,
+    tools/runs/rNN: `cu_state_walk.py --mode <form> --states 3200 --k 1 --no-check`).  Quoted,
+    not measured by this run: each entry names its file."""
+    import csv
+    import glob
+    out = {"note": "rocprofv3 summaries of tools/cu_state_walk.py --states 3200 --k 1 --no-check, "
+                   "committed under profiles/ (not re-measured by this run; launches include the "
+                   "result copies)"}
+    for form in ("serial", "chained", "live"):
+        files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_cu_state_%s_kernel_stats.csv" % form)))
+        if not files:
+            continue
+        calls = sum(int(r["Calls"]) for r in csv.DictReader(open(files[-1])))
+        out[form] = {"kernel_launches_per_state": round(calls / 3200.0, 2),
+                     "file": os.path.relpath(files[-1], ROOT)}
+    return out
 
 
 def quoted_cpu_baseline():

@@ -676,12 +676,19 @@ __constant__ int8_t kSubpelOff[2][9][2] = {
     {{0, 0}, {0, -1}, {0, 1}, {-1, 0}, {1, 0}, {-1, -1}, {1, -1}, {-1, 1}, {1, 1}},
     {{0, 0}, {0, -1}, {0, 1}, {-1, -1}, {1, -1}, {-1, 0}, {1, 0}, {-1, 1}, {1, 1}}};
 
-// i-th candidate MV of sub-pel pass `pass` (0 = half, 1 = quarter) around base.
+// i-th candidate MV of sub-pel pass `pass` (0 = half, 1 = quarter) around base.  The
+// offsets of kSubpelOff as nibbles (dx + 1) | (dy + 1) << 2 of a constant, entry i + pass: a
+// shift instead of a (per-lane) table read from memory.
 __device__ __forceinline__ void me2_subpel_mv(int pass, int i, int base_x, int base_y,
                                               int &mx, int &my) {
-  const int k = i + pass, scale = pass == 0 ? 8 : 4;
-  mx = base_x + kSubpelOff[pass][k][0] * scale;
-  my = base_y + kSubpelOff[pass][k][1] * scale;
+  //                   (1,1)(-1,1)(1,-1)(-1,-1)(1,0)(-1,0)(0,1)(0,-1)(0,0)
+  const unsigned long long half = 0xA82064915ull;   // kSubpelOff[0][0..8]
+  //                   (1,1)(-1,1)(1,0)(-1,0)(1,-1)(-1,-1)(0,1)(0,-1)
+  const uint32_t quarter = 0xA8642091u;             // kSubpelOff[1][1..8]
+  const uint32_t nib = pass == 0 ? (uint32_t)(half >> (4 * i)) & 15u : (quarter >> (4 * i)) & 15u;
+  const int scale = pass == 0 ? 8 : 4;
+  mx = base_x + ((int)(nib & 3u) - 1) * scale;
+  my = base_y + ((int)(nib >> 2) - 1) * scale;
 }
 
 __device__ __forceinline__ bool me2_subpel_fast(int w, int h, int bd, bool ac = false) {
@@ -692,9 +699,12 @@ __device__ __forceinline__ bool me2_subpel_fast(int w, int h, int bd, bool ac = 
 
 // Order in which a pass's candidates are stored for the sweep (k_subpel.h takes them two at
 // a time): the pairs above / below a position first - (-1,-+1), (+1,-+1), (0,-+1) in units
-// of the pass's step -, then left / right of the centre, then (half-pel pass) the centre.
-// Entry = index in issue order (kSubpelOff with the pass's skip of the centre).
-__constant__ int8_t kSubpelOrder[2][9] = {{5, 7, 6, 8, 1, 2, 3, 4, 0}, {2, 6, 3, 7, 0, 1, 4, 5, 0}};
+// of the pass's step -, then left / right of the centre, then (half-pel pass) the centre:
+// {5,7,6,8,1,2,3,4,0} / {2,6,3,7,0,1,4,5}, indices in issue order (kSubpelOff with the pass's
+// skip of the centre).
+__device__ __forceinline__ int me2_subpel_order(int pass, int i) {   // nibble i of a constant
+  return pass == 0 ? (int)((0x043218675ull >> (4 * i)) & 15u) : (int)((0x54107362u >> (4 * i)) & 15u);
+}
 
 // Fast path of a sub-pel pass (k_subpel.h; both sides >= 8, bd <= 10, plain SATD), by one
 // wave (NW = 1) or a team of NW waves: s.orig is column-major, the window is staged.
@@ -720,7 +730,7 @@ __device__ __forceinline__ int me2_subpel_fast_pass(Me2Shared<MS> &s, const MeCt
   const int n = pass < 0 ? 1 : 9 - pass;
   const bool need = lane < n;
   // this lane's candidate (lanes >= n idle; every wave of a team computes the same)
-  const int oi = (pass >= 0 && need) ? kSubpelOrder[pass][lane] : 0;
+  const int oi = (pass >= 0 && need) ? me2_subpel_order(pass, lane) : 0;
   int mx = base_x, my = base_y;
   if (pass >= 0 && need) me2_subpel_mv(pass, oi, base_x, base_y, mx, my);
   d_clip_mv(b.x, b.y, pic_w, pic_h, mx, my);  // MotionCompensationMv, :749

@@ -63,8 +63,8 @@ __device__ __forceinline__ void tx2_stage(const int16_t *A, const int16_t *B,
                                           int na, int nb, int add, int shift,
                                           int16_t *out) {
   const int lane = ME2_LANE & (G - 1);
-  const int gb = nb / OPL;
-  const int a = lane / gb, b0 = (lane - a * gb) * OPL;
+  const int gb = nb / OPL;              // a power of two (block sides are)
+  const int a = lane >> (31 - __clz(gb)), b0 = (lane & (gb - 1)) * OPL;
   if (a >= na) return;
   uint32_t ra[NJ / 2];
   tx2_load_row<NJ>(A + a * NJ, ra);
@@ -186,7 +186,7 @@ __device__ __forceinline__ int tx2_job(Tx2Shared &sh, const xvcgpu_tx_block &b, 
   const int lane = ME2_LANE & (G - 1);
   const int w = b.w, h = b.h;
   const int lw = 31 - __clz(w);
-  const int lgw = d_log2_size(w), lgh = d_log2_size(h);
+  const int lgw = lw, lgh = 31 - __clz(h);   // sides 4 ... 16: powers of two
   int16_t *lv = (levels && level_off) ? levels + level_off[bi] : nullptr;
   const int offh = tx_table_off(lay, b.tx_hor, w), offv = tx_table_off(lay, b.tx_ver, h);
   const int16_t *Mh = tx_tables + offh, *Mv = tx_tables + offv;
@@ -274,7 +274,7 @@ __device__ __forceinline__ int tx2_job(Tx2Shared &sh, const xvcgpu_tx_block &b, 
       }
       if (lv)
         for (int i = lane; i < n_el; i += G) {
-          const int x = i / h, k2 = i - x * h;  // C[x][k2]
+          const int x = i >> lgh, k2 = i & (h - 1);  // C[x][k2] (h a power of two)
           lv[k2 * w + x] = s.c[i];
         }
       return 0;
@@ -328,7 +328,7 @@ __device__ __forceinline__ int tx2_job(Tx2Shared &sh, const xvcgpu_tx_block &b, 
       const int gw = w >> 2, gh = h >> 2;
       auto idx = [h](int x, int y) { return x * h + y; };
       const bool mine = lane < gw * gh;
-      const int sx = mine ? lane % gw : 0, sy = mine ? lane / gw : 0;
+      const int sx = mine ? (lane & (gw - 1)) : 0, sy = mine ? (lane >> (lgw - 2)) : 0;
       bool any = false;
       if (mine)
         for (int k = 0; k < 16; k++) any |= s.r[idx(4 * sx + (k & 3), 4 * sy + (k >> 2))] != 0;
@@ -350,7 +350,7 @@ __device__ __forceinline__ int tx2_job(Tx2Shared &sh, const xvcgpu_tx_block &b, 
     if (lv) {
       wave_sync();
       for (int i = lane; i < n_el; i += G) {
-        const int x = i / h, k2 = i - x * h;
+        const int x = i >> lgh, k2 = i & (h - 1);
         lv[k2 * w + x] = s.r[i];
       }
     }
@@ -358,7 +358,7 @@ __device__ __forceinline__ int tx2_job(Tx2Shared &sh, const xvcgpu_tx_block &b, 
     nnz = nnz_out[bi];
     if (nnz)
       for (int i = lane; i < n_el; i += G) {
-        const int x = i / h, k2 = i - x * h;
+        const int x = i >> lgh, k2 = i & (h - 1);
         s.r[i] = lv[k2 * w + x];
       }
   }
@@ -581,11 +581,15 @@ residual_cu_body(const PicView &orig, const PicView &pred, const PicView &rec, c
     pred_p = pp.p + (ptrdiff_t)sp.y * pp.stride + sp.x;
   }
   if (tx_small_job(b)) {
-    if (threadIdx.x >= 64) return;
-    Small &u = *reinterpret_cast<Small *>(raw);
-    tx2_job<MODE, 64, RDOQ>(u.s, b, idx, pred.bd, orig_v.c[b.comp], pred_p, pp.stride,
-                            rec.c[b.comp], levels, level_off, nnz_out, tx_tables, tx_tables_t,
-                            lay, nullptr, 0, &u.rq, rq_ctx, rq_prm, nullptr);
+    // the first wave's job; the others wait at the barrier below (when there is one) - no
+    // wave leaves in front of a barrier the rest of its workgroup still reaches
+    if (!ecands && threadIdx.x >= 64) return;
+    if (threadIdx.x < 64) {
+      Small &u = *reinterpret_cast<Small *>(raw);
+      tx2_job<MODE, 64, RDOQ>(u.s, b, idx, pred.bd, orig_v.c[b.comp], pred_p, pp.stride,
+                              rec.c[b.comp], levels, level_off, nnz_out, tx_tables, tx_tables_t,
+                              lay, nullptr, 0, &u.rq, rq_ctx, rq_prm, nullptr);
+    }
   } else {
     Big &u = *reinterpret_cast<Big *>(raw);
     residual_job<MODE, RDOQ ? 1024 : 4>(u.s, idx, orig_v, pred, rec, blocks, levels, level_off,
@@ -594,8 +598,8 @@ residual_cu_body(const PicView &orig, const PicView &pred, const PicView &rec, c
   }
   if (ecands) {
     // the block's reconstruction was written by this workgroup: visible to its first
-    // wave behind a workgroup-scope release / acquire around the barrier (the waves that
-    // left early are not waited for)
+    // wave behind a workgroup-scope release / acquire around the barrier (every wave of
+    // the workgroup arrives here)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __syncthreads();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");

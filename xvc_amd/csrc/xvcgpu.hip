@@ -296,6 +296,14 @@ xvcgpu_status xvcgpu_create(int device, xvcgpu_ctx **out) {
       return XVCGPU_OUT_OF_MEMORY;
     }
   }
+  // the flag the four-lane-only promise is checked with (xvcgpu_quant_rdo_set_four_lane_only):
+  // allocated here, not on first use - that first use may sit inside a stream capture
+  if (hipHostMalloc(reinterpret_cast<void **>(&ctx->h_rdoq_misuse), sizeof(int),
+                    hipHostMallocMapped) != hipSuccess) {
+    xvcgpu_destroy(ctx);
+    return XVCGPU_OUT_OF_MEMORY;
+  }
+  *ctx->h_rdoq_misuse = 0;
   *out = ctx;
   return XVCGPU_OK;
 }
@@ -407,16 +415,23 @@ xvcgpu_status xvcgpu_wait_for(xvcgpu_ctx *ctx, xvcgpu_ctx *other) {
   return XVCGPU_OK;
 }
 
-xvcgpu_status xvcgpu_sync(xvcgpu_ctx *ctx) {
-  if (!ctx) return XVCGPU_INVALID_ARGUMENT;
-  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-  if (ctx->h_rdoq_misuse && *ctx->h_rdoq_misuse) {
+// Every host-side wait ends here: a broken four-lane-only promise
+// (xvcgpu_quant_rdo_set_four_lane_only) is reported by the first wait that follows the walk,
+// whichever entry point it is.
+xvcgpu_status xvcgpu_internal_after_wait(xvcgpu_ctx *ctx) {
+  if (ctx && ctx->h_rdoq_misuse && *ctx->h_rdoq_misuse) {
     *ctx->h_rdoq_misuse = 0;
     return fail(ctx, XVCGPU_INVALID_ARGUMENT,
                 "quant_rdo: a block outside the four-lane classes in a batch declared "
                 "xvcgpu_quant_rdo_set_four_lane_only (its levels were not computed)");
   }
   return XVCGPU_OK;
+}
+
+xvcgpu_status xvcgpu_sync(xvcgpu_ctx *ctx) {
+  if (!ctx) return XVCGPU_INVALID_ARGUMENT;
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return xvcgpu_internal_after_wait(ctx);
 }
 
 xvcgpu_status xvcgpu_timer_begin(xvcgpu_ctx *ctx) {
@@ -565,7 +580,7 @@ xvcgpu_status xvcgpu_memcpy_d2h(xvcgpu_ctx *ctx, void *dst, const void *src,
   if (!bytes) return XVCGPU_OK;
   HIP_TRY(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-  return XVCGPU_OK;
+  return xvcgpu_internal_after_wait(ctx);
 }
 
 xvcgpu_status xvcgpu_memset(xvcgpu_ctx *ctx, void *dst, int value, size_t bytes) {
@@ -1250,13 +1265,6 @@ xvcgpu_status xvcgpu_quant_rdo_set_prove_zero(xvcgpu_ctx *ctx, int mode) {
 
 xvcgpu_status xvcgpu_quant_rdo_set_four_lane_only(xvcgpu_ctx *ctx, int on) {
   if (!ctx) return XVCGPU_INVALID_ARGUMENT;
-  if (on && !ctx->h_rdoq_misuse) {
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
-    if (hipHostMalloc(reinterpret_cast<void **>(&ctx->h_rdoq_misuse), sizeof(int),
-                      hipHostMallocMapped) != hipSuccess)
-      return fail(ctx, XVCGPU_OUT_OF_MEMORY, "quant_rdo misuse flag");
-    *ctx->h_rdoq_misuse = 0;
-  }
   ctx->rdoq_four_lane_only = on ? 1 : 0;
   return XVCGPU_OK;
 }
@@ -2726,8 +2734,14 @@ xvcgpu_status xvcgpu_cs_segs_launch(xvcgpu_ctx *ctx, int kind, const xvcgpu_cs_s
         hipLaunchKernelGGL(cs_seg_inter_pred_kernel, dim3(max_n, gy), dim3(256), 0, st, a);
         break;
       case XVC_CS_SEG_RESIDUAL_AT:
-        for (int i = 0; i < cnt; i++)
-          if (segs[first + i].n > 64 || !segs[first + i].p[5]) return XVCGPU_INVALID_ARGUMENT;
+        // as xvcgpu_residual_rdoq_batch_at checks a single call: <= 64 blocks, the arrays
+        // of the blocks, 0 ... 64 head candidates, candidates and their output both or neither
+        for (int i = 0; i < cnt; i++) {
+          const xvcgpu_cs_seg &g = segs[first + i];
+          if (g.n > 64 || !g.p[5] || g.r0 < 0 || g.r0 > 64 || (g.p[6] != 0) != (g.p[7] != 0) ||
+              (g.n && (!g.p[0] || !g.p[1] || !g.p[2] || !g.p[3] || !g.p[4])))
+            return fail(ctx, XVCGPU_INVALID_ARGUMENT, "cs_segs_launch: residual segment");
+        }
         hipLaunchKernelGGL(cs_seg_residual_kernel, dim3(max_nh, gy), dim3(TX_THREADS), 0, st, a,
                            ctx->d_tx_tables, ctx->d_tx_tables_t, xvcgpu_tx_layout());
         break;

@@ -180,10 +180,12 @@ xvcgpu_status xvcgpu_upload_ahead(xvcgpu_ctx *ctx, void *d_dst, const void *h_sr
   return XVCGPU_OK;
 }
 
+xvcgpu_status xvcgpu_internal_after_wait(xvcgpu_ctx *ctx);   // xvcgpu.hip
+
 xvcgpu_status xvcgpu_event_synchronize(xvcgpu_event *ev) {
   if (!ev) return XVCGPU_INVALID_ARGUMENT;
   CHIP_TRY(ev->ctx, hipEventSynchronize(ev->ev));
-  return XVCGPU_OK;
+  return xvcgpu_internal_after_wait(ev->ctx);
 }
 
 xvcgpu_status xvcgpu_event_query(xvcgpu_event *ev, int *done) {
@@ -191,7 +193,7 @@ xvcgpu_status xvcgpu_event_query(xvcgpu_event *ev, int *done) {
   const hipError_t e = hipEventQuery(ev->ev);
   if (e == hipSuccess) {
     *done = 1;
-    return XVCGPU_OK;
+    return xvcgpu_internal_after_wait(ev->ctx);
   }
   if (e == hipErrorNotReady) {
     (void)hipGetLastError();

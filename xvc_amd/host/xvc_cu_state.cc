@@ -665,6 +665,15 @@ extern "C" int xvc_host_cs_run_programs_engine(xvcgpu_ctx *const *ctxs, int n_ct
           }
           at[c]++;
           fetched[c] = true;
+          // the read-backs of a round go out on stream 0 behind the chains' walk: a launch
+          // step that follows one (no SYNC between) must not be issued in the same round -
+          // it could overwrite what the read-back has not copied yet.  It waits for the next
+          // round, whose launches are behind this round's events.
+          if (at[c] < n_ops[c] && ops[c][at[c]].opcode != XVC_OP_FETCH &&
+              ops[c][at[c]].opcode != XVC_OP_SYNC) {
+            issued = true;
+            break;
+          }
           continue;
         }
         const int kind = SegKindOf(o);

@@ -163,6 +163,10 @@ typedef struct xvc_cs_stats {
 // predictions, 3 scratch reconstructions (METRIC, COPY, INTER_PRED).  The *_REFS ops are
 // a step into all the CU's reference pictures as one launch (xvcgpu_*_refs): p[0] jobs,
 // p[1] results, p[2] the jobs' slot bytes, i0 = block class / CU height.
+// Ordering inside a chain: ops take effect in program order.  The engine
+// (xvc_host_cs_run_engine) collects a round's FETCH ops into one copy launch behind the
+// round's walk; a launch step that follows a FETCH without a SYNC between is held back
+// to the next round, so it cannot overwrite an array the copy has not read yet.
 enum {
   XVC_OP_MC_METRIC = 0, XVC_OP_METRIC, XVC_OP_ME, XVC_OP_BI, XVC_OP_AFFINE, XVC_OP_COPY,
   XVC_OP_INTER_PRED, XVC_OP_RESIDUAL, XVC_OP_START_FOLD, XVC_OP_UNI_FOLD, XVC_OP_BI_FOLD,
