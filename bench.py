@@ -206,6 +206,8 @@ def stream_decode_figure(ctx, api):
     out["encoder_me_batches"] = encoder_me_figure(ctx, api, fx, pics, w, h)
     out["encoder_rd_batches"] = encoder_rd_figure(ctx, api, fx, pics, w, h)
     out["encoder_rd_serial"] = encoder_rd_serial_figure(ctx, api, fx, pics, w, h)
+    if out["encoder_rd_serial"]:
+        out["encoder_rd_serial"]["side_by_side"] = rd_side_by_side(out)
     dec.destroy()
     for p in pics:
         p.destroy()
@@ -388,6 +390,7 @@ def encoder_rd_serial_figure(ctx, api, fx, pics, w, h, n_states=4000):
         "round_trips_per_state": s1["round_trips_per_state"],
         "pictures_per_s": {k: v["pictures_per_s"] for k, v in serial["chains"].items()},
         "us_by_state_kind": s1["us_by_kind"],
+        "intra_picture_dag": intra_picture_dag(sp, c1.get("us_by_kind") or s1["us_by_kind"]),
         "chained": {"us_per_cu_state": c1["us_per_cu_state"],
                     "entry_point_calls_per_state": c1["api_calls_per_state"],
                     "round_trips_per_state": c1["round_trips_per_state"],
@@ -703,6 +706,76 @@ class HostStagedComm:
     def destroy(self):
         pass
 
+
+
+
+def intra_picture_dag(sp, us_by_kind):
+    """States / critical path of the picture's state-dependency DAG (tools/state_dag.py: what
+    a state reads of its spatial neighbours' decisions and of its CU's merge ranking; the
+    CABAC context chain is NOT modelled - with it the walk is serial): how many states of ONE
+    picture a walk that is handed the context snapshots could have in flight."""
+    import state_dag
+    names = ["merge_rank", "eval", "inter", "motion_only", "intra"]
+    out = {"by_count": state_dag.critical_path(sp.states)}
+    try:
+        w = [float(us_by_kind[n]) for n in names]
+        out["by_chained_us"] = state_dag.critical_path(sp.states, w)
+    except (KeyError, TypeError):
+        pass
+    out["note"] = ("upper bound: spatial-neighbour and merge-ranking dependencies only; the entropy "
+                   "coder's context state (restored per CU from everything coded before it, "
+                   "cu_encoder.cc:166-170) makes the reference's own order serial")
+    return out
+
+
+
+def quoted_ref_encoder_cpu():
+    """The reference encoder's own time on the clip the walk's picture comes from, measured by
+    tools/ref_encoder_time.py on a GPU box's host (a 1080p inter picture costs the reference
+    tens of seconds: too long for this run) - the newest committed
+    profiles/rNN_ref_encoder_cpu.json, quoted with its file name."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_ref_encoder_cpu.json")))
+    if not files:
+        return None
+    try:
+        d = json.load(open(files[-1]))
+    except ValueError:
+        return None
+    d["quoted_from"] = os.path.relpath(files[-1], ROOT) + " (not re-measured by this run)"
+    return d
+
+
+def rd_side_by_side(out):
+    """Three figures for ONE 1080p B picture's RD search, side by side: what the reference
+    encoder needs for a picture on the host's cores (quoted: quoted_ref_encoder_cpu), what
+    the device walk reaches in the reference's issue order with k = 16 pictures in flight
+    (this run: engine), and the ceiling the walk is chasing - the same searches and
+    TransformAndReconstruct calls as whole-picture batches (this run: encoder_me_batches +
+    encoder_rd_batches; a shape no bit-exact encoder can present)."""
+    rs = out["encoder_rd_serial"]
+    res = {}
+    cpu = quoted_ref_encoder_cpu()
+    if cpu:
+        res["reference_cpu"] = {
+            "pictures_per_s": {k: v["pictures_per_s"] for k, v in cpu["runs"].items()},
+            "threads": {k: v["threads"] for k, v in cpu["runs"].items()},
+            "host_cores": cpu.get("host_cores"), "quoted_from": cpu["quoted_from"],
+            "what": "the whole encode of the clip's pictures (RD search + entropy coding + "
+                    "filters): an upper bound on the time of the RD search alone"}
+    eng = (rs.get("engine") or {}).get("pictures_per_s") or {}
+    res["device_walk_pictures_per_s"] = {"engine_k16": eng.get("16"), "engine": eng,
+                                         "chained_k1": (rs.get("chained") or {}).get("pictures_per_s")}
+    try:
+        ms = float(out["encoder_me_batches"]["ms"]) + sum(
+            float(v) for v in out["encoder_rd_batches"]["ms"].values() if v)
+        res["batch_ceiling"] = {"ms_per_picture": ms, "pictures_per_s": 1e3 / ms,
+                                "what": "every search and TransformAndReconstruct call of the "
+                                        "picture as whole-picture batches (intra states not "
+                                        "included)"}
+    except (KeyError, TypeError, ValueError):
+        pass
+    return res
 
 
 def quoted_walk_profiles():

@@ -987,18 +987,20 @@ class SerialRun:
 
 
 # ======================================================================================
-# The chained form: passes (xvcgpu_cs_pass), work arrays the device composes, programs.
+# The chained form.  Its COMPOSER - the passes (xvcgpu_cs_pass), the work arrays the device
+# folds compose the searches' jobs in, the merge folds and evaluation slots, the distortion
+# candidates and the op programs - is C++ product code: xvc_gpu::CuStateBuilder
+# (xvc_amd/host/xvc_cu_state_builder.{h,cc}, bound by xvc_amd/cu_state_builder.py).  What is
+# left here turns the captured encode into the builder's input records - what CuEncoder
+# holds when it reaches a state (cu_encoder.cc:431-541, :579-642) - and, for the harness
+# only, matches captured merge-candidate evaluations to the slots a merge fold fills.
 # ======================================================================================
-R3 = 3               # XVC_CS_MAX_REFS
+from xvc_amd import cu_state_builder as csb  # noqa: E402
+
+R3 = csb.R3          # XVC_CS_MAX_REFS
 CS_FULLPEL, CS_FORCE_L1_MVD_ZERO, CS_LIC, CS_AFFINE = 1, 2, 4, 8
 CS_WHICH_UNSUPPORTED = 255
-
-PASS_DTYPE = np.dtype([
-    ("x", "<i2"), ("y", "<i2"), ("w", "u1"), ("h", "u1"), ("flags", "u1"), ("num_refs", "u1", 2),
-    ("same_poc_in_l0", "i1", R3), ("lambda16", "<u4"), ("ictx", of.ICTX_DTYPE),
-    ("mvp", "<i4", (2, R3, 2, 3, 2)), ("uni_job", "<i4", (2, R3)), ("start_dist", "<i4", (2, R3)),
-    ("prev_job", "<i4", (2, R3)), ("bi_job", "<i4"), ("plain_pass", "<i4"), ("eval", "<i4"),
-    ("slot", "i1", (2, R3)), ("bi_iterations", "u1"), ("reserved", "u1")], align=True)
+PASS_DTYPE = csb.PASS_DTYPE
 
 RESULT_DTYPE = np.dtype([
     ("start_idx", "u1", (2, R3)), ("mvp_idx", "u1", (2, R3)), ("mv", "<i4", (2, R3, 3, 2)),
@@ -1010,8 +1012,7 @@ RESULT_DTYPE = np.dtype([
     ("ref_idx", "i1", 2), ("out_mvp_idx", "u1", 2), ("zero_mvd", "u1"), ("chosen", "u1"),
     ("best_cost", "<u4"), ("out_mv", "<i4", (2, 3, 2)), ("out_mvd", "<i4", (2, 2, 2))], align=True)
 
-OP_DTYPE = np.dtype([("opcode", "<i4"), ("n", "<i4"), ("r0", "<i4"), ("r1", "<i4"), ("i0", "<i4"),
-                     ("reserved", "<i4"), ("f", "<f8"), ("p", "<u8", 8)], align=True)
+OP_DTYPE = csb.OP_DTYPE
 (OP_MC_METRIC, OP_METRIC, OP_ME, OP_BI, OP_AFFINE, OP_COPY, OP_INTER_PRED, OP_RESIDUAL,
  OP_START_FOLD, OP_UNI_FOLD, OP_BI_FOLD, OP_FETCH, OP_SYNC, OP_EVAL_DIST, OP_MC_METRIC_REFS,
  OP_ME_REFS, OP_BI_REFS, OP_AFFINE_REFS, OP_MERGE_FOLD, OP_BI_LIC, OP_INTRA_SATD, OP_INTRA_PRED,
@@ -1019,37 +1020,17 @@ OP_DTYPE = np.dtype([("opcode", "<i4"), ("n", "<i4"), ("r0", "<i4"), ("r1", "<i4
 PIC_ORIG, PIC_S_ORIG, PIC_S_PRED, PIC_S_REC, PIC_NB, PIC_REC, PIC_IPRED, PIC_IREC = 0, 1, 2, 3, 4, 5, 6, 7
 BI_SLOTS = 2 * R3 * R3
 
-
-MERGE_FOLD_DTYPE = np.dtype([("lambda_sqrt", "<f8"), ("dist", "<i4"), ("cand", "<i4"), ("slot", "<i4"),
-                             ("reserved", "<i4")], align=True)
+MERGE_FOLD_DTYPE = csb.MERGE_FOLD_DTYPE
 MERGE_RESULT_DTYPE = np.dtype([("cost", "<f8", 5), ("order", "<i4", 5), ("num", "<i4"),
                                ("reserved", "<i4", 2)], align=True)
 MERGE_SLOTS = 4      # XVC_CS_MERGE_SLOTS
 
 
-def build_merge_folds(sp):
-    """The records of xvcgpu_cs_merge_fold for every merge ranking of the picture, the
-    evaluation slots it fills (four per ranking: Y, U, V prediction jobs with the CU's
-    geometry, motion left to the fold) and, for the harness only, which slot each captured
-    merge-candidate evaluation corresponds to (its motion = a ranked candidate's): the
-    chain then predicts from the SLOT, not from the capture's job."""
-    api, st = sp.api, sp.states
-    n_m = len(sp.mg_inter)
-    mf = np.zeros(n_m, MERGE_FOLD_DTYPE)
-    mf["lambda_sqrt"] = sp.mg_want["lambda_sqrt"]
-    mf["dist"] = mf["cand"] = 5 * np.arange(n_m)
-    mf["slot"] = MERGE_SLOTS * np.arange(n_m)
-    slots = np.zeros((n_m * MERGE_SLOTS, 3), api.INTER_DTYPE)
-    g = np.repeat(sp.mg_want, MERGE_SLOTS)
-    for c in range(3):
-        sc = slots[:, c]
-        sc["x"], sc["y"], sc["w"], sc["h"], sc["comp"] = g["x"], g["y"], g["w"], g["h"], c
-        sc["ref"], sc["mv"] = -1, 0x7fffff          # the fold's to write (and XVC_INTER_LIC)
-        slots[:, c] = sc
-    # what a LIC candidate's prediction reads besides its motion: the CU's neighbours
-    any_lic = np.repeat((sp.mg_want["use_lic"] != 0).any(1), MERGE_SLOTS)
-    sp._lic_fields(slots, np.repeat(any_lic[:, None], 3, 1), np.repeat(g["nb_index"][:, None], 3, 1))
-    slots["flags"] = 0
+def match_merge_slots(sp):
+    """For the harness only: which evaluation slot of a merge fold each captured
+    merge-candidate evaluation corresponds to (its motion = a ranked candidate's) - the chain
+    then predicts from the SLOT the fold filled, not from the capture's job."""
+    st = sp.states
     ev_slot = np.full(len(sp.ev_inter), -1, np.int64)
     cur, used = None, set()
     for n in range(len(st)):
@@ -1075,10 +1056,78 @@ def build_merge_folds(sp):
                 ev_slot[e] = MERGE_SLOTS * m + r
                 used.add(r)
                 break
-    sp.mg_fold, sp.mg_slots, sp.ev_merge_slot = mf, slots, ev_slot
-    sp.merge_state = np.full(n_m, -1, np.int64)       # ranking -> its state
+    return ev_slot
+
+
+def builder_inputs(sp, ref_lists, lic_folds=True):
+    """The captured picture as xvc_csb_picture's records (xvc_cu_state_builder.h): per inter /
+    motion state the (list, picture) entries SearchRefIdx visits with their AMVP predictors,
+    lambda, the whole-sample flag and the inter contexts; per merge ranking its CU and
+    sqrt(lambda); per evaluation its position, cbf-zero candidates and weights."""
+    st = sp.states
+    cd_all = sp.tabs["cands"]
+    nbt = sp._nb_table()
+    nb = np.zeros(len(nbt), csb.NEIGHBOURS_DTYPE)
+    for f in ("has_above", "has_left", "above_x", "above_y", "left_x", "left_y"):
+        nb[f] = nbt[f]
+    motions, entries = [], []
+    for n in np.flatnonzero((st["kind"] == KIND_INTER) | (st["kind"] == KIND_MOTION)):
+        s = st[n]
+        cds = cd_all[int(s["cand_first"]):int(s["cand_first"]) + int(s["cand_count"])]
+        # (the folds run the default SearchMotion: xvcgpu_types.h; the captured encodes are such)
+        assert not cds["force_mvd_zero_other"].any(), "forced zero L1 mvd: XVC_CS_WHICH_UNSUPPORTED"
+        for kind_bi in (1, 3):
+            assert (cds["kind"] == kind_bi).sum() <= max(len(ref_lists[0]), len(ref_lists[1])), \
+                "refinement iterations > 1: XVC_CS_WHICH_UNSUPPORTED"
+        m = np.zeros((), csb.MOTION_DTYPE)
+        m["state"] = n
+        m["nb"] = sp.nb_of_state[n][0] if sp.nb_of_state.get(n) else -1
+        for name, kind in (("plain", 0), ("affine", 2)):
+            cu = cds[cds["kind"] == kind]
+            m[name]["first"], m[name]["n"] = len(entries), len(cu)
+            if len(cu):
+                m[name]["lambda16"] = cu[0]["lambda16"]
+                m[name]["fullpel"] = int(cu[0]["flags"]) & 1
+                m[name]["ictx"] = sp.order["ictx"][int(cu[0]["ictx_index"])]
+            for c in cu:
+                e = np.zeros((), csb.REF_ENTRY_DTYPE)
+                e["list"], e["ref_idx"], e["reused"], e["mvp"] = c["list"], c["ref_idx"], c["reused"], c["mvp"]
+                entries.append(e)
+        motions.append(m)
+    w = sp.mg_want
+    mg = np.zeros(len(sp.mg_inter), csb.MERGE_DTYPE)
+    mg["lambda_sqrt"], mg["x"], mg["y"], mg["w"], mg["h"] = w["lambda_sqrt"], w["x"], w["y"], w["w"], w["h"]
+    mg["any_lic"] = (w["use_lic"] != 0).any(1) if len(w) else 0
+    mg["nb"], mg["state"] = w["nb_index"], -1
     for n in np.flatnonzero(st["kind"] == KIND_MERGE_RANK):
-        sp.merge_state[int(st["merge"][n])] = n
+        mg["state"][int(st["merge"][n])] = n
+    ev = np.zeros(len(sp.ev_inter), csb.EVAL_DTYPE)
+    ev["x"], ev["y"] = sp.ev_want["x"], sp.ev_want["y"]
+    ev["dz"], ev["weight"] = sp.ev_dz, sp.ev_weight
+    ev["merge_slot"] = sp.ev_merge_slot
+    return dict(states=st, ref_lists=ref_lists, slot_pocs=np.asarray(sp.ref_pocs, np.int32),
+                lic_folds=lic_folds,
+                motions=np.array(motions, csb.MOTION_DTYPE) if motions else np.zeros(0, csb.MOTION_DTYPE),
+                entries=np.array(entries, csb.REF_ENTRY_DTYPE) if entries else np.zeros(0, csb.REF_ENTRY_DTYPE),
+                nb=nb, me_jobs=sp.me_jobs, me_ref=np.asarray(sp.me_ref, np.int8), aff_jobs=sp.aff_jobs,
+                aff_ref=np.asarray(sp.aff_ref, np.int8).reshape(-1), ev_inter=sp.ev_inter.reshape(-1),
+                merges=mg, evals=ev, ev_ctx=np.asarray(sp.ev_ctx, np.int32), call_cand=sp.call_cand,
+                call_comp=np.asarray(sp.call_tx["comp"], np.uint8),
+                call_ev=np.asarray(sp.call_ev, np.int32), mg_cands=sp.mg_cands.reshape(-1))
+
+
+def compose(sp, ref_lists, lic_folds=True):
+    """Runs xvc_gpu::CuStateBuilder on the picture and hangs its arrays on sp (passes,
+    pass_first / pass_count per state, work arrays, slots, merge folds, candidates)."""
+    sp.ev_merge_slot = match_merge_slots(sp)
+    sp.builder = b = csb.Builder(builder_inputs(sp, ref_lists, lic_folds))
+    for name, _ in csb.ARRAYS:
+        setattr(sp, name, getattr(b, name))
+    sp.folded = sp.folded.astype(bool)
+    sp.bi_slots, sp.aff_slots = sp.bi_slots.reshape(-1, 2), sp.aff_slots.reshape(-1, 2)
+    sp.ev_inter_work, sp.mg_slots = sp.ev_inter_work.reshape(-1, 3), sp.mg_slots.reshape(-1, 3)
+    sp.n_start_dist, sp.n_bi_slots, sp.n_edist = b.n_start_dist, b.n_bi_slots, b.n_edist
+    return b
 
 
 class CsEnv(C.Structure):
@@ -1088,238 +1137,6 @@ class CsEnv(C.Structure):
                 ("d_levels", C.c_void_p), ("d_results", C.c_void_p),
                 ("rec", C.c_void_p), ("nb", C.c_void_p), ("ipred", C.c_void_p), ("irec", C.c_void_p),
                 ("d_in_levels", C.c_void_p)]
-
-
-def build_passes(sp, ref_lists, lic_folds=True):
-    """The passes of every inter / motion state of the picture and the arrays the chained
-    form works on.  ref_lists: ([poc per ref_idx of list 0], [... list 1]) of the picture.
-    Adds to sp: passes, pass_first / pass_count per state, start cands, work jobs."""
-    api = sp.api
-    cd_all, st = sp.tabs["cands"], sp.states
-    slot_of = {p: i for i, p in enumerate(sp.ref_pocs)}
-    nref = [len(ref_lists[0]), len(ref_lists[1])]
-    same = [-1] * R3
-    for r, poc in enumerate(ref_lists[1]):
-        same[r] = ref_lists[0].index(poc) if poc in ref_lists[0] else -1
-    passes, pass_first, pass_count = [], np.full(len(st), -1, np.int64), np.zeros(len(st), np.int64)
-    start_cands = []            # plain passes: mc_metric candidates, grouped per pass by slot
-    start_groups = {}           # pass -> [(slot, first, n)]
-    aff_start = {}              # affine pass -> (first candidate index, n)
-    aff_inter, aff_dst, aff_cands, aff_copy = [], [], [], []
-    n_start_dist = 0
-    me_work = sp.me_jobs.copy()
-    aff_work_rows = []          # (source: index into sp.aff_jobs or -1 for a slot)
-    n_bi_slots = 0
-    uni_groups, aff_uni_groups = {}, {}
-    # a LIC state's SearchMotion is folded on the device too (XVC_CS_LIC) when the capture
-    # holds its neighbour record (the refinement's or the evaluation's: EvalStartMvp's
-    # compensated predictions read the same rows / columns); lic_folds=False: the serial form
-    lic = (st["flags"] & STATE_LIC) != 0
-    has_nb = np.array([bool(sp.nb_of_state.get(n)) for n in range(len(st))])
-    folded = ((st["kind"] == KIND_INTER) | (st["kind"] == KIND_MOTION)) & (st["supported"] != 0) & \
-        (~lic | (has_nb & bool(lic_folds)))
-    sp.folded = folded
-    bi_lic_rows = {}            # first refinement slot of a LIC pass -> the CU's xvcgpu_mc_lic_block
-    for n in np.flatnonzero(folded):
-        s = st[n]
-        s_lic = bool(lic[n])
-        nbr = sp._nb_table()[sp.nb_of_state[n][0]] if s_lic else None
-        cds = cd_all[int(s["cand_first"]):int(s["cand_first"]) + int(s["cand_count"])]
-        plain = cds[cds["kind"] == 0]
-        aff = cds[cds["kind"] == 2]
-        pass_first[n] = len(passes)
-        me_next = int(s["me_first"])
-        aff_next = int(s["aff_first"])
-        for which, cu in ((0, plain), (1, aff)):
-            if not len(cu):
-                continue
-            assert len(cu) == nref[0] + nref[1], (n, len(cu), nref)
-            p = np.zeros((), PASS_DTYPE)
-            p["x"], p["y"], p["w"], p["h"] = s["x"], s["y"], s["w"], s["h"]
-            p["flags"] = (int(cu[0]["flags"]) & 1) | (CS_AFFINE if which else 0) | (CS_LIC if s_lic else 0)
-            assert not (s_lic and which)        # (never together: inter_search.cc:215-219)
-            p["num_refs"] = nref
-            p["same_poc_in_l0"] = same
-            p["lambda16"] = cu[0]["lambda16"]
-            p["ictx"] = sp.order["ictx"][int(cu[0]["ictx_index"])]
-            p["uni_job"], p["start_dist"], p["prev_job"] = -1, -1, -1
-            p["plain_pass"], p["eval"] = -1, -1
-            # the folds run the default SearchMotion (one refinement iteration, no forced
-            # zero L1 vector difference: xvcgpu_types.h); the captured encodes are such
-            assert not cds["force_mvd_zero_other"].any(), \
-                "a pass the folds would answer XVC_CS_WHICH_UNSUPPORTED (forced zero L1 mvd)"
-            for kind_bi in (1, 3):   # one refinement iteration: a candidate per searched picture
-                assert (cds["kind"] == kind_bi).sum() <= max(nref), \
-                    "a pass the folds would answer XVC_CS_WHICH_UNSUPPORTED (iterations > 1)"
-            p["bi_iterations"] = 1
-            pi = len(passes)
-            entries = []
-            for c in cu:
-                l, r = int(c["list"]), int(c["ref_idx"])
-                p["mvp"][l, r] = c["mvp"]
-                p["slot"][l, r] = slot_of[ref_lists[l][r]]
-                entries.append((l, r, bool(c["reused"])))
-            if which == 0 and s_lic:
-                # EvalStartMvp of a LIC CU compares COMPENSATED predictions
-                # (MotionCompensationMv(..., post_filter = true), inter_search.cc:980): XVC_INTER_LIC
-                # jobs into the scratch slots + their SAD against the original, as the affine
-                # pass's start does
-                first = len(aff_inter)
-                for l, r, _ in entries:
-                    p["start_dist"][l, r] = n_start_dist
-                    for cand in range(2):
-                        k = len(aff_inter) - first
-                        ib = np.zeros((), api.INTER_DTYPE)
-                        ib["x"], ib["y"], ib["w"], ib["h"] = s["x"], s["y"], s["w"], s["h"]
-                        ib["flags"] = api.INTER_LIC
-                        ib["neighbors"] = int(nbr["has_above"]) * 1 + int(nbr["has_left"]) * 2
-                        for f in ("above_x", "above_y", "left_x", "left_y"):
-                            ib[f] = nbr[f]
-                        ib["ref"] = (int(p["slot"][l, r]), -1)
-                        ib["mv"][0][0] = p["mvp"][l, r, cand][0]
-                        aff_inter.append(ib)
-                        aff_dst.append((SLOT * k, 0))
-                        aff_cands.append((SLOT * k, 0, int(s["w"]), int(s["h"]), 3, 0, 0, 0))
-                        aff_copy.append((int(s["x"]), int(s["y"]), SLOT * k, 0, int(s["w"]), int(s["h"]), 0, 0))
-                        n_start_dist += 1
-                assert len(aff_inter) - first <= MAX_SLOTS, "more start candidates than scratch slots"
-                aff_start[pi] = (first, len(aff_inter) - first, int(p["start_dist"][entries[0][0], entries[0][1]]))
-                ug = []
-                for l, r, reused in entries:
-                    if reused:
-                        continue
-                    p["uni_job"][l, r] = me_next
-                    assert sp.me_ref[me_next] == p["slot"][l, r], (n, l, r)
-                    me_work["mvp_x"][me_next] = me_work["mvp_y"][me_next] = 0x7fffff
-                    ug.append((int(p["slot"][l, r]), me_next))
-                    me_next += 1
-                uni_groups[pi] = ug
-                p["bi_job"] = n_bi_slots
-                q = np.zeros((), api.LIC_DTYPE)
-                q["x"], q["y"], q["w"], q["h"] = s["x"], s["y"], s["w"], s["h"]
-                q["neighbors"] = int(nbr["has_above"]) * 1 + int(nbr["has_left"]) * 2
-                for f in ("above_x", "above_y", "left_x", "left_y"):
-                    q[f] = nbr[f]
-                bi_lic_rows[n_bi_slots] = q
-                n_bi_slots += BI_SLOTS
-            elif which == 0:
-                # EvalStartMvp: two luma predictions + SAD per (list, picture), re-used ones too
-                order = sorted(range(len(entries)), key=lambda k: int(p["slot"][entries[k][0], entries[k][1]]))
-                groups = []
-                for k in order:
-                    l, r, _ = entries[k]
-                    sl = int(p["slot"][l, r])
-                    p["start_dist"][l, r] = n_start_dist
-                    for cand in range(2):
-                        start_cands.append((int(s["x"]), int(s["y"]), int(s["w"]), int(s["h"]), 3, 0,
-                                            int(p["mvp"][l, r, cand, 0, 0]), int(p["mvp"][l, r, cand, 0, 1])))
-                    if groups and groups[-1][0] == sl:
-                        groups[-1][2] += 2
-                    else:        # (slot, first distortion, count, first candidate)
-                        groups.append([sl, n_start_dist, 2, len(start_cands) - 2])
-                    n_start_dist += 2
-                start_groups[pi] = groups
-                ug = []
-                for l, r, reused in entries:
-                    if reused:
-                        continue
-                    p["uni_job"][l, r] = me_next
-                    assert sp.me_ref[me_next] == p["slot"][l, r], (n, l, r)
-                    me_work["mvp_x"][me_next] = me_work["mvp_y"][me_next] = 0x7fffff
-                    ug.append((int(p["slot"][l, r]), me_next))
-                    me_next += 1
-                uni_groups[pi] = ug
-                p["bi_job"] = n_bi_slots
-                n_bi_slots += BI_SLOTS
-            else:
-                p["plain_pass"] = pi - 1
-                first = len(aff_inter)
-                for l, r, _ in entries:
-                    p["start_dist"][l, r] = n_start_dist
-                    for cand in range(2):
-                        k = len(aff_inter) - first
-                        ib = np.zeros((), api.INTER_DTYPE)
-                        ib["x"], ib["y"], ib["w"], ib["h"] = s["x"], s["y"], s["w"], s["h"]
-                        ib["flags"] = api.INTER_AFFINE
-                        ib["ref"] = (int(p["slot"][l, r]), -1)
-                        ib["mv"][0] = p["mvp"][l, r, cand]
-                        aff_inter.append(ib)
-                        aff_dst.append((SLOT * k, 0))
-                        aff_cands.append((SLOT * k, 0, int(s["w"]), int(s["h"]), 3, 0, 0, 0))
-                        aff_copy.append((int(s["x"]), int(s["y"]), SLOT * k, 0, int(s["w"]), int(s["h"]), 0, 0))
-                        n_start_dist += 1
-                assert len(aff_inter) - first <= MAX_SLOTS
-                aff_start[pi] = (first, len(aff_inter) - first, int(p["start_dist"][entries[0][0], entries[0][1]]))
-                ug = []
-                for l, r, reused in entries:
-                    if reused:
-                        continue
-                    p["uni_job"][l, r] = len(aff_work_rows)
-                    assert sp.aff_ref[aff_next][0] == p["slot"][l, r]
-                    ug.append((int(p["slot"][l, r]), len(aff_work_rows)))
-                    aff_work_rows.append(aff_next)
-                    aff_next += 1
-                aff_uni_groups[pi] = ug
-                p["bi_job"] = len(aff_work_rows)
-                aff_work_rows += [-1] * BI_SLOTS
-            passes.append(p)
-        if len(plain):
-            assert me_next == int(s["me_first"]) + int(s["me_count"]), (n, me_next, s)
-        if len(aff):
-            assert aff_next == int(s["aff_first"]) + int(s["aff_uni_count"]), (n, aff_next, s)
-        pass_count[n] = len(passes) - pass_first[n]
-        if s["kind"] == KIND_INTER:
-            passes[-1]["eval"] = s["ev"]
-    sp.passes = np.array(passes, PASS_DTYPE) if passes else np.zeros(0, PASS_DTYPE)
-    sp.pass_first, sp.pass_count = pass_first, pass_count
-    sp.start_cands = np.array(start_cands, api.MCM_DTYPE) if start_cands else np.zeros(0, api.MCM_DTYPE)
-    sp.start_groups, sp.uni_groups, sp.aff_uni_groups, sp.aff_start = start_groups, uni_groups, aff_uni_groups, aff_start
-    sp.n_start_dist = n_start_dist
-    sp.aff_start_inter = np.array(aff_inter, api.INTER_DTYPE) if aff_inter else np.zeros(0, api.INTER_DTYPE)
-    sp.aff_start_dst = np.array(aff_dst, api.POS_DTYPE) if aff_dst else np.zeros(0, api.POS_DTYPE)
-    sp.aff_start_cands = np.array(aff_cands, api.CAND_DTYPE) if aff_cands else np.zeros(0, api.CAND_DTYPE)
-    sp.aff_start_copy = np.array(aff_copy, api.COPY_BLOCK_DTYPE) if aff_copy else np.zeros(0, api.COPY_BLOCK_DTYPE)
-    sp.me_work = me_work
-    sp.n_bi_slots = n_bi_slots
-    sp.bi_lic_work = np.zeros(max(n_bi_slots, 1), api.LIC_DTYPE)
-    for a_, q in bi_lic_rows.items():
-        sp.bi_lic_work[a_:a_ + BI_SLOTS] = q
-    aw = np.zeros(len(aff_work_rows), api.AFFINE_ME_DTYPE)
-    rows = np.array(aff_work_rows, np.int64) if aff_work_rows else np.zeros(0, np.int64)
-    src = rows >= 0
-    if src.any():
-        aw[src] = sp.aff_jobs[rows[src]]
-        aw["mvp"][src] = 0x7fffff           # composed on the device
-        aw["bootstrap"][src] = 0x7fffff
-    sp.aff_work, sp.aff_work_src = aw, rows
-    # the *_refs forms: per job the slot(s) of the picture(s) it works on (255: no job)
-    sp.start_slots = np.full(len(sp.start_cands), 255, np.uint8)
-    for groups in start_groups.values():
-        for sl, a, k, ca in groups:
-            sp.start_slots[ca:ca + k] = sl
-    sp.me_slots = np.asarray(sp.me_ref, np.uint8).copy()
-    sp.bi_slots = np.full((max(n_bi_slots, 1), 2), 255, np.uint8)
-    sp.aff_slots = np.full((max(len(aw), 1), 2), 255, np.uint8)
-    for pi, p in enumerate(sp.passes):
-        affine = bool(p["flags"] & CS_AFFINE)
-        if affine:
-            for sl, j in aff_uni_groups[pi]:
-                sp.aff_slots[j] = (sl, sl)
-        if p["num_refs"][1]:
-            bj = int(p["bi_job"])
-            for sl_ in range(2):
-                for r in range(int(p["num_refs"][sl_])):
-                    for o in range(int(p["num_refs"][1 - sl_])):
-                        k = bj + (sl_ * R3 + r) * R3 + o
-                        pair = (int(p["slot"][sl_, r]), int(p["slot"][1 - sl_, o]))
-                        (sp.aff_slots if affine else sp.bi_slots)[k] = pair
-    # the evaluations' prediction jobs: motion composed on the device for inter states
-    ei = sp.ev_inter.copy()
-    for n in np.flatnonzero((st["kind"] == KIND_INTER) & folded):
-        e = int(st["ev"][n])
-        # overwritten by the fold (a LIC CU's neighbour fields stay: they are the caller's)
-        ei["ref"][e], ei["mv"][e], ei["flags"][e] = (0, -1), 12345, 0
-    sp.ev_inter_work = ei
 
 
 class ChainedRun(SerialRun):
@@ -1339,7 +1156,7 @@ class ChainedRun(SerialRun):
     def __init__(self, api, ctx, sp, pics, width, height, ref_lists):
         super().__init__(api, ctx, sp, pics, width, height)
         if not hasattr(sp, "passes"):
-            build_passes(sp, ref_lists, self.lic_folds)
+            compose(sp, ref_lists, self.lic_folds)
         self.lib.xvc_host_cs_run_program.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                                      C.c_void_p]
         up = self._upload
@@ -1353,8 +1170,6 @@ class ChainedRun(SerialRun):
         d["ev_inter_work"] = up(sp.ev_inter_work)
         d["start_slots"], d["me_slots"] = up(sp.start_slots), up(sp.me_slots)
         d["bi_slots"], d["aff_slots"] = up(sp.bi_slots), up(sp.aff_slots)
-        if not hasattr(sp, "mg_fold"):
-            build_merge_folds(sp)
         d["mg_fold"], d["mg_slots"] = up(sp.mg_fold), up(sp.mg_slots)
         self.cres = {}
         for name, dt, n in (("start_dist", np.dtype("<u8"), sp.n_start_dist),
@@ -1375,61 +1190,13 @@ class ChainedRun(SerialRun):
         # Small results land in page-locked host memory the device writes directly
         # (xvcgpu_host_alloc): no copy kernel, no read-back call - they are there when
         # the chain's one wait returns.  Per evaluation state one block of distortions:
-        # [3 cbf-zero (Y, U, V)] [one per TransformAndReconstruct call].
-        st = sp.states
-        evs = np.flatnonzero(st["ev"] >= 0)
-        self.edist_first = np.full(len(st), -1, np.int64)
-        n_ed = 0
-        cands = []
-        for ns in evs:
-            r = st[ns]
-            ev, cf = int(r["ev"]), int(r["call_first"])
-            k = int(r["call_pass0"]) + int(r["call_pass1"])
-            self.edist_first[ns] = n_ed
-            blk = np.zeros(3 + k, api.EVAL_CAND_DTYPE)
-            evr = sp.ev_want[ev]
-            for c in range(3):
-                d_ = sp.ev_dz[ev, c]
-                blk[c] = (d_["x"], d_["y"], d_["w"], d_["h"], d_["metric"], d_["qp"], c, 0,
-                          int(evr["x"]) >> (1 if c else 0), int(evr["y"]) >> (1 if c else 0), 1, 0,
-                          sp.ev_weight[ev, c])
-            cc = sp.call_cand[cf:cf + k]
-            comp = sp.call_tx["comp"][cf:cf + k]
-            b = blk[3:]
-            for f in ("x", "y", "w", "h", "metric", "qp"):
-                b[f] = cc[f]
-            b["comp"], b["versus"] = comp, 1
-            b["ox"], b["oy"], b["orig_at"] = int(evr["x"]) >> (comp != 0), int(evr["y"]) >> (comp != 0), 1
-            b["weight"] = sp.ev_weight[ev][comp]
-            blk[3:] = b
-            cands.append(blk)
-            n_ed += 3 + k
-        allc = np.concatenate(cands) if cands else np.zeros(0, api.EVAL_CAND_DTYPE)
-        d["ev_cands"] = up(allc)
-        allc = allc.copy()
-        allc["orig_at"] = 0           # the form with the originals copied beside the slots
-        d["ev_cands_copy"] = up(allc)
-        # per TransformAndReconstruct call: where its original lies in the picture and its
-        # prediction in the scratch picture (the evaluation's slot 0), component planes
-        ce = sp.ev_want[sp.call_ev] if len(sp.call_tx) else sp.ev_want[:0]
-        sh = (sp.call_tx["comp"] != 0).astype(np.int64)
-        pos = np.zeros((len(sp.call_tx), 2), api.POS_DTYPE)
-        pos["x"][:, 0], pos["y"][:, 0] = ce["x"] >> sh, ce["y"] >> sh
-        d["call_pos"] = up(pos)
-        # the merge rankings' and the affine start predictors' distortions as evaluation
-        # candidates against the original picture (weight 1: the distortion itself)
-        mc = np.zeros((len(sp.mg_inter), 5), api.EVAL_CAND_DTYPE)
-        for f in ("x", "y", "w", "h", "metric"):
-            mc[f] = sp.mg_cands[f]
-        mc["ox"], mc["oy"], mc["orig_at"], mc["weight"] = sp.mg_want["x"][:, None], sp.mg_want["y"][:, None], 1, 1.0
-        d["mg_ecands"] = up(mc)
-        ac = np.zeros(len(sp.aff_start_cands), api.EVAL_CAND_DTYPE)
-        for f in ("x", "y", "w", "h", "metric"):
-            ac[f] = sp.aff_start_cands[f]
-        if len(ac):
-            ac["ox"], ac["oy"] = sp.aff_start_copy["sx"], sp.aff_start_copy["sy"]
-        ac["orig_at"], ac["weight"] = 1, 1.0
-        d["aff_start_ecands"] = up(ac)
+        # [3 cbf-zero (Y, U, V)] [one per TransformAndReconstruct call] (the builder's
+        # ev_cands / edist_first).
+        self.edist_first = sp.edist_first
+        n_ed = sp.n_edist
+        d["ev_cands"], d["ev_cands_copy"] = up(sp.ev_cands), up(sp.ev_cands_copy)
+        d["call_pos"] = up(sp.call_pos)
+        d["mg_ecands"], d["aff_start_ecands"] = up(sp.mg_ecands), up(sp.aff_start_ecands)
         self.z = {}
         for name, dt, n in (("nnz", np.dtype("<i4"), len(sp.call_tx)), ("edist", np.dtype("<u8"), n_ed),
                             ("mg_dist", np.dtype("<u8"), 5 * len(sp.mg_inter)),
@@ -1449,358 +1216,52 @@ class ChainedRun(SerialRun):
         self.ctx.sync()
 
     # ---- program ---------------------------------------------------------------
+    def _addrs(self):
+        """xvc_csb_addrs: where the program's ops point (the serial form's tables, the
+        uploads of the builder's arrays, the result arrays)."""
+        if getattr(self, "_csb_addrs", None) is None:
+            t, d = self.t, self.d
+            a = csb.Addrs()
+            for f in csb.ADDR_FIELDS:
+                if f == "h_results":
+                    v = self.cres["results"][1]
+                elif f == "h_ev_inter_out":
+                    v = self.cres["ev_inter_out"][1]
+                elif f.startswith("z_"):
+                    v = self.z[f[2:]][1]
+                elif f in d:
+                    v = d[f]
+                else:
+                    v = getattr(t, f)
+                setattr(a, f, int(v) if v else 0)
+            sp = self.sp
+            self._csb_keep = k = dict(
+                in_stage=np.ascontiguousarray(sp.in_stage, np.int32),
+                in_ctx=np.ascontiguousarray(sp.in_ctx, np.int32),
+                in_comp=np.ascontiguousarray(sp.in_comp, np.int32),
+                in_weight=np.ascontiguousarray(sp.in_weight, np.float64),
+                in_off=np.ascontiguousarray(sp.in_off, np.uint32),
+                bi_ref=np.ascontiguousarray(sp.bi_ref, np.int8))
+            i = csb.Intra()
+            for name, v in k.items():
+                setattr(i, name, v.ctypes.data if v.size else None)
+            i.n_in, i.n_in_levels = len(sp.in_off), int(sp.n_in_levels)
+            self._csb_addrs, self._csb_intra = a, i
+        return self._csb_addrs, self._csb_intra
+
     def program(self, first, n, by_position=True, verify=True, refs_form=None, live=False):
-        """Ops of the states [first, first + n): one chain (ending in a SYNC) per state,
-        or per visit of a CU position (consecutive states of one CU).  refs_form: a step
-        of SearchMotion into all the CU's reference pictures as ONE launch
-        (xvcgpu_*_refs) instead of one launch per picture; the read-backs of a chain
-        merged where their ranges touch (one copy per result array and chain).
-        live: the chains a LIVE encoder could issue - a chain ends wherever the reference's
-        control reads a cost that needs the host's entropy coder (GetCuCostWithoutSplit):
-        after every CompressInter's evaluation, and inside it in front of the gated second
-        transform pass (cost_full > best_cu_cost * 1.1, inter_search.cc:347-361); what the
-        device folds decide - EvalStartMvp, the lists' folds, the three-way choice, affine
-        against plain, the merge ranking (xvcgpu_cs_merge_fold) - needs no wait: a merge
-        ranking and its candidates' evaluations are one chain."""
+        """Ops of the states [first, first + n) from xvc_gpu::CuStateBuilder::Program
+        (xvc_cu_state_builder.cc): one chain (ending in a SYNC) per state, or per visit of a
+        CU position; refs_form: a step of SearchMotion into all the CU's reference pictures
+        as ONE launch; live: the chains a LIVE encoder could issue (a chain ends wherever the
+        reference's control reads a cost that needs the host's entropy coder)."""
         refs_form = self.refs_form if refs_form is None else refs_form
-        sp, api, t, d = self.sp, self.api, self.t, self.d
-        st = sp.states
-        ops = []
-        I = {k: v.itemsize for k, v in (("me", api.ME_DTYPE), ("res", api.MERES_DTYPE),
-                                        ("bi", api.BI_DTYPE), ("aff", api.AFFINE_ME_DTYPE),
-                                        ("affr", api.AFFINE_ME_RESULT_DTYPE), ("pass", PASS_DTYPE),
-                                        ("mcm", api.MCM_DTYPE), ("inter", api.INTER_DTYPE),
-                                        ("pos", api.POS_DTYPE), ("cand", api.CAND_DTYPE),
-                                        ("copy", api.COPY_BLOCK_DTYPE), ("tx", api.TX_DTYPE),
-                                        ("prm", api.RDOQ_PARAMS_DTYPE), ("ctx", api.RDOQ_CTX_DTYPE),
-                                        ("result", RESULT_DTYPE), ("intra", api.INTRA_DTYPE))}
-
-        def op(code, n_=0, r0=0, r1=0, i0=0, f=0.0, p=()):
-            ops.append((code, n_, r0, r1, i0, 0, f, tuple(int(x) for x in p) + (0,) * (8 - len(p))))
-
-        pending = []                   # (device, host, bytes) read-backs of the open chain
-
-        def flush_fetches():
-            pending.sort()
-            merged = []
-            for dev, host, nb in pending:
-                if merged and merged[-1][0] + merged[-1][2] >= dev and \
-                        host - merged[-1][1] == dev - merged[-1][0]:
-                    merged[-1][2] = max(merged[-1][2], dev + nb - merged[-1][0])
-                else:
-                    merged.append([dev, host, nb])
-            for dev, host, nb in merged:
-                fetch_now(dev, host, nb)
-            del pending[:]
-
-        def fetch(dev, host, nbytes):
-            if nbytes <= 0:
-                return
-            if refs_form:
-                pending.append((int(dev), int(host), int(nbytes)))
-            else:
-                fetch_now(dev, host, nbytes)
-
-        def fetch_now(dev, host, nbytes):
-            if nbytes:
-                op(OP_FETCH, nbytes, p=(dev, host))
-
-        def stage(s):
-            if int(s["nb_count"]):   # the reconstruction of that moment around a LIC state's CU
-                op(OP_COPY, int(s["nb_count"]), r0=PIC_NB, r1=PIC_REC,
-                   p=(t.d_nb_copy + int(s["nb_first"]) * I["copy"],))
-
-        def motion_lic(s):
-            """A LIC state's SearchMotion in the serial form (the searches' inputs from the
-            capture, no device folds: EvalStartMvp's compensated predictions and the LIC
-            syntax bit have no fold): AC-only searches, then the refinement against the
-            compensated prediction of the other list."""
-            ms = max(int(s["w"]), int(s["h"]))
-            mf, mc = int(s["me_first"]), int(s["me_count"])
-            for j in range(mf, mf + mc):
-                op(OP_ME, 1, r0=int(sp.me_ref[j]), r1=1, i0=ms,
-                   p=(t.d_me + j * I["me"], t.d_me_res + j * I["res"]))
-            fetch(t.d_me_res + mf * I["res"], t.h_me_res + mf * I["res"], mc * I["res"])
-            bf, bc = int(s["bi_first"]), int(s["bi_count"])
-            if bc and live:           # the host's fold over lists and pictures picks the bootstrap
-                flush_fetches()
-                op(OP_SYNC, i0=0, r0=int(s["kind"]))
-            for j in range(bf, bf + bc):
-                op(OP_BI_LIC, 1, r0=int(sp.bi_ref[j][0]), r1=int(sp.bi_ref[j][1]), i0=ms,
-                   p=(t.d_bi + j * I["bi"], t.d_bi_res + j * I["res"], t.d_bi_lic + j * 24))
-            fetch(t.d_bi_res + bf * I["res"], t.h_bi_res + bf * I["res"], bc * I["res"])
-            if live and int(s["kind"]) == KIND_INTER:      # the three-way choice is the host's
-                flush_fetches()
-                op(OP_SYNC, i0=0, r0=int(s["kind"]))
-
-        def intra(s):
-            """CompressIntra: the SATD pre-selection, a wait (the host sorts with the mode
-            bits), then the kept luma modes' and the chroma modes' PredictAndTransform
-            alternatives one behind the other at the CU's place.  The mode loops decide
-            nothing between the modes (intra_search.cc:61-82, :118-150): a chain by
-            position / state waits once more at the end, a live chain behind the luma modes
-            and behind the chroma modes (CompressIntra prices luma before chroma starts)."""
-            ms = max(int(s["w"]), int(s["h"]))
-            k = int(s["in_satd"])
-            if k >= 0:
-                op(OP_INTRA_SATD, 1, i0=ms, p=(t.d_in_satd_jobs + k * I["intra"], t.d_in_satd + 4 * 67 * k))
-                fetch(t.d_in_satd + 4 * 67 * k, t.h_in_satd + 4 * 67 * k, 4 * 67)
-                flush_fetches()
-                op(OP_SYNC, i0=0, r0=KIND_INTRA)
-            a, nc_ = int(s["in_first"]), int(s["in_count"])
-            for c in range(a, a + nc_):
-                sf_, sc_ = int(sp.in_stage[c][0]), int(sp.in_stage[c][1])
-                if sc_:
-                    op(OP_COPY, sc_, r0=PIC_NB, r1=PIC_REC, p=(t.d_nb_copy + sf_ * I["copy"],))
-                op(OP_INTRA_PRED, 1, p=(t.d_in_pred + c * I["intra"],))
-                op(OP_RESIDUAL_INTRA, 1, p=(t.d_in_tx + c * I["tx"], t.d_in_off + 4 * c, t.d_in_nnz + 4 * c,
-                                            t.d_in_contexts + int(sp.in_ctx[c]) * I["ctx"], t.d_in_prm + c * I["prm"]))
-                op(OP_METRIC, 1, r0=PIC_ORIG, r1=PIC_IREC, i0=int(sp.in_comp[c]), f=float(sp.in_weight[c]),
-                   p=(t.d_in_cand + c * I["cand"], t.d_in_dist + 8 * c))
-                if live and c + 1 < a + nc_ and int(sp.in_comp[c]) == 0 and int(sp.in_comp[c + 1]) != 0:
-                    fetch(t.d_in_nnz + 4 * a, t.h_in_nnz + 4 * a, 4 * (c + 1 - a))
-                    fetch(t.d_in_dist + 8 * a, t.h_in_dist + 8 * a, 8 * (c + 1 - a))
-                    flush_fetches()
-                    op(OP_SYNC, i0=0, r0=KIND_INTRA)
-            fetch(t.d_in_nnz + 4 * a, t.h_in_nnz + 4 * a, 4 * nc_)
-            fetch(t.d_in_dist + 8 * a, t.h_in_dist + 8 * a, 8 * nc_)
-            if nc_:
-                la, lb = int(sp.in_off[a]), (int(sp.in_off[a + nc_]) if a + nc_ < len(sp.in_off) else sp.n_in_levels)
-                fetch(t.d_in_levels + 2 * la, t.h_in_levels + 2 * la, 2 * (lb - la))
-
-        def motion(s, n_state):
-            if (int(s["flags"]) & STATE_LIC) and not sp.folded[n_state]:
-                return motion_lic(s)
-            ms = max(int(s["w"]), int(s["h"]))
-            cls = 16 if ms <= 16 else (32 if ms <= 32 else 64)
-            pf, pc = int(sp.pass_first[n_state]), int(sp.pass_count[n_state])
-            for pi in range(pf, pf + pc):
-                p = sp.passes[pi]
-                affine = bool(p["flags"] & CS_AFFINE)
-                licp = bool(p["flags"] & CS_LIC)  # XVC_INTER_LIC start predictions, LIC searches per picture
-                P = d["passes"]                  # the folds index the arrays absolutely (i0 = pass)
-                if licp:
-                    a, k, sd = sp.aff_start[pi]
-                    op(OP_INTER_PRED, k, r0=1, r1=PIC_S_PRED, p=(d["aff_start_inter"] + a * I["inter"],
-                                                                 d["aff_start_dst"] + a * I["pos"]))
-                    if self.no_copies:
-                        op(OP_EVAL_DIST, k, r0=1, p=(d["aff_start_ecands"] + a * 24, d["start_dist"] + 8 * sd))
-                    else:
-                        op(OP_COPY, k, r0=PIC_ORIG, r1=PIC_S_ORIG, p=(d["aff_start_copy"] + a * I["copy"],))
-                        op(OP_METRIC, k, r0=PIC_S_ORIG, r1=PIC_S_PRED, i0=0, f=1.0,
-                           p=(d["aff_start_cands"] + a * I["cand"], d["start_dist"] + 8 * sd))
-                elif not affine and refs_form:
-                    g = sp.start_groups[pi]
-                    a0, ca0, kk = g[0][1], g[0][3], sum(x[2] for x in g)
-                    assert all(x[1] - a0 == x[3] - ca0 for x in g) and g[-1][3] + g[-1][2] == ca0 + kk
-                    op(OP_MC_METRIC_REFS, kk, p=(d["start_cands"] + ca0 * I["mcm"], d["start_dist"] + 8 * a0,
-                                                 d["start_slots"] + ca0))
-                elif not affine:
-                    for sl, a, k, ca in sp.start_groups[pi]:
-                        op(OP_MC_METRIC, k, r0=sl, p=(d["start_cands"] + ca * I["mcm"], d["start_dist"] + 8 * a))
-                else:
-                    a, k, sd = sp.aff_start[pi]
-                    if not self.no_copies:
-                        op(OP_COPY, k, r0=PIC_ORIG, r1=PIC_S_ORIG, p=(d["aff_start_copy"] + a * I["copy"],))
-                    op(OP_INTER_PRED, k, r1=PIC_S_PRED, p=(d["aff_start_inter"] + a * I["inter"],
-                                                           d["aff_start_dst"] + a * I["pos"]))
-                    if self.no_copies:
-                        op(OP_EVAL_DIST, k, r0=1, p=(d["aff_start_ecands"] + a * 24, d["start_dist"] + 8 * sd))
-                    else:
-                        op(OP_METRIC, k, r0=PIC_S_ORIG, r1=PIC_S_PRED, i0=0, f=1.0,
-                           p=(d["aff_start_cands"] + a * I["cand"], d["start_dist"] + 8 * sd))
-                op(OP_START_FOLD, 1, i0=pi, p=(P, d["start_dist"], d["me_work"], d["me_res_c"], d["aff_work"]))
-                ug = sp.aff_uni_groups[pi] if affine else sp.uni_groups[pi]
-                if licp:
-                    for sl, j in ug:
-                        op(OP_ME, 1, r0=sl, r1=1, i0=ms, p=(d["me_work"] + j * I["me"], d["me_res_c"] + j * I["res"]))
-                elif refs_form and ug:
-                    j0 = ug[0][1]
-                    assert [j for _, j in ug] == list(range(j0, j0 + len(ug)))
-                    if not affine:
-                        op(OP_ME_REFS, len(ug), i0=cls, p=(d["me_work"] + j0 * I["me"], d["me_res_c"] + j0 * I["res"],
-                                                           d["me_slots"] + j0))
-                    else:
-                        op(OP_AFFINE_REFS, len(ug), i0=int(s["h"]),
-                           p=(d["aff_work"] + j0 * I["aff"], d["aff_res_c"] + j0 * I["affr"], d["aff_slots"] + 2 * j0))
-                elif not affine:
-                    for sl, j in ug:
-                        op(OP_ME, 1, r0=sl, i0=ms, p=(d["me_work"] + j * I["me"], d["me_res_c"] + j * I["res"]))
-                else:
-                    for sl, j in ug:
-                        op(OP_AFFINE, 1, r0=sl, r1=sl, p=(d["aff_work"] + j * I["aff"], d["aff_res_c"] + j * I["affr"]))
-                op(OP_UNI_FOLD, 1, i0=pi, p=(P, d["me_res_c"], d["aff_res_c"], d["bi_work"], d["aff_work"]))
-                if p["num_refs"][1] and licp:
-                    bj = int(p["bi_job"])
-                    for sl_ in range(2):
-                        for r in range(int(p["num_refs"][sl_])):
-                            for o in range(int(p["num_refs"][1 - sl_])):
-                                k = bj + (sl_ * R3 + r) * R3 + o
-                                rs, ro = int(p["slot"][sl_, r]), int(p["slot"][1 - sl_, o])
-                                op(OP_BI_LIC, 1, r0=rs, r1=ro, i0=ms,
-                                   p=(d["bi_work"] + k * I["bi"], d["bi_res_c"] + k * I["res"],
-                                      d["bi_lic_work"] + k * 24))
-                elif p["num_refs"][1] and refs_form:
-                    bj = int(p["bi_job"])
-                    if not affine:
-                        op(OP_BI_REFS, BI_SLOTS, i0=cls, p=(d["bi_work"] + bj * I["bi"], d["bi_res_c"] + bj * I["res"],
-                                                            d["bi_slots"] + 2 * bj))
-                    else:
-                        op(OP_AFFINE_REFS, BI_SLOTS, i0=int(s["h"]),
-                           p=(d["aff_work"] + bj * I["aff"], d["aff_res_c"] + bj * I["affr"], d["aff_slots"] + 2 * bj))
-                elif p["num_refs"][1]:
-                    bj = int(p["bi_job"])
-                    for sl_ in range(2):
-                        for r in range(int(p["num_refs"][sl_])):
-                            for o in range(int(p["num_refs"][1 - sl_])):
-                                k = bj + (sl_ * R3 + r) * R3 + o
-                                rs, ro = int(p["slot"][sl_, r]), int(p["slot"][1 - sl_, o])
-                                if not affine:
-                                    op(OP_BI, 1, r0=rs, r1=ro, i0=ms,
-                                       p=(d["bi_work"] + k * I["bi"], d["bi_res_c"] + k * I["res"]))
-                                else:
-                                    op(OP_AFFINE, 1, r0=rs, r1=ro,
-                                       p=(d["aff_work"] + k * I["aff"], d["aff_res_c"] + k * I["affr"]))
-                op(OP_BI_FOLD, 1, i0=pi, p=(P, d["bi_res_c"], d["aff_res_c"], d["ev_inter_work"]))
-            fetch(d["results"] + pf * I["result"], self.cres["results"][1] + pf * I["result"], pc * I["result"])
-
-        def slot_of(e):
-            """the evaluation's slot, when its ranking is folded by THIS program"""
-            sl = int(sp.ev_merge_slot[e]) if self.merge_fold else -1
-            if sl >= 0 and not (first <= sp.merge_state[sl // MERGE_SLOTS] < first + n):
-                sl = -1
-            return sl
-
-        def evaluation(s, n_state):
-            lic_ = 1 if int(s["flags"]) & STATE_LIC else 0   # INTER_PRED: neighbours from the reconstruction
-            e = int(s["ev"])
-            n0, n1 = int(s["call_pass0"]), int(s["call_pass1"])
-            cf, k = int(s["call_first"]), n0 + n1
-            ed = int(self.edist_first[n_state])
-            z_nnz, z_ed = self.z["nnz"][1], self.z["edist"][1]
-            if live and n1:
-                # the first transform pass, a wait (the host prices it and decides the gate),
-                # then the second pass' calls
-                co = int(s["copy_first"])
-                sl = slot_of(e)
-                pred_jobs = d["mg_slots"] + 3 * sl * I["inter"] if sl >= 0 else \
-                    d["ev_inter_work"] + 3 * e * I["inter"]
-                nc_ = self.no_copies
-                ecands = d["ev_cands"] if nc_ else d["ev_cands_copy"]
-                if not nc_:
-                    op(OP_COPY, 3 + n0, r0=PIC_ORIG, r1=PIC_S_ORIG, p=(t.d_copy_orig + co * I["copy"],))
-                op(OP_INTER_PRED, 3, r0=lic_, r1=PIC_S_PRED, p=(pred_jobs, t.d_ev_dst + 3 * e * I["pos"]))
-                if not nc_:
-                    op(OP_COPY, n0, r0=PIC_S_PRED, r1=PIC_S_PRED, p=(t.d_call_copy_pred + cf * I["copy"],))
-                fe_ = nc_ and self.fused_eval
-                op(OP_RESIDUAL, n0, r0=3 if fe_ else 0,
-                   p=(t.d_call_tx + cf * I["tx"], t.d_call_off + 4 * cf, z_nnz + 4 * cf,
-                      t.d_contexts + int(sp.ev_ctx[e]) * I["ctx"], t.d_call_prm + cf * I["prm"],
-                      d["call_pos"] + 2 * cf * I["pos"] if nc_ else 0) +
-                   ((ecands + ed * 24, z_ed + 8 * ed) if fe_ else ()))
-                if not fe_:
-                    op(OP_EVAL_DIST, 3 + n0, r0=1 if nc_ else 0, p=(ecands + ed * 24, z_ed + 8 * ed))
-                flush_fetches()
-                op(OP_SYNC, i0=0, r0=int(s["kind"]))
-                c1_ = cf + n0
-                if not nc_:
-                    op(OP_COPY, n1, r0=PIC_ORIG, r1=PIC_S_ORIG, p=(t.d_copy_orig + (co + 3 + n0) * I["copy"],))
-                    op(OP_COPY, n1, r0=PIC_S_PRED, r1=PIC_S_PRED, p=(t.d_call_copy_pred + c1_ * I["copy"],))
-                op(OP_RESIDUAL, n1, r0=0,
-                   p=(t.d_call_tx + c1_ * I["tx"], t.d_call_off + 4 * c1_, z_nnz + 4 * c1_,
-                      t.d_contexts + int(sp.ev_ctx[e]) * I["ctx"], t.d_call_prm + c1_ * I["prm"],
-                      d["call_pos"] + 2 * c1_ * I["pos"] if nc_ else 0) +
-                   ((ecands + (ed + 3 + n0) * 24, z_ed + 8 * (ed + 3 + n0)) if fe_ else ()))
-                if not fe_:
-                    op(OP_EVAL_DIST, n1, r0=1 if nc_ else 0,
-                       p=(ecands + (ed + 3 + n0) * 24, z_ed + 8 * (ed + 3 + n0)))
-                fetch(t.d_levels + 2 * int(s["level_first"]), t.h_levels + 2 * int(s["level_first"]),
-                      2 * int(s["level_count"]))
-                if verify and s["kind"] == KIND_INTER:
-                    fetch(d["ev_inter_work"] + 3 * e * I["inter"],
-                          self.cres["ev_inter_out"][1] + 3 * e * I["inter"], 3 * I["inter"])
-                if verify and sl >= 0:
-                    fetch(pred_jobs, self.z["mg_slots_out"][1] + 3 * sl * I["inter"], 3 * I["inter"])
-                return
-            nc_ = self.no_copies
-            if not nc_:
-                op(OP_COPY, 3 + k, r0=PIC_ORIG, r1=PIC_S_ORIG, p=(t.d_copy_orig + int(s["copy_first"]) * I["copy"],))
-            sl = slot_of(e)
-            pred_jobs = d["mg_slots"] + 3 * sl * I["inter"] if sl >= 0 else \
-                d["ev_inter_work"] + 3 * e * I["inter"]
-            op(OP_INTER_PRED, 3, r0=lic_, r1=PIC_S_PRED, p=(pred_jobs, t.d_ev_dst + 3 * e * I["pos"]))
-            if verify and sl >= 0:      # the slot's motion, to be held against the capture
-                fetch(pred_jobs, self.z["mg_slots_out"][1] + 3 * sl * I["inter"], 3 * I["inter"])
-            if not nc_:
-                op(OP_COPY, k, r0=PIC_S_PRED, r1=PIC_S_PRED, p=(t.d_call_copy_pred + cf * I["copy"],))
-            if nc_ and self.fused_eval:
-                # the alternatives' reconstruction and all of the evaluation's distortions
-                # (three cbf-zero ones in front) in ONE launch
-                op(OP_RESIDUAL, k, r0=3,
-                   p=(t.d_call_tx + cf * I["tx"], t.d_call_off + 4 * cf, z_nnz + 4 * cf,
-                      t.d_contexts + int(sp.ev_ctx[e]) * I["ctx"], t.d_call_prm + cf * I["prm"],
-                      d["call_pos"] + 2 * cf * I["pos"], d["ev_cands"] + ed * 24, z_ed + 8 * ed))
-            else:
-                op(OP_RESIDUAL, k, p=(t.d_call_tx + cf * I["tx"], t.d_call_off + 4 * cf, z_nnz + 4 * cf,
-                                      t.d_contexts + int(sp.ev_ctx[e]) * I["ctx"], t.d_call_prm + cf * I["prm"],
-                                      d["call_pos"] + 2 * cf * I["pos"] if nc_ else 0))
-                # the three cbf-zero distortions and every alternative's, one launch
-                op(OP_EVAL_DIST, 3 + k, r0=1 if nc_ else 0,
-                   p=((d["ev_cands"] if nc_ else d["ev_cands_copy"]) + ed * 24, z_ed + 8 * ed))
-            fetch(t.d_levels + 2 * int(s["level_first"]), t.h_levels + 2 * int(s["level_first"]),
-                  2 * int(s["level_count"]))
-            if verify and s["kind"] == KIND_INTER:   # (an encoder reads the motion from `results`)
-                fetch(d["ev_inter_work"] + 3 * e * I["inter"],
-                      self.cres["ev_inter_out"][1] + 3 * e * I["inter"], 3 * I["inter"])
-
-        chain_states, chain_kind, prev_key = 0, 0, None
-        merge_open = False             # live: the open chain is a merge ranking + its candidates
-        for n_state in range(first, first + n):
-            s = st[n_state]
-            if not s["supported"]:
-                continue
-            key = (int(s["x"]), int(s["y"]), int(s["w"]), int(s["h"]))
-            if live:
-                stay = merge_open and key == prev_key and int(s["kind"]) == KIND_EVAL and \
-                    slot_of(int(s["ev"])) >= 0
-                merge_open = stay or (int(s["kind"]) == KIND_MERGE_RANK and self.merge_fold)
-                cut = not stay
-            else:
-                cut = not by_position or key != prev_key
-            if chain_states and cut:
-                flush_fetches()
-                op(OP_SYNC, i0=chain_states, r0=chain_kind)
-                chain_states = 0
-            prev_key = key
-            kind = int(s["kind"])
-            stage(s)
-            if kind == KIND_MERGE_RANK:
-                m = int(s["merge"]) * 5
-                if not self.no_copies:
-                    op(OP_COPY, 5, r0=PIC_ORIG, r1=PIC_S_ORIG, p=(t.d_mg_copy + m * I["copy"],))
-                op(OP_INTER_PRED, 5, r0=1 if int(s["flags"]) & STATE_LIC else 0, r1=PIC_S_PRED,
-                   p=(t.d_mg_inter + m * I["inter"], t.d_mg_dst + m * I["pos"]))
-                if self.no_copies:
-                    op(OP_EVAL_DIST, 5, r0=1, p=(d["mg_ecands"] + m * 24, self.z["mg_dist"][1] + 8 * m))
-                else:
-                    op(OP_METRIC, 5, r0=PIC_S_ORIG, r1=PIC_S_PRED, i0=0, f=1.0,
-                       p=(t.d_mg_cands + m * I["cand"], self.z["mg_dist"][1] + 8 * m))
-                if self.merge_fold:
-                    op(OP_MERGE_FOLD, 1, i0=m // 5,
-                       p=(d["mg_fold"], self.z["mg_dist"][1], t.d_mg_inter, self.z["mg_res"][1], d["mg_slots"]))
-            elif kind == KIND_INTRA:
-                intra(s)
-            else:
-                if kind in (KIND_INTER, KIND_MOTION):
-                    motion(s, n_state)
-                if kind in (KIND_EVAL, KIND_INTER):
-                    evaluation(s, n_state)
-            chain_kind = max(chain_kind, kind) if chain_states else kind
-            chain_states += 1
-        if chain_states:
-            flush_fetches()
-            op(OP_SYNC, i0=chain_states, r0=chain_kind)
-        return np.array(ops, OP_DTYPE)
+        a, i = self._addrs()
+        flags = (csb.BY_POSITION * bool(by_position) | csb.VERIFY * bool(verify) |
+                 csb.REFS_FORM * bool(refs_form) | csb.LIVE * bool(live) |
+                 csb.NO_COPIES * bool(self.no_copies) | csb.FUSED_EVAL * bool(self.fused_eval) |
+                 csb.MERGE_FOLD * bool(self.merge_fold))
+        return self.sp.builder.program(a, i, int(first), int(n), int(flags))
 
     def run_program(self, ops):
         stats = CsStats()

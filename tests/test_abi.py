@@ -243,3 +243,98 @@ def test_cpp_frame_pass_program_matches_oracle(api, tmp_path):
         assert (int(got[3]), int(got[5])) == ssd, n
         assert int(got[7], 16) == fnv(inner), n
         ref = rec
+
+
+def test_cpp_builder_composes_a_state(api, tmp_path):
+    """A caller written in C++ hands ONE CompressInter state to xvc_gpu::CuStateBuilder
+    (xvc_cu_state_builder.h: what CuEncoder holds - CU, reference lists, AMVP predictors per
+    (list, picture), lambda, contexts) and gets the pass record, the work arrays and the
+    chain's op program: built with plain g++ against libxvchost.so, no GPU needed."""
+    import subprocess
+    from xvc_amd import build
+    build.build_host()
+    src = tmp_path / "one_state.cc"
+    src.write_text(r'''
+#include <cstdio>
+#include <cstring>
+#include "xvc_cu_state_builder.h"
+#define CHECK(c) do { if (!(c)) { std::printf("FAILED %s (line %d)\n", #c, __LINE__); return 1; } } while (0)
+int main() {
+  // a 16x16 CU at (32, 16) of a B picture with one picture per list (POC 0 and POC 4)
+  xvc_cs_state st;
+  std::memset(&st, 0, sizeof(st));
+  st.kind = XVC_CS_INTER; st.x = 32; st.y = 16; st.w = 16; st.h = 16; st.supported = 1;
+  st.me_first = 0; st.me_count = 2; st.ev = 0; st.call_first = 0; st.call_pass0 = 3;
+  st.merge = -1; st.in_satd = -1; st.level_count = 384;
+  xvc_csb_ref_entry en[2];
+  std::memset(en, 0, sizeof(en));
+  en[0].list = 0; en[0].ref_idx = 0; en[0].mvp[0][0][0] = 16; en[0].mvp[1][0][1] = -32;
+  en[1].list = 1; en[1].ref_idx = 0; en[1].mvp[0][0][0] = -16;
+  xvc_csb_motion mo;
+  std::memset(&mo, 0, sizeof(mo));
+  mo.state = 0; mo.nb = -1; mo.plain.first = 0; mo.plain.n = 2; mo.plain.lambda16 = 123456;
+  xvcgpu_me_block me[2];
+  std::memset(me, 0, sizeof(me));
+  for (int k = 0; k < 2; k++) { me[k].x = 32; me[k].y = 16; me[k].w = me[k].h = 16; me[k].search_range = 64; }
+  const int8_t me_ref[2] = {0, 1};
+  const int32_t slot_pocs[2] = {0, 4};
+  xvcgpu_inter_block ev_inter[3];
+  std::memset(ev_inter, 0, sizeof(ev_inter));
+  xvc_csb_eval ev;
+  std::memset(&ev, 0, sizeof(ev));
+  ev.x = 32; ev.y = 16; ev.merge_slot = -1;
+  for (int c = 0; c < 3; c++) ev.weight[c] = 1.0;
+  const int32_t ev_ctx[1] = {0};
+  xvcgpu_metric_cand call_cand[3];
+  std::memset(call_cand, 0, sizeof(call_cand));
+  const uint8_t call_comp[3] = {0, 1, 2};
+  const int32_t call_ev[3] = {0, 0, 0};
+  xvc_csb_picture pic;
+  std::memset(&pic, 0, sizeof(pic));
+  pic.states = &st; pic.n_states = 1;
+  pic.ref_poc[0][0] = 0; pic.ref_poc[1][0] = 4; pic.n_ref[0] = pic.n_ref[1] = 1;
+  pic.slot_pocs = slot_pocs; pic.n_slots = 2; pic.lic_folds = 1;
+  pic.motions = &mo; pic.n_motions = 1; pic.entries = en;
+  pic.me_jobs = me; pic.me_ref = me_ref; pic.n_me = 2;
+  pic.ev_inter = ev_inter; pic.n_ev = 1; pic.evals = &ev; pic.ev_ctx = ev_ctx;
+  pic.call_cand = call_cand; pic.call_comp = call_comp; pic.call_ev = call_ev; pic.n_calls = 3;
+  xvc_csb *b = nullptr;
+  CHECK(xvc_host_csb_build(&pic, &b) == 0 && b);
+  int64_t bytes = 0;
+  const xvcgpu_cs_pass *ps = (const xvcgpu_cs_pass *)xvc_host_csb_array(b, XVC_CSB_PASSES, &bytes);
+  CHECK(bytes == (int64_t)sizeof(xvcgpu_cs_pass) && ps);
+  CHECK(ps->x == 32 && ps->w == 16 && ps->lambda16 == 123456 && ps->eval == 0 && ps->plain_pass == -1);
+  CHECK(ps->uni_job[0][0] == 0 && ps->uni_job[1][0] == 1 && ps->slot[0][0] == 0 && ps->slot[1][0] == 1);
+  CHECK(ps->mvp[0][0][1][0][1] == -32 && ps->same_poc_in_l0[0] == -1 && ps->bi_job == 0);
+  CHECK(xvc_host_csb_n_start_dist(b) == 4 && xvc_host_csb_n_bi_slots(b) == 2 * 3 * 3);
+  const xvcgpu_me_block *mw = (const xvcgpu_me_block *)xvc_host_csb_array(b, XVC_CSB_ME_WORK, &bytes);
+  CHECK(bytes == 2 * (int64_t)sizeof(xvcgpu_me_block) && mw[0].mvp_x == 0x7fffff);   // the device's to compose
+  xvc_csb_addrs a;
+  std::memset(&a, 0, sizeof(a));
+  xvc_csb_intra in;
+  std::memset(&in, 0, sizeof(in));
+  int64_t n_ops = 0;
+  const xvc_cs_op *ops = xvc_host_csb_program(
+      b, &a, &in, 0, 1, XVC_CSB_BY_POSITION | XVC_CSB_REFS_FORM | XVC_CSB_NO_COPIES | XVC_CSB_FUSED_EVAL, &n_ops);
+  const int want[] = {XVC_OP_MC_METRIC_REFS, XVC_OP_START_FOLD, XVC_OP_ME_REFS, XVC_OP_UNI_FOLD,
+                      XVC_OP_BI_REFS, XVC_OP_BI_FOLD, XVC_OP_INTER_PRED, XVC_OP_RESIDUAL};
+  CHECK(ops && n_ops >= 9);
+  for (int k = 0; k < 8; k++) CHECK(ops[k].opcode == want[k]);
+  CHECK(ops[0].n == 4 && ops[2].n == 2 && ops[2].i0 == 16 && ops[7].n == 3 && ops[7].r0 == 3);
+  CHECK(ops[n_ops - 1].opcode == XVC_OP_SYNC && ops[n_ops - 1].i0 == 1);
+  // an entry list that does not cover both lists is refused
+  mo.plain.n = 1;
+  xvc_csb *b2 = nullptr;
+  CHECK(xvc_host_csb_build(&pic, &b2) != 0 && !b2);
+  xvc_host_csb_destroy(b);
+  std::printf("OK %lld ops\n", (long long)n_ops);
+  return 0;
+}
+''')
+    exe = str(tmp_path / "one_state")
+    host = os.path.join(ROOT, "xvc_amd")
+    subprocess.check_call(["g++", "-std=c++11", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"),
+                           "-I", os.path.join(host, "host"), str(src), "-o", exe, "-L", host, "-lxvchost",
+                           "-lxvcgpu", "-Wl,-rpath," + host])
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 0 and r.stdout.startswith("OK"), r.stdout + r.stderr

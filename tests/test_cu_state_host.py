@@ -67,7 +67,7 @@ def test_passes_of_a_captured_picture():
     """Every SearchMotion of the picture becomes a pass whose entries are the (list,
     picture) pairs SearchRefIdx walked; the affine pass follows its plain pass."""
     sp = rd_serial.SerialPicture(api, "tiny", 2)
-    rd_serial.build_passes(sp, rd_serial.ref_lists_of("tiny", 2))
+    rd_serial.compose(sp, rd_serial.ref_lists_of("tiny", 2))
     st, ps = sp.states, sp.passes
     # (the LIC states too: XVC_CS_LIC passes, their neighbour records are in the capture)
     motion = ((st["kind"] == rd_serial.KIND_INTER) | (st["kind"] == rd_serial.KIND_MOTION)) & (st["supported"] != 0)
@@ -87,7 +87,7 @@ def test_passes_of_a_captured_picture():
 
 
 def test_merge_fold_records_of_a_captured_picture():
-    """tests/rd_serial.build_merge_folds: one xvcgpu_cs_merge record and four evaluation
+    """xvc_gpu::CuStateBuilder's merge folds: one xvcgpu_cs_merge record and four evaluation
     slots per merge ranking; the captured merge-candidate evaluations find their slot
     (ranked candidate with the same motion) - the harness-side map the GPU test checks the
     device's fold through.  Struct sizes as the C compiler lays them out."""
@@ -96,7 +96,7 @@ def test_merge_fold_records_of_a_captured_picture():
     # are not replayed, their plain candidates' evaluations keep the capture's job)
     for name, poc, least in (("tiny", 2, 0.5), ("c0", 4, 0.85)):
         sp = rd_serial.SerialPicture(api, name, poc)
-        rd_serial.build_merge_folds(sp)
+        rd_serial.compose(sp, rd_serial.ref_lists_of(name, poc))
         n_m = len(sp.mg_inter)
         assert len(sp.mg_fold) == n_m and sp.mg_slots.shape == (4 * n_m, 3)
         st = sp.states

@@ -37,7 +37,7 @@ def deps():
 
 HOST_OUT = os.path.join(HERE, "libxvchost.so")
 HOST_SOURCES = ["xvc_picture_decoder.cc", "xvc_picture_schedule.cc", "xvc_inter_search.cc",
-                "xvc_shard_filter.cc", "xvc_cu_state.cc", "xvc_shard_engine.cc", "xvc_picture_engine.cc"]
+                "xvc_shard_filter.cc", "xvc_cu_state.cc", "xvc_cu_state_builder.cc", "xvc_shard_engine.cc", "xvc_picture_engine.cc"]
 
 
 def build_host(force=False, verbose=False):
