@@ -517,13 +517,9 @@ extern "C" int xvc_host_cs_run_programs_interleaved(int k, xvcgpu_ctx *const *ct
 // groups the steps by kind (and kernel instance) and issues one xvcgpu_cs_segs_launch per
 // group - the chains' jobs side by side in the grid's y - so the launch path carries
 // (kinds per round) launches for k chain steps instead of k.  A chain's steps stay in order
-// by EVENTS: every launch is followed by an event on its stream, a chain remembers the event
-// of its last step, and a group's launch waits for exactly the events of the chains it holds
-// (round 5 made every stream wait for every stream's last round: a round then lasted as long
-// as its slowest kernel - a 64x64 CU's refinement, 89 us - for every chain in it).  A kind
-// of step keeps its stream (StreamOf), so the slow kinds queue behind each other and nobody
-// else.  A chain that reaches its SYNC sits out until its event has passed (the others keep
-// the device busy).  Steps without a batched form are issued as they are.
+// because a round issues at most one launch-step per chain and the stream is in order; a
+// chain that reaches its SYNC records an event and sits out until the event has passed
+// (the others keep the device busy).  Steps without a batched form are issued as they are.
 namespace {
 int SegKindOf(const xvc_cs_op &o) {
   switch (o.opcode) {
@@ -544,18 +540,14 @@ int SegKindOf(const xvc_cs_op &o) {
 }
 }  // namespace
 
-// The stream a kind of step is launched on (n streams): the long searches on streams of
-// their own - refinement, affine -, the uni-directional searches and the reconstruction on a
-// third, everything short (folds, start predictors, predictions, distortions, read-backs)
-// on stream 0.
-static int StreamOf(int kind, int n) {
-  if (n <= 1) return 0;
+// how long a kind's launch lasts, roughly (to deal the groups of a round over the streams)
+static int SegWeight(int kind, int key) {
   switch (kind) {
-    case XVC_CS_SEG_BI_REFS: return 1 % n;
-    case XVC_CS_SEG_AFFINE_REFS: return n > 2 ? 2 : 1 % n;
-    case XVC_CS_SEG_ME_REFS:
-    case XVC_CS_SEG_RESIDUAL_AT: return n > 3 ? 3 : (n > 2 ? 2 : 1) % n;
-    default: return 0;
+    case XVC_CS_SEG_BI_REFS: return key >= 64 ? 80 : (key >= 32 ? 36 : 22);
+    case XVC_CS_SEG_AFFINE_REFS: return 60;
+    case XVC_CS_SEG_RESIDUAL_AT: return 45;
+    case XVC_CS_SEG_ME_REFS: return key >= 64 ? 50 : (key >= 32 ? 30 : 13);
+    default: return 9;
   }
 }
 
@@ -570,11 +562,7 @@ extern "C" int xvc_host_cs_run_programs_engine(xvcgpu_ctx *const *ctxs, int n_ct
   xvcgpu_ctx *ctx = ctxs[0];
   std::memset(stats, 0, sizeof(*stats));
   std::vector<xvcgpu_cs_env *> denv(k, nullptr);
-  // a pool of events per stream, taken in turn: an event re-recorded while a chain still
-  // refers to its older record only makes that chain wait for a later point of the same stream
-  const int kPool = 128;
-  std::vector<std::vector<xvcgpu_event *> > pool(n_ctx, std::vector<xvcgpu_event *>(kPool, nullptr));
-  std::vector<int> pool_next(n_ctx, 0);
+  std::vector<xvcgpu_event *> round_ev(n_ctx, nullptr);
   xvcgpu_status st = XVCGPU_OK;
   for (int c = 0; c < k && st == XVCGPU_OK; c++) {
     const xvc_cs_env *e = envs[c];
@@ -582,25 +570,22 @@ extern "C" int xvc_host_cs_run_programs_engine(xvcgpu_ctx *const *ctxs, int n_ct
                               e->d_levels, e->d_results, &denv[c]);
   }
   for (int i = 0; i < n_ctx && st == XVCGPU_OK; i++) {
-    for (int q = 0; q < kPool && st == XVCGPU_OK; q++) st = xvcgpu_event_create(ctxs[i], &pool[i][q]);
+    st = xvcgpu_event_create(ctxs[i], &round_ev[i]);
     if (st == XVCGPU_OK) st = xvcgpu_sync(ctxs[i]);
   }
   std::vector<int64_t> at(k, 0), wait_states(k, -1);
-  std::vector<xvcgpu_event *> last_ev(k, nullptr);   // behind the chain's last step
-  std::vector<int> last_stream(k, -1);
-  std::vector<xvcgpu_event *> waited;
   // groups of a round: kind x kernel instance (i0 of the searches)
   struct Group {
     int kind, key;
     std::vector<xvcgpu_cs_seg> segs;
-    std::vector<int> chains;
   };
   std::vector<Group> groups;
-  std::vector<int> syncs;
+  std::vector<int> order, syncs;
   std::vector<xvcgpu_cs_seg> fetches;
   std::vector<char> fetched(k, 0);
   const double t0 = Now();
   int live = k;
+  bool used_last[8] = {false}, used_now[8] = {false}, met[8] = {false};
   // the chains that reach their SYNC in one round share its event (one record, one query)
   const int kSyncEvents = 64;
   std::vector<xvcgpu_event *> sync_ev(kSyncEvents, nullptr);
@@ -608,44 +593,33 @@ extern "C" int xvc_host_cs_run_programs_engine(xvcgpu_ctx *const *ctxs, int n_ct
   for (int i = 0; i < kSyncEvents && st == XVCGPU_OK; i++) st = xvcgpu_event_create(ctx, &sync_ev[i]);
   int qcache_round = 0, sync_next = 0;
   std::vector<int> qcache_at(kSyncEvents, -1);
-  // stream t waits for the last steps of the chains cs (those that ran on another stream)
-  auto WaitFor = [&](int t, const std::vector<int> &cs) -> xvcgpu_status {
-    waited.clear();
-    for (size_t i = 0; i < cs.size(); i++) {
-      const int c = cs[i];
-      if (!last_ev[c] || last_stream[c] == t) continue;
-      bool seen = false;
-      for (size_t q = 0; q < waited.size(); q++) seen |= waited[q] == last_ev[c];
-      if (seen) continue;
-      waited.push_back(last_ev[c]);
-      const xvcgpu_status r = xvcgpu_event_wait(ctxs[t], last_ev[c]);
-      if (r != XVCGPU_OK) return r;
-    }
+  auto Meet = [&](int t) -> xvcgpu_status {
+    if (met[t]) return XVCGPU_OK;
+    met[t] = true;
+    for (int sidx = 0; sidx < n_ctx; sidx++)
+      if (sidx != t && used_last[sidx]) {
+        const xvcgpu_status r = xvcgpu_event_wait(ctxs[t], round_ev[sidx]);
+        if (r != XVCGPU_OK) return r;
+      }
     return XVCGPU_OK;
   };
-  // an event behind what stream t holds now: the chains cs' last step
-  auto Mark = [&](int t, const std::vector<int> &cs) -> xvcgpu_status {
-    xvcgpu_event *e = pool[t][pool_next[t]];
-    pool_next[t] = (pool_next[t] + 1) % kPool;
-    const xvcgpu_status r = xvcgpu_event_record(ctxs[t], e);
-    for (size_t i = 0; i < cs.size(); i++) {
-      last_ev[cs[i]] = e;
-      last_stream[cs[i]] = t;
-    }
-    return r;
-  };
-  std::vector<int> one(1, 0), fetch_chains;
   while (live > 0 && st == XVCGPU_OK) {
     live = 0;
     bool issued = false;
     int first_waiting = -1;
-    for (Group &g : groups) {
-      g.segs.clear();
-      g.chains.clear();
-    }
+    for (Group &g : groups) g.segs.clear();
     fetches.clear();
-    fetch_chains.clear();
     syncs.clear();
+    // The streams meet between rounds: a chain's step of this round may run on another
+    // stream than its step of the last one (a round's groups are dealt over the streams so
+    // that a long search does not hold the others up)
+    // (a stream waits for the streams that had work in the last round when it gets its first
+    // launch of this one: Meet below)
+    for (int t = 0; t < n_ctx; t++) {
+      used_last[t] = used_now[t];
+      used_now[t] = false;
+      met[t] = false;
+    }
     qcache_round++;
     for (int c = 0; c < k && st == XVCGPU_OK; c++) {
       if (wait_states[c] >= 0) {           // at its SYNC: has the event passed?
@@ -680,10 +654,7 @@ extern "C" int xvc_host_cs_run_programs_engine(xvcgpu_ctx *const *ctxs, int n_ct
           // behind the chain's last launch (an earlier round).  The round's read-backs are
           // one launch of their own, on stream 0 in front of the SYNC events
           if ((o.n & 3) || ((o.p[0] | o.p[1]) & 3)) {
-            one[0] = c;
-            st = WaitFor(0, one);
-            if (st == XVCGPU_OK) st = IssueOp(ctx, envs[c], o);
-            if (st == XVCGPU_OK) st = Mark(0, one);
+            st = IssueOp(ctx, envs[c], o);
           } else {
             xvcgpu_cs_seg sg;
             std::memset(&sg, 0, sizeof(sg));
@@ -691,15 +662,13 @@ extern "C" int xvc_host_cs_run_programs_engine(xvcgpu_ctx *const *ctxs, int n_ct
             sg.p[0] = o.p[0];
             sg.p[1] = o.p[1];
             fetches.push_back(sg);
-            fetch_chains.push_back(c);
           }
           at[c]++;
           fetched[c] = true;
           // the read-backs of a round go out on stream 0 behind the chains' walk: a launch
           // step that follows one (no SYNC between) must not be issued in the same round -
           // it could overwrite what the read-back has not copied yet.  It waits for the next
-          // round: the read-backs' launch is then the chain's last step, and its event is
-          // what the next step waits for.
+          // round, whose launches are behind this round's events.
           if (at[c] < n_ops[c] && ops[c][at[c]].opcode != XVC_OP_FETCH &&
               ops[c][at[c]].opcode != XVC_OP_SYNC) {
             issued = true;
@@ -709,11 +678,10 @@ extern "C" int xvc_host_cs_run_programs_engine(xvcgpu_ctx *const *ctxs, int n_ct
         }
         const int kind = SegKindOf(o);
         if (kind < 0) {                    // no batched form (a LIC state's steps): as it is,
-          const int t = c % n_ctx;         // behind the chain's last step
-          one[0] = c;
-          st = WaitFor(t, one);
+          const int t = c % n_ctx;         // behind the last round's launches of every stream
+          st = Meet(t);
+          used_now[t] = true;
           if (st == XVCGPU_OK) st = IssueOp(ctxs[t], envs[c], o);
-          if (st == XVCGPU_OK) st = Mark(t, one);
           stats->api_calls++;
         } else {
           const int key = (kind == XVC_CS_SEG_ME_REFS || kind == XVC_CS_SEG_BI_REFS ||
@@ -735,7 +703,6 @@ extern "C" int xvc_host_cs_run_programs_engine(xvcgpu_ctx *const *ctxs, int n_ct
           for (int q = 0; q < 8; q++) sg.p[q] = o.p[q];
           sg.env = denv[c];
           grp->segs.push_back(sg);
-          grp->chains.push_back(c);
         }
         at[c]++;
         issued = true;
@@ -743,28 +710,14 @@ extern "C" int xvc_host_cs_run_programs_engine(xvcgpu_ctx *const *ctxs, int n_ct
       }
       if (wait_states[c] >= 0 || at[c] < n_ops[c]) live++;
     }
-    // the round's groups, each on its kind's stream behind the last steps of its chains
-    for (size_t i = 0; i < groups.size() && st == XVCGPU_OK; i++) {
-      Group &g = groups[i];
-      if (g.segs.empty()) continue;
-      const int t = StreamOf(g.kind, n_ctx);
-      st = WaitFor(t, g.chains);
-      if (st == XVCGPU_OK)
-        st = xvcgpu_cs_segs_launch(ctxs[t], g.kind, g.segs.data(), static_cast<int>(g.segs.size()));
-      if (st == XVCGPU_OK) st = Mark(t, g.chains);
-      stats->api_calls++;
-    }
-    // the round's read-backs (behind the last steps of their chains), then the event of the
-    // chains that wait for them (a chain at its SYNC without a read-back: its last step too)
+    // the round's read-backs, then the events of the chains that wait for them
+    if ((!fetches.empty() || !syncs.empty()) && st == XVCGPU_OK) st = Meet(0);
     if (!fetches.empty() && st == XVCGPU_OK) {
-      st = WaitFor(0, fetch_chains);
-      if (st == XVCGPU_OK)
-        st = xvcgpu_cs_segs_launch(ctx, XVC_CS_SEG_FETCH, fetches.data(), static_cast<int>(fetches.size()));
-      if (st == XVCGPU_OK) st = Mark(0, fetch_chains);
+      st = xvcgpu_cs_segs_launch(ctx, XVC_CS_SEG_FETCH, fetches.data(), static_cast<int>(fetches.size()));
       stats->api_calls++;
+      used_now[0] = true;
     }
     if (!syncs.empty() && st == XVCGPU_OK) {
-      st = WaitFor(0, syncs);
       int e = -1;
       for (int tries = 0; tries < kSyncEvents && e < 0; tries++) {
         const int cand = (sync_next + tries) % kSyncEvents;
@@ -772,7 +725,7 @@ extern "C" int xvc_host_cs_run_programs_engine(xvcgpu_ctx *const *ctxs, int n_ct
       }
       if (e < 0) {
         st = XVCGPU_DEVICE_ERROR;          // (k <= 256 chains can hold 64 events only if they
-      } else if (st == XVCGPU_OK) {        //  all wait, and then nothing reaches a SYNC)
+      } else {                             //  all wait, and then nothing reaches a SYNC)
         sync_next = (e + 1) % kSyncEvents;
         st = xvcgpu_event_record(ctx, sync_ev[e]);
         qcache_at[e] = -1;
@@ -780,6 +733,30 @@ extern "C" int xvc_host_cs_run_programs_engine(xvcgpu_ctx *const *ctxs, int n_ct
         sync_waiters[e] = static_cast<int>(syncs.size());
       }
     }
+    // the round's groups, the long ones first, dealt over the streams (least loaded next)
+    order.clear();
+    for (size_t i = 0; i < groups.size(); i++)
+      if (!groups[i].segs.empty()) order.push_back(static_cast<int>(i));
+    for (size_t i = 1; i < order.size(); i++)
+      for (size_t j2 = i; j2 > 0 && SegWeight(groups[order[j2]].kind, groups[order[j2]].key) >
+                                      SegWeight(groups[order[j2 - 1]].kind, groups[order[j2 - 1]].key);
+           j2--)
+        std::swap(order[j2], order[j2 - 1]);
+    int load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (size_t i = 0; i < order.size() && st == XVCGPU_OK; i++) {
+      Group &g = groups[order[i]];
+      int s_min = 0;
+      for (int t = 1; t < n_ctx; t++)
+        if (load[t] < load[s_min]) s_min = t;
+      load[s_min] += SegWeight(g.kind, g.key);
+      st = Meet(s_min);
+      used_now[s_min] = true;
+      if (st == XVCGPU_OK) st = xvcgpu_cs_segs_launch(ctxs[s_min], g.kind, g.segs.data(), static_cast<int>(g.segs.size()));
+      stats->api_calls++;
+    }
+    if (n_ctx > 1)
+      for (int t = 0; t < n_ctx && st == XVCGPU_OK; t++)
+        if (used_now[t]) st = xvcgpu_event_record(ctxs[t], round_ev[t]);
     // every chain waits for the device: wait for one of them instead of spinning
     if (!issued && first_waiting >= 0 && st == XVCGPU_OK)
       st = xvcgpu_event_synchronize(sync_ev[ev_of[first_waiting]]);
@@ -793,8 +770,7 @@ extern "C" int xvc_host_cs_run_programs_engine(xvcgpu_ctx *const *ctxs, int n_ct
     if (denv[c]) xvcgpu_cs_env_destroy(denv[c]);
   }
   for (int i = 0; i < n_ctx; i++)
-    for (int q = 0; q < kPool; q++)
-      if (pool[i][q]) xvcgpu_event_destroy(pool[i][q]);
+    if (round_ev[i]) xvcgpu_event_destroy(round_ev[i]);
   for (int i = 0; i < kSyncEvents; i++)
     if (sync_ev[i]) xvcgpu_event_destroy(sync_ev[i]);
   return st;
