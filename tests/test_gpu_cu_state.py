@@ -138,7 +138,10 @@ def test_live_chains_equal_reference(gpu, name, poc, n_states):
 @pytest.mark.parametrize("name,poc,k,n,threads,live", [("tiny", 2, 5, 1500, 1, False),
                                                        ("c1", 2, 8, 1500, 1, False),
                                                        ("c1", 2, 9, 1200, 3, False),
-                                                       ("c1", 2, 8, 1000, 2, True)])
+                                                       ("c1", 2, 8, 1000, 2, True),
+                                                       # the k an encoder can reach (the sub-GOP's
+                                                       # top layers, two sub-GOPs in flight)
+                                                       ("c1", 2, 16, 600, 4, False)])
 def test_engine_chains_equal_reference(gpu, name, poc, k, n, threads, live):
     """k chains on ONE context through the engine (xvc_host_cs_run_programs_engine): every
     round the chains' next steps grouped by kind, one launch per kind with the chains' jobs
@@ -158,7 +161,7 @@ def test_engine_chains_equal_reference(gpu, name, poc, k, n, threads, live):
     runs = [rd_serial.ChainedRun(api, ectx, sp, pics, w, h, lists) for _ in range(k)]
     n = min(n, len(sp.states) // k)
     firsts = [sp.position_start(c * (len(sp.states) - n - 64) // max(k - 1, 1)) for c in range(k)]
-    more = [api.Context(0) for _ in range(2)]        # two further streams for the rounds' groups
+    more = [api.Context(0) for _ in range(max(2, threads - 1))]   # further streams for the rounds' groups / engines
     for c in more:
         c.use_own_stream()
     stats = rd_serial.ChainedRun.run_engine(runs, firsts, n, by_position=True, verify=True, streams=more,
