@@ -935,55 +935,20 @@ __device__ __forceinline__ int me2_rotated_wg(int block, int n_wg, const Me2Rot 
 // LIC = the instance for the jobs with XVC_ME_USE_LIC (AC-only metrics); the
 // plain instances leave those jobs alone (or, when the caller did not announce
 // any - lic_launched false - report them unsupported).
-template <int MS, int PH, bool LIC = false>
+// One job by one wave, the descriptor read and checked (me_search_wave_body).  FW, FH > 0:
+// the instance for that exact block size - the shape every loop bound, shift and tile count
+// derives from is a constant then (a 1080p picture's 16x16 CUs: the bench's and most of a
+// real picture's jobs); 0: any size of the class.
+template <int MS, int PH, bool LIC, int FW, int FH, class Shared>
 __device__ __forceinline__ void
-me_search_wave_body(const PicView &orig, const PicView &ref,
-                    const xvcgpu_me_block *blocks, int n,
-                    xvcgpu_me_result *results, const TzCand *tz_pattern,
-                    Me2Sched sched, int max_launched, bool lic_launched,
-                    const RefTable *refs = nullptr, const uint8_t *slots = nullptr) {
-  constexpr int WPG = ME2_WAVES(MS);
+me2_search_job(Shared &s, const PicView &orig, const PicView &ref, const xvcgpu_me_block &b_in,
+               int bi, xvcgpu_me_result *results, const TzCand *tz_pattern, Me2Sched sched,
+               int chunk, int local, const RefTable *refs, const uint8_t *slots) {
   constexpr bool kSched = !LIC && (PH & XVCGPU_ME_FULLPEL) != 0;
-  typedef Me2SharedT<MS, (PH & XVCGPU_ME_SUBPEL) != 0> Shared;
-  __shared__ Shared s_all[WPG];
-  Shared &s = s_all[threadIdx.x >> 6];
-  // job = (workgroup, wave); workgroups are XCD-swizzled and rotated
-  const int n_wg = (n + WPG - 1) / WPG;
-  int chunk, local, len;
-  const int wg = me2_rotated_wg(blockIdx.x, n_wg, kSched ? sched.use : nullptr, chunk, local,
-                                len);
-  if (kSched && blockIdx.x == 0 && threadIdx.x < 8) sched.clear->first[threadIdx.x] = 0x7fffffff;
-  if (wg < 0) return;
-  // the job index is the same in all lanes of the wave: tell the compiler, so
-  // that the descriptor and everything derived from it sits in scalar registers
-  // (it cost a dozen VGPRs and, under the 128-register cap, five spilled dwords)
-  const int bi = __builtin_amdgcn_readfirstlane(wg * WPG + (int)(threadIdx.x >> 6));
-  if (bi >= n) return;
-  ME2_TRACE(0);
-  ME2_TRACE_RT(9);
-  const xvcgpu_me_block b = blocks[bi];
-  {
-    const int mx = b.w > b.h ? b.w : b.h;
-    // a job no instance of this call takes (a size the search does not have, or
-    // larger than the caller's max_block_size) is answered with the
-    // XVCGPU_ME_UNSUPPORTED record instead of being left as it was
-    const bool pow2 = (b.w & (b.w - 1)) == 0 && (b.h & (b.h - 1)) == 0;
-    const bool lic = (b.fullpel_mv & XVC_ME_USE_LIC) != 0;
-    const bool valid = pow2 && b.w >= 4 && b.h >= 4 && b.w <= 64 && b.h <= 64 &&
-                       mx <= max_launched && (!lic || lic_launched);
-    if (lic != LIC && valid) return;  // the other set of instances
-    if (MS == 16 && !LIC && !valid) {
-      if (ME2_LANE == 0) {
-        xvcgpu_me_result r;
-        r.fullpel_x = r.fullpel_y = r.mv_x = r.mv_y = 0;
-        r.fullpel_cost = r.subpel_dist = 0xffffffffu;
-        results[bi] = r;
-      }
-      return;
-    }
-    if (!valid || mx > MS || (MS > 16 && mx <= MS / 2)) return;  // other class
-    // me_subpel_team_kernel's jobs
-    if (MS == 64 && PH == XVCGPU_ME_SUBPEL && me2_subpel_fast(b.w, b.h, orig.bd, LIC)) return;
+  xvcgpu_me_block b = b_in;
+  if (FW > 0) {
+    b.w = FW;
+    b.h = FH;
   }
   const int lane = ME2_LANE;
   // (the *_refs form: the job's own reference picture out of the launch's table)
@@ -1389,6 +1354,65 @@ me_search_wave_body(const PicView &orig, const PicView &ref,
   ME2_COUNT_STORE();
   if (lane == 0) results[bi] = res;
 }
+
+template <int MS, int PH, bool LIC = false>
+__device__ __forceinline__ void
+me_search_wave_body(const PicView &orig, const PicView &ref,
+                    const xvcgpu_me_block *blocks, int n,
+                    xvcgpu_me_result *results, const TzCand *tz_pattern,
+                    Me2Sched sched, int max_launched, bool lic_launched,
+                    const RefTable *refs = nullptr, const uint8_t *slots = nullptr) {
+  constexpr int WPG = ME2_WAVES(MS);
+  constexpr bool kSched = !LIC && (PH & XVCGPU_ME_FULLPEL) != 0;
+  typedef Me2SharedT<MS, (PH & XVCGPU_ME_SUBPEL) != 0> Shared;
+  __shared__ Shared s_all[WPG];
+  Shared &s = s_all[threadIdx.x >> 6];
+  // job = (workgroup, wave); workgroups are XCD-swizzled and rotated
+  const int n_wg = (n + WPG - 1) / WPG;
+  int chunk, local, len;
+  const int wg = me2_rotated_wg(blockIdx.x, n_wg, kSched ? sched.use : nullptr, chunk, local,
+                                len);
+  if (kSched && blockIdx.x == 0 && threadIdx.x < 8) sched.clear->first[threadIdx.x] = 0x7fffffff;
+  if (wg < 0) return;
+  // the job index is the same in all lanes of the wave: tell the compiler, so
+  // that the descriptor and everything derived from it sits in scalar registers
+  // (it cost a dozen VGPRs and, under the 128-register cap, five spilled dwords)
+  const int bi = __builtin_amdgcn_readfirstlane(wg * WPG + (int)(threadIdx.x >> 6));
+  if (bi >= n) return;
+  ME2_TRACE(0);
+  ME2_TRACE_RT(9);
+  const xvcgpu_me_block b = blocks[bi];
+  {
+    const int mx = b.w > b.h ? b.w : b.h;
+    // a job no instance of this call takes (a size the search does not have, or
+    // larger than the caller's max_block_size) is answered with the
+    // XVCGPU_ME_UNSUPPORTED record instead of being left as it was
+    const bool pow2 = (b.w & (b.w - 1)) == 0 && (b.h & (b.h - 1)) == 0;
+    const bool lic = (b.fullpel_mv & XVC_ME_USE_LIC) != 0;
+    const bool valid = pow2 && b.w >= 4 && b.h >= 4 && b.w <= 64 && b.h <= 64 &&
+                       mx <= max_launched && (!lic || lic_launched);
+    if (lic != LIC && valid) return;  // the other set of instances
+    if (MS == 16 && !LIC && !valid) {
+      if (ME2_LANE == 0) {
+        xvcgpu_me_result r;
+        r.fullpel_x = r.fullpel_y = r.mv_x = r.mv_y = 0;
+        r.fullpel_cost = r.subpel_dist = 0xffffffffu;
+        results[bi] = r;
+      }
+      return;
+    }
+    if (!valid || mx > MS || (MS > 16 && mx <= MS / 2)) return;  // other class
+    // me_subpel_team_kernel's jobs
+    if (MS == 64 && PH == XVCGPU_ME_SUBPEL && me2_subpel_fast(b.w, b.h, orig.bd, LIC)) return;
+  }
+  if (MS == 16 && !LIC && b.w == 16 && b.h == 16)
+    me2_search_job<MS, PH, LIC, 16, 16>(s, orig, ref, b, bi, results, tz_pattern, sched, chunk, local,
+                                        refs, slots);
+  else
+    me2_search_job<MS, PH, LIC, 0, 0>(s, orig, ref, b, bi, results, tz_pattern, sched, chunk, local,
+                                      refs, slots);
+}
+
 
 template <int MS, int PH, bool LIC = false>
 __global__ void __launch_bounds__(64 * ME2_WAVES(MS), ME2_MIN_WAVES(MS))

@@ -90,14 +90,15 @@ __device__ __forceinline__ void wave_interp_block(int bd, int w, int h, int fx,
 // tap and loop iteration, and the horizontal pass on packed pairs
 // (v_dot2c_i32_i16: even outputs use the tap pairs as they are, odd outputs
 // the set shifted by one sample).  Blocks up to 16x16.
-template <bool CHROMA>
-__device__ __forceinline__ void wave_interp_block_lds(int bd, int w, int h, int fx, int fy,
+template <bool CHROMA, int FW = 0, int FH = 0>   // FW, FH > 0: that exact block size
+__device__ __forceinline__ void wave_interp_block_lds(int bd, int w_in, int h_in, int fx, int fy,
                                                       const uint16_t *ref, int rs,
                                                       uint16_t *win, int16_t *tmp,
                                                       uint16_t *dst) {
   constexpr int N = CHROMA ? 4 : 8;
   constexpr int BACK = N / 2 - 1;
   constexpr int NP = N / 2;  // tap pairs
+  const int w = FW ? FW : w_in, h = FH ? FH : h_in;
   const int lane = ME2_LANE;
   const int smax = (1 << bd) - 1;
   const int lw = 31 - __clz(w);
@@ -249,8 +250,12 @@ __device__ __forceinline__ void recon_from_me_kernel_body(PicView orig, PicView 
       const PlaneView prf = ref.c[c];
       const uint16_t *r =
           prf.p + (ptrdiff_t)(cy + (my >> shift)) * prf.stride + cx + (mx >> shift);
-      wave_interp_block_lds<true>(bd, cw, ch, fx, fy, r, prf.stride, s.win, s.tmp,
-                                  s.pred + (c - 1) * 64);
+      if (cw == 8 && ch == 8)    // (the chroma blocks of a 16x16 CU: nearly every job)
+        wave_interp_block_lds<true, 8, 8>(bd, cw, ch, fx, fy, r, prf.stride, s.win, s.tmp,
+                                          s.pred + (c - 1) * 64);
+      else
+        wave_interp_block_lds<true>(bd, cw, ch, fx, fy, r, prf.stride, s.win, s.tmp,
+                                    s.pred + (c - 1) * 64);
       wave_sync();
     }
     ME2_TRACE(1);
@@ -265,11 +270,18 @@ __device__ __forceinline__ void recon_from_me_kernel_body(PicView orig, PicView 
             *reinterpret_cast<const U16x4 *>(s.pred + g * 64 + i);
       }
     }
-    tx2_job<TXM, 32, RDOQ>(
-        s.tx, tb, 3 * ci + comp, bd, po, s.pred + g * 64, cw, pc, FWD ? coeffs : nullptr,
-        FWD ? coeff_off : nullptr, nnz_out, tx_tables, tx_tables_t, lay, &orig_pre, g * 128,
-        reinterpret_cast<RdoqShared<64> *>(rq_wave) + g, rq_ctx, rq_prm, nullptr,
-        FWD ? &fcl : nullptr);
+    if (cw == 8 && ch == 8)
+      tx2_job<TXM, 32, RDOQ, 8, 8>(
+          s.tx, tb, 3 * ci + comp, bd, po, s.pred + g * 64, cw, pc, FWD ? coeffs : nullptr,
+          FWD ? coeff_off : nullptr, nnz_out, tx_tables, tx_tables_t, lay, &orig_pre, g * 128,
+          reinterpret_cast<RdoqShared<64> *>(rq_wave) + g, rq_ctx, rq_prm, nullptr,
+          FWD ? &fcl : nullptr);
+    else
+      tx2_job<TXM, 32, RDOQ>(
+          s.tx, tb, 3 * ci + comp, bd, po, s.pred + g * 64, cw, pc, FWD ? coeffs : nullptr,
+          FWD ? coeff_off : nullptr, nnz_out, tx_tables, tx_tables_t, lay, &orig_pre, g * 128,
+          reinterpret_cast<RdoqShared<64> *>(rq_wave) + g, rq_ctx, rq_prm, nullptr,
+          FWD ? &fcl : nullptr);
     ME2_TRACE(8);
     return;
   }
@@ -287,7 +299,9 @@ __device__ __forceinline__ void recon_from_me_kernel_body(PicView orig, PicView 
           po.p + (ptrdiff_t)(cy + (i >> lw)) * po.stride + cx + (i & (cw - 1)));
     }
   }
-  wave_interp_block_lds<false>(bd, cw, ch, fx, fy, r, prf.stride, s.win, s.tmp, s.pred);
+  const bool sq16 = cw == 16 && ch == 16;    // (a 16x16 CU's luma block: nearly every job)
+  if (sq16) wave_interp_block_lds<false, 16, 16>(bd, cw, ch, fx, fy, r, prf.stride, s.win, s.tmp, s.pred);
+  else wave_interp_block_lds<false>(bd, cw, ch, fx, fy, r, prf.stride, s.win, s.tmp, s.pred);
   wave_sync();
   ME2_TRACE(1);
   tb.comp = 0;
@@ -299,11 +313,15 @@ __device__ __forceinline__ void recon_from_me_kernel_body(PicView orig, PicView 
       *reinterpret_cast<U16x4 *>(pc.p + (ptrdiff_t)(cy + (i >> lw)) * pc.stride + cx +
                                  (i & (cw - 1))) = *reinterpret_cast<const U16x4 *>(s.pred + i);
   }
-  const int nnz = tx2_job<TXM, 64, RDOQ>(s.tx, tb, 3 * ci, bd, orig.c[0], s.pred, cw,
-                                         rec.c[0], FWD ? coeffs : nullptr,
-                                         FWD ? coeff_off : nullptr, nnz_out,
-                                         tx_tables, tx_tables_t, lay, &orig_pre, 0,
-                                         rq_wave, rq_ctx, rq_prm, nullptr, FWD ? &fcl : nullptr);
+  const int nnz =
+      sq16 ? tx2_job<TXM, 64, RDOQ, 16, 16>(s.tx, tb, 3 * ci, bd, orig.c[0], s.pred, cw, rec.c[0],
+                                            FWD ? coeffs : nullptr, FWD ? coeff_off : nullptr,
+                                            nnz_out, tx_tables, tx_tables_t, lay, &orig_pre, 0,
+                                            rq_wave, rq_ctx, rq_prm, nullptr, FWD ? &fcl : nullptr)
+           : tx2_job<TXM, 64, RDOQ>(s.tx, tb, 3 * ci, bd, orig.c[0], s.pred, cw, rec.c[0],
+                                    FWD ? coeffs : nullptr, FWD ? coeff_off : nullptr, nnz_out,
+                                    tx_tables, tx_tables_t, lay, &orig_pre, 0, rq_wave, rq_ctx,
+                                    rq_prm, nullptr, FWD ? &fcl : nullptr);
   ME2_TRACE(8);
   // (FWD: the record with cbf_luma = 0; the quantiser's walk sets the flag of the
   // blocks it codes a level for, quant_rdo_packed_wave's cu_patch)

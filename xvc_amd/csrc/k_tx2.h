@@ -147,7 +147,9 @@ struct FwdClassify {
 // same size) side by side; `b`, `bi`, `po`, `pred_p`, `pr`, `orig_pre` are then
 // per-lane values of the lane's own half and `soff` places the half's working
 // set inside the shared arrays.
-template <int MODE, int G = 64, bool RDOQ = false>
+// FW, FH > 0: the instance for that exact block size (b.w, b.h must be it): every loop bound,
+// shift and dispatch below is a constant then.
+template <int MODE, int G = 64, bool RDOQ = false, int FW = 0, int FH = 0>
 __device__ __forceinline__ int tx2_job(Tx2Shared &sh, const xvcgpu_tx_block &b, int bi,
                                        int bd, const PlaneView &po, const uint16_t *pred_p,
                                        int pred_stride, const PlaneView &pr,
@@ -184,7 +186,7 @@ __device__ __forceinline__ int tx2_job(Tx2Shared &sh, const xvcgpu_tx_block &b, 
     if ((ME2_LANE & (G - 1)) == 0) dist_out[bi] = v >> (2 * (bd - 8));
   };
   const int lane = ME2_LANE & (G - 1);
-  const int w = b.w, h = b.h;
+  const int w = FW ? FW : b.w, h = FH ? FH : b.h;
   const int lw = 31 - __clz(w);
   const int lgw = lw, lgh = 31 - __clz(h);   // sides 4 ... 16: powers of two
   int16_t *lv = (levels && level_off) ? levels + level_off[bi] : nullptr;
