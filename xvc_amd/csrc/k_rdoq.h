@@ -2041,6 +2041,17 @@ __device__ __forceinline__ void quant_rdo_packed_wave(
       } else if (NSB == 64 && rq4_takes(64, uw, uh, uscan)) {
         // (more than sixteen sub-blocks or a 64-point side: four units per lane)
         nnz = wave_rdoq4<64, 4>(v, lane, bd, uw, uh, uqp, uluma != 0, ush, uprm, cf_at, lv_at);
+      } else if (G == 16 && NSB == 16 && uw == 16 && uh == 16) {
+        // (the instance for the exact 16x16 block beside the any-size one: the long lists of
+        // a large picture - RDOQ4_LATENCY_BLOCKS - are almost only these)
+        auto cf16 = [cf](int x, int y) {
+          return (int)cf[((y >> 2) * 4 + (x >> 2)) * RQ_CF_STRIDE + (((y & 3) << 2) | (x & 3))];
+        };
+        auto lv16 = [lv](int x, int y) {
+          return lv + ((y >> 2) * 4 + (x >> 2)) * RQ_CF_STRIDE + (((y & 3) << 2) | (x & 3));
+        };
+        nnz = wave_rdoq<G>(v, lane, bd, 16, 16, uqp, uluma != 0, uscan, ush, rq_ctx[cur], uprm,
+                           cf16, lv16, false, false);
       } else {
         nnz = wave_rdoq<G>(v, lane, bd, uw, uh, uqp, uluma != 0, uscan, ush, rq_ctx[cur], uprm,
                            cf_at, lv_at, false, false);
