@@ -1261,7 +1261,7 @@ def main():
                 ref, rec = recs[j % 2], recs[(j + 1) % 2]
                 slot = 2 * (j - base - cycle)
                 ctx.timer_mark(slot)
-                ctx.me_search_dev(o, ref, api.ME_FULLPEL | api.ME_SUBPEL, fp.d_me.ptr,
+                ctx.me_search_dev(o, ref, fp.me_flags, fp.d_me.ptr,
                                   d.n_cus, fp.d_res.ptr, d.cu_size)
                 ctx.timer_mark(slot + 1)
                 fp.run(o, ref, rec, ref_poc=j)     # the whole pass (search repeated)
@@ -1278,7 +1278,7 @@ def main():
             prof = json.load(open(os.path.join(
                 ROOT, "profiles",
                 "traffic_current.json" if args.quant == "rdoq" else "traffic_current_fast.json")))
-            kname = {"me_search": "me_search_wave_kernel<16, 3",
+            kname = {"me_search": "me_search_sq16_kernel",
                      "recon_from_me": "recon_from_me_kernel", "quant_rdo": "quant_rdo_packed4_kernel",
                      "fwd_transform": "residual_wave_kernel<1", "inv_transform": "residual_wave_kernel<2",
                      "mc_from_me": "mc_from_me_kernel",

@@ -302,10 +302,15 @@ xvcgpu_status xvcgpu_mc_metric_batch(xvcgpu_ctx *ctx, const xvcgpu_picture *orig
  * batch holds jobs with XVC_ME_USE_LIC (xvcgpu_types.h: AC-only metrics,
  * GetFullpelMetric / GetSubpelMetric inter_search.cc:1059-1076); their kernel
  * instances are launched beside the plain ones.  Without the flag such a job
- * is reported unsupported. */
+ * is reported unsupported.  XVCGPU_ME_HINT_SQ16: a performance hint, never a
+ * change of results - the caller expects (almost) every job of the 16 class to
+ * be a 16x16 (or 16x8) CU, as in a picture's frame pass on a 16-sample CU grid:
+ * the both-phases search then runs the kernel tuned for those shapes (five waves
+ * per SIMD); jobs of other sizes are still answered, more slowly. */
 #define XVCGPU_ME_FULLPEL 1
 #define XVCGPU_ME_SUBPEL 2
 #define XVCGPU_ME_LIC_JOBS 4
+#define XVCGPU_ME_HINT_SQ16 8
 #define XVCGPU_ME_UNSUPPORTED 0xffffffffu /* fullpel_cost / subpel_dist of a job not taken */
 xvcgpu_status xvcgpu_me_search(xvcgpu_ctx *ctx, const xvcgpu_picture *orig,
                                const xvcgpu_picture *ref, int flags,

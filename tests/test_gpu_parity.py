@@ -209,6 +209,18 @@ def test_me_search(gpu, xo, bd):
         r1 = ctx.me_search(O, R, blocks, flags=api.ME_FULLPEL | api.ME_LIC_JOBS)
         r2 = ctx.me_search(O, R, blocks, flags=api.ME_SUBPEL | api.ME_LIC_JOBS, results=r1)
         assert np.array_equal(r2, res)
+        # XVCGPU_ME_HINT_SQ16 picks another kernel for the 16 class (exact-shape instances
+        # for 16x16 / 16x8, the any-size instance under its register cap for the rest):
+        # a hint changes no result, whatever the sizes in the batch
+        r3 = ctx.me_search(O, R, blocks, flags=all_flags | api.ME_HINT_SQ16)
+        assert np.array_equal(r3, res)
+        sq = blocks.copy()
+        sq["w"] = 16
+        sq["h"] = np.where(np.arange(len(sq)) % 3 == 0, 8, 16)
+        sq["x"] = np.minimum(sq["x"], pw - 16)
+        sq["y"] = np.minimum(sq["y"], ph - 16)
+        assert np.array_equal(ctx.me_search(O, R, sq, flags=all_flags | api.ME_HINT_SQ16),
+                              ctx.me_search(O, R, sq, flags=all_flags))
         O.destroy()
         R.destroy()
 

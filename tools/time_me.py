@@ -17,8 +17,10 @@ def timed(fn, reps=20):
     fn(); ctx.sync(); ctx.timer_begin()
     for _ in range(reps): fn()
     return ctx.timer_end() / reps
-for name, flags in (("fullpel", 1), ("subpel", 2), ("both", 3)):
-    t = timed(lambda: ctx.me_search_dev(O, R, flags, fp.d_me.ptr, d.n_cus, fp.d_res.ptr))
+for name, flags in (("fullpel", 1), ("subpel", 2), ("both", 3), ("both, 16 class only", 3),
+                    ("both, 16 class only, sq16 hint", 3 | api.ME_HINT_SQ16)):
+    ms = 16 if "16 class" in name else 64
+    t = timed(lambda: ctx.me_search_dev(O, R, flags, fp.d_me.ptr, d.n_cus, fp.d_res.ptr, ms))
     print(name, "%.4f ms" % t)
 res = fp.d_res.to_array(api.MERES_DTYPE, d.n_cus)
 print("mv median", np.median(res["mv_x"]), np.median(res["mv_y"]))

@@ -20,6 +20,7 @@ BORDER_CHROMA = 64
 ME_FULLPEL = 1
 ME_SUBPEL = 2
 ME_LIC_JOBS = 4      # the batch holds XVC_ME_USE_LIC jobs (fullpel_mv bit 1)
+ME_HINT_SQ16 = 8     # performance hint: (almost) all jobs are 16x16 / 16x8 CUs (xvcgpu.h)
 
 METRIC_SSD, METRIC_SATD, METRIC_SATD_ACONLY, METRIC_SAD, METRIC_SAD_FAST, \
     METRIC_SAD_ACONLY, METRIC_SAD_ACONLY_FAST, METRIC_STRUCTURAL_SSD = range(8)

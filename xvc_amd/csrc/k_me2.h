@@ -132,6 +132,9 @@ __device__ __forceinline__ int wave_reduce_add_i32(int v) {
 #define ME2_WAVES(MS) ((MS) > 32 ? 2 : ((MS) > 16 ? 4 : ME2_WAVES16))
 // waves per SIMD the register allocator leaves room for: the 16-class fits 4
 // workgroups per CU by LDS, so cap its registers at 128 (measured +3 %)
+#ifndef ME2_SQ16_MIN_WAVES
+#define ME2_SQ16_MIN_WAVES 5
+#endif
 #define ME2_MIN_WAVES(MS) ((MS) <= 16 ? 4 : 1)  // 5 (96 VGPRs) spills: 80 -> 147 us
 
 // Orders LDS traffic between the lanes of ONE wave (jobs never share data
@@ -1355,7 +1358,9 @@ me2_search_job(Shared &s, const PicView &orig, const PicView &ref, const xvcgpu_
   if (lane == 0) results[bi] = res;
 }
 
-template <int MS, int PH, bool LIC = false>
+// SEL = 1: me_search_sq16_kernel's body (one more exact-shape instance: 16x8, the bottom
+// CU row of a 1080-line picture).
+template <int MS, int PH, bool LIC = false, int SEL = 0>
 __device__ __forceinline__ void
 me_search_wave_body(const PicView &orig, const PicView &ref,
                     const xvcgpu_me_block *blocks, int n,
@@ -1408,20 +1413,38 @@ me_search_wave_body(const PicView &orig, const PicView &ref,
   if (MS == 16 && !LIC && b.w == 16 && b.h == 16)
     me2_search_job<MS, PH, LIC, 16, 16>(s, orig, ref, b, bi, results, tz_pattern, sched, chunk, local,
                                         refs, slots);
+  else if (SEL == 1 && MS == 16 && !LIC && b.w == 16 && b.h == 8)
+    me2_search_job<MS, PH, LIC, 16, 8>(s, orig, ref, b, bi, results, tz_pattern, sched, chunk, local,
+                                       refs, slots);
   else
     me2_search_job<MS, PH, LIC, 0, 0>(s, orig, ref, b, bi, results, tz_pattern, sched, chunk, local,
                                       refs, slots);
 }
 
 
-template <int MS, int PH, bool LIC = false>
+template <int MS, int PH, bool LIC = false, int SEL = 0>
 __global__ void __launch_bounds__(64 * ME2_WAVES(MS), ME2_MIN_WAVES(MS))
 me_search_wave_kernel(PicView orig, PicView ref,
                       const xvcgpu_me_block *blocks, int n,
                       xvcgpu_me_result *results, const TzCand *tz_pattern,
                       Me2Sched sched, int max_launched, bool lic_launched = false) {
-  me_search_wave_body<MS, PH, LIC>(orig, ref, blocks, n, results, tz_pattern, sched, max_launched,
-                                   lic_launched);
+  me_search_wave_body<MS, PH, LIC, SEL>(orig, ref, blocks, n, results, tz_pattern, sched,
+                                        max_launched, lic_launched);
+}
+
+// The 16 class, both phases, for a job list that is (almost) all 16x16 CUs - a picture's
+// frame pass: under a 96-register cap, five waves per SIMD instead of four.  The exact-shape
+// instances (16x16, 16x8) fit it - their only spilled registers sit in the step-5 grid
+// loop, which one job in thousands runs; any other job of the class runs the any-size
+// instance with spills: same results, slower, so callers with mixed sizes keep
+// me_search_wave_kernel<16, 3> (XVCGPU_ME_HINT_SQ16 chooses).  Measured (three pictures
+// in flight): 1080p 7850 -> 7980 passes/s, 2160p 1758 -> 1818, 4320p 659 -> 697.
+__global__ void __launch_bounds__(64 * ME2_WAVES(16), ME2_SQ16_MIN_WAVES)
+me_search_sq16_kernel(PicView orig, PicView ref, const xvcgpu_me_block *blocks, int n,
+                      xvcgpu_me_result *results, const TzCand *tz_pattern, Me2Sched sched,
+                      int max_launched, bool lic_launched) {
+  me_search_wave_body<16, 3, false, 1>(orig, ref, blocks, n, results, tz_pattern, sched,
+                                       max_launched, lic_launched);
 }
 
 // The searches of one CU state into several reference pictures in one launch: job i

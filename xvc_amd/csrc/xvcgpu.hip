@@ -821,9 +821,15 @@ xvcgpu_status xvcgpu_me_search_sized(xvcgpu_ctx *ctx, const xvcgpu_picture *orig
     if (flags & XVCGPU_ME_FULLPEL) ME_LAUNCH_T(MS, 1, true);     \
     if (flags & XVCGPU_ME_SUBPEL) ME_LAUNCH_T(MS, 2, true);      \
   } while (0)
+#define ME_LAUNCH_SQ16()                                                                \
+  hipLaunchKernelGGL(me_search_sq16_kernel, me2_grid(n, ME2_WAVES(16)),                  \
+                     dim3(64 * ME2_WAVES(16)), 0, ctx->stream, orig->v, ref->v,         \
+                     d_blocks, n, d_results, ctx->d_tz_pattern, sched,                  \
+                     max_block_size > 32 ? 64 : (max_block_size > 16 ? 32 : 16), lic_jobs)
 #define ME_LAUNCH_CLASS(MS)                                \
   do {                                                     \
-    if ((flags & 3) == 3) ME_LAUNCH(MS, 3);                \
+    if ((flags & 3) == 3 && MS == 16 && (flags & XVCGPU_ME_HINT_SQ16)) ME_LAUNCH_SQ16(); \
+    else if ((flags & 3) == 3) ME_LAUNCH(MS, 3);           \
     else if (flags & XVCGPU_ME_FULLPEL) ME_LAUNCH(MS, 1);  \
     else ME_LAUNCH(MS, 2);                                 \
   } while (0)
@@ -2050,7 +2056,11 @@ xvcgpu_status xvcgpu_frame_pass(xvcgpu_ctx *ctx, const xvcgpu_frame_pass_args *a
     }
   } back = {ctx, &main_stream};
   if ((phases & XVC_FP_ENCODE) && a->n_cus > 0) {
-    st = xvcgpu_me_search_sized(ctx, a->orig, a->ref, XVCGPU_ME_FULLPEL | XVCGPU_ME_SUBPEL,
+    // the pass's jobs are the CUs of its grid: on a 16-sample grid all 16x16 (16x8 in the
+    // bottom row of a 1080-line picture)
+    st = xvcgpu_me_search_sized(ctx, a->orig, a->ref,
+                                XVCGPU_ME_FULLPEL | XVCGPU_ME_SUBPEL |
+                                    (a->max_block_size <= 16 ? XVCGPU_ME_HINT_SQ16 : 0),
                                 a->d_me, a->n_cus, a->d_results, a->max_block_size);
     if (st != XVCGPU_OK) return st;
     if (a->d_rdoq_params && a->pred) {

@@ -232,6 +232,8 @@ class FramePass:
         self.d_rdoq_ctx = ctx.buffer(d.rdoq_contexts) if rdoq else None
         self.d_rdoq_prm = ctx.buffer(d.rdoq_params) if rdoq else None
         self.d_me = ctx.buffer(d.me)
+        # the searches are the CUs of the grid: on the 16-sample grid (almost) all 16x16
+        self.me_flags = api.ME_FULLPEL | api.ME_SUBPEL | (api.ME_HINT_SQ16 if cu <= 16 else 0)
         self.d_tx = ctx.buffer(d.tx)
         # no block of the quantiser's general class (diagonal scan, 4x4 sub-blocks, sides up
         # to 32, at most sixteen sub-blocks): its launch can be left out (xvcgpu.h)
@@ -319,8 +321,7 @@ class FramePass:
         n = d.n_cus
         if n == 0:
             return
-        ctx.me_search_dev(orig, ref, api.ME_FULLPEL | api.ME_SUBPEL, self.d_me.ptr,
-                          n, self.d_res.ptr, d.cu_size)
+        ctx.me_search_dev(orig, ref, self.me_flags, self.d_me.ptr, n, self.d_res.ptr, d.cu_size)
         if self.fused and d.cu_size <= 16:
             # MC + transform/quant/recon + CU metadata in one launch; the
             # prediction never leaves LDS
@@ -392,8 +393,7 @@ class FramePass:
         if self.scratch is not None:
             rec = self.scratch
         steps = [("me_search", lambda: ctx.me_search_dev(
-            orig, ref, api.ME_FULLPEL | api.ME_SUBPEL, self.d_me.ptr, n, self.d_res.ptr,
-            d.cu_size))]
+            orig, ref, self.me_flags, self.d_me.ptr, n, self.d_res.ptr, d.cu_size))]
         if self.fused and d.cu_size <= 16:
             if self.rdoq:
                 steps.append(("recon_from_me", lambda: ctx.recon_from_me_rdoq_dev(
