@@ -349,8 +349,14 @@ __device__ __forceinline__ void recon_from_me_kernel_body(PicView orig, PicView 
   }
 }
 
+// Waves per SIMD the forward-only instance is compiled for: 6 = 80 registers, 16 spilled
+// dwords (5: 93, none; 7: 72, 37 spilled).  Measured 1080p / 2160p / 4320p passes/s:
+// 5: 8220 / 1818 / 688, 6: 8288 / 1837 / 698, 7: 7712 / 1667 / 607.
+#ifndef RECON_FWD_MIN_WAVES
+#define RECON_FWD_MIN_WAVES 6
+#endif
 template <bool RDOQ = false, bool FWD = false>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, FWD && !RDOQ ? RECON_FWD_MIN_WAVES : 1)
 recon_from_me_kernel(PicView orig, PicView ref, PicView rec, const xvcgpu_me_block *blocks, const xvcgpu_me_result *results, int n_cus, int qp_y, int qp_c, int intra_pic, int ref_poc, int32_t *nnz_out, xvcgpu_cu_info *cus, const int16_t *tx_tables, const int16_t *tx_tables_t, TxTableLayout lay, const xvcgpu_rdoq_contexts *rq_ctx = nullptr, const xvcgpu_rdoq_params *rq_prm = nullptr, int16_t *coeffs = nullptr, const uint32_t *coeff_off = nullptr, FwdClassify fc = FwdClassify()) {
   recon_from_me_kernel_body<RDOQ, FWD>(orig, ref, rec, blocks, results, n_cus, qp_y, qp_c, intra_pic, ref_poc, nnz_out, cus, tx_tables, tx_tables_t, lay, rq_ctx, rq_prm, coeffs, coeff_off, fc);
 }
