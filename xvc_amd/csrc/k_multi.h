@@ -125,7 +125,7 @@ struct TailMultiArgs {
   int shift, tiles;
   unsigned long long *part, *out;
 };
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, TAIL_MIN_WAVES)
 deblock_tail_multi_kernel(MultiArgs<TailMultiArgs> m) {
   const TailMultiArgs &a = m.a[blockIdx.y];   // (grid x padded to 8: the body drops the rest)
   deblock_tail_kernel_body<true>(a.d, a.src, a.dst, a.orig, a.shift, a.part);

@@ -451,8 +451,15 @@ __device__ __forceinline__ void deblock_tail_kernel_body(DbParams d, PicView src
   TAIL_MARK(6);
 }
 
+// Waves per SIMD the tail is compiled for (registers: 136 at 3, 128 at 4 with 8 spilled
+// dwords, 96 at 5 with 44).  Four pictures per launch, pictures not in the Infinity Cache
+// (tools/tail_batched.sh), share of 8 TB/s at 1080p / 4320p: 3: 26.0 / 33.2 %, 4: 29.5 /
+// 39.7 %, 5: 21.4 / 25.8 %; 4320p frame pass 697 -> 703 passes/s at 4.
+#ifndef TAIL_MIN_WAVES
+#define TAIL_MIN_WAVES 4
+#endif
 template <bool SSD>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, TAIL_MIN_WAVES)
 deblock_tail_kernel(DbParams d, PicView src, PicView dst, PlaneView orig, int shift, unsigned long long *part) {
   deblock_tail_kernel_body<SSD>(d, src, dst, orig, shift, part);
 }
