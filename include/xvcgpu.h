@@ -305,8 +305,9 @@ xvcgpu_status xvcgpu_mc_metric_batch(xvcgpu_ctx *ctx, const xvcgpu_picture *orig
  * is reported unsupported.  XVCGPU_ME_HINT_SQ16: a performance hint, never a
  * change of results - the caller expects (almost) every job of the 16 class to
  * be a 16x16 (or 16x8) CU, as in a picture's frame pass on a 16-sample CU grid:
- * the both-phases search then runs the kernel tuned for those shapes (five waves
- * per SIMD); jobs of other sizes are still answered, more slowly. */
+ * the both-phases search then runs a kernel that takes only those shapes (five
+ * waves per SIMD) and a second, small one that answers the jobs of any other size
+ * a few per wave, one after the other - more slowly, same results. */
 #define XVCGPU_ME_FULLPEL 1
 #define XVCGPU_ME_SUBPEL 2
 #define XVCGPU_ME_LIC_JOBS 4

@@ -977,7 +977,7 @@ me2_search_job(Shared &s, const PicView &orig, const PicView &ref, const xvcgpu_
   c.mvp_x = b.mvp_x;
   c.mvp_y = b.mvp_y;
   c.down = (b.fullpel_mv & XVC_ME_FULLPEL_MV) ? 2 : 0;
-  c.lambda = b.lambda16;
+  c.lambda = (uint32_t)__builtin_amdgcn_readfirstlane((int)b.lambda16);  // scalar: no register
   c.ac = LIC;
   c.orig_sum = 0;
 
@@ -1166,7 +1166,7 @@ me2_search_job(Shared &s, const PicView &orig, const PicView &ref, const xvcgpu_
     ME2_TRACE(4);  // neighbour
     // step-5 grid
     if (st.last_range > 5) {
-      if (kSched && lane == 0)  // slow job: ask the next call to start here
+      if (kSched && sched.record && lane == 0)  // slow job: ask the next call to start here
         atomicMin(&sched.record->first[chunk], local > ME2_LEAD ? local - ME2_LEAD : 0);
       st.last_range = 5;
       const int nx = (fs_max_x - fs_min_x) / 5 + 1;
@@ -1358,32 +1358,17 @@ me2_search_job(Shared &s, const PicView &orig, const PicView &ref, const xvcgpu_
   if (lane == 0) results[bi] = res;
 }
 
-// SEL = 1: me_search_sq16_kernel's body (one more exact-shape instance: 16x8, the bottom
-// CU row of a 1080-line picture).
-template <int MS, int PH, bool LIC = false, int SEL = 0>
+// Job bi of a search call by this wave: the descriptor read and checked, the instance
+// chosen.  SEL 0: every job of the class; 1: the exact-shape jobs only - 16x16 and 16x8, the
+// bottom CU row of a 1080-line picture - (me_search_sq16_kernel); 2: what that kernel
+// leaves (me_search_leftover_kernel).
+template <int MS, int PH, bool LIC, int SEL, typename Shared>
 __device__ __forceinline__ void
-me_search_wave_body(const PicView &orig, const PicView &ref,
-                    const xvcgpu_me_block *blocks, int n,
-                    xvcgpu_me_result *results, const TzCand *tz_pattern,
-                    Me2Sched sched, int max_launched, bool lic_launched,
-                    const RefTable *refs = nullptr, const uint8_t *slots = nullptr) {
-  constexpr int WPG = ME2_WAVES(MS);
-  constexpr bool kSched = !LIC && (PH & XVCGPU_ME_FULLPEL) != 0;
-  typedef Me2SharedT<MS, (PH & XVCGPU_ME_SUBPEL) != 0> Shared;
-  __shared__ Shared s_all[WPG];
-  Shared &s = s_all[threadIdx.x >> 6];
-  // job = (workgroup, wave); workgroups are XCD-swizzled and rotated
-  const int n_wg = (n + WPG - 1) / WPG;
-  int chunk, local, len;
-  const int wg = me2_rotated_wg(blockIdx.x, n_wg, kSched ? sched.use : nullptr, chunk, local,
-                                len);
-  if (kSched && blockIdx.x == 0 && threadIdx.x < 8) sched.clear->first[threadIdx.x] = 0x7fffffff;
-  if (wg < 0) return;
-  // the job index is the same in all lanes of the wave: tell the compiler, so
-  // that the descriptor and everything derived from it sits in scalar registers
-  // (it cost a dozen VGPRs and, under the 128-register cap, five spilled dwords)
-  const int bi = __builtin_amdgcn_readfirstlane(wg * WPG + (int)(threadIdx.x >> 6));
-  if (bi >= n) return;
+me_search_wave_take(Shared &s, const PicView &orig, const PicView &ref,
+                    const xvcgpu_me_block *blocks, int bi, xvcgpu_me_result *results,
+                    const TzCand *tz_pattern, Me2Sched sched, int chunk, int local,
+                    int max_launched, bool lic_launched, const RefTable *refs,
+                    const uint8_t *slots) {
   ME2_TRACE(0);
   ME2_TRACE_RT(9);
   const xvcgpu_me_block b = blocks[bi];
@@ -1410,15 +1395,50 @@ me_search_wave_body(const PicView &orig, const PicView &ref,
     // me_subpel_team_kernel's jobs
     if (MS == 64 && PH == XVCGPU_ME_SUBPEL && me2_subpel_fast(b.w, b.h, orig.bd, LIC)) return;
   }
+  // SEL 1: the exact-shape jobs only (me_search_sq16_kernel); SEL 2: what that kernel leaves
+  const bool sq = MS == 16 && !LIC && b.w == 16 && (b.h == 16 || b.h == 8);
+  if (SEL == 2 && sq) return;
   if (MS == 16 && !LIC && b.w == 16 && b.h == 16)
     me2_search_job<MS, PH, LIC, 16, 16>(s, orig, ref, b, bi, results, tz_pattern, sched, chunk, local,
                                         refs, slots);
-  else if (SEL == 1 && MS == 16 && !LIC && b.w == 16 && b.h == 8)
+  else if (SEL == 1 && sq)
     me2_search_job<MS, PH, LIC, 16, 8>(s, orig, ref, b, bi, results, tz_pattern, sched, chunk, local,
                                        refs, slots);
-  else
+  else if (SEL != 1)
     me2_search_job<MS, PH, LIC, 0, 0>(s, orig, ref, b, bi, results, tz_pattern, sched, chunk, local,
                                       refs, slots);
+}
+
+
+
+template <int MS, int PH, bool LIC = false, int SEL = 0>
+__device__ __forceinline__ void
+me_search_wave_body(const PicView &orig, const PicView &ref,
+                    const xvcgpu_me_block *blocks, int n,
+                    xvcgpu_me_result *results, const TzCand *tz_pattern,
+                    Me2Sched sched, int max_launched, bool lic_launched,
+                    const RefTable *refs = nullptr, const uint8_t *slots = nullptr) {
+  constexpr int WPG = ME2_WAVES(MS);
+  constexpr bool kSched = !LIC && (PH & XVCGPU_ME_FULLPEL) != 0;
+  typedef Me2SharedT<MS, (PH & XVCGPU_ME_SUBPEL) != 0> Shared;
+  __shared__ Shared s_all[WPG];
+  // one wave per workgroup: the lane number is threadIdx.x itself (one register, not two)
+  if (WPG == 1) __builtin_assume(threadIdx.x < 64u);
+  Shared &s = s_all[threadIdx.x >> 6];
+  // job = (workgroup, wave); workgroups are XCD-swizzled and rotated
+  const int n_wg = (n + WPG - 1) / WPG;
+  int chunk, local, len;
+  const int wg = me2_rotated_wg(blockIdx.x, n_wg, kSched ? sched.use : nullptr, chunk, local,
+                                len);
+  if (kSched && blockIdx.x == 0 && threadIdx.x < 8) sched.clear->first[threadIdx.x] = 0x7fffffff;
+  if (wg < 0) return;
+  // the job index is the same in all lanes of the wave: tell the compiler, so
+  // that the descriptor and everything derived from it sits in scalar registers
+  // (it cost a dozen VGPRs and, under the 128-register cap, five spilled dwords)
+  const int bi = __builtin_amdgcn_readfirstlane(wg * WPG + (int)(threadIdx.x >> 6));
+  if (bi >= n) return;
+  me_search_wave_take<MS, PH, LIC, SEL>(s, orig, ref, blocks, bi, results, tz_pattern, sched, chunk,
+                                        local, max_launched, lic_launched, refs, slots);
 }
 
 
@@ -1432,19 +1452,50 @@ me_search_wave_kernel(PicView orig, PicView ref,
                                         max_launched, lic_launched);
 }
 
-// The 16 class, both phases, for a job list that is (almost) all 16x16 CUs - a picture's
-// frame pass: under a 96-register cap, five waves per SIMD instead of four.  The exact-shape
-// instances (16x16, 16x8) fit it - their only spilled registers sit in the step-5 grid
-// loop, which one job in thousands runs; any other job of the class runs the any-size
-// instance with spills: same results, slower, so callers with mixed sizes keep
-// me_search_wave_kernel<16, 3> (XVCGPU_ME_HINT_SQ16 chooses).  Measured (three pictures
-// in flight): 1080p 7850 -> 7980 passes/s, 2160p 1758 -> 1818, 4320p 659 -> 697.
+// The exact-shape jobs of the 16 class (16x16, 16x8), both phases, in a kernel of their own
+// for a job list that is (almost) all such CUs - a picture's frame pass: with the block
+// size compiled in the job fits 96 registers, five waves per SIMD instead of four; the
+// spilled registers sit in the step-5 grid loop, which one job in thousands runs (with
+// the any-size instance in the same kernel the allocator spilled the lane number and
+// the descriptor at the kernel's entry: 7.5 MB of scratch writes per 1080p launch).
+// Followed by me_search_leftover_kernel; XVCGPU_ME_HINT_SQ16 chooses the pair, callers
+// with mixed sizes keep me_search_wave_kernel<16, 3>.  Measured (three pictures in
+// flight): 1080p 7850 -> 8190 passes/s, 2160p 1758 -> 1828, 4320p 659 -> 695.
 __global__ void __launch_bounds__(64 * ME2_WAVES(16), ME2_SQ16_MIN_WAVES)
 me_search_sq16_kernel(PicView orig, PicView ref, const xvcgpu_me_block *blocks, int n,
                       xvcgpu_me_result *results, const TzCand *tz_pattern, Me2Sched sched,
                       int max_launched, bool lic_launched) {
   me_search_wave_body<16, 3, false, 1>(orig, ref, blocks, n, results, tz_pattern, sched,
                                        max_launched, lic_launched);
+}
+
+// What me_search_sq16_kernel leaves: a wave looks at 64 job descriptors, one per lane, and
+// runs the ones of any other shape one after the other with the any-size instance - a
+// few dozen almost empty workgroups for a frame pass's list (no such job at all on a
+// 16-sample grid), correct for any list.  grid: ceil(n / 64), block 64.
+__global__ void __launch_bounds__(64, ME2_MIN_WAVES(16))
+me_search_leftover_kernel(PicView orig, PicView ref, const xvcgpu_me_block *blocks, int n,
+                          xvcgpu_me_result *results, const TzCand *tz_pattern,
+                          int max_launched, bool lic_launched) {
+  typedef Me2SharedT<16, true> Shared;
+  __shared__ Shared s;
+  __builtin_assume(threadIdx.x < 64u);
+  const int base = (int)blockIdx.x * 64, j = base + (int)threadIdx.x;
+  bool mine = false;
+  if (j < n) {
+    const int w = blocks[j].w, h = blocks[j].h;
+    mine = !(w == 16 && (h == 16 || h == 8));
+  }
+  unsigned long long m = __ballot(mine);
+  const Me2Sched none = {nullptr, nullptr, nullptr};
+  while (m) {
+    const int k = __builtin_ctzll(m);
+    m &= m - 1;
+    const int bi = __builtin_amdgcn_readfirstlane(base + k);
+    me_search_wave_take<16, 3, false, 2>(s, orig, ref, blocks, bi, results, tz_pattern, none, 0, 0,
+                                         max_launched, lic_launched, nullptr, nullptr);
+    wave_sync();
+  }
 }
 
 // The searches of one CU state into several reference pictures in one launch: job i

@@ -822,10 +822,15 @@ xvcgpu_status xvcgpu_me_search_sized(xvcgpu_ctx *ctx, const xvcgpu_picture *orig
     if (flags & XVCGPU_ME_SUBPEL) ME_LAUNCH_T(MS, 2, true);      \
   } while (0)
 #define ME_LAUNCH_SQ16()                                                                \
-  hipLaunchKernelGGL(me_search_sq16_kernel, me2_grid(n, ME2_WAVES(16)),                  \
-                     dim3(64 * ME2_WAVES(16)), 0, ctx->stream, orig->v, ref->v,         \
-                     d_blocks, n, d_results, ctx->d_tz_pattern, sched,                  \
-                     max_block_size > 32 ? 64 : (max_block_size > 16 ? 32 : 16), lic_jobs)
+  do {                                                                                  \
+    const int ml = max_block_size > 32 ? 64 : (max_block_size > 16 ? 32 : 16);          \
+    hipLaunchKernelGGL(me_search_sq16_kernel, me2_grid(n, ME2_WAVES(16)),                \
+                       dim3(64 * ME2_WAVES(16)), 0, ctx->stream, orig->v, ref->v,       \
+                       d_blocks, n, d_results, ctx->d_tz_pattern, sched, ml, lic_jobs); \
+    hipLaunchKernelGGL(me_search_leftover_kernel, dim3((n + 63) / 64), dim3(64), 0,      \
+                       ctx->stream, orig->v, ref->v, d_blocks, n, d_results,            \
+                       ctx->d_tz_pattern, ml, lic_jobs);                                \
+  } while (0)
 #define ME_LAUNCH_CLASS(MS)                                \
   do {                                                     \
     if ((flags & 3) == 3 && MS == 16 && (flags & XVCGPU_ME_HINT_SQ16)) ME_LAUNCH_SQ16(); \
