@@ -26,7 +26,17 @@
 #include "k_recon.h"
 #include "xvcgpu_internal.h"
 
-#define BI_WAVES(MS) ((MS) > 32 ? 3 : 4)
+// Waves per workgroup (= job).  The 64 class holds 17 KB of interpolation scratch per wave.
+// Round 6: 8 waves for the 32 / 64 classes (3 / 4 before: a 64x64 job took 88 us, the longest
+// launch of an engine round; 146 KB of LDS, one job per CU - these launches carry a few
+// jobs each).  Engine at k = 16: 0.72 -> 0.85 pictures/s, chained walk 109 -> 101 us / state.
+#ifndef BI_WAVES_64
+#define BI_WAVES_64 8
+#endif
+#ifndef BI_WAVES_32
+#define BI_WAVES_32 8
+#endif
+#define BI_WAVES(MS) ((MS) > 32 ? BI_WAVES_64 : ((MS) > 16 ? BI_WAVES_32 : 4))
 
 template <int MS>
 struct __attribute__((aligned(16))) BiShared {
@@ -46,6 +56,20 @@ __device__ __forceinline__ void bi_mc_luma(int bd, const xvcgpu_me_block &b,
   d_clip_mv(b.x, b.y, pr.w, pr.h, mx, my);
   const uint16_t *r = pr.p + (ptrdiff_t)(b.y + (my >> 4)) * pr.stride + b.x + (mx >> 4);
   wave_interp_block<false>(bd, b.w, b.h, mx & 15, my & 15, r, pr.stride, tmp, pred);
+}
+
+// The same by the waves of a workgroup: wave k the rows [k * h / n, (k + 1) * h / n) of the
+// block, n = min(waves, h / 4) (sample for sample what one wave computes; a slab's
+// horizontal pass covers its own 7 extra rows).  pred: the whole block's, tmp: the wave's.
+__device__ __forceinline__ void bi_mc_luma_slabs(int bd, const xvcgpu_me_block &b,
+                                                 const PlaneView &pr, int mx, int my,
+                                                 int16_t *tmp, uint16_t *pred, int wave, int nw) {
+  const int n = (b.h >> 2) < nw ? (b.h >> 2) : nw;
+  if (wave >= n) return;
+  const int rows = b.h / n, row0 = wave * rows;
+  d_clip_mv(b.x, b.y, pr.w, pr.h, mx, my);
+  const uint16_t *r = pr.p + (ptrdiff_t)(b.y + (my >> 4) + row0) * pr.stride + b.x + (mx >> 4);
+  wave_interp_block<false>(bd, b.w, rows, mx & 15, my & 15, r, pr.stride, tmp, pred + row0 * b.w);
 }
 
 // DeriveLicParams (inter_prediction.cc:1577-1663) by the first wave of the
@@ -175,8 +199,7 @@ bipred_search_body(const PlaneView &orig, const PlaneView &ref_other_arg,
   uint16_t *pred = s.wv[wave].pred;
 
   // prediction from the other list, then target = 2*orig - pred
-  if (wave == 0)
-    bi_mc_luma(bd, b, ref_other, job.other_mv_x, job.other_mv_y, tmp, pred);
+  bi_mc_luma_slabs(bd, b, ref_other, job.other_mv_x, job.other_mv_y, tmp, s.wv[0].pred, wave, NW);
   __syncthreads();
   if (LIC) {
     const xvcgpu_mc_lic_block q = nb[ji];
