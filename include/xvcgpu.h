@@ -307,11 +307,15 @@ xvcgpu_status xvcgpu_mc_metric_batch(xvcgpu_ctx *ctx, const xvcgpu_picture *orig
  * be a 16x16 (or 16x8) CU, as in a picture's frame pass on a 16-sample CU grid:
  * the both-phases search then runs a kernel that takes only those shapes (five
  * waves per SIMD) and a second, small one that answers the jobs of any other size
- * a few per wave, one after the other - more slowly, same results. */
+ * a few per wave, one after the other - more slowly, same results.
+ * XVCGPU_ME_ONLY_SQ16 (with both phases, max_block_size 16): the caller's word that
+ * every job IS a 16x16 or 16x8 block - the second kernel is not launched, and a job
+ * of any other shape is answered with the XVCGPU_ME_UNSUPPORTED record. */
 #define XVCGPU_ME_FULLPEL 1
 #define XVCGPU_ME_SUBPEL 2
 #define XVCGPU_ME_LIC_JOBS 4
 #define XVCGPU_ME_HINT_SQ16 8
+#define XVCGPU_ME_ONLY_SQ16 16
 #define XVCGPU_ME_UNSUPPORTED 0xffffffffu /* fullpel_cost / subpel_dist of a job not taken */
 xvcgpu_status xvcgpu_me_search(xvcgpu_ctx *ctx, const xvcgpu_picture *orig,
                                const xvcgpu_picture *ref, int flags,

@@ -566,7 +566,9 @@ typedef struct xvcgpu_frame_pass_args {
    * general class (xvcgpu_quant_rdo_set_four_lane_only, for this call's batch): pictures
    * of CUs 8x8 .. 16x16 coded with the diagonal scan, say */
   int32_t tx_four_lane_only;
-  int32_t reserved2;
+  /* the caller's word that every job of d_me is a 16x16 or a 16x8 CU (a picture whose width
+   * is a multiple of 16 on the 16-sample CU grid): XVCGPU_ME_ONLY_SQ16 for this call's search */
+  int32_t me_only_sq16;
 } xvcgpu_frame_pass_args;
 
 /* One job of xvcgpu_affine_me_batch: InterSearch::MotionEstAffine for one

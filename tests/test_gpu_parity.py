@@ -219,8 +219,25 @@ def test_me_search(gpu, xo, bd):
         sq["h"] = np.where(np.arange(len(sq)) % 3 == 0, 8, 16)
         sq["x"] = np.minimum(sq["x"], pw - 16)
         sq["y"] = np.minimum(sq["y"], ph - 16)
-        assert np.array_equal(ctx.me_search(O, R, sq, flags=all_flags | api.ME_HINT_SQ16),
-                              ctx.me_search(O, R, sq, flags=all_flags))
+        want = ctx.me_search(O, R, sq, flags=all_flags)
+        assert np.array_equal(ctx.me_search(O, R, sq, flags=all_flags | api.ME_HINT_SQ16), want)
+        # XVCGPU_ME_ONLY_SQ16: the caller's word that every job has such a shape (no second
+        # kernel); a job of another shape is answered XVCGPU_ME_UNSUPPORTED, never left as it was
+        plain = (sq["fullpel_mv"] & 2) == 0
+        got = ctx.me_search(O, R, sq, flags=api.ME_FULLPEL | api.ME_SUBPEL | api.ME_ONLY_SQ16,
+                            max_size=16)
+        assert np.array_equal(got[plain], ctx.me_search(O, R, sq, flags=api.ME_FULLPEL | api.ME_SUBPEL,
+                                                        max_size=16)[plain])
+        odd = sq.copy()
+        odd["fullpel_mv"] &= 1
+        odd["h"][::4] = 4
+        got = ctx.me_search(O, R, odd, flags=api.ME_FULLPEL | api.ME_SUBPEL | api.ME_ONLY_SQ16,
+                            max_size=16)
+        ref_ = ctx.me_search(O, R, odd, flags=api.ME_FULLPEL | api.ME_SUBPEL, max_size=16)
+        is_odd = odd["h"] == 4
+        assert (got["fullpel_cost"][is_odd] == 0xffffffff).all() and \
+            (got["subpel_dist"][is_odd] == 0xffffffff).all()
+        assert np.array_equal(got[~is_odd], ref_[~is_odd])
         O.destroy()
         R.destroy()
 

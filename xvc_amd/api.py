@@ -21,6 +21,7 @@ ME_FULLPEL = 1
 ME_SUBPEL = 2
 ME_LIC_JOBS = 4      # the batch holds XVC_ME_USE_LIC jobs (fullpel_mv bit 1)
 ME_HINT_SQ16 = 8     # performance hint: (almost) all jobs are 16x16 / 16x8 CUs (xvcgpu.h)
+ME_ONLY_SQ16 = 16    # the caller's word: every job is one (another shape: answered unsupported)
 
 METRIC_SSD, METRIC_SATD, METRIC_SATD_ACONLY, METRIC_SAD, METRIC_SAD_FAST, \
     METRIC_SAD_ACONLY, METRIC_SAD_ACONLY_FAST, METRIC_STRUCTURAL_SSD = range(8)
@@ -146,7 +147,7 @@ class FramePassArgs(C.Structure):
                 ("pred", C.c_void_p), ("d_tx", C.c_void_p), ("d_level_off", C.c_void_p),
                 ("d_luma_tx_index", C.c_void_p), ("d_coeffs", C.c_void_p),
                 ("d_levels", C.c_void_p), ("n_tx", C.c_int32), ("n_coeffs", C.c_uint32),
-                ("scratch_rec", C.c_void_p), ("tx_four_lane_only", C.c_int32), ("reserved2", C.c_int32)]
+                ("scratch_rec", C.c_void_p), ("tx_four_lane_only", C.c_int32), ("me_only_sq16", C.c_int32)]
 
 
 FP_ENCODE, FP_DEBLOCK_V, FP_DEBLOCK_H, FP_PAD, FP_SSD = 1, 2, 4, 8, 16
@@ -791,13 +792,13 @@ class Context:
         return out
 
     def me_search(self, orig, ref, blocks, flags=ME_FULLPEL | ME_SUBPEL,
-                  results=None):
+                  results=None, max_size=64):
         blocks = np.ascontiguousarray(blocks, ME_DTYPE)
         db = self.buffer(blocks)
         if results is None:
             results = np.zeros(len(blocks), MERES_DTYPE)
         dr = self.buffer(np.ascontiguousarray(results, MERES_DTYPE))
-        self.me_search_dev(orig, ref, flags, db.ptr, len(blocks), dr.ptr)
+        self.me_search_dev(orig, ref, flags, db.ptr, len(blocks), dr.ptr, max_size)
         out = dr.to_array(MERES_DTYPE, len(blocks))
         db.free()
         dr.free()

@@ -1368,7 +1368,7 @@ me_search_wave_take(Shared &s, const PicView &orig, const PicView &ref,
                     const xvcgpu_me_block *blocks, int bi, xvcgpu_me_result *results,
                     const TzCand *tz_pattern, Me2Sched sched, int chunk, int local,
                     int max_launched, bool lic_launched, const RefTable *refs,
-                    const uint8_t *slots) {
+                    const uint8_t *slots, bool only = false) {
   ME2_TRACE(0);
   ME2_TRACE_RT(9);
   const xvcgpu_me_block b = blocks[bi];
@@ -1407,6 +1407,12 @@ me_search_wave_take(Shared &s, const PicView &orig, const PicView &ref,
   else if (SEL != 1)
     me2_search_job<MS, PH, LIC, 0, 0>(s, orig, ref, b, bi, results, tz_pattern, sched, chunk, local,
                                       refs, slots);
+  else if (only && ME2_LANE == 0) {  // XVCGPU_ME_ONLY_SQ16: nobody else takes it
+    xvcgpu_me_result r;
+    r.fullpel_x = r.fullpel_y = r.mv_x = r.mv_y = 0;
+    r.fullpel_cost = r.subpel_dist = 0xffffffffu;
+    results[bi] = r;
+  }
 }
 
 
@@ -1417,7 +1423,8 @@ me_search_wave_body(const PicView &orig, const PicView &ref,
                     const xvcgpu_me_block *blocks, int n,
                     xvcgpu_me_result *results, const TzCand *tz_pattern,
                     Me2Sched sched, int max_launched, bool lic_launched,
-                    const RefTable *refs = nullptr, const uint8_t *slots = nullptr) {
+                    const RefTable *refs = nullptr, const uint8_t *slots = nullptr,
+                    bool only = false) {
   constexpr int WPG = ME2_WAVES(MS);
   constexpr bool kSched = !LIC && (PH & XVCGPU_ME_FULLPEL) != 0;
   typedef Me2SharedT<MS, (PH & XVCGPU_ME_SUBPEL) != 0> Shared;
@@ -1438,7 +1445,7 @@ me_search_wave_body(const PicView &orig, const PicView &ref,
   const int bi = __builtin_amdgcn_readfirstlane(wg * WPG + (int)(threadIdx.x >> 6));
   if (bi >= n) return;
   me_search_wave_take<MS, PH, LIC, SEL>(s, orig, ref, blocks, bi, results, tz_pattern, sched, chunk,
-                                        local, max_launched, lic_launched, refs, slots);
+                                        local, max_launched, lic_launched, refs, slots, only);
 }
 
 
@@ -1458,15 +1465,16 @@ me_search_wave_kernel(PicView orig, PicView ref,
 // spilled registers sit in the step-5 grid loop, which one job in thousands runs (with
 // the any-size instance in the same kernel the allocator spilled the lane number and
 // the descriptor at the kernel's entry: 7.5 MB of scratch writes per 1080p launch).
-// Followed by me_search_leftover_kernel; XVCGPU_ME_HINT_SQ16 chooses the pair, callers
+// Followed by me_search_leftover_kernel (not with XVCGPU_ME_ONLY_SQ16: `only` - another shape is
+// answered as unsupported then); XVCGPU_ME_HINT_SQ16 chooses the pair, callers
 // with mixed sizes keep me_search_wave_kernel<16, 3>.  Measured (three pictures in
 // flight): 1080p 7850 -> 8190 passes/s, 2160p 1758 -> 1828, 4320p 659 -> 695.
 __global__ void __launch_bounds__(64 * ME2_WAVES(16), ME2_SQ16_MIN_WAVES)
 me_search_sq16_kernel(PicView orig, PicView ref, const xvcgpu_me_block *blocks, int n,
                       xvcgpu_me_result *results, const TzCand *tz_pattern, Me2Sched sched,
-                      int max_launched, bool lic_launched) {
+                      int max_launched, bool lic_launched, bool only) {
   me_search_wave_body<16, 3, false, 1>(orig, ref, blocks, n, results, tz_pattern, sched,
-                                       max_launched, lic_launched);
+                                       max_launched, lic_launched, nullptr, nullptr, only);
 }
 
 // What me_search_sq16_kernel leaves: a wave looks at 64 job descriptors, one per lane, and

@@ -808,6 +808,8 @@ xvcgpu_status xvcgpu_me_search_sized(xvcgpu_ctx *ctx, const xvcgpu_picture *orig
     sched.clear = ctx->d_me_rot + (e + 2) % 3;
   }
   const bool lic_jobs = (flags & XVCGPU_ME_LIC_JOBS) != 0;
+  // (the caller's word only counts where it can be kept: both phases, the 16 class alone)
+  const bool only_sq16 = (flags & XVCGPU_ME_ONLY_SQ16) && (flags & 3) == 3 && max_block_size <= 16;
 #define ME_LAUNCH_T(MS, PH, LIC)                                                        \
   hipLaunchKernelGGL((me_search_wave_kernel<MS, PH, LIC>), me2_grid(n, ME2_WAVES(MS)),  \
                      dim3(64 * ME2_WAVES(MS)), 0, ctx->stream, orig->v, ref->v,         \
@@ -826,14 +828,17 @@ xvcgpu_status xvcgpu_me_search_sized(xvcgpu_ctx *ctx, const xvcgpu_picture *orig
     const int ml = max_block_size > 32 ? 64 : (max_block_size > 16 ? 32 : 16);          \
     hipLaunchKernelGGL(me_search_sq16_kernel, me2_grid(n, ME2_WAVES(16)),                \
                        dim3(64 * ME2_WAVES(16)), 0, ctx->stream, orig->v, ref->v,       \
-                       d_blocks, n, d_results, ctx->d_tz_pattern, sched, ml, lic_jobs); \
-    hipLaunchKernelGGL(me_search_leftover_kernel, dim3((n + 63) / 64), dim3(64), 0,      \
-                       ctx->stream, orig->v, ref->v, d_blocks, n, d_results,            \
-                       ctx->d_tz_pattern, ml, lic_jobs);                                \
+                       d_blocks, n, d_results, ctx->d_tz_pattern, sched, ml, lic_jobs,  \
+                       only_sq16);                                                      \
+    if (!only_sq16)                                                                     \
+      hipLaunchKernelGGL(me_search_leftover_kernel, dim3((n + 63) / 64), dim3(64), 0,    \
+                         ctx->stream, orig->v, ref->v, d_blocks, n, d_results,          \
+                         ctx->d_tz_pattern, ml, lic_jobs);                              \
   } while (0)
 #define ME_LAUNCH_CLASS(MS)                                \
   do {                                                     \
-    if ((flags & 3) == 3 && MS == 16 && (flags & XVCGPU_ME_HINT_SQ16)) ME_LAUNCH_SQ16(); \
+    if ((flags & 3) == 3 && MS == 16 && (flags & (XVCGPU_ME_HINT_SQ16 | XVCGPU_ME_ONLY_SQ16))) \
+      ME_LAUNCH_SQ16();                                                                  \
     else if ((flags & 3) == 3) ME_LAUNCH(MS, 3);           \
     else if (flags & XVCGPU_ME_FULLPEL) ME_LAUNCH(MS, 1);  \
     else ME_LAUNCH(MS, 2);                                 \
@@ -2065,7 +2070,8 @@ xvcgpu_status xvcgpu_frame_pass(xvcgpu_ctx *ctx, const xvcgpu_frame_pass_args *a
     // bottom row of a 1080-line picture)
     st = xvcgpu_me_search_sized(ctx, a->orig, a->ref,
                                 XVCGPU_ME_FULLPEL | XVCGPU_ME_SUBPEL |
-                                    (a->max_block_size <= 16 ? XVCGPU_ME_HINT_SQ16 : 0),
+                                    (a->max_block_size <= 16 ? XVCGPU_ME_HINT_SQ16 : 0) |
+                                    (a->me_only_sq16 ? XVCGPU_ME_ONLY_SQ16 : 0),
                                 a->d_me, a->n_cus, a->d_results, a->max_block_size);
     if (st != XVCGPU_OK) return st;
     if (a->d_rdoq_params && a->pred) {

@@ -234,6 +234,10 @@ class FramePass:
         self.d_me = ctx.buffer(d.me)
         # the searches are the CUs of the grid: on the 16-sample grid (almost) all 16x16
         self.me_flags = api.ME_FULLPEL | api.ME_SUBPEL | (api.ME_HINT_SQ16 if cu <= 16 else 0)
+        self.me_only_sq16 = cu == 16 and bool(len(d.me)) and bool(
+            ((d.me["w"] == 16) & ((d.me["h"] == 16) | (d.me["h"] == 8))).all())
+        if self.me_only_sq16:        # ... all of them: no second kernel for other shapes
+            self.me_flags |= api.ME_ONLY_SQ16
         self.d_tx = ctx.buffer(d.tx)
         # no block of the quantiser's general class (diagonal scan, 4x4 sub-blocks, sides up
         # to 32, at most sixteen sub-blocks): its launch can be left out (xvcgpu.h)
@@ -306,6 +310,7 @@ class FramePass:
         a.ref = ref.h_pic if ref is not None else None
         a.rec, a.ref_poc = rec.h_pic, ref_poc
         a.tx_four_lane_only = 1 if self.tx_four_lane_only else 0
+        a.me_only_sq16 = 1 if self.me_only_sq16 else 0
         if rows is not None:
             a.db_y_begin, a.db_y_end = rows
             a.dbh_y_end = dbh_end if dbh_end is not None else rows[1]
