@@ -19,18 +19,24 @@
 #include "k_me.h"
 #include "k_subpel.h"
 
-// NW = h / 16 waves per CU: every wave owns a 16-row slab of the block for the
-// plain-MC case, the distortions and the gradient sums, and a share of the
-// sub-blocks of the affine MC; the vectors, costs and the elimination are
-// carried redundantly (and identically) by all lanes.
+// NW = h / 8 waves per CU (round 6; h / 16 before: a 16-high CU was ONE wave, 60 - 73 us,
+// the longest launch of an engine round).  A wave owns a slab of the block for the
+// plain-MC case, the distortions and the gradient sums: 8 rows where the SATD tiles are 8
+// rows high (w >= h: 8x8 / 16x8 tiles; all NW waves), 16 rows for the tall blocks (w < h:
+// 8x16 tiles; the first h / 16 waves, the others only share the affine MC of all
+// sub-blocks, which is dealt over all threads).  Every sum is of integers, so the split
+// changes no result.  The vectors, costs and the elimination are carried redundantly
+// (and identically) by all lanes.
+__device__ __forceinline__ int affine_slab_rows(int w, int h) { return w >= h ? 8 : 16; }
+
 template <int NW>
 struct __attribute__((aligned(16))) AffineMeShared {
-  // filter intermediates: per wave a 64x16 slab (plain MC: 64 x 23), or for all
+  // filter intermediates: per wave a slab (plain MC: w x (rows + 7)), or for all
   // sub-blocks of the CU together (w x h x (sbh + 7) / sbh <= 2.75 w h)
-  int16_t tmp[NW * 16 * 64 * 11 / 4];
+  int16_t tmp[NW * 8 * 64 * 11 / 4];
   int sbmv[NW * 64][2];          // clipped vector of each (>= 4x4) sub-block
-  uint16_t pred[NW * 16 * 64];   // the CU's prediction, row stride w
-  int16_t target[NW * 16 * 64];  // bi-pred: 2 * orig - the other list's prediction
+  uint16_t pred[NW * 8 * 64];    // the CU's prediction, row stride w
+  int16_t target[NW * 8 * 64];   // bi-pred: 2 * orig - the other list's prediction
   long long part[NW][16];   // per-wave partial sums of the normal equations
   unsigned long long dpart[NW];
 };
@@ -51,11 +57,14 @@ __device__ __forceinline__ void affine_me_mc(int bd, int bx, int by, int w, int 
   }
   __syncthreads();  // earlier readers of s.pred are done
   if (mv[0][0] == mv[1][0] && mv[0][1] == mv[1][1]) {
-    // plain MC: the wave's 16-row slab as a block of its own
-    const uint16_t *r = pr.p + (ptrdiff_t)(by + wave * 16 + (mv[0][1] >> 4)) * pr.stride + bx +
-                        (mv[0][0] >> 4);
-    wave_interp_block<false>(bd, w, 16, mv[0][0] & 15, mv[0][1] & 15, r, pr.stride,
-                             s.tmp + wave * (16 * 64 * 11 / 4), s.pred + wave * 16 * w);
+    // plain MC: the wave's slab as a block of its own
+    const int rows = affine_slab_rows(w, h);
+    if (wave * rows < h) {
+      const uint16_t *r = pr.p + (ptrdiff_t)(by + wave * rows + (mv[0][1] >> 4)) * pr.stride + bx +
+                          (mv[0][0] >> 4);
+      wave_interp_block<false>(bd, w, rows, mv[0][0] & 15, mv[0][1] & 15, r, pr.stride,
+                               s.tmp + wave * (rows * 64 * 11 / 4), s.pred + wave * rows * w);
+    }
     __syncthreads();
     return;
   }
@@ -151,19 +160,20 @@ template <int NW, typename TOrig>
 __device__ __forceinline__ uint64_t affine_me_dist(int metric, int bd, int w, int h,
                                                    const TOrig *o, int os,
                                                    AffineMeShared<NW> &s) {
-  const int wave = threadIdx.x >> 6;
-  const TOrig *oo = o + (ptrdiff_t)wave * 16 * os;
-  const uint16_t *pp = s.pred + wave * 16 * w;
-  uint64_t part;
-  if (metric == XVC_METRIC_SAD)
-    part = (uint64_t)(int64_t)wave_sad(w, 16, 1, oo, os, pp, w);
+  const int wave = threadIdx.x >> 6, rows = affine_slab_rows(w, h);
+  const TOrig *oo = o + (ptrdiff_t)wave * rows * os;
+  const uint16_t *pp = s.pred + wave * rows * w;
+  uint64_t part = 0;
+  if (wave * rows >= h)
+    ;  // (a tall block's upper waves: no slab)
+  else if (metric == XVC_METRIC_SAD)
+    part = (uint64_t)(int64_t)wave_sad(w, rows, 1, oo, os, pp, w);
   else if (w == h)
-    part = wave_satd_tiles<8, 8>(w, 16, 0, oo, os, pp, w);
+    part = wave_satd_tiles<8, 8>(w, 8, 0, oo, os, pp, w);
   else if (w > h)
-    part = wave_satd_tiles<16, 8>(w, 16, 0, oo, os, pp, w);
+    part = wave_satd_tiles<16, 8>(w, 8, 0, oo, os, pp, w);
   else
     part = wave_satd_tiles<8, 16>(w, 16, 0, oo, os, pp, w);
-  if (NW == 1) return part >> (bd - 8);
   s.dpart[wave] = part;
   __syncthreads();
   uint64_t total = 0;
@@ -283,7 +293,9 @@ __device__ __forceinline__ void affine_gradient_search(int w, int h, const TOrig
   for (int k = 0; k < 10; k++) S[k] = 0;
 #pragma unroll
   for (int k = 0; k < 4; k++) R[k] = 0;
-  for (int i = wave * 16 * w + lane; i < (wave + 1) * 16 * w; i += 64) {
+  const int rows = affine_slab_rows(w, h);
+  const int i_end = (wave + 1) * rows <= h ? (wave + 1) * rows * w : 0;   // (no slab: empty)
+  for (int i = wave * rows * w + lane; i < i_end; i += 64) {
     const int x = i & (w - 1), y = i >> lw;
     // border gradients are copies of the nearest interior one (:772-783)
     const int xc = d_clip3(x, 1, w - 2), yc = d_clip3(y, 1, h - 2);
@@ -432,7 +444,7 @@ __device__ __forceinline__ void affine_me_search(int bd, const xvcgpu_affine_me_
 }
 
 // grid: n CUs; block: 64 * NW.  The instance with NW waves takes the jobs
-// whose height is 16 * NW and leaves the others to its siblings.
+// whose height is 8 * NW and leaves the others to its siblings.
 template <int NW>
 __device__ __forceinline__ void
 affine_me_body(const PlaneView &orig, const PlaneView &ref_arg, const PlaneView &ref_other_arg,
@@ -456,7 +468,7 @@ affine_me_body(const PlaneView &orig, const PlaneView &ref_arg, const PlaneView 
     // CodingUnit::CanUseAffine: width, height > 8 (coding_unit.h:308): 16, 32, 64
     const bool valid = (b.w == 16 || b.w == 32 || b.w == 64) &&
                        (b.h == 16 || b.h == 32 || b.h == 64);
-    if (NW == 1 && !valid) {  // nobody takes it: the XVCGPU_AFFINE_ME_UNSUPPORTED record
+    if (NW == 2 && !valid) {  // nobody takes it: the XVCGPU_AFFINE_ME_UNSUPPORTED record
       if (threadIdx.x == 0) {
         xvcgpu_affine_me_result r;
         for (int i = 0; i < 3; i++) r.mv[i][0] = r.mv[i][1] = 0;
@@ -468,7 +480,7 @@ affine_me_body(const PlaneView &orig, const PlaneView &ref_arg, const PlaneView 
     }
     if (!valid) return;
   }
-  if (b.h != 16 * NW) return;
+  if (b.h != 8 * NW) return;
   const uint16_t *o = orig.p + (ptrdiff_t)b.y * orig.stride + b.x;
   if (b.flags & XVC_AFFINE_ME_BIPRED) {
     // SearchBiIterative :415-420: the other list's prediction, SubtractWeighted

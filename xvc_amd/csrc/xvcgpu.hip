@@ -2431,12 +2431,12 @@ xvcgpu_status xvcgpu_affine_me_batch(xvcgpu_ctx *ctx, const xvcgpu_picture *orig
       ref_other->v.c[0].w != ref->v.c[0].w || ref_other->v.c[0].h != ref->v.c[0].h)
     return XVCGPU_INVALID_ARGUMENT;
   if (n == 0) return XVCGPU_OK;
-  // one instance per CU height (16 rows of the block per wave)
-  hipLaunchKernelGGL(affine_me_kernel<1>, dim3(n), dim3(64), 0, ctx->stream, orig->v.c[0],
-                     ref->v.c[0], ref_other->v.c[0], ref->v.bd, d_blocks, n, d_results);
+  // one instance per CU height (a wave per 8 rows of the block)
   hipLaunchKernelGGL(affine_me_kernel<2>, dim3(n), dim3(128), 0, ctx->stream, orig->v.c[0],
                      ref->v.c[0], ref_other->v.c[0], ref->v.bd, d_blocks, n, d_results);
   hipLaunchKernelGGL(affine_me_kernel<4>, dim3(n), dim3(256), 0, ctx->stream, orig->v.c[0],
+                     ref->v.c[0], ref_other->v.c[0], ref->v.bd, d_blocks, n, d_results);
+  hipLaunchKernelGGL(affine_me_kernel<8>, dim3(n), dim3(512), 0, ctx->stream, orig->v.c[0],
                      ref->v.c[0], ref_other->v.c[0], ref->v.bd, d_blocks, n, d_results);
   CHECK_LAUNCH(ctx, "affine_me_batch");
   return XVCGPU_OK;
@@ -2564,9 +2564,9 @@ xvcgpu_status xvcgpu_affine_me_batch_refs(xvcgpu_ctx *ctx, const xvcgpu_picture 
 #define AFF_REFS(NW)                                                                      \
   hipLaunchKernelGGL(affine_me_refs_kernel<NW>, dim3(n), dim3(64 * NW), 0, ctx->stream,   \
                      orig->v.c[0], t, d_slots, orig->bd, d_blocks, n, d_results)
-  if (cu_height == 16) AFF_REFS(1);
-  else if (cu_height == 32) AFF_REFS(2);
-  else AFF_REFS(4);
+  if (cu_height == 16) AFF_REFS(2);
+  else if (cu_height == 32) AFF_REFS(4);
+  else AFF_REFS(8);
 #undef AFF_REFS
   CHECK_LAUNCH(ctx, "affine_me_batch_refs");
   return XVCGPU_OK;
@@ -2746,9 +2746,9 @@ xvcgpu_status xvcgpu_cs_segs_launch(xvcgpu_ctx *ctx, int kind, const xvcgpu_cs_s
         break;
       }
       case XVC_CS_SEG_AFFINE_REFS:
-        if (key == 16) hipLaunchKernelGGL(cs_seg_affine_kernel<1>, dim3(max_n, gy), dim3(64), 0, st, a);
-        else if (key == 32) hipLaunchKernelGGL(cs_seg_affine_kernel<2>, dim3(max_n, gy), dim3(128), 0, st, a);
-        else if (key == 64) hipLaunchKernelGGL(cs_seg_affine_kernel<4>, dim3(max_n, gy), dim3(256), 0, st, a);
+        if (key == 16) hipLaunchKernelGGL(cs_seg_affine_kernel<2>, dim3(max_n, gy), dim3(128), 0, st, a);
+        else if (key == 32) hipLaunchKernelGGL(cs_seg_affine_kernel<4>, dim3(max_n, gy), dim3(256), 0, st, a);
+        else if (key == 64) hipLaunchKernelGGL(cs_seg_affine_kernel<8>, dim3(max_n, gy), dim3(512), 0, st, a);
         else return XVCGPU_INVALID_ARGUMENT;
         break;
       case XVC_CS_SEG_INTER_PRED:
