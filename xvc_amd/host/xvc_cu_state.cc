@@ -543,10 +543,11 @@ int SegKindOf(const xvc_cs_op &o) {
 // how long a kind's launch lasts, roughly (to deal the groups of a round over the streams)
 static int SegWeight(int kind, int key) {
   switch (kind) {
-    case XVC_CS_SEG_BI_REFS: return key >= 64 ? 80 : (key >= 32 ? 36 : 22);
-    case XVC_CS_SEG_AFFINE_REFS: return 60;
-    case XVC_CS_SEG_RESIDUAL_AT: return 45;
-    case XVC_CS_SEG_ME_REFS: return key >= 64 ? 50 : (key >= 32 ? 30 : 13);
+    // (microseconds per launch, profiles/r06_cu_state_engine_kernel_stats.csv)
+    case XVC_CS_SEG_BI_REFS: return key >= 64 ? 37 : (key >= 32 ? 24 : 21);
+    case XVC_CS_SEG_AFFINE_REFS: return key >= 64 ? 34 : (key >= 32 ? 36 : 42);
+    case XVC_CS_SEG_RESIDUAL_AT: return 34;
+    case XVC_CS_SEG_ME_REFS: return key >= 64 ? 34 : (key >= 32 ? 32 : 14);
     default: return 9;
   }
 }
