@@ -1165,7 +1165,7 @@ me2_search_job(Shared &s, const PicView &orig, const PicView &ref, const xvcgpu_
     if (st.last_range == 1) { st.last_range = 0; neighbor(); }
     ME2_TRACE(4);  // neighbour
     // step-5 grid
-    if (st.last_range > 5) {
+    if (__builtin_expect(st.last_range > 5, 0)) {  // rare: spills stay inside
       if (kSched && sched.record && lane == 0)  // slow job: ask the next call to start here
         atomicMin(&sched.record->first[chunk], local > ME2_LEAD ? local - ME2_LEAD : 0);
       st.last_range = 5;
