@@ -250,7 +250,7 @@ __device__ __forceinline__ void recon_from_me_kernel_body(PicView orig, PicView 
       const PlaneView prf = ref.c[c];
       const uint16_t *r =
           prf.p + (ptrdiff_t)(cy + (my >> shift)) * prf.stride + cx + (mx >> shift);
-      if (cw == 8 && ch == 8)    // (the chroma blocks of a 16x16 CU: nearly every job)
+      if (__builtin_expect(cw == 8 && ch == 8, 1))    // (the chroma blocks of a 16x16 CU: nearly every job)
         wave_interp_block_lds<true, 8, 8>(bd, cw, ch, fx, fy, r, prf.stride, s.win, s.tmp,
                                           s.pred + (c - 1) * 64);
       else
@@ -270,7 +270,7 @@ __device__ __forceinline__ void recon_from_me_kernel_body(PicView orig, PicView 
             *reinterpret_cast<const U16x4 *>(s.pred + g * 64 + i);
       }
     }
-    if (cw == 8 && ch == 8)
+    if (__builtin_expect(cw == 8 && ch == 8, 1))
       tx2_job<TXM, 32, RDOQ, 8, 8>(
           s.tx, tb, 3 * ci + comp, bd, po, s.pred + g * 64, cw, pc, FWD ? coeffs : nullptr,
           FWD ? coeff_off : nullptr, nnz_out, tx_tables, tx_tables_t, lay, &orig_pre, g * 128,
@@ -299,7 +299,7 @@ __device__ __forceinline__ void recon_from_me_kernel_body(PicView orig, PicView 
           po.p + (ptrdiff_t)(cy + (i >> lw)) * po.stride + cx + (i & (cw - 1)));
     }
   }
-  const bool sq16 = cw == 16 && ch == 16;    // (a 16x16 CU's luma block: nearly every job)
+  const bool sq16 = __builtin_expect(cw == 16 && ch == 16, 1);    // (a 16x16 CU's luma block: nearly every job)
   if (sq16) wave_interp_block_lds<false, 16, 16>(bd, cw, ch, fx, fy, r, prf.stride, s.win, s.tmp, s.pred);
   else wave_interp_block_lds<false>(bd, cw, ch, fx, fy, r, prf.stride, s.win, s.tmp, s.pred);
   wave_sync();
