@@ -349,11 +349,14 @@ __device__ __forceinline__ void recon_from_me_kernel_body(PicView orig, PicView 
   }
 }
 
-// Waves per SIMD the forward-only instance is compiled for: 6 = 80 registers, 16 spilled
-// dwords (5: 93, none; 7: 72, 37 spilled).  Measured 1080p / 2160p / 4320p passes/s:
-// 5: 8220 / 1818 / 688, 6: 8288 / 1837 / 698, 7: 7712 / 1667 / 607.
+// Waves per SIMD the forward-only instance is compiled for (LDS allows 7: 22 KB per workgroup
+// of four waves).  Registers / spilled dwords: 5: 93 / 0, 6: 80 / 68, 7: 72 / 104 - with the
+// exact 16x16 / 8x8 instances marked likely (above) the spills all sit in the any-size path.
+// Measured 1080p / 2160p / 4320p passes/s: 6: 8605 / 1928 / 745, 7: 8656 / 1943 / 768 (before the
+// likely marks the spills sat at the kernel's entry: 5: 8220 / 1818 / 688, 6: 8288 / 1837 /
+// 698, 7: 7712 / 1667 / 607).
 #ifndef RECON_FWD_MIN_WAVES
-#define RECON_FWD_MIN_WAVES 6
+#define RECON_FWD_MIN_WAVES 7
 #endif
 template <bool RDOQ = false, bool FWD = false>
 __global__ void __launch_bounds__(256, FWD && !RDOQ ? RECON_FWD_MIN_WAVES : 1)
