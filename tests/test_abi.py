@@ -338,3 +338,26 @@ int main() {
                            "-lxvcgpu", "-Wl,-rpath," + host])
     r = subprocess.run([exe], capture_output=True, text=True)
     assert r.returncode == 0 and r.stdout.startswith("OK"), r.stdout + r.stderr
+
+
+def test_cu_state_layouts_match_the_host_header():
+    """xvc_amd/cu_state.py (the walk's Python host side) mirrors the structs of
+    xvc_amd/host/xvc_cu_state.h: sizes and a late field of each, against g++."""
+    import subprocess
+    import tempfile
+    from xvc_amd import cu_state as cs
+    src = ("#include <stdio.h>\n#include <stddef.h>\n#include \"xvc_cu_state.h\"\nint main(){"
+           "printf(\"%zu %zu %zu %zu %zu %zu %zu %zu %zu\\n\", sizeof(xvc_cs_state),"
+           "offsetof(xvc_cs_state, level_first), sizeof(xvc_cs_tables), offsetof(xvc_cs_tables, h_in_levels),"
+           "sizeof(xvc_cs_stats), sizeof(xvc_cs_op), sizeof(xvc_cs_env), offsetof(xvc_cs_env, d_in_levels),"
+           "sizeof(xvcgpu_cs_result));return 0;}")
+    with tempfile.TemporaryDirectory() as d:
+        open(os.path.join(d, "t.cc"), "w").write(src)
+        subprocess.check_call(["g++", "-std=c++11", "-I", os.path.join(ROOT, "include"),
+                               "-I", os.path.join(ROOT, "xvc_amd", "host"),
+                               os.path.join(d, "t.cc"), "-o", os.path.join(d, "t")])
+        out = [int(v) for v in subprocess.check_output([os.path.join(d, "t")]).decode().split()]
+    assert out == [cs.STATE_DTYPE.itemsize, cs.STATE_DTYPE.fields["level_first"][1],
+                   C.sizeof(cs.CsTables), cs.CsTables.h_in_levels.offset, C.sizeof(cs.CsStats),
+                   cs.OP_DTYPE.itemsize, C.sizeof(cs.CsEnv), cs.CsEnv.d_in_levels.offset,
+                   cs.RESULT_DTYPE.itemsize]
