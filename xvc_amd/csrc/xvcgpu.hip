@@ -2066,12 +2066,13 @@ xvcgpu_status xvcgpu_frame_pass(xvcgpu_ctx *ctx, const xvcgpu_frame_pass_args *a
     }
   } back = {ctx, &main_stream};
   if ((phases & XVC_FP_ENCODE) && a->n_cus > 0) {
-    // the pass's jobs are the CUs of its grid: on a 16-sample grid all 16x16 (16x8 in the
-    // bottom row of a 1080-line picture)
+    // the pass's jobs are the CUs of its grid: where the caller vouches that they are all
+    // 16x16 (16x8 in the bottom row of a 1080-line picture) the search's exact-shape kernel
+    // (a pass of smaller CUs must not take it: its jobs would all be left to the few waves
+    // of the leftover kernel)
     st = xvcgpu_me_search_sized(ctx, a->orig, a->ref,
                                 XVCGPU_ME_FULLPEL | XVCGPU_ME_SUBPEL |
-                                    (a->max_block_size <= 16 ? XVCGPU_ME_HINT_SQ16 : 0) |
-                                    (a->me_only_sq16 ? XVCGPU_ME_ONLY_SQ16 : 0),
+                                    (a->me_only_sq16 ? XVCGPU_ME_HINT_SQ16 | XVCGPU_ME_ONLY_SQ16 : 0),
                                 a->d_me, a->n_cus, a->d_results, a->max_block_size);
     if (st != XVCGPU_OK) return st;
     if (a->d_rdoq_params && a->pred) {

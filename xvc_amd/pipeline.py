@@ -233,9 +233,12 @@ class FramePass:
         self.d_rdoq_prm = ctx.buffer(d.rdoq_params) if rdoq else None
         self.d_me = ctx.buffer(d.me)
         # the searches are the CUs of the grid: on the 16-sample grid (almost) all 16x16
-        self.me_flags = api.ME_FULLPEL | api.ME_SUBPEL | (api.ME_HINT_SQ16 if cu <= 16 else 0)
-        self.me_only_sq16 = cu == 16 and bool(len(d.me)) and bool(
-            ((d.me["w"] == 16) & ((d.me["h"] == 16) | (d.me["h"] == 8))).all())
+        # (the hint only where it is true: the jobs of any other shape go, 64 per wave and one
+        # after the other, through the leftover kernel - a pass of 8x8 CUs would crawl)
+        sq = (d.me["w"] == 16) & ((d.me["h"] == 16) | (d.me["h"] == 8)) if len(d.me) else np.zeros(0, bool)
+        self.me_flags = api.ME_FULLPEL | api.ME_SUBPEL | \
+            (api.ME_HINT_SQ16 if len(sq) and sq.mean() >= 0.98 else 0)
+        self.me_only_sq16 = bool(len(sq)) and bool(sq.all())
         if self.me_only_sq16:        # ... all of them: no second kernel for other shapes
             self.me_flags |= api.ME_ONLY_SQ16
         self.d_tx = ctx.buffer(d.tx)
